@@ -1,0 +1,242 @@
+/*
+ * meshfem_hip.h -- C ABI of libmeshfem_hip.so: the MI355X (gfx950) implementation of MeshFEM's
+ * per-element linear-elasticity stiffness assembly + sparse solve hot path.
+ *
+ * The reference (MeshFEM) has no FFI seam for this path: everything is C++ templates
+ * instantiated in the caller.  Every entry point below therefore cites the
+ * reference member function it replaces (paths relative to src/lib/MeshFEM/).  The C++ facade
+ * (include/MeshFEMHip/LinearElasticity.hh) and the Python mirror (meshfem_amd/) are thin
+ * wrappers around exactly these symbols.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller owns every host buffer, the library owns device memory
+ *   - every function returns mfh_status (0 = ok); mfh_last_error(ctx) gives the message that the
+ *     C++ facade rethrows as std::runtime_error (the reference's error convention)
+ *   - Real = double everywhere (Types.hh:8); vector fields are interleaved [x0 y0 z0 x1 ...]
+ *     (Fields.hh:15-17,49); local node order is MeshFEM/Gmsh order (Simplex.hh:30-47)
+ *   - one context per host thread / device; no hidden global state (the reference's static
+ *     HomogenousMaterialGetter material, LinearElasticity.hh:31-39,426-427, is per-context here)
+ *   - "_dev" entry points take DEVICE pointers (HIP allocations, e.g. torch tensors) and enqueue on
+ *     the context's stream; they exist for the multi-GPU driver that runs RCCL collectives between
+ *     the local kernels
+ */
+#ifndef MESHFEM_HIP_H
+#define MESHFEM_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mfh_ctx mfh_ctx;
+typedef int32_t mfh_status;
+
+enum {
+    MFH_OK = 0,
+    MFH_ERR_INVALID = 1,   /* bad argument / bad mesh (e.g. negatively oriented element) */
+    MFH_ERR_STATE = 2,     /* call order violated (e.g. solve before mesh) */
+    MFH_ERR_HIP = 3,       /* HIP runtime failure (no device, OOM, launch failure) */
+    MFH_ERR_NOT_CONVERGED = 4,
+    MFH_ERR_UNSUPPORTED = 5
+};
+
+/* assembly strategies (north_star: "colored or atomic" scatter, chosen by rocprof evidence) */
+enum {
+    MFH_ASSEMBLE_GATHER = 0, /* owner-computes row chunks, LDS accumulation, K written once    */
+    MFH_ASSEMBLE_ATOMIC = 1  /* element-major, global_atomic_add_f64 scatter (baseline variant) */
+};
+
+/* Neumann condition kinds (BoundaryConditions.hh NeumannType; LinearElasticity.hh:908-931) */
+enum { MFH_NEUMANN_TRACTION = 0, MFH_NEUMANN_PRESSURE = 1, MFH_NEUMANN_FORCE = 2 };
+
+/* preconditioners */
+enum { MFH_PRECOND_BLOCK_JACOBI = 0, MFH_PRECOND_JACOBI = 1, MFH_PRECOND_NONE = 2 };
+
+typedef struct mfh_solve_info {
+    int32_t iterations;      /* PCG iterations of the last right-hand side          */
+    int32_t converged;       /* 1 if ||r||/||b|| <= rtol                            */
+    double  rel_residual;    /* recurrence residual ||r||_2 / ||b||_2 at exit       */
+    double  true_rel_residual; /* ||b - A x||_2 / ||b||_2 recomputed at exit        */
+    double  solve_ms;        /* device time of the PCG loop (HIP events), last RHS  */
+    double  setup_ms;        /* device time of rhs/preconditioner setup             */
+} mfh_solve_info;
+
+typedef struct mfh_timing {
+    double symbolic_ms;      /* host: BSR pattern + gather/scatter maps (once per mesh/DoF map) */
+    double geometry_ms;      /* device: element embedding kernel (a1)                           */
+    double assemble_ms;      /* device: last numeric assembly launch (a4+a6+a9)                 */
+    double upload_ms;        /* host->device copies of the last mesh_set/build                  */
+} mfh_timing;
+
+/* ---------------------------------------------------------------- context
+ * device >= 0: HIP device ordinal (fails with MFH_ERR_HIP when there is none: NO CPU fallback).
+ * device == -1: host-only context; only the mesh / DoF-map / symbolic / boundary-condition host
+ * logic works, every numeric entry point returns MFH_ERR_HIP. Used by the CPU test-suite.        */
+mfh_status  mfh_create(int32_t device, mfh_ctx** out);
+void        mfh_destroy(mfh_ctx* ctx);
+const char* mfh_last_error(const mfh_ctx* ctx);
+const char* mfh_version(void);
+/* the HIP stream all work of this context is enqueued on (a hipStream_t) */
+void*       mfh_stream(mfh_ctx* ctx);
+
+/* ---------------------------------------------------------------- mesh
+ * mfh_mesh_build   == FEMMesh(elems, vertices) ctor (FEMMesh.inl:11-82): vertex nodes = vertices,
+ *                     edge nodes numbered nVert+k in first-encounter order over (element, local
+ *                     edge) (FEMMesh.inl:22-36), edge node = midpoint (FEMMesh.hh:228-233);
+ *                     boundary elements/vertices/nodes in the reference's enumeration order
+ *                     (TetMesh.inl:36-91, TriMesh.inl:86-118, FEMMesh.inl:39-59); embeds every
+ *                     element (FEMMesh.hh:58-66 -> EmbeddedElement.hh:162-241) and fails with
+ *                     MFH_ERR_INVALID on a negative volume (LinearElasticity.hh:465-472).
+ * mfh_mesh_set     == the same with the node table supplied by the caller (no topology built:
+ *                     boundary-condition helpers are unavailable). nOwned < nNode restricts K to
+ *                     the first nOwned block rows (row-partitioned multi-GPU; halo nodes last).
+ * dim in {2,3}; deg in {1,2}; simplices only (tri if dim==2, tet if dim==3).                  */
+mfh_status mfh_mesh_build(mfh_ctx* ctx, int32_t dim, int32_t deg, int64_t nElem, int64_t nVert,
+                          const int32_t* elemVerts /* nElem x (dim+1) */,
+                          const double* vertPos /* nVert x dim */);
+mfh_status mfh_mesh_set(mfh_ctx* ctx, int32_t dim, int32_t deg, int64_t nElem, int64_t nNode,
+                        int64_t nVert, int64_t nOwned,
+                        const int32_t* elemNodes /* nElem x nodesPerElem, MeshFEM local order */,
+                        const double* vertPos /* nVert x dim; vertex v is node v */);
+mfh_status mfh_mesh_sizes(const mfh_ctx* ctx, int64_t* nElem, int64_t* nNode, int64_t* nVert,
+                          int64_t* nBdryElem, int64_t* nBdryNode, int32_t* nodesPerElem,
+                          int32_t* nodesPerBdryElem);
+mfh_status mfh_mesh_get_elem_nodes(const mfh_ctx* ctx, int32_t* out /* nElem x nodesPerElem */);
+mfh_status mfh_mesh_get_node_positions(const mfh_ctx* ctx, double* out /* nNode x dim */);
+mfh_status mfh_mesh_get_boundary_elem_nodes(const mfh_ctx* ctx, int32_t* out /* nBE x npbe, volume node ids */);
+mfh_status mfh_mesh_get_boundary_nodes(const mfh_ctx* ctx, int32_t* out /* nBdryNode volume node ids */);
+mfh_status mfh_mesh_get_boundary_elem_geometry(const mfh_ctx* ctx, double* volume /* nBE */,
+                                               double* normal /* nBE x dim */);
+mfh_status mfh_mesh_get_elem_volumes(mfh_ctx* ctx, double* out /* nElem */);
+
+/* ---------------------------------------------------------------- materials
+ * mfh_material_const       == HomogenousMaterialGetter / Materials::Constant::setTensor
+ *                             (LinearElasticity.hh:31-39): one flattened D (flatLen x flatLen,
+ *                             Voigt xx,yy,zz,yz,xz,xy, Flattening.hh:47-60; tensor shear, not
+ *                             engineering) for every element.
+ * mfh_material_isotropic   == ElasticityTensor::setIsotropic(E,nu) (ElasticityTensor.hh:100-134;
+ *                             2D is plane stress), constant.
+ * mfh_material_iso_field   == per-element E,nu (ETensorStoreGetter, LinearElasticity.hh:20-29;
+ *                             Simulate_cli.cc:116-135).
+ * mfh_material_ortho_field == per-element setOrthotropic3D/2D (ElasticityTensor.hh:136-164),
+ *                             params per element: 3D Ex,Ey,Ez,nuYX,nuZX,nuZY,muYZ,muZX,muXY;
+ *                             2D Ex,Ey,nuYX,muXY. The compliance inverse runs on the device.
+ * mfh_material_tensor_field== per-element flattened D (flatLen x flatLen each).                */
+mfh_status mfh_material_const(mfh_ctx* ctx, const double* D);
+mfh_status mfh_material_isotropic(mfh_ctx* ctx, double E, double nu);
+mfh_status mfh_material_iso_field(mfh_ctx* ctx, const double* E, const double* nu);
+mfh_status mfh_material_ortho_field(mfh_ctx* ctx, const double* params);
+mfh_status mfh_material_tensor_field(mfh_ctx* ctx, const double* D);
+/* element e's flattened D as the kernels use it (flatLen x flatLen) */
+mfh_status mfh_material_get(mfh_ctx* ctx, int64_t elem, double* D);
+
+/* ---------------------------------------------------------------- DoF map
+ * == Simulator::applyPeriodicConditions' m_dofForNode (LinearElasticity.hh:825-854):
+ * variable index = dim*dofForNode[node] + c.  NULL restores DoF(node)=node.                    */
+mfh_status mfh_dof_map(mfh_ctx* ctx, const int32_t* dofForNode /* nNode or NULL */, int64_t nDoF);
+/* PeriodicCondition (BoundaryConditions.hh:452-561): builds dofForNode from the bounding-box cell
+ * with tolerance eps, installs it, flags internal boundary elements; returns nDoF.             */
+mfh_status mfh_apply_periodic_conditions(mfh_ctx* ctx, double eps, int64_t* nDoF);
+mfh_status mfh_get_dof_map(const mfh_ctx* ctx, int32_t* dofForNode /* nNode */, int64_t* nDoF);
+
+/* ---------------------------------------------------------------- assembly
+ * mfh_assemble == Simulator::m_assembleStiffnessMatrix (LinearElasticity.hh:1408-1466) followed
+ * by TripletMatrix::sumRepeated + CSC build (SparseMatrices.hh:280-374,422-447): perElementStiffness
+ * (LinearElasticity.hh:165-232) for every element, summed into a device-resident block-CSR K
+ * (dim x dim blocks, FULL symmetric storage, structural zeros kept).                           */
+mfh_status mfh_assemble(mfh_ctx* ctx, int32_t mode);
+/* The symbolic phase alone (block-CSR pattern + gather lists; implied by mfh_assemble). It is the
+ * hoisted, once-per-mesh part of sumRepeated's sort/merge (SparseMatrices.hh:280-374).          */
+mfh_status mfh_symbolic(mfh_ctx* ctx, int32_t withScatterMap);
+mfh_status mfh_symbolic_sizes(const mfh_ctx* ctx, int64_t* nChunk, int64_t* nContrib, int32_t* chunkSlots, int32_t* maxRowLen);
+/* introspection of the symbolic structure (tests): any pointer may be NULL; the gather lists are
+ * only retained on the host with option "keep_host_symbolic" (always in a host-only context)    */
+mfh_status mfh_symbolic_get(const mfh_ctx* ctx, int32_t* rowPtr, int32_t* colIdx, int32_t* chunkRow, int64_t* contribPtr,
+                            uint32_t* contribCode, uint16_t* contribSlot, int32_t* scatterSlot);
+mfh_status mfh_matrix_info(const mfh_ctx* ctx, int64_t* nBlockRows, int64_t* nBlockCols, int64_t* nnzBlocks);
+mfh_status mfh_export_bsr(mfh_ctx* ctx, int32_t* rowPtr /* nBlockRows+1 */, int32_t* colIdx /* nnzb */,
+                          double* vals /* nnzb x dim*dim, row-major blocks */);
+/* == TripletMatrix after m_assembleStiffnessMatrix + sumRepeated: upper triangle (row<=col) in
+ * column-major sorted order with exact zeros pruned (SparseMatrices.hh:231-234,370-373); same
+ * content as TripletMatrix::dumpBinary (SparseMatrices.hh:629-645). Call with i=j=v=NULL to get
+ * the count in *nnz; otherwise *nnz is the capacity on entry.                                  */
+mfh_status mfh_export_upper_triplets(mfh_ctx* ctx, uint64_t* i, uint64_t* j, double* v, uint64_t* nnz);
+/* per-element dense Ke (debug/parity): full symmetric (n*dim)^2 row-major, local dof = dim*node+c */
+mfh_status mfh_element_stiffness(mfh_ctx* ctx, int64_t firstElem, int64_t count, double* Ke);
+
+/* ---------------------------------------------------------------- constrained solve
+ * mfh_fix_variables == SPSDSystem::fixVariables (SparseMatrices.hh:2389-2500): variables (scalar
+ * indices dim*dof+c) pinned to values; K_rf u_f moves to the right-hand side (:2457-2470). Calls
+ * accumulate like the reference; fixing a variable twice is an error ("Variable already fixed.").
+ * mfh_solve == SPSDSystem::solve (SparseMatrices.hh:2515-2606) with CHOLMOD replaced by a HIP
+ * preconditioned CG on the free variables; u holds fixed values at fixed variables (:2592-2605).
+ * f/u: nrhs vectors of dim*nDoF doubles each.                                                  */
+mfh_status mfh_clear_fixed(mfh_ctx* ctx);
+mfh_status mfh_fix_variables(mfh_ctx* ctx, int64_t n, const int64_t* vars, const double* vals /* or NULL = 0 */);
+mfh_status mfh_set_preconditioner(mfh_ctx* ctx, int32_t kind);
+mfh_status mfh_solve(mfh_ctx* ctx, int32_t nrhs, const double* f, double* u,
+                     double rtol, int32_t maxit, mfh_solve_info* info);
+/* == Simulator::applyStiffnessMatrix (LinearElasticity.hh:801-823), using the assembled K       */
+mfh_status mfh_apply_K(mfh_ctx* ctx, const double* u /* dim*nDoF */, double* Ku);
+
+/* ---------------------------------------------------------------- Simulator-level helpers
+ * Box regions are inclusive (BBox::containsPoint, Geometry.hh:276-279).
+ * mfh_bc_dirichlet_box == DirichletCondition branch of applyBoundaryConditions (:939-949): every
+ *   BOUNDARY NODE whose position lies in the box gets `value` on the components in compMask
+ *   (bit c = component c); conflicting values (>1e-10) fail (LinearElasticity.hh:386-406).
+ * mfh_bc_neumann_box == NeumannCondition branch (:897-933): every BOUNDARY ELEMENT whose vertex
+ *   barycentre lies in the box; FORCE divides by the region area; PRESSURE uses value[0].
+ * relative != 0 interprets the corners relative to the mesh bounding box ("box%",
+ *   BoundaryConditions.cc:310-316).                                                             */
+mfh_status mfh_bc_clear(mfh_ctx* ctx);
+mfh_status mfh_bc_dirichlet_box(mfh_ctx* ctx, const double* minCorner, const double* maxCorner,
+                                int32_t relative, const double* value, int32_t compMask);
+mfh_status mfh_bc_neumann_box(mfh_ctx* ctx, const double* minCorner, const double* maxCorner,
+                              int32_t relative, const double* value, int32_t kind);
+mfh_status mfh_bc_delta_force(mfh_ctx* ctx, int64_t node, const double* force);
+/* == m_getDirichletVarsAndValues (:1469-1518). vars==NULL returns the count.                   */
+mfh_status mfh_bc_dirichlet_vars(mfh_ctx* ctx, int64_t* vars, double* vals, int64_t* n);
+/* == m_pinNode (:1595-1618): first non-boundary node, else node 0.                             */
+mfh_status mfh_pin_node(const mfh_ctx* ctx, int64_t* node);
+/* == Simulator::neumannLoad (:703-717); out: dim*nDoF                                          */
+mfh_status mfh_neumann_load(mfh_ctx* ctx, double* out);
+/* == Simulator::constantStrainLoad (:551-562, :135-162); cstrain flattened (flatLen, TENSOR shear) */
+mfh_status mfh_constant_strain_load(mfh_ctx* ctx, const double* cstrainFlat, double* out);
+/* == Simulator::solve(f) (:479-487 -> m_buildConstrainedSystem :1377-1404): assembles if needed,
+ * fixes the Dirichlet variables (+ the pin node if usePin), PCG-solves, returns dofToNodeField
+ * (:664-677) as nNode x dim. f==NULL uses neumannLoad() (:657).                                */
+mfh_status mfh_sim_solve(mfh_ctx* ctx, const double* f /* dim*nDoF or NULL */, int32_t usePin,
+                         double* uNodes /* nNode x dim */, double rtol, int32_t maxit, mfh_solve_info* info);
+/* == averageStrainField / averageStressField (:528-549, :99-123): per element, flattened (flatLen) */
+mfh_status mfh_average_strain(mfh_ctx* ctx, const double* uNodes, double* strain /* nElem x flatLen */);
+mfh_status mfh_average_stress(mfh_ctx* ctx, const double* uNodes, double* stress /* nElem x flatLen */);
+
+/* ---------------------------------------------------------------- device-pointer building blocks
+ * (multi-GPU driver: local kernels here, RCCL halo exchange / all-reduce in between)           */
+/* y[0:dim*nOwnedDoF] = K x ; x has dim*nColDoF entries (owned then halo). fixed-variable mask NOT applied */
+mfh_status mfh_dev_spmv(mfh_ctx* ctx, const double* x_dev, double* y_dev);
+/* z = M^-1 r on the owned rows (block-Jacobi of the assembled K, fixed variables decoupled)     */
+mfh_status mfh_dev_precond(mfh_ctx* ctx, const double* r_dev, double* z_dev);
+/* r[fixed] = 0 */
+mfh_status mfh_dev_mask_fixed(mfh_ctx* ctx, double* r_dev);
+/* copy the fixed-variable values into u (u[fixed] = value) */
+mfh_status mfh_dev_set_fixed_values(mfh_ctx* ctx, double* u_dev);
+mfh_status mfh_dev_sync(mfh_ctx* ctx);
+
+/* ---------------------------------------------------------------- introspection / measurement */
+mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
+/* average device time (ms, HIP events on the context stream) of `reps` back-to-back launches of
+ * the numeric assembly kernel alone (geometry kernel excluded) -- used by bench.py's roofline   */
+mfh_status mfh_time_assembly_kernel(mfh_ctx* ctx, int32_t mode, int32_t reps, double* avg_ms);
+/* the same for one SpMV on internal scratch vectors */
+mfh_status mfh_time_spmv_kernel(mfh_ctx* ctx, int32_t reps, double* avg_ms);
+/* option knobs (string key, numeric value): "chunk_slots", "contrib_order" (0 rank-major, 1 element-major,
+ * 2 slot-major), "check_every", "keep_host_symbolic" */
+mfh_status mfh_set_option(mfh_ctx* ctx, const char* key, double value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MESHFEM_HIP_H */

@@ -1,0 +1,10 @@
+"""meshfem_amd: MI355X-native per-element stiffness assembly + PCG solve for MeshFEM.
+
+Python mirror of the reference's interface for this path (LinearElasticity::Simulator,
+SPSDSystem, ElasticityTensor), on top of the C ABI in include/meshfem_hip.h
+(libmeshfem_hip.so, hand-written HIP for gfx950). There is no CPU fallback."""
+from ._lib import (MeshFEMHipError, ASSEMBLE_GATHER, ASSEMBLE_ATOMIC, NEUMANN_TRACTION, NEUMANN_PRESSURE,
+                   NEUMANN_FORCE, PRECOND_BLOCK_JACOBI, PRECOND_JACOBI, PRECOND_NONE, LIB_PATH)
+from .core import Context
+
+__all__ = ["Context", "MeshFEMHipError", "LIB_PATH"]

@@ -1,0 +1,143 @@
+"""ctypes binding of libmeshfem_hip.so (include/meshfem_hip.h). There is no fallback: if the
+shared object is missing this module raises, and if there is no HIP device `Context()` raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmeshfem_hip.so")
+
+OK, ERR_INVALID, ERR_STATE, ERR_HIP, ERR_NOT_CONVERGED, ERR_UNSUPPORTED = range(6)
+ASSEMBLE_GATHER, ASSEMBLE_ATOMIC = 0, 1
+NEUMANN_TRACTION, NEUMANN_PRESSURE, NEUMANN_FORCE = 0, 1, 2
+PRECOND_BLOCK_JACOBI, PRECOND_JACOBI, PRECOND_NONE = 0, 1, 2
+
+
+class SolveInfo(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
+                ("true_rel_residual", C.c_double), ("solve_ms", C.c_double), ("setup_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class Timing(C.Structure):
+    _fields_ = [("symbolic_ms", C.c_double), ("geometry_ms", C.c_double), ("assemble_ms", C.c_double),
+                ("upload_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_P = C.c_void_p
+_i32, _i64, _f64 = C.c_int32, C.c_int64, C.c_double
+_pi64, _pi32 = C.POINTER(C.c_int64), C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes). Mirrors include/meshfem_hip.h one to one (tests check the symbol list).
+PROTOTYPES = {
+    "mfh_create": (_i32, [_i32, C.POINTER(_P)]),
+    "mfh_destroy": (None, [_P]),
+    "mfh_last_error": (C.c_char_p, [_P]),
+    "mfh_version": (C.c_char_p, []),
+    "mfh_stream": (_P, [_P]),
+    "mfh_mesh_build": (_i32, [_P, _i32, _i32, _i64, _i64, _P, _P]),
+    "mfh_mesh_set": (_i32, [_P, _i32, _i32, _i64, _i64, _i64, _i64, _P, _P]),
+    "mfh_mesh_sizes": (_i32, [_P, _pi64, _pi64, _pi64, _pi64, _pi64, _pi32, _pi32]),
+    "mfh_mesh_get_elem_nodes": (_i32, [_P, _P]),
+    "mfh_mesh_get_node_positions": (_i32, [_P, _P]),
+    "mfh_mesh_get_boundary_elem_nodes": (_i32, [_P, _P]),
+    "mfh_mesh_get_boundary_nodes": (_i32, [_P, _P]),
+    "mfh_mesh_get_boundary_elem_geometry": (_i32, [_P, _P, _P]),
+    "mfh_mesh_get_elem_volumes": (_i32, [_P, _P]),
+    "mfh_material_const": (_i32, [_P, _P]),
+    "mfh_material_isotropic": (_i32, [_P, _f64, _f64]),
+    "mfh_material_iso_field": (_i32, [_P, _P, _P]),
+    "mfh_material_ortho_field": (_i32, [_P, _P]),
+    "mfh_material_tensor_field": (_i32, [_P, _P]),
+    "mfh_material_get": (_i32, [_P, _i64, _P]),
+    "mfh_dof_map": (_i32, [_P, _P, _i64]),
+    "mfh_apply_periodic_conditions": (_i32, [_P, _f64, _pi64]),
+    "mfh_get_dof_map": (_i32, [_P, _P, _pi64]),
+    "mfh_assemble": (_i32, [_P, _i32]),
+    "mfh_symbolic": (_i32, [_P, _i32]),
+    "mfh_symbolic_sizes": (_i32, [_P, _pi64, _pi64, _pi32, _pi32]),
+    "mfh_symbolic_get": (_i32, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "mfh_matrix_info": (_i32, [_P, _pi64, _pi64, _pi64]),
+    "mfh_export_bsr": (_i32, [_P, _P, _P, _P]),
+    "mfh_export_upper_triplets": (_i32, [_P, _P, _P, _P, C.POINTER(C.c_uint64)]),
+    "mfh_element_stiffness": (_i32, [_P, _i64, _i64, _P]),
+    "mfh_clear_fixed": (_i32, [_P]),
+    "mfh_fix_variables": (_i32, [_P, _i64, _P, _P]),
+    "mfh_set_preconditioner": (_i32, [_P, _i32]),
+    "mfh_solve": (_i32, [_P, _i32, _P, _P, _f64, _i32, C.POINTER(SolveInfo)]),
+    "mfh_apply_K": (_i32, [_P, _P, _P]),
+    "mfh_bc_clear": (_i32, [_P]),
+    "mfh_bc_dirichlet_box": (_i32, [_P, _P, _P, _i32, _P, _i32]),
+    "mfh_bc_neumann_box": (_i32, [_P, _P, _P, _i32, _P, _i32]),
+    "mfh_bc_delta_force": (_i32, [_P, _i64, _P]),
+    "mfh_bc_dirichlet_vars": (_i32, [_P, _P, _P, _pi64]),
+    "mfh_pin_node": (_i32, [_P, _pi64]),
+    "mfh_neumann_load": (_i32, [_P, _P]),
+    "mfh_constant_strain_load": (_i32, [_P, _P, _P]),
+    "mfh_sim_solve": (_i32, [_P, _P, _i32, _P, _f64, _i32, C.POINTER(SolveInfo)]),
+    "mfh_average_strain": (_i32, [_P, _P, _P]),
+    "mfh_average_stress": (_i32, [_P, _P, _P]),
+    "mfh_dev_spmv": (_i32, [_P, _P, _P]),
+    "mfh_dev_precond": (_i32, [_P, _P, _P]),
+    "mfh_dev_mask_fixed": (_i32, [_P, _P]),
+    "mfh_dev_set_fixed_values": (_i32, [_P, _P]),
+    "mfh_dev_sync": (_i32, [_P]),
+    "mfh_get_timing": (_i32, [_P, C.POINTER(Timing)]),
+    "mfh_time_assembly_kernel": (_i32, [_P, _i32, _i32, C.POINTER(_f64)]),
+    "mfh_time_spmv_kernel": (_i32, [_P, _i32, C.POINTER(_f64)]),
+    "mfh_set_option": (_i32, [_P, C.c_char_p, _f64]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmeshfem_hip.so and declare every prototype. Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libmeshfem_hip.so not found at %s: build it with `python -m meshfem_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class MeshFEMHipError(RuntimeError):
+    """The C ABI's status + message, raised like the reference's std::runtime_error."""
+
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+def ptr(a):
+    """Raw pointer of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def as_i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def as_i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)

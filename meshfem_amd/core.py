@@ -1,0 +1,340 @@
+"""Thin numpy-facing wrapper over the C ABI (one `Context` == one mfh_ctx)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import as_f64, as_i32, as_i64, ptr
+
+
+def flat_len(dim):
+    return dim * (dim + 1) // 2
+
+
+class Context:
+    def __init__(self, device=0):
+        self.lib = L.load()
+        h = C.c_void_p()
+        st = self.lib.mfh_create(int(device), C.byref(h))
+        if st != L.OK:
+            raise L.MeshFEMHipError(st, "mfh_create(device=%d) failed with status %d: no usable HIP device "
+                                        "(libmeshfem_hip has no CPU fallback)" % (device, st))
+        self.h = h
+        self.host_only = device == -1
+        self.dim = self.deg = None
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mfh_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, st):
+        if st != L.OK:
+            raise L.MeshFEMHipError(st, self.lib.mfh_last_error(self.h).decode())
+
+    # ---------------------------------------------------------------- mesh
+    def mesh_build(self, elems, verts, deg):
+        elems, verts = as_i32(elems), as_f64(verts)
+        self.dim, self.deg = verts.shape[1], deg
+        self._ck(self.lib.mfh_mesh_build(self.h, self.dim, deg, len(elems), len(verts), ptr(elems), ptr(verts)))
+        self._sizes()
+
+    def mesh_set(self, dim, deg, elem_nodes, vert_pos, n_node, n_owned=None):
+        elem_nodes, vert_pos = as_i32(elem_nodes), as_f64(vert_pos)
+        self.dim, self.deg = dim, deg
+        n_owned = n_node if n_owned is None else n_owned
+        self._ck(self.lib.mfh_mesh_set(self.h, dim, deg, len(elem_nodes), n_node, len(vert_pos), n_owned,
+                                       ptr(elem_nodes), ptr(vert_pos)))
+        self._sizes()
+
+    def _sizes(self):
+        v = [C.c_int64() for _ in range(5)]
+        a, b = C.c_int32(), C.c_int32()
+        self._ck(self.lib.mfh_mesh_sizes(self.h, *[C.byref(x) for x in v], C.byref(a), C.byref(b)))
+        self.n_elem, self.n_node, self.n_vert, self.n_bdry_elem, self.n_bdry_node = [x.value for x in v]
+        self.npe, self.npbe = a.value, b.value
+        self.n_dof = self.n_node
+
+    def elem_nodes(self):
+        out = np.empty((self.n_elem, self.npe), dtype=np.int32)
+        self._ck(self.lib.mfh_mesh_get_elem_nodes(self.h, ptr(out)))
+        return out
+
+    def node_positions(self):
+        out = np.empty((self.n_node, self.dim))
+        self._ck(self.lib.mfh_mesh_get_node_positions(self.h, ptr(out)))
+        return out
+
+    def boundary_elem_nodes(self):
+        out = np.empty((self.n_bdry_elem, self.npbe), dtype=np.int32)
+        self._ck(self.lib.mfh_mesh_get_boundary_elem_nodes(self.h, ptr(out)))
+        return out
+
+    def boundary_nodes(self):
+        out = np.empty(self.n_bdry_node, dtype=np.int32)
+        self._ck(self.lib.mfh_mesh_get_boundary_nodes(self.h, ptr(out)))
+        return out
+
+    def boundary_elem_geometry(self):
+        vol = np.empty(self.n_bdry_elem)
+        nrm = np.empty((self.n_bdry_elem, self.dim))
+        self._ck(self.lib.mfh_mesh_get_boundary_elem_geometry(self.h, ptr(vol), ptr(nrm)))
+        return vol, nrm
+
+    def elem_volumes(self):
+        out = np.empty(self.n_elem)
+        self._ck(self.lib.mfh_mesh_get_elem_volumes(self.h, ptr(out)))
+        return out
+
+    # ---------------------------------------------------------------- materials
+    def material_isotropic(self, E, nu):
+        self._ck(self.lib.mfh_material_isotropic(self.h, float(E), float(nu)))
+
+    def material_const(self, D):
+        D = as_f64(D)
+        assert D.shape == (flat_len(self.dim),) * 2
+        self._ck(self.lib.mfh_material_const(self.h, ptr(D)))
+
+    def material_iso_field(self, E, nu):
+        E, nu = as_f64(E), as_f64(nu)
+        assert len(E) == len(nu) == self.n_elem
+        self._ck(self.lib.mfh_material_iso_field(self.h, ptr(E), ptr(nu)))
+
+    def material_ortho_field(self, params):
+        params = as_f64(params)
+        assert params.shape == (self.n_elem, 9 if self.dim == 3 else 4)
+        self._ck(self.lib.mfh_material_ortho_field(self.h, ptr(params)))
+
+    def material_tensor_field(self, D):
+        D = as_f64(D)
+        assert D.shape == (self.n_elem,) + (flat_len(self.dim),) * 2
+        self._ck(self.lib.mfh_material_tensor_field(self.h, ptr(D)))
+
+    def material_get(self, e):
+        out = np.empty((flat_len(self.dim),) * 2)
+        self._ck(self.lib.mfh_material_get(self.h, int(e), ptr(out)))
+        return out
+
+    # ---------------------------------------------------------------- DoF map
+    def dof_map(self, dof_for_node, n_dof):
+        if dof_for_node is None:
+            self._ck(self.lib.mfh_dof_map(self.h, None, 0))
+            self.n_dof = self.n_node
+        else:
+            d = as_i32(dof_for_node)
+            self._ck(self.lib.mfh_dof_map(self.h, ptr(d), int(n_dof)))
+            self.n_dof = int(n_dof)
+
+    def apply_periodic_conditions(self, eps=1e-7):
+        n = C.c_int64()
+        self._ck(self.lib.mfh_apply_periodic_conditions(self.h, float(eps), C.byref(n)))
+        self.n_dof = n.value
+        return n.value
+
+    def get_dof_map(self):
+        out = np.empty(self.n_node, dtype=np.int32)
+        n = C.c_int64()
+        self._ck(self.lib.mfh_get_dof_map(self.h, ptr(out), C.byref(n)))
+        return out, n.value
+
+    # ---------------------------------------------------------------- assembly
+    def symbolic(self, with_scatter=False):
+        self._ck(self.lib.mfh_symbolic(self.h, int(with_scatter)))
+
+    def symbolic_sizes(self):
+        a, b = C.c_int64(), C.c_int64()
+        c, d = C.c_int32(), C.c_int32()
+        self._ck(self.lib.mfh_symbolic_sizes(self.h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return dict(n_chunk=a.value, n_contrib=b.value, chunk_slots=c.value, max_row_len=d.value)
+
+    def matrix_info(self):
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.lib.mfh_matrix_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    def symbolic_get(self, with_scatter=False):
+        nr, nc, nnzb = self.matrix_info()
+        sz = self.symbolic_sizes()
+        out = dict(rowPtr=np.empty(nr + 1, np.int32), colIdx=np.empty(nnzb, np.int32),
+                   chunkRow=np.empty(sz["n_chunk"] + 1, np.int32), contribPtr=np.empty(sz["n_chunk"] + 1, np.int64),
+                   contribCode=np.empty(sz["n_contrib"], np.uint32), contribSlot=np.empty(sz["n_contrib"], np.uint16))
+        sc = np.empty(self.n_elem * self.npe * self.npe, np.int32) if with_scatter else None
+        self._ck(self.lib.mfh_symbolic_get(self.h, ptr(out["rowPtr"]), ptr(out["colIdx"]), ptr(out["chunkRow"]),
+                                           ptr(out["contribPtr"]), ptr(out["contribCode"]), ptr(out["contribSlot"]), ptr(sc)))
+        if with_scatter:
+            out["scatterSlot"] = sc
+        out.update(sz)
+        return out
+
+    def assemble(self, mode=L.ASSEMBLE_GATHER):
+        self._ck(self.lib.mfh_assemble(self.h, int(mode)))
+
+    def export_bsr(self):
+        nr, nc, nnzb = self.matrix_info()
+        rp, ci = np.empty(nr + 1, np.int32), np.empty(nnzb, np.int32)
+        vals = np.empty((nnzb, self.dim, self.dim))
+        self._ck(self.lib.mfh_export_bsr(self.h, ptr(rp), ptr(ci), ptr(vals)))
+        return rp, ci, vals
+
+    def export_scipy(self):
+        import scipy.sparse as sp
+        rp, ci, vals = self.export_bsr()
+        nr, nc, _ = self.matrix_info()
+        return sp.bsr_matrix((vals, ci, rp), shape=(nr * self.dim, nc * self.dim)).tocsr()
+
+    def export_upper_triplets(self):
+        n = C.c_uint64(0)
+        self._ck(self.lib.mfh_export_upper_triplets(self.h, None, None, None, C.byref(n)))
+        i, j, v = np.empty(n.value, np.uint64), np.empty(n.value, np.uint64), np.empty(n.value)
+        self._ck(self.lib.mfh_export_upper_triplets(self.h, ptr(i), ptr(j), ptr(v), C.byref(n)))
+        return i, j, v
+
+    def element_stiffness(self, first=0, count=None):
+        count = self.n_elem - first if count is None else count
+        ks = self.npe * self.dim
+        out = np.empty((count, ks, ks))
+        self._ck(self.lib.mfh_element_stiffness(self.h, int(first), int(count), ptr(out)))
+        return out
+
+    # ---------------------------------------------------------------- solve
+    def clear_fixed(self):
+        self._ck(self.lib.mfh_clear_fixed(self.h))
+
+    def fix_variables(self, vars_, vals=None):
+        v = as_i64(vars_)
+        x = None if vals is None else as_f64(vals)
+        self._ck(self.lib.mfh_fix_variables(self.h, len(v), ptr(v), ptr(x)))
+
+    def set_preconditioner(self, kind):
+        self._ck(self.lib.mfh_set_preconditioner(self.h, int(kind)))
+
+    def solve(self, f, rtol=1e-8, maxit=100000):
+        f = as_f64(f)
+        n = self.dim * self.n_dof
+        nrhs = f.size // n
+        assert f.size == nrhs * n
+        u = np.empty_like(f)
+        info = L.SolveInfo()
+        st = self.lib.mfh_solve(self.h, nrhs, ptr(f), ptr(u), float(rtol), int(maxit), C.byref(info))
+        self.last_info = info.as_dict()
+        self._ck(st)
+        return u
+
+    def apply_K(self, u):
+        u = as_f64(u)
+        nr, nc, _ = self.matrix_info() if self._assembled_info() else (self.n_dof, self.n_dof, 0)
+        out = np.empty(nr * self.dim)
+        self._ck(self.lib.mfh_apply_K(self.h, ptr(u), ptr(out)))
+        return out
+
+    def _assembled_info(self):
+        a = C.c_int64()
+        return self.lib.mfh_matrix_info(self.h, C.byref(a), None, None) == L.OK
+
+    # ---------------------------------------------------------------- Simulator-level helpers
+    def bc_clear(self):
+        self._ck(self.lib.mfh_bc_clear(self.h))
+
+    def bc_dirichlet_box(self, mn, mx, value, relative=False, components=None):
+        mn, mx, value = as_f64(mn), as_f64(mx), as_f64(value)
+        mask = (1 << self.dim) - 1 if components is None else sum(1 << c for c in range(self.dim) if components[c])
+        self._ck(self.lib.mfh_bc_dirichlet_box(self.h, ptr(mn), ptr(mx), int(relative), ptr(value), mask))
+
+    def bc_neumann_box(self, mn, mx, value, kind=L.NEUMANN_TRACTION, relative=False):
+        mn, mx = as_f64(mn), as_f64(mx)
+        value = as_f64(np.atleast_1d(value))
+        if len(value) < self.dim:
+            value = np.concatenate([value, np.zeros(self.dim - len(value))])
+        self._ck(self.lib.mfh_bc_neumann_box(self.h, ptr(mn), ptr(mx), int(relative), ptr(value), int(kind)))
+
+    def bc_delta_force(self, node, force):
+        force = as_f64(force)
+        self._ck(self.lib.mfh_bc_delta_force(self.h, int(node), ptr(force)))
+
+    def bc_dirichlet_vars(self):
+        n = C.c_int64(0)
+        self._ck(self.lib.mfh_bc_dirichlet_vars(self.h, None, None, C.byref(n)))
+        v, x = np.empty(n.value, np.int64), np.empty(n.value)
+        self._ck(self.lib.mfh_bc_dirichlet_vars(self.h, ptr(v), ptr(x), C.byref(n)))
+        return v, x
+
+    def pin_node(self):
+        n = C.c_int64()
+        self._ck(self.lib.mfh_pin_node(self.h, C.byref(n)))
+        return n.value
+
+    def neumann_load(self):
+        out = np.empty((self.n_dof, self.dim))
+        self._ck(self.lib.mfh_neumann_load(self.h, ptr(out)))
+        return out
+
+    def constant_strain_load(self, cstrain_flat):
+        e = as_f64(cstrain_flat)
+        out = np.empty((self.n_dof, self.dim))
+        self._ck(self.lib.mfh_constant_strain_load(self.h, ptr(e), ptr(out)))
+        return out
+
+    def sim_solve(self, f=None, use_pin=False, rtol=1e-8, maxit=100000):
+        fp = None if f is None else as_f64(f)
+        u = np.empty((self.n_node, self.dim))
+        info = L.SolveInfo()
+        st = self.lib.mfh_sim_solve(self.h, ptr(fp), int(use_pin), ptr(u), float(rtol), int(maxit), C.byref(info))
+        self.last_info = info.as_dict()
+        self._ck(st)
+        return u
+
+    def average_strain(self, u_nodes):
+        u = as_f64(u_nodes)
+        out = np.empty((self.n_elem, flat_len(self.dim)))
+        self._ck(self.lib.mfh_average_strain(self.h, ptr(u), ptr(out)))
+        return out
+
+    def average_stress(self, u_nodes):
+        u = as_f64(u_nodes)
+        out = np.empty((self.n_elem, flat_len(self.dim)))
+        self._ck(self.lib.mfh_average_stress(self.h, ptr(u), ptr(out)))
+        return out
+
+    # ---------------------------------------------------------------- device pointers (torch interop)
+    def stream(self):
+        return self.lib.mfh_stream(self.h)
+
+    def dev_spmv(self, x_ptr, y_ptr):
+        self._ck(self.lib.mfh_dev_spmv(self.h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))
+
+    def dev_precond(self, r_ptr, z_ptr):
+        self._ck(self.lib.mfh_dev_precond(self.h, C.c_void_p(r_ptr), C.c_void_p(z_ptr)))
+
+    def dev_mask_fixed(self, r_ptr):
+        self._ck(self.lib.mfh_dev_mask_fixed(self.h, C.c_void_p(r_ptr)))
+
+    def dev_set_fixed_values(self, u_ptr):
+        self._ck(self.lib.mfh_dev_set_fixed_values(self.h, C.c_void_p(u_ptr)))
+
+    def dev_sync(self):
+        self._ck(self.lib.mfh_dev_sync(self.h))
+
+    # ---------------------------------------------------------------- measurement
+    def timing(self):
+        t = L.Timing()
+        self._ck(self.lib.mfh_get_timing(self.h, C.byref(t)))
+        return t.as_dict()
+
+    def time_assembly_kernel(self, mode=L.ASSEMBLE_GATHER, reps=5):
+        v = C.c_double()
+        self._ck(self.lib.mfh_time_assembly_kernel(self.h, int(mode), int(reps), C.byref(v)))
+        return v.value
+
+    def time_spmv_kernel(self, reps=10):
+        v = C.c_double()
+        self._ck(self.lib.mfh_time_spmv_kernel(self.h, int(reps), C.byref(v)))
+        return v.value
+
+    def set_option(self, key, value):
+        self._ck(self.lib.mfh_set_option(self.h, key.encode(), float(value)))

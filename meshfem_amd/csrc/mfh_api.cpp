@@ -1,0 +1,1264 @@
+// C ABI of libmeshfem_hip.so (include/meshfem_hip.h). Host orchestration only: every numeric
+// loop of the hot path runs in mfh_kernels.hip.
+#include "mfh_internal.hh"
+#include <cmath>
+#include <map>
+#include <mutex>
+
+using namespace mfh;
+
+struct mfh_ctx {
+    int device = 0;
+    bool hostOnly = false;            // device == -1: mesh/symbolic host logic only (CPU tests)
+    bool keepHostSymbolic = false;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // ---- mesh
+    HostMesh mesh;
+    bool haveMesh = false;
+    DBuf<int32_t> dElemNodes;
+    DBuf<double> dVertPos;
+
+    // ---- material
+    int matMode = 0;                  // see k_geometry
+    int matKind = MAT_ISO;
+    std::vector<double> matParams;    // host copy in the layout k_geometry expects
+    DBuf<double> dMatParams;
+    DBuf<double> dGeo;
+    DBuf<int> dNeg;
+    int geoStride = GEO_ISO_STRIDE;
+    bool geoValid = false;
+    std::vector<double> hGeo;         // lazily downloaded copy (loads / post-processing)
+    bool hGeoValid = false;
+
+    // ---- DoF map
+    std::vector<int32_t> dofForNode;  // empty = identity
+    int64_t nDoF = 0;
+
+    // ---- symbolic
+    Symbolic sym;
+    bool symValid = false;
+    bool symHasScatter = false;
+    DBuf<int32_t> dRowPtr, dColIdx, dChunkRow, dScatter;
+    DBuf<int64_t> dContribPtr;
+    DBuf<uint32_t> dContribCode;
+    DBuf<uint16_t> dContribSlot;
+    ShapeTables tables;
+    DBuf<double> dPairTable;
+
+    // ---- numeric
+    DBuf<double> dVals;
+    bool assembled = false;
+
+    // ---- constraints (SPSDSystem state)
+    std::vector<int64_t> fixedVars;
+    std::vector<double> fixedVals;
+    std::vector<uint8_t> hFixedMask;
+    DBuf<uint8_t> dFixedMask;
+    DBuf<int64_t> dFixedIdx;
+    DBuf<double> dFixedVal;
+    bool fixedUploaded = false;
+    bool anyFixedNonzero = false;
+
+    // ---- solver
+    int precond = MFH_PRECOND_BLOCK_JACOBI;
+    DBuf<double> dDinv;
+    bool dinvValid = false;
+    DBuf<double> wx, wr, wz, wp, wAp, wb, wf, wu0, scal, stop;
+    int checkEvery = 50;
+
+    // ---- Simulator-level boundary conditions
+    std::vector<double> neumannTraction;   // nBE x dim
+    std::vector<uint8_t> dirMask;          // nNode x dim
+    std::vector<double> dirVal;            // nNode x dim
+    std::vector<std::pair<int64_t, std::array<double, 3>>> deltaForces;
+
+    // ---- options
+    int chunkSlots = 512;
+    int contribOrder = 0;
+    mfh_timing timing{0, 0, 0, 0};
+
+    int dim() const { return mesh.dim; }
+    int64_t nOwnedDoF() const {
+        // owned rows: DoFs of the first nOwned nodes. With a periodic map all DoFs are owned.
+        if (mesh.nOwned == mesh.nNode) return nDoF;
+        return mesh.nOwned;
+    }
+};
+
+namespace {
+
+#define MFH_TRY(ctx) try {
+#define MFH_CATCH(ctx)                                              \
+    } catch (const mfh::Error &e) {                                 \
+        if (ctx) (ctx)->err = e.what();                             \
+        return e.code;                                              \
+    } catch (const std::bad_alloc &) {                              \
+        if (ctx) (ctx)->err = "host allocation failed";             \
+        return MFH_ERR_HIP;                                         \
+    } catch (const std::exception &e) {                             \
+        if (ctx) (ctx)->err = e.what();                             \
+        return MFH_ERR_INVALID;                                     \
+    }                                                               \
+    return MFH_OK;
+
+void require(bool cond, mfh_status code, const char *msg) {
+    if (!cond) throw Error(code, msg);
+}
+
+struct EventTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
+    explicit EventTimer(hipStream_t s_) : s(s_) {
+        MFH_HIP(hipEventCreate(&a));
+        MFH_HIP(hipEventCreate(&b));
+        MFH_HIP(hipEventRecord(a, s));
+    }
+    double stop() {
+        MFH_HIP(hipEventRecord(b, s));
+        MFH_HIP(hipEventSynchronize(b));
+        float ms = 0;
+        MFH_HIP(hipEventElapsedTime(&ms, a, b));
+        return ms;
+    }
+    ~EventTimer() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
+void invalidate_matrix(mfh_ctx *c) {
+    c->assembled = false;
+    c->dinvValid = false;
+}
+void invalidate_symbolic(mfh_ctx *c) {
+    c->symValid = false;
+    invalidate_matrix(c);
+}
+void reset_bcs(mfh_ctx *c) {
+    const HostMesh &m = c->mesh;
+    c->neumannTraction.assign((size_t)m.nBE() * m.dim, 0.0);
+    c->dirMask.assign((size_t)m.nNode * m.dim, 0);
+    c->dirVal.assign((size_t)m.nNode * m.dim, 0.0);
+    c->deltaForces.clear();
+}
+void clear_fixed(mfh_ctx *c) {
+    c->fixedVars.clear();
+    c->fixedVals.clear();
+    c->hFixedMask.assign((size_t)c->dim() * c->nDoF, 0);
+    c->fixedUploaded = false;
+    c->anyFixedNonzero = false;
+    c->dinvValid = false;
+}
+
+void upload_mesh(mfh_ctx *c) {
+    double t0 = now_ms();
+    if (!c->hostOnly) {
+        MFH_HIP(hipSetDevice(c->device));
+        c->dElemNodes.upload(c->mesh.elemNodes, c->stream);
+        c->dVertPos.upload(c->mesh.vertPos.data(), (size_t)c->mesh.nVert * c->mesh.dim, c->stream);
+    }
+    c->timing.upload_ms = now_ms() - t0;
+    c->haveMesh = true;
+    c->geoValid = false;
+    c->hGeoValid = false;
+    c->dofForNode.clear();
+    c->nDoF = c->mesh.nNode;
+    build_shape_tables(c->mesh.dim, c->mesh.deg, c->tables);
+    if (!c->hostOnly) c->dPairTable.upload(c->tables.pairTable, c->stream);
+    invalidate_symbolic(c);
+    reset_bcs(c);
+    clear_fixed(c);
+}
+
+// default material: E = 1, nu = 0.3 (Materials.hh:408)
+void set_isotropic(mfh_ctx *c, double E, double nu) {
+    double lam = (nu * E) / ((1.0 + nu) * (1.0 - 2.0 * nu));
+    if (c->haveMesh && c->mesh.dim == 2) lam = (nu * E) / (1.0 - nu * nu);
+    c->matMode = 0;
+    c->matKind = MAT_ISO;
+    c->matParams = {lam, E / (2.0 + 2.0 * nu), E, nu};
+    c->geoValid = false;
+    c->hGeoValid = false;
+    invalidate_matrix(c);
+}
+
+void ensure_geometry(mfh_ctx *c) {
+    require(c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    if (c->geoValid) return;
+    require(!c->hostOnly, MFH_ERR_HIP, "host-only context (device -1): no HIP device, and there is no CPU fallback");
+    MFH_HIP(hipSetDevice(c->device));
+    const HostMesh &m = c->mesh;
+    if (c->matParams.empty()) set_isotropic(c, 1.0, 0.3);
+    if (c->matMode == 0) {
+        // plane stress lambda depends on dim: recompute now that the mesh is known
+        double E = c->matParams[2], nu = c->matParams[3];
+        double lam = (nu * E) / ((1.0 + nu) * (1.0 - 2.0 * nu));
+        if (m.dim == 2) lam = (nu * E) / (1.0 - nu * nu);
+        c->matParams[0] = lam;
+    }
+    c->geoStride = c->matKind == MAT_ISO ? GEO_ISO_STRIDE : GEO_GEN_STRIDE;
+    c->dMatParams.upload(c->matParams, c->stream);
+    c->dGeo.alloc((size_t)m.nElem * c->geoStride);
+    c->dNeg.alloc(1);
+    c->dNeg.zero(c->stream);
+    EventTimer t(c->stream);
+    k::launch_geometry(m.dim, m.deg, c->matKind, m.nElem, c->dElemNodes.p, m.npe, c->dVertPos.p, c->dMatParams.p, c->matMode,
+                       c->dGeo.p, c->geoStride, c->dNeg.p, c->stream);
+    c->timing.geometry_ms = t.stop();
+    int neg = 0;
+    c->dNeg.download(&neg, 1, c->stream);
+    if (neg > 0)   // LinearElasticity.hh:465-472
+        throw Error(MFH_ERR_INVALID, "Mesh has negatively oriented elements.\nCorrect with: mesh_convert --reorientNegativeElements. (" +
+                                         std::to_string(neg) + " elements)");
+    c->geoValid = true;
+    c->hGeoValid = false;
+}
+
+const std::vector<double> &host_geo(mfh_ctx *c) {
+    ensure_geometry(c);
+    if (!c->hGeoValid) {
+        c->hGeo.resize(c->dGeo.n);
+        c->dGeo.download(c->hGeo.data(), c->dGeo.n, c->stream);
+        c->hGeoValid = true;
+    }
+    return c->hGeo;
+}
+
+void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
+    require(c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    if (c->symValid && (!wantScatter || c->symHasScatter)) return;
+    double t0 = now_ms();
+    build_symbolic(c->mesh, c->dofForNode, c->nDoF, c->nOwnedDoF(), c->chunkSlots, c->contribOrder, wantScatter, c->sym);
+    c->timing.symbolic_ms = now_ms() - t0;
+    const Symbolic &S = c->sym;
+    c->symHasScatter = wantScatter;
+    if (c->hostOnly) { c->symValid = true; return; }
+    MFH_HIP(hipSetDevice(c->device));
+    c->dRowPtr.upload(S.rowPtr, c->stream);
+    c->dColIdx.upload(S.colIdx, c->stream);
+    c->dChunkRow.upload(S.chunkRow, c->stream);
+    c->dContribPtr.upload(S.contribPtr, c->stream);
+    c->dContribCode.upload(S.contribCode, c->stream);
+    c->dContribSlot.upload(S.contribSlot, c->stream);
+    if (wantScatter) c->dScatter.upload(S.scatterSlot, c->stream);
+    c->symHasScatter = wantScatter;
+    if (!c->keepHostSymbolic) {   // host copies of the big gather lists are no longer needed
+        std::vector<uint32_t>().swap(c->sym.contribCode);
+        std::vector<uint16_t>().swap(c->sym.contribSlot);
+        std::vector<int32_t>().swap(c->sym.scatterSlot);
+    }
+    const size_t tiles = (size_t)((S.nnzb + 63) / 64);
+    c->dVals.alloc(tiles * 64 * (size_t)c->dim() * c->dim());
+    c->symValid = true;
+    invalidate_matrix(c);
+}
+
+k::AsmArgs asm_args(mfh_ctx *c) {
+    const HostMesh &m = c->mesh;
+    k::AsmArgs a{};
+    a.dim = m.dim; a.deg = m.deg; a.npe = m.npe; a.mat = c->matKind;
+    a.geoStride = c->geoStride; a.geo = c->dGeo.p; a.pairTable = c->dPairTable.p;
+    a.nChunk = c->sym.nChunk(); a.chunkRow = c->dChunkRow.p; a.rowPtr = c->dRowPtr.p;
+    a.contribPtr = c->dContribPtr.p; a.contribCode = c->dContribCode.p; a.contribSlot = c->dContribSlot.p;
+    a.chunkSlots = c->sym.chunkSlots;
+    a.nElem = m.nElem; a.scatterSlot = c->dScatter.p;
+    a.vals = c->dVals.p; a.nnzb = c->sym.nnzb;
+    return a;
+}
+
+void run_assembly(mfh_ctx *c, int mode) {
+    k::AsmArgs a = asm_args(c);
+    if (mode == MFH_ASSEMBLE_ATOMIC) {
+        c->dVals.zero(c->stream);
+        k::launch_assemble_atomic(a, c->stream);
+    } else {
+        k::launch_assemble_gather(a, c->stream);
+    }
+}
+
+void ensure_assembled(mfh_ctx *c) {
+    if (c->assembled) return;
+    ensure_geometry(c);
+    ensure_symbolic(c, false);
+    EventTimer t(c->stream);
+    run_assembly(c, MFH_ASSEMBLE_GATHER);
+    c->timing.assemble_ms = t.stop();
+    c->assembled = true;
+    c->dinvValid = false;
+}
+
+k::SpmvArgs spmv_args(mfh_ctx *c, bool masked) {
+    k::SpmvArgs a{};
+    a.dim = c->dim(); a.nChunk = c->sym.nChunk(); a.chunkRow = c->dChunkRow.p; a.rowPtr = c->dRowPtr.p;
+    a.colIdx = c->dColIdx.p; a.vals = c->dVals.p; a.chunkSlots = c->sym.chunkSlots;
+    a.fixedMask = masked ? c->dFixedMask.p : nullptr;
+    return a;
+}
+
+void ensure_fixed_uploaded(mfh_ctx *c) {
+    if (c->fixedUploaded) return;
+    const size_t n = (size_t)c->dim() * c->nDoF;
+    if (c->hFixedMask.size() != n) c->hFixedMask.assign(n, 0);
+    c->dFixedMask.upload(c->hFixedMask, c->stream);
+    c->dFixedIdx.upload(c->fixedVars, c->stream);
+    c->dFixedVal.upload(c->fixedVals, c->stream);
+    c->fixedUploaded = true;
+    c->dinvValid = false;
+}
+
+void ensure_precond(mfh_ctx *c) {
+    ensure_assembled(c);
+    ensure_fixed_uploaded(c);
+    if (c->dinvValid) return;
+    const int d = c->dim();
+    c->dDinv.alloc((size_t)c->sym.nRows * d * d);
+    k::launch_extract_diag_inv(d, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, c->dFixedMask.p, c->precond, c->dDinv.p,
+                               c->stream);
+    c->dinvValid = true;
+}
+
+double device_dot(mfh_ctx *c, int64_t n, const double *a, const double *b) {
+    c->stop.alloc(4);
+    MFH_HIP(hipMemsetAsync(c->stop.p + 1, 0, sizeof(double), c->stream));
+    k::launch_dot(n, a, b, c->stop.p + 1, c->stream);
+    double v = 0;
+    MFH_HIP(hipMemcpyAsync(&v, c->stop.p + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    MFH_HIP(hipStreamSynchronize(c->stream));
+    return v;
+}
+
+// PCG on the free variables of K (SPSDSystem::solve with CHOLMOD replaced).
+void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info) {
+    const int d = c->dim();
+    const int64_t n = (int64_t)d * c->nDoF;
+    require(c->sym.nRows == c->sym.nCols, MFH_ERR_STATE,
+            "mfh_solve needs all rows owned; use the mfh_dev_* building blocks for partitioned meshes");
+    hipStream_t s = c->stream;
+    c->wx.alloc(n); c->wr.alloc(n); c->wz.alloc(n); c->wp.alloc(n); c->wAp.alloc(n); c->wb.alloc(n); c->wf.alloc(n);
+    c->stop.alloc(4);
+    EventTimer tsetup(s);
+    MFH_HIP(hipMemcpyAsync(c->wf.p, f, n * sizeof(double), hipMemcpyHostToDevice, s));
+    // b = f - K ubar on the free variables (SparseMatrices.hh:2457-2470,2526-2535)
+    MFH_HIP(hipMemcpyAsync(c->wb.p, c->wf.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (c->anyFixedNonzero) {
+        c->wu0.alloc(n);
+        c->wu0.zero(s);
+        k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wu0.p, s);
+        k::launch_spmv(spmv_args(c, false), c->wu0.p, c->wAp.p, nullptr, s);
+        k::launch_axpby(n, -1.0, c->wAp.p, 1.0, c->wb.p, s);
+    }
+    if (!c->fixedVars.empty()) k::launch_mask(n, c->dFixedMask.p, c->wb.p, s);
+    const double bb = device_dot(c, n, c->wb.p, c->wb.p);
+    mfh_solve_info li{};
+    const size_t scalN = ((size_t)maxit + 2) * 4;
+    c->scal.alloc(scalN);
+    c->scal.zero(s);
+    const double stopv = rtol * rtol * bb;
+    MFH_HIP(hipMemcpyAsync(c->stop.p, &stopv, sizeof(double), hipMemcpyHostToDevice, s));
+    li.setup_ms = tsetup.stop();
+    int itDone = 0;
+    double rrFinal = 0;
+    if (bb == 0.0) {
+        c->wx.zero(s);
+        li.converged = 1;
+    } else {
+        EventTimer tsolve(s);
+        k::launch_pcg_init(d, c->sym.nRows, c->dDinv.p, c->wb.p, c->wx.p, c->wr.p, c->wz.p, c->wp.p, c->scal.p, s);
+        const k::SpmvArgs sa = spmv_args(c, !c->fixedVars.empty());
+        std::vector<double> hs;
+        int it = 0;
+        bool done = false;
+        int lastChecked = 0;
+        while (!done && it < maxit) {
+            const int itEnd = std::min(maxit, it + c->checkEvery);
+            for (; it < itEnd; ++it) {
+                k::launch_pcg_spmv(sa, c->wp.p, c->wAp.p, c->scal.p, it, c->stop.p, s);
+                k::launch_pcg_update(d, c->sym.nRows, c->dDinv.p, c->wp.p, c->wAp.p, c->wx.p, c->wr.p, c->wz.p, c->scal.p, it,
+                                     c->stop.p, s);
+                k::launch_pcg_direction(n, c->wz.p, c->wp.p, c->scal.p, it, c->stop.p, s);
+            }
+            // scan the residual history of the iterations just enqueued
+            hs.resize((size_t)(it - lastChecked + 1) * 4);
+            MFH_HIP(hipMemcpyAsync(hs.data(), c->scal.p + (size_t)lastChecked * 4, hs.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+            MFH_HIP(hipStreamSynchronize(s));
+            for (int k2 = lastChecked; k2 <= it; ++k2) {
+                const double rr = hs[(size_t)(k2 - lastChecked) * 4 + 2];
+                if (rr <= stopv) { done = true; itDone = k2; rrFinal = rr; break; }
+                if (!(rr == rr)) throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (NaN residual): K is not SPD on the free variables");
+            }
+            if (!done) { itDone = it; rrFinal = hs[(size_t)(it - lastChecked) * 4 + 2]; }
+            lastChecked = it;
+        }
+        li.solve_ms = tsolve.stop();
+        li.converged = done ? 1 : 0;
+    }
+    li.iterations = itDone;
+    li.rel_residual = bb > 0 ? std::sqrt(rrFinal / bb) : 0.0;
+    // u = x + ubar  (SparseMatrices.hh:2592-2605)
+    if (!c->fixedVars.empty())
+        k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wx.p, s);
+    // true residual on the free variables: || mask(f - K u) || / ||b||
+    if (bb > 0) {
+        k::launch_spmv(spmv_args(c, false), c->wx.p, c->wAp.p, nullptr, s);
+        k::launch_axpby(n, 1.0, c->wf.p, -1.0, c->wAp.p, s);
+        if (!c->fixedVars.empty()) k::launch_mask(n, c->dFixedMask.p, c->wAp.p, s);
+        li.true_rel_residual = std::sqrt(device_dot(c, n, c->wAp.p, c->wAp.p) / bb);
+    }
+    MFH_HIP(hipMemcpyAsync(u, c->wx.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    if (info) *info = li;
+}
+
+void box_corners(mfh_ctx *c, const double *mn, const double *mx, int relative, double *omn, double *omx) {
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    if (!relative) {
+        for (int a = 0; a < d; ++a) { omn[a] = mn[a]; omx[a] = mx[a]; }
+        return;
+    }
+    double bmn[3] = {1e300, 1e300, 1e300}, bmx[3] = {-1e300, -1e300, -1e300};
+    for (int64_t n = 0; n < m.nNode; ++n)
+        for (int a = 0; a < d; ++a) {
+            bmn[a] = std::min(bmn[a], m.nodePos[(size_t)n * d + a]);
+            bmx[a] = std::max(bmx[a], m.nodePos[(size_t)n * d + a]);
+        }
+    for (int a = 0; a < d; ++a) {   // BoundaryConditions.cc:310-316
+        omn[a] = bmn[a] + mn[a] * (bmx[a] - bmn[a]);
+        omx[a] = bmn[a] + mx[a] * (bmx[a] - bmn[a]);
+    }
+}
+
+inline int32_t dof_of(const mfh_ctx *c, int64_t node) { return c->dofForNode.empty() ? (int32_t)node : c->dofForNode[node]; }
+
+void dirichlet_vars(mfh_ctx *c, std::vector<int64_t> &vars, std::vector<double> &vals) {
+    // m_getDirichletVarsAndValues (LinearElasticity.hh:1469-1518)
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    std::vector<int32_t> constraintIndex((size_t)c->nDoF, -1);
+    std::vector<int32_t> cDoF;
+    std::vector<int64_t> cNode;
+    for (int32_t bn : m.bdryNodes) {
+        bool has = false;
+        for (int a = 0; a < d; ++a) has |= c->dirMask[(size_t)bn * d + a] != 0;
+        if (!has) continue;
+        const int32_t dof = dof_of(c, bn);
+        if (constraintIndex[dof] < 0) {
+            constraintIndex[dof] = (int32_t)cDoF.size();
+            cDoF.push_back(dof);
+            cNode.push_back(bn);
+        } else {
+            const int64_t o = cNode[constraintIndex[dof]];
+            double diff = 0;
+            bool cdiffer = false;
+            for (int a = 0; a < d; ++a) {
+                const double dd = c->dirVal[(size_t)bn * d + a] - c->dirVal[(size_t)o * d + a];
+                diff += dd * dd;
+                cdiffer |= c->dirMask[(size_t)bn * d + a] != c->dirMask[(size_t)o * d + a];
+            }
+            if (std::sqrt(diff) > 1e-10 || cdiffer) throw Error(MFH_ERR_INVALID, "Mismatched Dirichlet constraint on periodic DoF");
+        }
+    }
+    for (size_t k = 0; k < cDoF.size(); ++k)
+        for (int a = 0; a < d; ++a)
+            if (c->dirMask[(size_t)cNode[k] * d + a]) {
+                vars.push_back((int64_t)d * cDoF[k] + a);
+                vals.push_back(c->dirVal[(size_t)cNode[k] * d + a]);
+            }
+}
+
+int64_t pin_node(const mfh_ctx *c) {   // LinearElasticity.hh:1595-1609
+    const HostMesh &m = c->mesh;
+    for (int64_t i = 0; i < m.nNode; ++i)
+        if (!m.isBdryNode[i]) return i;
+    return 0;
+}
+
+void add_fixed(mfh_ctx *c, int64_t n, const int64_t *vars, const double *vals) {
+    const int64_t nv = (int64_t)c->dim() * c->nDoF;
+    if (c->hFixedMask.size() != (size_t)nv) c->hFixedMask.assign((size_t)nv, 0);
+    for (int64_t k = 0; k < n; ++k) {
+        require(vars[k] >= 0 && vars[k] < nv, MFH_ERR_INVALID, "fixed variable index out of range");
+        require(!c->hFixedMask[vars[k]], MFH_ERR_INVALID, "Variable already fixed.");   // SparseMatrices.hh:2433
+        c->hFixedMask[vars[k]] = 1;
+        c->fixedVars.push_back(vars[k]);
+        const double v = vals ? vals[k] : 0.0;
+        c->fixedVals.push_back(v);
+        if (v != 0.0) c->anyFixedNonzero = true;
+    }
+    c->fixedUploaded = false;
+    c->dinvValid = false;
+}
+
+// element material tensor D (flatLen x flatLen) from the geometry record
+void elem_D(const mfh_ctx *c, const double *g, double *D) {
+    const int d = c->mesh.dim, fl = flat_len(d);
+    std::fill(D, D + fl * fl, 0.0);
+    if (c->matKind == MAT_ISO) {
+        const double lam = g[13], mu = g[14];
+        for (int i = 0; i < d; ++i) {
+            for (int j = 0; j < d; ++j) D[i * fl + j] = lam;
+            D[i * fl + i] = lam + 2 * mu;
+        }
+        for (int k = d; k < fl; ++k) D[k * fl + k] = mu;
+    } else {
+        int idx = 0;
+        for (int r = 0; r < fl; ++r)
+            for (int cc = r; cc < fl; ++cc, ++idx) D[r * fl + cc] = D[cc * fl + r] = g[13 + idx];
+    }
+}
+
+} // namespace
+
+// =================================================================================================
+extern "C" {
+
+const char *mfh_version(void) { return "meshfem_hip 0.1 (gfx950)"; }
+
+mfh_status mfh_create(int32_t device, mfh_ctx **out) {
+    if (!out) return MFH_ERR_INVALID;
+    *out = nullptr;
+    mfh_ctx *c = new (std::nothrow) mfh_ctx();
+    if (!c) return MFH_ERR_HIP;
+    try {
+        if (device == -1) {   // host-only context for CPU tests of the mesh / symbolic logic
+            c->hostOnly = true;
+            c->keepHostSymbolic = true;
+            *out = c;
+            return MFH_OK;
+        }
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= 0)
+            throw Error(MFH_ERR_HIP, "no HIP device available: libmeshfem_hip has no CPU fallback");
+        require(device >= 0 && device < count, MFH_ERR_INVALID, "bad device ordinal");
+        c->device = device;
+        MFH_HIP(hipSetDevice(device));
+        MFH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    } catch (const mfh::Error &e) {
+        static thread_local std::string lastCreateError;
+        lastCreateError = e.what();
+        fprintf(stderr, "mfh_create: %s\n", e.what());
+        mfh_status code = e.code;
+        delete c;
+        return code;
+    }
+    *out = c;
+    return MFH_OK;
+}
+
+void mfh_destroy(mfh_ctx *c) {
+    if (!c) return;
+    if (!c->hostOnly) (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    hipStream_t s = c->stream;
+    c->stream = nullptr;
+    delete c;
+    if (s) (void)hipStreamDestroy(s);
+}
+
+const char *mfh_last_error(const mfh_ctx *c) { return c ? c->err.c_str() : "null context"; }
+void *mfh_stream(mfh_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ---------------------------------------------------------------- mesh
+mfh_status mfh_mesh_build(mfh_ctx *c, int32_t dim, int32_t deg, int64_t nElem, int64_t nVert, const int32_t *elemVerts,
+                          const double *vertPos) {
+    MFH_TRY(c)
+    require(c && elemVerts && vertPos, MFH_ERR_INVALID, "null argument");
+    build_fem_mesh(c->mesh, dim, deg, nElem, nVert, elemVerts, vertPos);
+    upload_mesh(c);
+    if (!c->hostOnly) ensure_geometry(c);   // throws on negative volumes like the Simulator ctor
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_mesh_set(mfh_ctx *c, int32_t dim, int32_t deg, int64_t nElem, int64_t nNode, int64_t nVert, int64_t nOwned,
+                        const int32_t *elemNodes, const double *vertPos) {
+    MFH_TRY(c)
+    require(c && elemNodes && vertPos, MFH_ERR_INVALID, "null argument");
+    require((dim == 2 || dim == 3) && (deg == 1 || deg == 2), MFH_ERR_INVALID, "dim must be 2/3 and deg 1/2");
+    require(nElem > 0 && nVert > 0 && nNode >= nVert && nOwned > 0 && nOwned <= nNode, MFH_ERR_INVALID, "bad mesh sizes");
+    HostMesh &m = c->mesh;
+    m = HostMesh();
+    m.dim = dim; m.deg = deg; m.npe = nodes_per_elem(dim, deg); m.npbe = nodes_per_bdry_elem(dim, deg);
+    m.nElem = nElem; m.nNode = nNode; m.nVert = nVert; m.nOwned = nOwned;
+    m.elemNodes.assign(elemNodes, elemNodes + nElem * m.npe);
+    for (int64_t e = 0; e < nElem; ++e)
+        for (int k = 0; k < m.npe; ++k) {
+            const int32_t v = elemNodes[e * m.npe + k];
+            require(v >= 0 && v < (k <= dim ? nVert : nNode), MFH_ERR_INVALID, "Bad node index encountered.");
+        }
+    m.vertPos.assign(vertPos, vertPos + nVert * dim);
+    compute_node_positions(m);
+    m.isBdryNode.assign((size_t)nNode, 0);
+    upload_mesh(c);
+    if (!c->hostOnly) ensure_geometry(c);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_mesh_sizes(const mfh_ctx *c, int64_t *nElem, int64_t *nNode, int64_t *nVert, int64_t *nBdryElem, int64_t *nBdryNode,
+                          int32_t *npe, int32_t *npbe) {
+    if (!c || !c->haveMesh) return MFH_ERR_STATE;
+    const HostMesh &m = c->mesh;
+    if (nElem) *nElem = m.nElem;
+    if (nNode) *nNode = m.nNode;
+    if (nVert) *nVert = m.nVert;
+    if (nBdryElem) *nBdryElem = m.nBE();
+    if (nBdryNode) *nBdryNode = (int64_t)m.bdryNodes.size();
+    if (npe) *npe = m.npe;
+    if (npbe) *npbe = m.npbe;
+    return MFH_OK;
+}
+
+mfh_status mfh_mesh_get_elem_nodes(const mfh_ctx *c, int32_t *out) {
+    if (!c || !c->haveMesh || !out) return MFH_ERR_STATE;
+    std::copy(c->mesh.elemNodes.begin(), c->mesh.elemNodes.end(), out);
+    return MFH_OK;
+}
+mfh_status mfh_mesh_get_node_positions(const mfh_ctx *c, double *out) {
+    if (!c || !c->haveMesh || !out) return MFH_ERR_STATE;
+    std::copy(c->mesh.nodePos.begin(), c->mesh.nodePos.end(), out);
+    return MFH_OK;
+}
+mfh_status mfh_mesh_get_boundary_elem_nodes(const mfh_ctx *c, int32_t *out) {
+    if (!c || !c->haveMesh || !out) return MFH_ERR_STATE;
+    std::copy(c->mesh.bdryElemNodes.begin(), c->mesh.bdryElemNodes.end(), out);
+    return MFH_OK;
+}
+mfh_status mfh_mesh_get_boundary_nodes(const mfh_ctx *c, int32_t *out) {
+    if (!c || !c->haveMesh || !out) return MFH_ERR_STATE;
+    std::copy(c->mesh.bdryNodes.begin(), c->mesh.bdryNodes.end(), out);
+    return MFH_OK;
+}
+mfh_status mfh_mesh_get_boundary_elem_geometry(const mfh_ctx *c, double *volume, double *normal) {
+    if (!c || !c->haveMesh) return MFH_ERR_STATE;
+    if (volume) std::copy(c->mesh.bdryVol.begin(), c->mesh.bdryVol.end(), volume);
+    if (normal) std::copy(c->mesh.bdryNormal.begin(), c->mesh.bdryNormal.end(), normal);
+    return MFH_OK;
+}
+mfh_status mfh_mesh_get_elem_volumes(mfh_ctx *c, double *out) {
+    MFH_TRY(c)
+    require(c && out, MFH_ERR_INVALID, "null argument");
+    const std::vector<double> &g = host_geo(c);
+    for (int64_t e = 0; e < c->mesh.nElem; ++e) out[e] = g[(size_t)e * c->geoStride + 12];
+    MFH_CATCH(c)
+}
+
+// ---------------------------------------------------------------- materials
+mfh_status mfh_material_isotropic(mfh_ctx *c, double E, double nu) {
+    MFH_TRY(c)
+    require(c, MFH_ERR_INVALID, "null context");
+    set_isotropic(c, E, nu);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_material_const(mfh_ctx *c, const double *D) {
+    MFH_TRY(c)
+    require(c && D && c->haveMesh, MFH_ERR_STATE, "set the mesh before the material");
+    const int fl = flat_len(c->dim());
+    c->matParams.clear();
+    for (int r = 0; r < fl; ++r)
+        for (int cc = r; cc < fl; ++cc) c->matParams.push_back(D[r * fl + cc]);   // upper triangle (_MajorSymmetry)
+    c->matMode = 2; c->matKind = MAT_GENERAL;
+    c->geoValid = false; c->hGeoValid = false;
+    invalidate_matrix(c);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_material_iso_field(mfh_ctx *c, const double *E, const double *nu) {
+    MFH_TRY(c)
+    require(c && E && nu && c->haveMesh, MFH_ERR_STATE, "set the mesh before the material");
+    const int64_t n = c->mesh.nElem;
+    c->matParams.assign((size_t)2 * n, 0.0);
+    std::copy(E, E + n, c->matParams.begin());
+    std::copy(nu, nu + n, c->matParams.begin() + n);
+    c->matMode = 1; c->matKind = MAT_ISO;
+    c->geoValid = false; c->hGeoValid = false;
+    invalidate_matrix(c);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_material_ortho_field(mfh_ctx *c, const double *params) {
+    MFH_TRY(c)
+    require(c && params && c->haveMesh, MFH_ERR_STATE, "set the mesh before the material");
+    const int np = c->dim() == 3 ? 9 : 4;
+    c->matParams.assign(params, params + (size_t)np * c->mesh.nElem);
+    c->matMode = 3; c->matKind = MAT_GENERAL;
+    c->geoValid = false; c->hGeoValid = false;
+    invalidate_matrix(c);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_material_tensor_field(mfh_ctx *c, const double *D) {
+    MFH_TRY(c)
+    require(c && D && c->haveMesh, MFH_ERR_STATE, "set the mesh before the material");
+    const int fl = flat_len(c->dim());
+    c->matParams.assign(D, D + (size_t)fl * fl * c->mesh.nElem);
+    c->matMode = 4; c->matKind = MAT_GENERAL;
+    c->geoValid = false; c->hGeoValid = false;
+    invalidate_matrix(c);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_material_get(mfh_ctx *c, int64_t elem, double *D) {
+    MFH_TRY(c)
+    require(c && D && c->haveMesh && elem >= 0 && elem < c->mesh.nElem, MFH_ERR_INVALID, "bad element");
+    const std::vector<double> &g = host_geo(c);
+    elem_D(c, &g[(size_t)elem * c->geoStride], D);
+    MFH_CATCH(c)
+}
+
+// ---------------------------------------------------------------- DoF map
+mfh_status mfh_dof_map(mfh_ctx *c, const int32_t *dofForNode, int64_t nDoF) {
+    MFH_TRY(c)
+    require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    if (!dofForNode) {
+        c->dofForNode.clear();
+        c->nDoF = c->mesh.nNode;
+    } else {
+        require(c->mesh.nOwned == c->mesh.nNode, MFH_ERR_UNSUPPORTED, "DoF maps on partitioned meshes are not supported");
+        require(nDoF > 0 && nDoF <= c->mesh.nNode, MFH_ERR_INVALID, "bad nDoF");
+        for (int64_t n = 0; n < c->mesh.nNode; ++n)
+            require(dofForNode[n] >= 0 && dofForNode[n] < nDoF, MFH_ERR_INVALID, "DoF index out of range");
+        c->dofForNode.assign(dofForNode, dofForNode + c->mesh.nNode);
+        c->nDoF = nDoF;
+    }
+    invalidate_symbolic(c);
+    clear_fixed(c);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_apply_periodic_conditions(mfh_ctx *c, double eps, int64_t *nDoF) {
+    MFH_TRY(c)
+    require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    std::vector<int32_t> dof;
+    int64_t nd = 0;
+    periodic_dof_map(c->mesh, eps, dof, nd, c->mesh.bdryInternal);
+    c->dofForNode.swap(dof);
+    c->nDoF = nd;
+    if (nDoF) *nDoF = nd;
+    invalidate_symbolic(c);
+    clear_fixed(c);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_get_dof_map(const mfh_ctx *c, int32_t *dofForNode, int64_t *nDoF) {
+    if (!c || !c->haveMesh) return MFH_ERR_STATE;
+    if (nDoF) *nDoF = c->nDoF;
+    if (dofForNode)
+        for (int64_t n = 0; n < c->mesh.nNode; ++n) dofForNode[n] = dof_of(c, n);
+    return MFH_OK;
+}
+
+// ---------------------------------------------------------------- assembly
+mfh_status mfh_symbolic(mfh_ctx *c, int32_t withScatterMap) {
+    MFH_TRY(c)
+    require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    ensure_symbolic(c, withScatterMap != 0);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_symbolic_sizes(const mfh_ctx *c, int64_t *nChunk, int64_t *nContrib, int32_t *chunkSlots, int32_t *maxRowLen) {
+    if (!c || !c->symValid) return MFH_ERR_STATE;
+    if (nChunk) *nChunk = c->sym.nChunk();
+    if (nContrib) *nContrib = c->sym.contribPtr.empty() ? 0 : c->sym.contribPtr.back();
+    if (chunkSlots) *chunkSlots = c->sym.chunkSlots;
+    if (maxRowLen) *maxRowLen = c->sym.maxRowLen;
+    return MFH_OK;
+}
+
+mfh_status mfh_symbolic_get(const mfh_ctx *c, int32_t *rowPtr, int32_t *colIdx, int32_t *chunkRow, int64_t *contribPtr,
+                            uint32_t *contribCode, uint16_t *contribSlot, int32_t *scatterSlot) {
+    if (!c || !c->symValid) return MFH_ERR_STATE;
+    const Symbolic &S = c->sym;
+    if (rowPtr) std::copy(S.rowPtr.begin(), S.rowPtr.end(), rowPtr);
+    if (colIdx) std::copy(S.colIdx.begin(), S.colIdx.end(), colIdx);
+    if (chunkRow) std::copy(S.chunkRow.begin(), S.chunkRow.end(), chunkRow);
+    if (contribPtr) std::copy(S.contribPtr.begin(), S.contribPtr.end(), contribPtr);
+    if (contribCode || contribSlot || scatterSlot) {
+        if (S.contribCode.empty()) return MFH_ERR_STATE;   // needs option keep_host_symbolic
+        if (contribCode) std::copy(S.contribCode.begin(), S.contribCode.end(), contribCode);
+        if (contribSlot) std::copy(S.contribSlot.begin(), S.contribSlot.end(), contribSlot);
+        if (scatterSlot) {
+            if (S.scatterSlot.empty()) return MFH_ERR_STATE;
+            std::copy(S.scatterSlot.begin(), S.scatterSlot.end(), scatterSlot);
+        }
+    }
+    return MFH_OK;
+}
+
+mfh_status mfh_assemble(mfh_ctx *c, int32_t mode) {
+    MFH_TRY(c)
+    require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    require(mode == MFH_ASSEMBLE_GATHER || mode == MFH_ASSEMBLE_ATOMIC, MFH_ERR_INVALID, "bad assembly mode");
+    ensure_geometry(c);
+    ensure_symbolic(c, mode == MFH_ASSEMBLE_ATOMIC);
+    EventTimer t(c->stream);
+    run_assembly(c, mode);
+    c->timing.assemble_ms = t.stop();
+    c->assembled = true;
+    c->dinvValid = false;
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_matrix_info(const mfh_ctx *c, int64_t *nBlockRows, int64_t *nBlockCols, int64_t *nnzBlocks) {
+    if (!c || !c->symValid) return MFH_ERR_STATE;
+    if (nBlockRows) *nBlockRows = c->sym.nRows;
+    if (nBlockCols) *nBlockCols = c->sym.nCols;
+    if (nnzBlocks) *nnzBlocks = c->sym.nnzb;
+    return MFH_OK;
+}
+
+mfh_status mfh_export_bsr(mfh_ctx *c, int32_t *rowPtr, int32_t *colIdx, double *vals) {
+    MFH_TRY(c)
+    require(c && c->assembled, MFH_ERR_STATE, "matrix not assembled");
+    const Symbolic &S = c->sym;
+    if (rowPtr) std::copy(S.rowPtr.begin(), S.rowPtr.end(), rowPtr);
+    if (colIdx) std::copy(S.colIdx.begin(), S.colIdx.end(), colIdx);
+    if (vals && S.nnzb) {
+        const int nb = c->dim() * c->dim();
+        DBuf<double> aos;
+        aos.alloc((size_t)S.nnzb * nb);
+        k::launch_untile_vals(c->dim(), S.nnzb, c->dVals.p, aos.p, c->stream);
+        aos.download(vals, (size_t)S.nnzb * nb, c->stream);
+    }
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_export_upper_triplets(mfh_ctx *c, uint64_t *oi, uint64_t *oj, double *ov, uint64_t *nnz) {
+    MFH_TRY(c)
+    require(c && c->assembled && nnz, MFH_ERR_STATE, "matrix not assembled");
+    require(c->sym.nRows == c->sym.nCols, MFH_ERR_STATE, "triplet export needs a square matrix");
+    const Symbolic &S = c->sym;
+    const int d = c->dim(), nb = d * d;
+    std::vector<double> vals((size_t)S.nnzb * nb);
+    {
+        DBuf<double> aos;
+        aos.alloc(vals.size());
+        k::launch_untile_vals(d, S.nnzb, c->dVals.p, aos.p, c->stream);
+        aos.download(vals.data(), vals.size(), c->stream);
+    }
+    struct T { uint64_t i, j; double v; };
+    std::vector<T> t;
+    for (int64_t r = 0; r < S.nRows; ++r)
+        for (int32_t s = S.rowPtr[r]; s < S.rowPtr[r + 1]; ++s) {
+            const int64_t col = S.colIdx[s];
+            if (col < r) continue;
+            for (int a = 0; a < d; ++a)
+                for (int b = 0; b < d; ++b) {
+                    const uint64_t gi = (uint64_t)r * d + a, gj = (uint64_t)col * d + b;
+                    const double v = vals[(size_t)s * nb + a * d + b];
+                    if (gi <= gj && v != 0.0) t.push_back(T{gi, gj, v});   // pruneTol = 0 (SparseMatrices.hh:370-373)
+                }
+        }
+    std::sort(t.begin(), t.end(), [](const T &x, const T &y) { return x.j != y.j ? x.j < y.j : x.i < y.i; });
+    if (oi && oj && ov) {
+        require(*nnz >= t.size(), MFH_ERR_INVALID, "triplet buffers too small");
+        for (size_t k2 = 0; k2 < t.size(); ++k2) { oi[k2] = t[k2].i; oj[k2] = t[k2].j; ov[k2] = t[k2].v; }
+    }
+    *nnz = t.size();
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_element_stiffness(mfh_ctx *c, int64_t first, int64_t count, double *Ke) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && Ke, MFH_ERR_STATE, "no mesh set");
+    require(first >= 0 && count > 0 && first + count <= c->mesh.nElem, MFH_ERR_INVALID, "bad element range");
+    ensure_geometry(c);
+    const size_t ks = (size_t)c->mesh.npe * c->dim();
+    DBuf<double> out;
+    out.alloc((size_t)count * ks * ks);
+    k::AsmArgs a = asm_args(c);
+    k::launch_element_stiffness(a, first, count, out.p, c->stream);
+    out.download(Ke, out.n, c->stream);
+    MFH_CATCH(c)
+}
+
+// ---------------------------------------------------------------- constrained solve
+mfh_status mfh_clear_fixed(mfh_ctx *c) {
+    MFH_TRY(c)
+    require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    clear_fixed(c);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_fix_variables(mfh_ctx *c, int64_t n, const int64_t *vars, const double *vals) {
+    MFH_TRY(c)
+    require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    if (n == 0) return MFH_OK;
+    require(vars && n > 0, MFH_ERR_INVALID, "null argument");
+    add_fixed(c, n, vars, vals);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_set_preconditioner(mfh_ctx *c, int32_t kind) {
+    if (!c || kind < 0 || kind > 2) return MFH_ERR_INVALID;
+    c->precond = kind;
+    c->dinvValid = false;
+    return MFH_OK;
+}
+
+mfh_status mfh_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, double rtol, int32_t maxit, mfh_solve_info *info) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && f && u && nrhs > 0 && maxit > 0 && rtol > 0, MFH_ERR_INVALID, "bad solve arguments");
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_precond(c);
+    const int64_t n = (int64_t)c->dim() * c->nDoF;
+    bool allConverged = true;
+    for (int k2 = 0; k2 < nrhs; ++k2) {
+        mfh_solve_info li{};
+        solve_one(c, f + (size_t)k2 * n, u + (size_t)k2 * n, rtol, maxit, &li);
+        if (info) info[0] = li;
+        allConverged &= li.converged != 0;
+    }
+    if (!allConverged) throw Error(MFH_ERR_NOT_CONVERGED, "PCG did not reach the requested tolerance within maxit iterations");
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_apply_K(mfh_ctx *c, const double *u, double *Ku) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && u && Ku, MFH_ERR_INVALID, "null argument");
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_assembled(c);
+    const int d = c->dim();
+    const int64_t nin = (int64_t)d * c->sym.nCols, nout = (int64_t)d * c->sym.nRows;
+    c->wx.alloc(nin);
+    c->wAp.alloc(std::max(nin, nout));
+    MFH_HIP(hipMemcpyAsync(c->wx.p, u, nin * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    k::launch_spmv(spmv_args(c, false), c->wx.p, c->wAp.p, nullptr, c->stream);
+    MFH_HIP(hipMemcpyAsync(Ku, c->wAp.p, nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    MFH_HIP(hipStreamSynchronize(c->stream));
+    MFH_CATCH(c)
+}
+
+// ---------------------------------------------------------------- Simulator-level helpers
+mfh_status mfh_bc_clear(mfh_ctx *c) {
+    MFH_TRY(c)
+    require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    reset_bcs(c);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_bc_dirichlet_box(mfh_ctx *c, const double *mn, const double *mx, int32_t relative, const double *value,
+                                int32_t compMask) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && c->mesh.hasTopology, MFH_ERR_STATE, "boundary conditions need mfh_mesh_build");
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    double bmn[3], bmx[3];
+    box_corners(c, mn, mx, relative, bmn, bmx);
+    for (int32_t bn : m.bdryNodes) {   // LinearElasticity.hh:941-948
+        bool in = true;
+        for (int a = 0; a < d; ++a) {
+            const double p = m.nodePos[(size_t)bn * d + a];
+            in &= (p >= bmn[a]) && (p <= bmx[a]);
+        }
+        if (!in) continue;
+        for (int a = 0; a < d; ++a) {   // BoundaryNode::setDirichlet :390-403
+            if (!(compMask & (1 << a))) continue;
+            if (!c->dirMask[(size_t)bn * d + a]) {
+                c->dirMask[(size_t)bn * d + a] = 1;
+                c->dirVal[(size_t)bn * d + a] = value[a];
+            } else if (std::fabs(c->dirVal[(size_t)bn * d + a] - value[a]) > 1e-10)
+                throw Error(MFH_ERR_INVALID, "Conflicting dirichlet displacements.");
+        }
+    }
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_bc_neumann_box(mfh_ctx *c, const double *mn, const double *mx, int32_t relative, const double *value, int32_t kind) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && c->mesh.hasTopology, MFH_ERR_STATE, "boundary conditions need mfh_mesh_build");
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    double bmn[3], bmx[3];
+    box_corners(c, mn, mx, relative, bmn, bmx);
+    std::vector<int64_t> region;
+    double area = 0;
+    for (int64_t b = 0; b < m.nBE(); ++b) {   // :899-913
+        double ctr[3] = {0, 0, 0};
+        const int32_t *bn = &m.bdryElemNodes[(size_t)b * m.npbe];
+        for (int k2 = 0; k2 < d; ++k2)
+            for (int a = 0; a < d; ++a) ctr[a] += m.vertPos[(size_t)bn[k2] * d + a];
+        bool in = true;
+        for (int a = 0; a < d; ++a) { ctr[a] /= d; in &= (ctr[a] >= bmn[a]) && (ctr[a] <= bmx[a]); }
+        if (!in) continue;
+        region.push_back(b);
+        area += m.bdryVol[b];
+        for (int a = 0; a < d; ++a)
+            c->neumannTraction[(size_t)b * d + a] = kind == MFH_NEUMANN_PRESSURE ? -value[0] * m.bdryNormal[(size_t)b * d + a] : value[a];
+    }
+    if (region.empty()) throw Error(MFH_ERR_INVALID, "Neumann region unmatched");
+    if (kind == MFH_NEUMANN_FORCE)   // :926-931
+        for (int64_t b : region)
+            for (int a = 0; a < d; ++a) c->neumannTraction[(size_t)b * d + a] /= area;
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_bc_delta_force(mfh_ctx *c, int64_t node, const double *force) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && force && node >= 0 && node < c->mesh.nNode, MFH_ERR_INVALID, "bad node");
+    std::array<double, 3> f{0, 0, 0};
+    for (int a = 0; a < c->dim(); ++a) f[a] = force[a];
+    c->deltaForces.emplace_back(node, f);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_bc_dirichlet_vars(mfh_ctx *c, int64_t *vars, double *vals, int64_t *n) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && n, MFH_ERR_STATE, "no mesh set");
+    std::vector<int64_t> v;
+    std::vector<double> x;
+    dirichlet_vars(c, v, x);
+    if (vars && vals) {
+        require(*n >= (int64_t)v.size(), MFH_ERR_INVALID, "buffers too small");
+        std::copy(v.begin(), v.end(), vars);
+        std::copy(x.begin(), x.end(), vals);
+    }
+    *n = (int64_t)v.size();
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_pin_node(const mfh_ctx *c, int64_t *node) {
+    if (!c || !c->haveMesh || !node) return MFH_ERR_STATE;
+    *node = pin_node(c);
+    return MFH_OK;
+}
+
+mfh_status mfh_neumann_load(mfh_ctx *c, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && out, MFH_ERR_STATE, "no mesh set");
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    std::fill(out, out + (size_t)d * c->nDoF, 0.0);
+    // integral of the boundary shape functions (Functions.hh:246-274): P1 1/K' each; P2 face {0,0,0,1/3,1/3,1/3};
+    // P2 edge {1/6,1/6,4/6}
+    double w[6] = {0, 0, 0, 0, 0, 0};
+    if (m.deg == 1) for (int k2 = 0; k2 < m.npbe; ++k2) w[k2] = 1.0 / m.npbe;
+    else if (d == 3) { w[3] = w[4] = w[5] = 1.0 / 3.0; }
+    else { w[0] = w[1] = 1.0 / 6.0; w[2] = 4.0 / 6.0; }
+    for (int64_t b = 0; b < m.nBE(); ++b)   // LinearElasticity.hh:706-710
+        for (int k2 = 0; k2 < m.npbe; ++k2) {
+            const int32_t dof = dof_of(c, m.bdryElemNodes[(size_t)b * m.npbe + k2]);
+            for (int a = 0; a < d; ++a) out[(size_t)dof * d + a] += (w[k2] * m.bdryVol[b]) * c->neumannTraction[(size_t)b * d + a];
+        }
+    for (auto &df : c->deltaForces)
+        for (int a = 0; a < d; ++a) out[(size_t)dof_of(c, df.first) * d + a] += df.second[a];
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_constant_strain_load(mfh_ctx *c, const double *cstrain, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && cstrain && out, MFH_ERR_STATE, "no mesh set");
+    const HostMesh &m = c->mesh;
+    const int d = m.dim, fl = flat_len(d);
+    const std::vector<double> &g = host_geo(c);
+    std::fill(out, out + (size_t)d * c->nDoF, 0.0);
+    double D[36], sd[6], cs[6], S[3][3];
+    for (int k2 = 0; k2 < fl; ++k2) sd[k2] = cstrain[k2] * (k2 < d ? 1.0 : 2.0);   // shearDoubled (ElasticityTensor.hh:437-441)
+    for (int64_t e = 0; e < m.nElem; ++e) {
+        const double *ge = &g[(size_t)e * c->geoStride];
+        elem_D(c, ge, D);
+        for (int r = 0; r < fl; ++r) { cs[r] = 0; for (int q = 0; q < fl; ++q) cs[r] += D[r * fl + q] * sd[q]; }
+        for (int a = 0; a < d; ++a)
+            for (int b = 0; b < d; ++b) S[a][b] = cs[a == b ? a : (fl - a - b)];
+        const double vol = ge[12];
+        for (int i = 0; i < m.npe; ++i) {   // l_i = cstress . int grad phi_i  (LinearElasticity.hh:157-160)
+            const double al = c->tables.intGrad[(size_t)i * 2] * vol, be = c->tables.intGrad[(size_t)i * 2 + 1] * vol;
+            const double *gs = ge + c->tables.sup_s[i] * d, *gt = ge + c->tables.sup_t[i] * d;
+            const int32_t dof = dof_of(c, m.elemNodes[(size_t)e * m.npe + i]);
+            for (int a = 0; a < d; ++a) {
+                double v = 0;
+                for (int b = 0; b < d; ++b) v += S[a][b] * (al * gs[b] + be * gt[b]);
+                out[(size_t)dof * d + a] += v;
+            }
+        }
+    }
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_sim_solve(mfh_ctx *c, const double *f, int32_t usePin, double *uNodes, double rtol, int32_t maxit,
+                         mfh_solve_info *info) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes, MFH_ERR_STATE, "no mesh set");
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    const int64_t n = (int64_t)d * c->nDoF;
+    // m_buildConstrainedSystem (LinearElasticity.hh:1377-1404): pin first (assembleConstrainedSystem :1217),
+    // then the Dirichlet variables (:1244)
+    std::vector<int64_t> vars;
+    std::vector<double> vals;
+    if (usePin) {
+        const int64_t pn = pin_node(c);
+        for (int a = 0; a < d; ++a) { vars.push_back((int64_t)d * dof_of(c, pn) + a); vals.push_back(0.0); }
+    }
+    dirichlet_vars(c, vars, vals);
+    clear_fixed(c);
+    add_fixed(c, (int64_t)vars.size(), vars.data(), vals.data());
+    std::vector<double> load;
+    if (!f) {
+        load.resize((size_t)n);
+        mfh_status st = mfh_neumann_load(c, load.data());
+        if (st != MFH_OK) throw Error(st, c->err);
+        f = load.data();
+    }
+    std::vector<double> x((size_t)n);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_precond(c);
+    mfh_solve_info li{};
+    solve_one(c, f, x.data(), rtol, maxit, &li);
+    if (info) *info = li;
+    for (int64_t i = 0; i < m.nNode; ++i)   // dofToNodeField :664-677
+        for (int a = 0; a < d; ++a) uNodes[(size_t)i * d + a] = x[(size_t)dof_of(c, i) * d + a];
+    if (!li.converged) throw Error(MFH_ERR_NOT_CONVERGED, "PCG did not reach the requested tolerance within maxit iterations");
+    MFH_CATCH(c)
+}
+
+static void average_strain_impl(mfh_ctx *c, const double *uNodes, double *out, bool stress) {
+    const HostMesh &m = c->mesh;
+    const int d = m.dim, fl = flat_len(d);
+    const std::vector<double> &g = host_geo(c);
+    double D[36];
+    for (int64_t e = 0; e < m.nElem; ++e) {
+        const double *ge = &g[(size_t)e * c->geoStride];
+        double eps[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        for (int i = 0; i < m.npe; ++i) {
+            // average of grad phi_i over the element = integral over unit volume
+            const double al = c->tables.intGrad[(size_t)i * 2], be = c->tables.intGrad[(size_t)i * 2 + 1];
+            const double *gs = ge + c->tables.sup_s[i] * d, *gt = ge + c->tables.sup_t[i] * d;
+            const double *ui = uNodes + (size_t)m.elemNodes[(size_t)e * m.npe + i] * d;
+            for (int a = 0; a < d; ++a)
+                for (int b = 0; b < d; ++b) {
+                    const double gb = al * gs[b] + be * gt[b], ga = al * gs[a] + be * gt[a];
+                    eps[a][b] += 0.5 * (ui[a] * gb + ui[b] * ga);   // LinearElasticity.hh:99-115
+                }
+        }
+        double ef[6];
+        for (int a = 0; a < d; ++a)
+            for (int b = a; b < d; ++b) ef[a == b ? a : (fl - a - b)] = eps[a][b];
+        if (!stress) {
+            for (int k2 = 0; k2 < fl; ++k2) out[(size_t)e * fl + k2] = ef[k2];
+        } else {
+            elem_D(c, ge, D);
+            for (int r = 0; r < fl; ++r) {
+                double v = 0;
+                for (int q = 0; q < fl; ++q) v += D[r * fl + q] * ef[q] * (q < d ? 1.0 : 2.0);
+                out[(size_t)e * fl + r] = v;
+            }
+        }
+    }
+}
+
+mfh_status mfh_average_strain(mfh_ctx *c, const double *uNodes, double *strain) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && strain, MFH_ERR_STATE, "no mesh set");
+    average_strain_impl(c, uNodes, strain, false);
+    MFH_CATCH(c)
+}
+mfh_status mfh_average_stress(mfh_ctx *c, const double *uNodes, double *stress) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && stress, MFH_ERR_STATE, "no mesh set");
+    average_strain_impl(c, uNodes, stress, true);
+    MFH_CATCH(c)
+}
+
+// ---------------------------------------------------------------- device-pointer building blocks
+mfh_status mfh_dev_spmv(mfh_ctx *c, const double *x_dev, double *y_dev) {
+    MFH_TRY(c)
+    require(c && x_dev && y_dev, MFH_ERR_INVALID, "null argument");
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_assembled(c);
+    k::launch_spmv(spmv_args(c, false), x_dev, y_dev, nullptr, c->stream);
+    MFH_CATCH(c)
+}
+mfh_status mfh_dev_precond(mfh_ctx *c, const double *r_dev, double *z_dev) {
+    MFH_TRY(c)
+    require(c && r_dev && z_dev, MFH_ERR_INVALID, "null argument");
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_precond(c);
+    k::launch_precond(c->dim(), c->sym.nRows, c->dDinv.p, r_dev, z_dev, c->stream);
+    MFH_CATCH(c)
+}
+mfh_status mfh_dev_mask_fixed(mfh_ctx *c, double *r_dev) {
+    MFH_TRY(c)
+    require(c && r_dev, MFH_ERR_INVALID, "null argument");
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_fixed_uploaded(c);
+    if (!c->fixedVars.empty()) k::launch_mask((int64_t)c->dim() * c->sym.nRows, c->dFixedMask.p, r_dev, c->stream);
+    MFH_CATCH(c)
+}
+mfh_status mfh_dev_set_fixed_values(mfh_ctx *c, double *u_dev) {
+    MFH_TRY(c)
+    require(c && u_dev, MFH_ERR_INVALID, "null argument");
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_fixed_uploaded(c);
+    k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, u_dev, c->stream);
+    MFH_CATCH(c)
+}
+mfh_status mfh_dev_sync(mfh_ctx *c) {
+    MFH_TRY(c)
+    require(c, MFH_ERR_INVALID, "null context");
+    MFH_HIP(hipStreamSynchronize(c->stream));
+    MFH_CATCH(c)
+}
+
+// ---------------------------------------------------------------- measurement
+mfh_status mfh_get_timing(const mfh_ctx *c, mfh_timing *out) {
+    if (!c || !out) return MFH_ERR_INVALID;
+    *out = c->timing;
+    return MFH_OK;
+}
+
+mfh_status mfh_time_assembly_kernel(mfh_ctx *c, int32_t mode, int32_t reps, double *avg_ms) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && avg_ms && reps > 0, MFH_ERR_INVALID, "bad arguments");
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    ensure_symbolic(c, mode == MFH_ASSEMBLE_ATOMIC);
+    k::AsmArgs a = asm_args(c);
+    double total = 0;
+    for (int r = 0; r < reps; ++r) {
+        if (mode == MFH_ASSEMBLE_ATOMIC) c->dVals.zero(c->stream);
+        EventTimer t(c->stream);
+        if (mode == MFH_ASSEMBLE_ATOMIC) k::launch_assemble_atomic(a, c->stream);
+        else k::launch_assemble_gather(a, c->stream);
+        total += t.stop();
+    }
+    *avg_ms = total / reps;
+    c->assembled = true;
+    c->dinvValid = false;
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_time_spmv_kernel(mfh_ctx *c, int32_t reps, double *avg_ms) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && avg_ms && reps > 0, MFH_ERR_INVALID, "bad arguments");
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_assembled(c);
+    const int d = c->dim();
+    const int64_t nin = (int64_t)d * c->sym.nCols, nout = (int64_t)d * c->sym.nRows;
+    c->wx.alloc(nin);
+    c->wAp.alloc(std::max(nin, nout));
+    k::launch_axpby(nin, 0.0, c->wx.p, 0.0, c->wx.p, c->stream);
+    std::vector<double> ones((size_t)nin, 1.0);
+    MFH_HIP(hipMemcpyAsync(c->wx.p, ones.data(), nin * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    k::launch_spmv(spmv_args(c, false), c->wx.p, c->wAp.p, nullptr, c->stream);   // warm-up
+    EventTimer t(c->stream);
+    for (int r = 0; r < reps; ++r) k::launch_spmv(spmv_args(c, false), c->wx.p, c->wAp.p, nullptr, c->stream);
+    *avg_ms = t.stop() / reps;
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
+    MFH_TRY(c)
+    require(c && key, MFH_ERR_INVALID, "null argument");
+    const std::string k2(key);
+    if (k2 == "chunk_slots") { c->chunkSlots = (int)value; invalidate_symbolic(c); }
+    else if (k2 == "contrib_order") { c->contribOrder = (int)value; invalidate_symbolic(c); }
+    else if (k2 == "check_every") { c->checkEvery = std::max(1, (int)value); }
+    else if (k2 == "keep_host_symbolic") { c->keepHostSymbolic = value != 0; }
+    else throw Error(MFH_ERR_INVALID, "unknown option " + k2);
+    MFH_CATCH(c)
+}
+
+} // extern "C"

@@ -1,0 +1,241 @@
+// Internal state of a libmeshfem_hip context. Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <stdexcept>
+#include <chrono>
+#include <thread>
+#include <functional>
+#include <algorithm>
+#include <array>
+#include <memory>
+#include <cstdlib>
+#include "../../include/meshfem_hip.h"
+
+namespace mfh {
+
+struct Error : std::runtime_error {
+    mfh_status code;
+    Error(mfh_status c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+#define MFH_HIP(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            throw mfh::Error(MFH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+inline double now_ms() {
+    using namespace std::chrono;
+    return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+
+// Simple parallel-for over [0, n) in contiguous ranges (host setup code only).
+void parallel_ranges(int64_t n, const std::function<void(int64_t, int64_t, int)> &f, int64_t minGrain = 4096);
+int  host_threads();
+
+// Device buffer with explicit size tracking.
+template <class T>
+struct DBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DBuf() = default;
+    DBuf(const DBuf &) = delete;
+    DBuf &operator=(const DBuf &) = delete;
+    ~DBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count) {
+        if (count == n && p) return;
+        release();
+        if (count == 0) return;
+        MFH_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        n = count;
+    }
+    void upload(const T *h, size_t count, hipStream_t s) {
+        alloc(count);
+        if (count) {
+            MFH_HIP(hipMemcpyAsync(p, h, count * sizeof(T), hipMemcpyHostToDevice, s));
+            MFH_HIP(hipStreamSynchronize(s));
+        }
+    }
+    void upload(const std::vector<T> &h, hipStream_t s) { upload(h.data(), h.size(), s); }
+    void download(T *h, size_t count, hipStream_t s) const {
+        if (count) {
+            MFH_HIP(hipMemcpyAsync(h, p, count * sizeof(T), hipMemcpyDeviceToHost, s));
+            MFH_HIP(hipStreamSynchronize(s));
+        }
+    }
+    void zero(hipStream_t s) {
+        if (n) MFH_HIP(hipMemsetAsync(p, 0, n * sizeof(T), s));
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Element-type constants
+// ------------------------------------------------------------------------------------------------
+inline int nodes_per_elem(int dim, int deg) {
+    if (dim == 3) return deg == 1 ? 4 : 10;
+    return deg == 1 ? 3 : 6;
+}
+inline int nodes_per_bdry_elem(int dim, int deg) {
+    if (dim == 3) return deg == 1 ? 3 : 6;
+    return deg == 1 ? 2 : 3;
+}
+inline int flat_len(int dim) { return dim * (dim + 1) / 2; }
+// Simplex.hh:43-44
+static const int kEdgeStart[6] = {0, 1, 2, 0, 2, 1};
+static const int kEdgeEnd[6] = {1, 2, 0, 3, 3, 3};
+
+// geometry record per element (doubles): gradLambda (dim*(dim+1), vertex-major: gl[k*dim+a] =
+// d lambda_k / d x_a), volume, then material: iso -> lambda, mu ; general -> 21 (3D) / 6 (2D)
+// upper-triangular entries of D row-major. Stride padded to a multiple of 2 doubles.
+constexpr int GEO_ISO_STRIDE = 16;      // 12 + 1 + 2 (+1 pad)  = 128 B, one cache line
+constexpr int GEO_GEN_STRIDE = 36;      // 12 + 1 + 21 (+2 pad) = 288 B
+
+enum MaterialKind { MAT_ISO = 0, MAT_GENERAL = 1 };
+
+// ------------------------------------------------------------------------------------------------
+// Host-side mesh (FEMMesh restatement)
+// ------------------------------------------------------------------------------------------------
+struct HostMesh {
+    int dim = 0, deg = 0, npe = 0, npbe = 0;
+    int64_t nElem = 0, nNode = 0, nVert = 0, nOwned = 0;
+    std::vector<int32_t> elemNodes;     // nElem x npe
+    std::vector<double> vertPos;        // nVert x dim
+    std::vector<double> nodePos;        // nNode x dim (built lazily for mesh_set)
+    bool hasTopology = false;
+    // boundary (only with topology)
+    std::vector<int32_t> bdryElemNodes; // nBE x npbe (volume node ids)
+    std::vector<int32_t> bdryNodes;     // volume node ids in boundary-node order
+    std::vector<uint8_t> isBdryNode;    // nNode
+    std::vector<double> bdryVol;        // nBE
+    std::vector<double> bdryNormal;     // nBE x dim
+    std::vector<uint8_t> bdryInternal;  // nBE (periodic)
+    int64_t nBE() const { return npbe ? (int64_t)bdryElemNodes.size() / npbe : 0; }
+};
+
+void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *elemVerts,
+                    const double *vertPos);
+void compute_node_positions(HostMesh &m);
+void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofForNode, int64_t &nDoF,
+                      std::vector<uint8_t> &bdryInternal);
+
+// ------------------------------------------------------------------------------------------------
+// Symbolic structure (BSR pattern + gather lists)
+// ------------------------------------------------------------------------------------------------
+struct Symbolic {
+    int64_t nRows = 0;                  // block rows (owned DoFs)
+    int64_t nCols = 0;                  // block cols (all local DoFs)
+    int64_t nnzb = 0;
+    std::vector<int32_t> rowPtr;        // nRows+1
+    std::vector<int32_t> colIdx;        // nnzb
+    // row chunks: consecutive rows whose slot count <= chunkSlots
+    std::vector<int32_t> chunkRow;      // nChunk+1
+    // gather lists, grouped by chunk
+    std::vector<int64_t> contribPtr;    // nChunk+1
+    std::vector<uint32_t> contribCode;  // e*npe*npe + i*npe + j
+    std::vector<uint16_t> contribSlot;  // slot - rowPtr[chunkRow[c]]
+    // element-major scatter map (built on demand for the atomic variant)
+    std::vector<int32_t> scatterSlot;   // nElem x npe x npe, -1 where row not owned
+    int chunkSlots = 0;
+    int maxRowLen = 0;
+    int64_t nChunk() const { return (int64_t)chunkRow.size() - 1; }
+};
+
+void build_symbolic(const HostMesh &m, const std::vector<int32_t> &dofForNode /* empty = identity */,
+                    int64_t nDoF, int64_t nOwnedDoF, int chunkSlots, int contribOrder, bool wantScatter,
+                    Symbolic &S);
+
+// ------------------------------------------------------------------------------------------------
+// P2 coefficient tables: for node i, grad phi_i(q) = alpha_i(q) gl[s_i] + beta_i(q) gl[t_i]
+// (EmbeddedElement.hh:315-332). pairTable[(i*npe+j)*4 + {aa,ab,ba,bb}] = sum_q w_q coef_i coef_j
+// with the reference's quadrature rule of degree 2(deg-1) (GaussQuadrature.hh:115-127,283-295).
+// ------------------------------------------------------------------------------------------------
+struct ShapeTables {
+    int npe = 0;
+    int sup_s[10], sup_t[10];
+    std::vector<double> pairTable;      // npe*npe*4
+    std::vector<double> intGrad;        // npe*2: integral (unit volume) of alpha_i, beta_i  (constantStrainLoad)
+};
+void build_shape_tables(int dim, int deg, ShapeTables &T);
+
+} // namespace mfh
+
+// ------------------------------------------------------------------------------------------------
+// Kernel launchers (mfh_kernels.hip)
+// ------------------------------------------------------------------------------------------------
+namespace mfh { namespace k {
+
+struct AsmArgs {
+    int dim, deg, npe, mat;             // mat: MaterialKind
+    int geoStride;
+    const double *geo;                  // nElem x geoStride
+    const double *pairTable;            // device copy of ShapeTables::pairTable
+    // gather
+    int64_t nChunk;
+    const int32_t *chunkRow;
+    const int32_t *rowPtr;
+    const int64_t *contribPtr;
+    const uint32_t *contribCode;
+    const uint16_t *contribSlot;
+    int chunkSlots;
+    // atomic
+    int64_t nElem;
+    const int32_t *scatterSlot;
+    // output
+    double *vals;                       // tiled [ceil(nnzb/64)][dim*dim][64]
+    int64_t nnzb;
+};
+
+void launch_geometry(int dim, int deg, int mat, int64_t nElem, const int32_t *elemNodes, int npe,
+                     const double *vertPos, const double *matParams, int matMode, double *geo, int geoStride,
+                     int *negCount, hipStream_t s);
+void launch_assemble_gather(const AsmArgs &a, hipStream_t s);
+void launch_assemble_atomic(const AsmArgs &a, hipStream_t s);
+void launch_element_stiffness(const AsmArgs &a, int64_t first, int64_t count, double *KeOut, hipStream_t s);
+
+struct SpmvArgs {
+    int dim;
+    int64_t nChunk;
+    const int32_t *chunkRow;
+    const int32_t *rowPtr;
+    const int32_t *colIdx;
+    const double *vals;
+    int chunkSlots;
+    const uint8_t *fixedMask;           // per scalar row, may be null
+};
+// y = A x (optionally masked), optional dot accumulation: dotOut[0] += x_rows . y
+void launch_spmv(const SpmvArgs &a, const double *x, double *y, double *dotOut, hipStream_t s);
+
+void launch_untile_vals(int dim, int64_t nnzb, const double *tiled, double *aos, hipStream_t s);
+void launch_extract_diag_inv(int dim, int64_t nRows, const int32_t *rowPtr, const int32_t *colIdx, const double *vals,
+                             const uint8_t *fixedMask, int precondKind, double *dinv, hipStream_t s);
+void launch_precond(int dim, int64_t nRows, const double *dinv, const double *r, double *z, hipStream_t s);
+
+// PCG step kernels. scal: device array of per-iteration reductions, 4 doubles per iteration
+// [r.z, p.Ap, r.r, unused], zero-filled once per solve. stopPtr[0] = rtol^2 * b.b: once
+// scal[it].rr <= stop every kernel of the remaining iterations is a no-op.
+void launch_pcg_init(int dim, int64_t nRows, const double *dinv, const double *b, double *x, double *r, double *z,
+                     double *p, double *scal, hipStream_t s);
+void launch_pcg_spmv(const SpmvArgs &a, const double *p, double *Ap, double *scal, int it, const double *stopPtr,
+                     hipStream_t s);
+void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double *p, const double *Ap, double *x,
+                       double *r, double *z, double *scal, int it, const double *stopPtr, hipStream_t s);
+void launch_pcg_direction(int64_t n, const double *z, double *p, const double *scal, int it, const double *stopPtr,
+                          hipStream_t s);
+
+void launch_axpby(int64_t n, double a, const double *x, double b, double *y, hipStream_t s); // y = a x + b y
+void launch_mask(int64_t n, const uint8_t *mask, double *v, hipStream_t s);                   // v[mask]=0
+void launch_scatter_values(int64_t n, const int64_t *idx, const double *val, double *v, hipStream_t s);
+void launch_dot(int64_t n, const double *a, const double *b, double *out, hipStream_t s);    // *out += a.b
+
+}} // namespace mfh::k

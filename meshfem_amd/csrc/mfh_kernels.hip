@@ -1,0 +1,679 @@
+// HIP kernels for gfx950 (MI355X, CDNA4): element embedding, per-element stiffness blocks,
+// owner-computes (gather) and atomic (scatter) assembly into a tiled block-CSR, block-CSR SpMV,
+// and the fused PCG vector kernels.  All arithmetic is FP64 (the reference's Real = double,
+// Types.hh:8); the path is HBM/LDS bound, so there is no MFMA here.
+//
+// Data layout of K values ("tiled BSR"): block slot s, component c (row-major in the dim x dim
+// block) lives at vals[((s >> 6) * NB + c) * 64 + (s & 63)], NB = dim*dim. Consecutive lanes that
+// own consecutive slots therefore read/write 512 contiguous bytes per component: every wave-wide
+// load/store of K is a fully coalesced 8 B/lane access on both the assembly and the SpMV side.
+#include "mfh_internal.hh"
+
+namespace mfh { namespace k {
+
+#define DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+DEV int64_t tiled_index(int64_t slot, int c, int NB) { return ((slot >> 6) * NB + c) * 64 + (slot & 63); }
+
+DEV double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-wide sum of up to 3 values; result valid in thread 0. blockDim.x == 256.
+template <int NV>
+DEV void block_sum(double (&v)[NV], double *lds /* >= 4*NV doubles */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) lds[w * NV + k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = lds[k] + lds[NV + k] + lds[2 * NV + k] + lds[3 * NV + k];
+    }
+    __syncthreads();
+}
+
+// Flattened symmetric index (Flattening.hh:47-60): 3D xx,yy,zz,yz,xz,xy ; 2D xx,yy,xy
+template <int DIM>
+DEV constexpr int flat_idx(int i, int j) { return i == j ? i : (DIM * (DIM + 1) / 2 - i - j); }
+// index into the packed upper triangle (row-major) of the flatLen x flatLen matrix D
+template <int DIM>
+DEV constexpr int dpack(int r, int c) {
+    constexpr int n = DIM * (DIM + 1) / 2;
+    int a = r <= c ? r : c, b = r <= c ? c : r;
+    return a * n - a * (a - 1) / 2 + (b - a);
+}
+
+// support vertices of node i: grad phi_i = alpha gl[s] + beta gl[t]   (EmbeddedElement.hh:315-332)
+// packed 4-bit tables: vertex nodes s=t=i; edge node k: s=edgeStart[k], t=edgeEnd[k] (Simplex.hh:43-44)
+template <int DIM, int DEG> DEV int sup_s(int i) {
+    if (DEG == 1) return i;
+    if (DIM == 3) return (int)((0x1202103210ull >> (4 * i)) & 0xf);   // nodes 0..9: 0,1,2,3,0,1,2,0,2,1
+    return (int)((0x210210ull >> (4 * i)) & 0xf);                     // nodes 0..5: 0,1,2,0,1,2
+}
+template <int DIM, int DEG> DEV int sup_t(int i) {
+    if (DEG == 1) return i;
+    if (DIM == 3) return (int)((0x3330213210ull >> (4 * i)) & 0xf);   // 0,1,2,3,1,2,0,3,3,3
+    return (int)((0x021210ull >> (4 * i)) & 0xf);                     // 0,1,2,1,2,0
+}
+
+// ------------------------------------------------------------------------------------------------
+// One dim x dim block of the element stiffness matrix:
+//   K_ij[c][d] = sum_q w_q sum_ab d_a phi_i(q) C_{acdb} d_b phi_j(q)      (LinearElasticity.hh:183-231)
+// With grad phi_i(q) = alpha_i(q) u_a + beta_i(q) u_b the quadrature sum collapses onto the four
+// precomputed pair coefficients S = vol * sum_q w_q {a_i a_j, a_i b_j, b_i a_j, b_i b_j}:
+//   H[a][b] = sum_q w_q d_a phi_i d_b phi_j = u_a (S0 v_a + S1 v_b)^T + u_b (S2 v_a + S3 v_b)^T
+// (same quadrature rule and points as the reference: GaussQuadrature.hh:115-127,283-295).
+// ------------------------------------------------------------------------------------------------
+template <int DIM, int DEG, int MAT>
+DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pairTab, int i, int j, double *K) {
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    const double vol = g[12];
+    double H[DIM][DIM];
+    if (DEG == 1) {
+        double gi[DIM], gj[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) { gi[a] = g[i * DIM + a]; gj[a] = g[j * DIM + a] * vol; }
+#pragma unroll
+        for (int a = 0; a < DIM; ++a)
+#pragma unroll
+            for (int b = 0; b < DIM; ++b) H[a][b] = gi[a] * gj[b];
+    } else {
+        const int si = sup_s<DIM, DEG>(i), ti = sup_t<DIM, DEG>(i), sj = sup_s<DIM, DEG>(j), tj = sup_t<DIM, DEG>(j);
+        const double *S = pairTab + (i * NPE + j) * 4;
+        const double S0 = S[0] * vol, S1 = S[1] * vol, S2 = S[2] * vol, S3 = S[3] * vol;
+        double ua[DIM], ub[DIM], p[DIM], q[DIM];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) {
+            ua[a] = g[si * DIM + a]; ub[a] = g[ti * DIM + a];
+            const double va = g[sj * DIM + a], vb = g[tj * DIM + a];
+            p[a] = S0 * va + S1 * vb;
+            q[a] = S2 * va + S3 * vb;
+        }
+#pragma unroll
+        for (int a = 0; a < DIM; ++a)
+#pragma unroll
+            for (int b = 0; b < DIM; ++b) H[a][b] = ua[a] * p[b] + ub[a] * q[b];
+    }
+    if (MAT == MAT_ISO) {
+        // C_acdb = lambda d_ac d_db + mu (d_ad d_cb + d_ab d_cd)  =>  K = lambda H + mu H^T + mu tr(H) I
+        const double lam = g[13], mu = g[14];
+        double tr = 0;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) tr += H[a][a];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) K[c * DIM + d] = lam * H[c][d] + mu * H[d][c] + (c == d ? mu * tr : 0.0);
+    } else {
+        // C_acdb = D(flat(a,c), flat(d,b))      (ElasticityTensor.hh:274-277)
+        constexpr int ND = (DIM * (DIM + 1) / 2) * (DIM * (DIM + 1) / 2 + 1) / 2;
+        double D[ND];
+#pragma unroll
+        for (int k = 0; k < ND; ++k) D[k] = g[13 + k];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) {
+                double acc = 0;
+#pragma unroll
+                for (int a = 0; a < DIM; ++a)
+#pragma unroll
+                    for (int b = 0; b < DIM; ++b) acc += H[a][b] * D[dpack<DIM>(flat_idx<DIM>(a, c), flat_idx<DIM>(d, b))];
+                K[c * DIM + d] = acc;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: element embedding + material record     (EmbeddedElement.hh:162-241, ElasticityTensor.hh:100-164)
+// matMode: 0 const (lambda,mu) | 1 iso field (E[],nu[]) | 2 const general D (packed upper) |
+//          3 orthotropic field (9 / 4 params per element) | 4 tensor field (flatLen^2 per element)
+// ------------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *__restrict__ elemNodes, int npe,
+                                                  const double *__restrict__ vertPos, const double *__restrict__ mp,
+                                                  int matMode, double *__restrict__ geo, int stride, int *negCount) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nElem) return;
+    double P[DIM + 1][DIM];
+#pragma unroll
+    for (int k = 0; k <= DIM; ++k) {
+        const int64_t v = elemNodes[e * npe + k];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) P[k][a] = vertPos[v * DIM + a];
+    }
+    double *g = geo + e * stride;
+    double vol;
+    if (DIM == 3) {
+        // n0 = (p3-p1)x(p2-p1); 6V = (p0-p1).n0; gl0 = n0/6V; gl1 = (p2-p0)x(p3-p0)/6V; ...   (:223-230)
+        auto cross = [](const double *a, const double *b, double *o) {
+            o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+        };
+        double d31[3], d21[3], d01[3], d20[3], d30[3], d10[3], n0[3], n1[3], n2[3], n3[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            d31[a] = P[3][a] - P[1][a]; d21[a] = P[2][a] - P[1][a]; d01[a] = P[0][a] - P[1][a];
+            d20[a] = P[2][a] - P[0][a]; d30[a] = P[3][a] - P[0][a]; d10[a] = P[1][a] - P[0][a];
+        }
+        cross(d31, d21, n0); cross(d20, d30, n1); cross(d30, d10, n2); cross(d10, d20, n3);
+        const double vol6 = d01[0] * n0[0] + d01[1] * n0[1] + d01[2] * n0[2];
+        vol = vol6 / 6.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            g[0 + a] = n0[a] / vol6; g[3 + a] = n1[a] / vol6; g[6 + a] = n2[a] / vol6; g[9 + a] = n3[a] / vol6;
+        }
+    } else {
+        // e0=p2-p1, e1=p0-p2, e2=p1-p0; 2A = e1.x e2.y - e1.y e2.x; gl_k = (-e_k.y, e_k.x)/2A   (:182-189)
+        double E[3][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { E[0][a] = P[2][a] - P[1][a]; E[1][a] = P[0][a] - P[2][a]; E[2][a] = P[1][a] - P[0][a]; }
+        const double dA = E[1][0] * E[2][1] - E[1][1] * E[2][0];
+        vol = dA / 2.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { g[k * 2 + 0] = -E[k][1] / dA; g[k * 2 + 1] = E[k][0] / dA; }
+#pragma unroll
+        for (int k = 6; k < 12; ++k) g[k] = 0.0;
+    }
+    g[12] = vol;
+    if (!(vol >= 0)) atomicAdd(negCount, 1);
+    constexpr int FL = DIM * (DIM + 1) / 2;
+    constexpr int ND = FL * (FL + 1) / 2;
+    if (matMode == 0) { g[13] = mp[0]; g[14] = mp[1]; }
+    else if (matMode == 1) {
+        const double E = mp[e], nu = mp[nElem + e];
+        double lam = (nu * E) / ((1.0 + nu) * (1.0 - 2.0 * nu));
+        if (DIM == 2) lam = (nu * E) / (1.0 - nu * nu);     // plane stress (ElasticityTensor.hh:108-112)
+        g[13] = lam; g[14] = E / (2.0 + 2.0 * nu);
+    } else if (matMode == 2) {
+        for (int k = 0; k < ND; ++k) g[13 + k] = mp[k];
+    } else if (matMode == 3) {
+        for (int k = 0; k < ND; ++k) g[13 + k] = 0.0;
+        if (DIM == 3) {
+            const double *q = mp + e * 9;   // Ex,Ey,Ez,nuYX,nuZX,nuZY,muYZ,muZX,muXY  (:136-152)
+            const double a00 = 1.0 / q[0], a01 = -q[3] / q[1], a02 = -q[4] / q[2], a11 = 1.0 / q[1], a12 = -q[5] / q[2],
+                         a22 = 1.0 / q[2];
+            const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+            const double c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+            const double det = a00 * c00 + a01 * c01 + a02 * c02;
+            g[13 + dpack<3>(0, 0)] = c00 / det; g[13 + dpack<3>(0, 1)] = c01 / det; g[13 + dpack<3>(0, 2)] = c02 / det;
+            g[13 + dpack<3>(1, 1)] = c11 / det; g[13 + dpack<3>(1, 2)] = c12 / det; g[13 + dpack<3>(2, 2)] = c22 / det;
+            g[13 + dpack<3>(3, 3)] = q[6]; g[13 + dpack<3>(4, 4)] = q[7]; g[13 + dpack<3>(5, 5)] = q[8];
+        } else {
+            const double *q = mp + e * 4;   // Ex,Ey,nuYX,muXY                          (:154-164)
+            const double a00 = 1.0 / q[0], a01 = -q[2] / q[1], a11 = 1.0 / q[1];
+            const double det = a00 * a11 - a01 * a01;
+            g[13 + dpack<2>(0, 0)] = a11 / det; g[13 + dpack<2>(0, 1)] = -a01 / det; g[13 + dpack<2>(1, 1)] = a00 / det;
+            g[13 + dpack<2>(2, 2)] = q[3];
+        }
+    } else {
+        const double *q = mp + e * FL * FL;
+        for (int r = 0; r < FL; ++r)
+            for (int c = r; c < FL; ++c) g[13 + dpack<DIM>(r, c)] = q[r * FL + c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2+K3+K4 fused, owner-computes: one workgroup per row chunk (<= chunkSlots blocks of consecutive
+// block rows). Every (element, i, j) contribution to those rows is computed by one lane and
+// accumulated in LDS with ds_add_f64; the finished rows are written once, coalesced, with plain
+// stores. No global atomics, no read-modify-write of K, no zero-fill pass.
+// ------------------------------------------------------------------------------------------------
+template <int DIM, int DEG, int MAT>
+__global__ void __launch_bounds__(256) k_assemble_gather(AsmArgs a) {
+    constexpr int NB = DIM * DIM;
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    extern __shared__ __attribute__((aligned(16))) double acc[];   // [NB][chunkSlots]
+    const int CS = a.chunkSlots;
+    const int64_t chunk = blockIdx.x;
+    const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
+    const int s0 = a.rowPtr[r0];
+    const int ns = a.rowPtr[r1] - s0;
+    for (int t = threadIdx.x; t < ns; t += 256)
+#pragma unroll
+        for (int c = 0; c < NB; ++c) acc[c * CS + t] = 0.0;
+    __syncthreads();
+    const int64_t kb = a.contribPtr[chunk], ke = a.contribPtr[chunk + 1];
+    for (int64_t k = kb + threadIdx.x; k < ke; k += 256) {
+        const uint32_t code = a.contribCode[k];
+        const int ls = a.contribSlot[k];
+        const uint32_t e = code / (NPE * NPE);
+        const int ij = (int)(code - e * (NPE * NPE));
+        const int i = ij / NPE, j = ij - i * NPE;
+        double K[NB];
+        elem_block<DIM, DEG, MAT>(a.geo + (int64_t)e * a.geoStride, a.pairTable, i, j, K);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&acc[c * CS + ls], K[c]);
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < ns; t += 256) {
+        const int64_t s = (int64_t)s0 + t;
+#pragma unroll
+        for (int c = 0; c < NB; ++c) a.vals[tiled_index(s, c, NB)] = acc[c * CS + t];
+    }
+}
+
+// Baseline variant: element-major, one lane per (element,i,j) block, global_atomic_add_f64 scatter
+// into the (pre-zeroed) tiled values through the element->slot scatter map.
+template <int DIM, int DEG, int MAT>
+__global__ void __launch_bounds__(256) k_assemble_atomic(AsmArgs a) {
+    constexpr int NB = DIM * DIM;
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    const int64_t total = a.nElem * (NPE * NPE);
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        const int32_t slot = a.scatterSlot[k];
+        if (slot < 0) continue;
+        const int64_t e = k / (NPE * NPE);
+        const int ij = (int)(k - e * (NPE * NPE));
+        const int i = ij / NPE, j = ij - i * NPE;
+        double K[NB];
+        elem_block<DIM, DEG, MAT>(a.geo + e * a.geoStride, a.pairTable, i, j, K);
+#pragma unroll
+        for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&a.vals[tiled_index(slot, c, NB)], K[c]);
+    }
+}
+
+// Dense per-element Ke (parity/debug): full (NPE*DIM)^2 row-major.
+template <int DIM, int DEG, int MAT>
+__global__ void __launch_bounds__(256) k_element_stiffness(AsmArgs a, int64_t first, int64_t count, double *out) {
+    constexpr int NB = DIM * DIM;
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    constexpr int KS = NPE * DIM;
+    const int64_t total = count * (NPE * NPE);
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        const int64_t el = k / (NPE * NPE);
+        const int ij = (int)(k - el * (NPE * NPE));
+        const int i = ij / NPE, j = ij - i * NPE;
+        double K[NB];
+        elem_block<DIM, DEG, MAT>(a.geo + (first + el) * a.geoStride, a.pairTable, i, j, K);
+        double *o = out + el * KS * KS;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) o[(i * DIM + c) * KS + j * DIM + d] = K[c * DIM + d];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-CSR SpMV over row chunks (persistent workgroups, grid-stride over chunks).
+// Phase 1: lane per block: coalesced loads of the NB components + column, gather x, block product
+//          -> LDS partials.  Phase 2: lane per scalar row sums its partials.
+// Optional: zero rows of fixed variables; accumulate dot(x_rows, y) into *dotOut (one atomic per WG).
+// ------------------------------------------------------------------------------------------------
+template <int DIM, bool PCG>
+__global__ void __launch_bounds__(256) k_spmv(SpmvArgs a, const double *__restrict__ x, double *__restrict__ y,
+                                             double *dotOut, double *scal, int it, const double *stopPtr) {
+    constexpr int NB = DIM * DIM;
+    extern __shared__ __attribute__((aligned(16))) double part[];  // [DIM][chunkSlots] + 16
+    const int CS = a.chunkSlots;
+    double *red = part + DIM * CS;
+    if (PCG) {
+        // converged: every kernel of the remaining iterations is a no-op
+        if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
+        dotOut = scal + (int64_t)it * 4 + 1;
+    }
+    double dot = 0.0;
+    for (int64_t chunk = blockIdx.x; chunk < a.nChunk; chunk += gridDim.x) {
+        const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
+        const int s0 = a.rowPtr[r0];
+        const int ns = a.rowPtr[r1] - s0;
+        for (int t = threadIdx.x; t < ns; t += 256) {
+            const int64_t s = (int64_t)s0 + t;
+            const int64_t col = a.colIdx[s];
+            double xv[DIM], A[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) A[c] = a.vals[tiled_index(s, c, NB)];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) xv[d] = x[col * DIM + d];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                double v = 0;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) v += A[c * DIM + d] * xv[d];
+                part[c * CS + t] = v;
+            }
+        }
+        __syncthreads();
+        const int nscalar = (r1 - r0) * DIM;
+        for (int idx = threadIdx.x; idx < nscalar; idx += 256) {
+            const int rl = idx / DIM, c = idx - rl * DIM;
+            const int64_t r = r0 + rl;
+            const int b = a.rowPtr[r] - s0, e = a.rowPtr[r + 1] - s0;
+            double v = 0;
+            for (int t = b; t < e; ++t) v += part[c * CS + t];
+            const int64_t gi = r * DIM + c;
+            if (a.fixedMask && a.fixedMask[gi]) v = 0.0;
+            y[gi] = v;
+            if (dotOut) dot += v * x[gi];
+        }
+        __syncthreads();
+    }
+    if (dotOut) {
+        double v[1] = {dot};
+        block_sum<1>(v, red);
+        if (threadIdx.x == 0) unsafeAtomicAdd(dotOut, v[0]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small dense helpers
+// ------------------------------------------------------------------------------------------------
+template <int DIM> DEV void invert_block(const double *A, double *Inv) {
+    if (DIM == 2) {
+        const double det = A[0] * A[3] - A[1] * A[2];
+        Inv[0] = A[3] / det; Inv[1] = -A[1] / det; Inv[2] = -A[2] / det; Inv[3] = A[0] / det;
+    } else {
+        const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+        const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+        Inv[0] = c00 / det; Inv[1] = (A[2] * A[7] - A[1] * A[8]) / det; Inv[2] = (A[1] * A[5] - A[2] * A[4]) / det;
+        Inv[3] = c01 / det; Inv[4] = (A[0] * A[8] - A[2] * A[6]) / det; Inv[5] = (A[2] * A[3] - A[0] * A[5]) / det;
+        Inv[6] = c02 / det; Inv[7] = (A[1] * A[6] - A[0] * A[7]) / det; Inv[8] = (A[0] * A[4] - A[1] * A[3]) / det;
+    }
+}
+
+// Inverse of the diagonal blocks of the constrained operator P K P + (I-P): rows/cols of fixed
+// components are replaced by identity before inversion. kind: 0 block-Jacobi, 1 Jacobi, 2 identity.
+template <int DIM>
+__global__ void __launch_bounds__(256) k_diag_inv(int64_t nRows, const int32_t *__restrict__ rowPtr,
+                                                  const int32_t *__restrict__ colIdx, const double *__restrict__ vals,
+                                                  const uint8_t *__restrict__ fixedMask, int kind, double *__restrict__ dinv) {
+    constexpr int NB = DIM * DIM;
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= nRows) return;
+    double A[NB], Inv[NB];
+#pragma unroll
+    for (int c = 0; c < NB; ++c) A[c] = (c % (DIM + 1) == 0) ? 1.0 : 0.0;
+    int lo = rowPtr[r], hi = rowPtr[r + 1];
+    while (lo < hi) {   // columns are sorted within a row
+        const int mid = (lo + hi) >> 1;
+        const int cv = colIdx[mid];
+        if (cv == r) {
+#pragma unroll
+            for (int c = 0; c < NB; ++c) A[c] = vals[tiled_index(mid, c, NB)];
+            break;
+        }
+        if (cv < r) lo = mid + 1; else hi = mid;
+    }
+    if (fixedMask) {
+#pragma unroll
+        for (int c = 0; c < DIM; ++c)
+            if (fixedMask[r * DIM + c]) {
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) { A[c * DIM + d] = 0.0; A[d * DIM + c] = 0.0; }
+                A[c * DIM + c] = 1.0;
+            }
+    }
+    if (kind == 0) invert_block<DIM>(A, Inv);
+    else {
+#pragma unroll
+        for (int c = 0; c < NB; ++c) Inv[c] = 0.0;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) Inv[c * DIM + c] = kind == 1 ? 1.0 / A[c * DIM + c] : 1.0;
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c) dinv[r * NB + c] = Inv[c];
+}
+
+template <int DIM> DEV void apply_block(const double *__restrict__ Dm, const double *r, double *z) {
+#pragma unroll
+    for (int c = 0; c < DIM; ++c) {
+        double v = 0;
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) v += Dm[c * DIM + d] * r[d];
+        z[c] = v;
+    }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256) k_precond(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ r,
+                                                 double *__restrict__ z) {
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nRows; n += (int64_t)gridDim.x * 256) {
+        double rv[DIM], zv[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) rv[c] = r[n * DIM + c];
+        apply_block<DIM>(dinv + n * DIM * DIM, rv, zv);
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) z[n * DIM + c] = zv[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// PCG vector kernels. scal[it*4 + {0: r.z, 1: p.Ap, 2: r.r}] hold the reductions of iteration `it`
+// (array zero-filled once per solve; nothing is reset inside the loop).
+// ------------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(256) k_pcg_init(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ b,
+                                                  double *__restrict__ x, double *__restrict__ r, double *__restrict__ z,
+                                                  double *__restrict__ p, double *scal) {
+    __shared__ double red[16];
+    double acc[2] = {0, 0};
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nRows; n += (int64_t)gridDim.x * 256) {
+        double rv[DIM], zv[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) rv[c] = b[n * DIM + c];
+        apply_block<DIM>(dinv + n * DIM * DIM, rv, zv);
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            x[n * DIM + c] = 0.0; r[n * DIM + c] = rv[c]; z[n * DIM + c] = zv[c]; p[n * DIM + c] = zv[c];
+            acc[0] += rv[c] * zv[c]; acc[1] += rv[c] * rv[c];
+        }
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) { unsafeAtomicAdd(&scal[0], acc[0]); unsafeAtomicAdd(&scal[2], acc[1]); }
+}
+
+// x += alpha p ; r -= alpha Ap ; z = Dinv r ; scal[it+1].{rz,rr} += ...
+template <int DIM>
+__global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ p,
+                                                    const double *__restrict__ Ap, double *__restrict__ x, double *__restrict__ r,
+                                                    double *__restrict__ z, double *scal, int it, const double *stopPtr) {
+    __shared__ double red[16];
+    if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
+    const double alpha = scal[(int64_t)it * 4 + 0] / scal[(int64_t)it * 4 + 1];
+    double acc[2] = {0, 0};
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nRows; n += (int64_t)gridDim.x * 256) {
+        double rv[DIM], zv[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            const int64_t g = n * DIM + c;
+            x[g] += alpha * p[g];
+            rv[c] = r[g] - alpha * Ap[g];
+            r[g] = rv[c];
+        }
+        apply_block<DIM>(dinv + n * DIM * DIM, rv, zv);
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) { z[n * DIM + c] = zv[c]; acc[0] += rv[c] * zv[c]; acc[1] += rv[c] * rv[c]; }
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        unsafeAtomicAdd(&scal[(int64_t)(it + 1) * 4 + 0], acc[0]);
+        unsafeAtomicAdd(&scal[(int64_t)(it + 1) * 4 + 2], acc[1]);
+    }
+}
+
+// p = z + beta p
+__global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, const double *__restrict__ z, double *__restrict__ p,
+                                                       const double *scal, int it, const double *stopPtr) {
+    if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
+    const double beta = scal[(int64_t)(it + 1) * 4 + 0] / scal[(int64_t)it * 4 + 0];
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) p[k] = z[k] + beta * p[k];
+}
+
+__global__ void __launch_bounds__(256) k_axpby(int64_t n, double a, const double *__restrict__ x, double b, double *__restrict__ y) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
+        y[k] = a * x[k] + (b == 0.0 ? 0.0 : b * y[k]);
+}
+__global__ void __launch_bounds__(256) k_mask(int64_t n, const uint8_t *__restrict__ m, double *__restrict__ v) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
+        if (m[k]) v[k] = 0.0;
+}
+__global__ void __launch_bounds__(256) k_scatter_values(int64_t n, const int64_t *__restrict__ idx, const double *__restrict__ val,
+                                                        double *__restrict__ v) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) v[idx[k]] = val[k];
+}
+__global__ void __launch_bounds__(256) k_dot(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *out) {
+    __shared__ double red[8];
+    double acc[1] = {0};
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) acc[0] += a[k] * b[k];
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(out, acc[0]);
+}
+// tiled -> array-of-blocks (export)
+__global__ void __launch_bounds__(256) k_untile(int NB, int64_t nnzb, const double *__restrict__ tiled, double *__restrict__ aos) {
+    const int64_t total = nnzb * NB;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        const int64_t s = k / NB;
+        const int c = (int)(k - s * NB);
+        aos[k] = tiled[tiled_index(s, c, NB)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static inline int grid_for(int64_t n, int cap = 2048) {
+    int64_t g = (n + 255) / 256;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
+}
+#define CHECK_LAUNCH() MFH_HIP(hipGetLastError())
+
+void launch_geometry(int dim, int /*deg*/, int /*mat*/, int64_t nElem, const int32_t *elemNodes, int npe, const double *vertPos,
+                     const double *matParams, int matMode, double *geo, int geoStride, int *negCount, hipStream_t s) {
+    const int grid = (int)((nElem + 255) / 256);
+    if (dim == 3) hipLaunchKernelGGL(k_geometry<3>, dim3(grid), dim3(256), 0, s, nElem, elemNodes, npe, vertPos, matParams, matMode, geo, geoStride, negCount);
+    else hipLaunchKernelGGL(k_geometry<2>, dim3(grid), dim3(256), 0, s, nElem, elemNodes, npe, vertPos, matParams, matMode, geo, geoStride, negCount);
+    CHECK_LAUNCH();
+}
+
+// dispatch on (dim, deg, mat)
+#define MFH_DISPATCH(a, CALL)                                                            \
+    do {                                                                                 \
+        const int key_ = (a.dim == 3 ? 0 : 4) + (a.deg == 2 ? 2 : 0) + (a.mat == MAT_GENERAL ? 1 : 0); \
+        switch (key_) {                                                                  \
+        case 0: { CALL(3, 1, MAT_ISO); } break;                                           \
+        case 1: { CALL(3, 1, MAT_GENERAL); } break;                                       \
+        case 2: { CALL(3, 2, MAT_ISO); } break;                                           \
+        case 3: { CALL(3, 2, MAT_GENERAL); } break;                                       \
+        case 4: { CALL(2, 1, MAT_ISO); } break;                                           \
+        case 5: { CALL(2, 1, MAT_GENERAL); } break;                                       \
+        case 6: { CALL(2, 2, MAT_ISO); } break;                                           \
+        default: { CALL(2, 2, MAT_GENERAL); } break;                                      \
+        }                                                                                \
+    } while (0)
+
+void launch_assemble_gather(const AsmArgs &a, hipStream_t s) {
+    if (a.nChunk == 0) return;
+    const size_t lds = (size_t)a.dim * a.dim * a.chunkSlots * sizeof(double);
+#define CALL(D, G, M)                                                                                          \
+    if (lds > 64 * 1024)                                                                                         \
+        MFH_HIP(hipFuncSetAttribute((const void *)k_assemble_gather<D, G, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_assemble_gather<D, G, M>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a)
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+    CHECK_LAUNCH();
+}
+
+void launch_assemble_atomic(const AsmArgs &a, hipStream_t s) {
+    const int64_t total = a.nElem * a.npe * a.npe;
+    const int grid = grid_for(total, 256 * 32);
+#define CALL(D, G, M) hipLaunchKernelGGL((k_assemble_atomic<D, G, M>), dim3(grid), dim3(256), 0, s, a)
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+    CHECK_LAUNCH();
+}
+
+void launch_element_stiffness(const AsmArgs &a, int64_t first, int64_t count, double *KeOut, hipStream_t s) {
+    const int grid = grid_for(count * a.npe * a.npe);
+#define CALL(D, G, M) hipLaunchKernelGGL((k_element_stiffness<D, G, M>), dim3(grid), dim3(256), 0, s, a, first, count, KeOut)
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+    CHECK_LAUNCH();
+}
+
+static int spmv_grid(const SpmvArgs &a) { return (int)std::max<int64_t>(1, std::min<int64_t>(a.nChunk, 256 * 8)); }
+
+void launch_spmv(const SpmvArgs &a, const double *x, double *y, double *dotOut, hipStream_t s) {
+    if (a.nChunk == 0) return;
+    const size_t lds = ((size_t)a.dim * a.chunkSlots + 16) * sizeof(double);
+    if (a.dim == 3) hipLaunchKernelGGL((k_spmv<3, false>), dim3(spmv_grid(a)), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr);
+    else hipLaunchKernelGGL((k_spmv<2, false>), dim3(spmv_grid(a)), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr);
+    CHECK_LAUNCH();
+}
+
+void launch_pcg_spmv(const SpmvArgs &a, const double *p, double *Ap, double *scal, int it, const double *stopPtr, hipStream_t s) {
+    if (a.nChunk == 0) return;
+    const size_t lds = ((size_t)a.dim * a.chunkSlots + 16) * sizeof(double);
+    if (a.dim == 3) hipLaunchKernelGGL((k_spmv<3, true>), dim3(spmv_grid(a)), dim3(256), lds, s, a, p, Ap, (double *)nullptr, scal, it, stopPtr);
+    else hipLaunchKernelGGL((k_spmv<2, true>), dim3(spmv_grid(a)), dim3(256), lds, s, a, p, Ap, (double *)nullptr, scal, it, stopPtr);
+    CHECK_LAUNCH();
+}
+
+void launch_untile_vals(int dim, int64_t nnzb, const double *tiled, double *aos, hipStream_t s) {
+    if (!nnzb) return;
+    hipLaunchKernelGGL(k_untile, dim3(grid_for(nnzb * dim * dim, 8192)), dim3(256), 0, s, dim * dim, nnzb, tiled, aos);
+    CHECK_LAUNCH();
+}
+
+void launch_extract_diag_inv(int dim, int64_t nRows, const int32_t *rowPtr, const int32_t *colIdx, const double *vals,
+                             const uint8_t *fixedMask, int kind, double *dinv, hipStream_t s) {
+    const int grid = (int)((nRows + 255) / 256);
+    if (dim == 3) hipLaunchKernelGGL(k_diag_inv<3>, dim3(grid), dim3(256), 0, s, nRows, rowPtr, colIdx, vals, fixedMask, kind, dinv);
+    else hipLaunchKernelGGL(k_diag_inv<2>, dim3(grid), dim3(256), 0, s, nRows, rowPtr, colIdx, vals, fixedMask, kind, dinv);
+    CHECK_LAUNCH();
+}
+
+void launch_precond(int dim, int64_t nRows, const double *dinv, const double *r, double *z, hipStream_t s) {
+    if (dim == 3) hipLaunchKernelGGL(k_precond<3>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, r, z);
+    else hipLaunchKernelGGL(k_precond<2>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, r, z);
+    CHECK_LAUNCH();
+}
+
+void launch_pcg_init(int dim, int64_t nRows, const double *dinv, const double *b, double *x, double *r, double *z, double *p,
+                     double *scal, hipStream_t s) {
+    if (dim == 3) hipLaunchKernelGGL(k_pcg_init<3>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal);
+    else hipLaunchKernelGGL(k_pcg_init<2>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal);
+    CHECK_LAUNCH();
+}
+
+void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double *p, const double *Ap, double *x, double *r,
+                       double *z, double *scal, int it, const double *stopPtr, hipStream_t s) {
+    if (dim == 3) hipLaunchKernelGGL(k_pcg_update<3>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
+    else hipLaunchKernelGGL(k_pcg_update<2>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
+    CHECK_LAUNCH();
+}
+
+void launch_pcg_direction(int64_t n, const double *z, double *p, const double *scal, int it, const double *stopPtr, hipStream_t s) {
+    hipLaunchKernelGGL(k_pcg_direction, dim3(grid_for(n)), dim3(256), 0, s, n, z, p, scal, it, stopPtr);
+    CHECK_LAUNCH();
+}
+
+void launch_axpby(int64_t n, double a, const double *x, double b, double *y, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_axpby, dim3(grid_for(n)), dim3(256), 0, s, n, a, x, b, y);
+    CHECK_LAUNCH();
+}
+void launch_mask(int64_t n, const uint8_t *mask, double *v, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_mask, dim3(grid_for(n)), dim3(256), 0, s, n, mask, v);
+    CHECK_LAUNCH();
+}
+void launch_scatter_values(int64_t n, const int64_t *idx, const double *val, double *v, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_scatter_values, dim3(grid_for(n)), dim3(256), 0, s, n, idx, val, v);
+    CHECK_LAUNCH();
+}
+void launch_dot(int64_t n, const double *a, const double *b, double *out, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_dot, dim3(grid_for(n)), dim3(256), 0, s, n, a, b, out);
+    CHECK_LAUNCH();
+}
+
+}} // namespace mfh::k

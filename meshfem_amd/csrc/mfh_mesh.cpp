@@ -1,0 +1,325 @@
+// Host-side FEM mesh construction: node numbering and boundary extraction in the reference's
+// enumeration order (FEMMesh.inl:11-82, TetMesh.inl:15-120, TriMesh.inl:15-130), written with
+// sorts/hash tables instead of std::map so that 5M-tet meshes build in seconds.
+#include "mfh_internal.hh"
+#include <cmath>
+#include <numeric>
+#include <unordered_map>
+
+namespace mfh {
+
+int host_threads() {
+    static int n = [] {
+        const char *e = getenv("MESHFEM_NUM_THREADS"); // python/parallelism.py:4-6
+        if (e && atoi(e) > 0) return atoi(e);
+        unsigned h = std::thread::hardware_concurrency();
+        return (int)std::max(1u, std::min(h, 64u));
+    }();
+    return n;
+}
+
+void parallel_ranges(int64_t n, const std::function<void(int64_t, int64_t, int)> &f, int64_t minGrain) {
+    int nt = host_threads();
+    if (n <= minGrain || nt == 1) {
+        f(0, n, 0);
+        return;
+    }
+    nt = (int)std::min<int64_t>(nt, (n + minGrain - 1) / minGrain);
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(nt);
+    for (int t = 0; t < nt; ++t) {
+        int64_t b = n * t / nt, e = n * (t + 1) / nt;
+        th.emplace_back([&, b, e, t] {
+            try { f(b, e, t); } catch (...) { err[t] = std::current_exception(); }
+        });
+    }
+    for (auto &t : th) t.join();
+    for (auto &e : err) if (e) std::rethrow_exception(e);
+}
+
+// tet half-face corner table (TetMesh.hh:221-226)
+static const int kFaceCorner[4][3] = {{1, 3, 2}, {0, 2, 3}, {0, 3, 1}, {0, 1, 2}};
+
+namespace {
+struct EdgeHash {
+    // open addressing, key = (min << 32) | max
+    std::vector<uint64_t> keys;
+    std::vector<int32_t> vals;
+    uint64_t mask = 0;
+    explicit EdgeHash(size_t expected) {
+        size_t cap = 16;
+        while (cap < expected * 2) cap <<= 1;
+        keys.assign(cap, ~0ull);
+        vals.assign(cap, -1);
+        mask = cap - 1;
+    }
+    static uint64_t mix(uint64_t k) {
+        k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+        return k;
+    }
+    // returns value; inserts `next` if absent
+    int32_t get_or_insert(uint64_t key, int32_t next, bool &inserted) {
+        uint64_t h = mix(key) & mask;
+        while (true) {
+            if (keys[h] == key) { inserted = false; return vals[h]; }
+            if (keys[h] == ~0ull) { keys[h] = key; vals[h] = next; inserted = true; return next; }
+            h = (h + 1) & mask;
+        }
+    }
+    int32_t at(uint64_t key) const {
+        uint64_t h = mix(key) & mask;
+        while (true) {
+            if (keys[h] == key) return vals[h];
+            if (keys[h] == ~0ull) throw Error(MFH_ERR_INVALID, "edge lookup failed");
+            h = (h + 1) & mask;
+        }
+    }
+};
+inline uint64_t edge_key(int32_t a, int32_t b) {
+    return a < b ? ((uint64_t)(uint32_t)a << 32) | (uint32_t)b : ((uint64_t)(uint32_t)b << 32) | (uint32_t)a;
+}
+} // namespace
+
+void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *ev,
+                    const double *vp) {
+    if (dim != 2 && dim != 3) throw Error(MFH_ERR_INVALID, "dim must be 2 or 3");
+    if (deg != 1 && deg != 2) throw Error(MFH_ERR_INVALID, "deg must be 1 or 2");
+    if (nElem <= 0 || nVert <= 0) throw Error(MFH_ERR_INVALID, "empty mesh");
+    const int nv = dim + 1;
+    const int nedge = dim == 3 ? 6 : 3;
+    m = HostMesh();
+    m.dim = dim; m.deg = deg; m.npe = nodes_per_elem(dim, deg); m.npbe = nodes_per_bdry_elem(dim, deg);
+    m.nElem = nElem; m.nVert = nVert;
+    m.vertPos.assign(vp, vp + nVert * dim);
+    for (int64_t k = 0; k < nElem * nv; ++k)
+        if (ev[k] < 0 || ev[k] >= nVert) throw Error(MFH_ERR_INVALID, "Bad vertex index encountered.");
+
+    // ---- edge nodes, first-encounter order over (element, local edge)        FEMMesh.inl:22-36
+    m.elemNodes.resize((size_t)nElem * m.npe);
+    int32_t nEdgeNodes = 0;
+    std::unique_ptr<EdgeHash> eh;
+    if (deg == 2) {
+        eh.reset(new EdgeHash((size_t)(nElem * (dim == 3 ? 1.4 : 1.7)) + 64));
+        for (int64_t e = 0; e < nElem; ++e) {
+            const int32_t *v = ev + e * nv;
+            int32_t *out = &m.elemNodes[(size_t)e * m.npe];
+            for (int c = 0; c < nv; ++c) out[c] = v[c];
+            for (int ei = 0; ei < nedge; ++ei) {
+                bool ins;
+                int32_t k = eh->get_or_insert(edge_key(v[kEdgeStart[ei]], v[kEdgeEnd[ei]]), nEdgeNodes, ins);
+                if (ins) ++nEdgeNodes;
+                out[nv + ei] = (int32_t)nVert + k;
+            }
+        }
+    } else {
+        std::copy(ev, ev + nElem * nv, m.elemNodes.begin());
+    }
+    m.nNode = nVert + nEdgeNodes;
+    m.nOwned = m.nNode;
+    compute_node_positions(m);
+
+    // ---- boundary extraction
+    std::vector<std::array<int32_t, 3>> bfaceVolCorners; // volume half-face corner order
+    if (dim == 3) {
+        struct HF { int32_t a, b, c; int32_t hf; };
+        std::vector<HF> hfs((size_t)nElem * 4);
+        parallel_ranges(nElem, [&](int64_t b, int64_t e, int) {
+            for (int64_t t = b; t < e; ++t)
+                for (int f = 0; f < 4; ++f) {
+                    int32_t x = ev[t * 4 + kFaceCorner[f][0]], y = ev[t * 4 + kFaceCorner[f][1]],
+                            z = ev[t * 4 + kFaceCorner[f][2]];
+                    int32_t lo = std::min(x, std::min(y, z)), hi = std::max(x, std::max(y, z));
+                    int32_t mid = x ^ y ^ z ^ lo ^ hi;
+                    hfs[(size_t)t * 4 + f] = HF{lo, mid, hi, (int32_t)(t * 4 + f)};
+                }
+        });
+        std::sort(hfs.begin(), hfs.end(), [](const HF &p, const HF &q) {
+            if (p.a != q.a) return p.a < q.a;
+            if (p.b != q.b) return p.b < q.b;
+            if (p.c != q.c) return p.c < q.c;
+            return p.hf < q.hf;
+        });
+        for (size_t k = 0; k < hfs.size();) {
+            size_t k2 = k + 1;
+            while (k2 < hfs.size() && hfs[k2].a == hfs[k].a && hfs[k2].b == hfs[k].b && hfs[k2].c == hfs[k].c) ++k2;
+            if (k2 - k > 2) throw Error(MFH_ERR_INVALID, "Non-manifold input detected.");
+            if (k2 - k == 1) {
+                int32_t hf = hfs[k].hf, t = hf / 4, f = hf % 4;
+                bfaceVolCorners.push_back({ev[(size_t)t * 4 + kFaceCorner[f][0]], ev[(size_t)t * 4 + kFaceCorner[f][1]],
+                                           ev[(size_t)t * 4 + kFaceCorner[f][2]]});
+            }
+            k = k2;
+        }
+    } else {
+        struct HE { int32_t a, b; int32_t tail, tip; };
+        std::vector<HE> hes((size_t)nElem * 3);
+        for (int64_t t = 0; t < nElem; ++t)
+            for (int c = 0; c < 3; ++c) {
+                int32_t tail = ev[t * 3 + (c + 1) % 3], tip = ev[t * 3 + (c + 2) % 3]; // TriMesh.hh:285-298
+                hes[(size_t)t * 3 + c] = HE{std::min(tail, tip), std::max(tail, tip), tail, tip};
+            }
+        std::sort(hes.begin(), hes.end(), [](const HE &p, const HE &q) {
+            if (p.a != q.a) return p.a < q.a;
+            if (p.b != q.b) return p.b < q.b;
+            return p.tail < q.tail;
+        });
+        for (size_t k = 0; k < hes.size();) {
+            size_t k2 = k + 1;
+            while (k2 < hes.size() && hes[k2].a == hes[k].a && hes[k2].b == hes[k].b) ++k2;
+            if (k2 - k > 2) throw Error(MFH_ERR_INVALID, "Non-manifold edge detected");
+            if (k2 - k == 2 && hes[k].tail != hes[k + 1].tip)
+                throw Error(MFH_ERR_INVALID, "Inconsistent triangle orientations.");
+            if (k2 - k == 1) bfaceVolCorners.push_back({hes[k].tail, hes[k].tip, -1});
+            k = k2;
+        }
+    }
+    const int64_t nBE = (int64_t)bfaceVolCorners.size();
+    const int nbv = dim; // vertices per boundary element
+    // boundary vertex numbering: first encounter in volume-corner order (TetMesh.inl:82-89;
+    // TriMesh.inl:103-104 visits tipVV = vol tail first, then tailVV = vol tip)
+    std::vector<int32_t> Vb((size_t)nVert, -1);
+    std::vector<int32_t> bV;
+    for (auto &fc : bfaceVolCorners)
+        for (int c = 0; c < nbv; ++c) {
+            int32_t v = fc[c];
+            if (Vb[v] < 0) { Vb[v] = (int32_t)bV.size(); bV.push_back(v); }
+        }
+    // boundary element vertices: 3D corner c = volume corner 2-c (TetMesh.hh:463-469);
+    // 2D vertex0 = boundary tail = volume tip, vertex1 = volume tail (TriMeshHandles.hh:269)
+    m.bdryElemNodes.assign((size_t)nBE * m.npbe, -1);
+    for (int64_t b = 0; b < nBE; ++b) {
+        int32_t *out = &m.bdryElemNodes[(size_t)b * m.npbe];
+        if (dim == 3) { out[0] = bfaceVolCorners[b][2]; out[1] = bfaceVolCorners[b][1]; out[2] = bfaceVolCorners[b][0]; }
+        else { out[0] = bfaceVolCorners[b][1]; out[1] = bfaceVolCorners[b][0]; }
+    }
+    m.bdryNodes.assign(bV.begin(), bV.end());
+    if (deg == 2) {
+        const int nbedge = dim == 3 ? 3 : 1;
+        std::vector<int32_t> bdryEdgeForVolEdge((size_t)nEdgeNodes, -1);
+        for (int64_t b = 0; b < nBE; ++b) {
+            int32_t *out = &m.bdryElemNodes[(size_t)b * m.npbe];
+            for (int ei = 0; ei < nbedge; ++ei) {
+                int32_t volEdge = eh->at(edge_key(out[kEdgeStart[ei]], out[kEdgeEnd[ei]]));
+                if (bdryEdgeForVolEdge[volEdge] < 0) {
+                    bdryEdgeForVolEdge[volEdge] = 1;
+                    m.bdryNodes.push_back((int32_t)nVert + volEdge);
+                }
+                out[nbv + ei] = (int32_t)nVert + volEdge;
+            }
+        }
+    }
+    m.isBdryNode.assign((size_t)m.nNode, 0);
+    for (int32_t n : m.bdryNodes) m.isBdryNode[n] = 1;
+    // boundary element embedding (EmbeddedElement.hh:128-149 tri in 3D, :87-104 edge in 2D)
+    m.bdryVol.resize(nBE);
+    m.bdryNormal.resize((size_t)nBE * dim);
+    for (int64_t b = 0; b < nBE; ++b) {
+        const int32_t *bn = &m.bdryElemNodes[(size_t)b * m.npbe];
+        if (dim == 3) {
+            const double *p0 = vp + 3 * (size_t)bn[0], *p1 = vp + 3 * (size_t)bn[1], *p2 = vp + 3 * (size_t)bn[2];
+            double e1[3], e2[3];
+            for (int a = 0; a < 3; ++a) { e1[a] = p0[a] - p2[a]; e2[a] = p1[a] - p0[a]; }
+            double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            double dA = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            m.bdryVol[b] = dA / 2.0;
+            for (int a = 0; a < 3; ++a) m.bdryNormal[(size_t)b * 3 + a] = n[a] / dA;
+        } else {
+            const double *p0 = vp + 2 * (size_t)bn[0], *p1 = vp + 2 * (size_t)bn[1];
+            double e[2] = {p1[0] - p0[0], p1[1] - p0[1]};
+            double L = std::sqrt(e[0] * e[0] + e[1] * e[1]);
+            m.bdryVol[b] = L;
+            m.bdryNormal[(size_t)b * 2 + 0] = -e[1] / L;
+            m.bdryNormal[(size_t)b * 2 + 1] = e[0] / L;
+        }
+    }
+    m.bdryInternal.assign((size_t)nBE, 0);
+    m.hasTopology = true;
+}
+
+// Node positions: vertex nodes = vertices; P2 edge node = midpoint of its end vertices
+// (FEMMesh.hh:221-237). Derived from the element node table so it also works for mesh_set.
+void compute_node_positions(HostMesh &m) {
+    const int dim = m.dim, nv = dim + 1;
+    m.nodePos.assign((size_t)m.nNode * dim, 0.0);
+    std::copy(m.vertPos.begin(), m.vertPos.begin() + (size_t)m.nVert * dim, m.nodePos.begin());
+    if (m.deg == 2) {
+        const int nedge = dim == 3 ? 6 : 3;
+        for (int64_t e = 0; e < m.nElem; ++e) {
+            const int32_t *en = &m.elemNodes[(size_t)e * m.npe];
+            for (int ei = 0; ei < nedge; ++ei) {
+                int32_t node = en[nv + ei];
+                const double *pa = &m.vertPos[(size_t)en[kEdgeStart[ei]] * dim], *pb = &m.vertPos[(size_t)en[kEdgeEnd[ei]] * dim];
+                for (int a = 0; a < dim; ++a) m.nodePos[(size_t)node * dim + a] = 0.5 * (pa[a] + pb[a]);
+            }
+        }
+    }
+}
+
+// PeriodicCondition (BoundaryConditions.hh:452-561, PeriodicBoundaryMatcher.hh:111-260):
+// nodes on opposite faces of the bounding-box cell are identified; DoF ids are assigned in
+// volume-node order, every identified node receiving the id at the first one's turn (:533-554).
+void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofForNode, int64_t &nDoF,
+                      std::vector<uint8_t> &bdryInternal) {
+    if (!m.hasTopology) throw Error(MFH_ERR_STATE, "periodic conditions need mesh topology (mfh_mesh_build)");
+    const int dim = m.dim;
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int64_t n = 0; n < m.nNode; ++n)
+        for (int a = 0; a < dim; ++a) {
+            mn[a] = std::min(mn[a], m.nodePos[(size_t)n * dim + a]);
+            mx[a] = std::max(mx[a], m.nodePos[(size_t)n * dim + a]);
+        }
+    auto onMin = [&](int64_t n, int a) { return std::fabs(m.nodePos[(size_t)n * dim + a] - mn[a]) <= eps; };
+    auto onMax = [&](int64_t n, int a) { return std::fabs(m.nodePos[(size_t)n * dim + a] - mx[a]) <= eps; };
+    // group boundary nodes lying on some cell face by their position wrapped onto the min faces
+    struct Key { int64_t q[3]; int32_t node; };
+    std::vector<Key> keys;
+    const double cell = 10 * eps;
+    for (int32_t n : m.bdryNodes) {
+        bool onFace = false;
+        for (int a = 0; a < dim; ++a) onFace |= onMin(n, a) || onMax(n, a);
+        if (!onFace) continue;
+        Key k{{0, 0, 0}, n};
+        for (int a = 0; a < dim; ++a) {
+            double p = onMax(n, a) ? mn[a] : m.nodePos[(size_t)n * dim + a];
+            k.q[a] = (int64_t)std::llround((p - mn[a]) / cell);
+        }
+        keys.push_back(k);
+    }
+    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+        for (int c = 0; c < 3; ++c) if (a.q[c] != b.q[c]) return a.q[c] < b.q[c];
+        return a.node < b.node;
+    });
+    std::vector<int32_t> groupOf((size_t)m.nNode, -1);
+    std::vector<std::vector<int32_t>> groups;
+    for (size_t k = 0; k < keys.size();) {
+        size_t k2 = k + 1;
+        while (k2 < keys.size() && keys[k2].q[0] == keys[k].q[0] && keys[k2].q[1] == keys[k].q[1] && keys[k2].q[2] == keys[k].q[2]) ++k2;
+        groups.emplace_back();
+        for (size_t t = k; t < k2; ++t) { groups.back().push_back(keys[t].node); groupOf[keys[t].node] = (int32_t)groups.size() - 1; }
+        k = k2;
+    }
+    dofForNode.assign((size_t)m.nNode, -1);
+    int32_t nd = 0;
+    for (int64_t n = 0; n < m.nNode; ++n) {
+        if (dofForNode[n] >= 0) continue;
+        if (groupOf[n] >= 0) for (int32_t o : groups[groupOf[n]]) dofForNode[o] = nd;
+        else dofForNode[n] = nd;
+        ++nd;
+    }
+    nDoF = nd;
+    // boundary elements whose nodes all lie on one cell face are internal (PeriodicBoundaryMatcher.hh:127-145)
+    const int64_t nBE = m.nBE();
+    bdryInternal.assign((size_t)nBE, 0);
+    for (int64_t b = 0; b < nBE; ++b) {
+        const int32_t *bn = &m.bdryElemNodes[(size_t)b * m.npbe];
+        bool internal = false;
+        for (int a = 0; a < dim && !internal; ++a) {
+            bool allMin = true, allMax = true;
+            for (int k = 0; k < m.npbe; ++k) { allMin &= onMin(bn[k], a); allMax &= onMax(bn[k], a); }
+            internal = allMin || allMax;
+        }
+        bdryInternal[b] = internal;
+    }
+}
+
+} // namespace mfh

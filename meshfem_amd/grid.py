@@ -1,0 +1,85 @@
+"""Synthetic grid meshes: vectorised restatement of the reference's `tools/grid AxBxC -t`
+(src/bin/tools/grid.cc:115-137 = gen_grid, filters/gen_grid.hh:51-92, followed by hex_tet_subdiv,
+filters/hex_tet_subdiv.hh:24-107: 24 tets per hex around the cell centre and shared face centres).
+Vertex and element ORDER are identical to the reference's loops (checked against the literal loop
+restatement in oracle/ by tests/test_host_logic.py)."""
+import numpy as np
+
+HEX_FACES = np.array([(0, 3, 2, 1), (0, 4, 7, 3), (4, 5, 6, 7), (1, 2, 6, 5), (0, 1, 5, 4), (2, 3, 7, 6)])
+
+
+def gen_grid_3d(sx, sy, sz, z0=0):
+    """Corner vertices (c, r, s) and GMSH-ordered hexes; z0 offsets the slice coordinate (slabs)."""
+    nC, nR, nS = sx, sy, sz
+    s, r, c = np.meshgrid(np.arange(nS + 1), np.arange(nR + 1), np.arange(nC + 1), indexing="ij")
+    verts = np.stack([c.ravel(), r.ravel(), s.ravel() + z0], axis=1).astype(np.float64)
+
+    def idx(s_, r_, c_):
+        return (nC + 1) * ((nR + 1) * s_ + r_) + c_
+    s, r, c = np.meshgrid(np.arange(nS), np.arange(nR), np.arange(nC), indexing="ij")
+    s, r, c = s.ravel(), r.ravel(), c.ravel()
+    hexes = np.stack([idx(s, r, c), idx(s, r, c + 1), idx(s, r + 1, c + 1), idx(s, r + 1, c),
+                      idx(s + 1, r, c), idx(s + 1, r, c + 1), idx(s + 1, r + 1, c + 1), idx(s + 1, r + 1, c)], axis=1)
+    return verts, hexes.astype(np.int64)
+
+
+def hex_tet_subdiv(verts, hexes):
+    """24 tets per hex. New vertices are appended in creation order: for every hex its centre, then
+    each not-yet-seen face centre in face order (hex_tet_subdiv.hh:71-103)."""
+    nV, nH = len(verts), len(hexes)
+    fv = hexes[:, HEX_FACES]                                   # [nH, 6, 4]
+    key = fv.min(axis=2) * np.int64(nV) + fv.max(axis=2)       # a grid face is identified by its diagonal
+    flat = key.ravel()
+    _, first, inv = np.unique(flat, return_index=True, return_inverse=True)
+    is_new = first[inv] == np.arange(flat.size)
+    new_before = np.cumsum(is_new) - is_new                    # new faces strictly before this flat index
+    hex_of = np.arange(flat.size) // 6
+    created = nV + (hex_of + 1) + new_before                   # vertex id if this (hex, face) creates it
+    fc = created[first[inv]].reshape(nH, 6)
+    new_per_hex_before = new_before.reshape(nH, 6)[:, 0]
+    hc = nV + np.arange(nH) + new_per_hex_before
+    n_out = nV + nH + int(is_new.sum())
+    out_v = np.empty((n_out, 3))
+    out_v[:nV] = verts
+    out_v[hc] = verts[hexes].sum(axis=1) / 8
+    fcenters = 0.25 * verts[fv].sum(axis=2).reshape(-1, 3)
+    out_v[created[is_new]] = fcenters[is_new]
+    a = fv[:, :, [1, 2, 3, 0]]                                 # e[f[(v+1)%4]]
+    b = fv                                                     # e[f[v]]
+    tets = np.stack([a, b, np.broadcast_to(fc[:, :, None], a.shape),
+                     np.broadcast_to(hc[:, None, None], a.shape)], axis=3).reshape(-1, 4)
+    return out_v, tets
+
+
+def grid_tet_mesh(sx, sy, sz, min_corner=None, max_corner=None):
+    """tools/grid AxBxC -t [--minCorner --maxCorner]: returns (vertices [nV,3] f64, tets [nE,4] i64)."""
+    v, h = gen_grid_3d(sx, sy, sz)
+    if min_corner is not None:
+        mn, mx = np.asarray(min_corner, float), np.asarray(max_corner, float)
+        v = v * ((mx - mn) / np.array([sx, sy, sz], float)) + mn
+    return hex_tet_subdiv(v, h)
+
+
+def gen_grid_2d(sx, sy):
+    r, c = np.meshgrid(np.arange(sy + 1), np.arange(sx + 1), indexing="ij")
+    verts = np.stack([c.ravel(), r.ravel()], axis=1).astype(np.float64)
+
+    def idx(r_, c_):
+        return (sx + 1) * r_ + c_
+    r, c = np.meshgrid(np.arange(sy), np.arange(sx), indexing="ij")
+    r, c = r.ravel(), c.ravel()
+    quads = np.stack([idx(r, c), idx(r, c + 1), idx(r + 1, c + 1), idx(r + 1, c)], axis=1)
+    return verts, quads.astype(np.int64)
+
+
+def grid_tri_mesh(sx, sy, min_corner=None, max_corner=None):
+    """2D grid split into 4 CCW triangles per quad around the quad centre."""
+    v, q = gen_grid_2d(sx, sy)
+    if min_corner is not None:
+        mn, mx = np.asarray(min_corner, float), np.asarray(max_corner, float)
+        v = v * ((mx - mn) / np.array([sx, sy], float)) + mn
+    nV, nQ = len(v), len(q)
+    centers = v[q].sum(axis=1) / 4
+    ci = nV + np.arange(nQ)
+    tris = np.stack([q, q[:, [1, 2, 3, 0]], np.broadcast_to(ci[:, None], q.shape)], axis=2).reshape(-1, 3)
+    return np.concatenate([v, centers]), tris
