@@ -42,12 +42,13 @@ static const int kFaceCorner[4][3] = {{1, 3, 2}, {0, 2, 3}, {0, 3, 1}, {0, 1, 2}
 
 namespace {
 struct EdgeHash {
-    // open addressing, key = (min << 32) | max
+    // open addressing with growth, key = (min << 32) | max
     std::vector<uint64_t> keys;
     std::vector<int32_t> vals;
     uint64_t mask = 0;
+    size_t count = 0;
     explicit EdgeHash(size_t expected) {
-        size_t cap = 16;
+        size_t cap = 64;
         while (cap < expected * 2) cap <<= 1;
         keys.assign(cap, ~0ull);
         vals.assign(cap, -1);
@@ -57,12 +58,28 @@ struct EdgeHash {
         k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
         return k;
     }
+    void grow() {
+        std::vector<uint64_t> ok;
+        std::vector<int32_t> ov;
+        ok.swap(keys); ov.swap(vals);
+        const size_t cap = ok.size() * 2;
+        keys.assign(cap, ~0ull);
+        vals.assign(cap, -1);
+        mask = cap - 1;
+        for (size_t i = 0; i < ok.size(); ++i) {
+            if (ok[i] == ~0ull) continue;
+            uint64_t h = mix(ok[i]) & mask;
+            while (keys[h] != ~0ull) h = (h + 1) & mask;
+            keys[h] = ok[i]; vals[h] = ov[i];
+        }
+    }
     // returns value; inserts `next` if absent
     int32_t get_or_insert(uint64_t key, int32_t next, bool &inserted) {
+        if ((count + 1) * 2 > keys.size()) grow();
         uint64_t h = mix(key) & mask;
         while (true) {
             if (keys[h] == key) { inserted = false; return vals[h]; }
-            if (keys[h] == ~0ull) { keys[h] = key; vals[h] = next; inserted = true; return next; }
+            if (keys[h] == ~0ull) { keys[h] = key; vals[h] = next; inserted = true; ++count; return next; }
             h = (h + 1) & mask;
         }
     }
