@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X-native MeshFEM hot path.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Metric (BASELINE.json): stiffness-assembly elements/s (+ PCG DOF/s), quadratic tets.
+  * workload at N=1: BASELINE.json configs[2] -- synthetic 60^3 grid -> 5,184,000 P2 tets
+    (22,292,283 DOF), isotropic E=200 nu=0.35, u=0 on x=0, traction (0,-1,0) on x=1.
+  * a STEP = one numeric pass of the hot path over the whole mesh: element embedding (a1) +
+    per-element stiffness blocks (a2-a5) + global assembly into the device block-CSR (a6,a9).
+    Inputs (connectivity, coordinates, material, gather lists) are resident in HBM.
+    The symbolic phase (pattern + gather lists) is once-per-mesh setup and reported separately.
+  * `value` = elements * K / (wall time of the K timed steps), max over ranks.
+  * N>1: weak scaling -- every rank owns a 60-layer z-slab of a 60 x 60 x 60N grid (row/element
+    partition, owner computes, no assembly communication); the PCG leg runs the distributed solver
+    (halo exchange + all-reduce over RCCL).
+Extra objects on the JSON line: `roofline` (assembly kernel), `pcg` (solve to 1e-8 incl. its own
+roofline for the SpMV kernel), `cpu_baseline` (plain-C port of the reference loop structure timed
+on the host cores, bounded sample), `variants` (atomic-scatter assembly for comparison).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
+ALG_BYTES = {(3, 2): 7736, (3, 1): 1328, (2, 2): 1368, (2, 1): 0}   # SURVEY.md section 8(d), const material
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--grid", type=int, default=60, help="hexes per side (per-rank slab thickness for N>1)")
+    ap.add_argument("--deg", type=int, default=2)
+    ap.add_argument("--rtol", type=float, default=1e-8)
+    ap.add_argument("--maxit", type=int, default=20000)
+    ap.add_argument("--no-solve", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-grid", type=int, default=0, help="grid size of the CPU-baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(deg, cpu_grid):
+    """Reference loop structure (threaded Ke -> serial triplet push -> sumRepeated -> CSC) in plain C
+    on the host cores, on a bounded sample of the same workload (same generator, smaller grid)."""
+    from oracle import c_oracle as CO
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    D = np.zeros((6, 6))
+    lam, mu = 0.35 * 200 / (1.35 * 0.3), 200 / 2.7
+    D[:3, :3] = lam
+    D[np.arange(3), np.arange(3)] = lam + 2 * mu
+    D[np.arange(3, 6), np.arange(3, 6)] = mu
+    best = None
+    sizes = [cpu_grid] if cpu_grid else [12, 24]
+    for n in sizes:
+        V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+        h = M.Context(-1)                      # host-only: node numbering only
+        h.mesh_build(T, V, deg)
+        en, nn = h.elem_nodes(), h.n_node
+        h.close()
+        _, _, _, t = CO.assemble_csc(3, deg, en, V, D, nn)
+        best = dict(value=len(T) / t["total"], unit="elements/s", cores=CO.num_threads(), kind="port",
+                    sample="%d^3 grid -> %d P%d tets; threaded Ke %.2fs + serial triplet push %.2fs + sumRepeated/CSC %.2fs"
+                           % (n, len(T), deg, t["ke"], t["push"], t["compress"]))
+        if t["total"] > 8.0:
+            break
+    return best
+
+
+def run_single(args):
+    import torch
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    torch.cuda.set_device(0)
+    n, deg = args.grid, args.deg
+    t0 = time.time()
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    t_gen = time.time() - t0
+    c = M.Context(0)
+    t0 = time.time(); c.mesh_build(T, V, deg); t_build = time.time() - t0
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+    c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    t0 = time.time(); c.symbolic(False); t_sym = time.time() - t0
+    c.set_option("reembed", 1)               # every step re-runs the embedding kernel too
+    nE = c.n_elem
+    for _ in range(args.warmup):
+        c.assemble()
+    torch.cuda.synchronize(); c.dev_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        c.assemble()
+    c.dev_sync(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms_step = dt / args.steps * 1e3
+    value = nE * args.steps / dt
+    # dominant kernel alone, HIP events on the context's stream
+    k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
+    alg = ALG_BYTES[(3, deg)] * nE
+    roof = dict(bound="hbm", kernel="k_assemble_gather", achieved=alg / k_ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s",
+                frac=alg / k_ms / 1e6 / HBM_PEAK_GBS, traffic=None, alg_bytes_per_launch=alg, kernel_ms=k_ms,
+                bytes_per_element=ALG_BYTES[(3, deg)])
+    nr, nc, nnzb = c.matrix_info()
+    out = dict(metric="stiffness_assembly_elements_per_s", value=value, unit="elements/s", n_gpus=1, steps=args.steps,
+               warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, scaling="weak", vs_baseline=None,
+               dtype="f64", data="synthetic",
+               config=dict(workload="configs[2]: %d^3 grid -> %d P%d tets, isotropic E=200 nu=0.35, Dirichlet x=0, traction x=1"
+                                    % (n, nE, deg), elements=nE, nodes=c.n_node, dof=3 * c.n_dof, nnz_blocks=nnzb,
+                           parallelism="1 GPU", step="embed + Ke blocks + assembly into block-CSR (gather/owner-computes)"),
+               roofline=roof,
+               setup=dict(mesh_gen_s=t_gen, femmesh_build_s=t_build, symbolic_s=t_sym, **c.timing(), **c.symbolic_sizes()))
+    # comparison variant: element-major global-atomic scatter (north_star: "colored or atomic ... by evidence")
+    try:
+        a_ms = c.time_assembly_kernel(M.ASSEMBLE_ATOMIC, 3)
+        out["variants"] = dict(atomic_scatter=dict(kernel_ms=a_ms, elements_per_s=nE / a_ms * 1e3, alg_GBs=alg / a_ms / 1e6))
+        c.assemble()
+    except M.MeshFEMHipError as e:
+        out["variants"] = dict(atomic_scatter=str(e))
+    if not args.no_solve:
+        t0 = time.time()
+        u = c.sim_solve(rtol=args.rtol, maxit=args.maxit)
+        info = dict(c.last_info)
+        ndof = 3 * c.n_dof
+        sp_ms = c.time_spmv_kernel(20)
+        sp_bytes = nnzb * 76 + nr * 3 * 16 + nr * 4
+        it_bytes = sp_bytes + ndof * 112
+        out["pcg"] = dict(iterations=info["iterations"], converged=info["converged"], rtol=args.rtol,
+                          rel_residual=info["rel_residual"], true_rel_residual=info["true_rel_residual"],
+                          solve_ms=info["solve_ms"], dof=ndof,
+                          dof_per_s=ndof * info["iterations"] / (info["solve_ms"] * 1e-3),
+                          ms_per_iteration=info["solve_ms"] / max(1, info["iterations"]),
+                          preconditioner="3x3 block-Jacobi", wall_s=time.time() - t0,
+                          max_abs_u=float(np.abs(u).max()),
+                          roofline=dict(bound="hbm", kernel="k_spmv", achieved=sp_bytes / sp_ms / 1e6, peak=HBM_PEAK_GBS,
+                                        unit="GB/s", frac=sp_bytes / sp_ms / 1e6 / HBM_PEAK_GBS, kernel_ms=sp_ms,
+                                        alg_bytes_per_launch=sp_bytes,
+                                        iteration_achieved=it_bytes / (info["solve_ms"] / max(1, info["iterations"])) / 1e6))
+    if not args.no_cpu:
+        out["cpu_baseline"] = cpu_baseline(deg, args.cpu_grid)
+    print(json.dumps(out), flush=True)
+
+
+def run_multi(args):
+    import torch
+    import torch.distributed as dist
+    from meshfem_amd import distributed as D
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    res = D.bench_slabs(args, rank, world, local)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    a = parse()
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        run_multi(a)
+    else:
+        run_single(a)

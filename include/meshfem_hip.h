@@ -233,7 +233,8 @@ mfh_status mfh_time_assembly_kernel(mfh_ctx* ctx, int32_t mode, int32_t reps, do
 /* the same for one SpMV on internal scratch vectors */
 mfh_status mfh_time_spmv_kernel(mfh_ctx* ctx, int32_t reps, double* avg_ms);
 /* option knobs (string key, numeric value): "chunk_slots", "contrib_order" (0 rank-major, 1 element-major,
- * 2 slot-major), "check_every", "keep_host_symbolic" */
+ * 2 slot-major), "check_every", "keep_host_symbolic", "reembed" (1: every mfh_assemble
+ * re-runs the element-embedding kernel as well) */
 mfh_status mfh_set_option(mfh_ctx* ctx, const char* key, double value);
 
 #ifdef __cplusplus

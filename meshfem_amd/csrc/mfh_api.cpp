@@ -11,6 +11,7 @@ struct mfh_ctx {
     int device = 0;
     bool hostOnly = false;            // device == -1: mesh/symbolic host logic only (CPU tests)
     bool keepHostSymbolic = false;
+    bool alwaysReembed = false;      // option "reembed": every mfh_assemble re-runs the embedding kernel
     hipStream_t stream = nullptr;
     std::string err;
 
@@ -791,6 +792,7 @@ mfh_status mfh_assemble(mfh_ctx *c, int32_t mode) {
     MFH_TRY(c)
     require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
     require(mode == MFH_ASSEMBLE_GATHER || mode == MFH_ASSEMBLE_ATOMIC, MFH_ERR_INVALID, "bad assembly mode");
+    if (c->alwaysReembed) { c->geoValid = false; c->hGeoValid = false; }
     ensure_geometry(c);
     ensure_symbolic(c, mode == MFH_ASSEMBLE_ATOMIC);
     EventTimer t(c->stream);
@@ -1257,6 +1259,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "contrib_order") { c->contribOrder = (int)value; invalidate_symbolic(c); }
     else if (k2 == "check_every") { c->checkEvery = std::max(1, (int)value); }
     else if (k2 == "keep_host_symbolic") { c->keepHostSymbolic = value != 0; }
+    else if (k2 == "reembed") { c->alwaysReembed = value != 0; }
     else throw Error(MFH_ERR_INVALID, "unknown option " + k2);
     MFH_CATCH(c)
 }
