@@ -77,7 +77,7 @@ struct mfh_ctx {
 
     // ---- options
     int chunkSlots = 512;
-    int contribOrder = 0;
+    int contribOrder = 1;            // element-major: 12% faster than rank-major on MI355X (profiles/r01_assembly_variants.md)
     mfh_timing timing{0, 0, 0, 0};
 
     int dim() const { return mesh.dim; }

@@ -1,0 +1,59 @@
+"""CPU tests of the drop-in boundary: the shared object loads, exports every symbol declared in
+include/meshfem_hip.h, and fails loudly (never silently falls back) when there is no device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import meshfem_amd as M
+from meshfem_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    with open(os.path.join(ROOT, "include", "meshfem_hip.h")) as f:
+        txt = f.read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(mfh_[a-z_A-Z0-9]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(M.LIB_PATH)
+    syms = _declared_symbols()
+    assert len(syms) >= 50
+    for s in syms:
+        assert hasattr(lib, s), "libmeshfem_hip.so does not export %s" % s
+    # the Python binding declares exactly the header's symbols
+    assert sorted(_lib.PROTOTYPES) == syms
+
+
+def test_no_cuda_shims_or_fallback_paths_in_product():
+    bad = re.compile(r"__HIP_PLATFORM_AMD__|cuda_runtime|hipify|import\s+oracle|from\s+oracle", re.I)
+    for d, _, files in os.walk(os.path.join(ROOT, "meshfem_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".cpp", ".hip", ".hh", ".h")):
+                with open(os.path.join(d, fn)) as f:
+                    assert not bad.search(f.read()), fn
+
+
+def test_no_device_fails_loudly(gpu_available):
+    if gpu_available:
+        pytest.skip("a GPU is present")
+    with pytest.raises(M.MeshFEMHipError):
+        M.Context(0)
+
+
+def test_host_only_context_refuses_numeric_work():
+    import numpy as np
+    from meshfem_amd import grid
+    V, T = grid.grid_tet_mesh(1, 1, 1)
+    c = M.Context(-1)
+    c.mesh_build(T, V, 1)
+    for call in (lambda: c.assemble(), lambda: c.element_stiffness(), lambda: c.solve(np.zeros(3 * c.n_dof)),
+                 lambda: c.apply_K(np.zeros(3 * c.n_dof)), lambda: c.elem_volumes()):
+        with pytest.raises(M.MeshFEMHipError) as ei:
+            call()
+        assert ei.value.code == _lib.ERR_HIP
+    assert b"gfx950" in _lib.load().mfh_version()

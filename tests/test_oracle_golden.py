@@ -1,0 +1,200 @@
+"""CPU tests pinning the oracle (oracle/) against the golden vectors the reference's own tests
+hold (ported from /root/reference/tests/*.cc, cited per test) and against exact mathematics."""
+import json
+import os
+from fractions import Fraction
+
+import numpy as np
+import pytest
+
+from oracle import meshfem_oracle as O
+from oracle import c_oracle as CO
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---- tests/test_quadrature.cc:26-40,137-170: every rule integrates the monomial basis up to its degree
+#      on the unit-volume simplex with relative error <= 1e-15
+def test_quadrature_monomials_reference_tables():
+    with open(os.path.join(GOLD, "quadrature_monomials.json")) as f:
+        tables = json.load(f)
+    maxdeg = {1: 4, 2: 5, 3: 4}
+    for K in (1, 2, 3):
+        for rule_deg in range(0, maxdeg[K] + 1):
+            for d in range(0, rule_deg + 1):
+                for entry in tables[str(K)][d]:
+                    ex = entry["exponents"]
+                    exact = float(Fraction(entry["value"]))
+                    val = O.integrate(K, rule_deg, lambda p: np.prod([p[k] ** ex[k] for k in range(len(ex))]), 1.0)
+                    assert abs((val - exact) / exact) <= 1e-15, (K, rule_deg, ex, val, exact)
+
+
+# ---- tests/test_shape_functions.cc:14-66: gradPhi(j)(x) == gradPhis(x).col(j); integrated phis
+@pytest.mark.parametrize("K,deg", [(2, 1), (2, 2), (3, 1), (3, 2)])
+def test_shape_function_gradients_self_consistent(K, deg):
+    rng = np.random.default_rng(K * 10 + deg)
+    n = O.num_nodes(K, deg)
+    for _ in range(100):
+        P = rng.standard_normal((K + 1, K))
+        vol, gl = O.embed(K, P)
+        for _ in range(20):
+            x = rng.random(K + 1)
+            x /= x.sum()
+            G = O.grad_phis_at(deg, K, gl, x)
+            for j in range(n):
+                gj = O.eval_interpolant(K, deg - 1, O.grad_phi_nodal(deg, K, gl, j), x)
+                assert np.abs(gj - G[:, j]).max() <= 1e-12 * max(1.0, np.abs(G).max())
+        # phis sum to one; integral of phi via quadrature equals integratedPhis
+        x = rng.random(K + 1); x /= x.sum()
+        assert abs(O.shape_functions(deg, K, x).sum() - 1) < 1e-14
+        quad = O.integrate(K, deg, lambda p: O.shape_functions(deg, K, p), 1.0)
+        assert np.abs(quad - O.integrated_shape_functions(deg, K)).max() < 1e-15
+        # partition of unity of the gradients
+        assert np.abs(G.sum(axis=1)).max() < 1e-10 * np.abs(G).max()
+
+
+# ---- tests/test_tensors.cc:4-27: flatten/unflatten round trip
+def test_flatten_unflatten_roundtrip():
+    for dim in (2, 3):
+        for k in range(O.flat_len(dim)):
+            i, j = O.unflatten_index(dim, k)
+            assert O.flatten_indices(dim, i, j) == k and O.flatten_indices(dim, j, i) == k
+    assert [O.flatten_indices(3, *p) for p in [(0, 0), (1, 1), (2, 2), (1, 2), (0, 2), (0, 1)]] == [0, 1, 2, 3, 4, 5]
+    assert [O.flatten_indices(2, *p) for p in [(0, 0), (1, 1), (0, 1)]] == [0, 1, 2]
+
+
+# ---- tests/test_sparse_matrices.cc:7-160: triplet <-> CSC round trip, symmetric upper apply
+def test_triplet_csc_roundtrip_and_symmetric_apply():
+    rng = np.random.default_rng(0)
+    n = 40
+    dense = rng.standard_normal((n, n)) * (rng.random((n, n)) < 0.15)
+    dense = dense + dense.T
+    iu, ju = np.nonzero(np.triu(dense))
+    # duplicate-split every entry to exercise sumRepeated
+    i = np.concatenate([iu, iu]); j = np.concatenate([ju, ju])
+    v = np.concatenate([0.25 * dense[iu, ju], 0.75 * dense[iu, ju]])
+    T = O.TripletMatrix.from_arrays(n, n, i, j, v)
+    Ap, Ai, Ax = T.to_csc()
+    assert len(Ax) == len(iu)
+    x = rng.standard_normal(n)
+    y = O.csc_apply_symmetric_upper(Ap, Ai, Ax, x)
+    assert np.abs(y - dense @ x).max() <= 1e-14 * np.abs(dense @ x).max() + 1e-15
+    full = T.to_scipy_full_from_upper().toarray()
+    assert np.abs(full - dense).max() < 5e-16 * np.abs(dense).max() + 1e-16
+    # exact zeros are pruned (pruneTol = 0)
+    Z = O.TripletMatrix.from_arrays(3, 3, [0, 0, 1], [1, 1, 2], [1.0, -1.0, 2.0]).sum_repeated()
+    assert Z.nnz() == 1 and Z.i[0] == 1 and Z.j[0] == 2
+
+
+# ---- exact (sympy rational) element stiffness: anchors A6 independent of any quadrature rule
+def test_ke_matches_exact_rational_integration():
+    with open(os.path.join(GOLD, "ke_exact.json")) as f:
+        cases = json.load(f)
+    assert len(cases) == 16
+    for cs in cases:
+        K, deg = cs["K"], cs["deg"]
+        P = np.array(cs["verts"])
+        vol, gl = O.embed(K, P)
+        assert abs(vol - cs["vol"]) < 1e-14
+        ten = O.ElasticityTensor(K, np.array(cs["D"]))
+        exact = np.array(cs["Ke"])
+        loop = O.per_element_stiffness_loop(deg, K, gl, vol, ten)
+        batch = O.per_element_stiffness_batch(deg, K, gl[None], np.array([vol]), ten.rank4()[None])[0]
+        iu = np.triu_indices(exact.shape[0])
+        s = np.abs(exact).max()
+        assert np.abs(loop[iu] - exact[iu]).max() < 5e-14 * s
+        assert np.abs(batch - exact).max() < 5e-14 * s
+        if K == 3:
+            en = np.arange(4)[None, :]
+            Kc, _ = CO.element_stiffness(3, deg, _p2_nodes(deg), _p2_verts(P, deg), ten.D)
+            assert np.abs(Kc[0][iu] - exact[iu]).max() < 5e-14 * s
+
+
+def _p2_nodes(deg):
+    return np.arange(4 if deg == 1 else 10, dtype=np.int32)[None, :]
+
+
+def _p2_verts(P, deg):
+    return P        # only the 4 corner nodes are read by the embedding
+
+
+# ---- patch properties of Ke (rigid modes, PSD, constant-strain energy)
+@pytest.mark.parametrize("deg", [1, 2])
+def test_ke_properties(deg):
+    rng = np.random.default_rng(7)
+    ten = O.ElasticityTensor.orthotropic3d(150, 200, 250, 0.3, 0.25, 0.2, 60, 70, 80)
+    for _ in range(5):
+        P = rng.random((4, 3))
+        vol, gl = O.embed_tet(P)
+        if vol < 0:
+            P[[0, 1]] = P[[1, 0]]
+            vol, gl = O.embed_tet(P)
+        Ke = O.per_element_stiffness_batch(deg, 3, gl[None], np.array([vol]), ten.rank4()[None])[0]
+        w = np.linalg.eigvalsh(Ke)
+        assert np.sum(np.abs(w) < 1e-9 * w.max()) == 6 and w.min() > -1e-9 * w.max()
+        # nodes: corners + edge midpoints; linear field u = G x  =>  u^T K u = vol * eps:C:eps
+        nodes = P if deg == 1 else np.vstack([P, [0.5 * (P[O.EDGE_START[e]] + P[O.EDGE_END[e]]) for e in range(6)]])
+        G = rng.standard_normal((3, 3))
+        u = (nodes @ G.T).ravel()
+        eps = 0.5 * (G + G.T)
+        energy = vol * np.sum(eps * ten.double_contract(eps))
+        assert abs(u @ Ke @ u - energy) < 1e-11 * abs(energy)
+
+
+# ---- committed end-to-end fixture of the oracle (see tests/golden/make_goldens.py)
+@pytest.mark.parametrize("deg", [1, 2])
+def test_cantilever_fixture_reproduced(deg):
+    g = np.load(os.path.join(GOLD, "cantilever_small.npz"))
+    sim = O.Simulator(g["T"], g["V"], deg)
+    assert np.array_equal(sim.mesh.elem_nodes, g["p%d_elem_nodes" % deg])
+    assert np.array_equal(sim.mesh.bdry_elem_nodes, g["p%d_bdry_elem_nodes" % deg])
+    assert np.array_equal(sim.mesh.bdry_nodes, g["p%d_bdry_nodes" % deg])
+    sim.set_material_constant(O.ElasticityTensor.isotropic(3, 200.0, 0.35))
+    mn, mx = sim.box_percent([-1e-4] * 3, [1e-4, 1.0001, 1.0001]); sim.apply_dirichlet_box(mn, mx, [0, 0, 0])
+    mn, mx = sim.box_percent([0.9999, -1e-4, -1e-4], [1.0001, 1.0001, 1.0001]); sim.apply_neumann_box(mn, mx, [0, -10, 0], "force")
+    Kt = sim.assembleStiffnessMatrix().sum_repeated()
+    import scipy.sparse as sp
+    n = Kt.m
+    A = sp.coo_matrix((Kt.v, (Kt.i, Kt.j)), shape=(n, n)).tocsr()
+    B = sp.coo_matrix((g["p%d_K_v" % deg], (g["p%d_K_i" % deg], g["p%d_K_j" % deg])), shape=(n, n)).tocsr()
+    assert abs(A - B).max() < 1e-12 * abs(B).max()
+    assert np.abs(sim.neumannLoad() - g["p%d_load" % deg]).max() < 1e-13
+    fv, _ = sim.dirichlet_vars_and_values()
+    assert np.array_equal(np.array(fv), g["p%d_fixed_vars" % deg])
+    u = sim.solve()
+    assert np.linalg.norm(u - g["p%d_u" % deg]) < 1e-9 * np.linalg.norm(u)
+    # the C restatement assembles the same matrix
+    Ap, Ai, Ax, _ = CO.assemble_csc(3, deg, sim.mesh.elem_nodes, g["V"], sim.D[0].D, sim.mesh.num_nodes)
+    C = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n)).tocsr()
+    assert abs(C - B).max() < 1e-12 * abs(B).max()
+
+
+def test_isotropic_and_orthotropic_tensors():
+    # ElasticityTensor.hh:100-134: Lame parameters; 2D is plane stress
+    t = O.ElasticityTensor.isotropic(3, 200.0, 0.35)
+    lam, mu = 0.35 * 200 / (1.35 * 0.3), 200 / 2.7
+    assert abs(t.D[0, 0] - (lam + 2 * mu)) < 1e-12 and abs(t.D[0, 1] - lam) < 1e-12 and abs(t.D[3, 3] - mu) < 1e-12
+    t2 = O.ElasticityTensor.isotropic(2, 200.0, 0.35)
+    assert abs(t2.D[0, 1] - 0.35 * 200 / (1 - 0.35 ** 2)) < 1e-12
+    # an isotropic material expressed through the orthotropic constructor gives the same D
+    E, nu = 200.0, 0.35
+    o = O.ElasticityTensor.orthotropic3d(E, E, E, nu, nu, nu, mu, mu, mu)
+    assert np.abs(o.D - t.D).max() < 1e-10
+    # double contraction doubles the shear entries (ElasticityTensor.hh:437-449)
+    eps = np.array([[1.0, 0.2, 0.3], [0.2, -0.5, 0.1], [0.3, 0.1, 0.7]])
+    sig = t.double_contract(eps)
+    assert np.abs(sig - (lam * np.trace(eps) * np.eye(3) + 2 * mu * eps)).max() < 1e-12
+
+
+def test_homogenization_of_solid_cube_returns_base_material():
+    """a homogeneous periodic cell homogenizes to its own tensor; fluctuations vanish."""
+    V, T = O.grid_tet_mesh(2, 2, 2)
+    sim = O.Simulator(T, V, 1)
+    base = O.ElasticityTensor.orthotropic3d(150, 200, 250, 0.3, 0.25, 0.2, 60, 70, 80)
+    sim.set_material_constant(base)
+    w = O.solve_cell_problems(sim)
+    assert max(np.abs(x).max() for x in w) < 1e-10
+    Ch = O.homogenized_elasticity_tensor(sim, w)
+    # Ch_ij reported with engineering-free (tensor) strains: column j = C : e_j
+    ref = np.column_stack([base.double_contract_flat(O.flatten_sym(3, O.canonical_strain(3, j))) for j in range(6)])
+    assert np.abs(Ch - ref).max() < 1e-9 * np.abs(ref).max()
