@@ -80,6 +80,9 @@ const char* mfh_last_error(const mfh_ctx* ctx);
 const char* mfh_version(void);
 /* the HIP stream all work of this context is enqueued on (a hipStream_t) */
 void*       mfh_stream(mfh_ctx* ctx);
+/* adopt a caller-owned hipStream_t (e.g. torch's current stream) so that the _dev entry points are
+ * stream-ordered with the caller's own kernels and RCCL collectives; the context never destroys it */
+mfh_status  mfh_set_stream(mfh_ctx* ctx, void* hipStream);
 
 /* ---------------------------------------------------------------- mesh
  * mfh_mesh_build   == FEMMesh(elems, vertices) ctor (FEMMesh.inl:11-82): vertex nodes = vertices,
@@ -96,10 +99,9 @@ void*       mfh_stream(mfh_ctx* ctx);
 mfh_status mfh_mesh_build(mfh_ctx* ctx, int32_t dim, int32_t deg, int64_t nElem, int64_t nVert,
                           const int32_t* elemVerts /* nElem x (dim+1) */,
                           const double* vertPos /* nVert x dim */);
-mfh_status mfh_mesh_set(mfh_ctx* ctx, int32_t dim, int32_t deg, int64_t nElem, int64_t nNode,
-                        int64_t nVert, int64_t nOwned,
-                        const int32_t* elemNodes /* nElem x nodesPerElem, MeshFEM local order */,
-                        const double* vertPos /* nVert x dim; vertex v is node v */);
+mfh_status mfh_mesh_set(mfh_ctx* ctx, int32_t dim, int32_t deg, int64_t nElem, int64_t nNode, int64_t nOwned,
+                        const int32_t* elemNodes /* nElem x nodesPerElem, MeshFEM local order, any numbering */,
+                        const double* nodePos /* nNode x dim (only corner-node positions enter the embedding) */);
 mfh_status mfh_mesh_sizes(const mfh_ctx* ctx, int64_t* nElem, int64_t* nNode, int64_t* nVert,
                           int64_t* nBdryElem, int64_t* nBdryNode, int32_t* nodesPerElem,
                           int32_t* nodesPerBdryElem);

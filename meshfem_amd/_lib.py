@@ -41,8 +41,9 @@ PROTOTYPES = {
     "mfh_last_error": (C.c_char_p, [_P]),
     "mfh_version": (C.c_char_p, []),
     "mfh_stream": (_P, [_P]),
+    "mfh_set_stream": (_i32, [_P, _P]),
     "mfh_mesh_build": (_i32, [_P, _i32, _i32, _i64, _i64, _P, _P]),
-    "mfh_mesh_set": (_i32, [_P, _i32, _i32, _i64, _i64, _i64, _i64, _P, _P]),
+    "mfh_mesh_set": (_i32, [_P, _i32, _i32, _i64, _i64, _i64, _P, _P]),
     "mfh_mesh_sizes": (_i32, [_P, _pi64, _pi64, _pi64, _pi64, _pi64, _pi32, _pi32]),
     "mfh_mesh_get_elem_nodes": (_i32, [_P, _P]),
     "mfh_mesh_get_node_positions": (_i32, [_P, _P]),

@@ -45,12 +45,13 @@ class Context:
         self._ck(self.lib.mfh_mesh_build(self.h, self.dim, deg, len(elems), len(verts), ptr(elems), ptr(verts)))
         self._sizes()
 
-    def mesh_set(self, dim, deg, elem_nodes, vert_pos, n_node, n_owned=None):
-        elem_nodes, vert_pos = as_i32(elem_nodes), as_f64(vert_pos)
+    def mesh_set(self, dim, deg, elem_nodes, node_pos, n_owned=None):
+        """Explicit node table (any numbering); rows of K = the first n_owned nodes (halo nodes last)."""
+        elem_nodes, node_pos = as_i32(elem_nodes), as_f64(node_pos)
         self.dim, self.deg = dim, deg
+        n_node = len(node_pos)
         n_owned = n_node if n_owned is None else n_owned
-        self._ck(self.lib.mfh_mesh_set(self.h, dim, deg, len(elem_nodes), n_node, len(vert_pos), n_owned,
-                                       ptr(elem_nodes), ptr(vert_pos)))
+        self._ck(self.lib.mfh_mesh_set(self.h, dim, deg, len(elem_nodes), n_node, n_owned, ptr(elem_nodes), ptr(node_pos)))
         self._sizes()
 
     def _sizes(self):
@@ -304,6 +305,10 @@ class Context:
     # ---------------------------------------------------------------- device pointers (torch interop)
     def stream(self):
         return self.lib.mfh_stream(self.h)
+
+    def set_stream(self, hip_stream):
+        """Adopt a caller-owned hipStream_t (int handle, e.g. torch.cuda.current_stream().cuda_stream)."""
+        self._ck(self.lib.mfh_set_stream(self.h, C.c_void_p(hip_stream)))
 
     def dev_spmv(self, x_ptr, y_ptr):
         self._ck(self.lib.mfh_dev_spmv(self.h, C.c_void_p(x_ptr), C.c_void_p(y_ptr)))

@@ -13,6 +13,7 @@ struct mfh_ctx {
     bool keepHostSymbolic = false;
     bool alwaysReembed = false;      // option "reembed": every mfh_assemble re-runs the embedding kernel
     hipStream_t stream = nullptr;
+    bool ownStream = true;
     std::string err;
 
     // ---- mesh
@@ -158,7 +159,7 @@ void upload_mesh(mfh_ctx *c) {
     if (!c->hostOnly) {
         MFH_HIP(hipSetDevice(c->device));
         c->dElemNodes.upload(c->mesh.elemNodes, c->stream);
-        c->dVertPos.upload(c->mesh.vertPos.data(), (size_t)c->mesh.nVert * c->mesh.dim, c->stream);
+        c->dVertPos.upload(c->mesh.nodePos, c->stream);   // corner nodes index into the node table
     }
     c->timing.upload_ms = now_ms() - t0;
     c->haveMesh = true;
@@ -554,13 +555,24 @@ void mfh_destroy(mfh_ctx *c) {
     if (!c->hostOnly) (void)hipSetDevice(c->device);
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     hipStream_t s = c->stream;
-    c->stream = nullptr;
-    delete c;
-    if (s) (void)hipStreamDestroy(s);
+    const bool own = c->ownStream;
+    delete c;   // device buffers are freed while the stream is still alive
+    if (s && own) (void)hipStreamDestroy(s);
 }
 
 const char *mfh_last_error(const mfh_ctx *c) { return c ? c->err.c_str() : "null context"; }
 void *mfh_stream(mfh_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+mfh_status mfh_set_stream(mfh_ctx *c, void *stream) {
+    MFH_TRY(c)
+    require(c && !c->hostOnly, MFH_ERR_STATE, "no device context");
+    MFH_HIP(hipSetDevice(c->device));
+    MFH_HIP(hipStreamSynchronize(c->stream));
+    if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)stream;   // nullptr = the legacy default stream
+    c->ownStream = false;
+    MFH_CATCH(c)
+}
 
 // ---------------------------------------------------------------- mesh
 mfh_status mfh_mesh_build(mfh_ctx *c, int32_t dim, int32_t deg, int64_t nElem, int64_t nVert, const int32_t *elemVerts,
@@ -573,24 +585,21 @@ mfh_status mfh_mesh_build(mfh_ctx *c, int32_t dim, int32_t deg, int64_t nElem, i
     MFH_CATCH(c)
 }
 
-mfh_status mfh_mesh_set(mfh_ctx *c, int32_t dim, int32_t deg, int64_t nElem, int64_t nNode, int64_t nVert, int64_t nOwned,
-                        const int32_t *elemNodes, const double *vertPos) {
+mfh_status mfh_mesh_set(mfh_ctx *c, int32_t dim, int32_t deg, int64_t nElem, int64_t nNode, int64_t nOwned,
+                        const int32_t *elemNodes, const double *nodePos) {
     MFH_TRY(c)
-    require(c && elemNodes && vertPos, MFH_ERR_INVALID, "null argument");
+    require(c && elemNodes && nodePos, MFH_ERR_INVALID, "null argument");
     require((dim == 2 || dim == 3) && (deg == 1 || deg == 2), MFH_ERR_INVALID, "dim must be 2/3 and deg 1/2");
-    require(nElem > 0 && nVert > 0 && nNode >= nVert && nOwned > 0 && nOwned <= nNode, MFH_ERR_INVALID, "bad mesh sizes");
+    require(nElem > 0 && nNode > 0 && nOwned > 0 && nOwned <= nNode, MFH_ERR_INVALID, "bad mesh sizes");
     HostMesh &m = c->mesh;
     m = HostMesh();
     m.dim = dim; m.deg = deg; m.npe = nodes_per_elem(dim, deg); m.npbe = nodes_per_bdry_elem(dim, deg);
-    m.nElem = nElem; m.nNode = nNode; m.nVert = nVert; m.nOwned = nOwned;
+    m.nElem = nElem; m.nNode = nNode; m.nVert = nNode; m.nOwned = nOwned;
     m.elemNodes.assign(elemNodes, elemNodes + nElem * m.npe);
-    for (int64_t e = 0; e < nElem; ++e)
-        for (int k = 0; k < m.npe; ++k) {
-            const int32_t v = elemNodes[e * m.npe + k];
-            require(v >= 0 && v < (k <= dim ? nVert : nNode), MFH_ERR_INVALID, "Bad node index encountered.");
-        }
-    m.vertPos.assign(vertPos, vertPos + nVert * dim);
-    compute_node_positions(m);
+    for (int64_t k = 0; k < nElem * m.npe; ++k)
+        require(elemNodes[k] >= 0 && elemNodes[k] < nNode, MFH_ERR_INVALID, "Bad node index encountered.");
+    m.nodePos.assign(nodePos, nodePos + nNode * dim);
+    m.vertPos = m.nodePos;
     m.isBdryNode.assign((size_t)nNode, 0);
     upload_mesh(c);
     if (!c->hostOnly) ensure_geometry(c);

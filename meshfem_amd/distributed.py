@@ -1,0 +1,319 @@
+"""Row-partitioned multi-GPU assembly + PCG.
+
+One process per GPU. Nodes (block rows of K) are partitioned; every rank keeps the elements
+incident to its owned nodes, numbers its nodes owned-first / halo-last and assembles the
+`nOwned x nLocal` block rows it owns with NO communication (owner computes). The PCG needs, per
+iteration, one halo exchange of the search direction (point-to-point with the neighbouring ranks)
+and two small all-reduces of the dot products -- `torch.distributed` (backend "nccl" = RCCL over
+xGMI on the GPU box, "gloo" in the CPU tests). The local kernels are the library's device-pointer
+entry points (`HipLocalOps`); the tests substitute their own local operator, the product never
+falls back to one.
+
+The reference has no distributed code: this module has no counterpart to cite
+beyond the serial path it parallelises (LinearElasticity.hh:479-487, SparseMatrices.hh:2515-2606).
+"""
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+TET_FACES = ((1, 3, 2), (0, 2, 3), (0, 3, 1), (0, 1, 2))          # TetMesh.hh:221-226
+EDGE_OF = {frozenset(p): 4 + e for e, p in enumerate(((0, 1), (1, 2), (2, 0), (0, 3), (2, 3), (1, 3)))}  # Simplex.hh:43-44
+
+
+# ------------------------------------------------------------------------------------------------
+# partitioning (pure numpy; identical on GPU and in the gloo tests)
+# ------------------------------------------------------------------------------------------------
+class LocalMesh:
+    """A rank's share: elements with >= 1 owned node, nodes renumbered owned-first (sorted by global
+    key), then halo nodes grouped by owner rank (sorted by key inside a group)."""
+
+    def __init__(self, elem_nodes, node_pos, keys, n_owned, halo_ranges, kept_elems):
+        self.elem_nodes = elem_nodes          # [nElemLocal, npe] local node ids
+        self.node_pos = node_pos              # [nLocal, dim]
+        self.keys = keys                      # [nLocal] global int64 key of every local node
+        self.n_owned = n_owned
+        self.halo_ranges = halo_ranges        # {owner rank: (start, end)} in local node numbering
+        self.kept_elems = kept_elems          # indices into the candidate element array
+        self.n_local = len(keys)
+
+
+def partition(elem_nodes, node_pos, node_keys, node_owner, rank):
+    """elem_nodes: candidate elements (any superset of the elements touching this rank's nodes) in
+    some local numbering; node_keys: globally unique int64 per node; node_owner: rank per node."""
+    elem_nodes = np.asarray(elem_nodes)
+    owned_mask = node_owner == rank
+    keep = owned_mask[elem_nodes].any(axis=1)
+    en = elem_nodes[keep]
+    used = np.unique(en)
+    owner_u, keys_u = node_owner[used], node_keys[used]
+    # owned first; halo grouped by owner; key-sorted inside each group
+    group = np.where(owner_u == rank, -1, owner_u)
+    order = np.lexsort((keys_u, group))
+    new_nodes = used[order]
+    remap = np.full(len(node_keys), -1, dtype=np.int64)
+    remap[new_nodes] = np.arange(len(new_nodes))
+    n_owned = int((group == -1).sum())
+    halo_ranges = {}
+    g_sorted = group[order]
+    for q in np.unique(g_sorted[n_owned:]):
+        idx = np.flatnonzero(g_sorted == q)
+        halo_ranges[int(q)] = (int(idx[0]), int(idx[-1]) + 1)
+    return LocalMesh(remap[en].astype(np.int32), node_pos[new_nodes], node_keys[new_nodes], n_owned, halo_ranges,
+                     np.flatnonzero(keep))
+
+
+class HaloExchange:
+    """Point-to-point exchange lists. Every rank asks the owners for its halo nodes by key."""
+
+    def __init__(self, lm: LocalMesh, rank, world, device, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.n_owned, self.n_local = lm.n_owned, lm.n_local
+        requests = [None] * world
+        for q, (s, e) in lm.halo_ranges.items():
+            requests[q] = lm.keys[s:e]
+        gathered = [None] * world
+        dist.all_gather_object(gathered, requests, group=group)     # setup only (python objects)
+        owned_keys = lm.keys[:lm.n_owned]
+        sorter = np.argsort(owned_keys)
+        self.send_idx = {}
+        for q in range(world):
+            req = gathered[q][rank] if gathered[q] is not None else None
+            if req is None or len(req) == 0:
+                continue
+            pos = np.searchsorted(owned_keys, req, sorter=sorter)
+            idx = sorter[np.clip(pos, 0, len(sorter) - 1)]
+            if not np.array_equal(owned_keys[idx], req):
+                raise RuntimeError("halo request for a node this rank does not own")
+            self.send_idx[q] = torch.as_tensor(idx, dtype=torch.long, device=device)
+        self.recv_range = dict(lm.halo_ranges)
+        self.bytes_per_exchange = 0
+
+    def exchange(self, v, dim):
+        """v: flat tensor of n_local*dim; fills the halo part from the owners."""
+        if self.world == 1:
+            return
+        v2 = v.view(-1, dim)
+        ops, keep = [], []
+        for q, idx in sorted(self.send_idx.items()):
+            buf = v2[idx].contiguous()
+            keep.append(buf)
+            ops.append(dist.P2POp(dist.isend, buf, q, group=self.group))
+        for q, (s, e) in sorted(self.recv_range.items()):
+            ops.append(dist.P2POp(dist.irecv, v2[s:e], q, group=self.group))
+        if ops:
+            for r in dist.batch_isend_irecv(ops):
+                r.wait()
+
+
+# ------------------------------------------------------------------------------------------------
+# local operators
+# ------------------------------------------------------------------------------------------------
+class HipLocalOps:
+    """The rank's block rows on its GPU, through the C ABI's device-pointer entry points."""
+
+    def __init__(self, ctx, dim):
+        self.ctx, self.dim = ctx, dim
+        nr, nc, _ = ctx.matrix_info()
+        self.n_rows, self.n_cols = nr * dim, nc * dim
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        # run the library's kernels on torch's current stream: ordered with torch ops and RCCL
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    def zeros(self, n):
+        return torch.zeros(n, dtype=torch.float64, device=self.device)
+
+    def spmv(self, x_local, out):
+        self.ctx.dev_spmv(x_local.data_ptr(), out.data_ptr())
+
+    def precond(self, r, out):
+        self.ctx.dev_precond(r.data_ptr(), out.data_ptr())
+
+    def mask_fixed(self, v):
+        self.ctx.dev_mask_fixed(v.data_ptr())
+
+    def set_fixed_values(self, u):
+        self.ctx.dev_set_fixed_values(u.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------------
+# distributed PCG (classic, two all-reduces per iteration)
+# ------------------------------------------------------------------------------------------------
+def _allreduce(vals, device, group):
+    t = torch.stack(vals) if isinstance(vals, (list, tuple)) else vals
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(t, group=group)
+    return t
+
+
+def distributed_pcg(ops, halo, f_owned, rtol=1e-8, maxit=20000, group=None, check_every=25):
+    """Solve K u = f on the free variables; f_owned: this rank's dim*nOwned right-hand side.
+    Returns (u_owned, info). All vectors are torch tensors on ops' device."""
+    dim = ops.dim
+    nr, nc = ops.n_rows, ops.n_cols
+    dev = f_owned.device
+    # b = P (f - K ubar): ubar = fixed values on every rank's owned nodes, halo part by exchange
+    u0 = ops.zeros(nc)
+    ops.set_fixed_values(u0)
+    halo.exchange(u0, dim)
+    Ku0 = ops.zeros(nr)
+    ops.spmv(u0, Ku0)
+    b = f_owned - Ku0
+    ops.mask_fixed(b)
+    x = ops.zeros(nr)
+    r = b.clone()
+    z = ops.zeros(nr)
+    ops.precond(r, z)
+    p = ops.zeros(nc)
+    p[:nr] = z
+    Ap = ops.zeros(nr)
+    red = _allreduce(torch.stack([torch.dot(r, z), torch.dot(r, r)]), dev, group)
+    rz, bb = red[0], red[1].item()
+    stop = rtol * rtol * bb
+    info = dict(iterations=0, converged=bb == 0.0, rel_residual=0.0)
+    it = 0
+    rr = bb
+    t0 = time.perf_counter()
+    hist = []
+    while it < maxit and not info["converged"]:
+        halo.exchange(p, dim)
+        ops.spmv(p, Ap)
+        ops.mask_fixed(Ap)
+        pAp = _allreduce(torch.dot(p[:nr], Ap).reshape(1), dev, group)[0]
+        alpha = rz / pAp
+        x.add_(p[:nr] * alpha)
+        r.sub_(Ap * alpha)
+        ops.precond(r, z)
+        red = _allreduce(torch.stack([torch.dot(r, z), torch.dot(r, r)]), dev, group)
+        beta = red[0] / rz
+        rz = red[0]
+        p[:nr].mul_(beta).add_(z)
+        hist.append(red[1])
+        it += 1
+        if it % check_every == 0 or it == maxit:
+            h = torch.stack(hist).cpu().numpy()        # one host sync per check_every iterations
+            hit = np.flatnonzero(h <= stop)
+            if len(hit):
+                info["converged"] = True
+                rr = float(h[hit[0]])
+                info["iterations"] = it - len(h) + int(hit[0]) + 1
+            else:
+                rr = float(h[-1])
+                info["iterations"] = it
+            hist = []
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
+    info["solve_s"] = time.perf_counter() - t0
+    info["loop_iterations"] = it
+    info["rel_residual"] = float(np.sqrt(rr / bb)) if bb > 0 else 0.0
+    u = x.clone()
+    full = ops.zeros(nc)
+    full[:nr] = u
+    ops.set_fixed_values(full)
+    return full[:nr].clone(), info
+
+
+# ------------------------------------------------------------------------------------------------
+# synthetic z-slab meshes (weak scaling): the reference generator restricted to a z-range
+# ------------------------------------------------------------------------------------------------
+def slab_local_mesh(n, rank, world, deg=2):
+    """Grid n x n x (n*world) of unit-cube cells of size 1/n; rank owns hex layers [n*rank, n*(rank+1)).
+    Returns the LocalMesh plus integer lattice coordinates (units of 1/(4n)) of every local node."""
+    from . import grid
+    from .core import Context
+    z0, z1 = n * rank, n * (rank + 1)
+    top = 1 if rank < world - 1 else 0                 # one halo hex layer above the owned interface plane
+    V, H = grid.gen_grid_3d(n, n, z1 - z0 + top, z0=z0)
+    V, T = grid.hex_tet_subdiv(V, H)
+    h = Context(-1)                                    # host-only: P2 node numbering (FEMMesh.inl:22-36)
+    h.mesh_build(T, V, deg)
+    en, pos = h.elem_nodes().astype(np.int64), h.node_positions()
+    h.close()
+    lat = np.rint(pos * 4).astype(np.int64)            # vertices/centres/midpoints live on the quarter lattice
+    M = 4 * n + 1
+    keys = (lat[:, 0] * M + lat[:, 1]) * (4 * n * world + 1) + lat[:, 2]
+    # rank r owns lattice z in (4n r, 4n (r+1)]; the global bottom plane belongs to rank 0
+    owner = np.clip((lat[:, 2] + 4 * n - 1) // (4 * n) - 1, 0, world - 1)
+    lm = partition(en, pos / n, keys, owner, rank)
+    lm.lattice = np.rint(lm.node_pos * 4 * n).astype(np.int64)
+    return lm
+
+
+def slab_traction_load(lm, n, traction):
+    """neumannLoad (LinearElasticity.hh:703-717) for a constant traction on the plane x = 1, P2 tets:
+    each boundary face contributes t*A/3 to its three edge nodes and nothing to its vertices
+    (Functions.hh:263-274). Every rank has all faces incident to its owned nodes."""
+    en, pos = lm.elem_nodes, lm.node_pos
+    lat_x = lm.lattice[:, 0]
+    load = np.zeros((lm.n_owned, 3))
+    on = lat_x[en[:, :4]] == 4 * n
+    for f, (a, b, c) in enumerate(TET_FACES):
+        sel = np.flatnonzero(on[:, a] & on[:, b] & on[:, c])
+        if not len(sel):
+            continue
+        pa, pb, pc = pos[en[sel, a]], pos[en[sel, b]], pos[en[sel, c]]
+        area = 0.5 * np.linalg.norm(np.cross(pb - pa, pc - pa), axis=1)
+        for u, v in ((a, b), (b, c), (c, a)):
+            node = en[sel, EDGE_OF[frozenset((u, v))]]
+            own = node < lm.n_owned
+            np.add.at(load, node[own], (area[own] / 3.0)[:, None] * np.asarray(traction)[None, :])
+    return load
+
+
+def bench_slabs(args, rank, world, local_rank):
+    """bench.py --gpus N>1: weak scaling over z-slabs; returns the JSON dict on every rank."""
+    import meshfem_amd as M
+    dev = torch.device("cuda", local_rank)
+    n, deg = args.grid, args.deg
+    t0 = time.time()
+    lm = slab_local_mesh(n, rank, world, deg)
+    t_mesh = time.time() - t0
+    c = M.Context(local_rank)
+    c.mesh_set(3, deg, lm.elem_nodes, lm.node_pos, lm.n_owned)
+    c.material_isotropic(200.0, 0.35)
+    t0 = time.time(); c.symbolic(False); t_sym = time.time() - t0
+    c.set_option("reembed", 1)
+    # elements are counted once globally: a rank "owns" the elements of its own hex layers
+    n_elem_global = 24 * n * n * n * world
+    for _ in range(args.warmup):
+        c.assemble()
+    c.dev_sync(); torch.cuda.synchronize(); dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        c.assemble()
+    c.dev_sync(); torch.cuda.synchronize(); dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    dt = dt.item()
+    k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
+    alg = 7736 if deg == 2 else 1328
+    out = dict(metric="stiffness_assembly_elements_per_s", value=n_elem_global * args.steps / dt, unit="elements/s",
+               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload="%d x %d x %d grid -> %d P%d tets, z-slabs of %d hex layers per GPU (configs[4] shape)"
+                                    % (n, n, n * world, n_elem_global, deg, n), elements=n_elem_global,
+                           local_elements=int(len(lm.elem_nodes)), local_nodes=int(lm.n_local), owned_nodes=int(lm.n_owned),
+                           parallelism="row/element partition x%d, owner computes" % world),
+               roofline=dict(bound="hbm", kernel="k_assemble_gather", achieved=alg * len(lm.elem_nodes) / k_ms / 1e6, peak=8000.0,
+                             unit="GB/s", frac=alg * len(lm.elem_nodes) / k_ms / 1e6 / 8000.0, traffic=None, kernel_ms=k_ms,
+                             note="rank 0's local launch (its elements incl. the halo layer)"),
+               setup=dict(local_mesh_s=t_mesh, symbolic_s=t_sym))
+    if not args.no_solve:
+        ops = HipLocalOps(c, 3)
+        halo = HaloExchange(lm, rank, world, dev)
+        fixed_nodes = np.flatnonzero(lm.lattice[:lm.n_owned, 0] == 0)
+        c.fix_variables((3 * fixed_nodes[:, None] + np.arange(3)[None, :]).ravel())
+        f = torch.as_tensor(slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel(), device=dev)
+        dist.barrier()
+        u, info = distributed_pcg(ops, halo, f, rtol=args.rtol, maxit=args.maxit)
+        nd = torch.tensor([3.0 * lm.n_owned], dtype=torch.float64, device=dev)
+        dist.all_reduce(nd)
+        ts = torch.tensor([info["solve_s"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        out["pcg"] = dict(iterations=info["iterations"], converged=bool(info["converged"]), rtol=args.rtol,
+                          rel_residual=info["rel_residual"], dof=int(nd.item()), solve_s=ts.item(),
+                          dof_per_s=nd.item() * info["loop_iterations"] / ts.item(),
+                          ms_per_iteration=ts.item() / max(1, info["loop_iterations"]) * 1e3,
+                          preconditioner="3x3 block-Jacobi", comm="halo P2P + 2 all-reduce / iteration (torch.distributed nccl=RCCL)")
+    return out

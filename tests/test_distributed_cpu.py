@@ -1,0 +1,142 @@
+"""World-size-2 gloo tests (CPU) of the multi-GPU path's host logic: row partitioning, halo
+exchange lists, slab-local mesh generation and the distributed PCG driver. The local operator is
+supplied HERE from the oracle's matrix (test infrastructure); the product's local operator is the
+HIP library (HipLocalOps) and is covered by the -m gpu tests."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import meshfem_oracle as O
+from meshfem_amd import distributed as D
+from meshfem_amd import grid
+
+
+class OracleLocalOps:
+    """Rows of the oracle's global K owned by this rank, columns in the rank's local numbering."""
+
+    def __init__(self, A_local, fixed_mask_owned, fixed_vals_owned, dim=3):
+        self.A, self.dim = A_local.tocsr(), dim
+        self.n_rows, self.n_cols = A_local.shape
+        self.fixed = fixed_mask_owned
+        self.fixed_vals = fixed_vals_owned
+        nb = self.n_rows // dim
+        self.dinv = np.zeros((nb, dim, dim))
+        for r in range(nb):
+            blk = self.A[r * dim:(r + 1) * dim, r * dim:(r + 1) * dim].toarray()
+            for c in range(dim):
+                if self.fixed[r * dim + c]:
+                    blk[c, :] = 0; blk[:, c] = 0; blk[c, c] = 1
+            self.dinv[r] = np.linalg.inv(blk)
+
+    def zeros(self, n):
+        return torch.zeros(n, dtype=torch.float64)
+
+    def spmv(self, x, out):
+        out.copy_(torch.from_numpy(self.A @ x.numpy()))
+
+    def precond(self, r, out):
+        out.copy_(torch.from_numpy(np.einsum("nij,nj->ni", self.dinv, r.numpy().reshape(-1, self.dim)).ravel()))
+
+    def mask_fixed(self, v):
+        v[torch.from_numpy(self.fixed)] = 0.0
+
+    def set_fixed_values(self, u):
+        idx = np.flatnonzero(self.fixed)
+        u[torch.from_numpy(idx)] = torch.from_numpy(self.fixed_vals[idx])
+
+
+def _global_problem(n, world):
+    """n x n x (n*world) grid, P2, unit cells of size 1/n; u=0 on x=0, traction (0,-1,0) on x=1."""
+    V, T = grid.grid_tet_mesh(n, n, n * world, [0, 0, 0], [1, 1, world])
+    sim = O.Simulator(T, V, 2)
+    sim.set_material_constant(O.ElasticityTensor.isotropic(3, 200.0, 0.35))
+    sim.apply_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9 + world], [0, 0, 0])
+    sim.apply_neumann_box([1 - 1e-9, -9, -9], [1 + 1e-9, 9, 9 + world], [0, -1, 0], "traction")
+    K = sim.assembleStiffnessMatrix().sum_repeated().to_scipy_full_from_upper().tocsr()
+    f = sim.neumannLoad()
+    u = sim.solve()
+    lat = np.rint(sim.mesh.node_pos * 4 * n).astype(np.int64)
+    M = 4 * n + 1
+    keys = (lat[:, 0] * M + lat[:, 1]) * (4 * n * world + 1) + lat[:, 2]
+    return sim, K, f, u, keys, lat
+
+
+def _worker(rank, world, port, n, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sim, K, f, u_ref, gkeys, glat = _global_problem(n, world)
+        # the slab generator (each rank builds only its share) ...
+        lm = D.slab_local_mesh(n, rank, world, 2)
+        # ... must agree with partitioning the global mesh by the same ownership rule
+        owner = np.clip((glat[:, 2] + 4 * n - 1) // (4 * n) - 1, 0, world - 1)
+        lm_g = D.partition(sim.mesh.elem_nodes, sim.mesh.node_pos, gkeys, owner, rank)
+        assert lm.n_owned == lm_g.n_owned and np.array_equal(lm.keys, lm_g.keys)
+        assert np.allclose(lm.node_pos, lm_g.node_pos)
+        assert sorted(map(tuple, lm.keys[lm.elem_nodes].tolist())) == sorted(map(tuple, lm_g.keys[lm_g.elem_nodes].tolist()))
+        assert set(lm.halo_ranges) == ({1} if rank == 0 else {0})
+        # local operator from the oracle's global matrix (rows = owned nodes, cols = local nodes)
+        key_to_global = {k: i for i, k in enumerate(gkeys)}
+        gid = np.array([key_to_global[k] for k in lm.keys])
+        rows = (3 * gid[:lm.n_owned, None] + np.arange(3)).ravel()
+        cols = (3 * gid[:, None] + np.arange(3)).ravel()
+        A_loc = K[rows][:, cols]
+        # every non-zero of the owned rows must fall on a local column (the halo is complete)
+        assert abs(K[rows]).sum() == pytest.approx(abs(A_loc).sum(), rel=1e-14)
+        fv, fx = sim.dirichlet_vars_and_values()
+        gfixed = np.zeros(K.shape[0], bool); gfixed[fv] = True
+        ops = OracleLocalOps(A_loc, gfixed[rows], np.zeros(len(rows)))
+        halo = D.HaloExchange(lm, rank, world, torch.device("cpu"))
+        # halo exchange moves owner values into halo slots
+        v = torch.zeros(lm.n_local * 3, dtype=torch.float64)
+        v[:3 * lm.n_owned] = torch.from_numpy(np.repeat(lm.keys[:lm.n_owned].astype(np.float64), 3))
+        halo.exchange(v, 3)
+        assert np.array_equal(v.numpy()[::3], lm.keys.astype(np.float64))
+        # slab traction load equals the oracle's neumannLoad on the owned nodes
+        load = D.slab_traction_load(lm, n, [0.0, -1.0, 0.0])
+        assert np.abs(load - f[gid[:lm.n_owned]]).max() < 1e-14
+        u, info = D.distributed_pcg(ops, halo, torch.from_numpy(load.ravel()), rtol=1e-10, maxit=5000, check_every=10)
+        assert info["converged"]
+        err = np.linalg.norm(u.numpy().reshape(-1, 3) - u_ref[gid[:lm.n_owned]]) / np.linalg.norm(u_ref)
+        ret[rank] = (err, info["iterations"], lm.n_owned)
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_slab_partition_and_pcg_gloo():
+    world, n = 2, 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, ret), nprocs=world, join=True)
+    assert set(ret.keys()) == {0, 1}
+    errs = [ret[r][0] for r in range(world)]
+    assert max(errs) < 1e-7, dict(ret)
+    assert ret[0][1] == ret[1][1]                       # both ranks agree on the iteration count
+    # every node is owned exactly once
+    V, T = grid.grid_tet_mesh(n, n, n * world)
+    assert ret[0][2] + ret[1][2] == O.FEMMesh(T, V, 2).num_nodes
+
+
+def test_single_rank_partition_is_identity():
+    V, T = grid.grid_tet_mesh(2, 2, 2)
+    m = O.FEMMesh(T, V, 2)
+    keys = np.arange(m.num_nodes, dtype=np.int64)
+    lm = D.partition(m.elem_nodes, m.node_pos, keys, np.zeros(m.num_nodes, np.int64), 0)
+    assert lm.n_owned == lm.n_local == m.num_nodes and not lm.halo_ranges
+    assert np.array_equal(lm.elem_nodes, m.elem_nodes)

@@ -135,7 +135,7 @@ def test_periodic_dof_map_and_partitioned_rows():
     c2 = M.Context(-1)
     m = sim.mesh
     n_owned = m.num_nodes // 2
-    c2.mesh_set(3, 2, m.elem_nodes, m.node_pos, m.num_nodes, n_owned)
+    c2.mesh_set(3, 2, m.elem_nodes, m.node_pos, n_owned)
     c2.symbolic(True)
     B, _ = _emulate_gather(c2, Ke, 3)
     sim2 = O.Simulator(T, V, 2, mesh=m)
