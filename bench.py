@@ -154,7 +154,9 @@ def run_multi(args):
     import torch
     import torch.distributed as dist
     from meshfem_amd import distributed as D
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29511")
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", rank))
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -167,7 +169,7 @@ def run_multi(args):
 
 if __name__ == "__main__":
     a = parse()
-    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("MFH_BENCH_FORCE_DISTRIBUTED"):
         run_multi(a)
     else:
         run_single(a)

@@ -107,6 +107,15 @@ def load():
         raise ImportError(
             "libmeshfem_hip.so not found at %s: build it with `python -m meshfem_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm wheels bundle their own libamdhip64; if torch is imported AFTER this library has
+    # initialised /opt/rocm's runtime the process ends up with two HIP runtimes and torch reports
+    # "No HIP GPUs are available". Loading torch first makes both share one runtime. (C/C++ users of
+    # the .so are unaffected; opt out with MESHFEM_NO_TORCH_PRELOAD=1.)
+    if os.environ.get("MESHFEM_NO_TORCH_PRELOAD", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol

@@ -11,6 +11,7 @@ struct mfh_ctx {
     int device = 0;
     bool hostOnly = false;            // device == -1: mesh/symbolic host logic only (CPU tests)
     bool keepHostSymbolic = false;
+    int debugVariant = 0;            // option "debug_variant": timing experiments of the gather kernel
     bool alwaysReembed = false;      // option "reembed": every mfh_assemble re-runs the embedding kernel
     hipStream_t stream = nullptr;
     bool ownStream = true;
@@ -42,7 +43,7 @@ struct mfh_ctx {
     Symbolic sym;
     bool symValid = false;
     bool symHasScatter = false;
-    DBuf<int32_t> dRowPtr, dColIdx, dChunkRow, dScatter;
+    DBuf<int32_t> dRowPtr, dColIdx, dChunkRow, dSpmvChunkRow, dScatter;
     DBuf<int64_t> dContribPtr;
     DBuf<uint32_t> dContribCode;
     DBuf<uint16_t> dContribSlot;
@@ -77,7 +78,7 @@ struct mfh_ctx {
     std::vector<std::pair<int64_t, std::array<double, 3>>> deltaForces;
 
     // ---- options
-    int chunkSlots = 512;
+    int chunkSlots = 256;            // assembly chunks: 18 KB of LDS accumulators, 8 workgroups per CU
     int contribOrder = 1;            // element-major: 12% faster than rank-major on MI355X (profiles/r01_assembly_variants.md)
     mfh_timing timing{0, 0, 0, 0};
 
@@ -241,6 +242,7 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
     c->dRowPtr.upload(S.rowPtr, c->stream);
     c->dColIdx.upload(S.colIdx, c->stream);
     c->dChunkRow.upload(S.chunkRow, c->stream);
+    c->dSpmvChunkRow.upload(S.spmvChunkRow, c->stream);
     c->dContribPtr.upload(S.contribPtr, c->stream);
     c->dContribCode.upload(S.contribCode, c->stream);
     c->dContribSlot.upload(S.contribSlot, c->stream);
@@ -262,11 +264,13 @@ k::AsmArgs asm_args(mfh_ctx *c) {
     k::AsmArgs a{};
     a.dim = m.dim; a.deg = m.deg; a.npe = m.npe; a.mat = c->matKind;
     a.geoStride = c->geoStride; a.geo = c->dGeo.p; a.pairTable = c->dPairTable.p;
+    for (int k2 = 0; k2 < 6; ++k2) a.pairConst[k2] = c->tables.pairConst[k2];
     a.nChunk = c->sym.nChunk(); a.chunkRow = c->dChunkRow.p; a.rowPtr = c->dRowPtr.p;
     a.contribPtr = c->dContribPtr.p; a.contribCode = c->dContribCode.p; a.contribSlot = c->dContribSlot.p;
     a.chunkSlots = c->sym.chunkSlots;
     a.nElem = m.nElem; a.scatterSlot = c->dScatter.p;
     a.vals = c->dVals.p; a.nnzb = c->sym.nnzb;
+    a.debugVariant = c->debugVariant;
     return a;
 }
 
@@ -293,8 +297,8 @@ void ensure_assembled(mfh_ctx *c) {
 
 k::SpmvArgs spmv_args(mfh_ctx *c, bool masked) {
     k::SpmvArgs a{};
-    a.dim = c->dim(); a.nChunk = c->sym.nChunk(); a.chunkRow = c->dChunkRow.p; a.rowPtr = c->dRowPtr.p;
-    a.colIdx = c->dColIdx.p; a.vals = c->dVals.p; a.chunkSlots = c->sym.chunkSlots;
+    a.dim = c->dim(); a.nChunk = (int64_t)c->sym.spmvChunkRow.size() - 1; a.chunkRow = c->dSpmvChunkRow.p; a.rowPtr = c->dRowPtr.p;
+    a.colIdx = c->dColIdx.p; a.vals = c->dVals.p; a.chunkSlots = c->sym.spmvChunkSlots;
     a.fixedMask = masked ? c->dFixedMask.p : nullptr;
     return a;
 }
@@ -1269,6 +1273,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "check_every") { c->checkEvery = std::max(1, (int)value); }
     else if (k2 == "keep_host_symbolic") { c->keepHostSymbolic = value != 0; }
     else if (k2 == "reembed") { c->alwaysReembed = value != 0; }
+    else if (k2 == "debug_variant") { c->debugVariant = (int)value; invalidate_matrix(c); }
     else throw Error(MFH_ERR_INVALID, "unknown option " + k2);
     MFH_CATCH(c)
 }

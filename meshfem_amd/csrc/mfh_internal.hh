@@ -139,7 +139,9 @@ struct Symbolic {
     std::vector<int32_t> rowPtr;        // nRows+1
     std::vector<int32_t> colIdx;        // nnzb
     // row chunks: consecutive rows whose slot count <= chunkSlots
-    std::vector<int32_t> chunkRow;      // nChunk+1
+    std::vector<int32_t> chunkRow;      // nChunk+1   (assembly chunks)
+    std::vector<int32_t> spmvChunkRow;  // row chunks of the SpMV kernel (<= spmvChunkSlots blocks)
+    int spmvChunkSlots = 0;
     // gather lists, grouped by chunk
     std::vector<int64_t> contribPtr;    // nChunk+1
     std::vector<uint32_t> contribCode;  // e*npe*npe + i*npe + j
@@ -164,6 +166,7 @@ struct ShapeTables {
     int npe = 0;
     int sup_s[10], sup_t[10];
     std::vector<double> pairTable;      // npe*npe*4
+    double pairConst[6] = {1, 0, 0, 0, 0, 0}; // [2*type + (a != b)], type 0/1/2 = two/one/no vertex-offset terms
     std::vector<double> intGrad;        // npe*2: integral (unit volume) of alpha_i, beta_i  (constantStrainLoad)
 };
 void build_shape_tables(int dim, int deg, ShapeTables &T);
@@ -180,6 +183,7 @@ struct AsmArgs {
     int geoStride;
     const double *geo;                  // nElem x geoStride
     const double *pairTable;            // device copy of ShapeTables::pairTable
+    double pairConst[6];                // the distinct pair coefficients (ShapeTables::pairConst)
     // gather
     int64_t nChunk;
     const int32_t *chunkRow;
@@ -194,6 +198,7 @@ struct AsmArgs {
     // output
     double *vals;                       // tiled [ceil(nnzb/64)][dim*dim][64]
     int64_t nnzb;
+    int debugVariant;                   // timing experiments only (0 = product kernel)
 };
 
 void launch_geometry(int dim, int deg, int mat, int64_t nElem, const int32_t *elemNodes, int npe,

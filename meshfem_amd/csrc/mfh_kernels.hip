@@ -52,6 +52,9 @@ DEV constexpr int dpack(int r, int c) {
     return a * n - a * (a - 1) / 2 + (b - a);
 }
 
+// the six distinct quadrature pair coefficients (named scalars: an indexed array would go to scratch)
+struct PairConst { double vv_eq, vv_ne, ve_eq, ve_ne, ee_eq, ee_ne; };
+
 // support vertices of node i: grad phi_i = alpha gl[s] + beta gl[t]   (EmbeddedElement.hh:315-332)
 // packed 4-bit tables: vertex nodes s=t=i; edge node k: s=edgeStart[k], t=edgeEnd[k] (Simplex.hh:43-44)
 template <int DIM, int DEG> DEV int sup_s(int i) {
@@ -73,10 +76,10 @@ template <int DIM, int DEG> DEV int sup_t(int i) {
 //   H[a][b] = sum_q w_q d_a phi_i d_b phi_j = u_a (S0 v_a + S1 v_b)^T + u_b (S2 v_a + S3 v_b)^T
 // (same quadrature rule and points as the reference: GaussQuadrature.hh:115-127,283-295).
 // ------------------------------------------------------------------------------------------------
-template <int DIM, int DEG, int MAT>
-DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pairTab, int i, int j, double *K) {
+template <int DIM, int DEG, int MAT, int ABL = 0>
+DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pairTab, const PairConst &pc, int i, int j, double *K) {
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
-    const double vol = g[12];
+    const double vol = (ABL & 2) ? 1.0 + i : g[12];
     double H[DIM][DIM];
     if (DEG == 1) {
         double gi[DIM], gj[DIM];
@@ -88,13 +91,32 @@ DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pai
             for (int b = 0; b < DIM; ++b) H[a][b] = gi[a] * gj[b];
     } else {
         const int si = sup_s<DIM, DEG>(i), ti = sup_t<DIM, DEG>(i), sj = sup_s<DIM, DEG>(j), tj = sup_t<DIM, DEG>(j);
-        const double *S = pairTab + (i * NPE + j) * 4;
-        const double S0 = S[0] * vol, S1 = S[1] * vol, S2 = S[2] * vol, S3 = S[3] * vol;
+        // Pair coefficients S = sum_q w_q coef_i(q) coef_j(q). Node i has the terms
+        //   A: (4 lambda_l - o) grad lambda_{s_i}, l = s_i, o = 1 (vertex node) | l = t_i, o = 0 (edge node)
+        //   B: (4 lambda_{s_i})  grad lambda_{t_i}, edge nodes only
+        // and sum_q w_q (4 l_a - o)(4 l_b - o') takes only six values with the reference's rule (by
+        // (o, o') class and a == b / a != b). They are read from the host-built quadrature table
+        // (build_shape_tables), so no per-lane table loads are needed.
+        constexpr int NV = DIM + 1;
+        const bool vi = i < NV, vj = j < NV;
+        const int lAi = vi ? si : ti, lBi = si, lAj = vj ? sj : tj, lBj = sj;
+        // closed form of the table: S = c1 + [a==b] c2 - c3 (o + o') + o o'  with c1 = 16 m_ab (a != b),
+        // c2 = 16 (m_aa - m_ab), c3 = 4 m_a (all three from the reference's quadrature rule). Pure
+        // arithmetic on purpose: select chains over named constants get turned into a scratch table.
+        const double c1 = pc.ee_ne, c2 = pc.ee_eq - pc.ee_ne, c3 = pc.ee_ne - pc.ve_ne;
+        const double oi = vi ? 1.0 : 0.0, oj = vj ? 1.0 : 0.0;
+        auto coef = [&](bool eq, double o, double o2) -> double { return (c1 + (eq ? c2 : 0.0)) - c3 * (o + o2) + o * o2; };
+        double S0 = coef(lAi == lAj, oi, oj);                                    // A_i A_j
+        double S1 = vj ? 0.0 : coef(lAi == lBj, oi, 0.0);                        // A_i B_j
+        double S2 = vi ? 0.0 : coef(lBi == lAj, 0.0, oj);                        // B_i A_j
+        double S3 = (vi | vj) ? 0.0 : coef(lBi == lBj, 0.0, 0.0);                // B_i B_j
+        if (ABL & 1) { S0 = pairTab[0]; S1 = pairTab[1]; S2 = pairTab[2]; S3 = pairTab[3]; }
+        S0 *= vol; S1 *= vol; S2 *= vol; S3 *= vol;
         double ua[DIM], ub[DIM], p[DIM], q[DIM];
 #pragma unroll
         for (int a = 0; a < DIM; ++a) {
-            ua[a] = g[si * DIM + a]; ub[a] = g[ti * DIM + a];
-            const double va = g[sj * DIM + a], vb = g[tj * DIM + a];
+            ua[a] = (ABL & 2) ? (double)(si + a) : g[si * DIM + a]; ub[a] = (ABL & 2) ? (double)(ti - a) : g[ti * DIM + a];
+            const double va = (ABL & 2) ? (double)(sj * a) : g[sj * DIM + a], vb = (ABL & 2) ? (double)(tj + 2 * a) : g[tj * DIM + a];
             p[a] = S0 * va + S1 * vb;
             q[a] = S2 * va + S3 * vb;
         }
@@ -105,7 +127,7 @@ DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pai
     }
     if (MAT == MAT_ISO) {
         // C_acdb = lambda d_ac d_db + mu (d_ad d_cb + d_ab d_cd)  =>  K = lambda H + mu H^T + mu tr(H) I
-        const double lam = g[13], mu = g[14];
+        const double lam = (ABL & 2) ? 0.5 : g[13], mu = (ABL & 2) ? 0.25 : g[14];
         double tr = 0;
 #pragma unroll
         for (int a = 0; a < DIM; ++a) tr += H[a][a];
@@ -227,37 +249,91 @@ __global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *
 // accumulated in LDS with ds_add_f64; the finished rows are written once, coalesced, with plain
 // stores. No global atomics, no read-modify-write of K, no zero-fill pass.
 // ------------------------------------------------------------------------------------------------
-template <int DIM, int DEG, int MAT>
+template <int DIM, int DEG, int MAT, int DBG = 0>
 __global__ void __launch_bounds__(256) k_assemble_gather(AsmArgs a) {
     constexpr int NB = DIM * DIM;
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
-    extern __shared__ __attribute__((aligned(16))) double acc[];   // [NB][chunkSlots]
-    const int CS = a.chunkSlots;
+    extern __shared__ __attribute__((aligned(16))) double acc[];   // [NB][chunkSlots + 2]
+    const int CS = a.chunkSlots + 2;
+    const PairConst pc{a.pairConst[0], a.pairConst[1], a.pairConst[2], a.pairConst[3], a.pairConst[4], a.pairConst[5]};
     const int64_t chunk = blockIdx.x;
     const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
     const int s0 = a.rowPtr[r0];
     const int ns = a.rowPtr[r1] - s0;
-    for (int t = threadIdx.x; t < ns; t += 256)
+    // LDS index = local slot + (s0 & 1): LDS pairs (2p, 2p+1) then coincide with 16-byte aligned
+    // pairs of the tiled global layout and the write-out can use dwordx4 stores
+    const int par = s0 & 1;
+    for (int t = threadIdx.x; t < ns + par; t += 256)
 #pragma unroll
         for (int c = 0; c < NB; ++c) acc[c * CS + t] = 0.0;
     __syncthreads();
     const int64_t kb = a.contribPtr[chunk], ke = a.contribPtr[chunk + 1];
-    for (int64_t k = kb + threadIdx.x; k < ke; k += 256) {
-        const uint32_t code = a.contribCode[k];
-        const int ls = a.contribSlot[k];
-        const uint32_t e = code / (NPE * NPE);
-        const int ij = (int)(code - e * (NPE * NPE));
-        const int i = ij / NPE, j = ij - i * NPE;
-        double K[NB];
-        elem_block<DIM, DEG, MAT>(a.geo + (int64_t)e * a.geoStride, a.pairTable, i, j, K);
+    // U independent contributions per lane and trip: their index loads, element-record loads and
+    // block arithmetic have no mutual dependence, so the loads of all U are in flight together
+    // (the kernel is latency-bound: rocprof shows 65 % of wave cycles in s_waitcnt at U = 1).
+    constexpr int U = (DBG >= 10 && DBG < 20) ? (DBG - 10) : 2;
+    constexpr int ABL = (DBG >= 20 && DBG < 24) ? (DBG - 20) : 0;
+    for (int64_t k0 = kb + threadIdx.x; k0 < ((DBG == 25 || DBG == 27) ? kb : ke); k0 += 256 * U) {
+        uint32_t code[U];
+        int ls[U];
+        bool ok[U];
 #pragma unroll
-        for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&acc[c * CS + ls], K[c]);
+        for (int u = 0; u < U; ++u) {
+            const int64_t kk = k0 + (int64_t)u * 256;
+            ok[u] = kk < ke;
+            code[u] = ok[u] ? a.contribCode[kk] : a.contribCode[kb];
+            ls[u] = (ok[u] ? (int)a.contribSlot[kk] : 0) + par;
+        }
+        double K[U][NB];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t e = code[u] / (NPE * NPE);
+            const int ij = (int)(code[u] - e * (NPE * NPE));
+            const int i = ij / NPE, j = ij - i * NPE;
+            elem_block<DIM, DEG, MAT, ABL>(a.geo + (int64_t)e * a.geoStride, a.pairTable, pc, i, j, K[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u]) continue;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) {
+                if (DBG == 1) acc[c * CS + ls[u]] += K[u][c];                     // timing experiment only (racy)
+                else if (DBG == 2) acc[c * CS + (threadIdx.x & (CS - 1))] = K[u][c]; // timing experiment only
+                else unsafeAtomicAdd(&acc[c * CS + ls[u]], K[u][c]);
+            }
+        }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < ns; t += 256) {
-        const int64_t s = (int64_t)s0 + t;
+    if (DBG == 24 && ns > 1) return;       // timing experiment: no write-out
+    // write-out: one 16-byte store per lane and component (two adjacent slots); the store path is
+    // issue-bound, so halving the store-instruction count matters more than anything else here
+    const int nl = ns + par;                               // LDS entries [par, nl) are live
+    const int64_t sbase = (int64_t)s0 - par;               // even: LDS index t <-> global slot sbase + t
+    const int pfirst = par;                                // first fully live pair (pair 0 holds a dead entry if par)
+    const int plast = nl >> 1;                             // pairs [pfirst, plast) are fully live
+    for (int p = pfirst + threadIdx.x; p < plast; p += 256) {
+        const int t = 2 * p;
+        const int64_t s = sbase + t;
 #pragma unroll
-        for (int c = 0; c < NB; ++c) a.vals[tiled_index(s, c, NB)] = acc[c * CS + t];
+        for (int c = 0; c < NB; ++c) {
+            const double2 v = *reinterpret_cast<const double2 *>(&acc[c * CS + t]);
+            double2 *dst = reinterpret_cast<double2 *>(&a.vals[tiled_index(s, c, NB)]);
+            typedef double dv2 __attribute__((ext_vector_type(2)));
+            // non-temporal: K is not re-read by this kernel; keeping it out of L2 leaves the cache to the
+            // element records and gather lists (2.12 -> 1.71 ms at 1.5 M P2 tets)
+            if (DBG != 28) { dv2 w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<dv2 *>(dst)); }
+            else *dst = v;
+        }
+    }
+    // the (at most two) slots that are not part of a fully live pair
+    if (threadIdx.x < 2) {
+        const int t = threadIdx.x == 0 ? 1 : nl - 1;       // LDS entry 1 (if par) / last entry (if nl odd)
+        const bool live = threadIdx.x == 0 ? (par == 1 && nl > 1) : ((nl & 1) && nl - 1 >= par && !(par == 1 && nl - 1 == 1));
+        if (live) {
+            const int64_t s = sbase + t;
+#pragma unroll
+            for (int c = 0; c < NB; ++c) a.vals[tiled_index(s, c, NB)] = acc[c * CS + t];
+        }
     }
 }
 
@@ -267,6 +343,7 @@ template <int DIM, int DEG, int MAT>
 __global__ void __launch_bounds__(256) k_assemble_atomic(AsmArgs a) {
     constexpr int NB = DIM * DIM;
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    const PairConst pc{a.pairConst[0], a.pairConst[1], a.pairConst[2], a.pairConst[3], a.pairConst[4], a.pairConst[5]};
     const int64_t total = a.nElem * (NPE * NPE);
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
         const int32_t slot = a.scatterSlot[k];
@@ -275,7 +352,7 @@ __global__ void __launch_bounds__(256) k_assemble_atomic(AsmArgs a) {
         const int ij = (int)(k - e * (NPE * NPE));
         const int i = ij / NPE, j = ij - i * NPE;
         double K[NB];
-        elem_block<DIM, DEG, MAT>(a.geo + e * a.geoStride, a.pairTable, i, j, K);
+        elem_block<DIM, DEG, MAT>(a.geo + e * a.geoStride, a.pairTable, pc, i, j, K);
 #pragma unroll
         for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&a.vals[tiled_index(slot, c, NB)], K[c]);
     }
@@ -287,13 +364,14 @@ __global__ void __launch_bounds__(256) k_element_stiffness(AsmArgs a, int64_t fi
     constexpr int NB = DIM * DIM;
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
     constexpr int KS = NPE * DIM;
+    const PairConst pc{a.pairConst[0], a.pairConst[1], a.pairConst[2], a.pairConst[3], a.pairConst[4], a.pairConst[5]};
     const int64_t total = count * (NPE * NPE);
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
         const int64_t el = k / (NPE * NPE);
         const int ij = (int)(k - el * (NPE * NPE));
         const int i = ij / NPE, j = ij - i * NPE;
         double K[NB];
-        elem_block<DIM, DEG, MAT>(a.geo + (first + el) * a.geoStride, a.pairTable, i, j, K);
+        elem_block<DIM, DEG, MAT>(a.geo + (first + el) * a.geoStride, a.pairTable, pc, i, j, K);
         double *o = out + el * KS * KS;
 #pragma unroll
         for (int c = 0; c < DIM; ++c)
@@ -571,12 +649,34 @@ void launch_geometry(int dim, int /*deg*/, int /*mat*/, int64_t nElem, const int
 
 void launch_assemble_gather(const AsmArgs &a, hipStream_t s) {
     if (a.nChunk == 0) return;
-    const size_t lds = (size_t)a.dim * a.dim * a.chunkSlots * sizeof(double);
+    const size_t lds = (size_t)a.dim * a.dim * (a.chunkSlots + 2) * sizeof(double);
 #define CALL(D, G, M)                                                                                          \
     if (lds > 64 * 1024)                                                                                         \
         MFH_HIP(hipFuncSetAttribute((const void *)k_assemble_gather<D, G, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((k_assemble_gather<D, G, M>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a)
-    MFH_DISPATCH(a, CALL);
+    if (a.debugVariant && a.dim == 3 && a.deg == 2 && a.mat == MAT_ISO) {
+        switch (a.debugVariant) {
+        case 1: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 1>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 2: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 2>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 21: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 21>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 22: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 22>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 23: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 23>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 24: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 24>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 28: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 28>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 25: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 25>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 26: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 26>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 27: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 27>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 11: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 11>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 12: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 12>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 13: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 13>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 14: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 14>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 16: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 16>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        case 18: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 18>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        default: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 0>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
+        }
+    } else {
+        MFH_DISPATCH(a, CALL);
+    }
 #undef CALL
     CHECK_LAUNCH();
 }

@@ -5,6 +5,7 @@
 // numeric assembly on the same mesh (the reference redoes the sort on every assembly).
 #include "mfh_internal.hh"
 #include <numeric>
+#include <cmath>
 
 namespace mfh {
 
@@ -149,6 +150,20 @@ void build_symbolic(const HostMesh &m, const std::vector<int32_t> &dofForNode, i
         }
     }
     const int64_t nChunk = S.nChunk();
+    // the SpMV kernel streams K and prefers larger chunks (fewer phase switches per byte)
+    S.spmvChunkSlots = std::max(512, chunkSlots);
+    S.spmvChunkRow.clear();
+    S.spmvChunkRow.push_back(0);
+    {
+        int64_t r = 0;
+        while (r < S.nRows) {
+            int32_t s0 = S.rowPtr[r];
+            int64_t r2 = r + 1;
+            while (r2 < S.nRows && S.rowPtr[r2 + 1] - s0 <= S.spmvChunkSlots) ++r2;
+            S.spmvChunkRow.push_back((int32_t)r2);
+            r = r2;
+        }
+    }
 
     // ---- contributions, concatenated in row order, then re-ordered inside every chunk
     const int64_t nContrib = rowContribPtr[S.nRows];
@@ -285,6 +300,36 @@ void build_shape_tables(int dim, int deg, ShapeTables &T) {
             }
             for (int k = 0; k < 4; ++k) T.pairTable[((size_t)i * npe + j) * 4 + k] = acc[k];
         }
+    // the four distinct pair coefficients the kernels select from (see elem_block), and a check
+    // that the selection rule reproduces the whole quadrature table
+    if (deg == 2) {
+        const int e0 = nv, e1 = nv + 1;   // edge nodes (0,1): A = 4 l_1 grad l_0, B = 4 l_0 grad l_1 ; (1,2): A = 4 l_2 ...
+        T.pairConst[0] = T.pairTable[((size_t)0 * npe + 0) * 4];         // vertex 0 x vertex 0         (a == b)
+        T.pairConst[1] = T.pairTable[((size_t)0 * npe + 1) * 4];         // vertex 0 x vertex 1         (a != b)
+        T.pairConst[2] = T.pairTable[((size_t)1 * npe + e0) * 4];        // vertex 1 x A(edge 01): l=1   (a == b)
+        T.pairConst[3] = T.pairTable[((size_t)0 * npe + e0) * 4];        // vertex 0 x A(edge 01): l=1   (a != b)
+        T.pairConst[4] = T.pairTable[((size_t)e0 * npe + e0) * 4];       // A(edge 01) x A(edge 01)      (a == b)
+        T.pairConst[5] = T.pairTable[((size_t)e0 * npe + e0) * 4 + 1];   // A(edge 01) x B(edge 01)      (a != b)
+        (void)e1;
+        for (int i = 0; i < npe; ++i)
+            for (int j = 0; j < npe; ++j) {
+                const bool vi = i < nv, vj = j < nv;
+                const int si = T.sup_s[i], ti = T.sup_t[i], sj = T.sup_s[j], tj = T.sup_t[j];
+                const int lAi = vi ? si : ti, lBi = si, lAj = vj ? sj : tj, lBj = sj;
+                const double *pc = T.pairConst;
+                const double c1 = pc[5], c2 = pc[4] - pc[5], c3 = pc[5] - pc[3];
+                auto coefS = [&](bool eq, double o, double o2) { return (c1 + (eq ? c2 : 0.0)) - c3 * (o + o2) + o * o2; };
+                const double oi = vi ? 1.0 : 0.0, oj = vj ? 1.0 : 0.0;
+                double S[4];
+                S[0] = coefS(lAi == lAj, oi, oj);
+                S[1] = vj ? 0.0 : coefS(lAi == lBj, oi, 0.0);
+                S[2] = vi ? 0.0 : coefS(lBi == lAj, 0.0, oj);
+                S[3] = (vi || vj) ? 0.0 : coefS(lBi == lBj, 0.0, 0.0);
+                for (int k = 0; k < 4; ++k)
+                    if (std::fabs(S[k] - T.pairTable[((size_t)i * npe + j) * 4 + k]) > 2e-15)
+                        throw Error(MFH_ERR_STATE, "internal: pair-coefficient selection rule does not reproduce the quadrature table");
+            }
+    }
     // integral of grad phi_i over a unit-volume element: the degree-(deg-1) interpolant is integrated
     // by Interpolant::integrate = vol/(K+1) * sum of vertex values (Functions.hh:246-253)
     for (int i = 0; i < npe; ++i) {
