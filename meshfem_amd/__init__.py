@@ -6,5 +6,9 @@ SPSDSystem, ElasticityTensor), on top of the C ABI in include/meshfem_hip.h
 from ._lib import (MeshFEMHipError, ASSEMBLE_GATHER, ASSEMBLE_ATOMIC, NEUMANN_TRACTION, NEUMANN_PRESSURE,
                    NEUMANN_FORCE, PRECOND_BLOCK_JACOBI, PRECOND_JACOBI, PRECOND_NONE, LIB_PATH)
 from .core import Context
+from .linear_elasticity import Simulator
+from .tensors import ElasticityTensor, ElasticityTensor2D, ElasticityTensor3D
+from . import homogenization
 
-__all__ = ["Context", "MeshFEMHipError", "LIB_PATH"]
+__all__ = ["Context", "Simulator", "ElasticityTensor", "ElasticityTensor2D", "ElasticityTensor3D", "homogenization",
+           "MeshFEMHipError", "LIB_PATH"]

@@ -109,6 +109,7 @@ namespace {
 void require(bool cond, mfh_status code, const char *msg) {
     if (!cond) throw Error(code, msg);
 }
+void require_device(const mfh_ctx *c);
 
 struct EventTimer {
     hipEvent_t a = nullptr, b = nullptr;
@@ -130,6 +131,11 @@ struct EventTimer {
         if (b) (void)hipEventDestroy(b);
     }
 };
+
+void require_device(const mfh_ctx *c) {
+    if (c->hostOnly)
+        throw Error(MFH_ERR_HIP, "host-only context (device -1): no HIP device, and there is no CPU fallback");
+}
 
 void invalidate_matrix(mfh_ctx *c) {
     c->assembled = false;
@@ -158,7 +164,8 @@ void clear_fixed(mfh_ctx *c) {
 void upload_mesh(mfh_ctx *c) {
     double t0 = now_ms();
     if (!c->hostOnly) {
-        MFH_HIP(hipSetDevice(c->device));
+        require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
         c->dElemNodes.upload(c->mesh.elemNodes, c->stream);
         c->dVertPos.upload(c->mesh.nodePos, c->stream);   // corner nodes index into the node table
     }
@@ -191,6 +198,7 @@ void ensure_geometry(mfh_ctx *c) {
     require(c->haveMesh, MFH_ERR_STATE, "no mesh set");
     if (c->geoValid) return;
     require(!c->hostOnly, MFH_ERR_HIP, "host-only context (device -1): no HIP device, and there is no CPU fallback");
+    require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     const HostMesh &m = c->mesh;
     if (c->matParams.empty()) set_isotropic(c, 1.0, 0.3);
@@ -238,6 +246,7 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
     const Symbolic &S = c->sym;
     c->symHasScatter = wantScatter;
     if (c->hostOnly) { c->symValid = true; return; }
+    require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     c->dRowPtr.upload(S.rowPtr, c->stream);
     c->dColIdx.upload(S.colIdx, c->stream);
@@ -570,6 +579,7 @@ void *mfh_stream(mfh_ctx *c) { return c ? (void *)c->stream : nullptr; }
 mfh_status mfh_set_stream(mfh_ctx *c, void *stream) {
     MFH_TRY(c)
     require(c && !c->hostOnly, MFH_ERR_STATE, "no device context");
+    require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     MFH_HIP(hipStreamSynchronize(c->stream));
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -916,6 +926,7 @@ mfh_status mfh_set_preconditioner(mfh_ctx *c, int32_t kind) {
 mfh_status mfh_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, double rtol, int32_t maxit, mfh_solve_info *info) {
     MFH_TRY(c)
     require(c && c->haveMesh && f && u && nrhs > 0 && maxit > 0 && rtol > 0, MFH_ERR_INVALID, "bad solve arguments");
+    require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
     const int64_t n = (int64_t)c->dim() * c->nDoF;
@@ -933,6 +944,7 @@ mfh_status mfh_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, doubl
 mfh_status mfh_apply_K(mfh_ctx *c, const double *u, double *Ku) {
     MFH_TRY(c)
     require(c && c->haveMesh && u && Ku, MFH_ERR_INVALID, "null argument");
+    require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_assembled(c);
     const int d = c->dim();
@@ -1118,6 +1130,7 @@ mfh_status mfh_sim_solve(mfh_ctx *c, const double *f, int32_t usePin, double *uN
         f = load.data();
     }
     std::vector<double> x((size_t)n);
+    require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
     mfh_solve_info li{};
@@ -1181,6 +1194,7 @@ mfh_status mfh_average_stress(mfh_ctx *c, const double *uNodes, double *stress) 
 mfh_status mfh_dev_spmv(mfh_ctx *c, const double *x_dev, double *y_dev) {
     MFH_TRY(c)
     require(c && x_dev && y_dev, MFH_ERR_INVALID, "null argument");
+    require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_assembled(c);
     k::launch_spmv(spmv_args(c, false), x_dev, y_dev, nullptr, c->stream);
@@ -1189,6 +1203,7 @@ mfh_status mfh_dev_spmv(mfh_ctx *c, const double *x_dev, double *y_dev) {
 mfh_status mfh_dev_precond(mfh_ctx *c, const double *r_dev, double *z_dev) {
     MFH_TRY(c)
     require(c && r_dev && z_dev, MFH_ERR_INVALID, "null argument");
+    require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
     k::launch_precond(c->dim(), c->sym.nRows, c->dDinv.p, r_dev, z_dev, c->stream);
@@ -1197,6 +1212,7 @@ mfh_status mfh_dev_precond(mfh_ctx *c, const double *r_dev, double *z_dev) {
 mfh_status mfh_dev_mask_fixed(mfh_ctx *c, double *r_dev) {
     MFH_TRY(c)
     require(c && r_dev, MFH_ERR_INVALID, "null argument");
+    require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_fixed_uploaded(c);
     if (!c->fixedVars.empty()) k::launch_mask((int64_t)c->dim() * c->sym.nRows, c->dFixedMask.p, r_dev, c->stream);
@@ -1205,6 +1221,7 @@ mfh_status mfh_dev_mask_fixed(mfh_ctx *c, double *r_dev) {
 mfh_status mfh_dev_set_fixed_values(mfh_ctx *c, double *u_dev) {
     MFH_TRY(c)
     require(c && u_dev, MFH_ERR_INVALID, "null argument");
+    require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_fixed_uploaded(c);
     k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, u_dev, c->stream);
@@ -1227,6 +1244,7 @@ mfh_status mfh_get_timing(const mfh_ctx *c, mfh_timing *out) {
 mfh_status mfh_time_assembly_kernel(mfh_ctx *c, int32_t mode, int32_t reps, double *avg_ms) {
     MFH_TRY(c)
     require(c && c->haveMesh && avg_ms && reps > 0, MFH_ERR_INVALID, "bad arguments");
+    require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_geometry(c);
     ensure_symbolic(c, mode == MFH_ASSEMBLE_ATOMIC);
@@ -1248,6 +1266,7 @@ mfh_status mfh_time_assembly_kernel(mfh_ctx *c, int32_t mode, int32_t reps, doub
 mfh_status mfh_time_spmv_kernel(mfh_ctx *c, int32_t reps, double *avg_ms) {
     MFH_TRY(c)
     require(c && c->haveMesh && avg_ms && reps > 0, MFH_ERR_INVALID, "bad arguments");
+    require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_assembled(c);
     const int d = c->dim();

@@ -1,0 +1,75 @@
+"""Periodic homogenization on the GPU path: mirror of `periodic_homogenization.homogenize`
+(src/python_bindings/periodic_homogenization.cc:36-90,159-171) = solveCellProblems
+(src/lib/MeshFEM/PeriodicHomogenization.hh:34-54) + homogenizedElasticityTensor (:72-103)."""
+import numpy as np
+
+from .core import flat_len
+from .linear_elasticity import Simulator
+
+
+def canonical_strain_flat(dim, k):
+    """SymmetricMatrix CanonicalBasis(k) flattened: 1 on the diagonal entries, 1/2 for shear
+    (SymmetricMatrix.hh:405-413)."""
+    v = np.zeros(flat_len(dim))
+    v[k] = 1.0 if k < dim else 0.5
+    return v
+
+
+def _unflatten(dim, v):
+    M = np.zeros((dim, dim))
+    idx = {2: [(0, 0), (1, 1), (0, 1)], 3: [(0, 0), (1, 1), (2, 2), (1, 2), (0, 2), (0, 1)]}[dim]
+    for k, (i, j) in enumerate(idx):
+        M[i, j] = M[j, i] = v[k]
+    return M
+
+
+def solve_cell_problems(sim: Simulator, cell_epsilon=1e-7):
+    """== solveCellProblems: periodic DoFs + pinned node, one solve per canonical strain with
+    rhs = constantStrainLoad(-e_ij). The matrix is assembled once; the 3/6 right-hand sides reuse it."""
+    sim.applyPeriodicConditions(cell_epsilon)
+    sim.applyNoRigidMotionConstraint()
+    sim.setUsePinNoRigidTranslationConstraint(True)
+    w, infos = [], []
+    for k in range(flat_len(sim.N)):
+        rhs = sim.constantStrainLoad(-canonical_strain_flat(sim.N, k))
+        w.append(sim.solve(rhs))
+        infos.append(sim.info)
+    return w, infos
+
+
+def homogenized_elasticity_tensor(sim: Simulator, w_ij, base_cell_volume=0.0):
+    """== homogenizedElasticityTensor (stress-like form): Eh.DRow(i) = 1/|Y| sum_e vol_e
+    [E_e : avg strain(w_i) + E_e.DRow(i)]. E_e.DRow(i) = E_e : e_i is obtained as the average stress of
+    the linear displacement field with constant strain e_i, so no per-element tensor is read back."""
+    N, fl = sim.N, flat_len(sim.N)
+    pos = sim.nodes()
+    vol = sim.ctx.elem_volumes()
+    if base_cell_volume == 0.0:
+        base_cell_volume = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
+    Eh = np.zeros((fl, fl))
+    for i in range(fl):
+        u_lin = pos @ _unflatten(N, canonical_strain_flat(N, i)).T
+        sig = sim.averageStressField(w_ij[i] + u_lin)
+        Eh[i, :] = (vol[:, None] * sig).sum(axis=0) / base_cell_volume
+    return Eh
+
+
+def homogenize(vertices, elements, degree=2, Cbase=None, E=None, nu=None, ortho_params=None, device=0, rtol=1e-8):
+    """Returns dict(Ch, w_ij, strain_w_ij, iterations) like the reference's `homogenize`.
+    Material: `Cbase` (flattened D or an object with .D) for a homogeneous base material, or
+    per-element `E`/`nu`, or per-element orthotropic parameters."""
+    sim = Simulator(elements, vertices, degree, device)
+    sim.rtol = rtol
+    if Cbase is not None:
+        sim.setMaterial(Cbase)
+    elif ortho_params is not None:
+        sim.setOrthotropicField(ortho_params)
+    elif E is not None:
+        if np.ndim(E) == 0:
+            sim.setIsotropicMaterial(E, nu)
+        else:
+            sim.setIsotropicField(E, nu)
+    w, infos = solve_cell_problems(sim)
+    Ch = homogenized_elasticity_tensor(sim, w)
+    return dict(Ch=Ch, w_ij=w, strain_w_ij=[sim.averageStrainField(x) for x in w],
+                iterations=[i["iterations"] for i in infos], sim=sim)

@@ -1,0 +1,94 @@
+"""`LinearElasticity.Simulator` with the reference's method names
+(src/lib/MeshFEM/LinearElasticity.hh:434-1659) on top of the C ABI. Every numeric step runs in
+libmeshfem_hip.so on the GPU; this class only forwards."""
+import numpy as np
+
+from . import _lib as L
+from .core import Context, flat_len
+
+
+class Simulator:
+    def __init__(self, elems, vertices, degree=2, device=0):
+        """== Simulator(elems, vertices) (:460-473): builds the FEMMesh, raises on inverted elements."""
+        self.ctx = Context(device)
+        self.ctx.mesh_build(elems, vertices, degree)
+        self.N = self.ctx.dim
+        self.degree = degree
+        self.rtol, self.maxit = 1e-8, 100000
+        self._use_pin = False
+
+    # ---- mesh queries (mesh.cc:47-70)
+    def numNodes(self):
+        return self.ctx.n_node
+
+    def numElements(self):
+        return self.ctx.n_elem
+
+    def numDoFs(self):
+        return self.ctx.n_dof
+
+    def nodes(self):
+        return self.ctx.node_positions()
+
+    def elements(self):
+        return self.ctx.elem_nodes()
+
+    # ---- materials
+    def setMaterial(self, tensor):
+        self.ctx.material_const(np.asarray(tensor.D if hasattr(tensor, "D") else tensor))
+
+    def setIsotropicMaterial(self, E, nu):
+        self.ctx.material_isotropic(E, nu)
+
+    def setIsotropicField(self, E, nu):
+        self.ctx.material_iso_field(E, nu)
+
+    def setOrthotropicField(self, params):
+        self.ctx.material_ortho_field(params)
+
+    # ---- boundary conditions (box regions of applyBoundaryConditions, :881-1027)
+    def applyDirichletBox(self, mn, mx, value, relative=False, components=None):
+        self.ctx.bc_dirichlet_box(mn, mx, value, relative, components)
+
+    def applyNeumannBox(self, mn, mx, value, kind=L.NEUMANN_TRACTION, relative=False):
+        self.ctx.bc_neumann_box(mn, mx, value, kind, relative)
+
+    def applyPeriodicConditions(self, epsilon=1e-7):                    # :845-854
+        return self.ctx.apply_periodic_conditions(epsilon)
+
+    def applyNoRigidMotionConstraint(self):                             # rotations are excluded by periodicity (:1534-1542)
+        pass
+
+    def setUsePinNoRigidTranslationConstraint(self, use):               # PeriodicHomogenization.hh:44-45
+        self._use_pin = bool(use)
+
+    # ---- loads / solve
+    def neumannLoad(self):                                              # :703-717
+        return self.ctx.neumann_load()
+
+    def constantStrainLoad(self, cstrain_flat):                         # :551-562
+        return self.ctx.constant_strain_load(cstrain_flat)
+
+    def solve(self, f=None):                                            # :479-487, :657
+        f = None if f is None else np.asarray(f, dtype=np.float64).ravel()
+        u = self.ctx.sim_solve(f, use_pin=self._use_pin, rtol=self.rtol, maxit=self.maxit)
+        self.info = dict(self.ctx.last_info)
+        return u
+
+    def applyStiffnessMatrix(self, u_dofs):                             # :801-823
+        return self.ctx.apply_K(np.asarray(u_dofs).ravel()).reshape(-1, self.N)
+
+    def averageStrainField(self, u_nodes):                              # :528-538
+        return self.ctx.average_strain(u_nodes)
+
+    def averageStressField(self, u_nodes):                              # :539-549
+        return self.ctx.average_stress(u_nodes)
+
+    def assembleStiffnessMatrix(self):
+        """m_assembleStiffnessMatrix (:1408-1466) + sumRepeated: upper triplets (i, j, v)."""
+        self.ctx.assemble()
+        return self.ctx.export_upper_triplets()
+
+    def stiffnessMatrix(self):
+        self.ctx.assemble()
+        return self.ctx.export_scipy()

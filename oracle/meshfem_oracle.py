@@ -1113,12 +1113,14 @@ def solve_cell_problems(sim: Simulator, eps=1e-7):                    # :34-54
 
 
 def homogenized_elasticity_tensor(sim: Simulator, w):
-    """Energy/volume-average form  Ch_ij = 1/|Y| sum_e vol_e [C:(e_j + strain(w_j))]_i
-    (PeriodicHomogenization.hh:72-100 homogenizedElasticityTensor)."""
+    """Stress-like form  Eh.DRow(j) = 1/|Y| sum_e vol_e [E_e : avg strain(w_j) + E_e.DRow(j)]
+    (PeriodicHomogenization.hh:72-103 homogenizedElasticityTensor). Returned as the flattened D
+    matrix with column j = row j (major symmetry holds up to solver tolerance)."""
     N = sim.N
     fl = flat_len(N)
     Ch = np.zeros((fl, fl))
-    tot = sim.vol.sum()
+    mn, mx = sim.mesh.bounding_box()
+    tot = float(np.prod(mx - mn))        # |Y| = periodic cell (bounding box) volume, not the material volume
     for j in range(fl):
         eps_w = sim.averageStrainField(w[j])
         ej = flatten_sym(N, canonical_strain(N, j))

@@ -1,0 +1,60 @@
+// C++ drop-in smoke test of the facade: the cantilever of examples/cantilever (one hex column),
+// written the way a Simulate_cli-style driver uses LinearElasticity::Simulator.
+// argv[1] = device ordinal (-1: host-only context -> the solve must throw, proving there is no fallback)
+#include <MeshFEMHip/LinearElasticity.hh>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+using namespace MeshFEMHip;
+
+int main(int argc, char **argv) {
+    const int device = argc > 1 ? atoi(argv[1]) : 0;
+    // 4 x 1 x 1 hexes -> 24 tets each (the same split as hex_tet_subdiv), built by hand: 5 tets per
+    // hex is enough here: use the 6-tet Kuhn split to keep the file short
+    const int nx = 4;
+    std::vector<std::array<Real, 3>> V;
+    for (int k = 0; k <= 1; ++k) for (int j = 0; j <= 1; ++j) for (int i = 0; i <= nx; ++i) V.push_back({(Real)i, (Real)j, (Real)k});
+    auto id = [&](int i, int j, int k) { return (int32_t)(i + (nx + 1) * (j + 2 * k)); };
+    std::vector<std::array<int32_t, 4>> T;
+    const int perm[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    for (int i = 0; i < nx; ++i)
+        for (auto &p : perm) {
+            int c[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {1, 1, 1}};
+            c[1][p[0]] = 1; c[2][p[0]] = 1; c[2][p[1]] = 1;
+            std::array<int32_t, 4> t;
+            for (int q = 0; q < 4; ++q) t[q] = id(i + c[q][0], c[q][1], c[q][2]);
+            // orient positively
+            auto &a = V[t[0]], &b = V[t[1]], &cc = V[t[2]], &d = V[t[3]];
+            Real u[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]}, v[3] = {cc[0] - a[0], cc[1] - a[1], cc[2] - a[2]},
+                 w[3] = {d[0] - a[0], d[1] - a[1], d[2] - a[2]};
+            Real det = u[0] * (v[1] * w[2] - v[2] * w[1]) - u[1] * (v[0] * w[2] - v[2] * w[0]) + u[2] * (v[0] * w[1] - v[1] * w[0]);
+            if (det < 0) std::swap(t[0], t[1]);
+            T.push_back(t);
+        }
+    try {
+        LinearElasticity::Simulator<3, 2> sim(T, V, device);
+        sim.setIsotropicMaterial(200.0, 0.35);
+        sim.applyDirichletBox({-1e-4, -1e-4, -1e-4}, {1e-4, 1.0001, 1.0001}, {0, 0, 0}, true);
+        sim.applyNeumannBox({0.9999, -1e-4, -1e-4}, {1.0001, 1.0001, 1.0001}, {0, -1, 0}, MFH_NEUMANN_FORCE, true);
+        auto f = sim.neumannLoad();
+        Real fy = 0;
+        for (auto &x : f) fy += x[1];
+        auto u = sim.solve();
+        Real tip = 0;
+        for (size_t n = 0; n < u.size(); ++n) tip = std::min(tip, u[n][1]);
+        TripletMatrix K;
+        sim.m_assembleStiffnessMatrix(K);
+        // Euler-Bernoulli: delta = F L^3 / (3 E I), I = 1/12 -> 64 / (3*200/12) = 1.28 (+ shear)
+        printf("nodes %zu total load %.6f tip deflection %.6f PCG iterations %d K nnz %zu\n", u.size(), fy, tip,
+               sim.info.iterations, K.nnz());
+        if (std::fabs(fy + 1.0) > 1e-12 || tip > -1.2 || tip < -1.6) return 2;
+        auto eps = sim.averageStrainField(u);
+        auto Ku = sim.applyStiffnessMatrix(u);
+        (void)eps; (void)Ku;
+        return 0;
+    } catch (const std::runtime_error &e) {
+        printf("runtime_error: %s\n", e.what());
+        return 3;
+    }
+}

@@ -1,0 +1,33 @@
+"""The header-only C++ facade (include/MeshFEMHip/LinearElasticity.hh) compiles with plain g++
+against the C ABI and behaves like the reference's Simulator: std::runtime_error without a device
+(no fallback), a correct cantilever on the GPU."""
+import os
+import subprocess
+
+import pytest
+
+import meshfem_amd as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "facade_cantilever")
+
+
+def _build():
+    src = os.path.join(ROOT, "tests", "cpp", "facade_cantilever.cc")
+    libdir = os.path.dirname(M.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
+                           "-L", libdir, "-lmeshfem_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_facade_compiles_and_throws_without_device():
+    _build()
+    r = subprocess.run([EXE, "-1"], capture_output=True, text=True)
+    assert r.returncode == 3 and "runtime_error" in r.stdout and "no CPU fallback" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_facade_cantilever_on_gpu():
+    _build()
+    r = subprocess.run([EXE, "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "tip deflection" in r.stdout
