@@ -49,6 +49,21 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(kernel_key, n, deg):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in their
+    own runs, calibrated on a known byte count: profiles/r01_pmc_traffic_n60.json). PMC counters cannot
+    be collected from inside this process; the figure is only attached when the workload matches."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_n60.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        if d["meta"]["n"] == n and deg == 2:
+            return d[kernel_key]["traffic_bytes"], os.path.relpath(path, ROOT)
+    except Exception:
+        pass
+    return None, None
+
+
 def cpu_baseline(deg, cpu_grid):
     """Reference loop structure (threaded Ke -> serial triplet push -> sumRepeated -> CSC) in plain C
     on the host cores, on a bounded sample of the same workload (same generator, smaller grid)."""
@@ -107,8 +122,10 @@ def run_single(args):
     # dominant kernel alone, HIP events on the context's stream
     k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
     alg = ALG_BYTES[(3, deg)] * nE
+    tb, tsrc = pmc_traffic("k_assemble_gather<3, 2, 0, 0>", n, deg)
     roof = dict(bound="hbm", kernel="k_assemble_gather", achieved=alg / k_ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s",
-                frac=alg / k_ms / 1e6 / HBM_PEAK_GBS, traffic=None, alg_bytes_per_launch=alg, kernel_ms=k_ms,
+                frac=alg / k_ms / 1e6 / HBM_PEAK_GBS, traffic=None if tb is None else tb / k_ms / 1e6,
+                traffic_bytes_per_launch=tb, traffic_source=tsrc, alg_bytes_per_launch=alg, kernel_ms=k_ms,
                 bytes_per_element=ALG_BYTES[(3, deg)])
     nr, nc, nnzb = c.matrix_info()
     out = dict(metric="stiffness_assembly_elements_per_s", value=value, unit="elements/s", n_gpus=1, steps=args.steps,
@@ -134,6 +151,7 @@ def run_single(args):
         sp_ms = c.time_spmv_kernel(20)
         sp_bytes = nnzb * 76 + nr * 3 * 16 + nr * 4
         it_bytes = sp_bytes + ndof * 112
+        stb, stsrc = pmc_traffic("k_spmv<3, false>", n, deg)
         out["pcg"] = dict(iterations=info["iterations"], converged=info["converged"], rtol=args.rtol,
                           rel_residual=info["rel_residual"], true_rel_residual=info["true_rel_residual"],
                           solve_ms=info["solve_ms"], dof=ndof,
@@ -143,6 +161,8 @@ def run_single(args):
                           max_abs_u=float(np.abs(u).max()),
                           roofline=dict(bound="hbm", kernel="k_spmv", achieved=sp_bytes / sp_ms / 1e6, peak=HBM_PEAK_GBS,
                                         unit="GB/s", frac=sp_bytes / sp_ms / 1e6 / HBM_PEAK_GBS, kernel_ms=sp_ms,
+                                        traffic=None if stb is None else stb / sp_ms / 1e6, traffic_bytes_per_launch=stb,
+                                        traffic_source=stsrc,
                                         alg_bytes_per_launch=sp_bytes,
                                         iteration_achieved=it_bytes / (info["solve_ms"] / max(1, info["iterations"])) / 1e6))
     if not args.no_cpu:
