@@ -37,6 +37,8 @@ struct mfh_ctx {
 
     // ---- DoF map
     std::vector<int32_t> dofForNode;  // empty = identity
+    DBuf<int32_t> dDofForNode;
+    bool dofUploaded = false;
     int64_t nDoF = 0;
 
     // ---- symbolic
@@ -143,6 +145,7 @@ void invalidate_matrix(mfh_ctx *c) {
 }
 void invalidate_symbolic(mfh_ctx *c) {
     c->symValid = false;
+    c->dofUploaded = false;
     invalidate_matrix(c);
 }
 void reset_bcs(mfh_ctx *c) {
@@ -1074,33 +1077,26 @@ mfh_status mfh_neumann_load(mfh_ctx *c, double *out) {
     MFH_CATCH(c)
 }
 
+static const int32_t *device_dof_map(mfh_ctx *c) {
+    if (c->dofForNode.empty()) return nullptr;
+    if (!c->dofUploaded) { c->dDofForNode.upload(c->dofForNode, c->stream); c->dofUploaded = true; }
+    return c->dDofForNode.p;
+}
+
 mfh_status mfh_constant_strain_load(mfh_ctx *c, const double *cstrain, double *out) {
     MFH_TRY(c)
     require(c && c->haveMesh && cstrain && out, MFH_ERR_STATE, "no mesh set");
-    const HostMesh &m = c->mesh;
-    const int d = m.dim, fl = flat_len(d);
-    const std::vector<double> &g = host_geo(c);
-    std::fill(out, out + (size_t)d * c->nDoF, 0.0);
-    double D[36], sd[6], cs[6], S[3][3];
-    for (int k2 = 0; k2 < fl; ++k2) sd[k2] = cstrain[k2] * (k2 < d ? 1.0 : 2.0);   // shearDoubled (ElasticityTensor.hh:437-441)
-    for (int64_t e = 0; e < m.nElem; ++e) {
-        const double *ge = &g[(size_t)e * c->geoStride];
-        elem_D(c, ge, D);
-        for (int r = 0; r < fl; ++r) { cs[r] = 0; for (int q = 0; q < fl; ++q) cs[r] += D[r * fl + q] * sd[q]; }
-        for (int a = 0; a < d; ++a)
-            for (int b = 0; b < d; ++b) S[a][b] = cs[a == b ? a : (fl - a - b)];
-        const double vol = ge[12];
-        for (int i = 0; i < m.npe; ++i) {   // l_i = cstress . int grad phi_i  (LinearElasticity.hh:157-160)
-            const double al = c->tables.intGrad[(size_t)i * 2] * vol, be = c->tables.intGrad[(size_t)i * 2 + 1] * vol;
-            const double *gs = ge + c->tables.sup_s[i] * d, *gt = ge + c->tables.sup_t[i] * d;
-            const int32_t dof = dof_of(c, m.elemNodes[(size_t)e * m.npe + i]);
-            for (int a = 0; a < d; ++a) {
-                double v = 0;
-                for (int b = 0; b < d; ++b) v += S[a][b] * (al * gs[b] + be * gt[b]);
-                out[(size_t)dof * d + a] += v;
-            }
-        }
-    }
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const int d = c->dim();
+    const int64_t n = (int64_t)d * c->nDoF;
+    double cs[6] = {0, 0, 0, 0, 0, 0};
+    for (int k2 = 0; k2 < flat_len(d); ++k2) cs[k2] = cstrain[k2];
+    c->wb.alloc(n);
+    c->wb.zero(c->stream);
+    k::launch_constant_strain_load(asm_args(c), c->dElemNodes.p, device_dof_map(c), c->tables.intGrad.data(), cs, c->wb.p, c->stream);
+    c->wb.download(out, (size_t)n, c->stream);
     MFH_CATCH(c)
 }
 
@@ -1143,38 +1139,17 @@ mfh_status mfh_sim_solve(mfh_ctx *c, const double *f, int32_t usePin, double *uN
 }
 
 static void average_strain_impl(mfh_ctx *c, const double *uNodes, double *out, bool stress) {
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
     const HostMesh &m = c->mesh;
     const int d = m.dim, fl = flat_len(d);
-    const std::vector<double> &g = host_geo(c);
-    double D[36];
-    for (int64_t e = 0; e < m.nElem; ++e) {
-        const double *ge = &g[(size_t)e * c->geoStride];
-        double eps[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        for (int i = 0; i < m.npe; ++i) {
-            // average of grad phi_i over the element = integral over unit volume
-            const double al = c->tables.intGrad[(size_t)i * 2], be = c->tables.intGrad[(size_t)i * 2 + 1];
-            const double *gs = ge + c->tables.sup_s[i] * d, *gt = ge + c->tables.sup_t[i] * d;
-            const double *ui = uNodes + (size_t)m.elemNodes[(size_t)e * m.npe + i] * d;
-            for (int a = 0; a < d; ++a)
-                for (int b = 0; b < d; ++b) {
-                    const double gb = al * gs[b] + be * gt[b], ga = al * gs[a] + be * gt[a];
-                    eps[a][b] += 0.5 * (ui[a] * gb + ui[b] * ga);   // LinearElasticity.hh:99-115
-                }
-        }
-        double ef[6];
-        for (int a = 0; a < d; ++a)
-            for (int b = a; b < d; ++b) ef[a == b ? a : (fl - a - b)] = eps[a][b];
-        if (!stress) {
-            for (int k2 = 0; k2 < fl; ++k2) out[(size_t)e * fl + k2] = ef[k2];
-        } else {
-            elem_D(c, ge, D);
-            for (int r = 0; r < fl; ++r) {
-                double v = 0;
-                for (int q = 0; q < fl; ++q) v += D[r * fl + q] * ef[q] * (q < d ? 1.0 : 2.0);
-                out[(size_t)e * fl + r] = v;
-            }
-        }
-    }
+    c->wx.alloc((size_t)m.nNode * d);
+    MFH_HIP(hipMemcpyAsync(c->wx.p, uNodes, (size_t)m.nNode * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    DBuf<double> res;
+    res.alloc((size_t)m.nElem * fl);
+    k::launch_average_strain(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), c->wx.p, res.p, stress ? 1 : 0, c->stream);
+    res.download(out, res.n, c->stream);
 }
 
 mfh_status mfh_average_strain(mfh_ctx *c, const double *uNodes, double *strain) {

@@ -207,6 +207,10 @@ void launch_geometry(int dim, int deg, int mat, int64_t nElem, const int32_t *el
 void launch_assemble_gather(const AsmArgs &a, hipStream_t s);
 void launch_assemble_atomic(const AsmArgs &a, hipStream_t s);
 void launch_element_stiffness(const AsmArgs &a, int64_t first, int64_t count, double *KeOut, hipStream_t s);
+void launch_constant_strain_load(const AsmArgs &a, const int32_t *elemNodes, const int32_t *dofForNode, const double *intGrad,
+                                 const double *cstrain, double *out, hipStream_t s);
+void launch_average_strain(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, double *out,
+                           int wantStress, hipStream_t s);
 
 struct SpmvArgs {
     int dim;

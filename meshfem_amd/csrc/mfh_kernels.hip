@@ -381,6 +381,123 @@ __global__ void __launch_bounds__(256) k_element_stiffness(AsmArgs a, int64_t fi
 }
 
 // ------------------------------------------------------------------------------------------------
+// K8: constantStrainLoad (LinearElasticity.hh:551-562, :135-162): l_i = (C_e : cstrain) . int grad phi_i,
+// one lane per (element, node); int grad phi_i = vol (al_i gl[s_i] + be_i gl[t_i]) with al/be the
+// integrals of the nodal coefficients (Interpolant::integrate, Functions.hh:246-253).
+// K10: per-element averaged strain / stress (LinearElasticity.hh:99-123, :528-549).
+// ------------------------------------------------------------------------------------------------
+template <int DIM, int MAT>
+DEV void elem_D_apply(const double *__restrict__ g, const double *sd /* shear-doubled flat strain */, double *out) {
+    constexpr int FL = DIM * (DIM + 1) / 2;
+    if (MAT == MAT_ISO) {
+        const double lam = g[13], mu = g[14];
+        double tr = 0;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) tr += sd[a];
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) out[a] = lam * tr + 2 * mu * sd[a];
+#pragma unroll
+        for (int k = DIM; k < FL; ++k) out[k] = mu * sd[k];
+    } else {
+#pragma unroll
+        for (int r = 0; r < FL; ++r) {
+            double v = 0;
+#pragma unroll
+            for (int c = 0; c < FL; ++c) v += g[13 + dpack<DIM>(r, c)] * sd[c];
+            out[r] = v;
+        }
+    }
+}
+
+struct LoadArgs {
+    int64_t nElem;
+    int npe, geoStride;
+    const double *geo;
+    const int32_t *elemNodes;
+    const int32_t *dofForNode;   // may be null
+    double intGrad[20];          // npe x {al, be}
+    double cstrain[6];           // flattened, TENSOR shear
+};
+
+template <int DIM, int DEG, int MAT>
+__global__ void __launch_bounds__(256) k_constant_strain_load(LoadArgs a, double *__restrict__ out) {
+    constexpr int FL = DIM * (DIM + 1) / 2;
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    const int64_t total = a.nElem * NPE;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        const int64_t e = k / NPE;
+        const int i = (int)(k - e * NPE);
+        const double *g = a.geo + e * a.geoStride;
+        double sd[FL], cs[FL];
+#pragma unroll
+        for (int q = 0; q < FL; ++q) sd[q] = a.cstrain[q] * (q < DIM ? 1.0 : 2.0);   // shearDoubled (ElasticityTensor.hh:437-441)
+        elem_D_apply<DIM, MAT>(g, sd, cs);
+        const int si = sup_s<DIM, DEG>(i), ti = sup_t<DIM, DEG>(i);
+        const double vol = g[12];
+        // runtime-indexed kernel-argument array: read through a select chain over the small table
+        double al = 0, be = 0;
+#pragma unroll
+        for (int q = 0; q < NPE; ++q) { al = (q == i) ? a.intGrad[2 * q] : al; be = (q == i) ? a.intGrad[2 * q + 1] : be; }
+        double gi[DIM];
+#pragma unroll
+        for (int b = 0; b < DIM; ++b) gi[b] = vol * (al * g[si * DIM + b] + be * g[ti * DIM + b]);
+        int64_t dof = a.elemNodes[e * NPE + i];
+        if (a.dofForNode) dof = a.dofForNode[dof];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            double v = 0;
+#pragma unroll
+            for (int b = 0; b < DIM; ++b) v += cs[flat_idx<DIM>(c, b)] * gi[b];
+            unsafeAtomicAdd(&out[dof * DIM + c], v);
+        }
+    }
+}
+
+template <int DIM, int DEG, int MAT>
+__global__ void __launch_bounds__(256) k_average_strain(LoadArgs a, const double *__restrict__ uNodes, double *__restrict__ out,
+                                                        int wantStress) {
+    constexpr int FL = DIM * (DIM + 1) / 2;
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.nElem; e += (int64_t)gridDim.x * 256) {
+        const double *g = a.geo + e * a.geoStride;
+        double eps[DIM][DIM];
+#pragma unroll
+        for (int x = 0; x < DIM; ++x)
+#pragma unroll
+            for (int y = 0; y < DIM; ++y) eps[x][y] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NPE; ++i) {
+            const int si = sup_s<DIM, DEG>(i), ti = sup_t<DIM, DEG>(i);
+            const double al = a.intGrad[2 * i], be = a.intGrad[2 * i + 1];
+            const int64_t node = a.elemNodes[e * NPE + i];
+            double gb[DIM], ui[DIM];
+#pragma unroll
+            for (int b = 0; b < DIM; ++b) { gb[b] = al * g[si * DIM + b] + be * g[ti * DIM + b]; ui[b] = uNodes[node * DIM + b]; }
+#pragma unroll
+            for (int x = 0; x < DIM; ++x)
+#pragma unroll
+                for (int y = 0; y < DIM; ++y) eps[x][y] += 0.5 * (ui[x] * gb[y] + ui[y] * gb[x]);   // LinearElasticity.hh:99-115
+        }
+        double ef[FL];
+#pragma unroll
+        for (int x = 0; x < DIM; ++x)
+#pragma unroll
+            for (int y = x; y < DIM; ++y) ef[flat_idx<DIM>(x, y)] = eps[x][y];
+        if (wantStress) {
+            double sd[FL], sg[FL];
+#pragma unroll
+            for (int q = 0; q < FL; ++q) sd[q] = ef[q] * (q < DIM ? 1.0 : 2.0);
+            elem_D_apply<DIM, MAT>(g, sd, sg);
+#pragma unroll
+            for (int q = 0; q < FL; ++q) out[e * FL + q] = sg[q];
+        } else {
+#pragma unroll
+            for (int q = 0; q < FL; ++q) out[e * FL + q] = ef[q];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Block-CSR SpMV over row chunks (persistent workgroups, grid-stride over chunks).
 // Phase 1: lane per block: coalesced loads of the NB components + column, gather x, block product
 //          -> LDS partials.  Phase 2: lane per scalar row sums its partials.
@@ -693,6 +810,35 @@ void launch_assemble_atomic(const AsmArgs &a, hipStream_t s) {
 void launch_element_stiffness(const AsmArgs &a, int64_t first, int64_t count, double *KeOut, hipStream_t s) {
     const int grid = grid_for(count * a.npe * a.npe);
 #define CALL(D, G, M) hipLaunchKernelGGL((k_element_stiffness<D, G, M>), dim3(grid), dim3(256), 0, s, a, first, count, KeOut)
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+    CHECK_LAUNCH();
+}
+
+static LoadArgs make_load_args(const AsmArgs &a, const int32_t *elemNodes, const int32_t *dofForNode, const double *intGrad,
+                               const double *cstrain) {
+    LoadArgs l{};
+    l.nElem = a.nElem; l.npe = a.npe; l.geoStride = a.geoStride; l.geo = a.geo; l.elemNodes = elemNodes; l.dofForNode = dofForNode;
+    for (int k = 0; k < 2 * a.npe; ++k) l.intGrad[k] = intGrad[k];
+    for (int k = 0; k < 6; ++k) l.cstrain[k] = cstrain ? cstrain[k] : 0.0;
+    return l;
+}
+
+void launch_constant_strain_load(const AsmArgs &a, const int32_t *elemNodes, const int32_t *dofForNode, const double *intGrad,
+                                 const double *cstrain, double *out, hipStream_t s) {
+    const LoadArgs l = make_load_args(a, elemNodes, dofForNode, intGrad, cstrain);
+    const int grid = grid_for(a.nElem * a.npe, 8192);
+#define CALL(D, G, M) hipLaunchKernelGGL((k_constant_strain_load<D, G, M>), dim3(grid), dim3(256), 0, s, l, out)
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+    CHECK_LAUNCH();
+}
+
+void launch_average_strain(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, double *out,
+                           int wantStress, hipStream_t s) {
+    const LoadArgs l = make_load_args(a, elemNodes, nullptr, intGrad, nullptr);
+    const int grid = grid_for(a.nElem, 8192);
+#define CALL(D, G, M) hipLaunchKernelGGL((k_average_strain<D, G, M>), dim3(grid), dim3(256), 0, s, l, uNodes, out, wantStress)
     MFH_DISPATCH(a, CALL);
 #undef CALL
     CHECK_LAUNCH();
