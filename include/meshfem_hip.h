@@ -52,7 +52,12 @@ enum {
 enum { MFH_NEUMANN_TRACTION = 0, MFH_NEUMANN_PRESSURE = 1, MFH_NEUMANN_FORCE = 2 };
 
 /* preconditioners */
-enum { MFH_PRECOND_BLOCK_JACOBI = 0, MFH_PRECOND_JACOBI = 1, MFH_PRECOND_NONE = 2 };
+enum {
+    MFH_PRECOND_BLOCK_JACOBI = 0, MFH_PRECOND_JACOBI = 1, MFH_PRECOND_NONE = 2,
+    /* block-Jacobi + additive coarse correction on per-aggregate rigid-body modes (falls back to
+     * block-Jacobi for periodic DoF maps / partitioned rows; see mfh_precond_info) */
+    MFH_PRECOND_TWO_LEVEL = 3
+};
 
 typedef struct mfh_solve_info {
     int32_t iterations;      /* PCG iterations of the last right-hand side          */
@@ -178,6 +183,8 @@ mfh_status mfh_element_stiffness(mfh_ctx* ctx, int64_t firstElem, int64_t count,
 mfh_status mfh_clear_fixed(mfh_ctx* ctx);
 mfh_status mfh_fix_variables(mfh_ctx* ctx, int64_t n, const int64_t* vars, const double* vals /* or NULL = 0 */);
 mfh_status mfh_set_preconditioner(mfh_ctx* ctx, int32_t kind);
+/* coarse-space facts of the last two-level setup: aggregates, coarse dimension, setup time (ms); note = why it fell back (or "") */
+mfh_status mfh_precond_info(const mfh_ctx* ctx, int32_t* nAggregates, int64_t* coarseDim, double* setup_ms, const char** note);
 mfh_status mfh_solve(mfh_ctx* ctx, int32_t nrhs, const double* f, double* u,
                      double rtol, int32_t maxit, mfh_solve_info* info);
 /* == Simulator::applyStiffnessMatrix (LinearElasticity.hh:801-823), using the assembled K       */
@@ -235,9 +242,13 @@ mfh_status mfh_time_assembly_kernel(mfh_ctx* ctx, int32_t mode, int32_t reps, do
 /* the same for one SpMV on internal scratch vectors */
 mfh_status mfh_time_spmv_kernel(mfh_ctx* ctx, int32_t reps, double* avg_ms);
 /* option knobs (string key, numeric value): "chunk_slots", "contrib_order" (0 rank-major, 1 element-major,
- * 2 slot-major), "check_every", "keep_host_symbolic", "reembed" (1: every mfh_assemble
+ * 2 slot-major), "check_every", "keep_host_symbolic", "agg_nodes" (target DoFs per aggregate of the two-level
+ * preconditioner), "reembed" (1: every mfh_assemble
  * re-runs the element-embedding kernel as well) */
 mfh_status mfh_set_option(mfh_ctx* ctx, const char* key, double value);
+/* test hook: in-place inverse of a dense SPD matrix (row-major n x n) with the threaded blocked
+ * Cholesky that inverts the two-level preconditioner's coarse operator; MFH_ERR_INVALID if not SPD */
+mfh_status mfh_debug_spd_inverse(int64_t n, double* A);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libmeshfem_hip.so")
 OK, ERR_INVALID, ERR_STATE, ERR_HIP, ERR_NOT_CONVERGED, ERR_UNSUPPORTED = range(6)
 ASSEMBLE_GATHER, ASSEMBLE_ATOMIC = 0, 1
 NEUMANN_TRACTION, NEUMANN_PRESSURE, NEUMANN_FORCE = 0, 1, 2
-PRECOND_BLOCK_JACOBI, PRECOND_JACOBI, PRECOND_NONE = 0, 1, 2
+PRECOND_BLOCK_JACOBI, PRECOND_JACOBI, PRECOND_NONE, PRECOND_TWO_LEVEL = 0, 1, 2, 3
 
 
 class SolveInfo(C.Structure):
@@ -71,6 +71,7 @@ PROTOTYPES = {
     "mfh_clear_fixed": (_i32, [_P]),
     "mfh_fix_variables": (_i32, [_P, _i64, _P, _P]),
     "mfh_set_preconditioner": (_i32, [_P, _i32]),
+    "mfh_precond_info": (_i32, [_P, _pi32, _pi64, C.POINTER(_f64), C.POINTER(C.c_char_p)]),
     "mfh_solve": (_i32, [_P, _i32, _P, _P, _f64, _i32, C.POINTER(SolveInfo)]),
     "mfh_apply_K": (_i32, [_P, _P, _P]),
     "mfh_bc_clear": (_i32, [_P]),
@@ -93,6 +94,7 @@ PROTOTYPES = {
     "mfh_time_assembly_kernel": (_i32, [_P, _i32, _i32, C.POINTER(_f64)]),
     "mfh_time_spmv_kernel": (_i32, [_P, _i32, C.POINTER(_f64)]),
     "mfh_set_option": (_i32, [_P, C.c_char_p, _f64]),
+    "mfh_debug_spd_inverse": (_i32, [_i64, _P]),
 }
 
 _lib = None

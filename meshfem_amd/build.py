@@ -6,7 +6,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmeshfem_hip.so")
-SOURCES = ["mfh_api.cpp", "mfh_mesh.cpp", "mfh_symbolic.cpp", "mfh_kernels.hip"]
+SOURCES = ["mfh_api.cpp", "mfh_mesh.cpp", "mfh_symbolic.cpp", "mfh_twolevel.cpp", "mfh_kernels.hip"]
+HOST_ONLY = ["mfh_twolevel.cpp"]
 HEADERS = ["mfh_internal.hh", os.path.join("..", "..", "include", "meshfem_hip.h")]
 
 
@@ -35,6 +36,8 @@ def build_lib(force=False, verbose=True):
     for s in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")
         cmd = [_hipcc()] + common + ["-c", os.path.join(CSRC, s), "-o", obj]
+        if s in HOST_ONLY:   # host code with dense inner loops: AVX2/FMA for the host pass only
+            cmd = [_hipcc()] + common + ["-Xarch_host", "-mavx2", "-Xarch_host", "-mfma", "-c", os.path.join(CSRC, s), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((subprocess.Popen(cmd), cmd))

@@ -215,6 +215,11 @@ class Context:
     def set_preconditioner(self, kind):
         self._ck(self.lib.mfh_set_preconditioner(self.h, int(kind)))
 
+    def precond_info(self):
+        a, m, t, note = C.c_int32(), C.c_int64(), C.c_double(), C.c_char_p()
+        self._ck(self.lib.mfh_precond_info(self.h, C.byref(a), C.byref(m), C.byref(t), C.byref(note)))
+        return dict(aggregates=a.value, coarse_dim=m.value, setup_ms=t.value, note=(note.value or b"").decode())
+
     def solve(self, f, rtol=1e-8, maxit=100000):
         f = as_f64(f)
         n = self.dim * self.n_dof

@@ -71,6 +71,17 @@ struct mfh_ctx {
     DBuf<double> dDinv;
     bool dinvValid = false;
     DBuf<double> wx, wr, wz, wp, wAp, wb, wf, wu0, scal, stop;
+    // two-level preconditioner (MFH_PRECOND_TWO_LEVEL)
+    struct TwoLevel {
+        bool valid = false;
+        int nModes = 0, nAgg = 0, nColor = 0;
+        int64_t m = 0;
+        double setup_ms = 0, H = 0;
+        DBuf<int32_t> aggOfDof, aggPtr, dofsByAgg, colorOfAgg, nbrOfColor;
+        DBuf<double> relPos, Ainv, rc, yc;
+    } tl;
+    int aggNodes = 0;                 // option "agg_nodes": target DoFs per aggregate (0 = auto)
+    std::string precondNote;
     int checkEvery = 50;
 
     // ---- Simulator-level boundary conditions
@@ -142,6 +153,7 @@ void require_device(const mfh_ctx *c) {
 void invalidate_matrix(mfh_ctx *c) {
     c->assembled = false;
     c->dinvValid = false;
+    c->tl.valid = false;
 }
 void invalidate_symbolic(mfh_ctx *c) {
     c->symValid = false;
@@ -162,6 +174,7 @@ void clear_fixed(mfh_ctx *c) {
     c->fixedUploaded = false;
     c->anyFixedNonzero = false;
     c->dinvValid = false;
+    c->tl.valid = false;
 }
 
 void upload_mesh(mfh_ctx *c) {
@@ -332,9 +345,117 @@ void ensure_precond(mfh_ctx *c) {
     if (c->dinvValid) return;
     const int d = c->dim();
     c->dDinv.alloc((size_t)c->sym.nRows * d * d);
-    k::launch_extract_diag_inv(d, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, c->dFixedMask.p, c->precond, c->dDinv.p,
-                               c->stream);
+    k::launch_extract_diag_inv(d, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, c->dFixedMask.p,
+                               c->precond == MFH_PRECOND_TWO_LEVEL ? MFH_PRECOND_BLOCK_JACOBI : c->precond, c->dDinv.p, c->stream);
     c->dinvValid = true;
+}
+
+k::TLArgs tl_args(mfh_ctx *c) {
+    k::TLArgs t{};
+    t.dim = c->dim(); t.nModes = c->tl.nModes; t.nAgg = c->tl.nAgg; t.nDoF = c->nDoF;
+    t.aggOfDof = c->tl.aggOfDof.p; t.relPos = c->tl.relPos.p; t.fixedMask = c->fixedVars.empty() ? nullptr : c->dFixedMask.p;
+    return t;
+}
+
+// Coarse space setup: aggregates, probing of Z^T K Z with 3^dim colours x nModes masked SpMVs, dense
+// inverse on the host. Returns false (and leaves block-Jacobi in charge) when the coarse space does
+// not apply: periodic DoF maps, partitioned rows, elements wider than an aggregate.
+bool ensure_twolevel(mfh_ctx *c) {
+    if (c->tl.valid) return true;
+    c->precondNote.clear();
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    if (!c->dofForNode.empty() || c->sym.nRows != c->sym.nCols) {
+        c->precondNote = "two-level preconditioner unavailable for periodic DoF maps / partitioned rows: using block-Jacobi";
+        return false;
+    }
+    double t0 = now_ms();
+    const int64_t nDoF = c->nDoF;
+    int target = c->aggNodes > 0 ? c->aggNodes : (int)std::max<int64_t>(512, nDoF / 1000);
+    Aggregates A;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        build_aggregates(d, nDoF, m.nodePos, target, A);
+        // K couples only DoFs of one element: every element must fit into adjacent bins
+        std::vector<uint8_t> bad((size_t)host_threads() + 1, 0);
+        parallel_ranges(m.nElem, [&](int64_t eb, int64_t ee, int tid) {
+            for (int64_t e = eb; e < ee; ++e) {
+                const int32_t *c0 = &A.binCoord[(size_t)A.aggOfDof[m.elemNodes[(size_t)e * m.npe]] * 3];
+                for (int k2 = 1; k2 < m.npe; ++k2) {
+                    const int32_t *c1 = &A.binCoord[(size_t)A.aggOfDof[m.elemNodes[(size_t)e * m.npe + k2]] * 3];
+                    if (std::abs(c0[0] - c1[0]) > 1 || std::abs(c0[1] - c1[1]) > 1 || std::abs(c0[2] - c1[2]) > 1) { bad[tid] = 1; return; }
+                }
+            }
+        });
+        bool ok = true;
+        for (uint8_t b : bad) ok &= !b;
+        if (ok) break;
+        target *= 4;
+        if (attempt == 5) { c->precondNote = "two-level preconditioner: elements span non-adjacent aggregates; using block-Jacobi"; return false; }
+    }
+    auto &T = c->tl;
+    T.nModes = d == 3 ? 6 : 3;
+    T.nAgg = A.nAgg; T.nColor = A.nColor; T.H = A.H;
+    T.m = (int64_t)T.nAgg * T.nModes;
+    std::vector<double> relPos((size_t)nDoF * 3, 0.0);
+    for (int64_t n = 0; n < nDoF; ++n)
+        for (int a = 0; a < d; ++a) relPos[(size_t)n * 3 + a] = (m.nodePos[(size_t)n * d + a] - A.centroid[(size_t)A.aggOfDof[n] * 3 + a]) / A.H;
+    hipStream_t s = c->stream;
+    T.aggOfDof.upload(A.aggOfDof, s); T.relPos.upload(relPos, s); T.aggPtr.upload(A.aggPtr, s); T.dofsByAgg.upload(A.dofsByAgg, s);
+    T.colorOfAgg.upload(A.colorOfAgg, s); T.nbrOfColor.upload(A.nbrOfColor, s);
+    T.rc.alloc((size_t)T.m); T.yc.alloc((size_t)T.m);
+    DBuf<double> Ac;
+    Ac.alloc((size_t)T.m * T.m);
+    Ac.zero(s);
+    const int64_t n = (int64_t)d * nDoF;
+    c->wx.alloc(n); c->wAp.alloc(n);
+    const k::TLArgs ta = tl_args(c);
+    const k::SpmvArgs sa = spmv_args(c, !c->fixedVars.empty());
+    for (int color = 0; color < T.nColor; ++color)
+        for (int mode = 0; mode < T.nModes; ++mode) {
+            k::launch_tl_fill(ta, T.colorOfAgg.p, color, mode, c->wx.p, s);
+            k::launch_spmv(sa, c->wx.p, c->wAp.p, nullptr, s);
+            k::launch_tl_restrict(ta, T.aggPtr.p, T.dofsByAgg.p, c->wAp.p, T.rc.p, s);
+            k::launch_tl_scatter(T.nAgg, T.nModes, T.nColor, T.nbrOfColor.p, color, mode, T.rc.p, Ac.p, s);
+        }
+    std::vector<double> hA((size_t)T.m * T.m);
+    Ac.download(hA.data(), hA.size(), s);
+    Ac.release();
+    const int64_t mm = T.m;
+    double maxd = 0;
+    for (int64_t i = 0; i < mm; ++i) maxd = std::max(maxd, hA[(size_t)i * mm + i]);
+    parallel_ranges(mm, [&](int64_t b, int64_t e, int) {   // symmetrise
+        for (int64_t i = b; i < e; ++i)
+            for (int64_t j = 0; j < i; ++j) {
+                const double v = 0.5 * (hA[(size_t)i * mm + j] + hA[(size_t)j * mm + i]);
+                hA[(size_t)i * mm + j] = v;
+            }
+    }, 64);
+    for (int64_t i = 0; i < mm; ++i)
+        for (int64_t j = 0; j < i; ++j) hA[(size_t)j * mm + i] = hA[(size_t)i * mm + j];
+    // modes without support (aggregate fully fixed, degenerate rotation): decouple them
+    for (int64_t i = 0; i < mm; ++i)
+        if (!(hA[(size_t)i * mm + i] > 1e-12 * maxd)) {
+            for (int64_t j = 0; j < mm; ++j) { hA[(size_t)i * mm + j] = 0; hA[(size_t)j * mm + i] = 0; }
+            hA[(size_t)i * mm + i] = maxd > 0 ? maxd : 1.0;
+        }
+    for (int64_t i = 0; i < mm; ++i) hA[(size_t)i * mm + i] *= 1.0 + 1e-10;
+    if (!spd_inverse_inplace(mm, hA.data())) {
+        c->precondNote = "two-level preconditioner: coarse operator not positive definite; using block-Jacobi";
+        return false;
+    }
+    T.Ainv.upload(hA, s);
+    T.setup_ms = now_ms() - t0;
+    T.valid = true;
+    return true;
+}
+
+// z = M^-1 r with the two-level preconditioner (restrict -> dense coarse solve -> prolong + block-Jacobi)
+void tl_precond(mfh_ctx *c, const double *r, double *z, double *scal, int it) {
+    const k::TLArgs ta = tl_args(c);
+    auto &T = c->tl;
+    k::launch_tl_restrict(ta, T.aggPtr.p, T.dofsByAgg.p, r, T.rc.p, c->stream);
+    k::launch_tl_gemv(T.m, T.Ainv.p, T.rc.p, T.yc.p, c->stream);
+    k::launch_tl_apply(ta, c->dDinv.p, r, T.yc.p, z, scal, it, c->stop.p, c->stream);
 }
 
 double device_dot(mfh_ctx *c, int64_t n, const double *a, const double *b) {
@@ -383,7 +504,13 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
         li.converged = 1;
     } else {
         EventTimer tsolve(s);
+        const bool useTL = c->precond == MFH_PRECOND_TWO_LEVEL && c->tl.valid;
         k::launch_pcg_init(d, c->sym.nRows, c->dDinv.p, c->wb.p, c->wx.p, c->wr.p, c->wz.p, c->wp.p, c->scal.p, s);
+        if (useTL) {   // replace z, p and r.z of the block-Jacobi initialisation
+            MFH_HIP(hipMemsetAsync(c->scal.p, 0, sizeof(double), s));
+            tl_precond(c, c->wr.p, c->wz.p, c->scal.p, -1);
+            MFH_HIP(hipMemcpyAsync(c->wp.p, c->wz.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
         const k::SpmvArgs sa = spmv_args(c, !c->fixedVars.empty());
         std::vector<double> hs;
         int it = 0;
@@ -393,8 +520,12 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
             const int itEnd = std::min(maxit, it + c->checkEvery);
             for (; it < itEnd; ++it) {
                 k::launch_pcg_spmv(sa, c->wp.p, c->wAp.p, c->scal.p, it, c->stop.p, s);
-                k::launch_pcg_update(d, c->sym.nRows, c->dDinv.p, c->wp.p, c->wAp.p, c->wx.p, c->wr.p, c->wz.p, c->scal.p, it,
-                                     c->stop.p, s);
+                if (useTL) {
+                    k::launch_pcg_update_noz(d, c->sym.nRows, c->wp.p, c->wAp.p, c->wx.p, c->wr.p, c->scal.p, it, c->stop.p, s);
+                    tl_precond(c, c->wr.p, c->wz.p, c->scal.p, it);
+                } else
+                    k::launch_pcg_update(d, c->sym.nRows, c->dDinv.p, c->wp.p, c->wAp.p, c->wx.p, c->wr.p, c->wz.p, c->scal.p, it,
+                                         c->stop.p, s);
                 k::launch_pcg_direction(n, c->wz.p, c->wp.p, c->scal.p, it, c->stop.p, s);
             }
             // scan the residual history of the iterations just enqueued
@@ -507,6 +638,7 @@ void add_fixed(mfh_ctx *c, int64_t n, const int64_t *vars, const double *vals) {
     }
     c->fixedUploaded = false;
     c->dinvValid = false;
+    c->tl.valid = false;
 }
 
 // element material tensor D (flatLen x flatLen) from the geometry record
@@ -920,9 +1052,18 @@ mfh_status mfh_fix_variables(mfh_ctx *c, int64_t n, const int64_t *vars, const d
 }
 
 mfh_status mfh_set_preconditioner(mfh_ctx *c, int32_t kind) {
-    if (!c || kind < 0 || kind > 2) return MFH_ERR_INVALID;
+    if (!c || kind < 0 || kind > 3) return MFH_ERR_INVALID;
     c->precond = kind;
     c->dinvValid = false;
+    return MFH_OK;
+}
+
+mfh_status mfh_precond_info(const mfh_ctx *c, int32_t *nAgg, int64_t *coarseDim, double *setup_ms, const char **note) {
+    if (!c) return MFH_ERR_INVALID;
+    if (nAgg) *nAgg = c->tl.valid ? c->tl.nAgg : 0;
+    if (coarseDim) *coarseDim = c->tl.valid ? c->tl.m : 0;
+    if (setup_ms) *setup_ms = c->tl.valid ? c->tl.setup_ms : 0.0;
+    if (note) *note = c->precondNote.c_str();
     return MFH_OK;
 }
 
@@ -932,6 +1073,7 @@ mfh_status mfh_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, doubl
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
+    if (c->precond == MFH_PRECOND_TWO_LEVEL) ensure_twolevel(c);
     const int64_t n = (int64_t)c->dim() * c->nDoF;
     bool allConverged = true;
     for (int k2 = 0; k2 < nrhs; ++k2) {
@@ -1116,8 +1258,10 @@ mfh_status mfh_sim_solve(mfh_ctx *c, const double *f, int32_t usePin, double *uN
         for (int a = 0; a < d; ++a) { vars.push_back((int64_t)d * dof_of(c, pn) + a); vals.push_back(0.0); }
     }
     dirichlet_vars(c, vars, vals);
-    clear_fixed(c);
-    add_fixed(c, (int64_t)vars.size(), vars.data(), vals.data());
+    if (vars != c->fixedVars || vals != c->fixedVals) {   // unchanged constraints keep the preconditioner setup
+        clear_fixed(c);
+        add_fixed(c, (int64_t)vars.size(), vars.data(), vals.data());
+    }
     std::vector<double> load;
     if (!f) {
         load.resize((size_t)n);
@@ -1129,6 +1273,7 @@ mfh_status mfh_sim_solve(mfh_ctx *c, const double *f, int32_t usePin, double *uN
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
+    if (c->precond == MFH_PRECOND_TWO_LEVEL) ensure_twolevel(c);
     mfh_solve_info li{};
     solve_one(c, f, x.data(), rtol, maxit, &li);
     if (info) *info = li;
@@ -1258,6 +1403,12 @@ mfh_status mfh_time_spmv_kernel(mfh_ctx *c, int32_t reps, double *avg_ms) {
     MFH_CATCH(c)
 }
 
+mfh_status mfh_debug_spd_inverse(int64_t n, double *A) {
+    try {
+        return spd_inverse_inplace(n, A) ? MFH_OK : MFH_ERR_INVALID;
+    } catch (...) { return MFH_ERR_INVALID; }
+}
+
 mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     MFH_TRY(c)
     require(c && key, MFH_ERR_INVALID, "null argument");
@@ -1267,6 +1418,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "check_every") { c->checkEvery = std::max(1, (int)value); }
     else if (k2 == "keep_host_symbolic") { c->keepHostSymbolic = value != 0; }
     else if (k2 == "reembed") { c->alwaysReembed = value != 0; }
+    else if (k2 == "agg_nodes") { c->aggNodes = (int)value; c->tl.valid = false; }
     else if (k2 == "debug_variant") { c->debugVariant = (int)value; invalidate_matrix(c); }
     else throw Error(MFH_ERR_INVALID, "unknown option " + k2);
     MFH_CATCH(c)

@@ -171,6 +171,24 @@ struct ShapeTables {
 };
 void build_shape_tables(int dim, int deg, ShapeTables &T);
 
+// ------------------------------------------------------------------------------------------------
+// Two-level preconditioner (mfh_twolevel.cpp)
+// ------------------------------------------------------------------------------------------------
+struct Aggregates {
+    int dim = 0, nAgg = 0, nColor = 0;
+    double H = 0;                        // bin edge (rotation modes are scaled by 1/H)
+    bool binsTooFew = false;
+    std::vector<int32_t> aggOfDof;       // nDoF
+    std::vector<double> centroid;        // nAgg x 3
+    std::vector<int32_t> aggPtr;         // nAgg+1
+    std::vector<int32_t> dofsByAgg;      // nDoF, grouped by aggregate
+    std::vector<int32_t> colorOfAgg;     // nAgg
+    std::vector<int32_t> binCoord;       // nAgg x 3 lattice coordinates
+    std::vector<int32_t> nbrOfColor;     // nAgg x nColor: the neighbour (or self) of that colour, -1 if none
+};
+void build_aggregates(int dim, int64_t nDoF, const std::vector<double> &dofPos, int targetNodes, Aggregates &A);
+bool spd_inverse_inplace(int64_t n, double *A);
+
 } // namespace mfh
 
 // ------------------------------------------------------------------------------------------------
@@ -241,6 +259,23 @@ void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double 
                        double *r, double *z, double *scal, int it, const double *stopPtr, hipStream_t s);
 void launch_pcg_direction(int64_t n, const double *z, double *p, const double *scal, int it, const double *stopPtr,
                           hipStream_t s);
+
+struct TLArgs {
+    int dim, nModes, nAgg;
+    int64_t nDoF;
+    const int32_t *aggOfDof;      // nDoF
+    const double *relPos;         // nDoF x 3: (position - aggregate centroid) / H
+    const uint8_t *fixedMask;     // per scalar variable, may be null
+};
+void launch_pcg_update_noz(int dim, int64_t nRows, const double *p, const double *Ap, double *x, double *r, double *scal, int it,
+                           const double *stopPtr, hipStream_t s);
+void launch_tl_fill(const TLArgs &t, const int32_t *colorOfAgg, int color, int mode, double *v, hipStream_t s);
+void launch_tl_restrict(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const double *w, double *rc, hipStream_t s);
+void launch_tl_scatter(int nAgg, int nModes, int nColor, const int32_t *nbrOfColor, int color, int mode, const double *R, double *Ac,
+                       hipStream_t s);
+void launch_tl_gemv(int64_t m, const double *A, const double *x, double *y, hipStream_t s);
+void launch_tl_apply(const TLArgs &t, const double *dinv, const double *r, const double *yc, double *z, double *scal, int it,
+                     const double *stopPtr, hipStream_t s);
 
 void launch_axpby(int64_t n, double a, const double *x, double b, double *y, hipStream_t s); // y = a x + b y
 void launch_mask(int64_t n, const uint8_t *mask, double *v, hipStream_t s);                   // v[mask]=0

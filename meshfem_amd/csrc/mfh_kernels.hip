@@ -641,6 +641,126 @@ __global__ void __launch_bounds__(256) k_precond(int64_t nRows, const double *__
 }
 
 // ------------------------------------------------------------------------------------------------
+// Two-level preconditioner  M^-1 = D^-1 + Z (Z^T K Z)^-1 Z^T  (mfh_twolevel.cpp): Z = rigid-body
+// modes of every aggregate (translations, and rotations about the aggregate centroid scaled by 1/H),
+// zero on fixed variables. Z is never stored: a mode's value at a DoF follows from its relative position.
+// ------------------------------------------------------------------------------------------------
+template <int DIM> DEV double tl_mode(int k, int c, const double *rp) {
+    if (k < DIM) return k == c ? 1.0 : 0.0;
+    if (DIM == 2) return c == 0 ? -rp[1] : rp[0];
+    const int ax = k - 3;                 // rotation about axis ax: u = e_ax x rp
+    const int c1 = (ax + 1) % 3, c2 = (ax + 2) % 3;
+    return c == c1 ? -rp[c2] : (c == c2 ? rp[c1] : 0.0);
+}
+
+// probing vector: sum over the aggregates of one colour of their mode `mode`
+template <int DIM>
+__global__ void __launch_bounds__(256) k_tl_fill(TLArgs t, const int32_t *__restrict__ colorOfAgg, int color, int mode, double *__restrict__ v) {
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < t.nDoF; n += (int64_t)gridDim.x * 256) {
+        const int a = t.aggOfDof[n];
+        const bool on = colorOfAgg[a] == color;
+        double rp[3] = {t.relPos[n * 3], t.relPos[n * 3 + 1], t.relPos[n * 3 + 2]};
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            const bool fixed = t.fixedMask && t.fixedMask[n * DIM + c];
+            v[n * DIM + c] = (on && !fixed) ? tl_mode<DIM>(mode, c, rp) : 0.0;
+        }
+    }
+}
+
+// rc[a*nModes + k] = sum_{DoFs n of aggregate a} z_{a,k}(n) . w(n); one workgroup per aggregate
+template <int DIM>
+__global__ void __launch_bounds__(256) k_tl_restrict(TLArgs t, const int32_t *__restrict__ aggPtr, const int32_t *__restrict__ dofsByAgg,
+                                                     const double *__restrict__ w, double *__restrict__ rc) {
+    __shared__ double red[4 * 6];
+    const int a = blockIdx.x;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = aggPtr[a] + threadIdx.x; q < aggPtr[a + 1]; q += 256) {
+        const int64_t n = dofsByAgg[q];
+        double rp[3] = {t.relPos[n * 3], t.relPos[n * 3 + 1], t.relPos[n * 3 + 2]};
+        double wv[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) wv[c] = (t.fixedMask && t.fixedMask[n * DIM + c]) ? 0.0 : w[n * DIM + c];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (k >= t.nModes) break;
+            double s = 0;
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) s += tl_mode<DIM>(k, c, rp) * wv[c];
+            acc[k] += s;
+        }
+    }
+    const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) red[wv_ * 6 + k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < t.nModes) rc[a * t.nModes + threadIdx.x] = red[threadIdx.x] + red[6 + threadIdx.x] + red[12 + threadIdx.x] + red[18 + threadIdx.x];
+}
+
+// coarse operator entries from one probe: Ac[(b,l), (nbr(b,colour), mode)] = R[(b,l)]
+__global__ void __launch_bounds__(256) k_tl_scatter(int nAgg, int nModes, int nColor, const int32_t *__restrict__ nbrOfColor, int color,
+                                                    int mode, const double *__restrict__ R, double *__restrict__ Ac) {
+    const int64_t m = (int64_t)nAgg * nModes;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < m; k += (int64_t)gridDim.x * 256) {
+        const int b = (int)(k / nModes);
+        const int a = nbrOfColor[(int64_t)b * nColor + color];
+        if (a >= 0) Ac[k * m + (int64_t)a * nModes + mode] = R[k];
+    }
+}
+
+// y = A x for the dense coarse inverse (row-major m x m); one workgroup per row
+__global__ void __launch_bounds__(256) k_tl_gemv(int64_t m, const double *__restrict__ A, const double *__restrict__ x, double *__restrict__ y) {
+    __shared__ double red[8];
+    const int64_t row = blockIdx.x;
+    double acc[1] = {0};
+    for (int64_t j = threadIdx.x; j < m; j += 256) acc[0] += A[row * m + j] * x[j];
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) y[row] = acc[0];
+}
+
+// z = D^-1 r + Z yc ; optionally accumulates r.z into *rzOut
+template <int DIM>
+__global__ void __launch_bounds__(256) k_tl_apply(TLArgs t, const double *__restrict__ dinv, const double *__restrict__ r,
+                                                  const double *__restrict__ yc, double *__restrict__ z, double *scal, int it,
+                                                  const double *stopPtr) {
+    __shared__ double red[8];
+    double *rzOut = nullptr;
+    if (scal) {
+        if (it >= 0 && scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
+        rzOut = scal + (int64_t)(it + 1) * 4;
+    }
+    double acc[1] = {0};
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < t.nDoF; n += (int64_t)gridDim.x * 256) {
+        double rv[DIM], zv[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) rv[c] = r[n * DIM + c];
+        apply_block<DIM>(dinv + n * DIM * DIM, rv, zv);
+        const int a = t.aggOfDof[n];
+        double rp[3] = {t.relPos[n * 3], t.relPos[n * 3 + 1], t.relPos[n * 3 + 2]};
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (k >= t.nModes) break;
+            const double y = yc[(int64_t)a * t.nModes + k];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) zv[c] += y * tl_mode<DIM>(k, c, rp);
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            if (t.fixedMask && t.fixedMask[n * DIM + c]) zv[c] = rv[c];   // identity on fixed variables (r is 0 there)
+            z[n * DIM + c] = zv[c];
+            acc[0] += rv[c] * zv[c];
+        }
+    }
+    if (rzOut) {
+        block_sum<1>(acc, red);
+        if (threadIdx.x == 0) unsafeAtomicAdd(rzOut, acc[0]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // PCG vector kernels. scal[it*4 + {0: r.z, 1: p.Ap, 2: r.r}] hold the reductions of iteration `it`
 // (array zero-filled once per solve; nothing is reset inside the loop).
 // ------------------------------------------------------------------------------------------------
@@ -666,7 +786,7 @@ __global__ void __launch_bounds__(256) k_pcg_init(int64_t nRows, const double *_
 }
 
 // x += alpha p ; r -= alpha Ap ; z = Dinv r ; scal[it+1].{rz,rr} += ...
-template <int DIM>
+template <int DIM, bool SKIPZ = false>
 __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ p,
                                                     const double *__restrict__ Ap, double *__restrict__ x, double *__restrict__ r,
                                                     double *__restrict__ z, double *scal, int it, const double *stopPtr) {
@@ -683,13 +803,17 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
             rv[c] = r[g] - alpha * Ap[g];
             r[g] = rv[c];
         }
-        apply_block<DIM>(dinv + n * DIM * DIM, rv, zv);
+        if (!SKIPZ) {
+            apply_block<DIM>(dinv + n * DIM * DIM, rv, zv);
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) { z[n * DIM + c] = zv[c]; acc[0] += rv[c] * zv[c]; acc[1] += rv[c] * rv[c]; }
+            for (int c = 0; c < DIM; ++c) { z[n * DIM + c] = zv[c]; acc[0] += rv[c] * zv[c]; }
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) acc[1] += rv[c] * rv[c];
     }
     block_sum<2>(acc, red);
     if (threadIdx.x == 0) {
-        unsafeAtomicAdd(&scal[(int64_t)(it + 1) * 4 + 0], acc[0]);
+        if (!SKIPZ) unsafeAtomicAdd(&scal[(int64_t)(it + 1) * 4 + 0], acc[0]);
         unsafeAtomicAdd(&scal[(int64_t)(it + 1) * 4 + 2], acc[1]);
     }
 }
@@ -891,8 +1015,41 @@ void launch_pcg_init(int dim, int64_t nRows, const double *dinv, const double *b
 
 void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double *p, const double *Ap, double *x, double *r,
                        double *z, double *scal, int it, const double *stopPtr, hipStream_t s) {
-    if (dim == 3) hipLaunchKernelGGL(k_pcg_update<3>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
-    else hipLaunchKernelGGL(k_pcg_update<2>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
+    if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
+    else hipLaunchKernelGGL((k_pcg_update<2, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
+    CHECK_LAUNCH();
+}
+
+void launch_pcg_update_noz(int dim, int64_t nRows, const double *p, const double *Ap, double *x, double *r, double *scal, int it,
+                           const double *stopPtr, hipStream_t s) {
+    if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, true>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, (const double *)nullptr, p, Ap, x, r, (double *)nullptr, scal, it, stopPtr);
+    else hipLaunchKernelGGL((k_pcg_update<2, true>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, (const double *)nullptr, p, Ap, x, r, (double *)nullptr, scal, it, stopPtr);
+    CHECK_LAUNCH();
+}
+
+void launch_tl_fill(const TLArgs &t, const int32_t *colorOfAgg, int color, int mode, double *v, hipStream_t s) {
+    if (t.dim == 3) hipLaunchKernelGGL(k_tl_fill<3>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, colorOfAgg, color, mode, v);
+    else hipLaunchKernelGGL(k_tl_fill<2>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, colorOfAgg, color, mode, v);
+    CHECK_LAUNCH();
+}
+void launch_tl_restrict(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const double *w, double *rc, hipStream_t s) {
+    if (t.dim == 3) hipLaunchKernelGGL(k_tl_restrict<3>, dim3(t.nAgg), dim3(256), 0, s, t, aggPtr, dofsByAgg, w, rc);
+    else hipLaunchKernelGGL(k_tl_restrict<2>, dim3(t.nAgg), dim3(256), 0, s, t, aggPtr, dofsByAgg, w, rc);
+    CHECK_LAUNCH();
+}
+void launch_tl_scatter(int nAgg, int nModes, int nColor, const int32_t *nbrOfColor, int color, int mode, const double *R, double *Ac,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_tl_scatter, dim3(grid_for((int64_t)nAgg * nModes)), dim3(256), 0, s, nAgg, nModes, nColor, nbrOfColor, color, mode, R, Ac);
+    CHECK_LAUNCH();
+}
+void launch_tl_gemv(int64_t m, const double *A, const double *x, double *y, hipStream_t s) {
+    hipLaunchKernelGGL(k_tl_gemv, dim3((unsigned)m), dim3(256), 0, s, m, A, x, y);
+    CHECK_LAUNCH();
+}
+void launch_tl_apply(const TLArgs &t, const double *dinv, const double *r, const double *yc, double *z, double *scal, int it,
+                     const double *stopPtr, hipStream_t s) {
+    if (t.dim == 3) hipLaunchKernelGGL(k_tl_apply<3>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr);
+    else hipLaunchKernelGGL(k_tl_apply<2>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr);
     CHECK_LAUNCH();
 }
 

@@ -448,3 +448,62 @@ def test_config2_full_size_properties():
     assert np.linalg.norm(r[~fixed]) < 2e-8 * np.linalg.norm(f)
     # K annihilates translations, so the unbalanced force on the clamped face equals the total load
     assert abs(r[fixed].reshape(-1, 3)[:, 1].sum() - f[:, 1].sum()) < 1e-6 * abs(f[:, 1].sum())
+
+
+# ------------------------------------------------------------------------------------------------
+# two-level preconditioner (block-Jacobi + rigid-body-mode coarse space)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("deg,dims,agg", [(1, (24, 6, 6), 250), (2, (12, 4, 4), 120)])
+def test_two_level_preconditioner_matches_direct_solve(deg, dims, agg):
+    V, T = grid.grid_tet_mesh(*dims)
+    c = _ctx()
+    c.mesh_build(T, V, deg)
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-4] * 3, [1e-4, 1.0001, 1.0001], [0, 0.01, 0], relative=True)     # non-zero Dirichlet data
+    c.bc_neumann_box([0.9999, -1e-4, -1e-4], [1.0001, 1.0001, 1.0001], [0, -10, 0], kind=M.NEUMANN_FORCE, relative=True)
+    u_bj = c.sim_solve(rtol=1e-10)
+    it_bj = c.last_info["iterations"]
+    c.set_preconditioner(M.PRECOND_TWO_LEVEL)
+    c.set_option("agg_nodes", agg)
+    u = c.sim_solve(rtol=1e-10)
+    info, pinfo = dict(c.last_info), c.precond_info()
+    assert info["converged"] == 1 and info["true_rel_residual"] < 1e-9
+    assert pinfo["aggregates"] > 8 and pinfo["coarse_dim"] == 6 * pinfo["aggregates"] and pinfo["note"] == ""
+    assert info["iterations"] < 0.6 * it_bj, (info["iterations"], it_bj)       # the coarse space must pay off
+    sim = O.Simulator(T, V, deg)
+    sim.set_material_constant(_iso())
+    mn, mx = sim.box_percent([-1e-4] * 3, [1e-4, 1.0001, 1.0001]); sim.apply_dirichlet_box(mn, mx, [0, 0.01, 0])
+    mn, mx = sim.box_percent([0.9999, -1e-4, -1e-4], [1.0001, 1.0001, 1.0001]); sim.apply_neumann_box(mn, mx, [0, -10, 0], "force")
+    u_ref = sim.solve()
+    assert np.linalg.norm(u - u_ref) / np.linalg.norm(u_ref) < U_RTOL
+    assert np.linalg.norm(u_bj - u_ref) / np.linalg.norm(u_ref) < U_RTOL
+    # a second solve with unchanged constraints reuses the coarse setup
+    t0 = c.precond_info()["setup_ms"]
+    c.sim_solve(rtol=1e-10)
+    assert c.precond_info()["setup_ms"] == t0
+
+
+def test_two_level_falls_back_for_periodic_and_2d_works():
+    V, T = _porous_cell(4)
+    c = _ctx()
+    c.mesh_build(T, V, 1)
+    c.material_isotropic(1.0, 0.3)
+    c.apply_periodic_conditions()
+    c.set_preconditioner(M.PRECOND_TWO_LEVEL)
+    rhs = c.constant_strain_load([-1.0, 0, 0, 0, 0, 0])
+    w = c.sim_solve(rhs.ravel(), use_pin=True, rtol=1e-9)
+    assert "block-Jacobi" in c.precond_info()["note"] and c.last_info["converged"] == 1 and np.isfinite(w).all()
+    V2, T2 = grid.grid_tri_mesh(24, 6, [0, 0], [4, 1])
+    c2 = _ctx()
+    c2.mesh_build(T2, V2, 2)
+    c2.material_isotropic(200.0, 0.35)
+    c2.bc_dirichlet_box([-1e-9, -9], [1e-9, 9], [0, 0])
+    c2.bc_neumann_box([4 - 1e-9, -9], [4 + 1e-9, 9], [0, -1.0])
+    u_bj = c2.sim_solve(rtol=1e-11)
+    it_bj = c2.last_info["iterations"]
+    c2.set_preconditioner(M.PRECOND_TWO_LEVEL)
+    c2.set_option("agg_nodes", 60)
+    u = c2.sim_solve(rtol=1e-11)
+    assert c2.precond_info()["coarse_dim"] == 3 * c2.precond_info()["aggregates"] > 0
+    assert c2.last_info["iterations"] < it_bj
+    assert np.linalg.norm(u - u_bj) / np.linalg.norm(u_bj) < 1e-7
