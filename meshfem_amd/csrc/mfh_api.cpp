@@ -81,6 +81,7 @@ struct mfh_ctx {
         DBuf<double> relPos, Ainv, rc, yc;
     } tl;
     int aggNodes = 0;                 // option "agg_nodes": target DoFs per aggregate (0 = auto)
+    bool tlProbe = false;             // option "tl_probe": build the coarse operator by SpMV probing (validation)
     std::string precondNote;
     int checkEvery = 50;
 
@@ -371,7 +372,8 @@ bool ensure_twolevel(mfh_ctx *c) {
     }
     double t0 = now_ms();
     const int64_t nDoF = c->nDoF;
-    int target = c->aggNodes > 0 ? c->aggNodes : (int)std::max<int64_t>(512, nDoF / 1000);
+    // default: ~500 aggregates (coarse dimension ~3000): the host-side dense inverse is O(m^3)
+    int target = c->aggNodes > 0 ? c->aggNodes : (int)std::max<int64_t>(512, nDoF / 500);
     Aggregates A;
     for (int attempt = 0; attempt < 6; ++attempt) {
         build_aggregates(d, nDoF, m.nodePos, target, A);
@@ -388,6 +390,7 @@ bool ensure_twolevel(mfh_ctx *c) {
         });
         bool ok = true;
         for (uint8_t b : bad) ok &= !b;
+        if (!c->tlProbe) ok = true;   // the Galerkin kernel handles any aggregate pair; only probing needs adjacency
         if (ok) break;
         target *= 4;
         if (attempt == 5) { c->precondNote = "two-level preconditioner: elements span non-adjacent aggregates; using block-Jacobi"; return false; }
@@ -407,20 +410,32 @@ bool ensure_twolevel(mfh_ctx *c) {
     Ac.alloc((size_t)T.m * T.m);
     Ac.zero(s);
     const int64_t n = (int64_t)d * nDoF;
-    c->wx.alloc(n); c->wAp.alloc(n);
     const k::TLArgs ta = tl_args(c);
-    const k::SpmvArgs sa = spmv_args(c, !c->fixedVars.empty());
-    for (int color = 0; color < T.nColor; ++color)
-        for (int mode = 0; mode < T.nModes; ++mode) {
-            k::launch_tl_fill(ta, T.colorOfAgg.p, color, mode, c->wx.p, s);
-            k::launch_spmv(sa, c->wx.p, c->wAp.p, nullptr, s);
-            k::launch_tl_restrict(ta, T.aggPtr.p, T.dofsByAgg.p, c->wAp.p, T.rc.p, s);
-            k::launch_tl_scatter(T.nAgg, T.nModes, T.nColor, T.nbrOfColor.p, color, mode, T.rc.p, Ac.p, s);
-        }
+    if (c->tlProbe) {   // reference construction: probe Z^T K Z with 3^dim colours x nModes masked SpMVs
+        c->wx.alloc(n); c->wAp.alloc(n);
+        const k::SpmvArgs sa = spmv_args(c, !c->fixedVars.empty());
+        for (int color = 0; color < T.nColor; ++color)
+            for (int mode = 0; mode < T.nModes; ++mode) {
+                k::launch_tl_fill(ta, T.colorOfAgg.p, color, mode, c->wx.p, s);
+                k::launch_spmv(sa, c->wx.p, c->wAp.p, nullptr, s);
+                k::launch_tl_restrict(ta, T.aggPtr.p, T.dofsByAgg.p, c->wAp.p, T.rc.p, s);
+                k::launch_tl_scatter(T.nAgg, T.nModes, T.nColor, T.nbrOfColor.p, color, mode, T.rc.p, Ac.p, s);
+            }
+    } else {            // one Galerkin pass over the assembled K
+        k::launch_tl_rap(ta, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac.p, s);
+    }
     std::vector<double> hA((size_t)T.m * T.m);
     Ac.download(hA.data(), hA.size(), s);
     Ac.release();
     const int64_t mm = T.m;
+    if (const char *dump = getenv("MFH_DEBUG_DUMP_AC")) {   // debugging aid: raw coarse operator + aggregates
+        FILE *f = fopen(dump, "wb");
+        if (f) { fwrite(hA.data(), sizeof(double), hA.size(), f); fclose(f); }
+        f = fopen((std::string(dump) + ".agg").c_str(), "wb");
+        if (f) { fwrite(A.aggOfDof.data(), sizeof(int32_t), A.aggOfDof.size(), f); fclose(f); }
+        f = fopen((std::string(dump) + ".relpos").c_str(), "wb");
+        if (f) { fwrite(relPos.data(), sizeof(double), relPos.size(), f); fclose(f); }
+    }
     double maxd = 0;
     for (int64_t i = 0; i < mm; ++i) maxd = std::max(maxd, hA[(size_t)i * mm + i]);
     parallel_ranges(mm, [&](int64_t b, int64_t e, int) {   // symmetrise
@@ -1419,6 +1434,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "keep_host_symbolic") { c->keepHostSymbolic = value != 0; }
     else if (k2 == "reembed") { c->alwaysReembed = value != 0; }
     else if (k2 == "agg_nodes") { c->aggNodes = (int)value; c->tl.valid = false; }
+    else if (k2 == "tl_probe") { c->tlProbe = value != 0; c->tl.valid = false; }
     else if (k2 == "debug_variant") { c->debugVariant = (int)value; invalidate_matrix(c); }
     else throw Error(MFH_ERR_INVALID, "unknown option " + k2);
     MFH_CATCH(c)

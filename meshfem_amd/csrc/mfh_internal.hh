@@ -273,6 +273,8 @@ void launch_tl_fill(const TLArgs &t, const int32_t *colorOfAgg, int color, int m
 void launch_tl_restrict(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const double *w, double *rc, hipStream_t s);
 void launch_tl_scatter(int nAgg, int nModes, int nColor, const int32_t *nbrOfColor, int color, int mode, const double *R, double *Ac,
                        hipStream_t s);
+void launch_tl_rap(const TLArgs &t, int64_t nRows, const int32_t *rowPtr, const int32_t *colIdx, const double *vals, double *Ac,
+                   hipStream_t s);
 void launch_tl_gemv(int64_t m, const double *A, const double *x, double *y, hipStream_t s);
 void launch_tl_apply(const TLArgs &t, const double *dinv, const double *r, const double *yc, double *z, double *scal, int it,
                      const double *stopPtr, hipStream_t s);

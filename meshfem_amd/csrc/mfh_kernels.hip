@@ -646,11 +646,13 @@ __global__ void __launch_bounds__(256) k_precond(int64_t nRows, const double *__
 // zero on fixed variables. Z is never stored: a mode's value at a DoF follows from its relative position.
 // ------------------------------------------------------------------------------------------------
 template <int DIM> DEV double tl_mode(int k, int c, const double *rp) {
+    const double rx = rp[0], ry = rp[1], rz = rp[2];
     if (k < DIM) return k == c ? 1.0 : 0.0;
-    if (DIM == 2) return c == 0 ? -rp[1] : rp[0];
-    const int ax = k - 3;                 // rotation about axis ax: u = e_ax x rp
-    const int c1 = (ax + 1) % 3, c2 = (ax + 2) % 3;
-    return c == c1 ? -rp[c2] : (c == c2 ? rp[c1] : 0.0);
+    if (DIM == 2) return c == 0 ? -ry : rx;
+    // rotation about axis k-3: u = e_axis x r
+    if (k == 3) return c == 1 ? -rz : (c == 2 ? ry : 0.0);
+    if (k == 4) return c == 0 ? rz : (c == 2 ? -rx : 0.0);
+    return c == 0 ? -ry : (c == 1 ? rx : 0.0);
 }
 
 // probing vector: sum over the aggregates of one colour of their mode `mode`
@@ -708,6 +710,78 @@ __global__ void __launch_bounds__(256) k_tl_scatter(int nAgg, int nModes, int nC
         const int b = (int)(k / nModes);
         const int a = nbrOfColor[(int64_t)b * nColor + color];
         if (a >= 0) Ac[k * m + (int64_t)a * nModes + mode] = R[k];
+    }
+}
+
+// Coarse operator in ONE pass over the assembled K (Galerkin product Z^T K Z): one wave per block
+// row; a lane takes a block K_rc, forms T[k][l] = z_k(r)^T K_rc z_l(c) for the modes of the two
+// aggregates and adds it to Ac[(agg r, k), (agg c, l)]. Blocks inside one aggregate (the vast
+// majority) are summed across the wave first, so only one set of atomics per row reaches memory.
+// Replaces 3^dim * nModes probing SpMVs (162 in 3D).
+template <int DIM>
+__global__ void __launch_bounds__(256) k_tl_rap(TLArgs t, int64_t nRows, const int32_t *__restrict__ rowPtr, const int32_t *__restrict__ colIdx,
+                                                const double *__restrict__ vals, double *__restrict__ Ac) {
+    constexpr int NB = DIM * DIM;
+    constexpr int NM = DIM == 3 ? 6 : 3;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nWaves = ((int64_t)gridDim.x * 256) >> 6;
+    const int64_t m = (int64_t)t.nAgg * NM;
+    for (int64_t r = wave; r < nRows; r += nWaves) {
+        const int a = t.aggOfDof[r];
+        const double rpr[3] = {t.relPos[r * 3], t.relPos[r * 3 + 1], t.relPos[r * 3 + 2]};
+        double zr[NM][DIM];
+#pragma unroll
+        for (int k = 0; k < NM; ++k)
+#pragma unroll
+            for (int x = 0; x < DIM; ++x) zr[k][x] = (t.fixedMask && t.fixedMask[r * DIM + x]) ? 0.0 : tl_mode<DIM>(k, x, rpr);
+        double acc[NM * NM];
+#pragma unroll
+        for (int q = 0; q < NM * NM; ++q) acc[q] = 0.0;
+        for (int s = rowPtr[r] + lane; s < rowPtr[r + 1]; s += 64) {
+            const int64_t c = colIdx[s];
+            const int b = t.aggOfDof[c];
+            const double rpc[3] = {t.relPos[c * 3], t.relPos[c * 3 + 1], t.relPos[c * 3 + 2]};
+            double K[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) K[q] = vals[tiled_index(s, q, NB)];
+            double T[NM * NM];
+#pragma unroll
+            for (int l = 0; l < NM; ++l) {
+                double zc[DIM], w[DIM];
+#pragma unroll
+                for (int y = 0; y < DIM; ++y) zc[y] = (t.fixedMask && t.fixedMask[c * DIM + y]) ? 0.0 : tl_mode<DIM>(l, y, rpc);
+#pragma unroll
+                for (int x = 0; x < DIM; ++x) {
+                    double v = 0;
+#pragma unroll
+                    for (int y = 0; y < DIM; ++y) v += K[x * DIM + y] * zc[y];
+                    w[x] = v;
+                }
+#pragma unroll
+                for (int k = 0; k < NM; ++k) {
+                    double v = 0;
+#pragma unroll
+                    for (int x = 0; x < DIM; ++x) v += zr[k][x] * w[x];
+                    T[k * NM + l] = v;
+                }
+            }
+            if (b == a) {
+#pragma unroll
+                for (int q = 0; q < NM * NM; ++q) acc[q] += T[q];
+            } else {
+#pragma unroll
+                for (int k = 0; k < NM; ++k)
+#pragma unroll
+                    for (int l = 0; l < NM; ++l) unsafeAtomicAdd(&Ac[((int64_t)a * NM + k) * m + (int64_t)b * NM + l], T[k * NM + l]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < NM * NM; ++q) acc[q] = wave_sum(acc[q]);
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < NM; ++k)
+#pragma unroll
+                for (int l = 0; l < NM; ++l) unsafeAtomicAdd(&Ac[((int64_t)a * NM + k) * m + (int64_t)a * NM + l], acc[k * NM + l]);
     }
 }
 
@@ -1040,6 +1114,13 @@ void launch_tl_restrict(const TLArgs &t, const int32_t *aggPtr, const int32_t *d
 void launch_tl_scatter(int nAgg, int nModes, int nColor, const int32_t *nbrOfColor, int color, int mode, const double *R, double *Ac,
                        hipStream_t s) {
     hipLaunchKernelGGL(k_tl_scatter, dim3(grid_for((int64_t)nAgg * nModes)), dim3(256), 0, s, nAgg, nModes, nColor, nbrOfColor, color, mode, R, Ac);
+    CHECK_LAUNCH();
+}
+void launch_tl_rap(const TLArgs &t, int64_t nRows, const int32_t *rowPtr, const int32_t *colIdx, const double *vals, double *Ac,
+                   hipStream_t s) {
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nRows + 3) / 4, 256 * 16));
+    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap<3>, dim3(grid), dim3(256), 0, s, t, nRows, rowPtr, colIdx, vals, Ac);
+    else hipLaunchKernelGGL(k_tl_rap<2>, dim3(grid), dim3(256), 0, s, t, nRows, rowPtr, colIdx, vals, Ac);
     CHECK_LAUNCH();
 }
 void launch_tl_gemv(int64_t m, const double *A, const double *x, double *y, hipStream_t s) {
