@@ -249,6 +249,8 @@ mfh_status mfh_set_option(mfh_ctx* ctx, const char* key, double value);
 /* test hook: in-place inverse of a dense SPD matrix (row-major n x n) with the threaded blocked
  * Cholesky that inverts the two-level preconditioner's coarse operator; MFH_ERR_INVALID if not SPD */
 mfh_status mfh_debug_spd_inverse(int64_t n, double* A);
+/* the same with the device implementation (blocked 64x64 Cholesky inverse in HBM) */
+mfh_status mfh_debug_spd_inverse_device(mfh_ctx* ctx, int64_t n, double* A);
 
 #ifdef __cplusplus
 }

@@ -95,6 +95,7 @@ PROTOTYPES = {
     "mfh_time_spmv_kernel": (_i32, [_P, _i32, C.POINTER(_f64)]),
     "mfh_set_option": (_i32, [_P, C.c_char_p, _f64]),
     "mfh_debug_spd_inverse": (_i32, [_i64, _P]),
+    "mfh_debug_spd_inverse_device": (_i32, [_P, _i64, _P]),
 }
 
 _lib = None

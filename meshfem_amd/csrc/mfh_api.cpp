@@ -75,13 +75,14 @@ struct mfh_ctx {
     struct TwoLevel {
         bool valid = false;
         int nModes = 0, nAgg = 0, nColor = 0;
-        int64_t m = 0;
+        int64_t m = 0, ldInv = 0;
         double setup_ms = 0, H = 0;
         DBuf<int32_t> aggOfDof, aggPtr, dofsByAgg, colorOfAgg, nbrOfColor;
         DBuf<double> relPos, Ainv, rc, yc;
     } tl;
     int aggNodes = 0;                 // option "agg_nodes": target DoFs per aggregate (0 = auto)
     bool tlProbe = false;             // option "tl_probe": build the coarse operator by SpMV probing (validation)
+    bool tlHostInverse = false;       // option "tl_host_inverse": invert the coarse operator on the host (validation)
     std::string precondNote;
     int checkEvery = 50;
 
@@ -372,8 +373,8 @@ bool ensure_twolevel(mfh_ctx *c) {
     }
     double t0 = now_ms();
     const int64_t nDoF = c->nDoF;
-    // default: ~500 aggregates (coarse dimension ~3000): the host-side dense inverse is O(m^3)
-    int target = c->aggNodes > 0 ? c->aggNodes : (int)std::max<int64_t>(512, nDoF / 500);
+    // default: ~1000 aggregates (coarse dimension ~6000): setup (Galerkin pass + device dense inverse) ~0.3 s
+    int target = c->aggNodes > 0 ? c->aggNodes : (int)std::max<int64_t>(512, nDoF / 1000);
     Aggregates A;
     for (int attempt = 0; attempt < 6; ++attempt) {
         build_aggregates(d, nDoF, m.nodePos, target, A);
@@ -424,10 +425,37 @@ bool ensure_twolevel(mfh_ctx *c) {
     } else {            // one Galerkin pass over the assembled K
         k::launch_tl_rap(ta, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac.p, s);
     }
+    const int64_t mm = T.m;
+    if (!c->tlHostInverse) {
+        // ---- device path: symmetrise/regularise + blocked Cholesky inverse, all in HBM
+        std::vector<double> diag((size_t)mm);
+        // pitch of (m + 1) doubles walks the diagonal
+        MFH_HIP(hipMemcpy2DAsync(diag.data(), sizeof(double), Ac.p, (size_t)(mm + 1) * sizeof(double), sizeof(double), (size_t)mm,
+                                 hipMemcpyDeviceToHost, s));
+        MFH_HIP(hipStreamSynchronize(s));
+        double maxd = 0;
+        for (double v : diag) maxd = std::max(maxd, v);
+        if (!(maxd > 0)) maxd = 1.0;
+        std::vector<uint8_t> dead((size_t)mm);
+        for (int64_t i = 0; i < mm; ++i) dead[i] = !(diag[i] > 1e-12 * maxd);   // mode without support: decoupled
+        DBuf<uint8_t> dDead;
+        dDead.upload(dead, s);
+        const int64_t mp = ((mm + 63) / 64) * 64;
+        DBuf<double> Ap, X, Dtile;
+        DBuf<int> flag;
+        Ap.alloc((size_t)mp * mp); X.alloc((size_t)mp * mp); Dtile.alloc((size_t)(mp / 64) * 64 * 64); flag.alloc(1);
+        T.Ainv.alloc((size_t)mp * mp);
+        k::launch_tl_prep(mm, mp, Ac.p, dDead.p, maxd, Ap.p, s);
+        Ac.release();
+        if (!k::dense_spd_inverse_device(Ap.p, X.p, T.Ainv.p, Dtile.p, mp, flag.p, s)) {
+            c->precondNote = "two-level preconditioner: coarse operator not positive definite; using block-Jacobi";
+            return false;
+        }
+        T.ldInv = mp;
+    } else {
     std::vector<double> hA((size_t)T.m * T.m);
     Ac.download(hA.data(), hA.size(), s);
     Ac.release();
-    const int64_t mm = T.m;
     if (const char *dump = getenv("MFH_DEBUG_DUMP_AC")) {   // debugging aid: raw coarse operator + aggregates
         FILE *f = fopen(dump, "wb");
         if (f) { fwrite(hA.data(), sizeof(double), hA.size(), f); fclose(f); }
@@ -459,6 +487,8 @@ bool ensure_twolevel(mfh_ctx *c) {
         return false;
     }
     T.Ainv.upload(hA, s);
+    T.ldInv = mm;
+    }
     T.setup_ms = now_ms() - t0;
     T.valid = true;
     return true;
@@ -469,7 +499,7 @@ void tl_precond(mfh_ctx *c, const double *r, double *z, double *scal, int it) {
     const k::TLArgs ta = tl_args(c);
     auto &T = c->tl;
     k::launch_tl_restrict(ta, T.aggPtr.p, T.dofsByAgg.p, r, T.rc.p, c->stream);
-    k::launch_tl_gemv(T.m, T.Ainv.p, T.rc.p, T.yc.p, c->stream);
+    k::launch_tl_gemv(T.m, T.ldInv, T.Ainv.p, T.rc.p, T.yc.p, c->stream);
     k::launch_tl_apply(ta, c->dDinv.p, r, T.yc.p, z, scal, it, c->stop.p, c->stream);
 }
 
@@ -1418,6 +1448,30 @@ mfh_status mfh_time_spmv_kernel(mfh_ctx *c, int32_t reps, double *avg_ms) {
     MFH_CATCH(c)
 }
 
+mfh_status mfh_debug_spd_inverse_device(mfh_ctx *c, int64_t n, double *A) {
+    MFH_TRY(c)
+    require(c && A && n > 0, MFH_ERR_INVALID, "bad arguments");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const int64_t mp = ((n + 63) / 64) * 64;
+    DBuf<double> Ac, Ap, X, Ainv, Dt;
+    DBuf<uint8_t> dead;
+    DBuf<int> flag;
+    Ac.upload(A, (size_t)n * n, s);
+    std::vector<uint8_t> hd((size_t)n, 0);
+    dead.upload(hd, s);
+    double maxd = 0;
+    for (int64_t i = 0; i < n; ++i) maxd = std::max(maxd, A[(size_t)i * n + i]);
+    Ap.alloc((size_t)mp * mp); X.alloc((size_t)mp * mp); Ainv.alloc((size_t)mp * mp); Dt.alloc((size_t)(mp / 64) * 4096); flag.alloc(1);
+    k::launch_tl_prep(n, mp, Ac.p, dead.p, maxd, Ap.p, s);
+    if (!k::dense_spd_inverse_device(Ap.p, X.p, Ainv.p, Dt.p, mp, flag.p, s)) throw Error(MFH_ERR_INVALID, "not SPD");
+    MFH_HIP(hipMemcpy2DAsync(A, (size_t)n * sizeof(double), Ainv.p, (size_t)mp * sizeof(double), (size_t)n * sizeof(double), (size_t)n,
+                             hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    MFH_CATCH(c)
+}
+
 mfh_status mfh_debug_spd_inverse(int64_t n, double *A) {
     try {
         return spd_inverse_inplace(n, A) ? MFH_OK : MFH_ERR_INVALID;
@@ -1435,6 +1489,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "reembed") { c->alwaysReembed = value != 0; }
     else if (k2 == "agg_nodes") { c->aggNodes = (int)value; c->tl.valid = false; }
     else if (k2 == "tl_probe") { c->tlProbe = value != 0; c->tl.valid = false; }
+    else if (k2 == "tl_host_inverse") { c->tlHostInverse = value != 0; c->tl.valid = false; }
     else if (k2 == "debug_variant") { c->debugVariant = (int)value; invalidate_matrix(c); }
     else throw Error(MFH_ERR_INVALID, "unknown option " + k2);
     MFH_CATCH(c)

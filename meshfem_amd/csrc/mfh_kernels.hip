@@ -785,12 +785,30 @@ __global__ void __launch_bounds__(256) k_tl_rap(TLArgs t, int64_t nRows, const i
     }
 }
 
+// symmetrise the raw coarse operator into the padded matrix the dense inverse works on; modes without
+// support (dead) are decoupled, the diagonal gets a tiny relative shift, the padding is scaled identity
+__global__ void __launch_bounds__(256) k_tl_prep(int64_t m, int64_t mp, const double *__restrict__ Ac, const uint8_t *__restrict__ dead,
+                                                 double maxd, double *__restrict__ Ap) {
+    const int64_t total = mp * mp;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t i = e / mp, j = e - i * mp;
+        double v;
+        if (i >= m || j >= m) v = (i == j) ? maxd : 0.0;
+        else if (dead[i] || dead[j]) v = (i == j) ? maxd : 0.0;
+        else {
+            v = 0.5 * (Ac[i * m + j] + Ac[j * m + i]);
+            if (i == j) v *= 1.0 + 1e-10;
+        }
+        Ap[e] = v;
+    }
+}
+
 // y = A x for the dense coarse inverse (row-major m x m); one workgroup per row
-__global__ void __launch_bounds__(256) k_tl_gemv(int64_t m, const double *__restrict__ A, const double *__restrict__ x, double *__restrict__ y) {
+__global__ void __launch_bounds__(256) k_tl_gemv(int64_t m, int64_t ld, const double *__restrict__ A, const double *__restrict__ x, double *__restrict__ y) {
     __shared__ double red[8];
     const int64_t row = blockIdx.x;
     double acc[1] = {0};
-    for (int64_t j = threadIdx.x; j < m; j += 256) acc[0] += A[row * m + j] * x[j];
+    for (int64_t j = threadIdx.x; j < m; j += 256) acc[0] += A[row * ld + j] * x[j];
     block_sum<1>(acc, red);
     if (threadIdx.x == 0) y[row] = acc[0];
 }
@@ -832,6 +850,179 @@ __global__ void __launch_bounds__(256) k_tl_apply(TLArgs t, const double *__rest
         block_sum<1>(acc, red);
         if (threadIdx.x == 0) unsafeAtomicAdd(rzOut, acc[0]);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Dense SPD inverse on the device for the coarse operator (m <= ~16k): blocked Cholesky with 64x64
+// tiles -> L^-1 by block forward substitution -> A^-1 = L^-T L^-1. FP64, LDS-tiled 4x4 micro-tiles.
+// The matrix is padded to a multiple of 64 with an identity block by the caller, so every tile is full.
+// (rocSOLVER is deliberately not used: PyTorch wheels ship their own rocBLAS/rocSOLVER and mixing the
+// two ROCm stacks in one process is not safe.)
+// ------------------------------------------------------------------------------------------------
+constexpr int DT = 64;         // tile edge
+constexpr int DTP = DT + 1;    // LDS leading dimension (bank-conflict padding)
+
+// C(64x64, registers 4x4 per thread) += A_s(64x64) * B_s(64x64), both in LDS as [row][DTP]
+DEV void dense_tile_mma(const double *As, const double *Bs, double (&c)[4][4], int ty, int tx) {
+#pragma unroll 4
+    for (int q = 0; q < DT; ++q) {
+        double a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = As[(ty * 4 + i) * DTP + q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = Bs[q * DTP + tx * 4 + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c[i][j] += a[i] * b[j];
+    }
+}
+// load a 64x64 tile of a row-major matrix (leading dim ld) into LDS, optionally transposed
+DEV void dense_tile_load(const double *__restrict__ G, int64_t ld, double *S, bool transpose) {
+    for (int e = threadIdx.x; e < DT * DT; e += 256) {
+        const int r = e / DT, c = e % DT;
+        const double v = G[(int64_t)r * ld + c];
+        if (transpose) S[c * DTP + r] = v; else S[r * DTP + c] = v;
+    }
+}
+
+// diagonal tile: Cholesky in LDS, L_kk written back (upper zeroed), its inverse to Dinv; *notSpd set on failure
+__global__ void __launch_bounds__(256) k_dense_potrf(double *A, int64_t ld, int k, double *Dinv, int *notSpd) {
+    __shared__ double L[DT * DTP];
+    __shared__ double X[DT * DTP];
+    double *Akk = A + ((int64_t)k * DT) * ld + (int64_t)k * DT;
+    dense_tile_load(Akk, ld, L, false);
+    __syncthreads();
+    for (int j = 0; j < DT; ++j) {
+        if (threadIdx.x == 0) {
+            const double d = L[j * DTP + j];
+            if (!(d > 0)) { *notSpd = 1; L[j * DTP + j] = 1.0; } else L[j * DTP + j] = sqrt(d);
+        }
+        __syncthreads();
+        const double djj = L[j * DTP + j];
+        for (int i = j + 1 + threadIdx.x; i < DT; i += 256) L[i * DTP + j] /= djj;
+        __syncthreads();
+        // trailing update of the lower triangle: L[i][c] -= L[i][j] * L[c][j], j < c <= i
+        const int rem = DT - j - 1;
+        for (int e = threadIdx.x; e < rem * rem; e += 256) {
+            const int i = j + 1 + e / rem, c = j + 1 + e % rem;
+            if (c <= i) L[i * DTP + c] -= L[i * DTP + j] * L[c * DTP + j];
+        }
+        __syncthreads();
+    }
+    // X = L^-1 (lower): one thread per column
+    if (threadIdx.x < DT) {
+        const int c = threadIdx.x;
+        for (int i = 0; i < DT; ++i) {
+            if (i < c) { X[i * DTP + c] = 0.0; continue; }
+            double sacc = (i == c) ? 1.0 : 0.0;
+            for (int q = c; q < i; ++q) sacc -= L[i * DTP + q] * X[q * DTP + c];
+            X[i * DTP + c] = sacc / L[i * DTP + i];
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < DT * DT; e += 256) {
+        const int r = e / DT, c = e % DT;
+        Akk[(int64_t)r * ld + c] = c <= r ? L[r * DTP + c] : 0.0;
+        Dinv[(int64_t)k * DT * DT + e] = X[r * DTP + c];
+    }
+}
+
+// panel: L_ik = A_ik * Linv_kk^T for i > k
+__global__ void __launch_bounds__(256) k_dense_trsm(double *A, int64_t ld, int k, const double *Dinv) {
+    __shared__ double As[DT * DTP];
+    __shared__ double Bs[DT * DTP];
+    const int i = k + 1 + blockIdx.x;
+    double *Aik = A + ((int64_t)i * DT) * ld + (int64_t)k * DT;
+    dense_tile_load(Aik, ld, As, false);
+    dense_tile_load(Dinv + (int64_t)k * DT * DT, DT, Bs, true);     // Bs[q][c] = Linv[c][q]
+    __syncthreads();
+    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    double c[4][4] = {};
+    dense_tile_mma(As, Bs, c, ty, tx);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Aik[(int64_t)(ty * 4 + a) * ld + tx * 4 + b] = c[a][b];
+}
+
+// trailing update: A_ij -= L_ik L_jk^T for k < j <= i ; 2D grid over (i-k-1, j-k-1)
+__global__ void __launch_bounds__(256) k_dense_syrk(double *A, int64_t ld, int k) {
+    const int i = k + 1 + blockIdx.y, j = k + 1 + blockIdx.x;
+    if (j > i) return;
+    __shared__ double As[DT * DTP];
+    __shared__ double Bs[DT * DTP];
+    dense_tile_load(A + ((int64_t)i * DT) * ld + (int64_t)k * DT, ld, As, false);
+    dense_tile_load(A + ((int64_t)j * DT) * ld + (int64_t)k * DT, ld, Bs, true);   // Bs[q][c] = L_jk[c][q]
+    __syncthreads();
+    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    double c[4][4] = {};
+    dense_tile_mma(As, Bs, c, ty, tx);
+    double *Aij = A + ((int64_t)i * DT) * ld + (int64_t)j * DT;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Aij[(int64_t)(ty * 4 + a) * ld + tx * 4 + b] -= c[a][b];
+}
+
+// X = L^-1, sub-diagonal d: X_{c+d,c} = -Linv_{c+d} * sum_{q=c}^{c+d-1} L_{c+d,q} X_{q,c}; d = 0 copies Linv
+__global__ void __launch_bounds__(256) k_dense_trinv(const double *A, double *X, int64_t ld, int d, const double *Dinv) {
+    __shared__ double As[DT * DTP];
+    __shared__ double Bs[DT * DTP];
+    const int cblk = blockIdx.x, i = cblk + d;
+    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    double *Xic = X + ((int64_t)i * DT) * ld + (int64_t)cblk * DT;
+    if (d == 0) {
+        for (int e = threadIdx.x; e < DT * DT; e += 256) Xic[(int64_t)(e / DT) * ld + e % DT] = Dinv[(int64_t)i * DT * DT + e];
+        return;
+    }
+    double s[4][4] = {};
+    for (int q = cblk; q < i; ++q) {
+        __syncthreads();
+        dense_tile_load(A + ((int64_t)i * DT) * ld + (int64_t)q * DT, ld, As, false);
+        dense_tile_load(X + ((int64_t)q * DT) * ld + (int64_t)cblk * DT, ld, Bs, false);
+        __syncthreads();
+        dense_tile_mma(As, Bs, s, ty, tx);
+    }
+    __syncthreads();
+    // As <- Linv_ii, Bs <- S ; X_ic = -Linv_ii * S
+    dense_tile_load(Dinv + (int64_t)i * DT * DT, DT, As, false);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Bs[(ty * 4 + a) * DTP + tx * 4 + b] = s[a][b];
+    __syncthreads();
+    double c[4][4] = {};
+    dense_tile_mma(As, Bs, c, ty, tx);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) Xic[(int64_t)(ty * 4 + a) * ld + tx * 4 + b] = -c[a][b];
+}
+
+// Ainv_IJ = sum_{Q >= I} X_QI^T X_QJ for J <= I (and its mirror); 2D grid (J, I)
+__global__ void __launch_bounds__(256) k_dense_xtx(const double *X, double *Ainv, int64_t ld, int nt) {
+    const int I = blockIdx.y, J = blockIdx.x;
+    if (J > I) return;
+    __shared__ double As[DT * DTP];
+    __shared__ double Bs[DT * DTP];
+    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    double c[4][4] = {};
+    for (int Q = I; Q < nt; ++Q) {
+        __syncthreads();
+        dense_tile_load(X + ((int64_t)Q * DT) * ld + (int64_t)I * DT, ld, As, true);    // As[r][q] = X_QI[q][r]
+        dense_tile_load(X + ((int64_t)Q * DT) * ld + (int64_t)J * DT, ld, Bs, false);
+        __syncthreads();
+        dense_tile_mma(As, Bs, c, ty, tx);
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int r = ty * 4 + a, cc = tx * 4 + b;
+            Ainv[((int64_t)I * DT + r) * ld + (int64_t)J * DT + cc] = c[a][b];
+            Ainv[((int64_t)J * DT + cc) * ld + (int64_t)I * DT + r] = c[a][b];
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1123,8 +1314,36 @@ void launch_tl_rap(const TLArgs &t, int64_t nRows, const int32_t *rowPtr, const 
     else hipLaunchKernelGGL(k_tl_rap<2>, dim3(grid), dim3(256), 0, s, t, nRows, rowPtr, colIdx, vals, Ac);
     CHECK_LAUNCH();
 }
-void launch_tl_gemv(int64_t m, const double *A, const double *x, double *y, hipStream_t s) {
-    hipLaunchKernelGGL(k_tl_gemv, dim3((unsigned)m), dim3(256), 0, s, m, A, x, y);
+// In-place-style dense SPD inverse: A (mp x mp, mp % 64 == 0) is overwritten by its Cholesky factor, the inverse
+// goes to Ainv; X and Dinv are scratch (mp x mp and (mp/64) x 64 x 64). Returns false if A is not SPD.
+bool dense_spd_inverse_device(double *A, double *X, double *Ainv, double *Dinv, int64_t mp, int *notSpdDev, hipStream_t s) {
+    const int nt = (int)(mp / DT);
+    MFH_HIP(hipMemsetAsync(notSpdDev, 0, sizeof(int), s));
+    MFH_HIP(hipMemsetAsync(X, 0, sizeof(double) * mp * mp, s));
+    for (int k = 0; k < nt; ++k) {
+        hipLaunchKernelGGL(k_dense_potrf, dim3(1), dim3(256), 0, s, A, mp, k, Dinv, notSpdDev);
+        const int rem = nt - k - 1;
+        if (rem > 0) {
+            hipLaunchKernelGGL(k_dense_trsm, dim3(rem), dim3(256), 0, s, A, mp, k, (const double *)Dinv);
+            hipLaunchKernelGGL(k_dense_syrk, dim3(rem, rem), dim3(256), 0, s, A, mp, k);
+        }
+    }
+    for (int d = 0; d < nt; ++d)
+        hipLaunchKernelGGL(k_dense_trinv, dim3(nt - d), dim3(256), 0, s, (const double *)A, X, mp, d, (const double *)Dinv);
+    hipLaunchKernelGGL(k_dense_xtx, dim3(nt, nt), dim3(256), 0, s, (const double *)X, Ainv, mp, nt);
+    CHECK_LAUNCH();
+    int bad = 0;
+    MFH_HIP(hipMemcpyAsync(&bad, notSpdDev, sizeof(int), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    return bad == 0;
+}
+
+void launch_tl_prep(int64_t m, int64_t mp, const double *Ac, const uint8_t *dead, double maxd, double *Ap, hipStream_t s) {
+    hipLaunchKernelGGL(k_tl_prep, dim3(grid_for(mp * mp, 16384)), dim3(256), 0, s, m, mp, Ac, dead, maxd, Ap);
+    CHECK_LAUNCH();
+}
+void launch_tl_gemv(int64_t m, int64_t ld, const double *A, const double *x, double *y, hipStream_t s) {
+    hipLaunchKernelGGL(k_tl_gemv, dim3((unsigned)m), dim3(256), 0, s, m, ld, A, x, y);
     CHECK_LAUNCH();
 }
 void launch_tl_apply(const TLArgs &t, const double *dinv, const double *r, const double *yc, double *z, double *scal, int it,
