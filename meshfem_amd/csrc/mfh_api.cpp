@@ -81,6 +81,7 @@ struct mfh_ctx {
         DBuf<double> relPos, Ainv, rc, yc;
     } tl;
     int aggNodes = 0;                 // option "agg_nodes": target DoFs per aggregate (0 = auto)
+    bool symbolicDevice = true;       // option "symbolic_device": build pattern + gather lists on the GPU (element-major order)
     bool tlProbe = false;             // option "tl_probe": build the coarse operator by SpMV probing (validation)
     bool tlHostInverse = false;       // option "tl_host_inverse": invert the coarse operator on the host (validation)
     std::string precondNote;
@@ -255,16 +256,53 @@ const std::vector<double> &host_geo(mfh_ctx *c) {
     return c->hGeo;
 }
 
+const int32_t *device_dof_map(mfh_ctx *c) {
+    if (c->dofForNode.empty()) return nullptr;
+    if (!c->dofUploaded) { c->dDofForNode.upload(c->dofForNode, c->stream); c->dofUploaded = true; }
+    return c->dDofForNode.p;
+}
+
+void ensure_host_colidx(mfh_ctx *c) {
+    if (!c->sym.colIdx.empty() || c->sym.nnzb == 0) return;
+    c->sym.colIdx.resize((size_t)c->sym.nnzb);
+    c->dColIdx.download(c->sym.colIdx.data(), c->sym.colIdx.size(), c->stream);
+}
+
 void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
     require(c->haveMesh, MFH_ERR_STATE, "no mesh set");
     if (c->symValid && (!wantScatter || c->symHasScatter)) return;
     double t0 = now_ms();
+    if (!c->hostOnly && c->symbolicDevice && c->contribOrder == 1) {
+        // ---- device path: two radix sorts (mfh_symbolic_gpu.hip)
+        require_device(c);
+        MFH_HIP(hipSetDevice(c->device));
+        build_symbolic_device(c->mesh, c->dElemNodes.p, device_dof_map(c), c->nDoF, c->nOwnedDoF(), c->chunkSlots, wantScatter, c->stream,
+                              c->sym, c->dRowPtr, c->dColIdx, c->dContribCode, c->dContribSlot, c->dScatter);
+        const Symbolic &S = c->sym;
+        c->dChunkRow.upload(S.chunkRow, c->stream);
+        c->dSpmvChunkRow.upload(S.spmvChunkRow, c->stream);
+        c->dContribPtr.upload(S.contribPtr, c->stream);
+        c->symHasScatter = wantScatter;
+        if (c->keepHostSymbolic) {
+            ensure_host_colidx(c);
+            c->sym.contribCode.resize(c->dContribCode.n);
+            c->sym.contribSlot.resize(c->dContribSlot.n);
+            c->dContribCode.download(c->sym.contribCode.data(), c->dContribCode.n, c->stream);
+            c->dContribSlot.download(c->sym.contribSlot.data(), c->dContribSlot.n, c->stream);
+            if (wantScatter) { c->sym.scatterSlot.resize(c->dScatter.n); c->dScatter.download(c->sym.scatterSlot.data(), c->dScatter.n, c->stream); }
+        }
+        c->timing.symbolic_ms = now_ms() - t0;
+        const size_t tilesD = (size_t)((S.nnzb + 63) / 64);
+        c->dVals.alloc(tilesD * 64 * (size_t)c->dim() * c->dim());
+        c->symValid = true;
+        invalidate_matrix(c);
+        return;
+    }
     build_symbolic(c->mesh, c->dofForNode, c->nDoF, c->nOwnedDoF(), c->chunkSlots, c->contribOrder, wantScatter, c->sym);
     c->timing.symbolic_ms = now_ms() - t0;
     const Symbolic &S = c->sym;
     c->symHasScatter = wantScatter;
     if (c->hostOnly) { c->symValid = true; return; }
-    require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     c->dRowPtr.upload(S.rowPtr, c->stream);
     c->dColIdx.upload(S.colIdx, c->stream);
@@ -274,7 +312,6 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
     c->dContribCode.upload(S.contribCode, c->stream);
     c->dContribSlot.upload(S.contribSlot, c->stream);
     if (wantScatter) c->dScatter.upload(S.scatterSlot, c->stream);
-    c->symHasScatter = wantScatter;
     if (!c->keepHostSymbolic) {   // host copies of the big gather lists are no longer needed
         std::vector<uint32_t>().swap(c->sym.contribCode);
         std::vector<uint16_t>().swap(c->sym.contribSlot);
@@ -1017,6 +1054,7 @@ mfh_status mfh_matrix_info(const mfh_ctx *c, int64_t *nBlockRows, int64_t *nBloc
 mfh_status mfh_export_bsr(mfh_ctx *c, int32_t *rowPtr, int32_t *colIdx, double *vals) {
     MFH_TRY(c)
     require(c && c->assembled, MFH_ERR_STATE, "matrix not assembled");
+    ensure_host_colidx(c);
     const Symbolic &S = c->sym;
     if (rowPtr) std::copy(S.rowPtr.begin(), S.rowPtr.end(), rowPtr);
     if (colIdx) std::copy(S.colIdx.begin(), S.colIdx.end(), colIdx);
@@ -1034,6 +1072,7 @@ mfh_status mfh_export_upper_triplets(mfh_ctx *c, uint64_t *oi, uint64_t *oj, dou
     MFH_TRY(c)
     require(c && c->assembled && nnz, MFH_ERR_STATE, "matrix not assembled");
     require(c->sym.nRows == c->sym.nCols, MFH_ERR_STATE, "triplet export needs a square matrix");
+    ensure_host_colidx(c);
     const Symbolic &S = c->sym;
     const int d = c->dim(), nb = d * d;
     std::vector<double> vals((size_t)S.nnzb * nb);
@@ -1264,12 +1303,6 @@ mfh_status mfh_neumann_load(mfh_ctx *c, double *out) {
     MFH_CATCH(c)
 }
 
-static const int32_t *device_dof_map(mfh_ctx *c) {
-    if (c->dofForNode.empty()) return nullptr;
-    if (!c->dofUploaded) { c->dDofForNode.upload(c->dofForNode, c->stream); c->dofUploaded = true; }
-    return c->dDofForNode.p;
-}
-
 mfh_status mfh_constant_strain_load(mfh_ctx *c, const double *cstrain, double *out) {
     MFH_TRY(c)
     require(c && c->haveMesh && cstrain && out, MFH_ERR_STATE, "no mesh set");
@@ -1488,6 +1521,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "keep_host_symbolic") { c->keepHostSymbolic = value != 0; }
     else if (k2 == "reembed") { c->alwaysReembed = value != 0; }
     else if (k2 == "agg_nodes") { c->aggNodes = (int)value; c->tl.valid = false; }
+    else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }
     else if (k2 == "tl_probe") { c->tlProbe = value != 0; c->tl.valid = false; }
     else if (k2 == "tl_host_inverse") { c->tlHostInverse = value != 0; c->tl.valid = false; }
     else if (k2 == "debug_variant") { c->debugVariant = (int)value; invalidate_matrix(c); }

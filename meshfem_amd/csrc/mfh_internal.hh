@@ -157,6 +157,11 @@ void build_symbolic(const HostMesh &m, const std::vector<int32_t> &dofForNode /*
                     int64_t nDoF, int64_t nOwnedDoF, int chunkSlots, int contribOrder, bool wantScatter,
                     Symbolic &S);
 
+// device implementation (mfh_symbolic_gpu.hip): element-major gather lists via two radix sorts
+void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nDoF, int64_t nOwnedDoF,
+                           int chunkSlots, bool wantScatter, hipStream_t s, Symbolic &S, DBuf<int32_t> &dRowPtr, DBuf<int32_t> &dColIdx,
+                           DBuf<uint32_t> &dContribCode, DBuf<uint16_t> &dContribSlot, DBuf<int32_t> &dScatter);
+
 // ------------------------------------------------------------------------------------------------
 // P2 coefficient tables: for node i, grad phi_i(q) = alpha_i(q) gl[s_i] + beta_i(q) gl[t_i]
 // (EmbeddedElement.hh:315-332). pairTable[(i*npe+j)*4 + {aa,ab,ba,bb}] = sum_q w_q coef_i coef_j

@@ -550,3 +550,33 @@ def test_two_level_setup_variants_agree():
     assert max(its) - min(its) <= 2, its
     for v in out.values():
         assert np.linalg.norm(v[0] - out[(0, 0)][0]) / np.linalg.norm(out[(0, 0)][0]) < 1e-8
+
+
+@pytest.mark.parametrize("case", ["p2", "p1_periodic", "partitioned"])
+def test_device_symbolic_identical_to_host_symbolic(case):
+    """The GPU symbolic phase (two radix sorts) must reproduce the host implementation bit for bit:
+    row pointers, columns, chunk tables, gather lists (element-major) and the scatter map."""
+    V, T = grid.grid_tet_mesh(4, 3, 3)
+    res = {}
+    for dev in (1, 0):
+        c = _ctx()
+        c.set_option("keep_host_symbolic", 1)
+        c.set_option("symbolic_device", dev)
+        c.set_option("chunk_slots", 192)
+        if case == "partitioned":
+            m = O.FEMMesh(T, V, 2)
+            c.mesh_set(3, 2, m.elem_nodes, m.node_pos, m.num_nodes // 3)
+        else:
+            c.mesh_build(T, V, 2 if case == "p2" else 1)
+            if case == "p1_periodic":
+                c.apply_periodic_conditions()
+        c.symbolic(True)
+        res[dev] = c.symbolic_get(True)
+        c.material_isotropic(200.0, 0.35)
+        c.assemble()
+        res[dev]["K"] = c.export_scipy()
+    a, b = res[1], res[0]
+    for k in ("rowPtr", "colIdx", "chunkRow", "contribPtr", "contribCode", "contribSlot", "scatterSlot"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["chunk_slots"] == b["chunk_slots"] and a["max_row_len"] == b["max_row_len"] and a["n_contrib"] == b["n_contrib"]
+    assert abs(a["K"] - b["K"]).max() <= 1e-13 * abs(b["K"]).max()
