@@ -81,6 +81,7 @@ struct mfh_ctx {
         DBuf<double> relPos, Ainv, rc, yc;
     } tl;
     int aggNodes = 0;                 // option "agg_nodes": target DoFs per aggregate (0 = auto)
+    bool topologyDevice = true;       // option "topology_device": edge numbering + boundary extraction by device radix sorts
     bool symbolicDevice = true;       // option "symbolic_device": build pattern + gather lists on the GPU (element-major order)
     bool tlProbe = false;             // option "tl_probe": build the coarse operator by SpMV probing (validation)
     bool tlHostInverse = false;       // option "tl_host_inverse": invert the coarse operator on the host (validation)
@@ -810,7 +811,8 @@ mfh_status mfh_mesh_build(mfh_ctx *c, int32_t dim, int32_t deg, int64_t nElem, i
                           const double *vertPos) {
     MFH_TRY(c)
     require(c && elemVerts && vertPos, MFH_ERR_INVALID, "null argument");
-    build_fem_mesh(c->mesh, dim, deg, nElem, nVert, elemVerts, vertPos);
+    if (!c->hostOnly) MFH_HIP(hipSetDevice(c->device));
+    build_fem_mesh(c->mesh, dim, deg, nElem, nVert, elemVerts, vertPos, !c->hostOnly && c->topologyDevice, c->stream);
     upload_mesh(c);
     if (!c->hostOnly) ensure_geometry(c);   // throws on negative volumes like the Simulator ctor
     MFH_CATCH(c)
@@ -1521,6 +1523,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "keep_host_symbolic") { c->keepHostSymbolic = value != 0; }
     else if (k2 == "reembed") { c->alwaysReembed = value != 0; }
     else if (k2 == "agg_nodes") { c->aggNodes = (int)value; c->tl.valid = false; }
+    else if (k2 == "topology_device") { c->topologyDevice = value != 0; }
     else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }
     else if (k2 == "tl_probe") { c->tlProbe = value != 0; c->tl.valid = false; }
     else if (k2 == "tl_host_inverse") { c->tlHostInverse = value != 0; c->tl.valid = false; }

@@ -124,7 +124,10 @@ struct HostMesh {
 };
 
 void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *elemVerts,
-                    const double *vertPos);
+                    const double *vertPos, bool useDevice = false, hipStream_t stream = nullptr);
+// device topology (mfh_symbolic_gpu.hip); false = mesh does not fit the packed sort keys, use the host path
+bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *hostElemVerts, hipStream_t s,
+                           std::vector<int32_t> &instEdge, int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst);
 void compute_node_positions(HostMesh &m);
 void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofForNode, int64_t &nDoF,
                       std::vector<uint8_t> &bdryInternal);

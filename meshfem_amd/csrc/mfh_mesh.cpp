@@ -97,57 +97,37 @@ inline uint64_t edge_key(int32_t a, int32_t b) {
 }
 } // namespace
 
-void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *ev,
-                    const double *vp) {
-    if (dim != 2 && dim != 3) throw Error(MFH_ERR_INVALID, "dim must be 2 or 3");
-    if (deg != 1 && deg != 2) throw Error(MFH_ERR_INVALID, "deg must be 1 or 2");
-    if (nElem <= 0 || nVert <= 0) throw Error(MFH_ERR_INVALID, "empty mesh");
-    const int nv = dim + 1;
-    const int nedge = dim == 3 ? 6 : 3;
-    m = HostMesh();
-    m.dim = dim; m.deg = deg; m.npe = nodes_per_elem(dim, deg); m.npbe = nodes_per_bdry_elem(dim, deg);
-    m.nElem = nElem; m.nVert = nVert;
-    m.vertPos.assign(vp, vp + nVert * dim);
-    for (int64_t k = 0; k < nElem * nv; ++k)
-        if (ev[k] < 0 || ev[k] >= nVert) throw Error(MFH_ERR_INVALID, "Bad vertex index encountered.");
-
-    // ---- edge nodes, first-encounter order over (element, local edge)        FEMMesh.inl:22-36
-    m.elemNodes.resize((size_t)nElem * m.npe);
-    int32_t nEdgeNodes = 0;
-    std::unique_ptr<EdgeHash> eh;
+// Host topology (used by host-only contexts and as fallback): first-encounter edge numbering with a
+// hash table, unmatched half-faces / half-edges by sorting. Same outputs as build_topology_device.
+static void build_topology_host(int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *ev, std::vector<int32_t> &instEdge,
+                                int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst) {
+    const int nv = dim + 1, nedge = dim == 3 ? 6 : 3;
+    nEdgeNodes = 0;
+    instEdge.clear();
     if (deg == 2) {
-        eh.reset(new EdgeHash((size_t)(nElem * (dim == 3 ? 1.4 : 1.7)) + 64));
+        instEdge.resize((size_t)nElem * nedge);
+        EdgeHash eh((size_t)(nElem * (dim == 3 ? 1.4 : 1.7)) + 64);
         for (int64_t e = 0; e < nElem; ++e) {
             const int32_t *v = ev + e * nv;
-            int32_t *out = &m.elemNodes[(size_t)e * m.npe];
-            for (int c = 0; c < nv; ++c) out[c] = v[c];
             for (int ei = 0; ei < nedge; ++ei) {
                 bool ins;
-                int32_t k = eh->get_or_insert(edge_key(v[kEdgeStart[ei]], v[kEdgeEnd[ei]]), nEdgeNodes, ins);
+                int32_t k = eh.get_or_insert(edge_key(v[kEdgeStart[ei]], v[kEdgeEnd[ei]]), nEdgeNodes, ins);
                 if (ins) ++nEdgeNodes;
-                out[nv + ei] = (int32_t)nVert + k;
+                instEdge[(size_t)e * nedge + ei] = k;
             }
         }
-    } else {
-        std::copy(ev, ev + nElem * nv, m.elemNodes.begin());
     }
-    m.nNode = nVert + nEdgeNodes;
-    m.nOwned = m.nNode;
-    compute_node_positions(m);
-
-    // ---- boundary extraction
-    std::vector<std::array<int32_t, 3>> bfaceVolCorners; // volume half-face corner order
+    bdryInst.clear();
     if (dim == 3) {
-        struct HF { int32_t a, b, c; int32_t hf; };
+        struct HF { int32_t a, b, c; uint32_t hf; };
         std::vector<HF> hfs((size_t)nElem * 4);
         parallel_ranges(nElem, [&](int64_t b, int64_t e, int) {
             for (int64_t t = b; t < e; ++t)
                 for (int f = 0; f < 4; ++f) {
-                    int32_t x = ev[t * 4 + kFaceCorner[f][0]], y = ev[t * 4 + kFaceCorner[f][1]],
-                            z = ev[t * 4 + kFaceCorner[f][2]];
+                    int32_t x = ev[t * 4 + kFaceCorner[f][0]], y = ev[t * 4 + kFaceCorner[f][1]], z = ev[t * 4 + kFaceCorner[f][2]];
                     int32_t lo = std::min(x, std::min(y, z)), hi = std::max(x, std::max(y, z));
                     int32_t mid = x ^ y ^ z ^ lo ^ hi;
-                    hfs[(size_t)t * 4 + f] = HF{lo, mid, hi, (int32_t)(t * 4 + f)};
+                    hfs[(size_t)t * 4 + f] = HF{lo, mid, hi, (uint32_t)(t * 4 + f)};
                 }
         });
         std::sort(hfs.begin(), hfs.end(), [](const HF &p, const HF &q) {
@@ -160,38 +140,82 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
             size_t k2 = k + 1;
             while (k2 < hfs.size() && hfs[k2].a == hfs[k].a && hfs[k2].b == hfs[k].b && hfs[k2].c == hfs[k].c) ++k2;
             if (k2 - k > 2) throw Error(MFH_ERR_INVALID, "Non-manifold input detected.");
-            if (k2 - k == 1) {
-                int32_t hf = hfs[k].hf, t = hf / 4, f = hf % 4;
-                bfaceVolCorners.push_back({ev[(size_t)t * 4 + kFaceCorner[f][0]], ev[(size_t)t * 4 + kFaceCorner[f][1]],
-                                           ev[(size_t)t * 4 + kFaceCorner[f][2]]});
-            }
+            if (k2 - k == 1) bdryInst.push_back(hfs[k].hf);
             k = k2;
         }
     } else {
-        struct HE { int32_t a, b; int32_t tail, tip; };
+        struct HE { int32_t a, b, tail, tip; uint32_t he; };
         std::vector<HE> hes((size_t)nElem * 3);
         for (int64_t t = 0; t < nElem; ++t)
             for (int c = 0; c < 3; ++c) {
                 int32_t tail = ev[t * 3 + (c + 1) % 3], tip = ev[t * 3 + (c + 2) % 3]; // TriMesh.hh:285-298
-                hes[(size_t)t * 3 + c] = HE{std::min(tail, tip), std::max(tail, tip), tail, tip};
+                hes[(size_t)t * 3 + c] = HE{std::min(tail, tip), std::max(tail, tip), tail, tip, (uint32_t)(t * 3 + c)};
             }
         std::sort(hes.begin(), hes.end(), [](const HE &p, const HE &q) {
             if (p.a != q.a) return p.a < q.a;
             if (p.b != q.b) return p.b < q.b;
-            return p.tail < q.tail;
+            return p.he < q.he;
         });
         for (size_t k = 0; k < hes.size();) {
             size_t k2 = k + 1;
             while (k2 < hes.size() && hes[k2].a == hes[k].a && hes[k2].b == hes[k].b) ++k2;
             if (k2 - k > 2) throw Error(MFH_ERR_INVALID, "Non-manifold edge detected");
-            if (k2 - k == 2 && hes[k].tail != hes[k + 1].tip)
-                throw Error(MFH_ERR_INVALID, "Inconsistent triangle orientations.");
-            if (k2 - k == 1) bfaceVolCorners.push_back({hes[k].tail, hes[k].tip, -1});
+            if (k2 - k == 2 && hes[k].tail != hes[k + 1].tip) throw Error(MFH_ERR_INVALID, "Inconsistent triangle orientations.");
+            if (k2 - k == 1) bdryInst.push_back(hes[k].he);
             k = k2;
         }
     }
-    const int64_t nBE = (int64_t)bfaceVolCorners.size();
+}
+
+void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *ev, const double *vp, bool useDevice,
+                    hipStream_t stream) {
+    if (dim != 2 && dim != 3) throw Error(MFH_ERR_INVALID, "dim must be 2 or 3");
+    if (deg != 1 && deg != 2) throw Error(MFH_ERR_INVALID, "deg must be 1 or 2");
+    if (nElem <= 0 || nVert <= 0) throw Error(MFH_ERR_INVALID, "empty mesh");
+    const int nv = dim + 1;
+    const int nedge = dim == 3 ? 6 : 3;
+    m = HostMesh();
+    m.dim = dim; m.deg = deg; m.npe = nodes_per_elem(dim, deg); m.npbe = nodes_per_bdry_elem(dim, deg);
+    m.nElem = nElem; m.nVert = nVert;
+    m.vertPos.assign(vp, vp + nVert * dim);
+    for (int64_t k = 0; k < nElem * nv; ++k)
+        if (ev[k] < 0 || ev[k] >= nVert) throw Error(MFH_ERR_INVALID, "Bad vertex index encountered.");
+
+    // ---- topology: edge nodes in first-encounter order over (element, local edge) (FEMMesh.inl:22-36) and
+    //      the unmatched half-faces / half-edges in sorted-key order (TetMesh.inl:36-79, TriMesh.inl:60-100)
+    std::vector<int32_t> instEdge;
+    std::vector<uint32_t> bdryInst;
+    int32_t nEdgeNodes = 0;
+    if (!(useDevice && build_topology_device(dim, deg, nElem, nVert, ev, stream, instEdge, nEdgeNodes, bdryInst)))
+        build_topology_host(dim, deg, nElem, nVert, ev, instEdge, nEdgeNodes, bdryInst);
+
+    m.elemNodes.resize((size_t)nElem * m.npe);
+    parallel_ranges(nElem, [&](int64_t b, int64_t e2, int) {
+        for (int64_t e = b; e < e2; ++e) {
+            int32_t *out = &m.elemNodes[(size_t)e * m.npe];
+            for (int c = 0; c < nv; ++c) out[c] = ev[e * nv + c];
+            if (deg == 2)
+                for (int ei = 0; ei < nedge; ++ei) out[nv + ei] = (int32_t)nVert + instEdge[(size_t)e * nedge + ei];
+        }
+    });
+    m.nNode = nVert + nEdgeNodes;
+    m.nOwned = m.nNode;
+    compute_node_positions(m);
+
+    // ---- boundary elements from the unmatched instances
+    const int64_t nBE = (int64_t)bdryInst.size();
     const int nbv = dim; // vertices per boundary element
+    std::vector<std::array<int32_t, 3>> bfaceVolCorners((size_t)nBE);   // volume half-face corner order
+    for (int64_t b = 0; b < nBE; ++b) {
+        const uint32_t inst = bdryInst[b];
+        if (dim == 3) {
+            const int64_t t = inst / 4; const int f = inst % 4;
+            bfaceVolCorners[b] = {ev[t * 4 + kFaceCorner[f][0]], ev[t * 4 + kFaceCorner[f][1]], ev[t * 4 + kFaceCorner[f][2]]};
+        } else {
+            const int64_t t = inst / 3; const int c = inst % 3;
+            bfaceVolCorners[b] = {ev[t * 3 + (c + 1) % 3], ev[t * 3 + (c + 2) % 3], -1};   // (tail, tip)
+        }
+    }
     // boundary vertex numbering: first encounter in volume-corner order (TetMesh.inl:82-89;
     // TriMesh.inl:103-104 visits tipVV = vol tail first, then tailVV = vol tip)
     std::vector<int32_t> Vb((size_t)nVert, -1);
@@ -211,12 +235,23 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
     }
     m.bdryNodes.assign(bV.begin(), bV.end());
     if (deg == 2) {
+        // local edge index of a pair of local corners (Simplex.hh:43-44)
+        int pairToEdge[4][4];
+        for (auto &row : pairToEdge) for (int &x : row) x = -1;
+        for (int ei = 0; ei < nedge; ++ei) { pairToEdge[kEdgeStart[ei]][kEdgeEnd[ei]] = ei; pairToEdge[kEdgeEnd[ei]][kEdgeStart[ei]] = ei; }
         const int nbedge = dim == 3 ? 3 : 1;
         std::vector<int32_t> bdryEdgeForVolEdge((size_t)nEdgeNodes, -1);
         for (int64_t b = 0; b < nBE; ++b) {
+            const uint32_t inst = bdryInst[b];
             int32_t *out = &m.bdryElemNodes[(size_t)b * m.npbe];
-            for (int ei = 0; ei < nbedge; ++ei) {
-                int32_t volEdge = eh->at(edge_key(out[kEdgeStart[ei]], out[kEdgeEnd[ei]]));
+            // local element corners of the boundary element's vertices, in boundary order
+            int lc[3];
+            int64_t t;
+            if (dim == 3) { t = inst / 4; const int f = inst % 4; lc[0] = kFaceCorner[f][2]; lc[1] = kFaceCorner[f][1]; lc[2] = kFaceCorner[f][0]; }
+            else { t = inst / 3; const int c = inst % 3; lc[0] = (c + 2) % 3; lc[1] = (c + 1) % 3; lc[2] = -1; }
+            for (int ei = 0; ei < nbedge; ++ei) {   // boundary-local edges (0,1),(1,2),(2,0)   FEMMesh.inl:43-58
+                const int le = pairToEdge[lc[kEdgeStart[ei]]][lc[kEdgeEnd[ei]]];
+                const int32_t volEdge = instEdge[(size_t)t * nedge + le];
                 if (bdryEdgeForVolEdge[volEdge] < 0) {
                     bdryEdgeForVolEdge[volEdge] = 1;
                     m.bdryNodes.push_back((int32_t)nVert + volEdge);

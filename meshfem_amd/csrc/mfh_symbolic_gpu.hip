@@ -206,4 +206,156 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     MFH_HIP(hipStreamSynchronize(s));
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// FEM mesh topology on the device: P2 edge-node numbering in first-encounter order (FEMMesh.inl:22-36)
+// and the unmatched half-faces / half-edges that form the boundary (TetMesh.inl:36-79,
+// TriMesh.inl:60-100), by radix sorts instead of the host's hash table + std::sort.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__constant__ int kEdgeS[6] = {0, 1, 2, 0, 2, 1};
+__constant__ int kEdgeE[6] = {1, 2, 0, 3, 3, 3};
+__constant__ int kFaceC[4][3] = {{1, 3, 2}, {0, 2, 3}, {0, 3, 1}, {0, 1, 2}};
+
+__global__ void __launch_bounds__(256) k_topo_edge_keys(int64_t nInst, int nv, int nedge, const int32_t *__restrict__ ev,
+                                                        uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nInst; k += (int64_t)gridDim.x * 256) {
+        const int64_t e = k / nedge;
+        const int ei = (int)(k - e * nedge);
+        const uint32_t a = (uint32_t)ev[e * nv + kEdgeS[ei]], b = (uint32_t)ev[e * nv + kEdgeE[ei]];
+        key[k] = a < b ? (((uint64_t)a << 32) | b) : (((uint64_t)b << 32) | a);
+        val[k] = (uint32_t)k;
+    }
+}
+// unique edges: at heads, uniq id = headCount-1; record first instance (smallest k: the sort is stable)
+__global__ void __launch_bounds__(256) k_topo_edge_first(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val,
+                                                         const uint32_t *__restrict__ headP1, uint32_t *__restrict__ firstInst) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
+        if (k == 0 || key[k] != key[k - 1]) firstInst[headP1[k] - 1] = val[k];
+}
+__global__ void __launch_bounds__(256) k_topo_iota(int64_t n, uint32_t *__restrict__ v) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) v[k] = (uint32_t)k;
+}
+// rankOfUniq[uniqSortedByFirst[r]] = r
+__global__ void __launch_bounds__(256) k_topo_rank(int64_t n, const uint32_t *__restrict__ uniqByFirst, uint32_t *__restrict__ rankOfUniq) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) rankOfUniq[uniqByFirst[k]] = (uint32_t)k;
+}
+// edge node of every (element, local edge) instance
+__global__ void __launch_bounds__(256) k_topo_edge_assign(int64_t n, const uint32_t *__restrict__ val, const uint32_t *__restrict__ headP1,
+                                                          const uint32_t *__restrict__ rankOfUniq, int32_t *__restrict__ instEdge) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) instEdge[val[k]] = (int32_t)rankOfUniq[headP1[k] - 1];
+}
+// half-face keys (3 x 21-bit sorted vertex ids) / half-edge keys
+__global__ void __launch_bounds__(256) k_topo_face_keys(int64_t nInst, int dim, const int32_t *__restrict__ ev, uint64_t *__restrict__ key,
+                                                        uint32_t *__restrict__ val) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nInst; k += (int64_t)gridDim.x * 256) {
+        if (dim == 3) {
+            const int64_t t = k >> 2;
+            const int f = (int)(k & 3);
+            const uint64_t x = (uint32_t)ev[t * 4 + kFaceC[f][0]], y = (uint32_t)ev[t * 4 + kFaceC[f][1]], z = (uint32_t)ev[t * 4 + kFaceC[f][2]];
+            const uint64_t lo = min(x, min(y, z)), hi = max(x, max(y, z)), mid = x ^ y ^ z ^ lo ^ hi;
+            key[k] = (lo << 42) | (mid << 21) | hi;
+        } else {
+            const int64_t t = k / 3;
+            const int c = (int)(k - t * 3);
+            const uint64_t tail = (uint32_t)ev[t * 3 + (c + 1) % 3], tip = (uint32_t)ev[t * 3 + (c + 2) % 3];
+            key[k] = (min(tail, tip) << 32) | max(tail, tip);
+        }
+        val[k] = (uint32_t)k;
+    }
+}
+// flag: 1 = unmatched (boundary), 2 = more than two incident (non-manifold)
+__global__ void __launch_bounds__(256) k_topo_face_flags(int64_t n, const uint64_t *__restrict__ key, uint32_t *__restrict__ flag, int *nonManifold) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        const bool sameP = k > 0 && key[k] == key[k - 1], sameN = k + 1 < n && key[k] == key[k + 1];
+        flag[k] = (!sameP && !sameN) ? 1u : 0u;
+        if (sameP && sameN) *nonManifold = 1;
+    }
+}
+__global__ void __launch_bounds__(256) k_topo_face_compact(int64_t n, const uint32_t *__restrict__ val, const uint32_t *__restrict__ flag,
+                                                           const uint32_t *__restrict__ posP1, uint32_t *__restrict__ out) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
+        if (flag[k]) out[posP1[k] - 1] = val[k];
+}
+} // namespace
+
+// Returns false when the mesh does not fit the packed keys (>= 2^21 vertices in 3D): the caller then uses
+// the host implementation. instEdge: nElem*nedge first-encounter edge-node ranks (deg 2 only);
+// bdryInst: half-face (4t+f) / half-edge (3t+c) instances without a mate, in sorted-key order.
+bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *hostElemVerts, hipStream_t s,
+                           std::vector<int32_t> &instEdge, int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst) {
+    if (dim == 3 && nVert >= (1 << 21)) return false;
+    const int nv = dim + 1, nedge = dim == 3 ? 6 : 3;
+    DBuf<int32_t> dEv;
+    dEv.upload(hostElemVerts, (size_t)nElem * nv, s);
+    DBuf<char> tmp;
+    auto ensureTmp = [&](size_t bytes) { if (bytes + 16 > tmp.n) tmp.alloc(bytes + 16); };
+    nEdgeNodes = 0;
+    instEdge.clear();
+    if (deg == 2) {
+        const int64_t n = nElem * nedge;
+        DBuf<uint64_t> kA, kB;
+        DBuf<uint32_t> vA, vB, headP1;
+        kA.alloc(n); kB.alloc(n); vA.alloc(n); vB.alloc(n); headP1.alloc(n);
+        hipLaunchKernelGGL(k_topo_edge_keys, dim3(grid_of(n)), dim3(256), 0, s, n, nv, nedge, dEv.p, kA.p, vA.p);
+        size_t b = 0;
+        RP(rocprim::radix_sort_pairs(nullptr, b, kA.p, kB.p, vA.p, vB.p, (size_t)n, 0u, 32 + bits_for((uint64_t)nVert), s));
+        ensureTmp(b);
+        RP(rocprim::radix_sort_pairs(tmp.p, b, kA.p, kB.p, vA.p, vB.p, (size_t)n, 0u, 32 + bits_for((uint64_t)nVert), s));
+        hipLaunchKernelGGL(k_sym_heads, dim3(grid_of(n)), dim3(256), 0, s, n, kB.p, headP1.p);
+        RP(rocprim::inclusive_scan(nullptr, b, headP1.p, headP1.p, (size_t)n, rocprim::plus<uint32_t>(), s));
+        ensureTmp(b);
+        RP(rocprim::inclusive_scan(tmp.p, b, headP1.p, headP1.p, (size_t)n, rocprim::plus<uint32_t>(), s));
+        uint32_t nU = 0;
+        MFH_HIP(hipMemcpyAsync(&nU, headP1.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MFH_HIP(hipStreamSynchronize(s));
+        nEdgeNodes = (int32_t)nU;
+        // order the unique edges by their first instance = first-encounter numbering
+        DBuf<uint32_t> firstInst, firstSorted, uniqId, uniqByFirst, rankOfUniq;
+        firstInst.alloc(nU); firstSorted.alloc(nU); uniqId.alloc(nU); uniqByFirst.alloc(nU); rankOfUniq.alloc(nU);
+        hipLaunchKernelGGL(k_topo_edge_first, dim3(grid_of(n)), dim3(256), 0, s, n, kB.p, vB.p, headP1.p, firstInst.p);
+        hipLaunchKernelGGL(k_topo_iota, dim3(grid_of(nU)), dim3(256), 0, s, (int64_t)nU, uniqId.p);
+        RP(rocprim::radix_sort_pairs(nullptr, b, firstInst.p, firstSorted.p, uniqId.p, uniqByFirst.p, (size_t)nU, 0u, bits_for((uint64_t)n), s));
+        ensureTmp(b);
+        RP(rocprim::radix_sort_pairs(tmp.p, b, firstInst.p, firstSorted.p, uniqId.p, uniqByFirst.p, (size_t)nU, 0u, bits_for((uint64_t)n), s));
+        hipLaunchKernelGGL(k_topo_rank, dim3(grid_of(nU)), dim3(256), 0, s, (int64_t)nU, uniqByFirst.p, rankOfUniq.p);
+        DBuf<int32_t> dInst;
+        dInst.alloc(n);
+        hipLaunchKernelGGL(k_topo_edge_assign, dim3(grid_of(n)), dim3(256), 0, s, n, vB.p, headP1.p, rankOfUniq.p, dInst.p);
+        RP(hipGetLastError());
+        instEdge.resize((size_t)n);
+        dInst.download(instEdge.data(), (size_t)n, s);
+    }
+    {   // boundary half-faces / half-edges
+        const int64_t n = nElem * (dim == 3 ? 4 : 3);
+        DBuf<uint64_t> kA, kB;
+        DBuf<uint32_t> vA, vB, flag, posP1, out;
+        DBuf<int> nm;
+        kA.alloc(n); kB.alloc(n); vA.alloc(n); vB.alloc(n); flag.alloc(n); posP1.alloc(n); nm.alloc(1);
+        nm.zero(s);
+        hipLaunchKernelGGL(k_topo_face_keys, dim3(grid_of(n)), dim3(256), 0, s, n, dim, dEv.p, kA.p, vA.p);
+        size_t b = 0;
+        const unsigned endBit = dim == 3 ? 63u : 32 + bits_for((uint64_t)nVert);
+        RP(rocprim::radix_sort_pairs(nullptr, b, kA.p, kB.p, vA.p, vB.p, (size_t)n, 0u, endBit, s));
+        ensureTmp(b);
+        RP(rocprim::radix_sort_pairs(tmp.p, b, kA.p, kB.p, vA.p, vB.p, (size_t)n, 0u, endBit, s));
+        hipLaunchKernelGGL(k_topo_face_flags, dim3(grid_of(n)), dim3(256), 0, s, n, kB.p, flag.p, nm.p);
+        RP(rocprim::inclusive_scan(nullptr, b, flag.p, posP1.p, (size_t)n, rocprim::plus<uint32_t>(), s));
+        ensureTmp(b);
+        RP(rocprim::inclusive_scan(tmp.p, b, flag.p, posP1.p, (size_t)n, rocprim::plus<uint32_t>(), s));
+        uint32_t nB = 0;
+        int nonManifold = 0;
+        MFH_HIP(hipMemcpyAsync(&nB, posP1.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MFH_HIP(hipMemcpyAsync(&nonManifold, nm.p, sizeof(int), hipMemcpyDeviceToHost, s));
+        MFH_HIP(hipStreamSynchronize(s));
+        if (nonManifold) throw Error(MFH_ERR_INVALID, dim == 3 ? "Non-manifold input detected." : "Non-manifold edge detected");
+        out.alloc(std::max<uint32_t>(nB, 1));
+        hipLaunchKernelGGL(k_topo_face_compact, dim3(grid_of(n)), dim3(256), 0, s, n, vB.p, flag.p, posP1.p, out.p);
+        RP(hipGetLastError());
+        bdryInst.resize(nB);
+        out.download(bdryInst.data(), nB, s);
+    }
+    return true;
+}
+
 } // namespace mfh

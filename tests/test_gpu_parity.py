@@ -580,3 +580,24 @@ def test_device_symbolic_identical_to_host_symbolic(case):
         assert np.array_equal(a[k], b[k]), k
     assert a["chunk_slots"] == b["chunk_slots"] and a["max_row_len"] == b["max_row_len"] and a["n_contrib"] == b["n_contrib"]
     assert abs(a["K"] - b["K"]).max() <= 1e-13 * abs(b["K"]).max()
+
+
+@pytest.mark.parametrize("dim,deg", [(3, 1), (3, 2), (2, 2)])
+def test_device_topology_identical_to_host(dim, deg):
+    """FEMMesh numbering built with device radix sorts == host hash/sort implementation == oracle."""
+    if dim == 3:
+        V, T = _porous_cell(4)                  # has interior boundary (void) as well
+    else:
+        V, T = grid.grid_tri_mesh(7, 5)
+    m = O.FEMMesh(T, V, deg)
+    for dev in (1, 0):
+        c = _ctx()
+        c.set_option("topology_device", dev)
+        c.mesh_build(T, V, deg)
+        assert np.array_equal(c.elem_nodes(), m.elem_nodes)
+        assert np.array_equal(c.boundary_elem_nodes(), m.bdry_elem_nodes)
+        assert np.array_equal(c.boundary_nodes(), m.bdry_nodes)
+        assert np.array_equal(c.node_positions(), m.node_pos)
+    c = _ctx()
+    with pytest.raises(M.MeshFEMHipError, match="manifold"):
+        c.mesh_build(np.array([[0, 1, 2, 3], [0, 1, 2, 4], [0, 1, 2, 5]]), np.random.default_rng(0).random((6, 3)), 1)
