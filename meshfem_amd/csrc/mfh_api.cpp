@@ -405,20 +405,41 @@ bool ensure_twolevel(mfh_ctx *c) {
     c->precondNote.clear();
     const HostMesh &m = c->mesh;
     const int d = m.dim;
-    if (!c->dofForNode.empty() || c->sym.nRows != c->sym.nCols) {
-        c->precondNote = "two-level preconditioner unavailable for periodic DoF maps / partitioned rows: using block-Jacobi";
+    if (c->sym.nRows != c->sym.nCols) {
+        c->precondNote = "two-level preconditioner unavailable for partitioned rows: using block-Jacobi";
+        return false;
+    }
+    if (!c->dofForNode.empty() && c->tlProbe) {
+        c->precondNote = "two-level preconditioner: SpMV probing needs lattice-local coupling (no periodic DoF maps); using block-Jacobi";
         return false;
     }
     double t0 = now_ms();
     const int64_t nDoF = c->nDoF;
     // default: ~1000 aggregates (coarse dimension ~6000): setup (Galerkin pass + device dense inverse) ~0.3 s
     int target = c->aggNodes > 0 ? c->aggNodes : (int)std::max<int64_t>(512, nDoF / 1000);
+    // position of a DoF = position of its first node (identity map: the node itself). With a periodic map the
+    // modes of aggregates at the seam are no longer exact rigid motions, but any full-rank Z is a valid
+    // Galerkin coarse space.
+    std::vector<double> dofPosStore;
+    const std::vector<double> *dofPosPtr = &m.nodePos;
+    if (!c->dofForNode.empty()) {
+        dofPosStore.assign((size_t)nDoF * d, 0.0);
+        std::vector<uint8_t> seen((size_t)nDoF, 0);
+        for (int64_t n = 0; n < m.nNode; ++n) {
+            const int32_t q = c->dofForNode[n];
+            if (seen[q]) continue;
+            seen[q] = 1;
+            for (int a = 0; a < d; ++a) dofPosStore[(size_t)q * d + a] = m.nodePos[(size_t)n * d + a];
+        }
+        dofPosPtr = &dofPosStore;
+    }
+    const std::vector<double> &dofPos = *dofPosPtr;
     Aggregates A;
     for (int attempt = 0; attempt < 6; ++attempt) {
-        build_aggregates(d, nDoF, m.nodePos, target, A);
+        build_aggregates(d, nDoF, dofPos, target, A);
         // K couples only DoFs of one element: every element must fit into adjacent bins
         std::vector<uint8_t> bad((size_t)host_threads() + 1, 0);
-        parallel_ranges(m.nElem, [&](int64_t eb, int64_t ee, int tid) {
+        if (c->tlProbe) parallel_ranges(m.nElem, [&](int64_t eb, int64_t ee, int tid) {
             for (int64_t e = eb; e < ee; ++e) {
                 const int32_t *c0 = &A.binCoord[(size_t)A.aggOfDof[m.elemNodes[(size_t)e * m.npe]] * 3];
                 for (int k2 = 1; k2 < m.npe; ++k2) {
@@ -440,7 +461,7 @@ bool ensure_twolevel(mfh_ctx *c) {
     T.m = (int64_t)T.nAgg * T.nModes;
     std::vector<double> relPos((size_t)nDoF * 3, 0.0);
     for (int64_t n = 0; n < nDoF; ++n)
-        for (int a = 0; a < d; ++a) relPos[(size_t)n * 3 + a] = (m.nodePos[(size_t)n * d + a] - A.centroid[(size_t)A.aggOfDof[n] * 3 + a]) / A.H;
+        for (int a = 0; a < d; ++a) relPos[(size_t)n * 3 + a] = (dofPos[(size_t)n * d + a] - A.centroid[(size_t)A.aggOfDof[n] * 3 + a]) / A.H;
     hipStream_t s = c->stream;
     T.aggOfDof.upload(A.aggOfDof, s); T.relPos.upload(relPos, s); T.aggPtr.upload(A.aggPtr, s); T.dofsByAgg.upload(A.dofsByAgg, s);
     T.colorOfAgg.upload(A.colorOfAgg, s); T.nbrOfColor.upload(A.nbrOfColor, s);

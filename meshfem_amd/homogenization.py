@@ -54,12 +54,15 @@ def homogenized_elasticity_tensor(sim: Simulator, w_ij, base_cell_volume=0.0):
     return Eh
 
 
-def homogenize(vertices, elements, degree=2, Cbase=None, E=None, nu=None, ortho_params=None, device=0, rtol=1e-8):
+def homogenize(vertices, elements, degree=2, Cbase=None, E=None, nu=None, ortho_params=None, device=0, rtol=1e-8,
+              preconditioner=None):
     """Returns dict(Ch, w_ij, strain_w_ij, iterations) like the reference's `homogenize`.
     Material: `Cbase` (flattened D or an object with .D) for a homogeneous base material, or
     per-element `E`/`nu`, or per-element orthotropic parameters."""
     sim = Simulator(elements, vertices, degree, device)
     sim.rtol = rtol
+    if preconditioner is not None:
+        sim.ctx.set_preconditioner(preconditioner)
     if Cbase is not None:
         sim.setMaterial(Cbase)
     elif ortho_params is not None:
