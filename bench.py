@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--maxit", type=int, default=20000)
     ap.add_argument("--no-solve", action="store_true")
+    ap.add_argument("--coarse-aggregates", type=int, default=0,
+                    help="N>1: global aggregates of the two-level preconditioner (0 = min(1000 N, 2048); -1 = block-Jacobi only)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid size of the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
@@ -196,10 +198,14 @@ def run_multi(args):
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     res = D.bench_slabs(args, rank, world, local)
-    if rank == 0:
-        print(json.dumps(res), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+    # RCCL writes its version banner through C stdio, which is flushed late when stdout is a pipe:
+    # flush it first so that the JSON line is the last line of the output
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":

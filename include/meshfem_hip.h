@@ -228,6 +228,16 @@ mfh_status mfh_average_stress(mfh_ctx* ctx, const double* uNodes, double* stress
 mfh_status mfh_dev_spmv(mfh_ctx* ctx, const double* x_dev, double* y_dev);
 /* z = M^-1 r on the owned rows (block-Jacobi of the assembled K, fixed variables decoupled)     */
 mfh_status mfh_dev_precond(mfh_ctx* ctx, const double* r_dev, double* z_dev);
+/* Two-level preconditioner with CALLER-supplied aggregates (row-partitioned contexts; the aggregates are global,
+ * the caller reduces over ranks): begin() takes, for every local node (owned then halo), its aggregate id in
+ * [0,nAgg) and relPos = (position - aggregate centre)/H (3 doubles per node, z = 0 in 2D), and writes this
+ * rank's Galerkin contribution Z^T K_ownedRows Z (m x m row-major, m = nAgg * (dim==3 ? 6 : 3)) into Ac_dev.
+ * The fixed-variable mask must cover halo nodes as well. After summing Ac_dev over ranks, finish() inverts it on
+ * the device. restrict: rc[m] = Z_owned^T r (to be summed over ranks); apply: z = D^-1 r + Z_owned (A_c^-1 rc). */
+mfh_status mfh_tl_partitioned_begin(mfh_ctx* ctx, int32_t nAgg, const int32_t* aggOfNode, const double* relPos, double* Ac_dev);
+mfh_status mfh_tl_partitioned_finish(mfh_ctx* ctx, const double* Ac_dev);
+mfh_status mfh_dev_tl_restrict(mfh_ctx* ctx, const double* r_dev, double* rc_dev);
+mfh_status mfh_dev_tl_apply(mfh_ctx* ctx, const double* r_dev, const double* rc_dev, double* z_dev);
 /* r[fixed] = 0 */
 mfh_status mfh_dev_mask_fixed(mfh_ctx* ctx, double* r_dev);
 /* copy the fixed-variable values into u (u[fixed] = value) */

@@ -87,6 +87,10 @@ PROTOTYPES = {
     "mfh_average_stress": (_i32, [_P, _P, _P]),
     "mfh_dev_spmv": (_i32, [_P, _P, _P]),
     "mfh_dev_precond": (_i32, [_P, _P, _P]),
+    "mfh_tl_partitioned_begin": (_i32, [_P, _i32, _P, _P, _P]),
+    "mfh_tl_partitioned_finish": (_i32, [_P, _P]),
+    "mfh_dev_tl_restrict": (_i32, [_P, _P, _P]),
+    "mfh_dev_tl_apply": (_i32, [_P, _P, _P, _P]),
     "mfh_dev_mask_fixed": (_i32, [_P, _P]),
     "mfh_dev_set_fixed_values": (_i32, [_P, _P]),
     "mfh_dev_sync": (_i32, [_P]),

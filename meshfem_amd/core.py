@@ -321,6 +321,26 @@ class Context:
     def dev_precond(self, r_ptr, z_ptr):
         self._ck(self.lib.mfh_dev_precond(self.h, C.c_void_p(r_ptr), C.c_void_p(z_ptr)))
 
+    def tl_partitioned_begin(self, n_agg, agg_of_node, rel_pos, ac_ptr):
+        """Caller-supplied (global) aggregates: this context's Galerkin contribution into the device
+        buffer at ac_ptr ((n_agg*modes)^2 doubles)."""
+        agg = np.ascontiguousarray(agg_of_node, dtype=np.int32)
+        rp = np.ascontiguousarray(rel_pos, dtype=np.float64)
+        n_local = self.matrix_info()[1]
+        if agg.shape != (n_local,) or rp.shape != (n_local, 3):
+            raise ValueError("agg_of_node / rel_pos must cover every local node")
+        self._ck(self.lib.mfh_tl_partitioned_begin(self.h, int(n_agg), agg.ctypes.data_as(C.c_void_p),
+                                                   rp.ctypes.data_as(C.c_void_p), C.c_void_p(ac_ptr)))
+
+    def tl_partitioned_finish(self, ac_ptr):
+        self._ck(self.lib.mfh_tl_partitioned_finish(self.h, C.c_void_p(ac_ptr)))
+
+    def dev_tl_restrict(self, r_ptr, rc_ptr):
+        self._ck(self.lib.mfh_dev_tl_restrict(self.h, C.c_void_p(r_ptr), C.c_void_p(rc_ptr)))
+
+    def dev_tl_apply(self, r_ptr, rc_ptr, z_ptr):
+        self._ck(self.lib.mfh_dev_tl_apply(self.h, C.c_void_p(r_ptr), C.c_void_p(rc_ptr), C.c_void_p(z_ptr)))
+
     def dev_mask_fixed(self, r_ptr):
         self._ck(self.lib.mfh_dev_mask_fixed(self.h, C.c_void_p(r_ptr)))
 

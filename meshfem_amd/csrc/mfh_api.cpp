@@ -392,9 +392,41 @@ void ensure_precond(mfh_ctx *c) {
 
 k::TLArgs tl_args(mfh_ctx *c) {
     k::TLArgs t{};
-    t.dim = c->dim(); t.nModes = c->tl.nModes; t.nAgg = c->tl.nAgg; t.nDoF = c->nDoF;
+    t.dim = c->dim(); t.nModes = c->tl.nModes; t.nAgg = c->tl.nAgg; t.nDoF = c->sym.nRows;   // loops run over the owned rows
     t.aggOfDof = c->tl.aggOfDof.p; t.relPos = c->tl.relPos.p; t.fixedMask = c->fixedVars.empty() ? nullptr : c->dFixedMask.p;
     return t;
+}
+
+// Coarse operator -> its inverse, all in HBM: symmetrise + regularise (modes without support are
+// decoupled), blocked Cholesky inverse. Ac: raw m x m row-major device matrix (left untouched).
+bool tl_invert_device(mfh_ctx *c, const double *Ac, bool noteOnFailure) {
+    auto &T = c->tl;
+    hipStream_t s = c->stream;
+    const int64_t mm = T.m;
+    std::vector<double> diag((size_t)mm);
+    // pitch of (m + 1) doubles walks the diagonal
+    MFH_HIP(hipMemcpy2DAsync(diag.data(), sizeof(double), Ac, (size_t)(mm + 1) * sizeof(double), sizeof(double), (size_t)mm,
+                             hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    double maxd = 0;
+    for (double v : diag) maxd = std::max(maxd, v);
+    if (!(maxd > 0)) maxd = 1.0;
+    std::vector<uint8_t> dead((size_t)mm);
+    for (int64_t i = 0; i < mm; ++i) dead[i] = !(diag[i] > 1e-12 * maxd);   // mode without support: decoupled
+    DBuf<uint8_t> dDead;
+    dDead.upload(dead, s);
+    const int64_t mp = ((mm + 63) / 64) * 64;
+    DBuf<double> Ap, X, Dtile;
+    DBuf<int> flag;
+    Ap.alloc((size_t)mp * mp); X.alloc((size_t)mp * mp); Dtile.alloc((size_t)(mp / 64) * 64 * 64); flag.alloc(1);
+    T.Ainv.alloc((size_t)mp * mp);
+    k::launch_tl_prep(mm, mp, Ac, dDead.p, maxd, Ap.p, s);
+    if (!k::dense_spd_inverse_device(Ap.p, X.p, T.Ainv.p, Dtile.p, mp, flag.p, s)) {
+        if (noteOnFailure) c->precondNote = "two-level preconditioner: coarse operator not positive definite; using block-Jacobi";
+        return false;
+    }
+    T.ldInv = mp;
+    return true;
 }
 
 // Coarse space setup: aggregates, probing of Z^T K Z with 3^dim colours x nModes masked SpMVs, dense
@@ -486,31 +518,8 @@ bool ensure_twolevel(mfh_ctx *c) {
     }
     const int64_t mm = T.m;
     if (!c->tlHostInverse) {
-        // ---- device path: symmetrise/regularise + blocked Cholesky inverse, all in HBM
-        std::vector<double> diag((size_t)mm);
-        // pitch of (m + 1) doubles walks the diagonal
-        MFH_HIP(hipMemcpy2DAsync(diag.data(), sizeof(double), Ac.p, (size_t)(mm + 1) * sizeof(double), sizeof(double), (size_t)mm,
-                                 hipMemcpyDeviceToHost, s));
-        MFH_HIP(hipStreamSynchronize(s));
-        double maxd = 0;
-        for (double v : diag) maxd = std::max(maxd, v);
-        if (!(maxd > 0)) maxd = 1.0;
-        std::vector<uint8_t> dead((size_t)mm);
-        for (int64_t i = 0; i < mm; ++i) dead[i] = !(diag[i] > 1e-12 * maxd);   // mode without support: decoupled
-        DBuf<uint8_t> dDead;
-        dDead.upload(dead, s);
-        const int64_t mp = ((mm + 63) / 64) * 64;
-        DBuf<double> Ap, X, Dtile;
-        DBuf<int> flag;
-        Ap.alloc((size_t)mp * mp); X.alloc((size_t)mp * mp); Dtile.alloc((size_t)(mp / 64) * 64 * 64); flag.alloc(1);
-        T.Ainv.alloc((size_t)mp * mp);
-        k::launch_tl_prep(mm, mp, Ac.p, dDead.p, maxd, Ap.p, s);
+        if (!tl_invert_device(c, Ac.p, true)) return false;
         Ac.release();
-        if (!k::dense_spd_inverse_device(Ap.p, X.p, T.Ainv.p, Dtile.p, mp, flag.p, s)) {
-            c->precondNote = "two-level preconditioner: coarse operator not positive definite; using block-Jacobi";
-            return false;
-        }
-        T.ldInv = mp;
     } else {
     std::vector<double> hA((size_t)T.m * T.m);
     Ac.download(hA.data(), hA.size(), s);
@@ -1430,6 +1439,75 @@ mfh_status mfh_dev_precond(mfh_ctx *c, const double *r_dev, double *z_dev) {
     k::launch_precond(c->dim(), c->sym.nRows, c->dDinv.p, r_dev, z_dev, c->stream);
     MFH_CATCH(c)
 }
+// ---- two-level preconditioner on a row-partitioned context: the caller owns the (global) aggregates
+// and the reduction over ranks; the library owns Z (implicit), the Galerkin pass over its rows, the
+// dense inverse and the restrict / prolong kernels. Works on an unpartitioned context too.
+mfh_status mfh_tl_partitioned_begin(mfh_ctx *c, int32_t nAgg, const int32_t *aggOfNode, const double *relPos, double *Ac_dev) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && aggOfNode && relPos && Ac_dev && nAgg > 0, MFH_ERR_INVALID, "bad two-level arguments");
+    require(c->dofForNode.empty(), MFH_ERR_UNSUPPORTED, "caller-supplied aggregates need the identity DoF map");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_precond(c);
+    auto &T = c->tl;
+    T.valid = false;
+    const int d = c->dim();
+    const int64_t nLocal = c->nDoF, nRows = c->sym.nRows;
+    double t0 = now_ms();
+    T.nModes = d == 3 ? 6 : 3;
+    T.nAgg = nAgg; T.nColor = 0; T.H = 1.0;
+    T.m = (int64_t)nAgg * T.nModes;
+    std::vector<int32_t> agg(aggOfNode, aggOfNode + nLocal), aggPtr((size_t)nAgg + 1, 0), byAgg((size_t)nRows);
+    for (int64_t n = 0; n < nLocal; ++n) require(agg[n] >= 0 && agg[n] < nAgg, MFH_ERR_INVALID, "aggregate id out of range");
+    for (int64_t n = 0; n < nRows; ++n) aggPtr[(size_t)agg[n] + 1]++;
+    for (int a = 0; a < nAgg; ++a) aggPtr[(size_t)a + 1] += aggPtr[a];
+    {
+        std::vector<int32_t> cur(aggPtr.begin(), aggPtr.end() - 1);
+        for (int64_t n = 0; n < nRows; ++n) byAgg[(size_t)cur[agg[n]]++] = (int32_t)n;
+    }
+    std::vector<double> rp(relPos, relPos + (size_t)nLocal * 3);
+    hipStream_t s = c->stream;
+    T.aggOfDof.upload(agg, s); T.relPos.upload(rp, s); T.aggPtr.upload(aggPtr, s); T.dofsByAgg.upload(byAgg, s);
+    T.rc.alloc((size_t)T.m); T.yc.alloc((size_t)T.m);
+    MFH_HIP(hipMemsetAsync(Ac_dev, 0, (size_t)T.m * T.m * sizeof(double), s));
+    k::launch_tl_rap(tl_args(c), nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac_dev, s);
+    MFH_HIP(hipStreamSynchronize(s));
+    T.setup_ms = now_ms() - t0;
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_tl_partitioned_finish(mfh_ctx *c, const double *Ac_dev) {
+    MFH_TRY(c)
+    require(c && Ac_dev && c->tl.m > 0 && c->tl.aggOfDof.p, MFH_ERR_STATE, "mfh_tl_partitioned_begin has not run");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    double t0 = now_ms();
+    if (!tl_invert_device(c, Ac_dev, false)) throw Error(MFH_ERR_NOT_CONVERGED, "two-level preconditioner: coarse operator not positive definite");
+    c->tl.setup_ms += now_ms() - t0;
+    c->tl.valid = true;
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_dev_tl_restrict(mfh_ctx *c, const double *r_dev, double *rc_dev) {
+    MFH_TRY(c)
+    require(c && r_dev && rc_dev, MFH_ERR_INVALID, "null argument");
+    require(c->tl.valid, MFH_ERR_STATE, "two-level preconditioner is not set up");
+    MFH_HIP(hipSetDevice(c->device));
+    k::launch_tl_restrict(tl_args(c), c->tl.aggPtr.p, c->tl.dofsByAgg.p, r_dev, rc_dev, c->stream);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_dev_tl_apply(mfh_ctx *c, const double *r_dev, const double *rc_dev, double *z_dev) {
+    MFH_TRY(c)
+    require(c && r_dev && rc_dev && z_dev, MFH_ERR_INVALID, "null argument");
+    require(c->tl.valid, MFH_ERR_STATE, "two-level preconditioner is not set up");
+    MFH_HIP(hipSetDevice(c->device));
+    auto &T = c->tl;
+    k::launch_tl_gemv(T.m, T.ldInv, T.Ainv.p, rc_dev, T.yc.p, c->stream);
+    k::launch_tl_apply(tl_args(c), c->dDinv.p, r_dev, T.yc.p, z_dev, nullptr, -1, nullptr, c->stream);
+    MFH_CATCH(c)
+}
+
 mfh_status mfh_dev_mask_fixed(mfh_ctx *c, double *r_dev) {
     MFH_TRY(c)
     require(c && r_dev, MFH_ERR_INVALID, "null argument");

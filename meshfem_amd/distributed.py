@@ -64,6 +64,12 @@ def partition(elem_nodes, node_pos, node_keys, node_owner, rank):
                      np.flatnonzero(keep))
 
 
+def _needs_staging(device, group=None):
+    """gloo moves host memory: device tensors are staged through the host (2-ranks-on-1-GPU tests).
+    With nccl (= RCCL) buffers go GPU to GPU over xGMI."""
+    return torch.device(device).type == "cuda" and dist.is_initialized() and dist.get_backend(group) == "gloo"
+
+
 class HaloExchange:
     """Point-to-point exchange lists. Every rank asks the owners for its halo nodes by key."""
 
@@ -88,23 +94,31 @@ class HaloExchange:
                 raise RuntimeError("halo request for a node this rank does not own")
             self.send_idx[q] = torch.as_tensor(idx, dtype=torch.long, device=device)
         self.recv_range = dict(lm.halo_ranges)
-        self.bytes_per_exchange = 0
+        self.stage = _needs_staging(device, group)
 
     def exchange(self, v, dim):
         """v: flat tensor of n_local*dim; fills the halo part from the owners."""
         if self.world == 1:
             return
         v2 = v.view(-1, dim)
-        ops, keep = [], []
+        ops, keep, staged = [], [], []
         for q, idx in sorted(self.send_idx.items()):
             buf = v2[idx].contiguous()
+            if self.stage:
+                buf = buf.cpu()
             keep.append(buf)
             ops.append(dist.P2POp(dist.isend, buf, q, group=self.group))
         for q, (s, e) in sorted(self.recv_range.items()):
-            ops.append(dist.P2POp(dist.irecv, v2[s:e], q, group=self.group))
+            dst = v2[s:e]
+            if self.stage:
+                dst = torch.empty(dst.shape, dtype=v.dtype)
+                staged.append((s, e, dst))
+            ops.append(dist.P2POp(dist.irecv, dst, q, group=self.group))
         if ops:
             for r in dist.batch_isend_irecv(ops):
                 r.wait()
+        for s, e, t in staged:
+            v2[s:e] = t.to(v.device)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -136,23 +150,113 @@ class HipLocalOps:
     def set_fixed_values(self, u):
         self.ctx.dev_set_fixed_values(u.data_ptr())
 
+    # two-level preconditioner building blocks (global aggregates; DistributedTwoLevel reduces over ranks)
+    def tl_begin(self, n_agg, agg_of_node, rel_pos):
+        m = n_agg * (6 if self.dim == 3 else 3)
+        Ac = torch.empty((m, m), dtype=torch.float64, device=self.device)
+        self.ctx.tl_partitioned_begin(n_agg, agg_of_node, rel_pos, Ac.data_ptr())
+        return Ac
+
+    def tl_finish(self, Ac):
+        self.ctx.tl_partitioned_finish(Ac.data_ptr())
+
+    def tl_restrict(self, r, rc):
+        self.ctx.dev_tl_restrict(r.data_ptr(), rc.data_ptr())
+
+    def tl_apply(self, r, rc, z):
+        self.ctx.dev_tl_apply(r.data_ptr(), rc.data_ptr(), z.data_ptr())
+
 
 # ------------------------------------------------------------------------------------------------
 # distributed PCG (classic, two all-reduces per iteration)
 # ------------------------------------------------------------------------------------------------
-def _allreduce(vals, device, group):
+def _allreduce(vals, device, group, op=None):
     t = torch.stack(vals) if isinstance(vals, (list, tuple)) else vals
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.all_reduce(t, group=group)
+        op = dist.ReduceOp.SUM if op is None else op
+        if _needs_staging(t.device, group):
+            h = t.cpu()
+            dist.all_reduce(h, op=op, group=group)
+            t.copy_(h)
+        else:
+            dist.all_reduce(t, op=op, group=group)
     return t
 
 
-def distributed_pcg(ops, halo, f_owned, rtol=1e-8, maxit=20000, group=None, check_every=25):
+def extend_fixed_to_halo(halo, n_local, dim, owned_vars, owned_vals, device):
+    """Fixed variables are known to the owner of a node; the Galerkin coarse operator needs the mask
+    on halo columns too. Returns (vars, vals) over all local variables (owned + halo)."""
+    m = torch.zeros(n_local * dim, dtype=torch.float64, device=device)
+    v = torch.zeros(n_local * dim, dtype=torch.float64, device=device)
+    idx = torch.as_tensor(np.asarray(owned_vars, dtype=np.int64), device=device)
+    m[idx] = 1.0
+    v[idx] = torch.as_tensor(np.asarray(owned_vals, dtype=np.float64) if owned_vals is not None else np.zeros(len(idx)), device=device)
+    halo.exchange(m, dim)
+    halo.exchange(v, dim)
+    sel = torch.nonzero(m > 0.5).ravel()
+    return sel.cpu().numpy(), v[sel].cpu().numpy()
+
+
+class DistributedTwoLevel:
+    """M^-1 = D^-1 + Z (Z^T K Z)^-1 Z^T with GLOBAL aggregates: geometric bins over the global bounding
+    box, six rigid-body modes per bin (three in 2D). Every rank contributes the Galerkin product of its
+    own rows; one all-reduce of the (small, dense) coarse operator at setup, every rank inverts it
+    redundantly; per application one extra all-reduce of the restricted residual (6 * bins doubles).
+    The local kernels are `ops.tl_*` (HipLocalOps: the library's device kernels)."""
+
+    def __init__(self, ops, halo, node_pos, n_owned, target_aggregates, group=None):
+        self.ops, self.group = ops, group
+        dim = ops.dim
+        dev = ops.zeros(1).device
+        pos = np.asarray(node_pos, dtype=np.float64)
+        lo = _allreduce(torch.as_tensor(pos.min(axis=0), device=dev), dev, group, dist.ReduceOp.MIN).cpu().numpy()
+        hi = _allreduce(torch.as_tensor(pos.max(axis=0), device=dev), dev, group, dist.ReduceOp.MAX).cpu().numpy()
+        ext = np.maximum(hi - lo, 1e-300)
+        H = (np.prod(ext) / max(1, target_aggregates)) ** (1.0 / dim)
+        nb = np.maximum(1, np.rint(ext / H)).astype(np.int64)
+        hb = ext / nb
+        cell = np.minimum(np.floor((pos - lo) / hb).astype(np.int64), nb - 1)
+        cell = np.maximum(cell, 0)
+        agg = cell[:, 0]
+        for a in range(1, dim):
+            agg = agg * nb[a] + cell[:, a]
+        # the owner's binning is authoritative (a node on a bin face must not depend on rounding)
+        t = torch.zeros(len(pos), dtype=torch.float64, device=dev)
+        t[:n_owned] = torch.as_tensor(agg[:n_owned].astype(np.float64), device=dev)
+        halo.exchange(t, 1)
+        agg = np.rint(t.cpu().numpy()).astype(np.int64)
+        cell = np.zeros((len(pos), dim), dtype=np.int64)
+        rem = agg.copy()
+        for a in range(dim - 1, -1, -1):
+            cell[:, a] = rem % nb[a]
+            rem //= nb[a]
+        centre = lo + (cell + 0.5) * hb
+        rel = np.zeros((len(pos), 3))
+        rel[:, :dim] = (pos - centre) / H
+        self.n_agg = int(np.prod(nb))
+        self.bins, self.H = nb, H
+        t0 = time.perf_counter()
+        Ac = ops.tl_begin(self.n_agg, agg.astype(np.int32), rel)
+        _allreduce(Ac, dev, group)
+        ops.tl_finish(Ac)
+        del Ac
+        self.m = self.n_agg * (6 if dim == 3 else 3)
+        self.rc = ops.zeros(self.m)
+        self.setup_s = time.perf_counter() - t0
+
+    def __call__(self, r, z):
+        self.ops.tl_restrict(r, self.rc)
+        _allreduce(self.rc, self.rc.device, self.group)
+        self.ops.tl_apply(r, self.rc, z)
+
+
+def distributed_pcg(ops, halo, f_owned, rtol=1e-8, maxit=20000, group=None, check_every=25, precond=None):
     """Solve K u = f on the free variables; f_owned: this rank's dim*nOwned right-hand side.
     Returns (u_owned, info). All vectors are torch tensors on ops' device."""
     dim = ops.dim
     nr, nc = ops.n_rows, ops.n_cols
     dev = f_owned.device
+    precond = ops.precond if precond is None else precond
     # b = P (f - K ubar): ubar = fixed values on every rank's owned nodes, halo part by exchange
     u0 = ops.zeros(nc)
     ops.set_fixed_values(u0)
@@ -164,7 +268,7 @@ def distributed_pcg(ops, halo, f_owned, rtol=1e-8, maxit=20000, group=None, chec
     x = ops.zeros(nr)
     r = b.clone()
     z = ops.zeros(nr)
-    ops.precond(r, z)
+    precond(r, z)
     p = ops.zeros(nc)
     p[:nr] = z
     Ap = ops.zeros(nr)
@@ -184,7 +288,7 @@ def distributed_pcg(ops, halo, f_owned, rtol=1e-8, maxit=20000, group=None, chec
         alpha = rz / pAp
         x.add_(p[:nr] * alpha)
         r.sub_(Ap * alpha)
-        ops.precond(r, z)
+        precond(r, z)
         red = _allreduce(torch.stack([torch.dot(r, z), torch.dot(r, r)]), dev, group)
         beta = red[0] / rz
         rz = red[0]
@@ -302,21 +406,47 @@ def bench_slabs(args, rank, world, local_rank):
     if not args.no_solve:
         ops = HipLocalOps(c, 3)
         halo = HaloExchange(lm, rank, world, dev)
-        fixed_nodes = np.flatnonzero(lm.lattice[:lm.n_owned, 0] == 0)
+        # u = 0 on x = 0: the mask covers the halo nodes too (needed by the Galerkin coarse operator)
+        fixed_nodes = np.flatnonzero(lm.lattice[:, 0] == 0)
         c.fix_variables((3 * fixed_nodes[:, None] + np.arange(3)[None, :]).ravel())
         f = torch.as_tensor(slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel(), device=dev)
+        n_coarse = getattr(args, "coarse_aggregates", 0)
+        if n_coarse == 0:
+            n_coarse = min(1000 * world, 2048)
+        pre, pre_desc, tl_info = None, "3x3 block-Jacobi", None
+        maxit = args.maxit
+        if n_coarse > 0:
+            pre = DistributedTwoLevel(ops, halo, lm.node_pos, lm.n_owned, n_coarse)
+            pre_desc = "two-level: 3x3 block-Jacobi + rigid-body modes of %d global bins" % pre.n_agg
+            tl_info = dict(bins=[int(b) for b in pre.bins], coarse_dim=int(pre.m), setup_s=pre.setup_s)
+        elif world > 1:
+            # the bar gets longer with N (weak scaling), so block-Jacobi alone needs O(N) more iterations:
+            # measure the per-iteration rate on a bounded number of iterations
+            maxit = min(args.maxit, 3000)
         dist.barrier()
-        # the bar gets longer with N (weak scaling), so block-Jacobi PCG needs O(N) more iterations: the
-        # multi-GPU leg measures the per-iteration rate on a bounded number of iterations
-        maxit = min(args.maxit, 3000) if world > 1 else args.maxit
-        u, info = distributed_pcg(ops, halo, f, rtol=args.rtol, maxit=maxit)
+        u, info = distributed_pcg(ops, halo, f, rtol=args.rtol, maxit=maxit, precond=pre)
         nd = torch.tensor([3.0 * lm.n_owned], dtype=torch.float64, device=dev)
         dist.all_reduce(nd)
         ts = torch.tensor([info["solve_s"]], dtype=torch.float64, device=dev)
         dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        # true residual of the returned displacement, over all ranks
+        full = ops.zeros(ops.n_cols)
+        full[:ops.n_rows] = u
+        halo.exchange(full, 3)
+        Ku = ops.zeros(ops.n_rows)
+        ops.spmv(full, Ku)
+        res = f - Ku
+        ops.mask_fixed(res)
+        fm = f.clone()
+        ops.mask_fixed(fm)
+        nrm = torch.stack([torch.dot(res, res), torch.dot(fm, fm), u.abs().max()])
+        dist.all_reduce(nrm[:2])
+        dist.all_reduce(nrm[2:], op=dist.ReduceOp.MAX)
         out["pcg"] = dict(iterations=info["iterations"], converged=bool(info["converged"]), rtol=args.rtol,
-                          rel_residual=info["rel_residual"], dof=int(nd.item()), solve_s=ts.item(),
+                          rel_residual=info["rel_residual"], true_rel_residual=float(torch.sqrt(nrm[0] / nrm[1]).item()),
+                          max_abs_u=float(nrm[2].item()), dof=int(nd.item()), solve_s=ts.item(),
                           dof_per_s=nd.item() * info["loop_iterations"] / ts.item(),
                           ms_per_iteration=ts.item() / max(1, info["loop_iterations"]) * 1e3,
-                          maxit=maxit, preconditioner="3x3 block-Jacobi", comm="halo P2P + 2 all-reduce / iteration (torch.distributed nccl=RCCL)")
+                          maxit=maxit, preconditioner=pre_desc, two_level=tl_info,
+                          comm="halo P2P + %d all-reduce / iteration (torch.distributed nccl=RCCL)" % (3 if pre else 2))
     return out

@@ -20,8 +20,9 @@ from meshfem_amd import grid
 class OracleLocalOps:
     """Rows of the oracle's global K owned by this rank, columns in the rank's local numbering."""
 
-    def __init__(self, A_local, fixed_mask_owned, fixed_vals_owned, dim=3):
+    def __init__(self, A_local, fixed_mask_owned, fixed_vals_owned, dim=3, fixed_mask_local=None):
         self.A, self.dim = A_local.tocsr(), dim
+        self.fixed_local = fixed_mask_local
         self.n_rows, self.n_cols = A_local.shape
         self.fixed = fixed_mask_owned
         self.fixed_vals = fixed_vals_owned
@@ -49,6 +50,44 @@ class OracleLocalOps:
     def set_fixed_values(self, u):
         idx = np.flatnonzero(self.fixed)
         u[torch.from_numpy(idx)] = torch.from_numpy(self.fixed_vals[idx])
+
+
+    # -- numpy statement of the two-level building blocks (include/meshfem_hip.h: mfh_tl_partitioned_*)
+    def tl_begin(self, n_agg, agg, rel):
+        dim, nm = self.dim, 6 if self.dim == 3 else 3
+        n_local = self.n_cols // dim
+        Z = np.zeros((self.n_cols, n_agg * nm))
+        for n in range(n_local):
+            rx, ry, rz = rel[n]
+            modes = np.zeros((nm, dim))
+            modes[:dim, :dim] = np.eye(dim)
+            if dim == 3:
+                modes[3] = [0, -rz, ry]; modes[4] = [rz, 0, -rx]; modes[5] = [-ry, rx, 0]
+            else:
+                modes[2] = [-ry, rx]
+            Z[n * dim:(n + 1) * dim, agg[n] * nm:(agg[n] + 1) * nm] = modes.T
+        Z[self.fixed_local] = 0.0
+        self.Z, self.Zo = Z, Z[:self.n_rows]
+        return torch.from_numpy(self.Zo.T @ (self.A @ Z))
+
+    def tl_finish(self, Ac):
+        A = Ac.numpy()
+        A = 0.5 * (A + A.T)
+        d = np.diag(A).copy()
+        dead = ~(d > 1e-12 * d.max())
+        A[dead, :] = 0; A[:, dead] = 0
+        A[dead, dead] = d.max()
+        A[np.diag_indices_from(A)] *= 1 + 1e-10
+        self.Ainv = np.linalg.inv(A)
+
+    def tl_restrict(self, r, rc):
+        rc.copy_(torch.from_numpy(self.Zo.T @ r.numpy()))
+
+    def tl_apply(self, r, rc, z):
+        self.precond(r, z)
+        z.add_(torch.from_numpy(self.Zo @ (self.Ainv @ rc.numpy())))
+        f = torch.from_numpy(self.fixed)
+        z[f] = r[f]
 
 
 def _global_problem(n, world):
@@ -92,7 +131,7 @@ def _worker(rank, world, port, n, ret):
         assert abs(K[rows]).sum() == pytest.approx(abs(A_loc).sum(), rel=1e-14)
         fv, fx = sim.dirichlet_vars_and_values()
         gfixed = np.zeros(K.shape[0], bool); gfixed[fv] = True
-        ops = OracleLocalOps(A_loc, gfixed[rows], np.zeros(len(rows)))
+        ops = OracleLocalOps(A_loc, gfixed[rows], np.zeros(len(rows)), fixed_mask_local=gfixed[cols])
         halo = D.HaloExchange(lm, rank, world, torch.device("cpu"))
         # halo exchange moves owner values into halo slots
         v = torch.zeros(lm.n_local * 3, dtype=torch.float64)
@@ -105,7 +144,15 @@ def _worker(rank, world, port, n, ret):
         u, info = D.distributed_pcg(ops, halo, torch.from_numpy(load.ravel()), rtol=1e-10, maxit=5000, check_every=10)
         assert info["converged"]
         err = np.linalg.norm(u.numpy().reshape(-1, 3) - u_ref[gid[:lm.n_owned]]) / np.linalg.norm(u_ref)
-        ret[rank] = (err, info["iterations"], lm.n_owned)
+        # fixed variables travel to the halo copies
+        ev, _ = D.extend_fixed_to_halo(halo, lm.n_local, 3, np.flatnonzero(gfixed[rows]), None, torch.device("cpu"))
+        assert np.array_equal(ev, np.flatnonzero(gfixed[cols]))
+        # two-level preconditioner with global aggregates: same solution, fewer iterations
+        pre = D.DistributedTwoLevel(ops, halo, lm.node_pos, lm.n_owned, 4 * world)
+        u2, info2 = D.distributed_pcg(ops, halo, torch.from_numpy(load.ravel()), rtol=1e-10, maxit=5000, check_every=10, precond=pre)
+        assert info2["converged"]
+        err2 = np.linalg.norm(u2.numpy().reshape(-1, 3) - u_ref[gid[:lm.n_owned]]) / np.linalg.norm(u_ref)
+        ret[rank] = (err, info["iterations"], lm.n_owned, err2, info2["iterations"], pre.n_agg)
     finally:
         dist.destroy_process_group()
 
@@ -128,6 +175,9 @@ def test_two_rank_slab_partition_and_pcg_gloo():
     errs = [ret[r][0] for r in range(world)]
     assert max(errs) < 1e-7, dict(ret)
     assert ret[0][1] == ret[1][1]                       # both ranks agree on the iteration count
+    assert max(ret[r][3] for r in range(world)) < 1e-7, dict(ret)
+    assert ret[0][4] == ret[1][4] and ret[0][4] < ret[0][1], dict(ret)
+    assert ret[0][5] == ret[1][5] >= 2
     # every node is owned exactly once
     V, T = grid.grid_tet_mesh(n, n, n * world)
     assert ret[0][2] + ret[1][2] == O.FEMMesh(T, V, 2).num_nodes
