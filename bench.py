@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--coarse-aggregates", type=int, default=0,
                     help="N>1: global aggregates of the two-level preconditioner (0 = min(1000 N, 2048); -1 = block-Jacobi only)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-orderings", action="store_true", help="skip the shuffled / Morton-ordered mesh variants")
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid size of the CPU-baseline sample (0 = auto)")
     return ap.parse_args()
 
@@ -182,6 +183,23 @@ def run_single(args):
                                         rel_l2_vs_block_jacobi=float(np.linalg.norm(u2 - u) / np.linalg.norm(u)))
         except M.MeshFEMHipError as e:
             out["pcg_two_level"] = str(e)
+    if not args.no_orderings:
+        # the same mesh with shuffled / space-filling-curve numbering (gather locality)
+        c.close()
+        out["variants"]["orderings"] = {"generator": dict(assembly_kernel_ms=k_ms, spmv_kernel_ms=out.get("pcg", {}).get("roofline", {}).get("kernel_ms"))}
+        for mode in ("morton", "shuffle"):
+            try:
+                V2, T2 = grid.reorder_mesh(V, T, mode)
+                c2 = M.Context(0)
+                c2.mesh_build(T2, V2, deg)
+                c2.material_isotropic(200.0, 0.35)
+                c2.assemble()
+                out["variants"]["orderings"][mode] = dict(assembly_kernel_ms=c2.time_assembly_kernel(M.ASSEMBLE_GATHER, 5),
+                                                          spmv_kernel_ms=c2.time_spmv_kernel(10))
+                c2.close()
+                del V2, T2
+            except M.MeshFEMHipError as e:
+                out["variants"]["orderings"][mode] = str(e)
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(deg, args.cpu_grid)
     print(json.dumps(out), flush=True)

@@ -83,3 +83,40 @@ def grid_tri_mesh(sx, sy, min_corner=None, max_corner=None):
     ci = nV + np.arange(nQ)
     tris = np.stack([q, q[:, [1, 2, 3, 0]], np.broadcast_to(ci[:, None], q.shape)], axis=2).reshape(-1, 3)
     return np.concatenate([v, centers]), tris
+
+
+def _morton(q):
+    """Interleave the bits of the integer columns of q (<= 21 bits each) into one uint64 key."""
+    def spread(x):
+        x = x.astype(np.uint64) & np.uint64(0x1FFFFF)
+        x = (x | (x << np.uint64(32))) & np.uint64(0x1F00000000FFFF)
+        x = (x | (x << np.uint64(16))) & np.uint64(0x1F0000FF0000FF)
+        x = (x | (x << np.uint64(8))) & np.uint64(0x100F00F00F00F00F)
+        x = (x | (x << np.uint64(4))) & np.uint64(0x10C30C30C30C30C3)
+        x = (x | (x << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return x
+    key = np.zeros(len(q), dtype=np.uint64)
+    for a in range(q.shape[1]):
+        key |= spread(q[:, a]) << np.uint64(a)
+    return key
+
+
+def reorder_mesh(V, T, mode, seed=0):
+    """Relabel vertices and permute elements: 'shuffle' (uniformly random, the worst case for gather
+    locality) or 'morton' (Z-order space-filling curve on vertex positions / element barycentres).
+    The mesh is the same up to numbering; SURVEY.md section 8(d) asks for these variants next to the
+    generator order."""
+    V, T = np.asarray(V, dtype=np.float64), np.asarray(T)
+    if mode == "shuffle":
+        rng = np.random.default_rng(seed)
+        pv, pe = rng.permutation(len(V)), rng.permutation(len(T))
+    elif mode == "morton":
+        lo, ext = V.min(axis=0), np.maximum(V.max(axis=0) - V.min(axis=0), 1e-300)
+        quant = lambda P: np.minimum(((P - lo) / ext * 2097151.0).astype(np.int64), 2097151)
+        pv = np.argsort(_morton(quant(V)), kind="stable")
+        pe = np.argsort(_morton(quant(V[T].mean(axis=1))), kind="stable")
+    else:
+        raise ValueError("mode must be 'shuffle' or 'morton'")
+    inv = np.empty(len(V), dtype=np.int64)
+    inv[pv] = np.arange(len(V))
+    return V[pv], inv[T[pe]].astype(T.dtype)

@@ -10,6 +10,10 @@
    Dirichlet variables, direct-solve displacements) of a 5x2x2 cantilever, P1 and P2, produced by
    oracle/meshfem_oracle.py. The reference itself cannot be run here (Eigen/SuiteSparse absent), so
    this fixture pins the ORACLE's output across refactors; it is not captured reference output.
+4. example_meshes.npz -- the same for the reference's unstructured example meshes (data files copied from
+   examples/meshes into tests/golden/meshes: cube_cross.msh, ball.msh, 2D_microstructure.msh):
+   direct-solve displacements under box Dirichlet / traction conditions (P1, P2) and periodic
+   homogenization results Ch, w_ij (cube_cross 3D, 2D_microstructure 2D). Oracle output, not reference output.
 """
 import json
 import os
@@ -144,10 +148,47 @@ def cantilever_fixture():
     return out
 
 
+def example_mesh_fixture():
+    from oracle import meshfem_oracle as O
+    from meshfem_amd import mesh_io            # host-only MSH reader (no device code involved)
+    out = {}
+    for name, lo_box, hi_box, trac in (("cube_cross", ([-1e-3] * 3, [0.02, 1.001, 1.001]), ([0.98, -1e-3, -1e-3], [1.001] * 3), [0, -1, 0]),
+                                       ("ball", ([-1e-3] * 3, [1.001, 1.001, 0.12]), ([-1e-3, -1e-3, 0.88], [1.001] * 3), [0.3, 0, -1])):
+        V, E, _ = mesh_io.load_msh(os.path.join(HERE, "meshes", name + ".msh"))
+        for deg in (1, 2):
+            sim = O.Simulator(E, V, deg)
+            sim.set_material_constant(O.ElasticityTensor.isotropic(3, 200.0, 0.35))
+            mn, mx = sim.box_percent(*lo_box); sim.apply_dirichlet_box(mn, mx, [0, 0, 0])
+            mn, mx = sim.box_percent(*hi_box); sim.apply_neumann_box(mn, mx, trac, "traction")
+            fv, _ = sim.dirichlet_vars_and_values()
+            load = sim.neumannLoad()
+            assert len(fv) >= 9 and np.abs(load).sum() > 0, (name, len(fv))
+            Kt = sim.assembleStiffnessMatrix().sum_repeated()
+            out.update({"%s_p%d_u" % (name, deg): sim.solve(), "%s_p%d_load" % (name, deg): load,
+                        "%s_p%d_fixed_vars" % (name, deg): np.array(fv), "%s_p%d_K_nnz" % (name, deg): np.array([Kt.nnz(), int((np.abs(Kt.v) > 1e-12 * np.abs(Kt.v).max()).sum())]),
+                        "%s_p%d_K_checksum" % (name, deg): np.array([Kt.v.sum(), np.abs(Kt.v).sum(), (Kt.v * (1 + Kt.i % 7) * (1 + Kt.j % 5)).sum()])})
+            print(name, deg, "fixed", len(fv), "nnz", Kt.nnz(), flush=True)
+    for name, dim in (("cube_cross", 3), ("2D_microstructure", 2)):
+        V, E, _ = mesh_io.load_msh(os.path.join(HERE, "meshes", name + ".msh"))
+        for deg in (1, 2):
+            sim = O.Simulator(E, V[:, :dim], deg)
+            sim.set_material_constant(O.ElasticityTensor.isotropic(dim, 200.0, 0.35))
+            w = O.solve_cell_problems(sim)
+            Ch = O.homogenized_elasticity_tensor(sim, w)
+            out.update({"%s_hom_p%d_Ch" % (name, deg): Ch, "%s_hom_p%d_w" % (name, deg): np.array(w),
+                        "%s_hom_p%d_ndof" % (name, deg): np.array([sim.numDoFs()])})
+            print(name, "homogenization", deg, np.round(np.diag(Ch), 4), flush=True)
+    return out
+
+
 if __name__ == "__main__":
+    if "--examples-only" in sys.argv:
+        np.savez_compressed(os.path.join(HERE, "example_meshes.npz"), **example_mesh_fixture())
+        sys.exit(0)
     with open(os.path.join(HERE, "quadrature_monomials.json"), "w") as f:
         json.dump(monomial_tables(), f, indent=0)
     np.savez_compressed(os.path.join(HERE, "cantilever_small.npz"), **cantilever_fixture())
+    np.savez_compressed(os.path.join(HERE, "example_meshes.npz"), **example_mesh_fixture())
     with open(os.path.join(HERE, "ke_exact.json"), "w") as f:
         json.dump(ke_fixtures(), f)
     print("done")

@@ -620,3 +620,64 @@ def test_device_topology_identical_to_host(dim, deg):
     c = _ctx()
     with pytest.raises(M.MeshFEMHipError, match="manifold"):
         c.mesh_build(np.array([[0, 1, 2, 3], [0, 1, 2, 4], [0, 1, 2, 5]]), np.random.default_rng(0).random((6, 3)), 1)
+
+
+# ---- the reference's unstructured example meshes (tests/golden/meshes) against the committed oracle goldens
+EXAMPLE_BCS = {"cube_cross": (([-1e-3] * 3, [0.02, 1.001, 1.001]), ([0.98, -1e-3, -1e-3], [1.001] * 3), [0, -1, 0]),
+               "ball": (([-1e-3] * 3, [1.001, 1.001, 0.12]), ([-1e-3, -1e-3, 0.88], [1.001] * 3), [0.3, 0, -1])}
+
+
+def _gold(name):
+    import os
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", name)
+
+
+@pytest.mark.parametrize("name", ["cube_cross", "ball"])
+@pytest.mark.parametrize("deg", [1, 2])
+@pytest.mark.parametrize("precond", ["block_jacobi", "two_level"])
+def test_example_meshes_solve_matches_golden(name, deg, precond):
+    """Unstructured tets (Gmsh output, irregular valence): BC regions, load, Dirichlet set bit-exact /
+    1e-13; displacements within the north-star tolerance of the committed direct solve."""
+    from meshfem_amd import mesh_io
+    g = np.load(_gold("example_meshes.npz"))
+    V, E, _ = mesh_io.load_msh(_gold("meshes/%s.msh" % name))
+    lo_box, hi_box, trac = EXAMPLE_BCS[name]
+    sim = M.Simulator(E, V, deg)
+    sim.setIsotropicMaterial(200.0, 0.35)
+    sim.ctx.bc_dirichlet_box(lo_box[0], lo_box[1], [0, 0, 0], relative=True)      # "box%" regions
+    sim.ctx.bc_neumann_box(hi_box[0], hi_box[1], trac, kind=M.NEUMANN_TRACTION, relative=True)
+    key = "%s_p%d_" % (name, deg)
+    load = sim.ctx.neumann_load()
+    assert np.abs(load - g[key + "load"]).max() < 1e-13
+    fv, _ = sim.ctx.bc_dirichlet_vars()
+    assert np.array_equal(np.sort(fv), np.sort(g[key + "fixed_vars"]))
+    sim.rtol = 1e-10
+    if precond == "two_level":
+        sim.ctx.set_preconditioner(M.PRECOND_TWO_LEVEL)
+        sim.ctx.set_option("agg_nodes", 30)
+    u = sim.solve()
+    err = np.linalg.norm(u - g[key + "u"]) / np.linalg.norm(g[key + "u"])
+    assert err < U_RTOL, err
+    i, j, v = sim.ctx.export_upper_triplets()
+    # exact zeros are dropped on both sides (pruneTol = 0, SparseMatrices.hh:370-373); entries that cancel to
+    # round-off in one summation order and to exactly 0 in another are not comparable, significant ones are
+    assert int((np.abs(v) > 1e-12 * np.abs(v).max()).sum()) == g[key + "K_nnz"][1]
+    assert g[key + "K_nnz"][1] <= len(v)
+    chk = np.array([v.sum(), np.abs(v).sum(), (v * (1 + i % 7) * (1 + j % 5)).sum()])
+    assert np.abs(chk - g[key + "K_checksum"]).max() < 1e-10 * np.abs(g[key + "K_checksum"]).max()
+
+
+@pytest.mark.parametrize("name,dim", [("cube_cross", 3), ("2D_microstructure", 2)])
+@pytest.mark.parametrize("deg", [1, 2])
+def test_example_meshes_homogenization_matches_golden(name, dim, deg):
+    from meshfem_amd import mesh_io, homogenization as H
+    g = np.load(_gold("example_meshes.npz"))
+    V, E, _ = mesh_io.load_msh(_gold("meshes/%s.msh" % name))
+    base = O.ElasticityTensor.isotropic(dim, 200.0, 0.35)
+    res = H.homogenize(V[:, :dim], E, deg, Cbase=base.D, rtol=1e-11)
+    key = "%s_hom_p%d_" % (name, deg)
+    assert 1 * res["sim"].numDoFs() == g[key + "ndof"][0]
+    assert np.abs(res["Ch"] - g[key + "Ch"]).max() < 1e-7 * np.abs(g[key + "Ch"]).max()
+    for k in range(len(res["w_ij"])):
+        err = np.linalg.norm(res["w_ij"][k] - g[key + "w"][k]) / np.linalg.norm(g[key + "w"][k])
+        assert err < U_RTOL, (k, err)

@@ -173,3 +173,16 @@ def test_boundary_condition_helpers(deg):
         c.bc_dirichlet_box([-1e-4] * 3, [1e-4, 1.0001, 1.0001], [1, 0, 0], relative=True)
     with pytest.raises(M.MeshFEMHipError, match="already fixed"):
         c.fix_variables([3, 3])
+
+
+def test_reorder_mesh_is_a_relabelling():
+    """grid.reorder_mesh (bench ordering variants): same elements up to numbering, orientation kept."""
+    from meshfem_amd import grid
+    V, T = grid.grid_tet_mesh(3, 2, 2)
+    ref = sorted(map(tuple, V[T].reshape(len(T), -1).round(12).tolist()))
+    for mode in ("shuffle", "morton"):
+        V2, T2 = grid.reorder_mesh(V, T, mode)
+        assert sorted(map(tuple, V2[T2].reshape(len(T), -1).round(12).tolist())) == ref
+        assert not np.array_equal(T2, T)
+    with pytest.raises(ValueError):
+        grid.reorder_mesh(V, T, "hilbert")
