@@ -51,11 +51,19 @@ enum {
 /* Neumann condition kinds (BoundaryConditions.hh NeumannType; LinearElasticity.hh:908-931) */
 enum { MFH_NEUMANN_TRACTION = 0, MFH_NEUMANN_PRESSURE = 1, MFH_NEUMANN_FORCE = 2 };
 
+/* operator assembled into K. The scalar operators run on the same machinery with 1x1 blocks: one variable per
+ * DoF, vectors of length nDoF, `mfh_element_stiffness` gives npe x npe matrices, Dirichlet boxes use value[0]
+ * (PoissonMesh::applyBoundaryConditions, Poisson.hh:57-89), `mfh_sim_solve(f = NULL)` solves with a zero
+ * right-hand side (Poisson.hh:91-117).
+ *   MFH_OP_LAPLACIAN  int grad phi_i . grad phi_j   (Laplacian::construct, Laplacian.hh:27-57; full degree)
+ *   MFH_OP_MASS       int phi_i phi_j               (MassMatrix::construct, MassMatrix.hh:50-86; full degree, not lumped) */
+enum { MFH_OP_ELASTICITY = 0, MFH_OP_LAPLACIAN = 1, MFH_OP_MASS = 2 };
+
 /* preconditioners */
 enum {
     MFH_PRECOND_BLOCK_JACOBI = 0, MFH_PRECOND_JACOBI = 1, MFH_PRECOND_NONE = 2,
     /* block-Jacobi + additive coarse correction on per-aggregate rigid-body modes (falls back to
-     * block-Jacobi for periodic DoF maps / partitioned rows; see mfh_precond_info) */
+     * block-Jacobi for partitioned rows and the scalar operators; see mfh_precond_info) */
     MFH_PRECOND_TWO_LEVEL = 3
 };
 
@@ -173,6 +181,12 @@ mfh_status mfh_export_upper_triplets(mfh_ctx* ctx, uint64_t* i, uint64_t* j, dou
 /* per-element dense Ke (debug/parity): full symmetric (n*dim)^2 row-major, local dof = dim*node+c */
 mfh_status mfh_element_stiffness(mfh_ctx* ctx, int64_t firstElem, int64_t count, double* Ke);
 
+
+/* SPSDSystem<Real>(K) for a CALLER-SUPPLIED symmetric positive (semi-)definite matrix (SparseMatrices.hh:2332-2348;
+ * python binding sparse_matrices.SPSDSystem, sparse_matrices.cc:47-57): upper-triangle triplets, repeated entries
+ * summed. Replaces any mesh in the context; afterwards mfh_fix_variables / mfh_solve / mfh_apply_K /
+ * mfh_export_* work on it (one scalar variable per row, Jacobi-preconditioned CG). */
+mfh_status mfh_matrix_set_upper_triplets(mfh_ctx* ctx, int64_t n, int64_t nnz, const uint64_t* i, const uint64_t* j, const double* v);
 /* ---------------------------------------------------------------- constrained solve
  * mfh_fix_variables == SPSDSystem::fixVariables (SparseMatrices.hh:2389-2500): variables (scalar
  * indices dim*dof+c) pinned to values; K_rf u_f moves to the right-hand side (:2457-2470). Calls
@@ -221,6 +235,11 @@ mfh_status mfh_sim_solve(mfh_ctx* ctx, const double* f /* dim*nDoF or NULL */, i
 /* == averageStrainField / averageStressField (:528-549, :99-123): per element, flattened (flatLen) */
 mfh_status mfh_average_strain(mfh_ctx* ctx, const double* uNodes, double* strain /* nElem x flatLen */);
 mfh_status mfh_average_stress(mfh_ctx* ctx, const double* uNodes, double* stress /* nElem x flatLen */);
+/* Select the operator (default MFH_OP_ELASTICITY). Keeps mesh, DoF map, pattern and gather lists; drops the
+ * assembled values and the fixed variables (their numbering depends on the block size). */
+mfh_status mfh_set_operator(mfh_ctx* ctx, int32_t op);
+/* PoissonMesh::gradUAverage (Poisson.hh:121-131): per-element average gradient of a scalar nodal field */
+mfh_status mfh_average_gradient(mfh_ctx* ctx, const double* uNodes /* nNode */, double* grad /* nElem x dim */);
 
 /* ---------------------------------------------------------------- device-pointer building blocks
  * (multi-GPU driver: local kernels here, RCCL halo exchange / all-reduce in between)           */

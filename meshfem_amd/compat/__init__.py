@@ -1,0 +1,13 @@
+"""Modules named like the reference's pybind11 extension modules (src/python_bindings/CMakeLists.txt:10-33)
+so that scripts written against them run on the MI355X path:
+
+    import sys, meshfem_amd.compat; sys.path.insert(0, meshfem_amd.compat.PATH)
+    import mesh, tensors, sparse_matrices, periodic_homogenization
+
+Only the surface that touches the hot path is provided: `mesh.Mesh`,
+`tensors.ElasticityTensor{2,3}D`, `sparse_matrices.{Triplet, TripletMatrix, SPSDSystem}`,
+`periodic_homogenization.{homogenize, probe}`. They are pure-Python shims over the C ABI (ctypes), not
+compiled pybind11 modules; viewers, filters, optimisers and the other bound modules are out of scope."""
+import os
+
+PATH = os.path.dirname(os.path.abspath(__file__))

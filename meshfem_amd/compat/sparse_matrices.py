@@ -1,0 +1,155 @@
+"""`sparse_matrices` (src/python_bindings/sparse_matrices.cc:15-66): Triplet, TripletMatrix and SPSDSystem.
+SPSDSystem hands the matrix to the HIP library (`mfh_matrix_set_upper_triplets`): full symmetric CSR in HBM,
+masked Jacobi-preconditioned CG instead of CHOLMOD, same fixVariables / solve semantics
+(SparseMatrices.hh:2389-2500,2515-2606)."""
+import struct
+
+import numpy as np
+
+from meshfem_amd.core import Context
+
+
+class Triplet:
+    def __init__(self, i=0, j=0, v=0.0):
+        self.i, self.j, self.v = int(i), int(j), float(v)
+
+    def __repr__(self):
+        return "%d\t%d\t%s" % (self.i, self.j, repr(self.v))
+
+
+class TripletMatrix:
+    """Sparse matrix in triplet (COO) format; symmetry_mode 'NONE' or 'UPPER_TRIANGLE' (SparseMatrices.hh:211-234)."""
+
+    def __init__(self, m=0, n=0):
+        self.m, self.n = int(m), int(n)
+        self._i, self._j, self._v = [], [], []
+        self.symmetry_mode = "NONE"
+
+    @staticmethod
+    def fromArrays(m, n, i, j, v, symmetry_mode="NONE"):
+        A = TripletMatrix(m, n)
+        A._i, A._j, A._v = list(map(int, i)), list(map(int, j)), list(map(float, v))
+        A.symmetry_mode = symmetry_mode
+        return A
+
+    @property
+    def nnz(self):
+        return len(self._v)
+
+    def entries(self):
+        return iter(Triplet(i, j, v) for i, j, v in zip(self._i, self._j, self._v))
+
+    def addNZ(self, i, j, v):
+        if i >= self.m or j >= self.n:
+            raise RuntimeError("Index out of bounds")
+        self._i.append(int(i)); self._j.append(int(j)); self._v.append(float(v))
+
+    def arrays(self):
+        return np.array(self._i, dtype=np.int64), np.array(self._j, dtype=np.int64), np.array(self._v, dtype=np.float64)
+
+    def sumRepeated(self):
+        """Sort by (column, row), sum duplicates, drop exact zeros (SparseMatrices.hh:280-374)."""
+        i, j, v = self.arrays()
+        order = np.lexsort((i, j))
+        i, j, v = i[order], j[order], v[order]
+        if len(v):
+            head = np.concatenate([[True], (i[1:] != i[:-1]) | (j[1:] != j[:-1])])
+            seg = np.cumsum(head) - 1
+            vs = np.zeros(seg[-1] + 1)
+            np.add.at(vs, seg, v)
+            i, j, v = i[head], j[head], vs
+            keep = v != 0.0
+            i, j, v = i[keep], j[keep], v[keep]
+        self._i, self._j, self._v = i.tolist(), j.tolist(), v.tolist()
+
+    def reflectUpperTriangle(self):
+        i, j, v = self.arrays()
+        up = i <= j
+        i, j, v = i[up], j[up], v[up]
+        off = i != j
+        self._i = np.concatenate([i, j[off]]).tolist()
+        self._j = np.concatenate([j, i[off]]).tolist()
+        self._v = np.concatenate([v, v[off]]).tolist()
+        self.symmetry_mode = "NONE"
+
+    def diag(self):
+        d = np.zeros(min(self.m, self.n))
+        i, j, v = self.arrays()
+        on = i == j
+        np.add.at(d, i[on], v[on])
+        return d
+
+    def apply(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        i, j, v = self.arrays()
+        y = np.zeros(self.m)
+        np.add.at(y, i, v * x[j])
+        if self.symmetry_mode == "UPPER_TRIANGLE":
+            off = i != j
+            np.add.at(y, j[off], v[off] * x[i[off]])
+        return y
+
+    def toSciPy(self):
+        import scipy.sparse as sp
+        i, j, v = self.arrays()
+        return sp.coo_matrix((v, (i, j)), shape=(self.m, self.n)).tocsc()
+
+    def dumpBinary(self, path):
+        """uint64 nnz, then all row indices, all column indices (uint64 each), all values (double)
+        (SparseMatrices.hh:623-645)."""
+        i, j, v = self.arrays()
+        with open(path, "wb") as f:
+            np.array([len(v)], dtype="<u8").tofile(f)
+            i.astype("<u8").tofile(f)
+            j.astype("<u8").tofile(f)
+            v.astype("<f8").tofile(f)
+
+    def readBinary(self, path):
+        """Sizes are inferred from the largest indices, like the reference (:647-670)."""
+        with open(path, "rb") as f:
+            (nnz,) = struct.unpack("<Q", f.read(8))
+            i = np.frombuffer(f.read(8 * nnz), dtype="<u8")
+            j = np.frombuffer(f.read(8 * nnz), dtype="<u8")
+            v = np.frombuffer(f.read(8 * nnz), dtype="<f8")
+        self.m = int(i.max()) + 1 if nnz else 0
+        self.n = int(j.max()) + 1 if nnz else 0
+        self._i, self._j, self._v = i.astype(np.int64).tolist(), j.astype(np.int64).tolist(), v.tolist()
+
+
+class SPSDSystem:
+    """A (constrained) SPSD system that can be solved for several right-hand sides. Constraint rows
+    (`C`, `C_rhs`: the Lagrange-multiplier / UMFPACK branch, SparseMatrices.hh:2572-2590) are not supported."""
+
+    def __init__(self, K, C=None, C_rhs=None, device=0):
+        if C is not None or C_rhs is not None:
+            raise RuntimeError("constraint rows (non-SPD KKT systems) are not supported on the GPU path")
+        if K.m != K.n:
+            raise RuntimeError("K must be square")
+        i, j, v = K.arrays()
+        if K.symmetry_mode != "UPPER_TRIANGLE":            # SPSDSystem::set keeps the upper triangle (:2337)
+            up = i <= j
+            i, j, v = i[up], j[up], v[up]
+        elif (i > j).any():
+            raise RuntimeError("entry below the diagonal in an UPPER_TRIANGLE matrix")
+        self.ctx = Context(device)
+        self.ctx.matrix_set_upper_triplets(K.m, i, j, v)
+        self.n = K.m
+        self.rtol, self.maxit = 1e-10, 100000
+        self.info = None
+
+    def fixVariables(self, fixedVars, fixedVarValues, keepFactorization=False):
+        if len(fixedVars) != len(fixedVarValues):
+            raise RuntimeError("Fixed variable index and value arrays must be the same size.")
+        if len(fixedVars):
+            self.ctx.fix_variables(np.asarray(fixedVars, dtype=np.int64), np.asarray(fixedVarValues, dtype=np.float64))
+
+    def setForceSupernodal(self, force):
+        pass                                               # a CHOLMOD tuning knob; meaningless for PCG
+
+    def solve(self, b):
+        b = np.asarray(b, dtype=np.float64)
+        if b.shape != (self.n,):
+            raise RuntimeError("Bad rhs size")
+        x = self.ctx.solve(b, rtol=self.rtol, maxit=self.maxit)
+        self.info = self.ctx.last_info
+        return x

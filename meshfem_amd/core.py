@@ -22,6 +22,8 @@ class Context:
         self.h = h
         self.host_only = device == -1
         self.dim = self.deg = None
+        self.op = L.OP_ELASTICITY
+        self.external = False
 
     def close(self):
         if getattr(self, "h", None):
@@ -61,6 +63,7 @@ class Context:
         self.n_elem, self.n_node, self.n_vert, self.n_bdry_elem, self.n_bdry_node = [x.value for x in v]
         self.npe, self.npbe = a.value, b.value
         self.n_dof = self.n_node
+        self.external = False
 
     def elem_nodes(self):
         out = np.empty((self.n_elem, self.npe), dtype=np.int32)
@@ -173,13 +176,41 @@ class Context:
         out.update(sz)
         return out
 
+    @property
+    def bs(self):
+        """Variables per DoF = block edge of K: dim for elasticity, 1 for the scalar operators and for
+        caller-supplied matrices."""
+        return self.dim if (self.op == L.OP_ELASTICITY and not self.external) else 1
+
+    def matrix_set_upper_triplets(self, n, i, j, v):
+        """SPSDSystem(K) for a caller-supplied SPD matrix (upper-triangle triplets, repeats summed)."""
+        i, j = np.ascontiguousarray(i, dtype=np.uint64), np.ascontiguousarray(j, dtype=np.uint64)
+        v = as_f64(v)
+        assert len(i) == len(j) == len(v)
+        self._ck(self.lib.mfh_matrix_set_upper_triplets(self.h, int(n), len(v), ptr(i), ptr(j), ptr(v)))
+        self.external, self.op = True, L.OP_ELASTICITY
+        self.n_dof = self.n_node = int(n)
+        self.dim = 1
+
+    def set_operator(self, op):
+        """OP_ELASTICITY (default) | OP_LAPLACIAN | OP_MASS: same mesh, pattern and kernels, 1x1 blocks
+        for the scalar operators (Laplacian.hh, MassMatrix.hh, Poisson.hh)."""
+        self._ck(self.lib.mfh_set_operator(self.h, int(op)))
+        self.op = int(op)
+
+    def average_gradient(self, u_nodes):
+        u = as_f64(u_nodes)
+        out = np.empty((self.n_elem, self.dim))
+        self._ck(self.lib.mfh_average_gradient(self.h, ptr(u), ptr(out)))
+        return out
+
     def assemble(self, mode=L.ASSEMBLE_GATHER):
         self._ck(self.lib.mfh_assemble(self.h, int(mode)))
 
     def export_bsr(self):
         nr, nc, nnzb = self.matrix_info()
         rp, ci = np.empty(nr + 1, np.int32), np.empty(nnzb, np.int32)
-        vals = np.empty((nnzb, self.dim, self.dim))
+        vals = np.empty((nnzb, self.bs, self.bs))
         self._ck(self.lib.mfh_export_bsr(self.h, ptr(rp), ptr(ci), ptr(vals)))
         return rp, ci, vals
 
@@ -187,7 +218,7 @@ class Context:
         import scipy.sparse as sp
         rp, ci, vals = self.export_bsr()
         nr, nc, _ = self.matrix_info()
-        return sp.bsr_matrix((vals, ci, rp), shape=(nr * self.dim, nc * self.dim)).tocsr()
+        return sp.bsr_matrix((vals, ci, rp), shape=(nr * self.bs, nc * self.bs)).tocsr()
 
     def export_upper_triplets(self):
         n = C.c_uint64(0)
@@ -198,7 +229,7 @@ class Context:
 
     def element_stiffness(self, first=0, count=None):
         count = self.n_elem - first if count is None else count
-        ks = self.npe * self.dim
+        ks = self.npe * self.bs
         out = np.empty((count, ks, ks))
         self._ck(self.lib.mfh_element_stiffness(self.h, int(first), int(count), ptr(out)))
         return out
@@ -222,7 +253,7 @@ class Context:
 
     def solve(self, f, rtol=1e-8, maxit=100000):
         f = as_f64(f)
-        n = self.dim * self.n_dof
+        n = self.bs * self.n_dof
         nrhs = f.size // n
         assert f.size == nrhs * n
         u = np.empty_like(f)
@@ -235,7 +266,7 @@ class Context:
     def apply_K(self, u):
         u = as_f64(u)
         nr, nc, _ = self.matrix_info() if self._assembled_info() else (self.n_dof, self.n_dof, 0)
-        out = np.empty(nr * self.dim)
+        out = np.empty(nr * self.bs)
         self._ck(self.lib.mfh_apply_K(self.h, ptr(u), ptr(out)))
         return out
 
@@ -288,7 +319,7 @@ class Context:
 
     def sim_solve(self, f=None, use_pin=False, rtol=1e-8, maxit=100000):
         fp = None if f is None else as_f64(f)
-        u = np.empty((self.n_node, self.dim))
+        u = np.empty((self.n_node, self.bs))
         info = L.SolveInfo()
         st = self.lib.mfh_sim_solve(self.h, ptr(fp), int(use_pin), ptr(u), float(rtol), int(maxit), C.byref(info))
         self.last_info = info.as_dict()

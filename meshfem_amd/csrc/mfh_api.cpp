@@ -20,12 +20,14 @@ struct mfh_ctx {
     // ---- mesh
     HostMesh mesh;
     bool haveMesh = false;
+    bool external = false;            // K supplied by the caller (mfh_matrix_set_upper_triplets): no mesh, scalar variables
     DBuf<int32_t> dElemNodes;
     DBuf<double> dVertPos;
 
     // ---- material
     int matMode = 0;                  // see k_geometry
     int matKind = MAT_ISO;
+    int op = MFH_OP_ELASTICITY;       // operator assembled into K: elasticity (dim x dim blocks) or scalar Laplacian / mass
     std::vector<double> matParams;    // host copy in the layout k_geometry expects
     DBuf<double> dMatParams;
     DBuf<double> dGeo;
@@ -50,7 +52,7 @@ struct mfh_ctx {
     DBuf<uint32_t> dContribCode;
     DBuf<uint16_t> dContribSlot;
     ShapeTables tables;
-    DBuf<double> dPairTable;
+    DBuf<double> dPairTable, dMassTable;
 
     // ---- numeric
     DBuf<double> dVals;
@@ -100,6 +102,8 @@ struct mfh_ctx {
     mfh_timing timing{0, 0, 0, 0};
 
     int dim() const { return mesh.dim; }
+    int bs() const { return (op == MFH_OP_ELASTICITY && !external) ? mesh.dim : 1; }   // variables per DoF = block edge of K
+    int asmMat() const { return op == MFH_OP_ELASTICITY ? matKind : (op == MFH_OP_LAPLACIAN ? (int)MAT_LAPLACE : (int)MAT_MASS); }
     int64_t nOwnedDoF() const {
         // owned rows: DoFs of the first nOwned nodes. With a periodic map all DoFs are owned.
         if (mesh.nOwned == mesh.nNode) return nDoF;
@@ -174,7 +178,7 @@ void reset_bcs(mfh_ctx *c) {
 void clear_fixed(mfh_ctx *c) {
     c->fixedVars.clear();
     c->fixedVals.clear();
-    c->hFixedMask.assign((size_t)c->dim() * c->nDoF, 0);
+    c->hFixedMask.assign((size_t)c->bs() * c->nDoF, 0);
     c->fixedUploaded = false;
     c->anyFixedNonzero = false;
     c->dinvValid = false;
@@ -191,12 +195,13 @@ void upload_mesh(mfh_ctx *c) {
     }
     c->timing.upload_ms = now_ms() - t0;
     c->haveMesh = true;
+    c->external = false;
     c->geoValid = false;
     c->hGeoValid = false;
     c->dofForNode.clear();
     c->nDoF = c->mesh.nNode;
     build_shape_tables(c->mesh.dim, c->mesh.deg, c->tables);
-    if (!c->hostOnly) c->dPairTable.upload(c->tables.pairTable, c->stream);
+    if (!c->hostOnly) { c->dPairTable.upload(c->tables.pairTable, c->stream); c->dMassTable.upload(c->tables.massRef, c->stream); }
     invalidate_symbolic(c);
     reset_bcs(c);
     clear_fixed(c);
@@ -327,8 +332,8 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
 k::AsmArgs asm_args(mfh_ctx *c) {
     const HostMesh &m = c->mesh;
     k::AsmArgs a{};
-    a.dim = m.dim; a.deg = m.deg; a.npe = m.npe; a.mat = c->matKind;
-    a.geoStride = c->geoStride; a.geo = c->dGeo.p; a.pairTable = c->dPairTable.p;
+    a.dim = m.dim; a.deg = m.deg; a.npe = m.npe; a.mat = c->asmMat();
+    a.geoStride = c->geoStride; a.geo = c->dGeo.p; a.pairTable = c->dPairTable.p; a.massTable = c->dMassTable.p;
     for (int k2 = 0; k2 < 6; ++k2) a.pairConst[k2] = c->tables.pairConst[k2];
     a.nChunk = c->sym.nChunk(); a.chunkRow = c->dChunkRow.p; a.rowPtr = c->dRowPtr.p;
     a.contribPtr = c->dContribPtr.p; a.contribCode = c->dContribCode.p; a.contribSlot = c->dContribSlot.p;
@@ -351,6 +356,7 @@ void run_assembly(mfh_ctx *c, int mode) {
 
 void ensure_assembled(mfh_ctx *c) {
     if (c->assembled) return;
+    require(!c->external, MFH_ERR_STATE, "no matrix set");
     ensure_geometry(c);
     ensure_symbolic(c, false);
     EventTimer t(c->stream);
@@ -362,7 +368,7 @@ void ensure_assembled(mfh_ctx *c) {
 
 k::SpmvArgs spmv_args(mfh_ctx *c, bool masked) {
     k::SpmvArgs a{};
-    a.dim = c->dim(); a.nChunk = (int64_t)c->sym.spmvChunkRow.size() - 1; a.chunkRow = c->dSpmvChunkRow.p; a.rowPtr = c->dRowPtr.p;
+    a.dim = c->bs(); a.nChunk = (int64_t)c->sym.spmvChunkRow.size() - 1; a.chunkRow = c->dSpmvChunkRow.p; a.rowPtr = c->dRowPtr.p;
     a.colIdx = c->dColIdx.p; a.vals = c->dVals.p; a.chunkSlots = c->sym.spmvChunkSlots;
     a.fixedMask = masked ? c->dFixedMask.p : nullptr;
     return a;
@@ -370,7 +376,7 @@ k::SpmvArgs spmv_args(mfh_ctx *c, bool masked) {
 
 void ensure_fixed_uploaded(mfh_ctx *c) {
     if (c->fixedUploaded) return;
-    const size_t n = (size_t)c->dim() * c->nDoF;
+    const size_t n = (size_t)c->bs() * c->nDoF;
     if (c->hFixedMask.size() != n) c->hFixedMask.assign(n, 0);
     c->dFixedMask.upload(c->hFixedMask, c->stream);
     c->dFixedIdx.upload(c->fixedVars, c->stream);
@@ -383,7 +389,7 @@ void ensure_precond(mfh_ctx *c) {
     ensure_assembled(c);
     ensure_fixed_uploaded(c);
     if (c->dinvValid) return;
-    const int d = c->dim();
+    const int d = c->bs();
     c->dDinv.alloc((size_t)c->sym.nRows * d * d);
     k::launch_extract_diag_inv(d, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, c->dFixedMask.p,
                                c->precond == MFH_PRECOND_TWO_LEVEL ? MFH_PRECOND_BLOCK_JACOBI : c->precond, c->dDinv.p, c->stream);
@@ -435,6 +441,10 @@ bool tl_invert_device(mfh_ctx *c, const double *Ac, bool noteOnFailure) {
 bool ensure_twolevel(mfh_ctx *c) {
     if (c->tl.valid) return true;
     c->precondNote.clear();
+    if (c->op != MFH_OP_ELASTICITY || c->external) {
+        c->precondNote = "two-level preconditioner is built on rigid-body modes (elasticity only): using Jacobi";
+        return false;
+    }
     const HostMesh &m = c->mesh;
     const int d = m.dim;
     if (c->sym.nRows != c->sym.nCols) {
@@ -583,7 +593,7 @@ double device_dot(mfh_ctx *c, int64_t n, const double *a, const double *b) {
 
 // PCG on the free variables of K (SPSDSystem::solve with CHOLMOD replaced).
 void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info) {
-    const int d = c->dim();
+    const int d = c->bs();
     const int64_t n = (int64_t)d * c->nDoF;
     require(c->sym.nRows == c->sym.nCols, MFH_ERR_STATE,
             "mfh_solve needs all rows owned; use the mfh_dev_* building blocks for partitioned meshes");
@@ -722,6 +732,14 @@ void dirichlet_vars(mfh_ctx *c, std::vector<int64_t> &vars, std::vector<double> 
             if (std::sqrt(diff) > 1e-10 || cdiffer) throw Error(MFH_ERR_INVALID, "Mismatched Dirichlet constraint on periodic DoF");
         }
     }
+    if (c->op != MFH_OP_ELASTICITY) {
+        // scalar PDE: the Dirichlet value is the first component of the "displacement" (Poisson.hh:57-60,80-84)
+        for (size_t k = 0; k < cDoF.size(); ++k) {
+            vars.push_back((int64_t)cDoF[k]);
+            vals.push_back(c->dirVal[(size_t)cNode[k] * d]);
+        }
+        return;
+    }
     for (size_t k = 0; k < cDoF.size(); ++k)
         for (int a = 0; a < d; ++a)
             if (c->dirMask[(size_t)cNode[k] * d + a]) {
@@ -738,7 +756,7 @@ int64_t pin_node(const mfh_ctx *c) {   // LinearElasticity.hh:1595-1609
 }
 
 void add_fixed(mfh_ctx *c, int64_t n, const int64_t *vars, const double *vals) {
-    const int64_t nv = (int64_t)c->dim() * c->nDoF;
+    const int64_t nv = (int64_t)c->bs() * c->nDoF;
     if (c->hFixedMask.size() != (size_t)nv) c->hFixedMask.assign((size_t)nv, 0);
     for (int64_t k = 0; k < n; ++k) {
         require(vars[k] >= 0 && vars[k] < nv, MFH_ERR_INVALID, "fixed variable index out of range");
@@ -1083,6 +1101,70 @@ mfh_status mfh_matrix_info(const mfh_ctx *c, int64_t *nBlockRows, int64_t *nBloc
     return MFH_OK;
 }
 
+// SPSDSystem(K) for a caller-supplied matrix (SparseMatrices.hh:2332-2348): upper-triangle triplets (repeated
+// entries are summed, like sumRepeated) become the full symmetric CSR the SpMV / PCG kernels run on (1x1 blocks).
+mfh_status mfh_matrix_set_upper_triplets(mfh_ctx *c, int64_t n, int64_t nnz, const uint64_t *ti, const uint64_t *tj, const double *tv) {
+    MFH_TRY(c)
+    require(c && n > 0 && nnz >= 0 && (nnz == 0 || (ti && tj && tv)), MFH_ERR_INVALID, "bad matrix arguments");
+    require(n < (int64_t)1 << 31, MFH_ERR_UNSUPPORTED, "matrix too large for 32-bit indices");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    struct Ent { int32_t r, c; double v; };
+    std::vector<Ent> ent;
+    ent.reserve((size_t)nnz * 2);
+    for (int64_t k = 0; k < nnz; ++k) {
+        require(ti[k] <= tj[k] && tj[k] < (uint64_t)n, MFH_ERR_INVALID, "triplet outside the upper triangle");
+        ent.push_back({(int32_t)ti[k], (int32_t)tj[k], tv[k]});
+        if (ti[k] != tj[k]) ent.push_back({(int32_t)tj[k], (int32_t)ti[k], tv[k]});
+    }
+    std::stable_sort(ent.begin(), ent.end(), [](const Ent &a, const Ent &b) { return a.r != b.r ? a.r < b.r : a.c < b.c; });
+    Symbolic &S = c->sym;
+    S = Symbolic();
+    S.nRows = S.nCols = n;
+    S.rowPtr.assign((size_t)n + 1, 0);
+    std::vector<double> vals;
+    for (size_t k = 0; k < ent.size();) {
+        size_t e = k;
+        double v = 0;
+        while (e < ent.size() && ent[e].r == ent[k].r && ent[e].c == ent[k].c) v += ent[e++].v;
+        S.colIdx.push_back(ent[k].c);
+        vals.push_back(v);
+        S.rowPtr[(size_t)ent[k].r + 1]++;
+        k = e;
+    }
+    for (int64_t r = 0; r < n; ++r) S.rowPtr[(size_t)r + 1] += S.rowPtr[r];
+    S.nnzb = (int64_t)vals.size();
+    S.chunkSlots = c->chunkSlots;
+    S.chunkRow.assign(1, 0);
+    S.contribPtr.assign(1, 0);
+    S.spmvChunkSlots = std::max(512, c->chunkSlots);
+    S.spmvChunkRow.assign(1, 0);
+    for (int64_t r = 0; r < n;) {
+        require(S.rowPtr[r + 1] - S.rowPtr[r] <= S.spmvChunkSlots, MFH_ERR_UNSUPPORTED, "matrix row longer than an SpMV chunk");
+        const int32_t s0 = S.rowPtr[r];
+        int64_t r2 = r + 1;
+        while (r2 < n && S.rowPtr[r2 + 1] - s0 <= S.spmvChunkSlots) ++r2;
+        S.spmvChunkRow.push_back((int32_t)r2);
+        r = r2;
+    }
+    c->haveMesh = false;
+    c->external = true;
+    c->op = MFH_OP_ELASTICITY;
+    c->dofForNode.clear();
+    c->nDoF = n;
+    c->dRowPtr.upload(S.rowPtr, c->stream);
+    c->dColIdx.upload(S.colIdx, c->stream);
+    c->dSpmvChunkRow.upload(S.spmvChunkRow, c->stream);
+    vals.resize(((vals.size() + 63) / 64) * 64, 0.0);      // tiled layout with 1 component per entry = plain array
+    c->dVals.upload(vals, c->stream);
+    c->symValid = true;
+    c->assembled = true;
+    c->dinvValid = false;
+    c->tl.valid = false;
+    clear_fixed(c);
+    MFH_CATCH(c)
+}
+
 mfh_status mfh_export_bsr(mfh_ctx *c, int32_t *rowPtr, int32_t *colIdx, double *vals) {
     MFH_TRY(c)
     require(c && c->assembled, MFH_ERR_STATE, "matrix not assembled");
@@ -1091,10 +1173,10 @@ mfh_status mfh_export_bsr(mfh_ctx *c, int32_t *rowPtr, int32_t *colIdx, double *
     if (rowPtr) std::copy(S.rowPtr.begin(), S.rowPtr.end(), rowPtr);
     if (colIdx) std::copy(S.colIdx.begin(), S.colIdx.end(), colIdx);
     if (vals && S.nnzb) {
-        const int nb = c->dim() * c->dim();
+        const int nb = c->bs() * c->bs();
         DBuf<double> aos;
         aos.alloc((size_t)S.nnzb * nb);
-        k::launch_untile_vals(c->dim(), S.nnzb, c->dVals.p, aos.p, c->stream);
+        k::launch_untile_vals(c->bs(), S.nnzb, c->dVals.p, aos.p, c->stream);
         aos.download(vals, (size_t)S.nnzb * nb, c->stream);
     }
     MFH_CATCH(c)
@@ -1106,7 +1188,7 @@ mfh_status mfh_export_upper_triplets(mfh_ctx *c, uint64_t *oi, uint64_t *oj, dou
     require(c->sym.nRows == c->sym.nCols, MFH_ERR_STATE, "triplet export needs a square matrix");
     ensure_host_colidx(c);
     const Symbolic &S = c->sym;
-    const int d = c->dim(), nb = d * d;
+    const int d = c->bs(), nb = d * d;
     std::vector<double> vals((size_t)S.nnzb * nb);
     {
         DBuf<double> aos;
@@ -1141,7 +1223,7 @@ mfh_status mfh_element_stiffness(mfh_ctx *c, int64_t first, int64_t count, doubl
     require(c && c->haveMesh && Ke, MFH_ERR_STATE, "no mesh set");
     require(first >= 0 && count > 0 && first + count <= c->mesh.nElem, MFH_ERR_INVALID, "bad element range");
     ensure_geometry(c);
-    const size_t ks = (size_t)c->mesh.npe * c->dim();
+    const size_t ks = (size_t)c->mesh.npe * c->bs();
     DBuf<double> out;
     out.alloc((size_t)count * ks * ks);
     k::AsmArgs a = asm_args(c);
@@ -1153,14 +1235,14 @@ mfh_status mfh_element_stiffness(mfh_ctx *c, int64_t first, int64_t count, doubl
 // ---------------------------------------------------------------- constrained solve
 mfh_status mfh_clear_fixed(mfh_ctx *c) {
     MFH_TRY(c)
-    require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    require(c && (c->haveMesh || c->external), MFH_ERR_STATE, "no mesh set");
     clear_fixed(c);
     MFH_CATCH(c)
 }
 
 mfh_status mfh_fix_variables(mfh_ctx *c, int64_t n, const int64_t *vars, const double *vals) {
     MFH_TRY(c)
-    require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    require(c && (c->haveMesh || c->external), MFH_ERR_STATE, "no mesh set");
     if (n == 0) return MFH_OK;
     require(vars && n > 0, MFH_ERR_INVALID, "null argument");
     add_fixed(c, n, vars, vals);
@@ -1185,12 +1267,12 @@ mfh_status mfh_precond_info(const mfh_ctx *c, int32_t *nAgg, int64_t *coarseDim,
 
 mfh_status mfh_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, double rtol, int32_t maxit, mfh_solve_info *info) {
     MFH_TRY(c)
-    require(c && c->haveMesh && f && u && nrhs > 0 && maxit > 0 && rtol > 0, MFH_ERR_INVALID, "bad solve arguments");
+    require(c && (c->haveMesh || c->external) && f && u && nrhs > 0 && maxit > 0 && rtol > 0, MFH_ERR_INVALID, "bad solve arguments");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
     if (c->precond == MFH_PRECOND_TWO_LEVEL) ensure_twolevel(c);
-    const int64_t n = (int64_t)c->dim() * c->nDoF;
+    const int64_t n = (int64_t)c->bs() * c->nDoF;
     bool allConverged = true;
     for (int k2 = 0; k2 < nrhs; ++k2) {
         mfh_solve_info li{};
@@ -1204,11 +1286,11 @@ mfh_status mfh_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, doubl
 
 mfh_status mfh_apply_K(mfh_ctx *c, const double *u, double *Ku) {
     MFH_TRY(c)
-    require(c && c->haveMesh && u && Ku, MFH_ERR_INVALID, "null argument");
+    require(c && (c->haveMesh || c->external) && u && Ku, MFH_ERR_INVALID, "null argument");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_assembled(c);
-    const int d = c->dim();
+    const int d = c->bs();
     const int64_t nin = (int64_t)d * c->sym.nCols, nout = (int64_t)d * c->sym.nRows;
     c->wx.alloc(nin);
     c->wAp.alloc(std::max(nin, nout));
@@ -1247,7 +1329,9 @@ mfh_status mfh_bc_dirichlet_box(mfh_ctx *c, const double *mn, const double *mx, 
             if (!c->dirMask[(size_t)bn * d + a]) {
                 c->dirMask[(size_t)bn * d + a] = 1;
                 c->dirVal[(size_t)bn * d + a] = value[a];
-            } else if (std::fabs(c->dirVal[(size_t)bn * d + a] - value[a]) > 1e-10)
+            } else if (c->op != MFH_OP_ELASTICITY)
+                c->dirVal[(size_t)bn * d + a] = value[a];   // scalar PDE: later conditions overwrite (Poisson.hh:75-83)
+            else if (std::fabs(c->dirVal[(size_t)bn * d + a] - value[a]) > 1e-10)
                 throw Error(MFH_ERR_INVALID, "Conflicting dirichlet displacements.");
         }
     }
@@ -1338,6 +1422,7 @@ mfh_status mfh_neumann_load(mfh_ctx *c, double *out) {
 mfh_status mfh_constant_strain_load(mfh_ctx *c, const double *cstrain, double *out) {
     MFH_TRY(c)
     require(c && c->haveMesh && cstrain && out, MFH_ERR_STATE, "no mesh set");
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "constantStrainLoad is defined for the elasticity operator");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_geometry(c);
@@ -1357,7 +1442,7 @@ mfh_status mfh_sim_solve(mfh_ctx *c, const double *f, int32_t usePin, double *uN
     MFH_TRY(c)
     require(c && c->haveMesh && uNodes, MFH_ERR_STATE, "no mesh set");
     const HostMesh &m = c->mesh;
-    const int d = m.dim;
+    const int d = c->bs();
     const int64_t n = (int64_t)d * c->nDoF;
     // m_buildConstrainedSystem (LinearElasticity.hh:1377-1404): pin first (assembleConstrainedSystem :1217),
     // then the Dirichlet variables (:1244)
@@ -1374,9 +1459,11 @@ mfh_status mfh_sim_solve(mfh_ctx *c, const double *f, int32_t usePin, double *uN
     }
     std::vector<double> load;
     if (!f) {
-        load.resize((size_t)n);
-        mfh_status st = mfh_neumann_load(c, load.data());
-        if (st != MFH_OK) throw Error(st, c->err);
+        load.assign((size_t)n, 0.0);
+        if (c->op == MFH_OP_ELASTICITY) {
+            mfh_status st = mfh_neumann_load(c, load.data());
+            if (st != MFH_OK) throw Error(st, c->err);
+        }   // scalar PDE: zero right-hand side, zero-Neumann natural condition (Poisson.hh:100-102)
         f = load.data();
     }
     std::vector<double> x((size_t)n);
@@ -1394,6 +1481,7 @@ mfh_status mfh_sim_solve(mfh_ctx *c, const double *f, int32_t usePin, double *uN
 }
 
 static void average_strain_impl(mfh_ctx *c, const double *uNodes, double *out, bool stress) {
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "strain / stress fields are defined for the elasticity operator");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_geometry(c);
@@ -1405,6 +1493,33 @@ static void average_strain_impl(mfh_ctx *c, const double *uNodes, double *out, b
     res.alloc((size_t)m.nElem * fl);
     k::launch_average_strain(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), c->wx.p, res.p, stress ? 1 : 0, c->stream);
     res.download(out, res.n, c->stream);
+}
+
+mfh_status mfh_set_operator(mfh_ctx *c, int32_t op) {
+    MFH_TRY(c)
+    require(c && (op == MFH_OP_ELASTICITY || op == MFH_OP_LAPLACIAN || op == MFH_OP_MASS), MFH_ERR_INVALID, "unknown operator");
+    if (op != c->op) {
+        c->op = op;
+        invalidate_matrix(c);          // pattern and gather lists are shared by all operators; only the values change
+        if (c->haveMesh) clear_fixed(c);   // the variable numbering changes with the block size
+    }
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_average_gradient(mfh_ctx *c, const double *uNodes, double *grad) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && grad, MFH_ERR_STATE, "no mesh set");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const HostMesh &m = c->mesh;
+    c->wx.alloc((size_t)m.nNode);
+    MFH_HIP(hipMemcpyAsync(c->wx.p, uNodes, (size_t)m.nNode * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    DBuf<double> res;
+    res.alloc((size_t)m.nElem * m.dim);
+    k::launch_average_gradient(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), c->wx.p, res.p, c->stream);
+    res.download(grad, res.n, c->stream);
+    MFH_CATCH(c)
 }
 
 mfh_status mfh_average_strain(mfh_ctx *c, const double *uNodes, double *strain) {
@@ -1436,7 +1551,7 @@ mfh_status mfh_dev_precond(mfh_ctx *c, const double *r_dev, double *z_dev) {
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
-    k::launch_precond(c->dim(), c->sym.nRows, c->dDinv.p, r_dev, z_dev, c->stream);
+    k::launch_precond(c->bs(), c->sym.nRows, c->dDinv.p, r_dev, z_dev, c->stream);
     MFH_CATCH(c)
 }
 // ---- two-level preconditioner on a row-partitioned context: the caller owns the (global) aggregates
@@ -1446,6 +1561,7 @@ mfh_status mfh_tl_partitioned_begin(mfh_ctx *c, int32_t nAgg, const int32_t *agg
     MFH_TRY(c)
     require(c && c->haveMesh && aggOfNode && relPos && Ac_dev && nAgg > 0, MFH_ERR_INVALID, "bad two-level arguments");
     require(c->dofForNode.empty(), MFH_ERR_UNSUPPORTED, "caller-supplied aggregates need the identity DoF map");
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_UNSUPPORTED, "the rigid-body-mode coarse space is defined for the elasticity operator");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
@@ -1514,7 +1630,7 @@ mfh_status mfh_dev_mask_fixed(mfh_ctx *c, double *r_dev) {
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_fixed_uploaded(c);
-    if (!c->fixedVars.empty()) k::launch_mask((int64_t)c->dim() * c->sym.nRows, c->dFixedMask.p, r_dev, c->stream);
+    if (!c->fixedVars.empty()) k::launch_mask((int64_t)c->bs() * c->sym.nRows, c->dFixedMask.p, r_dev, c->stream);
     MFH_CATCH(c)
 }
 mfh_status mfh_dev_set_fixed_values(mfh_ctx *c, double *u_dev) {
@@ -1568,7 +1684,7 @@ mfh_status mfh_time_spmv_kernel(mfh_ctx *c, int32_t reps, double *avg_ms) {
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_assembled(c);
-    const int d = c->dim();
+    const int d = c->bs();
     const int64_t nin = (int64_t)d * c->sym.nCols, nout = (int64_t)d * c->sym.nRows;
     c->wx.alloc(nin);
     c->wAp.alloc(std::max(nin, nout));

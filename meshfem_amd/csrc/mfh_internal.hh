@@ -101,7 +101,9 @@ static const int kEdgeEnd[6] = {1, 2, 0, 3, 3, 3};
 constexpr int GEO_ISO_STRIDE = 16;      // 12 + 1 + 2 (+1 pad)  = 128 B, one cache line
 constexpr int GEO_GEN_STRIDE = 36;      // 12 + 1 + 21 (+2 pad) = 288 B
 
-enum MaterialKind { MAT_ISO = 0, MAT_GENERAL = 1 };
+// MAT_LAPLACE / MAT_MASS: scalar operators on the same machinery (1x1 blocks; Laplacian.hh:27-57, MassMatrix.hh:50-86)
+enum MaterialKind { MAT_ISO = 0, MAT_GENERAL = 1, MAT_LAPLACE = 2, MAT_MASS = 3 };
+inline bool mat_is_scalar(int mat) { return mat == MAT_LAPLACE || mat == MAT_MASS; }
 
 // ------------------------------------------------------------------------------------------------
 // Host-side mesh (FEMMesh restatement)
@@ -176,6 +178,7 @@ struct ShapeTables {
     std::vector<double> pairTable;      // npe*npe*4
     double pairConst[6] = {1, 0, 0, 0, 0, 0}; // [2*type + (a != b)], type 0/1/2 = two/one/no vertex-offset terms
     std::vector<double> intGrad;        // npe*2: integral (unit volume) of alpha_i, beta_i  (constantStrainLoad)
+    std::vector<double> massRef;        // npe*npe: integral of phi_i phi_j over the unit-volume simplex (exact)
 };
 void build_shape_tables(int dim, int deg, ShapeTables &T);
 
@@ -209,6 +212,7 @@ struct AsmArgs {
     int geoStride;
     const double *geo;                  // nElem x geoStride
     const double *pairTable;            // device copy of ShapeTables::pairTable
+    const double *massTable;            // device copy of ShapeTables::massRef (npe x npe, unit-volume element)
     double pairConst[6];                // the distinct pair coefficients (ShapeTables::pairConst)
     // gather
     int64_t nChunk;
@@ -237,6 +241,8 @@ void launch_constant_strain_load(const AsmArgs &a, const int32_t *elemNodes, con
                                  const double *cstrain, double *out, hipStream_t s);
 void launch_average_strain(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, double *out,
                            int wantStress, hipStream_t s);
+void launch_average_gradient(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, double *out,
+                             hipStream_t s);
 
 struct SpmvArgs {
     int dim;

@@ -76,10 +76,19 @@ template <int DIM, int DEG> DEV int sup_t(int i) {
 //   H[a][b] = sum_q w_q d_a phi_i d_b phi_j = u_a (S0 v_a + S1 v_b)^T + u_b (S2 v_a + S3 v_b)^T
 // (same quadrature rule and points as the reference: GaussQuadrature.hh:115-127,283-295).
 // ------------------------------------------------------------------------------------------------
+// components per matrix entry: dim x dim blocks for elasticity, 1 for the scalar operators
+template <int DIM, int MAT> DEV constexpr int mat_nb() { return (MAT == MAT_LAPLACE || MAT == MAT_MASS) ? 1 : DIM * DIM; }
+
 template <int DIM, int DEG, int MAT, int ABL = 0>
 DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pairTab, const PairConst &pc, int i, int j, double *K) {
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
     const double vol = (ABL & 2) ? 1.0 + i : g[12];
+    if (MAT == MAT_MASS) {
+        // int phi_i phi_j = vol * (reference value): exact for straight-sided simplices, equal to the
+        // reference's Quadrature<K, 2 Deg> (exact for this integrand) up to rounding (MassMatrix.hh:66-77)
+        K[0] = vol * pairTab[i * NPE + j];
+        return;
+    }
     double H[DIM][DIM];
     if (DEG == 1) {
         double gi[DIM], gj[DIM];
@@ -125,7 +134,13 @@ DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pai
 #pragma unroll
             for (int b = 0; b < DIM; ++b) H[a][b] = ua[a] * p[b] + ub[a] * q[b];
     }
-    if (MAT == MAT_ISO) {
+    if (MAT == MAT_LAPLACE) {
+        // int grad phi_i . grad phi_j = tr(H)   (Laplacian.hh:38-48; Poisson.hh:33-38)
+        double tr = 0;
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) tr += H[a][a];
+        K[0] = tr;
+    } else if (MAT == MAT_ISO) {
         // C_acdb = lambda d_ac d_db + mu (d_ad d_cb + d_ab d_cd)  =>  K = lambda H + mu H^T + mu tr(H) I
         const double lam = (ABL & 2) ? 0.5 : g[13], mu = (ABL & 2) ? 0.25 : g[14];
         double tr = 0;
@@ -251,7 +266,7 @@ __global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *
 // ------------------------------------------------------------------------------------------------
 template <int DIM, int DEG, int MAT, int DBG = 0>
 __global__ void __launch_bounds__(256) k_assemble_gather(AsmArgs a) {
-    constexpr int NB = DIM * DIM;
+    constexpr int NB = mat_nb<DIM, MAT>();
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
     extern __shared__ __attribute__((aligned(16))) double acc[];   // [NB][chunkSlots + 2]
     const int CS = a.chunkSlots + 2;
@@ -290,7 +305,7 @@ __global__ void __launch_bounds__(256) k_assemble_gather(AsmArgs a) {
             const uint32_t e = code[u] / (NPE * NPE);
             const int ij = (int)(code[u] - e * (NPE * NPE));
             const int i = ij / NPE, j = ij - i * NPE;
-            elem_block<DIM, DEG, MAT, ABL>(a.geo + (int64_t)e * a.geoStride, a.pairTable, pc, i, j, K[u]);
+            elem_block<DIM, DEG, MAT, ABL>(a.geo + (int64_t)e * a.geoStride, MAT == MAT_MASS ? a.massTable : a.pairTable, pc, i, j, K[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -341,7 +356,7 @@ __global__ void __launch_bounds__(256) k_assemble_gather(AsmArgs a) {
 // into the (pre-zeroed) tiled values through the element->slot scatter map.
 template <int DIM, int DEG, int MAT>
 __global__ void __launch_bounds__(256) k_assemble_atomic(AsmArgs a) {
-    constexpr int NB = DIM * DIM;
+    constexpr int NB = mat_nb<DIM, MAT>();
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
     const PairConst pc{a.pairConst[0], a.pairConst[1], a.pairConst[2], a.pairConst[3], a.pairConst[4], a.pairConst[5]};
     const int64_t total = a.nElem * (NPE * NPE);
@@ -352,7 +367,7 @@ __global__ void __launch_bounds__(256) k_assemble_atomic(AsmArgs a) {
         const int ij = (int)(k - e * (NPE * NPE));
         const int i = ij / NPE, j = ij - i * NPE;
         double K[NB];
-        elem_block<DIM, DEG, MAT>(a.geo + e * a.geoStride, a.pairTable, pc, i, j, K);
+        elem_block<DIM, DEG, MAT>(a.geo + e * a.geoStride, MAT == MAT_MASS ? a.massTable : a.pairTable, pc, i, j, K);
 #pragma unroll
         for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&a.vals[tiled_index(slot, c, NB)], K[c]);
     }
@@ -361,9 +376,10 @@ __global__ void __launch_bounds__(256) k_assemble_atomic(AsmArgs a) {
 // Dense per-element Ke (parity/debug): full (NPE*DIM)^2 row-major.
 template <int DIM, int DEG, int MAT>
 __global__ void __launch_bounds__(256) k_element_stiffness(AsmArgs a, int64_t first, int64_t count, double *out) {
-    constexpr int NB = DIM * DIM;
+    constexpr int NB = mat_nb<DIM, MAT>();
+    constexpr int BS = NB == 1 ? 1 : DIM;          // block edge
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
-    constexpr int KS = NPE * DIM;
+    constexpr int KS = NPE * BS;
     const PairConst pc{a.pairConst[0], a.pairConst[1], a.pairConst[2], a.pairConst[3], a.pairConst[4], a.pairConst[5]};
     const int64_t total = count * (NPE * NPE);
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
@@ -371,12 +387,12 @@ __global__ void __launch_bounds__(256) k_element_stiffness(AsmArgs a, int64_t fi
         const int ij = (int)(k - el * (NPE * NPE));
         const int i = ij / NPE, j = ij - i * NPE;
         double K[NB];
-        elem_block<DIM, DEG, MAT>(a.geo + (first + el) * a.geoStride, a.pairTable, pc, i, j, K);
+        elem_block<DIM, DEG, MAT>(a.geo + (first + el) * a.geoStride, MAT == MAT_MASS ? a.massTable : a.pairTable, pc, i, j, K);
         double *o = out + el * KS * KS;
 #pragma unroll
-        for (int c = 0; c < DIM; ++c)
+        for (int c = 0; c < BS; ++c)
 #pragma unroll
-            for (int d = 0; d < DIM; ++d) o[(i * DIM + c) * KS + j * DIM + d] = K[c * DIM + d];
+            for (int d = 0; d < BS; ++d) o[(i * BS + c) * KS + j * BS + d] = K[c * BS + d];
     }
 }
 
@@ -497,6 +513,29 @@ __global__ void __launch_bounds__(256) k_average_strain(LoadArgs a, const double
     }
 }
 
+// Average gradient of a scalar nodal field per element (PoissonMesh::gradUAverage, Poisson.hh:121-131):
+// (1/vol) int sum_i u_i grad phi_i = sum_i u_i (al_i gl[s_i] + be_i gl[t_i]).
+template <int DIM, int DEG>
+__global__ void __launch_bounds__(256) k_average_gradient(LoadArgs a, const double *__restrict__ uNodes, double *__restrict__ out) {
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.nElem; e += (int64_t)gridDim.x * 256) {
+        const double *g = a.geo + e * a.geoStride;
+        double gr[DIM];
+#pragma unroll
+        for (int b = 0; b < DIM; ++b) gr[b] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NPE; ++i) {
+            const int si = sup_s<DIM, DEG>(i), ti = sup_t<DIM, DEG>(i);
+            const double al = a.intGrad[2 * i], be = a.intGrad[2 * i + 1];
+            const double ui = uNodes[a.elemNodes[e * NPE + i]];
+#pragma unroll
+            for (int b = 0; b < DIM; ++b) gr[b] += ui * (al * g[si * DIM + b] + be * g[ti * DIM + b]);
+        }
+#pragma unroll
+        for (int b = 0; b < DIM; ++b) out[e * DIM + b] = gr[b];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Block-CSR SpMV over row chunks (persistent workgroups, grid-stride over chunks).
 // Phase 1: lane per block: coalesced loads of the NB components + column, gather x, block product
@@ -562,7 +601,9 @@ __global__ void __launch_bounds__(256) k_spmv(SpmvArgs a, const double *__restri
 // small dense helpers
 // ------------------------------------------------------------------------------------------------
 template <int DIM> DEV void invert_block(const double *A, double *Inv) {
-    if (DIM == 2) {
+    if (DIM == 1) {
+        Inv[0] = 1.0 / A[0];
+    } else if (DIM == 2) {
         const double det = A[0] * A[3] - A[1] * A[2];
         Inv[0] = A[3] / det; Inv[1] = -A[1] / det; Inv[2] = -A[2] / det; Inv[3] = A[0] / det;
     } else {
@@ -1153,9 +1194,26 @@ void launch_geometry(int dim, int /*deg*/, int /*mat*/, int64_t nElem, const int
         }                                                                                \
     } while (0)
 
+// assembly kernels also come in the scalar-operator flavours
+#define MFH_DISPATCH_ASM(a, CALL)                                                        \
+    do {                                                                                 \
+        if (!mat_is_scalar(a.mat)) { MFH_DISPATCH(a, CALL); break; }                     \
+        const int key_ = (a.dim == 3 ? 0 : 4) + (a.deg == 2 ? 2 : 0) + (a.mat == MAT_MASS ? 1 : 0); \
+        switch (key_) {                                                                  \
+        case 0: { CALL(3, 1, MAT_LAPLACE); } break;                                       \
+        case 1: { CALL(3, 1, MAT_MASS); } break;                                          \
+        case 2: { CALL(3, 2, MAT_LAPLACE); } break;                                       \
+        case 3: { CALL(3, 2, MAT_MASS); } break;                                          \
+        case 4: { CALL(2, 1, MAT_LAPLACE); } break;                                       \
+        case 5: { CALL(2, 1, MAT_MASS); } break;                                          \
+        case 6: { CALL(2, 2, MAT_LAPLACE); } break;                                       \
+        default: { CALL(2, 2, MAT_MASS); } break;                                         \
+        }                                                                                \
+    } while (0)
+
 void launch_assemble_gather(const AsmArgs &a, hipStream_t s) {
     if (a.nChunk == 0) return;
-    const size_t lds = (size_t)a.dim * a.dim * (a.chunkSlots + 2) * sizeof(double);
+    const size_t lds = (size_t)(mat_is_scalar(a.mat) ? 1 : a.dim * a.dim) * (a.chunkSlots + 2) * sizeof(double);
 #define CALL(D, G, M)                                                                                          \
     if (lds > 64 * 1024)                                                                                         \
         MFH_HIP(hipFuncSetAttribute((const void *)k_assemble_gather<D, G, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -1181,7 +1239,7 @@ void launch_assemble_gather(const AsmArgs &a, hipStream_t s) {
         default: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 0>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
         }
     } else {
-        MFH_DISPATCH(a, CALL);
+        MFH_DISPATCH_ASM(a, CALL);
     }
 #undef CALL
     CHECK_LAUNCH();
@@ -1191,7 +1249,7 @@ void launch_assemble_atomic(const AsmArgs &a, hipStream_t s) {
     const int64_t total = a.nElem * a.npe * a.npe;
     const int grid = grid_for(total, 256 * 32);
 #define CALL(D, G, M) hipLaunchKernelGGL((k_assemble_atomic<D, G, M>), dim3(grid), dim3(256), 0, s, a)
-    MFH_DISPATCH(a, CALL);
+    MFH_DISPATCH_ASM(a, CALL);
 #undef CALL
     CHECK_LAUNCH();
 }
@@ -1199,7 +1257,7 @@ void launch_assemble_atomic(const AsmArgs &a, hipStream_t s) {
 void launch_element_stiffness(const AsmArgs &a, int64_t first, int64_t count, double *KeOut, hipStream_t s) {
     const int grid = grid_for(count * a.npe * a.npe);
 #define CALL(D, G, M) hipLaunchKernelGGL((k_element_stiffness<D, G, M>), dim3(grid), dim3(256), 0, s, a, first, count, KeOut)
-    MFH_DISPATCH(a, CALL);
+    MFH_DISPATCH_ASM(a, CALL);
 #undef CALL
     CHECK_LAUNCH();
 }
@@ -1233,12 +1291,27 @@ void launch_average_strain(const AsmArgs &a, const int32_t *elemNodes, const dou
     CHECK_LAUNCH();
 }
 
+void launch_average_gradient(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, double *out,
+                             hipStream_t s) {
+    const LoadArgs l = make_load_args(a, elemNodes, nullptr, intGrad, nullptr);
+    const int grid = grid_for(a.nElem, 8192);
+    if (a.dim == 3) {
+        if (a.deg == 2) hipLaunchKernelGGL((k_average_gradient<3, 2>), dim3(grid), dim3(256), 0, s, l, uNodes, out);
+        else hipLaunchKernelGGL((k_average_gradient<3, 1>), dim3(grid), dim3(256), 0, s, l, uNodes, out);
+    } else {
+        if (a.deg == 2) hipLaunchKernelGGL((k_average_gradient<2, 2>), dim3(grid), dim3(256), 0, s, l, uNodes, out);
+        else hipLaunchKernelGGL((k_average_gradient<2, 1>), dim3(grid), dim3(256), 0, s, l, uNodes, out);
+    }
+    CHECK_LAUNCH();
+}
+
 static int spmv_grid(const SpmvArgs &a) { return (int)std::max<int64_t>(1, std::min<int64_t>(a.nChunk, 256 * 8)); }
 
 void launch_spmv(const SpmvArgs &a, const double *x, double *y, double *dotOut, hipStream_t s) {
     if (a.nChunk == 0) return;
     const size_t lds = ((size_t)a.dim * a.chunkSlots + 16) * sizeof(double);
-    if (a.dim == 3) hipLaunchKernelGGL((k_spmv<3, false>), dim3(spmv_grid(a)), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr);
+    if (a.dim == 1) hipLaunchKernelGGL((k_spmv<1, false>), dim3(spmv_grid(a)), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr);
+    else if (a.dim == 3) hipLaunchKernelGGL((k_spmv<3, false>), dim3(spmv_grid(a)), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr);
     else hipLaunchKernelGGL((k_spmv<2, false>), dim3(spmv_grid(a)), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr);
     CHECK_LAUNCH();
 }
@@ -1246,7 +1319,8 @@ void launch_spmv(const SpmvArgs &a, const double *x, double *y, double *dotOut, 
 void launch_pcg_spmv(const SpmvArgs &a, const double *p, double *Ap, double *scal, int it, const double *stopPtr, hipStream_t s) {
     if (a.nChunk == 0) return;
     const size_t lds = ((size_t)a.dim * a.chunkSlots + 16) * sizeof(double);
-    if (a.dim == 3) hipLaunchKernelGGL((k_spmv<3, true>), dim3(spmv_grid(a)), dim3(256), lds, s, a, p, Ap, (double *)nullptr, scal, it, stopPtr);
+    if (a.dim == 1) hipLaunchKernelGGL((k_spmv<1, true>), dim3(spmv_grid(a)), dim3(256), lds, s, a, p, Ap, (double *)nullptr, scal, it, stopPtr);
+    else if (a.dim == 3) hipLaunchKernelGGL((k_spmv<3, true>), dim3(spmv_grid(a)), dim3(256), lds, s, a, p, Ap, (double *)nullptr, scal, it, stopPtr);
     else hipLaunchKernelGGL((k_spmv<2, true>), dim3(spmv_grid(a)), dim3(256), lds, s, a, p, Ap, (double *)nullptr, scal, it, stopPtr);
     CHECK_LAUNCH();
 }
@@ -1260,27 +1334,31 @@ void launch_untile_vals(int dim, int64_t nnzb, const double *tiled, double *aos,
 void launch_extract_diag_inv(int dim, int64_t nRows, const int32_t *rowPtr, const int32_t *colIdx, const double *vals,
                              const uint8_t *fixedMask, int kind, double *dinv, hipStream_t s) {
     const int grid = (int)((nRows + 255) / 256);
-    if (dim == 3) hipLaunchKernelGGL(k_diag_inv<3>, dim3(grid), dim3(256), 0, s, nRows, rowPtr, colIdx, vals, fixedMask, kind, dinv);
+    if (dim == 1) hipLaunchKernelGGL(k_diag_inv<1>, dim3(grid), dim3(256), 0, s, nRows, rowPtr, colIdx, vals, fixedMask, kind, dinv);
+    else if (dim == 3) hipLaunchKernelGGL(k_diag_inv<3>, dim3(grid), dim3(256), 0, s, nRows, rowPtr, colIdx, vals, fixedMask, kind, dinv);
     else hipLaunchKernelGGL(k_diag_inv<2>, dim3(grid), dim3(256), 0, s, nRows, rowPtr, colIdx, vals, fixedMask, kind, dinv);
     CHECK_LAUNCH();
 }
 
 void launch_precond(int dim, int64_t nRows, const double *dinv, const double *r, double *z, hipStream_t s) {
-    if (dim == 3) hipLaunchKernelGGL(k_precond<3>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, r, z);
+    if (dim == 1) hipLaunchKernelGGL(k_precond<1>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, r, z);
+    else if (dim == 3) hipLaunchKernelGGL(k_precond<3>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, r, z);
     else hipLaunchKernelGGL(k_precond<2>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, r, z);
     CHECK_LAUNCH();
 }
 
 void launch_pcg_init(int dim, int64_t nRows, const double *dinv, const double *b, double *x, double *r, double *z, double *p,
                      double *scal, hipStream_t s) {
-    if (dim == 3) hipLaunchKernelGGL(k_pcg_init<3>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal);
+    if (dim == 1) hipLaunchKernelGGL(k_pcg_init<1>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal);
+    else if (dim == 3) hipLaunchKernelGGL(k_pcg_init<3>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal);
     else hipLaunchKernelGGL(k_pcg_init<2>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal);
     CHECK_LAUNCH();
 }
 
 void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double *p, const double *Ap, double *x, double *r,
                        double *z, double *scal, int it, const double *stopPtr, hipStream_t s) {
-    if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
+    if (dim == 1) hipLaunchKernelGGL((k_pcg_update<1, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
+    else if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
     else hipLaunchKernelGGL((k_pcg_update<2, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
     CHECK_LAUNCH();
 }

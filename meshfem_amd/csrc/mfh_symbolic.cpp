@@ -346,6 +346,39 @@ void build_shape_tables(int dim, int deg, ShapeTables &T) {
         }
         T.intGrad[(size_t)i * 2] = al; T.intGrad[(size_t)i * 2 + 1] = be;
     }
+    // reference mass matrix int phi_i phi_j over the unit-volume simplex, exactly: shape functions are
+    // polynomials in the barycentric coordinates (Functions.hh:86-102) and
+    // int l^a = K! prod(a_k!) / (sum a + K)!  -- what Quadrature<K, 2 Deg> (MassMatrix.hh:66-77) evaluates
+    // exactly as well, so the two agree to rounding.
+    struct Mono { double c; int e[4]; };
+    auto shapePoly = [&](int i) {
+        std::vector<Mono> pnl;
+        if (deg == 1) { Mono m{1.0, {0, 0, 0, 0}}; m.e[i] = 1; pnl.push_back(m); return pnl; }
+        if (i < nv) {   // 2 l_i (l_i - 1/2) = 2 l_i^2 - l_i
+            Mono a{2.0, {0, 0, 0, 0}}, b{-1.0, {0, 0, 0, 0}};
+            a.e[i] = 2; b.e[i] = 1;
+            pnl.push_back(a); pnl.push_back(b);
+            return pnl;
+        }
+        Mono m{4.0, {0, 0, 0, 0}};   // 4 l_s l_t
+        m.e[kEdgeStart[i - nv]] += 1; m.e[kEdgeEnd[i - nv]] += 1;
+        pnl.push_back(m);
+        return pnl;
+    };
+    auto fact = [](int n) { double f = 1; for (int k = 2; k <= n; ++k) f *= k; return f; };
+    T.massRef.assign((size_t)npe * npe, 0.0);
+    for (int i = 0; i < npe; ++i)
+        for (int j = 0; j < npe; ++j) {
+            double acc = 0;
+            for (const Mono &a : shapePoly(i))
+                for (const Mono &b : shapePoly(j)) {
+                    int tot = 0;
+                    double num = fact(dim);
+                    for (int k = 0; k < nv; ++k) { const int ex = a.e[k] + b.e[k]; tot += ex; num *= fact(ex); }
+                    acc += a.c * b.c * num / fact(tot + dim);
+                }
+            T.massRef[(size_t)i * npe + j] = acc;
+        }
 }
 
 } // namespace mfh

@@ -54,6 +54,42 @@ def homogenized_elasticity_tensor(sim: Simulator, w_ij, base_cell_volume=0.0):
     return Eh
 
 
+def _bdry_shape_integrals(K, deg):
+    """Integrals of the boundary element's nodal shape functions over a unit-volume (K-1)-simplex
+    (Interpolant::integrate, Functions.hh:246-318): P1 equal weights; P2 edge 1/6,1/6,4/6; P2 triangle 0 at
+    the vertices, 1/3 at the edge nodes."""
+    if deg == 1:
+        return np.full(K, 1.0 / K)
+    return np.array([1 / 6.0, 1 / 6.0, 4 / 6.0]) if K == 2 else np.array([0, 0, 0, 1 / 3.0, 1 / 3.0, 1 / 3.0])
+
+
+def homogenized_elasticity_tensor_displacement_form(sim: Simulator, w_ij, base_cell_volume=0.0):
+    """== homogenizedElasticityTensorDisplacementForm (PeriodicHomogenization.hh:146-186), the form the
+    reference's Python binding returns: Eh.DRow(i) = 1/|Y| [E : sum_be sym(int_be w_i (x) n) + E vol(omega)].
+    Assumes a constant base tensor (element 0's), like the reference. A boundary sum over tens of thousands of
+    faces at most: evaluated on the host from the device solution."""
+    N, fl = sim.N, flat_len(sim.N)
+    c = sim.ctx
+    D = c.material_get(0)
+    ben = c.boundary_elem_nodes()
+    area, nrm = c.boundary_elem_geometry()
+    wts = _bdry_shape_integrals(N, sim.degree)
+    pos = sim.nodes()
+    if base_cell_volume == 0.0:
+        base_cell_volume = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
+    idx = {2: [(0, 0), (1, 1), (0, 1)], 3: [(0, 0), (1, 1), (2, 2), (1, 2), (0, 2), (0, 1)]}[N]
+    dbl = np.ones(fl)
+    dbl[N:] = 2.0
+    Eh = np.zeros((fl, fl))
+    for i in range(fl):
+        w_int = np.einsum("k,bkc->bc", wts, w_ij[i][ben]) * area[:, None]          # int_be w
+        nw = 0.5 * (w_int[:, :, None] * nrm[:, None, :] + nrm[:, :, None] * w_int[:, None, :]).sum(axis=0)
+        nw_flat = np.array([nw[a, b] for a, b in idx])
+        Eh[i, :] = D @ (nw_flat * dbl)                                               # doubleContract (ElasticityTensor.hh:437-449)
+    Eh += D * float(c.elem_volumes().sum())
+    return Eh / base_cell_volume
+
+
 def homogenize(vertices, elements, degree=2, Cbase=None, E=None, nu=None, ortho_params=None, device=0, rtol=1e-8,
               preconditioner=None):
     """Returns dict(Ch, w_ij, strain_w_ij, iterations) like the reference's `homogenize`.

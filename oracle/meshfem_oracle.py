@@ -1127,3 +1127,116 @@ def homogenized_elasticity_tensor(sim: Simulator, w):
         for e in range(len(eps_w)):
             Ch[:, j] += sim.vol[e] * sim.elem_D(e).double_contract_flat(ej + eps_w[e])
     return Ch / tot
+
+
+def homogenized_elasticity_tensor_displacement_form(sim: Simulator, w, base_cell_volume=0.0):
+    """homogenizedElasticityTensorDisplacementForm (PeriodicHomogenization.hh:146-186): boundary-integral
+    form used by the Python binding (periodic_homogenization.cc:59); constant base tensor = element 0's."""
+    N, fl = sim.N, flat_len(sim.N)
+    mesh = sim.mesh
+    if base_cell_volume == 0.0:
+        mn, mx = mesh.bounding_box()
+        base_cell_volume = float(np.prod(mx - mn))
+    EBase = sim.elem_D(0)
+    bvol, bnrm = mesh.bdry_elem_geometry()
+    wts = integrated_shape_functions(mesh.deg, mesh.K - 1)
+    Eh = np.zeros((fl, fl))
+    for b in range(len(mesh.bdry_elem_nodes)):
+        n = bnrm[b]
+        for i in range(fl):
+            w_be = w[i][mesh.bdry_elem_nodes[b]]                       # boundary-node displacements (:170-171)
+            w_int = (wts[:, None] * w_be).sum(axis=0) * bvol[b]       # w_be.integrate(be->volume())
+            nw = 0.5 * (np.outer(w_int, n) + np.outer(n, w_int))
+            Eh[i, :] += EBase.double_contract_flat(flatten_sym(N, nw))
+    Eh += EBase.D * float(np.sum(sim.vol))
+    return Eh / base_cell_volume
+
+
+# --------------------------------------------------------------------------------------
+# Scalar operators on the same mesh: Laplacian.hh, MassMatrix.hh, Poisson.hh
+# --------------------------------------------------------------------------------------
+def laplacian_triplets(mesh: FEMMesh):
+    """Laplacian::construct (Laplacian.hh:27-57,97-104): upper triangle of int grad phi_i . grad phi_j with
+    Quadrature<N, 2(Deg-1)>, local loop i <= j, entry placed at (min, max) of the global node indices.
+    The degree-1 specialisation (:60-81) is the same formula with constant gradients."""
+    K, deg = mesh.K, mesh.deg
+    vol, gl = mesh.embeddings_batch()
+    n = mesh.nodes_per_elem
+    pts, w = quadrature_rule(K, 2 * (deg - 1))
+    T = TripletMatrix(mesh.num_nodes, mesh.num_nodes)
+    I, J, V = [], [], []
+    for e in range(len(mesh.elems)):
+        G = [grad_phis_at(deg, K, gl[e], p) for p in pts]           # each N x n
+        nodes = mesh.elem_nodes[e]
+        for i in range(n):
+            for j in range(i, n):
+                val = 0.0
+                for q in range(len(w)):
+                    val += w[q] * float(G[q][:, i] @ G[q][:, j])
+                val *= vol[e]
+                ni, nj = int(nodes[i]), int(nodes[j])
+                I.append(min(ni, nj)); J.append(max(ni, nj)); V.append(val)
+    return TripletMatrix.from_arrays(mesh.num_nodes, mesh.num_nodes, np.array(I), np.array(J), np.array(V))
+
+
+def mass_triplets(mesh: FEMMesh, lumped=False):
+    """MassMatrix::construct (MassMatrix.hh:50-86,103-128): upper triangle of int phi_i phi_j with
+    Quadrature<K, 2 Deg>; `lumped` sums every row of the full matrix onto the diagonal (:110-124)."""
+    K, deg = mesh.K, mesh.deg
+    vol, _ = mesh.embeddings_batch()
+    n = mesh.nodes_per_elem
+    pts, w = quadrature_rule(K, 2 * deg)
+    Phi = np.array([shape_functions(deg, K, p) for p in pts])      # nq x n
+    Mref = np.einsum('q,qi,qj->ij', w, Phi, Phi)
+    I, J, V = [], [], []
+    for e in range(len(mesh.elems)):
+        nodes = mesh.elem_nodes[e]
+        for i in range(n):
+            for j in range(n):
+                ni, nj = int(nodes[i]), int(nodes[j])
+                if nj < ni:
+                    continue                                         # upper triangle only (:63)
+                I.append(ni); J.append(nj); V.append(Mref[i, j] * vol[e])
+    I, J, V = np.array(I), np.array(J), np.array(V)
+    if lumped:
+        diag = np.zeros(mesh.num_nodes)
+        np.add.at(diag, I, V)
+        off = I != J
+        np.add.at(diag, J[off], V[off])
+        r = np.arange(mesh.num_nodes)
+        return TripletMatrix.from_arrays(mesh.num_nodes, mesh.num_nodes, r, r, diag)
+    return TripletMatrix.from_arrays(mesh.num_nodes, mesh.num_nodes, I, J, V)
+
+
+def poisson_solve(mesh: FEMMesh, dirichlet_boxes):
+    """PoissonMesh::applyBoundaryConditions + solve (Poisson.hh:57-117): Dirichlet value on the BOUNDARY
+    nodes inside each (inclusive) box -- later conditions overwrite earlier ones -- zero right-hand side,
+    zero-Neumann elsewhere. dirichlet_boxes: list of (min_corner, max_corner, value)."""
+    ctype = {}
+    for mn, mx, val in dirichlet_boxes:
+        mn, mx = np.asarray(mn, dtype=np.float64), np.asarray(mx, dtype=np.float64)
+        for bn in mesh.bdry_nodes:
+            p = mesh.node_pos[bn]
+            if np.all(p >= mn) and np.all(p <= mx):
+                ctype[int(bn)] = float(val)
+    L = laplacian_triplets(mesh)
+    system = SPSDSystem(L)
+    fixed = [bn for bn in mesh.bdry_nodes if int(bn) in ctype]      # boundary-node order (:106-112)
+    system.fix_variables([int(b) for b in fixed], [ctype[int(b)] for b in fixed])
+    return system.solve(np.zeros(mesh.num_nodes)), np.array(fixed, dtype=np.int64)
+
+
+def grad_u_average(mesh: FEMMesh, u):
+    """PoissonMesh::gradUAverage (Poisson.hh:121-131): average over the element of sum_i u_i grad phi_i
+    (the degree-(Deg-1) interpolant's average = mean of its vertex values, Functions.hh:246-253)."""
+    K, deg = mesh.K, mesh.deg
+    _, gl = mesh.embeddings_batch()
+    out = np.zeros((len(mesh.elems), mesh.N))
+    for e in range(len(mesh.elems)):
+        nodes = mesh.elem_nodes[e]
+        acc = np.zeros(mesh.N)
+        for i in range(mesh.nodes_per_elem):
+            gp = grad_phi_nodal(deg, K, gl[e], i)                    # nodal values of the interpolant
+            acc += u[nodes[i]] * gp.mean(axis=0)
+        out[e] = acc
+    return out

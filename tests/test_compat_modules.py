@@ -1,0 +1,152 @@
+"""The reference's Python module names (mesh, tensors, sparse_matrices, periodic_homogenization) as shims over
+the C ABI (meshfem_amd/compat). CPU part: host-only behaviour; GPU part: solves against scipy / the goldens."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import meshfem_amd.compat as compat
+
+sys.path.insert(0, compat.PATH)
+import mesh as cmesh                     # noqa: E402
+import tensors as ctensors               # noqa: E402
+import sparse_matrices as csm            # noqa: E402
+import periodic_homogenization as cph    # noqa: E402
+
+from oracle import meshfem_oracle as O   # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_tensors_module():
+    t = ctensors.ElasticityTensor3D(200.0, 0.35)
+    ref = O.ElasticityTensor.isotropic(3, 200.0, 0.35)
+    assert np.abs(t.D - ref.D).max() < 1e-12
+    for idx in ((0, 0, 0, 0), (0, 1, 0, 1), (0, 0, 1, 1), (1, 2, 2, 1), (0, 2, 1, 1)):
+        assert abs(t(*idx) - ref(*idx)) < 1e-12
+    with pytest.raises(RuntimeError):
+        t(3, 0, 0, 0)
+    t.setOrthotropic(150, 200, 250, 0.3, 0.25, 0.2, 60, 70, 80)
+    assert np.abs(t.D - O.ElasticityTensor.orthotropic3d(150, 200, 250, 0.3, 0.25, 0.2, 60, 70, 80).D).max() < 1e-10
+    # inverse: S : (C : e) = e for a symmetric strain
+    e = np.array([0.3, -0.1, 0.2, 0.05, -0.07, 0.11])
+    assert np.abs(t.inverse().doubleContract(t.doubleContract(e)) - e).max() < 1e-13
+    t2 = ctensors.ElasticityTensor2D(10.0, 0.3)
+    assert abs(t2(0, 0, 1, 1) - 0.3 * 10 / (1 - 0.09)) < 1e-13
+    sm = ctensors.SymmetricMatrix([1.0, 2.0, 3.0, 0.4, 0.5, 0.6])
+    assert sm(1, 2) == 0.4 and sm(0, 2) == 0.5 and sm(0, 1) == 0.6 and np.allclose(sm.toMatrix(), sm.toMatrix().T)
+    assert np.allclose(ctensors.SymmetricMatrix(sm.toMatrix()).flat, sm.flat)
+    ident = ctensors.ElasticityTensor3D().setIdentity()
+    assert np.allclose(ident.doubleContract(e), e)
+
+
+def test_triplet_matrix_module(tmp_path):
+    A = csm.TripletMatrix(4, 4)
+    for i, j, v in ((0, 0, 2.0), (0, 1, -1.0), (1, 1, 2.0), (0, 1, 0.5), (2, 3, 1.0), (2, 3, -1.0), (3, 3, 4.0), (2, 2, 3.0)):
+        A.addNZ(i, j, v)
+    with pytest.raises(RuntimeError):
+        A.addNZ(4, 0, 1.0)
+    assert A.nnz == 8
+    A.sumRepeated()                        # duplicates summed, exact zero (2,3) dropped, (col,row) order
+    ents = [(t.i, t.j, t.v) for t in A.entries()]
+    assert ents == [(0, 0, 2.0), (0, 1, -0.5), (1, 1, 2.0), (2, 2, 3.0), (3, 3, 4.0)]
+    A.symmetry_mode = "UPPER_TRIANGLE"
+    x = np.array([1.0, 2.0, 3.0, 4.0])
+    full = np.array([[2, -0.5, 0, 0], [-0.5, 2, 0, 0], [0, 0, 3, 0], [0, 0, 0, 4.0]])
+    assert np.allclose(A.apply(x), full @ x)
+    assert np.allclose(A.diag(), np.diag(full))
+    p = str(tmp_path / "a.bin")
+    A.dumpBinary(p)
+    B = csm.TripletMatrix()
+    B.readBinary(p)
+    assert (B.m, B.n, B.nnz) == (4, 4, 5) and [(t.i, t.j, t.v) for t in B.entries()] == ents
+    # same bytes as the oracle's dumpBinary (SparseMatrices.hh:623-645)
+    T = O.TripletMatrix.from_arrays(4, 4, *A.arrays())
+    q = str(tmp_path / "b.bin")
+    T.dump_binary(q)
+    assert open(p, "rb").read() == open(q, "rb").read()
+    A.reflectUpperTriangle()
+    assert np.allclose(A.toSciPy().toarray(), full)
+
+
+def test_mesh_module_host_only():
+    m = cmesh.Mesh(os.path.join(GOLD, "meshes", "cube_cross.msh"), degree=2)
+    ref = O.FEMMesh(m.elements(), m.vertices(), 2)
+    assert (m.numVertices(), m.numElements(), m.numNodes()) == (64, 132, ref.num_nodes)
+    assert np.array_equal(m.elementNodes(), ref.elem_nodes) and np.allclose(m.nodes(), ref.node_pos)
+    assert np.array_equal(m.boundaryNodes(), ref.bdry_nodes)
+    assert m.degree == 2 and m.simplexDimension == 3 and m.embeddingDimension == 3
+    assert abs(m.volume - ref.embeddings_batch()[0].sum()) < 1e-13 and abs(m.bbox_volume - 8.0) < 1e-13
+    pc = cmesh.PeriodicCondition(m)
+    assert np.array_equal(pc.periodicDoFsForNodes(), O.periodic_dofs_for_nodes(ref)[0])
+    m2 = cmesh.Mesh(os.path.join(GOLD, "meshes", "2D_microstructure.msh"), degree=1, embeddingDimension=2)
+    assert m2.embeddingDimension == 2 and m2.vertices().shape[1] == 2 and m2.elementVolumes().min() > 0
+    V, F = m2.vertices(), m2.elements()
+    assert cmesh.Mesh(V, F, 2, 2).numNodes() == O.FEMMesh(F, V, 2).num_nodes
+
+
+@pytest.mark.gpu
+def test_spsd_system_on_caller_matrix():
+    """sparse_matrices.SPSDSystem(K).fixVariables / solve on an arbitrary SPD matrix (a 2D 9-point-like
+    stencil + random SPD perturbation), against scipy's direct solve."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    rng = np.random.default_rng(0)
+    n = 400
+    B = sp.random(n, n, density=0.01, random_state=1, format="csr")
+    A = (B @ B.T + sp.diags(np.full(n, 0.5)) + sp.diags([-0.1] * (n - 1), 1) + sp.diags([-0.1] * (n - 1), -1)).tocoo()
+    K = csm.TripletMatrix(n, n)
+    for i, j, v in zip(A.row, A.col, A.data):
+        if i <= j:
+            K.addNZ(int(i), int(j), float(v) * 0.5)      # split into two halves: SPSDSystem must sum repeats
+            K.addNZ(int(i), int(j), float(v) * 0.5)
+    K.symmetry_mode = "UPPER_TRIANGLE"
+    sysm = csm.SPSDSystem(K)
+    Afull = A.tocsr()
+    assert np.abs(sysm.ctx.export_scipy() - Afull).max() < 1e-13 * np.abs(Afull).max()
+    b = rng.standard_normal(n)
+    x = sysm.solve(b)
+    assert np.linalg.norm(x - spl.spsolve(Afull.tocsc(), b)) < 1e-8 * np.linalg.norm(x)
+    # fixVariables: reduced system with the fixed values moved to the right-hand side (SparseMatrices.hh:2457-2470)
+    fv = np.array([3, 77, 150, 399])
+    fx = np.array([0.5, -1.0, 0.0, 2.0])
+    sysm.fixVariables(fv.tolist(), fx.tolist())
+    x = sysm.solve(b)
+    free = np.setdiff1d(np.arange(n), fv)
+    xr = np.zeros(n); xr[fv] = fx
+    rhs = b[free] - Afull[free][:, fv] @ fx
+    xr[free] = spl.spsolve(Afull[free][:, free].tocsc(), rhs)
+    assert np.array_equal(x[fv], fx)
+    assert np.linalg.norm(x - xr) < 1e-8 * np.linalg.norm(xr)
+    with pytest.raises(Exception):
+        sysm.fixVariables([3], [1.0])                    # "Variable already fixed."
+    with pytest.raises(RuntimeError):
+        csm.SPSDSystem(K, C=K)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,dim,deg", [("cube_cross", 3, 2), ("2D_microstructure", 2, 2), ("2D_microstructure", 2, 1)])
+def test_periodic_homogenization_module(name, dim, deg):
+    g = np.load(os.path.join(GOLD, "example_meshes.npz"))
+    m = cmesh.Mesh(os.path.join(GOLD, "meshes", name + ".msh"), degree=deg, embeddingDimension=dim)
+    Cbase = (ctensors.ElasticityTensor3D if dim == 3 else ctensors.ElasticityTensor2D)(200.0, 0.35)
+    hr = cph.homogenize(m, Cbase)
+    key = "%s_hom_p%d_" % (name, deg)
+    # displacement form == stress form for the exact discrete solution (both in the golden's oracle)
+    assert np.abs(hr.Ch.D - g[key + "Ch"]).max() < 1e-7 * np.abs(g[key + "Ch"]).max()
+    for k in range(len(hr.w_ij)):
+        assert np.abs(hr.w_ij[k].mean(axis=0)).max() < 1e-12                  # centred
+        wg = g[key + "w"][k]
+        assert np.linalg.norm(hr.w_ij[k] - (wg - wg.mean(axis=0))) < 1e-6 * np.linalg.norm(wg)
+    # probe: u = E x + w with the face-average translation removed; strain = E + strain(w)
+    fl = 6 if dim == 3 else 3
+    ms = np.zeros(fl); ms[0] = 0.01; ms[fl - 1] = 0.005
+    u, su = cph.probe(m, hr, ctensors.SymmetricMatrix(ms))
+    assert u.shape == (m.numNodes(), dim) and su.shape == (m.numElements(), fl)
+    vol = m.elementVolumes()
+    sim = O.Simulator(m.elements(), m.vertices(), deg)
+    avg = (vol[:, None] * sim.averageStrainField(u)).sum(axis=0) / vol.sum()
+    assert np.abs(avg - (vol[:, None] * su).sum(axis=0) / vol.sum()).max() < 1e-10
+    u2, _ = cph.probe(m, Cbase, ms)
+    assert np.abs(u2 - u).max() < 1e-7 * np.abs(u).max()
