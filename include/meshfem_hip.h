@@ -232,6 +232,18 @@ mfh_status mfh_constant_strain_load(mfh_ctx* ctx, const double* cstrainFlat, dou
  * (:664-677) as nNode x dim. f==NULL uses neumannLoad() (:657).                                */
 mfh_status mfh_sim_solve(mfh_ctx* ctx, const double* f /* dim*nDoF or NULL */, int32_t usePin,
                          double* uNodes /* nNode x dim */, double rtol, int32_t maxit, mfh_solve_info* info);
+/* Simulator::solve with ALL of assembleConstrainedSystem (LinearElasticity.hh:1201-1249). flags:
+ *   MFH_SOLVE_PIN               m_useNRTPinConstraint: translations removed by pinning a node (:1595-1618) instead of rows
+ *   MFH_SOLVE_NO_RIGID_MOTION   m_useRigidMotionConstraint (`no_rigid_motion` in .bc files): rotation rows (:1525-1566,
+ *                               skipped under periodic conditions) + translation rows or pin; rigidMotionRHS optional
+ *   MFH_SOLVE_ALLOW_ILL_POSED   allowIllPosed: Dirichlet variables only
+ *   0                           default: analyzeDirichletPosedness (:1169-1190) adds translation constraints for the
+ *                               components without any Dirichlet condition; "Unimplemented" if nothing is constrained.
+ * The reference hands the resulting KKT system to UMFPACK; here the <= 6 constraint rows are eliminated around SPD
+ * PCG solves (one consistent singular solve when they exactly remove the rigid motions, k + 1 solves otherwise). */
+enum { MFH_SOLVE_PIN = 1, MFH_SOLVE_NO_RIGID_MOTION = 2, MFH_SOLVE_ALLOW_ILL_POSED = 4 };
+mfh_status mfh_sim_solve_constrained(mfh_ctx* ctx, const double* f, int32_t flags, const double* rigidMotionRHS,
+                                     int32_t nRigidRHS, double* uNodes, double rtol, int32_t maxit, mfh_solve_info* info);
 /* == averageStrainField / averageStressField (:528-549, :99-123): per element, flattened (flatLen) */
 mfh_status mfh_average_strain(mfh_ctx* ctx, const double* uNodes, double* strain /* nElem x flatLen */);
 mfh_status mfh_average_stress(mfh_ctx* ctx, const double* uNodes, double* stress /* nElem x flatLen */);

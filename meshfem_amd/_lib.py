@@ -13,6 +13,7 @@ ASSEMBLE_GATHER, ASSEMBLE_ATOMIC = 0, 1
 NEUMANN_TRACTION, NEUMANN_PRESSURE, NEUMANN_FORCE = 0, 1, 2
 PRECOND_BLOCK_JACOBI, PRECOND_JACOBI, PRECOND_NONE, PRECOND_TWO_LEVEL = 0, 1, 2, 3
 OP_ELASTICITY, OP_LAPLACIAN, OP_MASS = 0, 1, 2
+SOLVE_PIN, SOLVE_NO_RIGID_MOTION, SOLVE_ALLOW_ILL_POSED = 1, 2, 4
 
 
 class SolveInfo(C.Structure):
@@ -86,6 +87,7 @@ PROTOTYPES = {
     "mfh_sim_solve": (_i32, [_P, _P, _i32, _P, _f64, _i32, C.POINTER(SolveInfo)]),
     "mfh_average_strain": (_i32, [_P, _P, _P]),
     "mfh_average_stress": (_i32, [_P, _P, _P]),
+    "mfh_sim_solve_constrained": (_i32, [_P, _P, _i32, _P, _i32, _P, _f64, _i32, C.POINTER(SolveInfo)]),
     "mfh_set_operator": (_i32, [_P, _i32]),
     "mfh_matrix_set_upper_triplets": (_i32, [_P, _i64, _i64, _P, _P, _P]),
     "mfh_average_gradient": (_i32, [_P, _P, _P]),

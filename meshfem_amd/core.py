@@ -326,6 +326,19 @@ class Context:
         self._ck(st)
         return u
 
+    def sim_solve_constrained(self, f=None, flags=0, rigid_motion_rhs=None, rtol=1e-8, maxit=100000):
+        """Simulator::solve with the pin / translation / rotation constraints of assembleConstrainedSystem
+        (flags: SOLVE_PIN | SOLVE_NO_RIGID_MOTION | SOLVE_ALLOW_ILL_POSED; 0 = posedness analysis)."""
+        fp = None if f is None else as_f64(f)
+        rr = None if rigid_motion_rhs is None else as_f64(rigid_motion_rhs)
+        u = np.empty((self.n_node, self.bs))
+        info = L.SolveInfo()
+        st = self.lib.mfh_sim_solve_constrained(self.h, ptr(fp), int(flags), ptr(rr), 0 if rr is None else len(rr), ptr(u),
+                                                float(rtol), int(maxit), C.byref(info))
+        self.last_info = info.as_dict()
+        self._ck(st)
+        return u
+
     def average_strain(self, u_nodes):
         u = as_f64(u_nodes)
         out = np.empty((self.n_elem, flat_len(self.dim)))

@@ -67,6 +67,8 @@ struct mfh_ctx {
     DBuf<double> dFixedVal;
     bool fixedUploaded = false;
     bool anyFixedNonzero = false;
+    bool tlSuppress = false;          // solve_one: block-Jacobi for this solve (K singular on the free variables)
+    bool solveHomogeneous = false;    // solve_one: treat the fixed values as 0 (columns of the Schur complement)
 
     // ---- solver
     int precond = MFH_PRECOND_BLOCK_JACOBI;
@@ -604,7 +606,7 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
     MFH_HIP(hipMemcpyAsync(c->wf.p, f, n * sizeof(double), hipMemcpyHostToDevice, s));
     // b = f - K ubar on the free variables (SparseMatrices.hh:2457-2470,2526-2535)
     MFH_HIP(hipMemcpyAsync(c->wb.p, c->wf.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-    if (c->anyFixedNonzero) {
+    if (c->anyFixedNonzero && !c->solveHomogeneous) {
         c->wu0.alloc(n);
         c->wu0.zero(s);
         k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wu0.p, s);
@@ -627,7 +629,7 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
         li.converged = 1;
     } else {
         EventTimer tsolve(s);
-        const bool useTL = c->precond == MFH_PRECOND_TWO_LEVEL && c->tl.valid;
+        const bool useTL = c->precond == MFH_PRECOND_TWO_LEVEL && c->tl.valid && !c->tlSuppress;
         k::launch_pcg_init(d, c->sym.nRows, c->dDinv.p, c->wb.p, c->wx.p, c->wr.p, c->wz.p, c->wp.p, c->scal.p, s);
         if (useTL) {   // replace z, p and r.z of the block-Jacobi initialisation
             MFH_HIP(hipMemsetAsync(c->scal.p, 0, sizeof(double), s));
@@ -669,7 +671,7 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
     li.iterations = itDone;
     li.rel_residual = bb > 0 ? std::sqrt(rrFinal / bb) : 0.0;
     // u = x + ubar  (SparseMatrices.hh:2592-2605)
-    if (!c->fixedVars.empty())
+    if (!c->fixedVars.empty() && !c->solveHomogeneous)
         k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wx.p, s);
     // true residual on the free variables: || mask(f - K u) || / ||b||
     if (bb > 0) {
@@ -1437,20 +1439,146 @@ mfh_status mfh_constant_strain_load(mfh_ctx *c, const double *cstrain, double *o
     MFH_CATCH(c)
 }
 
-mfh_status mfh_sim_solve(mfh_ctx *c, const double *f, int32_t usePin, double *uNodes, double rtol, int32_t maxit,
-                         mfh_solve_info *info) {
-    MFH_TRY(c)
-    require(c && c->haveMesh && uNodes, MFH_ERR_STATE, "no mesh set");
+// ---- small dense helpers for the constraint rows (k <= 6)
+static bool dense_solve(int k, std::vector<double> A /* k x k row-major */, std::vector<double> &b) {
+    for (int col = 0; col < k; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < k; ++r)
+            if (std::fabs(A[(size_t)r * k + col]) > std::fabs(A[(size_t)piv * k + col])) piv = r;
+        if (!(std::fabs(A[(size_t)piv * k + col]) > 0)) return false;
+        if (piv != col) {
+            for (int q = 0; q < k; ++q) std::swap(A[(size_t)piv * k + q], A[(size_t)col * k + q]);
+            std::swap(b[piv], b[col]);
+        }
+        for (int r = col + 1; r < k; ++r) {
+            const double fct = A[(size_t)r * k + col] / A[(size_t)col * k + col];
+            for (int q = col; q < k; ++q) A[(size_t)r * k + q] -= fct * A[(size_t)col * k + q];
+            b[r] -= fct * b[col];
+        }
+    }
+    for (int r = k - 1; r >= 0; --r) {
+        double v = b[r];
+        for (int q = r + 1; q < k; ++q) v -= A[(size_t)r * k + q] * b[q];
+        b[r] = v / A[(size_t)r * k + r];
+    }
+    return true;
+}
+// cyclic Jacobi eigen-decomposition of a small symmetric matrix: A -> eigenvalues on the diagonal, V columns = eigenvectors
+static void jacobi_eig(int k, std::vector<double> &A, std::vector<double> &V) {
+    V.assign((size_t)k * k, 0.0);
+    for (int q = 0; q < k; ++q) V[(size_t)q * k + q] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p2 = 0; p2 < k; ++p2)
+            for (int q = p2 + 1; q < k; ++q) off += A[(size_t)p2 * k + q] * A[(size_t)p2 * k + q];
+        if (off < 1e-300) break;
+        for (int p2 = 0; p2 < k; ++p2)
+            for (int q = p2 + 1; q < k; ++q) {
+                const double apq = A[(size_t)p2 * k + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double th = (A[(size_t)q * k + q] - A[(size_t)p2 * k + p2]) / (2 * apq);
+                const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1));
+                const double cs = 1 / std::sqrt(t * t + 1), sn = t * cs;
+                for (int r = 0; r < k; ++r) {
+                    const double arp = A[(size_t)r * k + p2], arq = A[(size_t)r * k + q];
+                    A[(size_t)r * k + p2] = cs * arp - sn * arq; A[(size_t)r * k + q] = sn * arp + cs * arq;
+                }
+                for (int r = 0; r < k; ++r) {
+                    const double apr = A[(size_t)p2 * k + r], aqr = A[(size_t)q * k + r];
+                    A[(size_t)p2 * k + r] = cs * apr - sn * aqr; A[(size_t)q * k + r] = sn * apr + cs * aqr;
+                }
+                for (int r = 0; r < k; ++r) {
+                    const double vrp = V[(size_t)r * k + p2], vrq = V[(size_t)r * k + q];
+                    V[(size_t)r * k + p2] = cs * vrp - sn * vrq; V[(size_t)r * k + q] = sn * vrp + cs * vrq;
+                }
+            }
+    }
+}
+static double hdot(const std::vector<double> &a, const std::vector<double> &b) {
+    const int nt = host_threads();
+    std::vector<double> part((size_t)nt + 1, 0.0);
+    parallel_ranges((int64_t)a.size(), [&](int64_t lo, int64_t hi, int tid) {
+        double v = 0;
+        for (int64_t q = lo; q < hi; ++q) v += a[q] * b[q];
+        part[tid] += v;
+    });
+    double v = 0;
+    for (double x : part) v += x;
+    return v;
+}
+
+// Simulator::solve with the whole of assembleConstrainedSystem (LinearElasticity.hh:1201-1249): pin / translation /
+// rotation constraints, Dirichlet variables. The reference solves the resulting KKT system with UMFPACK
+// (SparseMatrices.hh:2572-2590); here the constraint rows C (k <= 6) are eliminated around SPD solves:
+//   * K singular on the free variables with null space Z (rigid motions vanishing on the fixed variables) and
+//     C Z square and regular: multipliers from Z^T (f - C^T l) = 0, ONE consistent singular PCG solve, rigid part of the
+//     solution from C u = c;
+//   * K regular on the free variables: Schur complement S = C K^-1 C^T with k + 1 PCG solves.
+static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const double *rmRHS, int32_t nRM, double *uNodes, double rtol,
+                           int32_t maxit, mfh_solve_info *info) {
     const HostMesh &m = c->mesh;
-    const int d = c->bs();
+    const int d = c->bs(), gd = m.dim;
     const int64_t n = (int64_t)d * c->nDoF;
-    // m_buildConstrainedSystem (LinearElasticity.hh:1377-1404): pin first (assembleConstrainedSystem :1217),
-    // then the Dirichlet variables (:1244)
+    if (c->op != MFH_OP_ELASTICITY) flags = MFH_SOLVE_ALLOW_ILL_POSED;   // rigid motions are an elasticity notion
+    const bool periodic = !c->dofForNode.empty();
     std::vector<int64_t> vars;
     std::vector<double> vals;
-    if (usePin) {
+    std::vector<std::vector<double>> C;
+    std::vector<double> crhs;
+    auto pin = [&](unsigned compMask) {   // m_pinNode (:1595-1618)
         const int64_t pn = pin_node(c);
-        for (int a = 0; a < d; ++a) { vars.push_back((int64_t)d * dof_of(c, pn) + a); vals.push_back(0.0); }
+        for (int a = 0; a < d; ++a)
+            if (compMask & (1u << a)) { vars.push_back((int64_t)d * dof_of(c, pn) + a); vals.push_back(0.0); }
+    };
+    auto addTranslationRows = [&](unsigned compMask) {   // m_appendTranslationMatrix (:1568-1590)
+        for (int a = 0; a < d; ++a) {
+            if (!(compMask & (1u << a))) continue;
+            std::vector<double> row((size_t)n, 0.0);
+            for (int64_t i = 0; i < c->nDoF; ++i) row[(size_t)i * d + a] = 1.0;
+            C.push_back(std::move(row));
+        }
+    };
+    auto rotationRows = [&](std::vector<std::vector<double>> &out) {   // rows of m_appendInfinitesimalRotationMatrix (:1525-1566)
+        const int nr = gd == 3 ? 3 : 1;
+        for (int r = 0; r < nr; ++r) out.emplace_back((size_t)n, 0.0);
+        std::vector<double> *R = &out[out.size() - nr];
+        for (int64_t k2 = 0; k2 < m.nNode; ++k2) {
+            const double *x = &m.nodePos[(size_t)k2 * gd];
+            if (gd == 3) {
+                R[0][(size_t)k2 * 3 + 1] = -x[2]; R[0][(size_t)k2 * 3 + 2] = x[1];
+                R[1][(size_t)k2 * 3 + 0] = x[2];  R[1][(size_t)k2 * 3 + 2] = -x[0];
+                R[2][(size_t)k2 * 3 + 0] = -x[1]; R[2][(size_t)k2 * 3 + 1] = x[0];
+            } else {
+                R[0][(size_t)k2 * 2 + 0] = -x[1]; R[0][(size_t)k2 * 2 + 1] = x[0];
+            }
+        }
+    };
+    const unsigned allComps = (1u << d) - 1;
+    if (flags & MFH_SOLVE_NO_RIGID_MOTION) {
+        // periodic conditions pin the rotations (:1534-1542)
+        bool rot = true;
+        if (gd == 2 && c->nDoF < m.nNode) rot = false;
+        else if (c->nDoF < m.nNode - 1) rot = false;
+        else if (c->nDoF < m.nNode) throw Error(MFH_ERR_UNSUPPORTED, "Single pair periodic BC unsupported in 3D.");
+        if (rot) rotationRows(C);
+        if (flags & MFH_SOLVE_PIN) pin(allComps);
+        else addTranslationRows(allComps);
+        if (rmRHS && nRM > 0) {
+            require((size_t)nRM == C.size(), MFH_ERR_INVALID, "Invalid rigid motion RHS");
+            crhs.assign(rmRHS, rmRHS + nRM);
+        } else crhs.assign(C.size(), 0.0);
+    } else if (!(flags & MFH_SOLVE_ALLOW_ILL_POSED)) {
+        // analyzeDirichletPosedness (:1169-1190)
+        unsigned needsT = allComps;
+        size_t total = 0;
+        for (int32_t bn : m.bdryNodes)
+            for (int a = 0; a < gd; ++a)
+                if (c->dirMask[(size_t)bn * gd + a]) { needsT &= ~(1u << a); ++total; }
+        if (needsT) {
+            if (flags & MFH_SOLVE_PIN) pin(needsT);
+            else { addTranslationRows(needsT); crhs.assign(C.size(), 0.0); }
+        }
+        if (total == 0) throw Error(MFH_ERR_UNSUPPORTED, "Unimplemented");   // needsRotations (:1240): ask for the rigid-motion constraint
     }
     dirichlet_vars(c, vars, vals);
     if (vars != c->fixedVars || vals != c->fixedVals) {   // unchanged constraints keep the preconditioner setup
@@ -1472,11 +1600,114 @@ mfh_status mfh_sim_solve(mfh_ctx *c, const double *f, int32_t usePin, double *uN
     ensure_precond(c);
     if (c->precond == MFH_PRECOND_TWO_LEVEL) ensure_twolevel(c);
     mfh_solve_info li{};
-    solve_one(c, f, x.data(), rtol, maxit, &li);
+    const int k = (int)C.size();
+    if (k == 0) {
+        solve_one(c, f, x.data(), rtol, maxit, &li);
+    } else {
+        // ---- candidate rigid motions (unit-normalised): translations, and rotations unless a periodic map excludes them
+        std::vector<std::vector<double>> Zc;
+        for (int a = 0; a < d; ++a) {
+            Zc.emplace_back((size_t)n, 0.0);
+            for (int64_t i = 0; i < c->nDoF; ++i) Zc.back()[(size_t)i * d + a] = 1.0;
+        }
+        if (!periodic) rotationRows(Zc);
+        const int nc = (int)Zc.size();
+        for (auto &z : Zc) {
+            const double nrm = std::sqrt(hdot(z, z));
+            if (nrm > 0) for (double &v : z) v /= nrm;
+        }
+        // null space of the candidates restricted to the fixed variables
+        std::vector<double> G((size_t)nc * nc, 0.0), V;
+        for (int64_t fv : c->fixedVars)
+            for (int a = 0; a < nc; ++a)
+                for (int b = 0; b < nc; ++b) G[(size_t)a * nc + b] += Zc[a][(size_t)fv] * Zc[b][(size_t)fv];
+        jacobi_eig(nc, G, V);
+        double evMax = 0;
+        for (int e = 0; e < nc; ++e) evMax = std::max(evMax, G[(size_t)e * nc + e]);
+        std::vector<std::vector<double>> Z;
+        for (int e = 0; e < nc; ++e) {
+            if (G[(size_t)e * nc + e] > 1e-12 * evMax) continue;   // the mode moves a fixed variable: not in the null space
+            Z.emplace_back((size_t)n, 0.0);
+            for (int a = 0; a < nc; ++a) {
+                const double w = V[(size_t)a * nc + e];
+                if (w == 0.0) continue;
+                for (int64_t q = 0; q < n; ++q) Z.back()[(size_t)q] += w * Zc[a][(size_t)q];
+            }
+            for (int64_t fv : c->fixedVars) Z.back()[(size_t)fv] = 0.0;
+        }
+        std::vector<std::vector<double>>().swap(Zc);
+        const int q = (int)Z.size();
+        // constraint rows on the free variables
+        std::vector<std::vector<double>> Cf = C;
+        for (auto &row : Cf)
+            for (int64_t fv : c->fixedVars) row[(size_t)fv] = 0.0;
+        if (q == k) {
+            std::vector<double> M((size_t)k * k), MT((size_t)k * k);
+            for (int r = 0; r < k; ++r)
+                for (int e = 0; e < k; ++e) { M[(size_t)r * k + e] = hdot(Cf[r], Z[e]); MT[(size_t)e * k + r] = M[(size_t)r * k + e]; }
+            std::vector<double> lam((size_t)k), fv2(f, f + n);
+            for (int e = 0; e < k; ++e) lam[e] = hdot(Z[e], fv2);
+            if (!dense_solve(k, MT, lam)) throw Error(MFH_ERR_UNSUPPORTED, "constraint rows do not fix the rigid motions of the system");
+            for (int r = 0; r < k; ++r)
+                for (int64_t i = 0; i < n; ++i) fv2[(size_t)i] -= lam[r] * Cf[r][(size_t)i];
+            // K is singular on the free variables, and so is the Galerkin coarse operator of the two-level
+            // preconditioner (the aggregates' modes span the global rigid motions): block-Jacobi for this solve
+            c->tlSuppress = true;
+            if (c->precond == MFH_PRECOND_TWO_LEVEL) c->precondNote = "two-level preconditioner: singular system (rigid-motion constraint rows); using block-Jacobi";
+            try { solve_one(c, fv2.data(), x.data(), rtol, maxit, &li); } catch (...) { c->tlSuppress = false; throw; }
+            c->tlSuppress = false;
+            std::vector<double> a((size_t)k);
+            for (int r = 0; r < k; ++r) a[r] = crhs[r] - hdot(C[r], x);
+            if (!dense_solve(k, M, a)) throw Error(MFH_ERR_UNSUPPORTED, "constraint rows do not fix the rigid motions of the system");
+            for (int e = 0; e < k; ++e)
+                for (int64_t i = 0; i < n; ++i) x[(size_t)i] += a[e] * Z[e][(size_t)i];
+        } else if (q == 0) {
+            solve_one(c, f, x.data(), rtol, maxit, &li);
+            std::vector<std::vector<double>> Y((size_t)k, std::vector<double>((size_t)n));
+            c->solveHomogeneous = true;
+            try {
+                for (int r = 0; r < k; ++r) {
+                    mfh_solve_info lj{};
+                    solve_one(c, Cf[r].data(), Y[r].data(), rtol, maxit, &lj);
+                    li.iterations += lj.iterations;
+                    li.solve_ms += lj.solve_ms;
+                    li.converged = li.converged && lj.converged;
+                }
+            } catch (...) { c->solveHomogeneous = false; throw; }
+            c->solveHomogeneous = false;
+            std::vector<double> S((size_t)k * k), lam((size_t)k);
+            for (int r = 0; r < k; ++r) {
+                for (int e = 0; e < k; ++e) S[(size_t)r * k + e] = hdot(Cf[r], Y[e]);
+                lam[r] = hdot(C[r], x) - crhs[r];
+            }
+            if (!dense_solve(k, S, lam)) throw Error(MFH_ERR_UNSUPPORTED, "constraint rows are linearly dependent on the free variables");
+            for (int r = 0; r < k; ++r)
+                for (int64_t i = 0; i < n; ++i) x[(size_t)i] -= lam[r] * Y[r][(size_t)i];
+        } else
+            throw Error(MFH_ERR_UNSUPPORTED, "constraint rows and the rigid motions left by the fixed variables do not match");
+    }
     if (info) *info = li;
     for (int64_t i = 0; i < m.nNode; ++i)   // dofToNodeField :664-677
         for (int a = 0; a < d; ++a) uNodes[(size_t)i * d + a] = x[(size_t)dof_of(c, i) * d + a];
     if (!li.converged) throw Error(MFH_ERR_NOT_CONVERGED, "PCG did not reach the requested tolerance within maxit iterations");
+}
+
+mfh_status mfh_sim_solve(mfh_ctx *c, const double *f, int32_t usePin, double *uNodes, double rtol, int32_t maxit,
+                         mfh_solve_info *info) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes, MFH_ERR_STATE, "no mesh set");
+    // usePin = solveCellProblems' configuration (PeriodicHomogenization.hh:43-45): rigid-motion constraint with the
+    // translations pinned; otherwise the Dirichlet variables alone
+    sim_solve_impl(c, f, usePin ? (MFH_SOLVE_PIN | MFH_SOLVE_NO_RIGID_MOTION) : MFH_SOLVE_ALLOW_ILL_POSED, nullptr, 0, uNodes, rtol, maxit, info);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_sim_solve_constrained(mfh_ctx *c, const double *f, int32_t flags, const double *rigidMotionRHS, int32_t nRigidRHS,
+                                     double *uNodes, double rtol, int32_t maxit, mfh_solve_info *info) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes, MFH_ERR_STATE, "no mesh set");
+    require(c->mesh.nOwned == c->mesh.nNode, MFH_ERR_UNSUPPORTED, "constrained solves need all rows owned");
+    sim_solve_impl(c, f, flags, rigidMotionRHS, nRigidRHS, uNodes, rtol, maxit, info);
     MFH_CATCH(c)
 }
 

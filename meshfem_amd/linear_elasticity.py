@@ -16,6 +16,8 @@ class Simulator:
         self.degree = degree
         self.rtol, self.maxit = 1e-8, 100000
         self._use_pin = False
+        self._no_rigid_motion = False
+        self._rigid_motion_rhs = None
 
     # ---- mesh queries (mesh.cc:47-70)
     def numNodes(self):
@@ -56,8 +58,14 @@ class Simulator:
     def applyPeriodicConditions(self, epsilon=1e-7):                    # :845-854
         return self.ctx.apply_periodic_conditions(epsilon)
 
-    def applyNoRigidMotionConstraint(self):                             # rotations are excluded by periodicity (:1534-1542)
-        pass
+    def applyNoRigidMotionConstraint(self):                             # m_useRigidMotionConstraint (:1214-1228)
+        self._no_rigid_motion = True
+
+    def removeNoRigidMotionConstraint(self):
+        self._no_rigid_motion = False
+
+    def setRigidMotionConstraintRHS(self, rhs):
+        self._rigid_motion_rhs = None if rhs is None else np.asarray(rhs, dtype=np.float64)
 
     def setUsePinNoRigidTranslationConstraint(self, use):               # PeriodicHomogenization.hh:44-45
         self._use_pin = bool(use)
@@ -71,7 +79,8 @@ class Simulator:
 
     def solve(self, f=None):                                            # :479-487, :657
         f = None if f is None else np.asarray(f, dtype=np.float64).ravel()
-        u = self.ctx.sim_solve(f, use_pin=self._use_pin, rtol=self.rtol, maxit=self.maxit)
+        flags = (L.SOLVE_PIN if self._use_pin else 0) | (L.SOLVE_NO_RIGID_MOTION if self._no_rigid_motion else 0)
+        u = self.ctx.sim_solve_constrained(f, flags, self._rigid_motion_rhs, rtol=self.rtol, maxit=self.maxit)
         self.info = dict(self.ctx.last_info)
         return u
 

@@ -55,8 +55,8 @@ def apply_boundary_conditions(sim, path):
     """readBoundaryConditions + applyBoundaryConditions for box / box% regions."""
     with open(path) as f:
         cfg = json.load(f)
-    if cfg.get("no_rigid_motion", False):
-        raise RuntimeError("no_rigid_motion (Lagrange-multiplier rigid-motion constraints) is not supported by the PCG path")
+    if cfg.get("no_rigid_motion", False):                    # BoundaryConditions.cc:236-239 -> applyNoRigidMotionConstraint
+        sim.applyNoRigidMotionConstraint()
     N = sim.N
     for r in cfg["regions"]:
         t = r["type"]

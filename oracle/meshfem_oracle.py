@@ -1240,3 +1240,102 @@ def grad_u_average(mesh: FEMMesh, u):
             acc += u[nodes[i]] * gp.mean(axis=0)
         out[e] = acc
     return out
+
+
+# --------------------------------------------------------------------------------------
+# Constrained (KKT) branch of Simulator::solve       LinearElasticity.hh:1169-1249,1520-1618
+# --------------------------------------------------------------------------------------
+def rotation_rows(sim: Simulator):
+    """m_appendInfinitesimalRotationMatrix (:1525-1566); empty under periodic conditions (:1534-1542)."""
+    N, m = sim.N, sim.mesh
+    nd = sim.numDoFs()
+    if (N == 2 and nd < m.num_nodes) or nd < m.num_nodes - 1:
+        return np.zeros((0, N * nd))
+    if nd < m.num_nodes:
+        raise RuntimeError("Single pair periodic BC unsupported in 3D.")
+    x = m.node_pos
+    if N == 3:
+        R = np.zeros((3, 3 * nd))
+        R[0, 1::3], R[0, 2::3] = -x[:, 2], x[:, 1]
+        R[1, 0::3], R[1, 2::3] = x[:, 2], -x[:, 0]
+        R[2, 0::3], R[2, 1::3] = -x[:, 1], x[:, 0]
+        return R
+    R = np.zeros((1, 2 * nd))
+    R[0, 0::2], R[0, 1::2] = -x[:, 1], x[:, 0]
+    return R
+
+
+def translation_rows(sim: Simulator, comps):
+    """m_appendTranslationMatrix (:1568-1590): one row per requested component, ones on every DoF."""
+    N, nd = sim.N, sim.numDoFs()
+    T = np.zeros((len(comps), N * nd))
+    for r, c in enumerate(comps):
+        T[r, c::N] = 1.0
+    return T
+
+
+def solve_constrained(sim: Simulator, f=None, use_pin=False, no_rigid_motion=False, allow_ill_posed=False, rm_rhs=None):
+    """Simulator::solve through assembleConstrainedSystem (:1201-1249) and SPSDSystem::setConstrained / solve
+    (SparseMatrices.hh:2340-2348,2572-2590): the KKT system [[K, C^T], [C, 0]] on the free variables is solved
+    with a general sparse LU (scipy splu standing in for UMFPACK)."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    N, m = sim.N, sim.mesh
+    n = N * sim.numDoFs()
+    fv, fx = [], []
+    rows = []
+    crhs = np.zeros(0)
+
+    def pin(comps):
+        interior = np.flatnonzero(~m.is_bdry_node)
+        node = int(interior[0]) if len(interior) else 0
+        for c in comps:
+            fv.append(N * sim.DoF(node) + c); fx.append(0.0)
+
+    if no_rigid_motion:
+        rows.append(rotation_rows(sim))
+        if use_pin:
+            pin(range(N))
+        else:
+            rows.append(translation_rows(sim, list(range(N))))
+        k = sum(len(r) for r in rows)
+        crhs = np.zeros(k) if rm_rhs is None else np.asarray(rm_rhs, dtype=np.float64)
+        if len(crhs) != k:
+            raise RuntimeError("Invalid rigid motion RHS")
+    elif not allow_ill_posed:
+        needs_t = [True] * N
+        total = 0
+        for bn in m.bdry_nodes:
+            for c in range(N):
+                if sim.dirichletMask[bn, c]:
+                    needs_t[c] = False
+                    total += 1
+        comps = [c for c in range(N) if needs_t[c]]
+        if comps:
+            if use_pin:
+                pin(comps)
+            else:
+                rows.append(translation_rows(sim, comps))
+                crhs = np.zeros(len(comps))
+        if total == 0:
+            raise RuntimeError("Unimplemented")
+    dv, dx = sim.dirichlet_vars_and_values()
+    fv, fx = np.array(fv + dv, dtype=np.int64), np.array(fx + dx, dtype=np.float64)
+    C = np.vstack(rows) if rows else np.zeros((0, n))
+    K = sim.assembleStiffnessMatrix().sum_repeated().to_scipy_full_from_upper().tocsr()
+    if f is None:
+        f = sim.neumannLoad()
+    f = np.asarray(f, dtype=np.float64).ravel()
+    free = np.ones(n, bool)
+    free[fv] = False
+    ubar = np.zeros(n)
+    ubar[fv] = fx
+    b = (f - K @ ubar)[free]
+    Cf = C[:, free]
+    c2 = crhs - C @ ubar
+    k = len(C)
+    A = sp.bmat([[K[free][:, free], sp.csr_matrix(Cf.T)], [sp.csr_matrix(Cf), None if k == 0 else sp.csr_matrix((k, k))]]).tocsc() if k else K[free][:, free].tocsc()
+    sol = spla.splu(A).solve(np.concatenate([b, c2]))
+    u = ubar.copy()
+    u[free] = sol[:free.sum()]
+    return sim.dofToNodeField(u)

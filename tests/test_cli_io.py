@@ -110,3 +110,28 @@ def test_simulate_cli_cantilever_config1(tmp_path, deg):
     Kt = sim.assembleStiffnessMatrix().sum_repeated()
     R = sp.coo_matrix((Kt.v, (Kt.i, Kt.j)), shape=(n, n)).tocsr()
     assert abs(U - R).max() / abs(R).max() < 1e-13
+
+
+@pytest.mark.gpu
+def test_simulate_cli_no_rigid_motion(tmp_path):
+    """A .bc file with `no_rigid_motion: true` and Neumann regions only (BoundaryConditions.cc:236-239): the
+    rigid-motion constraint rows replace Dirichlet conditions; result against the oracle's KKT solve."""
+    import json
+    V, T = grid.grid_tet_mesh(6, 2, 2)
+    mesh = str(tmp_path / "bar.msh")
+    w = mesh_io.MSHFieldWriter(mesh, V, T); w.close()
+    bc = str(tmp_path / "free.bc")
+    with open(bc, "w") as f:
+        json.dump({"no_rigid_motion": True, "regions": [
+            {"type": "traction", "value": [1.0, 0.0, 0.0], "box%": {"minCorner": [0.9999, -1e-4, -1e-4], "maxCorner": [1.0001, 1.0001, 1.0001]}},
+            {"type": "traction", "value": [-1.0, 0.2, 0.0], "box%": {"minCorner": [-1e-4, -1e-4, -1e-4], "maxCorner": [1e-4, 1.0001, 1.0001]}}]}, f)
+    out = str(tmp_path / "out.msh")
+    assert simulate_cli.main([mesh, "-m", os.path.join(GOLD, "B9Creator.material"), "-b", bc, "-d", "2", "-o", out, "--rtol", "1e-11"]) == 0
+    _, _, F = mesh_io.load_msh(out)
+    sim = O.Simulator(T, V, 2)
+    sim.set_material_constant(O.ElasticityTensor.isotropic(3, 200.0, 0.35))
+    mn, mx = sim.box_percent([0.9999, -1e-4, -1e-4], [1.0001, 1.0001, 1.0001]); sim.apply_neumann_box(mn, mx, [1, 0, 0], "traction")
+    mn, mx = sim.box_percent([-1e-4] * 3, [1e-4, 1.0001, 1.0001]); sim.apply_neumann_box(mn, mx, [-1, 0.2, 0], "traction")
+    u_ref = O.solve_constrained(sim, no_rigid_motion=True)
+    nv = len(V)
+    assert np.linalg.norm(F["u"][1] - u_ref[:nv]) / np.linalg.norm(u_ref[:nv]) < 1e-6
