@@ -681,3 +681,55 @@ def test_example_meshes_homogenization_matches_golden(name, dim, deg):
     for k in range(len(res["w_ij"])):
         err = np.linalg.norm(res["w_ij"][k] - g[key + "w"][k]) / np.linalg.norm(g[key + "w"][k])
         assert err < U_RTOL, (k, err)
+
+
+def test_config3_full_size_properties():
+    """BASELINE configs[2] at full size (60^3 grid -> 5,184,000 P2 tets, 22,292,283 DOF; the oracle's direct solve
+    does not run at this size): size-independent properties of the assembled operator and of the solution."""
+    n_grid = 60
+    V, T = grid.grid_tet_mesh(n_grid, n_grid, n_grid, [0, 0, 0], [1, 1, 1])
+    assert len(T) == 5184000
+    c = _ctx()
+    c.mesh_build(T, V, 2)
+    assert 3 * c.n_node == 22292283
+    c.material_isotropic(200.0, 0.35)
+    c.assemble()
+    nr, nc, nnzb = c.matrix_info()
+    pos = c.node_positions()
+    n = 3 * c.n_node
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(n)
+    Kx = c.apply_K(x)
+    scale = np.abs(Kx).max()
+    for mode in (0, 2, 3, 5):                                          # rigid motions in the null space
+        u = np.zeros_like(pos)
+        if mode < 3:
+            u[:, mode] = 1.0
+        else:
+            a, b = [(1, 2), (0, 2), (0, 1)][mode - 3]
+            u[:, a], u[:, b] = -pos[:, b], pos[:, a]
+        assert np.abs(c.apply_K(u.ravel())).max() < 1e-9 * scale
+    G = np.array([[0.01, 0.02, -0.01], [0.0, -0.015, 0.005], [0.02, 0.0, 0.01]])   # energy of a linear field = vol eps:C:eps
+    u = (pos @ G.T).ravel()
+    eps = 0.5 * (G + G.T)
+    assert abs(u @ c.apply_K(u) - np.sum(eps * _iso().double_contract(eps))) < 1e-9
+    # a quadratic field is in the P2 space too: u = (x^2, 0, 0) has strain eps_xx = 2x, energy (lam + 2 mu) int 4 x^2 = 4/3 (lam + 2 mu)
+    uq = np.zeros_like(pos); uq[:, 0] = pos[:, 0] ** 2
+    lam, mu = 0.35 * 200 / (1.35 * 0.3), 200 / 2.7
+    assert abs(uq.ravel() @ c.apply_K(uq.ravel()) - 4.0 / 3.0 * (lam + 2 * mu)) < 1e-8 * (lam + 2 * mu)
+    # config-3 boundary conditions, two-level PCG to 1e-8: true residual, equilibrium of the reaction, energy identity
+    c.bc_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9], [0, 0, 0])
+    c.bc_neumann_box([1 - 1e-9, -9, -9], [1 + 1e-9, 9, 9], [0, -1, 0])
+    c.set_preconditioner(M.PRECOND_TWO_LEVEL)
+    uh = c.sim_solve(rtol=1e-8)
+    info = c.last_info
+    assert info["converged"] == 1 and info["true_rel_residual"] < 2e-8 and info["iterations"] < 1000
+    f = c.neumann_load().ravel()
+    assert abs(f.reshape(-1, 3).sum(axis=0)[1] + 1.0) < 1e-12          # total load = traction x area
+    Ku = c.apply_K(uh.ravel())
+    fixed = np.zeros(n, bool); fixed[c.bc_dirichlet_vars()[0]] = True
+    assert np.linalg.norm((f - Ku)[~fixed]) < 2e-8 * np.linalg.norm(f)
+    reaction = Ku.reshape(-1, 3)[fixed.reshape(-1, 3).any(axis=1)].sum(axis=0)
+    assert np.abs(reaction - np.array([0.0, 1.0, 0.0])).max() < 1e-6   # clamped face carries the whole load
+    assert abs(uh.ravel() @ Ku - f @ uh.ravel()) < 1e-6 * abs(f @ uh.ravel())
+    assert uh[:, 1].min() < -0.03 and np.abs(uh[fixed.reshape(-1, 3).any(axis=1)]).max() == 0.0
