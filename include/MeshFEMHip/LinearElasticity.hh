@@ -143,6 +143,11 @@ public:
         m_numDoFs = (size_t)nd;
     }
     void setUsePinNoRigidTranslationConstraint(bool pin) { m_usePin = pin; }   // PeriodicHomogenization.hh:44-45
+    void applyNoRigidMotionConstraint() { m_noRigidMotion = true; }            // m_useRigidMotionConstraint (:1214-1228)
+    void removeNoRigidMotionConstraint() { m_noRigidMotion = false; }
+    void setRigidMotionConstraintRHS(const std::vector<Real> &rhs) { m_rigidMotionRHS = rhs; }
+    // block-Jacobi (MFH_PRECOND_BLOCK_JACOBI, default) or + rigid-body-mode coarse space (MFH_PRECOND_TWO_LEVEL)
+    void setPreconditioner(int kind) { check(ctx(), mfh_set_preconditioner(ctx(), kind)); }
 
     VField neumannLoad() const {                                 // :703-717
         VField f(m_numDoFs);
@@ -157,12 +162,14 @@ public:
 
     VField solve(const VField &f) const {                        // :479-487 + dofToNodeField :664-677
         VField u(m_numNodes);
-        check(ctx(), mfh_sim_solve(ctx(), &f[0][0], m_usePin, &u[0][0], rtol, maxit, &info));
+        check(ctx(), mfh_sim_solve_constrained(ctx(), &f[0][0], m_flags(), m_rigidMotionRHS.data(), (int32_t)m_rigidMotionRHS.size(),
+                                               &u[0][0], rtol, maxit, &info));
         return u;
     }
     VField solve() const {                                       // :657
         VField u(m_numNodes);
-        check(ctx(), mfh_sim_solve(ctx(), nullptr, m_usePin, &u[0][0], rtol, maxit, &info));
+        check(ctx(), mfh_sim_solve_constrained(ctx(), nullptr, m_flags(), m_rigidMotionRHS.data(), (int32_t)m_rigidMotionRHS.size(),
+                                               &u[0][0], rtol, maxit, &info));
         return u;
     }
 
@@ -203,10 +210,104 @@ private:
     Context m_owner;
     int64_t m_numElements = 0;
     size_t m_numNodes = 0, m_numDoFs = 0;
-    bool m_usePin = false;
+    bool m_usePin = false, m_noRigidMotion = false;
+    std::vector<Real> m_rigidMotionRHS;
+    int32_t m_flags() const { return (m_usePin ? MFH_SOLVE_PIN : 0) | (m_noRigidMotion ? MFH_SOLVE_NO_RIGID_MOTION : 0); }
 };
 
 } // namespace LinearElasticity
+
+// Scalar operators on the same kernels (1x1 blocks): Laplacian::construct (Laplacian.hh:97-104),
+// MassMatrix::construct (MassMatrix.hh:103-128), PoissonMesh (Poisson.hh:55-132).
+template <size_t N, size_t Deg>
+class PoissonMesh {
+public:
+    PoissonMesh(const std::vector<std::array<int32_t, N + 1>> &elems, const std::vector<std::array<Real, N>> &vertices, int device = 0)
+        : m_owner(device) {
+        check(ctx(), mfh_mesh_build(ctx(), (int32_t)N, (int32_t)Deg, (int64_t)elems.size(), (int64_t)vertices.size(),
+                                    &elems[0][0], &vertices[0][0]));
+        int64_t nn = 0;
+        check(ctx(), mfh_mesh_sizes(ctx(), &m_numElements, &nn, nullptr, nullptr, nullptr, nullptr, nullptr));
+        m_numNodes = (size_t)nn;
+        check(ctx(), mfh_set_operator(ctx(), MFH_OP_LAPLACIAN));
+    }
+    mfh_ctx *ctx() const { return m_owner.get(); }
+    size_t numNodes() const { return m_numNodes; }
+    size_t numElements() const { return (size_t)m_numElements; }
+
+    // one DirichletCondition of applyBoundaryConditions (Poisson.hh:69-84): boundary nodes in the inclusive box
+    void applyDirichletBox(const std::array<Real, N> &mn, const std::array<Real, N> &mx, Real value, bool relative = false) {
+        std::array<Real, N> v{};
+        v[0] = value;
+        check(ctx(), mfh_set_operator(ctx(), MFH_OP_LAPLACIAN));
+        check(ctx(), mfh_bc_dirichlet_box(ctx(), mn.data(), mx.data(), relative, v.data(), 1));
+    }
+    void solve(std::vector<Real> &x) {                                  // Poisson.hh:91-117
+        x.resize(m_numNodes);
+        check(ctx(), mfh_set_operator(ctx(), MFH_OP_LAPLACIAN));
+        check(ctx(), mfh_sim_solve(ctx(), nullptr, 0, x.data(), rtol, maxit, &info));
+    }
+    std::vector<std::array<Real, N>> gradUAverage(const std::vector<Real> &u) const {   // :121-131
+        std::vector<std::array<Real, N>> g((size_t)m_numElements);
+        check(ctx(), mfh_average_gradient(ctx(), u.data(), &g[0][0]));
+        return g;
+    }
+    // upper triangles after sumRepeated
+    TripletMatrix laplacian() { return m_operator(MFH_OP_LAPLACIAN); }
+    TripletMatrix massMatrix() { return m_operator(MFH_OP_MASS); }
+
+    double rtol = 1e-10;
+    int maxit = 100000;
+    mfh_solve_info info{};
+
+private:
+    TripletMatrix m_operator(int op) {
+        check(ctx(), mfh_set_operator(ctx(), op));
+        check(ctx(), mfh_assemble(ctx(), MFH_ASSEMBLE_GATHER));
+        uint64_t nnz = 0;
+        check(ctx(), mfh_export_upper_triplets(ctx(), nullptr, nullptr, nullptr, &nnz));
+        std::vector<uint64_t> i(nnz), j(nnz);
+        std::vector<Real> v(nnz);
+        check(ctx(), mfh_export_upper_triplets(ctx(), i.data(), j.data(), v.data(), &nnz));
+        TripletMatrix K;
+        K.m = K.n = m_numNodes;
+        K.nz.resize(nnz);
+        for (uint64_t k = 0; k < nnz; ++k) K.nz[k] = Triplet{(size_t)i[k], (size_t)j[k], v[k]};
+        return K;
+    }
+    Context m_owner;
+    int64_t m_numElements = 0;
+    size_t m_numNodes = 0;
+};
+
+// SPSDSystem<Real>(K) for a caller-supplied SPD matrix (SparseMatrices.hh:2332-2348): owns its context.
+class GenericSPSDSystem {
+public:
+    explicit GenericSPSDSystem(const TripletMatrix &K, int device = 0) : m_owner(device), m_n(K.m) {
+        if (K.m != K.n) throw std::runtime_error("K must be square");
+        std::vector<uint64_t> i, j;
+        std::vector<Real> v;
+        for (const auto &t : K.nz)
+            if (t.i <= t.j) { i.push_back(t.i); j.push_back(t.j); v.push_back(t.v); }   // setUpperTriangle (:2337)
+        check(m_owner.get(), mfh_matrix_set_upper_triplets(m_owner.get(), (int64_t)K.m, (int64_t)v.size(), i.data(), j.data(), v.data()));
+    }
+    void fixVariables(const std::vector<size_t> &fixedVars, const std::vector<Real> &fixedVarValues = std::vector<Real>()) {
+        std::vector<int64_t> v(fixedVars.begin(), fixedVars.end());
+        check(m_owner.get(), mfh_fix_variables(m_owner.get(), (int64_t)v.size(), v.data(), fixedVarValues.empty() ? nullptr : fixedVarValues.data()));
+    }
+    void solve(const std::vector<Real> &b, std::vector<Real> &x) {
+        if (b.size() != m_n) throw std::runtime_error("Bad RHS");
+        x.resize(m_n);
+        check(m_owner.get(), mfh_solve(m_owner.get(), 1, b.data(), x.data(), rtol, maxit, &info));
+    }
+    double rtol = 1e-10;
+    int maxit = 100000;
+    mfh_solve_info info{};
+
+private:
+    Context m_owner;
+    size_t m_n;
+};
 } // namespace MeshFEMHip
 
 #endif /* end of include guard: MESHFEMHIP_LINEARELASTICITY_HH */

@@ -12,10 +12,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXE = os.path.join(ROOT, "tests", "cpp", "facade_cantilever")
 
 
-def _build():
-    src = os.path.join(ROOT, "tests", "cpp", "facade_cantilever.cc")
+EXE2 = os.path.join(ROOT, "tests", "cpp", "facade_scalar_and_constraints")
+
+
+def _build(name="facade_cantilever"):
+    src = os.path.join(ROOT, "tests", "cpp", name + ".cc")
     libdir = os.path.dirname(M.LIB_PATH)
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o",
+                           os.path.join(ROOT, "tests", "cpp", name),
                            "-L", libdir, "-lmeshfem_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
 
 
@@ -31,3 +35,17 @@ def test_facade_cantilever_on_gpu():
     r = subprocess.run([EXE, "0"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "tip deflection" in r.stdout
+
+
+def test_facade_scalar_and_constraints_compiles():
+    _build("facade_scalar_and_constraints")
+    r = subprocess.run([EXE2, "-1"], capture_output=True, text=True)
+    assert r.returncode == 3 and "runtime_error" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_facade_scalar_and_constraints_on_gpu():
+    _build("facade_scalar_and_constraints")
+    r = subprocess.run([EXE2, "0"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "poisson" in r.stdout and "free body" in r.stdout and "generic SPSDSystem" in r.stdout
