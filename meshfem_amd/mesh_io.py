@@ -95,6 +95,33 @@ def load_msh(path):
     return V, E, fields
 
 
+def load_off(path):
+    """Object File Format surface meshes (MeshIO_OFF, MeshIO.cc): 'OFF', counts, vertices, polygons.
+    Returns (vertices [n,3], elements [m,k])."""
+    with open(path) as f:
+        tok = f.read().split()
+    if tok[0] != "OFF":
+        raise RuntimeError("Bad OFF file format")
+    nv, nf = int(tok[1]), int(tok[2])
+    pos = 4
+    V = np.array(tok[pos:pos + 3 * nv], dtype=np.float64).reshape(nv, 3)
+    pos += 3 * nv
+    E = []
+    for _ in range(nf):
+        k = int(tok[pos])
+        E.append([int(x) for x in tok[pos + 1:pos + 1 + k]])
+        pos += 1 + k
+    return V, np.array(E, dtype=np.int64)
+
+
+def load_mesh(path):
+    """MeshIO::load dispatch on the extension (.msh / .off)."""
+    if path.lower().endswith(".off"):
+        V, E = load_off(path)
+        return V, E, {}
+    return load_msh(path)
+
+
 class MSHFieldWriter:
     """== MSHFieldWriter (binary by default, like the reference)."""
 

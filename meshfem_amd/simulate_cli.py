@@ -22,8 +22,11 @@ from .tensors import ElasticityTensor
 
 def parse_material(path, dim):
     """Materials::Constant JSON (Materials.cc:301-311) -> ElasticityTensor."""
-    with open(path) as f:
-        cfg = json.load(f)
+    if isinstance(path, dict):
+        cfg = path
+    else:
+        with open(path) as f:
+            cfg = json.load(f)
     t = cfg["type"]
     ten = ElasticityTensor(dim)
     if t in ("isotropic_material", "isotropic"):
@@ -44,6 +47,11 @@ def parse_material(path, dim):
         ten.D = D
         return ten
     raise RuntimeError("Invalid type.")
+
+
+def material_json(tensor):
+    """Materials::Constant::getJson (Materials.cc:314-328): always the anisotropic form."""
+    return {"type": "anisotropic", "material_matrix": np.asarray(tensor.D).tolist()}
 
 
 def _vec(v, dim):

@@ -246,3 +246,59 @@ def test_homogenization_of_solid_cube_returns_base_material():
     # Ch_ij reported with engineering-free (tensor) strains: column j = C : e_j
     ref = np.column_stack([base.double_contract_flat(O.flatten_sym(3, O.canonical_strain(3, j))) for j in range(6)])
     assert np.abs(Ch - ref).max() < 1e-9 * np.abs(ref).max()
+
+
+# ---- tests/test_mass.cc:6-45 "L2 Norm Validation": u^T M u == quadrature of |u_h|^2 with Quadrature<N, 2 Deg>,
+# on the reference's own meshes (square_hole.off in 2D, ball.msh in 3D), tolerance 1e-14 relative like the reference
+def _mass_l2_case(dim, deg):
+    from meshfem_amd import mesh_io
+    path = os.path.join(GOLD, "meshes", "square_hole.off" if dim == 2 else "ball.msh")
+    V, E, _ = mesh_io.load_mesh(path)
+    return O.FEMMesh(E, V[:, :dim], deg)
+
+
+def _l2sq_direct(m, u):
+    vol, _ = m.embeddings_batch()
+    pts, w = O.quadrature_rule(m.K, 2 * m.deg)
+    Phi = np.array([O.shape_functions(m.deg, m.K, p) for p in pts])            # nq x n
+    uq = np.einsum("qn,enc->eqc", Phi, u[m.elem_nodes])                          # u_interp(p) at every point
+    return float(np.einsum("q,e,eqc,eqc->", w, vol, uq, uq))
+
+
+@pytest.mark.parametrize("dim,deg", [(2, 1), (2, 2), (3, 1), (3, 2)])
+def test_mass_matrix_l2_norm_validation(dim, deg):
+    m = _mass_l2_case(dim, deg)
+    Ms = O.mass_triplets(m).sum_repeated().to_scipy_full_from_upper()           # construct_vector_valued = scalar M per component
+    rng = np.random.default_rng(0)
+    for _ in range(16):
+        u = rng.uniform(-1, 1, (m.num_nodes, dim))                              # Eigen setRandom: uniform in [-1, 1]
+        l2_mass = sum(u[:, c] @ (Ms @ u[:, c]) for c in range(dim))
+        assert abs(l2_mass - _l2sq_direct(m, u)) < 1e-13 * abs(l2_mass)
+
+
+# ---- tests/test_materials.cc:28-90: the reference's sample material files survive read -> getJson -> read -> getJson
+MATERIAL_SAMPLES = {
+    "isotropic": ({"type": "isotropic", "young": 200, "poisson": 0.3},) * 2,
+    "orthotropic": ({"type": "orthotropic", "young": [2.933545, 2.933545], "poisson": [0.27186, 0.27186], "shear": [0.87212]},
+                    {"type": "orthotropic", "young": [1.0, 2.0, 3.0], "poisson": [0.6, 0.9, 0.9, 0.3, 0.3, 0.6], "shear": [0.1, 0.2, 0.3]}),
+    "anisotropic": ({"type": "anisotropic", "material_matrix": [[9.0, 0.1, 0.2], [0.1, 9.0, 0.3], [0.2, 0.3, 1.0]]},
+                    {"type": "anisotropic", "material_matrix": [[9.0, 0.1, 0.2, 0.5, 0.5, 0.5], [0.1, 9.0, 0.3, 0.5, 0.5, 0.5],
+                                                                [0.2, 0.3, 9.0, 0.5, 0.5, 0.5], [0.5, 0.5, 0.5, 1.5, 0.1, 0.2],
+                                                                [0.5, 0.5, 0.5, 0.1, 1.6, 0.3], [0.5, 0.5, 0.5, 0.2, 0.3, 1.7]]}),
+}
+
+
+@pytest.mark.parametrize("kind", sorted(MATERIAL_SAMPLES))
+def test_material_json_roundtrip_reference_samples(kind):
+    from meshfem_amd import simulate_cli
+    for dim, cfg in zip((2, 3), MATERIAL_SAMPLES[kind]):
+        mat = simulate_cli.parse_material(cfg, dim)
+        out1 = simulate_cli.material_json(mat)
+        out2 = simulate_cli.material_json(simulate_cli.parse_material(out1, dim))
+        assert out1 == out2 and out1["type"] == "anisotropic"
+        D = np.array(out1["material_matrix"])
+        assert D.shape == ((3, 3) if dim == 2 else (6, 6)) and np.abs(D - D.T).max() < 1e-12 * np.abs(D).max()
+        if kind == "isotropic":
+            assert np.abs(D - O.ElasticityTensor.isotropic(dim, 200.0, 0.3).D).max() < 1e-12
+        if kind == "orthotropic" and dim == 2:
+            assert np.abs(D - O.ElasticityTensor.orthotropic2d(2.933545, 2.933545, 0.27186, 0.87212).D).max() < 1e-12
