@@ -74,6 +74,8 @@ typedef struct mfh_solve_info {
     double  true_rel_residual; /* ||b - A x||_2 / ||b||_2 recomputed at exit        */
     double  solve_ms;        /* device time of the PCG loop (HIP events), last RHS  */
     double  setup_ms;        /* device time of rhs/preconditioner setup             */
+    int32_t used_graph;      /* 1 if the PCG iterations were replayed from a captured hipGraph */
+    int32_t reserved;
 } mfh_solve_info;
 
 typedef struct mfh_timing {

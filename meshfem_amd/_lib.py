@@ -18,7 +18,8 @@ SOLVE_PIN, SOLVE_NO_RIGID_MOTION, SOLVE_ALLOW_ILL_POSED = 1, 2, 4
 
 class SolveInfo(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32), ("rel_residual", C.c_double),
-                ("true_rel_residual", C.c_double), ("solve_ms", C.c_double), ("setup_ms", C.c_double)]
+                ("true_rel_residual", C.c_double), ("solve_ms", C.c_double), ("setup_ms", C.c_double),
+                ("used_graph", C.c_int32), ("reserved", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

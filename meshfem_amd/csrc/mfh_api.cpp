@@ -67,6 +67,7 @@ struct mfh_ctx {
     DBuf<double> dFixedVal;
     bool fixedUploaded = false;
     bool anyFixedNonzero = false;
+    bool useGraph = true;             // option "pcg_graph": capture blocks of check_every PCG iterations in a hipGraph
     bool tlSuppress = false;          // solve_one: block-Jacobi for this solve (K singular on the free variables)
     bool solveHomogeneous = false;    // solve_one: treat the fixed values as 0 (columns of the Schur complement)
 
@@ -616,10 +617,12 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
     if (!c->fixedVars.empty()) k::launch_mask(n, c->dFixedMask.p, c->wb.p, s);
     const double bb = device_dot(c, n, c->wb.p, c->wb.p);
     mfh_solve_info li{};
-    const size_t scalN = ((size_t)maxit + 2) * 4;
+    // the graph path runs whole blocks of check_every iterations, so the history may run past maxit
+    const size_t scalN = ((size_t)maxit + (size_t)c->checkEvery + 2) * 4;
     c->scal.alloc(scalN);
     c->scal.zero(s);
     const double stopv = rtol * rtol * bb;
+    MFH_HIP(hipMemsetAsync(c->stop.p, 0, 4 * sizeof(double), s));   // [0] threshold, [1] dot scratch, [3] iteration base
     MFH_HIP(hipMemcpyAsync(c->stop.p, &stopv, sizeof(double), hipMemcpyHostToDevice, s));
     li.setup_ms = tsetup.stop();
     int itDone = 0;
@@ -641,30 +644,57 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
         int it = 0;
         bool done = false;
         int lastChecked = 0;
+        auto enqueue = [&](int itLocal) {   // one PCG iteration; `itLocal` is relative to the iteration base stop[3]
+            k::launch_pcg_spmv(sa, c->wp.p, c->wAp.p, c->scal.p, itLocal, c->stop.p, s);
+            if (useTL) {
+                k::launch_pcg_update_noz(d, c->sym.nRows, c->wp.p, c->wAp.p, c->wx.p, c->wr.p, c->scal.p, itLocal, c->stop.p, s);
+                tl_precond(c, c->wr.p, c->wz.p, c->scal.p, itLocal);
+            } else
+                k::launch_pcg_update(d, c->sym.nRows, c->dDinv.p, c->wp.p, c->wAp.p, c->wx.p, c->wr.p, c->wz.p, c->scal.p, itLocal,
+                                     c->stop.p, s);
+            k::launch_pcg_direction(n, c->wz.p, c->wp.p, c->scal.p, itLocal, c->stop.p, s);
+        };
+        // Launch-bound regime (small meshes: a few tens of microseconds per kernel): capture one block of
+        // check_every iterations in a hipGraph and replay it; the kernels find their iteration through the
+        // device-side base stop[3], which the last node of the graph advances.
+        hipGraphExec_t exec = nullptr;
+        if (c->useGraph && c->checkEvery > 1) {
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                bool ok = true;
+                try {
+                    for (int j = 0; j < c->checkEvery; ++j) enqueue(j);
+                    k::launch_advance_base(c->stop.p, c->checkEvery, s);
+                } catch (...) { ok = false; }
+                if (hipStreamEndCapture(s, &graph) != hipSuccess || !ok || !graph) { graph = nullptr; (void)hipGetLastError(); }
+            } else (void)hipGetLastError();
+            if (graph) {
+                if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { exec = nullptr; (void)hipGetLastError(); }
+                (void)hipGraphDestroy(graph);
+            }
+        }
+        li.used_graph = exec ? 1 : 0;
         while (!done && it < maxit) {
-            const int itEnd = std::min(maxit, it + c->checkEvery);
-            for (; it < itEnd; ++it) {
-                k::launch_pcg_spmv(sa, c->wp.p, c->wAp.p, c->scal.p, it, c->stop.p, s);
-                if (useTL) {
-                    k::launch_pcg_update_noz(d, c->sym.nRows, c->wp.p, c->wAp.p, c->wx.p, c->wr.p, c->scal.p, it, c->stop.p, s);
-                    tl_precond(c, c->wr.p, c->wz.p, c->scal.p, it);
-                } else
-                    k::launch_pcg_update(d, c->sym.nRows, c->dDinv.p, c->wp.p, c->wAp.p, c->wx.p, c->wr.p, c->wz.p, c->scal.p, it,
-                                         c->stop.p, s);
-                k::launch_pcg_direction(n, c->wz.p, c->wp.p, c->scal.p, it, c->stop.p, s);
+            if (exec) {
+                MFH_HIP(hipGraphLaunch(exec, s));
+                it += c->checkEvery;
+            } else {
+                const int itEnd = std::min(maxit, it + c->checkEvery);
+                for (; it < itEnd; ++it) enqueue(it);
             }
             // scan the residual history of the iterations just enqueued
             hs.resize((size_t)(it - lastChecked + 1) * 4);
             MFH_HIP(hipMemcpyAsync(hs.data(), c->scal.p + (size_t)lastChecked * 4, hs.size() * sizeof(double), hipMemcpyDeviceToHost, s));
             MFH_HIP(hipStreamSynchronize(s));
-            for (int k2 = lastChecked; k2 <= it; ++k2) {
+            for (int k2 = lastChecked; k2 <= std::min(it, maxit); ++k2) {
                 const double rr = hs[(size_t)(k2 - lastChecked) * 4 + 2];
                 if (rr <= stopv) { done = true; itDone = k2; rrFinal = rr; break; }
                 if (!(rr == rr)) throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (NaN residual): K is not SPD on the free variables");
             }
-            if (!done) { itDone = it; rrFinal = hs[(size_t)(it - lastChecked) * 4 + 2]; }
+            if (!done) { itDone = std::min(it, maxit); rrFinal = hs[(size_t)(itDone - lastChecked) * 4 + 2]; }
             lastChecked = it;
         }
+        if (exec) (void)hipGraphExecDestroy(exec);
         li.solve_ms = tsolve.stop();
         li.converged = done ? 1 : 0;
     }
@@ -1971,6 +2001,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "agg_nodes") { c->aggNodes = (int)value; c->tl.valid = false; }
     else if (k2 == "topology_device") { c->topologyDevice = value != 0; }
     else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }
+    else if (k2 == "pcg_graph") c->useGraph = value != 0;
     else if (k2 == "tl_probe") { c->tlProbe = value != 0; c->tl.valid = false; }
     else if (k2 == "tl_host_inverse") { c->tlHostInverse = value != 0; c->tl.valid = false; }
     else if (k2 == "debug_variant") { c->debugVariant = (int)value; invalidate_matrix(c); }

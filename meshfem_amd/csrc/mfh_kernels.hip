@@ -550,6 +550,7 @@ __global__ void __launch_bounds__(256) k_spmv(SpmvArgs a, const double *__restri
     const int CS = a.chunkSlots;
     double *red = part + DIM * CS;
     if (PCG) {
+        it += (int)stopPtr[3];   // iteration base of the current graph launch (0 outside graphs)
         // converged: every kernel of the remaining iterations is a no-op
         if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
         dotOut = scal + (int64_t)it * 4 + 1;
@@ -862,6 +863,7 @@ __global__ void __launch_bounds__(256) k_tl_apply(TLArgs t, const double *__rest
     __shared__ double red[8];
     double *rzOut = nullptr;
     if (scal) {
+        it += (int)stopPtr[3];
         if (it >= 0 && scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
         rzOut = scal + (int64_t)(it + 1) * 4;
     }
@@ -1097,6 +1099,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
                                                     const double *__restrict__ Ap, double *__restrict__ x, double *__restrict__ r,
                                                     double *__restrict__ z, double *scal, int it, const double *stopPtr) {
     __shared__ double red[16];
+    it += (int)stopPtr[3];
     if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
     const double alpha = scal[(int64_t)it * 4 + 0] / scal[(int64_t)it * 4 + 1];
     double acc[2] = {0, 0};
@@ -1127,10 +1130,14 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
 // p = z + beta p
 __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, const double *__restrict__ z, double *__restrict__ p,
                                                        const double *scal, int it, const double *stopPtr) {
+    it += (int)stopPtr[3];
     if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
     const double beta = scal[(int64_t)(it + 1) * 4 + 0] / scal[(int64_t)it * 4 + 0];
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) p[k] = z[k] + beta * p[k];
 }
+
+// stop[3] += n: advances the iteration base at the end of a captured block of PCG iterations
+__global__ void k_advance_base(double *stop, double n) { stop[3] += n; }
 
 __global__ void __launch_bounds__(256) k_axpby(int64_t n, double a, const double *__restrict__ x, double b, double *__restrict__ y) {
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
@@ -1428,6 +1435,11 @@ void launch_tl_apply(const TLArgs &t, const double *dinv, const double *r, const
                      const double *stopPtr, hipStream_t s) {
     if (t.dim == 3) hipLaunchKernelGGL(k_tl_apply<3>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr);
     else hipLaunchKernelGGL(k_tl_apply<2>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr);
+    CHECK_LAUNCH();
+}
+
+void launch_advance_base(double *stop, int n, hipStream_t s) {
+    hipLaunchKernelGGL(k_advance_base, dim3(1), dim3(1), 0, s, stop, (double)n);
     CHECK_LAUNCH();
 }
 
