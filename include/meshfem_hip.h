@@ -271,6 +271,12 @@ mfh_status mfh_tl_partitioned_begin(mfh_ctx* ctx, int32_t nAgg, const int32_t* a
 mfh_status mfh_tl_partitioned_finish(mfh_ctx* ctx, const double* Ac_dev);
 mfh_status mfh_dev_tl_restrict(mfh_ctx* ctx, const double* r_dev, double* rc_dev);
 mfh_status mfh_dev_tl_apply(mfh_ctx* ctx, const double* r_dev, const double* rc_dev, double* z_dev);
+/* fused vector updates of the distributed PCG over the owned rows; scalars are read from DEVICE memory (they are
+ * results of all-reduces): x += (num/den) p, r -= (num/den) Ap ;  p = z + (num/den) p ;  out2 = {r.z, r.r} */
+mfh_status mfh_dev_pcg_update_xr(mfh_ctx* ctx, const double* num_dev, const double* den_dev, const double* p_dev, const double* Ap_dev,
+                                 double* x_dev, double* r_dev);
+mfh_status mfh_dev_pcg_direction(mfh_ctx* ctx, const double* num_dev, const double* den_dev, const double* z_dev, double* p_dev);
+mfh_status mfh_dev_dots(mfh_ctx* ctx, const double* r_dev, const double* z_dev, double* out2_dev);
 /* r[fixed] = 0 */
 mfh_status mfh_dev_mask_fixed(mfh_ctx* ctx, double* r_dev);
 /* copy the fixed-variable values into u (u[fixed] = value) */

@@ -98,6 +98,9 @@ PROTOTYPES = {
     "mfh_tl_partitioned_finish": (_i32, [_P, _P]),
     "mfh_dev_tl_restrict": (_i32, [_P, _P, _P]),
     "mfh_dev_tl_apply": (_i32, [_P, _P, _P, _P]),
+    "mfh_dev_pcg_update_xr": (_i32, [_P, _P, _P, _P, _P, _P, _P]),
+    "mfh_dev_pcg_direction": (_i32, [_P, _P, _P, _P, _P]),
+    "mfh_dev_dots": (_i32, [_P, _P, _P, _P]),
     "mfh_dev_mask_fixed": (_i32, [_P, _P]),
     "mfh_dev_set_fixed_values": (_i32, [_P, _P]),
     "mfh_dev_sync": (_i32, [_P]),

@@ -385,6 +385,15 @@ class Context:
     def dev_tl_apply(self, r_ptr, rc_ptr, z_ptr):
         self._ck(self.lib.mfh_dev_tl_apply(self.h, C.c_void_p(r_ptr), C.c_void_p(rc_ptr), C.c_void_p(z_ptr)))
 
+    def dev_pcg_update_xr(self, num_ptr, den_ptr, p_ptr, ap_ptr, x_ptr, r_ptr):
+        self._ck(self.lib.mfh_dev_pcg_update_xr(self.h, *[C.c_void_p(q) for q in (num_ptr, den_ptr, p_ptr, ap_ptr, x_ptr, r_ptr)]))
+
+    def dev_pcg_direction(self, num_ptr, den_ptr, z_ptr, p_ptr):
+        self._ck(self.lib.mfh_dev_pcg_direction(self.h, *[C.c_void_p(q) for q in (num_ptr, den_ptr, z_ptr, p_ptr)]))
+
+    def dev_dots(self, r_ptr, z_ptr, out_ptr):
+        self._ck(self.lib.mfh_dev_dots(self.h, C.c_void_p(r_ptr), C.c_void_p(z_ptr), C.c_void_p(out_ptr)))
+
     def dev_mask_fixed(self, r_ptr):
         self._ck(self.lib.mfh_dev_mask_fixed(self.h, C.c_void_p(r_ptr)))
 

@@ -1885,6 +1885,30 @@ mfh_status mfh_dev_tl_apply(mfh_ctx *c, const double *r_dev, const double *rc_de
     MFH_CATCH(c)
 }
 
+// fused vector updates of the distributed PCG; every scalar is read from device memory
+mfh_status mfh_dev_pcg_update_xr(mfh_ctx *c, const double *num_dev, const double *den_dev, const double *p_dev, const double *Ap_dev,
+                                 double *x_dev, double *r_dev) {
+    MFH_TRY(c)
+    require(c && num_dev && den_dev && p_dev && Ap_dev && x_dev && r_dev, MFH_ERR_INVALID, "null argument");
+    MFH_HIP(hipSetDevice(c->device));
+    k::launch_dev_update_xr((int64_t)c->bs() * c->sym.nRows, num_dev, den_dev, p_dev, Ap_dev, x_dev, r_dev, c->stream);
+    MFH_CATCH(c)
+}
+mfh_status mfh_dev_pcg_direction(mfh_ctx *c, const double *num_dev, const double *den_dev, const double *z_dev, double *p_dev) {
+    MFH_TRY(c)
+    require(c && num_dev && den_dev && z_dev && p_dev, MFH_ERR_INVALID, "null argument");
+    MFH_HIP(hipSetDevice(c->device));
+    k::launch_dev_direction((int64_t)c->bs() * c->sym.nRows, num_dev, den_dev, z_dev, p_dev, c->stream);
+    MFH_CATCH(c)
+}
+mfh_status mfh_dev_dots(mfh_ctx *c, const double *r_dev, const double *z_dev, double *out2_dev) {
+    MFH_TRY(c)
+    require(c && r_dev && z_dev && out2_dev, MFH_ERR_INVALID, "null argument");
+    MFH_HIP(hipSetDevice(c->device));
+    k::launch_dev_dots((int64_t)c->bs() * c->sym.nRows, r_dev, z_dev, out2_dev, c->stream);
+    MFH_CATCH(c)
+}
+
 mfh_status mfh_dev_mask_fixed(mfh_ctx *c, double *r_dev) {
     MFH_TRY(c)
     require(c && r_dev, MFH_ERR_INVALID, "null argument");

@@ -271,6 +271,9 @@ void launch_pcg_spmv(const SpmvArgs &a, const double *p, double *Ap, double *sca
                      hipStream_t s);
 void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double *p, const double *Ap, double *x,
                        double *r, double *z, double *scal, int it, const double *stopPtr, hipStream_t s);
+void launch_dev_update_xr(int64_t n, const double *num, const double *den, const double *p, const double *Ap, double *x, double *r, hipStream_t s);
+void launch_dev_direction(int64_t n, const double *num, const double *den, const double *z, double *p, hipStream_t s);
+void launch_dev_dots(int64_t n, const double *r, const double *z, double *out, hipStream_t s);
 void launch_advance_base(double *stop, int n, hipStream_t s);   // stop[3] += n (iteration base of graph-captured PCG blocks)
 void launch_pcg_direction(int64_t n, const double *z, double *p, const double *scal, int it, const double *stopPtr,
                           hipStream_t s);

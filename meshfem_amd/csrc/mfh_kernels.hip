@@ -1136,6 +1136,31 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, const double *
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) p[k] = z[k] + beta * p[k];
 }
 
+// distributed PCG building blocks: the scalars live in device memory (results of RCCL all-reduces), so no host sync
+// x += a p ; r -= a Ap  with a = num[0] / den[0]
+__global__ void __launch_bounds__(256) k_dev_update_xr(int64_t n, const double *num, const double *den, const double *__restrict__ p,
+                                                       const double *__restrict__ Ap, double *__restrict__ x, double *__restrict__ r) {
+    const double a = num[0] / den[0];
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        x[k] += a * p[k];
+        r[k] -= a * Ap[k];
+    }
+}
+// p = z + b p  with b = num[0] / den[0]
+__global__ void __launch_bounds__(256) k_dev_direction(int64_t n, const double *num, const double *den, const double *__restrict__ z,
+                                                       double *__restrict__ p) {
+    const double b = num[0] / den[0];
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) p[k] = z[k] + b * p[k];
+}
+// out[0] = r.z, out[1] = r.r (out zeroed by the caller)
+__global__ void __launch_bounds__(256) k_dev_dots(int64_t n, const double *__restrict__ r, const double *__restrict__ z, double *out) {
+    __shared__ double red[16];
+    double acc[2] = {0, 0};
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) { acc[0] += r[k] * z[k]; acc[1] += r[k] * r[k]; }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) { unsafeAtomicAdd(&out[0], acc[0]); unsafeAtomicAdd(&out[1], acc[1]); }
+}
+
 // stop[3] += n: advances the iteration base at the end of a captured block of PCG iterations
 __global__ void k_advance_base(double *stop, double n) { stop[3] += n; }
 
@@ -1435,6 +1460,20 @@ void launch_tl_apply(const TLArgs &t, const double *dinv, const double *r, const
                      const double *stopPtr, hipStream_t s) {
     if (t.dim == 3) hipLaunchKernelGGL(k_tl_apply<3>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr);
     else hipLaunchKernelGGL(k_tl_apply<2>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr);
+    CHECK_LAUNCH();
+}
+
+void launch_dev_update_xr(int64_t n, const double *num, const double *den, const double *p, const double *Ap, double *x, double *r, hipStream_t s) {
+    hipLaunchKernelGGL(k_dev_update_xr, dim3(grid_for(n)), dim3(256), 0, s, n, num, den, p, Ap, x, r);
+    CHECK_LAUNCH();
+}
+void launch_dev_direction(int64_t n, const double *num, const double *den, const double *z, double *p, hipStream_t s) {
+    hipLaunchKernelGGL(k_dev_direction, dim3(grid_for(n)), dim3(256), 0, s, n, num, den, z, p);
+    CHECK_LAUNCH();
+}
+void launch_dev_dots(int64_t n, const double *r, const double *z, double *out, hipStream_t s) {
+    MFH_HIP(hipMemsetAsync(out, 0, 2 * sizeof(double), s));
+    hipLaunchKernelGGL(k_dev_dots, dim3(grid_for(n)), dim3(256), 0, s, n, r, z, out);
     CHECK_LAUNCH();
 }
 

@@ -150,6 +150,16 @@ class HipLocalOps:
     def set_fixed_values(self, u):
         self.ctx.dev_set_fixed_values(u.data_ptr())
 
+    # fused vector updates; the scalars stay on the device (they come out of all-reduces)
+    def update_xr(self, num, den, p, Ap, x, r):
+        self.ctx.dev_pcg_update_xr(num.data_ptr(), den.data_ptr(), p.data_ptr(), Ap.data_ptr(), x.data_ptr(), r.data_ptr())
+
+    def direction(self, num, den, z, p):
+        self.ctx.dev_pcg_direction(num.data_ptr(), den.data_ptr(), z.data_ptr(), p.data_ptr())
+
+    def dots(self, r, z, out):
+        self.ctx.dev_dots(r.data_ptr(), z.data_ptr(), out.data_ptr())
+
     # two-level preconditioner building blocks (global aggregates; DistributedTwoLevel reduces over ranks)
     def tl_begin(self, n_agg, agg_of_node, rel_pos):
         m = n_agg * (6 if self.dim == 3 else 3)
@@ -272,8 +282,31 @@ def distributed_pcg(ops, halo, f_owned, rtol=1e-8, maxit=20000, group=None, chec
     p = ops.zeros(nc)
     p[:nr] = z
     Ap = ops.zeros(nr)
-    red = _allreduce(torch.stack([torch.dot(r, z), torch.dot(r, r)]), dev, group)
-    rz, bb = red[0], red[1].item()
+    # local kernels: the ops' fused ones (HipLocalOps) or plain torch (the CPU tests' operator)
+    def dots(rv, zv):
+        out = torch.empty(2, dtype=torch.float64, device=dev)
+        if hasattr(ops, "dots"):
+            ops.dots(rv, zv, out)
+        else:
+            out[0], out[1] = torch.dot(rv, zv), torch.dot(rv, rv)
+        return out
+
+    def update_xr(num, den):
+        if hasattr(ops, "update_xr"):
+            ops.update_xr(num, den, p, Ap, x, r)
+        else:
+            a = num / den
+            x.add_(p[:nr] * a)
+            r.sub_(Ap * a)
+
+    def direction(num, den):
+        if hasattr(ops, "direction"):
+            ops.direction(num, den, z, p)
+        else:
+            p[:nr].mul_(num / den).add_(z)
+
+    red = _allreduce(dots(r, z), dev, group)
+    rz, bb = red[0:1], red[1].item()
     stop = rtol * rtol * bb
     info = dict(iterations=0, converged=bb == 0.0, rel_residual=0.0)
     it = 0
@@ -284,15 +317,12 @@ def distributed_pcg(ops, halo, f_owned, rtol=1e-8, maxit=20000, group=None, chec
         halo.exchange(p, dim)
         ops.spmv(p, Ap)
         ops.mask_fixed(Ap)
-        pAp = _allreduce(torch.dot(p[:nr], Ap).reshape(1), dev, group)[0]
-        alpha = rz / pAp
-        x.add_(p[:nr] * alpha)
-        r.sub_(Ap * alpha)
+        pAp = _allreduce(torch.dot(p[:nr], Ap).reshape(1), dev, group)
+        update_xr(rz, pAp)                                   # x += (rz/pAp) p ; r -= (rz/pAp) Ap
         precond(r, z)
-        red = _allreduce(torch.stack([torch.dot(r, z), torch.dot(r, r)]), dev, group)
-        beta = red[0] / rz
-        rz = red[0]
-        p[:nr].mul_(beta).add_(z)
+        red = _allreduce(dots(r, z), dev, group)
+        direction(red[0:1], rz)                              # p = z + (rz_new/rz) p
+        rz = red[0:1]
         hist.append(red[1])
         it += 1
         if it % check_every == 0 or it == maxit:
