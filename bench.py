@@ -12,9 +12,10 @@ Metric (BASELINE.json): stiffness-assembly elements/s (+ PCG DOF/s), quadratic t
     Inputs (connectivity, coordinates, material, gather lists) are resident in HBM.
     The symbolic phase (pattern + gather lists) is once-per-mesh setup and reported separately.
   * `value` = elements * K / (wall time of the K timed steps), max over ranks.
-  * N>1: weak scaling -- every rank owns a 60-layer z-slab of a 60 x 60 x 60N grid (row/element
-    partition, owner computes, no assembly communication); the PCG leg runs the distributed solver
-    (halo exchange + all-reduce over RCCL).
+  * N>1: weak scaling towards BASELINE configs[4] -- the global grid is n x n x (L N) with n ~ 60 N^(1/3) and
+    L ~ 60^3 / n^2 hex layers per rank (N = 8: the 120^3 cube, 41.5 M P2 tets, 15-layer z-slabs), so every rank
+    keeps ~5.2 M elements (row/element partition, owner computes, no assembly communication); the PCG leg
+    runs the distributed solver (halo exchange + all-reduces over RCCL, global two-level preconditioner).
 Extra objects on the JSON line: `roofline` (assembly kernel), `pcg` (solve to 1e-8 incl. its own
 roofline for the SpMV kernel), `cpu_baseline` (plain-C port of the reference loop structure timed
 on the host cores, bounded sample), `variants` (atomic-scatter assembly for comparison).

@@ -351,12 +351,14 @@ def distributed_pcg(ops, halo, f_owned, rtol=1e-8, maxit=20000, group=None, chec
 # ------------------------------------------------------------------------------------------------
 # synthetic z-slab meshes (weak scaling): the reference generator restricted to a z-range
 # ------------------------------------------------------------------------------------------------
-def slab_local_mesh(n, rank, world, deg=2):
-    """Grid n x n x (n*world) of unit-cube cells of size 1/n; rank owns hex layers [n*rank, n*(rank+1)).
-    Returns the LocalMesh plus integer lattice coordinates (units of 1/(4n)) of every local node."""
+def slab_local_mesh(n, rank, world, deg=2, layers=None):
+    """Grid n x n x (layers*world) of cubic cells of size 1/n; rank owns hex layers [layers*rank, layers*(rank+1))
+    (layers defaults to n: a cube per rank). Returns the LocalMesh plus integer lattice coordinates (units of
+    1/(4n)) of every local node."""
     from . import grid
     from .core import Context
-    z0, z1 = n * rank, n * (rank + 1)
+    layers = n if layers is None else int(layers)
+    z0, z1 = layers * rank, layers * (rank + 1)
     top = 1 if rank < world - 1 else 0                 # one halo hex layer above the owned interface plane
     V, H = grid.gen_grid_3d(n, n, z1 - z0 + top, z0=z0)
     V, T = grid.hex_tet_subdiv(V, H)
@@ -366,9 +368,9 @@ def slab_local_mesh(n, rank, world, deg=2):
     h.close()
     lat = np.rint(pos * 4).astype(np.int64)            # vertices/centres/midpoints live on the quarter lattice
     M = 4 * n + 1
-    keys = (lat[:, 0] * M + lat[:, 1]) * (4 * n * world + 1) + lat[:, 2]
-    # rank r owns lattice z in (4n r, 4n (r+1)]; the global bottom plane belongs to rank 0
-    owner = np.clip((lat[:, 2] + 4 * n - 1) // (4 * n) - 1, 0, world - 1)
+    keys = (lat[:, 0] * M + lat[:, 1]) * (4 * layers * world + 1) + lat[:, 2]
+    # rank r owns lattice z in (4 L r, 4 L (r+1)]; the global bottom plane belongs to rank 0
+    owner = np.clip((lat[:, 2] + 4 * layers - 1) // (4 * layers) - 1, 0, world - 1)
     lm = partition(en, pos / n, keys, owner, rank)
     lm.lattice = np.rint(lm.node_pos * 4 * n).astype(np.int64)
     return lm
@@ -399,9 +401,13 @@ def bench_slabs(args, rank, world, local_rank):
     """bench.py --gpus N>1: weak scaling over z-slabs; returns the JSON dict on every rank."""
     import meshfem_amd as M
     dev = torch.device("cuda", local_rank)
-    n, deg = args.grid, args.deg
+    deg = args.deg
+    # weak scaling towards BASELINE configs[4] (a ~40 M-tet CUBE in 8 z-slabs, SURVEY.md 8e): the global grid is
+    # n x n x (layers * world) with n ~ grid * world^(1/3), and every rank keeps ~24 grid^3 elements
+    n = int(round(args.grid * world ** (1.0 / 3.0)))
+    layers = max(1, int(round(args.grid ** 3 / float(n * n))))
     t0 = time.time()
-    lm = slab_local_mesh(n, rank, world, deg)
+    lm = slab_local_mesh(n, rank, world, deg, layers)
     t_mesh = time.time() - t0
     c = M.Context(local_rank)
     c.mesh_set(3, deg, lm.elem_nodes, lm.node_pos, lm.n_owned)
@@ -409,7 +415,7 @@ def bench_slabs(args, rank, world, local_rank):
     t0 = time.time(); c.symbolic(False); t_sym = time.time() - t0
     c.set_option("reembed", 1)
     # elements are counted once globally: a rank "owns" the elements of its own hex layers
-    n_elem_global = 24 * n * n * n * world
+    n_elem_global = 24 * n * n * layers * world
     for _ in range(args.warmup):
         c.assemble()
     c.dev_sync(); torch.cuda.synchronize(); dist.barrier()
@@ -425,8 +431,8 @@ def bench_slabs(args, rank, world, local_rank):
     out = dict(metric="stiffness_assembly_elements_per_s", value=n_elem_global * args.steps / dt, unit="elements/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-               config=dict(workload="%d x %d x %d grid -> %d P%d tets, z-slabs of %d hex layers per GPU (configs[4] shape)"
-                                    % (n, n, n * world, n_elem_global, deg, n), elements=n_elem_global,
+               config=dict(workload="%d x %d x %d grid -> %d P%d tets, z-slabs of %d hex layers per GPU (configs[4] shape: 120^3 at 8 GPUs)"
+                                    % (n, n, layers * world, n_elem_global, deg, layers), elements=n_elem_global,
                            local_elements=int(len(lm.elem_nodes)), local_nodes=int(lm.n_local), owned_nodes=int(lm.n_owned),
                            parallelism="row/element partition x%d, owner computes" % world),
                roofline=dict(bound="hbm", kernel="k_assemble_gather", achieved=alg * len(lm.elem_nodes) / k_ms / 1e6, peak=8000.0,

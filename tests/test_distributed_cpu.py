@@ -90,32 +90,35 @@ class OracleLocalOps:
         z[f] = r[f]
 
 
-def _global_problem(n, world):
-    """n x n x (n*world) grid, P2, unit cells of size 1/n; u=0 on x=0, traction (0,-1,0) on x=1."""
-    V, T = grid.grid_tet_mesh(n, n, n * world, [0, 0, 0], [1, 1, world])
+def _global_problem(n, world, layers=None):
+    """n x n x (layers*world) grid, P2, cubic cells of size 1/n; u=0 on x=0, traction (0,-1,0) on x=1."""
+    layers = n if layers is None else layers
+    nz = layers * world
+    V, T = grid.grid_tet_mesh(n, n, nz, [0, 0, 0], [1, 1, nz / n])
     sim = O.Simulator(T, V, 2)
     sim.set_material_constant(O.ElasticityTensor.isotropic(3, 200.0, 0.35))
-    sim.apply_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9 + world], [0, 0, 0])
-    sim.apply_neumann_box([1 - 1e-9, -9, -9], [1 + 1e-9, 9, 9 + world], [0, -1, 0], "traction")
+    sim.apply_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9 + nz], [0, 0, 0])
+    sim.apply_neumann_box([1 - 1e-9, -9, -9], [1 + 1e-9, 9, 9 + nz], [0, -1, 0], "traction")
     K = sim.assembleStiffnessMatrix().sum_repeated().to_scipy_full_from_upper().tocsr()
     f = sim.neumannLoad()
     u = sim.solve()
     lat = np.rint(sim.mesh.node_pos * 4 * n).astype(np.int64)
     M = 4 * n + 1
-    keys = (lat[:, 0] * M + lat[:, 1]) * (4 * n * world + 1) + lat[:, 2]
+    keys = (lat[:, 0] * M + lat[:, 1]) * (4 * nz + 1) + lat[:, 2]
     return sim, K, f, u, keys, lat
 
 
-def _worker(rank, world, port, n, ret):
+def _worker(rank, world, port, n, ret, layers=None):
+    layers = n if layers is None else layers
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        sim, K, f, u_ref, gkeys, glat = _global_problem(n, world)
+        sim, K, f, u_ref, gkeys, glat = _global_problem(n, world, layers)
         # the slab generator (each rank builds only its share) ...
-        lm = D.slab_local_mesh(n, rank, world, 2)
+        lm = D.slab_local_mesh(n, rank, world, 2, layers)
         # ... must agree with partitioning the global mesh by the same ownership rule
-        owner = np.clip((glat[:, 2] + 4 * n - 1) // (4 * n) - 1, 0, world - 1)
+        owner = np.clip((glat[:, 2] + 4 * layers - 1) // (4 * layers) - 1, 0, world - 1)
         lm_g = D.partition(sim.mesh.elem_nodes, sim.mesh.node_pos, gkeys, owner, rank)
         assert lm.n_owned == lm_g.n_owned and np.array_equal(lm.keys, lm_g.keys)
         assert np.allclose(lm.node_pos, lm_g.node_pos)
@@ -166,11 +169,13 @@ def _free_port():
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_slab_partition_and_pcg_gloo():
-    world, n = 2, 2
+@pytest.mark.parametrize("n,layers", [(2, 2), (3, 1)])
+def test_two_rank_slab_partition_and_pcg_gloo(n, layers):
+    """(3, 1): slabs thinner than wide, the shape of the 8-GPU run (120 x 120 x 15 per rank)."""
+    world = 2
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), n, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, ret, layers), nprocs=world, join=True)
     assert set(ret.keys()) == {0, 1}
     errs = [ret[r][0] for r in range(world)]
     assert max(errs) < 1e-7, dict(ret)
@@ -179,7 +184,7 @@ def test_two_rank_slab_partition_and_pcg_gloo():
     assert ret[0][4] == ret[1][4] and ret[0][4] < ret[0][1], dict(ret)
     assert ret[0][5] == ret[1][5] >= 2
     # every node is owned exactly once
-    V, T = grid.grid_tet_mesh(n, n, n * world)
+    V, T = grid.grid_tet_mesh(n, n, layers * world)
     assert ret[0][2] + ret[1][2] == O.FEMMesh(T, V, 2).num_nodes
 
 
