@@ -152,7 +152,15 @@ def run_single(args):
         u = c.sim_solve(rtol=args.rtol, maxit=args.maxit)
         info = dict(c.last_info)
         ndof = 3 * c.n_dof
-        sp_ms = c.time_spmv_kernel(20)
+        c.set_option("matrix_free", 0)
+        sp_ms = c.time_spmv_kernel(20)           # assembled block-CSR SpMV (k_spmv)
+        c.set_option("matrix_free", 1)
+        mf_ms = c.time_spmv_kernel(20)           # matrix-free operator (k_mf_forces + k_mf_rows), the PCG default for P2
+        c.set_option("matrix_free", -1)
+        npe = 10 if deg == 2 else 4
+        # compulsory bytes of the matrix-free operator: element record + connectivity + nodal forces written and read
+        # back + pair lists, per element; x gather + y + x (dot) per node
+        mf_bytes = nE * (128 + 4 * npe + 2 * 24 * npe + 6 * npe) + c.n_dof * 3 * 24
         sp_bytes = nnzb * 76 + nr * 3 * 16 + nr * 4
         it_bytes = sp_bytes + ndof * 112
         stb, stsrc = pmc_traffic("k_spmv<3, false>", n, deg)
@@ -162,6 +170,10 @@ def run_single(args):
                           dof_per_s=ndof * info["iterations"] / (info["solve_ms"] * 1e-3),
                           ms_per_iteration=info["solve_ms"] / max(1, info["iterations"]),
                           preconditioner="3x3 block-Jacobi (north_star baseline preconditioner)", wall_s=time.time() - t0,
+                          operator="matrix-free (k_mf_forces + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
+                          matrix_free=dict(kernels_ms=mf_ms, speedup_vs_assembled_spmv=sp_ms / mf_ms, bytes_per_application=mf_bytes,
+                                           achieved=mf_bytes / mf_ms / 1e6, frac=mf_bytes / mf_ms / 1e6 / HBM_PEAK_GBS, unit="GB/s",
+                                           note="same operator as the assembled K to rounding; trades 72 B/block of matrix traffic for FP64 flops"),
                           max_abs_u=float(np.abs(u).max()),
                           roofline=dict(bound="hbm", kernel="k_spmv", achieved=sp_bytes / sp_ms / 1e6, peak=HBM_PEAK_GBS,
                                         unit="GB/s", frac=sp_bytes / sp_ms / 1e6 / HBM_PEAK_GBS, kernel_ms=sp_ms,

@@ -53,6 +53,20 @@ struct mfh_ctx {
     DBuf<uint16_t> dContribSlot;
     ShapeTables tables;
     DBuf<double> dPairTable, dMassTable;
+    // matrix-free operator (option "matrix_free"): (element, node) pair lists by row chunks
+    MfLists mf;
+    bool mfValid = false;
+    int matrixFree = -1;              // option "matrix_free": 1 on, 0 off, -1 auto (quadratic elasticity: 2x faster than the assembled SpMV)
+    bool use_mf() const {
+        if (external || !haveMesh || hostOnly) return false;
+        return matrixFree == 1 || (matrixFree < 0 && mesh.deg == 2 && op == MFH_OP_ELASTICITY);
+    }
+    DBuf<int32_t> dMfChunkRow;
+    DBuf<int64_t> dMfPairPtr;
+    DBuf<uint32_t> dMfPairCode;
+    DBuf<uint16_t> dMfPairRow;
+    DBuf<double> dMfSig;              // two-pass operator: per-element nodal forces
+    int mfMode = 2;                   // option "matrix_free_mode": 2 = two-pass (stress + rows), 1 = per-pair block evaluation
 
     // ---- numeric
     DBuf<double> dVals;
@@ -168,6 +182,7 @@ void invalidate_matrix(mfh_ctx *c) {
 }
 void invalidate_symbolic(mfh_ctx *c) {
     c->symValid = false;
+    c->mfValid = false;
     c->dofUploaded = false;
     invalidate_matrix(c);
 }
@@ -375,6 +390,44 @@ k::SpmvArgs spmv_args(mfh_ctx *c, bool masked) {
     a.colIdx = c->dColIdx.p; a.vals = c->dVals.p; a.chunkSlots = c->sym.spmvChunkSlots;
     a.fixedMask = masked ? c->dFixedMask.p : nullptr;
     return a;
+}
+
+void ensure_mf(mfh_ctx *c) {
+    if (c->mfValid) return;
+    require(c->haveMesh && !c->hostOnly, MFH_ERR_STATE, "the matrix-free operator needs a mesh on a device");
+    ensure_symbolic(c, false);   // row ownership (nRows) and the DoF map on the device
+    build_mf_lists_device(c->mesh, c->dElemNodes.p, device_dof_map(c), c->sym.nRows, c->stream, c->mf, c->dMfPairCode, c->dMfPairRow);
+    c->dMfChunkRow.upload(c->mf.chunkRow, c->stream);
+    c->dMfPairPtr.upload(c->mf.pairPtr, c->stream);
+    c->dMfSig.alloc((size_t)c->mesh.npe * c->mesh.dim * (size_t)c->mesh.nElem);   // nodal forces, element-major
+    c->mfValid = true;
+}
+
+k::SpmvMfArgs spmv_mf_args(mfh_ctx *c, bool masked) {
+    const HostMesh &m = c->mesh;
+    k::SpmvMfArgs a{};
+    a.dim = m.dim; a.deg = m.deg; a.npe = m.npe; a.mat = c->asmMat();
+    a.nChunk = (int64_t)c->mf.chunkRow.size() - 1; a.chunkRow = c->dMfChunkRow.p; a.pairPtr = c->dMfPairPtr.p;
+    a.pairCode = c->dMfPairCode.p; a.pairRow = c->dMfPairRow.p; a.elemNodes = c->dElemNodes.p; a.dofForNode = device_dof_map(c);
+    a.geo = c->dGeo.p; a.geoStride = c->geoStride; a.pairTable = c->dPairTable.p; a.massTable = c->dMassTable.p;
+    for (int k2 = 0; k2 < 6; ++k2) a.pairConst[k2] = c->tables.pairConst[k2];
+    a.maxRows = c->mf.maxRows;
+    a.variant = c->debugVariant;
+    a.nElem = m.nElem;
+    a.sig = c->dMfSig.p;
+    a.fixedMask = masked ? c->dFixedMask.p : nullptr;
+    return a;
+}
+
+// y = K x through the assembled matrix or the matrix-free operator (option "matrix_free")
+void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double *dotOut) {
+    if (c->use_mf()) {
+        ensure_geometry(c);
+        ensure_mf(c);
+        if (c->mfMode == 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
+        else k::launch_spmv_mf(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
+    } else
+        k::launch_spmv(spmv_args(c, masked), x, y, dotOut, c->stream);
 }
 
 void ensure_fixed_uploaded(mfh_ctx *c) {
@@ -611,7 +664,7 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
         c->wu0.alloc(n);
         c->wu0.zero(s);
         k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wu0.p, s);
-        k::launch_spmv(spmv_args(c, false), c->wu0.p, c->wAp.p, nullptr, s);
+        apply_operator(c, false, c->wu0.p, c->wAp.p, nullptr);
         k::launch_axpby(n, -1.0, c->wAp.p, 1.0, c->wb.p, s);
     }
     if (!c->fixedVars.empty()) k::launch_mask(n, c->dFixedMask.p, c->wb.p, s);
@@ -640,12 +693,17 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
             MFH_HIP(hipMemcpyAsync(c->wp.p, c->wz.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
         }
         const k::SpmvArgs sa = spmv_args(c, !c->fixedVars.empty());
+        const bool useMF = c->use_mf();
+        if (useMF) ensure_mf(c);
+        const k::SpmvMfArgs mfa = useMF ? spmv_mf_args(c, !c->fixedVars.empty()) : k::SpmvMfArgs{};
         std::vector<double> hs;
         int it = 0;
         bool done = false;
         int lastChecked = 0;
         auto enqueue = [&](int itLocal) {   // one PCG iteration; `itLocal` is relative to the iteration base stop[3]
-            k::launch_pcg_spmv(sa, c->wp.p, c->wAp.p, c->scal.p, itLocal, c->stop.p, s);
+            if (useMF && c->mfMode == 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
+            else if (useMF) k::launch_spmv_mf(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
+            else k::launch_pcg_spmv(sa, c->wp.p, c->wAp.p, c->scal.p, itLocal, c->stop.p, s);
             if (useTL) {
                 k::launch_pcg_update_noz(d, c->sym.nRows, c->wp.p, c->wAp.p, c->wx.p, c->wr.p, c->scal.p, itLocal, c->stop.p, s);
                 tl_precond(c, c->wr.p, c->wz.p, c->scal.p, itLocal);
@@ -705,7 +763,7 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
         k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wx.p, s);
     // true residual on the free variables: || mask(f - K u) || / ||b||
     if (bb > 0) {
-        k::launch_spmv(spmv_args(c, false), c->wx.p, c->wAp.p, nullptr, s);
+        apply_operator(c, false, c->wx.p, c->wAp.p, nullptr);
         k::launch_axpby(n, 1.0, c->wf.p, -1.0, c->wAp.p, s);
         if (!c->fixedVars.empty()) k::launch_mask(n, c->dFixedMask.p, c->wAp.p, s);
         li.true_rel_residual = std::sqrt(device_dot(c, n, c->wAp.p, c->wAp.p) / bb);
@@ -1327,7 +1385,7 @@ mfh_status mfh_apply_K(mfh_ctx *c, const double *u, double *Ku) {
     c->wx.alloc(nin);
     c->wAp.alloc(std::max(nin, nout));
     MFH_HIP(hipMemcpyAsync(c->wx.p, u, nin * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    k::launch_spmv(spmv_args(c, false), c->wx.p, c->wAp.p, nullptr, c->stream);
+    apply_operator(c, false, c->wx.p, c->wAp.p, nullptr);
     MFH_HIP(hipMemcpyAsync(Ku, c->wAp.p, nout * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     MFH_HIP(hipStreamSynchronize(c->stream));
     MFH_CATCH(c)
@@ -1803,7 +1861,7 @@ mfh_status mfh_dev_spmv(mfh_ctx *c, const double *x_dev, double *y_dev) {
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_assembled(c);
-    k::launch_spmv(spmv_args(c, false), x_dev, y_dev, nullptr, c->stream);
+    apply_operator(c, false, x_dev, y_dev, nullptr);
     MFH_CATCH(c)
 }
 mfh_status mfh_dev_precond(mfh_ctx *c, const double *r_dev, double *z_dev) {
@@ -1976,9 +2034,9 @@ mfh_status mfh_time_spmv_kernel(mfh_ctx *c, int32_t reps, double *avg_ms) {
     k::launch_axpby(nin, 0.0, c->wx.p, 0.0, c->wx.p, c->stream);
     std::vector<double> ones((size_t)nin, 1.0);
     MFH_HIP(hipMemcpyAsync(c->wx.p, ones.data(), nin * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    k::launch_spmv(spmv_args(c, false), c->wx.p, c->wAp.p, nullptr, c->stream);   // warm-up
+    apply_operator(c, false, c->wx.p, c->wAp.p, nullptr);   // warm-up
     EventTimer t(c->stream);
-    for (int r = 0; r < reps; ++r) k::launch_spmv(spmv_args(c, false), c->wx.p, c->wAp.p, nullptr, c->stream);
+    for (int r = 0; r < reps; ++r) apply_operator(c, false, c->wx.p, c->wAp.p, nullptr);
     *avg_ms = t.stop() / reps;
     MFH_CATCH(c)
 }
@@ -2026,6 +2084,8 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "topology_device") { c->topologyDevice = value != 0; }
     else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }
     else if (k2 == "pcg_graph") c->useGraph = value != 0;
+    else if (k2 == "matrix_free_mode") c->mfMode = (int)value;
+    else if (k2 == "matrix_free") c->matrixFree = value < 0 ? -1 : (value != 0 ? 1 : 0);   // K x without reading the assembled K (k_spmv_mf)
     else if (k2 == "tl_probe") { c->tlProbe = value != 0; c->tl.valid = false; }
     else if (k2 == "tl_host_inverse") { c->tlHostInverse = value != 0; c->tl.valid = false; }
     else if (k2 == "debug_variant") { c->debugVariant = (int)value; invalidate_matrix(c); }

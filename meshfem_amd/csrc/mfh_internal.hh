@@ -163,6 +163,15 @@ void build_symbolic(const HostMesh &m, const std::vector<int32_t> &dofForNode /*
                     Symbolic &S);
 
 // device implementation (mfh_symbolic_gpu.hip): element-major gather lists via two radix sorts
+// gather lists of the matrix-free operator (mfh_symbolic_gpu.hip)
+struct MfLists {
+    std::vector<int32_t> chunkRow;
+    std::vector<int64_t> pairPtr;
+    int maxRows = 0;
+    int64_t nPairs = 0;
+};
+void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nRows, hipStream_t s,
+                           MfLists &L, DBuf<uint32_t> &dPairCode, DBuf<uint16_t> &dPairRow);
 void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nDoF, int64_t nOwnedDoF,
                            int chunkSlots, bool wantScatter, hipStream_t s, Symbolic &S, DBuf<int32_t> &dRowPtr, DBuf<int32_t> &dColIdx,
                            DBuf<uint32_t> &dContribCode, DBuf<uint16_t> &dContribSlot, DBuf<int32_t> &dScatter);
@@ -254,6 +263,33 @@ struct SpmvArgs {
     int chunkSlots;
     const uint8_t *fixedMask;           // per scalar row, may be null
 };
+// Matrix-free operator: y = K x without reading the assembled K. One lane per (element, local node i) pair:
+// it evaluates the npe blocks K_e[i][j] in registers and applies them to the gathered x_j; pairs are grouped by
+// row chunks (element-major inside a chunk) and reduced in LDS.
+struct SpmvMfArgs {
+    int dim, deg, npe, mat;
+    int64_t nChunk;
+    const int32_t *chunkRow;            // nChunk+1: first row of every chunk
+    const int64_t *pairPtr;             // nChunk+1: first pair of every chunk
+    const uint32_t *pairCode;           // e * npe + i
+    const uint16_t *pairRow;            // row - chunkRow[chunk]
+    const int32_t *elemNodes;
+    const int32_t *dofForNode;          // may be null
+    const double *geo;
+    int geoStride;
+    const double *pairTable, *massTable;
+    double pairConst[6];
+    int maxRows;                        // rows per chunk (LDS accumulators)
+    int variant;                        // timing experiments only (0 = product kernel)
+    int64_t nElem;
+    double *sig;                        // two-pass operator: nodal forces of every element, [nElem][npe][dim]
+    const uint8_t *fixedMask;           // per scalar row, may be null
+};
+void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
+                    bool pcg, hipStream_t s);
+void launch_spmv_mf2(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
+                     bool pcg, hipStream_t s);
+
 // y = A x (optionally masked), optional dot accumulation: dotOut[0] += x_rows . y
 void launch_spmv(const SpmvArgs &a, const double *x, double *y, double *dotOut, hipStream_t s);
 

@@ -599,6 +599,295 @@ __global__ void __launch_bounds__(256) k_spmv(SpmvArgs a, const double *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// Matrix-free operator y = K x: one lane per (element, local node i) pair evaluates the row i of the
+// element matrix block by block in registers (same elem_block as the assembly: identical values) and
+// applies it to the gathered x; pairs of a row chunk are reduced in LDS. Trades the 72 B/block of the
+// assembled SpMV for ~73 FP64 flops/block: HBM traffic drops from nnzb*76 B to the element records +
+// pair lists + x, the FP64 VALU (idle in the assembled SpMV) does the work.
+// ------------------------------------------------------------------------------------------------
+template <int DIM, int DEG, int MAT, bool PCG, int UNR = 0>
+__global__ void __launch_bounds__(256) k_spmv_mf(SpmvMfArgs a, const double *__restrict__ x, double *__restrict__ y, double *dotOut,
+                                                 double *scal, int it, const double *stopPtr) {
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    constexpr int NB = mat_nb<DIM, MAT>();
+    constexpr int BS = NB == 1 ? 1 : DIM;
+    extern __shared__ __attribute__((aligned(16))) double mfacc[];   // [maxRows * BS] + 16
+    double *red = mfacc + a.maxRows * BS;
+    if (PCG) {
+        it += (int)stopPtr[3];
+        if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
+        dotOut = scal + (int64_t)it * 4 + 1;
+    }
+    const PairConst pc{a.pairConst[0], a.pairConst[1], a.pairConst[2], a.pairConst[3], a.pairConst[4], a.pairConst[5]};
+    const double *tab = MAT == MAT_MASS ? a.massTable : a.pairTable;
+    double dot = 0.0;
+    for (int64_t chunk = blockIdx.x; chunk < a.nChunk; chunk += gridDim.x) {
+        const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
+        const int nr = (r1 - r0) * BS;
+        for (int t = threadIdx.x; t < nr; t += 256) mfacc[t] = 0.0;
+        __syncthreads();
+        const int64_t kb = a.pairPtr[chunk], ke = a.pairPtr[chunk + 1];
+        for (int64_t k = kb + threadIdx.x; k < ke; k += 256) {
+            const uint32_t code = a.pairCode[k];
+            const int lr = a.pairRow[k];
+            const uint32_t e = code / NPE;
+            const int i = (int)(code - e * NPE);
+            const double *g = a.geo + (int64_t)e * a.geoStride;
+            const int32_t *en = a.elemNodes + (int64_t)e * NPE;
+            double out[BS];
+#pragma unroll
+            for (int c = 0; c < BS; ++c) out[c] = 0.0;
+#pragma unroll(UNR == 0 ? NPE : UNR)
+            for (int j = 0; j < NPE; ++j) {
+                int64_t col = en[j];
+                if (a.dofForNode) col = a.dofForNode[col];
+                double xv[BS], K[NB];
+#pragma unroll
+                for (int d = 0; d < BS; ++d) xv[d] = x[col * BS + d];
+                elem_block<DIM, DEG, MAT>(g, tab, pc, i, j, K);
+#pragma unroll
+                for (int c = 0; c < BS; ++c)
+#pragma unroll
+                    for (int d = 0; d < BS; ++d) out[c] += K[c * BS + d] * xv[d];
+            }
+#pragma unroll
+            for (int c = 0; c < BS; ++c) unsafeAtomicAdd(&mfacc[lr * BS + c], out[c]);
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nr; idx += 256) {
+            const int64_t gi = (int64_t)r0 * BS + idx;
+            double v = mfacc[idx];
+            if (a.fixedMask && a.fixedMask[gi]) v = 0.0;
+            y[gi] = v;
+            if (dotOut) dot += v * x[gi];
+        }
+        __syncthreads();
+    }
+    if (dotOut) {
+        double v[1] = {dot};
+        block_sum<1>(v, red);
+        if (threadIdx.x == 0) unsafeAtomicAdd(dotOut, v[0]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Matrix-free ELASTICITY operator in two passes -- the stresses are shared by the npe rows of an element
+// instead of being recomputed per (element, node) pair:
+//   k_mf_forces: one lane per element. With the reference's quadrature rule every point q belongs to a vertex
+//     (lambda_k(q) = c0 if k == q else c1), so grad u(q) = G_b + (a-b) x_q (x) gl_q + (A-B) sum_{k != q} x_edge(k,q) (x) gl_k
+//     with G_b = sum_k (b x_k + B sum_{edges m at k} x_m) (x) gl_k,  a = 4 c0 - 1, b = 4 c1 - 1, A = 4 c0, B = 4 c1
+//     (EmbeddedElement.hh:288-313). With S' = vol w sum_q sigma_q and R_q = vol w (a-b) sigma_q the nodal forces
+//     f_i = int sigma(u) grad phi_i are
+//     vertex k: (b S' + R_k) gl_k ;  edge (s,t): (B S' + R_t) gl_s + (B S' + R_s) gl_t ;  P1: vol sigma gl_i
+//     (same quadrature as the assembled K: identical up to rounding), written element-major: 240 B per P2 tet.
+//   k_mf_rows: one lane per (element, node) pair (lists of build_mf_lists_device): y_row = sum of the pairs' forces
+//     -- a pure gather-sum through LDS, no arithmetic.
+// HBM traffic: records + connectivity + x + 2 x 240 B/element of forces + pair lists ~ 4.5 GB at 5.2 M P2 tets,
+// against 15.7 GB for the assembled SpMV.
+// ------------------------------------------------------------------------------------------------
+template <int DIM> DEV constexpr int edge_between(int k, int q) {
+    // local edge index joining vertices k and q (Simplex.hh:43-47): (0,1),(1,2),(2,0),(0,3),(2,3),(1,3)
+    const int lo = k < q ? k : q, hi = k < q ? q : k;
+    if (lo == 0 && hi == 1) return 0;
+    if (lo == 1 && hi == 2) return 1;
+    if (lo == 0 && hi == 2) return 2;
+    if (lo == 0 && hi == 3) return 3;
+    if (lo == 2 && hi == 3) return 4;
+    return 5;   // (1,3)
+}
+
+template <int DIM, int DEG, int MAT>
+__global__ void __launch_bounds__(256) k_mf_forces(SpmvMfArgs a, const double *__restrict__ x, double *__restrict__ fbuf,
+                                                   const double *scal, int it, const double *stopPtr) {
+    constexpr int NV = DIM + 1;
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    constexpr int FL = DIM * (DIM + 1) / 2;
+    if (scal) {
+        it += (int)stopPtr[3];
+        if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
+    }
+    const int64_t nE = a.nElem;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nE; e += (int64_t)gridDim.x * 256) {
+        const double *g = a.geo + e * a.geoStride;
+        const int32_t *en = a.elemNodes + e * NPE;
+        double xl[NPE][DIM], gl[NV][DIM];
+#pragma unroll
+        for (int j = 0; j < NPE; ++j) {
+            int64_t col = en[j];
+            if (a.dofForNode) col = a.dofForNode[col];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) xl[j][d] = x[col * DIM + d];
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) gl[k][d] = g[k * DIM + d];
+        const double vol = g[12];
+        auto stress_of = [&](const double (&G)[DIM][DIM], double *out) {
+            double sd[FL];
+#pragma unroll
+            for (int p = 0; p < DIM; ++p)
+#pragma unroll
+                for (int q2 = p; q2 < DIM; ++q2)
+                    sd[flat_idx<DIM>(p, q2)] = (p == q2) ? G[p][p] : (G[p][q2] + G[q2][p]);   // shear-doubled strain
+            elem_D_apply<DIM, MAT>(g, sd, out);
+        };
+        auto symv = [&](const double *T, const double *v, double *o) {   // o += T v  (T flat symmetric)
+#pragma unroll
+            for (int p = 0; p < DIM; ++p)
+#pragma unroll
+                for (int q2 = 0; q2 < DIM; ++q2) o[p] += T[flat_idx<DIM>(p, q2)] * v[q2];
+        };
+        double f[NPE][DIM];
+#pragma unroll
+        for (int j = 0; j < NPE; ++j)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) f[j][d] = 0.0;
+        if (DEG == 1) {
+            double G[DIM][DIM];
+#pragma unroll
+            for (int p = 0; p < DIM; ++p)
+#pragma unroll
+                for (int q2 = 0; q2 < DIM; ++q2) {
+                    double v = 0;
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) v += xl[j][p] * gl[j][q2];
+                    G[p][q2] = v;
+                }
+            double sg[FL];
+            stress_of(G, sg);
+#pragma unroll
+            for (int c = 0; c < FL; ++c) sg[c] *= vol;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) symv(sg, gl[j], f[j]);
+        } else {
+            constexpr double c0 = DIM == 3 ? 0.58541019662496845446 : 2.0 / 3.0;     // GaussQuadrature.hh:283-295 / :115-127
+            constexpr double c1 = DIM == 3 ? 0.13819660112501051518 : 1.0 / 6.0;
+            constexpr double b_ = 4 * c1 - 1, A_ = 4 * c0, B_ = 4 * c1, dAB = A_ - B_;   // a - b = A - B
+            constexpr double wq = 1.0 / NV;
+            double Gb[DIM][DIM];
+#pragma unroll
+            for (int p = 0; p < DIM; ++p)
+#pragma unroll
+                for (int q2 = 0; q2 < DIM; ++q2) Gb[p][q2] = 0.0;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                double base[DIM];
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) {
+                    double sum = 0;
+#pragma unroll
+                    for (int o = 0; o < NV; ++o)
+                        if (o != k) sum += xl[NV + edge_between<DIM>(k, o)][d];
+                    base[d] = b_ * xl[k][d] + B_ * sum;
+                }
+#pragma unroll
+                for (int p = 0; p < DIM; ++p)
+#pragma unroll
+                    for (int q2 = 0; q2 < DIM; ++q2) Gb[p][q2] += base[p] * gl[k][q2];
+            }
+            double S[FL], R[NV][FL];
+#pragma unroll
+            for (int c = 0; c < FL; ++c) S[c] = 0.0;
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                double G[DIM][DIM];
+#pragma unroll
+                for (int p = 0; p < DIM; ++p)
+#pragma unroll
+                    for (int q2 = 0; q2 < DIM; ++q2) {
+                        double v = Gb[p][q2] + dAB * xl[q][p] * gl[q][q2];
+#pragma unroll
+                        for (int k = 0; k < NV; ++k)
+                            if (k != q) v += dAB * xl[NV + edge_between<DIM>(k, q)][p] * gl[k][q2];
+                        G[p][q2] = v;
+                    }
+                double sg[FL];
+                stress_of(G, sg);
+#pragma unroll
+                for (int c = 0; c < FL; ++c) { S[c] += sg[c]; R[q][c] = vol * wq * dAB * sg[c]; }
+            }
+            // vertex k: f = (b S' + R_k) gl_k ;  edge (s,t): f = (B S' + R_t) gl_s + (B S' + R_s) gl_t
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                double T[FL];
+#pragma unroll
+                for (int c = 0; c < FL; ++c) T[c] = (vol * wq * b_) * S[c] + R[k][c];
+                symv(T, gl[k], f[k]);
+            }
+#pragma unroll
+            for (int c = 0; c < FL; ++c) S[c] *= vol * wq * B_;
+#pragma unroll
+            for (int m = 0; m < NPE - NV; ++m) {
+                const int sI = sup_s<DIM, DEG>(NV + m), tI = sup_t<DIM, DEG>(NV + m);
+                double T1[FL], T2[FL];
+#pragma unroll
+                for (int c = 0; c < FL; ++c) { T1[c] = S[c] + R[tI][c]; T2[c] = S[c] + R[sI][c]; }
+                symv(T1, gl[sI], f[NV + m]);
+                symv(T2, gl[tI], f[NV + m]);
+            }
+        }
+        // element-major AoS: the (element, node) pair with code e*NPE + i owns fbuf[code*DIM .. +DIM)
+        double *o = fbuf + e * (NPE * DIM);
+        if ((NPE * DIM) % 2 == 0) {
+            typedef double dv2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int q = 0; q < NPE * DIM / 2; ++q) {
+                dv2 w = {f[(2 * q) / DIM][(2 * q) % DIM], f[(2 * q + 1) / DIM][(2 * q + 1) % DIM]};
+                *reinterpret_cast<dv2 *>(o + 2 * q) = w;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NPE * DIM; ++q) o[q] = f[q / DIM][q % DIM];
+        }
+    }
+}
+
+// y_row = sum over the (element, node) pairs of the row of their nodal force: a pure gather-sum
+template <int DIM, bool PCG>
+__global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__restrict__ fbuf, const double *__restrict__ x,
+                                                 double *__restrict__ y, double *dotOut, double *scal, int it, const double *stopPtr) {
+    extern __shared__ __attribute__((aligned(16))) double mfacc[];   // [maxRows * DIM] + 16
+    double *red = mfacc + a.maxRows * DIM;
+    if (PCG) {
+        it += (int)stopPtr[3];
+        if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
+        dotOut = scal + (int64_t)it * 4 + 1;
+    }
+    double dot = 0.0;
+    for (int64_t chunk = blockIdx.x; chunk < a.nChunk; chunk += gridDim.x) {
+        const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
+        const int nr = (r1 - r0) * DIM;
+        for (int t = threadIdx.x; t < nr; t += 256) mfacc[t] = 0.0;
+        __syncthreads();
+        const int64_t kb = a.pairPtr[chunk], ke = a.pairPtr[chunk + 1];
+        for (int64_t k = kb + threadIdx.x; k < ke; k += 256) {
+            const int64_t code = a.pairCode[k];
+            const int lr = a.pairRow[k];
+            double out[DIM];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) out[c] = fbuf[code * DIM + c];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) unsafeAtomicAdd(&mfacc[lr * DIM + c], out[c]);
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < nr; idx += 256) {
+            const int64_t gi = (int64_t)r0 * DIM + idx;
+            double v = mfacc[idx];
+            if (a.fixedMask && a.fixedMask[gi]) v = 0.0;
+            y[gi] = v;
+            if (dotOut) dot += v * x[gi];
+        }
+        __syncthreads();
+    }
+    if (dotOut) {
+        double v[1] = {dot};
+        block_sum<1>(v, red);
+        if (threadIdx.x == 0) unsafeAtomicAdd(dotOut, v[0]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // small dense helpers
 // ------------------------------------------------------------------------------------------------
 template <int DIM> DEV void invert_block(const double *A, double *Inv) {
@@ -1354,6 +1643,51 @@ void launch_pcg_spmv(const SpmvArgs &a, const double *p, double *Ap, double *sca
     if (a.dim == 1) hipLaunchKernelGGL((k_spmv<1, true>), dim3(spmv_grid(a)), dim3(256), lds, s, a, p, Ap, (double *)nullptr, scal, it, stopPtr);
     else if (a.dim == 3) hipLaunchKernelGGL((k_spmv<3, true>), dim3(spmv_grid(a)), dim3(256), lds, s, a, p, Ap, (double *)nullptr, scal, it, stopPtr);
     else hipLaunchKernelGGL((k_spmv<2, true>), dim3(spmv_grid(a)), dim3(256), lds, s, a, p, Ap, (double *)nullptr, scal, it, stopPtr);
+    CHECK_LAUNCH();
+}
+
+void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
+                    bool pcg, hipStream_t s) {
+    if (a.nChunk == 0) return;
+    const int bs = mat_is_scalar(a.mat) ? 1 : a.dim;
+    const size_t lds = ((size_t)a.maxRows * bs + 16) * sizeof(double);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(a.nChunk, 256 * 8));
+#define CALL(D, G, M)                                                                                                          \
+    if (pcg) hipLaunchKernelGGL((k_spmv_mf<D, G, M, true>), dim3(grid), dim3(256), lds, s, a, x, y, (double *)nullptr, scal, it, stopPtr); \
+    else hipLaunchKernelGGL((k_spmv_mf<D, G, M, false>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr)
+    if (a.variant && a.dim == 3 && a.deg == 2 && a.mat == MAT_ISO) {
+        // timing experiments: unroll factor of the j loop (register pressure vs ILP)
+        switch (a.variant) {
+        case 1: if (pcg) hipLaunchKernelGGL((k_spmv_mf<3, 2, MAT_ISO, true, 1>), dim3(grid), dim3(256), lds, s, a, x, y, (double *)nullptr, scal, it, stopPtr);
+                else hipLaunchKernelGGL((k_spmv_mf<3, 2, MAT_ISO, false, 1>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr); break;
+        case 2: if (pcg) hipLaunchKernelGGL((k_spmv_mf<3, 2, MAT_ISO, true, 2>), dim3(grid), dim3(256), lds, s, a, x, y, (double *)nullptr, scal, it, stopPtr);
+                else hipLaunchKernelGGL((k_spmv_mf<3, 2, MAT_ISO, false, 2>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr); break;
+        default: if (pcg) hipLaunchKernelGGL((k_spmv_mf<3, 2, MAT_ISO, true, 5>), dim3(grid), dim3(256), lds, s, a, x, y, (double *)nullptr, scal, it, stopPtr);
+                else hipLaunchKernelGGL((k_spmv_mf<3, 2, MAT_ISO, false, 5>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr); break;
+        }
+    } else {
+        MFH_DISPATCH_ASM(a, CALL);
+    }
+#undef CALL
+    CHECK_LAUNCH();
+}
+
+// two-pass matrix-free elasticity operator (k_mf_stress + k_mf_rows)
+void launch_spmv_mf2(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
+                     bool pcg, hipStream_t s) {
+    if (a.nChunk == 0) return;
+    const int gridE = grid_for(a.nElem, 256 * 32);
+#define CALL(D, G, M) hipLaunchKernelGGL((k_mf_forces<D, G, M>), dim3(gridE), dim3(256), 0, s, a, x, a.sig, pcg ? (const double *)scal : (const double *)nullptr, it, stopPtr)
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+    CHECK_LAUNCH();
+    const size_t lds = ((size_t)a.maxRows * a.dim + 16) * sizeof(double);
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(a.nChunk, 256 * 8));
+#define ROWS(D)                                                                                                                      \
+    if (pcg) hipLaunchKernelGGL((k_mf_rows<D, true>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, (double *)nullptr, scal, it, stopPtr); \
+    else hipLaunchKernelGGL((k_mf_rows<D, false>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr)
+    if (a.dim == 3) { ROWS(3); } else { ROWS(2); }
+#undef ROWS
     CHECK_LAUNCH();
 }
 

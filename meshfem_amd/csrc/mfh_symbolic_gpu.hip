@@ -208,6 +208,106 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
 
 
 // ------------------------------------------------------------------------------------------------
+// Gather lists of the matrix-free operator: the nElem*npe (element, local node) pairs grouped by the row
+// (DoF of that node), rows grouped into chunks, element-major inside a chunk. Two radix sorts.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) k_mf_gen(int64_t N, const int32_t *__restrict__ elemNodes, const int32_t *__restrict__ dofForNode,
+                                                int64_t nRows, uint32_t *__restrict__ key, uint32_t *__restrict__ val,
+                                                int32_t *__restrict__ rowCount) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < N; k += (int64_t)gridDim.x * 256) {
+        int64_t row = elemNodes[k];
+        if (dofForNode) row = dofForNode[row];
+        const bool ok = row < nRows;
+        key[k] = ok ? (uint32_t)row : (uint32_t)nRows;      // not-owned rows sort last
+        val[k] = (uint32_t)k;
+        if (ok) atomicAdd(&rowCount[row], 1);
+    }
+}
+__global__ void __launch_bounds__(256) k_mf_key2(int64_t n, const uint32_t *__restrict__ rowKey, const uint32_t *__restrict__ code,
+                                                 const int32_t *__restrict__ chunkOfRow, const int32_t *__restrict__ chunkFirstRow,
+                                                 uint64_t *__restrict__ key2, uint16_t *__restrict__ lrow) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        const int32_t row = (int32_t)rowKey[k];
+        const int32_t ch = chunkOfRow[row];
+        key2[k] = ((uint64_t)(uint32_t)ch << 32) | (uint64_t)code[k];
+        lrow[k] = (uint16_t)(row - chunkFirstRow[ch]);
+    }
+}
+} // namespace
+
+void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nRows, hipStream_t s,
+                           MfLists &L, DBuf<uint32_t> &dPairCode, DBuf<uint16_t> &dPairRow) {
+    const int64_t N = m.nElem * m.npe;
+    if ((double)N >= 4294967295.0) throw Error(MFH_ERR_UNSUPPORTED, "mesh too large for 32-bit pair codes");
+    DBuf<uint32_t> keyA, keyB, valA, valB;
+    DBuf<int32_t> rowCount, rowPtr;
+    keyA.alloc(N); keyB.alloc(N); valA.alloc(N); valB.alloc(N);
+    rowCount.alloc((size_t)nRows + 1);
+    rowCount.zero(s);
+    hipLaunchKernelGGL(k_mf_gen, dim3(grid_of(N)), dim3(256), 0, s, N, dElemNodes, dDofForNode, nRows, keyA.p, valA.p, rowCount.p);
+    RP(hipGetLastError());
+    const unsigned endBit1 = bits_for((uint64_t)nRows);
+    size_t tmpBytes = 0;
+    RP(rocprim::radix_sort_pairs(nullptr, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)N, 0u, endBit1, s));
+    DBuf<char> tmp;
+    tmp.alloc(tmpBytes + 16);
+    RP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)N, 0u, endBit1, s));
+    rowPtr.alloc((size_t)nRows + 1);
+    size_t exBytes = 0;
+    RP(rocprim::exclusive_scan(nullptr, exBytes, rowCount.p, rowPtr.p, (int32_t)0, (size_t)nRows + 1, rocprim::plus<int32_t>(), s));
+    if (exBytes + 16 > tmp.n) tmp.alloc(exBytes + 16);
+    RP(rocprim::exclusive_scan(tmp.p, exBytes, rowCount.p, rowPtr.p, (int32_t)0, (size_t)nRows + 1, rocprim::plus<int32_t>(), s));
+    std::vector<int32_t> hRowPtr((size_t)nRows + 1);
+    rowPtr.download(hRowPtr.data(), hRowPtr.size(), s);
+    const int64_t nP = hRowPtr[nRows];
+    if (nP == 0) throw Error(MFH_ERR_INVALID, "no element touches an owned row");
+    // ---- chunks: <= 256 rows and <= 2048 pairs (a single row may exceed the pair budget: it then forms its own chunk)
+    const int maxRowsCap = 256, maxPairs = 2048;
+    L = MfLists();
+    L.chunkRow.push_back(0);
+    int64_t r = 0;
+    while (r < nRows) {
+        int64_t r2 = r + 1;
+        while (r2 < nRows && r2 - r < maxRowsCap && hRowPtr[r2 + 1] - hRowPtr[r] <= maxPairs) ++r2;
+        L.maxRows = std::max<int>(L.maxRows, (int)(r2 - r));
+        L.chunkRow.push_back((int32_t)r2);
+        r = r2;
+    }
+    const int64_t nChunk = (int64_t)L.chunkRow.size() - 1;
+    L.pairPtr.resize((size_t)nChunk + 1);
+    std::vector<int32_t> chunkOfRow((size_t)nRows), chunkFirst((size_t)nChunk);
+    for (int64_t c = 0; c < nChunk; ++c) {
+        L.pairPtr[c] = hRowPtr[L.chunkRow[c]];
+        chunkFirst[c] = L.chunkRow[c];
+        for (int32_t q = L.chunkRow[c]; q < L.chunkRow[c + 1]; ++q) chunkOfRow[q] = (int32_t)c;
+    }
+    L.pairPtr[nChunk] = nP;
+    L.nPairs = nP;
+    // ---- element-major order inside every chunk
+    DBuf<int32_t> dChunkOfRow, dChunkFirst;
+    dChunkOfRow.upload(chunkOfRow, s);
+    dChunkFirst.upload(chunkFirst, s);
+    DBuf<uint64_t> k2A, k2B;
+    DBuf<uint16_t> lrA;
+    k2A.alloc((size_t)nP); k2B.alloc((size_t)nP); lrA.alloc((size_t)nP);
+    hipLaunchKernelGGL(k_mf_key2, dim3(grid_of(nP)), dim3(256), 0, s, nP, keyB.p, valB.p, dChunkOfRow.p, dChunkFirst.p, k2A.p, lrA.p);
+    RP(hipGetLastError());
+    keyA.release(); valA.release();
+    dPairRow.alloc((size_t)nP);
+    const unsigned endBit2 = 32 + bits_for((uint64_t)nChunk);
+    size_t tmp2 = 0;
+    RP(rocprim::radix_sort_pairs(nullptr, tmp2, k2A.p, k2B.p, lrA.p, dPairRow.p, (size_t)nP, 0u, endBit2, s));
+    if (tmp2 + 16 > tmp.n) tmp.alloc(tmp2 + 16);
+    RP(rocprim::radix_sort_pairs(tmp.p, tmp2, k2A.p, k2B.p, lrA.p, dPairRow.p, (size_t)nP, 0u, endBit2, s));
+    dPairCode.alloc((size_t)nP);
+    hipLaunchKernelGGL(k_sym_codes, dim3(grid_of(nP)), dim3(256), 0, s, nP, k2B.p, dPairCode.p);
+    RP(hipGetLastError());
+    MFH_HIP(hipStreamSynchronize(s));
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // FEM mesh topology on the device: P2 edge-node numbering in first-encounter order (FEMMesh.inl:22-36)
 // and the unmatched half-faces / half-edges that form the boundary (TetMesh.inl:36-79,
 // TriMesh.inl:60-100), by radix sorts instead of the host's hash table + std::sort.

@@ -733,3 +733,67 @@ def test_config3_full_size_properties():
     assert np.abs(reaction - np.array([0.0, 1.0, 0.0])).max() < 1e-6   # clamped face carries the whole load
     assert abs(uh.ravel() @ Ku - f @ uh.ravel()) < 1e-6 * abs(f @ uh.ravel())
     assert uh[:, 1].min() < -0.03 and np.abs(uh[fixed.reshape(-1, 3).any(axis=1)]).max() == 0.0
+
+
+@pytest.mark.parametrize("dim,deg", [(3, 2), (3, 1), (2, 2), (2, 1)])
+@pytest.mark.parametrize("mat", ["iso", "ortho_field"])
+def test_matrix_free_operator_equals_assembled(dim, deg, mat):
+    """k_mf_forces + k_mf_rows (and the per-pair variant k_spmv_mf) apply the same operator as the assembled K:
+    rel. difference <= 1e-13 on perturbed meshes, with a periodic DoF map, and inside PCG."""
+    if dim == 3:
+        V, T = grid.grid_tet_mesh(5, 4, 3)
+    else:
+        V, T = grid.grid_tri_mesh(7, 5)
+    rng = np.random.default_rng(4)
+    Vp = V + 0.04 * rng.standard_normal(V.shape)
+    nE = len(T)
+    for periodic in (False, True):
+        c = _ctx()
+        c.mesh_build(T, V if periodic else Vp, deg)
+        if mat == "iso":
+            c.material_isotropic(200.0, 0.35)
+        elif dim == 3:
+            c.material_ortho_field(np.column_stack([rng.uniform(100, 300, (nE, 3)), rng.uniform(0.2, 0.35, (nE, 3)), rng.uniform(40, 120, (nE, 3))]))
+        else:
+            c.material_ortho_field(np.column_stack([rng.uniform(100, 300, (nE, 2)), rng.uniform(0.2, 0.35, nE), rng.uniform(40, 120, nE)]))
+        if periodic:
+            c.apply_periodic_conditions()
+        c.assemble()
+        x = rng.standard_normal(dim * c.n_dof)
+        c.set_option("matrix_free", 0)
+        y0 = c.apply_K(x)
+        c.set_option("matrix_free", 1)
+        for mode in (2, 1):
+            c.set_option("matrix_free_mode", mode)
+            assert np.abs(c.apply_K(x) - y0).max() < 1e-13 * np.abs(y0).max(), (periodic, mode)
+        c.close()
+    # inside PCG: identical iteration counts and solutions (Dirichlet face, traction opposite)
+    sols = []
+    for mf in (0, 1):
+        c = _ctx()
+        c.mesh_build(T, Vp, deg)
+        c.material_isotropic(200.0, 0.35)
+        lo, hi = Vp.min(axis=0), Vp.max(axis=0)
+        big = 1e9
+        c.bc_dirichlet_box([lo[0] - big] + [-big] * (dim - 1), [lo[0] + 0.3] + [big] * (dim - 1), [0.0] * dim)
+        c.bc_neumann_box([hi[0] - 0.3] + [-big] * (dim - 1), [hi[0] + big] + [big] * (dim - 1), [0.0, -1.0, 0.0][:dim])
+        c.set_option("matrix_free", mf)
+        u = c.sim_solve(rtol=1e-10)
+        sols.append((u, c.last_info["iterations"]))
+        c.close()
+    assert abs(sols[0][1] - sols[1][1]) <= 1
+    assert np.linalg.norm(sols[0][0] - sols[1][0]) < 1e-8 * np.linalg.norm(sols[0][0])
+
+
+def test_matrix_free_is_the_default_for_quadratic_elasticity():
+    V, T = grid.grid_tet_mesh(4, 3, 3)
+    c = _ctx()
+    c.mesh_build(T, V, 2)
+    c.material_isotropic(200.0, 0.35)
+    c.assemble()
+    x = np.random.default_rng(0).standard_normal(3 * c.n_node)
+    y_auto = c.apply_K(x)
+    c.set_option("matrix_free", 0)
+    y_asm = c.apply_K(x)
+    assert not np.array_equal(y_auto, y_asm)                       # different summation order ...
+    assert np.abs(y_auto - y_asm).max() < 1e-13 * np.abs(y_asm).max()   # ... same operator
