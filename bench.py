@@ -175,7 +175,8 @@ def run_single(args):
                                            achieved=mf_bytes / mf_ms / 1e6, frac=mf_bytes / mf_ms / 1e6 / HBM_PEAK_GBS, unit="GB/s",
                                            note="same operator as the assembled K to rounding; trades 72 B/block of matrix traffic for FP64 flops"),
                           max_abs_u=float(np.abs(u).max()),
-                          roofline=dict(bound="hbm", kernel="k_spmv", achieved=sp_bytes / sp_ms / 1e6, peak=HBM_PEAK_GBS,
+                          roofline=dict(bound="hbm", kernel="k_spmv", note="assembled block-CSR SpMV (the PCG operator for P1; P2 solves use the matrix-free operator below)",
+                                        achieved=sp_bytes / sp_ms / 1e6, peak=HBM_PEAK_GBS,
                                         unit="GB/s", frac=sp_bytes / sp_ms / 1e6 / HBM_PEAK_GBS, kernel_ms=sp_ms,
                                         traffic=None if stb is None else stb / sp_ms / 1e6, traffic_bytes_per_launch=stb,
                                         traffic_source=stsrc,

@@ -66,6 +66,7 @@ struct mfh_ctx {
     DBuf<uint32_t> dMfPairCode;
     DBuf<uint16_t> dMfPairRow;
     DBuf<double> dMfSig;              // two-pass operator: per-element nodal forces
+    int mfChunkRows = 256, mfChunkPairs = 2048;   // options "mf_chunk_rows" / "mf_chunk_pairs"
     int mfMode = 2;                   // option "matrix_free_mode": 2 = two-pass (stress + rows), 1 = per-pair block evaluation
 
     // ---- numeric
@@ -396,7 +397,8 @@ void ensure_mf(mfh_ctx *c) {
     if (c->mfValid) return;
     require(c->haveMesh && !c->hostOnly, MFH_ERR_STATE, "the matrix-free operator needs a mesh on a device");
     ensure_symbolic(c, false);   // row ownership (nRows) and the DoF map on the device
-    build_mf_lists_device(c->mesh, c->dElemNodes.p, device_dof_map(c), c->sym.nRows, c->stream, c->mf, c->dMfPairCode, c->dMfPairRow);
+    build_mf_lists_device(c->mesh, c->dElemNodes.p, device_dof_map(c), c->sym.nRows, c->stream, c->mf, c->dMfPairCode, c->dMfPairRow,
+                          c->mfChunkRows, c->mfChunkPairs);
     c->dMfChunkRow.upload(c->mf.chunkRow, c->stream);
     c->dMfPairPtr.upload(c->mf.pairPtr, c->stream);
     c->dMfSig.alloc((size_t)c->mesh.npe * c->mesh.dim * (size_t)c->mesh.nElem);   // nodal forces, element-major
@@ -2085,6 +2087,8 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }
     else if (k2 == "pcg_graph") c->useGraph = value != 0;
     else if (k2 == "matrix_free_mode") c->mfMode = (int)value;
+    else if (k2 == "mf_chunk_rows") { c->mfChunkRows = std::max(16, std::min(4096, (int)value)); c->mfValid = false; }
+    else if (k2 == "mf_chunk_pairs") { c->mfChunkPairs = std::max(256, (int)value); c->mfValid = false; }
     else if (k2 == "matrix_free") c->matrixFree = value < 0 ? -1 : (value != 0 ? 1 : 0);   // K x without reading the assembled K (k_spmv_mf)
     else if (k2 == "tl_probe") { c->tlProbe = value != 0; c->tl.valid = false; }
     else if (k2 == "tl_host_inverse") { c->tlHostInverse = value != 0; c->tl.valid = false; }

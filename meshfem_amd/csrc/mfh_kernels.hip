@@ -861,14 +861,30 @@ __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__r
         for (int t = threadIdx.x; t < nr; t += 256) mfacc[t] = 0.0;
         __syncthreads();
         const int64_t kb = a.pairPtr[chunk], ke = a.pairPtr[chunk + 1];
-        for (int64_t k = kb + threadIdx.x; k < ke; k += 256) {
-            const int64_t code = a.pairCode[k];
-            const int lr = a.pairRow[k];
-            double out[DIM];
+        // U independent pairs per lane and trip: their list and force loads are all in flight together
+        constexpr int U = 2;
+        for (int64_t k0 = kb + threadIdx.x; k0 < ke; k0 += 256 * U) {
+            int64_t code[U];
+            int lr[U];
+            bool ok[U];
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) out[c] = fbuf[code * DIM + c];
+            for (int u = 0; u < U; ++u) {
+                const int64_t kk = k0 + (int64_t)u * 256;
+                ok[u] = kk < ke;
+                code[u] = ok[u] ? a.pairCode[kk] : a.pairCode[kb];
+                lr[u] = ok[u] ? (int)a.pairRow[kk] : 0;
+            }
+            double out[U][DIM];
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) unsafeAtomicAdd(&mfacc[lr * DIM + c], out[c]);
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) out[u][c] = fbuf[code[u] * DIM + c];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!ok[u]) continue;
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) unsafeAtomicAdd(&mfacc[lr[u] * DIM + c], out[u][c]);
+            }
         }
         __syncthreads();
         for (int idx = threadIdx.x; idx < nr; idx += 256) {

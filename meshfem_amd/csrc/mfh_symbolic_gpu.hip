@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(256) k_mf_key2(int64_t n, const uint32_t *__re
 } // namespace
 
 void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nRows, hipStream_t s,
-                           MfLists &L, DBuf<uint32_t> &dPairCode, DBuf<uint16_t> &dPairRow) {
+                           MfLists &L, DBuf<uint32_t> &dPairCode, DBuf<uint16_t> &dPairRow, int maxRowsCap, int maxPairs) {
     const int64_t N = m.nElem * m.npe;
     if ((double)N >= 4294967295.0) throw Error(MFH_ERR_UNSUPPORTED, "mesh too large for 32-bit pair codes");
     DBuf<uint32_t> keyA, keyB, valA, valB;
@@ -263,7 +263,6 @@ void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const i
     const int64_t nP = hRowPtr[nRows];
     if (nP == 0) throw Error(MFH_ERR_INVALID, "no element touches an owned row");
     // ---- chunks: <= 256 rows and <= 2048 pairs (a single row may exceed the pair budget: it then forms its own chunk)
-    const int maxRowsCap = 256, maxPairs = 2048;
     L = MfLists();
     L.chunkRow.push_back(0);
     int64_t r = 0;
