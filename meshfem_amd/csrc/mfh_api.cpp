@@ -63,11 +63,12 @@ struct mfh_ctx {
     }
     DBuf<int32_t> dMfChunkRow;
     DBuf<int64_t> dMfPairPtr;
-    DBuf<uint32_t> dMfPairCode;
+    DBuf<uint32_t> dMfPairCode, dMfPairPos;
     DBuf<uint16_t> dMfPairRow;
     DBuf<double> dMfSig;              // two-pass operator: per-element nodal forces
     int mfChunkRows = 256, mfChunkPairs = 2048;   // options "mf_chunk_rows" / "mf_chunk_pairs"
-    int mfMode = 2;                   // option "matrix_free_mode": 2 = two-pass (stress + rows), 1 = per-pair block evaluation
+    int mfMode = 3;                   // option "matrix_free_mode": 3 = two-pass, forces in list order (default); 2 = two-pass, forces
+                                      // element-major; 1 = per-pair block evaluation (k_spmv_mf)
 
     // ---- numeric
     DBuf<double> dVals;
@@ -398,7 +399,7 @@ void ensure_mf(mfh_ctx *c) {
     require(c->haveMesh && !c->hostOnly, MFH_ERR_STATE, "the matrix-free operator needs a mesh on a device");
     ensure_symbolic(c, false);   // row ownership (nRows) and the DoF map on the device
     build_mf_lists_device(c->mesh, c->dElemNodes.p, device_dof_map(c), c->sym.nRows, c->stream, c->mf, c->dMfPairCode, c->dMfPairRow,
-                          c->mfChunkRows, c->mfChunkPairs);
+                          c->dMfPairPos, c->mfChunkRows, c->mfChunkPairs);
     c->dMfChunkRow.upload(c->mf.chunkRow, c->stream);
     c->dMfPairPtr.upload(c->mf.pairPtr, c->stream);
     c->dMfSig.alloc((size_t)c->mesh.npe * c->mesh.dim * (size_t)c->mesh.nElem);   // nodal forces, element-major
@@ -410,7 +411,7 @@ k::SpmvMfArgs spmv_mf_args(mfh_ctx *c, bool masked) {
     k::SpmvMfArgs a{};
     a.dim = m.dim; a.deg = m.deg; a.npe = m.npe; a.mat = c->asmMat();
     a.nChunk = (int64_t)c->mf.chunkRow.size() - 1; a.chunkRow = c->dMfChunkRow.p; a.pairPtr = c->dMfPairPtr.p;
-    a.pairCode = c->dMfPairCode.p; a.pairRow = c->dMfPairRow.p; a.elemNodes = c->dElemNodes.p; a.dofForNode = device_dof_map(c);
+    a.pairCode = c->dMfPairCode.p; a.pairRow = c->dMfPairRow.p; a.pairPos = c->mfMode == 3 ? c->dMfPairPos.p : nullptr; a.elemNodes = c->dElemNodes.p; a.dofForNode = device_dof_map(c);
     a.geo = c->dGeo.p; a.geoStride = c->geoStride; a.pairTable = c->dPairTable.p; a.massTable = c->dMassTable.p;
     for (int k2 = 0; k2 < 6; ++k2) a.pairConst[k2] = c->tables.pairConst[k2];
     a.maxRows = c->mf.maxRows;
@@ -426,7 +427,7 @@ void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double 
     if (c->use_mf()) {
         ensure_geometry(c);
         ensure_mf(c);
-        if (c->mfMode == 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
+        if (c->mfMode >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
         else k::launch_spmv_mf(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
     } else
         k::launch_spmv(spmv_args(c, masked), x, y, dotOut, c->stream);
@@ -703,7 +704,7 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
         bool done = false;
         int lastChecked = 0;
         auto enqueue = [&](int itLocal) {   // one PCG iteration; `itLocal` is relative to the iteration base stop[3]
-            if (useMF && c->mfMode == 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
+            if (useMF && c->mfMode >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
             else if (useMF) k::launch_spmv_mf(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
             else k::launch_pcg_spmv(sa, c->wp.p, c->wAp.p, c->scal.p, itLocal, c->stop.p, s);
             if (useTL) {

@@ -171,7 +171,8 @@ struct MfLists {
     int64_t nPairs = 0;
 };
 void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nRows, hipStream_t s,
-                           MfLists &L, DBuf<uint32_t> &dPairCode, DBuf<uint16_t> &dPairRow, int maxRowsCap = 256, int maxPairs = 2048);
+                           MfLists &L, DBuf<uint32_t> &dPairCode, DBuf<uint16_t> &dPairRow, DBuf<uint32_t> &dPairPos, int maxRowsCap = 256,
+                           int maxPairs = 2048);
 void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nDoF, int64_t nOwnedDoF,
                            int chunkSlots, bool wantScatter, hipStream_t s, Symbolic &S, DBuf<int32_t> &dRowPtr, DBuf<int32_t> &dColIdx,
                            DBuf<uint32_t> &dContribCode, DBuf<uint16_t> &dContribSlot, DBuf<int32_t> &dScatter);
@@ -273,6 +274,7 @@ struct SpmvMfArgs {
     const int64_t *pairPtr;             // nChunk+1: first pair of every chunk
     const uint32_t *pairCode;           // e * npe + i
     const uint16_t *pairRow;            // row - chunkRow[chunk]
+    const uint32_t *pairPos;            // inverse of pairCode: list position of pair e*npe+i (0xffffffff: not owned); null = element-major forces
     const int32_t *elemNodes;
     const int32_t *dofForNode;          // may be null
     const double *geo;

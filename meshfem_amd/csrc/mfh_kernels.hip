@@ -827,6 +827,17 @@ __global__ void __launch_bounds__(256) k_mf_forces(SpmvMfArgs a, const double *_
                 symv(T2, gl[tI], f[NV + m]);
             }
         }
+        if (a.pairPos) {
+            // list order: the pair's force goes where the rows pass will stream it
+#pragma unroll
+            for (int j = 0; j < NPE; ++j) {
+                const uint32_t pp = a.pairPos[e * NPE + j];
+                if (pp == 0xffffffffu) continue;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) fbuf[(int64_t)pp * DIM + d] = f[j][d];
+            }
+            continue;
+        }
         // element-major AoS: the (element, node) pair with code e*NPE + i owns fbuf[code*DIM .. +DIM)
         double *o = fbuf + e * (NPE * DIM);
         if ((NPE * DIM) % 2 == 0) {
@@ -871,7 +882,7 @@ __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__r
             for (int u = 0; u < U; ++u) {
                 const int64_t kk = k0 + (int64_t)u * 256;
                 ok[u] = kk < ke;
-                code[u] = ok[u] ? a.pairCode[kk] : a.pairCode[kb];
+                code[u] = a.pairPos ? (ok[u] ? kk : kb) : (int64_t)(ok[u] ? a.pairCode[kk] : a.pairCode[kb]);
                 lr[u] = ok[u] ? (int)a.pairRow[kk] : 0;
             }
             double out[U][DIM];

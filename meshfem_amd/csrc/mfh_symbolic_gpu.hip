@@ -234,10 +234,15 @@ __global__ void __launch_bounds__(256) k_mf_key2(int64_t n, const uint32_t *__re
         lrow[k] = (uint16_t)(row - chunkFirstRow[ch]);
     }
 }
+// pos[code] = position of the (element, node) pair in the row-chunk-ordered list (0xffffffff: row not owned)
+__global__ void __launch_bounds__(256) k_mf_pos(int64_t n, const uint32_t *__restrict__ code, uint32_t *__restrict__ pos) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) pos[code[k]] = (uint32_t)k;
+}
 } // namespace
 
 void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nRows, hipStream_t s,
-                           MfLists &L, DBuf<uint32_t> &dPairCode, DBuf<uint16_t> &dPairRow, int maxRowsCap, int maxPairs) {
+                           MfLists &L, DBuf<uint32_t> &dPairCode, DBuf<uint16_t> &dPairRow, DBuf<uint32_t> &dPairPos, int maxRowsCap,
+                           int maxPairs) {
     const int64_t N = m.nElem * m.npe;
     if ((double)N >= 4294967295.0) throw Error(MFH_ERR_UNSUPPORTED, "mesh too large for 32-bit pair codes");
     DBuf<uint32_t> keyA, keyB, valA, valB;
@@ -301,6 +306,10 @@ void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const i
     RP(rocprim::radix_sort_pairs(tmp.p, tmp2, k2A.p, k2B.p, lrA.p, dPairRow.p, (size_t)nP, 0u, endBit2, s));
     dPairCode.alloc((size_t)nP);
     hipLaunchKernelGGL(k_sym_codes, dim3(grid_of(nP)), dim3(256), 0, s, nP, k2B.p, dPairCode.p);
+    RP(hipGetLastError());
+    dPairPos.alloc((size_t)N);
+    MFH_HIP(hipMemsetAsync(dPairPos.p, 0xff, (size_t)N * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_mf_pos, dim3(grid_of(nP)), dim3(256), 0, s, nP, dPairCode.p, dPairPos.p);
     RP(hipGetLastError());
     MFH_HIP(hipStreamSynchronize(s));
 }
