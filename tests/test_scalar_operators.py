@@ -111,6 +111,9 @@ def test_gpu_scalar_operators_match_oracle(dim, deg):
         # SpMV
         x = np.random.default_rng(1).standard_normal(n)
         assert np.abs(c.apply_K(x) - A_ref @ x).max() < 1e-12 * np.abs(A_ref @ x).max()
+        c.set_option("matrix_free", 1)                      # per-pair matrix-free variant (k_spmv_mf) on 1x1 blocks
+        assert np.abs(c.apply_K(x) - A_ref @ x).max() < 1e-12 * np.abs(A_ref @ x).max()
+        c.set_option("matrix_free", -1)
     # the elasticity operator still works on the same context afterwards (shared pattern)
     c.set_operator(M.OP_ELASTICITY)
     c.material_isotropic(200.0, 0.35)
