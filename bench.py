@@ -200,7 +200,8 @@ def run_single(args):
     if not args.no_orderings:
         # the same mesh with shuffled / space-filling-curve numbering (gather locality)
         c.close()
-        out["variants"]["orderings"] = {"generator": dict(assembly_kernel_ms=k_ms, spmv_kernel_ms=out.get("pcg", {}).get("roofline", {}).get("kernel_ms"))}
+        out["variants"]["orderings"] = {"generator": dict(assembly_kernel_ms=k_ms, spmv_kernel_ms=out.get("pcg", {}).get("roofline", {}).get("kernel_ms"),
+                                                          matrix_free_kernels_ms=out.get("pcg", {}).get("matrix_free", {}).get("kernels_ms"))}
         for mode in ("morton", "shuffle"):
             try:
                 V2, T2 = grid.reorder_mesh(V, T, mode)
@@ -208,8 +209,11 @@ def run_single(args):
                 c2.mesh_build(T2, V2, deg)
                 c2.material_isotropic(200.0, 0.35)
                 c2.assemble()
-                out["variants"]["orderings"][mode] = dict(assembly_kernel_ms=c2.time_assembly_kernel(M.ASSEMBLE_GATHER, 5),
-                                                          spmv_kernel_ms=c2.time_spmv_kernel(10))
+                ak = c2.time_assembly_kernel(M.ASSEMBLE_GATHER, 5)
+                c2.set_option("matrix_free", 0)
+                sk = c2.time_spmv_kernel(10)
+                c2.set_option("matrix_free", 1)
+                out["variants"]["orderings"][mode] = dict(assembly_kernel_ms=ak, spmv_kernel_ms=sk, matrix_free_kernels_ms=c2.time_spmv_kernel(10))
                 c2.close()
                 del V2, T2
             except M.MeshFEMHipError as e:
