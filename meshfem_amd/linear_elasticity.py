@@ -93,6 +93,17 @@ class Simulator:
     def averageStressField(self, u_nodes):                              # :539-549
         return self.ctx.average_stress(u_nodes)
 
+    def benchmarkReport(self):
+        """Timings under the reference's timer-section names (GlobalBenchmark.hh:14-34; sections of
+        LinearElasticity.hh:1206,1394-1399,482-485 and SparseMatrices.hh:283): milliseconds of the last operations.
+        "Compress Matrix" is the once-per-mesh symbolic phase here (sumRepeated's sort/merge hoisted out of the
+        numeric assembly); the CHOLMOD sections have no counterpart (PCG)."""
+        t = self.ctx.timing()
+        info = getattr(self, "info", None) or {}
+        return {"Assemble System": t["geometry_ms"] + t["assemble_ms"], "Compress Matrix": t["symbolic_ms"],
+                "Set System": t["upload_ms"], "Fix Variables": info.get("setup_ms", 0.0),
+                "Elasticity Solve": info.get("solve_ms", 0.0), "PCG iterations": info.get("iterations", 0)}
+
     def assembleStiffnessMatrix(self):
         """m_assembleStiffnessMatrix (:1408-1466) + sumRepeated: upper triplets (i, j, v)."""
         self.ctx.assemble()

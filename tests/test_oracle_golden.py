@@ -302,3 +302,28 @@ def test_material_json_roundtrip_reference_samples(kind):
             assert np.abs(D - O.ElasticityTensor.isotropic(dim, 200.0, 0.3).D).max() < 1e-12
         if kind == "orthotropic" and dim == 2:
             assert np.abs(D - O.ElasticityTensor.orthotropic2d(2.933545, 2.933545, 0.27186, 0.87212).D).max() < 1e-12
+
+
+# ---- tests/test_interpolant.cc:28-66: a degree-Deg interpolant reproduces every monomial of degree <= Deg on all of
+# R^K (20000 random points in the reference, 2000 here), and Interpolant::integrate equals Gauss quadrature
+@pytest.mark.parametrize("K", [1, 2, 3])
+@pytest.mark.parametrize("deg", [1, 2])
+def test_interpolant_reproduces_polynomials(K, deg):
+    import itertools
+    rng = np.random.default_rng(0)
+    # nodal positions in barycentric coordinates: vertices, then edge midpoints (Simplex.hh:30-47)
+    nodes = [np.eye(K + 1)[v] for v in range(K + 1)]
+    if deg == 2:
+        nodes += [0.5 * (np.eye(K + 1)[O.EDGE_START[e]] + np.eye(K + 1)[O.EDGE_END[e]]) for e in range(O.num_edges(K))]
+    for d in range(deg + 1):
+        for expo in itertools.product(range(d + 1), repeat=K):
+            if sum(expo) != d:
+                continue
+            f = lambda lam: float(np.prod([lam[c] ** expo[c] for c in range(K)]))      # monomial in the first K barycentric coords
+            nodal = np.array([f(x) for x in nodes])
+            for _ in range(2000):
+                lam = np.empty(K + 1)
+                lam[:K] = rng.random(K)                                             # not restricted to the simplex
+                lam[K] = 1.0 - lam[:K].sum()
+                assert abs(O.eval_interpolant(K, deg, nodal, lam) - f(lam)) <= 1e-13
+            assert abs(O.interpolant_integrate(K, deg, nodal, 1.0) - O.integrate(K, deg, f, 1.0)) <= 1e-15
