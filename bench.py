@@ -161,6 +161,9 @@ def run_single(args):
         # compulsory bytes of the matrix-free operator: element record + connectivity + nodal forces written and read
         # back + pair lists, per element; x gather + y + x (dot) per node
         mf_bytes = nE * (128 + 4 * npe + 2 * 24 * npe + 6 * npe) + c.n_dof * 3 * 24
+        t1, _ = pmc_traffic("k_mf_forces<3, 2, 0>", n, deg)
+        t2, _ = pmc_traffic("k_mf_rows<3, false>", n, deg)
+        mf_traffic = None if t1 is None or t2 is None else t1 + t2
         sp_bytes = nnzb * 76 + nr * 3 * 16 + nr * 4
         it_bytes = sp_bytes + ndof * 112
         stb, stsrc = pmc_traffic("k_spmv<3, false>", n, deg)
@@ -172,6 +175,7 @@ def run_single(args):
                           preconditioner="3x3 block-Jacobi (north_star baseline preconditioner)", wall_s=time.time() - t0,
                           operator="matrix-free (k_mf_forces + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
                           matrix_free=dict(kernels_ms=mf_ms, speedup_vs_assembled_spmv=sp_ms / mf_ms, bytes_per_application=mf_bytes,
+                                           traffic_bytes_per_application=mf_traffic, traffic=None if mf_traffic is None else mf_traffic / mf_ms / 1e6,
                                            achieved=mf_bytes / mf_ms / 1e6, frac=mf_bytes / mf_ms / 1e6 / HBM_PEAK_GBS, unit="GB/s",
                                            note="same operator as the assembled K to rounding; trades 72 B/block of matrix traffic for FP64 flops"),
                           max_abs_u=float(np.abs(u).max()),

@@ -1,21 +1,25 @@
-"""Workload for the rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE): a few launches of the
-assembly and SpMV kernels on a mesh whose K (4.3 GB at 40^3) exceeds the 256 MiB Infinity Cache,
-plus a calibration launch with a known byte count in the SAME 8-byte-per-lane access pattern
+"""Workload for the rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, one counter per run): a few launches of the
+assembly kernel, the assembled SpMV and the matrix-free operator on a mesh whose K exceeds the 256 MiB Infinity
+Cache, plus a calibration launch with a known byte count in the SAME 8-byte-per-lane access pattern
 (k_axpby over n doubles: reads 8n bytes, writes 8n bytes)."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import meshfem_amd as M
 from meshfem_amd import grid
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
 c = M.Context(0)
 c.mesh_build(T, V, 2)
 c.material_isotropic(200, 0.35)
 c.symbolic(False)
 ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, 3)
+c.set_option("matrix_free", 0)
 sp = c.time_spmv_kernel(3)          # launches k_axpby(n=3*nNode, b=0) once, then 1+3 k_spmv
+c.set_option("matrix_free", 1)
+mf = c.time_spmv_kernel(3)          # k_axpby again, then 1+3 x (k_mf_forces, k_mf_rows)
 nr, nc, nnzb = c.matrix_info()
-print(json.dumps(dict(n=n, elems=len(T), nnzb=nnzb, rows=nr, asm_ms=ms, spmv_ms=sp,
-                      calib_axpby_doubles=3 * nc, asm_alg_bytes=7736 * len(T), spmv_alg_bytes=nnzb * 76 + nr * 3 * 16 + nr * 4,
-                      asm_expected_hbm_bytes=nnzb * 72 + len(T) * 100 * 6 + len(T) * 128,
-                      )))
+nE, npe = len(T), 10
+print(json.dumps(dict(n=n, elems=nE, nnzb=nnzb, rows=nr, asm_ms=ms, spmv_ms=sp, mf_ms=mf,
+                      calib_axpby_doubles=3 * nc, asm_alg_bytes=7736 * nE, spmv_alg_bytes=nnzb * 76 + nr * 3 * 16 + nr * 4,
+                      asm_expected_hbm_bytes=nnzb * 72 + nE * 100 * 6 + nE * 128,
+                      mf_expected_hbm_bytes=nE * (128 + 4 * npe + 2 * 24 * npe + 6 * npe) + nr * 3 * 24)))
