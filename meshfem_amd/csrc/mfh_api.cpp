@@ -11,6 +11,8 @@ struct mfh_ctx {
     int device = 0;
     bool hostOnly = false;            // device == -1: mesh/symbolic host logic only (CPU tests)
     bool keepHostSymbolic = false;
+    int xcdSwizzle = 0;              // option "xcd_swizzle": XCD-contiguous work mapping in the chunked kernels (measured SLOWER
+                                     // than the round-robin default on MI355X: DESIGN.md section 4.8)
     int debugVariant = 0;            // option "debug_variant": timing experiments of the gather kernel
     bool alwaysReembed = false;      // option "reembed": every mfh_assemble re-runs the embedding kernel
     hipStream_t stream = nullptr;
@@ -361,6 +363,7 @@ k::AsmArgs asm_args(mfh_ctx *c) {
     a.nElem = m.nElem; a.scatterSlot = c->dScatter.p;
     a.vals = c->dVals.p; a.nnzb = c->sym.nnzb;
     a.debugVariant = c->debugVariant;
+    a.xcd = c->xcdSwizzle;
     return a;
 }
 
@@ -391,6 +394,7 @@ k::SpmvArgs spmv_args(mfh_ctx *c, bool masked) {
     a.dim = c->bs(); a.nChunk = (int64_t)c->sym.spmvChunkRow.size() - 1; a.chunkRow = c->dSpmvChunkRow.p; a.rowPtr = c->dRowPtr.p;
     a.colIdx = c->dColIdx.p; a.vals = c->dVals.p; a.chunkSlots = c->sym.spmvChunkSlots;
     a.fixedMask = masked ? c->dFixedMask.p : nullptr;
+    a.xcd = c->xcdSwizzle;
     return a;
 }
 
@@ -416,6 +420,7 @@ k::SpmvMfArgs spmv_mf_args(mfh_ctx *c, bool masked) {
     for (int k2 = 0; k2 < 6; ++k2) a.pairConst[k2] = c->tables.pairConst[k2];
     a.maxRows = c->mf.maxRows;
     a.variant = c->debugVariant;
+    a.xcd = c->xcdSwizzle;
     a.nElem = m.nElem;
     a.sig = c->dMfSig.p;
     a.fixedMask = masked ? c->dFixedMask.p : nullptr;
@@ -2086,6 +2091,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "agg_nodes") { c->aggNodes = (int)value; c->tl.valid = false; }
     else if (k2 == "topology_device") { c->topologyDevice = value != 0; }
     else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }
+    else if (k2 == "xcd_swizzle") c->xcdSwizzle = value != 0;
     else if (k2 == "pcg_graph") c->useGraph = value != 0;
     else if (k2 == "matrix_free_mode") c->mfMode = (int)value;
     else if (k2 == "mf_chunk_rows") { c->mfChunkRows = std::max(16, std::min(4096, (int)value)); c->mfValid = false; }

@@ -239,6 +239,7 @@ struct AsmArgs {
     double *vals;                       // tiled [ceil(nnzb/64)][dim*dim][64]
     int64_t nnzb;
     int debugVariant;                   // timing experiments only (0 = product kernel)
+    int xcd;                            // 1: XCD-contiguous chunk mapping (xcd_item)
 };
 
 void launch_geometry(int dim, int deg, int mat, int64_t nElem, const int32_t *elemNodes, int npe,
@@ -263,6 +264,7 @@ struct SpmvArgs {
     const double *vals;
     int chunkSlots;
     const uint8_t *fixedMask;           // per scalar row, may be null
+    int xcd;                            // 1: XCD-contiguous chunk ranges (xcd_span)
 };
 // Matrix-free operator: y = K x without reading the assembled K. One lane per (element, local node i) pair:
 // it evaluates the npe blocks K_e[i][j] in registers and applies them to the gathered x_j; pairs are grouped by
@@ -283,6 +285,7 @@ struct SpmvMfArgs {
     double pairConst[6];
     int maxRows;                        // rows per chunk (LDS accumulators)
     int variant;                        // timing experiments only (0 = product kernel)
+    int xcd;                            // 1: XCD-contiguous chunk / element-group ranges (xcd_span)
     int64_t nElem;
     double *sig;                        // two-pass operator: nodal forces of every element, [nElem][npe][dim]
     const uint8_t *fixedMask;           // per scalar row, may be null

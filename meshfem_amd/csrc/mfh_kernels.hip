@@ -41,6 +41,24 @@ DEV void block_sum(double (&v)[NV], double *lds /* >= 4*NV doubles */) {
     __syncthreads();
 }
 
+// XCD-aware work mapping. Workgroups are dispatched round-robin over the 8 XCDs (workgroup b runs on XCD b % 8) and
+// every XCD has its own L2, so neighbouring work items (row chunks, element groups: they share element records, gather
+// lists and x entries) should run on the SAME XCD: XCD x gets the x-th contiguous eighth of the n items.
+// One workgroup per item: a bijection of [0, n).
+DEV int64_t xcd_item(int64_t b, int64_t n) {
+    const int64_t q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
+    return x * q + (x < r ? x : r) + k;
+}
+// Persistent workgroups (gridDim.x a multiple of 8): the items of XCD x are [begin, end), visited with stride gridDim.x / 8
+// starting at begin + blockIdx.x / 8.
+DEV void xcd_span(int64_t n, int64_t &first, int64_t &end, int64_t &stride) {
+    const int64_t q = n >> 3, r = n & 7, x = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int64_t begin = x * q + (x < r ? x : r);
+    end = begin + q + (x < r ? 1 : 0);
+    first = begin + k;
+    stride = gridDim.x >> 3;
+}
+
 // Flattened symmetric index (Flattening.hh:47-60): 3D xx,yy,zz,yz,xz,xy ; 2D xx,yy,xy
 template <int DIM>
 DEV constexpr int flat_idx(int i, int j) { return i == j ? i : (DIM * (DIM + 1) / 2 - i - j); }
@@ -271,7 +289,7 @@ __global__ void __launch_bounds__(256) k_assemble_gather(AsmArgs a) {
     extern __shared__ __attribute__((aligned(16))) double acc[];   // [NB][chunkSlots + 2]
     const int CS = a.chunkSlots + 2;
     const PairConst pc{a.pairConst[0], a.pairConst[1], a.pairConst[2], a.pairConst[3], a.pairConst[4], a.pairConst[5]};
-    const int64_t chunk = blockIdx.x;
+    const int64_t chunk = a.xcd ? xcd_item(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
     const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
     const int s0 = a.rowPtr[r0];
     const int ns = a.rowPtr[r1] - s0;
@@ -556,7 +574,9 @@ __global__ void __launch_bounds__(256) k_spmv(SpmvArgs a, const double *__restri
         dotOut = scal + (int64_t)it * 4 + 1;
     }
     double dot = 0.0;
-    for (int64_t chunk = blockIdx.x; chunk < a.nChunk; chunk += gridDim.x) {
+    int64_t chunkFirst = blockIdx.x, chunkEnd = a.nChunk, chunkStride = gridDim.x;
+    if (a.xcd) xcd_span(a.nChunk, chunkFirst, chunkEnd, chunkStride);
+    for (int64_t chunk = chunkFirst; chunk < chunkEnd; chunk += chunkStride) {
         const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
         const int s0 = a.rowPtr[r0];
         const int ns = a.rowPtr[r1] - s0;
@@ -621,7 +641,9 @@ __global__ void __launch_bounds__(256) k_spmv_mf(SpmvMfArgs a, const double *__r
     const PairConst pc{a.pairConst[0], a.pairConst[1], a.pairConst[2], a.pairConst[3], a.pairConst[4], a.pairConst[5]};
     const double *tab = MAT == MAT_MASS ? a.massTable : a.pairTable;
     double dot = 0.0;
-    for (int64_t chunk = blockIdx.x; chunk < a.nChunk; chunk += gridDim.x) {
+    int64_t chunkFirst = blockIdx.x, chunkEnd = a.nChunk, chunkStride = gridDim.x;
+    if (a.xcd) xcd_span(a.nChunk, chunkFirst, chunkEnd, chunkStride);
+    for (int64_t chunk = chunkFirst; chunk < chunkEnd; chunk += chunkStride) {
         const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
         const int nr = (r1 - r0) * BS;
         for (int t = threadIdx.x; t < nr; t += 256) mfacc[t] = 0.0;
@@ -707,7 +729,12 @@ __global__ void __launch_bounds__(256) k_mf_forces(SpmvMfArgs a, const double *_
         if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
     }
     const int64_t nE = a.nElem;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nE; e += (int64_t)gridDim.x * 256) {
+    // element groups of 256: XCD-contiguous ranges of groups, see xcd_span
+    int64_t grpFirst = blockIdx.x, grpEnd = (nE + 255) / 256, grpStride = gridDim.x;
+    if (a.xcd) xcd_span(grpEnd, grpFirst, grpEnd, grpStride);
+    for (int64_t grp = grpFirst; grp < grpEnd; grp += grpStride) {
+        const int64_t e = grp * 256 + threadIdx.x;
+        if (e >= nE) continue;
         const double *g = a.geo + e * a.geoStride;
         const int32_t *en = a.elemNodes + e * NPE;
         double xl[NPE][DIM], gl[NV][DIM];
@@ -866,7 +893,9 @@ __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__r
         dotOut = scal + (int64_t)it * 4 + 1;
     }
     double dot = 0.0;
-    for (int64_t chunk = blockIdx.x; chunk < a.nChunk; chunk += gridDim.x) {
+    int64_t chunkFirst = blockIdx.x, chunkEnd = a.nChunk, chunkStride = gridDim.x;
+    if (a.xcd) xcd_span(a.nChunk, chunkFirst, chunkEnd, chunkStride);
+    for (int64_t chunk = chunkFirst; chunk < chunkEnd; chunk += chunkStride) {
         const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
         const int nr = (r1 - r0) * DIM;
         for (int t = threadIdx.x; t < nr; t += 256) mfacc[t] = 0.0;
@@ -1653,7 +1682,7 @@ void launch_average_gradient(const AsmArgs &a, const int32_t *elemNodes, const d
     CHECK_LAUNCH();
 }
 
-static int spmv_grid(const SpmvArgs &a) { return (int)std::max<int64_t>(1, std::min<int64_t>(a.nChunk, 256 * 8)); }
+static int spmv_grid(const SpmvArgs &a) { return 256 * 8; }   // persistent; a multiple of 8 (xcd_span)
 
 void launch_spmv(const SpmvArgs &a, const double *x, double *y, double *dotOut, hipStream_t s) {
     if (a.nChunk == 0) return;
@@ -1678,7 +1707,7 @@ void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dot
     if (a.nChunk == 0) return;
     const int bs = mat_is_scalar(a.mat) ? 1 : a.dim;
     const size_t lds = ((size_t)a.maxRows * bs + 16) * sizeof(double);
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(a.nChunk, 256 * 8));
+    const int grid = 256 * 8;
 #define CALL(D, G, M)                                                                                                          \
     if (pcg) hipLaunchKernelGGL((k_spmv_mf<D, G, M, true>), dim3(grid), dim3(256), lds, s, a, x, y, (double *)nullptr, scal, it, stopPtr); \
     else hipLaunchKernelGGL((k_spmv_mf<D, G, M, false>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr)
@@ -1703,13 +1732,13 @@ void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dot
 void launch_spmv_mf2(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
                      bool pcg, hipStream_t s) {
     if (a.nChunk == 0) return;
-    const int gridE = grid_for(a.nElem, 256 * 32);
+    const int gridE = 256 * 32;   // persistent over element groups; a multiple of 8 (xcd_span)
 #define CALL(D, G, M) hipLaunchKernelGGL((k_mf_forces<D, G, M>), dim3(gridE), dim3(256), 0, s, a, x, a.sig, pcg ? (const double *)scal : (const double *)nullptr, it, stopPtr)
     MFH_DISPATCH(a, CALL);
 #undef CALL
     CHECK_LAUNCH();
     const size_t lds = ((size_t)a.maxRows * a.dim + 16) * sizeof(double);
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>(a.nChunk, 256 * 8));
+    const int grid = 256 * 8;
 #define ROWS(D)                                                                                                                      \
     if (pcg) hipLaunchKernelGGL((k_mf_rows<D, true>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, (double *)nullptr, scal, it, stopPtr); \
     else hipLaunchKernelGGL((k_mf_rows<D, false>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr)
