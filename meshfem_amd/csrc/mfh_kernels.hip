@@ -1682,7 +1682,9 @@ void launch_average_gradient(const AsmArgs &a, const int32_t *elemNodes, const d
     CHECK_LAUNCH();
 }
 
-static int spmv_grid(const SpmvArgs &a) { return 256 * 8; }   // persistent; a multiple of 8 (xcd_span)
+// persistent workgroups; a multiple of 8 (xcd_span)
+static int persistent_grid(int64_t nItems, int cap) { return (int)std::max<int64_t>(8, std::min<int64_t>(cap, (nItems + 7) / 8 * 8)); }
+static int spmv_grid(const SpmvArgs &a) { return persistent_grid(a.nChunk, 256 * 8); }
 
 void launch_spmv(const SpmvArgs &a, const double *x, double *y, double *dotOut, hipStream_t s) {
     if (a.nChunk == 0) return;
@@ -1707,7 +1709,7 @@ void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dot
     if (a.nChunk == 0) return;
     const int bs = mat_is_scalar(a.mat) ? 1 : a.dim;
     const size_t lds = ((size_t)a.maxRows * bs + 16) * sizeof(double);
-    const int grid = 256 * 8;
+    const int grid = persistent_grid(a.nChunk, 256 * 8);
 #define CALL(D, G, M)                                                                                                          \
     if (pcg) hipLaunchKernelGGL((k_spmv_mf<D, G, M, true>), dim3(grid), dim3(256), lds, s, a, x, y, (double *)nullptr, scal, it, stopPtr); \
     else hipLaunchKernelGGL((k_spmv_mf<D, G, M, false>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr)
@@ -1732,13 +1734,13 @@ void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dot
 void launch_spmv_mf2(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
                      bool pcg, hipStream_t s) {
     if (a.nChunk == 0) return;
-    const int gridE = 256 * 32;   // persistent over element groups; a multiple of 8 (xcd_span)
+    const int gridE = persistent_grid((a.nElem + 255) / 256, 256 * 32);   // persistent over element groups
 #define CALL(D, G, M) hipLaunchKernelGGL((k_mf_forces<D, G, M>), dim3(gridE), dim3(256), 0, s, a, x, a.sig, pcg ? (const double *)scal : (const double *)nullptr, it, stopPtr)
     MFH_DISPATCH(a, CALL);
 #undef CALL
     CHECK_LAUNCH();
     const size_t lds = ((size_t)a.maxRows * a.dim + 16) * sizeof(double);
-    const int grid = 256 * 8;
+    const int grid = persistent_grid(a.nChunk, 256 * 8);
 #define ROWS(D)                                                                                                                      \
     if (pcg) hipLaunchKernelGGL((k_mf_rows<D, true>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, (double *)nullptr, scal, it, stopPtr); \
     else hipLaunchKernelGGL((k_mf_rows<D, false>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr)
