@@ -156,12 +156,14 @@ def run_single(args):
         sp_ms = c.time_spmv_kernel(20)           # assembled block-CSR SpMV (k_spmv)
         c.set_option("matrix_free", 1)
         mf_ms = c.time_spmv_kernel(20)           # matrix-free operator (k_mf_forces + k_mf_rows), the PCG default for P2
+        mf_info = c.matrix_free_info()
         c.set_option("matrix_free", -1)
         npe = 10 if deg == 2 else 4
-        # compulsory bytes of the matrix-free operator: element record + connectivity + nodal forces written and read
-        # back + pair lists, per element; x gather + y + x (dot) per node
-        mf_bytes = nE * (128 + 4 * npe + 2 * 24 * npe + 6 * npe) + c.n_dof * 3 * 24
-        t1, _ = pmc_traffic("k_mf_forces<3, 2, 0>", n, deg)
+        # compulsory bytes of the matrix-free operator (cluster variant): element record + connectivity + local row
+        # indices per element; x gather + y + x (dot) per node; interface partials written and read back + their lists
+        mf_bytes = (nE * (128 + 4 * npe + 2 * npe) + c.n_dof * 3 * 24 + mf_info["block_rows"] * 8
+                    + mf_info["interface_partials"] * (2 * 24 + 2))
+        t1, _ = pmc_traffic("k_mf_cluster<3, 2, 0, false>", n, deg)
         t2, _ = pmc_traffic("k_mf_rows<3, false>", n, deg)
         mf_traffic = None if t1 is None or t2 is None else t1 + t2
         sp_bytes = nnzb * 76 + nr * 3 * 16 + nr * 4
@@ -173,8 +175,8 @@ def run_single(args):
                           dof_per_s=ndof * info["iterations"] / (info["solve_ms"] * 1e-3),
                           ms_per_iteration=info["solve_ms"] / max(1, info["iterations"]),
                           preconditioner="3x3 block-Jacobi (north_star baseline preconditioner)", wall_s=time.time() - t0,
-                          operator="matrix-free (k_mf_forces + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
-                          matrix_free=dict(kernels_ms=mf_ms, speedup_vs_assembled_spmv=sp_ms / mf_ms, bytes_per_application=mf_bytes,
+                          operator="matrix-free (k_mf_cluster + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
+                          matrix_free=dict(kernels_ms=mf_ms, speedup_vs_assembled_spmv=sp_ms / mf_ms, bytes_per_application=mf_bytes, lists=mf_info,
                                            traffic_bytes_per_application=mf_traffic, traffic=None if mf_traffic is None else mf_traffic / mf_ms / 1e6,
                                            achieved=mf_bytes / mf_ms / 1e6, frac=mf_bytes / mf_ms / 1e6 / HBM_PEAK_GBS, unit="GB/s",
                                            note="same operator as the assembled K to rounding; trades 72 B/block of matrix traffic for FP64 flops"),

@@ -290,13 +290,18 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
 mfh_status mfh_time_assembly_kernel(mfh_ctx* ctx, int32_t mode, int32_t reps, double* avg_ms);
 /* the same for one application of the operator the PCG uses (see "matrix_free") on internal scratch vectors */
 mfh_status mfh_time_spmv_kernel(mfh_ctx* ctx, int32_t reps, double* avg_ms);
+/* matrix-free operator in use? (see option "matrix_free"); for the cluster variant (mode 4): number of element blocks,
+ * of (block, row) accumulators, of interface partial sums kept in HBM, and the largest block (LDS accumulators) */
+mfh_status mfh_matrix_free_info(mfh_ctx* ctx, int32_t* active, int32_t* mode, int64_t* nBlocks, int64_t* nBlockRows,
+                                int64_t* nInterface, int32_t* maxBlockRows);
 /* option knobs (string key, numeric value): "chunk_slots", "contrib_order" (0 rank-major, 1 element-major,
  * 2 slot-major), "check_every", "keep_host_symbolic", "agg_nodes" (target DoFs per aggregate of the two-level
  * preconditioner), "reembed" (1: every mfh_assemble re-runs the element-embedding kernel as well),
  * "matrix_free" (operator of mfh_solve / mfh_apply_K / mfh_dev_spmv: 0 = assembled block-CSR SpMV, 1 = matrix-free
  *   (k_mf_forces + k_mf_rows: element stresses recomputed, K not read), -1 = auto (default): matrix-free for quadratic
- *   elasticity, where it is 2.3-2.6x faster, assembled otherwise; both give K x up to rounding),
- * "matrix_free_mode" (3 default | 2 forces element-major | 1 per-pair block evaluation), "mf_chunk_rows", "mf_chunk_pairs",
+ *   elasticity, where it is 4-5x faster, assembled otherwise; both give K x up to rounding),
+ * "matrix_free_mode" (4 default: cluster variant, forces of 256 consecutive elements summed in LDS | 3 two-pass, forces in
+ *   list order | 2 two-pass, forces element-major | 1 per-pair block evaluation), "mf_chunk_rows", "mf_chunk_pairs",
  * "pcg_graph" (1 default: blocks of check_every PCG iterations are replayed from a hipGraph),
  * "symbolic_device", "topology_device", "tl_probe", "tl_host_inverse" (validation variants of setup phases) */
 mfh_status mfh_set_option(mfh_ctx* ctx, const char* key, double value);

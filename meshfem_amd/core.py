@@ -198,6 +198,13 @@ class Context:
         self._ck(self.lib.mfh_set_operator(self.h, int(op)))
         self.op = int(op)
 
+    def matrix_free_info(self):
+        a, mo, mb = C.c_int32(), C.c_int32(), C.c_int32()
+        nb, ne, ni = C.c_int64(), C.c_int64(), C.c_int64()
+        self._ck(self.lib.mfh_matrix_free_info(self.h, C.byref(a), C.byref(mo), C.byref(nb), C.byref(ne), C.byref(ni), C.byref(mb)))
+        return dict(active=bool(a.value), mode=mo.value, blocks=nb.value, block_rows=ne.value, interface_partials=ni.value,
+                    max_block_rows=mb.value)
+
     def average_gradient(self, u_nodes):
         u = as_f64(u_nodes)
         out = np.empty((self.n_elem, self.dim))

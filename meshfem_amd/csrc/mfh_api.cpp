@@ -67,10 +67,15 @@ struct mfh_ctx {
     DBuf<int64_t> dMfPairPtr;
     DBuf<uint32_t> dMfPairCode, dMfPairPos;
     DBuf<uint16_t> dMfPairRow;
+    MfClusterLists mfc;               // cluster variant (matrix_free_mode 4)
+    MfClusterDev mfcDev;
+    bool mfcValid = false;
+    int mfBlockElems = 0;             // option "mf_block_elems": elements per block of the cluster variant (0 = 256)
     DBuf<double> dMfSig;              // two-pass operator: per-element nodal forces
     int mfChunkRows = 256, mfChunkPairs = 2048;   // options "mf_chunk_rows" / "mf_chunk_pairs"
-    int mfMode = 3;                   // option "matrix_free_mode": 3 = two-pass, forces in list order (default); 2 = two-pass, forces
-                                      // element-major; 1 = per-pair block evaluation (k_spmv_mf)
+    int mfMode = 4;                   // option "matrix_free_mode": 4 = cluster variant (default: forces of 256 consecutive elements
+                                      // summed in LDS, interface partials only in HBM); 3 = two-pass, forces in list order;
+                                      // 2 = two-pass, forces element-major; 1 = per-pair block evaluation (k_spmv_mf)
 
     // ---- numeric
     DBuf<double> dVals;
@@ -187,6 +192,7 @@ void invalidate_matrix(mfh_ctx *c) {
 void invalidate_symbolic(mfh_ctx *c) {
     c->symValid = false;
     c->mfValid = false;
+    c->mfcValid = false;
     c->dofUploaded = false;
     invalidate_matrix(c);
 }
@@ -410,6 +416,40 @@ void ensure_mf(mfh_ctx *c) {
     c->mfValid = true;
 }
 
+void ensure_mf_cluster(mfh_ctx *c) {
+    if (c->mfcValid) return;
+    ensure_symbolic(c, false);
+    // block size: measured at config 3, 256 / 240 (hex-aligned) / 192 give 7.45 / 7.18 / 7.31 M interface partials and the
+    // same 0.69 ms -- the interface is set by the shape of a run of consecutive elements, not by its alignment
+    build_mf_cluster_lists_device(c->mesh, c->dElemNodes.p, device_dof_map(c), c->sym.nRows, c->stream, c->mfc, c->mfcDev,
+                                  c->mfBlockElems > 0 ? c->mfBlockElems : MF_BLOCK);
+    // LDS budget of k_mf_cluster: one accumulator per distinct row of a block
+    if ((size_t)c->mfc.maxLocal * c->mesh.dim * sizeof(double) > 60 * 1024) {
+        c->mfMode = 3;   // element order without locality: fall back to the two-pass operator
+        return;
+    }
+    c->mfcValid = true;
+}
+
+k::SpmvMfArgs spmv_mf_cluster_args(mfh_ctx *c, bool masked) {
+    const HostMesh &m = c->mesh;
+    k::SpmvMfArgs a{};
+    a.dim = m.dim; a.deg = m.deg; a.npe = m.npe; a.mat = c->asmMat();
+    a.elemNodes = c->dElemNodes.p; a.dofForNode = device_dof_map(c);
+    a.geo = c->dGeo.p; a.geoStride = c->geoStride; a.pairTable = c->dPairTable.p; a.massTable = c->dMassTable.p;
+    a.nElem = m.nElem;
+    a.fixedMask = masked ? c->dFixedMask.p : nullptr;
+    const auto &D = c->mfcDev;
+    a.clBlocks = c->mfc.nBlocks; a.clMaxLocal = c->mfc.maxLocal; a.clBlockElems = c->mfc.blockElems; a.clBlockPtr = D.blockPtr.p; a.clEntryRow = D.entryRow.p;
+    a.clEntryDest = D.entryDest.p; a.clLocalIdx = D.localIdx.p; a.clIfaceBuf = D.ifaceBuf.p; a.rowWrite = D.rowIsIface.p;
+    // second pass: k_mf_rows streaming the interface partials (pairPos != null selects the sequential read)
+    a.nChunk = c->mfc.nIface > 0 ? (int64_t)c->mfc.chunkRow.size() - 1 : 0;
+    a.chunkRow = D.chunkRow.p; a.pairPtr = D.pairPtr.p; a.pairRow = D.ifaceRow.p; a.pairCode = nullptr;
+    a.pairPos = reinterpret_cast<const uint32_t *>(D.ifaceRow.p);   // only tested against null
+    a.sig = D.ifaceBuf.p; a.maxRows = c->mfc.maxRows;
+    return a;
+}
+
 k::SpmvMfArgs spmv_mf_args(mfh_ctx *c, bool masked) {
     const HostMesh &m = c->mesh;
     k::SpmvMfArgs a{};
@@ -432,7 +472,9 @@ void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double 
     if (c->use_mf()) {
         ensure_geometry(c);
         ensure_mf(c);
-        if (c->mfMode >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
+        if (c->mfMode == 4 && c->op == MFH_OP_ELASTICITY) ensure_mf_cluster(c);
+        if (c->mfMode == 4 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf_cluster(spmv_mf_cluster_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
+        else if (c->mfMode >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
         else k::launch_spmv_mf(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
     } else
         k::launch_spmv(spmv_args(c, masked), x, y, dotOut, c->stream);
@@ -703,13 +745,17 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
         const k::SpmvArgs sa = spmv_args(c, !c->fixedVars.empty());
         const bool useMF = c->use_mf();
         if (useMF) ensure_mf(c);
-        const k::SpmvMfArgs mfa = useMF ? spmv_mf_args(c, !c->fixedVars.empty()) : k::SpmvMfArgs{};
+        if (useMF && c->mfMode == 4 && c->op == MFH_OP_ELASTICITY) ensure_mf_cluster(c);
+        const bool useCluster = useMF && c->mfMode == 4 && c->op == MFH_OP_ELASTICITY;
+        const k::SpmvMfArgs mfa = useCluster ? spmv_mf_cluster_args(c, !c->fixedVars.empty())
+                                             : (useMF ? spmv_mf_args(c, !c->fixedVars.empty()) : k::SpmvMfArgs{});
         std::vector<double> hs;
         int it = 0;
         bool done = false;
         int lastChecked = 0;
         auto enqueue = [&](int itLocal) {   // one PCG iteration; `itLocal` is relative to the iteration base stop[3]
-            if (useMF && c->mfMode >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
+            if (useCluster) k::launch_spmv_mf_cluster(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
+            else if (useMF && c->mfMode >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
             else if (useMF) k::launch_spmv_mf(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
             else k::launch_pcg_spmv(sa, c->wp.p, c->wAp.p, c->scal.p, itLocal, c->stop.p, s);
             if (useTL) {
@@ -1849,6 +1895,24 @@ mfh_status mfh_average_gradient(mfh_ctx *c, const double *uNodes, double *grad) 
     MFH_CATCH(c)
 }
 
+mfh_status mfh_matrix_free_info(mfh_ctx *c, int32_t *active, int32_t *mode, int64_t *nBlocks, int64_t *nBlockRows, int64_t *nInterface,
+                                int32_t *maxBlockRows) {
+    MFH_TRY(c)
+    require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    if (active) *active = c->use_mf() ? 1 : 0;
+    if (c->use_mf() && c->mfMode == 4 && c->op == MFH_OP_ELASTICITY) {
+        require_device(c);
+        MFH_HIP(hipSetDevice(c->device));
+        ensure_mf_cluster(c);
+    }
+    if (mode) *mode = c->mfMode;
+    if (nBlocks) *nBlocks = c->mfcValid ? c->mfc.nBlocks : 0;
+    if (nBlockRows) *nBlockRows = c->mfcValid ? c->mfc.nEntries : 0;
+    if (nInterface) *nInterface = c->mfcValid ? c->mfc.nIface : 0;
+    if (maxBlockRows) *maxBlockRows = c->mfcValid ? c->mfc.maxLocal : 0;
+    MFH_CATCH(c)
+}
+
 mfh_status mfh_average_strain(mfh_ctx *c, const double *uNodes, double *strain) {
     MFH_TRY(c)
     require(c && c->haveMesh && uNodes && strain, MFH_ERR_STATE, "no mesh set");
@@ -2094,6 +2158,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "xcd_swizzle") c->xcdSwizzle = value != 0;
     else if (k2 == "pcg_graph") c->useGraph = value != 0;
     else if (k2 == "matrix_free_mode") c->mfMode = (int)value;
+    else if (k2 == "mf_block_elems") { c->mfBlockElems = (int)value; c->mfcValid = false; }
     else if (k2 == "mf_chunk_rows") { c->mfChunkRows = std::max(16, std::min(4096, (int)value)); c->mfValid = false; }
     else if (k2 == "mf_chunk_pairs") { c->mfChunkPairs = std::max(256, (int)value); c->mfValid = false; }
     else if (k2 == "matrix_free") c->matrixFree = value < 0 ? -1 : (value != 0 ? 1 : 0);   // K x without reading the assembled K (k_spmv_mf)

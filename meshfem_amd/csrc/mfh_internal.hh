@@ -170,6 +170,32 @@ struct MfLists {
     int maxRows = 0;
     int64_t nPairs = 0;
 };
+// Cluster variant of the matrix-free operator: elements in blocks of MF_BLOCK consecutive elements; the nodal forces of
+// a block are summed in LDS. Rows whose elements all lie in one block are finished there; the others (interface rows)
+// leave one partial sum per (block, row) in a small buffer that a second pass sums.
+constexpr int MF_BLOCK = 256;
+struct MfClusterLists {
+    int64_t nBlocks = 0, nEntries = 0, nIface = 0;
+    int blockElems = MF_BLOCK;          // elements per block (<= MF_BLOCK threads)
+    int maxLocal = 0;                   // largest number of distinct rows of a block (LDS accumulators)
+    // second pass (interface partials in row order)
+    std::vector<int32_t> chunkRow;
+    std::vector<int64_t> pairPtr;
+    int maxRows = 0;
+};
+struct MfClusterDev {
+    DBuf<uint16_t> localIdx;            // [nElem*npe]: index of the pair's row among the block's rows
+    DBuf<int32_t> blockPtr;             // [nBlocks+1] into the entry arrays
+    DBuf<int32_t> entryRow;             // [nEntries] global row of the entry
+    DBuf<int32_t> entryDest;            // [nEntries] -1: finish here (write y), >= 0: slot in the interface buffer, -2: row not owned
+    DBuf<uint16_t> ifaceRow;            // [nIface] row - chunkRow[chunk] of every interface slot (row order)
+    DBuf<uint8_t> rowIsIface;           // [nRows]
+    DBuf<int32_t> chunkRow;
+    DBuf<int64_t> pairPtr;
+    DBuf<double> ifaceBuf;              // [nIface * dim]
+};
+void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nRows, hipStream_t s,
+                                   MfClusterLists &L, MfClusterDev &D, int blockElems = MF_BLOCK);
 void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nRows, hipStream_t s,
                            MfLists &L, DBuf<uint32_t> &dPairCode, DBuf<uint16_t> &dPairRow, DBuf<uint32_t> &dPairPos, int maxRowsCap = 256,
                            int maxPairs = 2048);
@@ -286,12 +312,21 @@ struct SpmvMfArgs {
     int maxRows;                        // rows per chunk (LDS accumulators)
     int variant;                        // timing experiments only (0 = product kernel)
     int xcd;                            // 1: XCD-contiguous chunk / element-group ranges (xcd_span)
+    // cluster variant (k_mf_cluster); rowWrite restricts the writes of k_mf_rows to the interface rows
+    int64_t clBlocks;
+    int clMaxLocal, clBlockElems;
+    const int32_t *clBlockPtr, *clEntryRow, *clEntryDest;
+    const uint16_t *clLocalIdx;
+    double *clIfaceBuf;
+    const uint8_t *rowWrite;
     int64_t nElem;
     double *sig;                        // two-pass operator: nodal forces of every element, [nElem][npe][dim]
     const uint8_t *fixedMask;           // per scalar row, may be null
 };
 void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
                     bool pcg, hipStream_t s);
+void launch_spmv_mf_cluster(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
+                            bool pcg, hipStream_t s);
 void launch_spmv_mf2(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
                      bool pcg, hipStream_t s);
 

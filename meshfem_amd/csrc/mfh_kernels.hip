@@ -718,12 +718,137 @@ template <int DIM> DEV constexpr int edge_between(int k, int q) {
     return 5;   // (1,3)
 }
 
+// nodal forces f_i = int sigma(u) grad phi_i of element e for the nodal vectors gathered from x
 template <int DIM, int DEG, int MAT>
-__global__ void __launch_bounds__(256) k_mf_forces(SpmvMfArgs a, const double *__restrict__ x, double *__restrict__ fbuf,
-                                                   const double *scal, int it, const double *stopPtr) {
+DEV void elem_forces(const SpmvMfArgs &a, int64_t e, const double *__restrict__ x,
+                     double (&f)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM]) {
     constexpr int NV = DIM + 1;
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
     constexpr int FL = DIM * (DIM + 1) / 2;
+    const double *g = a.geo + e * a.geoStride;
+    const int32_t *en = a.elemNodes + e * NPE;
+    double xl[NPE][DIM], gl[NV][DIM];
+#pragma unroll
+    for (int j = 0; j < NPE; ++j) {
+        int64_t col = en[j];
+        if (a.dofForNode) col = a.dofForNode[col];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) xl[j][d] = x[col * DIM + d];
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) gl[k][d] = g[k * DIM + d];
+    const double vol = g[12];
+    auto stress_of = [&](const double (&G)[DIM][DIM], double *out) {
+        double sd[FL];
+#pragma unroll
+        for (int p = 0; p < DIM; ++p)
+#pragma unroll
+            for (int q2 = p; q2 < DIM; ++q2)
+                sd[flat_idx<DIM>(p, q2)] = (p == q2) ? G[p][p] : (G[p][q2] + G[q2][p]);   // shear-doubled strain
+        elem_D_apply<DIM, MAT>(g, sd, out);
+    };
+    auto symv = [&](const double *T, const double *v, double *o) {   // o += T v  (T flat symmetric)
+#pragma unroll
+        for (int p = 0; p < DIM; ++p)
+#pragma unroll
+            for (int q2 = 0; q2 < DIM; ++q2) o[p] += T[flat_idx<DIM>(p, q2)] * v[q2];
+    };
+#pragma unroll
+    for (int j = 0; j < NPE; ++j)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) f[j][d] = 0.0;
+    if (DEG == 1) {
+        double G[DIM][DIM];
+#pragma unroll
+        for (int p = 0; p < DIM; ++p)
+#pragma unroll
+            for (int q2 = 0; q2 < DIM; ++q2) {
+                double v = 0;
+#pragma unroll
+                for (int j = 0; j < NV; ++j) v += xl[j][p] * gl[j][q2];
+                G[p][q2] = v;
+            }
+        double sg[FL];
+        stress_of(G, sg);
+#pragma unroll
+        for (int c = 0; c < FL; ++c) sg[c] *= vol;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) symv(sg, gl[j], f[j]);
+    } else {
+        constexpr double c0 = DIM == 3 ? 0.58541019662496845446 : 2.0 / 3.0;     // GaussQuadrature.hh:283-295 / :115-127
+        constexpr double c1 = DIM == 3 ? 0.13819660112501051518 : 1.0 / 6.0;
+        constexpr double b_ = 4 * c1 - 1, A_ = 4 * c0, B_ = 4 * c1, dAB = A_ - B_;   // a - b = A - B
+        constexpr double wq = 1.0 / NV;
+        double Gb[DIM][DIM];
+#pragma unroll
+        for (int p = 0; p < DIM; ++p)
+#pragma unroll
+            for (int q2 = 0; q2 < DIM; ++q2) Gb[p][q2] = 0.0;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            double base[DIM];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) {
+                double sum = 0;
+#pragma unroll
+                for (int o = 0; o < NV; ++o)
+                    if (o != k) sum += xl[NV + edge_between<DIM>(k, o)][d];
+                base[d] = b_ * xl[k][d] + B_ * sum;
+            }
+#pragma unroll
+            for (int p = 0; p < DIM; ++p)
+#pragma unroll
+                for (int q2 = 0; q2 < DIM; ++q2) Gb[p][q2] += base[p] * gl[k][q2];
+        }
+        double S[FL], R[NV][FL];
+#pragma unroll
+        for (int c = 0; c < FL; ++c) S[c] = 0.0;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            double G[DIM][DIM];
+#pragma unroll
+            for (int p = 0; p < DIM; ++p)
+#pragma unroll
+                for (int q2 = 0; q2 < DIM; ++q2) {
+                    double v = Gb[p][q2] + dAB * xl[q][p] * gl[q][q2];
+#pragma unroll
+                    for (int k = 0; k < NV; ++k)
+                        if (k != q) v += dAB * xl[NV + edge_between<DIM>(k, q)][p] * gl[k][q2];
+                    G[p][q2] = v;
+                }
+            double sg[FL];
+            stress_of(G, sg);
+#pragma unroll
+            for (int c = 0; c < FL; ++c) { S[c] += sg[c]; R[q][c] = vol * wq * dAB * sg[c]; }
+        }
+        // vertex k: f = (b S' + R_k) gl_k ;  edge (s,t): f = (B S' + R_t) gl_s + (B S' + R_s) gl_t
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            double T[FL];
+#pragma unroll
+            for (int c = 0; c < FL; ++c) T[c] = (vol * wq * b_) * S[c] + R[k][c];
+            symv(T, gl[k], f[k]);
+        }
+#pragma unroll
+        for (int c = 0; c < FL; ++c) S[c] *= vol * wq * B_;
+#pragma unroll
+        for (int m = 0; m < NPE - NV; ++m) {
+            const int sI = sup_s<DIM, DEG>(NV + m), tI = sup_t<DIM, DEG>(NV + m);
+            double T1[FL], T2[FL];
+#pragma unroll
+            for (int c = 0; c < FL; ++c) { T1[c] = S[c] + R[tI][c]; T2[c] = S[c] + R[sI][c]; }
+            symv(T1, gl[sI], f[NV + m]);
+            symv(T2, gl[tI], f[NV + m]);
+        }
+    }
+}
+
+template <int DIM, int DEG, int MAT>
+__global__ void __launch_bounds__(256) k_mf_forces(SpmvMfArgs a, const double *__restrict__ x, double *__restrict__ fbuf,
+                                                   const double *scal, int it, const double *stopPtr) {
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
     if (scal) {
         it += (int)stopPtr[3];
         if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
@@ -735,125 +860,8 @@ __global__ void __launch_bounds__(256) k_mf_forces(SpmvMfArgs a, const double *_
     for (int64_t grp = grpFirst; grp < grpEnd; grp += grpStride) {
         const int64_t e = grp * 256 + threadIdx.x;
         if (e >= nE) continue;
-        const double *g = a.geo + e * a.geoStride;
-        const int32_t *en = a.elemNodes + e * NPE;
-        double xl[NPE][DIM], gl[NV][DIM];
-#pragma unroll
-        for (int j = 0; j < NPE; ++j) {
-            int64_t col = en[j];
-            if (a.dofForNode) col = a.dofForNode[col];
-#pragma unroll
-            for (int d = 0; d < DIM; ++d) xl[j][d] = x[col * DIM + d];
-        }
-#pragma unroll
-        for (int k = 0; k < NV; ++k)
-#pragma unroll
-            for (int d = 0; d < DIM; ++d) gl[k][d] = g[k * DIM + d];
-        const double vol = g[12];
-        auto stress_of = [&](const double (&G)[DIM][DIM], double *out) {
-            double sd[FL];
-#pragma unroll
-            for (int p = 0; p < DIM; ++p)
-#pragma unroll
-                for (int q2 = p; q2 < DIM; ++q2)
-                    sd[flat_idx<DIM>(p, q2)] = (p == q2) ? G[p][p] : (G[p][q2] + G[q2][p]);   // shear-doubled strain
-            elem_D_apply<DIM, MAT>(g, sd, out);
-        };
-        auto symv = [&](const double *T, const double *v, double *o) {   // o += T v  (T flat symmetric)
-#pragma unroll
-            for (int p = 0; p < DIM; ++p)
-#pragma unroll
-                for (int q2 = 0; q2 < DIM; ++q2) o[p] += T[flat_idx<DIM>(p, q2)] * v[q2];
-        };
         double f[NPE][DIM];
-#pragma unroll
-        for (int j = 0; j < NPE; ++j)
-#pragma unroll
-            for (int d = 0; d < DIM; ++d) f[j][d] = 0.0;
-        if (DEG == 1) {
-            double G[DIM][DIM];
-#pragma unroll
-            for (int p = 0; p < DIM; ++p)
-#pragma unroll
-                for (int q2 = 0; q2 < DIM; ++q2) {
-                    double v = 0;
-#pragma unroll
-                    for (int j = 0; j < NV; ++j) v += xl[j][p] * gl[j][q2];
-                    G[p][q2] = v;
-                }
-            double sg[FL];
-            stress_of(G, sg);
-#pragma unroll
-            for (int c = 0; c < FL; ++c) sg[c] *= vol;
-#pragma unroll
-            for (int j = 0; j < NV; ++j) symv(sg, gl[j], f[j]);
-        } else {
-            constexpr double c0 = DIM == 3 ? 0.58541019662496845446 : 2.0 / 3.0;     // GaussQuadrature.hh:283-295 / :115-127
-            constexpr double c1 = DIM == 3 ? 0.13819660112501051518 : 1.0 / 6.0;
-            constexpr double b_ = 4 * c1 - 1, A_ = 4 * c0, B_ = 4 * c1, dAB = A_ - B_;   // a - b = A - B
-            constexpr double wq = 1.0 / NV;
-            double Gb[DIM][DIM];
-#pragma unroll
-            for (int p = 0; p < DIM; ++p)
-#pragma unroll
-                for (int q2 = 0; q2 < DIM; ++q2) Gb[p][q2] = 0.0;
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                double base[DIM];
-#pragma unroll
-                for (int d = 0; d < DIM; ++d) {
-                    double sum = 0;
-#pragma unroll
-                    for (int o = 0; o < NV; ++o)
-                        if (o != k) sum += xl[NV + edge_between<DIM>(k, o)][d];
-                    base[d] = b_ * xl[k][d] + B_ * sum;
-                }
-#pragma unroll
-                for (int p = 0; p < DIM; ++p)
-#pragma unroll
-                    for (int q2 = 0; q2 < DIM; ++q2) Gb[p][q2] += base[p] * gl[k][q2];
-            }
-            double S[FL], R[NV][FL];
-#pragma unroll
-            for (int c = 0; c < FL; ++c) S[c] = 0.0;
-#pragma unroll
-            for (int q = 0; q < NV; ++q) {
-                double G[DIM][DIM];
-#pragma unroll
-                for (int p = 0; p < DIM; ++p)
-#pragma unroll
-                    for (int q2 = 0; q2 < DIM; ++q2) {
-                        double v = Gb[p][q2] + dAB * xl[q][p] * gl[q][q2];
-#pragma unroll
-                        for (int k = 0; k < NV; ++k)
-                            if (k != q) v += dAB * xl[NV + edge_between<DIM>(k, q)][p] * gl[k][q2];
-                        G[p][q2] = v;
-                    }
-                double sg[FL];
-                stress_of(G, sg);
-#pragma unroll
-                for (int c = 0; c < FL; ++c) { S[c] += sg[c]; R[q][c] = vol * wq * dAB * sg[c]; }
-            }
-            // vertex k: f = (b S' + R_k) gl_k ;  edge (s,t): f = (B S' + R_t) gl_s + (B S' + R_s) gl_t
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                double T[FL];
-#pragma unroll
-                for (int c = 0; c < FL; ++c) T[c] = (vol * wq * b_) * S[c] + R[k][c];
-                symv(T, gl[k], f[k]);
-            }
-#pragma unroll
-            for (int c = 0; c < FL; ++c) S[c] *= vol * wq * B_;
-#pragma unroll
-            for (int m = 0; m < NPE - NV; ++m) {
-                const int sI = sup_s<DIM, DEG>(NV + m), tI = sup_t<DIM, DEG>(NV + m);
-                double T1[FL], T2[FL];
-#pragma unroll
-                for (int c = 0; c < FL; ++c) { T1[c] = S[c] + R[tI][c]; T2[c] = S[c] + R[sI][c]; }
-                symv(T1, gl[sI], f[NV + m]);
-                symv(T2, gl[tI], f[NV + m]);
-            }
-        }
+        elem_forces<DIM, DEG, MAT>(a, e, x, f);
         if (a.pairPos) {
             // list order: the pair's force goes where the rows pass will stream it
 #pragma unroll
@@ -878,6 +886,66 @@ __global__ void __launch_bounds__(256) k_mf_forces(SpmvMfArgs a, const double *_
 #pragma unroll
             for (int q = 0; q < NPE * DIM; ++q) o[q] = f[q / DIM][q % DIM];
         }
+    }
+}
+
+// Cluster variant: one workgroup per block of MF_BLOCK consecutive elements. The nodal forces of the block are summed
+// in LDS (one accumulator per distinct row of the block). Rows whose elements all belong to the block are finished
+// here and written to y; the other rows leave ONE partial sum per (block, row) in the interface buffer, in row order,
+// which k_mf_rows sums. With a spatially coherent element order most rows are finished in their block, so the
+// 240 B/element force buffer of k_mf_forces shrinks to a few tens of bytes per element.
+template <int DIM, int DEG, int MAT, bool PCG>
+__global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const double *__restrict__ x, double *__restrict__ y, double *dotOut,
+                                                         double *scal, int it, const double *stopPtr) {
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    extern __shared__ __attribute__((aligned(16))) double clacc[];   // [maxLocal * DIM] + 16
+    double *red = clacc + a.clMaxLocal * DIM;
+    if (PCG) {
+        it += (int)stopPtr[3];
+        if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
+        dotOut = scal + (int64_t)it * 4 + 1;
+    }
+    double dot = 0.0;
+    for (int64_t b = blockIdx.x; b < a.clBlocks; b += gridDim.x) {
+        const int u0 = a.clBlockPtr[b], nLocal = a.clBlockPtr[b + 1] - u0;
+        for (int t = threadIdx.x; t < nLocal * DIM; t += MF_BLOCK) clacc[t] = 0.0;
+        __syncthreads();
+        const int64_t e = b * a.clBlockElems + threadIdx.x;
+        if ((int)threadIdx.x < a.clBlockElems && e < a.nElem) {
+            double f[NPE][DIM];
+            elem_forces<DIM, DEG, MAT>(a, e, x, f);
+#pragma unroll
+            for (int j = 0; j < NPE; ++j) {
+                const int li = a.clLocalIdx[e * NPE + j];
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) unsafeAtomicAdd(&clacc[li * DIM + d], f[j][d]);
+            }
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < nLocal; t += MF_BLOCK) {
+            const int dest = a.clEntryDest[u0 + t];
+            if (dest == -2) continue;                                  // row owned by another rank
+            if (dest >= 0) {
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) a.clIfaceBuf[(int64_t)dest * DIM + d] = clacc[t * DIM + d];
+                continue;
+            }
+            const int64_t row = a.clEntryRow[u0 + t];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) {
+                const int64_t gi = row * DIM + d;
+                double v = clacc[t * DIM + d];
+                if (a.fixedMask && a.fixedMask[gi]) v = 0.0;
+                y[gi] = v;
+                if (dotOut) dot += v * x[gi];
+            }
+        }
+        __syncthreads();
+    }
+    if (dotOut) {
+        double v[1] = {dot};
+        block_sum<1>(v, red);
+        if (threadIdx.x == 0) unsafeAtomicAdd(dotOut, v[0]);
     }
 }
 
@@ -929,6 +997,7 @@ __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__r
         __syncthreads();
         for (int idx = threadIdx.x; idx < nr; idx += 256) {
             const int64_t gi = (int64_t)r0 * DIM + idx;
+            if (a.rowWrite && !a.rowWrite[gi / DIM]) continue;         // cluster variant: this pass owns the interface rows only
             double v = mfacc[idx];
             if (a.fixedMask && a.fixedMask[gi]) v = 0.0;
             y[gi] = v;
@@ -1739,6 +1808,28 @@ void launch_spmv_mf2(const SpmvMfArgs &a, const double *x, double *y, double *do
     MFH_DISPATCH(a, CALL);
 #undef CALL
     CHECK_LAUNCH();
+    const size_t lds = ((size_t)a.maxRows * a.dim + 16) * sizeof(double);
+    const int grid = persistent_grid(a.nChunk, 256 * 8);
+#define ROWS(D)                                                                                                                      \
+    if (pcg) hipLaunchKernelGGL((k_mf_rows<D, true>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, (double *)nullptr, scal, it, stopPtr); \
+    else hipLaunchKernelGGL((k_mf_rows<D, false>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr)
+    if (a.dim == 3) { ROWS(3); } else { ROWS(2); }
+#undef ROWS
+    CHECK_LAUNCH();
+}
+
+// cluster variant of the matrix-free elasticity operator (k_mf_cluster + k_mf_rows over the interface partials)
+void launch_spmv_mf_cluster(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
+                            bool pcg, hipStream_t s) {
+    const size_t ldsC = ((size_t)a.clMaxLocal * a.dim + 16) * sizeof(double);
+    const int gridC = (int)std::min<int64_t>(a.clBlocks, 256 * 64);
+#define CALL(D, G, M)                                                                                                                  \
+    if (pcg) hipLaunchKernelGGL((k_mf_cluster<D, G, M, true>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, (double *)nullptr, scal, it, stopPtr); \
+    else hipLaunchKernelGGL((k_mf_cluster<D, G, M, false>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr)
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+    CHECK_LAUNCH();
+    if (a.nChunk == 0) return;
     const size_t lds = ((size_t)a.maxRows * a.dim + 16) * sizeof(double);
     const int grid = persistent_grid(a.nChunk, 256 * 8);
 #define ROWS(D)                                                                                                                      \

@@ -316,6 +316,195 @@ void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const i
 
 
 // ------------------------------------------------------------------------------------------------
+// Lists of the cluster variant of the matrix-free operator (see MfClusterLists). Two radix sorts.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) k_mfc_gen(int64_t N, int npe, int blockElems, const int32_t *__restrict__ elemNodes, const int32_t *__restrict__ dofForNode,
+                                                 int64_t nRows, uint64_t *__restrict__ key, uint32_t *__restrict__ val,
+                                                 int32_t *__restrict__ rowCount) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < N; k += (int64_t)gridDim.x * 256) {
+        int64_t row = elemNodes[k];
+        if (dofForNode) row = dofForNode[row];
+        const bool ok = row < nRows;
+        const uint64_t b = (uint64_t)((k / npe) / blockElems);
+        key[k] = (b << 32) | (ok ? (uint64_t)row : 0xffffffffull);
+        val[k] = (uint32_t)k;
+        if (ok) atomicAdd(&rowCount[row], 1);
+    }
+}
+// per sorted pair: entry id (scan of heads - 1); at heads: entry row, run start; at block heads: blockPtr
+__global__ void __launch_bounds__(256) k_mfc_entries(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ entP1,
+                                                     int32_t *__restrict__ entryRow, int32_t *__restrict__ entryStart,
+                                                     int32_t *__restrict__ blockPtr) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        const uint64_t kk = key[k];
+        if (k != 0 && kk == key[k - 1]) continue;
+        const int32_t u = (int32_t)(entP1[k] - 1);
+        const uint32_t r = (uint32_t)(kk & 0xffffffffu);
+        entryRow[u] = r == 0xffffffffu ? -1 : (int32_t)r;
+        entryStart[u] = (int32_t)k;
+        if (k == 0 || (kk >> 32) != (key[k - 1] >> 32)) blockPtr[kk >> 32] = u;
+    }
+}
+// entry classification + interface keys; local index of every pair
+__global__ void __launch_bounds__(256) k_mfc_classify(int64_t nU, int64_t nSorted, const int32_t *__restrict__ entryRow,
+                                                      const int32_t *__restrict__ entryStart, const int32_t *__restrict__ rowCount,
+                                                      int32_t *__restrict__ entryDest, int32_t *__restrict__ rowIfaceCount) {
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < nU; u += (int64_t)gridDim.x * 256) {
+        const int32_t row = entryRow[u];
+        if (row < 0) { entryDest[u] = -2; continue; }
+        const int32_t cnt = (u + 1 < nU ? entryStart[u + 1] : (int32_t)nSorted) - entryStart[u];
+        if (cnt == rowCount[row]) entryDest[u] = -1;            // every element of the row is in this block
+        else { entryDest[u] = 0; atomicAdd(&rowIfaceCount[row], 1); }
+    }
+}
+__global__ void __launch_bounds__(256) k_mfc_local(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val,
+                                                   const uint32_t *__restrict__ entP1, const int32_t *__restrict__ blockPtr,
+                                                   uint16_t *__restrict__ localIdx) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
+        localIdx[val[k]] = (uint16_t)((int32_t)(entP1[k] - 1) - blockPtr[key[k] >> 32]);
+}
+// interface entries: (row, entry) pairs to be sorted by row
+__global__ void __launch_bounds__(256) k_mfc_iface_keys(int64_t nU, const int32_t *__restrict__ entryRow, const int32_t *__restrict__ entryDest,
+                                                        const uint32_t *__restrict__ ifP1, uint32_t *__restrict__ key, uint32_t *__restrict__ val) {
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < nU; u += (int64_t)gridDim.x * 256)
+        if (entryDest[u] == 0) { key[ifP1[u] - 1] = (uint32_t)entryRow[u]; val[ifP1[u] - 1] = (uint32_t)u; }
+}
+__global__ void __launch_bounds__(256) k_mfc_iface_flags(int64_t nU, const int32_t *__restrict__ entryDest, uint32_t *__restrict__ flag) {
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < nU; u += (int64_t)gridDim.x * 256) flag[u] = entryDest[u] == 0 ? 1u : 0u;
+}
+__global__ void __launch_bounds__(256) k_mfc_iface_assign(int64_t nI, const uint32_t *__restrict__ rowSorted, const uint32_t *__restrict__ entSorted,
+                                                          const int32_t *__restrict__ chunkOfRow, const int32_t *__restrict__ chunkFirstRow,
+                                                          int32_t *__restrict__ entryDest, uint16_t *__restrict__ ifaceRow) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nI; p += (int64_t)gridDim.x * 256) {
+        entryDest[entSorted[p]] = (int32_t)p;
+        const int32_t row = (int32_t)rowSorted[p];
+        ifaceRow[p] = (uint16_t)(row - chunkFirstRow[chunkOfRow[row]]);
+    }
+}
+__global__ void __launch_bounds__(256) k_mfc_rowflag(int64_t nRows, const int32_t *__restrict__ rowIfaceCount, uint8_t *__restrict__ flag) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nRows; r += (int64_t)gridDim.x * 256) flag[r] = rowIfaceCount[r] > 0;
+}
+} // namespace
+
+void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nRows, hipStream_t s,
+                                   MfClusterLists &L, MfClusterDev &D, int blockElems) {
+    const int npe = m.npe;
+    const int64_t N = m.nElem * npe;
+    if ((double)N >= 4294967295.0) throw Error(MFH_ERR_UNSUPPORTED, "mesh too large for 32-bit pair codes");
+    L = MfClusterLists();
+    L.blockElems = std::max(16, std::min(blockElems, MF_BLOCK));
+    L.nBlocks = (m.nElem + L.blockElems - 1) / L.blockElems;
+    DBuf<uint64_t> keyA, keyB;
+    DBuf<uint32_t> valA, valB, entP1;
+    DBuf<int32_t> rowCount, rowIfaceCount;
+    keyA.alloc(N); keyB.alloc(N); valA.alloc(N); valB.alloc(N);
+    rowCount.alloc((size_t)nRows + 1); rowCount.zero(s);
+    hipLaunchKernelGGL(k_mfc_gen, dim3(grid_of(N)), dim3(256), 0, s, N, npe, L.blockElems, dElemNodes, dDofForNode, nRows, keyA.p, valA.p, rowCount.p);
+    RP(hipGetLastError());
+    const unsigned endBit = 32 + bits_for((uint64_t)L.nBlocks);
+    size_t tmpBytes = 0;
+    RP(rocprim::radix_sort_pairs(nullptr, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)N, 0u, endBit, s));
+    DBuf<char> tmp;
+    tmp.alloc(tmpBytes + 16);
+    RP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)N, 0u, endBit, s));
+    keyA.release(); valA.release();
+    // ---- entries = distinct (block, row) pairs
+    entP1.alloc(N);
+    hipLaunchKernelGGL(k_sym_heads, dim3(grid_of(N)), dim3(256), 0, s, N, keyB.p, entP1.p);
+    size_t scanBytes = 0;
+    RP(rocprim::inclusive_scan(nullptr, scanBytes, entP1.p, entP1.p, (size_t)N, rocprim::plus<uint32_t>(), s));
+    if (scanBytes + 16 > tmp.n) tmp.alloc(scanBytes + 16);
+    RP(rocprim::inclusive_scan(tmp.p, scanBytes, entP1.p, entP1.p, (size_t)N, rocprim::plus<uint32_t>(), s));
+    uint32_t nU32 = 0;
+    MFH_HIP(hipMemcpyAsync(&nU32, entP1.p + (N - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    const int64_t nU = nU32;
+    L.nEntries = nU;
+    DBuf<int32_t> entryStart;
+    D.entryRow.alloc((size_t)nU); D.entryDest.alloc((size_t)nU); entryStart.alloc((size_t)nU);
+    D.blockPtr.alloc((size_t)L.nBlocks + 1);
+    hipLaunchKernelGGL(k_mfc_entries, dim3(grid_of(N)), dim3(256), 0, s, N, keyB.p, entP1.p, D.entryRow.p, entryStart.p, D.blockPtr.p);
+    RP(hipGetLastError());
+    const int32_t nUi = (int32_t)nU;
+    MFH_HIP(hipMemcpyAsync(D.blockPtr.p + L.nBlocks, &nUi, sizeof(int32_t), hipMemcpyHostToDevice, s));
+    D.localIdx.alloc((size_t)N);
+    hipLaunchKernelGGL(k_mfc_local, dim3(grid_of(N)), dim3(256), 0, s, N, keyB.p, valB.p, entP1.p, D.blockPtr.p, D.localIdx.p);
+    RP(hipGetLastError());
+    std::vector<int32_t> hBlockPtr((size_t)L.nBlocks + 1);
+    D.blockPtr.download(hBlockPtr.data(), hBlockPtr.size(), s);
+    for (int64_t b = 0; b < L.nBlocks; ++b) L.maxLocal = std::max(L.maxLocal, hBlockPtr[b + 1] - hBlockPtr[b]);
+    // ---- classification: finished in the block, or interface
+    rowIfaceCount.alloc((size_t)nRows + 1); rowIfaceCount.zero(s);
+    hipLaunchKernelGGL(k_mfc_classify, dim3(grid_of(nU)), dim3(256), 0, s, nU, N, D.entryRow.p, entryStart.p, rowCount.p, D.entryDest.p,
+                       rowIfaceCount.p);
+    RP(hipGetLastError());
+    keyB.release(); valB.release(); entP1.release(); entryStart.release();
+    DBuf<uint32_t> ifP1, ikA, ikB, ivA, ivB;
+    ifP1.alloc((size_t)nU);
+    hipLaunchKernelGGL(k_mfc_iface_flags, dim3(grid_of(nU)), dim3(256), 0, s, nU, D.entryDest.p, ifP1.p);
+    RP(rocprim::inclusive_scan(nullptr, scanBytes, ifP1.p, ifP1.p, (size_t)nU, rocprim::plus<uint32_t>(), s));
+    if (scanBytes + 16 > tmp.n) tmp.alloc(scanBytes + 16);
+    RP(rocprim::inclusive_scan(tmp.p, scanBytes, ifP1.p, ifP1.p, (size_t)nU, rocprim::plus<uint32_t>(), s));
+    uint32_t nI32 = 0;
+    MFH_HIP(hipMemcpyAsync(&nI32, ifP1.p + (nU - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    const int64_t nI = nI32;
+    L.nIface = nI;
+    D.rowIsIface.alloc((size_t)nRows);
+    hipLaunchKernelGGL(k_mfc_rowflag, dim3(grid_of(nRows)), dim3(256), 0, s, nRows, rowIfaceCount.p, D.rowIsIface.p);
+    // ---- second-pass chunks over the rows (only interface entries count)
+    DBuf<int32_t> rowIPtr;
+    rowIPtr.alloc((size_t)nRows + 1);
+    size_t exBytes = 0;
+    RP(rocprim::exclusive_scan(nullptr, exBytes, rowIfaceCount.p, rowIPtr.p, (int32_t)0, (size_t)nRows + 1, rocprim::plus<int32_t>(), s));
+    if (exBytes + 16 > tmp.n) tmp.alloc(exBytes + 16);
+    RP(rocprim::exclusive_scan(tmp.p, exBytes, rowIfaceCount.p, rowIPtr.p, (int32_t)0, (size_t)nRows + 1, rocprim::plus<int32_t>(), s));
+    std::vector<int32_t> hRowPtr((size_t)nRows + 1);
+    rowIPtr.download(hRowPtr.data(), hRowPtr.size(), s);
+    const int maxRowsCap = 2048, maxPairs = 2048;
+    L.chunkRow.assign(1, 0);
+    for (int64_t r = 0; r < nRows;) {
+        int64_t r2 = r + 1;
+        while (r2 < nRows && r2 - r < maxRowsCap && hRowPtr[r2 + 1] - hRowPtr[r] <= maxPairs) ++r2;
+        L.maxRows = std::max<int>(L.maxRows, (int)(r2 - r));
+        L.chunkRow.push_back((int32_t)r2);
+        r = r2;
+    }
+    const int64_t nChunk = (int64_t)L.chunkRow.size() - 1;
+    L.pairPtr.resize((size_t)nChunk + 1);
+    std::vector<int32_t> chunkOfRow((size_t)nRows), chunkFirst((size_t)nChunk);
+    for (int64_t c = 0; c < nChunk; ++c) {
+        L.pairPtr[c] = hRowPtr[L.chunkRow[c]];
+        chunkFirst[c] = L.chunkRow[c];
+        for (int32_t q = L.chunkRow[c]; q < L.chunkRow[c + 1]; ++q) chunkOfRow[q] = (int32_t)c;
+    }
+    L.pairPtr[nChunk] = nI;
+    D.chunkRow.upload(L.chunkRow, s);
+    D.pairPtr.upload(L.pairPtr, s);
+    D.ifaceRow.alloc((size_t)std::max<int64_t>(nI, 1));
+    D.ifaceBuf.alloc((size_t)std::max<int64_t>(nI, 1) * m.dim);
+    if (nI > 0) {
+        ikA.alloc((size_t)nI); ikB.alloc((size_t)nI); ivA.alloc((size_t)nI); ivB.alloc((size_t)nI);
+        hipLaunchKernelGGL(k_mfc_iface_keys, dim3(grid_of(nU)), dim3(256), 0, s, nU, D.entryRow.p, D.entryDest.p, ifP1.p, ikA.p, ivA.p);
+        size_t t2 = 0;
+        const unsigned eb = bits_for((uint64_t)nRows);
+        RP(rocprim::radix_sort_pairs(nullptr, t2, ikA.p, ikB.p, ivA.p, ivB.p, (size_t)nI, 0u, eb, s));
+        if (t2 + 16 > tmp.n) tmp.alloc(t2 + 16);
+        RP(rocprim::radix_sort_pairs(tmp.p, t2, ikA.p, ikB.p, ivA.p, ivB.p, (size_t)nI, 0u, eb, s));
+        DBuf<int32_t> dChunkOfRow, dChunkFirst;
+        dChunkOfRow.upload(chunkOfRow, s);
+        dChunkFirst.upload(chunkFirst, s);
+        hipLaunchKernelGGL(k_mfc_iface_assign, dim3(grid_of(nI)), dim3(256), 0, s, nI, ikB.p, ivB.p, dChunkOfRow.p, dChunkFirst.p, D.entryDest.p,
+                           D.ifaceRow.p);
+        RP(hipGetLastError());
+        MFH_HIP(hipStreamSynchronize(s));
+    }
+    MFH_HIP(hipStreamSynchronize(s));
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // FEM mesh topology on the device: P2 edge-node numbering in first-encounter order (FEMMesh.inl:22-36)
 // and the unmatched half-faces / half-edges that form the boundary (TetMesh.inl:36-79,
 // TriMesh.inl:60-100), by radix sorts instead of the host's hash table + std::sort.

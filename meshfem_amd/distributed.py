@@ -484,6 +484,6 @@ def bench_slabs(args, rank, world, local_rank):
                           dof_per_s=nd.item() * info["loop_iterations"] / ts.item(),
                           ms_per_iteration=ts.item() / max(1, info["loop_iterations"]) * 1e3,
                           maxit=maxit, preconditioner=pre_desc, two_level=tl_info,
-                          operator="matrix-free (k_mf_forces + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
+                          operator="matrix-free (k_mf_cluster + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
                           comm="halo P2P + %d all-reduce / iteration (torch.distributed nccl=RCCL)" % (3 if pre else 2))
     return out

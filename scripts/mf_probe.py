@@ -10,6 +10,6 @@ c = M.Context(0); c.mesh_build(T, V, 2); c.material_isotropic(200., 0.35); c.ass
 c.set_option("matrix_free", 0)
 print("assembled ms", c.time_spmv_kernel(10))
 c.set_option("matrix_free", 1)
-for mode in (1, 2, 3):
+for mode in (1, 2, 3, 4):
     c.set_option("matrix_free_mode", mode)
     print("matrix-free mode", mode, "ms", c.time_spmv_kernel(10))

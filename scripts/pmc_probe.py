@@ -16,10 +16,10 @@ ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, 3)
 c.set_option("matrix_free", 0)
 sp = c.time_spmv_kernel(3)          # launches k_axpby(n=3*nNode, b=0) once, then 1+3 k_spmv
 c.set_option("matrix_free", 1)
-mf = c.time_spmv_kernel(3)          # k_axpby again, then 1+3 x (k_mf_forces, k_mf_rows)
+mf = c.time_spmv_kernel(3)          # k_axpby again, then 1+3 x (k_mf_cluster, k_mf_rows over the interface partials)
 nr, nc, nnzb = c.matrix_info()
 nE, npe = len(T), 10
 print(json.dumps(dict(n=n, elems=nE, nnzb=nnzb, rows=nr, asm_ms=ms, spmv_ms=sp, mf_ms=mf,
                       calib_axpby_doubles=3 * nc, asm_alg_bytes=7736 * nE, spmv_alg_bytes=nnzb * 76 + nr * 3 * 16 + nr * 4,
                       asm_expected_hbm_bytes=nnzb * 72 + nE * 100 * 6 + nE * 128,
-                      mf_expected_hbm_bytes=nE * (128 + 4 * npe + 2 * 24 * npe + 6 * npe) + nr * 3 * 24)))
+                      mf_lists=c.matrix_free_info())))

@@ -763,7 +763,7 @@ def test_matrix_free_operator_equals_assembled(dim, deg, mat):
         c.set_option("matrix_free", 0)
         y0 = c.apply_K(x)
         c.set_option("matrix_free", 1)
-        for mode in (3, 2, 1):
+        for mode in (4, 3, 2, 1):
             c.set_option("matrix_free_mode", mode)
             assert np.abs(c.apply_K(x) - y0).max() < 1e-13 * np.abs(y0).max(), (periodic, mode)
         c.close()
