@@ -441,7 +441,7 @@ k::SpmvMfArgs spmv_mf_cluster_args(mfh_ctx *c, bool masked) {
     a.fixedMask = masked ? c->dFixedMask.p : nullptr;
     const auto &D = c->mfcDev;
     a.clBlocks = c->mfc.nBlocks; a.clMaxLocal = c->mfc.maxLocal; a.clBlockElems = c->mfc.blockElems; a.clBlockPtr = D.blockPtr.p; a.clEntryRow = D.entryRow.p;
-    a.clEntryDest = D.entryDest.p; a.clLocalIdx = D.localIdx.p; a.clIfaceBuf = D.ifaceBuf.p; a.rowWrite = D.rowIsIface.p;
+    a.clEntryDest = D.entryDest.p; a.clLocalIdx = D.localIdx.p; a.clIfaceBuf = D.ifaceBuf.p; a.rowWrite = nullptr; a.rowMap = D.rowMap.p;
     // second pass: k_mf_rows streaming the interface partials (pairPos != null selects the sequential read)
     a.nChunk = c->mfc.nIface > 0 ? (int64_t)c->mfc.chunkRow.size() - 1 : 0;
     a.chunkRow = D.chunkRow.p; a.pairPtr = D.pairPtr.p; a.pairRow = D.ifaceRow.p; a.pairCode = nullptr;

@@ -175,7 +175,7 @@ struct MfLists {
 // leave one partial sum per (block, row) in a small buffer that a second pass sums.
 constexpr int MF_BLOCK = 256;
 struct MfClusterLists {
-    int64_t nBlocks = 0, nEntries = 0, nIface = 0;
+    int64_t nBlocks = 0, nEntries = 0, nIface = 0, nIfaceRows = 0;
     int blockElems = MF_BLOCK;          // elements per block (<= MF_BLOCK threads)
     int maxLocal = 0;                   // largest number of distinct rows of a block (LDS accumulators)
     // second pass (interface partials in row order)
@@ -190,6 +190,7 @@ struct MfClusterDev {
     DBuf<int32_t> entryDest;            // [nEntries] -1: finish here (write y), >= 0: slot in the interface buffer, -2: row not owned
     DBuf<uint16_t> ifaceRow;            // [nIface] row - chunkRow[chunk] of every interface slot (row order)
     DBuf<uint8_t> rowIsIface;           // [nRows]
+    DBuf<int32_t> rowMap;               // [nIfaceRows] global row of every interface row (the second pass works in this numbering)
     DBuf<int32_t> chunkRow;
     DBuf<int64_t> pairPtr;
     DBuf<double> ifaceBuf;              // [nIface * dim]
@@ -319,6 +320,7 @@ struct SpmvMfArgs {
     const uint16_t *clLocalIdx;
     double *clIfaceBuf;
     const uint8_t *rowWrite;
+    const int32_t *rowMap;              // k_mf_rows: chunk rows are indices into rowMap (null: identity)
     int64_t nElem;
     double *sig;                        // two-pass operator: nodal forces of every element, [nElem][npe][dim]
     const uint8_t *fixedMask;           // per scalar row, may be null

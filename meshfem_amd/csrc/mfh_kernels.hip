@@ -996,8 +996,8 @@ __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__r
         }
         __syncthreads();
         for (int idx = threadIdx.x; idx < nr; idx += 256) {
-            const int64_t gi = (int64_t)r0 * DIM + idx;
-            if (a.rowWrite && !a.rowWrite[gi / DIM]) continue;         // cluster variant: this pass owns the interface rows only
+            int64_t gi = (int64_t)r0 * DIM + idx;
+            if (a.rowMap) gi = (int64_t)a.rowMap[r0 + idx / DIM] * DIM + idx % DIM;   // cluster variant: compact numbering of the interface rows
             double v = mfacc[idx];
             if (a.fixedMask && a.fixedMask[gi]) v = 0.0;
             y[gi] = v;

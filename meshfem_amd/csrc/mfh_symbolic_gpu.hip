@@ -374,12 +374,13 @@ __global__ void __launch_bounds__(256) k_mfc_iface_flags(int64_t nU, const int32
     for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < nU; u += (int64_t)gridDim.x * 256) flag[u] = entryDest[u] == 0 ? 1u : 0u;
 }
 __global__ void __launch_bounds__(256) k_mfc_iface_assign(int64_t nI, const uint32_t *__restrict__ rowSorted, const uint32_t *__restrict__ entSorted,
-                                                          const int32_t *__restrict__ chunkOfRow, const int32_t *__restrict__ chunkFirstRow,
-                                                          int32_t *__restrict__ entryDest, uint16_t *__restrict__ ifaceRow) {
+                                                          const int32_t *__restrict__ ifaceIdxOfRow, const int32_t *__restrict__ chunkOfIdx,
+                                                          const int32_t *__restrict__ chunkFirstIdx, int32_t *__restrict__ entryDest,
+                                                          uint16_t *__restrict__ ifaceRow) {
     for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nI; p += (int64_t)gridDim.x * 256) {
         entryDest[entSorted[p]] = (int32_t)p;
-        const int32_t row = (int32_t)rowSorted[p];
-        ifaceRow[p] = (uint16_t)(row - chunkFirstRow[chunkOfRow[row]]);
+        const int32_t ii = ifaceIdxOfRow[rowSorted[p]];                // index among the interface rows
+        ifaceRow[p] = (uint16_t)(ii - chunkFirstIdx[chunkOfIdx[ii]]);
     }
 }
 __global__ void __launch_bounds__(256) k_mfc_rowflag(int64_t nRows, const int32_t *__restrict__ rowIfaceCount, uint8_t *__restrict__ flag) {
@@ -462,26 +463,37 @@ void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes,
     RP(rocprim::exclusive_scan(tmp.p, exBytes, rowIfaceCount.p, rowIPtr.p, (int32_t)0, (size_t)nRows + 1, rocprim::plus<int32_t>(), s));
     std::vector<int32_t> hRowPtr((size_t)nRows + 1);
     rowIPtr.download(hRowPtr.data(), hRowPtr.size(), s);
-    const int maxRowsCap = 2048, maxPairs = 2048;
+    // the second pass works in the compact numbering of the interface rows (rows with at least one partial)
+    std::vector<int32_t> ifaceIdxOfRow((size_t)nRows, -1), ifaceRows, iptr{0};
+    for (int64_t r = 0; r < nRows; ++r)
+        if (hRowPtr[r + 1] > hRowPtr[r]) {
+            ifaceIdxOfRow[(size_t)r] = (int32_t)ifaceRows.size();
+            ifaceRows.push_back((int32_t)r);
+            iptr.push_back(hRowPtr[r + 1]);
+        }
+    const int64_t nIR = (int64_t)ifaceRows.size();
+    const int maxRowsCap = 512, maxPairs = 2048;
     L.chunkRow.assign(1, 0);
-    for (int64_t r = 0; r < nRows;) {
+    for (int64_t r = 0; r < nIR;) {
         int64_t r2 = r + 1;
-        while (r2 < nRows && r2 - r < maxRowsCap && hRowPtr[r2 + 1] - hRowPtr[r] <= maxPairs) ++r2;
+        while (r2 < nIR && r2 - r < maxRowsCap && iptr[r2 + 1] - iptr[r] <= maxPairs) ++r2;
         L.maxRows = std::max<int>(L.maxRows, (int)(r2 - r));
         L.chunkRow.push_back((int32_t)r2);
         r = r2;
     }
     const int64_t nChunk = (int64_t)L.chunkRow.size() - 1;
     L.pairPtr.resize((size_t)nChunk + 1);
-    std::vector<int32_t> chunkOfRow((size_t)nRows), chunkFirst((size_t)nChunk);
+    std::vector<int32_t> chunkOfIdx((size_t)std::max<int64_t>(nIR, 1)), chunkFirst((size_t)std::max<int64_t>(nChunk, 1));
     for (int64_t c = 0; c < nChunk; ++c) {
-        L.pairPtr[c] = hRowPtr[L.chunkRow[c]];
+        L.pairPtr[c] = iptr[L.chunkRow[c]];
         chunkFirst[c] = L.chunkRow[c];
-        for (int32_t q = L.chunkRow[c]; q < L.chunkRow[c + 1]; ++q) chunkOfRow[q] = (int32_t)c;
+        for (int32_t q = L.chunkRow[c]; q < L.chunkRow[c + 1]; ++q) chunkOfIdx[q] = (int32_t)c;
     }
     L.pairPtr[nChunk] = nI;
+    L.nIfaceRows = nIR;
     D.chunkRow.upload(L.chunkRow, s);
     D.pairPtr.upload(L.pairPtr, s);
+    D.rowMap.upload(ifaceRows.empty() ? std::vector<int32_t>{0} : ifaceRows, s);
     D.ifaceRow.alloc((size_t)std::max<int64_t>(nI, 1));
     D.ifaceBuf.alloc((size_t)std::max<int64_t>(nI, 1) * m.dim);
     if (nI > 0) {
@@ -492,11 +504,12 @@ void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes,
         RP(rocprim::radix_sort_pairs(nullptr, t2, ikA.p, ikB.p, ivA.p, ivB.p, (size_t)nI, 0u, eb, s));
         if (t2 + 16 > tmp.n) tmp.alloc(t2 + 16);
         RP(rocprim::radix_sort_pairs(tmp.p, t2, ikA.p, ikB.p, ivA.p, ivB.p, (size_t)nI, 0u, eb, s));
-        DBuf<int32_t> dChunkOfRow, dChunkFirst;
-        dChunkOfRow.upload(chunkOfRow, s);
+        DBuf<int32_t> dIdxOfRow, dChunkOfIdx, dChunkFirst;
+        dIdxOfRow.upload(ifaceIdxOfRow, s);
+        dChunkOfIdx.upload(chunkOfIdx, s);
         dChunkFirst.upload(chunkFirst, s);
-        hipLaunchKernelGGL(k_mfc_iface_assign, dim3(grid_of(nI)), dim3(256), 0, s, nI, ikB.p, ivB.p, dChunkOfRow.p, dChunkFirst.p, D.entryDest.p,
-                           D.ifaceRow.p);
+        hipLaunchKernelGGL(k_mfc_iface_assign, dim3(grid_of(nI)), dim3(256), 0, s, nI, ikB.p, ivB.p, dIdxOfRow.p, dChunkOfIdx.p, dChunkFirst.p,
+                           D.entryDest.p, D.ifaceRow.p);
         RP(hipGetLastError());
         MFH_HIP(hipStreamSynchronize(s));
     }
