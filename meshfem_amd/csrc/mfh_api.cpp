@@ -111,6 +111,7 @@ struct mfh_ctx {
     int aggNodes = 0;                 // option "agg_nodes": target DoFs per aggregate (0 = auto)
     bool topologyDevice = true;       // option "topology_device": edge numbering + boundary extraction by device radix sorts
     bool symbolicDevice = true;       // option "symbolic_device": build pattern + gather lists on the GPU (element-major order)
+    bool tlDeviceAggregates = true;   // option "tl_device_aggregates": build the aggregates on the device (0: host, validation)
     bool tlProbe = false;             // option "tl_probe": build the coarse operator by SpMV probing (validation)
     bool tlHostInverse = false;       // option "tl_host_inverse": invert the coarse operator on the host (validation)
     std::string precondNote;
@@ -565,6 +566,34 @@ bool ensure_twolevel(mfh_ctx *c) {
     const int64_t nDoF = c->nDoF;
     // default: ~1000 aggregates (coarse dimension ~6000): setup (Galerkin pass + device dense inverse) ~0.3 s
     int target = c->aggNodes > 0 ? c->aggNodes : (int)std::max<int64_t>(512, nDoF / 1000);
+    const bool tlTiming = getenv("MFH_TL_TIMING") != nullptr;
+    double tp = now_ms();
+    auto lap = [&](const char *what) {
+        if (!tlTiming) return;
+        MFH_HIP(hipStreamSynchronize(c->stream));
+        const double t = now_ms();
+        fprintf(stderr, "[two-level setup] %-28s %8.2f ms\n", what, t - tp);
+        tp = t;
+    };
+    hipStream_t s = c->stream;
+    auto &T = c->tl;
+    Aggregates A;
+    std::vector<double> relPos;   // host copy: validation / debug paths only
+    if (!c->tlProbe && c->tlDeviceAggregates) {
+        // ---- aggregates on the device: positions, bins, DoFs by aggregate, centroids and relPos never leave HBM
+        DBuf<double> dDofPos;
+        const double *dPos = c->dVertPos.p;
+        if (!c->dofForNode.empty()) {
+            dof_positions_device(m.nNode, d, device_dof_map(c), c->dVertPos.p, nDoF, s, dDofPos);
+            dPos = dDofPos.p;
+        }
+        build_aggregates_device(d, nDoF, dPos, target, s, A, T.aggOfDof, T.relPos, T.aggPtr, T.dofsByAgg);
+        lap("aggregates (device)");
+        T.nModes = d == 3 ? 6 : 3;
+        T.nAgg = A.nAgg; T.nColor = A.nColor; T.H = A.H;
+        T.m = (int64_t)T.nAgg * T.nModes;
+        T.colorOfAgg.upload(A.colorOfAgg, s); T.nbrOfColor.upload(A.nbrOfColor, s);
+    } else {
     // position of a DoF = position of its first node (identity map: the node itself). With a periodic map the
     // modes of aggregates at the seam are no longer exact rigid motions, but any full-rank Z is a valid
     // Galerkin coarse space.
@@ -582,7 +611,6 @@ bool ensure_twolevel(mfh_ctx *c) {
         dofPosPtr = &dofPosStore;
     }
     const std::vector<double> &dofPos = *dofPosPtr;
-    Aggregates A;
     for (int attempt = 0; attempt < 6; ++attempt) {
         build_aggregates(d, nDoF, dofPos, target, A);
         // K couples only DoFs of one element: every element must fit into adjacent bins
@@ -603,16 +631,17 @@ bool ensure_twolevel(mfh_ctx *c) {
         target *= 4;
         if (attempt == 5) { c->precondNote = "two-level preconditioner: elements span non-adjacent aggregates; using block-Jacobi"; return false; }
     }
-    auto &T = c->tl;
+    lap("aggregates (host)");
     T.nModes = d == 3 ? 6 : 3;
     T.nAgg = A.nAgg; T.nColor = A.nColor; T.H = A.H;
     T.m = (int64_t)T.nAgg * T.nModes;
-    std::vector<double> relPos((size_t)nDoF * 3, 0.0);
+    relPos.assign((size_t)nDoF * 3, 0.0);
     for (int64_t n = 0; n < nDoF; ++n)
         for (int a = 0; a < d; ++a) relPos[(size_t)n * 3 + a] = (dofPos[(size_t)n * d + a] - A.centroid[(size_t)A.aggOfDof[n] * 3 + a]) / A.H;
-    hipStream_t s = c->stream;
     T.aggOfDof.upload(A.aggOfDof, s); T.relPos.upload(relPos, s); T.aggPtr.upload(A.aggPtr, s); T.dofsByAgg.upload(A.dofsByAgg, s);
     T.colorOfAgg.upload(A.colorOfAgg, s); T.nbrOfColor.upload(A.nbrOfColor, s);
+    lap("relPos + uploads");
+    }
     T.rc.alloc((size_t)T.m); T.yc.alloc((size_t)T.m);
     DBuf<double> Ac;
     Ac.alloc((size_t)T.m * T.m);
@@ -632,22 +661,16 @@ bool ensure_twolevel(mfh_ctx *c) {
     } else {            // one Galerkin pass over the assembled K
         k::launch_tl_rap(ta, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac.p, s);
     }
+    lap("Galerkin product");
     const int64_t mm = T.m;
     if (!c->tlHostInverse) {
         if (!tl_invert_device(c, Ac.p, true)) return false;
         Ac.release();
+        lap("dense inverse");
     } else {
     std::vector<double> hA((size_t)T.m * T.m);
     Ac.download(hA.data(), hA.size(), s);
     Ac.release();
-    if (const char *dump = getenv("MFH_DEBUG_DUMP_AC")) {   // debugging aid: raw coarse operator + aggregates
-        FILE *f = fopen(dump, "wb");
-        if (f) { fwrite(hA.data(), sizeof(double), hA.size(), f); fclose(f); }
-        f = fopen((std::string(dump) + ".agg").c_str(), "wb");
-        if (f) { fwrite(A.aggOfDof.data(), sizeof(int32_t), A.aggOfDof.size(), f); fclose(f); }
-        f = fopen((std::string(dump) + ".relpos").c_str(), "wb");
-        if (f) { fwrite(relPos.data(), sizeof(double), relPos.size(), f); fclose(f); }
-    }
     double maxd = 0;
     for (int64_t i = 0; i < mm; ++i) maxd = std::max(maxd, hA[(size_t)i * mm + i]);
     parallel_ranges(mm, [&](int64_t b, int64_t e, int) {   // symmetrise
@@ -2162,6 +2185,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "mf_chunk_rows") { c->mfChunkRows = std::max(16, std::min(4096, (int)value)); c->mfValid = false; }
     else if (k2 == "mf_chunk_pairs") { c->mfChunkPairs = std::max(256, (int)value); c->mfValid = false; }
     else if (k2 == "matrix_free") c->matrixFree = value < 0 ? -1 : (value != 0 ? 1 : 0);   // K x without reading the assembled K (k_spmv_mf)
+    else if (k2 == "tl_device_aggregates") { c->tlDeviceAggregates = value != 0; c->tl.valid = false; }
     else if (k2 == "tl_probe") { c->tlProbe = value != 0; c->tl.valid = false; }
     else if (k2 == "tl_host_inverse") { c->tlHostInverse = value != 0; c->tl.valid = false; }
     else if (k2 == "debug_variant") { c->debugVariant = (int)value; invalidate_matrix(c); }

@@ -235,6 +235,14 @@ struct Aggregates {
     std::vector<int32_t> nbrOfColor;     // nAgg x nColor: the neighbour (or self) of that colour, -1 if none
 };
 void build_aggregates(int dim, int64_t nDoF, const std::vector<double> &dofPos, int targetNodes, Aggregates &A);
+// lattice tables (colours, bin coordinates, neighbours by colour) from the compact bin numbering
+void aggregate_lattice_tables(int dim, const int nb[3], const std::vector<int32_t> &binId, Aggregates &A);
+// the same aggregates built on the device (mfh_symbolic_gpu.hip): bins, DoFs by aggregate (radix sort), centroids and the
+// relative positions stay in HBM; only the bin occupancy and the per-aggregate counts visit the host
+void dof_positions_device(int64_t nNode, int dim, const int32_t *dDofForNode, const double *dNodePos, int64_t nDoF, hipStream_t s,
+                          DBuf<double> &out);
+void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targetNodes, hipStream_t s, Aggregates &A,
+                             DBuf<int32_t> &dAggOfDof, DBuf<double> &dRelPos, DBuf<int32_t> &dAggPtr, DBuf<int32_t> &dDofsByAgg);
 bool spd_inverse_inplace(int64_t n, double *A);
 
 } // namespace mfh

@@ -518,6 +518,178 @@ void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes,
 
 
 // ------------------------------------------------------------------------------------------------
+// Aggregates of the two-level preconditioner on the device (same bins as build_aggregates, mfh_twolevel.cpp)
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) k_agg_minmax(int64_t n, int dim, const double *__restrict__ pos, double *__restrict__ part) {
+    __shared__ double red[6 * 4];
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
+        for (int a = 0; a < dim; ++a) { const double v = pos[k * dim + a]; mn[a] = fmin(mn[a], v); mx[a] = fmax(mx[a], v); }
+    for (int a = 0; a < 3; ++a)
+        for (int off = 32; off > 0; off >>= 1) { mn[a] = fmin(mn[a], __shfl_down(mn[a], off, 64)); mx[a] = fmax(mx[a], __shfl_down(mx[a], off, 64)); }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) for (int a = 0; a < 3; ++a) { red[w * 6 + a] = mn[a]; red[w * 6 + 3 + a] = mx[a]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int a = threadIdx.x;
+        part[blockIdx.x * 6 + a] = fmin(fmin(red[a], red[6 + a]), fmin(red[12 + a], red[18 + a]));
+        part[blockIdx.x * 6 + 3 + a] = fmax(fmax(red[3 + a], red[9 + a]), fmax(red[15 + a], red[21 + a]));
+    }
+}
+struct AggBins { double mn[3], w[3]; int nb[3]; };
+__global__ void __launch_bounds__(256) k_agg_rawbin(int64_t n, int dim, AggBins B, const double *__restrict__ pos, int32_t *__restrict__ rawBin,
+                                                    int32_t *__restrict__ mark) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        int ib[3] = {0, 0, 0};
+        for (int a = 0; a < dim; ++a) {
+            int b = B.w[a] > 0 ? (int)floor((pos[k * dim + a] - B.mn[a]) / B.w[a]) : 0;
+            ib[a] = min(max(b, 0), B.nb[a] - 1);
+        }
+        const int32_t r = (ib[2] * B.nb[1] + ib[1]) * B.nb[0] + ib[0];
+        rawBin[k] = r;
+        mark[r] = 1;
+    }
+}
+__global__ void __launch_bounds__(256) k_agg_assign(int64_t n, const int32_t *__restrict__ rawBin, const int32_t *__restrict__ binId,
+                                                    int32_t *__restrict__ aggOfDof, uint32_t *__restrict__ key, uint32_t *__restrict__ val,
+                                                    int32_t *__restrict__ cnt) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        const int32_t a = binId[rawBin[k]];
+        aggOfDof[k] = a;
+        key[k] = (uint32_t)a;
+        val[k] = (uint32_t)k;
+        atomicAdd(&cnt[a], 1);
+    }
+}
+// one workgroup per aggregate: centroid = mean position of its DoFs
+__global__ void __launch_bounds__(256) k_agg_centroid(int dim, const int32_t *__restrict__ aggPtr, const uint32_t *__restrict__ dofsByAgg,
+                                                      const double *__restrict__ pos, double *__restrict__ centroid) {
+    __shared__ double red[3 * 4];
+    const int a = blockIdx.x;
+    double acc[3] = {0, 0, 0};
+    for (int q = aggPtr[a] + threadIdx.x; q < aggPtr[a + 1]; q += 256) {
+        const int64_t n = dofsByAgg[q];
+        for (int c = 0; c < dim; ++c) acc[c] += pos[n * dim + c];
+    }
+    for (int c = 0; c < 3; ++c)
+        for (int off = 32; off > 0; off >>= 1) acc[c] += __shfl_down(acc[c], off, 64);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) for (int c = 0; c < 3; ++c) red[w * 3 + c] = acc[c];
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int cnt = aggPtr[a + 1] - aggPtr[a];
+        centroid[a * 3 + threadIdx.x] = (red[threadIdx.x] + red[3 + threadIdx.x] + red[6 + threadIdx.x] + red[9 + threadIdx.x]) / (cnt > 0 ? cnt : 1);
+    }
+}
+__global__ void __launch_bounds__(256) k_agg_relpos(int64_t n, int dim, double invH, const int32_t *__restrict__ aggOfDof,
+                                                    const double *__restrict__ pos, const double *__restrict__ centroid, double *__restrict__ relPos) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        const int a = aggOfDof[k];
+        for (int c = 0; c < 3; ++c) relPos[k * 3 + c] = c < dim ? (pos[k * dim + c] - centroid[a * 3 + c]) * invH : 0.0;
+    }
+}
+__global__ void __launch_bounds__(256) k_agg_copy_u32_i32(int64_t n, const uint32_t *__restrict__ a, int32_t *__restrict__ b) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) b[k] = (int32_t)a[k];
+}
+} // namespace
+
+namespace {
+__global__ void __launch_bounds__(256) k_dof_first_node(int64_t nNode, const int32_t *__restrict__ dofForNode, int32_t *__restrict__ first) {
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nNode; n += (int64_t)gridDim.x * 256) atomicMin(&first[dofForNode[n]], (int32_t)n);
+}
+__global__ void __launch_bounds__(256) k_dof_pos(int64_t nDoF, int dim, const int32_t *__restrict__ first, const double *__restrict__ nodePos,
+                                                 double *__restrict__ dofPos) {
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nDoF; q += (int64_t)gridDim.x * 256)
+        for (int a = 0; a < dim; ++a) dofPos[q * dim + a] = nodePos[(int64_t)first[q] * dim + a];
+}
+} // namespace
+
+// position of a DoF = position of its first node (periodic DoF maps)
+void dof_positions_device(int64_t nNode, int dim, const int32_t *dDofForNode, const double *dNodePos, int64_t nDoF, hipStream_t s,
+                          DBuf<double> &out) {
+    DBuf<int32_t> first;
+    first.alloc((size_t)nDoF);
+    MFH_HIP(hipMemsetAsync(first.p, 0x7f, (size_t)nDoF * sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_dof_first_node, dim3(grid_of(nNode)), dim3(256), 0, s, nNode, dDofForNode, first.p);
+    out.alloc((size_t)nDoF * dim);
+    hipLaunchKernelGGL(k_dof_pos, dim3(grid_of(nDoF)), dim3(256), 0, s, nDoF, dim, first.p, dNodePos, out.p);
+    RP(hipGetLastError());
+    MFH_HIP(hipStreamSynchronize(s));
+}
+
+void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targetNodes, hipStream_t s, Aggregates &A,
+                             DBuf<int32_t> &dAggOfDof, DBuf<double> &dRelPos, DBuf<int32_t> &dAggPtr, DBuf<int32_t> &dDofsByAgg) {
+    A = Aggregates();
+    A.dim = dim;
+    // ---- bounding box
+    const int gridMM = 1024;
+    DBuf<double> part;
+    part.alloc((size_t)gridMM * 6);
+    hipLaunchKernelGGL(k_agg_minmax, dim3(gridMM), dim3(256), 0, s, nDoF, dim, dPos, part.p);
+    RP(hipGetLastError());
+    std::vector<double> hp((size_t)gridMM * 6);
+    part.download(hp.data(), hp.size(), s);
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int b = 0; b < gridMM; ++b)
+        for (int a = 0; a < dim; ++a) { mn[a] = std::min(mn[a], hp[(size_t)b * 6 + a]); mx[a] = std::max(mx[a], hp[(size_t)b * 6 + 3 + a]); }
+    // ---- the same bin lattice as build_aggregates (mfh_twolevel.cpp)
+    double vol = 1;
+    for (int a = 0; a < dim; ++a) vol *= std::max(mx[a] - mn[a], 1e-300);
+    const double H = std::pow(vol * std::max(1, targetNodes) / (double)std::max<int64_t>(1, nDoF), 1.0 / dim);
+    int nb[3] = {1, 1, 1};
+    for (int a = 0; a < dim; ++a) nb[a] = std::max(1, (int)std::floor((mx[a] - mn[a]) / H + 0.5));
+    A.H = H;
+    AggBins B{};
+    for (int a = 0; a < 3; ++a) { B.mn[a] = a < dim ? mn[a] : 0.0; B.nb[a] = nb[a]; B.w[a] = a < dim ? (mx[a] - mn[a]) / nb[a] : 0.0; }
+    const int64_t nBins = (int64_t)nb[0] * nb[1] * nb[2];
+    DBuf<int32_t> rawBin, mark, dBinId, cnt;
+    rawBin.alloc((size_t)nDoF);
+    mark.alloc((size_t)nBins);
+    mark.zero(s);
+    hipLaunchKernelGGL(k_agg_rawbin, dim3(grid_of(nDoF)), dim3(256), 0, s, nDoF, dim, B, dPos, rawBin.p, mark.p);
+    RP(hipGetLastError());
+    std::vector<int32_t> binId((size_t)nBins);
+    mark.download(binId.data(), binId.size(), s);
+    int32_t nAgg = 0;
+    for (auto &b : binId) b = b ? nAgg++ : -1;          // compact numbering of the non-empty bins, in bin order
+    A.nAgg = nAgg;
+    dBinId.upload(binId, s);
+    // ---- aggregate of every DoF, DoFs grouped by aggregate (stable sort: ascending DoF inside an aggregate)
+    DBuf<uint32_t> keyA, keyB, valA, valB;
+    keyA.alloc((size_t)nDoF); keyB.alloc((size_t)nDoF); valA.alloc((size_t)nDoF); valB.alloc((size_t)nDoF);
+    cnt.alloc((size_t)nAgg + 1);
+    cnt.zero(s);
+    dAggOfDof.alloc((size_t)nDoF);
+    hipLaunchKernelGGL(k_agg_assign, dim3(grid_of(nDoF)), dim3(256), 0, s, nDoF, rawBin.p, dBinId.p, dAggOfDof.p, keyA.p, valA.p, cnt.p);
+    RP(hipGetLastError());
+    size_t tmpBytes = 0;
+    const unsigned endBit = bits_for((uint64_t)nAgg);
+    RP(rocprim::radix_sort_pairs(nullptr, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)nDoF, 0u, endBit, s));
+    DBuf<char> tmp;
+    tmp.alloc(tmpBytes + 16);
+    RP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)nDoF, 0u, endBit, s));
+    std::vector<int32_t> hCnt((size_t)nAgg + 1);
+    cnt.download(hCnt.data(), hCnt.size(), s);
+    A.aggPtr.assign((size_t)nAgg + 1, 0);
+    for (int32_t a = 0; a < nAgg; ++a) A.aggPtr[(size_t)a + 1] = A.aggPtr[a] + hCnt[a];
+    dAggPtr.upload(A.aggPtr, s);
+    dDofsByAgg.alloc((size_t)nDoF);
+    hipLaunchKernelGGL(k_agg_copy_u32_i32, dim3(grid_of(nDoF)), dim3(256), 0, s, nDoF, valB.p, dDofsByAgg.p);
+    // ---- centroids and relative positions
+    DBuf<double> dCentroid;
+    dCentroid.alloc((size_t)nAgg * 3);
+    hipLaunchKernelGGL(k_agg_centroid, dim3(nAgg), dim3(256), 0, s, dim, dAggPtr.p, valB.p, dPos, dCentroid.p);
+    dRelPos.alloc((size_t)nDoF * 3);
+    hipLaunchKernelGGL(k_agg_relpos, dim3(grid_of(nDoF)), dim3(256), 0, s, nDoF, dim, 1.0 / H, dAggOfDof.p, dPos, dCentroid.p, dRelPos.p);
+    RP(hipGetLastError());
+    A.centroid.resize((size_t)nAgg * 3);
+    dCentroid.download(A.centroid.data(), A.centroid.size(), s);
+    aggregate_lattice_tables(dim, nb, binId, A);
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // FEM mesh topology on the device: P2 edge-node numbering in first-encounter order (FEMMesh.inl:22-36)
 // and the unmatched half-faces / half-edges that form the boundary (TetMesh.inl:36-79,
 // TriMesh.inl:60-100), by radix sorts instead of the host's hash table + std::sort.

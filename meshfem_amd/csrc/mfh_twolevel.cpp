@@ -70,6 +70,11 @@ void build_aggregates(int dim, int64_t nDoF, const std::vector<double> &dofPos, 
         std::vector<int32_t> cur(A.aggPtr.begin(), A.aggPtr.end() - 1);
         for (int64_t n = 0; n < nDoF; ++n) A.dofsByAgg[(size_t)cur[A.aggOfDof[n]]++] = (int32_t)n;
     }
+    aggregate_lattice_tables(dim, nb, binId, A);
+}
+
+void aggregate_lattice_tables(int dim, const int nb[3], const std::vector<int32_t> &binId, Aggregates &A) {
+    const int32_t nAgg = A.nAgg;
     // colours (3 x 3 x 3 on the bin lattice) and, per aggregate and colour, the unique aggregate of that
     // colour among its 3^dim lattice neighbours (K couples only DoFs of adjacent bins when H >> h)
     const int nColor = dim == 3 ? 27 : 9;
