@@ -105,12 +105,13 @@ struct mfh_ctx {
         int nModes = 0, nAgg = 0, nColor = 0;
         int64_t m = 0, ldInv = 0;
         double setup_ms = 0, H = 0;
-        DBuf<int32_t> aggOfDof, aggPtr, dofsByAgg, colorOfAgg, nbrOfColor;
+        DBuf<int32_t> aggOfDof, aggPtr, dofsByAgg, colorOfAgg, nbrOfColor, binCoord;
         DBuf<double> relPos, Ainv, rc, yc;
     } tl;
     int aggNodes = 0;                 // option "agg_nodes": target DoFs per aggregate (0 = auto)
     bool topologyDevice = true;       // option "topology_device": edge numbering + boundary extraction by device radix sorts
     bool symbolicDevice = true;       // option "symbolic_device": build pattern + gather lists on the GPU (element-major order)
+    bool tlRapAgg = true;             // option "tl_rap_agg": aggregate-centric Galerkin kernel (0: one wave per row, validation)
     bool tlDeviceAggregates = true;   // option "tl_device_aggregates": build the aggregates on the device (0: host, validation)
     bool tlProbe = false;             // option "tl_probe": build the coarse operator by SpMV probing (validation)
     bool tlHostInverse = false;       // option "tl_host_inverse": invert the coarse operator on the host (validation)
@@ -659,7 +660,9 @@ bool ensure_twolevel(mfh_ctx *c) {
                 k::launch_tl_scatter(T.nAgg, T.nModes, T.nColor, T.nbrOfColor.p, color, mode, T.rc.p, Ac.p, s);
             }
     } else {            // one Galerkin pass over the assembled K
-        k::launch_tl_rap(ta, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac.p, s);
+        T.binCoord.upload(A.binCoord, s);
+        if (c->tlRapAgg) k::launch_tl_rap_agg(ta, T.aggPtr.p, T.dofsByAgg.p, T.binCoord.p, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac.p, s);
+        else k::launch_tl_rap(ta, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac.p, s);
     }
     lap("Galerkin product");
     const int64_t mm = T.m;
@@ -2000,7 +2003,9 @@ mfh_status mfh_tl_partitioned_begin(mfh_ctx *c, int32_t nAgg, const int32_t *agg
     T.aggOfDof.upload(agg, s); T.relPos.upload(rp, s); T.aggPtr.upload(aggPtr, s); T.dofsByAgg.upload(byAgg, s);
     T.rc.alloc((size_t)T.m); T.yc.alloc((size_t)T.m);
     MFH_HIP(hipMemsetAsync(Ac_dev, 0, (size_t)T.m * T.m * sizeof(double), s));
-    k::launch_tl_rap(tl_args(c), nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac_dev, s);
+    // caller-supplied aggregates carry no lattice: neighbour blocks fall back to global atomics, the diagonal ones do not
+    if (c->tlRapAgg) k::launch_tl_rap_agg(tl_args(c), T.aggPtr.p, T.dofsByAgg.p, nullptr, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac_dev, s);
+    else k::launch_tl_rap(tl_args(c), nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac_dev, s);
     MFH_HIP(hipStreamSynchronize(s));
     T.setup_ms = now_ms() - t0;
     MFH_CATCH(c)
@@ -2185,6 +2190,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "mf_chunk_rows") { c->mfChunkRows = std::max(16, std::min(4096, (int)value)); c->mfValid = false; }
     else if (k2 == "mf_chunk_pairs") { c->mfChunkPairs = std::max(256, (int)value); c->mfValid = false; }
     else if (k2 == "matrix_free") c->matrixFree = value < 0 ? -1 : (value != 0 ? 1 : 0);   // K x without reading the assembled K (k_spmv_mf)
+    else if (k2 == "tl_rap_agg") { c->tlRapAgg = value != 0; c->tl.valid = false; }
     else if (k2 == "tl_device_aggregates") { c->tlDeviceAggregates = value != 0; c->tl.valid = false; }
     else if (k2 == "tl_probe") { c->tlProbe = value != 0; c->tl.valid = false; }
     else if (k2 == "tl_host_inverse") { c->tlHostInverse = value != 0; c->tl.valid = false; }

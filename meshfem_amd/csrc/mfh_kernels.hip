@@ -1241,6 +1241,113 @@ __global__ void __launch_bounds__(256) k_tl_rap(TLArgs t, int64_t nRows, const i
     }
 }
 
+// Galerkin product, aggregate-centric: one workgroup (8 waves) per ROW aggregate walks that aggregate's rows; the rows
+// (a, .) of the coarse operator are written by this workgroup alone, so nothing needs a global atomic:
+//   * blocks whose column lies in the same aggregate (the vast majority) are summed in registers over ALL rows of the wave;
+//   * blocks reaching a lattice neighbour go to an LDS table [27][NM*NM] (ds_add_f64);
+//   * anything else (no lattice information, non-adjacent aggregates) falls back to a global atomic.
+// The per-row version above pays 36 atomics per row on the same few addresses (7 400 rows of an aggregate hammer one
+// 6x6 block): 68 ms at config 3; this one streams K once.
+template <int DIM>
+__global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__restrict__ aggPtr, const int32_t *__restrict__ dofsByAgg,
+                                                     const int32_t *__restrict__ binCoord /* nAgg x 3, may be null */,
+                                                     const int32_t *__restrict__ rowPtr, const int32_t *__restrict__ colIdx,
+                                                     const double *__restrict__ vals, double *__restrict__ Ac) {
+    constexpr int NB = DIM * DIM;
+    constexpr int NM = DIM == 3 ? 6 : 3;
+    constexpr int NSLOT = DIM == 3 ? 27 : 9;
+    __shared__ double nbr[NSLOT * NM * NM];
+    __shared__ int nbrAgg[NSLOT];
+    __shared__ double diagRed[16 * NM * NM];
+    const int a = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
+    const int64_t m = (int64_t)t.nAgg * NM;
+    for (int q = threadIdx.x; q < NSLOT * NM * NM; q += blockDim.x) nbr[q] = 0.0;
+    if (threadIdx.x < NSLOT) nbrAgg[threadIdx.x] = -1;
+    __syncthreads();
+    int ca[3] = {0, 0, 0};
+    if (binCoord) { ca[0] = binCoord[a * 3]; ca[1] = binCoord[a * 3 + 1]; ca[2] = binCoord[a * 3 + 2]; }
+    double acc[NM * NM];
+#pragma unroll
+    for (int q = 0; q < NM * NM; ++q) acc[q] = 0.0;
+    for (int p = aggPtr[a] + wave; p < aggPtr[a + 1]; p += nWaves) {
+        const int64_t r = dofsByAgg[p];
+        const double rpr[3] = {t.relPos[r * 3], t.relPos[r * 3 + 1], t.relPos[r * 3 + 2]};
+        double zr[NM][DIM];
+#pragma unroll
+        for (int k = 0; k < NM; ++k)
+#pragma unroll
+            for (int x = 0; x < DIM; ++x) zr[k][x] = (t.fixedMask && t.fixedMask[r * DIM + x]) ? 0.0 : tl_mode<DIM>(k, x, rpr);
+        for (int s = rowPtr[r] + lane; s < rowPtr[r + 1]; s += 64) {
+            const int64_t c = colIdx[s];
+            const int b = t.aggOfDof[c];
+            const double rpc[3] = {t.relPos[c * 3], t.relPos[c * 3 + 1], t.relPos[c * 3 + 2]};
+            double K[NB];
+#pragma unroll
+            for (int q = 0; q < NB; ++q) K[q] = vals[tiled_index(s, q, NB)];
+            double T[NM * NM];
+#pragma unroll
+            for (int l = 0; l < NM; ++l) {
+                double zc[DIM], w[DIM];
+#pragma unroll
+                for (int y = 0; y < DIM; ++y) zc[y] = (t.fixedMask && t.fixedMask[c * DIM + y]) ? 0.0 : tl_mode<DIM>(l, y, rpc);
+#pragma unroll
+                for (int x = 0; x < DIM; ++x) {
+                    double v = 0;
+#pragma unroll
+                    for (int y = 0; y < DIM; ++y) v += K[x * DIM + y] * zc[y];
+                    w[x] = v;
+                }
+#pragma unroll
+                for (int k = 0; k < NM; ++k) {
+                    double v = 0;
+#pragma unroll
+                    for (int x = 0; x < DIM; ++x) v += zr[k][x] * w[x];
+                    T[k * NM + l] = v;
+                }
+            }
+            if (b == a) {
+#pragma unroll
+                for (int q = 0; q < NM * NM; ++q) acc[q] += T[q];
+                continue;
+            }
+            int slot = -1;
+            if (binCoord) {
+                const int dx = binCoord[b * 3] - ca[0], dy = binCoord[b * 3 + 1] - ca[1], dz = binCoord[b * 3 + 2] - ca[2];
+                if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1) slot = (dx + 1) + 3 * (dy + 1) + (DIM == 3 ? 9 * (dz + 1) : 0);
+            }
+            if (slot >= 0) {
+                nbrAgg[slot] = b;     // every writer stores the same value
+#pragma unroll
+                for (int q = 0; q < NM * NM; ++q) unsafeAtomicAdd(&nbr[slot * NM * NM + q], T[q]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NM; ++k)
+#pragma unroll
+                    for (int l = 0; l < NM; ++l) unsafeAtomicAdd(&Ac[((int64_t)a * NM + k) * m + (int64_t)b * NM + l], T[k * NM + l]);
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NM * NM; ++q) acc[q] = wave_sum(acc[q]);
+    if (lane == 0)
+#pragma unroll
+        for (int q = 0; q < NM * NM; ++q) diagRed[wave * NM * NM + q] = acc[q];
+    __syncthreads();
+    // rows (a, .) of Ac belong to this workgroup: plain read-modify-write (the fallback atomics above may have touched them too)
+    for (int q = threadIdx.x; q < NM * NM; q += blockDim.x) {
+        double v = 0;
+        for (int w = 0; w < nWaves; ++w) v += diagRed[w * NM * NM + q];
+        unsafeAtomicAdd(&Ac[((int64_t)a * NM + q / NM) * m + (int64_t)a * NM + q % NM], v);
+    }
+    for (int q = threadIdx.x; q < NSLOT * NM * NM; q += blockDim.x) {
+        const int slot = q / (NM * NM), e = q - slot * NM * NM;
+        const int b = nbrAgg[slot];
+        if (b < 0) continue;
+        unsafeAtomicAdd(&Ac[((int64_t)a * NM + e / NM) * m + (int64_t)b * NM + e % NM], nbr[q]);
+    }
+}
+
 // symmetrise the raw coarse operator into the padded matrix the dense inverse works on; modes without
 // support (dead) are decoupled, the diagonal gets a tiny relative shift, the padding is scaled identity
 __global__ void __launch_bounds__(256) k_tl_prep(int64_t m, int64_t mp, const double *__restrict__ Ac, const uint8_t *__restrict__ dead,
@@ -1458,6 +1565,45 @@ __global__ void __launch_bounds__(256) k_dense_trinv(const double *A, double *X,
 }
 
 // Ainv_IJ = sum_{Q >= I} X_QI^T X_QJ for J <= I (and its mirror); 2D grid (J, I)
+// L^-1 by recursive doubling instead of 94 dependent diagonal sweeps: with the inverses X11, X22 of two adjacent
+// diagonal blocks of bt tiles known, the block below the diagonal is X21 = -X22 (L21 X11): two batched tile GEMMs per
+// level, log2(nt) levels, every tile of a level independent.   step 1: W = L21 X11 (W in scratch), step 2: X21 = -X22 W.
+__global__ void __launch_bounds__(256) k_dense_linv_level(const double *__restrict__ L, double *X, double *W, int64_t ld, int nt, int bt, int step) {
+    __shared__ double As[DT * DTP];
+    __shared__ double Bs[DT * DTP];
+    const int pair = blockIdx.z, c0 = 2 * pair * bt, r0 = c0 + bt;
+    const int I = blockIdx.y, J = blockIdx.x;
+    if (r0 + I >= nt || r0 + I >= r0 + bt) return;
+    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
+    double c[4][4] = {};
+    if (step == 1) {
+        for (int q = J; q < bt; ++q) {            // X11 is lower triangular: tiles (q, J) with q >= J
+            __syncthreads();
+            dense_tile_load(L + ((int64_t)(r0 + I) * DT) * ld + (int64_t)(c0 + q) * DT, ld, As, false);
+            dense_tile_load(X + ((int64_t)(c0 + q) * DT) * ld + (int64_t)(c0 + J) * DT, ld, Bs, false);
+            __syncthreads();
+            dense_tile_mma(As, Bs, c, ty, tx);
+        }
+        double *o = W + ((int64_t)(r0 + I) * DT) * ld + (int64_t)(c0 + J) * DT;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) o[(int64_t)(ty * 4 + a) * ld + tx * 4 + b] = c[a][b];
+    } else {
+        for (int q = 0; q <= I; ++q) {            // X22 is lower triangular: tiles (I, q) with q <= I
+            __syncthreads();
+            dense_tile_load(X + ((int64_t)(r0 + I) * DT) * ld + (int64_t)(r0 + q) * DT, ld, As, false);
+            dense_tile_load(W + ((int64_t)(r0 + q) * DT) * ld + (int64_t)(c0 + J) * DT, ld, Bs, false);
+            __syncthreads();
+            dense_tile_mma(As, Bs, c, ty, tx);
+        }
+        double *o = X + ((int64_t)(r0 + I) * DT) * ld + (int64_t)(c0 + J) * DT;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) o[(int64_t)(ty * 4 + a) * ld + tx * 4 + b] = -c[a][b];
+    }
+}
 __global__ void __launch_bounds__(256) k_dense_xtx(const double *X, double *Ainv, int64_t ld, int nt) {
     const int I = blockIdx.y, J = blockIdx.x;
     if (J > I) return;
@@ -1907,6 +2053,12 @@ void launch_tl_rap(const TLArgs &t, int64_t nRows, const int32_t *rowPtr, const 
     else hipLaunchKernelGGL(k_tl_rap<2>, dim3(grid), dim3(256), 0, s, t, nRows, rowPtr, colIdx, vals, Ac);
     CHECK_LAUNCH();
 }
+void launch_tl_rap_agg(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const int32_t *binCoord, const int32_t *rowPtr,
+                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s) {
+    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap_agg<3>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac);
+    else hipLaunchKernelGGL(k_tl_rap_agg<2>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac);
+    CHECK_LAUNCH();
+}
 // In-place-style dense SPD inverse: A (mp x mp, mp % 64 == 0) is overwritten by its Cholesky factor, the inverse
 // goes to Ainv; X and Dinv are scratch (mp x mp and (mp/64) x 64 x 64). Returns false if A is not SPD.
 bool dense_spd_inverse_device(double *A, double *X, double *Ainv, double *Dinv, int64_t mp, int *notSpdDev, hipStream_t s) {
@@ -1921,8 +2073,13 @@ bool dense_spd_inverse_device(double *A, double *X, double *Ainv, double *Dinv, 
             hipLaunchKernelGGL(k_dense_syrk, dim3(rem, rem), dim3(256), 0, s, A, mp, k);
         }
     }
-    for (int d = 0; d < nt; ++d)
-        hipLaunchKernelGGL(k_dense_trinv, dim3(nt - d), dim3(256), 0, s, (const double *)A, X, mp, d, (const double *)Dinv);
+    // L^-1: diagonal tiles from the factorisation, then recursive doubling (Ainv doubles as scratch until the last kernel)
+    hipLaunchKernelGGL(k_dense_trinv, dim3(nt), dim3(256), 0, s, (const double *)A, X, mp, 0, (const double *)Dinv);
+    for (int bt = 1; bt < nt; bt *= 2) {
+        const dim3 grid(bt, bt, (nt + 2 * bt - 1) / (2 * bt));
+        hipLaunchKernelGGL(k_dense_linv_level, grid, dim3(256), 0, s, (const double *)A, X, Ainv, mp, nt, bt, 1);
+        hipLaunchKernelGGL(k_dense_linv_level, grid, dim3(256), 0, s, (const double *)A, X, Ainv, mp, nt, bt, 2);
+    }
     hipLaunchKernelGGL(k_dense_xtx, dim3(nt, nt), dim3(256), 0, s, (const double *)X, Ainv, mp, nt);
     CHECK_LAUNCH();
     int bad = 0;

@@ -534,7 +534,7 @@ def test_device_dense_spd_inverse_matches_numpy():
     import ctypes as C
     c = _ctx()
     rng = np.random.default_rng(0)
-    for n in (5, 64, 65, 200, 777):
+    for n in (5, 64, 65, 200, 777, 1500, 2113):          # 24 and 34 tiles: ragged recursive-doubling levels
         B = rng.standard_normal((n, n))
         A = B @ B.T + n * np.eye(n)
         Ai = A.copy()
@@ -572,6 +572,11 @@ def test_two_level_setup_variants_agree():
     u = c.sim_solve(rtol=1e-10)
     assert c.precond_info()["note"] == "" and c.precond_info()["aggregates"] > 1
     out["host_aggregates"] = (u, c.last_info["iterations"])
+    c.set_option("tl_device_aggregates", 1)
+    c.set_option("tl_rap_agg", 0)                       # Galerkin product with one wave per row + global atomics
+    u = c.sim_solve(rtol=1e-10)
+    out["row_rap"] = (u, c.last_info["iterations"])
+    c.set_option("tl_rap_agg", 1)
     its = [v[1] for v in out.values()]
     assert max(its) - min(its) <= 2, its
     for v in out.values():
