@@ -73,6 +73,8 @@ struct mfh_ctx {
     int mfBlockElems = 0;             // option "mf_block_elems": elements per block of the cluster variant (0 = 256)
     DBuf<double> dMfSig;              // two-pass operator: per-element nodal forces
     int mfChunkRows = 256, mfChunkPairs = 2048;   // options "mf_chunk_rows" / "mf_chunk_pairs"
+    bool mfClusterUnfit = false;      // element order without locality on this mesh: cluster variant not applicable
+    int mfModeEff() const { return (mfMode == 4 && mfClusterUnfit) ? 3 : mfMode; }
     int mfMode = 4;                   // option "matrix_free_mode": 4 = cluster variant (default: forces of 256 consecutive elements
                                       // summed in LDS, interface partials only in HBM); 3 = two-pass, forces in list order;
                                       // 2 = two-pass, forces element-major; 1 = per-pair block evaluation (k_spmv_mf)
@@ -195,6 +197,7 @@ void invalidate_symbolic(mfh_ctx *c) {
     c->symValid = false;
     c->mfValid = false;
     c->mfcValid = false;
+    c->mfClusterUnfit = false;
     c->dofUploaded = false;
     invalidate_matrix(c);
 }
@@ -425,9 +428,11 @@ void ensure_mf_cluster(mfh_ctx *c) {
     // same 0.69 ms -- the interface is set by the shape of a run of consecutive elements, not by its alignment
     build_mf_cluster_lists_device(c->mesh, c->dElemNodes.p, device_dof_map(c), c->sym.nRows, c->stream, c->mfc, c->mfcDev,
                                   c->mfBlockElems > 0 ? c->mfBlockElems : MF_BLOCK);
-    // LDS budget of k_mf_cluster: one accumulator per distinct row of a block
-    if ((size_t)c->mfc.maxLocal * c->mesh.dim * sizeof(double) > 60 * 1024) {
-        c->mfMode = 3;   // element order without locality: fall back to the two-pass operator
+    // The cluster variant pays when most rows are finished inside a block: one LDS accumulator per distinct row of a
+    // block (32 KB keeps several workgroups per CU) and an interface buffer well below the per-pair force buffer it replaces.
+    // An element order without locality (e.g. shuffled: ~2560 distinct rows per block) uses the two-pass variant instead.
+    if ((size_t)c->mfc.maxLocal * c->mesh.dim * sizeof(double) > 32 * 1024 || c->mfc.nIface * 3 > c->mesh.nElem * c->mesh.npe) {
+        c->mfClusterUnfit = true;
         return;
     }
     c->mfcValid = true;
@@ -457,7 +462,7 @@ k::SpmvMfArgs spmv_mf_args(mfh_ctx *c, bool masked) {
     k::SpmvMfArgs a{};
     a.dim = m.dim; a.deg = m.deg; a.npe = m.npe; a.mat = c->asmMat();
     a.nChunk = (int64_t)c->mf.chunkRow.size() - 1; a.chunkRow = c->dMfChunkRow.p; a.pairPtr = c->dMfPairPtr.p;
-    a.pairCode = c->dMfPairCode.p; a.pairRow = c->dMfPairRow.p; a.pairPos = c->mfMode == 3 ? c->dMfPairPos.p : nullptr; a.elemNodes = c->dElemNodes.p; a.dofForNode = device_dof_map(c);
+    a.pairCode = c->dMfPairCode.p; a.pairRow = c->dMfPairRow.p; a.pairPos = c->mfModeEff() == 3 ? c->dMfPairPos.p : nullptr; a.elemNodes = c->dElemNodes.p; a.dofForNode = device_dof_map(c);
     a.geo = c->dGeo.p; a.geoStride = c->geoStride; a.pairTable = c->dPairTable.p; a.massTable = c->dMassTable.p;
     for (int k2 = 0; k2 < 6; ++k2) a.pairConst[k2] = c->tables.pairConst[k2];
     a.maxRows = c->mf.maxRows;
@@ -474,9 +479,9 @@ void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double 
     if (c->use_mf()) {
         ensure_geometry(c);
         ensure_mf(c);
-        if (c->mfMode == 4 && c->op == MFH_OP_ELASTICITY) ensure_mf_cluster(c);
-        if (c->mfMode == 4 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf_cluster(spmv_mf_cluster_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
-        else if (c->mfMode >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
+        if (c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY) ensure_mf_cluster(c);
+        if (c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf_cluster(spmv_mf_cluster_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
+        else if (c->mfModeEff() >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
         else k::launch_spmv_mf(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
     } else
         k::launch_spmv(spmv_args(c, masked), x, y, dotOut, c->stream);
@@ -771,8 +776,8 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
         const k::SpmvArgs sa = spmv_args(c, !c->fixedVars.empty());
         const bool useMF = c->use_mf();
         if (useMF) ensure_mf(c);
-        if (useMF && c->mfMode == 4 && c->op == MFH_OP_ELASTICITY) ensure_mf_cluster(c);
-        const bool useCluster = useMF && c->mfMode == 4 && c->op == MFH_OP_ELASTICITY;
+        if (useMF && c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY) ensure_mf_cluster(c);
+        const bool useCluster = useMF && c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY;
         const k::SpmvMfArgs mfa = useCluster ? spmv_mf_cluster_args(c, !c->fixedVars.empty())
                                              : (useMF ? spmv_mf_args(c, !c->fixedVars.empty()) : k::SpmvMfArgs{});
         std::vector<double> hs;
@@ -781,7 +786,7 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
         int lastChecked = 0;
         auto enqueue = [&](int itLocal) {   // one PCG iteration; `itLocal` is relative to the iteration base stop[3]
             if (useCluster) k::launch_spmv_mf_cluster(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
-            else if (useMF && c->mfMode >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
+            else if (useMF && c->mfModeEff() >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
             else if (useMF) k::launch_spmv_mf(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
             else k::launch_pcg_spmv(sa, c->wp.p, c->wAp.p, c->scal.p, itLocal, c->stop.p, s);
             if (useTL) {
@@ -1926,12 +1931,12 @@ mfh_status mfh_matrix_free_info(mfh_ctx *c, int32_t *active, int32_t *mode, int6
     MFH_TRY(c)
     require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
     if (active) *active = c->use_mf() ? 1 : 0;
-    if (c->use_mf() && c->mfMode == 4 && c->op == MFH_OP_ELASTICITY) {
+    if (c->use_mf() && c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY) {
         require_device(c);
         MFH_HIP(hipSetDevice(c->device));
         ensure_mf_cluster(c);
     }
-    if (mode) *mode = c->mfMode;
+    if (mode) *mode = c->mfModeEff();
     if (nBlocks) *nBlocks = c->mfcValid ? c->mfc.nBlocks : 0;
     if (nBlockRows) *nBlockRows = c->mfcValid ? c->mfc.nEntries : 0;
     if (nInterface) *nInterface = c->mfcValid ? c->mfc.nIface : 0;
@@ -2185,7 +2190,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }
     else if (k2 == "xcd_swizzle") c->xcdSwizzle = value != 0;
     else if (k2 == "pcg_graph") c->useGraph = value != 0;
-    else if (k2 == "matrix_free_mode") c->mfMode = (int)value;
+    else if (k2 == "matrix_free_mode") { c->mfMode = (int)value; c->mfClusterUnfit = false; }
     else if (k2 == "mf_block_elems") { c->mfBlockElems = (int)value; c->mfcValid = false; }
     else if (k2 == "mf_chunk_rows") { c->mfChunkRows = std::max(16, std::min(4096, (int)value)); c->mfValid = false; }
     else if (k2 == "mf_chunk_pairs") { c->mfChunkPairs = std::max(256, (int)value); c->mfValid = false; }

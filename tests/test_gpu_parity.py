@@ -825,3 +825,24 @@ def test_matrix_free_is_the_default_for_quadratic_elasticity():
     y_asm = c.apply_K(x)
     assert not np.array_equal(y_auto, y_asm)                       # different summation order ...
     assert np.abs(y_auto - y_asm).max() < 1e-13 * np.abs(y_asm).max()   # ... same operator
+
+
+def test_matrix_free_cluster_variant_falls_back_without_element_locality():
+    """A uniformly shuffled mesh: a block of 256 consecutive elements touches ~2560 distinct rows (no sharing), more
+    than the LDS budget of k_mf_cluster -> the operator falls back to the two-pass variant; generator order uses mode 4."""
+    V, T = grid.grid_tet_mesh(12, 12, 12)
+    modes = {}
+    for name, (Vx, Tx) in (("generator", (V, T)), ("shuffle", grid.reorder_mesh(V, T, "shuffle"))):
+        c = _ctx()
+        c.mesh_build(Tx, Vx, 2)
+        c.material_isotropic(200.0, 0.35)
+        c.assemble()
+        info = c.matrix_free_info()
+        modes[name] = info["mode"]
+        x = np.random.default_rng(0).standard_normal(3 * c.n_node)
+        y_mf = c.apply_K(x)
+        c.set_option("matrix_free", 0)
+        y_asm = c.apply_K(x)
+        assert np.abs(y_mf - y_asm).max() < 1e-13 * np.abs(y_asm).max(), name
+        c.close()
+    assert modes == {"generator": 4, "shuffle": 3}, modes
