@@ -429,9 +429,9 @@ void ensure_mf_cluster(mfh_ctx *c) {
     build_mf_cluster_lists_device(c->mesh, c->dElemNodes.p, device_dof_map(c), c->sym.nRows, c->stream, c->mfc, c->mfcDev,
                                   c->mfBlockElems > 0 ? c->mfBlockElems : MF_BLOCK);
     // The cluster variant pays when most rows are finished inside a block: one LDS accumulator per distinct row of a
-    // block (32 KB keeps several workgroups per CU) and an interface buffer well below the per-pair force buffer it replaces.
+    // block plus the staged x of those rows (48 KB keeps three workgroups per CU) and an interface buffer well below the per-pair force buffer it replaces.
     // An element order without locality (e.g. shuffled: ~2560 distinct rows per block) uses the two-pass variant instead.
-    if ((size_t)c->mfc.maxLocal * c->mesh.dim * sizeof(double) > 32 * 1024 || c->mfc.nIface * 3 > c->mesh.nElem * c->mesh.npe) {
+    if ((size_t)2 * c->mfc.maxLocal * c->mesh.dim * sizeof(double) > 48 * 1024 || c->mfc.nIface * 3 > c->mesh.nElem * c->mesh.npe) {
         c->mfClusterUnfit = true;
         return;
     }

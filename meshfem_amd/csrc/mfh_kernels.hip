@@ -720,14 +720,15 @@ template <int DIM> DEV constexpr int edge_between(int k, int q) {
 
 // nodal forces f_i = int sigma(u) grad phi_i of element e for the nodal vectors gathered from x
 template <int DIM, int DEG, int MAT>
+DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM],
+                          double (&f)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM]);
+
+template <int DIM, int DEG, int MAT>
 DEV void elem_forces(const SpmvMfArgs &a, int64_t e, const double *__restrict__ x,
                      double (&f)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM]) {
-    constexpr int NV = DIM + 1;
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
-    constexpr int FL = DIM * (DIM + 1) / 2;
-    const double *g = a.geo + e * a.geoStride;
     const int32_t *en = a.elemNodes + e * NPE;
-    double xl[NPE][DIM], gl[NV][DIM];
+    double xl[NPE][DIM];
 #pragma unroll
     for (int j = 0; j < NPE; ++j) {
         int64_t col = en[j];
@@ -735,6 +736,18 @@ DEV void elem_forces(const SpmvMfArgs &a, int64_t e, const double *__restrict__ 
 #pragma unroll
         for (int d = 0; d < DIM; ++d) xl[j][d] = x[col * DIM + d];
     }
+    elem_forces_core<DIM, DEG, MAT>(a, e, xl, f);
+}
+
+// the arithmetic of elem_forces on nodal vectors that are already gathered
+template <int DIM, int DEG, int MAT>
+DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM],
+                          double (&f)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM]) {
+    constexpr int NV = DIM + 1;
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    constexpr int FL = DIM * (DIM + 1) / 2;
+    const double *g = a.geo + e * a.geoStride;
+    double gl[NV][DIM];
 #pragma unroll
     for (int k = 0; k < NV; ++k)
 #pragma unroll
@@ -898,8 +911,9 @@ template <int DIM, int DEG, int MAT, bool PCG>
 __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const double *__restrict__ x, double *__restrict__ y, double *dotOut,
                                                          double *scal, int it, const double *stopPtr) {
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
-    extern __shared__ __attribute__((aligned(16))) double clacc[];   // [maxLocal * DIM] + 16
-    double *red = clacc + a.clMaxLocal * DIM;
+    extern __shared__ __attribute__((aligned(16))) double clacc[];   // accumulators [maxLocal * DIM] + staged x [maxLocal * DIM] + 16
+    double *xs = clacc + a.clMaxLocal * DIM;
+    double *red = xs + a.clMaxLocal * DIM;
     if (PCG) {
         it += (int)stopPtr[3];
         if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
@@ -908,18 +922,29 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
     double dot = 0.0;
     for (int64_t b = blockIdx.x; b < a.clBlocks; b += gridDim.x) {
         const int u0 = a.clBlockPtr[b], nLocal = a.clBlockPtr[b + 1] - u0;
-        for (int t = threadIdx.x; t < nLocal * DIM; t += MF_BLOCK) clacc[t] = 0.0;
+        // x of every distinct row of the block is read ONCE into LDS (a block of 256 P2 tets gathers 2560 nodal vectors
+        // but touches only ~580 distinct rows); the lanes then pick their 10 vectors from LDS by local row index
+        for (int t = threadIdx.x; t < nLocal; t += MF_BLOCK) {
+            const int64_t row = a.clEntryRow[u0 + t];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) { xs[t * DIM + d] = x[row * DIM + d]; clacc[t * DIM + d] = 0.0; }
+        }
         __syncthreads();
         const int64_t e = b * a.clBlockElems + threadIdx.x;
         if ((int)threadIdx.x < a.clBlockElems && e < a.nElem) {
-            double f[NPE][DIM];
-            elem_forces<DIM, DEG, MAT>(a, e, x, f);
+            int li[NPE];
+            double xl[NPE][DIM], f[NPE][DIM];
 #pragma unroll
             for (int j = 0; j < NPE; ++j) {
-                const int li = a.clLocalIdx[e * NPE + j];
+                li[j] = a.clLocalIdx[e * NPE + j];
 #pragma unroll
-                for (int d = 0; d < DIM; ++d) unsafeAtomicAdd(&clacc[li * DIM + d], f[j][d]);
+                for (int d = 0; d < DIM; ++d) xl[j][d] = xs[li[j] * DIM + d];
             }
+            elem_forces_core<DIM, DEG, MAT>(a, e, xl, f);
+#pragma unroll
+            for (int j = 0; j < NPE; ++j)
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) unsafeAtomicAdd(&clacc[li[j] * DIM + d], f[j][d]);
         }
         __syncthreads();
         for (int t = threadIdx.x; t < nLocal; t += MF_BLOCK) {
@@ -1967,7 +1992,7 @@ void launch_spmv_mf2(const SpmvMfArgs &a, const double *x, double *y, double *do
 // cluster variant of the matrix-free elasticity operator (k_mf_cluster + k_mf_rows over the interface partials)
 void launch_spmv_mf_cluster(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
                             bool pcg, hipStream_t s) {
-    const size_t ldsC = ((size_t)a.clMaxLocal * a.dim + 16) * sizeof(double);
+    const size_t ldsC = ((size_t)2 * a.clMaxLocal * a.dim + 16) * sizeof(double);
     const int gridC = (int)std::min<int64_t>(a.clBlocks, 256 * 64);
 #define CALL(D, G, M)                                                                                                                  \
     if (pcg) hipLaunchKernelGGL((k_mf_cluster<D, G, M, true>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, (double *)nullptr, scal, it, stopPtr); \

@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) k_mfc_gen(int64_t N, int npe, int blockEl
         if (dofForNode) row = dofForNode[row];
         const bool ok = row < nRows;
         const uint64_t b = (uint64_t)((k / npe) / blockElems);
-        key[k] = (b << 32) | (ok ? (uint64_t)row : 0xffffffffull);
+        key[k] = (b << 32) | (uint64_t)row;              // rows of other ranks (row >= nRows) keep their id: x is gathered through the entries
         val[k] = (uint32_t)k;
         if (ok) atomicAdd(&rowCount[row], 1);
     }
@@ -340,19 +340,18 @@ __global__ void __launch_bounds__(256) k_mfc_entries(int64_t n, const uint64_t *
         const uint64_t kk = key[k];
         if (k != 0 && kk == key[k - 1]) continue;
         const int32_t u = (int32_t)(entP1[k] - 1);
-        const uint32_t r = (uint32_t)(kk & 0xffffffffu);
-        entryRow[u] = r == 0xffffffffu ? -1 : (int32_t)r;
+        entryRow[u] = (int32_t)(kk & 0xffffffffu);
         entryStart[u] = (int32_t)k;
         if (k == 0 || (kk >> 32) != (key[k - 1] >> 32)) blockPtr[kk >> 32] = u;
     }
 }
 // entry classification + interface keys; local index of every pair
-__global__ void __launch_bounds__(256) k_mfc_classify(int64_t nU, int64_t nSorted, const int32_t *__restrict__ entryRow,
+__global__ void __launch_bounds__(256) k_mfc_classify(int64_t nU, int64_t nSorted, int64_t nRows, const int32_t *__restrict__ entryRow,
                                                       const int32_t *__restrict__ entryStart, const int32_t *__restrict__ rowCount,
                                                       int32_t *__restrict__ entryDest, int32_t *__restrict__ rowIfaceCount) {
     for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < nU; u += (int64_t)gridDim.x * 256) {
         const int32_t row = entryRow[u];
-        if (row < 0) { entryDest[u] = -2; continue; }
+        if (row >= nRows) { entryDest[u] = -2; continue; }       // row owned by another rank: a column only
         const int32_t cnt = (u + 1 < nU ? entryStart[u + 1] : (int32_t)nSorted) - entryStart[u];
         if (cnt == rowCount[row]) entryDest[u] = -1;            // every element of the row is in this block
         else { entryDest[u] = 0; atomicAdd(&rowIfaceCount[row], 1); }
@@ -437,7 +436,7 @@ void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes,
     for (int64_t b = 0; b < L.nBlocks; ++b) L.maxLocal = std::max(L.maxLocal, hBlockPtr[b + 1] - hBlockPtr[b]);
     // ---- classification: finished in the block, or interface
     rowIfaceCount.alloc((size_t)nRows + 1); rowIfaceCount.zero(s);
-    hipLaunchKernelGGL(k_mfc_classify, dim3(grid_of(nU)), dim3(256), 0, s, nU, N, D.entryRow.p, entryStart.p, rowCount.p, D.entryDest.p,
+    hipLaunchKernelGGL(k_mfc_classify, dim3(grid_of(nU)), dim3(256), 0, s, nU, N, nRows, D.entryRow.p, entryStart.p, rowCount.p, D.entryDest.p,
                        rowIfaceCount.p);
     RP(hipGetLastError());
     keyB.release(); valB.release(); entP1.release(); entryStart.release();
