@@ -719,9 +719,9 @@ template <int DIM> DEV constexpr int edge_between(int k, int q) {
 }
 
 // nodal forces f_i = int sigma(u) grad phi_i of element e for the nodal vectors gathered from x
-template <int DIM, int DEG, int MAT>
+template <int DIM, int DEG, int MAT, class Emit>
 DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM],
-                          double (&f)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM]);
+                          const Emit &emit);
 
 template <int DIM, int DEG, int MAT>
 DEV void elem_forces(const SpmvMfArgs &a, int64_t e, const double *__restrict__ x,
@@ -736,13 +736,17 @@ DEV void elem_forces(const SpmvMfArgs &a, int64_t e, const double *__restrict__ 
 #pragma unroll
         for (int d = 0; d < DIM; ++d) xl[j][d] = x[col * DIM + d];
     }
-    elem_forces_core<DIM, DEG, MAT>(a, e, xl, f);
+    elem_forces_core<DIM, DEG, MAT>(a, e, xl, [&](int j, const double *fv) {
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) f[j][d] = fv[d];
+    });
 }
 
-// the arithmetic of elem_forces on nodal vectors that are already gathered
-template <int DIM, int DEG, int MAT>
+// the arithmetic of elem_forces on nodal vectors that are already gathered; every nodal force is handed to `emit(j, f_j)`
+// as soon as it is complete (the cluster kernel adds it to LDS right away instead of keeping 30 values live)
+template <int DIM, int DEG, int MAT, class Emit>
 DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM],
-                          double (&f)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM]) {
+                          const Emit &emit) {
     constexpr int NV = DIM + 1;
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
     constexpr int FL = DIM * (DIM + 1) / 2;
@@ -768,10 +772,6 @@ DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DI
 #pragma unroll
             for (int q2 = 0; q2 < DIM; ++q2) o[p] += T[flat_idx<DIM>(p, q2)] * v[q2];
     };
-#pragma unroll
-    for (int j = 0; j < NPE; ++j)
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) f[j][d] = 0.0;
     if (DEG == 1) {
         double G[DIM][DIM];
 #pragma unroll
@@ -788,7 +788,11 @@ DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DI
 #pragma unroll
         for (int c = 0; c < FL; ++c) sg[c] *= vol;
 #pragma unroll
-        for (int j = 0; j < NV; ++j) symv(sg, gl[j], f[j]);
+        for (int j = 0; j < NV; ++j) {
+            double fv[DIM] = {};
+            symv(sg, gl[j], fv);
+            emit(j, fv);
+        }
     } else {
         constexpr double c0 = DIM == 3 ? 0.58541019662496845446 : 2.0 / 3.0;     // GaussQuadrature.hh:283-295 / :115-127
         constexpr double c1 = DIM == 3 ? 0.13819660112501051518 : 1.0 / 6.0;
@@ -842,7 +846,9 @@ DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DI
             double T[FL];
 #pragma unroll
             for (int c = 0; c < FL; ++c) T[c] = (vol * wq * b_) * S[c] + R[k][c];
-            symv(T, gl[k], f[k]);
+            double fv[DIM] = {};
+            symv(T, gl[k], fv);
+            emit(k, fv);
         }
 #pragma unroll
         for (int c = 0; c < FL; ++c) S[c] *= vol * wq * B_;
@@ -852,8 +858,10 @@ DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DI
             double T1[FL], T2[FL];
 #pragma unroll
             for (int c = 0; c < FL; ++c) { T1[c] = S[c] + R[tI][c]; T2[c] = S[c] + R[sI][c]; }
-            symv(T1, gl[sI], f[NV + m]);
-            symv(T2, gl[tI], f[NV + m]);
+            double fv[DIM] = {};
+            symv(T1, gl[sI], fv);
+            symv(T2, gl[tI], fv);
+            emit(NV + m, fv);
         }
     }
 }
@@ -933,18 +941,17 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
         const int64_t e = b * a.clBlockElems + threadIdx.x;
         if ((int)threadIdx.x < a.clBlockElems && e < a.nElem) {
             int li[NPE];
-            double xl[NPE][DIM], f[NPE][DIM];
+            double xl[NPE][DIM];
 #pragma unroll
             for (int j = 0; j < NPE; ++j) {
                 li[j] = a.clLocalIdx[e * NPE + j];
 #pragma unroll
                 for (int d = 0; d < DIM; ++d) xl[j][d] = xs[li[j] * DIM + d];
             }
-            elem_forces_core<DIM, DEG, MAT>(a, e, xl, f);
+            elem_forces_core<DIM, DEG, MAT>(a, e, xl, [&](int j, const double *fv) {
 #pragma unroll
-            for (int j = 0; j < NPE; ++j)
-#pragma unroll
-                for (int d = 0; d < DIM; ++d) unsafeAtomicAdd(&clacc[li[j] * DIM + d], f[j][d]);
+                for (int d = 0; d < DIM; ++d) unsafeAtomicAdd(&clacc[li[j] * DIM + d], fv[d]);
+            });
         }
         __syncthreads();
         for (int t = threadIdx.x; t < nLocal; t += MF_BLOCK) {
