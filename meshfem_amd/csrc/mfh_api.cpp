@@ -474,12 +474,19 @@ k::SpmvMfArgs spmv_mf_args(mfh_ctx *c, bool masked) {
     return a;
 }
 
+// lists of the matrix-free operator in use: the cluster variant needs only its own; the pair lists (modes 1-3, scalar
+// operators, fallback of the cluster variant) are built on demand
+bool prepare_matrix_free(mfh_ctx *c) {
+    if (!c->use_mf()) return false;
+    ensure_geometry(c);
+    if (c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY) ensure_mf_cluster(c);
+    if (!(c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY)) ensure_mf(c);
+    return true;
+}
+
 // y = K x through the assembled matrix or the matrix-free operator (option "matrix_free")
 void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double *dotOut) {
-    if (c->use_mf()) {
-        ensure_geometry(c);
-        ensure_mf(c);
-        if (c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY) ensure_mf_cluster(c);
+    if (prepare_matrix_free(c)) {
         if (c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf_cluster(spmv_mf_cluster_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
         else if (c->mfModeEff() >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
         else k::launch_spmv_mf(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
@@ -738,6 +745,7 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
     c->wx.alloc(n); c->wr.alloc(n); c->wz.alloc(n); c->wp.alloc(n); c->wAp.alloc(n); c->wb.alloc(n); c->wf.alloc(n);
     c->stop.alloc(4);
     EventTimer tsetup(s);
+    prepare_matrix_free(c);   // gather lists of the operator: once per mesh / DoF map, part of the setup time
     MFH_HIP(hipMemcpyAsync(c->wf.p, f, n * sizeof(double), hipMemcpyHostToDevice, s));
     // b = f - K ubar on the free variables (SparseMatrices.hh:2457-2470,2526-2535)
     MFH_HIP(hipMemcpyAsync(c->wb.p, c->wf.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
@@ -775,8 +783,6 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
         }
         const k::SpmvArgs sa = spmv_args(c, !c->fixedVars.empty());
         const bool useMF = c->use_mf();
-        if (useMF) ensure_mf(c);
-        if (useMF && c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY) ensure_mf_cluster(c);
         const bool useCluster = useMF && c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY;
         const k::SpmvMfArgs mfa = useCluster ? spmv_mf_cluster_args(c, !c->fixedVars.empty())
                                              : (useMF ? spmv_mf_args(c, !c->fixedVars.empty()) : k::SpmvMfArgs{});
