@@ -846,3 +846,51 @@ def test_matrix_free_cluster_variant_falls_back_without_element_locality():
         assert np.abs(y_mf - y_asm).max() < 1e-13 * np.abs(y_asm).max(), name
         c.close()
     assert modes == {"generator": 4, "shuffle": 3}, modes
+
+
+@pytest.mark.parametrize("dim", [2, 3])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_random_delaunay_meshes(dim, seed):
+    """Unstructured meshes with irregular valence (Delaunay of random points, slivers included): mesh numbering,
+    K (<= 1e-12 rel; slivers amplify round-off through 1/vol), matrix-free operator, and the solve against the oracle."""
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    P = rng.random((60 if dim == 3 else 80, dim))
+    P = np.vstack([P, np.array(list(np.ndindex(*(2,) * dim)), dtype=float)])      # the unit box corners: a convex hull with flat faces
+    T = Delaunay(P).simplices.astype(np.int64)
+    Pe = P[T]
+    vol = np.linalg.det(Pe[:, 1:] - Pe[:, :1])
+    T[vol < 0] = T[vol < 0][:, [1, 0] + list(range(2, dim + 1))]                  # positive orientation
+    keep = np.abs(vol) > 1e-9                                                     # drop degenerate (flat) simplices
+    T = T[keep]
+    used = np.unique(T)
+    remap = np.full(len(P), -1); remap[used] = np.arange(len(used))
+    P, T = P[used], remap[T]
+    for deg in (1, 2):
+        sim = O.Simulator(T, P, deg)
+        ten = O.ElasticityTensor.isotropic(dim, 200.0, 0.35)
+        sim.set_material_constant(ten)
+        c = _ctx()
+        c.mesh_build(T, P, deg)
+        assert np.array_equal(c.elem_nodes(), sim.mesh.elem_nodes)
+        assert np.array_equal(c.boundary_nodes(), sim.mesh.bdry_nodes)
+        c.material_isotropic(200.0, 0.35)
+        c.assemble()
+        Kref = sim.assembleStiffnessMatrix().sum_repeated().to_scipy_full_from_upper()
+        A = c.export_scipy()
+        assert abs(A - Kref).max() < 1e-12 * abs(Kref).max()
+        x = rng.standard_normal(dim * c.n_node)
+        c.set_option("matrix_free", 1)
+        assert np.abs(c.apply_K(x) - Kref @ x).max() < 1e-11 * np.abs(Kref @ x).max()
+        c.set_option("matrix_free", -1)
+        lo, hi = [-1e-9] + [-9.0] * (dim - 1), [1e-9] + [9.0] * (dim - 1)
+        sim.apply_dirichlet_box(lo, hi, [0.0] * dim)
+        c.bc_dirichlet_box(lo, hi, [0.0] * dim)
+        lo2, hi2 = [1 - 1e-9] + [-9.0] * (dim - 1), [1 + 1e-9] + [9.0] * (dim - 1)
+        trac = [0.0, -1.0, 0.0][:dim]
+        sim.apply_neumann_box(lo2, hi2, trac, "traction")
+        c.bc_neumann_box(lo2, hi2, trac)
+        assert np.abs(c.neumann_load() - sim.neumannLoad()).max() < 1e-13
+        u = c.sim_solve(rtol=1e-11, maxit=200000)
+        assert np.linalg.norm(u - sim.solve()) < U_RTOL * np.linalg.norm(u)
+        c.close()
