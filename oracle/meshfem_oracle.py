@@ -14,10 +14,15 @@ the reference's own tests pin are checked against those golden values in tests/t
   * shape functions / grads  <- tests/test_shape_functions.cc:14-66
   * Voigt flattening         <- tests/test_tensors.cc:4-27
   * triplet/CSC/matvec       <- tests/test_sparse_matrices.cc:7-160
+  * interpolants             <- tests/test_interpolant.cc:28-66
+  * mass matrix L2 identity  <- tests/test_mass.cc:6-45 (on the reference's ball.msh / square_hole.off)
+  * material JSON samples    <- tests/test_materials.cc:28-90
 The end-to-end result (perElementStiffness -> K -> CHOLMOD solve) is pinned by NO reference test
 and CHOLMOD itself (SuiteSparse, conda pin 5.4.0) is absent: for that boundary this oracle is
 "PARITY UNPINNED" -- it is anchored instead on exact mathematics (sympy rational Ke, patch tests,
-rigid-mode null space, energy identity) and scipy.sparse.linalg.splu stands in for CHOLMOD.
+rigid-mode null space, energy identity) and scipy.sparse.linalg.splu stands in for CHOLMOD (a general sparse LU of
+the KKT matrix for UMFPACK in the constraint-row branch). Also restated here: Laplacian.hh / MassMatrix.hh / Poisson.hh,
+both homogenized-tensor forms of PeriodicHomogenization.hh, assembleConstrainedSystem's rigid-motion rows.
 
 All `file:line` citations are relative to /root/reference/src/lib/MeshFEM/ unless noted.
 """
