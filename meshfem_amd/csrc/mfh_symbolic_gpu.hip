@@ -753,6 +753,43 @@ __global__ void __launch_bounds__(256) k_topo_face_flags(int64_t n, const uint64
         if (sameP && sameN) *nonManifold = 1;
     }
 }
+// wide variant for meshes with >= 2^21 vertices: the sorted (lo, mid, hi) vertex triple does not fit one 64-bit key, so the
+// faces are ordered by two stable sorts (hi, then lo:mid) and the triples are compared through the instance ids
+__device__ inline void topo_face_triple(const int32_t *__restrict__ ev, uint32_t inst, uint32_t &lo, uint32_t &mid, uint32_t &hi) {
+    const int64_t t = inst >> 2;
+    const int f = (int)(inst & 3);
+    const uint32_t x = (uint32_t)ev[t * 4 + kFaceC[f][0]], y = (uint32_t)ev[t * 4 + kFaceC[f][1]], z = (uint32_t)ev[t * 4 + kFaceC[f][2]];
+    lo = min(x, min(y, z)); hi = max(x, max(y, z)); mid = x ^ y ^ z ^ lo ^ hi;
+}
+__global__ void __launch_bounds__(256) k_topo_face_keys_wide(int64_t nInst, const int32_t *__restrict__ ev, uint32_t *__restrict__ keyHi32,
+                                                             uint32_t *__restrict__ val) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nInst; k += (int64_t)gridDim.x * 256) {
+        uint32_t lo, mid, hi;
+        topo_face_triple(ev, (uint32_t)k, lo, mid, hi);
+        keyHi32[k] = hi;
+        val[k] = (uint32_t)k;
+    }
+}
+__global__ void __launch_bounds__(256) k_topo_face_keys_lomid(int64_t n, const int32_t *__restrict__ ev, const uint32_t *__restrict__ inst,
+                                                              uint64_t *__restrict__ key) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        uint32_t lo, mid, hi;
+        topo_face_triple(ev, inst[k], lo, mid, hi);
+        key[k] = ((uint64_t)lo << 32) | mid;
+    }
+}
+__global__ void __launch_bounds__(256) k_topo_face_flags_wide(int64_t n, const int32_t *__restrict__ ev, const uint32_t *__restrict__ inst,
+                                                              uint32_t *__restrict__ flag, int *nonManifold) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        uint32_t a0, a1, a2, b0, b1, b2;
+        topo_face_triple(ev, inst[k], a0, a1, a2);
+        bool sameP = false, sameN = false;
+        if (k > 0) { topo_face_triple(ev, inst[k - 1], b0, b1, b2); sameP = a0 == b0 && a1 == b1 && a2 == b2; }
+        if (k + 1 < n) { topo_face_triple(ev, inst[k + 1], b0, b1, b2); sameN = a0 == b0 && a1 == b1 && a2 == b2; }
+        flag[k] = (!sameP && !sameN) ? 1u : 0u;
+        if (sameP && sameN) *nonManifold = 1;
+    }
+}
 __global__ void __launch_bounds__(256) k_topo_face_compact(int64_t n, const uint32_t *__restrict__ val, const uint32_t *__restrict__ flag,
                                                            const uint32_t *__restrict__ posP1, uint32_t *__restrict__ out) {
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
@@ -760,12 +797,13 @@ __global__ void __launch_bounds__(256) k_topo_face_compact(int64_t n, const uint
 }
 } // namespace
 
-// Returns false when the mesh does not fit the packed keys (>= 2^21 vertices in 3D): the caller then uses
-// the host implementation. instEdge: nElem*nedge first-encounter edge-node ranks (deg 2 only);
+// Always returns true (kept for the caller's host fallback switch); meshes with >= 2^21 vertices in 3D use the
+// two-sort variant of the half-face ordering. instEdge: nElem*nedge first-encounter edge-node ranks (deg 2 only);
 // bdryInst: half-face (4t+f) / half-edge (3t+c) instances without a mate, in sorted-key order.
 bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *hostElemVerts, hipStream_t s,
                            std::vector<int32_t> &instEdge, int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst) {
-    if (dim == 3 && nVert >= (1 << 21)) return false;
+    // packed 3 x 21-bit face keys do not fit beyond 2^21 vertices: two-sort variant below (MFH_TOPO_FORCE_WIDE: tests)
+    const bool wide = dim == 3 && (nVert >= (1 << 21) || getenv("MFH_TOPO_FORCE_WIDE") != nullptr);
     const int nv = dim + 1, nedge = dim == 3 ? 6 : 3;
     DBuf<int32_t> dEv;
     dEv.upload(hostElemVerts, (size_t)nElem * nv, s);
@@ -814,13 +852,30 @@ bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const
         DBuf<int> nm;
         kA.alloc(n); kB.alloc(n); vA.alloc(n); vB.alloc(n); flag.alloc(n); posP1.alloc(n); nm.alloc(1);
         nm.zero(s);
-        hipLaunchKernelGGL(k_topo_face_keys, dim3(grid_of(n)), dim3(256), 0, s, n, dim, dEv.p, kA.p, vA.p);
         size_t b = 0;
+        if (wide) {
+            // order by (lo, mid, hi): stable sort by hi, then stable sort by lo:mid
+            DBuf<uint32_t> h32A, h32B;
+            h32A.alloc(n); h32B.alloc(n);
+            hipLaunchKernelGGL(k_topo_face_keys_wide, dim3(grid_of(n)), dim3(256), 0, s, n, dEv.p, h32A.p, vA.p);
+            RP(rocprim::radix_sort_pairs(nullptr, b, h32A.p, h32B.p, vA.p, vB.p, (size_t)n, 0u, bits_for((uint64_t)nVert), s));
+            ensureTmp(b);
+            RP(rocprim::radix_sort_pairs(tmp.p, b, h32A.p, h32B.p, vA.p, vB.p, (size_t)n, 0u, bits_for((uint64_t)nVert), s));
+            hipLaunchKernelGGL(k_topo_face_keys_lomid, dim3(grid_of(n)), dim3(256), 0, s, n, dEv.p, vB.p, kA.p);
+            const unsigned eb = 32 + bits_for((uint64_t)nVert);
+            RP(rocprim::radix_sort_pairs(nullptr, b, kA.p, kB.p, vB.p, vA.p, (size_t)n, 0u, eb, s));
+            ensureTmp(b);
+            RP(rocprim::radix_sort_pairs(tmp.p, b, kA.p, kB.p, vB.p, vA.p, (size_t)n, 0u, eb, s));
+            MFH_HIP(hipMemcpyAsync(vB.p, vA.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));   // vB = sorted instances, as below
+            hipLaunchKernelGGL(k_topo_face_flags_wide, dim3(grid_of(n)), dim3(256), 0, s, n, dEv.p, vB.p, flag.p, nm.p);
+        } else {
+        hipLaunchKernelGGL(k_topo_face_keys, dim3(grid_of(n)), dim3(256), 0, s, n, dim, dEv.p, kA.p, vA.p);
         const unsigned endBit = dim == 3 ? 63u : 32 + bits_for((uint64_t)nVert);
         RP(rocprim::radix_sort_pairs(nullptr, b, kA.p, kB.p, vA.p, vB.p, (size_t)n, 0u, endBit, s));
         ensureTmp(b);
         RP(rocprim::radix_sort_pairs(tmp.p, b, kA.p, kB.p, vA.p, vB.p, (size_t)n, 0u, endBit, s));
         hipLaunchKernelGGL(k_topo_face_flags, dim3(grid_of(n)), dim3(256), 0, s, n, kB.p, flag.p, nm.p);
+        }
         RP(rocprim::inclusive_scan(nullptr, b, flag.p, posP1.p, (size_t)n, rocprim::plus<uint32_t>(), s));
         ensureTmp(b);
         RP(rocprim::inclusive_scan(tmp.p, b, flag.p, posP1.p, (size_t)n, rocprim::plus<uint32_t>(), s));

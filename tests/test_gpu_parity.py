@@ -648,6 +648,20 @@ def test_device_topology_identical_to_host(dim, deg):
     c = _ctx()
     with pytest.raises(M.MeshFEMHipError, match="manifold"):
         c.mesh_build(np.array([[0, 1, 2, 3], [0, 1, 2, 4], [0, 1, 2, 5]]), np.random.default_rng(0).random((6, 3)), 1)
+    if dim == 3:
+        # meshes with >= 2^21 vertices order the half-faces by two stable sorts instead of one packed key: same result
+        import os
+        os.environ["MFH_TOPO_FORCE_WIDE"] = "1"
+        try:
+            c = _ctx()
+            c.mesh_build(T, V, deg)
+            assert np.array_equal(c.elem_nodes(), m.elem_nodes)
+            assert np.array_equal(c.boundary_elem_nodes(), m.bdry_elem_nodes)
+            assert np.array_equal(c.boundary_nodes(), m.bdry_nodes)
+            with pytest.raises(M.MeshFEMHipError, match="manifold"):
+                _ctx().mesh_build(np.array([[0, 1, 2, 3], [0, 1, 2, 4], [0, 1, 2, 5]]), np.random.default_rng(0).random((6, 3)), 1)
+        finally:
+            del os.environ["MFH_TOPO_FORCE_WIDE"]
 
 
 # ---- the reference's unstructured example meshes (tests/golden/meshes) against the committed oracle goldens
