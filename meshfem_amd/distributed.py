@@ -70,6 +70,47 @@ def _needs_staging(device, group=None):
     return torch.device(device).type == "cuda" and dist.is_initialized() and dist.get_backend(group) == "gloo"
 
 
+def rcb_node_owner(node_pos, world):
+    """Recursive coordinate bisection of the nodes ("general meshes: RCB"): split the longest axis of
+    the bounding box at the weighted median, recursively, into `world` parts of (almost) equal node counts. Deterministic
+    (stable sort on (coordinate, node index)), so every rank computes the same owners from the same global mesh."""
+    pos = np.asarray(node_pos, dtype=np.float64)
+    owner = np.zeros(len(pos), dtype=np.int64)
+
+    def split(idx, first, parts):
+        if parts == 1 or len(idx) == 0:
+            owner[idx] = first
+            return
+        left_parts = parts // 2
+        ext = pos[idx].max(axis=0) - pos[idx].min(axis=0)
+        ax = int(np.argmax(ext))
+        order = idx[np.lexsort((idx, pos[idx, ax]))]
+        cut = (len(idx) * left_parts) // parts
+        split(order[:cut], first, left_parts)
+        split(order[cut:], first + left_parts, parts - left_parts)
+
+    split(np.arange(len(pos)), 0, int(world))
+    return owner
+
+
+def distribute_mesh(vertices, elements, degree, rank, world):
+    """A rank's LocalMesh of a GLOBAL mesh that every rank holds (general unstructured meshes of moderate size; the
+    synthetic slabs below never materialise the global mesh): FEM node numbering on the host, RCB ownership of the
+    nodes, then the generic `partition`. Keys are the global node ids."""
+    from .core import Context
+    h = Context(-1)                                        # host-only: edge-node numbering (FEMMesh.inl:22-36)
+    h.mesh_build(np.asarray(elements), np.asarray(vertices, dtype=np.float64), degree)
+    en, pos = h.elem_nodes().astype(np.int64), h.node_positions()
+    bnodes = h.boundary_nodes()
+    h.close()
+    owner = rcb_node_owner(pos, world)
+    lm = partition(en, pos, np.arange(len(pos), dtype=np.int64), owner, rank)
+    lm.global_is_boundary = np.zeros(len(pos), dtype=bool)
+    lm.global_is_boundary[bnodes] = True
+    lm.n_global = len(pos)
+    return lm
+
+
 class HaloExchange:
     """Point-to-point exchange lists. Every rank asks the owners for its halo nodes by key."""
 
