@@ -50,7 +50,7 @@ def homogenized_elasticity_tensor(sim: Simulator, w_ij, base_cell_volume=0.0):
     for i in range(fl):
         u_lin = pos @ _unflatten(N, canonical_strain_flat(N, i)).T
         sig = sim.averageStressField(w_ij[i] + u_lin)
-        Eh[i, :] = (vol[:, None] * sig).sum(axis=0) / base_cell_volume
+        Eh[i, :] = (vol @ sig) / base_cell_volume
     return Eh
 
 
