@@ -392,7 +392,7 @@ def distributed_pcg(ops, halo, f_owned, rtol=1e-8, maxit=20000, group=None, chec
 # ------------------------------------------------------------------------------------------------
 # synthetic z-slab meshes (weak scaling): the reference generator restricted to a z-range
 # ------------------------------------------------------------------------------------------------
-def slab_local_mesh(n, rank, world, deg=2, layers=None):
+def slab_local_mesh(n, rank, world, deg=2, layers=None, device=-1):
     """Grid n x n x (layers*world) of cubic cells of size 1/n; rank owns hex layers [layers*rank, layers*(rank+1))
     (layers defaults to n: a cube per rank). Returns the LocalMesh plus integer lattice coordinates (units of
     1/(4n)) of every local node."""
@@ -403,7 +403,7 @@ def slab_local_mesh(n, rank, world, deg=2, layers=None):
     top = 1 if rank < world - 1 else 0                 # one halo hex layer above the owned interface plane
     V, H = grid.gen_grid_3d(n, n, z1 - z0 + top, z0=z0)
     V, T = grid.hex_tet_subdiv(V, H)
-    h = Context(-1)                                    # host-only: P2 node numbering (FEMMesh.inl:22-36)
+    h = Context(device)                                # P2 node numbering (FEMMesh.inl:22-36): host (-1) or device radix sorts
     h.mesh_build(T, V, deg)
     en, pos = h.elem_nodes().astype(np.int64), h.node_positions()
     h.close()
@@ -497,7 +497,7 @@ def bench_slabs(args, rank, world, local_rank):
     n = int(round(args.grid * world ** (1.0 / 3.0)))
     layers = max(1, int(round(args.grid ** 3 / float(n * n))))
     t0 = time.time()
-    lm = slab_local_mesh(n, rank, world, deg, layers)
+    lm = slab_local_mesh(n, rank, world, deg, layers, device=local_rank)
     t_mesh = time.time() - t0
     c = M.Context(local_rank)
     c.mesh_set(3, deg, lm.elem_nodes, lm.node_pos, lm.n_owned)
