@@ -510,7 +510,7 @@ void ensure_precond(mfh_ctx *c) {
     ensure_fixed_uploaded(c);
     if (c->dinvValid) return;
     const int d = c->bs();
-    c->dDinv.alloc((size_t)c->sym.nRows * d * d);
+    c->dDinv.alloc((size_t)c->sym.nRows * (d * (d + 1) / 2));   // symmetric-packed inverse diagonal blocks
     k::launch_extract_diag_inv(d, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, c->dFixedMask.p,
                                c->precond == MFH_PRECOND_TWO_LEVEL ? MFH_PRECOND_BLOCK_JACOBI : c->precond, c->dDinv.p, c->stream);
     c->dinvValid = true;

@@ -1101,16 +1101,25 @@ __global__ void __launch_bounds__(256) k_diag_inv(int64_t nRows, const int32_t *
 #pragma unroll
         for (int c = 0; c < DIM; ++c) Inv[c * DIM + c] = kind == 1 ? 1.0 / A[c * DIM + c] : 1.0;
     }
+    // the inverse of a symmetric block is symmetric: stored packed (flat symmetric index), 6 instead of 9 values in 3D
+    constexpr int NS = DIM * (DIM + 1) / 2;
 #pragma unroll
-    for (int c = 0; c < NB; ++c) dinv[r * NB + c] = Inv[c];
+    for (int c = 0; c < DIM; ++c)
+#pragma unroll
+        for (int d = c; d < DIM; ++d) dinv[r * NS + flat_idx<DIM>(c, d)] = 0.5 * (Inv[c * DIM + d] + Inv[d * DIM + c]);
 }
 
+// z = D^-1 r with the symmetric-packed inverse diagonal block (DIM (DIM+1)/2 values per block row)
 template <int DIM> DEV void apply_block(const double *__restrict__ Dm, const double *r, double *z) {
+    constexpr int NS = DIM * (DIM + 1) / 2;
+    double m[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) m[q] = Dm[q];
 #pragma unroll
     for (int c = 0; c < DIM; ++c) {
         double v = 0;
 #pragma unroll
-        for (int d = 0; d < DIM; ++d) v += Dm[c * DIM + d] * r[d];
+        for (int d = 0; d < DIM; ++d) v += m[flat_idx<DIM>(c, d)] * r[d];
         z[c] = v;
     }
 }
@@ -1122,7 +1131,7 @@ __global__ void __launch_bounds__(256) k_precond(int64_t nRows, const double *__
         double rv[DIM], zv[DIM];
 #pragma unroll
         for (int c = 0; c < DIM; ++c) rv[c] = r[n * DIM + c];
-        apply_block<DIM>(dinv + n * DIM * DIM, rv, zv);
+        apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
 #pragma unroll
         for (int c = 0; c < DIM; ++c) z[n * DIM + c] = zv[c];
     }
@@ -1425,7 +1434,7 @@ __global__ void __launch_bounds__(256) k_tl_apply(TLArgs t, const double *__rest
         double rv[DIM], zv[DIM];
 #pragma unroll
         for (int c = 0; c < DIM; ++c) rv[c] = r[n * DIM + c];
-        apply_block<DIM>(dinv + n * DIM * DIM, rv, zv);
+        apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
         const int a = t.aggOfDof[n];
         double rp[3] = {t.relPos[n * 3], t.relPos[n * 3 + 1], t.relPos[n * 3 + 2]};
 #pragma unroll
@@ -1674,7 +1683,7 @@ __global__ void __launch_bounds__(256) k_pcg_init(int64_t nRows, const double *_
         double rv[DIM], zv[DIM];
 #pragma unroll
         for (int c = 0; c < DIM; ++c) rv[c] = b[n * DIM + c];
-        apply_block<DIM>(dinv + n * DIM * DIM, rv, zv);
+        apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
             x[n * DIM + c] = 0.0; r[n * DIM + c] = rv[c]; z[n * DIM + c] = zv[c]; p[n * DIM + c] = zv[c];
@@ -1705,7 +1714,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
             r[g] = rv[c];
         }
         if (!SKIPZ) {
-            apply_block<DIM>(dinv + n * DIM * DIM, rv, zv);
+            apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
 #pragma unroll
             for (int c = 0; c < DIM; ++c) { z[n * DIM + c] = zv[c]; acc[0] += rv[c] * zv[c]; }
         }
