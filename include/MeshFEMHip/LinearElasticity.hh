@@ -14,6 +14,7 @@
 //       m_assembleStiffnessMatrix(K)      (:1408-1466)     same (upper triplets, summed)
 //       applyStiffnessMatrix(u)           (:801-823)       same
 //       averageStrainField/StressField    (:528-549)       same
+//       applyDeltaStiffnessMatrix, deltaConstantStrainLoad, deltaAverageStrainField (:1301-1374)   same
 //     SPSDSystem<Real>                                   MeshFEMHip::SPSDSystem
 //       fixVariables(vars, vals), solve(f, u)  (SparseMatrices.hh:2389-2606)   same
 //
@@ -200,6 +201,23 @@ public:
         SMField s((size_t)m_numElements);
         check(ctx(), mfh_average_stress(ctx(), &uNodes[0][0], &s[0][0]));
         return s;
+    }
+
+    // ---- discrete shape derivatives, forward mode (:1297-1374); deltaP is a per-vertex field
+    VField applyDeltaStiffnessMatrix(const VField &uNodes, const VField &deltaP) const {     // :1301-1328, per-DoF result
+        VField f(m_numDoFs);
+        check(ctx(), mfh_apply_delta_K(ctx(), &uNodes[0][0], &deltaP[0][0], &f[0][0]));
+        return f;
+    }
+    VField deltaConstantStrainLoad(const std::array<Real, N *(N + 1) / 2> &cstrainFlat, const VField &deltaP) const {   // :1331-1348
+        VField f(m_numDoFs);
+        check(ctx(), mfh_delta_constant_strain_load(ctx(), cstrainFlat.data(), &deltaP[0][0], &f[0][0]));
+        return f;
+    }
+    SMField deltaAverageStrainField(const VField &uNodes, const VField &deltaU, const VField &deltaP) const {   // :1364-1374
+        SMField e((size_t)m_numElements);
+        check(ctx(), mfh_delta_average_strain(ctx(), &uNodes[0][0], &deltaU[0][0], &deltaP[0][0], 0, &e[0][0]));
+        return e;
     }
 
     double rtol = 1e-8;

@@ -249,6 +249,26 @@ mfh_status mfh_sim_solve_constrained(mfh_ctx* ctx, const double* f, int32_t flag
 /* == averageStrainField / averageStressField (:528-549, :99-123): per element, flattened (flatLen) */
 mfh_status mfh_average_strain(mfh_ctx* ctx, const double* uNodes, double* strain /* nElem x flatLen */);
 mfh_status mfh_average_stress(mfh_ctx* ctx, const double* uNodes, double* stress /* nElem x flatLen */);
+
+/* ---- discrete shape derivatives, forward mode (LinearElasticity.hh:234-330 at element level; Simulator level
+ * :1297-1374). deltaP is a per-vertex perturbation field [nVert x dim] (indexed by the node id of the element corners:
+ * vertex nodes come first in the FEM numbering); nodal fields are held fixed. Each is the original device kernel
+ * evaluated on perturbed barycentric gradients (delta grad lambda, EmbeddedElement.hh:269-278; delta vol/vol, :366-372).
+ *   mfh_apply_delta_K               == Simulator::applyDeltaStiffnessMatrix(u, deltaP) (:1301-1328): (delta K) u,
+ *                                      u per NODE, result per DoF; deltaPerElementStiffness (:306-330) is never formed
+ *   mfh_delta_constant_strain_load  == Simulator::deltaConstantStrainLoad(cstrain, deltaP) (:1331-1348)
+ *   mfh_delta_average_strain        == Simulator::deltaAverageStrainField(u, deltaU, deltaP) (:1364-1374):
+ *                                      (delta strain)(u) + strain(deltaU); wantStress != 0 contracts with C (deltaStress :280-286)
+ *   mfh_mutual_energies             sum_e int (e^ij + eps(w^ij)) : C : (e^kl + eps(w^kl)) dV as a flatLen x flatLen
+ *                                      matrix (= |Y| Ch, energy form of PeriodicHomogenization.hh:146-186); with deltaP != NULL
+ *                                      its discrete shape derivative in the volume form of PeriodicHomogenization.hh:484-491
+ *                                      (what deltaHomogenizedElasticityTensor :492-514 evaluates through boundary integrals).
+ *                                      w: [flatLen][nNode][dim] per-node fluctuation displacements. */
+mfh_status mfh_apply_delta_K(mfh_ctx* ctx, const double* uNodes, const double* deltaP, double* out /* dim*nDoF */);
+mfh_status mfh_delta_constant_strain_load(mfh_ctx* ctx, const double* cstrainFlat, const double* deltaP, double* out /* dim*nDoF */);
+mfh_status mfh_delta_average_strain(mfh_ctx* ctx, const double* uNodes, const double* deltaU, const double* deltaP,
+                                    int32_t wantStress, double* out /* nElem x flatLen */);
+mfh_status mfh_mutual_energies(mfh_ctx* ctx, const double* w, const double* deltaP /* or NULL */, double* out /* flatLen^2 */);
 /* Select the operator (default MFH_OP_ELASTICITY). Keeps mesh, DoF map, pattern and gather lists; drops the
  * assembled values and the fixed variables (their numbering depends on the block size). */
 mfh_status mfh_set_operator(mfh_ctx* ctx, int32_t op);

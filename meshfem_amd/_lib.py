@@ -93,6 +93,10 @@ PROTOTYPES = {
     "mfh_set_operator": (_i32, [_P, _i32]),
     "mfh_matrix_set_upper_triplets": (_i32, [_P, _i64, _i64, _P, _P, _P]),
     "mfh_average_gradient": (_i32, [_P, _P, _P]),
+    "mfh_apply_delta_K": (_i32, [_P, _P, _P, _P]),
+    "mfh_delta_constant_strain_load": (_i32, [_P, _P, _P, _P]),
+    "mfh_delta_average_strain": (_i32, [_P, _P, _P, _P, _i32, _P]),
+    "mfh_mutual_energies": (_i32, [_P, _P, _P, _P]),
     "mfh_dev_spmv": (_i32, [_P, _P, _P]),
     "mfh_dev_precond": (_i32, [_P, _P, _P]),
     "mfh_tl_partitioned_begin": (_i32, [_P, _i32, _P, _P, _P]),

@@ -358,6 +358,44 @@ class Context:
         self._ck(self.lib.mfh_average_stress(self.h, ptr(u), ptr(out)))
         return out
 
+    # ---------------------------------------------------------------- discrete shape derivatives (forward mode)
+    def _delta_p(self, delta_p):
+        dp = as_f64(delta_p)
+        if dp.size != self.n_vert * self.dim:
+            raise ValueError("deltaP must be a per-vertex field [nVert x dim]")
+        return dp
+
+    def apply_delta_K(self, u_nodes, delta_p):
+        """(delta K) u for a per-node field u under the vertex perturbation delta_p; per-DoF result."""
+        u, dp = as_f64(u_nodes), self._delta_p(delta_p)
+        out = np.empty((self.n_dof, self.dim))
+        self._ck(self.lib.mfh_apply_delta_K(self.h, ptr(u), ptr(dp), ptr(out)))
+        return out
+
+    def delta_constant_strain_load(self, cstrain_flat, delta_p):
+        e, dp = as_f64(cstrain_flat), self._delta_p(delta_p)
+        out = np.empty((self.n_dof, self.dim))
+        self._ck(self.lib.mfh_delta_constant_strain_load(self.h, ptr(e), ptr(dp), ptr(out)))
+        return out
+
+    def delta_average_strain(self, u_nodes, delta_u, delta_p, stress=False):
+        u, du, dp = as_f64(u_nodes), as_f64(delta_u), self._delta_p(delta_p)
+        out = np.empty((self.n_elem, flat_len(self.dim)))
+        self._ck(self.lib.mfh_delta_average_strain(self.h, ptr(u), ptr(du), ptr(dp), int(bool(stress)), ptr(out)))
+        return out
+
+    def mutual_energies(self, w, delta_p=None):
+        """flatLen x flatLen matrix of sum_e int (e^ij + eps(w^ij)) : C : (e^kl + eps(w^kl)) dV, or its discrete shape
+        derivative under delta_p. w: flatLen per-node fields."""
+        fl = flat_len(self.dim)
+        wa = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.float64).reshape(self.n_node, self.dim) for x in w]))
+        if wa.shape[0] != fl:
+            raise ValueError("need one fluctuation displacement per canonical strain")
+        dp = None if delta_p is None else self._delta_p(delta_p)
+        out = np.empty((fl, fl))
+        self._ck(self.lib.mfh_mutual_energies(self.h, ptr(wa), ptr(dp), ptr(out)))
+        return out
+
     # ---------------------------------------------------------------- device pointers (torch interop)
     def stream(self):
         return self.lib.mfh_stream(self.h)

@@ -1600,9 +1600,14 @@ mfh_status mfh_neumann_load(mfh_ctx *c, double *out) {
     MFH_CATCH(c)
 }
 
-mfh_status mfh_constant_strain_load(mfh_ctx *c, const double *cstrain, double *out) {
-    MFH_TRY(c)
-    require(c && c->haveMesh && cstrain && out, MFH_ERR_STATE, "no mesh set");
+// per-vertex perturbation field on the device (shape derivatives); indexed by the node id of the element corners
+static void upload_delta_p(mfh_ctx *c, const double *deltaP, DBuf<double> &buf) {
+    const HostMesh &m = c->mesh;
+    buf.alloc((size_t)m.nVert * m.dim);
+    MFH_HIP(hipMemcpyAsync(buf.p, deltaP, (size_t)m.nVert * m.dim * sizeof(double), hipMemcpyHostToDevice, c->stream));
+}
+
+static void constant_strain_load_impl(mfh_ctx *c, const double *cstrain, const double *deltaP, double *out) {
     require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "constantStrainLoad is defined for the elasticity operator");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
@@ -1611,10 +1616,71 @@ mfh_status mfh_constant_strain_load(mfh_ctx *c, const double *cstrain, double *o
     const int64_t n = (int64_t)d * c->nDoF;
     double cs[6] = {0, 0, 0, 0, 0, 0};
     for (int k2 = 0; k2 < flat_len(d); ++k2) cs[k2] = cstrain[k2];
+    DBuf<double> dp;
+    if (deltaP) upload_delta_p(c, deltaP, dp);
     c->wb.alloc(n);
     c->wb.zero(c->stream);
-    k::launch_constant_strain_load(asm_args(c), c->dElemNodes.p, device_dof_map(c), c->tables.intGrad.data(), cs, c->wb.p, c->stream);
+    k::launch_constant_strain_load(asm_args(c), c->dElemNodes.p, device_dof_map(c), c->tables.intGrad.data(), cs, deltaP ? dp.p : nullptr,
+                                   c->wb.p, c->stream);
     c->wb.download(out, (size_t)n, c->stream);
+}
+
+mfh_status mfh_constant_strain_load(mfh_ctx *c, const double *cstrain, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && cstrain && out, MFH_ERR_STATE, "no mesh set");
+    constant_strain_load_impl(c, cstrain, nullptr, out);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_delta_constant_strain_load(mfh_ctx *c, const double *cstrain, const double *deltaP, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && cstrain && deltaP && out, MFH_ERR_STATE, "no mesh set");
+    constant_strain_load_impl(c, cstrain, deltaP, out);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_apply_delta_K(mfh_ctx *c, const double *uNodes, const double *deltaP, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && deltaP && out, MFH_ERR_STATE, "no mesh set");
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "applyDeltaStiffnessMatrix is defined for the elasticity operator");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    const int64_t n = (int64_t)d * c->nDoF;
+    DBuf<double> dp, u;
+    upload_delta_p(c, deltaP, dp);
+    u.alloc((size_t)m.nNode * d);
+    MFH_HIP(hipMemcpyAsync(u.p, uNodes, (size_t)m.nNode * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->wb.alloc(n);
+    c->wb.zero(c->stream);
+    k::launch_apply_delta_K(asm_args(c), c->dElemNodes.p, device_dof_map(c), c->tables.intGrad.data(), u.p, dp.p, c->wb.p, c->stream);
+    c->wb.download(out, (size_t)n, c->stream);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_mutual_energies(mfh_ctx *c, const double *w, const double *deltaP, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && w && out, MFH_ERR_STATE, "no mesh set");
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "mutual energies are defined for the elasticity operator");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const HostMesh &m = c->mesh;
+    const int d = m.dim, fl = flat_len(d), np = fl * (fl + 1) / 2;
+    DBuf<double> dp, wd, res;
+    if (deltaP) upload_delta_p(c, deltaP, dp);
+    wd.alloc((size_t)fl * m.nNode * d);
+    MFH_HIP(hipMemcpyAsync(wd.p, w, wd.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    res.alloc(np);
+    res.zero(c->stream);
+    k::launch_mutual_energies(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), wd.p, m.nNode, deltaP ? dp.p : nullptr, res.p, c->stream);
+    std::vector<double> h(np);
+    res.download(h.data(), (size_t)np, c->stream);
+    int p = 0;
+    for (int i = 0; i < fl; ++i)
+        for (int j = i; j < fl; ++j, ++p) out[i * fl + j] = out[j * fl + i] = h[p];
     MFH_CATCH(c)
 }
 
@@ -1890,7 +1956,8 @@ mfh_status mfh_sim_solve_constrained(mfh_ctx *c, const double *f, int32_t flags,
     MFH_CATCH(c)
 }
 
-static void average_strain_impl(mfh_ctx *c, const double *uNodes, double *out, bool stress) {
+static void average_strain_impl(mfh_ctx *c, const double *uNodes, double *out, bool stress, const double *uFixed = nullptr,
+                                const double *deltaP = nullptr) {
     require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "strain / stress fields are defined for the elasticity operator");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
@@ -1899,10 +1966,24 @@ static void average_strain_impl(mfh_ctx *c, const double *uNodes, double *out, b
     const int d = m.dim, fl = flat_len(d);
     c->wx.alloc((size_t)m.nNode * d);
     MFH_HIP(hipMemcpyAsync(c->wx.p, uNodes, (size_t)m.nNode * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    DBuf<double> res;
+    DBuf<double> res, dp, uf;
+    if (deltaP) {
+        upload_delta_p(c, deltaP, dp);
+        uf.alloc((size_t)m.nNode * d);
+        MFH_HIP(hipMemcpyAsync(uf.p, uFixed, (size_t)m.nNode * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
     res.alloc((size_t)m.nElem * fl);
-    k::launch_average_strain(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), c->wx.p, res.p, stress ? 1 : 0, c->stream);
+    k::launch_average_strain(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), c->wx.p, res.p, stress ? 1 : 0,
+                             deltaP ? uf.p : nullptr, deltaP ? dp.p : nullptr, c->stream);
     res.download(out, res.n, c->stream);
+}
+
+mfh_status mfh_delta_average_strain(mfh_ctx *c, const double *uNodes, const double *deltaU, const double *deltaP, int32_t wantStress,
+                                    double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && deltaU && deltaP && out, MFH_ERR_STATE, "no mesh set");
+    average_strain_impl(c, deltaU, out, wantStress != 0, uNodes, deltaP);
+    MFH_CATCH(c)
 }
 
 mfh_status mfh_set_operator(mfh_ctx *c, int32_t op) {

@@ -283,10 +283,17 @@ void launch_geometry(int dim, int deg, int mat, int64_t nElem, const int32_t *el
 void launch_assemble_gather(const AsmArgs &a, hipStream_t s);
 void launch_assemble_atomic(const AsmArgs &a, hipStream_t s);
 void launch_element_stiffness(const AsmArgs &a, int64_t first, int64_t count, double *KeOut, hipStream_t s);
+// deltaP != nullptr: the discrete shape derivative of the same quantity under the vertex perturbation deltaP
 void launch_constant_strain_load(const AsmArgs &a, const int32_t *elemNodes, const int32_t *dofForNode, const double *intGrad,
-                                 const double *cstrain, double *out, hipStream_t s);
+                                 const double *cstrain, const double *deltaP, double *out, hipStream_t s);
+// deltaP != nullptr: strain(uNodes) + (delta strain)(uFixed)  (deltaAverageStrainField)
 void launch_average_strain(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, double *out,
-                           int wantStress, hipStream_t s);
+                           int wantStress, const double *uFixed, const double *deltaP, hipStream_t s);
+void launch_apply_delta_K(const AsmArgs &a, const int32_t *elemNodes, const int32_t *dofForNode, const double *intGrad,
+                          const double *uNodes, const double *deltaP, double *out, hipStream_t s);
+// out[pair(ij<=kl)] += sum_e mutual energy (deltaP == nullptr) or its shape derivative; w: [flatLen][nNode][dim]
+void launch_mutual_energies(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *w, int64_t nNode,
+                            const double *deltaP, double *out, hipStream_t s);
 void launch_average_gradient(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, double *out,
                              hipStream_t s);
 

@@ -443,6 +443,10 @@ DEV void elem_D_apply(const double *__restrict__ g, const double *sd /* shear-do
     }
 }
 
+template <int DIM>
+DEV void load_corner_perturbation(const double *__restrict__ g, const int32_t *__restrict__ en, const double *__restrict__ deltaP,
+                                  double (&gl)[DIM + 1][DIM], double (&dgl)[DIM + 1][DIM], double &relDeltaVol);
+
 struct LoadArgs {
     int64_t nElem;
     int npe, geoStride;
@@ -454,7 +458,7 @@ struct LoadArgs {
 };
 
 template <int DIM, int DEG, int MAT>
-__global__ void __launch_bounds__(256) k_constant_strain_load(LoadArgs a, double *__restrict__ out) {
+__global__ void __launch_bounds__(256) k_constant_strain_load(LoadArgs a, const double *__restrict__ deltaP, double *__restrict__ out) {
     constexpr int FL = DIM * (DIM + 1) / 2;
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
     const int64_t total = a.nElem * NPE;
@@ -473,8 +477,27 @@ __global__ void __launch_bounds__(256) k_constant_strain_load(LoadArgs a, double
 #pragma unroll
         for (int q = 0; q < NPE; ++q) { al = (q == i) ? a.intGrad[2 * q] : al; be = (q == i) ? a.intGrad[2 * q + 1] : be; }
         double gi[DIM];
+        if (deltaP) {
+            // deltaConstantStrainLoad (LinearElasticity.hh:289-304, :1331-1348): delta (vol grad lambda) = vol (rel gl + dgl)
+            double gl[DIM + 1][DIM], dgl[DIM + 1][DIM], rel;
+            load_corner_perturbation<DIM>(g, a.elemNodes + e * NPE, deltaP, gl, dgl, rel);
+            double gs[DIM], gt[DIM];
 #pragma unroll
-        for (int b = 0; b < DIM; ++b) gi[b] = vol * (al * g[si * DIM + b] + be * g[ti * DIM + b]);
+            for (int b = 0; b < DIM; ++b) { gs[b] = 0.0; gt[b] = 0.0; }
+#pragma unroll
+            for (int k2 = 0; k2 < DIM + 1; ++k2)
+#pragma unroll
+                for (int b = 0; b < DIM; ++b) {
+                    const double v = rel * gl[k2][b] + dgl[k2][b];
+                    gs[b] = (k2 == si) ? v : gs[b];
+                    gt[b] = (k2 == ti) ? v : gt[b];
+                }
+#pragma unroll
+            for (int b = 0; b < DIM; ++b) gi[b] = vol * (al * gs[b] + be * gt[b]);
+        } else {
+#pragma unroll
+            for (int b = 0; b < DIM; ++b) gi[b] = vol * (al * g[si * DIM + b] + be * g[ti * DIM + b]);
+        }
         int64_t dof = a.elemNodes[e * NPE + i];
         if (a.dofForNode) dof = a.dofForNode[dof];
 #pragma unroll
@@ -489,7 +512,8 @@ __global__ void __launch_bounds__(256) k_constant_strain_load(LoadArgs a, double
 
 template <int DIM, int DEG, int MAT>
 __global__ void __launch_bounds__(256) k_average_strain(LoadArgs a, const double *__restrict__ uNodes, double *__restrict__ out,
-                                                        int wantStress) {
+                                                        int wantStress, const double *__restrict__ uFixed,
+                                                        const double *__restrict__ deltaP) {
     constexpr int FL = DIM * (DIM + 1) / 2;
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.nElem; e += (int64_t)gridDim.x * 256) {
@@ -511,6 +535,25 @@ __global__ void __launch_bounds__(256) k_average_strain(LoadArgs a, const double
             for (int x = 0; x < DIM; ++x)
 #pragma unroll
                 for (int y = 0; y < DIM; ++y) eps[x][y] += 0.5 * (ui[x] * gb[y] + ui[y] * gb[x]);   // LinearElasticity.hh:99-115
+        }
+        if (deltaP) {
+            // deltaAverageStrainField (LinearElasticity.hh:1364-1374): + (delta strain)(uFixed), the strain of the fixed
+            // field on the perturbed gradients (:259-277)
+            double gl[DIM + 1][DIM], dgl[DIM + 1][DIM], rel;
+            load_corner_perturbation<DIM>(g, a.elemNodes + e * NPE, deltaP, gl, dgl, rel);
+#pragma unroll
+            for (int i = 0; i < NPE; ++i) {
+                const int si = sup_s<DIM, DEG>(i), ti = sup_t<DIM, DEG>(i);
+                const double al = a.intGrad[2 * i], be = a.intGrad[2 * i + 1];
+                const int64_t node = a.elemNodes[e * NPE + i];
+                double gb[DIM], ui[DIM];
+#pragma unroll
+                for (int b = 0; b < DIM; ++b) { gb[b] = al * dgl[si][b] + be * dgl[ti][b]; ui[b] = uFixed[node * DIM + b]; }
+#pragma unroll
+                for (int x = 0; x < DIM; ++x)
+#pragma unroll
+                    for (int y = 0; y < DIM; ++y) eps[x][y] += 0.5 * (ui[x] * gb[y] + ui[y] * gb[x]);
+            }
         }
         double ef[FL];
 #pragma unroll
@@ -742,21 +785,19 @@ DEV void elem_forces(const SpmvMfArgs &a, int64_t e, const double *__restrict__ 
     });
 }
 
-// the arithmetic of elem_forces on nodal vectors that are already gathered; every nodal force is handed to `emit(j, f_j)`
-// as soon as it is complete (the cluster kernel adds it to LDS right away instead of keeping 30 values live)
+// The arithmetic of elem_forces on nodal vectors that are already gathered, as a bilinear form in the barycentric
+// gradients: the strain of u is built with glS, the test functions' gradients with glT,
+//     f_i = vol int sigma(u; glS) grad phi_i(glT).
+// The operator itself is glS == glT == grad lambda; the discrete shape derivative (k_apply_delta_K) feeds perturbed
+// gradients into either slot. Every nodal force is handed to `emit(j, f_j)` as soon as it is complete (the cluster
+// kernel adds it to LDS right away instead of keeping 30 values live).
 template <int DIM, int DEG, int MAT, class Emit>
-DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM],
-                          const Emit &emit) {
+DEV void elem_forces_bilinear(const double *__restrict__ g /* element record: material */, double vol,
+                              const double (&gl)[DIM + 1][DIM], const double (&glT)[DIM + 1][DIM],
+                              const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM], const Emit &emit) {
     constexpr int NV = DIM + 1;
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
     constexpr int FL = DIM * (DIM + 1) / 2;
-    const double *g = a.geo + e * a.geoStride;
-    double gl[NV][DIM];
-#pragma unroll
-    for (int k = 0; k < NV; ++k)
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) gl[k][d] = g[k * DIM + d];
-    const double vol = g[12];
     auto stress_of = [&](const double (&G)[DIM][DIM], double *out) {
         double sd[FL];
 #pragma unroll
@@ -790,7 +831,7 @@ DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DI
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             double fv[DIM] = {};
-            symv(sg, gl[j], fv);
+            symv(sg, glT[j], fv);
             emit(j, fv);
         }
     } else {
@@ -847,7 +888,7 @@ DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DI
 #pragma unroll
             for (int c = 0; c < FL; ++c) T[c] = (vol * wq * b_) * S[c] + R[k][c];
             double fv[DIM] = {};
-            symv(T, gl[k], fv);
+            symv(T, glT[k], fv);
             emit(k, fv);
         }
 #pragma unroll
@@ -859,10 +900,216 @@ DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DI
 #pragma unroll
             for (int c = 0; c < FL; ++c) { T1[c] = S[c] + R[tI][c]; T2[c] = S[c] + R[sI][c]; }
             double fv[DIM] = {};
-            symv(T1, gl[sI], fv);
-            symv(T2, gl[tI], fv);
+            symv(T1, glT[sI], fv);
+            symv(T2, glT[tI], fv);
             emit(NV + m, fv);
         }
+    }
+}
+
+template <int DIM, int DEG, int MAT, class Emit>
+DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM],
+                          const Emit &emit) {
+    constexpr int NV = DIM + 1;
+    const double *g = a.geo + e * a.geoStride;
+    double gl[NV][DIM];
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) gl[k][d] = g[k * DIM + d];
+    elem_forces_bilinear<DIM, DEG, MAT>(g, g[12], gl, gl, xl, emit);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Discrete shape derivatives (forward mode): change of the element quantities under a perturbation delta_p of the
+// mesh vertices, with the nodal fields held fixed (LinearElasticity.hh:238-330; Simulator level :1301-1374).
+// Everything depends on the geometry through (grad lambda, vol) only:
+//     delta grad lambda_i = - sum_k grad lambda_k (grad lambda_i . delta_p_k)      (EmbeddedElement.hh:269-278)
+//     delta vol / vol     =   sum_k grad lambda_k . delta_p_k                       (EmbeddedElement.hh:366-372)
+// and grad phi_i has the same (s,t) support form in delta grad lambda as in grad lambda (:338-363), so each
+// derivative is the original kernel evaluated on perturbed gradients (product rule on the bilinear forms).
+// ------------------------------------------------------------------------------------------------
+template <int DIM>
+DEV void load_corner_perturbation(const double *__restrict__ g, const int32_t *__restrict__ en /* element's nodes: corners first */,
+                                  const double *__restrict__ deltaP, double (&gl)[DIM + 1][DIM], double (&dgl)[DIM + 1][DIM],
+                                  double &relDeltaVol) {
+    constexpr int NV = DIM + 1;
+    double dp[NV][DIM];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        const int64_t v = en[k];
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) { gl[k][d] = g[k * DIM + d]; dp[k][d] = deltaP[v * DIM + d]; dgl[k][d] = 0.0; }
+    }
+    relDeltaVol = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+#pragma unroll
+        for (int d = 0; d < DIM; ++d) relDeltaVol += gl[k][d] * dp[k][d];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            double sdot = 0;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) sdot += gl[i][d] * dp[k][d];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) dgl[i][d] -= gl[k][d] * sdot;
+        }
+    }
+}
+
+// flattened (tensor-shear) symmetrised gradient of the nodal field xl at quadrature point q, built on the gradients gl:
+// sym(sum_i u_i (x) grad phi_i(x_q)); P2: grad phi_k = (4 lam_k - 1) gl_k, grad phi_(s,t) = 4 (lam_t gl_s + lam_s gl_t)
+// (EmbeddedElement.hh:315-332) at the vertex-associated points lam_k(x_q) = c0 if k == q else c1.
+template <int DIM, int DEG>
+DEV void sym_grad_u_at(const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM], const double (&gl)[DIM + 1][DIM],
+                       int q, double (&ef)[DIM * (DIM + 1) / 2]) {
+    constexpr int NV = DIM + 1;
+    constexpr double c0 = DIM == 3 ? 0.58541019662496845446 : 2.0 / 3.0;
+    constexpr double c1 = DIM == 3 ? 0.13819660112501051518 : 1.0 / 6.0;
+    double G[DIM][DIM];
+#pragma unroll
+    for (int p = 0; p < DIM; ++p)
+#pragma unroll
+        for (int r = 0; r < DIM; ++r) G[p][r] = 0.0;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double ck[DIM];
+        if (DEG == 1) {
+#pragma unroll
+            for (int p = 0; p < DIM; ++p) ck[p] = xl[k][p];
+        } else {
+            const double lk = (k == q) ? c0 : c1;
+#pragma unroll
+            for (int p = 0; p < DIM; ++p) ck[p] = (4 * lk - 1) * xl[k][p];
+#pragma unroll
+            for (int o = 0; o < NV; ++o)
+                if (o != k) {
+                    const double lo = (o == q) ? c0 : c1;
+#pragma unroll
+                    for (int p = 0; p < DIM; ++p) ck[p] += 4 * lo * xl[(DEG == 1 ? 0 : NV + edge_between<DIM>(k, o))][p];
+                }
+        }
+#pragma unroll
+        for (int p = 0; p < DIM; ++p)
+#pragma unroll
+            for (int r = 0; r < DIM; ++r) G[p][r] += ck[p] * gl[k][r];
+    }
+#pragma unroll
+    for (int p = 0; p < DIM; ++p)
+#pragma unroll
+        for (int r = p; r < DIM; ++r) ef[flat_idx<DIM>(p, r)] = 0.5 * (G[p][r] + G[r][p]);
+}
+
+// Mutual energies of the cell-problem fields, sum_e int (e^ij + eps(w^ij)) : C : (e^kl + eps(w^kl)) dV for every pair
+// ij <= kl (blockIdx.y), i.e. |Y| Ch in the energy form (PeriodicHomogenization.hh:146-186 without the averaging
+// shortcut), and with deltaP their discrete shape derivative in the volume form quoted at
+// PeriodicHomogenization.hh:484-491:  int rel G^ij:C:G^kl + (delta eps)(w^ij):C:G^kl + G^ij:C:(delta eps)(w^kl) dV
+// (the terms in delta w vanish by the cell problems' stationarity). w: [flatLen][nNode][DIM] per-node fields.
+template <int DIM, int DEG, int MAT>
+__global__ void __launch_bounds__(256) k_mutual_energies(LoadArgs a, const double *__restrict__ w, int64_t nNode,
+                                                         const double *__restrict__ deltaP, double *__restrict__ out) {
+    constexpr int NV = DIM + 1;
+    constexpr int FL = DIM * (DIM + 1) / 2;
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    constexpr int NQ = DEG == 1 ? 1 : NV;
+    // pair index -> (ij, kl), ij <= kl, row-major over the upper triangle
+    int ij = 0, rem = blockIdx.y;
+    while (rem >= FL - ij) { rem -= FL - ij; ++ij; }
+    const int kl = ij + rem;
+    const double *wij = w + (int64_t)ij * nNode * DIM, *wkl = w + (int64_t)kl * nNode * DIM;
+    double acc = 0.0;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.nElem; e += (int64_t)gridDim.x * 256) {
+        const double *g = a.geo + e * a.geoStride;
+        const int32_t *en = a.elemNodes + e * NPE;
+        double gl[NV][DIM], dgl[NV][DIM], rel = 0.0;
+        if (deltaP) load_corner_perturbation<DIM>(g, en, deltaP, gl, dgl, rel);
+        else {
+#pragma unroll
+            for (int k = 0; k < NV; ++k)
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) gl[k][d] = g[k * DIM + d];
+        }
+        double xa[NPE][DIM], xb[NPE][DIM];
+#pragma unroll
+        for (int j = 0; j < NPE; ++j) {
+            const int64_t node = en[j];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) { xa[j][d] = wij[node * DIM + d]; xb[j][d] = wkl[node * DIM + d]; }
+        }
+        double sum = 0.0;
+        for (int q = 0; q < NQ; ++q) {
+            double Ga[FL], Gb[FL], Sa[FL], Sb[FL], sd[FL];
+            sym_grad_u_at<DIM, DEG>(xa, gl, q, Ga);
+            sym_grad_u_at<DIM, DEG>(xb, gl, q, Gb);
+#pragma unroll
+            for (int c = 0; c < FL; ++c) {   // + canonical basis strains (SymmetricMatrix.hh:405-413)
+                Ga[c] += (c == ij) ? (c < DIM ? 1.0 : 0.5) : 0.0;
+                Gb[c] += (c == kl) ? (c < DIM ? 1.0 : 0.5) : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < FL; ++c) sd[c] = Gb[c] * (c < DIM ? 1.0 : 2.0);
+            elem_D_apply<DIM, MAT>(g, sd, Sb);
+            if (deltaP) {
+                double dA[FL], dB[FL];
+                sym_grad_u_at<DIM, DEG>(xa, dgl, q, dA);
+                sym_grad_u_at<DIM, DEG>(xb, dgl, q, dB);
+#pragma unroll
+                for (int c = 0; c < FL; ++c) sd[c] = Ga[c] * (c < DIM ? 1.0 : 2.0);
+                elem_D_apply<DIM, MAT>(g, sd, Sa);
+#pragma unroll
+                for (int c = 0; c < FL; ++c) {
+                    const double m = c < DIM ? 1.0 : 2.0;
+                    sum += m * ((rel * Ga[c] + dA[c]) * Sb[c] + dB[c] * Sa[c]);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < FL; ++c) sum += (c < DIM ? 1.0 : 2.0) * Ga[c] * Sb[c];
+            }
+        }
+        acc += sum * g[12] / NQ;
+    }
+    // wave reduction, one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&out[blockIdx.y], acc);
+}
+
+// (delta K) u, Simulator::applyDeltaStiffnessMatrix (LinearElasticity.hh:1301-1328) with deltaPerElementStiffness
+// (:306-330) never formed: delta f = vol [B(rel gl + dgl, gl) + B(gl, dgl)] u with B the bilinear form above
+// (rel = delta vol / vol). u is a per-NODE field, the result a per-DoF field, exactly as in the reference.
+template <int DIM, int DEG, int MAT>
+__global__ void __launch_bounds__(256) k_apply_delta_K(LoadArgs a, const double *__restrict__ uNodes, const double *__restrict__ deltaP,
+                                                       double *__restrict__ out) {
+    constexpr int NV = DIM + 1;
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.nElem; e += (int64_t)gridDim.x * 256) {
+        const double *g = a.geo + e * a.geoStride;
+        const int32_t *en = a.elemNodes + e * NPE;
+        double gl[NV][DIM], dgl[NV][DIM], glA[NV][DIM], rel;
+        load_corner_perturbation<DIM>(g, en, deltaP, gl, dgl, rel);
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) glA[k][d] = rel * gl[k][d] + dgl[k][d];
+        double xl[NPE][DIM];
+        int64_t dof[NPE];
+#pragma unroll
+        for (int j = 0; j < NPE; ++j) {
+            const int64_t node = en[j];
+            dof[j] = a.dofForNode ? (int64_t)a.dofForNode[node] : node;
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) xl[j][d] = uNodes[node * DIM + d];
+        }
+        // first term kept in registers so that every (node, component) costs one atomic, not two
+        double f1[NPE][DIM];
+        elem_forces_bilinear<DIM, DEG, MAT>(g, g[12], glA, gl, xl, [&](int j, const double *fv) {
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) f1[j][d] = fv[d];
+        });
+        elem_forces_bilinear<DIM, DEG, MAT>(g, g[12], gl, dgl, xl, [&](int j, const double *fv) {
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) unsafeAtomicAdd(&out[dof[j] * DIM + d], f1[j][d] + fv[d]);
+        });
     }
 }
 
@@ -1905,20 +2152,41 @@ static LoadArgs make_load_args(const AsmArgs &a, const int32_t *elemNodes, const
 }
 
 void launch_constant_strain_load(const AsmArgs &a, const int32_t *elemNodes, const int32_t *dofForNode, const double *intGrad,
-                                 const double *cstrain, double *out, hipStream_t s) {
+                                 const double *cstrain, const double *deltaP, double *out, hipStream_t s) {
     const LoadArgs l = make_load_args(a, elemNodes, dofForNode, intGrad, cstrain);
     const int grid = grid_for(a.nElem * a.npe, 8192);
-#define CALL(D, G, M) hipLaunchKernelGGL((k_constant_strain_load<D, G, M>), dim3(grid), dim3(256), 0, s, l, out)
+#define CALL(D, G, M) hipLaunchKernelGGL((k_constant_strain_load<D, G, M>), dim3(grid), dim3(256), 0, s, l, deltaP, out)
     MFH_DISPATCH(a, CALL);
 #undef CALL
     CHECK_LAUNCH();
 }
 
 void launch_average_strain(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, double *out,
-                           int wantStress, hipStream_t s) {
+                           int wantStress, const double *uFixed, const double *deltaP, hipStream_t s) {
     const LoadArgs l = make_load_args(a, elemNodes, nullptr, intGrad, nullptr);
     const int grid = grid_for(a.nElem, 8192);
-#define CALL(D, G, M) hipLaunchKernelGGL((k_average_strain<D, G, M>), dim3(grid), dim3(256), 0, s, l, uNodes, out, wantStress)
+#define CALL(D, G, M) hipLaunchKernelGGL((k_average_strain<D, G, M>), dim3(grid), dim3(256), 0, s, l, uNodes, out, wantStress, uFixed, deltaP)
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+    CHECK_LAUNCH();
+}
+
+void launch_apply_delta_K(const AsmArgs &a, const int32_t *elemNodes, const int32_t *dofForNode, const double *intGrad,
+                          const double *uNodes, const double *deltaP, double *out, hipStream_t s) {
+    const LoadArgs l = make_load_args(a, elemNodes, dofForNode, intGrad, nullptr);
+    const int grid = grid_for(a.nElem, 8192);
+#define CALL(D, G, M) hipLaunchKernelGGL((k_apply_delta_K<D, G, M>), dim3(grid), dim3(256), 0, s, l, uNodes, deltaP, out)
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+    CHECK_LAUNCH();
+}
+
+void launch_mutual_energies(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *w, int64_t nNode,
+                            const double *deltaP, double *out, hipStream_t s) {
+    const LoadArgs l = make_load_args(a, elemNodes, nullptr, intGrad, nullptr);
+    const int fl = a.dim * (a.dim + 1) / 2;
+    const dim3 grid(grid_for(a.nElem, 4096), fl * (fl + 1) / 2);
+#define CALL(D, G, M) hipLaunchKernelGGL((k_mutual_energies<D, G, M>), grid, dim3(256), 0, s, l, w, nNode, deltaP, out)
     MFH_DISPATCH(a, CALL);
 #undef CALL
     CHECK_LAUNCH();

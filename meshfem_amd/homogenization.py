@@ -90,6 +90,56 @@ def homogenized_elasticity_tensor_displacement_form(sim: Simulator, w_ij, base_c
     return Eh / base_cell_volume
 
 
+def homogenized_elasticity_tensor_energy_form(sim: Simulator, w_ij, base_cell_volume=0.0):
+    """Ch_ijkl = 1/|Y| int (e^ij + eps(w^ij)) : C : (e^kl + eps(w^kl)) dV, one device reduction per tensor entry.
+    Equal to the stress-like and displacement forms at the cell-problem solutions."""
+    if base_cell_volume == 0.0:
+        pos = sim.nodes()
+        base_cell_volume = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
+    return sim.ctx.mutual_energies(w_ij) / base_cell_volume
+
+
+def delta_fluctuation_displacements(sim: Simulator, w_ij, delta_p):
+    """== deltaFluctuationDisplacements (PeriodicHomogenization.hh:527-544): change of the cell-problem solutions
+    under the vertex perturbation delta_p: K dw = deltaConstantStrainLoad(-e_ij) - (delta K) w_ij, solved with the
+    constraints of the cell problems (the simulator left by solve_cell_problems)."""
+    out = []
+    for k in range(flat_len(sim.N)):
+        rhs = sim.deltaConstantStrainLoad(-canonical_strain_flat(sim.N, k), delta_p)
+        rhs -= sim.applyDeltaStiffnessMatrix(w_ij[k], delta_p)
+        out.append(sim.solve(rhs))
+    return out
+
+
+def delta_homogenized_elasticity_tensor(sim: Simulator, w_ij, delta_p, base_cell_volume=0.0):
+    """Change of Ch under delta_p (== deltaHomogenizedElasticityTensor, PeriodicHomogenization.hh:492-514) in the
+    volume form quoted there (:484-491); like the reference, the periodic cell volume |Y| is held fixed."""
+    if base_cell_volume == 0.0:
+        pos = sim.nodes()
+        base_cell_volume = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
+    return sim.ctx.mutual_energies(w_ij, delta_p) / base_cell_volume
+
+
+def delta_homogenized_compliance_tensor(sim: Simulator, w_ij, delta_p, base_cell_volume=0.0):
+    """== deltaHomogenizedComplianceTensor (:516-524): -Sh : dCh : Sh as flattened matrices with the shear-doubling
+    of doubleDoubleContract."""
+    Ch = homogenized_elasticity_tensor_energy_form(sim, w_ij, base_cell_volume)
+    dCh = delta_homogenized_elasticity_tensor(sim, w_ij, delta_p, base_cell_volume)
+    fl = flat_len(sim.N)
+    dbl = np.ones(fl)
+    dbl[sim.N:] = 2.0
+    # compliance in the same flattened-tensor storage: Sh = inverse of the rank-4 map  (ElasticityTensor.hh inverse())
+    Sh = np.linalg.inv(Ch * dbl[None, :]) / dbl[None, :]
+    return -(Sh * dbl[None, :]) @ dCh @ (dbl[:, None] * Sh)
+
+
+def delta_macro_strain_to_micro_strain_tensors(sim: Simulator, w_ij, delta_w_ij, delta_p):
+    """== deltaMacroStrainToMicroStrainTensors (:549-563): per element, column kl of delta G is
+    deltaAverageStrainField(w_kl, delta w_kl, delta_p). Returns [nElem, flatLen (ij), flatLen (kl)]."""
+    cols = [sim.deltaAverageStrainField(w_ij[k], delta_w_ij[k], delta_p) for k in range(flat_len(sim.N))]
+    return np.stack(cols, axis=2)
+
+
 def homogenize(vertices, elements, degree=2, Cbase=None, E=None, nu=None, ortho_params=None, device=0, rtol=1e-8,
               preconditioner=None):
     """Returns dict(Ch, w_ij, strain_w_ij, iterations) like the reference's `homogenize`.

@@ -93,6 +93,19 @@ class Simulator:
     def averageStressField(self, u_nodes):                              # :539-549
         return self.ctx.average_stress(u_nodes)
 
+    # ---- discrete shape derivatives (forward mode), :1297-1374
+    def applyDeltaStiffnessMatrix(self, u_nodes, deltaP):               # :1301-1328  per-node u -> per-DoF load
+        return self.ctx.apply_delta_K(u_nodes, deltaP)
+
+    def deltaConstantStrainLoad(self, cstrain_flat, deltaP):            # :1331-1348
+        return self.ctx.delta_constant_strain_load(cstrain_flat, deltaP)
+
+    def deltaAverageStrainField(self, u_nodes, deltaU, deltaP):         # :1364-1374
+        return self.ctx.delta_average_strain(u_nodes, deltaU, deltaP)
+
+    def deltaAverageStressField(self, u_nodes, deltaU, deltaP):         # C : deltaAverageStrainField (deltaStress :280-286)
+        return self.ctx.delta_average_strain(u_nodes, deltaU, deltaP, stress=True)
+
     def benchmarkReport(self):
         """Timings under the reference's timer-section names (GlobalBenchmark.hh:14-34; sections of
         LinearElasticity.hh:1206,1394-1399,482-485 and SparseMatrices.hh:283): milliseconds of the last operations.

@@ -22,7 +22,8 @@ and CHOLMOD itself (SuiteSparse, conda pin 5.4.0) is absent: for that boundary t
 "PARITY UNPINNED" -- it is anchored instead on exact mathematics (sympy rational Ke, patch tests,
 rigid-mode null space, energy identity) and scipy.sparse.linalg.splu stands in for CHOLMOD (a general sparse LU of
 the KKT matrix for UMFPACK in the constraint-row branch). Also restated here: Laplacian.hh / MassMatrix.hh / Poisson.hh,
-both homogenized-tensor forms of PeriodicHomogenization.hh, assembleConstrainedSystem's rigid-motion rows.
+both homogenized-tensor forms of PeriodicHomogenization.hh, assembleConstrainedSystem's rigid-motion rows, and the discrete
+shape derivatives (deltaPerElementStiffness & co., pinned on finite differences of this oracle's own operators).
 
 All `file:line` citations are relative to /root/reference/src/lib/MeshFEM/ unless noted.
 """
@@ -1155,6 +1156,200 @@ def homogenized_elasticity_tensor_displacement_form(sim: Simulator, w, base_cell
             Eh[i, :] += EBase.double_contract_flat(flatten_sym(N, nw))
     Eh += EBase.D * float(np.sum(sim.vol))
     return Eh / base_cell_volume
+
+
+# --------------------------------------------------------------------------------------
+# Discrete shape derivatives (forward mode)     LinearElasticity.hh:234-330, :1297-1374;
+# EmbeddedElement.hh:269-278,338-372; PeriodicHomogenization.hh:484-491,527-563
+# The reference pins none of these with a test; they are anchored in tests/ on central finite differences of
+# this oracle's own K(p), constantStrainLoad(p), strains and Ch(p) ("parity unpinned", exact mathematics).
+# --------------------------------------------------------------------------------------
+def delta_grad_barycentric(gl, i, delta_p):
+    """EmbeddedElement.hh:269-278: delta grad lambda_i = - sum_k grad lambda_k (grad lambda_i . delta_p[k]).
+    gl: N x (K+1) (column k = grad lambda_k); delta_p: (K+1) x N corner perturbations."""
+    res = np.zeros(gl.shape[0])
+    for k in range(gl.shape[1]):
+        res -= gl[:, k] * np.dot(gl[:, i], delta_p[k])
+    return res
+
+
+def relative_delta_volume(gl, delta_p):
+    """EmbeddedElement.hh:366-372."""
+    return sum(np.dot(gl[:, k], delta_p[k]) for k in range(gl.shape[1]))
+
+
+def delta_grad_phi_nodal(deg, K, gl, i, delta_p):
+    """EmbeddedElement::deltaGradPhi (:338-363): nodal values of the change of the grad phi_i interpolant."""
+    nv = K + 1
+    if deg == 1:
+        return delta_grad_barycentric(gl, i, delta_p)[None, :].copy()
+    out = np.zeros((nv, gl.shape[0]))
+    if i < nv:
+        d = delta_grad_barycentric(gl, i, delta_p)
+        for j in range(nv):
+            out[j] = -d
+        out[i] *= -3
+    else:
+        e = i - nv
+        out[EDGE_START[e]] = 4 * delta_grad_barycentric(gl, EDGE_END[e], delta_p)
+        out[EDGE_END[e]] = 4 * delta_grad_barycentric(gl, EDGE_START[e], delta_p)
+    return out
+
+
+def _vec_phi_strains(N, n, gphi_of):
+    """vecPhiStrains / deltaVecPhiStrains (LinearElasticity.hh:79-97, :239-254): strain interpolant (nodal symmetric
+    matrices [nInterp, N, N]) of the vector basis function i*N + c, from the nodal gradient values gphi_of(i)."""
+    out = []
+    for i in range(n):
+        g = gphi_of(i)
+        for c in range(N):
+            S = np.zeros((g.shape[0], N, N))
+            for inode in range(g.shape[0]):
+                for var in range(N):
+                    val = (1.0 if var == c else 0.5) * g[inode, var]
+                    S[inode, c, var] += val                         # SymmetricMatrix (c, var): one stored entry
+                    if var != c:
+                        S[inode, var, c] += val
+            out.append(S)
+    return out
+
+
+def delta_per_element_stiffness_loop(deg, K, gl, vol, D: "ElasticityTensor", delta_p):
+    """Literal restatement of deltaPerElementStiffness (LinearElasticity.hh:306-330), UPPER triangle (NaN below)."""
+    N = gl.shape[0]
+    n = num_nodes(K, deg)
+    strain_phi = _vec_phi_strains(N, n, lambda i: grad_phi_nodal(deg, K, gl, i))
+    dstrain_phi = _vec_phi_strains(N, n, lambda i: delta_grad_phi_nodal(deg, K, gl, i, delta_p))
+    dvol = vol * relative_delta_volume(gl, delta_p)
+    stress_phi = [np.stack([D.double_contract(S[k]) for k in range(S.shape[0])]) for S in strain_phi]
+    qdeg = 2 * (deg - 1)
+    dKe = np.full((n * N, n * N), np.nan)
+    at = lambda T, p: eval_interpolant(K, deg - 1, T, p)
+    for i in range(n * N):
+        for j in range(i, n * N):
+            v = integrate(K, qdeg, lambda p: np.sum(at(stress_phi[i], p) * at(dstrain_phi[j], p))
+                          + np.sum(at(stress_phi[j], p) * at(dstrain_phi[i], p)), vol)
+            v += integrate(K, qdeg, lambda p: np.sum(at(stress_phi[i], p) * at(strain_phi[j], p)), dvol)
+            dKe[i, j] = v
+    return dKe
+
+
+def delta_gl_batch(gl_batch, dp_batch):
+    """Vectorised delta grad lambda and delta vol / vol: gl_batch [nE, N, nv], dp_batch [nE, nv, N]."""
+    s = np.einsum('eai,eka->eik', gl_batch, dp_batch)                # grad lambda_i . delta_p_k
+    dgl = -np.einsum('eak,eik->eai', gl_batch, s)
+    rel = np.einsum('eak,eka->e', gl_batch, dp_batch)
+    return dgl, rel
+
+
+def delta_per_element_stiffness_batch(deg, K, gl_batch, vol_batch, C4_batch, dp_batch):
+    """Full symmetric delta Ke for many elements: product rule on per_element_stiffness_batch."""
+    dgl, rel = delta_gl_batch(gl_batch, dp_batch)
+    G, w = gradphi_at_quadrature(deg, K, gl_batch)
+    dG, _ = gradphi_at_quadrature(deg, K, dgl)
+    nE, nq, n, N = G.shape
+    H = np.einsum('q,eqia,eqjb->eiajb', w, dG, G, optimize=True) + np.einsum('q,eqia,eqjb->eiajb', w, G, dG, optimize=True) \
+        + rel[:, None, None, None, None] * np.einsum('q,eqia,eqjb->eiajb', w, G, G, optimize=True)
+    dKe = np.einsum('eiajb,eacdb->eicjd', H, np.broadcast_to(C4_batch, (nE, N, N, N, N)), optimize=True)
+    return (dKe * vol_batch[:, None, None, None, None]).reshape(nE, n * N, n * N)
+
+
+def _corner_perturbations(sim: "Simulator", deltaP):
+    """extractElementCornerValues (LinearElasticity.hh:1290-1295): [nE, nv, N]; vertex v is node v."""
+    m = sim.mesh
+    return np.asarray(deltaP, dtype=np.float64)[m.elem_nodes[:, :m.K + 1]]
+
+
+def apply_delta_stiffness_matrix(sim: "Simulator", u_nodes, deltaP):
+    """Simulator::applyDeltaStiffnessMatrix (LinearElasticity.hh:1301-1328): per-node u -> per-DoF load."""
+    m, N = sim.mesh, sim.N
+    dKe = delta_per_element_stiffness_batch(sim.deg, sim.K, sim.gl, sim.vol, sim.C4, _corner_perturbations(sim, deltaP))
+    ue = np.asarray(u_nodes)[m.elem_nodes].reshape(len(m.elems), -1)
+    fe = np.einsum('eij,ej->ei', dKe, ue).reshape(len(m.elems), m.nodes_per_elem, N)
+    out = np.zeros((sim.numDoFs(), N))
+    np.add.at(out, sim.dof_array()[m.elem_nodes], fe)
+    return out
+
+
+def delta_constant_strain_load(sim: "Simulator", cstrain, deltaP):
+    """Simulator::deltaConstantStrainLoad (:1331-1348) with deltaPerElementConstantStrainLoad (:289-304):
+    l(c,i) = [int_vol delta strain(phi_ic) + int_dvol strain(phi_ic)] : (C : cstrain)."""
+    m, N = sim.mesh, sim.N
+    dp = _corner_perturbations(sim, deltaP)
+    load = np.zeros((sim.numDoFs(), N))
+    for e in range(len(m.elems)):
+        gl, vol = sim.gl[e], sim.vol[e]
+        s = sim.elem_D(e).double_contract(cstrain)
+        dvol = vol * relative_delta_volume(gl, dp[e])
+        phi = _vec_phi_strains(N, m.nodes_per_elem, lambda i: grad_phi_nodal(sim.deg, sim.K, gl, i))
+        dphi = _vec_phi_strains(N, m.nodes_per_elem, lambda i: delta_grad_phi_nodal(sim.deg, sim.K, gl, i, dp[e]))
+        for i in range(m.nodes_per_elem):
+            for c in range(N):
+                l = np.sum(interpolant_integrate(sim.K, sim.deg - 1, dphi[i * N + c], vol) * s)
+                l += np.sum(interpolant_integrate(sim.K, sim.deg - 1, phi[i * N + c], dvol) * s)
+                load[sim.DoF(m.elem_nodes[e, i]), c] += l
+    return load
+
+
+def delta_average_strain_field(sim: "Simulator", u_nodes, delta_u, deltaP):
+    """Simulator::deltaAverageStrainField (:1364-1374): (delta strain)(u).average() + strain(delta u).average(),
+    with deltaStrain (:259-277). Flattened [nE, flatLen]."""
+    m, N = sim.mesh, sim.N
+    dp = _corner_perturbations(sim, deltaP)
+    out = sim.averageStrainField(np.asarray(delta_u))
+    for e in range(len(m.elems)):
+        deps = np.zeros((N, N))
+        for i in range(m.nodes_per_elem):
+            dg = interpolant_integrate(sim.K, sim.deg - 1, delta_grad_phi_nodal(sim.deg, sim.K, sim.gl[e], i, dp[e]), 1.0)
+            ui = np.asarray(u_nodes)[m.elem_nodes[e, i]]
+            deps += 0.5 * (np.outer(ui, dg) + np.outer(dg, ui))
+        out[e] += flatten_sym(N, deps)
+    return out
+
+
+def delta_fluctuation_displacements(sim: "Simulator", w, deltaP):
+    """deltaFluctuationDisplacements (PeriodicHomogenization.hh:527-544)."""
+    out = []
+    for ij in range(len(w)):
+        rhs = delta_constant_strain_load(sim, -canonical_strain(sim.N, ij), deltaP)
+        rhs -= apply_delta_stiffness_matrix(sim, w[ij], deltaP)
+        out.append(sim.solve(rhs))
+    return out
+
+
+def _strain_at_quadrature(sim: "Simulator", u_nodes, gl_batch):
+    """sym(sum_i u_i (x) grad phi_i) at the points of the degree-2(deg-1) rule: [nE, nq, N, N]."""
+    G, w = gradphi_at_quadrature(sim.deg, sim.K, gl_batch)
+    ue = np.asarray(u_nodes)[sim.mesh.elem_nodes]                     # [nE, n, N]
+    Gu = np.einsum('eic,eqib->eqcb', ue, G)
+    return 0.5 * (Gu + np.transpose(Gu, (0, 1, 3, 2))), w
+
+
+def mutual_energies(sim: "Simulator", w, deltaP=None):
+    """sum_e int (e^ij + eps(w^ij)) : C : (e^kl + eps(w^kl)) dV  (= |Y| Ch, energy form), or with deltaP the volume
+    form of its discrete shape derivative quoted at PeriodicHomogenization.hh:484-491."""
+    N, fl = sim.N, flat_len(sim.N)
+    nE = len(sim.mesh.elems)
+    C4 = np.broadcast_to(sim.C4, (nE,) + (N,) * 4)
+    G, dG = [], []
+    if deltaP is not None:
+        dgl, rel = delta_gl_batch(sim.gl, _corner_perturbations(sim, deltaP))
+    for ij in range(fl):
+        S, wq = _strain_at_quadrature(sim, w[ij], sim.gl)
+        G.append(S + canonical_strain(N, ij)[None, None])
+        if deltaP is not None:
+            dG.append(_strain_at_quadrature(sim, w[ij], dgl)[0])
+    out = np.zeros((fl, fl))
+    for ij in range(fl):
+        for kl in range(fl):
+            if deltaP is None:
+                v = np.einsum('q,e,eqab,eabcd,eqcd->', wq, sim.vol, G[ij], C4, G[kl], optimize=True)
+            else:
+                v = np.einsum('q,e,eqab,eabcd,eqcd->', wq, sim.vol * rel, G[ij], C4, G[kl], optimize=True) \
+                    + np.einsum('q,e,eqab,eabcd,eqcd->', wq, sim.vol, dG[ij], C4, G[kl], optimize=True) \
+                    + np.einsum('q,e,eqab,eabcd,eqcd->', wq, sim.vol, G[ij], C4, dG[kl], optimize=True)
+            out[ij, kl] = v
+    return out
 
 
 # --------------------------------------------------------------------------------------

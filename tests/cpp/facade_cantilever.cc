@@ -51,7 +51,16 @@ int main(int argc, char **argv) {
         if (std::fabs(fy + 1.0) > 1e-12 || tip > -1.2 || tip < -1.6) return 2;
         auto eps = sim.averageStrainField(u);
         auto Ku = sim.applyStiffnessMatrix(u);
-        (void)eps; (void)Ku;
+        (void)eps;
+        // shape derivative under the uniform dilation delta_p = x: K scales with length^(dim-2), so (delta K) u = K u in 3D
+        decltype(u) dp(V.size());
+        for (size_t n = 0; n < V.size(); ++n) dp[n] = {V[n][0], V[n][1], V[n][2]};
+        auto dKu = sim.applyDeltaStiffnessMatrix(u, dp);
+        Real err = 0, nrm = 0;
+        for (size_t n = 0; n < Ku.size(); ++n)
+            for (int c2 = 0; c2 < 3; ++c2) { err = std::max(err, std::fabs(dKu[n][c2] - Ku[n][c2])); nrm = std::max(nrm, std::fabs(Ku[n][c2])); }
+        printf("dilation shape derivative: |dK u - K u| / |K u| = %.2e\n", err / nrm);
+        if (err > 1e-10 * nrm) return 4;
         return 0;
     } catch (const std::runtime_error &e) {
         printf("runtime_error: %s\n", e.what());

@@ -1,0 +1,253 @@
+"""Discrete shape derivatives, forward mode (second half): deltaPerElementStiffness,
+applyDeltaStiffnessMatrix, deltaConstantStrainLoad, deltaAverageStrainField (LinearElasticity.hh:234-330,
+:1297-1374), deltaFluctuationDisplacements and the volume form of deltaHomogenizedElasticityTensor
+(PeriodicHomogenization.hh:484-544).
+
+No reference test pins these ("parity unpinned"): the oracle's literal restatement is anchored on central finite
+differences of its own operators on the perturbed mesh (CPU tests below), and the HIP path is compared with the
+oracle (GPU tests). Tolerances: FD_RTOL for finite differences (h = 1e-6, O(h^2) truncation + rounding / h),
+HIP_RTOL = 1e-11 relative for the device kernels against the oracle (same arithmetic, different summation order),
+U_RTOL on solved fields (PCG)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import meshfem_oracle as O
+
+FD_RTOL = 2e-8
+HIP_RTOL = 1e-11
+U_RTOL = 1e-6
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _material(dim, kind):
+    if kind == "iso":
+        return O.ElasticityTensor.isotropic(dim, 200.0, 0.35)
+    if dim == 3:
+        return O.ElasticityTensor.orthotropic3d(150, 200, 250, 0.3, 0.25, 0.2, 60, 70, 80)
+    return O.ElasticityTensor.orthotropic2d(150, 220, 0.28, 65)
+
+
+def _grid(dim):
+    if dim == 3:
+        V, T = O.grid_tet_mesh(2, 2, 2)
+        return V / 2.0, T
+    V, Q = O.gen_grid_2d(3, 3)
+    V, T = O.quad_tri_subdiv(V, Q)
+    return V[:, :2] / 3.0, T
+
+
+def _interior_perturbation(V, rng, scale=0.05):
+    """Random per-vertex perturbation that leaves the boundary of the (unit) cell alone, so that perturbed cells stay
+    periodic."""
+    dp = rng.normal(size=V.shape) * scale
+    on_bdry = (np.abs(V - V.min(axis=0)) < 1e-12).any(axis=1) | (np.abs(V - V.max(axis=0)) < 1e-12).any(axis=1)
+    dp[on_bdry] = 0.0
+    return dp
+
+
+def _sim(V, T, deg, mat, periodic=False):
+    sim = O.Simulator(T, V, deg)
+    sim.set_material_constant(mat)
+    if periodic:
+        sim.applyPeriodicConditions()
+    return sim
+
+
+# ------------------------------------------------------------------------------------------------ CPU: oracle
+@pytest.mark.parametrize("K,deg", [(3, 1), (3, 2), (2, 1), (2, 2)])
+def test_oracle_delta_ke_literal_vs_batch_vs_finite_differences(K, deg):
+    rng = np.random.default_rng(10 * K + deg)
+    P = rng.normal(size=(K + 1, K))
+    vol, gl = O.embed(K, P)
+    if vol < 0:
+        P[[0, 1]] = P[[1, 0]]
+        vol, gl = O.embed(K, P)
+    D = _material(K, "ortho")
+    dp = rng.normal(size=(K + 1, K))
+    lit = O.delta_per_element_stiffness_loop(deg, K, gl, vol, D, dp)
+    bat = O.delta_per_element_stiffness_batch(deg, K, gl[None], np.array([vol]), D.rank4()[None], dp[None])[0]
+    iu = np.triu_indices(lit.shape[0])
+    assert np.isnan(lit[np.tril_indices(lit.shape[0], -1)]).all()          # upper triangle only, like the reference
+    assert np.abs(lit[iu] - bat[iu]).max() < 1e-13 * np.abs(bat).max()
+    assert np.abs(bat - bat.T).max() < 1e-13 * np.abs(bat).max()
+
+    def Ke(Pp):
+        v, g = O.embed(K, Pp)
+        return O.per_element_stiffness_batch(deg, K, g[None], np.array([v]), D.rank4()[None])[0]
+    h = 1e-6
+    fd = (Ke(P + h * dp) - Ke(P - h * dp)) / (2 * h)
+    assert np.abs(fd - bat).max() < FD_RTOL * np.abs(bat).max()
+
+
+@pytest.mark.parametrize("dim,deg", [(3, 1), (3, 2), (2, 2)])
+def test_oracle_simulator_level_derivatives_vs_finite_differences(dim, deg):
+    rng = np.random.default_rng(dim + deg)
+    V, T = _grid(dim)
+    mat = _material(dim, "ortho")
+    dp = _interior_perturbation(V, rng) + 0.01 * rng.normal(size=V.shape)      # boundary moves too: no periodicity here
+    sim = _sim(V, T, deg, mat)
+    u = rng.normal(size=(sim.mesh.num_nodes, dim))
+    du = rng.normal(size=u.shape)
+    cs = O.canonical_strain(dim, dim) + 0.3 * O.canonical_strain(dim, 0)
+    h = 1e-6
+    sp, sm = _sim(V + h * dp, T, deg, mat), _sim(V - h * dp, T, deg, mat)
+
+    dKu = O.apply_delta_stiffness_matrix(sim, u, dp)
+    fd = (sp.applyStiffnessMatrix(u) - sm.applyStiffnessMatrix(u)) / (2 * h)
+    assert np.abs(dKu - fd).max() < FD_RTOL * np.abs(dKu).max()
+
+    dl = O.delta_constant_strain_load(sim, cs, dp)
+    fd = (sp.constantStrainLoad(cs) - sm.constantStrainLoad(cs)) / (2 * h)
+    assert np.abs(dl - fd).max() < FD_RTOL * np.abs(dl).max()
+
+    de = O.delta_average_strain_field(sim, u, du, dp)
+    fd = (sp.averageStrainField(u + h * du) - sm.averageStrainField(u - h * du)) / (2 * h)
+    assert np.abs(de - fd).max() < FD_RTOL * np.abs(de).max()
+
+
+def _cell(dim, deg, kind="iso"):
+    """A periodic cell with a soft inclusion (two-material isotropic field) so that the fluctuations do not vanish."""
+    V, T = _grid(dim)
+    sim = O.Simulator(T, V, deg)
+    bary = V[T].mean(axis=1)
+    soft = np.linalg.norm(bary - 0.5, axis=1) < 0.3
+    stiff, weak = _material(dim, kind), O.ElasticityTensor.isotropic(dim, 20.0, 0.3)
+    sim.set_material_field([weak if s else stiff for s in soft])
+    return V, T, sim, [weak if s else stiff for s in soft]
+
+
+@pytest.mark.parametrize("dim,deg", [(3, 1), (2, 2)])
+def test_oracle_homogenization_derivatives_vs_finite_differences(dim, deg):
+    rng = np.random.default_rng(7)
+    V, T, sim, mats = _cell(dim, deg)
+    dp = _interior_perturbation(V, rng, 0.04)
+    w = O.solve_cell_problems(sim)
+    tot = 1.0                                                            # unit cell
+    # the three forms of Ch agree at the cell-problem solutions
+    Ch = O.homogenized_elasticity_tensor(sim, w)
+    Che = O.mutual_energies(sim, w) / tot
+    assert np.abs(Ch - Che).max() < 1e-9 * np.abs(Ch).max()
+
+    def solved(Vp):
+        s = O.Simulator(T, Vp, deg)
+        s.set_material_field(mats)
+        ww = O.solve_cell_problems(s)
+        return s, ww
+    h = 1e-5
+    (sp, wp), (sm, wm) = solved(V + h * dp), solved(V - h * dp)
+    dw = O.delta_fluctuation_displacements(sim, w, dp)
+    for k in range(len(w)):
+        fd = (wp[k] - wm[k]) / (2 * h)
+        assert np.abs(dw[k] - fd).max() < 1e-6 * np.abs(dw[k]).max()
+    dCh = O.mutual_energies(sim, w, dp) / tot
+    fd = (O.homogenized_elasticity_tensor(sp, wp) - O.homogenized_elasticity_tensor(sm, wm)) / (2 * h)
+    assert np.abs(dCh - fd).max() < 1e-6 * np.abs(dCh).max()
+    # first variation of the per-element macro-to-micro strain tensors
+    dG = np.stack([O.delta_average_strain_field(sim, w[k], dw[k], dp) for k in range(len(w))], axis=2)
+    fdG = np.stack([(sp.averageStrainField(wp[k]) - sm.averageStrainField(wm[k])) / (2 * h) for k in range(len(w))], axis=2)
+    assert np.abs(dG - fdG).max() < 1e-6 * np.abs(dG).max()
+
+
+# ------------------------------------------------------------------------------------------------ GPU: HIP vs oracle
+def _hip_sim(V, T, deg, mats_D=None, mat=None):
+    from meshfem_amd.linear_elasticity import Simulator
+    sim = Simulator(T, V, deg)
+    sim.rtol = 1e-12
+    if mat is not None:
+        sim.setMaterial(mat.D)
+    else:
+        sim.ctx.material_tensor_field(np.stack(mats_D))
+    return sim
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,deg,kind", [(3, 1, "iso"), (3, 2, "iso"), (3, 2, "ortho"), (2, 1, "ortho"), (2, 2, "iso")])
+def test_hip_simulator_level_derivatives_match_oracle(dim, deg, kind):
+    rng = np.random.default_rng(3 * dim + deg)
+    V, T = _grid(dim)
+    mat = _material(dim, kind)
+    dp = rng.normal(size=V.shape) * 0.05
+    osim = _sim(V, T, deg, mat, periodic=True)
+    hsim = _hip_sim(V, T, deg, mat=mat)
+    hsim.applyPeriodicConditions()
+    u = rng.normal(size=(osim.mesh.num_nodes, dim))
+    du = rng.normal(size=u.shape)
+    cs = O.canonical_strain(dim, dim) + 0.3 * O.canonical_strain(dim, 0)
+    ref = O.apply_delta_stiffness_matrix(osim, u, dp)
+    got = hsim.applyDeltaStiffnessMatrix(u, dp)
+    assert got.shape == ref.shape and np.abs(got - ref).max() < HIP_RTOL * np.abs(ref).max()
+    ref = O.delta_constant_strain_load(osim, cs, dp)
+    got = hsim.deltaConstantStrainLoad(O.flatten_sym(dim, cs), dp)
+    assert np.abs(got - ref).max() < HIP_RTOL * np.abs(ref).max()
+    ref = O.delta_average_strain_field(osim, u, du, dp)
+    got = hsim.deltaAverageStrainField(u, du, dp)
+    assert np.abs(got - ref).max() < HIP_RTOL * np.abs(ref).max()
+    sig = hsim.deltaAverageStressField(u, du, dp)
+    refs = np.stack([mat.double_contract_flat(e) for e in ref])
+    assert np.abs(sig - refs).max() < HIP_RTOL * np.abs(refs).max()
+    # a rigid translation of the whole mesh changes nothing
+    rigid = np.tile(rng.normal(size=dim), (len(V), 1))
+    scale = np.abs(hsim.applyDeltaStiffnessMatrix(u, dp)).max()
+    assert np.abs(hsim.applyDeltaStiffnessMatrix(u, rigid)).max() < 1e-9 * scale
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,deg", [(3, 1), (3, 2), (2, 2)])
+def test_hip_homogenization_derivatives_match_oracle(dim, deg):
+    from meshfem_amd import homogenization as H
+    rng = np.random.default_rng(11)
+    V, T, osim, mats = _cell(dim, deg)
+    dp = _interior_perturbation(V, rng, 0.04)
+    hsim = _hip_sim(V, T, deg, mats_D=[m.D for m in mats])
+    w, _ = H.solve_cell_problems(hsim)
+    ow = O.solve_cell_problems(osim)
+    for a, b in zip(w, ow):
+        assert np.linalg.norm(a - b) < U_RTOL * np.linalg.norm(b)
+    E = H.homogenized_elasticity_tensor_energy_form(hsim, w)
+    assert np.abs(E - O.mutual_energies(osim, ow)).max() < 1e-8 * np.abs(E).max()
+    assert np.abs(E - H.homogenized_elasticity_tensor(hsim, w)).max() < 1e-8 * np.abs(E).max()
+    # same inputs -> kernel parity
+    assert np.abs(hsim.ctx.mutual_energies(ow) - O.mutual_energies(osim, ow)).max() < HIP_RTOL * np.abs(E).max()
+    dref = O.mutual_energies(osim, ow, dp)
+    assert np.abs(hsim.ctx.mutual_energies(ow, dp) - dref).max() < HIP_RTOL * np.abs(dref).max()
+    dCh = H.delta_homogenized_elasticity_tensor(hsim, w, dp)
+    assert np.abs(dCh - dref).max() < 1e-7 * np.abs(dref).max()
+    dw = H.delta_fluctuation_displacements(hsim, w, dp)
+    odw = O.delta_fluctuation_displacements(osim, ow, dp)
+    for a, b in zip(dw, odw):
+        assert np.linalg.norm(a - b) < U_RTOL * np.linalg.norm(b)
+    dG = H.delta_macro_strain_to_micro_strain_tensors(hsim, w, dw, dp)
+    odG = np.stack([O.delta_average_strain_field(osim, ow[k], odw[k], dp) for k in range(len(ow))], axis=2)
+    assert np.abs(dG - odG).max() < U_RTOL * np.abs(odG).max()
+    # compliance: d(Sh) = -Sh : dCh : Sh, checked through Sh(Ch + t dCh) on the flattened tensors
+    dS = H.delta_homogenized_compliance_tensor(hsim, w, dp)
+    dbl = np.ones(len(E)); dbl[dim:] = 2.0
+    comp = lambda C: np.linalg.inv(C * dbl[None, :]) / dbl[None, :]
+    t = 1e-6
+    fd = (comp(E + t * dCh) - comp(E - t * dCh)) / (2 * t)
+    assert np.abs(dS - fd).max() < 1e-6 * np.abs(dS).max()
+
+
+@pytest.mark.gpu
+def test_hip_delta_K_on_reference_example_mesh_vs_finite_difference_of_device_operator():
+    """cube_cross.msh (P2): (delta K) u from the shape-derivative kernel equals the central difference of the device's
+    own matrix-free K u on the perturbed meshes."""
+    from meshfem_amd import mesh_io
+    from meshfem_amd.linear_elasticity import Simulator
+    V, E, _ = mesh_io.load_msh(os.path.join(GOLD, "meshes", "cube_cross.msh"))
+    rng = np.random.default_rng(5)
+    dp = rng.normal(size=V.shape) * 0.02
+    mat = _material(3, "iso")
+
+    def make(Vp):
+        s = Simulator(E, Vp, 2)
+        s.setMaterial(mat.D)
+        return s
+    sim = make(V)
+    u = rng.normal(size=(sim.ctx.n_node, 3))
+    got = sim.applyDeltaStiffnessMatrix(u, dp)
+    h = 1e-6
+    fd = (make(V + h * dp).applyStiffnessMatrix(u) - make(V - h * dp).applyStiffnessMatrix(u)) / (2 * h)
+    assert np.abs(got - fd).max() < FD_RTOL * np.abs(got).max()
