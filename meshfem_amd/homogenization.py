@@ -90,6 +90,79 @@ def homogenized_elasticity_tensor_displacement_form(sim: Simulator, w_ij, base_c
     return Eh / base_cell_volume
 
 
+# ---- orthotropic base cell (OrthotropicHomogenization.hh): 1/4 (2D) or 1/8 (3D) of the period cell
+def ortho_cell_fixed_vars(sim: Simulator, cell_epsilon=1e-7):
+    """Fixed-variable sets of Orthotropic::solveCellProblems (OrthotropicHomogenization.hh:84-136): element 0 for the N
+    stretch probes (w_c = 0 on the reflection planes with normal e_c), then one per shear probe s (3D: always the
+    component perpendicular to the shear plane; for planes c != s also the component that is neither c nor s; 2D: the
+    component other than c). Variables are N * node + c."""
+    N, fl = sim.N, flat_len(sim.N)
+    pos = sim.nodes()
+    mn, mx = pos.min(axis=0), pos.max(axis=0)
+    on = (np.abs(pos - mn) <= cell_epsilon) | (np.abs(pos - mx) <= cell_epsilon)     # FaceMembership::onMinOrMaxFace
+    sets = [np.flatnonzero(on.ravel())]
+    for s in range(fl - N):
+        fix = np.zeros_like(on)
+        for c in range(N):
+            if N == 3:
+                fix[:, s] |= on[:, c]
+                if c != s:
+                    fix[:, N - (c + s)] |= on[:, c]
+            else:
+                fix[:, 1 if c == 0 else 0] |= on[:, c]
+        sets.append(np.flatnonzero(fix.ravel()))
+    return sets
+
+
+def solve_cell_problems_orthotropic(sim: Simulator, cell_epsilon=1e-7):
+    """== Orthotropic::solveCellProblems (OrthotropicHomogenization.hh:44-153): no periodicity, no rigid-motion rows;
+    symmetry planes fix components instead. The reference builds 1 + (flatLen - N) copies of K in separate SPSDSystems;
+    here the operator is assembled once and only the fixed-variable mask (and the diagonal blocks derived from it)
+    changes between the probes."""
+    sim.removePeriodicConditions()
+    sim.removeNoRigidMotionConstraint()
+    N, c = sim.N, sim.ctx
+    c.assemble()
+    loads = [sim.constantStrainLoad(-canonical_strain_flat(N, k)) for k in range(flat_len(N))]
+    sets = ortho_cell_fixed_vars(sim, cell_epsilon)
+    w, infos = [None] * flat_len(N), [None] * flat_len(N)
+    for si, fv in enumerate(sets):
+        probes = range(N) if si == 0 else [N + si - 1]
+        c.clear_fixed()
+        c.fix_variables(fv, np.zeros(len(fv)))
+        for k in probes:
+            w[k] = c.solve(loads[k].ravel(), rtol=sim.rtol, maxit=sim.maxit).reshape(-1, N)
+            infos[k] = dict(c.last_info)
+    c.clear_fixed()
+    return w, infos
+
+
+def fluctuation_displacement_sign(N, ij, r):
+    """OrthotropicHomogenization.hh:161-174: sign of probe ij's fluctuation under the reflection with bit mask r."""
+    if ij < N:
+        return 1.0
+    bits = [(r >> b) & 1 for b in range(N)]
+    if N == 3:
+        bits[ij - N] = 0
+    return -1.0 if sum(bits) == 1 else 1.0
+
+
+def homogenized_tensor_from_ortho_cell_quantity(N, EhO):
+    """OrthotropicHomogenization.hh:183-198: average of the sub-cell quantity over the 2^N reflections."""
+    fl = flat_len(N)
+    sg = np.array([[fluctuation_displacement_sign(N, ij, r) for ij in range(fl)] for r in range(1 << N)])
+    Eh = np.triu(np.einsum("ri,rj->ij", sg, sg) * np.asarray(EhO)) / (1 << N)
+    return Eh + np.triu(Eh, 1).T
+
+
+def homogenize_orthotropic_cell(sim: Simulator, base_cell_volume=0.0, form="displacement"):
+    """Orthotropic::homogenizedElasticityTensor{DisplacementForm} (:200-216) on the simulator of the orthotropic base
+    cell. Returns (Ch, w_ij, infos)."""
+    w, infos = solve_cell_problems_orthotropic(sim)
+    f = homogenized_elasticity_tensor_displacement_form if form == "displacement" else homogenized_elasticity_tensor
+    return homogenized_tensor_from_ortho_cell_quantity(sim.N, f(sim, w, base_cell_volume)), w, infos
+
+
 def homogenized_elasticity_tensor_energy_form(sim: Simulator, w_ij, base_cell_volume=0.0):
     """Ch_ijkl = 1/|Y| int (e^ij + eps(w^ij)) : C : (e^kl + eps(w^kl)) dV, one device reduction per tensor entry.
     Equal to the stress-like and displacement forms at the cell-problem solutions."""

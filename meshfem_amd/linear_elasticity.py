@@ -58,6 +58,9 @@ class Simulator:
     def applyPeriodicConditions(self, epsilon=1e-7):                    # :845-854
         return self.ctx.apply_periodic_conditions(epsilon)
 
+    def removePeriodicConditions(self):                                 # :874-879
+        self.ctx.dof_map(None, 0)
+
     def applyNoRigidMotionConstraint(self):                             # m_useRigidMotionConstraint (:1214-1228)
         self._no_rigid_motion = True
 

@@ -22,7 +22,8 @@ and CHOLMOD itself (SuiteSparse, conda pin 5.4.0) is absent: for that boundary t
 "PARITY UNPINNED" -- it is anchored instead on exact mathematics (sympy rational Ke, patch tests,
 rigid-mode null space, energy identity) and scipy.sparse.linalg.splu stands in for CHOLMOD (a general sparse LU of
 the KKT matrix for UMFPACK in the constraint-row branch). Also restated here: Laplacian.hh / MassMatrix.hh / Poisson.hh,
-both homogenized-tensor forms of PeriodicHomogenization.hh, assembleConstrainedSystem's rigid-motion rows, and the discrete
+both homogenized-tensor forms of PeriodicHomogenization.hh, OrthotropicHomogenization.hh (checked on the reference's
+2D_microstructure_orthocell.msh / 2D_microstructure.msh pair), assembleConstrainedSystem's rigid-motion rows, and the discrete
 shape derivatives (deltaPerElementStiffness & co., pinned on finite differences of this oracle's own operators).
 
 All `file:line` citations are relative to /root/reference/src/lib/MeshFEM/ unless noted.
@@ -1156,6 +1157,91 @@ def homogenized_elasticity_tensor_displacement_form(sim: Simulator, w, base_cell
             Eh[i, :] += EBase.double_contract_flat(flatten_sym(N, nw))
     Eh += EBase.D * float(np.sum(sim.vol))
     return Eh / base_cell_volume
+
+
+# --------------------------------------------------------------------------------------
+# Orthotropic-cell homogenization                         OrthotropicHomogenization.hh:44-219
+# --------------------------------------------------------------------------------------
+def face_membership(p, mn, mx, eps):
+    """PeriodicBoundaryMatcher::FaceMembership (PeriodicBoundaryMatcher.hh:37-50): (onMin[d], onMax[d])."""
+    p = np.asarray(p)
+    return np.abs(p - mn) <= eps, np.abs(p - mx) <= eps
+
+
+def ortho_cell_fixed_vars(sim: Simulator, eps=1e-7):
+    """Fixed-variable sets of Orthotropic::solveCellProblems (OrthotropicHomogenization.hh:84-136):
+    [stretch system, shear system s = 0 .. flatLen - N - 1]. Variables N * node + c, sorted."""
+    m, N = sim.mesh, sim.N
+    mn, mx = m.bounding_box()
+    bnodes = np.unique(m.bdry_elem_nodes)
+    pos = m.node_pos
+    sets = []
+    stretch = []
+    for n in bnodes:                                                  # :88-94  w^ii_c = 0 on reflection plane c
+        lo, hi = face_membership(pos[n], mn, mx, eps)
+        for c in range(N):
+            if lo[c] or hi[c]:
+                stretch.append(N * n + c)
+    sets.append(np.array(sorted(stretch), dtype=np.int64))
+    for s_ in range(flat_len(N) - N):                                 # :105-136
+        fix = np.zeros(N * m.num_nodes, dtype=bool)
+        for n in bnodes:
+            lo, hi = face_membership(pos[n], mn, mx, eps)
+            for c in range(N):
+                if lo[c] or hi[c]:
+                    if N == 3:
+                        fix[N * n + s_] = True                        # perpendicular to the shear plane
+                        if c != s_:
+                            fix[N * n + (N - (c + s_))] = True        # neither c nor s
+                    else:
+                        fix[N * n + (1 if c == 0 else 0)] = True
+        sets.append(np.flatnonzero(fix).astype(np.int64))
+    return sets
+
+
+def solve_cell_problems_orthotropic(sim: Simulator, eps=1e-7):
+    """Orthotropic::solveCellProblems: no periodicity / rigid-motion constraint; one SPD system for the N stretch probes,
+    one per shear probe (:44-153)."""
+    sim.dofForNode, sim.numDoFs_ = None, sim.mesh.num_nodes          # removePeriodicConditions (:874-879)
+    sim.beInternal[:] = False
+    sim.useRigidMotionConstraint = False
+    sim._system = None
+    N = sim.N
+    K = sim.assembleStiffnessMatrix()
+    K.sum_repeated()
+    systems = []
+    for fv in ortho_cell_fixed_vars(sim, eps):
+        sysm = SPSDSystem(K)
+        sysm.fix_variables(fv, np.zeros(len(fv)))
+        systems.append(sysm)
+    w = []
+    for ij in range(flat_len(N)):
+        l = sim.constantStrainLoad(-canonical_strain(N, ij))
+        sysm = systems[0] if ij < N else systems[ij - N + 1]
+        w.append(sysm.solve(l.ravel()).reshape(-1, N))
+    return w
+
+
+def fluctuation_displacement_sign(N, ij, r):
+    """OrthotropicHomogenization.hh:161-174."""
+    if ij < N:
+        return 1.0
+    bits = [(r >> b) & 1 for b in range(N)]
+    if N == 3:
+        bits[ij - N] = 0
+    return -1.0 if sum(bits) == 1 else 1.0
+
+
+def homogenized_tensor_from_ortho_cell_quantity(N, EhO):
+    """OrthotropicHomogenization.hh:183-198 (upper triangle accumulated, major-symmetric result)."""
+    fl = flat_len(N)
+    Eh = np.zeros((fl, fl))
+    for r in range(1 << N):
+        for kl in range(fl):
+            for ij in range(kl + 1):
+                Eh[ij, kl] += fluctuation_displacement_sign(N, ij, r) * fluctuation_displacement_sign(N, kl, r) * EhO[ij, kl]
+    Eh /= (1 << N)
+    return np.triu(Eh) + np.triu(Eh, 1).T
 
 
 # --------------------------------------------------------------------------------------

@@ -1,0 +1,174 @@
+"""Orthotropic-cell homogenization (OrthotropicHomogenization.hh:44-219; `homogenize(..., orthotropicCell=True)` of the
+Python binding, periodic_homogenization.cc:53-56): the cell problems on 1/4 (2D) or 1/8 (3D) of a reflection-symmetric
+period cell, with components fixed on the symmetry planes instead of periodicity, then the average over reflections.
+
+Anchors: the reference ships BOTH `2D_microstructure_orthocell.msh` and the full `2D_microstructure.msh` it is a quarter
+of (examples/meshes, data files copied to tests/golden/meshes): the ortho route on the former must equal the periodic
+route on the latter. In 3D the full cell is built by reflecting an octant. Tolerances: 1e-9 relative on Ch for the
+direct-solve oracle (an exact discrete identity on symmetric meshes), CH_RTOL for the PCG path."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import meshfem_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CH_RTOL = 1e-7
+U_RTOL = 1e-6
+
+
+def _load2d(name):
+    from meshfem_amd import mesh_io
+    V, E, _ = mesh_io.load_msh(os.path.join(GOLD, "meshes", name + ".msh"))
+    return V[:, :2].copy(), E
+
+
+def _octant():
+    """Octant [0,1]^3 of a period cell [0,2]^3... kept as [0,1]^3: 3x3x3 hexes split into tets, soft corner inclusion."""
+    V, T = O.grid_tet_mesh(3, 3, 3)
+    V = V / 3.0
+    soft = np.linalg.norm(V[T].mean(axis=1), axis=1) < 0.55
+    return V, T, soft
+
+
+def _reflect(V, T, tags):
+    """Full cell from the octant/quadrant: all 2^N reflections about the max planes, duplicate vertices merged,
+    orientation restored for odd reflections."""
+    N = V.shape[1]
+    mx = V.max(axis=0)
+    allV, allT, allTags = [], [], []
+    for r in range(1 << N):
+        Vr = V.copy()
+        odd = False
+        for d in range(N):
+            if (r >> d) & 1:
+                Vr[:, d] = 2 * mx[d] - Vr[:, d]
+                odd = not odd
+        Tr = T.copy()
+        if odd:
+            Tr[:, [0, 1]] = Tr[:, [1, 0]]
+        allT.append(Tr + len(V) * r)
+        allV.append(Vr)
+        allTags.append(tags)
+    Vc, Tc = np.vstack(allV), np.vstack(allT)
+    key = np.round(Vc * 1e9).astype(np.int64)
+    _, first, inv = np.unique(key, axis=0, return_index=True, return_inverse=True)
+    return Vc[first], inv.ravel()[Tc], np.concatenate(allTags)
+
+
+def _materials(dim, soft):
+    stiff = O.ElasticityTensor.orthotropic3d(150, 200, 250, 0.3, 0.25, 0.2, 60, 70, 80) if dim == 3 \
+        else O.ElasticityTensor.orthotropic2d(150, 220, 0.28, 65)
+    weak = O.ElasticityTensor.isotropic(dim, 20.0, 0.3)
+    return [weak if s else stiff for s in soft]
+
+
+# ------------------------------------------------------------------------------------------------ CPU: oracle
+def test_reflection_sign_table():
+    # stretch probes never flip; a 3D shear probe ij ignores the reflection perpendicular to its plane
+    assert all(O.fluctuation_displacement_sign(3, ij, r) == 1.0 for ij in range(3) for r in range(8))
+    assert [O.fluctuation_displacement_sign(2, 2, r) for r in range(4)] == [1.0, -1.0, -1.0, 1.0]
+    assert [O.fluctuation_displacement_sign(3, 3, r) for r in range(8)] == [1.0, 1.0, -1.0, -1.0, -1.0, -1.0, 1.0, 1.0]
+    EhO = np.arange(36, dtype=float).reshape(6, 6)
+    Eh = O.homogenized_tensor_from_ortho_cell_quantity(3, EhO + EhO.T)
+    assert np.abs(Eh[:3, 3:]).max() == 0 and np.abs(Eh[3, 4]) == 0       # couplings an orthotropic tensor cannot have
+    assert np.allclose(Eh[:3, :3], (EhO + EhO.T)[:3, :3]) and np.allclose(np.diag(Eh), np.diag(EhO + EhO.T))
+
+
+@pytest.mark.parametrize("deg", [1, 2])
+def test_oracle_reference_orthocell_mesh_equals_reference_full_cell_mesh(deg):
+    base = O.ElasticityTensor.isotropic(2, 200.0, 0.35)
+    Vo, Eo = _load2d("2D_microstructure_orthocell")
+    Vf, Ef = _load2d("2D_microstructure")
+    so = O.Simulator(Eo, Vo, deg); so.set_material_constant(base)
+    w = O.solve_cell_problems_orthotropic(so)
+    Cd = O.homogenized_tensor_from_ortho_cell_quantity(2, O.homogenized_elasticity_tensor_displacement_form(so, w))
+    Cs = O.homogenized_tensor_from_ortho_cell_quantity(2, O.homogenized_elasticity_tensor(so, w))
+    sf = O.Simulator(Ef, Vf, deg); sf.set_material_constant(base)
+    Cf = O.homogenized_elasticity_tensor(sf, O.solve_cell_problems(sf))
+    assert np.abs(Cd - Cf).max() < 1e-9 * np.abs(Cf).max()
+    assert np.abs(Cs - Cf).max() < 1e-9 * np.abs(Cf).max()
+
+
+def test_oracle_3d_octant_equals_reflected_full_cell():
+    V, T, soft = _octant()
+    mats = _materials(3, soft)
+    so = O.Simulator(T, V, 1); so.set_material_field(mats)
+    w = O.solve_cell_problems_orthotropic(so)
+    Co = O.homogenized_tensor_from_ortho_cell_quantity(3, O.homogenized_elasticity_tensor(so, w))
+    Vf, Tf, softf = _reflect(V, T, soft)
+    assert len(Tf) == 8 * len(T) and abs(np.prod(Vf.max(axis=0) - Vf.min(axis=0)) - 8.0) < 1e-12
+    sf = O.Simulator(Tf, Vf, 1); sf.set_material_field(_materials(3, softf))
+    Cf = O.homogenized_elasticity_tensor(sf, O.solve_cell_problems(sf))
+    assert np.abs(Co - Cf).max() < 1e-9 * np.abs(Cf).max()
+    assert np.abs(Cf[:3, 3:]).max() < 1e-9 * np.abs(Cf).max()            # the full cell is orthotropic
+
+
+# ------------------------------------------------------------------------------------------------ GPU: HIP path
+@pytest.mark.gpu
+@pytest.mark.parametrize("deg", [1, 2])
+def test_hip_orthocell_2d_matches_oracle_and_full_cell(deg):
+    from meshfem_amd import homogenization as H
+    from meshfem_amd.linear_elasticity import Simulator
+    base = O.ElasticityTensor.isotropic(2, 200.0, 0.35)
+    Vo, Eo = _load2d("2D_microstructure_orthocell")
+    so = O.Simulator(Eo, Vo, deg); so.set_material_constant(base)
+    ow = O.solve_cell_problems_orthotropic(so)
+    oC = O.homogenized_tensor_from_ortho_cell_quantity(2, O.homogenized_elasticity_tensor_displacement_form(so, ow))
+    sim = Simulator(Eo, Vo, deg); sim.rtol = 1e-11; sim.setMaterial(base.D)
+    sets = H.ortho_cell_fixed_vars(sim)
+    for a, b in zip(sets, O.ortho_cell_fixed_vars(so)):
+        assert np.array_equal(a, b)                                        # index work: bit-exact
+    for form in ("displacement", "stress"):
+        Ch, w, infos = H.homogenize_orthotropic_cell(sim, form=form)
+        assert all(i["converged"] for i in infos)
+        for a, b in zip(w, ow):
+            assert np.linalg.norm(a - b) < U_RTOL * np.linalg.norm(b)
+        assert np.abs(Ch - oC).max() < CH_RTOL * np.abs(oC).max()
+    # and the periodic route on the reference's full cell gives the same tensor
+    Vf, Ef = _load2d("2D_microstructure")
+    full = Simulator(Ef, Vf, deg); full.rtol = 1e-11; full.setMaterial(base.D)
+    wf, _ = H.solve_cell_problems(full)
+    Cf = H.homogenized_elasticity_tensor(full, wf)
+    assert np.abs(Ch - Cf).max() < CH_RTOL * np.abs(Cf).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deg", [1, 2])
+def test_hip_orthocell_3d_matches_oracle_and_reflected_cell(deg):
+    from meshfem_amd import homogenization as H
+    from meshfem_amd.linear_elasticity import Simulator
+    V, T, soft = _octant()
+    mats = _materials(3, soft)
+    sim = Simulator(T, V, deg); sim.rtol = 1e-11
+    sim.ctx.material_tensor_field(np.stack([m.D for m in mats]))
+    Ch, w, infos = H.homogenize_orthotropic_cell(sim, form="stress")
+    assert all(i["converged"] for i in infos)
+    if deg == 1:
+        so = O.Simulator(T, V, 1); so.set_material_field(mats)
+        ow = O.solve_cell_problems_orthotropic(so)
+        oC = O.homogenized_tensor_from_ortho_cell_quantity(3, O.homogenized_elasticity_tensor(so, ow))
+        for a, b in zip(w, ow):
+            assert np.linalg.norm(a - b) < U_RTOL * np.linalg.norm(b)
+        assert np.abs(Ch - oC).max() < CH_RTOL * np.abs(oC).max()
+    Vf, Tf, softf = _reflect(V, T, soft)
+    full = Simulator(Tf, Vf, deg); full.rtol = 1e-11
+    full.ctx.material_tensor_field(np.stack([m.D for m in _materials(3, softf)]))
+    wf, _ = H.solve_cell_problems(full)
+    Cf = H.homogenized_elasticity_tensor(full, wf)
+    assert np.abs(Ch - Cf).max() < CH_RTOL * np.abs(Cf).max()
+
+
+@pytest.mark.gpu
+def test_compat_homogenize_orthotropic_cell_flag():
+    """The binding-level call: homogenize(mesh, Cbase, orthotropicCell=True) on the reference's ortho-cell mesh equals
+    homogenize(full mesh, Cbase)."""
+    from meshfem_amd.compat import mesh as cmesh, periodic_homogenization as ph, tensors
+    C = tensors.ElasticityTensor2D(200.0, 0.35)
+    mo = cmesh.Mesh(os.path.join(GOLD, "meshes", "2D_microstructure_orthocell.msh"), degree=2, embeddingDimension=2)
+    mf = cmesh.Mesh(os.path.join(GOLD, "meshes", "2D_microstructure.msh"), degree=2, embeddingDimension=2)
+    ro = ph.homogenize(mo, C, orthotropicCell=True)
+    rf = ph.homogenize(mf, C)
+    assert np.abs(ro.Ch.D - rf.Ch.D).max() < CH_RTOL * np.abs(rf.Ch.D).max()
+    assert len(ro.w_ij) == 3 and ro.strain_w_ij[0].shape == (mo.numElements(), 3)
