@@ -269,6 +269,12 @@ mfh_status mfh_delta_constant_strain_load(mfh_ctx* ctx, const double* cstrainFla
 mfh_status mfh_delta_average_strain(mfh_ctx* ctx, const double* uNodes, const double* deltaU, const double* deltaP,
                                     int32_t wantStress, double* out /* nElem x flatLen */);
 mfh_status mfh_mutual_energies(mfh_ctx* ctx, const double* w, const double* deltaP /* or NULL */, double* out /* flatLen^2 */);
+/* == homogenizedElasticityTensorDiscreteDifferential (PeriodicHomogenization.hh:372-480) before its division by |Y|:
+ * the exact derivative of every mutual energy with respect to every vertex coordinate (reverse mode: all directions in
+ * one element sweep). out: [pair][nVert][dim], pair = row-major index over the upper triangle ij <= kl of the
+ * flatLen x flatLen tensor (flatLen (flatLen + 1) / 2 pairs). Contracting it with a perturbation field reproduces
+ * mfh_mutual_energies(w, deltaP). */
+mfh_status mfh_mutual_energy_differential(mfh_ctx* ctx, const double* w, double* out);
 /* Select the operator (default MFH_OP_ELASTICITY). Keeps mesh, DoF map, pattern and gather lists; drops the
  * assembled values and the fixed variables (their numbering depends on the block size). */
 mfh_status mfh_set_operator(mfh_ctx* ctx, int32_t op);

@@ -97,6 +97,7 @@ PROTOTYPES = {
     "mfh_delta_constant_strain_load": (_i32, [_P, _P, _P, _P]),
     "mfh_delta_average_strain": (_i32, [_P, _P, _P, _P, _i32, _P]),
     "mfh_mutual_energies": (_i32, [_P, _P, _P, _P]),
+    "mfh_mutual_energy_differential": (_i32, [_P, _P, _P]),
     "mfh_dev_spmv": (_i32, [_P, _P, _P]),
     "mfh_dev_precond": (_i32, [_P, _P, _P]),
     "mfh_tl_partitioned_begin": (_i32, [_P, _i32, _P, _P, _P]),

@@ -396,6 +396,16 @@ class Context:
         self._ck(self.lib.mfh_mutual_energies(self.h, ptr(wa), ptr(dp), ptr(out)))
         return out
 
+    def mutual_energy_differential(self, w):
+        """d(mutual energies)/d(vertex positions): [nPairs, nVert, dim], pairs = upper triangle ij <= kl row-major."""
+        fl = flat_len(self.dim)
+        wa = np.ascontiguousarray(np.stack([np.asarray(x, dtype=np.float64).reshape(self.n_node, self.dim) for x in w]))
+        if wa.shape[0] != fl:
+            raise ValueError("need one fluctuation displacement per canonical strain")
+        out = np.empty((fl * (fl + 1) // 2, self.n_vert, self.dim))
+        self._ck(self.lib.mfh_mutual_energy_differential(self.h, ptr(wa), ptr(out)))
+        return out
+
     # ---------------------------------------------------------------- device pointers (torch interop)
     def stream(self):
         return self.lib.mfh_stream(self.h)

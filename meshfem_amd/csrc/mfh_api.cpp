@@ -1956,6 +1956,25 @@ mfh_status mfh_sim_solve_constrained(mfh_ctx *c, const double *f, int32_t flags,
     MFH_CATCH(c)
 }
 
+mfh_status mfh_mutual_energy_differential(mfh_ctx *c, const double *w, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && w && out, MFH_ERR_STATE, "no mesh set");
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "mutual energies are defined for the elasticity operator");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const HostMesh &m = c->mesh;
+    const int d = m.dim, fl = flat_len(d), np = fl * (fl + 1) / 2;
+    DBuf<double> wd, res;
+    wd.alloc((size_t)fl * m.nNode * d);
+    MFH_HIP(hipMemcpyAsync(wd.p, w, wd.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    res.alloc((size_t)np * m.nVert * d);
+    res.zero(c->stream);
+    k::launch_mutual_energy_differential(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), wd.p, m.nNode, m.nVert, res.p, c->stream);
+    res.download(out, res.n, c->stream);
+    MFH_CATCH(c)
+}
+
 static void average_strain_impl(mfh_ctx *c, const double *uNodes, double *out, bool stress, const double *uFixed = nullptr,
                                 const double *deltaP = nullptr) {
     require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "strain / stress fields are defined for the elasticity operator");

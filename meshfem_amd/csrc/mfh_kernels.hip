@@ -961,12 +961,11 @@ DEV void load_corner_perturbation(const double *__restrict__ g, const int32_t *_
 // sym(sum_i u_i (x) grad phi_i(x_q)); P2: grad phi_k = (4 lam_k - 1) gl_k, grad phi_(s,t) = 4 (lam_t gl_s + lam_s gl_t)
 // (EmbeddedElement.hh:315-332) at the vertex-associated points lam_k(x_q) = c0 if k == q else c1.
 template <int DIM, int DEG>
-DEV void sym_grad_u_at(const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM], const double (&gl)[DIM + 1][DIM],
-                       int q, double (&ef)[DIM * (DIM + 1) / 2]) {
+DEV void grad_u_at(const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM], const double (&gl)[DIM + 1][DIM],
+                   int q, double (&G)[DIM][DIM]) {
     constexpr int NV = DIM + 1;
     constexpr double c0 = DIM == 3 ? 0.58541019662496845446 : 2.0 / 3.0;
     constexpr double c1 = DIM == 3 ? 0.13819660112501051518 : 1.0 / 6.0;
-    double G[DIM][DIM];
 #pragma unroll
     for (int p = 0; p < DIM; ++p)
 #pragma unroll
@@ -994,10 +993,102 @@ DEV void sym_grad_u_at(const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DE
 #pragma unroll
             for (int r = 0; r < DIM; ++r) G[p][r] += ck[p] * gl[k][r];
     }
+}
+
+template <int DIM, int DEG>
+DEV void sym_grad_u_at(const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM], const double (&gl)[DIM + 1][DIM],
+                       int q, double (&ef)[DIM * (DIM + 1) / 2]) {
+    double G[DIM][DIM];
+    grad_u_at<DIM, DEG>(xl, gl, q, G);
 #pragma unroll
     for (int p = 0; p < DIM; ++p)
 #pragma unroll
         for (int r = p; r < DIM; ++r) ef[flat_idx<DIM>(p, r)] = 0.5 * (G[p][r] + G[r][p]);
+}
+
+// The exact differential of the mutual energies with respect to every vertex coordinate
+// (homogenizedElasticityTensorDiscreteDifferential, PeriodicHomogenization.hh:372-480, before the division by |Y|):
+// for the unit perturbation e_c of vertex v, delta vol / vol = gl_v[c] and delta grad lambda_i = -gl_v gl_i[c], so that
+// (delta eps)(w) = -sym(grad w[:, c] (x) gl_v) and the element's contribution to d/dp_v is  Q gl_v  with the
+// Eshelby-like tensor
+//     Q = int (G^ij : S^kl) I - (grad w^ij)^T S^kl - (grad w^kl)^T S^ij dV,     S = C : G, G = e + eps(w).
+// One workgroup column per tensor entry ij <= kl (blockIdx.y); out: [pair][nVert][DIM], atomics per element corner.
+template <int DIM, int DEG, int MAT>
+__global__ void __launch_bounds__(256) k_mutual_energy_differential(LoadArgs a, const double *__restrict__ w, int64_t nNode,
+                                                                    int64_t nVert, double *__restrict__ out) {
+    constexpr int NV = DIM + 1;
+    constexpr int FL = DIM * (DIM + 1) / 2;
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    constexpr int NQ = DEG == 1 ? 1 : NV;
+    int ij = 0, rem = blockIdx.y;
+    while (rem >= FL - ij) { rem -= FL - ij; ++ij; }
+    const int kl = ij + rem;
+    const double *wij = w + (int64_t)ij * nNode * DIM, *wkl = w + (int64_t)kl * nNode * DIM;
+    double *o = out + (int64_t)blockIdx.y * nVert * DIM;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.nElem; e += (int64_t)gridDim.x * 256) {
+        const double *g = a.geo + e * a.geoStride;
+        const int32_t *en = a.elemNodes + e * NPE;
+        double gl[NV][DIM];
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) gl[k][d] = g[k * DIM + d];
+        double xa[NPE][DIM], xb[NPE][DIM];
+#pragma unroll
+        for (int j = 0; j < NPE; ++j) {
+            const int64_t node = en[j];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) { xa[j][d] = wij[node * DIM + d]; xb[j][d] = wkl[node * DIM + d]; }
+        }
+        double Q[DIM][DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c)
+#pragma unroll
+            for (int r = 0; r < DIM; ++r) Q[c][r] = 0.0;
+        for (int q = 0; q < NQ; ++q) {
+            double Wa[DIM][DIM], Wb[DIM][DIM], Ga[FL], Gb[FL], Sa[FL], Sb[FL], sd[FL];
+            grad_u_at<DIM, DEG>(xa, gl, q, Wa);
+            grad_u_at<DIM, DEG>(xb, gl, q, Wb);
+#pragma unroll
+            for (int p = 0; p < DIM; ++p)
+#pragma unroll
+                for (int r = p; r < DIM; ++r) {
+                    const int c = flat_idx<DIM>(p, r);
+                    Ga[c] = 0.5 * (Wa[p][r] + Wa[r][p]) + ((c == ij) ? (c < DIM ? 1.0 : 0.5) : 0.0);
+                    Gb[c] = 0.5 * (Wb[p][r] + Wb[r][p]) + ((c == kl) ? (c < DIM ? 1.0 : 0.5) : 0.0);
+                }
+#pragma unroll
+            for (int c = 0; c < FL; ++c) sd[c] = Ga[c] * (c < DIM ? 1.0 : 2.0);
+            elem_D_apply<DIM, MAT>(g, sd, Sa);
+#pragma unroll
+            for (int c = 0; c < FL; ++c) sd[c] = Gb[c] * (c < DIM ? 1.0 : 2.0);
+            elem_D_apply<DIM, MAT>(g, sd, Sb);
+            double E = 0.0;
+#pragma unroll
+            for (int c = 0; c < FL; ++c) E += (c < DIM ? 1.0 : 2.0) * Ga[c] * Sb[c];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c)
+#pragma unroll
+                for (int r = 0; r < DIM; ++r) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int p = 0; p < DIM; ++p) t += Wa[p][c] * Sb[flat_idx<DIM>(p, r)] + Wb[p][c] * Sa[flat_idx<DIM>(p, r)];
+                    Q[c][r] += ((c == r) ? E : 0.0) - t;
+                }
+        }
+        const double sc = g[12] / NQ;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int64_t v = en[k];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                double val = 0.0;
+#pragma unroll
+                for (int r = 0; r < DIM; ++r) val += Q[c][r] * gl[k][r];
+                unsafeAtomicAdd(&o[v * DIM + c], sc * val);
+            }
+        }
+    }
 }
 
 // Mutual energies of the cell-problem fields, sum_e int (e^ij + eps(w^ij)) : C : (e^kl + eps(w^kl)) dV for every pair
@@ -2187,6 +2278,17 @@ void launch_mutual_energies(const AsmArgs &a, const int32_t *elemNodes, const do
     const int fl = a.dim * (a.dim + 1) / 2;
     const dim3 grid(grid_for(a.nElem, 4096), fl * (fl + 1) / 2);
 #define CALL(D, G, M) hipLaunchKernelGGL((k_mutual_energies<D, G, M>), grid, dim3(256), 0, s, l, w, nNode, deltaP, out)
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+    CHECK_LAUNCH();
+}
+
+void launch_mutual_energy_differential(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *w,
+                                       int64_t nNode, int64_t nVert, double *out, hipStream_t s) {
+    const LoadArgs l = make_load_args(a, elemNodes, nullptr, intGrad, nullptr);
+    const int fl = a.dim * (a.dim + 1) / 2;
+    const dim3 grid(grid_for(a.nElem, 4096), fl * (fl + 1) / 2);
+#define CALL(D, G, M) hipLaunchKernelGGL((k_mutual_energy_differential<D, G, M>), grid, dim3(256), 0, s, l, w, nNode, nVert, out)
     MFH_DISPATCH(a, CALL);
 #undef CALL
     CHECK_LAUNCH();

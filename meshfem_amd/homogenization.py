@@ -193,6 +193,25 @@ def delta_homogenized_elasticity_tensor(sim: Simulator, w_ij, delta_p, base_cell
     return sim.ctx.mutual_energies(w_ij, delta_p) / base_cell_volume
 
 
+def homogenized_elasticity_tensor_discrete_differential(sim: Simulator, w_ij, base_cell_volume=0.0, full=False):
+    """== homogenizedElasticityTensorDiscreteDifferential (PeriodicHomogenization.hh:372-480): the exact derivative of Ch
+    with respect to every vertex coordinate (|Y| held fixed), all directions in one element sweep per tensor entry.
+    Returns [nPairs, nVert, N] over the upper triangle ij <= kl (row-major), or with full=True the reference's
+    OneForm layout [nVert, N, flatLen, flatLen]."""
+    if base_cell_volume == 0.0:
+        pos = sim.nodes()
+        base_cell_volume = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
+    d = sim.ctx.mutual_energy_differential(w_ij) / base_cell_volume
+    if not full:
+        return d
+    fl = flat_len(sim.N)
+    out = np.empty((d.shape[1], sim.N, fl, fl))
+    iu = np.triu_indices(fl)
+    out[:, :, iu[0], iu[1]] = np.transpose(d, (1, 2, 0))
+    out[:, :, iu[1], iu[0]] = np.transpose(d, (1, 2, 0))
+    return out
+
+
 def delta_homogenized_compliance_tensor(sim: Simulator, w_ij, delta_p, base_cell_volume=0.0):
     """== deltaHomogenizedComplianceTensor (:516-524): -Sh : dCh : Sh as flattened matrices with the shear-doubling
     of doubleDoubleContract."""

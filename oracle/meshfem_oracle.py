@@ -1438,6 +1438,54 @@ def mutual_energies(sim: "Simulator", w, deltaP=None):
     return out
 
 
+def homogenized_elasticity_tensor_discrete_differential(sim: "Simulator", w, base_cell_volume=0.0):
+    """homogenizedElasticityTensorDiscreteDifferential (PeriodicHomogenization.hh:372-480), literal loops: the one-form
+    dCh[vertex, component] as flatLen x flatLen tensors (upper triangle ij <= kl filled, mirrored at the end).
+    Returns [nVert, N, flatLen, flatLen]."""
+    m, N, K, deg = sim.mesh, sim.N, sim.K, sim.deg
+    fl = flat_len(N)
+    nv = K + 1
+    nvert = int(m.elem_nodes[:, :nv].max()) + 1
+    out = np.zeros((nvert, N, fl, fl))
+    at = lambda T, p: eval_interpolant(K, deg - 1, T, p)
+    for e in range(len(m.elems)):
+        gl, vol, D = sim.gl[e], sim.vol[e], sim.elem_D(e)
+        nodes = m.elem_nodes[e]
+        gphi = [grad_phi_nodal(deg, K, gl, n) for n in range(m.nodes_per_elem)]            # :429-431
+        ninterp = gphi[0].shape[0]
+        strain, stress = [], []
+        for ij in range(fl):                                                               # :421-426
+            S = np.zeros((ninterp, N, N))
+            for n in range(m.nodes_per_elem):
+                for k in range(ninterp):
+                    S[k] += 0.5 * (np.outer(w[ij][nodes[n]], gphi[n][k]) + np.outer(gphi[n][k], w[ij][nodes[n]]))
+            S += canonical_strain(N, ij)[None]
+            strain.append(S)
+            stress.append(np.stack([D.double_contract(S[k]) for k in range(ninterp)]))
+        for ij in range(fl):
+            for kl in range(ij, fl):
+                mutual = integrate(K, 2 * (deg - 1), lambda p: np.sum(at(strain[ij], p) * at(stress[kl], p)), vol)   # :437-438
+                for v in range(nv):
+                    out[nodes[v], :, ij, kl] += mutual * gl[:, v]                         # :439-442
+                for n in range(m.nodes_per_elem):
+                    scw = np.stack([stress[kl][k] @ w[ij][nodes[n]] for k in range(ninterp)])                         # :449-454
+                    if ij != kl:
+                        scw = scw + np.stack([stress[ij][k] @ w[kl][nodes[n]] for k in range(ninterp)])
+                    else:
+                        scw = 2 * scw
+                    for v in range(nv):
+                        gb = gl[:, v]
+                        term = integrate(K, deg, lambda p: np.dot(gb, at(scw, p)) * at(gphi[n], p), vol)             # :459-461
+                        out[nodes[v], :, ij, kl] -= term
+    if base_cell_volume == 0.0:
+        mn, mx = m.bounding_box()
+        base_cell_volume = float(np.prod(mx - mn))
+    out /= base_cell_volume                                                                # :477
+    iu = np.triu_indices(fl, 1)
+    out[:, :, iu[1], iu[0]] = out[:, :, iu[0], iu[1]]
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # Scalar operators on the same mesh: Laplacian.hh, MassMatrix.hh, Poisson.hh
 # --------------------------------------------------------------------------------------

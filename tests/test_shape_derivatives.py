@@ -150,6 +150,22 @@ def test_oracle_homogenization_derivatives_vs_finite_differences(dim, deg):
     assert np.abs(dG - fdG).max() < 1e-6 * np.abs(dG).max()
 
 
+@pytest.mark.parametrize("dim,deg", [(2, 1), (2, 2), (3, 1)])
+def test_oracle_discrete_differential_literal_restatement_contracts_to_directional_derivative(dim, deg):
+    """homogenizedElasticityTensorDiscreteDifferential restated loop by loop (per-vertex one-form) contracted with a
+    perturbation field equals the volume-form directional derivative (itself checked against finite differences)."""
+    rng = np.random.default_rng(2)
+    V, T, sim, _ = _cell(dim, deg)
+    w = O.solve_cell_problems(sim)
+    dC = O.homogenized_elasticity_tensor_discrete_differential(sim, w)
+    assert dC.shape == (len(V), dim, O.flat_len(dim), O.flat_len(dim))
+    dp = rng.normal(size=V.shape)
+    ref = O.mutual_energies(sim, w, dp)                                   # unit cell: |Y| = 1
+    assert np.abs(np.einsum("vcij,vc->ij", dC, dp) - ref).max() < 1e-12 * np.abs(ref).max()
+    # translating every vertex changes nothing
+    assert np.abs(dC.sum(axis=0)).max() < 1e-10 * np.abs(dC).max()
+
+
 # ------------------------------------------------------------------------------------------------ GPU: HIP vs oracle
 def _hip_sim(V, T, deg, mats_D=None, mat=None):
     from meshfem_amd.linear_elasticity import Simulator
@@ -251,3 +267,27 @@ def test_hip_delta_K_on_reference_example_mesh_vs_finite_difference_of_device_op
     h = 1e-6
     fd = (make(V + h * dp).applyStiffnessMatrix(u) - make(V - h * dp).applyStiffnessMatrix(u)) / (2 * h)
     assert np.abs(got - fd).max() < FD_RTOL * np.abs(got).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,deg,small", [(2, 2, False), (3, 1, False), (3, 2, True)])
+def test_hip_discrete_differential_matches_oracle(dim, deg, small):
+    from meshfem_amd import homogenization as H
+    rng = np.random.default_rng(4)
+    if small:                                                            # the literal oracle loops are slow for P2 tets
+        V, T = O.grid_tet_mesh(1, 1, 1)
+        osim = O.Simulator(T, V, deg)
+        mats = [O.ElasticityTensor.isotropic(3, 20.0 + 10 * (e % 5), 0.3) for e in range(len(T))]
+        osim.set_material_field(mats)
+    else:
+        V, T, osim, mats = _cell(dim, deg)
+    hsim = _hip_sim(V, T, deg, mats_D=[m.D for m in mats])
+    w = [rng.normal(size=(osim.mesh.num_nodes, dim)) * 0.1 for _ in range(O.flat_len(dim))]   # any fields: kernel parity
+    ref = O.homogenized_elasticity_tensor_discrete_differential(osim, w)
+    got = H.homogenized_elasticity_tensor_discrete_differential(hsim, w, full=True)
+    assert got.shape == ref.shape and np.abs(got - ref).max() < HIP_RTOL * np.abs(ref).max()
+    dp = rng.normal(size=V.shape)
+    packed = H.homogenized_elasticity_tensor_discrete_differential(hsim, w)
+    iu = np.triu_indices(O.flat_len(dim))
+    d = H.delta_homogenized_elasticity_tensor(hsim, w, dp)
+    assert np.abs(np.einsum("pvc,vc->p", packed, dp) - d[iu]).max() < HIP_RTOL * np.abs(d).max()
