@@ -135,3 +135,75 @@ def test_simulate_cli_no_rigid_motion(tmp_path):
     u_ref = O.solve_constrained(sim, no_rigid_motion=True)
     nv = len(V)
     assert np.linalg.norm(F["u"][1] - u_ref[:nv]) / np.linalg.norm(u_ref[:nv]) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------
+# PeriodicHomogenization_cli mirror (src/bin/PeriodicHomogenization_cli.cc)
+def test_tensor_helpers_used_by_the_homogenization_cli():
+    """inverse / computeEigenstrains / getOrthotropicParameters / anisotropy / closestIsotropicTensor
+    (ElasticityTensor.hh:166-268,315-323,555-579; TensorProjection.hh:22-75) on known tensors."""
+    from meshfem_amd.tensors import closest_isotropic_tensor
+    o = ElasticityTensor(3).setOrthotropic(150, 200, 250, 0.3, 0.25, 0.2, 60, 70, 80)
+    assert np.allclose(o.getOrthotropicParameters(), [150, 200, 250, 0.3, 0.25, 0.2, 60, 70, 80], rtol=1e-12)
+    # E : (S : e) = e for every strain, with the shear doubling of doubleContract
+    S = o.inverse()
+    e = np.array([0.3, -0.2, 0.5, 0.1, -0.4, 0.25])
+    assert np.abs(o.doubleContract(S.doubleContract(e)) - e).max() < 1e-13
+    lam, Q = o.computeEigenstrains()
+    assert np.all(np.diff(lam) >= 0)
+    for k in range(6):
+        assert np.abs(o.doubleContract(Q[:, k]) - lam[k] * Q[:, k]).max() < 1e-10 * lam[-1]
+    iso = ElasticityTensor(3, 200.0, 0.35)
+    assert abs(iso.anisotropy() - 1.0) < 1e-12
+    assert np.abs(closest_isotropic_tensor(iso).D - iso.D).max() < 1e-12
+    # the projection is orthogonal: the residual is Frobenius-orthogonal to every isotropic tensor
+    c = closest_isotropic_tensor(o)
+    assert abs((o - c).quadrupleContract(iso)) < 1e-9 * o.frobeniusNormSq() ** 0.5 * iso.frobeniusNormSq() ** 0.5
+    o2 = ElasticityTensor(2).setOrthotropic(150, 220, 0.28, 65)
+    assert np.allclose(o2.getOrthotropicParameters(), [150, 220, 0.28, 65], rtol=1e-12)
+    assert o2(0, 1, 0, 1) == o2.D[2, 2] and o2(0, 0, 1, 1) == o2.D[0, 1]
+
+
+def _parse_cli_tensor(text, header, n):
+    lines = text.splitlines()
+    k = lines.index(header)
+    return np.array([[float(x) for x in lines[k + 1 + r].split()] for r in range(n)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ortho", [False, True])
+def test_periodic_homogenization_cli_on_reference_example(tmp_path, ortho):
+    """The CLI on the reference's 2D_microstructure(.msh | _orthocell.msh) prints the tensor the oracle computes (both
+    routes give the same Ch, tests/test_orthotropic_cell.py), consistent moduli, and writes the -M / -o outputs."""
+    import io
+    from meshfem_amd import periodic_homogenization_cli as cli
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    mesh = os.path.join(gold, "meshes", "2D_microstructure_orthocell.msh" if ortho else "2D_microstructure.msh")
+    matf = tmp_path / "base.material"
+    matf.write_text(json.dumps({"type": "isotropic_material", "dim": 2, "young": 200.0, "poisson": 0.35}))
+    buf = io.StringIO()
+    cwd = os.getcwd()
+    os.chdir(tmp_path)                                   # gtensors.txt lands in the working directory, like the reference
+    try:
+        args = [mesh, "-m", str(matf), "-d", "2", "-M", "m2m.txt", "-o", "fields.msh", "-c", "--distanceToIsotropy",
+                "--distanceToMaterial", str(matf)] + (["-O"] if ortho else [])
+        assert cli.main(args, out=buf) == 0
+    finally:
+        os.chdir(cwd)
+    text = buf.getvalue()
+    Ch = _parse_cli_tensor(text, "Homogenized elasticity tensor:", 3)
+    g = np.load(os.path.join(gold, "example_meshes.npz"))
+    ref = g["2D_microstructure_hom_p2_Ch"]
+    assert np.abs(Ch - ref).max() < 1e-7 * np.abs(ref).max()
+    Sm = _parse_cli_tensor(text, "Homogenized compliance tensor:", 3)
+    t = ElasticityTensor(2); t.D = 0.5 * (ref + ref.T)
+    assert np.abs(Sm - t.inverse().D).max() < 1e-6 * np.abs(Sm).max()
+    young = [float(x) for x in [l for l in text.splitlines() if l.startswith("Approximate Young")][0].split("\t")[1:]]
+    assert np.allclose(young, t.getOrthotropicParameters()[:2], rtol=1e-6)
+    assert "Anisotropy:" in text and "Distance to Isotropy" in text and "Distance to Specified Tensor" in text
+    m2m = (tmp_path / "m2m.txt").read_text().splitlines()
+    V, E, fields = mesh_io.load_msh(str(tmp_path / "fields.msh"))
+    assert len(m2m) == len(E) and m2m[0].startswith("{{{{") and (tmp_path / "gtensors.txt").exists()
+    for k in range(3):
+        assert {"load_ij %d" % k, "w_ij %d" % k, "strain w_ij %d" % k} <= set(fields)
+        assert np.abs(fields["w_ij %d" % k][1].mean(axis=0)).max() < 0.2    # centred over ALL nodes, subsampled to vertices
