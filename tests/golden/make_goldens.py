@@ -11,7 +11,8 @@
    oracle/meshfem_oracle.py. The reference itself cannot be run here (Eigen/SuiteSparse absent), so
    this fixture pins the ORACLE's output across refactors; it is not captured reference output.
 4. example_meshes.npz -- the same for the reference's unstructured example meshes (data files copied from
-   examples/meshes into tests/golden/meshes: cube_cross.msh, ball.msh, 2D_microstructure.msh):
+   examples/meshes into tests/golden/meshes: cube_cross.msh, ball.msh, 2D_microstructure.msh, and the orthotropic base
+   cells 2D_microstructure_orthocell.msh, 3D_microstructure_orthocell.msh):
    direct-solve displacements under box Dirichlet / traction conditions (P1, P2) and periodic
    homogenization results Ch, w_ij (cube_cross 3D, 2D_microstructure 2D). Oracle output, not reference output.
 """
@@ -178,6 +179,16 @@ def example_mesh_fixture():
             out.update({"%s_hom_p%d_Ch" % (name, deg): Ch, "%s_hom_p%d_w" % (name, deg): np.array(w),
                         "%s_hom_p%d_ndof" % (name, deg): np.array([sim.numDoFs()])})
             print(name, "homogenization", deg, np.round(np.diag(Ch), 4), flush=True)
+    # orthotropic base cells of the reference (OrthotropicHomogenization.hh route, displacement form like the binding)
+    for name, dim, degs in (("2D_microstructure_orthocell", 2, (1, 2)), ("3D_microstructure_orthocell", 3, (1,))):
+        V, E, _ = mesh_io.load_msh(os.path.join(HERE, "meshes", name + ".msh"))
+        for deg in degs:
+            sim = O.Simulator(E, V[:, :dim], deg)
+            sim.set_material_constant(O.ElasticityTensor.isotropic(dim, 200.0, 0.35))
+            w = O.solve_cell_problems_orthotropic(sim)
+            Ch = O.homogenized_tensor_from_ortho_cell_quantity(dim, O.homogenized_elasticity_tensor_displacement_form(sim, w))
+            out.update({"%s_hom_p%d_Ch" % (name, deg): Ch, "%s_hom_p%d_w_norms" % (name, deg): np.array([np.linalg.norm(x) for x in w])})
+            print(name, "orthotropic-cell homogenization", deg, np.round(np.diag(Ch), 4), flush=True)
     return out
 
 

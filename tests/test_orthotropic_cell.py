@@ -172,3 +172,44 @@ def test_compat_homogenize_orthotropic_cell_flag():
     rf = ph.homogenize(mf, C)
     assert np.abs(ro.Ch.D - rf.Ch.D).max() < CH_RTOL * np.abs(rf.Ch.D).max()
     assert len(ro.w_ij) == 3 and ro.strain_w_ij[0].shape == (mo.numElements(), 3)
+
+
+@pytest.mark.parametrize("deg", [1, 2])
+def test_oracle_orthocell_fixture_reproduced(deg):
+    """tests/golden/example_meshes.npz (make_goldens.py --examples-only): committed oracle output on the reference's
+    2D ortho-cell mesh; equal to the committed full-cell tensor of 2D_microstructure.msh."""
+    g = np.load(os.path.join(GOLD, "example_meshes.npz"))
+    Vo, Eo = _load2d("2D_microstructure_orthocell")
+    so = O.Simulator(Eo, Vo, deg); so.set_material_constant(O.ElasticityTensor.isotropic(2, 200.0, 0.35))
+    w = O.solve_cell_problems_orthotropic(so)
+    C = O.homogenized_tensor_from_ortho_cell_quantity(2, O.homogenized_elasticity_tensor_displacement_form(so, w))
+    key = "2D_microstructure_orthocell_hom_p%d_" % deg
+    assert np.abs(C - g[key + "Ch"]).max() < 1e-10 * np.abs(C).max()
+    assert np.allclose([np.linalg.norm(x) for x in w], g[key + "w_norms"], rtol=1e-9)
+    full = g["2D_microstructure_hom_p%d_Ch" % deg]
+    assert np.abs(g[key + "Ch"] - full).max() < 1e-9 * np.abs(full).max()
+
+
+@pytest.mark.gpu
+def test_hip_orthocell_on_reference_3d_mesh():
+    """3D_microstructure_orthocell.msh (28 051 tets, a sparse truss-like cell): P1 against the committed oracle fixture;
+    P2 for the physics a homogenized tensor of an orthotropic cell must obey."""
+    from meshfem_amd import homogenization as H, mesh_io
+    from meshfem_amd.linear_elasticity import Simulator
+    g = np.load(os.path.join(GOLD, "example_meshes.npz"))
+    V, E, _ = mesh_io.load_msh(os.path.join(GOLD, "meshes", "3D_microstructure_orthocell.msh"))
+    base = O.ElasticityTensor.isotropic(3, 200.0, 0.35)
+    res = {}
+    for deg in (1, 2):
+        sim = Simulator(E, V, deg); sim.rtol = 1e-10; sim.setMaterial(base.D)
+        Ch, w, infos = H.homogenize_orthotropic_cell(sim)
+        assert all(i["converged"] for i in infos)
+        res[deg] = Ch
+        if deg == 1:
+            ref = g["3D_microstructure_orthocell_hom_p1_Ch"]
+            assert np.abs(Ch - ref).max() < 1e-6 * np.abs(ref).max()
+            assert np.allclose([np.linalg.norm(x) for x in w], g["3D_microstructure_orthocell_hom_p1_w_norms"], rtol=1e-6)
+        assert np.abs(Ch[:3, 3:]).max() == 0 and np.abs(Ch - Ch.T).max() < 1e-8 * np.abs(Ch).max()
+        assert np.linalg.eigvalsh(Ch).min() > 0 and np.linalg.eigvalsh(base.D - Ch).min() > 0
+    # quadratic elements are softer than linear ones on the same mesh (less locking in the thin members)
+    assert np.all(np.diag(res[2]) < np.diag(res[1]))
