@@ -220,6 +220,13 @@ mfh_status mfh_bc_dirichlet_box(mfh_ctx* ctx, const double* minCorner, const dou
                                 int32_t relative, const double* value, int32_t compMask);
 mfh_status mfh_bc_neumann_box(mfh_ctx* ctx, const double* minCorner, const double* maxCorner,
                               int32_t relative, const double* value, int32_t kind);
+/* == DirichletNodesCondition branch (:991-1002) and the carrier of expression-valued Dirichlet regions (ExpressionVector
+ * components are evaluated per node by the caller): per-node displacement values [n x dim]; "Condition applied to
+ * non-boundary node i" and "Conflicting dirichlet displacements." as in the reference. */
+mfh_status mfh_bc_dirichlet_nodes(mfh_ctx* ctx, int64_t n, const int64_t* nodes, const double* values, int32_t componentMask);
+/* == NeumannElementsCondition branch (:966-990) after matching and the force / region-area division, and the carrier of
+ * expression-valued traction regions: sets the traction [n x dim] of the listed boundary elements. */
+mfh_status mfh_bc_neumann_elements(mfh_ctx* ctx, int64_t n, const int64_t* bdryElems, const double* tractions);
 mfh_status mfh_bc_delta_force(mfh_ctx* ctx, int64_t node, const double* force);
 /* == m_getDirichletVarsAndValues (:1469-1518). vars==NULL returns the count.                   */
 mfh_status mfh_bc_dirichlet_vars(mfh_ctx* ctx, int64_t* vars, double* vals, int64_t* n);

@@ -81,6 +81,8 @@ PROTOTYPES = {
     "mfh_bc_dirichlet_box": (_i32, [_P, _P, _P, _i32, _P, _i32]),
     "mfh_bc_neumann_box": (_i32, [_P, _P, _P, _i32, _P, _i32]),
     "mfh_bc_delta_force": (_i32, [_P, _i64, _P]),
+    "mfh_bc_dirichlet_nodes": (_i32, [_P, _i64, _P, _P, _i32]),
+    "mfh_bc_neumann_elements": (_i32, [_P, _i64, _P, _P]),
     "mfh_bc_dirichlet_vars": (_i32, [_P, _P, _P, _pi64]),
     "mfh_pin_node": (_i32, [_P, _pi64]),
     "mfh_neumann_load": (_i32, [_P, _P]),

@@ -297,6 +297,17 @@ class Context:
             value = np.concatenate([value, np.zeros(self.dim - len(value))])
         self._ck(self.lib.mfh_bc_neumann_box(self.h, ptr(mn), ptr(mx), int(relative), ptr(value), int(kind)))
 
+    def bc_dirichlet_nodes(self, nodes, values, components=None):
+        nodes = as_i64(nodes)
+        values = as_f64(np.asarray(values, dtype=np.float64).reshape(len(nodes), self.dim))
+        mask = (1 << self.dim) - 1 if components is None else sum(1 << c for c in range(self.dim) if components[c])
+        self._ck(self.lib.mfh_bc_dirichlet_nodes(self.h, len(nodes), ptr(nodes), ptr(values), mask))
+
+    def bc_neumann_elements(self, bdry_elems, tractions):
+        be = as_i64(bdry_elems)
+        t = as_f64(np.asarray(tractions, dtype=np.float64).reshape(len(be), self.dim))
+        self._ck(self.lib.mfh_bc_neumann_elements(self.h, len(be), ptr(be), ptr(t)))
+
     def bc_delta_force(self, node, force):
         force = as_f64(force)
         self._ck(self.lib.mfh_bc_delta_force(self.h, int(node), ptr(force)))

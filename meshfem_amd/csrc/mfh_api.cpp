@@ -1548,6 +1548,45 @@ mfh_status mfh_bc_neumann_box(mfh_ctx *c, const double *mn, const double *mx, in
     MFH_CATCH(c)
 }
 
+mfh_status mfh_bc_dirichlet_nodes(mfh_ctx *c, int64_t n, const int64_t *nodes, const double *values, int32_t compMask) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && c->mesh.hasTopology, MFH_ERR_STATE, "boundary conditions need mfh_mesh_build");
+    require(n >= 0 && (n == 0 || (nodes && values)), MFH_ERR_INVALID, "bad node list");
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    std::vector<uint8_t> isBdry((size_t)m.nNode, 0);
+    for (int32_t bn : m.bdryNodes) isBdry[bn] = 1;
+    for (int64_t k = 0; k < n; ++k) {   // LinearElasticity.hh:991-1002
+        const int64_t ni = nodes[k];
+        require(ni >= 0 && ni < m.nNode, MFH_ERR_INVALID, "node index out of bounds");
+        if (!isBdry[ni]) throw Error(MFH_ERR_INVALID, "Condition applied to non-boundary node " + std::to_string(ni));
+        for (int a = 0; a < d; ++a) {   // BoundaryNode::setDirichlet :390-403
+            if (!(compMask & (1 << a))) continue;
+            const double v = values[(size_t)k * d + a];
+            if (!c->dirMask[(size_t)ni * d + a]) {
+                c->dirMask[(size_t)ni * d + a] = 1;
+                c->dirVal[(size_t)ni * d + a] = v;
+            } else if (std::fabs(c->dirVal[(size_t)ni * d + a] - v) > 1e-10)
+                throw Error(MFH_ERR_INVALID, "Conflicting dirichlet displacements.");
+        }
+    }
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_bc_neumann_elements(mfh_ctx *c, int64_t n, const int64_t *bdryElems, const double *tractions) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && c->mesh.hasTopology, MFH_ERR_STATE, "boundary conditions need mfh_mesh_build");
+    require(n >= 0 && (n == 0 || (bdryElems && tractions)), MFH_ERR_INVALID, "bad element list");
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t b = bdryElems[k];
+        require(b >= 0 && b < m.nBE(), MFH_ERR_INVALID, "boundary element index out of bounds");
+        for (int a = 0; a < d; ++a) c->neumannTraction[(size_t)b * d + a] = tractions[(size_t)k * d + a];
+    }
+    MFH_CATCH(c)
+}
+
 mfh_status mfh_bc_delta_force(mfh_ctx *c, int64_t node, const double *force) {
     MFH_TRY(c)
     require(c && c->haveMesh && force && node >= 0 && node < c->mesh.nNode, MFH_ERR_INVALID, "bad node");

@@ -55,6 +55,12 @@ class Simulator:
     def applyNeumannBox(self, mn, mx, value, kind=L.NEUMANN_TRACTION, relative=False):
         self.ctx.bc_neumann_box(mn, mx, value, kind, relative)
 
+    def applyDirichletNodes(self, nodes, values, components=None):      # DirichletNodesCondition, :991-1002
+        self.ctx.bc_dirichlet_nodes(nodes, values, components)
+
+    def applyNeumannElements(self, bdry_elems, tractions):             # NeumannElementsCondition, :966-990
+        self.ctx.bc_neumann_elements(bdry_elems, tractions)
+
     def applyPeriodicConditions(self, epsilon=1e-7):                    # :845-854
         return self.ctx.apply_periodic_conditions(epsilon)
 

@@ -6,7 +6,10 @@
 Reads a Gmsh 2.2 tri/tet mesh, a `.material` JSON (isotropic / orthotropic / symmetric_material,
 Materials.cc:178-311) or per-element material fields stored in an .msh (`E`,`nu` or the 9 (3D) /
 4 (2D) orthotropic fields, Simulate_cli.cc:116-163), and a `.bc` JSON with box / box% regions of
-type dirichlet[xyz] / force / traction / pressure / delta force (BoundaryConditions.cc:227-389).
+type dirichlet[xyz] / force / traction / pressure / delta force (BoundaryConditions.cc:227-389), numeric or
+expression-valued (`"sin(pi * x)"`, tinyexpr grammar: meshfem_amd/expressions.py), `dirichlet nodes` /
+`delta force nodes` lists and `traction | pressure | force elements` lists. Not supported: path / polygon regions,
+`dirichlet elements`, target / contact / fracture conditions.
 Writes the fields u, load, strain, stress, Ku like Simulate_cli.cc:207-242."""
 import argparse
 import json
@@ -18,6 +21,7 @@ from . import _lib as L
 from .linear_elasticity import Simulator
 from .mesh_io import MSHFieldWriter, load_msh
 from .tensors import ElasticityTensor
+from .expressions import ExpressionVector, environment
 
 
 def parse_material(path, dim):
@@ -55,17 +59,62 @@ def material_json(tensor):
 
 
 def _vec(v, dim):
-    out = [float(x) for x in v]          # expression strings are not supported (numbers only)
+    out = [float(x) for x in v]
     return np.array((out + [0.0] * 3)[:dim])
 
 
+def _is_expression_vector(v):
+    return not np.isscalar(v) and any(isinstance(x, str) for x in v)
+
+
+def _expression_vector(v, dim):
+    """parseExpressionVector + the 2D truncation of BoundaryConditions.cc:343-350."""
+    comps = list(v)
+    if dim == 2 and len(comps) == 3 and float(comps[2]) == 0:
+        comps.pop()
+    if len(comps) != dim:
+        raise RuntimeError("Incorrect expression vector size")
+    return ExpressionVector(comps)
+
+
+def _node_values(values, dim):
+    """parseNodeConditionValues (BoundaryConditions.cc:62-80): [[value, [node, ...]], ...]."""
+    idx, val = [], []
+    for value, nodes in values:
+        for nd in nodes:
+            idx.append(int(nd)); val.append(_vec(value, dim))
+    return np.array(idx, dtype=np.int64), np.array(val).reshape(len(idx), dim)
+
+
+def _boundary_element_lookup(sim):
+    """corner-index set -> boundary element (UnorderedTriplet matching of NeumannElementsCondition)."""
+    K = sim.N
+    ben = sim.ctx.boundary_elem_nodes()[:, :K]
+    return {tuple(sorted(int(x) for x in row)): b for b, row in enumerate(ben)}
+
+
 def apply_boundary_conditions(sim, path):
-    """readBoundaryConditions + applyBoundaryConditions for box / box% regions."""
-    with open(path) as f:
-        cfg = json.load(f)
+    """readBoundaryConditions + applyBoundaryConditions (BoundaryConditions.cc:227-389, LinearElasticity.hh:881-1027):
+    box / box% regions of type dirichlet[xyz] / force / traction / pressure / delta force with numeric or EXPRESSION
+    values (traction, dirichlet, delta force), node lists (dirichlet nodes, delta force nodes) and boundary-element lists
+    (traction / pressure / force elements)."""
+    if isinstance(path, dict):
+        cfg = path
+    else:
+        with open(path) as f:
+            cfg = json.load(f)
     if cfg.get("no_rigid_motion", False):                    # BoundaryConditions.cc:236-239 -> applyNoRigidMotionConstraint
         sim.applyNoRigidMotionConstraint()
     N = sim.N
+    be_lookup = None
+    geo = {}
+
+    def mesh_geometry():                                     # only list / expression / delta-force regions need it
+        if not geo:
+            p = sim.nodes()
+            nv = sim.ctx.n_vert
+            geo.update(pos=p, mn=p[:nv].min(axis=0), mx=p[:nv].max(axis=0))
+        return geo["pos"], geo["mn"], geo["mx"]
     for r in cfg["regions"]:
         t = r["type"]
         comps = None
@@ -74,16 +123,76 @@ def apply_boundary_conditions(sim, path):
             k = 0
             while k < len(rest) and rest[k] in "xyz":
                 k += 1
+            if k > 3:
+                raise RuntimeError("invalid mask")
             if k:
-                comps = ["xyz"[c] in rest[:k] for c in range(N)]
+                comps = ["xyz"[a] in rest[:k] for a in range(N)]
             t = "dirichlet" + rest[k:]
+        if t == "dirichlet nodes":
+            idx, val = _node_values(r["values"], N)
+            sim.applyDirichletNodes(idx, val, comps)
+            continue
+        if t == "delta force nodes":
+            idx, val = _node_values(r["values"], N)
+            for ni, f in zip(idx, val):
+                if ni > sim.numNodes():
+                    raise RuntimeError("DeltaForceNodesCondition node index out of bounds: %d" % ni)
+                sim.ctx.bc_delta_force(int(ni), f)
+            continue
+        if t in ("traction elements", "pressure elements", "force elements"):
+            if be_lookup is None:
+                be_lookup = _boundary_element_lookup(sim)
+            area, nrm = sim.ctx.boundary_elem_geometry()
+            bes, vals = [], []
+            for value, elems in r["values"]:
+                v = _vec(value, N)
+                for corners in elems:
+                    key = tuple(sorted(int(x) for x in corners))[:N] if len(corners) == N else None
+                    if key is None or key not in be_lookup:
+                        raise RuntimeError("Some element boundary conditions weren't matched.")
+                    bes.append(be_lookup[key]); vals.append(v)
+            bes, vals = np.array(bes, dtype=np.int64), np.array(vals).reshape(len(bes), N)
+            if t == "pressure elements":
+                vals = -vals[:, :1] * nrm[bes]
+            elif t == "force elements":                        # total force / area of the listed elements (:984-989)
+                vals = vals / area[bes].sum()
+            sim.applyNeumannElements(bes, vals)
+            continue
         if "box" in r:
             mn, mx, rel = _vec(r["box"]["minCorner"], N), _vec(r["box"]["maxCorner"], N), False
         elif "box%" in r:
             mn, mx, rel = _vec(r["box%"]["minCorner"], N), _vec(r["box%"]["maxCorner"], N), True
         else:
-            raise RuntimeError("only box / box% regions are supported")
+            raise RuntimeError("only box / box% regions, node lists and element lists are supported")
         val = r["value"]
+        if _is_expression_vector(val) or t == "delta force":
+            c = sim.ctx
+            pos, mesh_min, mesh_max = mesh_geometry()
+        if _is_expression_vector(val):
+            ev = _expression_vector(val, N)
+            amn, amx = (mesh_min + mn * (mesh_max - mesh_min), mesh_min + mx * (mesh_max - mesh_min)) if rel else (mn, mx)
+            inside = lambda P: np.all((P >= amn) & (P <= amx), axis=1)        # BBox::containsPoint, inclusive
+            if t == "dirichlet":                                # :939-949: boundary NODES inside the region
+                bn = c.boundary_nodes()
+                sel = bn[inside(pos[bn])]
+                env = environment(N, mesh_min, mesh_max, amn, amx, pos[sel])
+                sim.applyDirichletNodes(sel, ev.eval(env, len(sel)), comps)
+            elif t == "traction":                               # :897-913: boundary ELEMENTS by vertex barycentre
+                ben = c.boundary_elem_nodes()[:, :N]
+                ctr = pos[ben].mean(axis=1)
+                sel = np.flatnonzero(inside(ctr))
+                if len(sel) == 0:
+                    raise RuntimeError("Neumann region unmatched")
+                env = environment(N, mesh_min, mesh_max, amn, amx, ctr[sel])
+                sim.applyNeumannElements(sel, ev.eval(env, len(sel)))
+            elif t == "delta force":                            # :1009-1015: every NODE inside the region
+                sel = np.flatnonzero(inside(pos))
+                env = environment(N, mesh_min, mesh_max, amn, amx, pos[sel])
+                for ni, f in zip(sel, ev.eval(env, len(sel))):
+                    c.bc_delta_force(int(ni), f)
+            else:
+                raise RuntimeError("Only region-based traction, dirichlet, target, and delta force support expression vectors")
+            continue
         if t == "dirichlet":
             sim.applyDirichletBox(mn, mx, _vec(val, N), relative=rel, components=comps)
         elif t == "force":
@@ -92,6 +201,10 @@ def apply_boundary_conditions(sim, path):
             sim.applyNeumannBox(mn, mx, _vec(val, N), kind=L.NEUMANN_TRACTION, relative=rel)
         elif t == "pressure":
             sim.applyNeumannBox(mn, mx, [float(val if np.isscalar(val) else val[0])], kind=L.NEUMANN_PRESSURE, relative=rel)
+        elif t == "delta force":
+            amn, amx = (mesh_min + mn * (mesh_max - mesh_min), mesh_min + mx * (mesh_max - mesh_min)) if rel else (mn, mx)
+            for ni in np.flatnonzero(np.all((pos >= amn) & (pos <= amx), axis=1)):
+                c.bc_delta_force(int(ni), _vec(val, N))
         else:
             raise RuntimeError("Invalid type '%s'" % r["type"])
 

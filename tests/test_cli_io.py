@@ -207,3 +207,96 @@ def test_periodic_homogenization_cli_on_reference_example(tmp_path, ortho):
     for k in range(3):
         assert {"load_ij %d" % k, "w_ij %d" % k, "strain w_ij %d" % k} <= set(fields)
         assert np.abs(fields["w_ij %d" % k][1].mean(axis=0)).max() < 0.2    # centred over ALL nodes, subsampled to vertices
+
+
+# ------------------------------------------------------------------------------------------------
+# expression-valued conditions (ExpressionVector.hh, tinyexpr grammar), node lists and element lists
+def test_expression_grammar_follows_tinyexpr_defaults():
+    from meshfem_amd.expressions import Expression, ExpressionError, ExpressionVector, environment
+    ev = lambda s, **env: float(Expression(s).eval(env))
+    assert ev("1+2*3") == 7 and ev("(1+2)*3") == 9 and ev("7 % 4") == 3 and ev("1/4") == 0.25
+    assert ev("2^3^2") == 64 and ev("-2^2") == 4 and ev("2^-1") == 0.5          # left-assoc power, sign binds tighter
+    assert abs(ev("sin(pi * x)", x=0.5) - 1.0) < 1e-15 and abs(ev("sin pi")) < 1e-15 and abs(ev("e") - np.e) < 1e-15
+    assert ev("log 100") == 2 and abs(ev("ln(e)") - 1) < 1e-15 and ev("log10(1000)") == 3    # log is log10 by default
+    assert ev("fac 5") == 120 and ev("ncr(5, 2)") == 10 and ev("npr(5, 2)") == 20 and ev("pow(2, 10)") == 1024
+    assert ev("atan2(1, 1)") == np.arctan2(1, 1) and ev("abs(-3) + floor 2.7 + ceil(2.1)") == 8
+    assert ev("(1, 2, 3)") == 3 and ev("1e-3 * 2.5E+2") == 0.25 and ev("--3") == 3
+    assert ev("mesh_size_0 * region_min_1", mesh_size_0=2.0, region_min_1=0.5) == 1.0
+    for bad in ("1 +", "foo(1)", "sin(", "2 $ 3", "atan2(1)", "unknown_var"):
+        with pytest.raises(ExpressionError, match="Failed to parse expression"):
+            Expression(bad).eval({})
+    # vectorised over the points of a region, constants broadcast
+    P = np.array([[0.0, 1.0], [0.5, 1.0], [1.0, 1.0]])
+    env = environment(2, [0, 0], [1, 1], [0, 1], [1, 1], P)
+    vals = ExpressionVector([0, "sin(pi * x) * region_size_0", "0"][:2]).eval(env, 3)
+    assert vals.shape == (3, 2) and np.allclose(vals[:, 1], [0, 1, 0], atol=1e-15) and np.all(vals[:, 0] == 0)
+
+
+@pytest.mark.gpu
+def test_simulate_cli_reference_sin_top_bc_with_expression_values(tmp_path):
+    """experiments/elasticity_convergence/sin_top.bc of the reference (a data file: dirichlet [0, "sin(pi * x)", 0] on the
+    top edge of the unit square, clamped bottom) through the CLI, against the oracle with the same per-node values."""
+    V, Q = O.gen_grid_2d(12, 12)
+    V, T = O.quad_tri_subdiv(V, Q)
+    V = V / 12.0
+    mesh = tmp_path / "sq.msh"
+    mesh_io.save_msh(str(mesh), V, T) if hasattr(mesh_io, "save_msh") else mesh_io.MSHFieldWriter(str(mesh), V, T, binary=False).close()
+    bc = {"regions": [
+        {"type": "dirichlet", "value": [0, 0, 0], "box%": {"minCorner": [-0.0001, -0.0001, 0], "maxCorner": [1.0001, 0.0001, 0]}},
+        {"type": "dirichlet", "value": [0, "sin(pi * x)", 0], "box%": {"minCorner": [-0.0001, 0.9999, 0], "maxCorner": [1.0001, 1.0001, 0]}}]}
+    (tmp_path / "sin_top.bc").write_text(json.dumps(bc))
+    (tmp_path / "m.material").write_text(json.dumps({"type": "isotropic_material", "dim": 2, "young": 1.0, "poisson": 0.3}))
+    out = tmp_path / "out.msh"
+    assert simulate_cli.main([str(mesh), "-m", str(tmp_path / "m.material"), "-b", str(tmp_path / "sin_top.bc"), "-d", "2",
+                              "-o", str(out), "-D", "--rtol", "1e-12"]) == 0
+    _, _, fields = mesh_io.load_msh(str(out))
+    u = fields["u"][1][:, :2]
+    sim = O.Simulator(T, V[:, :2], 2)
+    sim.set_material_constant(O.ElasticityTensor.isotropic(2, 1.0, 0.3))
+    P = sim.mesh.node_pos
+    bot, top = np.abs(P[:, 1]) < 1e-9, np.abs(P[:, 1] - 1) < 1e-9
+    sim.dirichletMask[bot | top] = True
+    sim.dirichletValue[top, 1] = np.sin(np.pi * P[top, 0])
+    ref = sim.solve()
+    assert np.abs(u[top, 1] - np.sin(np.pi * P[top, 0])).max() < 1e-14
+    assert np.linalg.norm(u - ref) < 1e-8 * np.linalg.norm(ref)
+
+
+@pytest.mark.gpu
+def test_node_list_and_element_list_conditions_equal_their_box_forms(tmp_path):
+    """`dirichlet nodes`, `traction elements`, `force elements`, `pressure elements`, `delta force nodes` reproduce the box
+    regions selecting the same nodes / boundary elements; an expression-valued traction equals its constant."""
+    from meshfem_amd.linear_elasticity import Simulator
+    V, T = grid.grid_tet_mesh(4, 3, 3, [0, 0, 0], [1, 1, 1])
+
+    def solve(regions):
+        sim = Simulator(T, V, 1); sim.rtol = 1e-12
+        sim.setIsotropicMaterial(200.0, 0.35)
+        simulate_cli.apply_boundary_conditions(sim, {"regions": regions})
+        return sim, sim.solve(), sim.neumannLoad()
+    lo = {"minCorner": [-1e-9, -1, -1], "maxCorner": [1e-9, 2, 2]}
+    hi = {"minCorner": [1 - 1e-9, -1, -1], "maxCorner": [1 + 1e-9, 2, 2]}
+    sim, u0, f0 = solve([{"type": "dirichlet", "value": [0, 0, 0], "box": lo}, {"type": "traction", "value": [0.2, -1, 0.1], "box": hi}])
+    pos = sim.nodes()
+    left = np.flatnonzero(np.abs(pos[:, 0]) < 1e-9).tolist()
+    ben = sim.ctx.boundary_elem_nodes()[:, :3]
+    right = [r.tolist() for r in ben if np.all(np.abs(pos[r, 0] - 1) < 1e-9)]
+    clamp = {"type": "dirichlet nodes", "values": [[[0, 0, 0], left]]}
+    _, u1, f1 = solve([clamp, {"type": "traction elements", "values": [[[0.2, -1, 0.1], right]]}])
+    assert np.abs(f1 - f0).max() < 1e-14 and np.linalg.norm(u1 - u0) < 1e-9 * np.linalg.norm(u0)
+    _, u2, f2 = solve([clamp, {"type": "traction", "value": ["0.1 + 0.1 * mesh_size_0", "-cos(0)", "x / 10"], "box": hi}])
+    assert np.abs(f2 - f0).max() < 1e-14
+    _, _, f3 = solve([clamp, {"type": "force elements", "values": [[[0.2, -1, 0.1], right]]}])     # unit face: force == traction
+    assert np.abs(f3 - f0).max() < 1e-13
+    _, _, f4 = solve([clamp, {"type": "pressure elements", "values": [[[2.0, 0, 0], right]]}])
+    _, _, f5 = solve([clamp, {"type": "pressure", "value": 2.0, "box": hi}])
+    assert np.abs(f4 - f5).max() < 1e-14 and abs(f4[:, 0].sum() + 2.0) < 1e-12
+    corner = int(np.flatnonzero(np.all(np.abs(pos - 1.0) < 1e-9, axis=1))[0])
+    _, u6, f6 = solve([clamp, {"type": "delta force nodes", "values": [[[0, -1, 0], [corner]]]}])
+    _, u7, f7 = solve([clamp, {"type": "delta force", "value": [0, "-1", 0], "box": {"minCorner": [1 - 1e-9] * 3, "maxCorner": [1 + 1e-9] * 3}}])
+    assert np.abs(f6 - f7).max() == 0 and f6[corner, 1] == -1 and np.linalg.norm(u6 - u7) < 1e-12 * np.linalg.norm(u6)
+    with pytest.raises(RuntimeError, match="non-boundary node"):
+        inner = int(np.flatnonzero(np.all((pos > 1e-9) & (pos < 1 - 1e-9), axis=1))[0])
+        solve([{"type": "dirichlet nodes", "values": [[[0, 0, 0], [inner]]]}])
+    with pytest.raises(RuntimeError, match="weren't matched"):
+        solve([clamp, {"type": "traction elements", "values": [[[0, 0, 1], [[0, 1, 2]]]]}])
