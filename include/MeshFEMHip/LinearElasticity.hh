@@ -143,6 +143,21 @@ public:
         check(ctx(), mfh_apply_periodic_conditions(ctx(), epsilon, &nd));
         m_numDoFs = (size_t)nd;
     }
+    void removePeriodicConditions() {                            // :874-879
+        check(ctx(), mfh_dof_map(ctx(), nullptr, 0));
+        m_numDoFs = m_numNodes;
+    }
+    // node positions (vertex nodes first) and element volumes, as sim.mesh() exposes them
+    VField nodes() const {
+        VField p(m_numNodes);
+        check(ctx(), mfh_mesh_get_node_positions(ctx(), &p[0][0]));
+        return p;
+    }
+    std::vector<Real> elementVolumes() const {
+        std::vector<Real> v((size_t)m_numElements);
+        check(ctx(), mfh_mesh_get_elem_volumes(ctx(), v.data()));
+        return v;
+    }
     void setUsePinNoRigidTranslationConstraint(bool pin) { m_usePin = pin; }   // PeriodicHomogenization.hh:44-45
     void applyNoRigidMotionConstraint() { m_noRigidMotion = true; }            // m_useRigidMotionConstraint (:1214-1228)
     void removeNoRigidMotionConstraint() { m_noRigidMotion = false; }

@@ -49,3 +49,19 @@ def test_facade_scalar_and_constraints_on_gpu():
     r = subprocess.run([EXE2, "0"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "poisson" in r.stdout and "free body" in r.stdout and "generic SPSDSystem" in r.stdout
+
+
+EXE3 = os.path.join(ROOT, "tests", "cpp", "facade_homogenization")
+
+
+def test_facade_homogenization_compiles():
+    _build("facade_homogenization")
+    r = subprocess.run([EXE3, "-1"], capture_output=True, text=True)
+    assert r.returncode == 3 and "runtime_error" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_facade_homogenization_on_gpu():
+    _build("facade_homogenization")
+    r = subprocess.run([EXE3, "0"], capture_output=True, text=True)
+    assert r.returncode == 0 and "homogenization ok" in r.stdout, r.stdout + r.stderr
