@@ -336,6 +336,10 @@ mfh_status mfh_matrix_free_info(mfh_ctx* ctx, int32_t* active, int32_t* mode, in
  * "matrix_free_mode" (4 default: cluster variant, forces of 256 consecutive elements summed in LDS | 3 two-pass, forces in
  *   list order | 2 two-pass, forces element-major | 1 per-pair block evaluation), "mf_chunk_rows", "mf_chunk_pairs",
  * "pcg_graph" (1 default: blocks of check_every PCG iterations are replayed from a hipGraph),
+ * "periodic_ignore_mismatch" (1: nodes of a periodic face without a partner keep their own DoF, PeriodicCondition's
+ *   ignoreMismatch / matchPermittingMismatch; 0 default: a mismatch is an error like PeriodicBoundaryMatcher::match),
+ * "periodic_ignore_dims" (bit a set: dimension a is NOT periodic, PeriodicCondition's ignoreDims) -- both read by the next
+ *   mfh_apply_periodic_conditions,
  * "symbolic_device", "topology_device", "tl_probe", "tl_host_inverse" (validation variants of setup phases) */
 mfh_status mfh_set_option(mfh_ctx* ctx, const char* key, double value);
 /* test hook: in-place inverse of a dense SPD matrix (row-major n x n) with the threaded blocked

@@ -88,9 +88,11 @@ def Mesh(*args, degree=1, embeddingDimension=3, **kw):
 
 
 class _PeriodicCondition:
-    def __init__(self, m, eps):
+    def __init__(self, m, eps, ignore_mismatch=False, ignore_dims=()):
         h = Context(-1)
         h.mesh_build(m._F, m._V, m._deg)
+        h.set_option("periodic_ignore_mismatch", 1 if ignore_mismatch else 0)
+        h.set_option("periodic_ignore_dims", sum(1 << int(d) for d in ignore_dims))
         self._n = h.apply_periodic_conditions(eps)
         self._dofs = h.get_dof_map()[0]
         h.close()
@@ -100,6 +102,4 @@ class _PeriodicCondition:
 
 
 def PeriodicCondition(mesh, eps=1e-7, ignore_mismatch=False, ignore_dims=()):
-    if ignore_mismatch or len(ignore_dims):
-        raise RuntimeError("ignore_mismatch / ignore_dims are not supported on this path")
-    return _PeriodicCondition(mesh, eps)
+    return _PeriodicCondition(mesh, eps, ignore_mismatch, ignore_dims)

@@ -15,6 +15,8 @@ struct mfh_ctx {
                                      // than the round-robin default on MI355X: DESIGN.md section 4.8)
     int debugVariant = 0;            // option "debug_variant": timing experiments of the gather kernel
     bool alwaysReembed = false;      // option "reembed": every mfh_assemble re-runs the embedding kernel
+    bool periodicIgnoreMismatch = false;   // option "periodic_ignore_mismatch": PeriodicCondition(..., ignoreMismatch)
+    int periodicIgnoreDims = 0;            // option "periodic_ignore_dims": bit a set = dimension a is not periodic
     hipStream_t stream = nullptr;
     bool ownStream = true;
     std::string err;
@@ -1205,7 +1207,7 @@ mfh_status mfh_apply_periodic_conditions(mfh_ctx *c, double eps, int64_t *nDoF) 
     require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
     std::vector<int32_t> dof;
     int64_t nd = 0;
-    periodic_dof_map(c->mesh, eps, dof, nd, c->mesh.bdryInternal);
+    periodic_dof_map(c->mesh, eps, dof, nd, c->mesh.bdryInternal, c->periodicIgnoreMismatch, c->periodicIgnoreDims);
     c->dofForNode.swap(dof);
     c->nDoF = nd;
     if (nDoF) *nDoF = nd;
@@ -2330,6 +2332,8 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "check_every") { c->checkEvery = std::max(1, (int)value); }
     else if (k2 == "keep_host_symbolic") { c->keepHostSymbolic = value != 0; }
     else if (k2 == "reembed") { c->alwaysReembed = value != 0; }
+    else if (k2 == "periodic_ignore_mismatch") { c->periodicIgnoreMismatch = value != 0; }
+    else if (k2 == "periodic_ignore_dims") { c->periodicIgnoreDims = (int)value & 7; }
     else if (k2 == "agg_nodes") { c->aggNodes = (int)value; c->tl.valid = false; }
     else if (k2 == "topology_device") { c->topologyDevice = value != 0; }
     else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }

@@ -132,7 +132,7 @@ bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const
                            std::vector<int32_t> &instEdge, int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst);
 void compute_node_positions(HostMesh &m);
 void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofForNode, int64_t &nDoF,
-                      std::vector<uint8_t> &bdryInternal);
+                      std::vector<uint8_t> &bdryInternal, bool ignoreMismatch = false, int ignoreDimsMask = 0);
 
 // ------------------------------------------------------------------------------------------------
 // Symbolic structure (BSR pattern + gather lists)

@@ -311,7 +311,7 @@ void compute_node_positions(HostMesh &m) {
 // nodes on opposite faces of the bounding-box cell are identified; DoF ids are assigned in
 // volume-node order, every identified node receiving the id at the first one's turn (:533-554).
 void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofForNode, int64_t &nDoF,
-                      std::vector<uint8_t> &bdryInternal) {
+                      std::vector<uint8_t> &bdryInternal, bool ignoreMismatch, int ignoreDimsMask) {
     if (!m.hasTopology) throw Error(MFH_ERR_STATE, "periodic conditions need mesh topology (mfh_mesh_build)");
     const int dim = m.dim;
     double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
@@ -320,8 +320,11 @@ void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofFo
             mn[a] = std::min(mn[a], m.nodePos[(size_t)n * dim + a]);
             mx[a] = std::max(mx[a], m.nodePos[(size_t)n * dim + a]);
         }
-    auto onMin = [&](int64_t n, int a) { return std::fabs(m.nodePos[(size_t)n * dim + a] - mn[a]) <= eps; };
-    auto onMax = [&](int64_t n, int a) { return std::fabs(m.nodePos[(size_t)n * dim + a] - mx[a]) <= eps; };
+    // face membership restricted to the periodic dimensions (PeriodicCondition's ignoreDims, BoundaryConditions.hh:470-500:
+    // a node keeps only its memberships of non-ignored faces)
+    auto periodicDim = [&](int a) { return !(ignoreDimsMask & (1 << a)); };
+    auto onMin = [&](int64_t n, int a) { return periodicDim(a) && std::fabs(m.nodePos[(size_t)n * dim + a] - mn[a]) <= eps; };
+    auto onMax = [&](int64_t n, int a) { return periodicDim(a) && std::fabs(m.nodePos[(size_t)n * dim + a] - mx[a]) <= eps; };
     // group boundary nodes lying on some cell face by their position wrapped onto the min faces
     struct Key { int64_t q[3]; int32_t node; };
     std::vector<Key> keys;
@@ -350,6 +353,31 @@ void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofFo
         for (size_t t = k; t < k2; ++t) { groups.back().push_back(keys[t].node); groupOf[keys[t].node] = (int32_t)groups.size() - 1; }
         k = k2;
     }
+    if (!ignoreMismatch) {
+        // PeriodicBoundaryMatcher::match (PeriodicBoundaryMatcher.hh:149-260): a node on d periodic faces is identified with
+        // exactly 2^d nodes, one per combination of min / max faces; anything else is a mismatch and throws
+        for (const auto &g : groups) {
+            int d = 0;
+            for (int a = 0; a < dim; ++a) d += onMin(g[0], a) || onMax(g[0], a);
+            bool ok = g.size() == (size_t(1) << d);
+            std::vector<uint8_t> seen(size_t(1) << d, 0);
+            for (int32_t n : g) {
+                int dn = 0, code = 0, bit = 0;
+                for (int a = 0; a < dim; ++a) {
+                    const bool lo = onMin(n, a), hi = onMax(n, a);
+                    if (lo || hi) { ++dn; if (hi) code |= 1 << bit; ++bit; }
+                }
+                if (dn != d || seen[code & ((1 << d) - 1)]++) ok = false;
+            }
+            if (!ok) {
+                const double *p = &m.nodePos[(size_t)g[0] * dim];
+                char buf[256];
+                snprintf(buf, sizeof buf, "Couldn't find every periodic-identified node for boundary node %d at (%g, %g, %g): %zu of %d found",
+                         g[0], p[0], p[1], dim == 3 ? p[2] : 0.0, g.size(), 1 << d);
+                throw Error(MFH_ERR_INVALID, buf);
+            }
+        }
+    }
     dofForNode.assign((size_t)m.nNode, -1);
     int32_t nd = 0;
     for (int64_t n = 0; n < m.nNode; ++n) {
@@ -359,7 +387,7 @@ void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofFo
         ++nd;
     }
     nDoF = nd;
-    // boundary elements whose nodes all lie on one cell face are internal (PeriodicBoundaryMatcher.hh:127-145)
+    // boundary elements whose nodes all lie on one (periodic) cell face are internal (PeriodicBoundaryMatcher.hh:127-145)
     const int64_t nBE = m.nBE();
     bdryInternal.assign((size_t)nBE, 0);
     for (int64_t b = 0; b < nBE; ++b) {

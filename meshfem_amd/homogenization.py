@@ -23,10 +23,10 @@ def _unflatten(dim, v):
     return M
 
 
-def solve_cell_problems(sim: Simulator, cell_epsilon=1e-7):
+def solve_cell_problems(sim: Simulator, cell_epsilon=1e-7, ignore_periodic_mismatch=False):
     """== solveCellProblems: periodic DoFs + pinned node, one solve per canonical strain with
     rhs = constantStrainLoad(-e_ij). The matrix is assembled once; the 3/6 right-hand sides reuse it."""
-    sim.applyPeriodicConditions(cell_epsilon)
+    sim.applyPeriodicConditions(cell_epsilon, ignoreMismatch=ignore_periodic_mismatch)
     sim.applyNoRigidMotionConstraint()
     sim.setUsePinNoRigidTranslationConstraint(True)
     w, infos = [], []

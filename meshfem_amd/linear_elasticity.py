@@ -61,7 +61,9 @@ class Simulator:
     def applyNeumannElements(self, bdry_elems, tractions):             # NeumannElementsCondition, :966-990
         self.ctx.bc_neumann_elements(bdry_elems, tractions)
 
-    def applyPeriodicConditions(self, epsilon=1e-7):                    # :845-854
+    def applyPeriodicConditions(self, epsilon=1e-7, ignoreMismatch=False, ignoreDims=()):    # :845-854
+        self.ctx.set_option("periodic_ignore_mismatch", 1 if ignoreMismatch else 0)
+        self.ctx.set_option("periodic_ignore_dims", sum(1 << int(d) for d in ignoreDims))
         return self.ctx.apply_periodic_conditions(epsilon)
 
     def removePeriodicConditions(self):                                 # :874-879

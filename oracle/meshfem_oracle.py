@@ -838,27 +838,91 @@ class SPSDSystem:
 # --------------------------------------------------------------------------------------
 # Periodic DoFs              BoundaryConditions.hh:452-561, PeriodicBoundaryMatcher.hh:111-260
 # --------------------------------------------------------------------------------------
-def periodic_dofs_for_nodes(mesh: FEMMesh, eps=1e-7):
-    """dofForNode + numDoFs + per-boundary-element isInternal flag. Nodes on opposite faces of the
-    bounding-box cell are identified; DoF ids assigned in volume-node order, every identified node
-    receiving the id at the first one's turn (BoundaryConditions.hh:533-554)."""
+def periodic_dofs_for_nodes(mesh: FEMMesh, eps=1e-7, ignore_mismatch=False, ignore_dims=()):
+    """PeriodicCondition (BoundaryConditions.hh:457-561): dofForNode + numDoFs + per-boundary-element isInternal flag.
+    Nodes on opposite faces of the bounding-box cell are identified with PeriodicBoundaryMatcher::match (:149-260; a
+    mismatch throws) or ::matchPermittingMismatch (:262-360); `ignore_dims` removes the memberships of the non-periodic
+    dimensions (:470-500). DoF ids are assigned in volume-node order, every identified node receiving the id at the first
+    one's turn (:533-554)."""
     pos = mesh.node_pos
     mn, mx = mesh.bounding_box()
     N = mesh.N
-    on_min = np.abs(pos - mn) <= eps
-    on_max = np.abs(pos - mx) <= eps
-    # canonical representative position: wrap max faces onto min faces
-    rep = np.where(on_max, mn, pos)
-    key = np.round((rep - mn) / (10 * eps)).astype(np.int64)          # spatial hash cell = 10 eps
-    groups = {}
-    dof = np.full(mesh.num_nodes, -1, dtype=np.int64)
-    bdry = np.flatnonzero(mesh.is_bdry_node & (on_min | on_max).any(axis=1))
-    for ni in bdry:
-        groups.setdefault(tuple(key[ni]), []).append(ni)
+    periodic = np.array([d not in tuple(ignore_dims) for d in range(N)])
+    on_min = (np.abs(pos - mn) <= eps) & periodic[None, :]
+    on_max = (np.abs(pos - mx) <= eps) & periodic[None, :]
+    bn = np.flatnonzero(mesh.is_bdry_node)
+    P = pos[bn]
+    bmin, bmax = on_min[bn], on_max[bn]
+
+    def closest(query, cand):                                         # CollisionGrid::getClosestPoint(query, eps)
+        if len(cand) == 0:
+            return -1
+        d = np.linalg.norm(P[cand] - query, axis=1)
+        k = int(np.argmin(d))
+        return int(cand[k]) if d[k] <= eps else -1
+
+    nb = len(bn)
+    set_for = np.full(nb, -1, dtype=np.int64)
+    sets = []
+    if not ignore_mismatch:                                           # match
+        minimal = ~bmax.any(axis=1)
+        nonmin = np.flatnonzero(~minimal)
+        for i in range(nb):
+            if not minimal[i]:
+                continue
+            set_for[i] = len(sets)
+            dims = np.flatnonzero(bmin[i])
+            ns = [i]
+            for n in range(1, 1 << len(dims)):
+                q = P[i].copy()
+                for idx, d in enumerate(dims):
+                    if n & (1 << idx):
+                        q[d] = mx[d]
+                r = closest(q, nonmin)
+                if r < 0:
+                    raise RuntimeError("Couldn't find %dth periodic-identified node for minimal boundary node %d at %s; looking for %s"
+                                       % (n, i, P[i], q))
+                if set_for[r] != -1:
+                    raise RuntimeError("Non bijective node set assignment.")
+                set_for[r] = set_for[i]
+                ns.append(r)
+            sets.append(ns)
+        un = np.flatnonzero(set_for < 0)
+        if len(un):
+            raise RuntimeError("Unmatched non-minimal boundary node %d at %s" % (un[0], P[un[0]]))
+    else:                                                             # matchPermittingMismatch
+        pair = {}
+        for d in range(N):
+            cand = np.flatnonzero(bmin[:, d])
+            for i in np.flatnonzero(bmax[:, d]):
+                q = P[i].copy()
+                q[d] = mn[d]
+                pi = closest(q, cand)
+                if pi < 0:
+                    continue                                          # mismatch!
+                a, b = pair.setdefault(int(i), [-1] * N), pair.setdefault(pi, [-1] * N)
+                if a[d] != -1 or b[d] != -1:
+                    raise RuntimeError("Non-bijective boundary matching")
+                a[d], b[d] = pi, int(i)
+        for i in range(nb):                                           # connected components of the pair graph
+            if set_for[i] != -1:
+                continue
+            set_for[i] = len(sets)
+            comp, queue = [i], [i]
+            while queue:
+                u = queue.pop(0)
+                for v in pair.get(u, []):
+                    if v != -1 and set_for[v] == -1:
+                        set_for[v] = set_for[i]
+                        comp.append(v)
+                        queue.append(v)
+            sets.append(comp)
     ident = {}
-    for g in groups.values():
+    for ns in sets:
+        g = [int(bn[k]) for k in ns]
         for ni in g:
             ident[ni] = g
+    dof = np.full(mesh.num_nodes, -1, dtype=np.int64)
     nd = 0
     for ni in range(mesh.num_nodes):
         if dof[ni] >= 0:
@@ -928,8 +992,8 @@ class Simulator:
     def dof_array(self):
         return np.arange(self.mesh.num_nodes) if self.dofForNode is None else self.dofForNode
 
-    def applyPeriodicConditions(self, eps=1e-7):                      # :845-854
-        self.dofForNode, self.numDoFs_, self.beInternal = periodic_dofs_for_nodes(self.mesh, eps)
+    def applyPeriodicConditions(self, eps=1e-7, ignore_mismatch=False, ignore_dims=()):   # :845-854
+        self.dofForNode, self.numDoFs_, self.beInternal = periodic_dofs_for_nodes(self.mesh, eps, ignore_mismatch, ignore_dims)
         self._system = None
 
     # ---- boundary conditions (box regions)                         :881-1027
