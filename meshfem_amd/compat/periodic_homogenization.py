@@ -23,8 +23,6 @@ def _tensor_like(Cbase, D):
 
 def homogenize(mesh, Cbase, orthotropicCell=False, manualPeriodicVerticesFile="", centerFluctuationDisplacements=True,
                ignorePeriodicMismatch=False, device=0, preconditioner=L.PRECOND_TWO_LEVEL, rtol=1e-10):
-    if manualPeriodicVerticesFile:
-        raise RuntimeError("manualPeriodicVerticesFile is not supported on this path")
     N = mesh.embeddingDimension
     sim = Simulator(mesh.elements(), mesh.vertices(), mesh.degree, device)
     sim.rtol = rtol
@@ -33,7 +31,8 @@ def homogenize(mesh, Cbase, orthotropicCell=False, manualPeriodicVerticesFile=""
     if orthotropicCell:                                    # periodic_homogenization.cc:53-56
         Ch, w, _ = H.homogenize_orthotropic_cell(sim)
     else:
-        w, _ = H.solve_cell_problems(sim, ignore_periodic_mismatch=ignorePeriodicMismatch)
+        w, _ = H.solve_cell_problems(sim, ignore_periodic_mismatch=ignorePeriodicMismatch,
+                                     manual_periodic_vertices_file=manualPeriodicVerticesFile)
         Ch = H.homogenized_elasticity_tensor_displacement_form(sim, w)
     if centerFluctuationDisplacements:                     # periodic_homogenization.cc:62-70
         w = [x - x.mean(axis=0) for x in w]

@@ -702,7 +702,8 @@ __global__ void __launch_bounds__(256) k_spmv_mf(SpmvMfArgs a, const double *__r
             double out[BS];
 #pragma unroll
             for (int c = 0; c < BS; ++c) out[c] = 0.0;
-#pragma unroll(UNR == 0 ? NPE : UNR)
+            constexpr int UNROLL_PAIRS = UNR == 0 ? NPE : UNR;
+#pragma unroll UNROLL_PAIRS
             for (int j = 0; j < NPE; ++j) {
                 int64_t col = en[j];
                 if (a.dofForNode) col = a.dofForNode[col];

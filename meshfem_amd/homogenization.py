@@ -23,10 +23,43 @@ def _unflatten(dim, v):
     return M
 
 
-def solve_cell_problems(sim: Simulator, cell_epsilon=1e-7, ignore_periodic_mismatch=False):
+def periodic_dofs_from_file(path, num_nodes):
+    """PeriodicCondition(mesh, pcFile) (BoundaryConditions.hh:565-613): the file lists pairs of identified NODE indices; every
+    connected component of that graph shares one DoF, numbered in node order. Returns (dofForNode, numDoFs)."""
+    adj = [[] for _ in range(num_nodes)]
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if len(t) < 2:
+                continue
+            a, b = int(t[0]), int(t[1])
+            if not (0 <= a < num_nodes and 0 <= b < num_nodes):
+                raise RuntimeError("periodic vertex file: node index out of range")
+            adj[a].append(b); adj[b].append(a)
+    dof = np.full(num_nodes, -1, dtype=np.int32)
+    nd = 0
+    for n in range(num_nodes):
+        if dof[n] >= 0:
+            continue
+        dof[n] = nd
+        queue = [n]
+        while queue:
+            u = queue.pop()
+            for v in adj[u]:
+                if dof[v] < 0:
+                    dof[v] = nd
+                    queue.append(v)
+        nd += 1
+    return dof, nd
+
+
+def solve_cell_problems(sim: Simulator, cell_epsilon=1e-7, ignore_periodic_mismatch=False, manual_periodic_vertices_file=""):
     """== solveCellProblems: periodic DoFs + pinned node, one solve per canonical strain with
     rhs = constantStrainLoad(-e_ij). The matrix is assembled once; the 3/6 right-hand sides reuse it."""
-    sim.applyPeriodicConditions(cell_epsilon, ignoreMismatch=ignore_periodic_mismatch)
+    if manual_periodic_vertices_file:                       # PeriodicHomogenization_cli.cc:101-102
+        sim.ctx.dof_map(*periodic_dofs_from_file(manual_periodic_vertices_file, sim.numNodes()))
+    else:
+        sim.applyPeriodicConditions(cell_epsilon, ignoreMismatch=ignore_periodic_mismatch)
     sim.applyNoRigidMotionConstraint()
     sim.setUsePinNoRigidTranslationConstraint(True)
     w, infos = [], []

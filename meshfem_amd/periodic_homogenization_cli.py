@@ -10,7 +10,7 @@ OrthotropicHomogenization.hh) for a homogeneous base material and prints, in the
 (PeriodicHomogenization.hh:146-186), its extreme eigenstrains, the compliance tensor, approximate Young / shear
 moduli and Poisson ratios, and the anisotropy. -M dumps the per-element macro-stress-to-micro-stress tensors
 (and gtensors.txt) (:174-188), -o the fields `load_ij k`, `w_ij k`, `strain w_ij k` (:190-228, piecewise-linear
-subsample; -D full-degree nodal fields with the average strain). Not supported here: --manualPeriodicVertices (raises)."""
+subsample; -D full-degree nodal fields with the average strain)."""
 import argparse
 import sys
 
@@ -66,8 +66,6 @@ def main(argv=None, out=sys.stdout):
     a = ap.parse_args(argv)
     if a.degree not in (1, 2):
         ap.error("FEM Degree must be 1 or 2")
-    if a.manualPeriodicVertices:
-        raise RuntimeError("--manualPeriodicVertices is not supported on this path")
     V, E, _ = load_mesh(a.mesh)
     K = E.shape[1] - 1
     if K not in (2, 3):
@@ -83,7 +81,8 @@ def main(argv=None, out=sys.stdout):
     if a.orthotropicCell:
         Ch, w, infos = H.homogenize_orthotropic_cell(sim)
     else:
-        w, infos = H.solve_cell_problems(sim, ignore_periodic_mismatch=a.ignorePeriodicMismatch)
+        w, infos = H.solve_cell_problems(sim, ignore_periodic_mismatch=a.ignorePeriodicMismatch,
+                                         manual_periodic_vertices_file=a.manualPeriodicVertices)
         Ch = H.homogenized_elasticity_tensor_displacement_form(sim, w)
     Eh = ElasticityTensor(N)
     Eh.D = 0.5 * (Ch + Ch.T)                         # the reference stores the upper triangle of a major-symmetric tensor

@@ -77,3 +77,47 @@ def test_ignore_dims_keeps_the_cell_periodic_in_the_other_directions(deg):
     be = mesh.bdry_elem_nodes
     on_z = np.array([(np.abs(P[b, 2] - 1) < 1e-12).all() or (np.abs(P[b, 2]) < 1e-12).all() for b in be])
     assert not internal[on_z].any() and internal[~on_z].all()
+
+
+def test_manual_periodic_vertices_file_reproduces_the_detected_map(tmp_path):
+    """PeriodicCondition(mesh, pcFile): pairs of identified nodes -> connected components -> DoFs in node order."""
+    from meshfem_amd import homogenization as H
+    V, T = _grid(2, 4)
+    dofs, n = _host_dofs(V, T, 2)
+    groups = {}
+    for node, d in enumerate(dofs):
+        groups.setdefault(int(d), []).append(node)
+    lines = []
+    for g in groups.values():                                  # a chain per identified set (corners: 4 nodes)
+        lines += ["%d %d" % (a, b) for a, b in zip(g[1:], g[:-1])]
+    path = tmp_path / "pairs.txt"
+    path.write_text("\n".join(lines) + "\n")
+    fd, fn = H.periodic_dofs_from_file(str(path), len(dofs))
+    assert fn == n and np.array_equal(fd, dofs)
+    (tmp_path / "bad.txt").write_text("0 99999\n")
+    with pytest.raises(RuntimeError, match="out of range"):
+        H.periodic_dofs_from_file(str(tmp_path / "bad.txt"), len(dofs))
+
+
+@pytest.mark.gpu
+def test_manual_periodic_vertices_file_homogenization_equals_detected(tmp_path):
+    import os
+    from meshfem_amd import homogenization as H, mesh_io
+    from meshfem_amd.linear_elasticity import Simulator
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    V, E, _ = mesh_io.load_msh(os.path.join(gold, "meshes", "2D_microstructure.msh"))
+    V = V[:, :2].copy()
+    res = []
+    for manual in (False, True):
+        sim = Simulator(E, V, 2); sim.rtol = 1e-11; sim.setIsotropicMaterial(200.0, 0.35)
+        if manual:
+            w, _ = H.solve_cell_problems(sim, manual_periodic_vertices_file=str(tmp_path / "pairs.txt"))
+        else:
+            w, _ = H.solve_cell_problems(sim)
+            dofs = sim.ctx.get_dof_map()[0]
+            groups = {}
+            for node, d in enumerate(dofs):
+                groups.setdefault(int(d), []).append(node)
+            (tmp_path / "pairs.txt").write_text("\n".join("%d %d" % (a, b) for g in groups.values() for a, b in zip(g[1:], g[:-1])) + "\n")
+        res.append(H.homogenized_elasticity_tensor(sim, w))
+    assert np.abs(res[0] - res[1]).max() < 1e-8 * np.abs(res[0]).max()
