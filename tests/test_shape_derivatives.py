@@ -291,3 +291,42 @@ def test_hip_discrete_differential_matches_oracle(dim, deg, small):
     iu = np.triu_indices(O.flat_len(dim))
     d = H.delta_homogenized_elasticity_tensor(hsim, w, dp)
     assert np.abs(np.einsum("pvc,vc->p", packed, dp) - d[iu]).max() < HIP_RTOL * np.abs(d).max()
+
+
+@pytest.mark.gpu
+def test_hip_shape_derivative_scaling_identities_on_a_larger_mesh():
+    """Size-independent properties at a size the oracle does not run (16^3 grid -> 98 304 P2 tets): under the dilation
+    delta_p = x every length scales, so (delta K) u = (dim - 2) K u, delta constantStrainLoad = (dim - 1) load,
+    delta strain(u fixed) = -strain(u); a rigid translation of the mesh changes nothing; the one-form of the mutual
+    energies sums to zero over the vertices (translation) and contracts to the forward-mode derivative."""
+    from meshfem_amd import grid
+    from meshfem_amd.linear_elasticity import Simulator
+    rng = np.random.default_rng(8)
+    V, T = grid.grid_tet_mesh(16, 16, 16, [0, 0, 0], [1, 1, 1])
+    sim = Simulator(T, V, 2)
+    P = np.column_stack([rng.uniform(100, 300, (len(T), 3)), rng.uniform(0.2, 0.35, (len(T), 3)), rng.uniform(40, 120, (len(T), 3))])
+    sim.setOrthotropicField(P)
+    nn = sim.numNodes()
+    u = rng.normal(size=(nn, 3))
+    Ku = sim.applyStiffnessMatrix(u)
+    dKu = sim.applyDeltaStiffnessMatrix(u, V)
+    assert np.abs(dKu - Ku).max() < 1e-11 * np.abs(Ku).max()
+    cs = np.array([1.0, -0.5, 0.25, 0.3, 0.2, 0.1])
+    l, dl = sim.constantStrainLoad(cs), sim.deltaConstantStrainLoad(cs, V)
+    assert np.abs(dl - 2 * l).max() < 1e-11 * np.abs(l).max()
+    e, de = sim.averageStrainField(u), sim.deltaAverageStrainField(u, np.zeros_like(u), V)
+    assert np.abs(de + e).max() < 1e-11 * np.abs(e).max()
+    shift = np.tile([0.3, -0.2, 0.5], (len(V), 1))
+    assert np.abs(sim.applyDeltaStiffnessMatrix(u, shift)).max() < 1e-10 * np.abs(Ku).max()
+    w = [rng.normal(size=(nn, 3)) * 0.05 for _ in range(6)]
+    one = sim.ctx.mutual_energy_differential(w)                          # [21, nVert, 3]
+    assert np.abs(one.sum(axis=1)).max() < 1e-9 * np.abs(one).max() * len(V) ** 0.5
+    dp = rng.normal(size=V.shape) * 0.01
+    d = sim.ctx.mutual_energies(w, dp)
+    iu = np.triu_indices(6)
+    assert np.abs(np.einsum("pvc,vc->p", one, dp) - d[iu]).max() < 1e-11 * np.abs(d).max()
+    # dilation of the mutual energies at fixed nodal fields: strains of w scale like 1/length, the volume like length^3;
+    # with w = 0 only the volume term survives: dM = 3 M
+    zero = [np.zeros((nn, 3))] * 6
+    M0, dM0 = sim.ctx.mutual_energies(zero), sim.ctx.mutual_energies(zero, V)
+    assert np.abs(dM0 - 3 * M0).max() < 1e-11 * np.abs(M0).max()
