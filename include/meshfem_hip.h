@@ -256,6 +256,10 @@ mfh_status mfh_sim_solve_constrained(mfh_ctx* ctx, const double* f, int32_t flag
 /* == averageStrainField / averageStressField (:528-549, :99-123): per element, flattened (flatLen) */
 mfh_status mfh_average_strain(mfh_ctx* ctx, const double* uNodes, double* strain /* nElem x flatLen */);
 mfh_status mfh_average_stress(mfh_ctx* ctx, const double* uNodes, double* stress /* nElem x flatLen */);
+/* == strainField / stressField, elementStrain / elementStress (:493-526; Element::strain :99-117): the nodal values of the
+ * degree-(Deg-1) strain interpolant of every element -- one value for P1, the values at the dim+1 corners for P2 (edge
+ * nodes of an upsampled field are the means of their end points). out: [nElem][1 | dim+1][flatLen]. */
+mfh_status mfh_strain_field(mfh_ctx* ctx, const double* uNodes, int32_t wantStress, double* out);
 
 /* ---- discrete shape derivatives, forward mode (LinearElasticity.hh:234-330 at element level; Simulator level
  * :1297-1374). deltaP is a per-vertex perturbation field [nVert x dim] (indexed by the node id of the element corners:

@@ -363,6 +363,13 @@ class Context:
         self._ck(self.lib.mfh_average_strain(self.h, ptr(u), ptr(out)))
         return out
 
+    def strain_field(self, u_nodes, stress=False):
+        """per-element strain (stress) interpolant values: [nElem, 1 | dim+1, flatLen]"""
+        u = as_f64(u_nodes)
+        out = np.empty((self.n_elem, 1 if self.deg == 1 else self.dim + 1, flat_len(self.dim)))
+        self._ck(self.lib.mfh_strain_field(self.h, ptr(u), int(bool(stress)), ptr(out)))
+        return out
+
     def average_stress(self, u_nodes):
         u = as_f64(u_nodes)
         out = np.empty((self.n_elem, flat_len(self.dim)))

@@ -294,6 +294,9 @@ void launch_apply_delta_K(const AsmArgs &a, const int32_t *elemNodes, const int3
 // out[pair(ij<=kl)] += sum_e mutual energy (deltaP == nullptr) or its shape derivative; w: [flatLen][nNode][dim]
 void launch_mutual_energies(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *w, int64_t nNode,
                             const double *deltaP, double *out, hipStream_t s);
+// strain / stress interpolant values per element: [nElem][1 (P1) | dim+1 (P2)][flatLen]
+void launch_strain_field(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, int wantStress,
+                         double *out, hipStream_t s);
 // out[pair(ij<=kl)][nVert][dim] += d(mutual energy)/d(vertex position)
 void launch_mutual_energy_differential(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *w,
                                        int64_t nNode, int64_t nVert, double *out, hipStream_t s);

@@ -961,12 +961,13 @@ DEV void load_corner_perturbation(const double *__restrict__ g, const int32_t *_
 // flattened (tensor-shear) symmetrised gradient of the nodal field xl at quadrature point q, built on the gradients gl:
 // sym(sum_i u_i (x) grad phi_i(x_q)); P2: grad phi_k = (4 lam_k - 1) gl_k, grad phi_(s,t) = 4 (lam_t gl_s + lam_s gl_t)
 // (EmbeddedElement.hh:315-332) at the vertex-associated points lam_k(x_q) = c0 if k == q else c1.
-template <int DIM, int DEG>
+// AT_VERTEX: evaluate at vertex q instead (lam_k = [k == q]), the nodal values of the degree-(DEG-1) strain interpolant
+template <int DIM, int DEG, bool AT_VERTEX = false>
 DEV void grad_u_at(const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM], const double (&gl)[DIM + 1][DIM],
                    int q, double (&G)[DIM][DIM]) {
     constexpr int NV = DIM + 1;
-    constexpr double c0 = DIM == 3 ? 0.58541019662496845446 : 2.0 / 3.0;
-    constexpr double c1 = DIM == 3 ? 0.13819660112501051518 : 1.0 / 6.0;
+    constexpr double c0 = AT_VERTEX ? 1.0 : (DIM == 3 ? 0.58541019662496845446 : 2.0 / 3.0);
+    constexpr double c1 = AT_VERTEX ? 0.0 : (DIM == 3 ? 0.13819660112501051518 : 1.0 / 6.0);
 #pragma unroll
     for (int p = 0; p < DIM; ++p)
 #pragma unroll
@@ -1005,6 +1006,50 @@ DEV void sym_grad_u_at(const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DE
     for (int p = 0; p < DIM; ++p)
 #pragma unroll
         for (int r = p; r < DIM; ++r) ef[flat_idx<DIM>(p, r)] = 0.5 * (G[p][r] + G[r][p]);
+}
+
+// Strain (or stress) field as per-element interpolants (Simulator::strainField / stressField, LinearElasticity.hh:511-526;
+// Element::strain :99-117): the nodal values of the degree-(DEG-1) interpolant, i.e. one value per element for P1 and the
+// values at the NV corners for P2. out: [nElem][NQ][flatLen].
+template <int DIM, int DEG, int MAT>
+__global__ void __launch_bounds__(256) k_strain_field(LoadArgs a, const double *__restrict__ uNodes, int wantStress, double *__restrict__ out) {
+    constexpr int NV = DIM + 1;
+    constexpr int FL = DIM * (DIM + 1) / 2;
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    constexpr int NQ = DEG == 1 ? 1 : NV;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.nElem; e += (int64_t)gridDim.x * 256) {
+        const double *g = a.geo + e * a.geoStride;
+        const int32_t *en = a.elemNodes + e * NPE;
+        double gl[NV][DIM], xl[NPE][DIM];
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) gl[k][d] = g[k * DIM + d];
+#pragma unroll
+        for (int j = 0; j < NPE; ++j) {
+            const int64_t node = en[j];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) xl[j][d] = uNodes[node * DIM + d];
+        }
+        for (int q = 0; q < NQ; ++q) {
+            double G[DIM][DIM], ef[FL];
+            grad_u_at<DIM, DEG, true>(xl, gl, q, G);
+#pragma unroll
+            for (int p = 0; p < DIM; ++p)
+#pragma unroll
+                for (int r = p; r < DIM; ++r) ef[flat_idx<DIM>(p, r)] = 0.5 * (G[p][r] + G[r][p]);
+            if (wantStress) {
+                double sd[FL], sg[FL];
+#pragma unroll
+                for (int c = 0; c < FL; ++c) sd[c] = ef[c] * (c < DIM ? 1.0 : 2.0);
+                elem_D_apply<DIM, MAT>(g, sd, sg);
+#pragma unroll
+                for (int c = 0; c < FL; ++c) ef[c] = sg[c];
+            }
+#pragma unroll
+            for (int c = 0; c < FL; ++c) out[(e * NQ + q) * FL + c] = ef[c];
+        }
+    }
 }
 
 // The exact differential of the mutual energies with respect to every vertex coordinate
@@ -2279,6 +2324,16 @@ void launch_mutual_energies(const AsmArgs &a, const int32_t *elemNodes, const do
     const int fl = a.dim * (a.dim + 1) / 2;
     const dim3 grid(grid_for(a.nElem, 4096), fl * (fl + 1) / 2);
 #define CALL(D, G, M) hipLaunchKernelGGL((k_mutual_energies<D, G, M>), grid, dim3(256), 0, s, l, w, nNode, deltaP, out)
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+    CHECK_LAUNCH();
+}
+
+void launch_strain_field(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, int wantStress,
+                         double *out, hipStream_t s) {
+    const LoadArgs l = make_load_args(a, elemNodes, nullptr, intGrad, nullptr);
+    const int grid = grid_for(a.nElem, 8192);
+#define CALL(D, G, M) hipLaunchKernelGGL((k_strain_field<D, G, M>), dim3(grid), dim3(256), 0, s, l, uNodes, wantStress, out)
     MFH_DISPATCH(a, CALL);
 #undef CALL
     CHECK_LAUNCH();

@@ -98,6 +98,15 @@ class Simulator:
     def applyStiffnessMatrix(self, u_dofs):                             # :801-823
         return self.ctx.apply_K(np.asarray(u_dofs).ravel()).reshape(-1, self.N)
 
+    def strainField(self, u_nodes):                                     # :511-517 (interpolant values per element)
+        return self.ctx.strain_field(u_nodes)
+
+    def stressField(self, u_nodes):                                     # :519-526
+        return self.ctx.strain_field(u_nodes, stress=True)
+
+    def elementStrain(self, i, u_nodes):                                # :493-497 (one element of strainField)
+        return self.ctx.strain_field(u_nodes)[i]
+
     def averageStrainField(self, u_nodes):                              # :528-538
         return self.ctx.average_strain(u_nodes)
 

@@ -76,7 +76,7 @@ def load_msh(path):
             hdr = _readline(f)
             if not hdr:
                 break
-            if hdr not in ("$NodeData", "$ElementData"):
+            if hdr not in ("$NodeData", "$ElementData", "$ElementNodeData"):
                 continue
             nstr = int(_readline(f))
             name = [_readline(f).strip('"') for _ in range(nstr)][0]
@@ -85,6 +85,18 @@ def load_msh(path):
             ntag = int(_readline(f))
             itags = [int(_readline(f)) for _ in range(ntag)]
             dim, cnt = itags[1], itags[2]
+            if hdr == "$ElementNodeData":                    # elem_idx nodesPerElem values (MSHFieldWriter.hh:284-303)
+                rows = []
+                for _ in range(cnt):
+                    if binary:
+                        _, npe_ = struct.unpack("<2i", f.read(8))
+                        rows.append(np.frombuffer(f.read(8 * npe_ * dim), dtype="<f8").reshape(npe_, dim))
+                    else:
+                        t = _readline(f).split()
+                        rows.append(np.array([float(x) for x in t[2:]]).reshape(int(t[1]), dim))
+                fields[name] = ("element node", np.stack(rows))
+                _readline(f)
+                continue
             if binary:
                 rec = np.frombuffer(f.read(cnt * (4 + 8 * dim)), dtype=np.dtype([("i", "<i4"), ("v", "<f8", dim)]))
                 vals = rec["v"].reshape(cnt, dim).astype(np.float64)
@@ -120,6 +132,16 @@ def load_mesh(path):
         V, E = load_off(path)
         return V, E, {}
     return load_msh(path)
+
+
+def upsample_interpolant(values, dim):
+    """Degree-1 per-element interpolant values [nElem, dim+1, k] -> degree-2 nodal values [nElem, nodesPerElem, k]
+    (SymmetricMatrixInterpolant upsampling in Simulate_cli.cc:216-229): corners, then the edge midpoints in the
+    reference's edge order (Simplex.hh:43-47)."""
+    edges = [(0, 1), (1, 2), (2, 0)] if dim == 2 else [(0, 1), (1, 2), (2, 0), (0, 3), (2, 3), (1, 3)]
+    values = np.asarray(values)
+    mids = np.stack([0.5 * (values[:, a] + values[:, b]) for a, b in edges], axis=1)
+    return np.concatenate([values, mids], axis=1)
 
 
 class MSHFieldWriter:
@@ -192,6 +214,37 @@ class MSHFieldWriter:
             for i in range(n):
                 w(("%d %s\n" % (i + 1, " ".join("%.17g" % x for x in out[i]))).encode())
         w(("$End%s\n" % ("NodeData" if domain == "node" else "ElementData")).encode())
+
+    def addElementNodeField(self, name, values):
+        """Per-element interpolants as $ElementNodeData (MSHFieldWriter.hh:262-306): values [nElem, nodesPerElem, k] with
+        k = 1 | 2 | 3 (vectors padded to 3) or flatLen (symmetric matrices, padded 3x3 scanline)."""
+        values = np.asarray(values, dtype=np.float64)
+        if values.ndim != 3 or len(values) != self.n_elems:
+            raise RuntimeError("Vector-of-interpolants must be per-element.")
+        n, npe, k = values.shape
+        if k == 6 or (k == 3 and (name.startswith("strain") or name.startswith("stress"))):
+            N = 2 if k == 3 else 3
+            idx = {2: [(0, 0), (1, 1), (0, 1)], 3: [(0, 0), (1, 1), (2, 2), (1, 2), (0, 2), (0, 1)]}[N]
+            out = np.zeros((n, npe, 3, 3))
+            for q, (a, b) in enumerate(idx):
+                out[:, :, a, b] = out[:, :, b, a] = values[:, :, q]
+            out = out.reshape(n, npe, 9)
+        elif k == 2:
+            out = np.concatenate([values, np.zeros((n, npe, 1))], axis=2)
+        elif k in (1, 3):
+            out = values
+        else:
+            raise RuntimeError("Invalid field dimension.")
+        w = self.f.write
+        w(("$ElementNodeData\n1\n\"%s\"\n0\n3\n0\n%d\n%d\n" % (name, out.shape[2], n)).encode())
+        if self.binary:
+            rec = np.empty(n, dtype=np.dtype([("i", "<i4"), ("n", "<i4"), ("v", "<f8", npe * out.shape[2])]))
+            rec["i"], rec["n"], rec["v"] = np.arange(1, n + 1), npe, out.reshape(n, -1)
+            w(rec.tobytes() + b"\n")
+        else:
+            for i in range(n):
+                w(("%d %d %s\n" % (i + 1, npe, " ".join("%.17g" % x for x in out[i].ravel()))).encode())
+        w(b"$EndElementNodeData\n")
 
     def close(self):
         self.f.close()

@@ -10,7 +10,7 @@ OrthotropicHomogenization.hh) for a homogeneous base material and prints, in the
 (PeriodicHomogenization.hh:146-186), its extreme eigenstrains, the compliance tensor, approximate Young / shear
 moduli and Poisson ratios, and the anisotropy. -M dumps the per-element macro-stress-to-micro-stress tensors
 (and gtensors.txt) (:174-188), -o the fields `load_ij k`, `w_ij k`, `strain w_ij k` (:190-228, piecewise-linear
-subsample; -D full-degree nodal fields with the average strain)."""
+subsample; -D full-degree nodal fields and per-element strain interpolants as $ElementNodeData)."""
 import argparse
 import sys
 
@@ -20,7 +20,7 @@ from . import _lib as L
 from . import homogenization as H
 from .core import flat_len
 from .linear_elasticity import Simulator
-from .mesh_io import MSHFieldWriter, load_mesh
+from .mesh_io import MSHFieldWriter, load_mesh, upsample_interpolant
 from .simulate_cli import parse_material
 from .tensors import ElasticityTensor, closest_isotropic_tensor
 
@@ -136,7 +136,10 @@ def main(argv=None, out=sys.stdout):
             load = sim.constantStrainLoad(-H.canonical_strain_flat(N, k))[dm]          # dofToNodeField
             wr.addField("load_ij %d" % k, load[cut], "node")
             wr.addField("w_ij %d" % k, w[k][cut], "node")
-            wr.addField("strain w_ij %d" % k, sim.averageStrainField(w[k]), "element")
+            if a.fullDegreeFieldOutput and a.degree == 2:  # :214-226
+                wr.addElementNodeField("strain w_ij %d" % k, upsample_interpolant(sim.strainField(w[k]), N))
+            else:
+                wr.addField("strain w_ij %d" % k, sim.averageStrainField(w[k]), "element")
         wr.close()
 
     if a.distanceToIsotropy:                          # :230-236

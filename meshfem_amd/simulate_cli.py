@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib as L
 from .linear_elasticity import Simulator
-from .mesh_io import MSHFieldWriter, load_msh
+from .mesh_io import MSHFieldWriter, load_msh, upsample_interpolant
 from .tensors import ElasticityTensor
 from .expressions import ExpressionVector, environment
 
@@ -268,7 +268,11 @@ def main(argv=None):
         nv = len(V)
         w = MSHFieldWriter(a.outputMSH, nodes[:nv], elems[:, :K + 1], binary=not a.ascii)
         w.addField("u", u[:nv], "node"); w.addField("load", f[:nv], "node")
-    w.addField("strain", e, "element"); w.addField("stress", s, "element")
+    if a.fullDegreeFieldOutput and a.degree == 2:          # full-degree per-element strain / stress (Simulate_cli.cc:216-229)
+        w.addElementNodeField("strain", upsample_interpolant(sim.strainField(u), N))
+        w.addElementNodeField("stress", upsample_interpolant(sim.stressField(u), N))
+    else:
+        w.addField("strain", e, "element"); w.addField("stress", s, "element")
     if Ku is not None:
         w.addField("Ku", Ku if a.fullDegreeFieldOutput else Ku[:len(V)], "node")
     w.close()

@@ -1164,6 +1164,22 @@ class Simulator:
             out[e] = flatten_sym(N, eps)
         return out
 
+    def strainField(self, u_nodes, stress=False):                     # :511-526, Element::strain :99-117
+        """per-element strain (stress) interpolant: nodal values [nE, nInterp, flatLen] of degree deg-1."""
+        m, N = self.mesh, self.N
+        nint = 1 if self.deg == 1 else self.K + 1
+        out = np.zeros((len(m.elems), nint, flat_len(N)))
+        for e in range(len(m.elems)):
+            S = np.zeros((nint, N, N))
+            for i in range(m.nodes_per_elem):
+                g = grad_phi_nodal(self.deg, self.K, self.gl[e], i)
+                ui = u_nodes[m.elem_nodes[e, i]]
+                for k in range(nint):
+                    S[k] += 0.5 * (np.outer(ui, g[k]) + np.outer(g[k], ui))
+            for k in range(nint):
+                out[e, k] = self.elem_D(e).double_contract_flat(flatten_sym(N, S[k])) if stress else flatten_sym(N, S[k])
+        return out
+
     def averageStressField(self, u_nodes):
         eps = self.averageStrainField(u_nodes)
         return np.stack([self.elem_D(e).double_contract_flat(eps[e]) for e in range(len(eps))])

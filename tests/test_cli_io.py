@@ -30,6 +30,17 @@ def test_msh_roundtrip(tmp_path, binary):
     assert np.allclose(M9, np.transpose(M9, (0, 2, 1)))
     assert np.array_equal(M9[:, [0, 1, 2, 1, 0, 0], [0, 1, 2, 2, 2, 1]], e)
     assert np.array_equal(F["E"][1][:, 0], np.arange(len(T)))
+    # per-element interpolants as $ElementNodeData (MSHFieldWriter.hh:262-306), mixed with the other sections
+    sv = rng.random((len(T), 4, 6))
+    w = mesh_io.MSHFieldWriter(p, V, T, binary=binary)
+    w.addField("u", u, "node"); w.addElementNodeField("stress", sv); w.addElementNodeField("g", sv[:, :, :1]); w.addField("E", e[:, 0], "element")
+    w.close()
+    _, _, F = mesh_io.load_msh(p)
+    assert F["stress"][0] == "element node" and F["stress"][1].shape == (len(T), 4, 9) and np.array_equal(F["u"][1], u)
+    assert np.array_equal(F["stress"][1].reshape(len(T), 4, 3, 3)[:, :, [0, 1, 2, 1, 0, 0], [0, 1, 2, 2, 2, 1]], sv)
+    assert np.array_equal(F["g"][1], sv[:, :, :1]) and np.array_equal(F["E"][1][:, 0], e[:, 0])
+    up = mesh_io.upsample_interpolant(sv, 3)
+    assert up.shape == (len(T), 10, 6) and np.array_equal(up[:, 9], 0.5 * (sv[:, 1] + sv[:, 3])) and np.array_equal(up[:, :4], sv)
     # 2D meshes are padded with z = 0
     V2d, T2d = grid.grid_tri_mesh(2, 2)
     w = mesh_io.MSHFieldWriter(p, V2d, T2d, binary=binary); w.addField("u", rng.random((len(V2d), 2)), "node"); w.close()
@@ -300,3 +311,27 @@ def test_node_list_and_element_list_conditions_equal_their_box_forms(tmp_path):
         solve([{"type": "dirichlet nodes", "values": [[[0, 0, 0], [inner]]]}])
     with pytest.raises(RuntimeError, match="weren't matched"):
         solve([clamp, {"type": "traction elements", "values": [[[0, 0, 1], [[0, 1, 2]]]]}])
+
+
+@pytest.mark.gpu
+def test_simulate_cli_full_degree_output_writes_strain_interpolants(tmp_path):
+    """-D with quadratic elements: u / load on all nodes and per-element strain / stress interpolants upsampled to the 10
+    nodes as $ElementNodeData (Simulate_cli.cc:216-229); their corner mean is the average strain of the default output."""
+    V, T = grid.grid_tet_mesh(3, 2, 2, [0, 0, 0], [1.5, 1, 1])
+    mesh = tmp_path / "beam.msh"
+    mesh_io.MSHFieldWriter(str(mesh), V, T, binary=True).close()
+    bc = {"regions": [{"type": "dirichlet", "value": [0, 0, 0], "box%": {"minCorner": [-0.01, -0.01, -0.01], "maxCorner": [0.01, 1.01, 1.01]}},
+                      {"type": "force", "value": [0, -1, 0], "box%": {"minCorner": [0.99, -0.01, -0.01], "maxCorner": [1.01, 1.01, 1.01]}}]}
+    (tmp_path / "c.bc").write_text(json.dumps(bc))
+    outs = {}
+    for flag in ([], ["-D"]):
+        out = tmp_path / ("out%d.msh" % len(flag))
+        assert simulate_cli.main([str(mesh), "-b", str(tmp_path / "c.bc"), "-d", "2", "-o", str(out), "--rtol", "1e-12"] + flag) == 0
+        outs[len(flag)] = mesh_io.load_msh(str(out))
+    (V0, T0, F0), (V1, T1, F1) = outs[0], outs[1]
+    assert T0.shape[1] == 4 and T1.shape[1] == 10 and len(V1) > len(V0)
+    assert F1["strain"][0] == "element node" and F1["strain"][1].shape == (len(T), 10, 9)
+    corner_mean = F1["strain"][1][:, :4].mean(axis=1)
+    assert np.abs(corner_mean - F0["strain"][1]).max() < 1e-9 * np.abs(F0["strain"][1]).max()
+    assert np.allclose(F1["strain"][1][:, 4], 0.5 * (F1["strain"][1][:, 0] + F1["strain"][1][:, 1]))
+    assert np.abs(F1["u"][1][:len(V0)] - F0["u"][1]).max() < 1e-9 * np.abs(F0["u"][1]).max()

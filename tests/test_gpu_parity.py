@@ -908,3 +908,32 @@ def test_random_delaunay_meshes(dim, seed):
         u = c.sim_solve(rtol=1e-11, maxit=200000)
         assert np.linalg.norm(u - sim.solve()) < U_RTOL * np.linalg.norm(u)
         c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,deg", [(3, 1), (3, 2), (2, 2)])
+def test_strain_and_stress_interpolant_fields_match_oracle(dim, deg):
+    """strainField / stressField (LinearElasticity.hh:511-526): nodal values of the per-element strain interpolant; their
+    mean is averageStrainField. Tolerance 1e-12 relative (same arithmetic, different summation order)."""
+    from meshfem_amd.linear_elasticity import Simulator
+    rng = np.random.default_rng(dim * 10 + deg)
+    if dim == 3:
+        V, T = O.grid_tet_mesh(2, 2, 1)
+    else:
+        V, Q = O.gen_grid_2d(3, 2)
+        V, T = O.quad_tri_subdiv(V, Q)
+        V = V[:, :2]
+    V = V + 0.05 * rng.normal(size=V.shape) * (np.abs(V - V.min(0)) > 1e-9).all(axis=1)[:, None] * (np.abs(V - V.max(0)) > 1e-9).all(axis=1)[:, None]
+    osim = O.Simulator(T, V, deg)
+    mats = [O.ElasticityTensor.isotropic(dim, 100.0 + 10 * (e % 7), 0.3) for e in range(len(T))]
+    osim.set_material_field(mats)
+    sim = Simulator(T, V, deg)
+    sim.ctx.material_tensor_field(np.stack([m.D for m in mats]))
+    u = rng.normal(size=(osim.mesh.num_nodes, dim))
+    for stress in (False, True):
+        ref = osim.strainField(u, stress=stress)
+        got = sim.stressField(u) if stress else sim.strainField(u)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-12 * np.abs(ref).max()
+    avg = sim.strainField(u).mean(axis=1)
+    assert np.abs(avg - sim.averageStrainField(u)).max() < 1e-12 * np.abs(avg).max()
+    assert np.array_equal(sim.elementStrain(3, u), sim.strainField(u)[3])
