@@ -212,6 +212,13 @@ public:
         check(ctx(), mfh_average_strain(ctx(), &uNodes[0][0], &e[0][0]));
         return e;
     }
+    // strainField / stressField (:511-526): nodal values of every element's strain interpolant, [nElem][1 | N+1][flatLen]
+    std::vector<Real> strainField(const VField &uNodes, bool stress = false) const {
+        std::vector<Real> out((size_t)m_numElements * (Deg == 1 ? 1 : N + 1) * (N * (N + 1) / 2));
+        check(ctx(), mfh_strain_field(ctx(), &uNodes[0][0], stress ? 1 : 0, out.data()));
+        return out;
+    }
+    std::vector<Real> stressField(const VField &uNodes) const { return strainField(uNodes, true); }
     SMField averageStressField(const VField &uNodes) const {     // :539-549
         SMField s((size_t)m_numElements);
         check(ctx(), mfh_average_stress(ctx(), &uNodes[0][0], &s[0][0]));

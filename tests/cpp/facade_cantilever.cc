@@ -51,7 +51,16 @@ int main(int argc, char **argv) {
         if (std::fabs(fy + 1.0) > 1e-12 || tip > -1.2 || tip < -1.6) return 2;
         auto eps = sim.averageStrainField(u);
         auto Ku = sim.applyStiffnessMatrix(u);
-        (void)eps;
+        // per-element strain interpolants: their corner mean is the averaged strain
+        auto sf = sim.strainField(u);
+        Real dev = 0;
+        for (size_t e2 = 0; e2 < eps.size(); ++e2)
+            for (int c2 = 0; c2 < 6; ++c2) {
+                Real m = 0;
+                for (int k2 = 0; k2 < 4; ++k2) m += sf[(e2 * 4 + k2) * 6 + c2] / 4;
+                dev = std::max(dev, std::fabs(m - eps[e2][c2]));
+            }
+        if (dev > 1e-12) return 5;
         // shape derivative under the uniform dilation delta_p = x: K scales with length^(dim-2), so (delta K) u = K u in 3D
         decltype(u) dp(V.size());
         for (size_t n = 0; n < V.size(); ++n) dp[n] = {V[n][0], V[n][1], V[n][2]};
