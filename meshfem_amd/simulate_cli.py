@@ -108,6 +108,8 @@ def apply_boundary_conditions(sim, path):
     N = sim.N
     be_lookup = None
     geo = {}
+    region_of_node = {}                                      # BoundaryNode::dirichletRegionIdx (setDirichletRegion, :946,:962)
+    n_dirichlet_regions = 0
 
     def mesh_geometry():                                     # only list / expression / delta-force regions need it
         if not geo:
@@ -128,6 +130,17 @@ def apply_boundary_conditions(sim, path):
             if k:
                 comps = ["xyz"[a] in rest[:k] for a in range(N)]
             t = "dirichlet" + rest[k:]
+        if t == "dirichlet" and hasattr(sim, "ctx"):        # region index of the boundary nodes inside (:939-949)
+            n_dirichlet_regions += 1
+            if "box" in r or "box%" in r:
+                pos_, mn_, mx_ = mesh_geometry()
+                key = "box" if "box" in r else "box%"
+                lo_, hi_ = _vec(r[key]["minCorner"], N), _vec(r[key]["maxCorner"], N)
+                if key == "box%":
+                    lo_, hi_ = mn_ + lo_ * (mx_ - mn_), mn_ + hi_ * (mx_ - mn_)
+                bn_ = sim.ctx.boundary_nodes()
+                for nd in bn_[np.all((pos_[bn_] >= lo_) & (pos_[bn_] <= hi_), axis=1)]:
+                    region_of_node[int(nd)] = n_dirichlet_regions
         if t == "dirichlet nodes":
             idx, val = _node_values(r["values"], N)
             sim.applyDirichletNodes(idx, val, comps)
@@ -207,6 +220,18 @@ def apply_boundary_conditions(sim, path):
                 c.bc_delta_force(int(ni), _vec(val, N))
         else:
             raise RuntimeError("Invalid type '%s'" % r["type"])
+    return region_of_node
+
+
+def region_surface_forces(sim, u, region_of_node):
+    """reportRegionSurfaceForces (LinearElasticity.hh:1251-1270): K u summed over the boundary nodes of every Dirichlet
+    region (index 0 collects the boundary nodes outside all of them)."""
+    f = sim.applyStiffnessMatrix(u)
+    bn = sim.ctx.boundary_nodes()
+    idx = np.array([region_of_node.get(int(n), 0) for n in bn], dtype=np.int64)
+    forces = np.zeros((idx.max() + 1 if len(idx) else 1, sim.N))
+    np.add.at(forces, idx, f[bn])
+    return forces
 
 
 def main(argv=None):
@@ -253,7 +278,7 @@ def main(argv=None):
         with open(a.dumpMatrix, "wb") as f:
             np.array([len(v)], dtype=np.uint64).tofile(f); i.tofile(f); j.tofile(f); v.tofile(f)
         return 0
-    apply_boundary_conditions(sim, a.boundaryConditions)
+    regions = apply_boundary_conditions(sim, a.boundaryConditions)
     u = sim.solve()
     e, s = sim.averageStrainField(u), sim.averageStressField(u)
     dm, _ = sim.ctx.get_dof_map()
@@ -274,6 +299,8 @@ def main(argv=None):
     else:
         w.addField("strain", e, "element"); w.addField("stress", s, "element")
     if Ku is not None:
+        for ri, fr in enumerate(region_surface_forces(sim, u, regions)):     # Simulate_cli.cc:239
+            print("region %d force:" % ri + "".join("\t%g" % x for x in fr))
         w.addField("Ku", Ku if a.fullDegreeFieldOutput else Ku[:len(V)], "node")
     w.close()
     return 0

@@ -85,7 +85,7 @@ def test_bc_json_dispatch():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("deg", [1, 2])
-def test_simulate_cli_cantilever_config1(tmp_path, deg):
+def test_simulate_cli_cantilever_config1(tmp_path, deg, capsys):
     """BASELINE configs[0]: examples/cantilever via the Simulate_cli-compatible driver."""
     V, T = grid.grid_tet_mesh(20, 4, 4)
     mesh = str(tmp_path / "bar_tet_2.msh")
@@ -94,6 +94,10 @@ def test_simulate_cli_cantilever_config1(tmp_path, deg):
     rc = simulate_cli.main([mesh, "-m", os.path.join(GOLD, "B9Creator.material"), "-b", os.path.join(GOLD, "cantilever.bc"),
                             "-d", str(deg), "-o", out, "--rtol", "1e-10"])
     assert rc == 0
+    # reportRegionSurfaceForces (LinearElasticity.hh:1251-1270): the clamped region carries the reaction to the 10 N load
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("region ")]
+    forces = np.array([[float(x) for x in l.split("\t")[1:]] for l in lines])
+    assert len(lines) == 2 and np.abs(forces[1] - [0, 10, 0]).max() < 1e-6 and np.abs(forces[0] + forces[1]).max() < 1e-6
     Vo, To, F = mesh_io.load_msh(out)
     assert np.array_equal(To, T) and set(F) == {"u", "load", "strain", "stress", "Ku"}
     sim = O.Simulator(T, V, deg)
