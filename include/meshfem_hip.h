@@ -121,6 +121,13 @@ mfh_status mfh_mesh_sizes(const mfh_ctx* ctx, int64_t* nElem, int64_t* nNode, in
                           int64_t* nBdryElem, int64_t* nBdryNode, int32_t* nodesPerElem,
                           int32_t* nodesPerBdryElem);
 mfh_status mfh_mesh_get_elem_nodes(const mfh_ctx* ctx, int32_t* out /* nElem x nodesPerElem */);
+/* == Simulator::updateMeshNodePositions (LinearElasticity.hh:1279-1284; FEMMesh::setNodePositions): new vertex positions
+ * [nVert x dim] on the SAME connectivity. Elements are re-embedded at the next assembly / solve; topology, boundary
+ * numbering, DoF map, sparsity pattern, gather lists and matrix-free lists are kept (they depend on connectivity only), so a
+ * shape-optimisation step costs one vertex upload + geometry kernel + numeric assembly instead of a mesh rebuild.
+ * Boundary areas / normals are recomputed; boundary-condition VALUES already stored (tractions of pressure regions) are
+ * not, exactly like the reference. */
+mfh_status mfh_mesh_update_vertices(mfh_ctx* ctx, const double* vertPos);
 mfh_status mfh_mesh_get_node_positions(const mfh_ctx* ctx, double* out /* nNode x dim */);
 mfh_status mfh_mesh_get_boundary_elem_nodes(const mfh_ctx* ctx, int32_t* out /* nBE x npbe, volume node ids */);
 mfh_status mfh_mesh_get_boundary_nodes(const mfh_ctx* ctx, int32_t* out /* nBdryNode volume node ids */);

@@ -33,7 +33,9 @@ class _Mesh:
     def copy(self): return _Mesh(self._V, self._F, self._deg, self._N)
 
     def setVertices(self, V):
-        self.__init__(V, self._F, self._deg, self._N)
+        V = np.ascontiguousarray(np.asarray(V, dtype=np.float64)[:, :self._N])
+        self._h.mesh_update_vertices(V)                      # same connectivity: no topology rebuild
+        self._V = V
 
     def elementVolumes(self):
         P = self._V[self._F]

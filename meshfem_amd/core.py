@@ -96,6 +96,13 @@ class Context:
         self._ck(self.lib.mfh_mesh_get_elem_volumes(self.h, ptr(out)))
         return out
 
+    def mesh_update_vertices(self, verts):
+        """New vertex positions on the same connectivity (Simulator::updateMeshNodePositions): keeps every setup phase."""
+        v = as_f64(np.asarray(verts, dtype=np.float64)[:, :self.dim])
+        if v.shape != (self.n_vert, self.dim):
+            raise ValueError("expected %d x %d vertex positions" % (self.n_vert, self.dim))
+        self._ck(self.lib.mfh_mesh_update_vertices(self.h, ptr(v)))
+
     # ---------------------------------------------------------------- materials
     def material_isotropic(self, E, nu):
         self._ck(self.lib.mfh_material_isotropic(self.h, float(E), float(nu)))

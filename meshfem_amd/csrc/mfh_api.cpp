@@ -1070,6 +1070,32 @@ mfh_status mfh_mesh_set(mfh_ctx *c, int32_t dim, int32_t deg, int64_t nElem, int
     MFH_CATCH(c)
 }
 
+mfh_status mfh_mesh_update_vertices(mfh_ctx *c, const double *vertPos) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && vertPos, MFH_ERR_STATE, "no mesh set");
+    HostMesh &m = c->mesh;
+    require(m.nOwned == m.nNode, MFH_ERR_UNSUPPORTED, "vertex updates on partitioned meshes are not supported");
+    if (m.hasTopology) {
+        m.vertPos.assign(vertPos, vertPos + (size_t)m.nVert * m.dim);
+        compute_node_positions(m);
+        compute_boundary_geometry(m, m.vertPos.data());
+    } else {
+        // mfh_mesh_set: the caller owns the node table; vertPos then holds every node (nVert == nNode)
+        m.vertPos.assign(vertPos, vertPos + (size_t)m.nNode * m.dim);
+        m.nodePos = m.vertPos;
+    }
+    if (!c->hostOnly) {
+        require_device(c);
+        MFH_HIP(hipSetDevice(c->device));
+        c->dVertPos.upload(m.nodePos, c->stream);
+    }
+    // topology, DoF map, sparsity pattern, gather lists and the matrix-free lists only depend on connectivity: kept
+    c->geoValid = false;
+    c->hGeoValid = false;
+    invalidate_matrix(c);
+    MFH_CATCH(c)
+}
+
 mfh_status mfh_mesh_sizes(const mfh_ctx *c, int64_t *nElem, int64_t *nNode, int64_t *nVert, int64_t *nBdryElem, int64_t *nBdryNode,
                           int32_t *npe, int32_t *npbe) {
     if (!c || !c->haveMesh) return MFH_ERR_STATE;

@@ -131,6 +131,7 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
 bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *hostElemVerts, hipStream_t s,
                            std::vector<int32_t> &instEdge, int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst);
 void compute_node_positions(HostMesh &m);
+void compute_boundary_geometry(HostMesh &m, const double *vertPos);
 void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofForNode, int64_t &nDoF,
                       std::vector<uint8_t> &bdryInternal, bool ignoreMismatch = false, int ignoreDimsMask = 0);
 

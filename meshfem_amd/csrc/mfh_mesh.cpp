@@ -167,6 +167,33 @@ static void build_topology_host(int dim, int deg, int64_t nElem, int64_t nVert, 
     }
 }
 
+// boundary element embedding (EmbeddedElement.hh:128-149 tri in 3D, :87-104 edge in 2D) from the vertex positions vp
+void compute_boundary_geometry(HostMesh &m, const double *vp) {
+    const int dim = m.dim;
+    const int64_t nBE = m.nBE();
+    m.bdryVol.resize(nBE);
+    m.bdryNormal.resize((size_t)nBE * dim);
+    for (int64_t b = 0; b < nBE; ++b) {
+        const int32_t *bn = &m.bdryElemNodes[(size_t)b * m.npbe];
+        if (dim == 3) {
+            const double *p0 = vp + 3 * (size_t)bn[0], *p1 = vp + 3 * (size_t)bn[1], *p2 = vp + 3 * (size_t)bn[2];
+            double e1[3], e2[3];
+            for (int a = 0; a < 3; ++a) { e1[a] = p0[a] - p2[a]; e2[a] = p1[a] - p0[a]; }
+            double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+            double dA = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+            m.bdryVol[b] = dA / 2.0;
+            for (int a = 0; a < 3; ++a) m.bdryNormal[(size_t)b * 3 + a] = n[a] / dA;
+        } else {
+            const double *p0 = vp + 2 * (size_t)bn[0], *p1 = vp + 2 * (size_t)bn[1];
+            double e[2] = {p1[0] - p0[0], p1[1] - p0[1]};
+            double L = std::sqrt(e[0] * e[0] + e[1] * e[1]);
+            m.bdryVol[b] = L;
+            m.bdryNormal[(size_t)b * 2 + 0] = -e[1] / L;
+            m.bdryNormal[(size_t)b * 2 + 1] = e[0] / L;
+        }
+    }
+}
+
 void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *ev, const double *vp, bool useDevice,
                     hipStream_t stream) {
     if (dim != 2 && dim != 3) throw Error(MFH_ERR_INVALID, "dim must be 2 or 3");
@@ -262,28 +289,7 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
     }
     m.isBdryNode.assign((size_t)m.nNode, 0);
     for (int32_t n : m.bdryNodes) m.isBdryNode[n] = 1;
-    // boundary element embedding (EmbeddedElement.hh:128-149 tri in 3D, :87-104 edge in 2D)
-    m.bdryVol.resize(nBE);
-    m.bdryNormal.resize((size_t)nBE * dim);
-    for (int64_t b = 0; b < nBE; ++b) {
-        const int32_t *bn = &m.bdryElemNodes[(size_t)b * m.npbe];
-        if (dim == 3) {
-            const double *p0 = vp + 3 * (size_t)bn[0], *p1 = vp + 3 * (size_t)bn[1], *p2 = vp + 3 * (size_t)bn[2];
-            double e1[3], e2[3];
-            for (int a = 0; a < 3; ++a) { e1[a] = p0[a] - p2[a]; e2[a] = p1[a] - p0[a]; }
-            double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
-            double dA = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
-            m.bdryVol[b] = dA / 2.0;
-            for (int a = 0; a < 3; ++a) m.bdryNormal[(size_t)b * 3 + a] = n[a] / dA;
-        } else {
-            const double *p0 = vp + 2 * (size_t)bn[0], *p1 = vp + 2 * (size_t)bn[1];
-            double e[2] = {p1[0] - p0[0], p1[1] - p0[1]};
-            double L = std::sqrt(e[0] * e[0] + e[1] * e[1]);
-            m.bdryVol[b] = L;
-            m.bdryNormal[(size_t)b * 2 + 0] = -e[1] / L;
-            m.bdryNormal[(size_t)b * 2 + 1] = e[0] / L;
-        }
-    }
+    compute_boundary_geometry(m, vp);
     m.bdryInternal.assign((size_t)nBE, 0);
     m.hasTopology = true;
 }

@@ -35,6 +35,9 @@ class Simulator:
     def elements(self):
         return self.ctx.elem_nodes()
 
+    def updateMeshNodePositions(self, vertices):                        # :1279-1284
+        self.ctx.mesh_update_vertices(vertices)
+
     # ---- materials
     def setMaterial(self, tensor):
         self.ctx.material_const(np.asarray(tensor.D if hasattr(tensor, "D") else tensor))

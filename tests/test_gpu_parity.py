@@ -937,3 +937,42 @@ def test_strain_and_stress_interpolant_fields_match_oracle(dim, deg):
     avg = sim.strainField(u).mean(axis=1)
     assert np.abs(avg - sim.averageStrainField(u)).max() < 1e-12 * np.abs(avg).max()
     assert np.array_equal(sim.elementStrain(3, u), sim.strainField(u)[3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deg", [1, 2])
+def test_mesh_update_vertices_equals_a_fresh_context(deg):
+    """Shape-optimisation step: new vertex positions on the same connectivity (mfh_mesh_update_vertices) give the same
+    matrix, load and solution as a context rebuilt from scratch (matrix values to rounding: 1e-13 relative; solution to
+    the PCG tolerance), while the symbolic phase is not repeated."""
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    rng = np.random.default_rng(1)
+    V, T = grid.grid_tet_mesh(6, 4, 4, [0, 0, 0], [1.5, 1, 1])
+    dV = 0.01 * rng.normal(size=V.shape)
+    dV[(np.abs(V[:, 0]) < 1e-12) | (np.abs(V[:, 0] - 1.5) < 1e-12)] = 0.0
+
+    def setup(c):
+        c.material_isotropic(200.0, 0.35)
+        c.bc_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9], [0, 0, 0])
+        c.bc_neumann_box([1.5 - 1e-9, -9, -9], [1.5 + 1e-9, 9, 9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    a = M.Context(0); a.mesh_build(T, V, deg); setup(a)
+    u0 = a.sim_solve(rtol=1e-11)
+    sym_ms = a.timing()["symbolic_ms"]
+    a.mesh_update_vertices(V + dV)
+    u1 = a.sim_solve(rtol=1e-11)
+    assert a.timing()["symbolic_ms"] == sym_ms                       # pattern and gather lists reused
+    b = M.Context(0); b.mesh_build(T, V + dV, deg); setup(b)
+    u2 = b.sim_solve(rtol=1e-11)
+    ia, ja, va = a.export_upper_triplets()
+    ib, jb, vb = b.export_upper_triplets()
+    # same contributions; their summation order inside a block row depends on the (separately built) gather lists
+    assert np.array_equal(ia, ib) and np.array_equal(ja, jb) and np.abs(va - vb).max() < 1e-13 * np.abs(vb).max()
+    assert np.array_equal(a.neumann_load(), b.neumann_load())
+    assert np.linalg.norm(u1 - u2) < 1e-9 * np.linalg.norm(u2) and np.linalg.norm(u1 - u0) > 1e-4 * np.linalg.norm(u0)
+    assert np.array_equal(a.elem_volumes(), b.elem_volumes())
+    # an update that inverts an element is rejected like the Simulator constructor does
+    bad = V.copy(); bad[T[0, 0]] = 2 * V[T[0, 1:]].mean(axis=0) - V[T[0, 0]] + (V[T[0, 1:]].mean(axis=0) - V[T[0, 0]])
+    a.mesh_update_vertices(bad)
+    with pytest.raises(M.MeshFEMHipError, match="negatively oriented"):
+        a.assemble()

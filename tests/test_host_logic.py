@@ -186,3 +186,25 @@ def test_reorder_mesh_is_a_relabelling():
         assert not np.array_equal(T2, T)
     with pytest.raises(ValueError):
         grid.reorder_mesh(V, T, "hilbert")
+
+
+def test_mesh_update_vertices_keeps_topology_and_recomputes_geometry():
+    """mfh_mesh_update_vertices == updateMeshNodePositions (LinearElasticity.hh:1279-1284): node positions (P2 edge
+    midpoints) and boundary areas / normals follow the new vertices; numbering and boundary lists are untouched."""
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    rng = np.random.default_rng(0)
+    V, T = grid.grid_tet_mesh(3, 2, 2, [0, 0, 0], [1, 1, 1])
+    V2 = V + 0.02 * rng.normal(size=V.shape)
+    a, b = M.Context(-1), M.Context(-1)
+    a.mesh_build(T, V, 2)
+    en, ben, bn = a.elem_nodes(), a.boundary_elem_nodes(), a.boundary_nodes()
+    a.mesh_update_vertices(V2)
+    b.mesh_build(T, V2, 2)
+    assert np.array_equal(a.elem_nodes(), en) and np.array_equal(a.boundary_elem_nodes(), ben) and np.array_equal(a.boundary_nodes(), bn)
+    assert np.array_equal(a.node_positions(), b.node_positions())
+    (va, na), (vb, nb) = a.boundary_elem_geometry(), b.boundary_elem_geometry()
+    assert np.array_equal(va, vb) and np.array_equal(na, nb)
+    with pytest.raises(ValueError):
+        a.mesh_update_vertices(V2[:-1])
+    a.close(); b.close()
