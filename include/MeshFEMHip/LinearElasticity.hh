@@ -143,6 +143,10 @@ public:
         check(ctx(), mfh_apply_periodic_conditions(ctx(), epsilon, &nd));
         m_numDoFs = (size_t)nd;
     }
+    // new vertex positions on the same connectivity (:1279-1284): every setup phase is kept, elements are re-embedded
+    void updateMeshNodePositions(const std::vector<std::array<Real, N>> &vertices) {
+        check(ctx(), mfh_mesh_update_vertices(ctx(), &vertices[0][0]));
+    }
     void removePeriodicConditions() {                            // :874-879
         check(ctx(), mfh_dof_map(ctx(), nullptr, 0));
         m_numDoFs = m_numNodes;

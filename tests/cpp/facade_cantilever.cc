@@ -61,6 +61,16 @@ int main(int argc, char **argv) {
                 dev = std::max(dev, std::fabs(m - eps[e2][c2]));
             }
         if (dev > 1e-12) return 5;
+        // uniform dilation by 2 through updateMeshNodePositions. The stored boundary TRACTION (force / old area) is kept, as
+        // in the reference, so the total force grows by 4 while delta ~ F L^3 / (E I) ~ F / length: the deflection doubles
+        auto V2 = V;
+        for (auto &x : V2) for (auto &c2 : x) c2 *= 2.0;
+        sim.updateMeshNodePositions(V2);
+        auto u2 = sim.solve();
+        Real tip2 = 0;
+        for (size_t n = 0; n < u2.size(); ++n) tip2 = std::min(tip2, u2[n][1]);
+        printf("after dilation by 2: tip deflection %.6f (expected %.6f)\n", tip2, 2 * tip);
+        if (std::fabs(tip2 - 2 * tip) > 1e-6 * std::fabs(tip)) return 6;
         // shape derivative under the uniform dilation delta_p = x: K scales with length^(dim-2), so (delta K) u = K u in 3D
         decltype(u) dp(V.size());
         for (size_t n = 0; n < V.size(); ++n) dp[n] = {V[n][0], V[n][1], V[n][2]};
