@@ -96,11 +96,34 @@ def cpu_baseline(deg, cpu_grid):
     return best
 
 
+def hbm_stream_probe(torch, n_doubles=1 << 27, reps=10):
+    """Measured HBM rates of this box (peaks must be checked on the box): copy (1 read + 1 write) and triad
+    (2 reads + 1 write) over 1 GiB vectors with torch's elementwise kernels; context for the roofline fractions, which are
+    still quoted against the 8 TB/s spec."""
+    a = torch.ones(n_doubles, dtype=torch.float64, device="cuda")
+    b = torch.full((n_doubles,), 2.0, dtype=torch.float64, device="cuda")
+    c = torch.empty_like(a)
+    res = {}
+    for name, fn, passes in (("copy", lambda: c.copy_(a), 2), ("triad", lambda: torch.add(a, b, alpha=3.0, out=c), 3)):
+        fn(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        res[name + "_GBs"] = passes * n_doubles * 8 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b, c
+    torch.cuda.empty_cache()
+    res["note"] = "1 GiB f64 vectors, torch elementwise kernels, HIP events"
+    return res
+
+
 def run_single(args):
     import torch
     import meshfem_amd as M
     from meshfem_amd import grid
     torch.cuda.set_device(0)
+    hbm_measured = hbm_stream_probe(torch)
     n, deg = args.grid, args.deg
     t0 = time.time()
     V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
@@ -138,7 +161,7 @@ def run_single(args):
                config=dict(workload="configs[2]: %d^3 grid -> %d P%d tets, isotropic E=200 nu=0.35, Dirichlet x=0, traction x=1"
                                     % (n, nE, deg), elements=nE, nodes=c.n_node, dof=3 * c.n_dof, nnz_blocks=nnzb,
                            parallelism="1 GPU", step="embed + Ke blocks + assembly into block-CSR (gather/owner-computes)"),
-               roofline=roof,
+               roofline=roof, hbm_measured=hbm_measured,
                setup=dict(mesh_gen_s=t_gen, femmesh_build_s=t_build, symbolic_s=t_sym, **c.timing(), **c.symbolic_sizes()))
     # comparison variant: element-major global-atomic scatter (north_star: "colored or atomic ... by evidence")
     try:
