@@ -14,6 +14,7 @@ struct mfh_ctx {
     int xcdSwizzle = 0;              // option "xcd_swizzle": XCD-contiguous work mapping in the chunked kernels (measured SLOWER
                                      // than the round-robin default on MI355X: DESIGN.md section 4.8)
     int debugVariant = 0;            // option "debug_variant": timing experiments of the gather kernel
+    std::vector<double> hLoad, hX;   // host scratch of Simulator::solve (kept between solves)
     bool alwaysReembed = false;      // option "reembed": every mfh_assemble re-runs the embedding kernel
     bool periodicIgnoreMismatch = false;   // option "periodic_ignore_mismatch": PeriodicCondition(..., ignoreMismatch)
     int periodicIgnoreDims = 0;            // option "periodic_ignore_dims": bit a set = dimension a is not periodic
@@ -1833,6 +1834,15 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
     const int64_t n = (int64_t)d * c->nDoF;
     if (c->op != MFH_OP_ELASTICITY) flags = MFH_SOLVE_ALLOW_ILL_POSED;   // rigid motions are an elasticity notion
     const bool periodic = !c->dofForNode.empty();
+    // MFH_SOLVE_TIMING=1: host-side laps of one Simulator::solve on stderr (the device part is in mfh_solve_info)
+    const bool lapTiming = getenv("MFH_SOLVE_TIMING") != nullptr;
+    double lapT = now_ms();
+    auto lap = [&](const char *what) {
+        if (!lapTiming) return;
+        const double t = now_ms();
+        fprintf(stderr, "[mfh solve] %-32s %8.2f ms\n", what, t - lapT);
+        lapT = t;
+    };
     std::vector<int64_t> vars;
     std::vector<double> vals;
     std::vector<std::vector<double>> C;
@@ -1893,28 +1903,36 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
         if (total == 0) throw Error(MFH_ERR_UNSUPPORTED, "Unimplemented");   // needsRotations (:1240): ask for the rigid-motion constraint
     }
     dirichlet_vars(c, vars, vals);
+    lap("constraint rows + Dirichlet vars");
     if (vars != c->fixedVars || vals != c->fixedVals) {   // unchanged constraints keep the preconditioner setup
         clear_fixed(c);
         add_fixed(c, (int64_t)vars.size(), vars.data(), vals.data());
     }
-    std::vector<double> load;
+    lap("fixed-variable mask");
+    // host scratch vectors live in the context: a fresh 178 MB std::vector costs ~30 ms of page faults per solve at config 3
+    std::vector<double> &load = c->hLoad;
     if (!f) {
-        load.assign((size_t)n, 0.0);
+        load.resize((size_t)n);
         if (c->op == MFH_OP_ELASTICITY) {
-            mfh_status st = mfh_neumann_load(c, load.data());
+            mfh_status st = mfh_neumann_load(c, load.data());   // zero-fills first
             if (st != MFH_OK) throw Error(st, c->err);
-        }   // scalar PDE: zero right-hand side, zero-Neumann natural condition (Poisson.hh:100-102)
+        } else std::fill(load.begin(), load.end(), 0.0);   // scalar PDE: zero right-hand side, zero-Neumann natural condition (Poisson.hh:100-102)
         f = load.data();
     }
-    std::vector<double> x((size_t)n);
+    lap("load vector");
+    std::vector<double> &x = c->hX;
+    x.resize((size_t)n);
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
+    lap("assembly + diagonal blocks");
     if (c->precond == MFH_PRECOND_TWO_LEVEL) ensure_twolevel(c);
+    lap("two-level setup");
     mfh_solve_info li{};
     const int k = (int)C.size();
     if (k == 0) {
         solve_one(c, f, x.data(), rtol, maxit, &li);
+        lap("PCG incl. transfers");
     } else {
         // ---- candidate rigid motions (unit-normalised): translations, and rotations unless a periodic map excludes them
         std::vector<std::vector<double>> Zc;
@@ -2001,6 +2019,7 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
     if (info) *info = li;
     for (int64_t i = 0; i < m.nNode; ++i)   // dofToNodeField :664-677
         for (int a = 0; a < d; ++a) uNodes[(size_t)i * d + a] = x[(size_t)dof_of(c, i) * d + a];
+    lap("dofToNodeField");
     if (!li.converged) throw Error(MFH_ERR_NOT_CONVERGED, "PCG did not reach the requested tolerance within maxit iterations");
 }
 
