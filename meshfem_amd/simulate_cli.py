@@ -8,8 +8,8 @@ Materials.cc:178-311) or per-element material fields stored in an .msh (`E`,`nu`
 4 (2D) orthotropic fields, Simulate_cli.cc:116-163), and a `.bc` JSON with box / box% regions of
 type dirichlet[xyz] / force / traction / pressure / delta force (BoundaryConditions.cc:227-389), numeric or
 expression-valued (`"sin(pi * x)"`, tinyexpr grammar: meshfem_amd/expressions.py), `dirichlet nodes` /
-`delta force nodes` lists and `traction | pressure | force elements` lists. Not supported: path / polygon regions,
-`dirichlet elements`, target / contact / fracture conditions.
+`delta force nodes` lists, `traction | pressure | force elements` lists, `dirichlet elements`, and path / polygon
+regions (Geometry.hh:68-191). Not supported: target / contact / fracture conditions (no counterpart in a linear solve).
 Writes the fields u, load, strain, stress, Ku like Simulate_cli.cc:207-242."""
 import argparse
 import json
@@ -77,6 +77,55 @@ def _expression_vector(v, dim):
     return ExpressionVector(comps)
 
 
+class _PathRegion:
+    """PathRegion (Geometry.hh:68-124): points closer than 1e-5 to the polyline. minCorner / maxCorner stay zero like the
+    reference's default Region (they only feed the region_* expression variables)."""
+
+    def __init__(self, pts, dim):
+        self.pts = np.array([_vec(p, dim) for p in pts])
+        self.mn = self.mx = np.zeros(dim)
+
+    def contains(self, P):
+        P = np.asarray(P, dtype=np.float64)
+        inside = np.zeros(len(P), dtype=bool)
+        for e1, e2 in zip(self.pts[:-1], self.pts[1:]):
+            v = e2 - e1
+            t = np.clip(((P - e1) @ v) / (v @ v), 0.0, 1.0)
+            inside |= np.linalg.norm(P - (e1 + t[:, None] * v), axis=1) < 1e-5
+        return inside
+
+
+class _PolygonalRegion:
+    """PolygonalRegion (Geometry.hh:126-191): odd number of crossings of the segment from (min x - 1, 1.90588) to the point
+    with the polygon's edges, with the reference's intersection predicate (eps 1e-10). 2D only, like the reference."""
+
+    def __init__(self, pts, dim):
+        self.pts = np.array([_vec(p, dim)[:2] for p in pts])
+        self.outside = np.array([self.pts[:, 0].min() - 1.0, 1.90588])
+        self.mn = self.mx = np.zeros(dim)
+
+    def contains(self, P):
+        P = np.asarray(P, dtype=np.float64)[:, :2]
+        det = lambda u, v: u[..., 0] * v[..., 1] - u[..., 1] * v[..., 0]
+        count = np.zeros(len(P), dtype=np.int64)
+        c = self.outside
+        for k in range(len(self.pts)):
+            a, b = self.pts[k], self.pts[(k + 1) % len(self.pts)]
+            d = P
+            x, y, z = det(c - a, d - c), det(b - a, a - c), det(b - a, d - c)
+            miss = (np.abs(z) < 1e-10) | (x * z < 0) | (x * z > z * z) | (y * z < 0) | (y * z > z * z)
+            count += ~miss
+        return count % 2 == 1
+
+
+class _BoxRegion:
+    def __init__(self, mn, mx):
+        self.mn, self.mx = np.asarray(mn, dtype=np.float64), np.asarray(mx, dtype=np.float64)
+
+    def contains(self, P):                                   # BBox::containsPoint, inclusive (Geometry.hh:276-279)
+        return np.all((np.asarray(P) >= self.mn) & (np.asarray(P) <= self.mx), axis=1)
+
+
 def _node_values(values, dim):
     """parseNodeConditionValues (BoundaryConditions.cc:62-80): [[value, [node, ...]], ...]."""
     idx, val = [], []
@@ -132,7 +181,7 @@ def apply_boundary_conditions(sim, path):
             t = "dirichlet" + rest[k:]
         if t == "dirichlet" and hasattr(sim, "ctx"):        # region index of the boundary nodes inside (:939-949)
             n_dirichlet_regions += 1
-            if "box" in r or "box%" in r:
+            if ("box" in r or "box%" in r) and not _is_expression_vector(r["value"]):
                 pos_, mn_, mx_ = mesh_geometry()
                 key = "box" if "box" in r else "box%"
                 lo_, hi_ = _vec(r[key]["minCorner"], N), _vec(r[key]["maxCorner"], N)
@@ -171,40 +220,77 @@ def apply_boundary_conditions(sim, path):
                 vals = vals / area[bes].sum()
             sim.applyNeumannElements(bes, vals)
             continue
+        region = None
         if "box" in r:
             mn, mx, rel = _vec(r["box"]["minCorner"], N), _vec(r["box"]["maxCorner"], N), False
         elif "box%" in r:
             mn, mx, rel = _vec(r["box%"]["minCorner"], N), _vec(r["box%"]["maxCorner"], N), True
+        elif "path" in r:
+            region = _PathRegion(r["path"], N)
+        elif "polygon" in r:
+            region = _PolygonalRegion(r["polygon"], N)
+        elif t == "dirichlet elements" and "element vertices" in r:
+            region = "elements"
         else:
-            raise RuntimeError("only box / box% regions, node lists and element lists are supported")
+            raise RuntimeError("regions are box, box%, path, polygon, node lists or element lists")
         val = r["value"]
-        if _is_expression_vector(val) or t == "delta force":
+        needs_host = _is_expression_vector(val) or t == "delta force" or region is not None
+        if needs_host:
             c = sim.ctx
             pos, mesh_min, mesh_max = mesh_geometry()
-        if _is_expression_vector(val):
-            ev = _expression_vector(val, N)
-            amn, amx = (mesh_min + mn * (mesh_max - mesh_min), mesh_min + mx * (mesh_max - mesh_min)) if rel else (mn, mx)
-            inside = lambda P: np.all((P >= amn) & (P <= amx), axis=1)        # BBox::containsPoint, inclusive
-            if t == "dirichlet":                                # :939-949: boundary NODES inside the region
+            if region is None:
+                amn, amx = (mesh_min + mn * (mesh_max - mesh_min), mesh_min + mx * (mesh_max - mesh_min)) if rel else (mn, mx)
+                region = _BoxRegion(amn, amx)
+            ev = _expression_vector(val, N) if _is_expression_vector(val) else None
+
+            def values_at(P, k):                              # numeric value or the expression at the k selected points
+                if ev is None:
+                    return np.tile(_vec(val, N) if not np.isscalar(val) else [float(val)] + [0.0] * (N - 1), (k, 1))
+                return ev.eval(environment(N, mesh_min, mesh_max, region.mn, region.mx, P), k)
+            if t == "dirichlet elements":                   # DirichletElementsCondition (:951-965): all nodes of the listed boundary elements
+                if be_lookup is None:
+                    be_lookup = _boundary_element_lookup(sim)
+                ben_all = c.boundary_elem_nodes()
+                n_dirichlet_regions += 1
+                sel = []
+                for corners in r["element vertices"]:
+                    key = tuple(sorted(int(x) for x in corners))
+                    if len(key) != N:
+                        raise RuntimeError("Error parsing element vertices.")
+                    if key in be_lookup:
+                        sel.extend(int(x) for x in ben_all[be_lookup[key]])
+                sel = np.array(sorted(set(sel)), dtype=np.int64)
+                region = _BoxRegion(np.zeros(N), np.zeros(N))
+                sim.applyDirichletNodes(sel, values_at(pos[sel], len(sel)), comps)
+                for nd in sel:
+                    region_of_node[int(nd)] = n_dirichlet_regions
+            elif t == "dirichlet":                          # :939-949: boundary NODES inside the region
                 bn = c.boundary_nodes()
-                sel = bn[inside(pos[bn])]
-                env = environment(N, mesh_min, mesh_max, amn, amx, pos[sel])
-                sim.applyDirichletNodes(sel, ev.eval(env, len(sel)), comps)
-            elif t == "traction":                               # :897-913: boundary ELEMENTS by vertex barycentre
+                sel = bn[region.contains(pos[bn])]
+                sim.applyDirichletNodes(sel, values_at(pos[sel], len(sel)), comps)
+                for nd in sel:
+                    region_of_node[int(nd)] = n_dirichlet_regions
+            elif t in ("traction", "force", "pressure"):    # :897-933: boundary ELEMENTS by vertex barycentre
+                if ev is not None and t != "traction":
+                    raise RuntimeError("Only region-based traction, dirichlet, target, and delta force support expression vectors")
                 ben = c.boundary_elem_nodes()[:, :N]
                 ctr = pos[ben].mean(axis=1)
-                sel = np.flatnonzero(inside(ctr))
+                sel = np.flatnonzero(region.contains(ctr))
                 if len(sel) == 0:
                     raise RuntimeError("Neumann region unmatched")
-                env = environment(N, mesh_min, mesh_max, amn, amx, ctr[sel])
-                sim.applyNeumannElements(sel, ev.eval(env, len(sel)))
-            elif t == "delta force":                            # :1009-1015: every NODE inside the region
-                sel = np.flatnonzero(inside(pos))
-                env = environment(N, mesh_min, mesh_max, amn, amx, pos[sel])
-                for ni, f in zip(sel, ev.eval(env, len(sel))):
-                    c.bc_delta_force(int(ni), f)
+                area, nrm = c.boundary_elem_geometry()
+                v = values_at(ctr[sel], len(sel))
+                if t == "pressure":
+                    v = -v[:, :1] * nrm[sel]
+                elif t == "force":
+                    v = v / area[sel].sum()
+                sim.applyNeumannElements(sel, v)
+            elif t == "delta force":                        # :1009-1015: every NODE inside the region
+                sel = np.flatnonzero(region.contains(pos))
+                for ni, fv in zip(sel, values_at(pos[sel], len(sel))):
+                    c.bc_delta_force(int(ni), fv)
             else:
-                raise RuntimeError("Only region-based traction, dirichlet, target, and delta force support expression vectors")
+                raise RuntimeError("Invalid type '%s'" % r["type"])
             continue
         if t == "dirichlet":
             sim.applyDirichletBox(mn, mx, _vec(val, N), relative=rel, components=comps)
@@ -214,10 +300,6 @@ def apply_boundary_conditions(sim, path):
             sim.applyNeumannBox(mn, mx, _vec(val, N), kind=L.NEUMANN_TRACTION, relative=rel)
         elif t == "pressure":
             sim.applyNeumannBox(mn, mx, [float(val if np.isscalar(val) else val[0])], kind=L.NEUMANN_PRESSURE, relative=rel)
-        elif t == "delta force":
-            amn, amx = (mesh_min + mn * (mesh_max - mesh_min), mesh_min + mx * (mesh_max - mesh_min)) if rel else (mn, mx)
-            for ni in np.flatnonzero(np.all((pos >= amn) & (pos <= amx), axis=1)):
-                c.bc_delta_force(int(ni), _vec(val, N))
         else:
             raise RuntimeError("Invalid type '%s'" % r["type"])
     return region_of_node

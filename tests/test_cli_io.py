@@ -339,3 +339,55 @@ def test_simulate_cli_full_degree_output_writes_strain_interpolants(tmp_path):
     assert np.abs(corner_mean - F0["strain"][1]).max() < 1e-9 * np.abs(F0["strain"][1]).max()
     assert np.allclose(F1["strain"][1][:, 4], 0.5 * (F1["strain"][1][:, 0] + F1["strain"][1][:, 1]))
     assert np.abs(F1["u"][1][:len(V0)] - F0["u"][1]).max() < 1e-9 * np.abs(F0["u"][1]).max()
+
+
+def test_path_and_polygon_regions_follow_the_reference_predicates():
+    """PathRegion (distance < 1e-5 to the polyline) and PolygonalRegion (odd crossings towards (min x - 1, 1.90588))."""
+    P = np.array([[0.0, 0.0], [0.5, 0.0], [1.0, 0.5], [0.5, 0.5], [0.5, 1e-6], [0.5, 1e-4], [2.0, 2.0]])
+    path = simulate_cli._PathRegion([[0, 0, 0], [1, 0, 0], [1, 1, 0]], 2)
+    assert path.contains(P).tolist() == [True, True, True, False, True, False, False]
+    poly = simulate_cli._PolygonalRegion([[0, 0], [1, 0], [1, 1], [0, 1]], 2)
+    assert poly.contains(np.array([[0.5, 0.5], [0.25, 0.9], [1.5, 0.5], [-0.2, 0.3], [0.5, 1.5]])).tolist() == [True, True, False, False, False]
+    tri = simulate_cli._PolygonalRegion([[0, 0], [2, 0], [0, 2]], 2)
+    assert tri.contains(np.array([[0.5, 0.5], [1.5, 1.5], [0.1, 1.8]])).tolist() == [True, False, True]
+
+
+@pytest.mark.gpu
+def test_path_polygon_and_element_vertex_regions_equal_their_box_forms():
+    """2D plate: clamping the left edge through a path region or through `dirichlet elements`, loading the right edge
+    through a path, and a polygon-region delta force give the same system as the equivalent box / node-list conditions."""
+    from meshfem_amd.linear_elasticity import Simulator
+    V, Q = O.gen_grid_2d(6, 4)
+    V, T = O.quad_tri_subdiv(V, Q)
+    V = V[:, :2] / np.array([6.0, 4.0])
+
+    def solve(regions):
+        sim = Simulator(T, V, 2); sim.rtol = 1e-12
+        sim.setIsotropicMaterial(200.0, 0.3)
+        simulate_cli.apply_boundary_conditions(sim, {"regions": regions})
+        return sim, sim.solve(), sim.neumannLoad()
+    lo = {"minCorner": [-1e-9, -1, 0], "maxCorner": [1e-9, 2, 0]}
+    hi = {"minCorner": [1 - 1e-9, -1, 0], "maxCorner": [1 + 1e-9, 2, 0]}
+    sim, u0, f0 = solve([{"type": "dirichlet", "value": [0, 0, 0], "box": lo}, {"type": "force", "value": [0, -1, 0], "box": hi}])
+    _, u1, f1 = solve([{"type": "dirichlet", "value": [0, 0, 0], "path": [[0, 0, 0], [0, 1, 0]]},
+                       {"type": "force", "value": [0, -1, 0], "path": [[1, 0, 0], [1, 1, 0]]}])
+    assert np.abs(f1 - f0).max() < 1e-14 and np.linalg.norm(u1 - u0) < 1e-10 * np.linalg.norm(u0)
+    pos = sim.nodes()
+    ben = sim.ctx.boundary_elem_nodes()
+    left = [[int(a), int(b)] for a, b in ben[:, :2] if abs(pos[a, 0]) < 1e-12 and abs(pos[b, 0]) < 1e-12]
+    _, u2, f2 = solve([{"type": "dirichlet elements", "value": [0, 0, 0], "element vertices": left},
+                       {"type": "force", "value": [0, -1, 0], "box": hi}])
+    assert np.linalg.norm(u2 - u0) < 1e-10 * np.linalg.norm(u0)
+    # x-only clamp with an expression value through `dirichletx elements`
+    _, u3, _ = solve([{"type": "dirichletx elements", "value": ["0 * y", 0, 0], "element vertices": left},
+                      {"type": "dirichlet", "value": [0, 0, 0], "box": {"minCorner": [-1e-9, -1e-9, 0], "maxCorner": [1e-9, 1e-9, 0]}},
+                      {"type": "force", "value": [1, 0, 0], "box": hi}])
+    assert np.abs(u3[np.abs(pos[:, 0]) < 1e-12, 0]).max() == 0 and np.abs(u3[:, 0]).max() > 0
+    # delta forces on the nodes inside a polygon == the same nodes listed explicitly
+    poly = [[0.4, 0.4], [0.6, 0.4], [0.6, 0.6], [0.4, 0.6]]
+    inside = np.flatnonzero(simulate_cli._PolygonalRegion(poly, 2).contains(pos))
+    assert len(inside) > 0
+    clamp = {"type": "dirichlet", "value": [0, 0, 0], "box": lo}
+    _, u4, f4 = solve([clamp, {"type": "delta force", "value": [0, -0.1, 0], "polygon": poly}])
+    _, u5, f5 = solve([clamp, {"type": "delta force nodes", "values": [[[0, -0.1, 0], inside.tolist()]]}])
+    assert np.array_equal(f4, f5) and np.linalg.norm(u4 - u5) < 1e-12 * np.linalg.norm(u5)
