@@ -347,6 +347,8 @@ mfh_status mfh_matrix_free_info(mfh_ctx* ctx, int32_t* active, int32_t* mode, in
  * "matrix_free_mode" (4 default: cluster variant, forces of 256 consecutive elements summed in LDS | 3 two-pass, forces in
  *   list order | 2 two-pass, forces element-major | 1 per-pair block evaluation), "mf_chunk_rows", "mf_chunk_pairs",
  * "pcg_graph" (1 default: blocks of check_every PCG iterations are replayed from a hipGraph),
+ * "solve_homogeneous" (1: mfh_solve treats the fixed variables as fixed to ZERO whatever values were given -- the
+ *   homogeneous solves K y = C^T of a Schur-complement elimination of constraint rows, SparseMatrices.hh:2572-2590),
  * "periodic_ignore_mismatch" (1: nodes of a periodic face without a partner keep their own DoF, PeriodicCondition's
  *   ignoreMismatch / matchPermittingMismatch; 0 default: a mismatch is an error like PeriodicBoundaryMatcher::match),
  * "periodic_ignore_dims" (bit a set: dimension a is NOT periodic, PeriodicCondition's ignoreDims) -- both read by the next

@@ -117,12 +117,23 @@ class TripletMatrix:
 
 
 class SPSDSystem:
-    """A (constrained) SPSD system that can be solved for several right-hand sides. Constraint rows
-    (`C`, `C_rhs`: the Lagrange-multiplier / UMFPACK branch, SparseMatrices.hh:2572-2590) are not supported."""
+    """A (constrained) SPSD system that can be solved for several right-hand sides. Constraint rows `C x = C_rhs`
+    (the Lagrange-multiplier branch the reference hands to UMFPACK, SparseMatrices.hh:2340-2348,2572-2590) are eliminated
+    with a Schur complement around SPD solves: x = x0 - Y lambda with K x0 = b, K Y = C^T, (C Y) lambda = C x0 - C_rhs,
+    i.e. k + 1 PCG solves for k rows (the second and later right-hand sides reuse Y). K must be non-singular on the free
+    variables; singular elasticity systems with rigid-motion rows are handled at the Simulator level instead."""
 
     def __init__(self, K, C=None, C_rhs=None, device=0):
-        if C is not None or C_rhs is not None:
-            raise RuntimeError("constraint rows (non-SPD KKT systems) are not supported on the GPU path")
+        self._C = self._Crhs = self._Y = None
+        if C is not None:
+            if C.n != K.n:
+                raise RuntimeError("Constraint matrix has the wrong number of columns")
+            ci, cj, cv = C.arrays()
+            self._C = np.zeros((C.m, C.n))
+            np.add.at(self._C, (ci.astype(np.int64), cj.astype(np.int64)), cv)
+            self._Crhs = np.zeros(C.m) if C_rhs is None else np.asarray(C_rhs, dtype=np.float64).copy()
+            if self._Crhs.shape != (C.m,):
+                raise RuntimeError("Constraint rhs has the wrong size")
         if K.m != K.n:
             raise RuntimeError("K must be square")
         i, j, v = K.arrays()
@@ -142,6 +153,8 @@ class SPSDSystem:
             raise RuntimeError("Fixed variable index and value arrays must be the same size.")
         if len(fixedVars):
             self.ctx.fix_variables(np.asarray(fixedVars, dtype=np.int64), np.asarray(fixedVarValues, dtype=np.float64))
+            self._fixed = np.concatenate([getattr(self, "_fixed", np.zeros(0, np.int64)), np.asarray(fixedVars, dtype=np.int64)])
+            self._Y = None
 
     def setForceSupernodal(self, force):
         pass                                               # a CHOLMOD tuning knob; meaningless for PCG
@@ -152,4 +165,19 @@ class SPSDSystem:
             raise RuntimeError("Bad rhs size")
         x = self.ctx.solve(b, rtol=self.rtol, maxit=self.maxit)
         self.info = self.ctx.last_info
-        return x
+        if self._C is None:
+            return x
+        Cf = self._C.copy()
+        Cf[:, getattr(self, "_fixed", np.zeros(0, np.int64))] = 0.0       # rows restricted to the free variables
+        if self._Y is None:                                               # K Y = C^T with the fixed variables at zero
+            self.ctx.set_option("solve_homogeneous", 1)
+            try:
+                self._Y = np.stack([self.ctx.solve(Cf[r], rtol=self.rtol, maxit=self.maxit) for r in range(len(Cf))])
+            finally:
+                self.ctx.set_option("solve_homogeneous", 0)
+        S = Cf @ self._Y.T
+        try:
+            lam = np.linalg.solve(S, self._C @ x - self._Crhs)
+        except np.linalg.LinAlgError:
+            raise RuntimeError("constraint rows are linearly dependent on the free variables")
+        return x - lam @ self._Y

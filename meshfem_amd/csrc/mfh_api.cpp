@@ -2396,6 +2396,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "keep_host_symbolic") { c->keepHostSymbolic = value != 0; }
     else if (k2 == "reembed") { c->alwaysReembed = value != 0; }
     else if (k2 == "periodic_ignore_mismatch") { c->periodicIgnoreMismatch = value != 0; }
+    else if (k2 == "solve_homogeneous") { c->solveHomogeneous = value != 0; }
     else if (k2 == "periodic_ignore_dims") { c->periodicIgnoreDims = (int)value & 7; }
     else if (k2 == "agg_nodes") { c->aggNodes = (int)value; c->tl.valid = false; }
     else if (k2 == "topology_device") { c->topologyDevice = value != 0; }

@@ -122,7 +122,27 @@ def test_spsd_system_on_caller_matrix():
     with pytest.raises(Exception):
         sysm.fixVariables([3], [1.0])                    # "Variable already fixed."
     with pytest.raises(RuntimeError):
-        csm.SPSDSystem(K, C=K)
+        csm.SPSDSystem(K, C=csm.TripletMatrix(2, n + 1))   # wrong number of columns
+    # constraint rows C x = C_rhs (SPSDSystem(K, C, C_rhs), the reference's UMFPACK / KKT branch): k + 1 SPD solves;
+    # checked against a dense solve of [[K, C^T], [C, 0]] with the fixed variables eliminated
+    Cd = np.zeros((3, n))
+    Cd[0, :] = 1.0                                         # mean value
+    Cd[1, ::7] = rng.standard_normal(len(Cd[1, ::7]))
+    Cd[2, 5], Cd[2, 77] = 1.0, -2.0                        # touches a fixed variable: its value moves to the right-hand side
+    crhs = np.array([0.3, -1.0, 0.5])
+    C = csm.TripletMatrix(3, n)
+    for r, cidx in zip(*np.nonzero(Cd)):
+        C.addNZ(int(r), int(cidx), float(Cd[r, cidx]))
+    sysc = csm.SPSDSystem(K, C, crhs)
+    sysc.fixVariables(fv.tolist(), fx.tolist())
+    Ad = Afull.toarray()
+    kkt = np.block([[Ad[np.ix_(free, free)], Cd[:, free].T], [Cd[:, free], np.zeros((3, 3))]])
+    for rhs_vec in (b, rng.standard_normal(n)):
+        xc = sysc.solve(rhs_vec)
+        sol = np.linalg.solve(kkt, np.concatenate([rhs_vec[free] - Ad[np.ix_(free, fv)] @ fx, crhs - Cd[:, fv] @ fx]))
+        ref = np.zeros(n); ref[fv] = fx; ref[free] = sol[:len(free)]
+        assert np.array_equal(xc[fv], fx) and np.abs(Cd @ xc - crhs).max() < 1e-7
+        assert np.linalg.norm(xc - ref) < 1e-7 * np.linalg.norm(ref)
 
 
 @pytest.mark.gpu
