@@ -826,6 +826,9 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
             }
         }
         li.used_graph = exec ? 1 : 0;
+        double bestRR = 1e300;
+        int itBest = 0;
+        const int stagnationWindow = std::max(5000, 40 * c->checkEvery);
         while (!done && it < maxit) {
             if (exec) {
                 MFH_HIP(hipGraphLaunch(exec, s));
@@ -842,6 +845,17 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
                 const double rr = hs[(size_t)(k2 - lastChecked) * 4 + 2];
                 if (rr <= stopv) { done = true; itDone = k2; rrFinal = rr; break; }
                 if (!(rr == rr)) throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (NaN residual): K is not SPD on the free variables");
+                // CHOLMOD reports "not positive definite" at once; the iterative counterpart: negative curvature, or a
+                // residual whose best value has not improved by 10 % for thousands of iterations (a singular system with
+                // an inconsistent right-hand side: missing boundary conditions, unbalanced loads on a free body)
+                const double pAp = hs[(size_t)(k2 - lastChecked) * 4 + 1];
+                if (k2 < it && pAp < 0.0)
+                    throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (p.Kp < 0): K is not positive definite on the free variables");
+                if (rr < 0.9 * bestRR) { bestRR = rr; itBest = k2; }
+                else if (k2 - itBest > stagnationWindow)
+                    throw Error(MFH_ERR_NOT_CONVERGED, "PCG stagnated (no progress of the residual for " + std::to_string(stagnationWindow) +
+                                                           " iterations): the system is singular with an inconsistent right-hand side "
+                                                           "(missing boundary conditions?) or too ill-conditioned for this preconditioner");
             }
             if (!done) { itDone = std::min(it, maxit); rrFinal = hs[(size_t)(itDone - lastChecked) * 4 + 2]; }
             lastChecked = it;

@@ -976,3 +976,24 @@ def test_mesh_update_vertices_equals_a_fresh_context(deg):
     a.mesh_update_vertices(bad)
     with pytest.raises(M.MeshFEMHipError, match="negatively oriented"):
         a.assemble()
+
+
+@pytest.mark.gpu
+def test_singular_inconsistent_system_is_reported_not_iterated_to_maxit():
+    """A free body with an unbalanced load and no constraints (allow-ill-posed path): CHOLMOD would refuse the matrix; the
+    PCG must not grind through maxit = 100 000 iterations but report stagnation / breakdown."""
+    import time
+    import meshfem_amd as M
+    V, T = O.grid_tet_mesh(3, 2, 2)
+    c = M.Context(0)
+    c.mesh_build(T, V, 1)
+    c.material_isotropic(200.0, 0.35)
+    c.bc_neumann_box([3 - 1e-9, -9, -9], [3 + 1e-9, 9, 9], [1.0, 0.5, 0.0], kind=M.NEUMANN_TRACTION)
+    t0 = time.time()
+    with pytest.raises(M.MeshFEMHipError, match="stagnated|breakdown|not positive definite"):
+        c.sim_solve_constrained(flags=M.SOLVE_ALLOW_ILL_POSED, maxit=100000)
+    assert time.time() - t0 < 30
+    # the same body with the rigid motions constrained solves fine afterwards on the same context
+    c.bc_neumann_box([-1e-9, -9, -9], [1e-9, 9, 9], [-1.0, -0.5, 0.0], kind=M.NEUMANN_TRACTION)
+    u = c.sim_solve_constrained(flags=M.SOLVE_NO_RIGID_MOTION)
+    assert np.isfinite(u).all() and c.last_info["converged"]
