@@ -45,7 +45,7 @@ def build_lib(force=False, verbose=True):
     for p, cmd in procs:
         if p.wait() != 0:
             raise RuntimeError("compile failed: " + " ".join(cmd))
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread", "-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -4,8 +4,37 @@
 #include <cmath>
 #include <map>
 #include <mutex>
+#include <dlfcn.h>
 
 using namespace mfh;
+
+// ---- optional roctx ranges (see mfh_internal.hh)
+namespace {
+struct RoctxApi {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    RoctxApi() {
+        const char *en = getenv("MFH_ROCTX");
+        if (!en || en[0] == '0') return;
+        for (const char *lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "/opt/rocm/lib/libroctx64.so"}) {
+            if (void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr; pop = nullptr;
+            }
+        }
+    }
+};
+RoctxApi &roctx_api() { static RoctxApi a; return a; }
+}   // namespace
+mfh::RoctxRange::RoctxRange(const char *name) {
+    RoctxApi &a = roctx_api();
+    if (a.push) { a.push(name); active = true; }
+}
+mfh::RoctxRange::~RoctxRange() {
+    if (active) roctx_api().pop();
+}
 
 struct mfh_ctx {
     int device = 0;
@@ -313,6 +342,7 @@ void ensure_host_colidx(mfh_ctx *c) {
 void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
     require(c->haveMesh, MFH_ERR_STATE, "no mesh set");
     if (c->symValid && (!wantScatter || c->symHasScatter)) return;
+    RoctxRange range("Compress Matrix");   // sumRepeated's sort / merge, hoisted into the once-per-mesh symbolic phase
     double t0 = now_ms();
     if (!c->hostOnly && c->symbolicDevice && c->contribOrder == 1) {
         // ---- device path: two radix sorts (mfh_symbolic_gpu.hip)
@@ -396,6 +426,7 @@ void ensure_assembled(mfh_ctx *c) {
     require(!c->external, MFH_ERR_STATE, "no matrix set");
     ensure_geometry(c);
     ensure_symbolic(c, false);
+    RoctxRange range("Assemble System");
     EventTimer t(c->stream);
     run_assembly(c, MFH_ASSEMBLE_GATHER);
     c->timing.assemble_ms = t.stop();
@@ -740,6 +771,7 @@ double device_dot(mfh_ctx *c, int64_t n, const double *a, const double *b) {
 
 // PCG on the free variables of K (SPSDSystem::solve with CHOLMOD replaced).
 void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info) {
+    RoctxRange range("Elasticity Solve");
     const int d = c->bs();
     const int64_t n = (int64_t)d * c->nDoF;
     require(c->sym.nRows == c->sym.nCols, MFH_ERR_STATE,
@@ -1307,8 +1339,9 @@ mfh_status mfh_assemble(mfh_ctx *c, int32_t mode) {
     require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
     require(mode == MFH_ASSEMBLE_GATHER || mode == MFH_ASSEMBLE_ATOMIC, MFH_ERR_INVALID, "bad assembly mode");
     if (c->alwaysReembed) { c->geoValid = false; c->hGeoValid = false; }
-    ensure_geometry(c);
     ensure_symbolic(c, mode == MFH_ASSEMBLE_ATOMIC);
+    RoctxRange range("Assemble System");
+    ensure_geometry(c);
     EventTimer t(c->stream);
     run_assembly(c, mode);
     c->timing.assemble_ms = t.stop();

@@ -35,6 +35,18 @@ inline double now_ms() {
     return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
 }
 
+// Named ranges for rocprofv3 --marker-trace under the reference's timer-section names (GlobalBenchmark.hh:14-34:
+// "Assemble System", "Compress Matrix", "Elasticity Solve"). libroctx is looked up with dlopen the first time a range is
+// opened and only if MFH_ROCTX=1, so the library has no link-time dependency on the profiler.
+struct RoctxRange {
+    explicit RoctxRange(const char *name);
+    ~RoctxRange();
+    RoctxRange(const RoctxRange &) = delete;
+    RoctxRange &operator=(const RoctxRange &) = delete;
+private:
+    bool active = false;
+};
+
 // Simple parallel-for over [0, n) in contiguous ranges (host setup code only).
 void parallel_ranges(int64_t n, const std::function<void(int64_t, int64_t, int)> &f, int64_t minGrain = 4096);
 int  host_threads();
