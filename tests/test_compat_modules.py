@@ -170,3 +170,51 @@ def test_periodic_homogenization_module(name, dim, deg):
     assert np.abs(avg - (vol[:, None] * su).sum(axis=0) / vol.sum()).max() < 1e-10
     u2, _ = cph.probe(m, Cbase, ms)
     assert np.abs(u2 - u).max() < 1e-7 * np.abs(u).max()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,deg", [(3, 1), (3, 2), (2, 2)])
+def test_differential_operators_module(dim, deg):
+    """`differential_operators.{laplacian, mass, mass_elasticity, bilaplacian, gradient}` (differential_operators.cc:21-90)
+    against the oracle's Laplacian.hh / MassMatrix.hh restatement, incl. forceP1 on a quadratic mesh (vertex operators)."""
+    import differential_operators as cdo
+    import scipy.sparse as sp
+    if dim == 3:
+        V, T = O.grid_tet_mesh(2, 2, 1)
+    else:
+        V, Q = O.gen_grid_2d(3, 2)
+        V, T = O.quad_tri_subdiv(V, Q)
+        V = V[:, :2]
+    m = cmesh.Mesh(V, T, degree=deg, embeddingDimension=dim)
+
+    def dense(tm):
+        return sp.coo_matrix((tm.arrays()[2], (tm.arrays()[0].astype(np.int64), tm.arrays()[1].astype(np.int64))), shape=(tm.m, tm.n)).toarray()
+
+    def oracle_dense(tr, full=True):
+        A = sp.coo_matrix((tr.v, (tr.i, tr.j)), shape=(tr.m, tr.n)).toarray()
+        return A + np.triu(A, 1).T if full else A
+    for forceP1 in (False, True):
+        om = O.FEMMesh(T, V, 1 if forceP1 else deg)
+        Lr, Mr = oracle_dense(O.laplacian_triplets(om)), oracle_dense(O.mass_triplets(om))
+        Lg = cdo.laplacian(m, forceP1=forceP1)
+        assert Lg.m == om.num_nodes and np.abs(dense(Lg) - Lr).max() < 1e-12 * np.abs(Lr).max()
+        Lu = cdo.laplacian(m, forceP1=forceP1, upperTriOnly=True)
+        assert Lu.symmetry_mode == "UPPER_TRIANGLE" and np.abs(dense(Lu) - np.triu(Lr)).max() < 1e-12 * np.abs(Lr).max()
+        assert np.abs(dense(cdo.mass(m, forceP1=forceP1)) - Mr).max() < 1e-13 * np.abs(Mr).max()
+        Ml = cdo.mass(m, lumped=True, forceP1=forceP1)
+        assert np.abs(dense(Ml) - np.diag(Mr.sum(axis=1))).max() < 1e-13 * np.abs(Mr).max()
+        Me = dense(cdo.mass_elasticity(m, forceP1=forceP1))
+        assert Me.shape == (dim * om.num_nodes,) * 2
+        for c in range(dim):
+            assert np.abs(Me[c::dim, c::dim] - Mr).max() < 1e-13 * np.abs(Mr).max()
+        assert np.abs(Me[0::dim, 1::dim]).max() == 0
+        if np.abs(Mr.sum(axis=1)).min() > 1e-12:          # P2 triangles: int phi_vertex = 0, the lumped mass is singular
+            B = cdo.bilaplacian(m, forceP1=forceP1).toarray()
+            Br = Lr @ np.diag(1.0 / Mr.sum(axis=1)) @ Lr
+            assert np.abs(B - Br).max() < 1e-11 * np.abs(Br).max()
+    if deg == 1:
+        g = cdo.gradient(m, V @ np.arange(1.0, dim + 1))               # linear field: constant gradient
+        assert np.abs(g - np.arange(1.0, dim + 1)).max() < 1e-12
+    else:
+        with pytest.raises(RuntimeError, match="unimplemented"):
+            cdo.gradient(m, np.zeros(m.numNodes()))
