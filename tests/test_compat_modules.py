@@ -218,3 +218,17 @@ def test_differential_operators_module(dim, deg):
     else:
         with pytest.raises(RuntimeError, match="unimplemented"):
             cdo.gradient(m, np.zeros(m.numNodes()))
+
+
+def test_benchmark_module_timers():
+    import benchmark as cb
+    cb.reset()
+    cb.start_timer_section("Simulation"); cb.start_timer("Assemble System"); cb.stop_timer("Assemble System")
+    cb.stop_timer_section("Simulation")
+    d = cb.to_dict()
+    assert set(d) == {"Simulation"} and "Assemble System" in d["Simulation"][1] and d["Simulation"][0] >= d["Simulation"][1]["Assemble System"] >= 0
+    with pytest.raises(RuntimeError):
+        cb.stop_timer_section("Simulation")
+    import io
+    buf = io.StringIO(); cb.report(out=buf)
+    assert "Simulation" in buf.getvalue() and "Assemble System" in buf.getvalue()
