@@ -181,3 +181,81 @@ class SPSDSystem:
         except np.linalg.LinAlgError:
             raise RuntimeError("constraint rows are linearly dependent on the free variables")
         return x - lam @ self._Y
+
+
+_SYM_CODES = {"NONE": 0, "UPPER_TRIANGLE": 1, "LOWER_TRIANGLE": 2}      # SparseMatrices.hh SymmetryMode
+
+
+class SuiteSparseMatrix:
+    """Sparse matrix in compressed-column format (CSCMatrix<SuiteSparse_long, double>, SparseMatrices.hh:1300-1790;
+    binding sparse_matrices.cc:67-141): m, n, nz, Ap, Ai, Ax, symmetry_mode. `solve` hands an UPPER_TRIANGLE matrix to the
+    HIP PCG (the binding builds a CholmodFactorizer); plain Python attributes, so instances pickle like the binding's."""
+
+    def __init__(self, arg=None):
+        self.m = self.n = self.nz = 0
+        self.Ap, self.Ai, self.Ax = np.zeros(1, np.int64), np.zeros(0, np.int64), np.zeros(0)
+        self.symmetry_mode = "NONE"
+        if isinstance(arg, str):
+            self.readBinary(arg)
+        elif arg is not None:
+            self.setFromTMatrix(arg)
+
+    def setFromTMatrix(self, tm):                            # CSCMatrix::setFromTMatrix (:422-447): sorted, repeats summed
+        import scipy.sparse as sp
+        i, j, v = tm.arrays()
+        A = sp.coo_matrix((v, (i.astype(np.int64), j.astype(np.int64))), shape=(tm.m, tm.n)).tocsc()
+        A.sum_duplicates(); A.sort_indices()
+        self.m, self.n, self.nz = tm.m, tm.n, int(A.nnz)
+        self.Ap, self.Ai, self.Ax = A.indptr.astype(np.int64), A.indices.astype(np.int64), A.data.astype(np.float64)
+        self.symmetry_mode = tm.symmetry_mode
+
+    def getTripletMatrix(self):
+        cols = np.repeat(np.arange(self.n, dtype=np.int64), np.diff(self.Ap))
+        return TripletMatrix.fromArrays(self.m, self.n, self.Ai, cols, self.Ax, symmetry_mode=self.symmetry_mode)
+
+    def toSciPy(self):
+        import scipy.sparse as sp
+        return sp.csc_matrix((self.Ax, self.Ai, self.Ap), shape=(self.m, self.n))
+
+    def setZero(self): self.Ax[:] = 0.0
+    def fill(self, v): self.Ax[:] = v
+    def trace(self): return float(self.toSciPy().diagonal().sum())
+
+    def apply(self, vec, transpose=False):                   # symmetric storage expands like CSCMatrix::apply
+        x = np.asarray(vec, dtype=np.float64)
+        A = self.toSciPy()
+        if self.symmetry_mode != "NONE":
+            import scipy.sparse as sp
+            A = A + (sp.triu(A, 1) if self.symmetry_mode == "UPPER_TRIANGLE" else sp.tril(A, -1)).T
+        return (A.T if transpose else A) @ x
+
+    def solve(self, b, device=0, rtol=1e-10, maxit=100000):
+        if self.symmetry_mode != "UPPER_TRIANGLE":
+            raise RuntimeError("Only symmetric matrices are currently supported")
+        b = np.asarray(b, dtype=np.float64)
+        c = Context(device)
+        tm = self.getTripletMatrix()
+        i, j, v = tm.arrays()
+        c.matrix_set_upper_triplets(self.m, i, j, v)
+        x = c.solve(b, rtol=rtol, maxit=maxit)
+        c.close()
+        return x
+
+    def dumpBinary(self, path):                              # SparseMatrices.hh:1448-1471
+        with open(path, "wb") as f:
+            np.array([self.m, self.n, self.nz], dtype=np.int64).tofile(f)
+            np.array([_SYM_CODES[self.symmetry_mode]], dtype=np.uint32).tofile(f)
+            np.asarray(self.Ap, dtype=np.int64).tofile(f); np.asarray(self.Ai, dtype=np.int64).tofile(f)
+            np.asarray(self.Ax, dtype=np.float64).tofile(f)
+
+    def readBinary(self, path):                              # :1473-1495
+        with open(path, "rb") as f:
+            self.m, self.n, self.nz = (int(x) for x in np.fromfile(f, dtype=np.int64, count=3))
+            code = int(np.fromfile(f, dtype=np.uint32, count=1)[0])
+            inv = {v: k for k, v in _SYM_CODES.items()}
+            if code not in inv:
+                raise RuntimeError("Invalid symmetry_mode")
+            self.symmetry_mode = inv[code]
+            self.Ap = np.fromfile(f, dtype=np.int64, count=self.n + 1)
+            self.Ai = np.fromfile(f, dtype=np.int64, count=self.nz)
+            self.Ax = np.fromfile(f, dtype=np.float64, count=self.nz)

@@ -232,3 +232,50 @@ def test_benchmark_module_timers():
     import io
     buf = io.StringIO(); cb.report(out=buf)
     assert "Simulation" in buf.getvalue() and "Assemble System" in buf.getvalue()
+
+
+def _spd_triplets(n, seed=2):
+    import scipy.sparse as sp
+    B = sp.random(n, n, density=0.02, random_state=seed, format="csr")
+    A = (B @ B.T + sp.diags(np.full(n, 1.0))).tocoo()
+    K = csm.TripletMatrix(n, n)
+    for i, j, v in zip(A.row, A.col, A.data):
+        if i <= j:
+            K.addNZ(int(i), int(j), float(v))
+    K.symmetry_mode = "UPPER_TRIANGLE"
+    return K, A.tocsr()
+
+
+def test_suite_sparse_matrix_container(tmp_path):
+    """SuiteSparseMatrix (sparse_matrices.cc:67-141): CSC from triplets, apply with symmetric storage, trace, binary dump
+    round trip (SparseMatrices.hh:1448-1495), pickling."""
+    import pickle
+    K, A = _spd_triplets(60)
+    S = csm.SuiteSparseMatrix(K)
+    assert (S.m, S.n) == (60, 60) and S.nz == len(S.Ax) == S.Ap[-1] and S.symmetry_mode == "UPPER_TRIANGLE"
+    x = np.random.default_rng(0).standard_normal(60)
+    assert np.abs(S.apply(x) - A @ x).max() < 1e-12 and abs(S.trace() - A.diagonal().sum()) < 1e-12
+    p = str(tmp_path / "S.bin")
+    S.dumpBinary(p)
+    R = csm.SuiteSparseMatrix(p)
+    for a, b in ((R.Ap, S.Ap), (R.Ai, S.Ai), (R.Ax, S.Ax)):
+        assert np.array_equal(a, b)
+    assert R.symmetry_mode == "UPPER_TRIANGLE"
+    raw = np.fromfile(p, dtype=np.int64, count=3)
+    assert raw.tolist() == [60, 60, S.nz] and os.path.getsize(p) == 3 * 8 + 4 + 61 * 8 + S.nz * 16
+    P = pickle.loads(pickle.dumps(S))
+    assert np.array_equal(P.Ax, S.Ax) and P.symmetry_mode == S.symmetry_mode
+    T = S.getTripletMatrix()
+    assert T.nnz == S.nz and np.abs(csm.SuiteSparseMatrix(T).toSciPy() - S.toSciPy()).max() == 0
+    full = csm.SuiteSparseMatrix(K); full.symmetry_mode = "NONE"
+    with pytest.raises(RuntimeError, match="Only symmetric"):
+        full.solve(x)
+
+
+@pytest.mark.gpu
+def test_suite_sparse_matrix_solve():
+    import scipy.sparse.linalg as spl
+    K, A = _spd_triplets(300, seed=5)
+    b = np.random.default_rng(1).standard_normal(300)
+    x = csm.SuiteSparseMatrix(K).solve(b)
+    assert np.linalg.norm(x - spl.spsolve(A.tocsc(), b)) < 1e-8 * np.linalg.norm(x)
