@@ -80,7 +80,7 @@ def cpu_baseline(deg, cpu_grid):
     D[np.arange(3), np.arange(3)] = lam + 2 * mu
     D[np.arange(3, 6), np.arange(3, 6)] = mu
     best = None
-    sizes = [cpu_grid] if cpu_grid else [12, 24]
+    sizes = [cpu_grid] if cpu_grid else [12, 24, 32]      # the last size that starts is reported: ~10 s of CPU work
     for n in sizes:
         V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
         h = M.Context(-1)                      # host-only: node numbering only
