@@ -1,0 +1,213 @@
+// Context object behind the opaque mfh_ctx handle and the internal helpers shared by the translation units that implement
+// the C ABI (mfh_api.cpp: context, mesh, materials, assembly, solver, device-pointer building blocks, measurement;
+// mfh_simulator.cpp: boundary conditions, loads, Simulator-level solve with constraint rows, strain / stress fields,
+// shape derivatives).
+#pragma once
+#include "mfh_internal.hh"
+#include <cmath>
+#include <map>
+#include <mutex>
+
+using namespace mfh;   // private header of the library's own translation units
+
+struct mfh_ctx {
+    int device = 0;
+    bool hostOnly = false;            // device == -1: mesh/symbolic host logic only (CPU tests)
+    bool keepHostSymbolic = false;
+    int xcdSwizzle = 0;              // option "xcd_swizzle": XCD-contiguous work mapping in the chunked kernels (measured SLOWER
+                                     // than the round-robin default on MI355X: DESIGN.md section 4.8)
+    int debugVariant = 0;            // option "debug_variant": timing experiments of the gather kernel
+    std::vector<double> hLoad, hX;   // host scratch of Simulator::solve (kept between solves)
+    bool alwaysReembed = false;      // option "reembed": every mfh_assemble re-runs the embedding kernel
+    bool periodicIgnoreMismatch = false;   // option "periodic_ignore_mismatch": PeriodicCondition(..., ignoreMismatch)
+    int periodicIgnoreDims = 0;            // option "periodic_ignore_dims": bit a set = dimension a is not periodic
+    hipStream_t stream = nullptr;
+    bool ownStream = true;
+    std::string err;
+
+    // ---- mesh
+    HostMesh mesh;
+    bool haveMesh = false;
+    bool external = false;            // K supplied by the caller (mfh_matrix_set_upper_triplets): no mesh, scalar variables
+    DBuf<int32_t> dElemNodes;
+    DBuf<double> dVertPos;
+
+    // ---- material
+    int matMode = 0;                  // see k_geometry
+    int matKind = MAT_ISO;
+    int op = MFH_OP_ELASTICITY;       // operator assembled into K: elasticity (dim x dim blocks) or scalar Laplacian / mass
+    std::vector<double> matParams;    // host copy in the layout k_geometry expects
+    DBuf<double> dMatParams;
+    DBuf<double> dGeo;
+    DBuf<int> dNeg;
+    int geoStride = GEO_ISO_STRIDE;
+    bool geoValid = false;
+    std::vector<double> hGeo;         // lazily downloaded copy (loads / post-processing)
+    bool hGeoValid = false;
+
+    // ---- DoF map
+    std::vector<int32_t> dofForNode;  // empty = identity
+    DBuf<int32_t> dDofForNode;
+    bool dofUploaded = false;
+    int64_t nDoF = 0;
+
+    // ---- symbolic
+    Symbolic sym;
+    bool symValid = false;
+    bool symHasScatter = false;
+    DBuf<int32_t> dRowPtr, dColIdx, dChunkRow, dSpmvChunkRow, dScatter;
+    DBuf<int64_t> dContribPtr;
+    DBuf<uint32_t> dContribCode;
+    DBuf<uint16_t> dContribSlot;
+    ShapeTables tables;
+    DBuf<double> dPairTable, dMassTable;
+    // matrix-free operator (option "matrix_free"): (element, node) pair lists by row chunks
+    MfLists mf;
+    bool mfValid = false;
+    int matrixFree = -1;              // option "matrix_free": 1 on, 0 off, -1 auto (quadratic elasticity: 2x faster than the assembled SpMV)
+    bool use_mf() const {
+        if (external || !haveMesh || hostOnly) return false;
+        return matrixFree == 1 || (matrixFree < 0 && mesh.deg == 2 && op == MFH_OP_ELASTICITY);
+    }
+    DBuf<int32_t> dMfChunkRow;
+    DBuf<int64_t> dMfPairPtr;
+    DBuf<uint32_t> dMfPairCode, dMfPairPos;
+    DBuf<uint16_t> dMfPairRow;
+    MfClusterLists mfc;               // cluster variant (matrix_free_mode 4)
+    MfClusterDev mfcDev;
+    bool mfcValid = false;
+    int mfBlockElems = 0;             // option "mf_block_elems": elements per block of the cluster variant (0 = 256)
+    DBuf<double> dMfSig;              // two-pass operator: per-element nodal forces
+    int mfChunkRows = 256, mfChunkPairs = 2048;   // options "mf_chunk_rows" / "mf_chunk_pairs"
+    bool mfClusterUnfit = false;      // element order without locality on this mesh: cluster variant not applicable
+    int mfModeEff() const { return (mfMode == 4 && mfClusterUnfit) ? 3 : mfMode; }
+    int mfMode = 4;                   // option "matrix_free_mode": 4 = cluster variant (default: forces of 256 consecutive elements
+                                      // summed in LDS, interface partials only in HBM); 3 = two-pass, forces in list order;
+                                      // 2 = two-pass, forces element-major; 1 = per-pair block evaluation (k_spmv_mf)
+
+    // ---- numeric
+    DBuf<double> dVals;
+    bool assembled = false;
+
+    // ---- constraints (SPSDSystem state)
+    std::vector<int64_t> fixedVars;
+    std::vector<double> fixedVals;
+    std::vector<uint8_t> hFixedMask;
+    DBuf<uint8_t> dFixedMask;
+    DBuf<int64_t> dFixedIdx;
+    DBuf<double> dFixedVal;
+    bool fixedUploaded = false;
+    bool anyFixedNonzero = false;
+    bool useGraph = true;             // option "pcg_graph": capture blocks of check_every PCG iterations in a hipGraph
+    bool tlSuppress = false;          // solve_one: block-Jacobi for this solve (K singular on the free variables)
+    bool solveHomogeneous = false;    // solve_one: treat the fixed values as 0 (columns of the Schur complement)
+
+    // ---- solver
+    int precond = MFH_PRECOND_BLOCK_JACOBI;
+    DBuf<double> dDinv;
+    bool dinvValid = false;
+    DBuf<double> wx, wr, wz, wp, wAp, wb, wf, wu0, scal, stop;
+    // two-level preconditioner (MFH_PRECOND_TWO_LEVEL)
+    struct TwoLevel {
+        bool valid = false;
+        int nModes = 0, nAgg = 0, nColor = 0;
+        int64_t m = 0, ldInv = 0;
+        double setup_ms = 0, H = 0;
+        DBuf<int32_t> aggOfDof, aggPtr, dofsByAgg, colorOfAgg, nbrOfColor, binCoord;
+        DBuf<double> relPos, Ainv, rc, yc;
+    } tl;
+    int aggNodes = 0;                 // option "agg_nodes": target DoFs per aggregate (0 = auto)
+    bool topologyDevice = true;       // option "topology_device": edge numbering + boundary extraction by device radix sorts
+    bool symbolicDevice = true;       // option "symbolic_device": build pattern + gather lists on the GPU (element-major order)
+    bool tlRapAgg = true;             // option "tl_rap_agg": aggregate-centric Galerkin kernel (0: one wave per row, validation)
+    bool tlDeviceAggregates = true;   // option "tl_device_aggregates": build the aggregates on the device (0: host, validation)
+    bool tlProbe = false;             // option "tl_probe": build the coarse operator by SpMV probing (validation)
+    bool tlHostInverse = false;       // option "tl_host_inverse": invert the coarse operator on the host (validation)
+    std::string precondNote;
+    int checkEvery = 50;
+
+    // ---- Simulator-level boundary conditions
+    std::vector<double> neumannTraction;   // nBE x dim
+    std::vector<uint8_t> dirMask;          // nNode x dim
+    std::vector<double> dirVal;            // nNode x dim
+    std::vector<std::pair<int64_t, std::array<double, 3>>> deltaForces;
+
+    // ---- options
+    int chunkSlots = 256;            // assembly chunks: 18 KB of LDS accumulators, 8 workgroups per CU
+    int contribOrder = 1;            // element-major: 12% faster than rank-major on MI355X (profiles/r01_assembly_variants.md)
+    mfh_timing timing{0, 0, 0, 0};
+
+    int dim() const { return mesh.dim; }
+    int bs() const { return (op == MFH_OP_ELASTICITY && !external) ? mesh.dim : 1; }   // variables per DoF = block edge of K
+    int asmMat() const { return op == MFH_OP_ELASTICITY ? matKind : (op == MFH_OP_LAPLACIAN ? (int)MAT_LAPLACE : (int)MAT_MASS); }
+    int64_t nOwnedDoF() const {
+        // owned rows: DoFs of the first nOwned nodes. With a periodic map all DoFs are owned.
+        if (mesh.nOwned == mesh.nNode) return nDoF;
+        return mesh.nOwned;
+    }
+};
+
+namespace mfhi {   // internal helpers with external linkage (defined in mfh_api.cpp unless inline)
+using namespace mfh;
+
+#define MFH_TRY(ctx) try {
+#define MFH_CATCH(ctx)                                              \
+    } catch (const mfh::Error &e) {                                 \
+        if (ctx) (ctx)->err = e.what();                             \
+        return e.code;                                              \
+    } catch (const std::bad_alloc &) {                              \
+        if (ctx) (ctx)->err = "host allocation failed";             \
+        return MFH_ERR_HIP;                                         \
+    } catch (const std::exception &e) {                             \
+        if (ctx) (ctx)->err = e.what();                             \
+        return MFH_ERR_INVALID;                                     \
+    }                                                               \
+    return MFH_OK;
+
+inline void require(bool cond, mfh_status code, const char *msg) {
+    if (!cond) throw Error(code, msg);
+}
+inline void require_device(const mfh_ctx *c);
+
+struct EventTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
+    explicit EventTimer(hipStream_t s_) : s(s_) {
+        MFH_HIP(hipEventCreate(&a));
+        MFH_HIP(hipEventCreate(&b));
+        MFH_HIP(hipEventRecord(a, s));
+    }
+    double stop() {
+        MFH_HIP(hipEventRecord(b, s));
+        MFH_HIP(hipEventSynchronize(b));
+        float ms = 0;
+        MFH_HIP(hipEventElapsedTime(&ms, a, b));
+        return ms;
+    }
+    ~EventTimer() {
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+    }
+};
+
+inline void require_device(const mfh_ctx *c) {
+    if (c->hostOnly)
+        throw Error(MFH_ERR_HIP, "host-only context (device -1): no HIP device, and there is no CPU fallback");
+}
+
+inline int32_t dof_of(const mfh_ctx *c, int64_t node) { return c->dofForNode.empty() ? (int32_t)node : c->dofForNode[node]; }
+void invalidate_matrix(mfh_ctx *c);
+void reset_bcs(mfh_ctx *c);
+void clear_fixed(mfh_ctx *c);
+void add_fixed(mfh_ctx *c, int64_t n, const int64_t *vars, const double *vals);
+void ensure_geometry(mfh_ctx *c);
+void ensure_mf_cluster(mfh_ctx *c);
+void ensure_precond(mfh_ctx *c);
+bool ensure_twolevel(mfh_ctx *c);
+k::AsmArgs asm_args(mfh_ctx *c);
+const int32_t *device_dof_map(mfh_ctx *c);
+void box_corners(mfh_ctx *c, const double *mn, const double *mx, int relative, double *omn, double *omx);
+void dirichlet_vars(mfh_ctx *c, std::vector<int64_t> &vars, std::vector<double> &vals);
+int64_t pin_node(const mfh_ctx *c);
+void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info);
+}   // namespace mfhi

@@ -1,0 +1,667 @@
+// C ABI, Simulator level (include/meshfem_hip.h): boundary conditions and loads, Simulator::solve with the pin / translation
+// / rotation rows of assembleConstrainedSystem, strain / stress fields, discrete shape derivatives, operator selection.
+// Host orchestration only: every numeric loop runs in mfh_kernels.hip.
+#include "mfh_ctx.hh"
+
+using namespace mfh;
+using namespace mfhi;
+
+extern "C" {
+
+// ---------------------------------------------------------------- Simulator-level helpers
+mfh_status mfh_bc_clear(mfh_ctx *c) {
+    MFH_TRY(c)
+    require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    reset_bcs(c);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_bc_dirichlet_box(mfh_ctx *c, const double *mn, const double *mx, int32_t relative, const double *value,
+                                int32_t compMask) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && c->mesh.hasTopology, MFH_ERR_STATE, "boundary conditions need mfh_mesh_build");
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    double bmn[3], bmx[3];
+    box_corners(c, mn, mx, relative, bmn, bmx);
+    for (int32_t bn : m.bdryNodes) {   // LinearElasticity.hh:941-948
+        bool in = true;
+        for (int a = 0; a < d; ++a) {
+            const double p = m.nodePos[(size_t)bn * d + a];
+            in &= (p >= bmn[a]) && (p <= bmx[a]);
+        }
+        if (!in) continue;
+        for (int a = 0; a < d; ++a) {   // BoundaryNode::setDirichlet :390-403
+            if (!(compMask & (1 << a))) continue;
+            if (!c->dirMask[(size_t)bn * d + a]) {
+                c->dirMask[(size_t)bn * d + a] = 1;
+                c->dirVal[(size_t)bn * d + a] = value[a];
+            } else if (c->op != MFH_OP_ELASTICITY)
+                c->dirVal[(size_t)bn * d + a] = value[a];   // scalar PDE: later conditions overwrite (Poisson.hh:75-83)
+            else if (std::fabs(c->dirVal[(size_t)bn * d + a] - value[a]) > 1e-10)
+                throw Error(MFH_ERR_INVALID, "Conflicting dirichlet displacements.");
+        }
+    }
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_bc_neumann_box(mfh_ctx *c, const double *mn, const double *mx, int32_t relative, const double *value, int32_t kind) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && c->mesh.hasTopology, MFH_ERR_STATE, "boundary conditions need mfh_mesh_build");
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    double bmn[3], bmx[3];
+    box_corners(c, mn, mx, relative, bmn, bmx);
+    std::vector<int64_t> region;
+    double area = 0;
+    for (int64_t b = 0; b < m.nBE(); ++b) {   // :899-913
+        double ctr[3] = {0, 0, 0};
+        const int32_t *bn = &m.bdryElemNodes[(size_t)b * m.npbe];
+        for (int k2 = 0; k2 < d; ++k2)
+            for (int a = 0; a < d; ++a) ctr[a] += m.vertPos[(size_t)bn[k2] * d + a];
+        bool in = true;
+        for (int a = 0; a < d; ++a) { ctr[a] /= d; in &= (ctr[a] >= bmn[a]) && (ctr[a] <= bmx[a]); }
+        if (!in) continue;
+        region.push_back(b);
+        area += m.bdryVol[b];
+        for (int a = 0; a < d; ++a)
+            c->neumannTraction[(size_t)b * d + a] = kind == MFH_NEUMANN_PRESSURE ? -value[0] * m.bdryNormal[(size_t)b * d + a] : value[a];
+    }
+    if (region.empty()) throw Error(MFH_ERR_INVALID, "Neumann region unmatched");
+    if (kind == MFH_NEUMANN_FORCE)   // :926-931
+        for (int64_t b : region)
+            for (int a = 0; a < d; ++a) c->neumannTraction[(size_t)b * d + a] /= area;
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_bc_dirichlet_nodes(mfh_ctx *c, int64_t n, const int64_t *nodes, const double *values, int32_t compMask) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && c->mesh.hasTopology, MFH_ERR_STATE, "boundary conditions need mfh_mesh_build");
+    require(n >= 0 && (n == 0 || (nodes && values)), MFH_ERR_INVALID, "bad node list");
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    std::vector<uint8_t> isBdry((size_t)m.nNode, 0);
+    for (int32_t bn : m.bdryNodes) isBdry[bn] = 1;
+    for (int64_t k = 0; k < n; ++k) {   // LinearElasticity.hh:991-1002
+        const int64_t ni = nodes[k];
+        require(ni >= 0 && ni < m.nNode, MFH_ERR_INVALID, "node index out of bounds");
+        if (!isBdry[ni]) throw Error(MFH_ERR_INVALID, "Condition applied to non-boundary node " + std::to_string(ni));
+        for (int a = 0; a < d; ++a) {   // BoundaryNode::setDirichlet :390-403
+            if (!(compMask & (1 << a))) continue;
+            const double v = values[(size_t)k * d + a];
+            if (!c->dirMask[(size_t)ni * d + a]) {
+                c->dirMask[(size_t)ni * d + a] = 1;
+                c->dirVal[(size_t)ni * d + a] = v;
+            } else if (std::fabs(c->dirVal[(size_t)ni * d + a] - v) > 1e-10)
+                throw Error(MFH_ERR_INVALID, "Conflicting dirichlet displacements.");
+        }
+    }
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_bc_neumann_elements(mfh_ctx *c, int64_t n, const int64_t *bdryElems, const double *tractions) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && c->mesh.hasTopology, MFH_ERR_STATE, "boundary conditions need mfh_mesh_build");
+    require(n >= 0 && (n == 0 || (bdryElems && tractions)), MFH_ERR_INVALID, "bad element list");
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t b = bdryElems[k];
+        require(b >= 0 && b < m.nBE(), MFH_ERR_INVALID, "boundary element index out of bounds");
+        for (int a = 0; a < d; ++a) c->neumannTraction[(size_t)b * d + a] = tractions[(size_t)k * d + a];
+    }
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_bc_delta_force(mfh_ctx *c, int64_t node, const double *force) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && force && node >= 0 && node < c->mesh.nNode, MFH_ERR_INVALID, "bad node");
+    std::array<double, 3> f{0, 0, 0};
+    for (int a = 0; a < c->dim(); ++a) f[a] = force[a];
+    c->deltaForces.emplace_back(node, f);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_bc_dirichlet_vars(mfh_ctx *c, int64_t *vars, double *vals, int64_t *n) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && n, MFH_ERR_STATE, "no mesh set");
+    std::vector<int64_t> v;
+    std::vector<double> x;
+    dirichlet_vars(c, v, x);
+    if (vars && vals) {
+        require(*n >= (int64_t)v.size(), MFH_ERR_INVALID, "buffers too small");
+        std::copy(v.begin(), v.end(), vars);
+        std::copy(x.begin(), x.end(), vals);
+    }
+    *n = (int64_t)v.size();
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_pin_node(const mfh_ctx *c, int64_t *node) {
+    if (!c || !c->haveMesh || !node) return MFH_ERR_STATE;
+    *node = pin_node(c);
+    return MFH_OK;
+}
+
+mfh_status mfh_neumann_load(mfh_ctx *c, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && out, MFH_ERR_STATE, "no mesh set");
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    std::fill(out, out + (size_t)d * c->nDoF, 0.0);
+    // integral of the boundary shape functions (Functions.hh:246-274): P1 1/K' each; P2 face {0,0,0,1/3,1/3,1/3};
+    // P2 edge {1/6,1/6,4/6}
+    double w[6] = {0, 0, 0, 0, 0, 0};
+    if (m.deg == 1) for (int k2 = 0; k2 < m.npbe; ++k2) w[k2] = 1.0 / m.npbe;
+    else if (d == 3) { w[3] = w[4] = w[5] = 1.0 / 3.0; }
+    else { w[0] = w[1] = 1.0 / 6.0; w[2] = 4.0 / 6.0; }
+    for (int64_t b = 0; b < m.nBE(); ++b)   // LinearElasticity.hh:706-710
+        for (int k2 = 0; k2 < m.npbe; ++k2) {
+            const int32_t dof = dof_of(c, m.bdryElemNodes[(size_t)b * m.npbe + k2]);
+            for (int a = 0; a < d; ++a) out[(size_t)dof * d + a] += (w[k2] * m.bdryVol[b]) * c->neumannTraction[(size_t)b * d + a];
+        }
+    for (auto &df : c->deltaForces)
+        for (int a = 0; a < d; ++a) out[(size_t)dof_of(c, df.first) * d + a] += df.second[a];
+    MFH_CATCH(c)
+}
+
+// per-vertex perturbation field on the device (shape derivatives); indexed by the node id of the element corners
+static void upload_delta_p(mfh_ctx *c, const double *deltaP, DBuf<double> &buf) {
+    const HostMesh &m = c->mesh;
+    buf.alloc((size_t)m.nVert * m.dim);
+    MFH_HIP(hipMemcpyAsync(buf.p, deltaP, (size_t)m.nVert * m.dim * sizeof(double), hipMemcpyHostToDevice, c->stream));
+}
+
+static void constant_strain_load_impl(mfh_ctx *c, const double *cstrain, const double *deltaP, double *out) {
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "constantStrainLoad is defined for the elasticity operator");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const int d = c->dim();
+    const int64_t n = (int64_t)d * c->nDoF;
+    double cs[6] = {0, 0, 0, 0, 0, 0};
+    for (int k2 = 0; k2 < flat_len(d); ++k2) cs[k2] = cstrain[k2];
+    DBuf<double> dp;
+    if (deltaP) upload_delta_p(c, deltaP, dp);
+    c->wb.alloc(n);
+    c->wb.zero(c->stream);
+    k::launch_constant_strain_load(asm_args(c), c->dElemNodes.p, device_dof_map(c), c->tables.intGrad.data(), cs, deltaP ? dp.p : nullptr,
+                                   c->wb.p, c->stream);
+    c->wb.download(out, (size_t)n, c->stream);
+}
+
+mfh_status mfh_constant_strain_load(mfh_ctx *c, const double *cstrain, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && cstrain && out, MFH_ERR_STATE, "no mesh set");
+    constant_strain_load_impl(c, cstrain, nullptr, out);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_delta_constant_strain_load(mfh_ctx *c, const double *cstrain, const double *deltaP, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && cstrain && deltaP && out, MFH_ERR_STATE, "no mesh set");
+    constant_strain_load_impl(c, cstrain, deltaP, out);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_apply_delta_K(mfh_ctx *c, const double *uNodes, const double *deltaP, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && deltaP && out, MFH_ERR_STATE, "no mesh set");
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "applyDeltaStiffnessMatrix is defined for the elasticity operator");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    const int64_t n = (int64_t)d * c->nDoF;
+    DBuf<double> dp, u;
+    upload_delta_p(c, deltaP, dp);
+    u.alloc((size_t)m.nNode * d);
+    MFH_HIP(hipMemcpyAsync(u.p, uNodes, (size_t)m.nNode * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    c->wb.alloc(n);
+    c->wb.zero(c->stream);
+    k::launch_apply_delta_K(asm_args(c), c->dElemNodes.p, device_dof_map(c), c->tables.intGrad.data(), u.p, dp.p, c->wb.p, c->stream);
+    c->wb.download(out, (size_t)n, c->stream);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_mutual_energies(mfh_ctx *c, const double *w, const double *deltaP, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && w && out, MFH_ERR_STATE, "no mesh set");
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "mutual energies are defined for the elasticity operator");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const HostMesh &m = c->mesh;
+    const int d = m.dim, fl = flat_len(d), np = fl * (fl + 1) / 2;
+    DBuf<double> dp, wd, res;
+    if (deltaP) upload_delta_p(c, deltaP, dp);
+    wd.alloc((size_t)fl * m.nNode * d);
+    MFH_HIP(hipMemcpyAsync(wd.p, w, wd.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    res.alloc(np);
+    res.zero(c->stream);
+    k::launch_mutual_energies(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), wd.p, m.nNode, deltaP ? dp.p : nullptr, res.p, c->stream);
+    std::vector<double> h(np);
+    res.download(h.data(), (size_t)np, c->stream);
+    int p = 0;
+    for (int i = 0; i < fl; ++i)
+        for (int j = i; j < fl; ++j, ++p) out[i * fl + j] = out[j * fl + i] = h[p];
+    MFH_CATCH(c)
+}
+
+// ---- small dense helpers for the constraint rows (k <= 6)
+static bool dense_solve(int k, std::vector<double> A /* k x k row-major */, std::vector<double> &b) {
+    for (int col = 0; col < k; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < k; ++r)
+            if (std::fabs(A[(size_t)r * k + col]) > std::fabs(A[(size_t)piv * k + col])) piv = r;
+        if (!(std::fabs(A[(size_t)piv * k + col]) > 0)) return false;
+        if (piv != col) {
+            for (int q = 0; q < k; ++q) std::swap(A[(size_t)piv * k + q], A[(size_t)col * k + q]);
+            std::swap(b[piv], b[col]);
+        }
+        for (int r = col + 1; r < k; ++r) {
+            const double fct = A[(size_t)r * k + col] / A[(size_t)col * k + col];
+            for (int q = col; q < k; ++q) A[(size_t)r * k + q] -= fct * A[(size_t)col * k + q];
+            b[r] -= fct * b[col];
+        }
+    }
+    for (int r = k - 1; r >= 0; --r) {
+        double v = b[r];
+        for (int q = r + 1; q < k; ++q) v -= A[(size_t)r * k + q] * b[q];
+        b[r] = v / A[(size_t)r * k + r];
+    }
+    return true;
+}
+// cyclic Jacobi eigen-decomposition of a small symmetric matrix: A -> eigenvalues on the diagonal, V columns = eigenvectors
+static void jacobi_eig(int k, std::vector<double> &A, std::vector<double> &V) {
+    V.assign((size_t)k * k, 0.0);
+    for (int q = 0; q < k; ++q) V[(size_t)q * k + q] = 1.0;
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p2 = 0; p2 < k; ++p2)
+            for (int q = p2 + 1; q < k; ++q) off += A[(size_t)p2 * k + q] * A[(size_t)p2 * k + q];
+        if (off < 1e-300) break;
+        for (int p2 = 0; p2 < k; ++p2)
+            for (int q = p2 + 1; q < k; ++q) {
+                const double apq = A[(size_t)p2 * k + q];
+                if (std::fabs(apq) < 1e-300) continue;
+                const double th = (A[(size_t)q * k + q] - A[(size_t)p2 * k + p2]) / (2 * apq);
+                const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1));
+                const double cs = 1 / std::sqrt(t * t + 1), sn = t * cs;
+                for (int r = 0; r < k; ++r) {
+                    const double arp = A[(size_t)r * k + p2], arq = A[(size_t)r * k + q];
+                    A[(size_t)r * k + p2] = cs * arp - sn * arq; A[(size_t)r * k + q] = sn * arp + cs * arq;
+                }
+                for (int r = 0; r < k; ++r) {
+                    const double apr = A[(size_t)p2 * k + r], aqr = A[(size_t)q * k + r];
+                    A[(size_t)p2 * k + r] = cs * apr - sn * aqr; A[(size_t)q * k + r] = sn * apr + cs * aqr;
+                }
+                for (int r = 0; r < k; ++r) {
+                    const double vrp = V[(size_t)r * k + p2], vrq = V[(size_t)r * k + q];
+                    V[(size_t)r * k + p2] = cs * vrp - sn * vrq; V[(size_t)r * k + q] = sn * vrp + cs * vrq;
+                }
+            }
+    }
+}
+static double hdot(const std::vector<double> &a, const std::vector<double> &b) {
+    const int nt = host_threads();
+    std::vector<double> part((size_t)nt + 1, 0.0);
+    parallel_ranges((int64_t)a.size(), [&](int64_t lo, int64_t hi, int tid) {
+        double v = 0;
+        for (int64_t q = lo; q < hi; ++q) v += a[q] * b[q];
+        part[tid] += v;
+    });
+    double v = 0;
+    for (double x : part) v += x;
+    return v;
+}
+
+// Simulator::solve with the whole of assembleConstrainedSystem (LinearElasticity.hh:1201-1249): pin / translation /
+// rotation constraints, Dirichlet variables. The reference solves the resulting KKT system with UMFPACK
+// (SparseMatrices.hh:2572-2590); here the constraint rows C (k <= 6) are eliminated around SPD solves:
+//   * K singular on the free variables with null space Z (rigid motions vanishing on the fixed variables) and
+//     C Z square and regular: multipliers from Z^T (f - C^T l) = 0, ONE consistent singular PCG solve, rigid part of the
+//     solution from C u = c;
+//   * K regular on the free variables: Schur complement S = C K^-1 C^T with k + 1 PCG solves.
+static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const double *rmRHS, int32_t nRM, double *uNodes, double rtol,
+                           int32_t maxit, mfh_solve_info *info) {
+    const HostMesh &m = c->mesh;
+    const int d = c->bs(), gd = m.dim;
+    const int64_t n = (int64_t)d * c->nDoF;
+    if (c->op != MFH_OP_ELASTICITY) flags = MFH_SOLVE_ALLOW_ILL_POSED;   // rigid motions are an elasticity notion
+    const bool periodic = !c->dofForNode.empty();
+    // MFH_SOLVE_TIMING=1: host-side laps of one Simulator::solve on stderr (the device part is in mfh_solve_info)
+    const bool lapTiming = getenv("MFH_SOLVE_TIMING") != nullptr;
+    double lapT = now_ms();
+    auto lap = [&](const char *what) {
+        if (!lapTiming) return;
+        const double t = now_ms();
+        fprintf(stderr, "[mfh solve] %-32s %8.2f ms\n", what, t - lapT);
+        lapT = t;
+    };
+    std::vector<int64_t> vars;
+    std::vector<double> vals;
+    std::vector<std::vector<double>> C;
+    std::vector<double> crhs;
+    auto pin = [&](unsigned compMask) {   // m_pinNode (:1595-1618)
+        const int64_t pn = pin_node(c);
+        for (int a = 0; a < d; ++a)
+            if (compMask & (1u << a)) { vars.push_back((int64_t)d * dof_of(c, pn) + a); vals.push_back(0.0); }
+    };
+    auto addTranslationRows = [&](unsigned compMask) {   // m_appendTranslationMatrix (:1568-1590)
+        for (int a = 0; a < d; ++a) {
+            if (!(compMask & (1u << a))) continue;
+            std::vector<double> row((size_t)n, 0.0);
+            for (int64_t i = 0; i < c->nDoF; ++i) row[(size_t)i * d + a] = 1.0;
+            C.push_back(std::move(row));
+        }
+    };
+    auto rotationRows = [&](std::vector<std::vector<double>> &out) {   // rows of m_appendInfinitesimalRotationMatrix (:1525-1566)
+        const int nr = gd == 3 ? 3 : 1;
+        for (int r = 0; r < nr; ++r) out.emplace_back((size_t)n, 0.0);
+        std::vector<double> *R = &out[out.size() - nr];
+        for (int64_t k2 = 0; k2 < m.nNode; ++k2) {
+            const double *x = &m.nodePos[(size_t)k2 * gd];
+            if (gd == 3) {
+                R[0][(size_t)k2 * 3 + 1] = -x[2]; R[0][(size_t)k2 * 3 + 2] = x[1];
+                R[1][(size_t)k2 * 3 + 0] = x[2];  R[1][(size_t)k2 * 3 + 2] = -x[0];
+                R[2][(size_t)k2 * 3 + 0] = -x[1]; R[2][(size_t)k2 * 3 + 1] = x[0];
+            } else {
+                R[0][(size_t)k2 * 2 + 0] = -x[1]; R[0][(size_t)k2 * 2 + 1] = x[0];
+            }
+        }
+    };
+    const unsigned allComps = (1u << d) - 1;
+    if (flags & MFH_SOLVE_NO_RIGID_MOTION) {
+        // periodic conditions pin the rotations (:1534-1542)
+        bool rot = true;
+        if (gd == 2 && c->nDoF < m.nNode) rot = false;
+        else if (c->nDoF < m.nNode - 1) rot = false;
+        else if (c->nDoF < m.nNode) throw Error(MFH_ERR_UNSUPPORTED, "Single pair periodic BC unsupported in 3D.");
+        if (rot) rotationRows(C);
+        if (flags & MFH_SOLVE_PIN) pin(allComps);
+        else addTranslationRows(allComps);
+        if (rmRHS && nRM > 0) {
+            require((size_t)nRM == C.size(), MFH_ERR_INVALID, "Invalid rigid motion RHS");
+            crhs.assign(rmRHS, rmRHS + nRM);
+        } else crhs.assign(C.size(), 0.0);
+    } else if (!(flags & MFH_SOLVE_ALLOW_ILL_POSED)) {
+        // analyzeDirichletPosedness (:1169-1190)
+        unsigned needsT = allComps;
+        size_t total = 0;
+        for (int32_t bn : m.bdryNodes)
+            for (int a = 0; a < gd; ++a)
+                if (c->dirMask[(size_t)bn * gd + a]) { needsT &= ~(1u << a); ++total; }
+        if (needsT) {
+            if (flags & MFH_SOLVE_PIN) pin(needsT);
+            else { addTranslationRows(needsT); crhs.assign(C.size(), 0.0); }
+        }
+        if (total == 0) throw Error(MFH_ERR_UNSUPPORTED, "Unimplemented");   // needsRotations (:1240): ask for the rigid-motion constraint
+    }
+    dirichlet_vars(c, vars, vals);
+    lap("constraint rows + Dirichlet vars");
+    if (vars != c->fixedVars || vals != c->fixedVals) {   // unchanged constraints keep the preconditioner setup
+        clear_fixed(c);
+        add_fixed(c, (int64_t)vars.size(), vars.data(), vals.data());
+    }
+    lap("fixed-variable mask");
+    // host scratch vectors live in the context: a fresh 178 MB std::vector costs ~30 ms of page faults per solve at config 3
+    std::vector<double> &load = c->hLoad;
+    if (!f) {
+        load.resize((size_t)n);
+        if (c->op == MFH_OP_ELASTICITY) {
+            mfh_status st = mfh_neumann_load(c, load.data());   // zero-fills first
+            if (st != MFH_OK) throw Error(st, c->err);
+        } else std::fill(load.begin(), load.end(), 0.0);   // scalar PDE: zero right-hand side, zero-Neumann natural condition (Poisson.hh:100-102)
+        f = load.data();
+    }
+    lap("load vector");
+    std::vector<double> &x = c->hX;
+    x.resize((size_t)n);
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_precond(c);
+    lap("assembly + diagonal blocks");
+    if (c->precond == MFH_PRECOND_TWO_LEVEL) ensure_twolevel(c);
+    lap("two-level setup");
+    mfh_solve_info li{};
+    const int k = (int)C.size();
+    if (k == 0) {
+        solve_one(c, f, x.data(), rtol, maxit, &li);
+        lap("PCG incl. transfers");
+    } else {
+        // ---- candidate rigid motions (unit-normalised): translations, and rotations unless a periodic map excludes them
+        std::vector<std::vector<double>> Zc;
+        for (int a = 0; a < d; ++a) {
+            Zc.emplace_back((size_t)n, 0.0);
+            for (int64_t i = 0; i < c->nDoF; ++i) Zc.back()[(size_t)i * d + a] = 1.0;
+        }
+        if (!periodic) rotationRows(Zc);
+        const int nc = (int)Zc.size();
+        for (auto &z : Zc) {
+            const double nrm = std::sqrt(hdot(z, z));
+            if (nrm > 0) for (double &v : z) v /= nrm;
+        }
+        // null space of the candidates restricted to the fixed variables
+        std::vector<double> G((size_t)nc * nc, 0.0), V;
+        for (int64_t fv : c->fixedVars)
+            for (int a = 0; a < nc; ++a)
+                for (int b = 0; b < nc; ++b) G[(size_t)a * nc + b] += Zc[a][(size_t)fv] * Zc[b][(size_t)fv];
+        jacobi_eig(nc, G, V);
+        double evMax = 0;
+        for (int e = 0; e < nc; ++e) evMax = std::max(evMax, G[(size_t)e * nc + e]);
+        std::vector<std::vector<double>> Z;
+        for (int e = 0; e < nc; ++e) {
+            if (G[(size_t)e * nc + e] > 1e-12 * evMax) continue;   // the mode moves a fixed variable: not in the null space
+            Z.emplace_back((size_t)n, 0.0);
+            for (int a = 0; a < nc; ++a) {
+                const double w = V[(size_t)a * nc + e];
+                if (w == 0.0) continue;
+                for (int64_t q = 0; q < n; ++q) Z.back()[(size_t)q] += w * Zc[a][(size_t)q];
+            }
+            for (int64_t fv : c->fixedVars) Z.back()[(size_t)fv] = 0.0;
+        }
+        std::vector<std::vector<double>>().swap(Zc);
+        const int q = (int)Z.size();
+        // constraint rows on the free variables
+        std::vector<std::vector<double>> Cf = C;
+        for (auto &row : Cf)
+            for (int64_t fv : c->fixedVars) row[(size_t)fv] = 0.0;
+        if (q == k) {
+            std::vector<double> M((size_t)k * k), MT((size_t)k * k);
+            for (int r = 0; r < k; ++r)
+                for (int e = 0; e < k; ++e) { M[(size_t)r * k + e] = hdot(Cf[r], Z[e]); MT[(size_t)e * k + r] = M[(size_t)r * k + e]; }
+            std::vector<double> lam((size_t)k), fv2(f, f + n);
+            for (int e = 0; e < k; ++e) lam[e] = hdot(Z[e], fv2);
+            if (!dense_solve(k, MT, lam)) throw Error(MFH_ERR_UNSUPPORTED, "constraint rows do not fix the rigid motions of the system");
+            for (int r = 0; r < k; ++r)
+                for (int64_t i = 0; i < n; ++i) fv2[(size_t)i] -= lam[r] * Cf[r][(size_t)i];
+            // K is singular on the free variables, and so is the Galerkin coarse operator of the two-level
+            // preconditioner (the aggregates' modes span the global rigid motions): block-Jacobi for this solve
+            c->tlSuppress = true;
+            if (c->precond == MFH_PRECOND_TWO_LEVEL) c->precondNote = "two-level preconditioner: singular system (rigid-motion constraint rows); using block-Jacobi";
+            try { solve_one(c, fv2.data(), x.data(), rtol, maxit, &li); } catch (...) { c->tlSuppress = false; throw; }
+            c->tlSuppress = false;
+            std::vector<double> a((size_t)k);
+            for (int r = 0; r < k; ++r) a[r] = crhs[r] - hdot(C[r], x);
+            if (!dense_solve(k, M, a)) throw Error(MFH_ERR_UNSUPPORTED, "constraint rows do not fix the rigid motions of the system");
+            for (int e = 0; e < k; ++e)
+                for (int64_t i = 0; i < n; ++i) x[(size_t)i] += a[e] * Z[e][(size_t)i];
+        } else if (q == 0) {
+            solve_one(c, f, x.data(), rtol, maxit, &li);
+            std::vector<std::vector<double>> Y((size_t)k, std::vector<double>((size_t)n));
+            c->solveHomogeneous = true;
+            try {
+                for (int r = 0; r < k; ++r) {
+                    mfh_solve_info lj{};
+                    solve_one(c, Cf[r].data(), Y[r].data(), rtol, maxit, &lj);
+                    li.iterations += lj.iterations;
+                    li.solve_ms += lj.solve_ms;
+                    li.converged = li.converged && lj.converged;
+                }
+            } catch (...) { c->solveHomogeneous = false; throw; }
+            c->solveHomogeneous = false;
+            std::vector<double> S((size_t)k * k), lam((size_t)k);
+            for (int r = 0; r < k; ++r) {
+                for (int e = 0; e < k; ++e) S[(size_t)r * k + e] = hdot(Cf[r], Y[e]);
+                lam[r] = hdot(C[r], x) - crhs[r];
+            }
+            if (!dense_solve(k, S, lam)) throw Error(MFH_ERR_UNSUPPORTED, "constraint rows are linearly dependent on the free variables");
+            for (int r = 0; r < k; ++r)
+                for (int64_t i = 0; i < n; ++i) x[(size_t)i] -= lam[r] * Y[r][(size_t)i];
+        } else
+            throw Error(MFH_ERR_UNSUPPORTED, "constraint rows and the rigid motions left by the fixed variables do not match");
+    }
+    if (info) *info = li;
+    for (int64_t i = 0; i < m.nNode; ++i)   // dofToNodeField :664-677
+        for (int a = 0; a < d; ++a) uNodes[(size_t)i * d + a] = x[(size_t)dof_of(c, i) * d + a];
+    lap("dofToNodeField");
+    if (!li.converged) throw Error(MFH_ERR_NOT_CONVERGED, "PCG did not reach the requested tolerance within maxit iterations");
+}
+
+mfh_status mfh_sim_solve(mfh_ctx *c, const double *f, int32_t usePin, double *uNodes, double rtol, int32_t maxit,
+                         mfh_solve_info *info) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes, MFH_ERR_STATE, "no mesh set");
+    // usePin = solveCellProblems' configuration (PeriodicHomogenization.hh:43-45): rigid-motion constraint with the
+    // translations pinned; otherwise the Dirichlet variables alone
+    sim_solve_impl(c, f, usePin ? (MFH_SOLVE_PIN | MFH_SOLVE_NO_RIGID_MOTION) : MFH_SOLVE_ALLOW_ILL_POSED, nullptr, 0, uNodes, rtol, maxit, info);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_sim_solve_constrained(mfh_ctx *c, const double *f, int32_t flags, const double *rigidMotionRHS, int32_t nRigidRHS,
+                                     double *uNodes, double rtol, int32_t maxit, mfh_solve_info *info) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes, MFH_ERR_STATE, "no mesh set");
+    require(c->mesh.nOwned == c->mesh.nNode, MFH_ERR_UNSUPPORTED, "constrained solves need all rows owned");
+    sim_solve_impl(c, f, flags, rigidMotionRHS, nRigidRHS, uNodes, rtol, maxit, info);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_strain_field(mfh_ctx *c, const double *uNodes, int32_t wantStress, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && out, MFH_ERR_STATE, "no mesh set");
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "strain / stress fields are defined for the elasticity operator");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const HostMesh &m = c->mesh;
+    const int d = m.dim, fl = flat_len(d), nq = m.deg == 1 ? 1 : d + 1;
+    DBuf<double> u, res;
+    u.alloc((size_t)m.nNode * d);
+    MFH_HIP(hipMemcpyAsync(u.p, uNodes, (size_t)m.nNode * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    res.alloc((size_t)m.nElem * nq * fl);
+    k::launch_strain_field(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), u.p, wantStress, res.p, c->stream);
+    res.download(out, res.n, c->stream);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_mutual_energy_differential(mfh_ctx *c, const double *w, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && w && out, MFH_ERR_STATE, "no mesh set");
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "mutual energies are defined for the elasticity operator");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const HostMesh &m = c->mesh;
+    const int d = m.dim, fl = flat_len(d), np = fl * (fl + 1) / 2;
+    DBuf<double> wd, res;
+    wd.alloc((size_t)fl * m.nNode * d);
+    MFH_HIP(hipMemcpyAsync(wd.p, w, wd.n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    res.alloc((size_t)np * m.nVert * d);
+    res.zero(c->stream);
+    k::launch_mutual_energy_differential(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), wd.p, m.nNode, m.nVert, res.p, c->stream);
+    res.download(out, res.n, c->stream);
+    MFH_CATCH(c)
+}
+
+static void average_strain_impl(mfh_ctx *c, const double *uNodes, double *out, bool stress, const double *uFixed = nullptr,
+                                const double *deltaP = nullptr) {
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "strain / stress fields are defined for the elasticity operator");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const HostMesh &m = c->mesh;
+    const int d = m.dim, fl = flat_len(d);
+    c->wx.alloc((size_t)m.nNode * d);
+    MFH_HIP(hipMemcpyAsync(c->wx.p, uNodes, (size_t)m.nNode * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    DBuf<double> res, dp, uf;
+    if (deltaP) {
+        upload_delta_p(c, deltaP, dp);
+        uf.alloc((size_t)m.nNode * d);
+        MFH_HIP(hipMemcpyAsync(uf.p, uFixed, (size_t)m.nNode * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    }
+    res.alloc((size_t)m.nElem * fl);
+    k::launch_average_strain(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), c->wx.p, res.p, stress ? 1 : 0,
+                             deltaP ? uf.p : nullptr, deltaP ? dp.p : nullptr, c->stream);
+    res.download(out, res.n, c->stream);
+}
+
+mfh_status mfh_delta_average_strain(mfh_ctx *c, const double *uNodes, const double *deltaU, const double *deltaP, int32_t wantStress,
+                                    double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && deltaU && deltaP && out, MFH_ERR_STATE, "no mesh set");
+    average_strain_impl(c, deltaU, out, wantStress != 0, uNodes, deltaP);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_set_operator(mfh_ctx *c, int32_t op) {
+    MFH_TRY(c)
+    require(c && (op == MFH_OP_ELASTICITY || op == MFH_OP_LAPLACIAN || op == MFH_OP_MASS), MFH_ERR_INVALID, "unknown operator");
+    if (op != c->op) {
+        c->op = op;
+        invalidate_matrix(c);          // pattern and gather lists are shared by all operators; only the values change
+        if (c->haveMesh) clear_fixed(c);   // the variable numbering changes with the block size
+    }
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_average_gradient(mfh_ctx *c, const double *uNodes, double *grad) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && grad, MFH_ERR_STATE, "no mesh set");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const HostMesh &m = c->mesh;
+    c->wx.alloc((size_t)m.nNode);
+    MFH_HIP(hipMemcpyAsync(c->wx.p, uNodes, (size_t)m.nNode * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    DBuf<double> res;
+    res.alloc((size_t)m.nElem * m.dim);
+    k::launch_average_gradient(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), c->wx.p, res.p, c->stream);
+    res.download(grad, res.n, c->stream);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_matrix_free_info(mfh_ctx *c, int32_t *active, int32_t *mode, int64_t *nBlocks, int64_t *nBlockRows, int64_t *nInterface,
+                                int32_t *maxBlockRows) {
+    MFH_TRY(c)
+    require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    if (active) *active = c->use_mf() ? 1 : 0;
+    if (c->use_mf() && c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY) {
+        require_device(c);
+        MFH_HIP(hipSetDevice(c->device));
+        ensure_mf_cluster(c);
+    }
+    if (mode) *mode = c->mfModeEff();
+    if (nBlocks) *nBlocks = c->mfcValid ? c->mfc.nBlocks : 0;
+    if (nBlockRows) *nBlockRows = c->mfcValid ? c->mfc.nEntries : 0;
+    if (nInterface) *nInterface = c->mfcValid ? c->mfc.nIface : 0;
+    if (maxBlockRows) *maxBlockRows = c->mfcValid ? c->mfc.maxLocal : 0;
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_average_strain(mfh_ctx *c, const double *uNodes, double *strain) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && strain, MFH_ERR_STATE, "no mesh set");
+    average_strain_impl(c, uNodes, strain, false);
+    MFH_CATCH(c)
+}
+mfh_status mfh_average_stress(mfh_ctx *c, const double *uNodes, double *stress) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && stress, MFH_ERR_STATE, "no mesh set");
+    average_strain_impl(c, uNodes, stress, true);
+    MFH_CATCH(c)
+}
+
+} // extern "C"
