@@ -1,5 +1,5 @@
 // C ABI of libmeshfem_hip.so (include/meshfem_hip.h). Host orchestration only: every numeric
-// loop of the hot path runs in mfh_kernels.hip.
+// loop of the hot path runs in mfh_kernels.hip / mfh_kernels_solver.hip.
 #include "mfh_ctx.hh"
 #include <dlfcn.h>
 

@@ -1,0 +1,93 @@
+// Device-side helpers shared by the kernel translation units (mfh_kernels.hip: element embedding, assembly, operators and
+// element-level post-processing; mfh_kernels_solver.hip: diagonal blocks, two-level preconditioner, dense coarse inverse and
+// the PCG vector kernels).
+#pragma once
+#include "mfh_internal.hh"
+#include <algorithm>
+
+namespace mfh { namespace k {
+
+#define DEV __device__ __forceinline__
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+DEV int64_t tiled_index(int64_t slot, int c, int NB) { return ((slot >> 6) * NB + c) * 64 + (slot & 63); }
+
+DEV double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// block-wide sum of up to 3 values; result valid in thread 0. blockDim.x == 256.
+template <int NV>
+DEV void block_sum(double (&v)[NV], double *lds /* >= 4*NV doubles */) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) lds[w * NV + k] = v[k];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = lds[k] + lds[NV + k] + lds[2 * NV + k] + lds[3 * NV + k];
+    }
+    __syncthreads();
+}
+
+// XCD-aware work mapping. Workgroups are dispatched round-robin over the 8 XCDs (workgroup b runs on XCD b % 8) and
+// every XCD has its own L2, so neighbouring work items (row chunks, element groups: they share element records, gather
+// lists and x entries) should run on the SAME XCD: XCD x gets the x-th contiguous eighth of the n items.
+// One workgroup per item: a bijection of [0, n).
+DEV int64_t xcd_item(int64_t b, int64_t n) {
+    const int64_t q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
+    return x * q + (x < r ? x : r) + k;
+}
+// Persistent workgroups (gridDim.x a multiple of 8): the items of XCD x are [begin, end), visited with stride gridDim.x / 8
+// starting at begin + blockIdx.x / 8.
+DEV void xcd_span(int64_t n, int64_t &first, int64_t &end, int64_t &stride) {
+    const int64_t q = n >> 3, r = n & 7, x = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int64_t begin = x * q + (x < r ? x : r);
+    end = begin + q + (x < r ? 1 : 0);
+    first = begin + k;
+    stride = gridDim.x >> 3;
+}
+
+// Flattened symmetric index (Flattening.hh:47-60): 3D xx,yy,zz,yz,xz,xy ; 2D xx,yy,xy
+template <int DIM>
+DEV constexpr int flat_idx(int i, int j) { return i == j ? i : (DIM * (DIM + 1) / 2 - i - j); }
+// index into the packed upper triangle (row-major) of the flatLen x flatLen matrix D
+template <int DIM>
+DEV constexpr int dpack(int r, int c) {
+    constexpr int n = DIM * (DIM + 1) / 2;
+    int a = r <= c ? r : c, b = r <= c ? c : r;
+    return a * n - a * (a - 1) / 2 + (b - a);
+}
+
+// the six distinct quadrature pair coefficients (named scalars: an indexed array would go to scratch)
+struct PairConst { double vv_eq, vv_ne, ve_eq, ve_ne, ee_eq, ee_ne; };
+
+// support vertices of node i: grad phi_i = alpha gl[s] + beta gl[t]   (EmbeddedElement.hh:315-332)
+// packed 4-bit tables: vertex nodes s=t=i; edge node k: s=edgeStart[k], t=edgeEnd[k] (Simplex.hh:43-44)
+template <int DIM, int DEG> DEV int sup_s(int i) {
+    if (DEG == 1) return i;
+    if (DIM == 3) return (int)((0x1202103210ull >> (4 * i)) & 0xf);   // nodes 0..9: 0,1,2,3,0,1,2,0,2,1
+    return (int)((0x210210ull >> (4 * i)) & 0xf);                     // nodes 0..5: 0,1,2,0,1,2
+}
+template <int DIM, int DEG> DEV int sup_t(int i) {
+    if (DEG == 1) return i;
+    if (DIM == 3) return (int)((0x3330213210ull >> (4 * i)) & 0xf);   // 0,1,2,3,1,2,0,3,3,3
+    return (int)((0x021210ull >> (4 * i)) & 0xf);                     // 0,1,2,1,2,0
+}
+
+
+// ---- launch helpers
+static inline int grid_for(int64_t n, int cap = 2048) {
+    int64_t g = (n + 255) / 256;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
+}
+#define CHECK_LAUNCH() MFH_HIP(hipGetLastError())
+
+}} // namespace mfh::k

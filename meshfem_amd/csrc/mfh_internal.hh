@@ -261,7 +261,7 @@ bool spd_inverse_inplace(int64_t n, double *A);
 } // namespace mfh
 
 // ------------------------------------------------------------------------------------------------
-// Kernel launchers (mfh_kernels.hip)
+// Kernel launchers (mfh_kernels.hip: element kernels and operators; mfh_kernels_solver.hip: preconditioners, dense inverse, PCG vectors)
 // ------------------------------------------------------------------------------------------------
 namespace mfh { namespace k {
 

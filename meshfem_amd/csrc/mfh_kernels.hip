@@ -7,84 +7,9 @@
 // block) lives at vals[((s >> 6) * NB + c) * 64 + (s & 63)], NB = dim*dim. Consecutive lanes that
 // own consecutive slots therefore read/write 512 contiguous bytes per component: every wave-wide
 // load/store of K is a fully coalesced 8 B/lane access on both the assembly and the SpMV side.
-#include "mfh_internal.hh"
+#include "mfh_device.hh"
 
 namespace mfh { namespace k {
-
-#define DEV __device__ __forceinline__
-
-// ------------------------------------------------------------------------------------------------
-// helpers
-// ------------------------------------------------------------------------------------------------
-DEV int64_t tiled_index(int64_t slot, int c, int NB) { return ((slot >> 6) * NB + c) * 64 + (slot & 63); }
-
-DEV double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// block-wide sum of up to 3 values; result valid in thread 0. blockDim.x == 256.
-template <int NV>
-DEV void block_sum(double (&v)[NV], double *lds /* >= 4*NV doubles */) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = wave_sum(v[k]);
-    if (lane == 0)
-#pragma unroll
-        for (int k = 0; k < NV; ++k) lds[w * NV + k] = v[k];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) v[k] = lds[k] + lds[NV + k] + lds[2 * NV + k] + lds[3 * NV + k];
-    }
-    __syncthreads();
-}
-
-// XCD-aware work mapping. Workgroups are dispatched round-robin over the 8 XCDs (workgroup b runs on XCD b % 8) and
-// every XCD has its own L2, so neighbouring work items (row chunks, element groups: they share element records, gather
-// lists and x entries) should run on the SAME XCD: XCD x gets the x-th contiguous eighth of the n items.
-// One workgroup per item: a bijection of [0, n).
-DEV int64_t xcd_item(int64_t b, int64_t n) {
-    const int64_t q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
-    return x * q + (x < r ? x : r) + k;
-}
-// Persistent workgroups (gridDim.x a multiple of 8): the items of XCD x are [begin, end), visited with stride gridDim.x / 8
-// starting at begin + blockIdx.x / 8.
-DEV void xcd_span(int64_t n, int64_t &first, int64_t &end, int64_t &stride) {
-    const int64_t q = n >> 3, r = n & 7, x = blockIdx.x & 7, k = blockIdx.x >> 3;
-    const int64_t begin = x * q + (x < r ? x : r);
-    end = begin + q + (x < r ? 1 : 0);
-    first = begin + k;
-    stride = gridDim.x >> 3;
-}
-
-// Flattened symmetric index (Flattening.hh:47-60): 3D xx,yy,zz,yz,xz,xy ; 2D xx,yy,xy
-template <int DIM>
-DEV constexpr int flat_idx(int i, int j) { return i == j ? i : (DIM * (DIM + 1) / 2 - i - j); }
-// index into the packed upper triangle (row-major) of the flatLen x flatLen matrix D
-template <int DIM>
-DEV constexpr int dpack(int r, int c) {
-    constexpr int n = DIM * (DIM + 1) / 2;
-    int a = r <= c ? r : c, b = r <= c ? c : r;
-    return a * n - a * (a - 1) / 2 + (b - a);
-}
-
-// the six distinct quadrature pair coefficients (named scalars: an indexed array would go to scratch)
-struct PairConst { double vv_eq, vv_ne, ve_eq, ve_ne, ee_eq, ee_ne; };
-
-// support vertices of node i: grad phi_i = alpha gl[s] + beta gl[t]   (EmbeddedElement.hh:315-332)
-// packed 4-bit tables: vertex nodes s=t=i; edge node k: s=edgeStart[k], t=edgeEnd[k] (Simplex.hh:43-44)
-template <int DIM, int DEG> DEV int sup_s(int i) {
-    if (DEG == 1) return i;
-    if (DIM == 3) return (int)((0x1202103210ull >> (4 * i)) & 0xf);   // nodes 0..9: 0,1,2,3,0,1,2,0,2,1
-    return (int)((0x210210ull >> (4 * i)) & 0xf);                     // nodes 0..5: 0,1,2,0,1,2
-}
-template <int DIM, int DEG> DEV int sup_t(int i) {
-    if (DEG == 1) return i;
-    if (DIM == 3) return (int)((0x3330213210ull >> (4 * i)) & 0xf);   // 0,1,2,3,1,2,0,3,3,3
-    return (int)((0x021210ull >> (4 * i)) & 0xf);                     // 0,1,2,1,2,0
-}
 
 // ------------------------------------------------------------------------------------------------
 // One dim x dim block of the element stiffness matrix:
@@ -1429,763 +1354,8 @@ __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__r
 }
 
 // ------------------------------------------------------------------------------------------------
-// small dense helpers
-// ------------------------------------------------------------------------------------------------
-template <int DIM> DEV void invert_block(const double *A, double *Inv) {
-    if (DIM == 1) {
-        Inv[0] = 1.0 / A[0];
-    } else if (DIM == 2) {
-        const double det = A[0] * A[3] - A[1] * A[2];
-        Inv[0] = A[3] / det; Inv[1] = -A[1] / det; Inv[2] = -A[2] / det; Inv[3] = A[0] / det;
-    } else {
-        const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
-        const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
-        Inv[0] = c00 / det; Inv[1] = (A[2] * A[7] - A[1] * A[8]) / det; Inv[2] = (A[1] * A[5] - A[2] * A[4]) / det;
-        Inv[3] = c01 / det; Inv[4] = (A[0] * A[8] - A[2] * A[6]) / det; Inv[5] = (A[2] * A[3] - A[0] * A[5]) / det;
-        Inv[6] = c02 / det; Inv[7] = (A[1] * A[6] - A[0] * A[7]) / det; Inv[8] = (A[0] * A[4] - A[1] * A[3]) / det;
-    }
-}
-
-// Inverse of the diagonal blocks of the constrained operator P K P + (I-P): rows/cols of fixed
-// components are replaced by identity before inversion. kind: 0 block-Jacobi, 1 Jacobi, 2 identity.
-template <int DIM>
-__global__ void __launch_bounds__(256) k_diag_inv(int64_t nRows, const int32_t *__restrict__ rowPtr,
-                                                  const int32_t *__restrict__ colIdx, const double *__restrict__ vals,
-                                                  const uint8_t *__restrict__ fixedMask, int kind, double *__restrict__ dinv) {
-    constexpr int NB = DIM * DIM;
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (r >= nRows) return;
-    double A[NB], Inv[NB];
-#pragma unroll
-    for (int c = 0; c < NB; ++c) A[c] = (c % (DIM + 1) == 0) ? 1.0 : 0.0;
-    int lo = rowPtr[r], hi = rowPtr[r + 1];
-    while (lo < hi) {   // columns are sorted within a row
-        const int mid = (lo + hi) >> 1;
-        const int cv = colIdx[mid];
-        if (cv == r) {
-#pragma unroll
-            for (int c = 0; c < NB; ++c) A[c] = vals[tiled_index(mid, c, NB)];
-            break;
-        }
-        if (cv < r) lo = mid + 1; else hi = mid;
-    }
-    if (fixedMask) {
-#pragma unroll
-        for (int c = 0; c < DIM; ++c)
-            if (fixedMask[r * DIM + c]) {
-#pragma unroll
-                for (int d = 0; d < DIM; ++d) { A[c * DIM + d] = 0.0; A[d * DIM + c] = 0.0; }
-                A[c * DIM + c] = 1.0;
-            }
-    }
-    if (kind == 0) invert_block<DIM>(A, Inv);
-    else {
-#pragma unroll
-        for (int c = 0; c < NB; ++c) Inv[c] = 0.0;
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) Inv[c * DIM + c] = kind == 1 ? 1.0 / A[c * DIM + c] : 1.0;
-    }
-    // the inverse of a symmetric block is symmetric: stored packed (flat symmetric index), 6 instead of 9 values in 3D
-    constexpr int NS = DIM * (DIM + 1) / 2;
-#pragma unroll
-    for (int c = 0; c < DIM; ++c)
-#pragma unroll
-        for (int d = c; d < DIM; ++d) dinv[r * NS + flat_idx<DIM>(c, d)] = 0.5 * (Inv[c * DIM + d] + Inv[d * DIM + c]);
-}
-
-// z = D^-1 r with the symmetric-packed inverse diagonal block (DIM (DIM+1)/2 values per block row)
-template <int DIM> DEV void apply_block(const double *__restrict__ Dm, const double *r, double *z) {
-    constexpr int NS = DIM * (DIM + 1) / 2;
-    double m[NS];
-#pragma unroll
-    for (int q = 0; q < NS; ++q) m[q] = Dm[q];
-#pragma unroll
-    for (int c = 0; c < DIM; ++c) {
-        double v = 0;
-#pragma unroll
-        for (int d = 0; d < DIM; ++d) v += m[flat_idx<DIM>(c, d)] * r[d];
-        z[c] = v;
-    }
-}
-
-template <int DIM>
-__global__ void __launch_bounds__(256) k_precond(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ r,
-                                                 double *__restrict__ z) {
-    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nRows; n += (int64_t)gridDim.x * 256) {
-        double rv[DIM], zv[DIM];
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) rv[c] = r[n * DIM + c];
-        apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) z[n * DIM + c] = zv[c];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Two-level preconditioner  M^-1 = D^-1 + Z (Z^T K Z)^-1 Z^T  (mfh_twolevel.cpp): Z = rigid-body
-// modes of every aggregate (translations, and rotations about the aggregate centroid scaled by 1/H),
-// zero on fixed variables. Z is never stored: a mode's value at a DoF follows from its relative position.
-// ------------------------------------------------------------------------------------------------
-template <int DIM> DEV double tl_mode(int k, int c, const double *rp) {
-    const double rx = rp[0], ry = rp[1], rz = rp[2];
-    if (k < DIM) return k == c ? 1.0 : 0.0;
-    if (DIM == 2) return c == 0 ? -ry : rx;
-    // rotation about axis k-3: u = e_axis x r
-    if (k == 3) return c == 1 ? -rz : (c == 2 ? ry : 0.0);
-    if (k == 4) return c == 0 ? rz : (c == 2 ? -rx : 0.0);
-    return c == 0 ? -ry : (c == 1 ? rx : 0.0);
-}
-
-// probing vector: sum over the aggregates of one colour of their mode `mode`
-template <int DIM>
-__global__ void __launch_bounds__(256) k_tl_fill(TLArgs t, const int32_t *__restrict__ colorOfAgg, int color, int mode, double *__restrict__ v) {
-    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < t.nDoF; n += (int64_t)gridDim.x * 256) {
-        const int a = t.aggOfDof[n];
-        const bool on = colorOfAgg[a] == color;
-        double rp[3] = {t.relPos[n * 3], t.relPos[n * 3 + 1], t.relPos[n * 3 + 2]};
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            const bool fixed = t.fixedMask && t.fixedMask[n * DIM + c];
-            v[n * DIM + c] = (on && !fixed) ? tl_mode<DIM>(mode, c, rp) : 0.0;
-        }
-    }
-}
-
-// rc[a*nModes + k] = sum_{DoFs n of aggregate a} z_{a,k}(n) . w(n); one workgroup per aggregate
-template <int DIM>
-__global__ void __launch_bounds__(256) k_tl_restrict(TLArgs t, const int32_t *__restrict__ aggPtr, const int32_t *__restrict__ dofsByAgg,
-                                                     const double *__restrict__ w, double *__restrict__ rc) {
-    __shared__ double red[4 * 6];
-    const int a = blockIdx.x;
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int q = aggPtr[a] + threadIdx.x; q < aggPtr[a + 1]; q += 256) {
-        const int64_t n = dofsByAgg[q];
-        double rp[3] = {t.relPos[n * 3], t.relPos[n * 3 + 1], t.relPos[n * 3 + 2]};
-        double wv[DIM];
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) wv[c] = (t.fixedMask && t.fixedMask[n * DIM + c]) ? 0.0 : w[n * DIM + c];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            if (k >= t.nModes) break;
-            double s = 0;
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) s += tl_mode<DIM>(k, c, rp) * wv[c];
-            acc[k] += s;
-        }
-    }
-    const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) acc[k] = wave_sum(acc[k]);
-    if (lane == 0)
-#pragma unroll
-        for (int k = 0; k < 6; ++k) red[wv_ * 6 + k] = acc[k];
-    __syncthreads();
-    if (threadIdx.x < t.nModes) rc[a * t.nModes + threadIdx.x] = red[threadIdx.x] + red[6 + threadIdx.x] + red[12 + threadIdx.x] + red[18 + threadIdx.x];
-}
-
-// coarse operator entries from one probe: Ac[(b,l), (nbr(b,colour), mode)] = R[(b,l)]
-__global__ void __launch_bounds__(256) k_tl_scatter(int nAgg, int nModes, int nColor, const int32_t *__restrict__ nbrOfColor, int color,
-                                                    int mode, const double *__restrict__ R, double *__restrict__ Ac) {
-    const int64_t m = (int64_t)nAgg * nModes;
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < m; k += (int64_t)gridDim.x * 256) {
-        const int b = (int)(k / nModes);
-        const int a = nbrOfColor[(int64_t)b * nColor + color];
-        if (a >= 0) Ac[k * m + (int64_t)a * nModes + mode] = R[k];
-    }
-}
-
-// Coarse operator in ONE pass over the assembled K (Galerkin product Z^T K Z): one wave per block
-// row; a lane takes a block K_rc, forms T[k][l] = z_k(r)^T K_rc z_l(c) for the modes of the two
-// aggregates and adds it to Ac[(agg r, k), (agg c, l)]. Blocks inside one aggregate (the vast
-// majority) are summed across the wave first, so only one set of atomics per row reaches memory.
-// Replaces 3^dim * nModes probing SpMVs (162 in 3D).
-template <int DIM>
-__global__ void __launch_bounds__(256) k_tl_rap(TLArgs t, int64_t nRows, const int32_t *__restrict__ rowPtr, const int32_t *__restrict__ colIdx,
-                                                const double *__restrict__ vals, double *__restrict__ Ac) {
-    constexpr int NB = DIM * DIM;
-    constexpr int NM = DIM == 3 ? 6 : 3;
-    const int lane = threadIdx.x & 63;
-    const int64_t wave = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 6, nWaves = ((int64_t)gridDim.x * 256) >> 6;
-    const int64_t m = (int64_t)t.nAgg * NM;
-    for (int64_t r = wave; r < nRows; r += nWaves) {
-        const int a = t.aggOfDof[r];
-        const double rpr[3] = {t.relPos[r * 3], t.relPos[r * 3 + 1], t.relPos[r * 3 + 2]};
-        double zr[NM][DIM];
-#pragma unroll
-        for (int k = 0; k < NM; ++k)
-#pragma unroll
-            for (int x = 0; x < DIM; ++x) zr[k][x] = (t.fixedMask && t.fixedMask[r * DIM + x]) ? 0.0 : tl_mode<DIM>(k, x, rpr);
-        double acc[NM * NM];
-#pragma unroll
-        for (int q = 0; q < NM * NM; ++q) acc[q] = 0.0;
-        for (int s = rowPtr[r] + lane; s < rowPtr[r + 1]; s += 64) {
-            const int64_t c = colIdx[s];
-            const int b = t.aggOfDof[c];
-            const double rpc[3] = {t.relPos[c * 3], t.relPos[c * 3 + 1], t.relPos[c * 3 + 2]};
-            double K[NB];
-#pragma unroll
-            for (int q = 0; q < NB; ++q) K[q] = vals[tiled_index(s, q, NB)];
-            double T[NM * NM];
-#pragma unroll
-            for (int l = 0; l < NM; ++l) {
-                double zc[DIM], w[DIM];
-#pragma unroll
-                for (int y = 0; y < DIM; ++y) zc[y] = (t.fixedMask && t.fixedMask[c * DIM + y]) ? 0.0 : tl_mode<DIM>(l, y, rpc);
-#pragma unroll
-                for (int x = 0; x < DIM; ++x) {
-                    double v = 0;
-#pragma unroll
-                    for (int y = 0; y < DIM; ++y) v += K[x * DIM + y] * zc[y];
-                    w[x] = v;
-                }
-#pragma unroll
-                for (int k = 0; k < NM; ++k) {
-                    double v = 0;
-#pragma unroll
-                    for (int x = 0; x < DIM; ++x) v += zr[k][x] * w[x];
-                    T[k * NM + l] = v;
-                }
-            }
-            if (b == a) {
-#pragma unroll
-                for (int q = 0; q < NM * NM; ++q) acc[q] += T[q];
-            } else {
-#pragma unroll
-                for (int k = 0; k < NM; ++k)
-#pragma unroll
-                    for (int l = 0; l < NM; ++l) unsafeAtomicAdd(&Ac[((int64_t)a * NM + k) * m + (int64_t)b * NM + l], T[k * NM + l]);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < NM * NM; ++q) acc[q] = wave_sum(acc[q]);
-        if (lane == 0)
-#pragma unroll
-            for (int k = 0; k < NM; ++k)
-#pragma unroll
-                for (int l = 0; l < NM; ++l) unsafeAtomicAdd(&Ac[((int64_t)a * NM + k) * m + (int64_t)a * NM + l], acc[k * NM + l]);
-    }
-}
-
-// Galerkin product, aggregate-centric: one workgroup (8 waves) per ROW aggregate walks that aggregate's rows; the rows
-// (a, .) of the coarse operator are written by this workgroup alone, so nothing needs a global atomic:
-//   * blocks whose column lies in the same aggregate (the vast majority) are summed in registers over ALL rows of the wave;
-//   * blocks reaching a lattice neighbour go to an LDS table [27][NM*NM] (ds_add_f64);
-//   * anything else (no lattice information, non-adjacent aggregates) falls back to a global atomic.
-// The per-row version above pays 36 atomics per row on the same few addresses (7 400 rows of an aggregate hammer one
-// 6x6 block): 68 ms at config 3; this one streams K once.
-template <int DIM>
-__global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__restrict__ aggPtr, const int32_t *__restrict__ dofsByAgg,
-                                                     const int32_t *__restrict__ binCoord /* nAgg x 3, may be null */,
-                                                     const int32_t *__restrict__ rowPtr, const int32_t *__restrict__ colIdx,
-                                                     const double *__restrict__ vals, double *__restrict__ Ac) {
-    constexpr int NB = DIM * DIM;
-    constexpr int NM = DIM == 3 ? 6 : 3;
-    constexpr int NSLOT = DIM == 3 ? 27 : 9;
-    __shared__ double nbr[NSLOT * NM * NM];
-    __shared__ int nbrAgg[NSLOT];
-    __shared__ double diagRed[16 * NM * NM];
-    const int a = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
-    const int64_t m = (int64_t)t.nAgg * NM;
-    for (int q = threadIdx.x; q < NSLOT * NM * NM; q += blockDim.x) nbr[q] = 0.0;
-    if (threadIdx.x < NSLOT) nbrAgg[threadIdx.x] = -1;
-    __syncthreads();
-    int ca[3] = {0, 0, 0};
-    if (binCoord) { ca[0] = binCoord[a * 3]; ca[1] = binCoord[a * 3 + 1]; ca[2] = binCoord[a * 3 + 2]; }
-    double acc[NM * NM];
-#pragma unroll
-    for (int q = 0; q < NM * NM; ++q) acc[q] = 0.0;
-    for (int p = aggPtr[a] + wave; p < aggPtr[a + 1]; p += nWaves) {
-        const int64_t r = dofsByAgg[p];
-        const double rpr[3] = {t.relPos[r * 3], t.relPos[r * 3 + 1], t.relPos[r * 3 + 2]};
-        double zr[NM][DIM];
-#pragma unroll
-        for (int k = 0; k < NM; ++k)
-#pragma unroll
-            for (int x = 0; x < DIM; ++x) zr[k][x] = (t.fixedMask && t.fixedMask[r * DIM + x]) ? 0.0 : tl_mode<DIM>(k, x, rpr);
-        for (int s = rowPtr[r] + lane; s < rowPtr[r + 1]; s += 64) {
-            const int64_t c = colIdx[s];
-            const int b = t.aggOfDof[c];
-            const double rpc[3] = {t.relPos[c * 3], t.relPos[c * 3 + 1], t.relPos[c * 3 + 2]};
-            double K[NB];
-#pragma unroll
-            for (int q = 0; q < NB; ++q) K[q] = vals[tiled_index(s, q, NB)];
-            double T[NM * NM];
-#pragma unroll
-            for (int l = 0; l < NM; ++l) {
-                double zc[DIM], w[DIM];
-#pragma unroll
-                for (int y = 0; y < DIM; ++y) zc[y] = (t.fixedMask && t.fixedMask[c * DIM + y]) ? 0.0 : tl_mode<DIM>(l, y, rpc);
-#pragma unroll
-                for (int x = 0; x < DIM; ++x) {
-                    double v = 0;
-#pragma unroll
-                    for (int y = 0; y < DIM; ++y) v += K[x * DIM + y] * zc[y];
-                    w[x] = v;
-                }
-#pragma unroll
-                for (int k = 0; k < NM; ++k) {
-                    double v = 0;
-#pragma unroll
-                    for (int x = 0; x < DIM; ++x) v += zr[k][x] * w[x];
-                    T[k * NM + l] = v;
-                }
-            }
-            if (b == a) {
-#pragma unroll
-                for (int q = 0; q < NM * NM; ++q) acc[q] += T[q];
-                continue;
-            }
-            int slot = -1;
-            if (binCoord) {
-                const int dx = binCoord[b * 3] - ca[0], dy = binCoord[b * 3 + 1] - ca[1], dz = binCoord[b * 3 + 2] - ca[2];
-                if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1) slot = (dx + 1) + 3 * (dy + 1) + (DIM == 3 ? 9 * (dz + 1) : 0);
-            }
-            if (slot >= 0) {
-                nbrAgg[slot] = b;     // every writer stores the same value
-#pragma unroll
-                for (int q = 0; q < NM * NM; ++q) unsafeAtomicAdd(&nbr[slot * NM * NM + q], T[q]);
-            } else {
-#pragma unroll
-                for (int k = 0; k < NM; ++k)
-#pragma unroll
-                    for (int l = 0; l < NM; ++l) unsafeAtomicAdd(&Ac[((int64_t)a * NM + k) * m + (int64_t)b * NM + l], T[k * NM + l]);
-            }
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < NM * NM; ++q) acc[q] = wave_sum(acc[q]);
-    if (lane == 0)
-#pragma unroll
-        for (int q = 0; q < NM * NM; ++q) diagRed[wave * NM * NM + q] = acc[q];
-    __syncthreads();
-    // rows (a, .) of Ac belong to this workgroup: plain read-modify-write (the fallback atomics above may have touched them too)
-    for (int q = threadIdx.x; q < NM * NM; q += blockDim.x) {
-        double v = 0;
-        for (int w = 0; w < nWaves; ++w) v += diagRed[w * NM * NM + q];
-        unsafeAtomicAdd(&Ac[((int64_t)a * NM + q / NM) * m + (int64_t)a * NM + q % NM], v);
-    }
-    for (int q = threadIdx.x; q < NSLOT * NM * NM; q += blockDim.x) {
-        const int slot = q / (NM * NM), e = q - slot * NM * NM;
-        const int b = nbrAgg[slot];
-        if (b < 0) continue;
-        unsafeAtomicAdd(&Ac[((int64_t)a * NM + e / NM) * m + (int64_t)b * NM + e % NM], nbr[q]);
-    }
-}
-
-// symmetrise the raw coarse operator into the padded matrix the dense inverse works on; modes without
-// support (dead) are decoupled, the diagonal gets a tiny relative shift, the padding is scaled identity
-__global__ void __launch_bounds__(256) k_tl_prep(int64_t m, int64_t mp, const double *__restrict__ Ac, const uint8_t *__restrict__ dead,
-                                                 double maxd, double *__restrict__ Ap) {
-    const int64_t total = mp * mp;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t i = e / mp, j = e - i * mp;
-        double v;
-        if (i >= m || j >= m) v = (i == j) ? maxd : 0.0;
-        else if (dead[i] || dead[j]) v = (i == j) ? maxd : 0.0;
-        else {
-            v = 0.5 * (Ac[i * m + j] + Ac[j * m + i]);
-            if (i == j) v *= 1.0 + 1e-10;
-        }
-        Ap[e] = v;
-    }
-}
-
-// y = A x for the dense coarse inverse (row-major m x m); one workgroup per row
-__global__ void __launch_bounds__(256) k_tl_gemv(int64_t m, int64_t ld, const double *__restrict__ A, const double *__restrict__ x, double *__restrict__ y) {
-    __shared__ double red[8];
-    const int64_t row = blockIdx.x;
-    double acc[1] = {0};
-    for (int64_t j = threadIdx.x; j < m; j += 256) acc[0] += A[row * ld + j] * x[j];
-    block_sum<1>(acc, red);
-    if (threadIdx.x == 0) y[row] = acc[0];
-}
-
-// z = D^-1 r + Z yc ; optionally accumulates r.z into *rzOut
-template <int DIM>
-__global__ void __launch_bounds__(256) k_tl_apply(TLArgs t, const double *__restrict__ dinv, const double *__restrict__ r,
-                                                  const double *__restrict__ yc, double *__restrict__ z, double *scal, int it,
-                                                  const double *stopPtr) {
-    __shared__ double red[8];
-    double *rzOut = nullptr;
-    if (scal) {
-        it += (int)stopPtr[3];
-        if (it >= 0 && scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
-        rzOut = scal + (int64_t)(it + 1) * 4;
-    }
-    double acc[1] = {0};
-    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < t.nDoF; n += (int64_t)gridDim.x * 256) {
-        double rv[DIM], zv[DIM];
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) rv[c] = r[n * DIM + c];
-        apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
-        const int a = t.aggOfDof[n];
-        double rp[3] = {t.relPos[n * 3], t.relPos[n * 3 + 1], t.relPos[n * 3 + 2]};
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            if (k >= t.nModes) break;
-            const double y = yc[(int64_t)a * t.nModes + k];
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) zv[c] += y * tl_mode<DIM>(k, c, rp);
-        }
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            if (t.fixedMask && t.fixedMask[n * DIM + c]) zv[c] = rv[c];   // identity on fixed variables (r is 0 there)
-            z[n * DIM + c] = zv[c];
-            acc[0] += rv[c] * zv[c];
-        }
-    }
-    if (rzOut) {
-        block_sum<1>(acc, red);
-        if (threadIdx.x == 0) unsafeAtomicAdd(rzOut, acc[0]);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Dense SPD inverse on the device for the coarse operator (m <= ~16k): blocked Cholesky with 64x64
-// tiles -> L^-1 by block forward substitution -> A^-1 = L^-T L^-1. FP64, LDS-tiled 4x4 micro-tiles.
-// The matrix is padded to a multiple of 64 with an identity block by the caller, so every tile is full.
-// (rocSOLVER is deliberately not used: PyTorch wheels ship their own rocBLAS/rocSOLVER and mixing the
-// two ROCm stacks in one process is not safe.)
-// ------------------------------------------------------------------------------------------------
-constexpr int DT = 64;         // tile edge
-constexpr int DTP = DT + 1;    // LDS leading dimension (bank-conflict padding)
-
-// C(64x64, registers 4x4 per thread) += A_s(64x64) * B_s(64x64), both in LDS as [row][DTP]
-DEV void dense_tile_mma(const double *As, const double *Bs, double (&c)[4][4], int ty, int tx) {
-#pragma unroll 4
-    for (int q = 0; q < DT; ++q) {
-        double a[4], b[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) a[i] = As[(ty * 4 + i) * DTP + q];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = Bs[q * DTP + tx * 4 + j];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) c[i][j] += a[i] * b[j];
-    }
-}
-// load a 64x64 tile of a row-major matrix (leading dim ld) into LDS, optionally transposed
-DEV void dense_tile_load(const double *__restrict__ G, int64_t ld, double *S, bool transpose) {
-    for (int e = threadIdx.x; e < DT * DT; e += 256) {
-        const int r = e / DT, c = e % DT;
-        const double v = G[(int64_t)r * ld + c];
-        if (transpose) S[c * DTP + r] = v; else S[r * DTP + c] = v;
-    }
-}
-
-// diagonal tile: Cholesky in LDS, L_kk written back (upper zeroed), its inverse to Dinv; *notSpd set on failure
-__global__ void __launch_bounds__(256) k_dense_potrf(double *A, int64_t ld, int k, double *Dinv, int *notSpd) {
-    __shared__ double L[DT * DTP];
-    __shared__ double X[DT * DTP];
-    double *Akk = A + ((int64_t)k * DT) * ld + (int64_t)k * DT;
-    dense_tile_load(Akk, ld, L, false);
-    __syncthreads();
-    for (int j = 0; j < DT; ++j) {
-        if (threadIdx.x == 0) {
-            const double d = L[j * DTP + j];
-            if (!(d > 0)) { *notSpd = 1; L[j * DTP + j] = 1.0; } else L[j * DTP + j] = sqrt(d);
-        }
-        __syncthreads();
-        const double djj = L[j * DTP + j];
-        for (int i = j + 1 + threadIdx.x; i < DT; i += 256) L[i * DTP + j] /= djj;
-        __syncthreads();
-        // trailing update of the lower triangle: L[i][c] -= L[i][j] * L[c][j], j < c <= i
-        const int rem = DT - j - 1;
-        for (int e = threadIdx.x; e < rem * rem; e += 256) {
-            const int i = j + 1 + e / rem, c = j + 1 + e % rem;
-            if (c <= i) L[i * DTP + c] -= L[i * DTP + j] * L[c * DTP + j];
-        }
-        __syncthreads();
-    }
-    // X = L^-1 (lower): one thread per column
-    if (threadIdx.x < DT) {
-        const int c = threadIdx.x;
-        for (int i = 0; i < DT; ++i) {
-            if (i < c) { X[i * DTP + c] = 0.0; continue; }
-            double sacc = (i == c) ? 1.0 : 0.0;
-            for (int q = c; q < i; ++q) sacc -= L[i * DTP + q] * X[q * DTP + c];
-            X[i * DTP + c] = sacc / L[i * DTP + i];
-        }
-    }
-    __syncthreads();
-    for (int e = threadIdx.x; e < DT * DT; e += 256) {
-        const int r = e / DT, c = e % DT;
-        Akk[(int64_t)r * ld + c] = c <= r ? L[r * DTP + c] : 0.0;
-        Dinv[(int64_t)k * DT * DT + e] = X[r * DTP + c];
-    }
-}
-
-// panel: L_ik = A_ik * Linv_kk^T for i > k
-__global__ void __launch_bounds__(256) k_dense_trsm(double *A, int64_t ld, int k, const double *Dinv) {
-    __shared__ double As[DT * DTP];
-    __shared__ double Bs[DT * DTP];
-    const int i = k + 1 + blockIdx.x;
-    double *Aik = A + ((int64_t)i * DT) * ld + (int64_t)k * DT;
-    dense_tile_load(Aik, ld, As, false);
-    dense_tile_load(Dinv + (int64_t)k * DT * DT, DT, Bs, true);     // Bs[q][c] = Linv[c][q]
-    __syncthreads();
-    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
-    double c[4][4] = {};
-    dense_tile_mma(As, Bs, c, ty, tx);
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) Aik[(int64_t)(ty * 4 + a) * ld + tx * 4 + b] = c[a][b];
-}
-
-// trailing update: A_ij -= L_ik L_jk^T for k < j <= i ; 2D grid over (i-k-1, j-k-1)
-__global__ void __launch_bounds__(256) k_dense_syrk(double *A, int64_t ld, int k) {
-    const int i = k + 1 + blockIdx.y, j = k + 1 + blockIdx.x;
-    if (j > i) return;
-    __shared__ double As[DT * DTP];
-    __shared__ double Bs[DT * DTP];
-    dense_tile_load(A + ((int64_t)i * DT) * ld + (int64_t)k * DT, ld, As, false);
-    dense_tile_load(A + ((int64_t)j * DT) * ld + (int64_t)k * DT, ld, Bs, true);   // Bs[q][c] = L_jk[c][q]
-    __syncthreads();
-    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
-    double c[4][4] = {};
-    dense_tile_mma(As, Bs, c, ty, tx);
-    double *Aij = A + ((int64_t)i * DT) * ld + (int64_t)j * DT;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) Aij[(int64_t)(ty * 4 + a) * ld + tx * 4 + b] -= c[a][b];
-}
-
-// X = L^-1, sub-diagonal d: X_{c+d,c} = -Linv_{c+d} * sum_{q=c}^{c+d-1} L_{c+d,q} X_{q,c}; d = 0 copies Linv
-__global__ void __launch_bounds__(256) k_dense_trinv(const double *A, double *X, int64_t ld, int d, const double *Dinv) {
-    __shared__ double As[DT * DTP];
-    __shared__ double Bs[DT * DTP];
-    const int cblk = blockIdx.x, i = cblk + d;
-    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
-    double *Xic = X + ((int64_t)i * DT) * ld + (int64_t)cblk * DT;
-    if (d == 0) {
-        for (int e = threadIdx.x; e < DT * DT; e += 256) Xic[(int64_t)(e / DT) * ld + e % DT] = Dinv[(int64_t)i * DT * DT + e];
-        return;
-    }
-    double s[4][4] = {};
-    for (int q = cblk; q < i; ++q) {
-        __syncthreads();
-        dense_tile_load(A + ((int64_t)i * DT) * ld + (int64_t)q * DT, ld, As, false);
-        dense_tile_load(X + ((int64_t)q * DT) * ld + (int64_t)cblk * DT, ld, Bs, false);
-        __syncthreads();
-        dense_tile_mma(As, Bs, s, ty, tx);
-    }
-    __syncthreads();
-    // As <- Linv_ii, Bs <- S ; X_ic = -Linv_ii * S
-    dense_tile_load(Dinv + (int64_t)i * DT * DT, DT, As, false);
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) Bs[(ty * 4 + a) * DTP + tx * 4 + b] = s[a][b];
-    __syncthreads();
-    double c[4][4] = {};
-    dense_tile_mma(As, Bs, c, ty, tx);
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) Xic[(int64_t)(ty * 4 + a) * ld + tx * 4 + b] = -c[a][b];
-}
-
-// Ainv_IJ = sum_{Q >= I} X_QI^T X_QJ for J <= I (and its mirror); 2D grid (J, I)
-// L^-1 by recursive doubling instead of 94 dependent diagonal sweeps: with the inverses X11, X22 of two adjacent
-// diagonal blocks of bt tiles known, the block below the diagonal is X21 = -X22 (L21 X11): two batched tile GEMMs per
-// level, log2(nt) levels, every tile of a level independent.   step 1: W = L21 X11 (W in scratch), step 2: X21 = -X22 W.
-__global__ void __launch_bounds__(256) k_dense_linv_level(const double *__restrict__ L, double *X, double *W, int64_t ld, int nt, int bt, int step) {
-    __shared__ double As[DT * DTP];
-    __shared__ double Bs[DT * DTP];
-    const int pair = blockIdx.z, c0 = 2 * pair * bt, r0 = c0 + bt;
-    const int I = blockIdx.y, J = blockIdx.x;
-    if (r0 + I >= nt || r0 + I >= r0 + bt) return;
-    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
-    double c[4][4] = {};
-    if (step == 1) {
-        for (int q = J; q < bt; ++q) {            // X11 is lower triangular: tiles (q, J) with q >= J
-            __syncthreads();
-            dense_tile_load(L + ((int64_t)(r0 + I) * DT) * ld + (int64_t)(c0 + q) * DT, ld, As, false);
-            dense_tile_load(X + ((int64_t)(c0 + q) * DT) * ld + (int64_t)(c0 + J) * DT, ld, Bs, false);
-            __syncthreads();
-            dense_tile_mma(As, Bs, c, ty, tx);
-        }
-        double *o = W + ((int64_t)(r0 + I) * DT) * ld + (int64_t)(c0 + J) * DT;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) o[(int64_t)(ty * 4 + a) * ld + tx * 4 + b] = c[a][b];
-    } else {
-        for (int q = 0; q <= I; ++q) {            // X22 is lower triangular: tiles (I, q) with q <= I
-            __syncthreads();
-            dense_tile_load(X + ((int64_t)(r0 + I) * DT) * ld + (int64_t)(r0 + q) * DT, ld, As, false);
-            dense_tile_load(W + ((int64_t)(r0 + q) * DT) * ld + (int64_t)(c0 + J) * DT, ld, Bs, false);
-            __syncthreads();
-            dense_tile_mma(As, Bs, c, ty, tx);
-        }
-        double *o = X + ((int64_t)(r0 + I) * DT) * ld + (int64_t)(c0 + J) * DT;
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) o[(int64_t)(ty * 4 + a) * ld + tx * 4 + b] = -c[a][b];
-    }
-}
-__global__ void __launch_bounds__(256) k_dense_xtx(const double *X, double *Ainv, int64_t ld, int nt) {
-    const int I = blockIdx.y, J = blockIdx.x;
-    if (J > I) return;
-    __shared__ double As[DT * DTP];
-    __shared__ double Bs[DT * DTP];
-    const int ty = threadIdx.x / 16, tx = threadIdx.x % 16;
-    double c[4][4] = {};
-    for (int Q = I; Q < nt; ++Q) {
-        __syncthreads();
-        dense_tile_load(X + ((int64_t)Q * DT) * ld + (int64_t)I * DT, ld, As, true);    // As[r][q] = X_QI[q][r]
-        dense_tile_load(X + ((int64_t)Q * DT) * ld + (int64_t)J * DT, ld, Bs, false);
-        __syncthreads();
-        dense_tile_mma(As, Bs, c, ty, tx);
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int r = ty * 4 + a, cc = tx * 4 + b;
-            Ainv[((int64_t)I * DT + r) * ld + (int64_t)J * DT + cc] = c[a][b];
-            Ainv[((int64_t)J * DT + cc) * ld + (int64_t)I * DT + r] = c[a][b];
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
-// PCG vector kernels. scal[it*4 + {0: r.z, 1: p.Ap, 2: r.r}] hold the reductions of iteration `it`
-// (array zero-filled once per solve; nothing is reset inside the loop).
-// ------------------------------------------------------------------------------------------------
-template <int DIM>
-__global__ void __launch_bounds__(256) k_pcg_init(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ b,
-                                                  double *__restrict__ x, double *__restrict__ r, double *__restrict__ z,
-                                                  double *__restrict__ p, double *scal) {
-    __shared__ double red[16];
-    double acc[2] = {0, 0};
-    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nRows; n += (int64_t)gridDim.x * 256) {
-        double rv[DIM], zv[DIM];
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) rv[c] = b[n * DIM + c];
-        apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            x[n * DIM + c] = 0.0; r[n * DIM + c] = rv[c]; z[n * DIM + c] = zv[c]; p[n * DIM + c] = zv[c];
-            acc[0] += rv[c] * zv[c]; acc[1] += rv[c] * rv[c];
-        }
-    }
-    block_sum<2>(acc, red);
-    if (threadIdx.x == 0) { unsafeAtomicAdd(&scal[0], acc[0]); unsafeAtomicAdd(&scal[2], acc[1]); }
-}
-
-// x += alpha p ; r -= alpha Ap ; z = Dinv r ; scal[it+1].{rz,rr} += ...
-template <int DIM, bool SKIPZ = false>
-__global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ p,
-                                                    const double *__restrict__ Ap, double *__restrict__ x, double *__restrict__ r,
-                                                    double *__restrict__ z, double *scal, int it, const double *stopPtr) {
-    __shared__ double red[16];
-    it += (int)stopPtr[3];
-    if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
-    const double alpha = scal[(int64_t)it * 4 + 0] / scal[(int64_t)it * 4 + 1];
-    double acc[2] = {0, 0};
-    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nRows; n += (int64_t)gridDim.x * 256) {
-        double rv[DIM], zv[DIM];
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            const int64_t g = n * DIM + c;
-            x[g] += alpha * p[g];
-            rv[c] = r[g] - alpha * Ap[g];
-            r[g] = rv[c];
-        }
-        if (!SKIPZ) {
-            apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
-#pragma unroll
-            for (int c = 0; c < DIM; ++c) { z[n * DIM + c] = zv[c]; acc[0] += rv[c] * zv[c]; }
-        }
-#pragma unroll
-        for (int c = 0; c < DIM; ++c) acc[1] += rv[c] * rv[c];
-    }
-    block_sum<2>(acc, red);
-    if (threadIdx.x == 0) {
-        if (!SKIPZ) unsafeAtomicAdd(&scal[(int64_t)(it + 1) * 4 + 0], acc[0]);
-        unsafeAtomicAdd(&scal[(int64_t)(it + 1) * 4 + 2], acc[1]);
-    }
-}
-
-// p = z + beta p
-__global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, const double *__restrict__ z, double *__restrict__ p,
-                                                       const double *scal, int it, const double *stopPtr) {
-    it += (int)stopPtr[3];
-    if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
-    const double beta = scal[(int64_t)(it + 1) * 4 + 0] / scal[(int64_t)it * 4 + 0];
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) p[k] = z[k] + beta * p[k];
-}
-
-// distributed PCG building blocks: the scalars live in device memory (results of RCCL all-reduces), so no host sync
-// x += a p ; r -= a Ap  with a = num[0] / den[0]
-__global__ void __launch_bounds__(256) k_dev_update_xr(int64_t n, const double *num, const double *den, const double *__restrict__ p,
-                                                       const double *__restrict__ Ap, double *__restrict__ x, double *__restrict__ r) {
-    const double a = num[0] / den[0];
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
-        x[k] += a * p[k];
-        r[k] -= a * Ap[k];
-    }
-}
-// p = z + b p  with b = num[0] / den[0]
-__global__ void __launch_bounds__(256) k_dev_direction(int64_t n, const double *num, const double *den, const double *__restrict__ z,
-                                                       double *__restrict__ p) {
-    const double b = num[0] / den[0];
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) p[k] = z[k] + b * p[k];
-}
-// out[0] = r.z, out[1] = r.r (out zeroed by the caller)
-__global__ void __launch_bounds__(256) k_dev_dots(int64_t n, const double *__restrict__ r, const double *__restrict__ z, double *out) {
-    __shared__ double red[16];
-    double acc[2] = {0, 0};
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) { acc[0] += r[k] * z[k]; acc[1] += r[k] * r[k]; }
-    block_sum<2>(acc, red);
-    if (threadIdx.x == 0) { unsafeAtomicAdd(&out[0], acc[0]); unsafeAtomicAdd(&out[1], acc[1]); }
-}
-
-// stop[3] += n: advances the iteration base at the end of a captured block of PCG iterations
-__global__ void k_advance_base(double *stop, double n) { stop[3] += n; }
-
-__global__ void __launch_bounds__(256) k_axpby(int64_t n, double a, const double *__restrict__ x, double b, double *__restrict__ y) {
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
-        y[k] = a * x[k] + (b == 0.0 ? 0.0 : b * y[k]);
-}
-__global__ void __launch_bounds__(256) k_mask(int64_t n, const uint8_t *__restrict__ m, double *__restrict__ v) {
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
-        if (m[k]) v[k] = 0.0;
-}
-__global__ void __launch_bounds__(256) k_scatter_values(int64_t n, const int64_t *__restrict__ idx, const double *__restrict__ val,
-                                                        double *__restrict__ v) {
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) v[idx[k]] = val[k];
-}
-__global__ void __launch_bounds__(256) k_dot(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *out) {
-    __shared__ double red[8];
-    double acc[1] = {0};
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) acc[0] += a[k] * b[k];
-    block_sum<1>(acc, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, acc[0]);
-}
-// tiled -> array-of-blocks (export)
-__global__ void __launch_bounds__(256) k_untile(int NB, int64_t nnzb, const double *__restrict__ tiled, double *__restrict__ aos) {
-    const int64_t total = nnzb * NB;
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
-        const int64_t s = k / NB;
-        const int c = (int)(k - s * NB);
-        aos[k] = tiled[tiled_index(s, c, NB)];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
-static inline int grid_for(int64_t n, int cap = 2048) {
-    int64_t g = (n + 255) / 256;
-    return (int)std::max<int64_t>(1, std::min<int64_t>(g, cap));
-}
-#define CHECK_LAUNCH() MFH_HIP(hipGetLastError())
 
 void launch_geometry(int dim, int /*deg*/, int /*mat*/, int64_t nElem, const int32_t *elemNodes, int npe, const double *vertPos,
                      const double *matParams, int matMode, double *geo, int geoStride, int *negCount, hipStream_t s) {
@@ -2450,168 +1620,6 @@ void launch_spmv_mf_cluster(const SpmvMfArgs &a, const double *x, double *y, dou
     else hipLaunchKernelGGL((k_mf_rows<D, false>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr)
     if (a.dim == 3) { ROWS(3); } else { ROWS(2); }
 #undef ROWS
-    CHECK_LAUNCH();
-}
-
-void launch_untile_vals(int dim, int64_t nnzb, const double *tiled, double *aos, hipStream_t s) {
-    if (!nnzb) return;
-    hipLaunchKernelGGL(k_untile, dim3(grid_for(nnzb * dim * dim, 8192)), dim3(256), 0, s, dim * dim, nnzb, tiled, aos);
-    CHECK_LAUNCH();
-}
-
-void launch_extract_diag_inv(int dim, int64_t nRows, const int32_t *rowPtr, const int32_t *colIdx, const double *vals,
-                             const uint8_t *fixedMask, int kind, double *dinv, hipStream_t s) {
-    const int grid = (int)((nRows + 255) / 256);
-    if (dim == 1) hipLaunchKernelGGL(k_diag_inv<1>, dim3(grid), dim3(256), 0, s, nRows, rowPtr, colIdx, vals, fixedMask, kind, dinv);
-    else if (dim == 3) hipLaunchKernelGGL(k_diag_inv<3>, dim3(grid), dim3(256), 0, s, nRows, rowPtr, colIdx, vals, fixedMask, kind, dinv);
-    else hipLaunchKernelGGL(k_diag_inv<2>, dim3(grid), dim3(256), 0, s, nRows, rowPtr, colIdx, vals, fixedMask, kind, dinv);
-    CHECK_LAUNCH();
-}
-
-void launch_precond(int dim, int64_t nRows, const double *dinv, const double *r, double *z, hipStream_t s) {
-    if (dim == 1) hipLaunchKernelGGL(k_precond<1>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, r, z);
-    else if (dim == 3) hipLaunchKernelGGL(k_precond<3>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, r, z);
-    else hipLaunchKernelGGL(k_precond<2>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, r, z);
-    CHECK_LAUNCH();
-}
-
-void launch_pcg_init(int dim, int64_t nRows, const double *dinv, const double *b, double *x, double *r, double *z, double *p,
-                     double *scal, hipStream_t s) {
-    if (dim == 1) hipLaunchKernelGGL(k_pcg_init<1>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal);
-    else if (dim == 3) hipLaunchKernelGGL(k_pcg_init<3>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal);
-    else hipLaunchKernelGGL(k_pcg_init<2>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal);
-    CHECK_LAUNCH();
-}
-
-void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double *p, const double *Ap, double *x, double *r,
-                       double *z, double *scal, int it, const double *stopPtr, hipStream_t s) {
-    if (dim == 1) hipLaunchKernelGGL((k_pcg_update<1, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
-    else if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
-    else hipLaunchKernelGGL((k_pcg_update<2, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
-    CHECK_LAUNCH();
-}
-
-void launch_pcg_update_noz(int dim, int64_t nRows, const double *p, const double *Ap, double *x, double *r, double *scal, int it,
-                           const double *stopPtr, hipStream_t s) {
-    if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, true>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, (const double *)nullptr, p, Ap, x, r, (double *)nullptr, scal, it, stopPtr);
-    else hipLaunchKernelGGL((k_pcg_update<2, true>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, (const double *)nullptr, p, Ap, x, r, (double *)nullptr, scal, it, stopPtr);
-    CHECK_LAUNCH();
-}
-
-void launch_tl_fill(const TLArgs &t, const int32_t *colorOfAgg, int color, int mode, double *v, hipStream_t s) {
-    if (t.dim == 3) hipLaunchKernelGGL(k_tl_fill<3>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, colorOfAgg, color, mode, v);
-    else hipLaunchKernelGGL(k_tl_fill<2>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, colorOfAgg, color, mode, v);
-    CHECK_LAUNCH();
-}
-void launch_tl_restrict(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const double *w, double *rc, hipStream_t s) {
-    if (t.dim == 3) hipLaunchKernelGGL(k_tl_restrict<3>, dim3(t.nAgg), dim3(256), 0, s, t, aggPtr, dofsByAgg, w, rc);
-    else hipLaunchKernelGGL(k_tl_restrict<2>, dim3(t.nAgg), dim3(256), 0, s, t, aggPtr, dofsByAgg, w, rc);
-    CHECK_LAUNCH();
-}
-void launch_tl_scatter(int nAgg, int nModes, int nColor, const int32_t *nbrOfColor, int color, int mode, const double *R, double *Ac,
-                       hipStream_t s) {
-    hipLaunchKernelGGL(k_tl_scatter, dim3(grid_for((int64_t)nAgg * nModes)), dim3(256), 0, s, nAgg, nModes, nColor, nbrOfColor, color, mode, R, Ac);
-    CHECK_LAUNCH();
-}
-void launch_tl_rap(const TLArgs &t, int64_t nRows, const int32_t *rowPtr, const int32_t *colIdx, const double *vals, double *Ac,
-                   hipStream_t s) {
-    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((nRows + 3) / 4, 256 * 16));
-    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap<3>, dim3(grid), dim3(256), 0, s, t, nRows, rowPtr, colIdx, vals, Ac);
-    else hipLaunchKernelGGL(k_tl_rap<2>, dim3(grid), dim3(256), 0, s, t, nRows, rowPtr, colIdx, vals, Ac);
-    CHECK_LAUNCH();
-}
-void launch_tl_rap_agg(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const int32_t *binCoord, const int32_t *rowPtr,
-                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s) {
-    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap_agg<3>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac);
-    else hipLaunchKernelGGL(k_tl_rap_agg<2>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac);
-    CHECK_LAUNCH();
-}
-// In-place-style dense SPD inverse: A (mp x mp, mp % 64 == 0) is overwritten by its Cholesky factor, the inverse
-// goes to Ainv; X and Dinv are scratch (mp x mp and (mp/64) x 64 x 64). Returns false if A is not SPD.
-bool dense_spd_inverse_device(double *A, double *X, double *Ainv, double *Dinv, int64_t mp, int *notSpdDev, hipStream_t s) {
-    const int nt = (int)(mp / DT);
-    MFH_HIP(hipMemsetAsync(notSpdDev, 0, sizeof(int), s));
-    MFH_HIP(hipMemsetAsync(X, 0, sizeof(double) * mp * mp, s));
-    for (int k = 0; k < nt; ++k) {
-        hipLaunchKernelGGL(k_dense_potrf, dim3(1), dim3(256), 0, s, A, mp, k, Dinv, notSpdDev);
-        const int rem = nt - k - 1;
-        if (rem > 0) {
-            hipLaunchKernelGGL(k_dense_trsm, dim3(rem), dim3(256), 0, s, A, mp, k, (const double *)Dinv);
-            hipLaunchKernelGGL(k_dense_syrk, dim3(rem, rem), dim3(256), 0, s, A, mp, k);
-        }
-    }
-    // L^-1: diagonal tiles from the factorisation, then recursive doubling (Ainv doubles as scratch until the last kernel)
-    hipLaunchKernelGGL(k_dense_trinv, dim3(nt), dim3(256), 0, s, (const double *)A, X, mp, 0, (const double *)Dinv);
-    for (int bt = 1; bt < nt; bt *= 2) {
-        const dim3 grid(bt, bt, (nt + 2 * bt - 1) / (2 * bt));
-        hipLaunchKernelGGL(k_dense_linv_level, grid, dim3(256), 0, s, (const double *)A, X, Ainv, mp, nt, bt, 1);
-        hipLaunchKernelGGL(k_dense_linv_level, grid, dim3(256), 0, s, (const double *)A, X, Ainv, mp, nt, bt, 2);
-    }
-    hipLaunchKernelGGL(k_dense_xtx, dim3(nt, nt), dim3(256), 0, s, (const double *)X, Ainv, mp, nt);
-    CHECK_LAUNCH();
-    int bad = 0;
-    MFH_HIP(hipMemcpyAsync(&bad, notSpdDev, sizeof(int), hipMemcpyDeviceToHost, s));
-    MFH_HIP(hipStreamSynchronize(s));
-    return bad == 0;
-}
-
-void launch_tl_prep(int64_t m, int64_t mp, const double *Ac, const uint8_t *dead, double maxd, double *Ap, hipStream_t s) {
-    hipLaunchKernelGGL(k_tl_prep, dim3(grid_for(mp * mp, 16384)), dim3(256), 0, s, m, mp, Ac, dead, maxd, Ap);
-    CHECK_LAUNCH();
-}
-void launch_tl_gemv(int64_t m, int64_t ld, const double *A, const double *x, double *y, hipStream_t s) {
-    hipLaunchKernelGGL(k_tl_gemv, dim3((unsigned)m), dim3(256), 0, s, m, ld, A, x, y);
-    CHECK_LAUNCH();
-}
-void launch_tl_apply(const TLArgs &t, const double *dinv, const double *r, const double *yc, double *z, double *scal, int it,
-                     const double *stopPtr, hipStream_t s) {
-    if (t.dim == 3) hipLaunchKernelGGL(k_tl_apply<3>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr);
-    else hipLaunchKernelGGL(k_tl_apply<2>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr);
-    CHECK_LAUNCH();
-}
-
-void launch_dev_update_xr(int64_t n, const double *num, const double *den, const double *p, const double *Ap, double *x, double *r, hipStream_t s) {
-    hipLaunchKernelGGL(k_dev_update_xr, dim3(grid_for(n)), dim3(256), 0, s, n, num, den, p, Ap, x, r);
-    CHECK_LAUNCH();
-}
-void launch_dev_direction(int64_t n, const double *num, const double *den, const double *z, double *p, hipStream_t s) {
-    hipLaunchKernelGGL(k_dev_direction, dim3(grid_for(n)), dim3(256), 0, s, n, num, den, z, p);
-    CHECK_LAUNCH();
-}
-void launch_dev_dots(int64_t n, const double *r, const double *z, double *out, hipStream_t s) {
-    MFH_HIP(hipMemsetAsync(out, 0, 2 * sizeof(double), s));
-    hipLaunchKernelGGL(k_dev_dots, dim3(grid_for(n)), dim3(256), 0, s, n, r, z, out);
-    CHECK_LAUNCH();
-}
-
-void launch_advance_base(double *stop, int n, hipStream_t s) {
-    hipLaunchKernelGGL(k_advance_base, dim3(1), dim3(1), 0, s, stop, (double)n);
-    CHECK_LAUNCH();
-}
-
-void launch_pcg_direction(int64_t n, const double *z, double *p, const double *scal, int it, const double *stopPtr, hipStream_t s) {
-    hipLaunchKernelGGL(k_pcg_direction, dim3(grid_for(n)), dim3(256), 0, s, n, z, p, scal, it, stopPtr);
-    CHECK_LAUNCH();
-}
-
-void launch_axpby(int64_t n, double a, const double *x, double b, double *y, hipStream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_axpby, dim3(grid_for(n)), dim3(256), 0, s, n, a, x, b, y);
-    CHECK_LAUNCH();
-}
-void launch_mask(int64_t n, const uint8_t *mask, double *v, hipStream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_mask, dim3(grid_for(n)), dim3(256), 0, s, n, mask, v);
-    CHECK_LAUNCH();
-}
-void launch_scatter_values(int64_t n, const int64_t *idx, const double *val, double *v, hipStream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_scatter_values, dim3(grid_for(n)), dim3(256), 0, s, n, idx, val, v);
-    CHECK_LAUNCH();
-}
-void launch_dot(int64_t n, const double *a, const double *b, double *out, hipStream_t s) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_dot, dim3(grid_for(n)), dim3(256), 0, s, n, a, b, out);
     CHECK_LAUNCH();
 }
 

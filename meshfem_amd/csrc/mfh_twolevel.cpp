@@ -5,7 +5,7 @@
 // O(1/h) iterations on the same system. The additive coarse correction
 //     M^-1 = D^-1 + Z (Z^T K Z)^-1 Z^T,   Z = [rigid-body modes of every aggregate, masked on fixed DoFs]
 // removes the smooth error components that cause that growth; everything per-iteration runs on the
-// device (mfh_kernels.hip: k_tl_*), only this once-per-system setup touches the host.
+// device (mfh_kernels_solver.hip: k_tl_*), only this once-per-system setup touches the host.
 #include "mfh_internal.hh"
 #include <cmath>
 #include <unordered_map>
