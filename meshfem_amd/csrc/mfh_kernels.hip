@@ -1,6 +1,7 @@
 // HIP kernels for gfx950 (MI355X, CDNA4): element embedding, per-element stiffness blocks,
-// owner-computes (gather) and atomic (scatter) assembly into a tiled block-CSR, block-CSR SpMV,
-// and the fused PCG vector kernels.  All arithmetic is FP64 (the reference's Real = double,
+// owner-computes (gather) and atomic (scatter) assembly into a tiled block-CSR, block-CSR SpMV, the
+// matrix-free operators and the element-level post-processing / shape-derivative kernels (the solver-side
+// kernels are in mfh_kernels_solver.hip).  All arithmetic is FP64 (the reference's Real = double,
 // Types.hh:8); the path is HBM/LDS bound, so there is no MFMA here.
 //
 // Data layout of K values ("tiled BSR"): block slot s, component c (row-major in the dim x dim
