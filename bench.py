@@ -154,6 +154,10 @@ def run_single(args):
                 frac=alg / k_ms / 1e6 / HBM_PEAK_GBS, traffic=None if tb is None else tb / k_ms / 1e6,
                 traffic_bytes_per_launch=tb, traffic_source=tsrc, alg_bytes_per_launch=alg, kernel_ms=k_ms,
                 bytes_per_element=ALG_BYTES[(3, deg)])
+    # context: the kernel's MEASURED traffic rate against the triad rate measured on this box a minute ago
+    if roof["traffic"] is not None:
+        roof["measured_triad_GBs"] = hbm_measured["triad_GBs"]
+        roof["traffic_frac_of_measured_triad"] = roof["traffic"] / hbm_measured["triad_GBs"]
     nr, nc, nnzb = c.matrix_info()
     out = dict(metric="stiffness_assembly_elements_per_s", value=value, unit="elements/s", n_gpus=1, steps=args.steps,
                warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, scaling="weak", vs_baseline=None,
