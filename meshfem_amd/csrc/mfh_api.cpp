@@ -1098,9 +1098,12 @@ mfh_status mfh_apply_periodic_conditions(mfh_ctx *c, double eps, int64_t *nDoF) 
     std::vector<int32_t> dof;
     int64_t nd = 0;
     periodic_dof_map(c->mesh, eps, dof, nd, c->mesh.bdryInternal, c->periodicIgnoreMismatch, c->periodicIgnoreDims);
+    if (nDoF) *nDoF = nd;
+    // the same identification as before (e.g. re-applied after a vertex update that left the cell faces alone):
+    // pattern, lists and fixed variables stay valid
+    if (nd == c->nDoF && dof == c->dofForNode) return MFH_OK;
     c->dofForNode.swap(dof);
     c->nDoF = nd;
-    if (nDoF) *nDoF = nd;
     invalidate_symbolic(c);
     clear_fixed(c);
     MFH_CATCH(c)
