@@ -116,20 +116,23 @@ void ensure_geometry(mfh_ctx *c) {
         if (m.dim == 2) lam = (nu * E) / (1.0 - nu * nu);
         c->matParams[0] = lam;
     }
-    c->geoStride = c->matKind == MAT_ISO ? GEO_ISO_STRIDE : GEO_GEN_STRIDE;
+    c->geoStride = c->matKind == MAT_ISO ? GEO_ISO_STRIDE : (c->matKind == MAT_ORTHO ? GEO_ORTHO_STRIDE : GEO_GEN_STRIDE);
     c->dMatParams.upload(c->matParams, c->stream);
     c->dGeo.alloc((size_t)m.nElem * c->geoStride);
-    c->dNeg.alloc(1);
+    c->dNeg.alloc(2);   // [0] inverted elements, [1] elements with an indefinite orthotropic tensor
     c->dNeg.zero(c->stream);
     EventTimer t(c->stream);
     k::launch_geometry(m.dim, m.deg, c->matKind, m.nElem, c->dElemNodes.p, m.npe, c->dVertPos.p, c->dMatParams.p, c->matMode,
                        c->dGeo.p, c->geoStride, c->dNeg.p, c->stream);
     c->timing.geometry_ms = t.stop();
-    int neg = 0;
-    c->dNeg.download(&neg, 1, c->stream);
-    if (neg > 0)   // LinearElasticity.hh:465-472
+    int neg[2] = {0, 0};
+    c->dNeg.download(neg, 2, c->stream);
+    if (neg[0] > 0)   // LinearElasticity.hh:465-472
         throw Error(MFH_ERR_INVALID, "Mesh has negatively oriented elements.\nCorrect with: mesh_convert --reorientNegativeElements. (" +
-                                         std::to_string(neg) + " elements)");
+                                         std::to_string(neg[0]) + " elements)");
+    if (neg[1] > 0)   // the reference inverts the compliance blindly (ElasticityTensor.hh:136-164); a non-SPD K would only show up in the solver
+        throw Error(MFH_ERR_INVALID, "Orthotropic parameters of " + std::to_string(neg[1]) +
+                                         " elements give an indefinite elasticity tensor (compliance matrix not positive definite).");
     c->geoValid = true;
     c->hGeoValid = false;
 }
@@ -699,7 +702,8 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
                 // an inconsistent right-hand side: missing boundary conditions, unbalanced loads on a free body)
                 const double pAp = hs[(size_t)(k2 - lastChecked) * 4 + 1];
                 if (k2 < it && pAp < 0.0)
-                    throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (p.Kp < 0): K is not positive definite on the free variables");
+                    throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (p.Kp = " + std::to_string(pAp) + " < 0 at iteration " + std::to_string(k2) +
+                                                           ", residual^2 " + std::to_string(rr) + "): K is not positive definite on the free variables");
                 if (rr < 0.9 * bestRR) { bestRR = rr; itBest = k2; }
                 else if (k2 - itBest > stagnationWindow)
                     throw Error(MFH_ERR_NOT_CONVERGED, "PCG stagnated (no progress of the residual for " + std::to_string(stagnationWindow) +
@@ -829,6 +833,11 @@ void elem_D(const mfh_ctx *c, const double *g, double *D) {
             D[i * fl + i] = lam + 2 * mu;
         }
         for (int k = d; k < fl; ++k) D[k * fl + k] = mu;
+    } else if (c->matKind == MAT_ORTHO) {
+        int idx = 0;
+        for (int i = 0; i < d; ++i)
+            for (int j = i; j < d; ++j, ++idx) D[i * fl + j] = D[j * fl + i] = g[13 + idx];
+        for (int k = d; k < fl; ++k) D[k * fl + k] = g[13 + d * (d + 1) / 2 + k - d];
     } else {
         int idx = 0;
         for (int r = 0; r < fl; ++r)
@@ -1047,7 +1056,7 @@ mfh_status mfh_material_ortho_field(mfh_ctx *c, const double *params) {
     require(c && params && c->haveMesh, MFH_ERR_STATE, "set the mesh before the material");
     const int np = c->dim() == 3 ? 9 : 4;
     c->matParams.assign(params, params + (size_t)np * c->mesh.nElem);
-    c->matMode = 3; c->matKind = MAT_GENERAL;
+    c->matMode = 3; c->matKind = MAT_ORTHO;   // compact record: 6 + 3 (3D) / 3 + 1 (2D) stiffnesses instead of the 21 / 6 of a general D
     c->geoValid = false; c->hGeoValid = false;
     invalidate_matrix(c);
     MFH_CATCH(c)

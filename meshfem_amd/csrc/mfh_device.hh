@@ -66,6 +66,14 @@ DEV constexpr int dpack(int r, int c) {
     return a * n - a * (a - 1) / 2 + (b - a);
 }
 
+// orthotropic record (MAT_ORTHO): g[13 ..] = packed upper triangle of the DIM x DIM normal block of D, then the DIM(DIM-1)/2
+// shear stiffnesses in flattened order (yz, xz, xy | xy)
+template <int DIM> DEV constexpr int npack(int a, int b) {
+    const int lo = a <= b ? a : b, hi = a <= b ? b : a;
+    return lo * DIM - lo * (lo - 1) / 2 + (hi - lo);
+}
+template <int DIM> DEV constexpr int ortho_shear_offset() { return 13 + DIM * (DIM + 1) / 2; }
+
 // the six distinct quadrature pair coefficients (named scalars: an indexed array would go to scratch)
 struct PairConst { double vv_eq, vv_ne, ve_eq, ve_ne, ee_eq, ee_ne; };
 

@@ -112,9 +112,10 @@ static const int kEdgeEnd[6] = {1, 2, 0, 3, 3, 3};
 // upper-triangular entries of D row-major. Stride padded to a multiple of 2 doubles.
 constexpr int GEO_ISO_STRIDE = 16;      // 12 + 1 + 2 (+1 pad)  = 128 B, one cache line
 constexpr int GEO_GEN_STRIDE = 36;      // 12 + 1 + 21 (+2 pad) = 288 B
+constexpr int GEO_ORTHO_STRIDE = 24;    // 12 + 1 + 6 normal + 3 shear (+2 pad) = 192 B (orthotropic field: the zeros of D are not stored)
 
 // MAT_LAPLACE / MAT_MASS: scalar operators on the same machinery (1x1 blocks; Laplacian.hh:27-57, MassMatrix.hh:50-86)
-enum MaterialKind { MAT_ISO = 0, MAT_GENERAL = 1, MAT_LAPLACE = 2, MAT_MASS = 3 };
+enum MaterialKind { MAT_ISO = 0, MAT_GENERAL = 1, MAT_LAPLACE = 2, MAT_MASS = 3, MAT_ORTHO = 4 };
 inline bool mat_is_scalar(int mat) { return mat == MAT_LAPLACE || mat == MAT_MASS; }
 
 // ------------------------------------------------------------------------------------------------

@@ -94,6 +94,21 @@ DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pai
         for (int c = 0; c < DIM; ++c)
 #pragma unroll
             for (int d = 0; d < DIM; ++d) K[c * DIM + d] = lam * H[c][d] + mu * H[d][c] + (c == d ? mu * tr : 0.0);
+    } else if (MAT == MAT_ORTHO) {
+        // orthotropic D in its material axes: C_aadd = N[a][d], C_acac = C_acca = S(a,c) (a != c), every other entry 0
+        //   K[c][c] = N[c][c] H[c][c] + sum_{a != c} S(a,c) H[a][a] ;   K[c][d] = N[c][d] H[c][d] + S(c,d) H[d][c]   (c != d)
+#pragma unroll
+        for (int c = 0; c < DIM; ++c)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) {
+                double v = g[13 + npack<DIM>(c, d)] * H[c][d];
+                if (c == d) {
+#pragma unroll
+                    for (int a = 0; a < DIM; ++a)
+                        if (a != c) v += g[ortho_shear_offset<DIM>() + flat_idx<DIM>(a, c) - DIM] * H[a][a];
+                } else v += g[ortho_shear_offset<DIM>() + flat_idx<DIM>(c, d) - DIM] * H[d][c];
+                K[c * DIM + d] = v;
+            }
     } else {
         // C_acdb = D(flat(a,c), flat(d,b))      (ElasticityTensor.hh:274-277)
         constexpr int ND = (DIM * (DIM + 1) / 2) * (DIM * (DIM + 1) / 2 + 1) / 2;
@@ -177,7 +192,7 @@ __global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *
     } else if (matMode == 2) {
         for (int k = 0; k < ND; ++k) g[13 + k] = mp[k];
     } else if (matMode == 3) {
-        for (int k = 0; k < ND; ++k) g[13 + k] = 0.0;
+        // compact orthotropic record (MAT_ORTHO): normal block + shear stiffnesses, see npack / ortho_shear_offset
         if (DIM == 3) {
             const double *q = mp + e * 9;   // Ex,Ey,Ez,nuYX,nuZX,nuZY,muYZ,muZX,muXY  (:136-152)
             const double a00 = 1.0 / q[0], a01 = -q[3] / q[1], a02 = -q[4] / q[2], a11 = 1.0 / q[1], a12 = -q[5] / q[2],
@@ -185,15 +200,18 @@ __global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *
             const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
             const double c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
             const double det = a00 * c00 + a01 * c01 + a02 * c02;
-            g[13 + dpack<3>(0, 0)] = c00 / det; g[13 + dpack<3>(0, 1)] = c01 / det; g[13 + dpack<3>(0, 2)] = c02 / det;
-            g[13 + dpack<3>(1, 1)] = c11 / det; g[13 + dpack<3>(1, 2)] = c12 / det; g[13 + dpack<3>(2, 2)] = c22 / det;
-            g[13 + dpack<3>(3, 3)] = q[6]; g[13 + dpack<3>(4, 4)] = q[7]; g[13 + dpack<3>(5, 5)] = q[8];
+            // Sylvester on the compliance block + positive shear moduli: otherwise the tensor is indefinite (negCount[1])
+            if (!(a00 > 0 && c22 > 0 && det > 0 && q[6] > 0 && q[7] > 0 && q[8] > 0)) atomicAdd(negCount + 1, 1);
+            g[13 + npack<3>(0, 0)] = c00 / det; g[13 + npack<3>(0, 1)] = c01 / det; g[13 + npack<3>(0, 2)] = c02 / det;
+            g[13 + npack<3>(1, 1)] = c11 / det; g[13 + npack<3>(1, 2)] = c12 / det; g[13 + npack<3>(2, 2)] = c22 / det;
+            g[ortho_shear_offset<3>() + 0] = q[6]; g[ortho_shear_offset<3>() + 1] = q[7]; g[ortho_shear_offset<3>() + 2] = q[8];
         } else {
             const double *q = mp + e * 4;   // Ex,Ey,nuYX,muXY                          (:154-164)
             const double a00 = 1.0 / q[0], a01 = -q[2] / q[1], a11 = 1.0 / q[1];
             const double det = a00 * a11 - a01 * a01;
-            g[13 + dpack<2>(0, 0)] = a11 / det; g[13 + dpack<2>(0, 1)] = -a01 / det; g[13 + dpack<2>(1, 1)] = a00 / det;
-            g[13 + dpack<2>(2, 2)] = q[3];
+            if (!(a00 > 0 && det > 0 && q[3] > 0)) atomicAdd(negCount + 1, 1);
+            g[13 + npack<2>(0, 0)] = a11 / det; g[13 + npack<2>(0, 1)] = -a01 / det; g[13 + npack<2>(1, 1)] = a00 / det;
+            g[ortho_shear_offset<2>()] = q[3];
         }
     } else {
         const double *q = mp + e * FL * FL;
@@ -358,6 +376,16 @@ DEV void elem_D_apply(const double *__restrict__ g, const double *sd /* shear-do
         for (int a = 0; a < DIM; ++a) out[a] = lam * tr + 2 * mu * sd[a];
 #pragma unroll
         for (int k = DIM; k < FL; ++k) out[k] = mu * sd[k];
+    } else if (MAT == MAT_ORTHO) {
+#pragma unroll
+        for (int a = 0; a < DIM; ++a) {
+            double v = 0;
+#pragma unroll
+            for (int b = 0; b < DIM; ++b) v += g[13 + npack<DIM>(a, b)] * sd[b];
+            out[a] = v;
+        }
+#pragma unroll
+        for (int k = DIM; k < FL; ++k) out[k] = g[ortho_shear_offset<DIM>() + k - DIM] * sd[k];
     } else {
 #pragma unroll
         for (int r = 0; r < FL; ++r) {
@@ -1369,16 +1397,20 @@ void launch_geometry(int dim, int /*deg*/, int /*mat*/, int64_t nElem, const int
 // dispatch on (dim, deg, mat)
 #define MFH_DISPATCH(a, CALL)                                                            \
     do {                                                                                 \
-        const int key_ = (a.dim == 3 ? 0 : 4) + (a.deg == 2 ? 2 : 0) + (a.mat == MAT_GENERAL ? 1 : 0); \
+        const int key_ = (a.dim == 3 ? 0 : 6) + (a.deg == 2 ? 3 : 0) + (a.mat == MAT_GENERAL ? 1 : (a.mat == MAT_ORTHO ? 2 : 0)); \
         switch (key_) {                                                                  \
         case 0: { CALL(3, 1, MAT_ISO); } break;                                           \
         case 1: { CALL(3, 1, MAT_GENERAL); } break;                                       \
-        case 2: { CALL(3, 2, MAT_ISO); } break;                                           \
-        case 3: { CALL(3, 2, MAT_GENERAL); } break;                                       \
-        case 4: { CALL(2, 1, MAT_ISO); } break;                                           \
-        case 5: { CALL(2, 1, MAT_GENERAL); } break;                                       \
-        case 6: { CALL(2, 2, MAT_ISO); } break;                                           \
-        default: { CALL(2, 2, MAT_GENERAL); } break;                                      \
+        case 2: { CALL(3, 1, MAT_ORTHO); } break;                                         \
+        case 3: { CALL(3, 2, MAT_ISO); } break;                                           \
+        case 4: { CALL(3, 2, MAT_GENERAL); } break;                                       \
+        case 5: { CALL(3, 2, MAT_ORTHO); } break;                                         \
+        case 6: { CALL(2, 1, MAT_ISO); } break;                                           \
+        case 7: { CALL(2, 1, MAT_GENERAL); } break;                                       \
+        case 8: { CALL(2, 1, MAT_ORTHO); } break;                                         \
+        case 9: { CALL(2, 2, MAT_ISO); } break;                                           \
+        case 10: { CALL(2, 2, MAT_GENERAL); } break;                                      \
+        default: { CALL(2, 2, MAT_ORTHO); } break;                                        \
         }                                                                                \
     } while (0)
 

@@ -101,6 +101,30 @@ def _morton(q):
     return key
 
 
+def synthetic_orthotropic_field(n_elem, dim=3, seed=0):
+    """BASELINE configs[3]'s per-element orthotropic field: E_* in U[100,300], nu_* in U[0.2,0.35], mu_* in U[40,120]
+    (numpy default_rng(seed)), with the Poisson ratios of the rare draws whose compliance matrix is not positive definite
+    (1 element in 2 million) scaled by 0.8 until it is -- SURVEY.md 8d: "check compliance PD". 3D: columns
+    Ex,Ey,Ez,nuYX,nuZX,nuZY,muYZ,muZX,muXY; 2D: Ex,Ey,nuYX,muXY (ElasticityTensor.hh:136-164)."""
+    rng = np.random.default_rng(seed)
+    if dim == 3:
+        P = np.column_stack([rng.uniform(100, 300, (n_elem, 3)), rng.uniform(0.2, 0.35, (n_elem, 3)), rng.uniform(40, 120, (n_elem, 3))])
+        for _ in range(20):
+            a00, a11, a22 = 1 / P[:, 0], 1 / P[:, 1], 1 / P[:, 2]
+            a01, a02, a12 = -P[:, 3] / P[:, 1], -P[:, 4] / P[:, 2], -P[:, 5] / P[:, 2]
+            m2 = a00 * a11 - a01 * a01                             # Sylvester: leading minors of the compliance block
+            det = a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02)
+            bad = ~((m2 > 1e-6 * a00 * a11) & (det > 1e-6 * a00 * a11 * a22))
+            if not bad.any():
+                break
+            P[bad, 3:6] *= 0.8
+        return P
+    P = np.column_stack([rng.uniform(100, 300, (n_elem, 2)), rng.uniform(0.2, 0.35, n_elem), rng.uniform(40, 120, n_elem)])
+    bad = P[:, 2] ** 2 >= P[:, 1] / P[:, 0]                     # 1/(Ex Ey) - (nuYX/Ey)^2 > 0
+    P[bad, 2] = 0.5 * np.sqrt(P[bad, 1] / P[bad, 0])
+    return P
+
+
 def reorder_mesh(V, T, mode, seed=0):
     """Relabel vertices and permute elements: 'shuffle' (uniformly random, the worst case for gather
     locality) or 'morton' (Z-order space-filling curve on vertex positions / element barycentres).

@@ -997,3 +997,30 @@ def test_singular_inconsistent_system_is_reported_not_iterated_to_maxit():
     c.bc_neumann_box([-1e-9, -9, -9], [1e-9, 9, 9], [-1.0, -0.5, 0.0], kind=M.NEUMANN_TRACTION)
     u = c.sim_solve_constrained(flags=M.SOLVE_NO_RIGID_MOTION)
     assert np.isfinite(u).all() and c.last_info["converged"]
+
+
+@pytest.mark.gpu
+def test_indefinite_orthotropic_parameters_are_rejected_at_embedding():
+    """Orthotropic parameters whose compliance matrix is not positive definite give an indefinite elasticity tensor (the
+    reference inverts it blindly, ElasticityTensor.hh:136-164, and CHOLMOD would then refuse K); reported when the elements
+    are embedded. The synthetic config-4 field is positive definite by construction."""
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    V, T = O.grid_tet_mesh(2, 2, 1)
+    P = grid.synthetic_orthotropic_field(len(T), 3, seed=1)
+    c = M.Context(0); c.mesh_build(T, V, 1)
+    c.material_ortho_field(P); c.assemble()                           # fine
+    bad = P.copy()
+    bad[3, 3:6] = [0.9, 0.9, 0.9]                                     # Poisson ratios far outside the admissible range
+    c.material_ortho_field(bad)
+    with pytest.raises(M.MeshFEMHipError, match="indefinite elasticity tensor"):
+        c.assemble()
+    bad2 = P.copy(); bad2[0, 7] = -1.0                                # a negative shear modulus
+    c.material_ortho_field(bad2)
+    with pytest.raises(M.MeshFEMHipError, match="1 elements"):
+        c.assemble()
+    # 2 M draws of the raw config-4 distribution contain non-PD elements; the generator repairs them
+    raw = np.random.default_rng(0)
+    n = 24 * 44 ** 3
+    Q = np.column_stack([raw.uniform(100, 300, (n, 3)), raw.uniform(0.2, 0.35, (n, 3)), raw.uniform(40, 120, (n, 3))])
+    assert (np.abs(grid.synthetic_orthotropic_field(n) - Q).max(axis=1) > 0).sum() == 1
