@@ -131,8 +131,9 @@ void ensure_geometry(mfh_ctx *c) {
         throw Error(MFH_ERR_INVALID, "Mesh has negatively oriented elements.\nCorrect with: mesh_convert --reorientNegativeElements. (" +
                                          std::to_string(neg[0]) + " elements)");
     if (neg[1] > 0)   // the reference inverts the compliance blindly (ElasticityTensor.hh:136-164); a non-SPD K would only show up in the solver
-        throw Error(MFH_ERR_INVALID, "Orthotropic parameters of " + std::to_string(neg[1]) +
-                                         " elements give an indefinite elasticity tensor (compliance matrix not positive definite).");
+        throw Error(MFH_ERR_INVALID, std::string(c->matMode == 1 ? "Isotropic" : "Orthotropic") + " parameters of " + std::to_string(neg[1]) +
+                                         " elements give an indefinite elasticity tensor (" +
+                                         (c->matMode == 1 ? "need E > 0 and -1 < nu < 1/2, nu < 1 in plane stress" : "compliance matrix not positive definite") + ").");
     c->geoValid = true;
     c->hGeoValid = false;
 }

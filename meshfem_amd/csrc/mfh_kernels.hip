@@ -186,6 +186,8 @@ __global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *
     if (matMode == 0) { g[13] = mp[0]; g[14] = mp[1]; }
     else if (matMode == 1) {
         const double E = mp[e], nu = mp[nElem + e];
+        // positive definite iff E > 0 and -1 < nu < 1/2 (3D) or -1 < nu < 1 (2D plane stress)
+        if (!(E > 0 && nu > -1.0 && nu < (DIM == 3 ? 0.5 : 1.0))) atomicAdd(negCount + 1, 1);
         double lam = (nu * E) / ((1.0 + nu) * (1.0 - 2.0 * nu));
         if (DIM == 2) lam = (nu * E) / (1.0 - nu * nu);     // plane stress (ElasticityTensor.hh:108-112)
         g[13] = lam; g[14] = E / (2.0 + 2.0 * nu);

@@ -1019,6 +1019,13 @@ def test_indefinite_orthotropic_parameters_are_rejected_at_embedding():
     c.material_ortho_field(bad2)
     with pytest.raises(M.MeshFEMHipError, match="1 elements"):
         c.assemble()
+    E, nu = np.full(len(T), 200.0), np.full(len(T), 0.3)
+    nu[5] = 0.5                                                       # incompressible limit: lambda is infinite
+    c.material_iso_field(E, nu)
+    with pytest.raises(M.MeshFEMHipError, match="Isotropic parameters of 1 elements"):
+        c.assemble()
+    nu[5] = 0.3
+    c.material_iso_field(E, nu); c.assemble()
     # 2 M draws of the raw config-4 distribution contain non-PD elements; the generator repairs them
     raw = np.random.default_rng(0)
     n = 24 * 44 ** 3
