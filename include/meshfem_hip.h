@@ -146,8 +146,12 @@ mfh_status mfh_mesh_get_elem_volumes(mfh_ctx* ctx, double* out /* nElem */);
  *                             Simulate_cli.cc:116-135).
  * mfh_material_ortho_field == per-element setOrthotropic3D/2D (ElasticityTensor.hh:136-164),
  *                             params per element: 3D Ex,Ey,Ez,nuYX,nuZX,nuZY,muYZ,muZX,muXY;
- *                             2D Ex,Ey,nuYX,muXY. The compliance inverse runs on the device.
- * mfh_material_tensor_field== per-element flattened D (flatLen x flatLen each).                */
+ *                             2D Ex,Ey,nuYX,muXY. The compliance inverse runs on the device; the element
+ *                             record keeps only the normal block and the shear stiffnesses of D (192 B).
+ * mfh_material_tensor_field== per-element flattened D (flatLen x flatLen each).
+ * Per-element isotropic / orthotropic parameters that give an indefinite tensor (E <= 0, nu outside (-1, 1/2), a
+ * compliance matrix that is not positive definite, a non-positive shear modulus) are reported with MFH_ERR_INVALID when
+ * the elements are embedded (next assembly / solve): the reference inverts blindly and fails later in CHOLMOD.    */
 mfh_status mfh_material_const(mfh_ctx* ctx, const double* D);
 mfh_status mfh_material_isotropic(mfh_ctx* ctx, double E, double nu);
 mfh_status mfh_material_iso_field(mfh_ctx* ctx, const double* E, const double* nu);
