@@ -1029,11 +1029,24 @@ mfh_status mfh_material_isotropic(mfh_ctx *c, double E, double nu) {
 mfh_status mfh_material_const(mfh_ctx *c, const double *D) {
     MFH_TRY(c)
     require(c && D && c->haveMesh, MFH_ERR_STATE, "set the mesh before the material");
-    const int fl = flat_len(c->dim());
+    const int d = c->dim(), fl = flat_len(d);
     c->matParams.clear();
-    for (int r = 0; r < fl; ++r)
-        for (int cc = r; cc < fl; ++cc) c->matParams.push_back(D[r * fl + cc]);   // upper triangle (_MajorSymmetry)
-    c->matMode = 2; c->matKind = MAT_GENERAL;
+    // a tensor with the orthotropic pattern in the coordinate axes (no normal-shear coupling, diagonal shear block; every
+    // isotropic / orthotropic base material of the CLIs) takes the compact orthotropic record and kernels
+    bool ortho = true;
+    for (int r = 0; r < fl && ortho; ++r)
+        for (int cc = r + 1; cc < fl; ++cc)
+            if (cc >= d && D[r * fl + cc] != 0.0) { ortho = false; break; }
+    if (ortho) {
+        for (int r = 0; r < d; ++r)
+            for (int cc = r; cc < d; ++cc) c->matParams.push_back(D[r * fl + cc]);
+        for (int k2 = d; k2 < fl; ++k2) c->matParams.push_back(D[k2 * fl + k2]);
+        c->matMode = 5; c->matKind = MAT_ORTHO;
+    } else {
+        for (int r = 0; r < fl; ++r)
+            for (int cc = r; cc < fl; ++cc) c->matParams.push_back(D[r * fl + cc]);   // upper triangle (_MajorSymmetry)
+        c->matMode = 2; c->matKind = MAT_GENERAL;
+    }
     c->geoValid = false; c->hGeoValid = false;
     invalidate_matrix(c);
     MFH_CATCH(c)

@@ -131,7 +131,7 @@ DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pai
 
 // ------------------------------------------------------------------------------------------------
 // K1: element embedding + material record     (EmbeddedElement.hh:162-241, ElasticityTensor.hh:100-164)
-// matMode: 0 const (lambda,mu) | 1 iso field (E[],nu[]) | 2 const general D (packed upper) |
+// matMode: 0 const (lambda,mu) | 1 iso field (E[],nu[]) | 2 const general D (packed upper) | 5 const orthotropic-pattern D |
 //          3 orthotropic field (9 / 4 params per element) | 4 tensor field (flatLen^2 per element)
 // ------------------------------------------------------------------------------------------------
 template <int DIM>
@@ -193,6 +193,8 @@ __global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *
         g[13] = lam; g[14] = E / (2.0 + 2.0 * nu);
     } else if (matMode == 2) {
         for (int k = 0; k < ND; ++k) g[13 + k] = mp[k];
+    } else if (matMode == 5) {
+        for (int k = 0; k < DIM * (DIM + 1) / 2 + FL - DIM; ++k) g[13 + k] = mp[k];   // constant tensor with the orthotropic pattern
     } else if (matMode == 3) {
         // compact orthotropic record (MAT_ORTHO): normal block + shear stiffnesses, see npack / ortho_shear_offset
         if (DIM == 3) {
