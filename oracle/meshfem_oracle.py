@@ -24,7 +24,9 @@ rigid-mode null space, energy identity) and scipy.sparse.linalg.splu stands in f
 the KKT matrix for UMFPACK in the constraint-row branch). Also restated here: Laplacian.hh / MassMatrix.hh / Poisson.hh,
 both homogenized-tensor forms of PeriodicHomogenization.hh, OrthotropicHomogenization.hh (checked on the reference's
 2D_microstructure_orthocell.msh / 2D_microstructure.msh pair), assembleConstrainedSystem's rigid-motion rows, and the discrete
-shape derivatives (deltaPerElementStiffness & co., pinned on finite differences of this oracle's own operators).
+shape derivatives (deltaPerElementStiffness & co. and homogenizedElasticityTensorDiscreteDifferential, pinned on finite
+differences of this oracle's own operators), both node-matching algorithms of PeriodicBoundaryMatcher.hh (match,
+matchPermittingMismatch; ignoreDims), strainField / stressField.
 
 All `file:line` citations are relative to /root/reference/src/lib/MeshFEM/ unless noted.
 """
