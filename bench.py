@@ -97,14 +97,15 @@ def cpu_baseline(deg, cpu_grid):
 
 
 def hbm_stream_probe(torch, n_doubles=1 << 27, reps=10):
-    """Measured HBM rates of this box (peaks must be checked on the box): copy (1 read + 1 write) and triad
-    (2 reads + 1 write) over 1 GiB vectors with torch's elementwise kernels; context for the roofline fractions, which are
-    still quoted against the 8 TB/s spec."""
+    """Measured HBM rates of this box (peaks must be checked on the box): copy (1 read + 1 write), triad
+    (2 reads + 1 write), fill (write only) and a sum reduction (read only) over 1 GiB vectors with torch's kernels; context
+    for the roofline fractions, which are still quoted against the 8 TB/s spec."""
     a = torch.ones(n_doubles, dtype=torch.float64, device="cuda")
     b = torch.full((n_doubles,), 2.0, dtype=torch.float64, device="cuda")
     c = torch.empty_like(a)
     res = {}
-    for name, fn, passes in (("copy", lambda: c.copy_(a), 2), ("triad", lambda: torch.add(a, b, alpha=3.0, out=c), 3)):
+    for name, fn, passes in (("copy", lambda: c.copy_(a), 2), ("triad", lambda: torch.add(a, b, alpha=3.0, out=c), 3),
+                             ("fill", lambda: c.fill_(1.5), 1), ("read", lambda: a.sum(), 1)):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
