@@ -1,3 +1,4 @@
+"""Sweep of the cluster block size (elements per workgroup) of the matrix-free operator at the bench size."""
 import sys, os
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import meshfem_amd as M

@@ -1,3 +1,4 @@
+"""Host-side laps of Simulator::solve at the bench size: run with MFH_SOLVE_TIMING=1 (two solves: first with setup)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, meshfem_amd as M
