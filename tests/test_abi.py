@@ -57,3 +57,14 @@ def test_host_only_context_refuses_numeric_work():
             call()
         assert ei.value.code == _lib.ERR_HIP
     assert b"gfx950" in _lib.load().mfh_version()
+
+
+def test_public_header_is_plain_c99(tmp_path):
+    """The drop-in boundary is a C ABI: include/meshfem_hip.h must compile as C99 (no C++-isms, no torch / HIP types)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "c_abi_check.c"
+    src.write_text('#include "meshfem_hip.h"\nint main(void) { mfh_ctx* c = 0; (void)c; return (int)MFH_OK; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-fsyntax-only", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
