@@ -65,3 +65,26 @@ def test_facade_homogenization_on_gpu():
     _build("facade_homogenization")
     r = subprocess.run([EXE3, "0"], capture_output=True, text=True)
     assert r.returncode == 0 and "homogenization ok" in r.stdout, r.stdout + r.stderr
+
+
+EXE_C = os.path.join(ROOT, "tests", "cpp", "abi_plain_c")
+
+
+def _build_c():
+    libdir = os.path.dirname(M.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "abi_plain_c.c"), "-o", EXE_C, "-L", libdir, "-lmeshfem_hip", "-lm",
+                           "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+
+
+def test_plain_c_client_compiles_and_fails_loudly_without_device():
+    _build_c()
+    r = subprocess.run([EXE_C, "-1"], capture_output=True, text=True)
+    assert r.returncode == 3 and "2 elements, 5 nodes" in r.stdout and "no CPU fallback" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_client_on_gpu():
+    _build_c()
+    r = subprocess.run([EXE_C, "0"], capture_output=True, text=True)
+    assert r.returncode == 0 and "plain C client ok" in r.stdout, r.stdout + r.stderr
