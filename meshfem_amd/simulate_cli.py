@@ -361,6 +361,16 @@ def main(argv=None):
             np.array([len(v)], dtype=np.uint64).tofile(f); i.tofile(f); j.tofile(f); v.tofile(f)
         return 0
     regions = apply_boundary_conditions(sim, a.boundaryConditions)
+    if a.dumpMatrix:                                        # Simulate_cli.cc:195 sim.dumpSystem -> SPSDSystem::sumAndDumpUpper:
+        i, j, v = sim.assembleStiffnessMatrix()             # the REDUCED system, fixed variables removed and renumbered
+        fv, _ = sim.ctx.bc_dirichlet_vars()
+        keep = np.ones(N * sim.numDoFs(), dtype=bool)
+        keep[fv] = False
+        new = (np.cumsum(keep) - 1).astype(np.uint64)
+        sel = keep[i.astype(np.int64)] & keep[j.astype(np.int64)]
+        with open(a.dumpMatrix, "wb") as f:
+            np.array([int(sel.sum())], dtype=np.uint64).tofile(f)
+            new[i[sel].astype(np.int64)].tofile(f); new[j[sel].astype(np.int64)].tofile(f); v[sel].tofile(f)
     u = sim.solve()
     e, s = sim.averageStrainField(u), sim.averageStressField(u)
     dm, _ = sim.ctx.get_dof_map()

@@ -111,6 +111,23 @@ def test_simulate_cli_cantilever_config1(tmp_path, deg, capsys):
     eps = sim.averageStrainField(u_ref)
     M9 = F["strain"][1].reshape(-1, 3, 3)
     assert np.abs(M9[:, [0, 1, 2, 1, 0, 0], [0, 1, 2, 2, 2, 1]] - eps).max() < 1e-6 * np.abs(eps).max()
+    # --dumpMatrix WITH boundary conditions dumps the reduced SPSDSystem (Simulate_cli.cc:195, SparseMatrices.hh:2649-2655)
+    kred = str(tmp_path / "Kred.bin")
+    assert simulate_cli.main([mesh, "-m", os.path.join(GOLD, "B9Creator.material"), "-b", os.path.join(GOLD, "cantilever.bc"),
+                              "-d", str(deg), "-o", out, "--dumpMatrix", kred, "--rtol", "1e-10"]) == 0
+    raw = np.fromfile(kred, dtype=np.uint64)
+    nnzr = int(raw[0])
+    ir, jr = raw[1:1 + nnzr].astype(np.int64), raw[1 + nnzr:1 + 2 * nnzr].astype(np.int64)
+    vr = np.fromfile(kred, dtype=np.float64)[1 + 2 * nnzr:]
+    Ksys = O.SPSDSystem(sim.assembleStiffnessMatrix())
+    fvo, fxo = sim.dirichlet_vars_and_values()
+    Ksys.fix_variables(fvo, fxo)
+    Ksys.A.sum_repeated()
+    import scipy.sparse as sp
+    nred = Ksys.A.m
+    Rred = sp.coo_matrix((Ksys.A.v, (Ksys.A.i, Ksys.A.j)), shape=(nred, nred)).tocsr()
+    Ured = sp.coo_matrix((vr, (ir, jr)), shape=(nred, nred)).tocsr()
+    assert ir.max() < nred and np.all(ir <= jr) and abs(Ured - Rred).max() / abs(Rred).max() < 1e-13
     # --dumpMatrix without boundary conditions: TripletMatrix::dumpBinary format (SparseMatrices.hh:629-645)
     kbin = str(tmp_path / "K.bin")
     assert simulate_cli.main([mesh, "-m", os.path.join(GOLD, "B9Creator.material"), "-d", str(deg), "--dumpMatrix", kbin]) == 0
