@@ -9,7 +9,8 @@ Materials.cc:178-311) or per-element material fields stored in an .msh (`E`,`nu`
 type dirichlet[xyz] / force / traction / pressure / delta force (BoundaryConditions.cc:227-389), numeric or
 expression-valued (`"sin(pi * x)"`, tinyexpr grammar: meshfem_amd/expressions.py), `dirichlet nodes` /
 `delta force nodes` lists, `traction | pressure | force elements` lists, `dirichlet elements`, and path / polygon
-regions (Geometry.hh:68-191). Not supported: target / contact / fracture conditions (no counterpart in a linear solve).
+regions (Geometry.hh:68-191); top-level `no_rigid_motion`, `pin_translation` and `fix_periodic_pair_<c>`.
+Not supported: target / contact / fracture conditions (no counterpart in a linear solve).
 Writes the fields u, load, strain, stress, Ku like Simulate_cli.cc:207-242."""
 import argparse
 import json
@@ -157,6 +158,14 @@ def apply_boundary_conditions(sim, path):
     N = sim.N
     be_lookup = None
     geo = {}
+    if cfg.get("pin_translation") or any(("fix_periodic_pair_" + a) in cfg for a in "xyz"[:N]):
+        # Simulate_cli.cc:191-193: applyTranslationPins before, applyPeriodicPairDirichletConditions after the regions
+        pos_ = sim.nodes()
+        bn_ = sim.ctx.boundary_nodes()
+        for d in range(N):                                   # LinearElasticity.hh:1095-1111: pin component d of the
+            if "xyz"[d] in cfg.get("pin_translation", ""):   # boundary node with the smallest coordinate d (first one found)
+                node = bn_[int(np.argmin(pos_[bn_, d]))]
+                sim.applyDirichletNodes([int(node)], np.zeros((1, N)), [a == d for a in range(N)])
     region_of_node = {}                                      # BoundaryNode::dirichletRegionIdx (setDirichletRegion, :946,:962)
     n_dirichlet_regions = 0
 
@@ -302,6 +311,22 @@ def apply_boundary_conditions(sim, path):
             sim.applyNeumannBox(mn, mx, [float(val if np.isscalar(val) else val[0])], kind=L.NEUMANN_PRESSURE, relative=rel)
         else:
             raise RuntimeError("Invalid type '%s'" % r["type"])
+    for c_ in range(N):                                      # "fix_periodic_pair_<component>": "<orthogonal axis>"
+        key = "fix_periodic_pair_" + "xyz"[c_]               # (BoundaryConditions.cc:229-245, BoundaryConditions.hh:54-100,
+        if key not in cfg:                                   #  LinearElasticity.hh:1087-1093): component c of ONE matching node
+            continue                                         #  pair on the min / max faces of the axis is fixed to zero
+        face = "xyz"[:N].find(cfg[key]) if cfg[key] in ("x", "y", "z")[:N] and cfg[key] != "xyz"[c_] else -1
+        if face < 0:
+            raise RuntimeError("invalid " + key)
+        lo, hi = pos_[:sim.ctx.n_vert].min(axis=0), pos_[:sim.ctx.n_vert].max(axis=0)
+        first = next((int(n) for n in bn_ if abs(pos_[n, face] - lo[face]) <= 1e-5), None)
+        if first is None:
+            raise RuntimeError("No vertices on the periodic pair face.")
+        target = pos_[first].copy(); target[face] = hi[face]
+        second = next((int(n) for n in bn_ if np.linalg.norm(pos_[n] - target) <= 1e-5), None)
+        if second is None:
+            raise RuntimeError("Couldn't match vertex in periodic pair Dirichlet condition")
+        sim.applyDirichletNodes([first, second], np.zeros((2, N)), [a == c_ for a in range(N)])
     return region_of_node
 
 

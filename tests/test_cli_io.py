@@ -408,3 +408,26 @@ def test_path_polygon_and_element_vertex_regions_equal_their_box_forms():
     _, u4, f4 = solve([clamp, {"type": "delta force", "value": [0, -0.1, 0], "polygon": poly}])
     _, u5, f5 = solve([clamp, {"type": "delta force nodes", "values": [[[0, -0.1, 0], inside.tolist()]]}])
     assert np.array_equal(f4, f5) and np.linalg.norm(u4 - u5) < 1e-12 * np.linalg.norm(u5)
+
+
+def test_bc_top_level_keys_pin_translation_and_periodic_pair():
+    """`pin_translation` (applyTranslationPins, LinearElasticity.hh:1095-1111) and `fix_periodic_pair_<c>`
+    (PeriodicPairDirichletCondition, BoundaryConditions.hh:54-100) of a .bc file: which variables get fixed."""
+    import meshfem_amd as M
+    from meshfem_amd.linear_elasticity import Simulator
+    V, T = grid.grid_tet_mesh(2, 2, 2, [0, 0, 0], [1, 1, 1])
+    sim = Simulator(T, V, 1, device=-1)
+    cfg = {"pin_translation": "xz", "fix_periodic_pair_x": "y", "regions": []}
+    simulate_cli.apply_boundary_conditions(sim, cfg)
+    fv, fx = sim.ctx.bc_dirichlet_vars()
+    pos = sim.nodes()
+    assert np.all(fx == 0)
+    fixed = sorted((int(v) // 3, int(v) % 3) for v in fv)
+    comps = sorted(c for _, c in fixed)
+    assert comps == [0, 0, 0, 2] or comps == [0, 0, 2]               # x pin, z pin, the pair's x component (may coincide)
+    xs = [n for n, c in fixed if c == 0]
+    assert any(abs(pos[n, 1]) < 1e-12 for n in xs) and any(abs(pos[n, 1] - 1) < 1e-12 for n in xs)   # one node on y = 0, its partner on y = 1
+    pair = [n for n in xs if abs(pos[n, 1]) < 1e-12 or abs(pos[n, 1] - 1) < 1e-12]
+    assert any(np.allclose(pos[a][[0, 2]], pos[b][[0, 2]]) and abs(pos[a, 1] - pos[b, 1]) == 1 for a in pair for b in pair if a != b)
+    with pytest.raises(RuntimeError, match="invalid fix_periodic_pair_x"):
+        simulate_cli.apply_boundary_conditions(Simulator(T, V, 1, device=-1), {"fix_periodic_pair_x": "x", "regions": []})
