@@ -345,6 +345,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="simulate_cli")
     ap.add_argument("mesh")
     ap.add_argument("-m", "--material", default="")
+    ap.add_argument("-f", "--matFieldName", default="", help="name prefix of the material fields in the .msh passed as --material")
     ap.add_argument("-b", "--boundaryConditions")
     ap.add_argument("-o", "--outputMSH")
     ap.add_argument("--dumpMatrix", default="")
@@ -371,13 +372,24 @@ def main(argv=None):
     sim = Simulator(E, np.ascontiguousarray(V), degree=a.degree, device=a.device)
     sim.rtol = a.rtol
     sim.ctx.set_preconditioner({"two_level": L.PRECOND_TWO_LEVEL, "block_jacobi": L.PRECOND_BLOCK_JACOBI, "jacobi": L.PRECOND_JACOBI}[a.preconditioner])
-    if a.material.endswith(".msh"):
+    if a.material.endswith(".msh"):                        # heterogeneous material fields (Simulate_cli.cc:104-163)
         _, _, fields = load_msh(a.material)
-        if "E" in fields and "nu" in fields:
-            sim.setIsotropicField(fields["E"][1][:, 0], fields["nu"][1][:, 0])
+        pre = a.matFieldName
+
+        def elem_field(name):
+            kind, vals = fields[pre + name]
+            if kind != "element" or len(vals) != sim.numElements():
+                raise RuntimeError("Material parameter fields of incorrect size.")
+            return vals[:, 0]
+        if pre + "E" in fields and pre + "nu" in fields:
+            sim.setIsotropicField(elem_field("E"), elem_field("nu"))
+            print("Loaded %dD isotropic material" % N)
         else:
             names = ["E_x", "E_y", "E_z", "nu_yx", "nu_zx", "nu_zy", "mu_yz", "mu_zx", "mu_xy"] if N == 3 else ["E_x", "E_y", "nu_yx", "mu"]
-            sim.setOrthotropicField(np.column_stack([fields[k][1][:, 0] for k in names]))
+            if any(pre + k not in fields for k in names):
+                raise RuntimeError("No complete material parameter field was found.")
+            sim.setOrthotropicField(np.column_stack([elem_field(k) for k in names]))
+            print("Loaded %dD Orthotropic material" % N)
     elif a.material:
         sim.setMaterial(parse_material(a.material, N))
     if a.dumpMatrix and not a.boundaryConditions:          # Simulate_cli.cc:178-184

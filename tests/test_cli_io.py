@@ -431,3 +431,39 @@ def test_bc_top_level_keys_pin_translation_and_periodic_pair():
     assert any(np.allclose(pos[a][[0, 2]], pos[b][[0, 2]]) and abs(pos[a, 1] - pos[b, 1]) == 1 for a in pair for b in pair if a != b)
     with pytest.raises(RuntimeError, match="invalid fix_periodic_pair_x"):
         simulate_cli.apply_boundary_conditions(Simulator(T, V, 1, device=-1), {"fix_periodic_pair_x": "x", "regions": []})
+
+
+@pytest.mark.gpu
+def test_simulate_cli_material_fields_from_msh_with_prefix(tmp_path):
+    """Heterogeneous materials stored as per-element fields of an .msh (Simulate_cli.cc:104-163), with the -f name prefix:
+    isotropic E / nu and the nine orthotropic fields; incomplete or mis-sized fields raise the reference's messages."""
+    V, T = grid.grid_tet_mesh(3, 2, 2, [0, 0, 0], [1.5, 1, 1])
+    mesh = str(tmp_path / "m.msh")
+    mesh_io.MSHFieldWriter(mesh, V, T).close()
+    rng = np.random.default_rng(3)
+    P = grid.synthetic_orthotropic_field(len(T), 3, seed=4)
+    names = ["E_x", "E_y", "E_z", "nu_yx", "nu_zx", "nu_zy", "mu_yz", "mu_zx", "mu_xy"]
+    w = mesh_io.MSHFieldWriter(str(tmp_path / "mat.msh"), V, T)
+    for k, nm in enumerate(names):
+        w.addField("soft_" + nm, P[:, k], "element")
+    Ei, nui = rng.uniform(100, 200, len(T)), rng.uniform(0.2, 0.4, len(T))
+    w.addField("E", Ei, "element"); w.addField("nu", nui, "element"); w.addField("soft_E_only", Ei, "element")
+    w.close()
+    bc = tmp_path / "c.bc"
+    bc.write_text(json.dumps({"regions": [
+        {"type": "dirichlet", "value": [0, 0, 0], "box%": {"minCorner": [-0.01, -0.01, -0.01], "maxCorner": [0.01, 1.01, 1.01]}},
+        {"type": "force", "value": [0, -1, 0], "box%": {"minCorner": [0.99, -0.01, -0.01], "maxCorner": [1.01, 1.01, 1.01]}}]}))
+    res = {}
+    for tag, extra in (("ortho", ["-f", "soft_"]), ("iso", [])):
+        out = str(tmp_path / (tag + ".msh"))
+        assert simulate_cli.main([mesh, "-m", str(tmp_path / "mat.msh"), "-b", str(bc), "-d", "1", "-o", out, "--rtol", "1e-11"] + extra) == 0
+        res[tag] = mesh_io.load_msh(out)[2]["u"][1]
+    for tag, mats in (("ortho", [O.ElasticityTensor.orthotropic3d(*p) for p in P]), ("iso", [O.ElasticityTensor.isotropic(3, e, n) for e, n in zip(Ei, nui)])):
+        sim = O.Simulator(T, V, 1)
+        sim.set_material_field(mats)
+        mn, mx = sim.box_percent([-0.01] * 3, [0.01, 1.01, 1.01]); sim.apply_dirichlet_box(mn, mx, [0, 0, 0])
+        mn, mx = sim.box_percent([0.99, -0.01, -0.01], [1.01, 1.01, 1.01]); sim.apply_neumann_box(mn, mx, [0, -1, 0], "force")
+        ref = sim.solve()
+        assert np.linalg.norm(res[tag] - ref) < 1e-7 * np.linalg.norm(ref)
+    with pytest.raises(RuntimeError, match="No complete material parameter field"):
+        simulate_cli.main([mesh, "-m", str(tmp_path / "mat.msh"), "-f", "hard_", "-b", str(bc), "-d", "1", "-o", str(tmp_path / "x.msh")])
