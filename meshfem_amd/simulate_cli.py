@@ -1,7 +1,8 @@
 """Simulate_cli-compatible driver on the GPU path (mirror of src/bin/Simulate_cli.cc):
 
     python -m meshfem_amd.simulate_cli mesh.msh -m material.json -b conditions.bc -d 2 -o out.msh
-        [--dumpMatrix K.bin] [-D] [--device 0] [--rtol 1e-8] [--preconditioner two_level|block_jacobi]
+        [-f fieldPrefix] [-e extra.msh] [--dumpMatrix K.bin] [-D] [--device 0] [--rtol 1e-8]
+        [--preconditioner two_level|block_jacobi]
 
 Reads a Gmsh 2.2 tri/tet mesh, a `.material` JSON (isotropic / orthotropic / symmetric_material,
 Materials.cc:178-311) or per-element material fields stored in an .msh (`E`,`nu` or the 9 (3D) /
@@ -346,6 +347,7 @@ def main(argv=None):
     ap.add_argument("mesh")
     ap.add_argument("-m", "--material", default="")
     ap.add_argument("-f", "--matFieldName", default="", help="name prefix of the material fields in the .msh passed as --material")
+    ap.add_argument("-e", "--extraMesh", default="", help="adds another independent input mesh to the problem")
     ap.add_argument("-b", "--boundaryConditions")
     ap.add_argument("-o", "--outputMSH")
     ap.add_argument("--dumpMatrix", default="")
@@ -361,6 +363,12 @@ def main(argv=None):
     if a.outputMSH and not a.boundaryConditions:
         ap.error("must specify boundary conditions to run a simulation")
     V, E, _ = load_msh(a.mesh)
+    if a.extraMesh:                                         # a second, independent mesh in the same problem (Simulate_cli.cc:270-310)
+        V2, E2, _ = load_msh(a.extraMesh)
+        if E2.shape[1] != E.shape[1]:
+            raise RuntimeError("Extra mesh of different type.")
+        E = np.vstack([E, E2 + len(V)])
+        V = np.vstack([V, V2])
     K = E.shape[1] - 1
     if K not in (2, 3):
         raise RuntimeError("only triangle and tetrahedron meshes are supported")

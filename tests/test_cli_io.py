@@ -467,3 +467,25 @@ def test_simulate_cli_material_fields_from_msh_with_prefix(tmp_path):
         assert np.linalg.norm(res[tag] - ref) < 1e-7 * np.linalg.norm(ref)
     with pytest.raises(RuntimeError, match="No complete material parameter field"):
         simulate_cli.main([mesh, "-m", str(tmp_path / "mat.msh"), "-f", "hard_", "-b", str(bc), "-d", "1", "-o", str(tmp_path / "x.msh")])
+
+
+@pytest.mark.gpu
+def test_simulate_cli_extra_mesh_is_an_independent_body(tmp_path):
+    """--extraMesh (Simulate_cli.cc:270-310): a second mesh appended to the first; two disjoint bars under the same box
+    conditions deform like the single bar does."""
+    V, T = grid.grid_tet_mesh(3, 1, 1, [0, 0, 0], [1, 0.3, 0.3])
+    a, b = str(tmp_path / "a.msh"), str(tmp_path / "b.msh")
+    mesh_io.MSHFieldWriter(a, V, T).close()
+    mesh_io.MSHFieldWriter(b, V + np.array([0, 2.0, 0]), T).close()
+    bc = tmp_path / "c.bc"
+    bc.write_text(json.dumps({"regions": [
+        {"type": "dirichlet", "value": [0, 0, 0], "box": {"minCorner": [-1e-9, -9, -9], "maxCorner": [1e-9, 9, 9]}},
+        {"type": "traction", "value": [0, 0, -1], "box": {"minCorner": [1 - 1e-9, -9, -9], "maxCorner": [1 + 1e-9, 9, 9]}}]}))
+    one, two = str(tmp_path / "one.msh"), str(tmp_path / "two.msh")
+    assert simulate_cli.main([a, "-b", str(bc), "-d", "1", "-o", one, "--rtol", "1e-12", "--preconditioner", "block_jacobi"]) == 0
+    assert simulate_cli.main([a, "-e", b, "-b", str(bc), "-d", "1", "-o", two, "--rtol", "1e-12", "--preconditioner", "block_jacobi"]) == 0
+    u1 = mesh_io.load_msh(one)[2]["u"][1]
+    V2, T2, F2 = mesh_io.load_msh(two)
+    assert len(V2) == 2 * len(V) and len(T2) == 2 * len(T)
+    u2 = F2["u"][1]
+    assert np.linalg.norm(u2[:len(V)] - u1) < 1e-8 * np.linalg.norm(u1) and np.linalg.norm(u2[len(V):] - u1) < 1e-8 * np.linalg.norm(u1)
