@@ -126,10 +126,67 @@ def load_off(path):
     return V, np.array(E, dtype=np.int64)
 
 
+def load_obj(path):
+    """Wavefront OBJ surface meshes (MeshIO_OBJ, MeshIO.cc): `v x y z` and `f a b c ...` records (1-based, `a/t/n` forms
+    accepted, negative = relative indices); everything else is skipped."""
+    V, E = [], []
+    with open(path) as f:
+        for line in f:
+            t = line.split()
+            if not t:
+                continue
+            if t[0] == "v":
+                V.append([float(x) for x in t[1:4]])
+            elif t[0] == "f":
+                idx = [int(x.split("/")[0]) for x in t[1:]]
+                E.append([i - 1 if i > 0 else len(V) + i for i in idx])
+    return np.array(V, dtype=np.float64).reshape(-1, 3), np.array(E, dtype=np.int64)
+
+
+def load_medit(path):
+    """MEDIT .mesh files (MeshIO_MEDIT): `Vertices` (x y [z] ref) and `Triangles` / `Tetrahedra` (1-based indices + ref).
+    Tetrahedra win when both are present (the triangles are then the boundary)."""
+    with open(path) as f:
+        tok = f.read().split()
+    dim, pos = 3, 0
+    V, tris, tets = None, None, None
+    while pos < len(tok):
+        key = tok[pos].lower()
+        if key == "dimension":
+            dim = int(tok[pos + 1]); pos += 2
+        elif key == "vertices":
+            n = int(tok[pos + 1]); pos += 2
+            V = np.array(tok[pos:pos + n * (dim + 1)], dtype=np.float64).reshape(n, dim + 1)[:, :dim]; pos += n * (dim + 1)
+        elif key in ("triangles", "tetrahedra"):
+            k = 3 if key == "triangles" else 4
+            n = int(tok[pos + 1]); pos += 2
+            E = np.array(tok[pos:pos + n * (k + 1)], dtype=np.int64).reshape(n, k + 1)[:, :k] - 1; pos += n * (k + 1)
+            if k == 3:
+                tris = E
+            else:
+                tets = E
+        elif key == "end":
+            break
+        else:
+            pos += 1
+    if V is None or (tris is None and tets is None):
+        raise RuntimeError("Bad MEDIT file format")
+    if dim == 2:
+        V = np.column_stack([V, np.zeros(len(V))])
+    return V, (tets if tets is not None else tris)
+
+
 def load_mesh(path):
-    """MeshIO::load dispatch on the extension (.msh / .off)."""
-    if path.lower().endswith(".off"):
+    """MeshIO::load dispatch on the extension (.msh / .off / .obj / .mesh)."""
+    low = path.lower()
+    if low.endswith(".off"):
         V, E = load_off(path)
+        return V, E, {}
+    if low.endswith(".obj"):
+        V, E = load_obj(path)
+        return V, E, {}
+    if low.endswith(".mesh"):
+        V, E = load_medit(path)
         return V, E, {}
     return load_msh(path)
 

@@ -21,7 +21,7 @@ import numpy as np
 
 from . import _lib as L
 from .linear_elasticity import Simulator
-from .mesh_io import MSHFieldWriter, load_msh, upsample_interpolant
+from .mesh_io import MSHFieldWriter, load_mesh, load_msh, upsample_interpolant
 from .tensors import ElasticityTensor
 from .expressions import ExpressionVector, environment
 
@@ -362,9 +362,9 @@ def main(argv=None):
         ap.error("must specify output msh file (unless dumping a stiffness matrix)")
     if a.outputMSH and not a.boundaryConditions:
         ap.error("must specify boundary conditions to run a simulation")
-    V, E, _ = load_msh(a.mesh)
+    V, E, _ = load_mesh(a.mesh)                            # .msh / .off / .obj / .mesh (MeshIO::load)
     if a.extraMesh:                                         # a second, independent mesh in the same problem (Simulate_cli.cc:270-310)
-        V2, E2, _ = load_msh(a.extraMesh)
+        V2, E2, _ = load_mesh(a.extraMesh)
         if E2.shape[1] != E.shape[1]:
             raise RuntimeError("Extra mesh of different type.")
         E = np.vstack([E, E2 + len(V)])

@@ -489,3 +489,25 @@ def test_simulate_cli_extra_mesh_is_an_independent_body(tmp_path):
     assert len(V2) == 2 * len(V) and len(T2) == 2 * len(T)
     u2 = F2["u"][1]
     assert np.linalg.norm(u2[:len(V)] - u1) < 1e-8 * np.linalg.norm(u1) and np.linalg.norm(u2[len(V):] - u1) < 1e-8 * np.linalg.norm(u1)
+
+
+def test_obj_and_medit_readers(tmp_path):
+    """load_mesh dispatch (MeshIO::load): OBJ triangles and MEDIT tets / triangles carry the same mesh as the MSH writer."""
+    V, T = grid.grid_tet_mesh(2, 1, 1)
+    p = tmp_path / "m.mesh"
+    lines = ["MeshVersionFormatted 1", "Dimension 3", "Vertices", str(len(V))] + ["%.17g %.17g %.17g 0" % tuple(v) for v in V]
+    lines += ["Tetrahedra", str(len(T))] + ["%d %d %d %d 1" % tuple(t + 1) for t in T] + ["Triangles", "1", "1 2 3 0", "End"]
+    p.write_text("\n".join(lines) + "\n")
+    V2, T2, _ = mesh_io.load_mesh(str(p))
+    assert np.array_equal(V2, V) and np.array_equal(T2, T)
+    V2d, T2d = grid.grid_tri_mesh(2, 2)
+    o = tmp_path / "s.obj"
+    o.write_text("# comment\n" + "".join("v %.17g %.17g 0\n" % tuple(v) for v in V2d) + "vn 0 0 1\n"
+                 + "".join("f %d/1/1 %d/1/1 %d/1/1\n" % tuple(t + 1) for t in T2d[:-1]) + "f %d %d %d\n" % tuple(T2d[-1] - len(V2d)))
+    Vo, To, _ = mesh_io.load_mesh(str(o))
+    assert np.array_equal(Vo[:, :2], V2d) and np.array_equal(To, T2d)
+    m2 = tmp_path / "t.mesh"
+    m2.write_text("MeshVersionFormatted 1\nDimension 2\nVertices\n%d\n" % len(V2d) + "".join("%.17g %.17g 0\n" % tuple(v) for v in V2d)
+                  + "Triangles\n%d\n" % len(T2d) + "".join("%d %d %d 0\n" % tuple(t + 1) for t in T2d) + "End\n")
+    Vm, Tm, _ = mesh_io.load_mesh(str(m2))
+    assert np.array_equal(Vm[:, :2], V2d) and np.all(Vm[:, 2] == 0) and np.array_equal(Tm, T2d)
