@@ -105,3 +105,89 @@ class _PeriodicCondition:
 
 def PeriodicCondition(mesh, eps=1e-7, ignore_mismatch=False, ignore_dims=()):
     return _PeriodicCondition(mesh, eps, ignore_mismatch, ignore_dims)
+
+
+# ---- MSH field I/O (src/python_bindings/MSHFieldWriter_bindings.cc, MSHFieldParser_bindings.cc; bound into `mesh`)
+class MSHFieldWriter:
+    """MSHFieldWriter(path, V, F, binary=True).addField(name, field, dtype=GUESS): scalar (n or n x 1) and vector (n x 2|3)
+    fields per node or per element; GUESS decides by the number of rows like m_determineDomainTypeAndNumEntries."""
+
+    class DomainType:
+        PER_ELEMENT, PER_NODE, GUESS, ANY, UNKNOWN = "PER_ELEMENT", "PER_NODE", "GUESS", "ANY", "UNKNOWN"
+
+    def __init__(self, path, V, F, binary=True):
+        self._w = mesh_io.MSHFieldWriter(path, np.asarray(V, dtype=np.float64), np.asarray(F, dtype=np.int64), binary=binary)
+        self._nv, self._ne = len(V), len(F)
+
+    def addField(self, name, field, dtype="GUESS"):
+        field = np.asarray(field, dtype=np.float64)
+        n = len(field)
+        if dtype in ("GUESS", "ANY"):
+            if n == self._ne:
+                dtype = "PER_ELEMENT"
+            elif n == self._nv:
+                dtype = "PER_NODE"
+            else:
+                raise RuntimeError("Invalid field domain size.")
+        self._w.addField(name, field, "node" if dtype == "PER_NODE" else "element")
+
+    def close(self):
+        self._w.close()
+
+    def __del__(self):
+        try:
+            self._w.close()
+        except Exception:
+            pass
+
+
+class _MSHFieldParser:
+    """MSHFieldParser{2,3}: mesh + the fields of an .msh file (scalar / vector / symmetric-matrix, per node or element)."""
+
+    def __init__(self, path, permitDimMismatch=True):
+        self._V, self._F, self._fields = mesh_io.load_msh(path)
+        self._K = self._F.shape[1] - 1 if self._F.shape[1] in (3, 4) else (2 if self._F.shape[1] == 6 else 3)
+        self._deg = 1 if self._F.shape[1] in (3, 4) else 2
+
+    def vertices(self): return self._V.copy()
+    def elements(self): return self._F.copy()
+    def meshDegree(self): return self._deg
+    def meshDimension(self): return self._K
+    def numElements(self): return len(self._F)
+    def numVertices(self): return len(self._V)
+
+    def _get(self, name, domainType, widths):
+        if name not in self._fields:
+            raise RuntimeError("Field '%s' not found" % name)
+        kind, vals = self._fields[name]
+        want = {"PER_NODE": "node", "PER_ELEMENT": "element"}.get(domainType)
+        if (want and kind != want) or vals.ndim != 2 or vals.shape[1] not in widths:
+            raise RuntimeError("Field '%s' has the wrong type or domain" % name)
+        return vals
+
+    def scalarField(self, name, domainType="ANY"):
+        return self._get(name, domainType, (1,))[:, 0].copy()
+
+    def vectorField(self, name, domainType="ANY"):
+        return self._get(name, domainType, (3,))[:, :self._K].copy()
+
+    def symmetricMatrixField(self, name, domainType="ANY"):
+        M9 = self._get(name, domainType, (9,)).reshape(-1, 3, 3)
+        idx = [(0, 0), (1, 1), (0, 1)] if self._K == 2 else [(0, 0), (1, 1), (2, 2), (1, 2), (0, 2), (0, 1)]
+        return np.stack([M9[:, a, b] for a, b in idx], axis=1)
+
+    def _names(self, domainType, widths, kinds=("node", "element")):
+        want = {"PER_NODE": ("node",), "PER_ELEMENT": ("element",)}.get(domainType, kinds)
+        return [n for n, (k, v) in self._fields.items() if k in want and v.ndim == 2 and v.shape[1] in widths]
+
+    def scalarFieldNames(self, domainType="ANY"): return self._names(domainType, (1,))
+    def vectorFieldNames(self, domainType="ANY"): return self._names(domainType, (3,))
+    def symmetricMatrixFieldNames(self, domainType="ANY"): return self._names(domainType, (9,))
+    def _inames(self, width): return [n for n, (k, v) in self._fields.items() if k == "element node" and v.shape[2] == width]
+    def scalarInterpolantFieldNames(self, domainType="ANY"): return self._inames(1)
+    def vectorInterpolantFieldNames(self, domainType="ANY"): return self._inames(3)
+    def symmetricMatrixInterpolantFieldNames(self, domainType="ANY"): return self._inames(9)
+
+
+def MSHFieldParser(path, permitDimMismatch=True):
+    return _MSHFieldParser(path, permitDimMismatch)

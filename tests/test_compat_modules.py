@@ -279,3 +279,26 @@ def test_suite_sparse_matrix_solve():
     b = np.random.default_rng(1).standard_normal(300)
     x = csm.SuiteSparseMatrix(K).solve(b)
     assert np.linalg.norm(x - spl.spsolve(A.tocsc(), b)) < 1e-8 * np.linalg.norm(x)
+
+
+def test_msh_field_writer_and_parser_bindings(tmp_path):
+    """mesh.MSHFieldWriter / mesh.MSHFieldParser (MSHFieldWriter_bindings.cc, MSHFieldParser_bindings.cc)."""
+    V, T = O.grid_tet_mesh(2, 1, 1)
+    rng = np.random.default_rng(0)
+    p = str(tmp_path / "f.msh")
+    w = cmesh.MSHFieldWriter(p, V, T)
+    u, E, eps = rng.random((len(V), 3)), rng.random(len(T)), rng.random((len(T), 6))
+    w.addField("u", u); w.addField("E", E[:, None], cmesh.MSHFieldWriter.DomainType.PER_ELEMENT); w.close()
+    with pytest.raises(RuntimeError, match="Invalid field domain size"):
+        cmesh.MSHFieldWriter(str(tmp_path / "g.msh"), V, T).addField("bad", np.zeros(len(V) + len(T) + 1))
+    from meshfem_amd import mesh_io
+    w2 = mesh_io.MSHFieldWriter(str(tmp_path / "h.msh"), V, T); w2.addField("strain", eps, "element"); w2.addElementNodeField("s", rng.random((len(T), 4, 6))); w2.close()
+    fp = cmesh.MSHFieldParser(p)
+    assert fp.meshDimension() == 3 and fp.meshDegree() == 1 and fp.numElements() == len(T) and fp.numVertices() == len(V)
+    assert np.array_equal(fp.vertices(), V) and np.array_equal(fp.elements(), T)
+    assert np.array_equal(fp.vectorField("u"), u) and np.array_equal(fp.scalarField("E", "PER_ELEMENT"), E)
+    assert fp.vectorFieldNames() == ["u"] and fp.scalarFieldNames("PER_ELEMENT") == ["E"] and fp.scalarFieldNames("PER_NODE") == []
+    with pytest.raises(RuntimeError):
+        fp.scalarField("u")
+    fh = cmesh.MSHFieldParser(str(tmp_path / "h.msh"))
+    assert np.array_equal(fh.symmetricMatrixField("strain"), eps) and fh.symmetricMatrixInterpolantFieldNames() == ["s"]
