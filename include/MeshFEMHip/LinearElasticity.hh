@@ -223,6 +223,15 @@ public:
         return out;
     }
     std::vector<Real> stressField(const VField &uNodes) const { return strainField(uNodes, true); }
+    // the same interpolant restricted to the boundary elements (restrictInterpolant, InterpolantRestriction.hh:29-66):
+    // values at the boundary element's corners in its own vertex order, [nBdryElem][1 | N][flatLen]
+    std::vector<Real> boundaryStrainField(const VField &uNodes, bool stress = false) const {
+        int64_t nBE = 0;
+        check(ctx(), mfh_mesh_sizes(ctx(), nullptr, nullptr, nullptr, &nBE, nullptr, nullptr, nullptr));
+        std::vector<Real> out((size_t)nBE * (Deg == 1 ? 1 : N) * (N * (N + 1) / 2));
+        check(ctx(), mfh_boundary_strain_field(ctx(), &uNodes[0][0], stress ? 1 : 0, out.data()));
+        return out;
+    }
     SMField averageStressField(const VField &uNodes) const {     // :539-549
         SMField s((size_t)m_numElements);
         check(ctx(), mfh_average_stress(ctx(), &uNodes[0][0], &s[0][0]));

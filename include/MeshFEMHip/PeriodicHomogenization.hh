@@ -6,7 +6,9 @@
 //       homogenizedElasticityTensor(w_ij, sim, baseCellVolume)  :72-103      same (stress-like form)
 //       homogenizedElasticityTensorDisplacementForm(...)        :146-186     same (boundary-integral form, constant base tensor)
 //       deltaFluctuationDisplacements(sim, w, delta_p)          :527-544     same
-//       deltaHomogenizedElasticityTensor(sim, w, delta_p)       :492-514     same value, volume form (:484-491)
+//       deltaHomogenizedElasticityTensor(sim, w, delta_p)       :492-514     exact discrete derivative, volume form (:484-491)
+//       homogenizedElasticityTensorGradient(w, sim)             :226-288     same, packed [bdryElem][node][flatLen][flatLen]
+//       (boundary integral of the above against n . delta_p)    :492-514     deltaHomogenizedElasticityTensorBoundaryForm
 //       homogenizedElasticityTensorDiscreteDifferential(w, sim) :372-480     same, packed [pair][vertex][component]
 //     reference (OrthotropicHomogenization.hh)                              namespace ...::Orthotropic
 //       solveCellProblems(w_ij, sim, cellEpsilon)               :44-153      same (one assembled operator, 1 + flatLen - N masks)
@@ -70,6 +72,8 @@ std::vector<Real> stackFields(const LinearElasticity::Simulator<N, Deg> &sim, co
     }
     return out;
 }
+// end points of the boundary element's local edges (FEMMesh.inl:43-58)
+static const size_t es[3] = {0, 1, 2}, et[3] = {1, 2, 0};
 }   // namespace detail
 
 // Solve the cell problems -div E : [strain(w^ij) + e^ij] = 0, w^ij periodic, pinned (PeriodicHomogenization.hh:34-54).
@@ -206,6 +210,92 @@ ETensor<N> deltaHomogenizedElasticityTensor(const LinearElasticity::Simulator<N,
     ETensor<N> d;
     for (size_t i = 0; i < FL; ++i)
         for (size_t j = 0; j < FL; ++j) d.D[i][j] = out[i * FL + j] / cell;
+    return d;
+}
+
+// Steepest-ascent normal velocity of every component of Ch (:226-288): per boundary element the nodal values of the degree
+// 2 (Deg - 1) interpolant G_ijkl = 1/|bbox| (e_ij + eps(w_ij)) : E : (e_kl + eps(w_kl)), zero on the periodic boundary.
+// Packed [bdryElem][1 | nodesPerBdryElem][flatLen][flatLen]; boundary edge nodes are (0,1),(1,2),(2,0).
+template <size_t N, size_t Deg>
+std::vector<Real> homogenizedElasticityTensorGradient(const std::vector<typename LinearElasticity::Simulator<N, Deg>::VField> &w,
+                                                      const LinearElasticity::Simulator<N, Deg> &sim) {
+    constexpr size_t FL = flatLen(N), NQ = Deg == 1 ? 1 : N, NE = Deg == 1 ? 0 : (N == 2 ? 1 : 3), NN = NQ + NE;
+    if (w.size() != FL) throw std::runtime_error("need one fluctuation displacement per canonical strain");
+    const Real bbox = detail::cellVolume(sim, 0.0);
+    const auto pos = sim.nodes();
+    int64_t nBE = 0;
+    check(sim.ctx(), mfh_mesh_sizes(sim.ctx(), nullptr, nullptr, nullptr, &nBE, nullptr, nullptr, nullptr));
+    std::vector<uint8_t> internal((size_t)nBE);
+    check(sim.ctx(), mfh_mesh_get_boundary_elem_internal(sim.ctx(), internal.data()));
+    // G = e + eps(w) and S = E : G at the boundary corners, then at the edge midpoints (both are linear on the element)
+    std::vector<std::vector<Real>> G(FL), S(FL);
+    for (size_t k = 0; k < FL; ++k) {
+        size_t a, b;
+        detail::unflatten<N>(k, a, b);
+        auto u = w[k];
+        const Real sc = (a == b) ? 1.0 : 0.5;
+        for (size_t n = 0; n < u.size(); ++n) {   // u_lin = e_k x
+            u[n][a] += sc * pos[n][b];
+            if (a != b) u[n][b] += sc * pos[n][a];
+        }
+        G[k] = sim.boundaryStrainField(u, false);
+        S[k] = sim.boundaryStrainField(u, true);
+    }
+    using detail::es; using detail::et;
+    auto at = [&](const std::vector<Real> &X, size_t be, size_t n, size_t c) {
+        if (n < NQ) return X[(be * NQ + n) * FL + c];
+        return 0.5 * (X[(be * NQ + es[n - NQ]) * FL + c] + X[(be * NQ + et[n - NQ]) * FL + c]);
+    };
+    std::vector<Real> out((size_t)nBE * NN * FL * FL, 0.0);
+    for (size_t be = 0; be < (size_t)nBE; ++be) {
+        if (internal[be]) continue;
+        for (size_t n = 0; n < NN; ++n)
+            for (size_t i = 0; i < FL; ++i)
+                for (size_t k = i; k < FL; ++k) {
+                    Real v = 0.0;
+                    for (size_t c = 0; c < FL; ++c) v += (c < N ? 1.0 : 2.0) * at(S[i], be, n, c) * at(G[k], be, n, c);
+                    out[((be * NN + n) * FL + i) * FL + k] = out[((be * NN + n) * FL + k) * FL + i] = v / bbox;
+                }
+    }
+    return out;
+}
+
+// deltaHomogenizedElasticityTensor exactly as the reference evaluates it (:492-514): the linear normal velocity
+// n . delta_p of every boundary element integrated against homogenizedElasticityTensorGradient (continuous form).
+template <size_t N, size_t Deg>
+ETensor<N> deltaHomogenizedElasticityTensorBoundaryForm(const LinearElasticity::Simulator<N, Deg> &sim,
+                                                        const std::vector<typename LinearElasticity::Simulator<N, Deg>::VField> &w,
+                                                        const typename LinearElasticity::Simulator<N, Deg>::VField &delta_p) {
+    constexpr size_t FL = flatLen(N), NQ = Deg == 1 ? 1 : N, NE = Deg == 1 ? 0 : (N == 2 ? 1 : 3), NN = NQ + NE;
+    const auto sd = homogenizedElasticityTensorGradient(w, sim);
+    int64_t nBE = 0;
+    int32_t npbe = 0;
+    check(sim.ctx(), mfh_mesh_sizes(sim.ctx(), nullptr, nullptr, nullptr, &nBE, nullptr, nullptr, &npbe));
+    std::vector<int32_t> ben((size_t)nBE * npbe);
+    std::vector<Real> area((size_t)nBE), nrm((size_t)nBE * N);
+    check(sim.ctx(), mfh_mesh_get_boundary_elem_nodes(sim.ctx(), ben.data()));
+    check(sim.ctx(), mfh_mesh_get_boundary_elem_geometry(sim.ctx(), area.data(), nrm.data()));
+    using detail::es; using detail::et;
+    // W[a][n] = int lambda_a phi_n over the unit-volume boundary simplex (exact)
+    Real W[N][NN];
+    for (size_t a = 0; a < N; ++a)
+        for (size_t n = 0; n < NN; ++n) {
+            if (Deg == 1) W[a][n] = 1.0 / N;
+            else if (N == 2) W[a][n] = n == 2 ? 1.0 / 3.0 : (n == a ? 1.0 / 6.0 : 0.0);
+            else if (n < 3) W[a][n] = n == a ? 1.0 / 30.0 : -1.0 / 60.0;
+            else W[a][n] = (es[n - 3] == a || et[n - 3] == a) ? 2.0 / 15.0 : 1.0 / 15.0;
+        }
+    ETensor<N> d;
+    for (size_t be = 0; be < (size_t)nBE; ++be)
+        for (size_t a = 0; a < N; ++a) {
+            Real nsv = 0.0;
+            for (size_t c = 0; c < N; ++c) nsv += nrm[be * N + c] * delta_p[(size_t)ben[be * npbe + a]][c];
+            for (size_t n = 0; n < NN; ++n) {
+                const Real f = area[be] * nsv * W[a][n];
+                for (size_t i = 0; i < FL; ++i)
+                    for (size_t k = 0; k < FL; ++k) d.D[i][k] += f * sd[((be * NN + n) * FL + i) * FL + k];
+            }
+        }
     return d;
 }
 

@@ -131,6 +131,10 @@ mfh_status mfh_mesh_update_vertices(mfh_ctx* ctx, const double* vertPos);
 mfh_status mfh_mesh_get_node_positions(const mfh_ctx* ctx, double* out /* nNode x dim */);
 mfh_status mfh_mesh_get_boundary_elem_nodes(const mfh_ctx* ctx, int32_t* out /* nBE x npbe, volume node ids */);
 mfh_status mfh_mesh_get_boundary_nodes(const mfh_ctx* ctx, int32_t* out /* nBdryNode volume node ids */);
+/* the volume element each boundary element is a face / edge of (BoundaryElementHandle -> opposite simplex) */
+mfh_status mfh_mesh_get_boundary_elem_parents(const mfh_ctx* ctx, int32_t* out /* nBE */);
+/* BoundaryElementData::isInternal: 1 on the periodic cell boundary once a periodic condition is installed (else 0) */
+mfh_status mfh_mesh_get_boundary_elem_internal(const mfh_ctx* ctx, uint8_t* out /* nBE */);
 mfh_status mfh_mesh_get_boundary_elem_geometry(const mfh_ctx* ctx, double* volume /* nBE */,
                                                double* normal /* nBE x dim */);
 mfh_status mfh_mesh_get_elem_volumes(mfh_ctx* ctx, double* out /* nElem */);
@@ -271,6 +275,11 @@ mfh_status mfh_average_stress(mfh_ctx* ctx, const double* uNodes, double* stress
  * degree-(Deg-1) strain interpolant of every element -- one value for P1, the values at the dim+1 corners for P2 (edge
  * nodes of an upsampled field are the means of their end points). out: [nElem][1 | dim+1][flatLen]. */
 mfh_status mfh_strain_field(mfh_ctx* ctx, const double* uNodes, int32_t wantStress, double* out);
+/* The same interpolant restricted to the boundary elements (restrictInterpolant, InterpolantRestriction.hh:29-66, as used
+ * for the boundary stresses of PeriodicHomogenization.hh:316-340 and the integrand of homogenizedElasticityTensorGradient
+ * :226-288): values of the parent element's strain at the boundary element's corners, in the boundary element's vertex
+ * order. out: [nBE][1 | dim][flatLen]. */
+mfh_status mfh_boundary_strain_field(mfh_ctx* ctx, const double* uNodes, int32_t wantStress, double* out);
 
 /* ---- discrete shape derivatives, forward mode (LinearElasticity.hh:234-330 at element level; Simulator level
  * :1297-1374). deltaP is a per-vertex perturbation field [nVert x dim] (indexed by the node id of the element corners:

@@ -91,6 +91,9 @@ PROTOTYPES = {
     "mfh_average_strain": (_i32, [_P, _P, _P]),
     "mfh_average_stress": (_i32, [_P, _P, _P]),
     "mfh_strain_field": (_i32, [_P, _P, _i32, _P]),
+    "mfh_boundary_strain_field": (_i32, [_P, _P, _i32, _P]),
+    "mfh_mesh_get_boundary_elem_parents": (_i32, [_P, _P]),
+    "mfh_mesh_get_boundary_elem_internal": (_i32, [_P, _P]),
     "mfh_mesh_update_vertices": (_i32, [_P, _P]),
     "mfh_sim_solve_constrained": (_i32, [_P, _P, _i32, _P, _i32, _P, _f64, _i32, C.POINTER(SolveInfo)]),
     "mfh_matrix_free_info": (_i32, [_P, _P, _P, _P, _P, _P, _P]),

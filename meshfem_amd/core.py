@@ -80,6 +80,17 @@ class Context:
         self._ck(self.lib.mfh_mesh_get_boundary_elem_nodes(self.h, ptr(out)))
         return out
 
+    def boundary_elem_parents(self):
+        out = np.empty(self.n_bdry_elem, dtype=np.int32)
+        self._ck(self.lib.mfh_mesh_get_boundary_elem_parents(self.h, ptr(out)))
+        return out
+
+    def boundary_elem_internal(self):
+        """1 for boundary elements lying on the periodic cell boundary (BoundaryElementData::isInternal)"""
+        out = np.empty(self.n_bdry_elem, dtype=np.uint8)
+        self._ck(self.lib.mfh_mesh_get_boundary_elem_internal(self.h, ptr(out)))
+        return out
+
     def boundary_nodes(self):
         out = np.empty(self.n_bdry_node, dtype=np.int32)
         self._ck(self.lib.mfh_mesh_get_boundary_nodes(self.h, ptr(out)))
@@ -375,6 +386,13 @@ class Context:
         u = as_f64(u_nodes)
         out = np.empty((self.n_elem, 1 if self.deg == 1 else self.dim + 1, flat_len(self.dim)))
         self._ck(self.lib.mfh_strain_field(self.h, ptr(u), int(bool(stress)), ptr(out)))
+        return out
+
+    def boundary_strain_field(self, u_nodes, stress=False):
+        """the parent element's strain (stress) interpolant at the corners of every boundary element: [nBE, 1 | dim, flatLen]"""
+        u = as_f64(u_nodes)
+        out = np.empty((self.n_bdry_elem, 1 if self.deg == 1 else self.dim, flat_len(self.dim)))
+        self._ck(self.lib.mfh_boundary_strain_field(self.h, ptr(u), int(bool(stress)), ptr(out)))
         return out
 
     def average_stress(self, u_nodes):

@@ -999,6 +999,16 @@ mfh_status mfh_mesh_get_boundary_elem_nodes(const mfh_ctx *c, int32_t *out) {
     std::copy(c->mesh.bdryElemNodes.begin(), c->mesh.bdryElemNodes.end(), out);
     return MFH_OK;
 }
+mfh_status mfh_mesh_get_boundary_elem_parents(const mfh_ctx *c, int32_t *out) {
+    if (!c || !c->haveMesh || !out) return MFH_ERR_STATE;
+    std::copy(c->mesh.bdryParent.begin(), c->mesh.bdryParent.end(), out);
+    return MFH_OK;
+}
+mfh_status mfh_mesh_get_boundary_elem_internal(const mfh_ctx *c, uint8_t *out) {
+    if (!c || !c->haveMesh || !out) return MFH_ERR_STATE;
+    std::copy(c->mesh.bdryInternal.begin(), c->mesh.bdryInternal.end(), out);
+    return MFH_OK;
+}
 mfh_status mfh_mesh_get_boundary_nodes(const mfh_ctx *c, int32_t *out) {
     if (!c || !c->haveMesh || !out) return MFH_ERR_STATE;
     std::copy(c->mesh.bdryNodes.begin(), c->mesh.bdryNodes.end(), out);
@@ -1102,6 +1112,8 @@ mfh_status mfh_dof_map(mfh_ctx *c, const int32_t *dofForNode, int64_t nDoF) {
     if (!dofForNode) {
         c->dofForNode.clear();
         c->nDoF = c->mesh.nNode;
+        // removePeriodicConditions (LinearElasticity.hh:874-879) also clears the isInternal flags
+        std::fill(c->mesh.bdryInternal.begin(), c->mesh.bdryInternal.end(), (uint8_t)0);
     } else {
         require(c->mesh.nOwned == c->mesh.nNode, MFH_ERR_UNSUPPORTED, "DoF maps on partitioned meshes are not supported");
         require(nDoF > 0 && nDoF <= c->mesh.nNode, MFH_ERR_INVALID, "bad nDoF");

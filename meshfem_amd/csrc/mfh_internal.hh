@@ -132,6 +132,7 @@ struct HostMesh {
     bool hasTopology = false;
     // boundary (only with topology)
     std::vector<int32_t> bdryElemNodes; // nBE x npbe (volume node ids)
+    std::vector<int32_t> bdryParent;    // nBE: the volume element each boundary element is a face / edge of
     std::vector<int32_t> bdryNodes;     // volume node ids in boundary-node order
     std::vector<uint8_t> isBdryNode;    // nNode
     std::vector<double> bdryVol;        // nBE
@@ -311,6 +312,9 @@ void launch_apply_delta_K(const AsmArgs &a, const int32_t *elemNodes, const int3
 void launch_mutual_energies(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *w, int64_t nNode,
                             const double *deltaP, double *out, hipStream_t s);
 // strain / stress interpolant values per element: [nElem][1 (P1) | dim+1 (P2)][flatLen]
+void launch_boundary_strain_field(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, int64_t nBE,
+                                  const int32_t *bdryParent, const int32_t *bdryElemNodes, int npbe, const double *uNodes,
+                                  int wantStress, double *out, hipStream_t s);
 void launch_strain_field(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, int wantStress,
                          double *out, hipStream_t s);
 // out[pair(ij<=kl)][nVert][dim] += d(mutual energy)/d(vertex position)

@@ -1010,6 +1010,61 @@ __global__ void __launch_bounds__(256) k_strain_field(LoadArgs a, const double *
     }
 }
 
+// The strain (stress) interpolant of the parent element restricted to every boundary element (restrictInterpolant,
+// InterpolantRestriction.hh:29-66, applied to Element::strain): the nodal values of the degree-(DEG-1) interpolant on the
+// boundary simplex, i.e. one value for P1 and the values at the boundary element's DIM corners (in its own vertex order)
+// for P2. One thread per boundary element; the corner is located in the parent by its node id. out: [nBE][1 | DIM][flatLen].
+template <int DIM, int DEG, int MAT>
+__global__ void __launch_bounds__(256) k_boundary_strain_field(LoadArgs a, int64_t nBE, const int32_t *__restrict__ bdryParent,
+                                                               const int32_t *__restrict__ bdryElemNodes, int npbe,
+                                                               const double *__restrict__ uNodes, int wantStress, double *__restrict__ out) {
+    constexpr int NV = DIM + 1;
+    constexpr int FL = DIM * (DIM + 1) / 2;
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    constexpr int NQ = DEG == 1 ? 1 : DIM;
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nBE; b += (int64_t)gridDim.x * 256) {
+        const int64_t e = bdryParent[b];
+        const double *g = a.geo + e * a.geoStride;
+        const int32_t *en = a.elemNodes + e * NPE;
+        double gl[NV][DIM], xl[NPE][DIM];
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) gl[k][d] = g[k * DIM + d];
+#pragma unroll
+        for (int j = 0; j < NPE; ++j) {
+            const int64_t node = en[j];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) xl[j][d] = uNodes[node * DIM + d];
+        }
+        for (int c = 0; c < NQ; ++c) {
+            int q = 0;
+            if (DEG == 2) {
+                const int32_t corner = bdryElemNodes[b * npbe + c];
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+                    if (en[k] == corner) q = k;
+            }
+            double G[DIM][DIM], ef[FL];
+            grad_u_at<DIM, DEG, true>(xl, gl, q, G);
+#pragma unroll
+            for (int p = 0; p < DIM; ++p)
+#pragma unroll
+                for (int r = p; r < DIM; ++r) ef[flat_idx<DIM>(p, r)] = 0.5 * (G[p][r] + G[r][p]);
+            if (wantStress) {
+                double sd[FL], sg[FL];
+#pragma unroll
+                for (int i = 0; i < FL; ++i) sd[i] = ef[i] * (i < DIM ? 1.0 : 2.0);
+                elem_D_apply<DIM, MAT>(g, sd, sg);
+#pragma unroll
+                for (int i = 0; i < FL; ++i) ef[i] = sg[i];
+            }
+#pragma unroll
+            for (int i = 0; i < FL; ++i) out[(b * NQ + c) * FL + i] = ef[i];
+        }
+    }
+}
+
 // The exact differential of the mutual energies with respect to every vertex coordinate
 // (homogenizedElasticityTensorDiscreteDifferential, PeriodicHomogenization.hh:372-480, before the division by |Y|):
 // for the unit perturbation e_c of vertex v, delta vol / vol = gl_v[c] and delta grad lambda_i = -gl_v gl_i[c], so that
@@ -1541,6 +1596,19 @@ void launch_strain_field(const AsmArgs &a, const int32_t *elemNodes, const doubl
     const LoadArgs l = make_load_args(a, elemNodes, nullptr, intGrad, nullptr);
     const int grid = grid_for(a.nElem, 8192);
 #define CALL(D, G, M) hipLaunchKernelGGL((k_strain_field<D, G, M>), dim3(grid), dim3(256), 0, s, l, uNodes, wantStress, out)
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+    CHECK_LAUNCH();
+}
+
+void launch_boundary_strain_field(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, int64_t nBE,
+                                  const int32_t *bdryParent, const int32_t *bdryElemNodes, int npbe, const double *uNodes,
+                                  int wantStress, double *out, hipStream_t s) {
+    if (nBE == 0) return;
+    const LoadArgs l = make_load_args(a, elemNodes, nullptr, intGrad, nullptr);
+    const int grid = grid_for(nBE, 8192);
+#define CALL(D, G, M) hipLaunchKernelGGL((k_boundary_strain_field<D, G, M>), dim3(grid), dim3(256), 0, s, l, nBE, bdryParent, \
+                                         bdryElemNodes, npbe, uNodes, wantStress, out)
     MFH_DISPATCH(a, CALL);
 #undef CALL
     CHECK_LAUNCH();

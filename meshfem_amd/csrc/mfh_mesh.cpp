@@ -233,8 +233,10 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
     const int64_t nBE = (int64_t)bdryInst.size();
     const int nbv = dim; // vertices per boundary element
     std::vector<std::array<int32_t, 3>> bfaceVolCorners((size_t)nBE);   // volume half-face corner order
+    m.bdryParent.resize((size_t)nBE);
     for (int64_t b = 0; b < nBE; ++b) {
         const uint32_t inst = bdryInst[b];
+        m.bdryParent[b] = (int32_t)(inst / (dim + 1));
         if (dim == 3) {
             const int64_t t = inst / 4; const int f = inst % 4;
             bfaceVolCorners[b] = {ev[t * 4 + kFaceCorner[f][0]], ev[t * 4 + kFaceCorner[f][1]], ev[t * 4 + kFaceCorner[f][2]]};

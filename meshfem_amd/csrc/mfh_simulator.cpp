@@ -557,6 +557,30 @@ mfh_status mfh_strain_field(mfh_ctx *c, const double *uNodes, int32_t wantStress
     MFH_CATCH(c)
 }
 
+mfh_status mfh_boundary_strain_field(mfh_ctx *c, const double *uNodes, int32_t wantStress, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && out, MFH_ERR_STATE, "no mesh set");
+    require(c->mesh.hasTopology, MFH_ERR_STATE, "boundary elements need a mesh built with mfh_mesh_build");
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "strain / stress fields are defined for the elasticity operator");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const HostMesh &m = c->mesh;
+    const int d = m.dim, fl = flat_len(d), nq = m.deg == 1 ? 1 : d;
+    const int64_t nBE = m.nBE();
+    DBuf<double> u, res;
+    DBuf<int32_t> parent, ben;
+    u.alloc((size_t)m.nNode * d);
+    MFH_HIP(hipMemcpyAsync(u.p, uNodes, (size_t)m.nNode * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    parent.upload(m.bdryParent, c->stream);
+    ben.upload(m.bdryElemNodes, c->stream);
+    res.alloc((size_t)nBE * nq * fl);
+    k::launch_boundary_strain_field(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), nBE, parent.p, ben.p, m.npbe, u.p,
+                                    wantStress, res.p, c->stream);
+    res.download(out, res.n, c->stream);
+    MFH_CATCH(c)
+}
+
 mfh_status mfh_mutual_energy_differential(mfh_ctx *c, const double *w, double *out) {
     MFH_TRY(c)
     require(c && c->haveMesh && w && out, MFH_ERR_STATE, "no mesh set");

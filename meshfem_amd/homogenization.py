@@ -218,12 +218,80 @@ def delta_fluctuation_displacements(sim: Simulator, w_ij, delta_p):
 
 
 def delta_homogenized_elasticity_tensor(sim: Simulator, w_ij, delta_p, base_cell_volume=0.0):
-    """Change of Ch under delta_p (== deltaHomogenizedElasticityTensor, PeriodicHomogenization.hh:492-514) in the
-    volume form quoted there (:484-491); like the reference, the periodic cell volume |Y| is held fixed."""
+    """Change of Ch under delta_p in the volume form quoted at PeriodicHomogenization.hh:484-491 -- the exact derivative of
+    the discrete Ch; like the reference, the periodic cell volume |Y| is held fixed. The reference's own
+    deltaHomogenizedElasticityTensor (:492-514) evaluates the continuous boundary form instead:
+    `delta_homogenized_elasticity_tensor_boundary_form` reproduces that value."""
     if base_cell_volume == 0.0:
         pos = sim.nodes()
         base_cell_volume = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
     return sim.ctx.mutual_energies(w_ij, delta_p) / base_cell_volume
+
+
+def _bdry_gradient_weights(N, deg):
+    """W[a, n] = int over the unit-volume boundary simplex of lambda_a phi_n, phi the nodal basis of the degree 2 (deg - 1)
+    interpolant homogenizedElasticityTensorGradient returns (exact; the reference integrates with a quadrature rule of
+    degree 1 + GDeg, PeriodicHomogenization.hh:508-511)."""
+    from math import factorial
+
+    def mono(alpha):
+        num = factorial(N - 1)
+        for x in alpha:
+            num *= factorial(x)
+        return num / factorial(sum(alpha) + N - 1)
+    if deg == 1:
+        return np.full((N, 1), 1.0 / N)
+    edges = [(0, 1)] if N == 2 else [(0, 1), (1, 2), (2, 0)]
+    W = np.zeros((N, N + len(edges)))
+    for a in range(N):
+        for n in range(N):
+            a2 = [0] * N; a2[n] += 2; a2[a] += 1
+            a1 = [0] * N; a1[n] += 1; a1[a] += 1
+            W[a, n] = 2 * mono(a2) - mono(a1)
+        for k, (s, t) in enumerate(edges):
+            al = [0] * N; al[s] += 1; al[t] += 1; al[a] += 1
+            W[a, N + k] = 4 * mono(al)
+    return W
+
+
+def homogenized_elasticity_tensor_gradient(sim: Simulator, w_ij):
+    """== homogenizedElasticityTensorGradient (PeriodicHomogenization.hh:226-288): the steepest-ascent normal velocity of
+    every component of Ch as a per-boundary-element interpolant of degree 2 (Deg - 1): the nodal values
+    G_ijkl = 1/|bbox| (e_ij + eps(w_ij)) : E : (e_kl + eps(w_kl)) at the boundary element's nodes, zero on the periodic
+    (internal) boundary. Returns [nBE, 1 | npbe, flatLen, flatLen]. The strains and stresses at the boundary corners come
+    from the device (mfh_boundary_strain_field); the flatLen^2 contraction over a few 10^4 faces is done here."""
+    N, fl = sim.N, flat_len(sim.N)
+    c = sim.ctx
+    pos = sim.nodes()
+    bbox_vol = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
+    dbl = np.ones(fl)
+    dbl[N:] = 2.0
+    G = np.stack([c.boundary_strain_field(w_ij[k]) + canonical_strain_flat(N, k)[None, None, :] for k in range(fl)])      # [fl, nBE, nq, fl]
+    # stress(w) + E : e  ==  E : G (the device applies each element's own tensor)
+    S = np.stack([c.boundary_strain_field(w_ij[k] + pos @ _unflatten(N, canonical_strain_flat(N, k)).T, stress=True)
+                  for k in range(fl)])
+    if sim.degree == 2:                  # the linear interpolants at the boundary edge midpoints (0,1),(1,2),(2,0)
+        edges = [(0, 1)] if N == 2 else [(0, 1), (1, 2), (2, 0)]
+        mid = lambda X: np.concatenate([X] + [0.5 * (X[:, :, [s]] + X[:, :, [t]]) for s, t in edges], axis=2)
+        G, S = mid(G), mid(S)
+    out = np.einsum("ibnc,c,kbnc->bnik", S, dbl, G) / bbox_vol
+    out = 0.5 * (out + out.transpose(0, 1, 3, 2))      # major symmetry; the reference fills the upper triangle only
+    out[c.boundary_elem_internal().astype(bool)] = 0.0
+    return out
+
+
+def delta_homogenized_elasticity_tensor_boundary_form(sim: Simulator, w_ij, delta_p):
+    """== deltaHomogenizedElasticityTensor (PeriodicHomogenization.hh:492-514) exactly as the reference evaluates it: the
+    linear normal velocity n . delta_p of every boundary element integrated against homogenizedElasticityTensorGradient
+    (the continuous, Eulerian shape derivative; it differs from the exact discrete derivative of
+    `delta_homogenized_elasticity_tensor` by the discretisation error)."""
+    c = sim.ctx
+    sd = homogenized_elasticity_tensor_gradient(sim, w_ij)
+    area, nrm = c.boundary_elem_geometry()
+    ben = c.boundary_elem_nodes()[:, :sim.N]
+    nsv = np.einsum("bc,bac->ba", nrm, np.asarray(delta_p, dtype=np.float64)[ben])
+    W = _bdry_gradient_weights(sim.N, sim.degree)
+    return np.einsum("b,ba,an,bnik->ik", area, nsv, W, sd)
 
 
 def homogenized_elasticity_tensor_discrete_differential(sim: Simulator, w_ij, base_cell_volume=0.0, full=False):

@@ -113,6 +113,11 @@ class Simulator:
     def averageStrainField(self, u_nodes):                              # :528-538
         return self.ctx.average_strain(u_nodes)
 
+    def boundaryStrainField(self, u_nodes, stress=False):
+        """strain (stress) interpolants restricted to the boundary elements (restrictInterpolant, InterpolantRestriction.hh:29-66):
+        [nBdryElem, 1 | N, flatLen], values at the boundary element's corners in its own vertex order"""
+        return self.ctx.boundary_strain_field(u_nodes, stress=stress)
+
     def averageStressField(self, u_nodes):                              # :539-549
         return self.ctx.average_stress(u_nodes)
 

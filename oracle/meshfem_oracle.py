@@ -583,6 +583,7 @@ class FEMMesh:
     # boundary elements / vertices / nodes
     def _build_boundary(self):
         K, elems = self.K, self.elems
+        owner = {}                                                     # boundary simplex -> its volume element
         if K == 3:
             faces = {}
             for t in range(len(elems)):
@@ -593,6 +594,7 @@ class FEMMesh:
                         del faces[key]                                 # TetMesh.inl:59-68
                     else:
                         faces[key] = vs
+                        owner[key] = t
             bverts_of_elem = []
             for key in sorted(faces.keys()):                           # std::map order :75
                 vs = faces[key]
@@ -610,6 +612,7 @@ class FEMMesh:
                         del edges[key]
                     else:
                         edges[key] = (tail, tip)
+                        owner[key] = t
             bverts_of_elem = []
             order_src = []
             for key in sorted(edges.keys()):
@@ -621,6 +624,7 @@ class FEMMesh:
         else:
             raise ValueError(K)
         self.bdry_elem_verts = np.array(bverts_of_elem, dtype=np.int64).reshape(-1, K)
+        self.bdry_parent = np.array([owner[k] for k in sorted(faces.keys() if K == 3 else edges.keys())], dtype=np.int64)
         bv_index = {}
         for vs in order_src:
             for v in vs:
@@ -1517,6 +1521,97 @@ def mutual_energies(sim: "Simulator", w, deltaP=None):
                     + np.einsum('q,e,eqab,eabcd,eqcd->', wq, sim.vol, dG[ij], C4, G[kl], optimize=True) \
                     + np.einsum('q,e,eqab,eabcd,eqcd->', wq, sim.vol, G[ij], C4, dG[kl], optimize=True)
             out[ij, kl] = v
+    return out
+
+
+def boundary_strain_field(sim: "Simulator", u_nodes, stress=False):
+    """restrictInterpolant (InterpolantRestriction.hh:29-66) of Element::strain / stress to every boundary element:
+    [nBE, 1 | N, flatLen], the parent's interpolant at the boundary element's corners in the boundary vertex order."""
+    m, N = sim.mesh, sim.N
+    vol = sim.strainField(u_nodes, stress=stress)
+    nb = len(m.bdry_elem_verts)
+    out = np.zeros((nb, 1 if sim.deg == 1 else N, flat_len(N)))
+    for b in range(nb):
+        e = int(m.bdry_parent[b])
+        if sim.deg == 1:
+            out[b, 0] = vol[e, 0]                                       # degree 0 interpolants are not nodal (:45-48)
+            continue
+        for sdni in range(N):                                           # brute-force node search (:52-63)
+            for dni in range(sim.K + 1):
+                if m.elem_nodes[e, dni] == m.bdry_elem_verts[b, sdni]:
+                    out[b, sdni] = vol[e, dni]
+    return out
+
+
+def _simplex_monomial_integral(d, alpha):
+    """int over the unit-volume d-simplex of prod lambda_i^alpha_i = d! prod alpha_i! / (|alpha| + d)!"""
+    from math import factorial
+    num = factorial(d)
+    for a in alpha:
+        num *= factorial(a)
+    return num / factorial(sum(alpha) + d)
+
+
+def homogenized_elasticity_tensor_gradient(sim: "Simulator", w):
+    """homogenizedElasticityTensorGradient (PeriodicHomogenization.hh:226-288): per boundary element the nodal values of
+    G_ijkl = 1/|bbox| (e_ij + eps(w_ij)) : E : (e_kl + eps(w_kl)), a degree 2 (Deg - 1) interpolant; zero on the periodic
+    (internal) boundary. [nBE, nNodes(GDeg), flatLen, flatLen] (major-symmetric storage: upper triangle mirrored)."""
+    m, N, K, deg = sim.mesh, sim.N, sim.K, sim.deg
+    fl = flat_len(N)
+    bbox_vol = float(np.prod(m.node_pos.max(axis=0) - m.node_pos.min(axis=0)))      # mesh.boundingBox().volume() (:237)
+    nb = len(m.bdry_elem_nodes)
+    nn = 1 if deg == 1 else m.bdry_elem_nodes.shape[1]
+    strains = [sim.strainField(w[ij]) for ij in range(fl)]
+    out = np.zeros((nb, nn, fl, fl))
+    for b in range(nb):
+        if sim.beInternal[b]:
+            continue
+        e = int(m.bdry_parent[b])
+        en = list(m.elem_nodes[e])
+        D = sim.elem_D(e)
+        for n in range(nn):
+            def strain_at(ij):
+                if deg == 1:
+                    s = strains[ij][e, 0]
+                else:
+                    dni = en.index(m.bdry_elem_nodes[b, n])             # restriction by node id (InterpolantRestriction.hh:52-63)
+                    if dni <= K:
+                        s = strains[ij][e, dni]
+                    else:                                               # linear interpolant at an edge midpoint
+                        s = 0.5 * (strains[ij][e, EDGE_START[dni - K - 1]] + strains[ij][e, EDGE_END[dni - K - 1]])
+                return s + flatten_sym(N, canonical_strain(N, ij))
+            for ij in range(fl):
+                sij = D.double_contract_flat(strain_at(ij))
+                for kl in range(ij, fl):
+                    g = strain_at(kl)
+                    v = sum(sij[c] * g[c] * (1.0 if c < N else 2.0) for c in range(fl)) / bbox_vol
+                    out[b, n, ij, kl] = out[b, n, kl, ij] = v
+    return out
+
+
+def delta_homogenized_elasticity_tensor_boundary_form(sim: "Simulator", w, delta_p):
+    """deltaHomogenizedElasticityTensor (PeriodicHomogenization.hh:492-514): the boundary integral of the linear normal
+    velocity n . delta_p against homogenizedElasticityTensorGradient, integrated exactly."""
+    m, N, deg = sim.mesh, sim.N, sim.deg
+    fl = flat_len(N)
+    sd = homogenized_elasticity_tensor_gradient(sim, w)
+    bvol, bnrm = m.bdry_elem_geometry()
+    d = N - 1                                                           # boundary simplex dimension
+    out = np.zeros((fl, fl))
+    for b in range(len(m.bdry_elem_verts)):
+        nsv = [float(np.dot(bnrm[b], delta_p[m.bdry_elem_verts[b, a]])) for a in range(N)]
+        for a in range(N):
+            for n in range(sd.shape[1]):
+                if deg == 1:
+                    wgt = 1.0 / N                                       # int lambda_a
+                elif n < N:                                             # phi_n = lambda_n (2 lambda_n - 1)
+                    al2 = [0] * N; al2[n] += 2; al2[a] += 1
+                    al1 = [0] * N; al1[n] += 1; al1[a] += 1
+                    wgt = 2 * _simplex_monomial_integral(d, al2) - _simplex_monomial_integral(d, al1)
+                else:                                                   # phi = 4 lambda_s lambda_t on boundary edge n - N
+                    al = [0] * N; al[EDGE_START[n - N]] += 1; al[EDGE_END[n - N]] += 1; al[a] += 1
+                    wgt = 4 * _simplex_monomial_integral(d, al)
+                out += bvol[b] * wgt * nsv[a] * sd[b, n]
     return out
 
 
