@@ -294,6 +294,94 @@ def delta_homogenized_elasticity_tensor_boundary_form(sim: Simulator, w_ij, delt
     return np.einsum("b,ba,an,bnik->ik", area, nsv, W, sd)
 
 
+def normal_shape_velocity(sim: Simulator, delta_p):
+    """The linear normal velocity n . delta_p of every boundary element at its vertices (PeriodicHomogenization.hh:499-505): [nBE, N]"""
+    _, nrm = sim.ctx.boundary_elem_geometry()
+    ben = sim.ctx.boundary_elem_nodes()[:, :sim.N]
+    return np.einsum("bc,bac->ba", nrm, np.asarray(delta_p, dtype=np.float64)[ben])
+
+
+def _simplex_moments(d, order):
+    """int over the unit-volume d-simplex of mu_a mu_b (order 2) / mu_a mu_b mu_c (order 3)"""
+    from math import factorial
+    n = d + 1
+    out = np.zeros((n,) * order)
+    for idx in np.ndindex(*out.shape):
+        al = np.bincount(idx, minlength=n)
+        out[idx] = factorial(d) * np.prod([factorial(int(x)) for x in al]) / factorial(order + d)
+    return out
+
+
+def change_in_div_tensor_load(sim: Simulator, vn, t, ignore_periodic_bdry=True):
+    """== Simulator::changeInDivTensorLoad (LinearElasticity.hh:590-650): the per-DoF load -int_bdry vn strain(phi) : t dA
+    for boundary tensor interpolants t [nBE, 1 | N, flatLen] and the linear normal velocity vn [nBE, N]. A sum over the
+    boundary elements only (host): strain(phi_n e_c) : t = (t grad phi_n)_c with grad phi_n linear in the face's barycentric
+    coordinates, integrated exactly through the simplex moments instead of a quadrature rule."""
+    N, deg, c = sim.N, sim.degree, sim.ctx
+    K = N
+    area, _ = c.boundary_elem_geometry()
+    ben = c.boundary_elem_nodes()[:, :N]
+    parent = c.boundary_elem_parents().astype(np.int64)
+    en = sim.elements()[parent]                                              # parent element nodes [nBE, npe]
+    pos = sim.nodes()
+    P = pos[en[:, :K + 1]]
+    Minv = np.linalg.inv(np.transpose(P[:, :K] - P[:, [K]], (0, 2, 1)))     # rows: grad lambda_0..K-1
+    gl = np.concatenate([Minv, -Minv.sum(axis=1, keepdims=True)], axis=1)   # [nBE, K+1, N]
+    vn = np.asarray(vn, dtype=np.float64)
+    tm = np.stack([np.stack([_unflatten(N, x) for x in row]) for row in np.asarray(t)])     # [nBE, nq, N, N]
+    w = area.copy()
+    if ignore_periodic_bdry:
+        w[c.boundary_elem_internal().astype(bool)] = 0.0
+    if deg == 1:
+        contrib = np.einsum("e,e,eij,enj->eni", w, vn.mean(axis=1), tm[:, 0], gl)
+    else:
+        npe = en.shape[1]
+        L = (en[:, :K + 1, None] == ben[:, None, :]).astype(np.float64)      # lambda_k = sum_c L[k, c] mu_c on the face
+        A = np.zeros((len(en), npe, N))
+        B = np.zeros((len(en), npe, K + 1, N))
+        A[:, :K + 1] = -gl                                                   # grad phi_k = (4 lambda_k - 1) grad lambda_k
+        for k in range(K + 1):
+            B[:, k, k] = 4 * gl[:, k]
+        es, et = (0, 1, 2, 0, 2, 1), (1, 2, 0, 3, 3, 3)                      # Simplex.hh:43-44
+        for ei in range(npe - K - 1):                                        # grad phi_(s,t) = 4 (lambda_t grad lambda_s + lambda_s grad lambda_t)
+            B[:, K + 1 + ei, et[ei]] = 4 * gl[:, es[ei]]
+            B[:, K + 1 + ei, es[ei]] = 4 * gl[:, et[ei]]
+        Bm = np.einsum("enkj,ekc->encj", B, L)
+        M2, T3 = _simplex_moments(N - 1, 2), _simplex_moments(N - 1, 3)
+        contrib = np.einsum("e,ea,ebij,ab,enj->eni", w, vn, tm, M2, A, optimize=True) \
+            + np.einsum("e,ea,ebij,abc,encj->eni", w, vn, tm, T3, Bm, optimize=True)
+    dm, nd = c.get_dof_map()
+    load = np.zeros((nd, N))
+    np.subtract.at(load, dm[en], contrib)
+    return load
+
+
+def fluctuation_displacement_shape_derivatives(sim: Simulator, w_ij, vn, project_out_normal_stress=False):
+    """== fluctuationDisplacementShapeDerivatives (PeriodicHomogenization.hh:301-370): the Eulerian shape derivative of
+    every fluctuation displacement under the normal boundary velocity vn [nBE, N] (`normal_shape_velocity`), the "direct"
+    approach: cell problems loaded with -int_bdry vn strain(phi) : C : [strain(w^kl) + e^kl] dA. The boundary stresses come
+    from the device (mfh_boundary_strain_field), the solves reuse the assembled operator and its preconditioner."""
+    N, c = sim.N, sim.ctx
+    pos = sim.nodes()
+    _, nrm = c.boundary_elem_geometry()
+    internal = c.boundary_elem_internal().astype(bool)
+    out = []
+    for k in range(len(w_ij)):
+        st = c.boundary_strain_field(w_ij[k] + pos @ _unflatten(N, canonical_strain_flat(N, k)).T, stress=True)
+        st[internal] = 0.0
+        if project_out_normal_stress:                                        # s - (sn) n^T - n (sn)^T + (n^T s n) n n^T (:343-355)
+            sm = np.stack([np.stack([_unflatten(N, x) for x in row]) for row in st])
+            sn = np.einsum("bqij,bj->bqi", sm, nrm)
+            nsn = np.einsum("bqi,bi->bq", sn, nrm)
+            sm = sm - sn[..., :, None] * nrm[:, None, None, :] - nrm[:, None, :, None] * sn[..., None, :] \
+                + nsn[..., None, None] * (nrm[:, None, :, None] * nrm[:, None, None, :])
+            idx = {2: [(0, 0), (1, 1), (0, 1)], 3: [(0, 0), (1, 1), (2, 2), (1, 2), (0, 2), (0, 1)]}[N]
+            st = np.stack([sm[..., a, b] for a, b in idx], axis=-1)
+            st[internal] = 0.0
+        out.append(sim.solve(change_in_div_tensor_load(sim, vn, st, True)))
+    return out
+
+
 def homogenized_elasticity_tensor_discrete_differential(sim: Simulator, w_ij, base_cell_volume=0.0, full=False):
     """== homogenizedElasticityTensorDiscreteDifferential (PeriodicHomogenization.hh:372-480): the exact derivative of Ch
     with respect to every vertex coordinate (|Y| held fixed), all directions in one element sweep per tensor entry.

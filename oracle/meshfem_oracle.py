@@ -1615,6 +1615,54 @@ def delta_homogenized_elasticity_tensor_boundary_form(sim: "Simulator", w, delta
     return out
 
 
+def change_in_div_tensor_load(sim: "Simulator", vn, t, ignore_periodic_bdry=True):
+    """Simulator::changeInDivTensorLoad (LinearElasticity.hh:590-650), literal loops: the per-DoF load
+    -int_bdry vn strain(phi_n e_c) : t dA for the boundary tensor interpolants t [nBE, 1 | N, flatLen] (degree Deg - 1)
+    and the linear normal velocity vn [nBE, N] (boundary vertex order). strain(phi e_c) : t = (t grad phi)_c."""
+    m, N, K, deg = sim.mesh, sim.N, sim.K, sim.deg
+    load = np.zeros((sim.numDoFs(), N))
+    dof = sim.dof_array()
+    bvol, _ = m.bdry_elem_geometry()
+    pts, wts = quadrature_rule(K - 1, 1 + 2 * (deg - 1))                 # IntegrandDeg (:628-629)
+    for b in range(len(m.bdry_elem_verts)):
+        if ignore_periodic_bdry and sim.beInternal[b]:
+            continue
+        e = int(m.bdry_parent[b])
+        q = [list(m.elem_nodes[e, :K + 1]).index(v) for v in m.bdry_elem_verts[b]]
+        for mu, wq in zip(pts, wts):
+            lam = np.zeros(K + 1)
+            lam[q] = mu
+            gphi = grad_phis_at(deg, K, sim.gl[e], lam)                  # restrictInterpolant of the volume phi strains
+            tv = unflatten_sym(N, t[b, 0] if deg == 1 else sum(mu[c] * t[b, c] for c in range(N)))
+            vnv = float(np.dot(mu, vn[b]))
+            for n in range(m.nodes_per_elem):
+                load[dof[m.elem_nodes[e, n]]] -= bvol[b] * wq * vnv * (tv @ gphi[:, n])
+    return load
+
+
+def fluctuation_displacement_shape_derivatives(sim: "Simulator", w, vn, project_out_normal_stress=False):
+    """fluctuationDisplacementShapeDerivatives (PeriodicHomogenization.hh:301-370): the Eulerian shape derivative of every
+    w^kl under the normal boundary velocity vn, from cell problems loaded with -int_bdry vn strain(phi) : C : [strain(w^kl) + e^kl]."""
+    m, N = sim.mesh, sim.N
+    _, bnrm = m.bdry_elem_geometry()
+    out = []
+    for kl in range(len(w)):
+        st = boundary_strain_field(sim, w[kl]) + flatten_sym(N, canonical_strain(N, kl))[None, None, :]
+        for b in range(len(st)):
+            D = sim.elem_D(int(m.bdry_parent[b]))
+            for n in range(st.shape[1]):
+                st[b, n] = 0.0 if sim.beInternal[b] else D.double_contract_flat(st[b, n])
+                if project_out_normal_stress and not sim.beInternal[b]:   # s - (sn) n^T - n (sn)^T + (n^T s n) n n^T (:343-355)
+                    nn = bnrm[b]
+                    sm = unflatten_sym(N, st[b, n])
+                    half = 0.5 * (np.outer(sm @ nn, nn) + np.outer(nn, sm @ nn))
+                    sm = sm - 2.0 * half
+                    sm = sm - float(nn @ sm @ nn) * np.outer(nn, nn)
+                    st[b, n] = flatten_sym(N, sm)
+        out.append(sim.solve(change_in_div_tensor_load(sim, vn, st, True)))
+    return out
+
+
 def homogenized_elasticity_tensor_discrete_differential(sim: "Simulator", w, base_cell_volume=0.0):
     """homogenizedElasticityTensorDiscreteDifferential (PeriodicHomogenization.hh:372-480), literal loops: the one-form
     dCh[vertex, component] as flatLen x flatLen tensors (upper triangle ij <= kl filled, mirrored at the end).
