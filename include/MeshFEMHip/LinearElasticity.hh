@@ -125,8 +125,14 @@ public:
     // materials: Materials::Constant / per-element fields (Simulate_cli.cc:104-175)
     void setIsotropicMaterial(Real E, Real nu) { check(ctx(), mfh_material_isotropic(ctx(), E, nu)); }
     void setMaterialTensor(const std::vector<Real> &D /* flatLen^2 row-major */) { check(ctx(), mfh_material_const(ctx(), D.data())); }
-    void setIsotropicField(const std::vector<Real> &E, const std::vector<Real> &nu) { check(ctx(), mfh_material_iso_field(ctx(), E.data(), nu.data())); }
-    void setOrthotropicField(const std::vector<Real> &params) { check(ctx(), mfh_material_ortho_field(ctx(), params.data())); }
+    void setIsotropicField(const std::vector<Real> &E, const std::vector<Real> &nu) {
+        if (E.size() != numElements() || nu.size() != numElements()) throw std::runtime_error("setIsotropicField: one (E, nu) pair per element expected");
+        check(ctx(), mfh_material_iso_field(ctx(), E.data(), nu.data()));
+    }
+    void setOrthotropicField(const std::vector<Real> &params) {
+        if (params.size() != numElements() * (N == 3 ? 9 : 4)) throw std::runtime_error("setOrthotropicField: 9 (3D) / 4 (2D) parameters per element expected");
+        check(ctx(), mfh_material_ortho_field(ctx(), params.data()));
+    }
 
     // box-region boundary conditions (applyBoundaryConditions, :881-1027)
     void applyDirichletBox(const std::array<Real, N> &mn, const std::array<Real, N> &mx, const std::array<Real, N> &value,

@@ -227,7 +227,6 @@ k::AsmArgs asm_args(mfh_ctx *c) {
     a.chunkSlots = c->sym.chunkSlots;
     a.nElem = m.nElem; a.scatterSlot = c->dScatter.p;
     a.vals = c->dVals.p; a.nnzb = c->sym.nnzb;
-    a.debugVariant = c->debugVariant;
     a.xcd = c->xcdSwizzle;
     return a;
 }
@@ -321,7 +320,6 @@ k::SpmvMfArgs spmv_mf_args(mfh_ctx *c, bool masked) {
     a.geo = c->dGeo.p; a.geoStride = c->geoStride; a.pairTable = c->dPairTable.p; a.massTable = c->dMassTable.p;
     for (int k2 = 0; k2 < 6; ++k2) a.pairConst[k2] = c->tables.pairConst[k2];
     a.maxRows = c->mf.maxRows;
-    a.variant = c->debugVariant;
     a.xcd = c->xcdSwizzle;
     a.nElem = m.nElem;
     a.sig = c->dMfSig.p;
@@ -1219,6 +1217,8 @@ mfh_status mfh_matrix_set_upper_triplets(mfh_ctx *c, int64_t n, int64_t nnz, con
     MFH_TRY(c)
     require(c && n > 0 && nnz >= 0 && (nnz == 0 || (ti && tj && tv)), MFH_ERR_INVALID, "bad matrix arguments");
     require(n < (int64_t)1 << 31, MFH_ERR_UNSUPPORTED, "matrix too large for 32-bit indices");
+    // rowPtr / slots are 32-bit: the mirrored matrix has at most 2 nnz entries
+    require(nnz < ((int64_t)1 << 30), MFH_ERR_UNSUPPORTED, "matrix has too many non-zeros for 32-bit slots (2 nnz must stay below 2^31)");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     struct Ent { int32_t r, c; double v; };
@@ -1249,10 +1249,16 @@ mfh_status mfh_matrix_set_upper_triplets(mfh_ctx *c, int64_t n, int64_t nnz, con
     S.chunkSlots = c->chunkSlots;
     S.chunkRow.assign(1, 0);
     S.contribPtr.assign(1, 0);
-    S.spmvChunkSlots = std::max(512, c->chunkSlots);
+    // a chunk holds whole rows: it grows to the longest row, up to what 64 KB of LDS partials allow (8000 entries;
+    // the CHOLMOD path has no such limit -- rows denser than that need a different kernel and are rejected)
+    int32_t maxRow = 0;
+    for (int64_t r = 0; r < n; ++r) maxRow = std::max(maxRow, S.rowPtr[r + 1] - S.rowPtr[r]);
+    S.maxRowLen = maxRow;
+    S.spmvChunkSlots = std::max(std::max(512, c->chunkSlots), std::min(maxRow, 8000));
     S.spmvChunkRow.assign(1, 0);
     for (int64_t r = 0; r < n;) {
-        require(S.rowPtr[r + 1] - S.rowPtr[r] <= S.spmvChunkSlots, MFH_ERR_UNSUPPORTED, "matrix row longer than an SpMV chunk");
+        require(S.rowPtr[r + 1] - S.rowPtr[r] <= S.spmvChunkSlots, MFH_ERR_UNSUPPORTED,
+                "matrix row with more than 8000 entries: longer than the LDS partial-sum buffer of the SpMV kernel");
         const int32_t s0 = S.rowPtr[r];
         int64_t r2 = r + 1;
         while (r2 < n && S.rowPtr[r2 + 1] - s0 <= S.spmvChunkSlots) ++r2;
@@ -1658,7 +1664,6 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "tl_device_aggregates") { c->tlDeviceAggregates = value != 0; c->tl.valid = false; }
     else if (k2 == "tl_probe") { c->tlProbe = value != 0; c->tl.valid = false; }
     else if (k2 == "tl_host_inverse") { c->tlHostInverse = value != 0; c->tl.valid = false; }
-    else if (k2 == "debug_variant") { c->debugVariant = (int)value; invalidate_matrix(c); }
     else throw Error(MFH_ERR_INVALID, "unknown option " + k2);
     MFH_CATCH(c)
 }

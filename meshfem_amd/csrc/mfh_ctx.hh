@@ -16,7 +16,6 @@ struct mfh_ctx {
     bool keepHostSymbolic = false;
     int xcdSwizzle = 0;              // option "xcd_swizzle": XCD-contiguous work mapping in the chunked kernels (measured SLOWER
                                      // than the round-robin default on MI355X: DESIGN.md section 4.8)
-    int debugVariant = 0;            // option "debug_variant": timing experiments of the gather kernel
     std::vector<double> hLoad, hX;   // host scratch of Simulator::solve (kept between solves)
     bool alwaysReembed = false;      // option "reembed": every mfh_assemble re-runs the embedding kernel
     bool periodicIgnoreMismatch = false;   // option "periodic_ignore_mismatch": PeriodicCondition(..., ignoreMismatch)

@@ -290,7 +290,6 @@ struct AsmArgs {
     // output
     double *vals;                       // tiled [ceil(nnzb/64)][dim*dim][64]
     int64_t nnzb;
-    int debugVariant;                   // timing experiments only (0 = product kernel)
     int xcd;                            // 1: XCD-contiguous chunk mapping (xcd_item)
 };
 
@@ -352,7 +351,6 @@ struct SpmvMfArgs {
     const double *pairTable, *massTable;
     double pairConst[6];
     int maxRows;                        // rows per chunk (LDS accumulators)
-    int variant;                        // timing experiments only (0 = product kernel)
     int xcd;                            // 1: XCD-contiguous chunk / element-group ranges (xcd_span)
     // cluster variant (k_mf_cluster); rowWrite restricts the writes of k_mf_rows to the interface rows
     int64_t clBlocks;

@@ -23,10 +23,10 @@ namespace mfh { namespace k {
 // components per matrix entry: dim x dim blocks for elasticity, 1 for the scalar operators
 template <int DIM, int MAT> DEV constexpr int mat_nb() { return (MAT == MAT_LAPLACE || MAT == MAT_MASS) ? 1 : DIM * DIM; }
 
-template <int DIM, int DEG, int MAT, int ABL = 0>
+template <int DIM, int DEG, int MAT>
 DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pairTab, const PairConst &pc, int i, int j, double *K) {
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
-    const double vol = (ABL & 2) ? 1.0 + i : g[12];
+    const double vol = g[12];
     if (MAT == MAT_MASS) {
         // int phi_i phi_j = vol * (reference value): exact for straight-sided simplices, equal to the
         // reference's Quadrature<K, 2 Deg> (exact for this integrand) up to rounding (MassMatrix.hh:66-77)
@@ -63,13 +63,12 @@ DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pai
         double S1 = vj ? 0.0 : coef(lAi == lBj, oi, 0.0);                        // A_i B_j
         double S2 = vi ? 0.0 : coef(lBi == lAj, 0.0, oj);                        // B_i A_j
         double S3 = (vi | vj) ? 0.0 : coef(lBi == lBj, 0.0, 0.0);                // B_i B_j
-        if (ABL & 1) { S0 = pairTab[0]; S1 = pairTab[1]; S2 = pairTab[2]; S3 = pairTab[3]; }
         S0 *= vol; S1 *= vol; S2 *= vol; S3 *= vol;
         double ua[DIM], ub[DIM], p[DIM], q[DIM];
 #pragma unroll
         for (int a = 0; a < DIM; ++a) {
-            ua[a] = (ABL & 2) ? (double)(si + a) : g[si * DIM + a]; ub[a] = (ABL & 2) ? (double)(ti - a) : g[ti * DIM + a];
-            const double va = (ABL & 2) ? (double)(sj * a) : g[sj * DIM + a], vb = (ABL & 2) ? (double)(tj + 2 * a) : g[tj * DIM + a];
+            ua[a] = g[si * DIM + a]; ub[a] = g[ti * DIM + a];
+            const double va = g[sj * DIM + a], vb = g[tj * DIM + a];
             p[a] = S0 * va + S1 * vb;
             q[a] = S2 * va + S3 * vb;
         }
@@ -86,7 +85,7 @@ DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pai
         K[0] = tr;
     } else if (MAT == MAT_ISO) {
         // C_acdb = lambda d_ac d_db + mu (d_ad d_cb + d_ab d_cd)  =>  K = lambda H + mu H^T + mu tr(H) I
-        const double lam = (ABL & 2) ? 0.5 : g[13], mu = (ABL & 2) ? 0.25 : g[14];
+        const double lam = g[13], mu = g[14];
         double tr = 0;
 #pragma unroll
         for (int a = 0; a < DIM; ++a) tr += H[a][a];
@@ -230,7 +229,7 @@ __global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *
 // accumulated in LDS with ds_add_f64; the finished rows are written once, coalesced, with plain
 // stores. No global atomics, no read-modify-write of K, no zero-fill pass.
 // ------------------------------------------------------------------------------------------------
-template <int DIM, int DEG, int MAT, int DBG = 0>
+template <int DIM, int DEG, int MAT>
 __global__ void __launch_bounds__(256) k_assemble_gather(AsmArgs a) {
     constexpr int NB = mat_nb<DIM, MAT>();
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
@@ -252,9 +251,8 @@ __global__ void __launch_bounds__(256) k_assemble_gather(AsmArgs a) {
     // U independent contributions per lane and trip: their index loads, element-record loads and
     // block arithmetic have no mutual dependence, so the loads of all U are in flight together
     // (the kernel is latency-bound: rocprof shows 65 % of wave cycles in s_waitcnt at U = 1).
-    constexpr int U = (DBG >= 10 && DBG < 20) ? (DBG - 10) : 2;
-    constexpr int ABL = (DBG >= 20 && DBG < 24) ? (DBG - 20) : 0;
-    for (int64_t k0 = kb + threadIdx.x; k0 < ((DBG == 25 || DBG == 27) ? kb : ke); k0 += 256 * U) {
+    constexpr int U = 2;
+    for (int64_t k0 = kb + threadIdx.x; k0 < ke; k0 += 256 * U) {
         uint32_t code[U];
         int ls[U];
         bool ok[U];
@@ -271,21 +269,16 @@ __global__ void __launch_bounds__(256) k_assemble_gather(AsmArgs a) {
             const uint32_t e = code[u] / (NPE * NPE);
             const int ij = (int)(code[u] - e * (NPE * NPE));
             const int i = ij / NPE, j = ij - i * NPE;
-            elem_block<DIM, DEG, MAT, ABL>(a.geo + (int64_t)e * a.geoStride, MAT == MAT_MASS ? a.massTable : a.pairTable, pc, i, j, K[u]);
+            elem_block<DIM, DEG, MAT>(a.geo + (int64_t)e * a.geoStride, MAT == MAT_MASS ? a.massTable : a.pairTable, pc, i, j, K[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!ok[u]) continue;
 #pragma unroll
-            for (int c = 0; c < NB; ++c) {
-                if (DBG == 1) acc[c * CS + ls[u]] += K[u][c];                     // timing experiment only (racy)
-                else if (DBG == 2) acc[c * CS + (threadIdx.x & (CS - 1))] = K[u][c]; // timing experiment only
-                else unsafeAtomicAdd(&acc[c * CS + ls[u]], K[u][c]);
-            }
+            for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&acc[c * CS + ls[u]], K[u][c]);
         }
     }
     __syncthreads();
-    if (DBG == 24 && ns > 1) return;       // timing experiment: no write-out
     // write-out: one 16-byte store per lane and component (two adjacent slots); the store path is
     // issue-bound, so halving the store-instruction count matters more than anything else here
     const int nl = ns + par;                               // LDS entries [par, nl) are live
@@ -302,8 +295,8 @@ __global__ void __launch_bounds__(256) k_assemble_gather(AsmArgs a) {
             typedef double dv2 __attribute__((ext_vector_type(2)));
             // non-temporal: K is not re-read by this kernel; keeping it out of L2 leaves the cache to the
             // element records and gather lists (2.12 -> 1.71 ms at 1.5 M P2 tets)
-            if (DBG != 28) { dv2 w = {v.x, v.y}; __builtin_nontemporal_store(w, reinterpret_cast<dv2 *>(dst)); }
-            else *dst = v;
+            dv2 w = {v.x, v.y};
+            __builtin_nontemporal_store(w, reinterpret_cast<dv2 *>(dst));
         }
     }
     // the (at most two) slots that are not part of a fully live pair
@@ -626,7 +619,7 @@ __global__ void __launch_bounds__(256) k_spmv(SpmvArgs a, const double *__restri
 // assembled SpMV for ~73 FP64 flops/block: HBM traffic drops from nnzb*76 B to the element records +
 // pair lists + x, the FP64 VALU (idle in the assembled SpMV) does the work.
 // ------------------------------------------------------------------------------------------------
-template <int DIM, int DEG, int MAT, bool PCG, int UNR = 0>
+template <int DIM, int DEG, int MAT, bool PCG>
 __global__ void __launch_bounds__(256) k_spmv_mf(SpmvMfArgs a, const double *__restrict__ x, double *__restrict__ y, double *dotOut,
                                                  double *scal, int it, const double *stopPtr) {
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
@@ -660,8 +653,7 @@ __global__ void __launch_bounds__(256) k_spmv_mf(SpmvMfArgs a, const double *__r
             double out[BS];
 #pragma unroll
             for (int c = 0; c < BS; ++c) out[c] = 0.0;
-            constexpr int UNROLL_PAIRS = UNR == 0 ? NPE : UNR;
-#pragma unroll UNROLL_PAIRS
+#pragma unroll
             for (int j = 0; j < NPE; ++j) {
                 int64_t col = en[j];
                 if (a.dofForNode) col = a.dofForNode[col];
@@ -1497,29 +1489,7 @@ void launch_assemble_gather(const AsmArgs &a, hipStream_t s) {
     if (lds > 64 * 1024)                                                                                         \
         MFH_HIP(hipFuncSetAttribute((const void *)k_assemble_gather<D, G, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
     hipLaunchKernelGGL((k_assemble_gather<D, G, M>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a)
-    if (a.debugVariant && a.dim == 3 && a.deg == 2 && a.mat == MAT_ISO) {
-        switch (a.debugVariant) {
-        case 1: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 1>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 2: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 2>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 21: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 21>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 22: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 22>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 23: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 23>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 24: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 24>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 28: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 28>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 25: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 25>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 26: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 26>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 27: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 27>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 11: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 11>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 12: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 12>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 13: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 13>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 14: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 14>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 16: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 16>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        case 18: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 18>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        default: hipLaunchKernelGGL((k_assemble_gather<3, 2, MAT_ISO, 0>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); break;
-        }
-    } else {
-        MFH_DISPATCH_ASM(a, CALL);
-    }
+    MFH_DISPATCH_ASM(a, CALL);
 #undef CALL
     CHECK_LAUNCH();
 }
@@ -1670,19 +1640,7 @@ void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dot
 #define CALL(D, G, M)                                                                                                          \
     if (pcg) hipLaunchKernelGGL((k_spmv_mf<D, G, M, true>), dim3(grid), dim3(256), lds, s, a, x, y, (double *)nullptr, scal, it, stopPtr); \
     else hipLaunchKernelGGL((k_spmv_mf<D, G, M, false>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr)
-    if (a.variant && a.dim == 3 && a.deg == 2 && a.mat == MAT_ISO) {
-        // timing experiments: unroll factor of the j loop (register pressure vs ILP)
-        switch (a.variant) {
-        case 1: if (pcg) hipLaunchKernelGGL((k_spmv_mf<3, 2, MAT_ISO, true, 1>), dim3(grid), dim3(256), lds, s, a, x, y, (double *)nullptr, scal, it, stopPtr);
-                else hipLaunchKernelGGL((k_spmv_mf<3, 2, MAT_ISO, false, 1>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr); break;
-        case 2: if (pcg) hipLaunchKernelGGL((k_spmv_mf<3, 2, MAT_ISO, true, 2>), dim3(grid), dim3(256), lds, s, a, x, y, (double *)nullptr, scal, it, stopPtr);
-                else hipLaunchKernelGGL((k_spmv_mf<3, 2, MAT_ISO, false, 2>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr); break;
-        default: if (pcg) hipLaunchKernelGGL((k_spmv_mf<3, 2, MAT_ISO, true, 5>), dim3(grid), dim3(256), lds, s, a, x, y, (double *)nullptr, scal, it, stopPtr);
-                else hipLaunchKernelGGL((k_spmv_mf<3, 2, MAT_ISO, false, 5>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr); break;
-        }
-    } else {
-        MFH_DISPATCH_ASM(a, CALL);
-    }
+    MFH_DISPATCH_ASM(a, CALL);
 #undef CALL
     CHECK_LAUNCH();
 }

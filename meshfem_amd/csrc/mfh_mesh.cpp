@@ -333,56 +333,117 @@ void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofFo
     auto periodicDim = [&](int a) { return !(ignoreDimsMask & (1 << a)); };
     auto onMin = [&](int64_t n, int a) { return periodicDim(a) && std::fabs(m.nodePos[(size_t)n * dim + a] - mn[a]) <= eps; };
     auto onMax = [&](int64_t n, int a) { return periodicDim(a) && std::fabs(m.nodePos[(size_t)n * dim + a] - mx[a]) <= eps; };
-    // group boundary nodes lying on some cell face by their position wrapped onto the min faces
-    struct Key { int64_t q[3]; int32_t node; };
-    std::vector<Key> keys;
-    const double cell = 10 * eps;
+    // Identified node sets over the boundary nodes that lie on some periodic cell face. Matching is by DISTANCE, like the
+    // reference's CollisionGrid::getClosestPoint(query, eps) (CollisionGrid.hh:58-88): the closest candidate within eps of
+    // the translated position, found through a hash grid of cell size max(eps, 1e-7) whose cells overlapping
+    // [q - eps, q + eps] are probed.
+    std::vector<int32_t> faceNodes;                   // boundary nodes on a periodic face, in boundary-node order
     for (int32_t n : m.bdryNodes) {
         bool onFace = false;
         for (int a = 0; a < dim; ++a) onFace |= onMin(n, a) || onMax(n, a);
-        if (!onFace) continue;
-        Key k{{0, 0, 0}, n};
-        for (int a = 0; a < dim; ++a) {
-            double p = onMax(n, a) ? mn[a] : m.nodePos[(size_t)n * dim + a];
-            k.q[a] = (int64_t)std::llround((p - mn[a]) / cell);
-        }
-        keys.push_back(k);
+        if (onFace) faceNodes.push_back(n);
     }
-    std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
-        for (int c = 0; c < 3; ++c) if (a.q[c] != b.q[c]) return a.q[c] < b.q[c];
-        return a.node < b.node;
-    });
+    const double cs = std::max(eps, 1.0e-7);
+    struct CellKey { int64_t q[3]; bool operator==(const CellKey &o) const { return q[0] == o.q[0] && q[1] == o.q[1] && q[2] == o.q[2]; } };
+    struct CellHash { size_t operator()(const CellKey &k) const {
+        uint64_t h = 1469598103934665603ull;
+        for (int c = 0; c < 3; ++c) { h ^= (uint64_t)k.q[c]; h *= 1099511628211ull; h ^= h >> 29; }
+        return (size_t)h; } };
+    typedef std::unordered_map<CellKey, std::vector<int32_t>, CellHash> Grid;
+    auto cellOf = [&](const double *p) { CellKey k{{0, 0, 0}}; for (int a = 0; a < dim; ++a) k.q[a] = (int64_t)std::floor(p[a] / cs); return k; };
+    auto addPoint = [&](Grid &g, int32_t n) { g[cellOf(&m.nodePos[(size_t)n * dim])].push_back(n); };
+    auto closest = [&](const Grid &g, const double *q) -> int32_t {
+        int64_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+        for (int a = 0; a < dim; ++a) { lo[a] = (int64_t)std::floor((q[a] - eps) / cs); hi[a] = (int64_t)std::floor((q[a] + eps) / cs); }
+        int32_t best = -1;
+        double bestDist = eps;
+        for (int64_t i = lo[0]; i <= hi[0]; ++i)
+            for (int64_t j = lo[1]; j <= hi[1]; ++j)
+                for (int64_t k = lo[2]; k <= hi[2]; ++k) {
+                    auto it = g.find(CellKey{{i, j, k}});
+                    if (it == g.end()) continue;
+                    for (int32_t c : it->second) {
+                        double d2 = 0;
+                        for (int a = 0; a < dim; ++a) { const double d = q[a] - m.nodePos[(size_t)c * dim + a]; d2 += d * d; }
+                        const double dist = std::sqrt(d2);
+                        if (dist <= bestDist) { bestDist = dist; best = c; }
+                    }
+                }
+        return best;
+    };
+    auto isMinimal = [&](int32_t n) { for (int a = 0; a < dim; ++a) if (onMax(n, a)) return false; return true; };
     std::vector<int32_t> groupOf((size_t)m.nNode, -1);
     std::vector<std::vector<int32_t>> groups;
-    for (size_t k = 0; k < keys.size();) {
-        size_t k2 = k + 1;
-        while (k2 < keys.size() && keys[k2].q[0] == keys[k].q[0] && keys[k2].q[1] == keys[k].q[1] && keys[k2].q[2] == keys[k].q[2]) ++k2;
-        groups.emplace_back();
-        for (size_t t = k; t < k2; ++t) { groups.back().push_back(keys[t].node); groupOf[keys[t].node] = (int32_t)groups.size() - 1; }
-        k = k2;
-    }
     if (!ignoreMismatch) {
-        // PeriodicBoundaryMatcher::match (PeriodicBoundaryMatcher.hh:149-260): a node on d periodic faces is identified with
-        // exactly 2^d nodes, one per combination of min / max faces; anything else is a mismatch and throws
-        for (const auto &g : groups) {
-            int d = 0;
-            for (int a = 0; a < dim; ++a) d += onMin(g[0], a) || onMax(g[0], a);
-            bool ok = g.size() == (size_t(1) << d);
-            std::vector<uint8_t> seen(size_t(1) << d, 0);
-            for (int32_t n : g) {
-                int dn = 0, code = 0, bit = 0;
-                for (int a = 0; a < dim; ++a) {
-                    const bool lo = onMin(n, a), hi = onMax(n, a);
-                    if (lo || hi) { ++dn; if (hi) code |= 1 << bit; ++bit; }
+        // PeriodicBoundaryMatcher::match (PeriodicBoundaryMatcher.hh:149-260): every MINIMAL node (on min faces only) on d
+        // periodic faces looks up its 2^d - 1 translates among the non-minimal nodes; a missing translate, a node claimed
+        // twice or a non-minimal node left over is an error
+        Grid grid;
+        for (int32_t n : faceNodes) if (!isMinimal(n)) addPoint(grid, n);
+        char buf[320];
+        for (int32_t n : faceNodes) {
+            if (!isMinimal(n)) continue;
+            int dims[3], d = 0;
+            for (int a = 0; a < dim; ++a) if (onMin(n, a)) dims[d++] = a;
+            groupOf[n] = (int32_t)groups.size();
+            groups.emplace_back(1, n);
+            const double *p = &m.nodePos[(size_t)n * dim];
+            for (int t = 1; t < (1 << d); ++t) {
+                double q[3] = {p[0], p[1], dim == 3 ? p[2] : 0.0};
+                for (int b = 0; b < d; ++b) if (t & (1 << b)) q[dims[b]] = mx[dims[b]];
+                const int32_t r = closest(grid, q);
+                if (r < 0) {
+                    snprintf(buf, sizeof buf, "Couldn't find %dth periodic-identified node for minimal boundary node %d at (%g, %g, %g); looking for (%g, %g, %g)",
+                             t, n, p[0], p[1], dim == 3 ? p[2] : 0.0, q[0], q[1], q[2]);
+                    throw Error(MFH_ERR_INVALID, buf);
                 }
-                if (dn != d || seen[code & ((1 << d) - 1)]++) ok = false;
+                if (groupOf[r] >= 0) throw Error(MFH_ERR_INVALID, "Non bijective node set assignment.");
+                groupOf[r] = groupOf[n];
+                groups[(size_t)groupOf[n]].push_back(r);
             }
-            if (!ok) {
-                const double *p = &m.nodePos[(size_t)g[0] * dim];
-                char buf[256];
-                snprintf(buf, sizeof buf, "Couldn't find every periodic-identified node for boundary node %d at (%g, %g, %g): %zu of %d found",
-                         g[0], p[0], p[1], dim == 3 ? p[2] : 0.0, g.size(), 1 << d);
+        }
+        for (int32_t n : faceNodes)
+            if (groupOf[n] < 0) {
+                const double *p = &m.nodePos[(size_t)n * dim];
+                snprintf(buf, sizeof buf, "Unmatched non-minimal boundary node %d at (%g, %g, %g)", n, p[0], p[1], dim == 3 ? p[2] : 0.0);
                 throw Error(MFH_ERR_INVALID, buf);
+            }
+    } else {
+        // PeriodicBoundaryMatcher::matchPermittingMismatch (:262-360): per dimension, every node of the max face looks up its
+        // translate on the min face (a miss is a mismatch, not an error); node sets = connected components of the pair graph
+        std::unordered_map<int32_t, std::array<int32_t, 3>> pair;
+        for (int a = 0; a < dim; ++a) {
+            Grid grid;
+            for (int32_t n : faceNodes) if (onMin(n, a)) addPoint(grid, n);
+            for (int32_t n : faceNodes) {
+                if (!onMax(n, a)) continue;
+                const double *p = &m.nodePos[(size_t)n * dim];
+                double q[3] = {p[0], p[1], dim == 3 ? p[2] : 0.0};
+                q[a] = mn[a];
+                const int32_t r = closest(grid, q);
+                if (r < 0) continue;
+                if (!pair.count(n)) pair[n] = {-1, -1, -1};
+                if (!pair.count(r)) pair[r] = {-1, -1, -1};
+                if (pair[n][a] != -1 || pair[r][a] != -1) throw Error(MFH_ERR_INVALID, "Non-bijective boundary matching");
+                pair[n][a] = r;
+                pair[r][a] = n;
+            }
+        }
+        for (int32_t n : faceNodes) {
+            if (groupOf[n] >= 0) continue;
+            const int32_t gi = (int32_t)groups.size();
+            groupOf[n] = gi;
+            groups.emplace_back(1, n);
+            for (size_t head = 0; head < groups[(size_t)gi].size(); ++head) {
+                const int32_t u = groups[(size_t)gi][head];
+                auto it = pair.find(u);
+                if (it == pair.end()) continue;
+                for (int a = 0; a < dim; ++a) {
+                    const int32_t v = it->second[a];
+                    if (v < 0 || groupOf[v] >= 0) continue;
+                    groupOf[v] = gi;
+                    groups[(size_t)gi].push_back(v);
+                }
             }
         }
     }

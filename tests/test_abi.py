@@ -68,3 +68,21 @@ def test_public_header_is_plain_c99(tmp_path):
     r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"), "-fsyntax-only", str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_default_library_has_no_experiment_variants():
+    """The shipped library contains the product kernels only: no ablation / racy variant of the assembly kernel can be
+    selected (the timing experiments of round 1 are documented in profiles/r01_assembly_optimisation_log.md, not compiled
+    in), and no kernel symbol carries an extra experiment template argument."""
+    c = M.Context(-1)
+    with pytest.raises(M.MeshFEMHipError, match="unknown option"):
+        c.set_option("debug_variant", 1)
+    c.close()
+    import subprocess
+    out = subprocess.run(["nm", "-C", M.LIB_PATH], capture_output=True, text=True).stdout
+    names = set(re.findall(r"k_assemble_gather<[^>]*>", out))
+    assert names, "assembly kernel stubs not found"
+    for n in names:
+        assert n.count(",") == 2, "unexpected template arguments: " + n     # <DIM, DEG, MAT> only
+    src = open(os.path.join(ROOT, "meshfem_amd", "csrc", "mfh_kernels.hip")).read()
+    assert "racy" not in src and "DBG" not in src

@@ -121,3 +121,48 @@ def test_manual_periodic_vertices_file_homogenization_equals_detected(tmp_path):
             (tmp_path / "pairs.txt").write_text("\n".join("%d %d" % (a, b) for g in groups.values() for a, b in zip(g[1:], g[:-1])) + "\n")
         res.append(H.homogenized_elasticity_tensor(sim, w))
     assert np.abs(res[0] - res[1]).max() < 1e-8 * np.abs(res[0]).max()
+
+
+@pytest.mark.parametrize("ignore_mismatch", [False, True])
+def test_matching_is_by_distance_not_by_quantised_keys(ignore_mismatch):
+    """The reference matches with CollisionGrid::getClosestPoint(query, eps) (PeriodicBoundaryMatcher.hh:222, :300;
+    CollisionGrid.hh:58-88): partners within eps of the translated position are identified wherever they fall relative
+    to any quantisation grid. Coordinate noise 10x below eps on a 12^3 grid, ten seeds (a key-equality matcher fails
+    this in about four of ten), plus a half-cell coordinate offset by 4e-10."""
+    V0, T = O.grid_tet_mesh(12, 12, 12)
+    # spacing 0.0833335: every odd grid coordinate is an odd multiple of 0.5e-6, i.e. it sits on a rounding boundary of a
+    # key grid with cells of 10 eps = 1e-6
+    L = 12 * 0.0833335
+    V0 = V0 * 0.0833335
+    ref, nref = _host_dofs(V0, T, 1)
+    for seed in range(10):
+        rng = np.random.default_rng(seed)
+        V = V0 + rng.uniform(-1e-8, 1e-8, V0.shape)
+        # the bounding box itself must stay the unit cube: keep the eight corners exact
+        corner = np.all((V0 == 0.0) | (np.abs(V0 - L) < 1e-12), axis=1)
+        V[corner] = V0[corner]
+        dofs, n = _host_dofs(V, T, 1, ignore_mismatch=ignore_mismatch)
+        assert n == nref and np.array_equal(dofs, ref), "seed %d" % seed
+    V = V0.copy()
+    half = np.flatnonzero((np.abs(V0[:, 0] - L) < 1e-12) & (np.abs(V0[:, 1] - L / 2) < 1e-12))
+    V[half, 1] += 4e-10
+    dofs, n = _host_dofs(V, T, 1, ignore_mismatch=ignore_mismatch)
+    assert n == nref and np.array_equal(dofs, ref)
+    od, on_, _ = O.periodic_dofs_for_nodes(O.FEMMesh(T, V, 1), ignore_mismatch=ignore_mismatch)
+    assert on_ == n and np.array_equal(od, dofs)
+
+
+def test_distinct_nodes_closer_than_ten_eps_are_not_merged():
+    """Nodes of one face that are further apart than eps keep different DoFs even when they are closer than 10 eps
+    (a key grid of cell size 10 eps would merge them): eps = 0.02 on a grid whose nodes are 1/6 apart."""
+    V, T = O.grid_tet_mesh(3, 3, 3)
+    V = V / 3.0
+    c = M.Context(-1)
+    c.mesh_build(T, V, 1)
+    n = c.apply_periodic_conditions(0.02)
+    dofs = c.get_dof_map()[0]
+    c.close()
+    ref, nref = _host_dofs(V, T, 1)
+    assert n == nref and np.array_equal(dofs, ref)
+    od, on_, _ = O.periodic_dofs_for_nodes(O.FEMMesh(T, V, 1), eps=0.02)
+    assert on_ == n and np.array_equal(od, dofs)
