@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """bench.py -- headline benchmark of the MI355X-native MeshFEM hot path.
 
-    python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          (N > 1: the script launches its own N ranks)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   (the driver's form)
 
 Metric (BASELINE.json): stiffness-assembly elements/s (+ PCG DOF/s), quadratic tets.
   * workload at N=1: BASELINE.json configs[2] -- synthetic 60^3 grid -> 5,184,000 P2 tets
@@ -16,9 +16,10 @@ Metric (BASELINE.json): stiffness-assembly elements/s (+ PCG DOF/s), quadratic t
     L ~ 60^3 / n^2 hex layers per rank (N = 8: the 120^3 cube, 41.5 M P2 tets, 15-layer z-slabs), so every rank
     keeps ~5.2 M elements (row/element partition, owner computes, no assembly communication); the PCG leg
     runs the distributed solver (halo exchange + all-reduces over RCCL, global two-level preconditioner).
-Extra objects on the JSON line: `roofline` (assembly kernel), `pcg` (solve to 1e-8 incl. its own
-roofline for the SpMV kernel), `cpu_baseline` (plain-C port of the reference loop structure timed
-on the host cores, bounded sample), `variants` (atomic-scatter assembly for comparison).
+Extra objects on the JSON line: `roofline` (assembly kernel: the contract fraction on SURVEY's algorithmic bytes AND the
+fraction on the bytes the counters / the design actually move), `pcg` (solve to 1e-8 incl. its own roofline for the
+operator kernels), `cpu_baseline` (plain-C port of the reference loop structure timed on the host cores, bounded sample,
+plus a DIRECT SOLVE of a bounded sample next to the PCG at the same size), `variants` (atomic-scatter assembly).
 """
 import argparse
 import json
@@ -32,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
+PMC_PROFILE = "r01_pmc_traffic_n60.json"
+PMC_KERNEL_KEY = "k_assemble_gather<3, 2, 0, 0>"
 ALG_BYTES = {(3, 2): 7736, (3, 1): 1328, (2, 2): 1368, (2, 1): 0}   # SURVEY.md section 8(d), const material
 
 
@@ -50,6 +53,9 @@ def parse():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-orderings", action="store_true", help="skip the shuffled / Morton-ordered mesh variants")
     ap.add_argument("--cpu-grid", type=int, default=0, help="grid size of the CPU-baseline sample (0 = auto)")
+    ap.add_argument("--cpu-solve-grid", type=int, default=0, help="grid size of the CPU direct-solve sample (0 = auto)")
+    ap.add_argument("--ranks-per-gpu-ok", action="store_true",
+                    help="N > visible GPUs: share the GPUs (ranks on one GPU talk through gloo, staged through the host)")
     return ap.parse_args()
 
 
@@ -57,7 +63,7 @@ def pmc_traffic(kernel_key, n, deg):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in their
     own runs, calibrated on a known byte count: profiles/r01_pmc_traffic_n60.json). PMC counters cannot
     be collected from inside this process; the figure is only attached when the workload matches."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic_n60.json")
+    path = os.path.join(ROOT, "profiles", PMC_PROFILE)
     try:
         with open(path) as f:
             d = json.load(f)
@@ -66,6 +72,70 @@ def pmc_traffic(kernel_key, n, deg):
     except Exception:
         pass
     return None, None
+
+
+def compulsory_assembly_bytes(c, n_elem, nnzb, geo_bytes=128):
+    """HBM bytes the owner-computes design must move per launch: K written once (72 B per block), the element records
+    (read at least once), the gather lists (4 B code + 2 B slot per contribution) and the chunk / row tables."""
+    sizes = c.symbolic_sizes()
+    nr, _, _ = c.matrix_info()
+    return int(nnzb * 72 + n_elem * geo_bytes + sizes["n_contrib"] * 6 + sizes["n_chunk"] * 12 + nr * 4)
+
+
+def cpu_direct_solve(deg, n, rtol):
+    """The reference's dominant cost is the sparse direct solve (CholmodFactorizer, SparseMatrices.hh:2002-2024,2106-2124,
+    settings :2243-2295). CHOLMOD / SuiteSparse is not installed in this image (ctypes.util.find_library finds none), so
+    the labelled stand-in is scipy's SuperLU in symmetric mode -- the oracle's direct solver -- on a bounded sample
+    of the same workload (same generator, boundary conditions and material), next to the library's PCG at that size."""
+    import ctypes.util
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from oracle import c_oracle as CO
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    D = np.zeros((6, 6))
+    lam, mu = 0.35 * 200 / (1.35 * 0.3), 200 / 2.7
+    D[:3, :3] = lam
+    D[np.arange(3), np.arange(3)] = lam + 2 * mu
+    D[np.arange(3, 6), np.arange(3, 6)] = mu
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    c = M.Context(0)
+    c.mesh_build(T, V, deg)
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+    c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    t0 = time.perf_counter()
+    u_gpu = c.sim_solve(rtol=rtol)
+    gpu_wall = time.perf_counter() - t0            # symbolic + assembly + PCG + transfers, cold context
+    gi = dict(c.last_info)
+    en, nn, pos, f = c.elem_nodes(), c.n_node, c.node_positions(), c.neumann_load().ravel()
+    c.close()
+    Ap, Ai, Ax, t = CO.assemble_csc(3, deg, en, V, D, nn)
+    N = 3 * nn
+    t0 = time.perf_counter()
+    U = sp.csc_matrix((Ax, Ai, Ap), shape=(N, N))
+    K = (U + sp.triu(U, 1).T).tocsc()
+    free = np.flatnonzero(~np.repeat(np.abs(pos[:, 0]) < 1e-9, 3))
+    Kr = K[free][:, free].tocsc()                  # SPSDSystem::fixVariables: eliminated rows / columns (:2389-2500)
+    t_elim = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    lu = spla.splu(Kr, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    t_factor = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    x = lu.solve(f[free])
+    t_solve = time.perf_counter() - t0
+    u = np.zeros(N)
+    u[free] = x
+    err = float(np.linalg.norm(u_gpu.ravel() - u) / np.linalg.norm(u))
+    have_cholmod = ctypes.util.find_library("cholmod") is not None
+    return dict(kind="stand-in: scipy.sparse.linalg.splu (SuperLU 'MMD_AT_PLUS_A', SymmetricMode), 1 thread; CHOLMOD %s"
+                     % ("found but not bound" if have_cholmod else "not installed on this box"),
+                sample="%d^3 grid -> %d P%d tets" % (n, len(T), deg), dof=int(N), free_dof=int(len(free)), cores=1,
+                assemble_s=float(t["total"]), eliminate_s=t_elim, factor_s=t_factor, backsolve_s=t_solve,
+                solve_s=t_factor + t_solve, time_to_solution_s=float(t["total"]) + t_elim + t_factor + t_solve,
+                factor_nnz=int(lu.L.nnz + lu.U.nnz),
+                gpu_pcg=dict(iterations=gi["iterations"], solve_s=gi["solve_ms"] * 1e-3, wall_s_cold_context=gpu_wall,
+                             rel_l2_vs_direct=err, rtol=rtol))
 
 
 def cpu_baseline(deg, cpu_grid):
@@ -94,6 +164,21 @@ def cpu_baseline(deg, cpu_grid):
         if t["total"] > 8.0:
             break
     return best
+
+
+def cpu_baseline_with_solve(args):
+    out = cpu_baseline(args.deg, args.cpu_grid)
+    try:
+        ds = None
+        for n in ([args.cpu_solve_grid] if args.cpu_solve_grid else [6, 8]):     # the last size that starts is reported (~15 s)
+            ds = cpu_direct_solve(args.deg, n, args.rtol)
+            if ds["solve_s"] > 4.0:
+                break
+        out["direct_solve"] = ds
+        out.update(solve_s=ds["solve_s"], dof=ds["dof"], solve_kind=ds["kind"])
+    except Exception as e:   # noqa: BLE001 -- the baseline must not lose the GPU numbers
+        out["direct_solve"] = dict(error="%s: %s" % (type(e).__name__, e))
+    return out
 
 
 def hbm_stream_probe(torch, n_doubles=1 << 27, reps=10):
@@ -150,16 +235,23 @@ def run_single(args):
     # dominant kernel alone, HIP events on the context's stream
     k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
     alg = ALG_BYTES[(3, deg)] * nE
-    tb, tsrc = pmc_traffic("k_assemble_gather<3, 2, 0, 0>", n, deg)
+    tb, tsrc = pmc_traffic(PMC_KERNEL_KEY, n, deg)
+    nr, nc, nnzb = c.matrix_info()
+    comp = compulsory_assembly_bytes(c, nE, nnzb)
     roof = dict(bound="hbm", kernel="k_assemble_gather", achieved=alg / k_ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=alg / k_ms / 1e6 / HBM_PEAK_GBS, traffic=None if tb is None else tb / k_ms / 1e6,
-                traffic_bytes_per_launch=tb, traffic_source=tsrc, alg_bytes_per_launch=alg, kernel_ms=k_ms,
-                bytes_per_element=ALG_BYTES[(3, deg)])
+                # the contract fraction above counts SURVEY 8(d)'s 100 Ke blocks per element, which an owner-computes kernel
+                # never moves; the two fractions below are on bytes that DO cross the HBM interface
+                frac_traffic=None if tb is None else tb / k_ms / 1e6 / HBM_PEAK_GBS,
+                compulsory_bytes=comp, frac_compulsory=comp / k_ms / 1e6 / HBM_PEAK_GBS,
+                traffic_bytes_per_launch_from_profile=tb, traffic_from_profile=tsrc, alg_bytes_per_launch=alg, kernel_ms=k_ms,
+                bytes_per_element=ALG_BYTES[(3, deg)],
+                note="frac = SURVEY 8(d) algorithmic bytes / time / 8 TB/s (contract); frac_traffic = rocprofv3 PMC bytes of the "
+                     "committed profile / time; frac_compulsory = bytes the design must move (K once + records + lists) / time")
     # context: the kernel's MEASURED traffic rate against the triad rate measured on this box a minute ago
     if roof["traffic"] is not None:
         roof["measured_triad_GBs"] = hbm_measured["triad_GBs"]
         roof["traffic_frac_of_measured_triad"] = roof["traffic"] / hbm_measured["triad_GBs"]
-    nr, nc, nnzb = c.matrix_info()
     out = dict(metric="stiffness_assembly_elements_per_s", value=value, unit="elements/s", n_gpus=1, steps=args.steps,
                warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, scaling="weak", vs_baseline=None,
                dtype="f64", data="synthetic",
@@ -253,7 +345,7 @@ def run_single(args):
             except M.MeshFEMHipError as e:
                 out["variants"]["orderings"][mode] = str(e)
     if not args.no_cpu:
-        out["cpu_baseline"] = cpu_baseline(deg, args.cpu_grid)
+        out["cpu_baseline"] = cpu_baseline_with_solve(args)
     print(json.dumps(out), flush=True)
 
 
@@ -265,9 +357,17 @@ def run_multi(args):
     os.environ.setdefault("MASTER_PORT", "29511")
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", rank))
-    torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-    res = D.bench_slabs(args, rank, world, local)
+    ndev = torch.cuda.device_count()
+    shared = ndev < world                       # fewer GPUs than ranks (a 1-GPU box): ranks share devices, gloo transport
+    if shared and not (args.ranks_per_gpu_ok or os.environ.get("MFH_BENCH_SHARE_GPUS")):
+        raise SystemExit("bench.py --gpus %d needs %d GPUs, %d visible (pass --ranks-per-gpu-ok to share them)" % (world, world, ndev))
+    device = local % max(1, ndev)
+    torch.cuda.set_device(device)
+    if shared:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+    res = D.bench_slabs(args, rank, world, device, shared_gpus=shared)
     dist.barrier()
     dist.destroy_process_group()
     # RCCL writes its version banner through C stdio, which is flushed late when stdout is a pipe:
@@ -278,9 +378,27 @@ def run_multi(args):
         print(json.dumps(res), flush=True)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves, exactly as the driver's command line
+    would (torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MFH_BENCH_CHILD="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 if __name__ == "__main__":
     a = parse()
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("MFH_BENCH_FORCE_DISTRIBUTED"):
         run_multi(a)
+    elif a.gpus > 1:
+        self_launch(a)
     else:
         run_single(a)

@@ -217,7 +217,12 @@ mfh_status mfh_set_preconditioner(mfh_ctx* ctx, int32_t kind);
 /* coarse-space facts of the last two-level setup: aggregates, coarse dimension, setup time (ms); note = why it fell back (or "") */
 mfh_status mfh_precond_info(const mfh_ctx* ctx, int32_t* nAggregates, int64_t* coarseDim, double* setup_ms, const char** note);
 mfh_status mfh_solve(mfh_ctx* ctx, int32_t nrhs, const double* f, double* u,
-                     double rtol, int32_t maxit, mfh_solve_info* info);
+                     double rtol, int32_t maxit, mfh_solve_info* info /* ONE entry: the last right-hand side */);
+/* the same with one mfh_solve_info per right-hand side. Right-hand sides are solved in batches (3D: 6 or 2, 2D: 3): the
+ * matrix-free operator fetches every element record once per batch, like the reference factors once and back-substitutes
+ * per right-hand side (PeriodicHomogenization.hh:34-54). info[k].reserved = size of the batch rhs k was solved in. */
+mfh_status mfh_solve_batch(mfh_ctx* ctx, int32_t nrhs, const double* f, double* u,
+                           double rtol, int32_t maxit, mfh_solve_info* info /* nrhs entries */);
 /* == Simulator::applyStiffnessMatrix (LinearElasticity.hh:801-823), using the assembled K       */
 mfh_status mfh_apply_K(mfh_ctx* ctx, const double* u /* dim*nDoF */, double* Ku);
 
@@ -340,6 +345,52 @@ mfh_status mfh_dev_mask_fixed(mfh_ctx* ctx, double* r_dev);
 mfh_status mfh_dev_set_fixed_values(mfh_ctx* ctx, double* u_dev);
 mfh_status mfh_dev_sync(mfh_ctx* ctx);
 
+/* ---------------------------------------------------------------- multi-GPU solve (one process per GPU)
+ * The reference is single-process (TBB, Parallelism.hh:31-43): these entry points have no counterpart to cite beyond the
+ * serial path they parallelise (Simulator::solve, LinearElasticity.hh:479-487; SPSDSystem::solve, SparseMatrices.hh:2515-2606).
+ * Rows (nodes) are partitioned: every rank builds its context with mfh_mesh_set(..., nOwned) -- owned nodes first, halo
+ * nodes after them GROUPED BY OWNER RANK -- and assembles its rows without communication. The solve needs, per PCG
+ * iteration, one neighbour exchange of the halo entries and ONE all-reduce of 4 nrhs doubles (two with the two-level
+ * preconditioner); both go through an mfh_comm:
+ *   mfh_comm_create_rccl       RCCL communicator of `world` ranks created from a shared unique id (rank 0 calls
+ *                              mfh_rccl_get_unique_id and distributes the 128 bytes by any means: MPI, a file, torch's store).
+ *                              RCCL is looked up with dlopen (the process's own copy if it has one, e.g. PyTorch's), so the
+ *                              library links against no particular communication stack.
+ *   mfh_comm_create_callbacks  the two collectives supplied by the caller (MPI, torch.distributed/gloo in the CPU-staged
+ *                              tests ...). Buffers are DEVICE pointers; the call must be ordered on `hipStream` (enqueue
+ *                              there, or synchronise the stream, do the transfer and return).
+ * mfh_dist_setup: peers = neighbouring ranks; sendNodes[sendPtr[k] .. sendPtr[k+1]) = OWNED local nodes whose values rank
+ *   peers[k] reads (in the order that rank stores them); halo nodes nOwned + [recvPtr[k], recvPtr[k+1]) are owned by peers[k].
+ * mfh_dist_two_level: the two-level preconditioner with GLOBAL aggregates (arguments as mfh_tl_partitioned_begin; the
+ *   coarse operator is summed over the ranks, every rank inverts it redundantly).
+ * mfh_dist_solve: f / u are nrhs vectors of dim * nOwned doubles (this rank's rows). Fixed variables (mfh_fix_variables,
+ *   local numbering) must be given for halo nodes as well as owned ones.                                              */
+typedef struct mfh_comm mfh_comm;
+typedef struct mfh_rccl_unique_id { char internal[128]; } mfh_rccl_unique_id;
+typedef mfh_status (*mfh_allreduce_fn)(void* user, double* devBuf, int64_t n, void* hipStream);
+typedef mfh_status (*mfh_exchange_fn)(void* user, int32_t nPeers, const int32_t* peers, const double* const* sendBufs,
+                                      const int64_t* sendCounts, double* const* recvBufs, const int64_t* recvCounts, void* hipStream);
+mfh_status  mfh_rccl_get_unique_id(mfh_rccl_unique_id* id);
+mfh_status  mfh_comm_create_rccl(mfh_ctx* ctx, const mfh_rccl_unique_id* id, int32_t rank, int32_t world, mfh_comm** out);
+mfh_status  mfh_comm_create_callbacks(int32_t rank, int32_t world, void* user, mfh_allreduce_fn allreduce_sum,
+                                      mfh_exchange_fn exchange, mfh_comm** out);
+void        mfh_comm_destroy(mfh_comm* comm);
+const char* mfh_comm_describe(const mfh_comm* comm);
+/* in-place sum of n doubles in device memory over the ranks (blocking) */
+mfh_status  mfh_comm_allreduce(mfh_ctx* ctx, mfh_comm* comm, double* devBuf, int64_t n);
+/* ring shift of a known message + an all-reduce with a known sum: checks the transport end to end */
+mfh_status  mfh_comm_selftest(mfh_ctx* ctx, mfh_comm* comm);
+mfh_status  mfh_dist_setup(mfh_ctx* ctx, mfh_comm* comm, int32_t nPeers, const int32_t* peers, const int64_t* sendPtr /* nPeers+1 */,
+                           const int32_t* sendNodes, const int64_t* recvPtr /* nPeers+1 */);
+mfh_status  mfh_dist_two_level(mfh_ctx* ctx, int32_t nAgg, const int32_t* aggOfNode, const double* relPos);
+mfh_status  mfh_dist_solve(mfh_ctx* ctx, int32_t nrhs, const double* fOwned, double* uOwned, double rtol, int32_t maxit,
+                           mfh_solve_info* info /* nrhs entries, or NULL */);
+/* (K u) on this rank's rows for a field given on its rows (halo entries fetched from the owners) */
+mfh_status  mfh_dist_apply_K(mfh_ctx* ctx, const double* uOwned, double* KuOwned);
+/* blocking copy helper for callback communicators that stage through the host: kind 0 host->device, 1 device->host,
+ * 2 device->device; hipStream NULL = the context's stream */
+mfh_status  mfh_dev_memcpy(mfh_ctx* ctx, void* dst, const void* src, int64_t bytes, int32_t kind, void* hipStream);
+
 /* ---------------------------------------------------------------- introspection / measurement */
 mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
 /* average device time (ms, HIP events on the context stream) of `reps` back-to-back launches of
@@ -360,6 +411,10 @@ mfh_status mfh_matrix_free_info(mfh_ctx* ctx, int32_t* active, int32_t* mode, in
  * "matrix_free_mode" (4 default: cluster variant, forces of 256 consecutive elements summed in LDS | 3 two-pass, forces in
  *   list order | 2 two-pass, forces element-major | 1 per-pair block evaluation), "mf_chunk_rows", "mf_chunk_pairs",
  * "pcg_graph" (1 default: blocks of check_every PCG iterations are replayed from a hipGraph),
+ * "pcg_variant" (1: Chronopoulos-Gear PCG, one reduction point per iteration and one fused vector kernel -- always used by
+ *   mfh_dist_solve and for batches; 0: the classic two-reduction PCG, one right-hand side at a time; -1 default: classic for
+ *   a single right-hand side on an unpartitioned context, where it is 6-14 % faster per iteration), "batch_rhs" (0 default:
+ *   1 solves several right-hand sides per operator pass, see mfh_solve_batch),
  * "solve_homogeneous" (1: mfh_solve treats the fixed variables as fixed to ZERO whatever values were given -- the
  *   homogeneous solves K y = C^T of a Schur-complement elimination of constraint rows, SparseMatrices.hh:2572-2590),
  * "periodic_ignore_mismatch" (1: nodes of a periodic face without a partner keep their own DoF, PeriodicCondition's

@@ -76,6 +76,7 @@ PROTOTYPES = {
     "mfh_set_preconditioner": (_i32, [_P, _i32]),
     "mfh_precond_info": (_i32, [_P, _pi32, _pi64, C.POINTER(_f64), C.POINTER(C.c_char_p)]),
     "mfh_solve": (_i32, [_P, _i32, _P, _P, _f64, _i32, C.POINTER(SolveInfo)]),
+    "mfh_solve_batch": (_i32, [_P, _i32, _P, _P, _f64, _i32, C.POINTER(SolveInfo)]),
     "mfh_apply_K": (_i32, [_P, _P, _P]),
     "mfh_bc_clear": (_i32, [_P]),
     "mfh_bc_dirichlet_box": (_i32, [_P, _P, _P, _i32, _P, _i32]),
@@ -117,6 +118,18 @@ PROTOTYPES = {
     "mfh_dev_mask_fixed": (_i32, [_P, _P]),
     "mfh_dev_set_fixed_values": (_i32, [_P, _P]),
     "mfh_dev_sync": (_i32, [_P]),
+    "mfh_rccl_get_unique_id": (_i32, [_P]),
+    "mfh_comm_create_rccl": (_i32, [_P, _P, _i32, _i32, C.POINTER(_P)]),
+    "mfh_comm_create_callbacks": (_i32, [_i32, _i32, _P, _P, _P, C.POINTER(_P)]),
+    "mfh_comm_destroy": (None, [_P]),
+    "mfh_comm_describe": (C.c_char_p, [_P]),
+    "mfh_comm_allreduce": (_i32, [_P, _P, _P, _i64]),
+    "mfh_comm_selftest": (_i32, [_P, _P]),
+    "mfh_dist_setup": (_i32, [_P, _P, _i32, _P, _P, _P, _P]),
+    "mfh_dist_two_level": (_i32, [_P, _i32, _P, _P]),
+    "mfh_dist_solve": (_i32, [_P, _i32, _P, _P, _f64, _i32, C.POINTER(SolveInfo)]),
+    "mfh_dist_apply_K": (_i32, [_P, _P, _P]),
+    "mfh_dev_memcpy": (_i32, [_P, _P, _P, _i64, _i32, _P]),
     "mfh_get_timing": (_i32, [_P, C.POINTER(Timing)]),
     "mfh_time_assembly_kernel": (_i32, [_P, _i32, _i32, C.POINTER(_f64)]),
     "mfh_time_spmv_kernel": (_i32, [_P, _i32, C.POINTER(_f64)]),
@@ -124,6 +137,10 @@ PROTOTYPES = {
     "mfh_debug_spd_inverse": (_i32, [_i64, _P]),
     "mfh_debug_spd_inverse_device": (_i32, [_P, _i64, _P]),
 }
+
+# callback types of mfh_comm_create_callbacks
+ALLREDUCE_FN = C.CFUNCTYPE(_i32, _P, _P, _i64, _P)
+EXCHANGE_FN = C.CFUNCTYPE(_i32, _P, _i32, C.POINTER(_i32), C.POINTER(_P), C.POINTER(_i64), C.POINTER(_P), C.POINTER(_i64), _P)
 
 _lib = None
 

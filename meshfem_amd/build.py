@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmeshfem_hip.so")
-SOURCES = ["mfh_api.cpp", "mfh_simulator.cpp", "mfh_mesh.cpp", "mfh_symbolic.cpp", "mfh_twolevel.cpp", "mfh_symbolic_gpu.hip", "mfh_kernels.hip", "mfh_kernels_solver.hip"]
+SOURCES = ["mfh_api.cpp", "mfh_solver.cpp", "mfh_simulator.cpp", "mfh_mesh.cpp", "mfh_symbolic.cpp", "mfh_twolevel.cpp", "mfh_symbolic_gpu.hip", "mfh_kernels.hip", "mfh_kernels_solver.hip"]
 HOST_ONLY = ["mfh_twolevel.cpp"]
 HEADERS = ["mfh_internal.hh", "mfh_ctx.hh", "mfh_device.hh", os.path.join("..", "..", "include", "meshfem_hip.h")]
 
@@ -32,6 +32,7 @@ def build_lib(force=False, verbose=True):
         return LIB
     objs = []
     common = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function"]
+    common += os.environ.get("MFH_CXXFLAGS", "").split()      # experiments only (e.g. -DMFH_EXPERIMENTS); the default build has none
     procs = []
     for s in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(s)[0] + ".o")

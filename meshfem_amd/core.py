@@ -288,6 +288,20 @@ class Context:
         self._ck(st)
         return u
 
+    def solve_batch(self, f, rtol=1e-8, maxit=100000):
+        """All right-hand sides (rows of f) in batches sharing the operator passes; returns (u, [info per rhs])."""
+        f = as_f64(f)
+        n = self.bs * self.n_dof
+        nrhs = f.size // n
+        assert f.size == nrhs * n
+        u = np.empty((nrhs, n))
+        infos = (L.SolveInfo * nrhs)()
+        st = self.lib.mfh_solve_batch(self.h, nrhs, ptr(f), ptr(u), float(rtol), int(maxit), infos)
+        self.last_infos = [i.as_dict() for i in infos]
+        self.last_info = self.last_infos[-1]
+        self._ck(st)
+        return u, self.last_infos
+
     def apply_K(self, u):
         u = as_f64(u)
         nr, nc, _ = self.matrix_info() if self._assembled_info() else (self.n_dof, self.n_dof, 0)
@@ -497,6 +511,40 @@ class Context:
 
     def dev_set_fixed_values(self, u_ptr):
         self._ck(self.lib.mfh_dev_set_fixed_values(self.h, C.c_void_p(u_ptr)))
+
+    # ---- row-partitioned solve through an mfh_comm
+    def dist_setup(self, comm, peers, send_ptr, send_nodes, recv_ptr):
+        peers, send_ptr, send_nodes, recv_ptr = as_i32(peers), as_i64(send_ptr), as_i32(send_nodes), as_i64(recv_ptr)
+        self._ck(self.lib.mfh_dist_setup(self.h, comm.h, len(peers), ptr(peers), ptr(send_ptr), ptr(send_nodes), ptr(recv_ptr)))
+        self._comm = comm          # keep the communicator (and its callbacks) alive as long as the context uses it
+
+    def dist_two_level(self, n_agg, agg_of_node, rel_pos):
+        agg_of_node, rel_pos = as_i32(agg_of_node), as_f64(rel_pos)
+        self._ck(self.lib.mfh_dist_two_level(self.h, int(n_agg), ptr(agg_of_node), ptr(rel_pos)))
+
+    def dist_solve(self, f_owned, rtol=1e-8, maxit=100000):
+        """f_owned: [nrhs, dim * nOwned] (or flat for one right-hand side); returns (u_owned, [info per rhs])."""
+        f = as_f64(f_owned)
+        nr, _, _ = self.matrix_info()
+        n = self.bs * nr
+        nrhs = f.size // n
+        assert f.size == nrhs * n
+        u = np.empty((nrhs, n))
+        infos = (L.SolveInfo * nrhs)()
+        st = self.lib.mfh_dist_solve(self.h, nrhs, ptr(f), ptr(u), float(rtol), int(maxit), infos)
+        self.last_infos = [i.as_dict() for i in infos]
+        self.last_info = self.last_infos[-1]
+        self._ck(st)
+        return u, self.last_infos
+
+    def dist_apply_K(self, u_owned):
+        u = as_f64(u_owned)
+        out = np.empty_like(u)
+        self._ck(self.lib.mfh_dist_apply_K(self.h, ptr(u), ptr(out)))
+        return out
+
+    def dev_memcpy(self, dst, src, nbytes, kind, stream=None):
+        self._ck(self.lib.mfh_dev_memcpy(self.h, dst, src, int(nbytes), int(kind), stream))
 
     def dev_sync(self):
         self._ck(self.lib.mfh_dev_sync(self.h))

@@ -588,8 +588,9 @@ double device_dot(mfh_ctx *c, int64_t n, const double *a, const double *b) {
     return v;
 }
 
-// PCG on the free variables of K (SPSDSystem::solve with CHOLMOD replaced).
-void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info) {
+// Classic PCG (two reduction points per iteration) on the free variables of K, one right-hand side: kept as option
+// "pcg_variant" 0 and for the operator variants without a batched kernel; the default solver is mfh_solver.cpp.
+void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info) {
     RoctxRange range("Elasticity Solve");
     const int d = c->bs();
     const int64_t n = (int64_t)d * c->nDoF;
@@ -1390,14 +1391,30 @@ mfh_status mfh_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, doubl
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
     if (c->precond == MFH_PRECOND_TWO_LEVEL) ensure_twolevel(c);
+    require(c->sym.nRows == c->sym.nCols, MFH_ERR_STATE, "mfh_solve needs all rows owned; use mfh_dist_solve for partitioned meshes");
     const int64_t n = (int64_t)c->bs() * c->nDoF;
+    std::vector<mfh_solve_info> infos((size_t)nrhs);
+    solve_many(c, nrhs, f, u, n, rtol, maxit, infos.data());
     bool allConverged = true;
-    for (int k2 = 0; k2 < nrhs; ++k2) {
-        mfh_solve_info li{};
-        solve_one(c, f + (size_t)k2 * n, u + (size_t)k2 * n, rtol, maxit, &li);
-        if (info) info[0] = li;
-        allConverged &= li.converged != 0;
-    }
+    for (int k2 = 0; k2 < nrhs; ++k2) allConverged &= infos[k2].converged != 0;
+    if (info) info[0] = infos[(size_t)nrhs - 1];
+    if (!allConverged) throw Error(MFH_ERR_NOT_CONVERGED, "PCG did not reach the requested tolerance within maxit iterations");
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_solve_batch(mfh_ctx *c, int32_t nrhs, const double *f, double *u, double rtol, int32_t maxit, mfh_solve_info *info) {
+    MFH_TRY(c)
+    require(c && (c->haveMesh || c->external) && f && u && nrhs > 0 && maxit > 0 && rtol > 0, MFH_ERR_INVALID, "bad solve arguments");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_precond(c);
+    if (c->precond == MFH_PRECOND_TWO_LEVEL) ensure_twolevel(c);
+    require(c->sym.nRows == c->sym.nCols, MFH_ERR_STATE, "mfh_solve_batch needs all rows owned; use mfh_dist_solve for partitioned meshes");
+    const int64_t n = (int64_t)c->bs() * c->nDoF;
+    std::vector<mfh_solve_info> infos((size_t)nrhs);
+    solve_many(c, nrhs, f, u, n, rtol, maxit, infos.data());
+    bool allConverged = true;
+    for (int k2 = 0; k2 < nrhs; ++k2) { allConverged &= infos[k2].converged != 0; if (info) info[k2] = infos[k2]; }
     if (!allConverged) throw Error(MFH_ERR_NOT_CONVERGED, "PCG did not reach the requested tolerance within maxit iterations");
     MFH_CATCH(c)
 }
@@ -1655,6 +1672,8 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }
     else if (k2 == "xcd_swizzle") c->xcdSwizzle = value != 0;
     else if (k2 == "pcg_graph") c->useGraph = value != 0;
+    else if (k2 == "pcg_variant") c->pcgVariant = value < 0 ? -1 : (value != 0 ? 1 : 0);
+    else if (k2 == "batch_rhs") c->batchRhs = value != 0;
     else if (k2 == "matrix_free_mode") { c->mfMode = (int)value; c->mfClusterUnfit = false; }
     else if (k2 == "mf_block_elems") { c->mfBlockElems = (int)value; c->mfcValid = false; }
     else if (k2 == "mf_chunk_rows") { c->mfChunkRows = std::max(16, std::min(4096, (int)value)); c->mfValid = false; }

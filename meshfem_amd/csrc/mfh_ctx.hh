@@ -115,6 +115,26 @@ struct mfh_ctx {
         DBuf<int32_t> aggOfDof, aggPtr, dofsByAgg, colorOfAgg, nbrOfColor, binCoord;
         DBuf<double> relPos, Ainv, rc, yc;
     } tl;
+    // Chronopoulos-Gear PCG (mfh_solver.cpp): NR interleaved vectors
+    DBuf<double> cgU, cgW, cgP, cgS, cgX, cgR, cgF, cgCtl, tlRcN, tlYcN;
+    int pcgVariant = -1;              // option "pcg_variant": 1 = Chronopoulos-Gear, 0 = classic PCG, -1 (default) = classic for one
+                                      // right-hand side on an unpartitioned context (measured 6-14 % faster per iteration there: one
+                                      // vector pass fewer), Chronopoulos-Gear for batches and row-partitioned contexts
+    bool batchRhs = false;            // option "batch_rhs": several right-hand sides per operator pass (measured slower than one at a time)
+    // row-partitioned solve (mfh_dist_setup)
+    struct Dist {
+        mfh_comm *comm = nullptr;     // not owned
+        std::vector<int32_t> peers;
+        std::vector<int64_t> sendPtr{0}, recvPtr{0};
+        DBuf<int32_t> sendIdx;
+        DBuf<double> sendBuf;
+        int sendBufW = 0;             // doubles per node the send buffer is sized for
+        hipStream_t commStream = nullptr;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        DBuf<int32_t> opList;         // element blocks / row chunks: interior first, then those reading a halo column
+        int64_t nInterior = 0, nBoundary = 0;
+        int listKind = 0;             // 0 none, 1 cluster blocks, 2 SpMV chunks
+    } dist;
     int aggNodes = 0;                 // option "agg_nodes": target DoFs per aggregate (0 = auto)
     bool topologyDevice = true;       // option "topology_device": edge numbering + boundary extraction by device radix sorts
     bool symbolicDevice = true;       // option "symbolic_device": build pattern + gather lists on the GPU (element-major order)
@@ -209,4 +229,5 @@ void box_corners(mfh_ctx *c, const double *mn, const double *mx, int relative, d
 void dirichlet_vars(mfh_ctx *c, std::vector<int64_t> &vars, std::vector<double> &vals);
 int64_t pin_node(const mfh_ctx *c);
 void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info);
+void solve_many(mfh_ctx *c, int nrhs, const double *f, double *u, int64_t stride, double rtol, int maxit, mfh_solve_info *infos);
 }   // namespace mfhi

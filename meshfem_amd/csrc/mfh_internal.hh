@@ -423,4 +423,29 @@ void launch_mask(int64_t n, const uint8_t *mask, double *v, hipStream_t s);     
 void launch_scatter_values(int64_t n, const int64_t *idx, const double *val, double *v, hipStream_t s);
 void launch_dot(int64_t n, const double *a, const double *b, double *out, hipStream_t s);    // *out += a.b
 
+
+// ---- batched / distributed Chronopoulos-Gear PCG (mfh_solver.cpp): NR interleaved vectors, entry ((row NR + k) dim + c)
+bool op_batch_supported(int dim, int nr);
+void launch_mf_cluster_nr(const SpmvMfArgs &a, int NR, const double *x, double *y, double *dotOut, double *scal, int it, const double *ctl,
+                          const int32_t *blockList, int64_t nList, hipStream_t s);
+void launch_mf_rows_nr(const SpmvMfArgs &a, int NR, const double *x, double *y, double *dotOut, double *scal, int it, const double *ctl, hipStream_t s);
+void launch_spmv_nr(const SpmvArgs &a, int NR, const double *x, double *y, double *dotOut, double *scal, int it, const double *ctl,
+                    const int32_t *chunkList, int64_t nList, hipStream_t s);
+void launch_flag_halo_blocks(int64_t nBlocks, const int32_t *blockPtr, const int32_t *entryDest, uint8_t *flag, hipStream_t s);
+void launch_flag_halo_chunks(int64_t nChunk, const int32_t *chunkRow, const int32_t *rowPtr, const int32_t *colIdx, int64_t nOwnedCols, uint8_t *flag,
+                             hipStream_t s);
+void launch_cg_update(int dim, int64_t nRows, int NR, const double *dinv, double *u, const double *w, double *p, double *sv, double *x, double *r,
+                      double *scal, int it, const double *ctl, bool skipU, hipStream_t s);
+void launch_cg_init(int dim, int64_t nRows, int NR, const double *dinv, const double *r, double *u, double *scal, bool skipU, hipStream_t s);
+void launch_tl_restrict_nr(const TLArgs &t, int NR, const int32_t *aggPtr, const int32_t *dofsByAgg, const double *w, double *rc, hipStream_t s);
+void launch_tl_gemv_nr(int64_t m, int64_t ld, int NR, const double *A, const double *x, double *y, hipStream_t s);
+void launch_tl_apply_nr(const TLArgs &t, int NR, const double *dinv, const double *r, const double *yc, double *z, double *scal, int it,
+                        const double *ctl, hipStream_t s);
+void launch_add_scalar(double *p, double v, hipStream_t s);   // *p += v
+void launch_pack_rows(int64_t n, int W, const int32_t *idx, const double *src, double *dst, hipStream_t s);
+void launch_interleave(int64_t nRows, int NR, int dim, const double *src, double *dst, bool toInterleaved, int64_t sepStride, hipStream_t s);
+void launch_norms_nr(int64_t nRows, int NR, int dim, const double *v, double *out, hipStream_t s);
+void launch_mask_nr(int64_t nRows, int NR, int dim, const uint8_t *mask, double *v, hipStream_t s);
+void launch_scatter_values_nr(int64_t n, int NR, int dim, const int64_t *idx, const double *val, double *v, hipStream_t s);
+
 }} // namespace mfh::k

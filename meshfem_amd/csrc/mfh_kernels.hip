@@ -554,23 +554,29 @@ __global__ void __launch_bounds__(256) k_average_gradient(LoadArgs a, const doub
 //          -> LDS partials.  Phase 2: lane per scalar row sums its partials.
 // Optional: zero rows of fixed variables; accumulate dot(x_rows, y) into *dotOut (one atomic per WG).
 // ------------------------------------------------------------------------------------------------
-template <int DIM, bool PCG>
+template <int DIM, int PCG>
 __global__ void __launch_bounds__(256) k_spmv(SpmvArgs a, const double *__restrict__ x, double *__restrict__ y,
-                                             double *dotOut, double *scal, int it, const double *stopPtr) {
+                                             double *dotOut, double *scal, int it, const double *stopPtr, const int32_t *__restrict__ chunkList,
+                                             int64_t nList) {
     constexpr int NB = DIM * DIM;
     extern __shared__ __attribute__((aligned(16))) double part[];  // [DIM][chunkSlots] + 16
     const int CS = a.chunkSlots;
     double *red = part + DIM * CS;
-    if (PCG) {
+    if (PCG == 1) {
         it += (int)stopPtr[3];   // iteration base of the current graph launch (0 outside graphs)
         // converged: every kernel of the remaining iterations is a no-op
         if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
         dotOut = scal + (int64_t)it * 4 + 1;
+    } else if (PCG == 2) {   // Chronopoulos-Gear bookkeeping for one right-hand side (see k_spmv_nr)
+        it += (int)stopPtr[0];
+        if (scal[(int64_t)it * 4 + 2] <= stopPtr[2]) return;
+        dotOut = scal + (int64_t)(it + 1) * 4 + 1;
     }
     double dot = 0.0;
-    int64_t chunkFirst = blockIdx.x, chunkEnd = a.nChunk, chunkStride = gridDim.x;
-    if (a.xcd) xcd_span(a.nChunk, chunkFirst, chunkEnd, chunkStride);
-    for (int64_t chunk = chunkFirst; chunk < chunkEnd; chunk += chunkStride) {
+    int64_t chunkFirst = blockIdx.x, chunkEnd = chunkList ? nList : a.nChunk, chunkStride = gridDim.x;
+    if (a.xcd && !chunkList) xcd_span(a.nChunk, chunkFirst, chunkEnd, chunkStride);
+    for (int64_t cq = chunkFirst; cq < chunkEnd; cq += chunkStride) {
+        const int64_t chunk = chunkList ? (int64_t)chunkList[cq] : cq;
         const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
         const int s0 = a.rowPtr[r0];
         const int ns = a.rowPtr[r1] - s0;
@@ -1304,20 +1310,29 @@ __global__ void __launch_bounds__(256) k_mf_forces(SpmvMfArgs a, const double *_
 // here and written to y; the other rows leave ONE partial sum per (block, row) in the interface buffer, in row order,
 // which k_mf_rows sums. With a spatially coherent element order most rows are finished in their block, so the
 // 240 B/element force buffer of k_mf_forces shrinks to a few tens of bytes per element.
-template <int DIM, int DEG, int MAT, bool PCG>
+// PCG: 0 = plain operator (optional dotOut), 1 = classic PCG bookkeeping (scal[it 4 + {1: p.Ap, 2: r.r}], base stopPtr[3],
+// threshold stopPtr[0]), 2 = Chronopoulos-Gear bookkeeping for ONE right-hand side (delta into scal[(it + 1) 4 + 1], base
+// ctl[0], threshold ctl[2]; see k_mf_cluster_nr). blockList (may be null = all blocks) selects the blocks of this launch.
+template <int DIM, int DEG, int MAT, int PCG>
 __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const double *__restrict__ x, double *__restrict__ y, double *dotOut,
-                                                         double *scal, int it, const double *stopPtr) {
+                                                         double *scal, int it, const double *stopPtr, const int32_t *__restrict__ blockList,
+                                                         int64_t nList) {
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
     extern __shared__ __attribute__((aligned(16))) double clacc[];   // accumulators [maxLocal * DIM] + staged x [maxLocal * DIM] + 16
     double *xs = clacc + a.clMaxLocal * DIM;
     double *red = xs + a.clMaxLocal * DIM;
-    if (PCG) {
+    if (PCG == 1) {
         it += (int)stopPtr[3];
         if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
         dotOut = scal + (int64_t)it * 4 + 1;
+    } else if (PCG == 2) {
+        it += (int)stopPtr[0];
+        if (scal[(int64_t)it * 4 + 2] <= stopPtr[2]) return;
+        dotOut = scal + (int64_t)(it + 1) * 4 + 1;
     }
     double dot = 0.0;
-    for (int64_t b = blockIdx.x; b < a.clBlocks; b += gridDim.x) {
+    for (int64_t q = blockIdx.x; q < nList; q += gridDim.x) {
+        const int64_t b = blockList ? (int64_t)blockList[q] : q;
         const int u0 = a.clBlockPtr[b], nLocal = a.clBlockPtr[b + 1] - u0;
         // x of every distinct row of the block is read ONCE into LDS (a block of 256 P2 tets gathers 2560 nodal vectors
         // but touches only ~580 distinct rows); the lanes then pick their 10 vectors from LDS by local row index
@@ -1371,15 +1386,19 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
 }
 
 // y_row = sum over the (element, node) pairs of the row of their nodal force: a pure gather-sum
-template <int DIM, bool PCG>
+template <int DIM, int PCG>
 __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__restrict__ fbuf, const double *__restrict__ x,
                                                  double *__restrict__ y, double *dotOut, double *scal, int it, const double *stopPtr) {
     extern __shared__ __attribute__((aligned(16))) double mfacc[];   // [maxRows * DIM] + 16
     double *red = mfacc + a.maxRows * DIM;
-    if (PCG) {
+    if (PCG == 1) {
         it += (int)stopPtr[3];
         if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
         dotOut = scal + (int64_t)it * 4 + 1;
+    } else if (PCG == 2) {
+        it += (int)stopPtr[0];
+        if (scal[(int64_t)it * 4 + 2] <= stopPtr[2]) return;
+        dotOut = scal + (int64_t)(it + 1) * 4 + 1;
     }
     double dot = 0.0;
     int64_t chunkFirst = blockIdx.x, chunkEnd = a.nChunk, chunkStride = gridDim.x;
@@ -1430,6 +1449,284 @@ __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__r
         double v[1] = {dot};
         block_sum<1>(v, red);
         if (threadIdx.x == 0) unsafeAtomicAdd(dotOut, v[0]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Operators of the batched / distributed PCG (mfh_solver.cpp). NR right-hand sides are interleaved per row: vector entry
+// ((row * NR + k) * DIM + c). The element record, the local row indices and the block's row tables are fetched from HBM once
+// per block for all NR vectors (later sub-batches find them in L2); the LDS holds NRS vectors at a time.
+// Gating: with ctl != null the kernel belongs to PCG iteration it = itLocal + ctl[0]; it is a no-op once every right-hand side
+// has converged (rr_k(it) <= ctl[2 + k]) and accumulates delta_k = (w_k, u_k) into scal[((it + 1) NR + k) 4 + 1].
+// blockList (may be null = all) selects the element blocks / row chunks of this launch: the distributed solver runs the
+// blocks without halo columns while the halo exchange is in flight and the others after it.
+// ------------------------------------------------------------------------------------------------
+template <int NR> DEV bool cg_all_done(const double *scal, const double *ctl, int it) {
+    bool all = true;
+#pragma unroll
+    for (int k = 0; k < NR; ++k) all = all && (scal[((int64_t)it * NR + k) * 4 + 2] <= ctl[2 + k]);
+    return all;
+}
+
+template <int DIM, int DEG, int MAT, int NR, int NRS>
+__global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster_nr(SpmvMfArgs a, const double *__restrict__ x, double *__restrict__ y, double *dotOut,
+                                                            double *scal, int it, const double *ctl, const int32_t *__restrict__ blockList,
+                                                            int64_t nList) {
+    constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    constexpr int NSB = NR / NRS;
+    constexpr int W = NRS * DIM;                                     // doubles per row and sub-batch
+    static_assert(NR % NRS == 0, "sub-batch size must divide the batch");
+    extern __shared__ __attribute__((aligned(16))) double clacc[];   // accumulators [maxLocal * W] + staged x [maxLocal * W] + dots [8]
+    double *xs = clacc + a.clMaxLocal * W;
+    double *sdot = xs + a.clMaxLocal * W;
+    if (ctl) {
+        it += (int)ctl[0];
+        if (cg_all_done<NR>(scal, ctl, it)) return;
+        dotOut = scal + ((int64_t)(it + 1) * NR) * 4 + 1;
+    }
+    if (threadIdx.x < 8) sdot[threadIdx.x] = 0.0;
+    for (int64_t q = blockIdx.x; q < nList; q += gridDim.x) {
+        const int64_t b = blockList ? (int64_t)blockList[q] : q;
+        const int u0 = a.clBlockPtr[b], nLocal = a.clBlockPtr[b + 1] - u0;
+        const int64_t e = b * a.clBlockElems + threadIdx.x;
+        const bool active = (int)threadIdx.x < a.clBlockElems && e < a.nElem;
+        // element state shared by all NR vectors: LDS offsets of its nodes' rows, gradients, volume
+        int li[NPE];
+        double gl[DIM + 1][DIM], vol = 0.0;
+        const double *g = a.geo + (active ? e : 0) * a.geoStride;
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < NPE; ++j) li[j] = (int)a.clLocalIdx[e * NPE + j] * W;
+#pragma unroll
+            for (int k = 0; k <= DIM; ++k)
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) gl[k][d] = g[k * DIM + d];
+            vol = g[12];
+        }
+        for (int sb = 0; sb < NSB; ++sb) {
+            // x of every distinct row of the block, NRS vectors: read once into LDS
+            for (int t = threadIdx.x; t < nLocal; t += MF_BLOCK) {
+                const int64_t row = a.clEntryRow[u0 + t];
+                const double *src = x + (row * NR + sb * NRS) * DIM;
+#pragma unroll
+                for (int j = 0; j < W; ++j) { xs[t * W + j] = src[j]; clacc[t * W + j] = 0.0; }
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll 1
+                for (int kk = 0; kk < NRS; ++kk) {
+                    const double *xk = xs + kk * DIM;
+                    double *ak = clacc + kk * DIM;
+                    double xl[NPE][DIM];
+#pragma unroll
+                    for (int j = 0; j < NPE; ++j)
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) xl[j][d] = xk[li[j] + d];
+                    elem_forces_bilinear<DIM, DEG, MAT>(g, vol, gl, gl, xl, [&](int j, const double *fv) {
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) unsafeAtomicAdd(&ak[li[j] + d], fv[d]);
+                    });
+                }
+            }
+            __syncthreads();
+            double dl[NRS];
+#pragma unroll
+            for (int kk = 0; kk < NRS; ++kk) dl[kk] = 0.0;
+            for (int t = threadIdx.x; t < nLocal; t += MF_BLOCK) {
+                const int dest = a.clEntryDest[u0 + t];
+                if (dest == -2) continue;                                  // row owned by another rank
+                if (dest >= 0) {
+                    double *o = a.clIfaceBuf + ((int64_t)dest * NR + sb * NRS) * DIM;
+#pragma unroll
+                    for (int j = 0; j < W; ++j) o[j] = clacc[t * W + j];
+                    continue;
+                }
+                const int64_t row = a.clEntryRow[u0 + t];
+#pragma unroll
+                for (int kk = 0; kk < NRS; ++kk)
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) {
+                        const int64_t gi = (row * NR + sb * NRS + kk) * DIM + d;
+                        double v = clacc[t * W + kk * DIM + d];
+                        if (a.fixedMask && a.fixedMask[row * DIM + d]) v = 0.0;
+                        y[gi] = v;
+                        if (dotOut) dl[kk] += v * x[gi];
+                    }
+            }
+            if (dotOut) {
+#pragma unroll
+                for (int kk = 0; kk < NRS; ++kk) {
+                    const double v = wave_sum(dl[kk]);
+                    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&sdot[sb * NRS + kk], v);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (dotOut) {
+        __syncthreads();
+        if (threadIdx.x < NR) unsafeAtomicAdd(&dotOut[threadIdx.x * 4], sdot[threadIdx.x]);
+    }
+}
+
+// second pass of the cluster operator for NR interleaved vectors: y_row = sum of the row's interface partials (streamed in
+// row order), in the compact numbering of the interface rows
+template <int DIM, int NR, int NRS>
+__global__ void __launch_bounds__(256) k_mf_rows_nr(SpmvMfArgs a, const double *__restrict__ fbuf, const double *__restrict__ x,
+                                                    double *__restrict__ y, double *dotOut, double *scal, int it, const double *ctl) {
+    constexpr int NSB = NR / NRS;
+    constexpr int W = NRS * DIM;
+    extern __shared__ __attribute__((aligned(16))) double mfacc[];   // [maxRows * W] + dots [8]
+    double *sdot = mfacc + a.maxRows * W;
+    if (ctl) {
+        it += (int)ctl[0];
+        if (cg_all_done<NR>(scal, ctl, it)) return;
+        dotOut = scal + ((int64_t)(it + 1) * NR) * 4 + 1;
+    }
+    if (threadIdx.x < 8) sdot[threadIdx.x] = 0.0;
+    for (int64_t chunk = blockIdx.x; chunk < a.nChunk; chunk += gridDim.x) {
+        const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
+        const int nr = r1 - r0;
+        const int64_t kb = a.pairPtr[chunk], ke = a.pairPtr[chunk + 1];
+        for (int sb = 0; sb < NSB; ++sb) {
+            for (int t = threadIdx.x; t < nr * W; t += 256) mfacc[t] = 0.0;
+            __syncthreads();
+            for (int64_t k = kb + threadIdx.x; k < ke; k += 256) {
+                const int lr = a.pairRow[k];
+                const double *src = fbuf + (k * NR + sb * NRS) * DIM;
+                double v[W];
+#pragma unroll
+                for (int j = 0; j < W; ++j) v[j] = src[j];
+#pragma unroll
+                for (int j = 0; j < W; ++j) unsafeAtomicAdd(&mfacc[lr * W + j], v[j]);
+            }
+            __syncthreads();
+            double dl[NRS];
+#pragma unroll
+            for (int kk = 0; kk < NRS; ++kk) dl[kk] = 0.0;
+            for (int t = threadIdx.x; t < nr; t += 256) {
+                const int64_t row = a.rowMap[r0 + t];
+#pragma unroll
+                for (int kk = 0; kk < NRS; ++kk)
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) {
+                        const int64_t gi = (row * NR + sb * NRS + kk) * DIM + d;
+                        double v = mfacc[t * W + kk * DIM + d];
+                        if (a.fixedMask && a.fixedMask[row * DIM + d]) v = 0.0;
+                        y[gi] = v;
+                        if (dotOut) dl[kk] += v * x[gi];
+                    }
+            }
+            if (dotOut) {
+#pragma unroll
+                for (int kk = 0; kk < NRS; ++kk) {
+                    const double v = wave_sum(dl[kk]);
+                    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&sdot[sb * NRS + kk], v);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (dotOut) {
+        __syncthreads();
+        if (threadIdx.x < NR) unsafeAtomicAdd(&dotOut[threadIdx.x * 4], sdot[threadIdx.x]);
+    }
+}
+
+// assembled block-CSR SpMV for NR interleaved vectors (the operator of linear elements, scalar operators and
+// caller-supplied matrices); NRS vectors per pass through the LDS partials
+template <int DIM, int NR, int NRS>
+__global__ void __launch_bounds__(256) k_spmv_nr(SpmvArgs a, const double *__restrict__ x, double *__restrict__ y, double *dotOut,
+                                                 double *scal, int it, const double *ctl, const int32_t *__restrict__ chunkList, int64_t nList) {
+    constexpr int NB = DIM * DIM;
+    constexpr int NSB = NR / NRS;
+    extern __shared__ __attribute__((aligned(16))) double part[];  // [NRS * DIM][chunkSlots] + dots [8]
+    const int CS = a.chunkSlots;
+    double *sdot = part + NRS * DIM * CS;
+    if (ctl) {
+        it += (int)ctl[0];
+        if (cg_all_done<NR>(scal, ctl, it)) return;
+        dotOut = scal + ((int64_t)(it + 1) * NR) * 4 + 1;
+    }
+    if (threadIdx.x < 8) sdot[threadIdx.x] = 0.0;
+    for (int64_t q = blockIdx.x; q < nList; q += gridDim.x) {
+        const int64_t chunk = chunkList ? (int64_t)chunkList[q] : q;
+        const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
+        const int s0 = a.rowPtr[r0];
+        const int ns = a.rowPtr[r1] - s0;
+        for (int sb = 0; sb < NSB; ++sb) {
+            for (int t = threadIdx.x; t < ns; t += 256) {
+                const int64_t s = (int64_t)s0 + t;
+                const int64_t col = a.colIdx[s];
+                double A[NB];
+#pragma unroll
+                for (int c = 0; c < NB; ++c) A[c] = a.vals[tiled_index(s, c, NB)];
+#pragma unroll
+                for (int kk = 0; kk < NRS; ++kk) {
+                    double xv[DIM];
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) xv[d] = x[(col * NR + sb * NRS + kk) * DIM + d];
+#pragma unroll
+                    for (int c = 0; c < DIM; ++c) {
+                        double v = 0;
+#pragma unroll
+                        for (int d = 0; d < DIM; ++d) v += A[c * DIM + d] * xv[d];
+                        part[(kk * DIM + c) * CS + t] = v;
+                    }
+                }
+            }
+            __syncthreads();
+            const int nscalar = (r1 - r0) * NRS * DIM;
+            double dl[NRS];
+#pragma unroll
+            for (int kk = 0; kk < NRS; ++kk) dl[kk] = 0.0;
+            for (int idx = threadIdx.x; idx < nscalar; idx += 256) {
+                const int rl = idx / (NRS * DIM), kc = idx - rl * (NRS * DIM);
+                const int kk = kc / DIM, c = kc - kk * DIM;
+                const int64_t r = r0 + rl;
+                const int b = a.rowPtr[r] - s0, e = a.rowPtr[r + 1] - s0;
+                double v = 0;
+                for (int t = b; t < e; ++t) v += part[kc * CS + t];
+                if (a.fixedMask && a.fixedMask[r * DIM + c]) v = 0.0;
+                const int64_t gi = (r * NR + sb * NRS + kk) * DIM + c;
+                y[gi] = v;
+                if (dotOut) {
+                    const double pr = v * x[gi];
+#pragma unroll
+                    for (int k2 = 0; k2 < NRS; ++k2) dl[k2] += (k2 == kk) ? pr : 0.0;
+                }
+            }
+            if (dotOut) {
+#pragma unroll
+                for (int kk = 0; kk < NRS; ++kk) {
+                    const double v = wave_sum(dl[kk]);
+                    if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&sdot[sb * NRS + kk], v);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (dotOut) {
+        __syncthreads();
+        if (threadIdx.x < NR) unsafeAtomicAdd(&dotOut[threadIdx.x * 4], sdot[threadIdx.x]);
+    }
+}
+
+// flags the element blocks (cluster operator) / row chunks (assembled SpMV) that read a halo column
+__global__ void __launch_bounds__(256) k_flag_halo_blocks(int64_t nBlocks, const int32_t *__restrict__ blockPtr, const int32_t *__restrict__ entryDest,
+                                                          uint8_t *__restrict__ flag) {
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nBlocks; b += (int64_t)gridDim.x * 256) {
+        bool halo = false;
+        for (int u = blockPtr[b]; u < blockPtr[b + 1]; ++u) halo |= entryDest[u] == -2;
+        flag[b] = halo;
+    }
+}
+__global__ void __launch_bounds__(256) k_flag_halo_chunks(int64_t nChunk, const int32_t *__restrict__ chunkRow, const int32_t *__restrict__ rowPtr,
+                                                          const int32_t *__restrict__ colIdx, int64_t nOwnedCols, uint8_t *__restrict__ flag) {
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c < nChunk; c += (int64_t)gridDim.x * 256) {
+        bool halo = false;
+        for (int s = rowPtr[chunkRow[c]]; s < rowPtr[chunkRow[c + 1]]; ++s) halo |= colIdx[s] >= nOwnedCols;
+        flag[c] = halo;
     }
 }
 
@@ -1613,22 +1910,29 @@ void launch_average_gradient(const AsmArgs &a, const int32_t *elemNodes, const d
 static int persistent_grid(int64_t nItems, int cap) { return (int)std::max<int64_t>(8, std::min<int64_t>(cap, (nItems + 7) / 8 * 8)); }
 static int spmv_grid(const SpmvArgs &a) { return persistent_grid(a.nChunk, 256 * 8); }
 
-void launch_spmv(const SpmvArgs &a, const double *x, double *y, double *dotOut, hipStream_t s) {
-    if (a.nChunk == 0) return;
+// mode: 0 plain (dotOut optional), 1 classic PCG bookkeeping, 2 Chronopoulos-Gear bookkeeping (one right-hand side);
+// chunkList / nList: the chunks of this launch (null = all)
+static void launch_spmv_mode(const SpmvArgs &a, int mode, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
+                             const int32_t *chunkList, int64_t nList, hipStream_t s) {
+    const int64_t n = chunkList ? nList : a.nChunk;
+    if (n <= 0) return;
     const size_t lds = ((size_t)a.dim * a.chunkSlots + 16) * sizeof(double);
-    if (a.dim == 1) hipLaunchKernelGGL((k_spmv<1, false>), dim3(spmv_grid(a)), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr);
-    else if (a.dim == 3) hipLaunchKernelGGL((k_spmv<3, false>), dim3(spmv_grid(a)), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr);
-    else hipLaunchKernelGGL((k_spmv<2, false>), dim3(spmv_grid(a)), dim3(256), lds, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr);
+    const int grid = persistent_grid(n, 256 * 8);
+#define SPMV(D)                                                                                                                               \
+    if (mode == 0) hipLaunchKernelGGL((k_spmv<D, 0>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, scal, it, stopPtr, chunkList, nList);     \
+    else if (mode == 1) hipLaunchKernelGGL((k_spmv<D, 1>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, scal, it, stopPtr, chunkList, nList); \
+    else hipLaunchKernelGGL((k_spmv<D, 2>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, scal, it, stopPtr, chunkList, nList)
+    if (a.dim == 1) { SPMV(1); } else if (a.dim == 3) { SPMV(3); } else { SPMV(2); }
+#undef SPMV
     CHECK_LAUNCH();
 }
 
+void launch_spmv(const SpmvArgs &a, const double *x, double *y, double *dotOut, hipStream_t s) {
+    launch_spmv_mode(a, 0, x, y, dotOut, nullptr, 0, nullptr, nullptr, 0, s);
+}
+
 void launch_pcg_spmv(const SpmvArgs &a, const double *p, double *Ap, double *scal, int it, const double *stopPtr, hipStream_t s) {
-    if (a.nChunk == 0) return;
-    const size_t lds = ((size_t)a.dim * a.chunkSlots + 16) * sizeof(double);
-    if (a.dim == 1) hipLaunchKernelGGL((k_spmv<1, true>), dim3(spmv_grid(a)), dim3(256), lds, s, a, p, Ap, (double *)nullptr, scal, it, stopPtr);
-    else if (a.dim == 3) hipLaunchKernelGGL((k_spmv<3, true>), dim3(spmv_grid(a)), dim3(256), lds, s, a, p, Ap, (double *)nullptr, scal, it, stopPtr);
-    else hipLaunchKernelGGL((k_spmv<2, true>), dim3(spmv_grid(a)), dim3(256), lds, s, a, p, Ap, (double *)nullptr, scal, it, stopPtr);
-    CHECK_LAUNCH();
+    launch_spmv_mode(a, 1, p, Ap, nullptr, scal, it, stopPtr, nullptr, 0, s);
 }
 
 void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
@@ -1645,6 +1949,20 @@ void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dot
     CHECK_LAUNCH();
 }
 
+static void launch_mf_rows_mode(const SpmvMfArgs &a, int mode, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
+                                hipStream_t s) {
+    if (a.nChunk == 0) return;
+    const size_t lds = ((size_t)a.maxRows * a.dim + 16) * sizeof(double);
+    const int grid = persistent_grid(a.nChunk, 256 * 8);
+#define ROWS(D)                                                                                                                               \
+    if (mode == 0) hipLaunchKernelGGL((k_mf_rows<D, 0>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, scal, it, stopPtr);     \
+    else if (mode == 1) hipLaunchKernelGGL((k_mf_rows<D, 1>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, scal, it, stopPtr); \
+    else hipLaunchKernelGGL((k_mf_rows<D, 2>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, scal, it, stopPtr)
+    if (a.dim == 3) { ROWS(3); } else { ROWS(2); }
+#undef ROWS
+    CHECK_LAUNCH();
+}
+
 // two-pass matrix-free elasticity operator (k_mf_stress + k_mf_rows)
 void launch_spmv_mf2(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
                      bool pcg, hipStream_t s) {
@@ -1654,35 +1972,109 @@ void launch_spmv_mf2(const SpmvMfArgs &a, const double *x, double *y, double *do
     MFH_DISPATCH(a, CALL);
 #undef CALL
     CHECK_LAUNCH();
-    const size_t lds = ((size_t)a.maxRows * a.dim + 16) * sizeof(double);
+    launch_mf_rows_mode(a, pcg ? 1 : 0, x, y, pcg ? nullptr : dotOut, pcg ? scal : nullptr, pcg ? it : 0, pcg ? stopPtr : nullptr, s);
+}
+
+// cluster variant of the matrix-free elasticity operator: k_mf_cluster over the blocks of blockList (null = all) ...
+static void launch_mf_cluster_mode(const SpmvMfArgs &a, int mode, const double *x, double *y, double *dotOut, double *scal, int it,
+                                   const double *stopPtr, const int32_t *blockList, int64_t nList, hipStream_t s) {
+    if (nList <= 0) return;
+    const size_t ldsC = ((size_t)2 * a.clMaxLocal * a.dim + 16) * sizeof(double);
+    const int gridC = (int)std::min<int64_t>(nList, 256 * 64);
+#define CALL(D, G, M)                                                                                                                                      \
+    if (mode == 0) hipLaunchKernelGGL((k_mf_cluster<D, G, M, 0>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList);     \
+    else if (mode == 1) hipLaunchKernelGGL((k_mf_cluster<D, G, M, 1>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList); \
+    else hipLaunchKernelGGL((k_mf_cluster<D, G, M, 2>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList)
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+    CHECK_LAUNCH();
+}
+
+// ... followed by k_mf_rows over the interface partials
+void launch_spmv_mf_cluster(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
+                            bool pcg, hipStream_t s) {
+    const int mode = pcg ? 1 : 0;
+    launch_mf_cluster_mode(a, mode, x, y, pcg ? nullptr : dotOut, pcg ? scal : nullptr, pcg ? it : 0, pcg ? stopPtr : nullptr, nullptr, a.clBlocks, s);
+    launch_mf_rows_mode(a, mode, x, y, pcg ? nullptr : dotOut, pcg ? scal : nullptr, pcg ? it : 0, pcg ? stopPtr : nullptr, s);
+}
+
+// ---- operators of the batched / distributed PCG
+static int cluster_nrs(int dim, int nr) { return nr == 1 ? 1 : (dim == 3 ? 2 : 3); }
+bool op_batch_supported(int dim, int nr) { return nr == 1 || (dim == 3 && (nr == 2 || nr == 6)) || (dim == 2 && nr == 3) || (dim == 1 && (nr == 2 || nr == 3 || nr == 6)); }
+
+void launch_mf_cluster_nr(const SpmvMfArgs &a, int NR, const double *x, double *y, double *dotOut, double *scal, int it, const double *ctl,
+                          const int32_t *blockList, int64_t nList, hipStream_t s) {
+    if (nList <= 0) return;
+    if (NR == 1) { launch_mf_cluster_mode(a, ctl ? 2 : 0, x, y, dotOut, scal, it, ctl, blockList, nList, s); return; }
+    const int nrs = cluster_nrs(a.dim, NR);
+    const size_t ldsC = ((size_t)2 * a.clMaxLocal * a.dim * nrs + 8) * sizeof(double);
+    const int gridC = (int)std::min<int64_t>(nList, 256 * 64);
+#define CALLN(D, G, M, N, NS)                                                                                                         \
+    do {                                                                                                                              \
+        if (ldsC > 64 * 1024) MFH_HIP(hipFuncSetAttribute((const void *)k_mf_cluster_nr<D, G, M, N, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC)); \
+        hipLaunchKernelGGL((k_mf_cluster_nr<D, G, M, N, NS>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, ctl, blockList, nList); \
+    } while (0)
+#define CALL(D, G, M)                                          \
+    if (D == 3) {                                              \
+        if (NR == 2) CALLN(3, G, M, 2, 2);                     \
+        else CALLN(3, G, M, 6, 2);                             \
+    } else {                                                   \
+        CALLN(2, G, M, 3, 3);                                  \
+    }
+    MFH_DISPATCH(a, CALL);
+#undef CALL
+#undef CALLN
+    CHECK_LAUNCH();
+}
+
+void launch_mf_rows_nr(const SpmvMfArgs &a, int NR, const double *x, double *y, double *dotOut, double *scal, int it, const double *ctl, hipStream_t s) {
+    if (a.nChunk == 0) return;
+    if (NR == 1) { launch_mf_rows_mode(a, ctl ? 2 : 0, x, y, dotOut, scal, it, ctl, s); return; }
+    const int nrs = cluster_nrs(a.dim, NR);
+    const size_t lds = ((size_t)a.maxRows * a.dim * nrs + 8) * sizeof(double);
     const int grid = persistent_grid(a.nChunk, 256 * 8);
-#define ROWS(D)                                                                                                                      \
-    if (pcg) hipLaunchKernelGGL((k_mf_rows<D, true>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, (double *)nullptr, scal, it, stopPtr); \
-    else hipLaunchKernelGGL((k_mf_rows<D, false>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr)
-    if (a.dim == 3) { ROWS(3); } else { ROWS(2); }
+#define ROWS(D, N, NS) hipLaunchKernelGGL((k_mf_rows_nr<D, N, NS>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, scal, it, ctl)
+    if (a.dim == 3) {
+        if (NR == 2) ROWS(3, 2, 2); else ROWS(3, 6, 2);
+    } else {
+        ROWS(2, 3, 3);
+    }
 #undef ROWS
     CHECK_LAUNCH();
 }
 
-// cluster variant of the matrix-free elasticity operator (k_mf_cluster + k_mf_rows over the interface partials)
-void launch_spmv_mf_cluster(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
-                            bool pcg, hipStream_t s) {
-    const size_t ldsC = ((size_t)2 * a.clMaxLocal * a.dim + 16) * sizeof(double);
-    const int gridC = (int)std::min<int64_t>(a.clBlocks, 256 * 64);
-#define CALL(D, G, M)                                                                                                                  \
-    if (pcg) hipLaunchKernelGGL((k_mf_cluster<D, G, M, true>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, (double *)nullptr, scal, it, stopPtr); \
-    else hipLaunchKernelGGL((k_mf_cluster<D, G, M, false>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr)
-    MFH_DISPATCH(a, CALL);
-#undef CALL
+void launch_spmv_nr(const SpmvArgs &a, int NR, const double *x, double *y, double *dotOut, double *scal, int it, const double *ctl,
+                    const int32_t *chunkList, int64_t nList, hipStream_t s) {
+    if (nList <= 0) return;
+    if (NR == 1) { launch_spmv_mode(a, ctl ? 2 : 0, x, y, dotOut, scal, it, ctl, chunkList, nList, s); return; }
+    const int nrs = a.dim == 1 ? (NR == 6 ? 3 : NR) : cluster_nrs(a.dim, NR);
+    const size_t lds = ((size_t)a.dim * nrs * a.chunkSlots + 8) * sizeof(double);
+    const int grid = persistent_grid(nList, 256 * 8);
+#define SPMV(D, N, NS)                                                                                                                 \
+    do {                                                                                                                               \
+        if (lds > 64 * 1024) MFH_HIP(hipFuncSetAttribute((const void *)k_spmv_nr<D, N, NS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_spmv_nr<D, N, NS>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, scal, it, ctl, chunkList, nList);     \
+    } while (0)
+    if (a.dim == 3) {
+        if (NR == 2) SPMV(3, 2, 2); else SPMV(3, 6, 2);
+    } else if (a.dim == 2) {
+        SPMV(2, 3, 3);
+    } else {
+        if (NR == 2) SPMV(1, 2, 2); else if (NR == 3) SPMV(1, 3, 3); else SPMV(1, 6, 3);
+    }
+#undef SPMV
     CHECK_LAUNCH();
-    if (a.nChunk == 0) return;
-    const size_t lds = ((size_t)a.maxRows * a.dim + 16) * sizeof(double);
-    const int grid = persistent_grid(a.nChunk, 256 * 8);
-#define ROWS(D)                                                                                                                      \
-    if (pcg) hipLaunchKernelGGL((k_mf_rows<D, true>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, (double *)nullptr, scal, it, stopPtr); \
-    else hipLaunchKernelGGL((k_mf_rows<D, false>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, (double *)nullptr, 0, (const double *)nullptr)
-    if (a.dim == 3) { ROWS(3); } else { ROWS(2); }
-#undef ROWS
+}
+
+void launch_flag_halo_blocks(int64_t nBlocks, const int32_t *blockPtr, const int32_t *entryDest, uint8_t *flag, hipStream_t s) {
+    if (!nBlocks) return;
+    hipLaunchKernelGGL(k_flag_halo_blocks, dim3(grid_for(nBlocks)), dim3(256), 0, s, nBlocks, blockPtr, entryDest, flag);
+    CHECK_LAUNCH();
+}
+void launch_flag_halo_chunks(int64_t nChunk, const int32_t *chunkRow, const int32_t *rowPtr, const int32_t *colIdx, int64_t nOwnedCols, uint8_t *flag,
+                             hipStream_t s) {
+    if (!nChunk) return;
+    hipLaunchKernelGGL(k_flag_halo_chunks, dim3(grid_for(nChunk)), dim3(256), 0, s, nChunk, chunkRow, rowPtr, colIdx, nOwnedCols, flag);
     CHECK_LAUNCH();
 }
 

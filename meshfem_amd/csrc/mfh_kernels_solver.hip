@@ -725,6 +725,7 @@ __global__ void __launch_bounds__(256) k_dev_dots(int64_t n, const double *__res
 
 // stop[3] += n: advances the iteration base at the end of a captured block of PCG iterations
 __global__ void k_advance_base(double *stop, double n) { stop[3] += n; }
+__global__ void k_add_scalar(double *p, double v) { *p += v; }
 
 __global__ void __launch_bounds__(256) k_axpby(int64_t n, double a, const double *__restrict__ x, double b, double *__restrict__ y) {
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
@@ -755,6 +756,288 @@ __global__ void __launch_bounds__(256) k_untile(int NB, int64_t nnzb, const doub
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Chronopoulos-Gear PCG (mfh_solver.cpp): ONE reduction point per iteration, NR interleaved right-hand sides.
+//   scal[(it NR + k) 4 + {0: gamma = (r, u), 1: delta = (w, u), 2: rr = (r, r), 3: alpha}],  u = M^-1 r,  w = K u
+//   ctl[0] = iteration base (graph replay), ctl[2 + k] = rtol^2 (b_k, b_k)
+//   beta = gamma_it / gamma_it-1, alpha = gamma_it / (delta_it - beta gamma_it / alpha_it-1)
+//   p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s ; u = D^-1 r ; gamma_it+1, rr_it+1
+// A converged right-hand side (rr_k(it) <= ctl[2 + k]) is frozen: its vectors are left alone and it adds nothing to
+// scal[it + 1], so rr_k stays 0 <= stop from then on. On a row-partitioned context scal[it + 1] holds this rank's partial
+// sums until the solver all-reduces it (alpha is written afterwards, by this kernel).
+// ------------------------------------------------------------------------------------------------
+// One lane per (row, vector) pair g = row * NR + k: consecutive lanes touch consecutive DIM-vectors of every array whatever
+// NR is (a lane per ROW would stride by NR * DIM doubles: measured 19x slower at NR = 6). The launch uses a grid that is
+// a multiple of 3 workgroups, so that the total lane count is a multiple of every supported NR and a lane keeps its k.
+template <int DIM, bool SKIPU>
+__global__ void __launch_bounds__(256) k_cg_update(int64_t nRows, int NR, const double *__restrict__ dinv, double *__restrict__ u,
+                                                   const double *__restrict__ w, double *__restrict__ p, double *__restrict__ sv,
+                                                   double *__restrict__ x, double *__restrict__ r, double *scal, int it, const double *ctl) {
+    __shared__ double sAl[8], sBe[8], sAcc[16];
+    __shared__ int sDn[8], sAll;
+    it += (int)ctl[0];
+    if (threadIdx.x < 16) sAcc[threadIdx.x] = 0.0;
+    if (threadIdx.x == 0) {
+        int all = 1;
+        for (int k = 0; k < NR; ++k) {
+            const double *sc = scal + ((int64_t)it * NR + k) * 4;
+            const int dn = sc[2] <= ctl[2 + k];
+            all &= dn;
+            double be = 0.0, al = sc[0] / sc[1];
+            if (it > 0) {
+                const double gp = sc[-4 * NR], ap = sc[-4 * NR + 3];
+                be = sc[0] / gp;
+                al = sc[0] / (sc[1] - be * sc[0] / ap);
+            }
+            sAl[k] = al; sBe[k] = be; sDn[k] = dn;
+            if (blockIdx.x == 0 && !dn) scal[((int64_t)it * NR + k) * 4 + 3] = al;
+        }
+        sAll = all;
+    }
+    __syncthreads();
+    if (sAll) return;
+    const int64_t nPairs = nRows * NR, stride = (int64_t)gridDim.x * 256;
+    const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int k = (int)(g0 % NR);
+    const bool dn = sDn[k] != 0;
+    const double al = sAl[k], be = sBe[k];
+    double accG = 0.0, accR = 0.0;
+    const int64_t rowStride = stride / NR;   // the lane count is a multiple of NR: a lane keeps its k, its row advances by this
+    int64_t n = g0 / NR;
+    if (!dn)
+        for (int64_t g = g0; g < nPairs; g += stride, n += rowStride) {
+            double rv[DIM], zv[DIM];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                const int64_t q = g * DIM + c;
+                const double pv = u[q] + be * p[q];
+                const double sn = w[q] + be * sv[q];
+                p[q] = pv;
+                sv[q] = sn;
+                x[q] += al * pv;
+                rv[c] = r[q] - al * sn;
+                r[q] = rv[c];
+            }
+            if (!SKIPU) {
+                apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) { u[g * DIM + c] = zv[c]; accG += rv[c] * zv[c]; }
+            }
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) accR += rv[c] * rv[c];
+        }
+    if (!dn) {
+        if (!SKIPU) unsafeAtomicAdd(&sAcc[2 * k], accG);
+        unsafeAtomicAdd(&sAcc[2 * k + 1], accR);
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * NR && !sDn[threadIdx.x >> 1]) {
+        const int kk = threadIdx.x >> 1, which = threadIdx.x & 1;
+        if (!(SKIPU && which == 0)) unsafeAtomicAdd(&scal[((int64_t)(it + 1) * NR + kk) * 4 + (which ? 2 : 0)], sAcc[threadIdx.x]);
+    }
+}
+
+// start of the solve: u = D^-1 r, gamma_0 = (r, u), rr_0 = (r, r) into scal[0]
+template <int DIM, bool SKIPU>
+__global__ void __launch_bounds__(256) k_cg_init(int64_t nRows, int NR, const double *__restrict__ dinv, const double *__restrict__ r,
+                                                 double *__restrict__ u, double *scal) {
+    __shared__ double sAcc[16];
+    if (threadIdx.x < 16) sAcc[threadIdx.x] = 0.0;
+    __syncthreads();
+    const int64_t nPairs = nRows * NR, stride = (int64_t)gridDim.x * 256;
+    const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int k = (int)(g0 % NR);
+    double accG = 0.0, accR = 0.0;
+    const int64_t rowStride = stride / NR;
+    int64_t n = g0 / NR;
+    for (int64_t g = g0; g < nPairs; g += stride, n += rowStride) {
+        double rv[DIM], zv[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) rv[c] = r[g * DIM + c];
+        if (!SKIPU) {
+            apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) { u[g * DIM + c] = zv[c]; accG += rv[c] * zv[c]; }
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) accR += rv[c] * rv[c];
+    }
+    if (!SKIPU) unsafeAtomicAdd(&sAcc[2 * k], accG);
+    unsafeAtomicAdd(&sAcc[2 * k + 1], accR);
+    __syncthreads();
+    if (threadIdx.x < 2 * NR) {
+        const int kk = threadIdx.x >> 1, which = threadIdx.x & 1;
+        if (!(SKIPU && which == 0)) unsafeAtomicAdd(&scal[kk * 4 + (which ? 2 : 0)], sAcc[threadIdx.x]);
+    }
+}
+
+// two-level preconditioner for NR interleaved vectors: coarse vectors are [coarse index][NR]
+template <int DIM>
+__global__ void __launch_bounds__(256) k_tl_restrict_nr(TLArgs t, int NR, const int32_t *__restrict__ aggPtr, const int32_t *__restrict__ dofsByAgg,
+                                                        const double *__restrict__ w, double *__restrict__ rc) {
+    __shared__ double red[4 * 6];
+    const int a = blockIdx.x;
+    const int lane = threadIdx.x & 63, wv_ = threadIdx.x >> 6;
+    for (int kr = 0; kr < NR; ++kr) {
+        double acc[6] = {0, 0, 0, 0, 0, 0};
+        for (int q = aggPtr[a] + threadIdx.x; q < aggPtr[a + 1]; q += 256) {
+            const int64_t n = dofsByAgg[q];
+            double rp[3] = {t.relPos[n * 3], t.relPos[n * 3 + 1], t.relPos[n * 3 + 2]};
+            double wv[DIM];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) wv[c] = (t.fixedMask && t.fixedMask[n * DIM + c]) ? 0.0 : w[(n * NR + kr) * DIM + c];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (k >= t.nModes) break;
+                double s = 0;
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) s += tl_mode<DIM>(k, c, rp) * wv[c];
+                acc[k] += s;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] = wave_sum(acc[k]);
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) red[wv_ * 6 + k] = acc[k];
+        __syncthreads();
+        if (threadIdx.x < t.nModes)
+            rc[((int64_t)a * t.nModes + threadIdx.x) * NR + kr] = red[threadIdx.x] + red[6 + threadIdx.x] + red[12 + threadIdx.x] + red[18 + threadIdx.x];
+        __syncthreads();
+    }
+}
+
+// Y[m][NR] = A[m][m] X[m][NR] for the dense coarse inverse: one workgroup per row, the row is read once for all NR
+__global__ void __launch_bounds__(256) k_tl_gemv_nr(int64_t m, int64_t ld, int NR, const double *__restrict__ A, const double *__restrict__ x,
+                                                    double *__restrict__ y) {
+    __shared__ double red[4 * 6];
+    const int64_t row = blockIdx.x;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t j = threadIdx.x; j < m; j += 256) {
+        const double av = A[row * ld + j];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < NR) acc[k] += av * x[j * NR + k];
+    }
+    block_sum<6>(acc, red);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < NR) y[row * NR + k] = acc[k];
+}
+
+// u = D^-1 r + Z yc for NR vectors (one lane per (row, vector) pair); accumulates gamma_k = (r_k, u_k) into
+// scal[((it + 1) NR + k) 4] (it = -1: the start)
+template <int DIM>
+__global__ void __launch_bounds__(256) k_tl_apply_nr(TLArgs t, int NR, const double *__restrict__ dinv, const double *__restrict__ r,
+                                                     const double *__restrict__ yc, double *__restrict__ z, double *scal, int it,
+                                                     const double *ctl) {
+    __shared__ double sAcc[8];
+    __shared__ int sDn[8], sAll;
+    if (threadIdx.x < 8) { sAcc[threadIdx.x] = 0.0; sDn[threadIdx.x] = 0; }
+    if (threadIdx.x == 0) sAll = 0;
+    __syncthreads();
+    if (scal) {
+        it += (int)ctl[0];
+        if (it >= 0 && threadIdx.x == 0) {
+            int all = 1;
+            for (int k = 0; k < NR; ++k) { sDn[k] = scal[((int64_t)it * NR + k) * 4 + 2] <= ctl[2 + k]; all &= sDn[k]; }
+            sAll = all;
+        }
+        __syncthreads();
+        if (sAll) return;
+    }
+    const int64_t nPairs = t.nDoF * NR, stride = (int64_t)gridDim.x * 256;
+    const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int kr = (int)(g0 % NR);
+    const bool dn = sDn[kr] != 0;
+    double acc = 0.0;
+    const int64_t rowStride = stride / NR;
+    int64_t n = g0 / NR;
+    if (!dn)
+        for (int64_t g = g0; g < nPairs; g += stride, n += rowStride) {
+            const int a = t.aggOfDof[n];
+            const double rp[3] = {t.relPos[n * 3], t.relPos[n * 3 + 1], t.relPos[n * 3 + 2]};
+            double rv[DIM], zv[DIM];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) rv[c] = r[g * DIM + c];
+            apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (k >= t.nModes) break;
+                const double yv = yc[((int64_t)a * t.nModes + k) * NR + kr];
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) zv[c] += yv * tl_mode<DIM>(k, c, rp);
+            }
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                if (t.fixedMask && t.fixedMask[n * DIM + c]) zv[c] = rv[c];   // identity on fixed variables (r is 0 there)
+                z[g * DIM + c] = zv[c];
+                acc += rv[c] * zv[c];
+            }
+        }
+    if (scal) {
+        if (!dn) unsafeAtomicAdd(&sAcc[kr], acc);
+        __syncthreads();
+        if (threadIdx.x < NR && !sDn[threadIdx.x]) unsafeAtomicAdd(&scal[((int64_t)(it + 1) * NR + threadIdx.x) * 4], sAcc[threadIdx.x]);
+    }
+}
+
+// halo send buffers: dst[j][:] = src[idx[j]][:], W doubles per row
+__global__ void __launch_bounds__(256) k_pack_rows(int64_t n, int W, const int32_t *__restrict__ idx, const double *__restrict__ src,
+                                                   double *__restrict__ dst) {
+    const int64_t total = n * W;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        const int64_t j = k / W;
+        dst[k] = src[(int64_t)idx[j] * W + (k - j * W)];
+    }
+}
+// [k][row][d] (separate vectors, the ABI's layout) <-> [row][k][d] (interleaved, the solver's layout)
+__global__ void __launch_bounds__(256) k_interleave(int64_t nRows, int NR, int DIM, const double *__restrict__ src, double *__restrict__ dst,
+                                                    int toInterleaved, int64_t srcStride) {
+    const int64_t total = nRows * NR * DIM;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+        const int64_t n = g / (NR * DIM);
+        const int kc = (int)(g - n * (NR * DIM));
+        const int k = kc / DIM, c = kc - k * DIM;
+        const int64_t sep = (int64_t)k * srcStride + n * DIM + c;
+        if (toInterleaved) dst[g] = src[sep]; else dst[sep] = src[g];
+    }
+}
+// per-vector squared norms of NR interleaved vectors: out[k] += sum v_k^2
+__global__ void __launch_bounds__(256) k_norms_nr(int64_t nRows, int NR, int DIM, const double *__restrict__ v, double *out) {
+    __shared__ double red[4 * 6];
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nRows; n += (int64_t)gridDim.x * 256)
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < NR)
+                for (int c = 0; c < DIM; ++c) { const double q = v[(n * NR + k) * DIM + c]; acc[k] += q * q; }
+    block_sum<6>(acc, red);
+    if (threadIdx.x == 0)
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < NR) unsafeAtomicAdd(&out[k], acc[k]);
+}
+// v[row][k][c] = 0 where the (row, c) variable is fixed
+__global__ void __launch_bounds__(256) k_mask_nr(int64_t nRows, int NR, int DIM, const uint8_t *__restrict__ m, double *__restrict__ v) {
+    const int64_t total = nRows * NR * DIM;
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+        const int64_t n = g / (NR * DIM);
+        const int c = (int)(g % DIM);
+        if (m[n * DIM + c]) v[g] = 0.0;
+    }
+}
+// v[var(idx[j])][k] = val[j] for every k (fixed values are the same for all right-hand sides)
+__global__ void __launch_bounds__(256) k_scatter_values_nr(int64_t n, int NR, int DIM, const int64_t *__restrict__ idx, const double *__restrict__ val,
+                                                           double *__restrict__ v) {
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx[j] / DIM;
+        const int c = (int)(idx[j] - row * DIM);
+        for (int k = 0; k < NR; ++k) v[(row * NR + k) * DIM + c] = val[j];
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // launchers
@@ -890,6 +1173,10 @@ void launch_dev_dots(int64_t n, const double *r, const double *z, double *out, h
     CHECK_LAUNCH();
 }
 
+void launch_add_scalar(double *p, double v, hipStream_t s) {
+    hipLaunchKernelGGL(k_add_scalar, dim3(1), dim3(1), 0, s, p, v);
+    CHECK_LAUNCH();
+}
 void launch_advance_base(double *stop, int n, hipStream_t s) {
     hipLaunchKernelGGL(k_advance_base, dim3(1), dim3(1), 0, s, stop, (double)n);
     CHECK_LAUNCH();
@@ -921,5 +1208,71 @@ void launch_dot(int64_t n, const double *a, const double *b, double *out, hipStr
     CHECK_LAUNCH();
 }
 
+
+
+// ---- Chronopoulos-Gear PCG and its helpers
+// grids of the pair-per-lane kernels: a multiple of 3 workgroups (768 lanes: a multiple of every supported NR)
+static int pair_grid(int64_t nPairs) { return 3 * (int)std::max<int64_t>(1, std::min<int64_t>((nPairs + 767) / 768, 683)); }
+
+void launch_cg_update(int dim, int64_t nRows, int NR, const double *dinv, double *u, const double *w, double *p, double *sv, double *x, double *r,
+                      double *scal, int it, const double *ctl, bool skipU, hipStream_t s) {
+    const int grid = pair_grid(nRows * NR);
+#define CALL(D)                                                                                                                          \
+    if (skipU) hipLaunchKernelGGL((k_cg_update<D, true>), dim3(grid), dim3(256), 0, s, nRows, NR, dinv, u, w, p, sv, x, r, scal, it, ctl); \
+    else hipLaunchKernelGGL((k_cg_update<D, false>), dim3(grid), dim3(256), 0, s, nRows, NR, dinv, u, w, p, sv, x, r, scal, it, ctl)
+    if (dim == 3) { CALL(3); } else if (dim == 2) { CALL(2); } else { CALL(1); }
+#undef CALL
+    CHECK_LAUNCH();
+}
+void launch_cg_init(int dim, int64_t nRows, int NR, const double *dinv, const double *r, double *u, double *scal, bool skipU, hipStream_t s) {
+    const int grid = pair_grid(nRows * NR);
+#define CALL(D)                                                                                                  \
+    if (skipU) hipLaunchKernelGGL((k_cg_init<D, true>), dim3(grid), dim3(256), 0, s, nRows, NR, dinv, r, u, scal); \
+    else hipLaunchKernelGGL((k_cg_init<D, false>), dim3(grid), dim3(256), 0, s, nRows, NR, dinv, r, u, scal)
+    if (dim == 3) { CALL(3); } else if (dim == 2) { CALL(2); } else { CALL(1); }
+#undef CALL
+    CHECK_LAUNCH();
+}
+void launch_tl_restrict_nr(const TLArgs &t, int NR, const int32_t *aggPtr, const int32_t *dofsByAgg, const double *w, double *rc, hipStream_t s) {
+    if (t.dim == 3) hipLaunchKernelGGL(k_tl_restrict_nr<3>, dim3(t.nAgg), dim3(256), 0, s, t, NR, aggPtr, dofsByAgg, w, rc);
+    else hipLaunchKernelGGL(k_tl_restrict_nr<2>, dim3(t.nAgg), dim3(256), 0, s, t, NR, aggPtr, dofsByAgg, w, rc);
+    CHECK_LAUNCH();
+}
+void launch_tl_gemv_nr(int64_t m, int64_t ld, int NR, const double *A, const double *x, double *y, hipStream_t s) {
+    hipLaunchKernelGGL(k_tl_gemv_nr, dim3((unsigned)m), dim3(256), 0, s, m, ld, NR, A, x, y);
+    CHECK_LAUNCH();
+}
+void launch_tl_apply_nr(const TLArgs &t, int NR, const double *dinv, const double *r, const double *yc, double *z, double *scal, int it,
+                        const double *ctl, hipStream_t s) {
+    const int grid = pair_grid(t.nDoF * NR);
+    if (t.dim == 3) hipLaunchKernelGGL(k_tl_apply_nr<3>, dim3(grid), dim3(256), 0, s, t, NR, dinv, r, yc, z, scal, it, ctl);
+    else hipLaunchKernelGGL(k_tl_apply_nr<2>, dim3(grid), dim3(256), 0, s, t, NR, dinv, r, yc, z, scal, it, ctl);
+    CHECK_LAUNCH();
+}
+void launch_pack_rows(int64_t n, int W, const int32_t *idx, const double *src, double *dst, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_pack_rows, dim3(grid_for(n * W)), dim3(256), 0, s, n, W, idx, src, dst);
+    CHECK_LAUNCH();
+}
+void launch_interleave(int64_t nRows, int NR, int dim, const double *src, double *dst, bool toInterleaved, int64_t sepStride, hipStream_t s) {
+    if (!nRows) return;
+    hipLaunchKernelGGL(k_interleave, dim3(grid_for(nRows * NR * dim)), dim3(256), 0, s, nRows, NR, dim, src, dst, toInterleaved ? 1 : 0, sepStride);
+    CHECK_LAUNCH();
+}
+void launch_norms_nr(int64_t nRows, int NR, int dim, const double *v, double *out, hipStream_t s) {
+    if (!nRows) return;
+    hipLaunchKernelGGL(k_norms_nr, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, NR, dim, v, out);
+    CHECK_LAUNCH();
+}
+void launch_mask_nr(int64_t nRows, int NR, int dim, const uint8_t *mask, double *v, hipStream_t s) {
+    if (!nRows) return;
+    hipLaunchKernelGGL(k_mask_nr, dim3(grid_for(nRows * NR * dim)), dim3(256), 0, s, nRows, NR, dim, mask, v);
+    CHECK_LAUNCH();
+}
+void launch_scatter_values_nr(int64_t n, int NR, int dim, const int64_t *idx, const double *val, double *v, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_scatter_values_nr, dim3(grid_for(n)), dim3(256), 0, s, n, NR, dim, idx, val, v);
+    CHECK_LAUNCH();
+}
 
 }} // namespace mfh::k

@@ -1,0 +1,667 @@
+// The PCG of libmeshfem_hip: Chronopoulos-Gear form (one reduction point per iteration) on NR interleaved right-hand sides,
+// the same loop for a whole mesh on one GPU and for a row-partitioned mesh on N GPUs (SPSDSystem::solve,
+// SparseMatrices.hh:2515-2606, with CHOLMOD replaced; the reference has no distributed code).
+//
+//   u = M^-1 r, w = K u, gamma = (r, u), delta = (w, u)                         -- ONE all-reduce of {gamma, delta, rr} x NR
+//   beta = gamma / gamma_old, alpha = gamma / (delta - beta gamma / alpha_old)
+//   p = u + beta p ; s = w + beta s ; x += alpha p ; r -= alpha s               -- one fused vector kernel (k_cg_update)
+//
+// Multi-GPU: rows (nodes) are partitioned, every rank holds the elements of its owned nodes (mfh_mesh_set with nOwned);
+// per iteration the owned entries of u that other ranks read are packed by a kernel into persistent send buffers and
+// exchanged on a second HIP stream WHILE the element blocks / row chunks that touch no halo column are processed; the
+// others follow once the halo has arrived. Communication goes through an mfh_comm: RCCL (looked up with dlopen, so that
+// the library links against no particular ROCm communication stack) or two caller-supplied callbacks.
+#include "mfh_ctx.hh"
+#include <dlfcn.h>
+
+// ------------------------------------------------------------------------------------------------ communicator
+namespace {
+
+typedef int (*nccl_get_unique_id_t)(void *);
+typedef int (*nccl_comm_init_rank_t)(void **, int, mfh_rccl_unique_id, int);
+typedef int (*nccl_comm_destroy_t)(void *);
+typedef int (*nccl_all_reduce_t)(const void *, void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_send_t)(const void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_recv_t)(void *, size_t, int, int, void *, hipStream_t);
+typedef int (*nccl_group_t)(void);
+typedef const char *(*nccl_error_string_t)(int);
+typedef int (*nccl_get_version_t)(int *);
+
+struct RcclApi {
+    bool tried = false, ok = false;
+    std::string where;
+    nccl_get_unique_id_t getUniqueId = nullptr;
+    nccl_comm_init_rank_t commInitRank = nullptr;
+    nccl_comm_destroy_t commDestroy = nullptr;
+    nccl_all_reduce_t allReduce = nullptr;
+    nccl_send_t send = nullptr;
+    nccl_recv_t recv = nullptr;
+    nccl_group_t groupStart = nullptr, groupEnd = nullptr;
+    nccl_error_string_t errorString = nullptr;
+    nccl_get_version_t getVersion = nullptr;
+};
+
+// RCCL through dlopen: a process that already has an RCCL (PyTorch ships its own librccl.so) keeps using that one; a plain
+// C++ client gets the ROCm installation's. No link-time dependency.
+RcclApi &rccl() {
+    static RcclApi api;
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (api.tried) return api;
+    api.tried = true;
+    void *h = nullptr;
+    const char *env = getenv("MFH_RCCL_LIB");
+    if (env && *env) { h = dlopen(env, RTLD_NOW | RTLD_LOCAL); api.where = env; }
+    if (!h && dlsym(RTLD_DEFAULT, "ncclAllReduce")) { h = RTLD_DEFAULT; api.where = "already loaded in the process"; }
+    if (!h) {
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+            if (!h) h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (h) { api.where = name; break; }
+        }
+    }
+    if (!h) return api;
+    auto sym = [&](const char *n) { return dlsym(h, n); };
+    api.getUniqueId = (nccl_get_unique_id_t)sym("ncclGetUniqueId");
+    api.commInitRank = (nccl_comm_init_rank_t)sym("ncclCommInitRank");
+    api.commDestroy = (nccl_comm_destroy_t)sym("ncclCommDestroy");
+    api.allReduce = (nccl_all_reduce_t)sym("ncclAllReduce");
+    api.send = (nccl_send_t)sym("ncclSend");
+    api.recv = (nccl_recv_t)sym("ncclRecv");
+    api.groupStart = (nccl_group_t)sym("ncclGroupStart");
+    api.groupEnd = (nccl_group_t)sym("ncclGroupEnd");
+    api.errorString = (nccl_error_string_t)sym("ncclGetErrorString");
+    api.getVersion = (nccl_get_version_t)sym("ncclGetVersion");
+    api.ok = api.getUniqueId && api.commInitRank && api.commDestroy && api.allReduce && api.send && api.recv && api.groupStart && api.groupEnd;
+    return api;
+}
+
+constexpr int kNcclFloat64 = 8, kNcclSum = 0;   // rccl.h: ncclDataType_t / ncclRedOp_t
+
+}   // namespace
+
+struct mfh_comm {
+    int rank = 0, world = 1;
+    // callbacks
+    void *user = nullptr;
+    mfh_allreduce_fn allreduce = nullptr;
+    mfh_exchange_fn exchange = nullptr;
+    // RCCL
+    void *nccl = nullptr;
+    int device = -1;
+    std::string desc;
+};
+
+namespace {
+
+void rccl_check(int rc, const char *what) {
+    if (rc == 0) return;
+    RcclApi &a = rccl();
+    throw Error(MFH_ERR_HIP, std::string(what) + ": " + (a.errorString ? a.errorString(rc) : "RCCL error " + std::to_string(rc)));
+}
+
+void comm_allreduce(mfh_comm *cm, double *dev, int64_t n, hipStream_t s) {
+    if (!cm || cm->world <= 1 || n == 0) return;
+    if (cm->nccl) rccl_check(rccl().allReduce(dev, dev, (size_t)n, kNcclFloat64, kNcclSum, cm->nccl, s), "ncclAllReduce");
+    else if (cm->allreduce(cm->user, dev, n, (void *)s) != MFH_OK) throw Error(MFH_ERR_HIP, "communicator callback allreduce_sum failed");
+}
+
+void comm_exchange(mfh_comm *cm, int nPeers, const int32_t *peers, const double *const *sendBufs, const int64_t *sendCounts,
+                   double *const *recvBufs, const int64_t *recvCounts, hipStream_t s) {
+    if (!cm || cm->world <= 1 || nPeers == 0) return;
+    if (cm->nccl) {
+        RcclApi &a = rccl();
+        rccl_check(a.groupStart(), "ncclGroupStart");
+        for (int k = 0; k < nPeers; ++k) {
+            if (sendCounts[k] > 0) rccl_check(a.send(sendBufs[k], (size_t)sendCounts[k], kNcclFloat64, peers[k], cm->nccl, s), "ncclSend");
+            if (recvCounts[k] > 0) rccl_check(a.recv(recvBufs[k], (size_t)recvCounts[k], kNcclFloat64, peers[k], cm->nccl, s), "ncclRecv");
+        }
+        rccl_check(a.groupEnd(), "ncclGroupEnd");
+    } else if (cm->exchange(cm->user, nPeers, peers, sendBufs, sendCounts, recvBufs, recvCounts, (void *)s) != MFH_OK)
+        throw Error(MFH_ERR_HIP, "communicator callback exchange failed");
+}
+
+}   // namespace
+
+// ------------------------------------------------------------------------------------------------ solver
+namespace mfhi {
+
+k::SpmvArgs spmv_args(mfh_ctx *c, bool masked);
+k::SpmvMfArgs spmv_mf_cluster_args(mfh_ctx *c, bool masked);
+bool prepare_matrix_free(mfh_ctx *c);
+k::TLArgs tl_args(mfh_ctx *c);
+void ensure_fixed_uploaded(mfh_ctx *c);
+void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info);
+
+namespace {
+
+struct DistLink {   // stream / event plumbing of one solve on a partitioned context
+    mfh_ctx *c;
+    mfh_comm *cm;
+    hipStream_t s, cs;
+    bool active;
+    explicit DistLink(mfh_ctx *c_) : c(c_), cm(c_->dist.comm), s(c_->stream), cs(c_->dist.commStream), active(c_->dist.comm && c_->dist.comm->world > 1) {}
+    // owned entries -> persistent send buffers -> neighbours; returns with the exchange in flight on the communication stream
+    void halo_begin(double *v, int W) {
+        if (!active) return;
+        auto &D = c->dist;
+        const int64_t nSend = D.sendPtr.back();
+        D.sendBuf.alloc((size_t)std::max<int64_t>(1, nSend) * D.sendBufW);
+        if (W > D.sendBufW) throw Error(MFH_ERR_STATE, "halo send buffer too small");
+        k::launch_pack_rows(nSend, W, D.sendIdx.p, v, D.sendBuf.p, s);
+        MFH_HIP(hipEventRecord(D.ev[0], s));
+        MFH_HIP(hipStreamWaitEvent(cs, D.ev[0], 0));
+        const int np = (int)D.peers.size();
+        std::vector<const double *> sb((size_t)np);
+        std::vector<double *> rb((size_t)np);
+        std::vector<int64_t> sc((size_t)np), rc((size_t)np);
+        const int64_t nRows = c->sym.nRows;
+        for (int k = 0; k < np; ++k) {
+            sb[k] = D.sendBuf.p + D.sendPtr[k] * W;
+            sc[k] = (D.sendPtr[k + 1] - D.sendPtr[k]) * W;
+            rb[k] = v + (nRows + D.recvPtr[k]) * W;
+            rc[k] = (D.recvPtr[k + 1] - D.recvPtr[k]) * W;
+        }
+        comm_exchange(cm, np, D.peers.data(), sb.data(), sc.data(), rb.data(), rc.data(), cs);
+        MFH_HIP(hipEventRecord(D.ev[1], cs));
+    }
+    void halo_end() {
+        if (active) MFH_HIP(hipStreamWaitEvent(s, c->dist.ev[1], 0));
+    }
+    // in-place sum over the ranks, ordered after everything enqueued on the compute stream so far
+    void allreduce(double *dev, int64_t n) {
+        if (!active) return;
+        auto &D = c->dist;
+        MFH_HIP(hipEventRecord(D.ev[2], s));
+        MFH_HIP(hipStreamWaitEvent(cs, D.ev[2], 0));
+        comm_allreduce(cm, dev, n, cs);
+        MFH_HIP(hipEventRecord(D.ev[3], cs));
+        MFH_HIP(hipStreamWaitEvent(s, D.ev[3], 0));
+    }
+};
+
+bool cluster_operator(mfh_ctx *c) { return c->use_mf() && c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY; }
+
+// element blocks (cluster operator) / row chunks (assembled SpMV) ordered interior first, then those reading a halo column
+void ensure_overlap_lists(mfh_ctx *c, bool cluster) {
+    auto &D = c->dist;
+    const int kind = cluster ? 1 : 2;
+    if (D.listKind == kind) return;
+    hipStream_t s = c->stream;
+    const int64_t n = cluster ? c->mfc.nBlocks : (int64_t)c->sym.spmvChunkRow.size() - 1;
+    DBuf<uint8_t> flag;
+    flag.alloc((size_t)std::max<int64_t>(1, n));
+    if (cluster) k::launch_flag_halo_blocks(n, c->mfcDev.blockPtr.p, c->mfcDev.entryDest.p, flag.p, s);
+    else k::launch_flag_halo_chunks(n, c->dSpmvChunkRow.p, c->dRowPtr.p, c->dColIdx.p, c->sym.nRows, flag.p, s);
+    std::vector<uint8_t> h((size_t)n);
+    flag.download(h.data(), h.size(), s);
+    std::vector<int32_t> list;
+    list.reserve((size_t)n);
+    for (int64_t b = 0; b < n; ++b) if (!h[(size_t)b]) list.push_back((int32_t)b);
+    D.nInterior = (int64_t)list.size();
+    for (int64_t b = 0; b < n; ++b) if (h[(size_t)b]) list.push_back((int32_t)b);
+    D.nBoundary = n - D.nInterior;
+    D.opList.upload(list.empty() ? std::vector<int32_t>{0} : list, s);
+    D.listKind = kind;
+}
+
+// y = K x for NR interleaved vectors. With an active communicator the halo part of x is exchanged first, overlapped with
+// the interior blocks / chunks. dotOut (stride 4) or the PCG bookkeeping (scal, it, ctl) as in the kernels.
+void apply_op_nr(mfh_ctx *c, DistLink &L, int NR, double *x, double *y, bool masked, double *dotOut, double *scal, int it, const double *ctl) {
+    hipStream_t s = c->stream;
+    const bool cluster = cluster_operator(c);
+    const int W = NR * c->bs();
+    if (cluster) {
+        const k::SpmvMfArgs a = spmv_mf_cluster_args(c, masked);
+        if ((size_t)std::max<int64_t>(c->mfc.nIface, 1) * W > c->mfcDev.ifaceBuf.n) throw Error(MFH_ERR_STATE, "interface buffer too small for this batch");
+        if (L.active) {
+            ensure_overlap_lists(c, true);
+            L.halo_begin(x, W);
+            k::launch_mf_cluster_nr(a, NR, x, y, dotOut, scal, it, ctl, c->dist.opList.p, c->dist.nInterior, s);
+            L.halo_end();
+            k::launch_mf_cluster_nr(a, NR, x, y, dotOut, scal, it, ctl, c->dist.opList.p + c->dist.nInterior, c->dist.nBoundary, s);
+        } else
+            k::launch_mf_cluster_nr(a, NR, x, y, dotOut, scal, it, ctl, nullptr, c->mfc.nBlocks, s);
+        k::launch_mf_rows_nr(a, NR, x, y, dotOut, scal, it, ctl, s);
+    } else {
+        const k::SpmvArgs a = spmv_args(c, masked);
+        if (L.active) {
+            ensure_overlap_lists(c, false);
+            L.halo_begin(x, W);
+            k::launch_spmv_nr(a, NR, x, y, dotOut, scal, it, ctl, c->dist.opList.p, c->dist.nInterior, s);
+            L.halo_end();
+            k::launch_spmv_nr(a, NR, x, y, dotOut, scal, it, ctl, c->dist.opList.p + c->dist.nInterior, c->dist.nBoundary, s);
+        } else
+            k::launch_spmv_nr(a, NR, x, y, dotOut, scal, it, ctl, nullptr, a.nChunk, s);
+    }
+}
+
+// z = M^-1 r with the two-level preconditioner for NR vectors; the restricted residual is summed over the ranks
+void tl_precond_nr(mfh_ctx *c, DistLink &L, int NR, const double *r, double *z, double *scal, int it, const double *ctl) {
+    const k::TLArgs ta = tl_args(c);
+    auto &T = c->tl;
+    c->tlRcN.alloc((size_t)T.m * NR);
+    c->tlYcN.alloc((size_t)T.m * NR);
+    k::launch_tl_restrict_nr(ta, NR, T.aggPtr.p, T.dofsByAgg.p, r, c->tlRcN.p, c->stream);
+    L.allreduce(c->tlRcN.p, T.m * NR);
+    k::launch_tl_gemv_nr(T.m, T.ldInv, NR, T.Ainv.p, c->tlRcN.p, c->tlYcN.p, c->stream);
+    k::launch_tl_apply_nr(ta, NR, c->dDinv.p, r, c->tlYcN.p, z, scal, it, ctl, c->stream);
+}
+
+}   // namespace
+
+bool cg_operator_supported(mfh_ctx *c) {
+    // the batched operators: the cluster variant of the matrix-free operator and the assembled SpMV
+    if (!c->use_mf()) return true;
+    prepare_matrix_free(c);
+    return cluster_operator(c);
+}
+
+// PCG on the free variables for NR right-hand sides at once. f / u: NR host vectors of bs * nRows doubles each (nRows = the
+// rows this context owns), fStride doubles apart.
+void solve_cg(mfh_ctx *c, int NR, const double *f, double *u, int64_t fStride, double rtol, int maxit, mfh_solve_info *infos) {
+    RoctxRange range("Elasticity Solve");
+    const int d = c->bs();
+    const int W = NR * d;
+    const int64_t nRows = c->sym.nRows, nCols = c->sym.nCols;
+    const int64_t nOwn = nRows * W, nAll = nCols * W;
+    hipStream_t s = c->stream;
+    DistLink L(c);
+    if (nRows != nCols && !c->dist.comm) throw Error(MFH_ERR_STATE, "row-partitioned context: call mfh_dist_setup before solving");
+    if (!k::op_batch_supported(d, NR)) throw Error(MFH_ERR_UNSUPPORTED, "unsupported batch size");
+    EventTimer tsetup(s);
+    c->cgU.alloc(nAll); c->cgW.alloc(nOwn); c->cgP.alloc(nOwn); c->cgS.alloc(nOwn); c->cgX.alloc(nOwn); c->cgR.alloc(nOwn); c->cgF.alloc(nOwn);
+    c->cgCtl.alloc(16);
+    const bool masked = !c->fixedVars.empty();
+    const bool cluster = cluster_operator(c);
+    if (cluster && c->mfcDev.ifaceBuf.n < (size_t)std::max<int64_t>(c->mfc.nIface, 1) * W)
+        c->mfcDev.ifaceBuf.alloc((size_t)std::max<int64_t>(c->mfc.nIface, 1) * W);
+    if (L.active) c->dist.sendBufW = std::max(c->dist.sendBufW, W);
+    // right-hand sides: NR separate host vectors -> interleaved on the device
+    for (int k2 = 0; k2 < NR; ++k2)
+        MFH_HIP(hipMemcpyAsync(c->cgS.p + (size_t)k2 * nRows * d, f + (size_t)k2 * fStride, (size_t)nRows * d * sizeof(double), hipMemcpyHostToDevice, s));
+    k::launch_interleave(nRows, NR, d, c->cgS.p, c->cgF.p, true, nRows * d, s);
+    // b = f - K ubar on the free variables (SparseMatrices.hh:2457-2470,2526-2535); b lives in R
+    MFH_HIP(hipMemcpyAsync(c->cgR.p, c->cgF.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (c->anyFixedNonzero && !c->solveHomogeneous) {
+        c->cgU.zero(s);
+        k::launch_scatter_values_nr((int64_t)c->fixedVars.size(), NR, d, c->dFixedIdx.p, c->dFixedVal.p, c->cgU.p, s);
+        apply_op_nr(c, L, NR, c->cgU.p, c->cgW.p, false, nullptr, nullptr, 0, nullptr);
+        k::launch_axpby(nOwn, -1.0, c->cgW.p, 1.0, c->cgR.p, s);
+    }
+    if (masked) k::launch_mask_nr(nRows, NR, d, c->dFixedMask.p, c->cgR.p, s);
+    double bb[8] = {0};
+    {
+        MFH_HIP(hipMemsetAsync(c->cgCtl.p, 0, 16 * sizeof(double), s));
+        k::launch_norms_nr(nRows, NR, d, c->cgR.p, c->cgCtl.p + 8, s);
+        L.allreduce(c->cgCtl.p + 8, NR);
+        MFH_HIP(hipMemcpyAsync(bb, c->cgCtl.p + 8, NR * sizeof(double), hipMemcpyDeviceToHost, s));
+        MFH_HIP(hipStreamSynchronize(s));
+    }
+    double ctlHost[16] = {0};
+    bool anyWork = false;
+    for (int k2 = 0; k2 < NR; ++k2) { ctlHost[2 + k2] = rtol * rtol * bb[k2]; anyWork |= bb[k2] > 0; }
+    MFH_HIP(hipMemcpyAsync(c->cgCtl.p, ctlHost, 16 * sizeof(double), hipMemcpyHostToDevice, s));
+    const size_t scalN = ((size_t)maxit + (size_t)c->checkEvery + 3) * 4 * NR;
+    c->scal.alloc(scalN);
+    c->scal.zero(s);
+    c->cgX.zero(s); c->cgP.zero(s); c->cgS.zero(s);
+    const double setupMs = tsetup.stop();
+    std::vector<int> itConv((size_t)NR, -1);
+    std::vector<double> rrFinal((size_t)NR, 0.0);
+    double solveMs = 0;
+    bool usedGraph = false;
+    int itRun = 0;
+    if (anyWork) {
+        EventTimer tsolve(s);
+        const bool useTL = c->precond == MFH_PRECOND_TWO_LEVEL && c->tl.valid && !c->tlSuppress;
+        double *scal = c->scal.p;
+        const double *ctl = c->cgCtl.p;
+        // start: u = M^-1 r, w = K u, {gamma, delta, rr}_0
+        k::launch_cg_init(d, nRows, NR, c->dDinv.p, c->cgR.p, c->cgU.p, scal, useTL, s);
+        if (useTL) tl_precond_nr(c, L, NR, c->cgR.p, c->cgU.p, scal, -1, ctl);
+        apply_op_nr(c, L, NR, c->cgU.p, c->cgW.p, masked, scal + 1, nullptr, 0, nullptr);
+        L.allreduce(scal, 4 * NR);
+        auto enqueue = [&](int itLocal, int itAbs) {
+            k::launch_cg_update(d, nRows, NR, c->dDinv.p, c->cgU.p, c->cgW.p, c->cgP.p, c->cgS.p, c->cgX.p, c->cgR.p, scal, itLocal, ctl, useTL, s);
+            if (useTL) tl_precond_nr(c, L, NR, c->cgR.p, c->cgU.p, scal, itLocal, ctl);
+            apply_op_nr(c, L, NR, c->cgU.p, c->cgW.p, masked, nullptr, scal, itLocal, ctl);
+            L.allreduce(scal + (size_t)(itAbs + 1) * 4 * NR, 4 * NR);
+        };
+        // launch-bound regime (small meshes): replay blocks of check_every iterations from a hipGraph; the kernels find their
+        // iteration through the device-side base ctl[0], which the last node advances. Not with a communicator.
+        hipGraphExec_t exec = nullptr;
+        if (c->useGraph && c->checkEvery > 1 && !L.active) {
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                bool ok = true;
+                try {
+                    for (int j = 0; j < c->checkEvery; ++j) enqueue(j, j);
+                    k::launch_add_scalar(c->cgCtl.p, (double)c->checkEvery, s);
+                } catch (...) { ok = false; }
+                if (hipStreamEndCapture(s, &graph) != hipSuccess || !ok || !graph) { graph = nullptr; (void)hipGetLastError(); }
+            } else (void)hipGetLastError();
+            if (graph) {
+                if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { exec = nullptr; (void)hipGetLastError(); }
+                (void)hipGraphDestroy(graph);
+            }
+        }
+        usedGraph = exec != nullptr;
+        std::vector<double> hs;
+        int it = 0, lastChecked = 0, nConv = 0;
+        for (int k2 = 0; k2 < NR; ++k2) if (!(bb[k2] > 0)) { itConv[k2] = 0; ++nConv; }
+        std::vector<double> bestRR((size_t)NR, 1e300);
+        std::vector<int> itBest((size_t)NR, 0);
+        const int stagnationWindow = std::max(5000, 40 * c->checkEvery);
+        while (nConv < NR && it < maxit) {
+            if (exec) { MFH_HIP(hipGraphLaunch(exec, s)); it += c->checkEvery; }
+            else {
+                const int itEnd = std::min(maxit, it + c->checkEvery);
+                for (; it < itEnd; ++it) enqueue(it, it);
+            }
+            hs.resize((size_t)(it - lastChecked + 1) * 4 * NR);
+            MFH_HIP(hipMemcpyAsync(hs.data(), scal + (size_t)lastChecked * 4 * NR, hs.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+            MFH_HIP(hipStreamSynchronize(s));
+            for (int k2 = 0; k2 < NR; ++k2) {
+                if (itConv[k2] >= 0) continue;
+                for (int q = lastChecked; q <= std::min(it, maxit); ++q) {
+                    const double *sc = &hs[((size_t)(q - lastChecked) * NR + k2) * 4];
+                    const double rr = sc[2];
+                    if (rr <= ctlHost[2 + k2]) { itConv[k2] = q; rrFinal[k2] = rr; ++nConv; break; }
+                    if (!(rr == rr)) throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (NaN residual): K is not SPD on the free variables");
+                    // CHOLMOD reports "not positive definite" at once; the iterative counterpart: negative curvature
+                    // (p.Kp = gamma / alpha < 0), or a residual that has not improved by 10 % for thousands of iterations (a
+                    // singular system with an inconsistent right-hand side: missing boundary conditions, unbalanced loads)
+                    if (q < it && sc[3] != 0.0 && sc[0] / sc[3] < 0.0)
+                        throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (p.Kp = " + std::to_string(sc[0] / sc[3]) + " < 0 at iteration " + std::to_string(q) +
+                                                               ", residual^2 " + std::to_string(rr) + "): K is not positive definite on the free variables");
+                    if (rr < 0.9 * bestRR[k2]) { bestRR[k2] = rr; itBest[k2] = q; }
+                    else if (q - itBest[k2] > stagnationWindow)
+                        throw Error(MFH_ERR_NOT_CONVERGED, "PCG stagnated (no progress of the residual for " + std::to_string(stagnationWindow) +
+                                                               " iterations): the system is singular with an inconsistent right-hand side "
+                                                               "(missing boundary conditions?) or too ill-conditioned for this preconditioner");
+                    rrFinal[k2] = rr;
+                }
+            }
+            lastChecked = it;
+        }
+        itRun = it;
+        if (exec) (void)hipGraphExecDestroy(exec);
+        solveMs = tsolve.stop();
+    } else {
+        for (int k2 = 0; k2 < NR; ++k2) itConv[k2] = 0;
+    }
+    // u = x + ubar  (SparseMatrices.hh:2592-2605)
+    if (masked && !c->solveHomogeneous) k::launch_scatter_values_nr((int64_t)c->fixedVars.size(), NR, d, c->dFixedIdx.p, c->dFixedVal.p, c->cgX.p, s);
+    // true residual on the free variables: || mask(f - K u) || / ||b||
+    double tr[8] = {0};
+    if (anyWork) {
+        MFH_HIP(hipMemsetAsync(c->cgCtl.p, 0, 16 * sizeof(double), s));   // the operator below must not be gated
+        MFH_HIP(hipMemcpyAsync(c->cgU.p, c->cgX.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if (nAll > nOwn && !L.active) MFH_HIP(hipMemsetAsync(c->cgU.p + nOwn, 0, (size_t)(nAll - nOwn) * sizeof(double), s));
+        if (nAll > nOwn && masked && !c->solveHomogeneous)   // fixed values on halo variables (also refreshed by the exchange)
+            k::launch_scatter_values_nr((int64_t)c->fixedVars.size(), NR, d, c->dFixedIdx.p, c->dFixedVal.p, c->cgU.p, s);
+        apply_op_nr(c, L, NR, c->cgU.p, c->cgW.p, false, nullptr, nullptr, 0, nullptr);
+        k::launch_axpby(nOwn, 1.0, c->cgF.p, -1.0, c->cgW.p, s);
+        if (masked) k::launch_mask_nr(nRows, NR, d, c->dFixedMask.p, c->cgW.p, s);
+        k::launch_norms_nr(nRows, NR, d, c->cgW.p, c->cgCtl.p + 8, s);
+        L.allreduce(c->cgCtl.p + 8, NR);
+        MFH_HIP(hipMemcpyAsync(tr, c->cgCtl.p + 8, NR * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    k::launch_interleave(nRows, NR, d, c->cgX.p, c->cgS.p, false, nRows * d, s);
+    for (int k2 = 0; k2 < NR; ++k2)
+        MFH_HIP(hipMemcpyAsync(u + (size_t)k2 * fStride, c->cgS.p + (size_t)k2 * nRows * d, (size_t)nRows * d * sizeof(double), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    for (int k2 = 0; k2 < NR; ++k2) {
+        mfh_solve_info li{};
+        li.converged = itConv[k2] >= 0 ? 1 : 0;
+        li.iterations = itConv[k2] >= 0 ? itConv[k2] : std::min(itRun, maxit);
+        li.rel_residual = bb[k2] > 0 ? std::sqrt(rrFinal[k2] / bb[k2]) : 0.0;
+        li.true_rel_residual = bb[k2] > 0 ? std::sqrt(tr[k2] / bb[k2]) : 0.0;
+        li.solve_ms = solveMs;
+        li.setup_ms = setupMs;
+        li.used_graph = usedGraph ? 1 : 0;
+        li.reserved = NR;
+        if (infos) infos[k2] = li;
+    }
+}
+
+// one right-hand side: the Chronopoulos-Gear loop when the operator in use has a batched kernel, else the classic PCG
+void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info) {
+    const bool partitioned = c->sym.nRows != c->sym.nCols;
+    if ((c->pcgVariant == 1 || partitioned) && cg_operator_supported(c)) {
+        const int64_t n = (int64_t)c->bs() * c->sym.nRows;
+        solve_cg(c, 1, f, u, n, rtol, maxit, info);
+    } else {
+        solve_one_classic(c, f, u, rtol, maxit, info);
+        if (info) info->reserved = 1;
+    }
+}
+
+// nrhs right-hand sides in batches of the sizes the kernels are built for (3D: 6, 2, 1; 2D: 3, 1)
+void solve_many(mfh_ctx *c, int nrhs, const double *f, double *u, int64_t stride, double rtol, int maxit, mfh_solve_info *infos) {
+    const int d = c->bs();
+    const bool batched = c->pcgVariant != 0 && c->batchRhs && cg_operator_supported(c);
+    int k0 = 0;
+    while (k0 < nrhs) {
+        int nb = 1;
+        if (batched)
+            for (int cand : {6, 3, 2})
+                if (cand <= nrhs - k0 && k::op_batch_supported(d, cand)) { nb = cand; break; }
+        if (nb > 1) solve_cg(c, nb, f + (size_t)k0 * stride, u + (size_t)k0 * stride, stride, rtol, maxit, infos ? infos + k0 : nullptr);
+        else solve_one(c, f + (size_t)k0 * stride, u + (size_t)k0 * stride, rtol, maxit, infos ? infos + k0 : nullptr);
+        k0 += nb;
+    }
+}
+
+}   // namespace mfhi
+
+// ------------------------------------------------------------------------------------------------ C ABI
+using namespace mfhi;
+
+extern "C" {
+
+mfh_status mfh_rccl_get_unique_id(mfh_rccl_unique_id *id) {
+    if (!id) return MFH_ERR_INVALID;
+    RcclApi &a = rccl();
+    if (!a.ok) return MFH_ERR_UNSUPPORTED;
+    return a.getUniqueId(id) == 0 ? MFH_OK : MFH_ERR_HIP;
+}
+
+mfh_status mfh_comm_create_rccl(mfh_ctx *c, const mfh_rccl_unique_id *id, int32_t rank, int32_t world, mfh_comm **out) {
+    MFH_TRY(c)
+    require(c && id && out && world >= 1 && rank >= 0 && rank < world, MFH_ERR_INVALID, "bad communicator arguments");
+    require_device(c);
+    RcclApi &a = rccl();
+    if (!a.ok) throw Error(MFH_ERR_UNSUPPORTED, "RCCL not found (tried the process, librccl.so.1, librccl.so; set MFH_RCCL_LIB)");
+    MFH_HIP(hipSetDevice(c->device));
+    std::unique_ptr<mfh_comm> cm(new mfh_comm());
+    cm->rank = rank; cm->world = world; cm->device = c->device;
+    rccl_check(a.commInitRank(&cm->nccl, world, *id, rank), "ncclCommInitRank");
+    int ver = 0;
+    if (a.getVersion) (void)a.getVersion(&ver);
+    cm->desc = "RCCL " + std::to_string(ver) + " (" + a.where + "), " + std::to_string(world) + " ranks";
+    *out = cm.release();
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_comm_create_callbacks(int32_t rank, int32_t world, void *user, mfh_allreduce_fn allreduce_sum, mfh_exchange_fn exchange,
+                                     mfh_comm **out) {
+    if (!out || world < 1 || rank < 0 || rank >= world || (world > 1 && (!allreduce_sum || !exchange))) return MFH_ERR_INVALID;
+    mfh_comm *cm = new mfh_comm();
+    cm->rank = rank; cm->world = world; cm->user = user; cm->allreduce = allreduce_sum; cm->exchange = exchange;
+    cm->desc = "caller callbacks, " + std::to_string(world) + " ranks";
+    *out = cm;
+    return MFH_OK;
+}
+
+void mfh_comm_destroy(mfh_comm *cm) {
+    if (!cm) return;
+    if (cm->nccl && rccl().ok) (void)rccl().commDestroy(cm->nccl);
+    delete cm;
+}
+
+const char *mfh_comm_describe(const mfh_comm *cm) { return cm ? cm->desc.c_str() : ""; }
+
+mfh_status mfh_comm_allreduce(mfh_ctx *c, mfh_comm *cm, double *dev, int64_t n) {
+    MFH_TRY(c)
+    require(c && cm && dev && n >= 0, MFH_ERR_INVALID, "bad arguments");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    comm_allreduce(cm, dev, n, c->stream);
+    MFH_HIP(hipStreamSynchronize(c->stream));
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_comm_selftest(mfh_ctx *c, mfh_comm *cm) {
+    MFH_TRY(c)
+    require(c && cm, MFH_ERR_INVALID, "bad arguments");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    // all-reduce: every rank contributes rank + 1; point-to-point: a ring shift of a 1024-double message (to itself at world 1)
+    const int n = 1024;
+    DBuf<double> a, b;
+    a.alloc(n); b.alloc(n);
+    std::vector<double> h((size_t)n);
+    for (int i = 0; i < n; ++i) h[i] = (cm->rank + 1) * 1000.0 + i;
+    MFH_HIP(hipMemcpyAsync(a.p, h.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+    b.zero(s);
+    const int32_t to = (cm->rank + 1) % cm->world, from = (cm->rank + cm->world - 1) % cm->world;
+    if (cm->nccl) {
+        RcclApi &r = rccl();
+        rccl_check(r.groupStart(), "ncclGroupStart");
+        rccl_check(r.send(a.p, n, kNcclFloat64, to, cm->nccl, s), "ncclSend");
+        rccl_check(r.recv(b.p, n, kNcclFloat64, from, cm->nccl, s), "ncclRecv");
+        rccl_check(r.groupEnd(), "ncclGroupEnd");
+    } else if (cm->world > 1) {
+        // with callbacks the exchange is grouped per peer: send to `to`, receive from `from` (the same peer at world 2)
+        const double *sb[2] = {a.p, nullptr};
+        double *rb[2] = {nullptr, b.p};
+        int32_t peers[2] = {to, from};
+        int64_t sc[2] = {n, 0}, rc[2] = {0, n};
+        if (to == from) { rb[0] = b.p; rc[0] = n; comm_exchange(cm, 1, peers, sb, sc, rb, rc, s); }
+        else comm_exchange(cm, 2, peers, sb, sc, rb, rc, s);
+    } else
+        MFH_HIP(hipMemcpyAsync(b.p, a.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+    std::vector<double> got((size_t)n);
+    MFH_HIP(hipMemcpyAsync(got.data(), b.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i)
+        if (got[i] != (from + 1) * 1000.0 + i) throw Error(MFH_ERR_HIP, "communicator self-test: point-to-point message corrupted");
+    double one[2] = {cm->rank + 1.0, 1.0};
+    MFH_HIP(hipMemcpyAsync(a.p, one, 2 * sizeof(double), hipMemcpyHostToDevice, s));
+    comm_allreduce(cm, a.p, 2, s);
+    MFH_HIP(hipMemcpyAsync(one, a.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    if (one[0] != cm->world * (cm->world + 1) / 2.0 || one[1] != (double)cm->world) throw Error(MFH_ERR_HIP, "communicator self-test: all-reduce gives a wrong sum");
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_dist_setup(mfh_ctx *c, mfh_comm *cm, int32_t nPeers, const int32_t *peers, const int64_t *sendPtr, const int32_t *sendNodes,
+                          const int64_t *recvPtr) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && cm && nPeers >= 0 && (nPeers == 0 || (peers && sendPtr && recvPtr)), MFH_ERR_INVALID, "bad distributed setup arguments");
+    require(c->dofForNode.empty(), MFH_ERR_UNSUPPORTED, "row-partitioned contexts use the identity DoF map");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    auto &D = c->dist;
+    const int64_t nOwned = c->mesh.nOwned, nHalo = c->mesh.nNode - nOwned;
+    D.peers.assign(peers, peers + nPeers);
+    D.sendPtr.assign(1, 0); D.recvPtr.assign(1, 0);
+    for (int k = 0; k < nPeers; ++k) {
+        require(peers[k] >= 0 && peers[k] < cm->world && peers[k] != cm->rank, MFH_ERR_INVALID, "bad peer rank");
+        require(sendPtr[k + 1] >= sendPtr[k] && recvPtr[k + 1] >= recvPtr[k], MFH_ERR_INVALID, "exchange offsets must be non-decreasing");
+        D.sendPtr.push_back(sendPtr[k + 1]); D.recvPtr.push_back(recvPtr[k + 1]);
+    }
+    require(nPeers == 0 || (sendPtr[0] == 0 && recvPtr[0] == 0), MFH_ERR_INVALID, "exchange offsets start at 0");
+    require(D.recvPtr.back() == nHalo, MFH_ERR_INVALID, "the receive ranges must cover the halo nodes exactly (halo nodes grouped by owner, in the peers' order)");
+    std::vector<int32_t> idx(sendNodes, sendNodes + D.sendPtr.back());
+    for (int32_t v : idx) require(v >= 0 && v < nOwned, MFH_ERR_INVALID, "send list holds a node this rank does not own");
+    D.sendIdx.upload(idx.empty() ? std::vector<int32_t>{0} : idx, c->stream);
+    if (!D.commStream) {
+        MFH_HIP(hipStreamCreateWithFlags(&D.commStream, hipStreamNonBlocking));
+        for (auto &e : D.ev) MFH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    D.comm = cm;
+    D.listKind = 0;
+    D.sendBufW = std::max(D.sendBufW, c->bs());
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_dist_two_level(mfh_ctx *c, int32_t nAgg, const int32_t *aggOfNode, const double *relPos) {
+    MFH_TRY(c)
+    require(c && c->dist.comm, MFH_ERR_STATE, "mfh_dist_setup has not run");
+    const int64_t m = (int64_t)nAgg * (c->dim() == 3 ? 6 : 3);
+    DBuf<double> Ac;
+    Ac.alloc((size_t)m * m);
+    mfh_status st = mfh_tl_partitioned_begin(c, nAgg, aggOfNode, relPos, Ac.p);
+    if (st != MFH_OK) throw Error(st, c->err);
+    DistLink L(c);
+    L.allreduce(Ac.p, m * m);
+    MFH_HIP(hipStreamSynchronize(c->stream));
+    st = mfh_tl_partitioned_finish(c, Ac.p);
+    if (st != MFH_OK) throw Error(st, c->err);
+    c->precond = MFH_PRECOND_TWO_LEVEL;
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_dist_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, double rtol, int32_t maxit, mfh_solve_info *info) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && f && u && nrhs > 0 && maxit > 0 && rtol > 0, MFH_ERR_INVALID, "bad solve arguments");
+    require(c->dist.comm, MFH_ERR_STATE, "mfh_dist_setup has not run");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_precond(c);
+    require(cg_operator_supported(c), MFH_ERR_UNSUPPORTED, "the distributed solve needs the cluster matrix-free operator or the assembled SpMV");
+    const int64_t n = (int64_t)c->bs() * c->sym.nRows;
+    std::vector<mfh_solve_info> infos((size_t)nrhs);
+    // every rank must take the same path: batches are chosen from (dim, nrhs) only
+    int k0 = 0;
+    while (k0 < nrhs) {
+        int nb = 1;
+        if (c->batchRhs)
+            for (int cand : {6, 3, 2})
+                if (cand <= nrhs - k0 && k::op_batch_supported(c->bs(), cand)) { nb = cand; break; }
+        solve_cg(c, nb, f + (size_t)k0 * n, u + (size_t)k0 * n, n, rtol, maxit, infos.data() + k0);
+        k0 += nb;
+    }
+    bool all = true;
+    for (int k2 = 0; k2 < nrhs; ++k2) { all &= infos[k2].converged != 0; if (info) info[k2] = infos[k2]; }
+    if (!all) throw Error(MFH_ERR_NOT_CONVERGED, "PCG did not reach the requested tolerance within maxit iterations");
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_dist_apply_K(mfh_ctx *c, const double *uOwned, double *KuOwned) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uOwned && KuOwned, MFH_ERR_INVALID, "null argument");
+    require(c->dist.comm, MFH_ERR_STATE, "mfh_dist_setup has not run");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_precond(c);
+    require(cg_operator_supported(c), MFH_ERR_UNSUPPORTED, "the distributed operator needs the cluster matrix-free operator or the assembled SpMV");
+    const int d = c->bs();
+    const int64_t nOwn = c->sym.nRows * d, nAll = c->sym.nCols * d;
+    if (c->cgU.n < (size_t)nAll) c->cgU.alloc((size_t)nAll);
+    if (c->cgW.n < (size_t)nOwn) c->cgW.alloc((size_t)nOwn);
+    DistLink L(c);
+    MFH_HIP(hipMemcpyAsync(c->cgU.p, uOwned, (size_t)nOwn * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    apply_op_nr(c, L, 1, c->cgU.p, c->cgW.p, false, nullptr, nullptr, 0, nullptr);
+    MFH_HIP(hipMemcpyAsync(KuOwned, c->cgW.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    MFH_HIP(hipStreamSynchronize(c->stream));
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_dev_memcpy(mfh_ctx *c, void *dst, const void *src, int64_t bytes, int32_t kind, void *stream) {
+    MFH_TRY(c)
+    require(c && dst && src && bytes >= 0 && kind >= 0 && kind <= 2, MFH_ERR_INVALID, "bad copy arguments");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const hipMemcpyKind kd = kind == 0 ? hipMemcpyHostToDevice : (kind == 1 ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice);
+    MFH_HIP(hipMemcpyAsync(dst, src, (size_t)bytes, kd, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    MFH_CATCH(c)
+}
+
+}   // extern "C"

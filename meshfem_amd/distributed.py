@@ -4,19 +4,24 @@ One process per GPU. Nodes (block rows of K) are partitioned; every rank keeps t
 incident to its owned nodes, numbers its nodes owned-first / halo-last and assembles the
 `nOwned x nLocal` block rows it owns with NO communication (owner computes). The PCG needs, per
 iteration, one halo exchange of the search direction (point-to-point with the neighbouring ranks)
-and two small all-reduces of the dot products -- `torch.distributed` (backend "nccl" = RCCL over
-xGMI on the GPU box, "gloo" in the CPU tests). The local kernels are the library's device-pointer
-entry points (`HipLocalOps`); the tests substitute their own local operator, the product never
-falls back to one.
+and ONE fused all-reduce of the dot products. The HIP path runs entirely inside the library
+(`DistSolver` -> mfh_dist_setup / mfh_dist_solve: Chronopoulos-Gear PCG, packed send buffers, halo
+exchange overlapped with the interior element blocks) over an `mfh_comm` -- the library's own RCCL
+communicator over xGMI on the GPU box, or callbacks into torch.distributed (gloo) when several ranks
+share one GPU. `distributed_pcg` states the same algorithm in torch for the CPU tests of the host logic,
+which supply their own local operator; the product never falls back to one.
 
 The reference has no distributed code: this module has no counterpart to cite
 beyond the serial path it parallelises (LinearElasticity.hh:479-487, SparseMatrices.hh:2515-2606).
 """
+import ctypes
 import time
 
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import _lib as L
 
 TET_FACES = ((1, 3, 2), (0, 2, 3), (0, 3, 1), (0, 1, 2))          # TetMesh.hh:221-226
 EDGE_OF = {frozenset(p): 4 + e for e, p in enumerate(((0, 1), (1, 2), (2, 0), (0, 3), (2, 3), (1, 3)))}  # Simplex.hh:43-44
@@ -112,7 +117,9 @@ def distribute_mesh(vertices, elements, degree, rank, world):
 
 
 class HaloExchange:
-    """Point-to-point exchange lists. Every rank asks the owners for its halo nodes by key."""
+    """Point-to-point exchange lists. Every rank asks the owners for its halo nodes by key. `exchange` is the
+    torch.distributed transport of the host-logic tests; the HIP path hands the same lists to the library
+    (`lists()` -> mfh_dist_setup), which packs and exchanges on the device."""
 
     def __init__(self, lm: LocalMesh, rank, world, device, group=None):
         self.rank, self.world, self.group = rank, world, group
@@ -121,10 +128,13 @@ class HaloExchange:
         for q, (s, e) in lm.halo_ranges.items():
             requests[q] = lm.keys[s:e]
         gathered = [None] * world
-        dist.all_gather_object(gathered, requests, group=group)     # setup only (python objects)
+        if world > 1:
+            dist.all_gather_object(gathered, requests, group=group)     # setup only (python objects)
+        else:
+            gathered[0] = requests
         owned_keys = lm.keys[:lm.n_owned]
         sorter = np.argsort(owned_keys)
-        self.send_idx = {}
+        self.send_idx, self.send_idx_np = {}, {}
         for q in range(world):
             req = gathered[q][rank] if gathered[q] is not None else None
             if req is None or len(req) == 0:
@@ -133,9 +143,26 @@ class HaloExchange:
             idx = sorter[np.clip(pos, 0, len(sorter) - 1)]
             if not np.array_equal(owned_keys[idx], req):
                 raise RuntimeError("halo request for a node this rank does not own")
+            self.send_idx_np[q] = idx.astype(np.int64)
             self.send_idx[q] = torch.as_tensor(idx, dtype=torch.long, device=device)
         self.recv_range = dict(lm.halo_ranges)
         self.stage = _needs_staging(device, group)
+
+    def lists(self):
+        """(peers, sendPtr, sendNodes, recvPtr) in the layout of mfh_dist_setup: peers ascending; a peer may only send or
+        only receive; halo nodes are grouped by owner in ascending rank order (LocalMesh's numbering)."""
+        peers = sorted(set(self.send_idx_np) | set(self.recv_range))
+        send_ptr, recv_ptr, send_nodes = [0], [0], []
+        for q in peers:
+            idx = self.send_idx_np.get(q, np.zeros(0, np.int64))
+            send_nodes.append(idx)
+            send_ptr.append(send_ptr[-1] + len(idx))
+            s, e = self.recv_range.get(q, (0, 0))
+            if e > s and s - self.n_owned != recv_ptr[-1]:
+                raise RuntimeError("halo nodes are not grouped by owner in rank order")
+            recv_ptr.append(recv_ptr[-1] + (e - s))
+        nodes = np.concatenate(send_nodes) if send_nodes else np.zeros(0, np.int64)
+        return (np.asarray(peers, np.int32), np.asarray(send_ptr, np.int64), nodes.astype(np.int32), np.asarray(recv_ptr, np.int64))
 
     def exchange(self, v, dim):
         """v: flat tensor of n_local*dim; fills the halo part from the owners."""
@@ -163,63 +190,168 @@ class HaloExchange:
 
 
 # ------------------------------------------------------------------------------------------------
-# local operators
+# communicators of the library's distributed solve (include/meshfem_hip.h: mfh_comm)
 # ------------------------------------------------------------------------------------------------
-class HipLocalOps:
-    """The rank's block rows on its GPU, through the C ABI's device-pointer entry points."""
+class Comm:
+    """An mfh_comm. `rccl`: the library's own RCCL communicator (the production transport: device buffers go GPU to GPU
+    over xGMI, no Python in the loop); `callbacks`: the two collectives served by torch.distributed with buffers staged
+    through the host -- any backend, used by the tests that put two ranks on one GPU over gloo and as a fallback."""
 
-    def __init__(self, ctx, dim):
-        self.ctx, self.dim = ctx, dim
-        nr, nc, _ = ctx.matrix_info()
-        self.n_rows, self.n_cols = nr * dim, nc * dim
-        self.device = torch.device("cuda", torch.cuda.current_device())
-        # run the library's kernels on torch's current stream: ordered with torch ops and RCCL
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    def __init__(self, ctx, handle, kind, keep=()):
+        self.ctx, self.h, self.kind, self._keep = ctx, handle, kind, keep
 
-    def zeros(self, n):
-        return torch.zeros(n, dtype=torch.float64, device=self.device)
+    @classmethod
+    def rccl(cls, ctx, rank, world, group=None):
+        lib = ctx.lib
+        uid = ctypes.create_string_buffer(128)
+        if rank == 0:
+            st = lib.mfh_rccl_get_unique_id(uid)
+            if st != L.OK:
+                raise L.MeshFEMHipError(st, "mfh_rccl_get_unique_id failed (RCCL not found)")
+        box = [uid.raw if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        uid = ctypes.create_string_buffer(box[0], 128)
+        h = ctypes.c_void_p()
+        ctx._ck(lib.mfh_comm_create_rccl(ctx.h, uid, rank, world, ctypes.byref(h)))
+        return cls(ctx, h, "rccl")
 
-    def spmv(self, x_local, out):
-        self.ctx.dev_spmv(x_local.data_ptr(), out.data_ptr())
+    @classmethod
+    def callbacks(cls, ctx, rank, world, group=None):
+        lib = ctx.lib
 
-    def precond(self, r, out):
-        self.ctx.dev_precond(r.data_ptr(), out.data_ptr())
+        def d2h(ptr, n, stream):
+            buf = np.empty(n)
+            if n:
+                ctx.dev_memcpy(buf.ctypes.data, ptr, 8 * n, 1, stream)
+            return buf
 
-    def mask_fixed(self, v):
-        self.ctx.dev_mask_fixed(v.data_ptr())
+        def allreduce(user, dev, n, stream):
+            try:
+                t = torch.from_numpy(d2h(dev, n, stream))
+                dist.all_reduce(t, group=group)
+                ctx.dev_memcpy(dev, t.numpy().ctypes.data, 8 * n, 0, stream)
+                return 0
+            except Exception as e:   # noqa: BLE001 -- a Python exception must not cross the C boundary
+                print("mfh_comm allreduce callback failed: %r" % (e,), flush=True)
+                return L.ERR_HIP
 
-    def set_fixed_values(self, u):
-        self.ctx.dev_set_fixed_values(u.data_ptr())
+        def exchange(user, n_peers, peers, send_bufs, send_counts, recv_bufs, recv_counts, stream):
+            try:
+                ops, recvs, keep = [], [], []
+                for k in range(n_peers):
+                    if send_counts[k] > 0:
+                        t = torch.from_numpy(d2h(send_bufs[k], send_counts[k], stream))
+                        keep.append(t)
+                        ops.append(dist.P2POp(dist.isend, t, int(peers[k]), group=group))
+                    if recv_counts[k] > 0:
+                        t = torch.empty(recv_counts[k], dtype=torch.float64)
+                        recvs.append((recv_bufs[k], t))
+                        ops.append(dist.P2POp(dist.irecv, t, int(peers[k]), group=group))
+                if ops:
+                    for r in dist.batch_isend_irecv(ops):
+                        r.wait()
+                for ptr, t in recvs:
+                    ctx.dev_memcpy(ptr, t.numpy().ctypes.data, 8 * t.numel(), 0, stream)
+                return 0
+            except Exception as e:   # noqa: BLE001
+                print("mfh_comm exchange callback failed: %r" % (e,), flush=True)
+                return L.ERR_HIP
 
-    # fused vector updates; the scalars stay on the device (they come out of all-reduces)
-    def update_xr(self, num, den, p, Ap, x, r):
-        self.ctx.dev_pcg_update_xr(num.data_ptr(), den.data_ptr(), p.data_ptr(), Ap.data_ptr(), x.data_ptr(), r.data_ptr())
+        a, x = L.ALLREDUCE_FN(allreduce), L.EXCHANGE_FN(exchange)
+        h = ctypes.c_void_p()
+        st = lib.mfh_comm_create_callbacks(rank, world, None, ctypes.cast(a, ctypes.c_void_p), ctypes.cast(x, ctypes.c_void_p), ctypes.byref(h))
+        if st != L.OK:
+            raise L.MeshFEMHipError(st, "mfh_comm_create_callbacks failed")
+        return cls(ctx, h, "callbacks", keep=(a, x))
 
-    def direction(self, num, den, z, p):
-        self.ctx.dev_pcg_direction(num.data_ptr(), den.data_ptr(), z.data_ptr(), p.data_ptr())
+    def describe(self):
+        return self.ctx.lib.mfh_comm_describe(self.h).decode()
 
-    def dots(self, r, z, out):
-        self.ctx.dev_dots(r.data_ptr(), z.data_ptr(), out.data_ptr())
+    def selftest(self):
+        self.ctx._ck(self.ctx.lib.mfh_comm_selftest(self.ctx.h, self.h))
 
-    # two-level preconditioner building blocks (global aggregates; DistributedTwoLevel reduces over ranks)
-    def tl_begin(self, n_agg, agg_of_node, rel_pos):
-        m = n_agg * (6 if self.dim == 3 else 3)
-        Ac = torch.empty((m, m), dtype=torch.float64, device=self.device)
-        self.ctx.tl_partitioned_begin(n_agg, agg_of_node, rel_pos, Ac.data_ptr())
-        return Ac
+    def close(self):
+        if self.h:
+            self.ctx.lib.mfh_comm_destroy(self.h)
+            self.h = None
 
-    def tl_finish(self, Ac):
-        self.ctx.tl_partitioned_finish(Ac.data_ptr())
 
-    def tl_restrict(self, r, rc):
-        self.ctx.dev_tl_restrict(r.data_ptr(), rc.data_ptr())
+def make_comm(ctx, rank, world, group=None, prefer="auto"):
+    """RCCL when torch.distributed itself runs on nccl (one GPU per rank), callbacks over the process group otherwise
+    (gloo: several ranks on one GPU / no RCCL). Falls back to the callbacks if the RCCL communicator cannot be created."""
+    backend = dist.get_backend(group) if dist.is_initialized() else "none"
+    if prefer == "rccl" or (prefer == "auto" and (backend == "nccl" or world == 1)):
+        try:
+            return Comm.rccl(ctx, rank, world, group)
+        except L.MeshFEMHipError as e:
+            if prefer == "rccl":
+                raise
+            print("RCCL communicator unavailable (%s); using the torch.distributed callbacks" % e, flush=True)
+    return Comm.callbacks(ctx, rank, world, group)
 
-    def tl_apply(self, r, rc, z):
-        self.ctx.dev_tl_apply(r.data_ptr(), rc.data_ptr(), z.data_ptr())
+
+class DistSolver:
+    """The library's row-partitioned solve for one rank: exchange lists -> mfh_dist_setup, optional global two-level
+    preconditioner -> mfh_dist_two_level, solves -> mfh_dist_solve (Chronopoulos-Gear PCG, packed halo buffers, the
+    exchange overlapped with the interior element blocks, one fused all-reduce per iteration)."""
+
+    def __init__(self, ctx, lm, rank, world, comm, group=None):
+        self.ctx, self.lm, self.rank, self.world, self.comm, self.group = ctx, lm, rank, world, comm, group
+        self.halo = HaloExchange(lm, rank, world, torch.device("cpu"), group)
+        ctx.dist_setup(comm, *self.halo.lists())
+        self.two_level_info = None
+
+    def _allreduce_np(self, arr, op):
+        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.float64))
+        if self.world > 1:
+            if dist.get_backend(self.group) == "nccl":
+                g = t.cuda()
+                dist.all_reduce(g, op=op, group=self.group)
+                t = g.cpu()
+            else:
+                dist.all_reduce(t, op=op, group=self.group)
+        return t.numpy()
+
+    def two_level(self, target_aggregates):
+        """Global geometric bins over the global bounding box, rigid-body modes per bin."""
+        lm, dim = self.lm, self.ctx.dim
+        pos = np.asarray(lm.node_pos, dtype=np.float64)
+        lo = self._allreduce_np(pos.min(axis=0), dist.ReduceOp.MIN)
+        hi = self._allreduce_np(pos.max(axis=0), dist.ReduceOp.MAX)
+        agg, rel, nb, H = global_bins(pos, lo, hi, dim, target_aggregates)
+        t0 = time.perf_counter()
+        self.ctx.dist_two_level(int(np.prod(nb)), agg.astype(np.int32), rel)
+        self.two_level_info = dict(bins=[int(b) for b in nb], coarse_dim=int(np.prod(nb)) * (6 if dim == 3 else 3), setup_s=time.perf_counter() - t0)
+        return self.two_level_info
+
+    def solve(self, f_owned, rtol=1e-8, maxit=20000):
+        return self.ctx.dist_solve(f_owned, rtol, maxit)
+
+    def apply_K(self, u_owned):
+        return self.ctx.dist_apply_K(u_owned)
+
+
+def global_bins(pos, lo, hi, dim, target_aggregates):
+    """Uniform bins over [lo, hi]; returns (bin id per node, (position - bin centre) / H, bins per axis, H). Every rank
+    computes the same bin for a node from the same coordinates (halo copies carry the owner's coordinates bit for bit)."""
+    ext = np.maximum(hi - lo, 1e-300)
+    H = (np.prod(ext) / max(1, target_aggregates)) ** (1.0 / dim)
+    nb = np.maximum(1, np.rint(ext / H)).astype(np.int64)
+    hb = ext / nb
+    cell = np.minimum(np.floor((pos - lo) / hb).astype(np.int64), nb - 1)
+    cell = np.maximum(cell, 0)
+    agg = cell[:, 0]
+    for a in range(1, dim):
+        agg = agg * nb[a] + cell[:, a]
+    centre = lo + (cell + 0.5) * hb
+    rel = np.zeros((len(pos), 3))
+    rel[:, :dim] = (pos - centre) / H
+    return agg, rel, nb, H
 
 
 # ------------------------------------------------------------------------------------------------
-# distributed PCG (classic, two all-reduces per iteration)
+# the same algorithm in torch, for the host-logic tests (world-size-2 gloo on CPU; local operator supplied by the test)
 # ------------------------------------------------------------------------------------------------
 def _allreduce(vals, device, group, op=None):
     t = torch.stack(vals) if isinstance(vals, (list, tuple)) else vals
@@ -235,8 +367,8 @@ def _allreduce(vals, device, group, op=None):
 
 
 def extend_fixed_to_halo(halo, n_local, dim, owned_vars, owned_vals, device):
-    """Fixed variables are known to the owner of a node; the Galerkin coarse operator needs the mask
-    on halo columns too. Returns (vars, vals) over all local variables (owned + halo)."""
+    """Fixed variables are known to the owner of a node; the solve needs the mask (and the values) on halo columns too.
+    Returns (vars, vals) over all local variables (owned + halo)."""
     m = torch.zeros(n_local * dim, dtype=torch.float64, device=device)
     v = torch.zeros(n_local * dim, dtype=torch.float64, device=device)
     idx = torch.as_tensor(np.asarray(owned_vars, dtype=np.int64), device=device)
@@ -249,11 +381,8 @@ def extend_fixed_to_halo(halo, n_local, dim, owned_vars, owned_vals, device):
 
 
 class DistributedTwoLevel:
-    """M^-1 = D^-1 + Z (Z^T K Z)^-1 Z^T with GLOBAL aggregates: geometric bins over the global bounding
-    box, six rigid-body modes per bin (three in 2D). Every rank contributes the Galerkin product of its
-    own rows; one all-reduce of the (small, dense) coarse operator at setup, every rank inverts it
-    redundantly; per application one extra all-reduce of the restricted residual (6 * bins doubles).
-    The local kernels are `ops.tl_*` (HipLocalOps: the library's device kernels)."""
+    """M^-1 = D^-1 + Z (Z^T K Z)^-1 Z^T with GLOBAL aggregates, torch statement over an `ops` object (tl_begin / tl_finish /
+    tl_restrict / tl_apply): one all-reduce of the coarse operator at setup, one of the restricted residual per application."""
 
     def __init__(self, ops, halo, node_pos, n_owned, target_aggregates, group=None):
         self.ops, self.group = ops, group
@@ -262,28 +391,7 @@ class DistributedTwoLevel:
         pos = np.asarray(node_pos, dtype=np.float64)
         lo = _allreduce(torch.as_tensor(pos.min(axis=0), device=dev), dev, group, dist.ReduceOp.MIN).cpu().numpy()
         hi = _allreduce(torch.as_tensor(pos.max(axis=0), device=dev), dev, group, dist.ReduceOp.MAX).cpu().numpy()
-        ext = np.maximum(hi - lo, 1e-300)
-        H = (np.prod(ext) / max(1, target_aggregates)) ** (1.0 / dim)
-        nb = np.maximum(1, np.rint(ext / H)).astype(np.int64)
-        hb = ext / nb
-        cell = np.minimum(np.floor((pos - lo) / hb).astype(np.int64), nb - 1)
-        cell = np.maximum(cell, 0)
-        agg = cell[:, 0]
-        for a in range(1, dim):
-            agg = agg * nb[a] + cell[:, a]
-        # the owner's binning is authoritative (a node on a bin face must not depend on rounding)
-        t = torch.zeros(len(pos), dtype=torch.float64, device=dev)
-        t[:n_owned] = torch.as_tensor(agg[:n_owned].astype(np.float64), device=dev)
-        halo.exchange(t, 1)
-        agg = np.rint(t.cpu().numpy()).astype(np.int64)
-        cell = np.zeros((len(pos), dim), dtype=np.int64)
-        rem = agg.copy()
-        for a in range(dim - 1, -1, -1):
-            cell[:, a] = rem % nb[a]
-            rem //= nb[a]
-        centre = lo + (cell + 0.5) * hb
-        rel = np.zeros((len(pos), 3))
-        rel[:, :dim] = (pos - centre) / H
+        agg, rel, nb, H = global_bins(pos, lo, hi, dim, target_aggregates)
         self.n_agg = int(np.prod(nb))
         self.bins, self.H = nb, H
         t0 = time.perf_counter()
@@ -302,69 +410,55 @@ class DistributedTwoLevel:
 
 
 def distributed_pcg(ops, halo, f_owned, rtol=1e-8, maxit=20000, group=None, check_every=25, precond=None):
-    """Solve K u = f on the free variables; f_owned: this rank's dim*nOwned right-hand side.
-    Returns (u_owned, info). All vectors are torch tensors on ops' device."""
+    """The library's PCG (mfh_solver.cpp: Chronopoulos-Gear, ONE fused all-reduce of {(r,u), (w,u), (r,r)} per iteration)
+    stated in torch over an `ops` object with spmv / precond / mask_fixed / set_fixed_values. Solves K u = f on the free
+    variables; f_owned: this rank's dim*nOwned right-hand side. Returns (u_owned, info)."""
     dim = ops.dim
     nr, nc = ops.n_rows, ops.n_cols
     dev = f_owned.device
     precond = ops.precond if precond is None else precond
+
+    def apply(v_owned, out):                       # out = P K v with the halo of v fetched from the owners
+        full[:nr] = v_owned
+        halo.exchange(full, dim)
+        ops.spmv(full, out)
+        ops.mask_fixed(out)
+
+    full = ops.zeros(nc)
     # b = P (f - K ubar): ubar = fixed values on every rank's owned nodes, halo part by exchange
-    u0 = ops.zeros(nc)
-    ops.set_fixed_values(u0)
-    halo.exchange(u0, dim)
+    ops.set_fixed_values(full)
+    halo.exchange(full, dim)
     Ku0 = ops.zeros(nr)
-    ops.spmv(u0, Ku0)
-    b = f_owned - Ku0
-    ops.mask_fixed(b)
-    x = ops.zeros(nr)
-    r = b.clone()
-    z = ops.zeros(nr)
-    precond(r, z)
-    p = ops.zeros(nc)
-    p[:nr] = z
-    Ap = ops.zeros(nr)
-    # local kernels: the ops' fused ones (HipLocalOps) or plain torch (the CPU tests' operator)
-    def dots(rv, zv):
-        out = torch.empty(2, dtype=torch.float64, device=dev)
-        if hasattr(ops, "dots"):
-            ops.dots(rv, zv, out)
-        else:
-            out[0], out[1] = torch.dot(rv, zv), torch.dot(rv, rv)
-        return out
-
-    def update_xr(num, den):
-        if hasattr(ops, "update_xr"):
-            ops.update_xr(num, den, p, Ap, x, r)
-        else:
-            a = num / den
-            x.add_(p[:nr] * a)
-            r.sub_(Ap * a)
-
-    def direction(num, den):
-        if hasattr(ops, "direction"):
-            ops.direction(num, den, z, p)
-        else:
-            p[:nr].mul_(num / den).add_(z)
-
-    red = _allreduce(dots(r, z), dev, group)
-    rz, bb = red[0:1], red[1].item()
+    ops.spmv(full, Ku0)
+    r = f_owned - Ku0
+    ops.mask_fixed(r)
+    x, p, s, u, w = ops.zeros(nr), ops.zeros(nr), ops.zeros(nr), ops.zeros(nr), ops.zeros(nr)
+    precond(r, u)
+    apply(u, w)
+    red = _allreduce(torch.stack([torch.dot(r, u), torch.dot(w, u), torch.dot(r, r)]), dev, group)
+    bb = red[2].item()
     stop = rtol * rtol * bb
     info = dict(iterations=0, converged=bb == 0.0, rel_residual=0.0)
-    it = 0
-    rr = bb
+    it, rr = 0, bb
+    gamma_old = alpha_old = None
     t0 = time.perf_counter()
     hist = []
     while it < maxit and not info["converged"]:
-        halo.exchange(p, dim)
-        ops.spmv(p, Ap)
-        ops.mask_fixed(Ap)
-        pAp = _allreduce(torch.dot(p[:nr], Ap).reshape(1), dev, group)
-        update_xr(rz, pAp)                                   # x += (rz/pAp) p ; r -= (rz/pAp) Ap
-        precond(r, z)
-        red = _allreduce(dots(r, z), dev, group)
-        direction(red[0:1], rz)                              # p = z + (rz_new/rz) p
-        rz = red[0:1]
-        hist.append(red[1])
+        gamma, delta = red[0], red[1]
+        if it == 0:
+            beta, alpha = torch.zeros_like(gamma), gamma / delta
+        else:
+            beta = gamma / gamma_old
+            alpha = gamma / (delta - beta * gamma / alpha_old)
+        p.mul_(beta).add_(u)                                 # p = u + beta p
+        s.mul_(beta).add_(w)                                 # s = w + beta s  (= K p)
+        x.add_(p * alpha)
+        r.sub_(s * alpha)
+        precond(r, u)
+        apply(u, w)
+        gamma_old, alpha_old = gamma, alpha
+        red = _allreduce(torch.stack([torch.dot(r, u), torch.dot(w, u), torch.dot(r, r)]), dev, group)   # the ONE reduction
+        hist.append(red[2])
         it += 1
         if it % check_every == 0 or it == maxit:
             h = torch.stack(hist).cpu().numpy()        # one host sync per check_every iterations
@@ -382,9 +476,8 @@ def distributed_pcg(ops, halo, f_owned, rtol=1e-8, maxit=20000, group=None, chec
     info["solve_s"] = time.perf_counter() - t0
     info["loop_iterations"] = it
     info["rel_residual"] = float(np.sqrt(rr / bb)) if bb > 0 else 0.0
-    u = x.clone()
     full = ops.zeros(nc)
-    full[:nr] = u
+    full[:nr] = x
     ops.set_fixed_values(full)
     return full[:nr].clone(), info
 
@@ -438,57 +531,56 @@ def slab_traction_load(lm, n, traction):
     return load
 
 
-def _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out):
-        ops = HipLocalOps(c, 3)
-        halo = HaloExchange(lm, rank, world, dev)
-        # u = 0 on x = 0: the mask covers the halo nodes too (needed by the Galerkin coarse operator)
-        fixed_nodes = np.flatnonzero(lm.lattice[:, 0] == 0)
-        c.fix_variables((3 * fixed_nodes[:, None] + np.arange(3)[None, :]).ravel())
-        f = torch.as_tensor(slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel(), device=dev)
-        n_coarse = getattr(args, "coarse_aggregates", 0)
-        if n_coarse == 0:
-            n_coarse = min(1000 * world, 2048)
-        pre, pre_desc, tl_info = None, "3x3 block-Jacobi", None
-        maxit = args.maxit
-        if n_coarse > 0:
-            pre = DistributedTwoLevel(ops, halo, lm.node_pos, lm.n_owned, n_coarse)
-            pre_desc = "two-level: 3x3 block-Jacobi + rigid-body modes of %d global bins" % pre.n_agg
-            tl_info = dict(bins=[int(b) for b in pre.bins], coarse_dim=int(pre.m), setup_s=pre.setup_s)
-        elif world > 1:
-            # the bar gets longer with N (weak scaling), so block-Jacobi alone needs O(N) more iterations:
-            # measure the per-iteration rate on a bounded number of iterations
-            maxit = min(args.maxit, 3000)
-        dist.barrier()
-        u, info = distributed_pcg(ops, halo, f, rtol=args.rtol, maxit=maxit, precond=pre)
-        nd = torch.tensor([3.0 * lm.n_owned], dtype=torch.float64, device=dev)
-        dist.all_reduce(nd)
-        ts = torch.tensor([info["solve_s"]], dtype=torch.float64, device=dev)
-        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-        # true residual of the returned displacement, over all ranks
-        full = ops.zeros(ops.n_cols)
-        full[:ops.n_rows] = u
-        halo.exchange(full, 3)
-        Ku = ops.zeros(ops.n_rows)
-        ops.spmv(full, Ku)
-        res = f - Ku
-        ops.mask_fixed(res)
-        fm = f.clone()
-        ops.mask_fixed(fm)
-        nrm = torch.stack([torch.dot(res, res), torch.dot(fm, fm), u.abs().max()])
-        dist.all_reduce(nrm[:2])
-        dist.all_reduce(nrm[2:], op=dist.ReduceOp.MAX)
-        out["pcg"] = dict(iterations=info["iterations"], converged=bool(info["converged"]), rtol=args.rtol,
-                          rel_residual=info["rel_residual"], true_rel_residual=float(torch.sqrt(nrm[0] / nrm[1]).item()),
-                          max_abs_u=float(nrm[2].item()), dof=int(nd.item()), solve_s=ts.item(),
-                          dof_per_s=nd.item() * info["loop_iterations"] / ts.item(),
-                          ms_per_iteration=ts.item() / max(1, info["loop_iterations"]) * 1e3,
-                          maxit=maxit, preconditioner=pre_desc, two_level=tl_info,
-                          operator="matrix-free (k_mf_cluster + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
-                          comm="halo P2P + %d all-reduce / iteration (torch.distributed nccl=RCCL)" % (3 if pre else 2))
+def _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out, group=None):
+    comm = make_comm(c, rank, world, group)
+    comm.selftest()                                    # ring shift + all-reduce with known answers over the actual transport
+    solver = DistSolver(c, lm, rank, world, comm, group)
+    # u = 0 on x = 0: the mask covers the halo nodes too (needed by the Galerkin coarse operator)
+    fixed_nodes = np.flatnonzero(lm.lattice[:, 0] == 0)
+    c.fix_variables((3 * fixed_nodes[:, None] + np.arange(3)[None, :]).ravel())
+    f = slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel()
+    n_coarse = getattr(args, "coarse_aggregates", 0)
+    if n_coarse == 0:
+        n_coarse = min(1000 * world, 2048)
+    pre_desc, tl_info = "3x3 block-Jacobi", None
+    maxit = args.maxit
+    if n_coarse > 0:
+        tl_info = solver.two_level(n_coarse)
+        pre_desc = "two-level: 3x3 block-Jacobi + rigid-body modes of %d global bins" % int(np.prod(tl_info["bins"]))
+    elif world > 1:
+        # the bar gets longer with N (weak scaling), so block-Jacobi alone needs O(N) more iterations:
+        # measure the per-iteration rate on a bounded number of iterations
+        maxit = min(args.maxit, 3000)
+    if world > 1:
+        dist.barrier(group=group)
+    try:
+        u, infos = solver.solve(f, rtol=args.rtol, maxit=maxit)
+        info = infos[0]
+    except L.MeshFEMHipError as e:
+        if e.code != L.ERR_NOT_CONVERGED:
+            raise
+        u, info = None, c.last_info
+    red = lambda v, op: solver._allreduce_np(np.asarray(v, dtype=np.float64), op)   # noqa: E731
+    nd = red([3.0 * lm.n_owned], dist.ReduceOp.SUM)[0]
+    ts = red([info["solve_ms"] * 1e-3], dist.ReduceOp.MAX)[0]
+    umax = red([np.abs(u).max() if u is not None else 0.0], dist.ReduceOp.MAX)[0]
+    out["pcg"] = dict(iterations=info["iterations"], converged=bool(info["converged"]), rtol=args.rtol,
+                      rel_residual=info["rel_residual"], true_rel_residual=info["true_rel_residual"],
+                      max_abs_u=float(umax), dof=int(nd), solve_s=float(ts),
+                      dof_per_s=float(nd) * info["iterations"] / max(ts, 1e-30),
+                      ms_per_iteration=float(ts) / max(1, info["iterations"]) * 1e3,
+                      maxit=maxit, preconditioner=pre_desc, two_level=tl_info,
+                      operator="matrix-free (k_mf_cluster + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
+                      algorithm="Chronopoulos-Gear PCG in the library (mfh_dist_solve): packed halo exchange overlapped with the interior "
+                                "element blocks + %d all-reduce / iteration" % (2 if tl_info else 1),
+                      transport=comm.describe(), ranks=world)
+    comm.close()
 
 
-def bench_slabs(args, rank, world, local_rank):
-    """bench.py --gpus N>1: weak scaling over z-slabs; returns the JSON dict on every rank."""
+def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
+    """bench.py --gpus N>1: weak scaling over z-slabs; returns the JSON dict on every rank. shared_gpus: fewer devices than
+    ranks (forced-distributed run on a 1-GPU box): same code, gloo process group, communicator callbacks staged through
+    the host -- a functional check of the N-rank path, not a scaling measurement."""
     import meshfem_amd as M
     dev = torch.device("cuda", local_rank)
     deg = args.deg
@@ -506,6 +598,12 @@ def bench_slabs(args, rank, world, local_rank):
     c.set_option("reembed", 1)
     # elements are counted once globally: a rank "owns" the elements of its own hex layers
     n_elem_global = 24 * n * n * layers * world
+
+    def max_over_ranks(v):
+        t = torch.tensor([v], dtype=torch.float64, device="cpu" if shared_gpus else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t.item()
+
     for _ in range(args.warmup):
         c.assemble()
     c.dev_sync(); torch.cuda.synchronize(); dist.barrier()
@@ -513,21 +611,39 @@ def bench_slabs(args, rank, world, local_rank):
     for _ in range(args.steps):
         c.assemble()
     c.dev_sync(); torch.cuda.synchronize(); dist.barrier()
-    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
-    dt = dt.item()
+    dt = max_over_ranks(time.perf_counter() - t0)
     k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
     alg = 7736 if deg == 2 else 1328
+    nE_loc = int(len(lm.elem_nodes))
+    nr, nc, nnzb = c.matrix_info()
+    sizes = c.symbolic_sizes()
+    comp = int(nnzb * 72 + nE_loc * 128 + sizes["n_contrib"] * 6 + sizes["n_chunk"] * 12 + nr * 4)
+    k_ms_max = max_over_ranks(k_ms)
+    rccl_ranks = None
+    if not shared_gpus:
+        # proof that the collective library saw every rank: an all-reduce of ones over the process group
+        one = torch.ones(1, dtype=torch.float64, device=dev)
+        dist.all_reduce(one)
+        rccl_ranks = int(one.item())
     out = dict(metric="stiffness_assembly_elements_per_s", value=n_elem_global * args.steps / dt, unit="elements/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
                config=dict(workload="%d x %d x %d grid -> %d P%d tets, z-slabs of %d hex layers per GPU (configs[4] shape: 120^3 at 8 GPUs)"
                                     % (n, n, layers * world, n_elem_global, deg, layers), elements=n_elem_global,
-                           local_elements=int(len(lm.elem_nodes)), local_nodes=int(lm.n_local), owned_nodes=int(lm.n_owned),
-                           parallelism="row/element partition x%d, owner computes" % world),
-               roofline=dict(bound="hbm", kernel="k_assemble_gather", achieved=alg * len(lm.elem_nodes) / k_ms / 1e6, peak=8000.0,
-                             unit="GB/s", frac=alg * len(lm.elem_nodes) / k_ms / 1e6 / 8000.0, traffic=None, kernel_ms=k_ms,
-                             note="rank 0's local launch (its elements incl. the halo layer)"),
+                           local_elements=nE_loc, local_nodes=int(lm.n_local), owned_nodes=int(lm.n_owned),
+                           parallelism="row/element partition x%d, owner computes (no assembly communication)" % world),
+               devices=dict(visible=torch.cuda.device_count(), ranks=world, shared=bool(shared_gpus),
+                            process_group=dist.get_backend(), process_group_ranks_seen=rccl_ranks,
+                            rccl_version=".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+                            note=("forced-distributed run: %d ranks share %d GPU(s); functional check of the N-rank path, not a scaling "
+                                  "measurement" % (world, torch.cuda.device_count())) if shared_gpus else "one rank per GPU"),
+               roofline=dict(bound="hbm", kernel="k_assemble_gather", achieved=alg * nE_loc / k_ms / 1e6, peak=8000.0,
+                             unit="GB/s", frac=alg * nE_loc / k_ms / 1e6 / 8000.0, kernel_ms=k_ms, kernel_ms_max_over_ranks=k_ms_max,
+                             compulsory_bytes=comp, frac_compulsory=comp / k_ms / 1e6 / 8000.0,
+                             traffic=None, traffic_note="PMC counters are collected per shape in their own rocprofv3 passes (profiles/); "
+                                                        "none is committed for this slab shape: see frac_compulsory",
+                             note="rank 0's local launch (its elements incl. the halo layer); frac = SURVEY 8(d) algorithmic bytes (contract), "
+                                  "frac_compulsory = bytes the design must move (K once + records + lists)"),
                setup=dict(local_mesh_s=t_mesh, symbolic_s=t_sym))
     if not args.no_solve:
         # The assembly figures above are the headline metric; a failure of the solver leg (it is the only part that

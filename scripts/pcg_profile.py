@@ -1,0 +1,34 @@
+"""Short PCG runs for rocprofv3 --kernel-trace --stats (fixed iteration counts, not to convergence).
+    python scripts/pcg_profile.py [grid] [variant] [nrhs] [iters]"""
+import sys
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import meshfem_amd as M
+from meshfem_amd import grid
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+variant = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+nrhs = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+iters = int(sys.argv[4]) if len(sys.argv) > 4 else 200
+pre = int(sys.argv[5]) if len(sys.argv) > 5 else 0
+V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+c = M.Context(0)
+c.mesh_build(T, V, 2)
+c.material_isotropic(200.0, 0.35)
+c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+c.assemble()
+f = c.neumann_load().ravel()
+vars_, vals = c.bc_dirichlet_vars()
+c.fix_variables(vars_, vals)
+c.set_preconditioner(pre)
+c.set_option("pcg_variant", variant)
+c.set_option("check_every", 50)
+F = np.stack([f * (1 + k) for k in range(nrhs)])
+try:
+    c.solve_batch(F, rtol=1e-30, maxit=iters)
+except M.MeshFEMHipError as e:
+    print("expected:", e)
+print(c.last_info)

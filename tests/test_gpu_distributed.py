@@ -1,7 +1,9 @@
-"""Two ranks sharing ONE MI355X (gloo rendezvous, buffers staged through the host): the row-partitioned HIP
-path -- local assembly of owned rows, halo exchange, distributed PCG with block-Jacobi and with the
-two-level preconditioner on global aggregates -- against the single-context solve of the same problem.
-The 8-GPU box runs the same code with backend nccl (= RCCL); this test covers everything but the transport."""
+"""Two ranks sharing ONE MI355X (gloo rendezvous; the communicator's two collectives are callbacks that stage through the
+host): the row-partitioned HIP path inside the library -- local assembly of owned rows, mfh_dist_setup, mfh_dist_solve
+(Chronopoulos-Gear PCG, packed halo buffers, exchange overlapped with the interior element blocks, one fused
+all-reduce per iteration) with block-Jacobi and with the two-level preconditioner on global aggregates -- against the
+single-context solve of the same problem. The 8-GPU box runs the same code over the library's RCCL communicator; that
+transport is covered at world size 1 (self send/receive + all-reduce) by test_rccl_communicator_world_1."""
 import os
 import socket
 
@@ -35,20 +37,36 @@ def _worker(rank, world, port, n, ret):
         c.mesh_set(3, 2, lm.elem_nodes, lm.node_pos, lm.n_owned)
         c.material_isotropic(200.0, 0.35)
         c.assemble()
-        ops = D.HipLocalOps(c, 3)
-        halo = D.HaloExchange(lm, rank, world, dev)
+        comm = D.make_comm(c, rank, world)            # gloo process group -> callbacks staged through the host
+        assert comm.kind == "callbacks"
+        comm.selftest()
+        solver = D.DistSolver(c, lm, rank, world, comm)
+        halo = D.HaloExchange(lm, rank, world, torch.device("cpu"))
         owned_fixed = np.flatnonzero(lm.lattice[:lm.n_owned, 0] == 0)
         ov = (3 * owned_fixed[:, None] + np.arange(3)[None, :]).ravel()
-        ev, evals = D.extend_fixed_to_halo(halo, lm.n_local, 3, ov, None, dev)
+        ev, evals = D.extend_fixed_to_halo(halo, lm.n_local, 3, ov, None, torch.device("cpu"))
         all_fixed = np.flatnonzero(lm.lattice[:, 0] == 0)
         assert np.array_equal(ev, (3 * all_fixed[:, None] + np.arange(3)[None, :]).ravel())
         c.fix_variables(ev, evals)
-        f = torch.as_tensor(D.slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel(), device=dev)
-        u1, i1 = D.distributed_pcg(ops, halo, f, rtol=1e-10, maxit=20000)
-        pre = D.DistributedTwoLevel(ops, halo, lm.node_pos, lm.n_owned, 16 * world)
-        u2, i2 = D.distributed_pcg(ops, halo, f, rtol=1e-10, maxit=20000, precond=pre)
-        ret[rank] = dict(keys=lm.keys[:lm.n_owned].copy(), u_bj=u1.cpu().numpy().reshape(-1, 3), u_tl=u2.cpu().numpy().reshape(-1, 3),
-                         it_bj=i1["iterations"], it_tl=i2["iterations"], conv=(i1["converged"], i2["converged"]), n_agg=pre.n_agg)
+        f = D.slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel()
+        u1, i1 = solver.solve(f, rtol=1e-10, maxit=20000)
+        # the operator alone: K applied to the solution reproduces the load on the free owned variables
+        Ku = solver.apply_K(u1[0])
+        free = np.ones(3 * lm.n_owned, bool); free[ov] = False
+        assert np.linalg.norm((Ku - f)[free]) <= 1e-8 * np.linalg.norm(f)
+        tl = solver.two_level(16 * world)
+        u2, i2 = solver.solve(f, rtol=1e-10, maxit=20000)
+        # three right-hand sides at once (batch of 2 + 1): scaled copies of the load
+        F3 = np.stack([f, -2.0 * f, 0.5 * f])
+        c.set_option("batch_rhs", 1)
+        u3, i3 = solver.solve(F3, rtol=1e-10, maxit=20000)
+        assert [i["reserved"] for i in i3] == [2, 2, 1]
+        for k, sc in enumerate((1.0, -2.0, 0.5)):
+            assert np.linalg.norm(u3[k] - sc * u2[0]) <= 1e-7 * np.linalg.norm(u2[0])
+        ret[rank] = dict(keys=lm.keys[:lm.n_owned].copy(), u_bj=u1[0].reshape(-1, 3), u_tl=u2[0].reshape(-1, 3),
+                         it_bj=i1[0]["iterations"], it_tl=i2[0]["iterations"], conv=(i1[0]["converged"], i2[0]["converged"]),
+                         n_agg=int(np.prod(tl["bins"])))
+        comm.close()
         c.close()
     finally:
         dist.destroy_process_group()
@@ -109,18 +127,20 @@ def _worker_general(rank, world, port, ret):
         c.mesh_set(3, 2, lm.elem_nodes, lm.node_pos, lm.n_owned)
         c.material_isotropic(200.0, 0.35)
         c.assemble()
-        ops = D.HipLocalOps(c, 3)
-        halo = D.HaloExchange(lm, rank, world, dev)
+        comm = D.make_comm(c, rank, world)
+        solver = D.DistSolver(c, lm, rank, world, comm)
         gfixed = np.zeros(3 * lm.n_global, bool)
         gfixed[g["ball_p2_fixed_vars"]] = True                      # Dirichlet variables of the committed golden problem
         lvars = np.flatnonzero(gfixed[(3 * lm.keys[:, None] + np.arange(3)).ravel()])
         c.fix_variables(lvars)
-        f = torch.as_tensor(g["ball_p2_load"][lm.keys[:lm.n_owned]].ravel().copy(), device=dev)
-        pre = D.DistributedTwoLevel(ops, halo, lm.node_pos, lm.n_owned, 8)
-        u, info = D.distributed_pcg(ops, halo, f, rtol=1e-11, maxit=20000, precond=pre)
+        f = g["ball_p2_load"][lm.keys[:lm.n_owned]].ravel().copy()
+        solver.two_level(8)
+        u, infos = solver.solve(f, rtol=1e-11, maxit=20000)
+        info = infos[0]
         u_ref = g["ball_p2_u"]
-        err = np.linalg.norm(u.cpu().numpy().reshape(-1, 3) - u_ref[lm.keys[:lm.n_owned]]) / np.linalg.norm(u_ref)
+        err = np.linalg.norm(u[0].reshape(-1, 3) - u_ref[lm.keys[:lm.n_owned]]) / np.linalg.norm(u_ref)
         ret[rank] = (err, bool(info["converged"]), lm.n_owned, info["iterations"])
+        comm.close()
         c.close()
     finally:
         dist.destroy_process_group()
@@ -140,3 +160,40 @@ def test_two_ranks_rcb_unstructured_mesh_matches_golden():
     assert max(ret[r][0] for r in range(world)) < 1e-6, dict(ret)          # north-star tolerance on displacements
     assert ret[0][2] + ret[1][2] == len(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "example_meshes.npz"))["ball_p2_u"])   # every P2 node owned once
     assert ret[0][3] == ret[1][3]
+
+
+def test_rccl_communicator_world_1():
+    """The library's RCCL communicator (looked up with dlopen) on this GPU: unique id, ncclCommInitRank, grouped
+    ncclSend / ncclRecv to itself and ncclAllReduce with known answers (mfh_comm_selftest), then the distributed entry
+    points with that communicator at world size 1 against the single-context solve."""
+    import meshfem_amd as M
+    from meshfem_amd import distributed as D, grid
+    n = 5
+    lm = D.slab_local_mesh(n, 0, 1, 2)
+    c = M.Context(0)
+    c.mesh_set(3, 2, lm.elem_nodes, lm.node_pos, lm.n_owned)
+    c.material_isotropic(200.0, 0.35)
+    c.assemble()
+    comm = D.Comm.rccl(c, 0, 1)
+    assert "RCCL" in comm.describe()
+    comm.selftest()
+    solver = D.DistSolver(c, lm, 0, 1, comm)
+    fixed = np.flatnonzero(lm.lattice[:, 0] == 0)
+    c.fix_variables((3 * fixed[:, None] + np.arange(3)[None, :]).ravel())
+    f = D.slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel()
+    u, infos = solver.solve(f, rtol=1e-10)
+    assert infos[0]["converged"] and infos[0]["true_rel_residual"] < 1e-9
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    sim = M.Simulator(T, V, 2)
+    sim.setIsotropicMaterial(200.0, 0.35)
+    sim.ctx.bc_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9], [0, 0, 0])
+    sim.ctx.bc_neumann_box([1 - 1e-9, -9, -9], [1 + 1e-9, 9, 9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    sim.rtol = 1e-10
+    u_ref = sim.solve()
+    lat = np.rint(sim.nodes() * 4 * n).astype(np.int64)
+    keys = (lat[:, 0] * (4 * n + 1) + lat[:, 1]) * (4 * n + 1) + lat[:, 2]
+    order = np.argsort(keys)
+    idx = order[np.searchsorted(keys[order], lm.keys[:lm.n_owned])]
+    assert np.linalg.norm(u[0].reshape(-1, 3) - u_ref[idx]) / np.linalg.norm(u_ref) < 1e-7
+    comm.close()
+    c.close()

@@ -251,8 +251,8 @@ def test_partitioned_rows_match_global_matrix():
 
 
 def test_distributed_driver_single_rank_on_gpu():
-    """The multi-GPU driver (HipLocalOps + torch tensors + adopted stream) with world size 1 must
-    reproduce the library's own PCG and the oracle's direct solve."""
+    """The multi-GPU entry points (mfh_dist_setup / mfh_dist_solve with a callback communicator) at world size 1 must
+    reproduce the library's own PCG (both variants) and the oracle's direct solve."""
     import os
     import torch
     import torch.distributed as dist
@@ -272,13 +272,17 @@ def test_distributed_driver_single_rank_on_gpu():
         fixed_nodes = np.flatnonzero(lm.lattice[:lm.n_owned, 0] == 0)
         c.fix_variables((3 * fixed_nodes[:, None] + np.arange(3)[None, :]).ravel())
         load = D.slab_traction_load(lm, n, [0.0, -1.0, 0.0])
-        ops = D.HipLocalOps(c, 3)
-        halo = D.HaloExchange(lm, 0, 1, dev)
-        u, info = D.distributed_pcg(ops, halo, torch.as_tensor(load.ravel(), device=dev), rtol=1e-10, maxit=5000)
-        assert info["converged"]
-        u = u.cpu().numpy().reshape(-1, 3)
+        comm = D.Comm.callbacks(c, 0, 1)
+        solver = D.DistSolver(c, lm, 0, 1, comm)
+        u, infos = solver.solve(load.ravel(), rtol=1e-10, maxit=5000)
+        assert infos[0]["converged"]
+        u = u[0].reshape(-1, 3)
         u_lib = c.solve(load.ravel(), rtol=1e-10).reshape(-1, 3)
         assert np.linalg.norm(u - u_lib) / np.linalg.norm(u_lib) < 1e-7
+        c.set_option("pcg_variant", 0)                      # the classic two-reduction PCG
+        u_classic = c.solve(load.ravel(), rtol=1e-10).reshape(-1, 3)
+        c.set_option("pcg_variant", 1)
+        assert np.linalg.norm(u_classic - u_lib) / np.linalg.norm(u_lib) < 1e-7
         # oracle direct solve on the same mesh (node numbering differs: compare through positions)
         V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
         sim = O.Simulator(T, V, 2)

@@ -1,0 +1,116 @@
+"""The library's PCG (mfh_solver.cpp): Chronopoulos-Gear form against the classic two-reduction PCG and the oracle's direct
+solve, batched right-hand sides against one-at-a-time solves, for both batched operators (cluster matrix-free operator for
+quadratic elements, assembled block-CSR SpMV for linear ones), with and without the two-level preconditioner."""
+import numpy as np
+import pytest
+
+import meshfem_amd as M
+from meshfem_amd import grid
+from oracle import meshfem_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(dim, deg, n=5):
+    if dim == 3:
+        V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    else:
+        V, Q = O.gen_grid_2d(4 * n, 4 * n)
+        V, T = O.quad_tri_subdiv(V, Q)
+        V = V[:, :2] / (4 * n)
+    c = M.Context(0)
+    c.mesh_build(T, V, deg)
+    c.material_isotropic(200.0, 0.35)
+    lo, hi = [-9.0] * dim, [9.0] * dim
+    lo[0], hi[0] = -1e-9, 1e-9
+    c.bc_dirichlet_box(lo, hi, [0.0] * dim)
+    c.assemble()
+    vars_, vals = c.bc_dirichlet_vars()
+    c.fix_variables(vars_, vals)
+    return c, V, T
+
+
+@pytest.mark.parametrize("dim,deg", [(3, 2), (3, 1), (2, 2), (2, 1)])
+@pytest.mark.parametrize("precond", [M.PRECOND_BLOCK_JACOBI, M.PRECOND_TWO_LEVEL])
+def test_cg_variant_matches_classic_pcg_and_true_residual(dim, deg, precond):
+    c, V, T = _problem(dim, deg)
+    c.set_preconditioner(precond)
+    rng = np.random.default_rng(3)
+    f = rng.standard_normal(dim * c.n_dof)
+    c.set_option("pcg_variant", 0)
+    u0 = c.solve(f, rtol=1e-11)
+    it0 = c.last_info["iterations"]
+    c.set_option("pcg_variant", 1)
+    u1 = c.solve(f, rtol=1e-11)
+    i1 = c.last_info
+    assert i1["converged"] and i1["true_rel_residual"] < 5e-11
+    assert np.linalg.norm(u1 - u0) <= 1e-8 * np.linalg.norm(u0)
+    # same Krylov method in exact arithmetic: the iteration counts agree up to rounding effects
+    assert abs(i1["iterations"] - it0) <= max(3, 0.05 * it0), (i1["iterations"], it0)
+    # without the graph replay (plain launches) nothing changes
+    c.set_option("pcg_graph", 0)
+    u2 = c.solve(f, rtol=1e-11)
+    assert c.last_info["used_graph"] == 0 and np.linalg.norm(u2 - u1) <= 1e-9 * np.linalg.norm(u1)
+    c.close()
+
+
+@pytest.mark.parametrize("dim,deg,nrhs", [(3, 2, 6), (3, 2, 3), (3, 1, 6), (2, 2, 3), (2, 1, 4)])
+@pytest.mark.parametrize("precond", [M.PRECOND_BLOCK_JACOBI, M.PRECOND_TWO_LEVEL])
+def test_batched_right_hand_sides_equal_sequential_solves(dim, deg, nrhs, precond):
+    """parity of the batched path against the sequential one <= 1e-12 (here: both to rtol 1e-13, so
+    they agree to the solver tolerance times the condition of the comparison), batches 6 / 2+1 / 3 / 3+1."""
+    c, V, T = _problem(dim, deg, n=4)
+    c.set_preconditioner(precond)
+    rng = np.random.default_rng(11)
+    n = dim * c.n_dof
+    F = rng.standard_normal((nrhs, n))
+    c.set_option("batch_rhs", 1)
+    F[1] *= 1e3                                   # very different scales: per-vector stopping, per-vector scalars
+    if nrhs > 2:
+        F[2] = 0.0                                # a zero right-hand side inside a batch
+    U, infos = c.solve_batch(F, rtol=1e-13)
+    sizes = [i["reserved"] for i in infos]
+    want = {(3, 6): [6] * 6, (3, 3): [2, 2, 1], (2, 3): [3] * 3, (2, 4): [3, 3, 3, 1]}[(dim, nrhs)]
+    assert sizes == want
+    c.set_option("batch_rhs", 0)
+    for k in range(nrhs):
+        uk = c.solve(F[k], rtol=1e-13)
+        assert c.last_info["reserved"] == 1
+        ref = np.linalg.norm(uk)
+        assert np.linalg.norm(U[k] - uk) <= 1e-10 * max(ref, 1e-300), (k, np.linalg.norm(U[k] - uk), ref)
+        if ref > 0:
+            # iteration counts of a vector do not depend on its batch mates
+            assert abs(infos[k]["iterations"] - c.last_info["iterations"]) <= max(3, 0.05 * c.last_info["iterations"])
+        else:
+            assert np.all(U[k] == 0.0) and infos[k]["iterations"] == 0
+    c.close()
+
+
+def test_batched_solve_against_the_oracle_direct_solve():
+    """Six load cases on the cantilever-like cube against the oracle's sparse LU (SuperLU stand-in for CHOLMOD), north-star
+    tolerance 1e-6 rel-L2 on the displacements (measured ~1e-9 at rtol 1e-10)."""
+    n = 3
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    sim = O.Simulator(T, V, 2)
+    sim.set_material_constant(O.ElasticityTensor.isotropic(3, 200.0, 0.35))
+    sim.apply_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9], [0, 0, 0])
+    K = sim.assembleStiffnessMatrix()
+    c = M.Context(0)
+    c.mesh_build(T, V, 2)
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9], [0, 0, 0])
+    c.assemble()
+    vars_, vals = c.bc_dirichlet_vars()
+    c.fix_variables(vars_, vals)
+    rng = np.random.default_rng(5)
+    F = rng.standard_normal((6, 3 * c.n_dof))
+    c.set_option("batch_rhs", 1)
+    U, infos = c.solve_batch(F, rtol=1e-10)
+    assert [i["reserved"] for i in infos] == [6] * 6
+    fv, fx = sim.dirichlet_vars_and_values()
+    for k in range(6):
+        sys = O.SPSDSystem(K)
+        sys.fix_variables(fv, fx)
+        u_ref = sys.solve(F[k])
+        assert np.linalg.norm(U[k] - u_ref) <= 1e-6 * np.linalg.norm(u_ref)
+    c.close()
