@@ -308,6 +308,8 @@ k::SpmvMfArgs spmv_mf_cluster_args(mfh_ctx *c, bool masked) {
     a.chunkRow = D.chunkRow.p; a.pairPtr = D.pairPtr.p; a.pairRow = D.ifaceRow.p; a.pairCode = nullptr;
     a.pairPos = reinterpret_cast<const uint32_t *>(D.ifaceRow.p);   // only tested against null
     a.sig = D.ifaceBuf.p; a.maxRows = c->mfc.maxRows;
+    // constant material (k_geometry modes 0, 2, 5): the operator recomputes the gradients from the corner positions
+    a.vertPos = (c->mfGeoFromVerts && (c->matMode == 0 || c->matMode == 2 || c->matMode == 5)) ? c->dVertPos.p : nullptr;
     return a;
 }
 
@@ -873,6 +875,8 @@ mfh_status mfh_create(int32_t device, mfh_ctx **out) {
         c->device = device;
         MFH_HIP(hipSetDevice(device));
         MFH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->nCU = cus;
     } catch (const mfh::Error &e) {
         static thread_local std::string lastCreateError;
         lastCreateError = e.what();
@@ -1672,6 +1676,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }
     else if (k2 == "xcd_swizzle") c->xcdSwizzle = value != 0;
     else if (k2 == "pcg_graph") c->useGraph = value != 0;
+    else if (k2 == "mf_geometry_from_vertices") c->mfGeoFromVerts = value != 0;
     else if (k2 == "pcg_variant") c->pcgVariant = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k2 == "batch_rhs") c->batchRhs = value != 0;
     else if (k2 == "matrix_free_mode") { c->mfMode = (int)value; c->mfClusterUnfit = false; }

@@ -56,6 +56,7 @@ struct mfh_ctx {
     bool symHasScatter = false;
     DBuf<int32_t> dRowPtr, dColIdx, dChunkRow, dSpmvChunkRow, dScatter;
     DBuf<int64_t> dContribPtr;
+    int nCU = 256;                    // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     DBuf<uint32_t> dContribCode;
     DBuf<uint16_t> dContribSlot;
     ShapeTables tables;
@@ -75,6 +76,7 @@ struct mfh_ctx {
     MfClusterLists mfc;               // cluster variant (matrix_free_mode 4)
     MfClusterDev mfcDev;
     bool mfcValid = false;
+    bool mfGeoFromVerts = true;       // option "mf_geometry_from_vertices": constant materials recompute the gradients in the operator
     int mfBlockElems = 0;             // option "mf_block_elems": elements per block of the cluster variant (0 = 256)
     DBuf<double> dMfSig;              // two-pass operator: per-element nodal forces
     int mfChunkRows = 256, mfChunkPairs = 2048;   // options "mf_chunk_rows" / "mf_chunk_pairs"

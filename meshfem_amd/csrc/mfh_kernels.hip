@@ -133,6 +133,40 @@ DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pai
 // matMode: 0 const (lambda,mu) | 1 iso field (E[],nu[]) | 2 const general D (packed upper) | 5 const orthotropic-pattern D |
 //          3 orthotropic field (9 / 4 params per element) | 4 tensor field (flatLen^2 per element)
 // ------------------------------------------------------------------------------------------------
+// signed volume and barycentric gradients of a simplex from its corner positions (EmbeddedElement.hh:182-189 triangle,
+// :223-230 tet): gl[k] = grad lambda_k
+template <int DIM>
+DEV void embed_simplex(const double (&P)[DIM + 1][DIM], double (&gl)[DIM + 1][DIM], double &vol) {
+    if (DIM == 3) {
+        // n0 = (p3-p1)x(p2-p1); 6V = (p0-p1).n0; gl0 = n0/6V; gl1 = (p2-p0)x(p3-p0)/6V; ...   (:223-230)
+        auto cross = [](const double *a, const double *b, double *o) {
+            o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+        };
+        double d31[3], d21[3], d01[3], d20[3], d30[3], d10[3], n[4][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            d31[a] = P[3][a] - P[1][a]; d21[a] = P[2][a] - P[1][a]; d01[a] = P[0][a] - P[1][a];
+            d20[a] = P[2][a] - P[0][a]; d30[a] = P[3][a] - P[0][a]; d10[a] = P[1][a] - P[0][a];
+        }
+        cross(d31, d21, n[0]); cross(d20, d30, n[1]); cross(d30, d10, n[2]); cross(d10, d20, n[3]);
+        const double vol6 = d01[0] * n[0][0] + d01[1] * n[0][1] + d01[2] * n[0][2];
+        vol = vol6 / 6.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int a = 0; a < 3; ++a) gl[k][a] = n[k][a] / vol6;
+    } else {
+        // e0=p2-p1, e1=p0-p2, e2=p1-p0; 2A = e1.x e2.y - e1.y e2.x; gl_k = (-e_k.y, e_k.x)/2A   (:182-189)
+        double E[3][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) { E[0][a] = P[2][a] - P[1][a]; E[1][a] = P[0][a] - P[2][a]; E[2][a] = P[1][a] - P[0][a]; }
+        const double dA = E[1][0] * E[2][1] - E[1][1] * E[2][0];
+        vol = dA / 2.0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { gl[k][0] = -E[k][1] / dA; gl[k][1] = E[k][0] / dA; }
+    }
+}
+
 template <int DIM>
 __global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *__restrict__ elemNodes, int npe,
                                                   const double *__restrict__ vertPos, const double *__restrict__ mp,
@@ -147,34 +181,13 @@ __global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *
         for (int a = 0; a < DIM; ++a) P[k][a] = vertPos[v * DIM + a];
     }
     double *g = geo + e * stride;
-    double vol;
-    if (DIM == 3) {
-        // n0 = (p3-p1)x(p2-p1); 6V = (p0-p1).n0; gl0 = n0/6V; gl1 = (p2-p0)x(p3-p0)/6V; ...   (:223-230)
-        auto cross = [](const double *a, const double *b, double *o) {
-            o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
-        };
-        double d31[3], d21[3], d01[3], d20[3], d30[3], d10[3], n0[3], n1[3], n2[3], n3[3];
+    double vol, gl[DIM + 1][DIM];
+    embed_simplex<DIM>(P, gl, vol);
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            d31[a] = P[3][a] - P[1][a]; d21[a] = P[2][a] - P[1][a]; d01[a] = P[0][a] - P[1][a];
-            d20[a] = P[2][a] - P[0][a]; d30[a] = P[3][a] - P[0][a]; d10[a] = P[1][a] - P[0][a];
-        }
-        cross(d31, d21, n0); cross(d20, d30, n1); cross(d30, d10, n2); cross(d10, d20, n3);
-        const double vol6 = d01[0] * n0[0] + d01[1] * n0[1] + d01[2] * n0[2];
-        vol = vol6 / 6.0;
+    for (int k = 0; k <= DIM; ++k)
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            g[0 + a] = n0[a] / vol6; g[3 + a] = n1[a] / vol6; g[6 + a] = n2[a] / vol6; g[9 + a] = n3[a] / vol6;
-        }
-    } else {
-        // e0=p2-p1, e1=p0-p2, e2=p1-p0; 2A = e1.x e2.y - e1.y e2.x; gl_k = (-e_k.y, e_k.x)/2A   (:182-189)
-        double E[3][2];
-#pragma unroll
-        for (int a = 0; a < 2; ++a) { E[0][a] = P[2][a] - P[1][a]; E[1][a] = P[0][a] - P[2][a]; E[2][a] = P[1][a] - P[0][a]; }
-        const double dA = E[1][0] * E[2][1] - E[1][1] * E[2][0];
-        vol = dA / 2.0;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { g[k * 2 + 0] = -E[k][1] / dA; g[k * 2 + 1] = E[k][0] / dA; }
+        for (int a = 0; a < DIM; ++a) g[k * DIM + a] = gl[k][a];
+    if (DIM == 2) {
 #pragma unroll
         for (int k = 6; k < 12; ++k) g[k] = 0.0;
     }
@@ -229,8 +242,10 @@ __global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *
 // accumulated in LDS with ds_add_f64; the finished rows are written once, coalesced, with plain
 // stores. No global atomics, no read-modify-write of K, no zero-fill pass.
 // ------------------------------------------------------------------------------------------------
+// isotropic / scalar flavours: 8 waves per SIMD (64 VGPRs; 69 without the hint) so that the registers allow the 8 workgroups
+// per CU that the 18 KB of LDS accumulators do (measured 5.42 vs 5.67 ms at config 3 on one box)
 template <int DIM, int DEG, int MAT>
-__global__ void __launch_bounds__(256) k_assemble_gather(AsmArgs a) {
+__global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) ? 1 : 8) k_assemble_gather(AsmArgs a) {
     constexpr int NB = mat_nb<DIM, MAT>();
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
     extern __shared__ __attribute__((aligned(16))) double acc[];   // [NB][chunkSlots + 2]
@@ -1313,7 +1328,11 @@ __global__ void __launch_bounds__(256) k_mf_forces(SpmvMfArgs a, const double *_
 // PCG: 0 = plain operator (optional dotOut), 1 = classic PCG bookkeeping (scal[it 4 + {1: p.Ap, 2: r.r}], base stopPtr[3],
 // threshold stopPtr[0]), 2 = Chronopoulos-Gear bookkeeping for ONE right-hand side (delta into scal[(it + 1) 4 + 1], base
 // ctl[0], threshold ctl[2]; see k_mf_cluster_nr). blockList (may be null = all blocks) selects the blocks of this launch.
-template <int DIM, int DEG, int MAT, int PCG>
+// GEOV: the element's gradients and volume are RECOMPUTED from its four (three) corner positions instead of being read from
+// its 128-byte record: the positions (24 B per vertex, shared by ~24 tets) stay in L2 / the memory-side cache, so a block of
+// 256 P2 tets reads ~10 KB of connectivity instead of 32 KB of records from HBM, for ~80 more FP64 instructions per element.
+// Only with a constant material (its part of the record is then the same for every element: element 0's is used).
+template <int DIM, int DEG, int MAT, int PCG, bool GEOV = false>
 __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const double *__restrict__ x, double *__restrict__ y, double *dotOut,
                                                          double *scal, int it, const double *stopPtr, const int32_t *__restrict__ blockList,
                                                          int64_t nList) {
@@ -1352,10 +1371,23 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
 #pragma unroll
                 for (int d = 0; d < DIM; ++d) xl[j][d] = xs[li[j] * DIM + d];
             }
-            elem_forces_core<DIM, DEG, MAT>(a, e, xl, [&](int j, const double *fv) {
+            auto emit = [&](int j, const double *fv) {
 #pragma unroll
                 for (int d = 0; d < DIM; ++d) unsafeAtomicAdd(&clacc[li[j] * DIM + d], fv[d]);
-            });
+            };
+            if (GEOV) {
+                const int32_t *en = a.elemNodes + e * NPE;
+                double P[DIM + 1][DIM], gl[DIM + 1][DIM], vol;
+#pragma unroll
+                for (int k = 0; k <= DIM; ++k) {
+                    const int64_t v = en[k];
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) P[k][d] = a.vertPos[v * DIM + d];
+                }
+                embed_simplex<DIM>(P, gl, vol);
+                elem_forces_bilinear<DIM, DEG, MAT>(a.geo, vol, gl, gl, xl, emit);
+            } else
+                elem_forces_core<DIM, DEG, MAT>(a, e, xl, emit);
         }
         __syncthreads();
         for (int t = threadIdx.x; t < nLocal; t += MF_BLOCK) {
@@ -1981,12 +2013,16 @@ static void launch_mf_cluster_mode(const SpmvMfArgs &a, int mode, const double *
     if (nList <= 0) return;
     const size_t ldsC = ((size_t)2 * a.clMaxLocal * a.dim + 16) * sizeof(double);
     const int gridC = (int)std::min<int64_t>(nList, 256 * 64);
-#define CALL(D, G, M)                                                                                                                                      \
-    if (mode == 0) hipLaunchKernelGGL((k_mf_cluster<D, G, M, 0>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList);     \
-    else if (mode == 1) hipLaunchKernelGGL((k_mf_cluster<D, G, M, 1>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList); \
-    else hipLaunchKernelGGL((k_mf_cluster<D, G, M, 2>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList)
+#define CALLG(D, G, M, GV)                                                                                                                                         \
+    if (mode == 0) hipLaunchKernelGGL((k_mf_cluster<D, G, M, 0, GV>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList);     \
+    else if (mode == 1) hipLaunchKernelGGL((k_mf_cluster<D, G, M, 1, GV>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList); \
+    else hipLaunchKernelGGL((k_mf_cluster<D, G, M, 2, GV>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList)
+#define CALL(D, G, M)                     \
+    if (a.vertPos) { CALLG(D, G, M, true); } \
+    else { CALLG(D, G, M, false); }
     MFH_DISPATCH(a, CALL);
 #undef CALL
+#undef CALLG
     CHECK_LAUNCH();
 }
 

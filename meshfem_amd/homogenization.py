@@ -442,4 +442,4 @@ def homogenize(vertices, elements, degree=2, Cbase=None, E=None, nu=None, ortho_
     w, infos = solve_cell_problems(sim)
     Ch = homogenized_elasticity_tensor(sim, w)
     return dict(Ch=Ch, w_ij=w, strain_w_ij=[sim.averageStrainField(x) for x in w],
-                iterations=[i["iterations"] for i in infos], sim=sim)
+                iterations=[i["iterations"] for i in infos], infos=infos, sim=sim)

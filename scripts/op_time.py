@@ -1,7 +1,6 @@
-"""Kernel times of one PCG iteration's pieces at a given grid (HIP events inside the library + a short fixed-length solve).
+"""Per-iteration time of fixed-length PCG runs at a given grid, with and without the operator's geometry recomputation.
     python scripts/op_time.py [grid] [nrhs] [iters] [precond]"""
 import sys
-import time
 
 import numpy as np
 
@@ -24,14 +23,18 @@ f = c.neumann_load().ravel()
 vars_, vals = c.bc_dirichlet_vars()
 c.fix_variables(vars_, vals)
 c.set_preconditioner(pre)
+c.set_option("batch_rhs", 1 if nrhs > 1 else 0)
 F = np.stack([f * (1 + k) for k in range(nrhs)])
-for variant in (1, 0):
-    c.set_option("pcg_variant", variant)
-    for rep in range(2):
-        try:
-            c.solve_batch(F, rtol=1e-30, maxit=iters)
-        except M.MeshFEMHipError:
-            pass
-    i = c.last_infos
-    tot = sum(x["solve_ms"] for x in i) if variant == 0 or nrhs == 1 else i[0]["solve_ms"]
-    print("variant %d nrhs %d: %.3f ms per iteration (all rhs), %.3f per rhs" % (variant, nrhs, tot / iters, tot / iters / nrhs), flush=True)
+for geov in (1, 0):
+    c.set_option("mf_geometry_from_vertices", geov)
+    print("operator alone (geometry from vertices %d): %.4f ms" % (geov, c.time_spmv_kernel(50)), flush=True)
+    for variant in (1, 0):
+        c.set_option("pcg_variant", variant)
+        for rep in range(2):
+            try:
+                c.solve_batch(F, rtol=1e-30, maxit=iters)
+            except M.MeshFEMHipError:
+                pass
+        i = c.last_infos
+        tot = sum(x["solve_ms"] for x in i) if variant == 0 or nrhs == 1 else i[0]["solve_ms"]
+        print("  geov %d variant %d nrhs %d: %.3f ms per iteration (all rhs), %.3f per rhs" % (geov, variant, nrhs, tot / iters, tot / iters / nrhs), flush=True)

@@ -88,3 +88,20 @@ def test_plain_c_client_on_gpu():
     _build_c()
     r = subprocess.run([EXE_C, "0"], capture_output=True, text=True)
     assert r.returncode == 0 and "plain C client ok" in r.stdout, r.stdout + r.stderr
+
+
+EXE4 = os.path.join(ROOT, "tests", "cpp", "facade_distributed")
+
+
+def test_facade_distributed_compiles():
+    _build("facade_distributed")
+    r = subprocess.run([EXE4, "-1"], capture_output=True, text=True)
+    assert r.returncode == 3 and "runtime_error" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_facade_distributed_on_gpu():
+    """No Python / torch in this process: the library finds RCCL in the ROCm installation by itself."""
+    _build("facade_distributed")
+    r = subprocess.run([EXE4, "0"], capture_output=True, text=True)
+    assert r.returncode == 0 and "distributed facade ok" in r.stdout and "RCCL" in r.stdout, r.stdout + r.stderr
