@@ -33,8 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
-PMC_PROFILE = "r01_pmc_traffic_n60.json"
-PMC_KERNEL_KEY = "k_assemble_gather<3, 2, 0, 0>"
+PMC_PROFILE = "r02_pmc_traffic_n60.json"      # scripts/pmc_collect.py on the round-2 kernels
+PMC_KERNEL_KEY = "k_assemble_gather"
 ALG_BYTES = {(3, 2): 7736, (3, 1): 1328, (2, 2): 1368, (2, 1): 0}   # SURVEY.md section 8(d), const material
 
 
@@ -283,12 +283,12 @@ def run_single(args):
         # indices per element; x gather + y + x (dot) per node; interface partials written and read back + their lists
         mf_bytes = (nE * (128 + 4 * npe + 2 * npe) + c.n_dof * 3 * 24 + mf_info["block_rows"] * 8
                     + mf_info["interface_partials"] * (2 * 24 + 2))
-        t1, _ = pmc_traffic("k_mf_cluster<3, 2, 0, false>", n, deg)
-        t2, _ = pmc_traffic("k_mf_rows<3, false>", n, deg)
+        t1, _ = pmc_traffic("k_mf_cluster", n, deg)
+        t2, _ = pmc_traffic("k_mf_rows", n, deg)
         mf_traffic = None if t1 is None or t2 is None else t1 + t2
         sp_bytes = nnzb * 76 + nr * 3 * 16 + nr * 4
         it_bytes = sp_bytes + ndof * 112
-        stb, stsrc = pmc_traffic("k_spmv<3, false>", n, deg)
+        stb, stsrc = pmc_traffic("k_spmv", n, deg)
         out["pcg"] = dict(iterations=info["iterations"], converged=info["converged"], rtol=args.rtol,
                           rel_residual=info["rel_residual"], true_rel_residual=info["true_rel_residual"],
                           solve_ms=info["solve_ms"], dof=ndof,

@@ -37,8 +37,8 @@ res = dict(workload="%d^3 grid, %d P2 tets" % (n, meta["elems"]), meta=meta, raw
            calibration=dict(kernel="k_axpby(b=0): reads 8n, writes 8n bytes, n=%d" % meta["calib_axpby_doubles"],
                             fetch_reported_over_true=cal_f, write_reported_over_true=cal_w,
                             note="gfx950 FETCH_SIZE reports ~1/2 of coalesced read bytes (MI355X_MICROARCH.md, HBM section); corrected by the measured factor"))
-names = {"k_assemble_gather": "k_assemble_gather<3, 2, 0, 0>", "k_spmv": "k_spmv<3, false>", "k_mf_cluster": "k_mf_cluster<3, 2, 0, false>",
-         "k_mf_rows": "k_mf_rows<3, false>"}
+# keys = kernel names without template arguments (those changed between rounds; r01 profiles carry the r01 spellings)
+names = {"k_assemble_gather": "k_assemble_gather", "k_spmv": "k_spmv", "k_mf_cluster": "k_mf_cluster", "k_mf_rows": "k_mf_rows"}
 for k, full in names.items():
     fb = raw["FETCH_SIZE"][k]["avg_KB"] * 1024 / cal_f
     wb = raw["WRITE_SIZE"][k]["avg_KB"] * 1024 / cal_w
