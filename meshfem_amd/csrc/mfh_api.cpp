@@ -259,7 +259,7 @@ k::SpmvArgs spmv_args(mfh_ctx *c, bool masked) {
     a.dim = c->bs(); a.nChunk = (int64_t)c->sym.spmvChunkRow.size() - 1; a.chunkRow = c->dSpmvChunkRow.p; a.rowPtr = c->dRowPtr.p;
     a.colIdx = c->dColIdx.p; a.vals = c->dVals.p; a.chunkSlots = c->sym.spmvChunkSlots;
     a.fixedMask = masked ? c->dFixedMask.p : nullptr;
-    a.xcd = c->xcdSwizzle;
+    a.xcd = c->xcdSwizzle == 1;
     return a;
 }
 
@@ -299,6 +299,7 @@ k::SpmvMfArgs spmv_mf_cluster_args(mfh_ctx *c, bool masked) {
     a.elemNodes = c->dElemNodes.p; a.dofForNode = device_dof_map(c);
     a.geo = c->dGeo.p; a.geoStride = c->geoStride; a.pairTable = c->dPairTable.p; a.massTable = c->dMassTable.p;
     a.nElem = m.nElem;
+    a.xcd = c->mfXcdGroup > 1 ? c->mfXcdGroup : 0;    // runs of G consecutive element blocks per XCD (xcd_group_item)
     a.fixedMask = masked ? c->dFixedMask.p : nullptr;
     const auto &D = c->mfcDev;
     a.clBlocks = c->mfc.nBlocks; a.clMaxLocal = c->mfc.maxLocal; a.clBlockElems = c->mfc.blockElems; a.clBlockPtr = D.blockPtr.p; a.clEntryRow = D.entryRow.p;
@@ -322,7 +323,7 @@ k::SpmvMfArgs spmv_mf_args(mfh_ctx *c, bool masked) {
     a.geo = c->dGeo.p; a.geoStride = c->geoStride; a.pairTable = c->dPairTable.p; a.massTable = c->dMassTable.p;
     for (int k2 = 0; k2 < 6; ++k2) a.pairConst[k2] = c->tables.pairConst[k2];
     a.maxRows = c->mf.maxRows;
-    a.xcd = c->xcdSwizzle;
+    a.xcd = c->xcdSwizzle == 1;
     a.nElem = m.nElem;
     a.sig = c->dMfSig.p;
     a.fixedMask = masked ? c->dFixedMask.p : nullptr;
@@ -1674,9 +1675,10 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "agg_nodes") { c->aggNodes = (int)value; c->tl.valid = false; }
     else if (k2 == "topology_device") { c->topologyDevice = value != 0; }
     else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }
-    else if (k2 == "xcd_swizzle") c->xcdSwizzle = value != 0;
+    else if (k2 == "xcd_swizzle") c->xcdSwizzle = std::max(0, (int)value);   // 1: contiguous eighths; G > 1: runs of G items per XCD
     else if (k2 == "pcg_graph") c->useGraph = value != 0;
     else if (k2 == "mf_geometry_from_vertices") c->mfGeoFromVerts = value != 0;
+    else if (k2 == "mf_xcd_group") c->mfXcdGroup = std::max(0, (int)value);
     else if (k2 == "pcg_variant") c->pcgVariant = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k2 == "batch_rhs") c->batchRhs = value != 0;
     else if (k2 == "matrix_free_mode") { c->mfMode = (int)value; c->mfClusterUnfit = false; }

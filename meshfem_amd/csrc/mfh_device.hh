@@ -45,6 +45,15 @@ DEV int64_t xcd_item(int64_t b, int64_t n) {
     const int64_t q = n >> 3, r = n & 7, x = b & 7, k = b >> 3;
     return x * q + (x < r ? x : r) + k;
 }
+// Grouped variant: XCD x takes runs of G consecutive items, all eight XCDs staying inside one window of 8 G items -- neighbouring
+// items (which share element records / x entries) meet in one L2 while the HBM stream stays sequential across the chip.
+// A bijection of [0, n): the last, partial window keeps the identity.
+DEV int64_t xcd_group_item(int64_t b, int64_t n, int G) {
+    const int64_t win = (int64_t)8 * G, w = b / win;
+    if ((w + 1) * win > n) return b;
+    const int64_t r = b - w * win;
+    return w * win + (r & 7) * G + (r >> 3);
+}
 // Persistent workgroups (gridDim.x a multiple of 8): the items of XCD x are [begin, end), visited with stride gridDim.x / 8
 // starting at begin + blockIdx.x / 8.
 DEV void xcd_span(int64_t n, int64_t &first, int64_t &end, int64_t &stride) {

@@ -251,7 +251,7 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
     extern __shared__ __attribute__((aligned(16))) double acc[];   // [NB][chunkSlots + 2]
     const int CS = a.chunkSlots + 2;
     const PairConst pc{a.pairConst[0], a.pairConst[1], a.pairConst[2], a.pairConst[3], a.pairConst[4], a.pairConst[5]};
-    const int64_t chunk = a.xcd ? xcd_item(blockIdx.x, gridDim.x) : (int64_t)blockIdx.x;
+    const int64_t chunk = a.xcd == 1 ? xcd_item(blockIdx.x, gridDim.x) : (a.xcd > 1 ? xcd_group_item(blockIdx.x, gridDim.x, a.xcd) : (int64_t)blockIdx.x);
     const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
     const int s0 = a.rowPtr[r0];
     const int ns = a.rowPtr[r1] - s0;
@@ -1351,7 +1351,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
     }
     double dot = 0.0;
     for (int64_t q = blockIdx.x; q < nList; q += gridDim.x) {
-        const int64_t b = blockList ? (int64_t)blockList[q] : q;
+        const int64_t b = blockList ? (int64_t)blockList[q] : (a.xcd > 1 ? xcd_group_item(q, nList, a.xcd) : q);
         const int u0 = a.clBlockPtr[b], nLocal = a.clBlockPtr[b + 1] - u0;
         // x of every distinct row of the block is read ONCE into LDS (a block of 256 P2 tets gathers 2560 nodal vectors
         // but touches only ~580 distinct rows); the lanes then pick their 10 vectors from LDS by local row index
