@@ -281,7 +281,9 @@ def run_single(args):
         npe = 10 if deg == 2 else 4
         # compulsory bytes of the matrix-free operator (cluster variant): element record + connectivity + local row
         # indices per element; x gather + y + x (dot) per node; interface partials written and read back + their lists
-        mf_bytes = (nE * (128 + 4 * npe + 2 * npe) + c.n_dof * 3 * 24 + mf_info["block_rows"] * 8
+        # (constant material, round 2: the gradients are recomputed from the corner positions, so the 128-B record is not read;
+        # the vertex positions are counted once)
+        mf_bytes = (nE * (4 * npe + 2 * npe) + len(V) * 24 + c.n_dof * 3 * 24 + mf_info["block_rows"] * 8
                     + mf_info["interface_partials"] * (2 * 24 + 2))
         t1, _ = pmc_traffic("k_mf_cluster", n, deg)
         t2, _ = pmc_traffic("k_mf_rows", n, deg)
@@ -296,6 +298,7 @@ def run_single(args):
                           ms_per_iteration=info["solve_ms"] / max(1, info["iterations"]),
                           preconditioner="3x3 block-Jacobi (north_star baseline preconditioner)", wall_s=time.time() - t0,
                           operator="matrix-free (k_mf_cluster + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
+                          algorithm="classic PCG (two reduction points; the default for one right-hand side on one GPU)",
                           matrix_free=dict(kernels_ms=mf_ms, speedup_vs_assembled_spmv=sp_ms / mf_ms, bytes_per_application=mf_bytes, lists=mf_info,
                                            traffic_bytes_per_application=mf_traffic, traffic=None if mf_traffic is None else mf_traffic / mf_ms / 1e6,
                                            achieved=mf_bytes / mf_ms / 1e6, frac=mf_bytes / mf_ms / 1e6 / HBM_PEAK_GBS, unit="GB/s",
@@ -308,6 +311,18 @@ def run_single(args):
                                         traffic_source=stsrc,
                                         alg_bytes_per_launch=sp_bytes,
                                         iteration_achieved=it_bytes / (info["solve_ms"] / max(1, info["iterations"])) / 1e6))
+        # the loop the multi-GPU solve runs (Chronopoulos-Gear: one reduction point), here at world size 1
+        try:
+            c.set_option("pcg_variant", 1)
+            c.sim_solve(rtol=args.rtol, maxit=args.maxit)
+            icg = dict(c.last_info)
+            out["pcg"]["chronopoulos_gear"] = dict(iterations=icg["iterations"], solve_ms=icg["solve_ms"],
+                                                   ms_per_iteration=icg["solve_ms"] / max(1, icg["iterations"]),
+                                                   true_rel_residual=icg["true_rel_residual"],
+                                                   note="mfh_dist_solve's loop (one fused reduction per iteration) on the unpartitioned mesh")
+        except M.MeshFEMHipError as e:
+            out["pcg"]["chronopoulos_gear"] = str(e)
+        c.set_option("pcg_variant", -1)
         # same system with the two-level preconditioner (block-Jacobi + rigid-body-mode coarse space)
         try:
             c.set_preconditioner(M.PRECOND_TWO_LEVEL)

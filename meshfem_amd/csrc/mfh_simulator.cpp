@@ -510,8 +510,79 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
             if (!dense_solve(k, S, lam)) throw Error(MFH_ERR_UNSUPPORTED, "constraint rows are linearly dependent on the free variables");
             for (int r = 0; r < k; ++r)
                 for (int64_t i = 0; i < n; ++i) x[(size_t)i] -= lam[r] * Y[r][(size_t)i];
+        } else if (q < k) {
+            // Mixed case (e.g. x-displacements fixed on a face + translation rows for y and z: the rotation about x survives
+            // as well, q = 3 null modes for k = 2 ... or more rows than null modes): the KKT system is regular iff B = C Z has full
+            // column rank. With lambda = lambda0 + N mu (B^T lambda0 = Z^T f, N = null(B^T)) every right-hand side below is
+            // consistent with the singular K:  u = K^+(f - C^T lambda0) - sum_j mu_j K^+ C^T N_j + Z a,  and (mu, a) follow from
+            // C u = c. (k - q) + 1 PCG solves; reduces to the two branches above for q == k and q == 0.
+            std::vector<double> B((size_t)k * q);
+            for (int r = 0; r < k; ++r)
+                for (int e = 0; e < q; ++e) B[(size_t)r * q + e] = hdot(Cf[r], Z[e]);
+            std::vector<double> BtB((size_t)q * q, 0.0), rhsq((size_t)q), fv2(f, f + n);
+            for (int e = 0; e < q; ++e) {
+                rhsq[e] = hdot(Z[e], fv2);
+                for (int g = 0; g < q; ++g)
+                    for (int r = 0; r < k; ++r) BtB[(size_t)e * q + g] += B[(size_t)r * q + e] * B[(size_t)r * q + g];
+            }
+            if (!dense_solve(q, BtB, rhsq))
+                throw Error(MFH_ERR_UNSUPPORTED, "constraint rows do not fix the " + std::to_string(q) + " rigid motions the fixed variables leave free");
+            std::vector<double> lam0((size_t)k, 0.0);
+            for (int r = 0; r < k; ++r)
+                for (int e = 0; e < q; ++e) lam0[r] += B[(size_t)r * q + e] * rhsq[e];
+            // N: eigenvectors of B B^T with eigenvalue 0 (k - q of them)
+            std::vector<double> BBt((size_t)k * k, 0.0), Vn;
+            for (int r = 0; r < k; ++r)
+                for (int t2 = 0; t2 < k; ++t2)
+                    for (int e = 0; e < q; ++e) BBt[(size_t)r * k + t2] += B[(size_t)r * q + e] * B[(size_t)t2 * q + e];
+            jacobi_eig(k, BBt, Vn);
+            double evm = 0;
+            for (int e = 0; e < k; ++e) evm = std::max(evm, BBt[(size_t)e * k + e]);
+            std::vector<int> nullCols;
+            for (int e = 0; e < k; ++e)
+                if (BBt[(size_t)e * k + e] <= 1e-12 * evm) nullCols.push_back(e);
+            if ((int)nullCols.size() != k - q)
+                throw Error(MFH_ERR_UNSUPPORTED, "constraint rows do not fix the " + std::to_string(q) + " rigid motions the fixed variables leave free");
+            const int nm = k - q;
+            for (int r = 0; r < k; ++r)
+                for (int64_t i = 0; i < n; ++i) fv2[(size_t)i] -= lam0[r] * Cf[r][(size_t)i];
+            c->tlSuppress = true;
+            if (c->precond == MFH_PRECOND_TWO_LEVEL) c->precondNote = "two-level preconditioner: singular system (rigid-motion constraint rows); using block-Jacobi";
+            std::vector<std::vector<double>> Y((size_t)nm, std::vector<double>((size_t)n));
+            try {
+                solve_one(c, fv2.data(), x.data(), rtol, maxit, &li);
+                c->solveHomogeneous = true;
+                std::vector<double> rhs((size_t)n);
+                for (int j = 0; j < nm; ++j) {
+                    std::fill(rhs.begin(), rhs.end(), 0.0);
+                    for (int r = 0; r < k; ++r) {
+                        const double w = Vn[(size_t)r * k + nullCols[j]];
+                        if (w == 0.0) continue;
+                        for (int64_t i = 0; i < n; ++i) rhs[(size_t)i] += w * Cf[r][(size_t)i];
+                    }
+                    mfh_solve_info lj{};
+                    solve_one(c, rhs.data(), Y[j].data(), rtol, maxit, &lj);
+                    li.iterations += lj.iterations;
+                    li.solve_ms += lj.solve_ms;
+                    li.converged = li.converged && lj.converged;
+                }
+            } catch (...) { c->solveHomogeneous = false; c->tlSuppress = false; throw; }
+            c->solveHomogeneous = false;
+            c->tlSuppress = false;
+            std::vector<double> S((size_t)k * k), un((size_t)k);
+            for (int r = 0; r < k; ++r) {
+                for (int j = 0; j < nm; ++j) S[(size_t)r * k + j] = -hdot(Cf[r], Y[j]);
+                for (int e = 0; e < q; ++e) S[(size_t)r * k + nm + e] = B[(size_t)r * q + e];
+                un[r] = crhs[r] - hdot(C[r], x);
+            }
+            if (!dense_solve(k, S, un)) throw Error(MFH_ERR_UNSUPPORTED, "constraint rows are linearly dependent on the free variables");
+            for (int j = 0; j < nm; ++j)
+                for (int64_t i = 0; i < n; ++i) x[(size_t)i] -= un[j] * Y[j][(size_t)i];
+            for (int e = 0; e < q; ++e)
+                for (int64_t i = 0; i < n; ++i) x[(size_t)i] += un[nm + e] * Z[e][(size_t)i];
         } else
-            throw Error(MFH_ERR_UNSUPPORTED, "constraint rows and the rigid motions left by the fixed variables do not match");
+            throw Error(MFH_ERR_UNSUPPORTED, "the fixed variables leave " + std::to_string(q) + " rigid motions free but there are only " + std::to_string(k) +
+                                                 " constraint rows: the system is singular (add no_rigid_motion or pin more nodes)");
     }
     if (info) *info = li;
     for (int64_t i = 0; i < m.nNode; ++i)   // dofToNodeField :664-677

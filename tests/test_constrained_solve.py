@@ -158,3 +158,25 @@ def test_periodic_cell_translation_rows_instead_of_pin():
     dm, nd = sim.ctx.get_dof_map()
     first = np.unique(dm, return_index=True)[1]
     assert np.abs(u[first].sum(axis=0)).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deg", [1, 2])
+def test_mixed_case_fixed_component_plus_rigid_motion_rows(deg):
+    """only the x component is fixed on the face x = 0, so the translations along y, z AND the rotation about x
+    survive (3 null modes), while `no_rigid_motion` adds 6 rows: neither "rows match the null space" (q == k) nor "K
+    regular" (q == 0). Round 1 rejected this; the general elimination (lambda = lambda0 + N mu, (k - q) + 1 consistent
+    singular solves) must reproduce the oracle's sparse-LU KKT solve."""
+    import meshfem_amd as M
+    V, T = _grid(3, deg)
+    ref = _oracle_sim(V, T, deg, 3)
+    sim = _gpu_sim(V, T, deg)
+    ref.apply_dirichlet_box(*_face(3, 0, 0.0), [0.01, 0, 0], (True, False, False))
+    sim.applyDirichletBox(*_face(3, 0, 0.0), [0.01, 0, 0], components=[True, False, False])
+    ref.apply_neumann_box(*_face(3, 0, 1.0), [0.3, -1, 0.2], "traction")
+    sim.applyNeumannBox(*_face(3, 0, 1.0), [0.3, -1, 0.2])
+    ref.useRigidMotionConstraint = True
+    sim.applyNoRigidMotionConstraint()
+    sim.setUsePinNoRigidTranslationConstraint(False)
+    u_ref = O.solve_constrained(ref, no_rigid_motion=True)
+    assert _err(sim.solve(), u_ref) < U_RTOL
