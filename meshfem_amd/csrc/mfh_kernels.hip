@@ -1405,7 +1405,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
                 double v = clacc[t * DIM + d];
                 if (a.fixedMask && a.fixedMask[gi]) v = 0.0;
                 y[gi] = v;
-                if (dotOut) dot += v * x[gi];
+                if (dotOut) dot += v * xs[t * DIM + d];     // x of this row is still staged in LDS: no second (scattered) global read
             }
         }
         __syncthreads();

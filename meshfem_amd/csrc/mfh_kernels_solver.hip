@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(256) k_diag_inv(int64_t nRows, const int32_t *
     for (int c = 0; c < NB; ++c) A[c] = (c % (DIM + 1) == 0) ? 1.0 : 0.0;
     int lo = rowPtr[r], hi = rowPtr[r + 1];
     while (lo < hi) {   // columns are sorted within a row
-        const int mid = (lo + hi) >> 1;
+        const int mid = lo + ((hi - lo) >> 1);   // (lo + hi) overflows int beyond 2^30 blocks (found at 31.9 M P2 tets: 1.24e9 blocks)
         const int cv = colIdx[mid];
         if (cv == r) {
 #pragma unroll

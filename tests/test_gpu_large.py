@@ -1,0 +1,44 @@
+"""BASELINE configs[4]'s mesh (119^3 grid -> 40,443,816 P2 tets, 172.9 M DOF; sized for 8 GPUs) on ONE MI355X: 113 GB of K, 171 GB
+of device memory in all. No oracle runs at this size; size-independent properties instead: the block count of the generator's
+mesh, rigid translations in the null space of the operator, a converged two-level PCG with a TRUE residual below 2 rtol, and
+the tip deflection of the mesh-converged cantilever (config 3 gives 0.03607 for the same boundary-value problem).
+Regression test of the int overflow in k_diag_inv's binary search (slots beyond 2^30), which this size found."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.timeout(900)
+def test_config5_size_on_one_gpu():
+    import torch
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    free, total = torch.cuda.mem_get_info(0)
+    if free < 200e9:
+        pytest.skip("needs 200 GB of free device memory (MI355X: 288 GiB)")
+    n = 119
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    assert len(T) == 24 * n ** 3 == 40443816
+    c = M.Context(0)
+    c.mesh_build(T, V, 2)
+    del V, T
+    assert c.n_node == 57635985                                   # 8 511 119 vertices + 49 124 866 edges
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+    c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    c.assemble()
+    nr, nc, nnzb = c.matrix_info()
+    assert nr == nc == c.n_node and nnzb > 2 ** 30                # the size the overflow needed
+    # rigid translations are in the null space of K (matrix-free operator = assembled K to rounding)
+    t = np.tile([0.3, -1.0, 0.7], c.n_node)
+    Kt = c.apply_K(t)
+    f = c.neumann_load().ravel()
+    assert np.abs(Kt).max() <= 1e-9 * 200.0                      # |K entries| ~ E h = 200 / 119 ... 200
+    c.set_preconditioner(M.PRECOND_TWO_LEVEL)
+    u = c.sim_solve(rtol=1e-8, maxit=5000)
+    i = c.last_info
+    assert i["converged"] and i["true_rel_residual"] <= 2e-8 and i["iterations"] < 1500
+    assert abs(np.abs(u).max() - 0.03607) <= 2e-4                 # the cantilever's deflection does not depend on the mesh size
+    assert abs(f.sum() + 1.0) <= 1e-9                             # total traction (0, -1, 0) on the unit face
+    c.close()
