@@ -412,6 +412,7 @@ mfh_status mfh_matrix_free_info(mfh_ctx* ctx, int32_t* active, int32_t* mode, in
  *   list order | 2 two-pass, forces element-major | 1 per-pair block evaluation), "mf_chunk_rows", "mf_chunk_pairs",
  * "mf_geometry_from_vertices" (1 default: with a constant material the matrix-free operator recomputes the element gradients from the
  *   corner positions instead of reading the element records), "mf_xcd_group" (32 default: consecutive element blocks per XCD),
+ *   "mf_lane_stride" (37 default: lane-to-element stride inside a block, against same-address LDS atomics),
  * "pcg_graph" (1 default: blocks of check_every PCG iterations are replayed from a hipGraph),
  * "pcg_variant" (1: Chronopoulos-Gear PCG, one reduction point per iteration and one fused vector kernel -- always used by
  *   mfh_dist_solve and for batches; 0: the classic two-reduction PCG, one right-hand side at a time; -1 default: classic for

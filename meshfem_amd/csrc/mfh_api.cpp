@@ -299,6 +299,12 @@ k::SpmvMfArgs spmv_mf_cluster_args(mfh_ctx *c, bool masked) {
     a.elemNodes = c->dElemNodes.p; a.dofForNode = device_dof_map(c);
     a.geo = c->dGeo.p; a.geoStride = c->geoStride; a.pairTable = c->dPairTable.p; a.massTable = c->dMassTable.p;
     a.nElem = m.nElem;
+    a.clLaneStride = 1;
+    if (c->mfLaneStride > 1) {   // usable only if coprime to the block size (a bijection of the lanes)
+        int x = c->mfLaneStride, y = c->mfc.blockElems;
+        while (y) { const int t = x % y; x = y; y = t; }
+        if (x == 1) a.clLaneStride = c->mfLaneStride;
+    }
     a.xcd = c->mfXcdGroup > 1 ? c->mfXcdGroup : 0;    // runs of G consecutive element blocks per XCD (xcd_group_item)
     a.fixedMask = masked ? c->dFixedMask.p : nullptr;
     const auto &D = c->mfcDev;
@@ -1679,6 +1685,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "pcg_graph") c->useGraph = value != 0;
     else if (k2 == "mf_geometry_from_vertices") c->mfGeoFromVerts = value != 0;
     else if (k2 == "mf_xcd_group") c->mfXcdGroup = std::max(0, (int)value);
+    else if (k2 == "mf_lane_stride") c->mfLaneStride = std::max(1, (int)value);
     else if (k2 == "pcg_variant") c->pcgVariant = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k2 == "batch_rhs") c->batchRhs = value != 0;
     else if (k2 == "matrix_free_mode") { c->mfMode = (int)value; c->mfClusterUnfit = false; }

@@ -363,6 +363,7 @@ struct SpmvMfArgs {
     int64_t nElem;
     double *sig;                        // two-pass operator: nodal forces of every element, [nElem][npe][dim]
     const uint8_t *fixedMask;           // per scalar row, may be null
+    int clLaneStride;                   // lane t of a block takes element (t * stride) % blockElems (1: identity); coprime to blockElems
     const double *vertPos;              // cluster variant, constant material: corner positions [nVert][dim]; gradients recomputed (null: read the records)
 };
 void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,

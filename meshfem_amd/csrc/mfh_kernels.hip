@@ -1361,7 +1361,11 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
             for (int d = 0; d < DIM; ++d) { xs[t * DIM + d] = x[row * DIM + d]; clacc[t * DIM + d] = 0.0; }
         }
         __syncthreads();
-        const int64_t e = b * a.clBlockElems + threadIdx.x;
+        // lane -> element of the block: with a stride coprime to the block size the lanes of a wave take elements that are
+        // far apart in the block, so they rarely add to the SAME row at the same instruction (consecutive elements share
+        // nodes -- the 24 tets of a generator hex all contain its centre vertex -- and same-address LDS atomics serialise)
+        const int le = a.clLaneStride > 1 ? (int)((threadIdx.x * (unsigned)a.clLaneStride) % (unsigned)a.clBlockElems) : (int)threadIdx.x;
+        const int64_t e = b * a.clBlockElems + le;
         if ((int)threadIdx.x < a.clBlockElems && e < a.nElem) {
             int li[NPE];
             double xl[NPE][DIM];
