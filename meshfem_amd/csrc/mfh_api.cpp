@@ -660,12 +660,11 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
             else if (useMF) k::launch_spmv_mf(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
             else k::launch_pcg_spmv(sa, c->wp.p, c->wAp.p, c->scal.p, itLocal, c->stop.p, s);
             if (useTL) {
-                k::launch_pcg_update_noz(d, c->sym.nRows, c->wp.p, c->wAp.p, c->wx.p, c->wr.p, c->scal.p, itLocal, c->stop.p, s);
+                k::launch_pcg_update_noz(d, c->sym.nRows, c->wAp.p, c->wr.p, c->scal.p, itLocal, c->stop.p, s);
                 tl_precond(c, c->wr.p, c->wz.p, c->scal.p, itLocal);
             } else
-                k::launch_pcg_update(d, c->sym.nRows, c->dDinv.p, c->wp.p, c->wAp.p, c->wx.p, c->wr.p, c->wz.p, c->scal.p, itLocal,
-                                     c->stop.p, s);
-            k::launch_pcg_direction(n, c->wz.p, c->wp.p, c->scal.p, itLocal, c->stop.p, s);
+                k::launch_pcg_update(d, c->sym.nRows, c->dDinv.p, c->wAp.p, c->wr.p, c->wz.p, c->scal.p, itLocal, c->stop.p, s);
+            k::launch_pcg_direction(n, c->wz.p, c->wp.p, c->wx.p, c->scal.p, itLocal, c->stop.p, s);
         };
         // Launch-bound regime (small meshes: a few tens of microseconds per kernel): capture one block of
         // check_every iterations in a hipGraph and replay it; the kernels find their iteration through the

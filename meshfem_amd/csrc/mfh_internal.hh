@@ -388,13 +388,13 @@ void launch_pcg_init(int dim, int64_t nRows, const double *dinv, const double *b
                      double *p, double *scal, hipStream_t s);
 void launch_pcg_spmv(const SpmvArgs &a, const double *p, double *Ap, double *scal, int it, const double *stopPtr,
                      hipStream_t s);
-void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double *p, const double *Ap, double *x,
+void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double *Ap,
                        double *r, double *z, double *scal, int it, const double *stopPtr, hipStream_t s);
 void launch_dev_update_xr(int64_t n, const double *num, const double *den, const double *p, const double *Ap, double *x, double *r, hipStream_t s);
 void launch_dev_direction(int64_t n, const double *num, const double *den, const double *z, double *p, hipStream_t s);
 void launch_dev_dots(int64_t n, const double *r, const double *z, double *out, hipStream_t s);
 void launch_advance_base(double *stop, int n, hipStream_t s);   // stop[3] += n (iteration base of graph-captured PCG blocks)
-void launch_pcg_direction(int64_t n, const double *z, double *p, const double *scal, int it, const double *stopPtr,
+void launch_pcg_direction(int64_t n, const double *z, double *p, double *x, const double *scal, int it, const double *stopPtr,
                           hipStream_t s);
 
 struct TLArgs {
@@ -404,7 +404,7 @@ struct TLArgs {
     const double *relPos;         // nDoF x 3: (position - aggregate centroid) / H
     const uint8_t *fixedMask;     // per scalar variable, may be null
 };
-void launch_pcg_update_noz(int dim, int64_t nRows, const double *p, const double *Ap, double *x, double *r, double *scal, int it,
+void launch_pcg_update_noz(int dim, int64_t nRows, const double *Ap, double *r, double *scal, int it,
                            const double *stopPtr, hipStream_t s);
 void launch_tl_fill(const TLArgs &t, const int32_t *colorOfAgg, int color, int mode, double *v, hipStream_t s);
 void launch_tl_restrict(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const double *w, double *rc, hipStream_t s);

@@ -655,10 +655,11 @@ __global__ void __launch_bounds__(256) k_pcg_init(int64_t nRows, const double *_
     if (threadIdx.x == 0) { unsafeAtomicAdd(&scal[0], acc[0]); unsafeAtomicAdd(&scal[2], acc[1]); }
 }
 
-// x += alpha p ; r -= alpha Ap ; z = Dinv r ; scal[it+1].{rz,rr} += ...
+// r -= alpha Ap ; z = Dinv r ; scal[it+1].{rz,rr} += ...   (x += alpha p happens in k_pcg_direction, which reads p anyway: one
+// vector read less per iteration than updating x here)
 template <int DIM, bool SKIPZ = false>
-__global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ p,
-                                                    const double *__restrict__ Ap, double *__restrict__ x, double *__restrict__ r,
+__global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double *__restrict__ dinv,
+                                                    const double *__restrict__ Ap, double *__restrict__ r,
                                                     double *__restrict__ z, double *scal, int it, const double *stopPtr) {
     __shared__ double red[16];
     it += (int)stopPtr[3];
@@ -670,7 +671,6 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
             const int64_t g = n * DIM + c;
-            x[g] += alpha * p[g];
             rv[c] = r[g] - alpha * Ap[g];
             r[g] = rv[c];
         }
@@ -689,13 +689,18 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
     }
 }
 
-// p = z + beta p
-__global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, const double *__restrict__ z, double *__restrict__ p,
+// x += alpha p ; p = z + beta p   (alpha of this iteration, beta from the reductions k_pcg_update / the preconditioner just made)
+__global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, const double *__restrict__ z, double *__restrict__ p, double *__restrict__ x,
                                                        const double *scal, int it, const double *stopPtr) {
     it += (int)stopPtr[3];
     if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
+    const double alpha = scal[(int64_t)it * 4 + 0] / scal[(int64_t)it * 4 + 1];
     const double beta = scal[(int64_t)(it + 1) * 4 + 0] / scal[(int64_t)it * 4 + 0];
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) p[k] = z[k] + beta * p[k];
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        const double pv = p[k];
+        x[k] += alpha * pv;
+        p[k] = z[k] + beta * pv;
+    }
 }
 
 // distributed PCG building blocks: the scalars live in device memory (results of RCCL all-reduces), so no host sync
@@ -1072,18 +1077,18 @@ void launch_pcg_init(int dim, int64_t nRows, const double *dinv, const double *b
     CHECK_LAUNCH();
 }
 
-void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double *p, const double *Ap, double *x, double *r,
+void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double *Ap, double *r,
                        double *z, double *scal, int it, const double *stopPtr, hipStream_t s) {
-    if (dim == 1) hipLaunchKernelGGL((k_pcg_update<1, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
-    else if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
-    else hipLaunchKernelGGL((k_pcg_update<2, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, p, Ap, x, r, z, scal, it, stopPtr);
+    if (dim == 1) hipLaunchKernelGGL((k_pcg_update<1, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr);
+    else if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr);
+    else hipLaunchKernelGGL((k_pcg_update<2, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr);
     CHECK_LAUNCH();
 }
 
-void launch_pcg_update_noz(int dim, int64_t nRows, const double *p, const double *Ap, double *x, double *r, double *scal, int it,
+void launch_pcg_update_noz(int dim, int64_t nRows, const double *Ap, double *r, double *scal, int it,
                            const double *stopPtr, hipStream_t s) {
-    if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, true>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, (const double *)nullptr, p, Ap, x, r, (double *)nullptr, scal, it, stopPtr);
-    else hipLaunchKernelGGL((k_pcg_update<2, true>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, (const double *)nullptr, p, Ap, x, r, (double *)nullptr, scal, it, stopPtr);
+    if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, true>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, (const double *)nullptr, Ap, r, (double *)nullptr, scal, it, stopPtr);
+    else hipLaunchKernelGGL((k_pcg_update<2, true>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, (const double *)nullptr, Ap, r, (double *)nullptr, scal, it, stopPtr);
     CHECK_LAUNCH();
 }
 
@@ -1182,8 +1187,8 @@ void launch_advance_base(double *stop, int n, hipStream_t s) {
     CHECK_LAUNCH();
 }
 
-void launch_pcg_direction(int64_t n, const double *z, double *p, const double *scal, int it, const double *stopPtr, hipStream_t s) {
-    hipLaunchKernelGGL(k_pcg_direction, dim3(grid_for(n)), dim3(256), 0, s, n, z, p, scal, it, stopPtr);
+void launch_pcg_direction(int64_t n, const double *z, double *p, double *x, const double *scal, int it, const double *stopPtr, hipStream_t s) {
+    hipLaunchKernelGGL(k_pcg_direction, dim3(grid_for(n)), dim3(256), 0, s, n, z, p, x, scal, it, stopPtr);
     CHECK_LAUNCH();
 }
 
