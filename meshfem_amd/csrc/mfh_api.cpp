@@ -280,8 +280,15 @@ void ensure_mf_cluster(mfh_ctx *c) {
     ensure_symbolic(c, false);
     // block size: measured at config 3, 256 / 240 (hex-aligned) / 192 give 7.45 / 7.18 / 7.31 M interface partials and the
     // same 0.69 ms -- the interface is set by the shape of a run of consecutive elements, not by its alignment
-    build_mf_cluster_lists_device(c->mesh, c->dElemNodes.p, device_dof_map(c), c->sym.nRows, c->stream, c->mfc, c->mfcDev,
-                                  c->mfBlockElems > 0 ? c->mfBlockElems : MF_BLOCK);
+    const int32_t *conn = c->dElemNodes.p;
+    const int be = c->mfBlockElems > 0 ? std::min(c->mfBlockElems, (int)MF_BLOCK) : (int)MF_BLOCK;
+    std::vector<int32_t> blockStart;
+    if (c->mfReorder) {
+        build_element_order_device(c->mesh, c->dElemNodes.p, c->dVertPos.p, c->stream, c->dMfElemPerm, c->dMfElemNodes, be, blockStart);
+        conn = c->dMfElemNodes.p;
+    } else { c->dMfElemPerm.release(); c->dMfElemNodes.release(); }
+    build_mf_cluster_lists_device(c->mesh, conn, device_dof_map(c), c->sym.nRows, c->stream, c->mfc, c->mfcDev, be,
+                                  blockStart.empty() ? nullptr : &blockStart);
     // The cluster variant pays when most rows are finished inside a block: one LDS accumulator per distinct row of a
     // block plus the staged x of those rows (48 KB keeps three workgroups per CU) and an interface buffer well below the per-pair force buffer it replaces.
     // An element order without locality (e.g. shuffled: ~2560 distinct rows per block) uses the two-pass variant instead.
@@ -299,9 +306,11 @@ k::SpmvMfArgs spmv_mf_cluster_args(mfh_ctx *c, bool masked) {
     a.elemNodes = c->dElemNodes.p; a.dofForNode = device_dof_map(c);
     a.geo = c->dGeo.p; a.geoStride = c->geoStride; a.pairTable = c->dPairTable.p; a.massTable = c->dMassTable.p;
     a.nElem = m.nElem;
+    if (c->dMfElemPerm.p) { a.elemNodes = c->dMfElemNodes.p; a.clElemPerm = c->dMfElemPerm.p; }
+    a.clElemPtr = c->mfcDev.elemPtr.p;
     a.clLaneStride = 1;
     if (c->mfLaneStride > 1) {   // usable only if coprime to the block size (a bijection of the lanes)
-        int x = c->mfLaneStride, y = c->mfc.blockElems;
+        int x = c->mfLaneStride, y = c->mfcDev.elemPtr.p ? (int)MF_BLOCK : c->mfc.blockElems;
         while (y) { const int t = x % y; x = y; y = t; }
         if (x == 1) a.clLaneStride = c->mfLaneStride;
     }
@@ -1685,6 +1694,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "mf_geometry_from_vertices") c->mfGeoFromVerts = value != 0;
     else if (k2 == "mf_xcd_group") c->mfXcdGroup = std::max(0, (int)value);
     else if (k2 == "mf_lane_stride") c->mfLaneStride = std::max(1, (int)value);
+    else if (k2 == "mf_reorder") { c->mfReorder = value != 0; c->mfcValid = false; c->mfClusterUnfit = false; }
     else if (k2 == "pcg_variant") c->pcgVariant = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k2 == "batch_rhs") c->batchRhs = value != 0;
     else if (k2 == "matrix_free_mode") { c->mfMode = (int)value; c->mfClusterUnfit = false; }

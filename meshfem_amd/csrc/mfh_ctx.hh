@@ -79,6 +79,8 @@ struct mfh_ctx {
     int mfXcdGroup = 32;              // option "mf_xcd_group": every XCD takes runs of this many consecutive element blocks, all eight inside one
                                       // window (neighbouring blocks share x entries and interface rows in one L2): 0.510 vs 0.527 ms at config 3;
                                       // the same mapping makes the assembly kernel SLOWER (5.42 vs 5.34 ms) and is not used there
+    bool mfReorder = true;            // option "mf_reorder": the cluster operator walks the elements in Morton order of their centroids
+    DBuf<int32_t> dMfElemPerm, dMfElemNodes;   // perm[new] = old, connectivity in the new order
     int mfLaneStride = 37;            // option "mf_lane_stride": lane t of a block takes element (37 t) % blockElems, so that the lanes of a wave rarely
                                       // add to the same LDS accumulator at once (operator 0.481 vs 0.519 ms at config 3 in one process; 5, 37, 101 alike)
     bool mfGeoFromVerts = true;       // option "mf_geometry_from_vertices": constant materials recompute the gradients in the operator

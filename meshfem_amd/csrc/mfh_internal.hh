@@ -211,9 +211,13 @@ struct MfClusterDev {
     DBuf<int32_t> chunkRow;
     DBuf<int64_t> pairPtr;
     DBuf<double> ifaceBuf;              // [nIface * dim]
+    DBuf<int32_t> elemPtr;              // [nBlocks+1] variable-size blocks (whole cells), empty = uniform blocks
 };
+// blockStart (may be null): element offsets of variable-size blocks [nBlocks+1], every block <= MF_BLOCK elements
 void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nRows, hipStream_t s,
-                                   MfClusterLists &L, MfClusterDev &D, int blockElems = MF_BLOCK);
+                                   MfClusterLists &L, MfClusterDev &D, int blockElems = MF_BLOCK, const std::vector<int32_t> *blockStart = nullptr);
+void build_element_order_device(const HostMesh &m, const int32_t *dElemNodes, const double *dNodePos, hipStream_t s, DBuf<int32_t> &perm,
+                                DBuf<int32_t> &elemNodesOut, int maxBlock, std::vector<int32_t> &blockStart);
 void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nRows, hipStream_t s,
                            MfLists &L, DBuf<uint32_t> &dPairCode, DBuf<uint16_t> &dPairRow, DBuf<uint32_t> &dPairPos, int maxRowsCap = 256,
                            int maxPairs = 2048);
@@ -363,6 +367,8 @@ struct SpmvMfArgs {
     int64_t nElem;
     double *sig;                        // two-pass operator: nodal forces of every element, [nElem][npe][dim]
     const uint8_t *fixedMask;           // per scalar row, may be null
+    const int32_t *clElemPtr;           // cluster variant: block b holds the elements [clElemPtr[b], clElemPtr[b+1]) of the operator's order (null: clBlockElems each)
+    const int32_t *clElemPerm;          // cluster variant: original element of the operator's element e (null: identity); elemNodes is then in the new order
     int clLaneStride;                   // lane t of a block takes element (t * stride) % blockElems (1: identity); coprime to blockElems
     const double *vertPos;              // cluster variant, constant material: corner positions [nVert][dim]; gradients recomputed (null: read the records)
 };

@@ -1364,9 +1364,13 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
         // lane -> element of the block: with a stride coprime to the block size the lanes of a wave take elements that are
         // far apart in the block, so they rarely add to the SAME row at the same instruction (consecutive elements share
         // nodes -- the 24 tets of a generator hex all contain its centre vertex -- and same-address LDS atomics serialise)
-        const int le = a.clLaneStride > 1 ? (int)((threadIdx.x * (unsigned)a.clLaneStride) % (unsigned)a.clBlockElems) : (int)threadIdx.x;
-        const int64_t e = b * a.clBlockElems + le;
-        if ((int)threadIdx.x < a.clBlockElems && e < a.nElem) {
+        // blocks of whole cells (clElemPtr, <= MF_BLOCK elements each) or of clBlockElems consecutive elements
+        const int64_t e0 = a.clElemPtr ? (int64_t)a.clElemPtr[b] : b * a.clBlockElems;
+        const int ne = a.clElemPtr ? a.clElemPtr[b + 1] - a.clElemPtr[b] : a.clBlockElems;
+        const int span = a.clElemPtr ? MF_BLOCK : a.clBlockElems;      // the lane permutation is a bijection of [0, span)
+        const int le = a.clLaneStride > 1 ? (int)((threadIdx.x * (unsigned)a.clLaneStride) % (unsigned)span) : (int)threadIdx.x;
+        const int64_t e = e0 + le;
+        if ((int)threadIdx.x < span && le < ne && e < a.nElem) {
             int li[NPE];
             double xl[NPE][DIM];
 #pragma unroll
@@ -1391,7 +1395,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
                 embed_simplex<DIM>(P, gl, vol);
                 elem_forces_bilinear<DIM, DEG, MAT>(a.geo, vol, gl, gl, xl, emit);
             } else
-                elem_forces_core<DIM, DEG, MAT>(a, e, xl, emit);
+                elem_forces_core<DIM, DEG, MAT>(a, a.clElemPerm ? (int64_t)a.clElemPerm[e] : e, xl, emit);   // the record of the ORIGINAL element
         }
         __syncthreads();
         for (int t = threadIdx.x; t < nLocal; t += MF_BLOCK) {
@@ -1524,12 +1528,14 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster_nr(SpmvMfArgs a, const 
     for (int64_t q = blockIdx.x; q < nList; q += gridDim.x) {
         const int64_t b = blockList ? (int64_t)blockList[q] : q;
         const int u0 = a.clBlockPtr[b], nLocal = a.clBlockPtr[b + 1] - u0;
-        const int64_t e = b * a.clBlockElems + threadIdx.x;
-        const bool active = (int)threadIdx.x < a.clBlockElems && e < a.nElem;
+        const int64_t e0 = a.clElemPtr ? (int64_t)a.clElemPtr[b] : b * a.clBlockElems;
+        const int ne = a.clElemPtr ? a.clElemPtr[b + 1] - a.clElemPtr[b] : a.clBlockElems;
+        const int64_t e = e0 + threadIdx.x;
+        const bool active = (int)threadIdx.x < ne && e < a.nElem;
         // element state shared by all NR vectors: LDS offsets of its nodes' rows, gradients, volume
         int li[NPE];
         double gl[DIM + 1][DIM], vol = 0.0;
-        const double *g = a.geo + (active ? e : 0) * a.geoStride;
+        const double *g = a.geo + (active ? (a.clElemPerm ? (int64_t)a.clElemPerm[e] : e) : 0) * a.geoStride;   // record of the original element
         if (active) {
 #pragma unroll
             for (int j = 0; j < NPE; ++j) li[j] = (int)a.clLocalIdx[e * NPE + j] * W;

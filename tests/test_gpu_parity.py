@@ -845,25 +845,29 @@ def test_matrix_free_is_the_default_for_quadratic_elasticity():
     assert np.abs(y_auto - y_asm).max() < 1e-13 * np.abs(y_asm).max()   # ... same operator
 
 
-def test_matrix_free_cluster_variant_falls_back_without_element_locality():
-    """A uniformly shuffled mesh: a block of 256 consecutive elements touches ~2560 distinct rows (no sharing), more
-    than the LDS budget of k_mf_cluster -> the operator falls back to the two-pass variant; generator order uses mode 4."""
+def test_matrix_free_cluster_variant_and_element_order():
+    """A uniformly shuffled mesh: a block of 256 consecutive elements touches ~2560 distinct rows (no sharing), more than
+    the LDS budget of k_mf_cluster. With the operator's own element order (cells along the Z-curve, `mf_reorder` 1, the
+    default) the cluster variant works on it as on the generator's order; with the caller's order (`mf_reorder` 0) it falls
+    back to the two-pass variant. Every combination equals the assembled operator."""
     V, T = grid.grid_tet_mesh(12, 12, 12)
     modes = {}
     for name, (Vx, Tx) in (("generator", (V, T)), ("shuffle", grid.reorder_mesh(V, T, "shuffle"))):
-        c = _ctx()
-        c.mesh_build(Tx, Vx, 2)
-        c.material_isotropic(200.0, 0.35)
-        c.assemble()
-        info = c.matrix_free_info()
-        modes[name] = info["mode"]
-        x = np.random.default_rng(0).standard_normal(3 * c.n_node)
-        y_mf = c.apply_K(x)
-        c.set_option("matrix_free", 0)
-        y_asm = c.apply_K(x)
-        assert np.abs(y_mf - y_asm).max() < 1e-13 * np.abs(y_asm).max(), name
-        c.close()
-    assert modes == {"generator": 4, "shuffle": 3}, modes
+        for reorder in (1, 0):
+            c = _ctx()
+            c.set_option("mf_reorder", reorder)
+            c.mesh_build(Tx, Vx, 2)
+            c.material_iso_field(np.linspace(100.0, 300.0, len(Tx)), np.full(len(Tx), 0.3))   # per-element records: read by ORIGINAL element id
+            c.assemble()
+            x = np.random.default_rng(0).standard_normal(3 * c.n_node)
+            y_mf = c.apply_K(x)
+            info = c.matrix_free_info()
+            modes[(name, reorder)] = info["mode"]
+            c.set_option("matrix_free", 0)
+            y_asm = c.apply_K(x)
+            assert np.abs(y_mf - y_asm).max() < 1e-13 * np.abs(y_asm).max(), (name, reorder)
+            c.close()
+    assert modes == {("generator", 1): 4, ("generator", 0): 4, ("shuffle", 1): 4, ("shuffle", 0): 3}, modes
 
 
 @pytest.mark.parametrize("dim", [2, 3])
