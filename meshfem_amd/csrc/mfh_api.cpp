@@ -1693,6 +1693,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "pcg_graph") c->useGraph = value != 0;
     else if (k2 == "mf_geometry_from_vertices") c->mfGeoFromVerts = value != 0;
     else if (k2 == "mf_xcd_group") c->mfXcdGroup = std::max(0, (int)value);
+    else if (k2 == "vec_grid_cap") k::g_vecGridCap = std::max(256, (int)value);
     else if (k2 == "mf_lane_stride") c->mfLaneStride = std::max(1, (int)value);
     else if (k2 == "mf_reorder") { c->mfReorder = value != 0; c->mfcValid = false; c->mfClusterUnfit = false; }
     else if (k2 == "pcg_variant") c->pcgVariant = value < 0 ? -1 : (value != 0 ? 1 : 0);

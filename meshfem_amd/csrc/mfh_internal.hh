@@ -449,6 +449,7 @@ void launch_tl_restrict_nr(const TLArgs &t, int NR, const int32_t *aggPtr, const
 void launch_tl_gemv_nr(int64_t m, int64_t ld, int NR, const double *A, const double *x, double *y, hipStream_t s);
 void launch_tl_apply_nr(const TLArgs &t, int NR, const double *dinv, const double *r, const double *yc, double *z, double *scal, int it,
                         const double *ctl, hipStream_t s);
+extern int g_vecGridCap;
 void launch_add_scalar(double *p, double v, hipStream_t s);   // *p += v
 void launch_pack_rows(int64_t n, int W, const int32_t *idx, const double *src, double *dst, hipStream_t s);
 void launch_interleave(int64_t nRows, int NR, int dim, const double *src, double *dst, bool toInterleaved, int64_t sepStride, hipStream_t s);

@@ -666,7 +666,40 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
     if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
     const double alpha = scal[(int64_t)it * 4 + 0] / scal[(int64_t)it * 4 + 1];
     double acc[2] = {0, 0};
-    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nRows; n += (int64_t)gridDim.x * 256) {
+    constexpr int NS = DIM * (DIM + 1) / 2;
+    // a lane takes TWO consecutive rows: 2 DIM doubles of Ap / r / z and 2 NS of the packed inverse blocks are contiguous and
+    // 16-byte aligned, so everything moves in 16-byte accesses (the arrays come from hipMalloc)
+    const int64_t nPair = nRows >> 1;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nPair; q += (int64_t)gridDim.x * 256) {
+        double av[2 * DIM], rv[2 * DIM], zv[2 * DIM], dm[2 * NS];
+        const double2 *a2 = reinterpret_cast<const double2 *>(Ap + q * 2 * DIM);
+        double2 *r2 = reinterpret_cast<double2 *>(r + q * 2 * DIM);
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            const double2 t = a2[c], u = r2[c];
+            av[2 * c] = t.x; av[2 * c + 1] = t.y; rv[2 * c] = u.x; rv[2 * c + 1] = u.y;
+        }
+#pragma unroll
+        for (int c = 0; c < 2 * DIM; ++c) rv[c] -= alpha * av[c];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) r2[c] = make_double2(rv[2 * c], rv[2 * c + 1]);
+        if (!SKIPZ) {
+            const double2 *d2 = reinterpret_cast<const double2 *>(dinv + q * 2 * NS);
+#pragma unroll
+            for (int c = 0; c < NS; ++c) { const double2 t = d2[c]; dm[2 * c] = t.x; dm[2 * c + 1] = t.y; }
+            apply_block<DIM>(dm, rv, zv);
+            apply_block<DIM>(dm + NS, rv + DIM, zv + DIM);
+            double2 *z2 = reinterpret_cast<double2 *>(z + q * 2 * DIM);
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) z2[c] = make_double2(zv[2 * c], zv[2 * c + 1]);
+#pragma unroll
+            for (int c = 0; c < 2 * DIM; ++c) acc[0] += rv[c] * zv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 2 * DIM; ++c) acc[1] += rv[c] * rv[c];
+    }
+    if ((nRows & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // the odd last row
+        const int64_t n = nRows - 1;
         double rv[DIM], zv[DIM];
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
@@ -675,7 +708,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
             r[g] = rv[c];
         }
         if (!SKIPZ) {
-            apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
+            apply_block<DIM>(dinv + n * NS, rv, zv);
 #pragma unroll
             for (int c = 0; c < DIM; ++c) { z[n * DIM + c] = zv[c]; acc[0] += rv[c] * zv[c]; }
         }
@@ -689,6 +722,8 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
     }
 }
 
+int g_vecGridCap = 16384;   // workgroups of k_pcg_direction (option "vec_grid_cap"; 0.899 vs 0.911 ms per iteration against 2048). Kernels that end in a
+                            // reduction keep 2048: 16384 workgroups x 2 atomics on the same scalars cost 0.14 ms
 // x += alpha p ; p = z + beta p   (alpha of this iteration, beta from the reductions k_pcg_update / the preconditioner just made)
 __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, const double *__restrict__ z, double *__restrict__ p, double *__restrict__ x,
                                                        const double *scal, int it, const double *stopPtr) {
@@ -696,10 +731,21 @@ __global__ void __launch_bounds__(256) k_pcg_direction(int64_t n, const double *
     if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
     const double alpha = scal[(int64_t)it * 4 + 0] / scal[(int64_t)it * 4 + 1];
     const double beta = scal[(int64_t)(it + 1) * 4 + 0] / scal[(int64_t)it * 4 + 0];
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
-        const double pv = p[k];
-        x[k] += alpha * pv;
-        p[k] = z[k] + beta * pv;
+    // 16 bytes per lane and access (the arrays come from hipMalloc: 256-byte aligned)
+    const int64_t n2 = n >> 1;
+    const double2 *z2 = reinterpret_cast<const double2 *>(z);
+    double2 *p2 = reinterpret_cast<double2 *>(p), *x2 = reinterpret_cast<double2 *>(x);
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n2; k += (int64_t)gridDim.x * 256) {
+        const double2 pv = p2[k], zv = z2[k];
+        double2 xv = x2[k];
+        xv.x += alpha * pv.x; xv.y += alpha * pv.y;
+        x2[k] = xv;
+        p2[k] = make_double2(zv.x + beta * pv.x, zv.y + beta * pv.y);
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const double pv = p[n - 1];
+        x[n - 1] += alpha * pv;
+        p[n - 1] = z[n - 1] + beta * pv;
     }
 }
 
@@ -1079,16 +1125,18 @@ void launch_pcg_init(int dim, int64_t nRows, const double *dinv, const double *b
 
 void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double *Ap, double *r,
                        double *z, double *scal, int it, const double *stopPtr, hipStream_t s) {
-    if (dim == 1) hipLaunchKernelGGL((k_pcg_update<1, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr);
-    else if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr);
-    else hipLaunchKernelGGL((k_pcg_update<2, false>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr);
+    const int grid = grid_for(nRows / 2);   // 2048 workgroups at most: each ends with two atomics on the same two scalars
+    if (dim == 1) hipLaunchKernelGGL((k_pcg_update<1, false>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr);
+    else if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr);
+    else hipLaunchKernelGGL((k_pcg_update<2, false>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr);
     CHECK_LAUNCH();
 }
 
 void launch_pcg_update_noz(int dim, int64_t nRows, const double *Ap, double *r, double *scal, int it,
                            const double *stopPtr, hipStream_t s) {
-    if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, true>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, (const double *)nullptr, Ap, r, (double *)nullptr, scal, it, stopPtr);
-    else hipLaunchKernelGGL((k_pcg_update<2, true>), dim3(grid_for(nRows)), dim3(256), 0, s, nRows, (const double *)nullptr, Ap, r, (double *)nullptr, scal, it, stopPtr);
+    const int grid = grid_for(nRows / 2);
+    if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, true>), dim3(grid), dim3(256), 0, s, nRows, (const double *)nullptr, Ap, r, (double *)nullptr, scal, it, stopPtr);
+    else hipLaunchKernelGGL((k_pcg_update<2, true>), dim3(grid), dim3(256), 0, s, nRows, (const double *)nullptr, Ap, r, (double *)nullptr, scal, it, stopPtr);
     CHECK_LAUNCH();
 }
 
@@ -1188,7 +1236,7 @@ void launch_advance_base(double *stop, int n, hipStream_t s) {
 }
 
 void launch_pcg_direction(int64_t n, const double *z, double *p, double *x, const double *scal, int it, const double *stopPtr, hipStream_t s) {
-    hipLaunchKernelGGL(k_pcg_direction, dim3(grid_for(n)), dim3(256), 0, s, n, z, p, x, scal, it, stopPtr);
+    hipLaunchKernelGGL(k_pcg_direction, dim3(grid_for(n / 2, g_vecGridCap)), dim3(256), 0, s, n, z, p, x, scal, it, stopPtr);
     CHECK_LAUNCH();
 }
 
