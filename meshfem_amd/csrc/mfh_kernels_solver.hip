@@ -889,6 +889,87 @@ __global__ void __launch_bounds__(256) k_cg_update(int64_t nRows, int NR, const 
     }
 }
 
+// The same for ONE right-hand side (the distributed solve's usual case): two consecutive rows per lane, every array in
+// 16-byte accesses (like k_pcg_update).
+template <int DIM, bool SKIPU>
+__global__ void __launch_bounds__(256) k_cg_update1(int64_t nRows, const double *__restrict__ dinv, double *__restrict__ u,
+                                                    const double *__restrict__ w, double *__restrict__ p, double *__restrict__ sv,
+                                                    double *__restrict__ x, double *__restrict__ r, double *scal, int it, const double *ctl) {
+    __shared__ double red[16];
+    constexpr int NS = DIM * (DIM + 1) / 2;
+    it += (int)ctl[0];
+    const double *sc = scal + (int64_t)it * 4;
+    if (sc[2] <= ctl[2]) return;
+    double be = 0.0, al = sc[0] / sc[1];
+    if (it > 0) {
+        const double gp = sc[-4], ap = sc[-4 + 3];
+        be = sc[0] / gp;
+        al = sc[0] / (sc[1] - be * sc[0] / ap);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) scal[(int64_t)it * 4 + 3] = al;
+    double acc[2] = {0, 0};
+    const int64_t nPair = nRows >> 1;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nPair; q += (int64_t)gridDim.x * 256) {
+        double pv[2 * DIM], sn[2 * DIM], xv[2 * DIM], rv[2 * DIM], zv[2 * DIM];
+        const int64_t base = q * 2 * DIM;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            const double2 a = reinterpret_cast<const double2 *>(u + base)[c], b = reinterpret_cast<const double2 *>(w + base)[c],
+                          pp = reinterpret_cast<const double2 *>(p + base)[c], ss = reinterpret_cast<const double2 *>(sv + base)[c],
+                          xx = reinterpret_cast<const double2 *>(x + base)[c], rr = reinterpret_cast<const double2 *>(r + base)[c];
+            pv[2 * c] = a.x + be * pp.x; pv[2 * c + 1] = a.y + be * pp.y;
+            sn[2 * c] = b.x + be * ss.x; sn[2 * c + 1] = b.y + be * ss.y;
+            xv[2 * c] = xx.x + al * pv[2 * c]; xv[2 * c + 1] = xx.y + al * pv[2 * c + 1];
+            rv[2 * c] = rr.x - al * sn[2 * c]; rv[2 * c + 1] = rr.y - al * sn[2 * c + 1];
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            reinterpret_cast<double2 *>(p + base)[c] = make_double2(pv[2 * c], pv[2 * c + 1]);
+            reinterpret_cast<double2 *>(sv + base)[c] = make_double2(sn[2 * c], sn[2 * c + 1]);
+            reinterpret_cast<double2 *>(x + base)[c] = make_double2(xv[2 * c], xv[2 * c + 1]);
+            reinterpret_cast<double2 *>(r + base)[c] = make_double2(rv[2 * c], rv[2 * c + 1]);
+        }
+        if (!SKIPU) {
+            double dm[2 * NS];
+            const double2 *d2 = reinterpret_cast<const double2 *>(dinv + q * 2 * NS);
+#pragma unroll
+            for (int c = 0; c < NS; ++c) { const double2 t = d2[c]; dm[2 * c] = t.x; dm[2 * c + 1] = t.y; }
+            apply_block<DIM>(dm, rv, zv);
+            apply_block<DIM>(dm + NS, rv + DIM, zv + DIM);
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) reinterpret_cast<double2 *>(u + base)[c] = make_double2(zv[2 * c], zv[2 * c + 1]);
+#pragma unroll
+            for (int c = 0; c < 2 * DIM; ++c) acc[0] += rv[c] * zv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < 2 * DIM; ++c) acc[1] += rv[c] * rv[c];
+    }
+    if ((nRows & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // the odd last row
+        const int64_t n = nRows - 1;
+        double rv[DIM], zv[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            const int64_t g = n * DIM + c;
+            const double pv = u[g] + be * p[g], sn = w[g] + be * sv[g];
+            p[g] = pv; sv[g] = sn; x[g] += al * pv;
+            rv[c] = r[g] - al * sn;
+            r[g] = rv[c];
+        }
+        if (!SKIPU) {
+            apply_block<DIM>(dinv + n * NS, rv, zv);
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) { u[n * DIM + c] = zv[c]; acc[0] += rv[c] * zv[c]; }
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) acc[1] += rv[c] * rv[c];
+    }
+    block_sum<2>(acc, red);
+    if (threadIdx.x == 0) {
+        if (!SKIPU) unsafeAtomicAdd(&scal[(int64_t)(it + 1) * 4 + 0], acc[0]);
+        unsafeAtomicAdd(&scal[(int64_t)(it + 1) * 4 + 2], acc[1]);
+    }
+}
+
 // start of the solve: u = D^-1 r, gamma_0 = (r, u), rr_0 = (r, r) into scal[0]
 template <int DIM, bool SKIPU>
 __global__ void __launch_bounds__(256) k_cg_init(int64_t nRows, int NR, const double *__restrict__ dinv, const double *__restrict__ r,
@@ -1269,6 +1350,16 @@ static int pair_grid(int64_t nPairs) { return 3 * (int)std::max<int64_t>(1, std:
 
 void launch_cg_update(int dim, int64_t nRows, int NR, const double *dinv, double *u, const double *w, double *p, double *sv, double *x, double *r,
                       double *scal, int it, const double *ctl, bool skipU, hipStream_t s) {
+    if (NR == 1) {
+        const int g1 = grid_for(nRows / 2);
+#define CALL1(D)                                                                                                                      \
+    if (skipU) hipLaunchKernelGGL((k_cg_update1<D, true>), dim3(g1), dim3(256), 0, s, nRows, dinv, u, w, p, sv, x, r, scal, it, ctl);     \
+    else hipLaunchKernelGGL((k_cg_update1<D, false>), dim3(g1), dim3(256), 0, s, nRows, dinv, u, w, p, sv, x, r, scal, it, ctl)
+        if (dim == 3) { CALL1(3); } else if (dim == 2) { CALL1(2); } else { CALL1(1); }
+#undef CALL1
+        CHECK_LAUNCH();
+        return;
+    }
     const int grid = pair_grid(nRows * NR);
 #define CALL(D)                                                                                                                          \
     if (skipU) hipLaunchKernelGGL((k_cg_update<D, true>), dim3(grid), dim3(256), 0, s, nRows, NR, dinv, u, w, p, sv, x, r, scal, it, ctl); \

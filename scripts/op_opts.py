@@ -1,5 +1,7 @@
-"""Same-process A/B of runtime options of the matrix-free operator: operator alone and classic PCG iteration (min of 3).
-    python scripts/op_opts.py grid option v1 v2 ...      e.g.  python scripts/op_opts.py 60 mf_lane_stride 1 37 1"""
+"""Same-process A/B of runtime options: operator alone and PCG iteration (min of 3), classic loop (pcg_variant 0) unless PCGV is set.
+    python scripts/op_opts.py grid option v1 v2 ...      e.g.  python scripts/op_opts.py 60 mf_lane_stride 1 37 1
+    PCGV=1 python scripts/op_opts.py 60 pcg_variant 1 0   (Chronopoulos-Gear vs classic)"""
+import os
 import sys
 
 sys.path.insert(0, ".")
@@ -7,6 +9,7 @@ import meshfem_amd as M
 from meshfem_amd import grid
 
 n, opt, vals = int(sys.argv[1]), sys.argv[2], [float(v) for v in sys.argv[3:]]
+pre = int(os.environ.get("PRECOND", "0"))
 V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
 c = M.Context(0)
 c.mesh_build(T, V, 2)
@@ -17,6 +20,9 @@ c.assemble()
 f = c.neumann_load().ravel()
 vars_, vals_ = c.bc_dirichlet_vars()
 c.fix_variables(vars_, vals_)
+c.set_preconditioner(pre)
+if "PCGV" in os.environ:
+    c.set_option("pcg_variant", int(os.environ["PCGV"]))
 for v in vals:
     c.set_option(opt, v)
     ops = [c.time_spmv_kernel(50) for _ in range(3)]
