@@ -416,7 +416,9 @@ mfh_status mfh_matrix_free_info(mfh_ctx* ctx, int32_t* active, int32_t* mode, in
  * "pcg_graph" (1 default: blocks of check_every PCG iterations are replayed from a hipGraph),
  * "pcg_variant" (1: Chronopoulos-Gear PCG, one reduction point per iteration and one fused vector kernel -- always used by
  *   mfh_dist_solve and for batches; 0: the classic two-reduction PCG, one right-hand side at a time; -1 default: classic for
- *   a single right-hand side on an unpartitioned context, where it is 6-14 % faster per iteration), "batch_rhs" (0 default:
+ *   a single right-hand side on an unpartitioned context, where it is 6-14 % faster per iteration), "dist_pcg_variant"
+ *   (mfh_dist_solve with one right-hand side: 1 default = Chronopoulos-Gear, ONE all-reduce per iteration; 0 = classic loop, two
+ *   all-reduces and one vector pass less -- which is faster depends on the node's all-reduce latency), "batch_rhs" (0 default:
  *   1 solves several right-hand sides per operator pass, see mfh_solve_batch),
  * "solve_homogeneous" (1: mfh_solve treats the fixed variables as fixed to ZERO whatever values were given -- the
  *   homogeneous solves K y = C^T of a Schur-complement elimination of constraint rows, SparseMatrices.hh:2572-2590),

@@ -749,6 +749,7 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
     MFH_HIP(hipMemcpyAsync(u, c->wx.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
     MFH_HIP(hipStreamSynchronize(s));
     if (info) *info = li;
+    check_residual_gap(li, rtol);
 }
 
 void box_corners(mfh_ctx *c, const double *mn, const double *mx, int relative, double *omn, double *omx) {
@@ -1696,6 +1697,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "vec_grid_cap") k::g_vecGridCap = std::max(256, (int)value);
     else if (k2 == "mf_lane_stride") c->mfLaneStride = std::max(1, (int)value);
     else if (k2 == "mf_reorder") { c->mfReorder = value != 0; c->mfcValid = false; c->mfClusterUnfit = false; }
+    else if (k2 == "dist_pcg_variant") c->distPcgVariant = value != 0 ? 1 : 0;
     else if (k2 == "pcg_variant") c->pcgVariant = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k2 == "batch_rhs") c->batchRhs = value != 0;
     else if (k2 == "matrix_free_mode") { c->mfMode = (int)value; c->mfClusterUnfit = false; }

@@ -129,6 +129,8 @@ struct mfh_ctx {
     int pcgVariant = -1;              // option "pcg_variant": 1 = Chronopoulos-Gear, 0 = classic PCG, -1 (default) = classic for one
                                       // right-hand side on an unpartitioned context (measured 6-14 % faster per iteration there: one
                                       // vector pass fewer), Chronopoulos-Gear for batches and row-partitioned contexts
+    int distPcgVariant = 1;           // option "dist_pcg_variant": 1 = Chronopoulos-Gear (one all-reduce per iteration, default), 0 = classic
+                                      // (two all-reduces, one vector pass less per iteration)
     bool batchRhs = false;            // option "batch_rhs": several right-hand sides per operator pass (measured slower than one at a time)
     // row-partitioned solve (mfh_dist_setup)
     struct Dist {
@@ -221,6 +223,16 @@ struct EventTimer {
 inline void require_device(const mfh_ctx *c) {
     if (c->hostOnly)
         throw Error(MFH_ERR_HIP, "host-only context (device -1): no HIP device, and there is no CPU fallback");
+}
+
+// The recurrence residual of CG can drift away from the true one (a singular system with an inconsistent right-hand side: the
+// iterate grows along the null space, the recursively updated r keeps shrinking): "converged" then means nothing. CHOLMOD
+// would have refused such a matrix; report it instead of returning garbage.
+inline void check_residual_gap(const mfh_solve_info &li, double rtol) {
+    if (li.converged && li.true_rel_residual > std::max(1000.0 * rtol, 1e-4))
+        throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (residual gap): the recurrence residual reached " + std::to_string(li.rel_residual) +
+                                               " but the true residual ||f - K u|| / ||f|| is " + std::to_string(li.true_rel_residual) +
+                                               ": K is singular on the free variables with an inconsistent right-hand side, or too ill-conditioned");
 }
 
 inline int32_t dof_of(const mfh_ctx *c, int64_t node) { return c->dofForNode.empty() ? (int32_t)node : c->dofForNode[node]; }

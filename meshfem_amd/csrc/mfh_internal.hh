@@ -336,6 +336,7 @@ struct SpmvArgs {
     int chunkSlots;
     const uint8_t *fixedMask;           // per scalar row, may be null
     int xcd;                            // 1: XCD-contiguous chunk ranges (xcd_span)
+    int pcgMode;                        // launch_spmv_nr with one vector: 0 = by ctl (none / Chronopoulos-Gear), 1 = classic PCG bookkeeping
 };
 // Matrix-free operator: y = K x without reading the assembled K. One lane per (element, local node i) pair:
 // it evaluates the npe blocks K_e[i][j] in registers and applies them to the gathered x_j; pairs are grouped by
@@ -369,6 +370,7 @@ struct SpmvMfArgs {
     const uint8_t *fixedMask;           // per scalar row, may be null
     const int32_t *clElemPtr;           // cluster variant: block b holds the elements [clElemPtr[b], clElemPtr[b+1]) of the operator's order (null: clBlockElems each)
     const int32_t *clElemPerm;          // cluster variant: original element of the operator's element e (null: identity); elemNodes is then in the new order
+    int pcgMode;                        // launch_mf_*_nr with one vector: 0 = by ctl (none / Chronopoulos-Gear), 1 = classic PCG bookkeeping
     int clLaneStride;                   // lane t of a block takes element (t * stride) % blockElems (1: identity); coprime to blockElems
     const double *vertPos;              // cluster variant, constant material: corner positions [nVert][dim]; gradients recomputed (null: read the records)
 };

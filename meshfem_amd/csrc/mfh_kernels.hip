@@ -2051,7 +2051,7 @@ bool op_batch_supported(int dim, int nr) { return nr == 1 || (dim == 3 && (nr ==
 void launch_mf_cluster_nr(const SpmvMfArgs &a, int NR, const double *x, double *y, double *dotOut, double *scal, int it, const double *ctl,
                           const int32_t *blockList, int64_t nList, hipStream_t s) {
     if (nList <= 0) return;
-    if (NR == 1) { launch_mf_cluster_mode(a, ctl ? 2 : 0, x, y, dotOut, scal, it, ctl, blockList, nList, s); return; }
+    if (NR == 1) { launch_mf_cluster_mode(a, a.pcgMode ? a.pcgMode : (ctl ? 2 : 0), x, y, dotOut, scal, it, ctl, blockList, nList, s); return; }
     const int nrs = cluster_nrs(a.dim, NR);
     const size_t ldsC = ((size_t)2 * a.clMaxLocal * a.dim * nrs + 8) * sizeof(double);
     const int gridC = (int)std::min<int64_t>(nList, 256 * 64);
@@ -2075,7 +2075,7 @@ void launch_mf_cluster_nr(const SpmvMfArgs &a, int NR, const double *x, double *
 
 void launch_mf_rows_nr(const SpmvMfArgs &a, int NR, const double *x, double *y, double *dotOut, double *scal, int it, const double *ctl, hipStream_t s) {
     if (a.nChunk == 0) return;
-    if (NR == 1) { launch_mf_rows_mode(a, ctl ? 2 : 0, x, y, dotOut, scal, it, ctl, s); return; }
+    if (NR == 1) { launch_mf_rows_mode(a, a.pcgMode ? a.pcgMode : (ctl ? 2 : 0), x, y, dotOut, scal, it, ctl, s); return; }
     const int nrs = cluster_nrs(a.dim, NR);
     const size_t lds = ((size_t)a.maxRows * a.dim * nrs + 8) * sizeof(double);
     const int grid = persistent_grid(a.nChunk, 256 * 8);
@@ -2092,7 +2092,7 @@ void launch_mf_rows_nr(const SpmvMfArgs &a, int NR, const double *x, double *y, 
 void launch_spmv_nr(const SpmvArgs &a, int NR, const double *x, double *y, double *dotOut, double *scal, int it, const double *ctl,
                     const int32_t *chunkList, int64_t nList, hipStream_t s) {
     if (nList <= 0) return;
-    if (NR == 1) { launch_spmv_mode(a, ctl ? 2 : 0, x, y, dotOut, scal, it, ctl, chunkList, nList, s); return; }
+    if (NR == 1) { launch_spmv_mode(a, a.pcgMode ? a.pcgMode : (ctl ? 2 : 0), x, y, dotOut, scal, it, ctl, chunkList, nList, s); return; }
     const int nrs = a.dim == 1 ? (NR == 6 ? 3 : NR) : cluster_nrs(a.dim, NR);
     const size_t lds = ((size_t)a.dim * nrs * a.chunkSlots + 8) * sizeof(double);
     const int grid = persistent_grid(nList, 256 * 8);

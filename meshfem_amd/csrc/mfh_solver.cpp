@@ -207,12 +207,14 @@ void ensure_overlap_lists(mfh_ctx *c, bool cluster) {
 
 // y = K x for NR interleaved vectors. With an active communicator the halo part of x is exchanged first, overlapped with
 // the interior blocks / chunks. dotOut (stride 4) or the PCG bookkeeping (scal, it, ctl) as in the kernels.
-void apply_op_nr(mfh_ctx *c, DistLink &L, int NR, double *x, double *y, bool masked, double *dotOut, double *scal, int it, const double *ctl) {
+void apply_op_nr(mfh_ctx *c, DistLink &L, int NR, double *x, double *y, bool masked, double *dotOut, double *scal, int it, const double *ctl,
+                 int pcgMode = 0) {
     hipStream_t s = c->stream;
     const bool cluster = cluster_operator(c);
     const int W = NR * c->bs();
     if (cluster) {
-        const k::SpmvMfArgs a = spmv_mf_cluster_args(c, masked);
+        k::SpmvMfArgs a = spmv_mf_cluster_args(c, masked);
+        a.pcgMode = pcgMode;
         if ((size_t)std::max<int64_t>(c->mfc.nIface, 1) * W > c->mfcDev.ifaceBuf.n) throw Error(MFH_ERR_STATE, "interface buffer too small for this batch");
         if (L.active) {
             ensure_overlap_lists(c, true);
@@ -224,7 +226,8 @@ void apply_op_nr(mfh_ctx *c, DistLink &L, int NR, double *x, double *y, bool mas
             k::launch_mf_cluster_nr(a, NR, x, y, dotOut, scal, it, ctl, nullptr, c->mfc.nBlocks, s);
         k::launch_mf_rows_nr(a, NR, x, y, dotOut, scal, it, ctl, s);
     } else {
-        const k::SpmvArgs a = spmv_args(c, masked);
+        k::SpmvArgs a = spmv_args(c, masked);
+        a.pcgMode = pcgMode;
         if (L.active) {
             ensure_overlap_lists(c, false);
             L.halo_begin(x, W);
@@ -424,6 +427,133 @@ void solve_cg(mfh_ctx *c, int NR, const double *f, double *u, int64_t fStride, d
         li.reserved = NR;
         if (infos) infos[k2] = li;
     }
+    for (int k2 = 0; k2 < NR; ++k2) {
+        mfh_solve_info li{};
+        li.converged = itConv[k2] >= 0 ? 1 : 0;
+        li.rel_residual = bb[k2] > 0 ? std::sqrt(rrFinal[k2] / bb[k2]) : 0.0;
+        li.true_rel_residual = bb[k2] > 0 ? std::sqrt(tr[k2] / bb[k2]) : 0.0;
+        check_residual_gap(li, rtol);
+    }
+}
+
+// The CLASSIC PCG (two reduction points) on a row-partitioned context, one right-hand side: the same kernels as the
+// single-GPU classic loop (one vector pass less per iteration than Chronopoulos-Gear, 0.945 vs 1.089 ms at config 3), at the
+// price of a second all-reduce per iteration (p.Ap after the operator; {r.z, r.r} after the preconditioner). Which loop is
+// faster on N GPUs depends on the node's all-reduce latency: option "dist_pcg_variant" selects, bench.py measures both.
+void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info) {
+    RoctxRange range("Elasticity Solve");
+    const int d = c->bs();
+    const int64_t nRows = c->sym.nRows, nCols = c->sym.nCols, nOwn = nRows * d, nAll = nCols * d;
+    hipStream_t s = c->stream;
+    DistLink L(c);
+    EventTimer tsetup(s);
+    c->cgU.alloc(nAll);                                   // p (with its halo part)
+    c->wx.alloc(nOwn); c->wr.alloc(nOwn); c->wz.alloc(nOwn); c->wAp.alloc(nOwn); c->wf.alloc(nOwn);
+    c->stop.alloc(4);
+    c->cgCtl.alloc(16);
+    const bool masked = !c->fixedVars.empty();
+    if (cluster_operator(c) && c->mfcDev.ifaceBuf.n < (size_t)std::max<int64_t>(c->mfc.nIface, 1) * d) c->mfcDev.ifaceBuf.alloc((size_t)std::max<int64_t>(c->mfc.nIface, 1) * d);
+    if (L.active) c->dist.sendBufW = std::max(c->dist.sendBufW, d);
+    double *p = c->cgU.p;
+    MFH_HIP(hipMemcpyAsync(c->wf.p, f, (size_t)nOwn * sizeof(double), hipMemcpyHostToDevice, s));
+    MFH_HIP(hipMemcpyAsync(c->wr.p, c->wf.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToDevice, s));
+    if (c->anyFixedNonzero && !c->solveHomogeneous) {     // b = f - K ubar (SparseMatrices.hh:2457-2470,2526-2535)
+        c->cgU.zero(s);
+        k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, p, s);
+        apply_op_nr(c, L, 1, p, c->wAp.p, false, nullptr, nullptr, 0, nullptr);
+        k::launch_axpby(nOwn, -1.0, c->wAp.p, 1.0, c->wr.p, s);
+    }
+    if (masked) k::launch_mask(nOwn, c->dFixedMask.p, c->wr.p, s);
+    double bb = 0;
+    MFH_HIP(hipMemsetAsync(c->cgCtl.p, 0, 16 * sizeof(double), s));
+    k::launch_dot(nOwn, c->wr.p, c->wr.p, c->cgCtl.p + 8, s);
+    L.allreduce(c->cgCtl.p + 8, 1);
+    MFH_HIP(hipMemcpyAsync(&bb, c->cgCtl.p + 8, sizeof(double), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    const size_t scalN = ((size_t)maxit + (size_t)c->checkEvery + 2) * 4;
+    c->scal.alloc(scalN);
+    c->scal.zero(s);
+    const double stopv = rtol * rtol * bb;
+    MFH_HIP(hipMemsetAsync(c->stop.p, 0, 4 * sizeof(double), s));
+    MFH_HIP(hipMemcpyAsync(c->stop.p, &stopv, sizeof(double), hipMemcpyHostToDevice, s));
+    mfh_solve_info li{};
+    li.setup_ms = tsetup.stop();
+    li.reserved = 1;
+    int itDone = 0;
+    double rrFinal = 0;
+    if (bb == 0.0) { c->wx.zero(s); li.converged = 1; }
+    else {
+        EventTimer tsolve(s);
+        const bool useTL = c->precond == MFH_PRECOND_TWO_LEVEL && c->tl.valid && !c->tlSuppress;
+        double *scal = c->scal.p;
+        auto &T = c->tl;
+        auto tl_pre = [&](int it) {     // z = M^-1 r, r.z into scal[(it + 1) 4]; the restricted residual summed over the ranks
+            const k::TLArgs ta = tl_args(c);
+            k::launch_tl_restrict(ta, T.aggPtr.p, T.dofsByAgg.p, c->wr.p, T.rc.p, s);
+            L.allreduce(T.rc.p, T.m);
+            k::launch_tl_gemv(T.m, T.ldInv, T.Ainv.p, T.rc.p, T.yc.p, s);
+            k::launch_tl_apply(ta, c->dDinv.p, c->wr.p, T.yc.p, c->wz.p, scal, it, c->stop.p, s);
+        };
+        // x = 0, r = b, z = D^-1 r, p = z; {r.z, r.r}_0
+        MFH_HIP(hipMemsetAsync(p, 0, (size_t)nAll * sizeof(double), s));
+        MFH_HIP(hipMemcpyAsync(c->wAp.p, c->wr.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToDevice, s));
+        k::launch_pcg_init(d, nRows, c->dDinv.p, c->wAp.p, c->wx.p, c->wr.p, c->wz.p, p, scal, s);
+        if (useTL) {
+            MFH_HIP(hipMemsetAsync(scal, 0, sizeof(double), s));
+            tl_pre(-1);
+            MFH_HIP(hipMemcpyAsync(p, c->wz.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        L.allreduce(scal, 3);
+        std::vector<double> hs;
+        int it = 0, lastChecked = 0;
+        bool done = false;
+        while (!done && it < maxit) {
+            const int itEnd = std::min(maxit, it + c->checkEvery);
+            for (; it < itEnd; ++it) {
+                apply_op_nr(c, L, 1, p, c->wAp.p, masked, nullptr, scal, it, c->stop.p, 1);     // Ap, p.Ap (first reduction point)
+                L.allreduce(scal + (size_t)it * 4 + 1, 1);
+                if (useTL) { k::launch_pcg_update_noz(d, nRows, c->wAp.p, c->wr.p, scal, it, c->stop.p, s); tl_pre(it); }
+                else k::launch_pcg_update(d, nRows, c->dDinv.p, c->wAp.p, c->wr.p, c->wz.p, scal, it, c->stop.p, s);
+                L.allreduce(scal + (size_t)(it + 1) * 4, 3);                                    // {r.z, -, r.r} (second reduction point)
+                k::launch_pcg_direction(nOwn, c->wz.p, p, c->wx.p, scal, it, c->stop.p, s);
+            }
+            hs.resize((size_t)(it - lastChecked + 1) * 4);
+            MFH_HIP(hipMemcpyAsync(hs.data(), scal + (size_t)lastChecked * 4, hs.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+            MFH_HIP(hipStreamSynchronize(s));
+            for (int k2 = lastChecked; k2 <= it; ++k2) {
+                const double rr = hs[(size_t)(k2 - lastChecked) * 4 + 2];
+                if (rr <= stopv) { done = true; itDone = k2; rrFinal = rr; break; }
+                if (!(rr == rr)) throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (NaN residual): K is not SPD on the free variables");
+                const double pAp = hs[(size_t)(k2 - lastChecked) * 4 + 1];
+                if (k2 < it && pAp < 0.0) throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (p.Kp < 0): K is not positive definite on the free variables");
+            }
+            if (!done) { itDone = it; rrFinal = hs[(size_t)(it - lastChecked) * 4 + 2]; }
+            lastChecked = it;
+        }
+        li.solve_ms = tsolve.stop();
+        li.converged = done ? 1 : 0;
+    }
+    li.iterations = itDone;
+    li.rel_residual = bb > 0 ? std::sqrt(rrFinal / bb) : 0.0;
+    if (masked && !c->solveHomogeneous) k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wx.p, s);
+    if (bb > 0) {   // true residual on the free variables
+        MFH_HIP(hipMemcpyAsync(p, c->wx.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToDevice, s));
+        if (nAll > nOwn && masked && !c->solveHomogeneous) k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, p, s);
+        apply_op_nr(c, L, 1, p, c->wAp.p, false, nullptr, nullptr, 0, nullptr);
+        k::launch_axpby(nOwn, 1.0, c->wf.p, -1.0, c->wAp.p, s);
+        if (masked) k::launch_mask(nOwn, c->dFixedMask.p, c->wAp.p, s);
+        MFH_HIP(hipMemsetAsync(c->cgCtl.p + 8, 0, sizeof(double), s));
+        k::launch_dot(nOwn, c->wAp.p, c->wAp.p, c->cgCtl.p + 8, s);
+        L.allreduce(c->cgCtl.p + 8, 1);
+        double tr = 0;
+        MFH_HIP(hipMemcpyAsync(&tr, c->cgCtl.p + 8, sizeof(double), hipMemcpyDeviceToHost, s));
+        MFH_HIP(hipStreamSynchronize(s));
+        li.true_rel_residual = std::sqrt(tr / bb);
+    }
+    MFH_HIP(hipMemcpyAsync(u, c->wx.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    if (info) *info = li;
+    check_residual_gap(li, rtol);
 }
 
 // one right-hand side: the Chronopoulos-Gear loop when the operator in use has a batched kernel, else the classic PCG
@@ -623,7 +753,8 @@ mfh_status mfh_dist_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, 
         if (c->batchRhs)
             for (int cand : {6, 3, 2})
                 if (cand <= nrhs - k0 && k::op_batch_supported(c->bs(), cand)) { nb = cand; break; }
-        solve_cg(c, nb, f + (size_t)k0 * n, u + (size_t)k0 * n, n, rtol, maxit, infos.data() + k0);
+        if (nb == 1 && c->distPcgVariant == 0) solve_classic_partitioned(c, f + (size_t)k0 * n, u + (size_t)k0 * n, rtol, maxit, infos.data() + k0);
+        else solve_cg(c, nb, f + (size_t)k0 * n, u + (size_t)k0 * n, n, rtol, maxit, infos.data() + k0);
         k0 += nb;
     }
     bool all = true;

@@ -54,8 +54,18 @@ def _worker(rank, world, port, n, ret):
         Ku = solver.apply_K(u1[0])
         free = np.ones(3 * lm.n_owned, bool); free[ov] = False
         assert np.linalg.norm((Ku - f)[free]) <= 1e-8 * np.linalg.norm(f)
+        # the classic loop (two all-reduces per iteration) gives the same solution as Chronopoulos-Gear (one)
+        c.set_option("dist_pcg_variant", 0)
+        u1c, i1c = solver.solve(f, rtol=1e-10, maxit=20000)
+        assert i1c[0]["converged"] and np.linalg.norm(u1c[0] - u1[0]) <= 1e-8 * np.linalg.norm(u1[0])
+        assert abs(i1c[0]["iterations"] - i1[0]["iterations"]) <= max(3, 0.05 * i1[0]["iterations"])
+        c.set_option("dist_pcg_variant", 1)
         tl = solver.two_level(16 * world)
         u2, i2 = solver.solve(f, rtol=1e-10, maxit=20000)
+        c.set_option("dist_pcg_variant", 0)
+        u2c, i2c = solver.solve(f, rtol=1e-10, maxit=20000)
+        assert i2c[0]["converged"] and np.linalg.norm(u2c[0] - u2[0]) <= 1e-8 * np.linalg.norm(u2[0])
+        c.set_option("dist_pcg_variant", 1)
         # three right-hand sides at once (batch of 2 + 1): scaled copies of the load
         F3 = np.stack([f, -2.0 * f, 0.5 * f])
         c.set_option("batch_rhs", 1)
