@@ -574,6 +574,25 @@ def _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out, group=None):
                       algorithm="Chronopoulos-Gear PCG in the library (mfh_dist_solve): packed halo exchange overlapped with the interior "
                                 "element blocks + %d all-reduce / iteration" % (2 if tl_info else 1),
                       transport=comm.describe(), ranks=world)
+    # the same solve with the classic loop (two dependent all-reduces per iteration, lighter vector kernels): which of the two
+    # wins depends on the all-reduce latency of the transport, so the scaling run records both
+    try:
+        c.set_option("dist_pcg_variant", 0)
+        if world > 1:
+            dist.barrier(group=group)
+        try:
+            _, infos2 = solver.solve(f, rtol=args.rtol, maxit=maxit)
+            i2 = infos2[0]
+        except L.MeshFEMHipError as e:
+            if e.code != L.ERR_NOT_CONVERGED:
+                raise
+            i2 = c.last_info
+        ts2 = red([i2["solve_ms"] * 1e-3], dist.ReduceOp.MAX)[0]
+        out["pcg"]["classic_two_reductions"] = dict(iterations=i2["iterations"], converged=bool(i2["converged"]), solve_s=float(ts2),
+                                                     ms_per_iteration=float(ts2) / max(1, i2["iterations"]) * 1e3,
+                                                     true_rel_residual=i2["true_rel_residual"])
+    finally:
+        c.set_option("dist_pcg_variant", 1)
     comm.close()
 
 
