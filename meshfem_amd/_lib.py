@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmeshfem_hip.so")
+LIB_PATH = os.environ.get("MESHFEM_HIP_LIB") or os.path.join(_HERE, "libmeshfem_hip.so")   # override: A/B runs of two builds of the library
 
 OK, ERR_INVALID, ERR_STATE, ERR_HIP, ERR_NOT_CONVERGED, ERR_UNSUPPORTED = range(6)
 ASSEMBLE_GATHER, ASSEMBLE_ATOMIC = 0, 1

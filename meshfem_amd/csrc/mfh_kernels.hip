@@ -278,19 +278,21 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
             code[u] = ok[u] ? a.contribCode[kk] : a.contribCode[kb];
             ls[u] = (ok[u] ? (int)a.contribSlot[kk] : 0) + par;
         }
-        double K[U][NB];
+        // the element records are fetched one contribution after the other (sched_barrier): a record is 30+ VGPRs of loads in
+        // flight, and two at a time cost more in occupancy than they hide in latency (iso P2: 99 VGPRs / 5 waves per SIMD
+        // 6.4 ms against 64 VGPRs / 8 waves 5.1 ms; the anisotropic flavours drop from 168 / 129 to 100 / 80 VGPRs)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
+            double K[NB];
             const uint32_t e = code[u] / (NPE * NPE);
             const int ij = (int)(code[u] - e * (NPE * NPE));
             const int i = ij / NPE, j = ij - i * NPE;
-            elem_block<DIM, DEG, MAT>(a.geo + (int64_t)e * a.geoStride, MAT == MAT_MASS ? a.massTable : a.pairTable, pc, i, j, K[u]);
-        }
+            elem_block<DIM, DEG, MAT>(a.geo + (int64_t)e * a.geoStride, MAT == MAT_MASS ? a.massTable : a.pairTable, pc, i, j, K);
+            if (ok[u]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (!ok[u]) continue;
-#pragma unroll
-            for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&acc[c * CS + ls[u]], K[u][c]);
+                for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&acc[c * CS + ls[u]], K[c]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
