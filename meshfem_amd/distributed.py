@@ -15,6 +15,10 @@ The reference has no distributed code: this module has no 
 beyond the serial path it parallelises (LinearElasticity.hh:479-487, SparseMatrices.hh:2515-2606).
 """
 import ctypes
+import json
+import os
+import sys
+import threading
 import time
 
 import numpy as np
@@ -226,11 +230,15 @@ class Comm:
                 ctx.dev_memcpy(buf.ctypes.data, ptr, 8 * n, 1, stream)
             return buf
 
+        # a nccl process group moves device tensors only: the staged buffers take one more hop through torch's allocator
+        on_gpu = dist.is_initialized() and dist.get_backend(group) == "nccl"
+        up = (lambda t: t.cuda()) if on_gpu else (lambda t: t)
+
         def allreduce(user, dev, n, stream):
             try:
-                t = torch.from_numpy(d2h(dev, n, stream))
+                t = up(torch.from_numpy(d2h(dev, n, stream)))
                 dist.all_reduce(t, group=group)
-                ctx.dev_memcpy(dev, t.numpy().ctypes.data, 8 * n, 0, stream)
+                ctx.dev_memcpy(dev, t.cpu().numpy().ctypes.data, 8 * n, 0, stream)
                 return 0
             except Exception as e:   # noqa: BLE001 -- a Python exception must not cross the C boundary
                 print("mfh_comm allreduce callback failed: %r" % (e,), flush=True)
@@ -241,18 +249,18 @@ class Comm:
                 ops, recvs, keep = [], [], []
                 for k in range(n_peers):
                     if send_counts[k] > 0:
-                        t = torch.from_numpy(d2h(send_bufs[k], send_counts[k], stream))
+                        t = up(torch.from_numpy(d2h(send_bufs[k], send_counts[k], stream)))
                         keep.append(t)
                         ops.append(dist.P2POp(dist.isend, t, int(peers[k]), group=group))
                     if recv_counts[k] > 0:
-                        t = torch.empty(recv_counts[k], dtype=torch.float64)
+                        t = up(torch.empty(recv_counts[k], dtype=torch.float64))
                         recvs.append((recv_bufs[k], t))
                         ops.append(dist.P2POp(dist.irecv, t, int(peers[k]), group=group))
                 if ops:
                     for r in dist.batch_isend_irecv(ops):
                         r.wait()
                 for ptr, t in recvs:
-                    ctx.dev_memcpy(ptr, t.numpy().ctypes.data, 8 * t.numel(), 0, stream)
+                    ctx.dev_memcpy(ptr, t.cpu().numpy().ctypes.data, 8 * t.numel(), 0, stream)
                 return 0
             except Exception as e:   # noqa: BLE001
                 print("mfh_comm exchange callback failed: %r" % (e,), flush=True)
@@ -667,8 +675,27 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
     if not args.no_solve:
         # The assembly figures above are the headline metric; a failure of the solver leg (it is the only part that
         # depends on the interconnect) must not lose them: it is reported inside the JSON line instead.
+        # ... and neither must a hang: every rank arms the same timer; when it fires, rank 0 prints the line with the assembly
+        # figures and the reason, and every rank leaves.
+        limit = float(os.environ.get("MFH_BENCH_SOLVE_TIMEOUT_S", "420"))
+
+        def expired():
+            if not (isinstance(out.get("pcg"), dict) and "error" in out["pcg"]):
+                out["pcg"] = dict(error="the solver leg did not finish within %.0f s (collective / interconnect hang?); the assembly "
+                                        "figures of this line are complete" % limit)
+            if rank == 0:
+                sys.stdout.write(json.dumps(out) + "\n")
+                sys.stdout.flush()
+            os._exit(0)
+
+        timer = threading.Timer(limit, expired)
+        timer.daemon = True
+        timer.start()
         try:
             _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out)
+            timer.cancel()
         except Exception as e:   # noqa: BLE001
+            # the timer stays armed: the other ranks may be stuck in a collective this rank left, and so will this rank's
+            # closing barrier be
             out["pcg"] = dict(error="%s: %s" % (type(e).__name__, e))
     return out

@@ -207,3 +207,41 @@ def test_rccl_communicator_world_1():
     assert np.linalg.norm(u[0].reshape(-1, 3) - u_ref[idx]) / np.linalg.norm(u_ref) < 1e-7
     comm.close()
     c.close()
+
+
+def test_callback_communicator_over_a_nccl_process_group_world_1():
+    """The fallback transport when torch.distributed runs on nccl (= RCCL): the callbacks stage the library's device buffers
+    through DEVICE tensors (a nccl group moves nothing else). World size 1: the all-reduce path of a partitioned solve."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import meshfem_amd as M
+    from meshfem_amd import distributed as D
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        n = 4
+        lm = D.slab_local_mesh(n, 0, 1, 2)
+        c = M.Context(0)
+        c.mesh_set(3, 2, lm.elem_nodes, lm.node_pos, lm.n_owned)
+        c.material_isotropic(200.0, 0.35)
+        c.assemble()
+        comm = D.make_comm(c, 0, 1, prefer="callbacks")
+        assert "callbacks" in comm.describe()
+        comm.selftest()
+        solver = D.DistSolver(c, lm, 0, 1, comm)
+        fixed = np.flatnonzero(lm.lattice[:, 0] == 0)
+        c.fix_variables((3 * fixed[:, None] + np.arange(3)[None, :]).ravel())
+        f = D.slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel()
+        u, infos = solver.solve(f, rtol=1e-10)
+        assert infos[0]["converged"] and infos[0]["true_rel_residual"] < 1e-9
+        c.set_option("dist_pcg_variant", 0)
+        u2, infos2 = solver.solve(f, rtol=1e-10)
+        assert np.linalg.norm(u2 - u) < 1e-8 * np.linalg.norm(u)
+        comm.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
