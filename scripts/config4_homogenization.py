@@ -38,4 +38,4 @@ if len(res) == 2:
 # Voigt-average bound: Ch <= volume average of C (in the Loewner order); check the diagonal
 print(json.dumps({k: v for k, v in out.items() if k not in ("two_level", "block_jacobi")}))
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/config4_r01.json", "w"))
+json.dump(out, open("gpurun_out/config4_r02.json", "w"))
