@@ -646,6 +646,17 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
     sizes = c.symbolic_sizes()
     comp = int(nnzb * 72 + nE_loc * 128 + sizes["n_contrib"] * 6 + sizes["n_chunk"] * 12 + nr * 4)
     k_ms_max = max_over_ranks(k_ms)
+    # HBM traffic of the assembly kernel on a rank's slab: from the committed rocprofv3 --pmc profile of the same local shape
+    # (scripts/pmc_collect.py <grid> slab:<world>:<rank>, collected on one GPU: the assembly has no communication)
+    traffic, traffic_src = None, None
+    prof = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r02_pmc_traffic_slab_w%d.json" % world)
+    if rank == 0 and os.path.exists(prof):
+        try:
+            pj = json.load(open(prof))
+            if abs(pj["meta"]["elems"] - nE_loc) <= 0.02 * nE_loc and pj["meta"]["n"] == args.grid and deg == 2:
+                traffic, traffic_src = pj["k_assemble_gather"]["traffic_bytes"] * (nE_loc / float(pj["meta"]["elems"])), "profiles/" + os.path.basename(prof)
+        except (OSError, KeyError, ValueError):
+            pass
     rccl_ranks = None
     if not shared_gpus:
         # proof that the collective library saw every rank: an all-reduce of ones over the process group
@@ -667,8 +678,10 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
                roofline=dict(bound="hbm", kernel="k_assemble_gather", achieved=alg * nE_loc / k_ms / 1e6, peak=8000.0,
                              unit="GB/s", frac=alg * nE_loc / k_ms / 1e6 / 8000.0, kernel_ms=k_ms, kernel_ms_max_over_ranks=k_ms_max,
                              compulsory_bytes=comp, frac_compulsory=comp / k_ms / 1e6 / 8000.0,
-                             traffic=None, traffic_note="PMC counters are collected per shape in their own rocprofv3 passes (profiles/); "
-                                                        "none is committed for this slab shape: see frac_compulsory",
+                             traffic=(traffic / k_ms / 1e6) if traffic else None, frac_traffic=(traffic / k_ms / 1e6 / 8000.0) if traffic else None,
+                             traffic_bytes_per_launch_from_profile=traffic, traffic_from_profile=traffic_src,
+                             traffic_note="PMC counters are collected per shape in their own rocprofv3 passes on ONE GPU (the assembly has no "
+                                          "communication); committed for the default grid at 2 and 8 ranks (a middle rank's slab), else null",
                              note="rank 0's local launch (its elements incl. the halo layer); frac = SURVEY 8(d) algorithmic bytes (contract), "
                                   "frac_compulsory = bytes the design must move (K once + records + lists)"),
                setup=dict(local_mesh_s=t_mesh, symbolic_s=t_sym))

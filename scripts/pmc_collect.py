@@ -6,13 +6,14 @@ import csv, glob, json, os, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+slab = sys.argv[2] if len(sys.argv) > 2 else ""        # "slab:WORLD:RANK" (see pmc_probe.py)
 out_dir = os.path.join(ROOT, "gpurun_out", "pmc")
 os.makedirs(out_dir, exist_ok=True)
 raw, meta = {}, None
 for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     d = os.path.join(out_dir, counter)
     cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "pmc", "--", sys.executable,
-           os.path.join(ROOT, "scripts", "pmc_probe.py"), str(n)]
+           os.path.join(ROOT, "scripts", "pmc_probe.py"), str(n)] + ([slab] if slab else [])
     r = subprocess.run(cmd, capture_output=True, text=True, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=900)
     for line in r.stdout.splitlines():
         if line.startswith("{"):
@@ -33,16 +34,19 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
 true_b = 8.0 * meta["calib_axpby_doubles"]
 cal_f = raw["FETCH_SIZE"]["k_axpby"]["avg_KB"] * 1024 / true_b
 cal_w = raw["WRITE_SIZE"]["k_axpby"]["avg_KB"] * 1024 / true_b
-res = dict(workload="%d^3 grid, %d P2 tets" % (n, meta["elems"]), meta=meta, raw=raw,
+res = dict(workload=("%d^3 grid, %d P2 tets" % (n, meta["elems"])) if not slab else ("%s of a %s grid, %d local P2 tets" % (slab, meta["global_grid"], meta["elems"])), meta=meta, raw=raw,
            calibration=dict(kernel="k_axpby(b=0): reads 8n, writes 8n bytes, n=%d" % meta["calib_axpby_doubles"],
                             fetch_reported_over_true=cal_f, write_reported_over_true=cal_w,
                             note="gfx950 FETCH_SIZE reports ~1/2 of coalesced read bytes (MI355X_MICROARCH.md, HBM section); corrected by the measured factor"))
 # keys = kernel names without template arguments (those changed between rounds; r01 profiles carry the r01 spellings)
 names = {"k_assemble_gather": "k_assemble_gather", "k_spmv": "k_spmv", "k_mf_cluster": "k_mf_cluster", "k_mf_rows": "k_mf_rows"}
 for k, full in names.items():
+    if k not in raw["FETCH_SIZE"]:
+        continue
     fb = raw["FETCH_SIZE"][k]["avg_KB"] * 1024 / cal_f
     wb = raw["WRITE_SIZE"][k]["avg_KB"] * 1024 / cal_w
     res[full] = dict(fetch_bytes=fb, write_bytes=wb, traffic_bytes=fb + wb)
-json.dump(res, open(os.path.join(ROOT, "gpurun_out", "pmc_traffic_n%d.json" % n), "w"), indent=1)
-print(json.dumps({k: res[k] for k in names.values()}, indent=1))
+tag = ("_" + slab.replace(":", "_")) if slab else ""
+json.dump(res, open(os.path.join(ROOT, "gpurun_out", "pmc_traffic_n%d%s.json" % (n, tag)), "w"), indent=1)
+print(json.dumps({k: res[k] for k in names.values() if k in res}, indent=1))
 print("calibration", cal_f, cal_w)

@@ -7,8 +7,28 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import meshfem_amd as M
 from meshfem_amd import grid
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+slab = sys.argv[2] if len(sys.argv) > 2 else ""        # "slab:WORLD:RANK": that rank's share of bench.py --gpus WORLD (grid n per rank)
 c = M.Context(0)
+if slab:
+    from meshfem_amd import distributed as D
+    _, world, rank = slab.split(":")
+    world, rank = int(world), int(rank)
+    ng = int(round(n * world ** (1.0 / 3.0)))
+    layers = max(1, int(round(n ** 3 / float(ng * ng))))
+    lm = D.slab_local_mesh(ng, rank, world, 2, layers, device=0)
+    c.mesh_set(3, 2, lm.elem_nodes, lm.node_pos, lm.n_owned)
+    c.material_isotropic(200, 0.35)
+    c.symbolic(False)
+    c.set_option("reembed", 1)
+    ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, 3)
+    c.set_option("matrix_free", 0)
+    sp = c.time_spmv_kernel(3)      # k_axpby calibration launch + assembled SpMV on the local columns
+    nr, nc, nnzb = c.matrix_info()
+    nE = len(lm.elem_nodes)
+    print(json.dumps(dict(n=n, slab=slab, global_grid=[ng, ng, layers * world], elems=nE, nnzb=nnzb, rows=nr, asm_ms=ms, spmv_ms=sp,
+                          calib_axpby_doubles=3 * nc, asm_alg_bytes=7736 * nE, asm_expected_hbm_bytes=nnzb * 72 + nE * 100 * 6 + nE * 128)))
+    sys.exit(0)
+V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
 c.mesh_build(T, V, 2)
 c.material_isotropic(200, 0.35)
 c.symbolic(False)
