@@ -541,7 +541,24 @@ def slab_traction_load(lm, n, traction):
 
 def _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out, group=None):
     comm = make_comm(c, rank, world, group)
-    comm.selftest()                                    # ring shift + all-reduce with known answers over the actual transport
+    # ring shift + all-reduce with known answers over the actual transport; the ranks agree on the outcome through the process
+    # group, and if the library's own RCCL communicator fails anywhere, every rank falls back to the callback transport
+    ok = 1.0
+    try:
+        comm.selftest()
+    except L.MeshFEMHipError as e:
+        ok = 0.0
+        print("rank %d: %s self test failed: %s" % (rank, comm.describe(), e), flush=True)
+    if world > 1:
+        t = torch.tensor([ok], dtype=torch.float64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        ok = float(t.item())
+    if ok < 1.0:
+        if comm.kind == "callbacks":
+            raise RuntimeError("the communicator self test failed on at least one rank")
+        comm.close()
+        comm = make_comm(c, rank, world, group, prefer="callbacks")
+        comm.selftest()
     solver = DistSolver(c, lm, rank, world, comm, group)
     # u = 0 on x = 0: the mask covers the halo nodes too (needed by the Galerkin coarse operator)
     fixed_nodes = np.flatnonzero(lm.lattice[:, 0] == 0)
