@@ -170,7 +170,7 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
         require_device(c);
         MFH_HIP(hipSetDevice(c->device));
         build_symbolic_device(c->mesh, c->dElemNodes.p, device_dof_map(c), c->nDoF, c->nOwnedDoF(), c->chunkSlots, wantScatter, c->stream,
-                              c->sym, c->dRowPtr, c->dColIdx, c->dContribCode, c->dContribSlot, c->dScatter);
+                              c->sym, c->dRowPtr, c->dColIdx, c->dContribCode, c->dContribSlot, c->dScatter, c->upperOnly);
         const Symbolic &S = c->sym;
         c->dChunkRow.upload(S.chunkRow, c->stream);
         c->dSpmvChunkRow.upload(S.spmvChunkRow, c->stream);
@@ -191,7 +191,7 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
         invalidate_matrix(c);
         return;
     }
-    build_symbolic(c->mesh, c->dofForNode, c->nDoF, c->nOwnedDoF(), c->chunkSlots, c->contribOrder, wantScatter, c->sym);
+    build_symbolic(c->mesh, c->dofForNode, c->nDoF, c->nOwnedDoF(), c->chunkSlots, c->contribOrder, wantScatter, c->sym, c->upperOnly);
     c->timing.symbolic_ms = now_ms() - t0;
     const Symbolic &S = c->sym;
     c->symHasScatter = wantScatter;
@@ -361,8 +361,10 @@ void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double 
         if (c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf_cluster(spmv_mf_cluster_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
         else if (c->mfModeEff() >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
         else k::launch_spmv_mf(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
-    } else
+    } else {
+        require_full_storage(c, "the assembled SpMV");
         k::launch_spmv(spmv_args(c, masked), x, y, dotOut, c->stream);
+    }
 }
 
 void ensure_fixed_uploaded(mfh_ctx *c) {
@@ -526,6 +528,7 @@ bool ensure_twolevel(mfh_ctx *c) {
     T.colorOfAgg.upload(A.colorOfAgg, s); T.nbrOfColor.upload(A.nbrOfColor, s);
     lap("relPos + uploads");
     }
+    if (c->tlProbe || !c->tlRapAgg) require_full_storage(c, "this construction of the coarse operator (options tl_probe / tl_rap_agg 0)");
     T.rc.alloc((size_t)T.m); T.yc.alloc((size_t)T.m);
     DBuf<double> Ac;
     Ac.alloc((size_t)T.m * T.m);
@@ -544,7 +547,7 @@ bool ensure_twolevel(mfh_ctx *c) {
             }
     } else {            // one Galerkin pass over the assembled K
         T.binCoord.upload(A.binCoord, s);
-        if (c->tlRapAgg) k::launch_tl_rap_agg(ta, T.aggPtr.p, T.dofsByAgg.p, T.binCoord.p, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac.p, s);
+        if (c->tlRapAgg) k::launch_tl_rap_agg(ta, T.aggPtr.p, T.dofsByAgg.p, T.binCoord.p, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac.p, s, c->upperOnly);
         else k::launch_tl_rap(ta, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac.p, s);
     }
     lap("Galerkin product");
@@ -656,6 +659,7 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
         }
         const k::SpmvArgs sa = spmv_args(c, !c->fixedVars.empty());
         const bool useMF = c->use_mf();
+        if (!useMF) require_full_storage(c, "the assembled SpMV of the PCG");
         const bool useCluster = useMF && c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY;
         const k::SpmvMfArgs mfa = useCluster ? spmv_mf_cluster_args(c, !c->fixedVars.empty())
                                              : (useMF ? spmv_mf_args(c, !c->fixedVars.empty()) : k::SpmvMfArgs{});
@@ -1506,9 +1510,10 @@ mfh_status mfh_tl_partitioned_begin(mfh_ctx *c, int32_t nAgg, const int32_t *agg
     hipStream_t s = c->stream;
     T.aggOfDof.upload(agg, s); T.relPos.upload(rp, s); T.aggPtr.upload(aggPtr, s); T.dofsByAgg.upload(byAgg, s);
     T.rc.alloc((size_t)T.m); T.yc.alloc((size_t)T.m);
+    if (!c->tlRapAgg) require_full_storage(c, "this construction of the coarse operator (option tl_rap_agg 0)");
     MFH_HIP(hipMemsetAsync(Ac_dev, 0, (size_t)T.m * T.m * sizeof(double), s));
     // caller-supplied aggregates carry no lattice: neighbour blocks fall back to global atomics, the diagonal ones do not
-    if (c->tlRapAgg) k::launch_tl_rap_agg(tl_args(c), T.aggPtr.p, T.dofsByAgg.p, nullptr, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac_dev, s);
+    if (c->tlRapAgg) k::launch_tl_rap_agg(tl_args(c), T.aggPtr.p, T.dofsByAgg.p, nullptr, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac_dev, s, c->upperOnly);
     else k::launch_tl_rap(tl_args(c), nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac_dev, s);
     MFH_HIP(hipStreamSynchronize(s));
     T.setup_ms = now_ms() - t0;
@@ -1689,6 +1694,10 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "periodic_ignore_dims") { c->periodicIgnoreDims = (int)value & 7; }
     else if (k2 == "agg_nodes") { c->aggNodes = (int)value; c->tl.valid = false; }
     else if (k2 == "topology_device") { c->topologyDevice = value != 0; }
+    else if (k2 == "matrix_storage") {
+        require(value == 0 || value == 1, MFH_ERR_INVALID, "matrix_storage: 0 = both triangles, 1 = blocks (r, c >= r) only");
+        c->upperOnly = value == 1; invalidate_symbolic(c);
+    }
     else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }
     else if (k2 == "xcd_swizzle") c->xcdSwizzle = std::max(0, (int)value);   // 1: contiguous eighths; G > 1: runs of G items per XCD
     else if (k2 == "pcg_graph") c->useGraph = value != 0;

@@ -56,6 +56,11 @@ struct mfh_ctx {
     bool symHasScatter = false;
     DBuf<int32_t> dRowPtr, dColIdx, dChunkRow, dSpmvChunkRow, dScatter;
     DBuf<int64_t> dContribPtr;
+    // option "matrix_storage" 1: only the blocks (r, c >= r) of K are stored and assembled -- what the reference's TripletMatrix holds
+    // (LinearElasticity.hh assembles the upper triangle). Half the bytes and half the block arithmetic; serves the consumers that need
+    // K only through its diagonal blocks or its upper triangle (block-Jacobi PCG on the matrix-free operator, exports). Everything
+    // that multiplies by the stored K (assembled SpMV, Galerkin coarse operator, partitioned solves) refuses it.
+    bool upperOnly = false;
     int nCU = 256;                    // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     DBuf<uint32_t> dContribCode;
     DBuf<uint16_t> dContribSlot;
@@ -233,6 +238,11 @@ inline void check_residual_gap(const mfh_solve_info &li, double rtol) {
         throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (residual gap): the recurrence residual reached " + std::to_string(li.rel_residual) +
                                                " but the true residual ||f - K u|| / ||f|| is " + std::to_string(li.true_rel_residual) +
                                                ": K is singular on the free variables with an inconsistent right-hand side, or too ill-conditioned");
+}
+
+// consumers that multiply by the stored K cannot work on the upper-only storage (option "matrix_storage" 1)
+inline void require_full_storage(const mfh_ctx *c, const char *what) {
+    if (c->upperOnly) throw Error(MFH_ERR_UNSUPPORTED, std::string(what) + " needs both triangles of K: set option matrix_storage to 0");
 }
 
 inline int32_t dof_of(const mfh_ctx *c, int64_t node) { return c->dofForNode.empty() ? (int32_t)node : c->dofForNode[node]; }

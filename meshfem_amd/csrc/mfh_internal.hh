@@ -177,7 +177,7 @@ struct Symbolic {
 
 void build_symbolic(const HostMesh &m, const std::vector<int32_t> &dofForNode /* empty = identity */,
                     int64_t nDoF, int64_t nOwnedDoF, int chunkSlots, int contribOrder, bool wantScatter,
-                    Symbolic &S);
+                    Symbolic &S, bool upperOnly = false);
 
 // device implementation (mfh_symbolic_gpu.hip): element-major gather lists via two radix sorts
 // gather lists of the matrix-free operator (mfh_symbolic_gpu.hip)
@@ -223,7 +223,7 @@ void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const i
                            int maxPairs = 2048);
 void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nDoF, int64_t nOwnedDoF,
                            int chunkSlots, bool wantScatter, hipStream_t s, Symbolic &S, DBuf<int32_t> &dRowPtr, DBuf<int32_t> &dColIdx,
-                           DBuf<uint32_t> &dContribCode, DBuf<uint16_t> &dContribSlot, DBuf<int32_t> &dScatter);
+                           DBuf<uint32_t> &dContribCode, DBuf<uint16_t> &dContribSlot, DBuf<int32_t> &dScatter, bool upperOnly = false);
 
 // ------------------------------------------------------------------------------------------------
 // P2 coefficient tables: for node i, grad phi_i(q) = alpha_i(q) gl[s_i] + beta_i(q) gl[t_i]
@@ -421,7 +421,7 @@ void launch_tl_scatter(int nAgg, int nModes, int nColor, const int32_t *nbrOfCol
 void launch_tl_rap(const TLArgs &t, int64_t nRows, const int32_t *rowPtr, const int32_t *colIdx, const double *vals, double *Ac,
                    hipStream_t s);
 void launch_tl_rap_agg(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const int32_t *binCoord, const int32_t *rowPtr,
-                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s);
+                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly = false);
 bool dense_spd_inverse_device(double *A, double *X, double *Ainv, double *Dinv, int64_t mp, int *notSpdDev, hipStream_t s);
 void launch_tl_gemv(int64_t m, int64_t ld, const double *A, const double *x, double *y, hipStream_t s);
 void launch_tl_prep(int64_t m, int64_t mp, const double *Ac, const uint8_t *dead, double maxd, double *Ap, hipStream_t s);

@@ -254,7 +254,10 @@ template <int DIM>
 __global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__restrict__ aggPtr, const int32_t *__restrict__ dofsByAgg,
                                                      const int32_t *__restrict__ binCoord /* nAgg x 3, may be null */,
                                                      const int32_t *__restrict__ rowPtr, const int32_t *__restrict__ colIdx,
-                                                     const double *__restrict__ vals, double *__restrict__ Ac) {
+                                                     const double *__restrict__ vals, double *__restrict__ Ac, int upperOnly) {
+    // upperOnly: only the blocks (r, c >= r) are stored. A stored off-diagonal block inside the aggregate also contributes its
+    // transpose to the diagonal 6 x 6 block; between two aggregates this kernel writes the partial sums U[a][b] over the stored
+    // blocks and k_tl_mirror_upper completes them (Ac[a][b] = U[a][b] + U[b][a]^T).
     constexpr int NB = DIM * DIM;
     constexpr int NM = DIM == 3 ? 6 : 3;
     constexpr int NSLOT = DIM == 3 ? 27 : 9;
@@ -311,6 +314,10 @@ __global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__r
             if (b == a) {
 #pragma unroll
                 for (int q = 0; q < NM * NM; ++q) acc[q] += T[q];
+                if (upperOnly && c != r) {
+#pragma unroll
+                    for (int q = 0; q < NM * NM; ++q) acc[q] += T[(q % NM) * NM + q / NM];
+                }
                 continue;
             }
             int slot = -1;
@@ -1243,10 +1250,26 @@ void launch_tl_rap(const TLArgs &t, int64_t nRows, const int32_t *rowPtr, const 
     else hipLaunchKernelGGL(k_tl_rap<2>, dim3(grid), dim3(256), 0, s, t, nRows, rowPtr, colIdx, vals, Ac);
     CHECK_LAUNCH();
 }
+// Ac[i][j] and Ac[j][i] for entries of two DIFFERENT aggregates: both become the sum of the two partial values (see k_tl_rap_agg)
+__global__ void __launch_bounds__(256) k_tl_mirror_upper(double *__restrict__ Ac, int64_t m, int NM) {
+    const int64_t total = m * m;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int64_t i = q / m, j = q - i * m;
+        if (j <= i || i / NM == j / NM) continue;
+        const double v = Ac[i * m + j] + Ac[j * m + i];
+        Ac[i * m + j] = v;
+        Ac[j * m + i] = v;
+    }
+}
+
 void launch_tl_rap_agg(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const int32_t *binCoord, const int32_t *rowPtr,
-                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s) {
-    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap_agg<3>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac);
-    else hipLaunchKernelGGL(k_tl_rap_agg<2>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac);
+                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly) {
+    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap_agg<3>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0);
+    else hipLaunchKernelGGL(k_tl_rap_agg<2>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0);
+    if (upperOnly) {
+        const int64_t m = (int64_t)t.nAgg * (t.dim == 3 ? 6 : 3);
+        hipLaunchKernelGGL(k_tl_mirror_upper, dim3(grid_for(m * m)), dim3(256), 0, s, Ac, m, t.dim == 3 ? 6 : 3);
+    }
     CHECK_LAUNCH();
 }
 // In-place-style dense SPD inverse: A (mp x mp, mp % 64 == 0) is overwritten by its Cholesky factor, the inverse

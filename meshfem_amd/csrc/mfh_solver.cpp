@@ -226,6 +226,7 @@ void apply_op_nr(mfh_ctx *c, DistLink &L, int NR, double *x, double *y, bool mas
             k::launch_mf_cluster_nr(a, NR, x, y, dotOut, scal, it, ctl, nullptr, c->mfc.nBlocks, s);
         k::launch_mf_rows_nr(a, NR, x, y, dotOut, scal, it, ctl, s);
     } else {
+        require_full_storage(c, "the assembled SpMV of the PCG");
         k::SpmvArgs a = spmv_args(c, masked);
         a.pcgMode = pcgMode;
         if (L.active) {
@@ -689,6 +690,7 @@ mfh_status mfh_dist_setup(mfh_ctx *c, mfh_comm *cm, int32_t nPeers, const int32_
     MFH_TRY(c)
     require(c && c->haveMesh && cm && nPeers >= 0 && (nPeers == 0 || (peers && sendPtr && recvPtr)), MFH_ERR_INVALID, "bad distributed setup arguments");
     require(c->dofForNode.empty(), MFH_ERR_UNSUPPORTED, "row-partitioned contexts use the identity DoF map");
+    require_full_storage(c, "a row-partitioned context");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     auto &D = c->dist;

@@ -10,7 +10,7 @@
 namespace mfh {
 
 void build_symbolic(const HostMesh &m, const std::vector<int32_t> &dofForNode, int64_t nDoF, int64_t nOwnedDoF,
-                    int chunkSlots, int contribOrder, bool wantScatter, Symbolic &S) {
+                    int chunkSlots, int contribOrder, bool wantScatter, Symbolic &S, bool upperOnly) {
     const int npe = m.npe;
     const int64_t nElem = m.nElem;
     if ((double)nElem * npe * npe >= 4294967295.0)
@@ -82,6 +82,7 @@ void build_symbolic(const HostMesh &m, const std::vector<int32_t> &dofForNode, i
                         int64_t e = ei / npe;
                         for (int j = 0; j < npe; ++j) {
                             uint32_t col = (uint32_t)dofOf(e, j);
+                            if (upperOnly && (int64_t)col < r) continue;      // upper-only storage: blocks (r, c >= r)
                             pairs.push_back(((uint64_t)col << 32) | (uint64_t)(ei * (uint32_t)npe + (uint32_t)j));
                         }
                     }

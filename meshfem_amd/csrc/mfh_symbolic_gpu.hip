@@ -13,7 +13,7 @@ namespace {
 
 __global__ void __launch_bounds__(256) k_sym_gen(int64_t N, int npe, const int32_t *__restrict__ elemNodes,
                                                  const int32_t *__restrict__ dofForNode, int64_t nRows, uint64_t *__restrict__ key,
-                                                 uint32_t *__restrict__ val, unsigned long long *nValid) {
+                                                 uint32_t *__restrict__ val, unsigned long long *nValid, int upperOnly) {
     const int npe2 = npe * npe;
     unsigned long long local = 0;
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < N; k += (int64_t)gridDim.x * 256) {
@@ -22,8 +22,8 @@ __global__ void __launch_bounds__(256) k_sym_gen(int64_t N, int npe, const int32
         const int i = ij / npe, j = ij - i * npe;
         int64_t row = elemNodes[e * npe + i], col = elemNodes[e * npe + j];
         if (dofForNode) { row = dofForNode[row]; col = dofForNode[col]; }
-        const bool ok = row < nRows;
-        key[k] = ok ? (((uint64_t)row << 32) | (uint64_t)col) : ((uint64_t)nRows << 32);   // not-owned rows sort last
+        const bool ok = row < nRows && (!upperOnly || col >= row);
+        key[k] = ok ? (((uint64_t)row << 32) | (uint64_t)col) : ((uint64_t)nRows << 32);   // not-owned rows (and, with upper-only storage, the blocks below the diagonal) sort last
         val[k] = (uint32_t)k;
         local += ok;
     }
@@ -145,7 +145,7 @@ __global__ void __launch_bounds__(256) k_permute_rows_i32(int64_t n, int W, cons
 // contribPtr; colIdx and the gather lists stay on the device (downloaded on demand by the API layer).
 void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nDoF, int64_t nOwnedDoF,
                            int chunkSlots, bool wantScatter, hipStream_t s, Symbolic &S, DBuf<int32_t> &dRowPtr, DBuf<int32_t> &dColIdx,
-                           DBuf<uint32_t> &dContribCode, DBuf<uint16_t> &dContribSlot, DBuf<int32_t> &dScatter) {
+                           DBuf<uint32_t> &dContribCode, DBuf<uint16_t> &dContribSlot, DBuf<int32_t> &dScatter, bool upperOnly) {
     const int npe = m.npe;
     const int64_t N = m.nElem * npe * npe;
     if ((double)N >= 4294967295.0) throw Error(MFH_ERR_UNSUPPORTED, "mesh too large for 32-bit contribution codes (partition it across GPUs)");
@@ -160,7 +160,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     keyA.alloc(N); keyB.alloc(N); valA.alloc(N); valB.alloc(N);
     dCount.alloc(1);
     dCount.zero(s);
-    hipLaunchKernelGGL(k_sym_gen, dim3(grid_of(N)), dim3(256), 0, s, N, npe, dElemNodes, dDofForNode, nRows, keyA.p, valA.p, dCount.p);
+    hipLaunchKernelGGL(k_sym_gen, dim3(grid_of(N)), dim3(256), 0, s, N, npe, dElemNodes, dDofForNode, nRows, keyA.p, valA.p, dCount.p, upperOnly ? 1 : 0);
     RP(hipGetLastError());
 
     // ---- sort by (row, col); stable, so equal keys stay in code order

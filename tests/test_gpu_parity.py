@@ -1077,3 +1077,65 @@ def test_fully_anisotropic_constant_and_per_element_tensors(dim, deg):
         c.set_option("matrix_free", 1); y1 = c.apply_K(x)
         assert np.abs(y1 - y0).max() < 1e-12 * np.abs(y0).max()
         c.close()
+
+
+@pytest.mark.parametrize("mode", [M.ASSEMBLE_GATHER, M.ASSEMBLE_ATOMIC])
+@pytest.mark.parametrize("periodic", [False, True])
+def test_upper_only_storage_assembles_the_reference_triangle(mode, periodic):
+    """Option matrix_storage 1: only the blocks (r, c >= r) are stored and assembled -- the triangle the reference's
+    TripletMatrix holds (LinearElasticity.hh assembles i <= j only). The exported triplets are the reference's, the
+    block-Jacobi PCG on the matrix-free operator gives the full-storage solution, and everything that would multiply by
+    the stored K refuses loudly."""
+    V, T = grid.grid_tet_mesh(4, 3, 2)
+    sim = O.Simulator(T, V, 2)
+    sim.set_material_constant(_iso())
+    if periodic:
+        sim.applyPeriodicConditions()
+    Kt = sim.assembleStiffnessMatrix().sum_repeated()
+    out = {}
+    for storage in (0, 1):
+        c = _ctx()
+        c.set_option("matrix_storage", storage)
+        c.mesh_build(T, V, 2)
+        c.material_isotropic(200.0, 0.35)
+        if periodic:
+            c.apply_periodic_conditions()
+        c.assemble(mode)
+        i, j, v = c.export_upper_triplets()
+        big = np.abs(Kt.v) > 1e-9 * np.abs(Kt.v).max()
+        ref = {(a, b): x for a, b, x in zip(Kt.i[big], Kt.j[big], Kt.v[big])}
+        got = {(int(a), int(b)): x for a, b, x in zip(i, j, v)}
+        assert set(ref) <= set(got)
+        assert max(abs(got[k] - ref[k]) for k in ref) / np.abs(Kt.v).max() < K_RTOL
+        nr, nc, nnzb = c.matrix_info()
+        out[storage] = nnzb
+        # a solve that needs K only through its diagonal blocks: block-Jacobi PCG on the matrix-free operator
+        n = 3 * nr
+        rng = np.random.default_rng(3)
+        c.bc_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9], [0, 0, 0])
+        c.fix_variables(*c.bc_dirichlet_vars())
+        f = rng.standard_normal(n)
+        c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+        out["u%d" % storage] = c.solve(f, rtol=1e-10, maxit=20000)
+        # the two-level preconditioner: its Galerkin coarse operator Z^T K Z is completed from the stored triangle
+        c.set_preconditioner(M.PRECOND_TWO_LEVEL)
+        c.set_option("agg_nodes", 24)                        # a dozen aggregates: blocks between different aggregates exist
+        out["t%d" % storage] = c.solve(f, rtol=1e-10, maxit=20000)
+        out["it%d" % storage] = c.last_info["iterations"]
+        if storage == 1:
+            for what in ("spmv",) if periodic else ("probe", "spmv"):   # (probing is not offered with periodic DoF maps at all)
+                with pytest.raises(M.MeshFEMHipError) as ei:
+                    if what == "probe":
+                        c.set_option("tl_probe", 1)
+                        c.solve(f, rtol=1e-8)
+                    else:
+                        c.set_option("tl_probe", 0)
+                        c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+                        c.set_option("matrix_free", 0)
+                        c.apply_K(f)
+                assert ei.value.code == M._lib.ERR_UNSUPPORTED and "both triangles" in str(ei.value)
+        c.close()
+    assert out[1] == (out[0] + nr) // 2                        # diagonal blocks + one of every off-diagonal pair
+    assert np.linalg.norm(out["u1"] - out["u0"]) <= 1e-7 * np.linalg.norm(out["u0"])
+    assert np.linalg.norm(out["t1"] - out["u0"]) <= 1e-7 * np.linalg.norm(out["u0"])
+    assert abs(out["it1"] - out["it0"]) <= 1                   # the same coarse operator, to rounding

@@ -208,3 +208,30 @@ def test_mesh_update_vertices_keeps_topology_and_recomputes_geometry():
     with pytest.raises(ValueError):
         a.mesh_update_vertices(V2[:-1])
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_upper_only_storage_symbolic_phase(order):
+    """Option matrix_storage 1 (the triangle the reference's TripletMatrix holds): the gather lists cover exactly the blocks
+    (r, c >= r); applied to the oracle's Ke they give the block upper triangle of the oracle's K with 55 of every
+    element's 100 contributions."""
+    V, T = grid.grid_tet_mesh(3, 2, 2)
+    sim = O.Simulator(T, V, 2)
+    sim.set_material_constant(O.ElasticityTensor.isotropic(3, 200.0, 0.35))
+    Ke = sim.per_element_stiffness()
+    Kref = sim.assembleStiffnessMatrix().sum_repeated().to_scipy_full_from_upper()
+    c = M.Context(-1)
+    c.mesh_build(T, V, 2)
+    c.set_option("matrix_storage", 1)
+    c.set_option("contrib_order", order)
+    c.symbolic(True)
+    A, S = _emulate_gather(c, Ke, 3)
+    nb = len(S["rowPtr"]) - 1
+    B = sp.bsr_matrix(Kref.tocsr(), blocksize=(3, 3))
+    rows = np.repeat(np.arange(nb), np.diff(B.indptr))
+    keep = B.indices >= rows
+    U = sp.bsr_matrix((B.data[keep], B.indices[keep], np.concatenate([[0], np.cumsum(np.bincount(rows[keep], minlength=nb))])), shape=B.shape).tocsr()
+    assert abs(A - U).max() < 1e-14 * abs(Kref).max()
+    assert S["n_contrib"] == 55 * len(T) and len(S["colIdx"]) == (B.nnz // 9 + nb) // 2
+    srows = np.repeat(np.arange(nb), np.diff(S["rowPtr"]))
+    assert np.all(S["colIdx"] >= srows) and np.array_equal(S["colIdx"][S["rowPtr"][:-1]], np.arange(nb))   # the diagonal block leads every row
