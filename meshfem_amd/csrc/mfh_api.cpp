@@ -228,6 +228,7 @@ k::AsmArgs asm_args(mfh_ctx *c) {
     a.nElem = m.nElem; a.scatterSlot = c->dScatter.p;
     a.vals = c->dVals.p; a.nnzb = c->sym.nnzb;
     a.xcd = c->xcdSwizzle;
+    a.upperOnly = c->upperOnly ? 1 : 0;
     return a;
 }
 

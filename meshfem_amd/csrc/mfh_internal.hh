@@ -295,6 +295,7 @@ struct AsmArgs {
     double *vals;                       // tiled [ceil(nnzb/64)][dim*dim][64]
     int64_t nnzb;
     int xcd;                            // 1: XCD-contiguous chunk mapping (xcd_item)
+    int upperOnly;                      // the lists cover the blocks (r, c >= r) only (names the kernel instantiation)
 };
 
 void launch_geometry(int dim, int deg, int mat, int64_t nElem, const int32_t *elemNodes, int npe,

@@ -244,7 +244,9 @@ __global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *
 // ------------------------------------------------------------------------------------------------
 // isotropic / scalar flavours: 8 waves per SIMD (64 VGPRs; 69 without the hint) so that the registers allow the 8 workgroups
 // per CU that the 18 KB of LDS accumulators do (measured 5.42 vs 5.67 ms at config 3 on one box)
-template <int DIM, int DEG, int MAT>
+// UPPER only names the instantiation (profiles tell the launches on the upper-triangle storage from those on the full one):
+// which blocks exist is decided by the gather lists, the code is the same.
+template <int DIM, int DEG, int MAT, bool UPPER = false>
 __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) ? 1 : 8) k_assemble_gather(AsmArgs a) {
     constexpr int NB = mat_nb<DIM, MAT>();
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
@@ -1826,12 +1828,21 @@ void launch_geometry(int dim, int /*deg*/, int /*mat*/, int64_t nElem, const int
 void launch_assemble_gather(const AsmArgs &a, hipStream_t s) {
     if (a.nChunk == 0) return;
     const size_t lds = (size_t)(mat_is_scalar(a.mat) ? 1 : a.dim * a.dim) * (a.chunkSlots + 2) * sizeof(double);
+    if (a.upperOnly) {
 #define CALL(D, G, M)                                                                                          \
     if (lds > 64 * 1024)                                                                                         \
-        MFH_HIP(hipFuncSetAttribute((const void *)k_assemble_gather<D, G, M>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((k_assemble_gather<D, G, M>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a)
-    MFH_DISPATCH_ASM(a, CALL);
+        MFH_HIP(hipFuncSetAttribute((const void *)k_assemble_gather<D, G, M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_assemble_gather<D, G, M, true>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a)
+        MFH_DISPATCH_ASM(a, CALL);
 #undef CALL
+    } else {
+#define CALL(D, G, M)                                                                                          \
+    if (lds > 64 * 1024)                                                                                         \
+        MFH_HIP(hipFuncSetAttribute((const void *)k_assemble_gather<D, G, M, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((k_assemble_gather<D, G, M, false>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a)
+        MFH_DISPATCH_ASM(a, CALL);
+#undef CALL
+    }
     CHECK_LAUNCH();
 }
 

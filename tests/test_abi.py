@@ -84,6 +84,7 @@ def test_default_library_has_no_experiment_variants():
     names = set(re.findall(r"k_assemble_gather<[^>]*>", out))
     assert names, "assembly kernel stubs not found"
     for n in names:
-        assert n.count(",") == 2, "unexpected template arguments: " + n     # <DIM, DEG, MAT> only
+        # <DIM, DEG, MAT, UPPER>: UPPER only names the launches on the upper-triangle storage (option matrix_storage), same code
+        assert re.fullmatch(r"k_assemble_gather<\d, \d, \d, (true|false)>", n), "unexpected template arguments: " + n
     src = open(os.path.join(ROOT, "meshfem_amd", "csrc", "mfh_kernels.hip")).read()
     assert "racy" not in src and "DBG" not in src
