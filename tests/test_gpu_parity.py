@@ -603,7 +603,7 @@ def test_two_level_setup_variants_agree():
     assert np.linalg.norm(res[0][0] - res[1][0]) < 1e-8 * np.linalg.norm(res[0][0])
 
 
-@pytest.mark.parametrize("case", ["p2", "p1_periodic", "partitioned"])
+@pytest.mark.parametrize("case", ["p2", "p1_periodic", "partitioned", "p2_upper", "p2_periodic_upper"])
 def test_device_symbolic_identical_to_host_symbolic(case):
     """The GPU symbolic phase (two radix sorts) must reproduce the host implementation bit for bit:
     row pointers, columns, chunk tables, gather lists (element-major) and the scatter map."""
@@ -618,9 +618,11 @@ def test_device_symbolic_identical_to_host_symbolic(case):
             m = O.FEMMesh(T, V, 2)
             c.mesh_set(3, 2, m.elem_nodes, m.node_pos, m.num_nodes // 3)
         else:
-            c.mesh_build(T, V, 2 if case == "p2" else 1)
-            if case == "p1_periodic":
+            c.mesh_build(T, V, 1 if case == "p1_periodic" else 2)
+            if "periodic" in case:
                 c.apply_periodic_conditions()
+            if "upper" in case:
+                c.set_option("matrix_storage", 1)
         c.symbolic(True)
         res[dev] = c.symbolic_get(True)
         c.material_isotropic(200.0, 0.35)
