@@ -34,7 +34,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
 true_b = 8.0 * meta["calib_axpby_doubles"]
 cal_f = raw["FETCH_SIZE"]["k_axpby"]["avg_KB"] * 1024 / true_b
 cal_w = raw["WRITE_SIZE"]["k_axpby"]["avg_KB"] * 1024 / true_b
-res = dict(workload=("%d^3 grid, %d P2 tets" % (n, meta["elems"])) if not slab else ("%s of a %s grid, %d local P2 tets" % (slab, meta["global_grid"], meta["elems"])), meta=meta, raw=raw,
+res = dict(workload=("%d^3 grid, %d P2 tets" % (n, meta["elems"]) + (" (upper-triangle storage)" if meta.get("storage") == "upper" else "")) if not slab else ("%s of a %s grid, %d local P2 tets" % (slab, meta["global_grid"], meta["elems"])), meta=meta, raw=raw,
            calibration=dict(kernel="k_axpby(b=0): reads 8n, writes 8n bytes, n=%d" % meta["calib_axpby_doubles"],
                             fetch_reported_over_true=cal_f, write_reported_over_true=cal_w,
                             note="gfx950 FETCH_SIZE reports ~1/2 of coalesced read bytes (MI355X_MICROARCH.md, HBM section); corrected by the measured factor"))
@@ -46,7 +46,7 @@ for k, full in names.items():
     fb = raw["FETCH_SIZE"][k]["avg_KB"] * 1024 / cal_f
     wb = raw["WRITE_SIZE"][k]["avg_KB"] * 1024 / cal_w
     res[full] = dict(fetch_bytes=fb, write_bytes=wb, traffic_bytes=fb + wb)
-tag = ("_" + slab.replace(":", "_")) if slab else ""
+tag = ("_" + slab.replace(":", "_")) if slab else ("_upper" if os.environ.get("PMC_UPPER_STORAGE") == "1" else "")
 json.dump(res, open(os.path.join(ROOT, "gpurun_out", "pmc_traffic_n%d%s.json" % (n, tag)), "w"), indent=1)
 print(json.dumps({k: res[k] for k in names.values() if k in res}, indent=1))
 print("calibration", cal_f, cal_w)

@@ -29,6 +29,17 @@ if slab:
                           calib_axpby_doubles=3 * nc, asm_alg_bytes=7736 * nE, asm_expected_hbm_bytes=nnzb * 72 + nE * 100 * 6 + nE * 128)))
     sys.exit(0)
 V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+if os.environ.get("PMC_UPPER_STORAGE") == "1":      # the upper-triangle storage variant: assembly and matrix-free operator only
+    c.set_option("matrix_storage", 1)
+    c.mesh_build(T, V, 2)
+    c.material_isotropic(200, 0.35)
+    c.symbolic(False)
+    ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, 3)
+    mf = c.time_spmv_kernel(3)      # k_axpby calibration launch, then the matrix-free operator
+    nr, nc, nnzb = c.matrix_info()
+    print(json.dumps(dict(n=n, storage="upper", elems=len(T), nnzb=nnzb, rows=nr, asm_ms=ms, mf_ms=mf, calib_axpby_doubles=3 * nc,
+                          asm_alg_bytes=7736 * len(T), asm_expected_hbm_bytes=nnzb * 72 + len(T) * 55 * 6 + len(T) * 128)))
+    sys.exit(0)
 c.mesh_build(T, V, 2)
 c.material_isotropic(200, 0.35)
 c.symbolic(False)
