@@ -33,9 +33,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
-PMC_PROFILE = "r02_pmc_traffic_n60.json"      # scripts/pmc_collect.py on the round-2 kernels
+PMC_PROFILE = "r02_pmc_traffic_n60.json"      # scripts/pmc_collect.py on the round-2 kernels (both triangles of K stored)
+PMC_PROFILE_UPPER = "r02_pmc_traffic_n60_upper_storage.json"   # the same with the upper-triangle storage (PMC_UPPER_STORAGE=1)
 PMC_KERNEL_KEY = "k_assemble_gather"
-ALG_BYTES = {(3, 2): 7736, (3, 1): 1328, (2, 2): 1368, (2, 1): 0}   # SURVEY.md section 8(d), const material
+ALG_BYTES = {(3, 2): 7736, (3, 1): 1328, (2, 2): 1368, (2, 1): 0}   # SURVEY.md section 8(d), const material, both triangles
+# SURVEY.md section 8(d), row "upper-only variant, matches reference storage": 40 + 96 + 55 x 4 + 55 x 72 (P2 tet); P2 triangle alike
+ALG_BYTES_UPPER = {(3, 2): 4316, (2, 2): 24 + 48 + 21 * 4 + 21 * 32}
 
 
 def parse():
@@ -59,11 +62,11 @@ def parse():
     return ap.parse_args()
 
 
-def pmc_traffic(kernel_key, n, deg):
+def pmc_traffic(kernel_key, n, deg, profile=None):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in their
     own runs, calibrated on a known byte count: profiles/r01_pmc_traffic_n60.json). PMC counters cannot
     be collected from inside this process; the figure is only attached when the workload matches."""
-    path = os.path.join(ROOT, "profiles", PMC_PROFILE)
+    path = os.path.join(ROOT, "profiles", profile or PMC_PROFILE)
     try:
         with open(path) as f:
             d = json.load(f)
@@ -234,10 +237,15 @@ def run_single(args):
     value = nE * args.steps / dt
     # dominant kernel alone, HIP events on the context's stream
     k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
-    alg = ALG_BYTES[(3, deg)] * nE
-    tb, tsrc = pmc_traffic(PMC_KERNEL_KEY, n, deg)
+    # Storage of K: automatic (option matrix_storage -1). Quadratic elasticity solves on the matrix-free operator, nothing multiplies
+    # by the stored K, and the context stores / assembles the triangle the reference's TripletMatrix holds (SURVEY 8d's "upper-only
+    # variant, matches reference storage", 4 316 B per P2 tet); linear meshes keep both triangles for the assembled SpMV (7 736 / 1 328 B).
+    upper, stored_blocks = c.matrix_storage()
+    bytes_per_element = ALG_BYTES_UPPER[(3, deg)] if upper else ALG_BYTES[(3, deg)]
+    alg = bytes_per_element * nE
+    tb, tsrc = pmc_traffic(PMC_KERNEL_KEY, n, deg, PMC_PROFILE_UPPER if upper else PMC_PROFILE)
     nr, nc, nnzb = c.matrix_info()
-    comp = compulsory_assembly_bytes(c, nE, nnzb)
+    comp = compulsory_assembly_bytes(c, nE, stored_blocks)
     roof = dict(bound="hbm", kernel="k_assemble_gather", achieved=alg / k_ms / 1e6, peak=HBM_PEAK_GBS, unit="GB/s",
                 frac=alg / k_ms / 1e6 / HBM_PEAK_GBS, traffic=None if tb is None else tb / k_ms / 1e6,
                 # the contract fraction above counts SURVEY 8(d)'s 100 Ke blocks per element, which an owner-computes kernel
@@ -245,9 +253,11 @@ def run_single(args):
                 frac_traffic=None if tb is None else tb / k_ms / 1e6 / HBM_PEAK_GBS,
                 compulsory_bytes=comp, frac_compulsory=comp / k_ms / 1e6 / HBM_PEAK_GBS,
                 traffic_bytes_per_launch_from_profile=tb, traffic_from_profile=tsrc, alg_bytes_per_launch=alg, kernel_ms=k_ms,
-                bytes_per_element=ALG_BYTES[(3, deg)],
-                note="frac = SURVEY 8(d) algorithmic bytes / time / 8 TB/s (contract); frac_traffic = rocprofv3 PMC bytes of the "
-                     "committed profile / time; frac_compulsory = bytes the design must move (K once + records + lists) / time")
+                bytes_per_element=bytes_per_element,
+                matrix_storage="upper triangle (blocks (r, c >= r): what the reference assembles)" if upper else "both triangles",
+                note="frac = SURVEY 8(d) algorithmic bytes (the row of the storage in use) / time / 8 TB/s (contract); frac_traffic = "
+                     "rocprofv3 PMC bytes of the committed profile / time; frac_compulsory = bytes the design must move (stored K "
+                     "once + records + lists) / time")
     # context: the kernel's MEASURED traffic rate against the triad rate measured on this box a minute ago
     if roof["traffic"] is not None:
         roof["measured_triad_GBs"] = hbm_measured["triad_GBs"]
@@ -257,6 +267,7 @@ def run_single(args):
                dtype="f64", data="synthetic",
                config=dict(workload="configs[2]: %d^3 grid -> %d P%d tets, isotropic E=200 nu=0.35, Dirichlet x=0, traction x=1"
                                     % (n, nE, deg), elements=nE, nodes=c.n_node, dof=3 * c.n_dof, nnz_blocks=nnzb,
+                           stored_blocks=stored_blocks, matrix_storage="upper" if upper else "full",
                            parallelism="1 GPU", step="embed + Ke blocks + assembly into block-CSR (gather/owner-computes)"),
                roofline=roof, hbm_measured=hbm_measured,
                setup=dict(mesh_gen_s=t_gen, femmesh_build_s=t_build, symbolic_s=t_sym, **c.timing(), **c.symbolic_sizes()))
@@ -338,35 +349,39 @@ def run_single(args):
                                         rel_l2_vs_block_jacobi=float(np.linalg.norm(u2 - u) / np.linalg.norm(u)))
         except M.MeshFEMHipError as e:
             out["pcg_two_level"] = str(e)
-    # The same pass with the storage the reference's TripletMatrix uses (upper triangle only; option matrix_storage 1). A variant, not
-    # the headline: the default keeps both triangles because the assembled SpMV, the Galerkin coarse operator and the partitioned
-    # rows multiply by the stored K. Same timed region (embedding + blocks + assembly, args.steps passes).
-    try:
-        c.close()
-        cu = M.Context(0)
-        cu.set_option("matrix_storage", 1)
-        cu.mesh_build(T, V, deg)
-        cu.material_isotropic(200.0, 0.35)
-        cu.symbolic(False)
-        cu.set_option("reembed", 1)
-        for _ in range(args.warmup):
-            cu.assemble()
-        cu.dev_sync()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            cu.assemble()
-        cu.dev_sync()
-        dtu = (time.perf_counter() - t0) / args.steps
-        ku = cu.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
-        out["variants"]["upper_triangle_storage"] = dict(ms_per_step=dtu * 1e3, elements_per_s=nE / dtu, kernel_ms=ku, stored_blocks=int(cu.matrix_info()[2]),
-                                                         K_bytes=int(cu.matrix_info()[2]) * 72,
-                                                         note="option matrix_storage 1: blocks (r, c >= r) only, as the reference assembles; serves the exports and "
-                                                              "the block-Jacobi PCG on the matrix-free operator (tests/test_gpu_parity.py::test_upper_only_storage_*)")
-        cu.close()
-    except M.MeshFEMHipError as e:
-        out["variants"]["upper_triangle_storage"] = str(e)
+    # The same pass with BOTH triangles of K stored (option matrix_storage 0: the round-1 definition of this benchmark, and what a
+    # context does on its own when something multiplies by the stored K). Same timed region (embedding + blocks + assembly).
+    if upper:
+        try:
+            c.close()
+            cu = M.Context(0)
+            cu.set_option("matrix_storage", 0)
+            cu.mesh_build(T, V, deg)
+            cu.material_isotropic(200.0, 0.35)
+            cu.symbolic(False)
+            cu.set_option("reembed", 1)
+            for _ in range(args.warmup):
+                cu.assemble()
+            cu.dev_sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                cu.assemble()
+            cu.dev_sync()
+            dtu = (time.perf_counter() - t0) / args.steps
+            ku = cu.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
+            tbf, tsf = pmc_traffic(PMC_KERNEL_KEY, n, deg, PMC_PROFILE)
+            out["variants"]["both_triangles_storage"] = dict(
+                ms_per_step=dtu * 1e3, elements_per_s=nE / dtu, kernel_ms=ku, stored_blocks=int(cu.matrix_storage()[1]),
+                K_bytes=int(cu.matrix_storage()[1]) * 72, bytes_per_element=ALG_BYTES[(3, deg)],
+                frac=ALG_BYTES[(3, deg)] * nE / ku / 1e6 / HBM_PEAK_GBS, frac_traffic=None if tbf is None else tbf / ku / 1e6 / HBM_PEAK_GBS,
+                traffic_from_profile=tsf,
+                note="option matrix_storage 0; SURVEY 8(d) 7 736 B per P2 tet")
+            cu.close()
+        except M.MeshFEMHipError as e:
+            out["variants"]["both_triangles_storage"] = str(e)
     if not args.no_orderings:
         # the same mesh with shuffled / space-filling-curve numbering (gather locality)
+        c.close()
         out["variants"]["orderings"] = {"generator": dict(assembly_kernel_ms=k_ms, spmv_kernel_ms=out.get("pcg", {}).get("roofline", {}).get("kernel_ms"),
                                                           matrix_free_kernels_ms=out.get("pcg", {}).get("matrix_free", {}).get("kernels_ms"))}
         for mode in ("morton", "shuffle"):

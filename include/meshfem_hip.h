@@ -188,6 +188,9 @@ mfh_status mfh_symbolic_sizes(const mfh_ctx* ctx, int64_t* nChunk, int64_t* nCon
 mfh_status mfh_symbolic_get(const mfh_ctx* ctx, int32_t* rowPtr, int32_t* colIdx, int32_t* chunkRow, int64_t* contribPtr,
                             uint32_t* contribCode, uint16_t* contribSlot, int32_t* scatterSlot);
 mfh_status mfh_matrix_info(const mfh_ctx* ctx, int64_t* nBlockRows, int64_t* nBlockCols, int64_t* nnzBlocks);
+/* Storage of K (option "matrix_storage"): *upperOnly = 1 when only the blocks (r, c >= r) are stored and assembled -- the triangle the
+ * reference's TripletMatrix holds --, *storedBlocks = their number. mfh_matrix_info and mfh_export_bsr describe K itself either way. */
+mfh_status mfh_matrix_storage(const mfh_ctx* ctx, int32_t* upperOnly, int64_t* storedBlocks);
 mfh_status mfh_export_bsr(mfh_ctx* ctx, int32_t* rowPtr /* nBlockRows+1 */, int32_t* colIdx /* nnzb */,
                           double* vals /* nnzb x dim*dim, row-major blocks */);
 /* == TripletMatrix after m_assembleStiffnessMatrix + sumRepeated: upper triangle (row<=col) in

@@ -68,6 +68,7 @@ PROTOTYPES = {
     "mfh_symbolic_sizes": (_i32, [_P, _pi64, _pi64, _pi32, _pi32]),
     "mfh_symbolic_get": (_i32, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "mfh_matrix_info": (_i32, [_P, _pi64, _pi64, _pi64]),
+    "mfh_matrix_storage": (_i32, [_P, _pi32, _pi64]),
     "mfh_export_bsr": (_i32, [_P, _P, _P, _P]),
     "mfh_export_upper_triplets": (_i32, [_P, _P, _P, _P, C.POINTER(C.c_uint64)]),
     "mfh_element_stiffness": (_i32, [_P, _i64, _i64, _P]),

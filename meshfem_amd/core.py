@@ -180,8 +180,16 @@ class Context:
         self._ck(self.lib.mfh_matrix_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
         return a.value, b.value, c.value
 
+    def matrix_storage(self):
+        """(upper_only, stored_blocks): option "matrix_storage". matrix_info / export_bsr describe K itself either way; the
+        symbolic phase (symbolic_get) describes what is stored."""
+        u, n = C.c_int32(), C.c_int64()
+        self._ck(self.lib.mfh_matrix_storage(self.h, C.byref(u), C.byref(n)))
+        return bool(u.value), n.value
+
     def symbolic_get(self, with_scatter=False):
-        nr, nc, nnzb = self.matrix_info()
+        nr, nc, _ = self.matrix_info()
+        nnzb = self.matrix_storage()[1]
         sz = self.symbolic_sizes()
         out = dict(rowPtr=np.empty(nr + 1, np.int32), colIdx=np.empty(nnzb, np.int32),
                    chunkRow=np.empty(sz["n_chunk"] + 1, np.int32), contribPtr=np.empty(sz["n_chunk"] + 1, np.int64),

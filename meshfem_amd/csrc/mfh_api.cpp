@@ -160,9 +160,16 @@ void ensure_host_colidx(mfh_ctx *c) {
     c->dColIdx.download(c->sym.colIdx.data(), c->sym.colIdx.size(), c->stream);
 }
 
+// an option / operator change may have changed the storage the matrix should have: drop the K pattern (the operator lists stay)
+void refresh_storage_rule(mfh_ctx *c) {
+    if (c->symValid && resolve_upper_storage(c) != c->upperOnly) { c->symValid = false; invalidate_matrix(c); }
+}
+
 void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
     require(c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    refresh_storage_rule(c);
     if (c->symValid && (!wantScatter || c->symHasScatter)) return;
+    c->upperOnly = resolve_upper_storage(c);
     RoctxRange range("Compress Matrix");   // sumRepeated's sort / merge, hoisted into the once-per-mesh symbolic phase
     double t0 = now_ms();
     if (!c->hostOnly && c->symbolicDevice && c->contribOrder == 1) {
@@ -548,7 +555,7 @@ bool ensure_twolevel(mfh_ctx *c) {
             }
     } else {            // one Galerkin pass over the assembled K
         T.binCoord.upload(A.binCoord, s);
-        if (c->tlRapAgg) k::launch_tl_rap_agg(ta, T.aggPtr.p, T.dofsByAgg.p, T.binCoord.p, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac.p, s, c->upperOnly);
+        if (c->tlRapAgg) k::launch_tl_rap_agg(ta, T.aggPtr.p, T.dofsByAgg.p, T.binCoord.p, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac.p, s, c->upperOnly, c->sym.nRows);
         else k::launch_tl_rap(ta, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac.p, s);
     }
     lap("Galerkin product");
@@ -1233,7 +1240,14 @@ mfh_status mfh_matrix_info(const mfh_ctx *c, int64_t *nBlockRows, int64_t *nBloc
     if (!c || !c->symValid) return MFH_ERR_STATE;
     if (nBlockRows) *nBlockRows = c->sym.nRows;
     if (nBlockCols) *nBlockCols = c->sym.nCols;
-    if (nnzBlocks) *nnzBlocks = c->sym.nnzb;
+    if (nnzBlocks) *nnzBlocks = c->sym.nnzb + (c->upperOnly ? c->sym.nMirror : 0);   // blocks of K (mfh_export_bsr), whatever the storage
+    return MFH_OK;
+}
+
+mfh_status mfh_matrix_storage(const mfh_ctx *c, int32_t *upperOnly, int64_t *storedBlocks) {
+    if (!c || !c->symValid) return MFH_ERR_STATE;
+    if (upperOnly) *upperOnly = c->upperOnly ? 1 : 0;
+    if (storedBlocks) *storedBlocks = c->sym.nnzb;
     return MFH_OK;
 }
 
@@ -1314,14 +1328,60 @@ mfh_status mfh_export_bsr(mfh_ctx *c, int32_t *rowPtr, int32_t *colIdx, double *
     require(c && c->assembled, MFH_ERR_STATE, "matrix not assembled");
     ensure_host_colidx(c);
     const Symbolic &S = c->sym;
-    if (rowPtr) std::copy(S.rowPtr.begin(), S.rowPtr.end(), rowPtr);
-    if (colIdx) std::copy(S.colIdx.begin(), S.colIdx.end(), colIdx);
-    if (vals && S.nnzb) {
-        const int nb = c->bs() * c->bs();
-        DBuf<double> aos;
-        aos.alloc((size_t)S.nnzb * nb);
-        k::launch_untile_vals(c->bs(), S.nnzb, c->dVals.p, aos.p, c->stream);
-        aos.download(vals, (size_t)S.nnzb * nb, c->stream);
+    if (!c->upperOnly) {
+        if (rowPtr) std::copy(S.rowPtr.begin(), S.rowPtr.end(), rowPtr);
+        if (colIdx) std::copy(S.colIdx.begin(), S.colIdx.end(), colIdx);
+        if (vals && S.nnzb) {
+            const int nb = c->bs() * c->bs();
+            DBuf<double> aos;
+            aos.alloc((size_t)S.nnzb * nb);
+            k::launch_untile_vals(c->bs(), S.nnzb, c->dVals.p, aos.p, c->stream);
+            aos.download(vals, (size_t)S.nnzb * nb, c->stream);
+        }
+    } else {
+        // upper-triangle storage: the export is K all the same. Row r = the transposes of the stored blocks (q, r), q < r, in
+        // ascending q (= ascending column), then the stored blocks (r, c >= r).
+        const int d = c->bs(), nb = d * d;
+        const int64_t nR = S.nRows;
+        std::vector<int64_t> full((size_t)nR + 1, 0);
+        for (int64_t r = 0; r < nR; ++r) {
+            full[(size_t)r + 1] += S.rowPtr[r + 1] - S.rowPtr[r];
+            for (int32_t q = S.rowPtr[r]; q < S.rowPtr[r + 1]; ++q) {
+                const int64_t col = S.colIdx[q];
+                if (col > r && col < nR) ++full[(size_t)col + 1];
+            }
+        }
+        for (int64_t r = 0; r < nR; ++r) full[(size_t)r + 1] += full[(size_t)r];
+        require(full[(size_t)nR] == S.nnzb + S.nMirror, MFH_ERR_STATE, "inconsistent mirror count");
+        require(full[(size_t)nR] <= 2147483647LL, MFH_ERR_UNSUPPORTED, "more than 2^31 blocks: export the stored triangle (mfh_export_upper_triplets)");
+        if (rowPtr) for (int64_t r = 0; r <= nR; ++r) rowPtr[r] = (int32_t)full[(size_t)r];
+        std::vector<double> sv;
+        if (vals && S.nnzb) {
+            sv.resize((size_t)S.nnzb * nb);
+            DBuf<double> aos;
+            aos.alloc(sv.size());
+            k::launch_untile_vals(d, S.nnzb, c->dVals.p, aos.p, c->stream);
+            aos.download(sv.data(), sv.size(), c->stream);
+        }
+        if (colIdx || vals) {
+            std::vector<int64_t> cur(full.begin(), full.end() - 1);
+            for (int64_t r = 0; r < nR; ++r)        // transposed entries first: rows are visited in ascending order
+                for (int32_t q = S.rowPtr[r]; q < S.rowPtr[r + 1]; ++q) {
+                    const int64_t col = S.colIdx[q];
+                    if (!(col > r && col < nR)) continue;
+                    const int64_t at = cur[(size_t)col]++;
+                    if (colIdx) colIdx[at] = (int32_t)r;
+                    if (vals)
+                        for (int a2 = 0; a2 < d; ++a2)
+                            for (int b2 = 0; b2 < d; ++b2) vals[(size_t)at * nb + a2 * d + b2] = sv[(size_t)q * nb + b2 * d + a2];
+                }
+            for (int64_t r = 0; r < nR; ++r)
+                for (int32_t q = S.rowPtr[r]; q < S.rowPtr[r + 1]; ++q) {
+                    const int64_t at = cur[(size_t)r]++;
+                    if (colIdx) colIdx[at] = S.colIdx[q];
+                    if (vals) std::copy(sv.begin() + (size_t)q * nb, sv.begin() + (size_t)(q + 1) * nb, vals + (size_t)at * nb);
+                }
+        }
     }
     MFH_CATCH(c)
 }
@@ -1514,7 +1574,7 @@ mfh_status mfh_tl_partitioned_begin(mfh_ctx *c, int32_t nAgg, const int32_t *agg
     if (!c->tlRapAgg) require_full_storage(c, "this construction of the coarse operator (option tl_rap_agg 0)");
     MFH_HIP(hipMemsetAsync(Ac_dev, 0, (size_t)T.m * T.m * sizeof(double), s));
     // caller-supplied aggregates carry no lattice: neighbour blocks fall back to global atomics, the diagonal ones do not
-    if (c->tlRapAgg) k::launch_tl_rap_agg(tl_args(c), T.aggPtr.p, T.dofsByAgg.p, nullptr, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac_dev, s, c->upperOnly);
+    if (c->tlRapAgg) k::launch_tl_rap_agg(tl_args(c), T.aggPtr.p, T.dofsByAgg.p, nullptr, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac_dev, s, c->upperOnly, c->sym.nRows);
     else k::launch_tl_rap(tl_args(c), nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, Ac_dev, s);
     MFH_HIP(hipStreamSynchronize(s));
     T.setup_ms = now_ms() - t0;
@@ -1696,8 +1756,8 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "agg_nodes") { c->aggNodes = (int)value; c->tl.valid = false; }
     else if (k2 == "topology_device") { c->topologyDevice = value != 0; }
     else if (k2 == "matrix_storage") {
-        require(value == 0 || value == 1, MFH_ERR_INVALID, "matrix_storage: 0 = both triangles, 1 = blocks (r, c >= r) only");
-        c->upperOnly = value == 1; invalidate_symbolic(c);
+        require(value == 0 || value == 1 || value == -1, MFH_ERR_INVALID, "matrix_storage: 0 = both triangles, 1 = blocks (r, c >= r) only, -1 = automatic");
+        c->matrixStorage = (int)value;
     }
     else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }
     else if (k2 == "xcd_swizzle") c->xcdSwizzle = std::max(0, (int)value);   // 1: contiguous eighths; G > 1: runs of G items per XCD
@@ -1720,6 +1780,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "tl_probe") { c->tlProbe = value != 0; c->tl.valid = false; }
     else if (k2 == "tl_host_inverse") { c->tlHostInverse = value != 0; c->tl.valid = false; }
     else throw Error(MFH_ERR_INVALID, "unknown option " + k2);
+    refresh_storage_rule(c);   // matrix_storage, matrix_free, tl_probe, tl_rap_agg decide the storage of K
     MFH_CATCH(c)
 }
 

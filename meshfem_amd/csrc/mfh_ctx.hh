@@ -56,10 +56,13 @@ struct mfh_ctx {
     bool symHasScatter = false;
     DBuf<int32_t> dRowPtr, dColIdx, dChunkRow, dSpmvChunkRow, dScatter;
     DBuf<int64_t> dContribPtr;
-    // option "matrix_storage" 1: only the blocks (r, c >= r) of K are stored and assembled -- what the reference's TripletMatrix holds
-    // (LinearElasticity.hh assembles the upper triangle). Half the bytes and half the block arithmetic; serves the consumers that need
-    // K only through its diagonal blocks or its upper triangle (block-Jacobi PCG on the matrix-free operator, exports). Everything
-    // that multiplies by the stored K (assembled SpMV, Galerkin coarse operator, partitioned solves) refuses it.
+    // Storage of K. upperOnly: only the blocks (r, c >= r) are stored and assembled -- the triangle the reference's TripletMatrix holds
+    // (LinearElasticity.hh assembles i <= j; SURVEY.md 8(d) "upper-only variant, matches reference storage"): 55 of an element's 100
+    // blocks, half the bytes. Every consumer that needs K through its diagonal blocks, its stored triangle or the Galerkin product works
+    // on it; what multiplies by the stored K (the assembled SpMV) needs both triangles.
+    // Option "matrix_storage": 1 upper, 0 both, -1 (default) automatic = upper exactly when nothing will multiply by the stored K:
+    // quadratic elasticity on the matrix-free operator (resolve_upper_storage). upperOnly is the state of the CURRENT symbolic phase.
+    int matrixStorage = -1;
     bool upperOnly = false;
     int nCU = 256;                    // compute units of the device (hipDeviceProp_t::multiProcessorCount)
     DBuf<uint32_t> dContribCode;
@@ -240,13 +243,21 @@ inline void check_residual_gap(const mfh_solve_info &li, double rtol) {
                                                ": K is singular on the free variables with an inconsistent right-hand side, or too ill-conditioned");
 }
 
-// consumers that multiply by the stored K cannot work on the upper-only storage (option "matrix_storage" 1)
+// the storage the next symbolic phase will build (see mfh_ctx::matrixStorage)
+inline bool resolve_upper_storage(const mfh_ctx *c) {
+    if (c->matrixStorage >= 0) return c->matrixStorage == 1;
+    return c->haveMesh && !c->hostOnly && !c->external && c->mesh.deg == 2 && c->op == MFH_OP_ELASTICITY && c->use_mf() && !c->tlProbe && c->tlRapAgg;
+}
+
+// consumers that multiply by the stored K cannot work on the upper-only storage (option "matrix_storage" 1; the automatic
+// choice never puts them there)
 inline void require_full_storage(const mfh_ctx *c, const char *what) {
     if (c->upperOnly) throw Error(MFH_ERR_UNSUPPORTED, std::string(what) + " needs both triangles of K: set option matrix_storage to 0");
 }
 
 inline int32_t dof_of(const mfh_ctx *c, int64_t node) { return c->dofForNode.empty() ? (int32_t)node : c->dofForNode[node]; }
 void invalidate_matrix(mfh_ctx *c);
+void refresh_storage_rule(mfh_ctx *c);
 void reset_bcs(mfh_ctx *c);
 void clear_fixed(mfh_ctx *c);
 void add_fixed(mfh_ctx *c, int64_t n, const int64_t *vars, const double *vals);

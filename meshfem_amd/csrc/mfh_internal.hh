@@ -157,7 +157,8 @@ void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofFo
 struct Symbolic {
     int64_t nRows = 0;                  // block rows (owned DoFs)
     int64_t nCols = 0;                  // block cols (all local DoFs)
-    int64_t nnzb = 0;
+    int64_t nnzb = 0;                   // STORED blocks
+    int64_t nMirror = 0;                // stored blocks (r, c) with r < c < nRows: with upper-only storage the logical K has nnzb + nMirror blocks
     std::vector<int32_t> rowPtr;        // nRows+1
     std::vector<int32_t> colIdx;        // nnzb
     // row chunks: consecutive rows whose slot count <= chunkSlots
@@ -422,7 +423,7 @@ void launch_tl_scatter(int nAgg, int nModes, int nColor, const int32_t *nbrOfCol
 void launch_tl_rap(const TLArgs &t, int64_t nRows, const int32_t *rowPtr, const int32_t *colIdx, const double *vals, double *Ac,
                    hipStream_t s);
 void launch_tl_rap_agg(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const int32_t *binCoord, const int32_t *rowPtr,
-                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly = false);
+                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly = false, int64_t nOwnedRows = 0);
 bool dense_spd_inverse_device(double *A, double *X, double *Ainv, double *Dinv, int64_t mp, int *notSpdDev, hipStream_t s);
 void launch_tl_gemv(int64_t m, int64_t ld, const double *A, const double *x, double *y, hipStream_t s);
 void launch_tl_prep(int64_t m, int64_t mp, const double *Ac, const uint8_t *dead, double maxd, double *Ap, hipStream_t s);

@@ -254,10 +254,12 @@ template <int DIM>
 __global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__restrict__ aggPtr, const int32_t *__restrict__ dofsByAgg,
                                                      const int32_t *__restrict__ binCoord /* nAgg x 3, may be null */,
                                                      const int32_t *__restrict__ rowPtr, const int32_t *__restrict__ colIdx,
-                                                     const double *__restrict__ vals, double *__restrict__ Ac, int upperOnly) {
+                                                     const double *__restrict__ vals, double *__restrict__ Ac, int upperOnly, int64_t nOwnedRows) {
     // upperOnly: only the blocks (r, c >= r) are stored. A stored off-diagonal block inside the aggregate also contributes its
     // transpose to the diagonal 6 x 6 block; between two aggregates this kernel writes the partial sums U[a][b] over the stored
-    // blocks and k_tl_mirror_upper completes them (Ac[a][b] = U[a][b] + U[b][a]^T).
+    // blocks and k_tl_mirror_upper completes them (Ac[a][b] = U[a][b] + U[b][a]^T). On a row-partitioned context the blocks
+    // (owned row, halo column) are stored by BOTH ranks that share them (halo columns are numbered after the owned rows): each
+    // counts them half, and the all-reduce of the ranks' mirrored partial sums gives the whole.
     constexpr int NB = DIM * DIM;
     constexpr int NM = DIM == 3 ? 6 : 3;
     constexpr int NSLOT = DIM == 3 ? 27 : 9;
@@ -288,8 +290,9 @@ __global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__r
             const int b = t.aggOfDof[c];
             const double rpc[3] = {t.relPos[c * 3], t.relPos[c * 3 + 1], t.relPos[c * 3 + 2]};
             double K[NB];
+            const double wgt = (upperOnly && c >= nOwnedRows) ? 0.5 : 1.0;
 #pragma unroll
-            for (int q = 0; q < NB; ++q) K[q] = vals[tiled_index(s, q, NB)];
+            for (int q = 0; q < NB; ++q) K[q] = wgt * vals[tiled_index(s, q, NB)];
             double T[NM * NM];
 #pragma unroll
             for (int l = 0; l < NM; ++l) {
@@ -1263,9 +1266,9 @@ __global__ void __launch_bounds__(256) k_tl_mirror_upper(double *__restrict__ Ac
 }
 
 void launch_tl_rap_agg(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const int32_t *binCoord, const int32_t *rowPtr,
-                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly) {
-    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap_agg<3>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0);
-    else hipLaunchKernelGGL(k_tl_rap_agg<2>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0);
+                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly, int64_t nOwnedRows) {
+    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap_agg<3>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows);
+    else hipLaunchKernelGGL(k_tl_rap_agg<2>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows);
     if (upperOnly) {
         const int64_t m = (int64_t)t.nAgg * (t.dim == 3 ? 6 : 3);
         hipLaunchKernelGGL(k_tl_mirror_upper, dim3(grid_for(m * m)), dim3(256), 0, s, Ac, m, t.dim == 3 ? 6 : 3);

@@ -707,6 +707,7 @@ mfh_status mfh_set_operator(mfh_ctx *c, int32_t op) {
     if (op != c->op) {
         c->op = op;
         invalidate_matrix(c);          // pattern and gather lists are shared by all operators; only the values change
+        refresh_storage_rule(c);       // ... unless the storage of K follows the operator (quadratic elasticity: upper triangle)
         if (c->haveMesh) clear_fixed(c);   // the variable numbering changes with the block size
     }
     MFH_CATCH(c)

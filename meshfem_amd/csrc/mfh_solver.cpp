@@ -690,7 +690,6 @@ mfh_status mfh_dist_setup(mfh_ctx *c, mfh_comm *cm, int32_t nPeers, const int32_
     MFH_TRY(c)
     require(c && c->haveMesh && cm && nPeers >= 0 && (nPeers == 0 || (peers && sendPtr && recvPtr)), MFH_ERR_INVALID, "bad distributed setup arguments");
     require(c->dofForNode.empty(), MFH_ERR_UNSUPPORTED, "row-partitioned contexts use the identity DoF map");
-    require_full_storage(c, "a row-partitioned context");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     auto &D = c->dist;

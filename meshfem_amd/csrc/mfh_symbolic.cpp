@@ -131,6 +131,9 @@ void build_symbolic(const HostMesh &m, const std::vector<int32_t> &dofForNode, i
             std::vector<int32_t>().swap(parts[t].cols);
         }
     }
+    S.nMirror = 0;
+    for (int64_t r = 0; r < S.nRows; ++r)
+        for (int32_t q = S.rowPtr[r]; q < S.rowPtr[r + 1]; ++q) S.nMirror += S.colIdx[q] > r && S.colIdx[q] < S.nRows;
 
     // ---- chunks
     if (chunkSlots < 64) chunkSlots = 64;

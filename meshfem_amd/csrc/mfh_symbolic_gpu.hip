@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(256) k_sym_heads(int64_t n, const uint64_t *__
 // at slot heads: column index and row length; at row heads: first contribution of the row
 __global__ void __launch_bounds__(256) k_sym_pattern(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ slotP1,
                                                      int32_t *__restrict__ colIdx, int32_t *__restrict__ rowLen,
-                                                     int64_t *__restrict__ rowCStart) {
+                                                     int64_t *__restrict__ rowCStart, int64_t nRows, unsigned long long *__restrict__ nMirror) {
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
         const uint64_t kk = key[k];
         const bool head = k == 0 || kk != key[k - 1];
@@ -48,6 +48,8 @@ __global__ void __launch_bounds__(256) k_sym_pattern(int64_t n, const uint64_t *
         const int64_t row = (int64_t)(kk >> 32);
         colIdx[slotP1[k] - 1] = (int32_t)(kk & 0xffffffffu);
         atomicAdd(&rowLen[row], 1);
+        const int64_t col = (int64_t)(kk & 0xffffffffu);
+        if (col > row && col < nRows) atomicAdd(nMirror, 1ull);     // blocks whose transpose is a block of K too (Symbolic::nMirror)
         if (k == 0 || (int64_t)(key[k - 1] >> 32) != row) rowCStart[row] = k;
     }
 }
@@ -196,7 +198,13 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     rowLen.zero(s);
     rowCStart.alloc((size_t)nRows + 1);
     MFH_HIP(hipMemsetAsync(rowCStart.p, 0xff, (size_t)(nRows + 1) * sizeof(int64_t), s));   // -1 = empty row
-    hipLaunchKernelGGL(k_sym_pattern, dim3(grid_of(nC)), dim3(256), 0, s, nC, keyB.p, slotP1.p, dColIdx.p, rowLen.p, rowCStart.p);
+    dCount.zero(s);
+    hipLaunchKernelGGL(k_sym_pattern, dim3(grid_of(nC)), dim3(256), 0, s, nC, keyB.p, slotP1.p, dColIdx.p, rowLen.p, rowCStart.p, nRows, dCount.p);
+    {
+        unsigned long long nm = 0;
+        dCount.download(&nm, 1, s);
+        S.nMirror = (int64_t)nm;
+    }
     RP(hipGetLastError());
     dRowPtr.alloc((size_t)nRows + 1);
     size_t exBytes = 0;

@@ -657,11 +657,14 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
     c.dev_sync(); torch.cuda.synchronize(); dist.barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
-    alg = 7736 if deg == 2 else 1328
+    # storage of K on a rank: automatic, like on one GPU (quadratic elasticity: the upper triangle of the owned rows plus the blocks
+    # towards halo columns; SURVEY 8d's upper-only figure). Linear meshes keep both triangles.
+    upper, stored_blocks = c.matrix_storage()
+    alg = (4316 if upper else 7736) if deg == 2 else 1328
     nE_loc = int(len(lm.elem_nodes))
     nr, nc, nnzb = c.matrix_info()
     sizes = c.symbolic_sizes()
-    comp = int(nnzb * 72 + nE_loc * 128 + sizes["n_contrib"] * 6 + sizes["n_chunk"] * 12 + nr * 4)
+    comp = int(stored_blocks * 72 + nE_loc * 128 + sizes["n_contrib"] * 6 + sizes["n_chunk"] * 12 + nr * 4)
     k_ms_max = max_over_ranks(k_ms)
     # HBM traffic of the assembly kernel on a rank's slab: from the committed rocprofv3 --pmc profile of the same local shape
     # (scripts/pmc_collect.py <grid> slab:<world>:<rank>, collected on one GPU: the assembly has no communication)
@@ -670,7 +673,7 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
     if rank == 0 and os.path.exists(prof):
         try:
             pj = json.load(open(prof))
-            if abs(pj["meta"]["elems"] - nE_loc) <= 0.02 * nE_loc and pj["meta"]["n"] == args.grid and deg == 2:
+            if abs(pj["meta"]["elems"] - nE_loc) <= 0.02 * nE_loc and pj["meta"]["n"] == args.grid and deg == 2 and pj["meta"].get("storage", "full") == ("upper" if upper else "full"):
                 traffic, traffic_src = pj["k_assemble_gather"]["traffic_bytes"] * (nE_loc / float(pj["meta"]["elems"])), "profiles/" + os.path.basename(prof)
         except (OSError, KeyError, ValueError):
             pass
@@ -694,7 +697,8 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
                                   "measurement" % (world, torch.cuda.device_count())) if shared_gpus else "one rank per GPU"),
                roofline=dict(bound="hbm", kernel="k_assemble_gather", achieved=alg * nE_loc / k_ms / 1e6, peak=8000.0,
                              unit="GB/s", frac=alg * nE_loc / k_ms / 1e6 / 8000.0, kernel_ms=k_ms, kernel_ms_max_over_ranks=k_ms_max,
-                             compulsory_bytes=comp, frac_compulsory=comp / k_ms / 1e6 / 8000.0,
+                             compulsory_bytes=comp, frac_compulsory=comp / k_ms / 1e6 / 8000.0, bytes_per_element=alg,
+                             matrix_storage="upper triangle of the owned rows (+ the blocks towards halo columns)" if upper else "both triangles",
                              traffic=(traffic / k_ms / 1e6) if traffic else None, frac_traffic=(traffic / k_ms / 1e6 / 8000.0) if traffic else None,
                              traffic_bytes_per_launch_from_profile=traffic, traffic_from_profile=traffic_src,
                              traffic_note="PMC counters are collected per shape in their own rocprofv3 passes on ONE GPU (the assembly has no "

@@ -21,11 +21,11 @@ if slab:
     c.symbolic(False)
     c.set_option("reembed", 1)
     ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, 3)
-    c.set_option("matrix_free", 0)
-    sp = c.time_spmv_kernel(3)      # k_axpby calibration launch + assembled SpMV on the local columns
+    upper, stored = c.matrix_storage()      # automatic storage: upper triangle of the owned rows for quadratic elasticity
+    sp = c.time_spmv_kernel(3)      # k_axpby calibration launch + the operator on the local columns
     nr, nc, nnzb = c.matrix_info()
     nE = len(lm.elem_nodes)
-    print(json.dumps(dict(n=n, slab=slab, global_grid=[ng, ng, layers * world], elems=nE, nnzb=nnzb, rows=nr, asm_ms=ms, spmv_ms=sp,
+    print(json.dumps(dict(n=n, slab=slab, storage="upper" if upper else "full", stored_blocks=stored, global_grid=[ng, ng, layers * world], elems=nE, nnzb=nnzb, rows=nr, asm_ms=ms, spmv_ms=sp,
                           calib_axpby_doubles=3 * nc, asm_alg_bytes=7736 * nE, asm_expected_hbm_bytes=nnzb * 72 + nE * 100 * 6 + nE * 128)))
     sys.exit(0)
 V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
@@ -40,6 +40,7 @@ if os.environ.get("PMC_UPPER_STORAGE") == "1":      # the upper-triangle storage
     print(json.dumps(dict(n=n, storage="upper", elems=len(T), nnzb=nnzb, rows=nr, asm_ms=ms, mf_ms=mf, calib_axpby_doubles=3 * nc,
                           asm_alg_bytes=7736 * len(T), asm_expected_hbm_bytes=nnzb * 72 + len(T) * 55 * 6 + len(T) * 128)))
     sys.exit(0)
+c.set_option("matrix_storage", 0)       # both triangles throughout (the assembled SpMV below needs them); PMC_UPPER_STORAGE=1 for the other
 c.mesh_build(T, V, 2)
 c.material_isotropic(200, 0.35)
 c.symbolic(False)

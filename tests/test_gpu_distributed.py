@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n, ret):
+def _worker(rank, world, port, n, ret, storage=-1):
     import torch
     import torch.distributed as dist
     import meshfem_amd as M
@@ -34,9 +34,12 @@ def _worker(rank, world, port, n, ret):
         dev = torch.device("cuda", 0)
         lm = D.slab_local_mesh(n, rank, world, 2)
         c = M.Context(0)
+        c.set_option("matrix_storage", storage)
         c.mesh_set(3, 2, lm.elem_nodes, lm.node_pos, lm.n_owned)
         c.material_isotropic(200.0, 0.35)
         c.assemble()
+        # quadratic elasticity on the matrix-free operator: the automatic choice stores the upper triangle of the owned rows
+        assert c.matrix_storage()[0] == (storage != 0)
         comm = D.make_comm(c, rank, world)            # gloo process group -> callbacks staged through the host
         assert comm.kind == "callbacks"
         comm.selftest()
@@ -83,14 +86,18 @@ def _worker(rank, world, port, n, ret):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_one_gpu_partitioned_solve_matches_single_context():
+@pytest.mark.parametrize("storage", [-1, 0])
+def test_two_ranks_one_gpu_partitioned_solve_matches_single_context(storage):
+    """storage: option matrix_storage of the ranks' contexts (-1 automatic = upper triangle of the owned rows, the blocks towards
+    halo columns kept by both ranks and counted half in the Galerkin product; 0 = both triangles): same solutions, same
+    iteration counts."""
     import torch.multiprocessing as mp
     import meshfem_amd as M
     from meshfem_amd import grid
     world, n = 2, 6
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), n, ret), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n, ret, storage), nprocs=world, join=True)
     assert set(ret.keys()) == {0, 1}
     # the same problem in one context
     V, T = grid.grid_tet_mesh(n, n, n * world, [0, 0, 0], [1, 1, world])
@@ -116,6 +123,12 @@ def test_two_ranks_one_gpu_partitioned_solve_matches_single_context():
     assert seen == len(keys)                                   # every node owned exactly once
     assert ret[0]["it_bj"] == ret[1]["it_bj"] and ret[0]["it_tl"] == ret[1]["it_tl"]
     assert ret[0]["it_tl"] < 0.6 * ret[0]["it_bj"], (ret[0]["it_tl"], ret[0]["it_bj"])
+    _ITERATIONS[storage] = (ret[0]["it_bj"], ret[0]["it_tl"])
+    if len(_ITERATIONS) == 2:                                  # the coarse operator is the same whatever the storage
+        assert abs(_ITERATIONS[-1][1] - _ITERATIONS[0][1]) <= 1 and abs(_ITERATIONS[-1][0] - _ITERATIONS[0][0]) <= 1, _ITERATIONS
+
+
+_ITERATIONS = {}
 
 
 def _worker_general(rank, world, port, ret):

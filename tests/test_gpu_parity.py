@@ -1110,7 +1110,9 @@ def test_upper_only_storage_assembles_the_reference_triangle(mode, periodic):
         assert set(ref) <= set(got)
         assert max(abs(got[k] - ref[k]) for k in ref) / np.abs(Kt.v).max() < K_RTOL
         nr, nc, nnzb = c.matrix_info()
-        out[storage] = nnzb
+        out[storage] = (nnzb, c.matrix_storage())
+        A = c.export_scipy()                                    # K itself, whatever the storage (the missing triangle is mirrored)
+        assert abs(A - Kt.to_scipy_full_from_upper()).max() / np.abs(Kt.v).max() < K_RTOL
         # a solve that needs K only through its diagonal blocks: block-Jacobi PCG on the matrix-free operator
         n = 3 * nr
         rng = np.random.default_rng(3)
@@ -1137,7 +1139,47 @@ def test_upper_only_storage_assembles_the_reference_triangle(mode, periodic):
                         c.apply_K(f)
                 assert ei.value.code == M._lib.ERR_UNSUPPORTED and "both triangles" in str(ei.value)
         c.close()
-    assert out[1] == (out[0] + nr) // 2                        # diagonal blocks + one of every off-diagonal pair
+    assert out[0][0] == out[1][0] and out[0][1] == (False, out[0][0])          # matrix_info: the blocks of K; storage 0 holds them all,
+    assert out[1][1] == (True, (out[0][0] + nr) // 2)                          # storage 1 the diagonal blocks + one of every off-diagonal pair
     assert np.linalg.norm(out["u1"] - out["u0"]) <= 1e-7 * np.linalg.norm(out["u0"])
     assert np.linalg.norm(out["t1"] - out["u0"]) <= 1e-7 * np.linalg.norm(out["u0"])
     assert abs(out["it1"] - out["it0"]) <= 1                   # the same coarse operator, to rounding
+
+
+def test_storage_of_K_follows_what_will_read_it():
+    """Option matrix_storage -1 (default): quadratic elasticity runs its PCG on the matrix-free operator, nothing multiplies by
+    the stored K, and the context stores the upper triangle; asking for the assembled SpMV (matrix_free 0), a linear mesh or a
+    scalar operator switches to both triangles. The matrix every export shows is K either way."""
+    V, T = grid.grid_tet_mesh(3, 3, 2)
+    ref = {}
+    for deg in (1, 2):
+        sim = O.Simulator(T, V, deg)
+        sim.set_material_constant(_iso())
+        ref[deg] = sim.assembleStiffnessMatrix().sum_repeated().to_scipy_full_from_upper()
+    c = _ctx()
+    c.mesh_build(T, V, 2)
+    c.material_isotropic(200.0, 0.35)
+    c.assemble()
+    nr, nc, nnzb = c.matrix_info()
+    assert c.matrix_storage() == (True, (nnzb + nr) // 2)
+    assert abs(c.export_scipy() - ref[2]).max() < K_RTOL * abs(ref[2]).max()
+    x = np.random.default_rng(0).standard_normal(3 * nr)
+    y_mf = c.apply_K(x)
+    c.set_option("matrix_free", 0)                              # the assembled SpMV needs both triangles: re-assembled
+    y_sp = c.apply_K(x)
+    assert c.matrix_storage() == (False, nnzb) and c.matrix_info() == (nr, nc, nnzb)
+    assert np.linalg.norm(y_sp - ref[2] @ x) < 1e-12 * np.linalg.norm(y_sp) and np.linalg.norm(y_mf - y_sp) < 1e-12 * np.linalg.norm(y_sp)
+    c.set_option("matrix_free", -1)
+    c.assemble()
+    assert c.matrix_storage()[0]
+    c.set_operator(M.OP_LAPLACIAN)                              # scalar operators are applied through the assembled matrix
+    c.assemble()
+    assert not c.matrix_storage()[0]
+    c.close()
+    c = _ctx()
+    c.mesh_build(T, V, 1)
+    c.material_isotropic(200.0, 0.35)
+    c.assemble()
+    assert not c.matrix_storage()[0]
+    assert abs(c.export_scipy() - ref[1]).max() < K_RTOL * abs(ref[1]).max()
+    c.close()
