@@ -417,10 +417,13 @@ mfh_status mfh_matrix_free_info(mfh_ctx* ctx, int32_t* active, int32_t* mode, in
  *   corner positions instead of reading the element records), "mf_xcd_group" (32 default: consecutive element blocks per XCD),
  *   "mf_lane_stride" (37 default: lane-to-element stride inside a block, against same-address LDS atomics),
  * "pcg_graph" (1 default: blocks of check_every PCG iterations are replayed from a hipGraph),
- * "matrix_storage" (0 default: both triangles of K; 1: only the blocks (r, c >= r), the triangle the reference's TripletMatrix holds --
- *   half the bytes and block arithmetic of the assembly; serves mfh_export_upper_triplets, the (block-)Jacobi and two-level PCG on the
- *   matrix-free operator; the assembled SpMV, the probing construction of the coarse operator and row-partitioned contexts return
- *   MFH_ERR_UNSUPPORTED; mfh_export_bsr / mfh_matrix_info then describe the stored triangle),
+ * "matrix_storage" (which blocks of K are stored and assembled. 1: only the blocks (r, c >= r), the triangle the reference's TripletMatrix
+ *   holds -- half the bytes and block arithmetic of the assembly; serves mfh_export_upper_triplets, mfh_export_bsr (mirrored on the host),
+ *   the (block-)Jacobi and two-level PCG on the matrix-free operator; the assembled SpMV and the probing construction of the coarse
+ *   operator return MFH_ERR_UNSUPPORTED on it. 0: both triangles. -1 default: automatic -- the upper triangle exactly when nothing
+ *   multiplies by the stored K (quadratic elasticity on the matrix-free operator), both triangles otherwise; changing an option that
+ *   decides this re-runs the symbolic phase on the next use. mfh_matrix_info / mfh_export_bsr describe K itself either way,
+ *   mfh_matrix_storage what is stored),
  * "pcg_variant" (1: Chronopoulos-Gear PCG, one reduction point per iteration and one fused vector kernel -- always used by
  *   mfh_dist_solve and for batches; 0: the classic two-reduction PCG, one right-hand side at a time; -1 default: classic for
  *   a single right-hand side on an unpartitioned context, where it is 6-14 % faster per iteration), "dist_pcg_variant"
