@@ -101,7 +101,14 @@ void set_isotropic(mfh_ctx *c, double E, double nu) {
     invalidate_matrix(c);
 }
 
-void ensure_geometry(mfh_ctx *c) {
+void ensure_pass_events(mfh_ctx *c) {
+    if (c->passEv[0]) return;
+    for (auto &e : c->passEv) MFH_HIP(hipEventCreate(&e));
+    MFH_HIP(hipHostMalloc((void **)&c->negHost, 2 * sizeof(int), hipHostMallocDefault));
+}
+
+// deferCheck: launch only; the caller runs finish_geometry after it has queued more work behind the embedding kernel
+void ensure_geometry(mfh_ctx *c, bool deferCheck) {
     require(c->haveMesh, MFH_ERR_STATE, "no mesh set");
     if (c->geoValid) return;
     require(!c->hostOnly, MFH_ERR_HIP, "host-only context (device -1): no HIP device, and there is no CPU fallback");
@@ -121,12 +128,25 @@ void ensure_geometry(mfh_ctx *c) {
     c->dGeo.alloc((size_t)m.nElem * c->geoStride);
     c->dNeg.alloc(2);   // [0] inverted elements, [1] elements with an indefinite orthotropic tensor
     c->dNeg.zero(c->stream);
-    EventTimer t(c->stream);
+    ensure_pass_events(c);
+    MFH_HIP(hipEventRecord(c->passEv[0], c->stream));
     k::launch_geometry(m.dim, m.deg, c->matKind, m.nElem, c->dElemNodes.p, m.npe, c->dVertPos.p, c->dMatParams.p, c->matMode,
                        c->dGeo.p, c->geoStride, c->dNeg.p, c->stream);
-    c->timing.geometry_ms = t.stop();
-    int neg[2] = {0, 0};
-    c->dNeg.download(neg, 2, c->stream);
+    MFH_HIP(hipEventRecord(c->passEv[1], c->stream));
+    MFH_HIP(hipMemcpyAsync(c->negHost, c->dNeg.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    c->geoPending = true;
+    if (!deferCheck) finish_geometry(c);
+}
+
+// second half of the embedding: wait for it, read its time and its counters of inverted / indefinite elements
+void finish_geometry(mfh_ctx *c) {
+    if (!c->geoPending) return;
+    c->geoPending = false;
+    MFH_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    MFH_HIP(hipEventElapsedTime(&ms, c->passEv[0], c->passEv[1]));
+    c->timing.geometry_ms = ms;
+    const int neg[2] = {c->negHost[0], c->negHost[1]};
     if (neg[0] > 0)   // LinearElasticity.hh:465-472
         throw Error(MFH_ERR_INVALID, "Mesh has negatively oriented elements.\nCorrect with: mesh_convert --reorientNegativeElements. (" +
                                          std::to_string(neg[0]) + " elements)");
@@ -923,6 +943,8 @@ void mfh_destroy(mfh_ctx *c) {
     if (c->stream) { (void)hipStreamSynchronize(c->stream); }
     hipStream_t s = c->stream;
     const bool own = c->ownStream;
+    for (auto &e : c->passEv) if (e) (void)hipEventDestroy(e);
+    if (c->negHost) (void)hipHostFree(c->negHost);
     delete c;   // device buffers are freed while the stream is still alive
     if (s && own) (void)hipStreamDestroy(s);
 }
@@ -1227,10 +1249,18 @@ mfh_status mfh_assemble(mfh_ctx *c, int32_t mode) {
     if (c->alwaysReembed) { c->geoValid = false; c->hGeoValid = false; }
     ensure_symbolic(c, mode == MFH_ASSEMBLE_ATOMIC);
     RoctxRange range("Assemble System");
-    ensure_geometry(c);
-    EventTimer t(c->stream);
+    // embedding kernel and assembly kernel back to back, one synchronisation for both (their times and the embedding's
+    // counters of inverted elements are read afterwards: an inverted mesh is reported after K has been written, and left invalid)
+    ensure_geometry(c, true);
+    ensure_pass_events(c);
+    MFH_HIP(hipEventRecord(c->passEv[2], c->stream));
     run_assembly(c, mode);
-    c->timing.assemble_ms = t.stop();
+    MFH_HIP(hipEventRecord(c->passEv[3], c->stream));
+    if (c->geoPending) finish_geometry(c);
+    else MFH_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    MFH_HIP(hipEventElapsedTime(&ms, c->passEv[2], c->passEv[3]));
+    c->timing.assemble_ms = ms;
     c->assembled = true;
     c->dinvValid = false;
     MFH_CATCH(c)

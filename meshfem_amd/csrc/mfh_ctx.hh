@@ -41,6 +41,11 @@ struct mfh_ctx {
     DBuf<int> dNeg;
     int geoStride = GEO_ISO_STRIDE;
     bool geoValid = false;
+    // one assembly pass = embedding kernel + assembly kernel launched back to back and ONE synchronisation at the end (the
+    // negative-volume counters and the two kernel times are read then): persistent events and a pinned host word pair
+    hipEvent_t passEv[4] = {nullptr, nullptr, nullptr, nullptr};   // embedding start / stop, assembly start / stop
+    int *negHost = nullptr;                                        // hipHostMalloc'ed [2]
+    bool geoPending = false;                                       // embedding launched, counters not yet checked
     std::vector<double> hGeo;         // lazily downloaded copy (loads / post-processing)
     bool hGeoValid = false;
 
@@ -261,7 +266,8 @@ void refresh_storage_rule(mfh_ctx *c);
 void reset_bcs(mfh_ctx *c);
 void clear_fixed(mfh_ctx *c);
 void add_fixed(mfh_ctx *c, int64_t n, const int64_t *vars, const double *vals);
-void ensure_geometry(mfh_ctx *c);
+void ensure_geometry(mfh_ctx *c, bool deferCheck = false);
+void finish_geometry(mfh_ctx *c);
 void ensure_mf_cluster(mfh_ctx *c);
 void ensure_precond(mfh_ctx *c);
 bool ensure_twolevel(mfh_ctx *c);
