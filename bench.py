@@ -46,7 +46,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--grid", type=int, default=60, help="hexes per side (per-rank slab thickness for N>1)")
+    ap.add_argument("--grid", type=int, default=0, help="hexes per side (0 = 60: configs[2] / the per-rank volume of the weak-scaling run; "
+                                                        "119 with --scaling strong: configs[4])")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("MFH_BENCH_SCALING", "weak"),
+                    help="N > 1: weak = ~60^3 hexes per rank (N = 8: the 120^3 cube); strong = ONE grid^3 cube (default 119^3 = configs[4], "
+                         "40.4 M P2 tets) dealt out over the N ranks, N = 1 runs it in one context (north_star: >= 6x at 8 GPUs)")
     ap.add_argument("--deg", type=int, default=2)
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--maxit", type=int, default=20000)
@@ -59,7 +63,10 @@ def parse():
     ap.add_argument("--cpu-solve-grid", type=int, default=0, help="grid size of the CPU direct-solve sample (0 = auto)")
     ap.add_argument("--ranks-per-gpu-ok", action="store_true",
                     help="N > visible GPUs: share the GPUs (ranks on one GPU talk through gloo, staged through the host)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.grid <= 0:
+        a.grid = 119 if a.scaling == "strong" else 60
+    return a
 
 
 def pmc_traffic(kernel_key, n, deg, profile=None):
@@ -160,12 +167,31 @@ def cpu_baseline(deg, cpu_grid):
         h.mesh_build(T, V, deg)
         en, nn = h.elem_nodes(), h.n_node
         h.close()
-        _, _, _, t = CO.assemble_csc(3, deg, en, V, D, nn)
+        Ap, Ai, Ax, t = CO.assemble_csc(3, deg, en, V, D, nn)
         best = dict(value=len(T) / t["total"], unit="elements/s", cores=CO.num_threads(), kind="port",
                     sample="%d^3 grid -> %d P%d tets; threaded Ke %.2fs + serial triplet push %.2fs + sumRepeated/CSC %.2fs"
                            % (n, len(T), deg, t["ke"], t["push"], t["compress"]))
+        last = (n, V, T, Ap, Ai, Ax)
         if t["total"] > 8.0:
             break
+        del Ap, Ai, Ax
+    # the matrix the timing above produced is not thrown away: the HIP path assembles the SAME sample and its
+    # mfh_export_upper_triplets (== TripletMatrix::dumpBinary after sumRepeated) is compared entry by entry with the oracle's CSC
+    try:
+        from oracle import parity
+        n, V, T, Ap, Ai, Ax = last
+        c = M.Context(0)
+        c.mesh_build(T, V, deg)
+        c.material_isotropic(200.0, 0.35)
+        c.assemble()
+        i, j, v = c.export_upper_triplets()
+        c.close()
+        kp = parity.compare_upper_triplets_with_csc(i, j, v, Ap, Ai, Ax)
+        kp["sample"] = "%d^3 grid -> %d P%d tets" % (n, len(T), deg)
+        kp["ok"] = bool(kp["pattern_identical"] and kp["order_is_sumRepeated"] and kp["max_rel_err"] <= 1e-12)
+        best["k_parity"] = kp
+    except Exception as e:   # noqa: BLE001 -- reported inside the line, never silently dropped
+        best["k_parity"] = dict(ok=False, error="%s: %s" % (type(e).__name__, e))
     return best
 
 
@@ -214,6 +240,9 @@ def run_single(args):
     torch.cuda.set_device(0)
     hbm_measured = hbm_stream_probe(torch)
     n, deg = args.grid, args.deg
+    strong = args.scaling == "strong"
+    if strong:      # one 40 M-element context: no room (and no point) for the storage / ordering variants next to it
+        args.no_orderings = True
     t0 = time.time()
     V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
     t_gen = time.time() - t0
@@ -263,10 +292,11 @@ def run_single(args):
         roof["measured_triad_GBs"] = hbm_measured["triad_GBs"]
         roof["traffic_frac_of_measured_triad"] = roof["traffic"] / hbm_measured["triad_GBs"]
     out = dict(metric="stiffness_assembly_elements_per_s", value=value, unit="elements/s", n_gpus=1, steps=args.steps,
-               warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, scaling="weak", vs_baseline=None,
+               warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, scaling=args.scaling, vs_baseline=None,
                dtype="f64", data="synthetic",
-               config=dict(workload="configs[2]: %d^3 grid -> %d P%d tets, isotropic E=200 nu=0.35, Dirichlet x=0, traction x=1"
-                                    % (n, nE, deg), elements=nE, nodes=c.n_node, dof=3 * c.n_dof, nnz_blocks=nnzb,
+               config=dict(workload="%s: %d^3 grid -> %d P%d tets, isotropic E=200 nu=0.35, Dirichlet x=0, traction x=1"
+                                    % ("configs[4] on one GPU (the N = 1 point of the strong-scaling curve)" if strong else "configs[2]", n, nE, deg),
+                           elements=nE, nodes=c.n_node, dof=3 * c.n_dof, nnz_blocks=nnzb,
                            stored_blocks=stored_blocks, matrix_storage="upper" if upper else "full",
                            parallelism="1 GPU", step="embed + Ke blocks + assembly into block-CSR (gather/owner-computes)"),
                roofline=roof, hbm_measured=hbm_measured,
@@ -278,7 +308,20 @@ def run_single(args):
         c.assemble()
     except M.MeshFEMHipError as e:
         out["variants"] = dict(atomic_scatter=str(e))
-    if not args.no_solve:
+    if not args.no_solve and strong:
+        # the N = 1 point of the strong-scaling curve: the solver the N > 1 runs use (two-level PCG), time to rtol
+        c.set_preconditioner(M.PRECOND_TWO_LEVEL)
+        t0 = time.time()
+        u = c.sim_solve(rtol=args.rtol, maxit=args.maxit)
+        i2, p2 = dict(c.last_info), c.precond_info()
+        ndof = 3 * c.n_dof
+        out["pcg"] = dict(iterations=i2["iterations"], converged=bool(i2["converged"]), rtol=args.rtol, rel_residual=i2["rel_residual"],
+                          true_rel_residual=i2["true_rel_residual"], solve_s=i2["solve_ms"] * 1e-3, dof=ndof,
+                          dof_per_s=ndof * i2["iterations"] / (i2["solve_ms"] * 1e-3), ms_per_iteration=i2["solve_ms"] / max(1, i2["iterations"]),
+                          preconditioner="two-level: 3x3 block-Jacobi + rigid-body modes of %d aggregates" % p2["aggregates"],
+                          coarse_setup_ms=p2["setup_ms"], coarse_dim=p2["coarse_dim"], wall_s=time.time() - t0, max_abs_u=float(np.abs(u).max()),
+                          operator="matrix-free (k_mf_cluster + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)", ranks=1)
+    elif not args.no_solve:
         t0 = time.time()
         u = c.sim_solve(rtol=args.rtol, maxit=args.maxit)
         info = dict(c.last_info)
@@ -351,7 +394,7 @@ def run_single(args):
             out["pcg_two_level"] = str(e)
     # The same pass with BOTH triangles of K stored (option matrix_storage 0: the round-1 definition of this benchmark, and what a
     # context does on its own when something multiplies by the stored K). Same timed region (embedding + blocks + assembly).
-    if upper:
+    if upper and not strong:
         try:
             c.close()
             cu = M.Context(0)

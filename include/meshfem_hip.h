@@ -196,7 +196,8 @@ mfh_status mfh_export_bsr(mfh_ctx* ctx, int32_t* rowPtr /* nBlockRows+1 */, int3
 /* == TripletMatrix after m_assembleStiffnessMatrix + sumRepeated: upper triangle (row<=col) in
  * column-major sorted order with exact zeros pruned (SparseMatrices.hh:231-234,370-373); same
  * content as TripletMatrix::dumpBinary (SparseMatrices.hh:629-645). Call with i=j=v=NULL to get
- * the count in *nnz; otherwise *nnz is the capacity on entry.                                  */
+ * a sufficient capacity in *nnz (the structural entries of the triangle); otherwise *nnz is the
+ * capacity on entry and the number of entries written on return.                               */
 mfh_status mfh_export_upper_triplets(mfh_ctx* ctx, uint64_t* i, uint64_t* j, double* v, uint64_t* nnz);
 /* per-element dense Ke (debug/parity): full symmetric (n*dim)^2 row-major, local dof = dim*node+c */
 mfh_status mfh_element_stiffness(mfh_ctx* ctx, int64_t firstElem, int64_t count, double* Ke);

@@ -257,8 +257,8 @@ class Context:
         n = C.c_uint64(0)
         self._ck(self.lib.mfh_export_upper_triplets(self.h, None, None, None, C.byref(n)))
         i, j, v = np.empty(n.value, np.uint64), np.empty(n.value, np.uint64), np.empty(n.value)
-        self._ck(self.lib.mfh_export_upper_triplets(self.h, ptr(i), ptr(j), ptr(v), C.byref(n)))
-        return i, j, v
+        self._ck(self.lib.mfh_export_upper_triplets(self.h, ptr(i), ptr(j), ptr(v), C.byref(n)))   # n: entries written (zeros pruned)
+        return i[:n.value], j[:n.value], v[:n.value]
 
     def element_stiffness(self, first=0, count=None):
         count = self.n_elem - first if count is None else count

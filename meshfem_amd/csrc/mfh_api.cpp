@@ -43,6 +43,7 @@ void invalidate_matrix(mfh_ctx *c) {
     c->tl.valid = false;
 }
 void invalidate_symbolic(mfh_ctx *c) {
+    ++c->listsGen;                  // overlap lists of a partitioned solve (Dist::opList) are stale from here on
     c->symValid = false;
     c->mfValid = false;
     c->mfcValid = false;
@@ -85,6 +86,7 @@ void upload_mesh(mfh_ctx *c) {
     build_shape_tables(c->mesh.dim, c->mesh.deg, c->tables);
     if (!c->hostOnly) { c->dPairTable.upload(c->tables.pairTable, c->stream); c->dMassTable.upload(c->tables.massRef, c->stream); }
     invalidate_symbolic(c);
+    dist_detach(c);                  // exchange lists describe the previous mesh: mfh_dist_setup must run again
     reset_bcs(c);
     clear_fixed(c);
 }
@@ -215,6 +217,7 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
         const size_t tilesD = (size_t)((S.nnzb + 63) / 64);
         c->dVals.alloc(tilesD * 64 * (size_t)c->dim() * c->dim());
         c->symValid = true;
+        ++c->listsGen;
         invalidate_matrix(c);
         return;
     }
@@ -240,6 +243,7 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
     const size_t tiles = (size_t)((S.nnzb + 63) / 64);
     c->dVals.alloc(tiles * 64 * (size_t)c->dim() * c->dim());
     c->symValid = true;
+    ++c->listsGen;
     invalidate_matrix(c);
 }
 
@@ -325,6 +329,7 @@ void ensure_mf_cluster(mfh_ctx *c) {
         return;
     }
     c->mfcValid = true;
+    ++c->listsGen;
 }
 
 k::SpmvMfArgs spmv_mf_cluster_args(mfh_ctx *c, bool masked) {
@@ -656,7 +661,7 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
     if (c->anyFixedNonzero && !c->solveHomogeneous) {
         c->wu0.alloc(n);
         c->wu0.zero(s);
-        k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wu0.p, s);
+        k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wu0.p, n, s);
         apply_operator(c, false, c->wu0.p, c->wAp.p, nullptr);
         k::launch_axpby(n, -1.0, c->wAp.p, 1.0, c->wb.p, s);
     }
@@ -770,7 +775,7 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
     li.rel_residual = bb > 0 ? std::sqrt(rrFinal / bb) : 0.0;
     // u = x + ubar  (SparseMatrices.hh:2592-2605)
     if (!c->fixedVars.empty() && !c->solveHomogeneous)
-        k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wx.p, s);
+        k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wx.p, n, s);
     // true residual on the free variables: || mask(f - K u) || / ||b||
     if (bb > 0) {
         apply_operator(c, false, c->wx.p, c->wAp.p, nullptr);
@@ -944,6 +949,9 @@ void mfh_destroy(mfh_ctx *c) {
     hipStream_t s = c->stream;
     const bool own = c->ownStream;
     for (auto &e : c->passEv) if (e) (void)hipEventDestroy(e);
+    dist_detach(c);
+    for (auto &e : c->dist.ev) if (e) (void)hipEventDestroy(e);
+    if (c->dist.commStream) { (void)hipStreamSynchronize(c->dist.commStream); (void)hipStreamDestroy(c->dist.commStream); }
     if (c->negHost) (void)hipHostFree(c->negHost);
     delete c;   // device buffers are freed while the stream is still alive
     if (s && own) (void)hipStreamDestroy(s);
@@ -1346,6 +1354,7 @@ mfh_status mfh_matrix_set_upper_triplets(mfh_ctx *c, int64_t n, int64_t nnz, con
     vals.resize(((vals.size() + 63) / 64) * 64, 0.0);      // tiled layout with 1 component per entry = plain array
     c->dVals.upload(vals, c->stream);
     c->symValid = true;
+    ++c->listsGen;
     c->assembled = true;
     c->dinvValid = false;
     c->tl.valid = false;
@@ -1423,6 +1432,17 @@ mfh_status mfh_export_upper_triplets(mfh_ctx *c, uint64_t *oi, uint64_t *oj, dou
     ensure_host_colidx(c);
     const Symbolic &S = c->sym;
     const int d = c->bs(), nb = d * d;
+    if (!(oi && oj && ov)) {
+        // capacity query: the structural entries of the upper triangle (an upper bound of the count: exact zeros are pruned below)
+        uint64_t cap = 0;
+        for (int64_t r = 0; r < S.nRows; ++r)
+            for (int32_t q = S.rowPtr[r]; q < S.rowPtr[r + 1]; ++q) {
+                const int64_t col = S.colIdx[q];
+                if (col >= r) cap += col == r ? (uint64_t)d * (d + 1) / 2 : (uint64_t)nb;
+            }
+        *nnz = cap;
+        return MFH_OK;
+    }
     std::vector<double> vals((size_t)S.nnzb * nb);
     {
         DBuf<double> aos;
@@ -1430,25 +1450,35 @@ mfh_status mfh_export_upper_triplets(mfh_ctx *c, uint64_t *oi, uint64_t *oj, dou
         k::launch_untile_vals(d, S.nnzb, c->dVals.p, aos.p, c->stream);
         aos.download(vals.data(), vals.size(), c->stream);
     }
-    struct T { uint64_t i, j; double v; };
-    std::vector<T> t;
+    // (col, row) order without a comparison sort -- sumRepeated's own counting sort by column (SparseMatrices.hh:280-374): count the
+    // entries of every scalar column, then visit the scalar ROWS in ascending order, so that each column receives its rows ascending
+    const int64_t n = (int64_t)S.nRows * d;
+    std::vector<uint64_t> colPtr((size_t)n + 1, 0);
     for (int64_t r = 0; r < S.nRows; ++r)
-        for (int32_t s = S.rowPtr[r]; s < S.rowPtr[r + 1]; ++s) {
-            const int64_t col = S.colIdx[s];
+        for (int32_t q = S.rowPtr[r]; q < S.rowPtr[r + 1]; ++q) {
+            const int64_t col = S.colIdx[q];
             if (col < r) continue;
-            for (int a = 0; a < d; ++a)
-                for (int b = 0; b < d; ++b) {
-                    const uint64_t gi = (uint64_t)r * d + a, gj = (uint64_t)col * d + b;
-                    const double v = vals[(size_t)s * nb + a * d + b];
-                    if (gi <= gj && v != 0.0) t.push_back(T{gi, gj, v});   // pruneTol = 0 (SparseMatrices.hh:370-373)
-                }
+            for (int a2 = 0; a2 < d; ++a2)
+                for (int b2 = 0; b2 < d; ++b2)
+                    if (r * d + a2 <= col * d + b2 && vals[(size_t)q * nb + a2 * d + b2] != 0.0) ++colPtr[(size_t)(col * d + b2) + 1];   // pruneTol = 0 (:370-373)
         }
-    std::sort(t.begin(), t.end(), [](const T &x, const T &y) { return x.j != y.j ? x.j < y.j : x.i < y.i; });
-    if (oi && oj && ov) {
-        require(*nnz >= t.size(), MFH_ERR_INVALID, "triplet buffers too small");
-        for (size_t k2 = 0; k2 < t.size(); ++k2) { oi[k2] = t[k2].i; oj[k2] = t[k2].j; ov[k2] = t[k2].v; }
-    }
-    *nnz = t.size();
+    for (int64_t j2 = 0; j2 < n; ++j2) colPtr[(size_t)j2 + 1] += colPtr[(size_t)j2];
+    require(*nnz >= colPtr[(size_t)n], MFH_ERR_INVALID, "triplet buffers too small");
+    *nnz = colPtr[(size_t)n];
+    for (int64_t r = 0; r < S.nRows; ++r)
+        for (int a2 = 0; a2 < d; ++a2)
+            for (int32_t q = S.rowPtr[r]; q < S.rowPtr[r + 1]; ++q) {
+                const int64_t col = S.colIdx[q];
+                if (col < r) continue;
+                for (int b2 = 0; b2 < d; ++b2) {
+                    const uint64_t gi = (uint64_t)r * d + a2, gj = (uint64_t)col * d + b2;
+                    const double v = vals[(size_t)q * nb + a2 * d + b2];
+                    if (gi <= gj && v != 0.0) {
+                        const uint64_t at = colPtr[gj]++;
+                        oi[at] = gi; oj[at] = gj; ov[at] = v;
+                    }
+                }
+            }
     MFH_CATCH(c)
 }
 
@@ -1509,7 +1539,8 @@ mfh_status mfh_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, doubl
     require(c->sym.nRows == c->sym.nCols, MFH_ERR_STATE, "mfh_solve needs all rows owned; use mfh_dist_solve for partitioned meshes");
     const int64_t n = (int64_t)c->bs() * c->nDoF;
     std::vector<mfh_solve_info> infos((size_t)nrhs);
-    solve_many(c, nrhs, f, u, n, rtol, maxit, infos.data());
+    try { solve_many(c, nrhs, f, u, n, rtol, maxit, infos.data()); }
+    catch (...) { if (info) info[0] = infos[(size_t)nrhs - 1]; throw; }   // what is known reaches the caller even when a solve throws
     bool allConverged = true;
     for (int k2 = 0; k2 < nrhs; ++k2) allConverged &= infos[k2].converged != 0;
     if (info) info[0] = infos[(size_t)nrhs - 1];
@@ -1527,7 +1558,8 @@ mfh_status mfh_solve_batch(mfh_ctx *c, int32_t nrhs, const double *f, double *u,
     require(c->sym.nRows == c->sym.nCols, MFH_ERR_STATE, "mfh_solve_batch needs all rows owned; use mfh_dist_solve for partitioned meshes");
     const int64_t n = (int64_t)c->bs() * c->nDoF;
     std::vector<mfh_solve_info> infos((size_t)nrhs);
-    solve_many(c, nrhs, f, u, n, rtol, maxit, infos.data());
+    try { solve_many(c, nrhs, f, u, n, rtol, maxit, infos.data()); }
+    catch (...) { if (info) std::copy(infos.begin(), infos.end(), info); throw; }
     bool allConverged = true;
     for (int k2 = 0; k2 < nrhs; ++k2) { allConverged &= infos[k2].converged != 0; if (info) info[k2] = infos[k2]; }
     if (!allConverged) throw Error(MFH_ERR_NOT_CONVERGED, "PCG did not reach the requested tolerance within maxit iterations");
@@ -1682,7 +1714,7 @@ mfh_status mfh_dev_set_fixed_values(mfh_ctx *c, double *u_dev) {
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_fixed_uploaded(c);
-    k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, u_dev, c->stream);
+    k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, u_dev, (int64_t)c->bs() * c->sym.nCols, c->stream);
     MFH_CATCH(c)
 }
 mfh_status mfh_dev_sync(mfh_ctx *c) {

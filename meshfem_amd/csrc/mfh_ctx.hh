@@ -158,7 +158,11 @@ struct mfh_ctx {
         DBuf<int32_t> opList;         // element blocks / row chunks: interior first, then those reading a halo column
         int64_t nInterior = 0, nBoundary = 0;
         int listKind = 0;             // 0 none, 1 cluster blocks, 2 SpMV chunks
+        int64_t listGen = -1;         // mfh_ctx::listsGen the overlap lists were built from
+        bool anyFixedNonzeroGlobal = false;   // some rank holds a non-zero fixed value (agreed in mfh_dist_solve)
+        int transport = 0;            // what carried the last halo exchange: 1 RCCL send/recv, 2 peer copies, 3 caller callbacks
     } dist;
+    int64_t listsGen = 0;             // bumped whenever the element blocks of the cluster operator or the SpMV row chunks are rebuilt
     int aggNodes = 0;                 // option "agg_nodes": target DoFs per aggregate (0 = auto)
     bool topologyDevice = true;       // option "topology_device": edge numbering + boundary extraction by device radix sorts
     bool symbolicDevice = true;       // option "symbolic_device": build pattern + gather lists on the GPU (element-major order)
@@ -262,6 +266,8 @@ inline void require_full_storage(const mfh_ctx *c, const char *what) {
 
 inline int32_t dof_of(const mfh_ctx *c, int64_t node) { return c->dofForNode.empty() ? (int32_t)node : c->dofForNode[node]; }
 void invalidate_matrix(mfh_ctx *c);
+void dist_detach(mfh_ctx *c);
+void dist_agree(mfh_ctx *c);
 void refresh_storage_rule(mfh_ctx *c);
 void reset_bcs(mfh_ctx *c);
 void clear_fixed(mfh_ctx *c);

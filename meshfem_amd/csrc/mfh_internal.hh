@@ -72,6 +72,10 @@ struct DBuf {
         MFH_HIP(hipMalloc((void **)&p, count * sizeof(T)));
         n = count;
     }
+    // grow-only: work vectors whose size alternates between calls (batch widths 2, 1, 2, ...) are not reallocated every time
+    void reserve(size_t count) {
+        if (count > n || !p) alloc(count);
+    }
     void upload(const T *h, size_t count, hipStream_t s) {
         alloc(count);
         if (count) {
@@ -432,7 +436,7 @@ void launch_tl_apply(const TLArgs &t, const double *dinv, const double *r, const
 
 void launch_axpby(int64_t n, double a, const double *x, double b, double *y, hipStream_t s); // y = a x + b y
 void launch_mask(int64_t n, const uint8_t *mask, double *v, hipStream_t s);                   // v[mask]=0
-void launch_scatter_values(int64_t n, const int64_t *idx, const double *val, double *v, hipStream_t s);
+void launch_scatter_values(int64_t n, const int64_t *idx, const double *val, double *v, int64_t bound, hipStream_t s);
 void launch_dot(int64_t n, const double *a, const double *b, double *out, hipStream_t s);    // *out += a.b
 
 
@@ -459,6 +463,6 @@ void launch_pack_rows(int64_t n, int W, const int32_t *idx, const double *src, d
 void launch_interleave(int64_t nRows, int NR, int dim, const double *src, double *dst, bool toInterleaved, int64_t sepStride, hipStream_t s);
 void launch_norms_nr(int64_t nRows, int NR, int dim, const double *v, double *out, hipStream_t s);
 void launch_mask_nr(int64_t nRows, int NR, int dim, const uint8_t *mask, double *v, hipStream_t s);
-void launch_scatter_values_nr(int64_t n, int NR, int dim, const int64_t *idx, const double *val, double *v, hipStream_t s);
+void launch_scatter_values_nr(int64_t n, int NR, int dim, const int64_t *idx, const double *val, double *v, int64_t rowBound, hipStream_t s);
 
 }} // namespace mfh::k

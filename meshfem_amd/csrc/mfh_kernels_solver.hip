@@ -796,9 +796,12 @@ __global__ void __launch_bounds__(256) k_mask(int64_t n, const uint8_t *__restri
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
         if (m[k]) v[k] = 0.0;
 }
+// v[idx[k]] = val[k] for the indices below `bound` (the length of v: a vector of the owned rows of a partitioned context
+// must not receive the fixed values of halo variables, whose indices lie past its end)
 __global__ void __launch_bounds__(256) k_scatter_values(int64_t n, const int64_t *__restrict__ idx, const double *__restrict__ val,
-                                                        double *__restrict__ v) {
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) v[idx[k]] = val[k];
+                                                        double *__restrict__ v, int64_t bound) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
+        if (idx[k] < bound) v[idx[k]] = val[k];
 }
 __global__ void __launch_bounds__(256) k_dot(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *out) {
     __shared__ double red[8];
@@ -1173,9 +1176,10 @@ __global__ void __launch_bounds__(256) k_mask_nr(int64_t nRows, int NR, int DIM,
 }
 // v[var(idx[j])][k] = val[j] for every k (fixed values are the same for all right-hand sides)
 __global__ void __launch_bounds__(256) k_scatter_values_nr(int64_t n, int NR, int DIM, const int64_t *__restrict__ idx, const double *__restrict__ val,
-                                                           double *__restrict__ v) {
+                                                           double *__restrict__ v, int64_t rowBound) {
     for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
         const int64_t row = idx[j] / DIM;
+        if (row >= rowBound) continue;     // v holds rowBound rows (owned rows only, or owned + halo)
         const int c = (int)(idx[j] - row * DIM);
         for (int k = 0; k < NR; ++k) v[(row * NR + k) * DIM + c] = val[j];
     }
@@ -1357,9 +1361,9 @@ void launch_mask(int64_t n, const uint8_t *mask, double *v, hipStream_t s) {
     hipLaunchKernelGGL(k_mask, dim3(grid_for(n)), dim3(256), 0, s, n, mask, v);
     CHECK_LAUNCH();
 }
-void launch_scatter_values(int64_t n, const int64_t *idx, const double *val, double *v, hipStream_t s) {
+void launch_scatter_values(int64_t n, const int64_t *idx, const double *val, double *v, int64_t bound, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_scatter_values, dim3(grid_for(n)), dim3(256), 0, s, n, idx, val, v);
+    hipLaunchKernelGGL(k_scatter_values, dim3(grid_for(n)), dim3(256), 0, s, n, idx, val, v, bound);
     CHECK_LAUNCH();
 }
 void launch_dot(int64_t n, const double *a, const double *b, double *out, hipStream_t s) {
@@ -1439,9 +1443,9 @@ void launch_mask_nr(int64_t nRows, int NR, int dim, const uint8_t *mask, double 
     hipLaunchKernelGGL(k_mask_nr, dim3(grid_for(nRows * NR * dim)), dim3(256), 0, s, nRows, NR, dim, mask, v);
     CHECK_LAUNCH();
 }
-void launch_scatter_values_nr(int64_t n, int NR, int dim, const int64_t *idx, const double *val, double *v, hipStream_t s) {
+void launch_scatter_values_nr(int64_t n, int NR, int dim, const int64_t *idx, const double *val, double *v, int64_t rowBound, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_scatter_values_nr, dim3(grid_for(n)), dim3(256), 0, s, n, NR, dim, idx, val, v);
+    hipLaunchKernelGGL(k_scatter_values_nr, dim3(grid_for(n)), dim3(256), 0, s, n, NR, dim, idx, val, v, rowBound);
     CHECK_LAUNCH();
 }
 

@@ -90,6 +90,8 @@ struct mfh_comm {
     void *nccl = nullptr;
     int device = -1;
     std::string desc;
+    std::vector<mfh_ctx *> users;   // contexts whose mfh_dist_setup named this communicator (detached when it is destroyed)
+    std::mutex mu;
 };
 
 namespace {
@@ -125,6 +127,17 @@ void comm_exchange(mfh_comm *cm, int nPeers, const int32_t *peers, const double 
 
 // ------------------------------------------------------------------------------------------------ solver
 namespace mfhi {
+
+// the context stops referring to its communicator (mesh replaced, context destroyed)
+void dist_detach(mfh_ctx *c) {
+    mfh_comm *cm = c->dist.comm;
+    if (cm) {
+        std::lock_guard<std::mutex> lock(cm->mu);
+        cm->users.erase(std::remove(cm->users.begin(), cm->users.end(), c), cm->users.end());
+    }
+    c->dist.comm = nullptr;
+    c->dist.listKind = 0;
+}
 
 k::SpmvArgs spmv_args(mfh_ctx *c, bool masked);
 k::SpmvMfArgs spmv_mf_cluster_args(mfh_ctx *c, bool masked);
@@ -186,7 +199,7 @@ bool cluster_operator(mfh_ctx *c) { return c->use_mf() && c->mfModeEff() == 4 &&
 void ensure_overlap_lists(mfh_ctx *c, bool cluster) {
     auto &D = c->dist;
     const int kind = cluster ? 1 : 2;
-    if (D.listKind == kind) return;
+    if (D.listKind == kind && D.listGen == c->listsGen) return;
     hipStream_t s = c->stream;
     const int64_t n = cluster ? c->mfc.nBlocks : (int64_t)c->sym.spmvChunkRow.size() - 1;
     DBuf<uint8_t> flag;
@@ -203,6 +216,7 @@ void ensure_overlap_lists(mfh_ctx *c, bool cluster) {
     D.nBoundary = n - D.nInterior;
     D.opList.upload(list.empty() ? std::vector<int32_t>{0} : list, s);
     D.listKind = kind;
+    D.listGen = c->listsGen;
 }
 
 // y = K x for NR interleaved vectors. With an active communicator the halo part of x is exchanged first, overlapped with
@@ -244,8 +258,8 @@ void apply_op_nr(mfh_ctx *c, DistLink &L, int NR, double *x, double *y, bool mas
 void tl_precond_nr(mfh_ctx *c, DistLink &L, int NR, const double *r, double *z, double *scal, int it, const double *ctl) {
     const k::TLArgs ta = tl_args(c);
     auto &T = c->tl;
-    c->tlRcN.alloc((size_t)T.m * NR);
-    c->tlYcN.alloc((size_t)T.m * NR);
+    c->tlRcN.reserve((size_t)T.m * NR);
+    c->tlYcN.reserve((size_t)T.m * NR);
     k::launch_tl_restrict_nr(ta, NR, T.aggPtr.p, T.dofsByAgg.p, r, c->tlRcN.p, c->stream);
     L.allreduce(c->tlRcN.p, T.m * NR);
     k::launch_tl_gemv_nr(T.m, T.ldInv, NR, T.Ainv.p, c->tlRcN.p, c->tlYcN.p, c->stream);
@@ -261,6 +275,53 @@ bool cg_operator_supported(mfh_ctx *c) {
     return cluster_operator(c);
 }
 
+// Ranks agree on what the solve will do (see mfh_dist_solve). Collective: every rank of the communicator calls it.
+void dist_agree(mfh_ctx *c) {
+    DistLink L(c);
+    std::string localErr;
+    mfh_status localCode = MFH_OK;
+    bool supported = false;
+    auto prepare = [&]() {
+        try {
+            ensure_precond(c);
+            supported = cg_operator_supported(c);
+        } catch (const Error &e) { localErr = e.what(); localCode = e.code; }
+    };
+    prepare();
+    for (int round = 0; round < 2; ++round) {
+        const bool useTL = c->precond == MFH_PRECOND_TWO_LEVEL && c->tl.valid;
+        double h[8] = {c->anyFixedNonzero ? 1.0 : 0.0, localCode != MFH_OK ? 1.0 : 0.0, (localCode == MFH_OK && !supported) ? 1.0 : 0.0,
+                       (localCode == MFH_OK && supported && cluster_operator(c)) ? 1.0 : 0.0, useTL ? 1.0 : 0.0, 1.0, 0.0, 0.0};
+        c->cgCtl.alloc(16);
+        MFH_HIP(hipMemcpyAsync(c->cgCtl.p, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
+        L.allreduce(c->cgCtl.p, 8);
+        MFH_HIP(hipMemcpyAsync(h, c->cgCtl.p, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+        MFH_HIP(hipStreamSynchronize(c->stream));
+        const double world = h[5];
+        c->dist.anyFixedNonzeroGlobal = h[0] > 0;
+        if (h[1] > 0) {
+            if (localCode != MFH_OK) throw Error(localCode, localErr);
+            throw Error(MFH_ERR_STATE, "another rank failed while preparing the distributed solve");
+        }
+        const bool mixedOperator = h[3] > 0 && h[3] < world;
+        if (h[2] > 0 || mixedOperator) {
+            // some rank cannot run the cluster operator (element order without locality there): all ranks move to the assembled
+            // SpMV on both triangles of K, then agree again
+            if (round == 1 || c->external) throw Error(MFH_ERR_UNSUPPORTED, "the distributed solve needs the cluster matrix-free operator or the assembled SpMV on every rank");
+            c->matrixFree = 0;
+            refresh_storage_rule(c);
+            c->precondNote += " [a rank could not run the cluster operator: every rank uses the assembled SpMV]";
+            prepare();
+            continue;
+        }
+        if (h[4] > 0 && h[4] < world) {   // the coarse level is missing on some rank: block-Jacobi everywhere
+            c->tl.valid = false;
+            c->precondNote += " [two-level setup missing on a rank: block-Jacobi on every rank]";
+        }
+        return;
+    }
+}
+
 // PCG on the free variables for NR right-hand sides at once. f / u: NR host vectors of bs * nRows doubles each (nRows = the
 // rows this context owns), fStride doubles apart.
 void solve_cg(mfh_ctx *c, int NR, const double *f, double *u, int64_t fStride, double rtol, int maxit, mfh_solve_info *infos) {
@@ -274,7 +335,7 @@ void solve_cg(mfh_ctx *c, int NR, const double *f, double *u, int64_t fStride, d
     if (nRows != nCols && !c->dist.comm) throw Error(MFH_ERR_STATE, "row-partitioned context: call mfh_dist_setup before solving");
     if (!k::op_batch_supported(d, NR)) throw Error(MFH_ERR_UNSUPPORTED, "unsupported batch size");
     EventTimer tsetup(s);
-    c->cgU.alloc(nAll); c->cgW.alloc(nOwn); c->cgP.alloc(nOwn); c->cgS.alloc(nOwn); c->cgX.alloc(nOwn); c->cgR.alloc(nOwn); c->cgF.alloc(nOwn);
+    c->cgU.reserve(nAll); c->cgW.reserve(nOwn); c->cgP.reserve(nOwn); c->cgS.reserve(nOwn); c->cgX.reserve(nOwn); c->cgR.reserve(nOwn); c->cgF.reserve(nOwn);
     c->cgCtl.alloc(16);
     const bool masked = !c->fixedVars.empty();
     const bool cluster = cluster_operator(c);
@@ -287,9 +348,10 @@ void solve_cg(mfh_ctx *c, int NR, const double *f, double *u, int64_t fStride, d
     k::launch_interleave(nRows, NR, d, c->cgS.p, c->cgF.p, true, nRows * d, s);
     // b = f - K ubar on the free variables (SparseMatrices.hh:2457-2470,2526-2535); b lives in R
     MFH_HIP(hipMemcpyAsync(c->cgR.p, c->cgF.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToDevice, s));
-    if (c->anyFixedNonzero && !c->solveHomogeneous) {
+    // the lift exchanges halo entries: with a communicator EVERY rank applies it (a non-zero value may be visible to some ranks only)
+    if ((c->anyFixedNonzero || (L.active && c->dist.anyFixedNonzeroGlobal)) && !c->solveHomogeneous) {
         c->cgU.zero(s);
-        k::launch_scatter_values_nr((int64_t)c->fixedVars.size(), NR, d, c->dFixedIdx.p, c->dFixedVal.p, c->cgU.p, s);
+        k::launch_scatter_values_nr((int64_t)c->fixedVars.size(), NR, d, c->dFixedIdx.p, c->dFixedVal.p, c->cgU.p, nCols, s);
         apply_op_nr(c, L, NR, c->cgU.p, c->cgW.p, false, nullptr, nullptr, 0, nullptr);
         k::launch_axpby(nOwn, -1.0, c->cgW.p, 1.0, c->cgR.p, s);
     }
@@ -396,7 +458,7 @@ void solve_cg(mfh_ctx *c, int NR, const double *f, double *u, int64_t fStride, d
         for (int k2 = 0; k2 < NR; ++k2) itConv[k2] = 0;
     }
     // u = x + ubar  (SparseMatrices.hh:2592-2605)
-    if (masked && !c->solveHomogeneous) k::launch_scatter_values_nr((int64_t)c->fixedVars.size(), NR, d, c->dFixedIdx.p, c->dFixedVal.p, c->cgX.p, s);
+    if (masked && !c->solveHomogeneous) k::launch_scatter_values_nr((int64_t)c->fixedVars.size(), NR, d, c->dFixedIdx.p, c->dFixedVal.p, c->cgX.p, nRows, s);   // owned rows only: x has no halo part
     // true residual on the free variables: || mask(f - K u) || / ||b||
     double tr[8] = {0};
     if (anyWork) {
@@ -404,7 +466,7 @@ void solve_cg(mfh_ctx *c, int NR, const double *f, double *u, int64_t fStride, d
         MFH_HIP(hipMemcpyAsync(c->cgU.p, c->cgX.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToDevice, s));
         if (nAll > nOwn && !L.active) MFH_HIP(hipMemsetAsync(c->cgU.p + nOwn, 0, (size_t)(nAll - nOwn) * sizeof(double), s));
         if (nAll > nOwn && masked && !c->solveHomogeneous)   // fixed values on halo variables (also refreshed by the exchange)
-            k::launch_scatter_values_nr((int64_t)c->fixedVars.size(), NR, d, c->dFixedIdx.p, c->dFixedVal.p, c->cgU.p, s);
+            k::launch_scatter_values_nr((int64_t)c->fixedVars.size(), NR, d, c->dFixedIdx.p, c->dFixedVal.p, c->cgU.p, nCols, s);
         apply_op_nr(c, L, NR, c->cgU.p, c->cgW.p, false, nullptr, nullptr, 0, nullptr);
         k::launch_axpby(nOwn, 1.0, c->cgF.p, -1.0, c->cgW.p, s);
         if (masked) k::launch_mask_nr(nRows, NR, d, c->dFixedMask.p, c->cgW.p, s);
@@ -444,7 +506,7 @@ void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rt
     hipStream_t s = c->stream;
     DistLink L(c);
     EventTimer tsetup(s);
-    c->cgU.alloc(nAll);                                   // p (with its halo part)
+    c->cgU.reserve(nAll);                                 // p (with its halo part)
     c->wx.alloc(nOwn); c->wr.alloc(nOwn); c->wz.alloc(nOwn); c->wAp.alloc(nOwn); c->wf.alloc(nOwn);
     c->stop.alloc(4);
     c->cgCtl.alloc(16);
@@ -454,9 +516,9 @@ void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rt
     double *p = c->cgU.p;
     MFH_HIP(hipMemcpyAsync(c->wf.p, f, (size_t)nOwn * sizeof(double), hipMemcpyHostToDevice, s));
     MFH_HIP(hipMemcpyAsync(c->wr.p, c->wf.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToDevice, s));
-    if (c->anyFixedNonzero && !c->solveHomogeneous) {     // b = f - K ubar (SparseMatrices.hh:2457-2470,2526-2535)
+    if ((c->anyFixedNonzero || (L.active && c->dist.anyFixedNonzeroGlobal)) && !c->solveHomogeneous) {     // b = f - K ubar (SparseMatrices.hh:2457-2470,2526-2535); decided globally
         c->cgU.zero(s);
-        k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, p, s);
+        k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, p, nAll, s);
         apply_op_nr(c, L, 1, p, c->wAp.p, false, nullptr, nullptr, 0, nullptr);
         k::launch_axpby(nOwn, -1.0, c->wAp.p, 1.0, c->wr.p, s);
     }
@@ -532,10 +594,10 @@ void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rt
     }
     li.iterations = itDone;
     li.rel_residual = bb > 0 ? std::sqrt(rrFinal / bb) : 0.0;
-    if (masked && !c->solveHomogeneous) k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wx.p, s);
+    if (masked && !c->solveHomogeneous) k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wx.p, nOwn, s);   // owned rows only
     if (bb > 0) {   // true residual on the free variables
         MFH_HIP(hipMemcpyAsync(p, c->wx.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToDevice, s));
-        if (nAll > nOwn && masked && !c->solveHomogeneous) k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, p, s);
+        if (nAll > nOwn && masked && !c->solveHomogeneous) k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, p, nAll, s);
         apply_op_nr(c, L, 1, p, c->wAp.p, false, nullptr, nullptr, 0, nullptr);
         k::launch_axpby(nOwn, 1.0, c->wf.p, -1.0, c->wAp.p, s);
         if (masked) k::launch_mask(nOwn, c->dFixedMask.p, c->wAp.p, s);
@@ -624,6 +686,8 @@ mfh_status mfh_comm_create_callbacks(int32_t rank, int32_t world, void *user, mf
 
 void mfh_comm_destroy(mfh_comm *cm) {
     if (!cm) return;
+    for (mfh_ctx *c : cm->users) { c->dist.comm = nullptr; c->dist.listKind = 0; }   // no context keeps a dangling pointer
+    cm->users.clear();
     if (cm->nccl && rccl().ok) (void)rccl().commDestroy(cm->nccl);
     delete cm;
 }
@@ -710,6 +774,11 @@ mfh_status mfh_dist_setup(mfh_ctx *c, mfh_comm *cm, int32_t nPeers, const int32_
         MFH_HIP(hipStreamCreateWithFlags(&D.commStream, hipStreamNonBlocking));
         for (auto &e : D.ev) MFH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
+    if (D.comm != cm) {
+        dist_detach(c);
+        std::lock_guard<std::mutex> lock(cm->mu);
+        cm->users.push_back(c);
+    }
     D.comm = cm;
     D.listKind = 0;
     D.sendBufW = std::max(D.sendBufW, c->bs());
@@ -739,8 +808,10 @@ mfh_status mfh_dist_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, 
     require(c->dist.comm, MFH_ERR_STATE, "mfh_dist_setup has not run");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
-    ensure_precond(c);
-    require(cg_operator_supported(c), MFH_ERR_UNSUPPORTED, "the distributed solve needs the cluster matrix-free operator or the assembled SpMV");
+    // Every decision that changes the SEQUENCE of collectives is agreed on before the first one of the solve: a
+    // local error in the preparation, the operator in use, the lift of non-zero fixed values and the preconditioner. One
+    // all-reduce of six flags; a rank that cannot run the cluster operator takes every rank to the assembled SpMV.
+    dist_agree(c);
     const int64_t n = (int64_t)c->bs() * c->sym.nRows;
     std::vector<mfh_solve_info> infos((size_t)nrhs);
     // every rank must take the same path: batches are chosen from (dim, nrhs) only
@@ -766,8 +837,7 @@ mfh_status mfh_dist_apply_K(mfh_ctx *c, const double *uOwned, double *KuOwned) {
     require(c->dist.comm, MFH_ERR_STATE, "mfh_dist_setup has not run");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
-    ensure_precond(c);
-    require(cg_operator_supported(c), MFH_ERR_UNSUPPORTED, "the distributed operator needs the cluster matrix-free operator or the assembled SpMV");
+    dist_agree(c);
     const int d = c->bs();
     const int64_t nOwn = c->sym.nRows * d, nAll = c->sym.nCols * d;
     if (c->cgU.n < (size_t)nAll) c->cgU.alloc((size_t)nAll);

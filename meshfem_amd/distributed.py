@@ -493,14 +493,27 @@ def distributed_pcg(ops, halo, f_owned, rtol=1e-8, maxit=20000, group=None, chec
 # ------------------------------------------------------------------------------------------------
 # synthetic z-slab meshes (weak scaling): the reference generator restricted to a z-range
 # ------------------------------------------------------------------------------------------------
-def slab_local_mesh(n, rank, world, deg=2, layers=None, device=-1):
-    """Grid n x n x (layers*world) of cubic cells of size 1/n; rank owns hex layers [layers*rank, layers*(rank+1))
-    (layers defaults to n: a cube per rank). Returns the LocalMesh plus integer lattice coordinates (units of
-    1/(4n)) of every local node."""
+def slab_layer_ranges(nz, world):
+    """z-slabs of a grid with nz hex layers, as even as they come: rank r owns layers [b[r], b[r+1])."""
+    return [(nz * r) // world for r in range(world + 1)]
+
+
+def slab_local_mesh(n, rank, world, deg=2, layers=None, device=-1, nz=None):
+    """Grid n x n x nz of cubic cells of size 1/n in `world` z-slabs. Weak-scaling form: every rank owns `layers` hex layers
+    (nz = layers * world; layers defaults to n: a cube per rank). Strong-scaling form (nz given): the nz layers of ONE fixed
+    grid are dealt out as evenly as they come (slab_layer_ranges). Returns the LocalMesh plus integer lattice coordinates
+    (units of 1/(4n)) of every local node."""
     from . import grid
     from .core import Context
-    layers = n if layers is None else int(layers)
-    z0, z1 = layers * rank, layers * (rank + 1)
+    if nz is None:
+        layers = n if layers is None else int(layers)
+        bounds = [layers * r for r in range(world + 1)]
+    else:
+        bounds = slab_layer_ranges(int(nz), world)
+    nz = bounds[-1]
+    z0, z1 = bounds[rank], bounds[rank + 1]
+    if z1 <= z0:
+        raise ValueError("slab_local_mesh: rank %d of %d owns no hex layer of a grid with %d layers" % (rank, world, nz))
     top = 1 if rank < world - 1 else 0                 # one halo hex layer above the owned interface plane
     V, H = grid.gen_grid_3d(n, n, z1 - z0 + top, z0=z0)
     V, T = grid.hex_tet_subdiv(V, H)
@@ -510,11 +523,12 @@ def slab_local_mesh(n, rank, world, deg=2, layers=None, device=-1):
     h.close()
     lat = np.rint(pos * 4).astype(np.int64)            # vertices/centres/midpoints live on the quarter lattice
     M = 4 * n + 1
-    keys = (lat[:, 0] * M + lat[:, 1]) * (4 * layers * world + 1) + lat[:, 2]
-    # rank r owns lattice z in (4 L r, 4 L (r+1)]; the global bottom plane belongs to rank 0
-    owner = np.clip((lat[:, 2] + 4 * layers - 1) // (4 * layers) - 1, 0, world - 1)
+    keys = (lat[:, 0] * M + lat[:, 1]) * (4 * nz + 1) + lat[:, 2]
+    # rank r owns lattice z in (4 b[r], 4 b[r+1]]; the global bottom plane belongs to rank 0
+    owner = np.clip(np.searchsorted(4 * np.asarray(bounds[1:], dtype=np.int64), lat[:, 2], side="left"), 0, world - 1)
     lm = partition(en, pos / n, keys, owner, rank)
     lm.lattice = np.rint(lm.node_pos * 4 * n).astype(np.int64)
+    lm.layers = (z0, z1)
     return lm
 
 
@@ -630,10 +644,22 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
     deg = args.deg
     # weak scaling towards BASELINE configs[4] (a ~40 M-tet CUBE in 8 z-slabs): the global grid is
     # n x n x (layers * world) with n ~ grid * world^(1/3), and every rank keeps ~24 grid^3 elements
-    n = int(round(args.grid * world ** (1.0 / 3.0)))
-    layers = max(1, int(round(args.grid ** 3 / float(n * n))))
-    t0 = time.time()
-    lm = slab_local_mesh(n, rank, world, deg, layers, device=local_rank)
+    strong = getattr(args, "scaling", "weak") == "strong"
+    if strong:
+        # STRONG scaling (BASELINE.md section 2 / north_star: ">= 6x at 8 GPUs" on configs[4]): ONE fixed grid^3 cube (default 119^3 =
+        # 40 443 816 P2 tets) whose hex layers are dealt out over the ranks; N = 1 runs the same cube in one context (run_single)
+        n = args.grid
+        bounds = slab_layer_ranges(n, world)
+        layers = bounds[rank + 1] - bounds[rank]
+        nz_total = n
+        t0 = time.time()
+        lm = slab_local_mesh(n, rank, world, deg, device=local_rank, nz=n)
+    else:
+        n = int(round(args.grid * world ** (1.0 / 3.0)))
+        layers = max(1, int(round(args.grid ** 3 / float(n * n))))
+        nz_total = layers * world
+        t0 = time.time()
+        lm = slab_local_mesh(n, rank, world, deg, layers, device=local_rank)
     t_mesh = time.time() - t0
     c = M.Context(local_rank)
     c.mesh_set(3, deg, lm.elem_nodes, lm.node_pos, lm.n_owned)
@@ -641,7 +667,7 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
     t0 = time.time(); c.symbolic(False); t_sym = time.time() - t0
     c.set_option("reembed", 1)
     # elements are counted once globally: a rank "owns" the elements of its own hex layers
-    n_elem_global = 24 * n * n * layers * world
+    n_elem_global = 24 * n * n * nz_total
 
     def max_over_ranks(v):
         t = torch.tensor([v], dtype=torch.float64, device="cpu" if shared_gpus else dev)
@@ -685,9 +711,11 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
         rccl_ranks = int(one.item())
     out = dict(metric="stiffness_assembly_elements_per_s", value=n_elem_global * args.steps / dt, unit="elements/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="f64", data="synthetic",
-               config=dict(workload="%d x %d x %d grid -> %d P%d tets, z-slabs of %d hex layers per GPU (configs[4] shape: 120^3 at 8 GPUs)"
-                                    % (n, n, layers * world, n_elem_global, deg, layers), elements=n_elem_global,
+               scaling="strong" if strong else "weak", vs_baseline=None, dtype="f64", data="synthetic",
+               config=dict(workload=("configs[4]: %d^3 grid -> %d P%d tets (fixed), z-slabs of %d-%d hex layers per GPU"
+                                     % (n, n_elem_global, deg, n // world, -(-n // world))) if strong else
+                                    ("%d x %d x %d grid -> %d P%d tets, z-slabs of %d hex layers per GPU (configs[4] shape: 120^3 at 8 GPUs)"
+                                     % (n, n, nz_total, n_elem_global, deg, layers)), elements=n_elem_global,
                            local_elements=nE_loc, local_nodes=int(lm.n_local), owned_nodes=int(lm.n_owned),
                            parallelism="row/element partition x%d, owner computes (no assembly communication)" % world),
                devices=dict(visible=torch.cuda.device_count(), ranks=world, shared=bool(shared_gpus),

@@ -188,6 +188,30 @@ def test_two_rank_slab_partition_and_pcg_gloo(n, layers):
     assert ret[0][2] + ret[1][2] == O.FEMMesh(T, V, 2).num_nodes
 
 
+@pytest.mark.parametrize("n,world", [(3, 2), (5, 3)])
+def test_strong_scaling_slabs_deal_out_one_fixed_grid(n, world):
+    """bench.py --scaling strong: the nz = n hex layers of ONE n^3 cube are dealt out unevenly (119 = 7 x 15 + 14 at 8 ranks);
+    every rank's slab must be the partition of the global mesh under the same ownership rule, every node owned once."""
+    bounds = D.slab_layer_ranges(n, world)
+    assert bounds[0] == 0 and bounds[-1] == n and all(b1 > b0 for b0, b1 in zip(bounds, bounds[1:]))
+    assert max(np.diff(bounds)) - min(np.diff(bounds)) <= 1
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    m = O.FEMMesh(T, V, 2)
+    glat = np.rint(m.node_pos * 4 * n).astype(np.int64)
+    gkeys = (glat[:, 0] * (4 * n + 1) + glat[:, 1]) * (4 * n + 1) + glat[:, 2]
+    owner = np.clip(np.searchsorted(4 * np.asarray(bounds[1:]), glat[:, 2], side="left"), 0, world - 1)
+    owned, elems = 0, 0
+    for rank in range(world):
+        lm = D.slab_local_mesh(n, rank, world, 2, nz=n)
+        lm_g = D.partition(m.elem_nodes, m.node_pos, gkeys, owner, rank)
+        assert lm.n_owned == lm_g.n_owned and np.array_equal(lm.keys, lm_g.keys)
+        assert np.allclose(lm.node_pos, lm_g.node_pos)
+        assert sorted(map(tuple, lm.keys[lm.elem_nodes].tolist())) == sorted(map(tuple, lm_g.keys[lm_g.elem_nodes].tolist()))
+        assert lm.layers == (bounds[rank], bounds[rank + 1])
+        owned += lm.n_owned
+    assert owned == m.num_nodes
+
+
 def test_single_rank_partition_is_identity():
     V, T = grid.grid_tet_mesh(2, 2, 2)
     m = O.FEMMesh(T, V, 2)

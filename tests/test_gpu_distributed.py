@@ -131,6 +131,92 @@ def test_two_ranks_one_gpu_partitioned_solve_matches_single_context(storage):
 _ITERATIONS = {}
 
 
+def _worker_nonzero_dirichlet(rank, world, port, n, ret):
+    """Non-zero Dirichlet data (a) on the x = 0 face, which crosses the inter-rank plane -- the fixed list of a rank then holds
+    halo variables, whose indices lie past the end of the owned-row vectors (out-of-bounds scatter) -- and (b) on the
+    top z face, which only the last rank sees (the lift b = f - K ubar is a collective and must not depend on a
+    rank-local flag)."""
+    import torch
+    import torch.distributed as dist
+    import meshfem_amd as M
+    from meshfem_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lm = D.slab_local_mesh(n, rank, world, 2)
+        c = M.Context(0)
+        c.mesh_set(3, 2, lm.elem_nodes, lm.node_pos, lm.n_owned)
+        c.material_isotropic(200.0, 0.35)
+        c.assemble()
+        comm = D.make_comm(c, rank, world)
+        solver = D.DistSolver(c, lm, rank, world, comm)
+        halo = D.HaloExchange(lm, rank, world, torch.device("cpu"))
+        lat = lm.lattice[:lm.n_owned]
+        zmax = 4 * n * world
+        on_x0 = lat[:, 0] == 0
+        on_top = (lat[:, 2] == zmax) & ~on_x0
+        nodes = np.flatnonzero(on_x0 | on_top)
+        pos = lm.node_pos[nodes]
+        vals = np.where(on_x0[nodes][:, None], np.stack([0 * pos[:, 2], 0.01 * pos[:, 1], 0.02 * pos[:, 2]], 1),
+                        np.array([[0.03, 0.0, -0.01]]))
+        ov = (3 * nodes[:, None] + np.arange(3)[None, :]).ravel()
+        ev, evals = D.extend_fixed_to_halo(halo, lm.n_local, 3, ov, vals.ravel(), torch.device("cpu"))
+        if rank == 0:
+            assert ev.max() >= 3 * lm.n_owned            # halo variables in the fixed list of rank 0 ...
+            assert not np.any(on_top)                    # ... and the top face is invisible to it
+        c.fix_variables(ev, evals)
+        f = np.zeros(3 * lm.n_owned)
+        out = {}
+        for variant in (1, 0):
+            c.set_option("dist_pcg_variant", variant)
+            u, info = solver.solve(f, rtol=1e-10, maxit=20000)
+            assert info[0]["converged"]
+            out[variant] = u[0].reshape(-1, 3).copy()
+        assert np.linalg.norm(out[0] - out[1]) <= 1e-8 * np.linalg.norm(out[1])
+        assert np.allclose(out[1].ravel()[ov], vals.ravel(), rtol=0, atol=1e-15)     # u = x + ubar on the owned rows
+        ret[rank] = dict(keys=lm.keys[:lm.n_owned].copy(), u=out[1])
+        comm.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_nonzero_dirichlet_values_across_the_rank_interface():
+    import torch.multiprocessing as mp
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    world, n = 2, 5
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_nonzero_dirichlet, args=(world, _free_port(), n, ret), nprocs=world, join=True)
+    assert set(ret.keys()) == {0, 1}
+    V, T = grid.grid_tet_mesh(n, n, n * world, [0, 0, 0], [1, 1, world])
+    c = M.Context(0)
+    c.mesh_build(T, V, 2)
+    c.material_isotropic(200.0, 0.35)
+    pos = c.node_positions()
+    on_x0 = np.abs(pos[:, 0]) < 1e-12
+    on_top = (np.abs(pos[:, 2] - world) < 1e-12) & ~on_x0
+    nodes = np.flatnonzero(on_x0 | on_top)
+    p = pos[nodes]
+    vals = np.where(on_x0[nodes][:, None], np.stack([0 * p[:, 2], 0.01 * p[:, 1], 0.02 * p[:, 2]], 1), np.array([[0.03, 0.0, -0.01]]))
+    c.fix_variables((3 * nodes[:, None] + np.arange(3)[None, :]).ravel(), vals.ravel())
+    u_ref = c.solve(np.zeros(3 * len(pos)), rtol=1e-10).reshape(-1, 3)
+    c.close()
+    lat = np.rint(pos * 4 * n).astype(np.int64)
+    keys = (lat[:, 0] * (4 * n + 1) + lat[:, 1]) * (4 * n * world + 1) + lat[:, 2]
+    order = np.argsort(keys)
+    for r in range(world):
+        d = ret[r]
+        idx = order[np.searchsorted(keys[order], d["keys"])]
+        assert np.array_equal(keys[idx], d["keys"])
+        # both sides are PCG solutions to rtol 1e-10 of the same SPD system
+        assert np.linalg.norm(d["u"] - u_ref[idx]) / np.linalg.norm(u_ref) < 1e-7, r
+
+
 def _worker_general(rank, world, port, ret):
     import torch
     import torch.distributed as dist
