@@ -94,13 +94,15 @@ def compulsory_assembly_bytes(c, n_elem, nnzb, geo_bytes=128):
 
 def cpu_direct_solve(deg, n, rtol):
     """The reference's dominant cost is the sparse direct solve (CholmodFactorizer, SparseMatrices.hh:2002-2024,2106-2124,
-    settings :2243-2295). CHOLMOD / SuiteSparse is not installed in this image (ctypes.util.find_library finds none), so
-    the labelled stand-in is scipy's SuperLU in symmetric mode -- the oracle's direct solver -- on a bounded sample
-    of the same workload (same generator, boundary conditions and material), next to the library's PCG at that size."""
+    settings :2243-2295: supernodal LL^T, nested dissection among the orderings). CHOLMOD / SuiteSparse is not installed in
+    this image (ctypes.util.find_library finds none), so the same METHOD runs restated on LAPACK: a multifrontal Cholesky on a
+    geometric nested-dissection tree (oracle/direct_solve.py; potrf / trsm / gemm on the BLAS threads of the process) on a
+    bounded sample of the same workload (same generator, boundary conditions and material), next to the library's PCG at that
+    size; the two displacement fields are compared."""
     import ctypes.util
     import scipy.sparse as sp
-    import scipy.sparse.linalg as spla
     from oracle import c_oracle as CO
+    from oracle import direct_solve as DS
     import meshfem_amd as M
     from meshfem_amd import grid
     D = np.zeros((6, 6))
@@ -114,9 +116,10 @@ def cpu_direct_solve(deg, n, rtol):
     c.material_isotropic(200.0, 0.35)
     c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
     c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    c.set_preconditioner(M.PRECOND_TWO_LEVEL)
     t0 = time.perf_counter()
     u_gpu = c.sim_solve(rtol=rtol)
-    gpu_wall = time.perf_counter() - t0            # symbolic + assembly + PCG + transfers, cold context
+    gpu_wall = time.perf_counter() - t0            # symbolic + assembly + coarse setup + PCG + transfers, cold context
     gi = dict(c.last_info)
     en, nn, pos, f = c.elem_nodes(), c.n_node, c.node_positions(), c.neumann_load().ravel()
     c.close()
@@ -124,28 +127,29 @@ def cpu_direct_solve(deg, n, rtol):
     N = 3 * nn
     t0 = time.perf_counter()
     U = sp.csc_matrix((Ax, Ai, Ap), shape=(N, N))
-    K = (U + sp.triu(U, 1).T).tocsc()
-    free = np.flatnonzero(~np.repeat(np.abs(pos[:, 0]) < 1e-9, 3))
-    Kr = K[free][:, free].tocsc()                  # SPSDSystem::fixVariables: eliminated rows / columns (:2389-2500)
+    K = (U + sp.triu(U, 1).T).tocsr()
+    free_nodes = np.flatnonzero(np.abs(pos[:, 0]) >= 1e-9)
+    free = (3 * free_nodes[:, None] + np.arange(3)[None, :]).ravel()
+    Kr = K[free][:, free]                          # SPSDSystem::fixVariables: eliminated rows / columns (:2389-2500)
     t_elim = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    lu = spla.splu(Kr, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
-    t_factor = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    x = lu.solve(f[free])
-    t_solve = time.perf_counter() - t0
+    mf = DS.MultifrontalCholesky(Kr, pos[free_nodes], block=3)
+    mf.factor()
+    x = mf.solve(f[free])
     u = np.zeros(N)
     u[free] = x
     err = float(np.linalg.norm(u_gpu.ravel() - u) / np.linalg.norm(u))
+    res = float(np.linalg.norm(Kr @ x - f[free]) / np.linalg.norm(f[free]))
     have_cholmod = ctypes.util.find_library("cholmod") is not None
-    return dict(kind="stand-in: scipy.sparse.linalg.splu (SuperLU 'MMD_AT_PLUS_A', SymmetricMode), 1 thread; CHOLMOD %s"
-                     % ("found but not bound" if have_cholmod else "not installed on this box"),
-                sample="%d^3 grid -> %d P%d tets" % (n, len(T), deg), dof=int(N), free_dof=int(len(free)), cores=1,
-                assemble_s=float(t["total"]), eliminate_s=t_elim, factor_s=t_factor, backsolve_s=t_solve,
-                solve_s=t_factor + t_solve, time_to_solution_s=float(t["total"]) + t_elim + t_factor + t_solve,
-                factor_nnz=int(lu.L.nnz + lu.U.nnz),
+    threads = DS.blas_threads()
+    return dict(kind="port of the method: multifrontal (supernodal) Cholesky, geometric nested dissection, LAPACK potrf/trsm/gemm on %d BLAS "
+                     "threads (oracle/direct_solve.py); CHOLMOD %s" % (threads, "found but not bound" if have_cholmod else "not installed on this box"),
+                sample="%d^3 grid -> %d P%d tets" % (n, len(T), deg), dof=int(N), free_dof=int(len(free)), cores=threads,
+                assemble_s=float(t["total"]), eliminate_s=t_elim, ordering_s=mf.t_order, factor_s=mf.t_factor, backsolve_s=mf.t_solve,
+                solve_s=mf.t_order + mf.t_factor + mf.t_solve,
+                time_to_solution_s=float(t["total"]) + t_elim + mf.t_order + mf.t_factor + mf.t_solve,
+                factor_nnz=int(mf.factor_nnz), factor_gflops=mf.flops / 1e9, supernodes=len(mf.kids), rel_residual=res,
                 gpu_pcg=dict(iterations=gi["iterations"], solve_s=gi["solve_ms"] * 1e-3, wall_s_cold_context=gpu_wall,
-                             rel_l2_vs_direct=err, rtol=rtol))
+                             preconditioner="two-level", rel_l2_vs_direct=err, rtol=rtol))
 
 
 def cpu_baseline(deg, cpu_grid):
@@ -199,9 +203,10 @@ def cpu_baseline_with_solve(args):
     out = cpu_baseline(args.deg, args.cpu_grid)
     try:
         ds = None
-        for n in ([args.cpu_solve_grid] if args.cpu_solve_grid else [6, 8]):     # the last size that starts is reported (~15 s)
+        # grow the sample while the factorisation time (~ N^2) leaves room: 107 k, 288 k, 501 k DOF for quadratic tets
+        for n in ([args.cpu_solve_grid] if args.cpu_solve_grid else [10, 14, 17]):
             ds = cpu_direct_solve(args.deg, n, args.rtol)
-            if ds["solve_s"] > 4.0:
+            if ds["solve_s"] > 5.0:      # the next size costs ~7x (10 -> 14) / ~3x (14 -> 17) as much
                 break
         out["direct_solve"] = ds
         out.update(solve_s=ds["solve_s"], dof=ds["dof"], solve_kind=ds["kind"])

@@ -1,5 +1,6 @@
 """Thin numpy-facing wrapper over the C ABI (one `Context` == one mfh_ctx)."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -24,6 +25,11 @@ class Context:
         self.dim = self.deg = None
         self.op = L.OP_ELASTICITY
         self.external = False
+        # experiments: MFH_OPTIONS="name=value,name=value" presets mfh_set_option on every new context (A/B runs of the
+        # measurement scripts without editing them); unset in normal use
+        for kv in filter(None, os.environ.get("MFH_OPTIONS", "").split(",")):
+            k, v = kv.split("=")
+            self.set_option(k.strip(), float(v))
 
     def close(self):
         if getattr(self, "h", None):

@@ -37,6 +37,8 @@ mfh::RoctxRange::~RoctxRange() {
 namespace mfhi {
 using namespace mfh;
 
+void pack_gather_codes(mfh_ctx *c);
+
 void invalidate_matrix(mfh_ctx *c) {
     c->assembled = false;
     c->dinvValid = false;
@@ -213,6 +215,7 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
             c->dContribSlot.download(c->sym.contribSlot.data(), c->dContribSlot.n, c->stream);
             if (wantScatter) { c->sym.scatterSlot.resize(c->dScatter.n); c->dScatter.download(c->sym.scatterSlot.data(), c->dScatter.n, c->stream); }
         }
+        pack_gather_codes(c);
         c->timing.symbolic_ms = now_ms() - t0;
         const size_t tilesD = (size_t)((S.nnzb + 63) / 64);
         c->dVals.alloc(tilesD * 64 * (size_t)c->dim() * c->dim());
@@ -235,6 +238,7 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
     c->dContribCode.upload(S.contribCode, c->stream);
     c->dContribSlot.upload(S.contribSlot, c->stream);
     if (wantScatter) c->dScatter.upload(S.scatterSlot, c->stream);
+    pack_gather_codes(c);
     if (!c->keepHostSymbolic) {   // host copies of the big gather lists are no longer needed
         std::vector<uint32_t>().swap(c->sym.contribCode);
         std::vector<uint16_t>().swap(c->sym.contribSlot);
@@ -245,6 +249,16 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
     c->symValid = true;
     ++c->listsGen;
     invalidate_matrix(c);
+}
+
+// the device copy of the gather codes goes chunk-relative and packed (the host copy, mfh_symbolic_get, stays e npe^2 + ij)
+void pack_gather_codes(mfh_ctx *c) {
+    c->codesPacked = false;
+    if (!c->asmPackedCodes || c->hostOnly || c->sym.nChunk() == 0) return;
+    c->dChunkElemBase.alloc((size_t)c->sym.nChunk());
+    DBuf<int> flag;
+    flag.alloc(1);
+    c->codesPacked = k::launch_pack_codes(c->sym.nChunk(), c->dContribPtr.p, c->dContribCode.p, c->mesh.npe, c->dChunkElemBase.p, flag.p, c->stream);
 }
 
 k::AsmArgs asm_args(mfh_ctx *c) {
@@ -260,6 +274,25 @@ k::AsmArgs asm_args(mfh_ctx *c) {
     a.vals = c->dVals.p; a.nnzb = c->sym.nnzb;
     a.xcd = c->xcdSwizzle;
     a.upperOnly = c->upperOnly ? 1 : 0;
+    a.chunkElemBase = c->codesPacked ? c->dChunkElemBase.p : nullptr;
+    a.chunkOrder = nullptr;
+    if (c->asmChunkOrder && !c->hostOnly && a.nChunk > 1 && c->symValid && c->dContribPtr.p && c->dContribCode.p && c->contribOrder == 1) {
+        if (c->chunkOrderGen != c->listsGen) {
+            // launch order of the row chunks: by the element their median contribution comes from (the gather lists are element-major
+            // inside a chunk), so that the chunks holding an element's vertex rows and edge rows run at about the same time
+            DBuf<uint32_t> keys;
+            keys.alloc((size_t)a.nChunk);
+            k::launch_chunk_keys(a, keys.p, c->stream);
+            std::vector<uint32_t> hk((size_t)a.nChunk);
+            keys.download(hk.data(), hk.size(), c->stream);
+            std::vector<int32_t> order((size_t)a.nChunk);
+            for (int64_t b = 0; b < a.nChunk; ++b) order[(size_t)b] = (int32_t)b;
+            std::stable_sort(order.begin(), order.end(), [&](int32_t x, int32_t y) { return hk[(size_t)x] < hk[(size_t)y]; });
+            c->dChunkOrder.upload(order, c->stream);
+            c->chunkOrderGen = c->listsGen;
+        }
+        a.chunkOrder = c->dChunkOrder.p;
+    }
     return a;
 }
 
@@ -1807,7 +1840,9 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     MFH_TRY(c)
     require(c && key, MFH_ERR_INVALID, "null argument");
     const std::string k2(key);
-    if (k2 == "chunk_slots") { c->chunkSlots = (int)value; invalidate_symbolic(c); }
+    if (k2 == "asm_chunk_order") { c->asmChunkOrder = (int)value; }
+    else if (k2 == "asm_packed_codes") { c->asmPackedCodes = value != 0; invalidate_symbolic(c); }
+    else if (k2 == "chunk_slots") { c->chunkSlots = (int)value; invalidate_symbolic(c); }
     else if (k2 == "contrib_order") { c->contribOrder = (int)value; invalidate_symbolic(c); }
     else if (k2 == "check_every") { c->checkEvery = std::max(1, (int)value); }
     else if (k2 == "keep_host_symbolic") { c->keepHostSymbolic = value != 0; }

@@ -180,6 +180,13 @@ struct mfh_ctx {
     std::vector<std::pair<int64_t, std::array<double, 3>>> deltaForces;
 
     // ---- options
+    int asmChunkOrder = 0;           // option "asm_chunk_order": 1 = the assembly visits the row chunks in the order of the elements they gather
+                                     // from (an element's contributions then meet in time, its record is fetched once); 0 = in row order
+    DBuf<int32_t> dChunkOrder;
+    int64_t chunkOrderGen = -1;      // listsGen the order was built from
+    bool asmPackedCodes = true;      // option "asm_packed_codes": the device copy of the gather codes is chunk-relative and packed (k_assemble_gather)
+    bool codesPacked = false;        // state of dContribCode
+    DBuf<int32_t> dChunkElemBase;
     int chunkSlots = 256;            // assembly chunks: 18 KB of LDS accumulators, 8 workgroups per CU
     int contribOrder = 1;            // element-major: 12% faster than rank-major on MI355X (profiles/r01_assembly_variants.md)
     mfh_timing timing{0, 0, 0, 0};

@@ -300,6 +300,8 @@ struct AsmArgs {
     double *vals;                       // tiled [ceil(nnzb/64)][dim*dim][64]
     int64_t nnzb;
     int xcd;                            // 1: XCD-contiguous chunk mapping (xcd_item)
+    const int32_t *chunkElemBase;       // packed gather codes: (element - chunkElemBase[chunk]) << 7 | ij (nullptr: absolute codes e npe^2 + ij)
+    const int32_t *chunkOrder;          // workgroup b takes chunk chunkOrder[b] (nullptr: b): chunks visited in element order
     int upperOnly;                      // the lists cover the blocks (r, c >= r) only (names the kernel instantiation)
 };
 
@@ -307,6 +309,8 @@ void launch_geometry(int dim, int deg, int mat, int64_t nElem, const int32_t *el
                      const double *vertPos, const double *matParams, int matMode, double *geo, int geoStride,
                      int *negCount, hipStream_t s);
 void launch_assemble_gather(const AsmArgs &a, hipStream_t s);
+void launch_chunk_keys(const AsmArgs &a, uint32_t *keys, hipStream_t s);
+bool launch_pack_codes(int64_t nChunk, const int64_t *contribPtr, uint32_t *contribCode, int npe, int32_t *chunkElemBase, int *flag, hipStream_t s);
 void launch_assemble_atomic(const AsmArgs &a, hipStream_t s);
 void launch_element_stiffness(const AsmArgs &a, int64_t first, int64_t count, double *KeOut, hipStream_t s);
 // deltaP != nullptr: the discrete shape derivative of the same quantity under the vertex perturbation deltaP

@@ -23,6 +23,34 @@ namespace mfh { namespace k {
 // components per matrix entry: dim x dim blocks for elasticity, 1 for the scalar operators
 template <int DIM, int MAT> DEV constexpr int mat_nb() { return (MAT == MAT_LAPLACE || MAT == MAT_MASS) ? 1 : DIM * DIM; }
 
+// material part of a block: K from H = sum_q w_q grad phi_i (x) grad phi_j and the element's tensor
+template <int DIM, int MAT>
+DEV void block_from_H(const double *__restrict__ g, const double (&H)[DIM][DIM], double *K);
+
+// H from the (s,t) support offsets of the two nodes and the pair's four quadrature coefficients (one row of
+// ShapeTables::pairTable): the table-driven form of the assembly kernel (quadratic elements)
+template <int DIM>
+DEV void pair_H(const double *__restrict__ g, uint32_t offs /* bytes: 3 DIM-offsets of s_i, t_i, s_j, t_j */, double S0, double S1, double S2,
+                double S3, double (&H)[DIM][DIM]) {
+    const double vol = g[12];
+    S0 *= vol; S1 *= vol; S2 *= vol; S3 *= vol;
+    const char *gb = reinterpret_cast<const char *>(g);
+    const double *gsi = reinterpret_cast<const double *>(gb + (offs & 0xffu)), *gti = reinterpret_cast<const double *>(gb + ((offs >> 8) & 0xffu)),
+                 *gsj = reinterpret_cast<const double *>(gb + ((offs >> 16) & 0xffu)), *gtj = reinterpret_cast<const double *>(gb + (offs >> 24));
+    double ua[DIM], ub[DIM], p[DIM], q[DIM];
+#pragma unroll
+    for (int a = 0; a < DIM; ++a) {
+        ua[a] = gsi[a]; ub[a] = gti[a];
+        const double va = gsj[a], vb = gtj[a];
+        p[a] = S0 * va + S1 * vb;
+        q[a] = S2 * va + S3 * vb;
+    }
+#pragma unroll
+    for (int a = 0; a < DIM; ++a)
+#pragma unroll
+        for (int b = 0; b < DIM; ++b) H[a][b] = ua[a] * p[b] + ub[a] * q[b];
+}
+
 template <int DIM, int DEG, int MAT>
 DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pairTab, const PairConst &pc, int i, int j, double *K) {
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
@@ -77,6 +105,11 @@ DEV void elem_block(const double *__restrict__ g, const double *__restrict__ pai
 #pragma unroll
             for (int b = 0; b < DIM; ++b) H[a][b] = ua[a] * p[b] + ub[a] * q[b];
     }
+    block_from_H<DIM, MAT>(g, H, K);
+}
+
+template <int DIM, int MAT>
+DEV void block_from_H(const double *__restrict__ g, const double (&H)[DIM][DIM], double *K) {
     if (MAT == MAT_LAPLACE) {
         // int grad phi_i . grad phi_j = tr(H)   (Laplacian.hh:38-48; Poisson.hh:33-38)
         double tr = 0;
@@ -259,23 +292,46 @@ __global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *
 // per CU that the 18 KB of LDS accumulators do (measured 5.42 vs 5.67 ms at config 3 on one box)
 // UPPER only names the instantiation (profiles tell the launches on the upper-triangle storage from those on the full one):
 // which blocks exist is decided by the gather lists, the code is the same.
+// Gather lists in PACKED form (a.chunkElemBase != null): code = (element - chunkElemBase[chunk]) << 7 | (i NPE + j) -- a shift and a
+// mask instead of two divisions, and no 2^32 / NPE^2 ceiling on the element count. Quadratic elements read the pair's four quadrature
+// coefficients and the byte offsets of its four barycentric gradients from a table in LDS (one row of ShapeTables::pairTable per
+// (i, j): built by the workgroup from 3.2 KB of L2-resident data) instead of re-deriving them per contribution from the node
+// indices (support-vertex lookups, vertex / edge selects, the closed form of the coefficients: ~50 of the 141 VALU instructions
+// per contribution of the round-2 kernel).
+template <int DIM, int DEG, int MAT> DEV constexpr bool asm_uses_table() { return DEG == 2 && MAT != MAT_MASS; }
+constexpr int ASM_CODE_SHIFT = 7;
+
 template <int DIM, int DEG, int MAT, bool UPPER = false>
 __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) ? 1 : 8) k_assemble_gather(AsmArgs a) {
     constexpr int NB = mat_nb<DIM, MAT>();
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
-    extern __shared__ __attribute__((aligned(16))) double acc[];   // [NB][chunkSlots + 2]
+    constexpr bool TAB = asm_uses_table<DIM, DEG, MAT>();
+    extern __shared__ __attribute__((aligned(16))) double acc[];   // [NB][chunkSlots + 2] (+ pair table [NPE^2][4] doubles + [NPE^2] u32)
     const int CS = a.chunkSlots + 2;
+    double *tabS = acc + (size_t)NB * CS;
+    uint32_t *tabO = reinterpret_cast<uint32_t *>(tabS + NPE * NPE * 4);
     const PairConst pc{a.pairConst[0], a.pairConst[1], a.pairConst[2], a.pairConst[3], a.pairConst[4], a.pairConst[5]};
-    const int64_t chunk = a.xcd == 1 ? xcd_item(blockIdx.x, gridDim.x) : (a.xcd > 1 ? xcd_group_item(blockIdx.x, gridDim.x, a.xcd) : (int64_t)blockIdx.x);
+    const int64_t item = a.xcd == 1 ? xcd_item(blockIdx.x, gridDim.x) : (a.xcd > 1 ? xcd_group_item(blockIdx.x, gridDim.x, a.xcd) : (int64_t)blockIdx.x);
+    const int64_t chunk = a.chunkOrder ? (int64_t)a.chunkOrder[item] : item;
     const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
     const int s0 = a.rowPtr[r0];
     const int ns = a.rowPtr[r1] - s0;
+    const uint32_t eBase = a.chunkElemBase ? (uint32_t)a.chunkElemBase[chunk] : 0u;
     // LDS index = local slot + (s0 & 1): LDS pairs (2p, 2p+1) then coincide with 16-byte aligned
     // pairs of the tiled global layout and the write-out can use dwordx4 stores
     const int par = s0 & 1;
     for (int t = threadIdx.x; t < ns + par; t += 256)
 #pragma unroll
         for (int c = 0; c < NB; ++c) acc[c * CS + t] = 0.0;
+    if (TAB) {
+        for (int t = threadIdx.x; t < NPE * NPE; t += 256) {
+            const int i = t / NPE, j = t - i * NPE;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tabS[t * 4 + k] = a.pairTable[t * 4 + k];
+            tabO[t] = (uint32_t)(sup_s<DIM, DEG>(i) * DIM * 8) | ((uint32_t)(sup_t<DIM, DEG>(i) * DIM * 8) << 8) |
+                      ((uint32_t)(sup_s<DIM, DEG>(j) * DIM * 8) << 16) | ((uint32_t)(sup_t<DIM, DEG>(j) * DIM * 8) << 24);
+        }
+    }
     __syncthreads();
     const int64_t kb = a.contribPtr[chunk], ke = a.contribPtr[chunk + 1];
     // U independent contributions per lane and trip: their index loads, element-record loads and
@@ -299,10 +355,22 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             double K[NB];
-            const uint32_t e = code[u] / (NPE * NPE);
-            const int ij = (int)(code[u] - e * (NPE * NPE));
-            const int i = ij / NPE, j = ij - i * NPE;
-            elem_block<DIM, DEG, MAT>(a.geo + (int64_t)e * a.geoStride, MAT == MAT_MASS ? a.massTable : a.pairTable, pc, i, j, K);
+            uint32_t e;
+            int ij;
+            if (a.chunkElemBase) { e = eBase + (code[u] >> ASM_CODE_SHIFT); ij = (int)(code[u] & ((1u << ASM_CODE_SHIFT) - 1)); }
+            else { e = code[u] / (NPE * NPE); ij = (int)(code[u] - e * (NPE * NPE)); }
+            const double *g = a.geo + (int64_t)e * a.geoStride;
+            if (TAB) {
+                typedef double dv2 __attribute__((ext_vector_type(2)));
+                const dv2 s01 = *reinterpret_cast<const dv2 *>(&tabS[ij * 4]), s23 = *reinterpret_cast<const dv2 *>(&tabS[ij * 4 + 2]);
+                const uint32_t offs = tabO[ij];
+                double H[DIM][DIM];
+                pair_H<DIM>(g, offs, s01.x, s01.y, s23.x, s23.y, H);
+                block_from_H<DIM, MAT>(g, H, K);
+            } else {
+                const int i = ij / NPE, j = ij - i * NPE;
+                elem_block<DIM, DEG, MAT>(g, MAT == MAT_MASS ? a.massTable : a.pairTable, pc, i, j, K);
+            }
             if (ok[u]) {
 #pragma unroll
                 for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&acc[c * CS + ls[u]], K[c]);
@@ -340,6 +408,51 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
 #pragma unroll
             for (int c = 0; c < NB; ++c) a.vals[tiled_index(s, c, NB)] = acc[c * CS + t];
         }
+    }
+}
+
+// key of a row chunk for the launch order: the element of its median contribution (the lists are element-major inside a chunk)
+__global__ void __launch_bounds__(256) k_chunk_keys(int64_t nChunk, const int64_t *__restrict__ contribPtr, const uint32_t *__restrict__ contribCode,
+                                                    const int32_t *__restrict__ chunkElemBase, uint32_t npe2, uint32_t *__restrict__ keys) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= nChunk) return;
+    const int64_t kb = contribPtr[b], ke = contribPtr[b + 1];
+    if (ke <= kb) { keys[b] = 0xffffffffu; return; }
+    const uint32_t c = contribCode[kb + (ke - kb) / 2];
+    keys[b] = chunkElemBase ? (uint32_t)chunkElemBase[b] + (c >> ASM_CODE_SHIFT) : c / npe2;
+}
+
+// absolute codes e NPE^2 + ij -> packed chunk-relative codes (see k_assemble_gather); one wave per chunk. Pass 1 (rewrite == 0) finds
+// the smallest element of every chunk and raises flag[0] when a chunk's elements span 2^25 or more (the packed element field is 25
+// bits wide); pass 2 rewrites the codes in place.
+__global__ void __launch_bounds__(64) k_pack_codes(int64_t nChunk, const int64_t *__restrict__ contribPtr, uint32_t *__restrict__ contribCode,
+                                                   uint32_t npe2, int32_t *__restrict__ chunkElemBase, int *flag, int rewrite) {
+    const int64_t b = blockIdx.x;
+    const int64_t kb = contribPtr[b], ke = contribPtr[b + 1];
+    if (rewrite) {
+        const uint32_t lo = (uint32_t)chunkElemBase[b];
+        for (int64_t k = kb + threadIdx.x; k < ke; k += 64) {
+            const uint32_t c = contribCode[k], e = c / npe2;
+            contribCode[k] = ((e - lo) << ASM_CODE_SHIFT) | (c - e * npe2);
+        }
+        return;
+    }
+    uint32_t lo = 0xffffffffu, hi = 0;
+    for (int64_t k = kb + threadIdx.x; k < ke; k += 64) {
+        const uint32_t e = contribCode[k] / npe2;
+        lo = e < lo ? e : lo;
+        hi = e > hi ? e : hi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if (ke <= kb) lo = 0;
+    if (threadIdx.x == 0) {
+        chunkElemBase[b] = (int32_t)lo;
+        if (ke > kb && hi - lo >= (1u << (32 - ASM_CODE_SHIFT))) atomicExch(flag, 1);
     }
 }
 
@@ -1845,7 +1958,8 @@ void launch_geometry(int dim, int /*deg*/, int /*mat*/, int64_t nElem, const int
 
 void launch_assemble_gather(const AsmArgs &a, hipStream_t s) {
     if (a.nChunk == 0) return;
-    const size_t lds = (size_t)(mat_is_scalar(a.mat) ? 1 : a.dim * a.dim) * (a.chunkSlots + 2) * sizeof(double);
+    size_t lds = (size_t)(mat_is_scalar(a.mat) ? 1 : a.dim * a.dim) * (a.chunkSlots + 2) * sizeof(double);
+    if (a.deg == 2 && a.mat != MAT_MASS) lds += (size_t)a.npe * a.npe * (4 * sizeof(double) + sizeof(uint32_t));   // pair table
     if (a.upperOnly) {
 #define CALL(D, G, M)                                                                                          \
     if (lds > 64 * 1024)                                                                                         \
@@ -1862,6 +1976,27 @@ void launch_assemble_gather(const AsmArgs &a, hipStream_t s) {
 #undef CALL
     }
     CHECK_LAUNCH();
+}
+
+void launch_chunk_keys(const AsmArgs &a, uint32_t *keys, hipStream_t s) {
+    if (a.nChunk == 0) return;
+    hipLaunchKernelGGL(k_chunk_keys, dim3((unsigned)((a.nChunk + 255) / 256)), dim3(256), 0, s, a.nChunk, a.contribPtr, a.contribCode,
+                       a.chunkElemBase, (uint32_t)(a.npe * a.npe), keys);
+    CHECK_LAUNCH();
+}
+
+bool launch_pack_codes(int64_t nChunk, const int64_t *contribPtr, uint32_t *contribCode, int npe, int32_t *chunkElemBase, int *flag, hipStream_t s) {
+    if (nChunk == 0) return true;
+    MFH_HIP(hipMemsetAsync(flag, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_pack_codes, dim3((unsigned)nChunk), dim3(64), 0, s, nChunk, contribPtr, contribCode, (uint32_t)(npe * npe), chunkElemBase, flag, 0);
+    CHECK_LAUNCH();
+    int h = 0;
+    MFH_HIP(hipMemcpyAsync(&h, flag, sizeof(int), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    if (h) return false;      // some chunk gathers from elements more than 2^25 apart: the codes stay absolute
+    hipLaunchKernelGGL(k_pack_codes, dim3((unsigned)nChunk), dim3(64), 0, s, nChunk, contribPtr, contribCode, (uint32_t)(npe * npe), chunkElemBase, flag, 1);
+    CHECK_LAUNCH();
+    return true;
 }
 
 void launch_assemble_atomic(const AsmArgs &a, hipStream_t s) {

@@ -245,3 +245,32 @@ int64_t oracle_assemble_csc(int dim, int deg, int64_t nElem, const int32_t *elem
     free(KeAll); free(nz);
     return nnz <= cap ? nnz : -1;
 }
+
+/* Extend-add of the multifrontal Cholesky (oracle/direct_solve.py). The parent's frontal matrix is kept as a panel
+ * P ((ns + nb) x ns, row-major: the columns of the ns unknowns eliminated at this node) and the Schur-complement block
+ * S (nb x nb, row-major). A child's update matrix U (nbc x nbc, symmetric, row-major) is added at the positions loc[]:
+ * loc < ns -> an eliminated unknown, else ns + index into the parent's boundary. The block (eliminated row, boundary column)
+ * is the transpose of (boundary row, eliminated column) and is not stored. */
+void oracle_extend_add(double *P, double *S, int64_t ns, int64_t nb, const double *U, int64_t nbc, const int64_t *loc) {
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t i = 0; i < nbc; ++i) {
+        const int64_t li = loc[i];
+        const double *u = U + i * nbc;
+        double *prow = P + li * ns;
+        if (li < ns) {
+            for (int64_t j = 0; j < nbc; ++j) if (loc[j] < ns) prow[loc[j]] += u[j];
+        } else {
+            double *srow = S + (li - ns) * nb;
+            for (int64_t j = 0; j < nbc; ++j) {
+                const int64_t lj = loc[j];
+                if (lj < ns) prow[lj] += u[j]; else srow[lj - ns] += u[j];
+            }
+        }
+    }
+}
+
+/* zero fill on all threads (first touch spread over the NUMA nodes) */
+void oracle_zero(double *a, int64_t n) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) a[i] = 0.0;
+}

@@ -82,3 +82,28 @@ def assemble_csc(dim, deg, elem_nodes, vert_pos, D, n_dof, dof_for_node=None):
     if nnz < 0:
         raise RuntimeError("oracle_assemble_csc failed (%d)" % nnz)
     return Ap, Ai[:nnz].copy(), Ax[:nnz].copy(), dict(ke=times[0], push=times[1], compress=times[2], total=times[3])
+
+
+def extend_add(P, S, U, loc):
+    """Multifrontal extend-add (oracle/direct_solve.py): the child's update matrix U lands in the parent's panel P
+    ((ns + nb) x ns) and Schur block S (nb x nb) at the positions loc; all arrays C-contiguous float64."""
+    ns = P.shape[1]
+    if U.shape[0] < 256:          # small fronts: not worth waking the OpenMP team (it competes with the BLAS threads)
+        own = loc < ns
+        lo, lb = loc[own], loc[~own] - ns
+        P[np.ix_(loc, lo)] += U[:, own]
+        S[np.ix_(lb, lb)] += U[np.ix_(~own, ~own)]
+        return
+    lib = load()
+    loc = np.ascontiguousarray(loc, np.int64)
+    assert P.flags.c_contiguous and S.flags.c_contiguous and U.flags.c_contiguous
+    lib.oracle_extend_add(_p(P), _p(S), C.c_int64(P.shape[1]), C.c_int64(S.shape[0]), _p(U), C.c_int64(U.shape[0]), _p(loc))
+
+
+def zeros(shape):
+    """np.zeros with the fill done by all threads."""
+    if int(np.prod(shape)) < (1 << 22):
+        return np.zeros(shape)
+    a = np.empty(shape)
+    load().oracle_zero(_p(a), C.c_int64(a.size))
+    return a

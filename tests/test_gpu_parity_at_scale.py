@@ -28,7 +28,7 @@ def _check(kp):
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("deg,n", [(2, 24), (1, 40)])
 def test_isotropic_K_matches_oracle_at_scale(deg, n):
-    """24^3 grid -> 331 776 P2 tets (1.45 M DOF, ~59 M upper entries); 40^3 -> 1 536 000 P1 tets (BASELINE configs[1] is 35^3)."""
+    """24^3 grid -> 331 776 P2 tets (1.45 M DOF, ~41 M upper entries); 40^3 -> 1 536 000 P1 tets (BASELINE configs[1] is 35^3)."""
     V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
     c = M.Context(0)
     c.mesh_build(T, V, deg)
@@ -40,7 +40,7 @@ def test_isotropic_K_matches_oracle_at_scale(deg, n):
     D = O.ElasticityTensor.isotropic(3, 200.0, 0.35).D
     Ap, Ai, Ax, _ = CO.assemble_csc(3, deg, en, V, D, nn)
     kp = parity.compare_upper_triplets_with_csc(i, j, v, Ap, Ai, Ax)
-    assert kp["nnz_compared"] > (5e7 if deg == 2 else 1e7)
+    assert kp["nnz_compared"] > (4e7 if deg == 2 else 9e6)
     _check(kp)
 
 
