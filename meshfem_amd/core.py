@@ -290,6 +290,12 @@ class Context:
         self._ck(self.lib.mfh_precond_info(self.h, C.byref(a), C.byref(m), C.byref(t), C.byref(note)))
         return dict(aggregates=a.value, coarse_dim=m.value, setup_ms=t.value, note=(note.value or b"").decode())
 
+    def multigrid_info(self):
+        a, b = C.c_int64(), C.c_int64()
+        l0, l1, t = C.c_double(), C.c_double(), C.c_double()
+        self._ck(self.lib.mfh_multigrid_info(self.h, C.byref(a), C.byref(b), C.byref(l0), C.byref(l1), C.byref(t)))
+        return dict(fine_dof=a.value, coarse_dof=b.value, lambda_max_fine=l0.value, lambda_max_coarse=l1.value, setup_ms=t.value)
+
     def solve(self, f, rtol=1e-8, maxit=100000):
         f = as_f64(f)
         n = self.bs * self.n_dof

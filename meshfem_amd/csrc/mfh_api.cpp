@@ -43,6 +43,7 @@ void invalidate_matrix(mfh_ctx *c) {
     c->assembled = false;
     c->dinvValid = false;
     c->tl.valid = false;
+    c->mg.valid = false;
 }
 void invalidate_symbolic(mfh_ctx *c) {
     ++c->listsGen;                  // overlap lists of a partitioned solve (Dist::opList) are stale from here on
@@ -68,6 +69,7 @@ void clear_fixed(mfh_ctx *c) {
     c->anyFixedNonzero = false;
     c->dinvValid = false;
     c->tl.valid = false;
+    c->mg.valid = false;
 }
 
 void upload_mesh(mfh_ctx *c) {
@@ -451,7 +453,7 @@ void ensure_precond(mfh_ctx *c) {
     const int d = c->bs();
     c->dDinv.alloc((size_t)c->sym.nRows * (d * (d + 1) / 2));   // symmetric-packed inverse diagonal blocks
     k::launch_extract_diag_inv(d, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, c->dFixedMask.p,
-                               c->precond == MFH_PRECOND_TWO_LEVEL ? MFH_PRECOND_BLOCK_JACOBI : c->precond, c->dDinv.p, c->stream);
+                               (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) ? MFH_PRECOND_BLOCK_JACOBI : c->precond, c->dDinv.p, c->stream);
     c->dinvValid = true;
 }
 
@@ -656,6 +658,18 @@ bool ensure_twolevel(mfh_ctx *c) {
     return true;
 }
 
+// the levels below the Jacobi one that the preconditioner in use needs; the multigrid hierarchy falls back to the two-level
+// construction where it does not apply (linear elements, partitioned rows: precondNote says so)
+void ensure_coarse_levels(mfh_ctx *c, int /*nrhs*/) {
+    if (c->precond == MFH_PRECOND_MULTIGRID) {
+        if (ensure_multigrid(c)) return;
+        const std::string note = c->precondNote;
+        if (ensure_twolevel(c) && c->precondNote.empty()) c->precondNote = note;
+        return;
+    }
+    if (c->precond == MFH_PRECOND_TWO_LEVEL) ensure_twolevel(c);
+}
+
 // z = M^-1 r with the two-level preconditioner (restrict -> dense coarse solve -> prolong + block-Jacobi)
 void tl_precond(mfh_ctx *c, const double *r, double *z, double *scal, int it) {
     const k::TLArgs ta = tl_args(c);
@@ -716,11 +730,17 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
         li.converged = 1;
     } else {
         EventTimer tsolve(s);
-        const bool useTL = c->precond == MFH_PRECOND_TWO_LEVEL && c->tl.valid && !c->tlSuppress;
+        const bool useMG = c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && !c->tlSuppress;
+        const bool useTL = !useMG && (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) && c->tl.valid && !c->tlSuppress;
+        const uint8_t *maskPtr = c->fixedVars.empty() ? nullptr : c->dFixedMask.p;
         k::launch_pcg_init(d, c->sym.nRows, c->dDinv.p, c->wb.p, c->wx.p, c->wr.p, c->wz.p, c->wp.p, c->scal.p, s);
-        if (useTL) {   // replace z, p and r.z of the block-Jacobi initialisation
+        if (useTL || useMG) {   // replace z, p and r.z of the block-Jacobi initialisation
             MFH_HIP(hipMemsetAsync(c->scal.p, 0, sizeof(double), s));
-            tl_precond(c, c->wr.p, c->wz.p, c->scal.p, -1);
+            if (useMG) {
+                mg_precond(c, c->wr.p, c->wz.p, nullptr, -1, nullptr);
+                k::launch_mg_rz(n, c->wr.p, c->wz.p, maskPtr, c->scal.p, -1, nullptr, nullptr, s);
+            } else
+                tl_precond(c, c->wr.p, c->wz.p, c->scal.p, -1);
             MFH_HIP(hipMemcpyAsync(c->wp.p, c->wz.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
         }
         const k::SpmvArgs sa = spmv_args(c, !c->fixedVars.empty());
@@ -738,7 +758,11 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
             else if (useMF && c->mfModeEff() >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
             else if (useMF) k::launch_spmv_mf(mfa, c->wp.p, c->wAp.p, nullptr, c->scal.p, itLocal, c->stop.p, true, s);
             else k::launch_pcg_spmv(sa, c->wp.p, c->wAp.p, c->scal.p, itLocal, c->stop.p, s);
-            if (useTL) {
+            if (useMG) {
+                k::launch_pcg_update_noz(d, c->sym.nRows, c->wAp.p, c->wr.p, c->scal.p, itLocal, c->stop.p, s);
+                mg_precond(c, c->wr.p, c->wz.p, c->scal.p, itLocal, c->stop.p);
+                k::launch_mg_rz(n, c->wr.p, c->wz.p, maskPtr, c->scal.p, itLocal, c->scal.p, c->stop.p, s);
+            } else if (useTL) {
                 k::launch_pcg_update_noz(d, c->sym.nRows, c->wAp.p, c->wr.p, c->scal.p, itLocal, c->stop.p, s);
                 tl_precond(c, c->wr.p, c->wz.p, c->scal.p, itLocal);
             } else
@@ -748,14 +772,17 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
         // Launch-bound regime (small meshes: a few tens of microseconds per kernel): capture one block of
         // check_every iterations in a hipGraph and replay it; the kernels find their iteration through the
         // device-side base stop[3], which the last node of the graph advances.
+        // a multigrid iteration is tens of kernels and milliseconds long and only tens of them are needed: short blocks (the operator
+        // applications inside the V-cycle are not gated, so iterations past convergence would cost real time)
+        const int checkEvery = useMG ? std::min(c->checkEvery, 2) : c->checkEvery;
         hipGraphExec_t exec = nullptr;
-        if (c->useGraph && c->checkEvery > 1) {
+        if (c->useGraph && checkEvery > 1) {
             hipGraph_t graph = nullptr;
             if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
                 bool ok = true;
                 try {
-                    for (int j = 0; j < c->checkEvery; ++j) enqueue(j);
-                    k::launch_advance_base(c->stop.p, c->checkEvery, s);
+                    for (int j = 0; j < checkEvery; ++j) enqueue(j);
+                    k::launch_advance_base(c->stop.p, checkEvery, s);
                 } catch (...) { ok = false; }
                 if (hipStreamEndCapture(s, &graph) != hipSuccess || !ok || !graph) { graph = nullptr; (void)hipGetLastError(); }
             } else (void)hipGetLastError();
@@ -771,9 +798,9 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
         while (!done && it < maxit) {
             if (exec) {
                 MFH_HIP(hipGraphLaunch(exec, s));
-                it += c->checkEvery;
+                it += checkEvery;
             } else {
-                const int itEnd = std::min(maxit, it + c->checkEvery);
+                const int itEnd = std::min(maxit, it + checkEvery);
                 for (; it < itEnd; ++it) enqueue(it);
             }
             // scan the residual history of the iterations just enqueued
@@ -908,6 +935,7 @@ void add_fixed(mfh_ctx *c, int64_t n, const int64_t *vars, const double *vals) {
     c->fixedUploaded = false;
     c->dinvValid = false;
     c->tl.valid = false;
+    c->mg.valid = false;
 }
 
 // element material tensor D (flatLen x flatLen) from the geometry record
@@ -983,6 +1011,7 @@ void mfh_destroy(mfh_ctx *c) {
     const bool own = c->ownStream;
     for (auto &e : c->passEv) if (e) (void)hipEventDestroy(e);
     dist_detach(c);
+    destroy_multigrid(c);
     for (auto &e : c->dist.ev) if (e) (void)hipEventDestroy(e);
     if (c->dist.commStream) { (void)hipStreamSynchronize(c->dist.commStream); (void)hipStreamDestroy(c->dist.commStream); }
     if (c->negHost) (void)hipHostFree(c->negHost);
@@ -1547,7 +1576,7 @@ mfh_status mfh_fix_variables(mfh_ctx *c, int64_t n, const int64_t *vars, const d
 }
 
 mfh_status mfh_set_preconditioner(mfh_ctx *c, int32_t kind) {
-    if (!c || kind < 0 || kind > 3) return MFH_ERR_INVALID;
+    if (!c || kind < 0 || kind > 4) return MFH_ERR_INVALID;
     c->precond = kind;
     c->dinvValid = false;
     return MFH_OK;
@@ -1555,10 +1584,23 @@ mfh_status mfh_set_preconditioner(mfh_ctx *c, int32_t kind) {
 
 mfh_status mfh_precond_info(const mfh_ctx *c, int32_t *nAgg, int64_t *coarseDim, double *setup_ms, const char **note) {
     if (!c) return MFH_ERR_INVALID;
-    if (nAgg) *nAgg = c->tl.valid ? c->tl.nAgg : 0;
-    if (coarseDim) *coarseDim = c->tl.valid ? c->tl.m : 0;
-    if (setup_ms) *setup_ms = c->tl.valid ? c->tl.setup_ms : 0.0;
+    // with the multigrid hierarchy in use: the aggregates of its linear level, the setup time of the whole hierarchy
+    const mfh_ctx *t = (c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && c->mg.coarse) ? c->mg.coarse : c;
+    if (nAgg) *nAgg = t->tl.valid ? t->tl.nAgg : 0;
+    if (coarseDim) *coarseDim = t->tl.valid ? t->tl.m : 0;
+    if (setup_ms) *setup_ms = t != c ? c->mg.setup_ms : (c->tl.valid ? c->tl.setup_ms : 0.0);
     if (note) *note = c->precondNote.c_str();
+    return MFH_OK;
+}
+
+mfh_status mfh_multigrid_info(const mfh_ctx *c, int64_t *fineDoF, int64_t *coarseDoF, double *lambdaMaxFine, double *lambdaMaxCoarse, double *setup_ms) {
+    if (!c) return MFH_ERR_INVALID;
+    const bool v = c->mg.valid;
+    if (fineDoF) *fineDoF = v ? c->mg.nFine : 0;
+    if (coarseDoF) *coarseDoF = v ? c->mg.nCoarse : 0;
+    if (lambdaMaxFine) *lambdaMaxFine = v ? c->mg.lmax0 : 0.0;
+    if (lambdaMaxCoarse) *lambdaMaxCoarse = v ? c->mg.lmax1 : 0.0;
+    if (setup_ms) *setup_ms = v ? c->mg.setup_ms : 0.0;
     return MFH_OK;
 }
 
@@ -1568,7 +1610,7 @@ mfh_status mfh_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, doubl
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
-    if (c->precond == MFH_PRECOND_TWO_LEVEL) ensure_twolevel(c);
+    ensure_coarse_levels(c, nrhs);
     require(c->sym.nRows == c->sym.nCols, MFH_ERR_STATE, "mfh_solve needs all rows owned; use mfh_dist_solve for partitioned meshes");
     const int64_t n = (int64_t)c->bs() * c->nDoF;
     std::vector<mfh_solve_info> infos((size_t)nrhs);
@@ -1587,7 +1629,7 @@ mfh_status mfh_solve_batch(mfh_ctx *c, int32_t nrhs, const double *f, double *u,
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
-    if (c->precond == MFH_PRECOND_TWO_LEVEL) ensure_twolevel(c);
+    ensure_coarse_levels(c, nrhs);
     require(c->sym.nRows == c->sym.nCols, MFH_ERR_STATE, "mfh_solve_batch needs all rows owned; use mfh_dist_solve for partitioned meshes");
     const int64_t n = (int64_t)c->bs() * c->nDoF;
     std::vector<mfh_solve_info> infos((size_t)nrhs);
@@ -1841,6 +1883,13 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     require(c && key, MFH_ERR_INVALID, "null argument");
     const std::string k2(key);
     if (k2 == "asm_chunk_order") { c->asmChunkOrder = (int)value; }
+    else if (k2 == "mg_steps_fine") c->mgSteps0 = std::max(1, (int)value);
+    else if (k2 == "mg_steps_coarse") c->mgSteps1 = std::max(1, (int)value);
+    else if (k2 == "mg_ratio_fine") { require(value > 0 && value < 1, MFH_ERR_INVALID, "mg_ratio_fine must lie in (0, 1)"); c->mgRatio0 = value; }
+    else if (k2 == "mg_ratio_coarse") { require(value > 0 && value < 1, MFH_ERR_INVALID, "mg_ratio_coarse must lie in (0, 1)"); c->mgRatio1 = value; }
+    else if (k2 == "mg_coarse_cycles") c->mgCoarseCycles = std::max(1, (int)value);
+    else if (k2 == "mg_eig_margin") { require(value >= 1.0, MFH_ERR_INVALID, "mg_eig_margin must be >= 1"); c->mgEigMargin = value; c->mg.valid = false; }
+    else if (k2 == "mg_agg_nodes") { c->mgAggNodes = std::max(0, (int)value); c->mg.valid = false; }
     else if (k2 == "asm_packed_codes") { c->asmPackedCodes = value != 0; invalidate_symbolic(c); }
     else if (k2 == "chunk_slots") { c->chunkSlots = (int)value; invalidate_symbolic(c); }
     else if (k2 == "contrib_order") { c->contribOrder = (int)value; invalidate_symbolic(c); }

@@ -137,6 +137,21 @@ struct mfh_ctx {
         DBuf<int32_t> aggOfDof, aggPtr, dofsByAgg, colorOfAgg, nbrOfColor, binCoord;
         DBuf<double> relPos, Ainv, rc, yc;
     } tl;
+    // p-multigrid preconditioner (MFH_PRECOND_MULTIGRID, mfh_multigrid.cpp): quadratic level -> linear level (a context of its own) ->
+    // rigid-body modes of aggregates
+    struct Multigrid {
+        bool valid = false, rigidCoarse = false;
+        mfh_ctx *coarse = nullptr;    // owned: the linear level
+        int64_t nFine = 0, nCoarse = 0;
+        DBuf<int32_t> parA, parB, fineOf, resPtr, resIdx;
+        DBuf<double> r0, d0, t0, b1, x1, r1, d1, t1;
+        double lmax0 = 0, lmax1 = 0, setup_ms = 0;
+    } mg;
+    int mgSteps0 = 1, mgSteps1 = 3;                  // options "mg_steps_fine" / "mg_steps_coarse": Chebyshev steps before and after the coarse correction
+    double mgRatio0 = 0.3, mgRatio1 = 0.1;           // options "mg_ratio_fine" / "mg_ratio_coarse": the smoothers act on [ratio lambda_max, lambda_max]
+    int mgCoarseCycles = 1;                          // option "mg_coarse_cycles": cycles of the linear level per application
+    double mgEigMargin = 1.1;                        // option "mg_eig_margin": factor on the power-iteration estimates of lambda_max
+    int mgAggNodes = 0;                              // option "mg_agg_nodes": target DoFs per aggregate of the linear level's coarse space (0 = auto)
     // Chronopoulos-Gear PCG (mfh_solver.cpp): NR interleaved vectors
     DBuf<double> cgU, cgW, cgP, cgS, cgX, cgR, cgF, cgCtl, tlRcN, tlYcN;
     int pcgVariant = -1;              // option "pcg_variant": 1 = Chronopoulos-Gear, 0 = classic PCG, -1 (default) = classic for one
@@ -284,6 +299,10 @@ void finish_geometry(mfh_ctx *c);
 void ensure_mf_cluster(mfh_ctx *c);
 void ensure_precond(mfh_ctx *c);
 bool ensure_twolevel(mfh_ctx *c);
+bool ensure_multigrid(mfh_ctx *c);
+void ensure_coarse_levels(mfh_ctx *c, int nrhs);
+void destroy_multigrid(mfh_ctx *c);
+void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int it, const double *stop);
 k::AsmArgs asm_args(mfh_ctx *c);
 const int32_t *device_dof_map(mfh_ctx *c);
 void box_corners(mfh_ctx *c, const double *mn, const double *mx, int relative, double *omn, double *omx);

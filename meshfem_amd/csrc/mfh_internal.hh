@@ -462,6 +462,17 @@ void launch_tl_gemv_nr(int64_t m, int64_t ld, int NR, const double *A, const dou
 void launch_tl_apply_nr(const TLArgs &t, int NR, const double *dinv, const double *r, const double *yc, double *z, double *scal, int it,
                         const double *ctl, hipStream_t s);
 extern int g_vecGridCap;
+// p-multigrid (mfh_multigrid.cpp); scal / it / stop: the gate of the PCG iteration (null: none)
+void launch_mg_cheb(int dim, int64_t nRows, const double *dinv, const double *rin, const double *t, double *rout, double *d, double *x,
+                    double a, double b, bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s);
+void launch_mg_restrict(int dim, int64_t nCoarse, const int32_t *fineOf, const int32_t *resPtr, const int32_t *resIdx, const double *r, const double *t,
+                        const uint8_t *coarseMask, double *rc, const double *scal, int it, const double *stop, hipStream_t s);
+void launch_mg_prolong_add(int dim, int64_t nFine, const int32_t *parA, const int32_t *parB, const double *xc, const uint8_t *fineMask, double *x,
+                           const double *scal, int it, const double *stop, hipStream_t s);
+void launch_mg_tl_prolong_add(const TLArgs &t, const double *yc, double *x, const double *scal, int it, const double *stop, hipStream_t s);
+void launch_fill_hash(int64_t n, double *v, hipStream_t s);
+void launch_mg_diff(int64_t n, const double *a, const double *b, double *out, const double *scal, int it, const double *stop, hipStream_t s);
+void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, double *scalOut, int it, const double *scal, const double *stop, hipStream_t s);
 void launch_add_scalar(double *p, double v, hipStream_t s);   // *p += v
 void launch_pack_rows(int64_t n, int W, const int32_t *idx, const double *src, double *dst, hipStream_t s);
 void launch_interleave(int64_t nRows, int NR, int dim, const double *src, double *dst, bool toInterleaved, int64_t sepStride, hipStream_t s);

@@ -1186,6 +1186,142 @@ __global__ void __launch_bounds__(256) k_scatter_values_nr(int64_t n, int NR, in
 }
 
 // ------------------------------------------------------------------------------------------------
+// p-multigrid preconditioner (mfh_multigrid.cpp): quadratic level (matrix-free operator) -> linear level on the same
+// vertices (assembled K1 = P^T K2 P exactly: P1 is a subspace of P2 and both quadratures are exact for their integrands)
+// -> rigid-body modes of geometric aggregates (the dense coarse inverse of the two-level preconditioner). The prolongation is
+// the embedding of the shape functions: a vertex DoF copies its coarse value, an edge-node DoF takes the mean of its two ends
+// (phi^P1_v = phi^P2_v + 1/2 sum_{edges e at v} phi^P2_e; Functions.hh:238-318 nodal bases).
+// Every kernel takes the PCG gate (scal, it, stop): a no-op once the residual of iteration it has met the threshold, like
+// the vector kernels of the loop (blocks of check_every iterations are enqueued / replayed from a hipGraph without host sync).
+// ------------------------------------------------------------------------------------------------
+struct MgGate { const double *scal; int it; const double *stop; };
+DEV bool mg_closed(const MgGate &g) {
+    if (!g.scal) return false;
+    const int it = g.it + (int)g.stop[3];
+    return it >= 0 && g.scal[(int64_t)it * 4 + 2] <= g.stop[0];
+}
+
+// One Chebyshev step on the block-Jacobi-preconditioned operator:  r' = rin - t ; d = a d + b D^-1 r' ; x (+)= d
+//   t == null: r' = rin;  rout != null: the running residual is stored;  first: d is not read (a d = 0);  assign: x = d
+template <int DIM>
+__global__ void __launch_bounds__(256) k_mg_cheb(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ rin,
+                                                 const double *__restrict__ t, double *__restrict__ rout, double *__restrict__ d,
+                                                 double *__restrict__ x, double a, double b, int first, int assign, MgGate g) {
+    if (mg_closed(g)) return;
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nRows; n += (int64_t)gridDim.x * 256) {
+        double rv[DIM], zv[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) rv[c] = rin[n * DIM + c] - (t ? t[n * DIM + c] : 0.0);
+        if (rout)
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) rout[n * DIM + c] = rv[c];
+        apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            const double dv = (first ? 0.0 : a * d[n * DIM + c]) + b * zv[c];
+            d[n * DIM + c] = dv;
+            x[n * DIM + c] = assign ? dv : x[n * DIM + c] + dv;
+        }
+    }
+}
+
+// restriction R = P^T of the residual r - t (t may be null): coarse DoF q gets its own fine DoF plus half of every
+// edge-node DoF it is an end of
+template <int DIM>
+__global__ void __launch_bounds__(256) k_mg_restrict(int64_t nCoarse, const int32_t *__restrict__ fineOf, const int32_t *__restrict__ resPtr,
+                                                     const int32_t *__restrict__ resIdx, const double *__restrict__ r,
+                                                     const double *__restrict__ t, const uint8_t *__restrict__ coarseMask,
+                                                     double *__restrict__ rc, MgGate g) {
+    if (mg_closed(g)) return;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nCoarse; q += (int64_t)gridDim.x * 256) {
+        double acc[DIM];
+        const int64_t f = fineOf[q];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) acc[c] = r[f * DIM + c] - (t ? t[f * DIM + c] : 0.0);
+        for (int k = resPtr[q]; k < resPtr[q + 1]; ++k) {
+            const int64_t e = resIdx[k];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) acc[c] += 0.5 * (r[e * DIM + c] - (t ? t[e * DIM + c] : 0.0));
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) rc[q * DIM + c] = (coarseMask && coarseMask[q * DIM + c]) ? 0.0 : acc[c];
+    }
+}
+
+// x += P xc on the free fine variables
+template <int DIM>
+__global__ void __launch_bounds__(256) k_mg_prolong_add(int64_t nFine, const int32_t *__restrict__ parA, const int32_t *__restrict__ parB,
+                                                        const double *__restrict__ xc, const uint8_t *__restrict__ fineMask,
+                                                        double *__restrict__ x, MgGate g) {
+    if (mg_closed(g)) return;
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nFine; n += (int64_t)gridDim.x * 256) {
+        const int64_t a = parA[n], b = parB[n];
+        if (a < 0) continue;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            if (fineMask && fineMask[n * DIM + c]) continue;
+            x[n * DIM + c] += 0.5 * (xc[a * DIM + c] + xc[b * DIM + c]);
+        }
+    }
+}
+
+// x += Z yc on the free variables (prolongation of the rigid-body coarse correction, linear level)
+template <int DIM>
+__global__ void __launch_bounds__(256) k_mg_tl_prolong_add(TLArgs t, const double *__restrict__ yc, double *__restrict__ x, MgGate g) {
+    if (mg_closed(g)) return;
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < t.nDoF; n += (int64_t)gridDim.x * 256) {
+        const int a = t.aggOfDof[n];
+        const double rp[3] = {t.relPos[n * 3], t.relPos[n * 3 + 1], t.relPos[n * 3 + 2]};
+        double zv[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) zv[c] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (k >= t.nModes) break;
+            const double y = yc[(int64_t)a * t.nModes + k];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) zv[c] += y * tl_mode<DIM>(k, c, rp);
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c)
+            if (!(t.fixedMask && t.fixedMask[n * DIM + c])) x[n * DIM + c] += zv[c];
+    }
+}
+
+// pseudo-random values in (-1/2, 1/2) (start vector of the power iteration)
+__global__ void __launch_bounds__(256) k_fill_hash(int64_t n, double *__restrict__ v) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        uint64_t z = (uint64_t)k * 0x9e3779b97f4a7c15ull + 0x632be59bd9b4e019ull;     // splitmix64 finaliser
+        z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+        z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+        z ^= z >> 31;
+        v[k] = (double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+    }
+}
+
+// out = a - b (b may be null: copy), gated
+__global__ void __launch_bounds__(256) k_mg_diff(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out, MgGate g) {
+    if (mg_closed(g)) return;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) out[k] = a[k] - (b ? b[k] : 0.0);
+}
+
+// scal[(it + 1) 4] += r . z  (the preconditioned inner product of the PCG), z = r on the fixed variables first
+__global__ void __launch_bounds__(256) k_mg_rz(int64_t n, const double *__restrict__ r, double *__restrict__ z, const uint8_t *__restrict__ mask,
+                                               double *scal, MgGate g) {
+    __shared__ double red[8];
+    if (mg_closed(g)) return;
+    const int it = g.scal ? g.it + (int)g.stop[3] : g.it;
+    double acc[1] = {0};
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        double zv = z[k];
+        if (mask && mask[k]) { zv = r[k]; z[k] = zv; }
+        acc[0] += r[k] * zv;
+    }
+    block_sum<1>(acc, red);
+    if (threadIdx.x == 0) unsafeAtomicAdd(scal + (int64_t)(it + 1) * 4, acc[0]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 void launch_untile_vals(int dim, int64_t nnzb, const double *tiled, double *aos, hipStream_t s) {
@@ -1446,6 +1582,51 @@ void launch_mask_nr(int64_t nRows, int NR, int dim, const uint8_t *mask, double 
 void launch_scatter_values_nr(int64_t n, int NR, int dim, const int64_t *idx, const double *val, double *v, int64_t rowBound, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_scatter_values_nr, dim3(grid_for(n)), dim3(256), 0, s, n, NR, dim, idx, val, v, rowBound);
+    CHECK_LAUNCH();
+}
+
+
+// ---- p-multigrid
+static MgGate mk_gate(const double *scal, int it, const double *stop) { return MgGate{scal, it, stop}; }
+void launch_mg_cheb(int dim, int64_t nRows, const double *dinv, const double *rin, const double *t, double *rout, double *d, double *x,
+                    double a, double b, bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s) {
+    const MgGate g = mk_gate(scal, it, stop);
+    const int grid = grid_for(nRows, g_vecGridCap);
+    if (dim == 3) hipLaunchKernelGGL(k_mg_cheb<3>, dim3(grid), dim3(256), 0, s, nRows, dinv, rin, t, rout, d, x, a, b, first ? 1 : 0, assign ? 1 : 0, g);
+    else if (dim == 2) hipLaunchKernelGGL(k_mg_cheb<2>, dim3(grid), dim3(256), 0, s, nRows, dinv, rin, t, rout, d, x, a, b, first ? 1 : 0, assign ? 1 : 0, g);
+    else hipLaunchKernelGGL(k_mg_cheb<1>, dim3(grid), dim3(256), 0, s, nRows, dinv, rin, t, rout, d, x, a, b, first ? 1 : 0, assign ? 1 : 0, g);
+    CHECK_LAUNCH();
+}
+void launch_mg_restrict(int dim, int64_t nCoarse, const int32_t *fineOf, const int32_t *resPtr, const int32_t *resIdx, const double *r, const double *t,
+                        const uint8_t *coarseMask, double *rc, const double *scal, int it, const double *stop, hipStream_t s) {
+    const MgGate g = mk_gate(scal, it, stop);
+    if (dim == 3) hipLaunchKernelGGL(k_mg_restrict<3>, dim3(grid_for(nCoarse, g_vecGridCap)), dim3(256), 0, s, nCoarse, fineOf, resPtr, resIdx, r, t, coarseMask, rc, g);
+    else hipLaunchKernelGGL(k_mg_restrict<2>, dim3(grid_for(nCoarse, g_vecGridCap)), dim3(256), 0, s, nCoarse, fineOf, resPtr, resIdx, r, t, coarseMask, rc, g);
+    CHECK_LAUNCH();
+}
+void launch_mg_prolong_add(int dim, int64_t nFine, const int32_t *parA, const int32_t *parB, const double *xc, const uint8_t *fineMask, double *x,
+                           const double *scal, int it, const double *stop, hipStream_t s) {
+    const MgGate g = mk_gate(scal, it, stop);
+    if (dim == 3) hipLaunchKernelGGL(k_mg_prolong_add<3>, dim3(grid_for(nFine, g_vecGridCap)), dim3(256), 0, s, nFine, parA, parB, xc, fineMask, x, g);
+    else hipLaunchKernelGGL(k_mg_prolong_add<2>, dim3(grid_for(nFine, g_vecGridCap)), dim3(256), 0, s, nFine, parA, parB, xc, fineMask, x, g);
+    CHECK_LAUNCH();
+}
+void launch_mg_tl_prolong_add(const TLArgs &t, const double *yc, double *x, const double *scal, int it, const double *stop, hipStream_t s) {
+    const MgGate g = mk_gate(scal, it, stop);
+    if (t.dim == 3) hipLaunchKernelGGL(k_mg_tl_prolong_add<3>, dim3(grid_for(t.nDoF, g_vecGridCap)), dim3(256), 0, s, t, yc, x, g);
+    else hipLaunchKernelGGL(k_mg_tl_prolong_add<2>, dim3(grid_for(t.nDoF, g_vecGridCap)), dim3(256), 0, s, t, yc, x, g);
+    CHECK_LAUNCH();
+}
+void launch_fill_hash(int64_t n, double *v, hipStream_t s) {
+    hipLaunchKernelGGL(k_fill_hash, dim3(grid_for(n, g_vecGridCap)), dim3(256), 0, s, n, v);
+    CHECK_LAUNCH();
+}
+void launch_mg_diff(int64_t n, const double *a, const double *b, double *out, const double *scal, int it, const double *stop, hipStream_t s) {
+    hipLaunchKernelGGL(k_mg_diff, dim3(grid_for(n, g_vecGridCap)), dim3(256), 0, s, n, a, b, out, mk_gate(scal, it, stop));
+    CHECK_LAUNCH();
+}
+void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, double *scalOut, int it, const double *scal, const double *stop, hipStream_t s) {
+    hipLaunchKernelGGL(k_mg_rz, dim3(grid_for(n)), dim3(256), 0, s, n, r, z, mask, scalOut, mk_gate(scal, it, stop));
     CHECK_LAUNCH();
 }
 

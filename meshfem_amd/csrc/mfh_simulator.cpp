@@ -423,7 +423,7 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
     lap("assembly + diagonal blocks");
-    if (c->precond == MFH_PRECOND_TWO_LEVEL) ensure_twolevel(c);
+    ensure_coarse_levels(c, 1);
     lap("two-level setup");
     mfh_solve_info li{};
     const int k = (int)C.size();
@@ -480,7 +480,7 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
             // K is singular on the free variables, and so is the Galerkin coarse operator of the two-level
             // preconditioner (the aggregates' modes span the global rigid motions): block-Jacobi for this solve
             c->tlSuppress = true;
-            if (c->precond == MFH_PRECOND_TWO_LEVEL) c->precondNote = "two-level preconditioner: singular system (rigid-motion constraint rows); using block-Jacobi";
+            if (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) c->precondNote = "two-level / multigrid preconditioner: singular system (rigid-motion constraint rows); using block-Jacobi";
             try { solve_one(c, fv2.data(), x.data(), rtol, maxit, &li); } catch (...) { c->tlSuppress = false; throw; }
             c->tlSuppress = false;
             std::vector<double> a((size_t)k);
@@ -547,7 +547,7 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
             for (int r = 0; r < k; ++r)
                 for (int64_t i = 0; i < n; ++i) fv2[(size_t)i] -= lam0[r] * Cf[r][(size_t)i];
             c->tlSuppress = true;
-            if (c->precond == MFH_PRECOND_TWO_LEVEL) c->precondNote = "two-level preconditioner: singular system (rigid-motion constraint rows); using block-Jacobi";
+            if (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) c->precondNote = "two-level / multigrid preconditioner: singular system (rigid-motion constraint rows); using block-Jacobi";
             std::vector<std::vector<double>> Y((size_t)nm, std::vector<double>((size_t)n));
             try {
                 solve_one(c, fv2.data(), x.data(), rtol, maxit, &li);

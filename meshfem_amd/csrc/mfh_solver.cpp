@@ -289,7 +289,7 @@ void dist_agree(mfh_ctx *c) {
     };
     prepare();
     for (int round = 0; round < 2; ++round) {
-        const bool useTL = c->precond == MFH_PRECOND_TWO_LEVEL && c->tl.valid;
+        const bool useTL = (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) && c->tl.valid;
         double h[8] = {c->anyFixedNonzero ? 1.0 : 0.0, localCode != MFH_OK ? 1.0 : 0.0, (localCode == MFH_OK && !supported) ? 1.0 : 0.0,
                        (localCode == MFH_OK && supported && cluster_operator(c)) ? 1.0 : 0.0, useTL ? 1.0 : 0.0, 1.0, 0.0, 0.0};
         c->cgCtl.alloc(16);
@@ -380,7 +380,7 @@ void solve_cg(mfh_ctx *c, int NR, const double *f, double *u, int64_t fStride, d
     int itRun = 0;
     if (anyWork) {
         EventTimer tsolve(s);
-        const bool useTL = c->precond == MFH_PRECOND_TWO_LEVEL && c->tl.valid && !c->tlSuppress;
+        const bool useTL = (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) && c->tl.valid && !c->tlSuppress;
         double *scal = c->scal.p;
         const double *ctl = c->cgCtl.p;
         // start: u = M^-1 r, w = K u, {gamma, delta, rr}_0
@@ -543,7 +543,7 @@ void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rt
     if (bb == 0.0) { c->wx.zero(s); li.converged = 1; }
     else {
         EventTimer tsolve(s);
-        const bool useTL = c->precond == MFH_PRECOND_TWO_LEVEL && c->tl.valid && !c->tlSuppress;
+        const bool useTL = (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) && c->tl.valid && !c->tlSuppress;
         double *scal = c->scal.p;
         auto &T = c->tl;
         auto tl_pre = [&](int it) {     // z = M^-1 r, r.z into scal[(it + 1) 4]; the restricted residual summed over the ranks
@@ -618,7 +618,8 @@ void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rt
 // one right-hand side: the Chronopoulos-Gear loop when the operator in use has a batched kernel, else the classic PCG
 void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info) {
     const bool partitioned = c->sym.nRows != c->sym.nCols;
-    if ((c->pcgVariant == 1 || partitioned) && cg_operator_supported(c)) {
+    const bool multigrid = c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && !partitioned;   // the V-cycle lives in the classic loop
+    if (!multigrid && (c->pcgVariant == 1 || partitioned) && cg_operator_supported(c)) {
         const int64_t n = (int64_t)c->bs() * c->sym.nRows;
         solve_cg(c, 1, f, u, n, rtol, maxit, info);
     } else {

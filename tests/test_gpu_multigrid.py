@@ -1,0 +1,130 @@
+"""MFH_PRECOND_MULTIGRID: the p-multigrid V-cycle (quadratic level -> linear level on the same vertices -> rigid-body modes of
+aggregates; mfh_multigrid.cpp) as the preconditioner of the PCG that replaces the reference's CHOLMOD solve
+(SPSDSystem::solve, SparseMatrices.hh:2515-2606). The answers are those of the oracle's direct solve (north_star tolerance 1e-6
+rel-L2 on nodal displacements; measured ~1e-9 at rtol 1e-10); the iteration counts must be mesh-independent tens."""
+import numpy as np
+import pytest
+
+import meshfem_amd as M
+from meshfem_amd import grid
+from oracle import meshfem_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+U_RTOL = 1e-6
+
+
+def _cantilever(n, deg=2, dim=3):
+    if dim == 3:
+        V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    else:
+        V, Q = O.gen_grid_2d(n, n)
+        V, T = O.quad_tri_subdiv(V, Q)
+        V = V[:, :2] / n
+    c = M.Context(0)
+    c.mesh_build(T, V, deg)
+    c.material_isotropic(200.0, 0.35)
+    lo, hi = [-9.0] * dim, [9.0] * dim
+    lo[0], hi[0] = -1e-9, 1e-9
+    c.bc_dirichlet_box(lo, hi, [0.0] * dim)
+    lo2, hi2 = [-9.0] * dim, [9.0] * dim
+    lo2[0], hi2[0] = 1 - 1e-9, 1 + 1e-9
+    c.bc_neumann_box(lo2, hi2, [0.0, -1.0, 0.0][:dim], kind=M.NEUMANN_TRACTION)
+    return c, V, T
+
+
+@pytest.mark.parametrize("dim,n", [(3, 4), (2, 12)])
+def test_multigrid_pcg_matches_the_oracle_direct_solve(dim, n):
+    c, V, T = _cantilever(n, 2, dim)
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    u = c.sim_solve(rtol=1e-10)
+    i = c.last_info
+    g = c.multigrid_info()
+    assert i["converged"] and i["true_rel_residual"] < 2e-10
+    assert g["fine_dof"] == c.n_dof and 0 < g["coarse_dof"] < g["fine_dof"] and g["lambda_max_fine"] > 1.0
+    sim = O.Simulator(T, V, 2)
+    sim.set_material_constant(O.ElasticityTensor.isotropic(dim, 200.0, 0.35))
+    lo, hi = [-9.0] * dim, [9.0] * dim
+    lo[0], hi[0] = -1e-9, 1e-9
+    sim.apply_dirichlet_box(lo, hi, [0.0] * dim)
+    lo[0], hi[0] = 1 - 1e-9, 1 + 1e-9
+    sim.apply_neumann_box(lo, hi, [0.0, -1.0, 0.0][:dim], "traction")
+    uref = sim.solve()
+    assert np.linalg.norm(u - uref) / np.linalg.norm(uref) < U_RTOL
+    # the same system through the two-level preconditioner: same answer, more iterations
+    c.set_preconditioner(M.PRECOND_TWO_LEVEL)
+    u2 = c.sim_solve(rtol=1e-10)
+    assert np.linalg.norm(u2 - u) <= 1e-7 * np.linalg.norm(u)
+    assert i["iterations"] < c.last_info["iterations"]
+    c.close()
+
+
+def test_multigrid_iteration_count_does_not_grow_with_the_mesh():
+    its = {}
+    for n in (6, 12):
+        c, _, _ = _cantilever(n)
+        c.set_preconditioner(M.PRECOND_MULTIGRID)
+        c.sim_solve(rtol=1e-8)
+        its[n] = c.last_info["iterations"]
+        c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+        c.sim_solve(rtol=1e-8)
+        bj = c.last_info["iterations"]
+        c.close()
+        assert its[n] < 0.2 * bj, (n, its[n], bj)
+    assert its[12] <= 1.3 * its[6] + 3 and its[12] <= 60, its      # eight times the elements, (about) the same count
+
+
+def test_multigrid_nonzero_dirichlet_values_options_and_graph_free_loop():
+    c, V, T = _cantilever(5)
+    pos = c.node_positions()
+    right = np.flatnonzero(np.abs(pos[:, 0] - 1) < 1e-12)
+    c.assemble()
+    vars_, vals = c.bc_dirichlet_vars()
+    extra = (3 * right[:, None] + np.arange(3)[None, :]).ravel()
+    c.fix_variables(np.concatenate([vars_, extra]), np.concatenate([vals, np.tile([0.01, 0.0, -0.02], len(right))]))
+    f = np.zeros(3 * c.n_dof)
+    c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+    u_bj = c.solve(f, rtol=1e-11)
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    u = c.solve(f, rtol=1e-11)
+    it = c.last_info["iterations"]
+    assert np.linalg.norm(u - u_bj) <= 1e-8 * np.linalg.norm(u_bj)
+    assert np.allclose(u.reshape(-1, 3)[right], [0.01, 0.0, -0.02], atol=1e-15)
+    for opt, val in (("mg_steps_fine", 2), ("mg_steps_coarse", 2), ("mg_coarse_cycles", 2), ("pcg_graph", 0)):
+        c.set_option(opt, val)
+        u2 = c.solve(f, rtol=1e-11)
+        assert c.last_info["converged"] and np.linalg.norm(u2 - u) <= 1e-8 * np.linalg.norm(u), opt
+    assert c.last_info["used_graph"] == 0 and it < 60
+    c.close()
+
+
+def test_multigrid_orthotropic_field_and_periodic_cell_problems():
+    """BASELINE configs[3] in small: per-element orthotropic field, periodic DoF map, pinned node, six cell problems."""
+    from meshfem_amd import homogenization as H
+    n = 6
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    P = grid.synthetic_orthotropic_field(len(T), 3, seed=1)
+    res = {}
+    for pre in (M.PRECOND_TWO_LEVEL, M.PRECOND_MULTIGRID):
+        sim = M.Simulator(T, V, 2)
+        sim.ctx.material_ortho_field(P)
+        sim.ctx.set_preconditioner(pre)
+        sim.rtol = 1e-10
+        w, infos = H.solve_cell_problems(sim)
+        Ch = H.homogenized_elasticity_tensor(sim, w)
+        assert all(i["converged"] for i in infos)
+        res[pre] = (np.asarray(Ch), max(i["iterations"] for i in infos), sim.ctx.precond_info()["note"])
+        sim.ctx.close()
+    assert np.abs(res[M.PRECOND_MULTIGRID][0] - res[M.PRECOND_TWO_LEVEL][0]).max() <= 1e-7 * np.abs(res[M.PRECOND_TWO_LEVEL][0]).max()
+    assert res[M.PRECOND_MULTIGRID][1] < res[M.PRECOND_TWO_LEVEL][1], res
+
+
+def test_multigrid_on_linear_elements_falls_back_with_a_note():
+    c, V, T = _cantilever(4, deg=1)
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    u = c.sim_solve(rtol=1e-10)
+    assert c.last_info["converged"] and "quadratic" in c.precond_info()["note"]
+    assert c.multigrid_info()["fine_dof"] == 0 and c.precond_info()["aggregates"] > 0          # the two-level construction took over
+    c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+    assert np.linalg.norm(c.sim_solve(rtol=1e-10) - u) <= 1e-7 * np.linalg.norm(u)
+    c.close()
