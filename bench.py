@@ -259,7 +259,8 @@ def run_single(args):
     t0 = time.time(); c.symbolic(False); t_sym = time.time() - t0
     c.set_option("reembed", 1)               # every step re-runs the embedding kernel too
     nE = c.n_elem
-    for _ in range(args.warmup):
+    t0 = time.time(); c.assemble(); c.dev_sync(); t_first = time.time() - t0     # the first pass: what a one-shot caller pays on top of mesh build + symbolic phase
+    for _ in range(max(0, args.warmup - 1)):
         c.assemble()
     torch.cuda.synchronize(); c.dev_sync()
     t0 = time.perf_counter()
@@ -305,7 +306,11 @@ def run_single(args):
                            stored_blocks=stored_blocks, matrix_storage="upper" if upper else "full",
                            parallelism="1 GPU", step="embed + Ke blocks + assembly into block-CSR (gather/owner-computes)"),
                roofline=roof, hbm_measured=hbm_measured,
-               setup=dict(mesh_gen_s=t_gen, femmesh_build_s=t_build, symbolic_s=t_sym, **c.timing(), **c.symbolic_sizes()))
+               setup=dict(mesh_gen_s=t_gen, femmesh_build_s=t_build, symbolic_s=t_sym, first_assemble_call_s=t_first,
+                          # the timed step excludes what a one-shot caller pays once per mesh -- FEMMesh build (edge numbering,
+                          # boundary extraction, node table; includes the upload), symbolic phase (pattern + gather lists), first pass
+                          first_assembly_ms=(t_build + t_sym + t_first) * 1e3, first_assembly_elements_per_s=nE / (t_build + t_sym + t_first),
+                          **c.timing(), **c.symbolic_sizes()))
     # comparison variant: element-major global-atomic scatter (north_star: "colored or atomic ... by evidence")
     try:
         a_ms = c.time_assembly_kernel(M.ASSEMBLE_ATOMIC, 3)
@@ -397,6 +402,22 @@ def run_single(args):
                                         rel_l2_vs_block_jacobi=float(np.linalg.norm(u2 - u) / np.linalg.norm(u)))
         except M.MeshFEMHipError as e:
             out["pcg_two_level"] = str(e)
+        # same system with the p-multigrid preconditioner (quadratic level -> linear level -> rigid-body coarse level)
+        if deg == 2:
+            try:
+                c.set_preconditioner(M.PRECOND_MULTIGRID)
+                t0 = time.time()
+                u3 = c.sim_solve(rtol=args.rtol, maxit=args.maxit)
+                i3, p3, g3 = dict(c.last_info), c.precond_info(), c.multigrid_info()
+                out["pcg_multigrid"] = dict(iterations=i3["iterations"], converged=i3["converged"], true_rel_residual=i3["true_rel_residual"],
+                                            solve_ms=i3["solve_ms"], hierarchy_setup_ms=g3["setup_ms"], levels=dict(quadratic_dof=3 * g3["fine_dof"], linear_dof=3 * g3["coarse_dof"],
+                                                                                                            rigid_body_dim=p3["coarse_dim"]),
+                                            lambda_max=[g3["lambda_max_fine"], g3["lambda_max_coarse"]], note=p3["note"], wall_s=time.time() - t0,
+                                            ms_per_iteration=i3["solve_ms"] / max(1, i3["iterations"]),
+                                            speedup_time_to_solution_vs_block_jacobi=info["solve_ms"] / (i3["solve_ms"] + g3["setup_ms"]),
+                                            rel_l2_vs_block_jacobi=float(np.linalg.norm(u3 - u) / np.linalg.norm(u)))
+            except M.MeshFEMHipError as e:
+                out["pcg_multigrid"] = str(e)
     # The same pass with BOTH triangles of K stored (option matrix_storage 0: the round-1 definition of this benchmark, and what a
     # context does on its own when something multiplies by the stored K). Same timed region (embedding + blocks + assembly).
     if upper and not strong:

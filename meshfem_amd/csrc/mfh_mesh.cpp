@@ -205,8 +205,23 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
     m.dim = dim; m.deg = deg; m.npe = nodes_per_elem(dim, deg); m.npbe = nodes_per_bdry_elem(dim, deg);
     m.nElem = nElem; m.nVert = nVert;
     m.vertPos.assign(vp, vp + nVert * dim);
-    for (int64_t k = 0; k < nElem * nv; ++k)
-        if (ev[k] < 0 || ev[k] >= nVert) throw Error(MFH_ERR_INVALID, "Bad vertex index encountered.");
+    {
+        std::vector<uint8_t> bad((size_t)host_threads() + 1, 0);
+        parallel_ranges(nElem * nv, [&](int64_t b, int64_t e2, int tid) {
+            for (int64_t k = b; k < e2; ++k)
+                if (ev[k] < 0 || ev[k] >= nVert) bad[(size_t)tid] = 1;
+        });
+        for (uint8_t b : bad)
+            if (b) throw Error(MFH_ERR_INVALID, "Bad vertex index encountered.");
+    }
+    const bool timing = getenv("MFH_MESH_TIMING") != nullptr;
+    double tp = now_ms();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const double t = now_ms();
+        fprintf(stderr, "[mesh build] %-30s %8.2f ms\n", what, t - tp);
+        tp = t;
+    };
 
     // ---- topology: edge nodes in first-encounter order over (element, local edge) (FEMMesh.inl:22-36) and
     //      the unmatched half-faces / half-edges in sorted-key order (TetMesh.inl:36-79, TriMesh.inl:60-100)
@@ -216,6 +231,7 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
     if (!(useDevice && build_topology_device(dim, deg, nElem, nVert, ev, stream, instEdge, nEdgeNodes, bdryInst)))
         build_topology_host(dim, deg, nElem, nVert, ev, instEdge, nEdgeNodes, bdryInst);
 
+    lap("topology (edges, boundary)");
     m.elemNodes.resize((size_t)nElem * m.npe);
     parallel_ranges(nElem, [&](int64_t b, int64_t e2, int) {
         for (int64_t e = b; e < e2; ++e) {
@@ -227,7 +243,9 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
     });
     m.nNode = nVert + nEdgeNodes;
     m.nOwned = m.nNode;
+    lap("element node table");
     compute_node_positions(m);
+    lap("node positions");
 
     // ---- boundary elements from the unmatched instances
     const int64_t nBE = (int64_t)bdryInst.size();
@@ -294,24 +312,31 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
     compute_boundary_geometry(m, vp);
     m.bdryInternal.assign((size_t)nBE, 0);
     m.hasTopology = true;
+    lap("boundary elements + geometry");
 }
 
 // Node positions: vertex nodes = vertices; P2 edge node = midpoint of its end vertices
 // (FEMMesh.hh:221-237). Derived from the element node table so it also works for mesh_set.
 void compute_node_positions(HostMesh &m) {
     const int dim = m.dim, nv = dim + 1;
-    m.nodePos.assign((size_t)m.nNode * dim, 0.0);
+    m.nodePos.resize((size_t)m.nNode * dim);
     std::copy(m.vertPos.begin(), m.vertPos.begin() + (size_t)m.nVert * dim, m.nodePos.begin());
     if (m.deg == 2) {
         const int nedge = dim == 3 ? 6 : 3;
-        for (int64_t e = 0; e < m.nElem; ++e) {
-            const int32_t *en = &m.elemNodes[(size_t)e * m.npe];
-            for (int ei = 0; ei < nedge; ++ei) {
-                int32_t node = en[nv + ei];
-                const double *pa = &m.vertPos[(size_t)en[kEdgeStart[ei]] * dim], *pb = &m.vertPos[(size_t)en[kEdgeEnd[ei]] * dim];
-                for (int a = 0; a < dim; ++a) m.nodePos[(size_t)node * dim + a] = 0.5 * (pa[a] + pb[a]);
+        // on the host threads; the elements sharing an edge all store the same midpoint (relaxed atomic stores of equal bit patterns)
+        parallel_ranges(m.nElem, [&](int64_t eb, int64_t ee, int) {
+            for (int64_t e = eb; e < ee; ++e) {
+                const int32_t *en = &m.elemNodes[(size_t)e * m.npe];
+                for (int ei = 0; ei < nedge; ++ei) {
+                    const int32_t node = en[nv + ei];
+                    const double *pa = &m.vertPos[(size_t)en[kEdgeStart[ei]] * dim], *pb = &m.vertPos[(size_t)en[kEdgeEnd[ei]] * dim];
+                    for (int a = 0; a < dim; ++a) {
+                        double v = 0.5 * (pa[a] + pb[a]);
+                        __atomic_store(&m.nodePos[(size_t)node * dim + a], &v, __ATOMIC_RELAXED);
+                    }
+                }
             }
-        }
+        });
     }
 }
 

@@ -41,17 +41,21 @@ __global__ void __launch_bounds__(256) k_sym_heads(int64_t n, const uint64_t *__
 __global__ void __launch_bounds__(256) k_sym_pattern(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ slotP1,
                                                      int32_t *__restrict__ colIdx, int32_t *__restrict__ rowLen,
                                                      int64_t *__restrict__ rowCStart, int64_t nRows, unsigned long long *__restrict__ nMirror) {
+    unsigned long long mirror = 0;      // summed over the wave before it reaches the one global counter (59-98 ms -> a few ms at config 3:
+                                        // 50 M single-address atomics were the whole kernel)
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
         const uint64_t kk = key[k];
-        const bool head = k == 0 || kk != key[k - 1];
-        if (!head) continue;
+        const uint64_t prev = k == 0 ? ~kk : key[k - 1];
+        if (kk == prev) continue;                                     // not a slot head
         const int64_t row = (int64_t)(kk >> 32);
-        colIdx[slotP1[k] - 1] = (int32_t)(kk & 0xffffffffu);
-        atomicAdd(&rowLen[row], 1);
         const int64_t col = (int64_t)(kk & 0xffffffffu);
-        if (col > row && col < nRows) atomicAdd(nMirror, 1ull);     // blocks whose transpose is a block of K too (Symbolic::nMirror)
-        if (k == 0 || (int64_t)(key[k - 1] >> 32) != row) rowCStart[row] = k;
+        colIdx[slotP1[k] - 1] = (int32_t)col;
+        atomicAdd(&rowLen[row], 1);
+        if (col > row && col < nRows) ++mirror;                       // blocks whose transpose is a block of K too (Symbolic::nMirror)
+        if (k == 0 || (int64_t)(prev >> 32) != row) rowCStart[row] = k;
     }
+    for (int off = 32; off > 0; off >>= 1) mirror += __shfl_down(mirror, off, 64);
+    if ((threadIdx.x & 63) == 0 && mirror) atomicAdd(nMirror, mirror);
 }
 
 __global__ void __launch_bounds__(256) k_sym_key2(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val,

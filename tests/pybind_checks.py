@@ -1,0 +1,197 @@
+"""Checks of the COMPILED pybind11 modules (meshfem_amd/pybind: mesh, tensors, sparse_matrices, periodic_homogenization -- the
+reference's extension-module names and signatures, src/python_bindings/*.cc). Run as a script in its own interpreter
+(tests/test_pybind_modules.py): the pure-Python shims of meshfem_amd/compat use the same top-level module names.
+    python tests/pybind_checks.py cpu | gpu"""
+import os
+import pickle
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import meshfem_amd.pybind as pb                      # noqa: E402
+from meshfem_amd.pybind import build as pbuild       # noqa: E402
+
+pbuild.build(verbose=False)
+sys.path.insert(0, pb.PATH)
+import mesh as cmesh                                 # noqa: E402
+import tensors as ctensors                           # noqa: E402
+import sparse_matrices as csm                        # noqa: E402
+import periodic_homogenization as cph                # noqa: E402
+from oracle import meshfem_oracle as O               # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+for mod in (cmesh, ctensors, csm, cph):
+    assert mod.__file__.endswith(".so") and os.path.dirname(mod.__file__) == pb.PATH, mod.__file__      # compiled, in-tree
+
+
+def raises(exc, fn):
+    try:
+        fn()
+    except exc:
+        return True
+    return False
+
+
+def check_tensors():
+    t = ctensors.ElasticityTensor3D(200.0, 0.35)
+    ref = O.ElasticityTensor.isotropic(3, 200.0, 0.35)
+    assert np.abs(t.D - ref.D).max() < 1e-12
+    for idx in ((0, 0, 0, 0), (0, 1, 0, 1), (0, 0, 1, 1), (1, 2, 2, 1), (0, 2, 1, 1)):
+        assert abs(t(*idx) - ref(*idx)) < 1e-12
+    assert raises(RuntimeError, lambda: t(3, 0, 0, 0))
+    t.setOrthotropic(150, 200, 250, 0.3, 0.25, 0.2, 60, 70, 80)
+    assert np.abs(t.D - O.ElasticityTensor.orthotropic3d(150, 200, 250, 0.3, 0.25, 0.2, 60, 70, 80).D).max() < 1e-10
+    e = np.array([0.3, -0.1, 0.2, 0.05, -0.07, 0.11])
+    assert np.abs(t.inverse().doubleContract(t.doubleContract(e)) - e).max() < 1e-13
+    t2 = ctensors.ElasticityTensor2D(10.0, 0.3)
+    assert abs(t2(0, 0, 1, 1) - 0.3 * 10 / (1 - 0.09)) < 1e-13
+    t2.setOrthotropic(100.0, 150.0, 0.3, 40.0)
+    assert np.abs(t2.D - O.ElasticityTensor.orthotropic2d(100.0, 150.0, 0.3, 40.0).D).max() < 1e-10
+    sm = ctensors.SymmetricMatrix([1.0, 2.0, 3.0, 0.4, 0.5, 0.6])
+    assert sm(1, 2) == 0.4 and sm(0, 2) == 0.5 and sm(0, 1) == 0.6 and np.allclose(sm.toMatrix(), sm.toMatrix().T)
+    assert np.allclose(ctensors.SymmetricMatrix(sm.toMatrix()).flat, sm.flat)
+    ident = ctensors.ElasticityTensor3D().setIdentity()
+    assert np.allclose(ident.doubleContract(e), e) and np.allclose(ident.doubleContract(sm).flat, sm.flat)
+    assert np.allclose(t.doubleContract(np.stack([e, 2 * e])), np.stack([t.doubleContract(e), 2 * t.doubleContract(e)]))
+
+
+def check_triplets():
+    tmp = tempfile.mkdtemp()
+    A = csm.TripletMatrix(4, 4)
+    for i, j, v in ((0, 0, 2.0), (0, 1, -1.0), (1, 1, 2.0), (0, 1, 0.5), (2, 3, 1.0), (2, 3, -1.0), (3, 3, 4.0), (2, 2, 3.0)):
+        A.addNZ(i, j, v)
+    assert raises(RuntimeError, lambda: A.addNZ(4, 0, 1.0)) and A.nnz == 8
+    A.sumRepeated()                        # duplicates summed, exact zero (2,3) dropped, (col,row) order (SparseMatrices.hh:280-374)
+    ents = [(t.i, t.j, t.v) for t in A.entries()]
+    assert ents == [(0, 0, 2.0), (0, 1, -0.5), (1, 1, 2.0), (2, 2, 3.0), (3, 3, 4.0)]
+    A.symmetry_mode = csm.SymmetryMode.UPPER_TRIANGLE
+    x = np.array([1.0, 2.0, 3.0, 4.0])
+    full = np.array([[2, -0.5, 0, 0], [-0.5, 2, 0, 0], [0, 0, 3, 0], [0, 0, 0, 4.0]])
+    assert np.allclose(A.apply(x), full @ x) and np.allclose(A.diag(), np.diag(full))
+    p = os.path.join(tmp, "a.bin")
+    A.dumpBinary(p)
+    B = csm.TripletMatrix()
+    B.readBinary(p)
+    assert (B.m, B.n, B.nnz) == (4, 4, 5) and [(t.i, t.j, t.v) for t in B.entries()] == ents
+    T = O.TripletMatrix.from_arrays(4, 4, *A.arrays())          # same bytes as the oracle's dumpBinary (:623-645)
+    q = os.path.join(tmp, "b.bin")
+    T.dump_binary(q)
+    assert open(p, "rb").read() == open(q, "rb").read()
+    S = csm.SuiteSparseMatrix(A)
+    assert (S.m, S.n, S.nz) == (4, 4, 5) and S.symmetry_mode == csm.SymmetryMode.UPPER_TRIANGLE and abs(S.trace() - 11.0) < 1e-15
+    assert np.allclose(S.apply(x), full @ x) and np.allclose(np.triu(S.toSciPy().toarray()), np.triu(full))
+    P = pickle.loads(pickle.dumps(S))
+    assert P.Ax == S.Ax and P.Ai == S.Ai and P.symmetry_mode == S.symmetry_mode
+    sp_ = os.path.join(tmp, "s.bin")
+    S.dumpBinary(sp_)
+    R = csm.SuiteSparseMatrix(sp_)
+    assert R.Ap == S.Ap and R.Ax == S.Ax and os.path.getsize(sp_) == 3 * 8 + 4 + 5 * 8 + 5 * 16
+    A.reflectUpperTriangle()
+    assert np.allclose(A.compressedColumn().toarray(), full)
+    full_mode = csm.SuiteSparseMatrix(A)
+    assert raises(RuntimeError, lambda: full_mode.solve(x))      # "Only symmetric matrices are currently supported"
+
+
+def check_mesh():
+    m = cmesh.Mesh(os.path.join(GOLD, "meshes", "cube_cross.msh"), degree=2)
+    ref = O.FEMMesh(m.elements(), m.vertices(), 2)
+    assert (m.numVertices(), m.numElements(), m.numNodes()) == (64, 132, ref.num_nodes)
+    assert np.array_equal(m.elementNodes(), ref.elem_nodes) and np.allclose(m.nodes(), ref.node_pos)
+    assert np.array_equal(m.boundaryNodes(), ref.bdry_nodes)
+    assert m.degree == 2 and m.simplexDimension == 3 and m.embeddingDimension == 3
+    assert abs(m.volume - ref.embeddings_batch()[0].sum()) < 1e-13 and abs(m.bbox_volume - 8.0) < 1e-13
+    pc = cmesh.PeriodicCondition(m)
+    assert np.array_equal(pc.periodicDoFsForNodes(), O.periodic_dofs_for_nodes(ref)[0])
+    m2 = cmesh.Mesh(os.path.join(GOLD, "meshes", "2D_microstructure.msh"), degree=1, embeddingDimension=2)
+    assert m2.embeddingDimension == 2 and m2.vertices().shape[1] == 2 and m2.elementVolumes().min() > 0
+    V, F = m2.vertices(), m2.elements()
+    assert cmesh.Mesh(V, F, 2, 2).numNodes() == O.FEMMesh(F, V, 2).num_nodes
+
+
+def check_spsd_system_gpu():
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    rng = np.random.default_rng(0)
+    n = 400
+    B = sp.random(n, n, density=0.01, random_state=1, format="csr")
+    A = (B @ B.T + sp.diags(np.full(n, 0.5)) + sp.diags([-0.1] * (n - 1), 1) + sp.diags([-0.1] * (n - 1), -1)).tocoo()
+    K = csm.TripletMatrix(n, n)
+    for i, j, v in zip(A.row, A.col, A.data):
+        if i <= j:
+            K.addNZ(int(i), int(j), float(v) * 0.5)      # two halves: SPSDSystem must sum repeats
+            K.addNZ(int(i), int(j), float(v) * 0.5)
+    K.symmetry_mode = csm.SymmetryMode.UPPER_TRIANGLE
+    sysm = csm.SPSDSystem(K)
+    Afull = A.tocsr()
+    b = rng.standard_normal(n)
+    x = sysm.solve(b)
+    assert np.linalg.norm(x - spl.spsolve(Afull.tocsc(), b)) < 1e-8 * np.linalg.norm(x)
+    fv = np.array([3, 77, 150, 399])
+    fx = np.array([0.5, -1.0, 0.0, 2.0])
+    sysm.fixVariables(fv.tolist(), fx.tolist())
+    x = sysm.solve(b)
+    free = np.setdiff1d(np.arange(n), fv)
+    xr = np.zeros(n); xr[fv] = fx
+    xr[free] = spl.spsolve(Afull[free][:, free].tocsc(), b[free] - Afull[free][:, fv] @ fx)
+    assert np.array_equal(x[fv], fx) and np.linalg.norm(x - xr) < 1e-8 * np.linalg.norm(xr)
+    assert raises(Exception, lambda: sysm.fixVariables([3], [1.0]))        # "Variable already fixed."
+    assert raises(RuntimeError, lambda: csm.SPSDSystem(K, csm.TripletMatrix(2, n + 1), [0.0, 0.0]))
+    Cd = np.zeros((2, n))
+    Cd[0, :] = 1.0
+    Cd[1, 5], Cd[1, 77] = 1.0, -2.0                        # touches a fixed variable
+    crhs = [0.3, 0.5]
+    C = csm.TripletMatrix(2, n)
+    for r, cidx in zip(*np.nonzero(Cd)):
+        C.addNZ(int(r), int(cidx), float(Cd[r, cidx]))
+    sysc = csm.SPSDSystem(K, C, crhs)
+    sysc.fixVariables(fv.tolist(), fx.tolist())
+    Ad = Afull.toarray()
+    kkt = np.block([[Ad[np.ix_(free, free)], Cd[:, free].T], [Cd[:, free], np.zeros((2, 2))]])
+    xc = sysc.solve(b)
+    sol = np.linalg.solve(kkt, np.concatenate([b[free] - Ad[np.ix_(free, fv)] @ fx, np.array(crhs) - Cd[:, fv] @ fx]))
+    ref = np.zeros(n); ref[fv] = fx; ref[free] = sol[:len(free)]
+    assert np.array_equal(xc[fv], fx) and np.abs(Cd @ xc - crhs).max() < 1e-7 and np.linalg.norm(xc - ref) < 1e-7 * np.linalg.norm(ref)
+    S = csm.SuiteSparseMatrix(K)
+    assert np.linalg.norm(S.solve(b) - spl.spsolve(Afull.tocsc(), b)) < 1e-8 * np.linalg.norm(b)
+
+
+def check_homogenization_gpu():
+    g = np.load(os.path.join(GOLD, "example_meshes.npz"))
+    for name, dim, deg in (("cube_cross", 3, 2), ("2D_microstructure", 2, 2), ("2D_microstructure", 2, 1)):
+        m = cmesh.Mesh(os.path.join(GOLD, "meshes", name + ".msh"), degree=deg, embeddingDimension=dim)
+        Cbase = (ctensors.ElasticityTensor3D if dim == 3 else ctensors.ElasticityTensor2D)(200.0, 0.35)
+        hr = cph.homogenize(m, Cbase)
+        key = "%s_hom_p%d_" % (name, deg)
+        assert np.abs(hr.Ch.D - g[key + "Ch"]).max() < 1e-7 * np.abs(g[key + "Ch"]).max(), (name, deg)
+        for k in range(len(hr.w_ij)):
+            assert np.abs(hr.w_ij[k].mean(axis=0)).max() < 1e-12                  # centred
+            wg = g[key + "w"][k]
+            assert np.linalg.norm(hr.w_ij[k] - (wg - wg.mean(axis=0))) < 1e-6 * np.linalg.norm(wg)
+        fl = 6 if dim == 3 else 3
+        ms = np.zeros(fl); ms[0] = 0.01; ms[fl - 1] = 0.005
+        u, su = cph.probe(m, hr, ctensors.SymmetricMatrix(ms))
+        assert u.shape == (m.numNodes(), dim) and su.shape == (m.numElements(), fl)
+        vol = m.elementVolumes()
+        sim = O.Simulator(m.elements(), m.vertices(), deg)
+        avg = (vol[:, None] * sim.averageStrainField(u)).sum(axis=0) / vol.sum()
+        assert np.abs(avg - (vol[:, None] * su).sum(axis=0) / vol.sum()).max() < 1e-10
+        u2, _ = cph.probe(m, Cbase, ms)
+        assert np.abs(u2 - u).max() < 1e-7 * np.abs(u).max()
+    # the orthotropic-cell route on the reference's quarter cell gives the full cell's tensor (tests/test_orthotropic_cell.py)
+    mq = cmesh.Mesh(os.path.join(GOLD, "meshes", "2D_microstructure_orthocell.msh"), degree=2, embeddingDimension=2)
+    mf = cmesh.Mesh(os.path.join(GOLD, "meshes", "2D_microstructure.msh"), degree=2, embeddingDimension=2)
+    C2 = ctensors.ElasticityTensor2D(200.0, 0.35)
+    Chq, Chf = cph.homogenize(mq, C2, orthotropicCell=True).Ch.D, cph.homogenize(mf, C2).Ch.D
+    assert np.abs(Chq - Chf).max() < 1e-6 * np.abs(Chf).max()
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "cpu"
+    if what == "cpu":
+        check_tensors(); check_triplets(); check_mesh()
+    else:
+        check_spsd_system_gpu(); check_homogenization_gpu()
+    print("pybind checks (%s): ok" % what)
