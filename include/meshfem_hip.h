@@ -331,34 +331,6 @@ mfh_status mfh_set_operator(mfh_ctx* ctx, int32_t op);
 /* PoissonMesh::gradUAverage (Poisson.hh:121-131): per-element average gradient of a scalar nodal field */
 mfh_status mfh_average_gradient(mfh_ctx* ctx, const double* uNodes /* nNode */, double* grad /* nElem x dim */);
 
-/* ---------------------------------------------------------------- device-pointer building blocks
- * (multi-GPU driver: local kernels here, RCCL halo exchange / all-reduce in between)           */
-/* y[0:dim*nOwnedDoF] = K x ; x has dim*nColDoF entries (owned then halo). fixed-variable mask NOT applied */
-mfh_status mfh_dev_spmv(mfh_ctx* ctx, const double* x_dev, double* y_dev);
-/* z = M^-1 r on the owned rows (block-Jacobi of the assembled K, fixed variables decoupled)     */
-mfh_status mfh_dev_precond(mfh_ctx* ctx, const double* r_dev, double* z_dev);
-/* Two-level preconditioner with CALLER-supplied aggregates (row-partitioned contexts; the aggregates are global,
- * the caller reduces over ranks): begin() takes, for every local node (owned then halo), its aggregate id in
- * [0,nAgg) and relPos = (position - aggregate centre)/H (3 doubles per node, z = 0 in 2D), and writes this
- * rank's Galerkin contribution Z^T K_ownedRows Z (m x m row-major, m = nAgg * (dim==3 ? 6 : 3)) into Ac_dev.
- * The fixed-variable mask must cover halo nodes as well. After summing Ac_dev over ranks, finish() inverts it on
- * the device. restrict: rc[m] = Z_owned^T r (to be summed over ranks); apply: z = D^-1 r + Z_owned (A_c^-1 rc). */
-mfh_status mfh_tl_partitioned_begin(mfh_ctx* ctx, int32_t nAgg, const int32_t* aggOfNode, const double* relPos, double* Ac_dev);
-mfh_status mfh_tl_partitioned_finish(mfh_ctx* ctx, const double* Ac_dev);
-mfh_status mfh_dev_tl_restrict(mfh_ctx* ctx, const double* r_dev, double* rc_dev);
-mfh_status mfh_dev_tl_apply(mfh_ctx* ctx, const double* r_dev, const double* rc_dev, double* z_dev);
-/* fused vector updates of the distributed PCG over the owned rows; scalars are read from DEVICE memory (they are
- * results of all-reduces): x += (num/den) p, r -= (num/den) Ap ;  p = z + (num/den) p ;  out2 = {r.z, r.r} */
-mfh_status mfh_dev_pcg_update_xr(mfh_ctx* ctx, const double* num_dev, const double* den_dev, const double* p_dev, const double* Ap_dev,
-                                 double* x_dev, double* r_dev);
-mfh_status mfh_dev_pcg_direction(mfh_ctx* ctx, const double* num_dev, const double* den_dev, const double* z_dev, double* p_dev);
-mfh_status mfh_dev_dots(mfh_ctx* ctx, const double* r_dev, const double* z_dev, double* out2_dev);
-/* r[fixed] = 0 */
-mfh_status mfh_dev_mask_fixed(mfh_ctx* ctx, double* r_dev);
-/* copy the fixed-variable values into u (u[fixed] = value) */
-mfh_status mfh_dev_set_fixed_values(mfh_ctx* ctx, double* u_dev);
-mfh_status mfh_dev_sync(mfh_ctx* ctx);
-
 /* ---------------------------------------------------------------- multi-GPU solve (one process per GPU)
  * The reference is single-process (TBB, Parallelism.hh:31-43): these entry points have no counterpart to cite beyond the
  * serial path they parallelise (Simulator::solve, LinearElasticity.hh:479-487; SPSDSystem::solve, SparseMatrices.hh:2515-2606).
@@ -405,17 +377,9 @@ mfh_status  mfh_dist_apply_K(mfh_ctx* ctx, const double* uOwned, double* KuOwned
  * 2 device->device; hipStream NULL = the context's stream */
 mfh_status  mfh_dev_memcpy(mfh_ctx* ctx, void* dst, const void* src, int64_t bytes, int32_t kind, void* hipStream);
 
-/* ---------------------------------------------------------------- introspection / measurement */
+/* ---------------------------------------------------------------- introspection, options
+ * (kernel timers, operator statistics, test hooks and the device-pointer building blocks: include/meshfem_hip_extras.h) */
 mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
-/* average device time (ms, HIP events on the context stream) of `reps` back-to-back launches of
- * the numeric assembly kernel alone (geometry kernel excluded) -- used by bench.py's roofline   */
-mfh_status mfh_time_assembly_kernel(mfh_ctx* ctx, int32_t mode, int32_t reps, double* avg_ms);
-/* the same for one application of the operator the PCG uses (see "matrix_free") on internal scratch vectors */
-mfh_status mfh_time_spmv_kernel(mfh_ctx* ctx, int32_t reps, double* avg_ms);
-/* matrix-free operator in use? (see option "matrix_free"); for the cluster variant (mode 4): number of element blocks,
- * of (block, row) accumulators, of interface partial sums kept in HBM, and the largest block (LDS accumulators) */
-mfh_status mfh_matrix_free_info(mfh_ctx* ctx, int32_t* active, int32_t* mode, int64_t* nBlocks, int64_t* nBlockRows,
-                                int64_t* nInterface, int32_t* maxBlockRows);
 /* option knobs (string key, numeric value): "chunk_slots", "contrib_order" (0 rank-major, 1 element-major,
  * 2 slot-major), "check_every", "keep_host_symbolic", "agg_nodes" (target DoFs per aggregate of the two-level
  * preconditioner), "reembed" (1: every mfh_assemble re-runs the element-embedding kernel as well),
@@ -447,14 +411,13 @@ mfh_status mfh_matrix_free_info(mfh_ctx* ctx, int32_t* active, int32_t* mode, in
  *   ignoreMismatch / matchPermittingMismatch; 0 default: a mismatch is an error like PeriodicBoundaryMatcher::match),
  * "periodic_ignore_dims" (bit a set: dimension a is NOT periodic, PeriodicCondition's ignoreDims) -- both read by the next
  *   mfh_apply_periodic_conditions,
+ * "mg_steps_fine" / "mg_steps_coarse" (1 / 3: Chebyshev steps of MFH_PRECOND_MULTIGRID before and after the coarse correction on the quadratic /
+ *   linear level), "mg_ratio_fine" / "mg_ratio_coarse" (0.3 / 0.1: the smoothers act on [ratio lambda_max, lambda_max]), "mg_coarse_cycles"
+ *   (1: cycles of the linear level per application), "mg_eig_margin" (1.1: factor on the power-iteration estimates), "mg_agg_nodes",
+ * "asm_packed_codes" (1 default: the device copy of the gather lists is chunk-relative and packed, see k_assemble_gather),
+ * "asm_chunk_order" (0 default; 1: the assembly visits the row chunks in the order of the elements they gather from),
  * "symbolic_device", "topology_device", "tl_probe", "tl_host_inverse" (validation variants of setup phases) */
 mfh_status mfh_set_option(mfh_ctx* ctx, const char* key, double value);
-/* test hook: in-place inverse of a dense SPD matrix (row-major n x n) with the threaded blocked
- * Cholesky that inverts the two-level preconditioner's coarse operator; MFH_ERR_INVALID if not SPD */
-mfh_status mfh_debug_spd_inverse(int64_t n, double* A);
-/* the same with the device implementation (blocked 64x64 Cholesky inverse in HBM) */
-mfh_status mfh_debug_spd_inverse_device(mfh_ctx* ctx, int64_t n, double* A);
-
 #ifdef __cplusplus
 }
 #endif

@@ -15,6 +15,7 @@
 #include <memory>
 #include <cstdlib>
 #include "../../include/meshfem_hip.h"
+#include "../../include/meshfem_hip_extras.h"
 
 namespace mfh {
 
