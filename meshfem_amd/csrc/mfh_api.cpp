@@ -466,10 +466,8 @@ k::TLArgs tl_args(mfh_ctx *c) {
 
 // Coarse operator -> its inverse, all in HBM: symmetrise + regularise (modes without support are
 // decoupled), blocked Cholesky inverse. Ac: raw m x m row-major device matrix (left untouched).
-bool tl_invert_device(mfh_ctx *c, const double *Ac, bool noteOnFailure) {
-    auto &T = c->tl;
+bool dense_inverse_device(mfh_ctx *c, const double *Ac, int64_t mm, DBuf<double> &Ainv, int64_t &ldInv) {
     hipStream_t s = c->stream;
-    const int64_t mm = T.m;
     std::vector<double> diag((size_t)mm);
     // pitch of (m + 1) doubles walks the diagonal
     MFH_HIP(hipMemcpy2DAsync(diag.data(), sizeof(double), Ac, (size_t)(mm + 1) * sizeof(double), sizeof(double), (size_t)mm,
@@ -486,13 +484,19 @@ bool tl_invert_device(mfh_ctx *c, const double *Ac, bool noteOnFailure) {
     DBuf<double> Ap, X, Dtile;
     DBuf<int> flag;
     Ap.alloc((size_t)mp * mp); X.alloc((size_t)mp * mp); Dtile.alloc((size_t)(mp / 64) * 64 * 64); flag.alloc(1);
-    T.Ainv.alloc((size_t)mp * mp);
+    Ainv.alloc((size_t)mp * mp);
     k::launch_tl_prep(mm, mp, Ac, dDead.p, maxd, Ap.p, s);
-    if (!k::dense_spd_inverse_device(Ap.p, X.p, T.Ainv.p, Dtile.p, mp, flag.p, s)) {
+    if (!k::dense_spd_inverse_device(Ap.p, X.p, Ainv.p, Dtile.p, mp, flag.p, s)) return false;
+    ldInv = mp;
+    return true;
+}
+
+bool tl_invert_device(mfh_ctx *c, const double *Ac, bool noteOnFailure) {
+    auto &T = c->tl;
+    if (!dense_inverse_device(c, Ac, T.m, T.Ainv, T.ldInv)) {
         if (noteOnFailure) c->precondNote = "two-level preconditioner: coarse operator not positive definite; using block-Jacobi";
         return false;
     }
-    T.ldInv = mp;
     return true;
 }
 
@@ -1584,11 +1588,19 @@ mfh_status mfh_set_preconditioner(mfh_ctx *c, int32_t kind) {
 
 mfh_status mfh_precond_info(const mfh_ctx *c, int32_t *nAgg, int64_t *coarseDim, double *setup_ms, const char **note) {
     if (!c) return MFH_ERR_INVALID;
-    // with the multigrid hierarchy in use: the aggregates of its linear level, the setup time of the whole hierarchy
-    const mfh_ctx *t = (c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && c->mg.coarse) ? c->mg.coarse : c;
-    if (nAgg) *nAgg = t->tl.valid ? t->tl.nAgg : 0;
-    if (coarseDim) *coarseDim = t->tl.valid ? t->tl.m : 0;
-    if (setup_ms) *setup_ms = t != c ? c->mg.setup_ms : (c->tl.valid ? c->tl.setup_ms : 0.0);
+    // with the multigrid hierarchy in use: the aggregates below its linear level (the finest aggregate level), the dimension of the
+    // level that is inverted densely, the setup time of the whole hierarchy
+    if (c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && c->mg.coarse) {
+        const bool hier = !c->mg.agg.empty();
+        if (nAgg) *nAgg = hier ? (int32_t)c->mg.agg[0]->nAgg : (c->mg.coarse->tl.valid ? c->mg.coarse->tl.nAgg : 0);
+        if (coarseDim) *coarseDim = hier ? c->mg.denseM : (c->mg.coarse->tl.valid ? c->mg.coarse->tl.m : 0);
+        if (setup_ms) *setup_ms = c->mg.setup_ms;
+        if (note) *note = c->precondNote.c_str();
+        return MFH_OK;
+    }
+    if (nAgg) *nAgg = c->tl.valid ? c->tl.nAgg : 0;
+    if (coarseDim) *coarseDim = c->tl.valid ? c->tl.m : 0;
+    if (setup_ms) *setup_ms = c->tl.valid ? c->tl.setup_ms : 0.0;
     if (note) *note = c->precondNote.c_str();
     return MFH_OK;
 }
@@ -1889,6 +1901,11 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "mg_ratio_coarse") { require(value > 0 && value < 1, MFH_ERR_INVALID, "mg_ratio_coarse must lie in (0, 1)"); c->mgRatio1 = value; }
     else if (k2 == "mg_coarse_cycles") c->mgCoarseCycles = std::max(1, (int)value);
     else if (k2 == "mg_eig_margin") { require(value >= 1.0, MFH_ERR_INVALID, "mg_eig_margin must be >= 1"); c->mgEigMargin = value; c->mg.valid = false; }
+    else if (k2 == "mg_agg_target") { c->mgAggTarget = std::max(0, (int)value); c->mg.valid = false; }
+    else if (k2 == "mg_over_correction") { require(value > 0 && value < 4, MFH_ERR_INVALID, "mg_over_correction must lie in (0, 4)"); c->mgOverCorrection = value; }
+    else if (k2 == "mg_dense_max") { c->mgDenseMax = std::max(8, (int)value); c->mg.valid = false; }
+    else if (k2 == "mg_steps_agg") c->mgStepsAgg = std::max(1, (int)value);
+    else if (k2 == "mg_ratio_agg") { require(value > 0 && value < 1, MFH_ERR_INVALID, "mg_ratio_agg must lie in (0, 1)"); c->mgRatioAgg = value; }
     else if (k2 == "mg_agg_nodes") { c->mgAggNodes = std::max(0, (int)value); c->mg.valid = false; }
     else if (k2 == "asm_packed_codes") { c->asmPackedCodes = value != 0; invalidate_symbolic(c); }
     else if (k2 == "chunk_slots") { c->chunkSlots = (int)value; invalidate_symbolic(c); }

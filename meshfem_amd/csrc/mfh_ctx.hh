@@ -139,6 +139,15 @@ struct mfh_ctx {
     } tl;
     // p-multigrid preconditioner (MFH_PRECOND_MULTIGRID, mfh_multigrid.cpp): quadratic level -> linear level (a context of its own) ->
     // rigid-body modes of aggregates
+    struct AggLevel {                 // an aggregate level: rigid-body modes of lattice bins, operator in lattice-stencil storage
+        int64_t nAgg = 0;
+        double H = 0, lmax = 0;
+        DBuf<int32_t> nbr, parent, coord;     // neighbour table [nAgg][3^dim], parent aggregate on the next level, lattice coordinates [nAgg][3]
+        DBuf<double> A, Dinv, rel;            // stencil operator, inverse diagonal blocks, transfer data [nAgg][4] towards the parent
+        DBuf<double> x, b, r, d, t;
+        std::vector<int32_t> hCoord;
+        std::vector<double> hCentre;
+    };
     struct Multigrid {
         bool valid = false, rigidCoarse = false;
         mfh_ctx *coarse = nullptr;    // owned: the linear level
@@ -146,11 +155,21 @@ struct mfh_ctx {
         DBuf<int32_t> parA, parB, fineOf, resPtr, resIdx;
         DBuf<double> r0, d0, t0, b1, x1, r1, d1, t1;
         double lmax0 = 0, lmax1 = 0, setup_ms = 0;
+        // aggregate hierarchy below the linear level (empty: the linear level uses its context's ~1000-aggregate dense coarse space)
+        std::vector<std::unique_ptr<AggLevel>> agg;
+        DBuf<int32_t> aggOfDof2, aggPtr2, dofsByAgg2;      // linear-level DoFs <-> aggregates of agg[0]
+        DBuf<double> relPos2, denseInv;
+        int64_t denseM = 0, denseLd = 0;
     } mg;
-    int mgSteps0 = 1, mgSteps1 = 3;                  // options "mg_steps_fine" / "mg_steps_coarse": Chebyshev steps before and after the coarse correction
-    double mgRatio0 = 0.3, mgRatio1 = 0.1;           // options "mg_ratio_fine" / "mg_ratio_coarse": the smoothers act on [ratio lambda_max, lambda_max]
+    int mgSteps0 = 1, mgSteps1 = 1;                  // options "mg_steps_fine" / "mg_steps_coarse": Chebyshev steps before and after the coarse correction
+    double mgRatio0 = 0.3, mgRatio1 = 0.3;           // options "mg_ratio_fine" / "mg_ratio_coarse": the smoothers act on [ratio lambda_max, lambda_max]
     int mgCoarseCycles = 1;                          // option "mg_coarse_cycles": cycles of the linear level per application
     double mgEigMargin = 1.1;                        // option "mg_eig_margin": factor on the power-iteration estimates of lambda_max
+    int mgAggTarget = 32, mgDenseMax = 1200;         // options "mg_agg_target" (DoFs of the linear level per finest aggregate; 0: no aggregate hierarchy),
+                                                     // "mg_dense_max" (aggregates of the level that is inverted densely)
+    double mgOverCorrection = 1.5;                   // option "mg_over_correction": factor on the corrections prolonged from aggregate levels (piecewise-rigid
+                                                     // coarse functions under-estimate smooth corrections; the cycle stays symmetric)
+    int mgStepsAgg = 2; double mgRatioAgg = 0.2;     // options "mg_steps_agg" / "mg_ratio_agg": Chebyshev smoother of the aggregate levels
     int mgAggNodes = 0;                              // option "mg_agg_nodes": target DoFs per aggregate of the linear level's coarse space (0 = auto)
     // Chronopoulos-Gear PCG (mfh_solver.cpp): NR interleaved vectors
     DBuf<double> cgU, cgW, cgP, cgS, cgX, cgR, cgF, cgCtl, tlRcN, tlYcN;

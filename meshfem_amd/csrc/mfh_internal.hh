@@ -431,8 +431,20 @@ void launch_tl_scatter(int nAgg, int nModes, int nColor, const int32_t *nbrOfCol
                        hipStream_t s);
 void launch_tl_rap(const TLArgs &t, int64_t nRows, const int32_t *rowPtr, const int32_t *colIdx, const double *vals, double *Ac,
                    hipStream_t s);
+void launch_st_spmv(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const double *x, double *y, const double *scal, int it, const double *stop, hipStream_t s);
+void launch_st_dinv(int dim, int64_t nAgg, const double *A, double *Dinv, hipStream_t s);
+void launch_st_cheb(int dim, int64_t nAgg, const double *Dinv, const double *rin, const double *t, double *rout, double *d, double *x, double a, double b,
+                    bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s);
+void launch_st_rap(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const int32_t *parent, const double *rel, const int32_t *coordC, double *Ac, hipStream_t s);
+void launch_st_restrict(int dim, int64_t nAgg, const int32_t *parent, const double *rel, const double *r, const double *t, double *rc, const double *scal, int it,
+                        const double *stop, hipStream_t s);
+void launch_st_prolong_add(int dim, int64_t nAgg, const int32_t *parent, const double *rel, const double *xc, double *x, double alpha, const double *scal, int it,
+                           const double *stop, hipStream_t s);
+void launch_st_to_dense(int dim, int64_t nAgg, const int32_t *nbr, const double *A, double *Ad, hipStream_t s);
+void launch_mg_zero(int64_t n, double *v, const double *scal, int it, const double *stop, hipStream_t s);
 void launch_tl_rap_agg(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const int32_t *binCoord, const int32_t *rowPtr,
-                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly = false, int64_t nOwnedRows = 0);
+                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly = false, int64_t nOwnedRows = 0,
+                       double *stencil = nullptr, int *farCount = nullptr);
 bool dense_spd_inverse_device(double *A, double *X, double *Ainv, double *Dinv, int64_t mp, int *notSpdDev, hipStream_t s);
 void launch_tl_gemv(int64_t m, int64_t ld, const double *A, const double *x, double *y, hipStream_t s);
 void launch_tl_prep(int64_t m, int64_t mp, const double *Ac, const uint8_t *dead, double maxd, double *Ap, hipStream_t s);
@@ -470,7 +482,7 @@ void launch_mg_restrict(int dim, int64_t nCoarse, const int32_t *fineOf, const i
                         const uint8_t *coarseMask, double *rc, const double *scal, int it, const double *stop, hipStream_t s);
 void launch_mg_prolong_add(int dim, int64_t nFine, const int32_t *parA, const int32_t *parB, const double *xc, const uint8_t *fineMask, double *x,
                            const double *scal, int it, const double *stop, hipStream_t s);
-void launch_mg_tl_prolong_add(const TLArgs &t, const double *yc, double *x, const double *scal, int it, const double *stop, hipStream_t s);
+void launch_mg_tl_prolong_add(const TLArgs &t, const double *yc, double *x, double alpha, const double *scal, int it, const double *stop, hipStream_t s);
 void launch_fill_hash(int64_t n, double *v, hipStream_t s);
 void launch_mg_diff(int64_t n, const double *a, const double *b, double *out, const double *scal, int it, const double *stop, hipStream_t s);
 void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, double *scalOut, int it, const double *scal, const double *stop, hipStream_t s);

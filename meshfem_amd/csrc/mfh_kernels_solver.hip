@@ -254,7 +254,11 @@ template <int DIM>
 __global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__restrict__ aggPtr, const int32_t *__restrict__ dofsByAgg,
                                                      const int32_t *__restrict__ binCoord /* nAgg x 3, may be null */,
                                                      const int32_t *__restrict__ rowPtr, const int32_t *__restrict__ colIdx,
-                                                     const double *__restrict__ vals, double *__restrict__ Ac, int upperOnly, int64_t nOwnedRows) {
+                                                     const double *__restrict__ vals, double *__restrict__ Ac, int upperOnly, int64_t nOwnedRows,
+                                                     double *__restrict__ stencil, int *__restrict__ farCount) {
+    // stencil != null (multigrid hierarchy, mfh_multigrid.cpp): the rows (a, .) go to the lattice-stencil storage
+    // stencil[(a NSLOT + slot) NM^2 + k NM + l] (slot = the neighbour's lattice offset, centre = the aggregate itself) instead of the
+    // dense matrix; a block reaching a non-adjacent aggregate cannot be stored there and is counted in farCount (the caller coarsens less).
     // upperOnly: only the blocks (r, c >= r) are stored. A stored off-diagonal block inside the aggregate also contributes its
     // transpose to the diagonal 6 x 6 block; between two aggregates this kernel writes the partial sums U[a][b] over the stored
     // blocks and k_tl_mirror_upper completes them (Ac[a][b] = U[a][b] + U[b][a]^T). On a row-partitioned context the blocks
@@ -332,6 +336,8 @@ __global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__r
                 nbrAgg[slot] = b;     // every writer stores the same value
 #pragma unroll
                 for (int q = 0; q < NM * NM; ++q) unsafeAtomicAdd(&nbr[slot * NM * NM + q], T[q]);
+            } else if (stencil) {
+                atomicAdd(farCount, 1);
             } else {
 #pragma unroll
                 for (int k = 0; k < NM; ++k)
@@ -346,6 +352,16 @@ __global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__r
 #pragma unroll
         for (int q = 0; q < NM * NM; ++q) diagRed[wave * NM * NM + q] = acc[q];
     __syncthreads();
+    if (stencil) {
+        constexpr int CENTRE = NSLOT / 2;
+        for (int q = threadIdx.x; q < NSLOT * NM * NM; q += blockDim.x) {
+            const int slot = q / (NM * NM), e = q - slot * NM * NM;
+            double v = nbr[q];
+            if (slot == CENTRE) { v = 0; for (int w = 0; w < nWaves; ++w) v += diagRed[w * NM * NM + e]; }
+            stencil[(int64_t)a * NSLOT * NM * NM + q] = v;
+        }
+        return;
+    }
     // rows (a, .) of Ac belong to this workgroup: plain read-modify-write (the fallback atomics above may have touched them too)
     for (int q = threadIdx.x; q < NM * NM; q += blockDim.x) {
         double v = 0;
@@ -1219,32 +1235,49 @@ __global__ void __launch_bounds__(256) k_mg_cheb(int64_t nRows, const double *__
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
             const double dv = (first ? 0.0 : a * d[n * DIM + c]) + b * zv[c];
-            d[n * DIM + c] = dv;
+            if (d) d[n * DIM + c] = dv;                    // (a single-step sweep needs no direction vector)
             x[n * DIM + c] = assign ? dv : x[n * DIM + c] + dv;
         }
     }
 }
 
 // restriction R = P^T of the residual r - t (t may be null): coarse DoF q gets its own fine DoF plus half of every
-// edge-node DoF it is an end of
+// edge-node DoF it is an end of. A CSR row of ~13 scattered entries per coarse DoF: FOUR lanes share a row (every fourth entry
+// each, independent loads in flight) and add up with two shuffles -- one lane per row walked its 13 dependent-latency loads alone
+// and took 0.66 ms at config 3, more than an application of the quadratic operator.
 template <int DIM>
 __global__ void __launch_bounds__(256) k_mg_restrict(int64_t nCoarse, const int32_t *__restrict__ fineOf, const int32_t *__restrict__ resPtr,
                                                      const int32_t *__restrict__ resIdx, const double *__restrict__ r,
                                                      const double *__restrict__ t, const uint8_t *__restrict__ coarseMask,
                                                      double *__restrict__ rc, MgGate g) {
     if (mg_closed(g)) return;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nCoarse; q += (int64_t)gridDim.x * 256) {
+    const int sub = threadIdx.x & 3;
+    const int64_t nq = (nCoarse + 63) / 64 * 64;                 // whole waves take part in the shuffles
+    for (int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; q < nq; q += ((int64_t)gridDim.x * 256) >> 2) {
         double acc[DIM];
-        const int64_t f = fineOf[q];
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) acc[c] = r[f * DIM + c] - (t ? t[f * DIM + c] : 0.0);
-        for (int k = resPtr[q]; k < resPtr[q + 1]; ++k) {
-            const int64_t e = resIdx[k];
+        for (int c = 0; c < DIM; ++c) acc[c] = 0.0;
+        if (q < nCoarse) {
+            const int k0 = resPtr[q], k1 = resPtr[q + 1];
+            for (int k = k0 + sub; k < k1; k += 4) {
+                const int64_t e = resIdx[k];
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) acc[c] += 0.5 * (r[e * DIM + c] - (t ? t[e * DIM + c] : 0.0));
+                for (int c = 0; c < DIM; ++c) acc[c] += 0.5 * (r[e * DIM + c] - (t ? t[e * DIM + c] : 0.0));
+            }
+            if (sub == 0) {
+                const int64_t f = fineOf[q];
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) acc[c] += r[f * DIM + c] - (t ? t[f * DIM + c] : 0.0);
+            }
         }
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) rc[q * DIM + c] = (coarseMask && coarseMask[q * DIM + c]) ? 0.0 : acc[c];
+        for (int c = 0; c < DIM; ++c) {
+            acc[c] += __shfl_xor(acc[c], 1, 64);
+            acc[c] += __shfl_xor(acc[c], 2, 64);
+        }
+        if (q < nCoarse && sub == 0)
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) rc[q * DIM + c] = (coarseMask && coarseMask[q * DIM + c]) ? 0.0 : acc[c];
     }
 }
 
@@ -1267,7 +1300,7 @@ __global__ void __launch_bounds__(256) k_mg_prolong_add(int64_t nFine, const int
 
 // x += Z yc on the free variables (prolongation of the rigid-body coarse correction, linear level)
 template <int DIM>
-__global__ void __launch_bounds__(256) k_mg_tl_prolong_add(TLArgs t, const double *__restrict__ yc, double *__restrict__ x, MgGate g) {
+__global__ void __launch_bounds__(256) k_mg_tl_prolong_add(TLArgs t, const double *__restrict__ yc, double *__restrict__ x, double alpha, MgGate g) {
     if (mg_closed(g)) return;
     for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < t.nDoF; n += (int64_t)gridDim.x * 256) {
         const int a = t.aggOfDof[n];
@@ -1284,8 +1317,231 @@ __global__ void __launch_bounds__(256) k_mg_tl_prolong_add(TLArgs t, const doubl
         }
 #pragma unroll
         for (int c = 0; c < DIM; ++c)
-            if (!(t.fixedMask && t.fixedMask[n * DIM + c])) x[n * DIM + c] += zv[c];
+            if (!(t.fixedMask && t.fixedMask[n * DIM + c])) x[n * DIM + c] += alpha * zv[c];
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Aggregate levels of the multigrid hierarchy: NM rigid-body modes per aggregate (6 in 3D, 3 in 2D), operators in LATTICE-STENCIL
+// storage -- aggregates are the non-empty bins of a uniform lattice, an element spans at most adjacent bins, so row aggregate a
+// couples to its NS = 3^dim lattice neighbours only: A[(a NS + slot) NM^2 + k NM + l], nbr[a NS + slot] = neighbour's id or -1.
+// Coarser levels merge 2^dim bins; a parent mode (t, w) seen from a child reads  t_c = t + w x rho,  w_c = sc w  with
+// rho = (c_child - c_parent) / H_parent and sc = H_child / H_parent (rotations are scaled by 1 / H like tl_mode).
+// ------------------------------------------------------------------------------------------------
+template <int DIM> struct StDims { static constexpr int NM = DIM == 3 ? 6 : 3, NS = DIM == 3 ? 27 : 9; };
+
+// child = T parent (NM vectors): rel = {rho_x, rho_y, rho_z, sc}
+template <int DIM> DEV void st_transfer(const double *rel, const double *par, double *child) {
+    if (DIM == 3) {
+        const double rx = rel[0], ry = rel[1], rz = rel[2], sc = rel[3];
+        const double wx = par[3], wy = par[4], wz = par[5];
+        child[0] = par[0] + (wy * rz - wz * ry);
+        child[1] = par[1] + (wz * rx - wx * rz);
+        child[2] = par[2] + (wx * ry - wy * rx);
+        child[3] = sc * wx; child[4] = sc * wy; child[5] = sc * wz;
+    } else {
+        const double rx = rel[0], ry = rel[1], sc = rel[3], w = par[2];      // u = t + w (-r_y, r_x)
+        child[0] = par[0] - w * ry;
+        child[1] = par[1] + w * rx;
+        child[2] = sc * w;
+    }
+}
+// parent += T^T child
+template <int DIM> DEV void st_transfer_T(const double *rel, const double *ch, double *par) {
+    if (DIM == 3) {
+        const double rx = rel[0], ry = rel[1], rz = rel[2], sc = rel[3];
+        par[0] += ch[0]; par[1] += ch[1]; par[2] += ch[2];
+        // (w x rho) . f = w . (rho x f)
+        par[3] += sc * ch[3] + (ry * ch[2] - rz * ch[1]);
+        par[4] += sc * ch[4] + (rz * ch[0] - rx * ch[2]);
+        par[5] += sc * ch[5] + (rx * ch[1] - ry * ch[0]);
+    } else {
+        const double rx = rel[0], ry = rel[1], sc = rel[3];
+        par[0] += ch[0]; par[1] += ch[1];
+        par[2] += sc * ch[2] + (rx * ch[1] - ry * ch[0]);
+    }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256) k_st_spmv(int64_t nAgg, const int32_t *__restrict__ nbr, const double *__restrict__ A, const double *__restrict__ x,
+                                                 double *__restrict__ y, MgGate g) {
+    constexpr int NM = StDims<DIM>::NM, NS = StDims<DIM>::NS;
+    if (mg_closed(g)) return;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nAgg * NM; q += (int64_t)gridDim.x * 256) {
+        const int64_t a = q / NM;
+        const int k = (int)(q - a * NM);
+        double acc = 0;
+        for (int sl = 0; sl < NS; ++sl) {
+            const int b = nbr[a * NS + sl];
+            if (b < 0) continue;
+            const double *row = A + ((a * NS + sl) * NM + k) * NM;
+#pragma unroll
+            for (int l = 0; l < NM; ++l) acc += row[l] * x[(int64_t)b * NM + l];
+        }
+        y[q] = acc;
+    }
+}
+
+// inverse of the diagonal NM x NM blocks; a mode without stiffness of its own (empty direction, all its DoFs fixed, a one-node
+// aggregate's rotations) is dropped: its row and column of the inverse are zero, the level leaves it to the others
+template <int DIM>
+__global__ void __launch_bounds__(256) k_st_dinv(int64_t nAgg, const double *__restrict__ A, double *__restrict__ Dinv) {
+    constexpr int NM = StDims<DIM>::NM, NS = StDims<DIM>::NS;
+    for (int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x; a < nAgg; a += (int64_t)gridDim.x * 256) {
+        double M[NM][2 * NM];
+        const double *D = A + (a * NS + NS / 2) * NM * NM;
+        double dmax = 0;
+#pragma unroll
+        for (int i = 0; i < NM; ++i) dmax = fmax(dmax, D[i * NM + i]);
+        bool dead[NM];
+#pragma unroll
+        for (int i = 0; i < NM; ++i) dead[i] = !(D[i * NM + i] > 1e-10 * dmax);
+#pragma unroll
+        for (int i = 0; i < NM; ++i)
+#pragma unroll
+            for (int j = 0; j < NM; ++j) {
+                M[i][j] = (dead[i] || dead[j]) ? (i == j ? 1.0 : 0.0) : 0.5 * (D[i * NM + j] + D[j * NM + i]);
+                M[i][NM + j] = i == j ? 1.0 : 0.0;
+            }
+        // Gauss-Jordan without pivoting (SPD); a pivot that collapses marks a dependent mode, dropped like a dead one
+        for (int c = 0; c < NM; ++c) {
+            double p = M[c][c];
+            if (!(p > 1e-12 * dmax) && !dead[c]) {
+                dead[c] = true;
+                for (int j = 0; j < 2 * NM; ++j) M[c][j] = 0.0;
+                for (int i = 0; i < NM; ++i) M[i][c] = 0.0;
+                M[c][c] = 1.0; M[c][NM + c] = 1.0;
+                p = 1.0;
+            }
+            const double inv = 1.0 / p;
+            for (int j = 0; j < 2 * NM; ++j) M[c][j] *= inv;
+            for (int i = 0; i < NM; ++i) {
+                if (i == c) continue;
+                const double f = M[i][c];
+                if (f != 0.0) for (int j = 0; j < 2 * NM; ++j) M[i][j] -= f * M[c][j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NM; ++i)
+#pragma unroll
+            for (int j = 0; j < NM; ++j) Dinv[a * NM * NM + i * NM + j] = (dead[i] || dead[j]) ? 0.0 : M[i][NM + j];
+    }
+}
+
+// Chebyshev step on an aggregate level (see k_mg_cheb): block size NM, full inverse blocks
+template <int DIM>
+__global__ void __launch_bounds__(256) k_st_cheb(int64_t nAgg, const double *__restrict__ Dinv, const double *__restrict__ rin, const double *__restrict__ t,
+                                                 double *__restrict__ rout, double *__restrict__ d, double *__restrict__ x, double ca, double cb, int first,
+                                                 int assign, MgGate g) {
+    constexpr int NM = StDims<DIM>::NM;
+    if (mg_closed(g)) return;
+    for (int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x; a < nAgg; a += (int64_t)gridDim.x * 256) {
+        double rv[NM];
+#pragma unroll
+        for (int k = 0; k < NM; ++k) rv[k] = rin[a * NM + k] - (t ? t[a * NM + k] : 0.0);
+        if (rout)
+#pragma unroll
+            for (int k = 0; k < NM; ++k) rout[a * NM + k] = rv[k];
+#pragma unroll
+        for (int k = 0; k < NM; ++k) {
+            double z = 0;
+#pragma unroll
+            for (int l = 0; l < NM; ++l) z += Dinv[a * NM * NM + k * NM + l] * rv[l];
+            const double dv = (first ? 0.0 : ca * d[a * NM + k]) + cb * z;
+            if (d) d[a * NM + k] = dv;
+            x[a * NM + k] = assign ? dv : x[a * NM + k] + dv;
+        }
+    }
+}
+
+// Galerkin product between two aggregate levels: Ac[parent(a)][offset] += T_a^T A[a][slot] T_b
+template <int DIM>
+__global__ void __launch_bounds__(256) k_st_rap(int64_t nAgg, const int32_t *__restrict__ nbr, const double *__restrict__ A, const int32_t *__restrict__ parent,
+                                                const double *__restrict__ rel, const int32_t *__restrict__ coordC, double *__restrict__ Ac) {
+    constexpr int NM = StDims<DIM>::NM, NS = StDims<DIM>::NS;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nAgg * NS; q += (int64_t)gridDim.x * 256) {
+        const int64_t a = q / NS;
+        const int b = nbr[q];
+        if (b < 0) continue;
+        const int pa = parent[a], pb = parent[b];
+        const int dx = coordC[pb * 3] - coordC[pa * 3], dy = coordC[pb * 3 + 1] - coordC[pa * 3 + 1], dz = coordC[pb * 3 + 2] - coordC[pa * 3 + 2];
+        const int cs = (dx + 1) + 3 * (dy + 1) + (DIM == 3 ? 9 * (dz + 1) : 0);
+        const double *B = A + q * NM * NM;
+        // W = B T_b (columns: parent modes of b), then C = T_a^T W
+        double W[NM][NM];
+#pragma unroll
+        for (int l = 0; l < NM; ++l) {
+            double e[NM], tc[NM];
+#pragma unroll
+            for (int m = 0; m < NM; ++m) e[m] = m == l ? 1.0 : 0.0;
+            st_transfer<DIM>(rel + (int64_t)b * 4, e, tc);
+#pragma unroll
+            for (int k = 0; k < NM; ++k) {
+                double v = 0;
+#pragma unroll
+                for (int m = 0; m < NM; ++m) v += B[k * NM + m] * tc[m];
+                W[k][l] = v;
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NM; ++l) {
+            double col[NM], out[NM];
+#pragma unroll
+            for (int k = 0; k < NM; ++k) { col[k] = W[k][l]; out[k] = 0.0; }
+            st_transfer_T<DIM>(rel + a * 4, col, out);
+#pragma unroll
+            for (int k = 0; k < NM; ++k) unsafeAtomicAdd(&Ac[(((int64_t)pa * NS + cs) * NM + k) * NM + l], out[k]);
+        }
+    }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256) k_st_restrict(int64_t nAgg, const int32_t *__restrict__ parent, const double *__restrict__ rel, const double *__restrict__ r,
+                                                     const double *__restrict__ t, double *__restrict__ rc, MgGate g) {
+    constexpr int NM = StDims<DIM>::NM;
+    if (mg_closed(g)) return;
+    for (int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x; a < nAgg; a += (int64_t)gridDim.x * 256) {
+        double ch[NM], out[NM];
+#pragma unroll
+        for (int k = 0; k < NM; ++k) { ch[k] = r[a * NM + k] - (t ? t[a * NM + k] : 0.0); out[k] = 0.0; }
+        st_transfer_T<DIM>(rel + a * 4, ch, out);
+#pragma unroll
+        for (int k = 0; k < NM; ++k) unsafeAtomicAdd(&rc[(int64_t)parent[a] * NM + k], out[k]);
+    }
+}
+
+template <int DIM>
+__global__ void __launch_bounds__(256) k_st_prolong_add(int64_t nAgg, const int32_t *__restrict__ parent, const double *__restrict__ rel, const double *__restrict__ xc,
+                                                        double *__restrict__ x, double alpha, MgGate g) {
+    constexpr int NM = StDims<DIM>::NM;
+    if (mg_closed(g)) return;
+    for (int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x; a < nAgg; a += (int64_t)gridDim.x * 256) {
+        double ch[NM];
+        st_transfer<DIM>(rel + a * 4, xc + (int64_t)parent[a] * NM, ch);
+#pragma unroll
+        for (int k = 0; k < NM; ++k) x[a * NM + k] += alpha * ch[k];
+    }
+}
+
+// stencil -> dense row-major m x m (the coarsest level is inverted densely)
+template <int DIM>
+__global__ void __launch_bounds__(256) k_st_to_dense(int64_t nAgg, const int32_t *__restrict__ nbr, const double *__restrict__ A, double *__restrict__ Ad) {
+    constexpr int NM = StDims<DIM>::NM, NS = StDims<DIM>::NS;
+    const int64_t m = nAgg * NM;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nAgg * NS * NM * NM; q += (int64_t)gridDim.x * 256) {
+        const int64_t as = q / (NM * NM);
+        const int e = (int)(q - as * NM * NM);
+        const int b = nbr[as];
+        if (b < 0) continue;
+        const int64_t a = as / NS;
+        Ad[(a * NM + e / NM) * m + (int64_t)b * NM + e % NM] = A[q];
+    }
+}
+
+// gated zero fill
+__global__ void __launch_bounds__(256) k_mg_zero(int64_t n, double *__restrict__ v, MgGate g) {
+    if (mg_closed(g)) return;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) v[k] = 0.0;
 }
 
 // pseudo-random values in (-1/2, 1/2) (start vector of the power iteration)
@@ -1406,9 +1662,11 @@ __global__ void __launch_bounds__(256) k_tl_mirror_upper(double *__restrict__ Ac
 }
 
 void launch_tl_rap_agg(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const int32_t *binCoord, const int32_t *rowPtr,
-                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly, int64_t nOwnedRows) {
-    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap_agg<3>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows);
-    else hipLaunchKernelGGL(k_tl_rap_agg<2>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows);
+                       const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly, int64_t nOwnedRows, double *stencil,
+                       int *farCount) {
+    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap_agg<3>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows, stencil, farCount);
+    else hipLaunchKernelGGL(k_tl_rap_agg<2>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows, stencil, farCount);
+    if (stencil) { CHECK_LAUNCH(); return; }
     if (upperOnly) {
         const int64_t m = (int64_t)t.nAgg * (t.dim == 3 ? 6 : 3);
         hipLaunchKernelGGL(k_tl_mirror_upper, dim3(grid_for(m * m)), dim3(256), 0, s, Ac, m, t.dim == 3 ? 6 : 3);
@@ -1600,8 +1858,8 @@ void launch_mg_cheb(int dim, int64_t nRows, const double *dinv, const double *ri
 void launch_mg_restrict(int dim, int64_t nCoarse, const int32_t *fineOf, const int32_t *resPtr, const int32_t *resIdx, const double *r, const double *t,
                         const uint8_t *coarseMask, double *rc, const double *scal, int it, const double *stop, hipStream_t s) {
     const MgGate g = mk_gate(scal, it, stop);
-    if (dim == 3) hipLaunchKernelGGL(k_mg_restrict<3>, dim3(grid_for(nCoarse, g_vecGridCap)), dim3(256), 0, s, nCoarse, fineOf, resPtr, resIdx, r, t, coarseMask, rc, g);
-    else hipLaunchKernelGGL(k_mg_restrict<2>, dim3(grid_for(nCoarse, g_vecGridCap)), dim3(256), 0, s, nCoarse, fineOf, resPtr, resIdx, r, t, coarseMask, rc, g);
+    if (dim == 3) hipLaunchKernelGGL(k_mg_restrict<3>, dim3(grid_for(nCoarse * 4, 4 * g_vecGridCap)), dim3(256), 0, s, nCoarse, fineOf, resPtr, resIdx, r, t, coarseMask, rc, g);
+    else hipLaunchKernelGGL(k_mg_restrict<2>, dim3(grid_for(nCoarse * 4, 4 * g_vecGridCap)), dim3(256), 0, s, nCoarse, fineOf, resPtr, resIdx, r, t, coarseMask, rc, g);
     CHECK_LAUNCH();
 }
 void launch_mg_prolong_add(int dim, int64_t nFine, const int32_t *parA, const int32_t *parB, const double *xc, const uint8_t *fineMask, double *x,
@@ -1611,10 +1869,10 @@ void launch_mg_prolong_add(int dim, int64_t nFine, const int32_t *parA, const in
     else hipLaunchKernelGGL(k_mg_prolong_add<2>, dim3(grid_for(nFine, g_vecGridCap)), dim3(256), 0, s, nFine, parA, parB, xc, fineMask, x, g);
     CHECK_LAUNCH();
 }
-void launch_mg_tl_prolong_add(const TLArgs &t, const double *yc, double *x, const double *scal, int it, const double *stop, hipStream_t s) {
+void launch_mg_tl_prolong_add(const TLArgs &t, const double *yc, double *x, double alpha, const double *scal, int it, const double *stop, hipStream_t s) {
     const MgGate g = mk_gate(scal, it, stop);
-    if (t.dim == 3) hipLaunchKernelGGL(k_mg_tl_prolong_add<3>, dim3(grid_for(t.nDoF, g_vecGridCap)), dim3(256), 0, s, t, yc, x, g);
-    else hipLaunchKernelGGL(k_mg_tl_prolong_add<2>, dim3(grid_for(t.nDoF, g_vecGridCap)), dim3(256), 0, s, t, yc, x, g);
+    if (t.dim == 3) hipLaunchKernelGGL(k_mg_tl_prolong_add<3>, dim3(grid_for(t.nDoF, g_vecGridCap)), dim3(256), 0, s, t, yc, x, alpha, g);
+    else hipLaunchKernelGGL(k_mg_tl_prolong_add<2>, dim3(grid_for(t.nDoF, g_vecGridCap)), dim3(256), 0, s, t, yc, x, alpha, g);
     CHECK_LAUNCH();
 }
 void launch_fill_hash(int64_t n, double *v, hipStream_t s) {
@@ -1627,6 +1885,42 @@ void launch_mg_diff(int64_t n, const double *a, const double *b, double *out, co
 }
 void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, double *scalOut, int it, const double *scal, const double *stop, hipStream_t s) {
     hipLaunchKernelGGL(k_mg_rz, dim3(grid_for(n)), dim3(256), 0, s, n, r, z, mask, scalOut, mk_gate(scal, it, stop));
+    CHECK_LAUNCH();
+}
+
+
+// ---- aggregate (lattice-stencil) levels of the multigrid hierarchy
+#define ST_DISPATCH(dim, K, grid, ...)                                                      \
+    do {                                                                                    \
+        if ((dim) == 3) hipLaunchKernelGGL(K<3>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL(K<2>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);            \
+        CHECK_LAUNCH();                                                                     \
+    } while (0)
+void launch_st_spmv(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const double *x, double *y, const double *scal, int it, const double *stop, hipStream_t s) {
+    ST_DISPATCH(dim, k_st_spmv, grid_for(nAgg * 6), nAgg, nbr, A, x, y, mk_gate(scal, it, stop));
+}
+void launch_st_dinv(int dim, int64_t nAgg, const double *A, double *Dinv, hipStream_t s) { ST_DISPATCH(dim, k_st_dinv, grid_for(nAgg), nAgg, A, Dinv); }
+void launch_st_cheb(int dim, int64_t nAgg, const double *Dinv, const double *rin, const double *t, double *rout, double *d, double *x, double a, double b,
+                    bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s) {
+    ST_DISPATCH(dim, k_st_cheb, grid_for(nAgg), nAgg, Dinv, rin, t, rout, d, x, a, b, first ? 1 : 0, assign ? 1 : 0, mk_gate(scal, it, stop));
+}
+void launch_st_rap(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const int32_t *parent, const double *rel, const int32_t *coordC, double *Ac, hipStream_t s) {
+    ST_DISPATCH(dim, k_st_rap, grid_for(nAgg * 27), nAgg, nbr, A, parent, rel, coordC, Ac);
+}
+void launch_st_restrict(int dim, int64_t nAgg, const int32_t *parent, const double *rel, const double *r, const double *t, double *rc, const double *scal, int it,
+                        const double *stop, hipStream_t s) {
+    ST_DISPATCH(dim, k_st_restrict, grid_for(nAgg), nAgg, parent, rel, r, t, rc, mk_gate(scal, it, stop));
+}
+void launch_st_prolong_add(int dim, int64_t nAgg, const int32_t *parent, const double *rel, const double *xc, double *x, double alpha, const double *scal, int it,
+                           const double *stop, hipStream_t s) {
+    ST_DISPATCH(dim, k_st_prolong_add, grid_for(nAgg), nAgg, parent, rel, xc, x, alpha, mk_gate(scal, it, stop));
+}
+void launch_st_to_dense(int dim, int64_t nAgg, const int32_t *nbr, const double *A, double *Ad, hipStream_t s) {
+    ST_DISPATCH(dim, k_st_to_dense, grid_for(nAgg * 27 * 36), nAgg, nbr, A, Ad);
+}
+#undef ST_DISPATCH
+void launch_mg_zero(int64_t n, double *v, const double *scal, int it, const double *stop, hipStream_t s) {
+    hipLaunchKernelGGL(k_mg_zero, dim3(grid_for(n, g_vecGridCap)), dim3(256), 0, s, n, v, mk_gate(scal, it, stop));
     CHECK_LAUNCH();
 }
 

@@ -3,7 +3,9 @@
 //
 //   level 0  quadratic mesh            operator: matrix-free cluster kernel (k_mf_cluster)      smoother: Chebyshev on D0^-1 K
 //   level 1  linear mesh, same vertices operator: assembled block-CSR K1 (k_spmv)                smoother: Chebyshev on D1^-1 K1
-//   level 2  rigid-body modes of ~1000 geometric aggregates: dense inverse (the coarse level of the two-level preconditioner)
+//   level 2+ rigid-body modes of geometric aggregates (the bins of a uniform lattice, ~32 vertices each, merged 2^dim at a time),
+//            operators in lattice-stencil storage (3^dim blocks of 6 x 6 per aggregate), Chebyshev on the block-Jacobi-scaled operator
+//   last     the aggregate level with <= ~1200 aggregates is inverted densely (the machinery of the two-level preconditioner)
 //
 // P1 is a subspace of P2 (phi^P1_v = phi^P2_v + 1/2 sum_{edges e at v} phi^P2_e), so the Galerkin operator P^T K2 P IS the linear
 // stiffness matrix of the same elements: level 1 is a second context of this library (`coarse`) that assembles K1 with the same
@@ -18,70 +20,253 @@ void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double 
 void ensure_fixed_uploaded(mfh_ctx *c);
 double device_dot(mfh_ctx *c, int64_t n, const double *a, const double *b);
 void upload_mesh(mfh_ctx *c);
+bool dense_inverse_device(mfh_ctx *c, const double *Ac, int64_t mm, DBuf<double> &Ainv, int64_t &ldInv);
+const int32_t *device_dof_map(mfh_ctx *c);
 
 namespace {
 
-// largest eigenvalue of D^-1 K on the free variables: power iteration from a pseudo-random start, all on the device. The iterate is
-// not normalised (lambda_max <= dim + 1 for a block-Jacobi-scaled stiffness matrix: 16 steps grow it by < 1e10) and only the last
-// two norms are read back: one host synchronisation.
-double estimate_lambda_max(mfh_ctx *c, DBuf<double> &v, DBuf<double> &w, DBuf<double> &t) {
+// What a Chebyshev sweep needs of a level: y = A x, and the fused step  r' = rin - t; d = a d + b D^-1 r'; x (+)= d
+struct LevelOps {
+    int64_t n = 0;                                                        // scalar unknowns
+    std::function<void(const double *, double *)> apply;
+    std::function<void(const double *rin, const double *t, double *rout, double *d, double *x, double a, double b, bool first, bool assign)> step;
+    std::function<void(double *)> mask;                                   // zero the fixed variables (may be empty)
+    double lmax = 0, ratio = 0.3;
+    int steps = 1;
+};
+
+// the two nodal levels: the context's operator (matrix-free or assembled) and its block-Jacobi inverse
+LevelOps nodal_ops(mfh_ctx *c, const double *scal, int it, const double *stop) {
+    LevelOps L;
     const int d = c->bs();
-    const int64_t nRows = c->sym.nRows, n = nRows * d;
-    hipStream_t s = c->stream;
-    k::launch_fill_hash(n, v.p, s);
+    const int64_t nRows = c->sym.nRows;
     const bool masked = !c->fixedVars.empty();
-    if (masked) k::launch_mask(n, c->dFixedMask.p, v.p, s);
-    double *a = v.p, *b = w.p;
+    hipStream_t s = c->stream;
+    L.n = nRows * d;
+    L.apply = [=](const double *x, double *y) { apply_operator(c, masked, x, y, nullptr); };
+    L.step = [=](const double *rin, const double *t, double *rout, double *dv, double *x, double a, double b, bool first, bool assign) {
+        k::launch_mg_cheb(d, nRows, c->dDinv.p, rin, t, rout, dv, x, a, b, first, assign, scal, it, stop, s);
+    };
+    if (masked) L.mask = [=](double *v) { k::launch_mask(nRows * d, c->dFixedMask.p, v, s); };
+    return L;
+}
+
+LevelOps agg_ops(mfh_ctx *c, mfh_ctx::AggLevel &A, const double *scal, int it, const double *stop) {
+    LevelOps L;
+    const int dim = c->dim();
+    hipStream_t s = c->stream;
+    const int64_t nAgg = A.nAgg;
+    const int32_t *nbr = A.nbr.p;
+    const double *Ap = A.A.p, *Dinv = A.Dinv.p;
+    L.n = nAgg * (dim == 3 ? 6 : 3);
+    L.apply = [=](const double *x, double *y) { k::launch_st_spmv(dim, nAgg, nbr, Ap, x, y, scal, it, stop, s); };
+    L.step = [=](const double *rin, const double *t, double *rout, double *dv, double *x, double a, double b, bool first, bool assign) {
+        k::launch_st_cheb(dim, nAgg, Dinv, rin, t, rout, dv, x, a, b, first, assign, scal, it, stop, s);
+    };
+    return L;
+}
+
+// largest eigenvalue of D^-1 A: power iteration from a pseudo-random start, all on the device. The iterate is not normalised
+// (lambda_max of a block-Jacobi-scaled stiffness operator is a small number: 16 steps grow it by < 1e10) and only the last two
+// norms are read back: one host synchronisation.
+double estimate_lambda_max(mfh_ctx *c, const LevelOps &L, double *v, double *w, double *t) {
+    hipStream_t s = c->stream;
+    k::launch_fill_hash(L.n, v, s);
+    if (L.mask) L.mask(v);
+    double *a = v, *b = w;
     const int steps = 16;
     for (int it = 0; it < steps; ++it) {
-        apply_operator(c, masked, a, t.p, nullptr);                         // t = K a
-        // b = D^-1 t  (k_mg_cheb with first + assign: d = D^-1 rin, x = d)
-        k::launch_mg_cheb(d, nRows, c->dDinv.p, t.p, nullptr, nullptr, b, b, 0.0, 1.0, true, true, nullptr, 0, nullptr, s);
+        L.apply(a, t);
+        L.step(t, nullptr, nullptr, b, b, 0.0, 1.0, true, true);           // b = D^-1 t
         std::swap(a, b);
     }
-    // a = (D^-1 K)^steps v, b = the iterate before it
     c->stop.alloc(4);
     MFH_HIP(hipMemsetAsync(c->stop.p + 1, 0, 2 * sizeof(double), s));
-    k::launch_dot(n, a, a, c->stop.p + 1, s);
-    k::launch_dot(n, b, b, c->stop.p + 2, s);
+    k::launch_dot(L.n, a, a, c->stop.p + 1, s);
+    k::launch_dot(L.n, b, b, c->stop.p + 2, s);
     double h[2] = {0, 0};
     MFH_HIP(hipMemcpyAsync(h, c->stop.p + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     MFH_HIP(hipStreamSynchronize(s));
     return h[1] > 0 ? std::sqrt(h[0] / h[1]) : 1.0;
 }
 
-struct Level {   // what a Chebyshev sweep needs of a level
-    mfh_ctx *c;
-    double lmax, ratio;
-    int steps;
-};
-
-// x = S(b) (zeroInit) or x <- S(b, x): `steps` Chebyshev steps on D^-1 K over [lmax ratio, lmax]. r, dvec, t: work vectors.
-// On return (wantResidual) `r` and `t` are such that the residual b - K x equals r - t (the restriction subtracts on the fly).
-void chebyshev(const Level &L, const double *b, double *x, bool zeroInit, bool wantResidual, double *r, double *dvec, double *t,
-               const double *scal, int it, const double *stop) {
-    mfh_ctx *c = L.c;
-    const int d = c->bs();
-    const int64_t nRows = c->sym.nRows;
-    hipStream_t s = c->stream;
-    const bool masked = !c->fixedVars.empty();
+// x = S(b) (zeroInit) or x <- S(b, x): `steps` Chebyshev steps on D^-1 A over [lmax ratio, lmax]. r, dvec, t: work vectors.
+// With wantResidual the residual b - A x is left as the pair (*resA, *resB): residual = resA - resB (the restriction subtracts on
+// the fly). A single-step sweep stores neither the running residual nor the direction: from zero, x IS the direction.
+void chebyshev(const LevelOps &L, const double *b, double *x, bool zeroInit, bool wantResidual, double *r, double *dvec, double *t,
+               const double **resA = nullptr, const double **resB = nullptr) {
     const double lmin = L.lmax * L.ratio, theta = 0.5 * (L.lmax + lmin), delta = 0.5 * (L.lmax - lmin), sigma = theta / delta;
     double rho = 1.0 / sigma;
-    const double *rin = b;
     const double *tin = nullptr;
-    if (!zeroInit) {            // r = b - K x
-        apply_operator(c, masked, x, t, nullptr);
+    if (!zeroInit) {            // r = b - A x
+        L.apply(x, t);
         tin = t;
     }
+    if (L.steps == 1) {
+        L.step(b, tin, nullptr, zeroInit ? x : nullptr, x, 0.0, 1.0 / theta, true, zeroInit);
+        if (wantResidual) {
+            if (zeroInit) { L.apply(x, t); *resA = b; *resB = t; }          // residual = b - A x
+            else { L.apply(x, t); *resA = b; *resB = t; }
+        }
+        return;
+    }
     // step 1: d = D^-1 r / theta ; x (+)= d ; the running residual goes to r
-    k::launch_mg_cheb(d, nRows, c->dDinv.p, rin, tin, r, dvec, x, 0.0, 1.0 / theta, true, zeroInit, scal, it, stop, s);
+    L.step(b, tin, r, dvec, x, 0.0, 1.0 / theta, true, zeroInit);
     for (int j = 1; j < L.steps; ++j) {
         const double rhoNew = 1.0 / (2.0 * sigma - rho);
-        apply_operator(c, masked, dvec, t, nullptr);                        // r -= K d inside the next step
-        k::launch_mg_cheb(d, nRows, c->dDinv.p, r, t, r, dvec, x, rhoNew * rho, 2.0 * rhoNew / delta, false, false, scal, it, stop, s);
+        L.apply(dvec, t);                                                   // r -= A d inside the next step
+        L.step(r, t, r, dvec, x, rhoNew * rho, 2.0 * rhoNew / delta, false, false);
         rho = rhoNew;
     }
-    if (wantResidual) apply_operator(c, masked, dvec, t, nullptr);          // residual = r - K d_last
+    if (wantResidual) { L.apply(dvec, t); *resA = r; *resB = t; }           // residual = r - A d_last
+}
+
+// ---- aggregate hierarchy below the linear level --------------------------------------------------------------------------
+uint64_t pack_coord(const int32_t *q) { return ((uint64_t)(uint32_t)(q[0] + 2) << 42) | ((uint64_t)(uint32_t)(q[1] + 2) << 21) | (uint64_t)(uint32_t)(q[2] + 2); }
+
+// neighbour table of a level from its lattice coordinates
+void build_neighbours(int dim, mfh_ctx::AggLevel &A, hipStream_t s) {
+    const int NS = dim == 3 ? 27 : 9;
+    std::map<uint64_t, int32_t> idOf;
+    for (int64_t a = 0; a < A.nAgg; ++a) idOf[pack_coord(&A.hCoord[(size_t)a * 3])] = (int32_t)a;
+    std::vector<int32_t> nbr((size_t)A.nAgg * NS, -1);
+    for (int64_t a = 0; a < A.nAgg; ++a)
+        for (int sl = 0; sl < NS; ++sl) {
+            const int32_t q[3] = {A.hCoord[(size_t)a * 3] + sl % 3 - 1, A.hCoord[(size_t)a * 3 + 1] + (sl / 3) % 3 - 1,
+                                  A.hCoord[(size_t)a * 3 + 2] + (dim == 3 ? sl / 9 - 1 : 0)};
+            auto itf = idOf.find(pack_coord(q));
+            if (itf != idOf.end()) nbr[(size_t)a * NS + sl] = itf->second;
+        }
+    A.nbr.upload(nbr, s);
+    A.coord.upload(A.hCoord, s);
+}
+
+void alloc_level_vectors(int dim, mfh_ctx::AggLevel &A) {
+    const size_t n = (size_t)A.nAgg * (dim == 3 ? 6 : 3);
+    A.x.alloc(n); A.b.alloc(n); A.r.alloc(n); A.d.alloc(n); A.t.alloc(n);
+}
+
+// Builds c->mg.agg from the linear level c1. false: the lattice does not resolve the elements (an element reaches beyond
+// adjacent bins) or the dense level is not positive definite; the caller then keeps the context's own dense coarse space.
+bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void(const char *)> &lap) {
+    auto &G = c->mg;
+    G.agg.clear();
+    if (c->mgAggTarget <= 0) return false;
+    hipStream_t s = c->stream;
+    const int dim = c->dim(), NM = dim == 3 ? 6 : 3, NS = dim == 3 ? 27 : 9;
+    const int64_t nD = c1->nDoF;
+    DBuf<double> dDofPos;
+    const double *dPos = c1->dVertPos.p;
+    if (!c1->dofForNode.empty()) {
+        dof_positions_device(c1->mesh.nNode, dim, device_dof_map(c1), c1->dVertPos.p, nD, s, dDofPos);
+        dPos = dDofPos.p;
+    }
+    DBuf<int> far;
+    far.alloc(1);
+    int target = c->mgAggTarget;
+    std::unique_ptr<mfh_ctx::AggLevel> L0;
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        Aggregates A;
+        build_aggregates_device(dim, nD, dPos, target, s, A, G.aggOfDof2, G.relPos2, G.aggPtr2, G.dofsByAgg2);
+        L0.reset(new mfh_ctx::AggLevel());
+        L0->nAgg = A.nAgg; L0->H = A.H; L0->hCoord = A.binCoord; L0->hCentre = A.centroid;
+        build_neighbours(dim, *L0, s);
+        L0->A.alloc((size_t)A.nAgg * NS * NM * NM);
+        far.zero(s);
+        k::TLArgs ta{};
+        ta.dim = dim; ta.nModes = NM; ta.nAgg = A.nAgg; ta.nDoF = c1->sym.nRows; ta.aggOfDof = G.aggOfDof2.p; ta.relPos = G.relPos2.p;
+        ta.fixedMask = c1->fixedVars.empty() ? nullptr : c1->dFixedMask.p;
+        k::launch_tl_rap_agg(ta, G.aggPtr2.p, G.dofsByAgg2.p, L0->coord.p, c1->dRowPtr.p, c1->dColIdx.p, c1->dVals.p, nullptr, s, false, c1->sym.nRows,
+                             L0->A.p, far.p);
+        int nFar = 0;
+        far.download(&nFar, 1, s);
+        if (nFar == 0) break;
+        L0.reset();
+        target *= 8;                     // bins twice as wide
+    }
+    if (!L0) return false;
+    lap("aggregates + Galerkin product");
+    G.agg.push_back(std::move(L0));
+    // ---- coarser levels: 2^dim bins merge until the level is small enough for a dense inverse
+    while (G.agg.back()->nAgg > c->mgDenseMax) {
+        mfh_ctx::AggLevel &F = *G.agg.back();
+        std::unique_ptr<mfh_ctx::AggLevel> Cn(new mfh_ctx::AggLevel());
+        std::map<uint64_t, int32_t> idOf;
+        std::vector<int32_t> parent((size_t)F.nAgg);
+        std::vector<int32_t> cnt;
+        for (int64_t a = 0; a < F.nAgg; ++a) {
+            // floor division by 2 (lattice coordinates may be any integers)
+            const int32_t q[3] = {F.hCoord[(size_t)a * 3] >> 1, F.hCoord[(size_t)a * 3 + 1] >> 1, F.hCoord[(size_t)a * 3 + 2] >> 1};
+            auto ins = idOf.emplace(pack_coord(q), (int32_t)Cn->hCoord.size() / 3);
+            if (ins.second) { Cn->hCoord.insert(Cn->hCoord.end(), q, q + 3); Cn->hCentre.insert(Cn->hCentre.end(), 3, 0.0); cnt.push_back(0); }
+            const int32_t p = ins.first->second;
+            parent[(size_t)a] = p;
+            for (int k2 = 0; k2 < 3; ++k2) Cn->hCentre[(size_t)p * 3 + k2] += F.hCentre[(size_t)a * 3 + k2];
+            ++cnt[(size_t)p];
+        }
+        Cn->nAgg = (int64_t)cnt.size();
+        if (Cn->nAgg == F.nAgg) break;                                       // nothing merges any more
+        for (int64_t p = 0; p < Cn->nAgg; ++p)
+            for (int k2 = 0; k2 < 3; ++k2) Cn->hCentre[(size_t)p * 3 + k2] /= cnt[(size_t)p];
+        Cn->H = 2.0 * F.H;
+        std::vector<double> rel((size_t)F.nAgg * 4);
+        for (int64_t a = 0; a < F.nAgg; ++a) {
+            for (int k2 = 0; k2 < 3; ++k2) rel[(size_t)a * 4 + k2] = (F.hCentre[(size_t)a * 3 + k2] - Cn->hCentre[(size_t)parent[(size_t)a] * 3 + k2]) / Cn->H;
+            rel[(size_t)a * 4 + 3] = F.H / Cn->H;
+        }
+        F.parent.upload(parent, s);
+        F.rel.upload(rel, s);
+        build_neighbours(dim, *Cn, s);
+        Cn->A.alloc((size_t)Cn->nAgg * NS * NM * NM);
+        Cn->A.zero(s);
+        k::launch_st_rap(dim, F.nAgg, F.nbr.p, F.A.p, F.parent.p, F.rel.p, Cn->coord.p, Cn->A.p, s);
+        G.agg.push_back(std::move(Cn));
+    }
+    lap("coarser aggregate levels");
+    // ---- smoothers, dense inverse of the last level
+    for (auto &L : G.agg) {
+        L->Dinv.alloc((size_t)L->nAgg * NM * NM);
+        k::launch_st_dinv(dim, L->nAgg, L->A.p, L->Dinv.p, s);
+        alloc_level_vectors(dim, *L);
+    }
+    {
+        mfh_ctx::AggLevel &Last = *G.agg.back();
+        G.denseM = Last.nAgg * NM;
+        DBuf<double> Ad;
+        Ad.alloc((size_t)G.denseM * G.denseM);
+        Ad.zero(s);
+        k::launch_st_to_dense(dim, Last.nAgg, Last.nbr.p, Last.A.p, Ad.p, s);
+        if (!dense_inverse_device(c, Ad.p, G.denseM, G.denseInv, G.denseLd)) { G.agg.clear(); return false; }
+    }
+    lap("dense inverse of the last level");
+    for (size_t l = 0; l + 1 < G.agg.size(); ++l) {
+        mfh_ctx::AggLevel &L = *G.agg[l];
+        L.lmax = c->mgEigMargin * estimate_lambda_max(c, agg_ops(c, L, nullptr, 0, nullptr), L.r.p, L.d.p, L.t.p);
+    }
+    lap("spectra of the aggregate levels");
+    return true;
+}
+
+// x = (approximately) A_l^-1 b on aggregate level l: a symmetric V-cycle down to the dense level
+void agg_cycle(mfh_ctx *c, size_t l, const double *scal, int it, const double *stop) {
+    auto &G = c->mg;
+    mfh_ctx::AggLevel &L = *G.agg[l];
+    hipStream_t s = c->stream;
+    const int dim = c->dim(), NM = dim == 3 ? 6 : 3;
+    if (l + 1 == G.agg.size()) {
+        k::launch_tl_gemv(G.denseM, G.denseLd, G.denseInv.p, L.b.p, L.x.p, s);
+        return;
+    }
+    LevelOps ops = agg_ops(c, L, scal, it, stop);
+    ops.lmax = L.lmax; ops.ratio = c->mgRatioAgg; ops.steps = c->mgStepsAgg;
+    mfh_ctx::AggLevel &Cn = *G.agg[l + 1];
+    const double *ra = nullptr, *rb = nullptr;
+    chebyshev(ops, L.b.p, L.x.p, true, true, L.r.p, L.d.p, L.t.p, &ra, &rb);
+    k::launch_mg_zero(Cn.nAgg * NM, Cn.b.p, scal, it, stop, s);
+    k::launch_st_restrict(dim, L.nAgg, L.parent.p, L.rel.p, ra, rb, Cn.b.p, scal, it, stop, s);
+    agg_cycle(c, l + 1, scal, it, stop);
+    k::launch_st_prolong_add(dim, L.nAgg, L.parent.p, L.rel.p, Cn.x.p, L.x.p, c->mgOverCorrection, scal, it, stop, s);
+    chebyshev(ops, L.b.p, L.x.p, false, false, L.r.p, L.d.p, L.t.p);
 }
 
 }   // namespace
@@ -89,6 +274,7 @@ void chebyshev(const Level &L, const double *b, double *x, bool zeroInit, bool w
 void destroy_multigrid(mfh_ctx *c) {
     auto &G = c->mg;
     G.valid = false;
+    G.agg.clear();
     if (G.coarse) { mfh_destroy(G.coarse); G.coarse = nullptr; }
 }
 
@@ -220,8 +406,12 @@ bool ensure_multigrid(mfh_ctx *c) {
     c1->precond = MFH_PRECOND_TWO_LEVEL;
     ensure_precond(c1);
     lap("linear level: symbolic + assembly");
-    const bool haveCoarse = ensure_twolevel(c1);
-    lap("linear level: rigid-body coarse");
+    // below the linear level: the aggregate hierarchy; where the lattice cannot resolve the mesh, the context's own dense coarse space
+    bool haveCoarse = build_aggregate_hierarchy(c, c1, lap);
+    if (!haveCoarse) {
+        haveCoarse = ensure_twolevel(c1);
+        lap("linear level: rigid-body coarse (dense)");
+    }
     // ---- device copies, work vectors
     G.nFine = nDoF; G.nCoarse = nCD;
     G.parA.upload(parA, s); G.parB.upload(parB, s); G.fineOf.upload(fineOf, s); G.resPtr.upload(resPtr, s);
@@ -232,8 +422,8 @@ bool ensure_multigrid(mfh_ctx *c) {
     // ---- spectra of the two Jacobi-preconditioned operators
     ensure_precond(c);
     // the power iteration approaches the largest eigenvalue from below: a margin keeps the Chebyshev polynomials bounded on the whole spectrum
-    G.lmax0 = c->mgEigMargin * estimate_lambda_max(c, G.r0, G.d0, G.t0);
-    G.lmax1 = c->mgEigMargin * estimate_lambda_max(c1, G.r1, G.d1, G.t1);
+    G.lmax0 = c->mgEigMargin * estimate_lambda_max(c, nodal_ops(c, nullptr, 0, nullptr), G.r0.p, G.d0.p, G.t0.p);
+    G.lmax1 = c->mgEigMargin * estimate_lambda_max(c, nodal_ops(c1, nullptr, 0, nullptr), G.r1.p, G.d1.p, G.t1.p);
     lap("uploads + eigenvalue estimates");
     G.rigidCoarse = haveCoarse;
     G.setup_ms = now_ms() - t0;
@@ -248,27 +438,41 @@ void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int 
     mfh_ctx *c1 = G.coarse;
     hipStream_t s = c->stream;
     const int d = c->bs();
-    const Level L0{c, G.lmax0, c->mgRatio0, c->mgSteps0}, L1{c1, G.lmax1, c->mgRatio1, c->mgSteps1};
+    LevelOps L0 = nodal_ops(c, scal, it, stop), L1 = nodal_ops(c1, scal, it, stop);
+    L0.lmax = G.lmax0; L0.ratio = c->mgRatio0; L0.steps = c->mgSteps0;
+    L1.lmax = G.lmax1; L1.ratio = c->mgRatio1; L1.steps = c->mgSteps1;
     const bool masked0 = !c->fixedVars.empty(), masked1 = !c1->fixedVars.empty();
     // level 0, pre-smoothing from zero; residual r - K z = r0 - t0
-    chebyshev(L0, r, z, true, true, G.r0.p, G.d0.p, G.t0.p, scal, it, stop);
-    k::launch_mg_restrict(d, G.nCoarse, G.fineOf.p, G.resPtr.p, G.resIdx.p, G.r0.p, G.t0.p, masked1 ? c1->dFixedMask.p : nullptr, G.b1.p, scal, it, stop, s);
-    // level 1: (smooth, rigid-body correction, smooth) x mgCoarseCycles -- repeating one symmetric stationary iteration keeps M symmetric
+    const double *ra = nullptr, *rb = nullptr;
+    chebyshev(L0, r, z, true, true, G.r0.p, G.d0.p, G.t0.p, &ra, &rb);
+    k::launch_mg_restrict(d, G.nCoarse, G.fineOf.p, G.resPtr.p, G.resIdx.p, ra, rb, masked1 ? c1->dFixedMask.p : nullptr, G.b1.p, scal, it, stop, s);
+    // level 1: (smooth, coarse correction, smooth) x mgCoarseCycles -- repeating one symmetric stationary iteration keeps M symmetric
     for (int cyc = 0; cyc < c->mgCoarseCycles; ++cyc) {
-        chebyshev(L1, G.b1.p, G.x1.p, cyc == 0, G.rigidCoarse, G.r1.p, G.d1.p, G.t1.p, scal, it, stop);
+        const double *qa = nullptr, *qb = nullptr;
+        chebyshev(L1, G.b1.p, G.x1.p, cyc == 0, G.rigidCoarse, G.r1.p, G.d1.p, G.t1.p, &qa, &qb);
         if (G.rigidCoarse) {
-            auto &T = c1->tl;
-            const k::TLArgs ta = tl_args(c1);
-            k::launch_mg_diff((int64_t)d * G.nCoarse, G.r1.p, G.t1.p, G.r1.p, scal, it, stop, s);        // residual of level 1
-            k::launch_tl_restrict(ta, T.aggPtr.p, T.dofsByAgg.p, G.r1.p, T.rc.p, s);
-            k::launch_tl_gemv(T.m, T.ldInv, T.Ainv.p, T.rc.p, T.yc.p, s);
-            k::launch_mg_tl_prolong_add(ta, T.yc.p, G.x1.p, scal, it, stop, s);
+            k::launch_mg_diff((int64_t)d * G.nCoarse, qa, qb, G.r1.p, scal, it, stop, s);               // residual of level 1
+            if (!G.agg.empty()) {             // aggregate hierarchy
+                mfh_ctx::AggLevel &A0 = *G.agg[0];
+                k::TLArgs ta{};
+                ta.dim = c->dim(); ta.nModes = ta.dim == 3 ? 6 : 3; ta.nAgg = (int)A0.nAgg; ta.nDoF = c1->sym.nRows;
+                ta.aggOfDof = G.aggOfDof2.p; ta.relPos = G.relPos2.p; ta.fixedMask = masked1 ? c1->dFixedMask.p : nullptr;
+                k::launch_tl_restrict(ta, G.aggPtr2.p, G.dofsByAgg2.p, G.r1.p, A0.b.p, s);
+                agg_cycle(c, 0, scal, it, stop);
+                k::launch_mg_tl_prolong_add(ta, A0.x.p, G.x1.p, c->mgOverCorrection, scal, it, stop, s);
+            } else {                          // the linear context's own dense coarse space (~1000 aggregates)
+                auto &T = c1->tl;
+                const k::TLArgs ta = tl_args(c1);
+                k::launch_tl_restrict(ta, T.aggPtr.p, T.dofsByAgg.p, G.r1.p, T.rc.p, s);
+                k::launch_tl_gemv(T.m, T.ldInv, T.Ainv.p, T.rc.p, T.yc.p, s);
+                k::launch_mg_tl_prolong_add(ta, T.yc.p, G.x1.p, c->mgOverCorrection, scal, it, stop, s);
+            }
         }
-        chebyshev(L1, G.b1.p, G.x1.p, false, false, G.r1.p, G.d1.p, G.t1.p, scal, it, stop);
+        chebyshev(L1, G.b1.p, G.x1.p, false, false, G.r1.p, G.d1.p, G.t1.p);
     }
     // back to level 0: z += P x1, post-smoothing
     k::launch_mg_prolong_add(d, G.nFine, G.parA.p, G.parB.p, G.x1.p, masked0 ? c->dFixedMask.p : nullptr, z, scal, it, stop, s);
-    chebyshev(L0, r, z, false, false, G.r0.p, G.d0.p, G.t0.p, scal, it, stop);
+    chebyshev(L0, r, z, false, false, G.r0.p, G.d0.p, G.t0.p);
 }
 
 }   // namespace mfhi

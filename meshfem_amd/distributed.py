@@ -553,26 +553,55 @@ def slab_traction_load(lm, n, traction):
     return load
 
 
+def _agree(ok, world, group, dev):
+    """min over the ranks of a 0/1 flag, through the process group"""
+    if world <= 1:
+        return ok
+    t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(t.item() >= 1.0)
+
+
+def robust_comm(c, rank, world, dev, group=None, log=None):
+    """The communicator of a multi-GPU run, chosen so that one failing transport cannot lose the run. Every
+    candidate runs the library's self test (a ring shift and an all-reduce with known answers) and the ranks agree on the outcome
+    through the process group before anyone moves on; the first transport that passes everywhere is used:
+      1. the library's own RCCL communicator (device buffers GPU to GPU over xGMI, no Python in the loop),
+      2. the two collectives as callbacks on the nccl process group (PyTorch's RCCL build: another library, another communicator),
+      3. the same callbacks on a gloo group created up front (host-staged over TCP on 127.0.0.1: slow, independent of RCCL and of
+         peer access between the devices).
+    Returns (comm, group it runs on, list of (transport, outcome))."""
+    tried = []
+    backend = dist.get_backend(group) if dist.is_initialized() else "none"
+    gloo = None
+    if world > 1 and backend == "nccl":
+        gloo = dist.new_group(backend="gloo")          # collective: created by every rank whether or not it will be needed
+    candidates = []
+    if backend == "nccl" or world == 1:
+        candidates.append(("rccl (library)", lambda: Comm.rccl(c, rank, world, group), group))
+    candidates.append(("callbacks on the %s process group" % backend, lambda: Comm.callbacks(c, rank, world, group), group))
+    if gloo is not None:
+        candidates.append(("callbacks on a gloo group (host-staged)", lambda: Comm.callbacks(c, rank, world, gloo), gloo))
+    for name, make, grp in candidates:
+        comm, ok, why = None, True, ""
+        try:
+            comm = make()
+            comm.selftest()
+        except (L.MeshFEMHipError, RuntimeError) as e:
+            ok, why = False, str(e)
+        ok_all = _agree(ok, world, group, dev)
+        tried.append((name, "ok" if ok_all else ("failed here: " + why if not ok else "failed on another rank")))
+        if log and rank == 0:
+            log("transport %s: %s" % tried[-1])
+        if ok_all:
+            return comm, grp, tried
+        if comm is not None:
+            comm.close()
+    raise RuntimeError("no transport passed the communicator self test: %r" % (tried,))
+
+
 def _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out, group=None):
-    comm = make_comm(c, rank, world, group)
-    # ring shift + all-reduce with known answers over the actual transport; the ranks agree on the outcome through the process
-    # group, and if the library's own RCCL communicator fails anywhere, every rank falls back to the callback transport
-    ok = 1.0
-    try:
-        comm.selftest()
-    except L.MeshFEMHipError as e:
-        ok = 0.0
-        print("rank %d: %s self test failed: %s" % (rank, comm.describe(), e), flush=True)
-    if world > 1:
-        t = torch.tensor([ok], dtype=torch.float64, device=dev if dist.get_backend(group) == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-        ok = float(t.item())
-    if ok < 1.0:
-        if comm.kind == "callbacks":
-            raise RuntimeError("the communicator self test failed on at least one rank")
-        comm.close()
-        comm = make_comm(c, rank, world, group, prefer="callbacks")
-        comm.selftest()
+    comm, group, tried = robust_comm(c, rank, world, dev, group, log=lambda m: print(m, flush=True))
     solver = DistSolver(c, lm, rank, world, comm, group)
     # u = 0 on x = 0: the mask covers the halo nodes too (needed by the Galerkin coarse operator)
     fixed_nodes = np.flatnonzero(lm.lattice[:, 0] == 0)
@@ -612,7 +641,7 @@ def _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out, group=None):
                       operator="matrix-free (k_mf_cluster + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
                       algorithm="Chronopoulos-Gear PCG in the library (mfh_dist_solve): packed halo exchange overlapped with the interior "
                                 "element blocks + %d all-reduce / iteration" % (2 if tl_info else 1),
-                      transport=comm.describe(), ranks=world)
+                      transport=comm.describe(), transports_tried=tried, ranks=world)
     # the same solve with the classic loop (two dependent all-reduces per iteration, lighter vector kernels): which of the two
     # wins depends on the all-reduce latency of the transport, so the scaling run records both
     try:

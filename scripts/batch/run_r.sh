@@ -1,0 +1,5 @@
+set -x
+timeout 300 python -m pytest tests/test_gpu_multigrid.py -x -q -m gpu 2>&1 | tail -4
+timeout 300 python scripts/mg_probe.py 60 1,1,0.3,0.3,1 2>&1 | grep "multigrid\|two-level" | cut -c1-170
+timeout 300 python scripts/mg_probe.py 44 1,1,0.3,0.3,1 2>&1 | grep "multigrid\|two-level" | cut -c1-170
+timeout 300 python scripts/mg_probe.py 100 1,1,0.3,0.3,1 2>&1 | grep "multigrid\|two-level" | cut -c1-170

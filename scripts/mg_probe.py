@@ -26,6 +26,10 @@ for st in sets:
     k0, k1, r0, r1 = st[:4]
     cyc = st[4] if len(st) > 4 else 1
     c.set_option("mg_coarse_cycles", cyc)
+    if len(st) > 5:
+        c.set_option("mg_steps_agg", st[5])
+    if len(st) > 6:
+        c.set_option("mg_ratio_agg", st[6])
     c.set_option("mg_steps_fine", k0); c.set_option("mg_steps_coarse", k1); c.set_option("mg_ratio_fine", r0); c.set_option("mg_ratio_coarse", r1)
     for rep in range(2):
         t0 = time.time()
@@ -38,4 +42,4 @@ for st in sets:
     else:
         print("multigrid k0=%d k1=%d ratio0=%.3f ratio1=%.3f cycles=%d: %d iterations, %.1f ms (%.2f ms / iteration), true residual %.2e, rel-L2 vs two-level %.1e, %s %s"
               % (k0, k1, r0, r1, cyc, i["iterations"], i["solve_ms"], i["solve_ms"] / max(1, i["iterations"]), i["true_rel_residual"],
-                 np.linalg.norm(u - u_tl) / np.linalg.norm(u_tl), c.multigrid_info(), c.precond_info()["note"]), flush=True)
+                 np.linalg.norm(u - u_tl) / np.linalg.norm(u_tl), c.multigrid_info(), c.precond_info()), flush=True)

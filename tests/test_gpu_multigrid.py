@@ -119,6 +119,32 @@ def test_multigrid_orthotropic_field_and_periodic_cell_problems():
     assert res[M.PRECOND_MULTIGRID][1] < res[M.PRECOND_TWO_LEVEL][1], res
 
 
+@pytest.mark.parametrize("dim,n", [(3, 8), (2, 40)])
+def test_multigrid_aggregate_hierarchy_levels_and_the_dense_only_variant(dim, n):
+    """Below the linear level: rigid-body modes of lattice bins in stencil storage, merged 2^dim at a time, dense inverse at the end.
+    Small `mg_agg_target` / `mg_dense_max` force several stencil levels on a small mesh (3D and 2D code paths of the k_st_* kernels);
+    `mg_agg_target 0` switches the hierarchy off (the linear context's own ~1000-aggregate dense coarse space). Same solution every way."""
+    c, V, T = _cantilever(n, 2, dim)
+    c.set_preconditioner(M.PRECOND_TWO_LEVEL)
+    u_ref = c.sim_solve(rtol=1e-11)
+    it_tl = c.last_info["iterations"]
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    res = {}
+    for name, opts in (("default", {}), ("deep", {"mg_agg_target": 6, "mg_dense_max": 8}), ("dense_only", {"mg_agg_target": 0}),
+                       ("no_over_correction", {"mg_over_correction": 1.0})):
+        c.set_option("mg_agg_target", 32); c.set_option("mg_dense_max", 1200); c.set_option("mg_over_correction", 1.5)
+        for k, v in opts.items():
+            c.set_option(k, v)
+        u = c.sim_solve(rtol=1e-11)
+        i, p = c.last_info, c.precond_info()
+        assert i["converged"] and np.linalg.norm(u - u_ref) <= 1e-8 * np.linalg.norm(u_ref), name
+        res[name] = (i["iterations"], p["aggregates"], p["coarse_dim"])
+    nm = 6 if dim == 3 else 3
+    assert res["deep"][2] <= 8 * nm and res["deep"][1] > res["default"][1]          # more, smaller aggregates; tiny dense level
+    assert max(r[0] for r in res.values()) < it_tl, (res, it_tl)
+    c.close()
+
+
 def test_multigrid_on_linear_elements_falls_back_with_a_note():
     c, V, T = _cantilever(4, deg=1)
     c.set_preconditioner(M.PRECOND_MULTIGRID)
