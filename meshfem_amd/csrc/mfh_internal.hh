@@ -271,6 +271,9 @@ void dof_positions_device(int64_t nNode, int dim, const int32_t *dDofForNode, co
 void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targetNodes, hipStream_t s, Aggregates &A,
                              DBuf<int32_t> &dAggOfDof, DBuf<double> &dRelPos, DBuf<int32_t> &dAggPtr, DBuf<int32_t> &dDofsByAgg);
 bool spd_inverse_inplace(int64_t n, double *A);
+// transfer lists of the p-multigrid preconditioner on the device (meshes in the library's own numbering, identity DoF map)
+void build_mg_transfer_device(const HostMesh &m, const int32_t *dElemNodes, hipStream_t s, DBuf<int32_t> &parA, DBuf<int32_t> &parB,
+                              DBuf<int32_t> &fineOf, DBuf<int32_t> &resPtr, DBuf<int32_t> &resIdx);
 
 } // namespace mfh
 

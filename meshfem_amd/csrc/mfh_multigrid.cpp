@@ -306,24 +306,34 @@ bool ensure_multigrid(mfh_ctx *c) {
         fprintf(stderr, "[multigrid setup] %-34s %8.2f ms\n", what, t - tp);
         tp = t;
     };
+    // A mesh in the library's own numbering (mfh_mesh_build: vertices are the nodes [0, nVert)) with the identity DoF map takes the
+    // device route for the transfer lists; any other node table / a periodic DoF map goes through the host loops below.
+    const bool ownNumbering = m.hasTopology && c->dofForNode.empty();
+    std::vector<int32_t> coarseNode, coarseDofOfFine, parA, parB, fineOf, resPtr, resIdx;
+    int64_t nCN = 0, nCD = 0;
+    if (ownNumbering) {
+        nCN = nCD = m.nVert;
+        build_mg_transfer_device(m, c->dElemNodes.p, s, G.parA, G.parB, G.fineOf, G.resPtr, G.resIdx);
+        lap("transfer lists (device)");
+    } else {
     // ---- vertex nodes (the first dim + 1 nodes of every element) -> coarse nodes, coarse DoFs; parents of every fine DoF.
     // Element loops run on the host threads; several elements may store the SAME value to one entry (relaxed atomic stores).
-    std::vector<int32_t> coarseNode((size_t)m.nNode, -1);
+    coarseNode.assign((size_t)m.nNode, -1);
     parallel_ranges(m.nElem, [&](int64_t eb, int64_t ee, int) {
         for (int64_t e = eb; e < ee; ++e)
             for (int k2 = 0; k2 < nv; ++k2) __atomic_store_n(&coarseNode[(size_t)m.elemNodes[(size_t)e * npe + k2]], 0, __ATOMIC_RELAXED);
     });
-    int64_t nCN = 0;
+    nCN = 0;
     for (int64_t n = 0; n < m.nNode; ++n)
         if (coarseNode[(size_t)n] == 0) coarseNode[(size_t)n] = (int32_t)nCN++;
-    std::vector<int32_t> coarseDofOfFine((size_t)nDoF, -1);
-    int64_t nCD = 0;
+    coarseDofOfFine.assign((size_t)nDoF, -1);
+    nCD = 0;
     for (int64_t n = 0; n < m.nNode; ++n) {       // coarse DoFs numbered in node order, like applyPeriodicConditions numbers DoFs
         if (coarseNode[(size_t)n] < 0) continue;
         const int32_t f = dof_of(c, n);
         if (coarseDofOfFine[(size_t)f] < 0) coarseDofOfFine[(size_t)f] = (int32_t)nCD++;
     }
-    std::vector<int32_t> parA((size_t)nDoF, -1), parB((size_t)nDoF, -1), fineOf((size_t)nCD, -1);
+    parA.assign((size_t)nDoF, -1); parB.assign((size_t)nDoF, -1); fineOf.assign((size_t)nCD, -1);
     parallel_ranges(nDoF, [&](int64_t fb, int64_t fe, int) {
         for (int64_t f = fb; f < fe; ++f)
             if (coarseDofOfFine[(size_t)f] >= 0) { parA[(size_t)f] = parB[(size_t)f] = coarseDofOfFine[(size_t)f]; fineOf[(size_t)coarseDofOfFine[(size_t)f]] = (int32_t)f; }
@@ -344,17 +354,21 @@ bool ensure_multigrid(mfh_ctx *c) {
     });
     lap("vertices, coarse DoFs, parents");
     // restriction lists: coarse DoF -> the edge-node DoFs it is an end of
-    std::vector<int32_t> resPtr((size_t)nCD + 1, 0);
+    resPtr.assign((size_t)nCD + 1, 0);
     for (int64_t f = 0; f < nDoF; ++f)
         if (parA[(size_t)f] >= 0 && coarseDofOfFine[(size_t)f] < 0) { ++resPtr[(size_t)parA[(size_t)f] + 1]; ++resPtr[(size_t)parB[(size_t)f] + 1]; }
     for (int64_t q = 0; q < nCD; ++q) resPtr[(size_t)q + 1] += resPtr[(size_t)q];
-    std::vector<int32_t> resIdx((size_t)resPtr[(size_t)nCD]), cur(resPtr.begin(), resPtr.end() - 1);
+    resIdx.assign((size_t)resPtr[(size_t)nCD], 0);
+    std::vector<int32_t> cur(resPtr.begin(), resPtr.end() - 1);
     for (int64_t f = 0; f < nDoF; ++f)
         if (parA[(size_t)f] >= 0 && coarseDofOfFine[(size_t)f] < 0) {
             resIdx[(size_t)cur[(size_t)parA[(size_t)f]]++] = (int32_t)f;
             resIdx[(size_t)cur[(size_t)parB[(size_t)f]]++] = (int32_t)f;
         }
     lap("restriction lists");
+    }
+    auto coarse_node = [&](int64_t n) -> int32_t { return ownNumbering ? (n < m.nVert ? (int32_t)n : -1) : coarseNode[(size_t)n]; };
+    auto coarse_dof = [&](int64_t f) -> int32_t { return ownNumbering ? (f < m.nVert ? (int32_t)f : -1) : coarseDofOfFine[(size_t)f]; };
     // ---- level 1: a context of its own on the vertices (degree 1), sharing device and stream
     mfh_ctx *c1 = new mfh_ctx();
     G.coarse = c1;
@@ -367,13 +381,13 @@ bool ensure_multigrid(mfh_ctx *c) {
     m1.elemNodes.resize((size_t)m.nElem * nv);
     parallel_ranges(m.nElem, [&](int64_t eb, int64_t ee, int) {
         for (int64_t e = eb; e < ee; ++e)
-            for (int k2 = 0; k2 < nv; ++k2) m1.elemNodes[(size_t)e * nv + k2] = coarseNode[(size_t)m.elemNodes[(size_t)e * npe + k2]];
+            for (int k2 = 0; k2 < nv; ++k2) m1.elemNodes[(size_t)e * nv + k2] = coarse_node(m.elemNodes[(size_t)e * npe + k2]);
     });
     m1.nodePos.resize((size_t)nCN * d);
     parallel_ranges(m.nNode, [&](int64_t nb, int64_t ne, int) {
         for (int64_t n = nb; n < ne; ++n)
-            if (coarseNode[(size_t)n] >= 0)
-                for (int a = 0; a < d; ++a) m1.nodePos[(size_t)coarseNode[(size_t)n] * d + a] = m.nodePos[(size_t)n * d + a];
+            if (coarse_node(n) >= 0)
+                for (int a = 0; a < d; ++a) m1.nodePos[(size_t)coarse_node(n) * d + a] = m.nodePos[(size_t)n * d + a];
     });
     m1.vertPos = m1.nodePos;
     m1.isBdryNode.assign((size_t)nCN, 0);
@@ -386,7 +400,7 @@ bool ensure_multigrid(mfh_ctx *c) {
     if (nCD != nCN) {
         c1->dofForNode.assign((size_t)nCN, 0);
         for (int64_t n = 0; n < m.nNode; ++n)
-            if (coarseNode[(size_t)n] >= 0) c1->dofForNode[(size_t)coarseNode[(size_t)n]] = coarseDofOfFine[(size_t)dof_of(c, n)];
+            if (coarse_node(n) >= 0) c1->dofForNode[(size_t)coarse_node(n)] = coarse_dof(dof_of(c, n));
         c1->nDoF = nCD;
         c1->dofUploaded = false;
     }
@@ -395,7 +409,7 @@ bool ensure_multigrid(mfh_ctx *c) {
         std::vector<int64_t> fv;
         for (int64_t v : c->fixedVars) {
             const int64_t f = v / d;
-            if (coarseDofOfFine[(size_t)f] >= 0) fv.push_back((int64_t)coarseDofOfFine[(size_t)f] * d + v % d);
+            if (coarse_dof(f) >= 0) fv.push_back((int64_t)coarse_dof(f) * d + v % d);
         }
         clear_fixed(c1);
         if (!fv.empty()) add_fixed(c1, (int64_t)fv.size(), fv.data(), nullptr);
@@ -414,8 +428,10 @@ bool ensure_multigrid(mfh_ctx *c) {
     }
     // ---- device copies, work vectors
     G.nFine = nDoF; G.nCoarse = nCD;
-    G.parA.upload(parA, s); G.parB.upload(parB, s); G.fineOf.upload(fineOf, s); G.resPtr.upload(resPtr, s);
-    G.resIdx.upload(resIdx.empty() ? std::vector<int32_t>{0} : resIdx, s);
+    if (!ownNumbering) {
+        G.parA.upload(parA, s); G.parB.upload(parB, s); G.fineOf.upload(fineOf, s); G.resPtr.upload(resPtr, s);
+        G.resIdx.upload(resIdx.empty() ? std::vector<int32_t>{0} : resIdx, s);
+    }
     const int64_t n0 = (int64_t)d * nDoF, n1 = (int64_t)d * nCD;
     G.r0.alloc((size_t)n0); G.d0.alloc((size_t)n0); G.t0.alloc((size_t)n0);
     G.b1.alloc((size_t)n1); G.x1.alloc((size_t)n1); G.r1.alloc((size_t)n1); G.d1.alloc((size_t)n1); G.t1.alloc((size_t)n1);

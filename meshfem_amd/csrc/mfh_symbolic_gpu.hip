@@ -688,6 +688,75 @@ void dof_positions_device(int64_t nNode, int dim, const int32_t *dDofForNode, co
     MFH_HIP(hipStreamSynchronize(s));
 }
 
+// ------------------------------------------------------------------------------------------------
+// Transfer lists of the p-multigrid preconditioner (mfh_multigrid.cpp) for a mesh in the library's own numbering (vertices are
+// the nodes [0, nVert), identity DoF map): the two ends of every edge node from the element table, and the CSR lists
+// vertex -> edge nodes it is an end of (one stable radix sort of the 2 (nNode - nVert) (end, edge node) pairs).
+// ------------------------------------------------------------------------------------------------
+namespace {
+__constant__ int kMgEdgeS[6] = {0, 1, 2, 0, 2, 1};      // Simplex.hh:43-44
+__constant__ int kMgEdgeE[6] = {1, 2, 0, 3, 3, 3};
+__global__ void __launch_bounds__(256) k_mg_parents(int64_t nElem, int npe, int nv, int dim, const int32_t *__restrict__ elemNodes, int64_t nVert,
+                                                    int32_t *__restrict__ parA, int32_t *__restrict__ parB) {
+    const int nedge = npe - nv;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nElem * nedge; k += (int64_t)gridDim.x * 256) {
+        const int64_t e = k / nedge;
+        const int ei = (int)(k - e * nedge);
+        const int32_t *en = elemNodes + e * npe;
+        int32_t a = en[dim == 3 ? kMgEdgeS[ei] : ei], b = en[dim == 3 ? kMgEdgeE[ei] : (ei + 1) % 3];
+        if (a > b) { const int32_t t = a; a = b; b = t; }
+        const int32_t f = en[nv + ei];
+        parA[f] = a; parB[f] = b;                 // every element of the edge stores the same pair
+    }
+}
+__global__ void __launch_bounds__(256) k_mg_vertex_identity(int64_t nVert, int32_t *__restrict__ parA, int32_t *__restrict__ parB, int32_t *__restrict__ fineOf) {
+    for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nVert; v += (int64_t)gridDim.x * 256) { parA[v] = parB[v] = (int32_t)v; fineOf[v] = (int32_t)v; }
+}
+__global__ void __launch_bounds__(256) k_mg_pairs(int64_t nEdgeNodes, int64_t nVert, const int32_t *__restrict__ parA, const int32_t *__restrict__ parB,
+                                                  uint32_t *__restrict__ key, uint32_t *__restrict__ val, int32_t *__restrict__ cnt) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < nEdgeNodes; k += (int64_t)gridDim.x * 256) {
+        const int32_t f = (int32_t)(nVert + k);
+        key[2 * k] = (uint32_t)parA[f]; val[2 * k] = (uint32_t)f;
+        key[2 * k + 1] = (uint32_t)parB[f]; val[2 * k + 1] = (uint32_t)f;
+        atomicAdd(&cnt[parA[f]], 1);
+        atomicAdd(&cnt[parB[f]], 1);
+    }
+}
+} // namespace
+
+void build_mg_transfer_device(const HostMesh &m, const int32_t *dElemNodes, hipStream_t s, DBuf<int32_t> &parA, DBuf<int32_t> &parB,
+                              DBuf<int32_t> &fineOf, DBuf<int32_t> &resPtr, DBuf<int32_t> &resIdx) {
+    const int64_t nVert = m.nVert, nEdgeNodes = m.nNode - m.nVert;
+    const int nv = m.dim + 1;
+    parA.alloc((size_t)m.nNode); parB.alloc((size_t)m.nNode); fineOf.alloc((size_t)nVert);
+    hipLaunchKernelGGL(k_mg_vertex_identity, dim3(grid_of(nVert)), dim3(256), 0, s, nVert, parA.p, parB.p, fineOf.p);
+    hipLaunchKernelGGL(k_mg_parents, dim3(grid_of(m.nElem * (m.npe - nv))), dim3(256), 0, s, m.nElem, m.npe, nv, m.dim, dElemNodes, nVert, parA.p, parB.p);
+    RP(hipGetLastError());
+    const int64_t N = 2 * nEdgeNodes;
+    DBuf<uint32_t> keyA, keyB, valA, valB;
+    DBuf<int32_t> cnt;
+    keyA.alloc((size_t)std::max<int64_t>(1, N)); keyB.alloc(keyA.n); valA.alloc(keyA.n); valB.alloc(keyA.n);
+    cnt.alloc((size_t)nVert + 1);
+    cnt.zero(s);
+    hipLaunchKernelGGL(k_mg_pairs, dim3(grid_of(std::max<int64_t>(1, nEdgeNodes))), dim3(256), 0, s, nEdgeNodes, nVert, parA.p, parB.p, keyA.p, valA.p, cnt.p);
+    RP(hipGetLastError());
+    size_t tmpBytes = 0;
+    const unsigned endBit = bits_for((uint64_t)nVert);
+    RP(rocprim::radix_sort_pairs(nullptr, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)N, 0u, endBit, s));
+    DBuf<char> tmp;
+    tmp.alloc(tmpBytes + 16);
+    RP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)N, 0u, endBit, s));
+    resPtr.alloc((size_t)nVert + 1);
+    size_t exBytes = 0;
+    RP(rocprim::exclusive_scan(nullptr, exBytes, cnt.p, resPtr.p, (int32_t)0, (size_t)nVert + 1, rocprim::plus<int32_t>(), s));
+    if (exBytes + 16 > tmp.n) tmp.alloc(exBytes + 16);
+    RP(rocprim::exclusive_scan(tmp.p, exBytes, cnt.p, resPtr.p, (int32_t)0, (size_t)nVert + 1, rocprim::plus<int32_t>(), s));
+    resIdx.alloc((size_t)std::max<int64_t>(1, N));
+    hipLaunchKernelGGL(k_agg_copy_u32_i32, dim3(grid_of(std::max<int64_t>(1, N))), dim3(256), 0, s, N, valB.p, resIdx.p);
+    RP(hipGetLastError());
+    MFH_HIP(hipStreamSynchronize(s));
+}
+
 void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targetNodes, hipStream_t s, Aggregates &A,
                              DBuf<int32_t> &dAggOfDof, DBuf<double> &dRelPos, DBuf<int32_t> &dAggPtr, DBuf<int32_t> &dDofsByAgg) {
     A = Aggregates();

@@ -145,6 +145,33 @@ def test_multigrid_aggregate_hierarchy_levels_and_the_dense_only_variant(dim, n)
     c.close()
 
 
+def test_multigrid_on_a_caller_supplied_node_table():
+    """mfh_mesh_set (any node numbering, no topology): the transfer lists come from the host loops over the element table instead of
+    the device route of the library's own numbering; same solution as block-Jacobi."""
+    n = 5
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    h = M.Context(-1)
+    h.mesh_build(T, V, 2)
+    en, pos = h.elem_nodes(), h.node_positions()
+    h.close()
+    perm = np.random.default_rng(5).permutation(len(pos))          # new id of old node k: perm[k]
+    pos2 = np.empty_like(pos); pos2[perm] = pos
+    c = M.Context(0)
+    c.mesh_set(3, 2, perm[en].astype(np.int32), pos2)
+    c.material_isotropic(200.0, 0.35)
+    fixed = np.flatnonzero(np.abs(pos2[:, 0]) < 1e-12)
+    c.fix_variables((3 * fixed[:, None] + np.arange(3)[None, :]).ravel())
+    f = np.zeros((len(pos2), 3)); f[np.abs(pos2[:, 0] - 1) < 1e-12, 1] = -1e-3
+    c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+    u_bj = c.solve(f.ravel(), rtol=1e-11)
+    it_bj = c.last_info["iterations"]
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    u = c.solve(f.ravel(), rtol=1e-11)
+    assert c.last_info["converged"] and c.multigrid_info()["coarse_dof"] == len(V)
+    assert np.linalg.norm(u - u_bj) <= 1e-8 * np.linalg.norm(u_bj) and c.last_info["iterations"] < 0.3 * it_bj
+    c.close()
+
+
 def test_multigrid_on_linear_elements_falls_back_with_a_note():
     c, V, T = _cantilever(4, deg=1)
     c.set_preconditioner(M.PRECOND_MULTIGRID)
