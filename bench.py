@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
 PMC_PROFILE = "r02_pmc_traffic_n60.json"      # scripts/pmc_collect.py on the round-2 kernels (both triangles of K stored)
-PMC_PROFILE_UPPER = "r02_pmc_traffic_n60_upper_storage.json"   # the same with the upper-triangle storage (PMC_UPPER_STORAGE=1)
+PMC_PROFILE_UPPER = "r03_pmc_traffic_n60_upper_storage.json"   # the same with the upper-triangle storage (PMC_UPPER_STORAGE=1), round-3 kernel
 PMC_KERNEL_KEY = "k_assemble_gather"
 ALG_BYTES = {(3, 2): 7736, (3, 1): 1328, (2, 2): 1368, (2, 1): 0}   # SURVEY.md section 8(d), const material, both triangles
 # SURVEY.md section 8(d), row "upper-only variant, matches reference storage": 40 + 96 + 55 x 4 + 55 x 72 (P2 tet); P2 triangle alike
@@ -132,15 +132,18 @@ def cpu_direct_solve(deg, n, rtol):
     free = (3 * free_nodes[:, None] + np.arange(3)[None, :]).ravel()
     Kr = K[free][:, free]                          # SPSDSystem::fixVariables: eliminated rows / columns (:2389-2500)
     t_elim = time.perf_counter() - t0
-    mf = DS.MultifrontalCholesky(Kr, pos[free_nodes], block=3)
-    mf.factor()
-    x = mf.solve(f[free])
+    # 16 BLAS threads: the fronts of this size are small enough that 64 OpenBLAS threads lose to 16 (measured 18.6 vs 12.2 s at 107 k DOF)
+    from threadpoolctl import threadpool_limits
+    with threadpool_limits(limits=min(16, os.cpu_count() or 1), user_api="blas"):
+        threads = DS.blas_threads()
+        mf = DS.MultifrontalCholesky(Kr, pos[free_nodes], block=3)
+        mf.factor()
+        x = mf.solve(f[free])
     u = np.zeros(N)
     u[free] = x
     err = float(np.linalg.norm(u_gpu.ravel() - u) / np.linalg.norm(u))
     res = float(np.linalg.norm(Kr @ x - f[free]) / np.linalg.norm(f[free]))
     have_cholmod = ctypes.util.find_library("cholmod") is not None
-    threads = DS.blas_threads()
     return dict(kind="port of the method: multifrontal (supernodal) Cholesky, geometric nested dissection, LAPACK potrf/trsm/gemm on %d BLAS "
                      "threads (oracle/direct_solve.py); CHOLMOD %s" % (threads, "found but not bound" if have_cholmod else "not installed on this box"),
                 sample="%d^3 grid -> %d P%d tets" % (n, len(T), deg), dof=int(N), free_dof=int(len(free)), cores=threads,
@@ -203,10 +206,10 @@ def cpu_baseline_with_solve(args):
     out = cpu_baseline(args.deg, args.cpu_grid)
     try:
         ds = None
-        # grow the sample while the factorisation time (~ N^2) leaves room: 107 k, 288 k, 501 k DOF for quadratic tets
-        for n in ([args.cpu_solve_grid] if args.cpu_solve_grid else [10, 14, 17]):
+        # grow the sample while the factorisation time (~ N^2) leaves room: 57 k, 107 k, 288 k, 501 k DOF for quadratic tets
+        for n in ([args.cpu_solve_grid] if args.cpu_solve_grid else [8, 10, 14, 17]):
             ds = cpu_direct_solve(args.deg, n, args.rtol)
-            if ds["solve_s"] > 5.0:      # the next size costs ~7x (10 -> 14) / ~3x (14 -> 17) as much
+            if ds["solve_s"] > 4.0:      # the next size costs ~4x (8 -> 10), ~7x (10 -> 14), ~3x (14 -> 17) as much
                 break
         out["direct_solve"] = ds
         out.update(solve_s=ds["solve_s"], dof=ds["dof"], solve_kind=ds["kind"])
@@ -301,7 +304,8 @@ def run_single(args):
                warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, scaling=args.scaling, vs_baseline=None,
                dtype="f64", data="synthetic",
                config=dict(workload="%s: %d^3 grid -> %d P%d tets, isotropic E=200 nu=0.35, Dirichlet x=0, traction x=1"
-                                    % ("configs[4] on one GPU (the N = 1 point of the strong-scaling curve)" if strong else "configs[2]", n, nE, deg),
+                                    % (("configs[4] on one GPU" if n == 119 else "the %d^3 cube of the strong-scaling run on one GPU" % n) + " (the N = 1 point of the strong-scaling curve)"
+                                       if strong else ("configs[2]" if (n, deg) == (60, 2) else "configs[2] generator at another size"), n, nE, deg),
                            elements=nE, nodes=c.n_node, dof=3 * c.n_dof, nnz_blocks=nnzb,
                            stored_blocks=stored_blocks, matrix_storage="upper" if upper else "full",
                            parallelism="1 GPU", step="embed + Ke blocks + assembly into block-CSR (gather/owner-computes)"),

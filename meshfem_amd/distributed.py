@@ -741,8 +741,9 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
     out = dict(metric="stiffness_assembly_elements_per_s", value=n_elem_global * args.steps / dt, unit="elements/s",
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                scaling="strong" if strong else "weak", vs_baseline=None, dtype="f64", data="synthetic",
-               config=dict(workload=("configs[4]: %d^3 grid -> %d P%d tets (fixed), z-slabs of %d-%d hex layers per GPU"
-                                     % (n, n_elem_global, deg, n // world, -(-n // world))) if strong else
+               config=dict(workload=("%s: %d^3 grid -> %d P%d tets (fixed), z-slabs of %d-%d hex layers per GPU"
+                                     % ("configs[4]" if (n, deg) == (119, 2) else "configs[4]'s cube at another size", n, n_elem_global, deg, n // world,
+                                        -(-n // world))) if strong else
                                     ("%d x %d x %d grid -> %d P%d tets, z-slabs of %d hex layers per GPU (configs[4] shape: 120^3 at 8 GPUs)"
                                      % (n, n, nz_total, n_elem_global, deg, layers)), elements=n_elem_global,
                            local_elements=nE_loc, local_nodes=int(lm.n_local), owned_nodes=int(lm.n_owned),
