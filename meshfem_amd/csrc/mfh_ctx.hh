@@ -147,6 +147,8 @@ struct mfh_ctx {
         DBuf<double> x, b, r, d, t;
         std::vector<int32_t> hCoord;
         std::vector<double> hCentre;
+        int nb[3] = {1, 1, 1};               // bins per axis
+        int wrap[3] = {0, 0, 0};             // nb of the axes along which the lattice is periodic (periodic DoF maps), else 0
     };
     struct Multigrid {
         bool valid = false, rigidCoarse = false;

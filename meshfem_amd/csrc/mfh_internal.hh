@@ -251,6 +251,7 @@ void build_shape_tables(int dim, int deg, ShapeTables &T);
 // ------------------------------------------------------------------------------------------------
 struct Aggregates {
     int dim = 0, nAgg = 0, nColor = 0;
+    int nb[3] = {1, 1, 1};               // bins of the lattice per axis
     double H = 0;                        // bin edge (rotation modes are scaled by 1/H)
     bool binsTooFew = false;
     std::vector<int32_t> aggOfDof;       // nDoF
@@ -438,7 +439,8 @@ void launch_st_spmv(int dim, int64_t nAgg, const int32_t *nbr, const double *A, 
 void launch_st_dinv(int dim, int64_t nAgg, const double *A, double *Dinv, hipStream_t s);
 void launch_st_cheb(int dim, int64_t nAgg, const double *Dinv, const double *rin, const double *t, double *rout, double *d, double *x, double a, double b,
                     bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s);
-void launch_st_rap(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const int32_t *parent, const double *rel, const int32_t *coordC, double *Ac, hipStream_t s);
+void launch_st_rap(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const int32_t *parent, const double *rel, const int32_t *coordC, double *Ac,
+                   const int *wrapNbC, hipStream_t s);
 void launch_st_restrict(int dim, int64_t nAgg, const int32_t *parent, const double *rel, const double *r, const double *t, double *rc, const double *scal, int it,
                         const double *stop, hipStream_t s);
 void launch_st_prolong_add(int dim, int64_t nAgg, const int32_t *parent, const double *rel, const double *xc, double *x, double alpha, const double *scal, int it,
@@ -447,7 +449,7 @@ void launch_st_to_dense(int dim, int64_t nAgg, const int32_t *nbr, const double 
 void launch_mg_zero(int64_t n, double *v, const double *scal, int it, const double *stop, hipStream_t s);
 void launch_tl_rap_agg(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const int32_t *binCoord, const int32_t *rowPtr,
                        const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly = false, int64_t nOwnedRows = 0,
-                       double *stencil = nullptr, int *farCount = nullptr);
+                       double *stencil = nullptr, int *farCount = nullptr, const int *wrapNb = nullptr);
 bool dense_spd_inverse_device(double *A, double *X, double *Ainv, double *Dinv, int64_t mp, int *notSpdDev, hipStream_t s);
 void launch_tl_gemv(int64_t m, int64_t ld, const double *A, const double *x, double *y, hipStream_t s);
 void launch_tl_prep(int64_t m, int64_t mp, const double *Ac, const uint8_t *dead, double maxd, double *Ap, hipStream_t s);

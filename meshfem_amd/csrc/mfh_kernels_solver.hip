@@ -243,6 +243,9 @@ __global__ void __launch_bounds__(256) k_tl_rap(TLArgs t, int64_t nRows, const i
     }
 }
 
+// offset between two bins of a lattice that is periodic with nb bins along this axis (nb <= 2: every bin is adjacent anyway)
+DEV int lattice_wrap(int d, int nb) { return nb > 2 ? (d == nb - 1 ? -1 : (d == 1 - nb ? 1 : d)) : d; }
+
 // Galerkin product, aggregate-centric: one workgroup (8 waves) per ROW aggregate walks that aggregate's rows; the rows
 // (a, .) of the coarse operator are written by this workgroup alone, so nothing needs a global atomic:
 //   * blocks whose column lies in the same aggregate (the vast majority) are summed in registers over ALL rows of the wave;
@@ -255,7 +258,9 @@ __global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__r
                                                      const int32_t *__restrict__ binCoord /* nAgg x 3, may be null */,
                                                      const int32_t *__restrict__ rowPtr, const int32_t *__restrict__ colIdx,
                                                      const double *__restrict__ vals, double *__restrict__ Ac, int upperOnly, int64_t nOwnedRows,
-                                                     double *__restrict__ stencil, int *__restrict__ farCount) {
+                                                     double *__restrict__ stencil, int *__restrict__ farCount, int wrapX, int wrapY, int wrapZ) {
+    // wrapA > 2: the lattice is periodic along that axis with wrapA bins (periodic DoF maps: elements at the seam couple the first and
+    // the last bin), offsets +-(wrapA - 1) count as -+1
     // stencil != null (multigrid hierarchy, mfh_multigrid.cpp): the rows (a, .) go to the lattice-stencil storage
     // stencil[(a NSLOT + slot) NM^2 + k NM + l] (slot = the neighbour's lattice offset, centre = the aggregate itself) instead of the
     // dense matrix; a block reaching a non-adjacent aggregate cannot be stored there and is counted in farCount (the caller coarsens less).
@@ -329,7 +334,8 @@ __global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__r
             }
             int slot = -1;
             if (binCoord) {
-                const int dx = binCoord[b * 3] - ca[0], dy = binCoord[b * 3 + 1] - ca[1], dz = binCoord[b * 3 + 2] - ca[2];
+                int dx = binCoord[b * 3] - ca[0], dy = binCoord[b * 3 + 1] - ca[1], dz = binCoord[b * 3 + 2] - ca[2];
+                dx = lattice_wrap(dx, wrapX); dy = lattice_wrap(dy, wrapY); dz = lattice_wrap(dz, wrapZ);
                 if (dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1) slot = (dx + 1) + 3 * (dy + 1) + (DIM == 3 ? 9 * (dz + 1) : 0);
             }
             if (slot >= 0) {
@@ -1457,14 +1463,16 @@ __global__ void __launch_bounds__(256) k_st_cheb(int64_t nAgg, const double *__r
 // Galerkin product between two aggregate levels: Ac[parent(a)][offset] += T_a^T A[a][slot] T_b
 template <int DIM>
 __global__ void __launch_bounds__(256) k_st_rap(int64_t nAgg, const int32_t *__restrict__ nbr, const double *__restrict__ A, const int32_t *__restrict__ parent,
-                                                const double *__restrict__ rel, const int32_t *__restrict__ coordC, double *__restrict__ Ac) {
+                                                const double *__restrict__ rel, const int32_t *__restrict__ coordC, double *__restrict__ Ac, int wrapX, int wrapY,
+                                                int wrapZ) {
     constexpr int NM = StDims<DIM>::NM, NS = StDims<DIM>::NS;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nAgg * NS; q += (int64_t)gridDim.x * 256) {
         const int64_t a = q / NS;
         const int b = nbr[q];
         if (b < 0) continue;
         const int pa = parent[a], pb = parent[b];
-        const int dx = coordC[pb * 3] - coordC[pa * 3], dy = coordC[pb * 3 + 1] - coordC[pa * 3 + 1], dz = coordC[pb * 3 + 2] - coordC[pa * 3 + 2];
+        const int dx = lattice_wrap(coordC[pb * 3] - coordC[pa * 3], wrapX), dy = lattice_wrap(coordC[pb * 3 + 1] - coordC[pa * 3 + 1], wrapY),
+                  dz = lattice_wrap(coordC[pb * 3 + 2] - coordC[pa * 3 + 2], wrapZ);
         const int cs = (dx + 1) + 3 * (dy + 1) + (DIM == 3 ? 9 * (dz + 1) : 0);
         const double *B = A + q * NM * NM;
         // W = B T_b (columns: parent modes of b), then C = T_a^T W
@@ -1663,9 +1671,10 @@ __global__ void __launch_bounds__(256) k_tl_mirror_upper(double *__restrict__ Ac
 
 void launch_tl_rap_agg(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const int32_t *binCoord, const int32_t *rowPtr,
                        const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly, int64_t nOwnedRows, double *stencil,
-                       int *farCount) {
-    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap_agg<3>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows, stencil, farCount);
-    else hipLaunchKernelGGL(k_tl_rap_agg<2>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows, stencil, farCount);
+                       int *farCount, const int *wrapNb) {
+    const int wx = wrapNb ? wrapNb[0] : 0, wy = wrapNb ? wrapNb[1] : 0, wz = wrapNb ? wrapNb[2] : 0;
+    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap_agg<3>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows, stencil, farCount, wx, wy, wz);
+    else hipLaunchKernelGGL(k_tl_rap_agg<2>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows, stencil, farCount, wx, wy, wz);
     if (stencil) { CHECK_LAUNCH(); return; }
     if (upperOnly) {
         const int64_t m = (int64_t)t.nAgg * (t.dim == 3 ? 6 : 3);
@@ -1904,8 +1913,10 @@ void launch_st_cheb(int dim, int64_t nAgg, const double *Dinv, const double *rin
                     bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s) {
     ST_DISPATCH(dim, k_st_cheb, grid_for(nAgg), nAgg, Dinv, rin, t, rout, d, x, a, b, first ? 1 : 0, assign ? 1 : 0, mk_gate(scal, it, stop));
 }
-void launch_st_rap(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const int32_t *parent, const double *rel, const int32_t *coordC, double *Ac, hipStream_t s) {
-    ST_DISPATCH(dim, k_st_rap, grid_for(nAgg * 27), nAgg, nbr, A, parent, rel, coordC, Ac);
+void launch_st_rap(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const int32_t *parent, const double *rel, const int32_t *coordC, double *Ac,
+                   const int *wrapNbC, hipStream_t s) {
+    const int wx = wrapNbC ? wrapNbC[0] : 0, wy = wrapNbC ? wrapNbC[1] : 0, wz = wrapNbC ? wrapNbC[2] : 0;
+    ST_DISPATCH(dim, k_st_rap, grid_for(nAgg * 27), nAgg, nbr, A, parent, rel, coordC, Ac, wx, wy, wz);
 }
 void launch_st_restrict(int dim, int64_t nAgg, const int32_t *parent, const double *rel, const double *r, const double *t, double *rc, const double *scal, int it,
                         const double *stop, hipStream_t s) {

@@ -132,8 +132,10 @@ void build_neighbours(int dim, mfh_ctx::AggLevel &A, hipStream_t s) {
     std::vector<int32_t> nbr((size_t)A.nAgg * NS, -1);
     for (int64_t a = 0; a < A.nAgg; ++a)
         for (int sl = 0; sl < NS; ++sl) {
-            const int32_t q[3] = {A.hCoord[(size_t)a * 3] + sl % 3 - 1, A.hCoord[(size_t)a * 3 + 1] + (sl / 3) % 3 - 1,
-                                  A.hCoord[(size_t)a * 3 + 2] + (dim == 3 ? sl / 9 - 1 : 0)};
+            int32_t q[3] = {A.hCoord[(size_t)a * 3] + sl % 3 - 1, A.hCoord[(size_t)a * 3 + 1] + (sl / 3) % 3 - 1,
+                            A.hCoord[(size_t)a * 3 + 2] + (dim == 3 ? sl / 9 - 1 : 0)};
+            for (int k2 = 0; k2 < 3; ++k2)                     // periodic axes: the first and the last bin are neighbours
+                if (A.wrap[k2] > 2) q[k2] = (q[k2] + A.wrap[k2]) % A.wrap[k2];
             auto itf = idOf.find(pack_coord(q));
             if (itf != idOf.end()) nbr[(size_t)a * NS + sl] = itf->second;
         }
@@ -170,6 +172,11 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
         build_aggregates_device(dim, nD, dPos, target, s, A, G.aggOfDof2, G.relPos2, G.aggPtr2, G.dofsByAgg2);
         L0.reset(new mfh_ctx::AggLevel());
         L0->nAgg = A.nAgg; L0->H = A.H; L0->hCoord = A.binCoord; L0->hCentre = A.centroid;
+        for (int k2 = 0; k2 < 3; ++k2) {
+            L0->nb[k2] = A.nb[k2];
+            // a periodic DoF map identifies nodes of opposite cell faces: elements at the seam couple the first and the last bin
+            L0->wrap[k2] = (!c1->dofForNode.empty() && k2 < dim && !(c->periodicIgnoreDims & (1 << k2))) ? A.nb[k2] : 0;
+        }
         build_neighbours(dim, *L0, s);
         L0->A.alloc((size_t)A.nAgg * NS * NM * NM);
         far.zero(s);
@@ -177,7 +184,7 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
         ta.dim = dim; ta.nModes = NM; ta.nAgg = A.nAgg; ta.nDoF = c1->sym.nRows; ta.aggOfDof = G.aggOfDof2.p; ta.relPos = G.relPos2.p;
         ta.fixedMask = c1->fixedVars.empty() ? nullptr : c1->dFixedMask.p;
         k::launch_tl_rap_agg(ta, G.aggPtr2.p, G.dofsByAgg2.p, L0->coord.p, c1->dRowPtr.p, c1->dColIdx.p, c1->dVals.p, nullptr, s, false, c1->sym.nRows,
-                             L0->A.p, far.p);
+                             L0->A.p, far.p, L0->wrap);
         int nFar = 0;
         far.download(&nFar, 1, s);
         if (nFar == 0) break;
@@ -209,6 +216,7 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
         for (int64_t p = 0; p < Cn->nAgg; ++p)
             for (int k2 = 0; k2 < 3; ++k2) Cn->hCentre[(size_t)p * 3 + k2] /= cnt[(size_t)p];
         Cn->H = 2.0 * F.H;
+        for (int k2 = 0; k2 < 3; ++k2) { Cn->nb[k2] = (F.nb[k2] + 1) / 2; Cn->wrap[k2] = F.wrap[k2] > 0 ? Cn->nb[k2] : 0; }
         std::vector<double> rel((size_t)F.nAgg * 4);
         for (int64_t a = 0; a < F.nAgg; ++a) {
             for (int k2 = 0; k2 < 3; ++k2) rel[(size_t)a * 4 + k2] = (F.hCentre[(size_t)a * 3 + k2] - Cn->hCentre[(size_t)parent[(size_t)a] * 3 + k2]) / Cn->H;
@@ -219,7 +227,7 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
         build_neighbours(dim, *Cn, s);
         Cn->A.alloc((size_t)Cn->nAgg * NS * NM * NM);
         Cn->A.zero(s);
-        k::launch_st_rap(dim, F.nAgg, F.nbr.p, F.A.p, F.parent.p, F.rel.p, Cn->coord.p, Cn->A.p, s);
+        k::launch_st_rap(dim, F.nAgg, F.nbr.p, F.A.p, F.parent.p, F.rel.p, Cn->coord.p, Cn->A.p, Cn->wrap, s);
         G.agg.push_back(std::move(Cn));
     }
     lap("coarser aggregate levels");

@@ -74,6 +74,7 @@ void build_aggregates(int dim, int64_t nDoF, const std::vector<double> &dofPos, 
 }
 
 void aggregate_lattice_tables(int dim, const int nb[3], const std::vector<int32_t> &binId, Aggregates &A) {
+    for (int a = 0; a < 3; ++a) A.nb[a] = nb[a];
     const int32_t nAgg = A.nAgg;
     // colours (3 x 3 x 3 on the bin lattice) and, per aggregate and colour, the unique aggregate of that
     // colour among its 3^dim lattice neighbours (K couples only DoFs of adjacent bins when H >> h)
