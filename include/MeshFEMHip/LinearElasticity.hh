@@ -11,6 +11,9 @@
 //       solve(f) / solve()                (:479-487,:657)  same, returns a per-node VField
 //       neumannLoad(), constantStrainLoad (:703-717,:551)  same
 //       applyPeriodicConditions(eps)      (:845-854)       same
+//       applyBoundaryConditions(conds)    (:881-1027)      same, conds from readBoundaryConditions (BoundaryConditions.hh)
+//       applyTranslationPins, applyPeriodicPairDirichletConditions, reportRegionSurfaceForces (:1087-1111,:1251-1270)  same
+//       setMaterial(Materials::Constant)  (Simulate_cli.cc:104-175)   same (Materials.hh reads the .material JSON)
 //       m_assembleStiffnessMatrix(K)      (:1408-1466)     same (upper triplets, summed)
 //       applyStiffnessMatrix(u)           (:801-823)       same
 //       averageStrainField/StressField    (:528-549)       same
@@ -33,6 +36,8 @@
 #include <vector>
 
 #include "../meshfem_hip.h"
+#include "BoundaryConditions.hh"
+#include "Materials.hh"
 
 namespace MeshFEMHip {
 
@@ -134,7 +139,191 @@ public:
         check(ctx(), mfh_material_ortho_field(ctx(), params.data()));
     }
 
-    // box-region boundary conditions (applyBoundaryConditions, :881-1027)
+    void setMaterial(const Materials::Constant<N> &mat) { setMaterialTensor(mat.getTensor().flat()); }
+
+    // ---- boundary conditions as the reference's condition objects (applyBoundaryConditions, :881-1027). Regions are
+    // matched here on the host against the mesh tables of the context (boundary nodes / boundary elements by vertex
+    // barycentre), expression values are evaluated per matched node / element, and the outcome is handed to the C ABI as
+    // node lists (mfh_bc_dirichlet_nodes: "Condition applied to non-boundary node", "Conflicting dirichlet displacements."),
+    // boundary-element tractions (mfh_bc_neumann_elements) and nodal forces (mfh_bc_delta_force).
+    void applyBoundaryConditions(const std::vector<CondPtr<N>> &conds) {
+        if (conds.empty()) return;
+        const Geometry &g = m_geometry();
+        ExpressionEnvironment env;
+        BBox<N> mbb = boundingBox();
+        env.setVectorValue("mesh_size_", mbb.dimensions());
+        env.setVectorValue("mesh_min_", mbb.minCorner);
+        env.setVectorValue("mesh_max_", mbb.maxCorner);
+        const size_t nBE = g.area.size(), npbe = nBE ? g.beNodes.size() / nBE : 0;
+        auto beCentre = [&](size_t b) {
+            VectorND<N> c{};
+            for (size_t k = 0; k < N; ++k) for (size_t d = 0; d < N; ++d) c[d] += g.pos[(size_t)g.beNodes[b * npbe + k]][d];
+            for (size_t d = 0; d < N; ++d) c[d] /= (Real)N;
+            return c;
+        };
+        auto setDirichlet = [&](const std::vector<int64_t> &nodes, const std::vector<VectorND<N>> &vals, const ComponentMask &mask) {
+            if (nodes.empty()) return;
+            check(ctx(), mfh_bc_dirichlet_nodes(ctx(), (int64_t)nodes.size(), nodes.data(), &vals[0][0], mask.bits(N)));
+        };
+        auto setTractions = [&](const std::vector<int64_t> &bes, const std::vector<VectorND<N>> &t) {
+            if (bes.empty()) return;
+            check(ctx(), mfh_bc_neumann_elements(ctx(), (int64_t)bes.size(), bes.data(), &t[0][0]));
+        };
+        for (const auto &cond : conds) {
+            env.setVectorValue("region_size_", cond->region->dimensions());
+            env.setVectorValue("region_min_", cond->region->minCorner);
+            env.setVectorValue("region_max_", cond->region->maxCorner);
+            if (auto nc = dynamic_cast<const NeumannCondition<N> *>(cond.get())) {
+                Real regionArea = 0;
+                std::vector<int64_t> region;
+                std::vector<VectorND<N>> tractions;
+                for (size_t b = 0; b < nBE; ++b) {
+                    VectorND<N> centre = beCentre(b);
+                    if (!nc->containsPoint(centre)) continue;
+                    env.setXYZ(centre);
+                    regionArea += g.area[b];
+                    region.push_back((int64_t)b);
+                    VectorND<N> t;
+                    if (nc->type == NeumannType::Pressure) {
+                        Real p = nc->pressure(env);
+                        for (size_t d = 0; d < N; ++d) t[d] = -p * g.normal[b * N + d];
+                    } else t = nc->traction(env);
+                    tractions.push_back(t);
+                }
+                if (region.empty()) throw std::runtime_error("Neumann region unmatched");
+                if (nc->type == NeumannType::Force)                 // a total force, spread uniformly over the region
+                    for (auto &t : tractions) for (auto &x : t) x /= regionArea;
+                setTractions(region, tractions);
+            } else if (dynamic_cast<const TargetCondition<N> *>(cond.get()) || dynamic_cast<const TargetNodesCondition<N> *>(cond.get())) {
+                fprintf(stderr, "WARNING: ignoring target boundary conditions.\n");
+            } else if (auto dc = dynamic_cast<const DirichletCondition<N> *>(cond.get())) {
+                ++m_dirichletRegionCount;
+                std::vector<int64_t> nodes;
+                std::vector<VectorND<N>> vals;
+                for (int32_t n : g.bdryNodes) {
+                    const VectorND<N> &p = g.pos[(size_t)n];
+                    if (!dc->containsPoint(p)) continue;
+                    env.setXYZ(p);
+                    nodes.push_back(n);
+                    vals.push_back(dc->displacement(env));
+                    m_dirichletRegionOfNode[(size_t)n] = m_dirichletRegionCount;
+                }
+                setDirichlet(nodes, vals, dc->componentMask);
+            } else if (auto dec = dynamic_cast<const DirichletElementsCondition<N> *>(cond.get())) {
+                ++m_dirichletRegionCount;
+                std::vector<int64_t> nodes;
+                std::vector<VectorND<N>> vals;
+                for (size_t b = 0; b < nBE; ++b) {
+                    IVectorND<N> idx;
+                    for (size_t k = 0; k < N; ++k) idx[k] = (size_t)g.beNodes[b * npbe + k];
+                    if (!dec->containsElement(idx)) continue;
+                    for (size_t k = 0; k < npbe; ++k) {
+                        int32_t n = g.beNodes[b * npbe + k];
+                        env.setXYZ(g.pos[(size_t)n]);
+                        nodes.push_back(n);
+                        vals.push_back(dec->displacement(env));
+                        m_dirichletRegionOfNode[(size_t)n] = m_dirichletRegionCount;
+                    }
+                }
+                setDirichlet(nodes, vals, dec->componentMask);
+            } else if (auto nec = dynamic_cast<const NeumannElementsCondition<N> *>(cond.get())) {
+                size_t numSet = 0;
+                Real regionArea = 0;
+                std::vector<int64_t> bes;
+                std::vector<VectorND<N>> tractions;
+                std::vector<size_t> forceEntries;
+                for (size_t b = 0; b < nBE; ++b) {
+                    UnorderedTriplet elem((size_t)g.beNodes[b * npbe], (size_t)g.beNodes[b * npbe + 1], N == 3 ? (size_t)g.beNodes[b * npbe + 2] : 0);
+                    if (!nec->hasValueForElement(elem)) continue;
+                    const auto &val = nec->getValue(elem);
+                    VectorND<N> t;
+                    if (val.type == NeumannType::Pressure) for (size_t d = 0; d < N; ++d) t[d] = -val.pressure() * g.normal[b * N + d];
+                    else t = val.traction();
+                    if (val.type == NeumannType::Force) { regionArea += g.area[b]; forceEntries.push_back(bes.size()); }
+                    bes.push_back((int64_t)b);
+                    tractions.push_back(t);
+                    ++numSet;
+                }
+                if (numSet != nec->numElements()) throw std::runtime_error("Some element boundary conditions weren't matched.");
+                for (size_t e : forceEntries) for (auto &x : tractions[e]) x /= regionArea;
+                setTractions(bes, tractions);
+            } else if (auto dnc = dynamic_cast<const DirichletNodesCondition<N> *>(cond.get())) {
+                fprintf(stderr, "WARNING: dirichlet region index currently not set for DirichletNodesCondition; region force printout will be inaccurate.\n");
+                std::vector<int64_t> nodes(dnc->indices.begin(), dnc->indices.end());
+                setDirichlet(nodes, dnc->displacements, dnc->componentMask);
+            } else if (auto fc = dynamic_cast<const DeltaForceCondition<N> *>(cond.get())) {
+                for (size_t n = 0; n < g.pos.size(); ++n) {
+                    if (!fc->containsPoint(g.pos[n])) continue;
+                    env.setXYZ(g.pos[n]);
+                    VectorND<N> f = fc->force(env);
+                    check(ctx(), mfh_bc_delta_force(ctx(), (int64_t)n, f.data()));
+                }
+            } else if (auto fnc = dynamic_cast<const DeltaForceNodesCondition<N> *>(cond.get())) {
+                for (size_t i = 0; i < fnc->indices.size(); ++i) {
+                    size_t ni = fnc->indices[i];
+                    if (ni > m_numNodes) throw std::runtime_error("DeltaForceNodesCondition node index out of bounds: " + std::to_string(ni));
+                    check(ctx(), mfh_bc_delta_force(ctx(), (int64_t)ni, fnc->forces[i].data()));
+                }
+            } else throw std::runtime_error("Illegal BC type");
+        }
+    }
+    // component d of the boundary node with the smallest coordinate d is pinned to zero (:1095-1111)
+    void applyTranslationPins(const ComponentMask &c) {
+        const Geometry &g = m_geometry();
+        for (size_t d = 0; d < N; ++d) {
+            if (!c.has(d) || g.bdryNodes.empty()) continue;
+            int32_t best = g.bdryNodes[0];
+            for (int32_t n : g.bdryNodes) if (g.pos[(size_t)n][d] < g.pos[(size_t)best][d]) best = n;
+            ComponentMask dmask;
+            dmask.set(d);
+            int64_t node = best;
+            VectorND<N> zero{};
+            check(ctx(), mfh_bc_dirichlet_nodes(ctx(), 1, &node, zero.data(), dmask.bits(N)));
+        }
+    }
+    void applyPeriodicPairDirichletConditions(std::vector<PeriodicPairDirichletCondition<N>> &pps) {     // :1087-1093
+        const Geometry &g = m_geometry();
+        std::vector<VectorND<N>> bpos;
+        for (int32_t n : g.bdryNodes) bpos.push_back(g.pos[(size_t)n]);
+        BBox<N> bb = boundingBox();
+        for (auto &pp : pps) {
+            auto p = pp.pair(bpos, bb);
+            int64_t nodes[2] = {g.bdryNodes[p.first], g.bdryNodes[p.second]};
+            std::array<VectorND<N>, 2> zero{};
+            check(ctx(), mfh_bc_dirichlet_nodes(ctx(), 2, nodes, &zero[0][0], pp.component().bits(N)));
+        }
+    }
+    void removeBoundaryConditions() {                            // mfh_bc_clear: Dirichlet, Neumann and delta forces
+        check(ctx(), mfh_bc_clear(ctx()));
+        m_dirichletRegionOfNode.clear();
+        m_dirichletRegionCount = 0;
+    }
+    // K u summed over the boundary nodes of every Dirichlet region; entry 0 collects the boundary nodes outside all of
+    // them (reportRegionSurfaceForces, :1251-1270)
+    std::vector<VectorND<N>> regionSurfaceForces(const VField &uNodes) const {
+        const Geometry &g = m_geometry();
+        if (m_numDoFs != m_numNodes) throw std::runtime_error("regionSurfaceForces: not available under periodic conditions");
+        VField f = applyStiffnessMatrix(uNodes);
+        std::vector<VectorND<N>> forces(m_dirichletRegionCount + 1, VectorND<N>{});
+        for (int32_t n : g.bdryNodes) {
+            auto it = m_dirichletRegionOfNode.find((size_t)n);
+            size_t r = it == m_dirichletRegionOfNode.end() ? 0 : it->second;
+            for (size_t d = 0; d < N; ++d) forces[r][d] += f[(size_t)n][d];
+        }
+        return forces;
+    }
+    void reportRegionSurfaceForces(const VField &uNodes) const {
+        auto forces = regionSurfaceForces(uNodes);
+        for (size_t r = 0; r < forces.size(); ++r) {
+            printf("region %zu surface force:", r);
+            for (size_t d = 0; d < N; ++d) printf("\t%.10g", forces[r][d]);
+            printf("\n");
+        }
+    }
+    BBox<N> boundingBox() const { return BBox<N>(m_geometry().pos); }
+    std::vector<int32_t> boundaryNodes() const { return m_geometry().bdryNodes; }
+
+    // box-region boundary conditions, straight to the C ABI
     void applyDirichletBox(const std::array<Real, N> &mn, const std::array<Real, N> &mx, const std::array<Real, N> &value,
                            bool relative = false, int componentMask = (1 << N) - 1) {
         check(ctx(), mfh_bc_dirichlet_box(ctx(), mn.data(), mx.data(), relative, value.data(), componentMask));
@@ -152,6 +341,7 @@ public:
     // new vertex positions on the same connectivity (:1279-1284): every setup phase is kept, elements are re-embedded
     void updateMeshNodePositions(const std::vector<std::array<Real, N>> &vertices) {
         check(ctx(), mfh_mesh_update_vertices(ctx(), &vertices[0][0]));
+        m_geo.valid = false;
     }
     void removePeriodicConditions() {                            // :874-879
         check(ctx(), mfh_dof_map(ctx(), nullptr, 0));
@@ -271,6 +461,32 @@ private:
     size_t m_numNodes = 0, m_numDoFs = 0;
     bool m_usePin = false, m_noRigidMotion = false;
     std::vector<Real> m_rigidMotionRHS;
+    // host copies of the mesh tables the condition matching reads (fetched once, refreshed after a vertex update)
+    struct Geometry {
+        bool valid = false;
+        VField pos;
+        std::vector<int32_t> bdryNodes, beNodes;
+        std::vector<Real> area, normal;
+    };
+    mutable Geometry m_geo;
+    std::map<size_t, size_t> m_dirichletRegionOfNode;            // BoundaryNode::dirichletRegionIdx
+    size_t m_dirichletRegionCount = 0;
+    const Geometry &m_geometry() const {
+        if (m_geo.valid) return m_geo;
+        int64_t nBE = 0, nBN = 0;
+        int32_t npbe = 0;
+        check(ctx(), mfh_mesh_sizes(ctx(), nullptr, nullptr, nullptr, &nBE, &nBN, nullptr, &npbe));
+        m_geo.pos = nodes();
+        m_geo.bdryNodes.resize((size_t)nBN);
+        m_geo.beNodes.resize((size_t)nBE * (size_t)npbe);
+        m_geo.area.resize((size_t)nBE);
+        m_geo.normal.resize((size_t)nBE * N);
+        check(ctx(), mfh_mesh_get_boundary_nodes(ctx(), m_geo.bdryNodes.data()));
+        check(ctx(), mfh_mesh_get_boundary_elem_nodes(ctx(), m_geo.beNodes.data()));
+        check(ctx(), mfh_mesh_get_boundary_elem_geometry(ctx(), m_geo.area.data(), m_geo.normal.data()));
+        m_geo.valid = true;
+        return m_geo;
+    }
     int32_t m_flags() const { return (m_usePin ? MFH_SOLVE_PIN : 0) | (m_noRigidMotion ? MFH_SOLVE_NO_RIGID_MOTION : 0); }
 };
 

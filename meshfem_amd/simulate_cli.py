@@ -11,7 +11,8 @@ type dirichlet[xyz] / force / traction / pressure / delta force (BoundaryConditi
 expression-valued (`"sin(pi * x)"`, tinyexpr grammar: meshfem_amd/expressions.py), `dirichlet nodes` /
 `delta force nodes` lists, `traction | pressure | force elements` lists, `dirichlet elements`, and path / polygon
 regions (Geometry.hh:68-191); top-level `no_rigid_motion`, `pin_translation` and `fix_periodic_pair_<c>`.
-Not supported: target / contact / fracture conditions (no counterpart in a linear solve).
+target conditions are skipped with the reference's warning, contact / fracture conditions are "Illegal BC type"
+(LinearElasticity.hh:933-938,:1024).
 Writes the fields u, load, strain, stress, Ku like Simulate_cli.cc:207-242."""
 import argparse
 import json
@@ -189,6 +190,11 @@ def apply_boundary_conditions(sim, path):
             if k:
                 comps = ["xyz"[a] in rest[:k] for a in range(N)]
             t = "dirichlet" + rest[k:]
+        if t.startswith("target"):                            # TargetCondition / TargetNodesCondition are not Dirichlet
+            print("WARNING: ignoring target boundary conditions.", file=sys.stderr)     # conditions (:933-938)
+            continue
+        if t in ("contact", "fracture"):
+            raise RuntimeError("Illegal BC type")              # :1024
         if t == "dirichlet" and hasattr(sim, "ctx"):        # region index of the boundary nodes inside (:939-949)
             n_dirichlet_regions += 1
             if ("box" in r or "box%" in r) and not _is_expression_vector(r["value"]):
