@@ -67,7 +67,8 @@ enum {
     MFH_PRECOND_TWO_LEVEL = 3,
     /* p-multigrid V-cycle for quadratic elasticity: Chebyshev-smoothed quadratic level (matrix-free operator) -> linear level on the
      * same vertices (its assembled stiffness matrix IS the Galerkin operator: P1 is a subspace of P2) -> rigid-body modes of
-     * aggregates (dense inverse). Mesh-independent iteration counts (tens instead of hundreds); one right-hand side at a time on an
+     * aggregates, merged 2^dim at a time down to a dense inverse. Linear elements enter the same hierarchy at its linear level (their own
+     * assembled K). Mesh-independent iteration counts (tens instead of hundreds); one right-hand side at a time on an
      * unpartitioned context, otherwise falls back to MFH_PRECOND_TWO_LEVEL (see mfh_precond_info). Options "mg_steps_fine",
      * "mg_steps_coarse", "mg_ratio_fine", "mg_ratio_coarse", "mg_agg_nodes". */
     MFH_PRECOND_MULTIGRID = 4
@@ -227,7 +228,8 @@ mfh_status mfh_set_preconditioner(mfh_ctx* ctx, int32_t kind);
 /* coarse-space facts of the last two-level setup: aggregates, coarse dimension, setup time (ms); note = why it fell back (or "") */
 mfh_status mfh_precond_info(const mfh_ctx* ctx, int32_t* nAggregates, int64_t* coarseDim, double* setup_ms, const char** note);
 /* the hierarchy MFH_PRECOND_MULTIGRID built at the last solve: DoFs of the quadratic and of the linear level, the largest eigenvalues
- * of their Jacobi-preconditioned operators (the Chebyshev smoothers' upper bounds), setup time; zeros when it is not in use */
+ * of their Jacobi-preconditioned operators (the Chebyshev smoothers' upper bounds), setup time; zeros when it is not in use. On
+ * linear elements there is no quadratic level: fineDoF == coarseDoF and lambdaMaxFine == 0. */
 mfh_status mfh_multigrid_info(const mfh_ctx* ctx, int64_t* fineDoF, int64_t* coarseDoF, double* lambdaMaxFine, double* lambdaMaxCoarse,
                               double* setup_ms);
 mfh_status mfh_solve(mfh_ctx* ctx, int32_t nrhs, const double* f, double* u,

@@ -1590,10 +1590,11 @@ mfh_status mfh_precond_info(const mfh_ctx *c, int32_t *nAgg, int64_t *coarseDim,
     if (!c) return MFH_ERR_INVALID;
     // with the multigrid hierarchy in use: the aggregates below its linear level (the finest aggregate level), the dimension of the
     // level that is inverted densely, the setup time of the whole hierarchy
-    if (c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && c->mg.coarse) {
+    if (c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && (c->mg.coarse || c->mg.linearOnly)) {
         const bool hier = !c->mg.agg.empty();
-        if (nAgg) *nAgg = hier ? (int32_t)c->mg.agg[0]->nAgg : (c->mg.coarse->tl.valid ? c->mg.coarse->tl.nAgg : 0);
-        if (coarseDim) *coarseDim = hier ? c->mg.denseM : (c->mg.coarse->tl.valid ? c->mg.coarse->tl.m : 0);
+        const mfh_ctx *lin = c->mg.linearOnly ? c : c->mg.coarse;           // the context of the linear level
+        if (nAgg) *nAgg = hier ? (int32_t)c->mg.agg[0]->nAgg : (lin->tl.valid ? lin->tl.nAgg : 0);
+        if (coarseDim) *coarseDim = hier ? c->mg.denseM : (lin->tl.valid ? lin->tl.m : 0);
         if (setup_ms) *setup_ms = c->mg.setup_ms;
         if (note) *note = c->precondNote.c_str();
         return MFH_OK;

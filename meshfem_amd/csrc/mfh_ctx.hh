@@ -152,6 +152,7 @@ struct mfh_ctx {
     };
     struct Multigrid {
         bool valid = false, rigidCoarse = false;
+        bool linearOnly = false;                 // linear elements: no quadratic level, the context itself is the linear level
         mfh_ctx *coarse = nullptr;    // owned: the linear level
         int64_t nFine = 0, nCoarse = 0;
         DBuf<int32_t> parA, parB, fineOf, resPtr, resIdx;

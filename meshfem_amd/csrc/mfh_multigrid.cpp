@@ -183,7 +183,7 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
         k::TLArgs ta{};
         ta.dim = dim; ta.nModes = NM; ta.nAgg = A.nAgg; ta.nDoF = c1->sym.nRows; ta.aggOfDof = G.aggOfDof2.p; ta.relPos = G.relPos2.p;
         ta.fixedMask = c1->fixedVars.empty() ? nullptr : c1->dFixedMask.p;
-        k::launch_tl_rap_agg(ta, G.aggPtr2.p, G.dofsByAgg2.p, L0->coord.p, c1->dRowPtr.p, c1->dColIdx.p, c1->dVals.p, nullptr, s, false, c1->sym.nRows,
+        k::launch_tl_rap_agg(ta, G.aggPtr2.p, G.dofsByAgg2.p, L0->coord.p, c1->dRowPtr.p, c1->dColIdx.p, c1->dVals.p, nullptr, s, c1->upperOnly, c1->sym.nRows,
                              L0->A.p, far.p, L0->wrap);
         int nFar = 0;
         far.download(&nFar, 1, s);
@@ -282,6 +282,7 @@ void agg_cycle(mfh_ctx *c, size_t l, const double *scal, int it, const double *s
 void destroy_multigrid(mfh_ctx *c) {
     auto &G = c->mg;
     G.valid = false;
+    G.linearOnly = false;
     G.agg.clear();
     if (G.coarse) { mfh_destroy(G.coarse); G.coarse = nullptr; }
 }
@@ -292,8 +293,8 @@ bool ensure_multigrid(mfh_ctx *c) {
     if (G.valid) return true;
     c->precondNote.clear();
     const HostMesh &m = c->mesh;
-    if (c->op != MFH_OP_ELASTICITY || c->external || !c->haveMesh || m.deg != 2) {
-        c->precondNote = "p-multigrid needs quadratic elasticity elements: using the two-level preconditioner";
+    if (c->op != MFH_OP_ELASTICITY || c->external || !c->haveMesh) {
+        c->precondNote = "multigrid is built for the elasticity operator of a mesh: using the two-level preconditioner";
         return false;
     }
     if (c->sym.nRows != c->sym.nCols) {
@@ -314,6 +315,28 @@ bool ensure_multigrid(mfh_ctx *c) {
         fprintf(stderr, "[multigrid setup] %-34s %8.2f ms\n", what, t - tp);
         tp = t;
     };
+    if (m.deg == 1) {
+        // linear elements: the context itself is the linear level -- smoother on its assembled K, the aggregate hierarchy below it
+        G.linearOnly = true;
+        ensure_precond(c);
+        lap("assembly + block-Jacobi");
+        bool haveCoarse = build_aggregate_hierarchy(c, c, lap);
+        if (!haveCoarse) {
+            haveCoarse = ensure_twolevel(c);
+            lap("rigid-body coarse (dense)");
+        }
+        G.nFine = G.nCoarse = nDoF;
+        const int64_t n1 = (int64_t)d * nDoF;
+        G.r1.alloc((size_t)n1); G.d1.alloc((size_t)n1); G.t1.alloc((size_t)n1);
+        G.lmax0 = 0;
+        G.lmax1 = c->mgEigMargin * estimate_lambda_max(c, nodal_ops(c, nullptr, 0, nullptr), G.r1.p, G.d1.p, G.t1.p);
+        lap("eigenvalue estimate");
+        G.rigidCoarse = haveCoarse;
+        G.setup_ms = now_ms() - t0;
+        G.valid = true;
+        if (!haveCoarse) c->precondNote = "multigrid: no rigid-body coarse level (" + c->precondNote + "); the linear level is smoothed only";
+        return true;
+    }
     // A mesh in the library's own numbering (mfh_mesh_build: vertices are the nodes [0, nVert)) with the identity DoF map takes the
     // device route for the transfer lists; any other node table / a periodic DoF map goes through the host loops below.
     const bool ownNumbering = m.hasTopology && c->dofForNode.empty();
@@ -456,26 +479,20 @@ bool ensure_multigrid(mfh_ctx *c) {
     return true;
 }
 
-// z = M^-1 r: one symmetric V-cycle. scal / it / stop: the gate of the PCG iteration this application belongs to (null: none).
-void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int it, const double *stop) {
+// The linear level: x = (approximately) K1^-1 b -- (smooth, aggregate / dense coarse correction, smooth) x mgCoarseCycles. Repeating
+// one symmetric stationary iteration keeps M symmetric.
+static void linear_level(mfh_ctx *c, mfh_ctx *c1, const double *b, double *x, const double *scal, int it, const double *stop) {
     auto &G = c->mg;
-    mfh_ctx *c1 = G.coarse;
     hipStream_t s = c->stream;
     const int d = c->bs();
-    LevelOps L0 = nodal_ops(c, scal, it, stop), L1 = nodal_ops(c1, scal, it, stop);
-    L0.lmax = G.lmax0; L0.ratio = c->mgRatio0; L0.steps = c->mgSteps0;
+    LevelOps L1 = nodal_ops(c1, scal, it, stop);
     L1.lmax = G.lmax1; L1.ratio = c->mgRatio1; L1.steps = c->mgSteps1;
-    const bool masked0 = !c->fixedVars.empty(), masked1 = !c1->fixedVars.empty();
-    // level 0, pre-smoothing from zero; residual r - K z = r0 - t0
-    const double *ra = nullptr, *rb = nullptr;
-    chebyshev(L0, r, z, true, true, G.r0.p, G.d0.p, G.t0.p, &ra, &rb);
-    k::launch_mg_restrict(d, G.nCoarse, G.fineOf.p, G.resPtr.p, G.resIdx.p, ra, rb, masked1 ? c1->dFixedMask.p : nullptr, G.b1.p, scal, it, stop, s);
-    // level 1: (smooth, coarse correction, smooth) x mgCoarseCycles -- repeating one symmetric stationary iteration keeps M symmetric
+    const bool masked1 = !c1->fixedVars.empty();
     for (int cyc = 0; cyc < c->mgCoarseCycles; ++cyc) {
         const double *qa = nullptr, *qb = nullptr;
-        chebyshev(L1, G.b1.p, G.x1.p, cyc == 0, G.rigidCoarse, G.r1.p, G.d1.p, G.t1.p, &qa, &qb);
+        chebyshev(L1, b, x, cyc == 0, G.rigidCoarse, G.r1.p, G.d1.p, G.t1.p, &qa, &qb);
         if (G.rigidCoarse) {
-            k::launch_mg_diff((int64_t)d * G.nCoarse, qa, qb, G.r1.p, scal, it, stop, s);               // residual of level 1
+            k::launch_mg_diff((int64_t)d * G.nCoarse, qa, qb, G.r1.p, scal, it, stop, s);               // residual of the linear level
             if (!G.agg.empty()) {             // aggregate hierarchy
                 mfh_ctx::AggLevel &A0 = *G.agg[0];
                 k::TLArgs ta{};
@@ -483,17 +500,37 @@ void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int 
                 ta.aggOfDof = G.aggOfDof2.p; ta.relPos = G.relPos2.p; ta.fixedMask = masked1 ? c1->dFixedMask.p : nullptr;
                 k::launch_tl_restrict(ta, G.aggPtr2.p, G.dofsByAgg2.p, G.r1.p, A0.b.p, s);
                 agg_cycle(c, 0, scal, it, stop);
-                k::launch_mg_tl_prolong_add(ta, A0.x.p, G.x1.p, c->mgOverCorrection, scal, it, stop, s);
+                k::launch_mg_tl_prolong_add(ta, A0.x.p, x, c->mgOverCorrection, scal, it, stop, s);
             } else {                          // the linear context's own dense coarse space (~1000 aggregates)
                 auto &T = c1->tl;
                 const k::TLArgs ta = tl_args(c1);
                 k::launch_tl_restrict(ta, T.aggPtr.p, T.dofsByAgg.p, G.r1.p, T.rc.p, s);
                 k::launch_tl_gemv(T.m, T.ldInv, T.Ainv.p, T.rc.p, T.yc.p, s);
-                k::launch_mg_tl_prolong_add(ta, T.yc.p, G.x1.p, c->mgOverCorrection, scal, it, stop, s);
+                k::launch_mg_tl_prolong_add(ta, T.yc.p, x, c->mgOverCorrection, scal, it, stop, s);
             }
         }
-        chebyshev(L1, G.b1.p, G.x1.p, false, false, G.r1.p, G.d1.p, G.t1.p);
+        chebyshev(L1, b, x, false, false, G.r1.p, G.d1.p, G.t1.p);
     }
+}
+
+// z = M^-1 r: one symmetric V-cycle. scal / it / stop: the gate of the PCG iteration this application belongs to (null: none).
+void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int it, const double *stop) {
+    auto &G = c->mg;
+    if (G.linearOnly) {                        // linear elements: the V-cycle starts on the context's own level
+        linear_level(c, c, r, z, scal, it, stop);
+        return;
+    }
+    mfh_ctx *c1 = G.coarse;
+    hipStream_t s = c->stream;
+    const int d = c->bs();
+    LevelOps L0 = nodal_ops(c, scal, it, stop);
+    L0.lmax = G.lmax0; L0.ratio = c->mgRatio0; L0.steps = c->mgSteps0;
+    const bool masked0 = !c->fixedVars.empty(), masked1 = !c1->fixedVars.empty();
+    // level 0, pre-smoothing from zero; residual r - K z = r0 - t0
+    const double *ra = nullptr, *rb = nullptr;
+    chebyshev(L0, r, z, true, true, G.r0.p, G.d0.p, G.t0.p, &ra, &rb);
+    k::launch_mg_restrict(d, G.nCoarse, G.fineOf.p, G.resPtr.p, G.resIdx.p, ra, rb, masked1 ? c1->dFixedMask.p : nullptr, G.b1.p, scal, it, stop, s);
+    linear_level(c, c1, G.b1.p, G.x1.p, scal, it, stop);
     // back to level 0: z += P x1, post-smoothing
     k::launch_mg_prolong_add(d, G.nFine, G.parA.p, G.parB.p, G.x1.p, masked0 ? c->dFixedMask.p : nullptr, z, scal, it, stop, s);
     chebyshev(L0, r, z, false, false, G.r0.p, G.d0.p, G.t0.p);

@@ -1,11 +1,12 @@
 """p-multigrid preconditioner: iteration counts and times over smoother settings, against the two-level preconditioner.
-    python scripts/mg_probe.py [grid] [k0,k1,ratio0,ratio1 ...]"""
+    python scripts/mg_probe.py [grid] [k0,k1,ratio0,ratio1 ...]        (MG_DEGREE=1: linear elements, BASELINE configs[1] at grid 55)"""
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import meshfem_amd as M
 from meshfem_amd import grid
 
@@ -13,7 +14,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 sets = [tuple(float(v) for v in a.split(",")) for a in sys.argv[2:]] or [(2, 4, 0.25, 0.05, 1)]
 V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
 c = M.Context(0)
-c.mesh_build(T, V, 2)
+c.mesh_build(T, V, int(os.environ.get("MG_DEGREE", "2")))
+print("%d elements, %d DoFs" % (len(T), 3 * c.n_dof), flush=True)
 c.material_isotropic(200.0, 0.35)
 c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
 c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)

@@ -172,12 +172,63 @@ def test_multigrid_on_a_caller_supplied_node_table():
     c.close()
 
 
-def test_multigrid_on_linear_elements_falls_back_with_a_note():
-    c, V, T = _cantilever(4, deg=1)
+@pytest.mark.parametrize("dim,n", [(3, 6), (2, 24)])
+def test_multigrid_on_linear_elements_matches_the_oracle(dim, n):
+    """Linear elements enter the hierarchy at its linear level: Chebyshev on the context's own assembled K, aggregates below."""
+    c, V, T = _cantilever(n, 1, dim)
     c.set_preconditioner(M.PRECOND_MULTIGRID)
     u = c.sim_solve(rtol=1e-10)
-    assert c.last_info["converged"] and "quadratic" in c.precond_info()["note"]
-    assert c.multigrid_info()["fine_dof"] == 0 and c.precond_info()["aggregates"] > 0          # the two-level construction took over
+    i, g, p = c.last_info, c.multigrid_info(), c.precond_info()
+    assert i["converged"] and i["true_rel_residual"] < 2e-10 and p["note"] == ""
+    assert g["fine_dof"] == g["coarse_dof"] == c.n_dof and g["lambda_max_fine"] == 0 and g["lambda_max_coarse"] > 1.0 and p["aggregates"] > 0
+    sim = O.Simulator(T, V, 1)
+    sim.set_material_constant(O.ElasticityTensor.isotropic(dim, 200.0, 0.35))
+    lo, hi = [-9.0] * dim, [9.0] * dim
+    lo[0], hi[0] = -1e-9, 1e-9
+    sim.apply_dirichlet_box(lo, hi, [0.0] * dim)
+    lo[0], hi[0] = 1 - 1e-9, 1 + 1e-9
+    sim.apply_neumann_box(lo, hi, [0.0, -1.0, 0.0][:dim], "traction")
+    uref = sim.solve()
+    assert np.linalg.norm(u - uref) / np.linalg.norm(uref) < U_RTOL
+    it_mg = i["iterations"]
     c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
-    assert np.linalg.norm(c.sim_solve(rtol=1e-10) - u) <= 1e-7 * np.linalg.norm(u)
+    u2 = c.sim_solve(rtol=1e-10)
+    assert np.linalg.norm(u2 - u) <= 1e-7 * np.linalg.norm(u) and it_mg < 0.5 * c.last_info["iterations"]
+    # deep hierarchy / dense-only variants on the same context
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    for opts in ({"mg_agg_target": 6, "mg_dense_max": 8}, {"mg_agg_target": 0}):
+        for k, v in opts.items():
+            c.set_option(k, v)
+        u3 = c.sim_solve(rtol=1e-10)
+        assert c.last_info["converged"] and np.linalg.norm(u3 - u) <= 1e-7 * np.linalg.norm(u), opts
+    c.close()
+
+
+def test_multigrid_on_linear_elements_iteration_count_does_not_grow_with_the_mesh():
+    """BASELINE configs[1] in small (linear tets, one face clamped, traction opposite)."""
+    its = {}
+    for n in (10, 20):
+        c, _, _ = _cantilever(n, 1)
+        c.set_preconditioner(M.PRECOND_MULTIGRID)
+        c.sim_solve(rtol=1e-8)
+        its[n] = c.last_info["iterations"]
+        c.set_preconditioner(M.PRECOND_TWO_LEVEL)
+        c.sim_solve(rtol=1e-8)
+        tl = c.last_info["iterations"]
+        c.close()
+        assert its[n] < tl, (n, its[n], tl)
+    assert its[20] <= 1.3 * its[10] + 3 and its[20] <= 60, its
+
+
+def test_multigrid_on_the_scalar_operators_falls_back_with_a_note():
+    V, T = grid.grid_tet_mesh(4, 4, 4, [0, 0, 0], [1, 1, 1])
+    c = M.Context(0)
+    c.mesh_build(T, V, 2)
+    c.set_operator(M.OP_LAPLACIAN)
+    c.bc_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9], [1.0, 0, 0], components=[True, False, False])
+    c.bc_dirichlet_box([1 - 1e-9, -9, -9], [1 + 1e-9, 9, 9], [0.0, 0, 0], components=[True, False, False])
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    x = c.sim_solve(rtol=1e-10)
+    assert c.last_info["converged"] and c.multigrid_info()["fine_dof"] == 0 and c.precond_info()["note"] != ""
+    assert np.abs(x.ravel() - (1 - c.node_positions()[:, 0])).max() < 1e-8            # the harmonic function 1 - x
     c.close()
