@@ -132,22 +132,27 @@ def cpu_direct_solve(deg, n, rtol):
     free = (3 * free_nodes[:, None] + np.arange(3)[None, :]).ravel()
     Kr = K[free][:, free]                          # SPSDSystem::fixVariables: eliminated rows / columns (:2389-2500)
     t_elim = time.perf_counter() - t0
-    # 16 BLAS threads: the fronts of this size are small enough that 64 OpenBLAS threads lose to 16 (measured 18.6 vs 12.2 s at 107 k DOF)
+    # the fronts one after the other on 16 BLAS threads: measured on this pool's 128-core hosts, 515 k DOF factor in 13.3 s
+    # (570 GFlop/s); more OpenBLAS threads lose on fronts of this size (64: 1.5x slower), and factoring independent subtrees on
+    # worker threads with single-threaded BLAS first (factor(workers=32)) ends slower too (19.9 s): the top fronts dominate
+    ncpu = os.cpu_count() or 1
+    workers, top_threads = 1, max(1, min(16, ncpu))
+    threads = top_threads
+    mf = DS.MultifrontalCholesky(Kr, pos[free_nodes], block=3)
+    mf.factor(workers=workers, blas_threads=top_threads)
     from threadpoolctl import threadpool_limits
-    with threadpool_limits(limits=min(16, os.cpu_count() or 1), user_api="blas"):
-        threads = DS.blas_threads()
-        mf = DS.MultifrontalCholesky(Kr, pos[free_nodes], block=3)
-        mf.factor()
+    with threadpool_limits(limits=top_threads, user_api="blas"):
         x = mf.solve(f[free])
     u = np.zeros(N)
     u[free] = x
     err = float(np.linalg.norm(u_gpu.ravel() - u) / np.linalg.norm(u))
     res = float(np.linalg.norm(Kr @ x - f[free]) / np.linalg.norm(f[free]))
     have_cholmod = ctypes.util.find_library("cholmod") is not None
-    return dict(kind="port of the method: multifrontal (supernodal) Cholesky, geometric nested dissection, LAPACK potrf/trsm/gemm on %d BLAS "
-                     "threads (oracle/direct_solve.py); CHOLMOD %s" % (threads, "found but not bound" if have_cholmod else "not installed on this box"),
+    return dict(kind="port of the method: multifrontal (supernodal) Cholesky, geometric nested dissection, LAPACK potrf/trsm/syrk on %d BLAS threads "
+                     "(oracle/direct_solve.py); CHOLMOD %s"
+                     % (top_threads, "found but not bound" if have_cholmod else "not installed on this box"),
                 sample="%d^3 grid -> %d P%d tets" % (n, len(T), deg), dof=int(N), free_dof=int(len(free)), cores=threads,
-                assemble_s=float(t["total"]), eliminate_s=t_elim, ordering_s=mf.t_order, factor_s=mf.t_factor, backsolve_s=mf.t_solve,
+                assemble_s=float(t["total"]), eliminate_s=t_elim, ordering_s=mf.t_order, factor_s=mf.t_factor, factor_subtrees_s=mf.t_subtrees, backsolve_s=mf.t_solve,
                 solve_s=mf.t_order + mf.t_factor + mf.t_solve,
                 time_to_solution_s=float(t["total"]) + t_elim + mf.t_order + mf.t_factor + mf.t_solve,
                 factor_nnz=int(mf.factor_nnz), factor_gflops=mf.flops / 1e9, supernodes=len(mf.kids), rel_residual=res,
@@ -206,10 +211,10 @@ def cpu_baseline_with_solve(args):
     out = cpu_baseline(args.deg, args.cpu_grid)
     try:
         ds = None
-        # grow the sample while the factorisation time (~ N^2) leaves room: 57 k, 107 k, 288 k, 501 k DOF for quadratic tets
-        for n in ([args.cpu_solve_grid] if args.cpu_solve_grid else [8, 10, 14, 17]):
+        # grow the sample while the factorisation time (~ N^2) leaves room: 289 k, 515 k DOF for quadratic tets (~5 s, ~15 s on 16 threads)
+        for n in ([args.cpu_solve_grid] if args.cpu_solve_grid else [14, 17]):
             ds = cpu_direct_solve(args.deg, n, args.rtol)
-            if ds["solve_s"] > 4.0:      # the next size costs ~4x (8 -> 10), ~7x (10 -> 14), ~3x (14 -> 17) as much
+            if ds["solve_s"] > 8.0:      # the next size costs ~3x as much
                 break
         out["direct_solve"] = ds
         out.update(solve_s=ds["solve_s"], dof=ds["dof"], solve_kind=ds["kind"])

@@ -153,6 +153,10 @@ struct mfh_ctx {
     struct Multigrid {
         bool valid = false, rigidCoarse = false;
         bool linearOnly = false;                 // linear elements: no quadratic level, the context itself is the linear level
+        bool distributed = false;                // row-partitioned context: nodal levels partitioned like it (halo exchanges inside the smoothers and the
+                                                 // transfers), aggregate levels replicated on every rank (one small all-reduce per application)
+        const void *distComm = nullptr;          // the communicator the hierarchy was built on
+        DBuf<double> rfull;                      // fine residual with its halo part (restriction reads the edge nodes of halo elements)
         mfh_ctx *coarse = nullptr;    // owned: the linear level
         int64_t nFine = 0, nCoarse = 0;
         DBuf<int32_t> parA, parB, fineOf, resPtr, resIdx;
@@ -188,6 +192,7 @@ struct mfh_ctx {
         std::vector<int32_t> peers;
         std::vector<int64_t> sendPtr{0}, recvPtr{0};
         DBuf<int32_t> sendIdx;
+        std::vector<int32_t> sendNodesHost;   // host copy of sendIdx (the linear level of the multigrid hierarchy filters it)
         DBuf<double> sendBuf;
         int sendBufW = 0;             // doubles per node the send buffer is sized for
         hipStream_t commStream = nullptr;
@@ -311,6 +316,13 @@ inline void require_full_storage(const mfh_ctx *c, const char *what) {
 inline int32_t dof_of(const mfh_ctx *c, int64_t node) { return c->dofForNode.empty() ? (int32_t)node : c->dofForNode[node]; }
 void invalidate_matrix(mfh_ctx *c);
 void dist_detach(mfh_ctx *c);
+bool dist_active(const mfh_ctx *c);
+int dist_rank(const mfh_ctx *c);
+int dist_world(const mfh_ctx *c);
+void dist_apply(mfh_ctx *c, double *x, double *y, bool masked);
+void dist_halo(mfh_ctx *c, double *v, int W);
+void dist_allreduce(mfh_ctx *c, double *dev, int64_t n);
+void dist_setup_child(mfh_ctx *c, mfh_ctx *child, const std::vector<int32_t> &keep);
 void dist_agree(mfh_ctx *c);
 void refresh_storage_rule(mfh_ctx *c);
 void reset_bcs(mfh_ctx *c);

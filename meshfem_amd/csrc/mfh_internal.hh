@@ -270,7 +270,9 @@ void aggregate_lattice_tables(int dim, const int nb[3], const std::vector<int32_
 void dof_positions_device(int64_t nNode, int dim, const int32_t *dDofForNode, const double *dNodePos, int64_t nDoF, hipStream_t s,
                           DBuf<double> &out);
 void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targetNodes, hipStream_t s, Aggregates &A,
-                             DBuf<int32_t> &dAggOfDof, DBuf<double> &dRelPos, DBuf<int32_t> &dAggPtr, DBuf<int32_t> &dDofsByAgg);
+                             DBuf<int32_t> &dAggOfDof, DBuf<double> &dRelPos, DBuf<int32_t> &dAggPtr, DBuf<int32_t> &dDofsByAgg,
+                             const double *globalBox = nullptr, int64_t globalCount = 0, bool fullLattice = false);
+void bounding_box_device(int dim, int64_t nDoF, const double *dPos, hipStream_t s, double mn[3], double mx[3]);
 bool spd_inverse_inplace(int64_t n, double *A);
 // transfer lists of the p-multigrid preconditioner on the device (meshes in the library's own numbering, identity DoF map)
 void build_mg_transfer_device(const HostMesh &m, const int32_t *dElemNodes, hipStream_t s, DBuf<int32_t> &parA, DBuf<int32_t> &parB,

@@ -31,6 +31,7 @@ struct LevelOps {
     std::function<void(const double *, double *)> apply;
     std::function<void(const double *rin, const double *t, double *rout, double *d, double *x, double a, double b, bool first, bool assign)> step;
     std::function<void(double *)> mask;                                   // zero the fixed variables (may be empty)
+    std::function<void(double *, int64_t)> reduce;                        // sum of device scalars over the ranks (row-partitioned levels)
     double lmax = 0, ratio = 0.3;
     int steps = 1;
 };
@@ -43,7 +44,12 @@ LevelOps nodal_ops(mfh_ctx *c, const double *scal, int it, const double *stop) {
     const bool masked = !c->fixedVars.empty();
     hipStream_t s = c->stream;
     L.n = nRows * d;
-    L.apply = [=](const double *x, double *y) { apply_operator(c, masked, x, y, nullptr); };
+    if (c->sym.nRows != c->sym.nCols) {
+        // row-partitioned level: the vectors the operator is applied to hold nCols block rows; their halo part is fetched first
+        L.apply = [=](const double *x, double *y) { dist_apply(c, const_cast<double *>(x), y, masked); };
+        L.reduce = [=](double *dev, int64_t n) { dist_allreduce(c, dev, n); };
+    } else
+        L.apply = [=](const double *x, double *y) { apply_operator(c, masked, x, y, nullptr); };
     L.step = [=](const double *rin, const double *t, double *rout, double *dv, double *x, double a, double b, bool first, bool assign) {
         k::launch_mg_cheb(d, nRows, c->dDinv.p, rin, t, rout, dv, x, a, b, first, assign, scal, it, stop, s);
     };
@@ -84,6 +90,7 @@ double estimate_lambda_max(mfh_ctx *c, const LevelOps &L, double *v, double *w, 
     MFH_HIP(hipMemsetAsync(c->stop.p + 1, 0, 2 * sizeof(double), s));
     k::launch_dot(L.n, a, a, c->stop.p + 1, s);
     k::launch_dot(L.n, b, b, c->stop.p + 2, s);
+    if (L.reduce) L.reduce(c->stop.p + 1, 2);
     double h[2] = {0, 0};
     MFH_HIP(hipMemcpyAsync(h, c->stop.p + 1, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
     MFH_HIP(hipStreamSynchronize(s));
@@ -166,10 +173,50 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
     DBuf<int> far;
     far.alloc(1);
     int target = c->mgAggTarget;
+    // row-partitioned linear level: one lattice over the whole mesh -- the ranks' bounding boxes and owned counts are gathered by a
+    // sum all-reduce (every rank fills its own slot) -- with every bin an aggregate, so that the numbering needs no exchange
+    const bool distributed = c1->sym.nRows != c1->sym.nCols;
+    const int64_t nOwnD = c1->sym.nRows;
+    double box[6] = {0, 0, 0, 0, 0, 0};
+    int64_t globalCount = 0;
+    if (distributed) {
+        const int world = dist_world(c1), rank = dist_rank(c1);
+        double mn[3], mx[3];
+        bounding_box_device(dim, nOwnD, dPos, s, mn, mx);
+        std::vector<double> slots((size_t)world * 7, 0.0);
+        for (int a = 0; a < 3; ++a) { slots[(size_t)rank * 7 + a] = a < dim ? mn[a] : 0.0; slots[(size_t)rank * 7 + 3 + a] = a < dim ? mx[a] : 0.0; }
+        slots[(size_t)rank * 7 + 6] = (double)nOwnD;
+        DBuf<double> dSlots;
+        dSlots.upload(slots, s);
+        dist_allreduce(c1, dSlots.p, (int64_t)slots.size());
+        dSlots.download(slots.data(), slots.size(), s);
+        for (int a = 0; a < 3; ++a) { box[a] = 1e300; box[3 + a] = -1e300; }
+        for (int r = 0; r < world; ++r) {
+            if (slots[(size_t)r * 7 + 6] <= 0) continue;
+            for (int a = 0; a < 3; ++a) { box[a] = std::min(box[a], slots[(size_t)r * 7 + a]); box[3 + a] = std::max(box[3 + a], slots[(size_t)r * 7 + 3 + a]); }
+            globalCount += (int64_t)slots[(size_t)r * 7 + 6];
+        }
+    }
+    auto sum_over_ranks = [&](double v) {
+        if (!distributed) return v;
+        DBuf<double> one;
+        one.upload(std::vector<double>{v}, s);
+        dist_allreduce(c1, one.p, 1);
+        one.download(&v, 1, s);
+        return v;
+    };
     std::unique_ptr<mfh_ctx::AggLevel> L0;
     for (int attempt = 0; attempt < 4; ++attempt) {
         Aggregates A;
-        build_aggregates_device(dim, nD, dPos, target, s, A, G.aggOfDof2, G.relPos2, G.aggPtr2, G.dofsByAgg2);
+        if (distributed) {
+            // aggregate and relative position of every local DoF (halo columns included); the DoF lists hold the owned rows only
+            DBuf<int32_t> tmpPtr, tmpList, tmpAgg;
+            DBuf<double> tmpRel;
+            Aggregates Aown;
+            build_aggregates_device(dim, nD, dPos, target, s, A, G.aggOfDof2, G.relPos2, tmpPtr, tmpList, box, globalCount, true);
+            build_aggregates_device(dim, nOwnD, dPos, target, s, Aown, tmpAgg, tmpRel, G.aggPtr2, G.dofsByAgg2, box, globalCount, true);
+        } else
+            build_aggregates_device(dim, nD, dPos, target, s, A, G.aggOfDof2, G.relPos2, G.aggPtr2, G.dofsByAgg2);
         L0.reset(new mfh_ctx::AggLevel());
         L0->nAgg = A.nAgg; L0->H = A.H; L0->hCoord = A.binCoord; L0->hCentre = A.centroid;
         for (int k2 = 0; k2 < 3; ++k2) {
@@ -179,6 +226,7 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
         }
         build_neighbours(dim, *L0, s);
         L0->A.alloc((size_t)A.nAgg * NS * NM * NM);
+        L0->A.zero(s);                   // (aggregates without a row of this rank keep zero blocks)
         far.zero(s);
         k::TLArgs ta{};
         ta.dim = dim; ta.nModes = NM; ta.nAgg = A.nAgg; ta.nDoF = c1->sym.nRows; ta.aggOfDof = G.aggOfDof2.p; ta.relPos = G.relPos2.p;
@@ -187,7 +235,10 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
                              L0->A.p, far.p, L0->wrap);
         int nFar = 0;
         far.download(&nFar, 1, s);
-        if (nFar == 0) break;
+        if (sum_over_ranks((double)nFar) == 0) {
+            if (distributed) dist_allreduce(c1, L0->A.p, (int64_t)A.nAgg * NS * NM * NM);   // every rank added the rows it owns
+            break;
+        }
         L0.reset();
         target *= 8;                     // bins twice as wide
     }

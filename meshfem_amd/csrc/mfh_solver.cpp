@@ -268,6 +268,65 @@ void tl_precond_nr(mfh_ctx *c, DistLink &L, int NR, const double *r, double *z, 
 
 }   // namespace
 
+// ---- the same plumbing for callers outside this file (the distributed multigrid levels, mfh_multigrid.cpp)
+bool dist_active(const mfh_ctx *c) { return c->dist.comm && c->dist.comm->world > 1; }
+int dist_rank(const mfh_ctx *c) { return c->dist.comm ? c->dist.comm->rank : 0; }
+int dist_world(const mfh_ctx *c) { return c->dist.comm ? c->dist.comm->world : 1; }
+// y = K x on the owned rows; x holds nCols block rows, its halo part is fetched from the owners first
+void dist_apply(mfh_ctx *c, double *x, double *y, bool masked) {
+    DistLink L(c);
+    if (cluster_operator(c) && c->mfcDev.ifaceBuf.n < (size_t)std::max<int64_t>(c->mfc.nIface, 1) * c->bs())
+        c->mfcDev.ifaceBuf.alloc((size_t)std::max<int64_t>(c->mfc.nIface, 1) * c->bs());
+    apply_op_nr(c, L, 1, x, y, masked, nullptr, nullptr, 0, nullptr);
+}
+// the halo block rows of v (nCols x W doubles) <- the owners' values
+void dist_halo(mfh_ctx *c, double *v, int W) {
+    DistLink L(c);
+    if (!L.active) return;
+    c->dist.sendBufW = std::max(c->dist.sendBufW, W);
+    L.halo_begin(v, W);
+    L.halo_end();
+}
+void dist_allreduce(mfh_ctx *c, double *dev, int64_t n) {
+    DistLink L(c);
+    L.allreduce(dev, n);
+}
+// a second context on the same communicator whose nodes are a subset of c's (the linear level of the multigrid hierarchy): its
+// exchange lists are c's, filtered. keep[n] >= 0: the node's id in the child (children numbered in c's node order).
+void dist_setup_child(mfh_ctx *c, mfh_ctx *child, const std::vector<int32_t> &keep) {
+    auto &D = c->dist;
+    auto &E = child->dist;
+    const int64_t nOwned = c->mesh.nOwned;
+    E.peers = D.peers;
+    E.sendPtr.assign(1, 0); E.recvPtr.assign(1, 0);
+    std::vector<int32_t> idx;
+    for (size_t k = 0; k < D.peers.size(); ++k) {
+        for (int64_t q = D.sendPtr[k]; q < D.sendPtr[k + 1]; ++q) {
+            const int32_t ch = keep[(size_t)D.sendNodesHost[(size_t)q]];
+            if (ch >= 0) idx.push_back(ch);
+        }
+        E.sendPtr.push_back((int64_t)idx.size());
+        int64_t cnt = 0;
+        for (int64_t q = D.recvPtr[k]; q < D.recvPtr[k + 1]; ++q) cnt += keep[(size_t)(nOwned + q)] >= 0;
+        E.recvPtr.push_back(E.recvPtr.back() + cnt);
+    }
+    if (E.recvPtr.back() != child->mesh.nNode - child->mesh.nOwned) throw Error(MFH_ERR_STATE, "child halo does not match the filtered receive lists");
+    E.sendNodesHost = idx;
+    E.sendIdx.upload(idx.empty() ? std::vector<int32_t>{0} : idx, child->stream);
+    if (!E.commStream) {
+        MFH_HIP(hipStreamCreateWithFlags(&E.commStream, hipStreamNonBlocking));
+        for (auto &e : E.ev) MFH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    mfh_comm *cm = D.comm;
+    if (E.comm != cm) {
+        dist_detach(child);
+        if (cm) { std::lock_guard<std::mutex> lock(cm->mu); cm->users.push_back(child); }
+    }
+    E.comm = cm;
+    E.listKind = 0;
+    E.sendBufW = std::max(E.sendBufW, child->bs());
+}
+
 bool cg_operator_supported(mfh_ctx *c) {
     // the batched operators: the cluster variant of the matrix-free operator and the assembled SpMV
     if (!c->use_mf()) return true;
@@ -770,6 +829,7 @@ mfh_status mfh_dist_setup(mfh_ctx *c, mfh_comm *cm, int32_t nPeers, const int32_
     require(D.recvPtr.back() == nHalo, MFH_ERR_INVALID, "the receive ranges must cover the halo nodes exactly (halo nodes grouped by owner, in the peers' order)");
     std::vector<int32_t> idx(sendNodes, sendNodes + D.sendPtr.back());
     for (int32_t v : idx) require(v >= 0 && v < nOwned, MFH_ERR_INVALID, "send list holds a node this rank does not own");
+    D.sendNodesHost = idx;
     D.sendIdx.upload(idx.empty() ? std::vector<int32_t>{0} : idx, c->stream);
     if (!D.commStream) {
         MFH_HIP(hipStreamCreateWithFlags(&D.commStream, hipStreamNonBlocking));

@@ -757,11 +757,7 @@ void build_mg_transfer_device(const HostMesh &m, const int32_t *dElemNodes, hipS
     MFH_HIP(hipStreamSynchronize(s));
 }
 
-void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targetNodes, hipStream_t s, Aggregates &A,
-                             DBuf<int32_t> &dAggOfDof, DBuf<double> &dRelPos, DBuf<int32_t> &dAggPtr, DBuf<int32_t> &dDofsByAgg) {
-    A = Aggregates();
-    A.dim = dim;
-    // ---- bounding box
+void bounding_box_device(int dim, int64_t nDoF, const double *dPos, hipStream_t s, double mn[3], double mx[3]) {
     const int gridMM = 1024;
     DBuf<double> part;
     part.alloc((size_t)gridMM * 6);
@@ -769,13 +765,27 @@ void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targ
     RP(hipGetLastError());
     std::vector<double> hp((size_t)gridMM * 6);
     part.download(hp.data(), hp.size(), s);
-    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int a = 0; a < 3; ++a) { mn[a] = 1e300; mx[a] = -1e300; }
     for (int b = 0; b < gridMM; ++b)
         for (int a = 0; a < dim; ++a) { mn[a] = std::min(mn[a], hp[(size_t)b * 6 + a]); mx[a] = std::max(mx[a], hp[(size_t)b * 6 + 3 + a]); }
+}
+
+// globalBox (mn[3], mx[3]) / globalCount: the lattice of a mesh this context holds a part of (row-partitioned contexts: every rank
+// lays the same bins over the whole mesh). fullLattice: every bin is an aggregate, empty or not, numbered in bin order, and the
+// reference point of its rigid-body modes is the bin centre -- the same numbers on every rank without any exchange.
+void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targetNodes, hipStream_t s, Aggregates &A,
+                             DBuf<int32_t> &dAggOfDof, DBuf<double> &dRelPos, DBuf<int32_t> &dAggPtr, DBuf<int32_t> &dDofsByAgg,
+                             const double *globalBox, int64_t globalCount, bool fullLattice) {
+    A = Aggregates();
+    A.dim = dim;
+    // ---- bounding box
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    if (globalBox) { for (int a = 0; a < 3; ++a) { mn[a] = globalBox[a]; mx[a] = globalBox[3 + a]; } }
+    else bounding_box_device(dim, nDoF, dPos, s, mn, mx);
     // ---- the same bin lattice as build_aggregates (mfh_twolevel.cpp)
     double vol = 1;
     for (int a = 0; a < dim; ++a) vol *= std::max(mx[a] - mn[a], 1e-300);
-    const double H = std::pow(vol * std::max(1, targetNodes) / (double)std::max<int64_t>(1, nDoF), 1.0 / dim);
+    const double H = std::pow(vol * std::max(1, targetNodes) / (double)std::max<int64_t>(1, globalCount > 0 ? globalCount : nDoF), 1.0 / dim);
     int nb[3] = {1, 1, 1};
     for (int a = 0; a < dim; ++a) nb[a] = std::max(1, (int)std::floor((mx[a] - mn[a]) / H + 0.5));
     A.H = H;
@@ -791,7 +801,11 @@ void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targ
     std::vector<int32_t> binId((size_t)nBins);
     mark.download(binId.data(), binId.size(), s);
     int32_t nAgg = 0;
-    for (auto &b : binId) b = b ? nAgg++ : -1;          // compact numbering of the non-empty bins, in bin order
+    if (fullLattice) {
+        if (nBins > 2000000000LL) throw Error(MFH_ERR_UNSUPPORTED, "too many lattice bins");
+        for (auto &b : binId) b = nAgg++;
+    } else
+        for (auto &b : binId) b = b ? nAgg++ : -1;      // compact numbering of the non-empty bins, in bin order
     A.nAgg = nAgg;
     dBinId.upload(binId, s);
     // ---- aggregate of every DoF, DoFs grouped by aggregate (stable sort: ascending DoF inside an aggregate)
@@ -818,7 +832,18 @@ void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targ
     // ---- centroids and relative positions
     DBuf<double> dCentroid;
     dCentroid.alloc((size_t)nAgg * 3);
-    hipLaunchKernelGGL(k_agg_centroid, dim3(nAgg), dim3(256), 0, s, dim, dAggPtr.p, valB.p, dPos, dCentroid.p);
+    if (fullLattice) {
+        std::vector<double> centre((size_t)nAgg * 3, 0.0);
+        for (int iz = 0; iz < nb[2]; ++iz)
+            for (int iy = 0; iy < nb[1]; ++iy)
+                for (int ix = 0; ix < nb[0]; ++ix) {
+                    const size_t b = ((size_t)iz * nb[1] + iy) * nb[0] + ix;
+                    const int q[3] = {ix, iy, iz};
+                    for (int a = 0; a < dim; ++a) centre[b * 3 + a] = B.mn[a] + (q[a] + 0.5) * B.w[a];
+                }
+        dCentroid.upload(centre, s);
+    } else
+        hipLaunchKernelGGL(k_agg_centroid, dim3(nAgg), dim3(256), 0, s, dim, dAggPtr.p, valB.p, dPos, dCentroid.p);
     dRelPos.alloc((size_t)nDoF * 3);
     hipLaunchKernelGGL(k_agg_relpos, dim3(grid_of(nDoF)), dim3(256), 0, s, nDoF, dim, 1.0 / H, dAggOfDof.p, dPos, dCentroid.p, dRelPos.p);
     RP(hipGetLastError());

@@ -251,20 +251,23 @@ int64_t oracle_assemble_csc(int dim, int deg, int64_t nElem, const int32_t *elem
  * S (nb x nb, row-major). A child's update matrix U (nbc x nbc, symmetric, row-major) is added at the positions loc[]:
  * loc < ns -> an eliminated unknown, else ns + index into the parent's boundary. The block (eliminated row, boundary column)
  * is the transpose of (boundary row, eliminated column) and is not stored. */
-void oracle_extend_add(double *P, double *S, int64_t ns, int64_t nb, const double *U, int64_t nbc, const int64_t *loc) {
-#pragma omp parallel for schedule(dynamic, 16)
+void oracle_extend_add(double *P, double *S, int64_t ns, int64_t nb, const double *U, int64_t nbc, const int64_t *loc, int threads) {
+    /* loc is increasing (child boundary and parent boundary are both sorted; the parent's own range lies below its boundary):
+     * entries [0, k0) land in the panel's own columns, the rest in S. Only the lower triangle (j <= i) is read and written --
+     * the fronts are symmetric and potrf / trsm / syrk use the lower parts. threads == 1 (fronts inside a subtree that a worker
+     * thread factors on its own): the calling thread does it all; the fronts above the subtrees pass the BLAS thread count. */
+    int64_t k0 = 0;
+    while (k0 < nbc && loc[k0] < ns) ++k0;
+#pragma omp parallel for schedule(dynamic, 8) num_threads(threads) if (threads > 1 && nbc >= 512)
     for (int64_t i = 0; i < nbc; ++i) {
         const int64_t li = loc[i];
         const double *u = U + i * nbc;
         double *prow = P + li * ns;
-        if (li < ns) {
-            for (int64_t j = 0; j < nbc; ++j) if (loc[j] < ns) prow[loc[j]] += u[j];
-        } else {
-            double *srow = S + (li - ns) * nb;
-            for (int64_t j = 0; j < nbc; ++j) {
-                const int64_t lj = loc[j];
-                if (lj < ns) prow[lj] += u[j]; else srow[lj - ns] += u[j];
-            }
+        const int64_t jo = i < k0 ? i + 1 : k0;          /* own columns: j < k0 and j <= i */
+        for (int64_t j = 0; j < jo; ++j) prow[loc[j]] += u[j];
+        if (i >= k0) {
+            double *srow = S + (li - ns) * nb - ns;
+            for (int64_t j = k0; j <= i; ++j) srow[loc[j]] += u[j];
         }
     }
 }

@@ -84,25 +84,18 @@ def assemble_csc(dim, deg, elem_nodes, vert_pos, D, n_dof, dof_for_node=None):
     return Ap, Ai[:nnz].copy(), Ax[:nnz].copy(), dict(ke=times[0], push=times[1], compress=times[2], total=times[3])
 
 
-def extend_add(P, S, U, loc):
-    """Multifrontal extend-add (oracle/direct_solve.py): the child's update matrix U lands in the parent's panel P
-    ((ns + nb) x ns) and Schur block S (nb x nb) at the positions loc; all arrays C-contiguous float64."""
-    ns = P.shape[1]
-    if U.shape[0] < 256:          # small fronts: not worth waking the OpenMP team (it competes with the BLAS threads)
-        own = loc < ns
-        lo, lb = loc[own], loc[~own] - ns
-        P[np.ix_(loc, lo)] += U[:, own]
-        S[np.ix_(lb, lb)] += U[np.ix_(~own, ~own)]
-        return
+def extend_add(P, S, U, loc, threads=1):
+    """Multifrontal extend-add (oracle/direct_solve.py): the LOWER triangle of the child's update matrix U lands in the parent's
+    panel P ((ns + nb) x ns) and Schur block S (nb x nb) at the increasing positions loc; all arrays C-contiguous float64."""
     lib = load()
     loc = np.ascontiguousarray(loc, np.int64)
     assert P.flags.c_contiguous and S.flags.c_contiguous and U.flags.c_contiguous
-    lib.oracle_extend_add(_p(P), _p(S), C.c_int64(P.shape[1]), C.c_int64(S.shape[0]), _p(U), C.c_int64(U.shape[0]), _p(loc))
+    lib.oracle_extend_add(_p(P), _p(S), C.c_int64(P.shape[1]), C.c_int64(S.shape[0]), _p(U), C.c_int64(U.shape[0]), _p(loc), C.c_int(int(threads)))
 
 
-def zeros(shape):
-    """np.zeros with the fill done by all threads."""
-    if int(np.prod(shape)) < (1 << 22):
+def zeros(shape, threads=0):
+    """np.zeros; big arrays are filled by all threads (threads != 1: the caller is not itself one of many worker threads)."""
+    if threads == 1 or int(np.prod(shape)) < (1 << 22):
         return np.zeros(shape)
     a = np.empty(shape)
     load().oracle_zero(_p(a), C.c_int64(a.size))

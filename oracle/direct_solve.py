@@ -14,6 +14,7 @@ threads of the process' BLAS (threadpoolctl reports how many): that is the "TBB/
 `scipy.sparse.linalg.splu` (SuperLU, sequential, scalar updates) stays the oracle's direct solver at the sizes of the parity
 tests; it cannot factor 5e5 - 1e6 unknowns of a 3D quadratic mesh in a benchmark's time budget, this can."""
 import time
+from contextlib import nullcontext as _nullcontext
 
 import numpy as np
 import scipy.linalg as sl
@@ -126,58 +127,109 @@ class MultifrontalCholesky:
         self.factor_nnz = 0
         self.flops = 0.0
 
-    def factor(self):
-        t0 = time.perf_counter()
+    def _front(self, k, upd, dsyrk, threads=1):
+        """Assembles and eliminates the front of tree node k; the children's update matrices are consumed from `upd`."""
         Kp, first = self.Kp, self.first
         indptr, indices, data = Kp.indptr, Kp.indices, Kp.data
-        upd = [None] * len(self.kids)
-        dgemm = sl.get_blas_funcs("gemm", dtype=np.float64)
-        for k in range(len(self.kids)):
-            s0, s1 = int(first[k]), int(first[k + 1])
-            ns = s1 - s0
-            # boundary = rows > own range in the own columns, plus the children's boundaries beyond the own range
-            lo, hi = indptr[s0], indptr[s1]
-            rows = indices[lo:hi]
-            cols = np.repeat(np.arange(s0, s1), np.diff(indptr[s0:s1 + 1]))
-            below = rows >= s1
-            parts = [rows[below]]
-            for c in self.kids[k]:
-                b = self.bnd[c]
-                parts.append(b[b >= s1])
-            bnd = np.unique(np.concatenate(parts)) if parts else np.zeros(0, np.int64)
-            nb = len(bnd)
-            # frontal matrix as a panel P = [F11; F21] ((ns + nb) x ns, lower part of F11) and the Schur block S = F22 (nb x nb).
-            # K only feeds the panel: its entries among boundary unknowns are assembled where one of them is eliminated
-            P = _zeros((ns + nb, ns))
-            S = _zeros((nb, nb))
-            inown = (rows >= s0) & (rows < s1)
-            P[rows[inown] - s0, cols[inown] - s0] = data[lo:hi][inown]
-            if nb:
-                P[ns + np.searchsorted(bnd, rows[below]), cols[below] - s0] = data[lo:hi][below]
-            for c in self.kids[k]:                      # extend-add of the children's update matrices
-                b, U = self.bnd[c], upd[c]
-                if U is None or not len(b):
-                    continue
-                loc = np.where(b < s1, b - s0, ns + np.searchsorted(bnd, b))
-                _extend_add(P, S, U, loc)
-                upd[c] = None
-            if ns:
-                L11 = sl.cholesky(P[:ns], lower=True, overwrite_a=True, check_finite=False)
-                self.flops += ns ** 3 / 3.0
-            else:
-                L11 = np.zeros((0, 0))
-            if nb and ns:
-                L21 = sl.solve_triangular(L11, P[ns:].T, lower=True, check_finite=False).T      # nb x ns
-                # S -= L21 L21^T in place: S is symmetric, so its row-major buffer read column-major is the same matrix
-                L21f = np.asfortranarray(L21)
-                dgemm(alpha=-1.0, a=L21f, b=L21f, trans_b=True, beta=1.0, c=S.T, overwrite_c=True)
-                self.flops += ns * ns * nb + ns * nb * nb
-                L21 = np.ascontiguousarray(L21)
-            else:
-                L21 = np.zeros((nb, ns))
-            self.L11[k], self.L21[k], self.bnd[k] = L11, L21, bnd
-            upd[k] = S if nb else None
-            self.factor_nnz += ns * (ns + 1) // 2 + ns * nb
+        s0, s1 = int(first[k]), int(first[k + 1])
+        ns = s1 - s0
+        # boundary = rows > own range in the own columns, plus the children's boundaries beyond the own range
+        lo, hi = indptr[s0], indptr[s1]
+        rows = indices[lo:hi]
+        cols = np.repeat(np.arange(s0, s1), np.diff(indptr[s0:s1 + 1]))
+        below = rows >= s1
+        parts = [rows[below]]
+        for c in self.kids[k]:
+            b = self.bnd[c]
+            parts.append(b[b >= s1])
+        bnd = np.unique(np.concatenate(parts)) if parts else np.zeros(0, np.int64)
+        nb = len(bnd)
+        # frontal matrix as a panel P = [F11; F21] ((ns + nb) x ns, lower part of F11) and the Schur block S = F22 (nb x nb, lower
+        # part). K only feeds the panel: its entries among boundary unknowns are assembled where one of them is eliminated
+        P = _zeros((ns + nb, ns), threads)
+        S = _zeros((nb, nb), threads)
+        inown = (rows >= s0) & (rows < s1)
+        P[rows[inown] - s0, cols[inown] - s0] = data[lo:hi][inown]
+        if nb:
+            P[ns + np.searchsorted(bnd, rows[below]), cols[below] - s0] = data[lo:hi][below]
+        for c in self.kids[k]:                      # extend-add of the children's update matrices (lower triangles)
+            b, U = self.bnd[c], upd[c]
+            if U is None or not len(b):
+                continue
+            loc = np.where(b < s1, b - s0, ns + np.searchsorted(bnd, b))
+            _extend_add(P, S, U, loc)                # on the calling thread: an OpenMP team here fights the BLAS threads (measured 2x slower)
+            upd[c] = None
+        flops = 0.0
+        if ns:
+            L11 = sl.cholesky(P[:ns], lower=True, overwrite_a=True, check_finite=False)
+            flops += ns ** 3 / 3.0
+        else:
+            L11 = np.zeros((0, 0))
+        if nb and ns:
+            L21 = sl.solve_triangular(L11, P[ns:].T, lower=True, check_finite=False).T      # nb x ns
+            # S -= L21 L21^T on the lower triangle, in place: the row-major buffer of S read column-major is S^T, whose UPPER
+            # triangle is the lower triangle of S
+            L21f = np.asfortranarray(L21)
+            dsyrk(alpha=-1.0, a=L21f, beta=1.0, c=S.T, lower=0, overwrite_c=True)
+            flops += ns * ns * nb + ns * nb * nb
+            L21 = np.ascontiguousarray(L21)
+        else:
+            L21 = np.zeros((nb, ns))
+        self.L11[k], self.L21[k], self.bnd[k] = L11, L21, bnd
+        upd[k] = S if nb else None
+        self._node_flops[k] = flops
+        self._node_nnz[k] = ns * (ns + 1) // 2 + ns * nb
+
+    def factor(self, workers=1, blas_threads=None):
+        """Numeric factorisation. workers > 1: independent subtrees of the elimination tree are factored concurrently by that many
+        threads with single-threaded BLAS (LAPACK releases the interpreter lock), the fronts above them one after the other on
+        `blas_threads` BLAS threads -- the two levels of parallelism a supernodal solver uses."""
+        t0 = time.perf_counter()
+        n_nodes = len(self.kids)
+        upd = [None] * n_nodes
+        dsyrk = sl.get_blas_funcs("syrk", dtype=np.float64)
+        self._node_flops, self._node_nnz = np.zeros(n_nodes), np.zeros(n_nodes, dtype=np.int64)
+        top = np.zeros(n_nodes, dtype=bool)             # nodes handled after the subtrees
+        roots = [n_nodes - 1]
+        if workers > 1:
+            # split the tree from the root down until there are enough subtrees to keep the workers busy
+            size = np.diff(self.first).astype(np.float64)
+            for k in range(n_nodes):                     # post-order: children before parents
+                for c in self.kids[k]:
+                    size[k] += size[c]
+            while len(roots) < 4 * workers:
+                big = max(roots, key=lambda r: size[r])
+                if not self.kids[big]:
+                    break
+                roots.remove(big)
+                top[big] = True
+                roots.extend(self.kids[big])
+        self.subtrees = len(roots)
+
+        def subtree(r):
+            stack, order = [r], []
+            while stack:                                 # nodes of the subtree, then reversed pre-order = a valid elimination order
+                k = stack.pop()
+                order.append(k)
+                stack.extend(self.kids[k])
+            for k in reversed(order):
+                self._front(k, upd, dsyrk)
+        if workers > 1 and len(roots) > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            from threadpoolctl import threadpool_limits
+            with threadpool_limits(limits=1, user_api="blas"):
+                with ThreadPoolExecutor(max_workers=workers) as ex:
+                    list(ex.map(subtree, sorted(roots, key=lambda r: -size[r])))
+            self.t_subtrees = time.perf_counter() - t0
+            with threadpool_limits(limits=blas_threads, user_api="blas") if blas_threads else _nullcontext():
+                for k in range(n_nodes):
+                    if top[k]:
+                        self._front(k, upd, dsyrk, blas_threads or 1)
+        else:
+            subtree(n_nodes - 1)
+            self.t_subtrees = time.perf_counter() - t0
+        self.flops = float(self._node_flops.sum())
+        self.factor_nnz = int(self._node_nnz.sum())
         self.t_factor = time.perf_counter() - t0
         return self
 

@@ -52,3 +52,22 @@ def test_multifrontal_cholesky_scalar_unknowns_and_every_variable_eliminated_onc
     x = mf.solve(b)
     assert np.linalg.norm(A @ x - b) <= 1e-12 * np.linalg.norm(b)
     assert mf.factor_nnz < 0.2 * (n ** 3) ** 2 / 2            # sparse factor: far below the dense triangle
+
+
+def test_multifrontal_cholesky_subtree_parallel_factorisation_is_the_same_factor():
+    """workers > 1: independent subtrees on threads with single-threaded BLAS, the fronts above them afterwards -- the same
+    fronts in another order, so the factor and the solution agree to rounding."""
+    sim, K, f = _cantilever(3, 1)
+    pos = sim.mesh.node_pos
+    free_nodes = np.flatnonzero(np.abs(pos[:, 0]) >= 1e-9)
+    free = (3 * free_nodes[:, None] + np.arange(3)[None, :]).ravel()
+    Kr = K[free][:, free]
+    a = DS.MultifrontalCholesky(Kr, pos[free_nodes], block=3, leaf=4).factor()
+    b = DS.MultifrontalCholesky(Kr, pos[free_nodes], block=3, leaf=4).factor(workers=3, blas_threads=2)
+    assert b.subtrees >= 6 and a.subtrees == 1 and a.factor_nnz == b.factor_nnz and a.flops == b.flops
+    for k in range(len(a.kids)):
+        assert np.array_equal(a.bnd[k], b.bnd[k]) and np.allclose(np.tril(a.L11[k]), np.tril(b.L11[k]), rtol=1e-12, atol=1e-14)
+        assert np.allclose(a.L21[k], b.L21[k], rtol=1e-11, atol=1e-13)
+    xa, xb = a.solve(f[free]), b.solve(f[free])
+    assert np.linalg.norm(xa - xb) <= 1e-12 * np.linalg.norm(xa)
+    assert np.linalg.norm(Kr @ xb - f[free]) <= 1e-12 * np.linalg.norm(f[free])
