@@ -545,6 +545,7 @@ class Context:
     def dist_solve(self, f_owned, rtol=1e-8, maxit=100000):
         """f_owned: [nrhs, dim * nOwned] (or flat for one right-hand side); returns (u_owned, [info per rhs])."""
         f = as_f64(f_owned)
+        self.symbolic(False)                       # (the row count comes from the pattern; a no-op once it exists)
         nr, _, _ = self.matrix_info()
         n = self.bs * nr
         nrhs = f.size // n

@@ -201,6 +201,7 @@ struct mfh_ctx {
         int64_t nInterior = 0, nBoundary = 0;
         int listKind = 0;             // 0 none, 1 cluster blocks, 2 SpMV chunks
         int64_t listGen = -1;         // mfh_ctx::listsGen the overlap lists were built from
+        bool multigridAgreed = false;         // every rank asked for MFH_PRECOND_MULTIGRID (agreed in mfh_dist_solve)
         bool anyFixedNonzeroGlobal = false;   // some rank holds a non-zero fixed value (agreed in mfh_dist_solve)
         int transport = 0;            // what carried the last halo exchange: 1 RCCL send/recv, 2 peer copies, 3 caller callbacks
     } dist;

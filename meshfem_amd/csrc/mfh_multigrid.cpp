@@ -341,19 +341,25 @@ void destroy_multigrid(mfh_ctx *c) {
 // Builds (or rebuilds) the hierarchy. false (with a note in precondNote) when it does not apply; the caller then falls back.
 bool ensure_multigrid(mfh_ctx *c) {
     auto &G = c->mg;
-    if (G.valid) return true;
+    // Row-partitioned contexts (mfh_dist_setup ran, more than one rank): the call is COLLECTIVE -- every rank builds its part of the
+    // nodal levels and the same replicated aggregate levels. The decision to call it is agreed on in mfh_dist_solve.
+    const bool distributed = dist_active(c);
+    if (G.valid && G.distributed == distributed && (!distributed || G.distComm == (const void *)c->dist.comm)) return true;
+    G.valid = false;
     c->precondNote.clear();
     const HostMesh &m = c->mesh;
     if (c->op != MFH_OP_ELASTICITY || c->external || !c->haveMesh) {
         c->precondNote = "multigrid is built for the elasticity operator of a mesh: using the two-level preconditioner";
         return false;
     }
-    if (c->sym.nRows != c->sym.nCols) {
-        c->precondNote = "p-multigrid unavailable for partitioned rows: using block-Jacobi";
+    if (c->sym.nRows != c->sym.nCols && !distributed) {
+        c->precondNote = "multigrid on partitioned rows needs the communicator of mfh_dist_setup: using block-Jacobi";
         return false;
     }
     const double t0 = now_ms();
     destroy_multigrid(c);
+    G.distributed = distributed;
+    G.distComm = distributed ? (const void *)c->dist.comm : nullptr;
     hipStream_t s = c->stream;
     const int d = m.dim, nv = d + 1, npe = m.npe;
     const int64_t nDoF = c->nDoF;
@@ -372,13 +378,14 @@ bool ensure_multigrid(mfh_ctx *c) {
         ensure_precond(c);
         lap("assembly + block-Jacobi");
         bool haveCoarse = build_aggregate_hierarchy(c, c, lap);
-        if (!haveCoarse) {
+        if (!haveCoarse && !distributed) {
             haveCoarse = ensure_twolevel(c);
             lap("rigid-body coarse (dense)");
         }
-        G.nFine = G.nCoarse = nDoF;
-        const int64_t n1 = (int64_t)d * nDoF;
+        G.nFine = G.nCoarse = c->sym.nRows;                    // (the rows this rank owns; all of them on an unpartitioned context)
+        const int64_t n1 = (int64_t)d * nDoF;                   // work vectors hold the halo rows too: the operator is applied to them
         G.r1.alloc((size_t)n1); G.d1.alloc((size_t)n1); G.t1.alloc((size_t)n1);
+        G.r1.zero(s); G.d1.zero(s); G.t1.zero(s);
         G.lmax0 = 0;
         G.lmax1 = c->mgEigMargin * estimate_lambda_max(c, nodal_ops(c, nullptr, 0, nullptr), G.r1.p, G.d1.p, G.t1.p);
         lap("eigenvalue estimate");
@@ -390,7 +397,7 @@ bool ensure_multigrid(mfh_ctx *c) {
     }
     // A mesh in the library's own numbering (mfh_mesh_build: vertices are the nodes [0, nVert)) with the identity DoF map takes the
     // device route for the transfer lists; any other node table / a periodic DoF map goes through the host loops below.
-    const bool ownNumbering = m.hasTopology && c->dofForNode.empty();
+    const bool ownNumbering = m.hasTopology && c->dofForNode.empty() && !distributed;
     std::vector<int32_t> coarseNode, coarseDofOfFine, parA, parB, fineOf, resPtr, resIdx;
     int64_t nCN = 0, nCD = 0;
     if (ownNumbering) {
@@ -460,6 +467,12 @@ bool ensure_multigrid(mfh_ctx *c) {
     m1 = HostMesh();
     m1.dim = d; m1.deg = 1; m1.npe = nv; m1.npbe = nodes_per_bdry_elem(d, 1);
     m1.nElem = m.nElem; m1.nNode = nCN; m1.nVert = nCN; m1.nOwned = nCN;
+    if (distributed) {
+        // the vertices this rank owns come first in the parent's numbering, hence in the child's: the child is partitioned the same way
+        int64_t nOwnedCoarse = 0;
+        for (int64_t n = 0; n < m.nOwned; ++n) nOwnedCoarse += coarse_node(n) >= 0;
+        m1.nOwned = nOwnedCoarse;
+    }
     m1.elemNodes.resize((size_t)m.nElem * nv);
     parallel_ranges(m.nElem, [&](int64_t eb, int64_t ee, int) {
         for (int64_t e = eb; e < ee; ++e)
@@ -499,17 +512,18 @@ bool ensure_multigrid(mfh_ctx *c) {
     c1->matrixFree = 0;                         // the linear level multiplies by its assembled matrix
     c1->matrixStorage = 0;
     c1->aggNodes = c->mgAggNodes;
-    c1->precond = MFH_PRECOND_TWO_LEVEL;
+    c1->precond = distributed ? MFH_PRECOND_BLOCK_JACOBI : MFH_PRECOND_TWO_LEVEL;
+    if (distributed) dist_setup_child(c, c1, coarseNode);     // the parent's exchange lists, restricted to the vertices
     ensure_precond(c1);
     lap("linear level: symbolic + assembly");
     // below the linear level: the aggregate hierarchy; where the lattice cannot resolve the mesh, the context's own dense coarse space
     bool haveCoarse = build_aggregate_hierarchy(c, c1, lap);
-    if (!haveCoarse) {
+    if (!haveCoarse && !distributed) {
         haveCoarse = ensure_twolevel(c1);
         lap("linear level: rigid-body coarse (dense)");
     }
     // ---- device copies, work vectors
-    G.nFine = nDoF; G.nCoarse = nCD;
+    G.nFine = c->sym.nRows; G.nCoarse = c1->sym.nRows;           // the rows this rank owns (all of them unless partitioned)
     if (!ownNumbering) {
         G.parA.upload(parA, s); G.parB.upload(parB, s); G.fineOf.upload(fineOf, s); G.resPtr.upload(resPtr, s);
         G.resIdx.upload(resIdx.empty() ? std::vector<int32_t>{0} : resIdx, s);
@@ -517,6 +531,10 @@ bool ensure_multigrid(mfh_ctx *c) {
     const int64_t n0 = (int64_t)d * nDoF, n1 = (int64_t)d * nCD;
     G.r0.alloc((size_t)n0); G.d0.alloc((size_t)n0); G.t0.alloc((size_t)n0);
     G.b1.alloc((size_t)n1); G.x1.alloc((size_t)n1); G.r1.alloc((size_t)n1); G.d1.alloc((size_t)n1); G.t1.alloc((size_t)n1);
+    if (distributed) {                          // the vectors an operator is applied to carry their halo rows; start from defined values
+        G.rfull.alloc((size_t)n0);
+        for (DBuf<double> *v : {&G.r0, &G.d0, &G.t0, &G.rfull, &G.b1, &G.x1, &G.r1, &G.d1, &G.t1}) v->zero(s);
+    }
     // ---- spectra of the two Jacobi-preconditioned operators
     ensure_precond(c);
     // the power iteration approaches the largest eigenvalue from below: a margin keeps the Chebyshev polynomials bounded on the whole spectrum
@@ -550,6 +568,7 @@ static void linear_level(mfh_ctx *c, mfh_ctx *c1, const double *b, double *x, co
                 ta.dim = c->dim(); ta.nModes = ta.dim == 3 ? 6 : 3; ta.nAgg = (int)A0.nAgg; ta.nDoF = c1->sym.nRows;
                 ta.aggOfDof = G.aggOfDof2.p; ta.relPos = G.relPos2.p; ta.fixedMask = masked1 ? c1->dFixedMask.p : nullptr;
                 k::launch_tl_restrict(ta, G.aggPtr2.p, G.dofsByAgg2.p, G.r1.p, A0.b.p, s);
+                if (G.distributed) dist_allreduce(c, A0.b.p, A0.nAgg * ta.nModes);       // every rank restricted the rows it owns
                 agg_cycle(c, 0, scal, it, stop);
                 k::launch_mg_tl_prolong_add(ta, A0.x.p, x, c->mgOverCorrection, scal, it, stop, s);
             } else {                          // the linear context's own dense coarse space (~1000 aggregates)
@@ -580,8 +599,16 @@ void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int 
     // level 0, pre-smoothing from zero; residual r - K z = r0 - t0
     const double *ra = nullptr, *rb = nullptr;
     chebyshev(L0, r, z, true, true, G.r0.p, G.d0.p, G.t0.p, &ra, &rb);
-    k::launch_mg_restrict(d, G.nCoarse, G.fineOf.p, G.resPtr.p, G.resIdx.p, ra, rb, masked1 ? c1->dFixedMask.p : nullptr, G.b1.p, scal, it, stop, s);
+    if (G.distributed) {
+        // the restriction to an owned vertex reads the edge nodes around it, some of them owned by a neighbour: the residual is formed
+        // on the owned rows, its halo rows fetched
+        k::launch_mg_diff((int64_t)d * G.nFine, ra, rb, G.rfull.p, scal, it, stop, s);
+        dist_halo(c, G.rfull.p, d);
+        k::launch_mg_restrict(d, G.nCoarse, G.fineOf.p, G.resPtr.p, G.resIdx.p, G.rfull.p, nullptr, masked1 ? c1->dFixedMask.p : nullptr, G.b1.p, scal, it, stop, s);
+    } else
+        k::launch_mg_restrict(d, G.nCoarse, G.fineOf.p, G.resPtr.p, G.resIdx.p, ra, rb, masked1 ? c1->dFixedMask.p : nullptr, G.b1.p, scal, it, stop, s);
     linear_level(c, c1, G.b1.p, G.x1.p, scal, it, stop);
+    if (G.distributed) dist_halo(c1, G.x1.p, d);              // an owned edge node may hang between vertices of a neighbour
     // back to level 0: z += P x1, post-smoothing
     k::launch_mg_prolong_add(d, G.nFine, G.parA.p, G.parB.p, G.x1.p, masked0 ? c->dFixedMask.p : nullptr, z, scal, it, stop, s);
     chebyshev(L0, r, z, false, false, G.r0.p, G.d0.p, G.t0.p);

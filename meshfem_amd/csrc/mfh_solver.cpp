@@ -350,7 +350,8 @@ void dist_agree(mfh_ctx *c) {
     for (int round = 0; round < 2; ++round) {
         const bool useTL = (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) && c->tl.valid;
         double h[8] = {c->anyFixedNonzero ? 1.0 : 0.0, localCode != MFH_OK ? 1.0 : 0.0, (localCode == MFH_OK && !supported) ? 1.0 : 0.0,
-                       (localCode == MFH_OK && supported && cluster_operator(c)) ? 1.0 : 0.0, useTL ? 1.0 : 0.0, 1.0, 0.0, 0.0};
+                       (localCode == MFH_OK && supported && cluster_operator(c)) ? 1.0 : 0.0, useTL ? 1.0 : 0.0, 1.0,
+                       c->precond == MFH_PRECOND_MULTIGRID ? 1.0 : 0.0, 0.0};
         c->cgCtl.alloc(16);
         MFH_HIP(hipMemcpyAsync(c->cgCtl.p, h, sizeof(h), hipMemcpyHostToDevice, c->stream));
         L.allreduce(c->cgCtl.p, 8);
@@ -358,6 +359,8 @@ void dist_agree(mfh_ctx *c) {
         MFH_HIP(hipStreamSynchronize(c->stream));
         const double world = h[5];
         c->dist.anyFixedNonzeroGlobal = h[0] > 0;
+        c->dist.multigridAgreed = h[6] > 0 && h[6] == world;      // building the hierarchy is collective: every rank or none
+        if (h[6] > 0 && h[6] < world) c->precondNote += " [multigrid requested on some ranks only: not used]";
         if (h[1] > 0) {
             if (localCode != MFH_OK) throw Error(localCode, localErr);
             throw Error(MFH_ERR_STATE, "another rank failed while preparing the distributed solve");
@@ -566,7 +569,10 @@ void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rt
     DistLink L(c);
     EventTimer tsetup(s);
     c->cgU.reserve(nAll);                                 // p (with its halo part)
-    c->wx.alloc(nOwn); c->wr.alloc(nOwn); c->wz.alloc(nOwn); c->wAp.alloc(nOwn); c->wf.alloc(nOwn);
+    // the multigrid V-cycle applies the operator to z: it then carries its halo rows like p
+    const bool useMG = c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && c->mg.distributed == L.active && !c->tlSuppress;
+    c->wx.alloc(nOwn); c->wr.alloc(nOwn); c->wz.alloc(useMG ? nAll : nOwn); c->wAp.alloc(nOwn); c->wf.alloc(nOwn);
+    if (useMG) c->wz.zero(s);
     c->stop.alloc(4);
     c->cgCtl.alloc(16);
     const bool masked = !c->fixedVars.empty();
@@ -602,7 +608,9 @@ void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rt
     if (bb == 0.0) { c->wx.zero(s); li.converged = 1; }
     else {
         EventTimer tsolve(s);
-        const bool useTL = (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) && c->tl.valid && !c->tlSuppress;
+        const bool useTL = !useMG && (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) && c->tl.valid && !c->tlSuppress;
+        const uint8_t *maskPtr = masked ? c->dFixedMask.p : nullptr;
+        const int checkEvery = useMG ? std::min(c->checkEvery, 2) : c->checkEvery;     // a V-cycle is milliseconds long and tens of them are needed
         double *scal = c->scal.p;
         auto &T = c->tl;
         auto tl_pre = [&](int it) {     // z = M^-1 r, r.z into scal[(it + 1) 4]; the restricted residual summed over the ranks
@@ -616,9 +624,13 @@ void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rt
         MFH_HIP(hipMemsetAsync(p, 0, (size_t)nAll * sizeof(double), s));
         MFH_HIP(hipMemcpyAsync(c->wAp.p, c->wr.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToDevice, s));
         k::launch_pcg_init(d, nRows, c->dDinv.p, c->wAp.p, c->wx.p, c->wr.p, c->wz.p, p, scal, s);
-        if (useTL) {
+        if (useTL || useMG) {
             MFH_HIP(hipMemsetAsync(scal, 0, sizeof(double), s));
-            tl_pre(-1);
+            if (useMG) {      // z = M^-1 r by one V-cycle (halo exchanges and one small all-reduce inside), r.z into scal[(it + 1) 4]
+                mg_precond(c, c->wr.p, c->wz.p, nullptr, -1, nullptr);
+                k::launch_mg_rz(nOwn, c->wr.p, c->wz.p, maskPtr, scal, -1, nullptr, nullptr, s);
+            } else
+                tl_pre(-1);
             MFH_HIP(hipMemcpyAsync(p, c->wz.p, (size_t)nOwn * sizeof(double), hipMemcpyDeviceToDevice, s));
         }
         L.allreduce(scal, 3);
@@ -626,11 +638,15 @@ void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rt
         int it = 0, lastChecked = 0;
         bool done = false;
         while (!done && it < maxit) {
-            const int itEnd = std::min(maxit, it + c->checkEvery);
+            const int itEnd = std::min(maxit, it + checkEvery);
             for (; it < itEnd; ++it) {
                 apply_op_nr(c, L, 1, p, c->wAp.p, masked, nullptr, scal, it, c->stop.p, 1);     // Ap, p.Ap (first reduction point)
                 L.allreduce(scal + (size_t)it * 4 + 1, 1);
-                if (useTL) { k::launch_pcg_update_noz(d, nRows, c->wAp.p, c->wr.p, scal, it, c->stop.p, s); tl_pre(it); }
+                if (useMG) {
+                    k::launch_pcg_update_noz(d, nRows, c->wAp.p, c->wr.p, scal, it, c->stop.p, s);
+                    mg_precond(c, c->wr.p, c->wz.p, scal, it, c->stop.p);
+                    k::launch_mg_rz(nOwn, c->wr.p, c->wz.p, maskPtr, scal, it, scal, c->stop.p, s);
+                } else if (useTL) { k::launch_pcg_update_noz(d, nRows, c->wAp.p, c->wr.p, scal, it, c->stop.p, s); tl_pre(it); }
                 else k::launch_pcg_update(d, nRows, c->dDinv.p, c->wAp.p, c->wr.p, c->wz.p, scal, it, c->stop.p, s);
                 L.allreduce(scal + (size_t)(it + 1) * 4, 3);                                    // {r.z, -, r.r} (second reduction point)
                 k::launch_pcg_direction(nOwn, c->wz.p, p, c->wx.p, scal, it, c->stop.p, s);
@@ -843,6 +859,7 @@ mfh_status mfh_dist_setup(mfh_ctx *c, mfh_comm *cm, int32_t nPeers, const int32_
     D.comm = cm;
     D.listKind = 0;
     D.sendBufW = std::max(D.sendBufW, c->bs());
+    c->mg.valid = false;             // a multigrid hierarchy holds exchange lists derived from the previous ones
     MFH_CATCH(c)
 }
 
@@ -873,16 +890,21 @@ mfh_status mfh_dist_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, 
     // local error in the preparation, the operator in use, the lift of non-zero fixed values and the preconditioner. One
     // all-reduce of six flags; a rank that cannot run the cluster operator takes every rank to the assembled SpMV.
     dist_agree(c);
+    // MFH_PRECOND_MULTIGRID on every rank: the V-cycle with partitioned nodal levels and replicated aggregate levels (collective setup;
+    // one right-hand side at a time in the classic loop)
+    bool useMG = false;
+    if (c->dist.multigridAgreed) useMG = ensure_multigrid(c) && c->mg.distributed == dist_active(c);
+    else if (c->mg.valid && c->mg.distributed) destroy_multigrid(c);
     const int64_t n = (int64_t)c->bs() * c->sym.nRows;
     std::vector<mfh_solve_info> infos((size_t)nrhs);
     // every rank must take the same path: batches are chosen from (dim, nrhs) only
     int k0 = 0;
     while (k0 < nrhs) {
         int nb = 1;
-        if (c->batchRhs)
+        if (c->batchRhs && !useMG)
             for (int cand : {6, 3, 2})
                 if (cand <= nrhs - k0 && k::op_batch_supported(c->bs(), cand)) { nb = cand; break; }
-        if (nb == 1 && c->distPcgVariant == 0) solve_classic_partitioned(c, f + (size_t)k0 * n, u + (size_t)k0 * n, rtol, maxit, infos.data() + k0);
+        if (nb == 1 && (c->distPcgVariant == 0 || useMG)) solve_classic_partitioned(c, f + (size_t)k0 * n, u + (size_t)k0 * n, rtol, maxit, infos.data() + k0);
         else solve_cg(c, nb, f + (size_t)k0 * n, u + (size_t)k0 * n, n, rtol, maxit, infos.data() + k0);
         k0 += nb;
     }

@@ -533,9 +533,9 @@ def slab_local_mesh(n, rank, world, deg=2, layers=None, device=-1, nz=None):
 
 
 def slab_traction_load(lm, n, traction):
-    """neumannLoad (LinearElasticity.hh:703-717) for a constant traction on the plane x = 1, P2 tets:
-    each boundary face contributes t*A/3 to its three edge nodes and nothing to its vertices
-    (Functions.hh:263-274). Every rank has all faces incident to its owned nodes."""
+    """neumannLoad (LinearElasticity.hh:703-717) for a constant traction on the plane x = 1: each boundary face of a P2 tet
+    contributes t*A/3 to its three edge nodes and nothing to its vertices (Functions.hh:263-274), of a P1 tet t*A/3 to its three
+    vertices. Every rank has all faces incident to its owned nodes."""
     en, pos = lm.elem_nodes, lm.node_pos
     lat_x = lm.lattice[:, 0]
     load = np.zeros((lm.n_owned, 3))
@@ -547,7 +547,7 @@ def slab_traction_load(lm, n, traction):
         pa, pb, pc = pos[en[sel, a]], pos[en[sel, b]], pos[en[sel, c]]
         area = 0.5 * np.linalg.norm(np.cross(pb - pa, pc - pa), axis=1)
         for u, v in ((a, b), (b, c), (c, a)):
-            node = en[sel, EDGE_OF[frozenset((u, v))]]
+            node = en[sel, EDGE_OF[frozenset((u, v))]] if en.shape[1] == 10 else en[sel, u]
             own = node < lm.n_owned
             np.add.at(load, node[own], (area[own] / 3.0)[:, None] * np.asarray(traction)[None, :])
     return load
@@ -661,6 +661,30 @@ def _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out, group=None):
                                                      true_rel_residual=i2["true_rel_residual"])
     finally:
         c.set_option("dist_pcg_variant", 1)
+    # the same solve with the multigrid V-cycle: nodal levels partitioned like the mesh, aggregate levels replicated on every rank
+    # (mfh_multigrid.cpp). Collective setup: every rank takes this branch.
+    try:
+        c.set_preconditioner(L.PRECOND_MULTIGRID)
+        if world > 1:
+            dist.barrier(group=group)
+        t0 = time.perf_counter()
+        try:
+            _, infos3 = solver.solve(f, rtol=args.rtol, maxit=min(maxit, 2000))
+            i3 = infos3[0]
+        except L.MeshFEMHipError as e:
+            if e.code != L.ERR_NOT_CONVERGED:
+                raise
+            i3 = c.last_info
+        wall3 = time.perf_counter() - t0
+        g3, p3 = c.multigrid_info(), c.precond_info()
+        ts3 = red([i3["solve_ms"] * 1e-3], dist.ReduceOp.MAX)[0]
+        out["pcg"]["multigrid"] = dict(iterations=i3["iterations"], converged=bool(i3["converged"]), solve_s=float(ts3),
+                                       ms_per_iteration=float(ts3) / max(1, i3["iterations"]) * 1e3, true_rel_residual=i3["true_rel_residual"],
+                                       hierarchy_setup_ms=g3["setup_ms"], wall_s_with_setup=wall3, aggregates=p3["aggregates"],
+                                       dense_level_dim=p3["coarse_dim"], note=p3["note"],
+                                       speedup_solve_vs_two_level=float(ts) / max(float(ts3), 1e-30))
+    except Exception as e:   # noqa: BLE001 -- the record keeps the two-level numbers
+        out["pcg"]["multigrid"] = dict(error="%s: %s" % (type(e).__name__, e))
     comm.close()
 
 

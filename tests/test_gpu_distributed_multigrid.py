@@ -1,0 +1,99 @@
+"""MFH_PRECOND_MULTIGRID on row-partitioned contexts: ranks sharing ONE MI355X (gloo rendezvous, the communicator's collectives are
+host-staged callbacks). The nodal levels (quadratic, linear) are partitioned like the mesh -- halo exchanges inside the Chebyshev
+smoothers, before the restriction and before the prolongation --, the aggregate levels are replicated (one all-reduce of the
+restricted residual per V-cycle). Checked against the single-context solve of the same problem: same displacements, (about) the
+same mesh-independent iteration count as the unpartitioned V-cycle, far fewer iterations than the partitioned two-level solve."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n, deg, ret):
+    import torch
+    import torch.distributed as dist
+    import meshfem_amd as M
+    from meshfem_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lm = D.slab_local_mesh(n, rank, world, deg)
+        c = M.Context(0)
+        c.mesh_set(3, deg, lm.elem_nodes, lm.node_pos, lm.n_owned)
+        c.material_isotropic(200.0, 0.35)
+        comm = D.make_comm(c, rank, world)
+        solver = D.DistSolver(c, lm, rank, world, comm)
+        all_fixed = np.flatnonzero(lm.lattice[:, 0] == 0)
+        c.fix_variables((3 * all_fixed[:, None] + np.arange(3)[None, :]).ravel())
+        f = D.slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel()
+        c.set_preconditioner(M.PRECOND_MULTIGRID)
+        u_mg, i_mg = solver.solve(f, rtol=1e-10, maxit=2000)
+        g, p = c.multigrid_info(), c.precond_info()
+        # a second solve reuses the hierarchy; other smoother settings keep the answer
+        c.set_option("mg_steps_fine", 2); c.set_option("mg_steps_coarse", 2)
+        u_mg2, i_mg2 = solver.solve(f, rtol=1e-10, maxit=2000)
+        c.set_option("mg_steps_fine", 1); c.set_option("mg_steps_coarse", 1)
+        tl = solver.two_level(16 * world)                       # switches the context to the two-level preconditioner
+        u_tl, i_tl = solver.solve(f, rtol=1e-10, maxit=20000)
+        ret[rank] = dict(keys=lm.keys[:lm.n_owned].copy(), u_mg=u_mg[0].reshape(-1, 3), u_mg2=u_mg2[0].reshape(-1, 3), u_tl=u_tl[0].reshape(-1, 3),
+                         it_mg=i_mg[0]["iterations"], it_mg2=i_mg2[0]["iterations"], it_tl=i_tl[0]["iterations"],
+                         conv=(i_mg[0]["converged"], i_mg2[0]["converged"], i_tl[0]["converged"]), res=i_mg[0]["true_rel_residual"],
+                         info=g, pinfo=p, owned=lm.n_owned)
+        comm.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,n,deg", [(2, 6, 2), (3, 4, 2), (2, 10, 1)])
+def test_partitioned_multigrid_matches_the_single_context_solve(world, n, deg):
+    import torch.multiprocessing as mp
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), n, deg, ret), nprocs=world, join=True)
+    assert set(ret.keys()) == set(range(world))
+    V, T = grid.grid_tet_mesh(n, n, n * world, [0, 0, 0], [1, 1, world])
+    sim = M.Simulator(T, V, deg)
+    sim.setIsotropicMaterial(200.0, 0.35)
+    sim.ctx.bc_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9 + world], [0, 0, 0])
+    sim.ctx.bc_neumann_box([1 - 1e-9, -9, -9], [1 + 1e-9, 9, 9 + world], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    sim.ctx.set_preconditioner(M.PRECOND_MULTIGRID)
+    sim.rtol = 1e-10
+    u_ref = sim.solve()
+    it_single = sim.info["iterations"]
+    m = 4 * n                                                 # quarter lattice of the node keys (slab_local_mesh)
+    lat = np.rint(sim.nodes() * m).astype(np.int64)
+    keys = (lat[:, 0] * (m + 1) + lat[:, 1]) * (m * world + 1) + lat[:, 2]
+    order = np.argsort(keys)
+    seen = 0
+    for r in range(world):
+        d = ret[r]
+        assert all(d["conv"]) and d["res"] < 2e-10, (r, d["conv"], d["res"])
+        idx = order[np.searchsorted(keys[order], d["keys"])]
+        assert np.array_equal(keys[idx], d["keys"])
+        for name in ("u_mg", "u_mg2", "u_tl"):
+            assert np.linalg.norm(d[name] - u_ref[idx]) / np.linalg.norm(u_ref) < 1e-7, (r, name)
+        assert d["info"]["fine_dof"] == d["owned"] and d["pinfo"]["aggregates"] > 0 and d["pinfo"]["note"] == ""
+        seen += len(idx)
+    assert seen == len(keys)
+    its = [ret[r]["it_mg"] for r in range(world)]
+    assert len(set(its)) == 1                                  # every rank counts the same iterations
+    # the partitioned V-cycle is the unpartitioned one up to the aggregate lattice (global bins instead of occupied bins)
+    assert its[0] <= 1.3 * it_single + 4, (its, it_single)
+    assert its[0] < 0.5 * ret[0]["it_tl"], (its, ret[0]["it_tl"])
