@@ -68,8 +68,9 @@ enum {
     /* p-multigrid V-cycle for quadratic elasticity: Chebyshev-smoothed quadratic level (matrix-free operator) -> linear level on the
      * same vertices (its assembled stiffness matrix IS the Galerkin operator: P1 is a subspace of P2) -> rigid-body modes of
      * aggregates, merged 2^dim at a time down to a dense inverse. Linear elements enter the same hierarchy at its linear level (their own
-     * assembled K). Mesh-independent iteration counts (tens instead of hundreds); one right-hand side at a time on an
-     * unpartitioned context, otherwise falls back to MFH_PRECOND_TWO_LEVEL (see mfh_precond_info). Options "mg_steps_fine",
+     * assembled K). Mesh-independent iteration counts (tens instead of hundreds); one right-hand side at a time. On a row-partitioned
+     * context (mfh_dist_solve, the preconditioner set on EVERY rank) the nodal levels are partitioned like the mesh and the aggregate
+     * levels replicated; scalar operators and batches fall back to MFH_PRECOND_TWO_LEVEL (see mfh_precond_info). Options "mg_steps_fine",
      * "mg_steps_coarse", "mg_ratio_fine", "mg_ratio_coarse", "mg_agg_nodes". */
     MFH_PRECOND_MULTIGRID = 4
 };
