@@ -1017,7 +1017,7 @@ void mfh_destroy(mfh_ctx *c) {
     dist_detach(c);
     destroy_multigrid(c);
     for (auto &e : c->dist.ev) if (e) (void)hipEventDestroy(e);
-    if (c->dist.commStream) { (void)hipStreamSynchronize(c->dist.commStream); (void)hipStreamDestroy(c->dist.commStream); }
+    if (c->dist.commStream && !c->dist.commStreamBorrowed) { (void)hipStreamSynchronize(c->dist.commStream); (void)hipStreamDestroy(c->dist.commStream); }
     if (c->negHost) (void)hipHostFree(c->negHost);
     delete c;   // device buffers are freed while the stream is still alive
     if (s && own) (void)hipStreamDestroy(s);

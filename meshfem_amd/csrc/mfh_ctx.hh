@@ -196,6 +196,7 @@ struct mfh_ctx {
         DBuf<double> sendBuf;
         int sendBufW = 0;             // doubles per node the send buffer is sized for
         hipStream_t commStream = nullptr;
+        bool commStreamBorrowed = false;      // the stream belongs to the parent context (linear level of a multigrid hierarchy)
         hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
         DBuf<int32_t> opList;         // element blocks / row chunks: interior first, then those reading a halo column
         int64_t nInterior = 0, nBoundary = 0;

@@ -313,10 +313,11 @@ void dist_setup_child(mfh_ctx *c, mfh_ctx *child, const std::vector<int32_t> &ke
     if (E.recvPtr.back() != child->mesh.nNode - child->mesh.nOwned) throw Error(MFH_ERR_STATE, "child halo does not match the filtered receive lists");
     E.sendNodesHost = idx;
     E.sendIdx.upload(idx.empty() ? std::vector<int32_t>{0} : idx, child->stream);
-    if (!E.commStream) {
-        MFH_HIP(hipStreamCreateWithFlags(&E.commStream, hipStreamNonBlocking));
+    // ONE communication stream per communicator: the child's collectives are issued on the parent's, in program order with them
+    E.commStream = D.commStream;
+    E.commStreamBorrowed = true;
+    if (!E.ev[0])
         for (auto &e : E.ev) MFH_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
     mfh_comm *cm = D.comm;
     if (E.comm != cm) {
         dist_detach(child);

@@ -6,6 +6,7 @@ R=$GRAFT_REPO_ROOT
 timeout 900 python bench.py > gpurun_out/final/bench_n1.json 2> gpurun_out/final/bench_n1.err < /dev/null
 timeout 600 python bench.py --gpus 2 --ranks-per-gpu-ok --no-cpu > gpurun_out/final/bench_n2_weak.out 2> gpurun_out/final/bench_n2_weak.err < /dev/null
 timeout 600 python bench.py --gpus 2 --ranks-per-gpu-ok --scaling strong --grid 48 --no-cpu > gpurun_out/final/bench_n2_strong48.out 2> gpurun_out/final/bench_n2_strong48.err < /dev/null
+timeout 600 python bench.py --gpus 4 --ranks-per-gpu-ok --scaling strong --grid 48 --no-cpu > gpurun_out/final/bench_n4_strong48.out 2> gpurun_out/final/bench_n4_strong48.err < /dev/null
 timeout 600 python bench.py --gpus 1 --scaling strong --grid 48 --no-cpu > gpurun_out/final/bench_n1_strong48.out 2> gpurun_out/final/bench_n1_strong48.err < /dev/null
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/final/prof -- python $R/bench.py --no-cpu > $R/gpurun_out/final/bench_prof.json 2> $R/gpurun_out/final/bench_prof.err < /dev/null
