@@ -100,6 +100,9 @@ public:
         if (aggOfNode.size() != m_numLocal || relPos.size() != 3 * m_numLocal) throw std::runtime_error("setTwoLevelPreconditioner: one entry per local node");
         check(ctx(), mfh_dist_two_level(ctx(), nAggregates, aggOfNode.data(), relPos.data()));
     }
+    // multigrid V-cycle (call it on EVERY rank): nodal levels partitioned like the mesh, aggregate levels replicated; the
+    // hierarchy is built collectively inside the next solve. Needs no aggregates from the caller.
+    void setMultigridPreconditioner() { check(ctx(), mfh_set_preconditioner(ctx(), MFH_PRECOND_MULTIGRID)); }
     std::vector<Real> solve(const std::vector<Real> &fOwned) {
         if (fOwned.size() != N * m_numOwned) throw std::runtime_error("solve: the load has N entries per owned node");
         std::vector<Real> u(fOwned.size());

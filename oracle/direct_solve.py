@@ -226,7 +226,9 @@ class MultifrontalCholesky:
                     if top[k]:
                         self._front(k, upd, dsyrk, blas_threads or 1)
         else:
-            subtree(n_nodes - 1)
+            from threadpoolctl import threadpool_limits
+            with threadpool_limits(limits=blas_threads, user_api="blas") if blas_threads else _nullcontext():
+                subtree(n_nodes - 1)
             self.t_subtrees = time.perf_counter() - t0
         self.flops = float(self._node_flops.sum())
         self.factor_nnz = int(self._node_nnz.sum())
