@@ -134,7 +134,8 @@ mfh_status mfh_mesh_get_elem_nodes(const mfh_ctx* ctx, int32_t* out /* nElem x n
  * numbering, DoF map, sparsity pattern, gather lists and matrix-free lists are kept (they depend on connectivity only), so a
  * shape-optimisation step costs one vertex upload + geometry kernel + numeric assembly instead of a mesh rebuild.
  * Boundary areas / normals are recomputed; boundary-condition VALUES already stored (tractions of pressure regions) are
- * not, exactly like the reference. */
+ * not, exactly like the reference. Contexts built by mfh_mesh_set (row-partitioned ones among them) pass the positions of ALL
+ * their nodes [nNode x dim], halo nodes with the coordinates their owners hold; the exchange lists of mfh_dist_setup stay. */
 mfh_status mfh_mesh_update_vertices(mfh_ctx* ctx, const double* vertPos);
 mfh_status mfh_mesh_get_node_positions(const mfh_ctx* ctx, double* out /* nNode x dim */);
 mfh_status mfh_mesh_get_boundary_elem_nodes(const mfh_ctx* ctx, int32_t* out /* nBE x npbe, volume node ids */);

@@ -1075,7 +1075,9 @@ mfh_status mfh_mesh_update_vertices(mfh_ctx *c, const double *vertPos) {
     MFH_TRY(c)
     require(c && c->haveMesh && vertPos, MFH_ERR_STATE, "no mesh set");
     HostMesh &m = c->mesh;
-    require(m.nOwned == m.nNode, MFH_ERR_UNSUPPORTED, "vertex updates on partitioned meshes are not supported");
+    // row-partitioned contexts come from mfh_mesh_set: the caller hands over the positions of ALL local nodes, the halo nodes with the
+    // coordinates their owners hold (a shape-optimisation step moves the whole mesh on every rank)
+    require(m.nOwned == m.nNode || !m.hasTopology, MFH_ERR_UNSUPPORTED, "vertex updates on a partitioned mesh need the caller's node table (mfh_mesh_set)");
     if (m.hasTopology) {
         m.vertPos.assign(vertPos, vertPos + (size_t)m.nVert * m.dim);
         compute_node_positions(m);
