@@ -258,6 +258,7 @@ def run_single(args):
         args.no_orderings = True
     t0 = time.time()
     V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    T = np.ascontiguousarray(T, dtype=np.int32)            # the C ABI's index type: the conversion belongs to the generator, not to the FEMMesh build
     t_gen = time.time() - t0
     c = M.Context(0)
     t0 = time.time(); c.mesh_build(T, V, deg); t_build = time.time() - t0

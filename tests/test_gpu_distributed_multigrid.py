@@ -167,3 +167,74 @@ def test_partitioned_multigrid_on_an_unstructured_rcb_split():
         assert len({ret[r][name][2] for r in range(world)}) == 1
         assert ret[0][name][2] < 0.5 * ret[0]["block_jacobi_iterations"], (name, ret[0][name][2], ret[0]["block_jacobi_iterations"])
     assert ret[0]["small_bins"][3]["aggregates"] > ret[0]["default"][3]["aggregates"]
+
+
+def _worker_2d(rank, world, port, nx, deg, ret):
+    import torch
+    import torch.distributed as dist
+    import meshfem_amd as M
+    from meshfem_amd import distributed as D, grid
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        V, T = grid.grid_tri_mesh(nx, nx)
+        V = V / float(nx)
+        lm = D.distribute_mesh(V, T, deg, rank, world)
+        c = M.Context(0)
+        c.mesh_set(2, deg, lm.elem_nodes, lm.node_pos[:, :2], lm.n_owned)
+        c.material_isotropic(200.0, 0.35)
+        comm = D.make_comm(c, rank, world)
+        solver = D.DistSolver(c, lm, rank, world, comm)
+        pos = np.asarray(lm.node_pos)[:, :2]
+        fixed = np.flatnonzero(np.abs(pos[:, 0]) < 1e-12)
+        c.fix_variables((2 * fixed[:, None] + np.arange(2)[None, :]).ravel())
+        f = np.zeros((lm.n_owned, 2))
+        f[np.abs(pos[:lm.n_owned, 0] - 1.0) < 1e-12, 1] = -1e-2                      # nodal forces on the right edge
+        c.set_preconditioner(M.PRECOND_MULTIGRID)
+        u, infos = solver.solve(f.ravel(), rtol=1e-10, maxit=2000)
+        it_mg = infos[0]["iterations"]
+        c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+        u2, infos2 = solver.solve(f.ravel(), rtol=1e-10, maxit=50000)
+        ret[rank] = dict(keys=lm.keys[:lm.n_owned].copy(), u=u[0].reshape(-1, 2), u_bj=u2[0].reshape(-1, 2), it_mg=it_mg, it_bj=infos2[0]["iterations"],
+                         conv=bool(infos[0]["converged"]) and bool(infos2[0]["converged"]), pinfo=c.precond_info())
+        comm.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("deg", [2, 1])
+def test_partitioned_multigrid_in_two_dimensions(deg):
+    """Triangles, RCB over two ranks (the 2D instances of the transfer, stencil and aggregate kernels on a partitioned context)."""
+    import torch.multiprocessing as mp
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    world, nx = 2, 24
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_2d, args=(world, _free_port(), nx, deg, ret), nprocs=world, join=True)
+    assert set(ret.keys()) == {0, 1}
+    V, T = grid.grid_tri_mesh(nx, nx)
+    c = M.Context(0)
+    c.mesh_build(T, V / float(nx), deg)
+    c.material_isotropic(200.0, 0.35)
+    pos = c.node_positions()
+    fixed = np.flatnonzero(np.abs(pos[:, 0]) < 1e-12)
+    c.fix_variables((2 * fixed[:, None] + np.arange(2)[None, :]).ravel())
+    f = np.zeros((len(pos), 2)); f[np.abs(pos[:, 0] - 1.0) < 1e-12, 1] = -1e-2
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    u_ref = c.solve(f.ravel(), rtol=1e-10).reshape(-1, 2)
+    it_single = c.last_info["iterations"]
+    c.close()
+    seen = 0
+    for r in range(world):
+        d = ret[r]
+        assert d["conv"] and d["pinfo"]["aggregates"] >= 0
+        for name in ("u", "u_bj"):
+            assert np.linalg.norm(d[name] - u_ref[d["keys"]]) / np.linalg.norm(u_ref) < 1e-7, (r, name)
+        seen += len(d["keys"])
+    assert seen == len(pos)
+    assert ret[0]["it_mg"] == ret[1]["it_mg"] and ret[0]["it_mg"] <= 1.3 * it_single + 4 and ret[0]["it_mg"] < 0.3 * ret[0]["it_bj"], (dict(ret[0]), it_single)
