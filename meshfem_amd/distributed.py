@@ -685,6 +685,7 @@ def _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out, group=None):
                                        speedup_solve_vs_two_level=float(ts) / max(float(ts3), 1e-30))
     except Exception as e:   # noqa: BLE001 -- the record keeps the two-level numbers
         out["pcg"]["multigrid"] = dict(error="%s: %s" % (type(e).__name__, e))
+    out["pcg_multigrid"] = out["pcg"]["multigrid"]             # the key the one-GPU line uses
     comm.close()
 
 
@@ -796,7 +797,12 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
         limit = float(os.environ.get("MFH_BENCH_SOLVE_TIMEOUT_S", "420"))
 
         def expired():
-            if not (isinstance(out.get("pcg"), dict) and "error" in out["pcg"]):
+            msg = "did not finish within %.0f s (collective / interconnect hang?)" % limit
+            if isinstance(out.get("pcg"), dict) and "iterations" in out["pcg"]:
+                # the main solve is on record: what hung is a later leg (classic loop, multigrid)
+                for leg in ("classic_two_reductions", "multigrid"):
+                    out["pcg"].setdefault(leg, dict(error="this leg or the one before it " + msg))
+            elif not (isinstance(out.get("pcg"), dict) and "error" in out["pcg"]):
                 out["pcg"] = dict(error="the solver leg did not finish within %.0f s (collective / interconnect hang?); the assembly "
                                         "figures of this line are complete" % limit)
             if rank == 0:
