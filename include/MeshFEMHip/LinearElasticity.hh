@@ -428,6 +428,12 @@ public:
         check(ctx(), mfh_boundary_strain_field(ctx(), &uNodes[0][0], stress ? 1 : 0, out.data()));
         return out;
     }
+    // sum_e vol_e C_e : (average strain_e(u) + cstrain), reduced on the device (the element loop of homogenizedElasticityTensor)
+    std::array<Real, N *(N + 1) / 2> integratedStress(const VField &uNodes, const std::array<Real, N *(N + 1) / 2> *cstrainFlat = nullptr) const {
+        std::array<Real, N *(N + 1) / 2> out{};
+        check(ctx(), mfh_integrated_stress(ctx(), &uNodes[0][0], cstrainFlat ? cstrainFlat->data() : nullptr, out.data()));
+        return out;
+    }
     SMField averageStressField(const VField &uNodes) const {     // :539-549
         SMField s((size_t)m_numElements);
         check(ctx(), mfh_average_stress(ctx(), &uNodes[0][0], &s[0][0]));

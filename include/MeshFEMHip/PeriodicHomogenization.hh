@@ -95,21 +95,13 @@ ETensor<N> homogenizedElasticityTensor(const std::vector<typename LinearElastici
                                        const LinearElasticity::Simulator<N, Deg> &sim, Real baseCellVolume = 0.0) {
     constexpr size_t FL = flatLen(N);
     const Real cell = detail::cellVolume(sim, baseCellVolume);
-    const auto pos = sim.nodes();
-    const auto vol = sim.elementVolumes();
     ETensor<N> Eh;
     for (size_t i = 0; i < FL; ++i) {
-        size_t a, b;
-        detail::unflatten<N>(i, a, b);
-        auto u = w_ij.at(i);
-        const Real s = (a == b) ? 1.0 : 0.5;
-        for (size_t n = 0; n < u.size(); ++n) {   // u_lin = e_i x
-            u[n][a] += s * pos[n][b];
-            if (a != b) u[n][b] += s * pos[n][a];
-        }
-        const auto sig = sim.averageStressField(u);
-        for (size_t e = 0; e < sig.size(); ++e)
-            for (size_t j = 0; j < FL; ++j) Eh.D[i][j] += vol[e] * sig[e][j] / cell;
+        // Eh.DRow(i) = 1/|Y| sum_e vol_e E_e : (avg strain(w_i) + e_i): one device reduction (mfh_integrated_stress)
+        std::array<Real, FL> ei{};
+        ei[i] = i < N ? 1.0 : 0.5;               // CanonicalBasis(i), tensor shear entries
+        const auto row = sim.integratedStress(w_ij.at(i), &ei);
+        for (size_t j = 0; j < FL; ++j) Eh.D[i][j] = row[j] / cell;
     }
     return Eh;
 }

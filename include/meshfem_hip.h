@@ -294,6 +294,10 @@ mfh_status mfh_sim_solve_constrained(mfh_ctx* ctx, const double* f, int32_t flag
 /* == averageStrainField / averageStressField (:528-549, :99-123): per element, flattened (flatLen) */
 mfh_status mfh_average_strain(mfh_ctx* ctx, const double* uNodes, double* strain /* nElem x flatLen */);
 mfh_status mfh_average_stress(mfh_ctx* ctx, const double* uNodes, double* stress /* nElem x flatLen */);
+/* sum_e vol_e C_e : (averageStrain_e(u) + cstrain)  [flatLen values]: the element loop of homogenizedElasticityTensor
+ * (PeriodicHomogenization.hh:72-100: Eh.DRow(i) = 1/|Y| sum_e vol_e [E_e : strain(w_i) + E_e.DRow(i)]) reduced on the device; cstrainFlat
+ * (flattened, tensor shear entries; NULL = none) stands for the affine displacement of the probe strain e_i. */
+mfh_status mfh_integrated_stress(mfh_ctx* ctx, const double* uNodes, const double* cstrainFlat, double* out /* flatLen */);
 /* == strainField / stressField, elementStrain / elementStress (:493-526; Element::strain :99-117): the nodal values of the
  * degree-(Deg-1) strain interpolant of every element -- one value for P1, the values at the dim+1 corners for P2 (edge
  * nodes of an upsampled field are the means of their end points). out: [nElem][1 | dim+1][flatLen]. */

@@ -93,6 +93,7 @@ PROTOTYPES = {
     "mfh_sim_solve": (_i32, [_P, _P, _i32, _P, _f64, _i32, C.POINTER(SolveInfo)]),
     "mfh_average_strain": (_i32, [_P, _P, _P]),
     "mfh_average_stress": (_i32, [_P, _P, _P]),
+    "mfh_integrated_stress": (_i32, [_P, _P, _P, _P]),
     "mfh_strain_field": (_i32, [_P, _P, _i32, _P]),
     "mfh_boundary_strain_field": (_i32, [_P, _P, _i32, _P]),
     "mfh_mesh_get_boundary_elem_parents": (_i32, [_P, _P]),

@@ -435,6 +435,15 @@ class Context:
         self._ck(self.lib.mfh_average_stress(self.h, ptr(u), ptr(out)))
         return out
 
+    def integrated_stress(self, u_nodes, cstrain_flat=None):
+        """sum_e vol_e C_e : (average strain_e(u) + cstrain) reduced on the device (flatLen values): the element loop of
+        homogenizedElasticityTensor (PeriodicHomogenization.hh:72-100) without a per-element field on the host."""
+        u = as_f64(u_nodes)
+        cs = None if cstrain_flat is None else as_f64(cstrain_flat)
+        out = np.empty(flat_len(self.dim))
+        self._ck(self.lib.mfh_integrated_stress(self.h, ptr(u), None if cs is None else ptr(cs), ptr(out)))
+        return out
+
     # ---------------------------------------------------------------- discrete shape derivatives (forward mode)
     def _delta_p(self, delta_p):
         dp = as_f64(delta_p)

@@ -325,7 +325,8 @@ void launch_constant_strain_load(const AsmArgs &a, const int32_t *elemNodes, con
                                  const double *cstrain, const double *deltaP, double *out, hipStream_t s);
 // deltaP != nullptr: strain(uNodes) + (delta strain)(uFixed)  (deltaAverageStrainField)
 void launch_average_strain(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, double *out,
-                           int wantStress, const double *uFixed, const double *deltaP, hipStream_t s);
+                           int wantStress, const double *uFixed, const double *deltaP, hipStream_t s, const double *addStrain = nullptr,
+                           double *integral = nullptr);
 void launch_apply_delta_K(const AsmArgs &a, const int32_t *elemNodes, const int32_t *dofForNode, const double *intGrad,
                           const double *uNodes, const double *deltaP, double *out, hipStream_t s);
 // out[pair(ij<=kl)] += sum_e mutual energy (deltaP == nullptr) or its shape derivative; w: [flatLen][nNode][dim]

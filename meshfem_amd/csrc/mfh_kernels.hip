@@ -606,12 +606,20 @@ __global__ void __launch_bounds__(256) k_constant_strain_load(LoadArgs a, const 
     }
 }
 
+// add.on: a constant strain (flattened, TENSOR shear) is added to every element's average strain -- the strain of the affine field
+// x -> E x, which then never has to exist as a nodal vector. integral != null: sum_e vol_e * (the element's result) is accumulated
+// there (FL doubles, zeroed by the caller) and `out` may be null: the per-element field stays in registers.
+struct StrainShift { double v[6]; int on; };
 template <int DIM, int DEG, int MAT>
 __global__ void __launch_bounds__(256) k_average_strain(LoadArgs a, const double *__restrict__ uNodes, double *__restrict__ out,
                                                         int wantStress, const double *__restrict__ uFixed,
-                                                        const double *__restrict__ deltaP) {
+                                                        const double *__restrict__ deltaP, StrainShift add, double *__restrict__ integral) {
     constexpr int FL = DIM * (DIM + 1) / 2;
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
+    __shared__ double red[12];
+    double total[FL];
+#pragma unroll
+    for (int q = 0; q < FL; ++q) total[q] = 0.0;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < a.nElem; e += (int64_t)gridDim.x * 256) {
         const double *g = a.geo + e * a.geoStride;
         double eps[DIM][DIM];
@@ -656,16 +664,34 @@ __global__ void __launch_bounds__(256) k_average_strain(LoadArgs a, const double
         for (int x = 0; x < DIM; ++x)
 #pragma unroll
             for (int y = x; y < DIM; ++y) ef[flat_idx<DIM>(x, y)] = eps[x][y];
+        if (add.on)
+#pragma unroll
+            for (int q = 0; q < FL; ++q) ef[q] += add.v[q];
         if (wantStress) {
             double sd[FL], sg[FL];
 #pragma unroll
             for (int q = 0; q < FL; ++q) sd[q] = ef[q] * (q < DIM ? 1.0 : 2.0);
             elem_D_apply<DIM, MAT>(g, sd, sg);
 #pragma unroll
-            for (int q = 0; q < FL; ++q) out[e * FL + q] = sg[q];
-        } else {
+            for (int q = 0; q < FL; ++q) ef[q] = sg[q];
+        }
+        if (out)
 #pragma unroll
             for (int q = 0; q < FL; ++q) out[e * FL + q] = ef[q];
+        if (integral) {
+            const double vol = g[12];
+#pragma unroll
+            for (int q = 0; q < FL; ++q) total[q] += vol * ef[q];
+        }
+    }
+    if (integral) {
+#pragma unroll
+        for (int h = 0; h < FL; h += 3) {
+            double v[3] = {total[h], total[h + 1], total[h + 2]};
+            block_sum<3>(v, red);
+            if (threadIdx.x == 0)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) unsafeAtomicAdd(&integral[h + q], v[q]);
         }
     }
 }
@@ -2036,10 +2062,12 @@ void launch_constant_strain_load(const AsmArgs &a, const int32_t *elemNodes, con
 }
 
 void launch_average_strain(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, double *out,
-                           int wantStress, const double *uFixed, const double *deltaP, hipStream_t s) {
+                           int wantStress, const double *uFixed, const double *deltaP, hipStream_t s, const double *addStrain, double *integral) {
     const LoadArgs l = make_load_args(a, elemNodes, nullptr, intGrad, nullptr);
-    const int grid = grid_for(a.nElem, 8192);
-#define CALL(D, G, M) hipLaunchKernelGGL((k_average_strain<D, G, M>), dim3(grid), dim3(256), 0, s, l, uNodes, out, wantStress, uFixed, deltaP)
+    const int grid = grid_for(a.nElem, integral ? 1024 : 8192);
+    StrainShift add{};
+    if (addStrain) { add.on = 1; for (int q = 0; q < a.dim * (a.dim + 1) / 2; ++q) add.v[q] = addStrain[q]; }
+#define CALL(D, G, M) hipLaunchKernelGGL((k_average_strain<D, G, M>), dim3(grid), dim3(256), 0, s, l, uNodes, out, wantStress, uFixed, deltaP, add, integral)
     MFH_DISPATCH(a, CALL);
 #undef CALL
     CHECK_LAUNCH();

@@ -759,5 +759,24 @@ mfh_status mfh_average_stress(mfh_ctx *c, const double *uNodes, double *stress) 
     average_strain_impl(c, uNodes, stress, true);
     MFH_CATCH(c)
 }
+// sum_e vol_e C_e : (average strain_e(u) + cstrain): the element loop of homogenizedElasticityTensor reduced on the device
+mfh_status mfh_integrated_stress(mfh_ctx *c, const double *uNodes, const double *cstrainFlat, double *out) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && out, MFH_ERR_STATE, "no mesh set");
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "strain / stress fields are defined for the elasticity operator");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    ensure_geometry(c);
+    const HostMesh &m = c->mesh;
+    const int d = m.dim, fl = flat_len(d);
+    c->wx.alloc((size_t)m.nNode * d);
+    MFH_HIP(hipMemcpyAsync(c->wx.p, uNodes, (size_t)m.nNode * d * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    DBuf<double> acc;
+    acc.alloc((size_t)fl);
+    acc.zero(c->stream);
+    k::launch_average_strain(asm_args(c), c->dElemNodes.p, c->tables.intGrad.data(), c->wx.p, nullptr, 1, nullptr, nullptr, c->stream, cstrainFlat, acc.p);
+    acc.download(out, (size_t)fl, c->stream);
+    MFH_CATCH(c)
+}
 
 } // extern "C"

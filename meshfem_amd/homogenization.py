@@ -71,19 +71,16 @@ def solve_cell_problems(sim: Simulator, cell_epsilon=1e-7, ignore_periodic_misma
 
 
 def homogenized_elasticity_tensor(sim: Simulator, w_ij, base_cell_volume=0.0):
-    """== homogenizedElasticityTensor (stress-like form): Eh.DRow(i) = 1/|Y| sum_e vol_e
-    [E_e : avg strain(w_i) + E_e.DRow(i)]. E_e.DRow(i) = E_e : e_i is obtained as the average stress of
-    the linear displacement field with constant strain e_i, so no per-element tensor is read back."""
+    """== homogenizedElasticityTensor (stress-like form, PeriodicHomogenization.hh:72-100): Eh.DRow(i) = 1/|Y| sum_e vol_e
+    [E_e : avg strain(w_i) + E_e.DRow(i)] = 1/|Y| sum_e vol_e E_e : (avg strain(w_i) + e_i): one device reduction per probe
+    strain (mfh_integrated_stress); no per-element field and no affine displacement field visit the host."""
     N, fl = sim.N, flat_len(sim.N)
-    pos = sim.nodes()
-    vol = sim.ctx.elem_volumes()
     if base_cell_volume == 0.0:
+        pos = sim.nodes()
         base_cell_volume = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
     Eh = np.zeros((fl, fl))
     for i in range(fl):
-        u_lin = pos @ _unflatten(N, canonical_strain_flat(N, i)).T
-        sig = sim.averageStressField(w_ij[i] + u_lin)
-        Eh[i, :] = (vol @ sig) / base_cell_volume
+        Eh[i, :] = sim.ctx.integrated_stress(w_ij[i], canonical_strain_flat(N, i)) / base_cell_volume
     return Eh
 
 

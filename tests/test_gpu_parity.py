@@ -1183,3 +1183,30 @@ def test_storage_of_K_follows_what_will_read_it():
     assert not c.matrix_storage()[0]
     assert abs(c.export_scipy() - ref[1]).max() < K_RTOL * abs(ref[1]).max()
     c.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,deg", [(3, 2), (3, 1), (2, 2)])
+def test_integrated_stress_is_the_volume_weighted_sum_of_the_average_stress_field(dim, deg):
+    """mfh_integrated_stress (the element loop of homogenizedElasticityTensor, PeriodicHomogenization.hh:72-100, reduced on the device)
+    against the per-element fields: sum_e vol_e sigma_e(u + E x) with the affine field built on the host."""
+    from meshfem_amd.homogenization import _unflatten
+    if dim == 3:
+        V, T = grid.grid_tet_mesh(3, 4, 2, [0, 0, 0], [1.5, 1, 0.7])
+    else:
+        V, T = grid.grid_tri_mesh(5, 4)
+    c = M.Context(0)
+    c.mesh_build(T, V, deg)
+    c.material_ortho_field(grid.synthetic_orthotropic_field(len(T), dim, seed=3))
+    rng = np.random.default_rng(1)
+    pos = c.node_positions()
+    u = rng.standard_normal(pos.shape)
+    fl = dim * (dim + 1) // 2
+    cs = rng.standard_normal(fl)
+    vol = c.elem_volumes()
+    ref0 = vol @ c.average_stress(u)
+    ref1 = vol @ c.average_stress(u + pos @ _unflatten(dim, cs).T)
+    got0, got1 = c.integrated_stress(u), c.integrated_stress(u, cs)
+    assert np.abs(got0 - ref0).max() <= 1e-12 * np.abs(ref0).max()
+    assert np.abs(got1 - ref1).max() <= 1e-12 * np.abs(ref1).max() and np.abs(ref1 - ref0).max() > 1e-3 * np.abs(ref0).max()
+    c.close()
