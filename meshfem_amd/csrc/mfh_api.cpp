@@ -54,17 +54,26 @@ void invalidate_symbolic(mfh_ctx *c) {
     c->dofUploaded = false;
     invalidate_matrix(c);
 }
+// v = n copies of value, written by all host threads (these per-node tables are hundreds of MB at the benchmark sizes: a
+// single-threaded assign was a third of the mesh upload)
+template <class V, class T>
+static void parallel_assign(V &v, size_t n, T value) {
+    v.resize(n);
+    auto *p = v.data();
+    parallel_ranges((int64_t)n, [&](int64_t b, int64_t e, int) { for (int64_t k = b; k < e; ++k) p[k] = value; });
+}
+
 void reset_bcs(mfh_ctx *c) {
     const HostMesh &m = c->mesh;
     c->neumannTraction.assign((size_t)m.nBE() * m.dim, 0.0);
-    c->dirMask.assign((size_t)m.nNode * m.dim, 0);
-    c->dirVal.assign((size_t)m.nNode * m.dim, 0.0);
+    parallel_assign(c->dirMask, (size_t)m.nNode * m.dim, (uint8_t)0);
+    parallel_assign(c->dirVal, (size_t)m.nNode * m.dim, 0.0);
     c->deltaForces.clear();
 }
 void clear_fixed(mfh_ctx *c) {
     c->fixedVars.clear();
     c->fixedVals.clear();
-    c->hFixedMask.assign((size_t)c->bs() * c->nDoF, 0);
+    parallel_assign(c->hFixedMask, (size_t)c->bs() * c->nDoF, (uint8_t)0);
     c->fixedUploaded = false;
     c->anyFixedNonzero = false;
     c->dinvValid = false;
@@ -556,8 +565,9 @@ bool ensure_twolevel(mfh_ctx *c) {
     // modes of aggregates at the seam are no longer exact rigid motions, but any full-rank Z is a valid
     // Galerkin coarse space.
     std::vector<double> dofPosStore;
-    const std::vector<double> *dofPosPtr = &m.nodePos;
-    if (!c->dofForNode.empty()) {
+    const std::vector<double> *dofPosPtr = &dofPosStore;
+    if (c->dofForNode.empty()) dofPosStore.assign(m.nodePos.begin(), m.nodePos.end());     // (host validation variant of the setup)
+    else {
         dofPosStore.assign((size_t)nDoF * d, 0.0);
         std::vector<uint8_t> seen((size_t)nDoF, 0);
         for (int64_t n = 0; n < m.nNode; ++n) {
@@ -1045,8 +1055,12 @@ mfh_status mfh_mesh_build(mfh_ctx *c, int32_t dim, int32_t deg, int64_t nElem, i
     require(c && elemVerts && vertPos, MFH_ERR_INVALID, "null argument");
     if (!c->hostOnly) MFH_HIP(hipSetDevice(c->device));
     build_fem_mesh(c->mesh, dim, deg, nElem, nVert, elemVerts, vertPos, !c->hostOnly && c->topologyDevice, c->stream);
+    const bool timing = getenv("MFH_MESH_TIMING") != nullptr;
+    double t0 = now_ms();
     upload_mesh(c);
+    if (timing) { if (!c->hostOnly) (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[mesh build] %-30s %8.2f ms\n", "upload + tables", now_ms() - t0); t0 = now_ms(); }
     if (!c->hostOnly) ensure_geometry(c);   // throws on negative volumes like the Simulator ctor
+    if (timing) fprintf(stderr, "[mesh build] %-30s %8.2f ms\n", "embedding kernel + check", now_ms() - t0);
     MFH_CATCH(c)
 }
 

@@ -113,7 +113,7 @@ struct mfh_ctx {
     // ---- constraints (SPSDSystem state)
     std::vector<int64_t> fixedVars;
     std::vector<double> fixedVals;
-    std::vector<uint8_t> hFixedMask;
+    RawVec<uint8_t> hFixedMask;
     DBuf<uint8_t> dFixedMask;
     DBuf<int64_t> dFixedIdx;
     DBuf<double> dFixedVal;
@@ -219,8 +219,8 @@ struct mfh_ctx {
 
     // ---- Simulator-level boundary conditions
     std::vector<double> neumannTraction;   // nBE x dim
-    std::vector<uint8_t> dirMask;          // nNode x dim
-    std::vector<double> dirVal;            // nNode x dim
+    RawVec<uint8_t> dirMask;               // nNode x dim   (RawVec: sized, then filled by all host threads, see parallel_assign)
+    RawVec<double> dirVal;                 // nNode x dim
     std::vector<std::pair<int64_t, std::array<double, 3>>> deltaForces;
 
     // ---- options

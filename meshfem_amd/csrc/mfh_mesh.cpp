@@ -201,6 +201,7 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
     if (nElem <= 0 || nVert <= 0) throw Error(MFH_ERR_INVALID, "empty mesh");
     const int nv = dim + 1;
     const int nedge = dim == 3 ? 6 : 3;
+    const double tEnter = now_ms();
     m = HostMesh();
     m.dim = dim; m.deg = deg; m.npe = nodes_per_elem(dim, deg); m.npbe = nodes_per_bdry_elem(dim, deg);
     m.nElem = nElem; m.nVert = nVert;
@@ -215,7 +216,7 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
             if (b) throw Error(MFH_ERR_INVALID, "Bad vertex index encountered.");
     }
     const bool timing = getenv("MFH_MESH_TIMING") != nullptr;
-    double tp = now_ms();
+    double tp = tEnter;
     auto lap = [&](const char *what) {
         if (!timing) return;
         const double t = now_ms();
@@ -223,6 +224,7 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
         tp = t;
     };
 
+    lap("vertex copy + index check");
     // ---- topology: edge nodes in first-encounter order over (element, local edge) (FEMMesh.inl:22-36) and
     //      the unmatched half-faces / half-edges in sorted-key order (TetMesh.inl:36-79, TriMesh.inl:60-100)
     std::vector<int32_t> instEdge;

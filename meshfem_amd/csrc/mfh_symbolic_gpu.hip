@@ -159,6 +159,15 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     S.nRows = nOwnedDoF;
     S.nCols = nDoF;
     const int64_t nRows = S.nRows;
+    const bool timing = getenv("MFH_SYM_TIMING") != nullptr;
+    double tp = now_ms();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        const double t = now_ms();
+        fprintf(stderr, "[symbolic] %-36s %8.2f ms\n", what, t - tp);
+        tp = t;
+    };
 
     DBuf<uint64_t> keyA, keyB;
     DBuf<uint32_t> valA, valB, slotP1;
@@ -169,6 +178,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     hipLaunchKernelGGL(k_sym_gen, dim3(grid_of(N)), dim3(256), 0, s, N, npe, dElemNodes, dDofForNode, nRows, keyA.p, valA.p, dCount.p, upperOnly ? 1 : 0);
     RP(hipGetLastError());
 
+    lap("allocate + generate keys");
     // ---- sort by (row, col); stable, so equal keys stay in code order
     const unsigned endBit1 = 32 + bits_for((uint64_t)nRows);
     size_t tmpBytes = 0;
@@ -181,6 +191,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     const int64_t nC = (int64_t)nValidU;                 // contributions whose row is owned (sorted first)
     if (nC == 0) throw Error(MFH_ERR_INVALID, "no element touches an owned row");
 
+    lap("sort by (row, col)");
     // ---- slots = distinct (row, col) pairs
     slotP1.alloc(nC);
     valA.release();
@@ -195,6 +206,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     if (nnzbU > 2147483647u) throw Error(MFH_ERR_UNSUPPORTED, "more than 2^31 blocks on one device");
     S.nnzb = nnzbU;
 
+    lap("slot heads + scan");
     dColIdx.alloc((size_t)S.nnzb);
     DBuf<int32_t> rowLen;
     DBuf<int64_t> rowCStart;
@@ -223,6 +235,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     for (int64_t r = nRows - 1; r >= 0; --r) if (hCStart[r] < 0) hCStart[r] = hCStart[r + 1];   // empty rows
     for (int64_t r = 0; r < nRows; ++r) S.maxRowLen = std::max(S.maxRowLen, S.rowPtr[r + 1] - S.rowPtr[r]);
 
+    lap("pattern + row pointers + downloads");
     // ---- chunks (host: a scan over the row pointers)
     if (chunkSlots < 64) chunkSlots = 64;
     if (S.maxRowLen > chunkSlots) chunkSlots = ((S.maxRowLen + 63) / 64) * 64;
@@ -242,6 +255,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     }
     S.contribPtr[nChunk] = nC;
 
+    lap("chunks (host)");
     // ---- element-major order inside every chunk: sort by (chunk, code)
     DBuf<int32_t> dChunkOfRow, dChunkBase;
     dChunkOfRow.upload(chunkOfRow, s);
@@ -263,6 +277,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     hipLaunchKernelGGL(k_sym_codes, dim3(grid_of(nC)), dim3(256), 0, s, nC, keyB.p, dContribCode.p);
     RP(hipGetLastError());
     MFH_HIP(hipStreamSynchronize(s));
+    lap("sort by (chunk, code) + lists");
 }
 
 
