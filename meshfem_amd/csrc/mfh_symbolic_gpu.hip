@@ -229,11 +229,20 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     RP(rocprim::exclusive_scan(tmp.p, exBytes, rowLen.p, dRowPtr.p, (int32_t)0, (size_t)nRows + 1, rocprim::plus<int32_t>(), s));
     S.rowPtr.resize((size_t)nRows + 1);
     dRowPtr.download(S.rowPtr.data(), S.rowPtr.size(), s);
-    std::vector<int64_t> hCStart((size_t)nRows + 1);
+    RawVec<int64_t> hCStart;                        // (filled by the download: no zero fill)
+    hCStart.resize((size_t)nRows + 1);
     rowCStart.download(hCStart.data(), hCStart.size(), s);
     hCStart[nRows] = nC;
     for (int64_t r = nRows - 1; r >= 0; --r) if (hCStart[r] < 0) hCStart[r] = hCStart[r + 1];   // empty rows
-    for (int64_t r = 0; r < nRows; ++r) S.maxRowLen = std::max(S.maxRowLen, S.rowPtr[r + 1] - S.rowPtr[r]);
+    {
+        std::vector<int32_t> mx((size_t)host_threads() + 1, 0);
+        parallel_ranges(nRows, [&](int64_t b, int64_t e, int tid) {
+            int32_t v = 0;
+            for (int64_t r = b; r < e; ++r) v = std::max(v, S.rowPtr[r + 1] - S.rowPtr[r]);
+            mx[(size_t)tid] = std::max(mx[(size_t)tid], v);
+        });
+        for (int32_t v : mx) S.maxRowLen = std::max(S.maxRowLen, v);
+    }
 
     lap("pattern + row pointers + downloads");
     // ---- chunks (host: a scan over the row pointers)
@@ -242,17 +251,24 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     if (chunkSlots > 2048)
         throw Error(MFH_ERR_UNSUPPORTED, "a block row has more than 2048 blocks (vertex valence too high for LDS accumulation)");
     S.chunkSlots = chunkSlots;
-    S.chunkRow = make_chunks(S.rowPtr, nRows, chunkSlots);
     S.spmvChunkSlots = std::max(512, chunkSlots);
-    S.spmvChunkRow = make_chunks(S.rowPtr, nRows, S.spmvChunkSlots);
-    const int64_t nChunk = S.nChunk();
-    std::vector<int32_t> chunkOfRow((size_t)nRows), chunkBase((size_t)nChunk);
-    S.contribPtr.resize((size_t)nChunk + 1);
-    for (int64_t c = 0; c < nChunk; ++c) {
-        chunkBase[c] = S.rowPtr[S.chunkRow[c]];
-        S.contribPtr[c] = hCStart[S.chunkRow[c]];
-        for (int32_t r = S.chunkRow[c]; r < S.chunkRow[c + 1]; ++r) chunkOfRow[r] = (int32_t)c;
+    {   // the two greedy scans are sequential by nature: they run side by side
+        std::thread other([&]() { S.spmvChunkRow = make_chunks(S.rowPtr, nRows, S.spmvChunkSlots); });
+        S.chunkRow = make_chunks(S.rowPtr, nRows, chunkSlots);
+        other.join();
     }
+    const int64_t nChunk = S.nChunk();
+    RawVec<int32_t> chunkOfRow;
+    chunkOfRow.resize((size_t)nRows);
+    std::vector<int32_t> chunkBase((size_t)nChunk);
+    S.contribPtr.resize((size_t)nChunk + 1);
+    parallel_ranges(nChunk, [&](int64_t cb, int64_t ce, int) {
+        for (int64_t c = cb; c < ce; ++c) {
+            chunkBase[c] = S.rowPtr[S.chunkRow[c]];
+            S.contribPtr[c] = hCStart[S.chunkRow[c]];
+            for (int32_t r = S.chunkRow[c]; r < S.chunkRow[c + 1]; ++r) chunkOfRow[r] = (int32_t)c;
+        }
+    });
     S.contribPtr[nChunk] = nC;
 
     lap("chunks (host)");
