@@ -32,6 +32,43 @@ __global__ void __launch_bounds__(256) k_sym_gen(int64_t N, int npe, const int32
     if ((threadIdx.x & 63) == 0 && local) atomicAdd(nValid, local);
 }
 
+// The same keys, only the valid ones (owned row; with upper-only storage: col >= row), in code order: pass 1 counts them per element,
+// an exclusive scan gives every element its offset, pass 2 writes. The sort then runs over nC instead of nElem npe^2 entries
+// (55 % of them with the upper triangle of a quadratic mesh).
+__global__ void __launch_bounds__(256) k_sym_count(int64_t nElem, int npe, const int32_t *__restrict__ elemNodes, const int32_t *__restrict__ dofForNode,
+                                                   int64_t nRows, int upperOnly, uint32_t *__restrict__ cnt) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nElem; e += (int64_t)gridDim.x * 256) {
+        int64_t dof[10];
+        for (int i = 0; i < npe; ++i) { const int32_t n = elemNodes[e * npe + i]; dof[i] = dofForNode ? dofForNode[n] : n; }
+        uint32_t c = 0;
+        for (int i = 0; i < npe; ++i) {
+            if (dof[i] >= nRows) continue;
+            if (!upperOnly) { c += (uint32_t)npe; continue; }
+            for (int j = 0; j < npe; ++j) c += dof[j] >= dof[i];
+        }
+        cnt[e] = c;
+    }
+}
+__global__ void __launch_bounds__(256) k_sym_gen_compact(int64_t nElem, int npe, const int32_t *__restrict__ elemNodes, const int32_t *__restrict__ dofForNode,
+                                                         int64_t nRows, int upperOnly, const uint32_t *__restrict__ off, uint64_t *__restrict__ key,
+                                                         uint32_t *__restrict__ val) {
+    const int npe2 = npe * npe;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nElem; e += (int64_t)gridDim.x * 256) {
+        int64_t dof[10];
+        for (int i = 0; i < npe; ++i) { const int32_t n = elemNodes[e * npe + i]; dof[i] = dofForNode ? dofForNode[n] : n; }
+        int64_t w = off[e];
+        for (int i = 0; i < npe; ++i) {
+            if (dof[i] >= nRows) continue;
+            for (int j = 0; j < npe; ++j) {
+                if (upperOnly && dof[j] < dof[i]) continue;
+                key[w] = ((uint64_t)dof[i] << 32) | (uint64_t)dof[j];
+                val[w] = (uint32_t)(e * npe2 + i * npe + j);
+                ++w;
+            }
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) k_sym_heads(int64_t n, const uint64_t *__restrict__ key, uint32_t *__restrict__ head) {
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
         head[k] = (k == 0 || key[k] != key[k - 1]) ? 1u : 0u;
@@ -171,25 +208,37 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
 
     DBuf<uint64_t> keyA, keyB;
     DBuf<uint32_t> valA, valB, slotP1;
-    DBuf<unsigned long long> dCount;
-    keyA.alloc(N); keyB.alloc(N); valA.alloc(N); valB.alloc(N);
-    dCount.alloc(1);
-    dCount.zero(s);
-    hipLaunchKernelGGL(k_sym_gen, dim3(grid_of(N)), dim3(256), 0, s, N, npe, dElemNodes, dDofForNode, nRows, keyA.p, valA.p, dCount.p, upperOnly ? 1 : 0);
+    // ---- the valid contributions only, in code order (count per element, scan, write)
+    DBuf<uint32_t> cnt;
+    cnt.alloc((size_t)m.nElem + 1);
+    MFH_HIP(hipMemsetAsync(cnt.p + m.nElem, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_sym_count, dim3(grid_of(m.nElem)), dim3(256), 0, s, m.nElem, npe, dElemNodes, dDofForNode, nRows, upperOnly ? 1 : 0, cnt.p);
     RP(hipGetLastError());
+    DBuf<char> tmp;
+    {
+        size_t scanBytes0 = 0;
+        RP(rocprim::exclusive_scan(nullptr, scanBytes0, cnt.p, cnt.p, (uint32_t)0, (size_t)m.nElem + 1, rocprim::plus<uint32_t>(), s));
+        tmp.alloc(scanBytes0 + 16);
+        RP(rocprim::exclusive_scan(tmp.p, scanBytes0, cnt.p, cnt.p, (uint32_t)0, (size_t)m.nElem + 1, rocprim::plus<uint32_t>(), s));
+    }
+    uint32_t nValidU = 0;
+    MFH_HIP(hipMemcpyAsync(&nValidU, cnt.p + m.nElem, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    const int64_t nC = (int64_t)nValidU;                 // contributions whose row is owned (and, with upper-only storage, col >= row)
+    if (nC == 0) throw Error(MFH_ERR_INVALID, "no element touches an owned row");
+    keyA.alloc(nC); keyB.alloc(nC); valA.alloc(nC); valB.alloc(nC);
+    hipLaunchKernelGGL(k_sym_gen_compact, dim3(grid_of(m.nElem)), dim3(256), 0, s, m.nElem, npe, dElemNodes, dDofForNode, nRows, upperOnly ? 1 : 0, cnt.p,
+                       keyA.p, valA.p);
+    RP(hipGetLastError());
+    cnt.release();
 
     lap("allocate + generate keys");
     // ---- sort by (row, col); stable, so equal keys stay in code order
     const unsigned endBit1 = 32 + bits_for((uint64_t)nRows);
     size_t tmpBytes = 0;
-    RP(rocprim::radix_sort_pairs(nullptr, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)N, 0u, endBit1, s));
-    DBuf<char> tmp;
-    tmp.alloc(tmpBytes + 16);
-    RP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)N, 0u, endBit1, s));
-    unsigned long long nValidU = 0;
-    dCount.download(&nValidU, 1, s);
-    const int64_t nC = (int64_t)nValidU;                 // contributions whose row is owned (sorted first)
-    if (nC == 0) throw Error(MFH_ERR_INVALID, "no element touches an owned row");
+    RP(rocprim::radix_sort_pairs(nullptr, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)nC, 0u, endBit1, s));
+    if (tmpBytes + 16 > tmp.n) tmp.alloc(tmpBytes + 16);
+    RP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)nC, 0u, endBit1, s));
 
     lap("sort by (row, col)");
     // ---- slots = distinct (row, col) pairs
@@ -214,6 +263,8 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     rowLen.zero(s);
     rowCStart.alloc((size_t)nRows + 1);
     MFH_HIP(hipMemsetAsync(rowCStart.p, 0xff, (size_t)(nRows + 1) * sizeof(int64_t), s));   // -1 = empty row
+    DBuf<unsigned long long> dCount;
+    dCount.alloc(1);
     dCount.zero(s);
     hipLaunchKernelGGL(k_sym_pattern, dim3(grid_of(nC)), dim3(256), 0, s, nC, keyB.p, slotP1.p, dColIdx.p, rowLen.p, rowCStart.p, nRows, dCount.p);
     {
