@@ -229,7 +229,9 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
         pack_gather_codes(c);
         c->timing.symbolic_ms = now_ms() - t0;
         const size_t tilesD = (size_t)((S.nnzb + 63) / 64);
+        const double tV = now_ms();
         c->dVals.alloc(tilesD * 64 * (size_t)c->dim() * c->dim());
+        if (getenv("MFH_SYM_TIMING")) fprintf(stderr, "[symbolic] value array %.1f MB: allocation %.2f ms\n", tilesD * 64.0 * c->dim() * c->dim() * 8 / 1e6, now_ms() - tV);
         c->symValid = true;
         ++c->listsGen;
         invalidate_matrix(c);

@@ -103,7 +103,7 @@ __global__ void __launch_bounds__(256) k_sym_key2(int64_t n, const uint64_t *__r
         const int64_t row = (int64_t)(key[k] >> 32);
         const int32_t ch = chunkOfRow[row];
         const int32_t slot = (int32_t)(slotP1[k] - 1);
-        key2[k] = ((uint64_t)(uint32_t)ch << 32) | (uint64_t)val[k];
+        if (key2) key2[k] = ((uint64_t)(uint32_t)ch << 32) | (uint64_t)val[k];
         lslot[k] = (uint16_t)(slot - chunkBase[ch]);
         if (scatterSlot) scatterSlot[val[k]] = slot;
     }
@@ -198,9 +198,11 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     const int64_t nRows = S.nRows;
     const bool timing = getenv("MFH_SYM_TIMING") != nullptr;
     double tp = now_ms();
+    // every phase ends with a stream synchronisation: the buffers released and allocated in between then never meet kernels in
+    // flight (hipFree / hipMalloc behind a busy stream stalled for 0.2 - 0.8 s, erratically, at 5 M elements)
     auto lap = [&](const char *what) {
-        if (!timing) return;
         (void)hipStreamSynchronize(s);
+        if (!timing) return;
         const double t = now_ms();
         fprintf(stderr, "[symbolic] %-36s %8.2f ms\n", what, t - tp);
         tp = t;
@@ -237,8 +239,17 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     const unsigned endBit1 = 32 + bits_for((uint64_t)nRows);
     size_t tmpBytes = 0;
     RP(rocprim::radix_sort_pairs(nullptr, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)nC, 0u, endBit1, s));
-    if (tmpBytes + 16 > tmp.n) tmp.alloc(tmpBytes + 16);
-    RP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)nC, 0u, endBit1, s));
+    {
+        const double tA = now_ms();
+        if (tmpBytes + 16 > tmp.n) tmp.alloc(tmpBytes + 16);
+        const double tB = now_ms();
+        RP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)nC, 0u, endBit1, s));
+        if (timing) {
+            const double tC = now_ms();
+            (void)hipStreamSynchronize(s);
+            fprintf(stderr, "[symbolic] first sort: %.1f MB temporary, allocation %.2f ms, enqueue %.2f ms, run %.2f ms\n", tmpBytes / 1e6, tB - tA, tC - tB, now_ms() - tC);
+        }
+    }
 
     lap("sort by (row, col)");
     // ---- slots = distinct (row, col) pairs
@@ -330,19 +341,27 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     DBuf<uint16_t> lsA;
     lsA.alloc((size_t)nC);
     if (wantScatter) { dScatter.alloc((size_t)N); MFH_HIP(hipMemsetAsync(dScatter.p, 0xff, (size_t)N * sizeof(int32_t), s)); }
-    hipLaunchKernelGGL(k_sym_key2, dim3(grid_of(nC)), dim3(256), 0, s, nC, keyB.p, valB.p, slotP1.p, dChunkOfRow.p, dChunkBase.p, keyA.p,
+    keyA.release();
+    hipLaunchKernelGGL(k_sym_key2, dim3(grid_of(nC)), dim3(256), 0, s, nC, keyB.p, valB.p, slotP1.p, dChunkOfRow.p, dChunkBase.p, (uint64_t *)nullptr,
                        lsA.p, wantScatter ? dScatter.p : nullptr);
     RP(hipGetLastError());
-    slotP1.release(); valB.release(); rowLen.release(); rowCStart.release();
+    slotP1.release(); rowLen.release(); rowCStart.release();
+    // The contributions are already grouped by chunk (chunks are ranges of rows, the first sort ordered the rows): what is left is the
+    // order inside each chunk, a SEGMENTED sort of 32-bit codes over ~650-entry segments instead of a second full-length 64-bit sort
     dContribSlot.alloc((size_t)nC);
-    const unsigned endBit2 = 32 + bits_for((uint64_t)nChunk);
-    size_t tmp2 = 0;
-    RP(rocprim::radix_sort_pairs(nullptr, tmp2, keyA.p, keyB.p, lsA.p, dContribSlot.p, (size_t)nC, 0u, endBit2, s));
-    if (tmp2 + 16 > tmp.n) tmp.alloc(tmp2 + 16);
-    RP(rocprim::radix_sort_pairs(tmp.p, tmp2, keyA.p, keyB.p, lsA.p, dContribSlot.p, (size_t)nC, 0u, endBit2, s));
     dContribCode.alloc((size_t)nC);
-    hipLaunchKernelGGL(k_sym_codes, dim3(grid_of(nC)), dim3(256), 0, s, nC, keyB.p, dContribCode.p);
-    RP(hipGetLastError());
+    DBuf<int64_t> dSeg;
+    dSeg.upload(S.contribPtr, s);
+    const unsigned endBit2 = bits_for((uint64_t)N);
+    size_t tmp2 = 0;
+    RP(rocprim::segmented_radix_sort_pairs(nullptr, tmp2, valB.p, dContribCode.p, lsA.p, dContribSlot.p, (unsigned int)nC, (unsigned int)nChunk, dSeg.p,
+                                           dSeg.p + 1, 0u, endBit2, s));
+    const double tA = now_ms();
+    if (tmp2 + 16 > tmp.n) tmp.alloc(tmp2 + 16);
+    const double tB = now_ms();
+    if (getenv("MFH_SYM_TIMING")) fprintf(stderr, "[symbolic] segmented sort: %.1f MB of temporary storage, allocation %.2f ms\n", tmp2 / 1e6, tB - tA);
+    RP(rocprim::segmented_radix_sort_pairs(tmp.p, tmp2, valB.p, dContribCode.p, lsA.p, dContribSlot.p, (unsigned int)nC, (unsigned int)nChunk, dSeg.p,
+                                           dSeg.p + 1, 0u, endBit2, s));
     MFH_HIP(hipStreamSynchronize(s));
     lap("sort by (chunk, code) + lists");
 }

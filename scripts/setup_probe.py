@@ -12,7 +12,7 @@ from meshfem_amd import grid
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 deg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
-for rep in range(2):
+for rep in range(int(os.environ.get("REPS", "2"))):
     c = M.Context(0)
     t0 = time.perf_counter()
     c.mesh_build(T, V, deg)
