@@ -95,6 +95,18 @@ __global__ void __launch_bounds__(256) k_sym_pattern(int64_t n, const uint64_t *
     if ((threadIdx.x & 63) == 0 && mirror) atomicAdd(nMirror, mirror);
 }
 
+// first contribution of every chunk = that of its first row (an empty row takes the next row's: none in a valid mesh)
+__global__ void __launch_bounds__(256) k_sym_chunk_starts(int64_t nChunk, const int32_t *__restrict__ chunkRow, const int64_t *__restrict__ rowCStart,
+                                                          int64_t nRows, int64_t nC, int64_t *__restrict__ contribPtr) {
+    for (int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x; c <= nChunk; c += (int64_t)gridDim.x * 256) {
+        int64_t v = nC;
+        if (c < nChunk)
+            for (int64_t r = chunkRow[c]; r < nRows; ++r)
+                if (rowCStart[r] >= 0) { v = rowCStart[r]; break; }
+        contribPtr[c] = v;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_sym_key2(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val,
                                                   const uint32_t *__restrict__ slotP1, const int32_t *__restrict__ chunkOfRow,
                                                   const int32_t *__restrict__ chunkBase, uint64_t *__restrict__ key2,
@@ -291,11 +303,6 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     RP(rocprim::exclusive_scan(tmp.p, exBytes, rowLen.p, dRowPtr.p, (int32_t)0, (size_t)nRows + 1, rocprim::plus<int32_t>(), s));
     S.rowPtr.resize((size_t)nRows + 1);
     dRowPtr.download(S.rowPtr.data(), S.rowPtr.size(), s);
-    RawVec<int64_t> hCStart;                        // (filled by the download: no zero fill)
-    hCStart.resize((size_t)nRows + 1);
-    rowCStart.download(hCStart.data(), hCStart.size(), s);
-    hCStart[nRows] = nC;
-    for (int64_t r = nRows - 1; r >= 0; --r) if (hCStart[r] < 0) hCStart[r] = hCStart[r + 1];   // empty rows
     {
         std::vector<int32_t> mx((size_t)host_threads() + 1, 0);
         parallel_ranges(nRows, [&](int64_t b, int64_t e, int tid) {
@@ -324,14 +331,22 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     chunkOfRow.resize((size_t)nRows);
     std::vector<int32_t> chunkBase((size_t)nChunk);
     S.contribPtr.resize((size_t)nChunk + 1);
+    DBuf<int64_t> dSeg;                            // the chunks' first contributions: gathered on the device (the per-row table stays there)
+    DBuf<int32_t> dCR;
+    {
+        dCR.upload(S.chunkRow, s);
+        dSeg.alloc((size_t)nChunk + 1);
+        hipLaunchKernelGGL(k_sym_chunk_starts, dim3(grid_of(nChunk + 1)), dim3(256), 0, s, nChunk, dCR.p, rowCStart.p, nRows, nC, dSeg.p);
+        RP(hipGetLastError());
+        MFH_HIP(hipMemcpyAsync(S.contribPtr.data(), dSeg.p, (size_t)(nChunk + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    }
     parallel_ranges(nChunk, [&](int64_t cb, int64_t ce, int) {
         for (int64_t c = cb; c < ce; ++c) {
             chunkBase[c] = S.rowPtr[S.chunkRow[c]];
-            S.contribPtr[c] = hCStart[S.chunkRow[c]];
             for (int32_t r = S.chunkRow[c]; r < S.chunkRow[c + 1]; ++r) chunkOfRow[r] = (int32_t)c;
         }
     });
-    S.contribPtr[nChunk] = nC;
+    MFH_HIP(hipStreamSynchronize(s));
 
     lap("chunks (host)");
     // ---- element-major order inside every chunk: sort by (chunk, code)
@@ -350,8 +365,6 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     // order inside each chunk, a SEGMENTED sort of 32-bit codes over ~650-entry segments instead of a second full-length 64-bit sort
     dContribSlot.alloc((size_t)nC);
     dContribCode.alloc((size_t)nC);
-    DBuf<int64_t> dSeg;
-    dSeg.upload(S.contribPtr, s);
     const unsigned endBit2 = bits_for((uint64_t)N);
     size_t tmp2 = 0;
     RP(rocprim::segmented_radix_sort_pairs(nullptr, tmp2, valB.p, dContribCode.p, lsA.p, dContribSlot.p, (unsigned int)nC, (unsigned int)nChunk, dSeg.p,
