@@ -341,6 +341,21 @@ def run_single(args):
                           preconditioner="two-level: 3x3 block-Jacobi + rigid-body modes of %d aggregates" % p2["aggregates"],
                           coarse_setup_ms=p2["setup_ms"], coarse_dim=p2["coarse_dim"], wall_s=time.time() - t0, max_abs_u=float(np.abs(u).max()),
                           operator="matrix-free (k_mf_cluster + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)", ranks=1)
+        # ... and the multigrid V-cycle, which the N > 1 runs report as pcg_multigrid too (partitioned nodal levels there)
+        try:
+            c.set_preconditioner(M.PRECOND_MULTIGRID)
+            t0 = time.time()
+            u3 = c.sim_solve(rtol=args.rtol, maxit=min(args.maxit, 2000))
+            i3, p3, g3 = dict(c.last_info), c.precond_info(), c.multigrid_info()
+            out["pcg_multigrid"] = dict(iterations=i3["iterations"], converged=bool(i3["converged"]), true_rel_residual=i3["true_rel_residual"],
+                                        solve_s=i3["solve_ms"] * 1e-3, ms_per_iteration=i3["solve_ms"] / max(1, i3["iterations"]),
+                                        hierarchy_setup_ms=g3["setup_ms"], wall_s_with_setup=time.time() - t0, aggregates=p3["aggregates"],
+                                        dense_level_dim=p3["coarse_dim"], note=p3["note"],
+                                        speedup_solve_vs_two_level=i2["solve_ms"] / max(i3["solve_ms"], 1e-30),
+                                        rel_l2_vs_two_level=float(np.linalg.norm(u3 - u) / np.linalg.norm(u)))
+            del u3
+        except M.MeshFEMHipError as e:
+            out["pcg_multigrid"] = str(e)
     elif not args.no_solve:
         t0 = time.time()
         u = c.sim_solve(rtol=args.rtol, maxit=args.maxit)
