@@ -211,8 +211,13 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
         // ---- device path: two radix sorts (mfh_symbolic_gpu.hip)
         require_device(c);
         MFH_HIP(hipSetDevice(c->device));
+        // the gather codes leave the phase chunk-relative and packed (what k_assemble_gather reads) unless the host copy of the lists is
+        // wanted (absolute codes, the host implementation's format) or the option is off
+        const bool directPacked = c->asmPackedCodes && !c->keepHostSymbolic;
+        bool packed = false;
         build_symbolic_device(c->mesh, c->dElemNodes.p, device_dof_map(c), c->nDoF, c->nOwnedDoF(), c->chunkSlots, wantScatter, c->stream,
-                              c->sym, c->dRowPtr, c->dColIdx, c->dContribCode, c->dContribSlot, c->dScatter, c->upperOnly);
+                              c->sym, c->dRowPtr, c->dColIdx, c->dContribCode, c->dContribSlot, c->dScatter, c->upperOnly,
+                              directPacked ? &c->dChunkElemBase : nullptr, &packed);
         const Symbolic &S = c->sym;
         c->dChunkRow.upload(S.chunkRow, c->stream);
         c->dSpmvChunkRow.upload(S.spmvChunkRow, c->stream);
@@ -226,7 +231,8 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
             c->dContribSlot.download(c->sym.contribSlot.data(), c->dContribSlot.n, c->stream);
             if (wantScatter) { c->sym.scatterSlot.resize(c->dScatter.n); c->dScatter.download(c->sym.scatterSlot.data(), c->dScatter.n, c->stream); }
         }
-        pack_gather_codes(c);
+        if (directPacked) c->codesPacked = packed;
+        else pack_gather_codes(c);
         c->timing.symbolic_ms = now_ms() - t0;
         const size_t tilesD = (size_t)((S.nnzb + 63) / 64);
         const double tV = now_ms();

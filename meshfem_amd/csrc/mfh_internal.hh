@@ -242,7 +242,8 @@ void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const i
                            int maxPairs = 2048);
 void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nDoF, int64_t nOwnedDoF,
                            int chunkSlots, bool wantScatter, hipStream_t s, Symbolic &S, DBuf<int32_t> &dRowPtr, DBuf<int32_t> &dColIdx,
-                           DBuf<uint32_t> &dContribCode, DBuf<uint16_t> &dContribSlot, DBuf<int32_t> &dScatter, bool upperOnly = false);
+                           DBuf<uint32_t> &dContribCode, DBuf<uint16_t> &dContribSlot, DBuf<int32_t> &dScatter, bool upperOnly = false,
+                           DBuf<int32_t> *dChunkElemBase = nullptr, bool *codesPacked = nullptr);
 
 // ------------------------------------------------------------------------------------------------
 // P2 coefficient tables: for node i, grad phi_i(q) = alpha_i(q) gl[s_i] + beta_i(q) gl[t_i]

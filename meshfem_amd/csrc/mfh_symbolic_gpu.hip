@@ -11,26 +11,15 @@ namespace mfh {
 
 namespace {
 
-__global__ void __launch_bounds__(256) k_sym_gen(int64_t N, int npe, const int32_t *__restrict__ elemNodes,
-                                                 const int32_t *__restrict__ dofForNode, int64_t nRows, uint64_t *__restrict__ key,
-                                                 uint32_t *__restrict__ val, unsigned long long *nValid, int upperOnly) {
-    const int npe2 = npe * npe;
-    unsigned long long local = 0;
-    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < N; k += (int64_t)gridDim.x * 256) {
-        const int64_t e = k / npe2;
-        const int ij = (int)(k - e * npe2);
-        const int i = ij / npe, j = ij - i * npe;
-        int64_t row = elemNodes[e * npe + i], col = elemNodes[e * npe + j];
-        if (dofForNode) { row = dofForNode[row]; col = dofForNode[col]; }
-        const bool ok = row < nRows && (!upperOnly || col >= row);
-        key[k] = ok ? (((uint64_t)row << 32) | (uint64_t)col) : ((uint64_t)nRows << 32);   // not-owned rows (and, with upper-only storage, the blocks below the diagonal) sort last
-        val[k] = (uint32_t)k;
-        local += ok;
-    }
-    // one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) local += __shfl_down(local, off, 64);
-    if ((threadIdx.x & 63) == 0 && local) atomicAdd(nValid, local);
-}
+// Sort keys of the contributions: (row, col, ij) = ((row 2^cb + col) << 7) | ij with cb = bits of the column count and ij = i npe + j
+// the position inside the element matrix; the value carried along is the ELEMENT. The sort looks at the bits above ij only, so equal
+// (row, col) keep their element order; element and ij together are the gather code. Nothing here multiplies the element count by
+// npe^2: the 2^32 / 100 = 42.9 M ceiling on quadratic tets per device is gone (what remains: 2^32 contributions after the
+// owned-row / upper-triangle filter, i.e. 78 M quadratic tets with upper-triangle storage, and rb + cb <= 57 bits of row and column).
+constexpr int SYM_IJ_BITS = 7;
+__device__ __host__ inline uint64_t sym_key(uint64_t row, uint64_t col, unsigned ij, unsigned cb) { return (((row << cb) | col) << SYM_IJ_BITS) | ij; }
+__device__ inline int64_t sym_row(uint64_t key, unsigned cb) { return (int64_t)(key >> (cb + SYM_IJ_BITS)); }
+__device__ inline int64_t sym_col(uint64_t key, unsigned cb) { return (int64_t)((key >> SYM_IJ_BITS) & ((1ull << cb) - 1)); }
 
 // The same keys, only the valid ones (owned row; with upper-only storage: col >= row), in code order: pass 1 counts them per element,
 // an exclusive scan gives every element its offset, pass 2 writes. The sort then runs over nC instead of nElem npe^2 entries
@@ -51,8 +40,7 @@ __global__ void __launch_bounds__(256) k_sym_count(int64_t nElem, int npe, const
 }
 __global__ void __launch_bounds__(256) k_sym_gen_compact(int64_t nElem, int npe, const int32_t *__restrict__ elemNodes, const int32_t *__restrict__ dofForNode,
                                                          int64_t nRows, int upperOnly, const uint32_t *__restrict__ off, uint64_t *__restrict__ key,
-                                                         uint32_t *__restrict__ val) {
-    const int npe2 = npe * npe;
+                                                         uint32_t *__restrict__ val, unsigned cb) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nElem; e += (int64_t)gridDim.x * 256) {
         int64_t dof[10];
         for (int i = 0; i < npe; ++i) { const int32_t n = elemNodes[e * npe + i]; dof[i] = dofForNode ? dofForNode[n] : n; }
@@ -61,35 +49,35 @@ __global__ void __launch_bounds__(256) k_sym_gen_compact(int64_t nElem, int npe,
             if (dof[i] >= nRows) continue;
             for (int j = 0; j < npe; ++j) {
                 if (upperOnly && dof[j] < dof[i]) continue;
-                key[w] = ((uint64_t)dof[i] << 32) | (uint64_t)dof[j];
-                val[w] = (uint32_t)(e * npe2 + i * npe + j);
+                key[w] = sym_key((uint64_t)dof[i], (uint64_t)dof[j], (unsigned)(i * npe + j), cb);
+                val[w] = (uint32_t)e;
                 ++w;
             }
         }
     }
 }
 
-__global__ void __launch_bounds__(256) k_sym_heads(int64_t n, const uint64_t *__restrict__ key, uint32_t *__restrict__ head) {
+__global__ void __launch_bounds__(256) k_sym_heads(int64_t n, const uint64_t *__restrict__ key, uint32_t *__restrict__ head, unsigned shift = 0) {
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
-        head[k] = (k == 0 || key[k] != key[k - 1]) ? 1u : 0u;
+        head[k] = (k == 0 || (key[k] >> shift) != (key[k - 1] >> shift)) ? 1u : 0u;
 }
 
 // at slot heads: column index and row length; at row heads: first contribution of the row
 __global__ void __launch_bounds__(256) k_sym_pattern(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ slotP1,
                                                      int32_t *__restrict__ colIdx, int32_t *__restrict__ rowLen,
-                                                     int64_t *__restrict__ rowCStart, int64_t nRows, unsigned long long *__restrict__ nMirror) {
+                                                     int64_t *__restrict__ rowCStart, int64_t nRows, unsigned long long *__restrict__ nMirror, unsigned cb) {
     unsigned long long mirror = 0;      // summed over the wave before it reaches the one global counter (59-98 ms -> a few ms at config 3:
                                         // 50 M single-address atomics were the whole kernel)
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
-        const uint64_t kk = key[k];
-        const uint64_t prev = k == 0 ? ~kk : key[k - 1];
+        const uint64_t kk = key[k] >> SYM_IJ_BITS;                    // (row, col) without the position inside the element matrix
+        const uint64_t prev = k == 0 ? ~kk : key[k - 1] >> SYM_IJ_BITS;
         if (kk == prev) continue;                                     // not a slot head
-        const int64_t row = (int64_t)(kk >> 32);
-        const int64_t col = (int64_t)(kk & 0xffffffffu);
+        const int64_t row = sym_row(key[k], cb);
+        const int64_t col = sym_col(key[k], cb);
         colIdx[slotP1[k] - 1] = (int32_t)col;
         atomicAdd(&rowLen[row], 1);
         if (col > row && col < nRows) ++mirror;                       // blocks whose transpose is a block of K too (Symbolic::nMirror)
-        if (k == 0 || (int64_t)(prev >> 32) != row) rowCStart[row] = k;
+        if (k == 0 || sym_row(key[k - 1], cb) != row) rowCStart[row] = k;
     }
     for (int off = 32; off > 0; off >>= 1) mirror += __shfl_down(mirror, off, 64);
     if ((threadIdx.x & 63) == 0 && mirror) atomicAdd(nMirror, mirror);
@@ -107,17 +95,61 @@ __global__ void __launch_bounds__(256) k_sym_chunk_starts(int64_t nChunk, const 
     }
 }
 
-__global__ void __launch_bounds__(256) k_sym_key2(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val,
+// smallest element a chunk gathers from (one wave per chunk); flag[0] is raised when a chunk's elements span 2^25 or more: the
+// chunk-relative packed code (see k_assemble_gather) has 25 bits for the element
+__global__ void __launch_bounds__(64) k_sym_chunk_elem_base(int64_t nChunk, const int64_t *__restrict__ contribPtr, const uint32_t *__restrict__ elem,
+                                                            int32_t *__restrict__ chunkElemBase, int *flag, int32_t *__restrict__ offenders, int maxOffenders) {
+    const int64_t b = blockIdx.x;
+    const int64_t kb = contribPtr[b], ke = contribPtr[b + 1];
+    uint32_t lo = 0xffffffffu, hi = 0;
+    for (int64_t k = kb + threadIdx.x; k < ke; k += 64) {
+        const uint32_t e = elem[k];
+        lo = e < lo ? e : lo;
+        hi = e > hi ? e : hi;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t l2 = __shfl_xor(lo, off, 64), h2 = __shfl_xor(hi, off, 64);
+        lo = l2 < lo ? l2 : lo;
+        hi = h2 > hi ? h2 : hi;
+    }
+    if (ke <= kb) lo = 0;
+    if (threadIdx.x == 0) {
+        chunkElemBase[b] = (int32_t)lo;
+        if (ke > kb && hi - lo >= (1u << (32 - SYM_IJ_BITS))) {
+            const int q = atomicAdd(flag, 1);                        // flag[0] = number of offending chunks
+            if (q < maxOffenders) offenders[q] = (int32_t)b;
+        }
+    }
+}
+// element of the first contribution of every row of the offending chunks (a representative of where the row gathers from)
+__global__ void __launch_bounds__(256) k_sym_row_rep(int nOff, const int32_t *__restrict__ offenders, const int32_t *__restrict__ chunkRow,
+                                                     const int64_t *__restrict__ rowCStart, const uint32_t *__restrict__ elem, int stride,
+                                                     uint32_t *__restrict__ out) {
+    const int o = blockIdx.x;
+    if (o >= nOff) return;
+    const int32_t c = offenders[o];
+    const int32_t r0 = chunkRow[c], r1 = chunkRow[c + 1];
+    for (int r = r0 + (int)threadIdx.x; r < r1 && r - r0 < stride; r += 256) {
+        const int64_t k = rowCStart[r];
+        out[(int64_t)o * stride + (r - r0)] = k >= 0 ? elem[k] : 0xffffffffu;
+    }
+}
+
+// per contribution: its slot inside the chunk and its gather code -- chunk-relative and packed, ((element - chunk's first element) << 7) | ij
+// (chunkElemBase != null), or absolute, element npe^2 + ij. Either orders a chunk's contributions element-major.
+__global__ void __launch_bounds__(256) k_sym_key2(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ elem,
                                                   const uint32_t *__restrict__ slotP1, const int32_t *__restrict__ chunkOfRow,
-                                                  const int32_t *__restrict__ chunkBase, uint64_t *__restrict__ key2,
-                                                  uint16_t *__restrict__ lslot, int32_t *__restrict__ scatterSlot) {
+                                                  const int32_t *__restrict__ chunkBase, const int32_t *__restrict__ chunkElemBase, unsigned cb, unsigned npe2,
+                                                  uint32_t *__restrict__ code, uint16_t *__restrict__ lslot, int32_t *__restrict__ scatterSlot) {
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
-        const int64_t row = (int64_t)(key[k] >> 32);
+        const int64_t row = sym_row(key[k], cb);
         const int32_t ch = chunkOfRow[row];
         const int32_t slot = (int32_t)(slotP1[k] - 1);
-        if (key2) key2[k] = ((uint64_t)(uint32_t)ch << 32) | (uint64_t)val[k];
+        const uint32_t ij = (uint32_t)(key[k] & ((1u << SYM_IJ_BITS) - 1)), e = elem[k];
+        code[k] = chunkElemBase ? (((e - (uint32_t)chunkElemBase[ch]) << SYM_IJ_BITS) | ij) : e * npe2 + ij;
         lslot[k] = (uint16_t)(slot - chunkBase[ch]);
-        if (scatterSlot) scatterSlot[val[k]] = slot;
+        if (scatterSlot) scatterSlot[(int64_t)e * npe2 + ij] = slot;
     }
 }
 
@@ -134,13 +166,17 @@ inline unsigned bits_for(uint64_t v) { unsigned b = 1; while ((v >> b) != 0 && b
         if (e_ != hipSuccess) throw mfh::Error(MFH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
-std::vector<int32_t> make_chunks(const std::vector<int32_t> &rowPtr, int64_t nRows, int chunkSlots) {
+// breaks: rows (ascending) at which a chunk must end
+std::vector<int32_t> make_chunks(const std::vector<int32_t> &rowPtr, int64_t nRows, int chunkSlots, const std::vector<int64_t> &breaks = {}) {
     std::vector<int32_t> chunkRow{0};
     int64_t r = 0;
+    size_t nb = 0;
     while (r < nRows) {
         const int32_t s0 = rowPtr[r];
         int64_t r2 = r + 1;
-        while (r2 < nRows && rowPtr[r2 + 1] - s0 <= chunkSlots) ++r2;
+        while (nb < breaks.size() && breaks[nb] <= r) ++nb;
+        const int64_t stop = nb < breaks.size() ? breaks[nb] : -1;
+        while (r2 < nRows && r2 != stop && rowPtr[r2 + 1] - s0 <= chunkSlots) ++r2;
         chunkRow.push_back((int32_t)r2);
         r = r2;
     }
@@ -200,10 +236,22 @@ __global__ void __launch_bounds__(256) k_permute_rows_i32(int64_t n, int W, cons
 // contribPtr; colIdx and the gather lists stay on the device (downloaded on demand by the API layer).
 void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nDoF, int64_t nOwnedDoF,
                            int chunkSlots, bool wantScatter, hipStream_t s, Symbolic &S, DBuf<int32_t> &dRowPtr, DBuf<int32_t> &dColIdx,
-                           DBuf<uint32_t> &dContribCode, DBuf<uint16_t> &dContribSlot, DBuf<int32_t> &dScatter, bool upperOnly) {
+                           DBuf<uint32_t> &dContribCode, DBuf<uint16_t> &dContribSlot, DBuf<int32_t> &dScatter, bool upperOnly,
+                           DBuf<int32_t> *dChunkElemBase, bool *codesPacked) {
+    // dChunkElemBase != null: the gather codes come out chunk-relative and packed (what k_assemble_gather reads) whenever every chunk's
+    // elements span less than 2^25; *codesPacked says which. Absolute codes (element npe^2 + ij, the format of the host lists) and the
+    // element -> slot scatter map of the atomic variant need nElem npe^2 < 2^32.
     const int npe = m.npe;
     const int64_t N = m.nElem * npe * npe;
-    if ((double)N >= 4294967295.0) throw Error(MFH_ERR_UNSUPPORTED, "mesh too large for 32-bit contribution codes (partition it across GPUs)");
+    const bool fitsAbsolute = (double)N < 4294967295.0;
+    if (codesPacked) *codesPacked = false;
+    if (!fitsAbsolute && (wantScatter || !dChunkElemBase))
+        throw Error(MFH_ERR_UNSUPPORTED, "mesh too large for 32-bit absolute contribution codes: needs the packed gather codes (option asm_packed_codes 1, no "
+                                         "host copy of the lists, gather assembly)");
+    if ((double)m.nElem >= 4294967295.0) throw Error(MFH_ERR_UNSUPPORTED, "more than 2^32 elements on one device");
+    const unsigned cb = bits_for((uint64_t)std::max<int64_t>(nDoF, 1));
+    if (bits_for((uint64_t)std::max<int64_t>(nOwnedDoF, 1)) + cb + SYM_IJ_BITS > 64 || npe * npe > (1 << SYM_IJ_BITS))
+        throw Error(MFH_ERR_UNSUPPORTED, "row and column counts do not fit the 64-bit sort keys of the symbolic phase");
     S = Symbolic();
     S.nRows = nOwnedDoF;
     S.nCols = nDoF;
@@ -242,20 +290,20 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     if (nC == 0) throw Error(MFH_ERR_INVALID, "no element touches an owned row");
     keyA.alloc(nC); keyB.alloc(nC); valA.alloc(nC); valB.alloc(nC);
     hipLaunchKernelGGL(k_sym_gen_compact, dim3(grid_of(m.nElem)), dim3(256), 0, s, m.nElem, npe, dElemNodes, dDofForNode, nRows, upperOnly ? 1 : 0, cnt.p,
-                       keyA.p, valA.p);
+                       keyA.p, valA.p, cb);
     RP(hipGetLastError());
     cnt.release();
 
     lap("allocate + generate keys");
     // ---- sort by (row, col); stable, so equal keys stay in code order
-    const unsigned endBit1 = 32 + bits_for((uint64_t)nRows);
+    const unsigned beginBit1 = SYM_IJ_BITS, endBit1 = SYM_IJ_BITS + cb + bits_for((uint64_t)nRows);   // (row, col) only: ij rides along
     size_t tmpBytes = 0;
-    RP(rocprim::radix_sort_pairs(nullptr, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)nC, 0u, endBit1, s));
+    RP(rocprim::radix_sort_pairs(nullptr, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)nC, beginBit1, endBit1, s));
     {
         const double tA = now_ms();
         if (tmpBytes + 16 > tmp.n) tmp.alloc(tmpBytes + 16);
         const double tB = now_ms();
-        RP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)nC, 0u, endBit1, s));
+        RP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)nC, beginBit1, endBit1, s));
         if (timing) {
             const double tC = now_ms();
             (void)hipStreamSynchronize(s);
@@ -267,7 +315,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     // ---- slots = distinct (row, col) pairs
     slotP1.alloc(nC);
     valA.release();
-    hipLaunchKernelGGL(k_sym_heads, dim3(grid_of(nC)), dim3(256), 0, s, nC, keyB.p, slotP1.p);
+    hipLaunchKernelGGL(k_sym_heads, dim3(grid_of(nC)), dim3(256), 0, s, nC, keyB.p, slotP1.p, (unsigned)SYM_IJ_BITS);
     size_t scanBytes = 0;
     RP(rocprim::inclusive_scan(nullptr, scanBytes, slotP1.p, slotP1.p, (size_t)nC, rocprim::plus<uint32_t>(), s));
     if (scanBytes + 16 > tmp.n) tmp.alloc(scanBytes + 16);
@@ -289,7 +337,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     DBuf<unsigned long long> dCount;
     dCount.alloc(1);
     dCount.zero(s);
-    hipLaunchKernelGGL(k_sym_pattern, dim3(grid_of(nC)), dim3(256), 0, s, nC, keyB.p, slotP1.p, dColIdx.p, rowLen.p, rowCStart.p, nRows, dCount.p);
+    hipLaunchKernelGGL(k_sym_pattern, dim3(grid_of(nC)), dim3(256), 0, s, nC, keyB.p, slotP1.p, dColIdx.p, rowLen.p, rowCStart.p, nRows, dCount.p, cb);
     {
         unsigned long long nm = 0;
         dCount.download(&nm, 1, s);
@@ -321,32 +369,75 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
         throw Error(MFH_ERR_UNSUPPORTED, "a block row has more than 2048 blocks (vertex valence too high for LDS accumulation)");
     S.chunkSlots = chunkSlots;
     S.spmvChunkSlots = std::max(512, chunkSlots);
-    {   // the two greedy scans are sequential by nature: they run side by side
-        std::thread other([&]() { S.spmvChunkRow = make_chunks(S.rowPtr, nRows, S.spmvChunkSlots); });
-        S.chunkRow = make_chunks(S.rowPtr, nRows, chunkSlots);
-        other.join();
-    }
-    const int64_t nChunk = S.nChunk();
+    std::thread spmvChunks([&]() { S.spmvChunkRow = make_chunks(S.rowPtr, nRows, S.spmvChunkSlots); });   // (the greedy scans are sequential by nature)
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{spmvChunks};          // also when a step below throws
+    // The gather codes are packed relative to the smallest element of their chunk (25 bits). On meshes of 2^25 elements and more a chunk
+    // that holds rows from two ends of the node numbering -- the last corner vertices and the first cell centres of the generator's
+    // meshes, the last vertex rows and the first edge-node rows -- gathers from elements further apart than that: such chunks are found
+    // (k_sym_chunk_elem_base), cut where the rows' first elements jump, and the chunk tables rebuilt (a handful of chunks, two rounds).
+    std::vector<int64_t> breaks;
+    int64_t nChunk = 0;
     RawVec<int32_t> chunkOfRow;
     chunkOfRow.resize((size_t)nRows);
-    std::vector<int32_t> chunkBase((size_t)nChunk);
-    S.contribPtr.resize((size_t)nChunk + 1);
+    std::vector<int32_t> chunkBase;
     DBuf<int64_t> dSeg;                            // the chunks' first contributions: gathered on the device (the per-row table stays there)
     DBuf<int32_t> dCR;
-    {
+    bool packed = false;
+    for (int round = 0; round < 4; ++round) {
+        S.chunkRow = make_chunks(S.rowPtr, nRows, chunkSlots, breaks);
+        nChunk = S.nChunk();
+        chunkBase.assign((size_t)nChunk, 0);
+        S.contribPtr.resize((size_t)nChunk + 1);
         dCR.upload(S.chunkRow, s);
         dSeg.alloc((size_t)nChunk + 1);
         hipLaunchKernelGGL(k_sym_chunk_starts, dim3(grid_of(nChunk + 1)), dim3(256), 0, s, nChunk, dCR.p, rowCStart.p, nRows, nC, dSeg.p);
         RP(hipGetLastError());
         MFH_HIP(hipMemcpyAsync(S.contribPtr.data(), dSeg.p, (size_t)(nChunk + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    }
-    parallel_ranges(nChunk, [&](int64_t cb, int64_t ce, int) {
-        for (int64_t c = cb; c < ce; ++c) {
-            chunkBase[c] = S.rowPtr[S.chunkRow[c]];
-            for (int32_t r = S.chunkRow[c]; r < S.chunkRow[c + 1]; ++r) chunkOfRow[r] = (int32_t)c;
+        parallel_ranges(nChunk, [&](int64_t cb2, int64_t ce, int) {
+            for (int64_t c = cb2; c < ce; ++c) {
+                chunkBase[c] = S.rowPtr[S.chunkRow[c]];
+                for (int32_t r = S.chunkRow[c]; r < S.chunkRow[c + 1]; ++r) chunkOfRow[r] = (int32_t)c;
+            }
+        });
+        MFH_HIP(hipStreamSynchronize(s));
+        if (!dChunkElemBase) break;
+        constexpr int MAXOFF = 1024;
+        const int stride = chunkSlots;             // a chunk holds at most chunkSlots rows
+        DBuf<int> flag;
+        DBuf<int32_t> off;
+        flag.alloc(1);
+        flag.zero(s);
+        off.alloc(MAXOFF);
+        dChunkElemBase->alloc((size_t)nChunk);
+        hipLaunchKernelGGL(k_sym_chunk_elem_base, dim3((unsigned)nChunk), dim3(64), 0, s, nChunk, dSeg.p, valB.p, dChunkElemBase->p, flag.p, off.p, MAXOFF);
+        RP(hipGetLastError());
+        int nOff = 0;
+        flag.download(&nOff, 1, s);
+        if (nOff == 0) { packed = true; break; }
+        if (nOff > MAXOFF || round == 3) break;    // no locality to speak of: absolute codes (if they fit)
+        std::vector<int32_t> hOff((size_t)nOff);
+        off.download(hOff.data(), hOff.size(), s);
+        DBuf<uint32_t> rep;
+        rep.alloc((size_t)nOff * stride);
+        hipLaunchKernelGGL(k_sym_row_rep, dim3(nOff), dim3(256), 0, s, nOff, off.p, dCR.p, rowCStart.p, valB.p, stride, rep.p);
+        RP(hipGetLastError());
+        std::vector<uint32_t> hRep((size_t)nOff * stride);
+        rep.download(hRep.data(), hRep.size(), s);
+        for (int o = 0; o < nOff; ++o) {
+            const int32_t c = hOff[(size_t)o], r0 = S.chunkRow[c], r1 = S.chunkRow[c + 1];
+            uint32_t base = 0xffffffffu;
+            for (int32_t r = r0; r < r1; ++r) {
+                const uint32_t e = hRep[(size_t)o * stride + (r - r0)];
+                if (e == 0xffffffffu) continue;
+                if (base == 0xffffffffu) { base = e; continue; }
+                const uint32_t d = e > base ? e - base : base - e;
+                if (d >= (1u << 24)) { breaks.push_back(r); base = e; }          // half the field: the rows' other elements lie nearby
+            }
         }
-    });
-    MFH_HIP(hipStreamSynchronize(s));
+        std::sort(breaks.begin(), breaks.end());
+        breaks.erase(std::unique(breaks.begin(), breaks.end()), breaks.end());
+    }
+    spmvChunks.join();
 
     lap("chunks (host)");
     // ---- element-major order inside every chunk: sort by (chunk, code)
@@ -357,23 +448,29 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     lsA.alloc((size_t)nC);
     if (wantScatter) { dScatter.alloc((size_t)N); MFH_HIP(hipMemsetAsync(dScatter.p, 0xff, (size_t)N * sizeof(int32_t), s)); }
     keyA.release();
-    hipLaunchKernelGGL(k_sym_key2, dim3(grid_of(nC)), dim3(256), 0, s, nC, keyB.p, valB.p, slotP1.p, dChunkOfRow.p, dChunkBase.p, (uint64_t *)nullptr,
-                       lsA.p, wantScatter ? dScatter.p : nullptr);
-    RP(hipGetLastError());
-    slotP1.release(); rowLen.release(); rowCStart.release();
-    // The contributions are already grouped by chunk (chunks are ranges of rows, the first sort ordered the rows): what is left is the
-    // order inside each chunk, a SEGMENTED sort of 32-bit codes over ~650-entry segments instead of a second full-length 64-bit sort
+    if (!packed && !fitsAbsolute)
+        throw Error(MFH_ERR_UNSUPPORTED, "mesh too large for absolute contribution codes and without element locality inside the row chunks (reorder the elements)");
     dContribSlot.alloc((size_t)nC);
     dContribCode.alloc((size_t)nC);
-    const unsigned endBit2 = bits_for((uint64_t)N);
+    DBuf<uint32_t> codeA;
+    codeA.alloc((size_t)nC);
+    hipLaunchKernelGGL(k_sym_key2, dim3(grid_of(nC)), dim3(256), 0, s, nC, keyB.p, valB.p, slotP1.p, dChunkOfRow.p, dChunkBase.p,
+                       packed ? dChunkElemBase->p : (const int32_t *)nullptr, cb, (unsigned)(npe * npe), codeA.p, lsA.p, wantScatter ? dScatter.p : nullptr);
+    RP(hipGetLastError());
+    MFH_HIP(hipStreamSynchronize(s));
+    slotP1.release(); rowLen.release(); rowCStart.release(); valB.release(); keyB.release();
+    if (codesPacked) *codesPacked = packed;
+    // The contributions are already grouped by chunk (chunks are ranges of rows, the first sort ordered the rows): what is left is the
+    // order inside each chunk, a SEGMENTED sort of 32-bit codes over ~650-entry segments instead of a second full-length 64-bit sort
+    const unsigned endBit2 = packed ? 32u : bits_for((uint64_t)N);
     size_t tmp2 = 0;
-    RP(rocprim::segmented_radix_sort_pairs(nullptr, tmp2, valB.p, dContribCode.p, lsA.p, dContribSlot.p, (unsigned int)nC, (unsigned int)nChunk, dSeg.p,
+    RP(rocprim::segmented_radix_sort_pairs(nullptr, tmp2, codeA.p, dContribCode.p, lsA.p, dContribSlot.p, (unsigned int)nC, (unsigned int)nChunk, dSeg.p,
                                            dSeg.p + 1, 0u, endBit2, s));
     const double tA = now_ms();
     if (tmp2 + 16 > tmp.n) tmp.alloc(tmp2 + 16);
     const double tB = now_ms();
     if (getenv("MFH_SYM_TIMING")) fprintf(stderr, "[symbolic] segmented sort: %.1f MB of temporary storage, allocation %.2f ms\n", tmp2 / 1e6, tB - tA);
-    RP(rocprim::segmented_radix_sort_pairs(tmp.p, tmp2, valB.p, dContribCode.p, lsA.p, dContribSlot.p, (unsigned int)nC, (unsigned int)nChunk, dSeg.p,
+    RP(rocprim::segmented_radix_sort_pairs(tmp.p, tmp2, codeA.p, dContribCode.p, lsA.p, dContribSlot.p, (unsigned int)nC, (unsigned int)nChunk, dSeg.p,
                                            dSeg.p + 1, 0u, endBit2, s));
     MFH_HIP(hipStreamSynchronize(s));
     lap("sort by (chunk, code) + lists");
@@ -596,7 +693,7 @@ void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes,
     keyA.release(); valA.release();
     // ---- entries = distinct (block, row) pairs
     entP1.alloc(N);
-    hipLaunchKernelGGL(k_sym_heads, dim3(grid_of(N)), dim3(256), 0, s, N, keyB.p, entP1.p);
+    hipLaunchKernelGGL(k_sym_heads, dim3(grid_of(N)), dim3(256), 0, s, N, keyB.p, entP1.p, 0u);
     size_t scanBytes = 0;
     RP(rocprim::inclusive_scan(nullptr, scanBytes, entP1.p, entP1.p, (size_t)N, rocprim::plus<uint32_t>(), s));
     if (scanBytes + 16 > tmp.n) tmp.alloc(scanBytes + 16);
@@ -1100,7 +1197,7 @@ bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const
         RP(rocprim::radix_sort_pairs(nullptr, b, kA.p, kB.p, vA.p, vB.p, (size_t)n, 0u, 32 + bits_for((uint64_t)nVert), s));
         ensureTmp(b);
         RP(rocprim::radix_sort_pairs(tmp.p, b, kA.p, kB.p, vA.p, vB.p, (size_t)n, 0u, 32 + bits_for((uint64_t)nVert), s));
-        hipLaunchKernelGGL(k_sym_heads, dim3(grid_of(n)), dim3(256), 0, s, n, kB.p, headP1.p);
+        hipLaunchKernelGGL(k_sym_heads, dim3(grid_of(n)), dim3(256), 0, s, n, kB.p, headP1.p, 0u);
         RP(rocprim::inclusive_scan(nullptr, b, headP1.p, headP1.p, (size_t)n, rocprim::plus<uint32_t>(), s));
         ensureTmp(b);
         RP(rocprim::inclusive_scan(tmp.p, b, headP1.p, headP1.p, (size_t)n, rocprim::plus<uint32_t>(), s));

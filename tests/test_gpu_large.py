@@ -42,3 +42,38 @@ def test_config5_size_on_one_gpu():
     assert abs(np.abs(u).max() - 0.03607) <= 2e-4                 # the cantilever's deflection does not depend on the mesh size
     assert abs(f.sum() + 1.0) <= 1e-9                             # total traction (0, -1, 0) on the unit face
     c.close()
+
+
+@pytest.mark.timeout(900)
+def test_more_than_2_to_the_32_element_matrix_entries_on_one_gpu():
+    """122^3 grid -> 43,580,352 P2 tets: nElem * 100 = 4.36e9 no longer fits the 32-bit (element, i, j) codes the symbolic phase used to
+    sort (the 42.9 M-element ceiling of rounds 1-3). The phase now carries the element and the position inside the element matrix
+    separately and emits chunk-relative packed codes; the same size-independent checks as above, with the multigrid PCG."""
+    import torch
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    free, total = torch.cuda.mem_get_info(0)
+    if free < 220e9:
+        pytest.skip("needs 220 GB of free device memory (MI355X: 288 GiB)")
+    n = 122
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    T = np.ascontiguousarray(T, dtype=np.int32)
+    assert len(T) * 100 > 2 ** 32
+    c = M.Context(0)
+    c.mesh_build(T, V, 2)
+    del V, T
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+    c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    c.assemble()
+    nr, nc, nnzb = c.matrix_info()
+    assert nr == nc == c.n_node and c.matrix_storage()[0]
+    t = np.tile([0.3, -1.0, 0.7], c.n_node)
+    assert np.abs(c.apply_K(t)).max() <= 1e-9 * 200.0             # rigid translations: matrix-free operator
+    # the ASSEMBLED matrix too: its diagonal blocks feed the block-Jacobi smoothers, its Galerkin products the hierarchy
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    u = c.sim_solve(rtol=1e-8, maxit=300)
+    i = c.last_info
+    assert i["converged"] and i["true_rel_residual"] <= 2e-8 and i["iterations"] < 60
+    assert abs(np.abs(u).max() - 0.03607) <= 2e-4
+    c.close()
