@@ -752,7 +752,7 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
         li.converged = 1;
     } else {
         EventTimer tsolve(s);
-        const bool useMG = c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && !c->tlSuppress;
+        const bool useMG = c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && c->mg.singular == c->tlSuppress;
         const bool useTL = !useMG && (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) && c->tl.valid && !c->tlSuppress;
         const uint8_t *maskPtr = c->fixedVars.empty() ? nullptr : c->dFixedMask.p;
         k::launch_pcg_init(d, c->sym.nRows, c->dDinv.p, c->wb.p, c->wx.p, c->wr.p, c->wz.p, c->wp.p, c->scal.p, s);

@@ -152,6 +152,7 @@ struct mfh_ctx {
     };
     struct Multigrid {
         bool valid = false, rigidCoarse = false;
+        bool singular = false;                   // built for a K that is singular on the free variables (rigid-motion rows): the dense last level is pinned
         bool linearOnly = false;                 // linear elements: no quadratic level, the context itself is the linear level
         bool distributed = false;                // row-partitioned context: nodal levels partitioned like it (halo exchanges inside the smoothers and the
                                                  // transfers), aggregate levels replicated on every rank (one small all-reduce per application)

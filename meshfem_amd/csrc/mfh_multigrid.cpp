@@ -295,6 +295,8 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
         Ad.alloc((size_t)G.denseM * G.denseM);
         Ad.zero(s);
         k::launch_st_to_dense(dim, Last.nAgg, Last.nbr.p, Last.A.p, Ad.p, s);
+        if (G.singular)          // zero diagonal = "mode without support": dense_inverse_device decouples the NM modes of aggregate 0 (the pin)
+            MFH_HIP(hipMemset2DAsync(Ad.p, (size_t)(G.denseM + 1) * sizeof(double), 0, sizeof(double), (size_t)NM, s));
         if (!dense_inverse_device(c, Ad.p, G.denseM, G.denseInv, G.denseLd)) { G.agg.clear(); return false; }
     }
     lap("dense inverse of the last level");
@@ -344,7 +346,10 @@ bool ensure_multigrid(mfh_ctx *c) {
     // Row-partitioned contexts (mfh_dist_setup ran, more than one rank): the call is COLLECTIVE -- every rank builds its part of the
     // nodal levels and the same replicated aggregate levels. The decision to call it is agreed on in mfh_dist_solve.
     const bool distributed = dist_active(c);
-    if (G.valid && G.distributed == distributed && (!distributed || G.distComm == (const void *)c->dist.comm)) return true;
+    // K singular on the free variables (the solves under rigid-motion constraint rows set tlSuppress): every level carries the rigid motions
+    // in its null space; the smoothers do not mind, the dense last level is inverted with the six modes of one aggregate pinned
+    const bool singular = c->tlSuppress;
+    if (G.valid && G.singular == singular && G.distributed == distributed && (!distributed || G.distComm == (const void *)c->dist.comm)) return true;
     G.valid = false;
     c->precondNote.clear();
     const HostMesh &m = c->mesh;
@@ -356,9 +361,14 @@ bool ensure_multigrid(mfh_ctx *c) {
         c->precondNote = "multigrid on partitioned rows needs the communicator of mfh_dist_setup: using block-Jacobi";
         return false;
     }
+    if (singular && (distributed || c->mgAggTarget <= 0)) {
+        c->precondNote = "multigrid for a singular system needs the aggregate hierarchy on an unpartitioned context: using block-Jacobi";
+        return false;
+    }
     const double t0 = now_ms();
     destroy_multigrid(c);
     G.distributed = distributed;
+    G.singular = singular;
     G.distComm = distributed ? (const void *)c->dist.comm : nullptr;
     hipStream_t s = c->stream;
     const int d = m.dim, nv = d + 1, npe = m.npe;
@@ -378,7 +388,7 @@ bool ensure_multigrid(mfh_ctx *c) {
         ensure_precond(c);
         lap("assembly + block-Jacobi");
         bool haveCoarse = build_aggregate_hierarchy(c, c, lap);
-        if (!haveCoarse && !distributed) {
+        if (!haveCoarse && !distributed && !singular) {
             haveCoarse = ensure_twolevel(c);
             lap("rigid-body coarse (dense)");
         }
@@ -518,7 +528,7 @@ bool ensure_multigrid(mfh_ctx *c) {
     lap("linear level: symbolic + assembly");
     // below the linear level: the aggregate hierarchy; where the lattice cannot resolve the mesh, the context's own dense coarse space
     bool haveCoarse = build_aggregate_hierarchy(c, c1, lap);
-    if (!haveCoarse && !distributed) {
+    if (!haveCoarse && !distributed && !singular) {
         haveCoarse = ensure_twolevel(c1);
         lap("linear level: rigid-body coarse (dense)");
     }

@@ -6,6 +6,17 @@
 using namespace mfh;
 using namespace mfhi;
 
+// K is singular on the free variables (rigid-motion constraint rows) and so are the Galerkin coarse operators: the two-level preconditioner
+// steps aside for block-Jacobi; the multigrid hierarchy is rebuilt with its dense last level pinned (mfh_multigrid.cpp) and stays in use
+static void singular_system_preconditioner(mfh_ctx *c) {
+    if (c->precond == MFH_PRECOND_MULTIGRID) {
+        ensure_precond(c);
+        if (ensure_multigrid(c)) { c->precondNote = "multigrid preconditioner on a singular system (rigid-motion constraint rows): dense level pinned"; return; }
+    }
+    if (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID)
+        c->precondNote = "two-level / multigrid preconditioner: singular system (rigid-motion constraint rows); using block-Jacobi";
+}
+
 extern "C" {
 
 // ---------------------------------------------------------------- Simulator-level helpers
@@ -480,7 +491,7 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
             // K is singular on the free variables, and so is the Galerkin coarse operator of the two-level
             // preconditioner (the aggregates' modes span the global rigid motions): block-Jacobi for this solve
             c->tlSuppress = true;
-            if (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) c->precondNote = "two-level / multigrid preconditioner: singular system (rigid-motion constraint rows); using block-Jacobi";
+            singular_system_preconditioner(c);
             try { solve_one(c, fv2.data(), x.data(), rtol, maxit, &li); } catch (...) { c->tlSuppress = false; throw; }
             c->tlSuppress = false;
             std::vector<double> a((size_t)k);
@@ -547,7 +558,7 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
             for (int r = 0; r < k; ++r)
                 for (int64_t i = 0; i < n; ++i) fv2[(size_t)i] -= lam0[r] * Cf[r][(size_t)i];
             c->tlSuppress = true;
-            if (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) c->precondNote = "two-level / multigrid preconditioner: singular system (rigid-motion constraint rows); using block-Jacobi";
+            singular_system_preconditioner(c);
             std::vector<std::vector<double>> Y((size_t)nm, std::vector<double>((size_t)n));
             try {
                 solve_one(c, fv2.data(), x.data(), rtol, maxit, &li);

@@ -571,7 +571,7 @@ void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rt
     EventTimer tsetup(s);
     c->cgU.reserve(nAll);                                 // p (with its halo part)
     // the multigrid V-cycle applies the operator to z: it then carries its halo rows like p
-    const bool useMG = c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && c->mg.distributed == L.active && !c->tlSuppress;
+    const bool useMG = c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && c->mg.distributed == L.active && c->mg.singular == c->tlSuppress;
     c->wx.alloc(nOwn); c->wr.alloc(nOwn); c->wz.alloc(useMG ? nAll : nOwn); c->wAp.alloc(nOwn); c->wf.alloc(nOwn);
     if (useMG) c->wz.zero(s);
     c->stop.alloc(4);

@@ -180,3 +180,39 @@ def test_mixed_case_fixed_component_plus_rigid_motion_rows(deg):
     sim.setUsePinNoRigidTranslationConstraint(False)
     u_ref = O.solve_constrained(ref, no_rigid_motion=True)
     assert _err(sim.solve(), u_ref) < U_RTOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,deg,n", [(3, 2, 6), (3, 1, 10), (2, 2, 16)])
+def test_free_body_with_the_multigrid_preconditioner(dim, deg, n):
+    """K singular on the free variables (no Dirichlet condition; six / three rigid-motion rows): the multigrid hierarchy is rebuilt with its
+    dense last level pinned and stays in use -- same displacements as the block-Jacobi solve of the same singular system (which test_free_body_no_rigid_motion checks against the
+    oracle's KKT solve), a fraction of its iterations; a
+    regular solve on the same context afterwards switches the hierarchy back."""
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    if dim == 3:
+        V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    else:
+        V, T = grid.grid_tri_mesh(n, n)
+        V = V / float(n)
+    t1 = [1.0, 0.3, 0.0][:dim]; t0 = [-1.0, 0.1, 0.0][:dim]
+    sim = _gpu_sim(V, T, deg)
+    sim.rtol = 1e-10
+    sim.applyNeumannBox(*_face(dim, 0, 1.0), t1); sim.applyNeumannBox(*_face(dim, 0, 0.0), t0)
+    sim.applyNoRigidMotionConstraint()
+    sim.ctx.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+    u_bj = sim.solve()
+    it_bj = sim.info["iterations"]
+    sim.ctx.set_preconditioner(M.PRECOND_MULTIGRID)
+    u = sim.solve()
+    it_mg, note = sim.info["iterations"], sim.ctx.precond_info()["note"]
+    assert sim.info["converged"] and "pinned" in note, note
+    assert _err(u, u_bj) < 1e-7 and it_mg < 0.35 * it_bj, (it_mg, it_bj)
+    # a regular system on the same context: clamp a face, drop the rows
+    sim.removeNoRigidMotionConstraint()
+    sim.applyDirichletBox(*_face(dim, 0, 0.0), [0.0] * dim)
+    u2 = sim.solve()
+    assert sim.info["converged"] and sim.info["iterations"] < 70 and "pinned" not in sim.ctx.precond_info()["note"]
+    sim.ctx.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+    assert _err(u2, sim.solve()) < 1e-7
