@@ -9,6 +9,7 @@ using namespace mfhi;
 // K is singular on the free variables (rigid-motion constraint rows) and so are the Galerkin coarse operators: the two-level preconditioner
 // steps aside for block-Jacobi; the multigrid hierarchy is rebuilt with its dense last level pinned (mfh_multigrid.cpp) and stays in use
 static void singular_system_preconditioner(mfh_ctx *c) {
+    c->precondNote.clear();
     if (c->precond == MFH_PRECOND_MULTIGRID) {
         ensure_precond(c);
         if (ensure_multigrid(c)) { c->precondNote = "multigrid preconditioner on a singular system (rigid-motion constraint rows): dense level pinned"; return; }
@@ -315,6 +316,16 @@ static void jacobi_eig(int k, std::vector<double> &A, std::vector<double> &V) {
             }
     }
 }
+// y += a x and y *= a on all host threads (the constraint rows and rigid modes are full-length vectors: tens of them at 20 M DoFs)
+static void paxpy(std::vector<double> &y, double a, const std::vector<double> &x) {
+    double *yp = y.data();
+    const double *xp = x.data();
+    parallel_ranges((int64_t)y.size(), [&](int64_t lo, int64_t hi, int) { for (int64_t q = lo; q < hi; ++q) yp[q] += a * xp[q]; });
+}
+static void pscale(std::vector<double> &y, double a) {
+    double *yp = y.data();
+    parallel_ranges((int64_t)y.size(), [&](int64_t lo, int64_t hi, int) { for (int64_t q = lo; q < hi; ++q) yp[q] *= a; });
+}
 static double hdot(const std::vector<double> &a, const std::vector<double> &b) {
     const int nt = host_threads();
     std::vector<double> part((size_t)nt + 1, 0.0);
@@ -363,8 +374,12 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
     auto addTranslationRows = [&](unsigned compMask) {   // m_appendTranslationMatrix (:1568-1590)
         for (int a = 0; a < d; ++a) {
             if (!(compMask & (1u << a))) continue;
-            std::vector<double> row((size_t)n, 0.0);
-            for (int64_t i = 0; i < c->nDoF; ++i) row[(size_t)i * d + a] = 1.0;
+            std::vector<double> row((size_t)n);
+            double *rp = row.data();
+            parallel_ranges(c->nDoF, [&](int64_t lo, int64_t hi, int) {
+                for (int64_t i = lo; i < hi; ++i)
+                    for (int b = 0; b < d; ++b) rp[(size_t)i * d + b] = b == a ? 1.0 : 0.0;
+            });
             C.push_back(std::move(row));
         }
     };
@@ -372,16 +387,18 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
         const int nr = gd == 3 ? 3 : 1;
         for (int r = 0; r < nr; ++r) out.emplace_back((size_t)n, 0.0);
         std::vector<double> *R = &out[out.size() - nr];
-        for (int64_t k2 = 0; k2 < m.nNode; ++k2) {
-            const double *x = &m.nodePos[(size_t)k2 * gd];
-            if (gd == 3) {
-                R[0][(size_t)k2 * 3 + 1] = -x[2]; R[0][(size_t)k2 * 3 + 2] = x[1];
-                R[1][(size_t)k2 * 3 + 0] = x[2];  R[1][(size_t)k2 * 3 + 2] = -x[0];
-                R[2][(size_t)k2 * 3 + 0] = -x[1]; R[2][(size_t)k2 * 3 + 1] = x[0];
-            } else {
-                R[0][(size_t)k2 * 2 + 0] = -x[1]; R[0][(size_t)k2 * 2 + 1] = x[0];
+        parallel_ranges(m.nNode, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t k2 = lo; k2 < hi; ++k2) {
+                const double *x = &m.nodePos[(size_t)k2 * gd];
+                if (gd == 3) {
+                    R[0][(size_t)k2 * 3 + 1] = -x[2]; R[0][(size_t)k2 * 3 + 2] = x[1];
+                    R[1][(size_t)k2 * 3 + 0] = x[2];  R[1][(size_t)k2 * 3 + 2] = -x[0];
+                    R[2][(size_t)k2 * 3 + 0] = -x[1]; R[2][(size_t)k2 * 3 + 1] = x[0];
+                } else {
+                    R[0][(size_t)k2 * 2 + 0] = -x[1]; R[0][(size_t)k2 * 2 + 1] = x[0];
+                }
             }
-        }
+        });
     };
     const unsigned allComps = (1u << d) - 1;
     if (flags & MFH_SOLVE_NO_RIGID_MOTION) {
@@ -434,7 +451,9 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);
     lap("assembly + diagonal blocks");
-    ensure_coarse_levels(c, 1);
+    // the multigrid hierarchy depends on whether the solve ahead is singular (pinned dense level): it is built where that is known -- right
+    // before the first solve_one of the branch taken (solve_one makes sure of it) -- instead of here and then again
+    if (c->precond != MFH_PRECOND_MULTIGRID) ensure_coarse_levels(c, 1);
     lap("two-level setup");
     mfh_solve_info li{};
     const int k = (int)C.size();
@@ -445,14 +464,18 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
         // ---- candidate rigid motions (unit-normalised): translations, and rotations unless a periodic map excludes them
         std::vector<std::vector<double>> Zc;
         for (int a = 0; a < d; ++a) {
-            Zc.emplace_back((size_t)n, 0.0);
-            for (int64_t i = 0; i < c->nDoF; ++i) Zc.back()[(size_t)i * d + a] = 1.0;
+            Zc.emplace_back((size_t)n);
+            double *zp = Zc.back().data();
+            parallel_ranges(c->nDoF, [&](int64_t lo, int64_t hi, int) {
+                for (int64_t i = lo; i < hi; ++i)
+                    for (int b = 0; b < d; ++b) zp[(size_t)i * d + b] = b == a ? 1.0 : 0.0;
+            });
         }
         if (!periodic) rotationRows(Zc);
         const int nc = (int)Zc.size();
         for (auto &z : Zc) {
             const double nrm = std::sqrt(hdot(z, z));
-            if (nrm > 0) for (double &v : z) v /= nrm;
+            if (nrm > 0) pscale(z, 1.0 / nrm);
         }
         // null space of the candidates restricted to the fixed variables
         std::vector<double> G((size_t)nc * nc, 0.0), V;
@@ -463,22 +486,28 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
         double evMax = 0;
         for (int e = 0; e < nc; ++e) evMax = std::max(evMax, G[(size_t)e * nc + e]);
         std::vector<std::vector<double>> Z;
+        if (c->fixedVars.empty()) Z = std::move(Zc);               // nothing is fixed: every candidate is a null vector as it stands
+        else
         for (int e = 0; e < nc; ++e) {
             if (G[(size_t)e * nc + e] > 1e-12 * evMax) continue;   // the mode moves a fixed variable: not in the null space
             Z.emplace_back((size_t)n, 0.0);
             for (int a = 0; a < nc; ++a) {
                 const double w = V[(size_t)a * nc + e];
                 if (w == 0.0) continue;
-                for (int64_t q = 0; q < n; ++q) Z.back()[(size_t)q] += w * Zc[a][(size_t)q];
+                paxpy(Z.back(), w, Zc[a]);
             }
             for (int64_t fv : c->fixedVars) Z.back()[(size_t)fv] = 0.0;
         }
         std::vector<std::vector<double>>().swap(Zc);
         const int q = (int)Z.size();
         // constraint rows on the free variables
-        std::vector<std::vector<double>> Cf = C;
-        for (auto &row : Cf)
-            for (int64_t fv : c->fixedVars) row[(size_t)fv] = 0.0;
+        std::vector<std::vector<double>> CfStore;
+        if (!c->fixedVars.empty()) {
+            CfStore = C;
+            for (auto &row : CfStore)
+                for (int64_t fv : c->fixedVars) row[(size_t)fv] = 0.0;
+        }
+        const std::vector<std::vector<double>> &Cf = c->fixedVars.empty() ? C : CfStore;   // (full-length vectors: no copy without a reason)
         if (q == k) {
             std::vector<double> M((size_t)k * k), MT((size_t)k * k);
             for (int r = 0; r < k; ++r)
@@ -486,8 +515,7 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
             std::vector<double> lam((size_t)k), fv2(f, f + n);
             for (int e = 0; e < k; ++e) lam[e] = hdot(Z[e], fv2);
             if (!dense_solve(k, MT, lam)) throw Error(MFH_ERR_UNSUPPORTED, "constraint rows do not fix the rigid motions of the system");
-            for (int r = 0; r < k; ++r)
-                for (int64_t i = 0; i < n; ++i) fv2[(size_t)i] -= lam[r] * Cf[r][(size_t)i];
+            for (int r = 0; r < k; ++r) paxpy(fv2, -lam[r], Cf[r]);
             // K is singular on the free variables, and so is the Galerkin coarse operator of the two-level
             // preconditioner (the aggregates' modes span the global rigid motions): block-Jacobi for this solve
             c->tlSuppress = true;
@@ -497,8 +525,7 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
             std::vector<double> a((size_t)k);
             for (int r = 0; r < k; ++r) a[r] = crhs[r] - hdot(C[r], x);
             if (!dense_solve(k, M, a)) throw Error(MFH_ERR_UNSUPPORTED, "constraint rows do not fix the rigid motions of the system");
-            for (int e = 0; e < k; ++e)
-                for (int64_t i = 0; i < n; ++i) x[(size_t)i] += a[e] * Z[e][(size_t)i];
+            for (int e = 0; e < k; ++e) paxpy(x, a[e], Z[e]);
         } else if (q == 0) {
             solve_one(c, f, x.data(), rtol, maxit, &li);
             std::vector<std::vector<double>> Y((size_t)k, std::vector<double>((size_t)n));

@@ -694,6 +694,8 @@ void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rt
 // one right-hand side: the Chronopoulos-Gear loop when the operator in use has a batched kernel, else the classic PCG
 void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info) {
     const bool partitioned = c->sym.nRows != c->sym.nCols;
+    // the hierarchy for THIS solve (regular, or pinned for a system that is singular on the free variables): a no-op once it exists
+    if (c->precond == MFH_PRECOND_MULTIGRID && !partitioned && !(c->mg.valid && c->mg.singular == c->tlSuppress)) ensure_coarse_levels(c, 1);
     const bool multigrid = c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && !partitioned;   // the V-cycle lives in the classic loop
     if (!multigrid && (c->pcgVariant == 1 || partitioned) && cg_operator_supported(c)) {
         const int64_t n = (int64_t)c->bs() * c->sym.nRows;
