@@ -376,6 +376,16 @@ public:
         return f;
     }
 
+    // per-DoF field -> per-node field through the DoF map (identity unless periodic conditions are installed)   (:664-677)
+    VField dofToNodeField(const VField &dofField) const {
+        if (dofField.size() != m_numDoFs) throw std::runtime_error("dofToNodeField: one entry per DoF expected");
+        std::vector<int32_t> dm(m_numNodes);
+        int64_t nd = 0;
+        check(ctx(), mfh_get_dof_map(ctx(), dm.data(), &nd));
+        VField out(m_numNodes);
+        for (size_t n = 0; n < m_numNodes; ++n) out[n] = dofField[(size_t)dm[n]];
+        return out;
+    }
     VField solve(const VField &f) const {                        // :479-487 + dofToNodeField :664-677
         VField u(m_numNodes);
         check(ctx(), mfh_sim_solve_constrained(ctx(), &f[0][0], m_flags(), m_rigidMotionRHS.data(), (int32_t)m_rigidMotionRHS.size(),

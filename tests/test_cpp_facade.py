@@ -105,3 +105,21 @@ def test_facade_distributed_on_gpu():
     _build("facade_distributed")
     r = subprocess.run([EXE4, "0"], capture_output=True, text=True)
     assert r.returncode == 0 and "distributed facade ok" in r.stdout and "RCCL" in r.stdout, r.stdout + r.stderr
+
+
+EXE5 = os.path.join(ROOT, "tests", "cpp", "abi_solver_only_swap")
+
+
+def test_solver_only_swap_compiles_and_fails_loudly_without_device():
+    """INTEGRATION.md section 1b as a program: a host simulator with its own node numbering, per-element tensors, DoF map and Dirichlet
+    variables hands them to the C ABI (mfh_mesh_set ... mfh_solve)."""
+    _build("abi_solver_only_swap")
+    r = subprocess.run([EXE5, "-1"], capture_output=True, text=True)
+    assert r.returncode == 3 and "18 elements, 63 nodes" in r.stdout and "no CPU fallback" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_solver_only_swap_on_gpu():
+    _build("abi_solver_only_swap")
+    r = subprocess.run([EXE5, "0"], capture_output=True, text=True)
+    assert r.returncode == 0 and "solver-only swap ok" in r.stdout, r.stdout + r.stderr
