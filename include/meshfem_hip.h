@@ -181,6 +181,10 @@ mfh_status mfh_dof_map(mfh_ctx* ctx, const int32_t* dofForNode /* nNode or NULL 
  * with tolerance eps, installs it, flags internal boundary elements; returns nDoF.             */
 mfh_status mfh_apply_periodic_conditions(mfh_ctx* ctx, double eps, int64_t* nDoF);
 mfh_status mfh_get_dof_map(const mfh_ctx* ctx, int32_t* dofForNode /* nNode */, int64_t* nDoF);
+/* The same on a ROW-PARTITIONED context (mfh_mesh_set; periodic cell problems across GPUs): the rank's local nodes map to local DoFs numbered
+ * owned-first -- the rows of K are the first nOwnedDoF DoFs -- and the halo DoFs after them grouped by owner rank; mfh_dist_setup then takes its
+ * lists in DoF numbers (send: owned DoFs, receive ranges: cover the halo DoFs). Every element that touches a node of an owned DoF must be local. */
+mfh_status mfh_dof_map_partitioned(mfh_ctx* ctx, const int32_t* dofForNode /* nNode */, int64_t nDoF, int64_t nOwnedDoF);
 
 /* ---------------------------------------------------------------- assembly
  * mfh_assemble == Simulator::m_assembleStiffnessMatrix (LinearElasticity.hh:1408-1466) followed

@@ -63,6 +63,7 @@ PROTOTYPES = {
     "mfh_dof_map": (_i32, [_P, _P, _i64]),
     "mfh_apply_periodic_conditions": (_i32, [_P, _f64, _pi64]),
     "mfh_get_dof_map": (_i32, [_P, _P, _pi64]),
+    "mfh_dof_map_partitioned": (_i32, [_P, _P, _i64, _i64]),
     "mfh_assemble": (_i32, [_P, _i32]),
     "mfh_symbolic": (_i32, [_P, _i32]),
     "mfh_symbolic_sizes": (_i32, [_P, _pi64, _pi64, _pi32, _pi32]),

@@ -165,6 +165,12 @@ class Context:
         self.n_dof = n.value
         return n.value
 
+    def dof_map_partitioned(self, dof_for_node, n_dof, n_owned_dof):
+        """DoF map of a row-partitioned context (mfh_mesh_set): local DoFs owned-first, the rows of K are the first n_owned_dof."""
+        dm = as_i32(dof_for_node)
+        self._ck(self.lib.mfh_dof_map_partitioned(self.h, ptr(dm), int(n_dof), int(n_owned_dof)))
+        self.n_dof = int(n_dof)
+
     def get_dof_map(self):
         out = np.empty(self.n_node, dtype=np.int32)
         n = C.c_int64()

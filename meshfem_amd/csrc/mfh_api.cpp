@@ -1260,13 +1260,14 @@ mfh_status mfh_material_get(mfh_ctx *c, int64_t elem, double *D) {
 mfh_status mfh_dof_map(mfh_ctx *c, const int32_t *dofForNode, int64_t nDoF) {
     MFH_TRY(c)
     require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
+    c->nOwnedDoFSet = -1;
     if (!dofForNode) {
         c->dofForNode.clear();
         c->nDoF = c->mesh.nNode;
         // removePeriodicConditions (LinearElasticity.hh:874-879) also clears the isInternal flags
         std::fill(c->mesh.bdryInternal.begin(), c->mesh.bdryInternal.end(), (uint8_t)0);
     } else {
-        require(c->mesh.nOwned == c->mesh.nNode, MFH_ERR_UNSUPPORTED, "DoF maps on partitioned meshes are not supported");
+        require(c->mesh.nOwned == c->mesh.nNode, MFH_ERR_UNSUPPORTED, "a DoF map on a partitioned mesh says which DoFs are this rank's rows: mfh_dof_map_partitioned");
         require(nDoF > 0 && nDoF <= c->mesh.nNode, MFH_ERR_INVALID, "bad nDoF");
         for (int64_t n = 0; n < c->mesh.nNode; ++n)
             require(dofForNode[n] >= 0 && dofForNode[n] < nDoF, MFH_ERR_INVALID, "DoF index out of range");
@@ -1275,6 +1276,24 @@ mfh_status mfh_dof_map(mfh_ctx *c, const int32_t *dofForNode, int64_t nDoF) {
     }
     invalidate_symbolic(c);
     clear_fixed(c);
+    MFH_CATCH(c)
+}
+
+// Row-partitioned context with a DoF map (periodic cell problems across GPUs): the rank's local nodes map to local DoFs numbered owned-first
+// (rows of K = the first nOwnedDoF DoFs), halo DoFs after them grouped by owner; mfh_dist_setup then takes its lists in DoF numbers.
+mfh_status mfh_dof_map_partitioned(mfh_ctx *c, const int32_t *dofForNode, int64_t nDoF, int64_t nOwnedDoF) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && dofForNode, MFH_ERR_STATE, "no mesh set");
+    require(!c->mesh.hasTopology, MFH_ERR_UNSUPPORTED, "partitioned contexts are built by mfh_mesh_set");
+    require(nDoF > 0 && nDoF <= c->mesh.nNode && nOwnedDoF > 0 && nOwnedDoF <= nDoF, MFH_ERR_INVALID, "bad DoF counts");
+    for (int64_t n = 0; n < c->mesh.nNode; ++n)
+        require(dofForNode[n] >= 0 && dofForNode[n] < nDoF, MFH_ERR_INVALID, "DoF index out of range");
+    c->dofForNode.assign(dofForNode, dofForNode + c->mesh.nNode);
+    c->nDoF = nDoF;
+    c->nOwnedDoFSet = nOwnedDoF;
+    invalidate_symbolic(c);
+    clear_fixed(c);
+    dist_detach(c);                  // exchange lists are in DoF numbers: mfh_dist_setup must run (again)
     MFH_CATCH(c)
 }
 

@@ -239,8 +239,10 @@ struct mfh_ctx {
     int dim() const { return mesh.dim; }
     int bs() const { return (op == MFH_OP_ELASTICITY && !external) ? mesh.dim : 1; }   // variables per DoF = block edge of K
     int asmMat() const { return op == MFH_OP_ELASTICITY ? matKind : (op == MFH_OP_LAPLACIAN ? (int)MAT_LAPLACE : (int)MAT_MASS); }
+    int64_t nOwnedDoFSet = -1;        // mfh_dof_map_partitioned: the first nOwnedDoFSet DoFs are this rank's rows (-1: not set)
     int64_t nOwnedDoF() const {
-        // owned rows: DoFs of the first nOwned nodes. With a periodic map all DoFs are owned.
+        // owned rows: DoFs of the first nOwned nodes; with a DoF map all DoFs are owned unless mfh_dof_map_partitioned said otherwise
+        if (nOwnedDoFSet >= 0) return nOwnedDoFSet;
         if (mesh.nOwned == mesh.nNode) return nDoF;
         return mesh.nOwned;
     }

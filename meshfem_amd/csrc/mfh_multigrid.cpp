@@ -361,6 +361,10 @@ bool ensure_multigrid(mfh_ctx *c) {
         c->precondNote = "multigrid on partitioned rows needs the communicator of mfh_dist_setup: using block-Jacobi";
         return false;
     }
+    if (distributed && !c->dofForNode.empty()) {
+        c->precondNote = "multigrid on a partitioned context with a DoF map is not built: using block-Jacobi";
+        return false;
+    }
     if (singular && (distributed || c->mgAggTarget <= 0)) {
         c->precondNote = "multigrid for a singular system needs the aggregate hierarchy on an unpartitioned context: using block-Jacobi";
         return false;

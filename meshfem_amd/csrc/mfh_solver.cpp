@@ -832,11 +832,13 @@ mfh_status mfh_dist_setup(mfh_ctx *c, mfh_comm *cm, int32_t nPeers, const int32_
                           const int64_t *recvPtr) {
     MFH_TRY(c)
     require(c && c->haveMesh && cm && nPeers >= 0 && (nPeers == 0 || (peers && sendPtr && recvPtr)), MFH_ERR_INVALID, "bad distributed setup arguments");
-    require(c->dofForNode.empty(), MFH_ERR_UNSUPPORTED, "row-partitioned contexts use the identity DoF map");
+    require(c->dofForNode.empty() || c->nOwnedDoFSet >= 0, MFH_ERR_UNSUPPORTED,
+            "a row-partitioned context with a DoF map needs mfh_dof_map_partitioned (which DoFs are this rank's rows)");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     auto &D = c->dist;
-    const int64_t nOwned = c->mesh.nOwned, nHalo = c->mesh.nNode - nOwned;
+    // block rows of the vectors: nodes, or DoFs when a DoF map is installed (the lists are in the same numbering)
+    const int64_t nOwned = c->nOwnedDoF(), nHalo = c->nDoF - nOwned;
     D.peers.assign(peers, peers + nPeers);
     D.sendPtr.assign(1, 0); D.recvPtr.assign(1, 0);
     for (int k = 0; k < nPeers; ++k) {

@@ -120,6 +120,56 @@ def distribute_mesh(vertices, elements, degree, rank, world):
     return lm
 
 
+class LocalPeriodicMesh:
+    """A rank's share of a mesh under a periodic DoF map (`distribute_periodic_mesh`): the elements that touch a node of an owned DoF, their
+    nodes in any order, and the local DoF numbering -- owned DoFs first (by global id), halo DoFs after them grouped by owner rank. `keys`,
+    `n_owned`, `n_local`, `halo_ranges` describe the DoFs in the vocabulary HaloExchange reads (it then produces mfh_dist_setup's lists in
+    DoF numbers)."""
+
+    def __init__(self, elem_nodes, node_pos, node_ids, dof_for_node, keys, n_owned, halo_ranges, n_global_dof, kept_elems):
+        self.elem_nodes, self.node_pos, self.node_ids, self.kept_elems = elem_nodes, node_pos, node_ids, kept_elems
+        self.dof_for_node = dof_for_node      # [nLocalNodes] local DoF of every local node
+        self.keys = keys                      # [nLocalDoF] global DoF id of every local DoF
+        self.n_owned, self.n_local = n_owned, len(keys)
+        self.halo_ranges = halo_ranges
+        self.n_global_dof = n_global_dof
+
+
+def distribute_periodic_mesh(vertices, elements, degree, rank, world, eps=1e-7):
+    """Every rank holds the global mesh of a periodic cell: FEM node numbering and the periodic DoF map on the host (a host-only context),
+    RCB ownership of the DoFs (by the position of a DoF's first node), then the rank's elements / nodes / DoFs."""
+    from .core import Context
+    h = Context(-1)
+    h.mesh_build(np.asarray(elements), np.asarray(vertices, dtype=np.float64), degree)
+    en, pos = h.elem_nodes().astype(np.int64), h.node_positions()
+    n_dof = h.apply_periodic_conditions(eps)
+    dm, _ = h.get_dof_map()
+    dm = dm.astype(np.int64)
+    h.close()
+    first_node = np.full(n_dof, -1, dtype=np.int64)
+    first_node[dm[::-1]] = np.arange(len(dm))[::-1]                    # smallest node id of every DoF
+    owner = rcb_node_owner(pos[first_node], world)                      # per DoF
+    keep = (owner[dm[en]] == rank).any(axis=1)
+    en_l = en[keep]
+    nodes = np.unique(en_l)
+    node_remap = np.full(len(pos), -1, dtype=np.int64)
+    node_remap[nodes] = np.arange(len(nodes))
+    dofs = np.unique(dm[nodes])
+    group = np.where(owner[dofs] == rank, -1, owner[dofs])
+    order = np.lexsort((dofs, group))
+    dofs = dofs[order]
+    g_sorted = group[order]
+    n_owned = int((g_sorted == -1).sum())
+    halo_ranges = {}
+    for q in np.unique(g_sorted[n_owned:]):
+        idx = np.flatnonzero(g_sorted == q)
+        halo_ranges[int(q)] = (int(idx[0]), int(idx[-1]) + 1)
+    dof_remap = np.full(n_dof, -1, dtype=np.int64)
+    dof_remap[dofs] = np.arange(len(dofs))
+    return LocalPeriodicMesh(node_remap[en_l].astype(np.int32), pos[nodes], nodes, dof_remap[dm[nodes]].astype(np.int32), dofs, n_owned,
+                             halo_ranges, n_dof, np.flatnonzero(keep))
+
+
 class HaloExchange:
     """Point-to-point exchange lists. Every rank asks the owners for its halo nodes by key. `exchange` is the
     torch.distributed transport of the host-logic tests; the HIP path hands the same lists to the library

@@ -344,3 +344,81 @@ def test_callback_communicator_over_a_nccl_process_group_world_1():
         c.close()
     finally:
         dist.destroy_process_group()
+
+
+def _worker_periodic(rank, world, port, n, ret):
+    import torch
+    import torch.distributed as dist
+    import meshfem_amd as M
+    from meshfem_amd import distributed as D, grid
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+        E, nu = _periodic_cell_material(V, T)
+        lm = D.distribute_periodic_mesh(V, T, 2, rank, world)
+        c = M.Context(0)
+        c.mesh_set(3, 2, lm.elem_nodes, lm.node_pos)
+        c.material_iso_field(E[lm.kept_elems], nu[lm.kept_elems])
+        c.dof_map_partitioned(lm.dof_for_node, lm.n_local, lm.n_owned)
+        comm = D.make_comm(c, rank, world)
+        solver = D.DistSolver(c, lm, rank, world, comm)          # exchange lists in DoF numbers
+        pinned = np.flatnonzero(lm.keys == 0)                     # global DoF 0, on every rank that sees it (owner or halo)
+        c.fix_variables((3 * pinned[:, None] + np.arange(3)[None, :]).ravel())
+        out = {}
+        for k in (0, 5):                                          # a stretch and a shear probe
+            cs = np.zeros(6); cs[k] = -1.0 if k < 3 else -0.5
+            f = c.constant_strain_load(cs)[:lm.n_owned].ravel().copy()
+            u, infos = solver.solve(f, rtol=1e-10, maxit=20000)
+            out[k] = (u[0].reshape(-1, 3), bool(infos[0]["converged"]), infos[0]["iterations"])
+            Ku = solver.apply_K(u[0])
+            free = np.ones(3 * lm.n_owned, bool)
+            free[(3 * pinned[pinned < lm.n_owned][:, None] + np.arange(3)[None, :]).ravel()] = False
+            assert np.linalg.norm((Ku - f)[free]) <= 1e-8 * np.linalg.norm(f)
+        ret[rank] = dict(keys=lm.keys[:lm.n_owned].copy(), out=out)
+        comm.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def _periodic_cell_material(V, T):
+    """a smooth periodic stiffness field (an inclusion in the middle of the cell), the same on every rank"""
+    ctr = V[T].mean(axis=1)
+    r2 = ((ctr - 0.5) ** 2).sum(axis=1)
+    return 100.0 + 200.0 * np.exp(-r2 / 0.05), np.full(len(T), 0.3)
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_periodic_cell_problem_with_a_partitioned_dof_map():
+    """mfh_dof_map_partitioned: the periodic DoF map of a homogenization cell on a row-partitioned context -- rows and exchange lists in DoF
+    numbers, a DoF's nodes on opposite cell faces possibly on different ranks' local meshes. Against the single-context solve."""
+    import torch.multiprocessing as mp
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    world, n = 2, 5
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_periodic, args=(world, _free_port(), n, ret), nprocs=world, join=True)
+    assert set(ret.keys()) == {0, 1}
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    E, nu = _periodic_cell_material(V, T)
+    c = M.Context(0)
+    c.mesh_build(T, V, 2)
+    c.material_iso_field(E, nu)
+    nd = c.apply_periodic_conditions()
+    c.fix_variables(np.arange(3))
+    seen = sum(len(ret[r]["keys"]) for r in range(world))
+    assert seen == nd                                           # every DoF owned exactly once
+    for k in (0, 5):
+        cs = np.zeros(6); cs[k] = -1.0 if k < 3 else -0.5
+        f = c.constant_strain_load(cs)
+        u_ref = c.solve(f.ravel(), rtol=1e-10).reshape(-1, 3)
+        assert np.abs(u_ref).max() > 1e-3                       # the inclusion makes the fluctuation non-trivial
+        for r in range(world):
+            u, conv, _ = ret[r]["out"][k]
+            assert conv and np.linalg.norm(u - u_ref[ret[r]["keys"]]) / np.linalg.norm(u_ref) < 1e-7, (r, k)
+        assert ret[0]["out"][k][2] == ret[1]["out"][k][2]
+    c.close()
