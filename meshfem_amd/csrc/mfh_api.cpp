@@ -1739,7 +1739,8 @@ mfh_status mfh_dev_precond(mfh_ctx *c, const double *r_dev, double *z_dev) {
 mfh_status mfh_tl_partitioned_begin(mfh_ctx *c, int32_t nAgg, const int32_t *aggOfNode, const double *relPos, double *Ac_dev) {
     MFH_TRY(c)
     require(c && c->haveMesh && aggOfNode && relPos && Ac_dev && nAgg > 0, MFH_ERR_INVALID, "bad two-level arguments");
-    require(c->dofForNode.empty(), MFH_ERR_UNSUPPORTED, "caller-supplied aggregates need the identity DoF map");
+    // (with mfh_dof_map_partitioned the two arrays are per local DoF: the rows are DoFs there)
+    require(c->dofForNode.empty() || c->nOwnedDoFSet >= 0, MFH_ERR_UNSUPPORTED, "caller-supplied aggregates need the identity DoF map or mfh_dof_map_partitioned");
     require(c->op == MFH_OP_ELASTICITY, MFH_ERR_UNSUPPORTED, "the rigid-body-mode coarse space is defined for the elasticity operator");
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));

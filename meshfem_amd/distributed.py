@@ -129,6 +129,7 @@ class LocalPeriodicMesh:
     def __init__(self, elem_nodes, node_pos, node_ids, dof_for_node, keys, n_owned, halo_ranges, n_global_dof, kept_elems):
         self.elem_nodes, self.node_pos, self.node_ids, self.kept_elems = elem_nodes, node_pos, node_ids, kept_elems
         self.dof_for_node = dof_for_node      # [nLocalNodes] local DoF of every local node
+        self.dof_pos = None                   # [nLocalDoF, dim] position of every local DoF's first (global) node: the same on every rank
         self.keys = keys                      # [nLocalDoF] global DoF id of every local DoF
         self.n_owned, self.n_local = n_owned, len(keys)
         self.halo_ranges = halo_ranges
@@ -166,8 +167,10 @@ def distribute_periodic_mesh(vertices, elements, degree, rank, world, eps=1e-7):
         halo_ranges[int(q)] = (int(idx[0]), int(idx[-1]) + 1)
     dof_remap = np.full(n_dof, -1, dtype=np.int64)
     dof_remap[dofs] = np.arange(len(dofs))
-    return LocalPeriodicMesh(node_remap[en_l].astype(np.int32), pos[nodes], nodes, dof_remap[dm[nodes]].astype(np.int32), dofs, n_owned,
-                             halo_ranges, n_dof, np.flatnonzero(keep))
+    lm = LocalPeriodicMesh(node_remap[en_l].astype(np.int32), pos[nodes], nodes, dof_remap[dm[nodes]].astype(np.int32), dofs, n_owned,
+                           halo_ranges, n_dof, np.flatnonzero(keep))
+    lm.dof_pos = pos[first_node[dofs]]
+    return lm
 
 
 class HaloExchange:
@@ -374,7 +377,9 @@ class DistSolver:
     def two_level(self, target_aggregates):
         """Global geometric bins over the global bounding box, rigid-body modes per bin."""
         lm, dim = self.lm, self.ctx.dim
-        pos = np.asarray(lm.node_pos, dtype=np.float64)
+        # block rows are nodes, or DoFs under mfh_dof_map_partitioned (a DoF sits where its first node sits: the modes of aggregates at the
+        # periodic seam are then not exact rigid motions, but any full-rank coarse space is a valid one)
+        pos = np.asarray(lm.dof_pos if getattr(lm, "dof_pos", None) is not None else lm.node_pos, dtype=np.float64)
         lo = self._allreduce_np(pos.min(axis=0), dist.ReduceOp.MIN)
         hi = self._allreduce_np(pos.max(axis=0), dist.ReduceOp.MAX)
         agg, rel, nb, H = global_bins(pos, lo, hi, dim, target_aggregates)

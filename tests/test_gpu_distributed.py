@@ -377,6 +377,12 @@ def _worker_periodic(rank, world, port, n, ret):
             free = np.ones(3 * lm.n_owned, bool)
             free[(3 * pinned[pinned < lm.n_owned][:, None] + np.arange(3)[None, :]).ravel()] = False
             assert np.linalg.norm((Ku - f)[free]) <= 1e-8 * np.linalg.norm(f)
+        # the two-level preconditioner on global aggregates of the DoFs: same solution, fewer iterations
+        solver.two_level(8 * world)
+        u_tl, infos = solver.solve(f, rtol=1e-10, maxit=20000)
+        assert infos[0]["converged"], infos[0]
+        assert np.linalg.norm(u_tl[0] - u[0]) <= 1e-7 * np.linalg.norm(u[0]), np.linalg.norm(u_tl[0] - u[0]) / np.linalg.norm(u[0])
+        assert infos[0]["iterations"] <= out[5][2], (infos[0]["iterations"], out[5][2])
         ret[rank] = dict(keys=lm.keys[:lm.n_owned].copy(), out=out)
         comm.close()
         c.close()
