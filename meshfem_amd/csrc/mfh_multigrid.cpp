@@ -182,7 +182,9 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
     if (distributed) {
         const int world = dist_world(c1), rank = dist_rank(c1);
         double mn[3], mx[3];
-        bounding_box_device(dim, nOwnD, dPos, s, mn, mx);
+        // (with a DoF map: the box of the local NODES -- a DoF's position is that of whichever periodic image this rank holds)
+        if (!c1->dofForNode.empty()) bounding_box_device(dim, c1->mesh.nNode, c1->dVertPos.p, s, mn, mx);
+        else bounding_box_device(dim, nOwnD, dPos, s, mn, mx);
         std::vector<double> slots((size_t)world * 7, 0.0);
         for (int a = 0; a < 3; ++a) { slots[(size_t)rank * 7 + a] = a < dim ? mn[a] : 0.0; slots[(size_t)rank * 7 + 3 + a] = a < dim ? mx[a] : 0.0; }
         slots[(size_t)rank * 7 + 6] = (double)nOwnD;
@@ -196,6 +198,8 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
             for (int a = 0; a < 3; ++a) { box[a] = std::min(box[a], slots[(size_t)r * 7 + a]); box[3 + a] = std::max(box[3 + a], slots[(size_t)r * 7 + 3 + a]); }
             globalCount += (int64_t)slots[(size_t)r * 7 + 6];
         }
+        // periodic images of a DoF sit on opposite faces of the cell: wrapped to the minimal faces they fall into the same bin on every rank
+        if (!c1->dofForNode.empty()) wrap_positions_device(nD, dim, box, s, dDofPos.p);
     }
     auto sum_over_ranks = [&](double v) {
         if (!distributed) return v;
@@ -361,10 +365,6 @@ bool ensure_multigrid(mfh_ctx *c) {
         c->precondNote = "multigrid on partitioned rows needs the communicator of mfh_dist_setup: using block-Jacobi";
         return false;
     }
-    if (distributed && !c->dofForNode.empty()) {
-        c->precondNote = "multigrid on a partitioned context with a DoF map is not built: using block-Jacobi";
-        return false;
-    }
     if (singular && (distributed || c->mgAggTarget <= 0)) {
         c->precondNote = "multigrid for a singular system needs the aggregate hierarchy on an unpartitioned context: using block-Jacobi";
         return false;
@@ -431,6 +431,14 @@ bool ensure_multigrid(mfh_ctx *c) {
         if (coarseNode[(size_t)n] == 0) coarseNode[(size_t)n] = (int32_t)nCN++;
     coarseDofOfFine.assign((size_t)nDoF, -1);
     nCD = 0;
+    const bool partitionedDofMap = distributed && !c->dofForNode.empty();
+    if (partitionedDofMap) {
+        // row-partitioned context with a DoF map: the coarse DoFs keep the order of the fine ones (owned first, halo grouped by owner)
+        for (int64_t n = 0; n < m.nNode; ++n)
+            if (coarseNode[(size_t)n] >= 0) coarseDofOfFine[(size_t)dof_of(c, n)] = 0;
+        for (int64_t f = 0; f < nDoF; ++f)
+            if (coarseDofOfFine[(size_t)f] == 0) coarseDofOfFine[(size_t)f] = (int32_t)nCD++;
+    } else
     for (int64_t n = 0; n < m.nNode; ++n) {       // coarse DoFs numbered in node order, like applyPeriodicConditions numbers DoFs
         if (coarseNode[(size_t)n] < 0) continue;
         const int32_t f = dof_of(c, n);
@@ -481,11 +489,15 @@ bool ensure_multigrid(mfh_ctx *c) {
     m1 = HostMesh();
     m1.dim = d; m1.deg = 1; m1.npe = nv; m1.npbe = nodes_per_bdry_elem(d, 1);
     m1.nElem = m.nElem; m1.nNode = nCN; m1.nVert = nCN; m1.nOwned = nCN;
-    if (distributed) {
+    int64_t nOwnedCoarseDoF = -1;
+    if (distributed && c->dofForNode.empty()) {
         // the vertices this rank owns come first in the parent's numbering, hence in the child's: the child is partitioned the same way
         int64_t nOwnedCoarse = 0;
         for (int64_t n = 0; n < m.nOwned; ++n) nOwnedCoarse += coarse_node(n) >= 0;
         m1.nOwned = nOwnedCoarse;
+    } else if (distributed) {
+        nOwnedCoarseDoF = 0;                    // rows are DoFs: the coarse DoFs among the fine DoFs this rank owns
+        for (int64_t f = 0; f < c->nOwnedDoF(); ++f) nOwnedCoarseDoF += coarse_dof(f) >= 0;
     }
     m1.elemNodes.resize((size_t)m.nElem * nv);
     parallel_ranges(m.nElem, [&](int64_t eb, int64_t ee, int) {
@@ -506,11 +518,12 @@ bool ensure_multigrid(mfh_ctx *c) {
     c1->matMode = c->matMode; c1->matKind = c->matKind; c1->matParams = c->matParams;
     c1->geoValid = false;
     // DoF map of the vertices (periodic identifications carry over)
-    if (nCD != nCN) {
+    if (nCD != nCN || nOwnedCoarseDoF >= 0) {
         c1->dofForNode.assign((size_t)nCN, 0);
         for (int64_t n = 0; n < m.nNode; ++n)
             if (coarse_node(n) >= 0) c1->dofForNode[(size_t)coarse_node(n)] = coarse_dof(dof_of(c, n));
         c1->nDoF = nCD;
+        c1->nOwnedDoFSet = nOwnedCoarseDoF;     // (-1 unless the parent's rows are the DoFs of a partitioned DoF map)
         c1->dofUploaded = false;
     }
     // fixed variables of the vertices (homogeneous: the preconditioner acts on corrections)
@@ -527,7 +540,7 @@ bool ensure_multigrid(mfh_ctx *c) {
     c1->matrixStorage = 0;
     c1->aggNodes = c->mgAggNodes;
     c1->precond = distributed ? MFH_PRECOND_BLOCK_JACOBI : MFH_PRECOND_TWO_LEVEL;
-    if (distributed) dist_setup_child(c, c1, coarseNode);     // the parent's exchange lists, restricted to the vertices
+    if (distributed) dist_setup_child(c, c1, c->dofForNode.empty() ? coarseNode : coarseDofOfFine);   // the parent's exchange lists, restricted to the vertices' block rows
     ensure_precond(c1);
     lap("linear level: symbolic + assembly");
     // below the linear level: the aggregate hierarchy; where the lattice cannot resolve the mesh, the context's own dense coarse space

@@ -296,7 +296,7 @@ void dist_allreduce(mfh_ctx *c, double *dev, int64_t n) {
 void dist_setup_child(mfh_ctx *c, mfh_ctx *child, const std::vector<int32_t> &keep) {
     auto &D = c->dist;
     auto &E = child->dist;
-    const int64_t nOwned = c->mesh.nOwned;
+    const int64_t nOwned = c->nOwnedDoF();              // block rows: nodes, or DoFs under a partitioned DoF map
     E.peers = D.peers;
     E.sendPtr.assign(1, 0); E.recvPtr.assign(1, 0);
     std::vector<int32_t> idx;
@@ -310,7 +310,7 @@ void dist_setup_child(mfh_ctx *c, mfh_ctx *child, const std::vector<int32_t> &ke
         for (int64_t q = D.recvPtr[k]; q < D.recvPtr[k + 1]; ++q) cnt += keep[(size_t)(nOwned + q)] >= 0;
         E.recvPtr.push_back(E.recvPtr.back() + cnt);
     }
-    if (E.recvPtr.back() != child->mesh.nNode - child->mesh.nOwned) throw Error(MFH_ERR_STATE, "child halo does not match the filtered receive lists");
+    if (E.recvPtr.back() != child->nDoF - child->nOwnedDoF()) throw Error(MFH_ERR_STATE, "child halo does not match the filtered receive lists");
     E.sendNodesHost = idx;
     E.sendIdx.upload(idx.empty() ? std::vector<int32_t>{0} : idx, child->stream);
     // ONE communication stream per communicator: the child's collectives are issued on the parent's, in program order with them
