@@ -20,7 +20,7 @@
 using namespace MeshFEMHip;
 
 struct Args {
-    std::string mesh, material, boundaryConditions, outputMSH, dumpMatrix, dumpConditions, preconditioner = "two_level";
+    std::string mesh, material, boundaryConditions, outputMSH, dumpMatrix, dumpConditions, preconditioner = "multigrid";
     int degree = 2, device = 0;
     bool ascii = false, printMaterial = false;
     double rtol = 1e-8;
