@@ -22,7 +22,7 @@ def _tensor_like(Cbase, D):
 
 
 def homogenize(mesh, Cbase, orthotropicCell=False, manualPeriodicVerticesFile="", centerFluctuationDisplacements=True,
-               ignorePeriodicMismatch=False, device=0, preconditioner=L.PRECOND_TWO_LEVEL, rtol=1e-10):
+               ignorePeriodicMismatch=False, device=0, preconditioner=L.PRECOND_MULTIGRID, rtol=1e-10):
     N = mesh.embeddingDimension
     sim = Simulator(mesh.elements(), mesh.vertices(), mesh.degree, device)
     sim.rtol = rtol

@@ -141,10 +141,10 @@ PYBIND11_MODULE(periodic_homogenization, m) {
         return homogenizeN<NN>(mesh, Cbase, orthotropicCell, file, center, ignoreMismatch, device, preconditioner, rtol);                 \
     }, py::arg("mesh"), py::arg("Cbase"), py::arg("orthotropicCell") = false, py::arg("manualPeriodicVerticesFile") = std::string(),     \
        py::arg("centerFluctuationDisplacements") = true, py::arg("ignorePeriodicMismatch") = false, py::arg("device") = 0,               \
-       py::arg("preconditioner") = (int)MFH_PRECOND_TWO_LEVEL, py::arg("rtol") = 1e-10);                                                  \
+       py::arg("preconditioner") = (int)MFH_PRECOND_MULTIGRID, py::arg("rtol") = 1e-10);                                                  \
     m.def("probe", [](const py::object &mesh, const ETensor<NN> &Cbase, const py::object &macroStrain, bool orthotropicCell,             \
                       const std::string &file, bool ignoreMismatch) {                                                                   \
-        const auto hr = homogenizeN<NN>(mesh, Cbase, orthotropicCell, file, false, ignoreMismatch, 0, (int)MFH_PRECOND_TWO_LEVEL, 1e-10); \
+        const auto hr = homogenizeN<NN>(mesh, Cbase, orthotropicCell, file, false, ignoreMismatch, 0, (int)MFH_PRECOND_MULTIGRID, 1e-10); \
         return probeN<NN>(mesh, hr, strainOf<NN>(macroStrain));                                                                          \
     }, py::arg("mesh"), py::arg("Cbase"), py::arg("macroStrain"), py::arg("orthotropicCell") = false,                                   \
        py::arg("manualPeriodicVerticesFile") = std::string(), py::arg("ignorePeriodicMismatch") = false)
