@@ -76,8 +76,8 @@ def homogenized_elasticity_tensor(sim: Simulator, w_ij, base_cell_volume=0.0):
     strain (mfh_integrated_stress); no per-element field and no affine displacement field visit the host."""
     N, fl = sim.N, flat_len(sim.N)
     if base_cell_volume == 0.0:
-        pos = sim.nodes()
-        base_cell_volume = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
+        mn, mx = sim.boundingBox()
+        base_cell_volume = float(np.prod(mx - mn))
     Eh = np.zeros((fl, fl))
     for i in range(fl):
         Eh[i, :] = sim.ctx.integrated_stress(w_ij[i], canonical_strain_flat(N, i)) / base_cell_volume
@@ -106,7 +106,7 @@ def homogenized_elasticity_tensor_displacement_form(sim: Simulator, w_ij, base_c
     wts = _bdry_shape_integrals(N, sim.degree)
     pos = sim.nodes()
     if base_cell_volume == 0.0:
-        base_cell_volume = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
+        base_cell_volume = float(np.prod(sim.boundingBox()[1] - sim.boundingBox()[0]))
     idx = {2: [(0, 0), (1, 1), (0, 1)], 3: [(0, 0), (1, 1), (2, 2), (1, 2), (0, 2), (0, 1)]}[N]
     dbl = np.ones(fl)
     dbl[N:] = 2.0
@@ -128,7 +128,7 @@ def ortho_cell_fixed_vars(sim: Simulator, cell_epsilon=1e-7):
     component other than c). Variables are N * node + c."""
     N, fl = sim.N, flat_len(sim.N)
     pos = sim.nodes()
-    mn, mx = pos.min(axis=0), pos.max(axis=0)
+    mn, mx = sim.boundingBox()
     on = (np.abs(pos - mn) <= cell_epsilon) | (np.abs(pos - mx) <= cell_epsilon)     # FaceMembership::onMinOrMaxFace
     sets = [np.flatnonzero(on.ravel())]
     for s in range(fl - N):
@@ -197,8 +197,8 @@ def homogenized_elasticity_tensor_energy_form(sim: Simulator, w_ij, base_cell_vo
     """Ch_ijkl = 1/|Y| int (e^ij + eps(w^ij)) : C : (e^kl + eps(w^kl)) dV, one device reduction per tensor entry.
     Equal to the stress-like and displacement forms at the cell-problem solutions."""
     if base_cell_volume == 0.0:
-        pos = sim.nodes()
-        base_cell_volume = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
+        mn, mx = sim.boundingBox()
+        base_cell_volume = float(np.prod(mx - mn))
     return sim.ctx.mutual_energies(w_ij) / base_cell_volume
 
 
@@ -220,8 +220,8 @@ def delta_homogenized_elasticity_tensor(sim: Simulator, w_ij, delta_p, base_cell
     deltaHomogenizedElasticityTensor (:492-514) evaluates the continuous boundary form instead:
     `delta_homogenized_elasticity_tensor_boundary_form` reproduces that value."""
     if base_cell_volume == 0.0:
-        pos = sim.nodes()
-        base_cell_volume = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
+        mn, mx = sim.boundingBox()
+        base_cell_volume = float(np.prod(mx - mn))
     return sim.ctx.mutual_energies(w_ij, delta_p) / base_cell_volume
 
 
@@ -260,7 +260,7 @@ def homogenized_elasticity_tensor_gradient(sim: Simulator, w_ij):
     N, fl = sim.N, flat_len(sim.N)
     c = sim.ctx
     pos = sim.nodes()
-    bbox_vol = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
+    bbox_vol = float(np.prod(sim.boundingBox()[1] - sim.boundingBox()[0]))
     dbl = np.ones(fl)
     dbl[N:] = 2.0
     G = np.stack([c.boundary_strain_field(w_ij[k]) + canonical_strain_flat(N, k)[None, None, :] for k in range(fl)])      # [fl, nBE, nq, fl]
@@ -385,8 +385,8 @@ def homogenized_elasticity_tensor_discrete_differential(sim: Simulator, w_ij, ba
     Returns [nPairs, nVert, N] over the upper triangle ij <= kl (row-major), or with full=True the reference's
     OneForm layout [nVert, N, flatLen, flatLen]."""
     if base_cell_volume == 0.0:
-        pos = sim.nodes()
-        base_cell_volume = float(np.prod(pos.max(axis=0) - pos.min(axis=0)))
+        mn, mx = sim.boundingBox()
+        base_cell_volume = float(np.prod(mx - mn))
     d = sim.ctx.mutual_energy_differential(w_ij) / base_cell_volume
     if not full:
         return d

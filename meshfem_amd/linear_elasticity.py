@@ -18,6 +18,7 @@ class Simulator:
         self._use_pin = False
         self._no_rigid_motion = False
         self._rigid_motion_rhs = None
+        self._bbox = None
 
     # ---- mesh queries (mesh.cc:47-70)
     def numNodes(self):
@@ -35,8 +36,18 @@ class Simulator:
     def elements(self):
         return self.ctx.elem_nodes()
 
+    def boundingBox(self):
+        """(min corner, max corner) of the mesh (BoundaryConditions.hh:452-470 builds the periodic cell from it); edge nodes are
+        midpoints, so the box of the nodes is the box of anything that contains the vertices. Column by column: numpy's axis-0
+        reduction of an (n, 3) array is three times slower."""
+        if self._bbox is None:
+            pos = self.nodes()
+            self._bbox = (np.array([pos[:, k].min() for k in range(pos.shape[1])]), np.array([pos[:, k].max() for k in range(pos.shape[1])]))
+        return self._bbox
+
     def updateMeshNodePositions(self, vertices):                        # :1279-1284
         self.ctx.mesh_update_vertices(vertices)
+        self._bbox = None
 
     # ---- materials
     def setMaterial(self, tensor):
