@@ -130,8 +130,8 @@ void ensure_geometry(mfh_ctx *c, bool deferCheck) {
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     const HostMesh &m = c->mesh;
-    if (c->matParams.empty()) set_isotropic(c, 1.0, 0.3);
-    if (c->matMode == 0) {
+    if (c->matParams.empty() && !c->dMatBorrowed) set_isotropic(c, 1.0, 0.3);
+    if (c->matMode == 0 && !c->dMatBorrowed) {
         // plane stress lambda depends on dim: recompute now that the mesh is known
         double E = c->matParams[2], nu = c->matParams[3];
         double lam = (nu * E) / ((1.0 + nu) * (1.0 - 2.0 * nu));
@@ -139,13 +139,14 @@ void ensure_geometry(mfh_ctx *c, bool deferCheck) {
         c->matParams[0] = lam;
     }
     c->geoStride = c->matKind == MAT_ISO ? GEO_ISO_STRIDE : (c->matKind == MAT_ORTHO ? GEO_ORTHO_STRIDE : GEO_GEN_STRIDE);
-    c->dMatParams.upload(c->matParams, c->stream);
+    if (!c->dMatBorrowed) c->dMatParams.upload(c->matParams, c->stream);
+    const double *dMat = c->dMatBorrowed ? c->dMatBorrowed : c->dMatParams.p;
     c->dGeo.alloc((size_t)m.nElem * c->geoStride);
     c->dNeg.alloc(2);   // [0] inverted elements, [1] elements with an indefinite orthotropic tensor
     c->dNeg.zero(c->stream);
     ensure_pass_events(c);
     MFH_HIP(hipEventRecord(c->passEv[0], c->stream));
-    k::launch_geometry(m.dim, m.deg, c->matKind, m.nElem, c->dElemNodes.p, m.npe, c->dVertPos.p, c->dMatParams.p, c->matMode,
+    k::launch_geometry(m.dim, m.deg, c->matKind, m.nElem, c->dElemNodes.p, m.npe, c->dVertPos.p, dMat, c->matMode,
                        c->dGeo.p, c->geoStride, c->dNeg.p, c->stream);
     MFH_HIP(hipEventRecord(c->passEv[1], c->stream));
     MFH_HIP(hipMemcpyAsync(c->negHost, c->dNeg.p, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));

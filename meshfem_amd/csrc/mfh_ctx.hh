@@ -37,6 +37,7 @@ struct mfh_ctx {
     int op = MFH_OP_ELASTICITY;       // operator assembled into K: elasticity (dim x dim blocks) or scalar Laplacian / mass
     std::vector<double> matParams;    // host copy in the layout k_geometry expects
     DBuf<double> dMatParams;
+    const double *dMatBorrowed = nullptr;   // linear level of a multigrid hierarchy: the parent's per-element table on the device (the child lives no longer than it)
     DBuf<double> dGeo;
     DBuf<int> dNeg;
     int geoStride = GEO_ISO_STRIDE;

@@ -515,7 +515,11 @@ bool ensure_multigrid(mfh_ctx *c) {
     upload_mesh(c1);
     lap("linear mesh + upload");
     // material: the same per-element parameters (k_geometry rebuilds the records of the linear elements from them)
-    c1->matMode = c->matMode; c1->matKind = c->matKind; c1->matParams = c->matParams;
+    c1->matMode = c->matMode; c1->matKind = c->matKind;
+    if (c->matParams.size() > 64) {             // a per-element field: the linear elements read the parent's table where it lies on the device
+        ensure_geometry(c);
+        c1->dMatBorrowed = c->dMatParams.p;
+    } else c1->matParams = c->matParams;
     c1->geoValid = false;
     // DoF map of the vertices (periodic identifications carry over)
     if (nCD != nCN || nOwnedCoarseDoF >= 0) {
@@ -541,6 +545,7 @@ bool ensure_multigrid(mfh_ctx *c) {
     c1->aggNodes = c->mgAggNodes;
     c1->precond = distributed ? MFH_PRECOND_BLOCK_JACOBI : MFH_PRECOND_TWO_LEVEL;
     if (distributed) dist_setup_child(c, c1, c->dofForNode.empty() ? coarseNode : coarseDofOfFine);   // the parent's exchange lists, restricted to the vertices' block rows
+    lap("linear level: material, DoF map, fixed variables");
     ensure_precond(c1);
     lap("linear level: symbolic + assembly");
     // below the linear level: the aggregate hierarchy; where the lattice cannot resolve the mesh, the context's own dense coarse space
