@@ -25,8 +25,10 @@ if slab:
     sp = c.time_spmv_kernel(3)      # k_axpby calibration launch + the operator on the local columns
     nr, nc, nnzb = c.matrix_info()
     nE = len(lm.elem_nodes)
+    # SURVEY 8(d) per quadratic tet: 7 736 B with both triangles, 4 316 B with the upper triangle (the row of the storage in use)
     print(json.dumps(dict(n=n, slab=slab, storage="upper" if upper else "full", stored_blocks=stored, global_grid=[ng, ng, layers * world], elems=nE, nnzb=nnzb, rows=nr, asm_ms=ms, spmv_ms=sp,
-                          calib_axpby_doubles=3 * nc, asm_alg_bytes=7736 * nE, asm_expected_hbm_bytes=nnzb * 72 + nE * 100 * 6 + nE * 128)))
+                          calib_axpby_doubles=3 * nc, asm_alg_bytes=(4316 if upper else 7736) * nE,
+                          asm_expected_hbm_bytes=stored * 72 + nE * (55 if upper else 100) * 6 + nE * 128)))
     sys.exit(0)
 V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
 if os.environ.get("PMC_UPPER_STORAGE") == "1":      # the upper-triangle storage variant: assembly and matrix-free operator only
@@ -37,8 +39,10 @@ if os.environ.get("PMC_UPPER_STORAGE") == "1":      # the upper-triangle storage
     ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, 3)
     mf = c.time_spmv_kernel(3)      # k_axpby calibration launch, then the matrix-free operator
     nr, nc, nnzb = c.matrix_info()
-    print(json.dumps(dict(n=n, storage="upper", elems=len(T), nnzb=nnzb, rows=nr, asm_ms=ms, mf_ms=mf, calib_axpby_doubles=3 * nc,
-                          asm_alg_bytes=7736 * len(T), asm_expected_hbm_bytes=nnzb * 72 + len(T) * 55 * 6 + len(T) * 128)))
+    upper, stored = c.matrix_storage()
+    # SURVEY 8(d), upper-only row: 4 316 B per quadratic tet; expected HBM bytes: the stored blocks once + gather codes + element records
+    print(json.dumps(dict(n=n, storage="upper", elems=len(T), nnzb=nnzb, stored_blocks=stored, rows=nr, asm_ms=ms, mf_ms=mf, calib_axpby_doubles=3 * nc,
+                          asm_alg_bytes=4316 * len(T), asm_expected_hbm_bytes=stored * 72 + len(T) * 55 * 6 + len(T) * 128)))
     sys.exit(0)
 c.set_option("matrix_storage", 0)       # both triangles throughout (the assembled SpMV below needs them); PMC_UPPER_STORAGE=1 for the other
 c.mesh_build(T, V, 2)
