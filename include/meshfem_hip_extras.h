@@ -25,6 +25,10 @@ mfh_status mfh_matrix_free_info(mfh_ctx* ctx, int32_t* active, int32_t* mode, in
 mfh_status mfh_debug_spd_inverse(int64_t n, double* A);
 /* the same with the device implementation (blocked 64x64 Cholesky inverse in HBM) */
 mfh_status mfh_debug_spd_inverse_device(mfh_ctx* ctx, int64_t n, double* A);
+/* test hook: the DEVICE copies of the node table (nElem x nodesPerElem) and of the node positions (nNode x dim) that the kernels
+ * read -- mfh_mesh_build writes them on the device from the uploaded vertices; they must equal what mfh_mesh_elem_nodes /
+ * mfh_mesh_node_positions return from the host tables (FEMMesh.inl:17-59), bit for bit */
+mfh_status mfh_debug_device_node_tables(mfh_ctx* ctx, int32_t* elemNodes, double* nodePos);
 
 
 /* ---------------------------------------------------------------- device-pointer building blocks

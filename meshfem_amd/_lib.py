@@ -140,6 +140,7 @@ PROTOTYPES = {
     "mfh_set_option": (_i32, [_P, C.c_char_p, _f64]),
     "mfh_debug_spd_inverse": (_i32, [_i64, _P]),
     "mfh_debug_spd_inverse_device": (_i32, [_P, _i64, _P]),
+    "mfh_debug_device_node_tables": (_i32, [_P, _P, _P]),
 }
 
 # callback types of mfh_comm_create_callbacks

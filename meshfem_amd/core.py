@@ -265,6 +265,12 @@ class Context:
         nr, nc, _ = self.matrix_info()
         return sp.bsr_matrix((vals, ci, rp), shape=(nr * self.bs, nc * self.bs)).tocsr()
 
+    def debug_device_node_tables(self):
+        """(elem_nodes, node_pos) as the kernels see them (device copies; test hook)."""
+        en, pos = np.empty((self.n_elem, self.npe), dtype=np.int32), np.empty((self.n_node, self.dim))
+        self._ck(self.lib.mfh_debug_device_node_tables(self.h, ptr(en), ptr(pos)))
+        return en, pos
+
     def export_upper_triplets(self):
         n = C.c_uint64(0)
         self._ck(self.lib.mfh_export_upper_triplets(self.h, None, None, None, C.byref(n)))

@@ -81,11 +81,11 @@ void clear_fixed(mfh_ctx *c) {
     c->mg.valid = false;
 }
 
-void upload_mesh(mfh_ctx *c) {
+void upload_mesh(mfh_ctx *c, bool deviceTables) {
     double t0 = now_ms();
-    if (!c->hostOnly) {
+    if (!c->hostOnly && !deviceTables) {      // (deviceTables: the device topology has written both from the vertices)
         require_device(c);
-    MFH_HIP(hipSetDevice(c->device));
+        MFH_HIP(hipSetDevice(c->device));
         c->dElemNodes.upload(c->mesh.elemNodes, c->stream);
         c->dVertPos.upload(c->mesh.nodePos, c->stream);   // corner nodes index into the node table
     }
@@ -1063,10 +1063,11 @@ mfh_status mfh_mesh_build(mfh_ctx *c, int32_t dim, int32_t deg, int64_t nElem, i
     MFH_TRY(c)
     require(c && elemVerts && vertPos, MFH_ERR_INVALID, "null argument");
     if (!c->hostOnly) MFH_HIP(hipSetDevice(c->device));
-    build_fem_mesh(c->mesh, dim, deg, nElem, nVert, elemVerts, vertPos, !c->hostOnly && c->topologyDevice, c->stream);
+    bool deviceTables = false;
+    build_fem_mesh(c->mesh, dim, deg, nElem, nVert, elemVerts, vertPos, !c->hostOnly && c->topologyDevice, c->stream, &c->dElemNodes, &c->dVertPos, &deviceTables);
     const bool timing = getenv("MFH_MESH_TIMING") != nullptr;
     double t0 = now_ms();
-    upload_mesh(c);
+    upload_mesh(c, deviceTables);
     if (timing) { if (!c->hostOnly) (void)hipStreamSynchronize(c->stream); fprintf(stderr, "[mesh build] %-30s %8.2f ms\n", "upload + tables", now_ms() - t0); t0 = now_ms(); }
     if (!c->hostOnly) ensure_geometry(c);   // throws on negative volumes like the Simulator ctor
     if (timing) fprintf(stderr, "[mesh build] %-30s %8.2f ms\n", "embedding kernel + check", now_ms() - t0);
@@ -1089,7 +1090,7 @@ mfh_status mfh_mesh_set(mfh_ctx *c, int32_t dim, int32_t deg, int64_t nElem, int
     m.nodePos.assign(nodePos, nodePos + nNode * dim);
     m.vertPos = m.nodePos;
     m.isBdryNode.assign((size_t)nNode, 0);
-    upload_mesh(c);
+    upload_mesh(c, false);
     if (!c->hostOnly) ensure_geometry(c);
     MFH_CATCH(c)
 }
@@ -1903,6 +1904,17 @@ mfh_status mfh_time_spmv_kernel(mfh_ctx *c, int32_t reps, double *avg_ms) {
     EventTimer t(c->stream);
     for (int r = 0; r < reps; ++r) apply_operator(c, false, c->wx.p, c->wAp.p, nullptr);
     *avg_ms = t.stop() / reps;
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_debug_device_node_tables(mfh_ctx *c, int32_t *elemNodes, double *nodePos) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && !c->hostOnly && elemNodes && nodePos, MFH_ERR_STATE, "no mesh on a device");
+    MFH_HIP(hipSetDevice(c->device));
+    const HostMesh &m = c->mesh;
+    require(c->dElemNodes.n == (size_t)m.nElem * m.npe && c->dVertPos.n == (size_t)m.nNode * m.dim, MFH_ERR_STATE, "device node tables have another size than the host's");
+    c->dElemNodes.download(elemNodes, c->dElemNodes.n, c->stream);
+    c->dVertPos.download(nodePos, c->dVertPos.n, c->stream);
     MFH_CATCH(c)
 }
 

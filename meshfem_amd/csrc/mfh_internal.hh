@@ -159,11 +159,15 @@ struct HostMesh {
     int64_t nBE() const { return npbe ? (int64_t)bdryElemNodes.size() / npbe : 0; }
 };
 
+// dElemNodesOut / dNodePosOut (device topology only): the device copies of the node table and the node positions, built on the device
+// from the vertices; *deviceTables says whether they were written
 void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *elemVerts,
-                    const double *vertPos, bool useDevice = false, hipStream_t stream = nullptr);
+                    const double *vertPos, bool useDevice = false, hipStream_t stream = nullptr, DBuf<int32_t> *dElemNodesOut = nullptr,
+                    DBuf<double> *dNodePosOut = nullptr, bool *deviceTables = nullptr);
 // device topology (mfh_symbolic_gpu.hip); false = mesh does not fit the packed sort keys, use the host path
 bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *hostElemVerts, hipStream_t s,
-                           std::vector<int32_t> &instEdge, int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst);
+                           std::vector<int32_t> &instEdge, int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst,
+                           const double *hostVertPos = nullptr, DBuf<int32_t> *dElemNodesOut = nullptr, DBuf<double> *dNodePosOut = nullptr);
 void compute_node_positions(HostMesh &m);
 void compute_boundary_geometry(HostMesh &m, const double *vertPos);
 void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofForNode, int64_t &nDoF,

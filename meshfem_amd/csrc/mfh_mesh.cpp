@@ -195,7 +195,7 @@ void compute_boundary_geometry(HostMesh &m, const double *vp) {
 }
 
 void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *ev, const double *vp, bool useDevice,
-                    hipStream_t stream) {
+                    hipStream_t stream, DBuf<int32_t> *dElemNodesOut, DBuf<double> *dNodePosOut, bool *deviceTables) {
     if (dim != 2 && dim != 3) throw Error(MFH_ERR_INVALID, "dim must be 2 or 3");
     if (deg != 1 && deg != 2) throw Error(MFH_ERR_INVALID, "deg must be 1 or 2");
     if (nElem <= 0 || nVert <= 0) throw Error(MFH_ERR_INVALID, "empty mesh");
@@ -230,7 +230,10 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
     std::vector<int32_t> instEdge;
     std::vector<uint32_t> bdryInst;
     int32_t nEdgeNodes = 0;
-    if (!(useDevice && build_topology_device(dim, deg, nElem, nVert, ev, stream, instEdge, nEdgeNodes, bdryInst)))
+    if (deviceTables) *deviceTables = false;
+    if (useDevice && build_topology_device(dim, deg, nElem, nVert, ev, stream, instEdge, nEdgeNodes, bdryInst, vp, dElemNodesOut, dNodePosOut)) {
+        if (deviceTables) *deviceTables = dElemNodesOut && dNodePosOut;
+    } else
         build_topology_host(dim, deg, nElem, nVert, ev, instEdge, nEdgeNodes, bdryInst);
 
     lap("topology (edges, boundary)");

@@ -19,7 +19,7 @@ k::TLArgs tl_args(mfh_ctx *c);
 void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double *dotOut);
 void ensure_fixed_uploaded(mfh_ctx *c);
 double device_dot(mfh_ctx *c, int64_t n, const double *a, const double *b);
-void upload_mesh(mfh_ctx *c);
+void upload_mesh(mfh_ctx *c, bool deviceTables);
 bool dense_inverse_device(mfh_ctx *c, const double *Ac, int64_t mm, DBuf<double> &Ainv, int64_t &ldInv);
 const int32_t *device_dof_map(mfh_ctx *c);
 
@@ -512,7 +512,7 @@ bool ensure_multigrid(mfh_ctx *c) {
     });
     m1.vertPos = m1.nodePos;
     m1.isBdryNode.assign((size_t)nCN, 0);
-    upload_mesh(c1);
+    upload_mesh(c1, false);
     lap("linear mesh + upload");
     // material: the same per-element parameters (k_geometry rebuilds the records of the linear elements from them)
     c1->matMode = c->matMode; c1->matKind = c->matKind;

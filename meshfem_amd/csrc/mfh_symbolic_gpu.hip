@@ -1101,6 +1101,24 @@ __global__ void __launch_bounds__(256) k_topo_edge_keys(int64_t nInst, int nv, i
         val[k] = (uint32_t)k;
     }
 }
+// the node table and the node positions of the FEMMesh, written where the assembly reads them (the host builds its own copies for the
+// queries of the API meanwhile): corners, then for quadratic elements the edge nodes nVert + instEdge and their midpoints -- every
+// element of an edge stores the same 0.5 (a + b), bit for bit what compute_node_positions stores on the host
+__global__ void __launch_bounds__(256) k_topo_node_tables(int64_t nElem, int dim, int deg, int64_t nVert, const int32_t *__restrict__ ev,
+                                                          const int32_t *__restrict__ instEdge, int32_t *__restrict__ elemNodes,
+                                                          double *__restrict__ nodePos) {
+    const int nv = dim + 1, nedge = deg == 2 ? (dim == 3 ? 6 : 3) : 0, npe = nv + nedge;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nElem; e += (int64_t)gridDim.x * 256) {
+        int32_t v[4];
+        for (int c = 0; c < nv; ++c) { v[c] = ev[e * nv + c]; elemNodes[e * npe + c] = v[c]; }
+        for (int ei = 0; ei < nedge; ++ei) {
+            const int64_t node = nVert + instEdge[e * nedge + ei];
+            elemNodes[e * npe + nv + ei] = (int32_t)node;
+            const double *pa = nodePos + (int64_t)v[kEdgeS[ei]] * dim, *pb = nodePos + (int64_t)v[kEdgeE[ei]] * dim;
+            for (int a = 0; a < dim; ++a) nodePos[node * dim + a] = 0.5 * (pa[a] + pb[a]);
+        }
+    }
+}
 // unique edges: at heads, uniq id = headCount-1; record first instance (smallest k: the sort is stable)
 __global__ void __launch_bounds__(256) k_topo_edge_first(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ val,
                                                          const uint32_t *__restrict__ headP1, uint32_t *__restrict__ firstInst) {
@@ -1194,7 +1212,8 @@ __global__ void __launch_bounds__(256) k_topo_face_compact(int64_t n, const uint
 // two-sort variant of the half-face ordering. instEdge: nElem*nedge first-encounter edge-node ranks (deg 2 only);
 // bdryInst: half-face (4t+f) / half-edge (3t+c) instances without a mate, in sorted-key order.
 bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *hostElemVerts, hipStream_t s,
-                           std::vector<int32_t> &instEdge, int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst) {
+                           std::vector<int32_t> &instEdge, int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst,
+                           const double *hostVertPos, DBuf<int32_t> *dElemNodesOut, DBuf<double> *dNodePosOut) {
     // packed 3 x 21-bit face keys do not fit beyond 2^21 vertices: two-sort variant below (MFH_TOPO_FORCE_WIDE: tests)
     const bool wide = dim == 3 && (nVert >= (1 << 21) || getenv("MFH_TOPO_FORCE_WIDE") != nullptr);
     const int nv = dim + 1, nedge = dim == 3 ? 6 : 3;
@@ -1204,6 +1223,7 @@ bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const
     auto ensureTmp = [&](size_t bytes) { if (bytes + 16 > tmp.n) tmp.alloc(bytes + 16); };
     nEdgeNodes = 0;
     instEdge.clear();
+    DBuf<int32_t> dInst;
     if (deg == 2) {
         const int64_t n = nElem * nedge;
         DBuf<uint64_t> kA, kB;
@@ -1231,12 +1251,20 @@ bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const
         ensureTmp(b);
         RP(rocprim::radix_sort_pairs(tmp.p, b, firstInst.p, firstSorted.p, uniqId.p, uniqByFirst.p, (size_t)nU, 0u, bits_for((uint64_t)n), s));
         hipLaunchKernelGGL(k_topo_rank, dim3(grid_of(nU)), dim3(256), 0, s, (int64_t)nU, uniqByFirst.p, rankOfUniq.p);
-        DBuf<int32_t> dInst;
         dInst.alloc(n);
         hipLaunchKernelGGL(k_topo_edge_assign, dim3(grid_of(n)), dim3(256), 0, s, n, vB.p, headP1.p, rankOfUniq.p, dInst.p);
         RP(hipGetLastError());
         instEdge.resize((size_t)n);
         dInst.download(instEdge.data(), (size_t)n, s);
+    }
+    if (dElemNodesOut && dNodePosOut && hostVertPos) {
+        // the device copies of the node table and of the node positions: only the vertices cross the bus
+        const int64_t nNode = nVert + nEdgeNodes;
+        dElemNodesOut->alloc((size_t)nElem * (nv + (deg == 2 ? nedge : 0)));
+        dNodePosOut->alloc((size_t)nNode * dim);
+        MFH_HIP(hipMemcpyAsync(dNodePosOut->p, hostVertPos, (size_t)nVert * dim * sizeof(double), hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_topo_node_tables, dim3(grid_of(nElem)), dim3(256), 0, s, nElem, dim, deg, nVert, dEv.p, dInst.p, dElemNodesOut->p, dNodePosOut->p);
+        RP(hipGetLastError());
     }
     {   // boundary half-faces / half-edges
         const int64_t n = nElem * (dim == 3 ? 4 : 3);

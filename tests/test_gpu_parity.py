@@ -635,6 +635,19 @@ def test_device_symbolic_identical_to_host_symbolic(case):
     assert abs(a["K"] - b["K"]).max() <= 1e-13 * abs(b["K"]).max()
 
 
+@pytest.mark.parametrize("deg", [1, 2])
+def test_device_node_tables_equal_the_host_tables_at_scale(deg):
+    """mfh_mesh_build writes the node table and the node positions the kernels read on the device (corners; edge nodes nVert + first-encounter
+    rank and their midpoints, FEMMesh.inl:17-59) instead of uploading the host tables: same bits at 331 776 tets, where every edge is written by
+    several elements at once."""
+    V, T = grid.grid_tet_mesh(24, 24, 24, [0, 0, 0], [1.0, 2.0, 0.5])
+    c = _ctx()
+    c.mesh_build(T, V, deg)
+    en, pos = c.debug_device_node_tables()
+    assert np.array_equal(en, c.elem_nodes())
+    assert np.array_equal(pos, c.node_positions())
+
+
 @pytest.mark.parametrize("dim,deg", [(3, 1), (3, 2), (2, 2)])
 def test_device_topology_identical_to_host(dim, deg):
     """FEMMesh numbering built with device radix sorts == host hash/sort implementation == oracle."""
@@ -651,6 +664,11 @@ def test_device_topology_identical_to_host(dim, deg):
         assert np.array_equal(c.boundary_elem_nodes(), m.bdry_elem_nodes)
         assert np.array_equal(c.boundary_nodes(), m.bdry_nodes)
         assert np.array_equal(c.node_positions(), m.node_pos)
+        # the device topology also writes the DEVICE copies of the node table and the node positions (edge midpoints from the uploaded
+        # vertices) that the host path uploads: the kernels must see the host's tables, bit for bit
+        en, pos = c.debug_device_node_tables()
+        assert np.array_equal(en, m.elem_nodes)
+        assert np.array_equal(pos, m.node_pos)
     c = _ctx()
     with pytest.raises(M.MeshFEMHipError, match="manifold"):
         c.mesh_build(np.array([[0, 1, 2, 3], [0, 1, 2, 4], [0, 1, 2, 5]]), np.random.default_rng(0).random((6, 3)), 1)
