@@ -12,6 +12,7 @@ from meshfem_amd import grid
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 deg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+T = T.astype("int32")      # the ABI's index type (the generator returns int64: converting 20 M indices in numpy would be 20-30 ms of the first lap)
 for rep in range(int(os.environ.get("REPS", "2"))):
     c = M.Context(0)
     t0 = time.perf_counter()
