@@ -623,8 +623,10 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
                                                  " constraint rows: the system is singular (add no_rigid_motion or pin more nodes)");
     }
     if (info) *info = li;
-    for (int64_t i = 0; i < m.nNode; ++i)   // dofToNodeField :664-677
-        for (int a = 0; a < d; ++a) uNodes[(size_t)i * d + a] = x[(size_t)dof_of(c, i) * d + a];
+    parallel_ranges(m.nNode, [&](int64_t nb, int64_t ne, int) {   // dofToNodeField :664-677
+        for (int64_t i = nb; i < ne; ++i)
+            for (int a = 0; a < d; ++a) uNodes[(size_t)i * d + a] = x[(size_t)dof_of(c, i) * d + a];
+    });
     lap("dofToNodeField");
     if (!li.converged) throw Error(MFH_ERR_NOT_CONVERGED, "PCG did not reach the requested tolerance within maxit iterations");
 }
