@@ -1063,6 +1063,7 @@ mfh_status mfh_mesh_build(mfh_ctx *c, int32_t dim, int32_t deg, int64_t nElem, i
     MFH_TRY(c)
     require(c && elemVerts && vertPos, MFH_ERR_INVALID, "null argument");
     if (!c->hostOnly) MFH_HIP(hipSetDevice(c->device));
+    c->haveMesh = false;              // a build that throws half way (bad indices, non-manifold input) leaves a context without a mesh, not with half of one
     bool deviceTables = false;
     build_fem_mesh(c->mesh, dim, deg, nElem, nVert, elemVerts, vertPos, !c->hostOnly && c->topologyDevice, c->stream, &c->dElemNodes, &c->dVertPos, &deviceTables);
     const bool timing = getenv("MFH_MESH_TIMING") != nullptr;
@@ -1081,6 +1082,7 @@ mfh_status mfh_mesh_set(mfh_ctx *c, int32_t dim, int32_t deg, int64_t nElem, int
     require((dim == 2 || dim == 3) && (deg == 1 || deg == 2), MFH_ERR_INVALID, "dim must be 2/3 and deg 1/2");
     require(nElem > 0 && nNode > 0 && nOwned > 0 && nOwned <= nNode, MFH_ERR_INVALID, "bad mesh sizes");
     HostMesh &m = c->mesh;
+    c->haveMesh = false;
     m = HostMesh();
     m.dim = dim; m.deg = deg; m.npe = nodes_per_elem(dim, deg); m.npbe = nodes_per_bdry_elem(dim, deg);
     m.nElem = nElem; m.nNode = nNode; m.nVert = nNode; m.nOwned = nOwned;

@@ -69,6 +69,12 @@ def test_unstructured_disjoint_tets_and_bad_input():
         c.mesh_build(np.array([[0, 1, 2, 99999]]), V, 1)      # "Bad vertex index encountered."
     with pytest.raises(M.MeshFEMHipError):
         c.mesh_build(np.array([[0, 1, 2, 3], [0, 1, 2, 4], [0, 1, 2, 5]]), V, 1)   # non-manifold face
+    # a build that fails leaves a context WITHOUT a mesh (not with half of the new one or the tables of the old one) ...
+    with pytest.raises(M.MeshFEMHipError, match="no mesh"):
+        c.fix_variables(np.array([0]))
+    # ... and the context takes the next mesh as if nothing had happened
+    c.mesh_build(T, V, 2)
+    assert np.array_equal(c.elem_nodes(), m.elem_nodes)
 
 
 def _emulate_gather(c, Ke, dim):
