@@ -404,6 +404,9 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
  *   corner positions instead of reading the element records), "mf_xcd_group" (32 default: consecutive element blocks per XCD),
  *   "mf_lane_stride" (37 default: lane-to-element stride inside a block, against same-address LDS atomics),
  * "pcg_graph" (1 default: blocks of check_every PCG iterations are replayed from a hipGraph),
+ * "refine" (1 default: when a converged solve of mfh_solve / mfh_sim_solve* ends with a TRUE residual ||f - K u|| / ||b|| above twice the
+ *   tolerance -- the recurrence residual drifts over thousands of iterations -- the correction K du = f - K u is solved to what is missing
+ *   and added, up to three times: the answer is as good as the tolerance says, like a direct solver's; solves that end within it are untouched),
  * "matrix_storage" (which blocks of K are stored and assembled. 1: only the blocks (r, c >= r), the triangle the reference's TripletMatrix
  *   holds -- half the bytes and block arithmetic of the assembly; serves mfh_export_upper_triplets, mfh_export_bsr (mirrored on the host),
  *   the (block-)Jacobi and two-level PCG on the matrix-free operator; the assembled SpMV and the probing construction of the coarse

@@ -1987,6 +1987,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "symbolic_device") { c->symbolicDevice = value != 0; invalidate_symbolic(c); }
     else if (k2 == "xcd_swizzle") c->xcdSwizzle = std::max(0, (int)value);   // 1: contiguous eighths; G > 1: runs of G items per XCD
     else if (k2 == "pcg_graph") c->useGraph = value != 0;
+    else if (k2 == "refine") c->refine = value != 0;
     else if (k2 == "mf_geometry_from_vertices") c->mfGeoFromVerts = value != 0;
     else if (k2 == "mf_xcd_group") c->mfXcdGroup = std::max(0, (int)value);
     else if (k2 == "vec_grid_cap") k::g_vecGridCap = std::max(256, (int)value);

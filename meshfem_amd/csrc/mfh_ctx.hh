@@ -122,6 +122,7 @@ struct mfh_ctx {
     bool anyFixedNonzero = false;
     bool useGraph = true;             // option "pcg_graph": capture blocks of check_every PCG iterations in a hipGraph
     bool tlSuppress = false;          // solve_one: block-Jacobi for this solve (K singular on the free variables)
+    bool refine = true;               // option "refine": iterative refinement when the true residual of a converged solve ends above 2 rtol (solve_one)
     bool solveHomogeneous = false;    // solve_one: treat the fixed values as 0 (columns of the Schur complement)
 
     // ---- solver

@@ -145,6 +145,7 @@ bool prepare_matrix_free(mfh_ctx *c);
 k::TLArgs tl_args(mfh_ctx *c);
 void ensure_fixed_uploaded(mfh_ctx *c);
 void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info);
+void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double *dotOut);
 
 namespace {
 
@@ -694,7 +695,7 @@ void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rt
 }
 
 // one right-hand side: the Chronopoulos-Gear loop when the operator in use has a batched kernel, else the classic PCG
-void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info) {
+static void solve_one_pass(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info) {
     const bool partitioned = c->sym.nRows != c->sym.nCols;
     // the hierarchy for THIS solve (regular, or pinned for a system that is singular on the free variables): a no-op once it exists
     if (c->precond == MFH_PRECOND_MULTIGRID && !partitioned && !(c->mg.valid && c->mg.singular == c->tlSuppress)) ensure_coarse_levels(c, 1);
@@ -706,6 +707,49 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
         solve_one_classic(c, f, u, rtol, maxit, info);
         if (info) info->reserved = 1;
     }
+}
+
+// One right-hand side on a context that owns all its rows, with ITERATIVE REFINEMENT: over thousands of iterations the recurrence residual
+// of the PCG drifts away from f - K u (block-Jacobi on a thin plate: 9.5e-9 reached, 3.9e-8 true), and the answer of the direct solver this
+// replaces has no such gap. When the true residual ends above twice the tolerance, the correction K du = f - K u (du = 0 on the fixed
+// variables) is solved to what is missing and added; option "refine" 0 switches it off. Solves that end within the tolerance -- all of the
+// benchmark's -- never get here.
+void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info) {
+    mfh_solve_info li{};
+    solve_one_pass(c, f, u, rtol, maxit, &li);
+    const bool partitioned = c->sym.nRows != c->sym.nCols;
+    if (c->refine && !partitioned && !c->solveHomogeneous && rtol > 0) {
+        const int64_t n = (int64_t)c->bs() * c->nDoF;
+        RawVec<double> r, du;
+        DBuf<double> dU, dKu;
+        for (int pass = 0; pass < 3 && li.converged && li.true_rel_residual > 2.0 * rtol && li.true_rel_residual < 1.0; ++pass) {
+            r.resize((size_t)n); du.resize((size_t)n);
+            dU.alloc((size_t)n); dKu.alloc((size_t)n);
+            MFH_HIP(hipMemcpyAsync(dU.p, u, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+            apply_operator(c, false, dU.p, dKu.p, nullptr);
+            dKu.download(r.data(), (size_t)n, c->stream);
+            const uint8_t *mask = c->fixedVars.empty() ? nullptr : c->hFixedMask.data();
+            parallel_ranges(n, [&](int64_t b, int64_t e, int) {
+                for (int64_t i = b; i < e; ++i) r[(size_t)i] = (mask && mask[i]) ? 0.0 : f[i] - r[(size_t)i];
+            });
+            mfh_solve_info l2{};
+            const double before = li.true_rel_residual;
+            c->solveHomogeneous = true;
+            try { solve_one_pass(c, r.data(), du.data(), std::min(0.5, rtol / before), maxit, &l2); }
+            catch (...) { c->solveHomogeneous = false; throw; }
+            c->solveHomogeneous = false;
+            parallel_ranges(n, [&](int64_t b, int64_t e, int) {
+                for (int64_t i = b; i < e; ++i) u[i] += du[(size_t)i];
+            });
+            li.iterations += l2.iterations;
+            li.solve_ms += l2.solve_ms;
+            li.setup_ms += l2.setup_ms;
+            li.rel_residual = l2.rel_residual * before;        // both are relative to the residual the pass started from
+            li.true_rel_residual = l2.true_rel_residual * before;
+            li.converged = l2.converged;
+        }
+    }
+    if (info) *info = li;
 }
 
 // nrhs right-hand sides in batches of the sizes the kernels are built for (3D: 6, 2, 1; 2D: 3, 1)

@@ -1022,12 +1022,21 @@ def test_plateau_of_the_residual_is_not_reported_as_stagnation():
     for pre in (M.PRECOND_BLOCK_JACOBI, M.PRECOND_TWO_LEVEL, M.PRECOND_MULTIGRID):
         c.set_preconditioner(pre)
         sol[pre] = c.sim_solve(rtol=1e-9, maxit=100000)
-        assert c.last_info["converged"] and c.last_info["true_rel_residual"] < 1e-7, (pre, c.last_info)
+        # ... and the TRUE residual ends within twice the tolerance: after thousands of iterations the recurrence residual has drifted
+        # (3.9e-8 true at 9.5e-9 reached for rtol 1e-8), the solve then refines (K du = f - K u) like a direct solver's answer needs not
+        assert c.last_info["converged"] and c.last_info["true_rel_residual"] <= 2e-9, (pre, c.last_info)
         its = c.last_info["iterations"]
         assert (its > 3000) if pre == M.PRECOND_BLOCK_JACOBI else (its < 1000), (pre, its)
     ref = sol[M.PRECOND_MULTIGRID]
     for pre in (M.PRECOND_BLOCK_JACOBI, M.PRECOND_TWO_LEVEL):
         assert np.linalg.norm(sol[pre] - ref) <= 1e-5 * np.linalg.norm(ref), pre
+    # without the refinement the drift is visible
+    c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+    c.set_option("refine", 0)
+    c.sim_solve(rtol=1e-9, maxit=100000)
+    drift = c.last_info["true_rel_residual"]
+    c.set_option("refine", 1)
+    assert c.last_info["converged"] and drift < 1e-6
 
 
 @pytest.mark.gpu
