@@ -62,3 +62,26 @@ for pre, pn in ((M.PRECOND_MULTIGRID, "mg"), (M.PRECOND_TWO_LEVEL, "tl"), (M.PRE
     run("two_components %s" % pn, lambda: two_components(pre))
     run("thin_slab %s" % pn, lambda: thin_slab(pre))
 print("DONE")
+
+
+def all_fixed_nonzero(pre):
+    V, T = grid.grid_tet_mesh(3, 3, 3, [0, 0, 0], [1, 1, 1])
+    c = M.Context(0); c.mesh_build(T, V, 2); c.material_isotropic(1.0, 0.3)
+    vals = np.linspace(-1, 1, 3 * c.n_node)
+    c.fix_variables(np.arange(3 * c.n_node), vals); c.set_preconditioner(pre)
+    u = c.solve(np.ones(3 * c.n_node), rtol=1e-10); return c.last_info["iterations"], float(np.abs(u - vals).max())
+
+def rebuild_same_context(pre):
+    c = M.Context(0); c.set_preconditioner(pre); out = []
+    for n, deg in ((6, 2), (3, 1), (8, 2), (5, 1)):
+        V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+        c.mesh_build(T, V, deg); c.material_isotropic(1.0, 0.3)
+        c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+        c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+        c.sim_solve(rtol=1e-8); out.append((c.last_info["iterations"], "%.1e" % c.last_info["true_rel_residual"]))
+    return out
+
+for pre, pn in ((M.PRECOND_MULTIGRID, "mg"), (M.PRECOND_TWO_LEVEL, "tl"), (M.PRECOND_BLOCK_JACOBI, "bj")):
+    run("all_fixed_nonzero %s" % pn, lambda: all_fixed_nonzero(pre))
+    run("rebuild_same_context %s" % pn, lambda: rebuild_same_context(pre))
+print("DONE 2")
