@@ -1248,24 +1248,27 @@ __global__ void __launch_bounds__(256) k_mg_cheb(int64_t nRows, const double *__
 }
 
 // restriction R = P^T of the residual r - t (t may be null): coarse DoF q gets its own fine DoF plus half of every
-// edge-node DoF it is an end of. A CSR row of ~13 scattered entries per coarse DoF: FOUR lanes share a row (every fourth entry
-// each, independent loads in flight) and add up with two shuffles -- one lane per row walked its 13 dependent-latency loads alone
+// edge-node DoF it is an end of. A CSR row of ~13 scattered entries per coarse DoF: EIGHT lanes share a row (every eighth entry
+// each, independent loads in flight) and add up with three shuffles -- one lane per row walked its 13 dependent-latency loads alone
 // and took 0.66 ms at config 3, more than an application of the quadratic operator.
+#ifndef MG_RESTRICT_LANES
+#define MG_RESTRICT_LANES 8     // lanes per coarse row: 4 / 8 / 16 -> 316 / 274 / 291 us at config 3 (rocprofv3, same box)
+#endif
 template <int DIM>
 __global__ void __launch_bounds__(256) k_mg_restrict(int64_t nCoarse, const int32_t *__restrict__ fineOf, const int32_t *__restrict__ resPtr,
                                                      const int32_t *__restrict__ resIdx, const double *__restrict__ r,
                                                      const double *__restrict__ t, const uint8_t *__restrict__ coarseMask,
                                                      double *__restrict__ rc, MgGate g) {
     if (mg_closed(g)) return;
-    const int sub = threadIdx.x & 3;
+    const int sub = threadIdx.x & (MG_RESTRICT_LANES - 1);
     const int64_t nq = (nCoarse + 63) / 64 * 64;                 // whole waves take part in the shuffles
-    for (int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 2; q < nq; q += ((int64_t)gridDim.x * 256) >> 2) {
+    for (int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) / MG_RESTRICT_LANES; q < nq; q += ((int64_t)gridDim.x * 256) / MG_RESTRICT_LANES) {
         double acc[DIM];
 #pragma unroll
         for (int c = 0; c < DIM; ++c) acc[c] = 0.0;
         if (q < nCoarse) {
             const int k0 = resPtr[q], k1 = resPtr[q + 1];
-            for (int k = k0 + sub; k < k1; k += 4) {
+            for (int k = k0 + sub; k < k1; k += MG_RESTRICT_LANES) {
                 const int64_t e = resIdx[k];
 #pragma unroll
                 for (int c = 0; c < DIM; ++c) acc[c] += 0.5 * (r[e * DIM + c] - (t ? t[e * DIM + c] : 0.0));
@@ -1278,8 +1281,8 @@ __global__ void __launch_bounds__(256) k_mg_restrict(int64_t nCoarse, const int3
         }
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
-            acc[c] += __shfl_xor(acc[c], 1, 64);
-            acc[c] += __shfl_xor(acc[c], 2, 64);
+#pragma unroll
+            for (int m = 1; m < MG_RESTRICT_LANES; m <<= 1) acc[c] += __shfl_xor(acc[c], m, 64);
         }
         if (q < nCoarse && sub == 0)
 #pragma unroll
@@ -1867,8 +1870,8 @@ void launch_mg_cheb(int dim, int64_t nRows, const double *dinv, const double *ri
 void launch_mg_restrict(int dim, int64_t nCoarse, const int32_t *fineOf, const int32_t *resPtr, const int32_t *resIdx, const double *r, const double *t,
                         const uint8_t *coarseMask, double *rc, const double *scal, int it, const double *stop, hipStream_t s) {
     const MgGate g = mk_gate(scal, it, stop);
-    if (dim == 3) hipLaunchKernelGGL(k_mg_restrict<3>, dim3(grid_for(nCoarse * 4, 4 * g_vecGridCap)), dim3(256), 0, s, nCoarse, fineOf, resPtr, resIdx, r, t, coarseMask, rc, g);
-    else hipLaunchKernelGGL(k_mg_restrict<2>, dim3(grid_for(nCoarse * 4, 4 * g_vecGridCap)), dim3(256), 0, s, nCoarse, fineOf, resPtr, resIdx, r, t, coarseMask, rc, g);
+    if (dim == 3) hipLaunchKernelGGL(k_mg_restrict<3>, dim3(grid_for(nCoarse * MG_RESTRICT_LANES, MG_RESTRICT_LANES * g_vecGridCap)), dim3(256), 0, s, nCoarse, fineOf, resPtr, resIdx, r, t, coarseMask, rc, g);
+    else hipLaunchKernelGGL(k_mg_restrict<2>, dim3(grid_for(nCoarse * MG_RESTRICT_LANES, MG_RESTRICT_LANES * g_vecGridCap)), dim3(256), 0, s, nCoarse, fineOf, resPtr, resIdx, r, t, coarseMask, rc, g);
     CHECK_LAUNCH();
 }
 void launch_mg_prolong_add(int dim, int64_t nFine, const int32_t *parA, const int32_t *parB, const double *xc, const uint8_t *fineMask, double *x,
