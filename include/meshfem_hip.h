@@ -376,8 +376,21 @@ void        mfh_comm_destroy(mfh_comm* comm);
 const char* mfh_comm_describe(const mfh_comm* comm);
 /* in-place sum of n doubles in device memory over the ranks (blocking) */
 mfh_status  mfh_comm_allreduce(mfh_ctx* ctx, mfh_comm* comm, double* devBuf, int64_t n);
-/* ring shift of a known message + an all-reduce with a known sum: checks the transport end to end */
+/* ring shift of a known message + all-reduces with known sums (several rounds when peer transfers are enabled): checks the transport
+ * in use end to end */
 mfh_status  mfh_comm_selftest(mfh_ctx* ctx, mfh_comm* comm);
+/* Direct device-to-device transfers for the ranks of ONE node, layered on an existing communicator (collective; the HIP IPC handles
+ * travel through the communicator's own all-reduce): every rank exports one slab of fine-grained device memory; the halo exchange of
+ * the PCG then writes straight into the neighbours' slabs (stores over xGMI, one release flag per message, two buffers per pair) and
+ * all-reduces of up to 2^21 doubles (the dot products: ONE single-workgroup kernel; the replicated coarse levels) are all-to-all
+ * writes summed in rank order -- no library call and no host code per iteration, bit-identical sums on every rank. Larger
+ * all-reduces and halo widths the staging was not sized for keep using the communicator underneath. The ranks must be separate
+ * processes (several may share a device); needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver only supports dmabuf IPC.
+ * A rank that waits longer than MFH_PEER_TIMEOUT_S (60) seconds for a neighbour gives up and the solve returns MFH_ERR_HIP: the
+ * device is never left spinning. mfh_comm_selftest exercises the path; mfh_comm_disable_peer (collective) returns to the transport
+ * underneath. */
+mfh_status  mfh_comm_enable_peer(mfh_ctx* ctx, mfh_comm* comm);
+mfh_status  mfh_comm_disable_peer(mfh_ctx* ctx, mfh_comm* comm);
 mfh_status  mfh_dist_setup(mfh_ctx* ctx, mfh_comm* comm, int32_t nPeers, const int32_t* peers, const int64_t* sendPtr /* nPeers+1 */,
                            const int32_t* sendNodes, const int64_t* recvPtr /* nPeers+1 */);
 mfh_status  mfh_dist_two_level(mfh_ctx* ctx, int32_t nAgg, const int32_t* aggOfNode, const double* relPos);
@@ -385,6 +398,22 @@ mfh_status  mfh_dist_solve(mfh_ctx* ctx, int32_t nrhs, const double* fOwned, dou
                            mfh_solve_info* info /* nrhs entries, or NULL */);
 /* (K u) on this rank's rows for a field given on its rows (halo entries fetched from the owners) */
 mfh_status  mfh_dist_apply_K(mfh_ctx* ctx, const double* uOwned, double* KuOwned);
+/* What the last mfh_dist_solve did on this rank. transport: what carried the halo exchange (1 RCCL send/recv, 2 peer copies over HIP
+ * IPC, 3 caller callbacks). With option "dist_profile" 1 the first operator applications of a solve are bracketed by HIP events:
+ * exchange_ms (pack done -> halo arrived, communication stream), interior_ms (the element blocks / row chunks that read no halo column),
+ * exposed_wait_ms (how long the compute stream then still waited for the halo: 0 = the exchange is hidden), boundary_ms (the blocks
+ * that read the halo), operator_ms (all of it), averages over profiled_applications. */
+typedef struct mfh_dist_stats {
+    int32_t world, rank, transport, peer_enabled;
+    int64_t halo_nodes_sent, halo_nodes_received, halo_bytes_per_exchange /* sent + received, one right-hand side */;
+    int64_t interior_items, boundary_items;
+    double  exchange_ms, interior_ms, boundary_ms, exposed_wait_ms, operator_ms;
+    int32_t profiled_applications, reserved;
+    int64_t exchanges;                                   /* since mfh_dist_setup */
+    int64_t peer_halo_messages, peer_halo_bytes;         /* through the peer transfers, since they were enabled */
+    int64_t allreduces_small, allreduces_large, fallback_exchanges, fallback_allreduces;
+} mfh_dist_stats;
+mfh_status  mfh_dist_get_stats(mfh_ctx* ctx, mfh_dist_stats* out);
 /* blocking copy helper for callback communicators that stage through the host: kind 0 host->device, 1 device->host,
  * 2 device->device; hipStream NULL = the context's stream */
 mfh_status  mfh_dev_memcpy(mfh_ctx* ctx, void* dst, const void* src, int64_t bytes, int32_t kind, void* hipStream);
@@ -431,6 +460,8 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
  *   (1: cycles of the linear level per application), "mg_eig_margin" (1.1: factor on the power-iteration estimates), "mg_agg_nodes",
  * "asm_packed_codes" (1 default: the device copy of the gather lists is chunk-relative and packed, see k_assemble_gather),
  * "asm_chunk_order" (0 default; 1: the assembly visits the row chunks in the order of the elements they gather from),
+ * "dist_profile" (1: time the halo exchange against the interior work in the first operator applications of every mfh_dist_solve,
+ *   see mfh_dist_get_stats),
  * "symbolic_device", "topology_device", "tl_probe", "tl_host_inverse" (validation variants of setup phases) */
 mfh_status mfh_set_option(mfh_ctx* ctx, const char* key, double value);
 #ifdef __cplusplus

@@ -25,6 +25,21 @@ class SolveInfo(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class DistStats(C.Structure):
+    _fields_ = [("world", C.c_int32), ("rank", C.c_int32), ("transport", C.c_int32), ("peer_enabled", C.c_int32),
+                ("halo_nodes_sent", C.c_int64), ("halo_nodes_received", C.c_int64), ("halo_bytes_per_exchange", C.c_int64),
+                ("interior_items", C.c_int64), ("boundary_items", C.c_int64),
+                ("exchange_ms", C.c_double), ("interior_ms", C.c_double), ("boundary_ms", C.c_double), ("exposed_wait_ms", C.c_double),
+                ("operator_ms", C.c_double), ("profiled_applications", C.c_int32), ("reserved", C.c_int32), ("exchanges", C.c_int64),
+                ("peer_halo_messages", C.c_int64), ("peer_halo_bytes", C.c_int64), ("allreduces_small", C.c_int64),
+                ("allreduces_large", C.c_int64), ("fallback_exchanges", C.c_int64), ("fallback_allreduces", C.c_int64)]
+
+    def as_dict(self):
+        d = {k: getattr(self, k) for k, _ in self._fields_}
+        d["transport_name"] = {0: "none", 1: "RCCL send/recv", 2: "peer copies (HIP IPC)", 3: "caller callbacks"}.get(d["transport"], "?")
+        return d
+
+
 class Timing(C.Structure):
     _fields_ = [("symbolic_ms", C.c_double), ("geometry_ms", C.c_double), ("assemble_ms", C.c_double),
                 ("upload_ms", C.c_double)]
@@ -129,6 +144,9 @@ PROTOTYPES = {
     "mfh_comm_describe": (C.c_char_p, [_P]),
     "mfh_comm_allreduce": (_i32, [_P, _P, _P, _i64]),
     "mfh_comm_selftest": (_i32, [_P, _P]),
+    "mfh_comm_enable_peer": (_i32, [_P, _P]),
+    "mfh_comm_disable_peer": (_i32, [_P, _P]),
+    "mfh_dist_get_stats": (_i32, [_P, _P]),
     "mfh_dist_setup": (_i32, [_P, _P, _i32, _P, _P, _P, _P]),
     "mfh_dist_two_level": (_i32, [_P, _i32, _P, _P]),
     "mfh_dist_solve": (_i32, [_P, _i32, _P, _P, _f64, _i32, C.POINTER(SolveInfo)]),

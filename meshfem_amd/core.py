@@ -585,6 +585,11 @@ class Context:
         self._ck(self.lib.mfh_dist_apply_K(self.h, ptr(u), ptr(out)))
         return out
 
+    def dist_stats(self):
+        st = L.DistStats()
+        self._ck(self.lib.mfh_dist_get_stats(self.h, C.byref(st)))
+        return st.as_dict()
+
     def dev_memcpy(self, dst, src, nbytes, kind, stream=None):
         self._ck(self.lib.mfh_dev_memcpy(self.h, dst, src, int(nbytes), int(kind), stream))
 

@@ -1038,6 +1038,7 @@ void mfh_destroy(mfh_ctx *c) {
     dist_detach(c);
     destroy_multigrid(c);
     for (auto &e : c->dist.ev) if (e) (void)hipEventDestroy(e);
+    for (auto &P : c->dist.prof) for (auto &e : P.ev) if (e) (void)hipEventDestroy(e);
     if (c->dist.commStream && !c->dist.commStreamBorrowed) { (void)hipStreamSynchronize(c->dist.commStream); (void)hipStreamDestroy(c->dist.commStream); }
     if (c->negHost) (void)hipHostFree(c->negHost);
     delete c;   // device buffers are freed while the stream is still alive
@@ -1056,6 +1057,9 @@ mfh_status mfh_set_stream(mfh_ctx *c, void *stream) {
     if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
     c->stream = (hipStream_t)stream;   // nullptr = the legacy default stream
     c->ownStream = false;
+    // the linear level of a multigrid hierarchy is a context of its own that launches on a copy of the parent's stream: drop the hierarchy
+    // (it is rebuilt on the new stream by the next solve that wants it) rather than leave it on a stream that may be gone
+    destroy_multigrid(c);
     MFH_CATCH(c)
 }
 
@@ -1994,6 +1998,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "mf_lane_stride") c->mfLaneStride = std::max(1, (int)value);
     else if (k2 == "mf_reorder") { c->mfReorder = value != 0; c->mfcValid = false; c->mfClusterUnfit = false; }
     else if (k2 == "dist_pcg_variant") c->distPcgVariant = value != 0 ? 1 : 0;
+    else if (k2 == "dist_profile") c->dist.profile = value != 0;
     else if (k2 == "pcg_variant") c->pcgVariant = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k2 == "batch_rhs") c->batchRhs = value != 0;
     else if (k2 == "matrix_free_mode") { c->mfMode = (int)value; c->mfClusterUnfit = false; }

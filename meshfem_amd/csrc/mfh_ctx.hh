@@ -208,6 +208,15 @@ struct mfh_ctx {
         bool multigridAgreed = false;         // every rank asked for MFH_PRECOND_MULTIGRID (agreed in mfh_dist_solve)
         bool anyFixedNonzeroGlobal = false;   // some rank holds a non-zero fixed value (agreed in mfh_dist_solve)
         int transport = 0;            // what carried the last halo exchange: 1 RCCL send/recv, 2 peer copies, 3 caller callbacks
+        int64_t nExchanges = 0;       // halo exchanges since mfh_dist_setup
+        // option "dist_profile": timed events around the first operator applications of a solve. ev[0] compute stream before the pack, ev[1] / ev[2]
+        // communication stream before / after the exchange, ev[3] compute stream after the interior items, ev[4] after the items that read the halo
+        struct Profile { hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; };
+        bool profile = false;
+        std::vector<Profile> prof = std::vector<Profile>(24);
+        int profUsed = 0, profOpen = -1;
+        double exchangeMs = 0, interiorMs = 0, boundaryMs = 0, exposedMs = 0, operatorMs = 0;   // averages of the last profiled solve
+        int profiled = 0;
     } dist;
     int64_t listsGen = 0;             // bumped whenever the element blocks of the cluster operator or the SpMV row chunks are rebuilt
     int aggNodes = 0;                 // option "agg_nodes": target DoFs per aggregate (0 = auto)
@@ -331,6 +340,7 @@ void dist_halo(mfh_ctx *c, double *v, int W);
 void dist_allreduce(mfh_ctx *c, double *dev, int64_t n);
 void dist_setup_child(mfh_ctx *c, mfh_ctx *child, const std::vector<int32_t> &keep);
 void dist_agree(mfh_ctx *c);
+void dist_profile_collect(mfh_ctx *c);
 void refresh_storage_rule(mfh_ctx *c);
 void reset_bcs(mfh_ctx *c);
 void clear_fixed(mfh_ctx *c);

@@ -291,7 +291,7 @@ void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targ
                              DBuf<int32_t> &dAggOfDof, DBuf<double> &dRelPos, DBuf<int32_t> &dAggPtr, DBuf<int32_t> &dDofsByAgg,
                              const double *globalBox = nullptr, int64_t globalCount = 0, bool fullLattice = false);
 void bounding_box_device(int dim, int64_t nDoF, const double *dPos, hipStream_t s, double mn[3], double mx[3]);
-void wrap_positions_device(int64_t n, int dim, const double box[6], hipStream_t s, double *dPos);
+void wrap_positions_device(int64_t n, int dim, const double box[6], hipStream_t s, double *dPos, int skipDims = 0);
 bool spd_inverse_inplace(int64_t n, double *A);
 // transfer lists of the p-multigrid preconditioner on the device (meshes in the library's own numbering, identity DoF map)
 void build_mg_transfer_device(const HostMesh &m, const int32_t *dElemNodes, hipStream_t s, DBuf<int32_t> &parA, DBuf<int32_t> &parB,

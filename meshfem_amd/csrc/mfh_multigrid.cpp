@@ -199,7 +199,7 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
             globalCount += (int64_t)slots[(size_t)r * 7 + 6];
         }
         // periodic images of a DoF sit on opposite faces of the cell: wrapped to the minimal faces they fall into the same bin on every rank
-        if (!c1->dofForNode.empty()) wrap_positions_device(nD, dim, box, s, dDofPos.p);
+        if (!c1->dofForNode.empty()) wrap_positions_device(nD, dim, box, s, dDofPos.p, c->periodicIgnoreDims);
     }
     auto sum_over_ranks = [&](double v) {
         if (!distributed) return v;

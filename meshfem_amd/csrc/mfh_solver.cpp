@@ -12,6 +12,7 @@
 // others follow once the halo has arrived. Communication goes through an mfh_comm: RCCL (looked up with dlopen, so that
 // the library links against no particular ROCm communication stack) or two caller-supplied callbacks.
 #include "mfh_ctx.hh"
+#include "mfh_comm.hh"
 #include <dlfcn.h>
 
 // ------------------------------------------------------------------------------------------------ communicator
@@ -80,20 +81,6 @@ constexpr int kNcclFloat64 = 8, kNcclSum = 0;   // rccl.h: ncclDataType_t / nccl
 
 }   // namespace
 
-struct mfh_comm {
-    int rank = 0, world = 1;
-    // callbacks
-    void *user = nullptr;
-    mfh_allreduce_fn allreduce = nullptr;
-    mfh_exchange_fn exchange = nullptr;
-    // RCCL
-    void *nccl = nullptr;
-    int device = -1;
-    std::string desc;
-    std::vector<mfh_ctx *> users;   // contexts whose mfh_dist_setup named this communicator (detached when it is destroyed)
-    std::mutex mu;
-};
-
 namespace {
 
 void rccl_check(int rc, const char *what) {
@@ -102,13 +89,17 @@ void rccl_check(int rc, const char *what) {
     throw Error(MFH_ERR_HIP, std::string(what) + ": " + (a.errorString ? a.errorString(rc) : "RCCL error " + std::to_string(rc)));
 }
 
-void comm_allreduce(mfh_comm *cm, double *dev, int64_t n, hipStream_t s) {
+}   // namespace
+
+namespace mfh {
+// the transport underneath: RCCL or the caller's callbacks
+void base_allreduce(mfh_comm *cm, double *dev, int64_t n, hipStream_t s) {
     if (!cm || cm->world <= 1 || n == 0) return;
     if (cm->nccl) rccl_check(rccl().allReduce(dev, dev, (size_t)n, kNcclFloat64, kNcclSum, cm->nccl, s), "ncclAllReduce");
     else if (cm->allreduce(cm->user, dev, n, (void *)s) != MFH_OK) throw Error(MFH_ERR_HIP, "communicator callback allreduce_sum failed");
 }
 
-void comm_exchange(mfh_comm *cm, int nPeers, const int32_t *peers, const double *const *sendBufs, const int64_t *sendCounts,
+void base_exchange(mfh_comm *cm, int nPeers, const int32_t *peers, const double *const *sendBufs, const int64_t *sendCounts,
                    double *const *recvBufs, const int64_t *recvCounts, hipStream_t s) {
     if (!cm || cm->world <= 1 || nPeers == 0) return;
     if (cm->nccl) {
@@ -121,6 +112,32 @@ void comm_exchange(mfh_comm *cm, int nPeers, const int32_t *peers, const double 
         rccl_check(a.groupEnd(), "ncclGroupEnd");
     } else if (cm->exchange(cm->user, nPeers, peers, sendBufs, sendCounts, recvBufs, recvCounts, (void *)s) != MFH_OK)
         throw Error(MFH_ERR_HIP, "communicator callback exchange failed");
+}
+}   // namespace mfh
+
+namespace {
+
+// what the solver calls: direct device-to-device transfers (mfh_peer.hip) when the communicator has them and the message fits, the
+// transport underneath otherwise. Both decisions come out the same on every rank (peer_can_*).
+void comm_allreduce(mfh_comm *cm, double *dev, int64_t n, hipStream_t s) {
+    if (!cm || cm->world <= 1 || n == 0) return;
+    if (peer_can_allreduce(cm, n)) peer_allreduce(cm, dev, n, s);
+    else { base_allreduce(cm, dev, n, s); if (cm->peer.enabled) ++cm->peer.fallbackAllreduces; }
+}
+
+void comm_exchange(mfh_comm *cm, int nPeers, const int32_t *peers, const double *const *sendBufs, const int64_t *sendCounts,
+                   double *const *recvBufs, const int64_t *recvCounts, hipStream_t s, int *transport = nullptr, bool widthReserved = true) {
+    if (!cm || cm->world <= 1 || nPeers == 0) return;
+    // widthReserved: the doubles per block row do not exceed what mfh_dist_setup sized the staging for (2 bs) -- the same on every rank,
+    // unlike the byte counts of a particular pair
+    if (widthReserved && peer_can_exchange(cm, nPeers, peers, sendCounts, recvCounts)) {
+        peer_exchange(cm, nPeers, peers, sendBufs, sendCounts, recvBufs, recvCounts, s);
+        if (transport) *transport = 2;
+    } else {
+        base_exchange(cm, nPeers, peers, sendBufs, sendCounts, recvBufs, recvCounts, s);
+        if (cm->peer.enabled) ++cm->peer.fallbackExchanges;
+        if (transport) *transport = cm->nccl ? 1 : 3;
+    }
 }
 
 }   // namespace
@@ -176,12 +193,36 @@ struct DistLink {   // stream / event plumbing of one solve on a partitioned con
             rb[k] = v + (nRows + D.recvPtr[k]) * W;
             rc[k] = (D.recvPtr[k + 1] - D.recvPtr[k]) * W;
         }
-        comm_exchange(cm, np, D.peers.data(), sb.data(), sc.data(), rb.data(), rc.data(), cs);
+        Dist::Profile *pf = profile_slot();
+        if (pf) MFH_HIP(hipEventRecord(pf->ev[1], cs));
+        comm_exchange(cm, np, D.peers.data(), sb.data(), sc.data(), rb.data(), rc.data(), cs, &D.transport, W <= 2 * c->bs());
         MFH_HIP(hipEventRecord(D.ev[1], cs));
+        if (pf) MFH_HIP(hipEventRecord(pf->ev[2], cs));
+        ++D.nExchanges;
     }
     void halo_end() {
         if (active) MFH_HIP(hipStreamWaitEvent(s, c->dist.ev[1], 0));
     }
+    // option "dist_profile": the first applications of the operator in a solve are bracketed by timed events (read at the end of the solve)
+    using Dist = mfh_ctx::Dist;
+    Dist::Profile *profile_slot() {
+        auto &D = c->dist;
+        if (!D.profile || D.profOpen < 0) return nullptr;
+        return &D.prof[(size_t)D.profOpen];
+    }
+    void profile_begin() {
+        auto &D = c->dist;
+        D.profOpen = -1;
+        if (!active || !D.profile || D.profUsed >= (int)D.prof.size()) return;
+        D.profOpen = D.profUsed++;
+        auto &P = D.prof[(size_t)D.profOpen];
+        if (!P.ev[0]) for (auto &e : P.ev) MFH_HIP(hipEventCreate(&e));
+        MFH_HIP(hipEventRecord(P.ev[0], s));
+    }
+    void profile_mark(int k) {
+        if (Dist::Profile *pf = profile_slot()) MFH_HIP(hipEventRecord(pf->ev[k], s));
+    }
+    void profile_end() { profile_mark(4); c->dist.profOpen = -1; }
     // in-place sum over the ranks, ordered after everything enqueued on the compute stream so far
     void allreduce(double *dev, int64_t n) {
         if (!active) return;
@@ -233,10 +274,13 @@ void apply_op_nr(mfh_ctx *c, DistLink &L, int NR, double *x, double *y, bool mas
         if ((size_t)std::max<int64_t>(c->mfc.nIface, 1) * W > c->mfcDev.ifaceBuf.n) throw Error(MFH_ERR_STATE, "interface buffer too small for this batch");
         if (L.active) {
             ensure_overlap_lists(c, true);
+            L.profile_begin();
             L.halo_begin(x, W);
             k::launch_mf_cluster_nr(a, NR, x, y, dotOut, scal, it, ctl, c->dist.opList.p, c->dist.nInterior, s);
+            L.profile_mark(3);
             L.halo_end();
             k::launch_mf_cluster_nr(a, NR, x, y, dotOut, scal, it, ctl, c->dist.opList.p + c->dist.nInterior, c->dist.nBoundary, s);
+            L.profile_end();
         } else
             k::launch_mf_cluster_nr(a, NR, x, y, dotOut, scal, it, ctl, nullptr, c->mfc.nBlocks, s);
         k::launch_mf_rows_nr(a, NR, x, y, dotOut, scal, it, ctl, s);
@@ -246,10 +290,13 @@ void apply_op_nr(mfh_ctx *c, DistLink &L, int NR, double *x, double *y, bool mas
         a.pcgMode = pcgMode;
         if (L.active) {
             ensure_overlap_lists(c, false);
+            L.profile_begin();
             L.halo_begin(x, W);
             k::launch_spmv_nr(a, NR, x, y, dotOut, scal, it, ctl, c->dist.opList.p, c->dist.nInterior, s);
+            L.profile_mark(3);
             L.halo_end();
             k::launch_spmv_nr(a, NR, x, y, dotOut, scal, it, ctl, c->dist.opList.p + c->dist.nInterior, c->dist.nBoundary, s);
+            L.profile_end();
         } else
             k::launch_spmv_nr(a, NR, x, y, dotOut, scal, it, ctl, nullptr, a.nChunk, s);
     }
@@ -327,6 +374,28 @@ void dist_setup_child(mfh_ctx *c, mfh_ctx *child, const std::vector<int32_t> &ke
     E.comm = cm;
     E.listKind = 0;
     E.sendBufW = std::max(E.sendBufW, child->bs());
+}
+
+// averages of the timed events of option "dist_profile" (the stream is idle: the solve has downloaded its result)
+void dist_profile_collect(mfh_ctx *c) {
+    auto &D = c->dist;
+    D.profiled = 0;
+    D.exchangeMs = D.interiorMs = D.boundaryMs = D.exposedMs = D.operatorMs = 0;
+    if (!D.profile || D.profUsed == 0) return;
+    MFH_HIP(hipStreamSynchronize(c->stream));
+    if (D.commStream) MFH_HIP(hipStreamSynchronize(D.commStream));
+    // the first applications of a solve include one-time work (buffers, lists): skip two when there are enough
+    const int first = D.profUsed > 6 ? 2 : 0;
+    for (int q = first; q < D.profUsed; ++q) {
+        auto &P = D.prof[(size_t)q];
+        float ex = 0, t2 = 0, t3 = 0, t4 = 0;
+        if (hipEventElapsedTime(&ex, P.ev[1], P.ev[2]) != hipSuccess || hipEventElapsedTime(&t2, P.ev[0], P.ev[2]) != hipSuccess ||
+            hipEventElapsedTime(&t3, P.ev[0], P.ev[3]) != hipSuccess || hipEventElapsedTime(&t4, P.ev[0], P.ev[4]) != hipSuccess) { (void)hipGetLastError(); continue; }
+        D.exchangeMs += ex; D.interiorMs += t3; D.boundaryMs += t4 - std::max(t2, t3); D.exposedMs += std::max(0.0f, t2 - t3); D.operatorMs += t4;
+        ++D.profiled;
+    }
+    if (D.profiled) { const double f = 1.0 / D.profiled; D.exchangeMs *= f; D.interiorMs *= f; D.boundaryMs *= f; D.exposedMs *= f; D.operatorMs *= f; }
+    D.profUsed = 0;
 }
 
 bool cg_operator_supported(mfh_ctx *c) {
@@ -755,7 +824,8 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
 // nrhs right-hand sides in batches of the sizes the kernels are built for (3D: 6, 2, 1; 2D: 3, 1)
 void solve_many(mfh_ctx *c, int nrhs, const double *f, double *u, int64_t stride, double rtol, int maxit, mfh_solve_info *infos) {
     const int d = c->bs();
-    const bool batched = c->pcgVariant != 0 && c->batchRhs && cg_operator_supported(c);
+    // the V-cycle lives in the one-right-hand-side loop: with the multigrid preconditioner batches would silently run block-Jacobi
+    const bool batched = c->pcgVariant != 0 && c->batchRhs && c->precond != MFH_PRECOND_MULTIGRID && cg_operator_supported(c);
     int k0 = 0;
     while (k0 < nrhs) {
         int nb = 1;
@@ -813,11 +883,62 @@ void mfh_comm_destroy(mfh_comm *cm) {
     if (!cm) return;
     for (mfh_ctx *c : cm->users) { c->dist.comm = nullptr; c->dist.listKind = 0; }   // no context keeps a dangling pointer
     cm->users.clear();
+    peer_release(cm);
     if (cm->nccl && rccl().ok) (void)rccl().commDestroy(cm->nccl);
     delete cm;
 }
 
-const char *mfh_comm_describe(const mfh_comm *cm) { return cm ? cm->desc.c_str() : ""; }
+const char *mfh_comm_describe(const mfh_comm *cm) { return cm ? ((cm->peer.enabled && !cm->descFull.empty()) ? cm->descFull.c_str() : cm->desc.c_str()) : ""; }
+
+// Direct device-to-device transfers on top of an existing communicator (mfh_peer.hip). Collective; the IPC handles travel through the
+// communicator's own all-reduce. Fails (and leaves the communicator as it was) when the ranks are not separate processes of one node.
+mfh_status mfh_comm_enable_peer(mfh_ctx *c, mfh_comm *cm) {
+    MFH_TRY(c)
+    require(c && cm, MFH_ERR_INVALID, "bad arguments");
+    require_device(c);
+    MFH_HIP(hipSetDevice(c->device));
+    try { peer_enable(cm, c->device, c->stream); }
+    catch (const Error &e) { cm->peer.why = e.what(); throw; }
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_comm_disable_peer(mfh_ctx *c, mfh_comm *cm) {
+    MFH_TRY(c)
+    require(c && cm, MFH_ERR_INVALID, "bad arguments");
+    if (cm->peer.enabled) {
+        MFH_HIP(hipSetDevice(c->device));
+        MFH_HIP(hipDeviceSynchronize());
+        // the other ranks may still be reading this rank's flags: leave together
+        double one = 1.0;
+        DBuf<double> d;
+        d.upload(&one, 1, c->stream);
+        base_allreduce(cm, d.p, 1, c->stream);
+        MFH_HIP(hipStreamSynchronize(c->stream));
+        peer_release(cm);
+    }
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_dist_get_stats(mfh_ctx *c, mfh_dist_stats *out) {
+    MFH_TRY(c)
+    require(c && out, MFH_ERR_INVALID, "null argument");
+    require(c->dist.comm, MFH_ERR_STATE, "mfh_dist_setup has not run");
+    auto &D = c->dist;
+    mfh_comm *cm = D.comm;
+    mfh_dist_stats st{};
+    st.world = cm->world; st.rank = cm->rank; st.transport = D.transport; st.peer_enabled = cm->peer.enabled ? 1 : 0;
+    st.halo_nodes_sent = D.sendPtr.back(); st.halo_nodes_received = D.recvPtr.back();
+    st.halo_bytes_per_exchange = (D.sendPtr.back() + D.recvPtr.back()) * (int64_t)c->bs() * (int64_t)sizeof(double);
+    st.interior_items = D.nInterior; st.boundary_items = D.nBoundary;
+    st.exchange_ms = D.exchangeMs; st.interior_ms = D.interiorMs; st.boundary_ms = D.boundaryMs; st.exposed_wait_ms = D.exposedMs; st.operator_ms = D.operatorMs;
+    st.profiled_applications = D.profiled;
+    st.exchanges = D.nExchanges;
+    st.peer_halo_messages = cm->peer.haloMessages; st.peer_halo_bytes = cm->peer.haloBytes;
+    st.allreduces_small = cm->peer.smallAllreduces; st.allreduces_large = cm->peer.largeAllreduces;
+    st.fallback_exchanges = cm->peer.fallbackExchanges; st.fallback_allreduces = cm->peer.fallbackAllreduces;
+    *out = st;
+    MFH_CATCH(c)
+}
 
 mfh_status mfh_comm_allreduce(mfh_ctx *c, mfh_comm *cm, double *dev, int64_t n) {
     MFH_TRY(c)
@@ -826,6 +947,7 @@ mfh_status mfh_comm_allreduce(mfh_ctx *c, mfh_comm *cm, double *dev, int64_t n) 
     MFH_HIP(hipSetDevice(c->device));
     comm_allreduce(cm, dev, n, c->stream);
     MFH_HIP(hipStreamSynchronize(c->stream));
+    peer_check(cm, c->stream);
     MFH_CATCH(c)
 }
 
@@ -835,42 +957,54 @@ mfh_status mfh_comm_selftest(mfh_ctx *c, mfh_comm *cm) {
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    // all-reduce: every rank contributes rank + 1; point-to-point: a ring shift of a 1024-double message (to itself at world 1)
-    const int n = 1024;
-    DBuf<double> a, b;
-    a.alloc(n); b.alloc(n);
-    std::vector<double> h((size_t)n);
-    for (int i = 0; i < n; ++i) h[i] = (cm->rank + 1) * 1000.0 + i;
-    MFH_HIP(hipMemcpyAsync(a.p, h.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
-    b.zero(s);
+    // point-to-point: a ring shift of a 1024-double message (to itself at world 1); all-reduce: every rank contributes rank + 1 (and a
+    // longer vector). Several rounds with different contents: the peer transfers alternate between two staging buffers.
+    const int n = 1024, nLong = 3000;
+    DBuf<double> a, b, v;
+    a.alloc(n); b.alloc(n); v.alloc(nLong);
+    std::vector<double> h((size_t)n), got((size_t)n), hv((size_t)nLong);
     const int32_t to = (cm->rank + 1) % cm->world, from = (cm->rank + cm->world - 1) % cm->world;
-    if (cm->nccl) {
-        RcclApi &r = rccl();
-        rccl_check(r.groupStart(), "ncclGroupStart");
-        rccl_check(r.send(a.p, n, kNcclFloat64, to, cm->nccl, s), "ncclSend");
-        rccl_check(r.recv(b.p, n, kNcclFloat64, from, cm->nccl, s), "ncclRecv");
-        rccl_check(r.groupEnd(), "ncclGroupEnd");
-    } else if (cm->world > 1) {
-        // with callbacks the exchange is grouped per peer: send to `to`, receive from `from` (the same peer at world 2)
-        const double *sb[2] = {a.p, nullptr};
-        double *rb[2] = {nullptr, b.p};
-        int32_t peers[2] = {to, from};
-        int64_t sc[2] = {n, 0}, rc[2] = {0, n};
-        if (to == from) { rb[0] = b.p; rc[0] = n; comm_exchange(cm, 1, peers, sb, sc, rb, rc, s); }
-        else comm_exchange(cm, 2, peers, sb, sc, rb, rc, s);
-    } else
-        MFH_HIP(hipMemcpyAsync(b.p, a.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
-    std::vector<double> got((size_t)n);
-    MFH_HIP(hipMemcpyAsync(got.data(), b.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
-    MFH_HIP(hipStreamSynchronize(s));
-    for (int i = 0; i < n; ++i)
-        if (got[i] != (from + 1) * 1000.0 + i) throw Error(MFH_ERR_HIP, "communicator self-test: point-to-point message corrupted");
-    double one[2] = {cm->rank + 1.0, 1.0};
-    MFH_HIP(hipMemcpyAsync(a.p, one, 2 * sizeof(double), hipMemcpyHostToDevice, s));
-    comm_allreduce(cm, a.p, 2, s);
-    MFH_HIP(hipMemcpyAsync(one, a.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
-    MFH_HIP(hipStreamSynchronize(s));
-    if (one[0] != cm->world * (cm->world + 1) / 2.0 || one[1] != (double)cm->world) throw Error(MFH_ERR_HIP, "communicator self-test: all-reduce gives a wrong sum");
+    if (cm->peer.enabled) peer_reserve(cm, n, 1, (1u << to) | (1u << from), s);
+    const int rounds = cm->peer.enabled ? 6 : 1;
+    for (int round = 0; round < rounds; ++round) {
+        for (int i = 0; i < n; ++i) h[i] = (cm->rank + 1) * 1000.0 + i + 7.0 * round;
+        MFH_HIP(hipMemcpyAsync(a.p, h.data(), n * sizeof(double), hipMemcpyHostToDevice, s));
+        b.zero(s);
+        if (cm->world > 1) {
+            // the exchange is grouped per peer: send to `to`, receive from `from` (the same peer at world 2)
+            const double *sb[2] = {a.p, nullptr};
+            double *rb[2] = {nullptr, b.p};
+            int32_t peers[2] = {to, from};
+            int64_t sc[2] = {n, 0}, rc[2] = {0, n};
+            if (to == from) { rb[0] = b.p; rc[0] = n; comm_exchange(cm, 1, peers, sb, sc, rb, rc, s); }
+            else comm_exchange(cm, 2, peers, sb, sc, rb, rc, s);
+        } else if (cm->nccl) {
+            RcclApi &r = rccl();
+            rccl_check(r.groupStart(), "ncclGroupStart");
+            rccl_check(r.send(a.p, n, kNcclFloat64, to, cm->nccl, s), "ncclSend");
+            rccl_check(r.recv(b.p, n, kNcclFloat64, from, cm->nccl, s), "ncclRecv");
+            rccl_check(r.groupEnd(), "ncclGroupEnd");
+        } else
+            MFH_HIP(hipMemcpyAsync(b.p, a.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        MFH_HIP(hipMemcpyAsync(got.data(), b.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
+        MFH_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < n; ++i)
+            if (got[i] != (from + 1) * 1000.0 + i + 7.0 * round) throw Error(MFH_ERR_HIP, "communicator self-test: point-to-point message corrupted");
+        double one[2] = {cm->rank + 1.0 + round, 1.0};
+        MFH_HIP(hipMemcpyAsync(a.p, one, 2 * sizeof(double), hipMemcpyHostToDevice, s));
+        comm_allreduce(cm, a.p, 2, s);
+        MFH_HIP(hipMemcpyAsync(one, a.p, 2 * sizeof(double), hipMemcpyDeviceToHost, s));
+        for (int i = 0; i < nLong; ++i) hv[i] = (cm->rank + 1.0) * (i % 17) + round;
+        MFH_HIP(hipMemcpyAsync(v.p, hv.data(), nLong * sizeof(double), hipMemcpyHostToDevice, s));
+        comm_allreduce(cm, v.p, nLong, s);
+        MFH_HIP(hipMemcpyAsync(hv.data(), v.p, nLong * sizeof(double), hipMemcpyDeviceToHost, s));
+        MFH_HIP(hipStreamSynchronize(s));
+        const double tri = cm->world * (cm->world + 1) / 2.0;
+        if (one[0] != tri + (double)round * cm->world || one[1] != (double)cm->world) throw Error(MFH_ERR_HIP, "communicator self-test: all-reduce gives a wrong sum");
+        for (int i = 0; i < nLong; ++i)
+            if (hv[i] != tri * (i % 17) + (double)round * cm->world) throw Error(MFH_ERR_HIP, "communicator self-test: all-reduce of a vector gives a wrong sum");
+    }
+    peer_check(cm, s);
     MFH_CATCH(c)
 }
 
@@ -910,6 +1044,16 @@ mfh_status mfh_dist_setup(mfh_ctx *c, mfh_comm *cm, int32_t nPeers, const int32_
     D.comm = cm;
     D.listKind = 0;
     D.sendBufW = std::max(D.sendBufW, c->bs());
+    D.nExchanges = 0;
+    if (cm->peer.enabled) {          // collective: every rank of the communicator is in mfh_dist_setup
+        int64_t maxPair = 0;
+        uint32_t mask = 0;
+        for (int k = 0; k < nPeers; ++k) {
+            maxPair = std::max(maxPair, std::max(sendPtr[k + 1] - sendPtr[k], recvPtr[k + 1] - recvPtr[k]));
+            mask |= 1u << peers[k];
+        }
+        peer_reserve(cm, maxPair, 2 * c->bs(), mask, c->stream);
+    }
     c->mg.valid = false;             // a multigrid hierarchy holds exchange lists derived from the previous ones
     MFH_CATCH(c)
 }
@@ -941,6 +1085,7 @@ mfh_status mfh_dist_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, 
     // local error in the preparation, the operator in use, the lift of non-zero fixed values and the preconditioner. One
     // all-reduce of six flags; a rank that cannot run the cluster operator takes every rank to the assembled SpMV.
     dist_agree(c);
+    c->dist.profUsed = 0;
     // MFH_PRECOND_MULTIGRID on every rank: the V-cycle with partitioned nodal levels and replicated aggregate levels (collective setup;
     // one right-hand side at a time in the classic loop)
     bool useMG = false;
@@ -961,6 +1106,8 @@ mfh_status mfh_dist_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, 
     }
     bool all = true;
     for (int k2 = 0; k2 < nrhs; ++k2) { all &= infos[k2].converged != 0; if (info) info[k2] = infos[k2]; }
+    dist_profile_collect(c);
+    peer_check(c->dist.comm, c->stream);
     if (!all) throw Error(MFH_ERR_NOT_CONVERGED, "PCG did not reach the requested tolerance within maxit iterations");
     MFH_CATCH(c)
 }

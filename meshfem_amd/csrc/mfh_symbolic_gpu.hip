@@ -888,19 +888,20 @@ __global__ void __launch_bounds__(256) k_dof_pos(int64_t nDoF, int dim, const in
 
 namespace {
 __global__ void __launch_bounds__(256) k_wrap_positions(int64_t n, int dim, double lx, double ly, double lz, double hx, double hy, double hz, double eps,
-                                                        double *__restrict__ pos) {
+                                                        int skipDims, double *__restrict__ pos) {
     const double lo[3] = {lx, ly, lz}, hi[3] = {hx, hy, hz};
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (int64_t)gridDim.x * 256)
         for (int a = 0; a < dim; ++a)
-            if (pos[q * dim + a] >= hi[a] - eps) pos[q * dim + a] = lo[a];
+            if (!((skipDims >> a) & 1) && pos[q * dim + a] >= hi[a] - eps) pos[q * dim + a] = lo[a];
 }
 } // namespace
 // positions on the maximal faces of the box go to the minimal ones: every periodic image of a point then sits at the same place, whichever image
 // a rank happens to hold (aggregates of a periodic cell on a partitioned context)
-void wrap_positions_device(int64_t n, int dim, const double box[6], hipStream_t s, double *dPos) {
+// (skipDims: bit a set = axis a is not periodic -- option "periodic_ignore_dims" -- and keeps its maximal face)
+void wrap_positions_device(int64_t n, int dim, const double box[6], hipStream_t s, double *dPos, int skipDims) {
     double ext = 0;
     for (int a = 0; a < dim; ++a) ext = std::max(ext, box[3 + a] - box[a]);
-    hipLaunchKernelGGL(k_wrap_positions, dim3(grid_of(n)), dim3(256), 0, s, n, dim, box[0], box[1], box[2], box[3], box[4], box[5], 1e-9 * ext, dPos);
+    hipLaunchKernelGGL(k_wrap_positions, dim3(grid_of(n)), dim3(256), 0, s, n, dim, box[0], box[1], box[2], box[3], box[4], box[5], 1e-9 * ext, skipDims, dPos);
     RP(hipGetLastError());
 }
 // position of a DoF = position of its first node (periodic DoF maps)

@@ -256,6 +256,7 @@ class Comm:
 
     def __init__(self, ctx, handle, kind, keep=()):
         self.ctx, self.h, self.kind, self._keep = ctx, handle, kind, keep
+        self.peer = False
 
     @classmethod
     def rccl(cls, ctx, rank, world, group=None):
@@ -328,6 +329,16 @@ class Comm:
 
     def describe(self):
         return self.ctx.lib.mfh_comm_describe(self.h).decode()
+
+    def enable_peer(self):
+        """Direct device-to-device transfers (HIP IPC) on top of this communicator; collective. Raises if the ranks cannot map each
+        other's memory (the communicator then stays as it was)."""
+        self.ctx._ck(self.ctx.lib.mfh_comm_enable_peer(self.ctx.h, self.h))
+        self.peer = True
+
+    def disable_peer(self):
+        self.ctx._ck(self.ctx.lib.mfh_comm_disable_peer(self.ctx.h, self.h))
+        self.peer = False
 
     def selftest(self):
         self.ctx._ck(self.ctx.lib.mfh_comm_selftest(self.ctx.h, self.h))
