@@ -48,9 +48,13 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=0, help="hexes per side (0 = 60: configs[2] / the per-rank volume of the weak-scaling run; "
                                                         "119 with --scaling strong: configs[4])")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("MFH_BENCH_SCALING", "weak"),
-                    help="N > 1: weak = ~60^3 hexes per rank (N = 8: the 120^3 cube); strong = ONE grid^3 cube (default 119^3 = configs[4], "
-                         "40.4 M P2 tets) dealt out over the N ranks, N = 1 runs it in one context (north_star: >= 6x at 8 GPUs)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=os.environ.get("MFH_BENCH_SCALING") or None,
+                    help="default: N = 1 runs configs[2] (60^3) and adds the 119^3 cube in one context as `strong_scaling_n1`; N > 1 runs the "
+                         "STRONG-scaling line -- ONE grid^3 cube (119^3 = configs[4], 40.4 M P2 tets) dealt out over the N ranks (north_star: "
+                         ">= 6x at 8 GPUs) -- and adds the weak-scaling run (~60^3 hexes per rank; N = 8: the 120^3 cube) as `weak_scaling`. "
+                         "--scaling weak: the weak line alone; --scaling strong with N = 1: the 119^3 cube as the line itself")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the secondary weak-scaling object")
+    ap.add_argument("--no-strong-n1", action="store_true", help="N = 1: skip the strong_scaling_n1 object (the 119^3 cube in one context)")
     ap.add_argument("--deg", type=int, default=2)
     ap.add_argument("--rtol", type=float, default=1e-8)
     ap.add_argument("--maxit", type=int, default=20000)
@@ -65,7 +69,7 @@ def parse():
                     help="N > visible GPUs: share the GPUs (ranks on one GPU talk through gloo, staged through the host)")
     a = ap.parse_args()
     if a.grid <= 0:
-        a.grid = 119 if a.scaling == "strong" else 60
+        a.grid = 119 if (a.scaling == "strong" or (a.scaling is None and a.gpus > 1)) else 60
     return a
 
 
@@ -307,7 +311,7 @@ def run_single(args):
         roof["measured_triad_GBs"] = hbm_measured["triad_GBs"]
         roof["traffic_frac_of_measured_triad"] = roof["traffic"] / hbm_measured["triad_GBs"]
     out = dict(metric="stiffness_assembly_elements_per_s", value=value, unit="elements/s", n_gpus=1, steps=args.steps,
-               warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, scaling=args.scaling, vs_baseline=None,
+               warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, scaling=args.scaling or "weak", vs_baseline=None,
                dtype="f64", data="synthetic",
                config=dict(workload="%s: %d^3 grid -> %d P%d tets, isotropic E=200 nu=0.35, Dirichlet x=0, traction x=1"
                                     % (("configs[4] on one GPU" if n == 119 else "the %d^3 cube of the strong-scaling run on one GPU" % n) + " (the N = 1 point of the strong-scaling curve)"
@@ -494,9 +498,70 @@ def run_single(args):
                 del V2, T2
             except M.MeshFEMHipError as e:
                 out["variants"]["orderings"][mode] = str(e)
+    if not strong and not args.no_strong_n1 and deg == 2:
+        # the N = 1 point of the strong-scaling curve the N > 1 runs measure by default (configs[4]'s 119^3 cube in ONE context), so that
+        # one driver pass over N = 1, 2, 4, 8 holds the whole curve
+        try:
+            c.close()
+        except Exception:   # noqa: BLE001 -- already closed by the variants above
+            pass
+        try:
+            out["strong_scaling_n1"] = strong_n1(args, torch)
+        except Exception as e:   # noqa: BLE001 -- the line above is complete
+            out["strong_scaling_n1"] = dict(error="%s: %s" % (type(e).__name__, e))
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_with_solve(args)
     print(json.dumps(out), flush=True)
+
+
+def strong_n1(args, torch, n=119):
+    """BASELINE configs[4]'s cube on one GPU: the same timed step as the line itself (embedding + blocks + assembly), the one-shot cost
+    of the first assembly, and the time to solution of the multigrid PCG -- what `bench.py --gpus N` (N > 1) reports for the cube dealt
+    out over N ranks."""
+    import gc
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    gc.collect(); torch.cuda.empty_cache()
+    free, total = torch.cuda.mem_get_info(0)
+    if free < 200e9:
+        return dict(skipped="needs 200 GB of free device memory, %.0f GB free" % (free / 1e9))
+    deg = args.deg
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    T = np.ascontiguousarray(T, dtype=np.int32)
+    c = M.Context(0)
+    t0 = time.time(); c.mesh_build(T, V, deg); t_build = time.time() - t0
+    del V, T
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+    c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    t0 = time.time(); c.symbolic(False); t_sym = time.time() - t0
+    c.set_option("reembed", 1)
+    nE = c.n_elem
+    t0 = time.time(); c.assemble(); c.dev_sync(); t_first = time.time() - t0
+    steps = max(3, min(args.steps, 5))
+    c.assemble(); c.dev_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        c.assemble()
+    c.dev_sync()
+    dt = (time.perf_counter() - t0) / steps
+    k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, 3)
+    res = dict(workload="configs[4]: %d^3 grid -> %d P%d tets in ONE context" % (n, nE, deg), elements=nE, dof=3 * c.n_dof,
+               value=nE / dt, unit="elements/s", ms_per_step=dt * 1e3, steps=steps, kernel_ms=k_ms,
+               setup=dict(femmesh_build_s=t_build, symbolic_s=t_sym, first_assemble_call_s=t_first,
+                          first_assembly_ms=(t_build + t_sym + t_first) * 1e3, first_assembly_elements_per_s=nE / (t_build + t_sym + t_first)))
+    if not args.no_solve:
+        c.set_preconditioner(M.PRECOND_MULTIGRID)
+        t0 = time.time()
+        u = c.sim_solve(rtol=args.rtol, maxit=min(args.maxit, 2000))
+        i3, g3 = dict(c.last_info), c.multigrid_info()
+        res["pcg_multigrid"] = dict(iterations=i3["iterations"], converged=bool(i3["converged"]), true_rel_residual=i3["true_rel_residual"],
+                                    solve_s=i3["solve_ms"] * 1e-3, ms_per_iteration=i3["solve_ms"] / max(1, i3["iterations"]),
+                                    hierarchy_setup_ms=g3["setup_ms"], wall_s_with_setup=time.time() - t0, max_abs_u=float(np.abs(u).max()))
+    free2, _ = torch.cuda.mem_get_info(0)
+    res["memory"] = dict(device_used_GB=(total - free2) / 1e9)
+    c.close()
+    return res
 
 
 def run_multi(args):
@@ -517,7 +582,7 @@ def run_multi(args):
         dist.init_process_group("gloo", rank=rank, world_size=world)
     else:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
-    res = D.bench_slabs(args, rank, world, device, shared_gpus=shared)
+    res = D.bench_multi(args, rank, world, device, shared_gpus=shared)
     dist.barrier()
     dist.destroy_process_group()
     # RCCL writes its version banner through C stdio, which is flushed late when stdout is a pipe:

@@ -460,6 +460,14 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
  *   (1: cycles of the linear level per application), "mg_eig_margin" (1.1: factor on the power-iteration estimates), "mg_agg_nodes",
  * "asm_packed_codes" (1 default: the device copy of the gather lists is chunk-relative and packed, see k_assemble_gather),
  * "asm_chunk_order" (0 default; 1: the assembly visits the row chunks in the order of the elements they gather from),
+ * "deterministic" (1: run-to-run BIT-REPRODUCIBLE assembly, operator and PCG -- the counterpart of the reference's serial, reproducible
+ *   scatter into the triplet list (LinearElasticity.hh:1454-1455; SparseMatrices.hh:288,319-324 switches its one unordered loop off). The
+ *   default kernels accumulate with LDS / global atomics in the order the waves happen to arrive, so the last bits of K, K x and the dot
+ *   products differ between two runs; with the option the waves of a workgroup add in wave order (assembly, interface rows of the
+ *   operator) or into accumulators of their own summed in wave order (element blocks of the operator), every dot product goes through a
+ *   fixed two-stage tree, and the PCG runs the classic loop. Two assemblies give identical bits, two solves identical displacements.
+ *   Preconditioners: block-Jacobi / Jacobi / none (the coarse levels of the two-level and multigrid preconditioners are built with
+ *   unordered atomics: MFH_ERR_UNSUPPORTED); the global-atomic assembly variant is refused. Measured cost: bench.py variants.deterministic),
  * "dist_profile" (1: time the halo exchange against the interior work in the first operator applications of every mfh_dist_solve,
  *   see mfh_dist_get_stats),
  * "symbolic_device", "topology_device", "tl_probe", "tl_host_inverse" (validation variants of setup phases) */

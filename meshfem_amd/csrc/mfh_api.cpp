@@ -294,6 +294,7 @@ k::AsmArgs asm_args(mfh_ctx *c) {
     a.vals = c->dVals.p; a.nnzb = c->sym.nnzb;
     a.xcd = c->xcdSwizzle;
     a.upperOnly = c->upperOnly ? 1 : 0;
+    a.det = c->deterministic ? 1 : 0;
     a.chunkElemBase = c->codesPacked ? c->dChunkElemBase.p : nullptr;
     a.chunkOrder = nullptr;
     if (c->asmChunkOrder && !c->hostOnly && a.nChunk > 1 && c->symValid && c->dContribPtr.p && c->dContribCode.p && c->contribOrder == 1) {
@@ -465,6 +466,13 @@ void ensure_fixed_uploaded(mfh_ctx *c) {
 }
 
 void ensure_precond(mfh_ctx *c) {
+    if (c->deterministic) {
+        if (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID)
+            throw Error(MFH_ERR_UNSUPPORTED, "option deterministic: the coarse levels of the two-level / multigrid preconditioners are built with unordered atomics; "
+                                             "use MFH_PRECOND_BLOCK_JACOBI (or JACOBI / NONE) for bit-reproducible solves");
+        if (c->use_mf() && c->mfModeEff() != 4)
+            throw Error(MFH_ERR_UNSUPPORTED, "option deterministic: the matrix-free operator must be the cluster variant (matrix_free_mode 4) or the assembled SpMV (matrix_free 0)");
+    }
     ensure_assembled(c);
     ensure_fixed_uploaded(c);
     if (c->dinvValid) return;
@@ -1373,6 +1381,7 @@ mfh_status mfh_assemble(mfh_ctx *c, int32_t mode) {
     MFH_TRY(c)
     require(c && c->haveMesh, MFH_ERR_STATE, "no mesh set");
     require(mode == MFH_ASSEMBLE_GATHER || mode == MFH_ASSEMBLE_ATOMIC, MFH_ERR_INVALID, "bad assembly mode");
+    require(!(c->deterministic && mode == MFH_ASSEMBLE_ATOMIC), MFH_ERR_UNSUPPORTED, "option deterministic: the global-atomic assembly variant is not reproducible");
     if (c->alwaysReembed) { c->geoValid = false; c->hGeoValid = false; }
     ensure_symbolic(c, mode == MFH_ASSEMBLE_ATOMIC);
     RoctxRange range("Assemble System");
@@ -1999,6 +2008,18 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "mf_reorder") { c->mfReorder = value != 0; c->mfcValid = false; c->mfClusterUnfit = false; }
     else if (k2 == "dist_pcg_variant") c->distPcgVariant = value != 0 ? 1 : 0;
     else if (k2 == "dist_profile") c->dist.profile = value != 0;
+    else if (k2 == "deterministic") {
+        const bool on = value != 0;
+        if (on && !c->detPartials.p) {
+            require_device(c);
+            MFH_HIP(hipSetDevice(c->device));
+            c->detPartials.alloc((size_t)65536 * 4);
+            c->detCounter.alloc(64);
+            c->detCounter.zero(c->stream);
+            MFH_HIP(hipStreamSynchronize(c->stream));
+        }
+        if (on != c->deterministic) { c->deterministic = on; invalidate_matrix(c); destroy_multigrid(c); c->tl.valid = false; }
+    }
     else if (k2 == "pcg_variant") c->pcgVariant = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k2 == "batch_rhs") c->batchRhs = value != 0;
     else if (k2 == "matrix_free_mode") { c->mfMode = (int)value; c->mfClusterUnfit = false; }

@@ -18,6 +18,16 @@ struct mfh_ctx {
                                      // than the round-robin default on MI355X: DESIGN.md section 4.8)
     std::vector<double> hLoad, hX;   // host scratch of Simulator::solve (kept between solves)
     bool alwaysReembed = false;      // option "reembed": every mfh_assemble re-runs the embedding kernel
+    // option "deterministic": run-to-run bit-reproducible assembly, operator and PCG. The reference's scatter into the triplet list is serial
+    // and therefore reproducible (LinearElasticity.hh:1454-1455; the one place that is not, it documents and switches off,
+    // SparseMatrices.hh:288,319-324). Here the default kernels accumulate with LDS / global atomics in whatever order the waves arrive; the
+    // option orders them: the waves of a workgroup add one after the other (k_assemble_gather, k_mf_rows) or into arrays of their own
+    // (k_mf_cluster), the dot products go through a fixed two-stage tree (commit_sums), the PCG runs the classic loop. Block-Jacobi /
+    // Jacobi / no preconditioner; contexts that own all their rows and row-partitioned ones (whose all-reduce is in rank order with the
+    // peer transfers).
+    bool deterministic = false;
+    DBuf<double> detPartials;
+    DBuf<unsigned> detCounter;
     bool periodicIgnoreMismatch = false;   // option "periodic_ignore_mismatch": PeriodicCondition(..., ignoreMismatch)
     int periodicIgnoreDims = 0;            // option "periodic_ignore_dims": bit a set = dimension a is not periodic
     hipStream_t stream = nullptr;
@@ -262,7 +272,8 @@ struct mfh_ctx {
 namespace mfhi {   // internal helpers with external linkage (defined in mfh_api.cpp unless inline)
 using namespace mfh;
 
-#define MFH_TRY(ctx) try {
+#define MFH_TRY(ctx) try {         \
+    mfh::k::DetScope detScope_(mfhi::det_buf(ctx));
 #define MFH_CATCH(ctx)                                              \
     } catch (const mfh::Error &e) {                                 \
         if (ctx) (ctx)->err = e.what();                             \
@@ -275,6 +286,13 @@ using namespace mfh;
         return MFH_ERR_INVALID;                                     \
     }                                                               \
     return MFH_OK;
+
+// the scratch of the reproducible global sums for the launches of this API call (null members unless option "deterministic" is on)
+inline mfh::k::DetBuf det_buf(const mfh_ctx *c) {
+    mfh::k::DetBuf d;
+    if (c && c->deterministic && c->detPartials.p) { d.partials = c->detPartials.p; d.counter = c->detCounter.p; d.cap = (int)(c->detPartials.n / 4); }
+    return d;
+}
 
 inline void require(bool cond, mfh_status code, const char *msg) {
     if (!cond) throw Error(code, msg);

@@ -37,6 +37,48 @@ DEV void block_sum(double (&v)[NV], double *lds /* >= 4*NV doubles */) {
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Global sums of workgroup partials (dot products of the PCG). Default: one unsafeAtomicAdd per workgroup onto the target -- the
+// order in which the workgroups arrive, and with it the last bits of the sum, changes from run to run. Option "deterministic"
+// (d.partials != null): every workgroup stores its partials, the LAST one to arrive (device-scope ticket) adds all of them up in
+// workgroup order with a fixed tree and adds the total onto the target with a plain read-modify-write -- the same bits on every run
+// (kernels of one stream never overlap, so the single counter and the plain update are safe). blockDim.x == 256.
+// v: valid in thread 0. target[k] == nullptr: that sum is not wanted.
+// ------------------------------------------------------------------------------------------------
+template <int NV>
+DEV void commit_sums(double (&v)[NV], double *const (&target)[NV], const DetBuf &d, double *lds /* >= 4 NV + 1 doubles */) {
+    if (!d.partials) {
+        if (threadIdx.x == 0)
+#pragma unroll
+            for (int k = 0; k < NV; ++k) if (target[k]) unsafeAtomicAdd(target[k], v[k]);
+        return;
+    }
+    int *flag = reinterpret_cast<int *>(lds + 4 * NV);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) d.partials[(int64_t)blockIdx.x * NV + k] = v[k];
+        __threadfence();
+        const unsigned t = atomicAdd(d.counter, 1u);
+        *flag = t == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!*flag) return;
+    __threadfence();
+    double s[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) s[k] = 0.0;
+    for (int64_t b = threadIdx.x; b < (int64_t)gridDim.x; b += 256)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) s[k] += __hip_atomic_load(&d.partials[b * NV + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    block_sum<NV>(s, lds);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) if (target[k]) *target[k] += s[k];
+        *d.counter = 0u;
+    }
+}
+
 // XCD-aware work mapping. Workgroups are dispatched round-robin over the 8 XCDs (workgroup b runs on XCD b % 8) and
 // every XCD has its own L2, so neighbouring work items (row chunks, element groups: they share element records, gather
 // lists and x entries) should run on the SAME XCD: XCD x gets the x-th contiguous eighth of the n items.

@@ -304,6 +304,23 @@ void build_mg_transfer_device(const HostMesh &m, const int32_t *dElemNodes, hipS
 // ------------------------------------------------------------------------------------------------
 namespace mfh { namespace k {
 
+// option "deterministic": scratch of the run-to-run reproducible global sums (commit_sums, mfh_device.hh). The launchers read the
+// calling thread's current buffer (a context's solve installs its own for the duration: DetScope), so that no launch signature changes.
+struct DetBuf {
+    double *partials = nullptr;      // [cap][4] workgroup partials
+    unsigned *counter = nullptr;     // arrival ticket
+    int cap = 0;                     // workgroups the scratch holds: deterministic launches use at most this many
+};
+extern thread_local DetBuf t_det;
+struct DetScope {
+    DetBuf saved;
+    explicit DetScope(const DetBuf &d) : saved(t_det) { t_det = d; }
+    ~DetScope() { t_det = saved; }
+    DetScope(const DetScope &) = delete;
+    DetScope &operator=(const DetScope &) = delete;
+};
+inline int det_grid(int grid) { return t_det.partials ? std::min(grid, t_det.cap) : grid; }
+
 struct AsmArgs {
     int dim, deg, npe, mat;             // mat: MaterialKind
     int geoStride;
@@ -329,6 +346,7 @@ struct AsmArgs {
     const int32_t *chunkElemBase;       // packed gather codes: (element - chunkElemBase[chunk]) << 7 | ij (nullptr: absolute codes e npe^2 + ij)
     const int32_t *chunkOrder;          // workgroup b takes chunk chunkOrder[b] (nullptr: b): chunks visited in element order
     int upperOnly;                      // the lists cover the blocks (r, c >= r) only (names the kernel instantiation)
+    int det;                            // option "deterministic": the waves of a workgroup add their contributions in wave order
 };
 
 void launch_geometry(int dim, int deg, int mat, int64_t nElem, const int32_t *elemNodes, int npe,
@@ -374,6 +392,7 @@ struct SpmvArgs {
     const uint8_t *fixedMask;           // per scalar row, may be null
     int xcd;                            // 1: XCD-contiguous chunk ranges (xcd_span)
     int pcgMode;                        // launch_spmv_nr with one vector: 0 = by ctl (none / Chronopoulos-Gear), 1 = classic PCG bookkeeping
+    DetBuf det;                         // filled by the launcher (t_det)
 };
 // Matrix-free operator: y = K x without reading the assembled K. One lane per (element, local node i) pair:
 // it evaluates the npe blocks K_e[i][j] in registers and applies them to the gathered x_j; pairs are grouped by
@@ -410,6 +429,7 @@ struct SpmvMfArgs {
     int pcgMode;                        // launch_mf_*_nr with one vector: 0 = by ctl (none / Chronopoulos-Gear), 1 = classic PCG bookkeeping
     int clLaneStride;                   // lane t of a block takes element (t * stride) % blockElems (1: identity); coprime to blockElems
     const double *vertPos;              // cluster variant, constant material: corner positions [nVert][dim]; gradients recomputed (null: read the records)
+    DetBuf det;                         // filled by the launcher (t_det); non-null = deterministic accumulation as well
 };
 void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
                     bool pcg, hipStream_t s);

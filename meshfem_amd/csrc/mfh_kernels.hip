@@ -337,8 +337,13 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
     // U independent contributions per lane and trip: their index loads, element-record loads and
     // block arithmetic have no mutual dependence, so the loads of all U are in flight together
     // (the kernel is latency-bound: rocprof shows 65 % of wave cycles in s_waitcnt at U = 1).
+    // Option "deterministic" (a.det): the four waves of the workgroup add their contributions to the LDS accumulators one wave after the
+    // other, trip by trip, so that the contributions of a slot always meet in list order (inside one wave the lanes of an LDS atomic are
+    // applied in a fixed order; between waves the order is a matter of timing, and the last bits of K with it). Every lane then runs the
+    // same number of trips (barriers inside the loop).
     constexpr int U = 2;
-    for (int64_t k0 = kb + threadIdx.x; k0 < ke; k0 += 256 * U) {
+    const bool det = a.det != 0;
+    for (int64_t k0 = kb + threadIdx.x; det ? (k0 - threadIdx.x < ke) : (k0 < ke); k0 += 256 * U) {
         uint32_t code[U];
         int ls[U];
         bool ok[U];
@@ -371,7 +376,15 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
                 const int i = ij / NPE, j = ij - i * NPE;
                 elem_block<DIM, DEG, MAT>(g, MAT == MAT_MASS ? a.massTable : a.pairTable, pc, i, j, K);
             }
-            if (ok[u]) {
+            if (det) {
+                for (int w = 0; w < 4; ++w) {
+                    if ((int)(threadIdx.x >> 6) == w && ok[u]) {
+#pragma unroll
+                        for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&acc[c * CS + ls[u]], K[c]);
+                    }
+                    __syncthreads();
+                }
+            } else if (ok[u]) {
 #pragma unroll
                 for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&acc[c * CS + ls[u]], K[c]);
             }
@@ -785,7 +798,8 @@ __global__ void __launch_bounds__(256) k_spmv(SpmvArgs a, const double *__restri
     if (dotOut) {
         double v[1] = {dot};
         block_sum<1>(v, red);
-        if (threadIdx.x == 0) unsafeAtomicAdd(dotOut, v[0]);
+        double *const tg[1] = {dotOut};
+        commit_sums<1>(v, tg, a.det, red);
     }
 }
 
@@ -859,7 +873,8 @@ __global__ void __launch_bounds__(256) k_spmv_mf(SpmvMfArgs a, const double *__r
     if (dotOut) {
         double v[1] = {dot};
         block_sum<1>(v, red);
-        if (threadIdx.x == 0) unsafeAtomicAdd(dotOut, v[0]);
+        double *const tg[1] = {dotOut};
+        commit_sums<1>(v, tg, a.det, red);
     }
 }
 
@@ -1493,9 +1508,15 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
                                                          double *scal, int it, const double *stopPtr, const int32_t *__restrict__ blockList,
                                                          int64_t nList) {
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
-    extern __shared__ __attribute__((aligned(16))) double clacc[];   // accumulators [maxLocal * DIM] + staged x [maxLocal * DIM] + 16
-    double *xs = clacc + a.clMaxLocal * DIM;
-    double *red = xs + a.clMaxLocal * DIM;
+    extern __shared__ __attribute__((aligned(16))) double clacc[];   // accumulators [maxLocal * DIM] (x 4 when deterministic) + staged x [maxLocal * DIM] + 16
+    // Option "deterministic": the order in which the four waves reach a shared accumulator changes from run to run, so every wave sums
+    // into an array of its own (inside ONE wave the hardware applies the lanes of an LDS atomic in a fixed order) and the write-out adds
+    // the four in wave order.
+    const bool det = a.det.partials != nullptr;
+    const int accStride = a.clMaxLocal * DIM;
+    double *xs = clacc + (det ? 4 : 1) * accStride;
+    double *red = xs + accStride;
+    double *accw = clacc + (det ? (int)(threadIdx.x >> 6) * accStride : 0);
     if (PCG == 1) {
         it += (int)stopPtr[3];
         if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
@@ -1514,7 +1535,10 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
         for (int t = threadIdx.x; t < nLocal; t += MF_BLOCK) {
             const int64_t row = a.clEntryRow[u0 + t];
 #pragma unroll
-            for (int d = 0; d < DIM; ++d) { xs[t * DIM + d] = x[row * DIM + d]; clacc[t * DIM + d] = 0.0; }
+            for (int d = 0; d < DIM; ++d) {
+                xs[t * DIM + d] = x[row * DIM + d]; clacc[t * DIM + d] = 0.0;
+                if (det) { clacc[accStride + t * DIM + d] = 0.0; clacc[2 * accStride + t * DIM + d] = 0.0; clacc[3 * accStride + t * DIM + d] = 0.0; }
+            }
         }
         __syncthreads();
         // lane -> element of the block: with a stride coprime to the block size the lanes of a wave take elements that are
@@ -1537,7 +1561,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
             }
             auto emit = [&](int j, const double *fv) {
 #pragma unroll
-                for (int d = 0; d < DIM; ++d) unsafeAtomicAdd(&clacc[li[j] * DIM + d], fv[d]);
+                for (int d = 0; d < DIM; ++d) unsafeAtomicAdd(&accw[li[j] * DIM + d], fv[d]);
             };
             if (GEOV) {
                 const int32_t *en = a.elemNodes + e * NPE;
@@ -1557,6 +1581,11 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
         for (int t = threadIdx.x; t < nLocal; t += MF_BLOCK) {
             const int dest = a.clEntryDest[u0 + t];
             if (dest == -2) continue;                                  // row owned by another rank
+            if (det) {
+#pragma unroll
+                for (int d = 0; d < DIM; ++d)
+                    clacc[t * DIM + d] = ((clacc[t * DIM + d] + clacc[accStride + t * DIM + d]) + clacc[2 * accStride + t * DIM + d]) + clacc[3 * accStride + t * DIM + d];
+            }
             if (dest >= 0) {
 #pragma unroll
                 for (int d = 0; d < DIM; ++d) a.clIfaceBuf[(int64_t)dest * DIM + d] = clacc[t * DIM + d];
@@ -1577,7 +1606,8 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
     if (dotOut) {
         double v[1] = {dot};
         block_sum<1>(v, red);
-        if (threadIdx.x == 0) unsafeAtomicAdd(dotOut, v[0]);
+        double *const tg[1] = {dotOut};
+        commit_sums<1>(v, tg, a.det, red);
     }
 }
 
@@ -1607,7 +1637,8 @@ __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__r
         const int64_t kb = a.pairPtr[chunk], ke = a.pairPtr[chunk + 1];
         // U independent pairs per lane and trip: their list and force loads are all in flight together
         constexpr int U = 2;
-        for (int64_t k0 = kb + threadIdx.x; k0 < ke; k0 += 256 * U) {
+        // (deterministic mode has barriers inside the loop: every lane runs the same number of trips)
+        for (int64_t k0 = kb + threadIdx.x; a.det.partials ? (k0 - threadIdx.x < ke) : (k0 < ke); k0 += 256 * U) {
             int64_t code[U];
             int lr[U];
             bool ok[U];
@@ -1623,6 +1654,21 @@ __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__r
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int c = 0; c < DIM; ++c) out[u][c] = fbuf[code[u] * DIM + c];
+            if (a.det.partials) {
+                // option "deterministic": one wave after the other (a row's partials then meet in list order, whatever the timing)
+                for (int w = 0; w < 4; ++w) {
+                    if ((int)(threadIdx.x >> 6) == w) {
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            if (!ok[u]) continue;
+#pragma unroll
+                            for (int c = 0; c < DIM; ++c) unsafeAtomicAdd(&mfacc[lr[u] * DIM + c], out[u][c]);
+                        }
+                    }
+                    __syncthreads();
+                }
+                continue;
+            }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (!ok[u]) continue;
@@ -1644,7 +1690,8 @@ __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__r
     if (dotOut) {
         double v[1] = {dot};
         block_sum<1>(v, red);
-        if (threadIdx.x == 0) unsafeAtomicAdd(dotOut, v[0]);
+        double *const tg[1] = {dotOut};
+        commit_sums<1>(v, tg, a.det, red);
     }
 }
 
@@ -2148,12 +2195,15 @@ static int spmv_grid(const SpmvArgs &a) { return persistent_grid(a.nChunk, 256 *
 
 // mode: 0 plain (dotOut optional), 1 classic PCG bookkeeping, 2 Chronopoulos-Gear bookkeeping (one right-hand side);
 // chunkList / nList: the chunks of this launch (null = all)
-static void launch_spmv_mode(const SpmvArgs &a, int mode, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
+static void launch_spmv_mode(const SpmvArgs &a_, int mode, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
                              const int32_t *chunkList, int64_t nList, hipStream_t s) {
-    const int64_t n = chunkList ? nList : a.nChunk;
+    const int64_t n = chunkList ? nList : a_.nChunk;
     if (n <= 0) return;
+    SpmvArgs ad = a_;
+    ad.det = t_det;
+    const SpmvArgs &a = ad;
     const size_t lds = ((size_t)a.dim * a.chunkSlots + 16) * sizeof(double);
-    const int grid = persistent_grid(n, 256 * 8);
+    const int grid = det_grid(persistent_grid(n, 256 * 8));
 #define SPMV(D)                                                                                                                               \
     if (mode == 0) hipLaunchKernelGGL((k_spmv<D, 0>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, scal, it, stopPtr, chunkList, nList);     \
     else if (mode == 1) hipLaunchKernelGGL((k_spmv<D, 1>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, scal, it, stopPtr, chunkList, nList); \
@@ -2185,11 +2235,14 @@ void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dot
     CHECK_LAUNCH();
 }
 
-static void launch_mf_rows_mode(const SpmvMfArgs &a, int mode, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
+static void launch_mf_rows_mode(const SpmvMfArgs &a_, int mode, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
                                 hipStream_t s) {
-    if (a.nChunk == 0) return;
+    if (a_.nChunk == 0) return;
+    SpmvMfArgs ad = a_;
+    ad.det = t_det;
+    const SpmvMfArgs &a = ad;
     const size_t lds = ((size_t)a.maxRows * a.dim + 16) * sizeof(double);
-    const int grid = persistent_grid(a.nChunk, 256 * 8);
+    const int grid = det_grid(persistent_grid(a.nChunk, 256 * 8));
 #define ROWS(D)                                                                                                                               \
     if (mode == 0) hipLaunchKernelGGL((k_mf_rows<D, 0>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, scal, it, stopPtr);     \
     else if (mode == 1) hipLaunchKernelGGL((k_mf_rows<D, 1>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, scal, it, stopPtr); \
@@ -2212,12 +2265,20 @@ void launch_spmv_mf2(const SpmvMfArgs &a, const double *x, double *y, double *do
 }
 
 // cluster variant of the matrix-free elasticity operator: k_mf_cluster over the blocks of blockList (null = all) ...
-static void launch_mf_cluster_mode(const SpmvMfArgs &a, int mode, const double *x, double *y, double *dotOut, double *scal, int it,
+static void launch_mf_cluster_mode(const SpmvMfArgs &a_, int mode, const double *x, double *y, double *dotOut, double *scal, int it,
                                    const double *stopPtr, const int32_t *blockList, int64_t nList, hipStream_t s) {
     if (nList <= 0) return;
-    const size_t ldsC = ((size_t)2 * a.clMaxLocal * a.dim + 16) * sizeof(double);
-    const int gridC = (int)std::min<int64_t>(nList, 256 * 64);
+    SpmvMfArgs ad = a_;
+    ad.det = t_det;
+    const SpmvMfArgs &a = ad;
+    const size_t ldsC = ((size_t)(a.det.partials ? 5 : 2) * a.clMaxLocal * a.dim + 16) * sizeof(double);
+    const int gridC = det_grid((int)std::min<int64_t>(nList, 256 * 64));
 #define CALLG(D, G, M, GV)                                                                                                                                         \
+    if (ldsC > 64 * 1024) {                                                                                                                                        \
+        MFH_HIP(hipFuncSetAttribute((const void *)k_mf_cluster<D, G, M, 0, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC));                              \
+        MFH_HIP(hipFuncSetAttribute((const void *)k_mf_cluster<D, G, M, 1, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC));                              \
+        MFH_HIP(hipFuncSetAttribute((const void *)k_mf_cluster<D, G, M, 2, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC));                              \
+    }                                                                                                                                                              \
     if (mode == 0) hipLaunchKernelGGL((k_mf_cluster<D, G, M, 0, GV>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList);     \
     else if (mode == 1) hipLaunchKernelGGL((k_mf_cluster<D, G, M, 1, GV>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList); \
     else hipLaunchKernelGGL((k_mf_cluster<D, G, M, 2, GV>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList)

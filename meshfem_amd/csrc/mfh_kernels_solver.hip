@@ -414,7 +414,7 @@ __global__ void __launch_bounds__(256) k_tl_gemv(int64_t m, int64_t ld, const do
 template <int DIM>
 __global__ void __launch_bounds__(256) k_tl_apply(TLArgs t, const double *__restrict__ dinv, const double *__restrict__ r,
                                                   const double *__restrict__ yc, double *__restrict__ z, double *scal, int it,
-                                                  const double *stopPtr) {
+                                                  const double *stopPtr, DetBuf det) {
     __shared__ double red[8];
     double *rzOut = nullptr;
     if (scal) {
@@ -446,7 +446,8 @@ __global__ void __launch_bounds__(256) k_tl_apply(TLArgs t, const double *__rest
     }
     if (rzOut) {
         block_sum<1>(acc, red);
-        if (threadIdx.x == 0) unsafeAtomicAdd(rzOut, acc[0]);
+        double *const tg[1] = {rzOut};
+        commit_sums<1>(acc, tg, det, red);
     }
 }
 
@@ -669,7 +670,7 @@ __global__ void __launch_bounds__(256) k_dense_xtx(const double *X, double *Ainv
 template <int DIM>
 __global__ void __launch_bounds__(256) k_pcg_init(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ b,
                                                   double *__restrict__ x, double *__restrict__ r, double *__restrict__ z,
-                                                  double *__restrict__ p, double *scal) {
+                                                  double *__restrict__ p, double *scal, DetBuf det) {
     __shared__ double red[16];
     double acc[2] = {0, 0};
     for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nRows; n += (int64_t)gridDim.x * 256) {
@@ -684,7 +685,8 @@ __global__ void __launch_bounds__(256) k_pcg_init(int64_t nRows, const double *_
         }
     }
     block_sum<2>(acc, red);
-    if (threadIdx.x == 0) { unsafeAtomicAdd(&scal[0], acc[0]); unsafeAtomicAdd(&scal[2], acc[1]); }
+    double *const tg[2] = {&scal[0], &scal[2]};
+    commit_sums<2>(acc, tg, det, red);
 }
 
 // r -= alpha Ap ; z = Dinv r ; scal[it+1].{rz,rr} += ...   (x += alpha p happens in k_pcg_direction, which reads p anyway: one
@@ -692,7 +694,7 @@ __global__ void __launch_bounds__(256) k_pcg_init(int64_t nRows, const double *_
 template <int DIM, bool SKIPZ = false>
 __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double *__restrict__ dinv,
                                                     const double *__restrict__ Ap, double *__restrict__ r,
-                                                    double *__restrict__ z, double *scal, int it, const double *stopPtr) {
+                                                    double *__restrict__ z, double *scal, int it, const double *stopPtr, DetBuf det) {
     __shared__ double red[16];
     it += (int)stopPtr[3];
     if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
@@ -748,12 +750,11 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
         for (int c = 0; c < DIM; ++c) acc[1] += rv[c] * rv[c];
     }
     block_sum<2>(acc, red);
-    if (threadIdx.x == 0) {
-        if (!SKIPZ) unsafeAtomicAdd(&scal[(int64_t)(it + 1) * 4 + 0], acc[0]);
-        unsafeAtomicAdd(&scal[(int64_t)(it + 1) * 4 + 2], acc[1]);
-    }
+    double *const tg[2] = {SKIPZ ? nullptr : &scal[(int64_t)(it + 1) * 4 + 0], &scal[(int64_t)(it + 1) * 4 + 2]};
+    commit_sums<2>(acc, tg, det, red);
 }
 
+thread_local DetBuf t_det;
 int g_vecGridCap = 16384;   // workgroups of k_pcg_direction (option "vec_grid_cap"; 0.899 vs 0.911 ms per iteration against 2048). Kernels that end in a
                             // reduction keep 2048: 16384 workgroups x 2 atomics on the same scalars cost 0.14 ms
 // x += alpha p ; p = z + beta p   (alpha of this iteration, beta from the reductions k_pcg_update / the preconditioner just made)
@@ -798,12 +799,13 @@ __global__ void __launch_bounds__(256) k_dev_direction(int64_t n, const double *
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) p[k] = z[k] + b * p[k];
 }
 // out[0] = r.z, out[1] = r.r (out zeroed by the caller)
-__global__ void __launch_bounds__(256) k_dev_dots(int64_t n, const double *__restrict__ r, const double *__restrict__ z, double *out) {
+__global__ void __launch_bounds__(256) k_dev_dots(int64_t n, const double *__restrict__ r, const double *__restrict__ z, double *out, DetBuf det) {
     __shared__ double red[16];
     double acc[2] = {0, 0};
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) { acc[0] += r[k] * z[k]; acc[1] += r[k] * r[k]; }
     block_sum<2>(acc, red);
-    if (threadIdx.x == 0) { unsafeAtomicAdd(&out[0], acc[0]); unsafeAtomicAdd(&out[1], acc[1]); }
+    double *const tg[2] = {&out[0], &out[1]};
+    commit_sums<2>(acc, tg, det, red);
 }
 
 // stop[3] += n: advances the iteration base at the end of a captured block of PCG iterations
@@ -825,12 +827,13 @@ __global__ void __launch_bounds__(256) k_scatter_values(int64_t n, const int64_t
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
         if (idx[k] < bound) v[idx[k]] = val[k];
 }
-__global__ void __launch_bounds__(256) k_dot(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *out) {
+__global__ void __launch_bounds__(256) k_dot(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *out, DetBuf det) {
     __shared__ double red[8];
     double acc[1] = {0};
     for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) acc[0] += a[k] * b[k];
     block_sum<1>(acc, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(out, acc[0]);
+    double *const tg[1] = {out};
+    commit_sums<1>(acc, tg, det, red);
 }
 // tiled -> array-of-blocks (export)
 __global__ void __launch_bounds__(256) k_untile(int NB, int64_t nnzb, const double *__restrict__ tiled, double *__restrict__ aos) {
@@ -1574,7 +1577,7 @@ __global__ void __launch_bounds__(256) k_mg_diff(int64_t n, const double *__rest
 
 // scal[(it + 1) 4] += r . z  (the preconditioned inner product of the PCG), z = r on the fixed variables first
 __global__ void __launch_bounds__(256) k_mg_rz(int64_t n, const double *__restrict__ r, double *__restrict__ z, const uint8_t *__restrict__ mask,
-                                               double *scal, MgGate g) {
+                                               double *scal, MgGate g, DetBuf det) {
     __shared__ double red[8];
     if (mg_closed(g)) return;
     const int it = g.scal ? g.it + (int)g.stop[3] : g.it;
@@ -1585,7 +1588,8 @@ __global__ void __launch_bounds__(256) k_mg_rz(int64_t n, const double *__restri
         acc[0] += r[k] * zv;
     }
     block_sum<1>(acc, red);
-    if (threadIdx.x == 0) unsafeAtomicAdd(scal + (int64_t)(it + 1) * 4, acc[0]);
+    double *const tg[1] = {scal + (int64_t)(it + 1) * 4};
+    commit_sums<1>(acc, tg, det, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1615,26 +1619,26 @@ void launch_precond(int dim, int64_t nRows, const double *dinv, const double *r,
 
 void launch_pcg_init(int dim, int64_t nRows, const double *dinv, const double *b, double *x, double *r, double *z, double *p,
                      double *scal, hipStream_t s) {
-    if (dim == 1) hipLaunchKernelGGL(k_pcg_init<1>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal);
-    else if (dim == 3) hipLaunchKernelGGL(k_pcg_init<3>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal);
-    else hipLaunchKernelGGL(k_pcg_init<2>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal);
+    if (dim == 1) hipLaunchKernelGGL(k_pcg_init<1>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal, t_det);
+    else if (dim == 3) hipLaunchKernelGGL(k_pcg_init<3>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal, t_det);
+    else hipLaunchKernelGGL(k_pcg_init<2>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal, t_det);
     CHECK_LAUNCH();
 }
 
 void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double *Ap, double *r,
                        double *z, double *scal, int it, const double *stopPtr, hipStream_t s) {
     const int grid = grid_for(nRows / 2);   // 2048 workgroups at most: each ends with two atomics on the same two scalars
-    if (dim == 1) hipLaunchKernelGGL((k_pcg_update<1, false>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr);
-    else if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr);
-    else hipLaunchKernelGGL((k_pcg_update<2, false>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr);
+    if (dim == 1) hipLaunchKernelGGL((k_pcg_update<1, false>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr, t_det);
+    else if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr, t_det);
+    else hipLaunchKernelGGL((k_pcg_update<2, false>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr, t_det);
     CHECK_LAUNCH();
 }
 
 void launch_pcg_update_noz(int dim, int64_t nRows, const double *Ap, double *r, double *scal, int it,
                            const double *stopPtr, hipStream_t s) {
     const int grid = grid_for(nRows / 2);
-    if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, true>), dim3(grid), dim3(256), 0, s, nRows, (const double *)nullptr, Ap, r, (double *)nullptr, scal, it, stopPtr);
-    else hipLaunchKernelGGL((k_pcg_update<2, true>), dim3(grid), dim3(256), 0, s, nRows, (const double *)nullptr, Ap, r, (double *)nullptr, scal, it, stopPtr);
+    if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, true>), dim3(grid), dim3(256), 0, s, nRows, (const double *)nullptr, Ap, r, (double *)nullptr, scal, it, stopPtr, t_det);
+    else hipLaunchKernelGGL((k_pcg_update<2, true>), dim3(grid), dim3(256), 0, s, nRows, (const double *)nullptr, Ap, r, (double *)nullptr, scal, it, stopPtr, t_det);
     CHECK_LAUNCH();
 }
 
@@ -1724,8 +1728,8 @@ void launch_tl_gemv(int64_t m, int64_t ld, const double *A, const double *x, dou
 }
 void launch_tl_apply(const TLArgs &t, const double *dinv, const double *r, const double *yc, double *z, double *scal, int it,
                      const double *stopPtr, hipStream_t s) {
-    if (t.dim == 3) hipLaunchKernelGGL(k_tl_apply<3>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr);
-    else hipLaunchKernelGGL(k_tl_apply<2>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr);
+    if (t.dim == 3) hipLaunchKernelGGL(k_tl_apply<3>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr, t_det);
+    else hipLaunchKernelGGL(k_tl_apply<2>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr, t_det);
     CHECK_LAUNCH();
 }
 
@@ -1739,7 +1743,7 @@ void launch_dev_direction(int64_t n, const double *num, const double *den, const
 }
 void launch_dev_dots(int64_t n, const double *r, const double *z, double *out, hipStream_t s) {
     MFH_HIP(hipMemsetAsync(out, 0, 2 * sizeof(double), s));
-    hipLaunchKernelGGL(k_dev_dots, dim3(grid_for(n)), dim3(256), 0, s, n, r, z, out);
+    hipLaunchKernelGGL(k_dev_dots, dim3(grid_for(n)), dim3(256), 0, s, n, r, z, out, t_det);
     CHECK_LAUNCH();
 }
 
@@ -1774,7 +1778,7 @@ void launch_scatter_values(int64_t n, const int64_t *idx, const double *val, dou
 }
 void launch_dot(int64_t n, const double *a, const double *b, double *out, hipStream_t s) {
     if (!n) return;
-    hipLaunchKernelGGL(k_dot, dim3(grid_for(n)), dim3(256), 0, s, n, a, b, out);
+    hipLaunchKernelGGL(k_dot, dim3(grid_for(n)), dim3(256), 0, s, n, a, b, out, t_det);
     CHECK_LAUNCH();
 }
 
@@ -1896,7 +1900,7 @@ void launch_mg_diff(int64_t n, const double *a, const double *b, double *out, co
     CHECK_LAUNCH();
 }
 void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, double *scalOut, int it, const double *scal, const double *stop, hipStream_t s) {
-    hipLaunchKernelGGL(k_mg_rz, dim3(grid_for(n)), dim3(256), 0, s, n, r, z, mask, scalOut, mk_gate(scal, it, stop));
+    hipLaunchKernelGGL(k_mg_rz, dim3(grid_for(n)), dim3(256), 0, s, n, r, z, mask, scalOut, mk_gate(scal, it, stop), t_det);
     CHECK_LAUNCH();
 }
 

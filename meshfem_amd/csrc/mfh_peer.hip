@@ -210,9 +210,11 @@ void peer_enable(mfh_comm *cm, int device, hipStream_t s) {
     if (cm->device < 0) cm->device = device;
     const int world = cm->world, me = cm->rank;
     if (const char *e = getenv("MFH_PEER_TIMEOUT_S")) P.timeoutS = std::max(1.0, atof(e));
-    // 2^21 doubles = 16 MiB per (buffer, source rank): a z-slab interface of BASELINE configs[4] (2.4e5 nodes x 6 doubles) and the
-    // replicated aggregate levels of the multigrid hierarchy (6 x 262 144 doubles) both fit; 64 MiB x world per rank in all
-    P.haloCap = P.arCap = (int64_t)1 << 21;
+    // halo messages: 2^22 doubles = 32 MiB per (buffer, source rank) -- the larger direction of a z-slab interface of BASELINE configs[4] is
+    // 3.8e5 nodes x 3 doubles = 1.1 M; all-reduces: 2^21 doubles -- the replicated aggregate levels of the multigrid hierarchy
+    // (6 x 262 144 doubles) fit; 96 MiB x world per rank in all
+    P.haloCap = (int64_t)1 << 22;
+    P.arCap = (int64_t)1 << 21;
     if (const char *e = getenv("MFH_PEER_HALO_CAP")) P.haloCap = std::max<int64_t>(1024, atoll(e));
     if (const char *e = getenv("MFH_PEER_AR_CAP")) P.arCap = std::max<int64_t>(PEER_AR_SMALL, atoll(e));
     MFH_HIP(hipSetDevice(cm->device));

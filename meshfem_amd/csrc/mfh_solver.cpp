@@ -128,7 +128,7 @@ void comm_allreduce(mfh_comm *cm, double *dev, int64_t n, hipStream_t s) {
 void comm_exchange(mfh_comm *cm, int nPeers, const int32_t *peers, const double *const *sendBufs, const int64_t *sendCounts,
                    double *const *recvBufs, const int64_t *recvCounts, hipStream_t s, int *transport = nullptr, bool widthReserved = true) {
     if (!cm || cm->world <= 1 || nPeers == 0) return;
-    // widthReserved: the doubles per block row do not exceed what mfh_dist_setup sized the staging for (2 bs) -- the same on every rank,
+    // widthReserved: the doubles per block row do not exceed what mfh_dist_setup registered with the staging (bs: one right-hand side) -- the same on every rank,
     // unlike the byte counts of a particular pair
     if (widthReserved && peer_can_exchange(cm, nPeers, peers, sendCounts, recvCounts)) {
         peer_exchange(cm, nPeers, peers, sendBufs, sendCounts, recvBufs, recvCounts, s);
@@ -195,7 +195,7 @@ struct DistLink {   // stream / event plumbing of one solve on a partitioned con
         }
         Dist::Profile *pf = profile_slot();
         if (pf) MFH_HIP(hipEventRecord(pf->ev[1], cs));
-        comm_exchange(cm, np, D.peers.data(), sb.data(), sc.data(), rb.data(), rc.data(), cs, &D.transport, W <= 2 * c->bs());
+        comm_exchange(cm, np, D.peers.data(), sb.data(), sc.data(), rb.data(), rc.data(), cs, &D.transport, W <= c->bs());
         MFH_HIP(hipEventRecord(D.ev[1], cs));
         if (pf) MFH_HIP(hipEventRecord(pf->ev[2], cs));
         ++D.nExchanges;
@@ -769,7 +769,7 @@ static void solve_one_pass(mfh_ctx *c, const double *f, double *u, double rtol, 
     // the hierarchy for THIS solve (regular, or pinned for a system that is singular on the free variables): a no-op once it exists
     if (c->precond == MFH_PRECOND_MULTIGRID && !partitioned && !(c->mg.valid && c->mg.singular == c->tlSuppress)) ensure_coarse_levels(c, 1);
     const bool multigrid = c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && !partitioned;   // the V-cycle lives in the classic loop
-    if (!multigrid && (c->pcgVariant == 1 || partitioned) && cg_operator_supported(c)) {
+    if (!multigrid && !c->deterministic && (c->pcgVariant == 1 || partitioned) && cg_operator_supported(c)) {
         const int64_t n = (int64_t)c->bs() * c->sym.nRows;
         solve_cg(c, 1, f, u, n, rtol, maxit, info);
     } else {
@@ -825,7 +825,7 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
 void solve_many(mfh_ctx *c, int nrhs, const double *f, double *u, int64_t stride, double rtol, int maxit, mfh_solve_info *infos) {
     const int d = c->bs();
     // the V-cycle lives in the one-right-hand-side loop: with the multigrid preconditioner batches would silently run block-Jacobi
-    const bool batched = c->pcgVariant != 0 && c->batchRhs && c->precond != MFH_PRECOND_MULTIGRID && cg_operator_supported(c);
+    const bool batched = c->pcgVariant != 0 && c->batchRhs && !c->deterministic && c->precond != MFH_PRECOND_MULTIGRID && cg_operator_supported(c);
     int k0 = 0;
     while (k0 < nrhs) {
         int nb = 1;
@@ -1052,7 +1052,7 @@ mfh_status mfh_dist_setup(mfh_ctx *c, mfh_comm *cm, int32_t nPeers, const int32_
             maxPair = std::max(maxPair, std::max(sendPtr[k + 1] - sendPtr[k], recvPtr[k + 1] - recvPtr[k]));
             mask |= 1u << peers[k];
         }
-        peer_reserve(cm, maxPair, 2 * c->bs(), mask, c->stream);
+        peer_reserve(cm, maxPair, c->bs(), mask, c->stream);
     }
     c->mg.valid = false;             // a multigrid hierarchy holds exchange lists derived from the previous ones
     MFH_CATCH(c)
@@ -1097,10 +1097,10 @@ mfh_status mfh_dist_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, 
     int k0 = 0;
     while (k0 < nrhs) {
         int nb = 1;
-        if (c->batchRhs && !useMG)
+        if (c->batchRhs && !useMG && !c->deterministic)
             for (int cand : {6, 3, 2})
                 if (cand <= nrhs - k0 && k::op_batch_supported(c->bs(), cand)) { nb = cand; break; }
-        if (nb == 1 && (c->distPcgVariant == 0 || useMG)) solve_classic_partitioned(c, f + (size_t)k0 * n, u + (size_t)k0 * n, rtol, maxit, infos.data() + k0);
+        if (nb == 1 && (c->distPcgVariant == 0 || useMG || c->deterministic)) solve_classic_partitioned(c, f + (size_t)k0 * n, u + (size_t)k0 * n, rtol, maxit, infos.data() + k0);
         else solve_cg(c, nb, f + (size_t)k0 * n, u + (size_t)k0 * n, n, rtol, maxit, infos.data() + k0);
         k0 += nb;
     }

@@ -666,105 +666,205 @@ def robust_comm(c, rank, world, dev, group=None, log=None):
     raise RuntimeError("no transport passed the communicator self test: %r" % (tried,))
 
 
-def _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out, group=None):
-    comm, group, tried = robust_comm(c, rank, world, dev, group, log=lambda m: print(m, flush=True))
-    solver = DistSolver(c, lm, rank, world, comm, group)
-    # u = 0 on x = 0: the mask covers the halo nodes too (needed by the Galerkin coarse operator)
-    fixed_nodes = np.flatnonzero(lm.lattice[:, 0] == 0)
-    c.fix_variables((3 * fixed_nodes[:, None] + np.arange(3)[None, :]).ravel())
-    f = slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel()
-    n_coarse = getattr(args, "coarse_aggregates", 0)
-    if n_coarse == 0:
-        n_coarse = min(1000 * world, 2048)
-    pre_desc, tl_info = "3x3 block-Jacobi", None
-    maxit = args.maxit
-    if n_coarse > 0:
-        tl_info = solver.two_level(n_coarse)
-        pre_desc = "two-level: 3x3 block-Jacobi + rigid-body modes of %d global bins" % int(np.prod(tl_info["bins"]))
-    elif world > 1:
-        # the bar gets longer with N (weak scaling), so block-Jacobi alone needs O(N) more iterations:
-        # measure the per-iteration rate on a bounded number of iterations
-        maxit = min(args.maxit, 3000)
-    if world > 1:
-        dist.barrier(group=group)
+def try_enable_peer(comm, rank, world, dev, group=None, log=None):
+    """Peer transfers (HIP IPC) on top of a communicator that has passed its self test: enabled on every rank or on none.
+    mfh_comm_enable_peer fails on every rank when one rank cannot export or map a slab; the self test (ring shift + short and long
+    all-reduces, six rounds) then runs through the peer path and the ranks agree on its outcome. Returns (enabled, outcome)."""
+    if world <= 1:
+        return False, "one rank"
+    ok, why = True, ""
     try:
-        u, infos = solver.solve(f, rtol=args.rtol, maxit=maxit)
+        comm.enable_peer()
+    except L.MeshFEMHipError as e:
+        ok, why = False, str(e)
+    if not _agree(ok, world, group, dev):
+        if ok:
+            comm.disable_peer()
+        outcome = "unavailable: " + (why or "failed on another rank")
+        if log and rank == 0:
+            log("peer transfers " + outcome)
+        return False, outcome
+    try:
+        comm.selftest()
+    except (L.MeshFEMHipError, RuntimeError) as e:
+        ok, why = False, str(e)
+    if not _agree(ok, world, group, dev):
+        comm.disable_peer()
+        outcome = "self test failed: " + (why or "on another rank")
+        if log and rank == 0:
+            log("peer transfers " + outcome)
+        return False, outcome
+    if log and rank == 0:
+        log("peer transfers: ok (%s)" % comm.describe())
+    return True, "ok"
+
+
+def _solve_record(c, solver, f, rtol, maxit, red, lm):
+    """One mfh_dist_solve with its numbers (max over the ranks of the solve time) and this rank's exchange statistics."""
+    try:
+        u, infos = solver.solve(f, rtol=rtol, maxit=maxit)
         info = infos[0]
     except L.MeshFEMHipError as e:
         if e.code != L.ERR_NOT_CONVERGED:
             raise
         u, info = None, c.last_info
+    ts = red([info["solve_ms"] * 1e-3], dist.ReduceOp.MAX)[0]
+    st = c.dist_stats()
+    rec = dict(iterations=info["iterations"], converged=bool(info["converged"]), true_rel_residual=info["true_rel_residual"],
+               rel_residual=info["rel_residual"], solve_s=float(ts), ms_per_iteration=float(ts) / max(1, info["iterations"]) * 1e3,
+               transport=st["transport_name"],
+               overlap=dict(exchange_ms=st["exchange_ms"], interior_ms=st["interior_ms"], boundary_ms=st["boundary_ms"],
+                            exposed_wait_ms=st["exposed_wait_ms"], operator_ms=st["operator_ms"], applications_timed=st["profiled_applications"],
+                            note="HIP events on rank 0 around the first operator applications of the solve: exchange = pack done -> halo arrived "
+                                 "(communication stream), interior = the element blocks that read no halo entry (compute stream, concurrently), "
+                                 "exposed_wait = how long the compute stream then still waited for the halo (0 = hidden)"))
+    return u, info, rec
+
+
+def _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out, group=None, lean=False):
+    """The solver leg of bench.py --gpus N. The transport underneath (RCCL, or callbacks when ranks share a device) runs first and is on
+    record before the peer transfers are tried; `lean` (the secondary weak-scaling object) keeps the two-level and multigrid solves on the
+    best transport only."""
+    log = lambda m: print(m, flush=True)   # noqa: E731
+    comm, group, tried = robust_comm(c, rank, world, dev, group, log=log)
+    c.set_option("dist_profile", 1)
+    solver = DistSolver(c, lm, rank, world, comm, group)
+    # u = 0 on x = 0: the mask covers the halo nodes too (needed by the Galerkin coarse operator)
+    fixed_nodes = np.flatnonzero(lm.lattice[:, 0] == 0)
+    c.fix_variables((3 * fixed_nodes[:, None] + np.arange(3)[None, :]).ravel())
+    f = slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel()
     red = lambda v, op: solver._allreduce_np(np.asarray(v, dtype=np.float64), op)   # noqa: E731
     nd = red([3.0 * lm.n_owned], dist.ReduceOp.SUM)[0]
-    ts = red([info["solve_ms"] * 1e-3], dist.ReduceOp.MAX)[0]
-    umax = red([np.abs(u).max() if u is not None else 0.0], dist.ReduceOp.MAX)[0]
-    out["pcg"] = dict(iterations=info["iterations"], converged=bool(info["converged"]), rtol=args.rtol,
-                      rel_residual=info["rel_residual"], true_rel_residual=info["true_rel_residual"],
-                      max_abs_u=float(umax), dof=int(nd), solve_s=float(ts),
-                      dof_per_s=float(nd) * info["iterations"] / max(ts, 1e-30),
-                      ms_per_iteration=float(ts) / max(1, info["iterations"]) * 1e3,
-                      maxit=maxit, preconditioner=pre_desc, two_level=tl_info,
-                      operator="matrix-free (k_mf_cluster + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
-                      algorithm="Chronopoulos-Gear PCG in the library (mfh_dist_solve): packed halo exchange overlapped with the interior "
-                                "element blocks + %d all-reduce / iteration" % (2 if tl_info else 1),
-                      transport=comm.describe(), transports_tried=tried, ranks=world)
-    # the same solve with the classic loop (two dependent all-reduces per iteration, lighter vector kernels): which of the two
-    # wins depends on the all-reduce latency of the transport, so the scaling run records both
-    try:
-        c.set_option("dist_pcg_variant", 0)
-        if world > 1:
-            dist.barrier(group=group)
-        try:
-            _, infos2 = solver.solve(f, rtol=args.rtol, maxit=maxit)
-            i2 = infos2[0]
-        except L.MeshFEMHipError as e:
-            if e.code != L.ERR_NOT_CONVERGED:
-                raise
-            i2 = c.last_info
-        ts2 = red([i2["solve_ms"] * 1e-3], dist.ReduceOp.MAX)[0]
-        out["pcg"]["classic_two_reductions"] = dict(iterations=i2["iterations"], converged=bool(i2["converged"]), solve_s=float(ts2),
-                                                     ms_per_iteration=float(ts2) / max(1, i2["iterations"]) * 1e3,
-                                                     true_rel_residual=i2["true_rel_residual"])
-    finally:
+    # proof that the LIBRARY's communicator saw every rank: an all-reduce of ones through mfh_comm_allreduce
+    ones = torch.ones(1, dtype=torch.float64, device=dev)
+    c._ck(c.lib.mfh_comm_allreduce(c.h, comm.h, ctypes.c_void_p(ones.data_ptr()), 1))
+    ranks_seen = int(round(ones.item()))
+    n_coarse = getattr(args, "coarse_aggregates", 0)
+    if n_coarse == 0:
+        n_coarse = min(1000 * world, 2048)
+    maxit = args.maxit
+
+    def two_level_and_multigrid(tag):
+        """two-level (Chronopoulos-Gear and classic loop) + multigrid on the transport in use"""
+        res = {}
+        tl_info, pre_desc = None, "3x3 block-Jacobi"
+        mi = maxit
+        if n_coarse > 0:
+            tl_info = solver.two_level(n_coarse)
+            pre_desc = "two-level: 3x3 block-Jacobi + rigid-body modes of %d global bins" % int(np.prod(tl_info["bins"]))
+        elif world > 1:
+            mi = min(maxit, 3000)       # block-Jacobi alone needs O(N) more iterations on the longer bar: bounded
         c.set_option("dist_pcg_variant", 1)
-    # the same solve with the multigrid V-cycle: nodal levels partitioned like the mesh, aggregate levels replicated on every rank
-    # (mfh_multigrid.cpp). Collective setup: every rank takes this branch.
-    try:
-        c.set_preconditioner(L.PRECOND_MULTIGRID)
         if world > 1:
             dist.barrier(group=group)
-        t0 = time.perf_counter()
+        u, info, rec = _solve_record(c, solver, f, args.rtol, mi, red, lm)
+        umax = red([np.abs(u).max() if u is not None else 0.0], dist.ReduceOp.MAX)[0]
+        rec.update(rtol=args.rtol, max_abs_u=float(umax), dof=int(nd), dof_per_s=float(nd) * rec["iterations"] / max(rec["solve_s"], 1e-30), maxit=mi,
+                   preconditioner=pre_desc, two_level=tl_info,
+                   operator="matrix-free (k_mf_cluster + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
+                   algorithm="Chronopoulos-Gear PCG in the library (mfh_dist_solve): packed halo exchange overlapped with the interior "
+                             "element blocks + %d all-reduce / iteration" % (2 if tl_info else 1))
+        res["two_level"] = rec
+        if not lean:
+            # the classic loop (two dependent all-reduces per iteration, one vector pass less): which of the two wins depends on the
+            # all-reduce latency of the transport, so the scaling run records both
+            try:
+                c.set_option("dist_pcg_variant", 0)
+                if world > 1:
+                    dist.barrier(group=group)
+                _, _, rec2 = _solve_record(c, solver, f, args.rtol, mi, red, lm)
+                res["classic_two_reductions"] = rec2
+            finally:
+                c.set_option("dist_pcg_variant", 1)
+        # the multigrid V-cycle: nodal levels partitioned like the mesh, aggregate levels replicated on every rank (mfh_multigrid.cpp).
+        # Collective setup: every rank takes this branch.
         try:
-            _, infos3 = solver.solve(f, rtol=args.rtol, maxit=min(maxit, 2000))
-            i3 = infos3[0]
-        except L.MeshFEMHipError as e:
-            if e.code != L.ERR_NOT_CONVERGED:
-                raise
-            i3 = c.last_info
-        wall3 = time.perf_counter() - t0
-        g3, p3 = c.multigrid_info(), c.precond_info()
-        ts3 = red([i3["solve_ms"] * 1e-3], dist.ReduceOp.MAX)[0]
-        out["pcg"]["multigrid"] = dict(iterations=i3["iterations"], converged=bool(i3["converged"]), solve_s=float(ts3),
-                                       ms_per_iteration=float(ts3) / max(1, i3["iterations"]) * 1e3, true_rel_residual=i3["true_rel_residual"],
-                                       hierarchy_setup_ms=g3["setup_ms"], wall_s_with_setup=wall3, aggregates=p3["aggregates"],
-                                       dense_level_dim=p3["coarse_dim"], note=p3["note"],
-                                       speedup_solve_vs_two_level=float(ts) / max(float(ts3), 1e-30))
-    except Exception as e:   # noqa: BLE001 -- the record keeps the two-level numbers
-        out["pcg"]["multigrid"] = dict(error="%s: %s" % (type(e).__name__, e))
-    out["pcg_multigrid"] = out["pcg"]["multigrid"]             # the key the one-GPU line uses
+            c.set_preconditioner(L.PRECOND_MULTIGRID)
+            if world > 1:
+                dist.barrier(group=group)
+            t0 = time.perf_counter()
+            _, _, rec3 = _solve_record(c, solver, f, args.rtol, min(maxit, 2000), red, lm)
+            g3, p3 = c.multigrid_info(), c.precond_info()
+            rec3.update(hierarchy_setup_ms=g3["setup_ms"], hierarchy_setup_ms_max_over_ranks=float(red([g3["setup_ms"]], dist.ReduceOp.MAX)[0]),
+                        wall_s_with_setup=time.perf_counter() - t0, aggregates=p3["aggregates"], dense_level_dim=p3["coarse_dim"], note=p3["note"],
+                        speedup_solve_vs_two_level=rec["solve_s"] / max(rec3["solve_s"], 1e-30))
+            res["multigrid"] = rec3
+        except Exception as e:   # noqa: BLE001 -- the record keeps the two-level numbers
+            res["multigrid"] = dict(error="%s: %s" % (type(e).__name__, e))
+        return res
+
+    st0 = None
+    base = None
+    peer_ok, peer_outcome = False, "not tried"
+    if not lean:
+        base = two_level_and_multigrid("base")
+        st0 = c.dist_stats()
+        out["pcg"] = dict(base["two_level"], classic_two_reductions=base.get("classic_two_reductions"), multigrid=base["multigrid"],
+                          transports_tried=tried, ranks=world, transport_description=comm.describe())
+        out["pcg_multigrid"] = base["multigrid"]
+    # peer transfers (HIP IPC) on top: the halo exchange and the small all-reduces without a library call; everything above is on record
+    peer_ok, peer_outcome = try_enable_peer(comm, rank, world, dev, group, log=log)
+    if peer_ok:
+        solver = DistSolver(c, lm, rank, world, comm, group)       # mfh_dist_setup again: registers this mesh's halos with the staging
+        c.set_preconditioner(L.PRECOND_BLOCK_JACOBI)
+    if peer_ok or lean:
+        best = two_level_and_multigrid("peer" if peer_ok else "base")
+        if lean:
+            out["pcg"] = dict(best["two_level"], multigrid=best["multigrid"], transports_tried=tried, ranks=world, transport_description=comm.describe())
+            out["pcg_multigrid"] = best["multigrid"]
+        else:
+            out["pcg"]["peer_transfers"] = dict(two_level=best["two_level"], classic_two_reductions=best.get("classic_two_reductions"), multigrid=best["multigrid"],
+                                                transport_description=comm.describe())
+            # the headline solve of the line = the faster transport, said so
+            mg_b, mg_p = base["multigrid"], best["multigrid"]
+            if "solve_s" in mg_p and ("solve_s" not in mg_b or mg_p["solve_s"] < mg_b["solve_s"]):
+                out["pcg_multigrid"] = dict(mg_p, note_transport="peer transfers (faster than the transport underneath: %.3f s against %s)"
+                                                                 % (mg_p["solve_s"], ("%.3f s" % mg_b["solve_s"]) if "solve_s" in mg_b else "an error"))
+    st = c.dist_stats()
+    out["dist"] = dict(ranks_seen_by_allreduce=ranks_seen, world=world, communicator=comm.describe(), transports_tried=tried,
+                       peer_transfers=peer_outcome, halo_transport_last_solve=st["transport_name"],
+                       halo_nodes_sent=st["halo_nodes_sent"], halo_nodes_received=st["halo_nodes_received"],
+                       halo_bytes_per_exchange=st["halo_bytes_per_exchange"], interior_items=st["interior_items"], boundary_items=st["boundary_items"],
+                       peer_counters=dict(halo_messages=st["peer_halo_messages"], halo_bytes=st["peer_halo_bytes"], allreduces_small=st["allreduces_small"],
+                                          allreduces_large=st["allreduces_large"], fallback_exchanges=st["fallback_exchanges"],
+                                          fallback_allreduces=st["fallback_allreduces"]),
+                       note="rank 0's figures; halo_bytes_per_exchange = (sent + received) x 24 B, one exchange per operator application")
+    if peer_ok:
+        comm.disable_peer()
     comm.close()
 
 
-def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
-    """bench.py --gpus N>1: weak scaling over z-slabs; returns the JSON dict on every rank. shared_gpus: fewer devices than
-    ranks (forced-distributed run on a 1-GPU box): same code, gloo process group, communicator callbacks staged through
-    the host -- a functional check of the N-rank path, not a scaling measurement."""
+def bench_multi(args, rank, world, local_rank, shared_gpus=False):
+    """bench.py --gpus N > 1. Default (and --scaling strong): the STRONG-scaling line on BASELINE configs[4]'s 119^3 cube -- north_star's
+    ">= 6x at 8 GPUs" is a statement about one fixed problem -- with the weak-scaling run (~60^3 hexes per rank) as the secondary object
+    `weak_scaling`; --scaling weak: the weak-scaling line alone."""
+    scaling = getattr(args, "scaling", None) or "strong"
+    if scaling == "weak":
+        return bench_slabs(args, rank, world, local_rank, shared_gpus, scaling="weak")
+    res = bench_slabs(args, rank, world, local_rank, shared_gpus, scaling="strong")
+    if getattr(args, "no_weak", False):
+        return res
+    try:
+        import copy
+        a2 = copy.copy(args)
+        a2.grid = getattr(args, "weak_grid", 0) or 60
+        w = bench_slabs(a2, rank, world, local_rank, shared_gpus, scaling="weak", lean=True)
+        res["weak_scaling"] = {k: w[k] for k in ("value", "unit", "ms_per_step", "config", "roofline", "setup", "pcg", "pcg_multigrid", "dist", "memory") if k in w}
+    except Exception as e:   # noqa: BLE001 -- the primary line is complete
+        res["weak_scaling"] = dict(error="%s: %s" % (type(e).__name__, e))
+    return res
+
+
+def bench_slabs(args, rank, world, local_rank, shared_gpus=False, scaling=None, lean=False):
+    """One scaling run over z-slabs; returns the JSON dict on every rank. shared_gpus: fewer devices than ranks (forced-distributed
+    run on a 1-GPU box): same code, gloo process group, communicator callbacks staged through the host (+ peer transfers between the
+    processes, which work on one device as well) -- a functional check of the N-rank path, not a scaling measurement."""
     import meshfem_amd as M
     dev = torch.device("cuda", local_rank)
     deg = args.deg
     # weak scaling towards BASELINE configs[4] (a ~40 M-tet CUBE in 8 z-slabs, SURVEY.md 8e): the global grid is
     # n x n x (layers * world) with n ~ grid * world^(1/3), and every rank keeps ~24 grid^3 elements
-    strong = getattr(args, "scaling", "weak") == "strong"
+    strong = (scaling or getattr(args, "scaling", None) or "strong") == "strong"
     if strong:
         # STRONG scaling (BASELINE.md section 2 / north_star: ">= 6x at 8 GPUs" on configs[4]): ONE fixed grid^3 cube (default 119^3 =
         # 40 443 816 P2 tets) whose hex layers are dealt out over the ranks; N = 1 runs the same cube in one context (run_single)
@@ -854,7 +954,14 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
                                           "communication); committed for the default grid at 2 and 8 ranks (a middle rank's slab), else null",
                              note="rank 0's local launch (its elements incl. the halo layer); frac = SURVEY 8(d) algorithmic bytes (contract), "
                                   "frac_compulsory = bytes the design must move (K once + records + lists)"),
-               setup=dict(local_mesh_s=t_mesh, symbolic_s=t_sym))
+               setup=dict(local_mesh_s=t_mesh, symbolic_s=t_sym, local_mesh_s_max_over_ranks=max_over_ranks(t_mesh),
+                          symbolic_s_max_over_ranks=max_over_ranks(t_sym)))
+
+    def memory_record():
+        free, total = torch.cuda.mem_get_info(dev)
+        return dict(device_used_GB=(total - free) / 1e9, device_total_GB=total / 1e9,
+                    note="hipMemGetInfo on rank 0's device after the solves: all ranks of the device together" if shared_gpus else
+                         "hipMemGetInfo on rank 0's device after the solves")
     if not args.no_solve:
         # The assembly figures above are the headline metric; a failure of the solver leg (it is the only part that
         # depends on the interconnect) must not lose them: it is reported inside the JSON line instead.
@@ -865,9 +972,8 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
         def expired():
             msg = "did not finish within %.0f s (collective / interconnect hang?)" % limit
             if isinstance(out.get("pcg"), dict) and "iterations" in out["pcg"]:
-                # the main solve is on record: what hung is a later leg (classic loop, multigrid)
-                for leg in ("classic_two_reductions", "multigrid"):
-                    out["pcg"].setdefault(leg, dict(error="this leg or the one before it " + msg))
+                # the solves on the transport underneath are on record: what hung is a later leg (the peer transfers)
+                out["pcg"].setdefault("peer_transfers", dict(error="this leg " + msg))
             elif not (isinstance(out.get("pcg"), dict) and "error" in out["pcg"]):
                 out["pcg"] = dict(error="the solver leg did not finish within %.0f s (collective / interconnect hang?); the assembly "
                                         "figures of this line are complete" % limit)
@@ -880,10 +986,15 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False):
         timer.daemon = True
         timer.start()
         try:
-            _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out)
+            _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out, lean=lean)
+            out["memory"] = memory_record()
             timer.cancel()
         except Exception as e:   # noqa: BLE001
             # the timer stays armed: the other ranks may be stuck in a collective this rank left, and so will this rank's
             # closing barrier be
-            out["pcg"] = dict(error="%s: %s" % (type(e).__name__, e))
+            if isinstance(out.get("pcg"), dict) and "iterations" in out["pcg"]:
+                out["pcg"]["later_leg_error"] = "%s: %s" % (type(e).__name__, e)
+            else:
+                out["pcg"] = dict(error="%s: %s" % (type(e).__name__, e))
+    c.close()
     return out
