@@ -447,6 +447,36 @@ def run_single(args):
                                             rel_l2_vs_block_jacobi=float(np.linalg.norm(u3 - u) / np.linalg.norm(u)))
             except M.MeshFEMHipError as e:
                 out["pcg_multigrid"] = str(e)
+    # Option "deterministic" (bit-reproducible assembly, operator and PCG): the same timed step and the block-Jacobi PCG
+    # with the waves adding in order and the dot products through the fixed tree, next to the default figures of this line
+    if not strong and isinstance(out.get("variants"), dict):
+        try:
+            c.set_option("deterministic", 1)
+            c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+            for _ in range(2):
+                c.assemble()
+            c.dev_sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                c.assemble()
+            c.dev_sync()
+            dtd = (time.perf_counter() - t0) / args.steps
+            kd = c.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
+            det = dict(ms_per_step=dtd * 1e3, elements_per_s=nE / dtd, kernel_ms=kd, step_cost_vs_default=dtd * 1e3 / ms_step, kernel_cost_vs_default=kd / k_ms,
+                       note="option deterministic 1: two runs give identical bits (tests/test_gpu_deterministic.py)")
+            if not args.no_solve and "pcg" in out:
+                ud = c.sim_solve(rtol=args.rtol, maxit=args.maxit)
+                idt = dict(c.last_info)
+                det["pcg_block_jacobi"] = dict(iterations=idt["iterations"], converged=bool(idt["converged"]), solve_ms=idt["solve_ms"],
+                                               ms_per_iteration=idt["solve_ms"] / max(1, idt["iterations"]),
+                                               cost_per_iteration_vs_default=(idt["solve_ms"] / max(1, idt["iterations"])) / out["pcg"]["ms_per_iteration"],
+                                               rel_l2_vs_default=float(np.linalg.norm(ud - u) / np.linalg.norm(u)))
+                del ud
+            out["variants"]["deterministic"] = det
+        except M.MeshFEMHipError as e:
+            out["variants"]["deterministic"] = str(e)
+        finally:
+            c.set_option("deterministic", 0)
     # The same pass with BOTH triangles of K stored (option matrix_storage 0: the round-1 definition of this benchmark, and what a
     # context does on its own when something multiplies by the stored K). Same timed region (embedding + blocks + assembly).
     if upper and not strong:
