@@ -144,6 +144,8 @@ PROTOTYPES = {
     "mfh_comm_describe": (C.c_char_p, [_P]),
     "mfh_comm_allreduce": (_i32, [_P, _P, _P, _i64]),
     "mfh_comm_selftest": (_i32, [_P, _P]),
+    "mfh_device_cache_trim": (_i32, []),
+    "mfh_device_cache_stats": (_i32, [_i32, _pi64, _pi64, _pi64, _pi64, _pi64]),
     "mfh_comm_enable_peer": (_i32, [_P, _P]),
     "mfh_comm_disable_peer": (_i32, [_P, _P]),
     "mfh_dist_get_stats": (_i32, [_P, _P]),

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmeshfem_hip.so")
-SOURCES = ["mfh_api.cpp", "mfh_solver.cpp", "mfh_simulator.cpp", "mfh_mesh.cpp", "mfh_symbolic.cpp", "mfh_twolevel.cpp", "mfh_multigrid.cpp", "mfh_symbolic_gpu.hip", "mfh_kernels.hip", "mfh_kernels_solver.hip", "mfh_peer.hip"]
+SOURCES = ["mfh_api.cpp", "mfh_pool.cpp", "mfh_solver.cpp", "mfh_simulator.cpp", "mfh_mesh.cpp", "mfh_symbolic.cpp", "mfh_twolevel.cpp", "mfh_multigrid.cpp", "mfh_symbolic_gpu.hip", "mfh_kernels.hip", "mfh_kernels_solver.hip", "mfh_peer.hip"]
 HOST_ONLY = ["mfh_twolevel.cpp"]
 HEADERS = ["mfh_internal.hh", "mfh_ctx.hh", "mfh_device.hh", "mfh_comm.hh", os.path.join("..", "..", "include", "meshfem_hip.h")]
 

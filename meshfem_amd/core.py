@@ -614,3 +614,15 @@ class Context:
 
     def set_option(self, key, value):
         self._ck(self.lib.mfh_set_option(self.h, key.encode(), float(value)))
+
+
+def device_cache_trim():
+    """Return every cached device block of this process to the driver (mfh_device_cache_trim)."""
+    L.load().mfh_device_cache_trim()
+
+
+def device_cache_stats(device=0):
+    lib = L.load()
+    v = [C.c_int64() for _ in range(5)]
+    lib.mfh_device_cache_stats(int(device), *[C.byref(x) for x in v])
+    return dict(zip(("cached_bytes", "blocks", "hits", "misses", "flushes"), [x.value for x in v]))

@@ -1056,6 +1056,16 @@ void mfh_destroy(mfh_ctx *c) {
 const char *mfh_last_error(const mfh_ctx *c) { return c ? c->err.c_str() : "null context"; }
 void *mfh_stream(mfh_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
+/* the per-process cache of released device blocks (mfh_pool.cpp) */
+mfh_status mfh_device_cache_trim(void) {
+    try { mfh::device_cache_trim(); } catch (...) { return MFH_ERR_HIP; }
+    return MFH_OK;
+}
+mfh_status mfh_device_cache_stats(int32_t device, int64_t *cachedBytes, int64_t *blocks, int64_t *hits, int64_t *misses, int64_t *flushes) {
+    mfh::device_cache_stats(device, cachedBytes, blocks, hits, misses, flushes);
+    return MFH_OK;
+}
+
 mfh_status mfh_set_stream(mfh_ctx *c, void *stream) {
     MFH_TRY(c)
     require(c && !c->hostOnly, MFH_ERR_STATE, "no device context");
@@ -2013,7 +2023,8 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
         if (on && !c->detPartials.p) {
             require_device(c);
             MFH_HIP(hipSetDevice(c->device));
-            c->detPartials.alloc((size_t)65536 * 4);
+            c->detPartials.alloc((size_t)8 + (size_t)16384 * 4);     // header + 16 384 workgroups x 4 partials
+            c->detPartials.zero(c->stream);
             c->detCounter.alloc(64);
             c->detCounter.zero(c->stream);
             MFH_HIP(hipStreamSynchronize(c->stream));

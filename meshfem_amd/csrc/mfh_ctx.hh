@@ -290,7 +290,7 @@ using namespace mfh;
 // the scratch of the reproducible global sums for the launches of this API call (null members unless option "deterministic" is on)
 inline mfh::k::DetBuf det_buf(const mfh_ctx *c) {
     mfh::k::DetBuf d;
-    if (c && c->deterministic && c->detPartials.p) { d.partials = c->detPartials.p; d.counter = c->detCounter.p; d.cap = (int)(c->detPartials.n / 4); }
+    if (c && c->deterministic && c->detPartials.p) { d.partials = c->detPartials.p; d.counter = c->detCounter.p; d.cap = (int)((c->detPartials.n - 8) / 4); }
     return d;
 }
 

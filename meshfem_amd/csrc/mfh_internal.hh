@@ -52,6 +52,12 @@ private:
 void parallel_ranges(int64_t n, const std::function<void(int64_t, int64_t, int)> &f, int64_t minGrain = 4096);
 int  host_threads();
 
+// device memory of the library: hipMalloc / hipFree behind a cache of released blocks (mfh_pool.cpp)
+void *device_alloc(size_t bytes);
+void device_free(void *p);
+void device_cache_trim();
+void device_cache_stats(int dev, int64_t *cachedBytes, int64_t *blocks, int64_t *hits, int64_t *misses, int64_t *flushes);
+
 // Device buffer with explicit size tracking.
 template <class T>
 struct DBuf {
@@ -62,7 +68,7 @@ struct DBuf {
     DBuf &operator=(const DBuf &) = delete;
     ~DBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) device_free(p);
         p = nullptr;
         n = 0;
     }
@@ -70,7 +76,7 @@ struct DBuf {
         if (count == n && p) return;
         release();
         if (count == 0) return;
-        MFH_HIP(hipMalloc((void **)&p, count * sizeof(T)));
+        p = (T *)device_alloc(count * sizeof(T));
         n = count;
     }
     // grow-only: work vectors whose size alternates between calls (batch widths 2, 1, 2, ...) are not reallocated every time
@@ -320,6 +326,8 @@ struct DetScope {
     DetScope &operator=(const DetScope &) = delete;
 };
 inline int det_grid(int grid) { return t_det.partials ? std::min(grid, t_det.cap) : grid; }
+// the second stage of a deterministic global sum: call right after a launch whose kernel ends in commit_sums (no-op unless t_det is set)
+void launch_det_finish(hipStream_t s);
 
 struct AsmArgs {
     int dim, deg, npe, mat;             // mat: MaterialKind

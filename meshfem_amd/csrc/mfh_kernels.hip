@@ -2210,6 +2210,7 @@ static void launch_spmv_mode(const SpmvArgs &a_, int mode, const double *x, doub
     else hipLaunchKernelGGL((k_spmv<D, 2>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, scal, it, stopPtr, chunkList, nList)
     if (a.dim == 1) { SPMV(1); } else if (a.dim == 3) { SPMV(3); } else { SPMV(2); }
 #undef SPMV
+    if (dotOut || scal) launch_det_finish(s);
     CHECK_LAUNCH();
 }
 
@@ -2249,6 +2250,7 @@ static void launch_mf_rows_mode(const SpmvMfArgs &a_, int mode, const double *x,
     else hipLaunchKernelGGL((k_mf_rows<D, 2>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, scal, it, stopPtr)
     if (a.dim == 3) { ROWS(3); } else { ROWS(2); }
 #undef ROWS
+    if (dotOut || scal) launch_det_finish(s);
     CHECK_LAUNCH();
 }
 
@@ -2288,6 +2290,7 @@ static void launch_mf_cluster_mode(const SpmvMfArgs &a_, int mode, const double 
     MFH_DISPATCH(a, CALL);
 #undef CALL
 #undef CALLG
+    if (dotOut || scal) launch_det_finish(s);
     CHECK_LAUNCH();
 }
 

@@ -755,6 +755,32 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
 }
 
 thread_local DetBuf t_det;
+
+// second stage of commit_sums: one workgroup adds the producers' partials in workgroup order (thread t takes b = t, t + 256, ...; then the
+// fixed tree of block_sum) and adds the totals onto the targets the producer named
+__global__ void __launch_bounds__(256) k_det_finish(double *scratch) {
+    __shared__ double red[20];
+    unsigned long long *h = reinterpret_cast<unsigned long long *>(scratch);
+    const int nv = (int)h[0];
+    if (nv == 0) return;
+    const int64_t nb = (int64_t)h[1];
+    double s4[4] = {0, 0, 0, 0};
+    for (int64_t b = threadIdx.x; b < nb; b += 256)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (k < nv) s4[k] += scratch[DET_HEADER + b * 4 + k];
+    block_sum<4>(s4, red);
+    if (threadIdx.x == 0) {
+        for (int k = 0; k < nv; ++k) {
+            double *t = reinterpret_cast<double *>(h[2 + k]);
+            if (t) *t += s4[k];
+        }
+        h[0] = 0;
+    }
+}
+void launch_det_finish(hipStream_t s) {
+    if (!t_det.partials) return;
+    hipLaunchKernelGGL(k_det_finish, dim3(1), dim3(256), 0, s, t_det.partials);
+}
 int g_vecGridCap = 16384;   // workgroups of k_pcg_direction (option "vec_grid_cap"; 0.899 vs 0.911 ms per iteration against 2048). Kernels that end in a
                             // reduction keep 2048: 16384 workgroups x 2 atomics on the same scalars cost 0.14 ms
 // x += alpha p ; p = z + beta p   (alpha of this iteration, beta from the reductions k_pcg_update / the preconditioner just made)
@@ -1622,6 +1648,7 @@ void launch_pcg_init(int dim, int64_t nRows, const double *dinv, const double *b
     if (dim == 1) hipLaunchKernelGGL(k_pcg_init<1>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal, t_det);
     else if (dim == 3) hipLaunchKernelGGL(k_pcg_init<3>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal, t_det);
     else hipLaunchKernelGGL(k_pcg_init<2>, dim3(grid_for(nRows)), dim3(256), 0, s, nRows, dinv, b, x, r, z, p, scal, t_det);
+    launch_det_finish(s);
     CHECK_LAUNCH();
 }
 
@@ -1631,6 +1658,7 @@ void launch_pcg_update(int dim, int64_t nRows, const double *dinv, const double 
     if (dim == 1) hipLaunchKernelGGL((k_pcg_update<1, false>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr, t_det);
     else if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr, t_det);
     else hipLaunchKernelGGL((k_pcg_update<2, false>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr, t_det);
+    launch_det_finish(s);
     CHECK_LAUNCH();
 }
 
@@ -1639,6 +1667,7 @@ void launch_pcg_update_noz(int dim, int64_t nRows, const double *Ap, double *r, 
     const int grid = grid_for(nRows / 2);
     if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, true>), dim3(grid), dim3(256), 0, s, nRows, (const double *)nullptr, Ap, r, (double *)nullptr, scal, it, stopPtr, t_det);
     else hipLaunchKernelGGL((k_pcg_update<2, true>), dim3(grid), dim3(256), 0, s, nRows, (const double *)nullptr, Ap, r, (double *)nullptr, scal, it, stopPtr, t_det);
+    launch_det_finish(s);
     CHECK_LAUNCH();
 }
 
@@ -1730,6 +1759,7 @@ void launch_tl_apply(const TLArgs &t, const double *dinv, const double *r, const
                      const double *stopPtr, hipStream_t s) {
     if (t.dim == 3) hipLaunchKernelGGL(k_tl_apply<3>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr, t_det);
     else hipLaunchKernelGGL(k_tl_apply<2>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, dinv, r, yc, z, scal, it, stopPtr, t_det);
+    launch_det_finish(s);
     CHECK_LAUNCH();
 }
 
@@ -1744,6 +1774,7 @@ void launch_dev_direction(int64_t n, const double *num, const double *den, const
 void launch_dev_dots(int64_t n, const double *r, const double *z, double *out, hipStream_t s) {
     MFH_HIP(hipMemsetAsync(out, 0, 2 * sizeof(double), s));
     hipLaunchKernelGGL(k_dev_dots, dim3(grid_for(n)), dim3(256), 0, s, n, r, z, out, t_det);
+    launch_det_finish(s);
     CHECK_LAUNCH();
 }
 
@@ -1779,6 +1810,7 @@ void launch_scatter_values(int64_t n, const int64_t *idx, const double *val, dou
 void launch_dot(int64_t n, const double *a, const double *b, double *out, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_dot, dim3(grid_for(n)), dim3(256), 0, s, n, a, b, out, t_det);
+    launch_det_finish(s);
     CHECK_LAUNCH();
 }
 
@@ -1901,6 +1933,7 @@ void launch_mg_diff(int64_t n, const double *a, const double *b, double *out, co
 }
 void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, double *scalOut, int it, const double *scal, const double *stop, hipStream_t s) {
     hipLaunchKernelGGL(k_mg_rz, dim3(grid_for(n)), dim3(256), 0, s, n, r, z, mask, scalOut, mk_gate(scal, it, stop), t_det);
+    launch_det_finish(s);
     CHECK_LAUNCH();
 }
 
