@@ -1,0 +1,119 @@
+// A C++ PeriodicHomogenization_cli on the facade: the tensor part of the reference's driver (src/bin/PeriodicHomogenization_cli.cc:
+// cell problems :95-108, displacement form :113-115, printed tensor / compliance / moduli :122-170) with the includes and the
+// namespace swapped. The field, distance and shape-derivative outputs of the reference's tool are served by the Python driver
+// (meshfem_amd/periodic_homogenization_cli.py).
+//
+//     PeriodicHomogenization_cli mesh.msh [-m material.json] [-d 1|2] [-O] [--ignorePeriodicMismatch] [--device 0] [--rtol 1e-10]
+//
+// exit code 3 + "runtime_error: ..." on any std::runtime_error (no device, bad files, unmatched periodic nodes, ...)
+#include <MeshFEMHip/PeriodicHomogenization.hh>
+#include <MeshFEMHip/Materials.hh>
+#include <MeshFEMHip/MeshIO.hh>
+
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+using namespace MeshFEMHip;
+namespace PH = MeshFEMHip::PeriodicHomogenization;
+
+struct Args {
+    std::string mesh, material;
+    int degree = 2, device = 0;
+    bool orthotropicCell = false, ignorePeriodicMismatch = false;
+    double rtol = 1e-10;
+};
+
+template <size_t FL>
+static bool invert(const std::array<std::array<Real, FL>, FL> &A, Real (&X)[FL][FL]) {       // Gauss-Jordan with partial pivoting (6 x 6 at most)
+    Real M[FL][2 * FL];
+    for (size_t i = 0; i < FL; ++i)
+        for (size_t j = 0; j < FL; ++j) { M[i][j] = A[i][j]; M[i][FL + j] = i == j ? 1.0 : 0.0; }
+    for (size_t c = 0; c < FL; ++c) {
+        size_t p = c;
+        for (size_t r = c + 1; r < FL; ++r) if (std::fabs(M[r][c]) > std::fabs(M[p][c])) p = r;
+        if (M[p][c] == 0.0) return false;
+        for (size_t j = 0; j < 2 * FL; ++j) std::swap(M[c][j], M[p][j]);
+        const Real d = M[c][c];
+        for (size_t j = 0; j < 2 * FL; ++j) M[c][j] /= d;
+        for (size_t r = 0; r < FL; ++r) {
+            if (r == c) continue;
+            const Real f = M[r][c];
+            for (size_t j = 0; j < 2 * FL; ++j) M[r][j] -= f * M[c][j];
+        }
+    }
+    for (size_t i = 0; i < FL; ++i) for (size_t j = 0; j < FL; ++j) X[i][j] = M[i][FL + j];
+    return true;
+}
+
+template <size_t N, size_t Deg>
+int execute(const Args &args, const std::vector<MeshIO::IOVertex> &inVertices, const std::vector<MeshIO::IOElement> &inElements) {
+    constexpr size_t FL = N * (N + 1) / 2;
+    std::vector<std::array<Real, N>> V(inVertices.size());
+    std::vector<std::array<int32_t, N + 1>> T(inElements.size());
+    for (size_t i = 0; i < V.size(); ++i) for (size_t c = 0; c < N; ++c) V[i][c] = inVertices[i][c];
+    for (size_t e = 0; e < T.size(); ++e) for (size_t c = 0; c < N + 1; ++c) T[e][c] = (int32_t)inElements[e][c];
+    using Sim = LinearElasticity::Simulator<N, Deg>;
+    Sim sim(T, V, args.device);
+    sim.rtol = args.rtol;
+    if (!args.material.empty()) { Materials::Constant<N> mat(args.material); sim.setMaterial(mat); }
+    if (args.ignorePeriodicMismatch) check(sim.ctx(), mfh_set_option(sim.ctx(), "periodic_ignore_mismatch", 1.0));
+    std::vector<typename Sim::VField> w_ij;
+    PH::ETensor<N> Eh;
+    if (!args.orthotropicCell) { PH::solveCellProblems(w_ij, sim, 1e-7); Eh = PH::homogenizedElasticityTensorDisplacementForm(w_ij, sim); }
+    else { PH::Orthotropic::solveCellProblems(w_ij, sim, 1e-7); Eh = PH::Orthotropic::homogenizedElasticityTensorDisplacementForm(w_ij, sim); }
+    printf("Homogenized elasticity tensor:\n");
+    for (size_t i = 0; i < FL; ++i) { for (size_t j = 0; j < FL; ++j) printf("%.16g%s", Eh.D[i][j], j + 1 < FL ? "\t" : "\n"); }
+    Real S[FL][FL];
+    if (!invert<FL>(Eh.D, S)) throw std::runtime_error("homogenized tensor is singular");
+    // compliance in the reference's flattening: shear rows / columns of the inverse of D carry the factors of the flattened double contraction
+    printf("\nHomogenized compliance tensor:\n");
+    for (size_t i = 0; i < FL; ++i) { for (size_t j = 0; j < FL; ++j) { const Real f = (i < N ? 1.0 : 0.5) * (j < N ? 1.0 : 0.5); printf("%.16g%s", f * S[i][j], j + 1 < FL ? "\t" : "\n"); } }
+    // moduli (PeriodicHomogenization_cli.cc:141-170): Young 1 / S_ii, shear 0.25 / S^flat_ii = 1 / S_ii of the plain inverse
+    Real young[3] = {0, 0, 0}, shear[3] = {0, 0, 0};
+    for (size_t i = 0; i < N; ++i) young[i] = 1.0 / S[i][i];
+    for (size_t i = N; i < FL; ++i) shear[i - N] = 1.0 / S[i][i];
+    if (N == 2) {
+        printf("Approximate Young moduli:\t%.16g\t%.16g\nApproximate shear modulus:\t%.16g\n", young[0], young[1], shear[0]);
+        printf("v_yx, v_xy:\t%.16g\t%.16g\n", -S[0][1] / S[1][1], -S[1][0] / S[0][0]);
+    } else {
+        printf("Approximate Young moduli:\t%.16g\t%.16g\t%.16g\nApproximate shear moduli:\t%.16g\t%.16g\t%.16g\n", young[0], young[1], young[2], shear[0], shear[1], shear[2]);
+        printf("v_yx, v_zx, v_zy:\t%.16g\t%.16g\t%.16g\n", -S[0][1] / S[1][1], -S[0][2] / S[2][2], -S[1][2] / S[2][2]);
+        printf("v_xy, v_xz, v_yz:\t%.16g\t%.16g\t%.16g\n", -S[1][0] / S[0][0], -S[2][0] / S[0][0], -S[2][1] / S[1][1]);
+    }
+    return 0;
+}
+
+int main(int argc, char **argv) {
+    Args args;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto value = [&]() -> std::string {
+            if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(1); }
+            return argv[++i];
+        };
+        if (a == "-m" || a == "--material") args.material = value();
+        else if (a == "-d" || a == "--degree") args.degree = atoi(value().c_str());
+        else if (a == "-O" || a == "--orthotropicCell") args.orthotropicCell = true;
+        else if (a == "--ignorePeriodicMismatch") args.ignorePeriodicMismatch = true;
+        else if (a == "--device") args.device = atoi(value().c_str());
+        else if (a == "--rtol") args.rtol = atof(value().c_str());
+        else if (a[0] == '-') { fprintf(stderr, "unknown option %s\n", a.c_str()); return 1; }
+        else args.mesh = a;
+    }
+    if (args.mesh.empty()) { fprintf(stderr, "Usage: PeriodicHomogenization_cli [options] mesh\n"); return 1; }
+    if (args.degree < 1 || args.degree > 2) { fprintf(stderr, "Error: FEM Degree must be 1 or 2\n"); return 1; }
+    try {
+        std::vector<MeshIO::IOVertex> vertices;
+        std::vector<MeshIO::IOElement> elements;
+        auto type = MeshIO::load(args.mesh, vertices, elements);
+        if (type == MeshIO::MeshType::TET) return args.degree == 2 ? execute<3, 2>(args, vertices, elements) : execute<3, 1>(args, vertices, elements);
+        if (type == MeshIO::MeshType::TRI) return args.degree == 2 ? execute<2, 2>(args, vertices, elements) : execute<2, 1>(args, vertices, elements);
+        throw std::runtime_error("Mesh must be pure triangle or tet.");
+    } catch (const std::runtime_error &e) {
+        printf("runtime_error: %s\n", e.what());
+        return 3;
+    }
+}

@@ -33,8 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
-PMC_PROFILE = "r02_pmc_traffic_n60.json"      # scripts/pmc_collect.py on the round-2 kernels (both triangles of K stored)
-PMC_PROFILE_UPPER = "r03_pmc_traffic_n60_upper_storage.json"   # the same with the upper-triangle storage (PMC_UPPER_STORAGE=1), round-3 kernel
+PMC_PROFILE = "r04_pmc_traffic_n60.json"      # scripts/pmc_collect.py at this round's kernels, both triangles of K stored (k_spmv, k_mf_*)
+PMC_PROFILE_UPPER = "r04_pmc_traffic_n60_upper_storage.json"   # the same with the upper-triangle storage (PMC_UPPER_STORAGE=1): the default of configs[2]
 PMC_KERNEL_KEY = "k_assemble_gather"
 ALG_BYTES = {(3, 2): 7736, (3, 1): 1328, (2, 2): 1368, (2, 1): 0}   # SURVEY.md section 8(d), const material, both triangles
 # SURVEY.md section 8(d), row "upper-only variant, matches reference storage": 40 + 96 + 55 x 4 + 55 x 72 (P2 tet); P2 triangle alike
@@ -245,7 +245,8 @@ def hbm_stream_probe(torch, n_doubles=1 << 27, reps=10):
         e1.record(); torch.cuda.synchronize()
         res[name + "_GBs"] = passes * n_doubles * 8 * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
     del a, b, c
-    torch.cuda.empty_cache()
+    # (no torch.cuda.empty_cache(): a hipFree of gigabytes makes the next large hipMalloc of the process stall for up to seconds on this
+    # driver stack -- profiles/r04_malloc_probe.txt; the 3 GiB stay in torch's allocator)
     res["note"] = "1 GiB f64 vectors, torch elementwise kernels, HIP events"
     return res
 
@@ -528,6 +529,17 @@ def run_single(args):
                 del V2, T2
             except M.MeshFEMHipError as e:
                 out["variants"]["orderings"][mode] = str(e)
+    if not strong and (n, deg) == (60, 2) and isinstance(out.get("variants"), dict):
+        # BASELINE configs[1] (35^3 grid -> 1,029,000 LINEAR tets, the same boundary-value problem) in every driver line: the assembly step, the
+        # assembled block-CSR SpMV (the PCG operator of linear meshes) against its own algorithmic bytes, and the multigrid PCG to rtol
+        try:
+            c.close()
+        except Exception:   # noqa: BLE001
+            pass
+        try:
+            out["variants"]["config1_p1"] = config1_p1(args)
+        except Exception as e:   # noqa: BLE001
+            out["variants"]["config1_p1"] = dict(error="%s: %s" % (type(e).__name__, e))
     if not strong and not args.no_strong_n1 and deg == 2:
         # the N = 1 point of the strong-scaling curve the N > 1 runs measure by default (configs[4]'s 119^3 cube in ONE context), so that
         # one driver pass over N = 1, 2, 4, 8 holds the whole curve
@@ -542,6 +554,58 @@ def run_single(args):
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_with_solve(args)
     print(json.dumps(out), flush=True)
+
+
+def config1_p1(args, n=35):
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    T = np.ascontiguousarray(T, dtype=np.int32)
+    c = M.Context(0)
+    t0 = time.time(); c.mesh_build(T, V, 1); t_build = time.time() - t0
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+    c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    t0 = time.time(); c.symbolic(False); t_sym = time.time() - t0
+    c.set_option("reembed", 1)
+    t0 = time.time(); c.assemble(); c.dev_sync(); t_first = time.time() - t0
+    for _ in range(args.warmup):
+        c.assemble()
+    c.dev_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        c.assemble()
+    c.dev_sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    nE = c.n_elem
+    k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
+    nr, nc, nnzb = c.matrix_info()
+    upper, stored = c.matrix_storage()
+    alg = ALG_BYTES[(3, 1)] * nE
+    comp = compulsory_assembly_bytes(c, nE, stored)
+    res = dict(workload="configs[1]: %d^3 grid -> %d P1 tets, %d DOF" % (n, nE, 3 * c.n_dof), elements=nE, dof=3 * c.n_dof, nnz_blocks=nnzb, stored_blocks=stored,
+               matrix_storage="upper" if upper else "full", value=nE / dt, unit="elements/s", ms_per_step=dt * 1e3,
+               roofline=dict(kernel="k_assemble_gather", kernel_ms=k_ms, bytes_per_element=ALG_BYTES[(3, 1)], frac=alg / k_ms / 1e6 / HBM_PEAK_GBS,
+                             compulsory_bytes=comp, frac_compulsory=comp / k_ms / 1e6 / HBM_PEAK_GBS,
+                             note="%.0f MB per launch: the working set is of the order of the 256 MiB memory-side cache; the fractions are against the "
+                                  "8 TB/s HBM peak all the same" % (comp / 1e6)),
+               setup=dict(femmesh_build_s=t_build, symbolic_s=t_sym, first_assemble_call_s=t_first, first_assembly_ms=(t_build + t_sym + t_first) * 1e3))
+    if not args.no_solve:
+        sp_ms = c.time_spmv_kernel(20)
+        sp_bytes = stored * 76 + nr * 3 * 16 + nr * 4
+        res["spmv"] = dict(kernel="k_spmv", kernel_ms=sp_ms, alg_bytes_per_launch=sp_bytes, achieved=sp_bytes / sp_ms / 1e6, frac=sp_bytes / sp_ms / 1e6 / HBM_PEAK_GBS,
+                           unit="GB/s", note="stored blocks x 76 B + vectors")
+        for name, pre in (("pcg_block_jacobi", M.PRECOND_BLOCK_JACOBI), ("pcg_multigrid", M.PRECOND_MULTIGRID)):
+            c.set_preconditioner(pre)
+            t0 = time.time()
+            u = c.sim_solve(rtol=args.rtol, maxit=args.maxit)
+            i = dict(c.last_info)
+            res[name] = dict(iterations=i["iterations"], converged=bool(i["converged"]), true_rel_residual=i["true_rel_residual"], solve_ms=i["solve_ms"],
+                             ms_per_iteration=i["solve_ms"] / max(1, i["iterations"]), wall_s=time.time() - t0, max_abs_u=float(np.abs(u).max()),
+                             dof_per_s=3 * c.n_dof * i["iterations"] / (i["solve_ms"] * 1e-3))
+        res["pcg_multigrid"]["hierarchy_setup_ms"] = c.multigrid_info()["setup_ms"]
+    c.close()
+    return res
 
 
 def strong_n1(args, torch, n=119):

@@ -5,7 +5,7 @@
     import mesh, tensors, sparse_matrices, periodic_homogenization
 
 `meshfem_amd.pybind.build.build()` compiles them in-tree (g++, pybind11 headers); `__graft_entry__.build()` does so too.
-The pure-Python shims of `meshfem_amd/compat` carry the wider surface (differential_operators, MSH field I/O, benchmark)."""
+They are the ONE implementation of the Python binding surface (the pure-Python shims of rounds 1-3 were retired in round 4)."""
 import os
 
 PATH = os.path.dirname(os.path.abspath(__file__))

@@ -37,7 +37,11 @@ cal_w = raw["WRITE_SIZE"]["k_axpby"]["avg_KB"] * 1024 / true_b
 res = dict(workload=("%d^3 grid, %d P2 tets" % (n, meta["elems"]) + (" (upper-triangle storage)" if meta.get("storage") == "upper" else "")) if not slab else ("%s of a %s grid, %d local P2 tets" % (slab, meta["global_grid"], meta["elems"])), meta=meta, raw=raw,
            calibration=dict(kernel="k_axpby(b=0): reads 8n, writes 8n bytes, n=%d" % meta["calib_axpby_doubles"],
                             fetch_reported_over_true=cal_f, write_reported_over_true=cal_w,
-                            note="gfx950 FETCH_SIZE reports ~1/2 of coalesced read bytes (MI355X_MICROARCH.md, HBM section); corrected by the measured factor"))
+                            note="gfx950 FETCH_SIZE reports ~1/2 of coalesced read bytes (MI355X_MICROARCH.md, HBM section); corrected by the measured factor",
+                            gather_patterns="scripts/probe/gather_probe.hip under rocprofv3 --pmc FETCH_SIZE (profiles/r04_gather_probe_fetch_size.csv): 64.0 B counted per "
+                                            "128-byte line for the coalesced stream, 66.0 / 66.6 / 67.3 B per line when a lane reads 8 / 24 / 128 bytes of a line of its own "
+                                            "(lines in random order), 64.0 B with the lines in order -- the counter counts LINES x 64 B whatever the width of the access, so the "
+                                            "streaming factor holds for the record gathers of k_assemble_gather to within 5 % (it over-reports them by that much)"))
 # keys = kernel names without template arguments (those changed between rounds; r01 profiles carry the r01 spellings)
 names = {"k_assemble_gather": "k_assemble_gather", "k_spmv": "k_spmv", "k_mf_cluster": "k_mf_cluster", "k_mf_rows": "k_mf_rows"}
 for k, full in names.items():

@@ -1,6 +1,6 @@
 """Checks of the COMPILED pybind11 modules (meshfem_amd/pybind: mesh, tensors, sparse_matrices, periodic_homogenization -- the
 reference's extension-module names and signatures, src/python_bindings/*.cc). Run as a script in its own interpreter
-(tests/test_pybind_modules.py): the pure-Python shims of meshfem_amd/compat use the same top-level module names.
+(tests/test_pybind_modules.py), so that their top-level names (`mesh`, `tensors`, ...) shadow nothing in the test process.
     python tests/pybind_checks.py cpu | gpu"""
 import os
 import pickle

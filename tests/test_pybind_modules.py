@@ -1,6 +1,6 @@
 """The compiled pybind11 modules of meshfem_amd/pybind (mesh, tensors, sparse_matrices, periodic_homogenization: the reference's
 extension-module names and signatures) -- checked in an interpreter of their own (tests/pybind_checks.py), because the
-pure-Python shims of meshfem_amd/compat claim the same top-level module names in this one (tests/test_compat_modules.py)."""
+module names `mesh`, `tensors`, ... are too generic to put on the path of the whole test process."""
 import os
 import subprocess
 import sys
