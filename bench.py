@@ -671,6 +671,8 @@ def run_multi(args):
     if shared and not (args.ranks_per_gpu_ok or os.environ.get("MFH_BENCH_SHARE_GPUS")):
         raise SystemExit("bench.py --gpus %d needs %d GPUs, %d visible (pass --ranks-per-gpu-ok to share them)" % (world, world, ndev))
     device = local % max(1, ndev)
+    if shared:      # several ranks per device: keep the per-process cache of released device blocks small (mfh_pool.cpp), the ranks' own data nearly fills the device
+        os.environ.setdefault("MFH_DEVICE_CACHE_MB", "2048")
     torch.cuda.set_device(device)
     if shared:
         dist.init_process_group("gloo", rank=rank, world_size=world)

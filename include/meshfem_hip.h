@@ -475,8 +475,9 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
  *   products differ between two runs; with the option the waves of a workgroup add in wave order (assembly, interface rows of the
  *   operator) or into accumulators of their own summed in wave order (element blocks of the operator), every dot product goes through a
  *   fixed two-stage tree, and the PCG runs the classic loop. Two assemblies give identical bits, two solves identical displacements.
- *   Preconditioners: block-Jacobi / Jacobi / none (the coarse levels of the two-level and multigrid preconditioners are built with
- *   unordered atomics: MFH_ERR_UNSUPPORTED); the global-atomic assembly variant is refused. Measured cost: bench.py variants.deterministic),
+ *   Every preconditioner (the Galerkin products of the coarse levels keep one accumulator table per wave, the transfers between the
+ *   aggregate levels gather); the global-atomic assembly variant and matrix_free_mode 1 - 3 are refused. Measured cost: bench.py
+ *   variants.deterministic),
  * "dist_profile" (1: time the halo exchange against the interior work in the first operator applications of every mfh_dist_solve,
  *   see mfh_dist_get_stats),
  * "symbolic_device", "topology_device", "tl_probe", "tl_host_inverse" (validation variants of setup phases) */

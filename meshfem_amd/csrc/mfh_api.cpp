@@ -467,9 +467,6 @@ void ensure_fixed_uploaded(mfh_ctx *c) {
 
 void ensure_precond(mfh_ctx *c) {
     if (c->deterministic) {
-        if (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID)
-            throw Error(MFH_ERR_UNSUPPORTED, "option deterministic: the coarse levels of the two-level / multigrid preconditioners are built with unordered atomics; "
-                                             "use MFH_PRECOND_BLOCK_JACOBI (or JACOBI / NONE) for bit-reproducible solves");
         if (c->use_mf() && c->mfModeEff() != 4)
             throw Error(MFH_ERR_UNSUPPORTED, "option deterministic: the matrix-free operator must be the cluster variant (matrix_free_mode 4) or the assembled SpMV (matrix_free 0)");
     }
@@ -1991,6 +1988,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "mg_dense_max") { c->mgDenseMax = std::max(8, (int)value); c->mg.valid = false; }
     else if (k2 == "mg_steps_agg") c->mgStepsAgg = std::max(1, (int)value);
     else if (k2 == "mg_ratio_agg") { require(value > 0 && value < 1, MFH_ERR_INVALID, "mg_ratio_agg must lie in (0, 1)"); c->mgRatioAgg = value; }
+    else if (k2 == "mg_anisotropic_bins") { c->mgAnisotropicBins = value != 0; c->mg.valid = false; }
     else if (k2 == "mg_agg_nodes") { c->mgAggNodes = std::max(0, (int)value); c->mg.valid = false; }
     else if (k2 == "asm_packed_codes") { c->asmPackedCodes = value != 0; invalidate_symbolic(c); }
     else if (k2 == "chunk_slots") { c->chunkSlots = (int)value; invalidate_symbolic(c); }

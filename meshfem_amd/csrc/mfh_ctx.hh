@@ -22,9 +22,9 @@ struct mfh_ctx {
     // and therefore reproducible (LinearElasticity.hh:1454-1455; the one place that is not, it documents and switches off,
     // SparseMatrices.hh:288,319-324). Here the default kernels accumulate with LDS / global atomics in whatever order the waves arrive; the
     // option orders them: the waves of a workgroup add one after the other (k_assemble_gather, k_mf_rows) or into arrays of their own
-    // (k_mf_cluster), the dot products go through a fixed two-stage tree (commit_sums), the PCG runs the classic loop. Block-Jacobi /
-    // Jacobi / no preconditioner; contexts that own all their rows and row-partitioned ones (whose all-reduce is in rank order with the
-    // peer transfers).
+    // (k_mf_cluster, k_tl_rap_agg), the dot products go through a fixed two-stage tree (commit_sums), the PCG runs the classic loop; the
+    // transfers and Galerkin products between the aggregate levels of the multigrid hierarchy gather (no atomics) in every mode. All
+    // preconditioners; contexts that own all their rows and row-partitioned ones (whose all-reduce is in rank order with the peer transfers).
     bool deterministic = false;
     DBuf<double> detPartials;
     DBuf<unsigned> detCounter;
@@ -155,6 +155,7 @@ struct mfh_ctx {
         int64_t nAgg = 0;
         double H = 0, lmax = 0;
         DBuf<int32_t> nbr, parent, coord;     // neighbour table [nAgg][3^dim], parent aggregate on the next level, lattice coordinates [nAgg][3]
+        DBuf<int32_t> childPtr, childIdx;     // the inverse of `parent`: the aggregates of every parent, ascending (the transfers towards the parent gather)
         DBuf<double> A, Dinv, rel;            // stencil operator, inverse diagonal blocks, transfer data [nAgg][4] towards the parent
         DBuf<double> x, b, r, d, t;
         std::vector<int32_t> hCoord;
@@ -190,6 +191,7 @@ struct mfh_ctx {
     double mgOverCorrection = 1.5;                   // option "mg_over_correction": factor on the corrections prolonged from aggregate levels (piecewise-rigid
                                                      // coarse functions under-estimate smooth corrections; the cycle stays symmetric)
     int mgStepsAgg = 2; double mgRatioAgg = 0.2;     // options "mg_steps_agg" / "mg_ratio_agg": Chebyshev smoother of the aggregate levels
+    bool mgAnisotropicBins = false;                  // option "mg_anisotropic_bins": lattice bins of the aggregate levels with the elements' proportions (measured: no gain)
     int mgAggNodes = 0;                              // option "mg_agg_nodes": target DoFs per aggregate of the linear level's coarse space (0 = auto)
     // Chronopoulos-Gear PCG (mfh_solver.cpp): NR interleaved vectors
     DBuf<double> cgU, cgW, cgP, cgS, cgX, cgR, cgF, cgCtl, tlRcN, tlYcN;

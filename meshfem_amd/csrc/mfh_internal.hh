@@ -295,7 +295,8 @@ void dof_positions_device(int64_t nNode, int dim, const int32_t *dDofForNode, co
                           DBuf<double> &out);
 void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targetNodes, hipStream_t s, Aggregates &A,
                              DBuf<int32_t> &dAggOfDof, DBuf<double> &dRelPos, DBuf<int32_t> &dAggPtr, DBuf<int32_t> &dDofsByAgg,
-                             const double *globalBox = nullptr, int64_t globalCount = 0, bool fullLattice = false);
+                             const double *globalBox = nullptr, int64_t globalCount = 0, bool fullLattice = false, const double *aspect = nullptr);
+void element_extent_sums_device(int dim, int64_t nElem, int npe, const int32_t *dElemNodes, const double *dPos, hipStream_t s, double out[3]);
 void bounding_box_device(int dim, int64_t nDoF, const double *dPos, hipStream_t s, double mn[3], double mx[3]);
 void wrap_positions_device(int64_t n, int dim, const double box[6], hipStream_t s, double *dPos, int skipDims = 0);
 bool spd_inverse_inplace(int64_t n, double *A);
@@ -489,10 +490,10 @@ void launch_st_spmv(int dim, int64_t nAgg, const int32_t *nbr, const double *A, 
 void launch_st_dinv(int dim, int64_t nAgg, const double *A, double *Dinv, hipStream_t s);
 void launch_st_cheb(int dim, int64_t nAgg, const double *Dinv, const double *rin, const double *t, double *rout, double *d, double *x, double a, double b,
                     bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s);
-void launch_st_rap(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const int32_t *parent, const double *rel, const int32_t *coordC, double *Ac,
-                   const int *wrapNbC, hipStream_t s);
-void launch_st_restrict(int dim, int64_t nAgg, const int32_t *parent, const double *rel, const double *r, const double *t, double *rc, const double *scal, int it,
-                        const double *stop, hipStream_t s);
+void launch_st_rap(int dim, int64_t nParents, const int32_t *childPtr, const int32_t *childIdx, const int32_t *nbr, const double *A, const int32_t *parent,
+                   const double *rel, const int32_t *coordC, double *Ac, const int *wrapNbC, hipStream_t s);
+void launch_st_restrict(int dim, int64_t nParents, const int32_t *childPtr, const int32_t *childIdx, const double *rel, const double *r, const double *t, double *rc,
+                        const double *scal, int it, const double *stop, hipStream_t s);
 void launch_st_prolong_add(int dim, int64_t nAgg, const int32_t *parent, const double *rel, const double *xc, double *x, double alpha, const double *scal, int it,
                            const double *stop, hipStream_t s);
 void launch_st_to_dense(int dim, int64_t nAgg, const int32_t *nbr, const double *A, double *Ad, hipStream_t s);

@@ -1512,6 +1512,13 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
     // Option "deterministic": the order in which the four waves reach a shared accumulator changes from run to run, so every wave sums
     // into an array of its own (inside ONE wave the hardware applies the lanes of an LDS atomic in a fixed order) and the write-out adds
     // the four in wave order.
+    // LDS layout of the staged x and of the accumulators: [row][DIM] (default) or, with -DMFH_XS_SOA (experiment: fewer bank conflicts
+    // on the 8-byte gathers by local row index?), [DIM][row]
+#ifdef MFH_XS_SOA
+#define LIDX(t, d) ((d) * a.clMaxLocal + (t))
+#else
+#define LIDX(t, d) ((t) * DIM + (d))
+#endif
     const bool det = a.det.partials != nullptr;
     const int accStride = a.clMaxLocal * DIM;
     double *xs = clacc + (det ? 4 : 1) * accStride;
@@ -1536,8 +1543,8 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
             const int64_t row = a.clEntryRow[u0 + t];
 #pragma unroll
             for (int d = 0; d < DIM; ++d) {
-                xs[t * DIM + d] = x[row * DIM + d]; clacc[t * DIM + d] = 0.0;
-                if (det) { clacc[accStride + t * DIM + d] = 0.0; clacc[2 * accStride + t * DIM + d] = 0.0; clacc[3 * accStride + t * DIM + d] = 0.0; }
+                xs[LIDX(t, d)] = x[row * DIM + d]; clacc[LIDX(t, d)] = 0.0;
+                if (det) { clacc[accStride + LIDX(t, d)] = 0.0; clacc[2 * accStride + LIDX(t, d)] = 0.0; clacc[3 * accStride + LIDX(t, d)] = 0.0; }
             }
         }
         __syncthreads();
@@ -1557,11 +1564,11 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
             for (int j = 0; j < NPE; ++j) {
                 li[j] = a.clLocalIdx[e * NPE + j];
 #pragma unroll
-                for (int d = 0; d < DIM; ++d) xl[j][d] = xs[li[j] * DIM + d];
+                for (int d = 0; d < DIM; ++d) xl[j][d] = xs[LIDX(li[j], d)];
             }
             auto emit = [&](int j, const double *fv) {
 #pragma unroll
-                for (int d = 0; d < DIM; ++d) unsafeAtomicAdd(&accw[li[j] * DIM + d], fv[d]);
+                for (int d = 0; d < DIM; ++d) unsafeAtomicAdd(&accw[LIDX(li[j], d)], fv[d]);
             };
             if (GEOV) {
                 const int32_t *en = a.elemNodes + e * NPE;
@@ -1584,21 +1591,21 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
             if (det) {
 #pragma unroll
                 for (int d = 0; d < DIM; ++d)
-                    clacc[t * DIM + d] = ((clacc[t * DIM + d] + clacc[accStride + t * DIM + d]) + clacc[2 * accStride + t * DIM + d]) + clacc[3 * accStride + t * DIM + d];
+                    clacc[LIDX(t, d)] = ((clacc[LIDX(t, d)] + clacc[accStride + LIDX(t, d)]) + clacc[2 * accStride + LIDX(t, d)]) + clacc[3 * accStride + LIDX(t, d)];
             }
             if (dest >= 0) {
 #pragma unroll
-                for (int d = 0; d < DIM; ++d) a.clIfaceBuf[(int64_t)dest * DIM + d] = clacc[t * DIM + d];
+                for (int d = 0; d < DIM; ++d) a.clIfaceBuf[(int64_t)dest * DIM + d] = clacc[LIDX(t, d)];
                 continue;
             }
             const int64_t row = a.clEntryRow[u0 + t];
 #pragma unroll
             for (int d = 0; d < DIM; ++d) {
                 const int64_t gi = row * DIM + d;
-                double v = clacc[t * DIM + d];
+                double v = clacc[LIDX(t, d)];
                 if (a.fixedMask && a.fixedMask[gi]) v = 0.0;
                 y[gi] = v;
-                if (dotOut) dot += v * xs[t * DIM + d];     // x of this row is still staged in LDS: no second (scattered) global read
+                if (dotOut) dot += v * xs[LIDX(t, d)];     // x of this row is still staged in LDS: no second (scattered) global read
             }
         }
         __syncthreads();
@@ -1610,6 +1617,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
         commit_sums<1>(v, tg, a.det, red);
     }
 }
+#undef LIDX
 
 // y_row = sum over the (element, node) pairs of the row of their nodal force: a pure gather-sum
 template <int DIM, int PCG>

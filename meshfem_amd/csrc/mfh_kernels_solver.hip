@@ -258,7 +258,7 @@ __global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__r
                                                      const int32_t *__restrict__ binCoord /* nAgg x 3, may be null */,
                                                      const int32_t *__restrict__ rowPtr, const int32_t *__restrict__ colIdx,
                                                      const double *__restrict__ vals, double *__restrict__ Ac, int upperOnly, int64_t nOwnedRows,
-                                                     double *__restrict__ stencil, int *__restrict__ farCount, int wrapX, int wrapY, int wrapZ) {
+                                                     double *__restrict__ stencil, int *__restrict__ farCount, int wrapX, int wrapY, int wrapZ, int det) {
     // wrapA > 2: the lattice is periodic along that axis with wrapA bins (periodic DoF maps: elements at the seam couple the first and
     // the last bin), offsets +-(wrapA - 1) count as -+1
     // stencil != null (multigrid hierarchy, mfh_multigrid.cpp): the rows (a, .) go to the lattice-stencil storage
@@ -272,13 +272,18 @@ __global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__r
     constexpr int NB = DIM * DIM;
     constexpr int NM = DIM == 3 ? 6 : 3;
     constexpr int NSLOT = DIM == 3 ? 27 : 9;
-    __shared__ double nbr[NSLOT * NM * NM];
+    // det (option "deterministic"): the waves of the workgroup add into neighbour tables of their OWN, summed in wave order at the end --
+    // between waves the order of LDS atomics is a matter of timing (inside one wave the hardware applies the lanes in a fixed order)
+    extern __shared__ __attribute__((aligned(16))) double rapLds[];   // neighbour tables [det ? nWaves : 1][NSLOT NM^2] + diagRed [16 NM^2]
     __shared__ int nbrAgg[NSLOT];
-    __shared__ double diagRed[16 * NM * NM];
     const int a = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nWaves = blockDim.x >> 6;
+    const int nTab = det ? nWaves : 1;
+    double *nbrAll = rapLds;
+    double *nbr = rapLds + (det ? wave : 0) * (NSLOT * NM * NM);
+    double *diagRed = rapLds + nTab * (NSLOT * NM * NM);
     const int64_t m = (int64_t)t.nAgg * NM;
-    for (int q = threadIdx.x; q < NSLOT * NM * NM; q += blockDim.x) nbr[q] = 0.0;
+    for (int q = threadIdx.x; q < nTab * NSLOT * NM * NM; q += blockDim.x) nbrAll[q] = 0.0;
     if (threadIdx.x < NSLOT) nbrAgg[threadIdx.x] = -1;
     __syncthreads();
     int ca[3] = {0, 0, 0};
@@ -358,6 +363,15 @@ __global__ void __launch_bounds__(512) k_tl_rap_agg(TLArgs t, const int32_t *__r
 #pragma unroll
         for (int q = 0; q < NM * NM; ++q) diagRed[wave * NM * NM + q] = acc[q];
     __syncthreads();
+    if (det) {
+        for (int q = threadIdx.x; q < NSLOT * NM * NM; q += blockDim.x) {
+            double v = nbrAll[q];
+            for (int w = 1; w < nWaves; ++w) v += nbrAll[w * (NSLOT * NM * NM) + q];
+            nbrAll[q] = v;
+        }
+        __syncthreads();
+        nbr = nbrAll;
+    }
     if (stencil) {
         constexpr int CENTRE = NSLOT / 2;
         for (int q = threadIdx.x; q < NSLOT * NM * NM; q += blockDim.x) {
@@ -1492,61 +1506,88 @@ __global__ void __launch_bounds__(256) k_st_cheb(int64_t nAgg, const double *__r
     }
 }
 
-// Galerkin product between two aggregate levels: Ac[parent(a)][offset] += T_a^T A[a][slot] T_b
+// Galerkin product between two aggregate levels: Ac[p][offset] = sum over the children a of p and their stencil slots towards a child b of
+// the parent at that lattice offset of T_a^T A[a][slot] T_b. GATHER form: one lane per (parent, offset) walks the parent's children in
+// index order and keeps the 6 x 6 sum in registers -- no atomics, no zero fill, the same bits on every run (the scatter form this replaces
+// added with unsafeAtomicAdd in arrival order).
 template <int DIM>
-__global__ void __launch_bounds__(256) k_st_rap(int64_t nAgg, const int32_t *__restrict__ nbr, const double *__restrict__ A, const int32_t *__restrict__ parent,
+__global__ void __launch_bounds__(256) k_st_rap(int64_t nParents, const int32_t *__restrict__ childPtr, const int32_t *__restrict__ childIdx,
+                                                const int32_t *__restrict__ nbr, const double *__restrict__ A, const int32_t *__restrict__ parent,
                                                 const double *__restrict__ rel, const int32_t *__restrict__ coordC, double *__restrict__ Ac, int wrapX, int wrapY,
                                                 int wrapZ) {
     constexpr int NM = StDims<DIM>::NM, NS = StDims<DIM>::NS;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nAgg * NS; q += (int64_t)gridDim.x * 256) {
-        const int64_t a = q / NS;
-        const int b = nbr[q];
-        if (b < 0) continue;
-        const int pa = parent[a], pb = parent[b];
-        const int dx = lattice_wrap(coordC[pb * 3] - coordC[pa * 3], wrapX), dy = lattice_wrap(coordC[pb * 3 + 1] - coordC[pa * 3 + 1], wrapY),
-                  dz = lattice_wrap(coordC[pb * 3 + 2] - coordC[pa * 3 + 2], wrapZ);
-        const int cs = (dx + 1) + 3 * (dy + 1) + (DIM == 3 ? 9 * (dz + 1) : 0);
-        const double *B = A + q * NM * NM;
-        // W = B T_b (columns: parent modes of b), then C = T_a^T W
-        double W[NM][NM];
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nParents * NS; q += (int64_t)gridDim.x * 256) {
+        const int64_t pa = q / NS;
+        const int cs = (int)(q - pa * NS);
+        double C[NM][NM];
 #pragma unroll
-        for (int l = 0; l < NM; ++l) {
-            double e[NM], tc[NM];
+        for (int k = 0; k < NM; ++k)
 #pragma unroll
-            for (int m = 0; m < NM; ++m) e[m] = m == l ? 1.0 : 0.0;
-            st_transfer<DIM>(rel + (int64_t)b * 4, e, tc);
+            for (int l = 0; l < NM; ++l) C[k][l] = 0.0;
+        for (int ci = childPtr[pa]; ci < childPtr[pa + 1]; ++ci) {
+            const int64_t a = childIdx[ci];
+            for (int slot = 0; slot < NS; ++slot) {
+                const int b = nbr[a * NS + slot];
+                if (b < 0) continue;
+                const int pb = parent[b];
+                const int dx = lattice_wrap(coordC[pb * 3] - coordC[pa * 3], wrapX), dy = lattice_wrap(coordC[pb * 3 + 1] - coordC[pa * 3 + 1], wrapY),
+                          dz = lattice_wrap(coordC[pb * 3 + 2] - coordC[pa * 3 + 2], wrapZ);
+                if ((dx + 1) + 3 * (dy + 1) + (DIM == 3 ? 9 * (dz + 1) : 0) != cs) continue;
+                const double *B = A + (a * NS + slot) * NM * NM;
+                // W = B T_b (columns: parent modes of b), then C += T_a^T W
+                double W[NM][NM];
 #pragma unroll
-            for (int k = 0; k < NM; ++k) {
-                double v = 0;
+                for (int l = 0; l < NM; ++l) {
+                    double e[NM], tc[NM];
 #pragma unroll
-                for (int m = 0; m < NM; ++m) v += B[k * NM + m] * tc[m];
-                W[k][l] = v;
+                    for (int m = 0; m < NM; ++m) e[m] = m == l ? 1.0 : 0.0;
+                    st_transfer<DIM>(rel + (int64_t)b * 4, e, tc);
+#pragma unroll
+                    for (int k = 0; k < NM; ++k) {
+                        double v = 0;
+#pragma unroll
+                        for (int m = 0; m < NM; ++m) v += B[k * NM + m] * tc[m];
+                        W[k][l] = v;
+                    }
+                }
+#pragma unroll
+                for (int l = 0; l < NM; ++l) {
+                    double col[NM], out[NM];
+#pragma unroll
+                    for (int k = 0; k < NM; ++k) { col[k] = W[k][l]; out[k] = 0.0; }
+                    st_transfer_T<DIM>(rel + a * 4, col, out);
+#pragma unroll
+                    for (int k = 0; k < NM; ++k) C[k][l] += out[k];
+                }
             }
         }
 #pragma unroll
-        for (int l = 0; l < NM; ++l) {
-            double col[NM], out[NM];
+        for (int k = 0; k < NM; ++k)
 #pragma unroll
-            for (int k = 0; k < NM; ++k) { col[k] = W[k][l]; out[k] = 0.0; }
-            st_transfer_T<DIM>(rel + a * 4, col, out);
-#pragma unroll
-            for (int k = 0; k < NM; ++k) unsafeAtomicAdd(&Ac[(((int64_t)pa * NS + cs) * NM + k) * NM + l], out[k]);
-        }
+            for (int l = 0; l < NM; ++l) Ac[(q * NM + k) * NM + l] = C[k][l];
     }
 }
 
+// restriction between two aggregate levels, gather form: rc[p] = sum over the children a of p, in index order, of T_a^T (r - t)[a]
 template <int DIM>
-__global__ void __launch_bounds__(256) k_st_restrict(int64_t nAgg, const int32_t *__restrict__ parent, const double *__restrict__ rel, const double *__restrict__ r,
-                                                     const double *__restrict__ t, double *__restrict__ rc, MgGate g) {
+__global__ void __launch_bounds__(256) k_st_restrict(int64_t nParents, const int32_t *__restrict__ childPtr, const int32_t *__restrict__ childIdx,
+                                                     const double *__restrict__ rel, const double *__restrict__ r, const double *__restrict__ t,
+                                                     double *__restrict__ rc, MgGate g) {
     constexpr int NM = StDims<DIM>::NM;
     if (mg_closed(g)) return;
-    for (int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x; a < nAgg; a += (int64_t)gridDim.x * 256) {
-        double ch[NM], out[NM];
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nParents; p += (int64_t)gridDim.x * 256) {
+        double out[NM];
 #pragma unroll
-        for (int k = 0; k < NM; ++k) { ch[k] = r[a * NM + k] - (t ? t[a * NM + k] : 0.0); out[k] = 0.0; }
-        st_transfer_T<DIM>(rel + a * 4, ch, out);
+        for (int k = 0; k < NM; ++k) out[k] = 0.0;
+        for (int ci = childPtr[p]; ci < childPtr[p + 1]; ++ci) {
+            const int64_t a = childIdx[ci];
+            double ch[NM];
 #pragma unroll
-        for (int k = 0; k < NM; ++k) unsafeAtomicAdd(&rc[(int64_t)parent[a] * NM + k], out[k]);
+            for (int k = 0; k < NM; ++k) ch[k] = r[a * NM + k] - (t ? t[a * NM + k] : 0.0);
+            st_transfer_T<DIM>(rel + a * 4, ch, out);
+        }
+#pragma unroll
+        for (int k = 0; k < NM; ++k) rc[p * NM + k] = out[k];
     }
 }
 
@@ -1709,8 +1750,12 @@ void launch_tl_rap_agg(const TLArgs &t, const int32_t *aggPtr, const int32_t *do
                        const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly, int64_t nOwnedRows, double *stencil,
                        int *farCount, const int *wrapNb) {
     const int wx = wrapNb ? wrapNb[0] : 0, wy = wrapNb ? wrapNb[1] : 0, wz = wrapNb ? wrapNb[2] : 0;
-    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap_agg<3>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows, stencil, farCount, wx, wy, wz);
-    else hipLaunchKernelGGL(k_tl_rap_agg<2>, dim3(t.nAgg), dim3(512), 0, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows, stencil, farCount, wx, wy, wz);
+    const int det = t_det.partials ? 1 : 0;
+    const int NMl = t.dim == 3 ? 6 : 3, NSl = t.dim == 3 ? 27 : 9;
+    const int threads = det ? 256 : 512;                    // deterministic: four waves, four neighbour tables (35 KB of LDS)
+    const size_t lds = ((size_t)(det ? threads / 64 : 1) * NSl * NMl * NMl + (size_t)16 * NMl * NMl) * sizeof(double);
+    if (t.dim == 3) hipLaunchKernelGGL(k_tl_rap_agg<3>, dim3(t.nAgg), dim3(threads), lds, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows, stencil, farCount, wx, wy, wz, det);
+    else hipLaunchKernelGGL(k_tl_rap_agg<2>, dim3(t.nAgg), dim3(threads), lds, s, t, aggPtr, dofsByAgg, binCoord, rowPtr, colIdx, vals, Ac, upperOnly ? 1 : 0, nOwnedRows, stencil, farCount, wx, wy, wz, det);
     if (stencil) { CHECK_LAUNCH(); return; }
     if (upperOnly) {
         const int64_t m = (int64_t)t.nAgg * (t.dim == 3 ? 6 : 3);
@@ -1953,14 +1998,14 @@ void launch_st_cheb(int dim, int64_t nAgg, const double *Dinv, const double *rin
                     bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s) {
     ST_DISPATCH(dim, k_st_cheb, grid_for(nAgg), nAgg, Dinv, rin, t, rout, d, x, a, b, first ? 1 : 0, assign ? 1 : 0, mk_gate(scal, it, stop));
 }
-void launch_st_rap(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const int32_t *parent, const double *rel, const int32_t *coordC, double *Ac,
-                   const int *wrapNbC, hipStream_t s) {
+void launch_st_rap(int dim, int64_t nParents, const int32_t *childPtr, const int32_t *childIdx, const int32_t *nbr, const double *A, const int32_t *parent,
+                   const double *rel, const int32_t *coordC, double *Ac, const int *wrapNbC, hipStream_t s) {
     const int wx = wrapNbC ? wrapNbC[0] : 0, wy = wrapNbC ? wrapNbC[1] : 0, wz = wrapNbC ? wrapNbC[2] : 0;
-    ST_DISPATCH(dim, k_st_rap, grid_for(nAgg * 27), nAgg, nbr, A, parent, rel, coordC, Ac, wx, wy, wz);
+    ST_DISPATCH(dim, k_st_rap, grid_for(nParents * 27), nParents, childPtr, childIdx, nbr, A, parent, rel, coordC, Ac, wx, wy, wz);
 }
-void launch_st_restrict(int dim, int64_t nAgg, const int32_t *parent, const double *rel, const double *r, const double *t, double *rc, const double *scal, int it,
-                        const double *stop, hipStream_t s) {
-    ST_DISPATCH(dim, k_st_restrict, grid_for(nAgg), nAgg, parent, rel, r, t, rc, mk_gate(scal, it, stop));
+void launch_st_restrict(int dim, int64_t nParents, const int32_t *childPtr, const int32_t *childIdx, const double *rel, const double *r, const double *t, double *rc,
+                        const double *scal, int it, const double *stop, hipStream_t s) {
+    ST_DISPATCH(dim, k_st_restrict, grid_for(nParents), nParents, childPtr, childIdx, rel, r, t, rc, mk_gate(scal, it, stop));
 }
 void launch_st_prolong_add(int dim, int64_t nAgg, const int32_t *parent, const double *rel, const double *xc, double *x, double alpha, const double *scal, int it,
                            const double *stop, hipStream_t s) {

@@ -179,19 +179,32 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
     const int64_t nOwnD = c1->sym.nRows;
     double box[6] = {0, 0, 0, 0, 0, 0};
     int64_t globalCount = 0;
+    // Mean element size per axis (option "mg_anisotropic_bins", default on): on stretched elements -- the reference's own cantilever bars are
+    // 5 2^i x 2^i x 2^i hexes scaled to a bounding box, examples/cantilever/gen.sh:5 -- cubic bins as wide as the longest element edge hold
+    // hundreds of elements across the short directions and the coarse space is useless (16 : 1 : 1: 370 iterations); bins
+    // with the elements' proportions keep about the same number of elements across a bin along every axis.
+    double extSum[3] = {0, 0, 0}, extCount = (double)c1->mesh.nElem, aspectBuf[3] = {1, 1, 1};
+    const double *aspect = nullptr;
+    if (c->mgAnisotropicBins && c1->haveMesh && c1->mesh.nElem > 0)
+        element_extent_sums_device(dim, c1->mesh.nElem, c1->mesh.npe, c1->dElemNodes.p, c1->dVertPos.p, s, extSum);
     if (distributed) {
         const int world = dist_world(c1), rank = dist_rank(c1);
         double mn[3], mx[3];
         // (with a DoF map: the box of the local NODES -- a DoF's position is that of whichever periodic image this rank holds)
         if (!c1->dofForNode.empty()) bounding_box_device(dim, c1->mesh.nNode, c1->dVertPos.p, s, mn, mx);
         else bounding_box_device(dim, nOwnD, dPos, s, mn, mx);
-        std::vector<double> slots((size_t)world * 7, 0.0);
+        std::vector<double> slots((size_t)world * 7 + 4, 0.0);
         for (int a = 0; a < 3; ++a) { slots[(size_t)rank * 7 + a] = a < dim ? mn[a] : 0.0; slots[(size_t)rank * 7 + 3 + a] = a < dim ? mx[a] : 0.0; }
         slots[(size_t)rank * 7 + 6] = (double)nOwnD;
+        // the elements' extents: summed over the ranks (halo elements are counted by both neighbours: a mean, not a census)
+        for (int a = 0; a < 3; ++a) slots[(size_t)world * 7 + a] = extSum[a];
+        slots[(size_t)world * 7 + 3] = (double)c1->mesh.nElem;
         DBuf<double> dSlots;
         dSlots.upload(slots, s);
         dist_allreduce(c1, dSlots.p, (int64_t)slots.size());
         dSlots.download(slots.data(), slots.size(), s);
+        for (int a = 0; a < 3; ++a) extSum[a] = slots[(size_t)world * 7 + a];
+        extCount = slots[(size_t)world * 7 + 3];
         for (int a = 0; a < 3; ++a) { box[a] = 1e300; box[3 + a] = -1e300; }
         for (int r = 0; r < world; ++r) {
             if (slots[(size_t)r * 7 + 6] <= 0) continue;
@@ -209,6 +222,11 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
         one.download(&v, 1, s);
         return v;
     };
+    if (c->mgAnisotropicBins && extCount > 0) {
+        double lo = 1e300, hi = 0;
+        for (int a = 0; a < dim; ++a) { aspectBuf[a] = extSum[a] / extCount; lo = std::min(lo, aspectBuf[a]); hi = std::max(hi, aspectBuf[a]); }
+        if (lo > 0 && hi > 1.25 * lo) aspect = aspectBuf;      // (isotropic meshes keep the cubic bins, bit for bit)
+    }
     std::unique_ptr<mfh_ctx::AggLevel> L0;
     for (int attempt = 0; attempt < 4; ++attempt) {
         Aggregates A;
@@ -217,10 +235,10 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
             DBuf<int32_t> tmpPtr, tmpList, tmpAgg;
             DBuf<double> tmpRel;
             Aggregates Aown;
-            build_aggregates_device(dim, nD, dPos, target, s, A, G.aggOfDof2, G.relPos2, tmpPtr, tmpList, box, globalCount, true);
-            build_aggregates_device(dim, nOwnD, dPos, target, s, Aown, tmpAgg, tmpRel, G.aggPtr2, G.dofsByAgg2, box, globalCount, true);
+            build_aggregates_device(dim, nD, dPos, target, s, A, G.aggOfDof2, G.relPos2, tmpPtr, tmpList, box, globalCount, true, aspect);
+            build_aggregates_device(dim, nOwnD, dPos, target, s, Aown, tmpAgg, tmpRel, G.aggPtr2, G.dofsByAgg2, box, globalCount, true, aspect);
         } else
-            build_aggregates_device(dim, nD, dPos, target, s, A, G.aggOfDof2, G.relPos2, G.aggPtr2, G.dofsByAgg2);
+            build_aggregates_device(dim, nD, dPos, target, s, A, G.aggOfDof2, G.relPos2, G.aggPtr2, G.dofsByAgg2, nullptr, 0, false, aspect);
         L0.reset(new mfh_ctx::AggLevel());
         L0->nAgg = A.nAgg; L0->H = A.H; L0->hCoord = A.binCoord; L0->hCentre = A.centroid;
         for (int k2 = 0; k2 < 3; ++k2) {
@@ -279,10 +297,18 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
         }
         F.parent.upload(parent, s);
         F.rel.upload(rel, s);
+        {   // children of every parent in ascending order: the Galerkin product and the restriction gather over them (no atomics)
+            std::vector<int32_t> cp((size_t)Cn->nAgg + 1, 0), ci((size_t)F.nAgg);
+            for (int64_t a = 0; a < F.nAgg; ++a) ++cp[(size_t)parent[(size_t)a] + 1];
+            for (int64_t p = 0; p < Cn->nAgg; ++p) cp[(size_t)p + 1] += cp[(size_t)p];
+            std::vector<int32_t> fill(cp.begin(), cp.end() - 1);
+            for (int64_t a = 0; a < F.nAgg; ++a) ci[(size_t)fill[(size_t)parent[(size_t)a]]++] = (int32_t)a;
+            F.childPtr.upload(cp, s);
+            F.childIdx.upload(ci, s);
+        }
         build_neighbours(dim, *Cn, s);
         Cn->A.alloc((size_t)Cn->nAgg * NS * NM * NM);
-        Cn->A.zero(s);
-        k::launch_st_rap(dim, F.nAgg, F.nbr.p, F.A.p, F.parent.p, F.rel.p, Cn->coord.p, Cn->A.p, Cn->wrap, s);
+        k::launch_st_rap(dim, Cn->nAgg, F.childPtr.p, F.childIdx.p, F.nbr.p, F.A.p, F.parent.p, F.rel.p, Cn->coord.p, Cn->A.p, Cn->wrap, s);
         G.agg.push_back(std::move(Cn));
     }
     lap("coarser aggregate levels");
@@ -317,7 +343,7 @@ void agg_cycle(mfh_ctx *c, size_t l, const double *scal, int it, const double *s
     auto &G = c->mg;
     mfh_ctx::AggLevel &L = *G.agg[l];
     hipStream_t s = c->stream;
-    const int dim = c->dim(), NM = dim == 3 ? 6 : 3;
+    const int dim = c->dim();
     if (l + 1 == G.agg.size()) {
         k::launch_tl_gemv(G.denseM, G.denseLd, G.denseInv.p, L.b.p, L.x.p, s);
         return;
@@ -327,8 +353,7 @@ void agg_cycle(mfh_ctx *c, size_t l, const double *scal, int it, const double *s
     mfh_ctx::AggLevel &Cn = *G.agg[l + 1];
     const double *ra = nullptr, *rb = nullptr;
     chebyshev(ops, L.b.p, L.x.p, true, true, L.r.p, L.d.p, L.t.p, &ra, &rb);
-    k::launch_mg_zero(Cn.nAgg * NM, Cn.b.p, scal, it, stop, s);
-    k::launch_st_restrict(dim, L.nAgg, L.parent.p, L.rel.p, ra, rb, Cn.b.p, scal, it, stop, s);
+    k::launch_st_restrict(dim, Cn.nAgg, L.childPtr.p, L.childIdx.p, L.rel.p, ra, rb, Cn.b.p, scal, it, stop, s);
     agg_cycle(c, l + 1, scal, it, stop);
     k::launch_st_prolong_add(dim, L.nAgg, L.parent.p, L.rel.p, Cn.x.p, L.x.p, c->mgOverCorrection, scal, it, stop, s);
     chebyshev(ops, L.b.p, L.x.p, false, false, L.r.p, L.d.p, L.t.p);
@@ -484,6 +509,7 @@ bool ensure_multigrid(mfh_ctx *c) {
     mfh_ctx *c1 = new mfh_ctx();
     G.coarse = c1;
     c1->device = c->device; c1->stream = c->stream; c1->ownStream = false; c1->nCU = c->nCU;
+    c1->deterministic = c->deterministic;     // its assembly orders the waves too; its launches use the calling thread's scratch (the parent's: k::t_det)
     c1->symbolicDevice = c->symbolicDevice; c1->topologyDevice = c->topologyDevice;
     HostMesh &m1 = c1->mesh;
     m1 = HostMesh();

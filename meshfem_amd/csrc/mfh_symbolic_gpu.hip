@@ -986,6 +986,42 @@ void build_mg_transfer_device(const HostMesh &m, const int32_t *dElemNodes, hipS
     MFH_HIP(hipStreamSynchronize(s));
 }
 
+namespace {
+// per-workgroup sums of the elements' extents along every axis (max - min over the element's corners)
+__global__ void __launch_bounds__(256) k_elem_extent(int64_t nElem, int dim, int npe, const int32_t *__restrict__ elemNodes, const double *__restrict__ pos,
+                                                     double *__restrict__ part) {
+    __shared__ double red[3 * 256];
+    double acc[3] = {0, 0, 0};
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nElem; e += (int64_t)gridDim.x * 256) {
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int k = 0; k <= dim; ++k) {
+            const int64_t v = elemNodes[e * npe + k];
+            for (int a = 0; a < dim; ++a) { const double x = pos[v * dim + a]; lo[a] = x < lo[a] ? x : lo[a]; hi[a] = x > hi[a] ? x : hi[a]; }
+        }
+        for (int a = 0; a < dim; ++a) acc[a] += hi[a] - lo[a];
+    }
+    for (int a = 0; a < 3; ++a) red[a * 256 + threadIdx.x] = acc[a];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) for (int a = 0; a < 3; ++a) red[a * 256 + threadIdx.x] += red[a * 256 + threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) part[blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x * 256];
+}
+}   // namespace
+// sum over the elements of their extent along every axis (the caller divides by the element count: the mean element size per axis)
+void element_extent_sums_device(int dim, int64_t nElem, int npe, const int32_t *dElemNodes, const double *dPos, hipStream_t s, double out[3]) {
+    const int grid = 512;
+    DBuf<double> part;
+    part.alloc((size_t)grid * 3);
+    hipLaunchKernelGGL(k_elem_extent, dim3(grid), dim3(256), 0, s, nElem, dim, npe, dElemNodes, dPos, part.p);
+    RP(hipGetLastError());
+    std::vector<double> hp((size_t)grid * 3);
+    part.download(hp.data(), hp.size(), s);
+    for (int a = 0; a < 3; ++a) out[a] = 0.0;
+    for (int b = 0; b < grid; ++b) for (int a = 0; a < dim; ++a) out[a] += hp[(size_t)b * 3 + a];
+}
+
 void bounding_box_device(int dim, int64_t nDoF, const double *dPos, hipStream_t s, double mn[3], double mx[3]) {
     const int gridMM = 1024;
     DBuf<double> part;
@@ -1004,7 +1040,7 @@ void bounding_box_device(int dim, int64_t nDoF, const double *dPos, hipStream_t 
 // reference point of its rigid-body modes is the bin centre -- the same numbers on every rank without any exchange.
 void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targetNodes, hipStream_t s, Aggregates &A,
                              DBuf<int32_t> &dAggOfDof, DBuf<double> &dRelPos, DBuf<int32_t> &dAggPtr, DBuf<int32_t> &dDofsByAgg,
-                             const double *globalBox, int64_t globalCount, bool fullLattice) {
+                             const double *globalBox, int64_t globalCount, bool fullLattice, const double *aspect) {
     A = Aggregates();
     A.dim = dim;
     // ---- bounding box
@@ -1015,8 +1051,17 @@ void build_aggregates_device(int dim, int64_t nDoF, const double *dPos, int targ
     double vol = 1;
     for (int a = 0; a < dim; ++a) vol *= std::max(mx[a] - mn[a], 1e-300);
     const double H = std::pow(vol * std::max(1, targetNodes) / (double)std::max<int64_t>(1, globalCount > 0 ? globalCount : nDoF), 1.0 / dim);
+    // aspect (may be null): relative element size per axis. The bins then have the proportions of the elements -- about the same number
+    // of elements across a bin along every axis -- at the same bin volume H^dim; the rigid-body modes keep the one length scale H.
+    double Ha[3] = {H, H, H};
+    if (aspect) {
+        double g = 1;
+        for (int a = 0; a < dim; ++a) g *= aspect[a];
+        g = std::pow(g, 1.0 / dim);
+        for (int a = 0; a < dim; ++a) Ha[a] = H * aspect[a] / g;
+    }
     int nb[3] = {1, 1, 1};
-    for (int a = 0; a < dim; ++a) nb[a] = std::max(1, (int)std::floor((mx[a] - mn[a]) / H + 0.5));
+    for (int a = 0; a < dim; ++a) nb[a] = std::max(1, (int)std::floor((mx[a] - mn[a]) / Ha[a] + 0.5));
     A.H = H;
     AggBins B{};
     for (int a = 0; a < 3; ++a) { B.mn[a] = a < dim ? mn[a] : 0.0; B.nb[a] = nb[a]; B.w[a] = a < dim ? (mx[a] - mn[a]) / nb[a] : 0.0; }

@@ -16,8 +16,30 @@ c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
 c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
 c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
 c.set_option("reembed", 1)
+import time
 for _ in range(5):
     c.assemble()
+c.dev_sync()
+t0 = time.perf_counter()
+for _ in range(20):
+    c.assemble()
+c.dev_sync()
+print("det %d: assembly pass %.3f ms" % (det, (time.perf_counter() - t0) / 20 * 1e3))
+if det:
+    c.set_option("deterministic", 0)
+    c.assemble(); c.assemble(); c.dev_sync()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        c.assemble()
+    c.dev_sync()
+    print("det %d -> 0 on the same context: assembly pass %.3f ms" % (det, (time.perf_counter() - t0) / 20 * 1e3))
+    c.set_option("deterministic", 1)
+    c.assemble(); c.assemble(); c.dev_sync()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        c.assemble()
+    c.dev_sync()
+    print("det 0 -> 1 on the same context: assembly pass %.3f ms" % ((time.perf_counter() - t0) / 20 * 1e3))
 try:
     c.sim_solve(rtol=1e-30, maxit=its)
 except M.MeshFEMHipError:

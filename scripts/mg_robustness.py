@@ -11,9 +11,12 @@ from meshfem_amd import grid
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 
 
-def run(name, box, material):
-    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], box)
+def run(name, box, material, cells=None, options=()):
+    cx, cy, cz = cells or (n, n, n)
+    V, T = grid.grid_tet_mesh(cx, cy, cz, [0, 0, 0], box)
     c = M.Context(0)
+    for k, v in options:
+        c.set_option(k, v)
     c.mesh_build(T, V, 2)
     material(c, V, T)
     big = 1e9
@@ -54,3 +57,10 @@ run("elements stretched 16 : 1 : 1", [16, 1, 1], iso(200.0, 0.35))
 run("stiff inclusion, contrast 1e2", [1, 1, 1], contrast(1e2))
 run("stiff inclusion, contrast 1e4", [1, 1, 1], contrast(1e4))
 run("soft inclusion, contrast 1e-4", [1, 1, 1], contrast(1e-4))
+# the reference's own cantilever bars (examples/cantilever/gen.sh:5: grid 5 2^i x 2^i x 2^i, cubic cells): a slender DOMAIN of isotropic elements
+run("reference bar_tet_2 (20 x 4 x 4 cells)", [5, 1, 1], iso(200.0, 0.35), cells=(20, 4, 4))
+run("reference bar_tet_4 (80 x 16 x 16 cells)", [5, 1, 1], iso(200.0, 0.35), cells=(80, 16, 16))
+# stretched elements again with the bins of the aggregate levels in the elements' proportions / a stronger fine smoother
+run("16 : 1 : 1, mg_anisotropic_bins 1", [16, 1, 1], iso(200.0, 0.35), options=(("mg_anisotropic_bins", 1),))
+run("16 : 1 : 1, 4 fine steps on [0.02, 1] lambda_max", [16, 1, 1], iso(200.0, 0.35), options=(("mg_steps_fine", 4), ("mg_ratio_fine", 0.02), ("mg_steps_coarse", 4), ("mg_ratio_coarse", 0.02)))
+run("16 : 1 : 1, 8 fine steps on [0.005, 1] lambda_max", [16, 1, 1], iso(200.0, 0.35), options=(("mg_steps_fine", 8), ("mg_ratio_fine", 0.005), ("mg_steps_coarse", 8), ("mg_ratio_coarse", 0.005)))

@@ -40,9 +40,17 @@ def _worker(rank, world, port, n, ret):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MFH_PEER_TIMEOUT_S", "120")
+    # eight processes share this device: the per-process cache of released device blocks (mfh_pool.cpp) would keep 8 x ~20 GB of setup
+    # temporaries next to the 141 GB the contexts hold -- more than the device has
+    os.environ.setdefault("MFH_DEVICE_CACHE_MB", "2048")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
     rec = dict(rank=rank)
+    t_start = time.time()
+
+    def note(msg):
+        if os.environ.get("MFH_TEST_VERBOSE"):
+            print("[rank %d %7.1f s] %s" % (rank, time.time() - t_start, msg), flush=True)
     try:
         dev = torch.device("cuda", 0)
         t0 = time.time()
@@ -54,6 +62,7 @@ def _worker(rank, world, port, n, ret):
         t0 = time.time(); c.assemble(); c.dev_sync(); rec["first_assembly_s"] = time.time() - t0
         rec.update(elements=int(len(lm.elem_nodes)), owned_nodes=int(lm.n_owned), local_nodes=int(lm.n_local), layers=list(lm.layers),
                    stored_blocks=int(c.matrix_storage()[1]))
+        note("assembled")
         comm = D.Comm.callbacks(c, rank, world)
         comm.selftest()
         peer_ok, peer_outcome = D.try_enable_peer(comm, rank, world, dev)
@@ -72,15 +81,19 @@ def _worker(rank, world, port, n, ret):
         problems = []
 
         def run(name, maxit):
+            note("barrier before " + name)
             dist.barrier()
+            note("solve " + name)
             t0 = time.time()
             try:
                 u, infos = solver.solve(f, rtol=1e-8, maxit=maxit)
+                note("solved %s: %d iterations" % (name, infos[0]["iterations"]))
                 i = infos[0]
                 d = u[0].reshape(-1, 3) - ur
                 rec[name] = dict(iterations=i["iterations"], converged=bool(i["converged"]), solve_s=i["solve_ms"] * 1e-3, wall_s=time.time() - t0,
                                  true_rel_residual=i["true_rel_residual"], err_sq=float((d ** 2).sum()), stats=c.dist_stats())
             except M.MeshFEMHipError as e:
+                note("FAILED %s: %s" % (name, e))
                 rec[name] = dict(error=str(e), info=dict(c.last_info))
                 problems.append((name, str(e)))
 
@@ -146,6 +159,7 @@ def test_config4_row_partitioned_over_8_ranks_matches_the_single_context_solve()
     one["wall_s"] = time.time() - t0
     del u, keys, order
     c.close()
+    M.device_cache_trim()        # this process keeps the device blocks its contexts release (mfh_pool.cpp): hand the 130 GB back before the ranks start
     torch.cuda.empty_cache()
     # ---- the same cube dealt out over 8 ranks on this device
     try:

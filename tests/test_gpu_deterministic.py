@@ -66,12 +66,21 @@ def test_two_assemblies_and_two_solves_give_identical_bits(dim, deg, n):
     u3 = c3.sim_solve(rtol=1e-10)
     assert np.linalg.norm(u3 - u1) <= 1e-7 * np.linalg.norm(u1)
     c3.close()
+    # the two-level and the multigrid preconditioner: their coarse levels are built and applied reproducibly too -- on this context and on a
+    # fresh one (hierarchy built from scratch)
+    for pre in (M.PRECOND_TWO_LEVEL, M.PRECOND_MULTIGRID):
+        c.set_preconditioner(pre)
+        ua = c.sim_solve(rtol=1e-10)
+        ita = c.last_info["iterations"]
+        ub = c.sim_solve(rtol=1e-10)
+        assert c.last_info["iterations"] == ita and np.array_equal(ua, ub), pre
+        assert np.linalg.norm(ua - u1) <= 1e-7 * np.linalg.norm(u1)
+        c4 = _context(M, grid, dim, deg, n, True)
+        c4.set_preconditioner(pre)
+        uc = c4.sim_solve(rtol=1e-10)
+        assert c4.last_info["iterations"] == ita and np.array_equal(ua, uc), pre
+        c4.close()
     # what the mode does not cover says so
-    c.set_preconditioner(M.PRECOND_MULTIGRID)
-    with pytest.raises(M.MeshFEMHipError) as e:
-        c.sim_solve(rtol=1e-8)
-    from meshfem_amd import _lib as L
-    assert e.value.code == L.ERR_UNSUPPORTED
     with pytest.raises(M.MeshFEMHipError):
         c.assemble(M.ASSEMBLE_ATOMIC)
     c.close()
@@ -95,13 +104,15 @@ def test_config2_assembled_twice_and_solved_twice_is_bit_identical():
     _, _, v2 = c.export_bsr()
     assert c.matrix_storage()[1] == 104436901 and v1.shape[0] >= 104436901 and np.array_equal(v1, v2)   # (the export mirrors the stored triangle)
     del v1, v2
-    c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
-    u1 = c.sim_solve(rtol=1e-8, maxit=20000)
-    i1 = dict(c.last_info)
-    u2 = c.sim_solve(rtol=1e-8, maxit=20000)
-    i2 = dict(c.last_info)
-    assert i1["converged"] and i1["iterations"] == i2["iterations"] and np.array_equal(u1, u2)
-    assert abs(np.abs(u1).max() - 0.03607) <= 2e-4
+    for pre in (M.PRECOND_BLOCK_JACOBI, M.PRECOND_MULTIGRID):
+        c.set_preconditioner(pre)
+        u1 = c.sim_solve(rtol=1e-8, maxit=20000)
+        i1 = dict(c.last_info)
+        u2 = c.sim_solve(rtol=1e-8, maxit=20000)
+        i2 = dict(c.last_info)
+        assert i1["converged"] and i1["iterations"] == i2["iterations"] and np.array_equal(u1, u2), pre
+        assert abs(np.abs(u1).max() - 0.03607) <= 2e-4
+    assert i1["iterations"] < 60                                         # the V-cycle's count, not block-Jacobi's 3 183
     c.close()
 
 
