@@ -464,6 +464,7 @@ def run_single(args):
             dtd = (time.perf_counter() - t0) / args.steps
             kd = c.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
             det = dict(ms_per_step=dtd * 1e3, elements_per_s=nE / dtd, kernel_ms=kd, step_cost_vs_default=dtd * 1e3 / ms_step, kernel_cost_vs_default=kd / k_ms,
+                       pass_timers=c.timing(), storage="upper" if c.matrix_storage()[0] else "full",
                        note="option deterministic 1: two runs give identical bits (tests/test_gpu_deterministic.py)")
             if not args.no_solve and "pcg" in out:
                 ud = c.sim_solve(rtol=args.rtol, maxit=args.maxit)

@@ -9,6 +9,7 @@
 #define MESHFEMHIP_JSON_HH
 
 #include <cmath>
+#include <charconv>
 #include <cstdlib>
 #include <fstream>
 #include <memory>
@@ -184,13 +185,29 @@ private:
             else if (literal("false")) { v.m_kind = Kind::Bool; v.m_bool = false; }
             else if (literal("null")) { v.m_kind = Kind::Null; }
             else {
-                const char *b = s.c_str() + pos;
-                char *e = nullptr;
-                double x = std::strtod(b, &e);
-                if (e == b) fail("unexpected character");
+                // the JSON number grammar, -?(0|[1-9][0-9]*)(\.[0-9]+)?([eE][+-]?[0-9]+)?, checked BEFORE the conversion: a bare strtod also takes
+                // nan / inf / hex floats / a leading '+' or '.', which nlohmann::json (the reference's reader) rejects, and reads the decimal
+                // point of the process's LC_NUMERIC; std::from_chars is locale-independent
+                size_t q = pos;
+                auto digit = [&](size_t i) { return i < s.size() && s[i] >= '0' && s[i] <= '9'; };
+                if (q < s.size() && s[q] == '-') ++q;
+                if (!digit(q)) fail("unexpected character");
+                if (s[q] == '0') ++q; else while (digit(q)) ++q;
+                if (q < s.size() && s[q] == '.') { ++q; if (!digit(q)) fail("invalid number: digits expected after the decimal point"); while (digit(q)) ++q; }
+                if (q < s.size() && (s[q] == 'e' || s[q] == 'E')) {
+                    ++q;
+                    if (q < s.size() && (s[q] == '+' || s[q] == '-')) ++q;
+                    if (!digit(q)) fail("invalid number: digits expected in the exponent");
+                    while (digit(q)) ++q;
+                }
+                double x = 0;
+                const auto res = std::from_chars(s.data() + pos, s.data() + q, x);
+                if (res.ec == std::errc::invalid_argument || res.ptr != s.data() + q) fail("invalid number");
+                // (out of range: from_chars leaves x unmodified; like nlohmann, overflow to infinity is an error, underflow to zero is not)
+                if (res.ec == std::errc::result_out_of_range) { x = std::strtod(std::string(s, pos, q - pos).c_str(), nullptr); if (!(x == x) || x > 1.7e308 || x < -1.7e308) fail("number out of range"); }
                 v.m_kind = Kind::Number;
                 v.m_num = x;
-                pos += (size_t)(e - b);
+                pos = q;
             }
             return v;
         }

@@ -2021,7 +2021,8 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
         if (on && !c->detPartials.p) {
             require_device(c);
             MFH_HIP(hipSetDevice(c->device));
-            c->detPartials.alloc((size_t)8 + (size_t)16384 * 4);     // header + 16 384 workgroups x 4 partials
+            c->detPartials.alloc((size_t)8 + (size_t)4096 * 4);      // header + 4 096 workgroups x 4 partials (launches with global sums use at most that many
+                                                                     // workgroups in this mode: the one-workgroup second stage reads 16 partials per lane and sum)
             c->detPartials.zero(c->stream);
             c->detCounter.alloc(64);
             c->detCounter.zero(c->stream);
