@@ -1046,7 +1046,11 @@ void mfh_destroy(mfh_ctx *c) {
     for (auto &P : c->dist.prof) for (auto &e : P.ev) if (e) (void)hipEventDestroy(e);
     if (c->dist.commStream && !c->dist.commStreamBorrowed) { (void)hipStreamSynchronize(c->dist.commStream); (void)hipStreamDestroy(c->dist.commStream); }
     if (c->negHost) (void)hipHostFree(c->negHost);
-    delete c;   // device buffers are freed while the stream is still alive
+    {
+        // the context's streams are idle (synchronised above): its device buffers go back to the cache without waiting for anybody else's work
+        mfh::PoolScope idle(nullptr, nullptr, c->hostOnly ? 0 : 2);
+        delete c;   // device buffers are freed while the stream is still alive
+    }
     if (s && own) (void)hipStreamDestroy(s);
 }
 

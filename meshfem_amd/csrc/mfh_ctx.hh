@@ -275,7 +275,8 @@ namespace mfhi {   // internal helpers with external linkage (defined in mfh_api
 using namespace mfh;
 
 #define MFH_TRY(ctx) try {         \
-    mfh::k::DetScope detScope_(mfhi::det_buf(ctx));
+    mfh::k::DetScope detScope_(mfhi::det_buf(ctx)); \
+    mfh::PoolScope poolScope_((ctx) ? mfhi::ctx_stream(ctx) : nullptr, (ctx) ? mfhi::ctx_comm_stream(ctx) : nullptr, ((ctx) && !mfhi::ctx_host_only(ctx)) ? 1 : 0);
 #define MFH_CATCH(ctx)                                              \
     } catch (const mfh::Error &e) {                                 \
         if (ctx) (ctx)->err = e.what();                             \
@@ -295,6 +296,10 @@ inline mfh::k::DetBuf det_buf(const mfh_ctx *c) {
     if (c && c->deterministic && c->detPartials.p) { d.partials = c->detPartials.p; d.counter = c->detCounter.p; d.cap = (int)((c->detPartials.n - 8) / 4); }
     return d;
 }
+
+inline hipStream_t ctx_stream(const mfh_ctx *c) { return c->stream; }
+inline hipStream_t ctx_comm_stream(const mfh_ctx *c) { return c->dist.commStream; }
+inline bool ctx_host_only(const mfh_ctx *c) { return c->hostOnly; }
 
 inline void require(bool cond, mfh_status code, const char *msg) {
     if (!cond) throw Error(code, msg);

@@ -56,6 +56,17 @@ int  host_threads();
 void *device_alloc(size_t bytes);
 void device_free(void *p);
 void device_cache_trim();
+// What a release waits for before the block may be handed to somebody else: the streams of the context the calling thread is working for
+// (PoolScope, installed by every API entry), not the whole device -- hipDeviceSynchronize from one host thread invalidates a stream
+// capture another thread has open (tests/test_gpu_threads.py). Outside any scope: the device.
+struct PoolScope {
+    hipStream_t saved[2];
+    int savedMode;
+    PoolScope(hipStream_t a, hipStream_t b, int mode);     // mode 1: synchronise a and b; 2: nothing (the caller has synchronised)
+    ~PoolScope();
+    PoolScope(const PoolScope &) = delete;
+    PoolScope &operator=(const PoolScope &) = delete;
+};
 void device_cache_stats(int dev, int64_t *cachedBytes, int64_t *blocks, int64_t *hits, int64_t *misses, int64_t *flushes);
 
 // Device buffer with explicit size tracking.

@@ -155,6 +155,23 @@ void alloc_level_vectors(int dim, mfh_ctx::AggLevel &A) {
     A.x.alloc(n); A.b.alloc(n); A.r.alloc(n); A.d.alloc(n); A.t.alloc(n);
 }
 
+// The dense inverse of the last aggregate level, regular or -- for a K that is singular on the free variables (G.singular) -- with the
+// modes of one aggregate pinned. The only part of the hierarchy that differs between the two kinds of solve.
+bool invert_last_level(mfh_ctx *c) {
+    auto &G = c->mg;
+    hipStream_t s = c->stream;
+    const int dim = c->dim(), NM = dim == 3 ? 6 : 3;
+    mfh_ctx::AggLevel &Last = *G.agg.back();
+    G.denseM = Last.nAgg * NM;
+    DBuf<double> Ad;
+    Ad.alloc((size_t)G.denseM * G.denseM);
+    Ad.zero(s);
+    k::launch_st_to_dense(dim, Last.nAgg, Last.nbr.p, Last.A.p, Ad.p, s);
+    if (G.singular)          // zero diagonal = "mode without support": dense_inverse_device decouples the NM modes of aggregate 0 (the pin)
+        MFH_HIP(hipMemset2DAsync(Ad.p, (size_t)(G.denseM + 1) * sizeof(double), 0, sizeof(double), (size_t)NM, s));
+    return dense_inverse_device(c, Ad.p, G.denseM, G.denseInv, G.denseLd);
+}
+
 // Builds c->mg.agg from the linear level c1. false: the lattice does not resolve the elements (an element reaches beyond
 // adjacent bins) or the dense level is not positive definite; the caller then keeps the context's own dense coarse space.
 bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void(const char *)> &lap) {
@@ -318,17 +335,7 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
         k::launch_st_dinv(dim, L->nAgg, L->A.p, L->Dinv.p, s);
         alloc_level_vectors(dim, *L);
     }
-    {
-        mfh_ctx::AggLevel &Last = *G.agg.back();
-        G.denseM = Last.nAgg * NM;
-        DBuf<double> Ad;
-        Ad.alloc((size_t)G.denseM * G.denseM);
-        Ad.zero(s);
-        k::launch_st_to_dense(dim, Last.nAgg, Last.nbr.p, Last.A.p, Ad.p, s);
-        if (G.singular)          // zero diagonal = "mode without support": dense_inverse_device decouples the NM modes of aggregate 0 (the pin)
-            MFH_HIP(hipMemset2DAsync(Ad.p, (size_t)(G.denseM + 1) * sizeof(double), 0, sizeof(double), (size_t)NM, s));
-        if (!dense_inverse_device(c, Ad.p, G.denseM, G.denseInv, G.denseLd)) { G.agg.clear(); return false; }
-    }
+    if (!invert_last_level(c)) { G.agg.clear(); return false; }
     lap("dense inverse of the last level");
     for (size_t l = 0; l + 1 < G.agg.size(); ++l) {
         mfh_ctx::AggLevel &L = *G.agg[l];
@@ -379,6 +386,14 @@ bool ensure_multigrid(mfh_ctx *c) {
     // in its null space; the smoothers do not mind, the dense last level is inverted with the six modes of one aggregate pinned
     const bool singular = c->tlSuppress;
     if (G.valid && G.singular == singular && G.distributed == distributed && (!distributed || G.distComm == (const void *)c->dist.comm)) return true;
+    // the other kind of solve on an unchanged hierarchy (workflows that alternate regular solves and solves under rigid-motion rows): the levels,
+    // their Galerkin products and spectra are the same, only the dense inverse of the last level differs
+    if (G.valid && G.singular != singular && !distributed && !G.distributed && !G.agg.empty()) {
+        const double t1 = now_ms();
+        G.singular = singular;
+        if (invert_last_level(c)) { G.setup_ms += now_ms() - t1; return true; }
+        G.singular = !singular;
+    }
     G.valid = false;
     c->precondNote.clear();
     const HostMesh &m = c->mesh;

@@ -9,7 +9,7 @@
 //
 // What: a released block goes to a size-ordered free list instead of back to the driver; an allocation takes the smallest cached block
 // that fits without wasting more than a quarter (+1 MiB), else asks the driver; when the driver is out of memory the cache is flushed
-// and the request repeated. The cache is bounded (MFH_DEVICE_CACHE_MB, default half the device's memory): beyond that the largest blocks go
+// and the request repeated. The cache is bounded (MFH_DEVICE_CACHE_MB, default a third of the device's memory): beyond that the largest blocks go
 // back to the driver. MFH_DEVICE_CACHE_MB=0 restores plain hipMalloc / hipFree. mfh_device_cache_trim() empties it on request.
 #include "mfh_internal.hh"
 #include <map>
@@ -28,6 +28,18 @@ struct DevCache {
 };
 std::mutex g_mu;
 std::map<int, DevCache> g_cache;
+thread_local hipStream_t t_streams[2] = {nullptr, nullptr};
+thread_local int t_mode = 0;
+
+void wait_for_users() {
+    if (t_mode == 2) return;
+    if (t_mode == 1) {
+        (void)hipStreamSynchronize(t_streams[0]);
+        if (t_streams[1]) (void)hipStreamSynchronize(t_streams[1]);
+        return;
+    }
+    (void)hipDeviceSynchronize();
+}
 
 DevCache &cache_of(int dev) {
     DevCache &C = g_cache[dev];
@@ -35,7 +47,7 @@ DevCache &cache_of(int dev) {
         C.init = true;
         size_t fr = 0, total = 0;
         if (hipMemGetInfo(&fr, &total) != hipSuccess) { (void)hipGetLastError(); total = (size_t)64 << 30; }
-        C.limit = total / 2;
+        C.limit = total / 3;
         if (const char *e = getenv("MFH_DEVICE_CACHE_MB")) {
             const long long mb = atoll(e);
             if (mb <= 0) C.enabled = false;
@@ -101,7 +113,7 @@ void device_free(void *p) {
     }
     const size_t bytes = it->second;
     lock.unlock();
-    (void)hipDeviceSynchronize();      // what hipFree did implicitly: nothing in flight uses the block when somebody else gets it
+    wait_for_users();                  // what hipFree did implicitly: nothing in flight uses the block when somebody else gets it
     lock.lock();
     C.free.emplace(bytes, p);
     C.cachedBytes += bytes;
@@ -113,6 +125,12 @@ void device_free(void *p) {
         C.free.erase(last);
     }
 }
+
+PoolScope::PoolScope(hipStream_t a, hipStream_t b, int mode) {
+    saved[0] = t_streams[0]; saved[1] = t_streams[1]; savedMode = t_mode;
+    t_streams[0] = a; t_streams[1] = b; t_mode = mode;
+}
+PoolScope::~PoolScope() { t_streams[0] = saved[0]; t_streams[1] = saved[1]; t_mode = savedMode; }
 
 void device_cache_trim() {
     std::lock_guard<std::mutex> lock(g_mu);

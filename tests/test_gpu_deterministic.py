@@ -92,6 +92,7 @@ def test_config2_assembled_twice_and_solved_twice_is_bit_identical():
     import torch
     import meshfem_amd as M
     from meshfem_amd import grid
+    M.device_cache_trim()      # (this process keeps the device blocks earlier tests released: hand them back before asking what is free)
     free, _ = torch.cuda.mem_get_info(0)
     if free < 60e9:
         pytest.skip("needs 60 GB of free device memory")
