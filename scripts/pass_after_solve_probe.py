@@ -24,6 +24,21 @@ def passes(tag):
 
 
 passes("fresh context")
+if len(sys.argv) > 2:
+    import torch
+    a = torch.ones(1 << 27, dtype=torch.float64, device="cuda"); b = a * 2; del a, b
+    passes("after torch allocated and released 2 GiB (kept in its allocator)")
+    c.time_assembly_kernel(M.ASSEMBLE_GATHER, 5)
+    passes("after time_assembly_kernel(gather)")
+    c.time_assembly_kernel(M.ASSEMBLE_ATOMIC, 3); c.assemble()
+    passes("after the atomic-scatter variant (scatter map built)")
+    c.set_option("pcg_variant", 1)
+    try:
+        c.sim_solve(rtol=1e-30, maxit=50)
+    except M.MeshFEMHipError:
+        pass
+    c.set_option("pcg_variant", -1)
+    passes("after a Chronopoulos-Gear solve")
 try:
     c.sim_solve(rtol=1e-30, maxit=100)
 except M.MeshFEMHipError:
