@@ -161,6 +161,7 @@ PROTOTYPES = {
     "mfh_debug_spd_inverse": (_i32, [_i64, _P]),
     "mfh_debug_spd_inverse_device": (_i32, [_P, _i64, _P]),
     "mfh_debug_device_node_tables": (_i32, [_P, _P, _P]),
+    "mfh_debug_row_chunks": (_i32, [_i64, _P, _i32, _i64, _P, _i64, _i32, _P, _i64, _P]),
 }
 
 # callback types of mfh_comm_create_callbacks

@@ -1036,7 +1036,7 @@ mfh_status mfh_create(int32_t device, mfh_ctx **out) {
 void mfh_destroy(mfh_ctx *c) {
     if (!c) return;
     if (!c->hostOnly) (void)hipSetDevice(c->device);
-    if (c->stream) { (void)hipStreamSynchronize(c->stream); }
+    if (!c->hostOnly) (void)hipStreamSynchronize(c->stream);   // (a borrowed null stream too: the buffers below go back to the block cache)
     hipStream_t s = c->stream;
     const bool own = c->ownStream;
     for (auto &e : c->passEv) if (e) (void)hipEventDestroy(e);
@@ -1933,6 +1933,20 @@ mfh_status mfh_time_spmv_kernel(mfh_ctx *c, int32_t reps, double *avg_ms) {
     for (int r = 0; r < reps; ++r) apply_operator(c, false, c->wx.p, c->wAp.p, nullptr);
     *avg_ms = t.stop() / reps;
     MFH_CATCH(c)
+}
+
+mfh_status mfh_debug_row_chunks(int64_t nRows, const int32_t *rowPtr, int32_t chunkSlots, int64_t nBreaks, const int64_t *breaks, int64_t grain, int32_t threads,
+                                int32_t *chunkRow, int64_t cap, int64_t *nOut) {
+    mfh_ctx *none = nullptr;
+    MFH_TRY(none)
+    require(nRows > 0 && rowPtr && chunkRow && nOut && chunkSlots > 0, MFH_ERR_INVALID, "mfh_debug_row_chunks: arguments");
+    const std::vector<int32_t> rp(rowPtr, rowPtr + nRows + 1);
+    const std::vector<int64_t> br(breaks, breaks + (breaks ? nBreaks : 0));
+    const std::vector<int32_t> cr = mfh::make_chunks(rp, nRows, chunkSlots, br, grain, threads);
+    *nOut = (int64_t)cr.size();
+    require((int64_t)cr.size() <= cap, MFH_ERR_INVALID, "mfh_debug_row_chunks: output capacity");
+    std::copy(cr.begin(), cr.end(), chunkRow);
+    MFH_CATCH(none)
 }
 
 mfh_status mfh_debug_device_node_tables(mfh_ctx *c, int32_t *elemNodes, double *nodePos) {

@@ -261,6 +261,10 @@ void build_element_order_device(const HostMesh &m, const int32_t *dElemNodes, co
 void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nRows, hipStream_t s,
                            MfLists &L, DBuf<uint32_t> &dPairCode, DBuf<uint16_t> &dPairRow, DBuf<uint32_t> &dPairPos, int maxRowsCap = 256,
                            int maxPairs = 2048);
+// greedy row chunks of at most chunkSlots slots (whole rows); breaks = rows (ascending) at which a chunk must end; scanned by the host threads in
+// ranges of `grain` rows and stitched to the sequential result (mfh_symbolic_gpu.hip)
+std::vector<int32_t> make_chunks(const std::vector<int32_t> &rowPtr, int64_t nRows, int chunkSlots, const std::vector<int64_t> &breaks = {},
+                                 int64_t grain = (int64_t)1 << 18, int maxThreads = 0);
 void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nDoF, int64_t nOwnedDoF,
                            int chunkSlots, bool wantScatter, hipStream_t s, Symbolic &S, DBuf<int32_t> &dRowPtr, DBuf<int32_t> &dColIdx,
                            DBuf<uint32_t> &dContribCode, DBuf<uint16_t> &dContribSlot, DBuf<int32_t> &dScatter, bool upperOnly = false,

@@ -237,20 +237,26 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
         build_topology_host(dim, deg, nElem, nVert, ev, instEdge, nEdgeNodes, bdryInst);
 
     lap("topology (edges, boundary)");
-    m.elemNodes.resize((size_t)nElem * m.npe);
-    parallel_ranges(nElem, [&](int64_t b, int64_t e2, int) {
-        for (int64_t e = b; e < e2; ++e) {
-            int32_t *out = &m.elemNodes[(size_t)e * m.npe];
-            for (int c = 0; c < nv; ++c) out[c] = ev[e * nv + c];
-            if (deg == 2)
-                for (int ei = 0; ei < nedge; ++ei) out[nv + ei] = (int32_t)nVert + instEdge[(size_t)e * nedge + ei];
-        }
-    });
     m.nNode = nVert + nEdgeNodes;
     m.nOwned = m.nNode;
-    lap("element node table");
-    compute_node_positions(m);
-    lap("node positions");
+    // the element node table and the node positions (the two large host tables) are filled by a second thread, itself fanning out over the
+    // host threads, while this one builds the boundary section below: they share only read-only inputs (ev, instEdge, vertPos)
+    std::exception_ptr tablesErr;
+    std::thread tables([&] {
+        try {
+            m.elemNodes.resize((size_t)nElem * m.npe);
+            parallel_ranges(nElem, [&](int64_t b, int64_t e2, int) {
+                for (int64_t e = b; e < e2; ++e) {
+                    int32_t *out = &m.elemNodes[(size_t)e * m.npe];
+                    for (int c = 0; c < nv; ++c) out[c] = ev[e * nv + c];
+                    if (deg == 2)
+                        for (int ei = 0; ei < nedge; ++ei) out[nv + ei] = (int32_t)nVert + instEdge[(size_t)e * nedge + ei];
+                }
+            });
+            compute_node_positions(m);
+        } catch (...) { tablesErr = std::current_exception(); }
+    });
+    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{tables};
 
     // ---- boundary elements from the unmatched instances
     const int64_t nBE = (int64_t)bdryInst.size();
@@ -292,7 +298,7 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
         for (auto &row : pairToEdge) for (int &x : row) x = -1;
         for (int ei = 0; ei < nedge; ++ei) { pairToEdge[kEdgeStart[ei]][kEdgeEnd[ei]] = ei; pairToEdge[kEdgeEnd[ei]][kEdgeStart[ei]] = ei; }
         const int nbedge = dim == 3 ? 3 : 1;
-        std::vector<int32_t> bdryEdgeForVolEdge((size_t)nEdgeNodes, -1);
+        m.isBdryNode.assign((size_t)m.nNode, 0);      // doubles as the "edge node already listed" marker (one byte per node instead of a 4-byte table over all edges)
         for (int64_t b = 0; b < nBE; ++b) {
             const uint32_t inst = bdryInst[b];
             int32_t *out = &m.bdryElemNodes[(size_t)b * m.npbe];
@@ -304,20 +310,23 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
             for (int ei = 0; ei < nbedge; ++ei) {   // boundary-local edges (0,1),(1,2),(2,0)   FEMMesh.inl:43-58
                 const int le = pairToEdge[lc[kEdgeStart[ei]]][lc[kEdgeEnd[ei]]];
                 const int32_t volEdge = instEdge[(size_t)t * nedge + le];
-                if (bdryEdgeForVolEdge[volEdge] < 0) {
-                    bdryEdgeForVolEdge[volEdge] = 1;
+                if (!m.isBdryNode[(size_t)nVert + volEdge]) {
+                    m.isBdryNode[(size_t)nVert + volEdge] = 1;
                     m.bdryNodes.push_back((int32_t)nVert + volEdge);
                 }
                 out[nbv + ei] = (int32_t)nVert + volEdge;
             }
         }
     }
-    m.isBdryNode.assign((size_t)m.nNode, 0);
+    if (deg != 2) m.isBdryNode.assign((size_t)m.nNode, 0);
     for (int32_t n : m.bdryNodes) m.isBdryNode[n] = 1;
     compute_boundary_geometry(m, vp);
     m.bdryInternal.assign((size_t)nBE, 0);
     m.hasTopology = true;
     lap("boundary elements + geometry");
+    tables.join();
+    if (tablesErr) std::rethrow_exception(tablesErr);
+    lap("element node table + node positions (second thread): wait");
 }
 
 // Node positions: vertex nodes = vertices; P2 edge node = midpoint of its end vertices

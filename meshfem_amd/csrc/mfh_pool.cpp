@@ -19,26 +19,29 @@
 namespace mfh {
 
 namespace {
+struct Block { size_t bytes; int dev; };
 struct DevCache {
     std::multimap<size_t, void *> free;      // released blocks by size
-    std::unordered_map<void *, size_t> sizeOf;   // every live or cached block handed out by device_alloc
     size_t cachedBytes = 0, limit = 0;
     bool init = false, enabled = true;
     int64_t hits = 0, misses = 0, flushes = 0;
 };
 std::mutex g_mu;
-std::map<int, DevCache> g_cache;
+std::map<int, DevCache> g_cache;                 // one free list per device
+std::unordered_map<void *, Block> g_blocks;      // every live or cached block handed out by device_alloc, with the device it lives on
 thread_local hipStream_t t_streams[2] = {nullptr, nullptr};
 thread_local int t_mode = 0;
 
-void wait_for_users() {
+void wait_for_users(int blockDev, int currentDev) {
     if (t_mode == 2) return;
     if (t_mode == 1) {
         (void)hipStreamSynchronize(t_streams[0]);
         if (t_streams[1]) (void)hipStreamSynchronize(t_streams[1]);
         return;
     }
+    if (blockDev != currentDev) (void)hipSetDevice(blockDev);     // (a block released from a thread whose current device is another one)
     (void)hipDeviceSynchronize();
+    if (blockDev != currentDev) (void)hipSetDevice(currentDev);
 }
 
 DevCache &cache_of(int dev) {
@@ -58,7 +61,7 @@ DevCache &cache_of(int dev) {
 }
 
 void flush_locked(DevCache &C) {
-    for (auto &kv : C.free) { C.sizeOf.erase(kv.second); (void)hipFree(kv.second); }
+    for (auto &kv : C.free) { g_blocks.erase(kv.second); (void)hipFree(kv.second); }
     C.free.clear();
     C.cachedBytes = 0;
     ++C.flushes;
@@ -93,34 +96,33 @@ void *device_alloc(size_t bytes) {
         (void)hipGetLastError();
         throw Error(MFH_ERR_HIP, std::string("hipMalloc of ") + std::to_string(bytes >> 20) + " MiB: " + hipGetErrorString(e));
     }
-    if (C.enabled) C.sizeOf[p] = bytes;
+    if (C.enabled) g_blocks[p] = Block{bytes, dev};
     ++C.misses;
     return p;
 }
 
 void device_free(void *p) {
     if (!p) return;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return; }
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return; }
     std::unique_lock<std::mutex> lock(g_mu);
-    DevCache &C = cache_of(dev);
-    auto it = C.sizeOf.find(p);
-    if (!C.enabled || it == C.sizeOf.end()) {
-        if (it != C.sizeOf.end()) C.sizeOf.erase(it);
+    auto it = g_blocks.find(p);
+    if (it == g_blocks.end()) {            // allocated with the cache disabled
         lock.unlock();
         (void)hipFree(p);
         return;
     }
-    const size_t bytes = it->second;
+    const Block blk = it->second;          // the block goes back to the list of the device it lives on, whatever the caller's current device
     lock.unlock();
-    wait_for_users();                  // what hipFree did implicitly: nothing in flight uses the block when somebody else gets it
+    wait_for_users(blk.dev, cur);          // what hipFree did implicitly: nothing in flight uses the block when somebody else gets it
     lock.lock();
-    C.free.emplace(bytes, p);
-    C.cachedBytes += bytes;
+    DevCache &C = cache_of(blk.dev);
+    C.free.emplace(blk.bytes, p);
+    C.cachedBytes += blk.bytes;
     while (C.cachedBytes > C.limit && !C.free.empty()) {      // over the bound: the largest blocks go back to the driver
         auto last = std::prev(C.free.end());
         C.cachedBytes -= last->first;
-        C.sizeOf.erase(last->second);
+        g_blocks.erase(last->second);
         (void)hipFree(last->second);
         C.free.erase(last);
     }
@@ -134,11 +136,15 @@ PoolScope::~PoolScope() { t_streams[0] = saved[0]; t_streams[1] = saved[1]; t_mo
 
 void device_cache_trim() {
     std::lock_guard<std::mutex> lock(g_mu);
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
     for (auto &kv : g_cache) {
+        if (kv.second.free.empty()) continue;
         (void)hipSetDevice(kv.first);
         (void)hipDeviceSynchronize();
         flush_locked(kv.second);
     }
+    if (cur >= 0) (void)hipSetDevice(cur);     // the caller's current device is left as it was
 }
 
 void device_cache_stats(int dev, int64_t *cachedBytes, int64_t *blocks, int64_t *hits, int64_t *misses, int64_t *flushes) {
