@@ -1037,18 +1037,21 @@ void mfh_destroy(mfh_ctx *c) {
     if (!c) return;
     if (!c->hostOnly) (void)hipSetDevice(c->device);
     if (!c->hostOnly) (void)hipStreamSynchronize(c->stream);   // (a borrowed null stream too: the buffers below go back to the block cache)
+    if (!c->hostOnly && c->dist.commStream) (void)hipStreamSynchronize(c->dist.commStream);
     hipStream_t s = c->stream;
     const bool own = c->ownStream;
-    for (auto &e : c->passEv) if (e) (void)hipEventDestroy(e);
-    dist_detach(c);
-    destroy_multigrid(c);
-    for (auto &e : c->dist.ev) if (e) (void)hipEventDestroy(e);
-    for (auto &P : c->dist.prof) for (auto &e : P.ev) if (e) (void)hipEventDestroy(e);
-    if (c->dist.commStream && !c->dist.commStreamBorrowed) { (void)hipStreamSynchronize(c->dist.commStream); (void)hipStreamDestroy(c->dist.commStream); }
-    if (c->negHost) (void)hipHostFree(c->negHost);
     {
-        // the context's streams are idle (synchronised above): its device buffers go back to the cache without waiting for anybody else's work
+        // the context's streams are idle (synchronised above; a hierarchy's child context synchronises its own in its mfh_destroy): every device
+        // buffer released from here on -- hierarchy levels, partition state, the context's own -- goes back to the cache without waiting for
+        // anybody else's work (a device-wide wait would invalidate the stream captures of other host threads)
         mfh::PoolScope idle(nullptr, nullptr, c->hostOnly ? 0 : 2);
+        for (auto &e : c->passEv) if (e) (void)hipEventDestroy(e);
+        dist_detach(c);
+        destroy_multigrid(c);
+        for (auto &e : c->dist.ev) if (e) (void)hipEventDestroy(e);
+        for (auto &P : c->dist.prof) for (auto &e : P.ev) if (e) (void)hipEventDestroy(e);
+        if (c->dist.commStream && !c->dist.commStreamBorrowed) (void)hipStreamDestroy(c->dist.commStream);
+        if (c->negHost) (void)hipHostFree(c->negHost);
         delete c;   // device buffers are freed while the stream is still alive
     }
     if (s && own) (void)hipStreamDestroy(s);

@@ -39,9 +39,7 @@ void wait_for_users(int blockDev, int currentDev) {
         if (t_streams[1]) (void)hipStreamSynchronize(t_streams[1]);
         return;
     }
-    if (blockDev != currentDev) (void)hipSetDevice(blockDev);     // (a block released from a thread whose current device is another one)
-    (void)hipDeviceSynchronize();
-    if (blockDev != currentDev) (void)hipSetDevice(currentDev);
+    (void)blockDev; (void)currentDev;                             // (mode 0 never reaches here: device_free hands such blocks to hipFree)
 }
 
 DevCache &cache_of(int dev) {
@@ -113,6 +111,14 @@ void device_free(void *p) {
         return;
     }
     const Block blk = it->second;          // the block goes back to the list of the device it lives on, whatever the caller's current device
+    if (t_mode == 0) {
+        // released outside any API entry (no PoolScope: the streams that may still use the block are unknown): plain hipFree, which waits for
+        // the block's users by itself -- NOT a device-wide wait, which would invalidate the stream captures of other host threads
+        g_blocks.erase(it);
+        lock.unlock();
+        (void)hipFree(p);
+        return;
+    }
     lock.unlock();
     wait_for_users(blk.dev, cur);          // what hipFree did implicitly: nothing in flight uses the block when somebody else gets it
     lock.lock();
