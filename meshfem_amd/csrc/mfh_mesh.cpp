@@ -239,24 +239,21 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
     lap("topology (edges, boundary)");
     m.nNode = nVert + nEdgeNodes;
     m.nOwned = m.nNode;
-    // the element node table and the node positions (the two large host tables) are filled by a second thread, itself fanning out over the
-    // host threads, while this one builds the boundary section below: they share only read-only inputs (ev, instEdge, vertPos)
-    std::exception_ptr tablesErr;
-    std::thread tables([&] {
-        try {
-            m.elemNodes.resize((size_t)nElem * m.npe);
-            parallel_ranges(nElem, [&](int64_t b, int64_t e2, int) {
-                for (int64_t e = b; e < e2; ++e) {
-                    int32_t *out = &m.elemNodes[(size_t)e * m.npe];
-                    for (int c = 0; c < nv; ++c) out[c] = ev[e * nv + c];
-                    if (deg == 2)
-                        for (int ei = 0; ei < nedge; ++ei) out[nv + ei] = (int32_t)nVert + instEdge[(size_t)e * nedge + ei];
-                }
-            });
-            compute_node_positions(m);
-        } catch (...) { tablesErr = std::current_exception(); }
+    // the two large host tables, on the host threads. (Filling them on a second thread beside the boundary section below was measured SLOWER at
+    // 57.6 M nodes -- 0.85-1.1 s against 0.68-0.85 s for the whole build on one box: 128 threads taking their first-touch page faults contend
+    // with the allocations of the boundary section for the process's memory map.)
+    m.elemNodes.resize((size_t)nElem * m.npe);
+    parallel_ranges(nElem, [&](int64_t b, int64_t e2, int) {
+        for (int64_t e = b; e < e2; ++e) {
+            int32_t *out = &m.elemNodes[(size_t)e * m.npe];
+            for (int c = 0; c < nv; ++c) out[c] = ev[e * nv + c];
+            if (deg == 2)
+                for (int ei = 0; ei < nedge; ++ei) out[nv + ei] = (int32_t)nVert + instEdge[(size_t)e * nedge + ei];
+        }
     });
-    struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{tables};
+    lap("element node table");
+    compute_node_positions(m);
+    lap("node positions");
 
     // ---- boundary elements from the unmatched instances
     const int64_t nBE = (int64_t)bdryInst.size();
@@ -324,9 +321,6 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
     m.bdryInternal.assign((size_t)nBE, 0);
     m.hasTopology = true;
     lap("boundary elements + geometry");
-    tables.join();
-    if (tablesErr) std::rethrow_exception(tablesErr);
-    lap("element node table + node positions (second thread): wait");
 }
 
 // Node positions: vertex nodes = vertices; P2 edge node = midpoint of its end vertices

@@ -9,8 +9,9 @@
 //
 // What: a released block goes to a size-ordered free list instead of back to the driver; an allocation takes the smallest cached block
 // that fits without wasting more than a quarter (+1 MiB), else asks the driver; when the driver is out of memory the cache is flushed
-// and the request repeated. The cache is bounded (MFH_DEVICE_CACHE_MB, default a third of the device's memory): beyond that the largest blocks go
-// back to the driver. MFH_DEVICE_CACHE_MB=0 restores plain hipMalloc / hipFree. mfh_device_cache_trim() empties it on request.
+// and the request repeated. The cache is bounded (MFH_DEVICE_CACHE_MB, default HALF of the device's memory): beyond that the largest blocks go
+// back to the driver -- and the next large hipMalloc pays for it: with a bound of a third, a 129 GB context (configs[4]) lost its 58 GB value
+// array on release and the next context waited 1 - 3 s for a new one (scripts/setup_probe.py 119, round 4). MFH_DEVICE_CACHE_MB=0 restores plain hipMalloc / hipFree. mfh_device_cache_trim() empties it on request.
 #include "mfh_internal.hh"
 #include <map>
 #include <mutex>
@@ -48,7 +49,7 @@ DevCache &cache_of(int dev) {
         C.init = true;
         size_t fr = 0, total = 0;
         if (hipMemGetInfo(&fr, &total) != hipSuccess) { (void)hipGetLastError(); total = (size_t)64 << 30; }
-        C.limit = total / 3;
+        C.limit = total / 2;
         if (const char *e = getenv("MFH_DEVICE_CACHE_MB")) {
             const long long mb = atoll(e);
             if (mb <= 0) C.enabled = false;
