@@ -447,8 +447,9 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
  *   and added, up to three times: the answer is as good as the tolerance says, like a direct solver's; solves that end within it are untouched),
  * "matrix_storage" (which blocks of K are stored and assembled. 1: only the blocks (r, c >= r), the triangle the reference's TripletMatrix
  *   holds -- half the bytes and block arithmetic of the assembly; serves mfh_export_upper_triplets, mfh_export_bsr (mirrored on the host),
- *   the (block-)Jacobi and two-level PCG on the matrix-free operator; the assembled SpMV and the probing construction of the coarse
- *   operator return MFH_ERR_UNSUPPORTED on it. 0: both triangles. -1 default: automatic -- the upper triangle exactly when nothing
+ *   the (block-)Jacobi and two-level PCG on the matrix-free operator, and mfh_apply_K / mfh_dev_spmv through k_spmv_sym (the transposed half
+ *   of the product added with global atomics: 2.5x slower than the product from both triangles); the PCG on the assembled SpMV and the probing
+ *   construction of the coarse operator return MFH_ERR_UNSUPPORTED on it. 0: both triangles. -1 default: automatic -- the upper triangle exactly when nothing
  *   multiplies by the stored K (quadratic elasticity on the matrix-free operator), both triangles otherwise; changing an option that
  *   decides this re-runs the symbolic phase on the next use. mfh_matrix_info / mfh_export_bsr describe K itself either way,
  *   mfh_matrix_storage what is stored),

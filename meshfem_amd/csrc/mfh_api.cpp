@@ -448,8 +448,11 @@ void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double 
         if (c->mfModeEff() == 4 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf_cluster(spmv_mf_cluster_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
         else if (c->mfModeEff() >= 2 && c->op == MFH_OP_ELASTICITY) k::launch_spmv_mf2(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
         else k::launch_spmv_mf(spmv_mf_args(c, masked), x, y, dotOut, nullptr, 0, nullptr, false, c->stream);
+    } else if (c->upperOnly) {
+        // the stored triangle serves both halves of the product (k_spmv_sym: transposed parts added with global atomics; measured slower than
+        // k_spmv on both triangles, DESIGN 4.4: the PCG keeps asking for the full storage, this serves mfh_apply_K / mfh_dev_spmv)
+        k::launch_spmv_sym(spmv_args(c, masked), c->sym.nRows, x, y, dotOut, c->stream);
     } else {
-        require_full_storage(c, "the assembled SpMV");
         k::launch_spmv(spmv_args(c, masked), x, y, dotOut, c->stream);
     }
 }

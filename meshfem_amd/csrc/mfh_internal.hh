@@ -464,6 +464,8 @@ void launch_spmv_mf2(const SpmvMfArgs &a, const double *x, double *y, double *do
 
 // y = A x (optionally masked), optional dot accumulation: dotOut[0] += x_rows . y
 void launch_spmv(const SpmvArgs &a, const double *x, double *y, double *dotOut, hipStream_t s);
+// the same product from the upper-triangle storage (blocks (r, c >= r)): A^T x_r of every stored off-diagonal block added to y_c with global atomics
+void launch_spmv_sym(const SpmvArgs &a, int64_t nRows, const double *x, double *y, double *dotOut, hipStream_t s);
 
 void launch_untile_vals(int dim, int64_t nnzb, const double *tiled, double *aos, hipStream_t s);
 void launch_extract_diag_inv(int dim, int64_t nRows, const int32_t *rowPtr, const int32_t *colIdx, const double *vals,

@@ -804,6 +804,71 @@ __global__ void __launch_bounds__(256) k_spmv(SpmvArgs a, const double *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// y = K x from the UPPER-TRIANGLE storage (blocks (r, c >= r): what the reference's TripletMatrix holds, SparseMatrices.hh:231-234) -- the
+// "symmetric-storage SpMV" of VERDICT r3 item 7. Same chunks as k_spmv. A stored off-diagonal block serves twice: A x_c goes to the row's
+// LDS partial as in k_spmv, A^T x_r is ADDED to y_c -- a row of another chunk (in the lattice order of the generator's meshes the columns of a
+// row lie up to a plane of the grid away), hence a global FP64 atomic; the rows' own sums are added atomically too (other workgroups scatter into
+// them), y is zeroed by the launcher. Half the matrix bytes of k_spmv, plus 3 atomics per off-diagonal block.
+// ------------------------------------------------------------------------------------------------
+template <int DIM>
+__global__ void __launch_bounds__(256) k_spmv_sym(SpmvArgs a, int64_t nRows, const double *__restrict__ x, double *__restrict__ y) {
+    constexpr int NB = DIM * DIM;
+    extern __shared__ __attribute__((aligned(16))) double part[];  // [DIM][chunkSlots] + row of every slot (u16)
+    const int CS = a.chunkSlots;
+    unsigned short *rowOf = reinterpret_cast<unsigned short *>(part + DIM * CS);
+    int64_t chunkFirst = blockIdx.x, chunkEnd = a.nChunk, chunkStride = gridDim.x;
+    if (a.xcd) xcd_span(a.nChunk, chunkFirst, chunkEnd, chunkStride);
+    for (int64_t chunk = chunkFirst; chunk < chunkEnd; chunk += chunkStride) {
+        const int r0 = a.chunkRow[chunk], r1 = a.chunkRow[chunk + 1];
+        const int s0 = a.rowPtr[r0];
+        const int ns = a.rowPtr[r1] - s0;
+        for (int rl = threadIdx.x; rl < r1 - r0; rl += 256) {
+            const int b = a.rowPtr[r0 + rl] - s0, e = a.rowPtr[r0 + rl + 1] - s0;
+            for (int t = b; t < e; ++t) rowOf[t] = (unsigned short)rl;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < ns; t += 256) {
+            const int64_t s = (int64_t)s0 + t;
+            const int64_t col = a.colIdx[s], row = r0 + rowOf[t];
+            double xc[DIM], xr[DIM], A[NB];
+#pragma unroll
+            for (int c = 0; c < NB; ++c) A[c] = a.vals[tiled_index(s, c, NB)];
+#pragma unroll
+            for (int d = 0; d < DIM; ++d) { xc[d] = x[col * DIM + d]; xr[d] = x[row * DIM + d]; }
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) {
+                double v = 0;
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) v += A[c * DIM + d] * xc[d];
+                part[c * CS + t] = v;
+            }
+            if (col != row && col < nRows) {     // (a halo column's row belongs to another rank, which stores the block itself)
+#pragma unroll
+                for (int d = 0; d < DIM; ++d) {
+                    double w = 0;
+#pragma unroll
+                    for (int c = 0; c < DIM; ++c) w += A[c * DIM + d] * xr[c];
+                    const int64_t gj = col * DIM + d;
+                    if (!(a.fixedMask && a.fixedMask[gj])) unsafeAtomicAdd(&y[gj], w);
+                }
+            }
+        }
+        __syncthreads();
+        const int nscalar = (r1 - r0) * DIM;
+        for (int idx = threadIdx.x; idx < nscalar; idx += 256) {
+            const int rl = idx / DIM, c = idx - rl * DIM;
+            const int64_t r = r0 + rl;
+            const int b = a.rowPtr[r] - s0, e = a.rowPtr[r + 1] - s0;
+            double v = 0;
+            for (int t = b; t < e; ++t) v += part[c * CS + t];
+            const int64_t gi = r * DIM + c;
+            if (!(a.fixedMask && a.fixedMask[gi])) unsafeAtomicAdd(&y[gi], v);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Matrix-free operator y = K x: one lane per (element, local node i) pair evaluates the row i of the
 // element matrix block by block in registers (same elem_block as the assembly: identical values) and
 // applies it to the gathered x; pairs of a row chunk are reduced in LDS. Trades the 72 B/block of the
@@ -2224,6 +2289,19 @@ static void launch_spmv_mode(const SpmvArgs &a_, int mode, const double *x, doub
 
 void launch_spmv(const SpmvArgs &a, const double *x, double *y, double *dotOut, hipStream_t s) {
     launch_spmv_mode(a, 0, x, y, dotOut, nullptr, 0, nullptr, nullptr, 0, s);
+}
+
+// y = K x from the upper-triangle storage (k_spmv_sym); nRows = rows of y (zeroed here); dotOut (optional): *dotOut += x . y
+void launch_spmv_sym(const SpmvArgs &a, int64_t nRows, const double *x, double *y, double *dotOut, hipStream_t s) {
+    if (a.nChunk <= 0) return;
+    MFH_HIP(hipMemsetAsync(y, 0, (size_t)nRows * a.dim * sizeof(double), s));
+    const size_t lds = ((size_t)a.dim * a.chunkSlots + 16) * sizeof(double) + (size_t)a.chunkSlots * sizeof(unsigned short);
+    const int grid = spmv_grid(a);
+    if (a.dim == 1) hipLaunchKernelGGL((k_spmv_sym<1>), dim3(grid), dim3(256), lds, s, a, nRows, x, y);
+    else if (a.dim == 3) hipLaunchKernelGGL((k_spmv_sym<3>), dim3(grid), dim3(256), lds, s, a, nRows, x, y);
+    else hipLaunchKernelGGL((k_spmv_sym<2>), dim3(grid), dim3(256), lds, s, a, nRows, x, y);
+    CHECK_LAUNCH();
+    if (dotOut) launch_dot(nRows * a.dim, x, y, dotOut, s);
 }
 
 void launch_pcg_spmv(const SpmvArgs &a, const double *p, double *Ap, double *scal, int it, const double *stopPtr, hipStream_t s) {

@@ -1177,24 +1177,29 @@ def test_upper_only_storage_assembles_the_reference_triangle(mode, periodic):
         c.set_option("agg_nodes", 24)                        # a dozen aggregates: blocks between different aggregates exist
         out["t%d" % storage] = c.solve(f, rtol=1e-10, maxit=20000)
         out["it%d" % storage] = c.last_info["iterations"]
+        if storage == 1 and not periodic:                        # (probing is not offered with periodic DoF maps at all)
+            with pytest.raises(M.MeshFEMHipError) as ei:
+                c.set_option("tl_probe", 1)
+                c.solve(f, rtol=1e-8)
+            assert ei.value.code == M._lib.ERR_UNSUPPORTED and "both triangles" in str(ei.value)
+        # the assembled product: from both triangles (k_spmv), or from the stored triangle with the transposed parts scattered (k_spmv_sym);
+        # the PCG on the assembled SpMV keeps asking for both triangles
+        c.set_option("tl_probe", 0)
+        c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+        c.set_option("matrix_free", 0)
+        out["y%d" % storage] = c.apply_K(f)
+        assert c.matrix_storage()[0] == (storage == 1)
         if storage == 1:
-            for what in ("spmv",) if periodic else ("probe", "spmv"):   # (probing is not offered with periodic DoF maps at all)
-                with pytest.raises(M.MeshFEMHipError) as ei:
-                    if what == "probe":
-                        c.set_option("tl_probe", 1)
-                        c.solve(f, rtol=1e-8)
-                    else:
-                        c.set_option("tl_probe", 0)
-                        c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
-                        c.set_option("matrix_free", 0)
-                        c.apply_K(f)
-                assert ei.value.code == M._lib.ERR_UNSUPPORTED and "both triangles" in str(ei.value)
+            with pytest.raises(M.MeshFEMHipError) as ei:
+                c.solve(f, rtol=1e-8)
+            assert ei.value.code == M._lib.ERR_UNSUPPORTED and "both triangles" in str(ei.value)
         c.close()
     assert out[0][0] == out[1][0] and out[0][1] == (False, out[0][0])          # matrix_info: the blocks of K; storage 0 holds them all,
     assert out[1][1] == (True, (out[0][0] + nr) // 2)                          # storage 1 the diagonal blocks + one of every off-diagonal pair
     assert np.linalg.norm(out["u1"] - out["u0"]) <= 1e-7 * np.linalg.norm(out["u0"])
     assert np.linalg.norm(out["t1"] - out["u0"]) <= 1e-7 * np.linalg.norm(out["u0"])
     assert abs(out["it1"] - out["it0"]) <= 1                   # the same coarse operator, to rounding
+    assert np.abs(out["y1"] - out["y0"]).max() <= 1e-13 * np.abs(out["y0"]).max()
 
 
 def test_storage_of_K_follows_what_will_read_it():
