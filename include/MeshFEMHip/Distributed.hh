@@ -56,6 +56,15 @@ public:
     std::string describe() const { return mfh_comm_describe(m_comm); }
     // ring shift + all-reduce with known answers over the actual transport
     void selfTest(mfh_ctx *ctx) const { check(ctx, mfh_comm_selftest(ctx, m_comm)); }
+    // Direct peer transfers on top of this communicator (collective; the ranks are separate processes of one node): halos and small
+    // all-reduces become device stores into the neighbours' staging slabs mapped through HIP IPC. Returns false -- on EVERY rank -- when
+    // they cannot be set up (one rank, no IPC on this host): the communicator underneath stays in use, why() says why.
+    bool enablePeerTransfers(mfh_ctx *ctx, std::string *why = nullptr) {
+        if (mfh_comm_enable_peer(ctx, m_comm) == MFH_OK) return true;
+        if (why) *why = mfh_last_error(ctx);
+        return false;
+    }
+    void disablePeerTransfers(mfh_ctx *ctx) { check(ctx, mfh_comm_disable_peer(ctx, m_comm)); }
 private:
     Communicator() = default;
     mfh_comm *m_comm = nullptr;
@@ -114,6 +123,10 @@ public:
         check(ctx(), mfh_dist_apply_K(ctx(), uOwned.data(), Ku.data()));
         return Ku;
     }
+    // transport in use, halo sizes, exchange / overlap timings (option "dist_profile"), message counters: mfh_dist_stats
+    mfh_dist_stats stats() { mfh_dist_stats st{}; check(ctx(), mfh_dist_get_stats(ctx(), &st)); return st; }
+    // run-to-run bit-reproducible operator and dot products (all-reduces in rank order need the peer transfers or a reproducible transport)
+    void setDeterministic(bool on) { check(ctx(), mfh_set_option(ctx(), "deterministic", on ? 1.0 : 0.0)); }
     size_t numOwnedNodes() const { return m_numOwned; }
     size_t numLocalNodes() const { return m_numLocal; }
     double rtol = 1e-8;

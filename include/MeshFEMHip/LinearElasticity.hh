@@ -62,6 +62,10 @@ private:
     mfh_ctx *m_ctx = nullptr;
 };
 
+// The per-process cache of released device blocks (meshfem_hip.h, "Device memory"): hand everything back to the driver, e.g. before
+// another library or process needs the device's memory
+inline void deviceCacheTrim() { mfh_device_cache_trim(); }
+
 // Triplet / TripletMatrix with the reference's field names (SparseMatrices.hh:45-72,191-773)
 struct Triplet { size_t i, j; Real v; };
 struct TripletMatrix {

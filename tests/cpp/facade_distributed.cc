@@ -59,6 +59,10 @@ int main(int argc, char **argv) {
         Communicator comm = Communicator::rccl(sim.ctx(), uid, 0, 1);
         printf("communicator: %s\n", comm.describe().c_str());
         comm.selfTest(sim.ctx());
+        std::string why;
+        if (comm.enablePeerTransfers(sim.ctx(), &why)) return 5;        // one rank: refused with a reason, the communicator stays as it is
+        printf("peer transfers with one rank: %s\n", why.c_str());
+        if (why.find("two ranks") == std::string::npos) return 6;
         sim.setExchange(comm, {}, {0}, {}, {0});
         sim.fixVariables(std::vector<size_t>(fv.begin(), fv.end()), fx);
         std::vector<Real> fFlat(3 * nNode);
@@ -78,6 +82,15 @@ int main(int argc, char **argv) {
         Real r = 0, fn = 0;
         for (size_t i = 0; i < Ku.size(); ++i) if (!fixed[i]) { r += (Ku[i] - fFlat[i]) * (Ku[i] - fFlat[i]); fn += fFlat[i] * fFlat[i]; }
         if (std::sqrt(r / fn) > 1e-8) return 4;
+        const mfh_dist_stats st = sim.stats();
+        printf("stats: world %d, transport %d, peer %d, exchanges %lld\n", st.world, st.transport, st.peer_enabled, (long long)st.exchanges);
+        if (st.world != 1 || st.peer_enabled != 0) return 7;
+        // bit-reproducible mode through the facade: two solves, identical bits
+        sim.setDeterministic(true);
+        auto d1 = sim.solve(fFlat), d2 = sim.solve(fFlat);
+        if (d1 != d2) return 8;
+        sim.setDeterministic(false);
+        deviceCacheTrim();
         printf("distributed facade ok\n");
         return 0;
     } catch (const std::runtime_error &e) {
