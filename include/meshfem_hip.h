@@ -419,7 +419,7 @@ mfh_status  mfh_dist_get_stats(mfh_ctx* ctx, mfh_dist_stats* out);
 mfh_status  mfh_dev_memcpy(mfh_ctx* ctx, void* dst, const void* src, int64_t bytes, int32_t kind, void* hipStream);
 
 /* Device memory. The library keeps the device blocks its contexts release in a per-process cache (size-ordered free list, bounded by
- * MFH_DEVICE_CACHE_MB, default half of the device's memory; 0 = plain hipMalloc / hipFree) instead of returning them to the driver: on
+ * MFH_DEVICE_CACHE_MB, default four fifths of the device's memory; 0 = plain hipMalloc / hipFree) instead of returning them to the driver: on
  * ROCm 7.2 / MI355X a hipMalloc that follows large hipFree calls takes seconds (profiles/r04_malloc_probe.txt), and the setup phases of a
  * context allocate and release several times the memory they keep. The reference reserves its triplet storage once
  * (LinearElasticity.hh:1441-1443). A request the driver cannot serve flushes the cache and is repeated. mfh_device_cache_trim returns

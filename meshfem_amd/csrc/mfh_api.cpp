@@ -63,17 +63,32 @@ static void parallel_assign(V &v, size_t n, T value) {
     parallel_ranges((int64_t)n, [&](int64_t b, int64_t e, int) { for (int64_t k = b; k < e; ++k) p[k] = value; });
 }
 
+// The per-node Dirichlet tables (mask + value per node and component: 1.6 GB at 57.6 M nodes) exist from the first Dirichlet condition on:
+// a context that only assembles never pays for them (they were 60-90 ms of every mfh_mesh_build at 119^3). Empty = no condition set.
+void ensure_dirichlet_tables(mfh_ctx *c) {
+    const size_t n = (size_t)c->mesh.nNode * c->mesh.dim;
+    if (c->dirMask.size() == n && c->dirVal.size() == n) return;
+    parallel_assign(c->dirMask, n, (uint8_t)0);
+    parallel_assign(c->dirVal, n, 0.0);
+}
 void reset_bcs(mfh_ctx *c) {
     const HostMesh &m = c->mesh;
     c->neumannTraction.assign((size_t)m.nBE() * m.dim, 0.0);
-    parallel_assign(c->dirMask, (size_t)m.nNode * m.dim, (uint8_t)0);
-    parallel_assign(c->dirVal, (size_t)m.nNode * m.dim, 0.0);
+    const size_t n = (size_t)m.nNode * m.dim;
+    if (c->dirMask.size() == n && c->dirVal.size() == n) {     // same mesh size as before: cleared in place
+        parallel_assign(c->dirMask, n, (uint8_t)0);
+        parallel_assign(c->dirVal, n, 0.0);
+    } else {
+        RawVec<uint8_t>().swap(c->dirMask);
+        RawVec<double>().swap(c->dirVal);
+    }
     c->deltaForces.clear();
 }
 void clear_fixed(mfh_ctx *c) {
     c->fixedVars.clear();
     c->fixedVals.clear();
-    parallel_assign(c->hFixedMask, (size_t)c->bs() * c->nDoF, (uint8_t)0);
+    if (c->hFixedMask.size() == (size_t)c->bs() * c->nDoF) parallel_assign(c->hFixedMask, c->hFixedMask.size(), (uint8_t)0);
+    else RawVec<uint8_t>().swap(c->hFixedMask);                // (sized again by the first use: mfh_fix_variables / the first solve)
     c->fixedUploaded = false;
     c->anyFixedNonzero = false;
     c->dinvValid = false;
@@ -460,7 +475,7 @@ void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double 
 void ensure_fixed_uploaded(mfh_ctx *c) {
     if (c->fixedUploaded) return;
     const size_t n = (size_t)c->bs() * c->nDoF;
-    if (c->hFixedMask.size() != n) c->hFixedMask.assign(n, 0);
+    if (c->hFixedMask.size() != n) parallel_assign(c->hFixedMask, n, (uint8_t)0);
     c->dFixedMask.upload(c->hFixedMask, c->stream);
     c->dFixedIdx.upload(c->fixedVars, c->stream);
     c->dFixedVal.upload(c->fixedVals, c->stream);
@@ -906,6 +921,7 @@ void dirichlet_vars(mfh_ctx *c, std::vector<int64_t> &vars, std::vector<double> 
     // m_getDirichletVarsAndValues (LinearElasticity.hh:1469-1518)
     const HostMesh &m = c->mesh;
     const int d = m.dim;
+    if (c->dirMask.empty()) return;               // no Dirichlet condition was ever set (ensure_dirichlet_tables)
     std::vector<int32_t> constraintIndex((size_t)c->nDoF, -1);
     std::vector<int32_t> cDoF;
     std::vector<int64_t> cNode;
@@ -955,7 +971,7 @@ int64_t pin_node(const mfh_ctx *c) {   // LinearElasticity.hh:1595-1609
 
 void add_fixed(mfh_ctx *c, int64_t n, const int64_t *vars, const double *vals) {
     const int64_t nv = (int64_t)c->bs() * c->nDoF;
-    if (c->hFixedMask.size() != (size_t)nv) c->hFixedMask.assign((size_t)nv, 0);
+    if (c->hFixedMask.size() != (size_t)nv) parallel_assign(c->hFixedMask, (size_t)nv, (uint8_t)0);
     for (int64_t k = 0; k < n; ++k) {
         require(vars[k] >= 0 && vars[k] < nv, MFH_ERR_INVALID, "fixed variable index out of range");
         require(!c->hFixedMask[vars[k]], MFH_ERR_INVALID, "Variable already fixed.");   // SparseMatrices.hh:2433
@@ -1946,9 +1962,8 @@ mfh_status mfh_debug_row_chunks(int64_t nRows, const int32_t *rowPtr, int32_t ch
     mfh_ctx *none = nullptr;
     MFH_TRY(none)
     require(nRows > 0 && rowPtr && chunkRow && nOut && chunkSlots > 0, MFH_ERR_INVALID, "mfh_debug_row_chunks: arguments");
-    const std::vector<int32_t> rp(rowPtr, rowPtr + nRows + 1);
     const std::vector<int64_t> br(breaks, breaks + (breaks ? nBreaks : 0));
-    const std::vector<int32_t> cr = mfh::make_chunks(rp, nRows, chunkSlots, br, grain, threads);
+    const std::vector<int32_t> cr = mfh::make_chunks(rowPtr, nRows, chunkSlots, br, grain, threads);
     *nOut = (int64_t)cr.size();
     require((int64_t)cr.size() <= cap, MFH_ERR_INVALID, "mfh_debug_row_chunks: output capacity");
     std::copy(cr.begin(), cr.end(), chunkRow);

@@ -356,6 +356,7 @@ inline void require_full_storage(const mfh_ctx *c, const char *what) {
 
 inline int32_t dof_of(const mfh_ctx *c, int64_t node) { return c->dofForNode.empty() ? (int32_t)node : c->dofForNode[node]; }
 void invalidate_matrix(mfh_ctx *c);
+void ensure_dirichlet_tables(mfh_ctx *c);
 void dist_detach(mfh_ctx *c);
 bool dist_active(const mfh_ctx *c);
 int dist_rank(const mfh_ctx *c);

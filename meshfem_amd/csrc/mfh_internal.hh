@@ -50,6 +50,9 @@ private:
 
 // Simple parallel-for over [0, n) in contiguous ranges (host setup code only).
 void parallel_ranges(int64_t n, const std::function<void(int64_t, int64_t, int)> &f, int64_t minGrain = 4096);
+// madvise(MADV_HUGEPAGE) on the 2 MiB-aligned interior of a fresh host range (no-op below 8 MiB or with MFH_HOST_HUGE_PAGES=0): the tables of a
+// 40 M-element mesh are ~4 GB of untouched memory, i.e. a million 4 KiB page faults without it (mfh_mesh.cpp)
+void host_advise_huge_pages(void *p, size_t bytes);
 int  host_threads();
 
 // device memory of the library: hipMalloc / hipFree behind a cache of released blocks (mfh_pool.cpp)
@@ -157,6 +160,20 @@ struct DefaultInitAllocator : std::allocator<T> {
     template <class U, class... Args> void construct(U *ptr, Args &&...args) { ::new (static_cast<void *>(ptr)) U(std::forward<Args>(args)...); }
 };
 template <class T> using RawVec = std::vector<T, DefaultInitAllocator<T>>;
+// size a RawVec and take its first-touch page faults on all host threads (one write per page): a download or a single-threaded fill that
+// follows then runs at memory speed instead of at the page-fault rate of one thread (0.97 GB of edge-node ranks at 119^3: ~0.2 s)
+template <class T> void resize_prefaulted(RawVec<T> &v, size_t n) {
+    const size_t old = v.size();
+    v.resize(n);
+    if (n <= old) return;
+    char *base = reinterpret_cast<char *>(v.data());
+    const int64_t b0 = (int64_t)(old * sizeof(T)), b1 = (int64_t)(n * sizeof(T));
+    host_advise_huge_pages(base + b0, (size_t)(b1 - b0));
+    const int64_t pages = (b1 - b0 + 4095) / 4096;
+    parallel_ranges(pages, [&](int64_t pb, int64_t pe, int) {
+        for (int64_t q = pb; q < pe; ++q) base[std::min<int64_t>(b0 + q * 4096, b1 - 1)] = 0;
+    }, 1024);
+}
 
 struct HostMesh {
     int dim = 0, deg = 0, npe = 0, npbe = 0;
@@ -183,8 +200,10 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
                     DBuf<double> *dNodePosOut = nullptr, bool *deviceTables = nullptr);
 // device topology (mfh_symbolic_gpu.hip); false = mesh does not fit the packed sort keys, use the host path
 bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *hostElemVerts, hipStream_t s,
-                           std::vector<int32_t> &instEdge, int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst,
-                           const double *hostVertPos = nullptr, DBuf<int32_t> *dElemNodesOut = nullptr, DBuf<double> *dNodePosOut = nullptr);
+                           RawVec<int32_t> &instEdge, int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst,
+                           const double *hostVertPos = nullptr, DBuf<int32_t> *dElemNodesOut = nullptr, DBuf<double> *dNodePosOut = nullptr,
+                           // host work to run while the device is busy: (0, 0) once the edge sort is queued, (1, nEdgeNodes) once the half-face sort is
+                           const std::function<void(int, int32_t)> &hostOverlap = {});
 void compute_node_positions(HostMesh &m);
 void compute_boundary_geometry(HostMesh &m, const double *vertPos);
 void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofForNode, int64_t &nDoF,
@@ -198,7 +217,7 @@ struct Symbolic {
     int64_t nCols = 0;                  // block cols (all local DoFs)
     int64_t nnzb = 0;                   // STORED blocks
     int64_t nMirror = 0;                // stored blocks (r, c) with r < c < nRows: with upper-only storage the logical K has nnzb + nMirror blocks
-    std::vector<int32_t> rowPtr;        // nRows+1
+    RawVec<int32_t> rowPtr;             // nRows+1 (RawVec: sized, pre-faulted by the host threads, then downloaded)
     std::vector<int32_t> colIdx;        // nnzb
     // row chunks: consecutive rows whose slot count <= chunkSlots
     std::vector<int32_t> chunkRow;      // nChunk+1   (assembly chunks)
@@ -263,7 +282,7 @@ void build_mf_lists_device(const HostMesh &m, const int32_t *dElemNodes, const i
                            int maxPairs = 2048);
 // greedy row chunks of at most chunkSlots slots (whole rows); breaks = rows (ascending) at which a chunk must end; scanned by the host threads in
 // ranges of `grain` rows and stitched to the sequential result (mfh_symbolic_gpu.hip)
-std::vector<int32_t> make_chunks(const std::vector<int32_t> &rowPtr, int64_t nRows, int chunkSlots, const std::vector<int64_t> &breaks = {},
+std::vector<int32_t> make_chunks(const int32_t *rowPtr /* nRows + 1 */, int64_t nRows, int chunkSlots, const std::vector<int64_t> &breaks = {},
                                  int64_t grain = (int64_t)1 << 18, int maxThreads = 0);
 void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const int32_t *dDofForNode, int64_t nDoF, int64_t nOwnedDoF,
                            int chunkSlots, bool wantScatter, hipStream_t s, Symbolic &S, DBuf<int32_t> &dRowPtr, DBuf<int32_t> &dColIdx,

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <numeric>
 #include <unordered_map>
+#include <sys/mman.h>
 
 namespace mfh {
 
@@ -16,6 +17,14 @@ int host_threads() {
         return (int)std::max(1u, std::min(h, 64u));
     }();
     return n;
+}
+
+void host_advise_huge_pages(void *p, size_t bytes) {
+    static const bool on = [] { const char *e = getenv("MFH_HOST_HUGE_PAGES"); return !(e && atoi(e) == 0); }();
+    if (!on || bytes < ((size_t)8 << 20)) return;
+    const uintptr_t a = ((uintptr_t)p + (((uintptr_t)2 << 20) - 1)) & ~(((uintptr_t)2 << 20) - 1);
+    const uintptr_t e = ((uintptr_t)p + bytes) & ~(((uintptr_t)2 << 20) - 1);
+    if (e > a) (void)madvise((void *)a, (size_t)(e - a), MADV_HUGEPAGE);    // advisory: failure changes nothing
 }
 
 void parallel_ranges(int64_t n, const std::function<void(int64_t, int64_t, int)> &f, int64_t minGrain) {
@@ -99,7 +108,7 @@ inline uint64_t edge_key(int32_t a, int32_t b) {
 
 // Host topology (used by host-only contexts and as fallback): first-encounter edge numbering with a
 // hash table, unmatched half-faces / half-edges by sorting. Same outputs as build_topology_device.
-static void build_topology_host(int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *ev, std::vector<int32_t> &instEdge,
+static void build_topology_host(int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *ev, RawVec<int32_t> &instEdge,
                                 int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst) {
     const int nv = dim + 1, nedge = dim == 3 ? 6 : 3;
     nEdgeNodes = 0;
@@ -205,7 +214,8 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
     m = HostMesh();
     m.dim = dim; m.deg = deg; m.npe = nodes_per_elem(dim, deg); m.npbe = nodes_per_bdry_elem(dim, deg);
     m.nElem = nElem; m.nVert = nVert;
-    m.vertPos.assign(vp, vp + nVert * dim);
+    m.vertPos.resize((size_t)nVert * dim);
+    parallel_ranges(nVert * dim, [&](int64_t b, int64_t e2, int) { std::copy(vp + b, vp + e2, m.vertPos.data() + b); });   // (first touch on all threads)
     {
         std::vector<uint8_t> bad((size_t)host_threads() + 1, 0);
         parallel_ranges(nElem * nv, [&](int64_t b, int64_t e2, int tid) {
@@ -227,11 +237,17 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
     lap("vertex copy + index check");
     // ---- topology: edge nodes in first-encounter order over (element, local edge) (FEMMesh.inl:22-36) and
     //      the unmatched half-faces / half-edges in sorted-key order (TetMesh.inl:36-79, TriMesh.inl:60-100)
-    std::vector<int32_t> instEdge;
+    RawVec<int32_t> instEdge;
     std::vector<uint32_t> bdryInst;
     int32_t nEdgeNodes = 0;
     if (deviceTables) *deviceTables = false;
-    if (useDevice && build_topology_device(dim, deg, nElem, nVert, ev, stream, instEdge, nEdgeNodes, bdryInst, vp, dElemNodesOut, dNodePosOut)) {
+    // the two large host tables are sized, and take their first-touch page faults on all host threads, while the device sorts edges and faces
+    // (filled below: the fills then run at memory speed)
+    auto sizeTables = [&](int stage, int32_t nEdge) {
+        if (stage == 0) resize_prefaulted(m.elemNodes, (size_t)nElem * m.npe);
+        else resize_prefaulted(m.nodePos, (size_t)(nVert + nEdge) * dim);
+    };
+    if (useDevice && build_topology_device(dim, deg, nElem, nVert, ev, stream, instEdge, nEdgeNodes, bdryInst, vp, dElemNodesOut, dNodePosOut, sizeTables)) {
         if (deviceTables) *deviceTables = dElemNodesOut && dNodePosOut;
     } else
         build_topology_host(dim, deg, nElem, nVert, ev, instEdge, nEdgeNodes, bdryInst);
@@ -328,7 +344,7 @@ void build_fem_mesh(HostMesh &m, int dim, int deg, int64_t nElem, int64_t nVert,
 void compute_node_positions(HostMesh &m) {
     const int dim = m.dim, nv = dim + 1;
     m.nodePos.resize((size_t)m.nNode * dim);
-    std::copy(m.vertPos.begin(), m.vertPos.begin() + (size_t)m.nVert * dim, m.nodePos.begin());
+    parallel_ranges(m.nVert * dim, [&](int64_t b, int64_t e, int) { std::copy(m.vertPos.data() + b, m.vertPos.data() + e, m.nodePos.data() + b); });
     if (m.deg == 2) {
         const int nedge = dim == 3 ? 6 : 3;
         // on the host threads; the elements sharing an edge all store the same midpoint (relaxed atomic stores of equal bit patterns)

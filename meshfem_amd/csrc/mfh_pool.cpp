@@ -9,9 +9,11 @@
 //
 // What: a released block goes to a size-ordered free list instead of back to the driver; an allocation takes the smallest cached block
 // that fits without wasting more than a quarter (+1 MiB), else asks the driver; when the driver is out of memory the cache is flushed
-// and the request repeated. The cache is bounded (MFH_DEVICE_CACHE_MB, default HALF of the device's memory): beyond that the largest blocks go
-// back to the driver -- and the next large hipMalloc pays for it: with a bound of a third, a 129 GB context (configs[4]) lost its 58 GB value
-// array on release and the next context waited 1 - 3 s for a new one (scripts/setup_probe.py 119, round 4). MFH_DEVICE_CACHE_MB=0 restores plain hipMalloc / hipFree. mfh_device_cache_trim() empties it on request.
+// and the request repeated. The cache is bounded (MFH_DEVICE_CACHE_MB, default FOUR FIFTHS of the device's memory): beyond that the largest blocks
+// go back to the driver -- and the next large hipMalloc pays for it (the stall grows with the bytes freed, ~18 GB/s): with a bound of a third, and
+// still with half, a released 129 GB context (configs[4]) on top of the setup's cached temporaries lost its 58 GB value array and the next
+// context waited 1 - 3 s for a new one (scripts/setup_probe.py 119, round 4). What the library itself cannot allocate any more flushes the
+// cache and is retried; OTHER allocators of the process (torch, RCCL) do not know about it: mfh_device_cache_trim() before handing them the device. MFH_DEVICE_CACHE_MB=0 restores plain hipMalloc / hipFree. mfh_device_cache_trim() empties it on request.
 #include "mfh_internal.hh"
 #include <map>
 #include <mutex>
@@ -25,7 +27,8 @@ struct DevCache {
     std::multimap<size_t, void *> free;      // released blocks by size
     size_t cachedBytes = 0, limit = 0;
     bool init = false, enabled = true;
-    int64_t hits = 0, misses = 0, flushes = 0;
+    int64_t hits = 0, misses = 0, flushes = 0, bypassed = 0;
+    size_t evictedBytes = 0;
 };
 std::mutex g_mu;
 std::map<int, DevCache> g_cache;                 // one free list per device
@@ -49,7 +52,7 @@ DevCache &cache_of(int dev) {
         C.init = true;
         size_t fr = 0, total = 0;
         if (hipMemGetInfo(&fr, &total) != hipSuccess) { (void)hipGetLastError(); total = (size_t)64 << 30; }
-        C.limit = total / 2;
+        C.limit = total / 5 * 4;
         if (const char *e = getenv("MFH_DEVICE_CACHE_MB")) {
             const long long mb = atoll(e);
             if (mb <= 0) C.enabled = false;
@@ -85,7 +88,15 @@ void *device_alloc(size_t bytes) {
         }
     }
     void *p = nullptr;
+    static const bool trace = getenv("MFH_POOL_TRACE") != nullptr;
+    const double tTrace = trace ? now_ms() : 0.0;
     hipError_t e = hipMalloc(&p, bytes);
+    if (trace && (now_ms() - tTrace > 20.0 || bytes >= ((size_t)4 << 30))) {
+        size_t fr = 0, tot = 0;
+        (void)hipMemGetInfo(&fr, &tot);
+        fprintf(stderr, "[pool] hipMalloc %.1f MB: %.1f ms; cached %.1f GB in %zu blocks, device free %.1f GB, returned to the driver so far %.1f GB (%lld blocks outside an API scope)\n",
+                bytes / 1e6, now_ms() - tTrace, C.cachedBytes / 1e9, C.free.size(), fr / 1e9, C.evictedBytes / 1e9, (long long)C.bypassed);
+    }
     if (e != hipSuccess && C.enabled && !C.free.empty()) {
         (void)hipGetLastError();
         flush_locked(C);
@@ -115,6 +126,9 @@ void device_free(void *p) {
     if (t_mode == 0) {
         // released outside any API entry (no PoolScope: the streams that may still use the block are unknown): plain hipFree, which waits for
         // the block's users by itself -- NOT a device-wide wait, which would invalidate the stream captures of other host threads
+        DevCache &C0 = cache_of(blk.dev);
+        ++C0.bypassed;
+        C0.evictedBytes += blk.bytes;
         g_blocks.erase(it);
         lock.unlock();
         (void)hipFree(p);
@@ -129,6 +143,7 @@ void device_free(void *p) {
     while (C.cachedBytes > C.limit && !C.free.empty()) {      // over the bound: the largest blocks go back to the driver
         auto last = std::prev(C.free.end());
         C.cachedBytes -= last->first;
+        C.evictedBytes += last->first;
         g_blocks.erase(last->second);
         (void)hipFree(last->second);
         C.free.erase(last);

@@ -36,6 +36,7 @@ mfh_status mfh_bc_dirichlet_box(mfh_ctx *c, const double *mn, const double *mx, 
     const int d = m.dim;
     double bmn[3], bmx[3];
     box_corners(c, mn, mx, relative, bmn, bmx);
+    ensure_dirichlet_tables(c);
     for (int32_t bn : m.bdryNodes) {   // LinearElasticity.hh:941-948
         bool in = true;
         for (int a = 0; a < d; ++a) {
@@ -94,6 +95,7 @@ mfh_status mfh_bc_dirichlet_nodes(mfh_ctx *c, int64_t n, const int64_t *nodes, c
     const int d = m.dim;
     std::vector<uint8_t> isBdry((size_t)m.nNode, 0);
     for (int32_t bn : m.bdryNodes) isBdry[bn] = 1;
+    ensure_dirichlet_tables(c);
     for (int64_t k = 0; k < n; ++k) {   // LinearElasticity.hh:991-1002
         const int64_t ni = nodes[k];
         require(ni >= 0 && ni < m.nNode, MFH_ERR_INVALID, "node index out of bounds");
@@ -420,7 +422,7 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
         size_t total = 0;
         for (int32_t bn : m.bdryNodes)
             for (int a = 0; a < gd; ++a)
-                if (c->dirMask[(size_t)bn * gd + a]) { needsT &= ~(1u << a); ++total; }
+                if (!c->dirMask.empty() && c->dirMask[(size_t)bn * gd + a]) { needsT &= ~(1u << a); ++total; }
         if (needsT) {
             if (flags & MFH_SOLVE_PIN) pin(needsT);
             else { addTranslationRows(needsT); crhs.assign(C.size(), 0.0); }

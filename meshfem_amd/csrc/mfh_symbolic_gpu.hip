@@ -182,7 +182,7 @@ inline unsigned bits_for(uint64_t v) { unsigned b = 1; while ((v >> b) != 0 && b
 // the true chain into every range only until it meets a boundary that range's own scan produced (a few chunks), then adopts the rest.
 // The result is the sequential one (57.6 M rows at 119^3: 2 x 55 ms of the first assembly before).
 namespace {
-inline int64_t greedy_step(const std::vector<int32_t> &rowPtr, int64_t nRows, int chunkSlots, const std::vector<int64_t> &breaks, int64_t r) {
+inline int64_t greedy_step(const int32_t *rowPtr, int64_t nRows, int chunkSlots, const std::vector<int64_t> &breaks, int64_t r) {
     const int32_t s0 = rowPtr[r];
     const auto it = std::upper_bound(breaks.begin(), breaks.end(), r);
     const int64_t stop = it != breaks.end() ? *it : -1;
@@ -194,7 +194,7 @@ inline int64_t greedy_step(const std::vector<int32_t> &rowPtr, int64_t nRows, in
 
 } // namespace
 
-std::vector<int32_t> make_chunks(const std::vector<int32_t> &rowPtr, int64_t nRows, int chunkSlots, const std::vector<int64_t> &breaks, int64_t grain,
+std::vector<int32_t> make_chunks(const int32_t *rowPtr, int64_t nRows, int chunkSlots, const std::vector<int64_t> &breaks, int64_t grain,
                                  int maxThreads) {
     std::vector<int32_t> chunkRow{0};
     const int nt = (int)std::min<int64_t>(maxThreads > 0 ? maxThreads : host_threads(), nRows / std::max<int64_t>(1, grain));
@@ -399,7 +399,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     RP(rocprim::exclusive_scan(nullptr, exBytes, rowLen.p, dRowPtr.p, (int32_t)0, (size_t)nRows + 1, rocprim::plus<int32_t>(), s));
     if (exBytes + 16 > tmp.n) tmp.alloc(exBytes + 16);
     RP(rocprim::exclusive_scan(tmp.p, exBytes, rowLen.p, dRowPtr.p, (int32_t)0, (size_t)nRows + 1, rocprim::plus<int32_t>(), s));
-    S.rowPtr.resize((size_t)nRows + 1);
+    resize_prefaulted(S.rowPtr, (size_t)nRows + 1);      // (page faults on all host threads while the scan runs on the device)
     dRowPtr.download(S.rowPtr.data(), S.rowPtr.size(), s);
     {
         std::vector<int32_t> mx((size_t)host_threads() + 1, 0);
@@ -419,7 +419,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
         throw Error(MFH_ERR_UNSUPPORTED, "a block row has more than 2048 blocks (vertex valence too high for LDS accumulation)");
     S.chunkSlots = chunkSlots;
     S.spmvChunkSlots = std::max(512, chunkSlots);
-    std::thread spmvChunks([&]() { S.spmvChunkRow = make_chunks(S.rowPtr, nRows, S.spmvChunkSlots); });   // (the greedy scans are sequential by nature)
+    std::thread spmvChunks([&]() { S.spmvChunkRow = make_chunks(S.rowPtr.data(), nRows, S.spmvChunkSlots); });   // (the greedy scans are sequential by nature)
     struct Joiner { std::thread &t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{spmvChunks};          // also when a step below throws
     // The gather codes are packed relative to the smallest element of their chunk (25 bits). On meshes of 2^25 elements and more a chunk
     // that holds rows from two ends of the node numbering -- the last corner vertices and the first cell centres of the generator's
@@ -431,7 +431,8 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     DBuf<int32_t> dCR;
     bool packed = false;
     for (int round = 0; round < 4; ++round) {
-        S.chunkRow = make_chunks(S.rowPtr, nRows, chunkSlots, breaks);
+        S.chunkRow = make_chunks(S.rowPtr.data(), nRows, chunkSlots, breaks);
+        lap("  chunks: greedy scan");
         nChunk = S.nChunk();
         S.contribPtr.resize((size_t)nChunk + 1);
         dCR.upload(S.chunkRow, s);
@@ -440,6 +441,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
         RP(hipGetLastError());
         MFH_HIP(hipMemcpyAsync(S.contribPtr.data(), dSeg.p, (size_t)(nChunk + 1) * sizeof(int64_t), hipMemcpyDeviceToHost, s));
         MFH_HIP(hipStreamSynchronize(s));
+        lap("  chunks: upload + first contributions");
         if (!dChunkElemBase) break;
         constexpr int MAXOFF = 1024;
         const int stride = chunkSlots;             // a chunk holds at most chunkSlots rows
@@ -453,6 +455,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
         RP(hipGetLastError());
         int nOff = 0;
         flag.download(&nOff, 1, s);
+        lap("  chunks: element span of every chunk");
         if (nOff == 0) { packed = true; break; }
         if (nOff > MAXOFF || round == 3) break;    // no locality to speak of: absolute codes (if they fit)
         std::vector<int32_t> hOff((size_t)nOff);
@@ -479,7 +482,7 @@ void build_symbolic_device(const HostMesh &m, const int32_t *dElemNodes, const i
     }
     spmvChunks.join();
 
-    lap("chunks (host)");
+    lap("chunks (host): rest");
     // ---- element-major order inside every chunk: sort by (chunk, code)
     DBuf<int32_t> dChunkOfRow, dChunkBase;
     dChunkOfRow.alloc((size_t)nRows);
@@ -1300,8 +1303,9 @@ __global__ void __launch_bounds__(256) k_topo_face_compact(int64_t n, const uint
 // two-sort variant of the half-face ordering. instEdge: nElem*nedge first-encounter edge-node ranks (deg 2 only);
 // bdryInst: half-face (4t+f) / half-edge (3t+c) instances without a mate, in sorted-key order.
 bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const int32_t *hostElemVerts, hipStream_t s,
-                           std::vector<int32_t> &instEdge, int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst,
-                           const double *hostVertPos, DBuf<int32_t> *dElemNodesOut, DBuf<double> *dNodePosOut) {
+                           RawVec<int32_t> &instEdge, int32_t &nEdgeNodes, std::vector<uint32_t> &bdryInst,
+                           const double *hostVertPos, DBuf<int32_t> *dElemNodesOut, DBuf<double> *dNodePosOut,
+                           const std::function<void(int, int32_t)> &hostOverlap) {
     // packed 3 x 21-bit face keys do not fit beyond 2^21 vertices: two-sort variant below (MFH_TOPO_FORCE_WIDE: tests)
     const bool wide = dim == 3 && (nVert >= (1 << 21) || getenv("MFH_TOPO_FORCE_WIDE") != nullptr);
     const int nv = dim + 1, nedge = dim == 3 ? 6 : 3;
@@ -1322,6 +1326,10 @@ bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const
         RP(rocprim::radix_sort_pairs(nullptr, b, kA.p, kB.p, vA.p, vB.p, (size_t)n, 0u, 32 + bits_for((uint64_t)nVert), s));
         ensureTmp(b);
         RP(rocprim::radix_sort_pairs(tmp.p, b, kA.p, kB.p, vA.p, vB.p, (size_t)n, 0u, 32 + bits_for((uint64_t)nVert), s));
+        // the host table the ranks are downloaded into (0.97 GB at 119^3) takes its page faults on all host threads while the sort runs,
+        // and so does whatever the caller wants sized meanwhile (stage 0: the element node table)
+        resize_prefaulted(instEdge, (size_t)n);
+        if (hostOverlap) hostOverlap(0, 0);
         hipLaunchKernelGGL(k_sym_heads, dim3(grid_of(n)), dim3(256), 0, s, n, kB.p, headP1.p, 0u);
         RP(rocprim::inclusive_scan(nullptr, b, headP1.p, headP1.p, (size_t)n, rocprim::plus<uint32_t>(), s));
         ensureTmp(b);
@@ -1342,8 +1350,6 @@ bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const
         dInst.alloc(n);
         hipLaunchKernelGGL(k_topo_edge_assign, dim3(grid_of(n)), dim3(256), 0, s, n, vB.p, headP1.p, rankOfUniq.p, dInst.p);
         RP(hipGetLastError());
-        instEdge.resize((size_t)n);
-        dInst.download(instEdge.data(), (size_t)n, s);
     }
     if (dElemNodesOut && dNodePosOut && hostVertPos) {
         // the device copies of the node table and of the node positions: only the vertices cross the bus
@@ -1390,6 +1396,10 @@ bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const
         RP(rocprim::inclusive_scan(tmp.p, b, flag.p, posP1.p, (size_t)n, rocprim::plus<uint32_t>(), s));
         uint32_t nB = 0;
         int nonManifold = 0;
+        // everything up to here is queued: the caller's second batch of host work (stage 1: the node positions, whose size is known now)
+        // runs while the device sorts the half-faces; the edge-node ranks come down behind it
+        if (hostOverlap) hostOverlap(1, nEdgeNodes);
+        if (deg == 2) dInst.download(instEdge.data(), instEdge.size(), s);
         MFH_HIP(hipMemcpyAsync(&nB, posP1.p + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         MFH_HIP(hipMemcpyAsync(&nonManifold, nm.p, sizeof(int), hipMemcpyDeviceToHost, s));
         MFH_HIP(hipStreamSynchronize(s));
