@@ -422,7 +422,7 @@ k::SpmvMfArgs spmv_mf_cluster_args(mfh_ctx *c, bool masked) {
     a.clBlocks = c->mfc.nBlocks; a.clMaxLocal = c->mfc.maxLocal; a.clBlockElems = c->mfc.blockElems; a.clBlockPtr = D.blockPtr.p; a.clEntryRow = D.entryRow.p;
     a.clEntryDest = D.entryDest.p; a.clLocalIdx = D.localIdx.p; a.clIfaceBuf = D.ifaceBuf.p; a.rowWrite = nullptr; a.rowMap = D.rowMap.p;
     // second pass: k_mf_rows streaming the interface partials (pairPos != null selects the sequential read)
-    a.nChunk = c->mfc.nIface > 0 ? (int64_t)c->mfc.chunkRow.size() - 1 : 0;
+    a.nChunk = c->mfc.nIface > 0 ? c->mfc.nChunk : 0;
     a.chunkRow = D.chunkRow.p; a.pairPtr = D.pairPtr.p; a.pairRow = D.ifaceRow.p; a.pairCode = nullptr;
     a.pairPos = reinterpret_cast<const uint32_t *>(D.ifaceRow.p);   // only tested against null
     a.sig = D.ifaceBuf.p; a.maxRows = c->mfc.maxRows;
@@ -922,7 +922,10 @@ void dirichlet_vars(mfh_ctx *c, std::vector<int64_t> &vars, std::vector<double> 
     const HostMesh &m = c->mesh;
     const int d = m.dim;
     if (c->dirMask.empty()) return;               // no Dirichlet condition was ever set (ensure_dirichlet_tables)
-    std::vector<int32_t> constraintIndex((size_t)c->nDoF, -1);
+    // two boundary nodes can share a DoF only under a DoF map (periodic identification): without one every constrained node is the first of
+    // its DoF and the DoF -> constraint table (230 MB filled with -1 at 119^3: 65 ms of every solve) is not needed
+    const bool shared = !c->dofForNode.empty();
+    std::vector<int32_t> constraintIndex(shared ? (size_t)c->nDoF : (size_t)0, -1);
     std::vector<int32_t> cDoF;
     std::vector<int64_t> cNode;
     for (int32_t bn : m.bdryNodes) {
@@ -930,7 +933,10 @@ void dirichlet_vars(mfh_ctx *c, std::vector<int64_t> &vars, std::vector<double> 
         for (int a = 0; a < d; ++a) has |= c->dirMask[(size_t)bn * d + a] != 0;
         if (!has) continue;
         const int32_t dof = dof_of(c, bn);
-        if (constraintIndex[dof] < 0) {
+        if (!shared) {
+            cDoF.push_back(dof);
+            cNode.push_back(bn);
+        } else if (constraintIndex[dof] < 0) {
             constraintIndex[dof] = (int32_t)cDoF.size();
             cDoF.push_back(dof);
             cNode.push_back(bn);

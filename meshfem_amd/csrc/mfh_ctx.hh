@@ -16,7 +16,8 @@ struct mfh_ctx {
     bool keepHostSymbolic = false;
     int xcdSwizzle = 0;              // option "xcd_swizzle": XCD-contiguous work mapping in the chunked kernels (measured SLOWER
                                      // than the round-robin default on MI355X: DESIGN.md section 4.8)
-    std::vector<double> hLoad, hX;   // host scratch of Simulator::solve (kept between solves)
+    RawVec<double> hLoad, hX;        // host scratch of Simulator::solve (kept between solves; sized with resize_prefaulted: a value-initialising
+                                     // resize of 1.4 GB at 119^3 is 0.25 s of single-threaded page faults, twice per first solve)
     bool alwaysReembed = false;      // option "reembed": every mfh_assemble re-runs the embedding kernel
     // option "deterministic": run-to-run bit-reproducible assembly, operator and PCG. The reference's scatter into the triplet list is serial
     // and therefore reproducible (LinearElasticity.hh:1454-1455; the one place that is not, it documents and switches off,

@@ -252,12 +252,10 @@ struct MfLists {
 constexpr int MF_BLOCK = 256;
 struct MfClusterLists {
     int64_t nBlocks = 0, nEntries = 0, nIface = 0, nIfaceRows = 0;
+    int64_t nChunk = 0;                 // chunks of the second pass (chunkRow / pairPtr live on the device only: MfClusterDev)
     int blockElems = MF_BLOCK;          // elements per block (<= MF_BLOCK threads)
     int maxLocal = 0;                   // largest number of distinct rows of a block (LDS accumulators)
-    // second pass (interface partials in row order)
-    std::vector<int32_t> chunkRow;
-    std::vector<int64_t> pairPtr;
-    int maxRows = 0;
+    int maxRows = 0;                    // most interface rows of a second-pass chunk (LDS of k_mf_rows)
 };
 struct MfClusterDev {
     DBuf<uint16_t> localIdx;            // [nElem*npe]: index of the pair's row among the block's rows

@@ -17,6 +17,7 @@ namespace mfhi {
 
 k::TLArgs tl_args(mfh_ctx *c);
 void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double *dotOut);
+bool prepare_matrix_free(mfh_ctx *c);
 void ensure_fixed_uploaded(mfh_ctx *c);
 double device_dot(mfh_ctx *c, int64_t n, const double *a, const double *b);
 void upload_mesh(mfh_ctx *c, bool deviceTables);
@@ -608,12 +609,17 @@ bool ensure_multigrid(mfh_ctx *c) {
         G.rfull.alloc((size_t)n0);
         for (DBuf<double> *v : {&G.r0, &G.d0, &G.t0, &G.rfull, &G.b1, &G.x1, &G.r1, &G.d1, &G.t1}) v->zero(s);
     }
+    lap("uploads + work vectors");
     // ---- spectra of the two Jacobi-preconditioned operators
     ensure_precond(c);
+    lap("quadratic level: diagonal blocks");
+    if (!distributed) prepare_matrix_free(c);          // (what the first application of the operator would do; here for the lap)
+    lap("quadratic level: operator lists");
     // the power iteration approaches the largest eigenvalue from below: a margin keeps the Chebyshev polynomials bounded on the whole spectrum
     G.lmax0 = c->mgEigMargin * estimate_lambda_max(c, nodal_ops(c, nullptr, 0, nullptr), G.r0.p, G.d0.p, G.t0.p);
+    lap("spectrum of the quadratic level");
     G.lmax1 = c->mgEigMargin * estimate_lambda_max(c, nodal_ops(c1, nullptr, 0, nullptr), G.r1.p, G.d1.p, G.t1.p);
-    lap("uploads + eigenvalue estimates");
+    lap("spectrum of the linear level");
     G.rigidCoarse = haveCoarse;
     G.setup_ms = now_ms() - t0;
     G.valid = true;

@@ -162,7 +162,7 @@ mfh_status mfh_neumann_load(mfh_ctx *c, double *out) {
     require(c && c->haveMesh && out, MFH_ERR_STATE, "no mesh set");
     const HostMesh &m = c->mesh;
     const int d = m.dim;
-    std::fill(out, out + (size_t)d * c->nDoF, 0.0);
+    parallel_ranges((int64_t)d * c->nDoF, [&](int64_t lo, int64_t hi, int) { std::fill(out + lo, out + hi, 0.0); });
     // integral of the boundary shape functions (Functions.hh:246-274): P1 1/K' each; P2 face {0,0,0,1/3,1/3,1/3};
     // P2 edge {1/6,1/6,4/6}
     double w[6] = {0, 0, 0, 0, 0, 0};
@@ -319,19 +319,19 @@ static void jacobi_eig(int k, std::vector<double> &A, std::vector<double> &V) {
     }
 }
 // y += a x and y *= a on all host threads (the constraint rows and rigid modes are full-length vectors: tens of them at 20 M DoFs)
-static void paxpy(std::vector<double> &y, double a, const std::vector<double> &x) {
-    double *yp = y.data();
-    const double *xp = x.data();
-    parallel_ranges((int64_t)y.size(), [&](int64_t lo, int64_t hi, int) { for (int64_t q = lo; q < hi; ++q) yp[q] += a * xp[q]; });
+static void paxpy_n(double *yp, double a, const double *xp, int64_t n) {
+    parallel_ranges(n, [&](int64_t lo, int64_t hi, int) { for (int64_t q = lo; q < hi; ++q) yp[q] += a * xp[q]; });
 }
+static void paxpy(std::vector<double> &y, double a, const std::vector<double> &x) { paxpy_n(y.data(), a, x.data(), (int64_t)y.size()); }
+static void paxpy(RawVec<double> &y, double a, const std::vector<double> &x) { paxpy_n(y.data(), a, x.data(), (int64_t)y.size()); }
 static void pscale(std::vector<double> &y, double a) {
     double *yp = y.data();
     parallel_ranges((int64_t)y.size(), [&](int64_t lo, int64_t hi, int) { for (int64_t q = lo; q < hi; ++q) yp[q] *= a; });
 }
-static double hdot(const std::vector<double> &a, const std::vector<double> &b) {
+static double hdot_n(const double *a, const double *b, int64_t n) {
     const int nt = host_threads();
     std::vector<double> part((size_t)nt + 1, 0.0);
-    parallel_ranges((int64_t)a.size(), [&](int64_t lo, int64_t hi, int tid) {
+    parallel_ranges(n, [&](int64_t lo, int64_t hi, int tid) {
         double v = 0;
         for (int64_t q = lo; q < hi; ++q) v += a[q] * b[q];
         part[tid] += v;
@@ -340,6 +340,8 @@ static double hdot(const std::vector<double> &a, const std::vector<double> &b) {
     for (double x : part) v += x;
     return v;
 }
+static double hdot(const std::vector<double> &a, const std::vector<double> &b) { return hdot_n(a.data(), b.data(), (int64_t)a.size()); }
+static double hdot(const std::vector<double> &a, const RawVec<double> &b) { return hdot_n(a.data(), b.data(), (int64_t)a.size()); }
 
 // Simulator::solve with the whole of assembleConstrainedSystem (LinearElasticity.hh:1201-1249): pin / translation /
 // rotation constraints, Dirichlet variables. The reference solves the resulting KKT system with UMFPACK
@@ -437,18 +439,18 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
     }
     lap("fixed-variable mask");
     // host scratch vectors live in the context: a fresh 178 MB std::vector costs ~30 ms of page faults per solve at config 3
-    std::vector<double> &load = c->hLoad;
+    RawVec<double> &load = c->hLoad;
     if (!f) {
-        load.resize((size_t)n);
+        resize_prefaulted(load, (size_t)n);
         if (c->op == MFH_OP_ELASTICITY) {
             mfh_status st = mfh_neumann_load(c, load.data());   // zero-fills first
             if (st != MFH_OK) throw Error(st, c->err);
-        } else std::fill(load.begin(), load.end(), 0.0);   // scalar PDE: zero right-hand side, zero-Neumann natural condition (Poisson.hh:100-102)
+        } else parallel_ranges(n, [&](int64_t lo, int64_t hi, int) { std::fill(load.data() + lo, load.data() + hi, 0.0); });   // scalar PDE: zero right-hand side, zero-Neumann natural condition (Poisson.hh:100-102)
         f = load.data();
     }
     lap("load vector");
-    std::vector<double> &x = c->hX;
-    x.resize((size_t)n);
+    RawVec<double> &x = c->hX;
+    resize_prefaulted(x, (size_t)n);
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     ensure_precond(c);

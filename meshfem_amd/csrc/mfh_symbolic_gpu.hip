@@ -270,6 +270,11 @@ __global__ void __launch_bounds__(256) k_elem_morton(int64_t nElem, int npe, int
         val[e] = (uint32_t)e;
     }
 }
+__global__ void __launch_bounds__(256) k_cell_starts(int64_t n, const uint64_t *__restrict__ key, const uint32_t *__restrict__ cellP1,
+                                                     int32_t *__restrict__ cellStart) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256)
+        if (k == 0 || key[k] != key[k - 1]) cellStart[cellP1[k] - 1] = (int32_t)k;
+}
 __global__ void __launch_bounds__(256) k_permute_rows_i32(int64_t n, int W, const uint32_t *__restrict__ perm, const int32_t *__restrict__ src,
                                                          int32_t *__restrict__ dst, int32_t *__restrict__ permOut) {
     const int64_t total = n * W;
@@ -698,6 +703,48 @@ __global__ void __launch_bounds__(256) k_mfc_iface_assign(int64_t nI, const uint
         ifaceRow[p] = (uint16_t)(ii - chunkFirstIdx[chunkOfIdx[ii]]);
     }
 }
+__global__ void __launch_bounds__(256) k_mfc_block_of_elem(int64_t nElem, int32_t nBlocks, const int32_t *__restrict__ elemPtr, int32_t *__restrict__ blockOfElem) {
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nElem; e += (int64_t)gridDim.x * 256) {
+        int32_t lo = 0, hi = nBlocks;                     // the block b with elemPtr[b] <= e < elemPtr[b + 1]
+        while (hi - lo > 1) {
+            const int32_t mid = (lo + hi) >> 1;
+            if ((int64_t)elemPtr[mid] <= e) lo = mid; else hi = mid;
+        }
+        blockOfElem[e] = lo;
+    }
+}
+__global__ void __launch_bounds__(256) k_mfc_rowflag32(int64_t nRows, const int32_t *__restrict__ rowIfaceCount, int32_t *__restrict__ flag) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r <= nRows; r += (int64_t)gridDim.x * 256) flag[r] = (r < nRows && rowIfaceCount[r] > 0) ? 1 : 0;
+}
+// interface row ii (compact numbering): its global row, the end of its partials in the row-ordered interface list
+__global__ void __launch_bounds__(256) k_mfc_iface_rows(int64_t nRows, const int32_t *__restrict__ rowIfaceCount, const int32_t *__restrict__ idxOfRow,
+                                                        const int32_t *__restrict__ rowIPtr, int32_t *__restrict__ rowMap, int32_t *__restrict__ iptr) {
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nRows; r += (int64_t)gridDim.x * 256)
+        if (rowIfaceCount[r] > 0) { const int32_t ii = idxOfRow[r]; rowMap[ii] = (int32_t)r; iptr[ii + 1] = rowIPtr[r + 1]; }
+}
+// chunks of the second pass: one thread per group of maxRows consecutive interface rows; chunkBase == null counts, otherwise writes
+__global__ void __launch_bounds__(256) k_mfc_chunks(int64_t nGroups, int64_t nIR, int maxRows, int maxPairs, const int32_t *__restrict__ iptr,
+                                                    const int32_t *__restrict__ chunkBase, int32_t *__restrict__ chunksOfGroup,
+                                                    int32_t *__restrict__ chunkRow, int64_t *__restrict__ pairPtr, int32_t *__restrict__ chunkOfIdx) {
+    for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < nGroups; g += (int64_t)gridDim.x * 256) {
+        const int64_t end = min(nIR, (g + 1) * (int64_t)maxRows);
+        int32_t cnt = 0;
+        for (int64_t r = g * (int64_t)maxRows; r < end;) {
+            const int32_t base = iptr[r];
+            int64_t r2 = r + 1;
+            while (r2 < end && iptr[r2 + 1] - base <= maxPairs) ++r2;
+            if (chunkBase) {
+                const int32_t ch = chunkBase[g] + cnt;
+                chunkRow[ch] = (int32_t)r;
+                pairPtr[ch] = base;
+                for (int64_t q = r; q < r2; ++q) chunkOfIdx[q] = ch;
+            }
+            ++cnt;
+            r = r2;
+        }
+        if (!chunkBase) chunksOfGroup[g] = cnt;
+    }
+}
 __global__ void __launch_bounds__(256) k_mfc_rowflag(int64_t nRows, const int32_t *__restrict__ rowIfaceCount, uint8_t *__restrict__ flag) {
     for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < nRows; r += (int64_t)gridDim.x * 256) flag[r] = rowIfaceCount[r] > 0;
 }
@@ -708,6 +755,15 @@ void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes,
     const int npe = m.npe;
     const int64_t N = m.nElem * npe;
     if ((double)N >= 4294967295.0) throw Error(MFH_ERR_UNSUPPORTED, "mesh too large for 32-bit pair codes");
+    const bool timing = getenv("MFH_MFC_TIMING") != nullptr;
+    double tp = now_ms();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        const double t = now_ms();
+        fprintf(stderr, "[operator lists] %-40s %8.2f ms\n", what, t - tp);
+        tp = t;
+    };
     L = MfClusterLists();
     L.blockElems = std::max(16, std::min(blockElems, MF_BLOCK));
     L.nBlocks = (m.nElem + L.blockElems - 1) / L.blockElems;
@@ -715,12 +771,12 @@ void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes,
     D.elemPtr.release();
     if (blockStart && blockStart->size() >= 2) {
         L.nBlocks = (int64_t)blockStart->size() - 1;
-        std::vector<int32_t> boe((size_t)m.nElem);
-        for (int64_t b = 0; b < L.nBlocks; ++b)
-            for (int32_t e = (*blockStart)[(size_t)b]; e < (*blockStart)[(size_t)b + 1]; ++e) boe[(size_t)e] = (int32_t)b;
-        dBlockOfElem.upload(boe, s);
         D.elemPtr.upload(*blockStart, s);
+        dBlockOfElem.alloc((size_t)m.nElem);      // (a host loop over the 40 M elements of a 119^3 grid + the upload of its result took 49 ms)
+        hipLaunchKernelGGL(k_mfc_block_of_elem, dim3(grid_of(m.nElem)), dim3(256), 0, s, m.nElem, (int32_t)L.nBlocks, (const int32_t *)D.elemPtr.p, dBlockOfElem.p);
+        RP(hipGetLastError());
     }
+    lap("block of every element");
     DBuf<uint64_t> keyA, keyB;
     DBuf<uint32_t> valA, valB, entP1;
     DBuf<int32_t> rowCount, rowIfaceCount;
@@ -736,6 +792,7 @@ void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes,
     tmp.alloc(tmpBytes + 16);
     RP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)N, 0u, endBit, s));
     keyA.release(); valA.release();
+    lap("keys + sort by (block, row)");
     // ---- entries = distinct (block, row) pairs
     entP1.alloc(N);
     hipLaunchKernelGGL(k_sym_heads, dim3(grid_of(N)), dim3(256), 0, s, N, keyB.p, entP1.p, 0u);
@@ -761,6 +818,7 @@ void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes,
     std::vector<int32_t> hBlockPtr((size_t)L.nBlocks + 1);
     D.blockPtr.download(hBlockPtr.data(), hBlockPtr.size(), s);
     for (int64_t b = 0; b < L.nBlocks; ++b) L.maxLocal = std::max(L.maxLocal, hBlockPtr[b + 1] - hBlockPtr[b]);
+    lap("entries, local indices, block table");
     // ---- classification: finished in the block, or interface
     rowIfaceCount.alloc((size_t)nRows + 1); rowIfaceCount.zero(s);
     hipLaunchKernelGGL(k_mfc_classify, dim3(grid_of(nU)), dim3(256), 0, s, nU, N, nRows, D.entryRow.p, entryStart.p, rowCount.p, D.entryDest.p,
@@ -780,6 +838,7 @@ void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes,
     L.nIface = nI;
     D.rowIsIface.alloc((size_t)nRows);
     hipLaunchKernelGGL(k_mfc_rowflag, dim3(grid_of(nRows)), dim3(256), 0, s, nRows, rowIfaceCount.p, D.rowIsIface.p);
+    lap("classification + interface count");
     // ---- second-pass chunks over the rows (only interface entries count)
     DBuf<int32_t> rowIPtr;
     rowIPtr.alloc((size_t)nRows + 1);
@@ -787,41 +846,66 @@ void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes,
     RP(rocprim::exclusive_scan(nullptr, exBytes, rowIfaceCount.p, rowIPtr.p, (int32_t)0, (size_t)nRows + 1, rocprim::plus<int32_t>(), s));
     if (exBytes + 16 > tmp.n) tmp.alloc(exBytes + 16);
     RP(rocprim::exclusive_scan(tmp.p, exBytes, rowIfaceCount.p, rowIPtr.p, (int32_t)0, (size_t)nRows + 1, rocprim::plus<int32_t>(), s));
-    std::vector<int32_t> hRowPtr((size_t)nRows + 1);
-    rowIPtr.download(hRowPtr.data(), hRowPtr.size(), s);
-    // the second pass works in the compact numbering of the interface rows (rows with at least one partial)
-    std::vector<int32_t> ifaceIdxOfRow((size_t)nRows, -1), ifaceRows, iptr{0};
-    for (int64_t r = 0; r < nRows; ++r)
-        if (hRowPtr[r + 1] > hRowPtr[r]) {
-            ifaceIdxOfRow[(size_t)r] = (int32_t)ifaceRows.size();
-            ifaceRows.push_back((int32_t)r);
-            iptr.push_back(hRowPtr[r + 1]);
-        }
-    const int64_t nIR = (int64_t)ifaceRows.size();
+    lap("interface row pointers (scan)");
+    // The second pass works in the compact numbering of the interface rows (rows with at least one partial). Everything below used to be a host
+    // loop over the rows (download of 230 MB of row pointers, 57.6 M iterations, uploads of the tables: 0.24 s at 119^3); it is a scan, a
+    // compaction and two small kernels now. Chunks: groups of at most maxRowsCap consecutive interface rows, cut where the partials of a
+    // group exceed maxPairs -- one thread walks one group, so the cuts need no sequential pass over all rows.
     const int maxRowsCap = 512, maxPairs = 2048;
-    L.chunkRow.assign(1, 0);
-    for (int64_t r = 0; r < nIR;) {
-        int64_t r2 = r + 1;
-        while (r2 < nIR && r2 - r < maxRowsCap && iptr[r2 + 1] - iptr[r] <= maxPairs) ++r2;
-        L.maxRows = std::max<int>(L.maxRows, (int)(r2 - r));
-        L.chunkRow.push_back((int32_t)r2);
-        r = r2;
-    }
-    const int64_t nChunk = (int64_t)L.chunkRow.size() - 1;
-    L.pairPtr.resize((size_t)nChunk + 1);
-    std::vector<int32_t> chunkOfIdx((size_t)std::max<int64_t>(nIR, 1)), chunkFirst((size_t)std::max<int64_t>(nChunk, 1));
-    for (int64_t c = 0; c < nChunk; ++c) {
-        L.pairPtr[c] = iptr[L.chunkRow[c]];
-        chunkFirst[c] = L.chunkRow[c];
-        for (int32_t q = L.chunkRow[c]; q < L.chunkRow[c + 1]; ++q) chunkOfIdx[q] = (int32_t)c;
-    }
-    L.pairPtr[nChunk] = nI;
+    DBuf<int32_t> ifl, dIdxOfRow, iptr, chunksOfGroup, chunkBase, dChunkOfIdx;
+    ifl.alloc((size_t)nRows + 1); dIdxOfRow.alloc((size_t)nRows + 1);
+    hipLaunchKernelGGL(k_mfc_rowflag32, dim3(grid_of(nRows + 1)), dim3(256), 0, s, nRows, rowIfaceCount.p, ifl.p);
+    RP(rocprim::exclusive_scan(nullptr, exBytes, ifl.p, dIdxOfRow.p, (int32_t)0, (size_t)nRows + 1, rocprim::plus<int32_t>(), s));
+    if (exBytes + 16 > tmp.n) tmp.alloc(exBytes + 16);
+    RP(rocprim::exclusive_scan(tmp.p, exBytes, ifl.p, dIdxOfRow.p, (int32_t)0, (size_t)nRows + 1, rocprim::plus<int32_t>(), s));
+    int32_t nIR32 = 0;
+    MFH_HIP(hipMemcpyAsync(&nIR32, dIdxOfRow.p + nRows, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    const int64_t nIR = nIR32;
+    ifl.release();
     L.nIfaceRows = nIR;
-    D.chunkRow.upload(L.chunkRow, s);
-    D.pairPtr.upload(L.pairPtr, s);
-    D.rowMap.upload(ifaceRows.empty() ? std::vector<int32_t>{0} : ifaceRows, s);
+    L.maxRows = (int)std::min<int64_t>(nIR, maxRowsCap);
+    D.rowMap.alloc((size_t)std::max<int64_t>(nIR, 1));
+    iptr.alloc((size_t)nIR + 1);
+    MFH_HIP(hipMemsetAsync(iptr.p, 0, sizeof(int32_t), s));
+    if (nIR == 0) MFH_HIP(hipMemsetAsync(D.rowMap.p, 0, sizeof(int32_t), s));
+    hipLaunchKernelGGL(k_mfc_iface_rows, dim3(grid_of(nRows)), dim3(256), 0, s, nRows, rowIfaceCount.p, dIdxOfRow.p, rowIPtr.p, D.rowMap.p, iptr.p);
+    RP(hipGetLastError());
+    const int64_t nGroups = (nIR + maxRowsCap - 1) / maxRowsCap;
+    chunksOfGroup.alloc((size_t)nGroups + 1); chunkBase.alloc((size_t)nGroups + 1);
+    MFH_HIP(hipMemsetAsync(chunksOfGroup.p + nGroups, 0, sizeof(int32_t), s));
+    if (nGroups > 0) {
+        hipLaunchKernelGGL(k_mfc_chunks, dim3(grid_of(nGroups)), dim3(256), 0, s, nGroups, nIR, maxRowsCap, maxPairs, iptr.p, (const int32_t *)nullptr,
+                           chunksOfGroup.p, (int32_t *)nullptr, (int64_t *)nullptr, (int32_t *)nullptr);
+        RP(hipGetLastError());
+    }
+    RP(rocprim::exclusive_scan(nullptr, exBytes, chunksOfGroup.p, chunkBase.p, (int32_t)0, (size_t)nGroups + 1, rocprim::plus<int32_t>(), s));
+    if (exBytes + 16 > tmp.n) tmp.alloc(exBytes + 16);
+    RP(rocprim::exclusive_scan(tmp.p, exBytes, chunksOfGroup.p, chunkBase.p, (int32_t)0, (size_t)nGroups + 1, rocprim::plus<int32_t>(), s));
+    int32_t nChunk32 = 0;
+    MFH_HIP(hipMemcpyAsync(&nChunk32, chunkBase.p + nGroups, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    const int64_t nChunk = nChunk32;
+    L.nChunk = nChunk;
+    D.chunkRow.alloc((size_t)nChunk + 1);
+    D.pairPtr.alloc((size_t)nChunk + 1);
+    dChunkOfIdx.alloc((size_t)std::max<int64_t>(nIR, 1));
+    if (nGroups > 0) {
+        hipLaunchKernelGGL(k_mfc_chunks, dim3(grid_of(nGroups)), dim3(256), 0, s, nGroups, nIR, maxRowsCap, maxPairs, iptr.p, (const int32_t *)chunkBase.p,
+                           (int32_t *)nullptr, D.chunkRow.p, D.pairPtr.p, dChunkOfIdx.p);
+        RP(hipGetLastError());
+    }
+    {
+        const int32_t endRow = (int32_t)nIR;
+        const int64_t endPair = nI;
+        MFH_HIP(hipMemcpyAsync(D.chunkRow.p + nChunk, &endRow, sizeof(int32_t), hipMemcpyHostToDevice, s));
+        MFH_HIP(hipMemcpyAsync(D.pairPtr.p + nChunk, &endPair, sizeof(int64_t), hipMemcpyHostToDevice, s));
+        MFH_HIP(hipStreamSynchronize(s));
+    }
+    lap("interface rows + chunks");
     D.ifaceRow.alloc((size_t)std::max<int64_t>(nI, 1));
     D.ifaceBuf.alloc((size_t)std::max<int64_t>(nI, 1) * m.dim);
+    lap("interface buffers");
     if (nI > 0) {
         ikA.alloc((size_t)nI); ikB.alloc((size_t)nI); ivA.alloc((size_t)nI); ivB.alloc((size_t)nI);
         hipLaunchKernelGGL(k_mfc_iface_keys, dim3(grid_of(nU)), dim3(256), 0, s, nU, D.entryRow.p, D.entryDest.p, ifP1.p, ikA.p, ivA.p);
@@ -830,15 +914,12 @@ void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes,
         RP(rocprim::radix_sort_pairs(nullptr, t2, ikA.p, ikB.p, ivA.p, ivB.p, (size_t)nI, 0u, eb, s));
         if (t2 + 16 > tmp.n) tmp.alloc(t2 + 16);
         RP(rocprim::radix_sort_pairs(tmp.p, t2, ikA.p, ikB.p, ivA.p, ivB.p, (size_t)nI, 0u, eb, s));
-        DBuf<int32_t> dIdxOfRow, dChunkOfIdx, dChunkFirst;
-        dIdxOfRow.upload(ifaceIdxOfRow, s);
-        dChunkOfIdx.upload(chunkOfIdx, s);
-        dChunkFirst.upload(chunkFirst, s);
-        hipLaunchKernelGGL(k_mfc_iface_assign, dim3(grid_of(nI)), dim3(256), 0, s, nI, ikB.p, ivB.p, dIdxOfRow.p, dChunkOfIdx.p, dChunkFirst.p,
+        hipLaunchKernelGGL(k_mfc_iface_assign, dim3(grid_of(nI)), dim3(256), 0, s, nI, ikB.p, ivB.p, dIdxOfRow.p, dChunkOfIdx.p, (const int32_t *)D.chunkRow.p,
                            D.entryDest.p, D.ifaceRow.p);
         RP(hipGetLastError());
         MFH_HIP(hipStreamSynchronize(s));
     }
+    lap("interface sort + assignment");
     MFH_HIP(hipStreamSynchronize(s));
 }
 
@@ -1421,14 +1502,21 @@ bool build_topology_device(int dim, int deg, int64_t nElem, int64_t nVert, const
 // connectivity in the new order.
 void build_element_order_device(const HostMesh &m, const int32_t *dElemNodes, const double *dNodePos, hipStream_t s, DBuf<int32_t> &perm,
                                 DBuf<int32_t> &elemNodesOut, int maxBlock, std::vector<int32_t> &blockStart) {
+    const bool timing = getenv("MFH_MFC_TIMING") != nullptr;
+    double tp = now_ms();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        (void)hipStreamSynchronize(s);
+        const double t = now_ms();
+        fprintf(stderr, "[element order]  %-40s %8.2f ms\n", what, t - tp);
+        tp = t;
+    };
     const int dim = m.dim;
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int64_t n = 0; n < m.nNode; ++n)
-        for (int a = 0; a < dim; ++a) {
-            const double v = m.nodePos[(size_t)n * dim + a];
-            lo[a] = std::min(lo[a], v);
-            hi[a] = std::max(hi[a], v);
-        }
+    // bounding box of the nodes: a reduction on the device copy (minima / maxima are exact in any order; the host loop over the 57.6 M
+    // nodes of a 119^3 grid took 130 ms)
+    double lo[3], hi[3];
+    bounding_box_device(dim, m.nNode, dNodePos, s, lo, hi);
+    lap("bounding box");
     // Cells of ~24 elements (one hex of the reference's grid generator): the elements of a cell share a key and keep their
     // original order (stable sort), the cells follow the Z-curve. Finer keys were measured WORSE than the generator's own
     // order (interface partials 8.64 M vs 7.45 M at config 3): the curve then cuts through the hexes and the blocks get ragged.
@@ -1449,28 +1537,45 @@ void build_element_order_device(const HostMesh &m, const int32_t *dElemNodes, co
     DBuf<char> tmp;
     tmp.alloc(tmpBytes + 16);
     RP(rocprim::radix_sort_pairs(tmp.p, tmpBytes, keyA.p, keyB.p, valA.p, valB.p, (size_t)m.nElem, 0u, 63u, s));
+    lap("keys + sort");
     // blocks = whole cells packed greedily along the curve, at most maxBlock elements each (a block boundary inside a cell
     // would put that cell's shared rows on the interface); a cell larger than a block is split
+    // The greedy packing is sequential over the CELLS (1.7 M at 119^3), not over the elements: the device compacts the first element of
+    // every cell, the host walks those (the sorted keys themselves, 323 MB at 119^3, stay on the device: download + scan took 95 ms)
     {
-        std::vector<uint64_t> hk((size_t)m.nElem);
-        keyB.download(hk.data(), hk.size(), s);
+        DBuf<uint32_t> cellP1;
+        DBuf<int32_t> cellStart;
+        cellP1.alloc((size_t)m.nElem);
+        hipLaunchKernelGGL(k_sym_heads, dim3(grid_of(m.nElem)), dim3(256), 0, s, m.nElem, keyB.p, cellP1.p, 0u);
+        size_t scanBytes = 0;
+        RP(rocprim::inclusive_scan(nullptr, scanBytes, cellP1.p, cellP1.p, (size_t)m.nElem, rocprim::plus<uint32_t>(), s));
+        if (scanBytes + 16 > tmp.n) tmp.alloc(scanBytes + 16);
+        RP(rocprim::inclusive_scan(tmp.p, scanBytes, cellP1.p, cellP1.p, (size_t)m.nElem, rocprim::plus<uint32_t>(), s));
+        uint32_t nCells = 0;
+        MFH_HIP(hipMemcpyAsync(&nCells, cellP1.p + (m.nElem - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        MFH_HIP(hipStreamSynchronize(s));
+        cellStart.alloc((size_t)nCells);
+        hipLaunchKernelGGL(k_cell_starts, dim3(grid_of(m.nElem)), dim3(256), 0, s, m.nElem, keyB.p, cellP1.p, cellStart.p);
+        RP(hipGetLastError());
+        std::vector<int32_t> cs((size_t)nCells + 1);
+        cellStart.download(cs.data(), (size_t)nCells, s);
+        cs[(size_t)nCells] = (int32_t)m.nElem;
         blockStart.assign(1, 0);
         int64_t cur = 0;                                   // elements in the open block
-        for (int64_t e = 0; e < m.nElem;) {
-            int64_t e2 = e + 1;
-            while (e2 < m.nElem && hk[(size_t)e2] == hk[(size_t)e]) ++e2;
-            int64_t len = e2 - e;
+        for (size_t ci = 0; ci < (size_t)nCells; ++ci) {
+            int64_t e = cs[ci], len = cs[ci + 1] - cs[ci];
             if (cur > 0 && cur + len > maxBlock) { blockStart.push_back((int32_t)e); cur = 0; }
             while (len > maxBlock) { e += maxBlock; len -= maxBlock; blockStart.push_back((int32_t)e); }
             cur += len;
-            e = e2;
         }
         blockStart.push_back((int32_t)m.nElem);
     }
+    lap("cell starts + block scan");
     perm.alloc((size_t)m.nElem);
     elemNodesOut.alloc((size_t)m.nElem * m.npe);
     hipLaunchKernelGGL(k_permute_rows_i32, dim3(grid_of(m.nElem * m.npe)), dim3(256), 0, s, m.nElem, m.npe, valB.p, dElemNodes, elemNodesOut.p, perm.p);
     RP(hipGetLastError());
+    lap("permuted connectivity");
     MFH_HIP(hipStreamSynchronize(s));
 }
 
