@@ -574,6 +574,7 @@ void launch_mg_prolong_add(int dim, int64_t nFine, const int32_t *parA, const in
                            const double *scal, int it, const double *stop, hipStream_t s);
 void launch_mg_tl_prolong_add(const TLArgs &t, const double *yc, double *x, double alpha, const double *scal, int it, const double *stop, hipStream_t s);
 void launch_fill_hash(int64_t n, double *v, hipStream_t s);
+void launch_take_columns_i32(int64_t n, int W, int w, const int32_t *src, int32_t *dst, hipStream_t s);
 void launch_mg_diff(int64_t n, const double *a, const double *b, double *out, const double *scal, int it, const double *stop, hipStream_t s);
 void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, double *scalOut, int it, const double *scal, const double *stop, hipStream_t s);
 void launch_add_scalar(double *p, double v, hipStream_t s);   // *p += v

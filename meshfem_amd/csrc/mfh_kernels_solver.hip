@@ -1636,6 +1636,15 @@ __global__ void __launch_bounds__(256) k_fill_hash(int64_t n, double *__restrict
     }
 }
 
+// dst[e][0..w) = src[e][0..w): the corner columns of a node table (linear level of the multigrid hierarchy on the device)
+__global__ void __launch_bounds__(256) k_take_columns_i32(int64_t n, int W, int w, const int32_t *__restrict__ src, int32_t *__restrict__ dst) {
+    const int64_t total = n * w;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        const int64_t e = k / w;
+        dst[k] = src[e * W + (k - e * w)];
+    }
+}
+
 // out = a - b (b may be null: copy), gated
 __global__ void __launch_bounds__(256) k_mg_diff(int64_t n, const double *__restrict__ a, const double *__restrict__ b, double *__restrict__ out, MgGate g) {
     if (mg_closed(g)) return;
@@ -1970,6 +1979,10 @@ void launch_mg_tl_prolong_add(const TLArgs &t, const double *yc, double *x, doub
 }
 void launch_fill_hash(int64_t n, double *v, hipStream_t s) {
     hipLaunchKernelGGL(k_fill_hash, dim3(grid_for(n, g_vecGridCap)), dim3(256), 0, s, n, v);
+    CHECK_LAUNCH();
+}
+void launch_take_columns_i32(int64_t n, int W, int w, const int32_t *src, int32_t *dst, hipStream_t s) {
+    hipLaunchKernelGGL(k_take_columns_i32, dim3(grid_for(n * w, g_vecGridCap)), dim3(256), 0, s, n, W, w, src, dst);
     CHECK_LAUNCH();
 }
 void launch_mg_diff(int64_t n, const double *a, const double *b, double *out, const double *scal, int it, const double *stop, hipStream_t s) {

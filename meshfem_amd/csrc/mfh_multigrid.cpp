@@ -135,18 +135,48 @@ uint64_t pack_coord(const int32_t *q) { return ((uint64_t)(uint32_t)(q[0] + 2) <
 // neighbour table of a level from its lattice coordinates
 void build_neighbours(int dim, mfh_ctx::AggLevel &A, hipStream_t s) {
     const int NS = dim == 3 ? 27 : 9;
-    std::map<uint64_t, int32_t> idOf;
-    for (int64_t a = 0; a < A.nAgg; ++a) idOf[pack_coord(&A.hCoord[(size_t)a * 3])] = (int32_t)a;
-    std::vector<int32_t> nbr((size_t)A.nAgg * NS, -1);
+    // id of the aggregate at a lattice point: a dense table over the box of the coordinates when that box is not much larger than the level
+    // (lattices of bins are nearly full), a map otherwise. 262 144 aggregates x 27 map lookups were ~0.15 s of the hierarchy setup at 119^3.
+    int32_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
     for (int64_t a = 0; a < A.nAgg; ++a)
-        for (int sl = 0; sl < NS; ++sl) {
-            int32_t q[3] = {A.hCoord[(size_t)a * 3] + sl % 3 - 1, A.hCoord[(size_t)a * 3 + 1] + (sl / 3) % 3 - 1,
-                            A.hCoord[(size_t)a * 3 + 2] + (dim == 3 ? sl / 9 - 1 : 0)};
-            for (int k2 = 0; k2 < 3; ++k2)                     // periodic axes: the first and the last bin are neighbours
-                if (A.wrap[k2] > 2) q[k2] = (q[k2] + A.wrap[k2]) % A.wrap[k2];
-            auto itf = idOf.find(pack_coord(q));
-            if (itf != idOf.end()) nbr[(size_t)a * NS + sl] = itf->second;
+        for (int k2 = 0; k2 < 3; ++k2) {
+            const int32_t v = A.hCoord[(size_t)a * 3 + k2];
+            if (a == 0 || v < lo[k2]) lo[k2] = v;
+            if (a == 0 || v > hi[k2]) hi[k2] = v;
         }
+    const int64_t ext[3] = {(int64_t)hi[0] - lo[0] + 1, (int64_t)hi[1] - lo[1] + 1, (int64_t)hi[2] - lo[2] + 1};
+    const double boxCells = (double)ext[0] * (double)ext[1] * (double)ext[2];
+    const bool dense = A.nAgg > 0 && boxCells <= 16.0 * (double)A.nAgg + 4096.0;
+    std::vector<int32_t> table;
+    std::map<uint64_t, int32_t> idOf;
+    if (dense) {
+        table.assign((size_t)boxCells, -1);
+        for (int64_t a = 0; a < A.nAgg; ++a) {
+            const int32_t *q = &A.hCoord[(size_t)a * 3];
+            table[(size_t)(((int64_t)(q[2] - lo[2]) * ext[1] + (q[1] - lo[1])) * ext[0] + (q[0] - lo[0]))] = (int32_t)a;
+        }
+    } else
+        for (int64_t a = 0; a < A.nAgg; ++a) idOf[pack_coord(&A.hCoord[(size_t)a * 3])] = (int32_t)a;
+    auto id_at = [&](const int32_t *q) -> int32_t {
+        if (dense) {
+            for (int k2 = 0; k2 < 3; ++k2)
+                if (q[k2] < lo[k2] || q[k2] > hi[k2]) return -1;
+            return table[(size_t)(((int64_t)(q[2] - lo[2]) * ext[1] + (q[1] - lo[1])) * ext[0] + (q[0] - lo[0]))];
+        }
+        auto itf = idOf.find(pack_coord(q));
+        return itf != idOf.end() ? itf->second : -1;
+    };
+    std::vector<int32_t> nbr((size_t)A.nAgg * NS, -1);
+    parallel_ranges(A.nAgg, [&](int64_t ab, int64_t ae, int) {
+        for (int64_t a = ab; a < ae; ++a)
+            for (int sl = 0; sl < NS; ++sl) {
+                int32_t q[3] = {A.hCoord[(size_t)a * 3] + sl % 3 - 1, A.hCoord[(size_t)a * 3 + 1] + (sl / 3) % 3 - 1,
+                                A.hCoord[(size_t)a * 3 + 2] + (dim == 3 ? sl / 9 - 1 : 0)};
+                for (int k2 = 0; k2 < 3; ++k2)                     // periodic axes: the first and the last bin are neighbours
+                    if (A.wrap[k2] > 2) q[k2] = (q[k2] + A.wrap[k2]) % A.wrap[k2];
+                nbr[(size_t)a * NS + sl] = id_at(q);
+            }
+    });
     A.nbr.upload(nbr, s);
     A.coord.upload(A.hCoord, s);
 }
@@ -264,7 +294,9 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
             // a periodic DoF map identifies nodes of opposite cell faces: elements at the seam couple the first and the last bin
             L0->wrap[k2] = (!c1->dofForNode.empty() && k2 < dim && !(c->periodicIgnoreDims & (1 << k2))) ? A.nb[k2] : 0;
         }
+        lap("aggregates of the linear level");
         build_neighbours(dim, *L0, s);
+        lap("neighbour table");
         L0->A.alloc((size_t)A.nAgg * NS * NM * NM);
         L0->A.zero(s);                   // (aggregates without a row of this rank keep zero blocks)
         far.zero(s);
@@ -283,7 +315,7 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
         target *= 8;                     // bins twice as wide
     }
     if (!L0) return false;
-    lap("aggregates + Galerkin product");
+    lap("Galerkin product");
     G.agg.push_back(std::move(L0));
     // ---- coarser levels: 2^dim bins merge until the level is small enough for a dense inverse
     while (G.agg.back()->nAgg > c->mgDenseMax) {
@@ -554,7 +586,17 @@ bool ensure_multigrid(mfh_ctx *c) {
     });
     m1.vertPos = m1.nodePos;
     m1.isBdryNode.assign((size_t)nCN, 0);
-    upload_mesh(c1, false);
+    // the library's own numbering: the vertices are the first nodes, so the device copies of the child are the corner columns of the parent's
+    // node table and the head of its position array -- copied where they lie instead of uploaded again (0.69 GB at 119^3)
+    const bool childTablesOnDevice = ownNumbering && c->dElemNodes.p && c->dVertPos.p && c->dElemNodes.n == (size_t)m.nElem * npe && c->dVertPos.n >= (size_t)nCN * d;
+    if (childTablesOnDevice) {
+        MFH_HIP(hipSetDevice(c->device));
+        c1->dElemNodes.alloc((size_t)m.nElem * nv);
+        k::launch_take_columns_i32(m.nElem, npe, nv, c->dElemNodes.p, c1->dElemNodes.p, s);
+        c1->dVertPos.alloc((size_t)nCN * d);
+        MFH_HIP(hipMemcpyAsync(c1->dVertPos.p, c->dVertPos.p, (size_t)nCN * d * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
+    upload_mesh(c1, childTablesOnDevice);
     lap("linear mesh + upload");
     // material: the same per-element parameters (k_geometry rebuilds the records of the linear elements from them)
     c1->matMode = c->matMode; c1->matKind = c->matKind;
