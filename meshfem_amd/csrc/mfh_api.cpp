@@ -40,6 +40,7 @@ using namespace mfh;
 void pack_gather_codes(mfh_ctx *c);
 
 void invalidate_matrix(mfh_ctx *c) {
+    c->dVals32.release();
     c->assembled = false;
     c->dinvValid = false;
     c->tl.valid = false;
@@ -63,10 +64,11 @@ static void parallel_assign(V &v, size_t n, T value) {
     parallel_ranges((int64_t)n, [&](int64_t b, int64_t e, int) { for (int64_t k = b; k < e; ++k) p[k] = value; });
 }
 
-// The per-node Dirichlet tables (mask + value per node and component: 1.6 GB at 57.6 M nodes) exist from the first Dirichlet condition on:
-// a context that only assembles never pays for them (they were 60-90 ms of every mfh_mesh_build at 119^3). Empty = no condition set.
+// The Dirichlet tables (mask + value per BOUNDARY node and component, in the order of mesh.bdryNodes: only boundary nodes take Dirichlet
+// conditions, BoundaryNode::setDirichlet, LinearElasticity.hh:390-403) exist from the first Dirichlet condition on. Indexed by volume node they
+// were 1.6 GB at 57.6 M nodes: 60-90 ms of every mfh_mesh_build at 119^3, then 0.1 s of the first condition. Empty = no condition set.
 void ensure_dirichlet_tables(mfh_ctx *c) {
-    const size_t n = (size_t)c->mesh.nNode * c->mesh.dim;
+    const size_t n = c->mesh.bdryNodes.size() * (size_t)c->mesh.dim;
     if (c->dirMask.size() == n && c->dirVal.size() == n) return;
     parallel_assign(c->dirMask, n, (uint8_t)0);
     parallel_assign(c->dirVal, n, 0.0);
@@ -74,8 +76,8 @@ void ensure_dirichlet_tables(mfh_ctx *c) {
 void reset_bcs(mfh_ctx *c) {
     const HostMesh &m = c->mesh;
     c->neumannTraction.assign((size_t)m.nBE() * m.dim, 0.0);
-    const size_t n = (size_t)m.nNode * m.dim;
-    if (c->dirMask.size() == n && c->dirVal.size() == n) {     // same mesh size as before: cleared in place
+    const size_t n = m.bdryNodes.size() * (size_t)m.dim;
+    if (n > 0 && c->dirMask.size() == n && c->dirVal.size() == n) {     // same boundary size as before: cleared in place
         parallel_assign(c->dirMask, n, (uint8_t)0);
         parallel_assign(c->dirVal, n, 0.0);
     } else {
@@ -333,6 +335,7 @@ k::AsmArgs asm_args(mfh_ctx *c) {
 }
 
 void run_assembly(mfh_ctx *c, int mode) {
+    c->dVals32.release();             // (a copy of the values about to be rewritten)
     k::AsmArgs a = asm_args(c);
     if (mode == MFH_ASSEMBLE_ATOMIC) {
         c->dVals.zero(c->stream);
@@ -470,6 +473,17 @@ void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double 
     } else {
         k::launch_spmv(spmv_args(c, masked), x, y, dotOut, c->stream);
     }
+}
+
+// y = K x for a smoother inside the multigrid preconditioner: the assembled matrix read from its FP32 copy when the hierarchy made one
+// (option mg_coarse_fp32; products and sums in FP64), the context's operator otherwise
+void apply_operator_smoother(mfh_ctx *c, bool masked, const double *x, double *y) {
+    if (c->dVals32.p && c->dVals32.n == c->dVals.n && c->assembled && !c->use_mf() && !c->upperOnly) {
+        k::SpmvArgs a = spmv_args(c, masked);
+        a.vals32 = c->dVals32.p;
+        k::launch_spmv(a, x, y, nullptr, c->stream);
+    } else
+        apply_operator(c, masked, x, y, nullptr);
 }
 
 void ensure_fixed_uploaded(mfh_ctx *c) {
@@ -904,12 +918,28 @@ void box_corners(mfh_ctx *c, const double *mn, const double *mx, int relative, d
         for (int a = 0; a < d; ++a) { omn[a] = mn[a]; omx[a] = mx[a]; }
         return;
     }
+    // bounding box of the nodes on the host threads (minima / maxima: exact in any order; one thread over the 57.6 M nodes of a 119^3 grid took 0.13 s)
     double bmn[3] = {1e300, 1e300, 1e300}, bmx[3] = {-1e300, -1e300, -1e300};
-    for (int64_t n = 0; n < m.nNode; ++n)
-        for (int a = 0; a < d; ++a) {
-            bmn[a] = std::min(bmn[a], m.nodePos[(size_t)n * d + a]);
-            bmx[a] = std::max(bmx[a], m.nodePos[(size_t)n * d + a]);
-        }
+    {
+        const int nt = host_threads();
+        std::vector<double> part((size_t)(nt + 1) * 6);
+        for (int t = 0; t <= nt; ++t)
+            for (int a = 0; a < 3; ++a) { part[(size_t)t * 6 + a] = 1e300; part[(size_t)t * 6 + 3 + a] = -1e300; }
+        parallel_ranges(m.nNode, [&](int64_t lo, int64_t hi, int tid) {
+            double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+            for (int64_t n = lo; n < hi; ++n)
+                for (int a = 0; a < d; ++a) {
+                    mn[a] = std::min(mn[a], m.nodePos[(size_t)n * d + a]);
+                    mx[a] = std::max(mx[a], m.nodePos[(size_t)n * d + a]);
+                }
+            for (int a = 0; a < 3; ++a) {
+                part[(size_t)tid * 6 + a] = std::min(part[(size_t)tid * 6 + a], mn[a]);
+                part[(size_t)tid * 6 + 3 + a] = std::max(part[(size_t)tid * 6 + 3 + a], mx[a]);
+            }
+        });
+        for (int t = 0; t <= nt; ++t)
+            for (int a = 0; a < 3; ++a) { bmn[a] = std::min(bmn[a], part[(size_t)t * 6 + a]); bmx[a] = std::max(bmx[a], part[(size_t)t * 6 + 3 + a]); }
+    }
     for (int a = 0; a < d; ++a) {   // BoundaryConditions.cc:310-316
         omn[a] = bmn[a] + mn[a] * (bmx[a] - bmn[a]);
         omx[a] = bmn[a] + mx[a] * (bmx[a] - bmn[a]);
@@ -927,27 +957,28 @@ void dirichlet_vars(mfh_ctx *c, std::vector<int64_t> &vars, std::vector<double> 
     const bool shared = !c->dofForNode.empty();
     std::vector<int32_t> constraintIndex(shared ? (size_t)c->nDoF : (size_t)0, -1);
     std::vector<int32_t> cDoF;
-    std::vector<int64_t> cNode;
-    for (int32_t bn : m.bdryNodes) {
+    std::vector<int64_t> cNode;                    // position of the constrained node in mesh.bdryNodes (the index of the tables)
+    for (size_t bi = 0; bi < m.bdryNodes.size(); ++bi) {
+        const int32_t bn = m.bdryNodes[bi];
         bool has = false;
-        for (int a = 0; a < d; ++a) has |= c->dirMask[(size_t)bn * d + a] != 0;
+        for (int a = 0; a < d; ++a) has |= c->dirMask[bi * d + a] != 0;
         if (!has) continue;
         const int32_t dof = dof_of(c, bn);
         if (!shared) {
             cDoF.push_back(dof);
-            cNode.push_back(bn);
+            cNode.push_back((int64_t)bi);
         } else if (constraintIndex[dof] < 0) {
             constraintIndex[dof] = (int32_t)cDoF.size();
             cDoF.push_back(dof);
-            cNode.push_back(bn);
+            cNode.push_back((int64_t)bi);
         } else {
             const int64_t o = cNode[constraintIndex[dof]];
             double diff = 0;
             bool cdiffer = false;
             for (int a = 0; a < d; ++a) {
-                const double dd = c->dirVal[(size_t)bn * d + a] - c->dirVal[(size_t)o * d + a];
+                const double dd = c->dirVal[bi * d + a] - c->dirVal[(size_t)o * d + a];
                 diff += dd * dd;
-                cdiffer |= c->dirMask[(size_t)bn * d + a] != c->dirMask[(size_t)o * d + a];
+                cdiffer |= c->dirMask[bi * d + a] != c->dirMask[(size_t)o * d + a];
             }
             if (std::sqrt(diff) > 1e-10 || cdiffer) throw Error(MFH_ERR_INVALID, "Mismatched Dirichlet constraint on periodic DoF");
         }
@@ -2029,6 +2060,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "mg_coarse_cycles") c->mgCoarseCycles = std::max(1, (int)value);
     else if (k2 == "mg_eig_margin") { require(value >= 1.0, MFH_ERR_INVALID, "mg_eig_margin must be >= 1"); c->mgEigMargin = value; c->mg.valid = false; }
     else if (k2 == "mg_agg_target") { c->mgAggTarget = std::max(0, (int)value); c->mg.valid = false; }
+    else if (k2 == "mg_coarse_fp32") { c->mgCoarseFp32 = value != 0; c->mg.valid = false; }
     else if (k2 == "mg_over_correction") { require(value > 0 && value < 4, MFH_ERR_INVALID, "mg_over_correction must lie in (0, 4)"); c->mgOverCorrection = value; }
     else if (k2 == "mg_dense_max") { c->mgDenseMax = std::max(8, (int)value); c->mg.valid = false; }
     else if (k2 == "mg_steps_agg") c->mgStepsAgg = std::max(1, (int)value);

@@ -120,6 +120,7 @@ struct mfh_ctx {
 
     // ---- numeric
     DBuf<double> dVals;
+    DBuf<float> dVals32;              // FP32 copy of dVals for the smoother of a multigrid linear level (built by ensure_multigrid, dropped whenever dVals is rewritten)
     bool assembled = false;
 
     // ---- constraints (SPSDSystem state)
@@ -158,6 +159,7 @@ struct mfh_ctx {
         DBuf<int32_t> nbr, parent, coord;     // neighbour table [nAgg][3^dim], parent aggregate on the next level, lattice coordinates [nAgg][3]
         DBuf<int32_t> childPtr, childIdx;     // the inverse of `parent`: the aggregates of every parent, ascending (the transfers towards the parent gather)
         DBuf<double> A, Dinv, rel;            // stencil operator, inverse diagonal blocks, transfer data [nAgg][4] towards the parent
+        DBuf<float> A32;                      // A rounded to FP32 for the level's smoother (option mg_coarse_fp32; empty = off)
         DBuf<double> x, b, r, d, t;
         std::vector<int32_t> hCoord;
         std::vector<double> hCentre;
@@ -189,6 +191,9 @@ struct mfh_ctx {
     double mgEigMargin = 1.1;                        // option "mg_eig_margin": factor on the power-iteration estimates of lambda_max
     int mgAggTarget = 32, mgDenseMax = 1200;         // options "mg_agg_target" (DoFs of the linear level per finest aggregate; 0: no aggregate hierarchy),
                                                      // "mg_dense_max" (aggregates of the level that is inverted densely)
+    bool mgCoarseFp32 = true;                        // option "mg_coarse_fp32": inside the multigrid preconditioner the assembled operator of the linear level and the
+                                                     // stencil operators of the aggregate levels are READ from FP32 copies (products and sums in FP64): those kernels are
+                                                     // bound by the matrix bytes, and a smoother / coarse correction needs no more than single precision of its matrix
     double mgOverCorrection = 1.5;                   // option "mg_over_correction": factor on the corrections prolonged from aggregate levels (piecewise-rigid
                                                      // coarse functions under-estimate smooth corrections; the cycle stays symmetric)
     int mgStepsAgg = 2; double mgRatioAgg = 0.2;     // options "mg_steps_agg" / "mg_ratio_agg": Chebyshev smoother of the aggregate levels
@@ -244,8 +249,8 @@ struct mfh_ctx {
 
     // ---- Simulator-level boundary conditions
     std::vector<double> neumannTraction;   // nBE x dim
-    RawVec<uint8_t> dirMask;               // nNode x dim   (RawVec: sized, then filled by all host threads, see parallel_assign)
-    RawVec<double> dirVal;                 // nNode x dim
+    RawVec<uint8_t> dirMask;               // nBdryNodes x dim, in the order of mesh.bdryNodes (empty until the first Dirichlet condition)
+    RawVec<double> dirVal;                 // nBdryNodes x dim
     std::vector<std::pair<int64_t, std::array<double, 3>>> deltaForces;
 
     // ---- options

@@ -429,6 +429,8 @@ struct SpmvArgs {
     const int32_t *rowPtr;
     const int32_t *colIdx;
     const double *vals;
+    const float *vals32;                // non-null: the same tiled array rounded to FP32 (the linear level inside the multigrid preconditioner reads this
+                                        // copy: the operator of a smoother tolerates it, and k_spmv is bound by exactly these bytes); products and sums stay FP64
     int chunkSlots;
     const uint8_t *fixedMask;           // per scalar row, may be null
     int xcd;                            // 1: XCD-contiguous chunk ranges (xcd_span)
@@ -520,7 +522,7 @@ void launch_tl_scatter(int nAgg, int nModes, int nColor, const int32_t *nbrOfCol
                        hipStream_t s);
 void launch_tl_rap(const TLArgs &t, int64_t nRows, const int32_t *rowPtr, const int32_t *colIdx, const double *vals, double *Ac,
                    hipStream_t s);
-void launch_st_spmv(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const double *x, double *y, const double *scal, int it, const double *stop, hipStream_t s);
+void launch_st_spmv(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const float *A32, const double *x, double *y, const double *scal, int it, const double *stop, hipStream_t s);
 void launch_st_dinv(int dim, int64_t nAgg, const double *A, double *Dinv, hipStream_t s);
 void launch_st_cheb(int dim, int64_t nAgg, const double *Dinv, const double *rin, const double *t, double *rout, double *d, double *x, double a, double b,
                     bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s);
@@ -574,6 +576,7 @@ void launch_mg_prolong_add(int dim, int64_t nFine, const int32_t *parA, const in
                            const double *scal, int it, const double *stop, hipStream_t s);
 void launch_mg_tl_prolong_add(const TLArgs &t, const double *yc, double *x, double alpha, const double *scal, int it, const double *stop, hipStream_t s);
 void launch_fill_hash(int64_t n, double *v, hipStream_t s);
+void launch_to_f32(int64_t n, const double *src, float *dst, hipStream_t s);
 void launch_take_columns_i32(int64_t n, int W, int w, const int32_t *src, int32_t *dst, hipStream_t s);
 void launch_mg_diff(int64_t n, const double *a, const double *b, double *out, const double *scal, int it, const double *stop, hipStream_t s);
 void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, double *scalOut, int it, const double *scal, const double *stop, hipStream_t s);

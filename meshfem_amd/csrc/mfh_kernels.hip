@@ -768,8 +768,13 @@ __global__ void __launch_bounds__(256) k_spmv(SpmvArgs a, const double *__restri
             const int64_t s = (int64_t)s0 + t;
             const int64_t col = a.colIdx[s];
             double xv[DIM], A[NB];
+            if (a.vals32) {              // (uniform over the launch: the FP32 copy of the matrix, SpmvArgs)
 #pragma unroll
-            for (int c = 0; c < NB; ++c) A[c] = a.vals[tiled_index(s, c, NB)];
+                for (int c = 0; c < NB; ++c) A[c] = (double)a.vals32[tiled_index(s, c, NB)];
+            } else {
+#pragma unroll
+                for (int c = 0; c < NB; ++c) A[c] = a.vals[tiled_index(s, c, NB)];
+            }
 #pragma unroll
             for (int d = 0; d < DIM; ++d) xv[d] = x[col * DIM + d];
 #pragma unroll

@@ -128,7 +128,8 @@ __global__ void __launch_bounds__(256) k_tl_fill(TLArgs t, const int32_t *__rest
     }
 }
 
-// rc[a*nModes + k] = sum_{DoFs n of aggregate a} z_{a,k}(n) . w(n); one workgroup per aggregate
+// rc[a*nModes + k] = sum_{DoFs n of aggregate a} z_{a,k}(n) . w(n); one workgroup per aggregate (the ~1 000 aggregates of ~1 000 nodes of the
+// two-level preconditioner)
 template <int DIM>
 __global__ void __launch_bounds__(256) k_tl_restrict(TLArgs t, const int32_t *__restrict__ aggPtr, const int32_t *__restrict__ dofsByAgg,
                                                      const double *__restrict__ w, double *__restrict__ rc) {
@@ -158,6 +159,39 @@ __global__ void __launch_bounds__(256) k_tl_restrict(TLArgs t, const int32_t *__
         for (int k = 0; k < 6; ++k) red[wv_ * 6 + k] = acc[k];
     __syncthreads();
     if (threadIdx.x < t.nModes) rc[a * t.nModes + threadIdx.x] = red[threadIdx.x] + red[6 + threadIdx.x] + red[12 + threadIdx.x] + red[18 + threadIdx.x];
+}
+
+// The same restriction with one WAVE per aggregate, four aggregates per workgroup: the first aggregate level of the multigrid hierarchy holds
+// ~32 vertices per aggregate (32 768 aggregates at config 3), where a 256-lane workgroup per aggregate keeps an eighth of its lanes busy and pays a
+// barrier for a sum one wave holds (113 -> us at config 3, rocprofv3).
+template <int DIM>
+__global__ void __launch_bounds__(256) k_tl_restrict_wave(TLArgs t, const int32_t *__restrict__ aggPtr, const int32_t *__restrict__ dofsByAgg,
+                                                          const double *__restrict__ w, double *__restrict__ rc) {
+    const int lane = threadIdx.x & 63;
+    const int64_t a = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= t.nAgg) return;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = aggPtr[a] + lane; q < aggPtr[a + 1]; q += 64) {
+        const int64_t n = dofsByAgg[q];
+        double rp[3] = {t.relPos[n * 3], t.relPos[n * 3 + 1], t.relPos[n * 3 + 2]};
+        double wv[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) wv[c] = (t.fixedMask && t.fixedMask[n * DIM + c]) ? 0.0 : w[n * DIM + c];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (k >= t.nModes) break;
+            double s = 0;
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) s += tl_mode<DIM>(k, c, rp) * wv[c];
+            acc[k] += s;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc[k] = wave_sum(acc[k]);
+    if (lane == 0)
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+            if (k < t.nModes) rc[a * t.nModes + k] = acc[k];
 }
 
 // coarse operator entries from one probe: Ac[(b,l), (nbr(b,colour), mode)] = R[(b,l)]
@@ -1415,14 +1449,23 @@ template <int DIM> DEV void st_transfer_T(const double *rel, const double *ch, d
 }
 
 template <int DIM>
-__global__ void __launch_bounds__(256) k_st_spmv(int64_t nAgg, const int32_t *__restrict__ nbr, const double *__restrict__ A, const double *__restrict__ x,
-                                                 double *__restrict__ y, MgGate g) {
+__global__ void __launch_bounds__(256) k_st_spmv(int64_t nAgg, const int32_t *__restrict__ nbr, const double *__restrict__ A, const float *__restrict__ A32,
+                                                 const double *__restrict__ x, double *__restrict__ y, MgGate g) {
     constexpr int NM = StDims<DIM>::NM, NS = StDims<DIM>::NS;
     if (mg_closed(g)) return;
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nAgg * NM; q += (int64_t)gridDim.x * 256) {
         const int64_t a = q / NM;
         const int k = (int)(q - a * NM);
         double acc = 0;
+        if (A32) {                       // the stencil blocks rounded to FP32 (option mg_coarse_fp32): half the bytes this kernel is bound by
+            for (int sl = 0; sl < NS; ++sl) {
+                const int b = nbr[a * NS + sl];
+                if (b < 0) continue;
+                const float *row = A32 + ((a * NS + sl) * NM + k) * NM;
+#pragma unroll
+                for (int l = 0; l < NM; ++l) acc += (double)row[l] * x[(int64_t)b * NM + l];
+            }
+        } else
         for (int sl = 0; sl < NS; ++sl) {
             const int b = nbr[a * NS + sl];
             if (b < 0) continue;
@@ -1636,6 +1679,10 @@ __global__ void __launch_bounds__(256) k_fill_hash(int64_t n, double *__restrict
     }
 }
 
+// dst = (float)src
+__global__ void __launch_bounds__(256) k_to_f32(int64_t n, const double *__restrict__ src, float *__restrict__ dst) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) dst[k] = (float)src[k];
+}
 // dst[e][0..w) = src[e][0..w): the corner columns of a node table (linear level of the multigrid hierarchy on the device)
 __global__ void __launch_bounds__(256) k_take_columns_i32(int64_t n, int W, int w, const int32_t *__restrict__ src, int32_t *__restrict__ dst) {
     const int64_t total = n * w;
@@ -1727,7 +1774,11 @@ void launch_tl_fill(const TLArgs &t, const int32_t *colorOfAgg, int color, int m
     CHECK_LAUNCH();
 }
 void launch_tl_restrict(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const double *w, double *rc, hipStream_t s) {
-    if (t.dim == 3) hipLaunchKernelGGL(k_tl_restrict<3>, dim3(t.nAgg), dim3(256), 0, s, t, aggPtr, dofsByAgg, w, rc);
+    if (t.nDoF < (int64_t)t.nAgg * 160) {           // small aggregates: a wave each
+        const unsigned grid = (unsigned)((t.nAgg + 3) / 4);
+        if (t.dim == 3) hipLaunchKernelGGL(k_tl_restrict_wave<3>, dim3(grid), dim3(256), 0, s, t, aggPtr, dofsByAgg, w, rc);
+        else hipLaunchKernelGGL(k_tl_restrict_wave<2>, dim3(grid), dim3(256), 0, s, t, aggPtr, dofsByAgg, w, rc);
+    } else if (t.dim == 3) hipLaunchKernelGGL(k_tl_restrict<3>, dim3(t.nAgg), dim3(256), 0, s, t, aggPtr, dofsByAgg, w, rc);
     else hipLaunchKernelGGL(k_tl_restrict<2>, dim3(t.nAgg), dim3(256), 0, s, t, aggPtr, dofsByAgg, w, rc);
     CHECK_LAUNCH();
 }
@@ -1981,6 +2032,10 @@ void launch_fill_hash(int64_t n, double *v, hipStream_t s) {
     hipLaunchKernelGGL(k_fill_hash, dim3(grid_for(n, g_vecGridCap)), dim3(256), 0, s, n, v);
     CHECK_LAUNCH();
 }
+void launch_to_f32(int64_t n, const double *src, float *dst, hipStream_t s) {
+    hipLaunchKernelGGL(k_to_f32, dim3(grid_for(n, g_vecGridCap)), dim3(256), 0, s, n, src, dst);
+    CHECK_LAUNCH();
+}
 void launch_take_columns_i32(int64_t n, int W, int w, const int32_t *src, int32_t *dst, hipStream_t s) {
     hipLaunchKernelGGL(k_take_columns_i32, dim3(grid_for(n * w, g_vecGridCap)), dim3(256), 0, s, n, W, w, src, dst);
     CHECK_LAUNCH();
@@ -2003,8 +2058,8 @@ void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, do
         else hipLaunchKernelGGL(K<2>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);            \
         CHECK_LAUNCH();                                                                     \
     } while (0)
-void launch_st_spmv(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const double *x, double *y, const double *scal, int it, const double *stop, hipStream_t s) {
-    ST_DISPATCH(dim, k_st_spmv, grid_for(nAgg * 6), nAgg, nbr, A, x, y, mk_gate(scal, it, stop));
+void launch_st_spmv(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const float *A32, const double *x, double *y, const double *scal, int it, const double *stop, hipStream_t s) {
+    ST_DISPATCH(dim, k_st_spmv, grid_for(nAgg * 6), nAgg, nbr, A, A32, x, y, mk_gate(scal, it, stop));
 }
 void launch_st_dinv(int dim, int64_t nAgg, const double *A, double *Dinv, hipStream_t s) { ST_DISPATCH(dim, k_st_dinv, grid_for(nAgg), nAgg, A, Dinv); }
 void launch_st_cheb(int dim, int64_t nAgg, const double *Dinv, const double *rin, const double *t, double *rout, double *d, double *x, double a, double b,

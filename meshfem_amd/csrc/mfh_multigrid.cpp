@@ -18,6 +18,7 @@ namespace mfhi {
 k::TLArgs tl_args(mfh_ctx *c);
 void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double *dotOut);
 bool prepare_matrix_free(mfh_ctx *c);
+void apply_operator_smoother(mfh_ctx *c, bool masked, const double *x, double *y);
 void ensure_fixed_uploaded(mfh_ctx *c);
 double device_dot(mfh_ctx *c, int64_t n, const double *a, const double *b);
 void upload_mesh(mfh_ctx *c, bool deviceTables);
@@ -50,7 +51,7 @@ LevelOps nodal_ops(mfh_ctx *c, const double *scal, int it, const double *stop) {
         L.apply = [=](const double *x, double *y) { dist_apply(c, const_cast<double *>(x), y, masked); };
         L.reduce = [=](double *dev, int64_t n) { dist_allreduce(c, dev, n); };
     } else
-        L.apply = [=](const double *x, double *y) { apply_operator(c, masked, x, y, nullptr); };
+        L.apply = [=](const double *x, double *y) { apply_operator_smoother(c, masked, x, y); };      // (FP32 copy of an assembled K if the hierarchy made one)
     L.step = [=](const double *rin, const double *t, double *rout, double *dv, double *x, double a, double b, bool first, bool assign) {
         k::launch_mg_cheb(d, nRows, c->dDinv.p, rin, t, rout, dv, x, a, b, first, assign, scal, it, stop, s);
     };
@@ -65,8 +66,9 @@ LevelOps agg_ops(mfh_ctx *c, mfh_ctx::AggLevel &A, const double *scal, int it, c
     const int64_t nAgg = A.nAgg;
     const int32_t *nbr = A.nbr.p;
     const double *Ap = A.A.p, *Dinv = A.Dinv.p;
+    const float *Ap32 = A.A32.n == A.A.n ? A.A32.p : nullptr;
     L.n = nAgg * (dim == 3 ? 6 : 3);
-    L.apply = [=](const double *x, double *y) { k::launch_st_spmv(dim, nAgg, nbr, Ap, x, y, scal, it, stop, s); };
+    L.apply = [=](const double *x, double *y) { k::launch_st_spmv(dim, nAgg, nbr, Ap, Ap32, x, y, scal, it, stop, s); };
     L.step = [=](const double *rin, const double *t, double *rout, double *dv, double *x, double a, double b, bool first, bool assign) {
         k::launch_st_cheb(dim, nAgg, Dinv, rin, t, rout, dv, x, a, b, first, assign, scal, it, stop, s);
     };
@@ -367,6 +369,10 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
         L->Dinv.alloc((size_t)L->nAgg * NM * NM);
         k::launch_st_dinv(dim, L->nAgg, L->A.p, L->Dinv.p, s);
         alloc_level_vectors(dim, *L);
+        if (c->mgCoarseFp32 && L != G.agg.back()) {          // (the last level is inverted densely, its stencil is not applied)
+            L->A32.alloc(L->A.n);
+            k::launch_to_f32((int64_t)L->A.n, L->A.p, L->A32.p, s);
+        } else L->A32.release();
     }
     if (!invert_last_level(c)) { G.agg.clear(); return false; }
     lap("dense inverse of the last level");
@@ -400,6 +406,15 @@ void agg_cycle(mfh_ctx *c, size_t l, const double *scal, int it, const double *s
 }
 
 }   // namespace
+
+// FP32 copy of a linear level's assembled matrix for its smoother (option mg_coarse_fp32; apply_operator_smoother reads it). Not on partitioned
+// levels (their operator runs through dist_apply) nor where the level multiplies matrix-free or from the stored triangle.
+static void make_fp32_copy(mfh_ctx *parent, mfh_ctx *lvl, bool distributed) {
+    lvl->dVals32.release();
+    if (!parent->mgCoarseFp32 || distributed || lvl->use_mf() || lvl->upperOnly || !lvl->dVals.p) return;
+    lvl->dVals32.alloc(lvl->dVals.n);
+    k::launch_to_f32((int64_t)lvl->dVals.n, lvl->dVals.p, lvl->dVals32.p, lvl->stream);
+}
 
 void destroy_multigrid(mfh_ctx *c) {
     auto &G = c->mg;
@@ -463,6 +478,7 @@ bool ensure_multigrid(mfh_ctx *c) {
         // linear elements: the context itself is the linear level -- smoother on its assembled K, the aggregate hierarchy below it
         G.linearOnly = true;
         ensure_precond(c);
+        make_fp32_copy(c, c, distributed);
         lap("assembly + block-Jacobi");
         bool haveCoarse = build_aggregate_hierarchy(c, c, lap);
         if (!haveCoarse && !distributed && !singular) {
@@ -631,6 +647,7 @@ bool ensure_multigrid(mfh_ctx *c) {
     if (distributed) dist_setup_child(c, c1, c->dofForNode.empty() ? coarseNode : coarseDofOfFine);   // the parent's exchange lists, restricted to the vertices' block rows
     lap("linear level: material, DoF map, fixed variables");
     ensure_precond(c1);
+    make_fp32_copy(c, c1, distributed);
     lap("linear level: symbolic + assembly");
     // below the linear level: the aggregate hierarchy; where the lattice cannot resolve the mesh, the context's own dense coarse space
     bool haveCoarse = build_aggregate_hierarchy(c, c1, lap);

@@ -37,7 +37,8 @@ mfh_status mfh_bc_dirichlet_box(mfh_ctx *c, const double *mn, const double *mx, 
     double bmn[3], bmx[3];
     box_corners(c, mn, mx, relative, bmn, bmx);
     ensure_dirichlet_tables(c);
-    for (int32_t bn : m.bdryNodes) {   // LinearElasticity.hh:941-948
+    for (size_t bi = 0; bi < m.bdryNodes.size(); ++bi) {   // LinearElasticity.hh:941-948
+        const int32_t bn = m.bdryNodes[bi];
         bool in = true;
         for (int a = 0; a < d; ++a) {
             const double p = m.nodePos[(size_t)bn * d + a];
@@ -46,12 +47,12 @@ mfh_status mfh_bc_dirichlet_box(mfh_ctx *c, const double *mn, const double *mx, 
         if (!in) continue;
         for (int a = 0; a < d; ++a) {   // BoundaryNode::setDirichlet :390-403
             if (!(compMask & (1 << a))) continue;
-            if (!c->dirMask[(size_t)bn * d + a]) {
-                c->dirMask[(size_t)bn * d + a] = 1;
-                c->dirVal[(size_t)bn * d + a] = value[a];
+            if (!c->dirMask[bi * d + a]) {
+                c->dirMask[bi * d + a] = 1;
+                c->dirVal[bi * d + a] = value[a];
             } else if (c->op != MFH_OP_ELASTICITY)
-                c->dirVal[(size_t)bn * d + a] = value[a];   // scalar PDE: later conditions overwrite (Poisson.hh:75-83)
-            else if (std::fabs(c->dirVal[(size_t)bn * d + a] - value[a]) > 1e-10)
+                c->dirVal[bi * d + a] = value[a];   // scalar PDE: later conditions overwrite (Poisson.hh:75-83)
+            else if (std::fabs(c->dirVal[bi * d + a] - value[a]) > 1e-10)
                 throw Error(MFH_ERR_INVALID, "Conflicting dirichlet displacements.");
         }
     }
@@ -93,13 +94,17 @@ mfh_status mfh_bc_dirichlet_nodes(mfh_ctx *c, int64_t n, const int64_t *nodes, c
     require(n >= 0 && (n == 0 || (nodes && values)), MFH_ERR_INVALID, "bad node list");
     const HostMesh &m = c->mesh;
     const int d = m.dim;
-    std::vector<uint8_t> isBdry((size_t)m.nNode, 0);
-    for (int32_t bn : m.bdryNodes) isBdry[bn] = 1;
+    // volume node -> position in mesh.bdryNodes (the index of the Dirichlet tables): sorted pairs, searched per listed node
+    std::vector<std::pair<int32_t, int32_t>> bdryIndex(m.bdryNodes.size());
+    for (size_t bi = 0; bi < m.bdryNodes.size(); ++bi) bdryIndex[bi] = {m.bdryNodes[bi], (int32_t)bi};
+    std::sort(bdryIndex.begin(), bdryIndex.end());
     ensure_dirichlet_tables(c);
     for (int64_t k = 0; k < n; ++k) {   // LinearElasticity.hh:991-1002
-        const int64_t ni = nodes[k];
-        require(ni >= 0 && ni < m.nNode, MFH_ERR_INVALID, "node index out of bounds");
-        if (!isBdry[ni]) throw Error(MFH_ERR_INVALID, "Condition applied to non-boundary node " + std::to_string(ni));
+        const int64_t nodeId = nodes[k];
+        require(nodeId >= 0 && nodeId < m.nNode, MFH_ERR_INVALID, "node index out of bounds");
+        auto itb = std::lower_bound(bdryIndex.begin(), bdryIndex.end(), std::make_pair((int32_t)nodeId, (int32_t)-1));
+        if (itb == bdryIndex.end() || itb->first != (int32_t)nodeId) throw Error(MFH_ERR_INVALID, "Condition applied to non-boundary node " + std::to_string(nodeId));
+        const size_t ni = (size_t)itb->second;
         for (int a = 0; a < d; ++a) {   // BoundaryNode::setDirichlet :390-403
             if (!(compMask & (1 << a))) continue;
             const double v = values[(size_t)k * d + a];
@@ -422,9 +427,9 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
         // analyzeDirichletPosedness (:1169-1190)
         unsigned needsT = allComps;
         size_t total = 0;
-        for (int32_t bn : m.bdryNodes)
+        for (size_t bi = 0; bi < m.bdryNodes.size(); ++bi)
             for (int a = 0; a < gd; ++a)
-                if (!c->dirMask.empty() && c->dirMask[(size_t)bn * gd + a]) { needsT &= ~(1u << a); ++total; }
+                if (!c->dirMask.empty() && c->dirMask[bi * gd + a]) { needsT &= ~(1u << a); ++total; }
         if (needsT) {
             if (flags & MFH_SOLVE_PIN) pin(needsT);
             else { addTranslationRows(needsT); crhs.assign(C.size(), 0.0); }

@@ -316,11 +316,17 @@ def test_callback_communicator_over_a_nccl_process_group_world_1():
     import torch.distributed as dist
     import meshfem_amd as M
     from meshfem_amd import distributed as D
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    for attempt in range(5):       # a port found free may be taken again before the store binds it (seen once on a busy box: EADDRINUSE)
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        try:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+            break
+        except dist.DistNetworkError:
+            if attempt == 4:
+                raise
     try:
         n = 4
         lm = D.slab_local_mesh(n, 0, 1, 2)
