@@ -445,9 +445,19 @@ def run_single(args):
                                             lambda_max=[g3["lambda_max_fine"], g3["lambda_max_coarse"]], note=p3["note"], wall_s=time.time() - t0,
                                             ms_per_iteration=i3["solve_ms"] / max(1, i3["iterations"]),
                                             speedup_time_to_solution_vs_block_jacobi=info["solve_ms"] / (i3["solve_ms"] + g3["setup_ms"]),
-                                            rel_l2_vs_block_jacobi=float(np.linalg.norm(u3 - u) / np.linalg.norm(u)))
+                                            rel_l2_vs_block_jacobi=float(np.linalg.norm(u3 - u) / np.linalg.norm(u)),
+                                            coarse_storage="FP32 copies of the linear level's K and of the aggregate stencils inside the preconditioner "
+                                                           "(option mg_coarse_fp32; products and sums FP64)")
+                # the same solve with the preconditioner's matrices kept in FP64 (what the option buys; the hierarchy is rebuilt for it and back)
+                c.set_option("mg_coarse_fp32", 0)
+                u4 = c.sim_solve(rtol=args.rtol, maxit=args.maxit)
+                i4 = dict(c.last_info)
+                out["pcg_multigrid"]["fp64_coarse_storage"] = dict(iterations=i4["iterations"], solve_ms=i4["solve_ms"],
+                                                                   ms_per_iteration=i4["solve_ms"] / max(1, i4["iterations"]),
+                                                                   rel_l2_vs_default=float(np.linalg.norm(u4 - u3) / np.linalg.norm(u3)))
+                c.set_option("mg_coarse_fp32", 1)
             except M.MeshFEMHipError as e:
-                out["pcg_multigrid"] = str(e)
+                out["pcg_multigrid"] = str(e) if not isinstance(out.get("pcg_multigrid"), dict) else out["pcg_multigrid"]
     # Option "deterministic" (bit-reproducible assembly, operator and PCG): the same timed step and the block-Jacobi PCG
     # with the waves adding in order and the dot products through the fixed tree, next to the default figures of this line
     if not strong and isinstance(out.get("variants"), dict):

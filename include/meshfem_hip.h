@@ -468,6 +468,9 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
  * "mg_steps_fine" / "mg_steps_coarse" (1 / 3: Chebyshev steps of MFH_PRECOND_MULTIGRID before and after the coarse correction on the quadratic /
  *   linear level), "mg_ratio_fine" / "mg_ratio_coarse" (0.3 / 0.1: the smoothers act on [ratio lambda_max, lambda_max]), "mg_coarse_cycles"
  *   (1: cycles of the linear level per application), "mg_eig_margin" (1.1: factor on the power-iteration estimates), "mg_agg_nodes",
+ * "mg_coarse_fp32" (1 default: INSIDE the multigrid preconditioner the assembled matrix of the linear level and the stencil operators of the
+ *   aggregate levels are read from FP32 copies -- products, sums and every vector stay FP64, and so do K, K x and the residuals of the PCG itself;
+ *   the preconditioner is a fixed SPD operator either way, the solution is the FP64 one; 0: FP64 storage throughout),
  * "asm_packed_codes" (1 default: the device copy of the gather lists is chunk-relative and packed, see k_assemble_gather),
  * "asm_chunk_order" (0 default; 1: the assembly visits the row chunks in the order of the elements they gather from),
  * "deterministic" (1: run-to-run BIT-REPRODUCIBLE assembly, operator and PCG -- the counterpart of the reference's serial, reproducible
