@@ -286,3 +286,32 @@ def test_stretched_elements_converge_and_are_the_documented_weak_case():
     assert np.linalg.norm(res["default"][0] - res["strong_smoothers"][0]) <= 1e-6 * np.linalg.norm(res["default"][0])
     assert res["strong_smoothers"][1] < 0.7 * res["default"][1]          # the smoother is the weak part, not the coarse space
     assert 60 < res["default"][1] < 1500
+
+
+@pytest.mark.parametrize("deg,n", [(2, 8), (1, 14)])
+def test_fp32_copies_of_the_coarse_operators_change_neither_the_answer_nor_the_iteration_count(deg, n):
+    """Option mg_coarse_fp32 (default on): inside the preconditioner the linear level's assembled K and the aggregate stencils are read
+    from FP32 copies, products and sums in FP64. The preconditioner stays one fixed SPD operator, so the PCG converges to the FP64
+    solution of K u = f -- checked against the FP64-storage hierarchy and, through it, the oracle's direct solve -- in the same number
+    of iterations (+-1). A re-assembly drops the copy (the smoother then reads the FP64 matrix) and the solve still converges."""
+    c, V, T = _cantilever(n, deg)
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    res = {}
+    for fp32 in (1, 0, 1):
+        c.set_option("mg_coarse_fp32", fp32)
+        u = c.sim_solve(rtol=1e-10)
+        assert c.last_info["converged"] and c.last_info["true_rel_residual"] < 2e-10
+        res[fp32] = (u, c.last_info["iterations"])
+    assert abs(res[1][1] - res[0][1]) <= 1
+    assert np.linalg.norm(res[1][0] - res[0][0]) <= 1e-8 * np.linalg.norm(res[0][0])
+    sim = O.Simulator(T, V, deg)
+    sim.set_material_constant(O.ElasticityTensor.isotropic(3, 200.0, 0.35))
+    sim.apply_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9], [0, 0, 0])
+    sim.apply_neumann_box([1 - 1e-9, -9, -9], [1 + 1e-9, 9, 9], [0, -1, 0], "traction")
+    uref = sim.solve()
+    assert np.linalg.norm(res[1][0] - uref) <= U_RTOL * np.linalg.norm(uref)
+    c.assemble()                         # rewrites the values: the FP32 copy is gone, the hierarchy stays
+    u2 = c.sim_solve(rtol=1e-10)
+    assert c.last_info["converged"]
+    assert np.linalg.norm(u2 - res[0][0]) <= 1e-8 * np.linalg.norm(res[0][0])
+    c.close()
