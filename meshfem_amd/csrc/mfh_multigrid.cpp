@@ -407,11 +407,12 @@ void agg_cycle(mfh_ctx *c, size_t l, const double *scal, int it, const double *s
 
 }   // namespace
 
-// FP32 copy of a linear level's assembled matrix for its smoother (option mg_coarse_fp32; apply_operator_smoother reads it). Not on partitioned
-// levels (their operator runs through dist_apply) nor where the level multiplies matrix-free or from the stored triangle.
+// FP32 copy of a linear level's assembled matrix for its smoother (option mg_coarse_fp32; apply_operator_smoother -- on partitioned levels
+// dist_apply -- reads it). Not where the level multiplies matrix-free or from the stored triangle.
 static void make_fp32_copy(mfh_ctx *parent, mfh_ctx *lvl, bool distributed) {
+    (void)distributed;
     lvl->dVals32.release();
-    if (!parent->mgCoarseFp32 || distributed || lvl->use_mf() || lvl->upperOnly || !lvl->dVals.p) return;
+    if (!parent->mgCoarseFp32 || lvl->use_mf() || lvl->upperOnly || !lvl->dVals.p) return;
     lvl->dVals32.alloc(lvl->dVals.n);
     k::launch_to_f32((int64_t)lvl->dVals.n, lvl->dVals.p, lvl->dVals32.p, lvl->stream);
 }

@@ -264,7 +264,7 @@ void ensure_overlap_lists(mfh_ctx *c, bool cluster) {
 // y = K x for NR interleaved vectors. With an active communicator the halo part of x is exchanged first, overlapped with
 // the interior blocks / chunks. dotOut (stride 4) or the PCG bookkeeping (scal, it, ctl) as in the kernels.
 void apply_op_nr(mfh_ctx *c, DistLink &L, int NR, double *x, double *y, bool masked, double *dotOut, double *scal, int it, const double *ctl,
-                 int pcgMode = 0) {
+                 int pcgMode = 0, bool smoother = false) {
     hipStream_t s = c->stream;
     const bool cluster = cluster_operator(c);
     const int W = NR * c->bs();
@@ -288,6 +288,8 @@ void apply_op_nr(mfh_ctx *c, DistLink &L, int NR, double *x, double *y, bool mas
         require_full_storage(c, "the assembled SpMV of the PCG");
         k::SpmvArgs a = spmv_args(c, masked);
         a.pcgMode = pcgMode;
+        // inside the multigrid preconditioner (dist_apply) the assembled matrix is read from its FP32 copy when the hierarchy made one (mg_coarse_fp32)
+        if (smoother && NR == 1 && c->dVals32.p && c->dVals32.n == c->dVals.n) a.vals32 = c->dVals32.p;
         if (L.active) {
             ensure_overlap_lists(c, false);
             L.profile_begin();
@@ -325,7 +327,7 @@ void dist_apply(mfh_ctx *c, double *x, double *y, bool masked) {
     DistLink L(c);
     if (cluster_operator(c) && c->mfcDev.ifaceBuf.n < (size_t)std::max<int64_t>(c->mfc.nIface, 1) * c->bs())
         c->mfcDev.ifaceBuf.alloc((size_t)std::max<int64_t>(c->mfc.nIface, 1) * c->bs());
-    apply_op_nr(c, L, 1, x, y, masked, nullptr, nullptr, 0, nullptr);
+    apply_op_nr(c, L, 1, x, y, masked, nullptr, nullptr, 0, nullptr, 0, true);      // (only the levels of the multigrid preconditioner come through here)
 }
 // the halo block rows of v (nCols x W doubles) <- the owners' values
 void dist_halo(mfh_ctx *c, double *v, int W) {
