@@ -465,8 +465,8 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
  *   ignoreMismatch / matchPermittingMismatch; 0 default: a mismatch is an error like PeriodicBoundaryMatcher::match),
  * "periodic_ignore_dims" (bit a set: dimension a is NOT periodic, PeriodicCondition's ignoreDims) -- both read by the next
  *   mfh_apply_periodic_conditions,
- * "mg_steps_fine" / "mg_steps_coarse" (1 / 3: Chebyshev steps of MFH_PRECOND_MULTIGRID before and after the coarse correction on the quadratic /
- *   linear level), "mg_ratio_fine" / "mg_ratio_coarse" (0.3 / 0.1: the smoothers act on [ratio lambda_max, lambda_max]), "mg_coarse_cycles"
+ * "mg_steps_fine" / "mg_steps_coarse" (1 / 1: Chebyshev steps of MFH_PRECOND_MULTIGRID before and after the coarse correction on the quadratic /
+ *   linear level), "mg_ratio_fine" / "mg_ratio_coarse" (0.3 / 0.3: the smoothers act on [ratio lambda_max, lambda_max]), "mg_coarse_cycles"
  *   (1: cycles of the linear level per application), "mg_eig_margin" (1.1: factor on the power-iteration estimates), "mg_agg_nodes",
  * "mg_coarse_fp32" (1 default: INSIDE the multigrid preconditioner the assembled matrix of the linear level and the stencil operators of the
  *   aggregate levels are read from FP32 copies -- products, sums and every vector stay FP64, and so do K, K x and the residuals of the PCG itself;
