@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) k_geometry(int64_t nElem, const int32_t *
 template <int DIM, int DEG, int MAT> DEV constexpr bool asm_uses_table() { return DEG == 2 && MAT != MAT_MASS; }
 constexpr int ASM_CODE_SHIFT = 7;
 
-template <int DIM, int DEG, int MAT, bool UPPER = false>
+template <int DIM, int DEG, int MAT, bool UPPER = false, bool DET = false>
 __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) ? 1 : 8) k_assemble_gather(AsmArgs a) {
     constexpr int NB = mat_nb<DIM, MAT>();
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
@@ -337,12 +337,12 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
     // U independent contributions per lane and trip: their index loads, element-record loads and
     // block arithmetic have no mutual dependence, so the loads of all U are in flight together
     // (the kernel is latency-bound: rocprof shows 65 % of wave cycles in s_waitcnt at U = 1).
-    // Option "deterministic" (a.det): the four waves of the workgroup add their contributions to the LDS accumulators one wave after the
+    // Option "deterministic" (template parameter DET, chosen by the launcher from a.det): the four waves of the workgroup add their contributions to the LDS accumulators one wave after the
     // other, trip by trip, so that the contributions of a slot always meet in list order (inside one wave the lanes of an LDS atomic are
     // applied in a fixed order; between waves the order is a matter of timing, and the last bits of K with it). Every lane then runs the
     // same number of trips (barriers inside the loop).
     constexpr int U = 2;
-    const bool det = a.det != 0;
+    constexpr bool det = DET;          // a template parameter: the default instantiations carry no barrier inside the loop
     for (int64_t k0 = kb + threadIdx.x; det ? (k0 - threadIdx.x < ke) : (k0 < ke); k0 += 256 * U) {
         uint32_t code[U];
         int ls[U];
@@ -1573,7 +1573,7 @@ __global__ void __launch_bounds__(256) k_mf_forces(SpmvMfArgs a, const double *_
 // its 128-byte record: the positions (24 B per vertex, shared by ~24 tets) stay in L2 / the memory-side cache, so a block of
 // 256 P2 tets reads ~10 KB of connectivity instead of 32 KB of records from HBM, for ~80 more FP64 instructions per element.
 // Only with a constant material (its part of the record is then the same for every element: element 0's is used).
-template <int DIM, int DEG, int MAT, int PCG, bool GEOV = false>
+template <int DIM, int DEG, int MAT, int PCG, bool GEOV = false, bool DET = false>
 __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const double *__restrict__ x, double *__restrict__ y, double *dotOut,
                                                          double *scal, int it, const double *stopPtr, const int32_t *__restrict__ blockList,
                                                          int64_t nList) {
@@ -1589,7 +1589,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
 #else
 #define LIDX(t, d) ((t) * DIM + (d))
 #endif
-    const bool det = a.det.partials != nullptr;
+    constexpr bool det = DET;          // = (a.det.partials != nullptr), chosen by the launcher: the default instantiation has one accumulator array
     const int accStride = a.clMaxLocal * DIM;
     double *xs = clacc + (det ? 4 : 1) * accStride;
     double *red = xs + accStride;
@@ -1690,7 +1690,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
 #undef LIDX
 
 // y_row = sum over the (element, node) pairs of the row of their nodal force: a pure gather-sum
-template <int DIM, int PCG>
+template <int DIM, int PCG, bool DET = false>
 __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__restrict__ fbuf, const double *__restrict__ x,
                                                  double *__restrict__ y, double *dotOut, double *scal, int it, const double *stopPtr) {
     extern __shared__ __attribute__((aligned(16))) double mfacc[];   // [maxRows * DIM] + 16
@@ -1716,7 +1716,7 @@ __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__r
         // U independent pairs per lane and trip: their list and force loads are all in flight together
         constexpr int U = 2;
         // (deterministic mode has barriers inside the loop: every lane runs the same number of trips)
-        for (int64_t k0 = kb + threadIdx.x; a.det.partials ? (k0 - threadIdx.x < ke) : (k0 < ke); k0 += 256 * U) {
+        for (int64_t k0 = kb + threadIdx.x; DET ? (k0 - threadIdx.x < ke) : (k0 < ke); k0 += 256 * U) {
             int64_t code[U];
             int lr[U];
             bool ok[U];
@@ -1732,8 +1732,8 @@ __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__r
             for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int c = 0; c < DIM; ++c) out[u][c] = fbuf[code[u] * DIM + c];
-            if (a.det.partials) {
-                // option "deterministic": one wave after the other (a row's partials then meet in list order, whatever the timing)
+            if (DET) {
+                // option "deterministic" (DET = (a.det.partials != nullptr), chosen by the launcher): one wave after the other (a row's partials then meet in list order, whatever the timing)
                 for (int w = 0; w < 4; ++w) {
                     if ((int)(threadIdx.x >> 6) == w) {
 #pragma unroll
@@ -2111,21 +2111,19 @@ void launch_assemble_gather(const AsmArgs &a, hipStream_t s) {
     if (a.nChunk == 0) return;
     size_t lds = (size_t)(mat_is_scalar(a.mat) ? 1 : a.dim * a.dim) * (a.chunkSlots + 2) * sizeof(double);
     if (a.deg == 2 && a.mat != MAT_MASS) lds += (size_t)a.npe * a.npe * (4 * sizeof(double) + sizeof(uint32_t));   // pair table
-    if (a.upperOnly) {
-#define CALL(D, G, M)                                                                                          \
-    if (lds > 64 * 1024)                                                                                         \
-        MFH_HIP(hipFuncSetAttribute((const void *)k_assemble_gather<D, G, M, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((k_assemble_gather<D, G, M, true>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a)
-        MFH_DISPATCH_ASM(a, CALL);
+#define CALLV(D, G, M, UP, DT)                                                                                 \
+    do {                                                                                                         \
+        if (lds > 64 * 1024)                                                                                     \
+            MFH_HIP(hipFuncSetAttribute((const void *)k_assemble_gather<D, G, M, UP, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_assemble_gather<D, G, M, UP, DT>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a); \
+    } while (0)
+    // the deterministic flavour is an instantiation of its own (barriers inside the contribution loop): the default kernels keep the plain loop
+#define CALL(D, G, M)                                                     \
+    if (a.det) { if (a.upperOnly) CALLV(D, G, M, true, true); else CALLV(D, G, M, false, true); } \
+    else { if (a.upperOnly) CALLV(D, G, M, true, false); else CALLV(D, G, M, false, false); }
+    MFH_DISPATCH_ASM(a, CALL);
 #undef CALL
-    } else {
-#define CALL(D, G, M)                                                                                          \
-    if (lds > 64 * 1024)                                                                                         \
-        MFH_HIP(hipFuncSetAttribute((const void *)k_assemble_gather<D, G, M, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((k_assemble_gather<D, G, M, false>), dim3((unsigned)a.nChunk), dim3(256), lds, s, a)
-        MFH_DISPATCH_ASM(a, CALL);
-#undef CALL
-    }
+#undef CALLV
     CHECK_LAUNCH();
 }
 
@@ -2335,11 +2333,12 @@ static void launch_mf_rows_mode(const SpmvMfArgs &a_, int mode, const double *x,
     const SpmvMfArgs &a = ad;
     const size_t lds = ((size_t)a.maxRows * a.dim + 16) * sizeof(double);
     const int grid = det_grid(persistent_grid(a.nChunk, 256 * 8));
-#define ROWS(D)                                                                                                                               \
-    if (mode == 0) hipLaunchKernelGGL((k_mf_rows<D, 0>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, scal, it, stopPtr);     \
-    else if (mode == 1) hipLaunchKernelGGL((k_mf_rows<D, 1>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, scal, it, stopPtr); \
-    else hipLaunchKernelGGL((k_mf_rows<D, 2>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, scal, it, stopPtr)
-    if (a.dim == 3) { ROWS(3); } else { ROWS(2); }
+#define ROWS(D, DT)                                                                                                                               \
+    if (mode == 0) hipLaunchKernelGGL((k_mf_rows<D, 0, DT>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, scal, it, stopPtr);     \
+    else if (mode == 1) hipLaunchKernelGGL((k_mf_rows<D, 1, DT>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, scal, it, stopPtr); \
+    else hipLaunchKernelGGL((k_mf_rows<D, 2, DT>), dim3(grid), dim3(256), lds, s, a, (const double *)a.sig, x, y, dotOut, scal, it, stopPtr)
+    if (a.det.partials) { if (a.dim == 3) { ROWS(3, true); } else { ROWS(2, true); } }
+    else { if (a.dim == 3) { ROWS(3, false); } else { ROWS(2, false); } }
 #undef ROWS
     if (dotOut || scal) launch_det_finish(s);
     CHECK_LAUNCH();
@@ -2366,18 +2365,19 @@ static void launch_mf_cluster_mode(const SpmvMfArgs &a_, int mode, const double 
     const SpmvMfArgs &a = ad;
     const size_t ldsC = ((size_t)(a.det.partials ? 5 : 2) * a.clMaxLocal * a.dim + 16) * sizeof(double);
     const int gridC = det_grid((int)std::min<int64_t>(nList, 256 * 64));
-#define CALLG(D, G, M, GV)                                                                                                                                         \
+#define CALLG(D, G, M, GV, DT)                                                                                                                                     \
     if (ldsC > 64 * 1024) {                                                                                                                                        \
-        MFH_HIP(hipFuncSetAttribute((const void *)k_mf_cluster<D, G, M, 0, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC));                              \
-        MFH_HIP(hipFuncSetAttribute((const void *)k_mf_cluster<D, G, M, 1, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC));                              \
-        MFH_HIP(hipFuncSetAttribute((const void *)k_mf_cluster<D, G, M, 2, GV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC));                              \
+        MFH_HIP(hipFuncSetAttribute((const void *)k_mf_cluster<D, G, M, 0, GV, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC));                          \
+        MFH_HIP(hipFuncSetAttribute((const void *)k_mf_cluster<D, G, M, 1, GV, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC));                          \
+        MFH_HIP(hipFuncSetAttribute((const void *)k_mf_cluster<D, G, M, 2, GV, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC));                          \
     }                                                                                                                                                              \
-    if (mode == 0) hipLaunchKernelGGL((k_mf_cluster<D, G, M, 0, GV>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList);     \
-    else if (mode == 1) hipLaunchKernelGGL((k_mf_cluster<D, G, M, 1, GV>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList); \
-    else hipLaunchKernelGGL((k_mf_cluster<D, G, M, 2, GV>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList)
-#define CALL(D, G, M)                     \
-    if (a.vertPos) { CALLG(D, G, M, true); } \
-    else { CALLG(D, G, M, false); }
+    if (mode == 0) hipLaunchKernelGGL((k_mf_cluster<D, G, M, 0, GV, DT>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList);     \
+    else if (mode == 1) hipLaunchKernelGGL((k_mf_cluster<D, G, M, 1, GV, DT>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList); \
+    else hipLaunchKernelGGL((k_mf_cluster<D, G, M, 2, GV, DT>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, x, y, dotOut, scal, it, stopPtr, blockList, nList)
+    // the deterministic flavour (per-wave accumulators) is an instantiation of its own
+#define CALL(D, G, M)                                                                                  \
+    if (a.det.partials) { if (a.vertPos) { CALLG(D, G, M, true, true); } else { CALLG(D, G, M, false, true); } } \
+    else { if (a.vertPos) { CALLG(D, G, M, true, false); } else { CALLG(D, G, M, false, false); } }
     MFH_DISPATCH(a, CALL);
 #undef CALL
 #undef CALLG
