@@ -379,6 +379,11 @@ mfh_status  mfh_comm_allreduce(mfh_ctx* ctx, mfh_comm* comm, double* devBuf, int
 /* ring shift of a known message + all-reduces with known sums (several rounds when peer transfers are enabled): checks the transport
  * in use end to end */
 mfh_status  mfh_comm_selftest(mfh_ctx* ctx, mfh_comm* comm);
+/* First contact with the devices and links of a node, before any solve (collective): device memory head-room, the devices of all ranks
+ * and hipDeviceCanAccessPeer towards each, which IPC slabs are mapped (after mfh_comm_enable_peer), an all-reduce of ones, and the
+ * bandwidth of a ring of messageBytes-long messages (send to rank + 1 while receiving from rank - 1) on the transport underneath and
+ * through the peer transfers. Layout of `out` (>= 16 + 2 world doubles): meshfem_amd/csrc/mfh_solver.cpp, mfh_comm_preflight. */
+mfh_status  mfh_comm_preflight(mfh_ctx* ctx, mfh_comm* comm, int64_t messageBytes, double* out, int64_t nOut);
 /* Direct device-to-device transfers for the ranks of ONE node, layered on an existing communicator (collective; the HIP IPC handles
  * travel through the communicator's own all-reduce): every rank exports one slab of fine-grained device memory; the halo exchange of
  * the PCG then writes straight into the neighbours' slabs (stores over xGMI, one release flag per message, two buffers per pair) and
@@ -418,14 +423,20 @@ mfh_status  mfh_dist_get_stats(mfh_ctx* ctx, mfh_dist_stats* out);
  * 2 device->device; hipStream NULL = the context's stream */
 mfh_status  mfh_dev_memcpy(mfh_ctx* ctx, void* dst, const void* src, int64_t bytes, int32_t kind, void* hipStream);
 
-/* Device memory. The library keeps the device blocks its contexts release in a per-process cache (size-ordered free list, bounded by
- * MFH_DEVICE_CACHE_MB, default four fifths of the device's memory; 0 = plain hipMalloc / hipFree) instead of returning them to the driver: on
- * ROCm 7.2 / MI355X a hipMalloc that follows large hipFree calls takes seconds (profiles/r04_malloc_probe.txt), and the setup phases of a
- * context allocate and release several times the memory they keep. The reference reserves its triplet storage once
- * (LinearElasticity.hh:1441-1443). A request the driver cannot serve flushes the cache and is repeated. mfh_device_cache_trim returns
- * every cached block to the driver (e.g. before another library needs the memory). */
+/* Device memory. The library allocates from a per-process ARENA (meshfem_amd/csrc/mfh_pool.cpp): released device memory is not returned to
+ * the driver but kept in the hipMalloc segments it came in, where free neighbours are merged and any later request is cut from the smallest
+ * free chunk that holds it; the driver is asked for a new segment only when nothing fits. Reason: on ROCm 7.2 / MI355X a hipMalloc that
+ * follows large hipFree calls of the same process takes seconds (profiles/r04_malloc_probe.txt), and the setup phases of a context allocate
+ * and release several times the memory they keep. The reference reserves its triplet storage once (LinearElasticity.hh:1441-1443).
+ * Bounds: free bytes kept while contexts are alive <= MFH_DEVICE_CACHE_MB (default half of the device's memory; 0 = plain hipMalloc /
+ * hipFree); mfh_destroy trims the arena to the high-water mark of its live bytes, and when the LAST context of a device closes to at most
+ * MFH_DEVICE_CACHE_IDLE_MB of free memory (default an eighth of the device), so that other allocators of the process (torch, RCCL) find the
+ * rest. A request the driver cannot serve releases every free segment and is repeated. mfh_device_cache_trim returns every free segment to
+ * the driver at once. mfh_device_arena_stats: out8 = {bytes held, live bytes, live high-water mark, segments, free chunks, bytes returned
+ * to the driver so far, bytes waiting for a device-wide synchronisation, bound on the free bytes}. */
 mfh_status mfh_device_cache_trim(void);
 mfh_status mfh_device_cache_stats(int32_t device, int64_t* cachedBytes, int64_t* blocks, int64_t* hits, int64_t* misses, int64_t* flushes);
+mfh_status mfh_device_arena_stats(int32_t device, int64_t* out8);
 
 /* ---------------------------------------------------------------- introspection, options
  * (kernel timers, operator statistics, test hooks and the device-pointer building blocks: include/meshfem_hip_extras.h) */

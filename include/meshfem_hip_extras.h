@@ -29,6 +29,10 @@ mfh_status mfh_debug_spd_inverse_device(mfh_ctx* ctx, int64_t n, double* A);
  * read -- mfh_mesh_build writes them on the device from the uploaded vertices; they must equal what mfh_mesh_elem_nodes /
  * mfh_mesh_node_positions return from the host tables (FEMMesh.inl:17-59), bit for bit */
 mfh_status mfh_debug_device_node_tables(mfh_ctx* ctx, int32_t* elemNodes, double* nodePos);
+/* test hooks: one allocation / release through the library's device arena (meshfem_hip.h "Device memory"), as the library's own buffers
+ * make them; tests/test_gpu_arena.py checks splitting, merging, the bounds and the trims with them */
+mfh_status mfh_debug_arena_alloc(mfh_ctx* ctx, int64_t bytes, void** out);
+mfh_status mfh_debug_arena_free(mfh_ctx* ctx, void* p);
 /* test hook (host only, no context): the row chunks of the assembly kernel -- greedy, whole rows, at most chunkSlots slots each, a chunk ends at
  * every row listed in breaks -- scanned by `threads` host threads over ranges of `grain` rows and stitched (threads = 1: the plain sequential
  * scan the result must equal). Writes the chunks' first rows + nRows to chunkRow (capacity cap); *nOut = entries (chunks + 1) */

@@ -144,8 +144,10 @@ PROTOTYPES = {
     "mfh_comm_describe": (C.c_char_p, [_P]),
     "mfh_comm_allreduce": (_i32, [_P, _P, _P, _i64]),
     "mfh_comm_selftest": (_i32, [_P, _P]),
+    "mfh_comm_preflight": (_i32, [_P, _P, _i64, C.POINTER(_f64), _i64]),
     "mfh_device_cache_trim": (_i32, []),
     "mfh_device_cache_stats": (_i32, [_i32, _pi64, _pi64, _pi64, _pi64, _pi64]),
+    "mfh_device_arena_stats": (_i32, [_i32, _pi64]),
     "mfh_comm_enable_peer": (_i32, [_P, _P]),
     "mfh_comm_disable_peer": (_i32, [_P, _P]),
     "mfh_dist_get_stats": (_i32, [_P, _P]),
@@ -161,6 +163,8 @@ PROTOTYPES = {
     "mfh_debug_spd_inverse": (_i32, [_i64, _P]),
     "mfh_debug_spd_inverse_device": (_i32, [_P, _i64, _P]),
     "mfh_debug_device_node_tables": (_i32, [_P, _P, _P]),
+    "mfh_debug_arena_alloc": (_i32, [_P, _i64, C.POINTER(_P)]),
+    "mfh_debug_arena_free": (_i32, [_P, _P]),
     "mfh_debug_row_chunks": (_i32, [_i64, _P, _i32, _i64, _P, _i64, _i32, _P, _i64, _P]),
 }
 

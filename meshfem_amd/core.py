@@ -626,3 +626,12 @@ def device_cache_stats(device=0):
     v = [C.c_int64() for _ in range(5)]
     lib.mfh_device_cache_stats(int(device), *[C.byref(x) for x in v])
     return dict(zip(("cached_bytes", "blocks", "hits", "misses", "flushes"), [x.value for x in v]))
+
+
+def device_arena_stats(device=0):
+    """State of the library's device arena (mfh_device_arena_stats): bytes held / live / live high-water mark, segments, free chunks, ..."""
+    lib = L.load()
+    v = (C.c_int64 * 8)()
+    lib.mfh_device_arena_stats(int(device), v)
+    return dict(zip(("held_bytes", "live_bytes", "live_high_water_bytes", "segments", "free_chunks", "returned_to_driver_bytes",
+                     "quarantined_bytes", "free_bound_bytes"), list(v)))

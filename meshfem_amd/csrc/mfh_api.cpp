@@ -469,6 +469,8 @@ void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double 
     } else if (c->upperOnly) {
         // the stored triangle serves both halves of the product (k_spmv_sym: transposed parts added with global atomics; measured slower than
         // k_spmv on both triangles, DESIGN 4.4: the PCG keeps asking for the full storage, this serves mfh_apply_K / mfh_dev_spmv)
+        // k_spmv_sym adds in arrival order: not run-to-run reproducible, which option "deterministic" promises for every operator
+        require(!c->deterministic, MFH_ERR_UNSUPPORTED, "deterministic 1: the product with an upper-triangle matrix (matrix_storage 1) adds with global atomics in arrival order; use matrix_storage 0 (both triangles) or the matrix-free operator");
         k::launch_spmv_sym(spmv_args(c, masked), c->sym.nRows, x, y, dotOut, c->stream);
     } else {
         k::launch_spmv(spmv_args(c, masked), x, y, dotOut, c->stream);
@@ -1075,6 +1077,8 @@ mfh_status mfh_create(int32_t device, mfh_ctx **out) {
         c->device = device;
         MFH_HIP(hipSetDevice(device));
         MFH_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        mfh::device_arena_context_opened(device);
+        c->arenaCounted = true;
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->nCU = cus;
     } catch (const mfh::Error &e) {
@@ -1082,6 +1086,7 @@ mfh_status mfh_create(int32_t device, mfh_ctx **out) {
         lastCreateError = e.what();
         fprintf(stderr, "mfh_create: %s\n", e.what());
         mfh_status code = e.code;
+        if (c->arenaCounted) mfh::device_arena_context_closed(c->device);
         delete c;
         return code;
     }
@@ -1096,6 +1101,8 @@ void mfh_destroy(mfh_ctx *c) {
     if (!c->hostOnly && c->dist.commStream) (void)hipStreamSynchronize(c->dist.commStream);
     hipStream_t s = c->stream;
     const bool own = c->ownStream;
+    const bool counted = c->arenaCounted;
+    const int dev = c->device;
     {
         // the context's streams are idle (synchronised above; a hierarchy's child context synchronises its own in its mfh_destroy): every device
         // buffer released from here on -- hierarchy levels, partition state, the context's own -- goes back to the cache without waiting for
@@ -1111,18 +1118,25 @@ void mfh_destroy(mfh_ctx *c) {
         delete c;   // device buffers are freed while the stream is still alive
     }
     if (s && own) (void)hipStreamDestroy(s);
+    // the arena keeps no more than the process has ever had live, and next to nothing once the last context of the device is gone (mfh_pool.cpp)
+    if (counted) mfh::device_arena_context_closed(dev);
 }
 
 const char *mfh_last_error(const mfh_ctx *c) { return c ? c->err.c_str() : "null context"; }
 void *mfh_stream(mfh_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
-/* the per-process cache of released device blocks (mfh_pool.cpp) */
+/* the per-process device arena (mfh_pool.cpp) */
 mfh_status mfh_device_cache_trim(void) {
     try { mfh::device_cache_trim(); } catch (...) { return MFH_ERR_HIP; }
     return MFH_OK;
 }
 mfh_status mfh_device_cache_stats(int32_t device, int64_t *cachedBytes, int64_t *blocks, int64_t *hits, int64_t *misses, int64_t *flushes) {
     mfh::device_cache_stats(device, cachedBytes, blocks, hits, misses, flushes);
+    return MFH_OK;
+}
+mfh_status mfh_device_arena_stats(int32_t device, int64_t *out8) {
+    if (!out8) return MFH_ERR_INVALID;
+    mfh::device_arena_stats(device, out8);
     return MFH_OK;
 }
 
@@ -1132,12 +1146,20 @@ mfh_status mfh_set_stream(mfh_ctx *c, void *stream) {
     require_device(c);
     MFH_HIP(hipSetDevice(c->device));
     MFH_HIP(hipStreamSynchronize(c->stream));
-    if (c->ownStream && c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->dist.commStream) MFH_HIP(hipStreamSynchronize(c->dist.commStream));
+    {
+        // the linear level of a multigrid hierarchy is a context of its own that launches on a copy of the parent's stream: drop the hierarchy
+        // (it is rebuilt on the new stream by the next solve that wants it) rather than leave it on a stream that may be gone --
+        // and drop it BEFORE the old stream is destroyed, with the streams known idle: the buffers it releases must not wait on a handle
+        // that no longer exists (use-after-destroy of the stream in the arena's wait)
+        mfh::PoolScope idle(nullptr, nullptr, 2);
+        destroy_multigrid(c);
+    }
+    hipStream_t old = c->stream;
+    const bool ownOld = c->ownStream;
     c->stream = (hipStream_t)stream;   // nullptr = the legacy default stream
     c->ownStream = false;
-    // the linear level of a multigrid hierarchy is a context of its own that launches on a copy of the parent's stream: drop the hierarchy
-    // (it is rebuilt on the new stream by the next solve that wants it) rather than leave it on a stream that may be gone
-    destroy_multigrid(c);
+    if (ownOld && old) (void)hipStreamDestroy(old);
     MFH_CATCH(c)
 }
 
@@ -2015,6 +2037,22 @@ mfh_status mfh_debug_device_node_tables(mfh_ctx *c, int32_t *elemNodes, double *
     require(c->dElemNodes.n == (size_t)m.nElem * m.npe && c->dVertPos.n == (size_t)m.nNode * m.dim, MFH_ERR_STATE, "device node tables have another size than the host's");
     c->dElemNodes.download(elemNodes, c->dElemNodes.n, c->stream);
     c->dVertPos.download(nodePos, c->dVertPos.n, c->stream);
+    MFH_CATCH(c)
+}
+
+// test hook: one allocation / release through the device arena, in the scope of the context (its streams are what a release waits for)
+mfh_status mfh_debug_arena_alloc(mfh_ctx *c, int64_t bytes, void **out) {
+    MFH_TRY(c)
+    require(c && !c->hostOnly && out && bytes > 0, MFH_ERR_INVALID, "mfh_debug_arena_alloc: arguments");
+    MFH_HIP(hipSetDevice(c->device));
+    *out = mfh::device_alloc((size_t)bytes);
+    MFH_CATCH(c)
+}
+mfh_status mfh_debug_arena_free(mfh_ctx *c, void *p) {
+    MFH_TRY(c)
+    require(c && !c->hostOnly, MFH_ERR_INVALID, "mfh_debug_arena_free: arguments");
+    MFH_HIP(hipSetDevice(c->device));
+    mfh::device_free(p);
     MFH_CATCH(c)
 }
 

@@ -33,6 +33,7 @@ struct mfh_ctx {
     int periodicIgnoreDims = 0;            // option "periodic_ignore_dims": bit a set = dimension a is not periodic
     hipStream_t stream = nullptr;
     bool ownStream = true;
+    bool arenaCounted = false;          // counted by the device arena (mfh_create of a device context): mfh_destroy reports the close
     std::string err;
 
     // ---- mesh

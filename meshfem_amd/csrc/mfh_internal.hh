@@ -55,10 +55,13 @@ void parallel_ranges(int64_t n, const std::function<void(int64_t, int64_t, int)>
 void host_advise_huge_pages(void *p, size_t bytes);
 int  host_threads();
 
-// device memory of the library: hipMalloc / hipFree behind a cache of released blocks (mfh_pool.cpp)
+// device memory of the library: an arena that splits and coalesces inside the hipMalloc segments it holds (mfh_pool.cpp)
 void *device_alloc(size_t bytes);
 void device_free(void *p);
 void device_cache_trim();
+void device_arena_context_opened(int dev);     // mfh_create / mfh_destroy of a device context: when a context closes the arena is trimmed
+void device_arena_context_closed(int dev);     // to its live high-water mark, when the last one closes to a small reserve
+void device_arena_stats(int dev, int64_t out[8]);   // held, live, live high-water mark, segments, free chunks, bytes returned to the driver, quarantined, bound
 // What a release waits for before the block may be handed to somebody else: the streams of the context the calling thread is working for
 // (PoolScope, installed by every API entry), not the whole device -- hipDeviceSynchronize from one host thread invalidates a stream
 // capture another thread has open (tests/test_gpu_threads.py). Outside any scope: the device.

@@ -230,10 +230,14 @@ void peer_enable(mfh_comm *cm, int device, hipStream_t s) {
     P.slabBytes = slab_size(world, P.haloCap, P.arCap);
     bool fine = true;
     std::string failure;
+    // The protocol needs cross-device coherence (remote plain stores + a flag polled by a kernel that is already running, data read in
+    // the same kernel): only fine-grained memory gives it. No coarse-grained fallback: without the fine-grained slab this
+    // rank reports failure and EVERY rank backs out to the next transport.
     if (hipExtMallocWithFlags(&P.slab, P.slabBytes, hipDeviceMallocFinegrained) != hipSuccess) {
         (void)hipGetLastError();
         fine = false;
-        if (hipMalloc(&P.slab, P.slabBytes) != hipSuccess) { (void)hipGetLastError(); P.slab = nullptr; failure = "allocation of the staging slab failed"; }
+        P.slab = nullptr;
+        failure = "fine-grained allocation of the staging slab failed";
     }
     hipIpcMemHandle_t h;
     memset(&h, 0, sizeof(h));
@@ -258,6 +262,10 @@ void peer_enable(mfh_comm *cm, int device, hipStream_t s) {
             if (r == me) { P.remote[r] = P.slab; continue; }
             hipIpcMemHandle_t hr;
             for (int j = 0; j < 64; ++j) reinterpret_cast<unsigned char *>(&hr)[j] = (unsigned char)all[(size_t)r * 66 + j];
+            // fault injection for the transport-chain test (tests/test_gpu_peer_transport.py): rank MFH_PEER_FAULT_RANK opens a handle whose
+            // bytes were overwritten -- the open fails there, the second agreement round makes EVERY rank back out
+            if (const char *fe = getenv("MFH_PEER_FAULT_RANK"))
+                if (atoi(fe) == me) memset(&hr, 0x5a, sizeof(hr));
             hipError_t e = hipIpcOpenMemHandle(&P.remote[r], hr, hipIpcMemLazyEnablePeerAccess);
             if (e != hipSuccess) {
                 (void)hipGetLastError();
@@ -282,7 +290,7 @@ void peer_enable(mfh_comm *cm, int device, hipStream_t s) {
     P.symmetric = true;
     for (auto &m : P.peerMask) m = 0;
     P.enabled = true;
-    cm->descFull = cm->desc + " + peer copies over HIP IPC (" + (fine ? "fine-grained" : "coarse-grained") + " staging, " +
+    cm->descFull = cm->desc + " + peer copies over HIP IPC (fine-grained staging, " +
                    std::to_string(P.slabBytes >> 20) + " MiB per rank)";
 }
 

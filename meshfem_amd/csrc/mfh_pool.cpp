@@ -1,72 +1,162 @@
-// Device allocations of the library (DBuf): a per-process cache of released blocks.
+// Device allocations of the library (DBuf): a per-process ARENA that sub-allocates inside the segments it holds.
 //
-// Why: on this driver stack a hipMalloc that follows large hipFree calls of the same process can take SECONDS (measured on MI355X / ROCm 7.2,
-// profiles/r04_malloc_probe.txt: 32 GB again after a free 1.75 s, 16 x (8 GB hipMalloc + hipFree) 3.65 s, 120 GB 5.7 s -- against 0.3 ms for
-// the first 32 GB of the process; the stream-ordered pool, which keeps its memory, serves the same sequence in 7 ms). The setup phases of a
-// context allocate and release about 3.5x the memory they end up holding (sort keys, scan storage, lists), so the first assembly of a
-// 40 M-element mesh in a process that had released memory before took 5.4 - 7.4 s, "almost all of it hipMalloc / hipFree" (VERDICT r3).
-// The reference reserves its triplet storage once (LinearElasticity.hh:1441-1443).
+// Why an arena at all: on this driver stack a hipMalloc that follows large hipFree calls of the same process can take SECONDS (measured on
+// MI355X / ROCm 7.2, profiles/r04_malloc_probe.txt: 32 GB again after a free 1.75 s, 16 x (8 GB hipMalloc + hipFree) 3.65 s, 120 GB 5.7 s --
+// against 0.3 ms for the first 32 GB of the process: memory the process never held is handed out lazily, memory it released is cleared
+// first, at ~18 GB/s). The setup phases of a context allocate and release about 3.5x the memory they end up holding (sort keys, scan
+// storage, lists). The reference reserves its triplet storage once (LinearElasticity.hh:1441-1443).
 //
-// What: a released block goes to a size-ordered free list instead of back to the driver; an allocation takes the smallest cached block
-// that fits without wasting more than a quarter (+1 MiB), else asks the driver; when the driver is out of memory the cache is flushed
-// and the request repeated. The cache is bounded (MFH_DEVICE_CACHE_MB, default FOUR FIFTHS of the device's memory): beyond that the largest blocks
-// go back to the driver -- and the next large hipMalloc pays for it (the stall grows with the bytes freed, ~18 GB/s): with a bound of a third, and
-// still with half, a released 129 GB context (configs[4]) on top of the setup's cached temporaries lost its 58 GB value array and the next
-// context waited 1 - 3 s for a new one (scripts/setup_probe.py 119, round 4). What the library itself cannot allocate any more flushes the
-// cache and is retried; OTHER allocators of the process (torch, RCCL) do not know about it: mfh_device_cache_trim() before handing them the device. MFH_DEVICE_CACHE_MB=0 restores plain hipMalloc / hipFree. mfh_device_cache_trim() empties it on request.
+// Why it splits and coalesces (round 5; rounds 3-4 had a size-bucket list that reused a released block only for a request of nearly the
+// same size): with buckets a process that had run other meshes first held its memory in blocks of the WRONG sizes, the next large context
+// missed all of them, and on a device that the cache had filled the driver was asked again -- 4.5 s in the symbolic phase of the 119^3 cube
+// on the round-4 driver box against 0.36 s in a fresh process. Here a released chunk merges with its free neighbours (address order, inside
+// its segment) and any request is cut from the smallest free chunk that holds it (best fit); the driver is asked for a new segment only
+// when nothing fits. Requests below 1 MiB share 64 MiB segments; larger ones are rounded up to 2 MiB, get a segment of their own size when
+// nothing fits (which later requests may split at 2 MiB boundaries) and never share a segment with the small ones.
+//
+// Bounds. (1) Free bytes the arena keeps while contexts are alive: MFH_DEVICE_CACHE_MB, default HALF the device; beyond it whole free
+// segments go back to the driver, largest first. (2) When the LAST context of a device closes (mfh_destroy ->
+// device_arena_context_closed) whole free segments go back until at most a quarter of the device stays (MFH_DEVICE_CACHE_IDLE_MB):
+// other allocators of the process (torch, RCCL) then find the memory. mfh_device_cache_trim() gives back every free segment;
+// MFH_DEVICE_CACHE_MB=0 restores plain hipMalloc / hipFree. A request the driver cannot serve releases the free segments and is repeated.
 #include "mfh_internal.hh"
 #include <map>
 #include <mutex>
+#include <set>
 #include <unordered_map>
+#include <vector>
 
 namespace mfh {
 
 namespace {
-struct Block { size_t bytes; int dev; };
-struct DevCache {
-    std::multimap<size_t, void *> free;      // released blocks by size
-    size_t cachedBytes = 0, limit = 0;
+// Two size classes that never share a segment. SMALL: requests below 1 MiB, multiples of 256 B, cut from 64 MiB segments -- the few
+// hundred long-lived tables of a context must not pin (or cut notches into) the multi-GB segments. LARGE: everything else, rounded up to
+// 2 MiB and cut at 2 MiB boundaries: a large buffer then starts on the same kind of boundary that a hipMalloc of its own would give it.
+constexpr size_t ALIGN = 256;
+constexpr size_t SMALL_REQUEST = (size_t)1 << 20;
+constexpr size_t SMALL_SEGMENT = (size_t)64 << 20;
+constexpr size_t SEGMENT_ROUND = (size_t)2 << 20;
+
+struct Chunk {
+    size_t bytes;
+    char *segment;      // base address of the segment it lies in
+    bool free;
+};
+struct Segment { size_t bytes, freeBytes; int cls; };
+struct Arena {
+    std::map<char *, Chunk> chunks;                       // every chunk of every segment, by address
+    std::set<std::pair<size_t, char *>> freeBySize[2];    // the free ones of either size class, by (size, address): best fit = lower_bound
+    std::map<char *, Segment> segments;
+    std::vector<std::pair<char *, size_t>> quarantine;    // released outside an API scope: users unknown until the next device-wide wait
+    size_t held = 0, live = 0, liveHigh = 0, limit = 0, idleLimit = 0, quarantined = 0;
     bool init = false, enabled = true;
+    int contexts = 0;
     int64_t hits = 0, misses = 0, flushes = 0, bypassed = 0;
-    size_t evictedBytes = 0;
+    size_t returnedBytes = 0;
+    size_t free_bytes() const { return held - live - quarantined; }
 };
 std::mutex g_mu;
-std::map<int, DevCache> g_cache;                 // one free list per device
-std::unordered_map<void *, Block> g_blocks;      // every live or cached block handed out by device_alloc, with the device it lives on
+std::map<int, Arena> g_arena;                            // one arena per device
+std::unordered_map<void *, int> g_owner;                 // live pointer handed out by device_alloc -> device
 thread_local hipStream_t t_streams[2] = {nullptr, nullptr};
 thread_local int t_mode = 0;
 
-void wait_for_users(int blockDev, int currentDev) {
-    if (t_mode == 2) return;
-    if (t_mode == 1) {
-        (void)hipStreamSynchronize(t_streams[0]);
-        if (t_streams[1]) (void)hipStreamSynchronize(t_streams[1]);
-        return;
-    }
-    (void)blockDev; (void)currentDev;                             // (mode 0 never reaches here: device_free hands such blocks to hipFree)
+void wait_for_users() {
+    if (t_mode != 1) return;
+    // a failed wait (e.g. a stream the caller has destroyed meanwhile) must not surface at an unrelated launch later: clear it
+    if (hipStreamSynchronize(t_streams[0]) != hipSuccess) (void)hipGetLastError();
+    if (t_streams[1] && hipStreamSynchronize(t_streams[1]) != hipSuccess) (void)hipGetLastError();
 }
 
-DevCache &cache_of(int dev) {
-    DevCache &C = g_cache[dev];
-    if (!C.init) {
-        C.init = true;
+Arena &arena_of(int dev) {
+    Arena &A = g_arena[dev];
+    if (!A.init) {
+        A.init = true;
         size_t fr = 0, total = 0;
         if (hipMemGetInfo(&fr, &total) != hipSuccess) { (void)hipGetLastError(); total = (size_t)64 << 30; }
-        C.limit = total / 5 * 4;
+        A.limit = total / 2;
+        A.idleLimit = total / 4;
         if (const char *e = getenv("MFH_DEVICE_CACHE_MB")) {
             const long long mb = atoll(e);
-            if (mb <= 0) C.enabled = false;
-            else C.limit = (size_t)mb << 20;
+            if (mb <= 0) A.enabled = false;
+            else A.limit = (size_t)mb << 20;
         }
+        if (const char *e = getenv("MFH_DEVICE_CACHE_IDLE_MB")) A.idleLimit = (size_t)std::max(0LL, atoll(e)) << 20;
+        A.idleLimit = std::min(A.idleLimit, A.limit);
     }
-    return C;
+    return A;
 }
 
-void flush_locked(DevCache &C) {
-    for (auto &kv : C.free) { g_blocks.erase(kv.second); (void)hipFree(kv.second); }
-    C.free.clear();
-    C.cachedBytes = 0;
-    ++C.flushes;
+void insert_free(Arena &A, char *p, size_t bytes, char *seg) {
+    // merge with the free neighbours of the same segment
+    auto &freeBySize = A.freeBySize[A.segments[seg].cls];
+    auto it = A.chunks.find(p);
+    if (it != A.chunks.begin()) {
+        auto prev = std::prev(it);
+        if (prev->second.free && prev->second.segment == seg && prev->first + prev->second.bytes == p) {
+            freeBySize.erase({prev->second.bytes, prev->first});
+            bytes += prev->second.bytes;
+            p = prev->first;
+            A.chunks.erase(it);
+            it = prev;
+        }
+    }
+    auto next = std::next(it);
+    if (next != A.chunks.end() && next->second.free && next->second.segment == seg && p + bytes == next->first) {
+        freeBySize.erase({next->second.bytes, next->first});
+        bytes += next->second.bytes;
+        A.chunks.erase(next);
+    }
+    it->second = Chunk{bytes, seg, true};
+    freeBySize.insert({bytes, p});
+}
+
+// give whole free segments back to the driver, largest first, while pred() holds; returns the bytes returned
+template <class Pred> size_t release_free_segments(Arena &A, Pred keepGoing) {
+    size_t done = 0;
+    while (keepGoing()) {
+        char *best = nullptr;
+        size_t bestBytes = 0;
+        for (auto &kv : A.segments)
+            if (kv.second.freeBytes == kv.second.bytes && kv.second.bytes > bestBytes) { best = kv.first; bestBytes = kv.second.bytes; }
+        if (!best) break;
+        A.freeBySize[A.segments[best].cls].erase({bestBytes, best});
+        A.chunks.erase(best);
+        A.segments.erase(best);
+        A.held -= bestBytes;
+        A.returnedBytes += bestBytes;
+        done += bestBytes;
+        (void)hipFree(best);
+    }
+    return done;
+}
+
+// chunks released outside an API scope become reusable after a device-wide wait (the caller has made one)
+void drain_quarantine(Arena &A) {
+    for (auto &q : A.quarantine) {
+        auto it = A.chunks.find(q.first);
+        if (it == A.chunks.end()) continue;
+        char *seg = it->second.segment;
+        A.segments[seg].freeBytes += q.second;
+        insert_free(A, q.first, q.second, seg);
+    }
+    A.quarantine.clear();
+    A.quarantined = 0;
+}
+
+char *carve(Arena &A, int cls, std::set<std::pair<size_t, char *>>::iterator fit, size_t bytes) {
+    char *p = fit->second;
+    const size_t have = fit->first;
+    A.freeBySize[cls].erase(fit);
+    Chunk &c = A.chunks[p];
+    char *seg = c.segment;
+    if (have > bytes) {                    // the rest stays free (a neighbour of p in address order; its other neighbour is not free: they were merged)
+        A.chunks[p + bytes] = Chunk{have - bytes, seg, true};
+        A.freeBySize[cls].insert({have - bytes, p + bytes});
+    }
+    c = Chunk{bytes, seg, false};
+    A.segments[seg].freeBytes -= bytes;
+    return p;
 }
 }   // namespace
 
@@ -74,80 +164,107 @@ void *device_alloc(size_t bytes) {
     if (bytes == 0) return nullptr;
     int dev = 0;
     MFH_HIP(hipGetDevice(&dev));
-    bytes = (bytes + 255) & ~(size_t)255;
+    const int cls = bytes < SMALL_REQUEST ? 0 : 1;
+    bytes = cls == 0 ? (bytes + ALIGN - 1) & ~(ALIGN - 1) : (bytes + SEGMENT_ROUND - 1) & ~(SEGMENT_ROUND - 1);
     std::lock_guard<std::mutex> lock(g_mu);
-    DevCache &C = cache_of(dev);
-    if (C.enabled) {
-        auto it = C.free.lower_bound(bytes);
-        if (it != C.free.end() && it->first <= bytes + bytes / 4 + ((size_t)1 << 20)) {
-            void *p = it->second;
-            C.cachedBytes -= it->first;
-            C.free.erase(it);
-            ++C.hits;
-            return p;
+    Arena &A = arena_of(dev);
+    if (!A.enabled) {
+        void *p = nullptr;
+        const hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); throw Error(MFH_ERR_HIP, std::string("hipMalloc of ") + std::to_string(bytes >> 20) + " MiB: " + hipGetErrorString(e)); }
+        return p;
+    }
+    auto &freeBySize = A.freeBySize[cls];
+    auto fit = freeBySize.lower_bound({bytes, nullptr});
+    if (fit != freeBySize.end()) ++A.hits;
+    else {
+        // nothing the arena holds fits: one new segment from the driver
+        ++A.misses;
+        size_t segBytes = cls == 0 ? SMALL_SEGMENT : bytes;
+        static const bool trace = getenv("MFH_POOL_TRACE") != nullptr;
+        const double tTrace = trace ? now_ms() : 0.0;
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, segBytes);
+        if (e != hipSuccess && segBytes > bytes) { (void)hipGetLastError(); segBytes = bytes; e = hipMalloc(&p, segBytes); }
+        if (e != hipSuccess) {
+            // the driver is out of memory: what the arena holds but does not use goes back, then once more
+            (void)hipGetLastError();
+            if (!A.quarantine.empty()) { (void)hipDeviceSynchronize(); drain_quarantine(A); }
+            ++A.flushes;
+            release_free_segments(A, [] { return true; });
+            fit = freeBySize.lower_bound({bytes, nullptr});      // (the quarantine may have completed a chunk that fits)
+            if (fit == freeBySize.end()) e = hipMalloc(&p, segBytes);
+            else e = hipSuccess, p = nullptr;
+        }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            throw Error(MFH_ERR_HIP, std::string("hipMalloc of ") + std::to_string(segBytes >> 20) + " MiB: " + hipGetErrorString(e));
+        }
+        if (trace && (now_ms() - tTrace > 20.0 || segBytes >= ((size_t)4 << 30))) {
+            size_t fr = 0, tot = 0;
+            (void)hipMemGetInfo(&fr, &tot);
+            fprintf(stderr, "[arena] new segment %.1f MB: %.1f ms; held %.1f GB in %zu segments (live %.1f GB), device free %.1f GB, returned to the driver so far %.1f GB\n",
+                    segBytes / 1e6, now_ms() - tTrace, A.held / 1e9, A.segments.size(), A.live / 1e9, fr / 1e9, A.returnedBytes / 1e9);
+        }
+        if (p) {
+            char *seg = (char *)p;
+            A.segments[seg] = Segment{segBytes, segBytes, cls};
+            A.chunks[seg] = Chunk{segBytes, seg, true};
+            A.held += segBytes;
+            fit = freeBySize.insert({segBytes, seg}).first;
         }
     }
-    void *p = nullptr;
-    static const bool trace = getenv("MFH_POOL_TRACE") != nullptr;
-    const double tTrace = trace ? now_ms() : 0.0;
-    hipError_t e = hipMalloc(&p, bytes);
-    if (trace && (now_ms() - tTrace > 20.0 || bytes >= ((size_t)4 << 30))) {
-        size_t fr = 0, tot = 0;
-        (void)hipMemGetInfo(&fr, &tot);
-        fprintf(stderr, "[pool] hipMalloc %.1f MB: %.1f ms; cached %.1f GB in %zu blocks, device free %.1f GB, returned to the driver so far %.1f GB (%lld blocks outside an API scope)\n",
-                bytes / 1e6, now_ms() - tTrace, C.cachedBytes / 1e9, C.free.size(), fr / 1e9, C.evictedBytes / 1e9, (long long)C.bypassed);
-    }
-    if (e != hipSuccess && C.enabled && !C.free.empty()) {
-        (void)hipGetLastError();
-        flush_locked(C);
-        e = hipMalloc(&p, bytes);
-    }
-    if (e != hipSuccess) {
-        (void)hipGetLastError();
-        throw Error(MFH_ERR_HIP, std::string("hipMalloc of ") + std::to_string(bytes >> 20) + " MiB: " + hipGetErrorString(e));
-    }
-    if (C.enabled) g_blocks[p] = Block{bytes, dev};
-    ++C.misses;
+    char *p = carve(A, cls, fit, bytes);
+    A.live += bytes;
+    A.liveHigh = std::max(A.liveHigh, A.live);
+    g_owner[p] = dev;
     return p;
 }
 
 void device_free(void *p) {
     if (!p) return;
-    int cur = 0;
-    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); return; }
     std::unique_lock<std::mutex> lock(g_mu);
-    auto it = g_blocks.find(p);
-    if (it == g_blocks.end()) {            // allocated with the cache disabled
+    auto own = g_owner.find(p);
+    if (own == g_owner.end()) {            // allocated with the arena disabled
         lock.unlock();
         (void)hipFree(p);
         return;
     }
-    const Block blk = it->second;          // the block goes back to the list of the device it lives on, whatever the caller's current device
-    if (t_mode == 0) {
-        // released outside any API entry (no PoolScope: the streams that may still use the block are unknown): plain hipFree, which waits for
-        // the block's users by itself -- NOT a device-wide wait, which would invalidate the stream captures of other host threads
-        DevCache &C0 = cache_of(blk.dev);
-        ++C0.bypassed;
-        C0.evictedBytes += blk.bytes;
-        g_blocks.erase(it);
+    const int dev = own->second;           // the chunk goes back to the arena of the device it lives on, whatever the caller's current device
+    const int mode = t_mode;
+    if (mode == 1) {
         lock.unlock();
-        (void)hipFree(p);
+        wait_for_users();                  // what hipFree did implicitly: nothing in flight uses the chunk when somebody else gets it
+        lock.lock();
+    }
+    g_owner.erase(p);
+    Arena &A = arena_of(dev);
+    auto it = A.chunks.find((char *)p);
+    if (it == A.chunks.end() || it->second.free) return;     // (cannot happen: every owned pointer is a live chunk)
+    const size_t bytes = it->second.bytes;
+    char *seg = it->second.segment;
+    A.live -= bytes;
+    if (mode == 0) {
+        // released outside any API entry (no PoolScope: the streams that may still use the chunk are unknown). A chunk that is a whole
+        // segment goes to hipFree, which waits for its users by itself -- NOT a device-wide wait here, which would invalidate the stream
+        // captures of other host threads; a part of a segment waits in quarantine for the next device-wide wait the arena makes anyway
+        ++A.bypassed;
+        if (bytes == A.segments[seg].bytes) {
+            A.chunks.erase(it);
+            A.segments.erase(seg);
+            A.held -= bytes;
+            A.returnedBytes += bytes;
+            lock.unlock();
+            (void)hipFree(p);
+            return;
+        }
+        A.quarantine.emplace_back((char *)p, bytes);
+        A.quarantined += bytes;
         return;
     }
-    lock.unlock();
-    wait_for_users(blk.dev, cur);          // what hipFree did implicitly: nothing in flight uses the block when somebody else gets it
-    lock.lock();
-    DevCache &C = cache_of(blk.dev);
-    C.free.emplace(blk.bytes, p);
-    C.cachedBytes += blk.bytes;
-    while (C.cachedBytes > C.limit && !C.free.empty()) {      // over the bound: the largest blocks go back to the driver
-        auto last = std::prev(C.free.end());
-        C.cachedBytes -= last->first;
-        C.evictedBytes += last->first;
-        g_blocks.erase(last->second);
-        (void)hipFree(last->second);
-        C.free.erase(last);
-    }
+    A.segments[seg].freeBytes += bytes;
+    insert_free(A, (char *)p, bytes, seg);
+    if (A.free_bytes() > A.limit) release_free_segments(A, [&] { return A.free_bytes() > A.limit; });
 }
 
 PoolScope::PoolScope(hipStream_t a, hipStream_t b, int mode) {
@@ -156,27 +273,57 @@ PoolScope::PoolScope(hipStream_t a, hipStream_t b, int mode) {
 }
 PoolScope::~PoolScope() { t_streams[0] = saved[0]; t_streams[1] = saved[1]; t_mode = savedMode; }
 
+void device_arena_context_opened(int dev) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    ++arena_of(dev).contexts;
+}
+
+void device_arena_context_closed(int dev) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Arena &A = arena_of(dev);
+    if (A.contexts > 0) --A.contexts;
+    if (!A.enabled) return;
+    // With no context left on the device only a reserve for the next one stays: the rest is for the process's other allocators (torch,
+    // RCCL). NOT trimmed while other contexts live, and not to the high-water mark of the live bytes either (first version of this
+    // arena, profiles/r05_arena_probe_119_warm_with_high_water_trim.log): memory this process has returned is what the driver hands out
+    // -- after clearing it -- for the next large request; 28 GB returned by the closes of two 60^3 contexts cost the 58.5 GB value array
+    // of the next 119^3 context 0.97 s, 167 GB returned 1.34 s (never-held memory: 0.3 ms).
+    if (A.contexts == 0) release_free_segments(A, [&] { return A.free_bytes() > A.idleLimit; });
+}
+
 void device_cache_trim() {
     std::lock_guard<std::mutex> lock(g_mu);
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
-    for (auto &kv : g_cache) {
-        if (kv.second.free.empty()) continue;
+    for (auto &kv : g_arena) {
+        Arena &A = kv.second;
+        if (A.held == A.live) continue;
         (void)hipSetDevice(kv.first);
-        (void)hipDeviceSynchronize();
-        flush_locked(kv.second);
+        if (!A.quarantine.empty()) {
+            if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+            drain_quarantine(A);
+        }
+        ++A.flushes;
+        release_free_segments(A, [] { return true; });
     }
     if (cur >= 0) (void)hipSetDevice(cur);     // the caller's current device is left as it was
 }
 
 void device_cache_stats(int dev, int64_t *cachedBytes, int64_t *blocks, int64_t *hits, int64_t *misses, int64_t *flushes) {
     std::lock_guard<std::mutex> lock(g_mu);
-    DevCache &C = g_cache[dev];
-    if (cachedBytes) *cachedBytes = (int64_t)C.cachedBytes;
-    if (blocks) *blocks = (int64_t)C.free.size();
-    if (hits) *hits = C.hits;
-    if (misses) *misses = C.misses;
-    if (flushes) *flushes = C.flushes;
+    Arena &A = g_arena[dev];
+    if (cachedBytes) *cachedBytes = (int64_t)(A.held - A.live);
+    if (blocks) *blocks = (int64_t)(A.freeBySize[0].size() + A.freeBySize[1].size());
+    if (hits) *hits = A.hits;
+    if (misses) *misses = A.misses;
+    if (flushes) *flushes = A.flushes;
+}
+
+void device_arena_stats(int dev, int64_t out[8]) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Arena &A = g_arena[dev];
+    out[0] = (int64_t)A.held; out[1] = (int64_t)A.live; out[2] = (int64_t)A.liveHigh; out[3] = (int64_t)A.segments.size();
+    out[4] = (int64_t)(A.freeBySize[0].size() + A.freeBySize[1].size()); out[5] = (int64_t)A.returnedBytes; out[6] = (int64_t)A.quarantined; out[7] = (int64_t)A.limit;
 }
 
 }   // namespace mfh

@@ -1010,6 +1010,85 @@ mfh_status mfh_comm_selftest(mfh_ctx *c, mfh_comm *cm) {
     MFH_CATCH(c)
 }
 
+// First contact with a node's devices and links, before any solve. Collective. out (PREFLIGHT_DOUBLES(world) doubles):
+//   [0] world  [1] rank  [2] device  [3] device memory free (bytes)  [4] total  [5] arena: held  [6] arena: live
+//   [7] bytes of the timed messages  [8] ring bandwidth on the transport underneath, GB/s per direction (send to rank + 1 while receiving
+//   from rank - 1)  [9] the same through the peer transfers (0: not enabled / message too long for the staging)  [10] all-reduce of ones
+//   through the communicator (must equal world)  [11] peer transfers enabled
+//   [16 + r]           hipDeviceCanAccessPeer(own device, device of rank r): 1 / 0, 2 = the same device
+//   [16 + world + r]   the IPC slab of rank r is mapped here: 1 / 0 (the result of hipIpcOpenMemHandle at mfh_comm_enable_peer)
+mfh_status mfh_comm_preflight(mfh_ctx *c, mfh_comm *cm, int64_t messageBytes, double *out, int64_t nOut) {
+    MFH_TRY(c)
+    require(c && cm && out, MFH_ERR_INVALID, "bad arguments");
+    require_device(c);
+    const int world = cm->world, me = cm->rank;
+    require(nOut >= 16 + 2 * (int64_t)world, MFH_ERR_INVALID, "mfh_comm_preflight: output needs 16 + 2 world doubles");
+    MFH_HIP(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    for (int64_t i = 0; i < nOut; ++i) out[i] = 0.0;
+    out[0] = world; out[1] = me; out[2] = c->device;
+    size_t fr = 0, tot = 0;
+    MFH_HIP(hipMemGetInfo(&fr, &tot));
+    int64_t ar[8];
+    mfh::device_arena_stats(c->device, ar);
+    out[3] = (double)fr; out[4] = (double)tot; out[5] = (double)ar[0]; out[6] = (double)ar[1];
+    // devices of all ranks: an all-reduce in which every rank fills its own slot
+    DBuf<double> slots;
+    slots.alloc((size_t)world + 2);
+    std::vector<double> hs((size_t)world + 2, 0.0);
+    hs[(size_t)me] = (double)c->device + 1.0;
+    hs[(size_t)world] = 1.0;
+    MFH_HIP(hipMemcpyAsync(slots.p, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    comm_allreduce(cm, slots.p, world + 1, s);
+    MFH_HIP(hipMemcpyAsync(hs.data(), slots.p, hs.size() * sizeof(double), hipMemcpyDeviceToHost, s));
+    MFH_HIP(hipStreamSynchronize(s));
+    out[10] = hs[(size_t)world];
+    out[11] = cm->peer.enabled ? 1.0 : 0.0;
+    for (int r = 0; r < world; ++r) {
+        const int devR = (int)hs[(size_t)r] - 1;
+        int can = 0;
+        if (devR == c->device) can = 2;
+        else if (devR >= 0 && hipDeviceCanAccessPeer(&can, c->device, devR) != hipSuccess) { (void)hipGetLastError(); can = 0; }
+        out[16 + r] = can;
+        out[16 + world + r] = (cm->peer.enabled && r < PEER_MAX_WORLD && cm->peer.remote[r]) ? 1.0 : 0.0;
+    }
+    // ring bandwidth: every rank sends messageBytes to rank + 1 and receives as much from rank - 1, `reps` times back to back
+    const int64_t n = std::max<int64_t>(messageBytes / 8, 1024);
+    out[7] = (double)(n * 8);
+    if (world > 1) {
+        DBuf<double> a, b;
+        a.alloc((size_t)n); b.alloc((size_t)n);
+        a.zero(s); b.zero(s);
+        const int32_t to = (me + 1) % world, from = (me + world - 1) % world;
+        const double *sb[2] = {a.p, nullptr};
+        double *rb[2] = {nullptr, b.p};
+        int32_t peers[2] = {to, from};
+        int64_t sc[2] = {n, 0}, rc[2] = {0, n};
+        int np = 2;
+        if (to == from) { rb[0] = b.p; rc[0] = n; np = 1; }
+        auto timed = [&](bool peerPath) {
+            const int reps = 5;
+            auto once = [&]() {
+                if (peerPath) peer_exchange(cm, np, peers, sb, sc, rb, rc, s);
+                else base_exchange(cm, np, peers, sb, sc, rb, rc, s);
+            };
+            once();                                        // warm-up: first touch of the links / of the callbacks' staging
+            MFH_HIP(hipStreamSynchronize(s));
+            const double t0 = now_ms();
+            for (int k = 0; k < reps; ++k) once();
+            MFH_HIP(hipStreamSynchronize(s));
+            return (double)(n * 8) * reps / ((now_ms() - t0) * 1e-3) / 1e9;
+        };
+        out[8] = timed(false);
+        if (cm->peer.enabled) {
+            peer_reserve(cm, n, 1, (1u << to) | (1u << from), s);
+            if (peer_can_exchange(cm, np, peers, sc, rc)) out[9] = timed(true);
+            peer_check(cm, s);
+        }
+    }
+    MFH_CATCH(c)
+}
+
 mfh_status mfh_dist_setup(mfh_ctx *c, mfh_comm *cm, int32_t nPeers, const int32_t *peers, const int64_t *sendPtr, const int32_t *sendNodes,
                           const int64_t *recvPtr) {
     MFH_TRY(c)

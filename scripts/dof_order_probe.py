@@ -1,0 +1,97 @@
+"""What would a solver-internal DoF order buy (VERDICT r4 "missing 3")? A bijective DoF map IS a legal mfh_dof_map, so any order can be tried
+from outside the library: the rows of K, x and y are then numbered by the permutation, everything else is unchanged.
+Orders: the reference's numbering (FEMMesh.inl:17-37: vertices first, edge nodes in first-encounter order), first touch along the elements
+in generator order, first touch along the elements in the Morton order of their generator cells (the order the cluster operator walks).
+    python scripts/dof_order_probe.py [grid] [deg]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import meshfem_amd as M
+from meshfem_amd import grid
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+deg = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+T = np.ascontiguousarray(T, dtype=np.int32)
+
+
+def part1by2(x):
+    x = x.astype(np.uint64) & np.uint64(0x1fffff)
+    x = (x | (x << np.uint64(32))) & np.uint64(0x1f00000000ffff)
+    x = (x | (x << np.uint64(16))) & np.uint64(0x1f0000ff0000ff)
+    x = (x | (x << np.uint64(8))) & np.uint64(0x100f00f00f00f00f)
+    x = (x | (x << np.uint64(4))) & np.uint64(0x10c30c30c30c30c3)
+    x = (x | (x << np.uint64(2))) & np.uint64(0x1249249249249249)
+    return x
+
+
+def first_touch(elem_nodes, order, n_node):
+    seq = elem_nodes[order].ravel()
+    _, first = np.unique(seq, return_index=True)          # first occurrence of every node along the walk
+    nodes_in_order = seq[np.sort(first)]
+    perm = np.empty(n_node, dtype=np.int32)
+    perm[nodes_in_order] = np.arange(n_node, dtype=np.int32)
+    return perm
+
+
+def measure(label, perm):
+    c = M.Context(0)
+    c.mesh_build(T, V, deg)
+    if perm is not None:
+        c.dof_map(perm, len(perm))
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+    c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    c.symbolic(False)
+    c.assemble(); c.dev_sync()
+    kern = [c.time_assembly_kernel(M.ASSEMBLE_GATHER, 20) for _ in range(3)]
+    rec = dict(order=label, kernel_ms=kern, symbolic=c.symbolic_sizes())
+    f = c.neumann_load().ravel() if perm is None else None
+    if deg == 2 or True:
+        c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+        c.sim_solve(rtol=1e-2, maxit=50)
+        rec["operator_ms"] = [c.time_spmv_kernel(50) for _ in range(3)]
+        try:
+            rec["matrix_free"] = c.matrix_free_info()
+        except Exception as e:
+            rec["matrix_free"] = str(e)
+        for name, pre in (("block_jacobi_300", M.PRECOND_BLOCK_JACOBI),):
+            c.set_preconditioner(pre)
+            try:
+                c.sim_solve(rtol=1e-30, maxit=300)
+            except M.MeshFEMHipError:
+                pass
+            rec[name + "_iteration_ms"] = c.last_info["solve_ms"] / max(1, c.last_info["iterations"])
+        c.set_preconditioner(M.PRECOND_MULTIGRID)
+        for rep in range(2):
+            u = c.sim_solve(rtol=1e-8, maxit=500)
+            rec["multigrid"] = dict(iterations=c.last_info["iterations"], solve_ms=c.last_info["solve_ms"], max_abs_u=float(np.abs(u).max()))
+    print(json.dumps(rec), flush=True)
+    c.close()
+    return rec
+
+
+c0 = M.Context(0)
+c0.mesh_build(T, V, deg)
+EN = c0.elem_nodes()
+P = c0.node_positions()
+nN = c0.n_node
+c0.close()
+cent = P[EN[:, :4]].mean(axis=1)
+cells = np.minimum((cent * n).astype(np.int64), n - 1)
+key = part1by2(cells[:, 0]) | (part1by2(cells[:, 1]) << np.uint64(1)) | (part1by2(cells[:, 2]) << np.uint64(2))
+morton_elems = np.argsort(key, kind="stable")
+out = [measure("reference numbering (identity)", None),
+       measure("first touch, generator element order", first_touch(EN, np.arange(len(EN)), nN)),
+       measure("first touch, Morton order of the generator cells", first_touch(EN, morton_elems, nN)),
+       measure("reference numbering (identity), again", None)]
+pn = np.minimum((P * n * 2).astype(np.int64), 2 * n)
+nkey = part1by2(pn[:, 0]) | (part1by2(pn[:, 1]) << np.uint64(1)) | (part1by2(pn[:, 2]) << np.uint64(2))
+perm = np.empty(nN, dtype=np.int32)
+perm[np.argsort(nkey, kind="stable")] = np.arange(nN, dtype=np.int32)
+out.append(measure("Morton order of the node positions", perm))
+print(json.dumps(out))

@@ -1,0 +1,155 @@
+"""The device arena behind every device buffer of the library (meshfem_amd/csrc/mfh_pool.cpp; include/meshfem_hip.h "Device memory"):
+released memory stays in the hipMalloc segments it came in, free neighbours merge, requests are cut from the smallest chunk that fits, and
+the arena is trimmed when contexts close. The reference's counterpart is the single reserve of LinearElasticity.hh:1441-1443."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+MB = 1 << 20
+
+
+def _alloc(c, nbytes):
+    p = C.c_void_p()
+    c._ck(c.lib.mfh_debug_arena_alloc(c.h, int(nbytes), C.byref(p)))
+    return p.value
+
+
+def _free(c, p):
+    c._ck(c.lib.mfh_debug_arena_free(c.h, C.c_void_p(p)))
+
+
+def test_split_merge_and_best_fit():
+    import meshfem_amd as M
+    M.device_cache_trim()
+    c = M.Context(0)
+    s0 = M.device_arena_stats(0)
+    big = _alloc(c, 1024 * MB)                       # a segment of its own
+    s1 = M.device_arena_stats(0)
+    assert s1["segments"] == s0["segments"] + 1 and s1["held_bytes"] - s0["held_bytes"] == 1024 * MB
+    _free(c, big)
+    # three requests cut from the released segment: no new segment, addresses inside it, in order
+    a = _alloc(c, 256 * MB)
+    b = _alloc(c, 256 * MB)
+    d = _alloc(c, 300 * MB)
+    s2 = M.device_arena_stats(0)
+    assert s2["segments"] == s1["segments"] and s2["held_bytes"] == s1["held_bytes"]
+    assert a == big and b == big + 256 * MB and d == big + 512 * MB
+    # free the middle one and its left neighbour: they merge, and a request of their joint size fits where neither did alone
+    _free(c, b)
+    _free(c, a)
+    e = _alloc(c, 512 * MB)
+    assert e == big
+    assert M.device_arena_stats(0)["segments"] == s1["segments"]
+    # best fit: with holes of 212 MB (tail) and 512 MB (head) free, a 200 MB request takes the tail
+    _free(c, e)
+    g = _alloc(c, 200 * MB)
+    assert g == big + 812 * MB
+    _free(c, g)
+    _free(c, d)
+    s3 = M.device_arena_stats(0)
+    assert s3["live_bytes"] == s0["live_bytes"] and s3["held_bytes"] == s1["held_bytes"]       # one free 1 GiB chunk again
+    h = _alloc(c, 1024 * MB)
+    assert h == big
+    _free(c, h)
+    c.close()
+
+
+def test_small_requests_share_segments_and_stay_out_of_the_large_ones():
+    import meshfem_amd as M
+    M.device_cache_trim()
+    c = M.Context(0)
+    big = _alloc(c, 512 * MB)
+    _free(c, big)                                    # a free large chunk: small requests must not be cut from it
+    s0 = M.device_arena_stats(0)
+    ps = [_alloc(c, 700 * 1024 + 8) for _ in range(40)]      # 28 MB of sub-MiB requests: one 64 MiB segment
+    s1 = M.device_arena_stats(0)
+    assert s1["segments"] - s0["segments"] == 1 and s1["held_bytes"] - s0["held_bytes"] == 64 * MB
+    assert len(set(ps)) == 40 and all(p % 256 == 0 for p in ps)
+    assert not any(big <= p < big + 512 * MB for p in ps)
+    # large requests are rounded up to 2 MiB and start on 2 MiB boundaries of their segment
+    q = [_alloc(c, 5 * MB + 123) for _ in range(3)]
+    assert q[0] == big and q[1] == big + 6 * MB and q[2] == big + 12 * MB
+    for p in ps + q:
+        _free(c, p)
+    assert M.device_arena_stats(0)["live_bytes"] == s0["live_bytes"]
+    c.close()
+
+
+def test_trim_on_close_and_bound():
+    """What ADVICE r4 asked for: a closed context does not leave the device to the arena. With no context left the arena keeps at most a
+    quarter of the device (default MFH_DEVICE_CACHE_IDLE_MB)."""
+    import torch
+    import meshfem_amd as M
+    M.device_cache_trim()
+    free0, total = torch.cuda.mem_get_info(0)
+    c = M.Context(0)
+    n = int(0.4 * total) // (8 * MB) * (8 * MB)
+    ps = [_alloc(c, n // 4) for _ in range(4)]       # 40 % of the device live
+    for p in ps:
+        _free(c, p)
+    s = M.device_arena_stats(0)
+    assert s["held_bytes"] >= n                      # kept while the context lives (bound: half of the device)
+    assert s["held_bytes"] - s["live_bytes"] <= s["free_bound_bytes"]
+    c.close()
+    s = M.device_arena_stats(0)
+    assert s["held_bytes"] - s["live_bytes"] <= total // 4 + 128 * MB
+    free1, _ = torch.cuda.mem_get_info(0)
+    assert free1 >= free0 - total // 4 - 256 * MB    # the rest is back with the driver: torch / RCCL can have it
+    M.device_cache_trim()
+    s = M.device_arena_stats(0)
+    assert s["held_bytes"] == s["live_bytes"]
+
+
+def test_contexts_reuse_released_memory_without_asking_the_driver():
+    """A second context of the same size as a closed one is served from the arena: no new segments."""
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    V, T = grid.grid_tet_mesh(16, 16, 16, [0, 0, 0], [1, 1, 1])
+
+    def run():
+        c = M.Context(0)
+        c.mesh_build(T, V, 2)
+        c.material_isotropic(200.0, 0.35)
+        c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+        c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+        c.set_preconditioner(M.PRECOND_MULTIGRID)
+        u = c.sim_solve(rtol=1e-8, maxit=500)
+        c.close()
+        return u
+
+    keep = M.Context(0)          # (keeps the arena out of its idle trim between the two runs)
+    u0 = run()
+    s0 = M.device_cache_stats(0)
+    a0 = M.device_arena_stats(0)
+    u1 = run()
+    s1 = M.device_cache_stats(0)
+    a1 = M.device_arena_stats(0)
+    assert s1["misses"] == s0["misses"] and a1["held_bytes"] == a0["held_bytes"]
+    assert np.array_equal(u0, u1) or np.abs(u0 - u1).max() <= 1e-10 * np.abs(u0).max()
+    keep.close()
+
+
+def test_set_stream_with_a_hierarchy():
+    """mfh_set_stream on a context that owns a multigrid hierarchy released the hierarchy's buffers in a scope that waited on the
+    stream it had just destroyed. The hierarchy is dropped before the stream now; the next solve rebuilds it on the new stream."""
+    import torch
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    V, T = grid.grid_tet_mesh(10, 10, 10, [0, 0, 0], [1, 1, 1])
+    c = M.Context(0)
+    c.mesh_build(T, V, 2)
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+    c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    u0 = c.sim_solve(rtol=1e-9, maxit=500)
+    st = torch.cuda.Stream(device=0)
+    c._ck(c.lib.mfh_set_stream(c.h, C.c_void_p(st.cuda_stream)))
+    u1 = c.sim_solve(rtol=1e-9, maxit=500)
+    assert c.last_info["converged"]
+    assert np.abs(u0 - u1).max() <= 1e-7 * np.abs(u0).max()
+    c.assemble()             # an unrelated launch after it: no stale error surfaces
+    c.dev_sync()
+    c.close()

@@ -40,9 +40,6 @@ def _worker(rank, world, port, n, ret):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ.setdefault("MFH_PEER_TIMEOUT_S", "120")
-    # eight processes share this device: the per-process cache of released device blocks (mfh_pool.cpp) would keep 8 x ~20 GB of setup
-    # temporaries next to the 141 GB the contexts hold -- more than the device has
-    os.environ.setdefault("MFH_DEVICE_CACHE_MB", "2048")
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
     rec = dict(rank=rank)

@@ -157,3 +157,79 @@ def test_a_missing_rank_times_out_instead_of_hanging_the_device():
     mp.spawn(_worker_timeout, args=(2, _free_port(), ret), nprocs=2, join=True)
     assert ret["status"] == L.ERR_HIP and "waited more than" in ret["message"], dict(ret)
     assert ret["alive"] == 4.0
+
+
+def _worker_fault(rank, world, port, ret):
+    """bench.py's chain on two ranks: the solves on the transport underneath, then the peer transfers -- with rank 1 opening a handle whose
+    bytes were overwritten (MFH_PEER_FAULT_RANK). Every rank must back out of the peer transfers, stay on the transport underneath, and
+    solve to the same u as before; the preflight record says which slabs were mapped when the peer path does work."""
+    import torch
+    import torch.distributed as dist
+    import meshfem_amd as M
+    from meshfem_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MFH_PEER_TIMEOUT_S", "10")
+    torch.cuda.set_device(0)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    try:
+        n, deg = 6, 2
+        lm = D.slab_local_mesh(n, rank, world, deg)
+        c = M.Context(0)
+        c.mesh_set(3, deg, lm.elem_nodes, lm.node_pos, lm.n_owned)
+        c.material_isotropic(200.0, 0.35)
+        c.set_option("deterministic", 1)       # run-to-run identical bits: "the same u" can then be checked with array_equal
+        dev = torch.device("cuda", 0)
+        comm, group, tried = D.robust_comm(c, rank, world, dev)
+        pf0 = comm.preflight(world, 1 << 20)
+        solver = D.DistSolver(c, lm, rank, world, comm, group)
+        all_fixed = np.flatnonzero(lm.lattice[:, 0] == 0)
+        c.fix_variables((3 * all_fixed[:, None] + np.arange(3)[None, :]).ravel())
+        f = D.slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel()
+        c.set_preconditioner(M.PRECOND_MULTIGRID)
+        u0, i0 = solver.solve(f, rtol=1e-10, maxit=2000)
+        # the peer leg with the fault: unavailable on EVERY rank, nobody left waiting
+        os.environ["MFH_PEER_FAULT_RANK"] = "1"
+        ok, outcome = D.try_enable_peer(comm, rank, world, dev, group)
+        del os.environ["MFH_PEER_FAULT_RANK"]
+        solver = D.DistSolver(c, lm, rank, world, comm, group)
+        u1, i1 = solver.solve(f, rtol=1e-10, maxit=2000)
+        st1 = c.dist_stats()
+        # ... and without the fault the same chain lands on the peer transfers
+        ok2, outcome2 = D.try_enable_peer(comm, rank, world, dev, group)
+        pf2 = comm.preflight(world, 1 << 20) if ok2 else None
+        solver = D.DistSolver(c, lm, rank, world, comm, group)
+        u2, i2 = solver.solve(f, rtol=1e-10, maxit=2000)
+        st2 = c.dist_stats()
+        ret[rank] = dict(tried=tried, pf0=pf0, pf2=pf2, fault=(ok, outcome), clean=(ok2, outcome2), it=(i0[0]["iterations"], i1[0]["iterations"], i2[0]["iterations"]),
+                         same_u_after_fault=bool(np.array_equal(u0[0], u1[0])), err_peer=float(np.linalg.norm(u2[0] - u0[0]) / np.linalg.norm(u0[0])),
+                         transport_after_fault=st1["transport"], peer_after_fault=st1["peer_enabled"], transport_clean=st2["transport"])
+        if ok2:
+            comm.disable_peer()
+        comm.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_a_failing_ipc_handle_lands_on_the_next_transport_with_identical_u():
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_fault, args=(2, _free_port(), ret), nprocs=2, join=True)
+    assert set(ret.keys()) == {0, 1}
+    for r in (0, 1):
+        rec = ret[r]
+        assert rec["fault"][0] is False and "unavailable" in rec["fault"][1], rec["fault"]
+        assert rec["same_u_after_fault"] and rec["it"][0] == rec["it"][1]          # same transport, same bits
+        assert rec["transport_after_fault"] == 3 and rec["peer_after_fault"] == 0  # callbacks (the ranks share one device: gloo)
+        assert rec["clean"][0] is True and rec["transport_clean"] == 2
+        assert rec["err_peer"] <= 1e-12 and rec["it"][2] == rec["it"][0]
+        pf0, pf2 = rec["pf0"], rec["pf2"]
+        assert pf0["allreduce_of_ones"] == 2.0 and pf0["ring_GBs_transport_underneath"] > 0 and pf0["peer_transfers_enabled"] is False
+        assert pf0["can_access_peer"] == ["same device", "same device"]
+        assert pf2["peer_transfers_enabled"] and pf2["ipc_slab_mapped"] == [True, True] and pf2["ring_GBs_peer_transfers"] > 0
+        assert pf2["device_free_GB"] > 0 and pf2["arena_held_GB"] >= pf2["arena_live_GB"] > 0
