@@ -53,7 +53,10 @@ def measure(label, perm):
     f = c.neumann_load().ravel() if perm is None else None
     if deg == 2 or True:
         c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
-        c.sim_solve(rtol=1e-2, maxit=50)
+        try:
+            c.sim_solve(rtol=1e-30, maxit=20)
+        except M.MeshFEMHipError:
+            pass
         rec["operator_ms"] = [c.time_spmv_kernel(50) for _ in range(3)]
         try:
             rec["matrix_free"] = c.matrix_free_info()
