@@ -2105,6 +2105,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "mg_ratio_agg") { require(value > 0 && value < 1, MFH_ERR_INVALID, "mg_ratio_agg must lie in (0, 1)"); c->mgRatioAgg = value; }
     else if (k2 == "mg_anisotropic_bins") { c->mgAnisotropicBins = value != 0; c->mg.valid = false; }
     else if (k2 == "mg_agg_nodes") { c->mgAggNodes = std::max(0, (int)value); c->mg.valid = false; }
+    else if (k2 == "mg_replicate_max") { c->mgReplicateMax = std::max(0, (int)value); c->mg.valid = false; }
     else if (k2 == "asm_packed_codes") { c->asmPackedCodes = value != 0; invalidate_symbolic(c); }
     else if (k2 == "chunk_slots") { c->chunkSlots = (int)value; invalidate_symbolic(c); }
     else if (k2 == "contrib_order") { c->contribOrder = (int)value; invalidate_symbolic(c); }

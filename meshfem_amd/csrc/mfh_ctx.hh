@@ -166,6 +166,20 @@ struct mfh_ctx {
         std::vector<double> hCentre;
         int nb[3] = {1, 1, 1};               // bins per axis
         int wrap[3] = {0, 0, 0};             // nb of the axes along which the lattice is periodic (periodic DoF maps), else 0
+        std::vector<int32_t> hNbr, hParent;  // host copies of nbr / parent (global numbering): the partition of the level is derived from them
+        // Row-partitioned contexts: the levels with more than mg_replicate_max aggregates are PARTITIONED (mfh_multigrid.cpp,
+        // localize_aggregate_levels): this rank keeps the stencil rows of the aggregates it owns and numbers its aggregates locally --
+        // owned ones first (ascending global id), then the halo (aggregates of other ranks that its rows, its DoFs or its children refer
+        // to), grouped by owner rank. nbr / parent / childIdx / the vectors are in that numbering; nAgg stays the GLOBAL count.
+        bool part = false;
+        int64_t nOwn = 0, nLoc = 0;
+        std::vector<int32_t> hOwner, hGlobalOf, hLocalOf;   // [nAgg] owner rank (-1: empty bin), [nLoc] global id, [nAgg] local id or -1
+        std::vector<int32_t> xPeers;                         // exchange lists of the level (the vocabulary of mfh_dist_setup)
+        std::vector<int64_t> xSendPtr{0}, xRecvPtr{0};
+        DBuf<int32_t> xSendIdx;
+        DBuf<double> xSendBuf, xRecvBuf;
+        int64_t rows() const { return part ? nOwn : nAgg; }      // rows this rank smooths
+        int64_t size() const { return part ? nLoc : nAgg; }      // entries of its vectors
     };
     struct Multigrid {
         bool valid = false, rigidCoarse = false;
@@ -198,6 +212,9 @@ struct mfh_ctx {
     double mgOverCorrection = 1.5;                   // option "mg_over_correction": factor on the corrections prolonged from aggregate levels (piecewise-rigid
                                                      // coarse functions under-estimate smooth corrections; the cycle stays symmetric)
     int mgStepsAgg = 2; double mgRatioAgg = 0.2;     // options "mg_steps_agg" / "mg_ratio_agg": Chebyshev smoother of the aggregate levels
+    int mgReplicateMax = 4096;                       // option "mg_replicate_max": row-partitioned contexts partition the aggregate levels with MORE aggregates than this
+                                                     // (stencil rows dealt out with the DoFs, one halo exchange per application); smaller levels are replicated on
+                                                     // every rank and summed with one small all-reduce. 0: every level replicated (rounds 3-4)
     bool mgAnisotropicBins = false;                  // option "mg_anisotropic_bins": lattice bins of the aggregate levels with the elements' proportions (measured: no gain)
     int mgAggNodes = 0;                              // option "mg_agg_nodes": target DoFs per aggregate of the linear level's coarse space (0 = auto)
     // Chronopoulos-Gear PCG (mfh_solver.cpp): NR interleaved vectors
@@ -371,6 +388,9 @@ int dist_world(const mfh_ctx *c);
 void dist_apply(mfh_ctx *c, double *x, double *y, bool masked);
 void dist_halo(mfh_ctx *c, double *v, int W);
 void dist_allreduce(mfh_ctx *c, double *dev, int64_t n);
+void dist_level_forward(mfh_ctx *c, mfh_ctx::AggLevel &A, double *v, int W);        // owned entries -> the halo copies on the other ranks
+void dist_level_reverse_add(mfh_ctx *c, mfh_ctx::AggLevel &A, double *v, int W);    // halo partial sums -> their owners, added there
+void dist_exchange_lists(mfh_ctx *c, const std::vector<std::vector<int32_t>> &toRank, std::vector<std::vector<int32_t>> &fromRank);   // setup: variable-length lists, all to all
 void dist_setup_child(mfh_ctx *c, mfh_ctx *child, const std::vector<int32_t> &keep);
 void dist_agree(mfh_ctx *c);
 void dist_profile_collect(mfh_ctx *c);

@@ -96,6 +96,7 @@ struct DBuf {
         p = (T *)device_alloc(count * sizeof(T));
         n = count;
     }
+    void swap(DBuf &o) { std::swap(p, o.p); std::swap(n, o.n); }
     // grow-only: work vectors whose size alternates between calls (batch widths 2, 1, 2, ...) are not reallocated every time
     void reserve(size_t count) {
         if (count > n || !p) alloc(count);
@@ -585,6 +586,9 @@ void launch_mg_diff(int64_t n, const double *a, const double *b, double *out, co
 void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, double *scalOut, int it, const double *scal, const double *stop, hipStream_t s);
 void launch_add_scalar(double *p, double v, hipStream_t s);   // *p += v
 void launch_pack_rows(int64_t n, int W, const int32_t *idx, const double *src, double *dst, hipStream_t s);
+void launch_unpack_add_rows(int64_t n, int W, const int32_t *idx, const double *src, double *dst, hipStream_t s);   // dst[idx[j]][:] += src[j][:]
+void launch_pack_rows_f32(int64_t n, int W, const int32_t *idx, const float *src, float *dst, hipStream_t s);
+void launch_remap_i32(int64_t n, const int32_t *map, int32_t *v, hipStream_t s);                                  // v[k] = map[v[k]] where v[k] >= 0
 void launch_interleave(int64_t nRows, int NR, int dim, const double *src, double *dst, bool toInterleaved, int64_t sepStride, hipStream_t s);
 void launch_norms_nr(int64_t nRows, int NR, int dim, const double *v, double *out, hipStream_t s);
 void launch_mask_nr(int64_t nRows, int NR, int dim, const uint8_t *mask, double *v, hipStream_t s);

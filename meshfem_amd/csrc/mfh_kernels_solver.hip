@@ -1237,6 +1237,31 @@ __global__ void __launch_bounds__(256) k_pack_rows(int64_t n, int W, const int32
         dst[k] = src[(int64_t)idx[j] * W + (k - j * W)];
     }
 }
+// the reverse of a halo exchange: dst[idx[j]][:] += src[j][:] (the entries of one peer's list are distinct rows; the peers are added one after
+// the other, in peer order: the same sum on every run)
+__global__ void __launch_bounds__(256) k_unpack_add_rows(int64_t n, int W, const int32_t *__restrict__ idx, const double *__restrict__ src,
+                                                         double *__restrict__ dst) {
+    const int64_t total = n * W;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        const int64_t j = k / W;
+        dst[(int64_t)idx[j] * W + (k - j * W)] += src[k];
+    }
+}
+__global__ void __launch_bounds__(256) k_pack_rows_f32(int64_t n, int W, const int32_t *__restrict__ idx, const float *__restrict__ src,
+                                                       float *__restrict__ dst) {
+    const int64_t total = n * W;
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (int64_t)gridDim.x * 256) {
+        const int64_t j = k / W;
+        dst[k] = src[(int64_t)idx[j] * W + (k - j * W)];
+    }
+}
+// v[k] = map[v[k]] (negative entries stay)
+__global__ void __launch_bounds__(256) k_remap_i32(int64_t n, const int32_t *__restrict__ map, int32_t *__restrict__ v) {
+    for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < n; k += (int64_t)gridDim.x * 256) {
+        const int32_t a = v[k];
+        v[k] = a >= 0 ? map[a] : a;
+    }
+}
 // [k][row][d] (separate vectors, the ABI's layout) <-> [row][k][d] (interleaved, the solver's layout)
 __global__ void __launch_bounds__(256) k_interleave(int64_t nRows, int NR, int DIM, const double *__restrict__ src, double *__restrict__ dst,
                                                     int toInterleaved, int64_t srcStride) {
@@ -1973,6 +1998,21 @@ void launch_tl_apply_nr(const TLArgs &t, int NR, const double *dinv, const doubl
 void launch_pack_rows(int64_t n, int W, const int32_t *idx, const double *src, double *dst, hipStream_t s) {
     if (!n) return;
     hipLaunchKernelGGL(k_pack_rows, dim3(grid_for(n * W)), dim3(256), 0, s, n, W, idx, src, dst);
+    CHECK_LAUNCH();
+}
+void launch_unpack_add_rows(int64_t n, int W, const int32_t *idx, const double *src, double *dst, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_unpack_add_rows, dim3(grid_for(n * W)), dim3(256), 0, s, n, W, idx, src, dst);
+    CHECK_LAUNCH();
+}
+void launch_pack_rows_f32(int64_t n, int W, const int32_t *idx, const float *src, float *dst, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_pack_rows_f32, dim3(grid_for(n * W)), dim3(256), 0, s, n, W, idx, src, dst);
+    CHECK_LAUNCH();
+}
+void launch_remap_i32(int64_t n, const int32_t *map, int32_t *v, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_remap_i32, dim3(grid_for(n)), dim3(256), 0, s, n, map, v);
     CHECK_LAUNCH();
 }
 void launch_interleave(int64_t nRows, int NR, int dim, const double *src, double *dst, bool toInterleaved, int64_t sepStride, hipStream_t s) {

@@ -341,6 +341,100 @@ void dist_allreduce(mfh_ctx *c, double *dev, int64_t n) {
     DistLink L(c);
     L.allreduce(dev, n);
 }
+// ---- exchanges of a PARTITIONED aggregate level of the multigrid hierarchy (mfh_multigrid.cpp, localize_aggregate_levels). Same plumbing as
+// the nodal halo exchange: pack on the compute stream, transfer on the communication stream, the compute stream waits for it.
+void dist_level_forward(mfh_ctx *c, mfh_ctx::AggLevel &A, double *v, int W) {
+    DistLink L(c);
+    if (!L.active || A.xPeers.empty()) return;
+    auto &D = c->dist;
+    const int np = (int)A.xPeers.size();
+    const int64_t nSend = A.xSendPtr.back();
+    A.xSendBuf.reserve((size_t)std::max<int64_t>(1, nSend) * W);
+    k::launch_pack_rows(nSend, W, A.xSendIdx.p, v, A.xSendBuf.p, L.s);
+    MFH_HIP(hipEventRecord(D.ev[0], L.s));
+    MFH_HIP(hipStreamWaitEvent(L.cs, D.ev[0], 0));
+    std::vector<const double *> sb((size_t)np);
+    std::vector<double *> rb((size_t)np);
+    std::vector<int64_t> sc((size_t)np), rc((size_t)np);
+    for (int k = 0; k < np; ++k) {
+        sb[k] = A.xSendBuf.p + A.xSendPtr[k] * W;
+        sc[k] = (A.xSendPtr[k + 1] - A.xSendPtr[k]) * W;
+        rb[k] = v + (A.nOwn + A.xRecvPtr[k]) * W;
+        rc[k] = (A.xRecvPtr[k + 1] - A.xRecvPtr[k]) * W;
+    }
+    comm_exchange(L.cm, np, A.xPeers.data(), sb.data(), sc.data(), rb.data(), rc.data(), L.cs);
+    MFH_HIP(hipEventRecord(D.ev[1], L.cs));
+    MFH_HIP(hipStreamWaitEvent(L.s, D.ev[1], 0));
+}
+void dist_level_reverse_add(mfh_ctx *c, mfh_ctx::AggLevel &A, double *v, int W) {
+    DistLink L(c);
+    if (!L.active || A.xPeers.empty()) return;
+    auto &D = c->dist;
+    const int np = (int)A.xPeers.size();
+    const int64_t nSend = A.xSendPtr.back();
+    A.xRecvBuf.reserve((size_t)std::max<int64_t>(1, nSend) * W);
+    MFH_HIP(hipEventRecord(D.ev[0], L.s));
+    MFH_HIP(hipStreamWaitEvent(L.cs, D.ev[0], 0));
+    std::vector<const double *> sb((size_t)np);
+    std::vector<double *> rb((size_t)np);
+    std::vector<int64_t> sc((size_t)np), rc((size_t)np);
+    for (int k = 0; k < np; ++k) {           // the halo entries of peer k lie together: sent where they are
+        sb[k] = v + (A.nOwn + A.xRecvPtr[k]) * W;
+        sc[k] = (A.xRecvPtr[k + 1] - A.xRecvPtr[k]) * W;
+        rb[k] = A.xRecvBuf.p + A.xSendPtr[k] * W;
+        rc[k] = (A.xSendPtr[k + 1] - A.xSendPtr[k]) * W;
+    }
+    comm_exchange(L.cm, np, A.xPeers.data(), sb.data(), sc.data(), rb.data(), rc.data(), L.cs);
+    MFH_HIP(hipEventRecord(D.ev[1], L.cs));
+    MFH_HIP(hipStreamWaitEvent(L.s, D.ev[1], 0));
+    for (int k = 0; k < np; ++k)             // one peer after the other: an owned aggregate may be on several lists
+        k::launch_unpack_add_rows(A.xSendPtr[k + 1] - A.xSendPtr[k], W, A.xSendIdx.p + A.xSendPtr[k], A.xRecvBuf.p + A.xSendPtr[k] * W, v, L.s);
+}
+// Setup helper: rank r hands every rank q the list toRank[q] and gets fromRank[q] back (lengths agreed through an all-reduce of the
+// world x world count matrix, the lists travel as doubles through the communicator's exchange). Blocking.
+void dist_exchange_lists(mfh_ctx *c, const std::vector<std::vector<int32_t>> &toRank, std::vector<std::vector<int32_t>> &fromRank) {
+    DistLink L(c);
+    const int world = dist_world(c), me = dist_rank(c);
+    fromRank.assign((size_t)world, {});
+    if (!L.active) return;
+    hipStream_t s = L.s;
+    std::vector<double> cnt((size_t)world * world, 0.0);
+    for (int q = 0; q < world; ++q) cnt[(size_t)me * world + q] = (double)toRank[(size_t)q].size();
+    DBuf<double> dCnt;
+    dCnt.upload(cnt, s);
+    L.allreduce(dCnt.p, (int64_t)cnt.size());
+    dCnt.download(cnt.data(), cnt.size(), s);
+    std::vector<int32_t> peers;
+    std::vector<int64_t> sPtr{0}, rPtr{0};
+    std::vector<double> hs;
+    for (int q = 0; q < world; ++q) {
+        if (q == me) continue;
+        const int64_t ns = (int64_t)toRank[(size_t)q].size(), nr = (int64_t)cnt[(size_t)q * world + me];
+        if (ns == 0 && nr == 0) continue;
+        peers.push_back(q);
+        for (int32_t v : toRank[(size_t)q]) hs.push_back((double)v);
+        sPtr.push_back(sPtr.back() + ns);
+        rPtr.push_back(rPtr.back() + nr);
+    }
+    if (peers.empty()) return;
+    DBuf<double> dS, dR;
+    dS.upload(hs.empty() ? std::vector<double>{0.0} : hs, s);
+    dR.alloc((size_t)std::max<int64_t>(1, rPtr.back()));
+    const int np = (int)peers.size();
+    std::vector<const double *> sb((size_t)np);
+    std::vector<double *> rb((size_t)np);
+    std::vector<int64_t> sc((size_t)np), rc((size_t)np);
+    for (int k = 0; k < np; ++k) { sb[k] = dS.p + sPtr[k]; sc[k] = sPtr[k + 1] - sPtr[k]; rb[k] = dR.p + rPtr[k]; rc[k] = rPtr[k + 1] - rPtr[k]; }
+    MFH_HIP(hipStreamSynchronize(s));
+    base_exchange(L.cm, np, peers.data(), sb.data(), sc.data(), rb.data(), rc.data(), s);      // (setup: the transport underneath, whatever the peer transfers are sized for)
+    std::vector<double> hr((size_t)std::max<int64_t>(1, rPtr.back()));
+    dR.download(hr.data(), hr.size(), s);
+    for (int k = 0; k < np; ++k) {
+        auto &dst = fromRank[(size_t)peers[k]];
+        dst.resize((size_t)(rPtr[k + 1] - rPtr[k]));
+        for (int64_t i = rPtr[k]; i < rPtr[k + 1]; ++i) dst[(size_t)(i - rPtr[k])] = (int32_t)hr[(size_t)i];
+    }
+}
 // a second context on the same communicator whose nodes are a subset of c's (the linear level of the multigrid hierarchy): its
 // exchange lists are c's, filtered. keep[n] >= 0: the node's id in the child (children numbered in c's node order).
 void dist_setup_child(mfh_ctx *c, mfh_ctx *child, const std::vector<int32_t> &keep) {

@@ -238,3 +238,68 @@ def test_partitioned_multigrid_in_two_dimensions(deg):
         seen += len(d["keys"])
     assert seen == len(pos)
     assert ret[0]["it_mg"] == ret[1]["it_mg"] and ret[0]["it_mg"] <= 1.3 * it_single + 4 and ret[0]["it_mg"] < 0.3 * ret[0]["it_bj"], (dict(ret[0]), it_single)
+
+
+def _worker_partitioned_levels(rank, world, port, n, deg, ret):
+    """The same solve with the aggregate levels replicated on every rank (mg_replicate_max 0: rounds 3-4) and PARTITIONED (every level
+    with more than 10 aggregates; several of them, forced by a small dense level): the V-cycle is the same operator, only the sums of the
+    shared aggregates are formed in another order -- same iteration count, u to rounding."""
+    import torch
+    import torch.distributed as dist
+    import meshfem_amd as M
+    from meshfem_amd import distributed as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MFH_PEER_TIMEOUT_S", "20")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lm = D.slab_local_mesh(n, rank, world, deg)
+        c = M.Context(0)
+        c.mesh_set(3, deg, lm.elem_nodes, lm.node_pos, lm.n_owned)
+        c.material_isotropic(200.0, 0.35)
+        comm = D.make_comm(c, rank, world)
+        solver = D.DistSolver(c, lm, rank, world, comm)
+        all_fixed = np.flatnonzero(lm.lattice[:, 0] == 0)
+        c.fix_variables((3 * all_fixed[:, None] + np.arange(3)[None, :]).ravel())
+        f = D.slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel()
+        c.set_option("mg_dense_max", 5)
+        out = {}
+        for name, rmax in (("replicated", 0), ("partitioned", 10)):
+            c.set_option("mg_replicate_max", rmax)
+            c.set_preconditioner(M.PRECOND_MULTIGRID)
+            u, i = solver.solve(f, rtol=1e-10, maxit=2000)
+            out[name] = (u[0].copy(), i[0]["iterations"], bool(i[0]["converged"]), i[0]["true_rel_residual"], c.precond_info())
+        # ... and through the peer transfers (the level exchanges ride on the same lists): the same again
+        comm.enable_peer()
+        solver = D.DistSolver(c, lm, rank, world, comm)
+        c.set_preconditioner(M.PRECOND_MULTIGRID)
+        u, i = solver.solve(f, rtol=1e-10, maxit=2000)
+        st = c.dist_stats()
+        out["partitioned_peer"] = (u[0].copy(), i[0]["iterations"], bool(i[0]["converged"]), i[0]["true_rel_residual"], c.precond_info())
+        comm.disable_peer()
+        ur = out["replicated"][0]
+        ret[rank] = {k: dict(it=v[1], conv=v[2], res=v[3], err=float(np.linalg.norm(v[0] - ur) / np.linalg.norm(ur)), aggregates=v[4]["aggregates"]) for k, v in out.items()}
+        ret[rank]["peer_stats"] = dict(transport=st["transport"], fallback_exchanges=st["fallback_exchanges"], fallback_allreduces=st["fallback_allreduces"])
+        comm.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,n,deg", [(2, 8, 2), (3, 6, 2), (2, 12, 1)])
+def test_partitioned_aggregate_levels_equal_the_replicated_ones(world, n, deg):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_partitioned_levels, args=(world, _free_port(), n, deg, ret), nprocs=world, join=True)
+    assert set(ret.keys()) == set(range(world))
+    for r in range(world):
+        d = ret[r]
+        for k in ("replicated", "partitioned", "partitioned_peer"):
+            assert d[k]["conv"] and d[k]["res"] < 2e-10, (r, k, d[k])
+            assert d[k]["it"] == ret[0]["replicated"]["it"], (r, k, d[k]["it"], ret[0]["replicated"]["it"])
+            assert d[k]["err"] <= 1e-9, (r, k, d[k]["err"])
+        assert d["peer_stats"]["transport"] == 2 and d["peer_stats"]["fallback_exchanges"] == 0, d["peer_stats"]
