@@ -19,6 +19,12 @@ mfh_status mfh_time_spmv_kernel(mfh_ctx* ctx, int32_t reps, double* avg_ms);
 mfh_status mfh_matrix_free_info(mfh_ctx* ctx, int32_t* active, int32_t* mode, int64_t* nBlocks, int64_t* nBlockRows,
                                 int64_t* nInterface, int32_t* maxBlockRows);
 
+/* the aggregate levels of the multigrid hierarchy (MFH_PRECOND_MULTIGRID), finest first: out7[l] = {aggregates of the level, rows this rank
+ * smooths, entries of its vectors (rows + halo), 1 if the level is partitioned over the ranks (row-partitioned contexts: levels with more
+ * than option mg_replicate_max aggregates) else 0 (replicated / unpartitioned context), exchange peers, halo aggregates received and owned
+ * aggregates sent per exchange}; *nLevels = levels of the hierarchy (cap = rows of out7) */
+mfh_status mfh_multigrid_level_info(const mfh_ctx* ctx, int32_t cap, int64_t* out7, int32_t* nLevels);
+
 /* ---------------------------------------------------------------- test hooks */
 /* test hook: in-place inverse of a dense SPD matrix (row-major n x n) with the threaded blocked
  * Cholesky that inverts the two-level preconditioner's coarse operator; MFH_ERR_INVALID if not SPD */

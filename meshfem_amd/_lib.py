@@ -93,6 +93,7 @@ PROTOTYPES = {
     "mfh_set_preconditioner": (_i32, [_P, _i32]),
     "mfh_precond_info": (_i32, [_P, _pi32, _pi64, C.POINTER(_f64), C.POINTER(C.c_char_p)]),
     "mfh_multigrid_info": (_i32, [_P, _pi64, _pi64, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64)]),
+    "mfh_multigrid_level_info": (_i32, [_P, _i32, _pi64, _pi32]),
     "mfh_solve": (_i32, [_P, _i32, _P, _P, _f64, _i32, C.POINTER(SolveInfo)]),
     "mfh_solve_batch": (_i32, [_P, _i32, _P, _P, _f64, _i32, C.POINTER(SolveInfo)]),
     "mfh_apply_K": (_i32, [_P, _P, _P]),

@@ -308,6 +308,14 @@ class Context:
         self._ck(self.lib.mfh_multigrid_info(self.h, C.byref(a), C.byref(b), C.byref(l0), C.byref(l1), C.byref(t)))
         return dict(fine_dof=a.value, coarse_dof=b.value, lambda_max_fine=l0.value, lambda_max_coarse=l1.value, setup_ms=t.value)
 
+    def multigrid_levels(self):
+        """Aggregate levels of the multigrid hierarchy, finest first (mfh_multigrid_level_info)."""
+        out = (C.c_int64 * (7 * 16))()
+        n = C.c_int32()
+        self._ck(self.lib.mfh_multigrid_level_info(self.h, 16, out, C.byref(n)))
+        keys = ("aggregates", "rows", "entries", "partitioned", "peers", "halo_received", "owned_sent")
+        return [dict(zip(keys, [int(out[7 * l + k]) for k in range(7)])) for l in range(min(n.value, 16))]
+
     def solve(self, f, rtol=1e-8, maxit=100000):
         f = as_f64(f)
         n = self.bs * self.n_dof

@@ -1771,6 +1771,21 @@ mfh_status mfh_multigrid_info(const mfh_ctx *c, int64_t *fineDoF, int64_t *coars
     return MFH_OK;
 }
 
+// the aggregate levels of the hierarchy: per level {aggregates (global), rows this rank smooths, entries of its vectors, 1 = partitioned,
+// exchange peers, halo aggregates received per exchange, owned aggregates sent per exchange}
+mfh_status mfh_multigrid_level_info(const mfh_ctx *c, int32_t cap, int64_t *out7, int32_t *nLevels) {
+    if (!c || !nLevels) return MFH_ERR_INVALID;
+    const auto &agg = c->mg.agg;
+    *nLevels = c->mg.valid ? (int32_t)agg.size() : 0;
+    for (int32_t l = 0; l < *nLevels && l < cap && out7; ++l) {
+        const auto &L = *agg[(size_t)l];
+        int64_t *o = out7 + (size_t)l * 7;
+        o[0] = L.nAgg; o[1] = L.rows(); o[2] = L.size(); o[3] = L.part ? 1 : 0; o[4] = (int64_t)L.xPeers.size();
+        o[5] = L.part ? L.xRecvPtr.back() : 0; o[6] = L.part ? L.xSendPtr.back() : 0;
+    }
+    return MFH_OK;
+}
+
 mfh_status mfh_solve(mfh_ctx *c, int32_t nrhs, const double *f, double *u, double rtol, int32_t maxit, mfh_solve_info *info) {
     MFH_TRY(c)
     require(c && (c->haveMesh || c->external) && f && u && nrhs > 0 && maxit > 0 && rtol > 0, MFH_ERR_INVALID, "bad solve arguments");

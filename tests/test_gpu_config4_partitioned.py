@@ -98,6 +98,7 @@ def _worker(rank, world, port, n, ret):
         run("multigrid", 300)
         rec["multigrid"]["hierarchy_setup_ms"] = c.multigrid_info()["setup_ms"]
         rec["multigrid"]["aggregates"] = c.precond_info()["aggregates"]
+        rec["multigrid"]["levels"] = c.multigrid_levels()
         tl = solver.two_level(min(1000 * world, 2048))
         rec["two_level_setup"] = tl
         run("two_level", 5000)
@@ -183,7 +184,7 @@ def test_config4_row_partitioned_over_8_ranks_matches_the_single_context_solve()
     record["summary"] = summary
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, "r04_config4_partitioned_8ranks.json"), "w") as fh:
+    with open(os.path.join(out_dir, "r05_config4_partitioned_8ranks.json"), "w") as fh:
         json.dump(record, fh, indent=1, default=float)
     # ---- the bars
     assert sum(r["owned_nodes"] for r in recs) == n_nodes == 57635985            # every node owned exactly once

@@ -265,12 +265,13 @@ def _worker_partitioned_levels(rank, world, port, n, deg, ret):
         c.fix_variables((3 * all_fixed[:, None] + np.arange(3)[None, :]).ravel())
         f = D.slab_traction_load(lm, n, [0.0, -1.0, 0.0]).ravel()
         c.set_option("mg_dense_max", 5)
-        out = {}
+        out, levels = {}, {}
         for name, rmax in (("replicated", 0), ("partitioned", 10)):
             c.set_option("mg_replicate_max", rmax)
             c.set_preconditioner(M.PRECOND_MULTIGRID)
             u, i = solver.solve(f, rtol=1e-10, maxit=2000)
             out[name] = (u[0].copy(), i[0]["iterations"], bool(i[0]["converged"]), i[0]["true_rel_residual"], c.precond_info())
+            levels[name] = c.multigrid_levels()
         # ... and through the peer transfers (the level exchanges ride on the same lists): the same again
         comm.enable_peer()
         solver = D.DistSolver(c, lm, rank, world, comm)
@@ -280,8 +281,10 @@ def _worker_partitioned_levels(rank, world, port, n, deg, ret):
         out["partitioned_peer"] = (u[0].copy(), i[0]["iterations"], bool(i[0]["converged"]), i[0]["true_rel_residual"], c.precond_info())
         comm.disable_peer()
         ur = out["replicated"][0]
-        ret[rank] = {k: dict(it=v[1], conv=v[2], res=v[3], err=float(np.linalg.norm(v[0] - ur) / np.linalg.norm(ur)), aggregates=v[4]["aggregates"]) for k, v in out.items()}
-        ret[rank]["peer_stats"] = dict(transport=st["transport"], fallback_exchanges=st["fallback_exchanges"], fallback_allreduces=st["fallback_allreduces"])
+        rec = {k: dict(it=v[1], conv=v[2], res=v[3], err=float(np.linalg.norm(v[0] - ur) / np.linalg.norm(ur)), aggregates=v[4]["aggregates"]) for k, v in out.items()}
+        rec["levels"] = levels
+        rec["peer_stats"] = dict(transport=st["transport"], fallback_exchanges=st["fallback_exchanges"], fallback_allreduces=st["fallback_allreduces"])
+        ret[rank] = rec
         comm.close()
         c.close()
     finally:
@@ -303,3 +306,15 @@ def test_partitioned_aggregate_levels_equal_the_replicated_ones(world, n, deg):
             assert d[k]["it"] == ret[0]["replicated"]["it"], (r, k, d[k]["it"], ret[0]["replicated"]["it"])
             assert d[k]["err"] <= 1e-9, (r, k, d[k]["err"])
         assert d["peer_stats"]["transport"] == 2 and d["peer_stats"]["fallback_exchanges"] == 0, d["peer_stats"]
+        rep, par = d["levels"]["replicated"], d["levels"]["partitioned"]
+        assert len(rep) == len(par) >= 3 and not any(L["partitioned"] for L in rep)
+        assert [L["aggregates"] for L in rep] == [L["aggregates"] for L in par]
+        for L in par:           # partitioned exactly where the level has more than 10 aggregates, never the dense last one
+            assert L["partitioned"] == (1 if (L["aggregates"] > 10 and L is not par[-1]) else 0), par
+            if L["partitioned"]:
+                assert L["rows"] < L["aggregates"] and L["peers"] >= 1 and L["halo_received"] > 0 and L["entries"] == L["rows"] + L["halo_received"]
+    # every aggregate of a partitioned level is owned by exactly one rank
+    for l, L in enumerate(ret[0]["levels"]["partitioned"]):
+        if L["partitioned"]:
+            assert sum(ret[r]["levels"]["partitioned"][l]["rows"] for r in range(world)) <= L["aggregates"]       # (< : empty bins of the lattice have no owner)
+            assert sum(ret[r]["levels"]["partitioned"][l]["rows"] for r in range(world)) >= 0.5 * L["aggregates"]
