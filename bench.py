@@ -33,8 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
-PMC_PROFILE = "r04_pmc_traffic_n60.json"      # scripts/pmc_collect.py at this round's kernels, both triangles of K stored (k_spmv, k_mf_*)
-PMC_PROFILE_UPPER = "r04_pmc_traffic_n60_upper_storage.json"   # the same with the upper-triangle storage (PMC_UPPER_STORAGE=1): the default of configs[2]
+PMC_PROFILE = "r05_pmc_traffic_n60.json"      # scripts/pmc_collect.py at this round's kernels, both triangles of K stored (k_spmv, k_mf_*)
+PMC_PROFILE_UPPER = "r05_pmc_traffic_n60_upper_storage.json"   # the same with the upper-triangle storage (PMC_UPPER_STORAGE=1): the default of configs[2]
 PMC_KERNEL_KEY = "k_assemble_gather"
 ALG_BYTES = {(3, 2): 7736, (3, 1): 1328, (2, 2): 1368, (2, 1): 0}   # SURVEY.md section 8(d), const material, both triangles
 # SURVEY.md section 8(d), row "upper-only variant, matches reference storage": 40 + 96 + 55 x 4 + 55 x 72 (P2 tet); P2 triangle alike
@@ -706,10 +706,52 @@ def run_leg_subprocess(args, leg, timeout_s=900):
     return dict(error="leg %s: exit code %d, no JSON; stderr tail: %s" % (leg, p.returncode, p.stderr[-400:]))
 
 
+def config2_trace_leg(args, n=60):
+    """configs[2] alone, for a per-workload kernel trace: the timed assembly passes, one multigrid solve to rtol, 300
+    block-Jacobi PCG iterations -- no deterministic launches, no other mesh in the process."""
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    T = np.ascontiguousarray(T, dtype=np.int32)
+    c = M.Context(0)
+    c.mesh_build(T, V, 2)
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+    c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    c.symbolic(False)
+    c.set_option("reembed", 1)
+    for _ in range(args.warmup):
+        c.assemble()
+    c.dev_sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        c.assemble()
+    c.dev_sync()
+    dt = (time.perf_counter() - t0) / args.steps
+    k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
+    res = dict(workload="configs[2]: %d^3 grid -> %d P2 tets" % (n, c.n_elem), elements=int(c.n_elem), ms_per_step=dt * 1e3, value=c.n_elem / dt, kernel_ms=k_ms)
+    if not args.no_solve:
+        c.set_preconditioner(M.PRECOND_MULTIGRID)
+        u = c.sim_solve(rtol=args.rtol, maxit=500)
+        res["pcg_multigrid"] = dict(iterations=c.last_info["iterations"], solve_ms=c.last_info["solve_ms"], hierarchy_setup_ms=c.multigrid_info()["setup_ms"],
+                                    max_abs_u=float(np.abs(u).max()))
+        c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
+        try:
+            c.sim_solve(rtol=1e-30, maxit=300)
+        except M.MeshFEMHipError:
+            pass
+        res["pcg_block_jacobi_300"] = dict(ms_per_iteration=c.last_info["solve_ms"] / 300)
+        res["operator_ms"] = c.time_spmv_kernel(50)
+    c.close()
+    return res
+
+
 def run_leg(args):
     import torch
     torch.cuda.set_device(0)
-    if args.leg == "strong_n1":
+    if args.leg == "config2":
+        res = config2_trace_leg(args)
+    elif args.leg == "strong_n1":
         res = strong_n1(args, torch)
     elif args.leg == "config3":
         res = config3_homogenization(args)
