@@ -262,9 +262,11 @@ def run_single(args):
     strong = args.scaling == "strong"
     # configs[4]'s cube in ONE context as a one-shot caller sees it: a process of its own, run BEFORE this one touches the device
     # (inside a process that had run the other legs the same code took 4.8 s instead of 0.6 s for the first assembly)
-    strong_fresh = None
+    strong_first = None
     if not strong and not args.no_strong_n1 and deg == 2:
-        strong_fresh = run_leg_subprocess(args, "strong_n1")
+        # ... once now, before anything else has used the device (on a box nobody has used since boot the driver clears whatever a process
+        # takes beyond the first ~66 GB at 25-40 GB/s: profiles/r05_large_allocation_trace_119.log), and once at the end of the line
+        strong_first = run_leg_subprocess(args, "strong_n1", extra=["--no-solve"])
     torch.cuda.set_device(0)
     hbm_measured = hbm_stream_probe(torch)
     if strong:      # one 40 M-element context: no room (and no point) for the storage / ordering variants next to it
@@ -310,6 +312,8 @@ def run_single(args):
                 frac_traffic=None if tb is None else tb / k_ms / 1e6 / HBM_PEAK_GBS,
                 compulsory_bytes=comp, frac_compulsory=comp / k_ms / 1e6 / HBM_PEAK_GBS,
                 traffic_bytes_per_launch_from_profile=tb, traffic_from_profile=tsrc, alg_bytes_per_launch=alg, kernel_ms=k_ms,
+                kernel_trace="profiles/r05_config2_kernel_stats.csv: rocprofv3 --kernel-trace --stats of `python bench.py --leg config2` (this workload alone: "
+                             "k_assemble_gather<3, 2, 0, true, false>, no deterministic and no 119^3 launches in the file)",
                 bytes_per_element=bytes_per_element,
                 matrix_storage="upper triangle (blocks (r, c >= r): what the reference assembles)" if upper else "both triangles",
                 note="frac = SURVEY 8(d) algorithmic bytes (the row of the storage in use) / time / 8 TB/s (contract); frac_traffic = "
@@ -320,7 +324,7 @@ def run_single(args):
         roof["measured_triad_GBs"] = hbm_measured["triad_GBs"]
         roof["traffic_frac_of_measured_triad"] = roof["traffic"] / hbm_measured["triad_GBs"]
     out = dict(metric="stiffness_assembly_elements_per_s", value=value, unit="elements/s", n_gpus=1, steps=args.steps,
-               warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, scaling=args.scaling or "weak", vs_baseline=None,
+               warmup=args.warmup, ms_per_step=ms_step, higher_is_better=True, scaling=args.scaling or "strong", vs_baseline=None,
                dtype="f64", data="synthetic",
                config=dict(workload="%s: %d^3 grid -> %d P%d tets, isotropic E=200 nu=0.35, Dirichlet x=0, traction x=1"
                                     % (("configs[4] on one GPU" if n == 119 else "the %d^3 cube of the strong-scaling run on one GPU" % n) + " (the N = 1 point of the strong-scaling curve)"
@@ -574,11 +578,24 @@ def run_single(args):
             c.close()
         except Exception:   # noqa: BLE001 -- already closed by the variants above
             pass
-        out["strong_scaling_n1"] = strong_fresh if strong_fresh is not None else dict(error="leg not run")
-        try:      # the same leg INSIDE this process, after everything above: what the device arena makes of a process that held other meshes before
-            out["strong_scaling_n1"]["warm_process"] = strong_n1(args, torch)
+        try:      # the leg INSIDE this process, after everything above: what the device arena makes of a process that held other meshes before
+            warm = strong_n1(args, torch)
         except Exception as e:   # noqa: BLE001 -- the line above is complete
-            out["strong_scaling_n1"]["warm_process"] = dict(error="%s: %s" % (type(e).__name__, e))
+            warm = dict(error="%s: %s" % (type(e).__name__, e))
+        # ... and in a fresh process on a device that has been in use (the usual state of a production box): everything of this process released first
+        try:
+            M.device_cache_trim()
+            torch.cuda.empty_cache()
+        except Exception:   # noqa: BLE001
+            pass
+        out["strong_scaling_n1"] = run_leg_subprocess(args, "strong_n1")
+        out["strong_scaling_n1"]["warm_process"] = warm
+        if strong_first is not None:
+            out["strong_scaling_n1"]["first_process_of_the_line"] = dict(
+                setup=strong_first.get("setup"), value=strong_first.get("value"), kernel_ms=strong_first.get("kernel_ms"), error=strong_first.get("error"),
+                process=strong_first.get("process"),
+                note="the same leg (assembly only) run BEFORE this process touched the device: on a box that nobody has used since boot the driver clears "
+                     "the memory a process takes beyond the first ~66 GB while it is being allocated (profiles/r05_large_allocation_trace_119.log)")
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_with_solve(args)
     print(json.dumps(out), flush=True)
@@ -617,7 +634,8 @@ def config1_p1(args, n=35):
                              compulsory_bytes=comp, frac_compulsory=comp / k_ms / 1e6 / HBM_PEAK_GBS,
                              note="%.0f MB per launch: the working set is of the order of the 256 MiB memory-side cache; the fractions are against the "
                                   "8 TB/s HBM peak all the same" % (comp / 1e6)),
-               setup=dict(femmesh_build_s=t_build, symbolic_s=t_sym, first_assemble_call_s=t_first, first_assembly_ms=(t_build + t_sym + t_first) * 1e3))
+               setup=dict(femmesh_build_s=t_build, symbolic_s=t_sym, first_assemble_call_s=t_first, first_assembly_ms=(t_build + t_sym + t_first) * 1e3),
+               kernel_trace="profiles/r05_config1_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py --leg config1`)")
     if not args.no_solve:
         sp_ms = c.time_spmv_kernel(20)
         sp_bytes = stored * 76 + nr * 3 * 16 + nr * 4
@@ -685,11 +703,11 @@ def config3_homogenization(args, n=44):
     return res
 
 
-def run_leg_subprocess(args, leg, timeout_s=900):
+def run_leg_subprocess(args, leg, timeout_s=900, extra=()):
     """One leg of the line in a FRESH process (a one-shot caller of that size is one): returns the leg's JSON object."""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--leg", leg, "--steps", str(args.steps), "--warmup", str(args.warmup), "--rtol", str(args.rtol),
-           "--maxit", str(args.maxit), "--deg", str(args.deg)] + (["--no-solve"] if args.no_solve else [])
+           "--maxit", str(args.maxit), "--deg", str(args.deg)] + (["--no-solve"] if (args.no_solve or "--no-solve" in extra) else [])
     t0 = time.time()
     try:
         p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
@@ -796,6 +814,7 @@ def strong_n1(args, torch, n=119):
     k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, 3)
     res = dict(workload="configs[4]: %d^3 grid -> %d P%d tets in ONE context" % (n, nE, deg), elements=nE, dof=3 * c.n_dof,
                value=nE / dt, unit="elements/s", ms_per_step=dt * 1e3, steps=steps, kernel_ms=k_ms,
+               kernel_trace="profiles/r05_strong_n1_kernel_stats.csv + r05_strong_n1_kernel_trace_summary.txt (per launch size: the aggregate levels apart)",
                setup=dict(femmesh_build_s=t_build, symbolic_s=t_sym, first_assemble_call_s=t_first,
                           first_assembly_ms=(t_build + t_sym + t_first) * 1e3, first_assembly_elements_per_s=nE / (t_build + t_sym + t_first)))
     if not args.no_solve:

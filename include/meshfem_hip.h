@@ -393,7 +393,9 @@ mfh_status  mfh_comm_preflight(mfh_ctx* ctx, mfh_comm* comm, int64_t messageByte
  * processes (several may share a device); needs HSA_ENABLE_IPC_MODE_LEGACY=0 on hosts whose driver only supports dmabuf IPC.
  * A rank that waits longer than MFH_PEER_TIMEOUT_S (60) seconds for a neighbour gives up and the solve returns MFH_ERR_HIP: the
  * device is never left spinning. mfh_comm_selftest exercises the path; mfh_comm_disable_peer (collective) returns to the transport
- * underneath. */
+ * underneath. A communicator serves ONE host thread and one collective at a time (like a context): the message numbers and staging
+ * buffers of a pair are shared by everything that runs on it -- two contexts may name the same communicator in mfh_dist_setup, their
+ * solves must not overlap. */
 mfh_status  mfh_comm_enable_peer(mfh_ctx* ctx, mfh_comm* comm);
 mfh_status  mfh_comm_disable_peer(mfh_ctx* ctx, mfh_comm* comm);
 mfh_status  mfh_dist_setup(mfh_ctx* ctx, mfh_comm* comm, int32_t nPeers, const int32_t* peers, const int64_t* sendPtr /* nPeers+1 */,

@@ -127,7 +127,10 @@ __global__ void __launch_bounds__(256) k_peer_allreduce_small(PeerSmallArgs a) {
 size_t ctl_bytes() { return 4096; }
 uint64_t *ctl_word(void *slab, int src, int w) { return reinterpret_cast<uint64_t *>(slab) + (size_t)src * PEER_CTL_WORDS + w; }
 uint64_t *err_word(void *slab) { return reinterpret_cast<uint64_t *>(slab) + (size_t)PEER_MAX_WORLD * PEER_CTL_WORDS; }
-unsigned *counter_word(void *slab) { return reinterpret_cast<unsigned *>(reinterpret_cast<uint64_t *>(slab) + (size_t)PEER_MAX_WORLD * PEER_CTL_WORDS + 1); }
+// workgroup counters of the copy kernels (local words of the control page, zeroed with it): one per launch site -- halo push, halo pull,
+// all-reduce push -- so that collectives of different kinds never count on the same word. Two collectives of the SAME kind on
+// one communicator must still be ordered by the caller: a communicator serves one host thread / one solve at a time (meshfem_hip.h).
+unsigned *counter_word(void *slab, int site = 0) { return reinterpret_cast<unsigned *>(reinterpret_cast<uint64_t *>(slab) + (size_t)PEER_MAX_WORLD * PEER_CTL_WORDS + 1 + site); }
 double *halo_slot(const PeerState &P, void *slab, int parity, int src, int world) {
     return reinterpret_cast<double *>(reinterpret_cast<char *>(slab) + ctl_bytes()) + ((size_t)parity * world + src) * (size_t)P.haloCap;
 }
@@ -317,7 +320,8 @@ void peer_exchange(mfh_comm *cm, int nPeers, const int32_t *peers, const double 
     int64_t outTotal = 0, inTotal = 0;
     push.n = pull.n = nPeers;
     push.nSig = nPeers; pull.nSig = 0;
-    push.counter = pull.counter = counter_word(P.slab);
+    push.counter = counter_word(P.slab, 0);
+    pull.counter = counter_word(P.slab, 1);
     w.n = nPeers; w.err = err_word(P.slab); w.timeoutTicks = timeout_ticks(P, cm->device);
     push.start[0] = pull.start[0] = 0;
     for (int k = 0; k < nPeers; ++k) {
@@ -369,7 +373,7 @@ void peer_allreduce(mfh_comm *cm, double *dev, int64_t n, hipStream_t s) {
     }
     PeerCopyArgs push{};
     PeerWaitArgs w{};
-    push.counter = counter_word(P.slab);
+    push.counter = counter_word(P.slab, 2);
     w.err = err_word(P.slab); w.timeoutTicks = timeout_ticks(P, cm->device);
     push.start[0] = 0;
     int k = 0;

@@ -271,6 +271,73 @@ def test_two_ranks_rcb_unstructured_mesh_matches_golden():
     assert ret[0][3] == ret[1][3]
 
 
+def _worker_scatter(rank, world, port, ret):
+    """scatter_mesh (only rank 0 reads the mesh, every rank numbers its own share) feeding the HIP path: the golden problem of ball.msh, with
+    the golden's global vectors indexed through the node keys (vertex id / edge_node_key of the end vertices)."""
+    import torch
+    import torch.distributed as dist
+    import meshfem_amd as M
+    from meshfem_amd import distributed as D, mesh_io
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+        V = E = None
+        if rank == 0:
+            V, E, _ = mesh_io.load_msh(os.path.join(gold, "meshes", "ball.msh"))
+        lm = D.scatter_mesh(V, E, 2, rank, world)
+        # the test's own reference numbering (global FEM node ids <-> keys)
+        Vg, Eg, _ = mesh_io.load_msh(os.path.join(gold, "meshes", "ball.msh"))
+        h = M.Context(-1)
+        h.mesh_build(Eg, Vg, 2)
+        en_g = h.elem_nodes().astype(np.int64)
+        n_glob = h.n_node
+        h.close()
+        key_g = np.arange(n_glob, dtype=np.int64)
+        for k, (a, b) in enumerate(D._LOCAL_EDGES[3]):
+            key_g[en_g[:, 4 + k]] = D.edge_node_key(en_g[:, a], en_g[:, b], len(Vg))
+        order = np.argsort(key_g)
+        gid = order[np.searchsorted(key_g[order], lm.keys)]
+        g = np.load(os.path.join(gold, "example_meshes.npz"))
+        c = M.Context(0)
+        c.mesh_set(3, 2, lm.elem_nodes, lm.node_pos, lm.n_owned)
+        c.material_isotropic(200.0, 0.35)
+        comm = D.make_comm(c, rank, world)
+        solver = D.DistSolver(c, lm, rank, world, comm)
+        gfixed = np.zeros(3 * n_glob, bool)
+        gfixed[g["ball_p2_fixed_vars"]] = True
+        c.fix_variables(np.flatnonzero(gfixed[(3 * gid[:, None] + np.arange(3)).ravel()]))
+        f = g["ball_p2_load"][gid[:lm.n_owned]].ravel().copy()
+        c.set_preconditioner(M.PRECOND_MULTIGRID)
+        u, infos = solver.solve(f, rtol=1e-11, maxit=5000)
+        u_ref = g["ball_p2_u"]
+        err = np.linalg.norm(u[0].reshape(-1, 3) - u_ref[gid[:lm.n_owned]]) / np.linalg.norm(u_ref)
+        ret[rank] = (err, bool(infos[0]["converged"]), lm.n_owned, infos[0]["iterations"], int(lm.n_local), int(n_glob))
+        comm.close()
+        c.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_scatter_mesh_three_ranks_matches_golden():
+    """ball.msh (P2) scattered from rank 0 over three ranks sharing the GPU, multigrid PCG on the partitioned contexts, against the committed
+    direct solve (north-star tolerance 1e-6 on the displacements)."""
+    import torch.multiprocessing as mp
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_scatter, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert set(ret.keys()) == {0, 1, 2}
+    assert all(ret[r][1] for r in range(world))
+    assert max(ret[r][0] for r in range(world)) < 1e-6, dict(ret)
+    assert sum(ret[r][2] for r in range(world)) == ret[0][5]             # every P2 node owned once
+    assert len({ret[r][3] for r in range(world)}) == 1
+    assert max(ret[r][4] for r in range(world)) < 0.8 * ret[0][5]         # no rank holds the whole mesh
+
+
 def test_rccl_communicator_world_1():
     """The library's RCCL communicator (looked up with dlopen) on this GPU: unique id, ncclCommInitRank, grouped
     ncclSend / ncclRecv to itself and ncclAllReduce with known answers (mfh_comm_selftest), then the distributed entry
