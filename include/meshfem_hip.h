@@ -436,6 +436,13 @@ mfh_status  mfh_dev_memcpy(mfh_ctx* ctx, void* dst, const void* src, int64_t byt
  * rest. A request the driver cannot serve releases every free segment and is repeated. mfh_device_cache_trim returns every free segment to
  * the driver at once. mfh_device_arena_stats: out8 = {bytes held, live bytes, live high-water mark, segments, free chunks, bytes returned
  * to the driver so far, bytes waiting for a device-wide synchronisation, bound on the free bytes}. */
+/* mfh_device_reserve: ONE segment of `bytes` taken from the driver now and kept as free space of the arena -- the reference's "reserve once"
+ * (LinearElasticity.hh:1441-1443) for a caller that knows roughly what its mesh will need (about 3.6 kB per quadratic tet for assembly +
+ * multigrid solve, 0.9 kB per linear tet). Contexts created afterwards cut their buffers from it: no call to the driver during their
+ * setup. With async != 0 the call returns at once and the allocation runs on a thread of its own (e.g. while the caller reads its mesh);
+ * the library's next allocation that finds nothing waits for it. Worth it on a device nobody has used since boot, where the driver
+ * clears the memory a process takes beyond the first ~66 GB while it is being allocated (profiles/r05_large_allocation_trace_119.log). */
+mfh_status mfh_device_reserve(int32_t device, int64_t bytes, int32_t async);
 mfh_status mfh_device_cache_trim(void);
 mfh_status mfh_device_cache_stats(int32_t device, int64_t* cachedBytes, int64_t* blocks, int64_t* hits, int64_t* misses, int64_t* flushes);
 mfh_status mfh_device_arena_stats(int32_t device, int64_t* out8);

@@ -636,6 +636,14 @@ def device_cache_stats(device=0):
     return dict(zip(("cached_bytes", "blocks", "hits", "misses", "flushes"), [x.value for x in v]))
 
 
+def device_reserve(nbytes, device=0, wait=False):
+    """One free segment of `nbytes` for the library's device arena, taken from the driver now (mfh_device_reserve) -- on a thread of its own
+    unless `wait`: call it before reading / generating the mesh."""
+    st = L.load().mfh_device_reserve(int(device), int(nbytes), 0 if wait else 1)
+    if st != L.OK:
+        raise L.MeshFEMHipError(st, "mfh_device_reserve failed")
+
+
 def device_arena_stats(device=0):
     """State of the library's device arena (mfh_device_arena_stats): bytes held / live / live high-water mark, segments, free chunks, ..."""
     lib = L.load()

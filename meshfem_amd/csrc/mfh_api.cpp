@@ -1134,6 +1134,15 @@ mfh_status mfh_device_cache_stats(int32_t device, int64_t *cachedBytes, int64_t 
     mfh::device_cache_stats(device, cachedBytes, blocks, hits, misses, flushes);
     return MFH_OK;
 }
+mfh_status mfh_device_reserve(int32_t device, int64_t bytes, int32_t async) {
+    if (bytes < 0) return MFH_ERR_INVALID;
+    try {
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) { (void)hipGetLastError(); return MFH_ERR_INVALID; }
+        mfh::device_arena_reserve(device, (size_t)bytes, async != 0);
+    } catch (...) { return MFH_ERR_HIP; }
+    return MFH_OK;
+}
 mfh_status mfh_device_arena_stats(int32_t device, int64_t *out8) {
     if (!out8) return MFH_ERR_INVALID;
     mfh::device_arena_stats(device, out8);

@@ -61,6 +61,7 @@ void device_free(void *p);
 void device_cache_trim();
 void device_arena_context_opened(int dev);     // mfh_create / mfh_destroy of a device context: when a context closes the arena is trimmed
 void device_arena_context_closed(int dev);     // to its live high-water mark, when the last one closes to a small reserve
+void device_arena_reserve(int dev, size_t bytes, bool async);   // one free segment of that size from the driver, now (on a thread of its own if async)
 void device_arena_stats(int dev, int64_t out[8]);   // held, live, live high-water mark, segments, free chunks, bytes returned to the driver, quarantined, bound
 // What a release waits for before the block may be handed to somebody else: the streams of the context the calling thread is working for
 // (PoolScope, installed by every API entry), not the whole device -- hipDeviceSynchronize from one host thread invalidates a stream

@@ -20,9 +20,11 @@
 // other allocators of the process (torch, RCCL) then find the memory. mfh_device_cache_trim() gives back every free segment;
 // MFH_DEVICE_CACHE_MB=0 restores plain hipMalloc / hipFree. A request the driver cannot serve releases the free segments and is repeated.
 #include "mfh_internal.hh"
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <set>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -51,11 +53,13 @@ struct Arena {
     size_t held = 0, live = 0, liveHigh = 0, limit = 0, idleLimit = 0, quarantined = 0;
     bool init = false, enabled = true;
     int contexts = 0;
+    int pendingReserve = 0;                               // reservations under way on other threads (device_arena_reserve)
     int64_t hits = 0, misses = 0, flushes = 0, bypassed = 0;
     size_t returnedBytes = 0;
     size_t free_bytes() const { return held - live - quarantined; }
 };
 std::mutex g_mu;
+std::condition_variable g_cv;                            // a reservation has arrived
 std::map<int, Arena> g_arena;                            // one arena per device
 std::unordered_map<void *, int> g_owner;                 // live pointer handed out by device_alloc -> device
 thread_local hipStream_t t_streams[2] = {nullptr, nullptr};
@@ -166,7 +170,7 @@ void *device_alloc(size_t bytes) {
     MFH_HIP(hipGetDevice(&dev));
     const int cls = bytes < SMALL_REQUEST ? 0 : 1;
     bytes = cls == 0 ? (bytes + ALIGN - 1) & ~(ALIGN - 1) : (bytes + SEGMENT_ROUND - 1) & ~(SEGMENT_ROUND - 1);
-    std::lock_guard<std::mutex> lock(g_mu);
+    std::unique_lock<std::mutex> lock(g_mu);
     Arena &A = arena_of(dev);
     if (!A.enabled) {
         void *p = nullptr;
@@ -176,6 +180,12 @@ void *device_alloc(size_t bytes) {
     }
     auto &freeBySize = A.freeBySize[cls];
     auto fit = freeBySize.lower_bound({bytes, nullptr});
+    // a reservation under way on another thread (mfh_device_reserve, asynchronous) may bring what this request needs: wait for it rather
+    // than ask the driver for the same memory a second time
+    while (fit == freeBySize.end() && cls == 1 && A.pendingReserve > 0) {
+        g_cv.wait(lock);
+        fit = freeBySize.lower_bound({bytes, nullptr});
+    }
     if (fit != freeBySize.end()) ++A.hits;
     else {
         // nothing the arena holds fits: one new segment from the driver
@@ -273,14 +283,69 @@ PoolScope::PoolScope(hipStream_t a, hipStream_t b, int mode) {
 }
 PoolScope::~PoolScope() { t_streams[0] = saved[0]; t_streams[1] = saved[1]; t_mode = savedMode; }
 
+// One segment of `bytes` (rounded up to 2 MiB) taken from the driver NOW and put into the arena as free space: what the contexts created
+// afterwards need is then cut from it -- no call to the driver during their setup, and the temporaries of the setup phases merge back
+// into one chunk. The reference's counterpart is the single reserve of its triplet storage (LinearElasticity.hh:1441-1443). Why a caller
+// would ask: on a box whose device nobody has used since boot the driver clears whatever a process takes beyond the first ~66 GB WHILE it
+// is being allocated, at 25-40 GB/s (profiles/r05_large_allocation_trace_119.log) -- 2-3 s inside the first assembly of a 40 M-element
+// mesh. Asynchronous: the call returns at once and the allocation proceeds on a thread of its own, e.g. while the caller reads its mesh;
+// an allocation of the library that finds nothing waits for it. Free space the arena already holds counts: nothing happens if a free
+// chunk of that size exists. The bound on the free bytes is raised to the reservation while contexts are alive.
+void device_arena_reserve(int dev, size_t bytes, bool async) {
+    bytes = (bytes + SEGMENT_ROUND - 1) & ~(SEGMENT_ROUND - 1);
+    if (bytes == 0) return;
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        int cur = 0;
+        const bool haveCur = hipGetDevice(&cur) == hipSuccess;
+        if (!haveCur) (void)hipGetLastError();
+        (void)hipSetDevice(dev);
+        Arena &A = arena_of(dev);            // (reads the device's memory size the first time)
+        if (haveCur) (void)hipSetDevice(cur);
+        if (!A.enabled) return;
+        if (!A.freeBySize[1].empty() && std::prev(A.freeBySize[1].end())->first >= bytes) return;
+        ++A.pendingReserve;
+        A.limit = std::max(A.limit, bytes + A.idleLimit);      // (the reservation itself must not count as "too much free memory" when something else is released)
+    }
+    static std::once_flag once;
+    std::call_once(once, [] {
+        std::atexit([] {                        // a reservation still under way when the process ends is waited for (never abandoned inside the driver)
+            std::unique_lock<std::mutex> lock(g_mu);
+            g_cv.wait(lock, [] { for (auto &kv : g_arena) if (kv.second.pendingReserve > 0) return false; return true; });
+        });
+    });
+    auto work = [dev, bytes]() {
+        void *p = nullptr;
+        const double t0 = now_ms();
+        hipError_t e = hipSetDevice(dev);
+        if (e == hipSuccess) e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+        std::lock_guard<std::mutex> lock(g_mu);
+        Arena &A = g_arena[dev];
+        if (p) {
+            char *seg = (char *)p;
+            A.segments[seg] = Segment{bytes, bytes, 1};
+            A.chunks[seg] = Chunk{bytes, seg, true};
+            A.held += bytes;
+            A.freeBySize[1].insert({bytes, seg});
+        }
+        if (getenv("MFH_POOL_TRACE")) fprintf(stderr, "[arena] reservation of %.1f MB: %s after %.1f ms\n", bytes / 1e6, p ? "arrived" : "FAILED", now_ms() - t0);
+        --A.pendingReserve;
+        g_cv.notify_all();
+    };
+    if (async) std::thread(work).detach();
+    else work();
+}
+
 void device_arena_context_opened(int dev) {
     std::lock_guard<std::mutex> lock(g_mu);
     ++arena_of(dev).contexts;
 }
 
 void device_arena_context_closed(int dev) {
-    std::lock_guard<std::mutex> lock(g_mu);
+    std::unique_lock<std::mutex> lock(g_mu);
     Arena &A = arena_of(dev);
+    g_cv.wait(lock, [&] { return A.pendingReserve == 0; });
     if (A.contexts > 0) --A.contexts;
     if (!A.enabled) return;
     // With no context left on the device only a reserve for the next one stays: the rest is for the process's other allocators (torch,
@@ -292,7 +357,8 @@ void device_arena_context_closed(int dev) {
 }
 
 void device_cache_trim() {
-    std::lock_guard<std::mutex> lock(g_mu);
+    std::unique_lock<std::mutex> lock(g_mu);
+    g_cv.wait(lock, [] { for (auto &kv : g_arena) if (kv.second.pendingReserve > 0) return false; return true; });
     int cur = -1;
     if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
     for (auto &kv : g_arena) {

@@ -153,3 +153,35 @@ def test_set_stream_with_a_hierarchy():
     c.assemble()             # an unrelated launch after it: no stale error surfaces
     c.dev_sync()
     c.close()
+
+
+def test_reservation_arrives_asynchronously_and_serves_the_context():
+    """mfh_device_reserve: one free segment from the driver, on a thread of its own; the context created afterwards is cut from it (no new
+    segment for its large buffers), an allocation that finds nothing waits for a reservation under way instead of asking the driver too."""
+    import time
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    M.device_cache_trim()
+    keep = M.Context(0)
+    s0 = M.device_arena_stats(0)
+    M.device_reserve(6 << 30, 0)                       # asynchronous
+    p = _alloc(keep, 512 * MB)                        # finds nothing -> waits for the reservation, is cut from it
+    s1 = M.device_arena_stats(0)
+    assert s1["held_bytes"] - s0["held_bytes"] == 6 << 30 and s1["segments"] == s0["segments"] + 1
+    _free(keep, p)
+    V, T = grid.grid_tet_mesh(20, 20, 20, [0, 0, 0], [1, 1, 1])
+    c = M.Context(0)
+    c.mesh_build(T, V, 2)
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+    c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    u = c.sim_solve(rtol=1e-8, maxit=500)
+    s2 = M.device_arena_stats(0)
+    # the large buffers of the whole context (192 000 quadratic tets: ~0.7 GB) came out of the reserved segment: at most small-class segments were added
+    assert s2["held_bytes"] - s1["held_bytes"] <= 4 * 64 * MB, (s1, s2)
+    assert abs(np.abs(u).max() - 0.036) < 2e-3
+    M.device_reserve(1 << 30, 0, wait=True)           # a free chunk of that size exists: nothing to do
+    assert M.device_arena_stats(0)["held_bytes"] == s2["held_bytes"]
+    c.close()
+    keep.close()
