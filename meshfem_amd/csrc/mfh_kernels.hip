@@ -310,6 +310,7 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
     const int CS = a.chunkSlots + 2;
     double *tabS = acc + (size_t)NB * CS;
     uint32_t *tabO = reinterpret_cast<uint32_t *>(tabS + NPE * NPE * 4);
+    uint32_t *turn = tabO + NPE * NPE;                                 // DET: whose turn it is to add (see below); the launcher sizes the LDS for it
     const PairConst pc{a.pairConst[0], a.pairConst[1], a.pairConst[2], a.pairConst[3], a.pairConst[4], a.pairConst[5]};
     const int64_t item = a.xcd == 1 ? xcd_item(blockIdx.x, gridDim.x) : (a.xcd > 1 ? xcd_group_item(blockIdx.x, gridDim.x, a.xcd) : (int64_t)blockIdx.x);
     const int64_t chunk = a.chunkOrder ? (int64_t)a.chunkOrder[item] : item;
@@ -323,6 +324,7 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
     for (int t = threadIdx.x; t < ns + par; t += 256)
 #pragma unroll
         for (int c = 0; c < NB; ++c) acc[c * CS + t] = 0.0;
+    if (DET && threadIdx.x == 0) *turn = 0u;
     if (TAB) {
         for (int t = threadIdx.x; t < NPE * NPE; t += 256) {
             const int i = t / NPE, j = t - i * NPE;
@@ -338,11 +340,14 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
     // block arithmetic have no mutual dependence, so the loads of all U are in flight together
     // (the kernel is latency-bound: rocprof shows 65 % of wave cycles in s_waitcnt at U = 1).
     // Option "deterministic" (template parameter DET, chosen by the launcher from a.det): the four waves of the workgroup add their contributions to the LDS accumulators one wave after the
-    // other, trip by trip, so that the contributions of a slot always meet in list order (inside one wave the lanes of an LDS atomic are
-    // applied in a fixed order; between waves the order is a matter of timing, and the last bits of K with it). Every lane then runs the
-    // same number of trips (barriers inside the loop).
+    // other, trip by trip, so that the contributions of a slot always meet in the same order (inside one wave the lanes of an LDS atomic are
+    // applied in a fixed order; between waves the order is a matter of timing, and the last bits of K with it). Every lane runs the same
+    // number of trips. The turns are handed on through a token in LDS -- the wave whose (trip, u, wave) number the token shows adds, makes
+    // its adds visible and increments the token -- instead of a workgroup barrier per turn (round 4: eight barriers per trip, kernel 1.15x
+    // the default): only the wave that is next waits, the others go on fetching and computing their next contribution.
     constexpr int U = 2;
     constexpr bool det = DET;          // a template parameter: the default instantiations carry no barrier inside the loop
+    unsigned turnNo = threadIdx.x >> 6;                                // this wave's next turn: (trip U + u) 4 + wave
     for (int64_t k0 = kb + threadIdx.x; det ? (k0 - threadIdx.x < ke) : (k0 < ke); k0 += 256 * U) {
         uint32_t code[U];
         int ls[U];
@@ -377,13 +382,15 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
                 elem_block<DIM, DEG, MAT>(g, MAT == MAT_MASS ? a.massTable : a.pairTable, pc, i, j, K);
             }
             if (det) {
-                for (int w = 0; w < 4; ++w) {
-                    if ((int)(threadIdx.x >> 6) == w && ok[u]) {
+                if ((threadIdx.x & 63) == 0)
+                    while (__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != turnNo) __builtin_amdgcn_s_sleep(1);
+                if (ok[u]) {
 #pragma unroll
-                        for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&acc[c * CS + ls[u]], K[c]);
-                    }
-                    __syncthreads();
+                    for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&acc[c * CS + ls[u]], K[c]);
                 }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the adds are performed before the token moves on
+                if ((threadIdx.x & 63) == 0) __hip_atomic_store(turn, turnNo + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                turnNo += 4u;
             } else if (ok[u]) {
 #pragma unroll
                 for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&acc[c * CS + ls[u]], K[c]);
@@ -2111,6 +2118,8 @@ void launch_assemble_gather(const AsmArgs &a, hipStream_t s) {
     if (a.nChunk == 0) return;
     size_t lds = (size_t)(mat_is_scalar(a.mat) ? 1 : a.dim * a.dim) * (a.chunkSlots + 2) * sizeof(double);
     if (a.deg == 2 && a.mat != MAT_MASS) lds += (size_t)a.npe * a.npe * (4 * sizeof(double) + sizeof(uint32_t));   // pair table
+    // (the token of the deterministic flavour sits behind the pair-table region whether or not the flavour has a table)
+    if (a.det) lds = (size_t)(mat_is_scalar(a.mat) ? 1 : a.dim * a.dim) * (a.chunkSlots + 2) * sizeof(double) + (size_t)a.npe * a.npe * (4 * sizeof(double) + sizeof(uint32_t)) + 16;
 #define CALLV(D, G, M, UP, DT)                                                                                 \
     do {                                                                                                         \
         if (lds > 64 * 1024)                                                                                     \
