@@ -365,6 +365,10 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             double K[NB];
+            // Lanes past the end of the chunk's list skip the block arithmetic, and a wave none of whose lanes has a contribution left
+            // skips it altogether (round 5; before, they computed a dummy block: with ~655 contributions per chunk and trips of 512 that
+            // was a fifth of the executed block evaluations and record fetches).
+            if (ok[u]) {
             uint32_t e;
             int ij;
             if (a.chunkElemBase) { e = eBase + (code[u] >> ASM_CODE_SHIFT); ij = (int)(code[u] & ((1u << ASM_CODE_SHIFT) - 1)); }
@@ -380,6 +384,7 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
             } else {
                 const int i = ij / NPE, j = ij - i * NPE;
                 elem_block<DIM, DEG, MAT>(g, MAT == MAT_MASS ? a.massTable : a.pairTable, pc, i, j, K);
+            }
             }
             if (det) {
                 if ((threadIdx.x & 63) == 0)
