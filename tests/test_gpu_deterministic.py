@@ -170,3 +170,27 @@ def test_row_partitioned_solve_is_bit_reproducible_with_the_peer_transfers():
     mp.spawn(_worker, args=(2, _free_port(), 6, ret), nprocs=2, join=True)
     for r in range(2):
         assert ret[r]["conv"] and ret[r]["equal"] and ret[r]["it"][0] == ret[r]["it"][1], dict(ret[r])
+
+
+def test_deterministic_refuses_the_symmetric_storage_product():
+    """on an assembled upper-triangle matrix (matrix_storage 1, matrix_free 0) the product goes through k_spmv_sym, which adds the
+    transposed half with global atomics in arrival order -- not reproducible. Option deterministic says so instead of returning bits that
+    change from run to run; with both triangles stored the same context is served."""
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    V, T = grid.grid_tet_mesh(6, 6, 6, [0, 0, 0], [1, 1, 1])
+    c = M.Context(0)
+    c.set_option("deterministic", 1)
+    c.set_option("matrix_free", 0)
+    c.set_option("matrix_storage", 1)
+    c.mesh_build(T, V, 1)
+    c.material_isotropic(200.0, 0.35)
+    c.assemble()
+    x = np.random.default_rng(0).standard_normal(3 * c.n_dof)
+    with pytest.raises(M.MeshFEMHipError, match="deterministic"):
+        c.apply_K(x)
+    c.set_option("matrix_storage", 0)
+    c.assemble()
+    y0, y1 = c.apply_K(x), c.apply_K(x)
+    assert np.array_equal(y0, y1)
+    c.close()

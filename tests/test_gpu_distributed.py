@@ -310,11 +310,16 @@ def _worker_scatter(rank, world, port, ret):
         gfixed[g["ball_p2_fixed_vars"]] = True
         c.fix_variables(np.flatnonzero(gfixed[(3 * gid[:, None] + np.arange(3)).ravel()]))
         f = g["ball_p2_load"][gid[:lm.n_owned]].ravel().copy()
+        # an unstructured RCB partition with the aggregate levels PARTITIONED too (forced: the mesh is far below the default threshold)
+        c.set_option("mg_replicate_max", 6)
+        c.set_option("mg_dense_max", 4)
+        c.set_option("mg_agg_target", 8)
         c.set_preconditioner(M.PRECOND_MULTIGRID)
         u, infos = solver.solve(f, rtol=1e-11, maxit=5000)
+        levels = c.multigrid_levels()
         u_ref = g["ball_p2_u"]
         err = np.linalg.norm(u[0].reshape(-1, 3) - u_ref[gid[:lm.n_owned]]) / np.linalg.norm(u_ref)
-        ret[rank] = (err, bool(infos[0]["converged"]), lm.n_owned, infos[0]["iterations"], int(lm.n_local), int(n_glob))
+        ret[rank] = (err, bool(infos[0]["converged"]), lm.n_owned, infos[0]["iterations"], int(lm.n_local), int(n_glob), levels)
         comm.close()
         c.close()
     finally:
@@ -336,6 +341,9 @@ def test_scatter_mesh_three_ranks_matches_golden():
     assert sum(ret[r][2] for r in range(world)) == ret[0][5]             # every P2 node owned once
     assert len({ret[r][3] for r in range(world)}) == 1
     assert max(ret[r][4] for r in range(world)) < 0.8 * ret[0][5]         # no rank holds the whole mesh
+    lv = ret[0][6]
+    assert len(lv) >= 2 and lv[0]["partitioned"] == 1 and lv[-1]["partitioned"] == 0, lv
+    assert sum(ret[r][6][0]["rows"] for r in range(world)) <= lv[0]["aggregates"]
 
 
 def test_rccl_communicator_world_1():
