@@ -16,6 +16,9 @@ Metric (BASELINE.json): stiffness-assembly elements/s (+ PCG DOF/s), quadratic t
     L ~ 60^3 / n^2 hex layers per rank (N = 8: the 120^3 cube, 41.5 M P2 tets, 15-layer z-slabs), so every rank
     keeps ~5.2 M elements (row/element partition, owner computes, no assembly communication); the PCG leg
     runs the distributed solver (halo exchange + all-reduces over RCCL, global two-level preconditioner).
+Every N = 1 line also carries BASELINE configs[1] (`variants.config1_p1`), configs[3] (`variants.config3_homogenization`: six cell problems end to end, Ch
+checked in-line) and configs[4]'s cube in one context (`strong_scaling_n1`: run FIRST, in a process of its own -- `python bench.py --leg strong_n1` --, and
+again inside this process at the end as `warm_process`); `--leg config{1,2,3}|strong_n1` runs one workload alone (one rocprofv3 trace per workload).
 Extra objects on the JSON line: `roofline` (assembly kernel: the contract fraction on SURVEY's algorithmic bytes AND the
 fraction on the bytes the counters / the design actually move), `pcg` (solve to 1e-8 incl. its own roofline for the
 operator kernels), `cpu_baseline` (plain-C port of the reference loop structure timed on the host cores, bounded sample,
