@@ -382,21 +382,32 @@ void ensure_mf(mfh_ctx *c) {
 void ensure_mf_cluster(mfh_ctx *c) {
     if (c->mfcValid) return;
     ensure_symbolic(c, false);
-    // block size: measured at config 3, 256 / 240 (hex-aligned) / 192 give 7.45 / 7.18 / 7.31 M interface partials and the
-    // same 0.69 ms -- the interface is set by the shape of a run of consecutive elements, not by its alignment
-    const int32_t *conn = c->dElemNodes.p;
-    const int be = c->mfBlockElems > 0 ? std::min(c->mfBlockElems, (int)MF_BLOCK) : (int)MF_BLOCK;
-    std::vector<int32_t> blockStart;
-    if (c->mfReorder) {
-        build_element_order_device(c->mesh, c->dElemNodes.p, c->dVertPos.p, c->stream, c->dMfElemPerm, c->dMfElemNodes, be, blockStart);
-        conn = c->dMfElemNodes.p;
-    } else { c->dMfElemPerm.release(); c->dMfElemNodes.release(); }
-    build_mf_cluster_lists_device(c->mesh, conn, device_dof_map(c), c->sym.nRows, c->stream, c->mfc, c->mfcDev, be,
-                                  blockStart.empty() ? nullptr : &blockStart);
+    // Block size (elements per workgroup). Round 5: the lanes take the elements of a block in rounds, and 512 elements per block (two
+    // rounds) is the default where the block's rows still fit the LDS budget of three workgroups per CU -- the staging of x, the barriers
+    // and the write-out of a block are shared by twice the elements, and a larger clump has fewer interface rows (scripts/mf_block_sweep.py:
+    // 0.70 / 0.68 / 0.60 / 0.50 / 0.47 ms at 96 / 128 / 144 / 192 / 256 elements). Deterministic accumulation keeps four more accumulator
+    // arrays and batched right-hand sides NRS-fold ones: 256 there. (Earlier: 256 / 240 / 192 give the same time with the generator's
+    // element order: the interface is set by the shape of a run of consecutive elements.)
+    const bool wide = c->deterministic || c->batchRhs;
+    int be = c->mfBlockElems > 0 ? std::min(c->mfBlockElems, (int)MF_BLOCK_ELEMS_MAX) : (wide ? (int)MF_BLOCK : (int)MF_BLOCK_ELEMS_MAX);
+    const size_t ldsBudget = 52 * 1024;        // three workgroups per CU (160 KB of LDS) -- what the registers of the quadratic kernel allow anyway
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        const int32_t *conn = c->dElemNodes.p;
+        std::vector<int32_t> blockStart;
+        if (c->mfReorder) {
+            build_element_order_device(c->mesh, c->dElemNodes.p, c->dVertPos.p, c->stream, c->dMfElemPerm, c->dMfElemNodes, be, blockStart);
+            conn = c->dMfElemNodes.p;
+        } else { c->dMfElemPerm.release(); c->dMfElemNodes.release(); }
+        build_mf_cluster_lists_device(c->mesh, conn, device_dof_map(c), c->sym.nRows, c->stream, c->mfc, c->mfcDev, be,
+                                      blockStart.empty() ? nullptr : &blockStart);
+        // blocks of more than MF_BLOCK elements whose rows do not fit the budget: once more with one round per block
+        if (be > (int)MF_BLOCK && (size_t)2 * c->mfc.maxLocal * c->mesh.dim * sizeof(double) > ldsBudget && c->mfBlockElems <= 0) { be = MF_BLOCK; continue; }
+        break;
+    }
     // The cluster variant pays when most rows are finished inside a block: one LDS accumulator per distinct row of a
-    // block plus the staged x of those rows (48 KB keeps three workgroups per CU) and an interface buffer well below the per-pair force buffer it replaces.
+    // block plus the staged x of those rows and an interface buffer well below the per-pair force buffer it replaces.
     // An element order without locality (e.g. shuffled: ~2560 distinct rows per block) uses the two-pass variant instead.
-    if ((size_t)2 * c->mfc.maxLocal * c->mesh.dim * sizeof(double) > 48 * 1024 || c->mfc.nIface * 3 > c->mesh.nElem * c->mesh.npe) {
+    if ((size_t)2 * c->mfc.maxLocal * c->mesh.dim * sizeof(double) > ldsBudget || c->mfc.nIface * 3 > c->mesh.nElem * c->mesh.npe) {
         c->mfClusterUnfit = true;
         return;
     }
@@ -415,7 +426,7 @@ k::SpmvMfArgs spmv_mf_cluster_args(mfh_ctx *c, bool masked) {
     a.clElemPtr = c->mfcDev.elemPtr.p;
     a.clLaneStride = 1;
     if (c->mfLaneStride > 1) {   // usable only if coprime to the block size (a bijection of the lanes)
-        int x = c->mfLaneStride, y = c->mfcDev.elemPtr.p ? (int)MF_BLOCK : c->mfc.blockElems;
+        int x = c->mfLaneStride, y = (c->mfcDev.elemPtr.p || c->mfc.blockElems > (int)MF_BLOCK) ? (int)MF_BLOCK : c->mfc.blockElems;
         while (y) { const int t = x % y; x = y; y = t; }
         if (x == 1) a.clLaneStride = c->mfLaneStride;
     }
@@ -2168,12 +2179,12 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
             c->detCounter.zero(c->stream);
             MFH_HIP(hipStreamSynchronize(c->stream));
         }
-        if (on != c->deterministic) { c->deterministic = on; invalidate_matrix(c); destroy_multigrid(c); c->tl.valid = false; }
+        if (on != c->deterministic) { c->deterministic = on; invalidate_matrix(c); destroy_multigrid(c); c->tl.valid = false; c->mfcValid = false; c->mfClusterUnfit = false; }   // (the block size of the cluster operator depends on it)
     }
     else if (k2 == "pcg_variant") c->pcgVariant = value < 0 ? -1 : (value != 0 ? 1 : 0);
-    else if (k2 == "batch_rhs") c->batchRhs = value != 0;
+    else if (k2 == "batch_rhs") { if (c->batchRhs != (value != 0)) { c->mfcValid = false; c->mfClusterUnfit = false; } c->batchRhs = value != 0; }
     else if (k2 == "matrix_free_mode") { c->mfMode = (int)value; c->mfClusterUnfit = false; }
-    else if (k2 == "mf_block_elems") { c->mfBlockElems = (int)value; c->mfcValid = false; }
+    else if (k2 == "mf_block_elems") { c->mfBlockElems = (int)value; c->mfcValid = false; c->mfClusterUnfit = false; }
     else if (k2 == "mf_chunk_rows") { c->mfChunkRows = std::max(16, std::min(4096, (int)value)); c->mfValid = false; }
     else if (k2 == "mf_chunk_pairs") { c->mfChunkPairs = std::max(256, (int)value); c->mfValid = false; }
     else if (k2 == "matrix_free") c->matrixFree = value < 0 ? -1 : (value != 0 ? 1 : 0);   // K x without reading the assembled K (k_spmv_mf)

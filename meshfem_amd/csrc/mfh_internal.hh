@@ -254,11 +254,12 @@ struct MfLists {
 // Cluster variant of the matrix-free operator: elements in blocks of MF_BLOCK consecutive elements; the nodal forces of
 // a block are summed in LDS. Rows whose elements all lie in one block are finished there; the others (interface rows)
 // leave one partial sum per (block, row) in a small buffer that a second pass sums.
-constexpr int MF_BLOCK = 256;
+constexpr int MF_BLOCK = 256;             // threads of a workgroup of the cluster operator
+constexpr int MF_BLOCK_ELEMS_MAX = 512;   // elements of a block: the lanes take them in rounds of MF_BLOCK
 struct MfClusterLists {
     int64_t nBlocks = 0, nEntries = 0, nIface = 0, nIfaceRows = 0;
     int64_t nChunk = 0;                 // chunks of the second pass (chunkRow / pairPtr live on the device only: MfClusterDev)
-    int blockElems = MF_BLOCK;          // elements per block (<= MF_BLOCK threads)
+    int blockElems = MF_BLOCK;          // elements per block (<= MF_BLOCK_ELEMS_MAX)
     int maxLocal = 0;                   // largest number of distinct rows of a block (LDS accumulators)
     int maxRows = 0;                    // most interface rows of a second-pass chunk (LDS of k_mf_rows)
 };

@@ -1636,8 +1636,13 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
         // blocks of whole cells (clElemPtr, <= MF_BLOCK elements each) or of clBlockElems consecutive elements
         const int64_t e0 = a.clElemPtr ? (int64_t)a.clElemPtr[b] : b * a.clBlockElems;
         const int ne = a.clElemPtr ? a.clElemPtr[b + 1] - a.clElemPtr[b] : a.clBlockElems;
-        const int span = a.clElemPtr ? MF_BLOCK : a.clBlockElems;      // the lane permutation is a bijection of [0, span)
-        const int le = a.clLaneStride > 1 ? (int)((threadIdx.x * (unsigned)a.clLaneStride) % (unsigned)span) : (int)threadIdx.x;
+        // A block may hold more elements than the workgroup has lanes (up to MF_BLOCK_ELEMS_MAX, round 5): the lanes take them in rounds of
+        // MF_BLOCK -- the staging of x, the two barriers and the write-out of a block are then shared by twice the elements (operator 0.68 /
+        // 0.47 ms at 128 / 256 elements per block).
+        const int span = (a.clElemPtr || a.clBlockElems > MF_BLOCK) ? MF_BLOCK : a.clBlockElems;      // the lane permutation is a bijection of [0, span)
+        const int le0 = a.clLaneStride > 1 ? (int)((threadIdx.x * (unsigned)a.clLaneStride) % (unsigned)span) : (int)threadIdx.x;
+        for (int base = 0; base < ne; base += MF_BLOCK) {
+        const int le = base + le0;
         const int64_t e = e0 + le;
         if ((int)threadIdx.x < span && le < ne && e < a.nElem) {
             int li[NPE];
@@ -1665,6 +1670,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
                 elem_forces_bilinear<DIM, DEG, MAT>(a.geo, vol, gl, gl, xl, emit);
             } else
                 elem_forces_core<DIM, DEG, MAT>(a, a.clElemPerm ? (int64_t)a.clElemPerm[e] : e, xl, emit);   // the record of the ORIGINAL element
+        }
         }
         __syncthreads();
         for (int t = threadIdx.x; t < nLocal; t += MF_BLOCK) {
@@ -1823,21 +1829,6 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster_nr(SpmvMfArgs a, const 
         const int u0 = a.clBlockPtr[b], nLocal = a.clBlockPtr[b + 1] - u0;
         const int64_t e0 = a.clElemPtr ? (int64_t)a.clElemPtr[b] : b * a.clBlockElems;
         const int ne = a.clElemPtr ? a.clElemPtr[b + 1] - a.clElemPtr[b] : a.clBlockElems;
-        const int64_t e = e0 + threadIdx.x;
-        const bool active = (int)threadIdx.x < ne && e < a.nElem;
-        // element state shared by all NR vectors: LDS offsets of its nodes' rows, gradients, volume
-        int li[NPE];
-        double gl[DIM + 1][DIM], vol = 0.0;
-        const double *g = a.geo + (active ? (a.clElemPerm ? (int64_t)a.clElemPerm[e] : e) : 0) * a.geoStride;   // record of the original element
-        if (active) {
-#pragma unroll
-            for (int j = 0; j < NPE; ++j) li[j] = (int)a.clLocalIdx[e * NPE + j] * W;
-#pragma unroll
-            for (int k = 0; k <= DIM; ++k)
-#pragma unroll
-                for (int d = 0; d < DIM; ++d) gl[k][d] = g[k * DIM + d];
-            vol = g[12];
-        }
         for (int sb = 0; sb < NSB; ++sb) {
             // x of every distinct row of the block, NRS vectors: read once into LDS
             for (int t = threadIdx.x; t < nLocal; t += MF_BLOCK) {
@@ -1847,7 +1838,22 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster_nr(SpmvMfArgs a, const 
                 for (int j = 0; j < W; ++j) { xs[t * W + j] = src[j]; clacc[t * W + j] = 0.0; }
             }
             __syncthreads();
+            // (a block may hold more elements than lanes: rounds of MF_BLOCK, see k_mf_cluster; the element state -- LDS offsets of its nodes'
+            // rows, gradients, volume -- is shared by the NRS vectors of the sub-batch and fetched again per sub-batch and round)
+            for (int base = 0; base < ne; base += MF_BLOCK) {
+            const int64_t e = e0 + base + threadIdx.x;
+            const bool active = base + (int)threadIdx.x < ne && e < a.nElem;
             if (active) {
+                int li[NPE];
+                double gl[DIM + 1][DIM];
+                const double *g = a.geo + (a.clElemPerm ? (int64_t)a.clElemPerm[e] : e) * a.geoStride;   // record of the original element
+#pragma unroll
+                for (int j = 0; j < NPE; ++j) li[j] = (int)a.clLocalIdx[e * NPE + j] * W;
+#pragma unroll
+                for (int k = 0; k <= DIM; ++k)
+#pragma unroll
+                    for (int d = 0; d < DIM; ++d) gl[k][d] = g[k * DIM + d];
+                const double vol = g[12];
 #pragma unroll 1
                 for (int kk = 0; kk < NRS; ++kk) {
                     const double *xk = xs + kk * DIM;
@@ -1862,6 +1868,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster_nr(SpmvMfArgs a, const 
                         for (int d = 0; d < DIM; ++d) unsafeAtomicAdd(&ak[li[j] + d], fv[d]);
                     });
                 }
+            }
             }
             __syncthreads();
             double dl[NRS];

@@ -765,7 +765,7 @@ void build_mf_cluster_lists_device(const HostMesh &m, const int32_t *dElemNodes,
         tp = t;
     };
     L = MfClusterLists();
-    L.blockElems = std::max(16, std::min(blockElems, MF_BLOCK));
+    L.blockElems = std::max(16, std::min(blockElems, MF_BLOCK_ELEMS_MAX));
     L.nBlocks = (m.nElem + L.blockElems - 1) / L.blockElems;
     DBuf<int32_t> dBlockOfElem;
     D.elemPtr.release();
