@@ -41,7 +41,7 @@ PMC_PROFILE_UPPER = "r05_pmc_traffic_n60_upper_storage.json"   # the same with t
 PMC_KERNEL_KEY = "k_assemble_gather"
 ALG_BYTES = {(3, 2): 7736, (3, 1): 1328, (2, 2): 1368, (2, 1): 0}   # SURVEY.md section 8(d), const material, both triangles
 # SURVEY.md section 8(d), row "upper-only variant, matches reference storage": 40 + 96 + 55 x 4 + 55 x 72 (P2 tet); P2 triangle alike
-ALG_BYTES_UPPER = {(3, 2): 4316, (2, 2): 24 + 48 + 21 * 4 + 21 * 32}
+ALG_BYTES_UPPER = {(3, 2): 4316, (3, 1): 872, (2, 2): 24 + 48 + 21 * 4 + 21 * 32}   # (3, 1): 112 + 10 blocks x 76 B (1 328 - 6 x 76)
 
 
 def parse():
@@ -297,9 +297,9 @@ def run_single(args):
     value = nE * args.steps / dt
     # dominant kernel alone, HIP events on the context's stream
     k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
-    # Storage of K: automatic (option matrix_storage -1). Quadratic elasticity solves on the matrix-free operator, nothing multiplies
-    # by the stored K, and the context stores / assembles the triangle the reference's TripletMatrix holds (SURVEY 8d's "upper-only
-    # variant, matches reference storage", 4 316 B per P2 tet); linear meshes keep both triangles for the assembled SpMV (7 736 / 1 328 B).
+    # Storage of K: automatic (option matrix_storage -1). Elasticity solves on the matrix-free operator, nothing multiplies by the stored K,
+    # and the context stores / assembles the triangle the reference's TripletMatrix holds (SURVEY 8d's "upper-only variant, matches
+    # reference storage", 4 316 B per P2 tet, 872 B per P1 tet); both triangles (7 736 / 1 328 B) with option matrix_free 0.
     upper, stored_blocks = c.matrix_storage()
     bytes_per_element = ALG_BYTES_UPPER[(3, deg)] if upper else ALG_BYTES[(3, deg)]
     alg = bytes_per_element * nE
@@ -358,7 +358,7 @@ def run_single(args):
                           dof_per_s=ndof * i2["iterations"] / (i2["solve_ms"] * 1e-3), ms_per_iteration=i2["solve_ms"] / max(1, i2["iterations"]),
                           preconditioner="two-level: 3x3 block-Jacobi + rigid-body modes of %d aggregates" % p2["aggregates"],
                           coarse_setup_ms=p2["setup_ms"], coarse_dim=p2["coarse_dim"], wall_s=time.time() - t0, max_abs_u=float(np.abs(u).max()),
-                          operator="matrix-free (k_mf_cluster + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)", ranks=1)
+                          operator="matrix-free (k_mf_cluster + k_mf_rows)", ranks=1)
         # ... and the multigrid V-cycle, which the N > 1 runs report as pcg_multigrid too (partitioned nodal levels there)
         try:
             c.set_preconditioner(M.PRECOND_MULTIGRID)
@@ -404,14 +404,14 @@ def run_single(args):
                           dof_per_s=ndof * info["iterations"] / (info["solve_ms"] * 1e-3),
                           ms_per_iteration=info["solve_ms"] / max(1, info["iterations"]),
                           preconditioner="3x3 block-Jacobi (north_star baseline preconditioner)", wall_s=time.time() - t0,
-                          operator="matrix-free (k_mf_cluster + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
+                          operator="matrix-free (k_mf_cluster + k_mf_rows)",
                           algorithm="classic PCG (two reduction points; the default for one right-hand side on one GPU)",
                           matrix_free=dict(kernels_ms=mf_ms, speedup_vs_assembled_spmv=sp_ms / mf_ms, bytes_per_application=mf_bytes, lists=mf_info,
                                            traffic_bytes_per_application=mf_traffic, traffic=None if mf_traffic is None else mf_traffic / mf_ms / 1e6,
                                            achieved=mf_bytes / mf_ms / 1e6, frac=mf_bytes / mf_ms / 1e6 / HBM_PEAK_GBS, unit="GB/s",
                                            note="same operator as the assembled K to rounding; trades 72 B/block of matrix traffic for FP64 flops"),
                           max_abs_u=float(np.abs(u).max()),
-                          roofline=dict(bound="hbm", kernel="k_spmv", note="assembled block-CSR SpMV (the PCG operator for P1; P2 solves use the matrix-free operator below)",
+                          roofline=dict(bound="hbm", kernel="k_spmv", note="assembled block-CSR SpMV (option matrix_free 0; the solves use the matrix-free operator below)",
                                         achieved=sp_bytes / sp_ms / 1e6, peak=HBM_PEAK_GBS,
                                         unit="GB/s", frac=sp_bytes / sp_ms / 1e6 / HBM_PEAK_GBS, kernel_ms=sp_ms,
                                         traffic=None if stb is None else stb / sp_ms / 1e6, traffic_bytes_per_launch=stb,
@@ -614,21 +614,21 @@ def config1_p1(args, n=35):
     k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
     nr, nc, nnzb = c.matrix_info()
     upper, stored = c.matrix_storage()
-    alg = ALG_BYTES[(3, 1)] * nE
+    bpe = ALG_BYTES_UPPER[(3, 1)] if upper else ALG_BYTES[(3, 1)]
+    alg = bpe * nE
     comp = compulsory_assembly_bytes(c, nE, stored)
     res = dict(workload="configs[1]: %d^3 grid -> %d P1 tets, %d DOF" % (n, nE, 3 * c.n_dof), elements=nE, dof=3 * c.n_dof, nnz_blocks=nnzb, stored_blocks=stored,
                matrix_storage="upper" if upper else "full", value=nE / dt, unit="elements/s", ms_per_step=dt * 1e3,
-               roofline=dict(kernel="k_assemble_gather", kernel_ms=k_ms, bytes_per_element=ALG_BYTES[(3, 1)], frac=alg / k_ms / 1e6 / HBM_PEAK_GBS,
+               roofline=dict(kernel="k_assemble_gather", kernel_ms=k_ms, bytes_per_element=bpe, frac=alg / k_ms / 1e6 / HBM_PEAK_GBS,
                              compulsory_bytes=comp, frac_compulsory=comp / k_ms / 1e6 / HBM_PEAK_GBS,
                              note="%.0f MB per launch: the working set is of the order of the 256 MiB memory-side cache; the fractions are against the "
                                   "8 TB/s HBM peak all the same" % (comp / 1e6)),
                setup=dict(femmesh_build_s=t_build, symbolic_s=t_sym, first_assemble_call_s=t_first, first_assembly_ms=(t_build + t_sym + t_first) * 1e3),
                kernel_trace="profiles/r05_config1_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py --leg config1`)")
     if not args.no_solve:
-        sp_ms = c.time_spmv_kernel(20)
-        sp_bytes = stored * 76 + nr * 3 * 16 + nr * 4
-        res["spmv"] = dict(kernel="k_spmv", kernel_ms=sp_ms, alg_bytes_per_launch=sp_bytes, achieved=sp_bytes / sp_ms / 1e6, frac=sp_bytes / sp_ms / 1e6 / HBM_PEAK_GBS,
-                           unit="GB/s", note="stored blocks x 76 B + vectors")
+        op_ms = c.time_spmv_kernel(20)
+        mf_info = c.matrix_free_info()
+        res["operator"] = dict(kernels="k_mf_cluster + k_mf_rows (matrix-free, the PCG default of elasticity since round 5)", kernels_ms=op_ms, lists=mf_info)
         for name, pre in (("pcg_block_jacobi", M.PRECOND_BLOCK_JACOBI), ("pcg_multigrid", M.PRECOND_MULTIGRID)):
             c.set_preconditioner(pre)
             t0 = time.time()
@@ -638,6 +638,13 @@ def config1_p1(args, n=35):
                              ms_per_iteration=i["solve_ms"] / max(1, i["iterations"]), wall_s=time.time() - t0, max_abs_u=float(np.abs(u).max()),
                              dof_per_s=3 * c.n_dof * i["iterations"] / (i["solve_ms"] * 1e-3))
         res["pcg_multigrid"]["hierarchy_setup_ms"] = c.multigrid_info()["setup_ms"]
+        # the assembled SpMV of rounds 1-4 beside it (needs both triangles: the option re-assembles)
+        c.set_option("matrix_free", 0)
+        sp_ms = c.time_spmv_kernel(20)
+        sp_bytes = nnzb * 76 + nr * 3 * 16 + nr * 4
+        res["spmv"] = dict(kernel="k_spmv", kernel_ms=sp_ms, alg_bytes_per_launch=sp_bytes, achieved=sp_bytes / sp_ms / 1e6, frac=sp_bytes / sp_ms / 1e6 / HBM_PEAK_GBS,
+                           unit="GB/s", note="both triangles x 76 B + vectors; not what the solves above ran on")
+        res["operator"]["speedup_vs_assembled_spmv"] = sp_ms / op_ms
     c.close()
     return res
 

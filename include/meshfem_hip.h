@@ -454,9 +454,10 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
  * 2 slot-major), "check_every", "keep_host_symbolic", "agg_nodes" (target DoFs per aggregate of the two-level
  * preconditioner), "reembed" (1: every mfh_assemble re-runs the element-embedding kernel as well),
  * "matrix_free" (operator of mfh_solve / mfh_apply_K / mfh_dev_spmv: 0 = assembled block-CSR SpMV, 1 = matrix-free
- *   (k_mf_forces + k_mf_rows: element stresses recomputed, K not read), -1 = auto (default): matrix-free for quadratic
- *   elasticity, where it is 4-5x faster, assembled otherwise; both give K x up to rounding),
- * "matrix_free_mode" (4 default: cluster variant, forces of 256 consecutive elements summed in LDS | 3 two-pass, forces in
+ *   (k_mf_cluster + k_mf_rows: element stresses recomputed, K not read), -1 = auto (default): matrix-free for elasticity
+ *   (quadratic: 6x faster than the assembled SpMV; linear: 1.2x at 1 M tets, 1.8x from 6 M on), assembled for the scalar operators; both give
+ *   K x up to rounding),
+ * "matrix_free_mode" (4 default: cluster variant, forces of a block of 512-1024 consecutive elements summed in LDS | 3 two-pass, forces in
  *   list order | 2 two-pass, forces element-major | 1 per-pair block evaluation), "mf_chunk_rows", "mf_chunk_pairs",
  * "mf_geometry_from_vertices" (1 default: with a constant material the matrix-free operator recomputes the element gradients from the
  *   corner positions instead of reading the element records), "mf_xcd_group" (32 default: consecutive element blocks per XCD),
@@ -470,7 +471,7 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
  *   the (block-)Jacobi and two-level PCG on the matrix-free operator, and mfh_apply_K / mfh_dev_spmv through k_spmv_sym (the transposed half
  *   of the product added with global atomics: 2.5x slower than the product from both triangles); the PCG on the assembled SpMV and the probing
  *   construction of the coarse operator return MFH_ERR_UNSUPPORTED on it. 0: both triangles. -1 default: automatic -- the upper triangle exactly when nothing
- *   multiplies by the stored K (quadratic elasticity on the matrix-free operator), both triangles otherwise; changing an option that
+ *   multiplies by the stored K (elasticity on the matrix-free operator), both triangles otherwise; changing an option that
  *   decides this re-runs the symbolic phase on the next use. mfh_matrix_info / mfh_export_bsr describe K itself either way,
  *   mfh_matrix_storage what is stored),
  * "pcg_variant" (1: Chronopoulos-Gear PCG, one reduction point per iteration and one fused vector kernel -- always used by

@@ -389,7 +389,10 @@ void ensure_mf_cluster(mfh_ctx *c) {
     // arrays and batched right-hand sides NRS-fold ones: 256 there. (Earlier: 256 / 240 / 192 give the same time with the generator's
     // element order: the interface is set by the shape of a run of consecutive elements.)
     const bool wide = c->deterministic || c->batchRhs;
-    int be = c->mfBlockElems > 0 ? std::min(c->mfBlockElems, (int)MF_BLOCK_ELEMS_MAX) : (wide ? (int)MF_BLOCK : (int)MF_BLOCK_ELEMS_MAX);
+    // linear elements have a fifth of the rows per element: 1 024 per block once the mesh is large enough to fill the device with such blocks
+    // (scripts/p1_block_sweep.py: 0.192 / 0.157 / 0.147 / 0.148 ms at 256 / 512 / 1 024 / 2 048 for 6.3 M tets; 0.0375 / 0.0339 / 0.0344 for 1 M)
+    const int autoBlock = (c->mesh.deg == 1 && c->mesh.nElem >= (int64_t)3000000) ? 1024 : 512;
+    int be = c->mfBlockElems > 0 ? std::min(c->mfBlockElems, (int)MF_BLOCK_ELEMS_MAX) : (wide ? (int)MF_BLOCK : autoBlock);
     const size_t ldsBudget = 52 * 1024;        // three workgroups per CU (160 KB of LDS) -- what the registers of the quadratic kernel allow anyway
     for (int attempt = 0; attempt < 2; ++attempt) {
         const int32_t *conn = c->dElemNodes.p;

@@ -79,7 +79,7 @@ struct mfh_ctx {
     // blocks, half the bytes. Every consumer that needs K through its diagonal blocks, its stored triangle or the Galerkin product works
     // on it; what multiplies by the stored K (the assembled SpMV) needs both triangles.
     // Option "matrix_storage": 1 upper, 0 both, -1 (default) automatic = upper exactly when nothing will multiply by the stored K:
-    // quadratic elasticity on the matrix-free operator (resolve_upper_storage). upperOnly is the state of the CURRENT symbolic phase.
+    // elasticity on the matrix-free operator (resolve_upper_storage). upperOnly is the state of the CURRENT symbolic phase.
     int matrixStorage = -1;
     bool upperOnly = false;
     int nCU = 256;                    // compute units of the device (hipDeviceProp_t::multiProcessorCount)
@@ -90,10 +90,11 @@ struct mfh_ctx {
     // matrix-free operator (option "matrix_free"): (element, node) pair lists by row chunks
     MfLists mf;
     bool mfValid = false;
-    int matrixFree = -1;              // option "matrix_free": 1 on, 0 off, -1 auto (quadratic elasticity: 2x faster than the assembled SpMV)
+    int matrixFree = -1;              // option "matrix_free": 1 on, 0 off, -1 auto = on for elasticity (quadratic: 6x faster than the assembled SpMV; linear, since
+                                      // the blocks of the cluster operator hold 512-1024 elements: 0.15 against 0.27 ms at 6.3 M tets, 0.033 against 0.040 at 1 M)
     bool use_mf() const {
         if (external || !haveMesh || hostOnly) return false;
-        return matrixFree == 1 || (matrixFree < 0 && mesh.deg == 2 && op == MFH_OP_ELASTICITY);
+        return matrixFree == 1 || (matrixFree < 0 && op == MFH_OP_ELASTICITY);
     }
     DBuf<int32_t> dMfChunkRow;
     DBuf<int64_t> dMfPairPtr;
@@ -369,7 +370,7 @@ inline void check_residual_gap(const mfh_solve_info &li, double rtol) {
 // the storage the next symbolic phase will build (see mfh_ctx::matrixStorage)
 inline bool resolve_upper_storage(const mfh_ctx *c) {
     if (c->matrixStorage >= 0) return c->matrixStorage == 1;
-    return c->haveMesh && !c->hostOnly && !c->external && c->mesh.deg == 2 && c->op == MFH_OP_ELASTICITY && c->use_mf() && !c->tlProbe && c->tlRapAgg;
+    return c->haveMesh && !c->hostOnly && !c->external && c->op == MFH_OP_ELASTICITY && c->use_mf() && !c->tlProbe && c->tlRapAgg;
 }
 
 // consumers that multiply by the stored K cannot work on the upper-only storage (option "matrix_storage" 1; the automatic

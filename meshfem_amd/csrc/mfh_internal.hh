@@ -255,7 +255,7 @@ struct MfLists {
 // a block are summed in LDS. Rows whose elements all lie in one block are finished there; the others (interface rows)
 // leave one partial sum per (block, row) in a small buffer that a second pass sums.
 constexpr int MF_BLOCK = 256;             // threads of a workgroup of the cluster operator
-constexpr int MF_BLOCK_ELEMS_MAX = 512;   // elements of a block: the lanes take them in rounds of MF_BLOCK
+constexpr int MF_BLOCK_ELEMS_MAX = 4096;  // elements of a block: the lanes take them in rounds of MF_BLOCK (default 512 for quadratic elements, more for linear ones)
 struct MfClusterLists {
     int64_t nBlocks = 0, nEntries = 0, nIface = 0, nIfaceRows = 0;
     int64_t nChunk = 0;                 // chunks of the second pass (chunkRow / pairPtr live on the device only: MfClusterDev)
@@ -540,6 +540,7 @@ void launch_st_prolong_add(int dim, int64_t nAgg, const int32_t *parent, const d
                            const double *stop, hipStream_t s);
 void launch_st_to_dense(int dim, int64_t nAgg, const int32_t *nbr, const double *A, double *Ad, hipStream_t s);
 void launch_mg_zero(int64_t n, double *v, const double *scal, int it, const double *stop, hipStream_t s);
+void launch_st_mirror_upper(double *stencil, const int32_t *nbr, int64_t nAgg, int dim, hipStream_t s);
 void launch_tl_rap_agg(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const int32_t *binCoord, const int32_t *rowPtr,
                        const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly = false, int64_t nOwnedRows = 0,
                        double *stencil = nullptr, int *farCount = nullptr, const int *wrapNb = nullptr);

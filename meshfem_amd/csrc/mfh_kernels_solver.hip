@@ -1831,6 +1831,28 @@ __global__ void __launch_bounds__(256) k_tl_mirror_upper(double *__restrict__ Ac
     }
 }
 
+// the same for the lattice-stencil storage: S[a][slot(b)] and S[b][slot(a)]^T (slot(a) seen from b is the opposite offset) both become the
+// sum of the two partial sums; the pair is handled by the thread of its smaller aggregate
+__global__ void __launch_bounds__(256) k_st_mirror_upper(double *__restrict__ S, const int32_t *__restrict__ nbr, int64_t nAgg, int NSLOT, int NM) {
+    const int64_t total = nAgg * NSLOT * NM * NM;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int64_t a = q / (NSLOT * NM * NM);
+        const int r = (int)(q - a * NSLOT * NM * NM), sl = r / (NM * NM), e = r - sl * NM * NM, kk = e / NM, ll = e - kk * NM;
+        if (sl == NSLOT / 2) continue;
+        const int64_t b = nbr[a * NSLOT + sl];
+        if (b < 0 || b <= a) continue;
+        const int64_t ia = q, ib = (b * NSLOT + (NSLOT - 1 - sl)) * NM * NM + ll * NM + kk;
+        const double v = S[ia] + S[ib];
+        S[ia] = v;
+        S[ib] = v;
+    }
+}
+void launch_st_mirror_upper(double *stencil, const int32_t *nbr, int64_t nAgg, int dim, hipStream_t s) {
+    const int NS = dim == 3 ? 27 : 9, NM = dim == 3 ? 6 : 3;
+    hipLaunchKernelGGL(k_st_mirror_upper, dim3(grid_for(nAgg * NS * NM * NM)), dim3(256), 0, s, stencil, nbr, nAgg, NS, NM);
+    CHECK_LAUNCH();
+}
+
 void launch_tl_rap_agg(const TLArgs &t, const int32_t *aggPtr, const int32_t *dofsByAgg, const int32_t *binCoord, const int32_t *rowPtr,
                        const int32_t *colIdx, const double *vals, double *Ac, hipStream_t s, bool upperOnly, int64_t nOwnedRows, double *stencil,
                        int *farCount, const int *wrapNb) {

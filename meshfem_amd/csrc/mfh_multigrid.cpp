@@ -326,6 +326,9 @@ bool build_aggregate_hierarchy(mfh_ctx *c, mfh_ctx *c1, const std::function<void
         ta.fixedMask = c1->fixedVars.empty() ? nullptr : c1->dFixedMask.p;
         k::launch_tl_rap_agg(ta, G.aggPtr2.p, G.dofsByAgg2.p, L0->coord.p, c1->dRowPtr.p, c1->dColIdx.p, c1->dVals.p, nullptr, s, c1->upperOnly, c1->sym.nRows,
                              L0->A.p, far.p, L0->wrap);
+        // upper-triangle storage of the linear level (linear elements solved matrix-free): the kernel wrote the partial sums over the stored
+        // blocks, S[a][b] + S[b][a]^T completes the blocks between two aggregates
+        if (c1->upperOnly) k::launch_st_mirror_upper(L0->A.p, L0->nbr.p, A.nAgg, dim, s);
         int nFar = 0;
         far.download(&nFar, 1, s);
         if (sum_over_ranks((double)nFar) == 0) {

@@ -878,7 +878,7 @@ def _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out, group=None, l
         umax = red([np.abs(u).max() if u is not None else 0.0], dist.ReduceOp.MAX)[0]
         rec.update(rtol=args.rtol, max_abs_u=float(umax), dof=int(nd), dof_per_s=float(nd) * rec["iterations"] / max(rec["solve_s"], 1e-30), maxit=mi,
                    preconditioner=pre_desc, two_level=tl_info,
-                   operator="matrix-free (k_mf_cluster + k_mf_rows)" if deg == 2 else "assembled block-CSR (k_spmv)",
+                   operator="matrix-free (k_mf_cluster + k_mf_rows)",
                    algorithm="Chronopoulos-Gear PCG in the library (mfh_dist_solve): packed halo exchange overlapped with the interior "
                              "element blocks + %d all-reduce / iteration" % (2 if tl_info else 1))
         res["two_level"] = rec
@@ -1061,7 +1061,7 @@ def bench_slabs(args, rank, world, local_rank, shared_gpus=False, scaling=None, 
     # storage of K on a rank: automatic, like on one GPU (quadratic elasticity: the upper triangle of the owned rows plus the blocks
     # towards halo columns; SURVEY 8d's upper-only figure). Linear meshes keep both triangles.
     upper, stored_blocks = c.matrix_storage()
-    alg = (4316 if upper else 7736) if deg == 2 else 1328
+    alg = (4316 if upper else 7736) if deg == 2 else (872 if upper else 1328)
     nE_loc = int(len(lm.elem_nodes))
     nr, nc, nnzb = c.matrix_info()
     sizes = c.symbolic_sizes()

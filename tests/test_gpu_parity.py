@@ -1203,9 +1203,9 @@ def test_upper_only_storage_assembles_the_reference_triangle(mode, periodic):
 
 
 def test_storage_of_K_follows_what_will_read_it():
-    """Option matrix_storage -1 (default): quadratic elasticity runs its PCG on the matrix-free operator, nothing multiplies by
-    the stored K, and the context stores the upper triangle; asking for the assembled SpMV (matrix_free 0), a linear mesh or a
-    scalar operator switches to both triangles. The matrix every export shows is K either way."""
+    """Option matrix_storage -1 (default): elasticity runs its PCG on the matrix-free operator, nothing multiplies by the stored K,
+    and the context stores the upper triangle; asking for the assembled SpMV (matrix_free 0) or a scalar operator switches to both
+    triangles. The matrix every export shows is K either way."""
     V, T = grid.grid_tet_mesh(3, 3, 2)
     ref = {}
     for deg in (1, 2):
@@ -1236,8 +1236,15 @@ def test_storage_of_K_follows_what_will_read_it():
     c.mesh_build(T, V, 1)
     c.material_isotropic(200.0, 0.35)
     c.assemble()
-    assert not c.matrix_storage()[0]
+    nr, nc, nnzb = c.matrix_info()
+    assert c.matrix_storage() == (True, (nnzb + nr) // 2)       # linear elements: the same rule since round 5
     assert abs(c.export_scipy() - ref[1]).max() < K_RTOL * abs(ref[1]).max()
+    x = np.random.default_rng(1).standard_normal(3 * nr)
+    y_mf = c.apply_K(x)
+    c.set_option("matrix_free", 0)
+    y_sp = c.apply_K(x)
+    assert c.matrix_storage() == (False, nnzb)
+    assert np.linalg.norm(y_sp - ref[1] @ x) < 1e-12 * np.linalg.norm(y_sp) and np.linalg.norm(y_mf - y_sp) < 1e-12 * np.linalg.norm(y_sp)
     c.close()
 
 
