@@ -50,6 +50,7 @@ struct mfh_comm {
     mfh_exchange_fn exchange = nullptr;
     // RCCL
     void *nccl = nullptr;
+    bool aborted = false;           // the self test gave up on the RCCL communicator (ncclCommAbort): every further use fails
     int device = -1;
     std::string desc, descFull;
     std::vector<mfh_ctx *> users;   // contexts whose mfh_dist_setup named this communicator (detached when it is destroyed)

@@ -14,6 +14,8 @@
 #include "mfh_ctx.hh"
 #include "mfh_comm.hh"
 #include <dlfcn.h>
+#include <chrono>
+#include <thread>
 
 // ------------------------------------------------------------------------------------------------ communicator
 namespace {
@@ -33,7 +35,7 @@ struct RcclApi {
     std::string where;
     nccl_get_unique_id_t getUniqueId = nullptr;
     nccl_comm_init_rank_t commInitRank = nullptr;
-    nccl_comm_destroy_t commDestroy = nullptr;
+    nccl_comm_destroy_t commDestroy = nullptr, commAbort = nullptr;
     nccl_all_reduce_t allReduce = nullptr;
     nccl_send_t send = nullptr;
     nccl_recv_t recv = nullptr;
@@ -66,6 +68,7 @@ RcclApi &rccl() {
     api.getUniqueId = (nccl_get_unique_id_t)sym("ncclGetUniqueId");
     api.commInitRank = (nccl_comm_init_rank_t)sym("ncclCommInitRank");
     api.commDestroy = (nccl_comm_destroy_t)sym("ncclCommDestroy");
+    api.commAbort = (nccl_comm_destroy_t)sym("ncclCommAbort");
     api.allReduce = (nccl_all_reduce_t)sym("ncclAllReduce");
     api.send = (nccl_send_t)sym("ncclSend");
     api.recv = (nccl_recv_t)sym("ncclRecv");
@@ -95,6 +98,7 @@ namespace mfh {
 // the transport underneath: RCCL or the caller's callbacks
 void base_allreduce(mfh_comm *cm, double *dev, int64_t n, hipStream_t s) {
     if (!cm || cm->world <= 1 || n == 0) return;
+    if (cm->aborted) throw Error(MFH_ERR_HIP, "the RCCL communicator was aborted by a timed-out self test");
     if (cm->nccl) rccl_check(rccl().allReduce(dev, dev, (size_t)n, kNcclFloat64, kNcclSum, cm->nccl, s), "ncclAllReduce");
     else if (cm->allreduce(cm->user, dev, n, (void *)s) != MFH_OK) throw Error(MFH_ERR_HIP, "communicator callback allreduce_sum failed");
 }
@@ -102,6 +106,7 @@ void base_allreduce(mfh_comm *cm, double *dev, int64_t n, hipStream_t s) {
 void base_exchange(mfh_comm *cm, int nPeers, const int32_t *peers, const double *const *sendBufs, const int64_t *sendCounts,
                    double *const *recvBufs, const int64_t *recvCounts, hipStream_t s) {
     if (!cm || cm->world <= 1 || nPeers == 0) return;
+    if (cm->aborted) throw Error(MFH_ERR_HIP, "the RCCL communicator was aborted by a timed-out self test");
     if (cm->nccl) {
         RcclApi &a = rccl();
         rccl_check(a.groupStart(), "ncclGroupStart");
@@ -1047,6 +1052,30 @@ mfh_status mfh_comm_allreduce(mfh_ctx *c, mfh_comm *cm, double *dev, int64_t n) 
     MFH_CATCH(c)
 }
 
+// First contact with a transport must not be able to hang the run: the self test and the preflight wait for their stream with a deadline
+// (MFH_COMM_TIMEOUT_S, default 120 s). When it passes, an RCCL communicator is aborted (ncclCommAbort ends its kernels, the stream drains) and
+// the call fails like any other failed self test: the caller moves on to the next transport (distributed.py robust_comm). The peer transfers
+// carry their own 60 s limit inside the kernels (mfh_peer.hip).
+static void sync_with_deadline(mfh_comm *cm, hipStream_t s, const char *what) {
+    static const double limit = [] { const char *e = getenv("MFH_COMM_TIMEOUT_S"); const double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 120.0; }();
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(s);
+        if (q == hipSuccess) return;
+        if (q != hipErrorNotReady) { MFH_HIP(q); }
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit) break;
+        std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+    (void)hipGetLastError();
+    if (cm && cm->nccl && rccl().commAbort) {
+        (void)rccl().commAbort(cm->nccl);
+        cm->nccl = nullptr;                      // (aborted communicators are not destroyed again; the handle is gone)
+        cm->aborted = true;
+        (void)hipStreamSynchronize(s);
+    }
+    throw Error(MFH_ERR_HIP, std::string("communicator self-test: no answer within ") + std::to_string((int)limit) + " s (" + what + "); the transport is unusable");
+}
+
 mfh_status mfh_comm_selftest(mfh_ctx *c, mfh_comm *cm) {
     MFH_TRY(c)
     require(c && cm, MFH_ERR_INVALID, "bad arguments");
@@ -1083,7 +1112,7 @@ mfh_status mfh_comm_selftest(mfh_ctx *c, mfh_comm *cm) {
         } else
             MFH_HIP(hipMemcpyAsync(b.p, a.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
         MFH_HIP(hipMemcpyAsync(got.data(), b.p, n * sizeof(double), hipMemcpyDeviceToHost, s));
-        MFH_HIP(hipStreamSynchronize(s));
+        sync_with_deadline(cm, s, "ring shift");
         for (int i = 0; i < n; ++i)
             if (got[i] != (from + 1) * 1000.0 + i + 7.0 * round) throw Error(MFH_ERR_HIP, "communicator self-test: point-to-point message corrupted");
         double one[2] = {cm->rank + 1.0 + round, 1.0};
@@ -1094,7 +1123,7 @@ mfh_status mfh_comm_selftest(mfh_ctx *c, mfh_comm *cm) {
         MFH_HIP(hipMemcpyAsync(v.p, hv.data(), nLong * sizeof(double), hipMemcpyHostToDevice, s));
         comm_allreduce(cm, v.p, nLong, s);
         MFH_HIP(hipMemcpyAsync(hv.data(), v.p, nLong * sizeof(double), hipMemcpyDeviceToHost, s));
-        MFH_HIP(hipStreamSynchronize(s));
+        sync_with_deadline(cm, s, "all-reduce");
         const double tri = cm->world * (cm->world + 1) / 2.0;
         if (one[0] != tri + (double)round * cm->world || one[1] != (double)cm->world) throw Error(MFH_ERR_HIP, "communicator self-test: all-reduce gives a wrong sum");
         for (int i = 0; i < nLong; ++i)
@@ -1135,7 +1164,7 @@ mfh_status mfh_comm_preflight(mfh_ctx *c, mfh_comm *cm, int64_t messageBytes, do
     MFH_HIP(hipMemcpyAsync(slots.p, hs.data(), hs.size() * sizeof(double), hipMemcpyHostToDevice, s));
     comm_allreduce(cm, slots.p, world + 1, s);
     MFH_HIP(hipMemcpyAsync(hs.data(), slots.p, hs.size() * sizeof(double), hipMemcpyDeviceToHost, s));
-    MFH_HIP(hipStreamSynchronize(s));
+    sync_with_deadline(cm, s, "preflight");
     out[10] = hs[(size_t)world];
     out[11] = cm->peer.enabled ? 1.0 : 0.0;
     for (int r = 0; r < world; ++r) {
@@ -1167,10 +1196,10 @@ mfh_status mfh_comm_preflight(mfh_ctx *c, mfh_comm *cm, int64_t messageBytes, do
                 else base_exchange(cm, np, peers, sb, sc, rb, rc, s);
             };
             once();                                        // warm-up: first touch of the links / of the callbacks' staging
-            MFH_HIP(hipStreamSynchronize(s));
+            sync_with_deadline(cm, s, "preflight");
             const double t0 = now_ms();
             for (int k = 0; k < reps; ++k) once();
-            MFH_HIP(hipStreamSynchronize(s));
+            sync_with_deadline(cm, s, "preflight");
             return (double)(n * 8) * reps / ((now_ms() - t0) * 1e-3) / 1e9;
         };
         out[8] = timed(false);
