@@ -98,22 +98,24 @@ def test_multigrid_nonzero_dirichlet_values_options_and_graph_free_loop():
     c.close()
 
 
-def test_multigrid_orthotropic_field_and_periodic_cell_problems():
-    """BASELINE configs[3] in small: per-element orthotropic field, periodic DoF map, pinned node, six cell problems."""
+@pytest.mark.parametrize("deg,n", [(2, 6), (1, 16)])
+def test_multigrid_orthotropic_field_and_periodic_cell_problems(deg, n):
+    """BASELINE configs[3] in small: per-element orthotropic field, periodic DoF map, pinned node, six cell problems. Linear elements
+    (round 5: matrix-free operator, upper-triangle storage, the Galerkin product of the periodic lattice completed from the stored
+    triangle) on a grid whose lattice has more than two bins per axis."""
     from meshfem_amd import homogenization as H
-    n = 6
     V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
     P = grid.synthetic_orthotropic_field(len(T), 3, seed=1)
     res = {}
     for pre in (M.PRECOND_TWO_LEVEL, M.PRECOND_MULTIGRID):
-        sim = M.Simulator(T, V, 2)
+        sim = M.Simulator(T, V, deg)
         sim.ctx.material_ortho_field(P)
         sim.ctx.set_preconditioner(pre)
         sim.rtol = 1e-10
         w, infos = H.solve_cell_problems(sim)
         Ch = H.homogenized_elasticity_tensor(sim, w)
         assert all(i["converged"] for i in infos)
-        res[pre] = (np.asarray(Ch), max(i["iterations"] for i in infos), sim.ctx.precond_info()["note"])
+        res[pre] = (np.asarray(Ch), max(i["iterations"] for i in infos), sim.ctx.precond_info()["note"], sim.ctx.multigrid_levels() if pre == M.PRECOND_MULTIGRID else None)
         sim.ctx.close()
     assert np.abs(res[M.PRECOND_MULTIGRID][0] - res[M.PRECOND_TWO_LEVEL][0]).max() <= 1e-7 * np.abs(res[M.PRECOND_TWO_LEVEL][0]).max()
     assert res[M.PRECOND_MULTIGRID][1] < res[M.PRECOND_TWO_LEVEL][1], res
