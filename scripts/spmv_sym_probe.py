@@ -1,5 +1,7 @@
 """y = K x from the stored upper triangle (k_spmv_sym: the transposed half through global FP64 atomics) against k_spmv on both
-triangles, same mesh, same process. usage: spmv_sym_probe.py [grid=100] [degree=1]"""
+triangles, same mesh, same process. usage: spmv_sym_probe.py [grid=100] [degree=1] [order=reference|morton]
+order morton (round 5): the rows numbered along the Morton curve of the node positions through a bijective mfh_dof_map -- the order
+in which the transposed half of a row chunk would have the best chance to stay near the chunk."""
 import os
 import sys
 
@@ -12,8 +14,25 @@ from meshfem_amd import grid
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 deg = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+order = sys.argv[3] if len(sys.argv) > 3 else "reference"
 V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
 T = T.astype(np.int32)
+perm = None
+if order == "morton":
+    def part1by2(v):
+        v = v.astype(np.uint64) & np.uint64(0x1fffff)
+        v = (v | (v << np.uint64(32))) & np.uint64(0x1f00000000ffff)
+        v = (v | (v << np.uint64(16))) & np.uint64(0x1f0000ff0000ff)
+        v = (v | (v << np.uint64(8))) & np.uint64(0x100f00f00f00f00f)
+        v = (v | (v << np.uint64(4))) & np.uint64(0x10c30c30c30c30c3)
+        v = (v | (v << np.uint64(2))) & np.uint64(0x1249249249249249)
+        return v
+    c0 = M.Context(0); c0.mesh_build(T, V, deg); P = c0.node_positions(); c0.close()
+    q = np.minimum((P * n * 4).astype(np.int64), 4 * n)
+    key = part1by2(q[:, 0]) | (part1by2(q[:, 1]) << np.uint64(1)) | (part1by2(q[:, 2]) << np.uint64(2))
+    perm = np.empty(len(P), dtype=np.int32)
+    perm[np.argsort(key, kind="stable")] = np.arange(len(P), dtype=np.int32)
+print("row order:", order)
 res = {}
 x = None
 for storage in (0, 1, 0, 1):
@@ -21,6 +40,8 @@ for storage in (0, 1, 0, 1):
     c.set_option("matrix_storage", storage)
     c.set_option("matrix_free", 0)
     c.mesh_build(T, V, deg)
+    if perm is not None:
+        c.dof_map(perm, len(perm))
     c.material_isotropic(200.0, 0.35)
     c.assemble()
     if x is None:
