@@ -194,6 +194,17 @@ def cpu_baseline(deg, cpu_grid):
                     sample="%d^3 grid -> %d P%d tets; threaded Ke %.2fs + serial triplet push %.2fs + sumRepeated/CSC %.2fs"
                            % (n, len(T), deg, t["ke"], t["push"], t["compress"]))
         last = (n, V, T, Ap, Ai, Ax)
+        # the tuned host assembly beside the port (same Ke routine; no Ke array, no triplets, no sort: atomic adds into the known pattern):
+        # what the GPU figure should be read against if the CPU code were free to restructure the reference's loop too
+        try:
+            CO.assemble_fused(3, deg, en, V, D, nn, Ap, Ai)                    # (first touch of Ax, thread start-up)
+            Ax2, t2, missed = CO.assemble_fused(3, deg, en, V, D, nn, Ap, Ai)
+            best["tuned"] = dict(value=len(T) / t2, unit="elements/s", cores=CO.num_threads(), seconds=t2, kind="port, restructured",
+                                 max_rel_diff_vs_port=float(np.abs(Ax2 - Ax).max() / np.abs(Ax).max()), pruned_exact_zeros=int(missed),
+                                 note="Ke on the thread's stack (the port's routine), binary search + atomic add into the CSC pattern of the port's result")
+            del Ax2
+        except Exception as e:   # noqa: BLE001
+            best["tuned"] = dict(error="%s: %s" % (type(e).__name__, e))
         if t["total"] > 8.0:
             break
         del Ap, Ai, Ax

@@ -246,6 +246,56 @@ int64_t oracle_assemble_csc(int dim, int deg, int64_t nElem, const int32_t *elem
     return nnz <= cap ? nnz : -1;
 }
 
+/* A TUNED host assembly beside the port above (bench.py cpu_baseline.tuned): what a CPU code that is free to restructure the reference's
+ * loop would do -- the pattern is known (the CSC of the upper triangle the port produced), every thread computes the Ke of its elements on
+ * its stack and adds the entries straight into Ax (binary search of the row in the column, atomic add); no KeAll array, no triplets, no
+ * sort. Same Ke routine, same upper-triangle convention as oracle_push_triplets. Entries the port pruned as exact zeros are skipped
+ * (counted in *missed). Returns seconds. */
+double oracle_assemble_fused(int dim, int deg, int64_t nElem, const int32_t *elemNodes, int npe, const double *vertPos,
+                             const int32_t *dofForNode, const double *D, int64_t nD, const int64_t *Ap, const int64_t *Ai, double *Ax,
+                             int64_t n, int64_t *missed) {
+    const int ks = npe * dim, fl = dim * (dim + 1) / 2;
+    double t0 = now_s();
+    int64_t e, k, miss = 0;
+#pragma omp parallel for schedule(static)
+    for (k = 0; k < Ap[n]; ++k) Ax[k] = 0.0;
+#pragma omp parallel for schedule(static) reduction(+ : miss)
+    for (e = 0; e < nElem; ++e) {
+        double P[12], gl[12], Ke[30 * 30];
+        int a, i, j, ci, cj;
+        for (i = 0; i <= dim; ++i) for (a = 0; a < dim; ++a) P[i * dim + a] = vertPos[(int64_t)elemNodes[e * npe + i] * dim + a];
+        double vol = embed(dim, P, gl);
+        memset(Ke, 0, sizeof(double) * ks * ks);
+        per_element_stiffness(dim, deg, gl, vol, D + (nD == 1 ? 0 : e * fl * fl), Ke);
+        for (i = 0; i < npe; ++i) {
+            int64_t di = elemNodes[e * npe + i]; if (dofForNode) di = dofForNode[di];
+            for (j = 0; j < npe; ++j) {
+                int64_t dj = elemNodes[e * npe + j]; if (dofForNode) dj = dofForNode[dj];
+                if (di > dj) continue;
+                for (cj = 0; cj < dim; ++cj) {
+                    const int64_t col = dim * dj + cj;
+                    int64_t lo = Ap[col], hi = Ap[col + 1];
+                    for (ci = 0; ci < dim; ++ci) {
+                        const int64_t row = dim * di + ci;
+                        if (row > col) continue;
+                        const int r = dim * i + ci, c = dim * j + cj;
+                        const double val = (r <= c) ? Ke[r * ks + c] : Ke[c * ks + r];
+                        int64_t b = lo, t = hi;                 /* first index with Ai >= row */
+                        while (b < t) { int64_t m = (b + t) >> 1; if (Ai[m] < row) b = m + 1; else t = m; }
+                        if (b < hi && Ai[b] == row) {
+#pragma omp atomic
+                            Ax[b] += val;
+                        } else
+                            ++miss;
+                    }
+                }
+            }
+        }
+    }
+    if (missed) *missed = miss;
+    return now_s() - t0;
+}
+
 /* Extend-add of the multifrontal Cholesky (oracle/direct_solve.py). The parent's frontal matrix is kept as a panel
  * P ((ns + nb) x ns, row-major: the columns of the ns unknowns eliminated at this node) and the Schur-complement block
  * S (nb x nb, row-major). A child's update matrix U (nbc x nbc, symmetric, row-major) is added at the positions loc[]:

@@ -31,6 +31,7 @@ def load():
         _lib = C.CDLL(LIB)
         _lib.oracle_num_threads.restype = C.c_int
         _lib.oracle_assemble_csc.restype = C.c_int64
+        _lib.oracle_assemble_fused.restype = C.c_double
     return _lib
 
 
@@ -82,6 +83,26 @@ def assemble_csc(dim, deg, elem_nodes, vert_pos, D, n_dof, dof_for_node=None):
     if nnz < 0:
         raise RuntimeError("oracle_assemble_csc failed (%d)" % nnz)
     return Ap, Ai[:nnz].copy(), Ax[:nnz].copy(), dict(ke=times[0], push=times[1], compress=times[2], total=times[3])
+
+
+def assemble_fused(dim, deg, elem_nodes, vert_pos, D, n_dof, Ap, Ai, dof_for_node=None):
+    """The tuned host assembly (oracle_assemble_fused): Ke on the thread's stack, entries added atomically into the known CSC pattern
+    (Ap, Ai of assemble_csc). Returns (Ax, seconds, entries not in the pattern = exact zeros the port pruned)."""
+    lib = load()
+    en = np.ascontiguousarray(elem_nodes, np.int32)
+    vp = np.ascontiguousarray(vert_pos, np.float64)
+    D = np.ascontiguousarray(D, np.float64)
+    fl = dim * (dim + 1) // 2
+    nD = D.size // (fl * fl)
+    nE, npe = en.shape
+    Ap = np.ascontiguousarray(Ap, np.int64)
+    Ai = np.ascontiguousarray(Ai, np.int64)
+    Ax = np.empty(len(Ai))
+    missed = C.c_int64(0)
+    dm = None if dof_for_node is None else np.ascontiguousarray(dof_for_node, np.int32)
+    t = lib.oracle_assemble_fused(C.c_int(dim), C.c_int(deg), C.c_int64(nE), _p(en), C.c_int(npe), _p(vp), None if dm is None else _p(dm),
+                                  _p(D), C.c_int64(nD), _p(Ap), _p(Ai), _p(Ax), C.c_int64(dim * n_dof), C.byref(missed))
+    return Ax, t, missed.value
 
 
 def extend_add(P, S, U, loc, threads=1):

@@ -167,6 +167,9 @@ def test_cantilever_fixture_reproduced(deg):
     Ap, Ai, Ax, _ = CO.assemble_csc(3, deg, sim.mesh.elem_nodes, g["V"], sim.D[0].D, sim.mesh.num_nodes)
     C = sp.csc_matrix((Ax, Ai, Ap), shape=(n, n)).tocsr()
     assert abs(C - B).max() < 1e-12 * abs(B).max()
+    # ... and so does the restructured host assembly bench.py times beside it (cpu_baseline.tuned)
+    Ax2, _, _ = CO.assemble_fused(3, deg, sim.mesh.elem_nodes, g["V"], sim.D[0].D, sim.mesh.num_nodes, Ap, Ai)
+    assert np.abs(Ax2 - Ax).max() < 1e-13 * np.abs(Ax).max()
 
 
 EXAMPLE_BCS = {"cube_cross": (([-1e-3] * 3, [0.02, 1.001, 1.001]), ([0.98, -1e-3, -1e-3], [1.001] * 3), [0, -1, 0]),
