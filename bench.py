@@ -268,6 +268,22 @@ def hbm_stream_probe(torch, n_doubles=1 << 27, reps=10):
     return res
 
 
+def reserve_for(M, n, deg):
+    """mfh_device_reserve for a context on the n^3 grid, asynchronous, in TWO segments (the smaller one first: a reservation is a no-op when a
+    free chunk of its size exists): 43 % for the K values (40 % of a quadratic context) and the rest. One segment for everything puts the K
+    values and every other buffer into one physical run, and the assembly kernel then sits at the slow end of its placement spread on every
+    box (3.27-3.29 ms at configs[2] against 2.89-3.2 with the values in an allocation of their own: profiles/r05_where_the_K_values_lie.txt).
+    MFH_BENCH_RESERVE_SPLIT=0 asks for one segment."""
+    total = int((3.6e3 if deg == 2 else 0.9e3) * 24 * n ** 3)
+    split = float(os.environ.get("MFH_BENCH_RESERVE_SPLIT", "0.43"))
+    if 0 < split < 0.5:
+        M.device_reserve(int(total * split), 0)
+        M.device_reserve(int(total * (1 - split)), 0)
+    else:
+        M.device_reserve(total, 0)
+    return total
+
+
 def run_single(args):
     import torch
     import meshfem_amd as M
@@ -279,6 +295,13 @@ def run_single(args):
     strong_first = None
     if not strong and not args.no_strong_n1 and deg == 2:
         strong_first = run_leg_subprocess(args, "strong_n1")
+    # "reserve once", as in the strong_n1 leg: the memory of this leg (3.6 kB per quadratic tet) is asked for before anything else happens in
+    # the process, on a thread of the library: what the driver has to clear first -- the process before this one returned 146 GB -- is cleared
+    # while torch starts, the bandwidth probe runs and the mesh is generated (2.85 s inside the symbolic phase's hipMalloc otherwise,
+    # profiles/r05_bench_n1_without_reservation_after_the_119_leg.json)
+    reserve_main = 0
+    if not os.environ.get("MFH_BENCH_NO_RESERVE"):
+        reserve_main = reserve_for(M, n, deg)
     torch.cuda.set_device(0)
     hbm_measured = hbm_stream_probe(torch)
     if strong:      # one 40 M-element context: no room (and no point) for the storage / ordering variants next to it
@@ -349,6 +372,7 @@ def run_single(args):
                           # the timed step excludes what a one-shot caller pays once per mesh -- FEMMesh build (edge numbering,
                           # boundary extraction, node table; includes the upload), symbolic phase (pattern + gather lists), first pass
                           first_assembly_ms=(t_build + t_sym + t_first) * 1e3, first_assembly_elements_per_s=nE / (t_build + t_sym + t_first),
+                          reservation="mfh_device_reserve(%.1f GB in two segments, asynchronous) at process start" % (reserve_main / 1e9) if reserve_main else "none",
                           **c.timing(), **c.symbolic_sizes()))
     # comparison variant: element-major global-atomic scatter (north_star: "colored or atomic ... by evidence")
     try:
@@ -801,10 +825,8 @@ def strong_n1(args, torch, n=119):
     # "reserve once" (LinearElasticity.hh:1441-1443): the caller knows its mesh size before it has the mesh -- 3.6 kB of device memory per
     # quadratic tet cover assembly + multigrid solve -- and asks for it FIRST, asynchronously: the driver hands the memory out (and, on a
     # box nobody has used since boot, clears it: 2-3 s, profiles/r05_large_allocation_trace_119.log) while the mesh is being generated
-    reserve = int((3.6e3 if deg == 2 else 0.9e3) * 24 * n ** 3) if not os.environ.get("MFH_BENCH_NO_RESERVE") else 0
     t_res = time.time()
-    if reserve:
-        M.device_reserve(reserve, 0)
+    reserve = reserve_for(M, n, deg) if not os.environ.get("MFH_BENCH_NO_RESERVE") else 0
     V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
     T = np.ascontiguousarray(T, dtype=np.int32)
     c = M.Context(0)
@@ -831,7 +853,7 @@ def strong_n1(args, torch, n=119):
                setup=dict(femmesh_build_s=t_build, symbolic_s=t_sym, first_assemble_call_s=t_first,
                           first_assembly_ms=(t_build + t_sym + t_first) * 1e3, first_assembly_elements_per_s=nE / (t_build + t_sym + t_first),
                           device_memory_reserved_GB=reserve / 1e9,
-                          reservation="mfh_device_reserve(%.1f GB, asynchronous) issued before the mesh generation (outside the timed phases, like process "
+                          reservation="mfh_device_reserve(%.1f GB in two segments, asynchronous) issued before the mesh generation (outside the timed phases, like process "
                                       "start-up); MFH_BENCH_NO_RESERVE=1 runs without" % (reserve / 1e9) if reserve else "none"))
     if not args.no_solve:
         c.set_preconditioner(M.PRECOND_MULTIGRID)

@@ -167,6 +167,8 @@ PROTOTYPES = {
     "mfh_debug_device_node_tables": (_i32, [_P, _P, _P]),
     "mfh_debug_arena_alloc": (_i32, [_P, _i64, C.POINTER(_P)]),
     "mfh_debug_arena_free": (_i32, [_P, _P]),
+    "mfh_debug_move_buffer": (_i32, [_P, _i32]),
+    "mfh_debug_adopt_vals": (_i32, [_P, _P]),
     "mfh_debug_row_chunks": (_i32, [_i64, _P, _i32, _i64, _P, _i64, _i32, _P, _i64, _P]),
 }
 

@@ -2094,6 +2094,43 @@ mfh_status mfh_debug_arena_free(mfh_ctx *c, void *p) {
     MFH_CATCH(c)
 }
 
+// Experiment hook (scripts/buffer_move_probe.py): one of the assembly kernel's large buffers moves into a newly allocated buffer (contents
+// copied); the old one is held until the context is destroyed, so the new one cannot be the same memory. which: 0 K values, 1 gather codes,
+// 2 gather slots, 3 element records, 4 column indices.
+static std::vector<void *> g_debugHeld;
+mfh_status mfh_debug_move_buffer(mfh_ctx *c, int32_t which) {
+    MFH_TRY(c)
+    require(c && !c->hostOnly && c->symValid, MFH_ERR_INVALID, "mfh_debug_move_buffer: needs a symbolic phase");
+    MFH_HIP(hipSetDevice(c->device));
+    void **pp = nullptr;
+    size_t bytes = 0;
+    switch (which) {
+    case 0: pp = (void **)&c->dVals.p; bytes = c->dVals.n * sizeof(double); break;
+    case 1: pp = (void **)&c->dContribCode.p; bytes = c->dContribCode.n * sizeof(uint32_t); break;
+    case 2: pp = (void **)&c->dContribSlot.p; bytes = c->dContribSlot.n * sizeof(uint16_t); break;
+    case 3: pp = (void **)&c->dGeo.p; bytes = c->dGeo.n * sizeof(double); break;
+    case 4: pp = (void **)&c->dColIdx.p; bytes = c->dColIdx.n * sizeof(int32_t); break;
+    default: throw Error(MFH_ERR_INVALID, "mfh_debug_move_buffer: which");
+    }
+    require(*pp && bytes, MFH_ERR_STATE, "mfh_debug_move_buffer: empty buffer");
+    void *fresh = mfh::device_alloc(bytes);
+    MFH_HIP(hipMemcpyAsync(fresh, *pp, bytes, hipMemcpyDeviceToDevice, c->stream));
+    MFH_HIP(hipStreamSynchronize(c->stream));
+    g_debugHeld.push_back(*pp);
+    *pp = fresh;
+    MFH_CATCH(c)
+}
+
+// Experiment hook (scripts/vmm_probe.py): the K values move into a buffer the CALLER allocated (at least dVals.n doubles); the old one is held.
+mfh_status mfh_debug_adopt_vals(mfh_ctx *c, void *p) {
+    MFH_TRY(c)
+    require(c && !c->hostOnly && c->symValid && p && c->dVals.p, MFH_ERR_INVALID, "mfh_debug_adopt_vals: needs a symbolic phase");
+    g_debugHeld.push_back(c->dVals.p);
+    c->dVals.p = (double *)p;
+    c->assembled = false;
+    MFH_CATCH(c)
+}
+
 mfh_status mfh_debug_spd_inverse_device(mfh_ctx *c, int64_t n, double *A) {
     MFH_TRY(c)
     require(c && A && n > 0, MFH_ERR_INVALID, "bad arguments");

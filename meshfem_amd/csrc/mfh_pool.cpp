@@ -25,6 +25,8 @@
 #include <mutex>
 #include <set>
 #include <thread>
+#include <atomic>
+#include <cstring>
 #include <unordered_map>
 #include <vector>
 
@@ -38,6 +40,82 @@ constexpr size_t ALIGN = 256;
 constexpr size_t SMALL_REQUEST = (size_t)1 << 20;
 constexpr size_t SMALL_SEGMENT = (size_t)64 << 20;
 constexpr size_t SEGMENT_ROUND = (size_t)2 << 20;
+// Experiment knobs (scripts/layout_probe.sh): granularity of the LARGE class inside a segment and a stagger added to successive large requests,
+// so that the buffers of a context cut from ONE segment do not all start on 2 MiB boundaries of the same physical run.
+// Where the segments come from. MFH_ARENA_ALLOC = "plain" (hipMalloc), "contiguous" (hipExtMallocWithFlags, hipDeviceMallocContiguous),
+// "vmm" (hipMemCreate + hipMemMap: one physical allocation per segment mapped into a reserved address range). Experiment: scripts/vmm_probe.py.
+int alloc_kind() {
+    static const int k = [] {
+        const char *e = getenv("MFH_ARENA_ALLOC");
+        if (!e) return 0;
+        if (!strcmp(e, "contiguous")) return 1;
+        if (!strcmp(e, "vmm")) return 2;
+        return 0;
+    }();
+    return k;
+}
+std::unordered_map<void *, size_t> g_vmm;     // segments mapped through the virtual-memory API: base -> mapped bytes (under g_mu or single-threaded use)
+std::mutex g_vmmMu;
+hipError_t seg_malloc(void **p, size_t bytes) {
+    static const size_t minBytes = [] { const char *e = getenv("MFH_ARENA_ALLOC_MIN_MB"); const long v = e ? atol(e) : 0; return (size_t)(v > 0 ? v : 64) << 20; }();
+    static const size_t maxBytes = [] { const char *e = getenv("MFH_ARENA_ALLOC_MAX_MB"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v << 20 : ~(size_t)0; }();
+    const int kind = (bytes >= minBytes && bytes <= maxBytes) ? alloc_kind() : 0;
+    if (kind == 1) {
+        const hipError_t e = hipExtMallocWithFlags(p, bytes, hipDeviceMallocContiguous);
+        if (e == hipSuccess) return e;
+        (void)hipGetLastError();
+        return hipMalloc(p, bytes);
+    }
+    if (kind == 2) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        hipMemAllocationProp prop = {};
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) == hipSuccess && gran) {
+            const size_t total = (bytes + gran - 1) / gran * gran;
+            void *base = nullptr;
+            hipMemGenericAllocationHandle_t h;
+            if (hipMemAddressReserve(&base, total, (size_t)2 << 20, nullptr, 0) == hipSuccess) {
+                if (hipMemCreate(&h, total, &prop, 0) == hipSuccess) {
+                    hipMemAccessDesc acc = {};
+                    acc.location.type = hipMemLocationTypeDevice;
+                    acc.location.id = dev;
+                    acc.flags = hipMemAccessFlagsProtReadWrite;
+                    if (hipMemMap(base, total, 0, h, 0) == hipSuccess && hipMemSetAccess(base, total, &acc, 1) == hipSuccess) {
+                        (void)hipMemRelease(h);
+                        std::lock_guard<std::mutex> lk(g_vmmMu);
+                        g_vmm[base] = total;
+                        *p = base;
+                        return hipSuccess;
+                    }
+                    (void)hipMemRelease(h);
+                }
+                (void)hipMemAddressFree(base, total);
+            }
+        }
+        (void)hipGetLastError();
+        return hipMalloc(p, bytes);
+    }
+    return hipMalloc(p, bytes);
+}
+hipError_t seg_free(void *p) {
+    size_t total = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_vmmMu);
+        auto it = g_vmm.find(p);
+        if (it != g_vmm.end()) { total = it->second; g_vmm.erase(it); }
+    }
+    if (!total) return hipFree(p);
+    (void)hipDeviceSynchronize();
+    hipError_t e = hipMemUnmap(p, total);
+    if (e == hipSuccess) e = hipMemAddressFree(p, total);
+    return e;
+}
+size_t large_gran() { static const size_t g = [] { const char *e = getenv("MFH_ARENA_GRAN_KB"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v << 10 : SEGMENT_ROUND; }(); return g; }
+size_t large_stagger() { static const size_t g = [] { const char *e = getenv("MFH_ARENA_STAGGER_KB"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v << 10 : (size_t)0; }(); return g; }
 
 struct Chunk {
     size_t bytes;
@@ -130,7 +208,7 @@ template <class Pred> size_t release_free_segments(Arena &A, Pred keepGoing) {
         A.held -= bestBytes;
         A.returnedBytes += bestBytes;
         done += bestBytes;
-        (void)hipFree(best);
+        (void)seg_free(best);
     }
     return done;
 }
@@ -169,12 +247,13 @@ void *device_alloc(size_t bytes) {
     int dev = 0;
     MFH_HIP(hipGetDevice(&dev));
     const int cls = bytes < SMALL_REQUEST ? 0 : 1;
-    bytes = cls == 0 ? (bytes + ALIGN - 1) & ~(ALIGN - 1) : (bytes + SEGMENT_ROUND - 1) & ~(SEGMENT_ROUND - 1);
+    if (cls == 1 && large_stagger()) { static std::atomic<unsigned> turn{0}; bytes += (size_t)(turn.fetch_add(1) % 8u) * large_stagger(); }
+    bytes = cls == 0 ? (bytes + ALIGN - 1) & ~(ALIGN - 1) : (bytes + large_gran() - 1) / large_gran() * large_gran();
     std::unique_lock<std::mutex> lock(g_mu);
     Arena &A = arena_of(dev);
     if (!A.enabled) {
         void *p = nullptr;
-        const hipError_t e = hipMalloc(&p, bytes);
+        const hipError_t e = seg_malloc(&p, bytes);
         if (e != hipSuccess) { (void)hipGetLastError(); throw Error(MFH_ERR_HIP, std::string("hipMalloc of ") + std::to_string(bytes >> 20) + " MiB: " + hipGetErrorString(e)); }
         return p;
     }
@@ -194,8 +273,8 @@ void *device_alloc(size_t bytes) {
         static const bool trace = getenv("MFH_POOL_TRACE") != nullptr;
         const double tTrace = trace ? now_ms() : 0.0;
         void *p = nullptr;
-        hipError_t e = hipMalloc(&p, segBytes);
-        if (e != hipSuccess && segBytes > bytes) { (void)hipGetLastError(); segBytes = bytes; e = hipMalloc(&p, segBytes); }
+        hipError_t e = seg_malloc(&p, segBytes);
+        if (e != hipSuccess && segBytes > bytes) { (void)hipGetLastError(); segBytes = bytes; e = seg_malloc(&p, segBytes); }
         if (e != hipSuccess) {
             // the driver is out of memory: what the arena holds but does not use goes back, then once more
             (void)hipGetLastError();
@@ -203,7 +282,7 @@ void *device_alloc(size_t bytes) {
             ++A.flushes;
             release_free_segments(A, [] { return true; });
             fit = freeBySize.lower_bound({bytes, nullptr});      // (the quarantine may have completed a chunk that fits)
-            if (fit == freeBySize.end()) e = hipMalloc(&p, segBytes);
+            if (fit == freeBySize.end()) e = seg_malloc(&p, segBytes);
             else e = hipSuccess, p = nullptr;
         }
         if (e != hipSuccess) {
@@ -237,7 +316,7 @@ void device_free(void *p) {
     auto own = g_owner.find(p);
     if (own == g_owner.end()) {            // allocated with the arena disabled
         lock.unlock();
-        (void)hipFree(p);
+        (void)seg_free(p);
         return;
     }
     const int dev = own->second;           // the chunk goes back to the arena of the device it lives on, whatever the caller's current device
@@ -265,7 +344,7 @@ void device_free(void *p) {
             A.held -= bytes;
             A.returnedBytes += bytes;
             lock.unlock();
-            (void)hipFree(p);
+            (void)seg_free(p);
             return;
         }
         A.quarantine.emplace_back((char *)p, bytes);
@@ -318,7 +397,7 @@ void device_arena_reserve(int dev, size_t bytes, bool async) {
         void *p = nullptr;
         const double t0 = now_ms();
         hipError_t e = hipSetDevice(dev);
-        if (e == hipSuccess) e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) e = seg_malloc(&p, bytes);
         if (e != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
         std::lock_guard<std::mutex> lock(g_mu);
         Arena &A = g_arena[dev];
