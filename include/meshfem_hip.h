@@ -431,9 +431,8 @@ mfh_status  mfh_dev_memcpy(mfh_ctx* ctx, void* dst, const void* src, int64_t byt
  * follows large hipFree calls of the same process takes seconds (profiles/r04_malloc_probe.txt), and the setup phases of a context allocate
  * and release several times the memory they keep. The reference reserves its triplet storage once (LinearElasticity.hh:1441-1443).
  * Bounds: free bytes kept while contexts are alive <= MFH_DEVICE_CACHE_MB (default half of the device's memory; 0 = plain hipMalloc /
- * hipFree); mfh_destroy trims the arena to the high-water mark of its live bytes, and when the LAST context of a device closes to at most
- * MFH_DEVICE_CACHE_IDLE_MB of free memory (default an eighth of the device), so that other allocators of the process (torch, RCCL) find the
- * rest. A request the driver cannot serve releases every free segment and is repeated. mfh_device_cache_trim returns every free segment to
+ * hipFree); when the LAST context of a device closes the arena is trimmed to at most MFH_DEVICE_CACHE_IDLE_MB of free memory (default a
+ * quarter of the device), so that other allocators of the process (torch, RCCL) find the rest. A request the driver cannot serve releases every free segment and is repeated. mfh_device_cache_trim returns every free segment to
  * the driver at once. mfh_device_arena_stats: out8 = {bytes held, live bytes, live high-water mark, segments, free chunks, bytes returned
  * to the driver so far, bytes waiting for a device-wide synchronisation, bound on the free bytes}. */
 /* mfh_device_reserve: ONE segment of `bytes` taken from the driver now and kept as free space of the arena -- the reference's "reserve once"
@@ -441,7 +440,11 @@ mfh_status  mfh_dev_memcpy(mfh_ctx* ctx, void* dst, const void* src, int64_t byt
  * multigrid solve, 0.9 kB per linear tet). Contexts created afterwards cut their buffers from it: no call to the driver during their
  * setup. With async != 0 the call returns at once and the allocation runs on a thread of its own (e.g. while the caller reads its mesh);
  * the library's next allocation that finds nothing waits for it. Worth it on a device nobody has used since boot, where the driver
- * clears the memory a process takes beyond the first ~66 GB while it is being allocated (profiles/r05_large_allocation_trace_119.log). */
+ * clears the memory a process takes beyond the first ~66 GB while it is being allocated (profiles/r05_large_allocation_trace_119.log).
+ * Ask for the memory in TWO calls, the smaller first (a call is a no-op when a free chunk of its size exists): ~43 % for the values of K
+ * (40 % of a quadratic context) and the rest. With everything in ONE hipMalloc the values and all other buffers lie in one physical run, and the
+ * assembly kernel then runs at the slow end of its placement spread (24.4 against 22.6 ms per launch at 40 M quadratic tets;
+ * docs/design/04_2_k_assemble_gather.md (xi)). */
 mfh_status mfh_device_reserve(int32_t device, int64_t bytes, int32_t async);
 mfh_status mfh_device_cache_trim(void);
 mfh_status mfh_device_cache_stats(int32_t device, int64_t* cachedBytes, int64_t* blocks, int64_t* hits, int64_t* misses, int64_t* flushes);
