@@ -40,10 +40,9 @@ constexpr size_t ALIGN = 256;
 constexpr size_t SMALL_REQUEST = (size_t)1 << 20;
 constexpr size_t SMALL_SEGMENT = (size_t)64 << 20;
 constexpr size_t SEGMENT_ROUND = (size_t)2 << 20;
-// Experiment knobs (scripts/layout_probe.sh): granularity of the LARGE class inside a segment and a stagger added to successive large requests,
-// so that the buffers of a context cut from ONE segment do not all start on 2 MiB boundaries of the same physical run.
-// Where the segments come from. MFH_ARENA_ALLOC = "plain" (hipMalloc), "contiguous" (hipExtMallocWithFlags, hipDeviceMallocContiguous),
-// "vmm" (hipMemCreate + hipMemMap: one physical allocation per segment mapped into a reserved address range). Experiment: scripts/vmm_probe.py.
+// Experiment knob: where the segments come from. MFH_ARENA_ALLOC = "plain" (hipMalloc, the default), "contiguous" (hipExtMallocWithFlags, hipDeviceMallocContiguous),
+// "vmm" (hipMemCreate + hipMemMap: one physical allocation per segment mapped into a reserved address range), for segments of MFH_ARENA_ALLOC_MIN_MB ... _MAX_MB. Measured in docs/design/04_2_k_assemble_gather.md (xi):
+// contiguous memory is the WORST home for the K values and for the solver's vectors; nothing in the product path sets these.
 int alloc_kind() {
     static const int k = [] {
         const char *e = getenv("MFH_ARENA_ALLOC");
@@ -114,6 +113,8 @@ hipError_t seg_free(void *p) {
     if (e == hipSuccess) e = hipMemAddressFree(p, total);
     return e;
 }
+// Experiment knobs (scripts/layout_probe.sh; no effect measured, docs/design/04_2 (xi)): granularity of the LARGE class inside a segment and a stagger added to successive large requests,
+// so that the buffers of a context cut from ONE segment do not all start on 2 MiB boundaries of the same physical run.
 size_t large_gran() { static const size_t g = [] { const char *e = getenv("MFH_ARENA_GRAN_KB"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v << 10 : SEGMENT_ROUND; }(); return g; }
 size_t large_stagger() { static const size_t g = [] { const char *e = getenv("MFH_ARENA_STAGGER_KB"); const long v = e ? atol(e) : 0; return v > 0 ? (size_t)v << 10 : (size_t)0; }(); return g; }
 
