@@ -381,6 +381,34 @@ def run_single(args):
         c.assemble()
     except M.MeshFEMHipError as e:
         out["variants"] = dict(atomic_scatter=str(e))
+    # option placement_trials (off by default): the same workload on a second context that auditions three more buffers for the K values at its
+    # first assembly -- what a caller that assembles hundreds of times can buy, and what it costs the first assembly
+    # (docs/design/04_2_k_assemble_gather.md (xi): the kernel's time follows where the driver put the values)
+    if not strong and not args.no_orderings:
+        try:
+            cp = M.Context(0)
+            cp.set_option("placement_trials", 3)
+            t0 = time.time(); cp.mesh_build(T, V, deg); tbp = time.time() - t0
+            cp.material_isotropic(200.0, 0.35)
+            t0 = time.time(); cp.symbolic(False); ts = time.time() - t0
+            cp.set_option("reembed", 1)
+            t0 = time.time(); cp.assemble(); cp.dev_sync(); tf = time.time() - t0
+            for _ in range(args.warmup):
+                cp.assemble()
+            cp.dev_sync()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                cp.assemble()
+            cp.dev_sync()
+            dtp = (time.perf_counter() - t0) / args.steps
+            kp = cp.time_assembly_kernel(M.ASSEMBLE_GATHER, max(3, args.steps))
+            out["variants"]["placement_trials_3"] = dict(kernel_ms=kp, ms_per_step=dtp * 1e3, elements_per_s=nE / dtp, candidates_kernel_ms=cp.placement_info(),
+                                                         first_assembly_ms=(tbp + ts + tf) * 1e3, first_assemble_call_ms=tf * 1e3,
+                                                         frac_traffic=None if tb is None else tb / kp / 1e6 / HBM_PEAK_GBS,
+                                                         note="option placement_trials 3 (library default 0): the headline above is the default")
+            cp.close()
+        except Exception as e:   # noqa: BLE001 -- never lose the line over a variant
+            out["variants"]["placement_trials_3"] = dict(error="%s: %s" % (type(e).__name__, e))
     if not args.no_solve and strong:
         # the N = 1 point of the strong-scaling curve: the solver the N > 1 runs use (two-level PCG), time to rtol
         c.set_preconditioner(M.PRECOND_TWO_LEVEL)

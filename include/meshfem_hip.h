@@ -446,6 +446,8 @@ mfh_status  mfh_dev_memcpy(mfh_ctx* ctx, void* dst, const void* src, int64_t byt
  * assembly kernel then runs at the slow end of its placement spread (24.4 against 22.6 ms per launch at 40 M quadratic tets;
  * docs/design/04_2_k_assemble_gather.md (xi)). */
 mfh_status mfh_device_reserve(int32_t device, int64_t bytes, int32_t async);
+/* option "placement_trials": kernel time (ms) of every candidate of the last trials, the first being the buffer of the symbolic phase; *n = how many */
+mfh_status mfh_placement_info(const mfh_ctx* ctx, int32_t cap, double* ms, int32_t* n);
 mfh_status mfh_device_cache_trim(void);
 mfh_status mfh_device_cache_stats(int32_t device, int64_t* cachedBytes, int64_t* blocks, int64_t* hits, int64_t* misses, int64_t* flushes);
 mfh_status mfh_device_arena_stats(int32_t device, int64_t* out8);
@@ -477,6 +479,10 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
  *   multiplies by the stored K (elasticity on the matrix-free operator), both triangles otherwise; changing an option that
  *   decides this re-runs the symbolic phase on the next use. mfh_matrix_info / mfh_export_bsr describe K itself either way,
  *   mfh_matrix_storage what is stored),
+ * "placement_trials" (0 default; N <= 8: at the first gather-mode assembly after a symbolic phase the buffer of the K values is allocated up to N more
+ *   times, the assembly kernel timed on each (two passes), and the fastest kept -- where the driver puts these bytes moves the kernel between
+ *   2.9 and 3.3 ms at 5 M quadratic tets, docs/design/04_2_k_assemble_gather.md (xi); costs ~10 ms and one more buffer of the size of K per trial,
+ *   once per symbolic phase: for callers that assemble hundreds of times on one mesh. mfh_placement_info reads the candidates' times),
  * "pcg_variant" (1: Chronopoulos-Gear PCG, one reduction point per iteration and one fused vector kernel -- always used by
  *   mfh_dist_solve and for batches; 0: the classic two-reduction PCG, one right-hand side at a time; -1 default: classic for
  *   a single right-hand side on an unpartitioned context, where it is 6-14 % faster per iteration), "dist_pcg_variant"

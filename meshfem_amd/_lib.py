@@ -165,6 +165,7 @@ PROTOTYPES = {
     "mfh_debug_spd_inverse": (_i32, [_i64, _P]),
     "mfh_debug_spd_inverse_device": (_i32, [_P, _i64, _P]),
     "mfh_debug_device_node_tables": (_i32, [_P, _P, _P]),
+    "mfh_placement_info": (_i32, [_P, _i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
     "mfh_debug_arena_alloc": (_i32, [_P, _i64, C.POINTER(_P)]),
     "mfh_debug_arena_free": (_i32, [_P, _P]),
     "mfh_debug_move_buffer": (_i32, [_P, _i32]),

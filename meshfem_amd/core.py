@@ -308,6 +308,13 @@ class Context:
         self._ck(self.lib.mfh_multigrid_info(self.h, C.byref(a), C.byref(b), C.byref(l0), C.byref(l1), C.byref(t)))
         return dict(fine_dof=a.value, coarse_dof=b.value, lambda_max_fine=l0.value, lambda_max_coarse=l1.value, setup_ms=t.value)
 
+    def placement_info(self):
+        """Kernel time (ms) of every candidate of the last placement trials (option placement_trials); [] when none ran."""
+        out = (C.c_double * 16)()
+        n = C.c_int32()
+        self._ck(self.lib.mfh_placement_info(self.h, 16, out, C.byref(n)))
+        return [float(out[k]) for k in range(min(16, n.value))]
+
     def multigrid_levels(self):
         """Aggregate levels of the multigrid hierarchy, finest first (mfh_multigrid_level_info)."""
         out = (C.c_int64 * (7 * 16))()

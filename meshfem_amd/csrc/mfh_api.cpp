@@ -258,6 +258,7 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
         if (getenv("MFH_SYM_TIMING")) fprintf(stderr, "[symbolic] value array %.1f MB: allocation %.2f ms\n", tilesD * 64.0 * c->dim() * c->dim() * 8 / 1e6, now_ms() - tV);
         c->symValid = true;
         ++c->listsGen;
+        ++c->valsGen;
         invalidate_matrix(c);
         return;
     }
@@ -285,6 +286,7 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
     c->dVals.alloc(tiles * 64 * (size_t)c->dim() * c->dim());
     c->symValid = true;
     ++c->listsGen;
+    ++c->valsGen;
     invalidate_matrix(c);
 }
 
@@ -345,6 +347,45 @@ void run_assembly(mfh_ctx *c, int mode) {
     }
 }
 
+// Option "placement_trials": see mfh_ctx::placementTrials. Called after a gather-mode pass has written K into c->dVals. Every trial takes a
+// values buffer from the arena while the earlier candidates are still held (so it is other memory), writes K into it with two timed passes
+// and keeps it when it is at least 1 % faster than the best so far; the losers go back to the arena at the end. Trials stop when the device
+// has less than twice the buffer free. Whatever happens, c->dVals holds a completely assembled K afterwards.
+void placement_trials(mfh_ctx *c) {
+    c->placementGen = c->valsGen;
+    c->placementMs.clear();
+    const size_t n = c->dVals.n, bytes = n * sizeof(double);
+    if (c->placementTrials <= 0 || c->hostOnly || c->external || bytes < ((size_t)256 << 20)) return;
+    auto timed = [&]() {
+        k::AsmArgs a = asm_args(c);
+        double best = 1e300;
+        for (int r = 0; r < 2; ++r) {
+            EventTimer t(c->stream);
+            k::launch_assemble_gather(a, c->stream);
+            best = std::min(best, t.stop());
+        }
+        return best;
+    };
+    double best = timed();
+    c->placementMs.push_back(best);
+    std::vector<std::unique_ptr<DBuf<double>>> held;
+    for (int trial = 0; trial < c->placementTrials; ++trial) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (fr < 2 * bytes + ((size_t)1 << 30)) break;
+        std::unique_ptr<DBuf<double>> alt(new DBuf<double>());
+        alt->alloc(n);
+        alt->zero(c->stream);              // (the padding of the last tile is never read; zero all the same)
+        c->dVals.swap(*alt);               // dVals = candidate, alt = best so far
+        const double t = timed();
+        c->placementMs.push_back(t);
+        if (t < 0.99 * best) best = t;
+        else c->dVals.swap(*alt);          // back to the best so far (it still holds the K of its own passes)
+        held.push_back(std::move(alt));
+    }
+    // (held buffers are released here, inside the API scope of the caller: they become free chunks of the arena)
+}
+
 void ensure_assembled(mfh_ctx *c) {
     if (c->assembled) return;
     require(!c->external, MFH_ERR_STATE, "no matrix set");
@@ -354,6 +395,7 @@ void ensure_assembled(mfh_ctx *c) {
     EventTimer t(c->stream);
     run_assembly(c, MFH_ASSEMBLE_GATHER);
     c->timing.assemble_ms = t.stop();
+    if (c->placementTrials > 0 && c->placementGen != c->valsGen) placement_trials(c);
     c->assembled = true;
     c->dinvValid = false;
 }
@@ -1512,6 +1554,7 @@ mfh_status mfh_assemble(mfh_ctx *c, int32_t mode) {
     float ms = 0;
     MFH_HIP(hipEventElapsedTime(&ms, c->passEv[2], c->passEv[3]));
     c->timing.assemble_ms = ms;
+    if (mode == MFH_ASSEMBLE_GATHER && c->placementTrials > 0 && c->placementGen != c->valsGen) placement_trials(c);
     c->assembled = true;
     c->dinvValid = false;
     MFH_CATCH(c)
@@ -2094,6 +2137,14 @@ mfh_status mfh_debug_arena_free(mfh_ctx *c, void *p) {
     MFH_CATCH(c)
 }
 
+// kernel time of every candidate of the last placement trials (option "placement_trials"), the first being the buffer of the symbolic phase
+mfh_status mfh_placement_info(const mfh_ctx *c, int32_t cap, double *ms, int32_t *n) {
+    if (!c || !n) return MFH_ERR_INVALID;
+    *n = (int32_t)c->placementMs.size();
+    for (int32_t k = 0; ms && k < cap && k < *n; ++k) ms[k] = c->placementMs[(size_t)k];
+    return MFH_OK;
+}
+
 // Experiment hook (scripts/buffer_move_probe.py): one of the assembly kernel's large buffers moves into a newly allocated buffer (contents
 // copied); the old one is held until the context is destroyed, so the new one cannot be the same memory. which: 0 K values, 1 gather codes,
 // 2 gather slots, 3 element records, 4 column indices.
@@ -2171,6 +2222,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "mg_ratio_fine") { require(value > 0 && value < 1, MFH_ERR_INVALID, "mg_ratio_fine must lie in (0, 1)"); c->mgRatio0 = value; }
     else if (k2 == "mg_ratio_coarse") { require(value > 0 && value < 1, MFH_ERR_INVALID, "mg_ratio_coarse must lie in (0, 1)"); c->mgRatio1 = value; }
     else if (k2 == "mg_coarse_cycles") c->mgCoarseCycles = std::max(1, (int)value);
+    else if (k2 == "placement_trials") { c->placementTrials = std::max(0, std::min(8, (int)value)); c->placementGen = -1; }
     else if (k2 == "mg_eig_margin") { require(value >= 1.0, MFH_ERR_INVALID, "mg_eig_margin must be >= 1"); c->mgEigMargin = value; c->mg.valid = false; }
     else if (k2 == "mg_agg_target") { c->mgAggTarget = std::max(0, (int)value); c->mg.valid = false; }
     else if (k2 == "mg_coarse_fp32") { c->mgCoarseFp32 = value != 0; c->mg.valid = false; }

@@ -122,6 +122,12 @@ struct mfh_ctx {
 
     // ---- numeric
     DBuf<double> dVals;
+    // Option "placement_trials" (0 default): at the first assembly after a symbolic phase the values buffer is allocated up to N more times and
+    // the assembly kernel timed on each; the fastest stays. Where the driver puts these bytes moves the kernel between 2.9 and 3.3 ms at 5 M
+    // quadratic tets (docs/design/04_2_k_assemble_gather.md (xi)); a caller that assembles hundreds of times may want to pay ~10 ms per trial once.
+    int placementTrials = 0;
+    int64_t valsGen = 0, placementGen = -1;       // values buffer (re)allocated by the symbolic phase / generation the trials ran for
+    std::vector<double> placementMs;              // kernel time on every candidate of the last trials (first = the buffer of the symbolic phase)
     DBuf<float> dVals32;              // FP32 copy of dVals for the smoother of a multigrid linear level (built by ensure_multigrid, dropped whenever dVals is rewritten)
     bool assembled = false;
 

@@ -185,3 +185,41 @@ def test_reservation_arrives_asynchronously_and_serves_the_context():
     assert M.device_arena_stats(0)["held_bytes"] == s2["held_bytes"]
     c.close()
     keep.close()
+
+
+def test_placement_trials_keep_a_complete_K_and_report_their_times():
+    """Option placement_trials: the values buffer is allocated N more times at the first assembly, the kernel timed on every candidate and the
+    fastest kept. Whatever candidate stays, K is the K of a context without trials (same upper triplets, values to rounding), later
+    assemblies do not repeat the trials, a new symbolic phase does."""
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    V, T = grid.grid_tet_mesh(24, 24, 24, [0, 0, 0], [1, 1, 1])        # 331 776 quadratic tets: 480 MB of values (the trials skip buffers below 256 MB)
+    ref = None
+    for trials in (0, 3):
+        c = M.Context(0)
+        c.set_option("placement_trials", trials)
+        c.mesh_build(T, V, 2)
+        c.material_isotropic(200.0, 0.35)
+        c.assemble()
+        info = c.placement_info()
+        assert len(info) == (0 if trials == 0 else trials + 1), info
+        assert all(0.01 < t < 50.0 for t in info)
+        import scipy.sparse as sp
+        i, j, v = c.export_upper_triplets()              # (entries that sum to rounding noise are pruned: the patterns of two runs may differ by those)
+        nn = 3 * c.n_dof
+        K = sp.coo_matrix((v, (i.astype(np.int64), j.astype(np.int64))), shape=(nn, nn)).tocsr()
+        if ref is None:
+            ref = K
+        else:
+            assert abs(K - ref).max() <= 1e-12 * abs(ref).max()
+            c.assemble()
+            assert c.placement_info() == info                        # not repeated
+            c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+            c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+            c.set_preconditioner(M.PRECOND_MULTIGRID)
+            u = c.sim_solve(rtol=1e-8, maxit=500)
+            assert c.last_info["converged"] and abs(np.abs(u).max() - 0.036) < 2e-3
+            c.set_option("matrix_storage", 0)                        # forces a new symbolic phase: new values buffer, new trials
+            c.assemble()
+            assert len(c.placement_info()) == trials + 1
+        c.close()
