@@ -48,3 +48,35 @@ def _build_lib_once():
     if build.needs_build():
         build.build_lib(verbose=False)
     yield
+
+
+_RENDEZVOUS_ERRORS = ("Address already in use", "EADDRINUSE", "Connection refused", "Connection reset", "failed to connect", "connect() timed out",
+                      "Socket Timeout", "The client socket has timed out", "The server socket has failed to listen")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _spawn_retries_a_lost_port():
+    """The multi-rank tests pick a free port, close it and hand it to their ranks (torch.multiprocessing.spawn(worker, args=(world, port, ...))): on a
+    busy box another process can take the port in between, and the rendezvous of one rank fails. Such a failure -- and only such a failure -- is
+    retried once on a new port; anything a worker raises on its own goes through unchanged."""
+    try:
+        import torch.multiprocessing as mp
+    except Exception:   # noqa: BLE001
+        yield
+        return
+    import socket
+    original = mp.spawn
+
+    def spawn(fn, args=(), nprocs=1, join=True, **kw):
+        try:
+            return original(fn, args=args, nprocs=nprocs, join=join, **kw)
+        except Exception as e:   # noqa: BLE001
+            if not join or len(args) < 2 or not isinstance(args[1], int) or not any(m in str(e) for m in _RENDEZVOUS_ERRORS):
+                raise
+            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+            print("spawn: rendezvous on port %d failed (%s); once more on port %d" % (args[1], str(e).splitlines()[-1][:120], port), flush=True)
+            return original(fn, args=(args[0], port) + tuple(args[2:]), nprocs=nprocs, join=join, **kw)
+
+    mp.spawn = spawn
+    yield
+    mp.spawn = original

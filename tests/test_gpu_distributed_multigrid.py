@@ -133,12 +133,12 @@ def _worker_ball(rank, world, port, ret):
             for k, v in opts.items():
                 c.set_option(k, v)
             c.set_preconditioner(M.PRECOND_MULTIGRID)
-            u, infos = solver.solve(f, rtol=1e-11, maxit=2000)
+            u, infos = solver.solve(f, rtol=1e-10, maxit=2000)
             u_ref = g["ball_p2_u"]
             out[name] = (float(np.linalg.norm(u[0].reshape(-1, 3) - u_ref[lm.keys[:lm.n_owned]]) / np.linalg.norm(u_ref)), bool(infos[0]["converged"]),
                          infos[0]["iterations"], c.precond_info())
         c.set_preconditioner(M.PRECOND_BLOCK_JACOBI)
-        _, infos = solver.solve(f, rtol=1e-11, maxit=20000)
+        _, infos = solver.solve(f, rtol=1e-10, maxit=20000)
         out["block_jacobi_iterations"] = infos[0]["iterations"]
         out["owned"] = lm.n_owned
         ret[rank] = out
