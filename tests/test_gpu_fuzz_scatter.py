@@ -1,5 +1,5 @@
 """Randomised general meshes through distributed.scatter_mesh on 2-3 ranks sharing the GPU: partitioned multigrid and block-Jacobi PCG against the
-single-context solve (nodes matched by position). 40 seeds ran clean in round 5 (scripts/fuzz_scatter.py); two small ones are kept here."""
+single-context solve (nodes matched by position). 82 seeds ran clean in round 5 (scripts/fuzz_scatter.py); two small ones are kept here."""
 import pytest
 
 pytestmark = pytest.mark.gpu
