@@ -396,6 +396,26 @@ public:
                                                &u[0][0], rtol, maxit, &info));
         return u;
     }
+    // [solve(constantStrainLoad(e)) for e in cstrains] in one call -- the loop of solveCellProblems (PeriodicHomogenization.hh:47-53): under the
+    // multigrid preconditioner the load vectors are formed on the device and the right-hand sides share the V-cycle's coarse levels
+    std::vector<VField> solveConstantStrainLoads(const std::vector<std::array<Real, N *(N + 1) / 2>> &cstrains) const {
+        std::vector<VField> w;
+        if (!m_rigidMotionRHS.empty()) {          // a right-hand side for the constraint rows: one solve per strain
+            for (const auto &e : cstrains) w.push_back(solve(constantStrainLoad(e)));
+            return w;
+        }
+        const size_t ns = cstrains.size();
+        std::vector<Real> flat(ns * m_numNodes * N);
+        infos.assign(ns, mfh_solve_info{});
+        check(ctx(), mfh_solve_cell_problems(ctx(), (int32_t)ns, &cstrains[0][0], m_flags(), flat.data(), rtol, maxit, infos.data()));
+        if (ns) info = infos.back();
+        for (size_t k = 0; k < ns; ++k) {
+            VField u(m_numNodes);
+            std::copy(flat.begin() + k * m_numNodes * N, flat.begin() + (k + 1) * m_numNodes * N, &u[0][0]);
+            w.push_back(std::move(u));
+        }
+        return w;
+    }
     VField solve() const {                                       // :657
         VField u(m_numNodes);
         check(ctx(), mfh_sim_solve_constrained(ctx(), nullptr, m_flags(), m_rigidMotionRHS.data(), (int32_t)m_rigidMotionRHS.size(),
@@ -474,6 +494,7 @@ public:
     double rtol = 1e-8;
     int maxit = 100000;
     mutable mfh_solve_info info{};
+    mutable std::vector<mfh_solve_info> infos;    // one record per right-hand side of the last solveConstantStrainLoads
 
 private:
     Context m_owner;

@@ -84,8 +84,11 @@ void solveCellProblems(std::vector<typename LinearElasticity::Simulator<N, Deg>:
     sim.applyPeriodicConditions(cellEpsilon);
     sim.applyNoRigidMotionConstraint();
     sim.setUsePinNoRigidTranslationConstraint(true);
-    w_ij.clear();
-    for (size_t k = 0; k < flatLen(N); ++k) w_ij.push_back(sim.solve(sim.constantStrainLoad(canonicalStrain<N>(k, -1.0))));
+    // one system, flatLen right-hand sides (the reference factors once and back-substitutes per load): handed over together, so that the load
+    // vectors are formed on the device and the preconditioner's coarse levels serve all of them at once (mfh_solve_cell_problems)
+    std::vector<std::array<Real, flatLen(N)>> strains;
+    for (size_t k = 0; k < flatLen(N); ++k) strains.push_back(canonicalStrain<N>(k, -1.0));
+    w_ij = sim.solveConstantStrainLoads(strains);
 }
 
 // Stress-like form: Eh.DRow(i) = 1/|Y| sum_e vol_e [E_e : avg strain(w_i) + E_e.DRow(i)]  (:72-103). E_e.DRow(i) is the

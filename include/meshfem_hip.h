@@ -240,9 +240,11 @@ mfh_status mfh_multigrid_info(const mfh_ctx* ctx, int64_t* fineDoF, int64_t* coa
                               double* setup_ms);
 mfh_status mfh_solve(mfh_ctx* ctx, int32_t nrhs, const double* f, double* u,
                      double rtol, int32_t maxit, mfh_solve_info* info /* ONE entry: the last right-hand side */);
-/* the same with one mfh_solve_info per right-hand side. Right-hand sides are solved in batches (3D: 6 or 2, 2D: 3): the
- * matrix-free operator fetches every element record once per batch, like the reference factors once and back-substitutes
- * per right-hand side (PeriodicHomogenization.hh:34-54). info[k].reserved = size of the batch rhs k was solved in. */
+/* the same with one mfh_solve_info per right-hand side. Where batches pay, right-hand sides are solved in batches (3D: 6 or 2, 2D: 3), like
+ * the reference factors once and back-substitutes per right-hand side (PeriodicHomogenization.hh:34-54): under MFH_PRECOND_MULTIGRID the
+ * coarse levels of every V-cycle serve the whole batch (option "mg_batch", default on); the Chronopoulos-Gear batches of the other
+ * preconditioners (option "batch_rhs") are off by default (measured slower). info[k].reserved = size of the batch rhs k was solved in;
+ * info[k].solve_ms of a batch is the batch's device time. */
 mfh_status mfh_solve_batch(mfh_ctx* ctx, int32_t nrhs, const double* f, double* u,
                            double rtol, int32_t maxit, mfh_solve_info* info /* nrhs entries */);
 /* == Simulator::applyStiffnessMatrix (LinearElasticity.hh:801-823), using the assembled K       */
@@ -295,6 +297,23 @@ mfh_status mfh_sim_solve(mfh_ctx* ctx, const double* f /* dim*nDoF or NULL */, i
 enum { MFH_SOLVE_PIN = 1, MFH_SOLVE_NO_RIGID_MOTION = 2, MFH_SOLVE_ALLOW_ILL_POSED = 4 };
 mfh_status mfh_sim_solve_constrained(mfh_ctx* ctx, const double* f, int32_t flags, const double* rigidMotionRHS,
                                      int32_t nRigidRHS, double* uNodes, double rtol, int32_t maxit, mfh_solve_info* info);
+/* Simulator::solve for nrhs load vectors on ONE constrained system -- what solveCellProblems does with its 3 / 6 constantStrainLoad vectors
+ * (PeriodicHomogenization.hh:34-54: one Simulator, one factorisation, one back-substitution per load). f: nrhs x dim*nDoF, uNodes:
+ * nrhs x nNode*dim, info: nrhs entries. Where the constraints leave a positive definite system (Dirichlet conditions, or periodic conditions
+ * with the pinned node) the right-hand sides go through mfh_solve_batch's batches -- under MFH_PRECOND_MULTIGRID the linear / aggregate /
+ * dense levels of every V-cycle are run once for the whole batch (option "mg_batch") --; systems with constraint rows are solved one
+ * right-hand side after the other as by mfh_sim_solve_constrained. */
+mfh_status mfh_sim_solve_batch(mfh_ctx* ctx, int32_t nrhs, const double* f, int32_t flags, double* uNodes, double rtol, int32_t maxit,
+                               mfh_solve_info* info);
+/* == solveCellProblems' loop (PeriodicHomogenization.hh:47-53): w[k] = Simulator::solve(constantStrainLoad(cstrains[k])) for k < nStrains on the
+ * system the context's conditions describe (the caller has applied the periodic conditions; flags as for mfh_sim_solve_constrained:
+ * MFH_SOLVE_PIN | MFH_SOLVE_NO_RIGID_MOTION is solveCellProblems' configuration). cstrains: nStrains x flatLen, flattened with TENSOR shear
+ * like mfh_constant_strain_load's argument (the caller passes -e_ij); wNodes: nStrains x nNode*dim. Under MFH_PRECOND_MULTIGRID on a quadratic
+ * mesh nothing but the solutions crosses the PCIe bus: the load vectors are formed on the device through the matrix-free operator's lists
+ * (the element routine with u = 0 and the constant strain added), the right-hand sides share the coarse levels of every V-cycle (option
+ * "mg_batch"), dofToNodeField runs on the device. Every other configuration takes the general route (host load vectors, mfh_sim_solve_batch). */
+mfh_status mfh_solve_cell_problems(mfh_ctx* ctx, int32_t nStrains, const double* cstrains, int32_t flags, double* wNodes, double rtol,
+                                   int32_t maxit, mfh_solve_info* info);
 /* == averageStrainField / averageStressField (:528-549, :99-123): per element, flattened (flatLen) */
 mfh_status mfh_average_strain(mfh_ctx* ctx, const double* uNodes, double* strain /* nElem x flatLen */);
 mfh_status mfh_average_stress(mfh_ctx* ctx, const double* uNodes, double* stress /* nElem x flatLen */);
@@ -488,7 +507,9 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
  *   a single right-hand side on an unpartitioned context, where it is 6-14 % faster per iteration), "dist_pcg_variant"
  *   (mfh_dist_solve with one right-hand side: 1 default = Chronopoulos-Gear, ONE all-reduce per iteration; 0 = classic loop, two
  *   all-reduces and one vector pass less -- which is faster depends on the node's all-reduce latency), "batch_rhs" (0 default:
- *   1 solves several right-hand sides per operator pass, see mfh_solve_batch),
+ *   1 solves several right-hand sides per operator pass of the Chronopoulos-Gear loop, see mfh_solve_batch; block-Jacobi / two-level only),
+ * "mg_batch" (1 default: several right-hand sides under MFH_PRECOND_MULTIGRID on an unpartitioned quadratic context run one classic PCG loop
+ *   each, in lockstep, and share the linear / aggregate / dense levels of every V-cycle; 0: one right-hand side at a time),
  * "solve_homogeneous" (1: mfh_solve treats the fixed variables as fixed to ZERO whatever values were given -- the
  *   homogeneous solves K y = C^T of a Schur-complement elimination of constraint rows, SparseMatrices.hh:2572-2590),
  * "periodic_ignore_mismatch" (1: nodes of a periodic face without a partner keep their own DoF, PeriodicCondition's

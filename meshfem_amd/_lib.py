@@ -117,6 +117,8 @@ PROTOTYPES = {
     "mfh_mesh_get_boundary_elem_internal": (_i32, [_P, _P]),
     "mfh_mesh_update_vertices": (_i32, [_P, _P]),
     "mfh_sim_solve_constrained": (_i32, [_P, _P, _i32, _P, _i32, _P, _f64, _i32, C.POINTER(SolveInfo)]),
+    "mfh_sim_solve_batch": (_i32, [_P, _i32, _P, _i32, _P, _f64, _i32, C.POINTER(SolveInfo)]),
+    "mfh_solve_cell_problems": (_i32, [_P, _i32, _P, _i32, _P, _f64, _i32, C.POINTER(SolveInfo)]),
     "mfh_matrix_free_info": (_i32, [_P, _P, _P, _P, _P, _P, _P]),
     "mfh_set_operator": (_i32, [_P, _i32]),
     "mfh_matrix_set_upper_triplets": (_i32, [_P, _i64, _i64, _P, _P, _P]),

@@ -436,6 +436,37 @@ class Context:
         self._ck(st)
         return u
 
+    def sim_solve_batch(self, f, flags=0, rtol=1e-8, maxit=100000):
+        """Simulator::solve for several load vectors (rows of f, dim*nDoF each) on one constrained system: returns (u [nrhs, nNode, dim],
+        [info per load]). Positive definite systems go through the batches of mfh_solve_batch (the multigrid V-cycle's coarse levels serve the
+        whole batch), systems with constraint rows are solved one load after the other."""
+        f = as_f64(f)
+        n = self.bs * self.n_dof
+        nrhs = f.size // n
+        assert f.size == nrhs * n
+        u = np.empty((nrhs, self.n_node, self.bs))
+        infos = (L.SolveInfo * nrhs)()
+        st = self.lib.mfh_sim_solve_batch(self.h, nrhs, ptr(f), int(flags), ptr(u), float(rtol), int(maxit), infos)
+        self.last_infos = [i.as_dict() for i in infos]
+        self.last_info = self.last_infos[-1]
+        self._ck(st)
+        return u, self.last_infos
+
+    def solve_cell_problems(self, cstrains, flags=0, rtol=1e-8, maxit=100000):
+        """w[k] = Simulator::solve(constantStrainLoad(cstrains[k])) for every row of cstrains (flattened, tensor shear) on the constrained system
+        of the context (mfh_solve_cell_problems): returns (w [nStrains, nNode, dim], [info per strain])."""
+        cs = as_f64(cstrains)
+        fl = self.dim * (self.dim + 1) // 2
+        ns = cs.size // fl
+        assert cs.size == ns * fl
+        w = np.empty((ns, self.n_node, self.bs))
+        infos = (L.SolveInfo * ns)()
+        st = self.lib.mfh_solve_cell_problems(self.h, ns, ptr(cs), int(flags), ptr(w), float(rtol), int(maxit), infos)
+        self.last_infos = [i.as_dict() for i in infos]
+        self.last_info = self.last_infos[-1]
+        self._ck(st)
+        return w, self.last_infos
+
     def average_strain(self, u_nodes):
         u = as_f64(u_nodes)
         out = np.empty((self.n_elem, flat_len(self.dim)))

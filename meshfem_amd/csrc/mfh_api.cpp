@@ -969,6 +969,196 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
     check_residual_gap(li, rtol);
 }
 
+// constantStrainLoad (LinearElasticity.hh:551-562) on the device through the lists of the cluster operator: the element routine with u = 0 and
+// the constant strain added, summed in LDS like an application of the operator (0.25 ms at 2 M quadratic tets; the stand-alone kernel adds
+// every (element, node) contribution with a global FP64 atomic: 2.3 ms). outDev: dim * nDoF doubles on the device.
+bool constant_strain_load_device(mfh_ctx *c, const double *cstrainFlat, double *outDev) {
+    if (c->op != MFH_OP_ELASTICITY || !c->use_mf()) return false;
+    ensure_geometry(c);
+    prepare_matrix_free(c);
+    if (c->mfModeEff() != 4) return false;
+    const int d = c->bs();
+    if (c->mfcDev.ifaceBuf.n < (size_t)std::max<int64_t>(c->mfc.nIface, 1) * d) c->mfcDev.ifaceBuf.alloc((size_t)std::max<int64_t>(c->mfc.nIface, 1) * d);
+    MFH_HIP(hipMemsetAsync(outDev, 0, (size_t)d * c->nDoF * sizeof(double), c->stream));
+    k::launch_mf_cluster_constant_strain(spmv_mf_cluster_args(c, false), cstrainFlat, outDev, c->stream);
+    return true;
+}
+
+// NR right-hand sides under the multigrid preconditioner of an unpartitioned quadratic context (solve_many, option "mg_batch"): NR classic PCG
+// loops advancing in lockstep -- loop k with vectors of its own (k vecStride apart), its own history scal + k scalStride and control block
+// stop + 4 k, hence its own convergence: a loop that has met its threshold is frozen by its gate like in solve_one_classic -- and ONE pass
+// through the linear / aggregate / dense levels of every V-cycle for all of them (mg_precond_batch). The quadratic level's kernels are the
+// single-vector ones at their single-vector cost; what the batch shares is everything below, which is bound by matrix bytes and launch latency.
+// The reference's counterpart: one factorisation, one back-substitution per right-hand side (SparseMatrices.hh:2106-2124).
+void solve_multigrid_batch(mfh_ctx *c, int NR, const double *f, double *u, int64_t hostStride, double rtol, int maxit, mfh_solve_info *infos, const BatchIO *io) {
+    RoctxRange range("Elasticity Solve");
+    const int d = c->bs();
+    const int64_t n = (int64_t)d * c->nDoF;
+    require(c->sym.nRows == c->sym.nCols, MFH_ERR_STATE, "batched multigrid solve needs all rows owned");
+    require(NR >= 2 && NR <= 6, MFH_ERR_INVALID, "batch size");
+    hipStream_t s = c->stream;
+    const int64_t vs = (n + 31) / 32 * 32;                   // doubles between the vectors of consecutive loops (256-byte aligned: the vector kernels use 16-byte accesses)
+    const size_t tot = (size_t)vs * NR;
+    c->wx.reserve(tot); c->wr.reserve(tot); c->wz.reserve(tot); c->wp.reserve(tot); c->wAp.reserve(tot); c->wb.reserve(tot); c->wf.reserve(tot);
+    EventTimer tsetup(s);
+    prepare_matrix_free(c);
+    const bool masked = !c->fixedVars.empty();
+    const uint8_t *maskPtr = masked ? c->dFixedMask.p : nullptr;
+    if (io && io->cstrains) {               // constantStrainLoad vectors, formed where they are needed
+        const int fl = c->dim() * (c->dim() + 1) / 2;
+        for (int k2 = 0; k2 < NR; ++k2)
+            if (!constant_strain_load_device(c, io->cstrains + (size_t)k2 * fl, c->wf.p + (size_t)k2 * vs)) throw Error(MFH_ERR_STATE, "constant-strain loads need the cluster operator");
+    } else
+        for (int k2 = 0; k2 < NR; ++k2)
+            MFH_HIP(hipMemcpyAsync(c->wf.p + (size_t)k2 * vs, f + (size_t)k2 * hostStride, n * sizeof(double), hipMemcpyHostToDevice, s));
+    MFH_HIP(hipMemcpyAsync(c->wb.p, c->wf.p, tot * sizeof(double), hipMemcpyDeviceToDevice, s));
+    // b = f - K ubar on the free variables (SparseMatrices.hh:2457-2470,2526-2535): the same lift for every right-hand side
+    if (c->anyFixedNonzero && !c->solveHomogeneous) {
+        c->wu0.alloc(n);
+        c->wu0.zero(s);
+        k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, c->wu0.p, n, s);
+        apply_operator(c, false, c->wu0.p, c->wAp.p, nullptr);
+        for (int k2 = 0; k2 < NR; ++k2) k::launch_axpby(n, -1.0, c->wAp.p, 1.0, c->wb.p + (size_t)k2 * vs, s);
+    }
+    if (masked) for (int k2 = 0; k2 < NR; ++k2) k::launch_mask(n, c->dFixedMask.p, c->wb.p + (size_t)k2 * vs, s);
+    double bb[6] = {0, 0, 0, 0, 0, 0};
+    for (int k2 = 0; k2 < NR; ++k2) bb[k2] = device_dot(c, n, c->wb.p + (size_t)k2 * vs, c->wb.p + (size_t)k2 * vs);      // (uses c->stop: before the control blocks are set up)
+    const int checkEvery = std::min(c->checkEvery, 2);       // a V-cycle is milliseconds long and tens of them are needed: short blocks
+    const size_t scalStride = ((size_t)maxit + (size_t)checkEvery + 2) * 4;
+    c->scal.alloc(scalStride * NR);
+    c->scal.zero(s);
+    c->stop.alloc(4 * (size_t)NR);
+    double hstop[24] = {0};
+    bool anyWork = false;
+    for (int k2 = 0; k2 < NR; ++k2) { hstop[4 * k2] = rtol * rtol * bb[k2]; anyWork |= bb[k2] > 0; }
+    MFH_HIP(hipMemcpyAsync(c->stop.p, hstop, 4 * NR * sizeof(double), hipMemcpyHostToDevice, s));
+    const double setupMs = tsetup.stop();
+    std::vector<int> itConv((size_t)NR, -1);
+    std::vector<double> rrFinal((size_t)NR, 0.0);
+    double solveMs = 0;
+    bool usedGraph = false;
+    int itRun = 0;
+    auto vec = [&](DBuf<double> &b, int k2) { return b.p + (size_t)k2 * vs; };
+    auto sck = [&](int k2) { return c->scal.p + (size_t)k2 * scalStride; };
+    auto stk = [&](int k2) { return c->stop.p + 4 * (size_t)k2; };
+    if (!anyWork) {
+        MFH_HIP(hipMemsetAsync(c->wx.p, 0, tot * sizeof(double), s));
+        for (int k2 = 0; k2 < NR; ++k2) itConv[k2] = 0;
+    } else {
+        EventTimer tsolve(s);
+        // x = 0, r = b, z = M^-1 r (one V-cycle for all), p = z; {r.z, -, r.r}_0 per loop. A zero right-hand side starts converged (0 <= 0).
+        for (int k2 = 0; k2 < NR; ++k2) {
+            k::launch_pcg_init(d, c->sym.nRows, c->dDinv.p, vec(c->wb, k2), vec(c->wx, k2), vec(c->wr, k2), vec(c->wz, k2), vec(c->wp, k2), sck(k2), s);
+            MFH_HIP(hipMemsetAsync(sck(k2), 0, sizeof(double), s));
+        }
+        mg_precond_batch(c, NR, c->wr.p, c->wz.p, vs, nullptr, 0, -1, nullptr);
+        for (int k2 = 0; k2 < NR; ++k2) {
+            k::launch_mg_rz(n, vec(c->wr, k2), vec(c->wz, k2), maskPtr, sck(k2), -1, nullptr, nullptr, s);
+            MFH_HIP(hipMemcpyAsync(vec(c->wp, k2), vec(c->wz, k2), n * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        const k::SpmvMfArgs mfa = spmv_mf_cluster_args(c, masked);
+        auto enqueue = [&](int itLocal) {   // one iteration of every loop; `itLocal` is relative to the iteration bases stop[4 k + 3]
+            for (int k2 = 0; k2 < NR; ++k2) {
+                k::launch_spmv_mf_cluster(mfa, vec(c->wp, k2), vec(c->wAp, k2), nullptr, sck(k2), itLocal, stk(k2), true, s);
+                k::launch_pcg_update_noz(d, c->sym.nRows, vec(c->wAp, k2), vec(c->wr, k2), sck(k2), itLocal, stk(k2), s);
+            }
+            mg_precond_batch(c, NR, c->wr.p, c->wz.p, vs, c->scal.p, (int64_t)scalStride, itLocal, c->stop.p);
+            for (int k2 = 0; k2 < NR; ++k2) {
+                k::launch_mg_rz(n, vec(c->wr, k2), vec(c->wz, k2), maskPtr, sck(k2), itLocal, sck(k2), stk(k2), s);
+                k::launch_pcg_direction(n, vec(c->wz, k2), vec(c->wp, k2), vec(c->wx, k2), sck(k2), itLocal, stk(k2), s);
+            }
+        };
+        hipGraphExec_t exec = nullptr;
+        if (c->useGraph && checkEvery > 1) {
+            hipGraph_t graph = nullptr;
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                bool ok = true;
+                try {
+                    for (int j = 0; j < checkEvery; ++j) enqueue(j);
+                    for (int k2 = 0; k2 < NR; ++k2) k::launch_advance_base(stk(k2), checkEvery, s);
+                } catch (...) { ok = false; }
+                if (hipStreamEndCapture(s, &graph) != hipSuccess || !ok || !graph) { graph = nullptr; (void)hipGetLastError(); }
+            } else (void)hipGetLastError();
+            if (graph) {
+                if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { exec = nullptr; (void)hipGetLastError(); }
+                (void)hipGraphDestroy(graph);
+            }
+        }
+        usedGraph = exec != nullptr;
+        std::vector<double> hs;
+        int it = 0, lastChecked = 0, nConv = 0;
+        for (int k2 = 0; k2 < NR; ++k2) if (!(bb[k2] > 0)) { itConv[k2] = 0; ++nConv; }
+        while (nConv < NR && it < maxit) {
+            if (exec) { MFH_HIP(hipGraphLaunch(exec, s)); it += checkEvery; }
+            else {
+                const int itEnd = std::min(maxit, it + checkEvery);
+                for (; it < itEnd; ++it) enqueue(it);
+            }
+            const size_t per = (size_t)(it - lastChecked + 1) * 4;
+            hs.resize(per * NR);
+            for (int k2 = 0; k2 < NR; ++k2)
+                MFH_HIP(hipMemcpyAsync(hs.data() + per * k2, sck(k2) + (size_t)lastChecked * 4, per * sizeof(double), hipMemcpyDeviceToHost, s));
+            MFH_HIP(hipStreamSynchronize(s));
+            for (int k2 = 0; k2 < NR; ++k2) {
+                if (itConv[k2] >= 0) continue;
+                for (int q = lastChecked; q <= std::min(it, maxit); ++q) {
+                    const double *sc = &hs[per * k2 + (size_t)(q - lastChecked) * 4];
+                    const double rr = sc[2];
+                    if (rr <= hstop[4 * k2]) { itConv[k2] = q; rrFinal[k2] = rr; ++nConv; break; }
+                    if (!(rr == rr)) throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (NaN residual): K is not SPD on the free variables");
+                    if (q < it && sc[1] < 0.0)
+                        throw Error(MFH_ERR_NOT_CONVERGED, "PCG breakdown (p.Kp = " + std::to_string(sc[1]) + " < 0 at iteration " + std::to_string(q) +
+                                                               ", residual^2 " + std::to_string(rr) + "): K is not positive definite on the free variables");
+                    rrFinal[k2] = rr;
+                }
+            }
+            lastChecked = it;
+        }
+        itRun = it;
+        if (exec) (void)hipGraphExecDestroy(exec);
+        solveMs = tsolve.stop();
+    }
+    // u = x + ubar (SparseMatrices.hh:2592-2605); true residual on the free variables: || mask(f - K u) || / ||b||
+    double tr[6] = {0, 0, 0, 0, 0, 0};
+    for (int k2 = 0; k2 < NR; ++k2) {
+        if (masked && !c->solveHomogeneous) k::launch_scatter_values((int64_t)c->fixedVars.size(), c->dFixedIdx.p, c->dFixedVal.p, vec(c->wx, k2), n, s);
+        if (bb[k2] > 0) {
+            apply_operator(c, false, vec(c->wx, k2), c->wAp.p, nullptr);
+            k::launch_axpby(n, 1.0, vec(c->wf, k2), -1.0, c->wAp.p, s);
+            if (masked) k::launch_mask(n, c->dFixedMask.p, c->wAp.p, s);
+            tr[k2] = device_dot(c, n, c->wAp.p, c->wAp.p);
+        }
+        if (io && io->uNodes) {             // dofToNodeField (LinearElasticity.hh:664-677) on the device, then one download per nodal field
+            const int64_t nn = c->mesh.nNode * (int64_t)d;
+            const double *src = vec(c->wx, k2);
+            if (!c->dofForNode.empty()) {
+                c->wNodeField.reserve((size_t)nn * 2);
+                double *dst = c->wNodeField.p + (size_t)(k2 & 1) * nn;     // two halves: the gather of field k + 1 does not wait for the download of field k
+                k::launch_pack_rows(c->mesh.nNode, d, device_dof_map(c), src, dst, s);
+                src = dst;
+            }
+            MFH_HIP(hipMemcpyAsync(io->uNodes + (size_t)k2 * io->nodeStride, src, (size_t)nn * sizeof(double), hipMemcpyDeviceToHost, s));
+        } else
+            MFH_HIP(hipMemcpyAsync(u + (size_t)k2 * hostStride, vec(c->wx, k2), n * sizeof(double), hipMemcpyDeviceToHost, s));
+    }
+    MFH_HIP(hipStreamSynchronize(s));
+    mfh_solve_info gap[6];
+    for (int k2 = 0; k2 < NR; ++k2) {
+        mfh_solve_info li{};
+        li.converged = itConv[k2] >= 0 ? 1 : 0;
+        li.iterations = itConv[k2] >= 0 ? itConv[k2] : std::min(itRun, maxit);
+        li.rel_residual = bb[k2] > 0 ? std::sqrt(rrFinal[k2] / bb[k2]) : 0.0;
+        li.true_rel_residual = bb[k2] > 0 ? std::sqrt(tr[k2] / bb[k2]) : 0.0;
+        li.solve_ms = solveMs;               // the batch's device time (shared by its right-hand sides)
+        li.setup_ms = setupMs;
+        li.used_graph = usedGraph ? 1 : 0;
+        li.reserved = NR;
+        if (infos) infos[k2] = li;
+        gap[k2] = li;
+    }
+    for (int k2 = 0; k2 < NR; ++k2) check_residual_gap(gap[k2], rtol);
+}
+
 void box_corners(mfh_ctx *c, const double *mn, const double *mx, int relative, double *omn, double *omx) {
     const HostMesh &m = c->mesh;
     const int d = m.dim;
@@ -2274,6 +2464,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
         if (on != c->deterministic) { c->deterministic = on; invalidate_matrix(c); destroy_multigrid(c); c->tl.valid = false; c->mfcValid = false; c->mfClusterUnfit = false; }   // (the block size of the cluster operator depends on it)
     }
     else if (k2 == "pcg_variant") c->pcgVariant = value < 0 ? -1 : (value != 0 ? 1 : 0);
+    else if (k2 == "mg_batch") c->mgBatch = value != 0;
     else if (k2 == "batch_rhs") { if (c->batchRhs != (value != 0)) { c->mfcValid = false; c->mfClusterUnfit = false; } c->batchRhs = value != 0; }
     else if (k2 == "matrix_free_mode") { c->mfMode = (int)value; c->mfClusterUnfit = false; }
     else if (k2 == "mf_block_elems") { c->mfBlockElems = (int)value; c->mfcValid = false; c->mfClusterUnfit = false; }

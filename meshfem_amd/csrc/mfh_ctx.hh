@@ -16,7 +16,7 @@ struct mfh_ctx {
     bool keepHostSymbolic = false;
     int xcdSwizzle = 0;              // option "xcd_swizzle": XCD-contiguous work mapping in the chunked kernels (measured SLOWER
                                      // than the round-robin default on MI355X: DESIGN.md section 4.8)
-    RawVec<double> hLoad, hX;        // host scratch of Simulator::solve (kept between solves; sized with resize_prefaulted: a value-initialising
+    RawVec<double> hLoad, hX, hXBatch, hLoadBatch;   // host scratch of Simulator::solve (kept between solves; sized with resize_prefaulted: a value-initialising
                                      // resize of 1.4 GB at 119^3 is 0.25 s of single-threaded page faults, twice per first solve)
     bool alwaysReembed = false;      // option "reembed": every mfh_assemble re-runs the embedding kernel
     // option "deterministic": run-to-run bit-reproducible assembly, operator and PCG. The reference's scatter into the triplet list is serial
@@ -200,6 +200,7 @@ struct mfh_ctx {
         int64_t nFine = 0, nCoarse = 0;
         DBuf<int32_t> parA, parB, fineOf, resPtr, resIdx;
         DBuf<double> r0, d0, t0, b1, x1, r1, d1, t1;
+        int nrAlloc = 1;                         // right-hand sides the work vectors of every level hold at once (batched V-cycle: they grow on demand)
         double lmax0 = 0, lmax1 = 0, setup_ms = 0;
         // aggregate hierarchy below the linear level (empty: the linear level uses its context's ~1000-aggregate dense coarse space)
         std::vector<std::unique_ptr<AggLevel>> agg;
@@ -226,11 +227,14 @@ struct mfh_ctx {
     int mgAggNodes = 0;                              // option "mg_agg_nodes": target DoFs per aggregate of the linear level's coarse space (0 = auto)
     // Chronopoulos-Gear PCG (mfh_solver.cpp): NR interleaved vectors
     DBuf<double> cgU, cgW, cgP, cgS, cgX, cgR, cgF, cgCtl, tlRcN, tlYcN;
+    DBuf<double> wNodeField;          // nodal fields on their way to the host (dofToNodeField on the device, solve_multigrid_batch)
     int pcgVariant = -1;              // option "pcg_variant": 1 = Chronopoulos-Gear, 0 = classic PCG, -1 (default) = classic for one
                                       // right-hand side on an unpartitioned context (measured 6-14 % faster per iteration there: one
                                       // vector pass fewer), Chronopoulos-Gear for batches and row-partitioned contexts
     int distPcgVariant = 1;           // option "dist_pcg_variant": 1 = Chronopoulos-Gear (one all-reduce per iteration, default), 0 = classic
                                       // (two all-reduces, one vector pass less per iteration)
+    bool mgBatch = true;              // option "mg_batch": several right-hand sides under the multigrid preconditioner share the linear and aggregate levels of
+                                      // every V-cycle (solve_multigrid_batch); 0: one right-hand side at a time
     bool batchRhs = false;            // option "batch_rhs": several right-hand sides per operator pass (measured slower than one at a time)
     // row-partitioned solve (mfh_dist_setup)
     struct Dist {
@@ -414,6 +418,7 @@ bool ensure_multigrid(mfh_ctx *c);
 void ensure_coarse_levels(mfh_ctx *c, int nrhs);
 void destroy_multigrid(mfh_ctx *c);
 void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int it, const double *stop);
+void mg_precond_batch(mfh_ctx *c, int NR, const double *r, double *z, int64_t vecStride, const double *scal, int64_t scalStride, int it, const double *stop);
 k::AsmArgs asm_args(mfh_ctx *c);
 const int32_t *device_dof_map(mfh_ctx *c);
 void box_corners(mfh_ctx *c, const double *mn, const double *mx, int relative, double *omn, double *omx);
@@ -421,4 +426,14 @@ void dirichlet_vars(mfh_ctx *c, std::vector<int64_t> &vars, std::vector<double> 
 int64_t pin_node(const mfh_ctx *c);
 void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info);
 void solve_many(mfh_ctx *c, int nrhs, const double *f, double *u, int64_t stride, double rtol, int maxit, mfh_solve_info *infos);
+// Device-resident ends of a multigrid batch (mfh_solve_cell_problems): the right-hand sides are constantStrainLoad vectors formed on the device
+// (no host load vector exists), the solutions leave as nodal fields (dofToNodeField on the device, one download per field)
+struct BatchIO {
+    const double *cstrains = nullptr;     // NR x flatLen constant strains (flattened, tensor shear); null: right-hand sides come from the host
+    double *uNodes = nullptr;             // NR nodal fields, nodeStride doubles apart; null: DoF vectors to u
+    int64_t nodeStride = 0;
+};
+bool multigrid_batch_ready(mfh_ctx *c, int nrhs);     // the hierarchy exists (built if need be) and the batched V-cycle applies to this context
+void solve_multigrid_batch(mfh_ctx *c, int NR, const double *f, double *u, int64_t stride, double rtol, int maxit, mfh_solve_info *infos, const BatchIO *io = nullptr);
+bool constant_strain_load_device(mfh_ctx *c, const double *cstrainFlat, double *outDev);   // through the cluster operator's lists; false: not available
 }   // namespace mfhi

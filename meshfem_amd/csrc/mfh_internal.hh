@@ -479,7 +479,11 @@ struct SpmvMfArgs {
     int clLaneStride;                   // lane t of a block takes element (t * stride) % blockElems (1: identity); coprime to blockElems
     const double *vertPos;              // cluster variant, constant material: corner positions [nVert][dim]; gradients recomputed (null: read the records)
     DetBuf det;                         // filled by the launcher (t_det); non-null = deterministic accumulation as well
+    double shift[6];                    // launch_mf_cluster_constant_strain: the constant strain (flattened, TENSOR shear) added to grad u
 };
+// constantStrainLoad on the cluster operator's lists (LinearElasticity.hh:551-562): y = int (C : cstrain) grad phi_i = the operator's nodal forces
+// for a field of constant strain `cstrain` -- the element routine with u = 0 and the strain added, summed through the same LDS accumulators
+void launch_mf_cluster_constant_strain(const SpmvMfArgs &a, const double *cstrainFlat, double *y, hipStream_t s);
 void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
                     bool pcg, hipStream_t s);
 void launch_spmv_mf_cluster(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
@@ -528,16 +532,17 @@ void launch_tl_scatter(int nAgg, int nModes, int nColor, const int32_t *nbrOfCol
                        hipStream_t s);
 void launch_tl_rap(const TLArgs &t, int64_t nRows, const int32_t *rowPtr, const int32_t *colIdx, const double *vals, double *Ac,
                    hipStream_t s);
-void launch_st_spmv(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const float *A32, const double *x, double *y, const double *scal, int it, const double *stop, hipStream_t s);
+// (NR > 1: NR right-hand sides at once, vectors [aggregate][mode][NR])
+void launch_st_spmv(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const float *A32, const double *x, double *y, const double *scal, int it, const double *stop, hipStream_t s, int NR = 1);
 void launch_st_dinv(int dim, int64_t nAgg, const double *A, double *Dinv, hipStream_t s);
 void launch_st_cheb(int dim, int64_t nAgg, const double *Dinv, const double *rin, const double *t, double *rout, double *d, double *x, double a, double b,
-                    bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s);
+                    bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s, int NR = 1);
 void launch_st_rap(int dim, int64_t nParents, const int32_t *childPtr, const int32_t *childIdx, const int32_t *nbr, const double *A, const int32_t *parent,
                    const double *rel, const int32_t *coordC, double *Ac, const int *wrapNbC, hipStream_t s);
 void launch_st_restrict(int dim, int64_t nParents, const int32_t *childPtr, const int32_t *childIdx, const double *rel, const double *r, const double *t, double *rc,
-                        const double *scal, int it, const double *stop, hipStream_t s);
+                        const double *scal, int it, const double *stop, hipStream_t s, int NR = 1);
 void launch_st_prolong_add(int dim, int64_t nAgg, const int32_t *parent, const double *rel, const double *xc, double *x, double alpha, const double *scal, int it,
-                           const double *stop, hipStream_t s);
+                           const double *stop, hipStream_t s, int NR = 1);
 void launch_st_to_dense(int dim, int64_t nAgg, const int32_t *nbr, const double *A, double *Ad, hipStream_t s);
 void launch_mg_zero(int64_t n, double *v, const double *scal, int it, const double *stop, hipStream_t s);
 void launch_st_mirror_upper(double *stencil, const int32_t *nbr, int64_t nAgg, int dim, hipStream_t s);
@@ -574,14 +579,29 @@ void launch_tl_gemv_nr(int64_t m, int64_t ld, int NR, const double *A, const dou
 void launch_tl_apply_nr(const TLArgs &t, int NR, const double *dinv, const double *r, const double *yc, double *z, double *scal, int it,
                         const double *ctl, hipStream_t s);
 extern int g_vecGridCap;
-// p-multigrid (mfh_multigrid.cpp); scal / it / stop: the gate of the PCG iteration (null: none)
+// p-multigrid (mfh_multigrid.cpp); scal / it / stop: the gate of the PCG iteration (null: none) -- of ONE classic loop by default; inside a
+// GateScope(NR, stride) of NR loops advancing in lockstep (loop k: history scal + k stride, control block stop + 4 k), closed when all are.
+// NR > 1 on the linear level and below: NR interleaved right-hand sides (entry ((row NR + k) dim + c); coarse vectors [coarse index][NR]).
+extern thread_local int t_gateNr;
+extern thread_local int64_t t_gateStride;
+struct GateScope {
+    int saved;
+    int64_t savedStride;
+    explicit GateScope(int nr, int64_t stride = 0) : saved(t_gateNr), savedStride(t_gateStride) { t_gateNr = nr; t_gateStride = stride; }
+    ~GateScope() { t_gateNr = saved; t_gateStride = savedStride; }
+};
 void launch_mg_cheb(int dim, int64_t nRows, const double *dinv, const double *rin, const double *t, double *rout, double *d, double *x,
-                    double a, double b, bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s);
+                    double a, double b, bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s, int NR = 1);
+// NR > 1: fine vectors separate (fineStride doubles apart), coarse result interleaved
 void launch_mg_restrict(int dim, int64_t nCoarse, const int32_t *fineOf, const int32_t *resPtr, const int32_t *resIdx, const double *r, const double *t,
-                        const uint8_t *coarseMask, double *rc, const double *scal, int it, const double *stop, hipStream_t s);
+                        const uint8_t *coarseMask, double *rc, const double *scal, int it, const double *stop, hipStream_t s, int NR = 1, int64_t fineStride = 0);
+// ldc: doubles between coarse rows (0 = dim; NR dim with xc pointing at vector k of NR interleaved coarse vectors)
 void launch_mg_prolong_add(int dim, int64_t nFine, const int32_t *parA, const int32_t *parB, const double *xc, const uint8_t *fineMask, double *x,
-                           const double *scal, int it, const double *stop, hipStream_t s);
-void launch_mg_tl_prolong_add(const TLArgs &t, const double *yc, double *x, double alpha, const double *scal, int it, const double *stop, hipStream_t s);
+                           const double *scal, int it, const double *stop, hipStream_t s, int ldc = 0);
+// all NR right-hand sides of the batched V-cycle in one launch: xc interleaved, x separate (vector k at x + k vecStride), gated per loop
+void launch_mg_prolong_add_nr(int dim, int NR, int64_t nFine, const int32_t *parA, const int32_t *parB, const double *xc, const uint8_t *fineMask, double *x,
+                              int64_t vecStride, const double *scal, int64_t scalStride, int it, const double *stop, hipStream_t s);
+void launch_mg_tl_prolong_add(const TLArgs &t, const double *yc, double *x, double alpha, const double *scal, int it, const double *stop, hipStream_t s, int NR = 1);
 void launch_fill_hash(int64_t n, double *v, hipStream_t s);
 void launch_to_f32(int64_t n, const double *src, float *dst, hipStream_t s);
 void launch_take_columns_i32(int64_t n, int W, int w, const int32_t *src, int32_t *dst, hipStream_t s);

@@ -987,7 +987,7 @@ template <int DIM> DEV constexpr int edge_between(int k, int q) {
 }
 
 // nodal forces f_i = int sigma(u) grad phi_i of element e for the nodal vectors gathered from x
-template <int DIM, int DEG, int MAT, class Emit>
+template <int DIM, int DEG, int MAT, bool SHIFT = false, class Emit>
 DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM],
                           const Emit &emit);
 
@@ -1016,10 +1016,13 @@ DEV void elem_forces(const SpmvMfArgs &a, int64_t e, const double *__restrict__ 
 // The operator itself is glS == glT == grad lambda; the discrete shape derivative (k_apply_delta_K) feeds perturbed
 // gradients into either slot. Every nodal force is handed to `emit(j, f_j)` as soon as it is complete (the cluster
 // kernel adds it to LDS right away instead of keeping 30 values live).
-template <int DIM, int DEG, int MAT, class Emit>
+// SHIFT: the constant strain `shift` (flattened, tensor shear; a kernel argument) is added to grad u at every point -- with u = 0 the nodal
+// forces are constantStrainLoad's (LinearElasticity.hh:551-562).
+template <int DIM, int DEG, int MAT, bool SHIFT = false, class Emit>
 DEV void elem_forces_bilinear(const double *__restrict__ g /* element record: material */, double vol,
                               const double (&gl)[DIM + 1][DIM], const double (&glT)[DIM + 1][DIM],
-                              const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM], const Emit &emit) {
+                              const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM], const Emit &emit,
+                              const double *shift = nullptr) {
     constexpr int NV = DIM + 1;
     constexpr int NPE = (DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6);
     constexpr int FL = DIM * (DIM + 1) / 2;
@@ -1047,6 +1050,7 @@ DEV void elem_forces_bilinear(const double *__restrict__ g /* element record: ma
                 double v = 0;
 #pragma unroll
                 for (int j = 0; j < NV; ++j) v += xl[j][p] * gl[j][q2];
+                if (SHIFT) v += shift[flat_idx<DIM>(p, q2)];
                 G[p][q2] = v;
             }
         double sg[FL];
@@ -1068,7 +1072,7 @@ DEV void elem_forces_bilinear(const double *__restrict__ g /* element record: ma
 #pragma unroll
         for (int p = 0; p < DIM; ++p)
 #pragma unroll
-            for (int q2 = 0; q2 < DIM; ++q2) Gb[p][q2] = 0.0;
+            for (int q2 = 0; q2 < DIM; ++q2) Gb[p][q2] = SHIFT ? shift[flat_idx<DIM>(p, q2)] : 0.0;
 #pragma unroll
         for (int k = 0; k < NV; ++k) {
             double base[DIM];
@@ -1088,6 +1092,40 @@ DEV void elem_forces_bilinear(const double *__restrict__ g /* element record: ma
         double S[FL], R[NV][FL];
 #pragma unroll
         for (int c = 0; c < FL; ++c) S[c] = 0.0;
+        // Material flavours with more than two parameters (orthotropic: 9 doubles, general: 21): the four point strains are formed FIRST,
+        // with no material value live, and the tensor is fetched only once the 30 gathered nodal values are dead -- otherwise the
+        // scheduler requests the record's material part up front and the kernel needs 186 / 210 VGPRs (2 waves per SIMD) instead of the
+        // isotropic flavour's 166 (3 waves). The opaque asm ties the record pointer to the last strain, so no load can move above it.
+        if (MAT != MAT_ISO) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+#pragma unroll
+                for (int p = 0; p < DIM; ++p)
+#pragma unroll
+                    for (int q2 = p; q2 < DIM; ++q2) {
+                        double v = 0;
+#pragma unroll
+                        for (int side = 0; side < (p == q2 ? 1 : 2); ++side) {
+                            const int r = side ? q2 : p, cc = side ? p : q2;
+                            double w = Gb[r][cc] + dAB * xl[q][r] * gl[q][cc];
+#pragma unroll
+                            for (int k = 0; k < NV; ++k)
+                                if (k != q) w += dAB * xl[NV + edge_between<DIM>(k, q)][r] * gl[k][cc];
+                            v += w;
+                        }
+                        R[q][flat_idx<DIM>(p, q2)] = v;                     // shear-doubled flat strain of point q
+                    }
+            }
+            const double *gm = g;
+            asm volatile("" : "+v"(gm), "+v"(R[NV - 1][FL - 1]), "+v"(R[0][0]));
+#pragma unroll
+            for (int q = 0; q < NV; ++q) {
+                double sg[FL];
+                elem_D_apply<DIM, MAT>(gm, R[q], sg);
+#pragma unroll
+                for (int c = 0; c < FL; ++c) { S[c] += sg[c]; R[q][c] = vol * wq * dAB * sg[c]; }
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             double G[DIM][DIM];
@@ -1132,7 +1170,7 @@ DEV void elem_forces_bilinear(const double *__restrict__ g /* element record: ma
     }
 }
 
-template <int DIM, int DEG, int MAT, class Emit>
+template <int DIM, int DEG, int MAT, bool SHIFT, class Emit>
 DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DIM == 3) ? (DEG == 1 ? 4 : 10) : (DEG == 1 ? 3 : 6)][DIM],
                           const Emit &emit) {
     constexpr int NV = DIM + 1;
@@ -1142,7 +1180,7 @@ DEV void elem_forces_core(const SpmvMfArgs &a, int64_t e, const double (&xl)[(DI
     for (int k = 0; k < NV; ++k)
 #pragma unroll
         for (int d = 0; d < DIM; ++d) gl[k][d] = g[k * DIM + d];
-    elem_forces_bilinear<DIM, DEG, MAT>(g, g[12], gl, gl, xl, emit);
+    elem_forces_bilinear<DIM, DEG, MAT, SHIFT>(g, g[12], gl, gl, xl, emit, a.shift);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1585,7 +1623,7 @@ __global__ void __launch_bounds__(256) k_mf_forces(SpmvMfArgs a, const double *_
 // its 128-byte record: the positions (24 B per vertex, shared by ~24 tets) stay in L2 / the memory-side cache, so a block of
 // 256 P2 tets reads ~10 KB of connectivity instead of 32 KB of records from HBM, for ~80 more FP64 instructions per element.
 // Only with a constant material (its part of the record is then the same for every element: element 0's is used).
-template <int DIM, int DEG, int MAT, int PCG, bool GEOV = false, bool DET = false>
+template <int DIM, int DEG, int MAT, int PCG, bool GEOV = false, bool DET = false, bool SHIFT = false>
 __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const double *__restrict__ x, double *__restrict__ y, double *dotOut,
                                                          double *scal, int it, const double *stopPtr, const int32_t *__restrict__ blockList,
                                                          int64_t nList) {
@@ -1625,7 +1663,7 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
             const int64_t row = a.clEntryRow[u0 + t];
 #pragma unroll
             for (int d = 0; d < DIM; ++d) {
-                xs[LIDX(t, d)] = x[row * DIM + d]; clacc[LIDX(t, d)] = 0.0;
+                xs[LIDX(t, d)] = SHIFT ? 0.0 : x[row * DIM + d]; clacc[LIDX(t, d)] = 0.0;    // (SHIFT: u = 0, the load of a constant strain)
                 if (det) { clacc[accStride + LIDX(t, d)] = 0.0; clacc[2 * accStride + LIDX(t, d)] = 0.0; clacc[3 * accStride + LIDX(t, d)] = 0.0; }
             }
         }
@@ -1667,9 +1705,9 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
                     for (int d = 0; d < DIM; ++d) P[k][d] = a.vertPos[v * DIM + d];
                 }
                 embed_simplex<DIM>(P, gl, vol);
-                elem_forces_bilinear<DIM, DEG, MAT>(a.geo, vol, gl, gl, xl, emit);
+                elem_forces_bilinear<DIM, DEG, MAT, SHIFT>(a.geo, vol, gl, gl, xl, emit, a.shift);
             } else
-                elem_forces_core<DIM, DEG, MAT>(a, a.clElemPerm ? (int64_t)a.clElemPerm[e] : e, xl, emit);   // the record of the ORIGINAL element
+                elem_forces_core<DIM, DEG, MAT, SHIFT>(a, a.clElemPerm ? (int64_t)a.clElemPerm[e] : e, xl, emit);   // the record of the ORIGINAL element
         }
         }
         __syncthreads();
@@ -2001,8 +2039,13 @@ __global__ void __launch_bounds__(256) k_spmv_nr(SpmvArgs a, const double *__res
                 const int64_t s = (int64_t)s0 + t;
                 const int64_t col = a.colIdx[s];
                 double A[NB];
+                if (a.vals32) {          // (uniform over the launch: the FP32 copy of the matrix a multigrid level keeps for its smoother)
 #pragma unroll
-                for (int c = 0; c < NB; ++c) A[c] = a.vals[tiled_index(s, c, NB)];
+                    for (int c = 0; c < NB; ++c) A[c] = (double)a.vals32[tiled_index(s, c, NB)];
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NB; ++c) A[c] = a.vals[tiled_index(s, c, NB)];
+                }
 #pragma unroll
                 for (int kk = 0; kk < NRS; ++kk) {
                     double xv[DIM];
@@ -2406,6 +2449,31 @@ static void launch_mf_cluster_mode(const SpmvMfArgs &a_, int mode, const double 
     CHECK_LAUNCH();
 }
 
+// constantStrainLoad through the cluster operator (see mfh_internal.hh): the SHIFT flavour of k_mf_cluster over all blocks, then the interface pass
+void launch_mf_cluster_constant_strain(const SpmvMfArgs &a_, const double *cstrainFlat, double *y, hipStream_t s) {
+    SpmvMfArgs ad = a_;
+    ad.det = DetBuf{};
+    ad.fixedMask = nullptr;
+    for (int q = 0; q < 6; ++q) ad.shift[q] = q < ad.dim * (ad.dim + 1) / 2 ? cstrainFlat[q] : 0.0;
+    const SpmvMfArgs &a = ad;
+    if (a.clBlocks > 0) {
+        const size_t ldsC = ((size_t)2 * a.clMaxLocal * a.dim + 16) * sizeof(double);
+        const int gridC = (int)std::min<int64_t>(a.clBlocks, 256 * 64);
+#define CALLS(D, G, M, GV)                                                                                                                                    \
+    do {                                                                                                                                                      \
+        if (ldsC > 64 * 1024) MFH_HIP(hipFuncSetAttribute((const void *)k_mf_cluster<D, G, M, 0, GV, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsC)); \
+        hipLaunchKernelGGL((k_mf_cluster<D, G, M, 0, GV, false, true>), dim3(gridC), dim3(MF_BLOCK), ldsC, s, a, (const double *)y, y, (double *)nullptr, (double *)nullptr, 0, \
+                           (const double *)nullptr, (const int32_t *)nullptr, a.clBlocks);                                                                    \
+    } while (0)
+#define CALL(D, G, M) if (a.vertPos) { CALLS(D, G, M, true); } else { CALLS(D, G, M, false); }
+        MFH_DISPATCH(a, CALL);
+#undef CALL
+#undef CALLS
+        CHECK_LAUNCH();
+    }
+    launch_mf_rows_mode(a, 0, y, y, nullptr, nullptr, 0, nullptr, s);
+}
+
 // ... followed by k_mf_rows over the interface partials
 void launch_spmv_mf_cluster(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
                             bool pcg, hipStream_t s) {
@@ -2463,7 +2531,9 @@ void launch_spmv_nr(const SpmvArgs &a, int NR, const double *x, double *y, doubl
                     const int32_t *chunkList, int64_t nList, hipStream_t s) {
     if (nList <= 0) return;
     if (NR == 1) { launch_spmv_mode(a, a.pcgMode ? a.pcgMode : (ctl ? 2 : 0), x, y, dotOut, scal, it, ctl, chunkList, nList, s); return; }
-    const int nrs = a.dim == 1 ? (NR == 6 ? 3 : NR) : cluster_nrs(a.dim, NR);
+    // the smoother of a multigrid level (FP32 copy of the matrix) takes all six vectors in ONE pass over the matrix: it is bound by the matrix bytes
+    const bool onePass = a.dim == 3 && NR == 6 && a.vals32 && ((size_t)a.dim * 6 * a.chunkSlots + 8) * sizeof(double) <= 80 * 1024;
+    const int nrs = onePass ? 6 : (a.dim == 1 ? (NR == 6 ? 3 : NR) : cluster_nrs(a.dim, NR));
     const size_t lds = ((size_t)a.dim * nrs * a.chunkSlots + 8) * sizeof(double);
     const int grid = persistent_grid(nList, 256 * 8);
 #define SPMV(D, N, NS)                                                                                                                 \
@@ -2472,7 +2542,7 @@ void launch_spmv_nr(const SpmvArgs &a, int NR, const double *x, double *y, doubl
         hipLaunchKernelGGL((k_spmv_nr<D, N, NS>), dim3(grid), dim3(256), lds, s, a, x, y, dotOut, scal, it, ctl, chunkList, nList);     \
     } while (0)
     if (a.dim == 3) {
-        if (NR == 2) SPMV(3, 2, 2); else SPMV(3, 6, 2);
+        if (NR == 2) SPMV(3, 2, 2); else if (onePass) SPMV(3, 6, 6); else SPMV(3, 6, 2);
     } else if (a.dim == 2) {
         SPMV(2, 3, 3);
     } else {

@@ -194,6 +194,52 @@ __global__ void __launch_bounds__(256) k_tl_restrict_wave(TLArgs t, const int32_
             if (k < t.nModes) rc[a * t.nModes + k] = acc[k];
 }
 
+// the wave-per-aggregate restriction for NR interleaved vectors (w entry ((n NR + kr) DIM + c), result [coarse index][NR]): a DoF's relative
+// position and mask are fetched once for all NR
+template <int DIM, int NR>
+__global__ void __launch_bounds__(256) k_tl_restrict_wave_nr(TLArgs t, const int32_t *__restrict__ aggPtr, const int32_t *__restrict__ dofsByAgg,
+                                                             const double *__restrict__ w, double *__restrict__ rc) {
+    const int lane = threadIdx.x & 63;
+    const int64_t a = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (a >= t.nAgg) return;
+    double acc[NR][6];
+#pragma unroll
+    for (int kr = 0; kr < NR; ++kr)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[kr][k] = 0.0;
+    for (int q = aggPtr[a] + lane; q < aggPtr[a + 1]; q += 64) {
+        const int64_t n = dofsByAgg[q];
+        double rp[3] = {t.relPos[n * 3], t.relPos[n * 3 + 1], t.relPos[n * 3 + 2]};
+        bool fx[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) fx[c] = t.fixedMask && t.fixedMask[n * DIM + c];
+#pragma unroll
+        for (int kr = 0; kr < NR; ++kr) {
+            double wv[DIM];
+#pragma unroll
+            for (int c = 0; c < DIM; ++c) wv[c] = fx[c] ? 0.0 : w[(n * NR + kr) * DIM + c];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                if (k >= t.nModes) break;
+                double s = 0;
+#pragma unroll
+                for (int c = 0; c < DIM; ++c) s += tl_mode<DIM>(k, c, rp) * wv[c];
+                acc[kr][k] += s;
+            }
+        }
+    }
+#pragma unroll
+    for (int kr = 0; kr < NR; ++kr)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[kr][k] = wave_sum(acc[kr][k]);
+    if (lane == 0)
+#pragma unroll
+        for (int kr = 0; kr < NR; ++kr)
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                if (k < t.nModes) rc[(a * t.nModes + k) * NR + kr] = acc[kr][k];
+}
+
 // coarse operator entries from one probe: Ac[(b,l), (nbr(b,colour), mode)] = R[(b,l)]
 __global__ void __launch_bounds__(256) k_tl_scatter(int nAgg, int nModes, int nColor, const int32_t *__restrict__ nbrOfColor, int color,
                                                     int mode, const double *__restrict__ R, double *__restrict__ Ac) {
@@ -1318,28 +1364,41 @@ __global__ void __launch_bounds__(256) k_scatter_values_nr(int64_t n, int NR, in
 // Every kernel takes the PCG gate (scal, it, stop): a no-op once the residual of iteration it has met the threshold, like
 // the vector kernels of the loop (blocks of check_every iterations are enqueued / replayed from a hipGraph without host sync).
 // ------------------------------------------------------------------------------------------------
-struct MgGate { const double *scal; int it; const double *stop; };
+// nr == 0: the gate of ONE classic PCG loop (scal[it 4 + 2] against stop[0], iteration base stop[3]). nr >= 1: the batched V-cycle's coarse
+// levels serve nr classic loops that advance in lockstep -- loop k keeps its history at scal + k stride and its control block at stop + 4 k --
+// and are closed once EVERY one of them has converged.
+struct MgGate { const double *scal; int it; const double *stop; int nr; int64_t stride; };
 DEV bool mg_closed(const MgGate &g) {
     if (!g.scal) return false;
+    if (g.nr > 0) {
+        bool all = true;
+        for (int k = 0; k < g.nr; ++k) {
+            const double *st = g.stop + 4 * k;
+            const int it = g.it + (int)st[3];
+            all = all && it >= 0 && g.scal[k * g.stride + (int64_t)it * 4 + 2] <= st[0];
+        }
+        return all;
+    }
     const int it = g.it + (int)g.stop[3];
     return it >= 0 && g.scal[(int64_t)it * 4 + 2] <= g.stop[0];
 }
 
 // One Chebyshev step on the block-Jacobi-preconditioned operator:  r' = rin - t ; d = a d + b D^-1 r' ; x (+)= d
 //   t == null: r' = rin;  rout != null: the running residual is stored;  first: d is not read (a d = 0);  assign: x = d
-template <int DIM>
+// NR interleaved vectors (entry ((row NR + k) DIM + c), the batched PCG's layout): one lane per (row, vector) pair; NR = 1 is the plain kernel
+template <int DIM, int NR = 1>
 __global__ void __launch_bounds__(256) k_mg_cheb(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ rin,
                                                  const double *__restrict__ t, double *__restrict__ rout, double *__restrict__ d,
                                                  double *__restrict__ x, double a, double b, int first, int assign, MgGate g) {
     if (mg_closed(g)) return;
-    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nRows; n += (int64_t)gridDim.x * 256) {
+    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nRows * NR; n += (int64_t)gridDim.x * 256) {
         double rv[DIM], zv[DIM];
 #pragma unroll
         for (int c = 0; c < DIM; ++c) rv[c] = rin[n * DIM + c] - (t ? t[n * DIM + c] : 0.0);
         if (rout)
 #pragma unroll
             for (int c = 0; c < DIM; ++c) rout[n * DIM + c] = rv[c];
-        apply_block<DIM>(dinv + n * (DIM * (DIM + 1) / 2), rv, zv);
+        apply_block<DIM>(dinv + (n / NR) * (DIM * (DIM + 1) / 2), rv, zv);
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
             const double dv = (first ? 0.0 : a * d[n * DIM + c]) + b * zv[c];
@@ -1356,46 +1415,60 @@ __global__ void __launch_bounds__(256) k_mg_cheb(int64_t nRows, const double *__
 #ifndef MG_RESTRICT_LANES
 #define MG_RESTRICT_LANES 8     // lanes per coarse row: 4 / 8 / 16 -> 316 / 274 / 291 us at config 3 (rocprofv3, same box)
 #endif
-template <int DIM>
+// NR right-hand sides: the FINE vectors are separate (vector k at r + k fineStride: the quadratic level runs one PCG loop per right-hand side),
+// the COARSE ones interleaved (entry ((row NR + k) DIM + c): the linear level and everything below it serve all NR at once)
+template <int DIM, int NR = 1>
 __global__ void __launch_bounds__(256) k_mg_restrict(int64_t nCoarse, const int32_t *__restrict__ fineOf, const int32_t *__restrict__ resPtr,
                                                      const int32_t *__restrict__ resIdx, const double *__restrict__ r,
-                                                     const double *__restrict__ t, const uint8_t *__restrict__ coarseMask,
+                                                     const double *__restrict__ t, int64_t fineStride, const uint8_t *__restrict__ coarseMask,
                                                      double *__restrict__ rc, MgGate g) {
     if (mg_closed(g)) return;
+    constexpr int W = NR * DIM;
     const int sub = threadIdx.x & (MG_RESTRICT_LANES - 1);
     const int64_t nq = (nCoarse + 63) / 64 * 64;                 // whole waves take part in the shuffles
     for (int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) / MG_RESTRICT_LANES; q < nq; q += ((int64_t)gridDim.x * 256) / MG_RESTRICT_LANES) {
-        double acc[DIM];
+        double acc[W];
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) acc[c] = 0.0;
+        for (int c = 0; c < W; ++c) acc[c] = 0.0;
         if (q < nCoarse) {
             const int k0 = resPtr[q], k1 = resPtr[q + 1];
             for (int k = k0 + sub; k < k1; k += MG_RESTRICT_LANES) {
                 const int64_t e = resIdx[k];
 #pragma unroll
-                for (int c = 0; c < DIM; ++c) acc[c] += 0.5 * (r[e * DIM + c] - (t ? t[e * DIM + c] : 0.0));
+                for (int v = 0; v < NR; ++v)
+#pragma unroll
+                    for (int c = 0; c < DIM; ++c) {
+                        const int64_t i = v * fineStride + e * DIM + c;
+                        acc[v * DIM + c] += 0.5 * (r[i] - (t ? t[i] : 0.0));
+                    }
             }
             if (sub == 0) {
                 const int64_t f = fineOf[q];
 #pragma unroll
-                for (int c = 0; c < DIM; ++c) acc[c] += r[f * DIM + c] - (t ? t[f * DIM + c] : 0.0);
+                for (int v = 0; v < NR; ++v)
+#pragma unroll
+                    for (int c = 0; c < DIM; ++c) {
+                        const int64_t i = v * fineStride + f * DIM + c;
+                        acc[v * DIM + c] += r[i] - (t ? t[i] : 0.0);
+                    }
             }
         }
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) {
+        for (int c = 0; c < W; ++c) {
 #pragma unroll
             for (int m = 1; m < MG_RESTRICT_LANES; m <<= 1) acc[c] += __shfl_xor(acc[c], m, 64);
         }
         if (q < nCoarse && sub == 0)
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) rc[q * DIM + c] = (coarseMask && coarseMask[q * DIM + c]) ? 0.0 : acc[c];
+            for (int c = 0; c < W; ++c) rc[q * W + c] = (coarseMask && coarseMask[q * DIM + c % DIM]) ? 0.0 : acc[c];
     }
 }
 
 // x += P xc on the free fine variables
+// (ldc: doubles between consecutive coarse rows -- DIM, or NR DIM when xc points at vector k of NR interleaved coarse vectors)
 template <int DIM>
 __global__ void __launch_bounds__(256) k_mg_prolong_add(int64_t nFine, const int32_t *__restrict__ parA, const int32_t *__restrict__ parB,
-                                                        const double *__restrict__ xc, const uint8_t *__restrict__ fineMask,
+                                                        const double *__restrict__ xc, int ldc, const uint8_t *__restrict__ fineMask,
                                                         double *__restrict__ x, MgGate g) {
     if (mg_closed(g)) return;
     for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nFine; n += (int64_t)gridDim.x * 256) {
@@ -1404,16 +1477,51 @@ __global__ void __launch_bounds__(256) k_mg_prolong_add(int64_t nFine, const int
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
             if (fineMask && fineMask[n * DIM + c]) continue;
-            x[n * DIM + c] += 0.5 * (xc[a * DIM + c] + xc[b * DIM + c]);
+            x[n * DIM + c] += 0.5 * (xc[a * ldc + c] + xc[b * ldc + c]);
+        }
+    }
+}
+
+// The same for the NR right-hand sides of the batched V-cycle in ONE launch: coarse vectors interleaved (entry ((row NR + k) DIM + c)), fine
+// vectors separate (vector k at x + k vecStride); one lane per (fine row, vector) pair -- the NR lanes of a row read 24 NR contiguous bytes of each
+// parent. Loop k's own gate (history scal + k scalStride, control block stop + 4 k) freezes its vector once it has converged.
+template <int DIM, int NR>
+__global__ void __launch_bounds__(256) k_mg_prolong_add_nr(int64_t nFine, const int32_t *__restrict__ parA, const int32_t *__restrict__ parB,
+                                                           const double *__restrict__ xc, const uint8_t *__restrict__ fineMask, double *__restrict__ x,
+                                                           int64_t vecStride, const double *scal, int64_t scalStride, int it, const double *stop) {
+    __shared__ int sOpen[NR];
+    if (threadIdx.x < NR) {
+        int open = 1;
+        if (scal) {
+            const double *st = stop + 4 * threadIdx.x;
+            const int itk = it + (int)st[3];
+            open = !(itk >= 0 && scal[threadIdx.x * scalStride + (int64_t)itk * 4 + 2] <= st[0]);
+        }
+        sOpen[threadIdx.x] = open;
+    }
+    __syncthreads();
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nFine * NR; p += (int64_t)gridDim.x * 256) {
+        const int64_t n = p / NR;
+        const int k = (int)(p - n * NR);
+        if (!sOpen[k]) continue;
+        const int64_t a = parA[n], b = parB[n];
+        if (a < 0) continue;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            if (fineMask && fineMask[n * DIM + c]) continue;
+            x[k * vecStride + n * DIM + c] += 0.5 * (xc[(a * NR + k) * DIM + c] + xc[(b * NR + k) * DIM + c]);
         }
     }
 }
 
 // x += Z yc on the free variables (prolongation of the rigid-body coarse correction, linear level)
-template <int DIM>
+// (coarse vectors of NR right-hand sides are [coarse index][NR], like the two-level kernels')
+template <int DIM, int NR = 1>
 __global__ void __launch_bounds__(256) k_mg_tl_prolong_add(TLArgs t, const double *__restrict__ yc, double *__restrict__ x, double alpha, MgGate g) {
     if (mg_closed(g)) return;
-    for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < t.nDoF; n += (int64_t)gridDim.x * 256) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < t.nDoF * NR; p += (int64_t)gridDim.x * 256) {
+        const int64_t n = p / NR;
+        const int kr = (int)(p - n * NR);
         const int a = t.aggOfDof[n];
         const double rp[3] = {t.relPos[n * 3], t.relPos[n * 3 + 1], t.relPos[n * 3 + 2]};
         double zv[DIM];
@@ -1422,13 +1530,13 @@ __global__ void __launch_bounds__(256) k_mg_tl_prolong_add(TLArgs t, const doubl
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             if (k >= t.nModes) break;
-            const double y = yc[(int64_t)a * t.nModes + k];
+            const double y = yc[((int64_t)a * t.nModes + k) * NR + kr];
 #pragma unroll
             for (int c = 0; c < DIM; ++c) zv[c] += y * tl_mode<DIM>(k, c, rp);
         }
 #pragma unroll
         for (int c = 0; c < DIM; ++c)
-            if (!(t.fixedMask && t.fixedMask[n * DIM + c])) x[n * DIM + c] += alpha * zv[c];
+            if (!(t.fixedMask && t.fixedMask[n * DIM + c])) x[p * DIM + c] += alpha * zv[c];
     }
 }
 
@@ -1473,12 +1581,16 @@ template <int DIM> DEV void st_transfer_T(const double *rel, const double *ch, d
     }
 }
 
-template <int DIM>
+// NR right-hand sides: vectors are [aggregate][mode][NR] (the layout of the two-level kernels' coarse vectors); one lane per (aggregate, mode,
+// vector) -- the NR lanes of a matrix row read the same stencil entries (one pass over the matrix for all NR vectors)
+template <int DIM, int NR = 1>
 __global__ void __launch_bounds__(256) k_st_spmv(int64_t nAgg, const int32_t *__restrict__ nbr, const double *__restrict__ A, const float *__restrict__ A32,
                                                  const double *__restrict__ x, double *__restrict__ y, MgGate g) {
     constexpr int NM = StDims<DIM>::NM, NS = StDims<DIM>::NS;
     if (mg_closed(g)) return;
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nAgg * NM; q += (int64_t)gridDim.x * 256) {
+    for (int64_t q0 = (int64_t)blockIdx.x * 256 + threadIdx.x; q0 < nAgg * NM * NR; q0 += (int64_t)gridDim.x * 256) {
+        const int64_t q = q0 / NR;
+        const int kr = (int)(q0 - q * NR);
         const int64_t a = q / NM;
         const int k = (int)(q - a * NM);
         double acc = 0;
@@ -1488,7 +1600,7 @@ __global__ void __launch_bounds__(256) k_st_spmv(int64_t nAgg, const int32_t *__
                 if (b < 0) continue;
                 const float *row = A32 + ((a * NS + sl) * NM + k) * NM;
 #pragma unroll
-                for (int l = 0; l < NM; ++l) acc += (double)row[l] * x[(int64_t)b * NM + l];
+                for (int l = 0; l < NM; ++l) acc += (double)row[l] * x[((int64_t)b * NM + l) * NR + kr];
             }
         } else
         for (int sl = 0; sl < NS; ++sl) {
@@ -1496,9 +1608,9 @@ __global__ void __launch_bounds__(256) k_st_spmv(int64_t nAgg, const int32_t *__
             if (b < 0) continue;
             const double *row = A + ((a * NS + sl) * NM + k) * NM;
 #pragma unroll
-            for (int l = 0; l < NM; ++l) acc += row[l] * x[(int64_t)b * NM + l];
+            for (int l = 0; l < NM; ++l) acc += row[l] * x[((int64_t)b * NM + l) * NR + kr];
         }
-        y[q] = acc;
+        y[q0] = acc;
     }
 }
 
@@ -1549,27 +1661,30 @@ __global__ void __launch_bounds__(256) k_st_dinv(int64_t nAgg, const double *__r
 }
 
 // Chebyshev step on an aggregate level (see k_mg_cheb): block size NM, full inverse blocks
-template <int DIM>
+template <int DIM, int NR = 1>
 __global__ void __launch_bounds__(256) k_st_cheb(int64_t nAgg, const double *__restrict__ Dinv, const double *__restrict__ rin, const double *__restrict__ t,
                                                  double *__restrict__ rout, double *__restrict__ d, double *__restrict__ x, double ca, double cb, int first,
                                                  int assign, MgGate g) {
     constexpr int NM = StDims<DIM>::NM;
     if (mg_closed(g)) return;
-    for (int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x; a < nAgg; a += (int64_t)gridDim.x * 256) {
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nAgg * NR; p += (int64_t)gridDim.x * 256) {
+        const int64_t a = p / NR;
+        const int kr = (int)(p - a * NR);
         double rv[NM];
 #pragma unroll
-        for (int k = 0; k < NM; ++k) rv[k] = rin[a * NM + k] - (t ? t[a * NM + k] : 0.0);
+        for (int k = 0; k < NM; ++k) rv[k] = rin[(a * NM + k) * NR + kr] - (t ? t[(a * NM + k) * NR + kr] : 0.0);
         if (rout)
 #pragma unroll
-            for (int k = 0; k < NM; ++k) rout[a * NM + k] = rv[k];
+            for (int k = 0; k < NM; ++k) rout[(a * NM + k) * NR + kr] = rv[k];
 #pragma unroll
         for (int k = 0; k < NM; ++k) {
             double z = 0;
 #pragma unroll
             for (int l = 0; l < NM; ++l) z += Dinv[a * NM * NM + k * NM + l] * rv[l];
-            const double dv = (first ? 0.0 : ca * d[a * NM + k]) + cb * z;
-            if (d) d[a * NM + k] = dv;
-            x[a * NM + k] = assign ? dv : x[a * NM + k] + dv;
+            const int64_t o = (a * NM + k) * NR + kr;
+            const double dv = (first ? 0.0 : ca * d[o]) + cb * z;
+            if (d) d[o] = dv;
+            x[o] = assign ? dv : x[o] + dv;
         }
     }
 }
@@ -1637,13 +1752,15 @@ __global__ void __launch_bounds__(256) k_st_rap(int64_t nParents, const int32_t 
 }
 
 // restriction between two aggregate levels, gather form: rc[p] = sum over the children a of p, in index order, of T_a^T (r - t)[a]
-template <int DIM>
+template <int DIM, int NR = 1>
 __global__ void __launch_bounds__(256) k_st_restrict(int64_t nParents, const int32_t *__restrict__ childPtr, const int32_t *__restrict__ childIdx,
                                                      const double *__restrict__ rel, const double *__restrict__ r, const double *__restrict__ t,
                                                      double *__restrict__ rc, MgGate g) {
     constexpr int NM = StDims<DIM>::NM;
     if (mg_closed(g)) return;
-    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nParents; p += (int64_t)gridDim.x * 256) {
+    for (int64_t p0 = (int64_t)blockIdx.x * 256 + threadIdx.x; p0 < nParents * NR; p0 += (int64_t)gridDim.x * 256) {
+        const int64_t p = p0 / NR;
+        const int kr = (int)(p0 - p * NR);
         double out[NM];
 #pragma unroll
         for (int k = 0; k < NM; ++k) out[k] = 0.0;
@@ -1651,24 +1768,29 @@ __global__ void __launch_bounds__(256) k_st_restrict(int64_t nParents, const int
             const int64_t a = childIdx[ci];
             double ch[NM];
 #pragma unroll
-            for (int k = 0; k < NM; ++k) ch[k] = r[a * NM + k] - (t ? t[a * NM + k] : 0.0);
+            for (int k = 0; k < NM; ++k) ch[k] = r[(a * NM + k) * NR + kr] - (t ? t[(a * NM + k) * NR + kr] : 0.0);
             st_transfer_T<DIM>(rel + a * 4, ch, out);
         }
 #pragma unroll
-        for (int k = 0; k < NM; ++k) rc[p * NM + k] = out[k];
+        for (int k = 0; k < NM; ++k) rc[(p * NM + k) * NR + kr] = out[k];
     }
 }
 
-template <int DIM>
+template <int DIM, int NR = 1>
 __global__ void __launch_bounds__(256) k_st_prolong_add(int64_t nAgg, const int32_t *__restrict__ parent, const double *__restrict__ rel, const double *__restrict__ xc,
                                                         double *__restrict__ x, double alpha, MgGate g) {
     constexpr int NM = StDims<DIM>::NM;
     if (mg_closed(g)) return;
-    for (int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x; a < nAgg; a += (int64_t)gridDim.x * 256) {
-        double ch[NM];
-        st_transfer<DIM>(rel + a * 4, xc + (int64_t)parent[a] * NM, ch);
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < nAgg * NR; p += (int64_t)gridDim.x * 256) {
+        const int64_t a = p / NR;
+        const int kr = (int)(p - a * NR);
+        double par[NM], ch[NM];
+        const int64_t pa = parent[a];
 #pragma unroll
-        for (int k = 0; k < NM; ++k) x[a * NM + k] += alpha * ch[k];
+        for (int k = 0; k < NM; ++k) par[k] = xc[(pa * NM + k) * NR + kr];
+        st_transfer<DIM>(rel + a * 4, par, ch);
+#pragma unroll
+        for (int k = 0; k < NM; ++k) x[(a * NM + k) * NR + kr] += alpha * ch[k];
     }
 }
 
@@ -2002,6 +2124,14 @@ void launch_cg_init(int dim, int64_t nRows, int NR, const double *dinv, const do
     CHECK_LAUNCH();
 }
 void launch_tl_restrict_nr(const TLArgs &t, int NR, const int32_t *aggPtr, const int32_t *dofsByAgg, const double *w, double *rc, hipStream_t s) {
+    if (t.nDoF < (int64_t)t.nAgg * 160 && ((t.dim == 3 && (NR == 2 || NR == 6)) || (t.dim == 2 && NR == 3))) {      // small aggregates: a wave each
+        const unsigned grid = (unsigned)((t.nAgg + 3) / 4);
+        if (t.dim == 3 && NR == 6) hipLaunchKernelGGL((k_tl_restrict_wave_nr<3, 6>), dim3(grid), dim3(256), 0, s, t, aggPtr, dofsByAgg, w, rc);
+        else if (t.dim == 3) hipLaunchKernelGGL((k_tl_restrict_wave_nr<3, 2>), dim3(grid), dim3(256), 0, s, t, aggPtr, dofsByAgg, w, rc);
+        else hipLaunchKernelGGL((k_tl_restrict_wave_nr<2, 3>), dim3(grid), dim3(256), 0, s, t, aggPtr, dofsByAgg, w, rc);
+        CHECK_LAUNCH();
+        return;
+    }
     if (t.dim == 3) hipLaunchKernelGGL(k_tl_restrict_nr<3>, dim3(t.nAgg), dim3(256), 0, s, t, NR, aggPtr, dofsByAgg, w, rc);
     else hipLaunchKernelGGL(k_tl_restrict_nr<2>, dim3(t.nAgg), dim3(256), 0, s, t, NR, aggPtr, dofsByAgg, w, rc);
     CHECK_LAUNCH();
@@ -2060,35 +2190,55 @@ void launch_scatter_values_nr(int64_t n, int NR, int dim, const int64_t *idx, co
 
 
 // ---- p-multigrid
-static MgGate mk_gate(const double *scal, int it, const double *stop) { return MgGate{scal, it, stop}; }
+// the gate's layout (GateScope, mfh_internal.hh): 0 = one classic loop, NR >= 1 = closed when all of NR lockstep loops are (histories t_gateStride apart)
+thread_local int t_gateNr = 0;
+thread_local int64_t t_gateStride = 0;
+static MgGate mk_gate(const double *scal, int it, const double *stop) { return MgGate{scal, it, stop, t_gateNr, t_gateStride}; }
+// kernels templated on (DIM, NR): NR = 1 and the batch sizes of op_batch_supported (3D: 2, 6; 2D: 3)
+#define MG_NR_DISPATCH(dim, NR, K, grid, ...)                                                                     \
+    do {                                                                                                          \
+        if ((NR) == 1) {                                                                                          \
+            if ((dim) == 3) hipLaunchKernelGGL((K<3, 1>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);              \
+            else hipLaunchKernelGGL((K<2, 1>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);                         \
+        } else if ((dim) == 3 && (NR) == 2) hipLaunchKernelGGL((K<3, 2>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+        else if ((dim) == 3 && (NR) == 6) hipLaunchKernelGGL((K<3, 6>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);   \
+        else if ((dim) == 2 && (NR) == 3) hipLaunchKernelGGL((K<2, 3>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);   \
+        else throw Error(MFH_ERR_UNSUPPORTED, "multigrid kernels: unsupported batch size");                      \
+        CHECK_LAUNCH();                                                                                           \
+    } while (0)
 void launch_mg_cheb(int dim, int64_t nRows, const double *dinv, const double *rin, const double *t, double *rout, double *d, double *x,
-                    double a, double b, bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s) {
+                    double a, double b, bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s, int NR) {
     const MgGate g = mk_gate(scal, it, stop);
-    const int grid = grid_for(nRows, g_vecGridCap);
-    if (dim == 3) hipLaunchKernelGGL(k_mg_cheb<3>, dim3(grid), dim3(256), 0, s, nRows, dinv, rin, t, rout, d, x, a, b, first ? 1 : 0, assign ? 1 : 0, g);
-    else if (dim == 2) hipLaunchKernelGGL(k_mg_cheb<2>, dim3(grid), dim3(256), 0, s, nRows, dinv, rin, t, rout, d, x, a, b, first ? 1 : 0, assign ? 1 : 0, g);
-    else hipLaunchKernelGGL(k_mg_cheb<1>, dim3(grid), dim3(256), 0, s, nRows, dinv, rin, t, rout, d, x, a, b, first ? 1 : 0, assign ? 1 : 0, g);
-    CHECK_LAUNCH();
+    const int grid = grid_for(nRows * NR, g_vecGridCap);
+    if (dim == 1 && NR == 1) { hipLaunchKernelGGL(k_mg_cheb<1>, dim3(grid), dim3(256), 0, s, nRows, dinv, rin, t, rout, d, x, a, b, first ? 1 : 0, assign ? 1 : 0, g); CHECK_LAUNCH(); return; }
+    MG_NR_DISPATCH(dim, NR, k_mg_cheb, grid, nRows, dinv, rin, t, rout, d, x, a, b, first ? 1 : 0, assign ? 1 : 0, g);
 }
 void launch_mg_restrict(int dim, int64_t nCoarse, const int32_t *fineOf, const int32_t *resPtr, const int32_t *resIdx, const double *r, const double *t,
-                        const uint8_t *coarseMask, double *rc, const double *scal, int it, const double *stop, hipStream_t s) {
+                        const uint8_t *coarseMask, double *rc, const double *scal, int it, const double *stop, hipStream_t s, int NR, int64_t fineStride) {
     const MgGate g = mk_gate(scal, it, stop);
-    if (dim == 3) hipLaunchKernelGGL(k_mg_restrict<3>, dim3(grid_for(nCoarse * MG_RESTRICT_LANES, MG_RESTRICT_LANES * g_vecGridCap)), dim3(256), 0, s, nCoarse, fineOf, resPtr, resIdx, r, t, coarseMask, rc, g);
-    else hipLaunchKernelGGL(k_mg_restrict<2>, dim3(grid_for(nCoarse * MG_RESTRICT_LANES, MG_RESTRICT_LANES * g_vecGridCap)), dim3(256), 0, s, nCoarse, fineOf, resPtr, resIdx, r, t, coarseMask, rc, g);
-    CHECK_LAUNCH();
+    const int grid = grid_for(nCoarse * MG_RESTRICT_LANES, MG_RESTRICT_LANES * g_vecGridCap);
+    MG_NR_DISPATCH(dim, NR, k_mg_restrict, grid, nCoarse, fineOf, resPtr, resIdx, r, t, fineStride, coarseMask, rc, g);
 }
 void launch_mg_prolong_add(int dim, int64_t nFine, const int32_t *parA, const int32_t *parB, const double *xc, const uint8_t *fineMask, double *x,
-                           const double *scal, int it, const double *stop, hipStream_t s) {
+                           const double *scal, int it, const double *stop, hipStream_t s, int ldc) {
     const MgGate g = mk_gate(scal, it, stop);
-    if (dim == 3) hipLaunchKernelGGL(k_mg_prolong_add<3>, dim3(grid_for(nFine, g_vecGridCap)), dim3(256), 0, s, nFine, parA, parB, xc, fineMask, x, g);
-    else hipLaunchKernelGGL(k_mg_prolong_add<2>, dim3(grid_for(nFine, g_vecGridCap)), dim3(256), 0, s, nFine, parA, parB, xc, fineMask, x, g);
+    if (ldc <= 0) ldc = dim;
+    if (dim == 3) hipLaunchKernelGGL(k_mg_prolong_add<3>, dim3(grid_for(nFine, g_vecGridCap)), dim3(256), 0, s, nFine, parA, parB, xc, ldc, fineMask, x, g);
+    else hipLaunchKernelGGL(k_mg_prolong_add<2>, dim3(grid_for(nFine, g_vecGridCap)), dim3(256), 0, s, nFine, parA, parB, xc, ldc, fineMask, x, g);
     CHECK_LAUNCH();
 }
-void launch_mg_tl_prolong_add(const TLArgs &t, const double *yc, double *x, double alpha, const double *scal, int it, const double *stop, hipStream_t s) {
-    const MgGate g = mk_gate(scal, it, stop);
-    if (t.dim == 3) hipLaunchKernelGGL(k_mg_tl_prolong_add<3>, dim3(grid_for(t.nDoF, g_vecGridCap)), dim3(256), 0, s, t, yc, x, alpha, g);
-    else hipLaunchKernelGGL(k_mg_tl_prolong_add<2>, dim3(grid_for(t.nDoF, g_vecGridCap)), dim3(256), 0, s, t, yc, x, alpha, g);
+void launch_mg_prolong_add_nr(int dim, int NR, int64_t nFine, const int32_t *parA, const int32_t *parB, const double *xc, const uint8_t *fineMask, double *x,
+                              int64_t vecStride, const double *scal, int64_t scalStride, int it, const double *stop, hipStream_t s) {
+    const int grid = grid_for(nFine * NR, g_vecGridCap);
+    if (dim == 3 && NR == 6) hipLaunchKernelGGL((k_mg_prolong_add_nr<3, 6>), dim3(grid), dim3(256), 0, s, nFine, parA, parB, xc, fineMask, x, vecStride, scal, scalStride, it, stop);
+    else if (dim == 3 && NR == 2) hipLaunchKernelGGL((k_mg_prolong_add_nr<3, 2>), dim3(grid), dim3(256), 0, s, nFine, parA, parB, xc, fineMask, x, vecStride, scal, scalStride, it, stop);
+    else if (dim == 2 && NR == 3) hipLaunchKernelGGL((k_mg_prolong_add_nr<2, 3>), dim3(grid), dim3(256), 0, s, nFine, parA, parB, xc, fineMask, x, vecStride, scal, scalStride, it, stop);
+    else throw Error(MFH_ERR_UNSUPPORTED, "multigrid kernels: unsupported batch size");
     CHECK_LAUNCH();
+}
+void launch_mg_tl_prolong_add(const TLArgs &t, const double *yc, double *x, double alpha, const double *scal, int it, const double *stop, hipStream_t s, int NR) {
+    const MgGate g = mk_gate(scal, it, stop);
+    MG_NR_DISPATCH(t.dim, NR, k_mg_tl_prolong_add, grid_for(t.nDoF * NR, g_vecGridCap), t, yc, x, alpha, g);
 }
 void launch_fill_hash(int64_t n, double *v, hipStream_t s) {
     hipLaunchKernelGGL(k_fill_hash, dim3(grid_for(n, g_vecGridCap)), dim3(256), 0, s, n, v);
@@ -2120,13 +2270,13 @@ void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, do
         else hipLaunchKernelGGL(K<2>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);            \
         CHECK_LAUNCH();                                                                     \
     } while (0)
-void launch_st_spmv(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const float *A32, const double *x, double *y, const double *scal, int it, const double *stop, hipStream_t s) {
-    ST_DISPATCH(dim, k_st_spmv, grid_for(nAgg * 6), nAgg, nbr, A, A32, x, y, mk_gate(scal, it, stop));
+void launch_st_spmv(int dim, int64_t nAgg, const int32_t *nbr, const double *A, const float *A32, const double *x, double *y, const double *scal, int it, const double *stop, hipStream_t s, int NR) {
+    MG_NR_DISPATCH(dim, NR, k_st_spmv, grid_for(nAgg * 6 * NR), nAgg, nbr, A, A32, x, y, mk_gate(scal, it, stop));
 }
 void launch_st_dinv(int dim, int64_t nAgg, const double *A, double *Dinv, hipStream_t s) { ST_DISPATCH(dim, k_st_dinv, grid_for(nAgg), nAgg, A, Dinv); }
 void launch_st_cheb(int dim, int64_t nAgg, const double *Dinv, const double *rin, const double *t, double *rout, double *d, double *x, double a, double b,
-                    bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s) {
-    ST_DISPATCH(dim, k_st_cheb, grid_for(nAgg), nAgg, Dinv, rin, t, rout, d, x, a, b, first ? 1 : 0, assign ? 1 : 0, mk_gate(scal, it, stop));
+                    bool first, bool assign, const double *scal, int it, const double *stop, hipStream_t s, int NR) {
+    MG_NR_DISPATCH(dim, NR, k_st_cheb, grid_for(nAgg * NR), nAgg, Dinv, rin, t, rout, d, x, a, b, first ? 1 : 0, assign ? 1 : 0, mk_gate(scal, it, stop));
 }
 void launch_st_rap(int dim, int64_t nParents, const int32_t *childPtr, const int32_t *childIdx, const int32_t *nbr, const double *A, const int32_t *parent,
                    const double *rel, const int32_t *coordC, double *Ac, const int *wrapNbC, hipStream_t s) {
@@ -2134,17 +2284,18 @@ void launch_st_rap(int dim, int64_t nParents, const int32_t *childPtr, const int
     ST_DISPATCH(dim, k_st_rap, grid_for(nParents * 27), nParents, childPtr, childIdx, nbr, A, parent, rel, coordC, Ac, wx, wy, wz);
 }
 void launch_st_restrict(int dim, int64_t nParents, const int32_t *childPtr, const int32_t *childIdx, const double *rel, const double *r, const double *t, double *rc,
-                        const double *scal, int it, const double *stop, hipStream_t s) {
-    ST_DISPATCH(dim, k_st_restrict, grid_for(nParents), nParents, childPtr, childIdx, rel, r, t, rc, mk_gate(scal, it, stop));
+                        const double *scal, int it, const double *stop, hipStream_t s, int NR) {
+    MG_NR_DISPATCH(dim, NR, k_st_restrict, grid_for(nParents * NR), nParents, childPtr, childIdx, rel, r, t, rc, mk_gate(scal, it, stop));
 }
 void launch_st_prolong_add(int dim, int64_t nAgg, const int32_t *parent, const double *rel, const double *xc, double *x, double alpha, const double *scal, int it,
-                           const double *stop, hipStream_t s) {
-    ST_DISPATCH(dim, k_st_prolong_add, grid_for(nAgg), nAgg, parent, rel, xc, x, alpha, mk_gate(scal, it, stop));
+                           const double *stop, hipStream_t s, int NR) {
+    MG_NR_DISPATCH(dim, NR, k_st_prolong_add, grid_for(nAgg * NR), nAgg, parent, rel, xc, x, alpha, mk_gate(scal, it, stop));
 }
 void launch_st_to_dense(int dim, int64_t nAgg, const int32_t *nbr, const double *A, double *Ad, hipStream_t s) {
     ST_DISPATCH(dim, k_st_to_dense, grid_for(nAgg * 27 * 36), nAgg, nbr, A, Ad);
 }
 #undef ST_DISPATCH
+#undef MG_NR_DISPATCH
 void launch_mg_zero(int64_t n, double *v, const double *scal, int it, const double *stop, hipStream_t s) {
     hipLaunchKernelGGL(k_mg_zero, dim3(grid_for(n, g_vecGridCap)), dim3(256), 0, s, n, v, mk_gate(scal, it, stop));
     CHECK_LAUNCH();

@@ -19,6 +19,7 @@ k::TLArgs tl_args(mfh_ctx *c);
 void apply_operator(mfh_ctx *c, bool masked, const double *x, double *y, double *dotOut);
 bool prepare_matrix_free(mfh_ctx *c);
 void apply_operator_smoother(mfh_ctx *c, bool masked, const double *x, double *y);
+void batch_apply(mfh_ctx *c, int NR, double *x, double *y, bool masked);            // y = K x for NR interleaved vectors (mfh_solver.cpp)
 void ensure_fixed_uploaded(mfh_ctx *c);
 double device_dot(mfh_ctx *c, int64_t n, const double *a, const double *b);
 void upload_mesh(mfh_ctx *c, bool deviceTables);
@@ -39,13 +40,22 @@ struct LevelOps {
 };
 
 // the two nodal levels: the context's operator (matrix-free or assembled) and its block-Jacobi inverse
-LevelOps nodal_ops(mfh_ctx *c, const double *scal, int it, const double *stop) {
+// NR > 1: NR interleaved right-hand sides (unpartitioned contexts; the batched PCG's layout)
+LevelOps nodal_ops(mfh_ctx *c, const double *scal, int it, const double *stop, int NR = 1) {
     LevelOps L;
     const int d = c->bs();
     const int64_t nRows = c->sym.nRows;
     const bool masked = !c->fixedVars.empty();
     hipStream_t s = c->stream;
-    L.n = nRows * d;
+    L.n = nRows * d * NR;
+    if (NR > 1) {
+        L.apply = [=](const double *x, double *y) { batch_apply(c, NR, const_cast<double *>(x), y, masked); };
+        L.step = [=](const double *rin, const double *t, double *rout, double *dv, double *x, double a, double b, bool first, bool assign) {
+            k::launch_mg_cheb(d, nRows, c->dDinv.p, rin, t, rout, dv, x, a, b, first, assign, scal, it, stop, s, NR);
+        };
+        if (masked) L.mask = [=](double *v) { k::launch_mask_nr(nRows, NR, d, c->dFixedMask.p, v, s); };
+        return L;
+    }
     if (c->sym.nRows != c->sym.nCols) {
         // row-partitioned level: the vectors the operator is applied to hold nCols block rows; their halo part is fetched first
         L.apply = [=](const double *x, double *y) { dist_apply(c, const_cast<double *>(x), y, masked); };
@@ -59,7 +69,7 @@ LevelOps nodal_ops(mfh_ctx *c, const double *scal, int it, const double *stop) {
     return L;
 }
 
-LevelOps agg_ops(mfh_ctx *c, mfh_ctx::AggLevel &A, const double *scal, int it, const double *stop) {
+LevelOps agg_ops(mfh_ctx *c, mfh_ctx::AggLevel &A, const double *scal, int it, const double *stop, int NR = 1) {
     LevelOps L;
     const int dim = c->dim();
     hipStream_t s = c->stream;
@@ -68,7 +78,14 @@ LevelOps agg_ops(mfh_ctx *c, mfh_ctx::AggLevel &A, const double *scal, int it, c
     const double *Ap = A.A.p, *Dinv = A.Dinv.p;
     const float *Ap32 = A.A32.n == A.A.n ? A.A32.p : nullptr;
     const int NM = dim == 3 ? 6 : 3;
-    L.n = nAgg * NM;
+    L.n = nAgg * NM * NR;
+    if (NR > 1) {
+        L.apply = [=](const double *x, double *y) { k::launch_st_spmv(dim, nAgg, nbr, Ap, Ap32, x, y, scal, it, stop, s, NR); };
+        L.step = [=](const double *rin, const double *t, double *rout, double *dv, double *x, double a, double b, bool first, bool assign) {
+            k::launch_st_cheb(dim, nAgg, Dinv, rin, t, rout, dv, x, a, b, first, assign, scal, it, stop, s, NR);
+        };
+        return L;
+    }
     if (A.part) {
         // partitioned level: the rows this rank owns; the vector the stencil is applied to gets its halo entries from their owners first
         const int64_t nOwn = A.nOwn;
@@ -583,17 +600,19 @@ void localize_aggregate_levels(mfh_ctx *c, mfh_ctx *c1, const std::function<void
     lap("aggregate levels: localized");
 }
 
-// x = (approximately) A_l^-1 b on aggregate level l: a symmetric V-cycle down to the dense level
-void agg_cycle(mfh_ctx *c, size_t l, const double *scal, int it, const double *stop) {
+// x = (approximately) A_l^-1 b on aggregate level l: a symmetric V-cycle down to the dense level (NR right-hand sides at once on an
+// unpartitioned hierarchy)
+void agg_cycle(mfh_ctx *c, size_t l, const double *scal, int it, const double *stop, int NR = 1) {
     auto &G = c->mg;
     mfh_ctx::AggLevel &L = *G.agg[l];
     hipStream_t s = c->stream;
     const int dim = c->dim();
     if (l + 1 == G.agg.size()) {
-        k::launch_tl_gemv(G.denseM, G.denseLd, G.denseInv.p, L.b.p, L.x.p, s);
+        if (NR > 1) k::launch_tl_gemv_nr(G.denseM, G.denseLd, NR, G.denseInv.p, L.b.p, L.x.p, s);
+        else k::launch_tl_gemv(G.denseM, G.denseLd, G.denseInv.p, L.b.p, L.x.p, s);
         return;
     }
-    LevelOps ops = agg_ops(c, L, scal, it, stop);
+    LevelOps ops = agg_ops(c, L, scal, it, stop, NR);
     ops.lmax = L.lmax; ops.ratio = c->mgRatioAgg; ops.steps = c->mgStepsAgg;
     mfh_ctx::AggLevel &Cn = *G.agg[l + 1];
     const double *ra = nullptr, *rb = nullptr;
@@ -606,10 +625,10 @@ void agg_cycle(mfh_ctx *c, size_t l, const double *scal, int it, const double *s
         if (Cn.part) dist_level_reverse_add(c, Cn, Cn.b.p, NM);
         else dist_allreduce(c, Cn.b.p, Cn.nAgg * NM);
     } else
-        k::launch_st_restrict(dim, Cn.nAgg, L.childPtr.p, L.childIdx.p, L.rel.p, ra, rb, Cn.b.p, scal, it, stop, s);
-    agg_cycle(c, l + 1, scal, it, stop);
+        k::launch_st_restrict(dim, Cn.nAgg, L.childPtr.p, L.childIdx.p, L.rel.p, ra, rb, Cn.b.p, scal, it, stop, s, NR);
+    agg_cycle(c, l + 1, scal, it, stop, NR);
     if (L.part && Cn.part) dist_level_forward(c, Cn, Cn.x.p, NM);          // parents owned elsewhere
-    k::launch_st_prolong_add(dim, L.rows(), L.parent.p, L.rel.p, Cn.x.p, L.x.p, c->mgOverCorrection, scal, it, stop, s);
+    k::launch_st_prolong_add(dim, L.rows(), L.parent.p, L.rel.p, Cn.x.p, L.x.p, c->mgOverCorrection, scal, it, stop, s, NR);
     chebyshev(ops, L.b.p, L.x.p, false, false, L.r.p, L.d.p, L.t.p);
 }
 
@@ -629,6 +648,7 @@ void destroy_multigrid(mfh_ctx *c) {
     auto &G = c->mg;
     G.valid = false;
     G.linearOnly = false;
+    G.nrAlloc = 1;
     G.agg.clear();
     if (G.coarse) { mfh_destroy(G.coarse); G.coarse = nullptr; }
 }
@@ -897,41 +917,68 @@ bool ensure_multigrid(mfh_ctx *c) {
 
 // The linear level: x = (approximately) K1^-1 b -- (smooth, aggregate / dense coarse correction, smooth) x mgCoarseCycles. Repeating
 // one symmetric stationary iteration keeps M symmetric.
-static void linear_level(mfh_ctx *c, mfh_ctx *c1, const double *b, double *x, const double *scal, int it, const double *stop) {
+static void linear_level(mfh_ctx *c, mfh_ctx *c1, const double *b, double *x, const double *scal, int it, const double *stop, int NR = 1) {
     auto &G = c->mg;
     hipStream_t s = c->stream;
     const int d = c->bs();
-    LevelOps L1 = nodal_ops(c1, scal, it, stop);
+    LevelOps L1 = nodal_ops(c1, scal, it, stop, NR);
     L1.lmax = G.lmax1; L1.ratio = c->mgRatio1; L1.steps = c->mgSteps1;
     const bool masked1 = !c1->fixedVars.empty();
     for (int cyc = 0; cyc < c->mgCoarseCycles; ++cyc) {
         const double *qa = nullptr, *qb = nullptr;
         chebyshev(L1, b, x, cyc == 0, G.rigidCoarse, G.r1.p, G.d1.p, G.t1.p, &qa, &qb);
         if (G.rigidCoarse) {
-            k::launch_mg_diff((int64_t)d * G.nCoarse, qa, qb, G.r1.p, scal, it, stop, s);               // residual of the linear level
+            k::launch_mg_diff((int64_t)d * G.nCoarse * NR, qa, qb, G.r1.p, scal, it, stop, s);               // residual of the linear level
             if (!G.agg.empty()) {             // aggregate hierarchy
                 mfh_ctx::AggLevel &A0 = *G.agg[0];
                 k::TLArgs ta{};
                 ta.dim = c->dim(); ta.nModes = ta.dim == 3 ? 6 : 3; ta.nAgg = (int)A0.size(); ta.nDoF = c1->sym.nRows;
                 ta.aggOfDof = G.aggOfDof2.p; ta.relPos = G.relPos2.p; ta.fixedMask = masked1 ? c1->dFixedMask.p : nullptr;
-                k::launch_tl_restrict(ta, G.aggPtr2.p, G.dofsByAgg2.p, G.r1.p, A0.b.p, s);
+                if (NR > 1) k::launch_tl_restrict_nr(ta, NR, G.aggPtr2.p, G.dofsByAgg2.p, G.r1.p, A0.b.p, s);
+                else k::launch_tl_restrict(ta, G.aggPtr2.p, G.dofsByAgg2.p, G.r1.p, A0.b.p, s);
                 // every rank restricted the rows it owns: partitioned first level -> the partial sums of the aggregates it shares with a
                 // neighbour go to their owners; replicated -> summed on every rank
                 if (A0.part) dist_level_reverse_add(c, A0, A0.b.p, ta.nModes);
                 else if (G.distributed) dist_allreduce(c, A0.b.p, A0.nAgg * ta.nModes);
-                agg_cycle(c, 0, scal, it, stop);
+                agg_cycle(c, 0, scal, it, stop, NR);
                 if (A0.part) dist_level_forward(c, A0, A0.x.p, ta.nModes);              // aggregates of own DoFs that a neighbour owns
-                k::launch_mg_tl_prolong_add(ta, A0.x.p, x, c->mgOverCorrection, scal, it, stop, s);
+                k::launch_mg_tl_prolong_add(ta, A0.x.p, x, c->mgOverCorrection, scal, it, stop, s, NR);
             } else {                          // the linear context's own dense coarse space (~1000 aggregates)
                 auto &T = c1->tl;
                 const k::TLArgs ta = tl_args(c1);
-                k::launch_tl_restrict(ta, T.aggPtr.p, T.dofsByAgg.p, G.r1.p, T.rc.p, s);
-                k::launch_tl_gemv(T.m, T.ldInv, T.Ainv.p, T.rc.p, T.yc.p, s);
-                k::launch_mg_tl_prolong_add(ta, T.yc.p, x, c->mgOverCorrection, scal, it, stop, s);
+                if (NR > 1) {
+                    c1->tlRcN.reserve((size_t)T.m * NR); c1->tlYcN.reserve((size_t)T.m * NR);
+                    k::launch_tl_restrict_nr(ta, NR, T.aggPtr.p, T.dofsByAgg.p, G.r1.p, c1->tlRcN.p, s);
+                    k::launch_tl_gemv_nr(T.m, T.ldInv, NR, T.Ainv.p, c1->tlRcN.p, c1->tlYcN.p, s);
+                    k::launch_mg_tl_prolong_add(ta, c1->tlYcN.p, x, c->mgOverCorrection, scal, it, stop, s, NR);
+                } else {
+                    k::launch_tl_restrict(ta, T.aggPtr.p, T.dofsByAgg.p, G.r1.p, T.rc.p, s);
+                    k::launch_tl_gemv(T.m, T.ldInv, T.Ainv.p, T.rc.p, T.yc.p, s);
+                    k::launch_mg_tl_prolong_add(ta, T.yc.p, x, c->mgOverCorrection, scal, it, stop, s);
+                }
             }
         }
         chebyshev(L1, b, x, false, false, G.r1.p, G.d1.p, G.t1.p);
     }
+}
+
+// Work vectors of the hierarchy for NR right-hand sides at once (unpartitioned quadratic hierarchies; the vectors only ever grow)
+static void reserve_batch(mfh_ctx *c, int NR) {
+    auto &G = c->mg;
+    if (G.nrAlloc >= NR) return;
+    hipStream_t s = c->stream;
+    MFH_HIP(hipStreamSynchronize(s));                  // (the buffers being replaced may be in use by work enqueued earlier)
+    const int d = c->bs();
+    const int NM = c->dim() == 3 ? 6 : 3;
+    mfh_ctx *c1 = G.coarse;
+    const size_t n0 = (size_t)d * c->nDoF * NR, n1 = (size_t)d * c1->nDoF * NR;
+    G.r0.alloc(n0); G.d0.alloc(n0); G.t0.alloc(n0);
+    G.b1.alloc(n1); G.x1.alloc(n1); G.r1.alloc(n1); G.d1.alloc(n1); G.t1.alloc(n1);
+    for (auto &A : G.agg) {
+        const size_t n = (size_t)A->nAgg * NM * NR;
+        A->x.alloc(n); A->b.alloc(n); A->r.alloc(n); A->d.alloc(n); A->t.alloc(n);
+    }
+    G.nrAlloc = NR;
 }
 
 // z = M^-1 r: one symmetric V-cycle. scal / it / stop: the gate of the PCG iteration this application belongs to (null: none).
@@ -963,6 +1010,48 @@ void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int 
     // back to level 0: z += P x1, post-smoothing
     k::launch_mg_prolong_add(d, G.nFine, G.parA.p, G.parB.p, G.x1.p, masked0 ? c->dFixedMask.p : nullptr, z, scal, it, stop, s);
     chebyshev(L0, r, z, false, false, G.r0.p, G.d0.p, G.t0.p);
+}
+
+// The V-cycle for NR right-hand sides at once (solve_multigrid_batch; unpartitioned quadratic hierarchies). The quadratic level works on NR
+// SEPARATE vectors (vector k at r + k vecStride; its smoother is the tuned single-vector operator, gated by loop k's own history at
+// scal + k scalStride / stop + 4 k); the restriction interleaves them, and the linear level, the aggregate levels and the dense level run ONCE
+// for all NR -- their matrices are read once, their launch latencies paid once --, gated by "every loop has converged".
+void mg_precond_batch(mfh_ctx *c, int NR, const double *r, double *z, int64_t vecStride, const double *scal, int64_t scalStride, int it, const double *stop) {
+    auto &G = c->mg;
+    if (G.distributed || G.linearOnly) throw Error(MFH_ERR_UNSUPPORTED, "batched V-cycle: unpartitioned quadratic hierarchies only");
+    reserve_batch(c, NR);
+    mfh_ctx *c1 = G.coarse;
+    hipStream_t s = c->stream;
+    const int d = c->bs();
+    const bool masked0 = !c->fixedVars.empty(), masked1 = !c1->fixedVars.empty();
+    auto gate_k = [&](int k2, const double *&sc, const double *&st) { sc = scal ? scal + (size_t)k2 * scalStride : nullptr; st = stop ? stop + 4 * k2 : nullptr; };
+    const double *ra0 = nullptr, *rb0 = nullptr;
+    for (int k2 = 0; k2 < NR; ++k2) {          // pre-smoothing from zero, one right-hand side after the other
+        const double *sc, *st;
+        gate_k(k2, sc, st);
+        LevelOps L0 = nodal_ops(c, sc, it, st);
+        L0.lmax = G.lmax0; L0.ratio = c->mgRatio0; L0.steps = c->mgSteps0;
+        const double *ra = nullptr, *rb = nullptr;
+        const size_t o = (size_t)k2 * vecStride;
+        chebyshev(L0, r + o, z + o, true, true, G.r0.p + o, G.d0.p + o, G.t0.p + o, &ra, &rb);
+        if (k2 == 0) { ra0 = ra; rb0 = rb; }
+        else if (ra != ra0 + o || rb != rb0 + o) throw Error(MFH_ERR_STATE, "batched V-cycle: residual vectors are not equally spaced");
+    }
+    {
+        k::GateScope all(scal ? NR : 0, scalStride);      // from here to the prolongation: closed once every loop has converged
+        k::launch_mg_restrict(d, G.nCoarse, G.fineOf.p, G.resPtr.p, G.resIdx.p, ra0, rb0, masked1 ? c1->dFixedMask.p : nullptr, G.b1.p, scal, it, stop, s, NR, vecStride);
+        linear_level(c, c1, G.b1.p, G.x1.p, scal, it, stop, NR);
+    }
+    // z_k += P x1_k for all k in one launch (gated per loop), then post-smoothing, one right-hand side after the other
+    k::launch_mg_prolong_add_nr(d, NR, G.nFine, G.parA.p, G.parB.p, G.x1.p, masked0 ? c->dFixedMask.p : nullptr, z, vecStride, scal, scalStride, it, stop, s);
+    for (int k2 = 0; k2 < NR; ++k2) {
+        const double *sc, *st;
+        gate_k(k2, sc, st);
+        LevelOps L0 = nodal_ops(c, sc, it, st);
+        L0.lmax = G.lmax0; L0.ratio = c->mgRatio0; L0.steps = c->mgSteps0;
+        const size_t o = (size_t)k2 * vecStride;
+        chebyshev(L0, r + o, z + o, false, false, G.r0.p + o, G.d0.p + o, G.t0.p + o);
+    }
 }
 
 }   // namespace mfhi

@@ -203,6 +203,9 @@ static void constant_strain_load_impl(mfh_ctx *c, const double *cstrain, const d
     DBuf<double> dp;
     if (deltaP) upload_delta_p(c, deltaP, dp);
     c->wb.alloc(n);
+    // once the matrix-free operator's lists exist the load is an application of its element routine (LDS sums, 0.25 ms at 2 M quadratic tets);
+    // before that -- a caller that only wants load vectors -- the stand-alone kernel with its global atomics (2.3 ms) needs nothing but the records
+    if (!deltaP && c->mfcValid && constant_strain_load_device(c, cs, c->wb.p)) { c->wb.download(out, (size_t)n, c->stream); return; }
     c->wb.zero(c->stream);
     k::launch_constant_strain_load(asm_args(c), c->dElemNodes.p, device_dof_map(c), c->tables.intGrad.data(), cs, deltaP ? dp.p : nullptr,
                                    c->wb.p, c->stream);
@@ -355,8 +358,11 @@ static double hdot(const std::vector<double> &a, const RawVec<double> &b) { retu
 //     C Z square and regular: multipliers from Z^T (f - C^T l) = 0, ONE consistent singular PCG solve, rigid part of the
 //     solution from C u = c;
 //   * K regular on the free variables: Schur complement S = C K^-1 C^T with k + 1 PCG solves.
+// nrhs > 1 (mfh_sim_solve_batch): f / uNodes / info hold nrhs right-hand sides; systems that need constraint rows are refused (the caller
+// then solves one right-hand side after the other)
+// cstrains != null (mfh_solve_cell_problems): the nrhs right-hand sides are constantStrainLoad(cstrains[r]); f is not read
 static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const double *rmRHS, int32_t nRM, double *uNodes, double rtol,
-                           int32_t maxit, mfh_solve_info *info) {
+                           int32_t maxit, mfh_solve_info *info, int nrhs = 1, const double *cstrains = nullptr) {
     const HostMesh &m = c->mesh;
     const int d = c->bs(), gd = m.dim;
     const int64_t n = (int64_t)d * c->nDoF;
@@ -466,6 +472,58 @@ static void sim_solve_impl(mfh_ctx *c, const double *f, int32_t flags, const dou
     lap("two-level setup");
     mfh_solve_info li{};
     const int k = (int)C.size();
+    if (nrhs > 1) {
+        if (k != 0 || (!f && !cstrains)) throw Error(MFH_ERR_UNSUPPORTED, "batched Simulator::solve: the system needs constraint rows");
+        const int64_t nn = m.nNode * d;
+        if (cstrains) {
+            // loads formed on the device, solutions downloaded as nodal fields: no host copy of a load or of a DoF vector exists
+            const int fl = flat_len(gd);
+            if (!multigrid_batch_ready(c, nrhs)) throw Error(MFH_ERR_UNSUPPORTED, "batched cell problems: the batched V-cycle does not apply to this context");
+            int r0 = 0;
+            bool all = true;
+            std::vector<mfh_solve_info> lis((size_t)nrhs);
+            while (r0 < nrhs) {
+                int nb = 1;
+                for (int cand : {6, 3, 2})
+                    if (cand <= nrhs - r0 && k::op_batch_supported(d, cand)) { nb = cand; break; }
+                if (nb == 1) throw Error(MFH_ERR_UNSUPPORTED, "batched cell problems: right-hand sides left over");   // (3 / 6 strains fill their batches)
+                BatchIO io;
+                io.cstrains = cstrains + (size_t)r0 * fl; io.uNodes = uNodes + (size_t)r0 * nn; io.nodeStride = nn;
+                solve_multigrid_batch(c, nb, nullptr, nullptr, 0, rtol, maxit, lis.data() + r0, &io);
+                r0 += nb;
+            }
+            lap("PCG incl. loads and downloads (batch, device-resident)");
+            for (int r = 0; r < nrhs; ++r) {
+                // (a solve that needs iterative refinement -- true residual above twice the tolerance: rare -- is redone the long way)
+                if (c->refine && rtol > 0 && lis[(size_t)r].converged && lis[(size_t)r].true_rel_residual > 2.0 * rtol && lis[(size_t)r].true_rel_residual < 1.0) {
+                    resize_prefaulted(c->hLoad, (size_t)n);
+                    constant_strain_load_impl(c, cstrains + (size_t)r * fl, nullptr, c->hLoad.data());
+                    solve_one(c, c->hLoad.data(), x.data(), rtol, maxit, &lis[(size_t)r]);
+                    for (int64_t i = 0; i < m.nNode; ++i)
+                        for (int a = 0; a < d; ++a) uNodes[(size_t)r * nn + (size_t)i * d + a] = x[(size_t)dof_of(c, i) * d + a];
+                }
+                if (info) info[r] = lis[(size_t)r];
+                all = all && lis[(size_t)r].converged;
+            }
+            if (!all) throw Error(MFH_ERR_NOT_CONVERGED, "PCG did not reach the requested tolerance within maxit iterations");
+            return;
+        }
+        RawVec<double> &xs = c->hXBatch;
+        resize_prefaulted(xs, (size_t)n * nrhs);
+        std::vector<mfh_solve_info> lis((size_t)nrhs);
+        solve_many(c, nrhs, f, xs.data(), n, rtol, maxit, lis.data());
+        lap("PCG incl. transfers (batch)");
+        bool all = true;
+        for (int r = 0; r < nrhs; ++r) { if (info) info[r] = lis[(size_t)r]; all = all && lis[(size_t)r].converged; }
+        parallel_ranges(m.nNode, [&](int64_t nb, int64_t ne, int) {   // dofToNodeField :664-677
+            for (int r = 0; r < nrhs; ++r)
+                for (int64_t i = nb; i < ne; ++i)
+                    for (int a = 0; a < d; ++a) uNodes[(size_t)r * nn + (size_t)i * d + a] = xs[(size_t)r * n + (size_t)dof_of(c, i) * d + a];
+        });
+        lap("dofToNodeField");
+        if (!all) throw Error(MFH_ERR_NOT_CONVERGED, "PCG did not reach the requested tolerance within maxit iterations");
+        return;
+    }
     if (k == 0) {
         solve_one(c, f, x.data(), rtol, maxit, &li);
         lap("PCG incl. transfers");
@@ -656,6 +714,52 @@ mfh_status mfh_sim_solve_constrained(mfh_ctx *c, const double *f, int32_t flags,
     require(c && c->haveMesh && uNodes, MFH_ERR_STATE, "no mesh set");
     require(c->mesh.nOwned == c->mesh.nNode, MFH_ERR_UNSUPPORTED, "constrained solves need all rows owned");
     sim_solve_impl(c, f, flags, rigidMotionRHS, nRigidRHS, uNodes, rtol, maxit, info);
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_sim_solve_batch(mfh_ctx *c, int32_t nrhs, const double *f, int32_t flags, double *uNodes, double rtol, int32_t maxit,
+                               mfh_solve_info *info) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && uNodes && f && nrhs >= 1, MFH_ERR_INVALID, "bad arguments");
+    require(c->mesh.nOwned == c->mesh.nNode, MFH_ERR_UNSUPPORTED, "constrained solves need all rows owned");
+    bool batched = false;
+    if (nrhs > 1) {
+        try { sim_solve_impl(c, f, flags, nullptr, 0, uNodes, rtol, maxit, info, nrhs); batched = true; }
+        catch (const Error &e) { if (e.code != MFH_ERR_UNSUPPORTED) throw; }
+    }
+    if (!batched) {
+        const int64_t n = (int64_t)c->bs() * c->nDoF, nn = c->mesh.nNode * (int64_t)c->bs();
+        for (int r = 0; r < nrhs; ++r) sim_solve_impl(c, f + (size_t)r * n, flags, nullptr, 0, uNodes + (size_t)r * nn, rtol, maxit, info ? info + r : nullptr);
+    }
+    MFH_CATCH(c)
+}
+
+mfh_status mfh_solve_cell_problems(mfh_ctx *c, int32_t nStrains, const double *cstrains, int32_t flags, double *wNodes, double rtol, int32_t maxit,
+                                   mfh_solve_info *info) {
+    MFH_TRY(c)
+    require(c && c->haveMesh && cstrains && wNodes && nStrains >= 1, MFH_ERR_INVALID, "bad arguments");
+    require(c->mesh.nOwned == c->mesh.nNode, MFH_ERR_UNSUPPORTED, "constrained solves need all rows owned");
+    require(c->op == MFH_OP_ELASTICITY, MFH_ERR_STATE, "constantStrainLoad is defined for the elasticity operator");
+    bool done = false;
+    if (nStrains > 1) {
+        try { sim_solve_impl(c, nullptr, flags, nullptr, 0, wNodes, rtol, maxit, info, nStrains, cstrains); done = true; }
+        catch (const Error &e) { if (e.code != MFH_ERR_UNSUPPORTED) throw; }
+    }
+    if (!done) {
+        // the general route: host load vectors, right-hand sides in the batches of mfh_sim_solve_batch (or one after the other under constraint rows)
+        const int fl = flat_len(c->dim());
+        const int64_t n = (int64_t)c->bs() * c->nDoF, nn = c->mesh.nNode * (int64_t)c->bs();
+        RawVec<double> &F = c->hLoadBatch;
+        resize_prefaulted(F, (size_t)n * nStrains);
+        for (int r = 0; r < nStrains; ++r) constant_strain_load_impl(c, cstrains + (size_t)r * fl, nullptr, F.data() + (size_t)r * n);
+        bool batched = false;
+        if (nStrains > 1) {
+            try { sim_solve_impl(c, F.data(), flags, nullptr, 0, wNodes, rtol, maxit, info, nStrains); batched = true; }
+            catch (const Error &e) { if (e.code != MFH_ERR_UNSUPPORTED) throw; }
+        }
+        if (!batched)
+            for (int r = 0; r < nStrains; ++r) sim_solve_impl(c, F.data() + (size_t)r * n, flags, nullptr, 0, wNodes + (size_t)r * nn, rtol, maxit, info ? info + r : nullptr);
+    }
     MFH_CATCH(c)
 }
 

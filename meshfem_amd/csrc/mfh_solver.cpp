@@ -294,7 +294,7 @@ void apply_op_nr(mfh_ctx *c, DistLink &L, int NR, double *x, double *y, bool mas
         k::SpmvArgs a = spmv_args(c, masked);
         a.pcgMode = pcgMode;
         // inside the multigrid preconditioner (dist_apply) the assembled matrix is read from its FP32 copy when the hierarchy made one (mg_coarse_fp32)
-        if (smoother && NR == 1 && c->dVals32.p && c->dVals32.n == c->dVals.n) a.vals32 = c->dVals32.p;
+        if (smoother && c->dVals32.p && c->dVals32.n == c->dVals.n) a.vals32 = c->dVals32.p;
         if (L.active) {
             ensure_overlap_lists(c, false);
             L.profile_begin();
@@ -333,6 +333,14 @@ void dist_apply(mfh_ctx *c, double *x, double *y, bool masked) {
     if (cluster_operator(c) && c->mfcDev.ifaceBuf.n < (size_t)std::max<int64_t>(c->mfc.nIface, 1) * c->bs())
         c->mfcDev.ifaceBuf.alloc((size_t)std::max<int64_t>(c->mfc.nIface, 1) * c->bs());
     apply_op_nr(c, L, 1, x, y, masked, nullptr, nullptr, 0, nullptr, 0, true);      // (only the levels of the multigrid preconditioner come through here)
+}
+// y = K x for NR interleaved vectors on an unpartitioned context (the linear level of the batched V-cycle, mfh_multigrid.cpp)
+void batch_apply(mfh_ctx *c, int NR, double *x, double *y, bool masked) {
+    DistLink L(c);
+    if (L.active) throw Error(MFH_ERR_UNSUPPORTED, "batched operator inside the multigrid preconditioner of a row-partitioned context");
+    if (cluster_operator(c) && c->mfcDev.ifaceBuf.n < (size_t)std::max<int64_t>(c->mfc.nIface, 1) * c->bs() * NR)
+        c->mfcDev.ifaceBuf.alloc((size_t)std::max<int64_t>(c->mfc.nIface, 1) * c->bs() * NR);
+    apply_op_nr(c, L, NR, x, y, masked, nullptr, nullptr, 0, nullptr, 0, true);
 }
 // the halo block rows of v (nCols x W doubles) <- the owners' values
 void dist_halo(mfh_ctx *c, double *v, int W) {
@@ -922,18 +930,39 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
     if (info) *info = li;
 }
 
+// Multigrid preconditioner, several right-hand sides, unpartitioned quadratic context (option "mg_batch", default on): one classic PCG loop per
+// right-hand side on the quadratic level, advancing in lockstep, and ONE pass through the linear and aggregate levels of the V-cycle for
+// all of them -- those levels are bound by their matrices and by launch latency, both shared by the batch (the reference factors once and
+// back-substitutes per right-hand side, PeriodicHomogenization.hh:34-54, SparseMatrices.hh:2106-2124).
+bool multigrid_batch_ready(mfh_ctx *c, int nrhs) {
+    const bool partitioned = c->sym.nRows != c->sym.nCols;
+    if (!(c->precond == MFH_PRECOND_MULTIGRID && c->mgBatch && nrhs > 1 && !partitioned && !c->deterministic && !dist_active(c))) return false;
+    if (!(c->mg.valid && c->mg.singular == c->tlSuppress)) ensure_coarse_levels(c, nrhs);      // the hierarchy for THESE solves (see solve_one_pass)
+    return c->mg.valid && !c->mg.distributed && c->mg.singular == c->tlSuppress && !c->mg.linearOnly && cg_operator_supported(c) && cluster_operator(c);
+}
+
 // nrhs right-hand sides in batches of the sizes the kernels are built for (3D: 6, 2, 1; 2D: 3, 1)
 void solve_many(mfh_ctx *c, int nrhs, const double *f, double *u, int64_t stride, double rtol, int maxit, mfh_solve_info *infos) {
     const int d = c->bs();
-    // the V-cycle lives in the one-right-hand-side loop: with the multigrid preconditioner batches would silently run block-Jacobi
+    const bool mgBatch = multigrid_batch_ready(c, nrhs);
+    // the Chronopoulos-Gear batches (option "batch_rhs") have no V-cycle: with the multigrid preconditioner they would silently run block-Jacobi
     const bool batched = c->pcgVariant != 0 && c->batchRhs && !c->deterministic && c->precond != MFH_PRECOND_MULTIGRID && cg_operator_supported(c);
     int k0 = 0;
     while (k0 < nrhs) {
         int nb = 1;
-        if (batched)
+        if (batched || mgBatch)
             for (int cand : {6, 3, 2})
                 if (cand <= nrhs - k0 && k::op_batch_supported(d, cand)) { nb = cand; break; }
-        if (nb > 1) solve_cg(c, nb, f + (size_t)k0 * stride, u + (size_t)k0 * stride, stride, rtol, maxit, infos ? infos + k0 : nullptr);
+        if (nb > 1 && mgBatch) {
+            mfh_solve_info bi[6];
+            solve_multigrid_batch(c, nb, f + (size_t)k0 * stride, u + (size_t)k0 * stride, stride, rtol, maxit, bi);
+            // a right-hand side whose true residual ended above twice the tolerance gets what solve_one gives every single solve: iterative refinement
+            for (int q = 0; q < nb; ++q) {
+                if (c->refine && rtol > 0 && bi[q].converged && bi[q].true_rel_residual > 2.0 * rtol && bi[q].true_rel_residual < 1.0)
+                    solve_one(c, f + (size_t)(k0 + q) * stride, u + (size_t)(k0 + q) * stride, rtol, maxit, &bi[q]);
+                if (infos) infos[k0 + q] = bi[q];
+            }
+        } else if (nb > 1) solve_cg(c, nb, f + (size_t)k0 * stride, u + (size_t)k0 * stride, stride, rtol, maxit, infos ? infos + k0 : nullptr);
         else solve_one(c, f + (size_t)k0 * stride, u + (size_t)k0 * stride, rtol, maxit, infos ? infos + k0 : nullptr);
         k0 += nb;
     }

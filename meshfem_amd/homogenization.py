@@ -62,12 +62,10 @@ def solve_cell_problems(sim: Simulator, cell_epsilon=1e-7, ignore_periodic_misma
         sim.applyPeriodicConditions(cell_epsilon, ignoreMismatch=ignore_periodic_mismatch)
     sim.applyNoRigidMotionConstraint()
     sim.setUsePinNoRigidTranslationConstraint(True)
-    w, infos = [], []
-    for k in range(flat_len(sim.N)):
-        rhs = sim.constantStrainLoad(-canonical_strain_flat(sim.N, k))
-        w.append(sim.solve(rhs))
-        infos.append(sim.info)
-    return w, infos
+    # one Simulator, one system, 3 / 6 right-hand sides (the reference factors once and back-substitutes per load, :47-53): handed over together,
+    # so that the preconditioner's coarse levels serve all of them at once and the load vectors are formed where they are used
+    w = sim.solveConstantStrainLoads([-canonical_strain_flat(sim.N, k) for k in range(flat_len(sim.N))])
+    return w, list(sim.infos)
 
 
 def homogenized_elasticity_tensor(sim: Simulator, w_ij, base_cell_volume=0.0):

@@ -109,6 +109,33 @@ class Simulator:
         self.info = dict(self.ctx.last_info)
         return u
 
+    def solveMany(self, loads):
+        """solve() for several load vectors on the same constrained system (what solveCellProblems does with its constantStrainLoad vectors,
+        PeriodicHomogenization.hh:47-53): returns the list of nodal displacement fields; self.infos holds one record per load."""
+        F = np.stack([np.asarray(f, dtype=np.float64).ravel() for f in loads])
+        flags = (L.SOLVE_PIN if self._use_pin else 0) | (L.SOLVE_NO_RIGID_MOTION if self._no_rigid_motion else 0)
+        if self._rigid_motion_rhs is not None:          # (a right-hand side for the constraint rows: one load after the other)
+            out, self.infos = [], []
+            for f in F:
+                out.append(self.solve(f))
+                self.infos.append(self.info)
+            return out
+        u, infos = self.ctx.sim_solve_batch(F, flags, rtol=self.rtol, maxit=self.maxit)
+        self.infos = infos
+        self.info = dict(infos[-1])
+        return [u[k] for k in range(len(F))]
+
+    def solveConstantStrainLoads(self, cstrains):
+        """[solve(constantStrainLoad(e)) for e in cstrains] in one call (the loop of solveCellProblems, PeriodicHomogenization.hh:47-53): the load
+        vectors never visit the host where the library can form them on the device; self.infos holds one record per strain."""
+        if self._rigid_motion_rhs is not None:
+            return self.solveMany([self.constantStrainLoad(e) for e in cstrains])
+        flags = (L.SOLVE_PIN if self._use_pin else 0) | (L.SOLVE_NO_RIGID_MOTION if self._no_rigid_motion else 0)
+        w, infos = self.ctx.solve_cell_problems(np.asarray(cstrains, dtype=np.float64), flags, rtol=self.rtol, maxit=self.maxit)
+        self.infos = infos
+        self.info = dict(infos[-1])
+        return [w[k] for k in range(len(w))]
+
     def applyStiffnessMatrix(self, u_dofs):                             # :801-823
         return self.ctx.apply_K(np.asarray(u_dofs).ravel()).reshape(-1, self.N)
 

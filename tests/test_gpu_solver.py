@@ -55,24 +55,30 @@ def test_cg_variant_matches_classic_pcg_and_true_residual(dim, deg, precond):
 
 
 @pytest.mark.parametrize("dim,deg,nrhs", [(3, 2, 6), (3, 2, 3), (3, 1, 6), (2, 2, 3), (2, 1, 4)])
-@pytest.mark.parametrize("precond", [M.PRECOND_BLOCK_JACOBI, M.PRECOND_TWO_LEVEL])
+@pytest.mark.parametrize("precond", [M.PRECOND_BLOCK_JACOBI, M.PRECOND_TWO_LEVEL, M.PRECOND_MULTIGRID])
 def test_batched_right_hand_sides_equal_sequential_solves(dim, deg, nrhs, precond):
     """parity of the batched path against the sequential one <= 1e-12 (here: both to rtol 1e-13, so
-    they agree to the solver tolerance times the condition of the comparison), batches 6 / 2+1 / 3 / 3+1."""
+    they agree to the solver tolerance times the condition of the comparison), batches 6 / 2+1 / 3 / 3+1. VERDICT r5 item 1: the same
+    under the multigrid preconditioner, whose batches (option "mg_batch", default on) share the coarse levels of every V-cycle
+    (quadratic elements; linear elements keep one right-hand side at a time)."""
     c, V, T = _problem(dim, deg, n=4)
     c.set_preconditioner(precond)
     rng = np.random.default_rng(11)
     n = dim * c.n_dof
     F = rng.standard_normal((nrhs, n))
-    c.set_option("batch_rhs", 1)
+    mg = precond == M.PRECOND_MULTIGRID
+    batch_option = "mg_batch" if mg else "batch_rhs"
+    c.set_option(batch_option, 1)
     F[1] *= 1e3                                   # very different scales: per-vector stopping, per-vector scalars
     if nrhs > 2:
         F[2] = 0.0                                # a zero right-hand side inside a batch
     U, infos = c.solve_batch(F, rtol=1e-13)
     sizes = [i["reserved"] for i in infos]
     want = {(3, 6): [6] * 6, (3, 3): [2, 2, 1], (2, 3): [3] * 3, (2, 4): [3, 3, 3, 1]}[(dim, nrhs)]
+    if mg and deg == 1:
+        want = [1] * nrhs
     assert sizes == want
-    c.set_option("batch_rhs", 0)
+    c.set_option(batch_option, 0)
     for k in range(nrhs):
         uk = c.solve(F[k], rtol=1e-13)
         assert c.last_info["reserved"] == 1
@@ -83,6 +89,36 @@ def test_batched_right_hand_sides_equal_sequential_solves(dim, deg, nrhs, precon
             assert abs(infos[k]["iterations"] - c.last_info["iterations"]) <= max(3, 0.05 * c.last_info["iterations"])
         else:
             assert np.all(U[k] == 0.0) and infos[k]["iterations"] == 0
+    c.close()
+
+
+def test_multigrid_batch_with_nonzero_dirichlet_values_and_simulator_entry():
+    """The batched V-cycle behind Simulator::solve for several loads (mfh_sim_solve_batch): non-zero Dirichlet values (the lift f - K ubar is
+    shared by the batch), each load against its own single solve and against the oracle's direct solve."""
+    n = 3
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+    c = M.Context(0)
+    c.mesh_build(T, V, 2)
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9], [0.01, -0.02, 0.005])
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    rng = np.random.default_rng(7)
+    F = rng.standard_normal((6, 3 * c.n_dof))
+    U, infos = c.sim_solve_batch(F, M.SOLVE_ALLOW_ILL_POSED, rtol=1e-11)
+    assert [i["reserved"] for i in infos] == [6] * 6 and all(i["converged"] for i in infos)
+    sim = O.Simulator(T, V, 2)
+    sim.set_material_constant(O.ElasticityTensor.isotropic(3, 200.0, 0.35))
+    sim.apply_dirichlet_box([-1e-9, -9, -9], [1e-9, 9, 9], [0.01, -0.02, 0.005])
+    K = sim.assembleStiffnessMatrix()
+    fv, fx = sim.dirichlet_vars_and_values()
+    for k in range(6):
+        uk = c.sim_solve_constrained(F[k], M.SOLVE_ALLOW_ILL_POSED, rtol=1e-11)
+        assert c.last_info["reserved"] == 1
+        assert np.linalg.norm(U[k] - uk) <= 1e-8 * np.linalg.norm(uk)
+        sys = O.SPSDSystem(K)
+        sys.fix_variables(fv, fx)
+        u_ref = sys.solve(F[k])
+        assert np.linalg.norm(U[k].ravel() - u_ref) <= 1e-6 * np.linalg.norm(u_ref)
     c.close()
 
 
@@ -113,4 +149,43 @@ def test_batched_solve_against_the_oracle_direct_solve():
         sys.fix_variables(fv, fx)
         u_ref = sys.solve(F[k])
         assert np.linalg.norm(U[k] - u_ref) <= 1e-6 * np.linalg.norm(u_ref)
+    c.close()
+
+
+@pytest.mark.parametrize("dim,deg,mat", [(3, 2, "ortho"), (3, 2, "iso"), (3, 1, "iso"), (2, 2, "ortho")])
+def test_constant_strain_load_through_the_operator_lists(dim, deg, mat):
+    """constantStrainLoad (LinearElasticity.hh:551-562) formed by the matrix-free operator's element routine (u = 0 plus the constant strain; what
+    mfh_solve_cell_problems uses on the device) against the stand-alone kernel and the oracle, with a periodic DoF map."""
+    from meshfem_amd.linear_elasticity import Simulator
+    if dim == 3:
+        V, T = grid.grid_tet_mesh(4, 3, 3, [0, 0, 0], [1, 1, 1])
+    else:
+        V, Q = O.gen_grid_2d(8, 8)
+        V, T = O.quad_tri_subdiv(V, Q)
+        V = V[:, :2] / 8
+    T = np.ascontiguousarray(T, dtype=np.int32)
+    sim = Simulator(T, V, deg, 0)
+    osim = O.Simulator(T, V, deg)
+    if mat == "ortho":
+        P = grid.synthetic_orthotropic_field(len(T), dim, 1)
+        sim.setOrthotropicField(P)
+        osim.set_material_field([(O.ElasticityTensor.orthotropic3d if dim == 3 else O.ElasticityTensor.orthotropic2d)(*P[e]) for e in range(len(T))])
+    else:
+        sim.ctx.material_isotropic(200.0, 0.3)
+        osim.set_material_constant(O.ElasticityTensor.isotropic(dim, 200.0, 0.3))
+    sim.applyPeriodicConditions(1e-7)
+    osim.applyPeriodicConditions(1e-7)
+    fl = dim * (dim + 1) // 2
+    rng = np.random.default_rng(2)
+    c = sim.ctx
+    for k in range(3):
+        e = rng.standard_normal(fl)
+        l0 = c.constant_strain_load(e)                       # stand-alone kernel: the operator's lists do not exist yet
+        c.assemble()
+        c.time_spmv_kernel(1)                                # builds the operator's lists
+        l1 = c.constant_strain_load(e)
+        lo = osim.constantStrainLoad(O.unflatten_sym(dim, e))
+        scale = np.abs(lo).max()
+        assert np.abs(l1 - l0).max() <= 1e-12 * scale
+        assert np.abs(np.asarray(l1).reshape(lo.shape) - lo).max() <= 1e-12 * scale
     c.close()
