@@ -269,19 +269,38 @@ def hbm_stream_probe(torch, n_doubles=1 << 27, reps=10):
 
 
 def reserve_for(M, n, deg):
-    """mfh_device_reserve for a context on the n^3 grid, asynchronous, in TWO segments (the smaller one first: a reservation is a no-op when a
-    free chunk of its size exists): 43 % for the K values (40 % of a quadratic context) and the rest. One segment for everything puts the K
-    values and every other buffer into one physical run, and the assembly kernel then sits at the slow end of its placement spread on every
-    box (3.27-3.29 ms at configs[2] against 2.89-3.2 with the values in an allocation of their own: profiles/r05_where_the_K_values_lie.txt).
-    MFH_BENCH_RESERVE_SPLIT=0 asks for one segment."""
-    total = int((3.6e3 if deg == 2 else 0.9e3) * 24 * n ** 3)
-    split = float(os.environ.get("MFH_BENCH_RESERVE_SPLIT", "0.43"))
-    if 0 < split < 0.5:
-        M.device_reserve(int(total * split), 0)
-        M.device_reserve(int(total * (1 - split)), 0)
-    else:
-        M.device_reserve(total, 0)
-    return total
+    """mfh_device_reserve_for for a context on the n^3 grid, asynchronous: the library knows what such a context holds (mfh_context_bytes_estimate)
+    and reserves the value array of K in a segment of its own (round 5 did the split here by hand: the placement policy lives in the arena now,
+    docs/design/04_2_k_assemble_gather.md (xi), (xii))."""
+    return M.device_reserve_for(3, deg, 24 * n ** 3)
+
+
+def one_shot_fresh_context(M, T, V, deg, rtol, maxit):
+    """What a Simulate_cli caller pays end to end (VERDICT r5 item 4): a FRESH context, mesh_build -> boundary conditions -> Simulator::solve with
+    the drivers' default preconditioner (symbolic phase, first assembly, multigrid hierarchy, PCG, download of u), wall clock around all of it,
+    plus the library's own laps. The process is warm (HIP initialised, device memory in the library's arena): what a second mesh of a process pays."""
+    c = M.Context(0)
+    t0 = time.perf_counter()
+    c.mesh_build(T, V, deg)
+    t1 = time.perf_counter()
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+    c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    t2 = time.perf_counter()
+    u = c.sim_solve(rtol=rtol, maxit=maxit)
+    t3 = time.perf_counter()
+    i, g, tm = dict(c.last_info), c.multigrid_info(), c.timing()
+    nE = int(c.n_elem)
+    res = dict(wall_s=t3 - t0, elements_per_s=nE / (t3 - t0),
+               breakdown_s=dict(femmesh_build=t1 - t0, boundary_conditions=t2 - t1, solve_call=t3 - t2,
+                                symbolic=tm["symbolic_ms"] * 1e-3, embedding_and_assembly=(tm["geometry_ms"] + tm["assemble_ms"]) * 1e-3,
+                                hierarchy=g["setup_ms"] * 1e-3, pcg=i["solve_ms"] * 1e-3,
+                                rest_of_solve_call=(t3 - t2) - (tm["symbolic_ms"] + tm["geometry_ms"] + tm["assemble_ms"] + g["setup_ms"] + i["solve_ms"]) * 1e-3),
+               iterations=i["iterations"], converged=bool(i["converged"]), max_abs_u=float(np.abs(u).max()),
+               note="fresh context, warm process; from mesh_build to u on the host; the timed step of the headline is %.1f %% of it" % (100.0 * (tm["geometry_ms"] + tm["assemble_ms"]) * 1e-3 / (t3 - t0)))
+    c.close()
+    return res
 
 
 def run_single(args):
@@ -635,6 +654,16 @@ def run_single(args):
             out["variants"]["config3_homogenization"] = config3_homogenization(args)
         except Exception as e:   # noqa: BLE001
             out["variants"]["config3_homogenization"] = dict(error="%s: %s" % (type(e).__name__, e))
+    if not strong and (n, deg) == (60, 2) and not args.no_solve:
+        # the one-shot sum of configs[2]: a fresh context of the same mesh, from mesh_build to u on the host
+        try:
+            c.close()
+        except Exception:   # noqa: BLE001
+            pass
+        try:
+            out["one_shot"] = dict(workload=out["config"]["workload"], **one_shot_fresh_context(M, T, V, deg, args.rtol, min(args.maxit, 2000)))
+        except Exception as e:   # noqa: BLE001
+            out["one_shot"] = dict(error="%s: %s" % (type(e).__name__, e))
     if not strong and not args.no_strong_n1 and deg == 2:
         # the N = 1 point of the strong-scaling curve the N > 1 runs measure by default (configs[4]'s 119^3 cube in ONE context), so that
         # one driver pass over N = 1, 2, 4, 8 holds the whole curve
@@ -891,6 +920,14 @@ def strong_n1(args, torch, n=119):
         res["pcg_multigrid"] = dict(iterations=i3["iterations"], converged=bool(i3["converged"]), true_rel_residual=i3["true_rel_residual"],
                                     solve_s=i3["solve_ms"] * 1e-3, ms_per_iteration=i3["solve_ms"] / max(1, i3["iterations"]),
                                     hierarchy_setup_ms=g3["setup_ms"], wall_s_with_setup=time.time() - t0, max_abs_u=float(np.abs(u).max()))
+        # the one-shot sum of configs[4]'s cube in one context: the phases above ran once each, one after the other, on this
+        # context -- mesh build, symbolic phase, first assembly, then Simulator::solve (hierarchy + PCG + download)
+        w = t_build + t_sym + t_first + res["pcg_multigrid"]["wall_s_with_setup"]
+        res["one_shot"] = dict(wall_s=w, elements_per_s=nE / w,
+                               breakdown_s=dict(femmesh_build=t_build, symbolic=t_sym, first_assemble_call=t_first, hierarchy=g3["setup_ms"] * 1e-3,
+                                                pcg=i3["solve_ms"] * 1e-3,
+                                                rest_of_solve_call=res["pcg_multigrid"]["wall_s_with_setup"] - (g3["setup_ms"] + i3["solve_ms"]) * 1e-3),
+                               note="sum of the consecutive phases of this context, each run once (between them: the %d timed assembly passes of the step)" % (steps + 1))
     free2, _ = torch.cuda.mem_get_info(0)
     res["memory"] = dict(device_used_GB=(total - free2) / 1e9, arena={k: (v / 1e9 if k.endswith("bytes") else v) for k, v in M.device_arena_stats(0).items()})
     c.close()

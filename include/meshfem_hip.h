@@ -454,16 +454,20 @@ mfh_status  mfh_dev_memcpy(mfh_ctx* ctx, void* dst, const void* src, int64_t byt
  * quarter of the device), so that other allocators of the process (torch, RCCL) find the rest. A request the driver cannot serve releases every free segment and is repeated. mfh_device_cache_trim returns every free segment to
  * the driver at once. mfh_device_arena_stats: out8 = {bytes held, live bytes, live high-water mark, segments, free chunks, bytes returned
  * to the driver so far, bytes waiting for a device-wide synchronisation, bound on the free bytes}. */
-/* mfh_device_reserve: ONE segment of `bytes` taken from the driver now and kept as free space of the arena -- the reference's "reserve once"
- * (LinearElasticity.hh:1441-1443) for a caller that knows roughly what its mesh will need (about 3.6 kB per quadratic tet for assembly +
- * multigrid solve, 0.9 kB per linear tet). Contexts created afterwards cut their buffers from it: no call to the driver during their
- * setup. With async != 0 the call returns at once and the allocation runs on a thread of its own (e.g. while the caller reads its mesh);
- * the library's next allocation that finds nothing waits for it. Worth it on a device nobody has used since boot, where the driver
- * clears the memory a process takes beyond the first ~66 GB while it is being allocated (profiles/r05_large_allocation_trace_119.log).
- * Ask for the memory in TWO calls, the smaller first (a call is a no-op when a free chunk of its size exists): ~43 % for the values of K
- * (40 % of a quadratic context) and the rest. With everything in ONE hipMalloc the values and all other buffers lie in one physical run, and the
- * assembly kernel then runs at the slow end of its placement spread (24.4 against 22.6 ms per launch at 40 M quadratic tets;
- * docs/design/04_2_k_assemble_gather.md (xi)). */
+/* mfh_device_reserve: `bytes` taken from the driver now and kept as free space of the arena -- the reference's "reserve once"
+ * (LinearElasticity.hh:1441-1443) for a caller that knows roughly what its mesh will need (mfh_context_bytes_estimate; mfh_device_reserve_for
+ * does both). Contexts created afterwards cut their buffers from it: no call to the driver during their setup. With async != 0 the call returns
+ * at once and the allocation runs on threads of its own (e.g. while the caller reads its mesh); the library's next allocation that finds nothing
+ * waits for it. Worth it on a device nobody has used since boot, where the driver clears the memory a process takes beyond the first ~66 GB
+ * while it is being allocated (profiles/r05_large_allocation_trace_119.log).
+ * The reservation is made in TWO segments: one for the value array of K (its share of the request: mfh_device_reserve_for knows it from the mesh
+ * kind, mfh_device_reserve assumes the 43 % of a quadratic 3D context) and one for everything else -- the arena never puts anything else into
+ * the value array's segment (and gives the array a segment of its own when nothing was reserved): with everything in ONE hipMalloc the values and
+ * all other buffers lie in one physical run, and the assembly kernel then runs at the slow end of its placement spread (3.27 against 2.9-3.1 ms at
+ * 5 M quadratic tets, 24.4 against 22.6 ms at 40 M; docs/design/04_2_k_assemble_gather.md (xi)). A synchronous reservation the driver cannot
+ * serve returns MFH_ERR_HIP. */
+mfh_status mfh_context_bytes_estimate(int32_t dim, int32_t deg, int64_t nElem, int64_t* totalBytes, int64_t* kValueBytes);
+mfh_status mfh_device_reserve_for(int32_t device, int32_t dim, int32_t deg, int64_t nElem, int32_t async);
 mfh_status mfh_device_reserve(int32_t device, int64_t bytes, int32_t async);
 /* option "placement_trials": kernel time (ms) of every candidate of the last trials, the first being the buffer of the symbolic phase; *n = how many */
 mfh_status mfh_placement_info(const mfh_ctx* ctx, int32_t cap, double* ms, int32_t* n);

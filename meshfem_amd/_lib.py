@@ -152,6 +152,8 @@ PROTOTYPES = {
     "mfh_device_cache_stats": (_i32, [_i32, _pi64, _pi64, _pi64, _pi64, _pi64]),
     "mfh_device_arena_stats": (_i32, [_i32, _pi64]),
     "mfh_device_reserve": (_i32, [_i32, _i64, _i32]),
+    "mfh_device_reserve_for": (_i32, [_i32, _i32, _i32, _i64, _i32]),
+    "mfh_context_bytes_estimate": (_i32, [_i32, _i32, _i64, _P, _P]),
     "mfh_comm_enable_peer": (_i32, [_P, _P]),
     "mfh_comm_disable_peer": (_i32, [_P, _P]),
     "mfh_dist_get_stats": (_i32, [_P, _P]),

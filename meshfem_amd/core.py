@@ -682,6 +682,25 @@ def device_reserve(nbytes, device=0, wait=False):
         raise L.MeshFEMHipError(st, "mfh_device_reserve failed")
 
 
+def device_reserve_for(dim, deg, n_elem, device=0, wait=False):
+    """mfh_device_reserve_for: the reservation for a context on a mesh of n_elem simplices of that kind -- the value array of K in a segment of
+    its own, the rest in another. Returns the estimated total (bytes)."""
+    lib = L.load()
+    st = lib.mfh_device_reserve_for(int(device), int(dim), int(deg), int(n_elem), 0 if wait else 1)
+    if st != L.OK:
+        raise L.MeshFEMHipError(st, "mfh_device_reserve_for failed")
+    return context_bytes_estimate(dim, deg, n_elem)[0]
+
+
+def context_bytes_estimate(dim, deg, n_elem):
+    """(total bytes, bytes of K's value array) a context on such a mesh holds at its peak (mfh_context_bytes_estimate)."""
+    t, v = C.c_int64(), C.c_int64()
+    st = L.load().mfh_context_bytes_estimate(int(dim), int(deg), int(n_elem), C.byref(t), C.byref(v))
+    if st != L.OK:
+        raise L.MeshFEMHipError(st, "mfh_context_bytes_estimate failed")
+    return t.value, v.value
+
+
 def device_arena_stats(device=0):
     """State of the library's device arena (mfh_device_arena_stats): bytes held / live / live high-water mark, segments, free chunks, ..."""
     lib = L.load()

@@ -254,7 +254,7 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
         c->timing.symbolic_ms = now_ms() - t0;
         const size_t tilesD = (size_t)((S.nnzb + 63) / 64);
         const double tV = now_ms();
-        c->dVals.alloc(tilesD * 64 * (size_t)c->dim() * c->dim());
+        { mfh::PoolTag values(1); c->dVals.alloc(tiled_count(S.nnzb, c->dim() * c->dim())); }
         if (getenv("MFH_SYM_TIMING")) fprintf(stderr, "[symbolic] value array %.1f MB: allocation %.2f ms\n", tilesD * 64.0 * c->dim() * c->dim() * 8 / 1e6, now_ms() - tV);
         c->symValid = true;
         ++c->listsGen;
@@ -282,8 +282,7 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
         std::vector<uint16_t>().swap(c->sym.contribSlot);
         std::vector<int32_t>().swap(c->sym.scatterSlot);
     }
-    const size_t tiles = (size_t)((S.nnzb + 63) / 64);
-    c->dVals.alloc(tiles * 64 * (size_t)c->dim() * c->dim());
+    { mfh::PoolTag values(1); c->dVals.alloc(tiled_count(S.nnzb, c->dim() * c->dim())); }
     c->symValid = true;
     ++c->listsGen;
     ++c->valsGen;
@@ -374,7 +373,7 @@ void placement_trials(mfh_ctx *c) {
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); break; }
         if (fr < 2 * bytes + ((size_t)1 << 30)) break;
         std::unique_ptr<DBuf<double>> alt(new DBuf<double>());
-        alt->alloc(n);
+        { mfh::PoolTag values(1); alt->alloc(n); }
         alt->zero(c->stream);              // (the padding of the last tile is never read; zero all the same)
         c->dVals.swap(*alt);               // dVals = candidate, alt = best so far
         const double t = timed();
@@ -820,7 +819,7 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
     c->stop.alloc(4);
     EventTimer tsetup(s);
     prepare_matrix_free(c);   // gather lists of the operator: once per mesh / DoF map, part of the setup time
-    MFH_HIP(hipMemcpyAsync(c->wf.p, f, n * sizeof(double), hipMemcpyHostToDevice, s));
+    if (f) MFH_HIP(hipMemcpyAsync(c->wf.p, f, n * sizeof(double), hipMemcpyHostToDevice, s));      // (null: the caller has formed it in c->wf on the device)
     // b = f - K ubar on the free variables (SparseMatrices.hh:2457-2470,2526-2535)
     MFH_HIP(hipMemcpyAsync(c->wb.p, c->wf.p, n * sizeof(double), hipMemcpyDeviceToDevice, s));
     if (c->anyFixedNonzero && !c->solveHomogeneous) {
@@ -1380,14 +1379,44 @@ mfh_status mfh_device_cache_stats(int32_t device, int64_t *cachedBytes, int64_t 
     mfh::device_cache_stats(device, cachedBytes, blocks, hits, misses, flushes);
     return MFH_OK;
 }
-mfh_status mfh_device_reserve(int32_t device, int64_t bytes, int32_t async) {
-    if (bytes < 0) return MFH_ERR_INVALID;
+// Bytes a context on a mesh of nElem simplices of that kind will hold at its peak (assembly + multigrid solve), and the share of it that is the
+// value array of K. Measured on the generator's meshes (24 tets per hex / 8 triangles per quad patch; upper-triangle storage): 3.6 kB per
+// quadratic tet of which 1.45 kB are K values, 0.9 kB per linear tet (0.39), 1.2 kB per quadratic triangle (0.42), 0.35 kB per linear one (0.12).
+// An estimate: the arena asks the driver for more when it is short and returns what stays free.
+mfh_status mfh_context_bytes_estimate(int32_t dim, int32_t deg, int64_t nElem, int64_t *totalBytes, int64_t *kValueBytes) {
+    if (!(dim == 2 || dim == 3) || !(deg == 1 || deg == 2) || nElem < 0) return MFH_ERR_INVALID;
+    const double total = dim == 3 ? (deg == 2 ? 3600.0 : 900.0) : (deg == 2 ? 1200.0 : 350.0);
+    const double vals = dim == 3 ? (deg == 2 ? 1450.0 : 390.0) : (deg == 2 ? 420.0 : 120.0);
+    if (totalBytes) *totalBytes = (int64_t)(total * (double)nElem);
+    if (kValueBytes) *kValueBytes = (int64_t)(vals * (double)nElem * 1.07);      // (+7 %: a value array that misses its segment by a few MB would land in the other one)
+    return MFH_OK;
+}
+
+static mfh_status reserve_split(int32_t device, int64_t bytes, int64_t valueBytes, int32_t async) {
+    if (bytes < 0 || valueBytes < 0 || valueBytes > bytes) return MFH_ERR_INVALID;
     try {
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) { (void)hipGetLastError(); return MFH_ERR_INVALID; }
-        mfh::device_arena_reserve(device, (size_t)bytes, async != 0);
+        // the value array of K gets a segment of its own (the smaller request first: both may be under way at once): in one physical run with the
+        // context's other buffers the assembly kernel sits at the slow end of its placement spread (docs/design/04_2_k_assemble_gather.md (xi))
+        bool ok = true;
+        if (valueBytes > 0) ok = mfh::device_arena_reserve(device, (size_t)valueBytes, async != 0, 2) && ok;
+        if (bytes - valueBytes > 0) ok = mfh::device_arena_reserve(device, (size_t)(bytes - valueBytes), async != 0, 1) && ok;
+        if (!ok) return MFH_ERR_HIP;            // (synchronous reservations only: an asynchronous one that fails leaves the arena to ask again when it needs the memory)
     } catch (...) { return MFH_ERR_HIP; }
     return MFH_OK;
+}
+
+mfh_status mfh_device_reserve(int32_t device, int64_t bytes, int32_t async) {
+    // without knowledge of the mesh: the value array's share of a quadratic 3D context (40 %, rounded up)
+    return reserve_split(device, bytes, bytes >= ((int64_t)1 << 30) ? (int64_t)(0.43 * (double)bytes) : 0, async);
+}
+
+mfh_status mfh_device_reserve_for(int32_t device, int32_t dim, int32_t deg, int64_t nElem, int32_t async) {
+    int64_t total = 0, vals = 0;
+    const mfh_status st = mfh_context_bytes_estimate(dim, deg, nElem, &total, &vals);
+    if (st != MFH_OK) return st;
+    return reserve_split(device, total, vals, async);
 }
 mfh_status mfh_device_arena_stats(int32_t device, int64_t *out8) {
     if (!out8) return MFH_ERR_INVALID;

@@ -433,6 +433,7 @@ struct BatchIO {
     double *uNodes = nullptr;             // NR nodal fields, nodeStride doubles apart; null: DoF vectors to u
     int64_t nodeStride = 0;
 };
+bool device_rhs_supported(mfh_ctx *c);            // solve_one(c, nullptr, ...) -- right-hand side already in c->wf -- will work for this context
 bool multigrid_batch_ready(mfh_ctx *c, int nrhs);     // the hierarchy exists (built if need be) and the batched V-cycle applies to this context
 void solve_multigrid_batch(mfh_ctx *c, int NR, const double *f, double *u, int64_t stride, double rtol, int maxit, mfh_solve_info *infos, const BatchIO *io = nullptr);
 bool constant_strain_load_device(mfh_ctx *c, const double *cstrainFlat, double *outDev);   // through the cluster operator's lists; false: not available

@@ -12,7 +12,10 @@ namespace mfh { namespace k {
 // ------------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------------
-DEV int64_t tiled_index(int64_t slot, int c, int NB) { return ((slot >> 6) * NB + c) * 64 + (slot & 63); }
+// (tile geometry: MFH_TILE_LOG / MFH_TILE_PAD, mfh_internal.hh)
+DEV int64_t tiled_index(int64_t slot, int c, int NB) {
+    return (slot >> MFH_TILE_LOG) * (((int64_t)NB << MFH_TILE_LOG) + MFH_TILE_PAD) + ((int64_t)c << MFH_TILE_LOG) + (slot & ((1 << MFH_TILE_LOG) - 1));
+}
 
 DEV double wave_sum(double v) {
 #pragma unroll

@@ -61,7 +61,17 @@ void device_free(void *p);
 void device_cache_trim();
 void device_arena_context_opened(int dev);     // mfh_create / mfh_destroy of a device context: when a context closes the arena is trimmed
 void device_arena_context_closed(int dev);     // to its live high-water mark, when the last one closes to a small reserve
-void device_arena_reserve(int dev, size_t bytes, bool async);   // one free segment of that size from the driver, now (on a thread of its own if async)
+// one free segment of that size from the driver, now (on a thread of its own if async); cls 2: a segment for the value array of K (PoolTag);
+// false: a synchronous reservation did not get its memory
+bool device_arena_reserve(int dev, size_t bytes, bool async, int cls = 1);
+// Requests made while a PoolTag(1) is alive are the value array of K: served from segments that hold nothing else (mfh_pool.cpp, class 2)
+struct PoolTag {
+    int saved;
+    explicit PoolTag(int tag);
+    ~PoolTag();
+    PoolTag(const PoolTag &) = delete;
+    PoolTag &operator=(const PoolTag &) = delete;
+};
 void device_arena_stats(int dev, int64_t out[8]);   // held, live, live high-water mark, segments, free chunks, bytes returned to the driver, quarantined, bound
 // What a release waits for before the block may be handed to somebody else: the streams of the context the calling thread is working for
 // (PoolScope, installed by every API entry), not the whole device -- hipDeviceSynchronize from one host thread invalidates a stream
@@ -77,6 +87,19 @@ struct PoolScope {
 void device_cache_stats(int dev, int64_t *cachedBytes, int64_t *blocks, int64_t *hits, int64_t *misses, int64_t *flushes);
 
 // Device buffer with explicit size tracking.
+// K's value array: tiles of 64 consecutive slots x NB components (a wave reads / writes 512 contiguous bytes per component). MFH_TILE_LOG / MFH_TILE_PAD
+// (doubles of padding behind every tile) exist for the tile-geometry probe of round 6 (timing-only builds; docs/design/04_2 (xii)): the default build has 6 / 0.
+#ifndef MFH_TILE_LOG
+#define MFH_TILE_LOG 6
+#endif
+#ifndef MFH_TILE_PAD
+#define MFH_TILE_PAD 0
+#endif
+inline size_t tiled_count(int64_t slots, int NB) {      // doubles of a tiled array of `slots` slots
+    const size_t T = (size_t)1 << MFH_TILE_LOG;
+    return (((size_t)slots + T - 1) >> MFH_TILE_LOG) * (T * (size_t)NB + MFH_TILE_PAD);
+}
+
 template <class T>
 struct DBuf {
     T *p = nullptr;
@@ -484,6 +507,9 @@ struct SpmvMfArgs {
 // constantStrainLoad on the cluster operator's lists (LinearElasticity.hh:551-562): y = int (C : cstrain) grad phi_i = the operator's nodal forces
 // for a field of constant strain `cstrain` -- the element routine with u = 0 and the strain added, summed through the same LDS accumulators
 void launch_mf_cluster_constant_strain(const SpmvMfArgs &a, const double *cstrainFlat, double *y, hipStream_t s);
+// neumannLoad on the device (LinearElasticity.hh:703-717): out[DoF(node)] += w[local node] * |b| * traction_b over the boundary elements (out is NOT zeroed here)
+void launch_neumann_load(int64_t nBE, int npbe, int dim, const double *w6, const int32_t *bdryElemNodes, const int32_t *dofForNode, const double *bdryVol,
+                         const double *traction, double *out, hipStream_t s);
 void launch_spmv_mf(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,
                     bool pcg, hipStream_t s);
 void launch_spmv_mf_cluster(const SpmvMfArgs &a, const double *x, double *y, double *dotOut, double *scal, int it, const double *stopPtr,

@@ -631,6 +631,30 @@ __global__ void __launch_bounds__(256) k_constant_strain_load(LoadArgs a, const 
     }
 }
 
+// K8, neumannLoad (LinearElasticity.hh:703-717): f[DoF(node)] += traction_b * int phi_n over boundary element b, one lane per (boundary element,
+// local node); int phi_n = w[n] * |b| with the weights of Functions.hh:246-274 (kernel argument). The boundary of a mesh is a few per cent of
+// its nodes: global atomics are fine here. The vector stays on the device: it is the right-hand side of the solve that follows.
+struct NeumannArgs { int64_t nBE; int npbe, dim; double w[6]; };
+__global__ void __launch_bounds__(256) k_neumann_load(NeumannArgs a, const int32_t *__restrict__ bdryElemNodes, const int32_t *__restrict__ dofForNode,
+                                                      const double *__restrict__ bdryVol, const double *__restrict__ traction, double *__restrict__ out) {
+    const int64_t total = a.nBE * a.npbe;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < total; q += (int64_t)gridDim.x * 256) {
+        const int64_t b = q / a.npbe;
+        const int k = (int)(q - b * a.npbe);
+        double wk = 0;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) wk = (j == k) ? a.w[j] : wk;
+        if (wk == 0.0) continue;
+        int64_t dof = bdryElemNodes[q];
+        if (dofForNode) dof = dofForNode[dof];
+        const double wv = wk * bdryVol[b];
+        for (int c = 0; c < a.dim; ++c) {
+            const double t = traction[b * a.dim + c];
+            if (t != 0.0) unsafeAtomicAdd(&out[dof * a.dim + c], wv * t);
+        }
+    }
+}
+
 // add.on: a constant strain (flattened, TENSOR shear) is added to every element's average strain -- the strain of the affine field
 // x -> E x, which then never has to exist as a nodal vector. integral != null: sum_e vol_e * (the element's result) is accumulated
 // there (FL doubles, zeroed by the caller) and `out` may be null: the per-element field stays in registers.
@@ -2248,6 +2272,13 @@ void launch_constant_strain_load(const AsmArgs &a, const int32_t *elemNodes, con
     CHECK_LAUNCH();
 }
 
+void launch_neumann_load(int64_t nBE, int npbe, int dim, const double *w6, const int32_t *bdryElemNodes, const int32_t *dofForNode, const double *bdryVol,
+                         const double *traction, double *out, hipStream_t s) {
+    if (nBE <= 0) return;
+    NeumannArgs a{nBE, npbe, dim, {w6[0], w6[1], w6[2], w6[3], w6[4], w6[5]}};
+    hipLaunchKernelGGL(k_neumann_load, dim3(grid_for(nBE * npbe)), dim3(256), 0, s, a, bdryElemNodes, dofForNode, bdryVol, traction, out);
+    CHECK_LAUNCH();
+}
 void launch_average_strain(const AsmArgs &a, const int32_t *elemNodes, const double *intGrad, const double *uNodes, double *out,
                            int wantStress, const double *uFixed, const double *deltaP, hipStream_t s, const double *addStrain, double *integral) {
     const LoadArgs l = make_load_args(a, elemNodes, nullptr, intGrad, nullptr);

@@ -22,6 +22,7 @@
 #include "mfh_internal.hh"
 #include <condition_variable>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <set>
 #include <thread>
@@ -126,7 +127,7 @@ struct Chunk {
 struct Segment { size_t bytes, freeBytes; int cls; };
 struct Arena {
     std::map<char *, Chunk> chunks;                       // every chunk of every segment, by address
-    std::set<std::pair<size_t, char *>> freeBySize[2];    // the free ones of either size class, by (size, address): best fit = lower_bound
+    std::set<std::pair<size_t, char *>> freeBySize[3];    // the free ones of every class (0 small, 1 large, 2 K values), by (size, address): best fit = lower_bound
     std::map<char *, Segment> segments;
     std::vector<std::pair<char *, size_t>> quarantine;    // released outside an API scope: users unknown until the next device-wide wait
     size_t held = 0, live = 0, liveHigh = 0, limit = 0, idleLimit = 0, quarantined = 0;
@@ -143,6 +144,12 @@ std::map<int, Arena> g_arena;                            // one arena per device
 std::unordered_map<void *, int> g_owner;                 // live pointer handed out by device_alloc -> device
 thread_local hipStream_t t_streams[2] = {nullptr, nullptr};
 thread_local int t_mode = 0;
+thread_local int t_tag = 0;                              // PoolTag: 1 = the request is the value array of K
+// Class 2, "K values" (round 6; docs/design/04_2 (xi)): the assembly kernel's time follows WHERE the value array of K lies -- in one physical run with the
+// context's other buffers (one large hipMalloc cut into pieces) it sits at the slow end of its spread on every box (3.27 against 2.9-3.1 ms at 5 M
+// quadratic tets). The value array therefore never shares a segment with anything else: requests made under PoolTag(1) are served from segments of
+// their own (reserved by the values share of mfh_device_reserve, or taken from the driver on demand).
+constexpr size_t VALUES_MIN = (size_t)64 << 20;
 
 void wait_for_users() {
     if (t_mode != 1) return;
@@ -157,8 +164,12 @@ Arena &arena_of(int dev) {
         A.init = true;
         size_t fr = 0, total = 0;
         if (hipMemGetInfo(&fr, &total) != hipSuccess) { (void)hipGetLastError(); total = (size_t)64 << 30; }
-        A.limit = total / 2;
-        A.idleLimit = total / 4;
+        // several processes on one device (forced multi-rank runs, tests): every one of them has an arena, and the out-of-memory path of one cannot
+        // reclaim what another holds -- the bounds are shares of the device (MFH_DEVICE_SHARERS, set by meshfem_amd.distributed from the local world size)
+        size_t sharers = 1;
+        if (const char *e = getenv("MFH_DEVICE_SHARERS")) sharers = (size_t)std::max(1L, atol(e));
+        A.limit = total / 2 / sharers;
+        A.idleLimit = total / 4 / sharers;
         if (const char *e = getenv("MFH_DEVICE_CACHE_MB")) {
             const long long mb = atoll(e);
             if (mb <= 0) A.enabled = false;
@@ -247,7 +258,7 @@ void *device_alloc(size_t bytes) {
     if (bytes == 0) return nullptr;
     int dev = 0;
     MFH_HIP(hipGetDevice(&dev));
-    const int cls = bytes < SMALL_REQUEST ? 0 : 1;
+    const int cls = bytes < SMALL_REQUEST ? 0 : ((t_tag == 1 && bytes >= VALUES_MIN) ? 2 : 1);
     if (cls == 1 && large_stagger()) { static std::atomic<unsigned> turn{0}; bytes += (size_t)(turn.fetch_add(1) % 8u) * large_stagger(); }
     bytes = cls == 0 ? (bytes + ALIGN - 1) & ~(ALIGN - 1) : (bytes + large_gran() - 1) / large_gran() * large_gran();
     std::unique_lock<std::mutex> lock(g_mu);
@@ -262,7 +273,7 @@ void *device_alloc(size_t bytes) {
     auto fit = freeBySize.lower_bound({bytes, nullptr});
     // a reservation under way on another thread (mfh_device_reserve, asynchronous) may bring what this request needs: wait for it rather
     // than ask the driver for the same memory a second time
-    while (fit == freeBySize.end() && cls == 1 && A.pendingReserve > 0) {
+    while (fit == freeBySize.end() && cls >= 1 && A.pendingReserve > 0) {
         g_cv.wait(lock);
         fit = freeBySize.lower_bound({bytes, nullptr});
     }
@@ -371,9 +382,11 @@ PoolScope::~PoolScope() { t_streams[0] = saved[0]; t_streams[1] = saved[1]; t_mo
 // mesh. Asynchronous: the call returns at once and the allocation proceeds on a thread of its own, e.g. while the caller reads its mesh;
 // an allocation of the library that finds nothing waits for it. Free space the arena already holds counts: nothing happens if a free
 // chunk of that size exists. The bound on the free bytes is raised to the reservation while contexts are alive.
-void device_arena_reserve(int dev, size_t bytes, bool async) {
+// cls 2: a segment for the value array of K (see VALUES_MIN). Returns false when a synchronous reservation could not get its memory.
+bool device_arena_reserve(int dev, size_t bytes, bool async, int cls) {
     bytes = (bytes + SEGMENT_ROUND - 1) & ~(SEGMENT_ROUND - 1);
-    if (bytes == 0) return;
+    if (bytes == 0) return true;
+    if (cls != 2 || bytes < VALUES_MIN) cls = 1;
     {
         std::lock_guard<std::mutex> lock(g_mu);
         int cur = 0;
@@ -382,8 +395,8 @@ void device_arena_reserve(int dev, size_t bytes, bool async) {
         (void)hipSetDevice(dev);
         Arena &A = arena_of(dev);            // (reads the device's memory size the first time)
         if (haveCur) (void)hipSetDevice(cur);
-        if (!A.enabled) return;
-        if (!A.freeBySize[1].empty() && std::prev(A.freeBySize[1].end())->first >= bytes) return;
+        if (!A.enabled) return true;
+        if (!A.freeBySize[cls].empty() && std::prev(A.freeBySize[cls].end())->first >= bytes) return true;
         ++A.pendingReserve;
         A.limit = std::max(A.limit, bytes + A.idleLimit);      // (the reservation itself must not count as "too much free memory" when something else is released)
     }
@@ -394,7 +407,8 @@ void device_arena_reserve(int dev, size_t bytes, bool async) {
             g_cv.wait(lock, [] { for (auto &kv : g_arena) if (kv.second.pendingReserve > 0) return false; return true; });
         });
     });
-    auto work = [dev, bytes]() {
+    auto ok = std::make_shared<std::atomic<bool>>(true);
+    auto work = [dev, bytes, cls, ok]() {
         void *p = nullptr;
         const double t0 = now_ms();
         hipError_t e = hipSetDevice(dev);
@@ -404,18 +418,22 @@ void device_arena_reserve(int dev, size_t bytes, bool async) {
         Arena &A = g_arena[dev];
         if (p) {
             char *seg = (char *)p;
-            A.segments[seg] = Segment{bytes, bytes, 1};
+            A.segments[seg] = Segment{bytes, bytes, cls};
             A.chunks[seg] = Chunk{bytes, seg, true};
             A.held += bytes;
-            A.freeBySize[1].insert({bytes, seg});
-        }
+            A.freeBySize[cls].insert({bytes, seg});
+        } else *ok = false;
         if (getenv("MFH_POOL_TRACE")) fprintf(stderr, "[arena] reservation of %.1f MB: %s after %.1f ms\n", bytes / 1e6, p ? "arrived" : "FAILED", now_ms() - t0);
         --A.pendingReserve;
         g_cv.notify_all();
     };
-    if (async) std::thread(work).detach();
-    else work();
+    if (async) { std::thread(work).detach(); return true; }
+    work();
+    return *ok;
 }
+
+PoolTag::PoolTag(int tag) : saved(t_tag) { t_tag = tag; }
+PoolTag::~PoolTag() { t_tag = saved; }
 
 void device_arena_context_opened(int dev) {
     std::lock_guard<std::mutex> lock(g_mu);
@@ -428,6 +446,16 @@ void device_arena_context_closed(int dev) {
     g_cv.wait(lock, [&] { return A.pendingReserve == 0; });
     if (A.contexts > 0) --A.contexts;
     if (!A.enabled) return;
+    // chunks released outside an API scope wait in the quarantine for a device-wide synchronisation: with the last context gone nothing of this
+    // library is running on the device, so this is the place for one -- otherwise they would pin their segments against the trim below
+    if (A.contexts == 0 && !A.quarantine.empty()) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+        (void)hipSetDevice(dev);
+        if (hipDeviceSynchronize() != hipSuccess) (void)hipGetLastError();
+        drain_quarantine(A);
+        if (cur >= 0) (void)hipSetDevice(cur);
+    }
     // With no context left on the device only a reserve for the next one stays: the rest is for the process's other allocators (torch,
     // RCCL). NOT trimmed while other contexts live, and not to the high-water mark of the live bytes either (first version of this
     // arena, profiles/r05_arena_probe_119_warm_with_high_water_trim.log): memory this process has returned is what the driver hands out
@@ -459,7 +487,7 @@ void device_cache_stats(int dev, int64_t *cachedBytes, int64_t *blocks, int64_t 
     std::lock_guard<std::mutex> lock(g_mu);
     Arena &A = g_arena[dev];
     if (cachedBytes) *cachedBytes = (int64_t)(A.held - A.live);
-    if (blocks) *blocks = (int64_t)(A.freeBySize[0].size() + A.freeBySize[1].size());
+    if (blocks) *blocks = (int64_t)(A.freeBySize[0].size() + A.freeBySize[1].size() + A.freeBySize[2].size());
     if (hits) *hits = A.hits;
     if (misses) *misses = A.misses;
     if (flushes) *flushes = A.flushes;
@@ -469,7 +497,7 @@ void device_arena_stats(int dev, int64_t out[8]) {
     std::lock_guard<std::mutex> lock(g_mu);
     Arena &A = g_arena[dev];
     out[0] = (int64_t)A.held; out[1] = (int64_t)A.live; out[2] = (int64_t)A.liveHigh; out[3] = (int64_t)A.segments.size();
-    out[4] = (int64_t)(A.freeBySize[0].size() + A.freeBySize[1].size()); out[5] = (int64_t)A.returnedBytes; out[6] = (int64_t)A.quarantined; out[7] = (int64_t)A.limit;
+    out[4] = (int64_t)(A.freeBySize[0].size() + A.freeBySize[1].size() + A.freeBySize[2].size()); out[5] = (int64_t)A.returnedBytes; out[6] = (int64_t)A.quarantined; out[7] = (int64_t)A.limit;
 }
 
 }   // namespace mfh

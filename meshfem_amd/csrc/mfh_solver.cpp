@@ -872,12 +872,19 @@ void solve_classic_partitioned(mfh_ctx *c, const double *f, double *u, double rt
     check_residual_gap(li, rtol);
 }
 
+// The right-hand side of solve_one may already lie on the device, in c->wf (f == nullptr; neumannLoad formed by a kernel, mfh_simulator.cpp): the
+// classic loop of an unpartitioned context takes it from there. (The Chronopoulos-Gear loop interleaves host vectors: not for it.)
+bool device_rhs_supported(mfh_ctx *c) {
+    return !c->hostOnly && c->sym.nRows == c->sym.nCols && !dist_active(c) && !c->deterministic && c->pcgVariant != 1;
+}
+
 // one right-hand side: the Chronopoulos-Gear loop when the operator in use has a batched kernel, else the classic PCG
 static void solve_one_pass(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, mfh_solve_info *info) {
     const bool partitioned = c->sym.nRows != c->sym.nCols;
     // the hierarchy for THIS solve (regular, or pinned for a system that is singular on the free variables): a no-op once it exists
     if (c->precond == MFH_PRECOND_MULTIGRID && !partitioned && !(c->mg.valid && c->mg.singular == c->tlSuppress)) ensure_coarse_levels(c, 1);
     const bool multigrid = c->precond == MFH_PRECOND_MULTIGRID && c->mg.valid && !partitioned;   // the V-cycle lives in the classic loop
+    if (!f && !(!partitioned && c->pcgVariant != 1 && !c->deterministic)) throw Error(MFH_ERR_STATE, "device-resident right-hand side: classic loop only");
     if (!multigrid && !c->deterministic && (c->pcgVariant == 1 || partitioned) && cg_operator_supported(c)) {
         const int64_t n = (int64_t)c->bs() * c->sym.nRows;
         solve_cg(c, 1, f, u, n, rtol, maxit, info);
@@ -901,6 +908,11 @@ void solve_one(mfh_ctx *c, const double *f, double *u, double rtol, int maxit, m
         RawVec<double> r, du;
         DBuf<double> dU, dKu;
         for (int pass = 0; pass < 3 && li.converged && li.true_rel_residual > 2.0 * rtol && li.true_rel_residual < 1.0; ++pass) {
+            if (!f) {        // a device-resident right-hand side (still in c->wf: the loop does not write it) comes to the host for the refinement
+                resize_prefaulted(c->hLoad, (size_t)n);
+                c->wf.download(c->hLoad.data(), (size_t)n, c->stream);
+                f = c->hLoad.data();
+            }
             r.resize((size_t)n); du.resize((size_t)n);
             dU.alloc((size_t)n); dKu.alloc((size_t)n);
             MFH_HIP(hipMemcpyAsync(dU.p, u, (size_t)n * sizeof(double), hipMemcpyHostToDevice, c->stream));
