@@ -36,8 +36,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
-PMC_PROFILE = "r05_pmc_traffic_n60.json"      # scripts/pmc_collect.py at this round's kernels, both triangles of K stored (k_spmv, k_mf_*)
-PMC_PROFILE_UPPER = "r05_pmc_traffic_n60_upper_storage.json"   # the same with the upper-triangle storage (PMC_UPPER_STORAGE=1): the default of configs[2]
+PMC_PROFILE = "r06_pmc_traffic_n60.json"      # scripts/pmc_collect.py at this round's kernels, both triangles of K stored (k_spmv, k_mf_*)
+PMC_PROFILE_UPPER = "r06_pmc_traffic_n60_upper_storage.json"   # the same with the upper-triangle storage (PMC_UPPER_STORAGE=1): the default of configs[2]
 PMC_KERNEL_KEY = "k_assemble_gather"
 ALG_BYTES = {(3, 2): 7736, (3, 1): 1328, (2, 2): 1368, (2, 1): 0}   # SURVEY.md section 8(d), const material, both triangles
 # SURVEY.md section 8(d), row "upper-only variant, matches reference storage": 40 + 96 + 55 x 4 + 55 x 72 (P2 tet); P2 triangle alike
@@ -70,6 +70,7 @@ def parse():
     ap.add_argument("--cpu-solve-grid", type=int, default=0, help="grid size of the CPU direct-solve sample (0 = auto)")
     ap.add_argument("--leg", default="", help="internal: run ONE leg of the N = 1 line in this (fresh) process and print its JSON object "
                                               "(strong_n1: the 119^3 cube in one context, what a one-shot caller of that size sees)")
+    ap.add_argument("--no-forced-ranks", action="store_true", help="N = 1: skip variants.forced_2_ranks_one_gpu (48^3 cube over two processes on the one device)")
     ap.add_argument("--no-config3", action="store_true", help="N = 1: skip variants.config3_homogenization (44^3 periodic cell, 6 cell problems)")
     ap.add_argument("--ranks-per-gpu-ok", action="store_true",
                     help="N > visible GPUs: share the GPUs (ranks on one GPU talk through gloo, staged through the host)")
@@ -83,15 +84,41 @@ def pmc_traffic(kernel_key, n, deg, profile=None):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE in their
     own runs, calibrated on a known byte count: profiles/r01_pmc_traffic_n60.json). PMC counters cannot
     be collected from inside this process; the figure is only attached when the workload matches."""
-    path = os.path.join(ROOT, "profiles", profile or PMC_PROFILE)
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        if d["meta"]["n"] == n and deg == 2:
-            return d[kernel_key]["traffic_bytes"], os.path.relpath(path, ROOT)
-    except Exception:
-        pass
+    name = profile or PMC_PROFILE
+    for cand in (name, name.replace("r06_", "r05_")):      # this round's passes; the previous round's (same kernels) until they are committed
+        path = os.path.join(ROOT, "profiles", cand)
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if d["meta"]["n"] == n and deg == 2:
+                return d[kernel_key]["traffic_bytes"], os.path.relpath(path, ROOT)
+        except Exception:
+            pass
     return None, None
+
+
+PROFILE_ROUND = "r06"     # prefix of the committed per-workload traces under profiles/ (scripts/r06/final_run.sh writes them)
+
+
+def profile_kernel_avg_ms(csv_name, kernel_prefix):
+    """Average duration (ms) of a kernel in a committed rocprofv3 --kernel-trace --stats summary under profiles/ (None if the file or the kernel is
+    missing): the live figure of a bench line is one box's draw of the placement lottery, the committed trace is another -- both are printed."""
+    import csv
+    for cand in (csv_name, csv_name.replace("r06_", "r05_")):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", cand)
+        try:
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    if kernel_prefix in row.get("Name", ""):
+                        return float(row["AverageNs"]) * 1e-6, int(row["Calls"])
+        except Exception:   # noqa: BLE001
+            pass
+    return None, 0
+
+
+# FP64 flops of the matrix-free operator per element, counted in the ISA of the build (profiles/r06_operator_isa_counts.txt)
+MF_FLOPS_PER_ELEMENT = {"iso": 976, "ortho": 1028}
+FP64_PEAK_TFS = 78.6
 
 
 def compulsory_assembly_bytes(c, n_elem, nnzb, geo_bytes=128):
@@ -275,6 +302,59 @@ def reserve_for(M, n, deg):
     return M.device_reserve_for(3, deg, 24 * n ** 3)
 
 
+def forced_2_ranks_one_gpu(args, n=48, timeout_s=240):
+    """something multi-rank in the N = 1 driver line -- the n^3 cube dealt over TWO processes that share the one device
+    (`bench.py --gpus 2 --ranks-per-gpu-ok --scaling strong`): the library's preflight, the transport the halo exchange landed on (peer copies
+    over HIP IPC first, then the callbacks), multigrid iterations and two global figures of the solution against the SAME cube solved in one
+    context of this process. It measures no scaling (two ranks time-slice one GPU); it is the RCCL -> peer -> callbacks chain and the partitioned
+    hierarchy run on a box the builder never touched."""
+    import subprocess
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    t0 = time.time()
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "2", "--ranks-per-gpu-ok", "--scaling", "strong", "--grid", str(n), "--no-cpu", "--no-weak",
+           "--steps", "5", "--warmup", "1", "--rtol", str(args.rtol)]
+    env = dict(os.environ)
+    env.pop("MFH_BENCH_CHILD", None)
+    env["MFH_DEVICE_SHARERS"] = "2"
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        return dict(error="no answer within %d s" % timeout_s)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    if p.returncode != 0 or not lines:
+        return dict(error="exit code %d" % p.returncode, stderr_tail=p.stderr[-600:])
+    d = json.loads(lines[-1])
+    mg = d.get("pcg_multigrid") if isinstance(d.get("pcg_multigrid"), dict) else {}
+    res = dict(workload=d.get("config", {}).get("workload"), wall_s=time.time() - t0, devices=d.get("devices"),
+               preflight=dict(transports_tried=d.get("preflight", {}).get("transports_tried"), communicator=d.get("preflight", {}).get("communicator"),
+                              peer_transfers=(d.get("preflight", {}).get("peer_transfers") or {}).get("outcome")),
+               dist={k: d.get("dist", {}).get(k) for k in ("communicator", "halo_transport_last_solve", "halo_bytes_per_exchange", "interior_items", "boundary_items", "peer_counters")},
+               assembly=dict(value=d.get("value"), ms_per_step=d.get("ms_per_step")),
+               pcg_multigrid={k: mg.get(k) for k in ("iterations", "converged", "true_rel_residual", "solve_s", "transport", "overlap", "hierarchy_setup_ms", "max_abs_u", "u_l2")},
+               pcg_two_level={k: (d.get("pcg") or {}).get(k) for k in ("iterations", "converged", "solve_s", "transport")})
+    # the same cube in ONE context of this process
+    try:
+        V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], [1, 1, 1])
+        c = M.Context(0)
+        c.mesh_build(np.ascontiguousarray(T, dtype=np.int32), V, args.deg)
+        c.material_isotropic(200.0, 0.35)
+        c.bc_dirichlet_box([-1e-9, -1e9, -1e9], [1e-9, 1e9, 1e9], [0, 0, 0])
+        c.bc_neumann_box([1 - 1e-9, -1e9, -1e9], [1 + 1e-9, 1e9, 1e9], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+        c.set_preconditioner(M.PRECOND_MULTIGRID)
+        u = c.sim_solve(rtol=args.rtol, maxit=2000)
+        one = dict(iterations=int(c.last_info["iterations"]), max_abs_u=float(np.abs(u).max()), u_l2=float(np.sqrt(np.sum(u ** 2))))
+        c.close()
+        res["one_context"] = one
+        if mg.get("u_l2"):
+            res["against_one_context"] = dict(iterations_equal=bool(one["iterations"] == mg.get("iterations")),
+                                              u_l2_rel_diff=abs(mg["u_l2"] - one["u_l2"]) / one["u_l2"],
+                                              max_abs_u_rel_diff=abs(mg["max_abs_u"] - one["max_abs_u"]) / one["max_abs_u"])
+    except Exception as e:   # noqa: BLE001
+        res["one_context"] = dict(error="%s: %s" % (type(e).__name__, e))
+    return res
+
+
 def one_shot_fresh_context(M, T, V, deg, rtol, maxit):
     """What a Simulate_cli caller pays end to end (VERDICT r5 item 4): a FRESH context, mesh_build -> boundary conditions -> Simulator::solve with
     the drivers' default preconditioner (symbolic phase, first assembly, multigrid hierarchy, PCG, download of u), wall clock around all of it,
@@ -366,13 +446,20 @@ def run_single(args):
                 frac_traffic=None if tb is None else tb / k_ms / 1e6 / HBM_PEAK_GBS,
                 compulsory_bytes=comp, frac_compulsory=comp / k_ms / 1e6 / HBM_PEAK_GBS,
                 traffic_bytes_per_launch_from_profile=tb, traffic_from_profile=tsrc, alg_bytes_per_launch=alg, kernel_ms=k_ms,
-                kernel_trace="profiles/r05_config2_kernel_stats.csv: rocprofv3 --kernel-trace --stats of `python bench.py --leg config2` (this workload alone: "
+                kernel_trace="profiles/r06_config2_kernel_stats.csv: rocprofv3 --kernel-trace --stats of `python bench.py --leg config2` (this workload alone: "
                              "k_assemble_gather<3, 2, 0, true, false>, no deterministic and no 119^3 launches in the file)",
                 bytes_per_element=bytes_per_element,
                 matrix_storage="upper triangle (blocks (r, c >= r): what the reference assembles)" if upper else "both triangles",
                 note="frac = SURVEY 8(d) algorithmic bytes (the row of the storage in use) / time / 8 TB/s (contract); frac_traffic = "
                      "rocprofv3 PMC bytes of the committed profile / time; frac_compulsory = bytes the design must move (stored K "
                      "once + records + lists) / time")
+    # the committed trace's average of the same kernel (another box, another draw of where the driver put the K values): both on the line
+    if (n, deg) == (60, 2) and upper:
+        pavg, pcalls = profile_kernel_avg_ms(PROFILE_ROUND + "_config2_kernel_stats.csv", "k_assemble_gather<3, 2, 0, true, false>")
+        if pavg:
+            roof.update(kernel_ms_profile_avg=pavg, profile_launches=pcalls, frac_profile_avg=alg / pavg / 1e6 / HBM_PEAK_GBS,
+                        frac_traffic_profile_avg=None if tb is None else tb / pavg / 1e6 / HBM_PEAK_GBS,
+                        frac_compulsory_profile_avg=comp / pavg / 1e6 / HBM_PEAK_GBS)
     # context: the kernel's MEASURED traffic rate against the triad rate measured on this box a minute ago
     if roof["traffic"] is not None:
         roof["measured_triad_GBs"] = hbm_measured["triad_GBs"]
@@ -489,6 +576,11 @@ def run_single(args):
                           operator="matrix-free (k_mf_cluster + k_mf_rows)",
                           algorithm="classic PCG (two reduction points; the default for one right-hand side on one GPU)",
                           matrix_free=dict(kernels_ms=mf_ms, speedup_vs_assembled_spmv=sp_ms / mf_ms, bytes_per_application=mf_bytes, lists=mf_info,
+                                           **(dict(fp64_flops_per_element=MF_FLOPS_PER_ELEMENT["iso"], fp64_TFs=MF_FLOPS_PER_ELEMENT["iso"] * nE / mf_ms * 1e-9,
+                                                   fp64_frac_of_peak=MF_FLOPS_PER_ELEMENT["iso"] * nE / mf_ms * 1e-9 / FP64_PEAK_TFS,
+                                                   flop_per_byte=MF_FLOPS_PER_ELEMENT["iso"] * nE / mf_bytes, ridge_flop_per_byte=FP64_PEAK_TFS * 1e3 / HBM_PEAK_GBS,
+                                                   fp64_note="flops counted in the ISA of this build (profiles/r06_operator_isa_counts.txt): the operator is on the "
+                                                             "bandwidth side of the ridge") if deg == 2 else {}),
                                            traffic_bytes_per_application=mf_traffic, traffic=None if mf_traffic is None else mf_traffic / mf_ms / 1e6,
                                            achieved=mf_bytes / mf_ms / 1e6, frac=mf_bytes / mf_ms / 1e6 / HBM_PEAK_GBS, unit="GB/s",
                                            note="same operator as the assembled K to rounding; trades 72 B/block of matrix traffic for FP64 flops"),
@@ -664,6 +756,11 @@ def run_single(args):
             out["one_shot"] = dict(workload=out["config"]["workload"], **one_shot_fresh_context(M, T, V, deg, args.rtol, min(args.maxit, 2000)))
         except Exception as e:   # noqa: BLE001
             out["one_shot"] = dict(error="%s: %s" % (type(e).__name__, e))
+    if not strong and (n, deg) == (60, 2) and not args.no_solve and not args.no_forced_ranks and isinstance(out.get("variants"), dict):
+        try:
+            out["variants"]["forced_2_ranks_one_gpu"] = forced_2_ranks_one_gpu(args)
+        except Exception as e:   # noqa: BLE001
+            out["variants"]["forced_2_ranks_one_gpu"] = dict(error="%s: %s" % (type(e).__name__, e))
     if not strong and not args.no_strong_n1 and deg == 2:
         # the N = 1 point of the strong-scaling curve the N > 1 runs measure by default (configs[4]'s 119^3 cube in ONE context), so that
         # one driver pass over N = 1, 2, 4, 8 holds the whole curve
@@ -716,7 +813,7 @@ def config1_p1(args, n=35):
                              note="%.0f MB per launch: the working set is of the order of the 256 MiB memory-side cache; the fractions are against the "
                                   "8 TB/s HBM peak all the same" % (comp / 1e6)),
                setup=dict(femmesh_build_s=t_build, symbolic_s=t_sym, first_assemble_call_s=t_first, first_assembly_ms=(t_build + t_sym + t_first) * 1e3),
-               kernel_trace="profiles/r05_config1_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py --leg config1`)")
+               kernel_trace="profiles/r06_config1_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py --leg config1`)")
     if not args.no_solve:
         op_ms = c.time_spmv_kernel(20)
         mf_info = c.matrix_free_info()
@@ -785,7 +882,7 @@ def config3_homogenization(args, n=44):
                checks=dict(major_symmetry_rel_err=sym_err, min_eigenvalue=min_eig, reuss_le_Ch_le_voigt_on_diagonal=in_bounds,
                            all_converged=bool(all(i["converged"] for i in infos)),
                            passed=bool(sym_err <= 1e-9 and min_eig > 0 and in_bounds and all(i["converged"] for i in infos))),
-               trace="profiles/r05_config3_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py --leg config3`)")
+               trace="profiles/r06_config3_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `python bench.py --leg config3`)")
     c.close()
     return res
 
@@ -906,7 +1003,7 @@ def strong_n1(args, torch, n=119):
     k_ms = c.time_assembly_kernel(M.ASSEMBLE_GATHER, 3)
     res = dict(workload="configs[4]: %d^3 grid -> %d P%d tets in ONE context" % (n, nE, deg), elements=nE, dof=3 * c.n_dof,
                value=nE / dt, unit="elements/s", ms_per_step=dt * 1e3, steps=steps, kernel_ms=k_ms,
-               kernel_trace="profiles/r05_strong_n1_kernel_stats.csv + r05_strong_n1_kernel_trace_summary.txt (per launch size: the aggregate levels apart)",
+               kernel_trace="profiles/r06_strong_n1_kernel_stats.csv + r06_strong_n1_kernel_trace_summary.txt (per launch size: the aggregate levels apart)",
                setup=dict(femmesh_build_s=t_build, symbolic_s=t_sym, first_assemble_call_s=t_first,
                           first_assembly_ms=(t_build + t_sym + t_first) * 1e3, first_assembly_elements_per_s=nE / (t_build + t_sym + t_first),
                           device_memory_reserved_GB=reserve / 1e9,
@@ -947,6 +1044,8 @@ def run_multi(args):
     if shared and not (args.ranks_per_gpu_ok or os.environ.get("MFH_BENCH_SHARE_GPUS")):
         raise SystemExit("bench.py --gpus %d needs %d GPUs, %d visible (pass --ranks-per-gpu-ok to share them)" % (world, world, ndev))
     device = local % max(1, ndev)
+    if shared:          # the ranks of a device bound their arenas to their share of it (mfh_pool.cpp)
+        os.environ.setdefault("MFH_DEVICE_SHARERS", str((world + max(1, ndev) - 1) // max(1, ndev)))
     torch.cuda.set_device(device)
     if shared:
         dist.init_process_group("gloo", rank=rank, world_size=world)

@@ -900,8 +900,11 @@ def _bench_slabs_solve(args, rank, world, dev, c, lm, n, deg, out, group=None, l
             if world > 1:
                 dist.barrier(group=group)
             t0 = time.perf_counter()
-            _, _, rec3 = _solve_record(c, solver, f, args.rtol, min(maxit, 2000), red, lm)
+            u3, _, rec3 = _solve_record(c, solver, f, args.rtol, min(maxit, 2000), red, lm)
             g3, p3 = c.multigrid_info(), c.precond_info()
+            # two global figures of the solution (owned rows summed over the ranks): what a one-context solve of the same cube is compared with
+            rec3.update(max_abs_u=float(red([np.abs(u3).max() if u3 is not None else 0.0], dist.ReduceOp.MAX)[0]),
+                        u_l2=float(np.sqrt(red([float(np.sum(np.asarray(u3, dtype=np.float64) ** 2)) if u3 is not None else 0.0], dist.ReduceOp.SUM)[0])))
             rec3.update(hierarchy_setup_ms=g3["setup_ms"], hierarchy_setup_ms_max_over_ranks=float(red([g3["setup_ms"]], dist.ReduceOp.MAX)[0]),
                         wall_s_with_setup=time.perf_counter() - t0, aggregates=p3["aggregates"], dense_level_dim=p3["coarse_dim"], note=p3["note"],
                         speedup_solve_vs_two_level=rec["solve_s"] / max(rec3["solve_s"], 1e-30))

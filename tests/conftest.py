@@ -50,8 +50,17 @@ def _build_lib_once():
     yield
 
 
-_RENDEZVOUS_ERRORS = ("Address already in use", "EADDRINUSE", "Connection refused", "Connection reset", "failed to connect", "connect() timed out",
-                      "Socket Timeout", "The client socket has timed out", "The server socket has failed to listen")
+# (bind / listen failures of the rendezvous port only -- "connection reset / refused / timed out" also appear when a rank crashes or hangs mid-test,
+# and such a failure must not be retried into a pass)
+_RENDEZVOUS_ERRORS = ("Address already in use", "EADDRINUSE", "The server socket has failed to listen", "failed to listen")
+SPAWN_RETRIES = []          # every retry on record (printed in the session summary by pytest_terminal_summary)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if SPAWN_RETRIES:
+        terminalreporter.write_sep("=", "multi-rank spawns retried on a new rendezvous port: %d" % len(SPAWN_RETRIES))
+        for line in SPAWN_RETRIES:
+            terminalreporter.write_line("  " + line)
 
 
 @pytest.fixture(scope="session", autouse=True)
@@ -68,14 +77,27 @@ def _spawn_retries_a_lost_port():
     original = mp.spawn
 
     def spawn(fn, args=(), nprocs=1, join=True, **kw):
+        import os
+        import warnings
+        # the ranks of a test share ONE device: every rank's arena bounds its free memory to its share (mfh_pool.cpp)
+        saved = os.environ.get("MFH_DEVICE_SHARERS")
+        os.environ["MFH_DEVICE_SHARERS"] = str(max(1, int(nprocs)))
         try:
-            return original(fn, args=args, nprocs=nprocs, join=join, **kw)
-        except Exception as e:   # noqa: BLE001
-            if not join or len(args) < 2 or not isinstance(args[1], int) or not any(m in str(e) for m in _RENDEZVOUS_ERRORS):
-                raise
-            s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-            print("spawn: rendezvous on port %d failed (%s); once more on port %d" % (args[1], str(e).splitlines()[-1][:120], port), flush=True)
-            return original(fn, args=(args[0], port) + tuple(args[2:]), nprocs=nprocs, join=join, **kw)
+            try:
+                return original(fn, args=args, nprocs=nprocs, join=join, **kw)
+            except Exception as e:   # noqa: BLE001
+                if not join or len(args) < 2 or not isinstance(args[1], int) or not any(m in str(e) for m in _RENDEZVOUS_ERRORS):
+                    raise
+                s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+                msg = "spawn of %s: rendezvous port %d could not be bound (%s); once more on port %d" % (getattr(fn, "__name__", "?"), args[1], str(e).splitlines()[-1][:120], port)
+                SPAWN_RETRIES.append(msg)
+                warnings.warn(msg)
+                return original(fn, args=(args[0], port) + tuple(args[2:]), nprocs=nprocs, join=join, **kw)
+        finally:
+            if saved is None:
+                os.environ.pop("MFH_DEVICE_SHARERS", None)
+            else:
+                os.environ["MFH_DEVICE_SHARERS"] = saved
 
     mp.spawn = spawn
     yield
