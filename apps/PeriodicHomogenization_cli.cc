@@ -58,6 +58,7 @@ int execute(const Args &args, const std::vector<MeshIO::IOVertex> &inVertices, c
     using Sim = LinearElasticity::Simulator<N, Deg>;
     Sim sim(T, V, args.device);
     sim.rtol = args.rtol;
+    sim.setPreconditioner(MFH_PRECOND_AUTO);      // the V-cycle, or the two-level preconditioner on a mesh stretched past the measured crossover
     if (!args.material.empty()) { Materials::Constant<N> mat(args.material); sim.setMaterial(mat); }
     if (args.ignorePeriodicMismatch) check(sim.ctx(), mfh_set_option(sim.ctx(), "periodic_ignore_mismatch", 1.0));
     std::vector<typename Sim::VField> w_ij;

@@ -2,7 +2,7 @@
 // swapped): mesh.msh + .material + .bc -> u, load, strain, stress, Ku in an output .msh.
 //
 //     simulate_cli mesh.msh -m material.json -b conditions.bc -o out.msh [-d 1|2] [--device 0] [--ascii]
-//                  [--preconditioner block_jacobi|two_level|multigrid] [--rtol 1e-8] [--dumpMatrix K.bin]
+//                  [--preconditioner auto|block_jacobi|two_level|multigrid] [--rtol 1e-8] [--dumpMatrix K.bin]
 //                  [--printMaterial]         (the parsed material in the reference's getJson form)
 //                  [--dumpConditions file]   (after applying the conditions: fixed variables + values and the load, as
 //                                             text, then exit -- works on a host-only context, --device -1)
@@ -20,7 +20,7 @@
 using namespace MeshFEMHip;
 
 struct Args {
-    std::string mesh, material, boundaryConditions, outputMSH, dumpMatrix, dumpConditions, preconditioner = "multigrid";
+    std::string mesh, material, boundaryConditions, outputMSH, dumpMatrix, dumpConditions, preconditioner = "auto";
     int degree = 2, device = 0;
     bool ascii = false, printMaterial = false;
     double rtol = 1e-8;
@@ -40,8 +40,10 @@ int execute(const Args &args, const std::vector<MeshIO::IOVertex> &inVertices, c
     LinearElasticity::Simulator<N, Deg> sim(T, V, args.device);
     sim.rtol = args.rtol;
     if (args.device >= 0)
+        // auto (default): the multigrid V-cycle unless the mesh as a whole is stretched past the measured crossover with the two-level preconditioner
         sim.setPreconditioner(args.preconditioner == "block_jacobi" ? MFH_PRECOND_BLOCK_JACOBI
-                          : args.preconditioner == "multigrid" ? MFH_PRECOND_MULTIGRID : MFH_PRECOND_TWO_LEVEL);
+                          : args.preconditioner == "multigrid" ? MFH_PRECOND_MULTIGRID
+                          : args.preconditioner == "two_level" ? MFH_PRECOND_TWO_LEVEL : MFH_PRECOND_AUTO);
     if (!args.material.empty()) {
         Materials::Constant<N> mat(args.material);
         if (args.printMaterial) printf("material %s\n", mat.getJsonString().c_str());

@@ -68,11 +68,17 @@ enum {
     /* p-multigrid V-cycle for quadratic elasticity: Chebyshev-smoothed quadratic level (matrix-free operator) -> linear level on the
      * same vertices (its assembled stiffness matrix IS the Galerkin operator: P1 is a subspace of P2) -> rigid-body modes of
      * aggregates, merged 2^dim at a time down to a dense inverse. Linear elements enter the same hierarchy at its linear level (their own
-     * assembled K). Mesh-independent iteration counts (tens instead of hundreds); one right-hand side at a time. On a row-partitioned
-     * context (mfh_dist_solve, the preconditioner set on EVERY rank) the nodal levels are partitioned like the mesh and the aggregate
-     * levels replicated; scalar operators and batches fall back to MFH_PRECOND_TWO_LEVEL (see mfh_precond_info). Options "mg_steps_fine",
-     * "mg_steps_coarse", "mg_ratio_fine", "mg_ratio_coarse", "mg_agg_nodes". */
-    MFH_PRECOND_MULTIGRID = 4
+     * assembled K). Mesh-independent iteration counts (tens instead of hundreds); several right-hand sides share the coarse levels of every
+     * V-cycle (option "mg_batch"). On a row-partitioned context (mfh_dist_solve, the preconditioner set on EVERY rank) the nodal levels are
+     * partitioned like the mesh and the aggregate levels partitioned or replicated by size; scalar operators fall back to
+     * MFH_PRECOND_TWO_LEVEL (see mfh_precond_info). Options "mg_steps_fine", "mg_steps_coarse", "mg_ratio_fine", "mg_ratio_coarse", "mg_agg_nodes". */
+    MFH_PRECOND_MULTIGRID = 4,
+    /* the drivers' default: MFH_PRECOND_MULTIGRID unless the mesh as a whole is stretched by more than option "auto_stretch_max" (default 8:
+     * sqrt of the ratio of the extreme eigenvalues of the mesh's edge covariance sum_e sum_edges e e^T, reduced on the device -- 1 for an isotropic
+     * mesh whatever the shapes of its elements, s for a mesh stretched s : 1 : 1), where MFH_PRECOND_TWO_LEVEL is the faster one (measured
+     * crossover, docs/design/04_4c_multigrid.md). The reference's direct solve knows no such cliff (SparseMatrices.hh:1984-2296); the choice is
+     * made when a solve prepares itself and again after new vertices; mfh_precond_choice reads it. */
+    MFH_PRECOND_AUTO = 5
 };
 
 typedef struct mfh_solve_info {
@@ -232,6 +238,9 @@ mfh_status mfh_clear_fixed(mfh_ctx* ctx);
 mfh_status mfh_fix_variables(mfh_ctx* ctx, int64_t n, const int64_t* vars, const double* vals /* or NULL = 0 */);
 mfh_status mfh_set_preconditioner(mfh_ctx* ctx, int32_t kind);
 /* coarse-space facts of the last two-level setup: aggregates, coarse dimension, setup time (ms); note = why it fell back (or "") */
+/* the preconditioner in use (for MFH_PRECOND_AUTO: the choice made for the mesh in hand -- made now if it has not been), whether it was chosen
+ * automatically, and the stretch of the mesh the choice looked at (-1: not computed) */
+mfh_status mfh_precond_choice(mfh_ctx* ctx, int32_t* kind, int32_t* isAuto, double* meshStretch);
 mfh_status mfh_precond_info(const mfh_ctx* ctx, int32_t* nAggregates, int64_t* coarseDim, double* setup_ms, const char** note);
 /* the hierarchy MFH_PRECOND_MULTIGRID built at the last solve: DoFs of the quadratic and of the linear level, the largest eigenvalues
  * of their Jacobi-preconditioned operators (the Chebyshev smoothers' upper bounds), setup time; zeros when it is not in use. On

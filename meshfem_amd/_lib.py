@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("MESHFEM_HIP_LIB") or os.path.join(_HERE, "libmeshfem_
 OK, ERR_INVALID, ERR_STATE, ERR_HIP, ERR_NOT_CONVERGED, ERR_UNSUPPORTED = range(6)
 ASSEMBLE_GATHER, ASSEMBLE_ATOMIC = 0, 1
 NEUMANN_TRACTION, NEUMANN_PRESSURE, NEUMANN_FORCE = 0, 1, 2
-PRECOND_BLOCK_JACOBI, PRECOND_JACOBI, PRECOND_NONE, PRECOND_TWO_LEVEL, PRECOND_MULTIGRID = 0, 1, 2, 3, 4
+PRECOND_BLOCK_JACOBI, PRECOND_JACOBI, PRECOND_NONE, PRECOND_TWO_LEVEL, PRECOND_MULTIGRID, PRECOND_AUTO = 0, 1, 2, 3, 4, 5
 OP_ELASTICITY, OP_LAPLACIAN, OP_MASS = 0, 1, 2
 SOLVE_PIN, SOLVE_NO_RIGID_MOTION, SOLVE_ALLOW_ILL_POSED = 1, 2, 4
 
@@ -92,6 +92,7 @@ PROTOTYPES = {
     "mfh_fix_variables": (_i32, [_P, _i64, _P, _P]),
     "mfh_set_preconditioner": (_i32, [_P, _i32]),
     "mfh_precond_info": (_i32, [_P, _pi32, _pi64, C.POINTER(_f64), C.POINTER(C.c_char_p)]),
+    "mfh_precond_choice": (_i32, [_P, _P, _P, _P]),
     "mfh_multigrid_info": (_i32, [_P, _pi64, _pi64, C.POINTER(_f64), C.POINTER(_f64), C.POINTER(_f64)]),
     "mfh_multigrid_level_info": (_i32, [_P, _i32, _pi64, _pi32]),
     "mfh_solve": (_i32, [_P, _i32, _P, _P, _f64, _i32, C.POINTER(SolveInfo)]),

@@ -236,6 +236,12 @@ class Context:
         self._ck(self.lib.mfh_set_operator(self.h, int(op)))
         self.op = int(op)
 
+    def precond_choice(self):
+        """(kind, chosen automatically?, stretch of the mesh the choice looked at): mfh_precond_choice. With PRECOND_AUTO the choice is made now."""
+        k, a, st = C.c_int32(), C.c_int32(), C.c_double()
+        self._ck(self.lib.mfh_precond_choice(self.h, C.byref(k), C.byref(a), C.byref(st)))
+        return k.value, bool(a.value), st.value
+
     def matrix_free_info(self):
         a, mo, mb = C.c_int32(), C.c_int32(), C.c_int32()
         nb, ne, ni = C.c_int64(), C.c_int64(), C.c_int64()

@@ -100,6 +100,7 @@ void clear_fixed(mfh_ctx *c) {
 
 void upload_mesh(mfh_ctx *c, bool deviceTables) {
     double t0 = now_ms();
+    c->autoStretch = -1.0;           // MFH_PRECOND_AUTO looks at the new vertices
     if (!c->hostOnly && !deviceTables) {      // (deviceTables: the device topology has written both from the vertices)
         require_device(c);
         MFH_HIP(hipSetDevice(c->device));
@@ -554,7 +555,52 @@ void ensure_fixed_uploaded(mfh_ctx *c) {
     c->dinvValid = false;
 }
 
+// sqrt(lambda_max / lambda_min) of the edge covariance of the mesh: 1 for an isotropic mesh, s for one stretched s : 1 : 1 (k_edge_covariance)
+static double mesh_stretch(mfh_ctx *c) {
+    const HostMesh &m = c->mesh;
+    const int d = m.dim;
+    DBuf<double> acc;
+    acc.alloc(6);
+    acc.zero(c->stream);
+    k::launch_edge_covariance(m.nElem, d, m.npe, c->dElemNodes.p, c->dVertPos.p, acc.p, c->stream);
+    double h[6];
+    acc.download(h, 6, c->stream);
+    double A[3][3] = {{h[0], h[5], h[4]}, {h[5], h[1], h[3]}, {h[4], h[3], h[2]}};
+    if (d == 2) { A[2][2] = 0.5 * (A[0][0] + A[1][1]); A[0][2] = A[2][0] = A[1][2] = A[2][1] = 0.0; }
+    for (int sweep = 0; sweep < 30; ++sweep)            // cyclic Jacobi on a 3 x 3 symmetric matrix
+        for (int p = 0; p < 3; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (std::fabs(A[p][q]) < 1e-300) continue;
+                const double th = 0.5 * std::atan2(2.0 * A[p][q], A[q][q] - A[p][p]), cs = std::cos(th), sn = std::sin(th);
+                double B[3][3];
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B[i][j] = A[i][j];
+                for (int k2 = 0; k2 < 3; ++k2) { B[p][k2] = cs * A[p][k2] - sn * A[q][k2]; B[q][k2] = sn * A[p][k2] + cs * A[q][k2]; }
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = B[i][j];
+                for (int k2 = 0; k2 < 3; ++k2) { B[k2][p] = cs * A[k2][p] - sn * A[k2][q]; B[k2][q] = sn * A[k2][p] + cs * A[k2][q]; }
+                for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) A[i][j] = B[i][j];
+            }
+    double lo = 1e300, hi = 0;
+    for (int i = 0; i < 3; ++i) { lo = std::min(lo, A[i][i]); hi = std::max(hi, A[i][i]); }
+    return lo > 0 ? std::sqrt(hi / lo) : 1e300;
+}
+
+// MFH_PRECOND_AUTO: the preconditioner for the mesh in hand. The reference's direct solve is indifferent to the shape of the elements
+// (SparseMatrices.hh:1984-2296); here the V-cycle's point smoothers and isotropic aggregates lose their grip on stretched meshes faster than the
+// two-level preconditioner does, and past the measured crossover the latter is chosen. Row-partitioned contexts keep the V-cycle (the choice
+// must be the same on every rank, and their meshes are slabs of the whole).
+void resolve_auto_precond(mfh_ctx *c) {
+    if (!c->precondAuto || c->autoStretch >= 0 || !c->haveMesh || c->hostOnly) return;
+    int kind = MFH_PRECOND_MULTIGRID;
+    c->autoStretch = 1.0;
+    if (c->op == MFH_OP_ELASTICITY && !c->external && c->mesh.nOwned == c->mesh.nNode && c->dElemNodes.p && c->dVertPos.p) {
+        c->autoStretch = mesh_stretch(c);
+        if (c->autoStretch > c->autoStretchMax) kind = MFH_PRECOND_TWO_LEVEL;
+    }
+    if (kind != c->precond) { c->precond = kind; c->dinvValid = false; }
+}
+
 void ensure_precond(mfh_ctx *c) {
+    resolve_auto_precond(c);
     if (c->deterministic) {
         if (c->use_mf() && c->mfModeEff() != 4)
             throw Error(MFH_ERR_UNSUPPORTED, "option deterministic: the matrix-free operator must be the cluster variant (matrix_free_mode 4) or the assembled SpMV (matrix_free 0)");
@@ -1509,6 +1555,7 @@ mfh_status mfh_mesh_update_vertices(mfh_ctx *c, const double *vertPos) {
         c->dVertPos.upload(m.nodePos, c->stream);
     }
     // topology, DoF map, sparsity pattern, gather lists and the matrix-free lists only depend on connectivity: kept
+    c->autoStretch = -1.0;
     c->geoValid = false;
     c->hGeoValid = false;
     invalidate_matrix(c);
@@ -2019,10 +2066,22 @@ mfh_status mfh_fix_variables(mfh_ctx *c, int64_t n, const int64_t *vars, const d
 }
 
 mfh_status mfh_set_preconditioner(mfh_ctx *c, int32_t kind) {
-    if (!c || kind < 0 || kind > 4) return MFH_ERR_INVALID;
-    c->precond = kind;
+    if (!c || kind < 0 || kind > MFH_PRECOND_AUTO) return MFH_ERR_INVALID;
+    c->precondAuto = kind == MFH_PRECOND_AUTO;
+    c->autoStretch = -1.0;
+    c->precond = c->precondAuto ? MFH_PRECOND_MULTIGRID : kind;      // (AUTO: the choice is made for the mesh in hand when the next solve prepares itself)
     c->dinvValid = false;
     return MFH_OK;
+}
+
+mfh_status mfh_precond_choice(mfh_ctx *c, int32_t *kind, int32_t *isAuto, double *meshStretch) {
+    MFH_TRY(c)
+    require(c, MFH_ERR_INVALID, "null context");
+    if (c->precondAuto && c->haveMesh && !c->hostOnly) { require_device(c); MFH_HIP(hipSetDevice(c->device)); resolve_auto_precond(c); }
+    if (kind) *kind = c->precond;
+    if (isAuto) *isAuto = c->precondAuto ? 1 : 0;
+    if (meshStretch) *meshStretch = c->autoStretch;
+    MFH_CATCH(c)
 }
 
 mfh_status mfh_precond_info(const mfh_ctx *c, int32_t *nAgg, int64_t *coarseDim, double *setup_ms, const char **note) {
@@ -2494,6 +2553,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     }
     else if (k2 == "pcg_variant") c->pcgVariant = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k2 == "mg_batch") c->mgBatch = value != 0;
+    else if (k2 == "auto_stretch_max") { c->autoStretchMax = value > 1.0 ? value : 1.0; c->autoStretch = -1.0; }
     else if (k2 == "batch_rhs") { if (c->batchRhs != (value != 0)) { c->mfcValid = false; c->mfClusterUnfit = false; } c->batchRhs = value != 0; }
     else if (k2 == "matrix_free_mode") { c->mfMode = (int)value; c->mfClusterUnfit = false; }
     else if (k2 == "mf_block_elems") { c->mfBlockElems = (int)value; c->mfcValid = false; c->mfClusterUnfit = false; }

@@ -147,6 +147,11 @@ struct mfh_ctx {
 
     // ---- solver
     int precond = MFH_PRECOND_BLOCK_JACOBI;
+    // MFH_PRECOND_AUTO (mfh_set_preconditioner): `precond` then holds the choice made for the mesh in hand -- the multigrid V-cycle unless the mesh as
+    // a whole is stretched by more than autoStretchMax (option "auto_stretch_max"), where the two-level preconditioner is the faster one (measured
+    // crossover at 8 : 1 : 1, docs/design/04_4c_multigrid.md). autoStretch < 0: not looked at yet (new vertices).
+    bool precondAuto = false;
+    double autoStretch = -1.0, autoStretchMax = 8.0;
     DBuf<double> dDinv;
     bool dinvValid = false;
     DBuf<double> wx, wr, wz, wp, wAp, wb, wf, wu0, scal, stop;

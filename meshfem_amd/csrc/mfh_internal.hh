@@ -507,6 +507,8 @@ struct SpmvMfArgs {
 // constantStrainLoad on the cluster operator's lists (LinearElasticity.hh:551-562): y = int (C : cstrain) grad phi_i = the operator's nodal forces
 // for a field of constant strain `cstrain` -- the element routine with u = 0 and the strain added, summed through the same LDS accumulators
 void launch_mf_cluster_constant_strain(const SpmvMfArgs &a, const double *cstrainFlat, double *y, hipStream_t s);
+// out6 += sum over elements and edges of e e^T (xx, yy, zz, yz, xz, xy): the mesh's stretch for MFH_PRECOND_AUTO
+void launch_edge_covariance(int64_t nElem, int dim, int npe, const int32_t *elemNodes, const double *vertPos, double *out6, hipStream_t s);
 // neumannLoad on the device (LinearElasticity.hh:703-717): out[DoF(node)] += w[local node] * |b| * traction_b over the boundary elements (out is NOT zeroed here)
 void launch_neumann_load(int64_t nBE, int npbe, int dim, const double *w6, const int32_t *bdryElemNodes, const int32_t *dofForNode, const double *bdryVol,
                          const double *traction, double *out, hipStream_t s);

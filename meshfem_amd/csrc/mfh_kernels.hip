@@ -631,6 +631,31 @@ __global__ void __launch_bounds__(256) k_constant_strain_load(LoadArgs a, const 
     }
 }
 
+// Stretch of a mesh as a whole (MFH_PRECOND_AUTO): M = sum over the elements of sum over their edges of e e^T (flattened xx, yy, zz, yz, xz, xy). An
+// isotropic mesh -- whatever the shapes of its elements, as long as their directions average out -- has M ~ I; a mesh stretched s : 1 : 1 has
+// eigenvalues ~ (s^2, 1, 1). One lane per element, sums through the wave and one atomic per wave and entry.
+__global__ void __launch_bounds__(256) k_edge_covariance(int64_t nElem, int dim, int npe, const int32_t *__restrict__ elemNodes, const double *__restrict__ vertPos,
+                                                        double *__restrict__ out6) {
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < nElem; e += (int64_t)gridDim.x * 256) {
+        double P[4][3];
+        for (int k = 0; k <= dim; ++k) {
+            const int64_t v = elemNodes[e * npe + k];
+            for (int a = 0; a < 3; ++a) P[k][a] = a < dim ? vertPos[v * dim + a] : 0.0;
+        }
+        for (int i = 0; i <= dim; ++i)
+            for (int j = i + 1; j <= dim; ++j) {
+                const double x = P[j][0] - P[i][0], y = P[j][1] - P[i][1], z = P[j][2] - P[i][2];
+                acc[0] += x * x; acc[1] += y * y; acc[2] += z * z; acc[3] += y * z; acc[4] += x * z; acc[5] += x * y;
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const double v = wave_sum(acc[q]);
+        if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(&out6[q], v);
+    }
+}
+
 // K8, neumannLoad (LinearElasticity.hh:703-717): f[DoF(node)] += traction_b * int phi_n over boundary element b, one lane per (boundary element,
 // local node); int phi_n = w[n] * |b| with the weights of Functions.hh:246-274 (kernel argument). The boundary of a mesh is a few per cent of
 // its nodes: global atomics are fine here. The vector stays on the device: it is the right-hand side of the solve that follows.
@@ -2272,6 +2297,11 @@ void launch_constant_strain_load(const AsmArgs &a, const int32_t *elemNodes, con
     CHECK_LAUNCH();
 }
 
+void launch_edge_covariance(int64_t nElem, int dim, int npe, const int32_t *elemNodes, const double *vertPos, double *out6, hipStream_t s) {
+    if (nElem <= 0) return;
+    hipLaunchKernelGGL(k_edge_covariance, dim3(grid_for(nElem)), dim3(256), 0, s, nElem, dim, npe, elemNodes, vertPos, out6);
+    CHECK_LAUNCH();
+}
 void launch_neumann_load(int64_t nBE, int npbe, int dim, const double *w6, const int32_t *bdryElemNodes, const int32_t *dofForNode, const double *bdryVol,
                          const double *traction, double *out, hipStream_t s) {
     if (nBE <= 0) return;

@@ -2,7 +2,7 @@
 
     python -m meshfem_amd.periodic_homogenization_cli mesh.msh [-m material.json] [-d 2] [-O]
         [-M m2mstress.txt] [-o fields.msh] [-c] [--distanceToIsotropy] [--distanceToMaterial mat.json]
-        [--device 0] [--rtol 1e-10] [--preconditioner multigrid|two_level|block_jacobi]
+        [--device 0] [--rtol 1e-10] [--preconditioner auto|multigrid|two_level|block_jacobi]
 
 Solves the cell problems of a periodic tri/tet cell (or of its orthotropic base cell with -O,
 OrthotropicHomogenization.hh) for a homogeneous base material and prints, in the reference's order
@@ -61,8 +61,8 @@ def main(argv=None, out=sys.stdout):
     ap.add_argument("-O", "--orthotropicCell", action="store_true")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--rtol", type=float, default=1e-10)
-    ap.add_argument("--preconditioner", default="multigrid", choices=["multigrid", "two_level", "block_jacobi", "jacobi"],
-                    help="multigrid (default): the V-cycle; where it does not apply the library falls back to two_level / block_jacobi and says so")
+    ap.add_argument("--preconditioner", default="auto", choices=["auto", "multigrid", "two_level", "block_jacobi", "jacobi"],
+                    help="auto (default): the multigrid V-cycle, or two_level on a mesh stretched past the measured crossover (MFH_PRECOND_AUTO); where a preconditioner does not apply the library falls back and says so")
     ap.add_argument("--ascii", action="store_true", help="write an ASCII .msh (default binary like the reference)")
     a = ap.parse_args(argv)
     if a.degree not in (1, 2):
@@ -77,7 +77,7 @@ def main(argv=None, out=sys.stdout):
     mat = parse_material(a.material, N) if a.material else ElasticityTensor(N)      # Materials.hh default E = 1, nu = 0.3
     sim = Simulator(E, V, degree=a.degree, device=a.device)
     sim.rtol = a.rtol
-    sim.ctx.set_preconditioner({"multigrid": L.PRECOND_MULTIGRID, "two_level": L.PRECOND_TWO_LEVEL, "block_jacobi": L.PRECOND_BLOCK_JACOBI, "jacobi": L.PRECOND_JACOBI}[a.preconditioner])
+    sim.ctx.set_preconditioner({"auto": L.PRECOND_AUTO, "multigrid": L.PRECOND_MULTIGRID, "two_level": L.PRECOND_TWO_LEVEL, "block_jacobi": L.PRECOND_BLOCK_JACOBI, "jacobi": L.PRECOND_JACOBI}[a.preconditioner])
     sim.setMaterial(mat)
     if a.orthotropicCell:
         Ch, w, infos = H.homogenize_orthotropic_cell(sim)

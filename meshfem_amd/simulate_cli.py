@@ -2,7 +2,7 @@
 
     python -m meshfem_amd.simulate_cli mesh.msh -m material.json -b conditions.bc -d 2 -o out.msh
         [-f fieldPrefix] [-e extra.msh] [--dumpMatrix K.bin] [-D] [--device 0] [--rtol 1e-8]
-        [--preconditioner multigrid|two_level|block_jacobi]
+        [--preconditioner auto|multigrid|two_level|block_jacobi]
 
 Reads a Gmsh 2.2 tri/tet mesh, a `.material` JSON (isotropic / orthotropic / symmetric_material,
 Materials.cc:178-311) or per-element material fields stored in an .msh (`E`,`nu` or the 9 (3D) /
@@ -361,8 +361,8 @@ def main(argv=None):
     ap.add_argument("-D", "--fullDegreeFieldOutput", action="store_true")
     ap.add_argument("--device", type=int, default=0)
     ap.add_argument("--rtol", type=float, default=1e-8)
-    ap.add_argument("--preconditioner", default="multigrid", choices=["multigrid", "two_level", "block_jacobi", "jacobi"],
-                    help="multigrid (default): the V-cycle; where it does not apply the library falls back to two_level / block_jacobi and says so")
+    ap.add_argument("--preconditioner", default="auto", choices=["auto", "multigrid", "two_level", "block_jacobi", "jacobi"],
+                    help="auto (default): the multigrid V-cycle, or two_level on a mesh stretched past the measured crossover (MFH_PRECOND_AUTO); where a preconditioner does not apply the library falls back and says so")
     ap.add_argument("--ascii", action="store_true", help="write an ASCII .msh (default binary like the reference)")
     a = ap.parse_args(argv)
     if not a.dumpMatrix and not a.outputMSH:
@@ -386,7 +386,7 @@ def main(argv=None):
         V = V[:, :2]
     sim = Simulator(E, np.ascontiguousarray(V), degree=a.degree, device=a.device)
     sim.rtol = a.rtol
-    sim.ctx.set_preconditioner({"multigrid": L.PRECOND_MULTIGRID, "two_level": L.PRECOND_TWO_LEVEL, "block_jacobi": L.PRECOND_BLOCK_JACOBI, "jacobi": L.PRECOND_JACOBI}[a.preconditioner])
+    sim.ctx.set_preconditioner({"auto": L.PRECOND_AUTO, "multigrid": L.PRECOND_MULTIGRID, "two_level": L.PRECOND_TWO_LEVEL, "block_jacobi": L.PRECOND_BLOCK_JACOBI, "jacobi": L.PRECOND_JACOBI}[a.preconditioner])
     if a.material.endswith(".msh"):                        # heterogeneous material fields (Simulate_cli.cc:104-163)
         _, _, fields = load_msh(a.material)
         pre = a.matFieldName

@@ -290,6 +290,39 @@ def test_stretched_elements_converge_and_are_the_documented_weak_case():
     assert 60 < res["default"][1] < 1500
 
 
+@pytest.mark.parametrize("box,want", [([1, 1, 1], "multigrid"), ([4, 1, 1], "multigrid"), ([16, 1, 1], "two_level"), ([1, 12, 1], "two_level")])
+def test_stretched_elements_get_the_preconditioner_chosen_for_them(box, want):
+    """MFH_PRECOND_AUTO, the drivers' default: the stretch of the mesh as a whole (sqrt of the eigenvalue ratio of the edge
+    covariance, reduced on the device) decides between the V-cycle and the two-level preconditioner at the measured crossover (8 : 1 : 1;
+    profiles/r06_auto_preconditioner_table.jsonl: never more than 3 % behind the better of the two). The choice follows new vertices, and the
+    answer is the fixed preconditioner's."""
+    import meshfem_amd as M
+    from meshfem_amd import grid
+    n = 10
+    V, T = grid.grid_tet_mesh(n, n, n, [0, 0, 0], box)
+    c = M.Context(0)
+    c.mesh_build(T, V, 2)
+    c.material_isotropic(200.0, 0.35)
+    c.bc_dirichlet_box([-1e-9, -99, -99], [1e-9, 99, 99], [0, 0, 0])
+    c.bc_neumann_box([box[0] - 1e-9, -99, -99], [box[0] + 1e-9, 99, 99], [0, -1, 0], kind=M.NEUMANN_TRACTION)
+    c.set_preconditioner(M.PRECOND_AUTO)
+    u = c.sim_solve(rtol=1e-9, maxit=5000)
+    it_auto = c.last_info["iterations"]
+    kind, is_auto, stretch = c.precond_choice()
+    names = {M.PRECOND_MULTIGRID: "multigrid", M.PRECOND_TWO_LEVEL: "two_level"}
+    assert is_auto and names[kind] == want, (kind, stretch)
+    assert abs(stretch - max(box) / min(box)) <= 1e-6 * stretch          # a grid stretched s : 1 : 1 has stretch s
+    c.set_preconditioner(kind)                                            # the same preconditioner, named: same iterations, same answer
+    u2 = c.sim_solve(rtol=1e-9, maxit=5000)
+    assert c.last_info["iterations"] == it_auto and np.linalg.norm(u - u2) <= 1e-9 * np.linalg.norm(u2)
+    if want == "two_level":
+        # new vertices (the mesh squeezed back to a cube): the next solve chooses again
+        c.set_preconditioner(M.PRECOND_AUTO)
+        c.mesh_update_vertices(V / np.asarray(box, dtype=np.float64))
+        assert names[c.precond_choice()[0]] == "multigrid" and abs(c.precond_choice()[2] - 1.0) < 1e-6
+    c.close()
+
+
 @pytest.mark.parametrize("deg,n", [(2, 8), (1, 14)])
 def test_fp32_copies_of_the_coarse_operators_change_neither_the_answer_nor_the_iteration_count(deg, n):
     """Option mg_coarse_fp32 (default on): inside the preconditioner the linear level's assembled K and the aggregate stencils are read
