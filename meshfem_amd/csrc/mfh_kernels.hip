@@ -32,7 +32,13 @@ DEV void block_from_H(const double *__restrict__ g, const double (&H)[DIM][DIM],
 template <int DIM>
 DEV void pair_H(const double *__restrict__ g, uint32_t offs /* bytes: 3 DIM-offsets of s_i, t_i, s_j, t_j */, double S0, double S1, double S2,
                 double S3, double (&H)[DIM][DIM]) {
-    const double vol = g[12];
+    // MFH_ASM_ABLATE (timing-only builds of round 6, docs/design/04_2 (xiii): K comes out wrong): 1 = the loads that belong to the ROW node of a
+    // contribution (its two support gradients, the volume, the Lame parameters) are replaced by values the lane already has -- what a row-lane
+    // decomposition could save at most on the load side; 2 = no element record is read at all
+#ifndef MFH_ASM_ABLATE
+#define MFH_ASM_ABLATE 0
+#endif
+    const double vol = MFH_ASM_ABLATE >= 1 ? 1.0 : g[12];
     S0 *= vol; S1 *= vol; S2 *= vol; S3 *= vol;
     const char *gb = reinterpret_cast<const char *>(g);
     const double *gsi = reinterpret_cast<const double *>(gb + (offs & 0xffu)), *gti = reinterpret_cast<const double *>(gb + ((offs >> 8) & 0xffu)),
@@ -40,8 +46,8 @@ DEV void pair_H(const double *__restrict__ g, uint32_t offs /* bytes: 3 DIM-offs
     double ua[DIM], ub[DIM], p[DIM], q[DIM];
 #pragma unroll
     for (int a = 0; a < DIM; ++a) {
-        ua[a] = gsi[a]; ub[a] = gti[a];
-        const double va = gsj[a], vb = gtj[a];
+        ua[a] = MFH_ASM_ABLATE >= 1 ? S0 + a : gsi[a]; ub[a] = MFH_ASM_ABLATE >= 1 ? S1 - a : gti[a];
+        const double va = MFH_ASM_ABLATE >= 2 ? S2 + a : gsj[a], vb = MFH_ASM_ABLATE >= 2 ? S3 - a : gtj[a];
         p[a] = S0 * va + S1 * vb;
         q[a] = S2 * va + S3 * vb;
     }
@@ -118,7 +124,11 @@ DEV void block_from_H(const double *__restrict__ g, const double (&H)[DIM][DIM],
         K[0] = tr;
     } else if (MAT == MAT_ISO) {
         // C_acdb = lambda d_ac d_db + mu (d_ad d_cb + d_ab d_cd)  =>  K = lambda H + mu H^T + mu tr(H) I
+#if defined(MFH_ASM_ABLATE) && MFH_ASM_ABLATE >= 1
+        const double lam = H[0][0], mu = H[1][1];      // (timing-only build: no load of the Lame parameters)
+#else
         const double lam = g[13], mu = g[14];
+#endif
         double tr = 0;
 #pragma unroll
         for (int a = 0; a < DIM; ++a) tr += H[a][a];
