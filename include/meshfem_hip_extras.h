@@ -39,8 +39,6 @@ mfh_status mfh_debug_device_node_tables(mfh_ctx* ctx, int32_t* elemNodes, double
  * make them; tests/test_gpu_arena.py checks splitting, merging, the bounds and the trims with them */
 mfh_status mfh_debug_arena_alloc(mfh_ctx* ctx, int64_t bytes, void** out);
 mfh_status mfh_debug_arena_free(mfh_ctx* ctx, void* p);
-mfh_status mfh_debug_adopt_vals(mfh_ctx* ctx, void* p);   /* experiment hook */
-mfh_status mfh_debug_move_buffer(mfh_ctx* ctx, int32_t which);   /* experiment hook: see mfh_api.cpp */
 /* test hook (host only, no context): the row chunks of the assembly kernel -- greedy, whole rows, at most chunkSlots slots each, a chunk ends at
  * every row listed in breaks -- scanned by `threads` host threads over ranges of `grain` rows and stitched (threads = 1: the plain sequential
  * scan the result must equal). Writes the chunks' first rows + nRows to chunkRow (capacity cap); *nOut = entries (chunks + 1) */

@@ -173,8 +173,6 @@ PROTOTYPES = {
     "mfh_placement_info": (_i32, [_P, _i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
     "mfh_debug_arena_alloc": (_i32, [_P, _i64, C.POINTER(_P)]),
     "mfh_debug_arena_free": (_i32, [_P, _P]),
-    "mfh_debug_move_buffer": (_i32, [_P, _i32]),
-    "mfh_debug_adopt_vals": (_i32, [_P, _P]),
     "mfh_debug_row_chunks": (_i32, [_i64, _P, _i32, _i64, _P, _i64, _i32, _P, _i64, _P]),
 }
 

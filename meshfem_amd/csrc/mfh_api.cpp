@@ -354,6 +354,7 @@ void run_assembly(mfh_ctx *c, int mode) {
 void placement_trials(mfh_ctx *c) {
     c->placementGen = c->valsGen;
     c->placementMs.clear();
+    c->placementNote.clear();
     const size_t n = c->dVals.n, bytes = n * sizeof(double);
     if (c->placementTrials <= 0 || c->hostOnly || c->external || bytes < ((size_t)256 << 20)) return;
     auto timed = [&]() {
@@ -370,9 +371,11 @@ void placement_trials(mfh_ctx *c) {
     c->placementMs.push_back(best);
     std::vector<std::unique_ptr<DBuf<double>>> held;
     for (int trial = 0; trial < c->placementTrials; ++trial) {
+        // room for a candidate: what the driver still has, or a free chunk the arena already holds (e.g. a reservation) -- ADVICE r5: the
+        // driver's figure alone skipped the trials silently while the memory was sitting in the arena
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); break; }
-        if (fr < 2 * bytes + ((size_t)1 << 30)) break;
+        if (fr < 2 * bytes + ((size_t)1 << 30) && mfh::device_arena_largest_free(c->device) < bytes) { c->placementNote = "stopped after " + std::to_string(trial) + " trials: no room for another candidate"; break; }
         std::unique_ptr<DBuf<double>> alt(new DBuf<double>());
         { mfh::PoolTag values(1); alt->alloc(n); }
         alt->zero(c->stream);              // (the padding of the last tile is never read; zero all the same)
@@ -2421,43 +2424,6 @@ mfh_status mfh_placement_info(const mfh_ctx *c, int32_t cap, double *ms, int32_t
     *n = (int32_t)c->placementMs.size();
     for (int32_t k = 0; ms && k < cap && k < *n; ++k) ms[k] = c->placementMs[(size_t)k];
     return MFH_OK;
-}
-
-// Experiment hook (scripts/buffer_move_probe.py): one of the assembly kernel's large buffers moves into a newly allocated buffer (contents
-// copied); the old one is held until the context is destroyed, so the new one cannot be the same memory. which: 0 K values, 1 gather codes,
-// 2 gather slots, 3 element records, 4 column indices.
-static std::vector<void *> g_debugHeld;
-mfh_status mfh_debug_move_buffer(mfh_ctx *c, int32_t which) {
-    MFH_TRY(c)
-    require(c && !c->hostOnly && c->symValid, MFH_ERR_INVALID, "mfh_debug_move_buffer: needs a symbolic phase");
-    MFH_HIP(hipSetDevice(c->device));
-    void **pp = nullptr;
-    size_t bytes = 0;
-    switch (which) {
-    case 0: pp = (void **)&c->dVals.p; bytes = c->dVals.n * sizeof(double); break;
-    case 1: pp = (void **)&c->dContribCode.p; bytes = c->dContribCode.n * sizeof(uint32_t); break;
-    case 2: pp = (void **)&c->dContribSlot.p; bytes = c->dContribSlot.n * sizeof(uint16_t); break;
-    case 3: pp = (void **)&c->dGeo.p; bytes = c->dGeo.n * sizeof(double); break;
-    case 4: pp = (void **)&c->dColIdx.p; bytes = c->dColIdx.n * sizeof(int32_t); break;
-    default: throw Error(MFH_ERR_INVALID, "mfh_debug_move_buffer: which");
-    }
-    require(*pp && bytes, MFH_ERR_STATE, "mfh_debug_move_buffer: empty buffer");
-    void *fresh = mfh::device_alloc(bytes);
-    MFH_HIP(hipMemcpyAsync(fresh, *pp, bytes, hipMemcpyDeviceToDevice, c->stream));
-    MFH_HIP(hipStreamSynchronize(c->stream));
-    g_debugHeld.push_back(*pp);
-    *pp = fresh;
-    MFH_CATCH(c)
-}
-
-// Experiment hook (scripts/vmm_probe.py): the K values move into a buffer the CALLER allocated (at least dVals.n doubles); the old one is held.
-mfh_status mfh_debug_adopt_vals(mfh_ctx *c, void *p) {
-    MFH_TRY(c)
-    require(c && !c->hostOnly && c->symValid && p && c->dVals.p, MFH_ERR_INVALID, "mfh_debug_adopt_vals: needs a symbolic phase");
-    g_debugHeld.push_back(c->dVals.p);
-    c->dVals.p = (double *)p;
-    c->assembled = false;
-    MFH_CATCH(c)
 }
 
 mfh_status mfh_debug_spd_inverse_device(mfh_ctx *c, int64_t n, double *A) {

@@ -128,6 +128,7 @@ struct mfh_ctx {
     int placementTrials = 0;
     int64_t valsGen = 0, placementGen = -1;       // values buffer (re)allocated by the symbolic phase / generation the trials ran for
     std::vector<double> placementMs;              // kernel time on every candidate of the last trials (first = the buffer of the symbolic phase)
+    std::string placementNote;        // why the trials stopped early (empty: they did not)
     DBuf<float> dVals32;              // FP32 copy of dVals for the smoother of a multigrid linear level (built by ensure_multigrid, dropped whenever dVals is rewritten)
     bool assembled = false;
 

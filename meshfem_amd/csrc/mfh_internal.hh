@@ -72,6 +72,7 @@ struct PoolTag {
     PoolTag(const PoolTag &) = delete;
     PoolTag &operator=(const PoolTag &) = delete;
 };
+size_t device_arena_largest_free(int dev);
 void device_arena_stats(int dev, int64_t out[8]);   // held, live, live high-water mark, segments, free chunks, bytes returned to the driver, quarantined, bound
 // What a release waits for before the block may be handed to somebody else: the streams of the context the calling thread is working for
 // (PoolScope, installed by every API entry), not the whole device -- hipDeviceSynchronize from one host thread invalidates a stream

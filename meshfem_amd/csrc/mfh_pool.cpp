@@ -493,6 +493,15 @@ void device_cache_stats(int dev, int64_t *cachedBytes, int64_t *blocks, int64_t 
     if (flushes) *flushes = A.flushes;
 }
 
+size_t device_arena_largest_free(int dev) {          // the largest free chunk of the large and K-values classes
+    std::lock_guard<std::mutex> lock(g_mu);
+    Arena &A = g_arena[dev];
+    size_t best = 0;
+    for (int cls = 1; cls <= 2; ++cls)
+        if (!A.freeBySize[cls].empty()) best = std::max(best, std::prev(A.freeBySize[cls].end())->first);
+    return best;
+}
+
 void device_arena_stats(int dev, int64_t out[8]) {
     std::lock_guard<std::mutex> lock(g_mu);
     Arena &A = g_arena[dev];

@@ -1113,6 +1113,12 @@ static void sync_with_deadline(mfh_comm *cm, hipStream_t s, const char *what) {
         cm->nccl = nullptr;                      // (aborted communicators are not destroyed again; the handle is gone)
         cm->aborted = true;
         (void)hipStreamSynchronize(s);
+    } else {
+        // Callbacks / peer transfers cannot be aborted from here: throwing with the stream still busy would let the buffers of the caller
+        // be released -- and its host staging vectors destroyed -- under copies that are still in flight. Both transports end on their own (the peer
+        // kernels carry a 60 s limit, the callbacks' process group its own timeout): wait for the stream to drain, THEN report.
+        fprintf(stderr, "[meshfem_hip] communicator self-test: no answer within %d s (%s); this transport cannot be aborted -- waiting for its own time limit\n", (int)limit, what);
+        if (hipStreamSynchronize(s) != hipSuccess) (void)hipGetLastError();
     }
     throw Error(MFH_ERR_HIP, std::string("communicator self-test: no answer within ") + std::to_string((int)limit) + " s (" + what + "); the transport is unusable");
 }
