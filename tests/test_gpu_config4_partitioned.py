@@ -118,7 +118,7 @@ def _worker(rank, world, port, n, ret):
 
 
 @pytest.mark.timeout(1500)
-def test_config4_row_partitioned_over_8_ranks_matches_the_single_context_solve():
+def test_configs4_row_partitioned_over_8_ranks_matches_the_single_context_solve():
     import torch
     import torch.multiprocessing as mp
     import meshfem_amd as M

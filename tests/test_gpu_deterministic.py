@@ -87,7 +87,7 @@ def test_two_assemblies_and_two_solves_give_identical_bits(dim, deg, n):
 
 
 @pytest.mark.timeout(900)
-def test_config2_assembled_twice_and_solved_twice_is_bit_identical():
+def test_configs2_assembled_twice_and_solved_twice_is_bit_identical():
     """BASELINE configs[2]: 60^3 grid -> 5,184,000 quadratic tets, 22.3 M DOF; 104 M stored blocks compared value by value."""
     import torch
     import meshfem_amd as M

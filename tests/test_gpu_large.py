@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.timeout(900)
-def test_config5_size_on_one_gpu():
+def test_configs4_size_on_one_gpu():
     import torch
     import meshfem_amd as M
     from meshfem_amd import grid

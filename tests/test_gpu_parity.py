@@ -402,10 +402,10 @@ def test_python_simulator_mirror_cantilever():
 
 
 # ------------------------------------------------------------------------------------------------
-# BASELINE config 2 at FULL size (35^3 grid, 1,029,000 P1 tets, 665,493 DOF): the oracle's direct
+# BASELINE configs[1] at FULL size (35^3 grid, 1,029,000 P1 tets, 665,493 DOF): the oracle's direct
 # solve does not finish in seconds there, so parity is checked through size-independent properties
 # ------------------------------------------------------------------------------------------------
-def test_config2_full_size_properties():
+def test_configs1_full_size_properties():
     V, T = grid.grid_tet_mesh(35, 35, 35, [0, 0, 0], [1, 1, 1])
     assert len(T) == 1029000
     c = _ctx()
@@ -749,7 +749,7 @@ def test_example_meshes_homogenization_matches_golden(name, dim, deg):
         assert err < U_RTOL, (k, err)
 
 
-def test_config3_full_size_properties():
+def test_configs2_full_size_properties():
     """BASELINE configs[2] at full size (60^3 grid -> 5,184,000 P2 tets, 22,292,283 DOF; the oracle's direct solve
     does not run at this size): size-independent properties of the assembled operator and of the solution."""
     n_grid = 60

@@ -77,7 +77,7 @@ def test_hip_laminate_homogenization_matches_closed_form(deg, precond):
 
 @pytest.mark.gpu
 @pytest.mark.timeout(900)
-def test_config4_full_size_properties():
+def test_configs3_full_size_properties():
     """BASELINE configs[3]: 44^3 grid -> 2,044,416 P2 tets, per-element orthotropic field (SURVEY 8d ranges, seed 0), periodic
     DoFs, 6 cell problems (PeriodicHomogenization.hh:34-54). No direct solve exists at this size; size-independent
     properties instead: every solve converged with a TRUE residual <= 2 rtol, Ch has the major symmetry to 1e-10 and is
