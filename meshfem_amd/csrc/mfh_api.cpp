@@ -1429,12 +1429,13 @@ mfh_status mfh_device_cache_stats(int32_t device, int64_t *cachedBytes, int64_t 
     return MFH_OK;
 }
 // Bytes a context on a mesh of nElem simplices of that kind will hold at its peak (assembly + multigrid solve), and the share of it that is the
-// value array of K. Measured on the generator's meshes (24 tets per hex / 8 triangles per quad patch; upper-triangle storage): 3.6 kB per
-// quadratic tet of which 1.45 kB are K values, 0.9 kB per linear tet (0.39), 1.2 kB per quadratic triangle (0.42), 0.35 kB per linear one (0.12).
-// An estimate: the arena asks the driver for more when it is short and returns what stays free.
+// value array of K. Measured on the generator's meshes (24 tets per hex / 8 triangles per quad patch; upper-triangle storage): 3.9 kB per
+// quadratic tet of which 1.45 kB are K values (the rest must hold the peak of the symbolic phase by itself -- sort keys and temporaries next to
+// the mesh tables: 2.3 kB per tet at 40 M tets -- since nothing shares the values' segment), 1.0 kB per linear tet (0.39), 1.3 kB per quadratic
+// triangle (0.42), 0.4 kB per linear one (0.12). An estimate: the arena asks the driver for more when it is short and returns what stays free.
 mfh_status mfh_context_bytes_estimate(int32_t dim, int32_t deg, int64_t nElem, int64_t *totalBytes, int64_t *kValueBytes) {
     if (!(dim == 2 || dim == 3) || !(deg == 1 || deg == 2) || nElem < 0) return MFH_ERR_INVALID;
-    const double total = dim == 3 ? (deg == 2 ? 3600.0 : 900.0) : (deg == 2 ? 1200.0 : 350.0);
+    const double total = dim == 3 ? (deg == 2 ? 3900.0 : 1000.0) : (deg == 2 ? 1300.0 : 400.0);
     const double vals = dim == 3 ? (deg == 2 ? 1450.0 : 390.0) : (deg == 2 ? 420.0 : 120.0);
     if (totalBytes) *totalBytes = (int64_t)(total * (double)nElem);
     if (kValueBytes) *kValueBytes = (int64_t)(vals * (double)nElem * 1.07);      // (+7 %: a value array that misses its segment by a few MB would land in the other one)
@@ -1448,9 +1449,12 @@ static mfh_status reserve_split(int32_t device, int64_t bytes, int64_t valueByte
         if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) { (void)hipGetLastError(); return MFH_ERR_INVALID; }
         // the value array of K gets a segment of its own (the smaller request first: both may be under way at once): in one physical run with the
         // context's other buffers the assembly kernel sits at the slow end of its placement spread (docs/design/04_2_k_assemble_gather.md (xi))
+        // the segment for everything else FIRST: the mesh tables and the symbolic phase need it at once, the value array is allocated at the END of the
+        // symbolic phase -- and what a process takes beyond its first ~66 GB the driver clears while allocating (1 s for 83 GB at 119^3): with the
+        // values' segment first, the symbolic phase stood waiting for the slow one while the fast one lay idle (round 6, first version: 0.86 instead of 0.38 s)
         bool ok = true;
-        if (valueBytes > 0) ok = mfh::device_arena_reserve(device, (size_t)valueBytes, async != 0, 2) && ok;
         if (bytes - valueBytes > 0) ok = mfh::device_arena_reserve(device, (size_t)(bytes - valueBytes), async != 0, 1) && ok;
+        if (valueBytes > 0) ok = mfh::device_arena_reserve(device, (size_t)valueBytes, async != 0, 2) && ok;
         if (!ok) return MFH_ERR_HIP;            // (synchronous reservations only: an asynchronous one that fails leaves the arena to ask again when it needs the memory)
     } catch (...) { return MFH_ERR_HIP; }
     return MFH_OK;

@@ -372,11 +372,18 @@ void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofFo
     if (!m.hasTopology) throw Error(MFH_ERR_STATE, "periodic conditions need mesh topology (mfh_mesh_build)");
     const int dim = m.dim;
     double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
-    for (int64_t n = 0; n < m.nNode; ++n)
-        for (int a = 0; a < dim; ++a) {
-            mn[a] = std::min(mn[a], m.nodePos[(size_t)n * dim + a]);
-            mx[a] = std::max(mx[a], m.nodePos[(size_t)n * dim + a]);
-        }
+    {   // bounding box on the host threads (minima / maxima: exact in any order)
+        const int nt = host_threads();
+        std::vector<double> part((size_t)(nt + 1) * 6);
+        for (int t = 0; t <= nt; ++t) for (int a = 0; a < 3; ++a) { part[(size_t)t * 6 + a] = 1e300; part[(size_t)t * 6 + 3 + a] = -1e300; }
+        parallel_ranges(m.nNode, [&](int64_t lo, int64_t hi, int tid) {
+            double a0[3] = {1e300, 1e300, 1e300}, a1[3] = {-1e300, -1e300, -1e300};
+            for (int64_t n = lo; n < hi; ++n)
+                for (int a = 0; a < dim; ++a) { a0[a] = std::min(a0[a], m.nodePos[(size_t)n * dim + a]); a1[a] = std::max(a1[a], m.nodePos[(size_t)n * dim + a]); }
+            for (int a = 0; a < 3; ++a) { part[(size_t)tid * 6 + a] = std::min(part[(size_t)tid * 6 + a], a0[a]); part[(size_t)tid * 6 + 3 + a] = std::max(part[(size_t)tid * 6 + 3 + a], a1[a]); }
+        });
+        for (int t = 0; t <= nt; ++t) for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], part[(size_t)t * 6 + a]); mx[a] = std::max(mx[a], part[(size_t)t * 6 + 3 + a]); }
+    }
     // face membership restricted to the periodic dimensions (PeriodicCondition's ignoreDims, BoundaryConditions.hh:470-500:
     // a node keeps only its memberships of non-ignored faces)
     auto periodicDim = [&](int a) { return !(ignoreDimsMask & (1 << a)); };
@@ -394,13 +401,38 @@ void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofFo
     }
     const double cs = std::max(eps, 1.0e-7);
     struct CellKey { int64_t q[3]; bool operator==(const CellKey &o) const { return q[0] == o.q[0] && q[1] == o.q[1] && q[2] == o.q[2]; } };
-    struct CellHash { size_t operator()(const CellKey &k) const {
+    auto hashOf = [](const CellKey &k) {
         uint64_t h = 1469598103934665603ull;
         for (int c = 0; c < 3; ++c) { h ^= (uint64_t)k.q[c]; h *= 1099511628211ull; h ^= h >> 29; }
-        return (size_t)h; } };
-    typedef std::unordered_map<CellKey, std::vector<int32_t>, CellHash> Grid;
+        return (size_t)h; };
+    // Hash grid in flat arrays (round 6: a std::unordered_map of std::vectors cost one heap allocation per cell -- with cells of 1e-7 that is one per point, 75 k of
+    // them at configs[3]): open addressing over the cells, the points of one cell chained through `next`.
+    struct Grid {
+        std::vector<CellKey> key;
+        std::vector<int32_t> first;        // slot -> first entry of the cell (-1: empty slot)
+        std::vector<int32_t> node, next;   // entries
+        size_t mask = 0;
+        void reserve(size_t nPoints) {
+            size_t cap = 16;
+            while (cap < 2 * nPoints + 2) cap <<= 1;
+            key.assign(cap, CellKey{{0, 0, 0}}); first.assign(cap, -1); mask = cap - 1;
+            node.clear(); next.clear(); node.reserve(nPoints); next.reserve(nPoints);
+        }
+    };
     auto cellOf = [&](const double *p) { CellKey k{{0, 0, 0}}; for (int a = 0; a < dim; ++a) k.q[a] = (int64_t)std::floor(p[a] / cs); return k; };
-    auto addPoint = [&](Grid &g, int32_t n) { g[cellOf(&m.nodePos[(size_t)n * dim])].push_back(n); };
+    auto slotOf = [&](const Grid &g, const CellKey &k) {          // the slot of cell k, or the empty slot where it would go
+        size_t sl = hashOf(k) & g.mask;
+        while (g.first[sl] >= 0 && !(g.key[sl] == k)) sl = (sl + 1) & g.mask;
+        return sl;
+    };
+    auto addPoint = [&](Grid &g, int32_t n) {
+        const CellKey k = cellOf(&m.nodePos[(size_t)n * dim]);
+        const size_t sl = slotOf(g, k);
+        g.node.push_back(n);
+        g.next.push_back(g.first[sl]);
+        g.key[sl] = k;
+        g.first[sl] = (int32_t)g.node.size() - 1;
+    };
     auto closest = [&](const Grid &g, const double *q) -> int32_t {
         int64_t lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
         for (int a = 0; a < dim; ++a) { lo[a] = (int64_t)std::floor((q[a] - eps) / cs); hi[a] = (int64_t)std::floor((q[a] + eps) / cs); }
@@ -409,9 +441,14 @@ void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofFo
         for (int64_t i = lo[0]; i <= hi[0]; ++i)
             for (int64_t j = lo[1]; j <= hi[1]; ++j)
                 for (int64_t k = lo[2]; k <= hi[2]; ++k) {
-                    auto it = g.find(CellKey{{i, j, k}});
-                    if (it == g.end()) continue;
-                    for (int32_t c : it->second) {
+                    const size_t sl = slotOf(g, CellKey{{i, j, k}});
+                    // (entries of a cell are chained newest first; ties in distance go to the LATEST candidate probed, like the loop over a cell's vector did:
+                    // walk the chain into a small buffer and test oldest first)
+                    int32_t chain[16];
+                    int nc = 0;
+                    for (int32_t en = g.first[sl]; en >= 0; en = g.next[(size_t)en]) { if (nc < 16) chain[nc++] = g.node[(size_t)en]; }
+                    for (int t = nc - 1; t >= 0; --t) {
+                        const int32_t c = chain[t];
                         double d2 = 0;
                         for (int a = 0; a < dim; ++a) { const double d = q[a] - m.nodePos[(size_t)c * dim + a]; d2 += d * d; }
                         const double dist = std::sqrt(d2);
@@ -428,6 +465,7 @@ void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofFo
         // periodic faces looks up its 2^d - 1 translates among the non-minimal nodes; a missing translate, a node claimed
         // twice or a non-minimal node left over is an error
         Grid grid;
+        grid.reserve(faceNodes.size());
         for (int32_t n : faceNodes) if (!isMinimal(n)) addPoint(grid, n);
         char buf[320];
         for (int32_t n : faceNodes) {
@@ -463,6 +501,7 @@ void periodic_dof_map(const HostMesh &m, double eps, std::vector<int32_t> &dofFo
         std::unordered_map<int32_t, std::array<int32_t, 3>> pair;
         for (int a = 0; a < dim; ++a) {
             Grid grid;
+            grid.reserve(faceNodes.size());
             for (int32_t n : faceNodes) if (onMin(n, a)) addPoint(grid, n);
             for (int32_t n : faceNodes) {
                 if (!onMax(n, a)) continue;

@@ -134,6 +134,7 @@ struct Arena {
     bool init = false, enabled = true;
     int contexts = 0;
     int pendingReserve = 0;                               // reservations under way on other threads (device_arena_reserve)
+    size_t pendingBytes = 0;                              // ... and their bytes
     int64_t hits = 0, misses = 0, flushes = 0, bypassed = 0;
     size_t returnedBytes = 0;
     size_t free_bytes() const { return held - live - quarantined; }
@@ -398,7 +399,12 @@ bool device_arena_reserve(int dev, size_t bytes, bool async, int cls) {
         if (!A.enabled) return true;
         if (!A.freeBySize[cls].empty() && std::prev(A.freeBySize[cls].end())->first >= bytes) return true;
         ++A.pendingReserve;
-        A.limit = std::max(A.limit, bytes + A.idleLimit);      // (the reservation itself must not count as "too much free memory" when something else is released)
+        // The reservation itself must not count as "too much free memory" when something else is released -- neither this one nor the ones made just before it
+        // that have not been used yet (round 6: the two segments of one mfh_device_reserve_for, 95 + 63 GB, on top of 70 GB of free memory from earlier meshes:
+        // the bound of 154 + ... GB was passed, and the first release of a small buffer gave the LARGEST free segments -- the reservation -- back to the driver;
+        // the 119^3 context then waited 2.6 + 2.1 s for the driver to clear them again). The bound follows what is free now plus everything under way.
+        A.pendingBytes += bytes;
+        A.limit = std::max(A.limit, A.free_bytes() + A.pendingBytes + A.idleLimit / 4);
     }
     static std::once_flag once;
     std::call_once(once, [] {
@@ -425,6 +431,7 @@ bool device_arena_reserve(int dev, size_t bytes, bool async, int cls) {
         } else *ok = false;
         if (getenv("MFH_POOL_TRACE")) fprintf(stderr, "[arena] reservation of %.1f MB: %s after %.1f ms\n", bytes / 1e6, p ? "arrived" : "FAILED", now_ms() - t0);
         --A.pendingReserve;
+        A.pendingBytes -= std::min(A.pendingBytes, bytes);
         g_cv.notify_all();
     };
     if (async) { std::thread(work).detach(); return true; }
