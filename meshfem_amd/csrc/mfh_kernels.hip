@@ -1183,6 +1183,7 @@ DEV void elem_forces_bilinear(const double *__restrict__ g /* element record: ma
                 elem_D_apply<DIM, MAT>(gm, R[q], sg);
 #pragma unroll
                 for (int c = 0; c < FL; ++c) { S[c] += sg[c]; R[q][c] = vol * wq * dAB * sg[c]; }
+                if (MAT == MAT_GENERAL) __builtin_amdgcn_sched_barrier(0);
             }
         } else
 #pragma unroll
