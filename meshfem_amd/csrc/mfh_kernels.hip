@@ -409,6 +409,8 @@ __global__ void __launch_bounds__(256, (MAT == MAT_GENERAL || MAT == MAT_ORTHO) 
             } else if (ok[u]) {
 #pragma unroll
                 for (int c = 0; c < NB; ++c) unsafeAtomicAdd(&acc[c * CS + ls[u]], K[c]);
+                // (round 6, measured and removed: even / odd lanes walking the 9 components in opposite orders, or three rotations by lane % 3, so that lanes adding
+                // to the SAME slot do not meet at one address -- 3.10 -> 3.32 / 3.55 ms: a ds_add_f64 costs per INSTRUCTION, not per active lane, docs/design/04_2 (xiii))
             }
             __builtin_amdgcn_sched_barrier(0);
         }
