@@ -167,6 +167,11 @@ def test_reservation_arrives_asynchronously_and_serves_the_context():
     M.device_reserve(6 << 30, 0)                       # asynchronous
     p = _alloc(keep, 512 * MB)                        # finds nothing -> waits for the reservation, is cut from it
     s1 = M.device_arena_stats(0)
+    for _ in range(200):                              # (the segment for everything else arrives first and serves the request; the values' segment may still be under way)
+        if s1["segments"] >= s0["segments"] + 2:
+            break
+        time.sleep(0.05)
+        s1 = M.device_arena_stats(0)
     # (round 6: the reservation arrives in TWO segments -- one for the value array of K, one for the rest --, each rounded up to 2 MiB)
     assert abs(s1["held_bytes"] - s0["held_bytes"] - (6 << 30)) <= 4 * MB and s1["segments"] == s0["segments"] + 2
     _free(keep, p)

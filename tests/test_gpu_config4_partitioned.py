@@ -184,7 +184,7 @@ def test_configs4_row_partitioned_over_8_ranks_matches_the_single_context_solve(
     record["summary"] = summary
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
-    with open(os.path.join(out_dir, "r05_config4_partitioned_8ranks.json"), "w") as fh:
+    with open(os.path.join(out_dir, "r06_config4_partitioned_8ranks.json"), "w") as fh:
         json.dump(record, fh, indent=1, default=float)
     # ---- the bars
     assert sum(r["owned_nodes"] for r in recs) == n_nodes == 57635985            # every node owned exactly once
