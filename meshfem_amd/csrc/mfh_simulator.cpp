@@ -258,7 +258,8 @@ static void constant_strain_load_impl(mfh_ctx *c, const double *cstrain, const d
     c->wb.alloc(n);
     // once the matrix-free operator's lists exist the load is an application of its element routine (LDS sums, 0.25 ms at 2 M quadratic tets);
     // before that -- a caller that only wants load vectors -- the stand-alone kernel with its global atomics (2.3 ms) needs nothing but the records
-    if (!deltaP && c->mfcValid && constant_strain_load_device(c, cs, c->wb.p)) { c->wb.download(out, (size_t)n, c->stream); return; }
+    // (its LDS sums arrive in any order: not under option "deterministic")
+    if (!deltaP && c->mfcValid && !c->deterministic && constant_strain_load_device(c, cs, c->wb.p)) { c->wb.download(out, (size_t)n, c->stream); return; }
     c->wb.zero(c->stream);
     k::launch_constant_strain_load(asm_args(c), c->dElemNodes.p, device_dof_map(c), c->tables.intGrad.data(), cs, deltaP ? dp.p : nullptr,
                                    c->wb.p, c->stream);
