@@ -255,7 +255,9 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
         c->timing.symbolic_ms = now_ms() - t0;
         const size_t tilesD = (size_t)((S.nnzb + 63) / 64);
         const double tV = now_ms();
-        { mfh::PoolTag values(1); c->dVals.alloc(tiled_count(S.nnzb, c->dim() * c->dim())); }
+        // the value array of a caller's context lives in a segment class of its own (mfh_pool.cpp); the linear level of a hierarchy is served from the
+        // general class -- its 7.7 GB at 119^3 would otherwise miss the values' reservation (sized for the quadratic K) and wait 0.2 s for the driver
+        { mfh::PoolTag values(c->hierarchyLevel ? 0 : 1); c->dVals.alloc(tiled_count(S.nnzb, c->dim() * c->dim())); }
         if (getenv("MFH_SYM_TIMING")) fprintf(stderr, "[symbolic] value array %.1f MB: allocation %.2f ms\n", tilesD * 64.0 * c->dim() * c->dim() * 8 / 1e6, now_ms() - tV);
         c->symValid = true;
         ++c->listsGen;
@@ -283,7 +285,7 @@ void ensure_symbolic(mfh_ctx *c, bool wantScatter) {
         std::vector<uint16_t>().swap(c->sym.contribSlot);
         std::vector<int32_t>().swap(c->sym.scatterSlot);
     }
-    { mfh::PoolTag values(1); c->dVals.alloc(tiled_count(S.nnzb, c->dim() * c->dim())); }
+    { mfh::PoolTag values(c->hierarchyLevel ? 0 : 1); c->dVals.alloc(tiled_count(S.nnzb, c->dim() * c->dim())); }
     c->symValid = true;
     ++c->listsGen;
     ++c->valsGen;

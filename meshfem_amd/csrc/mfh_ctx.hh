@@ -13,6 +13,7 @@ using namespace mfh;   // private header of the library's own translation units
 struct mfh_ctx {
     int device = 0;
     bool hostOnly = false;            // device == -1: mesh/symbolic host logic only (CPU tests)
+    bool hierarchyLevel = false;      // the linear level of another context's multigrid hierarchy (mfh_multigrid.cpp)
     bool keepHostSymbolic = false;
     int xcdSwizzle = 0;              // option "xcd_swizzle": XCD-contiguous work mapping in the chunked kernels (measured SLOWER
                                      // than the round-robin default on MI355X: DESIGN.md section 4.8)

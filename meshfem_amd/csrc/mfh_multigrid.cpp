@@ -801,6 +801,7 @@ bool ensure_multigrid(mfh_ctx *c) {
     // ---- level 1: a context of its own on the vertices (degree 1), sharing device and stream
     mfh_ctx *c1 = new mfh_ctx();
     G.coarse = c1;
+    c1->hierarchyLevel = true;        // (its K values are an ordinary large buffer for the arena: only a caller's context gets the values' segment class)
     c1->device = c->device; c1->stream = c->stream; c1->ownStream = false; c1->nCU = c->nCU;
     c1->deterministic = c->deterministic;     // its assembly orders the waves too; its launches use the calling thread's scratch (the parent's: k::t_det)
     c1->symbolicDevice = c->symbolicDevice; c1->topologyDevice = c->topologyDevice;
