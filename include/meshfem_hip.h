@@ -523,6 +523,9 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
  *   1 solves several right-hand sides per operator pass of the Chronopoulos-Gear loop, see mfh_solve_batch; block-Jacobi / two-level only),
  * "mg_batch" (1 default: several right-hand sides under MFH_PRECOND_MULTIGRID on an unpartitioned quadratic context run one classic PCG loop
  *   each, in lockstep, and share the linear / aggregate / dense levels of every V-cycle; 0: one right-hand side at a time),
+ * "mg_fuse" (1 default: with one Chebyshev step on the quadratic level of an unpartitioned hierarchy, the PCG loop's residual update also writes
+ *   the V-cycle's pre-smoothed start and the cycle's last smoothing step also forms r.z -- two kernels and three vector passes less per
+ *   iteration, the same iterates; 0: separate kernels),
  * "solve_homogeneous" (1: mfh_solve treats the fixed variables as fixed to ZERO whatever values were given -- the
  *   homogeneous solves K y = C^T of a Schur-complement elimination of constraint rows, SparseMatrices.hh:2572-2590),
  * "periodic_ignore_mismatch" (1: nodes of a periodic face without a partner keep their own DoF, PeriodicCondition's

@@ -240,6 +240,7 @@ struct mfh_ctx {
                                       // vector pass fewer), Chronopoulos-Gear for batches and row-partitioned contexts
     int distPcgVariant = 1;           // option "dist_pcg_variant": 1 = Chronopoulos-Gear (one all-reduce per iteration, default), 0 = classic
                                       // (two all-reduces, one vector pass less per iteration)
+    bool mgFuse = true;               // option "mg_fuse": the PCG loop's residual update / r.z share kernels with the V-cycle's first / last smoothing step (MgFuse)
     bool mgBatch = true;              // option "mg_batch": several right-hand sides under the multigrid preconditioner share the linear and aggregate levels of
                                       // every V-cycle (solve_multigrid_batch); 0: one right-hand side at a time
     bool batchRhs = false;            // option "batch_rhs": several right-hand sides per operator pass (measured slower than one at a time)
@@ -424,8 +425,15 @@ bool ensure_twolevel(mfh_ctx *c);
 bool ensure_multigrid(mfh_ctx *c);
 void ensure_coarse_levels(mfh_ctx *c, int nrhs);
 void destroy_multigrid(mfh_ctx *c);
-void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int it, const double *stop);
-void mg_precond_batch(mfh_ctx *c, int NR, const double *r, double *z, int64_t vecStride, const double *scal, int64_t scalStride, int it, const double *stop);
+// What the PCG loop around the V-cycle takes over from it / hands to it when the first level's smoother is ONE step (mg_fuse_scale > 0):
+//   presmoothed: z already holds zs Dinv r (k_pcg_update's ZS flavour wrote it with the residual update) -- the cycle starts at its residual;
+//   rzScal:      the cycle's last kernel also forms r.z into the iteration's history (k_mg_cheb_rz; rzMask: the fixed-variable mask, may be null)
+//                -- the loop launches no k_mg_rz. Loop k of a batch: history rzScal + k scalStride.
+struct MgFuse { bool presmoothed = false; double *rzScal = nullptr; const uint8_t *rzMask = nullptr; };
+double mg_fuse_scale(const mfh_ctx *c);       // zs = 1 / theta of the first level's smoother when the fusion applies (unpartitioned quadratic hierarchy, one step), else 0
+void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int it, const double *stop, const MgFuse *fuse = nullptr);
+void mg_precond_batch(mfh_ctx *c, int NR, const double *r, double *z, int64_t vecStride, const double *scal, int64_t scalStride, int it, const double *stop,
+                      const MgFuse *fuse = nullptr);
 k::AsmArgs asm_args(mfh_ctx *c);
 const int32_t *device_dof_map(mfh_ctx *c);
 void box_corners(mfh_ctx *c, const double *mn, const double *mx, int relative, double *omn, double *omx);

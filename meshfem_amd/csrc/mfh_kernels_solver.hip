@@ -785,10 +785,12 @@ __global__ void __launch_bounds__(256) k_pcg_init(int64_t nRows, const double *_
 
 // r -= alpha Ap ; z = Dinv r ; scal[it+1].{rz,rr} += ...   (x += alpha p happens in k_pcg_direction, which reads p anyway: one
 // vector read less per iteration than updating x here)
-template <int DIM, bool SKIPZ = false>
+// ZS (the multigrid preconditioner's pre-smoothing from zero folded in, mg_precond's MgFuse): z = zs Dinv r, and r.z is NOT accumulated (the
+// preconditioner is not finished: the V-cycle's last kernel forms it, k_mg_cheb_rz)
+template <int DIM, bool SKIPZ = false, bool ZS = false>
 __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double *__restrict__ dinv,
                                                     const double *__restrict__ Ap, double *__restrict__ r,
-                                                    double *__restrict__ z, double *scal, int it, const double *stopPtr, DetBuf det) {
+                                                    double *__restrict__ z, double *scal, int it, const double *stopPtr, DetBuf det, double zs = 1.0) {
     __shared__ double red[16];
     it += (int)stopPtr[3];
     if (scal[(int64_t)it * 4 + 2] <= stopPtr[0]) return;
@@ -818,10 +820,14 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
             apply_block<DIM>(dm, rv, zv);
             apply_block<DIM>(dm + NS, rv + DIM, zv + DIM);
             double2 *z2 = reinterpret_cast<double2 *>(z + q * 2 * DIM);
+            if (ZS)
+#pragma unroll
+                for (int c = 0; c < 2 * DIM; ++c) zv[c] *= zs;
 #pragma unroll
             for (int c = 0; c < DIM; ++c) z2[c] = make_double2(zv[2 * c], zv[2 * c + 1]);
+            if (!ZS)
 #pragma unroll
-            for (int c = 0; c < 2 * DIM; ++c) acc[0] += rv[c] * zv[c];
+                for (int c = 0; c < 2 * DIM; ++c) acc[0] += rv[c] * zv[c];
         }
 #pragma unroll
         for (int c = 0; c < 2 * DIM; ++c) acc[1] += rv[c] * rv[c];
@@ -838,13 +844,16 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
         if (!SKIPZ) {
             apply_block<DIM>(dinv + n * NS, rv, zv);
 #pragma unroll
-            for (int c = 0; c < DIM; ++c) { z[n * DIM + c] = zv[c]; acc[0] += rv[c] * zv[c]; }
+            for (int c = 0; c < DIM; ++c) {
+                if (ZS) z[n * DIM + c] = zs * zv[c];
+                else { z[n * DIM + c] = zv[c]; acc[0] += rv[c] * zv[c]; }
+            }
         }
 #pragma unroll
         for (int c = 0; c < DIM; ++c) acc[1] += rv[c] * rv[c];
     }
     block_sum<2>(acc, red);
-    double *const tg[2] = {SKIPZ ? nullptr : &scal[(int64_t)(it + 1) * 4 + 0], &scal[(int64_t)(it + 1) * 4 + 2]};
+    double *const tg[2] = {(SKIPZ || ZS) ? nullptr : &scal[(int64_t)(it + 1) * 4 + 0], &scal[(int64_t)(it + 1) * 4 + 2]};
     commit_sums<2>(acc, tg, det, red);
 }
 
@@ -1408,6 +1417,63 @@ __global__ void __launch_bounds__(256) k_mg_cheb(int64_t nRows, const double *__
     }
 }
 
+// The V-cycle's LAST kernel with the PCG's inner product folded in (one-step smoother on the first level; mg_precond's MgFuse):
+//   x += b D^-1 (rin - t) ;  x = rin on the fixed variables (k_mg_rz's rule) ;  scal[(it + 1) 4] += rin . x
+// rin IS the PCG residual here (a one-step sweep smooths the right-hand side itself), so k_mg_rz's two vector reads disappear. A lane takes two
+// consecutive rows in 16-byte accesses like k_pcg_update.
+template <int DIM>
+__global__ void __launch_bounds__(256) k_mg_cheb_rz(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ rin,
+                                                    const double *__restrict__ t, double *__restrict__ x, double b,
+                                                    const uint8_t *__restrict__ mask, double *scalOut, MgGate g, DetBuf det) {
+    __shared__ double red[8];
+    if (mg_closed(g)) return;
+    const int it = g.scal ? g.it + (int)g.stop[3] : g.it;
+    constexpr int NS = DIM * (DIM + 1) / 2;
+    double acc[1] = {0};
+    const int64_t nPair = nRows >> 1;
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < nPair; q += (int64_t)gridDim.x * 256) {
+        double rv[2 * DIM], tv[2 * DIM], xv[2 * DIM], zv[2 * DIM], dm[2 * NS];
+        const double2 *r2 = reinterpret_cast<const double2 *>(rin + q * 2 * DIM);
+        const double2 *t2 = reinterpret_cast<const double2 *>(t + q * 2 * DIM);
+        double2 *x2 = reinterpret_cast<double2 *>(x + q * 2 * DIM);
+        const double2 *d2 = reinterpret_cast<const double2 *>(dinv + q * 2 * NS);
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            const double2 a = r2[c], u = t2[c], w = x2[c];
+            rv[2 * c] = a.x; rv[2 * c + 1] = a.y; tv[2 * c] = a.x - u.x; tv[2 * c + 1] = a.y - u.y; xv[2 * c] = w.x; xv[2 * c + 1] = w.y;
+        }
+#pragma unroll
+        for (int c = 0; c < NS; ++c) { const double2 a = d2[c]; dm[2 * c] = a.x; dm[2 * c + 1] = a.y; }
+        apply_block<DIM>(dm, tv, zv);
+        apply_block<DIM>(dm + NS, tv + DIM, zv + DIM);
+#pragma unroll
+        for (int c = 0; c < 2 * DIM; ++c) {
+            xv[c] += b * zv[c];
+            if (mask && mask[q * 2 * DIM + c]) xv[c] = rv[c];
+            acc[0] += rv[c] * xv[c];
+        }
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) x2[c] = make_double2(xv[2 * c], xv[2 * c + 1]);
+    }
+    if ((nRows & 1) && blockIdx.x == 0 && threadIdx.x == 0) {   // the odd last row
+        const int64_t n = nRows - 1;
+        double rv[DIM], tv[DIM], zv[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) { rv[c] = rin[n * DIM + c]; tv[c] = rv[c] - t[n * DIM + c]; }
+        apply_block<DIM>(dinv + n * NS, tv, zv);
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) {
+            double xv = x[n * DIM + c] + b * zv[c];
+            if (mask && mask[n * DIM + c]) xv = rv[c];
+            x[n * DIM + c] = xv;
+            acc[0] += rv[c] * xv;
+        }
+    }
+    block_sum<1>(acc, red);
+    double *const tg[1] = {scalOut + (int64_t)(it + 1) * 4};
+    commit_sums<1>(acc, tg, det, red);
+}
+
 // restriction R = P^T of the residual r - t (t may be null): coarse DoF q gets its own fine DoF plus half of every
 // edge-node DoF it is an end of. A CSR row of ~13 scattered entries per coarse DoF: EIGHT lanes share a row (every eighth entry
 // each, independent loads in flight) and add up with three shuffles -- one lane per row walked its 13 dependent-latency loads alone
@@ -1915,6 +1981,17 @@ void launch_pcg_update_noz(int dim, int64_t nRows, const double *Ap, double *r, 
     CHECK_LAUNCH();
 }
 
+// r -= alpha Ap, z = zs Dinv r, r.r (no r.z): the PCG update with the V-cycle's pre-smoothing from zero folded in
+void launch_pcg_update_presmooth(int dim, int64_t nRows, const double *dinv, const double *Ap, double *r, double *z, double zs, double *scal, int it,
+                                 const double *stopPtr, hipStream_t s) {
+    const int grid = grid_for(nRows / 2);
+    if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false, true>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr, t_det, zs);
+    else if (dim == 2) hipLaunchKernelGGL((k_pcg_update<2, false, true>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr, t_det, zs);
+    else hipLaunchKernelGGL((k_pcg_update<1, false, true>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr, t_det, zs);
+    launch_det_finish(s);
+    CHECK_LAUNCH();
+}
+
 void launch_tl_fill(const TLArgs &t, const int32_t *colorOfAgg, int color, int mode, double *v, hipStream_t s) {
     if (t.dim == 3) hipLaunchKernelGGL(k_tl_fill<3>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, colorOfAgg, color, mode, v);
     else hipLaunchKernelGGL(k_tl_fill<2>, dim3(grid_for(t.nDoF)), dim3(256), 0, s, t, colorOfAgg, color, mode, v);
@@ -2261,6 +2338,17 @@ void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, do
     launch_det_finish(s);
     CHECK_LAUNCH();
 }
+// the V-cycle's last smoothing step and the PCG's r.z in one kernel (k_mg_cheb_rz)
+void launch_mg_cheb_rz(int dim, int64_t nRows, const double *dinv, const double *rin, const double *t, double *x, double b, const uint8_t *mask,
+                       double *scalOut, int it, const double *scal, const double *stop, hipStream_t s) {
+    const int grid = grid_for(nRows / 2);
+    if (dim == 3) hipLaunchKernelGGL(k_mg_cheb_rz<3>, dim3(grid), dim3(256), 0, s, nRows, dinv, rin, t, x, b, mask, scalOut, mk_gate(scal, it, stop), t_det);
+    else if (dim == 2) hipLaunchKernelGGL(k_mg_cheb_rz<2>, dim3(grid), dim3(256), 0, s, nRows, dinv, rin, t, x, b, mask, scalOut, mk_gate(scal, it, stop), t_det);
+    else hipLaunchKernelGGL(k_mg_cheb_rz<1>, dim3(grid), dim3(256), 0, s, nRows, dinv, rin, t, x, b, mask, scalOut, mk_gate(scal, it, stop), t_det);
+    launch_det_finish(s);
+    CHECK_LAUNCH();
+}
+
 
 
 // ---- aggregate (lattice-stencil) levels of the multigrid hierarchy

@@ -982,9 +982,16 @@ static void reserve_batch(mfh_ctx *c, int NR) {
     G.nrAlloc = NR;
 }
 
+double mg_fuse_scale(const mfh_ctx *c) {
+    const auto &G = c->mg;
+    if (!G.valid || G.linearOnly || G.distributed || c->mgSteps0 != 1) return 0.0;
+    return 1.0 / (0.5 * G.lmax0 * (1.0 + c->mgRatio0));       // 1 / theta of chebyshev()
+}
+
 // z = M^-1 r: one symmetric V-cycle. scal / it / stop: the gate of the PCG iteration this application belongs to (null: none).
-void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int it, const double *stop) {
+void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int it, const double *stop, const MgFuse *fuse) {
     auto &G = c->mg;
+    if (fuse && (fuse->presmoothed || fuse->rzScal) && !(mg_fuse_scale(c) > 0)) throw Error(MFH_ERR_STATE, "multigrid: fused PCG kernels need a one-step smoother on an unpartitioned quadratic level");
     if (G.linearOnly) {                        // linear elements: the V-cycle starts on the context's own level
         linear_level(c, c, r, z, scal, it, stop);
         return;
@@ -997,7 +1004,8 @@ void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int 
     const bool masked0 = !c->fixedVars.empty(), masked1 = !c1->fixedVars.empty();
     // level 0, pre-smoothing from zero; residual r - K z = r0 - t0
     const double *ra = nullptr, *rb = nullptr;
-    chebyshev(L0, r, z, true, true, G.r0.p, G.d0.p, G.t0.p, &ra, &rb);
+    if (fuse && fuse->presmoothed) { L0.apply(z, G.t0.p); ra = r; rb = G.t0.p; }     // z = Dinv r / theta is there already
+    else chebyshev(L0, r, z, true, true, G.r0.p, G.d0.p, G.t0.p, &ra, &rb);
     if (G.distributed) {
         // the restriction to an owned vertex reads the edge nodes around it, some of them owned by a neighbour: the residual is formed
         // on the owned rows, its halo rows fetched
@@ -1010,16 +1018,22 @@ void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int 
     if (G.distributed) dist_halo(c1, G.x1.p, d);              // an owned edge node may hang between vertices of a neighbour
     // back to level 0: z += P x1, post-smoothing
     k::launch_mg_prolong_add(d, G.nFine, G.parA.p, G.parB.p, G.x1.p, masked0 ? c->dFixedMask.p : nullptr, z, scal, it, stop, s);
-    chebyshev(L0, r, z, false, false, G.r0.p, G.d0.p, G.t0.p);
+    if (fuse && fuse->rzScal) {                // the one post-smoothing step and the PCG's r.z in one kernel
+        L0.apply(z, G.t0.p);
+        k::launch_mg_cheb_rz(d, c->sym.nRows, c->dDinv.p, r, G.t0.p, z, mg_fuse_scale(c), fuse->rzMask, fuse->rzScal, it, scal, stop, s);
+    } else
+        chebyshev(L0, r, z, false, false, G.r0.p, G.d0.p, G.t0.p);
 }
 
 // The V-cycle for NR right-hand sides at once (solve_multigrid_batch; unpartitioned quadratic hierarchies). The quadratic level works on NR
 // SEPARATE vectors (vector k at r + k vecStride; its smoother is the tuned single-vector operator, gated by loop k's own history at
 // scal + k scalStride / stop + 4 k); the restriction interleaves them, and the linear level, the aggregate levels and the dense level run ONCE
 // for all NR -- their matrices are read once, their launch latencies paid once --, gated by "every loop has converged".
-void mg_precond_batch(mfh_ctx *c, int NR, const double *r, double *z, int64_t vecStride, const double *scal, int64_t scalStride, int it, const double *stop) {
+void mg_precond_batch(mfh_ctx *c, int NR, const double *r, double *z, int64_t vecStride, const double *scal, int64_t scalStride, int it, const double *stop,
+                      const MgFuse *fuse) {
     auto &G = c->mg;
     if (G.distributed || G.linearOnly) throw Error(MFH_ERR_UNSUPPORTED, "batched V-cycle: unpartitioned quadratic hierarchies only");
+    if (fuse && (fuse->presmoothed || fuse->rzScal) && !(mg_fuse_scale(c) > 0)) throw Error(MFH_ERR_STATE, "multigrid: fused PCG kernels need a one-step smoother");
     reserve_batch(c, NR);
     mfh_ctx *c1 = G.coarse;
     hipStream_t s = c->stream;
@@ -1034,7 +1048,8 @@ void mg_precond_batch(mfh_ctx *c, int NR, const double *r, double *z, int64_t ve
         L0.lmax = G.lmax0; L0.ratio = c->mgRatio0; L0.steps = c->mgSteps0;
         const double *ra = nullptr, *rb = nullptr;
         const size_t o = (size_t)k2 * vecStride;
-        chebyshev(L0, r + o, z + o, true, true, G.r0.p + o, G.d0.p + o, G.t0.p + o, &ra, &rb);
+        if (fuse && fuse->presmoothed) { L0.apply(z + o, G.t0.p + o); ra = r + o; rb = G.t0.p + o; }
+        else chebyshev(L0, r + o, z + o, true, true, G.r0.p + o, G.d0.p + o, G.t0.p + o, &ra, &rb);
         if (k2 == 0) { ra0 = ra; rb0 = rb; }
         else if (ra != ra0 + o || rb != rb0 + o) throw Error(MFH_ERR_STATE, "batched V-cycle: residual vectors are not equally spaced");
     }
@@ -1051,7 +1066,11 @@ void mg_precond_batch(mfh_ctx *c, int NR, const double *r, double *z, int64_t ve
         LevelOps L0 = nodal_ops(c, sc, it, st);
         L0.lmax = G.lmax0; L0.ratio = c->mgRatio0; L0.steps = c->mgSteps0;
         const size_t o = (size_t)k2 * vecStride;
-        chebyshev(L0, r + o, z + o, false, false, G.r0.p + o, G.d0.p + o, G.t0.p + o);
+        if (fuse && fuse->rzScal) {
+            L0.apply(z + o, G.t0.p + o);
+            k::launch_mg_cheb_rz(d, c->sym.nRows, c->dDinv.p, r + o, G.t0.p + o, z + o, mg_fuse_scale(c), fuse->rzMask, fuse->rzScal + (size_t)k2 * scalStride, it, sc, st, s);
+        } else
+            chebyshev(L0, r + o, z + o, false, false, G.r0.p + o, G.d0.p + o, G.t0.p + o);
     }
 }
 

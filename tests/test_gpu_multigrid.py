@@ -350,3 +350,40 @@ def test_fp32_copies_of_the_coarse_operators_change_neither_the_answer_nor_the_i
     assert c.last_info["converged"]
     assert np.linalg.norm(u2 - res[0][0]) <= 1e-8 * np.linalg.norm(res[0][0])
     c.close()
+
+
+@pytest.mark.parametrize("dim,n", [(3, 5), (2, 14)])
+def test_fused_pcg_kernels_walk_the_iterates_of_the_separate_ones(dim, n):
+    """Option mg_fuse (default on): r -= alpha Ap and the V-cycle's first smoothing step share a kernel, its last step and r.z another (MgFuse,
+    k_pcg_update's ZS flavour, k_mg_cheb_rz). The arithmetic per entry is the same, only the order of the r.z sum differs: the same iteration
+    counts and the same answer to rounding, with Dirichlet rows (masked), a deterministic run and several right-hand sides. (The kernels take two
+    rows per lane; the generator's 3D grids have odd node counts, so their single-row tail runs here too.)"""
+    c, V, T = _cantilever(n, 2, dim)
+    c.set_preconditioner(M.PRECOND_MULTIGRID)
+    out = {}
+    for fuse in (1, 0):
+        c.set_option("mg_fuse", fuse)
+        u = c.sim_solve(rtol=1e-10)
+        out[fuse] = (u, c.last_info["iterations"], c.last_info["true_rel_residual"])
+    assert out[1][1] == out[0][1] and out[1][2] < 2e-10
+    assert np.linalg.norm(out[1][0] - out[0][0]) <= 1e-11 * np.linalg.norm(out[0][0])
+    # deterministic reductions: two fused runs agree bit for bit
+    c.set_option("mg_fuse", 1)
+    c.set_option("deterministic", 1)
+    a = c.sim_solve(rtol=1e-10)
+    b = c.sim_solve(rtol=1e-10)
+    assert np.array_equal(a, b)
+    assert np.linalg.norm(a - out[0][0]) <= 1e-11 * np.linalg.norm(out[0][0])
+    c.set_option("deterministic", 0)
+    # several right-hand sides (the batched V-cycle takes the same switch)
+    rng = np.random.default_rng(3)
+    nrhs = 6 if dim == 3 else 3
+    F = rng.standard_normal((nrhs, c.n_dof * dim))
+    res = {}
+    for fuse in (1, 0):
+        c.set_option("mg_fuse", fuse)
+        U, infos = c.solve_batch(F, rtol=1e-10)
+        res[fuse] = (U, [i["iterations"] for i in infos])
+    assert res[1][1] == res[0][1]
+    assert np.linalg.norm(res[1][0] - res[0][0]) <= 1e-10 * np.linalg.norm(res[0][0])
+    c.close()
