@@ -1483,30 +1483,38 @@ __global__ void __launch_bounds__(256) k_mg_cheb_rz(int64_t nRows, const double 
 #endif
 // NR right-hand sides: the FINE vectors are separate (vector k at r + k fineStride: the quadratic level runs one PCG loop per right-hand side),
 // the COARSE ones interleaved (entry ((row NR + k) DIM + c): the linear level and everything below it serve all NR at once)
-template <int DIM, int NR = 1>
-__global__ void __launch_bounds__(256) k_mg_restrict(int64_t nCoarse, const int32_t *__restrict__ fineOf, const int32_t *__restrict__ resPtr,
-                                                     const int32_t *__restrict__ resIdx, const double *__restrict__ r,
-                                                     const double *__restrict__ t, int64_t fineStride, const uint8_t *__restrict__ coarseMask,
-                                                     double *__restrict__ rc, MgGate g) {
-    if (mg_closed(g)) return;
+// (HAST: t != null, decided once per launch -- a test per component inside the gather loop kept the loads of an entry from being issued together.
+// One right-hand side: TWO entries per lane and trip -- their index loads, then all their value loads, are in flight together.)
+template <int DIM, int NR, bool HAST>
+DEV void mg_restrict_body(int64_t nCoarse, const int32_t *__restrict__ fineOf, const int32_t *__restrict__ resPtr, const int32_t *__restrict__ resIdx,
+                          const double *__restrict__ r, const double *__restrict__ t, int64_t fineStride, const uint8_t *__restrict__ coarseMask,
+                          double *__restrict__ rc) {
     constexpr int W = NR * DIM;
-    const int sub = threadIdx.x & (MG_RESTRICT_LANES - 1);
+    constexpr int L = MG_RESTRICT_LANES;
+    const int sub = threadIdx.x & (L - 1);
     const int64_t nq = (nCoarse + 63) / 64 * 64;                 // whole waves take part in the shuffles
-    for (int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) / MG_RESTRICT_LANES; q < nq; q += ((int64_t)gridDim.x * 256) / MG_RESTRICT_LANES) {
+    for (int64_t q = ((int64_t)blockIdx.x * 256 + threadIdx.x) / L; q < nq; q += ((int64_t)gridDim.x * 256) / L) {
         double acc[W];
 #pragma unroll
         for (int c = 0; c < W; ++c) acc[c] = 0.0;
         if (q < nCoarse) {
             const int k0 = resPtr[q], k1 = resPtr[q + 1];
-            for (int k = k0 + sub; k < k1; k += MG_RESTRICT_LANES) {
-                const int64_t e = resIdx[k];
+            constexpr int U = NR == 1 ? 2 : 1;      // (two entries of NR = 6 vectors are 154 VGPRs: 900 against 670 us at configs[3])
+            for (int k = k0 + sub; k < k1; k += U * L) {
+                const bool two = U == 2 && k + L < k1;
+                const int64_t e0 = resIdx[k], e1 = two ? resIdx[k + L] : e0;
+                double v0[W], v1[U == 2 ? W : 1];
 #pragma unroll
                 for (int v = 0; v < NR; ++v)
 #pragma unroll
                     for (int c = 0; c < DIM; ++c) {
-                        const int64_t i = v * fineStride + e * DIM + c;
-                        acc[v * DIM + c] += 0.5 * (r[i] - (t ? t[i] : 0.0));
+                        const int64_t i0 = v * fineStride + e0 * DIM + c, i1 = v * fineStride + e1 * DIM + c;
+                        v0[v * DIM + c] = HAST ? r[i0] - t[i0] : r[i0];
+                        if (U == 2) v1[v * DIM + c] = HAST ? r[i1] - t[i1] : r[i1];
                     }
+                const double w1 = two ? 0.5 : 0.0;
+#pragma unroll
+                for (int c = 0; c < W; ++c) acc[c] += U == 2 ? 0.5 * v0[c] + w1 * v1[c] : 0.5 * v0[c];
             }
             if (sub == 0) {
                 const int64_t f = fineOf[q];
@@ -1515,19 +1523,28 @@ __global__ void __launch_bounds__(256) k_mg_restrict(int64_t nCoarse, const int3
 #pragma unroll
                     for (int c = 0; c < DIM; ++c) {
                         const int64_t i = v * fineStride + f * DIM + c;
-                        acc[v * DIM + c] += r[i] - (t ? t[i] : 0.0);
+                        acc[v * DIM + c] += HAST ? r[i] - t[i] : r[i];
                     }
             }
         }
 #pragma unroll
         for (int c = 0; c < W; ++c) {
 #pragma unroll
-            for (int m = 1; m < MG_RESTRICT_LANES; m <<= 1) acc[c] += __shfl_xor(acc[c], m, 64);
+            for (int m = 1; m < L; m <<= 1) acc[c] += __shfl_xor(acc[c], m, 64);
         }
         if (q < nCoarse && sub == 0)
 #pragma unroll
             for (int c = 0; c < W; ++c) rc[q * W + c] = (coarseMask && coarseMask[q * DIM + c % DIM]) ? 0.0 : acc[c];
     }
+}
+template <int DIM, int NR = 1>
+__global__ void __launch_bounds__(256) k_mg_restrict(int64_t nCoarse, const int32_t *__restrict__ fineOf, const int32_t *__restrict__ resPtr,
+                                                     const int32_t *__restrict__ resIdx, const double *__restrict__ r,
+                                                     const double *__restrict__ t, int64_t fineStride, const uint8_t *__restrict__ coarseMask,
+                                                     double *__restrict__ rc, MgGate g) {
+    if (mg_closed(g)) return;
+    if (t) mg_restrict_body<DIM, NR, true>(nCoarse, fineOf, resPtr, resIdx, r, t, fineStride, coarseMask, rc);
+    else mg_restrict_body<DIM, NR, false>(nCoarse, fineOf, resPtr, resIdx, r, t, fineStride, coarseMask, rc);
 }
 
 // x += P xc on the free fine variables
@@ -1540,11 +1557,15 @@ __global__ void __launch_bounds__(256) k_mg_prolong_add(int64_t nFine, const int
     for (int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x; n < nFine; n += (int64_t)gridDim.x * 256) {
         const int64_t a = parA[n], b = parB[n];
         if (a < 0) continue;
+        double xa[DIM], xb[DIM], xv[DIM];       // all loads first, unconditionally (a test per component kept them apart); the mask gates the stores
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            if (fineMask && fineMask[n * DIM + c]) continue;
-            x[n * DIM + c] += 0.5 * (xc[a * ldc + c] + xc[b * ldc + c]);
-        }
+        for (int c = 0; c < DIM; ++c) { xa[c] = xc[a * ldc + c]; xb[c] = xc[b * ldc + c]; xv[c] = x[n * DIM + c]; }
+        uint8_t fx[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) fx[c] = fineMask ? fineMask[n * DIM + c] : (uint8_t)0;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c)
+            if (!fx[c]) x[n * DIM + c] = xv[c] + 0.5 * (xa[c] + xb[c]);
     }
 }
 
@@ -1572,11 +1593,15 @@ __global__ void __launch_bounds__(256) k_mg_prolong_add_nr(int64_t nFine, const 
         if (!sOpen[k]) continue;
         const int64_t a = parA[n], b = parB[n];
         if (a < 0) continue;
+        double xa[DIM], xb[DIM], xv[DIM];
 #pragma unroll
-        for (int c = 0; c < DIM; ++c) {
-            if (fineMask && fineMask[n * DIM + c]) continue;
-            x[k * vecStride + n * DIM + c] += 0.5 * (xc[(a * NR + k) * DIM + c] + xc[(b * NR + k) * DIM + c]);
-        }
+        for (int c = 0; c < DIM; ++c) { xa[c] = xc[(a * NR + k) * DIM + c]; xb[c] = xc[(b * NR + k) * DIM + c]; xv[c] = x[k * vecStride + n * DIM + c]; }
+        uint8_t fx[DIM];
+#pragma unroll
+        for (int c = 0; c < DIM; ++c) fx[c] = fineMask ? fineMask[n * DIM + c] : (uint8_t)0;
+#pragma unroll
+        for (int c = 0; c < DIM; ++c)
+            if (!fx[c]) x[k * vecStride + n * DIM + c] = xv[c] + 0.5 * (xa[c] + xb[c]);
     }
 }
 

@@ -1051,7 +1051,7 @@ void mg_precond_batch(mfh_ctx *c, int NR, const double *r, double *z, int64_t ve
         if (fuse && fuse->presmoothed) { L0.apply(z + o, G.t0.p + o); ra = r + o; rb = G.t0.p + o; }
         else chebyshev(L0, r + o, z + o, true, true, G.r0.p + o, G.d0.p + o, G.t0.p + o, &ra, &rb);
         if (k2 == 0) { ra0 = ra; rb0 = rb; }
-        else if (ra != ra0 + o || rb != rb0 + o) throw Error(MFH_ERR_STATE, "batched V-cycle: residual vectors are not equally spaced");
+        else if (ra != ra0 + o || rb != (rb0 ? rb0 + o : nullptr)) throw Error(MFH_ERR_STATE, "batched V-cycle: residual vectors are not equally spaced");
     }
     {
         k::GateScope all(scal ? NR : 0, scalStride);      // from here to the prolongation: closed once every loop has converged
