@@ -1783,8 +1783,17 @@ __global__ void __launch_bounds__(MF_BLOCK) k_mf_cluster(SpmvMfArgs a, const dou
                     clacc[LIDX(t, d)] = ((clacc[LIDX(t, d)] + clacc[accStride + LIDX(t, d)]) + clacc[2 * accStride + LIDX(t, d)]) + clacc[3 * accStride + LIDX(t, d)];
             }
             if (dest >= 0) {
+                // an interface row: the partial goes to the second pass. Inside a PCG loop its share of p . (K p) is taken HERE, where p is staged
+                // (the inner product is linear in the partials), so that k_mf_rows needs no scattered read of p: 96 -> 59 us per iteration at
+                // configs[2]. No look at the fixed-variable mask (a row index and three mask bytes fetched here cost the kernel 60 us: loads in
+                // the write-out lengthen every block's critical path): a PCG's direction is zero on the fixed variables, so they add nothing.
+                // Plain applications (any x) leave the interface rows' share to k_mf_rows, which has the mask.
 #pragma unroll
-                for (int d = 0; d < DIM; ++d) a.clIfaceBuf[(int64_t)dest * DIM + d] = clacc[LIDX(t, d)];
+                for (int d = 0; d < DIM; ++d) {
+                    const double v = clacc[LIDX(t, d)];
+                    a.clIfaceBuf[(int64_t)dest * DIM + d] = v;
+                    if (PCG != 0) dot += v * xs[LIDX(t, d)];
+                }
                 continue;
             }
             const int64_t row = a.clEntryRow[u0 + t];
@@ -1880,11 +1889,11 @@ __global__ void __launch_bounds__(256) k_mf_rows(SpmvMfArgs a, const double *__r
             double v = mfacc[idx];
             if (a.fixedMask && a.fixedMask[gi]) v = 0.0;
             y[gi] = v;
-            if (dotOut) dot += v * x[gi];
+            if (dotOut && !(PCG != 0 && a.rowMap)) dot += v * x[gi];          // (cluster variant inside a PCG loop: k_mf_cluster has taken the interface rows' share from its staged p)
         }
         __syncthreads();
     }
-    if (dotOut) {
+    if (dotOut && !(PCG != 0 && a.rowMap)) {
         double v[1] = {dot};
         block_sum<1>(v, red);
         double *const tg[1] = {dotOut};
