@@ -526,6 +526,8 @@ mfh_status mfh_get_timing(const mfh_ctx* ctx, mfh_timing* out);
  * "mg_fuse" (1 default: with one Chebyshev step on the quadratic level of an unpartitioned hierarchy, the PCG loop's residual update also writes
  *   the V-cycle's pre-smoothed start and the cycle's last smoothing step also forms r.z -- two kernels and three vector passes less per
  *   iteration, the same iterates; 0: separate kernels),
+ * "mg_dinv_fp32" (1 default: those two fused kernels read an FP32 copy of the quadratic level's inverse diagonal blocks -- a third of their traffic;
+ *   the smoother only, both steps of a cycle the same copy; 0: the FP64 blocks),
  * "solve_homogeneous" (1: mfh_solve treats the fixed variables as fixed to ZERO whatever values were given -- the
  *   homogeneous solves K y = C^T of a Schur-complement elimination of constraint rows, SparseMatrices.hh:2572-2590),
  * "periodic_ignore_mismatch" (1: nodes of a periodic face without a partner keep their own DoF, PeriodicCondition's

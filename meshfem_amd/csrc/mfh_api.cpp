@@ -618,6 +618,20 @@ void ensure_precond(mfh_ctx *c) {
     k::launch_extract_diag_inv(d, c->sym.nRows, c->dRowPtr.p, c->dColIdx.p, c->dVals.p, c->dFixedMask.p,
                                (c->precond == MFH_PRECOND_TWO_LEVEL || c->precond == MFH_PRECOND_MULTIGRID) ? MFH_PRECOND_BLOCK_JACOBI : c->precond, c->dDinv.p, c->stream);
     c->dinvValid = true;
+    c->dinv32Valid = false;
+}
+
+// FP32 copy of the inverse diagonal blocks for the fused smoother kernels of the multigrid V-cycle (k_pcg_update's ZS flavour, k_mg_cheb_rz): the
+// blocks are a third of those kernels' traffic, and a smoother does not need their last 29 bits -- both smoothing steps of a cycle read the SAME
+// copy, so the preconditioner stays symmetric. The block-Jacobi preconditioner itself and every other kernel keep the FP64 blocks.
+const float *smoother_dinv32(mfh_ctx *c) {
+    if (!c->mgDinvFp32 || !c->dinvValid) return nullptr;
+    if (!c->dinv32Valid || c->dDinv32.n != c->dDinv.n) {
+        c->dDinv32.alloc(c->dDinv.n);
+        k::launch_to_f32((int64_t)c->dDinv.n, c->dDinv.p, c->dDinv32.p, c->stream);
+        c->dinv32Valid = true;
+    }
+    return c->dDinv32.p;
 }
 
 k::TLArgs tl_args(mfh_ctx *c) {
@@ -918,6 +932,7 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
         const k::SpmvMfArgs mfa = useCluster ? spmv_mf_cluster_args(c, !c->fixedVars.empty())
                                              : (useMF ? spmv_mf_args(c, !c->fixedVars.empty()) : k::SpmvMfArgs{});
         const double mgZs = useMG && c->mgFuse ? mg_fuse_scale(c) : 0.0;
+        const float *dinv32 = mgZs > 0 ? smoother_dinv32(c) : nullptr;
         std::vector<double> hs;
         int it = 0;
         bool done = false;
@@ -930,7 +945,7 @@ void solve_one_classic(mfh_ctx *c, const double *f, double *u, double rtol, int 
             if (useMG && mgZs > 0) {
                 // the V-cycle's first and last vector kernels folded into the loop's own (MgFuse): r -= alpha Ap and z = Dinv r / theta in one
                 // pass, the last smoothing step and r.z in another -- three vector passes of 24.6 less per iteration
-                k::launch_pcg_update_presmooth(d, c->sym.nRows, c->dDinv.p, c->wAp.p, c->wr.p, c->wz.p, mgZs, c->scal.p, itLocal, c->stop.p, s);
+                k::launch_pcg_update_presmooth(d, c->sym.nRows, c->dDinv.p, dinv32, c->wAp.p, c->wr.p, c->wz.p, mgZs, c->scal.p, itLocal, c->stop.p, s);
                 const MgFuse fz{true, c->scal.p, maskPtr};
                 mg_precond(c, c->wr.p, c->wz.p, c->scal.p, itLocal, c->stop.p, &fz);
             } else if (useMG) {
@@ -1115,10 +1130,11 @@ void solve_multigrid_batch(mfh_ctx *c, int NR, const double *f, double *u, int64
         }
         const k::SpmvMfArgs mfa = spmv_mf_cluster_args(c, masked);
         const double mgZs = c->mgFuse ? mg_fuse_scale(c) : 0.0;
+        const float *dinv32 = mgZs > 0 ? smoother_dinv32(c) : nullptr;
         auto enqueue = [&](int itLocal) {   // one iteration of every loop; `itLocal` is relative to the iteration bases stop[4 k + 3]
             for (int k2 = 0; k2 < NR; ++k2) {
                 k::launch_spmv_mf_cluster(mfa, vec(c->wp, k2), vec(c->wAp, k2), nullptr, sck(k2), itLocal, stk(k2), true, s);
-                if (mgZs > 0) k::launch_pcg_update_presmooth(d, c->sym.nRows, c->dDinv.p, vec(c->wAp, k2), vec(c->wr, k2), vec(c->wz, k2), mgZs, sck(k2), itLocal, stk(k2), s);
+                if (mgZs > 0) k::launch_pcg_update_presmooth(d, c->sym.nRows, c->dDinv.p, dinv32, vec(c->wAp, k2), vec(c->wr, k2), vec(c->wz, k2), mgZs, sck(k2), itLocal, stk(k2), s);
                 else k::launch_pcg_update_noz(d, c->sym.nRows, vec(c->wAp, k2), vec(c->wr, k2), sck(k2), itLocal, stk(k2), s);
             }
             const MgFuse fz{mgZs > 0, mgZs > 0 ? c->scal.p : nullptr, maskPtr};      // (see solve_one_classic)
@@ -2536,6 +2552,7 @@ mfh_status mfh_set_option(mfh_ctx *c, const char *key, double value) {
     else if (k2 == "pcg_variant") c->pcgVariant = value < 0 ? -1 : (value != 0 ? 1 : 0);
     else if (k2 == "mg_batch") c->mgBatch = value != 0;
     else if (k2 == "mg_fuse") c->mgFuse = value != 0;
+    else if (k2 == "mg_dinv_fp32") c->mgDinvFp32 = value != 0;
     else if (k2 == "auto_stretch_max") { c->autoStretchMax = value > 1.0 ? value : 1.0; c->autoStretch = -1.0; }
     else if (k2 == "batch_rhs") { if (c->batchRhs != (value != 0)) { c->mfcValid = false; c->mfClusterUnfit = false; } c->batchRhs = value != 0; }
     else if (k2 == "matrix_free_mode") { c->mfMode = (int)value; c->mfClusterUnfit = false; }

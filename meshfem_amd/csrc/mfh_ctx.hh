@@ -156,6 +156,8 @@ struct mfh_ctx {
     double autoStretch = -1.0, autoStretchMax = 8.0;
     DBuf<double> dDinv;
     bool dinvValid = false;
+    DBuf<float> dDinv32;              // FP32 copy of dDinv for the multigrid smoother's fused kernels (smoother_dinv32)
+    bool dinv32Valid = false;
     DBuf<double> wx, wr, wz, wp, wAp, wb, wf, wu0, scal, stop;
     // two-level preconditioner (MFH_PRECOND_TWO_LEVEL)
     struct TwoLevel {
@@ -240,6 +242,7 @@ struct mfh_ctx {
                                       // vector pass fewer), Chronopoulos-Gear for batches and row-partitioned contexts
     int distPcgVariant = 1;           // option "dist_pcg_variant": 1 = Chronopoulos-Gear (one all-reduce per iteration, default), 0 = classic
                                       // (two all-reduces, one vector pass less per iteration)
+    bool mgDinvFp32 = true;           // option "mg_dinv_fp32": the fused kernels of mg_fuse read an FP32 copy of the quadratic level's inverse diagonal blocks (smoother only)
     bool mgFuse = true;               // option "mg_fuse": the PCG loop's residual update / r.z share kernels with the V-cycle's first / last smoothing step (MgFuse)
     bool mgBatch = true;              // option "mg_batch": several right-hand sides under the multigrid preconditioner share the linear and aggregate levels of
                                       // every V-cycle (solve_multigrid_batch); 0: one right-hand side at a time
@@ -430,6 +433,7 @@ void destroy_multigrid(mfh_ctx *c);
 //   rzScal:      the cycle's last kernel also forms r.z into the iteration's history (k_mg_cheb_rz; rzMask: the fixed-variable mask, may be null)
 //                -- the loop launches no k_mg_rz. Loop k of a batch: history rzScal + k scalStride.
 struct MgFuse { bool presmoothed = false; double *rzScal = nullptr; const uint8_t *rzMask = nullptr; };
+const float *smoother_dinv32(mfh_ctx *c);     // the FP32 copy of the inverse diagonal blocks (made on first use after every change of dDinv), or null with option mg_dinv_fp32 0
 double mg_fuse_scale(const mfh_ctx *c);       // zs = 1 / theta of the first level's smoother when the fusion applies (unpartitioned quadratic hierarchy, one step), else 0
 void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int it, const double *stop, const MgFuse *fuse = nullptr);
 void mg_precond_batch(mfh_ctx *c, int NR, const double *r, double *z, int64_t vecStride, const double *scal, int64_t scalStride, int it, const double *stop,

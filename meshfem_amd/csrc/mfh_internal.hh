@@ -636,9 +636,9 @@ void launch_to_f32(int64_t n, const double *src, float *dst, hipStream_t s);
 void launch_take_columns_i32(int64_t n, int W, int w, const int32_t *src, int32_t *dst, hipStream_t s);
 void launch_mg_diff(int64_t n, const double *a, const double *b, double *out, const double *scal, int it, const double *stop, hipStream_t s);
 void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, double *scalOut, int it, const double *scal, const double *stop, hipStream_t s);
-void launch_mg_cheb_rz(int dim, int64_t nRows, const double *dinv, const double *rin, const double *t, double *x, double b, const uint8_t *mask,
+void launch_mg_cheb_rz(int dim, int64_t nRows, const double *dinv, const float *dinv32, const double *rin, const double *t, double *x, double b, const uint8_t *mask,
                        double *scalOut, int it, const double *scal, const double *stop, hipStream_t s);
-void launch_pcg_update_presmooth(int dim, int64_t nRows, const double *dinv, const double *Ap, double *r, double *z, double zs, double *scal, int it,
+void launch_pcg_update_presmooth(int dim, int64_t nRows, const double *dinv, const float *dinv32, const double *Ap, double *r, double *z, double zs, double *scal, int it,
                                  const double *stopPtr, hipStream_t s);
 void launch_add_scalar(double *p, double v, hipStream_t s);   // *p += v
 void launch_pack_rows(int64_t n, int W, const int32_t *idx, const double *src, double *dst, hipStream_t s);

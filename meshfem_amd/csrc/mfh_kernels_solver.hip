@@ -85,6 +85,32 @@ template <int DIM> DEV void apply_block(const double *__restrict__ Dm, const dou
     }
 }
 
+// the packed inverse diagonal blocks of TWO consecutive rows (2 NS values, contiguous) in the widest aligned accesses; the FP32 copy (the multigrid
+// smoother's fused kernels, option mg_dinv_fp32) is widened on the way in
+template <int NS> DEV void load_dinv_pair(const double *__restrict__ p, double (&dm)[2 * NS]) {
+    const double2 *d2 = reinterpret_cast<const double2 *>(p);
+#pragma unroll
+    for (int c = 0; c < NS; ++c) { const double2 t = d2[c]; dm[2 * c] = t.x; dm[2 * c + 1] = t.y; }
+}
+template <int NS> DEV void load_dinv_pair(const float *__restrict__ p, double (&dm)[2 * NS]) {
+    if (NS % 2 == 0) {          // 2 NS floats = NS / 2 sixteen-byte pieces (3D: 48 bytes per row pair)
+        const float4 *d4 = reinterpret_cast<const float4 *>(p);
+#pragma unroll
+        for (int c = 0; c < NS / 2; ++c) { const float4 t = d4[c]; dm[4 * c] = t.x; dm[4 * c + 1] = t.y; dm[4 * c + 2] = t.z; dm[4 * c + 3] = t.w; }
+    } else {
+        const float2 *d2 = reinterpret_cast<const float2 *>(p);
+#pragma unroll
+        for (int c = 0; c < NS; ++c) { const float2 t = d2[c]; dm[2 * c] = t.x; dm[2 * c + 1] = t.y; }
+    }
+}
+template <int DIM, class DT> DEV void apply_block_t(const DT *__restrict__ Dm, const double *r, double *z) {
+    constexpr int NS = DIM * (DIM + 1) / 2;
+    double m[NS];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) m[q] = (double)Dm[q];
+    apply_block<DIM>(m, r, z);
+}
+
 template <int DIM>
 __global__ void __launch_bounds__(256) k_precond(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ r,
                                                  double *__restrict__ z) {
@@ -787,8 +813,8 @@ __global__ void __launch_bounds__(256) k_pcg_init(int64_t nRows, const double *_
 // vector read less per iteration than updating x here)
 // ZS (the multigrid preconditioner's pre-smoothing from zero folded in, mg_precond's MgFuse): z = zs Dinv r, and r.z is NOT accumulated (the
 // preconditioner is not finished: the V-cycle's last kernel forms it, k_mg_cheb_rz)
-template <int DIM, bool SKIPZ = false, bool ZS = false>
-__global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double *__restrict__ dinv,
+template <int DIM, bool SKIPZ = false, bool ZS = false, class DT = double>
+__global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const DT *__restrict__ dinv,
                                                     const double *__restrict__ Ap, double *__restrict__ r,
                                                     double *__restrict__ z, double *scal, int it, const double *stopPtr, DetBuf det, double zs = 1.0) {
     __shared__ double red[16];
@@ -814,9 +840,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
 #pragma unroll
         for (int c = 0; c < DIM; ++c) r2[c] = make_double2(rv[2 * c], rv[2 * c + 1]);
         if (!SKIPZ) {
-            const double2 *d2 = reinterpret_cast<const double2 *>(dinv + q * 2 * NS);
-#pragma unroll
-            for (int c = 0; c < NS; ++c) { const double2 t = d2[c]; dm[2 * c] = t.x; dm[2 * c + 1] = t.y; }
+            load_dinv_pair<NS>(dinv + q * 2 * NS, dm);
             apply_block<DIM>(dm, rv, zv);
             apply_block<DIM>(dm + NS, rv + DIM, zv + DIM);
             double2 *z2 = reinterpret_cast<double2 *>(z + q * 2 * DIM);
@@ -842,7 +866,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const double 
             r[g] = rv[c];
         }
         if (!SKIPZ) {
-            apply_block<DIM>(dinv + n * NS, rv, zv);
+            apply_block_t<DIM, DT>(dinv + n * NS, rv, zv);
 #pragma unroll
             for (int c = 0; c < DIM; ++c) {
                 if (ZS) z[n * DIM + c] = zs * zv[c];
@@ -1421,8 +1445,8 @@ __global__ void __launch_bounds__(256) k_mg_cheb(int64_t nRows, const double *__
 //   x += b D^-1 (rin - t) ;  x = rin on the fixed variables (k_mg_rz's rule) ;  scal[(it + 1) 4] += rin . x
 // rin IS the PCG residual here (a one-step sweep smooths the right-hand side itself), so k_mg_rz's two vector reads disappear. A lane takes two
 // consecutive rows in 16-byte accesses like k_pcg_update.
-template <int DIM>
-__global__ void __launch_bounds__(256) k_mg_cheb_rz(int64_t nRows, const double *__restrict__ dinv, const double *__restrict__ rin,
+template <int DIM, class DT = double>
+__global__ void __launch_bounds__(256) k_mg_cheb_rz(int64_t nRows, const DT *__restrict__ dinv, const double *__restrict__ rin,
                                                     const double *__restrict__ t, double *__restrict__ x, double b,
                                                     const uint8_t *__restrict__ mask, double *scalOut, MgGate g, DetBuf det) {
     __shared__ double red[8];
@@ -1436,14 +1460,12 @@ __global__ void __launch_bounds__(256) k_mg_cheb_rz(int64_t nRows, const double 
         const double2 *r2 = reinterpret_cast<const double2 *>(rin + q * 2 * DIM);
         const double2 *t2 = reinterpret_cast<const double2 *>(t + q * 2 * DIM);
         double2 *x2 = reinterpret_cast<double2 *>(x + q * 2 * DIM);
-        const double2 *d2 = reinterpret_cast<const double2 *>(dinv + q * 2 * NS);
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
             const double2 a = r2[c], u = t2[c], w = x2[c];
             rv[2 * c] = a.x; rv[2 * c + 1] = a.y; tv[2 * c] = a.x - u.x; tv[2 * c + 1] = a.y - u.y; xv[2 * c] = w.x; xv[2 * c + 1] = w.y;
         }
-#pragma unroll
-        for (int c = 0; c < NS; ++c) { const double2 a = d2[c]; dm[2 * c] = a.x; dm[2 * c + 1] = a.y; }
+        load_dinv_pair<NS>(dinv + q * 2 * NS, dm);
         apply_block<DIM>(dm, tv, zv);
         apply_block<DIM>(dm + NS, tv + DIM, zv + DIM);
 #pragma unroll
@@ -1460,7 +1482,7 @@ __global__ void __launch_bounds__(256) k_mg_cheb_rz(int64_t nRows, const double 
         double rv[DIM], tv[DIM], zv[DIM];
 #pragma unroll
         for (int c = 0; c < DIM; ++c) { rv[c] = rin[n * DIM + c]; tv[c] = rv[c] - t[n * DIM + c]; }
-        apply_block<DIM>(dinv + n * NS, tv, zv);
+        apply_block_t<DIM, DT>(dinv + n * NS, tv, zv);
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
             double xv = x[n * DIM + c] + b * zv[c];
@@ -2007,9 +2029,14 @@ void launch_pcg_update_noz(int dim, int64_t nRows, const double *Ap, double *r, 
 }
 
 // r -= alpha Ap, z = zs Dinv r, r.r (no r.z): the PCG update with the V-cycle's pre-smoothing from zero folded in
-void launch_pcg_update_presmooth(int dim, int64_t nRows, const double *dinv, const double *Ap, double *r, double *z, double zs, double *scal, int it,
+void launch_pcg_update_presmooth(int dim, int64_t nRows, const double *dinv, const float *dinv32, const double *Ap, double *r, double *z, double zs, double *scal, int it,
                                  const double *stopPtr, hipStream_t s) {
     const int grid = grid_for(nRows / 2);
+    if (dinv32) {           // the smoother's FP32 copy of the inverse diagonal blocks: 5 vector passes instead of 6
+        if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false, true, float>), dim3(grid), dim3(256), 0, s, nRows, dinv32, Ap, r, z, scal, it, stopPtr, t_det, zs);
+        else if (dim == 2) hipLaunchKernelGGL((k_pcg_update<2, false, true, float>), dim3(grid), dim3(256), 0, s, nRows, dinv32, Ap, r, z, scal, it, stopPtr, t_det, zs);
+        else hipLaunchKernelGGL((k_pcg_update<1, false, true, float>), dim3(grid), dim3(256), 0, s, nRows, dinv32, Ap, r, z, scal, it, stopPtr, t_det, zs);
+    } else
     if (dim == 3) hipLaunchKernelGGL((k_pcg_update<3, false, true>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr, t_det, zs);
     else if (dim == 2) hipLaunchKernelGGL((k_pcg_update<2, false, true>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr, t_det, zs);
     else hipLaunchKernelGGL((k_pcg_update<1, false, true>), dim3(grid), dim3(256), 0, s, nRows, dinv, Ap, r, z, scal, it, stopPtr, t_det, zs);
@@ -2364,9 +2391,14 @@ void launch_mg_rz(int64_t n, const double *r, double *z, const uint8_t *mask, do
     CHECK_LAUNCH();
 }
 // the V-cycle's last smoothing step and the PCG's r.z in one kernel (k_mg_cheb_rz)
-void launch_mg_cheb_rz(int dim, int64_t nRows, const double *dinv, const double *rin, const double *t, double *x, double b, const uint8_t *mask,
+void launch_mg_cheb_rz(int dim, int64_t nRows, const double *dinv, const float *dinv32, const double *rin, const double *t, double *x, double b, const uint8_t *mask,
                        double *scalOut, int it, const double *scal, const double *stop, hipStream_t s) {
     const int grid = grid_for(nRows / 2);
+    if (dinv32) {
+        if (dim == 3) hipLaunchKernelGGL((k_mg_cheb_rz<3, float>), dim3(grid), dim3(256), 0, s, nRows, dinv32, rin, t, x, b, mask, scalOut, mk_gate(scal, it, stop), t_det);
+        else if (dim == 2) hipLaunchKernelGGL((k_mg_cheb_rz<2, float>), dim3(grid), dim3(256), 0, s, nRows, dinv32, rin, t, x, b, mask, scalOut, mk_gate(scal, it, stop), t_det);
+        else hipLaunchKernelGGL((k_mg_cheb_rz<1, float>), dim3(grid), dim3(256), 0, s, nRows, dinv32, rin, t, x, b, mask, scalOut, mk_gate(scal, it, stop), t_det);
+    } else
     if (dim == 3) hipLaunchKernelGGL(k_mg_cheb_rz<3>, dim3(grid), dim3(256), 0, s, nRows, dinv, rin, t, x, b, mask, scalOut, mk_gate(scal, it, stop), t_det);
     else if (dim == 2) hipLaunchKernelGGL(k_mg_cheb_rz<2>, dim3(grid), dim3(256), 0, s, nRows, dinv, rin, t, x, b, mask, scalOut, mk_gate(scal, it, stop), t_det);
     else hipLaunchKernelGGL(k_mg_cheb_rz<1>, dim3(grid), dim3(256), 0, s, nRows, dinv, rin, t, x, b, mask, scalOut, mk_gate(scal, it, stop), t_det);

@@ -1020,7 +1020,7 @@ void mg_precond(mfh_ctx *c, const double *r, double *z, const double *scal, int 
     k::launch_mg_prolong_add(d, G.nFine, G.parA.p, G.parB.p, G.x1.p, masked0 ? c->dFixedMask.p : nullptr, z, scal, it, stop, s);
     if (fuse && fuse->rzScal) {                // the one post-smoothing step and the PCG's r.z in one kernel
         L0.apply(z, G.t0.p);
-        k::launch_mg_cheb_rz(d, c->sym.nRows, c->dDinv.p, r, G.t0.p, z, mg_fuse_scale(c), fuse->rzMask, fuse->rzScal, it, scal, stop, s);
+        k::launch_mg_cheb_rz(d, c->sym.nRows, c->dDinv.p, smoother_dinv32(c), r, G.t0.p, z, mg_fuse_scale(c), fuse->rzMask, fuse->rzScal, it, scal, stop, s);
     } else
         chebyshev(L0, r, z, false, false, G.r0.p, G.d0.p, G.t0.p);
 }
@@ -1068,7 +1068,7 @@ void mg_precond_batch(mfh_ctx *c, int NR, const double *r, double *z, int64_t ve
         const size_t o = (size_t)k2 * vecStride;
         if (fuse && fuse->rzScal) {
             L0.apply(z + o, G.t0.p + o);
-            k::launch_mg_cheb_rz(d, c->sym.nRows, c->dDinv.p, r + o, G.t0.p + o, z + o, mg_fuse_scale(c), fuse->rzMask, fuse->rzScal + (size_t)k2 * scalStride, it, sc, st, s);
+            k::launch_mg_cheb_rz(d, c->sym.nRows, c->dDinv.p, smoother_dinv32(c), r + o, G.t0.p + o, z + o, mg_fuse_scale(c), fuse->rzMask, fuse->rzScal + (size_t)k2 * scalStride, it, sc, st, s);
         } else
             chebyshev(L0, r + o, z + o, false, false, G.r0.p + o, G.d0.p + o, G.t0.p + o);
     }

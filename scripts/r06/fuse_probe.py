@@ -18,11 +18,13 @@ c.assemble()
 c.set_preconditioner(M.PRECOND_MULTIGRID)
 u = c.sim_solve(rtol=1e-8, maxit=800)
 for rep in range(3):
-    for fuse in (1, 0):
+    for fuse, f32 in ((1, 1), (1, 0), (0, 0)):
         c.set_option("mg_fuse", fuse)
+        c.set_option("mg_dinv_fp32", f32)
         u = c.sim_solve(rtol=1e-8, maxit=800)
         i = c.last_info
-        print("configs[2] shape  mg_fuse %d: %d iterations, solve %.2f ms (%.3f ms / iteration), true residual %.2e, max|u| %.12g"
+        print("configs[2] shape  mg_dinv_fp32 %d" % f32, end="  ")
+        print("mg_fuse %d: %d iterations, solve %.2f ms (%.3f ms / iteration), true residual %.2e, max|u| %.12g"
               % (fuse, i["iterations"], i["solve_ms"], i["solve_ms"] / max(1, i["iterations"]), i["true_rel_residual"], np.abs(u).max()), flush=True)
 c.close()
 

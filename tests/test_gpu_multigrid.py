@@ -360,6 +360,11 @@ def test_fused_pcg_kernels_walk_the_iterates_of_the_separate_ones(dim, n):
     rows per lane; the generator's 3D grids have odd node counts, so their single-row tail runs here too.)"""
     c, V, T = _cantilever(n, 2, dim)
     c.set_preconditioner(M.PRECOND_MULTIGRID)
+    # the default also reads an FP32 copy of the inverse diagonal blocks in the two fused kernels (option mg_dinv_fp32; the smoother only): another
+    # preconditioner in the 8th digit -- the same answer to the tolerance, iteration counts within one
+    u32 = c.sim_solve(rtol=1e-10)
+    it32, res32 = c.last_info["iterations"], c.last_info["true_rel_residual"]
+    c.set_option("mg_dinv_fp32", 0)
     out = {}
     for fuse in (1, 0):
         c.set_option("mg_fuse", fuse)
@@ -367,6 +372,8 @@ def test_fused_pcg_kernels_walk_the_iterates_of_the_separate_ones(dim, n):
         out[fuse] = (u, c.last_info["iterations"], c.last_info["true_rel_residual"])
     assert out[1][1] == out[0][1] and out[1][2] < 2e-10
     assert np.linalg.norm(out[1][0] - out[0][0]) <= 1e-11 * np.linalg.norm(out[0][0])
+    assert abs(it32 - out[0][1]) <= 1 and res32 < 2e-10
+    assert np.linalg.norm(u32 - out[0][0]) <= 1e-8 * np.linalg.norm(out[0][0])
     # deterministic reductions: two fused runs agree bit for bit
     c.set_option("mg_fuse", 1)
     c.set_option("deterministic", 1)
