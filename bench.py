@@ -957,8 +957,8 @@ def config2_trace_leg(args, n=60):
 
 def run_leg(args):
     if args.leg == "config2" and not os.environ.get("MFH_BENCH_NO_RESERVE"):
-        # as the line itself does, and in the same place: FIRST in the process, before torch touches the device (where the K values lie
-        # depends on it: 3.17-3.29 ms for the kernel with the reservation made after torch's start or not at all, 3.0-3.1 ms like this)
+        # as the line itself does, and in the same place: FIRST in the process, before torch touches the device (the order of events in the
+        # process is one of the inputs of the placement lottery, profiles/r06_config2_profile_spread.txt: the trace should draw as the line draws)
         import meshfem_amd as M
         reserve_for(M, 60, 2)
     import torch
