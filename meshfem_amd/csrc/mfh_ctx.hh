@@ -209,6 +209,7 @@ struct mfh_ctx {
         int64_t nFine = 0, nCoarse = 0;
         DBuf<int32_t> parA, parB, fineOf, resPtr, resIdx;
         DBuf<double> r0, d0, t0, b1, x1, r1, d1, t1;
+        int64_t strideAlloc = 0;                 // ... and the spacing the quadratic level's work vectors were sized for (reserve_batch)
         int nrAlloc = 1;                         // right-hand sides the work vectors of every level hold at once (batched V-cycle: they grow on demand)
         double lmax0 = 0, lmax1 = 0, setup_ms = 0;
         // aggregate hierarchy below the linear level (empty: the linear level uses its context's ~1000-aggregate dense coarse space)

@@ -649,6 +649,7 @@ void destroy_multigrid(mfh_ctx *c) {
     G.valid = false;
     G.linearOnly = false;
     G.nrAlloc = 1;
+    G.strideAlloc = 0;
     G.agg.clear();
     if (G.coarse) { mfh_destroy(G.coarse); G.coarse = nullptr; }
 }
@@ -964,15 +965,20 @@ static void linear_level(mfh_ctx *c, mfh_ctx *c1, const double *b, double *x, co
 }
 
 // Work vectors of the hierarchy for NR right-hand sides at once (unpartitioned quadratic hierarchies; the vectors only ever grow)
-static void reserve_batch(mfh_ctx *c, int NR) {
+// (vecStride: doubles between the quadratic level's vectors of consecutive right-hand sides -- the caller's, >= their length: the level-0 work vectors are
+// addressed with it, so they are SIZED with it; sized by the length alone they were up to 5 x 31 doubles short, which the 2 MiB granularity of large
+// buffers hid and a 263-row periodic cell did not)
+static void reserve_batch(mfh_ctx *c, int NR, int64_t vecStride) {
     auto &G = c->mg;
-    if (G.nrAlloc >= NR) return;
+    if (G.nrAlloc >= NR && G.strideAlloc >= vecStride) return;
     hipStream_t s = c->stream;
     MFH_HIP(hipStreamSynchronize(s));                  // (the buffers being replaced may be in use by work enqueued earlier)
     const int d = c->bs();
     const int NM = c->dim() == 3 ? 6 : 3;
     mfh_ctx *c1 = G.coarse;
-    const size_t n0 = (size_t)d * c->nDoF * NR, n1 = (size_t)d * c1->nDoF * NR;
+    NR = std::max(NR, G.nrAlloc);
+    vecStride = std::max<int64_t>(std::max<int64_t>(vecStride, G.strideAlloc), (int64_t)d * c->nDoF);
+    const size_t n0 = (size_t)vecStride * NR, n1 = (size_t)d * c1->nDoF * NR;
     G.r0.alloc(n0); G.d0.alloc(n0); G.t0.alloc(n0);
     G.b1.alloc(n1); G.x1.alloc(n1); G.r1.alloc(n1); G.d1.alloc(n1); G.t1.alloc(n1);
     for (auto &A : G.agg) {
@@ -980,6 +986,7 @@ static void reserve_batch(mfh_ctx *c, int NR) {
         A->x.alloc(n); A->b.alloc(n); A->r.alloc(n); A->d.alloc(n); A->t.alloc(n);
     }
     G.nrAlloc = NR;
+    G.strideAlloc = vecStride;
 }
 
 double mg_fuse_scale(const mfh_ctx *c) {
@@ -1034,7 +1041,7 @@ void mg_precond_batch(mfh_ctx *c, int NR, const double *r, double *z, int64_t ve
     auto &G = c->mg;
     if (G.distributed || G.linearOnly) throw Error(MFH_ERR_UNSUPPORTED, "batched V-cycle: unpartitioned quadratic hierarchies only");
     if (fuse && (fuse->presmoothed || fuse->rzScal) && !(mg_fuse_scale(c) > 0)) throw Error(MFH_ERR_STATE, "multigrid: fused PCG kernels need a one-step smoother");
-    reserve_batch(c, NR);
+    reserve_batch(c, NR, vecStride);
     mfh_ctx *c1 = G.coarse;
     hipStream_t s = c->stream;
     const int d = c->bs();
