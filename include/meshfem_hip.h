@@ -462,7 +462,9 @@ mfh_status  mfh_dev_memcpy(mfh_ctx* ctx, void* dst, const void* src, int64_t byt
  * hipFree); when the LAST context of a device closes the arena is trimmed to at most MFH_DEVICE_CACHE_IDLE_MB of free memory (default a
  * quarter of the device), so that other allocators of the process (torch, RCCL) find the rest. A request the driver cannot serve releases every free segment and is repeated. mfh_device_cache_trim returns every free segment to
  * the driver at once. mfh_device_arena_stats: out8 = {bytes held, live bytes, live high-water mark, segments, free chunks, bytes returned
- * to the driver so far, bytes waiting for a device-wide synchronisation, bound on the free bytes}. */
+ * to the driver so far, bytes waiting for a device-wide synchronisation, bound on the free bytes}.
+ * Debug aid: MFH_ARENA_GUARD=1 puts 512 pattern bytes behind every buffer and checks them when the buffer is released -- a kernel that wrote past
+ * the end of its buffer aborts the process with the buffer's size (synchronous fills and read-backs: for test runs; scripts/r06/run_guard.sh). */
 /* mfh_device_reserve: `bytes` taken from the driver now and kept as free space of the arena -- the reference's "reserve once"
  * (LinearElasticity.hh:1441-1443) for a caller that knows roughly what its mesh will need (mfh_context_bytes_estimate; mfh_device_reserve_for
  * does both). Contexts created afterwards cut their buffers from it: no call to the driver during their setup. With async != 0 the call returns

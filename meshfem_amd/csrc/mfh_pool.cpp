@@ -255,10 +255,30 @@ char *carve(Arena &A, int cls, std::set<std::pair<size_t, char *>>::iterator fit
 }
 }   // namespace
 
+// Debug aid (MFH_ARENA_GUARD=1): every request is followed by GUARD bytes of a pattern that device_free checks -- a kernel that writes past the end of
+// its buffer (the batch's work vectors of round 6 did, into slack they happened to own) is reported with the buffer's size instead of corrupting a
+// neighbour some day. Synchronous fills and read-backs: for test runs, not for timing.
+constexpr size_t GUARD = 512;
+bool guard_on() { static const bool g = getenv("MFH_ARENA_GUARD") != nullptr && atoi(getenv("MFH_ARENA_GUARD")) != 0; return g; }
+std::unordered_map<void *, size_t> g_guarded;           // pointer -> requested bytes (under g_mu)
+static void guard_check(void *p, size_t requested) {
+    unsigned char h[GUARD];
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(h, (char *)p + requested, GUARD, hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+    size_t first = GUARD, count = 0;
+    for (size_t i = 0; i < GUARD; ++i) if (h[i] != 0xA5) { if (first == GUARD) first = i; ++count; }
+    if (count) {
+        fprintf(stderr, "[arena guard] OVERRUN: %zu of the %zu guard bytes behind a buffer of %zu bytes at %p were written (first at +%zu)\n", count, GUARD, requested, p, first);
+        abort();
+    }
+}
+
 void *device_alloc(size_t bytes) {
     if (bytes == 0) return nullptr;
     int dev = 0;
     MFH_HIP(hipGetDevice(&dev));
+    const size_t requested = bytes;
+    if (guard_on()) bytes += GUARD;
     const int cls = bytes < SMALL_REQUEST ? 0 : ((t_tag == 1 && bytes >= VALUES_MIN) ? 2 : 1);
     if (cls == 1 && large_stagger()) { static std::atomic<unsigned> turn{0}; bytes += (size_t)(turn.fetch_add(1) % 8u) * large_stagger(); }
     bytes = cls == 0 ? (bytes + ALIGN - 1) & ~(ALIGN - 1) : (bytes + large_gran() - 1) / large_gran() * large_gran();
@@ -320,12 +340,28 @@ void *device_alloc(size_t bytes) {
     A.live += bytes;
     A.liveHigh = std::max(A.liveHigh, A.live);
     g_owner[p] = dev;
+    if (guard_on()) {
+        g_guarded[p] = requested;
+        lock.unlock();
+        (void)hipDeviceSynchronize();
+        MFH_HIP(hipMemset(p + requested, 0xA5, GUARD));
+    }
     return p;
 }
 
 void device_free(void *p) {
     if (!p) return;
     std::unique_lock<std::mutex> lock(g_mu);
+    if (guard_on()) {
+        auto gi = g_guarded.find(p);
+        if (gi != g_guarded.end()) {
+            const size_t requested = gi->second;
+            g_guarded.erase(gi);
+            lock.unlock();
+            guard_check(p, requested);
+            lock.lock();
+        }
+    }
     auto own = g_owner.find(p);
     if (own == g_owner.end()) {            // allocated with the arena disabled
         lock.unlock();
