@@ -103,7 +103,7 @@ template <int NS> DEV void load_dinv_pair(const float *__restrict__ p, double (&
         for (int c = 0; c < NS; ++c) { const float2 t = d2[c]; dm[2 * c] = t.x; dm[2 * c + 1] = t.y; }
     }
 }
-template <int DIM, class DT> DEV void apply_block_t(const DT *__restrict__ Dm, const double *r, double *z) {
+template <int DIM, class DinvT> DEV void apply_block_t(const DinvT *__restrict__ Dm, const double *r, double *z) {
     constexpr int NS = DIM * (DIM + 1) / 2;
     double m[NS];
 #pragma unroll
@@ -813,8 +813,8 @@ __global__ void __launch_bounds__(256) k_pcg_init(int64_t nRows, const double *_
 // vector read less per iteration than updating x here)
 // ZS (the multigrid preconditioner's pre-smoothing from zero folded in, mg_precond's MgFuse): z = zs Dinv r, and r.z is NOT accumulated (the
 // preconditioner is not finished: the V-cycle's last kernel forms it, k_mg_cheb_rz)
-template <int DIM, bool SKIPZ = false, bool ZS = false, class DT = double>
-__global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const DT *__restrict__ dinv,
+template <int DIM, bool SKIPZ = false, bool ZS = false, class DinvT = double>
+__global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const DinvT *__restrict__ dinv,
                                                     const double *__restrict__ Ap, double *__restrict__ r,
                                                     double *__restrict__ z, double *scal, int it, const double *stopPtr, DetBuf det, double zs = 1.0) {
     __shared__ double red[16];
@@ -866,7 +866,7 @@ __global__ void __launch_bounds__(256) k_pcg_update(int64_t nRows, const DT *__r
             r[g] = rv[c];
         }
         if (!SKIPZ) {
-            apply_block_t<DIM, DT>(dinv + n * NS, rv, zv);
+            apply_block_t<DIM, DinvT>(dinv + n * NS, rv, zv);
 #pragma unroll
             for (int c = 0; c < DIM; ++c) {
                 if (ZS) z[n * DIM + c] = zs * zv[c];
@@ -1445,8 +1445,8 @@ __global__ void __launch_bounds__(256) k_mg_cheb(int64_t nRows, const double *__
 //   x += b D^-1 (rin - t) ;  x = rin on the fixed variables (k_mg_rz's rule) ;  scal[(it + 1) 4] += rin . x
 // rin IS the PCG residual here (a one-step sweep smooths the right-hand side itself), so k_mg_rz's two vector reads disappear. A lane takes two
 // consecutive rows in 16-byte accesses like k_pcg_update.
-template <int DIM, class DT = double>
-__global__ void __launch_bounds__(256) k_mg_cheb_rz(int64_t nRows, const DT *__restrict__ dinv, const double *__restrict__ rin,
+template <int DIM, class DinvT = double>
+__global__ void __launch_bounds__(256) k_mg_cheb_rz(int64_t nRows, const DinvT *__restrict__ dinv, const double *__restrict__ rin,
                                                     const double *__restrict__ t, double *__restrict__ x, double b,
                                                     const uint8_t *__restrict__ mask, double *scalOut, MgGate g, DetBuf det) {
     __shared__ double red[8];
@@ -1482,7 +1482,7 @@ __global__ void __launch_bounds__(256) k_mg_cheb_rz(int64_t nRows, const DT *__r
         double rv[DIM], tv[DIM], zv[DIM];
 #pragma unroll
         for (int c = 0; c < DIM; ++c) { rv[c] = rin[n * DIM + c]; tv[c] = rv[c] - t[n * DIM + c]; }
-        apply_block_t<DIM, DT>(dinv + n * NS, tv, zv);
+        apply_block_t<DIM, DinvT>(dinv + n * NS, tv, zv);
 #pragma unroll
         for (int c = 0; c < DIM; ++c) {
             double xv = x[n * DIM + c] + b * zv[c];
