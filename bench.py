@@ -458,6 +458,8 @@ def run_single(args):
         pavg, pcalls = profile_kernel_avg_ms(PROFILE_ROUND + "_config2_kernel_stats.csv", "k_assemble_gather<3, 2, 0, true, false>")
         if pavg:
             roof.update(kernel_ms_profile_avg=pavg, profile_launches=pcalls, frac_profile_avg=alg / pavg / 1e6 / HBM_PEAK_GBS,
+                        kernel_ms_spread="2.88-3.30 ms by process and box -- where the driver puts the K values (profiles/r06_config2_profile_spread.txt: five profiled "
+                                         "processes per box; the profile average and the process's own HIP events agree to 0.9 % inside every process)",
                         frac_traffic_profile_avg=None if tb is None else tb / pavg / 1e6 / HBM_PEAK_GBS,
                         frac_compulsory_profile_avg=comp / pavg / 1e6 / HBM_PEAK_GBS)
     # context: the kernel's MEASURED traffic rate against the triad rate measured on this box a minute ago
